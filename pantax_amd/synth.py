@@ -1,0 +1,331 @@
+"""Deterministic synthetic PanTax inputs.
+
+Generates, per species, a pangenome graph in the reference's `Graph` shape
+(types.rs:51-55: node lengths + one node walk per haplotype), the three DB side
+files' contents (species_range.txt, species_genomes_stats.txt, genomes_info.txt)
+and error-free reads as a packed structure-of-arrays stream (the layout the HIP
+path consumes) that can also be rendered as GAF text.  numpy only; no reference
+code is involved.  `seed = 20260501 + cfg_index` by convention.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+
+@dataclass
+class SpeciesGraph:
+    name: str                 # species taxid string
+    node_len: np.ndarray      # int64 [V]
+    path_off: np.ndarray      # uint64 [H+1]
+    path_nodes: np.ndarray    # uint32 [P], local 0-based
+    hap_names: List[str]      # byte-wise sorted (BTreeMap order)
+    range_start: int          # first global node id (1-based)
+    range_end: int            # last global node id
+    genome_len: np.ndarray    # int64 [H]
+    truth_depth: np.ndarray   # float64 [H] expected depth of each strain
+
+    @property
+    def n_nodes(self):
+        return len(self.node_len)
+
+    @property
+    def n_paths(self):
+        return len(self.hap_names)
+
+
+@dataclass
+class PackedReads:
+    step_off: np.ndarray      # uint64 [R+1]
+    node_id: np.ndarray       # uint32 [T] global ids (1-based, as in the GAF)
+    strand: np.ndarray        # uint8 [T] 0 '>' 1 '<' (GAF rendering only)
+    pstart: np.ndarray        # int64 [R] GAF col 8
+    pend: np.ndarray          # int64 [R] GAF col 9
+    qlen: np.ndarray          # int64 [R] GAF col 2
+    mapq: np.ndarray          # int64 [R] GAF col 12
+    plen: np.ndarray          # int64 [R] GAF col 7
+    read_id: List[str] = field(default_factory=list)  # only filled for small sets
+
+    @property
+    def n_reads(self):
+        return len(self.pstart)
+
+
+@dataclass
+class SyntheticSet:
+    species: List[SpeciesGraph]
+    reads: PackedReads
+
+    def range_table(self):
+        return [(g.name, g.range_start, g.range_end, 1 if g.n_paths > 1 else 0) for g in self.species]
+
+    def avg_len(self):
+        return np.array([g.genome_len.mean() for g in self.species], dtype=np.float64)
+
+
+def _random_clades(rng, H):
+    """Random binary tree over H strains -> list of clade bitmasks (internal nodes + leaves)."""
+    clades = []
+
+    def split(members):
+        if len(members) <= 1:
+            return
+        rng.shuffle(members)
+        k = int(rng.integers(1, len(members)))
+        left, right = members[:k], members[k:]
+        for part in (left, right):
+            m = 0
+            for h in part:
+                m |= 1 << int(h)
+            clades.append(m)
+            split(list(part))
+
+    split(list(range(H)))
+    return clades
+
+
+def make_species(rng, name, H, genome_len, range_start, hap_prefix, frac_snp=0.30, frac_acc=0.12,
+                 mean_len=32, present_frac=0.2, depth_mu=np.log(8.0), depth_sigma=1.0):
+    """One species graph. H == 1 uses fixed 1024-bp chunks like build_eq1.rs:26-36."""
+    hap_names = sorted("%s%03d.1" % (hap_prefix, h) for h in range(H))
+    if H == 1:
+        n = max(3, int(np.ceil(genome_len / 1024)))
+        node_len = np.full(n, 1024, dtype=np.int64)
+        node_len[-1] = max(1, genome_len - 1024 * (n - 1))
+        path_nodes = np.arange(n, dtype=np.uint32)
+        path_off = np.array([0, n], dtype=np.uint64)
+        glen = np.array([node_len.sum()], dtype=np.int64)
+        depth = np.array([rng.lognormal(depth_mu, depth_sigma)])
+        return SpeciesGraph(name, node_len, path_off, path_nodes, hap_names, range_start, range_start + n - 1, glen, depth)
+    assert H <= 63
+    clades = _random_clades(rng, H)
+    full = (1 << H) - 1
+    est_sites = int(genome_len / (mean_len * (1 - frac_snp) + frac_snp) * 1.25) + 16
+    kind = rng.choice(3, size=est_sites, p=[1 - frac_snp - frac_acc, frac_snp, frac_acc])  # 0 core 1 snp 2 acc
+    kind[0] = 0
+    kind[-1] = 0
+    seg_len = np.minimum(1024, 1 + rng.geometric(1.0 / mean_len, size=est_sites)).astype(np.int64)
+    clade_pick = np.array(clades, dtype=np.uint64)[rng.integers(0, len(clades), size=est_sites)]
+    # expand sites to nodes: core -> 1 node (all strains); snp -> 2 nodes (clade / complement); acc -> 1 node (clade)
+    n_nodes_site = np.where(kind == 1, 2, 1)
+    node_site = np.repeat(np.arange(est_sites), n_nodes_site)
+    first_of_site = np.concatenate([[0], np.cumsum(n_nodes_site)[:-1]])
+    is_second = np.arange(len(node_site)) - first_of_site[node_site]
+    nk = kind[node_site]
+    member = np.where(nk == 0, np.uint64(full), clade_pick[node_site])
+    member = np.where((nk == 1) & (is_second == 1), np.uint64(full) ^ clade_pick[node_site], member).astype(np.uint64)
+    nlen = np.where(nk == 1, 1, seg_len[node_site]).astype(np.int64)
+    # trim to genome_len of strain 0's walk
+    on0 = (member & np.uint64(1)) != 0
+    cum0 = np.cumsum(np.where(on0, nlen, 0))
+    cut = int(np.searchsorted(cum0, genome_len)) + 1
+    cut = min(max(cut, 8), len(nlen))
+    # keep whole sites
+    while cut < len(nlen) and node_site[cut] == node_site[cut - 1]:
+        cut += 1
+    member, nlen = member[:cut], nlen[:cut]
+    V = cut
+    paths = []
+    glen = np.zeros(H, dtype=np.int64)
+    for h in range(H):
+        sel = np.nonzero((member >> np.uint64(h)) & np.uint64(1))[0].astype(np.uint32)
+        paths.append(sel)
+        glen[h] = nlen[sel].sum()
+    path_off = np.zeros(H + 1, dtype=np.uint64)
+    path_off[1:] = np.cumsum([len(p) for p in paths])
+    path_nodes = np.concatenate(paths).astype(np.uint32)
+    n_present = max(1, int(round(present_frac * H)))
+    present = rng.choice(H, size=n_present, replace=False)
+    depth = np.zeros(H)
+    depth[present] = rng.lognormal(depth_mu, depth_sigma, size=n_present)
+    return SpeciesGraph(name, nlen, path_off, path_nodes, hap_names, range_start, range_start + V - 1, glen, depth)
+
+
+def _walks_for_strain(g, h, pos, rlen):
+    """Vectorised node walks of reads [pos, pos+rlen) on strain h (forward orientation).
+    Returns (i0, i1, off0): first/last step index in the strain's path and offset in first node."""
+    b, e = int(g.path_off[h]), int(g.path_off[h + 1])
+    lens = g.node_len[g.path_nodes[b:e]]
+    cum_end = np.cumsum(lens)
+    cum_start = cum_end - lens
+    i0 = np.searchsorted(cum_end, pos, side="right")
+    i1 = np.searchsorted(cum_end, pos + rlen - 1, side="right")
+    return i0, i1, pos - cum_start[i0], cum_end
+
+
+def make_reads(rng, species, n_reads, read_len=150, long_reads=False, adversarial_frac=0.001, with_ids=False):
+    """Error-free reads: path span == read length, pstart = offset in first node."""
+    S = len(species)
+    # read share: depth * genome_len weights
+    w = []
+    key = []
+    for si, g in enumerate(species):
+        for h in range(g.n_paths):
+            if g.truth_depth[h] > 0:
+                w.append(g.truth_depth[h] * g.genome_len[h])
+                key.append((si, h))
+    w = np.array(w, dtype=np.float64)
+    counts = rng.multinomial(n_reads, w / w.sum())
+    seg_off, seg_node, seg_strand = [], [], []
+    pstart_l, pend_l, qlen_l = [], [], []
+    total_steps = 0
+    for (si, h), c in zip(key, counts):
+        if c == 0:
+            continue
+        g = species[si]
+        glen = int(g.genome_len[h])
+        if long_reads:
+            rl = np.clip(rng.normal(15000, 3000, size=c), 2000, 25000).astype(np.int64)
+        else:
+            rl = np.full(c, read_len, dtype=np.int64)
+        rl = np.minimum(rl, glen)
+        pos = (rng.random(c) * (glen - rl + 1)).astype(np.int64)
+        i0, i1, off0, cum_end = _walks_for_strain(g, h, pos, rl)
+        nsteps = (i1 - i0 + 1).astype(np.int64)
+        rev = rng.random(c) < 0.5
+        b = int(g.path_off[h])
+        # flat step indices
+        starts = np.cumsum(nsteps) - nsteps
+        flat = np.arange(int(nsteps.sum()), dtype=np.int64) - np.repeat(starts, nsteps)
+        fwd_idx = np.repeat(i0, nsteps) + flat
+        rev_idx = np.repeat(i1, nsteps) - flat
+        idx = np.where(np.repeat(rev, nsteps), rev_idx, fwd_idx)
+        nodes = g.path_nodes[b + idx].astype(np.int64) + g.range_start  # global 1-based id
+        # offset in first node of the walk orientation
+        end_off = cum_end[i1] - (pos + rl)  # unused tail of last node (forward)
+        ps = np.where(rev, end_off, off0)
+        seg_node.append(nodes.astype(np.uint32))
+        seg_strand.append(np.repeat(rev, nsteps).astype(np.uint8))
+        seg_off.append(nsteps)
+        pstart_l.append(ps)
+        pend_l.append(ps + rl)
+        qlen_l.append(rl)
+        total_steps += int(nsteps.sum())
+    nsteps = np.concatenate(seg_off)
+    R = len(nsteps)
+    # shuffle reads so species are interleaved like a real GAF
+    perm = rng.permutation(R)
+    starts = np.cumsum(nsteps) - nsteps
+    node_all = np.concatenate(seg_node)
+    strand_all = np.concatenate(seg_strand)
+    ns_p = nsteps[perm]
+    new_starts = np.cumsum(ns_p) - ns_p
+    gather = np.repeat(starts[perm], ns_p) + (np.arange(int(ns_p.sum())) - np.repeat(new_starts, ns_p))
+    node_id = node_all[gather]
+    strand = strand_all[gather]
+    step_off = np.zeros(R + 1, dtype=np.uint64)
+    step_off[1:] = np.cumsum(ns_p)
+    pstart = np.concatenate(pstart_l)[perm].astype(np.int64)
+    pend = np.concatenate(pend_l)[perm].astype(np.int64)
+    qlen = np.concatenate(qlen_l)[perm].astype(np.int64)
+    mapq = np.where(rng.random(R) < 0.85, 60, rng.integers(0, 60, size=R)).astype(np.int64)
+    # adversarial records (0.1 %): single-node end<start, repeated node, cross-species walk
+    n_adv = int(R * adversarial_frac)
+    if n_adv > 0:
+        adv = rng.choice(R, size=n_adv, replace=False)
+        for r in adv:
+            b, e = int(step_off[r]), int(step_off[r + 1])
+            k = e - b
+            mode = int(rng.integers(0, 3))
+            if mode == 0 and k == 1:
+                pend[r] = pstart[r] - int(rng.integers(1, 50))       # end < start on a single node
+            elif mode == 1 and k >= 3:
+                node_id[b + 2] = node_id[b]                          # a,b,a repeat
+            elif mode == 2 and k >= 2 and S > 1:
+                other = species[int(rng.integers(0, S))]
+                node_id[e - 1] = np.uint32(other.range_start)       # crosses species -> "U" (or same species)
+    ids = []
+    if with_ids:
+        ids = ["S0R%d/1" % i for i in range(R)]
+    return PackedReads(step_off, node_id, strand, pstart, pend, qlen, mapq, qlen.copy(), ids)
+
+
+CONFIGS = {
+    # name: (n_species, haps per species, reads, genome_len, long_reads)
+    "tiny": (2, 4, 2000, 20000, False),
+    "small": (3, 6, 20000, 60000, False),
+    "cfg2": (1, 10, 1_000_000, 5_000_000, False),
+    "cfg3": (100, 10, 10_000_000, 5_000_000, False),
+    "cfg4_shard": (125, 10, 12_500_000, 5_000_000, False),  # 1/8 of cfg4 (1k species / 100M reads)
+}
+
+
+def make_set(seed, n_species, H, n_reads, genome_len, long_reads=False, with_ids=False, adversarial_frac=0.001,
+             single_strain_every=0):
+    rng = np.random.default_rng(seed)
+    species = []
+    start = 1
+    for s in range(n_species):
+        h = 1 if (single_strain_every and s % single_strain_every == single_strain_every - 1) else H
+        g = make_species(rng, str(1000 + s), h, genome_len, start, "GCF_%06d" % (s + 1))
+        species.append(g)
+        start = g.range_end + 1
+    reads = make_reads(rng, species, n_reads, long_reads=long_reads, with_ids=with_ids,
+                       adversarial_frac=adversarial_frac)
+    return SyntheticSet(species, reads)
+
+
+def make_config(name, cfg_index=0, **kw):
+    S, H, R, L, lr = CONFIGS[name]
+    return make_set(20260501 + cfg_index, S, H, R, L, long_reads=lr, **kw)
+
+
+# ---------------------------------------------------------------- file writers
+def write_db(sset, db_dir, write_gfa=True, write_bin=True):
+    """Write species_range.txt, species_genomes_stats.txt, genomes_info.txt,
+    species_gfa/<sp>.gfa (W lines) and species_graph_info/<sp>.bin (bincode-1 layout,
+    zip.rs:171-190: u64 len + i64s; u64 map len; per entry u64 key len + bytes + u64 vec len + u64s)."""
+    import os
+    import struct
+    os.makedirs(os.path.join(db_dir, "species_gfa"), exist_ok=True)
+    os.makedirs(os.path.join(db_dir, "species_graph_info"), exist_ok=True)
+    with open(os.path.join(db_dir, "species_range.txt"), "w") as f:
+        for name, s, e, pan in sset.range_table():
+            f.write("%s\t%d\t%d\t%d\n" % (name, s, e, pan))
+    with open(os.path.join(db_dir, "species_genomes_stats.txt"), "w") as f:
+        for g in sset.species:
+            f.write("%s\t%s\n" % (g.name, repr(float(g.genome_len.mean()))))
+    with open(os.path.join(db_dir, "genomes_info.txt"), "w") as f:
+        f.write("genome_ID\tstrain_taxid\tspecies_taxid\torganism_name\tid\n")
+        for g in sset.species:
+            for h, hn in enumerate(g.hap_names):
+                gid = "%s_ASM%sv1" % (hn, hn[4:10])
+                f.write("%s\t%s.%d\t%s\tSynthetic species %s\t/path/to/%s_genomic.fna\n" % (gid, g.name, h + 1, g.name, g.name, gid))
+    for g in sset.species:
+        if write_gfa:
+            with open(os.path.join(db_dir, "species_gfa", g.name + ".gfa"), "w") as f:
+                f.write("H\tVN:Z:1.1\n")
+                for v in range(g.n_nodes):
+                    f.write("S\t%d\t%s\n" % (v + 1, "A" * int(g.node_len[v])))
+                for h, hn in enumerate(g.hap_names):
+                    b, e = int(g.path_off[h]), int(g.path_off[h + 1])
+                    walk = "".join(">%d" % (int(v) + 1) for v in g.path_nodes[b:e])
+                    f.write("W\t%s\t1\tctg1\t0\t%d\t%s\n" % (hn, int(g.genome_len[h]), walk))
+        if write_bin:
+            with open(os.path.join(db_dir, "species_graph_info", g.name + ".bin"), "wb") as f:
+                f.write(struct.pack("<Q", g.n_nodes))
+                f.write(g.node_len.astype("<i8").tobytes())
+                f.write(struct.pack("<Q", g.n_paths))
+                for h, hn in enumerate(g.hap_names):
+                    b, e = int(g.path_off[h]), int(g.path_off[h + 1])
+                    hb = hn.encode()
+                    f.write(struct.pack("<Q", len(hb)))
+                    f.write(hb)
+                    f.write(struct.pack("<Q", e - b))
+                    f.write(g.path_nodes[b:e].astype("<u8").tobytes())
+
+
+def write_gaf(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1"):
+    """12 mandatory GAF columns + 4 fixed tags (constant column count)."""
+    with open(path, "w") as f:
+        R = reads.n_reads
+        for r in range(R):
+            b, e = int(reads.step_off[r]), int(reads.step_off[r + 1])
+            walk = "".join(("<" if reads.strand[i] else ">") + str(int(reads.node_id[i])) for i in range(b, e))
+            if not walk:
+                walk = "*"
+            rid = reads.read_id[r] if reads.read_id else "S0R%d/1" % r
+            ql = int(reads.qlen[r])
+            f.write("%s\t%d\t0\t%d\t+\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%s\n" % (
+                rid, ql, ql, walk, int(reads.plen[r]), int(reads.pstart[r]), int(reads.pend[r]), ql, ql,
+                int(reads.mapq[r]), tags))

@@ -1,0 +1,123 @@
+"""CPU tests: pin the oracle against the golden vectors (hand-computed micro graphs,
+SciPy-HiGHS LP solutions).  These run with -m "not gpu"."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.helpers import load_micro_bin, load_micro_cov
+
+
+def test_micro_trio_index():
+    """trio_nodes_info (profile.rs:658-740): windows canonicalised by the w0>w2 swap,
+    unique <=> exactly one (hap, position) occurrence."""
+    j, names, node_len, path_off, path_nodes, *_ = load_micro_cov()
+    g = orc.Graph(node_len, path_off, path_nodes)
+    t = orc.TrioTable(g)
+    exp = j["expected_trios"]
+    assert t.n_unique == len(exp["hap"])
+    assert t.abc.tolist() == exp["abc"]
+    assert t.hap.tolist() == exp["hap"]
+    assert t.len.tolist() == exp["len"]
+    assert t.hap_off.tolist() == exp["hap_off"]
+
+
+def test_micro_coverage():
+    """get_node_abundances (profile.rs:743-1026). Per-read derivation (node: +bases [bitmap range]):
+    r0 0,1,2 ps2 pe11: n0 +3 [2,5) n1 +3 [0,3) n2 +(9-6)=3 [0,3); trio u0 += 9
+    r1 3,2,1 ps1 pe7 : n3 +1 [1,2) n2 +4 [0,4) n1 +(6-5)=1 [0,1); (3,2,1)->(1,2,3) u1 += 6
+    r2 4 ps1 pe4     : n4 +3 [1,4)
+    r3 4 ps5 pe2     : dropped
+    r4 5 ps0 pe3     : n5 +3, bitmap untouched (3 > len 1)
+    r5 0,1,0 ps4 pe10: n0 +1 [4,5) n1 +3 [0,3) n0(repeat) aln 6-4=2 [0,2) no bases
+    r6 2,3,4 ps0 pe3 : n2 +4 [0,4) n3 +2 [0,2) n4 +max(3-6,0)=0
+    r7 4,7 ps3 pe8   : n4 +3 [3,6) n7 +(5-3)=2 [0,2)
+    r8 5,3,4 ps0 pe6 : n5 +1 [0,1) n3 +2 [0,2) n4 +3 [0,3); (5,3,4)->(4,3,5) u4 += 6
+    r9 0,6,2,3 ps0 pe11: n0 +5 [0,5) n6 +1 n2 +4 n3 +(11-10)=1 [0,1); u5 += 10, (6,2,3)->(3,2,6) u6 += 6
+    r10, r11         : reference would abort -> counted, skipped."""
+    j, names, node_len, path_off, path_nodes, rs, step_off, node_id, pstart, pend = load_micro_cov()
+    g = orc.Graph(node_len, path_off, path_nodes)
+    t = orc.TrioTable(g)
+    bases, cov, tb, nab = orc.node_coverage(g, t, rs, step_off, node_id, pstart, pend)
+    e = j["expected"]
+    assert bases.tolist() == e["bases_per_node"]
+    assert cov.tolist() == e["node_base_cov"]
+    assert tb.tolist() == e["trio_bases"]
+    assert nab == e["n_abort"]
+
+
+def test_micro_binning_and_counts():
+    j, step_off, node_id, qlen, mapq, species, rs, re = load_micro_bin()
+    sp = orc.bin_reads(step_off, node_id, rs, re)
+    assert sp.tolist() == species.tolist()
+    rc, bs, lm, uq = orc.species_counts(sp, qlen, mapq, len(rs))
+    e = j["expected_counts"]
+    assert rc.tolist() == e["read_count"] and bs.tolist() == e["base_sum"]
+    assert lm.tolist() == e["less_multi"] and uq.tolist() == e["uniq_count"]
+    # profile.rs:239-245: keep iff uniq_count>0 && less_multi > read_count/10 ; equal-length branch
+    keep, absolute, abundance = orc.species_profile(sp, qlen, (rc, bs, lm, uq), np.array([1000.0, 2000.0, 500.0]))
+    assert keep.tolist() == [1, 0, 0]
+    assert absolute[0] == pytest.approx(2 * 150 / 1000.0) and abundance[0] == 1.0
+    keep, absolute, abundance = orc.species_profile(sp, qlen, (rc, bs, lm, uq), np.array([1000.0, 2000.0, 500.0]),
+                                                    filtered=False)
+    assert keep.tolist() == [1, 1, 1]
+    assert abundance.sum() == pytest.approx(1.0)
+
+
+def test_lad_vs_highs_golden(golden_dir):
+    """The PAO LP (profile.rs:1312-1460): objective must equal HiGHS' to 1e-9 relative;
+    x must match to L1 <= 1e-6*sum on these (non-degenerate) instances."""
+    z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub, xh, objh = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], z["x_%d" % i], float(z["obj_%d" % i])
+        x, obj, it, st = orc.lad_solve(mask, a, len(ub), ub)
+        assert st == 0
+        assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), i
+        assert orc.lad_objective(mask, a, xh) == pytest.approx(objh, rel=1e-9, abs=1e-12)
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+        if bool(z["unique_%d" % i]):  # optimal face is a single point: x itself is comparable
+            assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
+
+
+def test_lad_degenerate_and_edge_cases():
+    # no valid rows -> x = 0
+    x, obj, it, st = orc.lad_solve(np.array([1, 3], dtype=np.uint64), np.zeros(2), 2, np.array([1.0, 1.0]))
+    assert st == 0 and x.tolist() == [0.0, 0.0] and obj == 0.0
+    # all rows identical pattern: x0 + x1 = median(a); objective value is what matters
+    a = np.array([1.0, 2.0, 3.0, 4.0, 100.0])
+    mask = np.full(5, 3, dtype=np.uint64)
+    x, obj, it, st = orc.lad_solve(mask, a, 2, np.array([105.0, 105.0]))
+    assert st == 0 and x.sum() == pytest.approx(3.0) and obj == pytest.approx((2 + 1 + 0 + 1 + 97) / 5)
+    # upper bound active
+    x, obj, it, st = orc.lad_solve(np.array([1, 1, 1], dtype=np.uint64), np.array([5.0, 6.0, 7.0]), 1, np.array([4.0]))
+    assert st == 0 and x[0] == pytest.approx(4.0)
+    # massive integer ties (depth-like data)
+    rng = np.random.default_rng(3)
+    n, p = 4000, 5
+    mask = rng.integers(1, 1 << p, size=n).astype(np.uint64)
+    truth = np.array([4.0, 0.0, 9.0, 0.0, 2.0])
+    A = np.stack([((mask >> np.uint64(k)) & np.uint64(1)).astype(float) for k in range(p)], 1)
+    a = A @ truth  # noise-free: optimum is exactly truth with objective 0
+    x, obj, it, st = orc.lad_solve(mask, a, p, np.full(p, 1.05 * a.max()))
+    assert st == 0 and obj == pytest.approx(0.0, abs=1e-9) and np.allclose(x, truth, atol=1e-8)
+
+
+def test_optimize_species_synthetic():
+    """optimize_otu (profile.rs:2884-3026) on a small synthetic species: present strains are
+    recovered, absent strains get no predicted coverage."""
+    from pantax_amd import synth
+    from tests.helpers import select_reads
+    rng = np.random.default_rng(11)
+    g = synth.make_species(rng, "1000", 6, 40000, 1, "GCF_000001", present_frac=0.5)
+    reads = synth.make_reads(rng, [g], 8000)
+    G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+    T = orc.TrioTable(G)
+    bases, cov, tb, nab = orc.node_coverage(G, T, g.range_start, reads.step_off, reads.node_id, reads.pstart, reads.pend)
+    assert nab == 0
+    rc, met, nc, o1, o2 = orc.optimize_species(G, T, bases, cov, tb)
+    assert rc == 0 and nc >= 1
+    d = orc.metrics_to_dicts(met)
+    present = set(np.nonzero(g.truth_depth > 0)[0].tolist())
+    called = {h for h, m in enumerate(d) if m["predicted_coverage"] not in (None, 0.0)}
+    assert called == present
