@@ -1,0 +1,178 @@
+/*
+ * pantax_hip.h -- C ABI of the MI355X-native PanTax profiling path.
+ *
+ * This is the drop-in boundary: a Rust `extern "C"` block
+ * (or cgo / ctypes) binds to exactly these symbols.  Plain pointers and sizes
+ * only; every array is caller-owned and only read unless marked [out].
+ * Conventions: 0 = success, negative = pantax_hip_status; nothing aborts or
+ * throws across the boundary; one ctx per process per GPU; calls on one ctx are
+ * serialised on its HIP stream.
+ *
+ * Reference seams this replaces (paths relative to pantax/src):
+ *   - pipeline seam:  profile::profile(ProfilingConfig)            profile.rs:3325 (called main.rs:51-54)
+ *   - solver seam:    match args.solver { "gurobi" | "highs" ... } profile.rs:2969-3009
+ *                     fn X_opt(&mut GurobiOptVar, nvert, paths, node_abundance_vec,
+ *                              node_base_cov, node_len, args)        profile.rs:2690-2698
+ *   - histogram seam: get_node_abundances(...)                      profile.rs:743-750
+ *   - binning seam:   rcls::rcls_profile / process_single_read_simple  rcls.rs:452-458, 237-258
+ * INTEGRATION.md shows the Rust-side binding for each.
+ */
+#ifndef PANTAX_HIP_H
+#define PANTAX_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PANTAX_HIP_OK = 0,
+    PANTAX_HIP_E_INVALID = -1,       /* bad argument */
+    PANTAX_HIP_E_HIP = -2,           /* HIP runtime error (message in last_error) */
+    PANTAX_HIP_E_NO_DEVICE = -3,     /* no usable gfx950 device: the product never falls back to CPU */
+    PANTAX_HIP_E_LIMIT = -4,         /* size limit of this build (e.g. > 64 candidate paths) */
+    PANTAX_HIP_E_SOLVER = -5,        /* LP did not reach optimality (reference: Err(e) => species dropped, profile.rs:2999-3003) */
+    PANTAX_HIP_E_IO = -6,            /* file missing / malformed (pipeline seam) */
+    PANTAX_HIP_E_STATE = -7          /* stage called before its prerequisite */
+} pantax_hip_status;
+
+typedef struct pantax_hip_ctx pantax_hip_ctx;     /* owns the HIP stream, scratch, timers */
+typedef struct pantax_hip_db pantax_hip_db;       /* device-resident graphs of the species this rank owns */
+typedef struct pantax_hip_reads pantax_hip_reads; /* device-resident packed alignment records */
+
+int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices); /* n_devices == 1 */
+void pantax_hip_destroy(pantax_hip_ctx *ctx);
+const char *pantax_hip_last_error(const pantax_hip_ctx *ctx); /* ctx may be NULL: init errors */
+const char *pantax_hip_version(void);
+
+/* ---- DB side: types.rs:51-55 `Graph` of every species, concatenated ---------------------- */
+typedef struct {
+    uint32_t n_species;
+    const int64_t *range_start; /* [S] first global node id, 1-based (species_range.txt col 2) */
+    const int64_t *range_end;   /* [S] last global node id (col 3) */
+    const uint64_t *node_off;   /* [S+1] species s owns node_len[node_off[s] .. node_off[s+1]) */
+    const int64_t *node_len;    /* [V] Graph::nodes_len */
+    const uint64_t *hap_off;    /* [S+1] species s owns haplotypes [hap_off[s] .. hap_off[s+1]) in BTreeMap (byte) order */
+    const uint64_t *path_off;   /* [H+1] walk of hap h = path_nodes[path_off[h] .. path_off[h+1]) */
+    const uint32_t *path_nodes; /* [P] species-local 0-based node ids (Graph::paths values) */
+} pantax_hip_graphs;
+
+int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax_hip_db **out);
+void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db);
+
+/* ---- read side: packed form of the GAF columns rcls.rs:127-137 selects ------------------- */
+#define PANTAX_HIP_READ_NULLFIELD 1u /* a selected column was `*`: dropped at strain level, profile.rs:380-399 */
+#define PANTAX_HIP_READ_DUPDROP 2u   /* duplicate read id spanning >1 species, profile.rs:406-437 */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_steps;
+    const uint32_t *step_off; /* [R+1] */
+    const uint32_t *node_id;  /* [T] node ids exactly as written in GAF col 6 */
+    const uint32_t *pstart;   /* [R] GAF col 8 (read_start) */
+    const uint32_t *pend;     /* [R] GAF col 9 (read_end) */
+    const uint32_t *qlen;     /* [R] GAF col 2 (read_len) */
+    const uint8_t *mapq;      /* [R] GAF col 12; 255 = null */
+    const uint8_t *flags;     /* [R] PANTAX_HIP_READ_* or NULL */
+} pantax_hip_packed_reads;
+
+int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *r, pantax_hip_reads **out);
+void pantax_hip_reads_free(pantax_hip_ctx *ctx, pantax_hip_reads *reads);
+
+/* ---- a2 + a3: read -> species binning (rcls.rs:237-258) and the species counters
+ * (profile.rs:208-297).  species_idx_out[r] = index into the db's species or -1 ("U").
+ * Counter arrays are [n_species]; any out pointer may be NULL. */
+int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hip_reads *reads,
+                         int32_t *species_idx_out, int64_t *read_count_out, int64_t *base_sum_out,
+                         int64_t *less_multi_out, int64_t *uniq_count_out);
+
+/* ---- a7: unique-trio index (profile.rs:658-740), built on device once per db.
+ * Rows are ordered (species, hap, window position). */
+int pantax_hip_trio_index(pantax_hip_ctx *ctx, pantax_hip_db *db, uint64_t *n_unique_total_out);
+/* copy the table out: abc [3*U] canonical species-local keys, hap [U] hap index within
+ * its species, len [U], hap_trio_off [H+1] (global hap numbering). NULLs are skipped. */
+int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *db, uint32_t *abc_out, uint32_t *hap_out,
+                        int64_t *len_out, uint64_t *hap_trio_off_out);
+
+/* ---- a8: get_node_abundances integer part (profile.rs:743-1026).  Requires bin_reads
+ * (and trio_index if trio_bases_out != NULL).  species_active: [S] 0/1 or NULL = all
+ * (the species load_species_range keeps, profile.rs:553-656).  Outputs: [V], [V], [U].
+ * n_abort_out counts reads on which the reference would abort (assert profile.rs:854 /
+ * index panic :849); they contribute nothing. */
+int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads,
+                             const uint8_t *species_active, int64_t *bases_per_node_out,
+                             uint64_t *node_base_cov_out, int64_t *trio_bases_out, uint64_t *n_abort_out);
+
+/* ---- a9..a14: strain level for every active species (optimize_otu profile.rs:2884-3026,
+ * abundace_constraint :3028-3070).  Requires node_coverage to have run on (db, reads). */
+#define PANTAX_HIP_HAS_FRACTION 1u
+#define PANTAX_HIP_HAS_FREQ_MEAN 2u
+#define PANTAX_HIP_HAS_RATIO 4u
+#define PANTAX_HIP_HAS_FIRST 8u
+#define PANTAX_HIP_HAS_DIVERGENCE 16u
+#define PANTAX_HIP_HAS_SECOND 32u
+#define PANTAX_HIP_HAS_RESCUE 64u
+#define PANTAX_HIP_HAS_TOTAL_DIFF 128u
+typedef struct { /* HapMetrics, profile.rs:1065-1078; `has` bit = Option::is_some() */
+    uint32_t has;
+    int32_t is_rescue;
+    double unique_trio_nodes_fraction, frequencies_mean, path_cov_ratio, first_sol, divergence, second_sol,
+        total_cov_diff;
+} pantax_hip_hap_metrics;
+
+typedef struct { /* the ProfilingConfig fields optimize_otu reads (types.rs:57-91, defaults main.rs:102-171) */
+    double unique_trio_nodes_fraction;     /* --fr: 0.3 short / 0.5 long */
+    double unique_trio_nodes_mean_count_f; /* --fc 0.46 */
+    double single_cov_ratio;               /* --sr 0.85 */
+    int64_t min_depth;                     /* --min_depth 0 */
+    int32_t shift;                         /* --shift */
+    int32_t sample_nodes;                  /* --sample: must be 0 (row sub-sampling, profile.rs:1394-1400, not implemented) */
+} pantax_hip_strain_config;
+
+typedef struct { /* per species solver report */
+    int32_t n_candidates, status1, status2, iters1, iters2;
+    uint32_t n_rows, n_patterns;
+    double obj1, obj2;
+} pantax_hip_solve_info;
+
+int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pantax_hip_strain_config *cfg,
+                              const uint8_t *species_active /*[S] or NULL*/,
+                              const double *species_coverage /*[S] predicted_coverage, profile.rs:3044-3047*/,
+                              pantax_hip_hap_metrics *metrics_out /*[H]*/, pantax_hip_solve_info *info_out /*[S] or NULL*/);
+
+/* ---- solver seam: one species, host buffers in, same meaning as X_opt's arguments
+ * (profile.rs:2690-2698).  cand_path_idx = possible_paths_idx; fixed_zero[k]=1 pins x_k = 0
+ * (second solve, profile.rs:1484-1488).  x_out [n_cand]; path_cov_ratio_out [n_cand] or NULL. */
+int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *node_len,
+                         const double *node_abundance, const uint64_t *node_base_cov, uint32_t n_paths,
+                         const uint64_t *path_off, const uint32_t *path_nodes, uint32_t n_cand,
+                         const uint32_t *cand_path_idx, const uint8_t *fixed_zero, double *x_out,
+                         float *path_cov_ratio_out, double *obj_out, int32_t *status_out);
+
+/* ---- pipeline seam: files in, files out (profile.rs:3325) -------------------------------- */
+typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = reference default under db/wd */
+    const char *db, *wd, *output_dir;
+    const char *genomes_metadata, *range_file, *input_aln_file, *species_len_file, *out_binning_file;
+    double min_species_abundance, unique_trio_nodes_fraction, unique_trio_nodes_mean_count_f, single_cov_ratio,
+        single_cov_diff;
+    int64_t min_cov, min_depth;
+    int32_t species, strain, shift, filtered, full, force, mode, sample_nodes;
+    const char *designated_species; /* --ds or NULL */
+    const char *zip;                /* "serialize" | NULL (= GFA); "lz"/"zstd" are rejected (no codec here) */
+    /* multi-GPU: this process handles species i with i % world_size == rank; world_size 1 = all */
+    int32_t rank, world_size;
+} pantax_hip_profiling_config;
+
+int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);
+
+/* ---- measurement: HIP-event timings of kernels launched on the ctx stream ---------------- */
+int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on);
+int pantax_hip_timing_reset(pantax_hip_ctx *ctx);
+/* fills up to cap entries; returns the number of distinct kernel names (or <0) */
+int pantax_hip_timing_get(pantax_hip_ctx *ctx, int cap, const char **names_out, uint64_t *launches_out,
+                          double *total_ms_out);
+int pantax_hip_sync(pantax_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

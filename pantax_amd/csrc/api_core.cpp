@@ -1,0 +1,169 @@
+// api_core.cpp -- upload of the resident DB / reads and the a2/a3/a8 entry points of
+// include/pantax_hip.h.  Host code only; kernels live in the stage_*.hip files.
+#include <algorithm>
+#include <memory>
+#include <numeric>
+#include "common.hpp"
+
+using namespace ptx;
+
+extern "C" {
+
+int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax_hip_db **out) {
+    if (!ctx || !g || !out) return PANTAX_HIP_E_INVALID;
+    *out = nullptr;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t S = g->n_species;
+    if (S == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: n_species == 0");
+    std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
+    db->S = S;
+    db->V = g->node_off[S];
+    db->H = g->hap_off[S];
+    db->P = g->path_off[db->H];
+    if (db->V >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu nodes on one GPU exceeds the 32-bit node index", (unsigned long long)db->V);
+    db->h_range_start.assign(g->range_start, g->range_start + S);
+    db->h_range_end.assign(g->range_end, g->range_end + S);
+    db->h_node_off.assign(g->node_off, g->node_off + S + 1);
+    db->h_hap_off.assign(g->hap_off, g->hap_off + S + 1);
+    db->h_path_off.assign(g->path_off, g->path_off + db->H + 1);
+    db->h_node_len.assign(g->node_len, g->node_len + db->V);
+    db->h_path_nodes.assign(g->path_nodes, g->path_nodes + db->P);
+    for (uint32_t s = 0; s < S; ++s) {
+        if (g->range_start[s] < 1 || g->range_end[s] > 0xFFFFFFFFll || g->range_end[s] < g->range_start[s])
+            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u has an invalid node id range [%lld,%lld]", s, (long long)g->range_start[s], (long long)g->range_end[s]);
+        uint64_t nv = g->node_off[s + 1] - g->node_off[s];
+        // optimize_otu derives nvert from the range (profile.rs:2938); the graph must agree
+        if ((uint64_t)(g->range_end[s] - g->range_start[s] + 1) != nv)
+            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u range spans %lld ids but its graph has %llu nodes", s, (long long)(g->range_end[s] - g->range_start[s] + 1), (unsigned long long)nv);
+    }
+    // binning table: sorted by start when the ranges are pairwise disjoint (sort_range.rs:25-33
+    // builds them contiguous), otherwise file order + linear scan
+    std::vector<uint32_t> order(S);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g->range_start[a] < g->range_start[b]; });
+    bool disjoint = true;
+    for (uint32_t i = 0; i + 1 < S; ++i)
+        if (g->range_end[order[i]] >= g->range_start[order[i + 1]]) disjoint = false;
+    db->ranges_sorted_disjoint = disjoint;
+    if (!disjoint) std::iota(order.begin(), order.end(), 0u);
+    std::vector<uint32_t> rs(S), re(S), first_id(S), node_base(S + 1), hap_species(db->H);
+    for (uint32_t i = 0; i < S; ++i) {
+        rs[i] = (uint32_t)g->range_start[order[i]];
+        re[i] = (uint32_t)g->range_end[order[i]];
+        first_id[i] = (uint32_t)g->range_start[i];
+        node_base[i] = (uint32_t)g->node_off[i];
+        for (uint64_t h = g->hap_off[i]; h < g->hap_off[i + 1]; ++h) hap_species[h] = i;
+    }
+    node_base[S] = (uint32_t)db->V;
+    std::vector<uint64_t> bit_off(db->V + 1);
+    bit_off[0] = 0;
+    for (uint64_t v = 0; v < db->V; ++v) {
+        if (g->node_len[v] <= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: node %llu has length %lld (reference asserts > 0, profile.rs:494)", (unsigned long long)v, (long long)g->node_len[v]);
+        bit_off[v + 1] = bit_off[v] + (uint64_t)g->node_len[v];
+    }
+    db->L = bit_off[db->V];
+    for (uint32_t s = 0; s < S; ++s) {
+        uint64_t nv = g->node_off[s + 1] - g->node_off[s];
+        for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h)
+            for (uint64_t q = g->path_off[h]; q < g->path_off[h + 1]; ++q)
+                if (g->path_nodes[q] >= nv) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %llu walks node %u outside its species graph", (unsigned long long)h, g->path_nodes[q]);
+    }
+    PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
+    PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
+    PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
+    PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
+    PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
+    PTX_TRY(upload(ctx, db->d_bit_off, bit_off.data(), db->V + 1));
+    PTX_TRY(upload(ctx, db->d_path_off, g->path_off, db->H + 1));
+    PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
+    PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
+    PTX_TRY(upload(ctx, db->d_hap_off, g->hap_off, S + 1));
+    PTX_HIP(ctx, db->d_trio_first.alloc(1));
+    PTX_HIP(ctx, db->d_trio_bc.alloc(1));
+    PTX_HIP(ctx, db->d_trio_row.alloc(1));
+    PTX_HIP(ctx, db->d_trio_bases.alloc(1));
+    PTX_HIP(ctx, db->d_active.alloc(S));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
+    *out = db.release();
+    return 0;
+}
+
+void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    delete db;
+}
+
+int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *r, pantax_hip_reads **out) {
+    if (!ctx || !r || !out) return PANTAX_HIP_E_INVALID;
+    *out = nullptr;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (r->n_steps >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: %llu steps exceed the 32-bit step offset; split the batch", (unsigned long long)r->n_steps);
+    if (r->n_reads && (r->step_off[0] != 0 || r->step_off[r->n_reads] != r->n_steps))
+        return fail(ctx, PANTAX_HIP_E_INVALID, "reads_upload: step_off must start at 0 and end at n_steps");
+    std::unique_ptr<pantax_hip_reads> rd(new pantax_hip_reads());
+    rd->R = r->n_reads;
+    rd->T = r->n_steps;
+    static const uint32_t zero = 0;
+    PTX_TRY(upload(ctx, rd->d_step_off, r->n_reads ? r->step_off : &zero, r->n_reads + 1));
+    PTX_TRY(upload(ctx, rd->d_node_id, r->node_id, r->n_steps));
+    PTX_TRY(upload(ctx, rd->d_pstart, r->pstart, r->n_reads));
+    PTX_TRY(upload(ctx, rd->d_pend, r->pend, r->n_reads));
+    PTX_TRY(upload(ctx, rd->d_qlen, r->qlen, r->n_reads));
+    PTX_TRY(upload(ctx, rd->d_mapq, r->mapq, r->n_reads));
+    rd->has_flags = r->flags != nullptr;
+    if (rd->has_flags) PTX_TRY(upload(ctx, rd->d_flags, r->flags, r->n_reads));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = rd.release();
+    return 0;
+}
+
+void pantax_hip_reads_free(pantax_hip_ctx *ctx, pantax_hip_reads *reads) {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    delete reads;
+}
+
+int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hip_reads *reads, int32_t *species_idx_out,
+                         int64_t *read_count_out, int64_t *base_sum_out, int64_t *less_multi_out, int64_t *uniq_count_out) {
+    if (!ctx || !db || !reads) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t S = db->S;
+    DevBuf<unsigned long long> d_cnt;
+    PTX_HIP(ctx, d_cnt.alloc(4ull * S));
+    PTX_TRY(bin_reads_launch(ctx, db, reads, d_cnt.p));
+    std::vector<unsigned long long> h(4ull * S);
+    PTX_TRY(download(ctx, h.data(), d_cnt.p, 4ull * S));
+    if (species_idx_out) PTX_TRY(download(ctx, species_idx_out, reads->d_species.p, reads->R));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t *outs[4] = {read_count_out, base_sum_out, less_multi_out, uniq_count_out};
+    for (int k = 0; k < 4; ++k)
+        if (outs[k]) for (uint32_t s = 0; s < S; ++s) outs[k][s] = (int64_t)h[(size_t)k * S + s];
+    return 0;
+}
+
+int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const uint8_t *species_active,
+                             int64_t *bases_per_node_out, uint64_t *node_base_cov_out, int64_t *trio_bases_out,
+                             uint64_t *n_abort_out) {
+    if (!ctx || !db || !reads) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!reads->binned) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: call pantax_hip_bin_reads on these reads first");
+    if (trio_bases_out && !db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: trio_bases requested but pantax_hip_trio_index has not run");
+    const uint8_t *d_active = nullptr;
+    if (species_active) {
+        PTX_TRY(upload(ctx, db->d_active, species_active, db->S));
+        d_active = db->d_active.p;
+    }
+    unsigned long long *d_abort = (unsigned long long *)ctx->d_scalars.p;
+    PTX_TRY(coverage_launch(ctx, db, reads, d_active, db->trio_built, d_abort));
+    unsigned long long h_abort = 0;
+    std::vector<uint32_t> cov32;
+    if (bases_per_node_out) PTX_TRY(download(ctx, (unsigned long long *)bases_per_node_out, db->d_bases.p, db->V));
+    if (node_base_cov_out) { cov32.resize(db->V); PTX_TRY(download(ctx, cov32.data(), db->d_cov.p, db->V)); }
+    if (trio_bases_out && db->U) PTX_TRY(download(ctx, (unsigned long long *)trio_bases_out, db->d_trio_bases.p, db->U));
+    PTX_TRY(download(ctx, &h_abort, d_abort, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (node_base_cov_out) for (uint64_t v = 0; v < db->V; ++v) node_base_cov_out[v] = cov32[v];
+    if (n_abort_out) *n_abort_out = h_abort;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// common.hpp -- internal state behind the opaque handles of include/pantax_hip.h.
+// gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/pantax_hip.h"
+
+namespace ptx {
+
+struct Ctx;
+
+// ---- error plumbing: HIP errors become PANTAX_HIP_E_HIP + message, never abort -------------
+int fail(Ctx *ctx, int code, const char *fmt, ...);
+#define PTX_HIP(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return ptx::fail((ctx), PANTAX_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                                     \
+    } while (0)
+#define PTX_TRY(expr)               \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// ---- device buffer ---------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count ? count : 1;
+        return e;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct TimedLaunch {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    std::map<std::string, std::pair<uint64_t, double>> acc;
+    int n_cu = 256;
+    // scratch reused across calls
+    DevBuf<uint64_t> d_scalars;  // small counters (n_abort, ...)
+};
+
+// RAII-less timing scope: records events around a launch when ctx->timing is on
+struct KTimer {
+    Ctx *ctx;
+    hipEvent_t start = nullptr, stop = nullptr;
+    const char *name;
+    KTimer(Ctx *c, const char *nm);
+    ~KTimer();
+};
+
+int collect_timings(Ctx *ctx);
+
+// ---- resident DB -----------------------------------------------------------------------------
+struct Db {
+    uint32_t S = 0;
+    uint64_t V = 0, H = 0, P = 0, L = 0;
+    std::vector<int64_t> h_range_start, h_range_end;
+    std::vector<uint64_t> h_node_off, h_hap_off, h_path_off;
+    std::vector<int64_t> h_node_len;     // kept for host-side finishing (f64 divides)
+    std::vector<uint32_t> h_path_nodes;  // kept for the identical-paths test (profile.rs:1188-1190)
+    bool ranges_sorted_disjoint = true;
+    // binning tables
+    DevBuf<uint32_t> d_rng_start, d_rng_end, d_rng_idx;  // sorted by start (or file order when overlapping)
+    // graph
+    DevBuf<uint32_t> d_sp_first_id;  // [S] range_start as u32
+    DevBuf<uint32_t> d_node_base;    // [S+1]
+    DevBuf<uint64_t> d_bit_off;      // [V+1] prefix sum of node_len; node_len[v] = bit_off[v+1]-bit_off[v]
+    DevBuf<uint64_t> d_path_off;     // [H+1]
+    DevBuf<uint32_t> d_path_nodes;   // [P]
+    DevBuf<uint32_t> d_hap_species;  // [H]
+    DevBuf<uint64_t> d_hap_off;      // [S+1]
+    // unique-trio index (a7)
+    bool trio_built = false;
+    uint64_t U = 0;
+    DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
+    DevBuf<uint2> d_trio_bc;         // [U] (b,c) sorted within each first-node row
+    DevBuf<uint32_t> d_trio_row;     // [U] sorted position -> row in (species,hap,position) order
+    DevBuf<uint32_t> d_trio_abc;     // [3U] row order
+    DevBuf<uint32_t> d_trio_hap;     // [U] hap index within species, row order
+    DevBuf<uint32_t> d_trio_len;     // [U]
+    DevBuf<uint64_t> d_hap_trio_off; // [H+1]
+    std::vector<uint64_t> h_hap_trio_off;
+    // coverage state (a8), resident for the strain step
+    bool cov_done = false;
+    DevBuf<unsigned long long> d_bases;      // [V]
+    DevBuf<uint32_t> d_bitmap;               // [ceil(L/32)+1]
+    DevBuf<uint32_t> d_cov;                  // [V]
+    DevBuf<unsigned long long> d_trio_bases; // [U]
+    DevBuf<uint8_t> d_active;                // [S]
+};
+
+struct Reads {
+    uint64_t R = 0, T = 0;
+    DevBuf<uint32_t> d_step_off, d_node_id, d_pstart, d_pend, d_qlen;
+    DevBuf<uint8_t> d_mapq, d_flags;
+    bool has_flags = false;
+    DevBuf<int32_t> d_species;
+    bool binned = false;
+};
+
+template <class T>
+int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
+    PTX_HIP(ctx, dst.alloc(n));
+    if (n) PTX_HIP(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+template <class T>
+int download(Ctx *ctx, T *dst, const T *src_dev, size_t n) {
+    if (n) PTX_HIP(ctx, hipMemcpyAsync(dst, src_dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
+    uint64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---- stage entry points (host launchers, defined in the .hip files) ---------------------------
+int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, unsigned long long *d_abort);
+int trio_index_build(Ctx *ctx, Db *db);
+
+}  // namespace ptx
+
+struct pantax_hip_ctx : ptx::Ctx {};
+struct pantax_hip_db : ptx::Db {};
+struct pantax_hip_reads : ptx::Reads {};

@@ -1,0 +1,255 @@
+// primitives.hip -- exclusive scan + stable LSD radix sort (see primitives.hpp).
+// Both are HBM-streaming: scan moves 2 reads + 1 write of the input; each sort pass moves
+// (8*nw + 4) bytes per record in the histogram sweep and twice that in the scatter sweep.
+#include "primitives.hpp"
+
+namespace ptx {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a block of NT threads (NT multiple of 64, <= 1024)
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT/64]*/, uint32_t *block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        uint32_t t = s_wave[w];
+        if (w < wave) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return woff + incl - v;
+}
+
+template <class T>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const T *__restrict__ in, uint64_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        uint64_t idx = base + (uint64_t)i * SCAN_BLOCK + threadIdx.x;
+        if (idx < n) s += (uint32_t)in[idx];
+    }
+    uint32_t tot;
+    (void)block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nb ? sums[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
+        if (i < nb) sums[i] = ex + carry;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+template <class T>
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T *in, uint32_t *out, uint64_t n,  // in may alias out
+                                                                const uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        uint64_t idx = base + i;
+        v[i] = idx < n ? (uint32_t)in[idx] : 0;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t off = block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        uint64_t idx = base + i;
+        if (idx < n) out[idx] = off;
+        off += v[i];
+    }
+}
+
+size_t scan_tmp_elems(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
+
+template <class T>
+static int exclusive_scan_impl(Ctx *ctx, const T *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
+    if (n == 0) {
+        if (d_total) PTX_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
+        return 0;
+    }
+    uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    KTimer t(ctx, "exclusive_scan");
+    hipLaunchKernelGGL((scan_reduce_kernel<T>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, d_in, n, d_tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_tmp, nb, d_total);
+    hipLaunchKernelGGL((scan_apply_kernel<T>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, d_in, d_out, n, d_tmp);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int exclusive_scan_u32(Ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
+    return exclusive_scan_impl<uint32_t>(ctx, d_in, d_out, n, d_tmp, d_total);
+}
+int exclusive_scan_u8(Ctx *ctx, const uint8_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
+    return exclusive_scan_impl<uint8_t>(ctx, d_in, d_out, n, d_tmp, d_total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ROUNDS = 4;                                  // 64-record rounds per wave per tile
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;             // 1024 records
+constexpr int SORT_SLOTS = (SORT_BLOCK / 64) * SORT_ROUNDS;     // (wave, round) slots per tile
+constexpr int SORT_MAX_BLOCKS = 2048;
+
+struct SortGeom {
+    uint32_t nb;
+    uint64_t chunk;  // records per block, multiple of SORT_TILE
+};
+static SortGeom sort_geom(uint64_t n) {
+    uint64_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    uint32_t nb = (uint32_t)(tiles < SORT_MAX_BLOCKS ? tiles : SORT_MAX_BLOCKS);
+    if (nb == 0) nb = 1;
+    uint64_t tiles_per_block = (tiles + nb - 1) / nb;
+    return {nb, tiles_per_block * SORT_TILE};
+}
+size_t sort_table_elems(uint64_t n) { return 256ull * SORT_MAX_BLOCKS + 1; }
+
+__global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *__restrict__ key, int shift, uint64_t n,
+                                                               uint64_t chunk, uint32_t nb, uint32_t *__restrict__ table) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t b = (uint64_t)blockIdx.x * chunk, e = b + chunk;
+    if (e > n) e = n;
+    for (uint64_t i = b + threadIdx.x; i < e; i += SORT_BLOCK) atomicAdd(&s_hist[(key[i] >> shift) & 0xFF], 1u);
+    __syncthreads();
+    table[(uint32_t)threadIdx.x * nb + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+template <int NW, bool HASV>
+__global__ void __launch_bounds__(SORT_BLOCK) sort_scatter_kernel(SortBufs in, SortBufs out, int word, int shift, uint64_t n,
+                                                                  uint64_t chunk, uint32_t nb, const uint32_t *__restrict__ table) {
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_slot[SORT_SLOTS][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    s_base[threadIdx.x] = table[(uint32_t)threadIdx.x * nb + blockIdx.x];
+    uint64_t b = (uint64_t)blockIdx.x * chunk, e = b + chunk;
+    if (e > n) e = n;
+    for (uint64_t tile = b; tile < e; tile += SORT_TILE) {
+#pragma unroll
+        for (int s = 0; s < SORT_SLOTS; ++s) s_slot[s][threadIdx.x] = 0;
+        __syncthreads();
+        uint64_t k[SORT_ROUNDS][NW];
+        uint32_t v[SORT_ROUNDS];
+        uint32_t dig[SORT_ROUNDS], rank[SORT_ROUNDS];
+        bool valid[SORT_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < SORT_ROUNDS; ++j) {
+            uint64_t idx = tile + (uint64_t)(wave * SORT_ROUNDS + j) * 64 + lane;
+            valid[j] = idx < e;
+            dig[j] = 0;
+            if (valid[j]) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) k[j][w] = in.k[w][idx];
+                if (HASV) v[j] = in.v[idx];
+                uint64_t kw = k[j][0];  // static indices only: a runtime index would spill k[][] to scratch
+                if (NW > 1 && word == 1) kw = k[j][1];
+                if (NW > 2 && word == 2) kw = k[j][2];
+                dig[j] = (uint32_t)(kw >> shift) & 0xFF;
+            }
+            // lanes of this wave holding the same digit (wave64 ballots, one per digit bit)
+            uint64_t peers = __ballot(valid[j]);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                bool one = (dig[j] >> bit) & 1;
+                uint64_t bm = __ballot(one);
+                peers &= one ? bm : ~bm;
+            }
+            rank[j] = __popcll(peers & lt);
+            if (valid[j] && rank[j] == 0) s_slot[wave * SORT_ROUNDS + j][dig[j]] = __popcll(peers);
+        }
+        __syncthreads();
+        {   // thread d turns the per-slot counts of digit d into output offsets, in record order
+            uint32_t run = s_base[threadIdx.x];
+#pragma unroll
+            for (int s = 0; s < SORT_SLOTS; ++s) {
+                uint32_t c = s_slot[s][threadIdx.x];
+                s_slot[s][threadIdx.x] = run;
+                run += c;
+            }
+            s_base[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SORT_ROUNDS; ++j) {
+            if (valid[j]) {
+                uint32_t pos = s_slot[wave * SORT_ROUNDS + j][dig[j]] + rank[j];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) out.k[w][pos] = k[j][w];
+                if (HASV) out.v[pos] = v[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NW>
+static void launch_scatter(Ctx *ctx, SortBufs in, SortBufs out, int word, int shift, uint64_t n, SortGeom g, const uint32_t *table) {
+    if (in.v) hipLaunchKernelGGL((sort_scatter_kernel<NW, true>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table);
+    else hipLaunchKernelGGL((sort_scatter_kernel<NW, false>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table);
+}
+
+int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *passes, int n_passes, uint32_t *d_table,
+               uint32_t *d_scan_tmp, bool *result_in_b) {
+    *result_in_b = false;
+    if (n == 0 || n_passes == 0) return 0;
+    if (n >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "radix_sort: %llu records exceed 32-bit positions", (unsigned long long)n);
+    SortGeom g = sort_geom(n);
+    SortBufs cur = a, nxt = b;
+    bool in_b = false;
+    KTimer t(ctx, "radix_sort");
+    for (int p = 0; p < n_passes; ++p) {
+        int word = passes[p].word, shift = passes[p].shift;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table);
+        uint64_t tn = 256ull * g.nb;
+        // in-place exclusive scan of the digit-major table
+        uint32_t nbk = (uint32_t)((tn + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL((scan_reduce_kernel<uint32_t>), dim3(nbk), dim3(SCAN_BLOCK), 0, ctx->stream, d_table, tn, d_scan_tmp);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_scan_tmp, nbk, (uint32_t *)nullptr);
+        hipLaunchKernelGGL((scan_apply_kernel<uint32_t>), dim3(nbk), dim3(SCAN_BLOCK), 0, ctx->stream, d_table, d_table, tn, d_scan_tmp);
+        switch (cur.nw) {
+        case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table); break;
+        case 2: launch_scatter<2>(ctx, cur, nxt, word, shift, n, g, d_table); break;
+        default: launch_scatter<3>(ctx, cur, nxt, word, shift, n, g, d_table); break;
+        }
+        SortBufs tmp = cur; cur = nxt; nxt = tmp;
+        in_b = !in_b;
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    *result_in_b = in_b;
+    return 0;
+}
+
+}  // namespace ptx

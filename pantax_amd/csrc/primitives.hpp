@@ -1,0 +1,42 @@
+// primitives.hpp -- device-wide exclusive scan and LSD radix sort used by the trio index (a7)
+// and the LP row grouping (a10/a12).  Hand-written for wave64 / gfx950: ranks inside a wave come
+// from __ballot matching (64-bit masks), block offsets from an LDS table, one launch per stage.
+#pragma once
+#include "common.hpp"
+
+namespace ptx {
+
+// out[i] = sum_{j<i} in[j] (u32 arithmetic); *d_total (device, may be null) = sum of all.
+// d_tmp must hold scan_tmp_elems(n) uint32.
+size_t scan_tmp_elems(uint64_t n);
+int exclusive_scan_u32(Ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total);
+int exclusive_scan_u8(Ctx *ctx, const uint8_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total);
+
+// Records are structure-of-arrays: up to 3 u64 key words + one u32 payload.
+constexpr int SORT_MAX_WORDS = 3;
+struct SortBufs {
+    int nw = 0;                       // key words in use
+    uint64_t *k[SORT_MAX_WORDS] = {}; // d pointers
+    uint32_t *v = nullptr;            // payload (may be null)
+};
+struct SortPass {
+    int word;   // which key word supplies the digit
+    int shift;  // digit = (k[word] >> shift) & 0xFF
+};
+// Stable LSD radix sort: passes[0] is the LEAST significant digit.  Ping-pongs between a and b;
+// returns (via *result_in_b) which side holds the sorted records.  d_table: >= sort_table_elems(n) u32.
+size_t sort_table_elems(uint64_t n);
+int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *passes, int n_passes, uint32_t *d_table,
+               uint32_t *d_scan_tmp, bool *result_in_b);
+
+// helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
+inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {
+    for (int s = lo; s < hi; s += 8) out.push_back({word, s});
+}
+inline int bits_for(uint64_t max_value) {
+    int b = 0;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b ? b : 1;
+}
+
+}  // namespace ptx

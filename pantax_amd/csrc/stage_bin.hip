@@ -1,0 +1,124 @@
+// stage_bin.hip -- a2 + a3: read -> species binning and per-species counters.
+//
+// Reference: process_single_read_simple rcls.rs:237-258 (min/max node id of the walk, first
+// range in file order with start <= min && max <= end, else "U"; empty walk => (-1,-1) => "U")
+// and the counters of equal_length_read_cls / non_equal_length_read_cls profile.rs:208-297
+// (read_count, sum(read_len), #(3<=mapq<=60), #(mapq==60)) over reads with species != "U".
+//
+// HBM-bound streaming kernel: algorithmic bytes = 4T (node ids) + 4(R+1) (offsets) + 4R (qlen)
+// + R (mapq) + 4R (species out).  One thread per read (short-read walks are ~6 steps; adjacent
+// threads read adjacent id runs so the wave's loads stay within a few cache lines); the species
+// counters are staged in an LDS histogram and flushed with one 64-bit atomic per touched bin.
+#include "common.hpp"
+
+namespace ptx {
+
+constexpr int BIN_BLOCK = 256;
+constexpr int BIN_LDS_SPECIES = 1024;
+
+template <bool SORTED>
+__device__ __forceinline__ int find_species(uint32_t mn, uint32_t mx, const uint32_t *__restrict__ rs,
+                                            const uint32_t *__restrict__ re, const uint32_t *__restrict__ ridx, int S) {
+    if (SORTED) {
+        // ranges sorted by start and pairwise disjoint: at most one range can contain [mn,mx],
+        // so "first match in file order" == "the match"
+        int lo = 0, hi = S;  // last i with rs[i] <= mn
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (rs[mid] <= mn) lo = mid + 1; else hi = mid;
+        }
+        int i = lo - 1;
+        if (i >= 0 && mx <= re[i]) return (int)ridx[i];
+        return -1;
+    } else {
+        for (int i = 0; i < S; ++i)  // file order, first match (rcls.rs:253-257)
+            if (mn >= rs[i] && mx <= re[i]) return (int)ridx[i];
+        return -1;
+    }
+}
+
+template <bool SORTED, bool LDS_HIST>
+__global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
+    uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+    const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, const uint32_t *__restrict__ rs,
+    const uint32_t *__restrict__ re, const uint32_t *__restrict__ ridx, int S, int32_t *__restrict__ species_out,
+    unsigned long long *__restrict__ counters /* [4][S]: read_count, base_sum, less_multi, uniq_count */) {
+    __shared__ unsigned int s_cnt[LDS_HIST ? 3 * BIN_LDS_SPECIES : 1];
+    __shared__ unsigned long long s_base[LDS_HIST ? BIN_LDS_SPECIES : 1];
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < 3 * S; i += BIN_BLOCK) s_cnt[i] = 0;
+        for (int i = threadIdx.x; i < S; i += BIN_BLOCK) s_base[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t r = (uint64_t)blockIdx.x * BIN_BLOCK + threadIdx.x; r < R; r += (uint64_t)gridDim.x * BIN_BLOCK) {
+        uint32_t b = step_off[r], e = step_off[r + 1];
+        int sp = -1;
+        if (e > b) {
+            uint32_t mn = 0xFFFFFFFFu, mx = 0;
+            for (uint32_t i = b; i < e; ++i) {
+                uint32_t v = node_id[i];
+                mn = min(mn, v);
+                mx = max(mx, v);
+            }
+            sp = find_species<SORTED>(mn, mx, rs, re, ridx, S);
+        }
+        species_out[r] = sp;
+        if (sp >= 0) {
+            uint32_t q = qlen[r];
+            uint32_t m = mapq[r];
+            bool lm = (m >= 3 && m <= 60);
+            bool uq = (m == 60);
+            if (LDS_HIST) {
+                atomicAdd(&s_cnt[sp], 1u);
+                atomicAdd(&s_base[sp], (unsigned long long)q);
+                if (lm) atomicAdd(&s_cnt[S + sp], 1u);
+                if (uq) atomicAdd(&s_cnt[2 * S + sp], 1u);
+            } else {
+                atomicAdd(&counters[sp], 1ull);
+                atomicAdd(&counters[S + sp], (unsigned long long)q);
+                if (lm) atomicAdd(&counters[2 * S + sp], 1ull);
+                if (uq) atomicAdd(&counters[3 * S + sp], 1ull);
+            }
+        }
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < S; i += BIN_BLOCK) {
+            unsigned int c = s_cnt[i];
+            if (c) {
+                atomicAdd(&counters[i], (unsigned long long)c);
+                atomicAdd(&counters[S + i], s_base[i]);
+                unsigned int l = s_cnt[S + i], u = s_cnt[2 * S + i];
+                if (l) atomicAdd(&counters[2 * S + i], (unsigned long long)l);
+                if (u) atomicAdd(&counters[3 * S + i], (unsigned long long)u);
+            }
+        }
+    }
+}
+
+int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters) {
+    int S = (int)db->S;
+    PTX_HIP(ctx, rd->d_species.alloc(rd->R));
+    PTX_HIP(ctx, hipMemsetAsync(d_counters, 0, 4ull * S * sizeof(unsigned long long), ctx->stream));
+    if (rd->R == 0) { rd->binned = true; return 0; }
+    int grid = grid_for(rd->R, BIN_BLOCK, ctx->n_cu * 8);
+    bool lds = S <= BIN_LDS_SPECIES;
+    {
+        KTimer t(ctx, "bin_reads_kernel");
+#define BIN_ARGS rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_qlen.p, rd->d_mapq.p, db->d_rng_start.p, db->d_rng_end.p, \
+                 db->d_rng_idx.p, S, rd->d_species.p, d_counters
+        if (db->ranges_sorted_disjoint) {
+            if (lds) hipLaunchKernelGGL((bin_reads_kernel<true, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+            else hipLaunchKernelGGL((bin_reads_kernel<true, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+        } else {
+            if (lds) hipLaunchKernelGGL((bin_reads_kernel<false, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+            else hipLaunchKernelGGL((bin_reads_kernel<false, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+        }
+#undef BIN_ARGS
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    rd->binned = true;
+    return 0;
+}
+
+}  // namespace ptx

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's profiling interface over the C ABI.
+
+Method names follow the reference functions they stand in for (profile.rs / rcls.rs)
+so the parity tests read like tests of the reference:
+    rcls_profile            rcls.rs:452-458   (+ species counters profile.rs:208-297)
+    trio_nodes_info         profile.rs:658-740
+    get_node_abundances     profile.rs:743-1026
+    strain_profiling        profile.rs:3291-3323 (optimize_otu + abundace_constraint per species)
+    pao_solve               the X_opt solver seam, profile.rs:2690-2698
+Everything here is plumbing: numpy arrays in, ctypes call, numpy arrays out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PantaxHipError, as_c, p
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = _ffi.load()
+        self.ctx = C.c_void_p()
+        dev = (C.c_int * 1)(device)
+        rc = self.lib.pantax_hip_init(C.byref(self.ctx), dev, 1)
+        if rc != 0:
+            raise PantaxHipError(rc, self.lib.pantax_hip_last_error(None).decode())
+        self.db = None
+        self.reads = None
+        self._keep = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise PantaxHipError(rc, self.lib.pantax_hip_last_error(self.ctx).decode())
+
+    def close(self):
+        if self.ctx:
+            if self.reads:
+                self.lib.pantax_hip_reads_free(self.ctx, self.reads)
+                self.reads = None
+            if self.db:
+                self.lib.pantax_hip_db_free(self.ctx, self.db)
+                self.db = None
+            self.lib.pantax_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._check(self.lib.pantax_hip_sync(self.ctx))
+
+    # ------------------------------------------------------------------ uploads
+    def upload_db(self, species):
+        """species: list of objects with node_len, path_off, path_nodes, range_start, range_end
+        (pantax_amd.synth.SpeciesGraph or pantax_amd.io graphs), haplotypes in byte order."""
+        if self.db:
+            self.lib.pantax_hip_db_free(self.ctx, self.db)
+            self.db = None
+        S = len(species)
+        self.S = S
+        self.range_start = as_c([g.range_start for g in species], np.int64)
+        self.range_end = as_c([g.range_end for g in species], np.int64)
+        self.node_off = np.zeros(S + 1, dtype=np.uint64)
+        self.node_off[1:] = np.cumsum([len(g.node_len) for g in species])
+        self.hap_off = np.zeros(S + 1, dtype=np.uint64)
+        self.hap_off[1:] = np.cumsum([len(g.path_off) - 1 for g in species])
+        self.node_len = as_c(np.concatenate([g.node_len for g in species]), np.int64)
+        offs = [np.zeros(1, dtype=np.uint64)]
+        base = 0
+        for g in species:
+            offs.append(np.asarray(g.path_off[1:], dtype=np.uint64) + np.uint64(base))
+            base += int(g.path_off[-1])
+        self.path_off = as_c(np.concatenate(offs), np.uint64)
+        self.path_nodes = as_c(np.concatenate([g.path_nodes for g in species]), np.uint32)
+        self.V = int(self.node_off[-1])
+        self.H = int(self.hap_off[-1])
+        gs = _ffi.Graphs(S, p(self.range_start), p(self.range_end), p(self.node_off), p(self.node_len),
+                         p(self.hap_off), p(self.path_off), p(self.path_nodes))
+        db = C.c_void_p()
+        self._check(self.lib.pantax_hip_db_upload(self.ctx, C.byref(gs), C.byref(db)))
+        self.db = db
+        self.U = None
+
+    def upload_reads(self, step_off, node_id, pstart, pend, qlen, mapq, flags=None):
+        if self.reads:
+            self.lib.pantax_hip_reads_free(self.ctx, self.reads)
+            self.reads = None
+        arrs = dict(step_off=as_c(step_off, np.uint32), node_id=as_c(node_id, np.uint32), pstart=as_c(pstart, np.uint32),
+                    pend=as_c(pend, np.uint32), qlen=as_c(qlen, np.uint32), mapq=as_c(mapq, np.uint8),
+                    flags=None if flags is None else as_c(flags, np.uint8))
+        R = len(arrs["pstart"])
+        self.R = R
+        self.T = len(arrs["node_id"])
+        pr = _ffi.PackedReads(R, self.T, p(arrs["step_off"]), p(arrs["node_id"]), p(arrs["pstart"]), p(arrs["pend"]),
+                              p(arrs["qlen"]), p(arrs["mapq"]), p(arrs["flags"]))
+        rd = C.c_void_p()
+        self._check(self.lib.pantax_hip_reads_upload(self.ctx, C.byref(pr), C.byref(rd)))
+        self.reads = rd
+
+    def upload_packed(self, reads, flags=None):
+        """reads: pantax_amd.synth.PackedReads (int64 host arrays)"""
+        mapq = np.where((reads.mapq < 0) | (reads.mapq > 254), 255, reads.mapq)
+        self.upload_reads(reads.step_off, reads.node_id, reads.pstart, reads.pend, reads.qlen, mapq, flags)
+
+    # ------------------------------------------------------------------ stages
+    def rcls_profile(self, want_species=True):
+        """-> (species_idx [R] int32 or None, read_count, base_sum, less_multi, uniq_count [S] int64)"""
+        sp = np.empty(self.R, dtype=np.int32) if want_species else None
+        outs = [np.zeros(self.S, dtype=np.int64) for _ in range(4)]
+        self._check(self.lib.pantax_hip_bin_reads(self.ctx, self.db, self.reads, p(sp), *[p(o) for o in outs]))
+        return (sp, *outs)
+
+    def trio_nodes_info(self, fetch=True):
+        n = C.c_uint64(0)
+        self._check(self.lib.pantax_hip_trio_index(self.ctx, self.db, C.byref(n)))
+        self.U = n.value
+        if not fetch:
+            return self.U
+        U = self.U
+        abc = np.zeros(max(U, 1) * 3, dtype=np.uint32)
+        hap = np.zeros(max(U, 1), dtype=np.uint32)
+        ln = np.zeros(max(U, 1), dtype=np.int64)
+        hto = np.zeros(self.H + 1, dtype=np.uint64)
+        self._check(self.lib.pantax_hip_trio_get(self.ctx, self.db, p(abc), p(hap), p(ln), p(hto)))
+        return abc[: 3 * U].reshape(-1, 3), hap[:U], ln[:U], hto
+
+    def get_node_abundances(self, species_active=None, fetch=True, with_trio=True):
+        """-> bases_per_node [V] int64, node_base_cov [V] uint64, trio_bases [U] int64, n_abort"""
+        act = None if species_active is None else as_c(species_active, np.uint8)
+        n_abort = C.c_uint64(0)
+        if not fetch:
+            self._check(self.lib.pantax_hip_node_coverage(self.ctx, self.db, self.reads, p(act), None, None, None,
+                                                          C.byref(n_abort)))
+            return n_abort.value
+        bases = np.zeros(self.V, dtype=np.int64)
+        cov = np.zeros(self.V, dtype=np.uint64)
+        tb = None
+        if with_trio and self.U is not None:
+            tb = np.zeros(max(self.U, 1), dtype=np.int64)
+        self._check(self.lib.pantax_hip_node_coverage(self.ctx, self.db, self.reads, p(act), p(bases), p(cov), p(tb),
+                                                      C.byref(n_abort)))
+        return bases, cov, (tb[: self.U] if tb is not None else None), n_abort.value
+
+    def strain_profiling(self, species_coverage, species_active=None, fr=0.3, fc=0.46, sr=0.85, min_depth=0,
+                         shift=False, sample_nodes=0):
+        cfg = _ffi.StrainConfig(fr, fc, sr, min_depth, int(shift), sample_nodes)
+        act = None if species_active is None else as_c(species_active, np.uint8)
+        cov = as_c(species_coverage, np.float64)
+        met = (_ffi.HapMetrics * max(self.H, 1))()
+        info = (_ffi.SolveInfo * self.S)()
+        self._check(self.lib.pantax_hip_strain_profile(self.ctx, self.db, C.byref(cfg), p(act), p(cov), met, info))
+        return met, info
+
+    def pao_solve(self, node_len, node_abundance, node_base_cov, path_off, path_nodes, cand, fixed_zero=None):
+        node_len = as_c(node_len, np.int64)
+        ab = as_c(node_abundance, np.float64)
+        cov = as_c(node_base_cov, np.uint64)
+        path_off = as_c(path_off, np.uint64)
+        path_nodes = as_c(path_nodes, np.uint32)
+        cand = as_c(cand, np.uint32)
+        fz = None if fixed_zero is None else as_c(fixed_zero, np.uint8)
+        x = np.zeros(len(cand))
+        ratio = np.zeros(len(cand), dtype=np.float32)
+        obj = C.c_double(0)
+        st = C.c_int32(0)
+        self._check(self.lib.pantax_hip_pao_solve(self.ctx, C.c_uint32(len(node_len)), p(node_len), p(ab), p(cov),
+                                                  C.c_uint32(len(path_off) - 1), p(path_off), p(path_nodes),
+                                                  C.c_uint32(len(cand)), p(cand), p(fz), p(x), p(ratio),
+                                                  C.byref(obj), C.byref(st)))
+        return x, ratio, obj.value, st.value
+
+    # ------------------------------------------------------------------ timing
+    def timing_enable(self, on=True):
+        self._check(self.lib.pantax_hip_timing_enable(self.ctx, int(on)))
+
+    def timing_reset(self):
+        self._check(self.lib.pantax_hip_timing_reset(self.ctx))
+
+    def timing_get(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        launches = (C.c_uint64 * cap)()
+        ms = (C.c_double * cap)()
+        n = self.lib.pantax_hip_timing_get(self.ctx, cap, names, launches, ms)
+        if n < 0:
+            self._check(n)
+        return {names[i].decode(): (int(launches[i]), float(ms[i])) for i in range(min(n, cap))}
+
+
+def metrics_to_dicts(met, n=None):
+    out = []
+    for i, m in enumerate(met):
+        if n is not None and i >= n:
+            break
+        d = {}
+        for name, bit, attr in [("unique_trio_fraction", 1, "unique_trio_nodes_fraction"),
+                                ("uniq_trio_cov_mean", 2, "frequencies_mean"), ("path_base_cov", 4, "path_cov_ratio"),
+                                ("first_sol", 8, "first_sol"), ("strain_cov_diff", 16, "divergence"),
+                                ("predicted_coverage", 32, "second_sol"), ("total_cov_diff", 128, "total_cov_diff")]:
+            d[name] = getattr(m, attr) if m.has & bit else None
+        d["is_rescue"] = bool(m.is_rescue) if m.has & 64 else None
+        out.append(d)
+    return out
