@@ -1,0 +1,760 @@
+// stage_lad.hip -- a9/a10/a12 on device: trio statistics, candidate masks + path_cov_ratio,
+// LP row grouping, and the batched exact LAD solver that replaces the Gurobi/HiGHS/CBC/GLPK
+// backends (profile.rs:1297-1511, 2689-2882).
+//
+// The reference LP per species (gurobi_opt, profile.rs:1312-1460):
+//     min (1/n) sum_{v: a_v>0} y_v,   y_v >= +-(sum_k A_vk x_k - a_v),   0 <= x_k <= 1.05*max(a)
+// with A_vk = 1 iff node v lies on candidate path k (:1333-1342); the binary indicators are inert
+// (SURVEY.md 8c).  That is a least-absolute-deviation fit in p <= 64 variables.  Rows with the
+// same membership pattern m (a p-bit mask) only see s_m = sum_{k in m} x_k, so after ONE
+// HBM-bound pass that sorts the n covered nodes by (species, mask, a) the objective is
+//     f(x) = (1/n) sum_patterns F_m(s_m),  F_m(s) = sum_{rows of m} |s - a|,
+// and f, its sub-gradient and exact line searches cost O(#patterns * log n) binary searches.
+// The solver is an exact active-set (Bloomfield-Steiger / Barrodale-Roberts) descent on that
+// representation, one workgroup per species, all species of the batch in one launch.
+#include <algorithm>
+#include "lad.hpp"
+#include "primitives.hpp"
+
+namespace ptx {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ double block_sum_f64(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += red[w];   // fixed order: deterministic
+    __syncthreads();
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += red[w];
+    __syncthreads();
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ double block_max_f64(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) t = fmax(t, red[w]);
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_a(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (a[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ uint32_t upper_bound_a(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (a[m] <= v) lo = m + 1; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ double mdot(uint64_t m, const double *x) {   // ascending-bit order
+    double s = 0.0;
+    while (m) { int j = __ffsll((long long)m) - 1; s += x[j]; m &= m - 1; }
+    return s;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9: per-hap unique-trio statistics.  One workgroup per haplotype; three passes over its rows
+// (they are contiguous because trio rows are ordered (species, hap, position)).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hap_trio_stats_kernel(const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
+                                                             const uint32_t *__restrict__ tlen, uint32_t *__restrict__ nnz_out,
+                                                             double *__restrict__ mean_out) {
+    __shared__ double red[4];
+    __shared__ unsigned long long redu[4];
+    const uint32_t h = blockIdx.x;
+    const uint64_t b = hto[h], e = hto[h + 1];
+    double sum = 0.0; unsigned long long cnt = 0;
+    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+        double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
+        if (x > 0.0) { sum += x; ++cnt; }                       // :1129-1133
+    }
+    sum = block_sum_f64<256>(sum, red);
+    cnt = block_sum_u64<256>(cnt, redu);
+    double meanf = 0.0;
+    if (cnt > 0) {
+        double mean = sum / (double)cnt;                         // :1037
+        double ss = 0.0;
+        for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+            double x = (double)(long long)tb[u] / (double)tlen[u];
+            if (x > 0.0) ss += (x - mean) * (x - mean);
+        }
+        ss = block_sum_f64<256>(ss, red);
+        double sd = sqrt(ss / (double)cnt);                      // :1038-1041 population std
+        if (sd != 0.0) {                                         // :1043-1045 std == 0 -> empty -> mean 0.0
+            double fs = 0.0; unsigned long long fc = 0;
+            for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+                double x = (double)(long long)tb[u] / (double)tlen[u];
+                if (x > 0.0 && fabs((x - mean) / sd) < 3.0) { fs += x; ++fc; }   // :1047-1050
+            }
+            fs = block_sum_f64<256>(fs, red);
+            fc = block_sum_u64<256>(fc, redu);
+            if (fc) meanf = fs / (double)fc;
+        }
+    }
+    if (threadIdx.x == 0) { nnz_out[h] = (uint32_t)cnt; mean_out[h] = meanf; }
+}
+
+int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBuf<double> &d_mean) {
+    PTX_HIP(ctx, d_nnz.alloc(db->H));
+    PTX_HIP(ctx, d_mean.alloc(db->H));
+    if (db->H == 0) return 0;
+    KTimer t(ctx, "hap_trio_stats_kernel");
+    hipLaunchKernelGGL(hap_trio_stats_kernel, dim3((uint32_t)db->H), dim3(256), 0, ctx->stream, db->d_hap_trio_off.p, db->d_trio_bases.p,
+                       db->d_trio_len.p, d_nnz.p, d_mean.p);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// node abundance + per-species statistics
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
+                                                          const unsigned long long *__restrict__ bases, double min_depth,
+                                                          double *__restrict__ ab_out, double *__restrict__ amax_out,
+                                                          uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
+                                                          uint32_t *__restrict__ nzcnt_out) {
+    __shared__ double red[16];
+    __shared__ unsigned long long redu[16];
+    const uint32_t s = blockIdx.x;
+    const uint32_t b = node_base[s], e = node_base[s + 1];
+    double mx = -INFINITY, zs = 0.0;
+    unsigned long long nv = 0, zc = 0;
+    for (uint32_t v = b + threadIdx.x; v < e; v += 1024) {
+        double len = (double)(bit_off[v + 1] - bit_off[v]);
+        double ab = (double)(long long)bases[v] / len;           // profile.rs:987-988
+        ab_out[v] = ab;
+        mx = fmax(mx, ab);
+        if (ab > 0.0) ++nv;
+        double o = ab > min_depth ? ab : 0.0;                    // :2941-2944
+        if (o > 0.0) { zs += o; ++zc; }
+    }
+    mx = block_max_f64<1024>(mx, red);
+    zs = block_sum_f64<1024>(zs, red);
+    nv = block_sum_u64<1024>(nv, redu);
+    zc = block_sum_u64<1024>(zc, redu);
+    if (threadIdx.x == 0) { amax_out[s] = mx; nvalid_out[s] = (uint32_t)nv; nzsum_out[s] = zs; nzcnt_out[s] = (uint32_t)zc; }
+}
+
+int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
+    uint32_t S = db->S;
+    lb->S = S;
+    PTX_HIP(ctx, lb->d_ab.alloc(db->V));
+    PTX_HIP(ctx, lb->d_amax.alloc(S)); PTX_HIP(ctx, lb->d_nvalid.alloc(S));
+    PTX_HIP(ctx, lb->d_nzsum.alloc(S)); PTX_HIP(ctx, lb->d_nzcnt.alloc(S));
+    KTimer t(ctx, "node_stats_kernel");
+    hipLaunchKernelGGL(node_stats_kernel, dim3(S), dim3(1024), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
+                       (double)min_depth, lb->d_ab.p, lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10: membership masks (the 0/1 coefficient matrix, one u64 row per node) and path_cov_ratio
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t find_hap_l(const uint64_t *__restrict__ path_off, uint32_t H, uint64_t q) {
+    uint32_t lo = 0, hi = H;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= q) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
+
+__global__ void __launch_bounds__(256) mask_kernel(uint64_t P, uint32_t H, const uint64_t *__restrict__ path_off,
+                                                   const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
+                                                   const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
+                                                   unsigned long long *__restrict__ mask) {
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
+        uint32_t h = find_hap_l(path_off, H, q);
+        int bit = hap_bit[h];
+        if (bit < 0) continue;
+        unsigned long long m = 1ull << bit;
+        unsigned long long *w = &mask[node_base[hap_species[h]] + path_nodes[q]];
+        if ((*w & m) == 0) atomicOr(w, m);   // coeff_matrix[(v,pos)] = 1.0 even for repeated visits (profile.rs:1336-1340)
+    }
+}
+
+constexpr int RATIO_CHUNKS = 32;
+__global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
+                                                    const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
+                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio) {
+    __shared__ unsigned long long acc[LAD_MAXP * 2];
+    const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
+    if (sp_p[s] <= 0) return;
+    if (threadIdx.x < LAD_MAXP * 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b = node_base[s], e = node_base[s + 1];
+    const uint32_t per = (e - b + RATIO_CHUNKS - 1) / RATIO_CHUNKS;
+    uint32_t lo = b + ch * per, hi = lo + per;
+    if (hi > e) hi = e;
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+        unsigned long long m = mask[v];
+        if (!m) continue;
+        unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+        while (m) {
+            int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (c) atomicAdd(&acc[2 * k], c);
+            atomicAdd(&acc[2 * k + 1], l);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < LAD_MAXP * 2 && acc[threadIdx.x]) atomicAdd(&ratio[(size_t)s * LAD_MAXP * 2 + threadIdx.x], acc[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LP rows: nodes with a_v > 0 (valid rows, profile.rs:1380-1385) and a non-empty mask; rows with an
+// empty mask only add the constant a_v to the objective and are handled by objective_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) row_flag_kernel(uint64_t V, const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
+                                                       uint8_t *__restrict__ flag) {
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256)
+        flag[v] = (ab[v] > 0.0 && mask[v] != 0ull) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
+                                                       const unsigned long long *__restrict__ mask, const uint8_t *__restrict__ flag,
+                                                       const uint32_t *__restrict__ pos, uint64_t *__restrict__ k0, uint64_t *__restrict__ k1,
+                                                       uint64_t *__restrict__ k2) {
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256) {
+        if (!flag[v]) continue;
+        uint32_t lo = 0, hi = S;   // species of node v: last s with node_base[s] <= v
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; }
+        uint32_t j = pos[v];
+        k0[j] = lo - 1;
+        k1[j] = mask[v];
+        k2[j] = (uint64_t)__double_as_longlong(ab[v]);   // positive doubles order like their bit patterns
+    }
+}
+__global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t n, const uint64_t *__restrict__ k0, const uint64_t *__restrict__ k1,
+                                                       uint8_t *__restrict__ head) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        head[i] = (i == 0 || k0[i] != k0[i - 1] || k1[i] != k1[i - 1]) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) pat_emit_kernel(uint64_t n, const uint64_t *__restrict__ k0, const uint64_t *__restrict__ k1,
+                                                       const uint8_t *__restrict__ head, const uint32_t *__restrict__ pidx,
+                                                       uint64_t *__restrict__ pat_mask, uint32_t *__restrict__ pat_start,
+                                                       uint32_t *__restrict__ pat_species) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        if (!head[i]) continue;
+        uint32_t j = pidx[i];
+        pat_mask[j] = k1[i];
+        pat_start[j] = (uint32_t)i;
+        pat_species[j] = (uint32_t)k0[i];
+    }
+}
+
+int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
+    const uint32_t S = db->S;
+    const uint64_t V = db->V, P = db->P, H = db->H;
+    // candidate bit per hap
+    std::vector<int32_t> hap_bit(H ? H : 1, -1);
+    int pmax = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        pmax = std::max(pmax, lb->h_p[s]);
+        for (int k = 0; k < lb->h_p[s]; ++k) hap_bit[db->h_hap_off[s] + lb->h_cand[(size_t)s * LAD_MAXP + k]] = k;
+    }
+    PTX_TRY(upload(ctx, lb->d_hap_bit, hap_bit.data(), hap_bit.size()));
+    PTX_TRY(upload(ctx, lb->d_p, lb->h_p.data(), S));
+    PTX_HIP(ctx, lb->d_mask.alloc(V));
+    PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
+    PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(lb->d_ratio.p, 0, (size_t)S * LAD_MAXP * 2 * sizeof(unsigned long long), ctx->stream));
+    lb->n_rows = 0; lb->K = 0;
+    lb->h_sp_pat_off.assign(S + 1, 0);
+    if (pmax == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
+    {
+        KTimer t(ctx, "mask_kernel");
+        hipLaunchKernelGGL(mask_kernel, dim3(grid_for(P, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, P, (uint32_t)H, db->d_path_off.p,
+                           db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
+    }
+    {
+        KTimer t(ctx, "ratio_kernel");
+        hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
+                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
+    }
+    // rows: flag -> scan -> emit -> sort by (species, mask, a)
+    DevBuf<uint8_t> flag;
+    DevBuf<uint32_t> pos, scan_tmp, table, d_tot;
+    PTX_HIP(ctx, flag.alloc(V)); PTX_HIP(ctx, pos.alloc(V));
+    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
+    PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
+    PTX_HIP(ctx, d_tot.alloc(2));
+    int gridV = grid_for(V, 256, ctx->n_cu * 8);
+    {
+        KTimer t(ctx, "row_flag_kernel");
+        hipLaunchKernelGGL(row_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, lb->d_ab.p, (unsigned long long *)lb->d_mask.p, flag.p);
+    }
+    PTX_TRY(exclusive_scan_u8(ctx, flag.p, pos.p, V, scan_tmp.p, d_tot.p));
+    uint32_t n_rows = 0;
+    PTX_TRY(download(ctx, &n_rows, d_tot.p, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lb->n_rows = n_rows;
+    if (n_rows == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
+    DevBuf<uint64_t> ka[3], kb[3];
+    for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(n_rows)); PTX_HIP(ctx, kb[w].alloc(n_rows)); }
+    {
+        KTimer t(ctx, "row_emit_kernel");
+        hipLaunchKernelGGL(row_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
+                           (unsigned long long *)lb->d_mask.p, flag.p, pos.p, ka[0].p, ka[1].p, ka[2].p);
+    }
+    std::vector<SortPass> passes;
+    add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
+    add_passes(passes, 1, 0, pmax);                    // mask bits in use
+    if (S > 1) add_passes(passes, 0, 0, bits_for(S - 1));
+    SortBufs A, B;
+    A.nw = B.nw = 3;
+    for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
+    bool in_b = false;
+    PTX_TRY(radix_sort(ctx, A, B, n_rows, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b));
+    SortBufs Sd = in_b ? B : A;
+    // patterns = runs of equal (species, mask)
+    DevBuf<uint8_t> head;
+    DevBuf<uint32_t> pidx;
+    PTX_HIP(ctx, head.alloc(n_rows)); PTX_HIP(ctx, pidx.alloc(n_rows));
+    int gridN = grid_for(n_rows, 256, ctx->n_cu * 8);
+    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p);
+    PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, n_rows, scan_tmp.p, d_tot.p + 1));
+    uint32_t K = 0;
+    PTX_TRY(download(ctx, &K, d_tot.p + 1, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lb->K = K;
+    PTX_HIP(ctx, lb->d_pat_mask.alloc(K)); PTX_HIP(ctx, lb->d_pat_start.alloc(K + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(K));
+    hipLaunchKernelGGL(pat_emit_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p, pidx.p,
+                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p);
+    PTX_HIP(ctx, hipMemcpyAsync(lb->d_pat_start.p + K, &lb->n_rows, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PTX_HIP(ctx, lb->d_row_a.alloc(n_rows));
+    PTX_HIP(ctx, hipMemcpyAsync(lb->d_row_a.p, Sd.k[2], (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<uint32_t> pat_species(K);
+    PTX_TRY(download(ctx, pat_species.data(), lb->d_pat_species.p, K));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {   // species -> pattern range (patterns are sorted by species)
+        uint32_t j = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            lb->h_sp_pat_off[s] = j;
+            while (j < K && pat_species[j] == s) ++j;
+        }
+        lb->h_sp_pat_off[S] = j;
+    }
+    PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1));
+    PTX_HIP(ctx, lb->d_pat_eps.alloc(K)); PTX_HIP(ctx, lb->d_sc_s.alloc(K)); PTX_HIP(ctx, lb->d_sc_rho.alloc(K));
+    PTX_HIP(ctx, lb->d_sc_lo.alloc(K)); PTX_HIP(ctx, lb->d_sc_up.alloc(K)); PTX_HIP(ctx, lb->d_ls_lo.alloc(K)); PTX_HIP(ctx, lb->d_ls_hi.alloc(K)); PTX_HIP(ctx, lb->d_ls_mid.alloc(K));
+    PTX_HIP(ctx, hipGetLastError());
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a12: the batched exact LAD solver
+// ---------------------------------------------------------------------------------------------
+constexpr int LAD_BLOCK = 256;
+enum { C_LB = 0, C_UB = 1, C_PAT = 2, C_FIXED = 3 };
+
+struct LadArgs {
+    const double *row_a;
+    const uint64_t *pat_mask;
+    const uint32_t *pat_start;
+    const uint32_t *sp_pat_off;
+    double *pat_eps, *sc_s, *sc_rho;
+    uint32_t *sc_lo, *sc_up, *ls_lo, *ls_hi, *ls_mid;
+    const int32_t *sp_p;
+    const double *ub;
+    const double *amax;
+    double *x_out;
+    int32_t *status, *iters;
+    const int32_t *solve_list;
+};
+
+struct LadShared {
+    double x[LAD_MAXP], c[LAD_MAXP], lam[LAD_MAXP], d[LAD_MAXP], ub[LAD_MAXP], fac[LAD_MAXP], score[LAD_MAXP], deriv[LAD_MAXP];
+    long long g[LAD_MAXP];
+    int act_type[LAD_MAXP], act_jk[LAD_MAXP], dir[LAD_MAXP];
+    uint32_t act_i0[LAD_MAXP], act_i1[LAD_MAXP];
+    double red[LAD_BLOCK / 64];
+    double red_t[LAD_BLOCK / 64];
+    int red_k[LAD_BLOCK / 64];
+    // control words written by one thread, read by all after a barrier
+    int best, bdir, done, bj, btype, status, ent_type, piv;
+    uint32_t ent_k, ent_i0, ent_i1;
+    double bderiv, tmax, S_lo;
+};
+
+// number of breakpoints of pattern k crossed when moving t along the search direction
+__device__ __forceinline__ uint32_t crossed(const double *__restrict__ a, double rho, double s0, double eps, uint32_t st, uint32_t en,
+                                            uint32_t lo, uint32_t up, double t, uint32_t c_lo, uint32_t c_hi) {
+    double sv = s0 - eps + t * rho;
+    if (rho > 0) return upper_bound_a(a, up + c_lo, up + c_hi, sv) - up;       // rows a_i <= sv among [up,en)
+    return lo - lower_bound_a(a, lo - c_hi, lo - c_lo, sv);                    // rows a_i >= sv among [st,lo)
+}
+
+template <int PS>
+__global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
+    __shared__ LadShared sh;
+    __shared__ double W[PS * PS];
+    __shared__ double G[PS * 2 * PS];
+    const int tid = threadIdx.x;
+    const int s = A.solve_list[blockIdx.x];
+    const int p = A.sp_p[s];
+    const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
+    const double *__restrict__ ra = A.row_a;
+    const double tol = 1e-7;
+    const double amax = A.amax[s];
+    const double delta = 1e-10 * (amax > 1.0 ? amax : 1.0);
+    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK)
+        A.pat_eps[k] = delta * (0.25 + 0.5 * (double)(splitmix64(A.pat_mask[k]) >> 11) * (1.0 / 9007199254740992.0));
+    if (tid < p) {
+        double u = A.ub[(size_t)s * LAD_MAXP + tid];
+        sh.ub[tid] = u;
+        sh.act_type[tid] = u > 0.0 ? C_LB : C_FIXED;
+        sh.act_jk[tid] = tid;
+        sh.act_i0[tid] = sh.act_i1[tid] = 0;
+    }
+    for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = (i / p == i % p) ? 1.0 : 0.0;
+    if (tid == 0) { sh.done = 0; sh.status = 0; }
+    __syncthreads();
+    const int max_it = 200 * p + 2000;
+    int it = 0;
+    for (; it < max_it; ++it) {
+        // ---- vertex of the perturbed problem: x = W c
+        if (tid < p) {
+            int ty = sh.act_type[tid];
+            sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra[sh.act_i0[tid]] + A.pat_eps[sh.act_jk[tid]] : 0.0;
+        }
+        __syncthreads();
+        if (tid < p) {
+            double v = 0.0;
+            for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
+            sh.x[tid] = v;
+            sh.g[tid] = 0;
+        }
+        __syncthreads();
+        // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
+        for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+            uint64_t mk = A.pat_mask[k];
+            uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
+            int ai = -1;
+            for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
+            uint32_t lo, up; double sk;
+            if (ai >= 0) { lo = sh.act_i0[ai]; up = sh.act_i1[ai]; sk = ra[lo] + A.pat_eps[k]; }
+            else {
+                sk = mdot(mk, sh.x);
+                double sv = sk - A.pat_eps[k];
+                lo = lower_bound_a(ra, st, en, sv);
+                up = upper_bound_a(ra, lo, en, sv);
+            }
+            A.sc_s[k] = sk; A.sc_lo[k] = lo; A.sc_up[k] = up;
+            long long sigma = (long long)(lo - st) - (long long)(en - up);
+            if (sigma) {
+                uint64_t m = mk;
+                while (m) { int j = __ffsll((long long)m) - 1; m &= m - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+            }
+        }
+        __syncthreads();
+        // ---- multipliers lam_i = -g . W[:,i]; steepest-edge choice of the constraint to relax
+        if (tid < p) {
+            double sdot = 0.0, nrm = 0.0;
+            for (int j = 0; j < p; ++j) { double w = W[j * PS + tid]; sdot += (double)sh.g[j] * w; nrm += w * w; }
+            double lam = -sdot; nrm = sqrt(nrm);
+            double deriv = 0.0; int dir = 0; int ty = sh.act_type[tid];
+            if (ty == C_PAT) {
+                double w = (double)(sh.act_i1[tid] - sh.act_i0[tid]);
+                if (lam > w + tol) { dir = +1; deriv = w - lam; } else if (lam < -w - tol) { dir = -1; deriv = w + lam; }
+            } else if (ty == C_LB) { if (lam > tol) { dir = +1; deriv = -lam; } }
+            else if (ty == C_UB) { if (lam < -tol) { dir = -1; deriv = lam; } }
+            sh.dir[tid] = dir; sh.deriv[tid] = deriv; sh.score[tid] = dir ? deriv / nrm : 0.0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int best = -1; double bs = -tol;
+            for (int i = 0; i < p; ++i) if (sh.dir[i] && sh.score[i] < bs) { bs = sh.score[i]; best = i; }
+            sh.best = best;
+            if (best < 0) sh.done = 1; else { sh.bdir = sh.dir[best]; sh.bderiv = sh.deriv[best]; }
+        }
+        __syncthreads();
+        if (sh.done) break;
+        const int best = sh.best; const double bdir = (double)sh.bdir;
+        if (tid < p) sh.d[tid] = bdir * W[tid * PS + best];
+        __syncthreads();
+        if (tid == 0) {   // ratio test against the box
+            double tmax = INFINITY; int bj = -1, bt = C_LB;
+            for (int j = 0; j < p; ++j) {
+                if (sh.ub[j] <= 0.0) continue;
+                double dj = sh.d[j];
+                if (dj < -1e-12) { double t = sh.x[j] / (-dj); if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_LB; } }
+                else if (dj > 1e-12) { double t = (sh.ub[j] - sh.x[j]) / dj; if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_UB; } }
+            }
+            sh.tmax = tmax; sh.bj = bj; sh.btype = bt;
+        }
+        // ---- line search set-up: rate rho_k of every pattern along d
+        double part = 0.0;
+        for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+            uint64_t mk = A.pat_mask[k];
+            int ai = -1;
+            for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
+            double rho;
+            if (ai >= 0) rho = (ai == best) ? bdir : 0.0;   // other tight patterns stay tight: n_i . d = 0
+            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; part += fabs(rho) * (double)(A.sc_up[k] - A.sc_lo[k]); }
+            A.sc_rho[k] = rho;
+            A.ls_lo[k] = 0;
+            A.ls_hi[k] = rho > 0 ? A.pat_start[k + 1] - A.sc_up[k] : rho < 0 ? A.sc_lo[k] - A.pat_start[k] : 0;
+        }
+        double S0 = sh.bderiv + block_sum_f64<LAD_BLOCK>(part, sh.red);   // slope just after t = 0
+        if (tid == 0) { sh.ent_type = -1; sh.S_lo = S0; }
+        __syncthreads();
+        const double tmax = sh.tmax;
+        if (S0 >= -tol) {
+            // degenerate: an unsplit tie group blocks the move at t = 0 -> it enters (step length 0)
+            double tb = INFINITY; int kb = 0x7fffffff;
+            for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK)
+                if (A.sc_rho[k] != 0.0 && A.sc_up[k] > A.sc_lo[k]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { int k2 = __shfl_down(kb, off); if (k2 < kb) kb = k2; }
+            if ((tid & 63) == 0) sh.red_k[tid >> 6] = kb;
+            __syncthreads();
+            if (tid == 0) {
+                int kk = sh.red_k[0];
+                for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red_k[w] < kk) kk = sh.red_k[w];
+                if (kk != 0x7fffffff) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = A.sc_lo[kk]; sh.ent_i1 = A.sc_up[kk]; }
+                else { sh.status = 4; sh.done = 1; }
+            }
+            (void)tb;
+            __syncthreads();
+        } else {
+            // ---- bracket: find t_hi with slope(t_hi) >= -tol (or the box bound enters)
+            double t_hi = isfinite(tmax) ? tmax : (amax > 1.0 ? amax : 1.0);
+            double S_hi = 0.0;
+            bool bound_enters = false;
+            for (int grow = 0; grow < 200; ++grow) {
+                double acc = 0.0;
+                for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                    double rho = A.sc_rho[k];
+                    if (rho == 0.0) continue;
+                    uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
+                    uint32_t cmax = rho > 0 ? en - A.sc_up[k] : A.sc_lo[k] - st;
+                    uint32_t c = crossed(ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
+                    A.ls_hi[k] = c;
+                    acc += fabs(rho) * 2.0 * (double)c;
+                }
+                S_hi = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
+                if (S_hi >= -tol) break;
+                if (isfinite(tmax)) { bound_enters = true; break; }
+                t_hi *= 4.0;
+                if (grow == 199) bound_enters = true;   // cannot happen: slope(inf) >= 0 for a LAD objective
+            }
+            if (bound_enters) {
+                if (tid == 0) {
+                    if (sh.bj >= 0) { sh.ent_type = sh.btype; sh.ent_k = (uint32_t)sh.bj; }
+                    else { sh.status = 2; sh.done = 1; }
+                }
+                __syncthreads();
+            } else {
+                // ---- bisection on t; ls_lo/ls_hi bracket the crossed-count of every pattern
+                double t_lo = 0.0, S_lo = S0;
+                for (int bi = 0; bi < 64; ++bi) {
+                    unsigned long long cand = 0;
+                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) cand += A.ls_hi[k] - A.ls_lo[k];
+                    cand = (unsigned long long)block_sum_f64<LAD_BLOCK>((double)cand, sh.red);
+                    if (cand <= 8) break;
+                    double t_mid = 0.5 * (t_lo + t_hi);
+                    if (!(t_mid > t_lo && t_mid < t_hi)) break;
+                    double acc = 0.0;
+                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                        double rho = A.sc_rho[k];
+                        if (rho == 0.0) continue;
+                        uint32_t c = crossed(ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
+                                             t_mid, A.ls_lo[k], A.ls_hi[k]);
+                        A.ls_mid[k] = c;
+                        acc += fabs(rho) * 2.0 * (double)c;
+                    }
+                    double S_mid = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
+                    bool go_hi = S_mid >= -tol;
+                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                        if (A.sc_rho[k] == 0.0) continue;
+                        if (go_hi) A.ls_hi[k] = A.ls_mid[k]; else A.ls_lo[k] = A.ls_mid[k];
+                    }
+                    if (go_hi) { t_hi = t_mid; S_hi = S_mid; } else { t_lo = t_mid; S_lo = S_mid; }
+                }
+                (void)S_hi;
+                if (tid == 0) sh.S_lo = S_lo;
+                __syncthreads();
+                // ---- walk the few remaining breakpoint groups in order of t
+                for (int step = 0; step < 4096; ++step) {
+                    double tb = INFINITY; int kb = 0x7fffffff;
+                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                        double rho = A.sc_rho[k];
+                        if (rho == 0.0 || A.ls_hi[k] <= A.ls_lo[k]) continue;
+                        uint32_t r = rho > 0 ? A.sc_up[k] + A.ls_lo[k] : A.sc_lo[k] - 1 - A.ls_lo[k];
+                        double t = (ra[r] + A.pat_eps[k] - A.sc_s[k]) / rho;
+                        if (t < 0) t = 0;
+                        if (t < tb || (t == tb && (int)k < kb)) { tb = t; kb = (int)k; }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        double t2 = __shfl_down(tb, off); int k2 = __shfl_down(kb, off);
+                        if (t2 < tb || (t2 == tb && k2 < kb)) { tb = t2; kb = k2; }
+                    }
+                    if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tb; sh.red_k[tid >> 6] = kb; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        double tt = sh.red_t[0]; int kk = sh.red_k[0];
+                        for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red_t[w] < tt || (sh.red_t[w] == tt && sh.red_k[w] < kk)) { tt = sh.red_t[w]; kk = sh.red_k[w]; }
+                        if (kk == 0x7fffffff) {
+                            // bracket exhausted without crossing (rounding): fall back to the box bound or fail
+                            if (sh.bj >= 0 && isfinite(sh.tmax)) { sh.ent_type = sh.btype; sh.ent_k = (uint32_t)sh.bj; } else { sh.status = 5; sh.done = 1; }
+                        } else {
+                            double rho = A.sc_rho[kk];
+                            uint32_t st = A.pat_start[kk], en = A.pat_start[kk + 1];
+                            uint32_t r = rho > 0 ? A.sc_up[kk] + A.ls_lo[kk] : A.sc_lo[kk] - 1 - A.ls_lo[kk];
+                            double av = ra[r];
+                            uint32_t g0 = lower_bound_a(ra, st, en, av), g1 = upper_bound_a(ra, g0, en, av);
+                            uint32_t gs = g1 - g0;
+                            double Sn = sh.S_lo + 2.0 * fabs(rho) * (double)gs;
+                            A.ls_lo[kk] += gs;
+                            sh.S_lo = Sn;
+                            if (Sn >= -tol) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = g0; sh.ent_i1 = g1; }
+                        }
+                    }
+                    __syncthreads();
+                    if (sh.ent_type >= 0 || sh.done) break;
+                }
+            }
+        }
+        if (sh.done) break;
+        if (sh.ent_type < 0) { if (tid == 0) { sh.status = 6; sh.done = 1; } __syncthreads(); break; }
+        // ---- pivot: constraint `best` leaves, the entering one takes its slot; W = N^-1 by Gauss-Jordan
+        if (tid == 0) {
+            sh.act_type[best] = sh.ent_type;
+            sh.act_jk[best] = (int)sh.ent_k;
+            sh.act_i0[best] = sh.ent_i0; sh.act_i1[best] = sh.ent_i1;
+        }
+        __syncthreads();
+        for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
+            int r = i / (2 * p), cc = i % (2 * p);
+            double v;
+            if (cc >= p) v = (cc - p == r) ? 1.0 : 0.0;
+            else if (sh.act_type[r] == C_PAT) v = (A.pat_mask[sh.act_jk[r]] >> cc) & 1ull ? 1.0 : 0.0;
+            else v = (sh.act_jk[r] == cc) ? 1.0 : 0.0;
+            G[r * 2 * PS + cc] = v;
+        }
+        __syncthreads();
+        for (int col = 0; col < p; ++col) {
+            if (tid == 0) {
+                int piv = col; double bestv = fabs(G[col * 2 * PS + col]);
+                for (int r = col + 1; r < p; ++r) { double v = fabs(G[r * 2 * PS + col]); if (v > bestv) { bestv = v; piv = r; } }
+                sh.piv = piv;
+                if (bestv < 1e-12) { sh.status = 3; sh.done = 1; }
+            }
+            __syncthreads();
+            if (sh.done) break;
+            int piv = sh.piv;
+            if (piv != col && tid < 2 * p) { double t = G[col * 2 * PS + tid]; G[col * 2 * PS + tid] = G[piv * 2 * PS + tid]; G[piv * 2 * PS + tid] = t; }
+            __syncthreads();
+            double dinv = 1.0 / G[col * 2 * PS + col];
+            if (tid < p) sh.fac[tid] = G[tid * 2 * PS + col];
+            __syncthreads();
+            if (tid < 2 * p) G[col * 2 * PS + tid] *= dinv;
+            __syncthreads();
+            for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
+                int r = i / (2 * p), cc = i % (2 * p);
+                if (r != col) G[r * 2 * PS + cc] -= sh.fac[r] * G[col * 2 * PS + cc];
+            }
+            __syncthreads();
+        }
+        if (sh.done) break;
+        for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = G[(i / p) * 2 * PS + p + (i % p)];
+        __syncthreads();
+    }
+    // ---- final vertex with the UNPERTURBED right-hand sides, clipped to the box
+    __syncthreads();
+    if (tid < p) {
+        int ty = sh.act_type[tid];
+        sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra[sh.act_i0[tid]] : 0.0;
+    }
+    __syncthreads();
+    if (tid < p) {
+        double v = 0.0;
+        for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
+        if (v < 0.0) v = 0.0;
+        if (v > sh.ub[tid]) v = sh.ub[tid];
+        A.x_out[(size_t)s * LAD_MAXP + tid] = v;
+    }
+    if (tid == 0) {
+        A.status[s] = (it >= max_it) ? 1 : sh.status;
+        A.iters[s] = it;
+    }
+}
+
+// objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450)
+__global__ void __launch_bounds__(1024) objective_kernel(const int32_t *__restrict__ solve_list, const uint32_t *__restrict__ node_base,
+                                                         const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
+                                                         const double *__restrict__ x, const uint32_t *__restrict__ nvalid,
+                                                         double *__restrict__ obj) {
+    __shared__ double red[16];
+    __shared__ double xs[LAD_MAXP];
+    const int s = solve_list[blockIdx.x];
+    if (threadIdx.x < LAD_MAXP) xs[threadIdx.x] = x[(size_t)s * LAD_MAXP + threadIdx.x];
+    __syncthreads();
+    const uint32_t b = node_base[s], e = node_base[s + 1];
+    double acc = 0.0;
+    for (uint32_t v = b + threadIdx.x; v < e; v += 1024) {
+        double a = ab[v];
+        if (a > 0.0) acc += fabs(mdot(mask[v], xs) - a);
+    }
+    acc = block_sum_f64<1024>(acc, red);
+    if (threadIdx.x == 0) obj[s] = nvalid[s] ? acc / (double)nvalid[s] : 0.0;
+}
+
+int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int32_t> &solve_list) {
+    uint32_t S = db->S;
+    PTX_HIP(ctx, lb->d_x.alloc((size_t)S * LAD_MAXP)); PTX_HIP(ctx, lb->d_obj.alloc(S));
+    PTX_HIP(ctx, lb->d_status.alloc(S)); PTX_HIP(ctx, lb->d_iters.alloc(S));
+    if (solve_list.empty()) return 0;
+    PTX_TRY(upload(ctx, lb->d_solve_list, solve_list.data(), solve_list.size()));
+    int pmax = 0;
+    for (int32_t s : solve_list) pmax = std::max(pmax, lb->h_p[s]);
+    LadArgs A;
+    A.row_a = lb->d_row_a.p; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
+    A.pat_eps = lb->d_pat_eps.p; A.sc_s = lb->d_sc_s.p; A.sc_rho = lb->d_sc_rho.p;
+    A.sc_lo = lb->d_sc_lo.p; A.sc_up = lb->d_sc_up.p; A.ls_lo = lb->d_ls_lo.p; A.ls_hi = lb->d_ls_hi.p; A.ls_mid = lb->d_ls_mid.p;
+    A.sp_p = lb->d_p.p; A.ub = lb->d_ub.p; A.amax = lb->d_amax.p; A.x_out = lb->d_x.p; A.status = lb->d_status.p; A.iters = lb->d_iters.p;
+    A.solve_list = lb->d_solve_list.p;
+    {
+        KTimer t(ctx, "lad_solve_kernel");
+        if (pmax <= 16) hipLaunchKernelGGL((lad_solve_kernel<16>), dim3((uint32_t)solve_list.size()), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP>), dim3((uint32_t)solve_list.size()), dim3(LAD_BLOCK), 0, ctx->stream, A);
+    }
+    {
+        KTimer t(ctx, "objective_kernel");
+        hipLaunchKernelGGL(objective_kernel, dim3((uint32_t)solve_list.size()), dim3(1024), 0, ctx->stream, lb->d_solve_list.p, db->d_node_base.p,
+                           lb->d_ab.p, (unsigned long long *)lb->d_mask.p, lb->d_x.p, lb->d_nvalid.p, lb->d_obj.p);
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace ptx

@@ -251,13 +251,13 @@ CONFIGS = {
 
 
 def make_set(seed, n_species, H, n_reads, genome_len, long_reads=False, with_ids=False, adversarial_frac=0.001,
-             single_strain_every=0):
+             single_strain_every=0, present_frac=0.2):
     rng = np.random.default_rng(seed)
     species = []
     start = 1
     for s in range(n_species):
         h = 1 if (single_strain_every and s % single_strain_every == single_strain_every - 1) else H
-        g = make_species(rng, str(1000 + s), h, genome_len, start, "GCF_%06d" % (s + 1))
+        g = make_species(rng, str(1000 + s), h, genome_len, start, "GCF_%06d" % (s + 1), present_frac=present_frac)
         species.append(g)
         start = g.range_end + 1
     reads = make_reads(rng, species, n_reads, long_reads=long_reads, with_ids=with_ids,

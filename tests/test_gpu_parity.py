@@ -55,11 +55,7 @@ def test_micro_coverage_golden(eng):
     sp, *_ = eng.rcls_profile()
     # the abort read that walks below the range is "U" for binning; force species 0 semantics by
     # checking only what the pipeline would feed: reads binned to species 0
-    trio = None
-    try:
-        trio = eng.trio_nodes_info()
-    except Exception:
-        pass
+    trio = eng.trio_nodes_info()
     bases, cov, tb, nab = eng.get_node_abundances()
     e = j["expected"]
     assert bases.tolist() == e["bases_per_node"]
@@ -89,10 +85,7 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L):
     for a, b in zip((rc, bs, lm, uq), ref_counts):
         assert np.array_equal(a, b)
     have_trio = True
-    try:
-        abc, hap, ln, hto = eng.trio_nodes_info()
-    except Exception:
-        have_trio = False
+    abc, hap, ln, hto = eng.trio_nodes_info()
     bases, cov, tb, nab = eng.get_node_abundances()
     ref = _oracle_cov_per_species(sset, ref_sp)
     tot_abort = 0
@@ -152,3 +145,97 @@ def test_long_reads_and_empty_inputs(eng):
     assert len(sp) == 0 and not rc.any()
     bases, cov, tb, nab = eng.get_node_abundances(with_trio=False)
     assert not bases.any() and not cov.any() and nab == 0
+
+
+def _paths_from_masks(mask, p):
+    offs = [0]
+    nodes = []
+    for k in range(p):
+        sel = np.nonzero((mask >> np.uint64(k)) & np.uint64(1))[0]
+        nodes.append(sel.astype(np.uint32))
+        offs.append(offs[-1] + len(sel))
+    return np.array(offs, dtype=np.uint64), (np.concatenate(nodes) if nodes else np.zeros(0, dtype=np.uint32))
+
+
+def test_pao_solve_vs_highs_golden(eng, golden_dir):
+    """Solver seam (X_opt, profile.rs:2690-2698) on the committed SciPy-HiGHS vectors: objective equal
+    to 1e-9 relative; x equal where the optimal face is a single point."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub, xh, objh = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], z["x_%d" % i], float(z["obj_%d" % i])
+        p = len(ub)
+        path_off, path_nodes = _paths_from_masks(mask, p)
+        x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), path_off,
+                                          path_nodes, np.arange(p), fixed_zero=(ub == 0).astype(np.uint8))
+        assert st == 0
+        assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), i
+        assert orc.lad_objective(mask, a, x) == pytest.approx(objh, rel=1e-9, abs=1e-12), i
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+        if bool(z["unique_%d" % i]):
+            assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
+
+
+def test_pao_solve_edge_cases(eng):
+    # no covered node: x = 0
+    po, pn = _paths_from_masks(np.array([1, 3], dtype=np.uint64), 2)
+    x, ratio, obj, st = eng.pao_solve([1, 1], [0.0, 0.0], [0, 0], po, pn, [0, 1])
+    assert st == 0 and x.tolist() == [0.0, 0.0] and obj == 0.0
+    # upper bound 1.05*max active: rows (x=5),(x=6),(x=7) plus a far row through path 1 only
+    mask = np.array([1, 1, 1, 2], dtype=np.uint64)
+    a = np.array([50.0, 60.0, 70.0, 1.0])
+    po, pn = _paths_from_masks(mask, 2)
+    x, ratio, obj, st = eng.pao_solve([1] * 4, a, [1, 0, 1, 1], po, pn, [0, 1])
+    assert st == 0 and x[0] == pytest.approx(60.0) and x[1] == pytest.approx(1.0)
+    assert ratio[0] == pytest.approx(2.0 / 3.0) and ratio[1] == pytest.approx(1.0)
+    # noise-free integer data with massive ties: exact recovery, objective 0
+    rng = np.random.default_rng(3)
+    n, p = 4000, 5
+    mask = rng.integers(1, 1 << p, size=n).astype(np.uint64)
+    truth = np.array([4.0, 0.0, 9.0, 0.0, 2.0])
+    A = np.stack([((mask >> np.uint64(k)) & np.uint64(1)).astype(float) for k in range(p)], 1)
+    po, pn = _paths_from_masks(mask, p)
+    x, ratio, obj, st = eng.pao_solve(np.ones(n, dtype=np.int64), A @ truth, np.zeros(n), po, pn, np.arange(p))
+    assert st == 0 and obj == pytest.approx(0.0, abs=1e-9) and np.allclose(x, truth, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed,S,H,R,L,pf", [(21, 2, 6, 30000, 40000, 0.5), (22, 4, 10, 80000, 30000, 0.4),
+                                             (23, 3, 5, 20000, 30000, 0.2)])
+def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
+    """optimize_otu + abundace_constraint (profile.rs:2884-3070) for every species, against the oracle."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    eng.trio_nodes_info(fetch=False)
+    eng.get_node_abundances(fetch=False)
+    met, info = eng.strain_profiling(absolute, species_active=keep)
+    got = metrics_to_dicts(met, eng.H)
+    ref = _oracle_cov_per_species(sset, sp)
+    for si, (G, T, b, c, t, na) in enumerate(ref):
+        if not keep[si]:
+            continue
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+        assert rc_ == 0
+        orc.abundance_constraint(absolute[si], omet)
+        exp = orc.metrics_to_dicts(omet)
+        h0 = int(eng.hap_off[si])
+        assert info[si].n_candidates == nc and info[si].status1 == 0 and info[si].status2 == 0
+        if nc:
+            assert info[si].obj1 == pytest.approx(o1, rel=1e-9, abs=1e-12)
+            if not np.isnan(o2):
+                assert info[si].obj2 == pytest.approx(o2, rel=1e-9, abs=1e-12)
+        for h, e in enumerate(exp):
+            g = got[h0 + h]
+            for key, ev in e.items():
+                gv = g[key]
+                if ev is None or gv is None or isinstance(ev, bool):
+                    assert gv == ev, (si, h, key, gv, ev)
+                else:
+                    assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
