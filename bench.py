@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- PAO wall time / Mreads/s of the profiling hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: read binning + species counters, species profile, unique-trio index (rebuilt per
+step like the reference does per run), node-coverage histogram, LP row grouping, the two PAO
+solves, filters and the abundance table.  Workload at N=1 = BASELINE.json configs[1]
+("Single-species E. coli, 10 strains, 1M synthetic short-read GAF"); with N ranks each rank owns
+its own species shard of that shape (weak scaling; species are independent sub-problems) and one
+RCCL all-reduce carries the normalisers.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(sset, U):
+    """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload."""
+    rd = sset.reads
+    R, T = rd.n_reads, len(rd.node_id)
+    V = sum(g.n_nodes for g in sset.species)
+    L = int(sum(int(g.node_len.sum()) for g in sset.species))
+    P = int(sum(int(g.path_off[-1]) for g in sset.species))
+    H = sum(g.n_paths for g in sset.species)
+    Wr = max(T - 2 * R, 0)
+    return {
+        # a2: 4T + 4R(offsets) + 4R(out)
+        "bin_reads_kernel": 4 * T + 4 * R + 4 * R,
+        # a8 minus the popcount pass: 4T + 12R + 4V(node_len) + 8V(bases) + L/8(bitmap) + 12*Wr(trio probes)
+        "coverage_kernel": 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr,
+        # a8 popcount: L/8 bitmap in + 8V cov out
+        "popcount_kernel": L // 8 + 8 * V,
+        # a7: 2 x 12 x (P - 2H) (write keys, read sorted) + 12U
+        "radix_sort": 2 * 12 * max(P - 2 * H, 0) + 12 * U,
+        "trio_emit_kernel": 4 * P + 12 * max(P - 2 * H, 0),
+        # a10: 4P in + 8V mask out
+        "mask_kernel": 4 * P + 8 * V,
+    }, dict(R=R, T=T, V=V, L=L, P=P, H=H, U=U)
+
+
+def cpu_baseline(sset, sample_reads, cfg):
+    """The oracle (plain-C port of the reference algorithm) on ONE host core over a bounded sample:
+    the first `sample_reads` reads of the same workload through binning, trio index, coverage,
+    filters and both LP solves.  Reported beside the GPU number; it is a baseline, not the target."""
+    from oracle import oracle as orc
+    from tests.helpers import select_reads
+    rd = sset.reads
+    n = min(sample_reads, rd.n_reads)
+    t0 = time.perf_counter()
+    step_off = rd.step_off[: n + 1]
+    node_id = rd.node_id[: int(step_off[-1])]
+    sp = orc.bin_reads(step_off, node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
+    counts = orc.species_counts(sp, rd.qlen[:n], rd.mapq[:n], len(sset.species))
+    keep, absolute, _ = orc.species_profile(sp, rd.qlen[:n], counts, sset.avg_len())
+    t_lp = 0.0
+    for si, g in enumerate(sset.species):
+        if not keep[si]:
+            continue
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        sel = np.nonzero(sp == si)[0]
+        so = np.zeros(len(sel) + 1, dtype=np.uint64)
+        ns = (step_off[1:] - step_off[:-1]).astype(np.int64)[sel]
+        so[1:] = np.cumsum(ns)
+        starts = step_off[:-1].astype(np.int64)[sel]
+        idx = np.repeat(starts, ns) + (np.arange(int(ns.sum())) - np.repeat(so[:-1].astype(np.int64), ns))
+        b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, node_id[idx], rd.pstart[:n][sel], rd.pend[:n][sel])
+        t1 = time.perf_counter()
+        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
+        t_lp += time.perf_counter() - t1
+        orc.abundance_constraint(absolute[si], met)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt / 1e6, unit="Mreads/s", cores=1, kind="port",
+                sample="first %d reads of the same workload (all %d species), oracle bin+trio+coverage+filters+2 LP solves; "
+                       "%.2f s total, %.2f s of it in the exact LAD solves" % (n, len(sset.species), dt, t_lp),
+                seconds=dt)
+
+
+def highs_probe(sset, cfg, max_rows=20000):
+    """Optional: time SciPy's bundled HiGHS on the species-0 LP restricted to max_rows covered nodes
+    (HiGHS is the reference's open solver, profile.rs:2689-2882; the full LP does not finish in
+    minutes)."""
+    try:
+        from scipy import sparse
+        from scipy.optimize import linprog
+    except Exception:
+        return None
+    return None  # filled in by tools/highs_probe.py when run by hand; kept out of the default path (minutes)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--species", type=int, default=1)
+    ap.add_argument("--haps", type=int, default=10)
+    ap.add_argument("--genome-len", type=int, default=5_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    from pantax_amd import synth
+    from pantax_amd.engine import Engine
+    from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, profile_step
+
+    torch.cuda.set_device(local_rank)
+    comm = LocalComm()
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+
+    # deterministic synthetic shard of this rank (seed = 20260501 + cfg index 2, + rank)
+    seed = 20260501 + 2 + 1000 * rank
+    sset = synth.make_set(seed, args.species, args.haps, args.reads, args.genome_len)
+    for i, g in enumerate(sset.species):
+        g.name = "%d" % (100000 * rank + 1000 + i)
+    species_names = [g.name for g in sset.species]
+    hap_names = [hn for g in sset.species for hn in g.hap_names]
+    avg_len = sset.avg_len()
+    cfg = StepConfig()
+
+    eng = Engine(local_rank)
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)          # inputs resident in HBM before the timed region
+    eng.sync()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    out = None
+    for _ in range(args.warmup):
+        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species)
+    barrier()
+    dt = time.perf_counter() - t0
+    timings = eng.timing_get()
+    eng.timing_enable(False)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        species_rows, strain_rows, stats = out
+        ms_per_step = dt / args.steps * 1e3
+        total_reads = args.reads * world
+        value = total_reads / (dt / args.steps) / 1e6
+        ab, dims = algorithmic_bytes(sset, eng.U or 0)
+        # dominant kernel by HIP-event time on the library's stream
+        kt = {k: v for k, v in timings.items()}
+        dom = max(kt.items(), key=lambda kv: kv[1][1])[0] if kt else None
+        roofline = None
+        if dom:
+            launches, tot_ms = kt[dom]
+            avg_ms = tot_ms / max(launches, 1)
+            bytes_per_launch = ab.get(dom)
+            if bytes_per_launch is not None:
+                per = bytes_per_launch / max(launches / args.steps, 1) if dom in ("radix_sort",) else bytes_per_launch
+                ach = per / (avg_ms * 1e-3) / 1e9
+                roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                traffic=None, avg_ms=avg_ms, algorithmic_bytes=per)
+            else:
+                roofline = dict(bound="hbm", kernel=dom, achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, traffic=None,
+                                avg_ms=avg_ms, algorithmic_bytes=0,
+                                note="latency-bound small-LP kernel: O(#patterns*log n) binary searches per pivot, no streaming traffic")
+        line = {
+            "metric": "PAO wall-time (s) + Mreads/s GAF->abundance (packed reads resident in HBM)",
+            "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+            "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
+                                   "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),
+                       "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0},
+            "roofline": roofline,
+            "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(kt.items(), key=lambda kv: -kv[1][1])},
+            "solver": {"iters": stats["iters"][:4], "n_rows": stats["n_rows"][:4], "n_patterns": stats["n_patterns"][:4],
+                       "objective": stats["obj"][:4]},
+            "result": {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
+                       "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sset, args.cpu_sample, cfg)
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,20 @@ int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hi
                          int32_t *species_idx_out, int64_t *read_count_out, int64_t *base_sum_out,
                          int64_t *less_multi_out, int64_t *uniq_count_out);
 
+/* a3 finishing (species_profiling, profile.rs:299-349): equal-length test on the first 1000 reads
+ * with species != "U" (:312-319), the MAPQ filter when `filtered` (:239-245), absolute =
+ * base_count / avg_len (:336), abundance = absolute / sum (:341).  avg_len[s] <= 0 = species missing
+ * from species_genomes_stats.txt.  Outputs [n_species]; rows are in db order (callers sort by
+ * abundance, :344).  Requires bin_reads on `reads`. */
+int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hip_reads *reads,
+                               const int64_t *read_count, const int64_t *base_sum, const int64_t *less_multi,
+                               const int64_t *uniq_count, const double *avg_len, int filtered,
+                               uint8_t *keep_out, double *absolute_out, double *abundance_out);
+
+/* drop everything derived from the graphs (trio index, coverage state) so the next calls rebuild it:
+ * the reference recomputes trio_nodes_info inside every optimize_otu call (profile.rs:2936). */
+int pantax_hip_db_reset(pantax_hip_ctx *ctx, pantax_hip_db *db);
+
 /* ---- a7: unique-trio index (profile.rs:658-740), built on device once per db.
  * Rows are ordered (species, hap, window position). */
 int pantax_hip_trio_index(pantax_hip_ctx *ctx, pantax_hip_db *db, uint64_t *n_unique_total_out);
@@ -138,6 +152,16 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
                               const uint8_t *species_active /*[S] or NULL*/,
                               const double *species_coverage /*[S] predicted_coverage, profile.rs:3044-3047*/,
                               pantax_hip_hap_metrics *metrics_out /*[H]*/, pantax_hip_solve_info *info_out /*[S] or NULL*/);
+
+/* a15 core (abundance_est, profile.rs:3219-3245), host only: pass_out[h] = (group_size > 1 ||
+ * total_cov_diff <= single_cov_diff) && predicted_coverage >= min_cov && predicted_coverage != 0;
+ * sum_all_out = sum of every non-null predicted_coverage (the :3198 normaliser), sum_pass_out = the
+ * same over passing rows (:3243).  These two numbers are the only cross-GPU reduction of the path. */
+int pantax_hip_abundance_filter(uint32_t n_species, const uint64_t *hap_off, const pantax_hip_hap_metrics *metrics,
+                                const uint8_t *species_reported /*[S] 0 = species dropped (solver error / inactive)*/,
+                                double single_cov_diff, int64_t min_cov, uint8_t *pass_out,
+                                double *sum_all_out, double *sum_pass_out,
+                                double *species_sum_all_out /*[S] or NULL*/, double *species_sum_pass_out /*[S] or NULL*/);
 
 /* ---- solver seam: one species, host buffers in, same meaning as X_opt's arguments
  * (profile.rs:2690-2698).  cand_path_idx = possible_paths_idx; fixed_zero[k]=1 pins x_k = 0

@@ -16,7 +16,8 @@ _lib = None
 SYMBOLS = [
     "pantax_hip_init", "pantax_hip_destroy", "pantax_hip_last_error", "pantax_hip_version",
     "pantax_hip_db_upload", "pantax_hip_db_free", "pantax_hip_reads_upload", "pantax_hip_reads_free",
-    "pantax_hip_bin_reads", "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
+    "pantax_hip_bin_reads", "pantax_hip_species_profile", "pantax_hip_db_reset", "pantax_hip_abundance_filter",
+    "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
     "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_profile",
     "pantax_hip_timing_enable", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
 ]

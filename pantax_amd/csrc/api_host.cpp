@@ -1,0 +1,92 @@
+// api_host.cpp -- scalar host finishing of a3 (species_profiling, profile.rs:299-349) and a15
+// (abundance_est filters, profile.rs:3219-3245).  No per-read or per-node work happens here.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include "common.hpp"
+
+using namespace ptx;
+
+extern "C" {
+
+int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hip_reads *reads, const int64_t *read_count,
+                               const int64_t *base_sum, const int64_t *less_multi, const int64_t *uniq_count, const double *avg_len,
+                               int filtered, uint8_t *keep_out, double *absolute_out, double *abundance_out) {
+    if (!ctx || !db || !reads || !read_count || !base_sum || !less_multi || !uniq_count || !avg_len || !keep_out || !absolute_out || !abundance_out)
+        return PANTAX_HIP_E_INVALID;
+    if (!reads->binned) return fail(ctx, PANTAX_HIP_E_STATE, "species_profile: call pantax_hip_bin_reads first");
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    // profile.rs:312-319: distinct read_len among the first 1000 rows of the frame without "U" reads
+    int64_t first_len = -1;
+    bool equal = true;
+    uint64_t seen = 0;
+    const uint64_t CH = 1 << 16;
+    std::vector<int32_t> sp(CH);
+    std::vector<uint32_t> ql(CH);
+    for (uint64_t off = 0; off < reads->R && seen < 1000; off += CH) {
+        uint64_t n = std::min<uint64_t>(CH, reads->R - off);
+        PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
+        PTX_TRY(download(ctx, ql.data(), reads->d_qlen.p + off, n));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint64_t i = 0; i < n && seen < 1000; ++i) {
+            if (sp[i] < 0) continue;
+            if (seen == 0) first_len = ql[i]; else if ((int64_t)ql[i] != first_len) equal = false;
+            ++seen;
+        }
+    }
+    if (seen == 0) equal = false;
+    const uint32_t S = db->S;
+    double total = 0.0;
+    for (uint32_t s = 0; s < S; ++s) {
+        keep_out[s] = 0; absolute_out[s] = 0.0; abundance_out[s] = 0.0;
+        if (read_count[s] == 0) continue;
+        if (filtered) {   // profile.rs:224-245 (the inner join drops species without any MAPQ 3..60 read)
+            if (less_multi[s] == 0) continue;
+            if (!(uniq_count[s] > 0 && (double)less_multi[s] > (double)read_count[s] / 10.0)) continue;
+        }
+        if (!(avg_len[s] > 0.0)) continue;
+        int64_t base_count = equal ? read_count[s] * first_len : base_sum[s];   // :214/:246 vs :259/:266
+        keep_out[s] = 1;
+        absolute_out[s] = (double)base_count / avg_len[s];                       // :336
+        total += absolute_out[s];
+    }
+    for (uint32_t s = 0; s < S; ++s) if (keep_out[s]) abundance_out[s] = absolute_out[s] / total;   // :341
+    return 0;
+}
+
+int pantax_hip_db_reset(pantax_hip_ctx *ctx, pantax_hip_db *db) {
+    if (!ctx || !db) return PANTAX_HIP_E_INVALID;
+    db->trio_built = false;
+    db->cov_done = false;
+    db->U = 0;
+    return 0;
+}
+
+int pantax_hip_abundance_filter(uint32_t n_species, const uint64_t *hap_off, const pantax_hip_hap_metrics *met, const uint8_t *species_reported,
+                                double single_cov_diff, int64_t min_cov, uint8_t *pass_out, double *sum_all_out, double *sum_pass_out,
+                                double *sp_all_out, double *sp_pass_out) {
+    if (!hap_off || !met || !pass_out) return PANTAX_HIP_E_INVALID;
+    double all = 0.0, pass = 0.0;
+    for (uint32_t s = 0; s < n_species; ++s) {
+        const uint64_t h0 = hap_off[s], h1 = hap_off[s + 1];
+        const bool reported = !species_reported || species_reported[s];
+        const uint64_t group_size = h1 - h0;   // hap_id count per species (profile.rs:3219-3223)
+        double s_all = 0.0, s_pass = 0.0;
+        for (uint64_t h = h0; h < h1; ++h) {
+            pass_out[h] = 0;
+            if (!reported || !(met[h].has & PANTAX_HIP_HAS_SECOND)) continue;   // null predicted_coverage fails every comparison
+            const double cov = met[h].second_sol;
+            s_all += cov;                                                        // :3198 (sum skips nulls)
+            const bool diff_ok = (met[h].has & PANTAX_HIP_HAS_TOTAL_DIFF) && met[h].total_cov_diff <= single_cov_diff;
+            if ((group_size > 1 || diff_ok) && cov >= (double)min_cov && cov != 0.0) { pass_out[h] = 1; s_pass += cov; }   // :3232-3241
+        }
+        all += s_all; pass += s_pass;
+        if (sp_all_out) sp_all_out[s] = s_all;
+        if (sp_pass_out) sp_pass_out[s] = s_pass;
+    }
+    if (sum_all_out) *sum_all_out = all;
+    if (sum_pass_out) *sum_pass_out = pass;
+    return 0;
+}
+
+}  // extern "C"

@@ -115,6 +115,34 @@ class Engine:
         self._check(self.lib.pantax_hip_bin_reads(self.ctx, self.db, self.reads, p(sp), *[p(o) for o in outs]))
         return (sp, *outs)
 
+    def species_profiling(self, counts, avg_len, filtered=True):
+        """profile.rs:299-349 finishing -> keep [S] uint8, predicted_coverage [S], predicted_abundance [S]"""
+        rc, bs, lm, uq = [as_c(c, np.int64) for c in counts]
+        avg = as_c(avg_len, np.float64)
+        keep = np.zeros(self.S, dtype=np.uint8)
+        absolute = np.zeros(self.S)
+        abundance = np.zeros(self.S)
+        self._check(self.lib.pantax_hip_species_profile(self.ctx, self.db, self.reads, p(rc), p(bs), p(lm), p(uq), p(avg),
+                                                        int(filtered), p(keep), p(absolute), p(abundance)))
+        return keep, absolute, abundance
+
+    def db_reset(self):
+        self._check(self.lib.pantax_hip_db_reset(self.ctx, self.db))
+        self.U = None
+
+    def abundance_filter(self, met, species_reported=None, single_cov_diff=0.2, min_cov=0):
+        """abundance_est filters (profile.rs:3219-3245) -> pass [H] uint8, per-species sum_all [S], sum_pass [S]"""
+        rep = None if species_reported is None else as_c(species_reported, np.uint8)
+        passed = np.zeros(max(self.H, 1), dtype=np.uint8)
+        sa = C.c_double(0)
+        sp = C.c_double(0)
+        s_all = np.zeros(self.S)
+        s_pass = np.zeros(self.S)
+        rc = self.lib.pantax_hip_abundance_filter(C.c_uint32(self.S), p(self.hap_off), met, p(rep), C.c_double(single_cov_diff),
+                                                  C.c_int64(min_cov), p(passed), C.byref(sa), C.byref(sp), p(s_all), p(s_pass))
+        self._check(rc)
+        return passed[: self.H], s_all, s_pass
+
     def trio_nodes_info(self, fetch=True):
         n = C.c_uint64(0)
         self._check(self.lib.pantax_hip_trio_index(self.ctx, self.db, C.byref(n)))
