@@ -58,9 +58,9 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     for (auto &i : info) i.obj1 = i.obj2 = NAN;
 
     // ---- device reductions: per-hap trio stats, node abundance + per-species stats
-    DevBuf<uint32_t> d_nnz;
-    DevBuf<double> d_mean;
-    LadBatch lb;
+    DevBuf<uint32_t> &d_nnz = db->d_hap_nnz;
+    DevBuf<double> &d_mean = db->d_hap_mean;
+    LadBatch &lb = db->lad;
     PTX_TRY(hap_trio_stats_launch(ctx, db, d_nnz, d_mean));
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));
     std::vector<uint32_t> nnz(H ? H : 1), nvalid(S), nzcnt(S);

@@ -137,18 +137,22 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 // ---------------------------------------------------------------------------------------------
 // node abundance + per-species statistics
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
-                                                          const unsigned long long *__restrict__ bases, double min_depth,
-                                                          double *__restrict__ ab_out, double *__restrict__ amax_out,
-                                                          uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
-                                                          uint32_t *__restrict__ nzcnt_out) {
-    __shared__ double red[16];
-    __shared__ unsigned long long redu[16];
-    const uint32_t s = blockIdx.x;
+constexpr int STAT_CHUNKS = 64;   // workgroups per species; partials are combined in fixed order (deterministic)
+struct NodePartial { double mx, zs; unsigned long long nv, zc; };
+
+__global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
+                                                         const unsigned long long *__restrict__ bases, double min_depth,
+                                                         double *__restrict__ ab_out, NodePartial *__restrict__ part) {
+    __shared__ double red[4];
+    __shared__ unsigned long long redu[4];
+    const uint32_t s = blockIdx.x / STAT_CHUNKS, ch = blockIdx.x % STAT_CHUNKS;
     const uint32_t b = node_base[s], e = node_base[s + 1];
+    const uint32_t per = (e - b + STAT_CHUNKS - 1) / STAT_CHUNKS;
+    uint32_t lo = b + ch * per, hi = lo + per;
+    if (hi > e) hi = e;
     double mx = -INFINITY, zs = 0.0;
     unsigned long long nv = 0, zc = 0;
-    for (uint32_t v = b + threadIdx.x; v < e; v += 1024) {
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         double len = (double)(bit_off[v + 1] - bit_off[v]);
         double ab = (double)(long long)bases[v] / len;           // profile.rs:987-988
         ab_out[v] = ab;
@@ -157,11 +161,20 @@ __global__ void __launch_bounds__(1024) node_stats_kernel(const uint32_t *__rest
         double o = ab > min_depth ? ab : 0.0;                    // :2941-2944
         if (o > 0.0) { zs += o; ++zc; }
     }
-    mx = block_max_f64<1024>(mx, red);
-    zs = block_sum_f64<1024>(zs, red);
-    nv = block_sum_u64<1024>(nv, redu);
-    zc = block_sum_u64<1024>(zc, redu);
-    if (threadIdx.x == 0) { amax_out[s] = mx; nvalid_out[s] = (uint32_t)nv; nzsum_out[s] = zs; nzcnt_out[s] = (uint32_t)zc; }
+    mx = block_max_f64<256>(mx, red);
+    zs = block_sum_f64<256>(zs, red);
+    nv = block_sum_u64<256>(nv, redu);
+    zc = block_sum_u64<256>(zc, redu);
+    if (threadIdx.x == 0) part[blockIdx.x] = {mx, zs, nv, zc};
+}
+__global__ void __launch_bounds__(64) node_stats_final_kernel(uint32_t S, const NodePartial *__restrict__ part, double *__restrict__ amax_out,
+                                                              uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
+                                                              uint32_t *__restrict__ nzcnt_out) {
+    uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    double mx = -INFINITY, zs = 0.0; unsigned long long nv = 0, zc = 0;
+    for (int c = 0; c < STAT_CHUNKS; ++c) { NodePartial p = part[(size_t)s * STAT_CHUNKS + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
+    amax_out[s] = mx; nvalid_out[s] = (uint32_t)nv; nzsum_out[s] = zs; nzcnt_out[s] = (uint32_t)zc;
 }
 
 int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
@@ -170,9 +183,12 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     PTX_HIP(ctx, lb->d_ab.alloc(db->V));
     PTX_HIP(ctx, lb->d_amax.alloc(S)); PTX_HIP(ctx, lb->d_nvalid.alloc(S));
     PTX_HIP(ctx, lb->d_nzsum.alloc(S)); PTX_HIP(ctx, lb->d_nzcnt.alloc(S));
+    PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
     KTimer t(ctx, "node_stats_kernel");
-    hipLaunchKernelGGL(node_stats_kernel, dim3(S), dim3(1024), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
-                       (double)min_depth, lb->d_ab.p, lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p);
+    hipLaunchKernelGGL(node_stats_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
+                       (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p);
+    hipLaunchKernelGGL(node_stats_final_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
+                       lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -299,8 +315,9 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
                            (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
     }
     // rows: flag -> scan -> emit -> sort by (species, mask, a)
-    DevBuf<uint8_t> flag;
-    DevBuf<uint32_t> pos, scan_tmp, table, d_tot;
+    Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
+    DevBuf<uint8_t> &flag = dbm->d_row_flag;
+    DevBuf<uint32_t> &pos = dbm->d_row_pos, &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table, &d_tot = dbm->d_tot2;
     PTX_HIP(ctx, flag.alloc(V)); PTX_HIP(ctx, pos.alloc(V));
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
@@ -316,7 +333,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     lb->n_rows = n_rows;
     if (n_rows == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
-    DevBuf<uint64_t> ka[3], kb[3];
+    DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
     for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(n_rows)); PTX_HIP(ctx, kb[w].alloc(n_rows)); }
     {
         KTimer t(ctx, "row_emit_kernel");
@@ -334,8 +351,8 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     PTX_TRY(radix_sort(ctx, A, B, n_rows, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b));
     SortBufs Sd = in_b ? B : A;
     // patterns = runs of equal (species, mask)
-    DevBuf<uint8_t> head;
-    DevBuf<uint32_t> pidx;
+    DevBuf<uint8_t> &head = dbm->d_pat_head;
+    DevBuf<uint32_t> &pidx = dbm->d_pat_idx;
     PTX_HIP(ctx, head.alloc(n_rows)); PTX_HIP(ctx, pidx.alloc(n_rows));
     int gridN = grid_for(n_rows, 256, ctx->n_cu * 8);
     hipLaunchKernelGGL(pat_flag_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p);
@@ -573,15 +590,46 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 }
                 __syncthreads();
             } else {
-                // ---- bisection on t; ls_lo/ls_hi bracket the crossed-count of every pattern
+                // ---- narrow the bracket.  Rounds alternate between two pivots so that the search is
+                // both scale-free and robust to many patterns: (even) the median remaining breakpoint of
+                // the pattern that still holds the most weighted candidates, (odd) the midpoint in t.
+                // ls_lo/ls_hi bracket the crossed-count of every pattern; slope(t_lo) < 0 <= slope(t_hi).
                 double t_lo = 0.0, S_lo = S0;
-                for (int bi = 0; bi < 64; ++bi) {
-                    unsigned long long cand = 0;
-                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) cand += A.ls_hi[k] - A.ls_lo[k];
+                unsigned long long prev_cand = ~0ull; int stall = 0;
+                for (int bi = 0; bi < 200; ++bi) {
+                    double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
+                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                        double rho = A.sc_rho[k];
+                        uint32_t cl = A.ls_lo[k], ch = A.ls_hi[k];
+                        if (rho == 0.0 || ch <= cl) continue;
+                        cand += ch - cl;
+                        double w = fabs(rho) * (double)(ch - cl);
+                        if (w > wbest) {
+                            uint32_t m = cl + (ch - cl) / 2;   // m-th breakpoint ahead (0-based) of this pattern
+                            uint32_t r = rho > 0 ? A.sc_up[k] + m : A.sc_lo[k] - 1 - m;
+                            double t = (ra[r] + A.pat_eps[k] - A.sc_s[k]) / rho;
+                            wbest = w; tprop = t < 0 ? 0 : t;
+                        }
+                    }
                     cand = (unsigned long long)block_sum_f64<LAD_BLOCK>((double)cand, sh.red);
                     if (cand <= 8) break;
-                    double t_mid = 0.5 * (t_lo + t_hi);
-                    if (!(t_mid > t_lo && t_mid < t_hi)) break;
+                    // two rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
+                    stall = (cand == prev_cand) ? stall + 1 : 0;
+                    prev_cand = cand;
+                    if (stall >= 2) break;
+                    // heaviest proposal: max over the block (ties -> smaller t)
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        double w2 = __shfl_down(wbest, off), t2 = __shfl_down(tprop, off);
+                        if (w2 > wbest || (w2 == wbest && t2 < tprop)) { wbest = w2; tprop = t2; }
+                    }
+                    if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tprop; sh.red[tid >> 6] = wbest; }
+                    __syncthreads();
+                    double bw = sh.red[0], bt = sh.red_t[0];
+                    for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red[w] > bw || (sh.red[w] == bw && sh.red_t[w] < bt)) { bw = sh.red[w]; bt = sh.red_t[w]; }
+                    __syncthreads();
+                    double t_mid = (bi & 1) ? 0.5 * (t_lo + t_hi) : bt;
+                    if (!(t_mid >= t_lo && t_mid <= t_hi)) t_mid = 0.5 * (t_lo + t_hi);
                     double acc = 0.0;
                     for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
                         double rho = A.sc_rho[k];
@@ -710,23 +758,35 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
 }
 
 // objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450)
-__global__ void __launch_bounds__(1024) objective_kernel(const int32_t *__restrict__ solve_list, const uint32_t *__restrict__ node_base,
-                                                         const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
-                                                         const double *__restrict__ x, const uint32_t *__restrict__ nvalid,
-                                                         double *__restrict__ obj) {
-    __shared__ double red[16];
+__global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ solve_list, const uint32_t *__restrict__ node_base,
+                                                        const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
+                                                        const double *__restrict__ x, double *__restrict__ part) {
+    __shared__ double red[4];
     __shared__ double xs[LAD_MAXP];
-    const int s = solve_list[blockIdx.x];
+    const int s = solve_list[blockIdx.x / STAT_CHUNKS];
+    const uint32_t ch = blockIdx.x % STAT_CHUNKS;
     if (threadIdx.x < LAD_MAXP) xs[threadIdx.x] = x[(size_t)s * LAD_MAXP + threadIdx.x];
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
+    const uint32_t per = (e - b + STAT_CHUNKS - 1) / STAT_CHUNKS;
+    uint32_t lo = b + ch * per, hi = lo + per;
+    if (hi > e) hi = e;
     double acc = 0.0;
-    for (uint32_t v = b + threadIdx.x; v < e; v += 1024) {
+    for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         double a = ab[v];
         if (a > 0.0) acc += fabs(mdot(mask[v], xs) - a);
     }
-    acc = block_sum_f64<1024>(acc, red);
-    if (threadIdx.x == 0) obj[s] = nvalid[s] ? acc / (double)nvalid[s] : 0.0;
+    acc = block_sum_f64<256>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(64) objective_final_kernel(uint32_t n, const int32_t *__restrict__ solve_list, const double *__restrict__ part,
+                                                             const uint32_t *__restrict__ nvalid, double *__restrict__ obj) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int s = solve_list[i];
+    double acc = 0.0;
+    for (int c = 0; c < STAT_CHUNKS; ++c) acc += part[(size_t)i * STAT_CHUNKS + c];
+    obj[s] = nvalid[s] ? acc / (double)nvalid[s] : 0.0;
 }
 
 int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int32_t> &solve_list) {
@@ -750,8 +810,12 @@ int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int
     }
     {
         KTimer t(ctx, "objective_kernel");
-        hipLaunchKernelGGL(objective_kernel, dim3((uint32_t)solve_list.size()), dim3(1024), 0, ctx->stream, lb->d_solve_list.p, db->d_node_base.p,
-                           lb->d_ab.p, (unsigned long long *)lb->d_mask.p, lb->d_x.p, lb->d_nvalid.p, lb->d_obj.p);
+        uint32_t ns = (uint32_t)solve_list.size();
+        PTX_HIP(ctx, lb->d_partial.alloc(std::max<size_t>((size_t)S * STAT_CHUNKS * 4, (size_t)ns * STAT_CHUNKS)));
+        hipLaunchKernelGGL(objective_kernel, dim3(ns * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_solve_list.p, db->d_node_base.p,
+                           lb->d_ab.p, (unsigned long long *)lb->d_mask.p, lb->d_x.p, lb->d_partial.p);
+        hipLaunchKernelGGL(objective_final_kernel, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, ns, lb->d_solve_list.p, lb->d_partial.p,
+                           lb->d_nvalid.p, lb->d_obj.p);
     }
     PTX_HIP(ctx, hipGetLastError());
     return 0;

@@ -90,6 +90,10 @@ class Engine:
         if self.reads:
             self.lib.pantax_hip_reads_free(self.ctx, self.reads)
             self.reads = None
+        for name, a in (("step_off", step_off), ("node_id", node_id), ("pstart", pstart), ("pend", pend), ("qlen", qlen)):
+            a = np.asarray(a)
+            if a.size and (a.min() < 0 or a.max() > 0xFFFFFFFF):
+                raise ValueError("%s outside the packed u32 range [0, 2^32): GAF columns are non-negative" % name)
         arrs = dict(step_off=as_c(step_off, np.uint32), node_id=as_c(node_id, np.uint32), pstart=as_c(pstart, np.uint32),
                     pend=as_c(pend, np.uint32), qlen=as_c(qlen, np.uint32), mapq=as_c(mapq, np.uint8),
                     flags=None if flags is None else as_c(flags, np.uint8))

@@ -228,7 +228,8 @@ def make_reads(rng, species, n_reads, read_len=150, long_reads=False, adversaria
             k = e - b
             mode = int(rng.integers(0, 3))
             if mode == 0 and k == 1:
-                pend[r] = pstart[r] - int(rng.integers(1, 50))       # end < start on a single node
+                pstart[r] += 50                                      # end < start on a single node (vg issue 4249),
+                pend[r] = pstart[r] - int(rng.integers(1, 50))       # both still valid non-negative GAF values
             elif mode == 1 and k >= 3:
                 node_id[b + 2] = node_id[b]                          # a,b,a repeat
             elif mode == 2 and k >= 2 and S > 1:
