@@ -74,6 +74,12 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
     PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
     PTX_TRY(upload(ctx, db->d_bit_off, bit_off.data(), db->V + 1));
+    std::vector<uint32_t> len32(db->V);
+    for (uint64_t v = 0; v < db->V; ++v) {
+        if (g->node_len[v] > 0xFFFFFFFFll) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: node %llu longer than 2^32", (unsigned long long)v);
+        len32[v] = (uint32_t)g->node_len[v];
+    }
+    PTX_TRY(upload(ctx, db->d_node_len, len32.data(), db->V));
     PTX_TRY(upload(ctx, db->d_path_off, g->path_off, db->H + 1));
     PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
     PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
@@ -112,6 +118,7 @@ int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *
     PTX_TRY(upload(ctx, rd->d_mapq, r->mapq, r->n_reads));
     rd->has_flags = r->flags != nullptr;
     if (rd->has_flags) PTX_TRY(upload(ctx, rd->d_flags, r->flags, r->n_reads));
+    PTX_TRY(build_step_read(ctx, rd.get()));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = rd.release();
     return 0;

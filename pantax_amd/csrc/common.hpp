@@ -143,6 +143,7 @@ struct Db {
     DevBuf<uint32_t> d_sp_first_id;  // [S] range_start as u32
     DevBuf<uint32_t> d_node_base;    // [S+1]
     DevBuf<uint64_t> d_bit_off;      // [V+1] prefix sum of node_len; node_len[v] = bit_off[v+1]-bit_off[v]
+    DevBuf<uint32_t> d_node_len;     // [V] the same lengths as 4-byte gathers
     DevBuf<uint64_t> d_path_off;     // [H+1]
     DevBuf<uint32_t> d_path_nodes;   // [P]
     DevBuf<uint32_t> d_hap_species;  // [H]
@@ -183,6 +184,7 @@ struct Reads {
     DevBuf<uint8_t> d_mapq, d_flags;
     bool has_flags = false;
     DevBuf<int32_t> d_species;
+    DevBuf<uint32_t> d_step_read;    // [T] read index of every step (derived at upload)
     bool binned = false;
 };
 
@@ -209,6 +211,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, unsigned long long *d_abort);
 int trio_index_build(Ctx *ctx, Db *db);
+int build_step_read(Ctx *ctx, Reads *rd);
 
 }  // namespace ptx
 
