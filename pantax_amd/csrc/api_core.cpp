@@ -80,13 +80,16 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         len32[v] = (uint32_t)g->node_len[v];
     }
     PTX_TRY(upload(ctx, db->d_node_len, len32.data(), db->V));
+    std::vector<uint4> nrec(db->V);
+    for (uint64_t v = 0; v < db->V; ++v) nrec[v] = make_uint4((uint32_t)bit_off[v], (uint32_t)(bit_off[v] >> 32), len32[v], 0u);
+    PTX_TRY(upload(ctx, db->d_node_rec, nrec.data(), db->V));
     PTX_TRY(upload(ctx, db->d_path_off, g->path_off, db->H + 1));
     PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
     PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
     PTX_TRY(upload(ctx, db->d_hap_off, g->hap_off, S + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
-    PTX_HIP(ctx, db->d_trio_bc.alloc(1));
-    PTX_HIP(ctx, db->d_trio_row.alloc(1));
+    PTX_HIP(ctx, db->d_trio_node.alloc(1));
+    PTX_HIP(ctx, db->d_trio_ent.alloc(1));
     PTX_HIP(ctx, db->d_trio_bases.alloc(1));
     PTX_HIP(ctx, db->d_active.alloc(S));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope

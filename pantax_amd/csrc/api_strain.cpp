@@ -194,19 +194,34 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
             for (int k = 0; k < p; ++k) { pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]]; m.second_sol = m.first_sol; m.has |= PANTAX_HIP_HAS_SECOND; }
         }
     }
-    // ---- solve #2 with dropped candidates pinned to 0 (profile.rs:1484-1508, Gurobi semantics)
+    // ---- solve #2 with dropped candidates pinned to 0 (profile.rs:1484-1508, Gurobi semantics).
+    // When the second filter drops nothing the second LP is the first LP again (m.reset() + no new
+    // constraint), so its optimum is the one already computed: reuse it instead of re-solving.
     if (!list2.empty()) {
-        for (int32_t s : list2)
-            for (int k = 0; k < lb.h_p[s]; ++k) if (!st[s].keep[k]) ub[(size_t)s * LAD_MAXP + k] = 0.0;
-        PTX_TRY(upload(ctx, lb.d_ub, ub.data(), ub.size()));
-        PTX_TRY(run_solve(ctx, db, &lb, list2, x2, obj2, st2, it2));
+        std::vector<int32_t> resolve;
+        for (int32_t s : list2) {
+            bool any_dropped = false;
+            for (int k = 0; k < lb.h_p[s]; ++k) if (!st[s].keep[k]) { ub[(size_t)s * LAD_MAXP + k] = 0.0; any_dropped = true; }
+            if (any_dropped) resolve.push_back(s);
+        }
+        if (!resolve.empty()) {
+            PTX_TRY(upload(ctx, lb.d_ub, ub.data(), ub.size()));
+            PTX_TRY(run_solve(ctx, db, &lb, resolve, x2, obj2, st2, it2));
+        }
+        std::vector<uint8_t> resolved(S, 0);
+        for (int32_t s : resolve) resolved[s] = 1;
         for (int32_t s : list2) {
             SpeciesState &ss = st[s];
-            info[s].status2 = st2[s]; info[s].iters2 = it2[s]; info[s].obj2 = obj2[s];
-            if (st2[s] != 0) { ss.failed = true; ss.fail_code = PANTAX_HIP_E_SOLVER; continue; }
+            const bool rs = resolved[s] != 0;
+            info[s].status2 = rs ? st2[s] : st1[s]; info[s].iters2 = rs ? it2[s] : 0; info[s].obj2 = rs ? obj2[s] : obj1[s];
+            if (info[s].status2 != 0) { ss.failed = true; ss.fail_code = PANTAX_HIP_E_SOLVER; continue; }
             const uint64_t h0 = db->h_hap_off[s];
             for (int k = 0; k < lb.h_p[s]; ++k)
-                if (ss.keep[k]) { pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]]; m.second_sol = x2[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_SECOND; }
+                if (ss.keep[k]) {
+                    pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]];
+                    m.second_sol = rs ? x2[(size_t)s * LAD_MAXP + k] : x1[(size_t)s * LAD_MAXP + k];
+                    m.has |= PANTAX_HIP_HAS_SECOND;
+                }
         }
     }
     // ---- failed species are dropped whole (reference returns None); abundace_constraint for the rest

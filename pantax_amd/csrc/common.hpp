@@ -144,6 +144,7 @@ struct Db {
     DevBuf<uint32_t> d_node_base;    // [S+1]
     DevBuf<uint64_t> d_bit_off;      // [V+1] prefix sum of node_len; node_len[v] = bit_off[v+1]-bit_off[v]
     DevBuf<uint32_t> d_node_len;     // [V] the same lengths as 4-byte gathers
+    DevBuf<uint4> d_node_rec;        // [V] {bit_off lo, bit_off hi, len, 0}: one 16-byte gather per step
     DevBuf<uint64_t> d_path_off;     // [H+1]
     DevBuf<uint32_t> d_path_nodes;   // [P]
     DevBuf<uint32_t> d_hap_species;  // [H]
@@ -152,8 +153,8 @@ struct Db {
     bool trio_built = false;
     uint64_t U = 0;
     DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
-    DevBuf<uint2> d_trio_bc;         // [U] (b,c) sorted within each first-node row
-    DevBuf<uint32_t> d_trio_row;     // [U] sorted position -> row in (species,hap,position) order
+    DevBuf<uint2> d_trio_node;       // [V] {first lookup row, #rows} of the windows whose smallest end is this node
+    DevBuf<uint4> d_trio_ent;        // [U] {b, c, row in (species,hap,position) order, 0}
     DevBuf<uint32_t> d_trio_abc;     // [3U] row order
     DevBuf<uint32_t> d_trio_hap;     // [U] hap index within species, row order
     DevBuf<uint32_t> d_trio_len;     // [U]
@@ -185,6 +186,7 @@ struct Reads {
     bool has_flags = false;
     DevBuf<int32_t> d_species;
     DevBuf<uint32_t> d_step_read;    // [T] read index of every step (derived at upload)
+    DevBuf<uint4> d_read_rec;        // [R] {first step, #steps, pstart, pend} (derived at upload)
     bool binned = false;
 };
 

@@ -84,15 +84,20 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
 // 4. lookup arrays: CSR over the first node, rows hold (b,c) and the row number in path order
 __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint8_t *__restrict__ uniq_q, const uint32_t *__restrict__ row_of_q,
                                                           const uint32_t *__restrict__ trio_first, uint32_t *__restrict__ cursor,
-                                                          uint2 *__restrict__ trio_bc, uint32_t *__restrict__ trio_row) {
+                                                          uint4 *__restrict__ trio_ent) {
     for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
         if (!uniq_q[q]) continue;
         uint32_t h, g, a, b, c;
         window_at(q, H, path_off, path_nodes, hap_species, node_base, h, g, a, b, c);
         uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
-        trio_bc[j] = make_uint2(b, c);
-        trio_row[j] = row_of_q[q];
+        trio_ent[j] = make_uint4(b, c, row_of_q[q], 0u);
     }
+}
+
+__global__ void __launch_bounds__(256) trio_node_kernel(uint64_t V, const uint32_t *__restrict__ trio_first, const uint32_t *__restrict__ first_cnt,
+                                                        uint2 *__restrict__ trio_node) {
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256)
+        trio_node[v] = make_uint2(trio_first[v], first_cnt[v]);
 }
 
 __global__ void __launch_bounds__(256) trio_rows_kernel(uint64_t P, uint32_t H, const uint64_t *__restrict__ path_off,
@@ -141,6 +146,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
     PTX_HIP(ctx, hipMemsetAsync(ts.uniq_q.p, 0, (P ? P : 1), ctx->stream));
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
+    PTX_HIP(ctx, db->d_trio_node.alloc(V));
     uint32_t tot[2] = {0, 0};
     int grid = grid_for(P ? P : 1, 256, ctx->n_cu * 8);
 #define TRIO_GRAPH P, H, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
@@ -169,12 +175,12 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t Utot = tot[1];
         db->U = Utot;
-        PTX_HIP(ctx, db->d_trio_bc.alloc(Utot)); PTX_HIP(ctx, db->d_trio_row.alloc(Utot));
+        PTX_HIP(ctx, db->d_trio_ent.alloc(Utot));
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
             hipLaunchKernelGGL(trio_lookup_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.uniq_q.p, ts.row_of_q.p,
-                               db->d_trio_first.p, ts.cursor.p, db->d_trio_bc.p, db->d_trio_row.p);
+                               db->d_trio_first.p, ts.cursor.p, db->d_trio_ent.p);
         }
         {
             KTimer t(ctx, "trio_rows_kernel");
@@ -189,6 +195,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
     }
+    hipLaunchKernelGGL(trio_node_kernel, dim3(grid_for(V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, V, db->d_trio_first.p,
+                       ts.first_cnt.p, db->d_trio_node.p);
 #undef TRIO_GRAPH
     db->h_hap_trio_off.resize(H + 1);
     PTX_TRY(download(ctx, db->h_hap_trio_off.data(), db->d_hap_trio_off.p, H + 1));
