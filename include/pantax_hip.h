@@ -175,7 +175,7 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
 /* ---- pipeline seam: files in, files out (profile.rs:3325) -------------------------------- */
 typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = reference default under db/wd */
     const char *db, *wd, *output_dir;
-    const char *genomes_metadata, *range_file, *input_aln_file, *species_len_file, *out_binning_file;
+    const char *genomes_metadata, *range_file, *input_aln_file, *species_len_file, *out_binning_file, *reads_binning_file;
     double min_species_abundance, unique_trio_nodes_fraction, unique_trio_nodes_mean_count_f, single_cov_ratio,
         single_cov_diff;
     int64_t min_cov, min_depth;

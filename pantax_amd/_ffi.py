@@ -62,7 +62,7 @@ class SolveInfo(C.Structure):
 class ProfilingConfig(C.Structure):
     _fields_ = [("db", C.c_char_p), ("wd", C.c_char_p), ("output_dir", C.c_char_p), ("genomes_metadata", C.c_char_p),
                 ("range_file", C.c_char_p), ("input_aln_file", C.c_char_p), ("species_len_file", C.c_char_p),
-                ("out_binning_file", C.c_char_p),
+                ("out_binning_file", C.c_char_p), ("reads_binning_file", C.c_char_p),
                 ("min_species_abundance", C.c_double), ("unique_trio_nodes_fraction", C.c_double),
                 ("unique_trio_nodes_mean_count_f", C.c_double), ("single_cov_ratio", C.c_double),
                 ("single_cov_diff", C.c_double), ("min_cov", C.c_int64), ("min_depth", C.c_int64),

@@ -17,6 +17,28 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     if (S == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: n_species == 0");
     std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
     db->S = S;
+    if (!g->node_len) {
+        // ranges-only db: enough for read binning (a2/a3) over ALL species of species_range.txt without
+        // loading any graph; the strain stages need a full db of the selected species
+        std::vector<uint32_t> order(S), rs(S), re(S);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g->range_start[a] < g->range_start[b]; });
+        bool disjoint = true;
+        for (uint32_t i = 0; i < S; ++i)
+            if (g->range_start[i] < 0 || g->range_end[i] > 0xFFFFFFFFll) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u has an invalid node id range", i);
+        for (uint32_t i = 0; i + 1 < S; ++i) if (g->range_end[order[i]] >= g->range_start[order[i + 1]]) disjoint = false;
+        db->ranges_sorted_disjoint = disjoint;
+        if (!disjoint) std::iota(order.begin(), order.end(), 0u);
+        for (uint32_t i = 0; i < S; ++i) { rs[i] = (uint32_t)g->range_start[order[i]]; re[i] = (uint32_t)g->range_end[order[i]]; }
+        db->h_range_start.assign(g->range_start, g->range_start + S);
+        db->h_range_end.assign(g->range_end, g->range_end + S);
+        PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
+        PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
+        PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *out = db.release();
+        return 0;
+    }
     db->V = g->node_off[S];
     db->H = g->hap_off[S];
     db->P = g->path_off[db->H];

@@ -1,0 +1,347 @@
+// api_profile.cpp -- the pipeline seam: pantax_hip_profile(cfg) == profile::profile(ProfilingConfig)
+// (profile.rs:3325-3436): files in (GAF + DB files), files out (species_abundance.txt,
+// strain_abundance.txt, ori_strain_abundance.txt, optional reads_classification.tsv).
+// Host orchestration only; every per-read / per-node computation goes through the device stages.
+#include <sys/stat.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include "common.hpp"
+#include "host_io.hpp"
+
+using namespace ptx;
+
+namespace {
+
+bool is_file(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+bool is_dir(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+std::string join(const std::string &a, const std::string &b) { return a.empty() ? b : (a.back() == '/' ? a + b : a + "/" + b); }
+std::string opt(const char *s) { return s ? std::string(s) : std::string(); }
+
+// choose_existing_file_from_two_files (profile.rs:107-134): explicit path wins, else the DB default
+std::string choose(const std::string &a, const std::string &b) { return is_file(a) ? a : (is_file(b) ? b : std::string()); }
+
+struct SpeciesProfileRow { std::string species; double abundance, coverage; };
+
+struct DbHolder {
+    pantax_hip_ctx *ctx;
+    pantax_hip_db *db = nullptr;
+    ~DbHolder() { if (db) pantax_hip_db_free(ctx, db); }
+};
+struct ReadsHolder {
+    pantax_hip_ctx *ctx;
+    pantax_hip_reads *rd = nullptr;
+    ~ReadsHolder() { if (rd) pantax_hip_reads_free(ctx, rd); }
+};
+
+inline double round2(double x) { return std::round(x * 100.0) / 100.0; }
+std::string cell(bool has, double v, bool rnd = false) { return has ? fmt_f64(rnd ? round2(v) : v) : std::string(); }
+
+}  // namespace
+
+extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg) {
+    if (!ctx || !cfg) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    // ---- check_args_valid (profile.rs:71-199)
+    if (!cfg->species && !cfg->strain) return fail(ctx, PANTAX_HIP_E_INVALID, "Please choose profiling level with --species or/and --strain.");
+    if (cfg->world_size > 1)
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: the file seam drives one GPU; multi-GPU runs shard species across processes through the stage API (pantax_amd.pipeline / bench.py)");
+    const std::string db_dir = opt(cfg->db), wd = opt(cfg->wd);
+    std::string out_dir = opt(cfg->output_dir);
+    if (out_dir.empty()) out_dir = wd;
+    if (!is_dir(db_dir)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax database directory '%s' is not a valid directory path", db_dir.c_str());
+    if (!is_dir(wd)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax work directory '%s' is not a valid directory path", wd.c_str());
+    if (cfg->sample_nodes != 0)
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: --sample %d: LP row sub-sampling (profile.rs:1394-1400) is not implemented; pass --sample 0", cfg->sample_nodes);
+    const std::string zip = opt(cfg->zip);
+    if (zip == "lz" || zip == "zstd" || zip == "h5")
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: graph codec '%s' is not available in this build; use serialize (.bin) or GFA", zip.c_str());
+    const std::string species_file = join(wd, "species_abundance.txt"), strain_file = join(wd, "strain_abundance.txt");
+    const bool species_exists = !cfg->force && is_file(species_file);
+    const bool strain_exists = !cfg->force && is_file(strain_file);
+    const bool full_path = cfg->species && !species_exists;
+    const bool strain_only = !full_path && cfg->strain && !strain_exists;
+    if (!full_path && !strain_only) return 0;   // profile.rs:3419-3427: outputs already present
+    mkdir(out_dir.c_str(), 0777);
+
+    const std::string gaf_path = opt(cfg->input_aln_file);
+    if (!is_file(gaf_path)) return fail(ctx, PANTAX_HIP_E_IO, "Specified GAF mapping file '%s' is not a valid file path", gaf_path.c_str());
+    const std::string range_path = choose(opt(cfg->range_file), join(db_dir, "species_range.txt"));
+    if (range_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species range file '%s' nor '%s' is a valid file path", opt(cfg->range_file).c_str(), join(db_dir, "species_range.txt").c_str());
+
+    std::vector<RangeRow> ranges;
+    std::string err = read_species_range(range_path, ranges);
+    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    const uint32_t S = (uint32_t)ranges.size();
+    if (S == 0) return fail(ctx, PANTAX_HIP_E_IO, "species range file %s is empty", range_path.c_str());
+
+    // ---- a1: GAF -> packed reads (rcls.rs:119-146)
+    MappedFile mf;
+    err = mf.open(gaf_path);
+    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    HostReads hr;
+    int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    err = parse_gaf(mf, hr, nthreads);
+    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    const uint64_t R = hr.pstart.size();
+
+    // ---- a2/a3: binning against ALL species ranges (ranges-only db), counters on device
+    std::vector<int64_t> rs(S), re(S);
+    for (uint32_t s = 0; s < S; ++s) { rs[s] = ranges[s].start; re[s] = ranges[s].end; }
+    DbHolder bin_db{ctx};
+    {
+        pantax_hip_graphs g{};
+        g.n_species = S; g.range_start = rs.data(); g.range_end = re.data();
+        PTX_TRY(pantax_hip_db_upload(ctx, &g, &bin_db.db));
+    }
+    ReadsHolder reads{ctx};
+    {
+        pantax_hip_packed_reads pr{};
+        pr.n_reads = R; pr.n_steps = hr.node_id.size();
+        pr.step_off = hr.step_off.data(); pr.node_id = hr.node_id.data(); pr.pstart = hr.pstart.data(); pr.pend = hr.pend.data();
+        pr.qlen = hr.qlen.data(); pr.mapq = hr.mapq.data(); pr.flags = nullptr;   // flags are added for the strain level below
+        PTX_TRY(pantax_hip_reads_upload(ctx, &pr, &reads.rd));
+    }
+    std::vector<int32_t> sp_idx(R);
+    std::vector<int64_t> rc(S), bs(S), lm(S), uq(S);
+    PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, sp_idx.data(), rc.data(), bs.data(), lm.data(), uq.data()));
+
+    std::vector<SpeciesProfileRow> sp_profile;   // species_taxid, predicted_abundance, predicted_coverage
+    if (full_path) {
+        // optional binning report: read_id, mapq, species, read_len; no header (profile.rs:3337-3351)
+        const std::string report = opt(cfg->out_binning_file);
+        if (!report.empty() && report != "None") {
+            std::ofstream f(report);
+            if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", report.c_str());
+            for (uint64_t r = 0; r < R; ++r) {
+                f.write(mf.data + hr.id_span[r].first, hr.id_span[r].second);
+                f << '\t';
+                if (hr.mapq[r] != 255) f << (int)hr.mapq[r];
+                f << '\t' << (sp_idx[r] >= 0 ? ranges[sp_idx[r]].species : std::string("U")) << '\t' << hr.qlen[r] << '\n';
+            }
+        }
+        const std::string len_path = choose(opt(cfg->species_len_file), join(db_dir, "species_genomes_stats.txt"));
+        if (len_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species length file '%s' nor '%s' is a valid file path", opt(cfg->species_len_file).c_str(), join(db_dir, "species_genomes_stats.txt").c_str());
+        std::vector<std::pair<std::string, double>> lens;
+        err = read_species_len(len_path, lens);
+        if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+        std::unordered_map<std::string, double> len_of(lens.begin(), lens.end());
+        std::vector<double> avg(S, 0.0);
+        for (uint32_t s = 0; s < S; ++s) { auto it = len_of.find(ranges[s].species); if (it != len_of.end()) avg[s] = it->second; }
+        std::vector<uint8_t> keep(S);
+        std::vector<double> absolute(S), abundance(S);
+        PTX_TRY(pantax_hip_species_profile(ctx, bin_db.db, reads.rd, rc.data(), bs.data(), lm.data(), uq.data(), avg.data(), cfg->filtered,
+                                           keep.data(), absolute.data(), abundance.data()));
+        for (uint32_t s = 0; s < S; ++s) if (keep[s]) sp_profile.push_back({ranges[s].species, abundance[s], absolute[s]});
+        std::stable_sort(sp_profile.begin(), sp_profile.end(), [](const SpeciesProfileRow &a, const SpeciesProfileRow &b) { return a.abundance > b.abundance; });   // :344
+        std::ofstream f(join(out_dir, "species_abundance.txt"));
+        if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", join(out_dir, "species_abundance.txt").c_str());
+        f << "species_taxid\tpredicted_abundance\tpredicted_coverage\n";
+        for (auto &r : sp_profile) f << r.species << '\t' << fmt_f64(r.abundance) << '\t' << fmt_f64(r.coverage) << '\n';
+        if (!cfg->strain || strain_exists) return 0;
+    } else {
+        // strain only (profile.rs:3365-3417): species column comes from the saved binning file (positional join)
+        std::string rb = choose(opt(cfg->reads_binning_file), join(wd, "reads_classification.tsv"));   // profile.rs:179-182
+        if (rb.empty()) return fail(ctx, PANTAX_HIP_E_IO, "reads binning file '%s' is not a valid file path", join(wd, "reads_classification.tsv").c_str());
+        std::unordered_map<std::string, int32_t> idx_of;
+        for (uint32_t s = 0; s < S; ++s) idx_of.emplace(ranges[s].species, (int32_t)s);
+        std::ifstream f(rb);
+        std::string line;
+        uint64_t r = 0;
+        while (std::getline(f, line)) {
+            if (r >= R) return fail(ctx, PANTAX_HIP_E_IO, "%s has more rows than the GAF (%llu)", rb.c_str(), (unsigned long long)R);
+            size_t t1 = line.find('\t'), t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1), t3 = t2 == std::string::npos ? t2 : line.find('\t', t2 + 1);
+            if (t2 == std::string::npos) return fail(ctx, PANTAX_HIP_E_IO, "malformed row in %s", rb.c_str());
+            std::string spn = line.substr(t2 + 1, t3 == std::string::npos ? std::string::npos : t3 - t2 - 1);
+            auto it = idx_of.find(spn);
+            sp_idx[r++] = it == idx_of.end() ? -1 : it->second;
+        }
+        if (r != R) return fail(ctx, PANTAX_HIP_E_IO, "%s has %llu rows but the GAF has %llu (the join is positional, profile.rs:3381-3384)", rb.c_str(), (unsigned long long)r, (unsigned long long)R);
+        if (!is_file(species_file)) return fail(ctx, PANTAX_HIP_E_IO, "species abundance file '%s' is not a valid file path", species_file.c_str());
+        std::ifstream sf(species_file);
+        bool header = true;
+        while (std::getline(sf, line)) {
+            if (header) { header = false; continue; }
+            size_t t1 = line.find('\t'), t2 = line.find('\t', t1 + 1);
+            if (t1 == std::string::npos || t2 == std::string::npos) continue;
+            sp_profile.push_back({line.substr(0, t1), std::stod(line.substr(t1 + 1, t2 - t1 - 1)), std::stod(line.substr(t2 + 1))});
+        }
+    }
+
+    // ---- a4: load_species_range (profile.rs:553-656)
+    std::set<std::string> ds;
+    const std::string ds_s = opt(cfg->designated_species);
+    if (!ds_s.empty() && ds_s != "None") {
+        std::stringstream ss(ds_s);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) {
+            size_t b = tok.find_first_not_of(" \t"), e = tok.find_last_not_of(" \t");
+            if (b != std::string::npos) ds.insert(tok.substr(b, e - b + 1));
+        }
+    }
+    std::unordered_map<std::string, uint32_t> range_idx;
+    for (uint32_t s = 0; s < S; ++s) range_idx.emplace(ranges[s].species, s);
+    std::vector<uint32_t> sel;          // indices into `ranges`, in species-profile order
+    std::vector<double> sel_cov;
+    bool any_after_ds = false;
+    for (auto &row : ranges) {
+        if ((cfg->mode == 0 && row.is_pan != 0) || (cfg->mode == 1 && row.is_pan != 1)) continue;
+        if (!ds.empty() && !ds.count(row.species)) continue;
+        any_after_ds = true;
+    }
+    if (!any_after_ds) return 0;        // reference: warn + exit(0) (profile.rs:595-598)
+    for (auto &row : sp_profile) {
+        if (!(row.abundance > cfg->min_species_abundance)) continue;                 // :602
+        auto it = range_idx.find(row.species);
+        if (it == range_idx.end()) continue;                                         // inner join :604-605
+        const RangeRow &rr = ranges[it->second];
+        if ((cfg->mode == 0 && rr.is_pan != 0) || (cfg->mode == 1 && rr.is_pan != 1)) continue;
+        if (!ds.empty() && !ds.count(rr.species)) continue;
+        sel.push_back(it->second);
+        sel_cov.push_back(row.coverage);
+    }
+
+    // ---- a5: rows with a null field are dropped; duplicate read ids (profile.rs:361-463)
+    std::vector<uint8_t> flags(hr.flags);
+    {
+        std::unordered_set<uint64_t> seen;
+        seen.reserve(R * 2);
+        bool unique = true;
+        for (uint64_t r = 0; r < R && unique; ++r) if (sp_idx[r] >= 0 && !seen.insert(hr.id_hash[r]).second) unique = false;
+        if (!unique) {   // process_with_duplicates: keep an id only if all of its (complete) alignments sit in one species
+            std::unordered_map<uint64_t, int32_t> first;
+            std::unordered_set<uint64_t> mixed;
+            for (uint64_t r = 0; r < R; ++r) {
+                if (sp_idx[r] < 0 || flags[r]) continue;
+                auto ins = first.emplace(hr.id_hash[r], sp_idx[r]);
+                if (!ins.second && ins.first->second != sp_idx[r]) mixed.insert(hr.id_hash[r]);
+            }
+            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0 && mixed.count(hr.id_hash[r])) flags[r] |= PANTAX_HIP_READ_DUPDROP;
+        }
+    }
+
+    // ---- a6: graphs of the selected species (optimize_otu file choice, profile.rs:2888-2932)
+    const uint32_t Ss = (uint32_t)sel.size();
+    std::vector<HostGraph> graphs(Ss);
+    std::vector<uint8_t> loaded(Ss, 1);
+    for (uint32_t i = 0; i < Ss; ++i) {
+        const std::string &otu = ranges[sel[i]].species;
+        std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
+        std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
+        std::string e2;
+        if (zip == "serialize" && is_file(bin)) e2 = read_graph_bin(bin, graphs[i]);
+        else if (is_file(gfa)) e2 = read_gfa(gfa, graphs[i]);
+        else return fail(ctx, PANTAX_HIP_E_IO, "gfa information file %s does not exist. Please check database.", gfa.c_str());
+        if (!e2.empty()) { loaded[i] = 0; continue; }            // "GFA read error" => species skipped (.ok()?)
+        const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
+        if ((int64_t)graphs[i].node_len.size() != nvert) return fail(ctx, PANTAX_HIP_E_IO, "species %s: graph has %zu nodes but its range spans %lld", otu.c_str(), graphs[i].node_len.size(), (long long)nvert);
+    }
+    std::vector<uint32_t> use;   // selected species with a loaded graph
+    for (uint32_t i = 0; i < Ss; ++i) if (loaded[i]) use.push_back(i);
+    const uint32_t Su = (uint32_t)use.size();
+    std::vector<pantax_hip_hap_metrics> met;
+    std::vector<pantax_hip_solve_info> info(Su);
+    std::vector<uint64_t> hap_off(Su + 1, 0);
+    std::vector<std::string> hap_names;
+    if (Su) {
+        std::vector<int64_t> g_rs(Su), g_re(Su), node_len;
+        std::vector<uint64_t> node_off(Su + 1, 0), path_off{0};
+        std::vector<uint32_t> path_nodes;
+        for (uint32_t k = 0; k < Su; ++k) {
+            const HostGraph &hg = graphs[use[k]];
+            g_rs[k] = ranges[sel[use[k]]].start; g_re[k] = ranges[sel[use[k]]].end;
+            node_len.insert(node_len.end(), hg.node_len.begin(), hg.node_len.end());
+            node_off[k + 1] = node_len.size();
+            for (size_t h = 0; h < hg.hap_names.size(); ++h) { path_off.push_back(path_nodes.size() + hg.path_off[h + 1]); hap_names.push_back(hg.hap_names[h]); }
+            path_nodes.insert(path_nodes.end(), hg.path_nodes.begin(), hg.path_nodes.end());
+            hap_off[k + 1] = hap_names.size();
+        }
+        DbHolder sdb{ctx};
+        pantax_hip_graphs g{Su, g_rs.data(), g_re.data(), node_off.data(), node_len.data(), hap_off.data(), path_off.data(), path_nodes.data()};
+        PTX_TRY(pantax_hip_db_upload(ctx, &g, &sdb.db));
+        // re-upload reads with the strain-level drop flags; species binned against the selected ranges
+        // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
+        // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
+        ReadsHolder sreads{ctx};
+        pantax_hip_packed_reads pr{};
+        pr.n_reads = R; pr.n_steps = hr.node_id.size();
+        pr.step_off = hr.step_off.data(); pr.node_id = hr.node_id.data(); pr.pstart = hr.pstart.data(); pr.pend = hr.pend.data();
+        pr.qlen = hr.qlen.data(); pr.mapq = hr.mapq.data(); pr.flags = flags.data();
+        if (strain_only) {
+            // species from the saved report decide membership: a read whose recorded species differs from
+            // where its nodes bin now is dropped for that species
+            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD;
+        }
+        PTX_TRY(pantax_hip_reads_upload(ctx, &pr, &sreads.rd));
+        PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads.rd, nullptr, nullptr, nullptr, nullptr, nullptr));
+        uint64_t nU = 0, n_abort = 0;
+        PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
+        PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads.rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
+        pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, 0};
+        std::vector<double> cov(Su);
+        for (uint32_t k = 0; k < Su; ++k) cov[k] = sel_cov[use[k]];
+        met.resize(hap_names.size());
+        PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data(), met.data(), info.data()));
+    }
+
+    // ---- a15: abundance_est (profile.rs:3091-3289)
+    std::vector<GenomeRow> genomes;
+    err = read_genomes_info(join(db_dir, "genomes_info.txt"), genomes);   // the reference always reads <db>/genomes_info.txt (:3099)
+    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    std::unordered_multimap<std::string, size_t> by_hap;
+    for (size_t i = 0; i < genomes.size(); ++i) by_hap.emplace(genomes[i].hap_id, i);
+    std::vector<uint8_t> reported(Su, 0), pass(hap_names.size() ? hap_names.size() : 1, 0);
+    for (uint32_t k = 0; k < Su; ++k) reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
+    double sum_all = 0.0, sum_pass = 0.0;
+    if (Su) PTX_TRY(pantax_hip_abundance_filter(Su, hap_off.data(), met.data(), reported.data(), cfg->single_cov_diff, cfg->min_cov, pass.data(), &sum_all, &sum_pass, nullptr, nullptr));
+    struct OutRow { std::string line; double key; };
+    auto row_text = [&](uint32_t k, uint64_t h, const GenomeRow *gr, double abund, bool has_abund, bool rnd) {
+        const pantax_hip_hap_metrics &m = met[h];
+        std::string s = ranges[sel[use[k]]].species;
+        s += '\t'; if (gr) s += gr->strain_taxid;
+        s += '\t'; if (gr) s += gr->genome_id;
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_SECOND, m.second_sol, rnd);
+        s += '\t' + (has_abund ? fmt_f64(abund) : std::string());
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_RATIO, m.path_cov_ratio, rnd);
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_FRACTION, m.unique_trio_nodes_fraction, rnd);
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_FREQ_MEAN, m.frequencies_mean, rnd);
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_FIRST, m.first_sol, rnd);
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_DIVERGENCE, m.divergence, rnd);
+        s += '\t' + cell(m.has & PANTAX_HIP_HAS_TOTAL_DIFF, m.total_cov_diff, rnd);
+        return s;
+    };
+    const char *header = "species_taxid\tstrain_taxid\tgenome_ID\tpredicted_coverage\tpredicted_abundance\tpath_base_cov\tunique_trio_fraction\tuniq_trio_cov_mean\tfirst_sol\tstrain_cov_diff\ttotal_cov_diff\n";
+    std::vector<OutRow> final_rows;
+    {
+        std::ofstream ori("ori_strain_abundance.txt");   // written to the current directory (profile.rs:3217)
+        if (ori) ori << header;
+        for (uint32_t k = 0; k < Su; ++k) {
+            if (!reported[k]) continue;
+            for (uint64_t h = hap_off[k]; h < hap_off[k + 1]; ++h) {
+                auto range = by_hap.equal_range(hap_names[h]);
+                std::vector<const GenomeRow *> grs;
+                for (auto it = range.first; it != range.second; ++it) grs.push_back(&genomes[it->second]);
+                if (grs.empty()) grs.push_back(nullptr);          // left join keeps the row with null metadata
+                const bool hs = met[h].has & PANTAX_HIP_HAS_SECOND;
+                for (const GenomeRow *gr : grs) {
+                    if (ori) ori << row_text(k, h, gr, hs ? met[h].second_sol / sum_all : 0.0, hs, false) << '\n';
+                    if (pass[h]) final_rows.push_back({row_text(k, h, gr, met[h].second_sol / sum_pass, true, !cfg->full), met[h].second_sol / sum_pass});   // :3250-3284
+                }
+            }
+        }
+    }
+    std::stable_sort(final_rows.begin(), final_rows.end(), [](const OutRow &a, const OutRow &b) { return a.key > b.key; });   // :3247-3248
+    std::ofstream f(strain_file);
+    if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", strain_file.c_str());
+    f << header;
+    for (auto &r : final_rows) f << r.line << '\n';
+    return 0;
+}

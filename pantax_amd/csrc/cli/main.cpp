@@ -1,0 +1,71 @@
+// pantax-hip -- command-line front end of the pipeline seam.  Takes the profiling flags of the
+// reference CLI (cli.rs:114-164, 222-240; defaults resolved as in main.rs:102-171) and calls
+// pantax_hip_profile, i.e. it stands where `pantax ... --species --strain` calls profile::profile.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "../../../include/pantax_hip.h"
+
+static void usage() {
+    fprintf(stderr,
+            "usage: pantax-hip -db <db_dir> --gaf <gfa_mapped.gaf> [-T <work_dir>] [--species] [--strain]\n"
+            "  --short-read | --long-read     (sets --fr default 0.3 / 0.5)\n"
+            "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
+            "  --min_cov N  --min_depth N  --sample N(must be 0)  --ds a,b,c  --smode 0|1  --no-filter\n"
+            "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
+            "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --round (2-decimal output)  --device N\n");
+}
+
+int main(int argc, char **argv) {
+    pantax_hip_profiling_config c;
+    memset(&c, 0, sizeof(c));
+    std::string wd = "pantax_db_tmp";
+    c.min_species_abundance = 1e-4; c.unique_trio_nodes_fraction = -1; c.unique_trio_nodes_mean_count_f = 0.46;
+    c.single_cov_ratio = 0.85; c.single_cov_diff = 0.2; c.filtered = 1; c.full = 1; c.mode = 2; c.sample_nodes = 0;
+    c.zip = "serialize"; c.world_size = 1;
+    bool long_read = false;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+        if (a == "-db" || a == "--db") c.db = next();
+        else if (a == "--gaf") c.input_aln_file = next();
+        else if (a == "-T") wd = next();
+        else if (a == "--species" || a == "-s") c.species = 1;
+        else if (a == "--strain" || a == "-S") c.strain = 1;
+        else if (a == "--short-read") long_read = false;
+        else if (a == "--long-read") long_read = true;
+        else if (a == "--fr") c.unique_trio_nodes_fraction = atof(next());
+        else if (a == "--fc") c.unique_trio_nodes_mean_count_f = atof(next());
+        else if (a == "-a") c.min_species_abundance = atof(next());
+        else if (a == "--sr") c.single_cov_ratio = atof(next());
+        else if (a == "--sd") c.single_cov_diff = atof(next());
+        else if (a == "--shift") c.shift = !strcasecmp(next(), "true");
+        else if (a == "--min_cov") c.min_cov = atoll(next());
+        else if (a == "--min_depth") c.min_depth = atoll(next());
+        else if (a == "--sample") c.sample_nodes = atoi(next());
+        else if (a == "--ds") c.designated_species = next();
+        else if (a == "--smode") c.mode = atoi(next());
+        else if (a == "--no-filter") c.filtered = 0;
+        else if (a == "--force") c.force = 1;
+        else if (a == "-R" || a == "--report") c.out_binning_file = next();
+        else if (a == "--range-file") c.range_file = next();
+        else if (a == "--species-len-file") c.species_len_file = next();
+        else if (a == "--reads-binning-file") c.reads_binning_file = next();
+        else if (a == "--gfa") c.zip = nullptr;
+        else if (a == "--round") c.full = 0;
+        else if (a == "--device") device = atoi(next());
+        else { usage(); return 2; }
+    }
+    if (!c.db || !c.input_aln_file) { usage(); return 2; }
+    if (c.unique_trio_nodes_fraction < 0) c.unique_trio_nodes_fraction = long_read ? 0.5 : 0.3;   // main.rs:108-114
+    c.wd = wd.c_str(); c.output_dir = wd.c_str();
+    pantax_hip_ctx *ctx = nullptr;
+    int rc = pantax_hip_init(&ctx, &device, 1);
+    if (rc != 0) { fprintf(stderr, "pantax-hip: %s\n", pantax_hip_last_error(nullptr)); return 1; }
+    rc = pantax_hip_profile(ctx, &c);
+    if (rc != 0) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx));
+    pantax_hip_destroy(ctx);
+    return rc == 0 ? 0 : 1;
+}

@@ -206,6 +206,23 @@ class Engine:
                                                   C.byref(obj), C.byref(st)))
         return x, ratio, obj.value, st.value
 
+    # ------------------------------------------------------------------ pipeline seam
+    def profile(self, db, wd, gaf, species=True, strain=True, output_dir=None, fr=0.3, fc=0.46, sr=0.85, sd=0.2,
+                min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,
+                mode=2, sample_nodes=0, designated_species=None, zip="serialize", out_binning_file=None,
+                reads_binning_file=None, range_file=None, species_len_file=None):
+        """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out."""
+        enc = lambda x: None if x is None else str(x).encode()
+        cfg = _ffi.ProfilingConfig(
+            db=enc(db), wd=enc(wd), output_dir=enc(output_dir or wd), genomes_metadata=None, range_file=enc(range_file),
+            input_aln_file=enc(gaf), species_len_file=enc(species_len_file), out_binning_file=enc(out_binning_file),
+            reads_binning_file=enc(reads_binning_file), min_species_abundance=min_species_abundance,
+            unique_trio_nodes_fraction=fr, unique_trio_nodes_mean_count_f=fc, single_cov_ratio=sr, single_cov_diff=sd,
+            min_cov=min_cov, min_depth=min_depth, species=int(species), strain=int(strain), shift=int(shift),
+            filtered=int(filtered), full=int(full), force=int(force), mode=mode, sample_nodes=sample_nodes,
+            designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1)
+        self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
+
     # ------------------------------------------------------------------ timing
     def timing_enable(self, on=True):
         self._check(self.lib.pantax_hip_timing_enable(self.ctx, int(on)))
