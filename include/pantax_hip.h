@@ -188,6 +188,24 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
 
 int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);
 
+/* ---- a1 / a6 host readers (no GPU needed): the file contracts of the pipeline seam, exposed so a
+ * caller that keeps its own orchestration can still reuse the tokenizer and graph loaders ---------- */
+typedef struct pantax_hip_gaf pantax_hip_gaf;     /* owns the packed arrays of one tokenised GAF */
+/* load_gaf_file_lazy (rcls.rs:119-146): columns 1,2,6,7,8,9,12; '@' comment lines skipped; "*" = null
+ * (=> PANTAX_HIP_READ_NULLFIELD for cols 6-9, mapq 255, qlen 0).  err_out (may be NULL) receives a
+ * static/thread-local message on failure. */
+int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, const char **err_out);
+int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *view_out);
+void pantax_hip_gaf_free(pantax_hip_gaf *gaf);
+
+typedef struct pantax_hip_graph pantax_hip_graph; /* one species graph in `Graph` shape (types.rs:51-55) */
+/* format 0 = GFA S/W/P lines (read_gfa, profile.rs:466-545), 1 = bincode-1 .bin (zip.rs:236-247) */
+int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, const char **err_out);
+/* sizes: n_nodes, n_haps, n_steps; arrays are valid until graph_free; hap_names_out[i] NUL-terminated */
+int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t *n_haps, const int64_t **node_len,
+                          const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names);
+void pantax_hip_graph_free(pantax_hip_graph *g);
+
 /* ---- measurement: HIP-event timings of kernels launched on the ctx stream ---------------- */
 int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on);
 int pantax_hip_timing_reset(pantax_hip_ctx *ctx);

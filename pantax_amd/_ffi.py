@@ -19,6 +19,8 @@ SYMBOLS = [
     "pantax_hip_bin_reads", "pantax_hip_species_profile", "pantax_hip_db_reset", "pantax_hip_abundance_filter",
     "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
     "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_profile",
+    "pantax_hip_gaf_load", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
+    "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free",
     "pantax_hip_timing_enable", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
 ]
 
@@ -85,6 +87,8 @@ def load():
         _lib.pantax_hip_destroy.restype = None
         _lib.pantax_hip_db_free.restype = None
         _lib.pantax_hip_reads_free.restype = None
+        _lib.pantax_hip_gaf_free.restype = None
+        _lib.pantax_hip_graph_free.restype = None
     return _lib
 
 

@@ -1,0 +1,64 @@
+// api_io.cpp -- C ABI over the host readers (a1 GAF tokenizer, a6 graph loaders). Host only.
+#include <string>
+#include <vector>
+#include "../../include/pantax_hip.h"
+#include "host_io.hpp"
+
+using namespace ptx;
+
+struct pantax_hip_gaf { MappedFile mf; HostReads reads; };
+struct pantax_hip_graph { HostGraph g; std::vector<const char *> names; };
+
+static thread_local std::string g_io_err;
+static int io_fail(const char **err_out, const std::string &msg) {
+    g_io_err = msg;
+    if (err_out) *err_out = g_io_err.c_str();
+    return PANTAX_HIP_E_IO;
+}
+
+extern "C" {
+
+int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, const char **err_out) {
+    if (!path || !out) return PANTAX_HIP_E_INVALID;
+    *out = nullptr;
+    pantax_hip_gaf *g = new pantax_hip_gaf();
+    std::string e = g->mf.open(path);
+    if (e.empty()) e = parse_gaf(g->mf, g->reads, n_threads);
+    if (!e.empty()) { delete g; return io_fail(err_out, e); }
+    *out = g;
+    return 0;
+}
+int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *v) {
+    if (!gaf || !v) return PANTAX_HIP_E_INVALID;
+    const HostReads &r = gaf->reads;
+    v->n_reads = r.pstart.size(); v->n_steps = r.node_id.size();
+    v->step_off = r.step_off.data(); v->node_id = r.node_id.data(); v->pstart = r.pstart.data(); v->pend = r.pend.data();
+    v->qlen = r.qlen.data(); v->mapq = r.mapq.data(); v->flags = r.flags.data();
+    return 0;
+}
+void pantax_hip_gaf_free(pantax_hip_gaf *gaf) { delete gaf; }
+
+int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, const char **err_out) {
+    if (!path || !out) return PANTAX_HIP_E_INVALID;
+    *out = nullptr;
+    pantax_hip_graph *g = new pantax_hip_graph();
+    std::string e = format == 1 ? read_graph_bin(path, g->g) : read_gfa(path, g->g);
+    if (!e.empty()) { delete g; return io_fail(err_out, e); }
+    for (auto &n : g->g.hap_names) g->names.push_back(n.c_str());
+    *out = g;
+    return 0;
+}
+int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t *n_haps, const int64_t **node_len,
+                          const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names) {
+    if (!g) return PANTAX_HIP_E_INVALID;
+    if (n_nodes) *n_nodes = g->g.node_len.size();
+    if (n_haps) *n_haps = g->g.hap_names.size();
+    if (node_len) *node_len = g->g.node_len.data();
+    if (path_off) *path_off = g->g.path_off.data();
+    if (path_nodes) *path_nodes = g->g.path_nodes.data();
+    if (hap_names) *hap_names = g->names.data();
+    return 0;
+}
+void pantax_hip_graph_free(pantax_hip_graph *g) { delete g; }
+
+}  // extern "C"

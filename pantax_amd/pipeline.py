@@ -70,20 +70,15 @@ class TorchComm:
         return [r for part in out for r in part]
 
 
-def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None):
-    """Returns (species_rows, strain_rows, stats) on rank 0 (empty lists elsewhere).
-    species_rows: (species_taxid, predicted_abundance, predicted_coverage) sorted descending.
-    strain_rows : (species_taxid, hap_id, predicted_coverage, predicted_abundance, path_base_cov,
-                   unique_trio_fraction, uniq_trio_cov_mean, first_sol, strain_cov_diff, total_cov_diff)."""
-    cfg = cfg or StepConfig()
-    comm = comm or LocalComm()
+def local_stage(eng, avg_len, cfg):
+    """Everything a rank computes on its own species shard (device stages + host filters)."""
     # a2 + a3 counters on device, a3 finishing on host
     _, rc, bs, lm, uq = eng.rcls_profile(want_species=False)
     keep, absolute, _ = eng.species_profiling((rc, bs, lm, uq), avg_len, filtered=cfg.filtered)
     # a7 (rebuilt per run like the reference), a8, a9..a14 for every species that survived the MAPQ
     # filter.  The -a abundance cut (profile.rs:602) needs the GLOBAL normaliser, so it is applied
-    # after the single exchange below; species are independent, so computing the few low-abundance
-    # ones too changes nothing else.
+    # after the single exchange in finalize_stage; species are independent, so computing the few
+    # low-abundance ones too changes nothing else.
     if cfg.rebuild_trio:
         eng.db_reset()
     eng.trio_nodes_info(fetch=False)
@@ -93,33 +88,51 @@ def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, sh
     solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
                        for s in range(eng.S)], dtype=np.uint8)
     passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)
-    # ---- the one cross-rank exchange: per species (absolute, sum_all, sum_pass)
-    local = np.stack([np.where(keep == 1, absolute, 0.0), s_all, s_pass], axis=1)
-    glob = comm.all_gather(local, shard_max)
-    total_abs = glob[:, 0].sum()                                    # profile.rs:341
-    g_active = (glob[:, 0] > 0) & (glob[:, 0] / total_abs > cfg.min_species_abundance)   # profile.rs:602
-    g_pass = glob[g_active, 2].sum()                                # profile.rs:3243
-    abundance = np.where(keep == 1, absolute / total_abs if total_abs > 0 else 0.0, 0.0)
-    active = (keep == 1) & (abundance > cfg.min_species_abundance)
-    strain_rows = []
+    rows = []   # candidate strain rows of this rank, before the global cut / normalisation
     for s in range(eng.S):
-        if not (active[s] and solved[s]):
+        if not solved[s]:
             continue
         for h in range(int(eng.hap_off[s]), int(eng.hap_off[s + 1])):
             if not passed[h]:
                 continue
             m = met[h]
             opt = lambda bit, v: v if m.has & bit else None
-            strain_rows.append((species_names[s], hap_names[h], m.second_sol, m.second_sol / g_pass,
-                                opt(4, m.path_cov_ratio), opt(1, m.unique_trio_nodes_fraction),
-                                opt(2, m.frequencies_mean), opt(8, m.first_sol), opt(16, m.divergence),
-                                opt(128, m.total_cov_diff)))
-    species_rows = [(species_names[s], float(abundance[s]), float(absolute[s])) for s in range(eng.S) if keep[s]]
+            rows.append((s, h, m.second_sol, opt(4, m.path_cov_ratio), opt(1, m.unique_trio_nodes_fraction),
+                         opt(2, m.frequencies_mean), opt(8, m.first_sol), opt(16, m.divergence), opt(128, m.total_cov_diff)))
+    stats = dict(n_abort=int(n_abort), iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)],
+                 n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
+                 obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)])
+    return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
+
+
+def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None):
+    """The one cross-rank exchange + the final tables (pure host code: no device, testable under gloo)."""
+    keep, absolute = local["keep"], local["absolute"]
+    loc = np.stack([np.where(keep == 1, absolute, 0.0), local["s_all"], local["s_pass"]], axis=1)
+    glob = comm.all_gather(loc, shard_max)
+    total_abs = glob[:, 0].sum()                                    # profile.rs:341
+    g_active = (glob[:, 0] > 0) & (glob[:, 0] / total_abs > cfg.min_species_abundance)   # profile.rs:602
+    g_pass = glob[g_active, 2].sum()                                # profile.rs:3243
+    abundance = np.where(keep == 1, absolute / total_abs if total_abs > 0 else 0.0, 0.0)
+    active = (keep == 1) & (abundance > cfg.min_species_abundance)
+    strain_rows = [(species_names[s], hap_names[h], cov, cov / g_pass) + tuple(rest)
+                   for (s, h, cov, *rest) in local["rows"] if active[s]]
+    species_rows = [(species_names[s], float(abundance[s]), float(absolute[s])) for s in range(len(keep)) if keep[s]]
     species_rows = comm.gather_rows(species_rows)
     strain_rows = comm.gather_rows(strain_rows)
     species_rows.sort(key=lambda r: -r[1])     # profile.rs:344
     strain_rows.sort(key=lambda r: -r[3])      # profile.rs:3247-3248
-    stats = dict(n_abort=int(n_abort), iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)],
-                 n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
-                 obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)], n_active=int(active.sum()))
+    return species_rows, strain_rows, int(active.sum())
+
+
+def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None):
+    """Returns (species_rows, strain_rows, stats) on rank 0 (empty lists elsewhere).
+    species_rows: (species_taxid, predicted_abundance, predicted_coverage) sorted descending.
+    strain_rows : (species_taxid, hap_id, predicted_coverage, predicted_abundance, path_base_cov,
+                   unique_trio_fraction, uniq_trio_cov_mean, first_sol, strain_cov_diff, total_cov_diff)."""
+    cfg = cfg or StepConfig()
+    comm = comm or LocalComm()
+    local = local_stage(eng, avg_len, cfg)
+    species_rows, strain_rows, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max)
+    stats = dict(local["stats"], n_active=n_active)
     return species_rows, strain_rows, stats

@@ -1,0 +1,59 @@
+"""CPU test of the N>1 path: two gloo processes run finalize_stage (the one all-reduce + row gather of
+pantax_amd.pipeline) on per-rank shards; the result must equal a single process holding both shards."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_finalize_matches_single_process(tmp_path):
+    from pantax_amd.pipeline import LocalComm, StepConfig, finalize_stage
+    from tests.dist_worker import fake_local, names
+    out = tmp_path / "dist.json"
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    got = json.load(open(out))
+    # single process with both shards concatenated
+    n_species = [4, 6]
+    loc = [fake_local(r, n) for r, n in enumerate(n_species)]
+    sn, hn = [], []
+    rows = []
+    s_off = h_off = 0
+    for r, n in enumerate(n_species):
+        a, b = names(r, n)
+        sn += a
+        hn += b
+        rows += [(s + s_off, h + h_off) + tuple(rest) for (s, h, *rest) in loc[r]["rows"]]
+        s_off += n
+        h_off += 3 * n
+    merged = dict(keep=np.concatenate([l["keep"] for l in loc]), absolute=np.concatenate([l["absolute"] for l in loc]),
+                  s_all=np.concatenate([l["s_all"] for l in loc]), s_pass=np.concatenate([l["s_pass"] for l in loc]), rows=rows)
+    exp_species, exp_strain, _ = finalize_stage(merged, sn, hn, StepConfig(), LocalComm())
+    assert [r[0] for r in got["species"]] == [r[0] for r in exp_species]
+    assert [(r[0], r[1]) for r in got["strain"]] == [(r[0], r[1]) for r in exp_strain]
+    for g, e in zip(got["species"], exp_species):
+        assert g[1] == pytest.approx(e[1], rel=1e-12) and g[2] == pytest.approx(e[2], rel=1e-12)
+    for g, e in zip(got["strain"], exp_strain):
+        assert g[2] == pytest.approx(e[2], rel=1e-12) and g[3] == pytest.approx(e[3], rel=1e-12)
+    assert sum(r[3] for r in got["strain"]) == pytest.approx(1.0, rel=1e-12)
+    # the species under the -a cut contributes no strain rows on either side
+    assert not any(r[0] == "sp1_0" for r in got["strain"])

@@ -1,0 +1,80 @@
+"""CPU tests of the host readers behind the pipeline seam (a1 GAF tokenizer, a6 graph loaders).
+They run through the C ABI of libpantax_hip.so but touch no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from pantax_amd import io as pio
+from pantax_amd import synth
+
+
+@pytest.fixture(scope="module")
+def small(tmp_path_factory):
+    sset = synth.make_set(5, 2, 4, 500, 8000, adversarial_frac=0.02)
+    root = tmp_path_factory.mktemp("io")
+    synth.write_db(sset, str(root))
+    synth.write_gaf(sset.reads, str(root / "x.gaf"))
+    return sset, root
+
+
+def test_gaf_tokenizer_roundtrip(small):
+    """rcls.rs:119-146: the packed arrays reproduce the generator's arrays exactly, for any thread count."""
+    sset, root = small
+    rd = sset.reads
+    for nt in (1, 3, 8):
+        g = pio.load_gaf(root / "x.gaf", n_threads=nt)
+        assert np.array_equal(g["step_off"], rd.step_off.astype(np.uint32))
+        assert np.array_equal(g["node_id"], rd.node_id)
+        assert np.array_equal(g["pstart"], rd.pstart.astype(np.uint32)) and np.array_equal(g["pend"], rd.pend.astype(np.uint32))
+        assert np.array_equal(g["qlen"], rd.qlen.astype(np.uint32)) and np.array_equal(g["mapq"], rd.mapq.astype(np.uint8))
+        assert not g["flags"].any()
+
+
+def test_gaf_nulls_comments_and_ragged(tmp_path):
+    p = tmp_path / "y.gaf"
+    p.write_text(
+        "@HD\tVN:1.0\n"
+        "r1\t150\t0\t150\t+\t>12<7>300\t400\t3\t153\t150\t150\t60\tNM:i:0\n"
+        "r2\t150\t0\t150\t+\t*\t*\t*\t*\t*\t*\t255\n"            # unmapped: null path/len/start/end
+        "r3\t100\t0\t100\t+\t<5\t30\t20\t10\t100\t100\t*\n"       # end<start single node, null mapq
+        "\n"
+        "r4\t90\t0\t90\t+\t>8>9\t200\t0\t90\n")                   # ragged (no mapq column), no trailing newline
+    g = pio.load_gaf(p)
+    assert g["step_off"].tolist() == [0, 3, 3, 4, 6]
+    assert g["node_id"].tolist() == [12, 7, 300, 5, 8, 9]
+    assert g["pstart"].tolist() == [3, 0, 20, 0] and g["pend"].tolist() == [153, 0, 10, 90]
+    assert g["qlen"].tolist() == [150, 150, 100, 90]
+    assert g["mapq"].tolist() == [60, 255, 255, 255]
+    assert g["flags"].tolist() == [0, 1, 0, 0]
+    with pytest.raises(Exception):
+        pio.load_gaf(tmp_path / "missing.gaf")
+
+
+def test_graph_loaders_agree(small):
+    """read_gfa (profile.rs:466-545) and the bincode .bin reader (zip.rs:236-247) give the generator's graph."""
+    sset, root = small
+    for g in sset.species:
+        for fmt, path in (("gfa", root / "species_gfa" / (g.name + ".gfa")), ("bin", root / "species_graph_info" / (g.name + ".bin"))):
+            node_len, names, path_off, path_nodes = pio.load_graph(path, fmt)
+            assert np.array_equal(node_len, g.node_len) and names == g.hap_names
+            assert np.array_equal(path_off, g.path_off) and np.array_equal(path_nodes, g.path_nodes)
+
+
+def test_gfa_quirks(tmp_path):
+    """P lines (hap = field 1 up to '#', ids by \\d+), several contigs of one hap concatenated (profile.rs:540),
+    BTreeMap byte order of hap names, walks are NOT reversed by the GFA loader (profile.rs:502-534)."""
+    p = tmp_path / "g.gfa"
+    p.write_text("H\tVN:Z:1.1\nS\t1\tACGT\nS\t2\tA\nS\t3\tGG\n"
+                 "P\tzeta#1#c1\t1+,2+\t*\n"
+                 "W\tAlpha\t1\tc1\t0\t5\t<3<2\n"
+                 "P\tzeta#1#c2\t3+\t*\n"
+                 "W\tB10\t1\tc1\t0\t4\t>1\n")
+    node_len, names, path_off, path_nodes = pio.load_graph(p, "gfa")
+    assert node_len.tolist() == [4, 1, 2]
+    assert names == ["Alpha", "B10", "zeta"]
+    assert path_off.tolist() == [0, 2, 3, 6] and path_nodes.tolist() == [2, 1, 0, 0, 1, 2]
+    bad = tmp_path / "bad.gfa"
+    bad.write_text("S\t2\tAC\n")
+    with pytest.raises(Exception):
+        pio.load_graph(bad, "gfa")
