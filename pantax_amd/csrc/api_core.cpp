@@ -143,7 +143,9 @@ int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *
     PTX_TRY(upload(ctx, rd->d_mapq, r->mapq, r->n_reads));
     rd->has_flags = r->flags != nullptr;
     if (rd->has_flags) PTX_TRY(upload(ctx, rd->d_flags, r->flags, r->n_reads));
-    PTX_TRY(build_step_read(ctx, rd.get()));
+    uint32_t max_id = 0;
+    for (uint64_t i = 0; i < r->n_steps; ++i) max_id = std::max(max_id, r->node_id[i]);
+    PTX_TRY(build_step_read(ctx, rd.get(), max_id));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = rd.release();
     return 0;

@@ -185,8 +185,9 @@ struct Reads {
     DevBuf<uint8_t> d_mapq, d_flags;
     bool has_flags = false;
     DevBuf<int32_t> d_species;
-    DevBuf<uint32_t> d_step_read;    // [T] read index of every step (derived at upload)
-    DevBuf<uint4> d_read_rec;        // [R] {first step, #steps, pstart, pend} (derived at upload)
+    // locus-grouped copy of the stream the coverage kernel walks (built once per upload)
+    DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_g_orig;   // [T] node ids, [T] slot of each step, [R'] slot -> original read
+    DevBuf<uint4> d_g_read_rec;      // [R'] {first step, #steps, pstart, pend}
     bool binned = false;
 };
 
@@ -213,7 +214,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, unsigned long long *d_abort);
 int trio_index_build(Ctx *ctx, Db *db);
-int build_step_read(Ctx *ctx, Reads *rd);
+int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 
 }  // namespace ptx
 

@@ -34,6 +34,7 @@
 // 1 byte, profile.rs:776-781).
 #include <cstdlib>
 #include "common.hpp"
+#include "primitives.hpp"
 
 namespace ptx {
 
@@ -83,27 +84,69 @@ __device__ __forceinline__ long long rl_from_memory(uint32_t j, uint32_t b, cons
     return (long long)node_rec[nb + (idj - first_id)].z;
 }
 
+constexpr int COV_CHUNK = 1024;   // steps per workgroup
+constexpr int COV_WIN = 1024;     // nodes in the LDS window
+constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the chunk's first start node
+
+__device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t *s_win, uint32_t wlo, uint32_t v, long long aln) {
+    const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
+    if (off < (uint32_t)COV_WIN && aln < (1ll << 18)) atomicAdd(&s_win[off], (uint32_t)aln);   // <= 8192 steps x 2^18 < 2^32
+    else atomicAdd(&bases[v], (unsigned long long)aln);
+}
+
+// Steps arrive grouped by the locus of their read's first node (group_reads below), so a workgroup's
+// chunk of COV_CHUNK consecutive steps lands in a narrow node window: `bases` is accumulated in an LDS
+// window of COV_WIN nodes (32-bit LDS atomics) and flushed with one 64-bit global atomic per touched
+// node -- the LDS-staged segmented reduction of the scatter.  Nodes outside the window (or oversized
+// lengths) fall back to the global atomic; the result is identical either way.
 template <bool WITH_TRIO>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
-    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ node_id,
-    const int32_t *__restrict__ species, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ active,
-    const uint32_t *__restrict__ sp_first_id, const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec,
-    unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node,
-    const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort) {
+    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ orig_read,
+    const uint32_t *__restrict__ node_id, const int32_t *__restrict__ species, const uint8_t *__restrict__ flags,
+    const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id, const uint32_t *__restrict__ node_base,
+    const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap,
+    const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
+    unsigned long long *__restrict__ n_abort) {
+    __shared__ uint32_t s_win[COV_WIN];
+    __shared__ uint32_t s_wlo;
     const int lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * COV_BLOCK;
-    for (uint64_t base = (uint64_t)blockIdx.x * COV_BLOCK + (threadIdx.x - lane); base < T; base += stride) {
+    const uint64_t chunk_b = (uint64_t)blockIdx.x * COV_CHUNK;
+    uint64_t chunk_e = chunk_b + COV_CHUNK;
+    if (chunk_e > T) chunk_e = T;
+    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
+    // window base = global node index of the first node of the first LIVE read of the chunk
+    if (threadIdx.x == 0) {
+        uint32_t w = 0;
+        for (uint64_t t0 = chunk_b; t0 < chunk_e;) {
+            const uint32_t slot = step_read[t0];
+            const uint4 rr = read_rec[slot];
+            const uint32_t o = orig_read[slot];
+            const int sp0 = species[o];
+            if (sp0 >= 0 && !(active && !active[sp0]) && !(flags && flags[o])) {
+                const uint32_t id0 = node_id[rr.x], f0 = sp_first_id[sp0];
+                const uint32_t v0 = node_base[sp0] + (id0 >= f0 ? id0 - f0 : 0u);
+                w = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
+                break;
+            }
+            t0 = (uint64_t)rr.x + rr.y;   // next read
+        }
+        s_wlo = w;
+    }
+    __syncthreads();
+    const uint32_t wlo = s_wlo;
+    for (uint64_t base = chunk_b + (threadIdx.x - lane); base < chunk_e; base += COV_BLOCK) {
         const uint64_t t = base + lane;
-        bool ok = t < T;
+        bool ok = t < chunk_e;
         uint32_t b = 0, k = 0, i = 0, id = 0, l = 0, v = 0, first_id = 0, nb = 0;
         long long ps = 0, pe = 0, nl = 0;
         uint64_t bo = 0;
         if (ok) {
-            const uint32_t r = step_read[t];
-            const int sp = species[r];
-            ok = sp >= 0 && !(active && !active[sp]) && !(flags && flags[r]);
+            const uint32_t slot = step_read[t];
+            const uint32_t o = orig_read[slot];
+            const int sp = species[o];
+            ok = sp >= 0 && !(active && !active[sp]) && !(flags && flags[o]);   // "U" / unselected species / dropped rows
             if (ok) {
-                const uint4 rr = read_rec[r];
+                const uint4 rr = read_rec[slot];
                 b = rr.x; k = rr.y; ps = rr.z; pe = rr.w;
                 i = (uint32_t)(t - b);
                 id = node_id[t];
@@ -126,7 +169,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         const long long target = pe - ps;                         // profile.rs:800
         if (ok && k == 1) {                                       // :811
             if (target >= 0) {                                    // :821-827
-                if (target) atomicAdd(&bases[v], (unsigned long long)target);
+                if (target) add_bases(bases, s_win, wlo, v, target);
                 if (ps < pe && pe <= nl) bitmap_or_range(bitmap, bo + ps, bo + pe);   // :832
             }
             ok = false;
@@ -173,7 +216,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             bitmap_or_range(bitmap, bo + sidx, bo + hi);
             if (jf < 0) {
                 rl = aln;
-                if (aln) atomicAdd(&bases[v], (unsigned long long)aln);   // :881
+                if (aln) add_bases(bases, s_win, wlo, v, aln);            // :881
             } else rl = (jf == 0) ? (len0 - ps) : nl;
         }
         if (WITH_TRIO) {                                          // :890-907
@@ -192,26 +235,70 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             }
         }
     }
-}
-
-// derived per-read / per-step indices of the packed stream, built once per upload
-__global__ void __launch_bounds__(256) read_index_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ pstart,
-                                                         const uint32_t *__restrict__ pend, uint4 *__restrict__ read_rec,
-                                                         uint32_t *__restrict__ step_read) {
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
-        const uint32_t b = step_off[r], e = step_off[r + 1];
-        read_rec[r] = make_uint4(b, e - b, pstart[r], pend[r]);
-        for (uint32_t q = b; q < e; ++q) step_read[q] = (uint32_t)r;
+    __syncthreads();
+    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
+        const uint32_t c = s_win[i];
+        if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
     }
 }
 
-int build_step_read(Ctx *ctx, Reads *rd) {
-    PTX_HIP(ctx, rd->d_step_read.alloc(rd->T));
-    PTX_HIP(ctx, rd->d_read_rec.alloc(rd->R));
-    if (rd->R == 0) return 0;
-    hipLaunchKernelGGL(read_index_kernel, dim3(grid_for(rd->R, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p,
-                       rd->d_pstart.p, rd->d_pend.p, rd->d_read_rec.p, rd->d_step_read.p);
+// ---------------------------------------------------------------------------------------------
+// Resident layout of the packed reads: grouped by the locus of their first node.  Key = first node
+// id >> shift (ids are globally ordered by species and position, sort_range.rs:25-33), counting sort
+// (histogram -> exclusive scans over reads and steps -> scatter) into {read_rec, orig_read, node_id,
+// step_read}.  Done once per upload: it depends on the reads only, not on the binning.  Slot order
+// inside a bucket is arbitrary; every output of the path is an order-independent integer sum, so
+// results stay bit-exact.  Reads with an empty walk own no step and are left out (profile.rs:794-796).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) group_count_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+                                                          int shift, uint32_t *__restrict__ cnt_r, uint32_t *__restrict__ cnt_s) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = step_off[r], k = step_off[r + 1] - b;
+        if (!k) continue;
+        const uint32_t key = node_id[b] >> shift;
+        atomicAdd(&cnt_r[key], 1u);
+        atomicAdd(&cnt_s[key], k);
+    }
+}
+__global__ void __launch_bounds__(256) group_scatter_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+                                                            const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, int shift,
+                                                            const uint32_t *__restrict__ base_r, const uint32_t *__restrict__ base_s,
+                                                            uint32_t *__restrict__ cur_r, uint32_t *__restrict__ cur_s,
+                                                            uint4 *__restrict__ g_read_rec, uint32_t *__restrict__ g_orig,
+                                                            uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = step_off[r], k = step_off[r + 1] - b;
+        if (!k) continue;
+        const uint32_t key = node_id[b] >> shift;
+        const uint32_t slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
+        const uint32_t sb = base_s[key] + atomicAdd(&cur_s[key], k);
+        g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
+        g_orig[slot] = (uint32_t)r;
+        for (uint32_t i = 0; i < k; ++i) { g_node_id[sb + i] = node_id[b + i]; g_step_read[sb + i] = slot; }
+    }
+}
+
+int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
+    if (rd->R == 0 || rd->T == 0) return 0;
+    int shift = 5;
+    while (((uint64_t)max_node_id >> shift) + 1 > (1u << 20)) ++shift;
+    const uint32_t NB = (uint32_t)(max_node_id >> shift) + 1;
+    DevBuf<uint32_t> cnt, scan_tmp;
+    PTX_HIP(ctx, cnt.alloc(4ull * NB + 8));
+    uint32_t *cnt_r = cnt.p, *cnt_s = cnt_r + NB, *base_r = cnt_s + NB, *base_s = base_r + NB;
+    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB)));
+    PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R)); PTX_HIP(ctx, rd->d_g_orig.alloc(rd->R));
+    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T));
+    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, 2ull * NB * sizeof(uint32_t), ctx->stream));
+    int gridR = grid_for(rd->R, 256, ctx->n_cu * 8);
+    hipLaunchKernelGGL(group_count_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, cnt_r, cnt_s);
+    PTX_TRY(exclusive_scan_u32(ctx, cnt_r, base_r, NB, scan_tmp.p, nullptr));
+    PTX_TRY(exclusive_scan_u32(ctx, cnt_s, base_s, NB, scan_tmp.p, nullptr));
+    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, 2ull * NB * sizeof(uint32_t), ctx->stream));   // reused as cursors
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
+                       rd->d_pend.p, shift, base_r, base_s, cnt_r, cnt_s, rd->d_g_read_rec.p, rd->d_g_orig.p, rd->d_g_node_id.p, rd->d_g_step_read.p);
     PTX_HIP(ctx, hipGetLastError());
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // cnt / scan_tmp are released on return
     return 0;
 }
 
@@ -248,12 +335,12 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         PTX_HIP(ctx, db->d_trio_bases.alloc(db->U));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_bases.p, 0, (db->U ? db->U : 1) * sizeof(unsigned long long), ctx->stream));
     }
-    if (rd->T) {
-        int grid = grid_for(rd->T, COV_BLOCK, ctx->n_cu * 16);
+    if (rd->R && rd->T) {
+        int grid = (int)((rd->T + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
-#define COVS_ARGS rd->T, rd->d_step_read.p, rd->d_read_rec.p, rd->d_node_id.p, rd->d_species.p, rd->has_flags ? rd->d_flags.p : nullptr, \
-                  d_active, db->d_sp_first_id.p, db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p,      \
-                  db->d_trio_ent.p, db->d_trio_bases.p, d_abort
+#define COVS_ARGS rd->T, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_orig.p, rd->d_g_node_id.p, rd->d_species.p,                    \
+                  rd->has_flags ? rd->d_flags.p : nullptr, d_active, db->d_sp_first_id.p, db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, \
+                  db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort
         if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
         else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
 #undef COVS_ARGS
