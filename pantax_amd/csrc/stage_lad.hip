@@ -69,6 +69,34 @@ __device__ __forceinline__ uint32_t upper_bound_a(const double *__restrict__ a, 
     while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (a[m] <= v) lo = m + 1; else hi = m; }
     return lo;
 }
+// 64-ary searches by a whole wave64 (all lanes pass the same arguments, all get the result): each
+// round probes 64 evenly spaced elements with one gather and narrows the range ~65x by a ballot, so a
+// search over 10^5 rows costs 3 dependent memory round trips instead of 17.
+__device__ __forceinline__ uint32_t wave_bound(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v, bool upper) {
+    const uint32_t lane = threadIdx.x & 63;
+    while (hi - lo > 64) {
+        const uint32_t m = hi - lo;
+        const uint32_t pj = lo + (uint32_t)(((uint64_t)(lane + 1) * m) / 65);
+        const double x = a[pj];
+        const bool before = upper ? (x <= v) : (x < v);
+        const int c = __popcll(__ballot(before));
+        const uint32_t nlo = c > 0 ? lo + (uint32_t)(((uint64_t)c * m) / 65) + 1 : lo;
+        const uint32_t nhi = c < 64 ? lo + (uint32_t)(((uint64_t)(c + 1) * m) / 65) : hi;
+        lo = nlo; hi = nhi;
+    }
+    bool before = false;
+    if (lo + lane < hi) { const double x = a[lo + lane]; before = upper ? (x <= v) : (x < v); }
+    return lo + (uint32_t)__popcll(__ballot(before));
+}
+template <bool COOP>
+__device__ __forceinline__ uint32_t lb(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    return COOP ? wave_bound(a, lo, hi, v, false) : lower_bound_a(a, lo, hi, v);
+}
+template <bool COOP>
+__device__ __forceinline__ uint32_t ub_(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    return COOP ? wave_bound(a, lo, hi, v, true) : upper_bound_a(a, lo, hi, v);
+}
+
 __device__ __forceinline__ double mdot(uint64_t m, const double *x) {   // ascending-bit order
     double s = 0.0;
     while (m) { int j = __ffsll((long long)m) - 1; s += x[j]; m &= m - 1; }
@@ -422,19 +450,24 @@ struct LadShared {
 };
 
 // number of breakpoints of pattern k crossed when moving t along the search direction
+template <bool COOP>
 __device__ __forceinline__ uint32_t crossed(const double *__restrict__ a, double rho, double s0, double eps, uint32_t st, uint32_t en,
                                             uint32_t lo, uint32_t up, double t, uint32_t c_lo, uint32_t c_hi) {
     double sv = s0 - eps + t * rho;
-    if (rho > 0) return upper_bound_a(a, up + c_lo, up + c_hi, sv) - up;       // rows a_i <= sv among [up,en)
-    return lo - lower_bound_a(a, lo - c_hi, lo - c_lo, sv);                    // rows a_i >= sv among [st,lo)
+    if (rho > 0) return ub_<COOP>(a, up + c_lo, up + c_hi, sv) - up;           // rows a_i <= sv among [up,en)
+    return lo - lb<COOP>(a, lo - c_hi, lo - c_lo, sv);                         // rows a_i >= sv among [st,lo)
 }
 
-template <int PS>
+// COOP = few patterns: every wave owns whole patterns (its 64 lanes search cooperatively, lane 0 is the
+// "leader" that accumulates and stores); otherwise one thread per pattern with scalar binary searches.
+#define PAT_LOOP(k) for (uint32_t k = k0 + (COOP ? (uint32_t)(tid >> 6) : (uint32_t)tid); k < k1; k += (COOP ? LAD_BLOCK / 64 : LAD_BLOCK))
+template <int PS, bool COOP>
 __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     __shared__ LadShared sh;
     __shared__ double W[PS * PS];
     __shared__ double G[PS * 2 * PS];
     const int tid = threadIdx.x;
+    const bool leader = COOP ? ((tid & 63) == 0) : true;
     const int s = A.solve_list[blockIdx.x];
     const int p = A.sp_p[s];
     const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
@@ -442,8 +475,8 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     const double tol = 1e-7;
     const double amax = A.amax[s];
     const double delta = 1e-10 * (amax > 1.0 ? amax : 1.0);
-    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK)
-        A.pat_eps[k] = delta * (0.25 + 0.5 * (double)(splitmix64(A.pat_mask[k]) >> 11) * (1.0 / 9007199254740992.0));
+    for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK)
+        A.pat_eps[kk] = delta * (0.25 + 0.5 * (double)(splitmix64(A.pat_mask[kk]) >> 11) * (1.0 / 9007199254740992.0));
     if (tid < p) {
         double u = A.ub[(size_t)s * LAD_MAXP + tid];
         sh.ub[tid] = u;
@@ -471,7 +504,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         }
         __syncthreads();
         // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
-        for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+        PAT_LOOP(k) {
             uint64_t mk = A.pat_mask[k];
             uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
             int ai = -1;
@@ -481,12 +514,12 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             else {
                 sk = mdot(mk, sh.x);
                 double sv = sk - A.pat_eps[k];
-                lo = lower_bound_a(ra, st, en, sv);
-                up = upper_bound_a(ra, lo, en, sv);
+                lo = lb<COOP>(ra, st, en, sv);
+                up = ub_<COOP>(ra, lo, en, sv);
             }
             A.sc_s[k] = sk; A.sc_lo[k] = lo; A.sc_up[k] = up;
             long long sigma = (long long)(lo - st) - (long long)(en - up);
-            if (sigma) {
+            if (sigma && leader) {
                 uint64_t m = mk;
                 while (m) { int j = __ffsll((long long)m) - 1; m &= m - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
             }
@@ -529,13 +562,13 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         }
         // ---- line search set-up: rate rho_k of every pattern along d
         double part = 0.0;
-        for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+        PAT_LOOP(k) {
             uint64_t mk = A.pat_mask[k];
             int ai = -1;
             for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
             double rho;
             if (ai >= 0) rho = (ai == best) ? bdir : 0.0;   // other tight patterns stay tight: n_i . d = 0
-            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; part += fabs(rho) * (double)(A.sc_up[k] - A.sc_lo[k]); }
+            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(A.sc_up[k] - A.sc_lo[k]); }
             A.sc_rho[k] = rho;
             A.ls_lo[k] = 0;
             A.ls_hi[k] = rho > 0 ? A.pat_start[k + 1] - A.sc_up[k] : rho < 0 ? A.sc_lo[k] - A.pat_start[k] : 0;
@@ -547,7 +580,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         if (S0 >= -tol) {
             // degenerate: an unsplit tie group blocks the move at t = 0 -> it enters (step length 0)
             double tb = INFINITY; int kb = 0x7fffffff;
-            for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK)
+            PAT_LOOP(k)
                 if (A.sc_rho[k] != 0.0 && A.sc_up[k] > A.sc_lo[k]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { int k2 = __shfl_down(kb, off); if (k2 < kb) kb = k2; }
@@ -568,14 +601,14 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             bool bound_enters = false;
             for (int grow = 0; grow < 200; ++grow) {
                 double acc = 0.0;
-                for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                PAT_LOOP(k) {
                     double rho = A.sc_rho[k];
                     if (rho == 0.0) continue;
                     uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
                     uint32_t cmax = rho > 0 ? en - A.sc_up[k] : A.sc_lo[k] - st;
-                    uint32_t c = crossed(ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
+                    uint32_t c = crossed<COOP>(ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
                     A.ls_hi[k] = c;
-                    acc += fabs(rho) * 2.0 * (double)c;
+                    if (leader) acc += fabs(rho) * 2.0 * (double)c;
                 }
                 S_hi = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
                 if (S_hi >= -tol) break;
@@ -598,11 +631,11 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 unsigned long long prev_cand = ~0ull; int stall = 0;
                 for (int bi = 0; bi < 200; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
-                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                    PAT_LOOP(k) {
                         double rho = A.sc_rho[k];
                         uint32_t cl = A.ls_lo[k], ch = A.ls_hi[k];
                         if (rho == 0.0 || ch <= cl) continue;
-                        cand += ch - cl;
+                        if (leader) cand += ch - cl;
                         double w = fabs(rho) * (double)(ch - cl);
                         if (w > wbest) {
                             uint32_t m = cl + (ch - cl) / 2;   // m-th breakpoint ahead (0-based) of this pattern
@@ -613,10 +646,10 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     }
                     cand = (unsigned long long)block_sum_f64<LAD_BLOCK>((double)cand, sh.red);
                     if (cand <= 8) break;
-                    // two rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
+                    // three rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
                     stall = (cand == prev_cand) ? stall + 1 : 0;
                     prev_cand = cand;
-                    if (stall >= 2) break;
+                    if (stall >= 3) break;
                     // heaviest proposal: max over the block (ties -> smaller t)
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) {
@@ -628,20 +661,26 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     double bw = sh.red[0], bt = sh.red_t[0];
                     for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red[w] > bw || (sh.red[w] == bw && sh.red_t[w] < bt)) { bw = sh.red[w]; bt = sh.red_t[w]; }
                     __syncthreads();
-                    double t_mid = (bi & 1) ? 0.5 * (t_lo + t_hi) : bt;
-                    if (!(t_mid >= t_lo && t_mid <= t_hi)) t_mid = 0.5 * (t_lo + t_hi);
+                    double t_mid;
+                    const int mode = bi % 3;   // 0: heaviest pattern's median breakpoint, 1: secant on the slope, 2: midpoint
+                    if (mode == 0) { t_mid = bt; if (!(t_mid >= t_lo && t_mid <= t_hi)) t_mid = 0.5 * (t_lo + t_hi); }
+                    else {
+                        const double den = S_hi - S_lo;
+                        t_mid = (mode == 1 && den > 0.0) ? t_lo + (t_hi - t_lo) * (-S_lo / den) : 0.5 * (t_lo + t_hi);
+                        if (!(t_mid > t_lo && t_mid < t_hi)) t_mid = 0.5 * (t_lo + t_hi);
+                    }
                     double acc = 0.0;
-                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                    PAT_LOOP(k) {
                         double rho = A.sc_rho[k];
                         if (rho == 0.0) continue;
-                        uint32_t c = crossed(ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
+                        uint32_t c = crossed<COOP>(ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
                                              t_mid, A.ls_lo[k], A.ls_hi[k]);
                         A.ls_mid[k] = c;
-                        acc += fabs(rho) * 2.0 * (double)c;
+                        if (leader) acc += fabs(rho) * 2.0 * (double)c;
                     }
                     double S_mid = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
                     bool go_hi = S_mid >= -tol;
-                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                    PAT_LOOP(k) {
                         if (A.sc_rho[k] == 0.0) continue;
                         if (go_hi) A.ls_hi[k] = A.ls_mid[k]; else A.ls_lo[k] = A.ls_mid[k];
                     }
@@ -653,7 +692,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 // ---- walk the few remaining breakpoint groups in order of t
                 for (int step = 0; step < 4096; ++step) {
                     double tb = INFINITY; int kb = 0x7fffffff;
-                    for (uint32_t k = k0 + tid; k < k1; k += LAD_BLOCK) {
+                    PAT_LOOP(k) {
                         double rho = A.sc_rho[k];
                         if (rho == 0.0 || A.ls_hi[k] <= A.ls_lo[k]) continue;
                         uint32_t r = rho > 0 ? A.sc_up[k] + A.ls_lo[k] : A.sc_lo[k] - 1 - A.ls_lo[k];
@@ -805,8 +844,12 @@ int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int
     A.solve_list = lb->d_solve_list.p;
     {
         KTimer t(ctx, "lad_solve_kernel");
-        if (pmax <= 16) hipLaunchKernelGGL((lad_solve_kernel<16>), dim3((uint32_t)solve_list.size()), dim3(LAD_BLOCK), 0, ctx->stream, A);
-        else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP>), dim3((uint32_t)solve_list.size()), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        uint32_t kmax = 0;
+        for (int32_t sp : solve_list) kmax = std::max(kmax, lb->h_sp_pat_off[sp + 1] - lb->h_sp_pat_off[sp]);
+        const bool coop = kmax <= 16;   // few patterns: one wave per pattern with 64-ary cooperative searches
+        dim3 g((uint32_t)solve_list.size()), b(LAD_BLOCK);
+        if (pmax <= 16) { if (coop) hipLaunchKernelGGL((lad_solve_kernel<16, true>), g, b, 0, ctx->stream, A); else hipLaunchKernelGGL((lad_solve_kernel<16, false>), g, b, 0, ctx->stream, A); }
+        else { if (coop) hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, true>), g, b, 0, ctx->stream, A); else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, false>), g, b, 0, ctx->stream, A); }
     }
     {
         KTimer t(ctx, "objective_kernel");
