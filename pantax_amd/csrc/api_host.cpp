@@ -20,11 +20,12 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
     int64_t first_len = -1;
     bool equal = true;
     uint64_t seen = 0;
-    const uint64_t CH = 1 << 16;
-    std::vector<int32_t> sp(CH);
-    std::vector<uint32_t> ql(CH);
-    for (uint64_t off = 0; off < reads->R && seen < 1000; off += CH) {
+    uint64_t CH = 2048;   // 1000 non-"U" rows are normally inside the first chunk; grow geometrically otherwise
+    std::vector<int32_t> sp;
+    std::vector<uint32_t> ql;
+    for (uint64_t off = 0; off < reads->R && seen < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
         uint64_t n = std::min<uint64_t>(CH, reads->R - off);
+        sp.resize(n); ql.resize(n);
         PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
         PTX_TRY(download(ctx, ql.data(), reads->d_qlen.p + off, n));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -173,6 +173,7 @@ struct Db {
     LadBatch lad;
     DevBuf<uint32_t> d_hap_nnz;              // [H]
     DevBuf<double> d_hap_mean;               // [H]
+    DevBuf<double> d_hap_part, d_hap_mean_sd; // two-level reduction scratch of the per-hap trio statistics
     // LP-row staging (lad_prepare)
     DevBuf<uint8_t> d_row_flag, d_pat_head;
     DevBuf<uint32_t> d_row_pos, d_pat_idx, d_scan_tmp, d_sort_table, d_tot2;

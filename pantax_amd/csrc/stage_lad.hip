@@ -113,51 +113,61 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // a9: per-hap unique-trio statistics.  One workgroup per haplotype; three passes over its rows
 // (they are contiguous because trio rows are ordered (species, hap, position)).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) hap_trio_stats_kernel(const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
-                                                             const uint32_t *__restrict__ tlen, uint32_t *__restrict__ nnz_out,
-                                                             double *__restrict__ mean_out) {
+constexpr int HAP_CHUNKS = 32;   // workgroups per haplotype; partials are combined in fixed order
+struct HapPartial { double a, b; unsigned long long c; };
+
+// pass = 0: (sum, -, count) of non-zero abundances; 1: (sum of squared deviations); 2: (sum, -, count) of |z|<3
+__global__ void __launch_bounds__(256) hap_trio_pass_kernel(int pass, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
+                                                            const uint32_t *__restrict__ tlen, const double *__restrict__ mean_sd,
+                                                            HapPartial *__restrict__ part) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
-    const uint32_t h = blockIdx.x;
+    const uint32_t h = blockIdx.x / HAP_CHUNKS, ch = blockIdx.x % HAP_CHUNKS;
     const uint64_t b = hto[h], e = hto[h + 1];
-    double sum = 0.0; unsigned long long cnt = 0;
-    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-        double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
-        if (x > 0.0) { sum += x; ++cnt; }                       // :1129-1133
-    }
-    sum = block_sum_f64<256>(sum, red);
+    const uint64_t per = (e - b + HAP_CHUNKS - 1) / HAP_CHUNKS;
+    uint64_t lo = b + ch * per, hi = lo + per;
+    if (hi > e) hi = e;
+    const double mean = pass ? mean_sd[2 * h] : 0.0, sd = pass == 2 ? mean_sd[2 * h + 1] : 0.0;
+    double acc = 0.0; unsigned long long cnt = 0;
+    if (!(pass == 2 && sd == 0.0))
+        for (uint64_t u = lo + threadIdx.x; u < hi; u += 256) {
+            double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
+            if (!(x > 0.0)) continue;                                // :1129-1133
+            if (pass == 0) { acc += x; ++cnt; }
+            else if (pass == 1) acc += (x - mean) * (x - mean);
+            else if (fabs((x - mean) / sd) < 3.0) { acc += x; ++cnt; }   // :1047-1050
+        }
+    acc = block_sum_f64<256>(acc, red);
     cnt = block_sum_u64<256>(cnt, redu);
-    double meanf = 0.0;
-    if (cnt > 0) {
-        double mean = sum / (double)cnt;                         // :1037
-        double ss = 0.0;
-        for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-            double x = (double)(long long)tb[u] / (double)tlen[u];
-            if (x > 0.0) ss += (x - mean) * (x - mean);
-        }
-        ss = block_sum_f64<256>(ss, red);
-        double sd = sqrt(ss / (double)cnt);                      // :1038-1041 population std
-        if (sd != 0.0) {                                         // :1043-1045 std == 0 -> empty -> mean 0.0
-            double fs = 0.0; unsigned long long fc = 0;
-            for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-                double x = (double)(long long)tb[u] / (double)tlen[u];
-                if (x > 0.0 && fabs((x - mean) / sd) < 3.0) { fs += x; ++fc; }   // :1047-1050
-            }
-            fs = block_sum_f64<256>(fs, red);
-            fc = block_sum_u64<256>(fc, redu);
-            if (fc) meanf = fs / (double)fc;
-        }
-    }
-    if (threadIdx.x == 0) { nnz_out[h] = (uint32_t)cnt; mean_out[h] = meanf; }
+    if (threadIdx.x == 0) part[blockIdx.x] = {acc, 0.0, cnt};
+}
+// combines the chunk partials of one pass: pass 0 -> mean (+count), pass 1 -> sd, pass 2 -> filtered mean
+__global__ void __launch_bounds__(64) hap_trio_combine_kernel(int pass, uint32_t H, const HapPartial *__restrict__ part, double *__restrict__ mean_sd,
+                                                              uint32_t *__restrict__ nnz_out, double *__restrict__ mean_out) {
+    uint32_t h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    double acc = 0.0; unsigned long long cnt = 0;
+    for (int c = 0; c < HAP_CHUNKS; ++c) { acc += part[(size_t)h * HAP_CHUNKS + c].a; cnt += part[(size_t)h * HAP_CHUNKS + c].c; }
+    if (pass == 0) { nnz_out[h] = (uint32_t)cnt; mean_sd[2 * h] = cnt ? acc / (double)cnt : 0.0; mean_out[h] = 0.0; }   // :1037
+    else if (pass == 1) { double n = (double)nnz_out[h]; mean_sd[2 * h + 1] = n > 0 ? sqrt(acc / n) : 0.0; }              // :1038-1041
+    else mean_out[h] = cnt ? acc / (double)cnt : 0.0;   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
 }
 
 int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBuf<double> &d_mean) {
     PTX_HIP(ctx, d_nnz.alloc(db->H));
     PTX_HIP(ctx, d_mean.alloc(db->H));
     if (db->H == 0) return 0;
+    Db *dbm = const_cast<Db *>(db);
+    const uint32_t H = (uint32_t)db->H;
+    PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)H * HAP_CHUNKS * 3));
+    PTX_HIP(ctx, dbm->d_hap_mean_sd.alloc((size_t)H * 2));
     KTimer t(ctx, "hap_trio_stats_kernel");
-    hipLaunchKernelGGL(hap_trio_stats_kernel, dim3((uint32_t)db->H), dim3(256), 0, ctx->stream, db->d_hap_trio_off.p, db->d_trio_bases.p,
-                       db->d_trio_len.p, d_nnz.p, d_mean.p);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(hap_trio_pass_kernel, dim3(H * HAP_CHUNKS), dim3(256), 0, ctx->stream, pass, db->d_hap_trio_off.p, db->d_trio_bases.p,
+                           db->d_trio_len.p, dbm->d_hap_mean_sd.p, (HapPartial *)dbm->d_hap_part.p);
+        hipLaunchKernelGGL(hap_trio_combine_kernel, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, pass, H, (const HapPartial *)dbm->d_hap_part.p,
+                           dbm->d_hap_mean_sd.p, d_nnz.p, d_mean.p);
+    }
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -313,6 +323,18 @@ __global__ void __launch_bounds__(256) pat_emit_kernel(uint64_t n, const uint64_
     }
 }
 
+// species -> first pattern (patterns are sorted by species); entry S = K; also closes pat_start[K] = n_rows
+__global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint32_t *__restrict__ d_K, const uint32_t *__restrict__ pat_species,
+                                                         uint32_t n_rows, uint32_t *__restrict__ pat_start, uint32_t *__restrict__ sp_pat_off) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s > S) return;
+    const uint32_t K = *d_K;
+    uint32_t lo = 0, hi = K;   // first pattern with species >= s
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (pat_species[m] < s) lo = m + 1; else hi = m; }
+    sp_pat_off[s] = (s == S) ? K : lo;
+    if (s == S) pat_start[K] = n_rows;
+}
+
 int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     const uint32_t S = db->S;
     const uint64_t V = db->V, P = db->P, H = db->H;
@@ -385,32 +407,22 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     int gridN = grid_for(n_rows, 256, ctx->n_cu * 8);
     hipLaunchKernelGGL(pat_flag_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p);
     PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, n_rows, scan_tmp.p, d_tot.p + 1));
-    uint32_t K = 0;
-    PTX_TRY(download(ctx, &K, d_tot.p + 1, 1));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    lb->K = K;
-    PTX_HIP(ctx, lb->d_pat_mask.alloc(K)); PTX_HIP(ctx, lb->d_pat_start.alloc(K + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(K));
+    // #patterns K <= n_rows: size the pattern arrays for the bound so that K need not be read back first
+    PTX_HIP(ctx, lb->d_pat_mask.alloc(n_rows)); PTX_HIP(ctx, lb->d_pat_start.alloc((size_t)n_rows + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(n_rows));
     hipLaunchKernelGGL(pat_emit_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p, pidx.p,
                        lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p);
-    PTX_HIP(ctx, hipMemcpyAsync(lb->d_pat_start.p + K, &lb->n_rows, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
+    hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_tot.p + 1, lb->d_pat_species.p, n_rows,
+                       lb->d_pat_start.p, lb->d_sp_pat_off.p);
     PTX_HIP(ctx, lb->d_row_a.alloc(n_rows));
     PTX_HIP(ctx, hipMemcpyAsync(lb->d_row_a.p, Sd.k[2], (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    std::vector<uint32_t> pat_species(K);
-    PTX_TRY(download(ctx, pat_species.data(), lb->d_pat_species.p, K));
+    PTX_TRY(download(ctx, lb->h_sp_pat_off.data(), lb->d_sp_pat_off.p, S + 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    {   // species -> pattern range (patterns are sorted by species)
-        uint32_t j = 0;
-        for (uint32_t s = 0; s < S; ++s) {
-            lb->h_sp_pat_off[s] = j;
-            while (j < K && pat_species[j] == s) ++j;
-        }
-        lb->h_sp_pat_off[S] = j;
-    }
-    PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1));
+    const uint32_t K = lb->h_sp_pat_off[S];
+    lb->K = K;
     PTX_HIP(ctx, lb->d_pat_eps.alloc(K)); PTX_HIP(ctx, lb->d_sc_s.alloc(K)); PTX_HIP(ctx, lb->d_sc_rho.alloc(K));
     PTX_HIP(ctx, lb->d_sc_lo.alloc(K)); PTX_HIP(ctx, lb->d_sc_up.alloc(K)); PTX_HIP(ctx, lb->d_ls_lo.alloc(K)); PTX_HIP(ctx, lb->d_ls_hi.alloc(K)); PTX_HIP(ctx, lb->d_ls_mid.alloc(K));
     PTX_HIP(ctx, hipGetLastError());
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
