@@ -39,12 +39,11 @@ def algorithmic_bytes(sset, U):
         # a2: 4T + 4R(offsets) + 4R(out)
         "bin_reads_kernel": 4 * T + 4 * R + 4 * R,
         # a8 minus the popcount pass: 4T + 12R + 4V(node_len) + 8V(bases) + L/8(bitmap) + 12*Wr(trio probes)
-        "coverage_kernel": 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr,
+        "coverage_step_kernel": 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr,
         # a8 popcount: L/8 bitmap in + 8V cov out
         "popcount_kernel": L // 8 + 8 * V,
-        # a7: 2 x 12 x (P - 2H) (write keys, read sorted) + 12U
-        "radix_sort": 2 * 12 * max(P - 2 * H, 0) + 12 * U,
-        "trio_emit_kernel": 4 * P + 12 * max(P - 2 * H, 0),
+        # a7 bucket scatter: 4P in + 16 B record per window out
+        "trio_fill_kernel": 4 * P + 16 * max(P - 2 * H, 0),
         # a10: 4P in + 8V mask out
         "mask_kernel": 4 * P + 8 * V,
     }, dict(R=R, T=T, V=V, L=L, P=P, H=H, U=U)
@@ -86,6 +85,20 @@ def cpu_baseline(sset, sample_reads, cfg):
                 sample="first %d reads of the same workload (all %d species), oracle bin+trio+coverage+filters+2 LP solves; "
                        "%.2f s total, %.2f s of it in the exact LAD solves" % (n, len(sset.species), dt, t_lp),
                 seconds=dt)
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE,
+    separate passes, KB units -> bytes; profiles/r01_pmc_coverage.json).  Only valid for the default
+    workload the passes were collected on; None otherwise.  See the file for the gfx950 FETCH_SIZE caveat."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_coverage.json")))
+        w = d["workload"]
+        if (w["reads"], w["species"], w["haps"], w["genome_len"]) != (args.reads, args.species, args.haps, args.genome_len):
+            return None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def highs_probe(sset, cfg, max_rows=20000):
@@ -186,10 +199,10 @@ def main():
             avg_ms = tot_ms / max(launches, 1)
             bytes_per_launch = ab.get(dom)
             if bytes_per_launch is not None:
-                per = bytes_per_launch / max(launches / args.steps, 1) if dom in ("radix_sort",) else bytes_per_launch
+                per = bytes_per_launch
                 ach = per / (avg_ms * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                traffic=None, avg_ms=avg_ms, algorithmic_bytes=per)
+                                traffic=pmc_traffic(dom, args), avg_ms=avg_ms, algorithmic_bytes=per)
             else:
                 roofline = dict(bound="hbm", kernel=dom, achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, traffic=None,
                                 avg_ms=avg_ms, algorithmic_bytes=0,
