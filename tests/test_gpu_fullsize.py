@@ -1,0 +1,203 @@
+"""GPU tests at BASELINE.json sizes (cfg2: 1 species x 10 strains, 1M reads, 5 Mbp) and a multi-species set:
+direct oracle comparison where the oracle finishes in seconds, plus size-independent properties of the
+path (conservation of aligned bases, order invariance, linearity over read sets, idempotence, local
+optimality of the LP solution, normalisation)."""
+import numpy as np
+import pytest
+
+from tests.helpers import select_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pantax_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    from pantax_amd import synth
+    return synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000)
+
+
+def _expected_total_bases(sset, sp):
+    """Sum of bases_per_node over all nodes, from the read records alone (numpy, no kernel logic):
+    one-node read -> target (dropped if < 0); otherwise seen = (len0 - ps) + interior lengths and the read
+    contributes seen + max(target - seen, 0) -- minus the lengths of repeated node occurrences, which the
+    generator only produces in its adversarial records (handled read by read)."""
+    rd = sset.reads
+    so = rd.step_off.astype(np.int64)
+    k = so[1:] - so[:-1]
+    gl = np.concatenate([g.node_len for g in sset.species])
+    base = np.cumsum([0] + [g.n_nodes for g in sset.species])[:-1]
+    first = np.array([g.range_start for g in sset.species])
+    live = (sp >= 0) & (k > 0)
+    spc = np.where(sp >= 0, sp, 0)
+    step_read = np.repeat(np.arange(len(k)), k)
+    v = base[spc[step_read]] + (rd.node_id.astype(np.int64) - first[spc[step_read]])
+    v = np.where(live[step_read], v, 0)
+    ln = gl[v]
+    tot_len = np.zeros(len(k), dtype=np.int64)
+    np.add.at(tot_len, step_read, ln)
+    len0 = np.zeros(len(k), dtype=np.int64)
+    len0[k > 0] = ln[so[:-1][k > 0]]
+    lenl = np.zeros(len(k), dtype=np.int64)
+    lenl[k > 0] = ln[so[1:][k > 0] - 1]
+    target = rd.pend - rd.pstart
+    seen = tot_len - lenl - rd.pstart           # (len0 - ps) + interior, for k >= 2
+    multi = np.where(target > seen, target, seen)
+    single = np.where(target >= 0, target, 0)
+    abort = (k >= 2) & (rd.pstart > len0)
+    per_read = np.where(k == 1, single, multi)
+    per_read = np.where(live & ~abort, per_read, 0)
+    # repeated nodes: subtract the aligned length of every non-first occurrence (rare; loop)
+    rep_fix = 0
+    order = np.lexsort((v, step_read))
+    same = (step_read[order][1:] == step_read[order][:-1]) & (v[order][1:] == v[order][:-1])
+    for r in np.unique(step_read[order][1:][same]):
+        if not live[r] or abort[r] or k[r] < 2:
+            continue
+        ids = v[so[r]:so[r + 1]]
+        lens = ln[so[r]:so[r + 1]].copy()
+        lens[0] -= rd.pstart[r]
+        s_ = int(lens[:-1].sum())
+        lens[-1] = max(int(target[r]), s_) - s_
+        seen_nodes = set()
+        for j, n in enumerate(ids):
+            if n in seen_nodes:
+                rep_fix += int(lens[j])
+            seen_nodes.add(n)
+    return int(per_read.sum()) - rep_fix
+
+
+def test_cfg2_against_oracle_and_properties(eng, cfg2):
+    from oracle import oracle as orc
+    sset = cfg2
+    rd = sset.reads
+    g = sset.species[0]
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    # binning: every read is either "U" or counted once; base_sum is the qlen sum of the binned reads
+    assert rc.sum() + (sp < 0).sum() == rd.n_reads
+    assert bs.sum() == rd.qlen[sp >= 0].sum()
+    ref_sp = orc.bin_reads(rd.step_off, rd.node_id, [g.range_start], [g.range_end])
+    assert np.array_equal(sp, ref_sp)
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    # full-size oracle (finishes in < 2 s): bit-exact integers
+    G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+    T = orc.TrioTable(G)
+    so, nid, ps, pe = select_reads(rd, np.nonzero(sp == 0)[0])
+    b, c, t, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+    assert np.array_equal(bases, b) and np.array_equal(cov, c) and np.array_equal(tb, t) and nab == na
+    assert np.array_equal(abc, T.abc) and np.array_equal(ln, T.len)
+    # conservation: total aligned bases from the read records alone
+    assert int(bases.sum()) == _expected_total_bases(sset, sp)
+    assert np.all(cov <= g.node_len.astype(np.uint64))
+    # idempotence
+    bases2, cov2, tb2, _ = eng.get_node_abundances()
+    assert np.array_equal(bases, bases2) and np.array_equal(cov, cov2) and np.array_equal(tb, tb2)
+    # strain level vs oracle at full size
+    keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
+    met, info = eng.strain_profiling(absolute, species_active=keep)
+    rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+    orc.abundance_constraint(absolute[0], omet)
+    assert info[0].n_candidates == nc and info[0].status1 == 0
+    assert info[0].obj1 == pytest.approx(o1, rel=1e-9)
+    from pantax_amd.engine import metrics_to_dicts
+    for gm, em in zip(metrics_to_dicts(met, eng.H), orc.metrics_to_dicts(omet)):
+        for key, ev in em.items():
+            if ev is None or isinstance(ev, bool):
+                assert gm[key] == ev
+            else:
+                assert gm[key] == pytest.approx(ev, rel=1e-7, abs=1e-9), key
+
+
+def test_cfg2_lp_local_optimality(eng, cfg2):
+    """The solver's x is a minimiser of the LAD objective: no coordinate move inside the box lowers it
+    (convex objective => coordinate-wise + random-direction probes from the optimum cannot go down)."""
+    from oracle import oracle as orc
+    sset = cfg2
+    g = sset.species[0]
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    eng.rcls_profile(want_species=False)
+    eng.trio_nodes_info(fetch=False)
+    bases, cov, tb, _ = eng.get_node_abundances()
+    ab = bases / g.node_len
+    cand = np.arange(g.n_paths)   # all ten strains as candidates: a 10-variable LP over ~2.4e5 rows
+    x, ratio, obj, st = eng.pao_solve(g.node_len, ab, cov, g.path_off, g.path_nodes, cand)
+    assert st == 0
+    mask = np.zeros(g.n_nodes, dtype=np.uint64)
+    for kk in range(g.n_paths):
+        mask[g.path_nodes[int(g.path_off[kk]):int(g.path_off[kk + 1])]] |= np.uint64(1 << kk)
+    f0 = orc.lad_objective(mask, ab, x)
+    assert f0 == pytest.approx(obj, rel=1e-9)
+    ub = 1.05 * ab.max()
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        d = np.zeros(len(x))
+        if trial < 2 * len(x):
+            d[trial // 2] = 1.0 if trial % 2 == 0 else -1.0
+        else:
+            d = rng.normal(size=len(x))
+        for step in (1e-6, 1e-3, 0.1):
+            y = np.clip(x + step * d, 0.0, ub)
+            assert orc.lad_objective(mask, ab, y) >= f0 - 1e-9 * max(1.0, f0)
+    # the oracle's exact solver agrees on the objective
+    xo, objo, it, sto = orc.lad_solve(mask, ab, len(x), np.full(len(x), ub))
+    assert sto == 0 and obj == pytest.approx(objo, rel=1e-9)
+
+
+def test_multispecies_order_invariance_and_linearity(eng):
+    """20 species / 1M reads: the integer outputs do not depend on read order (atomics, locus grouping) and
+    are additive over a split of the read set; the bitmap count is monotone and sub-additive."""
+    from pantax_amd import synth
+    sset = synth.make_set(77, 20, 8, 1_000_000, 400_000, single_strain_every=7)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+
+    def run(sel):
+        so, nid, ps, pe = select_reads(rd, sel)
+        eng.upload_reads(so, nid, ps, pe, rd.qlen[sel], rd.mapq[sel])
+        sp, rc, bs, lm, uq = eng.rcls_profile()
+        out = eng.get_node_abundances()
+        return sp, (rc, bs, lm, uq), out
+
+    eng.trio_nodes_info(fetch=False)
+    allr = np.arange(rd.n_reads)
+    sp, cnt, (b_all, c_all, t_all, n_all) = run(allr)
+    perm = np.random.default_rng(1).permutation(rd.n_reads)
+    sp_p, cnt_p, (b_p, c_p, t_p, n_p) = run(perm)
+    assert np.array_equal(sp_p, sp[perm])
+    for a, b in zip(cnt, cnt_p):
+        assert np.array_equal(a, b)
+    assert np.array_equal(b_all, b_p) and np.array_equal(c_all, c_p) and np.array_equal(t_all, t_p) and n_all == n_p
+    half = rd.n_reads // 2
+    _, cnt1, (b1, c1, t1, n1) = run(allr[:half])
+    _, cnt2, (b2, c2, t2, n2) = run(allr[half:])
+    assert np.array_equal(b1 + b2, b_all) and np.array_equal(t1 + t2, t_all) and n1 + n2 == n_all
+    for a, x, y in zip(cnt, cnt1, cnt2):
+        assert np.array_equal(a, x + y)
+    assert np.all(c_all >= np.maximum(c1, c2)) and np.all(c_all <= c1 + c2)
+    assert int(b_all.sum()) == _expected_total_bases(sset, sp)
+
+
+def test_step_normalisation(eng, cfg2):
+    from pantax_amd.pipeline import StepConfig, profile_step
+    sset = cfg2
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    sp_rows, st_rows, stats = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    assert sum(r[1] for r in sp_rows) == pytest.approx(1.0, rel=1e-12)
+    assert sum(r[3] for r in st_rows) == pytest.approx(1.0, rel=1e-12)
+    present = {sset.species[0].hap_names[h] for h in np.nonzero(sset.species[0].truth_depth > 0)[0]}
+    assert {r[1] for r in st_rows} == present
