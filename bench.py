@@ -178,6 +178,16 @@ def main():
     dt = time.perf_counter() - t0
     timings = eng.timing_get()
     eng.timing_enable(False)
+    # extra (not `value`): the same step when the unique-trio index, which depends on the DB only, stays
+    # resident between steps instead of being rebuilt like the reference does on every run
+    cfg_cached = StepConfig(rebuild_trio=False)
+    profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species)
+    barrier()
+    dt_cached = time.perf_counter() - t1
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -210,7 +220,8 @@ def main():
         line = {
             "metric": "PAO wall-time (s) + Mreads/s GAF->abundance (packed reads resident in HBM)",
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3, "upload_ms_once": upload_ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3, "upload_ms_once": upload_ms,
+            "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
                                    "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),

@@ -50,24 +50,55 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
         for (int i = threadIdx.x; i < S; i += BIN_BLOCK) s_base[i] = 0;
         __syncthreads();
     }
-    for (uint64_t r = (uint64_t)blockIdx.x * BIN_BLOCK + threadIdx.x; r < R; r += (uint64_t)gridDim.x * BIN_BLOCK) {
-        uint32_t b = step_off[r], e = step_off[r + 1];
+    const int lane = threadIdx.x & 63;
+    // whole waves iterate together (lanes past R stay in the loop, masked) so wave-level aggregation is legal
+    for (uint64_t base = (uint64_t)blockIdx.x * BIN_BLOCK + (threadIdx.x - lane); base < R; base += (uint64_t)gridDim.x * BIN_BLOCK) {
+        const uint64_t r = base + lane;
         int sp = -1;
-        if (e > b) {
-            uint32_t mn = 0xFFFFFFFFu, mx = 0;
-            for (uint32_t i = b; i < e; ++i) {
-                uint32_t v = node_id[i];
-                mn = min(mn, v);
-                mx = max(mx, v);
+        uint32_t q = 0;
+        bool lm = false, uq = false;
+        if (r < R) {
+            uint32_t b = step_off[r], e = step_off[r + 1];
+            if (e > b) {
+                uint32_t mn = 0xFFFFFFFFu, mx = 0;
+                for (uint32_t i = b; i < e; ++i) {
+                    uint32_t v = node_id[i];
+                    mn = min(mn, v);
+                    mx = max(mx, v);
+                }
+                sp = find_species<SORTED>(mn, mx, rs, re, ridx, S);
             }
-            sp = find_species<SORTED>(mn, mx, rs, re, ridx, S);
+            species_out[r] = sp;
+            if (sp >= 0) {
+                q = qlen[r];
+                uint32_t m = mapq[r];
+                lm = (m >= 3 && m <= 60);
+                uq = (m == 60);
+            }
         }
-        species_out[r] = sp;
-        if (sp >= 0) {
-            uint32_t q = qlen[r];
-            uint32_t m = mapq[r];
-            bool lm = (m >= 3 && m <= 60);
-            bool uq = (m == 60);
+        // counters: when every binned lane of the wave has the same species (the usual case inside one
+        // species' reads) one lane adds the wave totals; 64 same-address LDS atomics would serialise
+        const unsigned long long have = __ballot(sp >= 0);
+        if (have == 0) continue;
+        const int sp0 = __shfl(sp, __ffsll((long long)have) - 1);
+        const bool uniform = __all(sp < 0 || sp == sp0);
+        if (uniform) {
+            unsigned long long qs = q;   // q is 0 on lanes without a species
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) qs += __shfl_down(qs, off);
+            const unsigned int c = __popcll(have), l = __popcll(__ballot(lm)), u = __popcll(__ballot(uq));
+            if (lane == 0) {
+                if (LDS_HIST) {
+                    atomicAdd(&s_cnt[sp0], c); atomicAdd(&s_base[sp0], qs);
+                    if (l) atomicAdd(&s_cnt[S + sp0], l);
+                    if (u) atomicAdd(&s_cnt[2 * S + sp0], u);
+                } else {
+                    atomicAdd(&counters[sp0], (unsigned long long)c); atomicAdd(&counters[S + sp0], qs);
+                    if (l) atomicAdd(&counters[2 * S + sp0], (unsigned long long)l);
+                    if (u) atomicAdd(&counters[3 * S + sp0], (unsigned long long)u);
+                }
+            }
+        } else if (sp >= 0) {
             if (LDS_HIST) {
                 atomicAdd(&s_cnt[sp], 1u);
                 atomicAdd(&s_base[sp], (unsigned long long)q);

@@ -81,16 +81,25 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
         if (u) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
     }
 }
-// 4. lookup arrays: CSR over the first node, rows hold (b,c) and the row number in path order
-__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint8_t *__restrict__ uniq_q, const uint32_t *__restrict__ row_of_q,
+// 4. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
+//    order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
+__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint64_t *__restrict__ hap_off, const uint64_t *__restrict__ bit_off,
+                                                          const uint8_t *__restrict__ uniq_q, const uint32_t *__restrict__ row_of_q,
                                                           const uint32_t *__restrict__ trio_first, uint32_t *__restrict__ cursor,
-                                                          uint4 *__restrict__ trio_ent) {
+                                                          uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
+                                                          uint32_t *__restrict__ len_out) {
     for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
         if (!uniq_q[q]) continue;
         uint32_t h, g, a, b, c;
         window_at(q, H, path_off, path_nodes, hap_species, node_base, h, g, a, b, c);
-        uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
-        trio_ent[j] = make_uint4(b, c, row_of_q[q], 0u);
+        const uint32_t row = row_of_q[q];
+        const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
+        trio_ent[j] = make_uint4(b, c, row, 0u);
+        abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
+        const uint32_t s = hap_species[h], nb = node_base[s];
+        hap_out[row] = h - (uint32_t)hap_off[s];
+        len_out[row] = (uint32_t)((bit_off[nb + a + 1] - bit_off[nb + a]) + (bit_off[nb + b + 1] - bit_off[nb + b]) +
+                                  (bit_off[nb + c + 1] - bit_off[nb + c]));
     }
 }
 
@@ -98,27 +107,6 @@ __global__ void __launch_bounds__(256) trio_node_kernel(uint64_t V, const uint32
                                                         uint2 *__restrict__ trio_node) {
     for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256)
         trio_node[v] = make_uint2(trio_first[v], first_cnt[v]);
-}
-
-__global__ void __launch_bounds__(256) trio_rows_kernel(uint64_t P, uint32_t H, const uint64_t *__restrict__ path_off,
-                                                        const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
-                                                        const uint64_t *__restrict__ hap_off, const uint32_t *__restrict__ node_base,
-                                                        const uint64_t *__restrict__ bit_off, const uint8_t *__restrict__ uniq_q,
-                                                        const uint32_t *__restrict__ row_of_q, uint32_t *__restrict__ abc,
-                                                        uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
-    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
-        if (!uniq_q[q]) continue;
-        uint32_t h = find_hap(path_off, H, q);
-        uint32_t s = hap_species[h];
-        uint32_t a = path_nodes[q], b = path_nodes[q + 1], c = path_nodes[q + 2];
-        if (a > c) { uint32_t t = a; a = c; c = t; }
-        uint32_t row = row_of_q[q];
-        abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-        hap_out[row] = h - (uint32_t)hap_off[s];
-        uint32_t nb = node_base[s];
-        len_out[row] = (uint32_t)((bit_off[nb + a + 1] - bit_off[nb + a]) + (bit_off[nb + b + 1] - bit_off[nb + b]) +
-                                  (bit_off[nb + c + 1] - bit_off[nb + c]));   // profile.rs:712
-    }
 }
 
 __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, uint64_t P, const uint64_t *__restrict__ path_off,
@@ -179,14 +167,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
-            hipLaunchKernelGGL(trio_lookup_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.uniq_q.p, ts.row_of_q.p,
-                               db->d_trio_first.p, ts.cursor.p, db->d_trio_ent.p);
-        }
-        {
-            KTimer t(ctx, "trio_rows_kernel");
-            hipLaunchKernelGGL(trio_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, P, H, db->d_path_off.p, db->d_path_nodes.p,
-                               db->d_hap_species.p, db->d_hap_off.p, db->d_node_base.p, db->d_bit_off.p, ts.uniq_q.p, ts.row_of_q.p,
-                               db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p);
+            hipLaunchKernelGGL(trio_lookup_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_hap_off.p, db->d_bit_off.p, ts.uniq_q.p,
+                               ts.row_of_q.p, db->d_trio_first.p, ts.cursor.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p);
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, P, db->d_path_off.p,
                                ts.row_of_q.p, ts.d_tot.p + 1, db->d_hap_trio_off.p);
         }
