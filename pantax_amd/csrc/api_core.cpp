@@ -109,6 +109,18 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
     PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
     PTX_TRY(upload(ctx, db->d_hap_off, g->hap_off, S + 1));
+    {   // path tiles, ordered (species, chunk, hap)
+        std::vector<uint2> tiles;
+        for (uint32_t s = 0; s < S; ++s) {
+            uint64_t maxlen = 0;
+            for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h) maxlen = std::max<uint64_t>(maxlen, g->path_off[h + 1] - g->path_off[h]);
+            for (uint64_t c = 0; c * PATH_TILE < maxlen; ++c)
+                for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h)
+                    if (c * PATH_TILE < g->path_off[h + 1] - g->path_off[h]) tiles.push_back(make_uint2((uint32_t)h, (uint32_t)c));
+        }
+        db->n_tiles = tiles.size();
+        PTX_TRY(upload(ctx, db->d_tiles, tiles.data(), tiles.size()));
+    }
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_node.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(1));

@@ -81,6 +81,7 @@ struct KTimer {
 
 int collect_timings(Ctx *ctx);
 
+constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
 constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership mask per node)
 
 // One batch = every species that has at least one candidate path, solved concurrently
@@ -149,6 +150,8 @@ struct Db {
     DevBuf<uint32_t> d_path_nodes;   // [P]
     DevBuf<uint32_t> d_hap_species;  // [H]
     DevBuf<uint64_t> d_hap_off;      // [S+1]
+    DevBuf<uint2> d_tiles;           // path tiles {hap, chunk} ordered (species, chunk, hap); one workgroup each
+    uint64_t n_tiles = 0;
     // unique-trio index (a7)
     bool trio_built = false;
     uint64_t U = 0;

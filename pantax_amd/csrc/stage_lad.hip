@@ -240,16 +240,19 @@ __device__ __forceinline__ uint32_t find_hap_l(const uint64_t *__restrict__ path
     return lo - 1;
 }
 
-__global__ void __launch_bounds__(256) mask_kernel(uint64_t P, uint32_t H, const uint64_t *__restrict__ path_off,
+__global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
                                                    const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
                                                    const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
                                                    unsigned long long *__restrict__ mask) {
-    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
-        uint32_t h = find_hap_l(path_off, H, q);
-        int bit = hap_bit[h];
-        if (bit < 0) continue;
-        unsigned long long m = 1ull << bit;
-        unsigned long long *w = &mask[node_base[hap_species[h]] + path_nodes[q]];
+    const uint2 tile = tiles[blockIdx.x];   // {hap, chunk}: see stage_trio.hip
+    const uint32_t h = tile.x;
+    const int bit = hap_bit[h];
+    if (bit < 0) return;
+    const unsigned long long m = 1ull << bit;
+    const uint32_t nb = node_base[hap_species[h]];
+    const uint64_t q0 = path_off[h] + (uint64_t)tile.y * PATH_TILE, qend = path_off[h + 1];
+    for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
+        unsigned long long *w = &mask[nb + path_nodes[q]];
         if ((*w & m) == 0) atomicOr(w, m);   // coeff_matrix[(v,pos)] = 1.0 even for repeated visits (profile.rs:1336-1340)
     }
 }
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint3
 
 int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     const uint32_t S = db->S;
-    const uint64_t V = db->V, P = db->P, H = db->H;
+    const uint64_t V = db->V, H = db->H;
     // candidate bit per hap
     std::vector<int32_t> hap_bit(H ? H : 1, -1);
     int pmax = 0;
@@ -356,8 +359,9 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     if (pmax == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
     {
         KTimer t(ctx, "mask_kernel");
-        hipLaunchKernelGGL(mask_kernel, dim3(grid_for(P, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, P, (uint32_t)H, db->d_path_off.p,
-                           db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
+        if (db->n_tiles)
+            hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
+                               db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
     }
     {
         KTimer t(ctx, "ratio_kernel");

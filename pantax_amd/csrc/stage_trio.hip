@@ -22,44 +22,45 @@
 
 namespace ptx {
 
-__device__ __forceinline__ uint32_t find_hap(const uint64_t *__restrict__ path_off, uint32_t H, uint64_t q) {
-    uint32_t lo = 0, hi = H;  // last h with path_off[h] <= q
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (path_off[mid] <= q) lo = mid + 1; else hi = mid;
-    }
-    return lo - 1;
-}
+// Work decomposition of every per-path-step kernel: one workgroup per tile = PATH_TILE consecutive
+// positions of ONE haplotype (tile table built at db upload).  Tiles are ordered (species, chunk, hap):
+// the haplotypes of a species are largely collinear, so neighbouring workgroups touch the same node
+// buckets at the same time (L2 write-combining of the bucket scatter) and no per-position search for the
+// owning haplotype is needed.
+#define TRIO_GRAPH_ARGS const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ path_nodes, \
+                        const uint32_t *__restrict__ hap_species, const uint32_t *__restrict__ node_base
+#define TILE_LOOP(q, h, qend)                                                         \
+    const uint2 tile__ = tiles[blockIdx.x];                                           \
+    const uint32_t h = tile__.x;                                                      \
+    const uint64_t qend = path_off[h + 1];                                            \
+    const uint64_t qt0__ = path_off[h] + (uint64_t)tile__.y * PATH_TILE;              \
+    for (uint64_t q = qt0__ + threadIdx.x; q < qt0__ + PATH_TILE && q < qend; q += 256)
 
-// canonical window at q (profile.rs:672-678); returns false if q starts no window of its hap
-__device__ __forceinline__ bool window_at(uint64_t q, uint32_t H, const uint64_t *__restrict__ path_off,
-                                          const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
-                                          const uint32_t *__restrict__ node_base, uint32_t &h, uint32_t &g, uint32_t &a, uint32_t &b,
-                                          uint32_t &c) {
-    h = find_hap(path_off, H, q);
-    if (q + 2 >= path_off[h + 1]) return false;
+// canonical window at q of hap h (profile.rs:672-678); false if q starts no window
+__device__ __forceinline__ bool window_of(uint64_t q, uint64_t qend, uint32_t nb, const uint32_t *__restrict__ path_nodes, uint32_t &g,
+                                          uint32_t &a, uint32_t &b, uint32_t &c) {
+    if (q + 2 >= qend) return false;
     a = path_nodes[q]; b = path_nodes[q + 1]; c = path_nodes[q + 2];
     if (a > c) { uint32_t t = a; a = c; c = t; }
-    g = node_base[hap_species[h]] + a;
+    g = nb + a;
     return true;
 }
 
-#define TRIO_GRAPH_ARGS uint64_t P, uint32_t H, const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ path_nodes, \
-                        const uint32_t *__restrict__ hap_species, const uint32_t *__restrict__ node_base
-
 // 1. bucket sizes: windows per smallest-end node
 __global__ void __launch_bounds__(256) trio_count_kernel(TRIO_GRAPH_ARGS, uint32_t *__restrict__ cnt) {
-    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
-        uint32_t h, g, a, b, c;
-        if (window_at(q, H, path_off, path_nodes, hap_species, node_base, h, g, a, b, c)) atomicAdd(&cnt[g], 1u);
+    TILE_LOOP(q, h, qend) {
+        const uint32_t nb = node_base[hap_species[h]];
+        uint32_t g, a, b, c;
+        if (window_of(q, qend, nb, path_nodes, g, a, b, c)) atomicAdd(&cnt[g], 1u);
     }
 }
 // 2. scatter windows into their bucket (slot order inside a bucket is arbitrary and irrelevant)
 __global__ void __launch_bounds__(256) trio_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ bucket_off,
                                                         uint32_t *__restrict__ cursor, uint4 *__restrict__ bucket) {
-    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
-        uint32_t h, g, a, b, c;
-        if (!window_at(q, H, path_off, path_nodes, hap_species, node_base, h, g, a, b, c)) continue;
+    TILE_LOOP(q, h, qend) {
+        const uint32_t nb = node_base[hap_species[h]];
+        uint32_t g, a, b, c;
+        if (!window_of(q, qend, nb, path_nodes, g, a, b, c)) continue;
         uint32_t slot = bucket_off[g] + atomicAdd(&cursor[g], 1u);
         bucket[slot] = make_uint4((uint32_t)q, b, c, g);   // one 16-byte record per window
     }
@@ -88,15 +89,16 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
                                                           const uint32_t *__restrict__ trio_first, uint32_t *__restrict__ cursor,
                                                           uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
                                                           uint32_t *__restrict__ len_out) {
-    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (uint64_t)gridDim.x * 256) {
+    TILE_LOOP(q, h, qend) {
         if (!uniq_q[q]) continue;
-        uint32_t h, g, a, b, c;
-        window_at(q, H, path_off, path_nodes, hap_species, node_base, h, g, a, b, c);
+        const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
+        uint32_t g, a, b, c;
+        window_of(q, qend, nbase, path_nodes, g, a, b, c);
         const uint32_t row = row_of_q[q];
         const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
         trio_ent[j] = make_uint4(b, c, row, 0u);
         abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-        const uint32_t s = hap_species[h], nb = node_base[s];
+        const uint32_t s = sidx, nb = nbase;
         hap_out[row] = h - (uint32_t)hap_off[s];
         len_out[row] = (uint32_t)((bit_off[nb + a + 1] - bit_off[nb + a]) + (bit_off[nb + b + 1] - bit_off[nb + b]) +
                                   (bit_off[nb + c + 1] - bit_off[nb + c]));
@@ -136,17 +138,17 @@ int trio_index_build(Ctx *ctx, Db *db) {
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     PTX_HIP(ctx, db->d_trio_node.alloc(V));
     uint32_t tot[2] = {0, 0};
-    int grid = grid_for(P ? P : 1, 256, ctx->n_cu * 8);
-#define TRIO_GRAPH P, H, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
+#define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
+    const dim3 tgrid((uint32_t)db->n_tiles);
     if (P) {
         {
             KTimer t(ctx, "trio_count_kernel");
-            hipLaunchKernelGGL(trio_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.cnt.p);
+            hipLaunchKernelGGL(trio_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.cnt.p);
         }
         PTX_TRY(exclusive_scan_u32(ctx, ts.cnt.p, ts.bucket_off.p, V + 1, ts.scan_tmp.p, ts.d_tot.p));
         {
             KTimer t(ctx, "trio_fill_kernel");
-            hipLaunchKernelGGL(trio_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.bucket_off.p, ts.cursor.p, ts.bucket.p);
+            hipLaunchKernelGGL(trio_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.bucket_off.p, ts.cursor.p, ts.bucket.p);
         }
         // number of windows: every hap with len >= 3 contributes len-2
         uint64_t n_win = 0;
@@ -167,7 +169,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
-            hipLaunchKernelGGL(trio_lookup_kernel, dim3(grid), dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_hap_off.p, db->d_bit_off.p, ts.uniq_q.p,
+            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_hap_off.p, db->d_bit_off.p, ts.uniq_q.p,
                                ts.row_of_q.p, db->d_trio_first.p, ts.cursor.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p);
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, P, db->d_path_off.p,
                                ts.row_of_q.p, ts.d_tot.p + 1, db->d_hap_trio_off.p);
