@@ -179,6 +179,11 @@ int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hi
     std::vector<unsigned long long> h(4ull * S);
     PTX_TRY(download(ctx, h.data(), d_cnt.p, 4ull * S));
     if (species_idx_out) PTX_TRY(download(ctx, species_idx_out, reads->d_species.p, reads->R));
+    // the head of (species, qlen) rides on the same sync: species_profile's first-1000 test (profile.rs:312-319)
+    const uint64_t npre = std::min<uint64_t>(reads->R, 2048);
+    reads->h_pre_species.resize(npre); reads->h_pre_qlen.resize(npre);
+    PTX_TRY(download(ctx, reads->h_pre_species.data(), reads->d_species.p, npre));
+    PTX_TRY(download(ctx, reads->h_pre_qlen.data(), reads->d_qlen.p, npre));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int64_t *outs[4] = {read_count_out, base_sum_out, less_multi_out, uniq_count_out};
     for (int k = 0; k < 4; ++k)
@@ -205,6 +210,7 @@ int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_
     if (bases_per_node_out) PTX_TRY(download(ctx, (unsigned long long *)bases_per_node_out, db->d_bases.p, db->V));
     if (node_base_cov_out) { cov32.resize(db->V); PTX_TRY(download(ctx, cov32.data(), db->d_cov.p, db->V)); }
     if (trio_bases_out && db->U) PTX_TRY(download(ctx, (unsigned long long *)trio_bases_out, db->d_trio_bases.p, db->U));
+    if (!bases_per_node_out && !node_base_cov_out && !trio_bases_out && !n_abort_out) return 0;   // everything stays on the device: no host sync
     PTX_TRY(download(ctx, &h_abort, d_abort, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (node_base_cov_out) for (uint64_t v = 0; v < db->V; ++v) node_base_cov_out[v] = cov32[v];

@@ -20,20 +20,25 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
     int64_t first_len = -1;
     bool equal = true;
     uint64_t seen = 0;
-    uint64_t CH = 2048;   // 1000 non-"U" rows are normally inside the first chunk; grow geometrically otherwise
-    std::vector<int32_t> sp;
-    std::vector<uint32_t> ql;
-    for (uint64_t off = 0; off < reads->R && seen < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
-        uint64_t n = std::min<uint64_t>(CH, reads->R - off);
-        sp.resize(n); ql.resize(n);
-        PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
-        PTX_TRY(download(ctx, ql.data(), reads->d_qlen.p + off, n));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto scan = [&](const int32_t *sp, const uint32_t *ql, uint64_t n) {
         for (uint64_t i = 0; i < n && seen < 1000; ++i) {
             if (sp[i] < 0) continue;
             if (seen == 0) first_len = ql[i]; else if ((int64_t)ql[i] != first_len) equal = false;
             ++seen;
         }
+    };
+    uint64_t off = reads->h_pre_species.size();
+    scan(reads->h_pre_species.data(), reads->h_pre_qlen.data(), off);   // head fetched together with the counters
+    uint64_t CH = 16384;   // rarely needed: fewer than 1000 binned reads among the first 2048 rows
+    std::vector<int32_t> sp;
+    std::vector<uint32_t> ql;
+    for (; off < reads->R && seen < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
+        uint64_t n = std::min<uint64_t>(CH, reads->R - off);
+        sp.resize(n); ql.resize(n);
+        PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
+        PTX_TRY(download(ctx, ql.data(), reads->d_qlen.p + off, n));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        scan(sp.data(), ql.data(), n);
     }
     if (seen == 0) equal = false;
     const uint32_t S = db->S;

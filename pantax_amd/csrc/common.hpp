@@ -155,6 +155,8 @@ struct Db {
     // unique-trio index (a7)
     bool trio_built = false;
     uint64_t U = 0;
+    bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
+    uint64_t U_known = 0;
     DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
     DevBuf<uint2> d_trio_node;       // [V] {first lookup row, #rows} of the windows whose smallest end is this node
     DevBuf<uint4> d_trio_ent;        // [U] {b, c, row in (species,hap,position) order, 0}
@@ -189,6 +191,8 @@ struct Reads {
     DevBuf<uint8_t> d_mapq, d_flags;
     bool has_flags = false;
     DevBuf<int32_t> d_species;
+    std::vector<int32_t> h_pre_species;   // first rows of species/qlen, fetched with the counters (equal-length test)
+    std::vector<uint32_t> h_pre_qlen;
     // locus-grouped copy of the stream the coverage kernel walks (built once per upload)
     DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_g_orig;   // [T] node ids, [T] slot of each step, [R'] slot -> original read
     DevBuf<uint4> d_g_read_rec;      // [R'] {first step, #steps, pstart, pend}

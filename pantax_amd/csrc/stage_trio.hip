@@ -160,10 +160,15 @@ int trio_index_build(Ctx *ctx, Db *db) {
         }
         PTX_TRY(exclusive_scan_u8(ctx, ts.uniq_q.p, ts.row_of_q.p, P, ts.scan_tmp.p, ts.d_tot.p + 1));
         PTX_TRY(exclusive_scan_u32(ctx, ts.first_cnt.p, db->d_trio_first.p, V + 1, ts.scan_tmp.p, nullptr));
-        PTX_TRY(download(ctx, tot, ts.d_tot.p, 2));
         PTX_HIP(ctx, hipMemsetAsync(ts.cursor.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const uint32_t Utot = tot[1];
+        // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
+        // first build and needs no host round trip here
+        if (!db->trio_sizes_known) {
+            PTX_TRY(download(ctx, tot, ts.d_tot.p, 2));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            db->U_known = tot[1];
+        }
+        const uint32_t Utot = (uint32_t)db->U_known;
         db->U = Utot;
         PTX_HIP(ctx, db->d_trio_ent.alloc(Utot));
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
@@ -182,10 +187,14 @@ int trio_index_build(Ctx *ctx, Db *db) {
     hipLaunchKernelGGL(trio_node_kernel, dim3(grid_for(V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, V, db->d_trio_first.p,
                        ts.first_cnt.p, db->d_trio_node.p);
 #undef TRIO_GRAPH
-    db->h_hap_trio_off.resize(H + 1);
-    PTX_TRY(download(ctx, db->h_hap_trio_off.data(), db->d_hap_trio_off.p, H + 1));
     PTX_HIP(ctx, hipGetLastError());
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!db->trio_sizes_known) {
+        db->h_hap_trio_off.resize(H + 1);
+        PTX_TRY(download(ctx, db->h_hap_trio_off.data(), db->d_hap_trio_off.p, H + 1));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!P) db->U_known = 0;
+        db->trio_sizes_known = true;
+    }
     db->trio_built = true;
     db->cov_done = false;
     return 0;

@@ -165,10 +165,9 @@ class Engine:
         """-> bases_per_node [V] int64, node_base_cov [V] uint64, trio_bases [U] int64, n_abort"""
         act = None if species_active is None else as_c(species_active, np.uint8)
         n_abort = C.c_uint64(0)
-        if not fetch:
-            self._check(self.lib.pantax_hip_node_coverage(self.ctx, self.db, self.reads, p(act), None, None, None,
-                                                          C.byref(n_abort)))
-            return n_abort.value
+        if not fetch:   # results stay resident for strain_profiling; no host round trip
+            self._check(self.lib.pantax_hip_node_coverage(self.ctx, self.db, self.reads, p(act), None, None, None, None))
+            return None
         bases = np.zeros(self.V, dtype=np.int64)
         cov = np.zeros(self.V, dtype=np.uint64)
         tb = None

@@ -82,7 +82,7 @@ def local_stage(eng, avg_len, cfg):
     if cfg.rebuild_trio:
         eng.db_reset()
     eng.trio_nodes_info(fetch=False)
-    n_abort = eng.get_node_abundances(species_active=keep, fetch=False)
+    eng.get_node_abundances(species_active=keep, fetch=False)
     met, info = eng.strain_profiling(absolute, species_active=keep, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr,
                                      min_depth=cfg.min_depth, shift=cfg.shift)
     solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
@@ -99,7 +99,7 @@ def local_stage(eng, avg_len, cfg):
             opt = lambda bit, v: v if m.has & bit else None
             rows.append((s, h, m.second_sol, opt(4, m.path_cov_ratio), opt(1, m.unique_trio_nodes_fraction),
                          opt(2, m.frequencies_mean), opt(8, m.first_sol), opt(16, m.divergence), opt(128, m.total_cov_diff)))
-    stats = dict(n_abort=int(n_abort), iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)],
+    stats = dict(iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)],
                  n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
                  obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)])
     return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
