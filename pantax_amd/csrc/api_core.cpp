@@ -1,6 +1,7 @@
 // api_core.cpp -- upload of the resident DB / reads and the a2/a3/a8 entry points of
 // include/pantax_hip.h.  Host code only; kernels live in the stage_*.hip files.
 #include <algorithm>
+#include <cstring>
 #include <memory>
 #include <numeric>
 #include "common.hpp"
@@ -109,6 +110,21 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
     PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
     PTX_TRY(upload(ctx, db->d_hap_off, g->hap_off, S + 1));
+    {   // identical-walk test of first_filter_paths (profile.rs:1188-1190) is a property of the graphs: done once
+        db->h_all_same.assign(S, 0);
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint64_t h0 = g->hap_off[s], h1 = g->hap_off[s + 1];
+            if (h1 - h0 < 2) continue;
+            bool same = true;
+            const uint64_t q0 = g->path_off[h0], l0 = g->path_off[h0 + 1] - q0;
+            for (uint64_t h = h0 + 1; h < h1 && same; ++h) {
+                const uint64_t q = g->path_off[h], l = g->path_off[h + 1] - q;
+                if (l != l0 || std::memcmp(g->path_nodes + q, g->path_nodes + q0, l0 * sizeof(uint32_t)) != 0) same = false;
+            }
+            db->h_all_same[s] = same;
+        }
+        PTX_TRY(upload(ctx, db->d_all_same, db->h_all_same.data(), S));
+    }
     {   // path tiles, ordered (species, chunk, hap)
         std::vector<uint2> tiles;
         for (uint32_t s = 0; s < S; ++s) {

@@ -1,8 +1,12 @@
-// api_strain.cpp -- a9..a14 host orchestration: first_filter_paths (profile.rs:1080-1227), the two
-// LP solves on device, second_filter_paths (:1229-1285), abundace_constraint (:3028-3070), and the
-// solver seam pantax_hip_pao_solve (X_opt signature, profile.rs:2690-2698).
-// The scalar filter logic is host C++ (a handful of flops per haplotype); everything that touches
-// per-node or per-trio data runs in the kernels of stage_lad.hip.
+// api_strain.cpp -- a9..a14: first_filter_paths (profile.rs:1080-1227), the two LP solves,
+// second_filter_paths (:1229-1285), abundace_constraint (:3028-3070), and the solver seam
+// pantax_hip_pao_solve (X_opt signature, profile.rs:2690-2698).
+//
+// The whole strain step is enqueued on the ctx stream without waiting for the host: the two filter
+// decisions are taken by small device kernels (stage_lad.hip), row / pattern counts stay on the
+// device, and ONE download + synchronisation at the end brings back the raw per-haplotype and
+// per-species results.  The host then only redoes the reporting arithmetic (rounded fractions,
+// divergence, abundance constraint) on those values, using the decisions the device took.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -15,26 +19,67 @@ namespace {
 
 inline double round2(double x) { return std::round(x * 100.0) / 100.0; }   // f64::round: half away from zero
 
-struct SpeciesState {
-    std::vector<uint32_t> cand;   // possible_paths_idx (hap index within species)
-    std::vector<uint8_t> keep;    // second_possible_paths_idx membership per candidate
-    bool same_path = false, second_opt = false, failed = false;
-    int fail_code = 0;
+// Every small per-species / per-haplotype result of the step lives in ONE device arena (db->d_arena):
+// it is zeroed with one memset before the step and fetched with one copy after it.  The DevBufs that the
+// kernels write through are non-owning views into it.
+struct StrainRaw {   // host pointers into db->h_arena after fetch
+    const uint32_t *nnz, *nvalid, *nzcnt, *sp_pat_off, *counts;
+    const double *meanf, *amax, *nzsum, *x1, *x2, *obj1, *obj2;
+    const int32_t *hap_bit, *sp_p, *st1, *st2, *it1, *it2;
+    const uint8_t *fixed2, *need2;
+    const unsigned long long *ratio;
 };
 
-// shared by strain_profile and pao_solve: runs prepare + solve #1 (+ optional second solve driven
-// by `second` callback) on an already filled LadBatch/candidate list
-int run_solve(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int32_t> &list, std::vector<double> &x, std::vector<double> &obj,
-              std::vector<int32_t> &status, std::vector<int32_t> &iters) {
-    PTX_TRY(lad_solve_launch(ctx, db, lb, list));
-    uint32_t S = db->S;
-    x.resize((size_t)S * LAD_MAXP); obj.resize(S); status.resize(S); iters.resize(S);
-    if (list.empty()) return 0;
-    PTX_TRY(download(ctx, x.data(), lb->d_x.p, (size_t)S * LAD_MAXP));
-    PTX_TRY(download(ctx, obj.data(), lb->d_obj.p, S));
-    PTX_TRY(download(ctx, status.data(), lb->d_status.p, S));
-    PTX_TRY(download(ctx, iters.data(), lb->d_iters.p, S));
+struct ArenaLayout {
+    size_t amax, nzsum, obj1, obj2, x1, x2, ratio, meanf, nvalid, nzcnt, sp_p, sp_pat_off, st1, st2, it1, it2, counts, nnz, hap_bit, fixed2, need2, total;
+    ArenaLayout(uint32_t S, uint64_t H) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
+        const size_t Hn = H ? H : 1;
+        amax = take(8 * S); nzsum = take(8 * S); obj1 = take(8 * S); obj2 = take(8 * S);
+        x1 = take(8 * (size_t)S * LAD_MAXP); x2 = take(8 * (size_t)S * LAD_MAXP); ratio = take(8 * (size_t)S * LAD_MAXP * 2);
+        meanf = take(8 * Hn);
+        nvalid = take(4 * S); nzcnt = take(4 * S); sp_p = take(4 * S); sp_pat_off = take(4 * ((size_t)S + 1));
+        st1 = take(4 * S); st2 = take(4 * S); it1 = take(4 * S); it2 = take(4 * S); counts = take(16);
+        nnz = take(4 * Hn); hap_bit = take(4 * Hn);
+        fixed2 = take((size_t)S * LAD_MAXP); need2 = take(S);
+        total = off;
+    }
+};
+
+int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
+    const uint32_t S = db->S;
+    const size_t Hn = db->H ? db->H : 1;
+    PTX_HIP(ctx, db->d_arena.alloc(L.total));
+    uint8_t *b = db->d_arena.p;
+    PTX_HIP(ctx, hipMemsetAsync(b, 0, L.total, ctx->stream));   // unsolved species read back as x = 0, status 0, 0 pivots
+    lb.d_amax.view(b + L.amax, S); lb.d_nzsum.view(b + L.nzsum, S); lb.d_obj.view(b + L.obj1, S); lb.d_obj2.view(b + L.obj2, S);
+    lb.d_x.view(b + L.x1, (size_t)S * LAD_MAXP); lb.d_x2.view(b + L.x2, (size_t)S * LAD_MAXP);
+    lb.d_ratio.view(b + L.ratio, (size_t)S * LAD_MAXP * 2);
+    db->d_hap_mean.view(b + L.meanf, Hn);
+    lb.d_nvalid.view(b + L.nvalid, S); lb.d_nzcnt.view(b + L.nzcnt, S); lb.d_p.view(b + L.sp_p, S); lb.d_sp_pat_off.view(b + L.sp_pat_off, (size_t)S + 1);
+    lb.d_status.view(b + L.st1, S); lb.d_status2.view(b + L.st2, S); lb.d_iters.view(b + L.it1, S); lb.d_iters2.view(b + L.it2, S);
+    lb.d_counts.view(b + L.counts, 4);
+    db->d_hap_nnz.view(b + L.nnz, Hn); lb.d_hap_bit.view(b + L.hap_bit, Hn);
+    lb.d_fixed2.view(b + L.fixed2, (size_t)S * LAD_MAXP); lb.d_need2.view(b + L.need2, S);
+    return 0;
+}
+
+int fetch_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r) {
+    db->h_arena.resize(L.total);
+    PTX_TRY(download(ctx, db->h_arena.data(), db->d_arena.p, L.total));   // the one host round trip of the step
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t *b = db->h_arena.data();
+    r.amax = (const double *)(b + L.amax); r.nzsum = (const double *)(b + L.nzsum); r.obj1 = (const double *)(b + L.obj1); r.obj2 = (const double *)(b + L.obj2);
+    r.x1 = (const double *)(b + L.x1); r.x2 = (const double *)(b + L.x2); r.ratio = (const unsigned long long *)(b + L.ratio);
+    r.meanf = (const double *)(b + L.meanf);
+    r.nvalid = (const uint32_t *)(b + L.nvalid); r.nzcnt = (const uint32_t *)(b + L.nzcnt); r.sp_p = (const int32_t *)(b + L.sp_p);
+    r.sp_pat_off = (const uint32_t *)(b + L.sp_pat_off);
+    r.st1 = (const int32_t *)(b + L.st1); r.st2 = (const int32_t *)(b + L.st2); r.it1 = (const int32_t *)(b + L.it1); r.it2 = (const int32_t *)(b + L.it2);
+    r.counts = (const uint32_t *)(b + L.counts);
+    r.nnz = (const uint32_t *)(b + L.nnz); r.hap_bit = (const int32_t *)(b + L.hap_bit);
+    r.fixed2 = b + L.fixed2; r.need2 = b + L.need2;
+    if (r.counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "strain step: more than %u membership patterns on this GPU; this build sizes its pattern tables for S*8192+65536", lb.k_cap);
     return 0;
 }
 
@@ -57,181 +102,102 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     std::memset(info.data(), 0, sizeof(pantax_hip_solve_info) * S);
     for (auto &i : info) i.obj1 = i.obj2 = NAN;
 
-    // ---- device reductions: per-hap trio stats, node abundance + per-species stats
-    DevBuf<uint32_t> &d_nnz = db->d_hap_nnz;
-    DevBuf<double> &d_mean = db->d_hap_mean;
+    // ---- enqueue the whole step ---------------------------------------------------------------
     LadBatch &lb = db->lad;
-    PTX_TRY(hap_trio_stats_launch(ctx, db, d_nnz, d_mean));
-    PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));
-    std::vector<uint32_t> nnz(H ? H : 1), nvalid(S), nzcnt(S);
-    std::vector<double> meanf(H ? H : 1), amax(S), nzsum(S);
-    PTX_TRY(download(ctx, nnz.data(), d_nnz.p, H));
-    PTX_TRY(download(ctx, meanf.data(), d_mean.p, H));
-    PTX_TRY(download(ctx, amax.data(), lb.d_amax.p, S));
-    PTX_TRY(download(ctx, nvalid.data(), lb.d_nvalid.p, S));
-    PTX_TRY(download(ctx, nzsum.data(), lb.d_nzsum.p, S));
-    PTX_TRY(download(ctx, nzcnt.data(), lb.d_nzcnt.p, S));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const ArenaLayout L(S, H);
+    PTX_TRY(bind_arena(ctx, db, lb, L));
+    const uint8_t *d_active = nullptr;
+    if (species_active) { PTX_TRY(upload(ctx, db->d_active, species_active, S)); d_active = db->d_active.p; }
+    PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
+    PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
+    const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
+    PTX_TRY(first_filter_launch(ctx, db, &lb, d_active, fc));                               // a9 decision -> LP columns
+    int pmax_bound = 1;                                                                     // columns per species <= min(#haps, 64)
+    for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
+    PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
+    PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax_bound, nullptr, nullptr, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));        // LP 1
+    PTX_TRY(second_filter_launch(ctx, db, &lb, fc, lb.d_x.p, lb.d_status.p, lb.d_fixed2.p, lb.d_need2.p));                            // a13 decision
+    // LP 2 only where the second filter dropped a column; elsewhere LP2 == LP1 (m.reset() + no new constraint,
+    // profile.rs:1482-1490) and its optimum is the one already computed
+    PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax_bound, lb.d_need2.p, lb.d_fixed2.p, lb.d_x2.p, lb.d_obj2.p, lb.d_status2.p, lb.d_iters2.p));
+    StrainRaw r;
+    PTX_TRY(fetch_arena(ctx, db, lb, L, r));                                                // the one host round trip
+    lb.n_rows = r.counts[0]; lb.K = r.counts[1];
+    lb.h_sp_pat_off.assign(r.sp_pat_off, r.sp_pat_off + S + 1);
 
-    // ---- first_filter_paths (profile.rs:1080-1227)
-    std::vector<SpeciesState> st(S);
-    lb.h_p.assign(S, 0);
-    lb.h_cand.assign((size_t)S * LAD_MAXP, 0);
+    // ---- reporting (host): metrics of every haplotype from the raw values and the device's decisions
     for (uint32_t s = 0; s < S; ++s) {
         if (species_active && !species_active[s]) continue;
         const uint64_t h0 = db->h_hap_off[s], h1 = db->h_hap_off[s + 1];
         const uint32_t Hs = (uint32_t)(h1 - h0);
         if (Hs == 0) continue;
         const uint64_t Us = db->h_hap_trio_off[h1] - db->h_hap_trio_off[h0];
-        SpeciesState &ss = st[s];
-        if (Hs != 1 && Us != 0) {                                  // :1098
-            for (uint32_t h = 0; h < Hs; ++h) {
-                uint64_t nt = db->h_hap_trio_off[h0 + h + 1] - db->h_hap_trio_off[h0 + h];
-                if (nt == 0) continue;                             // :1119
-                double frac = (double)nnz[h0 + h] / (double)nt;    // :1135
-                pantax_hip_hap_metrics &m = met[h0 + h];
-                m.unique_trio_nodes_fraction = round2(frac); m.has |= PANTAX_HIP_HAS_FRACTION;   // :1136-1138
-                double fm = meanf[h0 + h];
-                if (cfg->shift) {                                  // :1140-1165
-                    double sh;
-                    if (fm >= 1.0) { sh = cfg->unique_trio_nodes_fraction + (0.8 - cfg->unique_trio_nodes_fraction) * fm / 100.0; if (sh > 0.8) sh = 0.8; }
-                    else sh = cfg->unique_trio_nodes_fraction * fm;
-                    if (frac < sh) continue;
-                } else if (frac < cfg->unique_trio_nodes_fraction) continue;   // :1168
-                m.frequencies_mean = fm; m.has |= PANTAX_HIP_HAS_FREQ_MEAN;
-                ss.cand.push_back(h);
+        const bool trio_mode = Hs != 1 && Us != 0;                                          // profile.rs:1098
+        const bool single_mode = !trio_mode && (Hs == 1 || db->h_all_same[s]);              // :1191-1205, :1211-1224
+        const int p = r.sp_p[s];
+        info[s].n_candidates = p < 0 ? -p : p;
+        bool failed = false; int fail_code = 0;
+        if (p < 0) { failed = true; fail_code = PANTAX_HIP_E_LIMIT; }                        // > 64 candidate paths
+        std::vector<uint64_t> cand(p > 0 ? p : 0);                                          // column k -> global hap
+        for (uint64_t h = h0; h < h1; ++h) if (r.hap_bit[h] >= 0 && r.hap_bit[h] < p) cand[r.hap_bit[h]] = h;
+        // first-filter metrics (set for every haplotype that was looked at, candidate or not)
+        if (trio_mode) {
+            for (uint64_t h = h0; h < h1; ++h) {
+                const uint64_t nt = db->h_hap_trio_off[h + 1] - db->h_hap_trio_off[h];
+                if (nt == 0) continue;                                                      // :1119
+                met[h].unique_trio_nodes_fraction = round2((double)r.nnz[h] / (double)nt); met[h].has |= PANTAX_HIP_HAS_FRACTION;   // :1136-1138
+                if (r.hap_bit[h] >= 0) { met[h].frequencies_mean = r.meanf[h]; met[h].has |= PANTAX_HIP_HAS_FREQ_MEAN; }            // :1165 / :1180
             }
-        } else {
-            bool all_same = true;
-            if (Hs != 1) {                                         // :1187-1190
-                const uint64_t q0 = db->h_path_off[h0], l0 = db->h_path_off[h0 + 1] - q0;
-                for (uint32_t h = 1; h < Hs && all_same; ++h) {
-                    const uint64_t q = db->h_path_off[h0 + h], l = db->h_path_off[h0 + h + 1] - q;
-                    if (l != l0 || std::memcmp(&db->h_path_nodes[q], &db->h_path_nodes[q0], l0 * sizeof(uint32_t)) != 0) all_same = false;
-                }
-            }
-            if (Hs == 1 || all_same) {                             // :1191-1205, :1211-1224
-                ss.same_path = Hs != 1;
-                double fm = nzcnt[s] ? nzsum[s] / (double)nzcnt[s] : 0.0;
-                met[h0].frequencies_mean = round2(fm); met[h0].has |= PANTAX_HIP_HAS_FREQ_MEAN;
-                ss.cand.push_back(0);
-            } else {
-                for (uint32_t h = 0; h < Hs; ++h) ss.cand.push_back(h);   // :1208
-            }
+        } else if (single_mode) {
+            const double fm = r.nzcnt[s] ? r.nzsum[s] / (double)r.nzcnt[s] : 0.0;
+            met[h0].frequencies_mean = round2(fm); met[h0].has |= PANTAX_HIP_HAS_FREQ_MEAN;  // :1203-1204, :1222-1223
         }
-        info[s].n_candidates = (int32_t)ss.cand.size();
-        if (ss.cand.size() > (size_t)LAD_MAXP) {
-            ss.failed = true; ss.fail_code = PANTAX_HIP_E_LIMIT;   // this build: <= 64 candidate paths per species
-            continue;
+        if (p > 0) {
+            info[s].status1 = r.st1[s]; info[s].iters1 = r.it1[s]; info[s].obj1 = r.obj1[s];
+            info[s].n_rows = r.nvalid[s];
+            info[s].n_patterns = r.sp_pat_off[s + 1] - r.sp_pat_off[s];
+            if (r.st1[s] != 0) { failed = true; fail_code = PANTAX_HIP_E_SOLVER; }           // profile.rs:2999-3003
         }
-        lb.h_p[s] = (int32_t)ss.cand.size();
-        for (size_t k = 0; k < ss.cand.size(); ++k) lb.h_cand[(size_t)s * LAD_MAXP + k] = ss.cand[k];
-    }
-
-    // ---- a10 + row grouping on device, then solve #1
-    PTX_TRY(lad_prepare(ctx, db, &lb));
-    std::vector<unsigned long long> ratio((size_t)S * LAD_MAXP * 2);
-    PTX_TRY(download(ctx, ratio.data(), lb.d_ratio.p, ratio.size()));
-    std::vector<double> ub((size_t)S * LAD_MAXP, 0.0);
-    std::vector<int32_t> list1;
-    for (uint32_t s = 0; s < S; ++s) {
-        if (lb.h_p[s] <= 0) continue;
-        list1.push_back((int32_t)s);
-        for (int k = 0; k < lb.h_p[s]; ++k) ub[(size_t)s * LAD_MAXP + k] = 1.05 * amax[s];   // profile.rs:1327
-    }
-    PTX_TRY(upload(ctx, lb.d_ub, ub.data(), ub.size()));
-    std::vector<double> x1, obj1, x2, obj2;
-    std::vector<int32_t> st1, it1, st2, it2;
-    PTX_TRY(run_solve(ctx, db, &lb, list1, x1, obj1, st1, it1));
-
-    // ---- path_cov_ratio, first_sol, second_filter_paths (profile.rs:1229-1285)
-    std::vector<int32_t> list2;
-    for (int32_t s : list1) {
-        SpeciesState &ss = st[s];
-        const uint64_t h0 = db->h_hap_off[s];
-        const uint32_t Hs = (uint32_t)(db->h_hap_off[s + 1] - h0);
-        const uint64_t Us = db->h_hap_trio_off[db->h_hap_off[s + 1]] - db->h_hap_trio_off[h0];
-        info[s].status1 = st1[s]; info[s].iters1 = it1[s]; info[s].obj1 = obj1[s];
-        info[s].n_rows = nvalid[s];
-        info[s].n_patterns = lb.h_sp_pat_off[s + 1] - lb.h_sp_pat_off[s];
-        if (st1[s] != 0) { ss.failed = true; ss.fail_code = PANTAX_HIP_E_SOLVER; continue; }   // profile.rs:2999-3003
-        const int p = lb.h_p[s];
-        ss.keep.assign(p, 0);
-        for (int k = 0; k < p; ++k) {
-            pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]];
-            // f32 ratio of exact integer sums (profile.rs:1344-1361 accumulates in f32; identical while sums < 2^24)
-            float cov = (float)ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
-            m.path_cov_ratio = (double)(cov / len); m.has |= PANTAX_HIP_HAS_RATIO;
-            m.first_sol = x1[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_FIRST;
-        }
-        if (Hs != 1 && Us > 0) {
-            ss.second_opt = true;
+        if (p > 0 && !failed) {
             for (int k = 0; k < p; ++k) {
-                pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]];
-                double fm = (m.has & PANTAX_HIP_HAS_FREQ_MEAN) ? m.frequencies_mean : 0.0;
-                if (fm == 0.0) continue;                            // :1238
-                double sol = m.first_sol;
-                double fr = round2(std::fabs(sol - fm) / (sol + fm));
-                m.divergence = fr; m.has |= PANTAX_HIP_HAS_DIVERGENCE;
-                if (fr > cfg->unique_trio_nodes_mean_count_f) {
-                    if (fr <= 0.6) {
-                        double sc = m.unique_trio_nodes_fraction * m.path_cov_ratio;
-                        if (sc < cfg->single_cov_ratio || sol == 0.0) continue;
-                        m.is_rescue = 1; m.has |= PANTAX_HIP_HAS_RESCUE; ss.keep[k] = 1;
+                pantax_hip_hap_metrics &m = met[cand[k]];
+                // f32 ratio of exact integer sums (profile.rs:1344-1361 accumulates in f32; identical while sums < 2^24)
+                const float cov = (float)r.ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)r.ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+                m.path_cov_ratio = (double)(cov / len); m.has |= PANTAX_HIP_HAS_RATIO;
+                m.first_sol = r.x1[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_FIRST;
+            }
+            if (trio_mode) {                                                                // second_filter_paths, :1234-1268
+                const bool rs = r.need2[s] != 0;                                            // LP 2 actually differed from LP 1
+                info[s].status2 = rs ? r.st2[s] : r.st1[s]; info[s].iters2 = rs ? r.it2[s] : 0; info[s].obj2 = rs ? r.obj2[s] : r.obj1[s];
+                if (info[s].status2 != 0) { failed = true; fail_code = PANTAX_HIP_E_SOLVER; }
+                for (int k = 0; k < p && !failed; ++k) {
+                    pantax_hip_hap_metrics &m = met[cand[k]];
+                    const double fm = (m.has & PANTAX_HIP_HAS_FREQ_MEAN) ? m.frequencies_mean : 0.0;
+                    const bool keep = !r.fixed2[(size_t)s * LAD_MAXP + k];
+                    if (fm != 0.0) {                                                        // :1238
+                        const double sol = m.first_sol;
+                        const double f = round2(std::fabs(sol - fm) / (sol + fm));
+                        m.divergence = f; m.has |= PANTAX_HIP_HAS_DIVERGENCE;
+                        if (keep && f > cfg->unique_trio_nodes_mean_count_f) { m.is_rescue = 1; m.has |= PANTAX_HIP_HAS_RESCUE; }   // :1251-1259
                     }
-                } else if (sol != 0.0) ss.keep[k] = 1;
-            }
-            list2.push_back(s);
-        } else if ((Hs != 1 && Us == 0 && ss.same_path) || Hs == 1) {
-            pantax_hip_hap_metrics &m = met[h0];
-            double fm = m.frequencies_mean;
-            if (fm > 0.0) {
-                double sol = m.first_sol;
-                m.divergence = round2(std::fabs(sol - fm) / (sol + fm)); m.has |= PANTAX_HIP_HAS_DIVERGENCE;
-                m.second_sol = sol; m.has |= PANTAX_HIP_HAS_SECOND;
-            }
-        } else {
-            for (int k = 0; k < p; ++k) { pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]]; m.second_sol = m.first_sol; m.has |= PANTAX_HIP_HAS_SECOND; }
-        }
-    }
-    // ---- solve #2 with dropped candidates pinned to 0 (profile.rs:1484-1508, Gurobi semantics).
-    // When the second filter drops nothing the second LP is the first LP again (m.reset() + no new
-    // constraint), so its optimum is the one already computed: reuse it instead of re-solving.
-    if (!list2.empty()) {
-        std::vector<int32_t> resolve;
-        for (int32_t s : list2) {
-            bool any_dropped = false;
-            for (int k = 0; k < lb.h_p[s]; ++k) if (!st[s].keep[k]) { ub[(size_t)s * LAD_MAXP + k] = 0.0; any_dropped = true; }
-            if (any_dropped) resolve.push_back(s);
-        }
-        if (!resolve.empty()) {
-            PTX_TRY(upload(ctx, lb.d_ub, ub.data(), ub.size()));
-            PTX_TRY(run_solve(ctx, db, &lb, resolve, x2, obj2, st2, it2));
-        }
-        std::vector<uint8_t> resolved(S, 0);
-        for (int32_t s : resolve) resolved[s] = 1;
-        for (int32_t s : list2) {
-            SpeciesState &ss = st[s];
-            const bool rs = resolved[s] != 0;
-            info[s].status2 = rs ? st2[s] : st1[s]; info[s].iters2 = rs ? it2[s] : 0; info[s].obj2 = rs ? obj2[s] : obj1[s];
-            if (info[s].status2 != 0) { ss.failed = true; ss.fail_code = PANTAX_HIP_E_SOLVER; continue; }
-            const uint64_t h0 = db->h_hap_off[s];
-            for (int k = 0; k < lb.h_p[s]; ++k)
-                if (ss.keep[k]) {
-                    pantax_hip_hap_metrics &m = met[h0 + ss.cand[k]];
-                    m.second_sol = rs ? x2[(size_t)s * LAD_MAXP + k] : x1[(size_t)s * LAD_MAXP + k];
-                    m.has |= PANTAX_HIP_HAS_SECOND;
+                    if (keep) { m.second_sol = rs ? r.x2[(size_t)s * LAD_MAXP + k] : r.x1[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_SECOND; }   // :1500-1508
                 }
+            } else if (single_mode) {                                                       // :1269-1278
+                pantax_hip_hap_metrics &m = met[h0];
+                const double fm = m.frequencies_mean;
+                if (fm > 0.0) {
+                    const double sol = m.first_sol;
+                    m.divergence = round2(std::fabs(sol - fm) / (sol + fm)); m.has |= PANTAX_HIP_HAS_DIVERGENCE;
+                    m.second_sol = sol; m.has |= PANTAX_HIP_HAS_SECOND;
+                }
+            } else {                                                                        // :1279-1283
+                for (int k = 0; k < p; ++k) { pantax_hip_hap_metrics &m = met[cand[k]]; m.second_sol = m.first_sol; m.has |= PANTAX_HIP_HAS_SECOND; }
+            }
         }
-    }
-    // ---- failed species are dropped whole (reference returns None); abundace_constraint for the rest
-    for (uint32_t s = 0; s < S; ++s) {
-        if (species_active && !species_active[s]) continue;
-        const uint64_t h0 = db->h_hap_off[s], h1 = db->h_hap_off[s + 1];
-        if (h1 == h0) continue;
-        if (st[s].failed) {
+        // ---- failed species are dropped whole (reference returns None); abundace_constraint for the rest
+        if (failed) {
             for (uint64_t h = h0; h < h1; ++h) std::memset(&met[h], 0, sizeof(met[h]));
-            info[s].status1 = info[s].status1 ? info[s].status1 : st[s].fail_code;
+            info[s].status1 = info[s].status1 ? info[s].status1 : fail_code;
             continue;
         }
         if (!species_coverage) continue;
@@ -273,8 +239,10 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
     pantax_hip_db *db = nullptr;
     PTX_TRY(pantax_hip_db_upload(ctx, &g, &db));
     std::unique_ptr<pantax_hip_db, void (*)(pantax_hip_db *)> guard(db, [](pantax_hip_db *d) { delete d; });
-    LadBatch lb;
+    LadBatch &lb = db->lad;
     lb.S = 1;
+    const ArenaLayout L(1, n_paths);
+    PTX_TRY(bind_arena(ctx, db, lb, L));
     std::vector<uint32_t> cov32(n_nodes, 0);
     if (node_base_cov) for (uint32_t v = 0; v < n_nodes; ++v) cov32[v] = (uint32_t)node_base_cov[v];
     PTX_TRY(upload(ctx, db->d_cov, cov32.data(), n_nodes));
@@ -289,24 +257,28 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
         if (cand_path_idx[k] >= n_paths) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: candidate %u names path %u of %u", k, cand_path_idx[k], n_paths);
         lb.h_cand[k] = cand_path_idx[k];
     }
-    PTX_TRY(lad_prepare(ctx, db, &lb));
-    std::vector<double> ub(LAD_MAXP, 0.0);
-    for (uint32_t k = 0; k < n_cand; ++k) ub[k] = (fixed_zero && fixed_zero[k]) ? 0.0 : 1.05 * amax;
-    PTX_TRY(upload(ctx, lb.d_ub, ub.data(), ub.size()));
-    std::vector<double> x, obj;
-    std::vector<int32_t> st, it;
-    PTX_TRY(run_solve(ctx, db, &lb, std::vector<int32_t>{0}, x, obj, st, it));
-    for (uint32_t k = 0; k < n_cand; ++k) x_out[k] = x[k];
-    if (path_cov_ratio_out) {
-        std::vector<unsigned long long> ratio(LAD_MAXP * 2);
-        PTX_TRY(download(ctx, ratio.data(), lb.d_ratio.p, ratio.size()));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t k = 0; k < n_cand; ++k) path_cov_ratio_out[k] = (float)ratio[2 * k] / (float)ratio[2 * k + 1];
-    }
-    if (obj_out) *obj_out = obj[0];
-    if (status_out) *status_out = st[0];
+    PTX_TRY(lad_prepare(ctx, db, &lb, false, (int)n_cand));
+    std::vector<uint8_t> fixed(LAD_MAXP, 0);
+    for (uint32_t k = 0; k < n_cand; ++k) fixed[k] = (fixed_zero && fixed_zero[k]) ? 1 : 0;
+    PTX_TRY(upload(ctx, lb.d_fixed2, fixed.data(), fixed.size()));
+    PTX_TRY(lad_solve_launch(ctx, db, &lb, (int)n_cand, nullptr, lb.d_fixed2.p, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));
+    std::vector<double> x(LAD_MAXP);
+    std::vector<unsigned long long> ratio(LAD_MAXP * 2);
+    std::vector<uint32_t> counts(4);
+    double obj = 0.0; int32_t st = 0, it = 0;
+    PTX_TRY(download(ctx, x.data(), lb.d_x.p, LAD_MAXP));
+    PTX_TRY(download(ctx, &obj, lb.d_obj.p, 1));
+    PTX_TRY(download(ctx, &st, lb.d_status.p, 1));
+    PTX_TRY(download(ctx, &it, lb.d_iters.p, 1));
+    PTX_TRY(download(ctx, ratio.data(), lb.d_ratio.p, ratio.size()));
+    PTX_TRY(download(ctx, counts.data(), lb.d_counts.p, 4));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (st[0] != 0) return fail(ctx, PANTAX_HIP_E_SOLVER, "pao_solve: LAD solver stopped with status %d after %d pivots", st[0], it[0]);
+    if (counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: more membership patterns than this build sizes for");
+    for (uint32_t k = 0; k < n_cand; ++k) x_out[k] = x[k];
+    if (path_cov_ratio_out) for (uint32_t k = 0; k < n_cand; ++k) path_cov_ratio_out[k] = (float)ratio[2 * k] / (float)ratio[2 * k + 1];
+    if (obj_out) *obj_out = nvalid ? obj : 0.0;
+    if (status_out) *status_out = st;
+    if (st != 0) return fail(ctx, PANTAX_HIP_E_SOLVER, "pao_solve: LAD solver stopped with status %d after %d pivots", st, it);
     return 0;
 }
 

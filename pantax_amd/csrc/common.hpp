@@ -33,14 +33,23 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        owned = true;
+    }
+    // non-owning window into a larger allocation (an arena that is zeroed / downloaded as one piece)
+    void view(void *ptr, size_t count) {
+        release();
+        p = static_cast<T *>(ptr);
+        n = count;
+        owned = false;
     }
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
@@ -106,7 +115,9 @@ struct LadBatch {
     // sorted LP rows (a_v > 0 and mask != 0), grouped into patterns
     uint64_t n_rows = 0;
     uint32_t K = 0;
-    DevBuf<double> d_row_a;             // [n_rows] abundances sorted by (species, mask, a)
+    const double *row_a = nullptr;      // [n_rows] abundances sorted by (species, mask, a) (points into the sort buffers)
+    DevBuf<uint32_t> d_counts;          // {n_rows, K, pattern overflow flag} kept on the device
+    uint32_t k_cap = 0;
     DevBuf<uint64_t> d_pat_mask;        // [K]
     DevBuf<uint32_t> d_pat_start;       // [K+1]
     DevBuf<uint32_t> d_pat_species;     // [K]
@@ -116,9 +127,9 @@ struct LadBatch {
     DevBuf<double> d_pat_eps, d_sc_s, d_sc_rho;
     DevBuf<uint32_t> d_sc_lo, d_sc_up, d_ls_lo, d_ls_hi, d_ls_mid;
     // solver in/out per species
-    DevBuf<double> d_ub, d_x, d_obj;    // [S*LAD_MAXP], [S*LAD_MAXP], [S]
-    DevBuf<int32_t> d_status, d_iters;  // [S]
-    DevBuf<int32_t> d_solve_list;       // [n_solve]
+    DevBuf<double> d_x, d_x2, d_obj, d_obj2;      // [S*LAD_MAXP] x of solve 1 / 2, [S] objectives
+    DevBuf<int32_t> d_status, d_iters, d_status2, d_iters2;   // [S]
+    DevBuf<uint8_t> d_fixed2, d_need2;  // [S*LAD_MAXP], [S] second-solve decisions (second_filter_kernel)
 };
 
 
@@ -150,6 +161,8 @@ struct Db {
     DevBuf<uint32_t> d_path_nodes;   // [P]
     DevBuf<uint32_t> d_hap_species;  // [H]
     DevBuf<uint64_t> d_hap_off;      // [S+1]
+    DevBuf<uint8_t> d_all_same;      // [S] every haplotype of the species walks the same nodes (profile.rs:1188-1190)
+    std::vector<uint8_t> h_all_same;
     DevBuf<uint2> d_tiles;           // path tiles {hap, chunk} ordered (species, chunk, hap); one workgroup each
     uint64_t n_tiles = 0;
     // unique-trio index (a7)
@@ -179,6 +192,8 @@ struct Db {
     DevBuf<uint32_t> d_hap_nnz;              // [H]
     DevBuf<double> d_hap_mean;               // [H]
     DevBuf<double> d_hap_part, d_hap_mean_sd; // two-level reduction scratch of the per-hap trio statistics
+    DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
+    std::vector<uint8_t> h_arena;
     // LP-row staging (lad_prepare)
     DevBuf<uint8_t> d_row_flag, d_pat_head;
     DevBuf<uint32_t> d_row_pos, d_pat_idx, d_scan_tmp, d_sort_table, d_tot2;

@@ -10,8 +10,15 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_ntrio_nz /
 // node abundance + per-species stats
 int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth);
 // a10: masks, ratios; then LP rows sorted and grouped into patterns
-int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb);
-// a12: solve every species in solve_list with bounds d_ub; writes d_x, d_obj, d_status, d_iters
-int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int32_t> &solve_list);
+int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int pmax_bound);
+// a12: one workgroup per species (those with d_p[s] > 0 and need[s], when given); variables with fixed[s*64+k]
+// are pinned to 0.  Writes x, obj, status, iters for the solved species.  Nothing is read back.
+int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
+                     double *d_obj, int32_t *d_status, int32_t *d_iters);
+// a9 / a13 decisions on the device (the host redoes only the reporting arithmetic at the end of the step)
+struct FilterCfg { double fr, fc, sr; int shift; };
+int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc);
+int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
+                         uint8_t *d_fixed2, uint8_t *d_need2);
 
 }  // namespace ptx

@@ -136,8 +136,10 @@ static SortGeom sort_geom(uint64_t n) {
 size_t sort_table_elems(uint64_t n) { return 256ull * SORT_MAX_BLOCKS + 1; }
 
 __global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *__restrict__ key, int shift, uint64_t n,
-                                                               uint64_t chunk, uint32_t nb, uint32_t *__restrict__ table) {
+                                                               uint64_t chunk, uint32_t nb, uint32_t *__restrict__ table,
+                                                               const uint32_t *__restrict__ d_n) {
     __shared__ uint32_t s_hist[256];
+    if (d_n) n = *d_n;   // actual record count lives on the device; n passed by the host is only the geometry bound
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     uint64_t b = (uint64_t)blockIdx.x * chunk, e = b + chunk;
@@ -149,14 +151,17 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *_
 
 template <int NW, bool HASV>
 __global__ void __launch_bounds__(SORT_BLOCK) sort_scatter_kernel(SortBufs in, SortBufs out, int word, int shift, uint64_t n,
-                                                                  uint64_t chunk, uint32_t nb, const uint32_t *__restrict__ table) {
+                                                                  uint64_t chunk, uint32_t nb, const uint32_t *__restrict__ table,
+                                                                  const uint32_t *__restrict__ d_n) {
     __shared__ uint32_t s_base[256];
+    if (d_n) n = *d_n;
     __shared__ uint32_t s_slot[SORT_SLOTS][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     s_base[threadIdx.x] = table[(uint32_t)threadIdx.x * nb + blockIdx.x];
     uint64_t b = (uint64_t)blockIdx.x * chunk, e = b + chunk;
     if (e > n) e = n;
+    if (b > e) b = e;
     for (uint64_t tile = b; tile < e; tile += SORT_TILE) {
 #pragma unroll
         for (int s = 0; s < SORT_SLOTS; ++s) s_slot[s][threadIdx.x] = 0;
@@ -216,13 +221,14 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_scatter_kernel(SortBufs in, S
 }
 
 template <int NW>
-static void launch_scatter(Ctx *ctx, SortBufs in, SortBufs out, int word, int shift, uint64_t n, SortGeom g, const uint32_t *table) {
-    if (in.v) hipLaunchKernelGGL((sort_scatter_kernel<NW, true>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table);
-    else hipLaunchKernelGGL((sort_scatter_kernel<NW, false>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table);
+static void launch_scatter(Ctx *ctx, SortBufs in, SortBufs out, int word, int shift, uint64_t n, SortGeom g, const uint32_t *table,
+                           const uint32_t *d_n) {
+    if (in.v) hipLaunchKernelGGL((sort_scatter_kernel<NW, true>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table, d_n);
+    else hipLaunchKernelGGL((sort_scatter_kernel<NW, false>), dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, in, out, word, shift, n, g.chunk, g.nb, table, d_n);
 }
 
 int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *passes, int n_passes, uint32_t *d_table,
-               uint32_t *d_scan_tmp, bool *result_in_b) {
+               uint32_t *d_scan_tmp, bool *result_in_b, const uint32_t *d_n) {
     *result_in_b = false;
     if (n == 0 || n_passes == 0) return 0;
     if (n >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "radix_sort: %llu records exceed 32-bit positions", (unsigned long long)n);
@@ -232,7 +238,7 @@ int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *pas
     KTimer t(ctx, "radix_sort");
     for (int p = 0; p < n_passes; ++p) {
         int word = passes[p].word, shift = passes[p].shift;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table, d_n);
         uint64_t tn = 256ull * g.nb;
         // in-place exclusive scan of the digit-major table
         uint32_t nbk = (uint32_t)((tn + SCAN_TILE - 1) / SCAN_TILE);
@@ -240,9 +246,9 @@ int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *pas
         hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_scan_tmp, nbk, (uint32_t *)nullptr);
         hipLaunchKernelGGL((scan_apply_kernel<uint32_t>), dim3(nbk), dim3(SCAN_BLOCK), 0, ctx->stream, d_table, d_table, tn, d_scan_tmp);
         switch (cur.nw) {
-        case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table); break;
-        case 2: launch_scatter<2>(ctx, cur, nxt, word, shift, n, g, d_table); break;
-        default: launch_scatter<3>(ctx, cur, nxt, word, shift, n, g, d_table); break;
+        case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
+        case 2: launch_scatter<2>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
+        default: launch_scatter<3>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
         }
         SortBufs tmp = cur; cur = nxt; nxt = tmp;
         in_b = !in_b;

@@ -26,8 +26,10 @@ struct SortPass {
 // Stable LSD radix sort: passes[0] is the LEAST significant digit.  Ping-pongs between a and b;
 // returns (via *result_in_b) which side holds the sorted records.  d_table: >= sort_table_elems(n) u32.
 size_t sort_table_elems(uint64_t n);
+// d_n (optional): the actual record count on the device (<= n); n then only fixes the launch geometry, so the
+// caller never has to read the count back.
 int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *passes, int n_passes, uint32_t *d_table,
-               uint32_t *d_scan_tmp, bool *result_in_b);
+               uint32_t *d_scan_tmp, bool *result_in_b, const uint32_t *d_n = nullptr);
 
 // helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
 inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {

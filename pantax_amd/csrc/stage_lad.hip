@@ -88,13 +88,11 @@ __device__ __forceinline__ uint32_t wave_bound(const double *__restrict__ a, uin
     if (lo + lane < hi) { const double x = a[lo + lane]; before = upper ? (x <= v) : (x < v); }
     return lo + (uint32_t)__popcll(__ballot(before));
 }
-template <bool COOP>
-__device__ __forceinline__ uint32_t lb(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
-    return COOP ? wave_bound(a, lo, hi, v, false) : lower_bound_a(a, lo, hi, v);
+__device__ __forceinline__ uint32_t lb(bool coop, const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    return coop ? wave_bound(a, lo, hi, v, false) : lower_bound_a(a, lo, hi, v);
 }
-template <bool COOP>
-__device__ __forceinline__ uint32_t ub_(const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
-    return COOP ? wave_bound(a, lo, hi, v, true) : upper_bound_a(a, lo, hi, v);
+__device__ __forceinline__ uint32_t ub_(bool coop, const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
+    return coop ? wave_bound(a, lo, hi, v, true) : upper_bound_a(a, lo, hi, v);
 }
 
 __device__ __forceinline__ double mdot(uint64_t m, const double *x) {   // ascending-bit order
@@ -308,18 +306,22 @@ __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, c
         k2[j] = (uint64_t)__double_as_longlong(ab[v]);   // positive doubles order like their bit patterns
     }
 }
-__global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t n, const uint64_t *__restrict__ k0, const uint64_t *__restrict__ k1,
-                                                       uint8_t *__restrict__ head) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        head[i] = (i == 0 || k0[i] != k0[i - 1] || k1[i] != k1[i - 1]) ? 1 : 0;
+__global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t bound, const uint32_t *__restrict__ d_n, const uint64_t *__restrict__ k0,
+                                                       const uint64_t *__restrict__ k1, uint8_t *__restrict__ head) {
+    const uint64_t n = *d_n;   // rows actually present; the flags past n are zero so the scan over `bound` is exact
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < bound; i += (uint64_t)gridDim.x * 256)
+        head[i] = (i < n && (i == 0 || k0[i] != k0[i - 1] || k1[i] != k1[i - 1])) ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) pat_emit_kernel(uint64_t n, const uint64_t *__restrict__ k0, const uint64_t *__restrict__ k1,
-                                                       const uint8_t *__restrict__ head, const uint32_t *__restrict__ pidx,
-                                                       uint64_t *__restrict__ pat_mask, uint32_t *__restrict__ pat_start,
-                                                       uint32_t *__restrict__ pat_species) {
+__global__ void __launch_bounds__(256) pat_emit_kernel(const uint32_t *__restrict__ d_n, uint32_t k_cap, const uint64_t *__restrict__ k0,
+                                                       const uint64_t *__restrict__ k1, const uint8_t *__restrict__ head,
+                                                       const uint32_t *__restrict__ pidx, uint64_t *__restrict__ pat_mask,
+                                                       uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species,
+                                                       uint32_t *__restrict__ overflow) {
+    const uint64_t n = *d_n;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         if (!head[i]) continue;
         uint32_t j = pidx[i];
+        if (j >= k_cap) { *overflow = 1; continue; }   // more patterns than this build sizes for: reported as PANTAX_HIP_E_LIMIT
         pat_mask[j] = k1[i];
         pat_start[j] = (uint32_t)i;
         pat_species[j] = (uint32_t)k0[i];
@@ -327,36 +329,36 @@ __global__ void __launch_bounds__(256) pat_emit_kernel(uint64_t n, const uint64_
 }
 
 // species -> first pattern (patterns are sorted by species); entry S = K; also closes pat_start[K] = n_rows
-__global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint32_t *__restrict__ d_K, const uint32_t *__restrict__ pat_species,
-                                                         uint32_t n_rows, uint32_t *__restrict__ pat_start, uint32_t *__restrict__ sp_pat_off) {
+__global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint32_t *__restrict__ d_K, uint32_t k_cap,
+                                                         const uint32_t *__restrict__ pat_species, const uint32_t *__restrict__ d_n,
+                                                         uint32_t *__restrict__ pat_start, uint32_t *__restrict__ sp_pat_off) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s > S) return;
-    const uint32_t K = *d_K;
+    const uint32_t K = min(*d_K, k_cap), n_rows = *d_n;
     uint32_t lo = 0, hi = K;   // first pattern with species >= s
     while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (pat_species[m] < s) lo = m + 1; else hi = m; }
     sp_pat_off[s] = (s == S) ? K : lo;
     if (s == S) pat_start[K] = n_rows;
 }
 
-int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
+// All of it is enqueued without a host round trip: the row count n and the pattern count K stay on the
+// device (lb->d_counts = {n_rows, K, overflow}); buffers are sized by their host-known bounds (n <= V,
+// K <= k_cap).  cand_on_device: lb->d_hap_bit / d_p were written by first_filter_kernel; otherwise they are
+// uploaded from lb->h_p / h_cand (solver seam).  pmax_bound = upper bound of candidates per species.
+int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int pmax_bound) {
     const uint32_t S = db->S;
     const uint64_t V = db->V, H = db->H;
-    // candidate bit per hap
-    std::vector<int32_t> hap_bit(H ? H : 1, -1);
-    int pmax = 0;
-    for (uint32_t s = 0; s < S; ++s) {
-        pmax = std::max(pmax, lb->h_p[s]);
-        for (int k = 0; k < lb->h_p[s]; ++k) hap_bit[db->h_hap_off[s] + lb->h_cand[(size_t)s * LAD_MAXP + k]] = k;
+    if (!cand_on_device) {
+        std::vector<int32_t> hap_bit(H ? H : 1, -1);
+        for (uint32_t s = 0; s < S; ++s)
+            for (int k = 0; k < lb->h_p[s]; ++k) hap_bit[db->h_hap_off[s] + lb->h_cand[(size_t)s * LAD_MAXP + k]] = k;
+        PTX_TRY(upload(ctx, lb->d_hap_bit, hap_bit.data(), hap_bit.size()));
+        PTX_TRY(upload(ctx, lb->d_p, lb->h_p.data(), S));
     }
-    PTX_TRY(upload(ctx, lb->d_hap_bit, hap_bit.data(), hap_bit.size()));
-    PTX_TRY(upload(ctx, lb->d_p, lb->h_p.data(), S));
     PTX_HIP(ctx, lb->d_mask.alloc(V));
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
     PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(lb->d_ratio.p, 0, (size_t)S * LAD_MAXP * 2 * sizeof(unsigned long long), ctx->stream));
-    lb->n_rows = 0; lb->K = 0;
-    lb->h_sp_pat_off.assign(S + 1, 0);
-    if (pmax == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
+    // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
     {
         KTimer t(ctx, "mask_kernel");
         if (db->n_tiles)
@@ -371,24 +373,20 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     // rows: flag -> scan -> emit -> sort by (species, mask, a)
     Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
     DevBuf<uint8_t> &flag = dbm->d_row_flag;
-    DevBuf<uint32_t> &pos = dbm->d_row_pos, &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table, &d_tot = dbm->d_tot2;
+    DevBuf<uint32_t> &pos = dbm->d_row_pos, &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, flag.alloc(V)); PTX_HIP(ctx, pos.alloc(V));
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
-    PTX_HIP(ctx, d_tot.alloc(2));
+    PTX_HIP(ctx, lb->d_counts.alloc(4));
+    uint32_t *d_n = lb->d_counts.p, *d_K = lb->d_counts.p + 1, *d_ovf = lb->d_counts.p + 2;
     int gridV = grid_for(V, 256, ctx->n_cu * 8);
     {
         KTimer t(ctx, "row_flag_kernel");
         hipLaunchKernelGGL(row_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, lb->d_ab.p, (unsigned long long *)lb->d_mask.p, flag.p);
     }
-    PTX_TRY(exclusive_scan_u8(ctx, flag.p, pos.p, V, scan_tmp.p, d_tot.p));
-    uint32_t n_rows = 0;
-    PTX_TRY(download(ctx, &n_rows, d_tot.p, 1));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    lb->n_rows = n_rows;
-    if (n_rows == 0) { PTX_TRY(upload(ctx, lb->d_sp_pat_off, lb->h_sp_pat_off.data(), S + 1)); return 0; }
+    PTX_TRY(exclusive_scan_u8(ctx, flag.p, pos.p, V, scan_tmp.p, d_n));
     DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
-    for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(n_rows)); PTX_HIP(ctx, kb[w].alloc(n_rows)); }
+    for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); PTX_HIP(ctx, kb[w].alloc(V)); }
     {
         KTimer t(ctx, "row_emit_kernel");
         hipLaunchKernelGGL(row_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
@@ -396,36 +394,124 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb) {
     }
     std::vector<SortPass> passes;
     add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
-    add_passes(passes, 1, 0, pmax);                    // mask bits in use
+    add_passes(passes, 1, 0, pmax_bound);              // mask bits that can be in use
     if (S > 1) add_passes(passes, 0, 0, bits_for(S - 1));
     SortBufs A, B;
     A.nw = B.nw = 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
     bool in_b = false;
-    PTX_TRY(radix_sort(ctx, A, B, n_rows, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b));
+    PTX_TRY(radix_sort(ctx, A, B, V, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b, d_n));
     SortBufs Sd = in_b ? B : A;
+    lb->row_a = reinterpret_cast<const double *>(Sd.k[2]);   // sorted abundances, used in place
     // patterns = runs of equal (species, mask)
     DevBuf<uint8_t> &head = dbm->d_pat_head;
     DevBuf<uint32_t> &pidx = dbm->d_pat_idx;
-    PTX_HIP(ctx, head.alloc(n_rows)); PTX_HIP(ctx, pidx.alloc(n_rows));
-    int gridN = grid_for(n_rows, 256, ctx->n_cu * 8);
-    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p);
-    PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, n_rows, scan_tmp.p, d_tot.p + 1));
-    // #patterns K <= n_rows: size the pattern arrays for the bound so that K need not be read back first
-    PTX_HIP(ctx, lb->d_pat_mask.alloc(n_rows)); PTX_HIP(ctx, lb->d_pat_start.alloc((size_t)n_rows + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(n_rows));
-    hipLaunchKernelGGL(pat_emit_kernel, dim3(gridN), dim3(256), 0, ctx->stream, (uint64_t)n_rows, Sd.k[0], Sd.k[1], head.p, pidx.p,
-                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p);
+    PTX_HIP(ctx, head.alloc(V)); PTX_HIP(ctx, pidx.alloc(V));
+    const uint64_t k_cap = std::min<uint64_t>(V, (uint64_t)S * 8192 + 65536);
+    lb->k_cap = (uint32_t)k_cap;
+    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, d_n, Sd.k[0], Sd.k[1], head.p);
+    PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, V, scan_tmp.p, d_K));
+    PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
+    hipLaunchKernelGGL(pat_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, d_n, (uint32_t)k_cap, Sd.k[0], Sd.k[1], head.p, pidx.p,
+                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf);
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
-    hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_tot.p + 1, lb->d_pat_species.p, n_rows,
+    hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
                        lb->d_pat_start.p, lb->d_sp_pat_off.p);
-    PTX_HIP(ctx, lb->d_row_a.alloc(n_rows));
-    PTX_HIP(ctx, hipMemcpyAsync(lb->d_row_a.p, Sd.k[2], (size_t)n_rows * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    PTX_TRY(download(ctx, lb->h_sp_pat_off.data(), lb->d_sp_pat_off.p, S + 1));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t K = lb->h_sp_pat_off[S];
-    lb->K = K;
-    PTX_HIP(ctx, lb->d_pat_eps.alloc(K)); PTX_HIP(ctx, lb->d_sc_s.alloc(K)); PTX_HIP(ctx, lb->d_sc_rho.alloc(K));
-    PTX_HIP(ctx, lb->d_sc_lo.alloc(K)); PTX_HIP(ctx, lb->d_sc_up.alloc(K)); PTX_HIP(ctx, lb->d_ls_lo.alloc(K)); PTX_HIP(ctx, lb->d_ls_hi.alloc(K)); PTX_HIP(ctx, lb->d_ls_mid.alloc(K));
+    PTX_HIP(ctx, lb->d_pat_eps.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_s.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_rho.alloc(k_cap));
+    PTX_HIP(ctx, lb->d_sc_lo.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_up.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_lo.alloc(k_cap));
+    PTX_HIP(ctx, lb->d_ls_hi.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_mid.alloc(k_cap));
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9 / a13 decisions on the device, so that the strain step never waits for the host between its stages.
+// Same arithmetic as the host reporting code in api_strain.cpp (IEEE f64, no contraction-sensitive forms).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_round2(double x) { return round(x * 100.0) / 100.0; }   // f64::round: half away from zero
+
+// first_filter_paths (profile.rs:1080-1227): which haplotypes become LP columns.  One thread per species.
+__global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint8_t *__restrict__ active, const uint64_t *__restrict__ hap_off,
+                                                          const uint64_t *__restrict__ hto, const uint32_t *__restrict__ nnz,
+                                                          const double *__restrict__ meanf, const uint8_t *__restrict__ all_same, double fr,
+                                                          int shift, int32_t *__restrict__ hap_bit, int32_t *__restrict__ sp_p) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    const uint64_t h0 = hap_off[s], h1 = hap_off[s + 1];
+    for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1;
+    int p = 0;
+    if (h1 > h0 && !(active && !active[s])) {
+        const uint64_t Hs = h1 - h0, Us = hto[h1] - hto[h0];
+        if (Hs != 1 && Us != 0) {                                          // :1098
+            for (uint64_t h = h0; h < h1; ++h) {
+                const uint64_t nt = hto[h + 1] - hto[h];
+                if (nt == 0) continue;                                     // :1119
+                const double frac = (double)nnz[h] / (double)nt;           // :1135
+                const double fm = meanf[h];
+                if (shift) {                                               // :1140-1165
+                    double sh;
+                    if (fm >= 1.0) { sh = fr + (0.8 - fr) * fm / 100.0; if (sh > 0.8) sh = 0.8; } else sh = fr * fm;
+                    if (frac < sh) continue;
+                } else if (frac < fr) continue;                            // :1168
+                if (p < LAD_MAXP) hap_bit[h] = p;
+                ++p;
+            }
+        } else if (Hs == 1 || all_same[s]) { hap_bit[h0] = 0; p = 1; }     // :1191-1205, :1211-1224
+        else { for (uint64_t h = h0; h < h1; ++h) { if (p < LAD_MAXP) hap_bit[h] = p; ++p; } }   // :1208
+        if (p > LAD_MAXP) { for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1; p = -p; }   // this build: <= 64 columns; species fails
+    }
+    sp_p[s] = p;
+}
+
+// second_filter_paths (profile.rs:1229-1285): which columns are pinned to zero in the second solve
+__global__ void __launch_bounds__(64) second_filter_kernel(uint32_t S, const uint64_t *__restrict__ hap_off, const uint64_t *__restrict__ hto,
+                                                           const int32_t *__restrict__ hap_bit, const int32_t *__restrict__ sp_p,
+                                                           const uint32_t *__restrict__ nnz, const double *__restrict__ meanf,
+                                                           const unsigned long long *__restrict__ ratio, const double *__restrict__ x1,
+                                                           const int32_t *__restrict__ status1, double fc, double sr,
+                                                           uint8_t *__restrict__ fixed2, uint8_t *__restrict__ need2) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    const uint64_t h0 = hap_off[s], h1 = hap_off[s + 1];
+    uint8_t need = 0;
+    for (int k = 0; k < LAD_MAXP; ++k) fixed2[(size_t)s * LAD_MAXP + k] = 0;
+    if (sp_p[s] > 0 && status1[s] == 0 && (h1 - h0) != 1 && hto[h1] - hto[h0] > 0) {
+        for (uint64_t h = h0; h < h1; ++h) {
+            const int k = hap_bit[h];
+            if (k < 0) continue;
+            const double fm = meanf[h];
+            bool keep = false;
+            if (fm != 0.0) {                                               // :1238
+                const double sol = x1[(size_t)s * LAD_MAXP + k];
+                const double f = d_round2(fabs(sol - fm) / (sol + fm));
+                if (f > fc) {
+                    if (f <= 0.6) {
+                        const double frac_r = d_round2((double)nnz[h] / (double)(hto[h + 1] - hto[h]));
+                        const float cov = (float)ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+                        const double sc = frac_r * (double)(cov / len);
+                        if (!(sc < sr || sol == 0.0)) keep = true;         // rescue
+                    }
+                } else if (sol != 0.0) keep = true;
+            }
+            if (!keep) { fixed2[(size_t)s * LAD_MAXP + k] = 1; need = 1; }
+        }
+    }
+    need2[s] = need;
+}
+
+int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc) {
+    const uint32_t S = db->S;
+    PTX_HIP(ctx, lb->d_hap_bit.alloc(db->H)); PTX_HIP(ctx, lb->d_p.alloc(S));
+    hipLaunchKernelGGL(first_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, d_active, db->d_hap_off.p, db->d_hap_trio_off.p,
+                       db->d_hap_nnz.p, db->d_hap_mean.p, db->d_all_same.p, fc.fr, fc.shift, lb->d_hap_bit.p, lb->d_p.p);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
+                         uint8_t *d_fixed2, uint8_t *d_need2) {
+    const uint32_t S = db->S;
+    hipLaunchKernelGGL(second_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, db->d_hap_off.p, db->d_hap_trio_off.p,
+                       lb->d_hap_bit.p, lb->d_p.p, db->d_hap_nnz.p, db->d_hap_mean.p, lb->d_ratio.p, d_x1, d_status1, fc.fc, fc.sr, d_fixed2, d_need2);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -444,11 +530,11 @@ struct LadArgs {
     double *pat_eps, *sc_s, *sc_rho;
     uint32_t *sc_lo, *sc_up, *ls_lo, *ls_hi, *ls_mid;
     const int32_t *sp_p;
-    const double *ub;
+    const uint8_t *need;    // [S] or null: solve only species with need[s] != 0
+    const uint8_t *fixed;   // [S*LAD_MAXP] or null: variables pinned to zero
     const double *amax;
     double *x_out;
     int32_t *status, *iters;
-    const int32_t *solve_list;
 };
 
 struct LadShared {
@@ -466,27 +552,29 @@ struct LadShared {
 };
 
 // number of breakpoints of pattern k crossed when moving t along the search direction
-template <bool COOP>
-__device__ __forceinline__ uint32_t crossed(const double *__restrict__ a, double rho, double s0, double eps, uint32_t st, uint32_t en,
+__device__ __forceinline__ uint32_t crossed(bool COOP, const double *__restrict__ a, double rho, double s0, double eps, uint32_t st, uint32_t en,
                                             uint32_t lo, uint32_t up, double t, uint32_t c_lo, uint32_t c_hi) {
     double sv = s0 - eps + t * rho;
-    if (rho > 0) return ub_<COOP>(a, up + c_lo, up + c_hi, sv) - up;           // rows a_i <= sv among [up,en)
-    return lo - lb<COOP>(a, lo - c_hi, lo - c_lo, sv);                         // rows a_i >= sv among [st,lo)
+    if (rho > 0) return ub_(COOP, a, up + c_lo, up + c_hi, sv) - up;           // rows a_i <= sv among [up,en)
+    return lo - lb(COOP, a, lo - c_hi, lo - c_lo, sv);                         // rows a_i >= sv among [st,lo)
 }
 
-// COOP = few patterns: every wave owns whole patterns (its 64 lanes search cooperatively, lane 0 is the
-// "leader" that accumulates and stores); otherwise one thread per pattern with scalar binary searches.
+// COOP (per species, block-uniform) = few patterns: every wave owns whole patterns (its 64 lanes search
+// cooperatively, lane 0 is the "leader" that accumulates); otherwise one thread per pattern with scalar searches.
 #define PAT_LOOP(k) for (uint32_t k = k0 + (COOP ? (uint32_t)(tid >> 6) : (uint32_t)tid); k < k1; k += (COOP ? LAD_BLOCK / 64 : LAD_BLOCK))
-template <int PS, bool COOP>
+template <int PS>
 __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     __shared__ LadShared sh;
     __shared__ double W[PS * PS];
     __shared__ double G[PS * 2 * PS];
     const int tid = threadIdx.x;
-    const bool leader = COOP ? ((tid & 63) == 0) : true;
-    const int s = A.solve_list[blockIdx.x];
+    const int s = blockIdx.x;   // one workgroup per species of the db; species without work leave at once
     const int p = A.sp_p[s];
+    if (A.need && !A.need[s]) return;
+    if (p <= 0) { if (tid == 0) { A.status[s] = 0; A.iters[s] = 0; } return; }
     const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
+    const bool COOP = (k1 - k0) <= 16;
+    const bool leader = COOP ? ((tid & 63) == 0) : true;
     const double *__restrict__ ra = A.row_a;
     const double tol = 1e-7;
     const double amax = A.amax[s];
@@ -494,7 +582,8 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK)
         A.pat_eps[kk] = delta * (0.25 + 0.5 * (double)(splitmix64(A.pat_mask[kk]) >> 11) * (1.0 / 9007199254740992.0));
     if (tid < p) {
-        double u = A.ub[(size_t)s * LAD_MAXP + tid];
+        // box: 0 <= x <= 1.05 * max(a) (profile.rs:1327); pinned to 0 in the second solve (:1484-1488)
+        double u = (A.fixed && A.fixed[(size_t)s * LAD_MAXP + tid]) ? 0.0 : 1.05 * A.amax[s];
         sh.ub[tid] = u;
         sh.act_type[tid] = u > 0.0 ? C_LB : C_FIXED;
         sh.act_jk[tid] = tid;
@@ -530,8 +619,8 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             else {
                 sk = mdot(mk, sh.x);
                 double sv = sk - A.pat_eps[k];
-                lo = lb<COOP>(ra, st, en, sv);
-                up = ub_<COOP>(ra, lo, en, sv);
+                lo = lb(COOP, ra, st, en, sv);
+                up = ub_(COOP, ra, lo, en, sv);
             }
             A.sc_s[k] = sk; A.sc_lo[k] = lo; A.sc_up[k] = up;
             long long sigma = (long long)(lo - st) - (long long)(en - up);
@@ -622,7 +711,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     if (rho == 0.0) continue;
                     uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
                     uint32_t cmax = rho > 0 ? en - A.sc_up[k] : A.sc_lo[k] - st;
-                    uint32_t c = crossed<COOP>(ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
+                    uint32_t c = crossed(COOP, ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
                     A.ls_hi[k] = c;
                     if (leader) acc += fabs(rho) * 2.0 * (double)c;
                 }
@@ -689,7 +778,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     PAT_LOOP(k) {
                         double rho = A.sc_rho[k];
                         if (rho == 0.0) continue;
-                        uint32_t c = crossed<COOP>(ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
+                        uint32_t c = crossed(COOP, ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
                                              t_mid, A.ls_lo[k], A.ls_hi[k]);
                         A.ls_mid[k] = c;
                         if (leader) acc += fabs(rho) * 2.0 * (double)c;
@@ -813,12 +902,14 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
 }
 
 // objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450)
-__global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ solve_list, const uint32_t *__restrict__ node_base,
-                                                        const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
-                                                        const double *__restrict__ x, double *__restrict__ part) {
+__global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need,
+                                                        const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
+                                                        const unsigned long long *__restrict__ mask, const double *__restrict__ x,
+                                                        double *__restrict__ part) {
     __shared__ double red[4];
     __shared__ double xs[LAD_MAXP];
-    const int s = solve_list[blockIdx.x / STAT_CHUNKS];
+    const int s = blockIdx.x / STAT_CHUNKS;
+    if (sp_p[s] <= 0 || (need && !need[s])) return;
     const uint32_t ch = blockIdx.x % STAT_CHUNKS;
     if (threadIdx.x < LAD_MAXP) xs[threadIdx.x] = x[(size_t)s * LAD_MAXP + threadIdx.x];
     __syncthreads();
@@ -834,47 +925,36 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
     acc = block_sum_f64<256>(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ void __launch_bounds__(64) objective_final_kernel(uint32_t n, const int32_t *__restrict__ solve_list, const double *__restrict__ part,
-                                                             const uint32_t *__restrict__ nvalid, double *__restrict__ obj) {
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const int s = solve_list[i];
+__global__ void __launch_bounds__(64) objective_final_kernel(uint32_t S, const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need,
+                                                             const double *__restrict__ part, const uint32_t *__restrict__ nvalid,
+                                                             double *__restrict__ obj) {
+    uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S || sp_p[s] <= 0 || (need && !need[s])) return;
     double acc = 0.0;
-    for (int c = 0; c < STAT_CHUNKS; ++c) acc += part[(size_t)i * STAT_CHUNKS + c];
+    for (int c = 0; c < STAT_CHUNKS; ++c) acc += part[(size_t)s * STAT_CHUNKS + c];
     obj[s] = nvalid[s] ? acc / (double)nvalid[s] : 0.0;
 }
 
-int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, const std::vector<int32_t> &solve_list) {
-    uint32_t S = db->S;
-    PTX_HIP(ctx, lb->d_x.alloc((size_t)S * LAD_MAXP)); PTX_HIP(ctx, lb->d_obj.alloc(S));
-    PTX_HIP(ctx, lb->d_status.alloc(S)); PTX_HIP(ctx, lb->d_iters.alloc(S));
-    if (solve_list.empty()) return 0;
-    PTX_TRY(upload(ctx, lb->d_solve_list, solve_list.data(), solve_list.size()));
-    int pmax = 0;
-    for (int32_t s : solve_list) pmax = std::max(pmax, lb->h_p[s]);
+int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
+                     double *d_obj, int32_t *d_status, int32_t *d_iters) {
+    const uint32_t S = db->S;
     LadArgs A;
-    A.row_a = lb->d_row_a.p; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
+    A.row_a = lb->row_a; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
     A.pat_eps = lb->d_pat_eps.p; A.sc_s = lb->d_sc_s.p; A.sc_rho = lb->d_sc_rho.p;
     A.sc_lo = lb->d_sc_lo.p; A.sc_up = lb->d_sc_up.p; A.ls_lo = lb->d_ls_lo.p; A.ls_hi = lb->d_ls_hi.p; A.ls_mid = lb->d_ls_mid.p;
-    A.sp_p = lb->d_p.p; A.ub = lb->d_ub.p; A.amax = lb->d_amax.p; A.x_out = lb->d_x.p; A.status = lb->d_status.p; A.iters = lb->d_iters.p;
-    A.solve_list = lb->d_solve_list.p;
+    A.sp_p = lb->d_p.p; A.need = d_need; A.fixed = d_fixed; A.amax = lb->d_amax.p; A.x_out = d_x; A.status = d_status; A.iters = d_iters;
     {
         KTimer t(ctx, "lad_solve_kernel");
-        uint32_t kmax = 0;
-        for (int32_t sp : solve_list) kmax = std::max(kmax, lb->h_sp_pat_off[sp + 1] - lb->h_sp_pat_off[sp]);
-        const bool coop = kmax <= 16;   // few patterns: one wave per pattern with 64-ary cooperative searches
-        dim3 g((uint32_t)solve_list.size()), b(LAD_BLOCK);
-        if (pmax <= 16) { if (coop) hipLaunchKernelGGL((lad_solve_kernel<16, true>), g, b, 0, ctx->stream, A); else hipLaunchKernelGGL((lad_solve_kernel<16, false>), g, b, 0, ctx->stream, A); }
-        else { if (coop) hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, true>), g, b, 0, ctx->stream, A); else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, false>), g, b, 0, ctx->stream, A); }
+        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
     }
     {
         KTimer t(ctx, "objective_kernel");
-        uint32_t ns = (uint32_t)solve_list.size();
-        PTX_HIP(ctx, lb->d_partial.alloc(std::max<size_t>((size_t)S * STAT_CHUNKS * 4, (size_t)ns * STAT_CHUNKS)));
-        hipLaunchKernelGGL(objective_kernel, dim3(ns * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_solve_list.p, db->d_node_base.p,
-                           lb->d_ab.p, (unsigned long long *)lb->d_mask.p, lb->d_x.p, lb->d_partial.p);
-        hipLaunchKernelGGL(objective_final_kernel, dim3((ns + 63) / 64), dim3(64), 0, ctx->stream, ns, lb->d_solve_list.p, lb->d_partial.p,
-                           lb->d_nvalid.p, lb->d_obj.p);
+        PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
+        hipLaunchKernelGGL(objective_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_p.p, d_need, db->d_node_base.p, lb->d_ab.p,
+                           (unsigned long long *)lb->d_mask.p, d_x, lb->d_partial.p);
+        hipLaunchKernelGGL(objective_final_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, lb->d_p.p, d_need, lb->d_partial.p,
+                           lb->d_nvalid.p, d_obj);
     }
     PTX_HIP(ctx, hipGetLastError());
     return 0;
