@@ -190,7 +190,7 @@ int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hi
     PTX_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t S = db->S;
     DevBuf<unsigned long long> &d_cnt = const_cast<pantax_hip_db *>(db)->d_counters;
-    PTX_HIP(ctx, d_cnt.alloc(4ull * S));
+    PTX_HIP(ctx, d_cnt.alloc(33ull * 4 * S));   // final sums + 32 replicas (stage_bin.hip)
     PTX_TRY(bin_reads_launch(ctx, db, reads, d_cnt.p));
     std::vector<unsigned long long> h(4ull * S);
     PTX_TRY(download(ctx, h.data(), d_cnt.p, 4ull * S));

@@ -15,6 +15,7 @@ namespace ptx {
 
 constexpr int BIN_BLOCK = 256;
 constexpr int BIN_LDS_SPECIES = 1024;
+constexpr int BIN_REPL = 32;
 
 template <bool SORTED>
 __device__ __forceinline__ int find_species(uint32_t mn, uint32_t mx, const uint32_t *__restrict__ rs,
@@ -42,7 +43,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
     uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
     const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, const uint32_t *__restrict__ rs,
     const uint32_t *__restrict__ re, const uint32_t *__restrict__ ridx, int S, int32_t *__restrict__ species_out,
-    unsigned long long *__restrict__ counters /* [4][S]: read_count, base_sum, less_multi, uniq_count */) {
+    unsigned long long *__restrict__ counters_rep /* [BIN_REPL][4][S]: read_count, base_sum, less_multi, uniq_count */) {
+    // every workgroup ends with a handful of global atomics on the same few words; spreading the workgroups
+    // over BIN_REPL replicas keeps that tail from serialising (same-address atomics cost ~12 ns each)
+    unsigned long long *__restrict__ counters = counters_rep + (size_t)(blockIdx.x % BIN_REPL) * 4 * S;
     __shared__ unsigned int s_cnt[LDS_HIST ? 3 * BIN_LDS_SPECIES : 1];
     __shared__ unsigned long long s_base[LDS_HIST ? BIN_LDS_SPECIES : 1];
     if (LDS_HIST) {
@@ -127,11 +131,22 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
     }
 }
 
+__global__ void __launch_bounds__(256) bin_reduce_kernel(int n, const unsigned long long *__restrict__ rep, unsigned long long *__restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = 0;
+    for (int r = 0; r < BIN_REPL; ++r) s += rep[(size_t)r * n + i];
+    out[i] = s;
+}
+
+// d_counters: [(BIN_REPL + 1) * 4 * S]; the final sums land in the first 4*S words
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters) {
     int S = (int)db->S;
     PTX_HIP(ctx, rd->d_species.alloc(rd->R));
-    PTX_HIP(ctx, hipMemsetAsync(d_counters, 0, 4ull * S * sizeof(unsigned long long), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(d_counters, 0, (size_t)(BIN_REPL + 1) * 4 * S * sizeof(unsigned long long), ctx->stream));
     if (rd->R == 0) { rd->binned = true; return 0; }
+    unsigned long long *d_final = d_counters;
+    d_counters = d_counters + 4ull * S;   // replicas
     int grid = grid_for(rd->R, BIN_BLOCK, ctx->n_cu * 8);
     bool lds = S <= BIN_LDS_SPECIES;
     {
@@ -147,6 +162,7 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
         }
 #undef BIN_ARGS
     }
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3((4 * S + 255) / 256), dim3(256), 0, ctx->stream, 4 * S, d_counters, d_final);
     PTX_HIP(ctx, hipGetLastError());
     rd->binned = true;
     return 0;
