@@ -120,7 +120,7 @@ constexpr int SORT_BLOCK = 256;
 constexpr int SORT_ROUNDS = 4;                                  // 64-record rounds per wave per tile
 constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;             // 1024 records
 constexpr int SORT_SLOTS = (SORT_BLOCK / 64) * SORT_ROUNDS;     // (wave, round) slots per tile
-constexpr int SORT_MAX_BLOCKS = 2048;
+constexpr int SORT_MAX_BLOCKS = 2048;                            // = SORT_BLOCK * 8: one rowscan sweep
 
 struct SortGeom {
     uint32_t nb;
@@ -133,7 +133,7 @@ static SortGeom sort_geom(uint64_t n) {
     uint64_t tiles_per_block = (tiles + nb - 1) / nb;
     return {nb, tiles_per_block * SORT_TILE};
 }
-size_t sort_table_elems(uint64_t n) { return 256ull * SORT_MAX_BLOCKS + 1; }
+size_t sort_table_elems(uint64_t n) { return 256ull * (SORT_MAX_BLOCKS + 1); }
 
 __global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *__restrict__ key, int shift, uint64_t n,
                                                                uint64_t chunk, uint32_t nb, uint32_t *__restrict__ table,
@@ -149,6 +149,23 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *_
     table[(uint32_t)threadIdx.x * nb + blockIdx.x] = s_hist[threadIdx.x];
 }
 
+// One workgroup per digit: exclusive scan of that digit's row of per-block counts (nb <= 2048 = one 8-item sweep)
+// and the digit total; the scatter kernel turns the 256 totals into digit bases itself.  Two launches fewer per
+// pass than a generic scan of the whole table.
+__global__ void __launch_bounds__(SORT_BLOCK) sort_rowscan_kernel(uint32_t *__restrict__ table, uint32_t nb) {
+    __shared__ uint32_t s_wave[SORT_BLOCK / 64];
+    uint32_t *row = table + (size_t)blockIdx.x * nb;
+    const uint32_t b = threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (b + i < nb) ? row[b + i] : 0; s += v[i]; }
+    uint32_t tot;
+    uint32_t off = block_excl_scan<SORT_BLOCK>(s, s_wave, &tot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (b + i < nb) row[b + i] = off; off += v[i]; }
+    if (threadIdx.x == 0) table[(size_t)256 * nb + blockIdx.x] = tot;
+}
+
 template <int NW, bool HASV>
 __global__ void __launch_bounds__(SORT_BLOCK) sort_scatter_kernel(SortBufs in, SortBufs out, int word, int shift, uint64_t n,
                                                                   uint64_t chunk, uint32_t nb, const uint32_t *__restrict__ table,
@@ -158,7 +175,12 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_scatter_kernel(SortBufs in, S
     __shared__ uint32_t s_slot[SORT_SLOTS][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    s_base[threadIdx.x] = table[(uint32_t)threadIdx.x * nb + blockIdx.x];
+    {
+        __shared__ uint32_t s_wave[SORT_BLOCK / 64];
+        uint32_t tot;
+        uint32_t digit_base = block_excl_scan<SORT_BLOCK>(table[(size_t)256 * nb + threadIdx.x], s_wave, &tot);
+        s_base[threadIdx.x] = digit_base + table[(uint32_t)threadIdx.x * nb + blockIdx.x];
+    }
     uint64_t b = (uint64_t)blockIdx.x * chunk, e = b + chunk;
     if (e > n) e = n;
     if (b > e) b = e;
@@ -239,12 +261,7 @@ int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *pas
     for (int p = 0; p < n_passes; ++p) {
         int word = passes[p].word, shift = passes[p].shift;
         hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table, d_n);
-        uint64_t tn = 256ull * g.nb;
-        // in-place exclusive scan of the digit-major table
-        uint32_t nbk = (uint32_t)((tn + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL((scan_reduce_kernel<uint32_t>), dim3(nbk), dim3(SCAN_BLOCK), 0, ctx->stream, d_table, tn, d_scan_tmp);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_scan_tmp, nbk, (uint32_t *)nullptr);
-        hipLaunchKernelGGL((scan_apply_kernel<uint32_t>), dim3(nbk), dim3(SCAN_BLOCK), 0, ctx->stream, d_table, d_table, tn, d_scan_tmp);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_table, g.nb);
         switch (cur.nw) {
         case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
         case 2: launch_scatter<2>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
