@@ -209,8 +209,12 @@ struct Reads {
     std::vector<int32_t> h_pre_species;   // first rows of species/qlen, fetched with the counters (equal-length test)
     std::vector<uint32_t> h_pre_qlen;
     // locus-grouped copy of the stream the coverage kernel walks (built once per upload)
-    DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_g_orig;   // [T] node ids, [T] slot of each step, [R'] slot -> original read
+    // Walks of at most 64 steps never straddle a 64-step boundary of the stream (pad steps carry slot 0xFFFFFFFF),
+    // so a wave of the coverage kernel always holds whole reads.
+    uint64_t T_pad = 0;              // steps in the padded stream
+    DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_slot_of;   // [T_pad] node ids, [T_pad] slot of each step, [R] read -> slot (~0: no walk)
     DevBuf<uint4> d_g_read_rec;      // [R'] {first step, #steps, pstart, pend}
+    DevBuf<int32_t> d_g_sp;          // [R'] species of the slot's read (-1: "U" or dropped row), written by the binning kernel
     bool binned = false;
 };
 

@@ -62,16 +62,6 @@ __device__ __forceinline__ void bitmap_or_range(uint32_t *__restrict__ bm, uint6
     }
 }
 
-__device__ __forceinline__ int trio_find(const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent, uint32_t gnode_a,
-                                         uint32_t b, uint32_t c) {
-    uint2 nd = trio_node[gnode_a];            // {first row, #rows}: usually 0-3 rows
-    for (uint32_t j = 0; j < nd.y; ++j) {
-        uint4 e = trio_ent[nd.x + j];
-        if (e.x == b && e.y == c) return (int)e.z;
-    }
-    return -1;
-}
-
 // read_nodes_len of position j (never the last position) recomputed from memory: the length aligned
 // at the node's FIRST occurrence in the read (profile.rs:879-882)
 __device__ __forceinline__ long long rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, uint32_t first_id,
@@ -86,90 +76,109 @@ __device__ __forceinline__ long long rl_from_memory(uint32_t j, uint32_t b, cons
 
 constexpr int COV_CHUNK = 1024;   // steps per workgroup
 constexpr int COV_WIN = 1024;     // nodes in the LDS window
-constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the chunk's first start node
+constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the node of the chunk's first live step
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
-__device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t *s_win, uint32_t wlo, uint32_t v, long long aln) {
+__device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t *s_win, uint32_t wlo, uint32_t win_n, uint32_t v,
+                                          long long aln) {
     const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
-    if (off < (uint32_t)COV_WIN && aln < (1ll << 18)) atomicAdd(&s_win[off], (uint32_t)aln);   // <= 8192 steps x 2^18 < 2^32
+    if (off < win_n && aln < (1ll << 18)) atomicAdd(&s_win[off], (uint32_t)aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
 }
 
-// Steps arrive grouped by the locus of their read's first node (group_reads below), so a workgroup's
+// Steps arrive grouped by the locus of their read's first node (build_step_read below), so a workgroup's
 // chunk of COV_CHUNK consecutive steps lands in a narrow node window: `bases` is accumulated in an LDS
 // window of COV_WIN nodes (32-bit LDS atomics) and flushed with one 64-bit global atomic per touched
 // node -- the LDS-staged segmented reduction of the scatter.  Nodes outside the window (or oversized
 // lengths) fall back to the global atomic; the result is identical either way.
+//
+// The kernel is latency-bound (a chain of dependent gathers per step), so the loads are ordered to keep
+// the chain short: {slot, node id} -> {read record, species of the slot} -> species tables (cached)
+// -> {node record, trio bucket head} -> {bitmap probe, trio entries}.  Walks of <= 64 steps never straddle
+// a wave (padded stream), so the memory fallbacks below run only for longer walks.
 template <bool WITH_TRIO>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
-    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ orig_read,
-    const uint32_t *__restrict__ node_id, const int32_t *__restrict__ species, const uint8_t *__restrict__ flags,
-    const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id, const uint32_t *__restrict__ node_base,
-    const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap,
-    const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
-    unsigned long long *__restrict__ n_abort) {
+    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
+    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
+    const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases,
+    uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
+    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort) {
     __shared__ uint32_t s_win[COV_WIN];
-    __shared__ uint32_t s_wlo;
     const int lane = threadIdx.x & 63;
     const uint64_t chunk_b = (uint64_t)blockIdx.x * COV_CHUNK;
     uint64_t chunk_e = chunk_b + COV_CHUNK;
     if (chunk_e > T) chunk_e = T;
     for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
-    // window base = global node index of the first node of the first LIVE read of the chunk
-    if (threadIdx.x == 0) {
-        uint32_t w = 0;
-        for (uint64_t t0 = chunk_b; t0 < chunk_e;) {
-            const uint32_t slot = step_read[t0];
-            const uint4 rr = read_rec[slot];
-            const uint32_t o = orig_read[slot];
-            const int sp0 = species[o];
-            if (sp0 >= 0 && !(active && !active[sp0]) && !(flags && flags[o])) {
-                const uint32_t id0 = node_id[rr.x], f0 = sp_first_id[sp0];
-                const uint32_t v0 = node_base[sp0] + (id0 >= f0 ? id0 - f0 : 0u);
-                w = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
-                break;
+    // window base: the node of the first live step among four probes of the chunk.  Every thread computes it
+    // (workgroup-uniform addresses), so nobody waits on a broadcast and the probes overlap the first gathers.
+    uint32_t wlo = 0, win_n = 0;
+#pragma unroll
+    for (int c = 0; c < COV_CHUNK / COV_BLOCK; ++c) {
+        const uint64_t tc = chunk_b + (uint64_t)c * COV_BLOCK;
+        if (win_n == 0 && tc < chunk_e) {
+            const uint32_t slot = step_read[tc];
+            if (slot != NO_SLOT) {
+                const int sp0 = slot_species[slot];
+                if (sp0 >= 0 && !(active && !active[sp0])) {
+                    const uint32_t id0 = node_id[tc], f0 = sp_first_id[sp0], nb0 = node_base[sp0];
+                    if (id0 >= f0 && id0 - f0 < node_base[sp0 + 1] - nb0) {
+                        const uint32_t v0 = nb0 + (id0 - f0);
+                        wlo = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
+                        win_n = COV_WIN;
+                    }
+                }
             }
-            t0 = (uint64_t)rr.x + rr.y;   // next read
         }
-        s_wlo = w;
     }
     __syncthreads();
-    const uint32_t wlo = s_wlo;
     for (uint64_t base = chunk_b + (threadIdx.x - lane); base < chunk_e; base += COV_BLOCK) {
         const uint64_t t = base + lane;
         bool ok = t < chunk_e;
-        uint32_t b = 0, k = 0, i = 0, id = 0, l = 0, v = 0, first_id = 0, nb = 0;
-        long long ps = 0, pe = 0, nl = 0;
-        uint64_t bo = 0;
+        uint32_t slot = NO_SLOT, id = 0;
+        if (ok) { slot = step_read[t]; id = node_id[t]; }
+        ok = ok && slot != NO_SLOT;
+        uint4 rr = make_uint4(0, 0, 0, 0);
+        int sp = -1;
+        if (ok) { rr = read_rec[slot]; sp = slot_species[slot]; }
+        ok = ok && sp >= 0 && !(active && !active[sp]);             // "U" / dropped rows / unselected species
+        const uint32_t b = rr.x, k = rr.y;
+        const long long ps = rr.z, pe = rr.w;
+        const uint32_t i = ok ? (uint32_t)(t - b) : 0u;
+        uint32_t l = 0, v = 0, first_id = 0, nb = 0;
         if (ok) {
-            const uint32_t slot = step_read[t];
-            const uint32_t o = orig_read[slot];
-            const int sp = species[o];
-            ok = sp >= 0 && !(active && !active[sp]) && !(flags && flags[o]);   // "U" / unselected species / dropped rows
-            if (ok) {
-                const uint4 rr = read_rec[slot];
-                b = rr.x; k = rr.y; ps = rr.z; pe = rr.w;
-                i = (uint32_t)(t - b);
-                id = node_id[t];
-                first_id = sp_first_id[sp]; nb = node_base[sp];
-                const uint32_t Vs = node_base[sp + 1] - nb;
-                if (id < first_id || id - first_id >= Vs) { atomicAdd(n_abort, 1ull); ok = false; }
-            }
-            if (ok) {
-                l = id - first_id; v = nb + l;
-                const uint4 nr = node_rec[v];
-                bo = ((uint64_t)nr.y << 32) | nr.x;
-                nl = (long long)nr.z;
-            }
+            first_id = sp_first_id[sp]; nb = node_base[sp];
+            const uint32_t Vs = node_base[sp + 1] - nb;
+            if (id < first_id || id - first_id >= Vs) { atomicAdd(n_abort, 1ull); ok = false; }
+            else { l = id - first_id; v = nb + l; }
         }
         const int dist = ok ? (int)min(i, (uint32_t)lane) : 0;   // earlier steps of my read held by lower lanes
+        const bool cross = ok && (int)i > lane;                   // the walk began before this wave (more than 64 steps)
+        // ---- gathers that only need (species, node): issued together
+        uint32_t l1 = __shfl_up(l, 1), l2 = __shfl_up(l, 2);
+        uint32_t tc_ = 0;
+        uint2 tn = make_uint2(0, 0);
+        if (WITH_TRIO && ok && i >= 2) {
+            if (lane < 1) l1 = node_id[b + i - 1] - first_id;
+            if (lane < 2) l2 = node_id[b + i - 2] - first_id;
+            uint32_t ta = l2; tc_ = l;
+            if (ta > tc_) { uint32_t tmp = ta; ta = tc_; tc_ = tmp; }
+            tn = trio_node[nb + ta];                              // {first row, #rows}: usually 0-3 rows
+        }
+        uint64_t bo = 0;
+        long long nl = 0;
+        if (ok) {
+            const uint4 nr = node_rec[v];
+            bo = ((uint64_t)nr.y << 32) | nr.x;
+            nl = (long long)nr.z;
+        }
         // first node length: from the lane that holds step b, else from memory
         const long long nl_src = __shfl(nl, lane - dist);
         long long len0 = nl;
-        if (ok && i > 0) len0 = ((int)i <= lane) ? nl_src : (long long)node_rec[nb + (node_id[b] - first_id)].z;
+        if (ok && i > 0) len0 = !cross ? nl_src : (long long)node_rec[nb + (node_id[b] - first_id)].z;
         const long long target = pe - ps;                         // profile.rs:800
         if (ok && k == 1) {                                       // :811
             if (target >= 0) {                                    // :821-827
-                if (target) add_bases(bases, s_win, wlo, v, target);
+                if (target) add_bases(bases, s_win, wlo, win_n, v, target);
                 if (ps < pe && pe <= nl) bitmap_or_range(bitmap, bo + ps, bo + pe);   // :832
             }
             ok = false;
@@ -195,7 +204,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         long long rl = 0;
         if (ok) {
             int jf = dmax ? (int)i - dmax : -1;
-            if ((int)i > lane) {                                  // the read began in the previous wave: finish from memory
+            if (cross) {                                          // finish from memory
                 const uint32_t nprev = i - (uint32_t)lane;
                 for (uint32_t j = 0; j < nprev; ++j) if (node_id[b + j] == id) { jf = (int)j; break; }
             }
@@ -203,7 +212,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
             else if (i == k - 1) {                                // :857-859
                 long long seen = incl - contrib;
-                if ((int)i > lane) {
+                if (cross) {
                     const uint32_t nprev = i - (uint32_t)lane;
                     seen += len0 - ps;
                     for (uint32_t j = 1; j < nprev; ++j) seen += (long long)node_rec[nb + (node_id[b + j] - first_id)].z;
@@ -216,18 +225,19 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             bitmap_or_range(bitmap, bo + sidx, bo + hi);
             if (jf < 0) {
                 rl = aln;
-                if (aln) add_bases(bases, s_win, wlo, v, aln);            // :881
+                if (aln) add_bases(bases, s_win, wlo, win_n, v, aln);     // :881
             } else rl = (jf == 0) ? (len0 - ps) : nl;
         }
         if (WITH_TRIO) {                                          // :890-907
-            uint32_t l1 = __shfl_up(l, 1), l2 = __shfl_up(l, 2);
             long long rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
             if (ok && i >= 2) {
-                if (lane < 1) { l1 = node_id[b + i - 1] - first_id; rl1 = rl_from_memory(i - 1, b, node_id, first_id, nb, node_rec, len0, ps); }
-                if (lane < 2) { l2 = node_id[b + i - 2] - first_id; rl2 = rl_from_memory(i - 2, b, node_id, first_id, nb, node_rec, len0, ps); }
-                uint32_t a = l2, c = l;
-                if (a > c) { uint32_t tmp = a; a = c; c = tmp; }
-                const int row = trio_find(trio_node, trio_ent, nb + a, l1, c);
+                if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, first_id, nb, node_rec, len0, ps);
+                if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, first_id, nb, node_rec, len0, ps);
+                int row = -1;
+                for (uint32_t j = 0; j < tn.y; ++j) {
+                    const uint4 e = trio_ent[tn.x + j];
+                    if (e.x == l1 && e.y == tc_) { row = (int)e.z; break; }
+                }
                 if (row >= 0) {
                     const long long sum = rl2 + rl1 + rl;
                     if (sum) atomicAdd(&trio_bases[row], (unsigned long long)sum);
@@ -236,69 +246,113 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
-        const uint32_t c = s_win[i];
-        if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
-    }
+    if (win_n)
+        for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
+            const uint32_t c = s_win[i];
+            if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Resident layout of the packed reads: grouped by the locus of their first node.  Key = first node
-// id >> shift (ids are globally ordered by species and position, sort_range.rs:25-33), counting sort
-// (histogram -> exclusive scans over reads and steps -> scatter) into {read_rec, orig_read, node_id,
-// step_read}.  Done once per upload: it depends on the reads only, not on the binning.  Slot order
-// inside a bucket is arbitrary; every output of the path is an order-independent integer sum, so
-// results stay bit-exact.  Reads with an empty walk own no step and are left out (profile.rs:794-796).
+// Resident layout of the packed reads: grouped by the locus of their first node and padded so that
+// a walk of <= 64 steps never straddles a 64-step boundary.  Key = first node id >> shift (ids are
+// globally ordered by species and position, sort_range.rs:25-33).  Counting sort of the reads into
+// slots (histogram -> scan -> scatter), then one thread per bucket lays its walks out (start moved to
+// the next multiple of 64 when the walk would straddle one; bucket sizes rounded up to 64), a scan of
+// the bucket sizes, and the fill.  Done once per upload: it depends on the reads only, not on the
+// binning.  Slot order inside a bucket is arbitrary; every output of the path is an order-independent
+// integer sum, so results stay bit-exact.  Reads with an empty walk own no slot (profile.rs:794-796).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) group_count_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
-                                                          int shift, uint32_t *__restrict__ cnt_r, uint32_t *__restrict__ cnt_s) {
+                                                          int shift, uint32_t *__restrict__ cnt_r) {
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
-        if (!k) continue;
-        const uint32_t key = node_id[b] >> shift;
-        atomicAdd(&cnt_r[key], 1u);
-        atomicAdd(&cnt_s[key], k);
+        if (k) atomicAdd(&cnt_r[node_id[b] >> shift], 1u);
     }
 }
-__global__ void __launch_bounds__(256) group_scatter_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
-                                                            const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, int shift,
-                                                            const uint32_t *__restrict__ base_r, const uint32_t *__restrict__ base_s,
-                                                            uint32_t *__restrict__ cur_r, uint32_t *__restrict__ cur_s,
-                                                            uint4 *__restrict__ g_read_rec, uint32_t *__restrict__ g_orig,
-                                                            uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read) {
+__global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+                                                         int shift, const uint32_t *__restrict__ base_r, uint32_t *__restrict__ cur_r,
+                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len) {
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
-        if (!k) continue;
-        const uint32_t key = node_id[b] >> shift;
-        const uint32_t slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
-        const uint32_t sb = base_s[key] + atomicAdd(&cur_s[key], k);
+        uint32_t slot = NO_SLOT;
+        if (k) {
+            const uint32_t key = node_id[b] >> shift;
+            slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
+            slot_len[slot] = k;
+        }
+        slot_of[r] = slot;
+    }
+}
+__global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, const uint32_t *__restrict__ base_r /*[NB+1]*/,
+                                                           const uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_rel,
+                                                           uint32_t *__restrict__ size_s) {
+    const uint32_t key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= NB) return;
+    uint32_t pos = 0;
+    for (uint32_t s = base_r[key], e = base_r[key + 1]; s < e; ++s) {
+        const uint32_t k = slot_len[s];
+        if (k <= 64 && (pos & 63) + k > 64) pos = (pos + 63) & ~63u;
+        slot_rel[s] = pos;
+        pos += k;
+    }
+    size_s[key] = (pos + 63) & ~63u;
+}
+__global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+                                                         const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, int shift,
+                                                         const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
+                                                         const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
+                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t slot = slot_of[r];
+        if (slot == NO_SLOT) continue;
+        const uint32_t b = step_off[r], k = step_off[r + 1] - b;
+        const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
-        g_orig[slot] = (uint32_t)r;
         for (uint32_t i = 0; i < k; ++i) { g_node_id[sb + i] = node_id[b + i]; g_step_read[sb + i] = slot; }
     }
 }
 
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
-    if (rd->R == 0 || rd->T == 0) return 0;
+    rd->T_pad = 0;
+    PTX_HIP(ctx, rd->d_slot_of.alloc(rd->R ? rd->R : 1));
+    PTX_HIP(ctx, rd->d_g_sp.alloc(rd->R ? rd->R : 1));
+    if (rd->R == 0) return 0;
+    if (rd->T == 0) {
+        PTX_HIP(ctx, hipMemsetAsync(rd->d_slot_of.p, 0xFF, rd->R * sizeof(uint32_t), ctx->stream));
+        return 0;
+    }
     int shift = 5;
     while (((uint64_t)max_node_id >> shift) + 1 > (1u << 20)) ++shift;
     const uint32_t NB = (uint32_t)(max_node_id >> shift) + 1;
-    DevBuf<uint32_t> cnt, scan_tmp;
-    PTX_HIP(ctx, cnt.alloc(4ull * NB + 8));
-    uint32_t *cnt_r = cnt.p, *cnt_s = cnt_r + NB, *base_r = cnt_s + NB, *base_s = base_r + NB;
-    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB)));
-    PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R)); PTX_HIP(ctx, rd->d_g_orig.alloc(rd->R));
-    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T));
-    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, 2ull * NB * sizeof(uint32_t), ctx->stream));
+    DevBuf<uint32_t> cnt, scan_tmp, slot_len, slot_rel;
+    PTX_HIP(ctx, cnt.alloc(4ull * (NB + 1) + 8));
+    uint32_t *cnt_r = cnt.p, *base_r = cnt_r + (NB + 1), *size_s = base_r + (NB + 1), *base_s = size_s + (NB + 1);
+    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB + 1)));
+    PTX_HIP(ctx, slot_len.alloc(rd->R)); PTX_HIP(ctx, slot_rel.alloc(rd->R));
+    PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R));
+    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));
     int gridR = grid_for(rd->R, 256, ctx->n_cu * 8);
-    hipLaunchKernelGGL(group_count_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, cnt_r, cnt_s);
-    PTX_TRY(exclusive_scan_u32(ctx, cnt_r, base_r, NB, scan_tmp.p, nullptr));
-    PTX_TRY(exclusive_scan_u32(ctx, cnt_s, base_s, NB, scan_tmp.p, nullptr));
-    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, 2ull * NB * sizeof(uint32_t), ctx->stream));   // reused as cursors
-    hipLaunchKernelGGL(group_scatter_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
-                       rd->d_pend.p, shift, base_r, base_s, cnt_r, cnt_s, rd->d_g_read_rec.p, rd->d_g_orig.p, rd->d_g_node_id.p, rd->d_g_step_read.p);
+    hipLaunchKernelGGL(group_count_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, cnt_r);
+    PTX_TRY(exclusive_scan_u32(ctx, cnt_r, base_r, NB + 1, scan_tmp.p, nullptr));
+    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));   // reused as cursors
+    hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_r, cnt_r,
+                       rd->d_slot_of.p, slot_len.p);
+    hipLaunchKernelGGL(group_layout_kernel, dim3((NB + 255) / 256), dim3(256), 0, ctx->stream, NB, base_r, slot_len.p, slot_rel.p, size_s);
+    uint32_t *d_total = (uint32_t *)ctx->d_scalars.p;
+    PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NB, scan_tmp.p, d_total));
+    uint32_t h_total = 0;
+    PTX_TRY(download(ctx, &h_total, d_total, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
+    rd->T_pad = h_total;
+    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad));
+    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
+                       rd->d_pend.p, shift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p);
     PTX_HIP(ctx, hipGetLastError());
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // cnt / scan_tmp are released on return
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // temporaries are released on return
     return 0;
 }
 
@@ -335,12 +389,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         PTX_HIP(ctx, db->d_trio_bases.alloc(db->U));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_bases.p, 0, (db->U ? db->U : 1) * sizeof(unsigned long long), ctx->stream));
     }
-    if (rd->R && rd->T) {
-        int grid = (int)((rd->T + COV_CHUNK - 1) / COV_CHUNK);
+    if (rd->R && rd->T_pad) {
+        int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
-#define COVS_ARGS rd->T, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_orig.p, rd->d_g_node_id.p, rd->d_species.p,                    \
-                  rd->has_flags ? rd->d_flags.p : nullptr, d_active, db->d_sp_first_id.p, db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, \
-                  db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort
+#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, d_active, db->d_sp_first_id.p, \
+                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort
         if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
         else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
 #undef COVS_ARGS
