@@ -46,19 +46,25 @@ constexpr int COV_BLOCK = 256;
 __device__ __forceinline__ uint32_t bm_peek(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void bitmap_or_range(uint32_t *__restrict__ bm, uint64_t g0, uint64_t g1) {
+// Bits [g0,g1) of the coverage bit vector are marked through the workgroup's LDS bit window (words
+// [bw0, bw0 + COV_BWIN) of the global vector); words outside the window take the global test-then-OR path.  The window is ORed into memory once per workgroup.
+constexpr uint32_t COV_BWIN = 2048;   // 32-bit words: 64 kbit of graph bases
+__device__ __forceinline__ void lds_or(uint32_t *s_bm, uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
+    const uint64_t off = w - bw0;     // unsigned wrap: words below the window are out of range too
+    if (off < bwn) {
+        if ((s_bm[off] & m) != m) atomicOr(&s_bm[off], m);
+    } else if ((bm_peek(&bm[w]) & m) != m) atomicOr(&bm[w], m);
+}
+__device__ __forceinline__ void mark_range(uint32_t *s_bm, uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t g0, uint64_t g1) {
     if (g1 <= g0) return;
     uint64_t w0 = g0 >> 5, w1 = (g1 - 1) >> 5;
     uint32_t m0 = 0xFFFFFFFFu << (g0 & 31);
     uint32_t m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
-    if (w0 == w1) {
-        uint32_t m = m0 & m1;
-        if ((bm_peek(&bm[w0]) & m) != m) atomicOr(&bm[w0], m);
-    } else {
-        if ((bm_peek(&bm[w0]) & m0) != m0) atomicOr(&bm[w0], m0);
-        for (uint64_t w = w0 + 1; w < w1; ++w)
-            if (bm_peek(&bm[w]) != 0xFFFFFFFFu) atomicOr(&bm[w], 0xFFFFFFFFu);
-        if ((bm_peek(&bm[w1]) & m1) != m1) atomicOr(&bm[w1], m1);
+    if (w0 == w1) lds_or(s_bm, bm, bw0, bwn, w0, m0 & m1);
+    else {
+        lds_or(s_bm, bm, bw0, bwn, w0, m0);
+        for (uint64_t w = w0 + 1; w < w1; ++w) lds_or(s_bm, bm, bw0, bwn, w, 0xFFFFFFFFu);
+        lds_or(s_bm, bm, bw0, bwn, w1, m1);
     }
 }
 
@@ -104,14 +110,17 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
     unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort) {
     __shared__ uint32_t s_win[COV_WIN];
+    __shared__ uint32_t s_bm[COV_BWIN];
     const int lane = threadIdx.x & 63;
     const uint64_t chunk_b = (uint64_t)blockIdx.x * COV_CHUNK;
     uint64_t chunk_e = chunk_b + COV_CHUNK;
     if (chunk_e > T) chunk_e = T;
     for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
+    for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
     // window base: the node of the first live step among four probes of the chunk.  Every thread computes it
     // (workgroup-uniform addresses), so nobody waits on a broadcast and the probes overlap the first gathers.
-    uint32_t wlo = 0, win_n = 0;
+    uint32_t wlo = 0, win_n = 0, bwn = 0;
+    uint64_t bw0 = 0;
 #pragma unroll
     for (int c = 0; c < COV_CHUNK / COV_BLOCK; ++c) {
         const uint64_t tc = chunk_b + (uint64_t)c * COV_BLOCK;
@@ -125,6 +134,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                         const uint32_t v0 = nb0 + (id0 - f0);
                         wlo = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
                         win_n = COV_WIN;
+                        const uint4 nr0 = node_rec[wlo];           // bit window starts at the window's first node
+                        bw0 = (((uint64_t)nr0.y << 32) | nr0.x) >> 5;
+                        bwn = COV_BWIN;
                     }
                 }
             }
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         if (ok && k == 1) {                                       // :811
             if (target >= 0) {                                    // :821-827
                 if (target) add_bases(bases, s_win, wlo, win_n, v, target);
-                if (ps < pe && pe <= nl) bitmap_or_range(bitmap, bo + ps, bo + pe);   // :832
+                if (ps < pe && pe <= nl) mark_range(s_bm, bitmap, bw0, bwn, bo + ps, bo + pe);   // :832
             }
             ok = false;
         }
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             } else { aln = nl; sidx = 0; }                        // :860-862
             long long hi = sidx + aln;
             if (hi > nl) hi = nl;                                 // :871
-            bitmap_or_range(bitmap, bo + sidx, bo + hi);
+            mark_range(s_bm, bitmap, bw0, bwn, bo + sidx, bo + hi);
             if (jf < 0) {
                 rl = aln;
                 if (aln) add_bases(bases, s_win, wlo, win_n, v, aln);     // :881
@@ -251,6 +263,10 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             const uint32_t c = s_win[i];
             if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
         }
+    for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
+        const uint32_t m = s_bm[i];
+        if (m && (bm_peek(&bitmap[bw0 + i]) & m) != m) atomicOr(&bitmap[bw0 + i], m);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
