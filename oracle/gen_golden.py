@@ -74,7 +74,9 @@ def main(out):
     cases = {}
     specs = [(60, 2, True, None), (300, 3, False, None), (800, 4, True, None), (1500, 6, False, None),
              (1500, 6, False, [1, 4]), (2500, 10, False, None), (2500, 10, True, [0, 2, 5]), (400, 1, False, None),
-             (1200, 8, True, None)]
+             (1200, 8, True, None),
+             # more than 16 candidates: the solver's wide (64-variable) instantiation
+             (3000, 24, False, None), (4000, 40, True, [3, 7, 20])]
     for i, (n, p, integer, fix) in enumerate(specs):
         mask, a, ub = make_case(rng, n, p, integer, fix=fix)
         x, obj, unique = highs_lad(mask, a, p, ub)

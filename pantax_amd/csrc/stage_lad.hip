@@ -88,12 +88,30 @@ __device__ __forceinline__ uint32_t wave_bound(const double *__restrict__ a, uin
     if (lo + lane < hi) { const double x = a[lo + lane]; before = upper ? (x <= v) : (x < v); }
     return lo + (uint32_t)__popcll(__ballot(before));
 }
-__device__ __forceinline__ uint32_t lb(bool coop, const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
-    return coop ? wave_bound(a, lo, hi, v, false) : lower_bound_a(a, lo, hi, v);
+// Two-level search: the solver keeps every (1 << shift)-th row of its species in LDS (sample j = row
+// row0 + (j << shift)); the samples narrow [lo,hi) to less than one stride without touching memory, the
+// remainder is one more (usually single) round in global memory.  Same result as the plain search.
+struct RowIdx {
+    const double *a;      // all rows (global)
+    const double *idx;    // samples (LDS)
+    uint32_t row0, shift, n_idx;
+};
+__device__ __forceinline__ uint32_t bound_idx(bool coop, const RowIdx &r, uint32_t lo, uint32_t hi, double v, bool upper) {
+    if (hi - lo > 8) {
+        const uint32_t mask = (1u << r.shift) - 1u;
+        const uint32_t j0 = (lo - r.row0 + mask) >> r.shift, j1 = (hi - r.row0 + mask) >> r.shift;   // samples with lo <= row < hi
+        if (j1 > j0) {
+            const uint32_t jj = coop ? wave_bound(r.idx, j0, j1, v, upper)
+                                     : (upper ? upper_bound_a(r.idx, j0, j1, v) : lower_bound_a(r.idx, j0, j1, v));
+            if (jj > j0) lo = r.row0 + ((jj - 1) << r.shift) + 1;
+            if (jj < j1) hi = r.row0 + (jj << r.shift);
+        }
+    }
+    if (coop) return wave_bound(r.a, lo, hi, v, upper);
+    return upper ? upper_bound_a(r.a, lo, hi, v) : lower_bound_a(r.a, lo, hi, v);
 }
-__device__ __forceinline__ uint32_t ub_(bool coop, const double *__restrict__ a, uint32_t lo, uint32_t hi, double v) {
-    return coop ? wave_bound(a, lo, hi, v, true) : upper_bound_a(a, lo, hi, v);
-}
+__device__ __forceinline__ uint32_t lb(bool coop, const RowIdx &r, uint32_t lo, uint32_t hi, double v) { return bound_idx(coop, r, lo, hi, v, false); }
+__device__ __forceinline__ uint32_t ub_(bool coop, const RowIdx &r, uint32_t lo, uint32_t hi, double v) { return bound_idx(coop, r, lo, hi, v, true); }
 
 __device__ __forceinline__ double mdot(uint64_t m, const double *x) {   // ascending-bit order
     double s = 0.0;
@@ -520,6 +538,7 @@ int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &
 // a12: the batched exact LAD solver
 // ---------------------------------------------------------------------------------------------
 constexpr int LAD_BLOCK = 256;
+constexpr int LAD_KLDS = 64;     // patterns whose solver state fits the LDS arrays
 enum { C_LB = 0, C_UB = 1, C_PAT = 2, C_FIXED = 3 };
 
 struct LadArgs {
@@ -552,7 +571,7 @@ struct LadShared {
 };
 
 // number of breakpoints of pattern k crossed when moving t along the search direction
-__device__ __forceinline__ uint32_t crossed(bool COOP, const double *__restrict__ a, double rho, double s0, double eps, uint32_t st, uint32_t en,
+__device__ __forceinline__ uint32_t crossed(bool COOP, const RowIdx &a, double rho, double s0, double eps, uint32_t st, uint32_t en,
                                             uint32_t lo, uint32_t up, double t, uint32_t c_lo, uint32_t c_hi) {
     double sv = s0 - eps + t * rho;
     if (rho > 0) return ub_(COOP, a, up + c_lo, up + c_hi, sv) - up;           // rows a_i <= sv among [up,en)
@@ -567,6 +586,14 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     __shared__ LadShared sh;
     __shared__ double W[PS * PS];
     __shared__ double G[PS * 2 * PS];
+    // per-pattern solver state: in LDS when the species has at most LAD_KLDS patterns (the usual case), else in
+    // the global scratch arrays
+    __shared__ double L_s[LAD_KLDS], L_rho[LAD_KLDS], L_eps[LAD_KLDS];
+    __shared__ uint64_t L_mask[LAD_KLDS];
+    __shared__ uint32_t L_lo[LAD_KLDS], L_up[LAD_KLDS], L_lslo[LAD_KLDS], L_lshi[LAD_KLDS], L_lsmid[LAD_KLDS], L_start[LAD_KLDS + 1];
+    // top level of every row search: every (1 << shift)-th row of the species' sorted rows
+    constexpr uint32_t IDX_N = 4096;
+    __shared__ double L_idx[IDX_N];
     const int tid = threadIdx.x;
     const int s = blockIdx.x;   // one workgroup per species of the db; species without work leave at once
     const int p = A.sp_p[s];
@@ -575,12 +602,34 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
     const bool COOP = (k1 - k0) <= 16;
     const bool leader = COOP ? ((tid & 63) == 0) : true;
-    const double *__restrict__ ra = A.row_a;
+    const bool useL = (k1 - k0) <= (uint32_t)LAD_KLDS;
+    const uint32_t kofs = useL ? k0 : 0u;     // LDS arrays are indexed from the species' first pattern
+    double *P_sc_s = useL ? L_s : A.sc_s, *P_sc_rho = useL ? L_rho : A.sc_rho, *P_pat_eps = useL ? L_eps : A.pat_eps;
+    uint32_t *P_sc_lo = useL ? L_lo : A.sc_lo, *P_sc_up = useL ? L_up : A.sc_up, *P_ls_lo = useL ? L_lslo : A.ls_lo,
+             *P_ls_hi = useL ? L_lshi : A.ls_hi, *P_ls_mid = useL ? L_lsmid : A.ls_mid;
+    const uint64_t *P_pat_mask = useL ? L_mask : A.pat_mask;
+    const uint32_t *P_pat_start = useL ? L_start : A.pat_start;
+    if (useL) {
+        for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK) L_mask[kk - k0] = A.pat_mask[kk];
+        for (uint32_t kk = k0 + tid; kk <= k1; kk += LAD_BLOCK) L_start[kk - k0] = A.pat_start[kk];
+    }
+    RowIdx ra;
+    ra.a = A.row_a; ra.idx = L_idx;
+    ra.row0 = A.pat_start[k0];
+    {
+        const uint32_t nrow = A.pat_start[k1] - ra.row0;
+        uint32_t sh_ = 0;
+        while (nrow && ((nrow - 1) >> sh_) + 1 > IDX_N) ++sh_;
+        ra.shift = sh_;
+        ra.n_idx = nrow ? ((nrow - 1) >> sh_) + 1 : 0;
+        for (uint32_t j = tid; j < ra.n_idx; j += LAD_BLOCK) L_idx[j] = A.row_a[ra.row0 + (j << sh_)];
+    }
+    __syncthreads();
     const double tol = 1e-7;
     const double amax = A.amax[s];
     const double delta = 1e-10 * (amax > 1.0 ? amax : 1.0);
     for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK)
-        A.pat_eps[kk] = delta * (0.25 + 0.5 * (double)(splitmix64(A.pat_mask[kk]) >> 11) * (1.0 / 9007199254740992.0));
+        P_pat_eps[kk - kofs] = delta * (0.25 + 0.5 * (double)(splitmix64(P_pat_mask[kk - kofs]) >> 11) * (1.0 / 9007199254740992.0));
     if (tid < p) {
         // box: 0 <= x <= 1.05 * max(a) (profile.rs:1327); pinned to 0 in the second solve (:1484-1488)
         double u = (A.fixed && A.fixed[(size_t)s * LAD_MAXP + tid]) ? 0.0 : 1.05 * A.amax[s];
@@ -598,7 +647,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         // ---- vertex of the perturbed problem: x = W c
         if (tid < p) {
             int ty = sh.act_type[tid];
-            sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra[sh.act_i0[tid]] + A.pat_eps[sh.act_jk[tid]] : 0.0;
+            sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra.a[sh.act_i0[tid]] + P_pat_eps[sh.act_jk[tid] - kofs] : 0.0;
         }
         __syncthreads();
         if (tid < p) {
@@ -610,19 +659,19 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         __syncthreads();
         // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
         PAT_LOOP(k) {
-            uint64_t mk = A.pat_mask[k];
-            uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
+            uint64_t mk = P_pat_mask[k - kofs];
+            uint32_t st = P_pat_start[k - kofs], en = P_pat_start[(k + 1) - kofs];
             int ai = -1;
             for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
             uint32_t lo, up; double sk;
-            if (ai >= 0) { lo = sh.act_i0[ai]; up = sh.act_i1[ai]; sk = ra[lo] + A.pat_eps[k]; }
+            if (ai >= 0) { lo = sh.act_i0[ai]; up = sh.act_i1[ai]; sk = ra.a[lo] + P_pat_eps[k - kofs]; }
             else {
                 sk = mdot(mk, sh.x);
-                double sv = sk - A.pat_eps[k];
+                double sv = sk - P_pat_eps[k - kofs];
                 lo = lb(COOP, ra, st, en, sv);
                 up = ub_(COOP, ra, lo, en, sv);
             }
-            A.sc_s[k] = sk; A.sc_lo[k] = lo; A.sc_up[k] = up;
+            P_sc_s[k - kofs] = sk; P_sc_lo[k - kofs] = lo; P_sc_up[k - kofs] = up;
             long long sigma = (long long)(lo - st) - (long long)(en - up);
             if (sigma && leader) {
                 uint64_t m = mk;
@@ -668,15 +717,15 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         // ---- line search set-up: rate rho_k of every pattern along d
         double part = 0.0;
         PAT_LOOP(k) {
-            uint64_t mk = A.pat_mask[k];
+            uint64_t mk = P_pat_mask[k - kofs];
             int ai = -1;
             for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
             double rho;
             if (ai >= 0) rho = (ai == best) ? bdir : 0.0;   // other tight patterns stay tight: n_i . d = 0
-            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(A.sc_up[k] - A.sc_lo[k]); }
-            A.sc_rho[k] = rho;
-            A.ls_lo[k] = 0;
-            A.ls_hi[k] = rho > 0 ? A.pat_start[k + 1] - A.sc_up[k] : rho < 0 ? A.sc_lo[k] - A.pat_start[k] : 0;
+            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(P_sc_up[k - kofs] - P_sc_lo[k - kofs]); }
+            P_sc_rho[k - kofs] = rho;
+            P_ls_lo[k - kofs] = 0;
+            P_ls_hi[k - kofs] = rho > 0 ? P_pat_start[(k + 1) - kofs] - P_sc_up[k - kofs] : rho < 0 ? P_sc_lo[k - kofs] - P_pat_start[k - kofs] : 0;
         }
         double S0 = sh.bderiv + block_sum_f64<LAD_BLOCK>(part, sh.red);   // slope just after t = 0
         if (tid == 0) { sh.ent_type = -1; sh.S_lo = S0; }
@@ -686,7 +735,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             // degenerate: an unsplit tie group blocks the move at t = 0 -> it enters (step length 0)
             double tb = INFINITY; int kb = 0x7fffffff;
             PAT_LOOP(k)
-                if (A.sc_rho[k] != 0.0 && A.sc_up[k] > A.sc_lo[k]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
+                if (P_sc_rho[k - kofs] != 0.0 && P_sc_up[k - kofs] > P_sc_lo[k - kofs]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { int k2 = __shfl_down(kb, off); if (k2 < kb) kb = k2; }
             if ((tid & 63) == 0) sh.red_k[tid >> 6] = kb;
@@ -694,7 +743,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             if (tid == 0) {
                 int kk = sh.red_k[0];
                 for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red_k[w] < kk) kk = sh.red_k[w];
-                if (kk != 0x7fffffff) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = A.sc_lo[kk]; sh.ent_i1 = A.sc_up[kk]; }
+                if (kk != 0x7fffffff) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = P_sc_lo[kk - kofs]; sh.ent_i1 = P_sc_up[kk - kofs]; }
                 else { sh.status = 4; sh.done = 1; }
             }
             (void)tb;
@@ -707,12 +756,12 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             for (int grow = 0; grow < 200; ++grow) {
                 double acc = 0.0;
                 PAT_LOOP(k) {
-                    double rho = A.sc_rho[k];
+                    double rho = P_sc_rho[k - kofs];
                     if (rho == 0.0) continue;
-                    uint32_t st = A.pat_start[k], en = A.pat_start[k + 1];
-                    uint32_t cmax = rho > 0 ? en - A.sc_up[k] : A.sc_lo[k] - st;
-                    uint32_t c = crossed(COOP, ra, rho, A.sc_s[k], A.pat_eps[k], st, en, A.sc_lo[k], A.sc_up[k], t_hi, 0, cmax);
-                    A.ls_hi[k] = c;
+                    uint32_t st = P_pat_start[k - kofs], en = P_pat_start[(k + 1) - kofs];
+                    uint32_t cmax = rho > 0 ? en - P_sc_up[k - kofs] : P_sc_lo[k - kofs] - st;
+                    uint32_t c = crossed(COOP, ra, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], st, en, P_sc_lo[k - kofs], P_sc_up[k - kofs], t_hi, 0, cmax);
+                    P_ls_hi[k - kofs] = c;
                     if (leader) acc += fabs(rho) * 2.0 * (double)c;
                 }
                 S_hi = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
@@ -737,15 +786,15 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 for (int bi = 0; bi < 200; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
                     PAT_LOOP(k) {
-                        double rho = A.sc_rho[k];
-                        uint32_t cl = A.ls_lo[k], ch = A.ls_hi[k];
+                        double rho = P_sc_rho[k - kofs];
+                        uint32_t cl = P_ls_lo[k - kofs], ch = P_ls_hi[k - kofs];
                         if (rho == 0.0 || ch <= cl) continue;
                         if (leader) cand += ch - cl;
                         double w = fabs(rho) * (double)(ch - cl);
                         if (w > wbest) {
                             uint32_t m = cl + (ch - cl) / 2;   // m-th breakpoint ahead (0-based) of this pattern
-                            uint32_t r = rho > 0 ? A.sc_up[k] + m : A.sc_lo[k] - 1 - m;
-                            double t = (ra[r] + A.pat_eps[k] - A.sc_s[k]) / rho;
+                            uint32_t r = rho > 0 ? P_sc_up[k - kofs] + m : P_sc_lo[k - kofs] - 1 - m;
+                            double t = (ra.a[r] + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
                             wbest = w; tprop = t < 0 ? 0 : t;
                         }
                     }
@@ -776,18 +825,18 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     }
                     double acc = 0.0;
                     PAT_LOOP(k) {
-                        double rho = A.sc_rho[k];
+                        double rho = P_sc_rho[k - kofs];
                         if (rho == 0.0) continue;
-                        uint32_t c = crossed(COOP, ra, rho, A.sc_s[k], A.pat_eps[k], A.pat_start[k], A.pat_start[k + 1], A.sc_lo[k], A.sc_up[k],
-                                             t_mid, A.ls_lo[k], A.ls_hi[k]);
-                        A.ls_mid[k] = c;
+                        uint32_t c = crossed(COOP, ra, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_pat_start[k - kofs], P_pat_start[(k + 1) - kofs], P_sc_lo[k - kofs], P_sc_up[k - kofs],
+                                             t_mid, P_ls_lo[k - kofs], P_ls_hi[k - kofs]);
+                        P_ls_mid[k - kofs] = c;
                         if (leader) acc += fabs(rho) * 2.0 * (double)c;
                     }
                     double S_mid = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
                     bool go_hi = S_mid >= -tol;
                     PAT_LOOP(k) {
-                        if (A.sc_rho[k] == 0.0) continue;
-                        if (go_hi) A.ls_hi[k] = A.ls_mid[k]; else A.ls_lo[k] = A.ls_mid[k];
+                        if (P_sc_rho[k - kofs] == 0.0) continue;
+                        if (go_hi) P_ls_hi[k - kofs] = P_ls_mid[k - kofs]; else P_ls_lo[k - kofs] = P_ls_mid[k - kofs];
                     }
                     if (go_hi) { t_hi = t_mid; S_hi = S_mid; } else { t_lo = t_mid; S_lo = S_mid; }
                 }
@@ -798,10 +847,10 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 for (int step = 0; step < 4096; ++step) {
                     double tb = INFINITY; int kb = 0x7fffffff;
                     PAT_LOOP(k) {
-                        double rho = A.sc_rho[k];
-                        if (rho == 0.0 || A.ls_hi[k] <= A.ls_lo[k]) continue;
-                        uint32_t r = rho > 0 ? A.sc_up[k] + A.ls_lo[k] : A.sc_lo[k] - 1 - A.ls_lo[k];
-                        double t = (ra[r] + A.pat_eps[k] - A.sc_s[k]) / rho;
+                        double rho = P_sc_rho[k - kofs];
+                        if (rho == 0.0 || P_ls_hi[k - kofs] <= P_ls_lo[k - kofs]) continue;
+                        uint32_t r = rho > 0 ? P_sc_up[k - kofs] + P_ls_lo[k - kofs] : P_sc_lo[k - kofs] - 1 - P_ls_lo[k - kofs];
+                        double t = (ra.a[r] + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
                         if (t < 0) t = 0;
                         if (t < tb || (t == tb && (int)k < kb)) { tb = t; kb = (int)k; }
                     }
@@ -819,14 +868,14 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                             // bracket exhausted without crossing (rounding): fall back to the box bound or fail
                             if (sh.bj >= 0 && isfinite(sh.tmax)) { sh.ent_type = sh.btype; sh.ent_k = (uint32_t)sh.bj; } else { sh.status = 5; sh.done = 1; }
                         } else {
-                            double rho = A.sc_rho[kk];
-                            uint32_t st = A.pat_start[kk], en = A.pat_start[kk + 1];
-                            uint32_t r = rho > 0 ? A.sc_up[kk] + A.ls_lo[kk] : A.sc_lo[kk] - 1 - A.ls_lo[kk];
-                            double av = ra[r];
-                            uint32_t g0 = lower_bound_a(ra, st, en, av), g1 = upper_bound_a(ra, g0, en, av);
+                            double rho = P_sc_rho[kk - kofs];
+                            uint32_t st = P_pat_start[kk - kofs], en = P_pat_start[(kk + 1) - kofs];
+                            uint32_t r = rho > 0 ? P_sc_up[kk - kofs] + P_ls_lo[kk - kofs] : P_sc_lo[kk - kofs] - 1 - P_ls_lo[kk - kofs];
+                            double av = ra.a[r];
+                            uint32_t g0 = lb(false, ra, st, en, av), g1 = ub_(false, ra, g0, en, av);
                             uint32_t gs = g1 - g0;
                             double Sn = sh.S_lo + 2.0 * fabs(rho) * (double)gs;
-                            A.ls_lo[kk] += gs;
+                            P_ls_lo[kk - kofs] += gs;
                             sh.S_lo = Sn;
                             if (Sn >= -tol) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = g0; sh.ent_i1 = g1; }
                         }
@@ -849,7 +898,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             int r = i / (2 * p), cc = i % (2 * p);
             double v;
             if (cc >= p) v = (cc - p == r) ? 1.0 : 0.0;
-            else if (sh.act_type[r] == C_PAT) v = (A.pat_mask[sh.act_jk[r]] >> cc) & 1ull ? 1.0 : 0.0;
+            else if (sh.act_type[r] == C_PAT) v = (P_pat_mask[sh.act_jk[r] - kofs] >> cc) & 1ull ? 1.0 : 0.0;
             else v = (sh.act_jk[r] == cc) ? 1.0 : 0.0;
             G[r * 2 * PS + cc] = v;
         }
@@ -885,7 +934,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     __syncthreads();
     if (tid < p) {
         int ty = sh.act_type[tid];
-        sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra[sh.act_i0[tid]] : 0.0;
+        sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra.a[sh.act_i0[tid]] : 0.0;
     }
     __syncthreads();
     if (tid < p) {
