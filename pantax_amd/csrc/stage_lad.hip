@@ -21,10 +21,58 @@ namespace ptx {
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+// Wave64 reductions on the VALU cross-lane path (DPP row operations + readlane): a few dozen cycles, where a
+// __shfl_down ladder (ds_bpermute, two per step for a double) costs over a thousand -- the solver's line search is
+// a serial chain of such reductions.  All 64 lanes must be active.  The combining order is fixed (deterministic).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false); }
+template <int CTRL, class T>
+__device__ __forceinline__ T dpp(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit lanes");
+    if constexpr (sizeof(T) == 4) {
+        uint32_t u; __builtin_memcpy(&u, &v, 4); u = dpp32<CTRL>(u);
+        T r; __builtin_memcpy(&r, &u, 4); return r;
+    } else {
+        uint64_t u; __builtin_memcpy(&u, &v, 8);
+        uint32_t lo = dpp32<CTRL>((uint32_t)u), hi = dpp32<CTRL>((uint32_t)(u >> 32));
+        u = ((uint64_t)hi << 32) | lo;
+        T r; __builtin_memcpy(&r, &u, 8); return r;
+    }
+}
+template <class T>
+__device__ __forceinline__ T lane_get(T v, int lane) {
+    if constexpr (sizeof(T) == 4) {
+        uint32_t u; __builtin_memcpy(&u, &v, 4); u = (uint32_t)__builtin_amdgcn_readlane((int)u, lane);
+        T r; __builtin_memcpy(&r, &u, 4); return r;
+    } else {
+        uint64_t u; __builtin_memcpy(&u, &v, 8);
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+        u = ((uint64_t)hi << 32) | lo;
+        T r; __builtin_memcpy(&r, &u, 8); return r;
+    }
+}
+// quad swap, quad-pair swap, row rotate by 4 and 8: every lane of a 16-lane row holds the row's result; the four
+// row results are combined from scalar registers, so every lane returns the wave's result
+template <class T, class Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+    v = op(v, dpp<0xB1>(v)); v = op(v, dpp<0x4E>(v)); v = op(v, dpp<0x124>(v)); v = op(v, dpp<0x128>(v));
+    return op(op(lane_get(v, 0), lane_get(v, 16)), op(lane_get(v, 32), lane_get(v, 48)));
+}
+// lexicographic pair reductions: (a, b) "better" as decided by `better(a2, b2, a, b)`
+template <class A, class B, class Better>
+__device__ __forceinline__ void wave_reduce_pair(A &a, B &b, Better better) {
+#define PTX_PAIR_STEP(CTRL) { A a2 = dpp<CTRL>(a); B b2 = dpp<CTRL>(b); if (better(a2, b2, a, b)) { a = a2; b = b2; } }
+    PTX_PAIR_STEP(0xB1) PTX_PAIR_STEP(0x4E) PTX_PAIR_STEP(0x124) PTX_PAIR_STEP(0x128)
+#undef PTX_PAIR_STEP
+    A ra = lane_get(a, 0); B rb = lane_get(b, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) { A a2 = lane_get(a, r); B b2 = lane_get(b, r); if (better(a2, b2, ra, rb)) { ra = a2; rb = b2; } }
+    a = ra; b = rb;
+}
+
 template <int NT>
 __device__ __forceinline__ double block_sum_f64(double v, double *red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    v = wave_reduce(v, [](double x, double y) { return x + y; });
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -36,8 +84,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
 }
 template <int NT>
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    v = wave_reduce(v, [](unsigned long long x, unsigned long long y) { return x + y; });
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -49,8 +96,7 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 }
 template <int NT>
 __device__ __forceinline__ double block_max_f64(double v, double *red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+    v = wave_reduce(v, [](double x, double y) { return fmax(x, y); });
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -95,8 +141,35 @@ struct RowIdx {
     const double *a;      // all rows (global)
     const double *idx;    // samples (LDS)
     uint32_t row0, shift, n_idx;
+    // optional LDS copy of rows [c_row0, c_row0 + c_n) (the line search caches each pattern's remaining candidates)
+    const double *cache;
+    uint32_t c_row0, c_n;
 };
+__device__ __forceinline__ double row_val(const RowIdx &r, uint32_t row) {
+    const uint32_t off = row - r.c_row0;
+    return off < r.c_n ? r.cache[off] : r.a[row];
+}
+// samples only, no memory access: rmin <= (first row of [lo,hi) that is not "before" v) <= rmax
+__device__ __forceinline__ void bound_idx_range(bool coop, const RowIdx &r, uint32_t lo, uint32_t hi, double v, bool upper, uint32_t &rmin,
+                                                uint32_t &rmax) {
+    rmin = lo; rmax = hi;
+    if (hi <= lo) return;
+    const uint32_t mask = (1u << r.shift) - 1u;
+    const uint32_t j0 = (lo - r.row0 + mask) >> r.shift, j1 = (hi - r.row0 + mask) >> r.shift;
+    if (j1 > j0) {
+        const uint32_t jj = coop ? wave_bound(r.idx, j0, j1, v, upper)
+                                 : (upper ? upper_bound_a(r.idx, j0, j1, v) : lower_bound_a(r.idx, j0, j1, v));
+        if (jj > j0) rmin = r.row0 + ((jj - 1) << r.shift) + 1;
+        if (jj < j1) rmax = r.row0 + (jj << r.shift);
+    }
+}
 __device__ __forceinline__ uint32_t bound_idx(bool coop, const RowIdx &r, uint32_t lo, uint32_t hi, double v, bool upper) {
+    if (r.c_n && lo >= r.c_row0 && hi <= r.c_row0 + r.c_n && hi >= lo) {   // entirely inside the cached window
+        const uint32_t l2 = lo - r.c_row0, h2 = hi - r.c_row0;
+        const uint32_t res = coop ? wave_bound(r.cache, l2, h2, v, upper)
+                                  : (upper ? upper_bound_a(r.cache, l2, h2, v) : lower_bound_a(r.cache, l2, h2, v));
+        return r.c_row0 + res;
+    }
     if (hi - lo > 8) {
         const uint32_t mask = (1u << r.shift) - 1u;
         const uint32_t j0 = (lo - r.row0 + mask) >> r.shift, j1 = (hi - r.row0 + mask) >> r.shift;   // samples with lo <= row < hi
@@ -578,31 +651,49 @@ __device__ __forceinline__ uint32_t crossed(bool COOP, const RowIdx &a, double r
     return lo - lb(COOP, a, lo - c_hi, lo - c_lo, sv);                         // rows a_i >= sv among [st,lo)
 }
 
+// the same count from the LDS samples alone: cmin <= crossed(...) <= cmax
+__device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double rho, double s0, double eps, uint32_t lo, uint32_t up, double t,
+                                              uint32_t c_lo, uint32_t c_hi, uint32_t &cmin, uint32_t &cmax) {
+    double sv = s0 - eps + t * rho;
+    uint32_t rmin, rmax;
+    if (rho > 0) { bound_idx_range(COOP, a, up + c_lo, up + c_hi, sv, true, rmin, rmax); cmin = rmin - up; cmax = rmax - up; }
+    else { bound_idx_range(COOP, a, lo - c_hi, lo - c_lo, sv, false, rmin, rmax); cmin = lo - rmax; cmax = lo - rmin; }
+}
+
 // COOP (per species, block-uniform) = few patterns: every wave owns whole patterns (its 64 lanes search
 // cooperatively, lane 0 is the "leader" that accumulates); otherwise one thread per pattern with scalar searches.
 #define PAT_LOOP(k) for (uint32_t k = k0 + (COOP ? (uint32_t)(tid >> 6) : (uint32_t)tid); k < k1; k += (COOP ? LAD_BLOCK / 64 : LAD_BLOCK))
+// LDS of one solver workgroup
 template <int PS>
-__global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
-    __shared__ LadShared sh;
-    __shared__ double W[PS * PS];
-    __shared__ double G[PS * 2 * PS];
-    // per-pattern solver state: in LDS when the species has at most LAD_KLDS patterns (the usual case), else in
-    // the global scratch arrays
-    __shared__ double L_s[LAD_KLDS], L_rho[LAD_KLDS], L_eps[LAD_KLDS];
-    __shared__ uint64_t L_mask[LAD_KLDS];
-    __shared__ uint32_t L_lo[LAD_KLDS], L_up[LAD_KLDS], L_lslo[LAD_KLDS], L_lshi[LAD_KLDS], L_lsmid[LAD_KLDS], L_start[LAD_KLDS + 1];
-    // top level of every row search: every (1 << shift)-th row of the species' sorted rows
-    constexpr uint32_t IDX_N = 4096;
-    __shared__ double L_idx[IDX_N];
+struct LadLds {
+    static constexpr uint32_t IDX_N = 4096;                       // samples of the row index
+    static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 1024;   // cached candidate rows of a line search
+    LadShared sh;
+    double W[PS * PS];
+    double G[PS * 2 * PS];
+    // per-pattern solver state (species with at most LAD_KLDS patterns, the usual case; else the global scratch arrays)
+    double L_s[LAD_KLDS], L_rho[LAD_KLDS], L_eps[LAD_KLDS];
+    uint64_t L_mask[LAD_KLDS];
+    uint32_t L_lo[LAD_KLDS], L_up[LAD_KLDS], L_lslo[LAD_KLDS], L_lshi[LAD_KLDS], L_lsmid[LAD_KLDS], L_start[LAD_KLDS + 1];
+    double L_idx[IDX_N];      // top level of every row search: every (1 << shift)-th row of the species' sorted rows
+    double L_cache[CACHE_N];
+    uint32_t L_lsmid2[LAD_KLDS], L_coff[LAD_KLDS + 1], L_cn[LAD_KLDS], L_crow0[LAD_KLDS];
+};
+
+// USEL is a compile-time constant so that every access to the pattern state is a plain LDS (or plain global)
+// instruction; a run-time choice between the two would turn them all into flat accesses.
+template <int PS, bool USEL>
+__device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, const int s, const int p, const uint32_t k0, const uint32_t k1) {
+    constexpr uint32_t IDX_N = LadLds<PS>::IDX_N, CACHE_N = LadLds<PS>::CACHE_N;
+    LadShared &sh = m.sh;
+    double *W = m.W, *G = m.G, *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache = m.L_cache;
+    uint64_t *L_mask = m.L_mask;
+    uint32_t *L_lo = m.L_lo, *L_up = m.L_up, *L_lslo = m.L_lslo, *L_lshi = m.L_lshi, *L_lsmid = m.L_lsmid, *L_start = m.L_start,
+             *L_lsmid2 = m.L_lsmid2, *L_coff = m.L_coff, *L_cn = m.L_cn, *L_crow0 = m.L_crow0;
     const int tid = threadIdx.x;
-    const int s = blockIdx.x;   // one workgroup per species of the db; species without work leave at once
-    const int p = A.sp_p[s];
-    if (A.need && !A.need[s]) return;
-    if (p <= 0) { if (tid == 0) { A.status[s] = 0; A.iters[s] = 0; } return; }
-    const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
     const bool COOP = (k1 - k0) <= 16;
     const bool leader = COOP ? ((tid & 63) == 0) : true;
-    const bool useL = (k1 - k0) <= (uint32_t)LAD_KLDS;
+    constexpr bool useL = USEL;
     const uint32_t kofs = useL ? k0 : 0u;     // LDS arrays are indexed from the species' first pattern
     double *P_sc_s = useL ? L_s : A.sc_s, *P_sc_rho = useL ? L_rho : A.sc_rho, *P_pat_eps = useL ? L_eps : A.pat_eps;
     uint32_t *P_sc_lo = useL ? L_lo : A.sc_lo, *P_sc_up = useL ? L_up : A.sc_up, *P_ls_lo = useL ? L_lslo : A.ls_lo,
@@ -614,7 +705,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         for (uint32_t kk = k0 + tid; kk <= k1; kk += LAD_BLOCK) L_start[kk - k0] = A.pat_start[kk];
     }
     RowIdx ra;
-    ra.a = A.row_a; ra.idx = L_idx;
+    ra.a = A.row_a; ra.idx = L_idx; ra.cache = L_cache; ra.c_row0 = 0; ra.c_n = 0;
     ra.row0 = A.pat_start[k0];
     {
         const uint32_t nrow = A.pat_start[k1] - ra.row0;
@@ -736,8 +827,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
             double tb = INFINITY; int kb = 0x7fffffff;
             PAT_LOOP(k)
                 if (P_sc_rho[k - kofs] != 0.0 && P_sc_up[k - kofs] > P_sc_lo[k - kofs]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { int k2 = __shfl_down(kb, off); if (k2 < kb) kb = k2; }
+            kb = wave_reduce(kb, [](int x, int y) { return x < y ? x : y; });
             if ((tid & 63) == 0) sh.red_k[tid >> 6] = kb;
             __syncthreads();
             if (tid == 0) {
@@ -783,7 +873,12 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                 // ls_lo/ls_hi bracket the crossed-count of every pattern; slope(t_lo) < 0 <= slope(t_hi).
                 double t_lo = 0.0, S_lo = S0;
                 unsigned long long prev_cand = ~0ull; int stall = 0;
-                for (int bi = 0; bi < 200; ++bi) {
+                // Rounds first run on the LDS samples alone (bounds on every crossed-count, no memory access) for
+                // as long as the sign of the slope at the pivot is certain; then the remaining candidate rows of
+                // every pattern are copied to LDS once and the exact rounds finish there.
+                bool approx = useL, cached = false;
+#define RK(k) RowIdx rk = ra; if (cached) { rk.cache = L_cache + L_coff[(k) - k0]; rk.c_row0 = L_crow0[(k) - k0]; rk.c_n = L_cn[(k) - k0]; }
+                for (int bi = 0; bi < 400; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
@@ -794,22 +889,56 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                         if (w > wbest) {
                             uint32_t m = cl + (ch - cl) / 2;   // m-th breakpoint ahead (0-based) of this pattern
                             uint32_t r = rho > 0 ? P_sc_up[k - kofs] + m : P_sc_lo[k - kofs] - 1 - m;
-                            double t = (ra.a[r] + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
+                            double av;
+                            bool have = false;
+                            if (approx) {   // a sampled row among the candidates serves as well as the exact median
+                                const uint32_t rl = rho > 0 ? P_sc_up[k - kofs] + cl : P_sc_lo[k - kofs] - ch;
+                                const uint32_t rh = rho > 0 ? P_sc_up[k - kofs] + ch : P_sc_lo[k - kofs] - cl;
+                                uint32_t j = (r - ra.row0) >> ra.shift;
+                                uint32_t rs = ra.row0 + (j << ra.shift);
+                                if (rs < rl) { ++j; rs += 1u << ra.shift; }
+                                if (rs < rh && j < ra.n_idx) { av = ra.idx[j]; have = true; }
+                            }
+                            if (!have) { RK(k); av = row_val(rk, r); }
+                            double t = (av + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
                             wbest = w; tprop = t < 0 ? 0 : t;
                         }
                     }
                     cand = (unsigned long long)block_sum_f64<LAD_BLOCK>((double)cand, sh.red);
                     if (cand <= 8) break;
-                    // three rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
-                    stall = (cand == prev_cand) ? stall + 1 : 0;
+                    // three exact rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
+                    const bool shrunk = cand != prev_cand;
                     prev_cand = cand;
-                    if (stall >= 3) break;
-                    // heaviest proposal: max over the block (ties -> smaller t)
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        double w2 = __shfl_down(wbest, off), t2 = __shfl_down(tprop, off);
-                        if (w2 > wbest || (w2 == wbest && t2 < tprop)) { wbest = w2; tprop = t2; }
+                    if (approx) { if (!shrunk) approx = false; }
+                    else {
+                        stall = shrunk ? 0 : stall + 1;
+                        if (stall >= 3) break;
                     }
+                    if (!approx && !cached && useL && cand <= CACHE_N) {
+                        if (tid == 0) {
+                            uint32_t off = 0;
+                            for (uint32_t kk = 0; kk < k1 - k0; ++kk) {
+                                const double rho = L_rho[kk];
+                                const uint32_t cl = L_lslo[kk], ch = L_lshi[kk];
+                                const uint32_t n = (rho != 0.0 && ch > cl) ? ch - cl : 0u;
+                                L_coff[kk] = off; L_cn[kk] = n;
+                                L_crow0[kk] = rho > 0 ? L_up[kk] + cl : L_lo[kk] - ch;
+                                off += n;
+                            }
+                            L_coff[k1 - k0] = off;
+                        }
+                        __syncthreads();
+                        const uint32_t total = L_coff[k1 - k0];
+                        for (uint32_t e = tid; e < total; e += LAD_BLOCK) {
+                            uint32_t kk = 0;
+                            while (kk + 1 < k1 - k0 && L_coff[kk + 1] <= e) ++kk;
+                            L_cache[e] = ra.a[L_crow0[kk] + (e - L_coff[kk])];
+                        }
+                        __syncthreads();
+                        cached = true;
+                    }
+                    // heaviest proposal: max over the block (ties -> smaller t)
+                    wave_reduce_pair(wbest, tprop, [](double w2, double t2, double w, double t) { return w2 > w || (w2 == w && t2 < t); });
                     if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tprop; sh.red[tid >> 6] = wbest; }
                     __syncthreads();
                     double bw = sh.red[0], bt = sh.red_t[0];
@@ -823,11 +952,36 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                         t_mid = (mode == 1 && den > 0.0) ? t_lo + (t_hi - t_lo) * (-S_lo / den) : 0.5 * (t_lo + t_hi);
                         if (!(t_mid > t_lo && t_mid < t_hi)) t_mid = 0.5 * (t_lo + t_hi);
                     }
+                    if (approx) {
+                        double acc0 = 0.0, acc1 = 0.0;
+                        PAT_LOOP(k) {
+                            double rho = P_sc_rho[k - kofs];
+                            if (rho == 0.0) continue;
+                            uint32_t cmin, cmax;
+                            crossed_range(COOP, ra, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_sc_lo[k - kofs], P_sc_up[k - kofs], t_mid,
+                                          P_ls_lo[k - kofs], P_ls_hi[k - kofs], cmin, cmax);
+                            P_ls_mid[k - kofs] = cmin; L_lsmid2[k - k0] = cmax;
+                            if (leader) { acc0 += fabs(rho) * 2.0 * (double)cmin; acc1 += fabs(rho) * 2.0 * (double)cmax; }
+                        }
+                        const double S_min = S0 + block_sum_f64<LAD_BLOCK>(acc0, sh.red), S_max = S0 + block_sum_f64<LAD_BLOCK>(acc1, sh.red);
+                        if (S_max < -tol) {          // certainly still descending at t_mid
+                            PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_lo[k - kofs] = P_ls_mid[k - kofs];
+                            t_lo = t_mid; S_lo = S_max;
+                            continue;
+                        }
+                        if (S_min >= -tol) {         // certainly past the minimiser
+                            PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_hi[k - kofs] = L_lsmid2[k - k0];
+                            t_hi = t_mid; S_hi = S_min;
+                            continue;
+                        }
+                        approx = false;              // undecided at sample resolution: exact from here on (same pivot)
+                    }
                     double acc = 0.0;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
                         if (rho == 0.0) continue;
-                        uint32_t c = crossed(COOP, ra, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_pat_start[k - kofs], P_pat_start[(k + 1) - kofs], P_sc_lo[k - kofs], P_sc_up[k - kofs],
+                        RK(k);
+                        uint32_t c = crossed(COOP, rk, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_pat_start[k - kofs], P_pat_start[(k + 1) - kofs], P_sc_lo[k - kofs], P_sc_up[k - kofs],
                                              t_mid, P_ls_lo[k - kofs], P_ls_hi[k - kofs]);
                         P_ls_mid[k - kofs] = c;
                         if (leader) acc += fabs(rho) * 2.0 * (double)c;
@@ -840,25 +994,30 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     }
                     if (go_hi) { t_hi = t_mid; S_hi = S_mid; } else { t_lo = t_mid; S_lo = S_mid; }
                 }
-                (void)S_hi;
-                if (tid == 0) sh.S_lo = S_lo;
+                (void)S_hi; (void)S_lo;
+                // slope of the crossed set the walk starts from (sample-only rounds leave lower bounds in ls_lo, so
+                // it is recomputed from the counts; with exact counts it equals the slope at t_lo)
+                {
+                    double acc = 0.0;
+                    PAT_LOOP(k) { double rho = P_sc_rho[k - kofs]; if (rho != 0.0 && leader) acc += fabs(rho) * 2.0 * (double)P_ls_lo[k - kofs]; }
+                    const double S_start = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
+                    if (tid == 0) sh.S_lo = S_start;
+                }
                 __syncthreads();
-                // ---- walk the few remaining breakpoint groups in order of t
+                // ---- walk the few remaining breakpoint groups in order of t.  ls_lo may split a tie group (sample
+                // bounds are not group aligned): a step crosses the rest of the group its first uncrossed row is in.
                 for (int step = 0; step < 4096; ++step) {
                     double tb = INFINITY; int kb = 0x7fffffff;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
                         if (rho == 0.0 || P_ls_hi[k - kofs] <= P_ls_lo[k - kofs]) continue;
                         uint32_t r = rho > 0 ? P_sc_up[k - kofs] + P_ls_lo[k - kofs] : P_sc_lo[k - kofs] - 1 - P_ls_lo[k - kofs];
-                        double t = (ra.a[r] + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
+                        RK(k);
+                        double t = (row_val(rk, r) + P_pat_eps[k - kofs] - P_sc_s[k - kofs]) / rho;
                         if (t < 0) t = 0;
                         if (t < tb || (t == tb && (int)k < kb)) { tb = t; kb = (int)k; }
                     }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        double t2 = __shfl_down(tb, off); int k2 = __shfl_down(kb, off);
-                        if (t2 < tb || (t2 == tb && k2 < kb)) { tb = t2; kb = k2; }
-                    }
+                    wave_reduce_pair(tb, kb, [](double t2, int k2, double t, int k) { return t2 < t || (t2 == t && k2 < k); });
                     if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tb; sh.red_k[tid >> 6] = kb; }
                     __syncthreads();
                     if (tid == 0) {
@@ -871,9 +1030,24 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                             double rho = P_sc_rho[kk - kofs];
                             uint32_t st = P_pat_start[kk - kofs], en = P_pat_start[(kk + 1) - kofs];
                             uint32_t r = rho > 0 ? P_sc_up[kk - kofs] + P_ls_lo[kk - kofs] : P_sc_lo[kk - kofs] - 1 - P_ls_lo[kk - kofs];
-                            double av = ra.a[r];
-                            uint32_t g0 = lb(false, ra, st, en, av), g1 = ub_(false, ra, g0, en, av);
-                            uint32_t gs = g1 - g0;
+                            RK(kk);
+                            double av = row_val(rk, r);
+                            // extent [g0,g1) of the tie group of r: a short scan through the cached rows, else the full searches
+                            uint32_t g0 = r, g1 = r + 1;
+                            bool open0 = true, open1 = true;
+                            for (int q = 0; q < 32 && open0; ++q) {
+                                if (g0 == st) { open0 = false; break; }
+                                if (g0 - 1 - rk.c_row0 >= rk.c_n) break;
+                                if (rk.cache[g0 - 1 - rk.c_row0] == av) --g0; else open0 = false;
+                            }
+                            for (int q = 0; q < 32 && open1; ++q) {
+                                if (g1 == en) { open1 = false; break; }
+                                if (g1 - rk.c_row0 >= rk.c_n) break;
+                                if (rk.cache[g1 - rk.c_row0] == av) ++g1; else open1 = false;
+                            }
+                            if (open0) g0 = lb(false, ra, st, g0, av);
+                            if (open1) g1 = ub_(false, ra, g1, en, av);
+                            uint32_t gs = rho > 0 ? g1 - r : r - g0 + 1;      // rows of the group not crossed yet
                             double Sn = sh.S_lo + 2.0 * fabs(rho) * (double)gs;
                             P_ls_lo[kk - kofs] += gs;
                             sh.S_lo = Sn;
@@ -883,6 +1057,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
                     __syncthreads();
                     if (sh.ent_type >= 0 || sh.done) break;
                 }
+#undef RK
             }
         }
         if (sh.done) break;
@@ -948,6 +1123,18 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
         A.status[s] = (it >= max_it) ? 1 : sh.status;
         A.iters[s] = it;
     }
+}
+
+template <int PS>
+__global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
+    __shared__ LadLds<PS> m;
+    const int s = blockIdx.x;   // one workgroup per species of the db; species without work leave at once
+    const int p = A.sp_p[s];
+    if (A.need && !A.need[s]) return;
+    if (p <= 0) { if (threadIdx.x == 0) { A.status[s] = 0; A.iters[s] = 0; } return; }
+    const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
+    if (k1 - k0 <= (uint32_t)LAD_KLDS) lad_solve_body<PS, true>(A, m, s, p, k0, k1);
+    else lad_solve_body<PS, false>(A, m, s, p, k0, k1);
 }
 
 // objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450)
