@@ -190,17 +190,20 @@ int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hi
     PTX_HIP(ctx, hipSetDevice(ctx->device));
     uint32_t S = db->S;
     DevBuf<unsigned long long> &d_cnt = const_cast<pantax_hip_db *>(db)->d_counters;
-    PTX_HIP(ctx, d_cnt.alloc(33ull * 4 * S));   // final sums + 32 replicas (stage_bin.hip)
+    PTX_HIP(ctx, d_cnt.alloc(bin_counter_words(S)));
     PTX_TRY(bin_reads_launch(ctx, db, reads, d_cnt.p));
-    std::vector<unsigned long long> h(4ull * S);
-    PTX_TRY(download(ctx, h.data(), d_cnt.p, 4ull * S));
+    // one pinned download: the sums and the head of (species, qlen) for species_profile's first-1000 test
+    const size_t res_bytes = bin_result_words(S) * sizeof(unsigned long long);
+    PTX_HIP(ctx, ctx->pin_down.reserve(res_bytes));
+    PTX_HIP(ctx, hipMemcpyAsync(ctx->pin_down.p, d_cnt.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (species_idx_out) PTX_TRY(download(ctx, species_idx_out, reads->d_species.p, reads->R));
-    // the head of (species, qlen) rides on the same sync: species_profile's first-1000 test (profile.rs:312-319)
-    const uint64_t npre = std::min<uint64_t>(reads->R, 2048);
-    reads->h_pre_species.resize(npre); reads->h_pre_qlen.resize(npre);
-    PTX_TRY(download(ctx, reads->h_pre_species.data(), reads->d_species.p, npre));
-    PTX_TRY(download(ctx, reads->h_pre_qlen.data(), reads->d_qlen.p, npre));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long *h = reinterpret_cast<const unsigned long long *>(ctx->pin_down.p);
+    const uint64_t npre = std::min<uint64_t>(reads->R, BIN_PREFIX);
+    const int32_t *pre_sp = reinterpret_cast<const int32_t *>(h + 4ull * S);
+    const uint32_t *pre_q = reinterpret_cast<const uint32_t *>(pre_sp + BIN_PREFIX);
+    reads->h_pre_species.assign(pre_sp, pre_sp + npre);
+    reads->h_pre_qlen.assign(pre_q, pre_q + npre);
     int64_t *outs[4] = {read_count_out, base_sum_out, less_multi_out, uniq_count_out};
     for (int k = 0; k < 4; ++k)
         if (outs[k]) for (uint32_t s = 0; s < S; ++s) outs[k][s] = (int64_t)h[(size_t)k * S + s];
@@ -216,11 +219,11 @@ int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_
     if (trio_bases_out && !db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: trio_bases requested but pantax_hip_trio_index has not run");
     const uint8_t *d_active = nullptr;
     if (species_active) {
-        PTX_TRY(upload(ctx, db->d_active, species_active, db->S));
+        PTX_TRY(upload_small(ctx, db->d_active, species_active, db->S));
         d_active = db->d_active.p;
     }
-    unsigned long long *d_abort = (unsigned long long *)ctx->d_scalars.p;
-    PTX_TRY(coverage_launch(ctx, db, reads, d_active, db->trio_built, d_abort));
+    PTX_TRY(coverage_launch(ctx, db, reads, d_active, db->trio_built));
+    unsigned long long *d_abort = db->d_abort;
     unsigned long long h_abort = 0;
     std::vector<uint32_t> cov32;
     if (bases_per_node_out) PTX_TRY(download(ctx, (unsigned long long *)bases_per_node_out, db->d_bases.p, db->V));

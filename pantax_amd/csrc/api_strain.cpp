@@ -66,10 +66,10 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
 }
 
 int fetch_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r) {
-    db->h_arena.resize(L.total);
-    PTX_TRY(download(ctx, db->h_arena.data(), db->d_arena.p, L.total));   // the one host round trip of the step
+    PTX_HIP(ctx, db->h_arena.reserve(L.total));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_arena.p, db->d_arena.p, L.total, hipMemcpyDeviceToHost, ctx->stream));   // the one host round trip of the step
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint8_t *b = db->h_arena.data();
+    const uint8_t *b = db->h_arena.p;
     r.amax = (const double *)(b + L.amax); r.nzsum = (const double *)(b + L.nzsum); r.obj1 = (const double *)(b + L.obj1); r.obj2 = (const double *)(b + L.obj2);
     r.x1 = (const double *)(b + L.x1); r.x2 = (const double *)(b + L.x2); r.ratio = (const unsigned long long *)(b + L.ratio);
     r.meanf = (const double *)(b + L.meanf);
@@ -107,7 +107,7 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     const ArenaLayout L(S, H);
     PTX_TRY(bind_arena(ctx, db, lb, L));
     const uint8_t *d_active = nullptr;
-    if (species_active) { PTX_TRY(upload(ctx, db->d_active, species_active, S)); d_active = db->d_active.p; }
+    if (species_active) { PTX_TRY(upload_small(ctx, db->d_active, species_active, S)); d_active = db->d_active.p; }
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};

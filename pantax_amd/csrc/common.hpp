@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/pantax_hip.h"
@@ -61,6 +62,26 @@ struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// page-locked host staging (grow-only): a copy from / to pageable memory makes the runtime stage and wait,
+// tens of microseconds per call; pinned copies are plain asynchronous DMA
+struct PinBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= n && p) return hipSuccess;
+        release();
+        size_t want = bytes < 65536 ? 65536 : bytes;
+        hipError_t e = hipHostMalloc((void **)&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+};
+
 struct TimedLaunch {
     const char *name;
     hipEvent_t start, stop;
@@ -77,6 +98,9 @@ struct Ctx {
     int n_cu = 256;
     // scratch reused across calls
     DevBuf<uint64_t> d_scalars;  // small counters (n_abort, ...)
+    PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
+    PinBuf pin_up;               // ring of small uploads; a step syncs at least once, far before the ring wraps
+    size_t pin_up_off = 0;
 };
 
 // RAII-less timing scope: records events around a launch when ctx->timing is on
@@ -90,6 +114,9 @@ struct KTimer {
 
 int collect_timings(Ctx *ctx);
 
+constexpr uint32_t BIN_PREFIX = 2048;   // head of (species, qlen) fetched with the counters (equal-length test, profile.rs:312-319)
+size_t bin_counter_words(uint32_t S);
+size_t bin_result_words(uint32_t S);
 constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
 constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership mask per node)
 
@@ -180,6 +207,9 @@ struct Db {
     std::vector<uint64_t> h_hap_trio_off;
     // coverage state (a8), resident for the strain step
     bool cov_done = false;
+    // d_bases, d_trio_bases, the abort counter and d_bitmap are windows of one arena: one memset per coverage pass
+    DevBuf<uint8_t> d_cov_arena;
+    unsigned long long *d_abort = nullptr;
     DevBuf<unsigned long long> d_bases;      // [V]
     DevBuf<uint32_t> d_bitmap;               // [ceil(L/32)+1]
     DevBuf<uint32_t> d_cov;                  // [V]
@@ -193,7 +223,7 @@ struct Db {
     DevBuf<double> d_hap_mean;               // [H]
     DevBuf<double> d_hap_part, d_hap_mean_sd; // two-level reduction scratch of the per-hap trio statistics
     DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
-    std::vector<uint8_t> h_arena;
+    PinBuf h_arena;                  // pinned mirror of d_arena
     // LP-row staging (lad_prepare)
     DevBuf<uint8_t> d_row_flag, d_pat_head;
     DevBuf<uint32_t> d_row_pos, d_pat_idx, d_scan_tmp, d_sort_table, d_tot2;
@@ -224,6 +254,21 @@ int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
     if (n) PTX_HIP(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
+// small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)
+constexpr size_t PIN_UP_RING = 1u << 20, PIN_UP_MAX = 1u << 16;
+template <class T>
+int upload_small(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
+    const size_t bytes = n * sizeof(T);
+    if (bytes == 0 || bytes > PIN_UP_MAX) return upload(ctx, dst, src, n);
+    PTX_HIP(ctx, dst.alloc(n));
+    PTX_HIP(ctx, ctx->pin_up.reserve(PIN_UP_RING));
+    size_t off = (ctx->pin_up_off + 63) & ~(size_t)63;
+    if (off + bytes > PIN_UP_RING) off = 0;
+    std::memcpy(ctx->pin_up.p + off, src, bytes);
+    ctx->pin_up_off = off + bytes;
+    PTX_HIP(ctx, hipMemcpyAsync(dst.p, ctx->pin_up.p + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
 template <class T>
 int download(Ctx *ctx, T *dst, const T *src_dev, size_t n) {
     if (n) PTX_HIP(ctx, hipMemcpyAsync(dst, src_dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
@@ -239,7 +284,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 
 // ---- stage entry points (host launchers, defined in the .hip files) ---------------------------
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
-int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, unsigned long long *d_abort);
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 

@@ -9,6 +9,7 @@
 // + R (mapq) + 4R (species out).  One thread per read (short-read walks are ~6 steps; adjacent
 // threads read adjacent id runs so the wave's loads stay within a few cache lines); the species
 // counters are staged in an LDS histogram and flushed with one 64-bit atomic per touched bin.
+#include <algorithm>
 #include "common.hpp"
 
 namespace ptx {
@@ -135,22 +136,35 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
     }
 }
 
-__global__ void __launch_bounds__(256) bin_reduce_kernel(int n, const unsigned long long *__restrict__ rep, unsigned long long *__restrict__ out) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    unsigned long long s = 0;
-    for (int r = 0; r < BIN_REPL; ++r) s += rep[(size_t)r * n + i];
-    out[i] = s;
+// sums the replicas and appends the head of (species, qlen) -- everything the host reads after binning sits in
+// one contiguous block: [4*S u64 sums][BIN_PREFIX i32 species][BIN_PREFIX u32 qlen]
+__global__ void __launch_bounds__(256) bin_reduce_kernel(int n, const unsigned long long *__restrict__ rep, unsigned long long *__restrict__ out,
+                                                         uint32_t npre, const int32_t *__restrict__ species, const uint32_t *__restrict__ qlen) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        unsigned long long s = 0;
+        for (int r = 0; r < BIN_REPL; ++r) s += rep[(size_t)r * n + i];
+        out[i] = s;
+    }
+    if ((uint32_t)i < npre) {
+        int32_t *pre_sp = reinterpret_cast<int32_t *>(out + n);
+        uint32_t *pre_q = reinterpret_cast<uint32_t *>(pre_sp + BIN_PREFIX);
+        pre_sp[i] = species[i];
+        pre_q[i] = qlen[i];
+    }
 }
 
-// d_counters: [(BIN_REPL + 1) * 4 * S]; the final sums land in the first 4*S words
+size_t bin_counter_words(uint32_t S) { return (size_t)(BIN_REPL + 1) * 4 * S + BIN_PREFIX; }
+size_t bin_result_words(uint32_t S) { return (size_t)4 * S + BIN_PREFIX; }
+
+// d_counters: bin_counter_words(S) u64 = [4*S sums][prefix block][BIN_REPL replicas of 4*S]
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters) {
     int S = (int)db->S;
     PTX_HIP(ctx, rd->d_species.alloc(rd->R));
-    PTX_HIP(ctx, hipMemsetAsync(d_counters, 0, (size_t)(BIN_REPL + 1) * 4 * S * sizeof(unsigned long long), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(d_counters, 0, bin_counter_words(S) * sizeof(unsigned long long), ctx->stream));
     if (rd->R == 0) { rd->binned = true; return 0; }
     unsigned long long *d_final = d_counters;
-    d_counters = d_counters + 4ull * S;   // replicas
+    d_counters = d_counters + bin_result_words(S);   // replicas
     int grid = grid_for(rd->R, BIN_BLOCK, ctx->n_cu * 8);
     bool lds = S <= BIN_LDS_SPECIES;
     {
@@ -166,7 +180,9 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
         }
 #undef BIN_ARGS
     }
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3((4 * S + 255) / 256), dim3(256), 0, ctx->stream, 4 * S, d_counters, d_final);
+    const uint32_t npre = (uint32_t)std::min<uint64_t>(rd->R, BIN_PREFIX);
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3((std::max<uint32_t>(4 * S, npre) + 255) / 256), dim3(256), 0, ctx->stream, 4 * S, d_counters, d_final,
+                       npre, rd->d_species.p, rd->d_qlen.p);
     PTX_HIP(ctx, hipGetLastError());
     rd->binned = true;
     return 0;

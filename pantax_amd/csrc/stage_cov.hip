@@ -393,18 +393,20 @@ __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_
     }
 }
 
-int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, unsigned long long *d_abort) {
-    uint64_t words = (db->L + 31) / 32 + 1;
-    PTX_HIP(ctx, db->d_bases.alloc(db->V));
-    PTX_HIP(ctx, db->d_bitmap.alloc(words));
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio) {
+    const uint64_t words = (db->L + 31) / 32 + 1;
+    const uint64_t U = with_trio ? db->U : 0;
+    // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32]
+    const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = off_abort + 8, total = off_bm + words * 4;
+    PTX_HIP(ctx, db->d_cov_arena.alloc(total));
+    uint8_t *base = db->d_cov_arena.p;
+    db->d_bases.view(base, db->V);
+    db->d_trio_bases.view(base + off_trio, U ? U : 1);
+    db->d_abort = reinterpret_cast<unsigned long long *>(base + off_abort);
+    db->d_bitmap.view(base + off_bm, words);
+    unsigned long long *d_abort = db->d_abort;
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
-    PTX_HIP(ctx, hipMemsetAsync(db->d_bases.p, 0, db->V * sizeof(unsigned long long), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(db->d_bitmap.p, 0, words * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(d_abort, 0, sizeof(unsigned long long), ctx->stream));
-    if (with_trio) {
-        PTX_HIP(ctx, db->d_trio_bases.alloc(db->U));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_trio_bases.p, 0, (db->U ? db->U : 1) * sizeof(unsigned long long), ctx->stream));
-    }
+    PTX_HIP(ctx, hipMemsetAsync(base, 0, total, ctx->stream));
     if (rd->R && rd->T_pad) {
         int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");

@@ -13,3 +13,13 @@ print("%-64s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg
 for n, c, t, a, mn, mx in rows:
     n = n.split("(")[0][-64:]
     print("%-64s %8d %14d %12.0f %12d %12d %6.2f%%" % (n, c, t, a, mn, mx, 100.0 * t / tot))
+
+# optional: --timeline N  prints the last N dispatches (start offset, duration, gap to the previous end) in us
+if "--timeline" in sys.argv:
+    n_last = int(sys.argv[sys.argv.index("--timeline") + 1])
+    tl = db.execute("select %s, start, end from kernels order by start" % name_col).fetchall()[-n_last:]
+    t0, prev = tl[0][1], None
+    print("\n%-56s %10s %9s %9s" % ("dispatch", "start_us", "dur_us", "gap_us"))
+    for n, st, en in tl:
+        print("%-56s %10.1f %9.1f %9.1f" % (n.split("(")[0][-56:], (st - t0) / 1e3, (en - st) / 1e3, (st - prev) / 1e3 if prev else 0.0))
+        prev = en
