@@ -98,6 +98,8 @@ struct Ctx {
     int n_cu = 256;
     // scratch reused across calls
     DevBuf<uint64_t> d_scalars;  // small counters (n_abort, ...)
+    DevBuf<uint32_t> d_scan_ws;  // chained-scan workspace: ticket + one state word per tile (primitives.hip)
+    uint32_t scan_epoch = 0;
     PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
     PinBuf pin_up;               // ring of small uploads; a step syncs at least once, far before the ring wraps
     size_t pin_up_off = 0;

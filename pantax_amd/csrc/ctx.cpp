@@ -99,6 +99,9 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto &p : ctx->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     ctx->d_scalars.release();
+    ctx->d_scan_ws.release();
+    ctx->pin_down.release();
+    ctx->pin_up.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1,7 +1,9 @@
 // primitives.hip -- exclusive scan + stable LSD radix sort (see primitives.hpp).
 // Both are HBM-streaming: scan moves 2 reads + 1 write of the input; each sort pass moves
 // (8*nw + 4) bytes per record in the histogram sweep and twice that in the scatter sweep.
+#include <algorithm>
 #include "primitives.hpp"
+#include "wave.hpp"
 
 namespace ptx {
 
@@ -38,71 +40,98 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
     return woff + incl - v;
 }
 
-template <class T>
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_reduce_kernel(const T *__restrict__ in, uint64_t n, uint32_t *__restrict__ sums) {
-    __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        uint64_t idx = base + (uint64_t)i * SCAN_BLOCK + threadIdx.x;
-        if (idx < n) s += (uint32_t)in[idx];
-    }
-    uint32_t tot;
-    (void)block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total) {
-    __shared__ uint32_t s_wave[16];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nb ? sums[i] : 0;
-        uint32_t tot;
-        uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
-        if (i < nb) sums[i] = ex + carry;
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
+// Single-pass chained scan (decoupled look-back): ONE launch per scan.  A workgroup takes a ticket (tiles are
+// therefore started in order, so the tiles it waits for are already running), scans its tile of SCAN_TILE items,
+// publishes {epoch, flag, value} of the tile in one 64-bit word -- first its aggregate, later its inclusive
+// prefix -- and wave 0 looks back over the predecessors 64 tiles at a time until it meets a published prefix.
+// The epoch (one per scan call) makes words left by earlier scans read as "not ready", so the workspace is never
+// cleared; the last ticket holder resets the ticket counter.  State words are agent-scope atomics: they are
+// served below the per-XCD L2s, which is what makes the hand-off visible across XCDs.
+constexpr uint64_t ST_AGG = 1, ST_PREFIX = 2;
+__device__ __forceinline__ uint64_t st_pack(uint32_t epoch, uint64_t flag, uint32_t v) { return ((uint64_t)epoch << 34) | (flag << 32) | v; }
 
 template <class T>
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_apply_kernel(const T *in, uint32_t *out, uint64_t n,  // in may alias out
-                                                                const uint32_t *__restrict__ sums) {
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(const T *in, uint32_t *out, uint64_t n,   // in may alias out
+                                                                  uint32_t *__restrict__ ws, uint32_t epoch, uint32_t *__restrict__ total) {
     __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+    __shared__ uint32_t s_tile, s_excl;
+    uint32_t *ticket = ws;
+    uint64_t *state = reinterpret_cast<uint64_t *>(ws + 2);
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile, nb = gridDim.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        uint64_t idx = base + i;
+        const uint64_t idx = base + i;
         v[i] = idx < n ? (uint32_t)in[idx] : 0;
         s += v[i];
     }
     uint32_t tot;
-    uint32_t off = block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot) + sums[blockIdx.x];
+    uint32_t off = block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot);
+    if (threadIdx.x < 64) {
+        uint32_t excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&state[0], st_pack(epoch, ST_PREFIX, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&state[tile], st_pack(epoch, ST_AGG, tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)tile - 1;
+            while (true) {
+                const int idx = look - lane;
+                uint64_t st;
+                bool ready;
+                do {
+                    st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st_pack(epoch, ST_PREFIX, 0);
+                    ready = (uint32_t)(st >> 34) == epoch && ((st >> 32) & 3) != 0;
+                } while (!__all(ready));
+                const unsigned long long pm = __ballot(((st >> 32) & 3) == ST_PREFIX);
+                const int first = pm ? __ffsll((long long)pm) - 1 : 64;
+                excl += wave_reduce(lane <= first ? (uint32_t)st : 0u, [](uint32_t x, uint32_t y) { return x + y; });
+                if (first < 64) break;
+                look -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&state[tile], st_pack(epoch, ST_PREFIX, excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    off += s_excl;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        uint64_t idx = base + i;
+        const uint64_t idx = base + i;
         if (idx < n) out[idx] = off;
         off += v[i];
     }
+    if (tile == nb - 1 && threadIdx.x == 0) {
+        if (total) *total = s_excl + tot;
+        *ticket = 0;   // every ticket of this launch has been taken
+    }
 }
 
-size_t scan_tmp_elems(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
+size_t scan_tmp_elems(uint64_t n) { return 16; }   // the scan workspace lives in the context (ctx->d_scan_ws); callers' scratch is unused
 
 template <class T>
 static int exclusive_scan_impl(Ctx *ctx, const T *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
+    (void)d_tmp;
     if (n == 0) {
         if (d_total) PTX_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
         return 0;
     }
-    uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    const uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    const size_t need = 2 + 2 * (size_t)nb;   // u32 words: ticket, pad, one u64 per tile
+    if (ctx->d_scan_ws.n < need) {
+        PTX_HIP(ctx, ctx->d_scan_ws.alloc(std::max<size_t>(need, 1u << 16)));
+        PTX_HIP(ctx, hipMemsetAsync(ctx->d_scan_ws.p, 0, ctx->d_scan_ws.bytes(), ctx->stream));
+        ctx->scan_epoch = 0;
+    }
+    if (++ctx->scan_epoch >= (1u << 30)) {   // epoch field wrapped: start over with a clean workspace
+        PTX_HIP(ctx, hipMemsetAsync(ctx->d_scan_ws.p, 0, ctx->d_scan_ws.bytes(), ctx->stream));
+        ctx->scan_epoch = 1;
+    }
     KTimer t(ctx, "exclusive_scan");
-    hipLaunchKernelGGL((scan_reduce_kernel<T>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, d_in, n, d_tmp);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_tmp, nb, d_total);
-    hipLaunchKernelGGL((scan_apply_kernel<T>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, d_in, d_out, n, d_tmp);
+    hipLaunchKernelGGL((scan_chained_kernel<T>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, d_in, d_out, n, ctx->d_scan_ws.p, ctx->scan_epoch, d_total);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
