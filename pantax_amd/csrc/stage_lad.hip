@@ -330,23 +330,49 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
 // LP rows: nodes with a_v > 0 (valid rows, profile.rs:1380-1385) and a non-empty mask; rows with an
 // empty mask only add the constant a_v to the objective and are handled by objective_kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) row_flag_kernel(uint64_t V, const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
-                                                       uint8_t *__restrict__ flag) {
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256)
-        flag[v] = (ab[v] > 0.0 && mask[v] != 0ull) ? 1 : 0;
-}
+// One launch: every workgroup compacts its tile of nodes and claims its output range with a single atomic
+// on the row counter.  Row order across workgroups is arbitrary, which is immaterial: the rows are sorted by
+// their full key (species, mask, a) next, and rows with equal keys are indistinguishable.
+constexpr int ROW_ITEMS = 8;
 __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
-                                                       const unsigned long long *__restrict__ mask, const uint8_t *__restrict__ flag,
-                                                       const uint32_t *__restrict__ pos, uint64_t *__restrict__ k0, uint64_t *__restrict__ k1,
-                                                       uint64_t *__restrict__ k2) {
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256) {
-        if (!flag[v]) continue;
+                                                       const unsigned long long *__restrict__ mask, uint32_t *__restrict__ n_rows,
+                                                       uint64_t *__restrict__ k0, uint64_t *__restrict__ k1, uint64_t *__restrict__ k2) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ROW_ITEMS;
+    double a[ROW_ITEMS];
+    unsigned long long m[ROW_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < ROW_ITEMS; ++i) {
+        const uint64_t v = base + i;
+        a[i] = 0.0; m[i] = 0;
+        if (v < V) { a[i] = ab[v]; m[i] = mask[v]; }
+        cnt += (a[i] > 0.0 && m[i] != 0ull) ? 1u : 0u;
+    }
+    // exclusive offsets inside the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { uint32_t t = s_wave[w]; if (w < wave) woff += t; tot += t; }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_rows, tot) : 0u;
+    __syncthreads();
+    uint32_t j = s_base + woff + incl - cnt;
+#pragma unroll
+    for (int i = 0; i < ROW_ITEMS; ++i) {
+        if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
+        const uint64_t v = base + i;
         uint32_t lo = 0, hi = S;   // species of node v: last s with node_base[s] <= v
         while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; }
-        uint32_t j = pos[v];
         k0[j] = lo - 1;
-        k1[j] = mask[v];
-        k2[j] = (uint64_t)__double_as_longlong(ab[v]);   // positive doubles order like their bit patterns
+        k1[j] = m[i];
+        k2[j] = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
+        ++j;
     }
 }
 __global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t bound, const uint32_t *__restrict__ d_n, const uint64_t *__restrict__ k0,
@@ -413,27 +439,21 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
                            (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
     }
-    // rows: flag -> scan -> emit -> sort by (species, mask, a)
+    // rows: compact -> sort by (species, mask, a)
     Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
-    DevBuf<uint8_t> &flag = dbm->d_row_flag;
-    DevBuf<uint32_t> &pos = dbm->d_row_pos, &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
-    PTX_HIP(ctx, flag.alloc(V)); PTX_HIP(ctx, pos.alloc(V));
+    DevBuf<uint32_t> &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
     PTX_HIP(ctx, lb->d_counts.alloc(4));
     uint32_t *d_n = lb->d_counts.p, *d_K = lb->d_counts.p + 1, *d_ovf = lb->d_counts.p + 2;
     int gridV = grid_for(V, 256, ctx->n_cu * 8);
-    {
-        KTimer t(ctx, "row_flag_kernel");
-        hipLaunchKernelGGL(row_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, lb->d_ab.p, (unsigned long long *)lb->d_mask.p, flag.p);
-    }
-    PTX_TRY(exclusive_scan_u8(ctx, flag.p, pos.p, V, scan_tmp.p, d_n));
     DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
     for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); PTX_HIP(ctx, kb[w].alloc(V)); }
     {
-        KTimer t(ctx, "row_emit_kernel");
-        hipLaunchKernelGGL(row_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
-                           (unsigned long long *)lb->d_mask.p, flag.p, pos.p, ka[0].p, ka[1].p, ka[2].p);
+        KTimer t(ctx, "row_emit_kernel");   // d_n was zeroed with the step's result arena
+        const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
+        hipLaunchKernelGGL(row_emit_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
+                           (unsigned long long *)lb->d_mask.p, d_n, ka[0].p, ka[1].p, ka[2].p);
     }
     std::vector<SortPass> passes;
     add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
