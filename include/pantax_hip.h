@@ -163,6 +163,25 @@ int pantax_hip_abundance_filter(uint32_t n_species, const uint64_t *hap_off, con
                                 double *sum_all_out, double *sum_pass_out,
                                 double *species_sum_all_out /*[S] or NULL*/, double *species_sum_pass_out /*[S] or NULL*/);
 
+/* ---- resident step: the in-memory core of profile::profile (profile.rs:3325-3364) between "GAF parsed"
+ * and "tables written", over a db and reads that are already in HBM.  One call = rcls_profile ->
+ * species_profiling -> trio_nodes_info (when rebuild_trio) -> get_node_abundances -> strain_profiling ->
+ * the abundance_est filters; the stages above remain available one by one and give identical results.
+ * The host waits once, at the end.  Outputs are the LOCAL quantities of this rank's species: the global
+ * normalisers (profile.rs:341, :3198, :3243) are sums of absolute_out / species_sum_*_out over ranks. */
+typedef struct {
+    double unique_trio_nodes_fraction, unique_trio_nodes_mean_count_f, single_cov_ratio, single_cov_diff; /* --fr --fc --sr --sd */
+    int64_t min_cov, min_depth;
+    int32_t shift, filtered, sample_nodes /* must be 0 */, rebuild_trio /* 1 = like the reference, every run */;
+} pantax_hip_step_config;
+
+int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads,
+                            const double *avg_len /*[S] species_genomes_stats.txt*/, const pantax_hip_step_config *cfg,
+                            uint8_t *keep_out /*[S] species kept by species_profiling*/, double *absolute_out /*[S] predicted_coverage*/,
+                            pantax_hip_hap_metrics *metrics_out /*[H]*/, pantax_hip_solve_info *info_out /*[S] or NULL*/,
+                            uint8_t *pass_out /*[H]*/, double *species_sum_all_out /*[S] or NULL*/,
+                            double *species_sum_pass_out /*[S] or NULL*/);
+
 /* ---- solver seam: one species, host buffers in, same meaning as X_opt's arguments
  * (profile.rs:2690-2698).  cand_path_idx = possible_paths_idx; fixed_zero[k]=1 pins x_k = 0
  * (second solve, profile.rs:1484-1488).  x_out [n_cand]; path_cov_ratio_out [n_cand] or NULL. */

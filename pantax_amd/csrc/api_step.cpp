@@ -1,0 +1,60 @@
+// api_step.cpp -- pantax_hip_profile_step: one pass of the hot path over RESIDENT inputs, the in-memory
+// core of profile::profile (profile.rs:3325-3364) between "GAF parsed" and "tables written":
+// rcls_profile -> species_profiling -> (trio_nodes_info) -> get_node_abundances -> strain_profiling ->
+// abundance_est filters.  Everything is enqueued on the ctx stream; the host waits ONCE, at the end.
+// The species decision (a3) is taken by a device kernel, so binning, coverage and the LP solves follow each
+// other without a round trip.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "lad.hpp"
+
+using namespace ptx;
+
+namespace {
+struct SpOut { Db *db; uint8_t *keep; double *absolute; };
+void copy_species_out(void *arg) {   // runs right after the step's single wait
+    SpOut *o = static_cast<SpOut *>(arg);
+    const uint32_t S = o->db->S;
+    std::memcpy(o->absolute, o->db->h_sp_out.p, sizeof(double) * S);
+    std::memcpy(o->keep, o->db->h_sp_out.p + sizeof(double) * S, S);
+}
+}  // namespace
+
+extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
+                                       const pantax_hip_step_config *cfg, uint8_t *keep_out, double *absolute_out,
+                                       pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, uint8_t *pass_out,
+                                       double *species_sum_all_out, double *species_sum_pass_out) {
+    if (!ctx || !db || !reads || !avg_len || !cfg || !keep_out || !absolute_out || !met || !pass_out) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step: the db was uploaded without graphs (ranges only)");
+    const uint32_t S = db->S;
+    // a2 + a3 counters
+    PTX_HIP(ctx, db->d_counters.alloc(bin_counter_words(S)));
+    PTX_TRY(bin_reads_launch(ctx, db, reads, db->d_counters.p));
+    // a3 decision on the device: keep -> d_active, predicted_coverage -> d_sp_abs
+    PTX_TRY(upload_small(ctx, db->d_avg_len, avg_len, S));
+    PTX_HIP(ctx, db->d_active.alloc(S)); PTX_HIP(ctx, db->d_sp_abs.alloc(S));
+    PTX_TRY(species_profile_launch(ctx, db, reads, db->d_counters.p, db->d_avg_len.p, cfg->filtered, db->d_active.p, db->d_sp_abs.p));
+    PTX_HIP(ctx, db->h_sp_out.reserve(sizeof(double) * S + S));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_abs.p, sizeof(double) * S, hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p + sizeof(double) * S, db->d_active.p, S, hipMemcpyDeviceToHost, ctx->stream));
+    // a7 (the reference rebuilds trio_nodes_info every run, profile.rs:2936), a8
+    if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
+    if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
+    PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));
+    // a9 .. a14
+    pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,
+                                cfg->shift, cfg->sample_nodes};
+    PTX_TRY(strain_enqueue(ctx, db, &sc, db->d_active.p));
+    SpOut so{db, keep_out, absolute_out};
+    std::vector<pantax_hip_solve_info> info(S);
+    PTX_TRY(strain_finish(ctx, db, &sc, keep_out, absolute_out, met, info.data(), copy_species_out, &so));
+    if (info_out) std::memcpy(info_out, info.data(), sizeof(pantax_hip_solve_info) * S);
+    // a15 filters (host scalars)
+    std::vector<uint8_t> reported(S);
+    for (uint32_t s = 0; s < S; ++s) reported[s] = (keep_out[s] && info[s].status1 == 0 && info[s].status2 == 0) ? 1 : 0;
+    return pantax_hip_abundance_filter(S, db->h_hap_off.data(), met, reported.data(), cfg->single_cov_diff, cfg->min_cov, pass_out, nullptr, nullptr,
+                                       species_sum_all_out, species_sum_pass_out);
+}

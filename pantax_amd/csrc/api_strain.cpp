@@ -65,9 +65,12 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
     return 0;
 }
 
-int fetch_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r) {
+int fetch_arena_enqueue(Ctx *ctx, Db *db, const ArenaLayout &L) {
     PTX_HIP(ctx, db->h_arena.reserve(L.total));
     PTX_HIP(ctx, hipMemcpyAsync(db->h_arena.p, db->d_arena.p, L.total, hipMemcpyDeviceToHost, ctx->stream));   // the one host round trip of the step
+    return 0;
+}
+int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r) {
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint8_t *b = db->h_arena.p;
     r.amax = (const double *)(b + L.amax); r.nzsum = (const double *)(b + L.nzsum); r.obj1 = (const double *)(b + L.obj1); r.obj2 = (const double *)(b + L.obj2);
@@ -85,29 +88,19 @@ int fetch_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw 
 
 }  // namespace
 
-extern "C" {
+namespace ptx {
 
-int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active,
-                              const double *species_coverage, pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out) {
-    if (!ctx || !db || !cfg || !met) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+// Enqueues the whole strain step and the download of its result arena; nothing waits for the host.
+// d_active: device [S] or null.
+int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active) {
     if (!db->cov_done) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_node_coverage first");
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_trio_index first");
     if (cfg->sample_nodes != 0)
         return fail(ctx, PANTAX_HIP_E_LIMIT, "strain_profile: --sample %d requested; row sub-sampling (profile.rs:1394-1400, rand 0.9.2 ChaCha12) is not implemented, run with sample 0", cfg->sample_nodes);
     const uint32_t S = db->S;
-    const uint64_t H = db->H;
-    std::memset(met, 0, sizeof(pantax_hip_hap_metrics) * H);
-    std::vector<pantax_hip_solve_info> info(S);
-    std::memset(info.data(), 0, sizeof(pantax_hip_solve_info) * S);
-    for (auto &i : info) i.obj1 = i.obj2 = NAN;
-
-    // ---- enqueue the whole step ---------------------------------------------------------------
     LadBatch &lb = db->lad;
-    const ArenaLayout L(S, H);
+    const ArenaLayout L(S, db->H);
     PTX_TRY(bind_arena(ctx, db, lb, L));
-    const uint8_t *d_active = nullptr;
-    if (species_active) { PTX_TRY(upload_small(ctx, db->d_active, species_active, S)); d_active = db->d_active.p; }
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
@@ -120,8 +113,26 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     // LP 2 only where the second filter dropped a column; elsewhere LP2 == LP1 (m.reset() + no new constraint,
     // profile.rs:1482-1490) and its optimum is the one already computed
     PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax_bound, lb.d_need2.p, lb.d_fixed2.p, lb.d_x2.p, lb.d_obj2.p, lb.d_status2.p, lb.d_iters2.p));
+    PTX_TRY(fetch_arena_enqueue(ctx, db, L));
+    return 0;
+}
+
+// Waits for the step (the one host round trip) and does the reporting arithmetic.  species_active /
+// species_coverage: host [S] (may be null), read only after the wait -- a resident step fills them from the
+// device's own species decisions through `after_wait`.
+int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active, const double *species_coverage,
+                  pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, void (*after_wait)(void *), void *after_wait_arg) {
+    const uint32_t S = db->S;
+    const uint64_t H = db->H;
+    std::memset(met, 0, sizeof(pantax_hip_hap_metrics) * H);
+    std::vector<pantax_hip_solve_info> info(S);
+    std::memset(info.data(), 0, sizeof(pantax_hip_solve_info) * S);
+    for (auto &i : info) i.obj1 = i.obj2 = NAN;
+    LadBatch &lb = db->lad;
+    const ArenaLayout L(S, H);
     StrainRaw r;
-    PTX_TRY(fetch_arena(ctx, db, lb, L, r));                                                // the one host round trip
+    PTX_TRY(fetch_arena_wait(ctx, db, lb, L, r));                                           // the one host round trip
+    if (after_wait) after_wait(after_wait_arg);
     lb.n_rows = r.counts[0]; lb.K = r.counts[1];
     lb.h_sp_pat_off.assign(r.sp_pat_off, r.sp_pat_off + S + 1);
 
@@ -222,6 +233,20 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     }
     if (info_out) std::memcpy(info_out, info.data(), sizeof(pantax_hip_solve_info) * S);
     return 0;
+}
+
+}  // namespace ptx
+
+extern "C" {
+
+int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active,
+                              const double *species_coverage, pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out) {
+    if (!ctx || !db || !cfg || !met) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint8_t *d_active = nullptr;
+    if (species_active) { PTX_TRY(upload_small(ctx, db->d_active, species_active, db->S)); d_active = db->d_active.p; }
+    PTX_TRY(strain_enqueue(ctx, db, cfg, d_active));
+    return strain_finish(ctx, db, cfg, species_active, species_coverage, met, info_out, nullptr, nullptr);
 }
 
 int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *node_len, const double *node_abundance,

@@ -119,6 +119,9 @@ int collect_timings(Ctx *ctx);
 constexpr uint32_t BIN_PREFIX = 2048;   // head of (species, qlen) fetched with the counters (equal-length test, profile.rs:312-319)
 size_t bin_counter_words(uint32_t S);
 size_t bin_result_words(uint32_t S);
+struct Db; struct Reads;
+int species_profile_launch(Ctx *ctx, const Db *db, const Reads *rd, const unsigned long long *d_counters, const double *d_avg_len, int filtered,
+                           uint8_t *d_keep, double *d_absolute);
 constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
 constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership mask per node)
 
@@ -226,6 +229,8 @@ struct Db {
     DevBuf<double> d_hap_part, d_hap_mean_sd; // two-level reduction scratch of the per-hap trio statistics
     DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
     PinBuf h_arena;                  // pinned mirror of d_arena
+    DevBuf<double> d_avg_len, d_sp_abs;   // resident step: species lengths in, predicted_coverage out (d_active holds keep)
+    PinBuf h_sp_out;                 // [S f64 absolute][S u8 keep]
     // LP-row staging (lad_prepare)
     DevBuf<uint8_t> d_row_flag, d_pat_head;
     DevBuf<uint32_t> d_row_pos, d_pat_idx, d_scan_tmp, d_sort_table, d_tot2;

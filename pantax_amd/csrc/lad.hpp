@@ -21,4 +21,10 @@ int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_a
 int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
                          uint8_t *d_fixed2, uint8_t *d_need2);
 
+// the strain step in two halves (api_strain.cpp): everything enqueued / the one wait + host reporting
+int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active);
+int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active, const double *species_coverage,
+                  pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, void (*after_wait)(void *), void *after_wait_arg);
+int trio_index_build(Ctx *ctx, Db *db);
+
 }  // namespace ptx

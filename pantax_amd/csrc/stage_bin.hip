@@ -188,4 +188,58 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// a3 finishing on the device (species_profiling, profile.rs:299-349; same arithmetic as
+// pantax_hip_species_profile in api_host.cpp), so that a resident step never waits for the host between
+// binning and coverage.  One wave: (1) the equal-length test over the first 1000 binned rows
+// (:312-319) by ballots over 64 rows at a time, (2) the MAPQ filter (:224-245) and
+// predicted_coverage = base_count / avg_len (:336) per species.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) species_profile_kernel(uint64_t R, const int32_t *__restrict__ species, const uint32_t *__restrict__ qlen,
+                                                             uint32_t S, const unsigned long long *__restrict__ counters /*[4][S]*/,
+                                                             const double *__restrict__ avg_len, int filtered, uint8_t *__restrict__ keep_out,
+                                                             double *__restrict__ absolute_out) {
+    const int lane = threadIdx.x;
+    uint32_t seen = 0;
+    long long first_len = -1;
+    bool equal = true;
+    for (uint64_t base = 0; base < R && seen < 1000; base += 64) {
+        const uint64_t r = base + lane;
+        int sp = -1;
+        uint32_t q = 0;
+        if (r < R) { sp = species[r]; q = qlen[r]; }
+        const unsigned long long b = __ballot(sp >= 0);
+        if (!b) continue;
+        if (seen == 0) first_len = (long long)__shfl(q, __ffsll((long long)b) - 1);
+        const uint32_t rank = seen + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (__any(sp >= 0 && rank < 1000 && (long long)q != first_len)) equal = false;
+        seen += (uint32_t)__popcll(b);
+    }
+    if (seen == 0) equal = false;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const long long rc = (long long)counters[s], bs = (long long)counters[(size_t)S + s], lm = (long long)counters[2 * (size_t)S + s],
+                        uq = (long long)counters[3 * (size_t)S + s];
+        uint8_t keep = 0;
+        double absolute = 0.0;
+        bool ok = rc != 0;
+        if (ok && filtered) ok = lm != 0 && uq > 0 && (double)lm > (double)rc / 10.0;
+        if (ok) ok = avg_len[s] > 0.0;
+        if (ok) {
+            const long long base_count = equal ? rc * first_len : bs;
+            keep = 1;
+            absolute = (double)base_count / avg_len[s];
+        }
+        keep_out[s] = keep;
+        absolute_out[s] = absolute;
+    }
+}
+
+int species_profile_launch(Ctx *ctx, const Db *db, const Reads *rd, const unsigned long long *d_counters, const double *d_avg_len, int filtered,
+                           uint8_t *d_keep, double *d_absolute) {
+    hipLaunchKernelGGL(species_profile_kernel, dim3(1), dim3(64), 0, ctx->stream, rd->R, rd->d_species.p, rd->d_qlen.p, db->S, d_counters, d_avg_len,
+                       filtered, d_keep, d_absolute);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 }  // namespace ptx

@@ -28,6 +28,7 @@ class Engine:
         self.db = None
         self.reads = None
         self._keep = []
+        self._step_buf = None
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -186,6 +187,23 @@ class Engine:
         info = (_ffi.SolveInfo * self.S)()
         self._check(self.lib.pantax_hip_strain_profile(self.ctx, self.db, C.byref(cfg), p(act), p(cov), met, info))
         return met, info
+
+    def profile_step(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
+                     rebuild_trio=True):
+        """One resident pass of the hot path in a single call (pantax_hip_profile_step): the host waits once.
+        -> keep [S] uint8, predicted_coverage [S], metrics [H], info [S], pass [H] uint8, sum_all [S], sum_pass [S]"""
+        if self._step_buf is None or self._step_buf[0] != (self.S, self.H):
+            self._step_buf = ((self.S, self.H), np.zeros(self.S, dtype=np.uint8), np.zeros(self.S),
+                              (_ffi.HapMetrics * max(self.H, 1))(), (_ffi.SolveInfo * self.S)(),
+                              np.zeros(max(self.H, 1), dtype=np.uint8), np.zeros(self.S), np.zeros(self.S))
+            self._step_ptr = [p(a) if isinstance(a, np.ndarray) else a for a in self._step_buf[1:]]
+        _, keep, absolute, met, info, passed, s_all, s_pass = self._step_buf
+        avg = as_c(avg_len, np.float64)
+        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), 0, int(rebuild_trio))
+        self._check(self.lib.pantax_hip_profile_step(self.ctx, self.db, self.reads, p(avg), C.byref(cfg), *self._step_ptr))
+        if rebuild_trio:
+            self.U = None
+        return keep, absolute, met, info, passed[: self.H], s_all, s_pass
 
     def pao_solve(self, node_len, node_abundance, node_base_cov, path_off, path_nodes, cand, fixed_zero=None):
         node_len = as_c(node_len, np.int64)

@@ -70,24 +70,34 @@ class TorchComm:
         return [r for part in out for r in part]
 
 
-def local_stage(eng, avg_len, cfg):
-    """Everything a rank computes on its own species shard (device stages + host filters)."""
-    # a2 + a3 counters on device, a3 finishing on host
-    _, rc, bs, lm, uq = eng.rcls_profile(want_species=False)
-    keep, absolute, _ = eng.species_profiling((rc, bs, lm, uq), avg_len, filtered=cfg.filtered)
-    # a7 (rebuilt per run like the reference), a8, a9..a14 for every species that survived the MAPQ
-    # filter.  The -a abundance cut (profile.rs:602) needs the GLOBAL normaliser, so it is applied
-    # after the single exchange in finalize_stage; species are independent, so computing the few
-    # low-abundance ones too changes nothing else.
-    if cfg.rebuild_trio:
-        eng.db_reset()
-    eng.trio_nodes_info(fetch=False)
-    eng.get_node_abundances(species_active=keep, fetch=False)
-    met, info = eng.strain_profiling(absolute, species_active=keep, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr,
-                                     min_depth=cfg.min_depth, shift=cfg.shift)
-    solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
-                       for s in range(eng.S)], dtype=np.uint8)
-    passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)
+def local_stage(eng, avg_len, cfg, single_call=True):
+    """Everything a rank computes on its own species shard (device stages + host filters).
+    single_call: the whole pass through pantax_hip_profile_step (one host wait); False drives the same stages
+    one C call at a time (rcls_profile, species_profiling, ... as the reference names them) -- identical results."""
+    if single_call:
+        keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(
+            avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
+            filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio)
+        keep, absolute, s_all, s_pass = keep.copy(), absolute.copy(), s_all.copy(), s_pass.copy()
+        solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
+                           for s in range(eng.S)], dtype=np.uint8)
+    else:
+        # a2 + a3 counters on device, a3 finishing on host
+        _, rc, bs, lm, uq = eng.rcls_profile(want_species=False)
+        keep, absolute, _ = eng.species_profiling((rc, bs, lm, uq), avg_len, filtered=cfg.filtered)
+        # a7 (rebuilt per run like the reference), a8, a9..a14 for every species that survived the MAPQ
+        # filter.  The -a abundance cut (profile.rs:602) needs the GLOBAL normaliser, so it is applied
+        # after the single exchange in finalize_stage; species are independent, so computing the few
+        # low-abundance ones too changes nothing else.
+        if cfg.rebuild_trio:
+            eng.db_reset()
+        eng.trio_nodes_info(fetch=False)
+        eng.get_node_abundances(species_active=keep, fetch=False)
+        met, info = eng.strain_profiling(absolute, species_active=keep, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr,
+                                         min_depth=cfg.min_depth, shift=cfg.shift)
+        solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
+                           for s in range(eng.S)], dtype=np.uint8)
+        passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)
     rows = []   # candidate strain rows of this rank, before the global cut / normalisation
     for s in range(eng.S):
         if not solved[s]:
@@ -125,14 +135,14 @@ def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None):
     return species_rows, strain_rows, int(active.sum())
 
 
-def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None):
+def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None, single_call=True):
     """Returns (species_rows, strain_rows, stats) on rank 0 (empty lists elsewhere).
     species_rows: (species_taxid, predicted_abundance, predicted_coverage) sorted descending.
     strain_rows : (species_taxid, hap_id, predicted_coverage, predicted_abundance, path_base_cov,
                    unique_trio_fraction, uniq_trio_cov_mean, first_sol, strain_cov_diff, total_cov_diff)."""
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
-    local = local_stage(eng, avg_len, cfg)
+    local = local_stage(eng, avg_len, cfg, single_call)
     species_rows, strain_rows, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max)
     stats = dict(local["stats"], n_active=n_active)
     return species_rows, strain_rows, stats

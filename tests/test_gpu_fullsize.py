@@ -201,3 +201,28 @@ def test_step_normalisation(eng, cfg2):
     assert sum(r[3] for r in st_rows) == pytest.approx(1.0, rel=1e-12)
     present = {sset.species[0].hap_names[h] for h in np.nonzero(sset.species[0].truth_depth > 0)[0]}
     assert {r[1] for r in st_rows} == present
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,S,H,R,L,filtered", [(31, 4, 5, 40000, 120000, True), (32, 6, 3, 30000, 90000, False), (33, 1, 8, 20000, 150000, True)])
+def test_single_call_step_equals_stage_by_stage(eng, seed, S, H, R, L, filtered):
+    """pantax_hip_profile_step (device-side species decision, one host wait) == the same stages called one
+    by one with the species decision taken on the host: identical tables, bit for bit."""
+    from pantax_amd import synth
+    from pantax_amd.pipeline import StepConfig, profile_step
+    sset = synth.make_set(seed, S, H, R, L)
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    avg = sset.avg_len()
+    if S > 2:
+        avg = np.array(avg, dtype=np.float64); avg[1] = 0.0   # a species without a genome length is dropped (profile.rs:329)
+    for rebuild in (True, False):
+        cfg = StepConfig(filtered=filtered, rebuild_trio=rebuild)
+        a = profile_step(eng, names, haps, avg, cfg, single_call=True)
+        b = profile_step(eng, names, haps, avg, cfg, single_call=False)
+        assert a[0] == b[0]
+        assert a[1] == b[1]
+        assert np.array_equal(np.array(a[2]["obj"], dtype=float), np.array(b[2]["obj"], dtype=float), equal_nan=True)
+        assert a[2]["n_active"] == b[2]["n_active"]
