@@ -108,11 +108,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     int pmax_bound = 1;                                                                     // columns per species <= min(#haps, 64)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
-    PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax_bound, nullptr, nullptr, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));        // LP 1
-    PTX_TRY(second_filter_launch(ctx, db, &lb, fc, lb.d_x.p, lb.d_status.p, lb.d_fixed2.p, lb.d_need2.p));                            // a13 decision
-    // LP 2 only where the second filter dropped a column; elsewhere LP2 == LP1 (m.reset() + no new constraint,
-    // profile.rs:1482-1490) and its optimum is the one already computed
-    PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax_bound, lb.d_need2.p, lb.d_fixed2.p, lb.d_x2.p, lb.d_obj2.p, lb.d_status2.p, lb.d_iters2.p));
+    PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
     PTX_TRY(fetch_arena_enqueue(ctx, db, L));
     return 0;
 }

@@ -144,6 +144,7 @@ struct LadBatch {
     DevBuf<double> d_nzsum;             // [S] sum of min_depth-filtered non-zero abundances (profile.rs:1193-1201)
     DevBuf<uint32_t> d_nzcnt;           // [S]
     DevBuf<double> d_partial;           // per-chunk partials of the two-level reductions
+    DevBuf<uint32_t> d_obj_done;        // [S] arrival counters of objective_kernel (zero between launches)
     // sorted LP rows (a_v > 0 and mask != 0), grouped into patterns
     uint64_t n_rows = 0;
     uint32_t K = 0;

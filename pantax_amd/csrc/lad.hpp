@@ -15,6 +15,9 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
 // are pinned to 0.  Writes x, obj, status, iters for the solved species.  Nothing is read back.
 int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
                      double *d_obj, int32_t *d_status, int32_t *d_iters);
+// the strain step's LP1 -> second filter -> LP2 (+ both objectives) as two launches
+struct FilterCfg;
+int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const FilterCfg &fc);
 // a9 / a13 decisions on the device (the host redoes only the reporting arithmetic at the end of the step)
 struct FilterCfg { double fr, fc, sr; int shift; };
 int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc);

@@ -527,39 +527,49 @@ __global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint
 }
 
 // second_filter_paths (profile.rs:1229-1285): which columns are pinned to zero in the second solve
-__global__ void __launch_bounds__(64) second_filter_kernel(uint32_t S, const uint64_t *__restrict__ hap_off, const uint64_t *__restrict__ hto,
-                                                           const int32_t *__restrict__ hap_bit, const int32_t *__restrict__ sp_p,
-                                                           const uint32_t *__restrict__ nnz, const double *__restrict__ meanf,
-                                                           const unsigned long long *__restrict__ ratio, const double *__restrict__ x1,
-                                                           const int32_t *__restrict__ status1, double fc, double sr,
-                                                           uint8_t *__restrict__ fixed2, uint8_t *__restrict__ need2) {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= S) return;
-    const uint64_t h0 = hap_off[s], h1 = hap_off[s + 1];
+struct SecondFilterArgs {
+    const uint64_t *hap_off, *hto;
+    const int32_t *hap_bit, *sp_p;
+    const uint32_t *nnz;
+    const double *meanf;
+    const unsigned long long *ratio;
+    const double *x1;
+    const int32_t *status1;
+    double fc, sr;
+    uint8_t *fixed2, *need2;
+};
+// second_filter_paths decisions of one species (profile.rs:1234-1268): which LP columns are pinned to zero in
+// the second solve, and whether there is a second solve at all
+__device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F, uint32_t s) {
+    const uint64_t h0 = F.hap_off[s], h1 = F.hap_off[s + 1];
     uint8_t need = 0;
-    for (int k = 0; k < LAD_MAXP; ++k) fixed2[(size_t)s * LAD_MAXP + k] = 0;
-    if (sp_p[s] > 0 && status1[s] == 0 && (h1 - h0) != 1 && hto[h1] - hto[h0] > 0) {
+    for (int k = 0; k < LAD_MAXP; ++k) F.fixed2[(size_t)s * LAD_MAXP + k] = 0;
+    if (F.sp_p[s] > 0 && F.status1[s] == 0 && (h1 - h0) != 1 && F.hto[h1] - F.hto[h0] > 0) {
         for (uint64_t h = h0; h < h1; ++h) {
-            const int k = hap_bit[h];
+            const int k = F.hap_bit[h];
             if (k < 0) continue;
-            const double fm = meanf[h];
+            const double fm = F.meanf[h];
             bool keep = false;
             if (fm != 0.0) {                                               // :1238
-                const double sol = x1[(size_t)s * LAD_MAXP + k];
+                const double sol = F.x1[(size_t)s * LAD_MAXP + k];
                 const double f = d_round2(fabs(sol - fm) / (sol + fm));
-                if (f > fc) {
+                if (f > F.fc) {
                     if (f <= 0.6) {
-                        const double frac_r = d_round2((double)nnz[h] / (double)(hto[h + 1] - hto[h]));
-                        const float cov = (float)ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+                        const double frac_r = d_round2((double)F.nnz[h] / (double)(F.hto[h + 1] - F.hto[h]));
+                        const float cov = (float)F.ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)F.ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
                         const double sc = frac_r * (double)(cov / len);
-                        if (!(sc < sr || sol == 0.0)) keep = true;         // rescue
+                        if (!(sc < F.sr || sol == 0.0)) keep = true;       // rescue
                     }
                 } else if (sol != 0.0) keep = true;
             }
-            if (!keep) { fixed2[(size_t)s * LAD_MAXP + k] = 1; need = 1; }
+            if (!keep) { F.fixed2[(size_t)s * LAD_MAXP + k] = 1; need = 1; }
         }
     }
-    need2[s] = need;
+    F.need2[s] = need;
+}
+__global__ void __launch_bounds__(64) second_filter_kernel(uint32_t S, SecondFilterArgs F) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s < S) second_filter_species(F, s);
 }
 
 int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc) {
@@ -570,11 +580,19 @@ int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_a
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
+static SecondFilterArgs second_filter_args(const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
+                                           uint8_t *d_fixed2, uint8_t *d_need2) {
+    SecondFilterArgs F;
+    F.hap_off = db->d_hap_off.p; F.hto = db->d_hap_trio_off.p; F.hap_bit = lb->d_hap_bit.p; F.sp_p = lb->d_p.p; F.nnz = db->d_hap_nnz.p;
+    F.meanf = db->d_hap_mean.p; F.ratio = lb->d_ratio.p; F.x1 = d_x1; F.status1 = d_status1; F.fc = fc.fc; F.sr = fc.sr;
+    F.fixed2 = d_fixed2; F.need2 = d_need2;
+    return F;
+}
 int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
                          uint8_t *d_fixed2, uint8_t *d_need2) {
     const uint32_t S = db->S;
-    hipLaunchKernelGGL(second_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, db->d_hap_off.p, db->d_hap_trio_off.p,
-                       lb->d_hap_bit.p, lb->d_p.p, db->d_hap_nnz.p, db->d_hap_mean.p, lb->d_ratio.p, d_x1, d_status1, fc.fc, fc.sr, d_fixed2, d_need2);
+    hipLaunchKernelGGL(second_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S,
+                       second_filter_args(db, lb, fc, d_x1, d_status1, d_fixed2, d_need2));
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1109,63 +1127,126 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     else lad_solve_body<PS, false>(A, m, s, p, k0, k1);
 }
 
-// objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450)
-__global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need,
+// Both LP solves of the strain step in ONE launch: solve, take the second-filter decision of this species
+// (one thread), and solve again with the dropped columns pinned to zero -- only where a column was dropped;
+// elsewhere LP2 == LP1 (m.reset() + no new constraint, profile.rs:1482-1490).
+template <int PS>
+__global__ void __launch_bounds__(LAD_BLOCK) lad_pair_kernel(LadArgs A1, LadArgs A2, SecondFilterArgs F) {
+    __shared__ LadLds<PS> m;
+    const int s = blockIdx.x;
+    const int p = A1.sp_p[s];
+    const uint32_t k0 = A1.sp_pat_off[s], k1 = A1.sp_pat_off[s + 1];
+    const bool lds_state = k1 - k0 <= (uint32_t)LAD_KLDS;
+    if (p > 0) {
+        if (lds_state) lad_solve_body<PS, true>(A1, m, s, p, k0, k1);
+        else lad_solve_body<PS, false>(A1, m, s, p, k0, k1);
+    } else if (threadIdx.x == 0) { A1.status[s] = 0; A1.iters[s] = 0; }
+    __syncthreads();   // x1 / status1 of this species are visible to the workgroup
+    if (threadIdx.x == 0) second_filter_species(F, (uint32_t)s);
+    __syncthreads();
+    if (p <= 0 || !F.need2[s]) return;
+    if (lds_state) lad_solve_body<PS, true>(A2, m, s, p, k0, k1);
+    else lad_solve_body<PS, false>(A2, m, s, p, k0, k1);
+}
+
+// objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450),
+// for the first solution and -- where need2 says there was a second solve -- the second one, in one pass over
+// the nodes.  The workgroup that finishes a species last adds the chunk partials in fixed order.
+__global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need2,
                                                         const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
-                                                        const unsigned long long *__restrict__ mask, const double *__restrict__ x,
-                                                        double *__restrict__ part) {
+                                                        const unsigned long long *__restrict__ mask, const double *__restrict__ x1,
+                                                        const double *__restrict__ x2, double *part /*[S][STAT_CHUNKS][2]*/,
+                                                        uint32_t *__restrict__ done /*[S], zero between launches*/,
+                                                        const uint32_t *__restrict__ nvalid, double *__restrict__ obj1, double *__restrict__ obj2) {
     __shared__ double red[4];
-    __shared__ double xs[LAD_MAXP];
+    __shared__ double xs1[LAD_MAXP], xs2[LAD_MAXP];
+    __shared__ int s_last;
     const int s = blockIdx.x / STAT_CHUNKS;
-    if (sp_p[s] <= 0 || (need && !need[s])) return;
+    if (sp_p[s] <= 0) return;
+    const bool two = x2 && need2 && need2[s];
     const uint32_t ch = blockIdx.x % STAT_CHUNKS;
-    if (threadIdx.x < LAD_MAXP) xs[threadIdx.x] = x[(size_t)s * LAD_MAXP + threadIdx.x];
+    if (threadIdx.x < LAD_MAXP) { xs1[threadIdx.x] = x1[(size_t)s * LAD_MAXP + threadIdx.x]; xs2[threadIdx.x] = two ? x2[(size_t)s * LAD_MAXP + threadIdx.x] : 0.0; }
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + STAT_CHUNKS - 1) / STAT_CHUNKS;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
-    double acc = 0.0;
+    double acc1 = 0.0, acc2 = 0.0;
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
-        double a = ab[v];
-        if (a > 0.0) acc += fabs(mdot(mask[v], xs) - a);
+        const double a = ab[v];
+        if (a > 0.0) {
+            const unsigned long long mk = mask[v];
+            acc1 += fabs(mdot(mk, xs1) - a);
+            if (two) acc2 += fabs(mdot(mk, xs2) - a);
+        }
     }
-    acc = block_sum_f64<256>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-}
-__global__ void __launch_bounds__(64) objective_final_kernel(uint32_t S, const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need,
-                                                             const double *__restrict__ part, const uint32_t *__restrict__ nvalid,
-                                                             double *__restrict__ obj) {
-    uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= S || sp_p[s] <= 0 || (need && !need[s])) return;
-    double acc = 0.0;
-    for (int c = 0; c < STAT_CHUNKS; ++c) acc += part[(size_t)s * STAT_CHUNKS + c];
-    obj[s] = nvalid[s] ? acc / (double)nvalid[s] : 0.0;
+    acc1 = block_sum_f64<256>(acc1, red);
+    acc2 = block_sum_f64<256>(acc2, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)s * STAT_CHUNKS + ch) * 2] = acc1;
+        part[((size_t)s * STAT_CHUNKS + ch) * 2 + 1] = acc2;
+        // release: the partials are visible device-wide before the count; acquire: the last arriver sees all of them
+        s_last = __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)STAT_CHUNKS - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = 0; c < STAT_CHUNKS; ++c) { t1 += part[((size_t)s * STAT_CHUNKS + c) * 2]; t2 += part[((size_t)s * STAT_CHUNKS + c) * 2 + 1]; }
+    obj1[s] = nvalid[s] ? t1 / (double)nvalid[s] : 0.0;
+    if (two) obj2[s] = nvalid[s] ? t2 / (double)nvalid[s] : 0.0;
+    done[s] = 0;
 }
 
-int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
-                     double *d_obj, int32_t *d_status, int32_t *d_iters) {
+static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_need2, const double *d_x1, const double *d_x2, double *d_obj1,
+                            double *d_obj2) {
     const uint32_t S = db->S;
+    KTimer t(ctx, "objective_kernel");
+    PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
+    if (lb->d_obj_done.n < S) {
+        PTX_HIP(ctx, lb->d_obj_done.alloc(S));
+        PTX_HIP(ctx, hipMemsetAsync(lb->d_obj_done.p, 0, lb->d_obj_done.bytes(), ctx->stream));   // the kernel leaves it zero
+    }
+    hipLaunchKernelGGL(objective_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, db->d_node_base.p, lb->d_ab.p,
+                       (unsigned long long *)lb->d_mask.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+static LadArgs lad_args(LadBatch *lb, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x, int32_t *d_status, int32_t *d_iters) {
     LadArgs A;
     A.row_a = lb->row_a; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
     A.pat_eps = lb->d_pat_eps.p; A.sc_s = lb->d_sc_s.p; A.sc_rho = lb->d_sc_rho.p;
     A.sc_lo = lb->d_sc_lo.p; A.sc_up = lb->d_sc_up.p; A.ls_lo = lb->d_ls_lo.p; A.ls_hi = lb->d_ls_hi.p; A.ls_mid = lb->d_ls_mid.p;
     A.sp_p = lb->d_p.p; A.need = d_need; A.fixed = d_fixed; A.amax = lb->d_amax.p; A.x_out = d_x; A.status = d_status; A.iters = d_iters;
+    return A;
+}
+
+// the strain step's two solves + second filter + both objectives: two launches
+int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const FilterCfg &fc) {
+    const uint32_t S = db->S;
+    LadArgs A1 = lad_args(lb, nullptr, nullptr, lb->d_x.p, lb->d_status.p, lb->d_iters.p);
+    LadArgs A2 = lad_args(lb, nullptr, lb->d_fixed2.p, lb->d_x2.p, lb->d_status2.p, lb->d_iters2.p);
+    SecondFilterArgs F = second_filter_args(db, lb, fc, lb->d_x.p, lb->d_status.p, lb->d_fixed2.p, lb->d_need2.p);
+    {
+        KTimer t(ctx, "lad_solve_kernel");
+        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        else hipLaunchKernelGGL((lad_pair_kernel<LAD_MAXP>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    return objective_launch(ctx, db, lb, lb->d_need2.p, lb->d_x.p, lb->d_x2.p, lb->d_obj.p, lb->d_obj2.p);
+}
+
+int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
+                     double *d_obj, int32_t *d_status, int32_t *d_iters) {
+    const uint32_t S = db->S;
+    LadArgs A = lad_args(lb, d_need, d_fixed, d_x, d_status, d_iters);
     {
         KTimer t(ctx, "lad_solve_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
         else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
     }
-    {
-        KTimer t(ctx, "objective_kernel");
-        PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
-        hipLaunchKernelGGL(objective_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_p.p, d_need, db->d_node_base.p, lb->d_ab.p,
-                           (unsigned long long *)lb->d_mask.p, d_x, lb->d_partial.p);
-        hipLaunchKernelGGL(objective_final_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, lb->d_p.p, d_need, lb->d_partial.p,
-                           lb->d_nvalid.p, d_obj);
-    }
     PTX_HIP(ctx, hipGetLastError());
-    return 0;
+    return objective_launch(ctx, db, lb, nullptr, d_x, nullptr, d_obj, nullptr);
 }
 
 }  // namespace ptx
