@@ -601,6 +601,7 @@ int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &
 // a12: the batched exact LAD solver
 // ---------------------------------------------------------------------------------------------
 constexpr int LAD_BLOCK = 256;
+constexpr int LAD_KWIDE = 16;    // patterns up to which a wave searches cooperatively / the line search runs wide rounds
 constexpr int LAD_KLDS = 64;     // patterns whose solver state fits the LDS arrays
 enum { C_LB = 0, C_UB = 1, C_PAT = 2, C_FIXED = 3 };
 
@@ -626,6 +627,7 @@ struct LadShared {
     uint32_t act_i0[LAD_MAXP], act_i1[LAD_MAXP];
     double red[LAD_BLOCK / 64];
     double red_t[LAD_BLOCK / 64];
+    double xs[2][LAD_BLOCK / 64][4];   // double-buffered exchange slots of the line search: one barrier per exchange
     int red_k[LAD_BLOCK / 64];
     // control words written by one thread, read by all after a barrier
     int best, bdir, done, bj, btype, status, ent_type, piv;
@@ -652,12 +654,36 @@ __device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double
 
 // COOP (per species, block-uniform) = few patterns: every wave owns whole patterns (its 64 lanes search
 // cooperatively, lane 0 is the "leader" that accumulates); otherwise one thread per pattern with scalar searches.
+#define LAD_BUILD_CACHE()                                                                                                   \
+    {                                                                                                                      \
+        if (tid == 0) {                                                                                                    \
+            uint32_t off = 0;                                                                                              \
+            for (uint32_t kk = 0; kk < k1 - k0; ++kk) {                                                                    \
+                const double rho = L_rho[kk];                                                                              \
+                const uint32_t cl = L_lslo[kk], ch = L_lshi[kk];                                                           \
+                const uint32_t n = (rho != 0.0 && ch > cl) ? ch - cl : 0u;                                                 \
+                L_coff[kk] = off; L_cn[kk] = n;                                                                            \
+                L_crow0[kk] = rho > 0 ? L_up[kk] + cl : L_lo[kk] - ch;                                                     \
+                off += n;                                                                                                  \
+            }                                                                                                              \
+            L_coff[k1 - k0] = off;                                                                                         \
+        }                                                                                                                  \
+        __syncthreads();                                                                                                   \
+        const uint32_t total = L_coff[k1 - k0];                                                                            \
+        for (uint32_t e = tid; e < total; e += LAD_BLOCK) {                                                                \
+            uint32_t kk = 0;                                                                                               \
+            while (kk + 1 < k1 - k0 && L_coff[kk + 1] <= e) ++kk;                                                          \
+            L_cache[e] = ra.a[L_crow0[kk] + (e - L_coff[kk])];                                                             \
+        }                                                                                                                  \
+        __syncthreads();                                                                                                   \
+        cached = true;                                                                                                     \
+    }
 #define PAT_LOOP(k) for (uint32_t k = k0 + (COOP ? (uint32_t)(tid >> 6) : (uint32_t)tid); k < k1; k += (COOP ? LAD_BLOCK / 64 : LAD_BLOCK))
 // LDS of one solver workgroup
 template <int PS>
 struct LadLds {
     static constexpr uint32_t IDX_N = 4096;                       // samples of the row index
-    static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 1024;   // cached candidate rows of a line search
+    static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 512;    // cached candidate rows of a line search
     LadShared sh;
     double W[PS * PS];
     double G[PS * 2 * PS];
@@ -668,6 +694,10 @@ struct LadLds {
     double L_idx[IDX_N];      // top level of every row search: every (1 << shift)-th row of the species' sorted rows
     double L_cache[CACHE_N];
     uint32_t L_lsmid2[LAD_KLDS], L_coff[LAD_KLDS + 1], L_cn[LAD_KLDS], L_crow0[LAD_KLDS];
+    // wide rounds of the line search (species with at most LAD_KWIDE patterns): crossed-count bounds of every
+    // pattern at 64 pivots, and the per-wave slope contributions at those pivots
+    uint32_t W_cmin[LAD_KWIDE][64], W_cmax[LAD_KWIDE][64];
+    double W_acc[LAD_BLOCK / 64][2][64];
 };
 
 // USEL is a compile-time constant so that every access to the pattern state is a plain LDS (or plain global)
@@ -680,8 +710,10 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
     uint64_t *L_mask = m.L_mask;
     uint32_t *L_lo = m.L_lo, *L_up = m.L_up, *L_lslo = m.L_lslo, *L_lshi = m.L_lshi, *L_lsmid = m.L_lsmid, *L_start = m.L_start,
              *L_lsmid2 = m.L_lsmid2, *L_coff = m.L_coff, *L_cn = m.L_cn, *L_crow0 = m.L_crow0;
+    uint32_t (*W_cmin)[64] = m.W_cmin, (*W_cmax)[64] = m.W_cmax;
+    double (*W_acc)[2][64] = m.W_acc;
     const int tid = threadIdx.x;
-    const bool COOP = (k1 - k0) <= 16;
+    const bool COOP = (k1 - k0) <= (uint32_t)LAD_KWIDE;
     const bool leader = COOP ? ((tid & 63) == 0) : true;
     constexpr bool useL = USEL;
     const uint32_t kofs = useL ? k0 : 0u;     // LDS arrays are indexed from the species' first pattern
@@ -867,7 +899,107 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 // as long as the sign of the slope at the pivot is certain; then the remaining candidate rows of
                 // every pattern are copied to LDS once and the exact rounds finish there.
                 bool approx = useL, cached = false;
+                int xp = 0;   // exchange buffer in use
 #define RK(k) RowIdx rk = ra; if (cached) { rk.cache = L_cache + L_coff[(k) - k0]; rk.c_row0 = L_crow0[(k) - k0]; rk.c_n = L_cn[(k) - k0]; }
+                if (COOP && useL) {
+                    // ---- wide rounds: the slope is bounded (samples) or evaluated (cached rows) at 64 pivots at once.
+                    // Pivots are evenly spaced candidates of the pattern that holds the most weighted candidates,
+                    // lane order = increasing t; every lane searches each pattern of its wave for its own pivot; the
+                    // bracket moves to the last pivot that is certainly before the minimiser and the first that is
+                    // certainly at or past it.  ~64x fewer candidates per round instead of 2x.
+                    const int lane = tid & 63, wave = tid >> 6;
+                    bool exact = false;
+                    unsigned long long prev_w = ~0ull;
+                    for (int wr = 0; wr < 64; ++wr) {
+                        double cs = 0.0, wb = 0.0;
+                        int kbest = 0x7fffffff;
+                        PAT_LOOP(k) {
+                            const double rho = P_sc_rho[k - kofs];
+                            const uint32_t cl = P_ls_lo[k - kofs], ch = P_ls_hi[k - kofs];
+                            if (rho == 0.0 || ch <= cl) continue;
+                            cs += (double)(ch - cl);
+                            const double w = fabs(rho) * (double)(ch - cl);
+                            if (w > wb || (w == wb && (int)k < kbest)) { wb = w; kbest = (int)k; }
+                        }
+                        if (lane == 0) { sh.xs[xp][wave][0] = cs; sh.xs[xp][wave][1] = wb; sh.xs[xp][wave][2] = (double)kbest; }
+                        __syncthreads();
+                        cs = 0.0; wb = 0.0; kbest = 0x7fffffff;
+#pragma unroll
+                        for (int w = 0; w < LAD_BLOCK / 64; ++w) {
+                            cs += sh.xs[xp][w][0];
+                            const double w2 = sh.xs[xp][w][1]; const int k2 = (int)sh.xs[xp][w][2];
+                            if (w2 > wb || (w2 == wb && w2 > 0.0 && k2 < kbest)) { wb = w2; kbest = k2; }
+                        }
+                        xp ^= 1;
+                        const unsigned long long cand = (unsigned long long)cs;
+                        if (cand <= 8 || kbest == 0x7fffffff) break;
+                        if (cand == prev_w) { if (exact) break; exact = true; }
+                        prev_w = cand;
+                        if (exact && !cached) { if (cand > CACHE_N) break; LAD_BUILD_CACHE() }
+                        // pivots of the heaviest pattern
+                        const uint32_t kq = (uint32_t)kbest - kofs;
+                        const double rho_b = P_sc_rho[kq], s_b = P_sc_s[kq], eps_b = P_pat_eps[kq];
+                        const uint32_t rl = rho_b > 0 ? P_sc_up[kq] + P_ls_lo[kq] : P_sc_lo[kq] - P_ls_hi[kq];
+                        const uint32_t rh = rho_b > 0 ? P_sc_up[kq] + P_ls_hi[kq] : P_sc_lo[kq] - P_ls_lo[kq];
+                        uint32_t pa, pn;   // pivot positions [pa, pa + pn): sample indices or rows
+                        if (!exact) {
+                            const uint32_t msk = (1u << ra.shift) - 1u;
+                            pa = (rl - ra.row0 + msk) >> ra.shift;
+                            const uint32_t pb = (rh - ra.row0 + msk) >> ra.shift;
+                            pn = pb > pa ? pb - pa : 0u;
+                            if (pn < 2) { exact = true; prev_w = ~0ull; continue; }   // too few samples left among the candidates
+                        } else { pa = rl; pn = rh - rl; }
+                        const uint32_t pm = pn < 64u ? pn : 64u;
+                        double t_piv = 0.0;
+                        bool valid = (uint32_t)lane < pm;
+                        if (valid) {
+                            const uint32_t q = (uint32_t)(((uint64_t)(2 * lane + 1) * pn) / (2ull * pm));
+                            const uint32_t pos = rho_b > 0 ? pa + q : pa + pn - 1 - q;
+                            double av;
+                            if (!exact) av = ra.idx[pos];
+                            else { RK(kbest); av = row_val(rk, pos); }
+                            t_piv = (av + eps_b - s_b) / rho_b;
+                            if (t_piv < 0) t_piv = 0;
+                            valid = t_piv > t_lo && t_piv < t_hi;
+                        }
+                        double a0 = 0.0, a1 = 0.0;
+                        PAT_LOOP(k) {
+                            const double rho = P_sc_rho[k - kofs];
+                            if (rho == 0.0) continue;
+                            uint32_t cmin = 0, cmax = 0;
+                            if (valid) {
+                                if (!exact) crossed_range(false, ra, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_sc_lo[k - kofs], P_sc_up[k - kofs], t_piv,
+                                                          P_ls_lo[k - kofs], P_ls_hi[k - kofs], cmin, cmax);
+                                else {
+                                    RK(k);
+                                    cmin = cmax = crossed(false, rk, rho, P_sc_s[k - kofs], P_pat_eps[k - kofs], P_pat_start[k - kofs], P_pat_start[(k + 1) - kofs],
+                                                          P_sc_lo[k - kofs], P_sc_up[k - kofs], t_piv, P_ls_lo[k - kofs], P_ls_hi[k - kofs]);
+                                }
+                            }
+                            W_cmin[k - k0][lane] = cmin; W_cmax[k - k0][lane] = cmax;
+                            a0 += fabs(rho) * 2.0 * (double)cmin; a1 += fabs(rho) * 2.0 * (double)cmax;
+                        }
+                        W_acc[wave][0][lane] = a0; W_acc[wave][1][lane] = a1;
+                        __syncthreads();
+                        double S_min = S0, S_max = S0;
+#pragma unroll
+                        for (int w = 0; w < LAD_BLOCK / 64; ++w) { S_min += W_acc[w][0][lane]; S_max += W_acc[w][1][lane]; }
+                        const unsigned long long mlo = __ballot(valid && S_max < -tol), mhi = __ballot(valid && S_min >= -tol);
+                        const int jl = mlo ? 63 - __clzll((long long)mlo) : -1;
+                        const int jh = mhi ? __ffsll((long long)mhi) - 1 : -1;
+                        if ((jl < 0 && jh < 0) || (jl >= 0 && jh >= 0 && jl >= jh)) { if (exact) break; exact = true; prev_w = ~0ull; continue; }
+                        if (jl >= 0) {
+                            t_lo = __shfl(t_piv, jl); S_lo = __shfl(S_max, jl);
+                            PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_lo[k - kofs] = W_cmin[k - k0][jl];
+                        }
+                        if (jh >= 0) {
+                            t_hi = __shfl(t_piv, jh); S_hi = __shfl(S_min, jh);
+                            PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_hi[k - kofs] = W_cmax[k - k0][jh];
+                        }
+                    }
+                    if (exact) approx = false;
+                    __syncthreads();   // bracket state written by the owning waves is read by everyone below
+                }
                 for (int bi = 0; bi < 400; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
                     PAT_LOOP(k) {
@@ -894,7 +1026,25 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                             wbest = w; tprop = t < 0 ? 0 : t;
                         }
                     }
-                    cand = (unsigned long long)block_sum_f64<LAD_BLOCK>((double)cand, sh.red);
+                    // one exchange: candidate count (sum) and the heaviest proposal (max over the block, ties -> smaller t)
+                    double bt;
+                    {
+                        double cs = wave_reduce((double)cand, [](double x, double y) { return x + y; });
+                        wave_reduce_pair(wbest, tprop, [](double w2, double t2, double w, double t) { return w2 > w || (w2 == w && t2 < t); });
+                        if ((tid & 63) == 0) { sh.xs[xp][tid >> 6][0] = cs; sh.xs[xp][tid >> 6][1] = wbest; sh.xs[xp][tid >> 6][2] = tprop; }
+                        __syncthreads();
+                        cs = 0.0;
+                        double bw = sh.xs[xp][0][1];
+                        bt = sh.xs[xp][0][2];
+#pragma unroll
+                        for (int w = 0; w < LAD_BLOCK / 64; ++w) {
+                            cs += sh.xs[xp][w][0];
+                            const double w2 = sh.xs[xp][w][1], t2 = sh.xs[xp][w][2];
+                            if (w > 0 && (w2 > bw || (w2 == bw && t2 < bt))) { bw = w2; bt = t2; }
+                        }
+                        xp ^= 1;
+                        cand = (unsigned long long)cs;
+                    }
                     if (cand <= 8) break;
                     // three exact rounds (one of each pivot kind) without shrinking: only tie groups remain -> walk them
                     const bool shrunk = cand != prev_cand;
@@ -904,36 +1054,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         stall = shrunk ? 0 : stall + 1;
                         if (stall >= 3) break;
                     }
-                    if (!approx && !cached && useL && cand <= CACHE_N) {
-                        if (tid == 0) {
-                            uint32_t off = 0;
-                            for (uint32_t kk = 0; kk < k1 - k0; ++kk) {
-                                const double rho = L_rho[kk];
-                                const uint32_t cl = L_lslo[kk], ch = L_lshi[kk];
-                                const uint32_t n = (rho != 0.0 && ch > cl) ? ch - cl : 0u;
-                                L_coff[kk] = off; L_cn[kk] = n;
-                                L_crow0[kk] = rho > 0 ? L_up[kk] + cl : L_lo[kk] - ch;
-                                off += n;
-                            }
-                            L_coff[k1 - k0] = off;
-                        }
-                        __syncthreads();
-                        const uint32_t total = L_coff[k1 - k0];
-                        for (uint32_t e = tid; e < total; e += LAD_BLOCK) {
-                            uint32_t kk = 0;
-                            while (kk + 1 < k1 - k0 && L_coff[kk + 1] <= e) ++kk;
-                            L_cache[e] = ra.a[L_crow0[kk] + (e - L_coff[kk])];
-                        }
-                        __syncthreads();
-                        cached = true;
-                    }
-                    // heaviest proposal: max over the block (ties -> smaller t)
-                    wave_reduce_pair(wbest, tprop, [](double w2, double t2, double w, double t) { return w2 > w || (w2 == w && t2 < t); });
-                    if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tprop; sh.red[tid >> 6] = wbest; }
-                    __syncthreads();
-                    double bw = sh.red[0], bt = sh.red_t[0];
-                    for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red[w] > bw || (sh.red[w] == bw && sh.red_t[w] < bt)) { bw = sh.red[w]; bt = sh.red_t[w]; }
-                    __syncthreads();
+                    if (!approx && !cached && useL && cand <= CACHE_N) LAD_BUILD_CACHE()
                     double t_mid;
                     const int mode = bi % 3;   // 0: heaviest pattern's median breakpoint, 1: secant on the slope, 2: midpoint
                     if (mode == 0) { t_mid = bt; if (!(t_mid >= t_lo && t_mid <= t_hi)) t_mid = 0.5 * (t_lo + t_hi); }
@@ -953,7 +1074,14 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                             P_ls_mid[k - kofs] = cmin; L_lsmid2[k - k0] = cmax;
                             if (leader) { acc0 += fabs(rho) * 2.0 * (double)cmin; acc1 += fabs(rho) * 2.0 * (double)cmax; }
                         }
-                        const double S_min = S0 + block_sum_f64<LAD_BLOCK>(acc0, sh.red), S_max = S0 + block_sum_f64<LAD_BLOCK>(acc1, sh.red);
+                        acc0 = wave_reduce(acc0, [](double x, double y) { return x + y; });
+                        acc1 = wave_reduce(acc1, [](double x, double y) { return x + y; });
+                        if ((tid & 63) == 0) { sh.xs[xp][tid >> 6][0] = acc0; sh.xs[xp][tid >> 6][1] = acc1; }
+                        __syncthreads();
+                        double S_min = S0, S_max = S0;
+#pragma unroll
+                        for (int w = 0; w < LAD_BLOCK / 64; ++w) { S_min += sh.xs[xp][w][0]; S_max += sh.xs[xp][w][1]; }
+                        xp ^= 1;
                         if (S_max < -tol) {          // certainly still descending at t_mid
                             PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_lo[k - kofs] = P_ls_mid[k - kofs];
                             t_lo = t_mid; S_lo = S_max;
@@ -976,7 +1104,13 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         P_ls_mid[k - kofs] = c;
                         if (leader) acc += fabs(rho) * 2.0 * (double)c;
                     }
-                    double S_mid = S0 + block_sum_f64<LAD_BLOCK>(acc, sh.red);
+                    acc = wave_reduce(acc, [](double x, double y) { return x + y; });
+                    if ((tid & 63) == 0) sh.xs[xp][tid >> 6][0] = acc;
+                    __syncthreads();
+                    double S_mid = S0;
+#pragma unroll
+                    for (int w = 0; w < LAD_BLOCK / 64; ++w) S_mid += sh.xs[xp][w][0];
+                    xp ^= 1;
                     bool go_hi = S_mid >= -tol;
                     PAT_LOOP(k) {
                         if (P_sc_rho[k - kofs] == 0.0) continue;
