@@ -898,7 +898,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 // Rounds first run on the LDS samples alone (bounds on every crossed-count, no memory access) for
                 // as long as the sign of the slope at the pivot is certain; then the remaining candidate rows of
                 // every pattern are copied to LDS once and the exact rounds finish there.
-                bool approx = useL, cached = false;
+                bool approx = useL, cached = false, wide_done = false;
                 int xp = 0;   // exchange buffer in use
 #define RK(k) RowIdx rk = ra; if (cached) { rk.cache = L_cache + L_coff[(k) - k0]; rk.c_row0 = L_crow0[(k) - k0]; rk.c_n = L_cn[(k) - k0]; }
                 if (COOP && useL) {
@@ -932,8 +932,9 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         }
                         xp ^= 1;
                         const unsigned long long cand = (unsigned long long)cs;
-                        if (cand <= 8 || kbest == 0x7fffffff) break;
-                        if (cand == prev_w) { if (exact) break; exact = true; }
+                        if (cand <= 8 || kbest == 0x7fffffff) { wide_done = true; break; }
+                        // exact rounds that cannot move the bracket any more: what is left sits on its ends (tie groups)
+                        if (cand == prev_w) { if (exact) { wide_done = cand <= 64; break; } exact = true; }
                         prev_w = cand;
                         if (exact && !cached) { if (cand > CACHE_N) break; LAD_BUILD_CACHE() }
                         // pivots of the heaviest pattern
@@ -987,7 +988,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         const unsigned long long mlo = __ballot(valid && S_max < -tol), mhi = __ballot(valid && S_min >= -tol);
                         const int jl = mlo ? 63 - __clzll((long long)mlo) : -1;
                         const int jh = mhi ? __ffsll((long long)mhi) - 1 : -1;
-                        if ((jl < 0 && jh < 0) || (jl >= 0 && jh >= 0 && jl >= jh)) { if (exact) break; exact = true; prev_w = ~0ull; continue; }
+                        if ((jl < 0 && jh < 0) || (jl >= 0 && jh >= 0 && jl >= jh)) { if (exact) { wide_done = cand <= 64; break; } exact = true; prev_w = ~0ull; continue; }
                         if (jl >= 0) {
                             t_lo = __shfl(t_piv, jl); S_lo = __shfl(S_max, jl);
                             PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_lo[k - kofs] = W_cmin[k - k0][jl];
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                     if (exact) approx = false;
                     __syncthreads();   // bracket state written by the owning waves is read by everyone below
                 }
-                for (int bi = 0; bi < 400; ++bi) {
+                for (int bi = 0; bi < 400 && !wide_done; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
@@ -1169,6 +1170,9 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                                 if (g1 - rk.c_row0 >= rk.c_n) break;
                                 if (rk.cache[g1 - rk.c_row0] == av) ++g1; else open1 = false;
                             }
+                            // the neighbours just outside the cached rows: one load each settles the usual case
+                            if (open0 && g0 > st && g0 - 1 - rk.c_row0 >= rk.c_n && ra.a[g0 - 1] != av) open0 = false;
+                            if (open1 && g1 < en && g1 - rk.c_row0 >= rk.c_n && ra.a[g1] != av) open1 = false;
                             if (open0) g0 = lb(false, ra, st, g0, av);
                             if (open1) g1 = ub_(false, ra, g1, en, av);
                             uint32_t gs = rho > 0 ? g1 - r : r - g0 + 1;      // rows of the group not crossed yet
