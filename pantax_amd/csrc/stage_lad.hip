@@ -898,7 +898,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 // Rounds first run on the LDS samples alone (bounds on every crossed-count, no memory access) for
                 // as long as the sign of the slope at the pivot is certain; then the remaining candidate rows of
                 // every pattern are copied to LDS once and the exact rounds finish there.
-                bool approx = useL, cached = false, wide_done = false;
+                bool approx = useL, cached = false, wide_done = false;   // wide_done: the wide rounds left only bracket-end tie groups
                 int xp = 0;   // exchange buffer in use
 #define RK(k) RowIdx rk = ra; if (cached) { rk.cache = L_cache + L_coff[(k) - k0]; rk.c_row0 = L_crow0[(k) - k0]; rk.c_n = L_cn[(k) - k0]; }
                 if (COOP && useL) {
@@ -934,7 +934,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         const unsigned long long cand = (unsigned long long)cs;
                         if (cand <= 8 || kbest == 0x7fffffff) { wide_done = true; break; }
                         // exact rounds that cannot move the bracket any more: what is left sits on its ends (tie groups)
-                        if (cand == prev_w) { if (exact) { wide_done = cand <= 64; break; } exact = true; }
+                        if (cand == prev_w) { if (exact) { wide_done = true; break; } exact = true; }
                         prev_w = cand;
                         if (exact && !cached) { if (cand > CACHE_N) break; LAD_BUILD_CACHE() }
                         // pivots of the heaviest pattern
@@ -988,7 +988,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         const unsigned long long mlo = __ballot(valid && S_max < -tol), mhi = __ballot(valid && S_min >= -tol);
                         const int jl = mlo ? 63 - __clzll((long long)mlo) : -1;
                         const int jh = mhi ? __ffsll((long long)mhi) - 1 : -1;
-                        if ((jl < 0 && jh < 0) || (jl >= 0 && jh >= 0 && jl >= jh)) { if (exact) { wide_done = cand <= 64; break; } exact = true; prev_w = ~0ull; continue; }
+                        if ((jl < 0 && jh < 0) || (jl >= 0 && jh >= 0 && jl >= jh)) { if (exact) { wide_done = true; break; } exact = true; prev_w = ~0ull; continue; }
                         if (jl >= 0) {
                             t_lo = __shfl(t_piv, jl); S_lo = __shfl(S_max, jl);
                             PAT_LOOP(k) if (P_sc_rho[k - kofs] != 0.0) P_ls_lo[k - kofs] = W_cmin[k - k0][jl];
@@ -1001,7 +1001,11 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                     if (exact) approx = false;
                     __syncthreads();   // bracket state written by the owning waves is read by everyone below
                 }
-                for (int bi = 0; bi < 400 && !wide_done; ++bi) {
+                // After finished wide rounds the walk starts at once (few tie groups are left); should it not close within
+                // a few dozen groups, the binary rounds narrow further and the walk runs again without a cap.
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                const bool quick = attempt == 0 && wide_done;
+                for (int bi = 0; bi < 400 && !quick; ++bi) {
                     double wbest = 0.0, tprop = 0.0; unsigned long long cand = 0;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
@@ -1131,7 +1135,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 __syncthreads();
                 // ---- walk the few remaining breakpoint groups in order of t.  ls_lo may split a tie group (sample
                 // bounds are not group aligned): a step crosses the rest of the group its first uncrossed row is in.
-                for (int step = 0; step < 4096; ++step) {
+                for (int step = 0, cap = quick ? 48 : 4096; step < cap; ++step) {
                     double tb = INFINITY; int kb = 0x7fffffff;
                     PAT_LOOP(k) {
                         double rho = P_sc_rho[k - kofs];
@@ -1145,46 +1149,51 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                     wave_reduce_pair(tb, kb, [](double t2, int k2, double t, int k) { return t2 < t || (t2 == t && k2 < k); });
                     if ((tid & 63) == 0) { sh.red_t[tid >> 6] = tb; sh.red_k[tid >> 6] = kb; }
                     __syncthreads();
-                    if (tid == 0) {
+                    if (tid < 64) {   // wave 0: its lanes search together, lane 0 writes
+                        const bool l0 = tid == 0;
                         double tt = sh.red_t[0]; int kk = sh.red_k[0];
                         for (int w = 1; w < LAD_BLOCK / 64; ++w) if (sh.red_t[w] < tt || (sh.red_t[w] == tt && sh.red_k[w] < kk)) { tt = sh.red_t[w]; kk = sh.red_k[w]; }
                         if (kk == 0x7fffffff) {
                             // bracket exhausted without crossing (rounding): fall back to the box bound or fail
-                            if (sh.bj >= 0 && isfinite(sh.tmax)) { sh.ent_type = sh.btype; sh.ent_k = (uint32_t)sh.bj; } else { sh.status = 5; sh.done = 1; }
+                            if (l0) { if (sh.bj >= 0 && isfinite(sh.tmax)) { sh.ent_type = sh.btype; sh.ent_k = (uint32_t)sh.bj; } else { sh.status = 5; sh.done = 1; } }
                         } else {
                             double rho = P_sc_rho[kk - kofs];
                             uint32_t st = P_pat_start[kk - kofs], en = P_pat_start[(kk + 1) - kofs];
                             uint32_t r = rho > 0 ? P_sc_up[kk - kofs] + P_ls_lo[kk - kofs] : P_sc_lo[kk - kofs] - 1 - P_ls_lo[kk - kofs];
                             RK(kk);
                             double av = row_val(rk, r);
-                            // extent [g0,g1) of the tie group of r: a short scan through the cached rows, else the full searches
+                            // extent [g0,g1) of the tie group of r: inside the cached rows first; a group that reaches the
+                            // end of the cached rows is settled by the neighbouring row, else by the full searches
                             uint32_t g0 = r, g1 = r + 1;
                             bool open0 = true, open1 = true;
-                            for (int q = 0; q < 32 && open0; ++q) {
-                                if (g0 == st) { open0 = false; break; }
-                                if (g0 - 1 - rk.c_row0 >= rk.c_n) break;
-                                if (rk.cache[g0 - 1 - rk.c_row0] == av) --g0; else open0 = false;
+                            if (r - rk.c_row0 < rk.c_n) {
+                                const uint32_t o = r - rk.c_row0;
+                                g0 = rk.c_row0 + wave_bound(rk.cache, 0, o, av, false);
+                                g1 = rk.c_row0 + wave_bound(rk.cache, o + 1, rk.c_n, av, true);
+                                open0 = g0 == rk.c_row0 && g0 > st;
+                                open1 = g1 == rk.c_row0 + rk.c_n && g1 < en;
                             }
-                            for (int q = 0; q < 32 && open1; ++q) {
-                                if (g1 == en) { open1 = false; break; }
-                                if (g1 - rk.c_row0 >= rk.c_n) break;
-                                if (rk.cache[g1 - rk.c_row0] == av) ++g1; else open1 = false;
-                            }
-                            // the neighbours just outside the cached rows: one load each settles the usual case
-                            if (open0 && g0 > st && g0 - 1 - rk.c_row0 >= rk.c_n && ra.a[g0 - 1] != av) open0 = false;
-                            if (open1 && g1 < en && g1 - rk.c_row0 >= rk.c_n && ra.a[g1] != av) open1 = false;
-                            if (open0) g0 = lb(false, ra, st, g0, av);
-                            if (open1) g1 = ub_(false, ra, g1, en, av);
+                            if (g0 <= st) open0 = false;
+                            if (g1 >= en) open1 = false;
+                            const double below = open0 ? ra.a[g0 - 1] : 0.0, above = open1 ? ra.a[g1] : 0.0;
+                            if (open0 && below != av) open0 = false;
+                            if (open1 && above != av) open1 = false;
+                            if (open0) g0 = lb(true, ra, st, g0, av);
+                            if (open1) g1 = ub_(true, ra, g1, en, av);
                             uint32_t gs = rho > 0 ? g1 - r : r - g0 + 1;      // rows of the group not crossed yet
                             double Sn = sh.S_lo + 2.0 * fabs(rho) * (double)gs;
-                            P_ls_lo[kk - kofs] += gs;
-                            sh.S_lo = Sn;
-                            if (Sn >= -tol) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = g0; sh.ent_i1 = g1; }
+                            if (l0) {
+                                P_ls_lo[kk - kofs] += gs;
+                                sh.S_lo = Sn;
+                                if (Sn >= -tol) { sh.ent_type = C_PAT; sh.ent_k = (uint32_t)kk; sh.ent_i0 = g0; sh.ent_i1 = g1; }
+                            }
                         }
                     }
                     __syncthreads();
                     if (sh.ent_type >= 0 || sh.done) break;
                 }
+                if (sh.ent_type >= 0 || sh.done || !quick) break;
+                }   // attempt
 #undef RK
             }
         }
