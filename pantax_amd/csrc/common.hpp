@@ -92,6 +92,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool timing = false;
+    std::string timing_filter;   // non-empty: only launches of this name are timed (two events per step instead of ~200)
     std::vector<TimedLaunch> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     std::map<std::string, std::pair<uint64_t, double>> acc;

@@ -20,6 +20,7 @@ int fail(Ctx *ctx, int code, const char *fmt, ...) {
 
 KTimer::KTimer(Ctx *c, const char *nm) : ctx(c), name(nm) {
     if (!ctx->timing) return;
+    if (!ctx->timing_filter.empty() && ctx->timing_filter != nm) return;   // only the named launch is bracketed
     if (!ctx->free_events.empty()) {
         start = ctx->free_events.back().first;
         stop = ctx->free_events.back().second;
@@ -116,6 +117,12 @@ int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
     PTX_TRY(collect_timings(ctx));
     ctx->timing = on != 0;
+    return 0;
+}
+
+int pantax_hip_timing_filter(pantax_hip_ctx *ctx, const char *name) {
+    if (!ctx) return PANTAX_HIP_E_INVALID;
+    ctx->timing_filter = name ? name : "";
     return 0;
 }
 

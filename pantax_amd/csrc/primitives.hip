@@ -286,11 +286,13 @@ int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *pas
     SortGeom g = sort_geom(n);
     SortBufs cur = a, nxt = b;
     bool in_b = false;
-    KTimer t(ctx, "radix_sort");
     for (int p = 0; p < n_passes; ++p) {
         int word = passes[p].word, shift = passes[p].shift;
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table, d_n);
-        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_table, g.nb);
+        { KTimer t(ctx, "sort_hist_kernel");
+          hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table, d_n); }
+        { KTimer t(ctx, "sort_rowscan_kernel");
+          hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_table, g.nb); }
+        KTimer t(ctx, "sort_scatter_kernel");
         switch (cur.nw) {
         case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;
         case 2: launch_scatter<2>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;

@@ -202,8 +202,8 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     const uint32_t H = (uint32_t)db->H;
     PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)H * HAP_CHUNKS * 3));
     PTX_HIP(ctx, dbm->d_hap_mean_sd.alloc((size_t)H * 2));
-    KTimer t(ctx, "hap_trio_stats_kernel");
     for (int pass = 0; pass < 3; ++pass) {
+        KTimer t(ctx, "hap_trio_pass_kernel");
         hipLaunchKernelGGL(hap_trio_pass_kernel, dim3(H * HAP_CHUNKS), dim3(256), 0, ctx->stream, pass, db->d_hap_trio_off.p, db->d_trio_bases.p,
                            db->d_trio_len.p, dbm->d_hap_mean_sd.p, (HapPartial *)dbm->d_hap_part.p);
         hipLaunchKernelGGL(hap_trio_combine_kernel, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, pass, H, (const HapPartial *)dbm->d_hap_part.p,

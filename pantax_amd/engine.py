@@ -244,6 +244,9 @@ class Engine:
     def timing_enable(self, on=True):
         self._check(self.lib.pantax_hip_timing_enable(self.ctx, int(on)))
 
+    def timing_filter(self, name=None):
+        self._check(self.lib.pantax_hip_timing_filter(self.ctx, name.encode() if name else None))
+
     def timing_reset(self):
         self._check(self.lib.pantax_hip_timing_reset(self.ctx))
 
