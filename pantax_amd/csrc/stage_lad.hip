@@ -216,7 +216,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 // ---------------------------------------------------------------------------------------------
 // node abundance + per-species statistics
 // ---------------------------------------------------------------------------------------------
-constexpr int STAT_CHUNKS = 64;   // workgroups per species; partials are combined in fixed order (deterministic)
+constexpr int STAT_CHUNKS = 256;  // workgroups per species; partials are combined in fixed order (deterministic)
 struct NodePartial { double mx, zs; unsigned long long nv, zc; };
 
 __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
@@ -298,7 +298,10 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
     }
 }
 
-constexpr int RATIO_CHUNKS = 32;
+constexpr int RATIO_CHUNKS = 128;
+// path_cov_ratio sums (profile.rs:1344-1361): per candidate k, sum of covered bases and of lengths over its
+// nodes.  The first 8 candidates (nearly always all of them) accumulate in registers and are combined by wave
+// reductions; 64 lanes hammering 2-4 LDS addresses with 64-bit atomics serialise.
 __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
                                                     const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio) {
@@ -311,15 +314,32 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
     const uint32_t per = (e - b + RATIO_CHUNKS - 1) / RATIO_CHUNKS;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
+    unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
         if (!m) continue;
-        unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+        const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = (m >> k) & 1ull;
+            c8[k] += on ? c : 0ull;
+            l8[k] += on ? l : 0ull;
+        }
+        m >>= 8;
         while (m) {
             int k = __ffsll((long long)m) - 1;
             m &= m - 1;
-            if (c) atomicAdd(&acc[2 * k], c);
-            atomicAdd(&acc[2 * k + 1], l);
+            if (c) atomicAdd(&acc[2 * (k + 8)], c);
+            atomicAdd(&acc[2 * (k + 8) + 1], l);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long cs = wave_reduce(c8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+        const unsigned long long ls = wave_reduce(l8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+        if ((threadIdx.x & 63) == 0) {
+            if (cs) atomicAdd(&acc[2 * k], cs);
+            if (ls) atomicAdd(&acc[2 * k + 1], ls);
         }
     }
     __syncthreads();
