@@ -136,6 +136,13 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         }
         db->n_tiles = tiles.size();
         PTX_TRY(upload(ctx, db->d_tiles, tiles.data(), tiles.size()));
+        // the same tiles numbered in path order (hap-major): rows of the trio table are numbered in that order
+        std::vector<uint32_t> hap_tile_off(db->H + 1, 0), tile_rank(tiles.size());
+        for (uint64_t h = 0; h < db->H; ++h)
+            hap_tile_off[h + 1] = hap_tile_off[h] + (uint32_t)((g->path_off[h + 1] - g->path_off[h] + PATH_TILE - 1) / PATH_TILE);
+        for (size_t i = 0; i < tiles.size(); ++i) tile_rank[i] = hap_tile_off[tiles[i].x] + tiles[i].y;
+        PTX_TRY(upload(ctx, db->d_tile_rank, tile_rank.data(), tile_rank.size()));
+        PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
     }
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_node.alloc(1));

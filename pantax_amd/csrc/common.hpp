@@ -169,7 +169,8 @@ struct LadBatch {
 
 // scratch of trio_index_build, kept across calls (grow-only) so a rebuild costs no hipMalloc
 struct TrioScratch {
-    DevBuf<uint32_t> cnt, cursor, bucket_off, scan_tmp, row_of_q, first_cnt, d_tot;
+    DevBuf<uint32_t> zero_arena;   // cnt | cursor | cursor2 | first_cnt | uniq_q: cleared by one memset per build
+    DevBuf<uint32_t> cnt, cursor, cursor2, bucket_off, scan_tmp, first_cnt, d_tot, tile_cnt, tile_base;
     DevBuf<uint4> bucket;   // (q, b, c, global first node) per window
     DevBuf<uint8_t> uniq_q;
 };
@@ -199,6 +200,8 @@ struct Db {
     std::vector<uint8_t> h_all_same;
     DevBuf<uint2> d_tiles;           // path tiles {hap, chunk} ordered (species, chunk, hap); one workgroup each
     uint64_t n_tiles = 0;
+    DevBuf<uint32_t> d_tile_rank;    // [n_tiles] rank of the tile in path order (hap-major)
+    DevBuf<uint32_t> d_hap_tile_off; // [H+1] first path-order tile of every haplotype
     // unique-trio index (a7)
     bool trio_built = false;
     uint64_t U = 0;

@@ -19,6 +19,7 @@
 // is arbitrary; results are compared as keyed sets.
 #include <algorithm>
 #include "primitives.hpp"
+#include "wave.hpp"
 
 namespace ptx {
 
@@ -82,26 +83,54 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
         if (u) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
     }
 }
-// 4. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
-//    order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
-__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint64_t *__restrict__ hap_off, const uint64_t *__restrict__ bit_off,
-                                                          const uint8_t *__restrict__ uniq_q, const uint32_t *__restrict__ row_of_q,
-                                                          const uint32_t *__restrict__ trio_first, uint32_t *__restrict__ cursor,
-                                                          uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
-                                                          uint32_t *__restrict__ len_out) {
-    TILE_LOOP(q, h, qend) {
-        if (!uniq_q[q]) continue;
-        const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
-        uint32_t g, a, b, c;
-        window_of(q, qend, nbase, path_nodes, g, a, b, c);
-        const uint32_t row = row_of_q[q];
-        const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
-        trio_ent[j] = make_uint4(b, c, row, 0u);
-        abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-        const uint32_t s = sidx, nb = nbase;
-        hap_out[row] = h - (uint32_t)hap_off[s];
-        len_out[row] = (uint32_t)((bit_off[nb + a + 1] - bit_off[nb + a]) + (bit_off[nb + b + 1] - bit_off[nb + b]) +
-                                  (bit_off[nb + c + 1] - bit_off[nb + c]));
+// 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
+//     its first unique window (rows are numbered (species, hap, position))
+__global__ void __launch_bounds__(256) trio_tilecount_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank,
+                                                             const uint8_t *__restrict__ uniq_q, uint32_t *__restrict__ tile_cnt) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t c = 0;
+    TILE_LOOP(q, h, qend) c += uniq_q[q];
+    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[tile_rank[blockIdx.x]] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+// 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
+//     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
+__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
+                                                          const uint64_t *__restrict__ bit_off, const uint8_t *__restrict__ uniq_q,
+                                                          const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
+                                                          uint32_t *__restrict__ cursor, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
+                                                          uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
+    __shared__ uint32_t s_wave[4];
+    const uint2 tile = tiles[blockIdx.x];
+    const uint32_t h = tile.x;
+    const uint64_t qend = path_off[h + 1], qt0 = path_off[h] + (uint64_t)tile.y * PATH_TILE;
+    const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
+    for (int r = 0; r < PATH_TILE / 256; ++r) {          // 256 consecutive positions per round: row = carry + rank in the round
+        const uint64_t q = qt0 + (uint64_t)r * 256 + threadIdx.x;
+        const uint32_t u = (q < qend) ? uniq_q[q] : 0u;
+        const unsigned long long bal = __ballot(u != 0);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; if (w < wave) woff += t; tot += t; }
+        __syncthreads();
+        if (u) {
+            const uint32_t row = carry + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            uint32_t g, a, b, c;
+            window_of(q, qend, nbase, path_nodes, g, a, b, c);
+            const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
+            trio_ent[j] = make_uint4(b, c, row, 0u);
+            abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
+            hap_out[row] = h - (uint32_t)hap_off[sidx];
+            len_out[row] = (uint32_t)((bit_off[nbase + a + 1] - bit_off[nbase + a]) + (bit_off[nbase + b + 1] - bit_off[nbase + b]) +
+                                      (bit_off[nbase + c + 1] - bit_off[nbase + c]));
+        }
+        carry += tot;
     }
 }
 
@@ -111,13 +140,11 @@ __global__ void __launch_bounds__(256) trio_node_kernel(uint64_t V, const uint32
         trio_node[v] = make_uint2(trio_first[v], first_cnt[v]);
 }
 
-__global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, uint64_t P, const uint64_t *__restrict__ path_off,
-                                                          const uint32_t *__restrict__ row_of_q, const uint32_t *__restrict__ total,
+__global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint32_t *__restrict__ hap_tile_off, const uint32_t *__restrict__ tile_base,
                                                           uint64_t *__restrict__ hap_trio_off) {
     uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h > H) return;
-    uint64_t q = path_off[h];
-    hap_trio_off[h] = (h == H || q >= P) ? (uint64_t)*total : (uint64_t)row_of_q[q];
+    hap_trio_off[h] = (uint64_t)tile_base[hap_tile_off[h]];   // entry n_tiles of the scan = total
 }
 
 int trio_index_build(Ctx *ctx, Db *db) {
@@ -125,15 +152,20 @@ int trio_index_build(Ctx *ctx, Db *db) {
     const uint32_t H = (uint32_t)db->H;
     if (P >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu path steps exceed 32-bit positions", (unsigned long long)P);
     TrioScratch &ts = db->trio_scratch;
-    PTX_HIP(ctx, ts.cnt.alloc(V + 1)); PTX_HIP(ctx, ts.cursor.alloc(V + 1)); PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
+    const uint32_t NT = (uint32_t)db->n_tiles;
+    // everything that must start at zero lives in one arena: cnt | cursor | cursor2 | first_cnt | tile_cnt | uniq_q (bytes)
+    const size_t zwords = 4 * (V + 1) + (NT + 1) + (P + 3) / 4 + 1;
+    PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
+    ts.cnt.view(ts.zero_arena.p, V + 1); ts.cursor.view(ts.zero_arena.p + (V + 1), V + 1);
+    ts.cursor2.view(ts.zero_arena.p + 2 * (V + 1), V + 1); ts.first_cnt.view(ts.zero_arena.p + 3 * (V + 1), V + 1);
+    ts.tile_cnt.view(ts.zero_arena.p + 4 * (V + 1), NT + 1);
+    ts.uniq_q.view(ts.zero_arena.p + 4 * (V + 1) + (NT + 1), P ? P : 1);
+    PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
     PTX_HIP(ctx, ts.bucket.alloc(P));
-    PTX_HIP(ctx, ts.scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(P, V + 1))));
-    PTX_HIP(ctx, ts.row_of_q.alloc(P)); PTX_HIP(ctx, ts.uniq_q.alloc(P)); PTX_HIP(ctx, ts.first_cnt.alloc(V + 1));
+    PTX_HIP(ctx, ts.scan_tmp.alloc(16));
+    PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
     PTX_HIP(ctx, ts.d_tot.alloc(2));
-    PTX_HIP(ctx, hipMemsetAsync(ts.cnt.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(ts.cursor.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(ts.uniq_q.p, 0, (P ? P : 1), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(ts.zero_arena.p, 0, zwords * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     PTX_HIP(ctx, db->d_trio_node.alloc(V));
@@ -158,9 +190,9 @@ int trio_index_build(Ctx *ctx, Db *db) {
             hipLaunchKernelGGL(trio_uniq_kernel, dim3(grid_for(n_win, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_win, ts.bucket.p,
                                ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
-        PTX_TRY(exclusive_scan_u8(ctx, ts.uniq_q.p, ts.row_of_q.p, P, ts.scan_tmp.p, ts.d_tot.p + 1));
+        hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
+        PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
         PTX_TRY(exclusive_scan_u32(ctx, ts.first_cnt.p, db->d_trio_first.p, V + 1, ts.scan_tmp.p, nullptr));
-        PTX_HIP(ctx, hipMemsetAsync(ts.cursor.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
@@ -174,10 +206,11 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
-            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_hap_off.p, db->d_bit_off.p, ts.uniq_q.p,
-                               ts.row_of_q.p, db->d_trio_first.p, ts.cursor.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p);
-            hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, P, db->d_path_off.p,
-                               ts.row_of_q.p, ts.d_tot.p + 1, db->d_hap_trio_off.p);
+            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_bit_off.p,
+                               ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.cursor2.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p,
+                               db->d_trio_len.p);
+            hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,
+                               db->d_hap_trio_off.p);
         }
     } else {
         db->U = 0;
