@@ -66,21 +66,37 @@ __global__ void __launch_bounds__(256) trio_fill_kernel(TRIO_GRAPH_ARGS, const u
         bucket[slot] = make_uint4((uint32_t)q, b, c, g);   // one 16-byte record per window
     }
 }
-// 3. a window is unique iff no other window of its bucket has the same (b,c): count == 1 (profile.rs:688-709)
+// 3. a window is unique iff no other window of its bucket has the same (b,c): count == 1 (profile.rs:688-709).
+//    Entries of a bucket are contiguous, so a wave compares its 64 consecutive entries through shuffles (one
+//    16-byte load per window instead of one per pair); only the part of a bucket that lies outside the wave's
+//    64 entries is read from memory.
 __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const uint4 *__restrict__ bucket,
                                                         const uint32_t *__restrict__ bucket_off, uint8_t *__restrict__ uniq_q,
                                                         uint32_t *__restrict__ first_cnt) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_win; i += (uint64_t)gridDim.x * 256) {
-        uint4 me = bucket[i];
-        uint32_t g = me.w;
-        uint32_t b0 = bucket_off[g], b1 = bucket_off[g + 1];
-        bool u = true;
-        for (uint32_t j = b0; j < b1 && u; ++j) {
-            if (j == i) continue;
-            uint4 o = bucket[j];
-            if (o.y == me.y && o.z == me.z) u = false;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) - lane; base < n_win; base += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = base + lane;
+        const bool valid = i < n_win;
+        uint4 me = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+        if (valid) me = bucket[i];
+        const uint32_t g = me.w;
+        bool dup = false;
+        // lanes d below me in the same bucket: equal (b,c) marks both of us
+        for (int d = 1; d < 64; ++d) {
+            const uint32_t og = __shfl(g, lane - d), oy = __shfl(me.y, lane - d), oz = __shfl(me.z, lane - d);
+            const bool same = valid && lane >= d && og == g;
+            if (!__any(same)) break;   // buckets are contiguous: no pair at distance d means none further apart
+            const unsigned long long eq = __ballot(same && oy == me.y && oz == me.z);
+            if ((eq >> lane) & 1ull) dup = true;                       // my partner is d below
+            if (lane + d < 64 && ((eq >> (lane + d)) & 1ull)) dup = true;   // my partner is d above
         }
-        if (u) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
+        if (valid && !dup) {
+            const uint32_t b0 = bucket_off[g], b1 = bucket_off[g + 1];
+            const uint64_t wend = base + 64;
+            for (uint64_t j = b0; j < b1 && j < base && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
+            for (uint64_t j = (wend > b0 ? wend : b0); j < b1 && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
+        }
+        if (valid && !dup) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
     }
 }
 // 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
