@@ -11,35 +11,6 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// exclusive scan of one value per thread across a block of NT threads (NT multiple of 64, <= 1024)
-template <int NT>
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT/64]*/, uint32_t *block_total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan(v);
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
-        uint32_t t = s_wave[w];
-        if (w < wave) woff += t;
-        tot += t;
-    }
-    __syncthreads();
-    *block_total = tot;
-    return woff + incl - v;
-}
-
 // Single-pass chained scan (decoupled look-back): ONE launch per scan.  A workgroup takes a ticket (tiles are
 // therefore started in order, so the tiles it waits for are already running), scans its tile of SCAN_TILE items,
 // publishes {epoch, flag, value} of the tile in one 64-bit word -- first its aggregate, later its inclusive
@@ -181,7 +152,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_hist_kernel(const uint64_t *_
 // One workgroup per digit: exclusive scan of that digit's row of per-block counts (nb <= 2048 = one 8-item sweep)
 // and the digit total; the scatter kernel turns the 256 totals into digit bases itself.  Two launches fewer per
 // pass than a generic scan of the whole table.
-__global__ void __launch_bounds__(SORT_BLOCK) sort_rowscan_kernel(uint32_t *__restrict__ table, uint32_t nb) {
+__global__ void __launch_bounds__(SORT_BLOCK) sort_rowscan_kernel(uint32_t *__restrict__ table, uint32_t rows, uint32_t nb) {
     __shared__ uint32_t s_wave[SORT_BLOCK / 64];
     uint32_t *row = table + (size_t)blockIdx.x * nb;
     const uint32_t b = threadIdx.x * 8;
@@ -192,7 +163,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) sort_rowscan_kernel(uint32_t *__re
     uint32_t off = block_excl_scan<SORT_BLOCK>(s, s_wave, &tot);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { if (b + i < nb) row[b + i] = off; off += v[i]; }
-    if (threadIdx.x == 0) table[(size_t)256 * nb + blockIdx.x] = tot;
+    if (threadIdx.x == 0) table[(size_t)rows * nb + blockIdx.x] = tot;
+}
+void sort_rowscan_launch(Ctx *ctx, uint32_t *d_table, uint32_t rows, uint32_t nb) {
+    hipLaunchKernelGGL(sort_rowscan_kernel, dim3(rows), dim3(SORT_BLOCK), 0, ctx->stream, d_table, rows, nb);
 }
 
 template <int NW, bool HASV>
@@ -291,7 +265,7 @@ int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *pas
         { KTimer t(ctx, "sort_hist_kernel");
           hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nb), dim3(SORT_BLOCK), 0, ctx->stream, cur.k[word], shift, n, g.chunk, g.nb, d_table, d_n); }
         { KTimer t(ctx, "sort_rowscan_kernel");
-          hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_table, g.nb); }
+          sort_rowscan_launch(ctx, d_table, 256, g.nb); }
         KTimer t(ctx, "sort_scatter_kernel");
         switch (cur.nw) {
         case 1: launch_scatter<1>(ctx, cur, nxt, word, shift, n, g, d_table, d_n); break;

@@ -31,6 +31,16 @@ size_t sort_table_elems(uint64_t n);
 int radix_sort(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n, const SortPass *passes, int n_passes, uint32_t *d_table,
                uint32_t *d_scan_tmp, bool *result_in_b, const uint32_t *d_n = nullptr);
 
+// shared by both sorts: exclusive scan of every row of table[rows][nb] (nb <= 2048) + row totals at table[rows*nb + row]
+void sort_rowscan_launch(Ctx *ctx, uint32_t *d_table, uint32_t rows, uint32_t nb);
+
+// Sample sort of three-word records without payload for inputs of at most SS_MAX_N rows: five launches instead
+// of 3 per radix pass (sample_sort.hip).  The sorted rows end up in `a`; `b` is scratch of the same size.
+// d_ws: >= sample_sort_ws_elems(n_bound) u32; d_n: the actual row count on the device (<= n_bound).
+constexpr uint64_t SS_MAX_N = 600000;
+size_t sample_sort_ws_elems(uint64_t n_bound);
+int sample_sort3(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n_bound, uint32_t *d_ws, const uint32_t *d_n);
+
 // helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
 inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {
     for (int s = lo; s < hi; s += 8) out.push_back({word, s});

@@ -475,15 +475,20 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         hipLaunchKernelGGL(row_emit_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
                            (unsigned long long *)lb->d_mask.p, d_n, ka[0].p, ka[1].p, ka[2].p);
     }
-    std::vector<SortPass> passes;
-    add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
-    add_passes(passes, 1, 0, pmax_bound);              // mask bits that can be in use
-    if (S > 1) add_passes(passes, 0, 0, bits_for(S - 1));
     SortBufs A, B;
     A.nw = B.nw = 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
     bool in_b = false;
-    PTX_TRY(radix_sort(ctx, A, B, V, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b, d_n));
+    if (V <= SS_MAX_N) {   // few rows: sample sort (5 launches) instead of 10+ radix passes of 3 launches each
+        PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_ws_elems(V)));
+        PTX_TRY(sample_sort3(ctx, A, B, V, dbm->d_ss_ws.p, d_n));
+    } else {
+        std::vector<SortPass> passes;
+        add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
+        add_passes(passes, 1, 0, pmax_bound);              // mask bits that can be in use
+        if (S > 1) add_passes(passes, 0, 0, bits_for(S - 1));
+        PTX_TRY(radix_sort(ctx, A, B, V, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b, d_n));
+    }
     SortBufs Sd = in_b ? B : A;
     lb->row_a = reinterpret_cast<const double *>(Sd.k[2]);   // sorted abundances, used in place
     // patterns = runs of equal (species, mask)

@@ -54,4 +54,34 @@ __device__ __forceinline__ void wave_reduce_pair(A &a, B &b, Better better) {
     a = ra; b = rb;
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a block of NT threads (NT multiple of 64, <= 1024)
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[NT/64]*/, uint32_t *block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        uint32_t t = s_wave[w];
+        if (w < wave) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return woff + incl - v;
+}
+
+
 }  // namespace ptx
