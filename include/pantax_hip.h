@@ -182,6 +182,11 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
                             uint8_t *pass_out /*[H]*/, double *species_sum_all_out /*[S] or NULL*/,
                             double *species_sum_pass_out /*[S] or NULL*/);
 
+/* ---- the device sort of the LP row grouping as a host-buffer utility: rows (k0[i], k1[i], k2[i]) sorted
+ * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
+ * 2 = sample sort (n <= 600000). */
+int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo);
+
 /* ---- solver seam: one species, host buffers in, same meaning as X_opt's arguments
  * (profile.rs:2690-2698).  cand_path_idx = possible_paths_idx; fixed_zero[k]=1 pins x_k = 0
  * (second solve, profile.rs:1484-1488).  x_out [n_cand]; path_cov_ratio_out [n_cand] or NULL. */

@@ -241,6 +241,12 @@ class Engine:
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
 
     # ------------------------------------------------------------------ timing
+    def sort_rows(self, k0, k1, k2, algo=0):
+        """Sort the rows (k0[i], k1[i], k2[i]) ascending as tuples on the device (0 auto, 1 radix, 2 sample sort)."""
+        k = [np.ascontiguousarray(x, dtype=np.uint64).copy() for x in (k0, k1, k2)]
+        self._check(self.lib.pantax_hip_sort_rows(self.ctx, C.c_uint64(len(k[0])), p(k[0]), p(k[1]), p(k[2]), int(algo)))
+        return k
+
     def timing_enable(self, on=True):
         self._check(self.lib.pantax_hip_timing_enable(self.ctx, int(on)))
 

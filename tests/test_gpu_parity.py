@@ -239,3 +239,38 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
                     assert gv == ev, (si, h, key, gv, ev)
                 else:
                     assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
+
+
+def _host_sorted(k0, k1, k2):
+    order = np.lexsort((k2, k1, k0))
+    return [k0[order], k1[order], k2[order]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", [1, 2])
+def test_device_sorts_against_host_sort(eng, algo):
+    """Both sorts of the LP row grouping (LSD radix, sample sort) against numpy on crafted inputs: sizes around
+    every internal boundary, massive ties (single-key buckets), presorted / reversed input, and inputs whose
+    sampled rows are unrepresentative so that one bucket exceeds the LDS capacities (1024 / 4096 rows)."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for n in (1, 2, 63, 4095, 4096, 4097, 5000, 70000):
+        cases.append((rng.integers(0, 3, n), rng.integers(0, 8, n), rng.integers(0, 2 ** 63, n)))
+    n = 200000
+    vals = rng.integers(0, 50, n)                                   # 50 distinct keys: every bucket is a single-key bucket
+    cases.append((np.zeros(n, np.uint64), rng.integers(0, 2, n), vals))
+    cases.append((np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.sort(rng.integers(0, 2 ** 62, n))))         # presorted
+    cases.append((np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.sort(rng.integers(0, 2 ** 62, n))[::-1]))   # reversed
+    for n in (8192, 12288, 20000):
+        # rows 0, n/4096, 2n/4096, ... are the sample: give them small keys, everything else large distinct keys, so
+        # that every other row lands above the last splitter (one bucket of n - 4096 rows)
+        k2 = rng.permutation(n).astype(np.uint64) + np.uint64(1 << 40)
+        pos = (np.arange(4096, dtype=np.uint64) * np.uint64(n)) // np.uint64(4096)
+        k2[pos] = np.arange(4096, dtype=np.uint64)
+        cases.append((np.zeros(n, np.uint64), np.zeros(n, np.uint64), k2))
+    for k0, k1, k2 in cases:
+        k0, k1, k2 = (np.asarray(x, dtype=np.uint64) for x in (k0, k1, k2))
+        got = eng.sort_rows(k0, k1, k2, algo=algo)
+        exp = _host_sorted(k0, k1, k2)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e), (algo, len(k0))
