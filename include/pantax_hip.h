@@ -219,6 +219,8 @@ typedef struct pantax_hip_gaf pantax_hip_gaf;     /* owns the packed arrays of o
  * (=> PANTAX_HIP_READ_NULLFIELD for cols 6-9, mapq 255, qlen 0).  err_out (may be NULL) receives a
  * static/thread-local message on failure. */
 int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, const char **err_out);
+/* the same tokenisation on the device (text uploaded once, five launches): identical arrays */
+int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path, pantax_hip_gaf **out);
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *view_out);
 void pantax_hip_gaf_free(pantax_hip_gaf *gaf);
 

@@ -6,7 +6,6 @@
 
 using namespace ptx;
 
-struct pantax_hip_gaf { MappedFile mf; HostReads reads; };
 struct pantax_hip_graph { HostGraph g; std::vector<const char *> names; };
 
 static thread_local std::string g_io_err;

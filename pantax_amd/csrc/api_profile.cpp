@@ -88,9 +88,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     err = mf.open(gaf_path);
     if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
     HostReads hr;
-    int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    err = parse_gaf(mf, hr, nthreads);
-    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr));   // a1 on the device (stage_gaf.hip); host_io.cpp:parse_gaf is its checker
     const uint64_t R = hr.pstart.size();
 
     // ---- a2/a3: binning against ALL species ranges (ranges-only db), counters on device

@@ -298,6 +298,8 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db);
+struct HostReads;
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out);   // stage_gaf.hip
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 
 }  // namespace ptx

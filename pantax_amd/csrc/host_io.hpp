@@ -44,6 +44,12 @@ struct MappedFile {
 };
 std::string parse_gaf(const MappedFile &mf, HostReads &out, int n_threads);
 
+}  // namespace ptx
+// the handle behind pantax_hip_gaf_load / pantax_hip_gaf_load_device
+struct pantax_hip_gaf { ptx::MappedFile mf; ptx::HostReads reads; };
+namespace ptx {
+
+
 // polars CsvWriter-style float text: shortest round-trip digits, integral values keep ".0"
 std::string fmt_f64(double v);
 

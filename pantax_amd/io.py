@@ -13,14 +13,20 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
 
 
-def load_gaf(path, n_threads=4):
-    """-> dict(step_off, node_id, pstart, pend, qlen, mapq, flags) of numpy arrays (packed layout)."""
+def load_gaf(path, n_threads=4, engine=None):
+    """-> dict(step_off, node_id, pstart, pend, qlen, mapq, flags) of numpy arrays (packed layout).
+    engine=None: the host tokenizer; an Engine: the same tokenisation on its GPU (pantax_hip_gaf_load_device)."""
     lib = _ffi.load()
     h = C.c_void_p()
     err = C.c_char_p()
-    rc = lib.pantax_hip_gaf_load(str(path).encode(), n_threads, C.byref(h), C.byref(err))
-    if rc != 0:
-        raise _ffi.PantaxHipError(rc, (err.value or b"").decode())
+    if engine is not None:
+        rc = lib.pantax_hip_gaf_load_device(engine.ctx, str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise _ffi.PantaxHipError(rc, lib.pantax_hip_last_error(engine.ctx).decode())
+    else:
+        rc = lib.pantax_hip_gaf_load(str(path).encode(), n_threads, C.byref(h), C.byref(err))
+        if rc != 0:
+            raise _ffi.PantaxHipError(rc, (err.value or b"").decode())
     try:
         v = _ffi.PackedReads()
         lib.pantax_hip_gaf_view(h, C.byref(v))

@@ -141,3 +141,48 @@ def test_profile_seam_errors(world):
         eng.profile(str(db), str(wd), str(gaf), sample_nodes=500000)
     with pytest.raises(PantaxHipError):
         eng.profile(str(db), str(wd), str(gaf), species=False, strain=False)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pantax_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path):
+    """pantax_hip_gaf_load_device (GAF text tokenised by HIP kernels) gives the arrays of the host tokenizer bit for
+    bit: a generated GAF plus every quirk of the format contract (comments, '*' nulls, CRLF, ragged and empty lines,
+    no trailing newline, overflowing numbers, 13+ fields, digits inside non-numeric fields)."""
+    from pantax_amd import io as pio, synth
+    sset = synth.make_set(77, 3, 4, 20000, 60000, with_ids=True)
+    p1 = tmp_path / "gen.gaf"
+    synth.write_gaf(sset.reads, p1)
+    p2 = tmp_path / "quirks.gaf"
+    p2.write_bytes(
+        b"@HD\tVN:1.0\n"
+        b"r1\t150\t0\t150\t+\t>12<7>300\t400\t3\t153\t150\t150\t60\tNM:i:0\n"
+        b"r2\t150\t0\t150\t+\t*\t*\t*\t*\t*\t*\t255\n"
+        b"r3\t100\t0\t100\t+\t<5\t30\t20\t10\t100\t100\t*\r\n"
+        b"\n"
+        b"\r\n"
+        b"r5\t99999999999\t0\t1\t+\t>4294967296>7\t1\t99999999999\t5\t1\t1\t300\ta\tb\tc\n"
+        b"r6\tx12\t0\t1\t+\t>1>2\t12x\t3\t4\t1\t1\t7\n"
+        b"r7\t10\t0\t10\t+\tabc>>9<<10zz11\t5\t\t6\n"
+        b"@ comment in the middle\n"
+        b"r8\n"
+        b"r9\t90\t0\t90\t+\t>8>9\t200\t0\t90")
+    for p in (p1, p2):
+        host = pio.load_gaf(p, n_threads=3)
+        dev = pio.load_gaf(p, engine=eng)
+        for k in host:
+            assert np.array_equal(host[k], dev[k]), (p.name, k)
+    empty = tmp_path / "empty.gaf"
+    empty.write_bytes(b"")
+    assert pio.load_gaf(empty, engine=eng)["step_off"].tolist() == [0]
+    only_comments = tmp_path / "c.gaf"
+    only_comments.write_bytes(b"@a\n@b\n")
+    d = pio.load_gaf(only_comments, engine=eng)
+    assert d["step_off"].tolist() == [0] and len(d["pstart"]) == 0
