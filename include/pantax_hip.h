@@ -222,6 +222,13 @@ int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, c
 /* the same tokenisation on the device (text uploaded once, five launches): identical arrays */
 int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path, pantax_hip_gaf **out);
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *view_out);
+/* file -> packed reads RESIDENT in HBM, tokenised on the device, ready for pantax_hip_bin_reads; the walks never
+ * visit the host.  gaf_out (optional) receives the host-side columns (read_len, mapq, flags; its view has
+ * node_id / step_off / pstart / pend = NULL). */
+int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, pantax_hip_reads **reads_out, pantax_hip_gaf **gaf_out);
+/* replace the per-read drop flags of resident reads (a5: null fields, duplicate ids); NULL clears them.  The reads
+ * must be binned again afterwards. */
+int pantax_hip_reads_set_flags(pantax_hip_ctx *ctx, pantax_hip_reads *reads, const uint8_t *flags);
 void pantax_hip_gaf_free(pantax_hip_gaf *gaf);
 
 typedef struct pantax_hip_graph pantax_hip_graph; /* one species graph in `Graph` shape (types.rs:51-55) */

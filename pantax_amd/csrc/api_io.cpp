@@ -30,8 +30,10 @@ int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, c
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *v) {
     if (!gaf || !v) return PANTAX_HIP_E_INVALID;
     const HostReads &r = gaf->reads;
-    v->n_reads = r.pstart.size(); v->n_steps = r.node_id.size();
-    v->step_off = r.step_off.data(); v->node_id = r.node_id.data(); v->pstart = r.pstart.data(); v->pend = r.pend.data();
+    const bool walks = r.pstart.size() == r.qlen.size();   // pantax_hip_reads_load_gaf keeps the walks on the device
+    v->n_reads = r.qlen.size(); v->n_steps = r.node_id.size();
+    v->step_off = walks ? r.step_off.data() : nullptr; v->node_id = walks ? r.node_id.data() : nullptr;
+    v->pstart = walks ? r.pstart.data() : nullptr; v->pend = walks ? r.pend.data() : nullptr;
     v->qlen = r.qlen.data(); v->mapq = r.mapq.data(); v->flags = r.flags.data();
     return 0;
 }

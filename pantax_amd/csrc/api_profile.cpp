@@ -87,9 +87,13 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     MappedFile mf;
     err = mf.open(gaf_path);
     if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    // tokenised on the device (stage_gaf.hip; host_io.cpp:parse_gaf is its checker): the packed reads stay in HBM,
+    // only read_len / mapq / flags / id hashes come back for the report and the duplicate-id rule
     HostReads hr;
-    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr));   // a1 on the device (stage_gaf.hip); host_io.cpp:parse_gaf is its checker
-    const uint64_t R = hr.pstart.size();
+    ReadsHolder reads{ctx};
+    reads.rd = new pantax_hip_reads();
+    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr, reads.rd));
+    const uint64_t R = hr.qlen.size();
 
     // ---- a2/a3: binning against ALL species ranges (ranges-only db), counters on device
     std::vector<int64_t> rs(S), re(S);
@@ -99,14 +103,6 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         pantax_hip_graphs g{};
         g.n_species = S; g.range_start = rs.data(); g.range_end = re.data();
         PTX_TRY(pantax_hip_db_upload(ctx, &g, &bin_db.db));
-    }
-    ReadsHolder reads{ctx};
-    {
-        pantax_hip_packed_reads pr{};
-        pr.n_reads = R; pr.n_steps = hr.node_id.size();
-        pr.step_off = hr.step_off.data(); pr.node_id = hr.node_id.data(); pr.pstart = hr.pstart.data(); pr.pend = hr.pend.data();
-        pr.qlen = hr.qlen.data(); pr.mapq = hr.mapq.data(); pr.flags = nullptr;   // flags are added for the strain level below
-        PTX_TRY(pantax_hip_reads_upload(ctx, &pr, &reads.rd));
     }
     std::vector<int32_t> sp_idx(R);
     std::vector<int64_t> rc(S), bs(S), lm(S), uq(S);
@@ -268,21 +264,20 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         // re-upload reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
         // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
-        ReadsHolder sreads{ctx};
-        pantax_hip_packed_reads pr{};
-        pr.n_reads = R; pr.n_steps = hr.node_id.size();
-        pr.step_off = hr.step_off.data(); pr.node_id = hr.node_id.data(); pr.pstart = hr.pstart.data(); pr.pend = hr.pend.data();
-        pr.qlen = hr.qlen.data(); pr.mapq = hr.mapq.data(); pr.flags = flags.data();
+        // the same resident reads with the strain-level drop flags; species binned against the selected ranges
+        // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
+        // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
         if (strain_only) {
             // species from the saved report decide membership: a read whose recorded species differs from
             // where its nodes bin now is dropped for that species
             for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD;
         }
-        PTX_TRY(pantax_hip_reads_upload(ctx, &pr, &sreads.rd));
-        PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads.rd, nullptr, nullptr, nullptr, nullptr, nullptr));
+        PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));
+        pantax_hip_reads *const sreads_rd = reads.rd;
+        PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, nullptr));
         uint64_t nU = 0, n_abort = 0;
         PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
-        PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads.rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
+        PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
         pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, 0};
         std::vector<double> cov(Su);
         for (uint32_t k = 0; k < Su; ++k) cov[k] = sel_cov[use[k]];

@@ -60,6 +60,8 @@ struct DevBuf {
         return e;
     }
     size_t bytes() const { return n * sizeof(T); }
+    // take over another buffer's allocation
+    void take(DevBuf &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
 };
 
 // page-locked host staging (grow-only): a copy from / to pageable memory makes the runtime stage and wait,
@@ -299,7 +301,8 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db);
 struct HostReads;
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out);   // stage_gaf.hip
+// stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 
 }  // namespace ptx

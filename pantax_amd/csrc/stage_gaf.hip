@@ -18,6 +18,7 @@
 // The text is read three times (byte-granular gathers per line: L2-friendly, each line is contiguous).
 // Algorithmic bytes: 3 N (text) + 4 T + 30 R (outputs).
 #include <algorithm>
+#include <memory>
 #include "common.hpp"
 #include "host_io.hpp"
 #include "primitives.hpp"
@@ -160,10 +161,28 @@ __global__ void __launch_bounds__(256) gaf_fill_kernel(const uint8_t *__restrict
     if (in_run) o.node_id[w++] = (uint32_t)v;
 }
 
-// text (host, `size` bytes) -> HostReads, tokenised on the device.  Returns "" or an error message.
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out) {
+__global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t *__restrict__ v, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = max(m, v[i]);
+    m = wave_reduce(m, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// text (host, `size` bytes) -> HostReads, tokenised on the device.  With `resident` the packed reads stay in HBM
+// (the object is ready for pantax_hip_bin_reads) and only the columns host code needs come back: read_len, mapq,
+// flags, id hashes and id spans -- the walks (node_id, step_off, path_start, path_end) are not downloaded.
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident) {
     out = HostReads();
-    if (size == 0) return 0;
+    if (size == 0) {
+        if (resident) {
+            static const uint32_t zero = 0;
+            resident->R = resident->T = 0;
+            PTX_TRY(upload(ctx, resident->d_step_off, &zero, 1));
+            PTX_TRY(build_step_read(ctx, resident, 0));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return 0;
+    }
     if (size >= 0xFFFFFFF0ull) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu bytes exceed 32-bit text positions; split the input", (unsigned long long)size);
     DevBuf<uint8_t> d_txt;
     PTX_HIP(ctx, d_txt.alloc(size + 16));
@@ -186,15 +205,14 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         KTimer t(ctx, "gaf_nl_emit_kernel");
         hipLaunchKernelGGL(gaf_nl_emit_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_base.p, nl_pos.p);
     }
-    if (n_raw == 0) return 0;
     DevBuf<uint32_t> r32[8], ridx, soff;
     DevBuf<uint64_t> r_hash;
     DevBuf<uint8_t> r8[3];
-    for (auto &b : r32) PTX_HIP(ctx, b.alloc(n_raw));
-    for (auto &b : r8) PTX_HIP(ctx, b.alloc(n_raw));
-    PTX_HIP(ctx, r_hash.alloc(n_raw)); PTX_HIP(ctx, ridx.alloc(n_raw)); PTX_HIP(ctx, soff.alloc(n_raw));
+    for (auto &b : r32) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
+    for (auto &b : r8) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
+    PTX_HIP(ctx, r_hash.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, ridx.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, soff.alloc(n_raw ? n_raw : 1));
     GafRaw raw{r32[0].p, r32[1].p, r32[2].p, r32[3].p, r32[4].p, r32[5].p, r32[6].p, r32[7].p, r_hash.p, r8[0].p, r8[1].p, r8[2].p};
-    const uint32_t grid = (n_raw + 255) / 256;
+    const uint32_t grid = (n_raw + 255) / 256 ? (n_raw + 255) / 256 : 1;
     {
         KTimer t(ctx, "gaf_parse_kernel");
         hipLaunchKernelGGL(gaf_parse_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, size, n_raw, n_nl, nl_pos.p, raw);
@@ -218,17 +236,32 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         hipLaunchKernelGGL(gaf_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, n_raw, raw, ridx.p, soff.p, (uint32_t)R, (uint32_t)T, go);
     }
     PTX_HIP(ctx, hipGetLastError());
-    out.step_off.resize(R + 1); out.node_id.resize(T); out.pstart.resize(R); out.pend.resize(R); out.qlen.resize(R);
-    out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R); out.id_span.resize(R);
+    out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R); out.id_span.resize(R);
     std::vector<uint32_t> id_off(R), id_len(R);
-    PTX_TRY(download(ctx, out.step_off.data(), o32[0].p, R + 1));
-    PTX_TRY(download(ctx, out.node_id.data(), o32[1].p, T));
-    PTX_TRY(download(ctx, out.pstart.data(), o32[2].p, R)); PTX_TRY(download(ctx, out.pend.data(), o32[3].p, R));
+    if (!resident) {
+        out.step_off.resize(R + 1); out.node_id.resize(T); out.pstart.resize(R); out.pend.resize(R);
+        PTX_TRY(download(ctx, out.step_off.data(), o32[0].p, R + 1));
+        PTX_TRY(download(ctx, out.node_id.data(), o32[1].p, T));
+        PTX_TRY(download(ctx, out.pstart.data(), o32[2].p, R)); PTX_TRY(download(ctx, out.pend.data(), o32[3].p, R));
+    } else {
+        PTX_HIP(ctx, hipMemsetAsync(tot.p + 3, 0, sizeof(uint32_t), ctx->stream));
+        if (T) hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(T, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, T, o32[1].p, tot.p + 3);
+    }
+    uint32_t max_id = 0;
     PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
     PTX_TRY(download(ctx, id_off.data(), o32[5].p, R)); PTX_TRY(download(ctx, id_len.data(), o32[6].p, R));
     PTX_TRY(download(ctx, out.mapq.data(), o8[0].p, R)); PTX_TRY(download(ctx, out.flags.data(), o8[1].p, R));
     PTX_TRY(download(ctx, out.id_hash.data(), o_hash.p, R));
+    if (resident) PTX_TRY(download(ctx, &max_id, tot.p + 3, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (resident) {
+        resident->R = R; resident->T = T;
+        resident->d_step_off.take(o32[0]); resident->d_node_id.take(o32[1]); resident->d_pstart.take(o32[2]); resident->d_pend.take(o32[3]);
+        resident->d_qlen.take(o32[4]); resident->d_mapq.take(o8[0]); resident->d_flags.take(o8[1]);
+        resident->has_flags = true;
+        PTX_TRY(build_step_read(ctx, resident, max_id));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     for (uint64_t k = 0; k < R; ++k) out.id_span[k] = {(uint64_t)id_off[k], id_len[k]};
     out.n_lines = R;
     return 0;
@@ -247,5 +280,29 @@ extern "C" int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path,
     const int rc = gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads);
     if (rc != 0) { delete g; return rc; }
     *out = g;
+    return 0;
+}
+
+extern "C" int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, pantax_hip_reads **reads_out, pantax_hip_gaf **gaf_out) {
+    if (!ctx || !path || !reads_out) return PANTAX_HIP_E_INVALID;
+    *reads_out = nullptr;
+    if (gaf_out) *gaf_out = nullptr;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<pantax_hip_gaf> g(new pantax_hip_gaf());
+    std::unique_ptr<pantax_hip_reads> rd(new pantax_hip_reads());
+    std::string e = g->mf.open(path);
+    if (!e.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str());
+    PTX_TRY(gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, rd.get()));
+    *reads_out = rd.release();
+    if (gaf_out) *gaf_out = g.release();
+    return 0;
+}
+
+extern "C" int pantax_hip_reads_set_flags(pantax_hip_ctx *ctx, pantax_hip_reads *reads, const uint8_t *flags) {
+    if (!ctx || !reads) return PANTAX_HIP_E_INVALID;
+    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    reads->has_flags = flags != nullptr;
+    if (flags) { PTX_TRY(upload(ctx, reads->d_flags, flags, reads->R)); PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    reads->binned = false;   // the per-slot species carry the drop flags: bin again
     return 0;
 }

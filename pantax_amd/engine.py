@@ -112,6 +112,29 @@ class Engine:
         mapq = np.where((reads.mapq < 0) | (reads.mapq > 254), 255, reads.mapq)
         self.upload_reads(reads.step_off, reads.node_id, reads.pstart, reads.pend, reads.qlen, mapq, flags)
 
+    def load_reads_from_gaf(self, path):
+        """GAF file -> packed reads resident in HBM, tokenised on the device (pantax_hip_reads_load_gaf).
+        -> dict(qlen, mapq, flags) of the host-side columns; the walks stay on the device."""
+        if self.reads:
+            self.lib.pantax_hip_reads_free(self.ctx, self.reads)
+            self.reads = None
+        rd, gaf = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.pantax_hip_reads_load_gaf(self.ctx, str(path).encode(), C.byref(rd), C.byref(gaf)))
+        self.reads = rd
+        try:
+            v = _ffi.PackedReads()
+            self.lib.pantax_hip_gaf_view(gaf, C.byref(v))
+            self.R = int(v.n_reads)
+            arr = lambda ptr, dt: (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(self.R,)).copy()
+                                   if self.R else np.zeros(0, dtype=dt))
+            return dict(qlen=arr(v.qlen, np.uint32), mapq=arr(v.mapq, np.uint8), flags=arr(v.flags, np.uint8))
+        finally:
+            self.lib.pantax_hip_gaf_free(gaf)
+
+    def set_read_flags(self, flags):
+        f = None if flags is None else as_c(flags, np.uint8)
+        self._check(self.lib.pantax_hip_reads_set_flags(self.ctx, self.reads, p(f)))
+
     # ------------------------------------------------------------------ stages
     def rcls_profile(self, want_species=True):
         """-> (species_idx [R] int32 or None, read_count, base_sum, less_multi, uniq_count [S] int64)"""

@@ -186,3 +186,38 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path):
     only_comments.write_bytes(b"@a\n@b\n")
     d = pio.load_gaf(only_comments, engine=eng)
     assert d["step_off"].tolist() == [0] and len(d["pstart"]) == 0
+
+
+@pytest.mark.gpu
+def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path):
+    """pantax_hip_reads_load_gaf (file -> device tokenizer -> resident reads, walks never on the host) gives the same
+    binning, counters, coverage histogram and trio bases as uploading the host-tokenised arrays; drop flags can be
+    replaced in place."""
+    from pantax_amd import io as pio, synth
+    sset = synth.make_set(78, 3, 4, 30000, 80000)
+    p1 = tmp_path / "gen.gaf"
+    synth.write_gaf(sset.reads, p1)
+    eng.upload_db(sset.species)
+    host = pio.load_gaf(p1)
+    flags = (np.arange(len(host["qlen"])) % 7 == 0).astype(np.uint8)
+
+    def run():
+        sp, *cnt = eng.rcls_profile()
+        eng.db_reset(); eng.trio_nodes_info(fetch=False)
+        b, c, t, n = eng.get_node_abundances()
+        return sp, cnt, b, c, t, n
+    eng.upload_reads(host["step_off"], host["node_id"], host["pstart"], host["pend"], host["qlen"], host["mapq"], host["flags"])
+    ref = run()
+    eng.upload_reads(host["step_off"], host["node_id"], host["pstart"], host["pend"], host["qlen"], host["mapq"], flags)
+    ref_f = run()
+    cols = eng.load_reads_from_gaf(p1)
+    assert np.array_equal(cols["qlen"], host["qlen"]) and np.array_equal(cols["mapq"], host["mapq"]) and np.array_equal(cols["flags"], host["flags"])
+    got = run()
+    eng.set_read_flags(flags)
+    got_f = run()
+    for a, b in ((ref, got), (ref_f, got_f)):
+        assert np.array_equal(a[0], b[0])
+        for x, y in zip(a[1], b[1]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
+    assert not np.array_equal(ref[2], ref_f[2])   # the flags did drop something

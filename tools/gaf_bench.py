@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Debug/measurement: host (multi-thread mmap) vs device GAF tokenizer on a cfg2-sized GAF (1M reads)."""
+import os, sys, time, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from pantax_amd import synth, io as pio
+from pantax_amd.engine import Engine
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+sset = synth.make_set(20260503, 1, 10, n, 5_000_000)
+d = tempfile.mkdtemp()
+p = os.path.join(d, "x.gaf")
+t0 = time.perf_counter(); synth.write_gaf(sset.reads, p); print("wrote %.1f MB in %.1f s" % (os.path.getsize(p) / 1e6, time.perf_counter() - t0))
+eng = Engine(0)
+for th in (1, 8):
+    t0 = time.perf_counter(); h = pio.load_gaf(p, n_threads=th); dt = time.perf_counter() - t0
+    print("host tokenizer %d threads: %.1f ms (%.1f Mreads/s, %.2f GB/s)" % (th, dt * 1e3, n / dt / 1e6, os.path.getsize(p) / dt / 1e9))
+pio.load_gaf(p, engine=eng)
+eng.timing_enable(True); eng.timing_reset()
+t0 = time.perf_counter(); g = pio.load_gaf(p, engine=eng); dt = time.perf_counter() - t0
+print("device tokenizer end to end (H2D text, kernels, D2H arrays, numpy copies): %.1f ms (%.1f Mreads/s)" % (dt * 1e3, n / dt / 1e6))
+print({k: round(v[1], 3) for k, v in eng.timing_get().items()})
+for k in h: assert np.array_equal(h[k], g[k]), k
+print("identical")
