@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gaf", action="store_true", help="skip the extra end-to-end-from-GAF-text measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,6 +201,25 @@ def main():
         profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species)
     barrier()
     dt_cached = time.perf_counter() - t1
+    # extra (not `value`): the same workload from GAF TEXT on disk -- device tokenizer (a1) -> resident reads -> one step
+    gaf_extra = None
+    if rank == 0 and not args.no_gaf:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            gp = os.path.join(td, "reads.gaf")
+            synth.write_gaf(sset.reads, gp)
+            eng.load_reads_from_gaf(gp)                      # warm (allocations)
+            eng.sync()
+            t2 = time.perf_counter()
+            eng.load_reads_from_gaf(gp)
+            eng.sync()
+            t_load = time.perf_counter() - t2
+            out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, comm if world == 1 else LocalComm(), shard_max=args.species)
+            eng.sync()
+            t_e2e = time.perf_counter() - t2
+            same = out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]
+            gaf_extra = {"gaf_bytes": os.path.getsize(gp), "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
+                         "end_to_end_mreads_per_s": args.reads / t_e2e / 1e6, "tables_equal_to_packed_input_run": bool(same)}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -241,6 +261,7 @@ def main():
             "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
                                    "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),
                        "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0},
+            "from_gaf_text": gaf_extra,
             "roofline": roofline,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
             "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel only",

@@ -22,3 +22,12 @@ print("device tokenizer end to end (H2D text, kernels, D2H arrays, numpy copies)
 print({k: round(v[1], 3) for k, v in eng.timing_get().items()})
 for k in h: assert np.array_equal(h[k], g[k]), k
 print("identical")
+eng.upload_db(sset.species)
+eng.timing_enable(False)
+t0 = time.perf_counter()
+h = pio.load_gaf(p, n_threads=8)
+eng.upload_reads(h["step_off"], h["node_id"], h["pstart"], h["pend"], h["qlen"], h["mapq"], h["flags"]); eng.sync()
+dt_host = time.perf_counter() - t0
+eng.load_reads_from_gaf(p)
+t0 = time.perf_counter(); eng.load_reads_from_gaf(p); eng.sync(); dt_dev = time.perf_counter() - t0
+print("file -> resident grouped reads: host tokenizer + upload %.1f ms | device tokenizer %.1f ms (%.1f Mreads/s)" % (dt_host * 1e3, dt_dev * 1e3, n / dt_dev / 1e6))
