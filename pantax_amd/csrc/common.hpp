@@ -104,6 +104,7 @@ struct Ctx {
     DevBuf<uint32_t> d_scan_ws;  // chained-scan workspace: ticket + one state word per tile (primitives.hip)
     uint32_t scan_epoch = 0;
     PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
+    PinBuf pin_text;             // two pinned chunks of the GAF text upload (stage_gaf.hip)
     PinBuf pin_up;               // ring of small uploads; a step syncs at least once, far before the ring wraps
     size_t pin_up_off = 0;
 };

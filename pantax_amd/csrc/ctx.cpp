@@ -103,6 +103,7 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     ctx->d_scan_ws.release();
     ctx->pin_down.release();
     ctx->pin_up.release();
+    ctx->pin_text.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
