@@ -226,3 +226,49 @@ def test_single_call_step_equals_stage_by_stage(eng, seed, S, H, R, L, filtered)
         assert a[1] == b[1]
         assert np.array_equal(np.array(a[2]["obj"], dtype=float), np.array(b[2]["obj"], dtype=float), equal_nan=True)
         assert a[2]["n_active"] == b[2]["n_active"]
+
+
+def test_many_species_radix_path_against_oracle(eng):
+    """8 species, 6.3e5 nodes in all: above the sample-sort limit, so the LP rows go through the LSD radix sort and
+    eight workgroups solve their LPs side by side.  Every species against the oracle: bit-exact integers, equal
+    objectives and metrics."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(4242, 8, 10, 800_000, 1_250_000)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    assert eng.V > 600_000
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    ref_sp = orc.bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
+    assert np.array_equal(sp, ref_sp)
+    eng.db_reset()
+    eng.trio_nodes_info(fetch=False)
+    bases, cov, tb, nab = eng.get_node_abundances()
+    keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
+    met, info = eng.strain_profiling(absolute, species_active=keep)
+    gm_all = metrics_to_dicts(met, eng.H)
+    nb = np.cumsum([0] + [g.n_nodes for g in sset.species])
+    hb = np.cumsum([0] + [g.n_paths for g in sset.species])
+    hto = eng.trio_nodes_info()[3].astype(np.int64)
+    for s, g in enumerate(sset.species):
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        so, nid, ps, pe = select_reads(rd, np.nonzero(sp == s)[0])
+        b, c, t, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        assert np.array_equal(bases[nb[s]:nb[s + 1]], b) and np.array_equal(cov[nb[s]:nb[s + 1]], c)
+        assert np.array_equal(tb[hto[hb[s]]:hto[hb[s + 1]]], t)
+        if not keep[s]:
+            continue
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+        orc.abundance_constraint(absolute[s], omet)
+        assert info[s].n_candidates == nc and info[s].status1 == 0, s
+        if nc:
+            assert info[s].obj1 == pytest.approx(o1, rel=1e-9), s
+        for gm, em in zip(gm_all[hb[s]:hb[s + 1]], orc.metrics_to_dicts(omet)):
+            for key, ev in em.items():
+                if ev is None or isinstance(ev, bool):
+                    assert gm[key] == ev, (s, key)
+                else:
+                    assert gm[key] == pytest.approx(ev, rel=1e-7, abs=1e-9), (s, key)
