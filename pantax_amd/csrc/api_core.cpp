@@ -125,14 +125,25 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         }
         PTX_TRY(upload(ctx, db->d_all_same, db->h_all_same.data(), S));
     }
-    {   // path tiles, ordered (species, chunk, hap)
+    {   // path tiles, ordered (species, chunk group, hap, chunk in group): workgroup b runs on XCD b % 8, so the
+        // tiles of ONE chunk (all haplotypes, largely collinear: same node buckets, same path neighbourhood) get
+        // workgroup ids that are congruent mod 8 -- their bucket / mask writes meet in one XCD's L2 instead of
+        // being written back piecemeal from eight
         std::vector<uint2> tiles;
+        constexpr uint64_t XCD = 8;
         for (uint32_t s = 0; s < S; ++s) {
             uint64_t maxlen = 0;
             for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h) maxlen = std::max<uint64_t>(maxlen, g->path_off[h + 1] - g->path_off[h]);
-            for (uint64_t c = 0; c * PATH_TILE < maxlen; ++c)
+            const uint64_t n_chunks = (maxlen + PATH_TILE - 1) / PATH_TILE;
+            for (uint64_t c0 = 0; c0 < n_chunks; c0 += XCD) {
+                // pad the workgroup ids so that the group starts on XCD 0
+                while (tiles.size() % XCD) tiles.push_back(make_uint2(0xFFFFFFFFu, 0u));
                 for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h)
-                    if (c * PATH_TILE < g->path_off[h + 1] - g->path_off[h]) tiles.push_back(make_uint2((uint32_t)h, (uint32_t)c));
+                    for (uint64_t c = c0; c < c0 + XCD; ++c) {
+                        const bool live = c < n_chunks && c * PATH_TILE < g->path_off[h + 1] - g->path_off[h];
+                        tiles.push_back(live ? make_uint2((uint32_t)h, (uint32_t)c) : make_uint2(0xFFFFFFFFu, 0u));
+                    }
+            }
         }
         db->n_tiles = tiles.size();
         PTX_TRY(upload(ctx, db->d_tiles, tiles.data(), tiles.size()));
@@ -140,7 +151,7 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         std::vector<uint32_t> hap_tile_off(db->H + 1, 0), tile_rank(tiles.size());
         for (uint64_t h = 0; h < db->H; ++h)
             hap_tile_off[h + 1] = hap_tile_off[h] + (uint32_t)((g->path_off[h + 1] - g->path_off[h] + PATH_TILE - 1) / PATH_TILE);
-        for (size_t i = 0; i < tiles.size(); ++i) tile_rank[i] = hap_tile_off[tiles[i].x] + tiles[i].y;
+        for (size_t i = 0; i < tiles.size(); ++i) tile_rank[i] = tiles[i].x == 0xFFFFFFFFu ? hap_tile_off[db->H] : hap_tile_off[tiles[i].x] + tiles[i].y;   // pads count into the spare last slot
         PTX_TRY(upload(ctx, db->d_tile_rank, tile_rank.data(), tile_rank.size()));
         PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
     }

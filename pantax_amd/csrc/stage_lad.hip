@@ -286,6 +286,7 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
                                                    const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
                                                    unsigned long long *__restrict__ mask) {
     const uint2 tile = tiles[blockIdx.x];   // {hap, chunk}: see stage_trio.hip
+    if (tile.x == 0xFFFFFFFFu) return;      // filler tile
     const uint32_t h = tile.x;
     const int bit = hap_bit[h];
     if (bit < 0) return;

@@ -32,9 +32,10 @@ namespace ptx {
                         const uint32_t *__restrict__ hap_species, const uint32_t *__restrict__ node_base
 #define TILE_LOOP(q, h, qend)                                                         \
     const uint2 tile__ = tiles[blockIdx.x];                                           \
-    const uint32_t h = tile__.x;                                                      \
-    const uint64_t qend = path_off[h + 1];                                            \
-    const uint64_t qt0__ = path_off[h] + (uint64_t)tile__.y * PATH_TILE;              \
+    const bool pad__ = tile__.x == 0xFFFFFFFFu;   /* filler that keeps chunk groups XCD-aligned */ \
+    const uint32_t h = pad__ ? 0u : tile__.x;                                         \
+    const uint64_t qend = pad__ ? 0ull : path_off[h + 1];                             \
+    const uint64_t qt0__ = pad__ ? 0ull : path_off[h] + (uint64_t)tile__.y * PATH_TILE; \
     for (uint64_t q = qt0__ + threadIdx.x; q < qt0__ + PATH_TILE && q < qend; q += 256)
 
 // canonical window at q of hap h (profile.rs:672-678); false if q starts no window
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
                                                           uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
     __shared__ uint32_t s_wave[4];
     const uint2 tile = tiles[blockIdx.x];
+    if (tile.x == 0xFFFFFFFFu) return;   // filler tile
     const uint32_t h = tile.x;
     const uint64_t qend = path_off[h + 1], qt0 = path_off[h] + (uint64_t)tile.y * PATH_TILE;
     const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
