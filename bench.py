@@ -176,7 +176,7 @@ def main():
         if i == 1:
             eng.timing_reset()      # the very first step also allocates: its launches are not representative
             n_warm_timed = 0
-        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species)
+        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species, rows_max=args.species * args.haps)
         n_warm_timed += 1
     warm = eng.timing_get() if args.warmup else {}
     dom = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else "coverage_step_kernel"
@@ -185,7 +185,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species)
+        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species, rows_max=args.species * args.haps)
     barrier()
     dt = time.perf_counter() - t0
     timings = eng.timing_get()
@@ -194,11 +194,11 @@ def main():
     # extra (not `value`): the same step when the unique-trio index, which depends on the DB only, stays
     # resident between steps instead of being rebuilt like the reference does on every run
     cfg_cached = StepConfig(rebuild_trio=False)
-    profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species)
+    profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species, rows_max=args.species * args.haps)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species)
+        profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species, rows_max=args.species * args.haps)
     barrier()
     dt_cached = time.perf_counter() - t1
     # extra (not `value`): the same workload from GAF TEXT on disk -- device tokenizer (a1) -> resident reads -> one step
@@ -214,7 +214,7 @@ def main():
             eng.load_reads_from_gaf(gp)
             eng.sync()
             t_load = time.perf_counter() - t2
-            out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, comm if world == 1 else LocalComm(), shard_max=args.species)
+            out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, comm if world == 1 else LocalComm(), shard_max=args.species, rows_max=args.species * args.haps)
             eng.sync()
             t_e2e = time.perf_counter() - t2
             same = out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]

@@ -3,9 +3,10 @@
 Mirrors profile::profile (profile.rs:3325-3364) from the point where the GAF is in memory:
 rcls_profile -> species_profiling -> strain_profiling (load_species_range filter, trio index,
 node coverage, PAO solves, abundace_constraint) -> abundance_est.  Species are sharded across
-ranks; the only cross-rank exchange is ONE all-reduce carrying three f64 per species (its
-predicted_coverage and its two strain-level sums: the normalisers of profile.rs:341, :3198, :3243
-are sums of those) followed by a gather of the result rows to rank 0.
+ranks; the only cross-rank exchange is ONE all-reduce per step: a small fixed-shape slab per rank with
+three f64 per species (its predicted_coverage and its two strain-level sums: the normalisers of
+profile.rs:341, :3198, :3243 are sums of those) and the candidate result rows; names are static
+metadata gathered once.
 """
 from dataclasses import dataclass
 
@@ -30,15 +31,15 @@ class LocalComm:
     """world_size == 1: the exchange is the identity."""
     rank, world = 0, 1
 
-    def all_gather(self, arr, nmax=None):
-        return np.asarray(arr, dtype=np.float64)
+    def exchange(self, slab):
+        return np.asarray(slab, dtype=np.float64)[None]
 
-    def gather_rows(self, rows):
-        return rows
+    def names(self, species_names, hap_names):
+        return [list(species_names)], [list(hap_names)]
 
 
 class TorchComm:
-    """torch.distributed plumbing (backend nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    """torch.distributed plumbing (backend nccl == RCCL on ROCm; gloo in the CPU tests).  ONE collective per step."""
 
     def __init__(self, device=None):
         import torch
@@ -46,28 +47,30 @@ class TorchComm:
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self._names = None
+        self._buf = None
 
-    def all_gather(self, arr, nmax=None):
-        """arr [n, k] float64 (n <= nmax on every rank) -> concatenation over ranks in rank order.
-        ONE all-reduce(sum) of a zero-padded [world, nmax+1, k] slab: each rank fills only its own
-        slice (row 0 carries its n), so the sum IS the gather and a single collective suffices."""
-        arr = np.asarray(arr, dtype=np.float64)
-        n, k = arr.shape
-        nmax = n if nmax is None else nmax
-        slab = np.zeros((self.world, nmax + 1, k), dtype=np.float64)
-        slab[self.rank, 0, 0] = float(n)
-        slab[self.rank, 1:n + 1] = arr
-        t = self.torch.from_numpy(slab).to(self.device) if self.device is not None else self.torch.from_numpy(slab)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        slab = t.cpu().numpy()
-        return np.concatenate([slab[r, 1:int(round(slab[r, 0, 0])) + 1] for r in range(self.world)], axis=0)
+    def exchange(self, slab):
+        """slab [rows, k] float64, same shape on every rank -> [world, rows, k].  ONE all-reduce(sum) of a zero-padded
+        buffer: each rank fills only its own slice, so the sum IS the gather and a single small collective suffices
+        (xGMI is point-to-point: the cost of a step's exchange is one latency-bound ring pass over a few KB)."""
+        slab = np.asarray(slab, dtype=np.float64)
+        if self._buf is None or tuple(self._buf.shape[1:]) != slab.shape:
+            self._buf = self.torch.zeros((self.world,) + slab.shape, dtype=self.torch.float64,
+                                         device=self.device if self.device is not None else "cpu")
+        else:
+            self._buf.zero_()
+        self._buf[self.rank].copy_(self.torch.from_numpy(slab))
+        self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
+        return self._buf.cpu().numpy()
 
-    def gather_rows(self, rows):
-        out = [None] * self.world if self.rank == 0 else None
-        self.dist.gather_object(rows, out, dst=0)
-        if self.rank != 0:
-            return []
-        return [r for part in out for r in part]
+    def names(self, species_names, hap_names):
+        """Static metadata: gathered once, not per step."""
+        if self._names is None:
+            out = [None] * self.world
+            self.dist.all_gather_object(out, (list(species_names), list(hap_names)))
+            self._names = ([o[0] for o in out], [o[1] for o in out])
+        return self._names
 
 
 def local_stage(eng, avg_len, cfg, single_call=True):
@@ -115,27 +118,59 @@ def local_stage(eng, avg_len, cfg, single_call=True):
     return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
 
 
-def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None):
-    """The one cross-rank exchange + the final tables (pure host code: no device, testable under gloo)."""
+_ROW_K = 10   # columns of the exchanged slab
+
+
+def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None, rows_max=None):
+    """The one cross-rank exchange + the final tables (pure host code: no device, testable under gloo).
+    Every rank contributes one fixed-shape slab: [n_species, n_rows | species: keep, predicted_coverage, sum of all
+    strain coverages, sum of passing | candidate strain rows: species, hap, coverage, Option bits, six metrics].
+    shard_max / rows_max: upper bounds of species / strain rows per rank (identical on all ranks)."""
     keep, absolute = local["keep"], local["absolute"]
-    loc = np.stack([np.where(keep == 1, absolute, 0.0), local["s_all"], local["s_pass"]], axis=1)
-    glob = comm.all_gather(loc, shard_max)
-    total_abs = glob[:, 0].sum()                                    # profile.rs:341
-    g_active = (glob[:, 0] > 0) & (glob[:, 0] / total_abs > cfg.min_species_abundance)   # profile.rs:602
-    g_pass = glob[g_active, 2].sum()                                # profile.rs:3243
-    abundance = np.where(keep == 1, absolute / total_abs if total_abs > 0 else 0.0, 0.0)
-    active = (keep == 1) & (abundance > cfg.min_species_abundance)
-    strain_rows = [(species_names[s], hap_names[h], cov, cov / g_pass) + tuple(rest)
-                   for (s, h, cov, *rest) in local["rows"] if active[s]]
-    species_rows = [(species_names[s], float(abundance[s]), float(absolute[s])) for s in range(len(keep)) if keep[s]]
-    species_rows = comm.gather_rows(species_rows)
-    strain_rows = comm.gather_rows(strain_rows)
-    species_rows.sort(key=lambda r: -r[1])     # profile.rs:344
-    strain_rows.sort(key=lambda r: -r[3])      # profile.rs:3247-3248
-    return species_rows, strain_rows, int(active.sum())
+    rows = local["rows"]
+    S_loc = len(keep)
+    S_max = S_loc if shard_max is None else shard_max
+    R_max = max(len(hap_names), 1) if rows_max is None else rows_max
+    slab = np.zeros((1 + S_max + R_max, _ROW_K))
+    slab[0, 0], slab[0, 1] = S_loc, len(rows)
+    slab[1:1 + S_loc, 0] = keep
+    slab[1:1 + S_loc, 1] = np.where(keep == 1, absolute, 0.0)
+    slab[1:1 + S_loc, 2] = local["s_all"]
+    slab[1:1 + S_loc, 3] = local["s_pass"]
+    for j, (s_, h_, cov, *opt) in enumerate(rows):
+        r = slab[1 + S_max + j]
+        r[0], r[1], r[2] = s_, h_, cov
+        r[3] = sum(1 << i for i, v in enumerate(opt) if v is not None)
+        r[4:4 + len(opt)] = [0.0 if v is None else v for v in opt]
+    glob = comm.exchange(slab)                                       # [world, rows, K]
+    W = glob.shape[0]
+    n_sp = [int(round(glob[r, 0, 0])) for r in range(W)]
+    n_rw = [int(round(glob[r, 0, 1])) for r in range(W)]
+    sp_blk = [glob[r, 1:1 + n_sp[r]] for r in range(W)]
+    total_abs = sum(float(b[:, 1].sum()) for b in sp_blk)            # profile.rs:341
+    act = [(b[:, 0] == 1) & (b[:, 1] > 0) & (b[:, 1] / total_abs > cfg.min_species_abundance) for b in sp_blk]   # profile.rs:602
+    g_pass = sum(float(b[a, 3].sum()) for b, a in zip(sp_blk, act))  # profile.rs:3243
+    n_active = int(act[comm.rank].sum())
+    all_sn, all_hn = comm.names(species_names, hap_names)          # collective on its first call only (cached)
+    if comm.rank != 0:
+        return [], [], n_active
+    species_rows, strain_rows = [], []
+    for r in range(W):
+        b = sp_blk[r]
+        species_rows += [(all_sn[r][s], float(b[s, 1] / total_abs), float(b[s, 1])) for s in range(n_sp[r]) if b[s, 0] == 1]
+        for row in glob[r, 1 + S_max:1 + S_max + n_rw[r]]:
+            s_, h_ = int(round(row[0])), int(round(row[1]))
+            if not act[r][s_]:
+                continue
+            has = int(round(row[3]))
+            strain_rows.append((all_sn[r][s_], all_hn[r][h_], float(row[2]), float(row[2] / g_pass)) +
+                               tuple(float(row[4 + i]) if has >> i & 1 else None for i in range(6)))
+    species_rows.sort(key=lambda t: -t[1])     # profile.rs:344
+    strain_rows.sort(key=lambda t: -t[3])      # profile.rs:3247-3248
+    return species_rows, strain_rows, n_active
 
 
-def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None, single_call=True):
+def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None, single_call=True, rows_max=None):
     """Returns (species_rows, strain_rows, stats) on rank 0 (empty lists elsewhere).
     species_rows: (species_taxid, predicted_abundance, predicted_coverage) sorted descending.
     strain_rows : (species_taxid, hap_id, predicted_coverage, predicted_abundance, path_base_cov,
@@ -143,6 +178,6 @@ def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, sh
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
     local = local_stage(eng, avg_len, cfg, single_call)
-    species_rows, strain_rows, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max)
+    species_rows, strain_rows, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max, rows_max)
     stats = dict(local["stats"], n_active=n_active)
     return species_rows, strain_rows, stats

@@ -44,7 +44,7 @@ if __name__ == "__main__":
     comm = TorchComm(device=None)
     sn, hn = names(rank, n_species[rank])
     species_rows, strain_rows, n_active = finalize_stage(fake_local(rank, n_species[rank]), sn, hn, StepConfig(), comm,
-                                                         shard_max=max(n_species))
+                                                         shard_max=max(n_species), rows_max=3 * max(n_species))
     if rank == 0:
         json.dump(dict(species=species_rows, strain=strain_rows), open(out, "w"))
     dist.destroy_process_group()
