@@ -58,6 +58,22 @@ __device__ __forceinline__ void bitonic_lds(uint64_t *ka, uint64_t *kb, uint64_t
     }
 }
 
+// the same network on one key word (buckets whose rows share the two leading words)
+template <int NT>
+__device__ __forceinline__ void bitonic_lds1(uint64_t *kc, uint32_t N) {
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += NT) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const uint64_t x = kc[i], y = kc[l];
+                const bool up = (i & k) == 0;
+                if (up ? (y < x) : (x < y)) { kc[i] = y; kc[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // workspace (u32 words)
 struct SsWs {
     uint32_t *flags;          // [0] = 1: the whole input was sorted by the sample kernel
@@ -210,7 +226,8 @@ __global__ void __launch_bounds__(256) ss_scatter_kernel(SortBufs a, SortBufs b,
 // CAP = SS_CAP : the rest.
 template <int CAP>
 __global__ void __launch_bounds__(256) ss_local_kernel(SortBufs a, SortBufs b, const uint32_t *__restrict__ d_n, uint32_t *__restrict__ flags,
-                                                       const uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ big_list) {
+                                                       const uint32_t *__restrict__ bucket_start, uint32_t *__restrict__ big_list,
+                                                       const uint64_t *__restrict__ spl) {
     __shared__ uint64_t ka[CAP], kb[CAP], kc[CAP];
     if (flags[0] != 0) {
         const uint32_t bid = blockIdx.x;   // small input: the sample kernel ranked every row into b
@@ -240,6 +257,17 @@ __global__ void __launch_bounds__(256) ss_local_kernel(SortBufs a, SortBufs b, c
     if (m <= (uint32_t)CAP) {
         uint32_t N = 2;
         while (N < m) N <<= 1;
+        // a bucket between two splitters that agree in the two leading words holds rows that agree in them too
+        // (the usual case: one species, one mask): only the third word moves through the network
+        const uint32_t sj = bid >> 1;
+        if (sj > 0 && sj < (uint32_t)SS_NSPLIT && spl[sj - 1] == spl[sj] && spl[1024 + sj - 1] == spl[1024 + sj]) {
+            const uint64_t k0v = spl[sj], k1v = spl[1024 + sj];
+            for (uint32_t i = threadIdx.x; i < N; i += 256) kc[i] = i < m ? b.k[2][st + i] : ~0ull;
+            __syncthreads();
+            bitonic_lds1<256>(kc, N);
+            for (uint32_t i = threadIdx.x; i < m; i += 256) { a.k[0][st + i] = k0v; a.k[1][st + i] = k1v; a.k[2][st + i] = kc[i]; }
+            continue;
+        }
         for (uint32_t i = threadIdx.x; i < N; i += 256) {
             if (i < m) { ka[i] = b.k[0][st + i]; kb[i] = b.k[1][st + i]; kc[i] = b.k[2][st + i]; }
             else { ka[i] = ~0ull; kb[i] = ~0ull; kc[i] = ~0ull; }
@@ -278,8 +306,8 @@ int sample_sort3(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n_bound, uint32_t *d
     { KTimer t(ctx, "ss_scatter_kernel");
       hipLaunchKernelGGL(ss_scatter_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, d_n, w.flags, nb, w.table, w.ids, w.bucket_start); }
     { KTimer t(ctx, "ss_local_kernel");
-      hipLaunchKernelGGL((ss_local_kernel<SS_CAP1>), dim3(SS_NBUCKET), dim3(256), 0, ctx->stream, a, b, d_n, w.flags, w.bucket_start, w.big_list);
-      hipLaunchKernelGGL((ss_local_kernel<SS_CAP>), dim3(64), dim3(256), 0, ctx->stream, a, b, d_n, w.flags, w.bucket_start, w.big_list); }
+      hipLaunchKernelGGL((ss_local_kernel<SS_CAP1>), dim3(SS_NBUCKET), dim3(256), 0, ctx->stream, a, b, d_n, w.flags, w.bucket_start, w.big_list, w.spl);
+      hipLaunchKernelGGL((ss_local_kernel<SS_CAP>), dim3(64), dim3(256), 0, ctx->stream, a, b, d_n, w.flags, w.bucket_start, w.big_list, w.spl); }
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -246,14 +246,18 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
     zc = block_sum_u64<256>(zc, redu);
     if (threadIdx.x == 0) part[blockIdx.x] = {mx, zs, nv, zc};
 }
+// one wave per species: lane l combines chunks l, l+64, ... in order, then a fixed-shape wave reduction
 __global__ void __launch_bounds__(64) node_stats_final_kernel(uint32_t S, const NodePartial *__restrict__ part, double *__restrict__ amax_out,
                                                               uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
                                                               uint32_t *__restrict__ nzcnt_out) {
-    uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= S) return;
+    const uint32_t s = blockIdx.x;
     double mx = -INFINITY, zs = 0.0; unsigned long long nv = 0, zc = 0;
-    for (int c = 0; c < STAT_CHUNKS; ++c) { NodePartial p = part[(size_t)s * STAT_CHUNKS + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
-    amax_out[s] = mx; nvalid_out[s] = (uint32_t)nv; nzsum_out[s] = zs; nzcnt_out[s] = (uint32_t)zc;
+    for (int c = threadIdx.x; c < STAT_CHUNKS; c += 64) { NodePartial p = part[(size_t)s * STAT_CHUNKS + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
+    mx = wave_reduce(mx, [](double x, double y) { return fmax(x, y); });
+    zs = wave_reduce(zs, [](double x, double y) { return x + y; });
+    nv = wave_reduce(nv, [](unsigned long long x, unsigned long long y) { return x + y; });
+    zc = wave_reduce(zc, [](unsigned long long x, unsigned long long y) { return x + y; });
+    if (threadIdx.x == 0) { amax_out[s] = mx; nvalid_out[s] = (uint32_t)nv; nzsum_out[s] = zs; nzcnt_out[s] = (uint32_t)zc; }
 }
 
 int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
@@ -266,7 +270,7 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     KTimer t(ctx, "node_stats_kernel");
     hipLaunchKernelGGL(node_stats_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
                        (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p);
-    hipLaunchKernelGGL(node_stats_final_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
+    hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
                        lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
@@ -1362,9 +1366,13 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
         s_last = __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)STAT_CHUNKS - 1;
     }
     __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
-    double t1 = 0.0, t2 = 0.0;
-    for (int c = 0; c < STAT_CHUNKS; ++c) { t1 += part[((size_t)s * STAT_CHUNKS + c) * 2]; t2 += part[((size_t)s * STAT_CHUNKS + c) * 2 + 1]; }
+    if (!s_last) return;
+    // the last workgroup adds the partials: thread c takes chunk c (STAT_CHUNKS == block size), fixed-shape block sum
+    static_assert(STAT_CHUNKS == 256, "one partial per thread");
+    double t1 = part[((size_t)s * STAT_CHUNKS + threadIdx.x) * 2], t2 = part[((size_t)s * STAT_CHUNKS + threadIdx.x) * 2 + 1];
+    t1 = block_sum_f64<256>(t1, red);
+    t2 = block_sum_f64<256>(t2, red);
+    if (threadIdx.x != 0) return;
     obj1[s] = nvalid[s] ? t1 / (double)nvalid[s] : 0.0;
     if (two) obj2[s] = nvalid[s] ? t2 / (double)nvalid[s] : 0.0;
     done[s] = 0;
