@@ -35,11 +35,12 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     PTX_TRY(bin_reads_launch(ctx, db, reads, db->d_counters.p));
     // a3 decision on the device: keep -> d_active, predicted_coverage -> d_sp_abs
     PTX_TRY(upload_small(ctx, db->d_avg_len, avg_len, S));
-    PTX_HIP(ctx, db->d_active.alloc(S)); PTX_HIP(ctx, db->d_sp_abs.alloc(S));
+    PTX_HIP(ctx, db->d_sp_out.alloc(sizeof(double) * S + S));             // [S f64 predicted_coverage][S u8 keep]: one copy back
+    db->d_sp_abs.view(db->d_sp_out.p, S);
+    db->d_active.view(db->d_sp_out.p + sizeof(double) * S, S);
     PTX_TRY(species_profile_launch(ctx, db, reads, db->d_counters.p, db->d_avg_len.p, cfg->filtered, db->d_active.p, db->d_sp_abs.p));
     PTX_HIP(ctx, db->h_sp_out.reserve(sizeof(double) * S + S));
-    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_abs.p, sizeof(double) * S, hipMemcpyDeviceToHost, ctx->stream));
-    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p + sizeof(double) * S, db->d_active.p, S, hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
     // a7 (the reference rebuilds trio_nodes_info every run, profile.rs:2936), a8
     if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
     if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));

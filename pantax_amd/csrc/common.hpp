@@ -238,6 +238,7 @@ struct Db {
     DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
     PinBuf h_arena;                  // pinned mirror of d_arena
     DevBuf<double> d_avg_len, d_sp_abs;   // resident step: species lengths in, predicted_coverage out (d_active holds keep)
+    DevBuf<uint8_t> d_sp_out;        // backing store of d_sp_abs + d_active in a resident step (one download)
     PinBuf h_sp_out;                 // [S f64 absolute][S u8 keep]
     // LP-row staging (lad_prepare)
     DevBuf<uint8_t> d_row_flag, d_pat_head;

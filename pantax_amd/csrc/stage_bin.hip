@@ -203,17 +203,33 @@ __global__ void __launch_bounds__(64) species_profile_kernel(uint64_t R, const i
     uint32_t seen = 0;
     long long first_len = -1;
     bool equal = true;
-    for (uint64_t base = 0; base < R && seen < 1000; base += 64) {
-        const uint64_t r = base + lane;
-        int sp = -1;
-        uint32_t q = 0;
-        if (r < R) { sp = species[r]; q = qlen[r]; }
+    // the head (2048 rows, nearly always enough to see 1000 binned reads) is loaded in one go: 32 independent loads
+    // per lane instead of 32 dependent round trips; further rows, if ever needed, 64 at a time
+    constexpr int PRE = 32;
+    int sp_pre[PRE];
+    uint32_t q_pre[PRE];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const uint64_t r = (uint64_t)it * 64 + lane;
+        sp_pre[it] = r < R ? species[r] : -1;
+        q_pre[it] = r < R ? qlen[r] : 0u;
+    }
+    auto feed = [&](int sp, uint32_t q) {
         const unsigned long long b = __ballot(sp >= 0);
-        if (!b) continue;
+        if (!b) return;
         if (seen == 0) first_len = (long long)__shfl(q, __ffsll((long long)b) - 1);
         const uint32_t rank = seen + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (__any(sp >= 0 && rank < 1000 && (long long)q != first_len)) equal = false;
         seen += (uint32_t)__popcll(b);
+    };
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) if (seen < 1000) feed(sp_pre[it], q_pre[it]);
+    for (uint64_t base = (uint64_t)PRE * 64; base < R && seen < 1000; base += 64) {
+        const uint64_t r = base + lane;
+        int sp = -1;
+        uint32_t q = 0;
+        if (r < R) { sp = species[r]; q = qlen[r]; }
+        feed(sp, q);
     }
     if (seen == 0) equal = false;
     for (uint32_t s = lane; s < S; s += 64) {
