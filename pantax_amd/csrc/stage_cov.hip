@@ -105,7 +105,7 @@ __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases
 template <bool WITH_TRIO>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
-    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
+    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
     const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases,
     uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
     unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort) {
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     for (uint64_t base = chunk_b + (threadIdx.x - lane); base < chunk_e; base += COV_BLOCK) {
         const uint64_t t = base + lane;
         bool ok = t < chunk_e;
-        uint32_t slot = NO_SLOT, id = 0;
-        if (ok) { slot = step_read[t]; id = node_id[t]; }
+        uint32_t slot = NO_SLOT, id = 0, dupc = 0;
+        if (ok) { slot = step_read[t]; id = node_id[t]; dupc = step_dup[t]; }
         ok = ok && slot != NO_SLOT;
         uint4 rr = make_uint4(0, 0, 0, 0);
         int sp = -1;
@@ -208,11 +208,17 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             if (dist >= d) incl += up;
         }
         // ---- first occurrence of this node in the read (:879): compare with the earlier lanes
+        // walks of <= 64 steps carry the answer from upload time (step_dup = distance back to the first occurrence,
+        // 0 = none); longer walks (code 255) compare through shuffles here and finish from memory below
         int dmax = 0;
-        for (int d = 1; __any(dist >= d); ++d) {
-            uint32_t other = __shfl_up(id, d);
-            if (dist >= d && other == id) dmax = d;
+        const bool scan_dup = ok && dupc == 255u;
+        if (__any(scan_dup)) {
+            for (int d = 1; __any(scan_dup && dist >= d); ++d) {
+                uint32_t other = __shfl_up(id, d);
+                if (scan_dup && dist >= d && other == id) dmax = d;
+            }
         }
+        if (ok && dupc != 255u) dmax = (int)dupc;
         long long rl = 0;
         if (ok) {
             int jf = dmax ? (int)i - dmax : -1;
@@ -318,14 +324,21 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint3
                                                          const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, int shift,
                                                          const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
                                                          const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
-                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read) {
+                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read,
+                                                         uint8_t *__restrict__ g_step_dup) {
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t slot = slot_of[r];
         if (slot == NO_SLOT) continue;
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
         const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
-        for (uint32_t i = 0; i < k; ++i) { g_node_id[sb + i] = node_id[b + i]; g_step_read[sb + i] = slot; }
+        for (uint32_t i = 0; i < k; ++i) {
+            const uint32_t id = node_id[b + i];
+            g_node_id[sb + i] = id; g_step_read[sb + i] = slot;
+            uint32_t dup = 255u;                         // walks longer than a wave: decided in the coverage kernel
+            if (k <= 64) { dup = 0; for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = i - j; break; } }
+            g_step_dup[sb + i] = (uint8_t)dup;
+        }
     }
 }
 
@@ -362,11 +375,11 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
     rd->T_pad = h_total;
-    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad));
+    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
-                       rd->d_pend.p, shift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p);
+                       rd->d_pend.p, shift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // temporaries are released on return
     return 0;
@@ -410,7 +423,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     if (rd->R && rd->T_pad) {
         int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
-#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, d_active, db->d_sp_first_id.p, \
+#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_sp_first_id.p, \
                   db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort
         if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
         else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
