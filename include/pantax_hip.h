@@ -232,7 +232,8 @@ int pantax_hip_reads_set_flags(pantax_hip_ctx *ctx, pantax_hip_reads *reads, con
 void pantax_hip_gaf_free(pantax_hip_gaf *gaf);
 
 typedef struct pantax_hip_graph pantax_hip_graph; /* one species graph in `Graph` shape (types.rs:51-55) */
-/* format 0 = GFA S/W/P lines (read_gfa, profile.rs:466-545), 1 = bincode-1 .bin (zip.rs:236-247) */
+/* format 0 = GFA S/W/P lines (read_gfa, profile.rs:466-545), 1 = bincode-1 .bin (zip.rs:236-247),
+ * 2 = .bin.lz4 (LZ4 frame), 3 = .bin.zst (zip.rs:250-265; liblz4.so.1 / libzstd.so.1 are bound at run time) */
 int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, const char **err_out);
 /* sizes: n_nodes, n_haps, n_steps; arrays are valid until graph_free; hap_names_out[i] NUL-terminated */
 int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t *n_haps, const int64_t **node_len,

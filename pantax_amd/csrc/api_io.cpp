@@ -43,7 +43,7 @@ int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, 
     if (!path || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
     pantax_hip_graph *g = new pantax_hip_graph();
-    std::string e = format == 1 ? read_graph_bin(path, g->g) : read_gfa(path, g->g);
+    std::string e = format == 1 ? read_graph_bin(path, g->g) : (format == 2 || format == 3) ? read_graph_zip(path, format, g->g) : read_gfa(path, g->g);
     if (!e.empty()) { delete g; return io_fail(err_out, e); }
     for (auto &n : g->g.hap_names) g->names.push_back(n.c_str());
     *out = g;

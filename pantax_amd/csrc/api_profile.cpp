@@ -62,8 +62,8 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (cfg->sample_nodes != 0)
         return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: --sample %d: LP row sub-sampling (profile.rs:1394-1400) is not implemented; pass --sample 0", cfg->sample_nodes);
     const std::string zip = opt(cfg->zip);
-    if (zip == "lz" || zip == "zstd" || zip == "h5")
-        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: graph codec '%s' is not available in this build; use serialize (.bin) or GFA", zip.c_str());
+    if (zip == "h5")
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: graph container '%s' is not available in this build (the reference gates it behind a cargo feature); use serialize / lz / zstd or GFA", zip.c_str());
     const std::string species_file = join(wd, "species_abundance.txt"), strain_file = join(wd, "strain_abundance.txt");
     const bool species_exists = !cfg->force && is_file(species_file);
     const bool strain_exists = !cfg->force && is_file(strain_file);
@@ -230,8 +230,11 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         const std::string &otu = ranges[sel[i]].species;
         std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
         std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
+        const std::string lz = bin + ".lz4", zst = bin + ".zst";
         std::string e2;
         if (zip == "serialize" && is_file(bin)) e2 = read_graph_bin(bin, graphs[i]);
+        else if (zip == "lz" && is_file(lz)) e2 = read_graph_zip(lz, 2, graphs[i]);
+        else if (zip == "zstd" && is_file(zst)) e2 = read_graph_zip(zst, 3, graphs[i]);
         else if (is_file(gfa)) e2 = read_gfa(gfa, graphs[i]);
         else return fail(ctx, PANTAX_HIP_E_IO, "gfa information file %s does not exist. Please check database.", gfa.c_str());
         if (!e2.empty()) { loaded[i] = 0; continue; }            // "GFA read error" => species skipped (.ok()?)

@@ -1,4 +1,5 @@
 // host_io.cpp -- see host_io.hpp.  Host-only C++17; no device code.
+#include <dlfcn.h>
 #include "host_io.hpp"
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -140,32 +141,130 @@ std::string read_gfa(const std::string &path, HostGraph &g) {
     return "";
 }
 
-std::string read_graph_bin(const std::string &path, HostGraph &g) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return "cannot open serialized graph " + path;
-    auto rd64 = [&](uint64_t &v) { f.read(reinterpret_cast<char *>(&v), 8); return (bool)f; };
-    uint64_t n = 0;
-    if (!rd64(n)) return "truncated graph file " + path;
-    g.node_len.resize(n);
-    f.read(reinterpret_cast<char *>(g.node_len.data()), (std::streamsize)(n * 8));
+// bincode-1 (fixed-int, little endian) image of `Graph { nodes_len: Vec<i64>, paths: BTreeMap<String, Vec<usize>> }`
+// (types.rs:51-55, zip.rs:171-190): u64 len + i64s; u64 map len; per entry u64 key len + bytes + u64 vec len + u64s
+static std::string parse_graph_bincode(const char *p, size_t n, const std::string &path, HostGraph &g) {
+    size_t off = 0;
+    auto rd64 = [&](uint64_t &v) { if (off + 8 > n) return false; std::memcpy(&v, p + off, 8); off += 8; return true; };
+    uint64_t nn = 0;
+    if (!rd64(nn) || nn > (n - off) / 8) return "truncated graph file " + path;
+    g.node_len.resize(nn);
+    std::memcpy(g.node_len.data(), p + off, nn * 8);
+    off += nn * 8;
     uint64_t m = 0;
     if (!rd64(m)) return "truncated graph file " + path;
     std::map<std::string, std::vector<uint32_t>> paths;
     for (uint64_t i = 0; i < m; ++i) {
         uint64_t kl = 0, vl = 0;
-        if (!rd64(kl) || kl > (1u << 20)) return "corrupt graph file " + path;
-        std::string key(kl, '\0');
-        f.read(&key[0], (std::streamsize)kl);
-        if (!rd64(vl)) return "truncated graph file " + path;
-        std::vector<uint64_t> tmp(vl);
-        f.read(reinterpret_cast<char *>(tmp.data()), (std::streamsize)(vl * 8));
-        if (!f) return "truncated graph file " + path;
+        if (!rd64(kl) || kl > (1u << 20) || off + kl > n) return "corrupt graph file " + path;
+        std::string key(p + off, kl);
+        off += kl;
+        if (!rd64(vl) || vl > (n - off) / 8) return "truncated graph file " + path;
         auto &dst = paths[key];
         dst.reserve(vl);
-        for (uint64_t x : tmp) { if (x > 0xFFFFFFFFull) return "node index out of range in " + path; dst.push_back((uint32_t)x); }
+        for (uint64_t j = 0; j < vl; ++j) {
+            uint64_t x;
+            std::memcpy(&x, p + off + 8 * j, 8);
+            if (x > 0xFFFFFFFFull) return "node index out of range in " + path;
+            dst.push_back((uint32_t)x);
+        }
+        off += vl * 8;
     }
     finish_graph(paths, g);
     return "";
+}
+
+static std::string slurp(const std::string &path, std::string &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return "cannot open serialized graph " + path;
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    out.resize((size_t)n);
+    if (n) f.read(&out[0], n);
+    return f ? "" : "cannot read " + path;
+}
+
+std::string read_graph_bin(const std::string &path, HostGraph &g) {
+    std::string buf;
+    std::string e = slurp(path, buf);
+    if (!e.empty()) return e;
+    return parse_graph_bincode(buf.data(), buf.size(), path, g);
+}
+
+// ---- the two stream codecs of zip.rs:191-223 (`--lz`: LZ4 frame, lz4_flex; `--zstd`).  The image ships the shared
+// libraries without headers, so the few entry points are bound at run time.
+namespace {
+struct ZstdIn { const void *src; size_t size, pos; };
+struct ZstdOut { void *dst; size_t size, pos; };
+void *codec_sym(const char *lib, const char *sym, std::string &err) {
+    static std::map<std::string, void *> handles;
+    void *&h = handles[lib];
+    if (!h) h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("codec library ") + lib + " is not available on this host"; return nullptr; }
+    void *f = dlsym(h, sym);
+    if (!f) err = std::string(sym) + " missing from " + lib;
+    return f;
+}
+std::string decode_lz4_frame(const std::string &in, std::string &out) {
+    std::string err;
+    auto create = (size_t(*)(void **, unsigned))codec_sym("liblz4.so.1", "LZ4F_createDecompressionContext", err);
+    auto destroy = (size_t(*)(void *))codec_sym("liblz4.so.1", "LZ4F_freeDecompressionContext", err);
+    auto dec = (size_t(*)(void *, void *, size_t *, const void *, size_t *, const void *))codec_sym("liblz4.so.1", "LZ4F_decompress", err);
+    auto is_err = (unsigned (*)(size_t))codec_sym("liblz4.so.1", "LZ4F_isError", err);
+    if (!create || !destroy || !dec || !is_err) return err;
+    void *dctx = nullptr;
+    if (is_err(create(&dctx, 100))) return "LZ4F_createDecompressionContext failed";
+    std::vector<char> chunk(4u << 20);
+    size_t pos = 0;
+    out.clear();
+    std::string res;
+    while (pos < in.size()) {
+        size_t dn = chunk.size(), sn = in.size() - pos;
+        const size_t r = dec(dctx, chunk.data(), &dn, in.data() + pos, &sn, nullptr);
+        if (is_err(r)) { res = "corrupt LZ4 frame"; break; }
+        out.append(chunk.data(), dn);
+        pos += sn;
+        if (sn == 0 && dn == 0) { res = "truncated LZ4 frame"; break; }
+    }
+    destroy(dctx);
+    return res;
+}
+std::string decode_zstd(const std::string &in, std::string &out) {
+    std::string err;
+    auto create = (void *(*)())codec_sym("libzstd.so.1", "ZSTD_createDStream", err);
+    auto init = (size_t(*)(void *))codec_sym("libzstd.so.1", "ZSTD_initDStream", err);
+    auto dec = (size_t(*)(void *, ZstdOut *, ZstdIn *))codec_sym("libzstd.so.1", "ZSTD_decompressStream", err);
+    auto destroy = (size_t(*)(void *))codec_sym("libzstd.so.1", "ZSTD_freeDStream", err);
+    auto is_err = (unsigned (*)(size_t))codec_sym("libzstd.so.1", "ZSTD_isError", err);
+    if (!create || !init || !dec || !destroy || !is_err) return err;
+    void *ds = create();
+    if (!ds || is_err(init(ds))) return "ZSTD_createDStream failed";
+    std::vector<char> chunk(4u << 20);
+    ZstdIn zi{in.data(), in.size(), 0};
+    out.clear();
+    std::string res;
+    size_t r = 1;
+    while (zi.pos < zi.size || r != 0) {
+        ZstdOut zo{chunk.data(), chunk.size(), 0};
+        const size_t before = zi.pos;
+        r = dec(ds, &zo, &zi);
+        if (is_err(r)) { res = "corrupt zstd stream"; break; }
+        out.append(chunk.data(), zo.pos);
+        if (zi.pos == before && zo.pos == 0) { if (r != 0) res = "truncated zstd stream"; break; }
+    }
+    destroy(ds);
+    return res;
+}
+}  // namespace
+
+std::string read_graph_zip(const std::string &path, int codec, HostGraph &g) {
+    std::string raw, img;
+    std::string e = slurp(path, raw);
+    if (!e.empty()) return e;
+    e = codec == 2 ? decode_lz4_frame(raw, img) : decode_zstd(raw, img);
+    if (!e.empty()) return e + " (" + path + ")";
+    return parse_graph_bincode(img.data(), img.size(), path, g);
 }
 
 MappedFile::~MappedFile() {

@@ -25,7 +25,9 @@ struct HostGraph {
     std::vector<uint32_t> path_nodes;
 };
 std::string read_gfa(const std::string &path, HostGraph &g);        // profile.rs:466-545 (no walk reversal)
-std::string read_graph_bin(const std::string &path, HostGraph &g);  // bincode 1.3 fixed-int little-endian
+std::string read_graph_bin(const std::string &path, HostGraph &g);
+// codec 2 = <otu>.bin.lz4 (LZ4 frame), 3 = <otu>.bin.zst: the same bincode image behind a stream codec (zip.rs:191-223, :250-265)
+std::string read_graph_zip(const std::string &path, int codec, HostGraph &g);  // bincode 1.3 fixed-int little-endian
 
 struct HostReads {
     std::vector<uint32_t> step_off{0}, node_id, pstart, pend, qlen;

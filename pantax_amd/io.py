@@ -43,7 +43,7 @@ def load_graph(path, fmt="gfa"):
     lib = _ffi.load()
     h = C.c_void_p()
     err = C.c_char_p()
-    rc = lib.pantax_hip_graph_load(str(path).encode(), 1 if fmt == "bin" else 0, C.byref(h), C.byref(err))
+    rc = lib.pantax_hip_graph_load(str(path).encode(), {"gfa": 0, "bin": 1, "lz4": 2, "zst": 3}[fmt], C.byref(h), C.byref(err))
     if rc != 0:
         raise _ffi.PantaxHipError(rc, (err.value or b"").decode())
     try:

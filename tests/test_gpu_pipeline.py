@@ -91,7 +91,14 @@ def test_profile_seam_bin_and_gfa(world):
     sset, root, db, gaf, eng = world
     exp_species, exp_strain, sp = _oracle_tables(sset)
     cwd = os.getcwd()
-    for name, zip_ in [("wd_bin", "serialize"), ("wd_gfa", None)]:
+    # the same graphs behind the two stream codecs of zip.rs:191-223 (pyarrow writes those container formats)
+    import pyarrow as pa
+    for f in os.listdir(db / "species_graph_info"):
+        if f.endswith(".bin"):
+            raw = open(db / "species_graph_info" / f, "rb").read()
+            (db / "species_graph_info" / (f + ".lz4")).write_bytes(pa.Codec("lz4").compress(raw, asbytes=True))
+            (db / "species_graph_info" / (f + ".zst")).write_bytes(pa.Codec("zstd").compress(raw, asbytes=True))
+    for name, zip_ in [("wd_bin", "serialize"), ("wd_gfa", None), ("wd_lz", "lz"), ("wd_zstd", "zstd")]:
         wd = root / name
         wd.mkdir()
         os.chdir(str(wd))   # ori_strain_abundance.txt goes to the current directory (profile.rs:3217)

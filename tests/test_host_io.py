@@ -78,3 +78,23 @@ def test_gfa_quirks(tmp_path):
     bad.write_text("S\t2\tAC\n")
     with pytest.raises(Exception):
         pio.load_graph(bad, "gfa")
+
+
+def test_graph_codecs_lz4_and_zstd(small, tmp_path):
+    """`--lz` / `--zstd` graph files (zip.rs:191-223): the bincode image behind an LZ4 frame or a zstd stream
+    (written here with pyarrow's codecs, which produce those container formats) load to the same graph as the .bin."""
+    import pyarrow as pa
+    sset, db = small
+    g0 = sset.species[0]
+    bin_path = os.path.join(db, "species_graph_info", g0.name + ".bin")
+    raw = open(bin_path, "rb").read()
+    ref = pio.load_graph(bin_path, "bin")
+    for fmt, codec in (("lz4", "lz4"), ("zst", "zstd")):
+        p = tmp_path / (g0.name + ".bin." + fmt)
+        p.write_bytes(pa.Codec(codec).compress(raw, asbytes=True))
+        got = pio.load_graph(p, fmt)
+        assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+        bad = tmp_path / ("bad.bin." + fmt)
+        bad.write_bytes(p.read_bytes()[: len(p.read_bytes()) // 2])
+        with pytest.raises(Exception):
+            pio.load_graph(bad, fmt)
