@@ -14,7 +14,7 @@ static void usage() {
             "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
             "  --min_cov N  --min_depth N  --sample N(must be 0)  --ds a,b,c  --smode 0|1  --no-filter\n"
             "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
-            "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --round (2-decimal output)  --device N\n");
+            "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n");
 }
 
 int main(int argc, char **argv) {
@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
         else if (a == "--species-len-file") c.species_len_file = next();
         else if (a == "--reads-binning-file") c.reads_binning_file = next();
         else if (a == "--gfa") c.zip = nullptr;
+        else if (a == "--zip") c.zip = next();        // serialize | lz | zstd (main.rs: --zip)
         else if (a == "--round") c.full = 0;
         else if (a == "--device") device = atoi(next());
         else { usage(); return 2; }

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import ROOT
 from tests.helpers import select_reads
 
 pytestmark = pytest.mark.gpu
@@ -228,3 +229,38 @@ def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path):
             assert np.array_equal(x, y)
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[5] == b[5]
     assert not np.array_equal(ref[2], ref_f[2])   # the flags did drop something
+
+
+@pytest.mark.gpu
+def test_cli_binary_matches_library_call(world):
+    """pantax_amd/lib/pantax-hip (the stand-alone front end of the pipeline seam) writes the same tables as the
+    library call, for the default .bin graphs and the zstd ones; bad usage exits non-zero."""
+    import subprocess
+    sset, root, db, gaf, eng = world
+    exe = os.path.join(ROOT, "pantax_amd", "lib", "pantax-hip")
+    assert os.path.exists(exe)
+    if not os.path.exists(db / "species_graph_info" / (sset.species[0].name + ".bin.zst")):
+        import pyarrow as pa
+        for f in os.listdir(db / "species_graph_info"):
+            if f.endswith(".bin"):
+                (db / "species_graph_info" / (f + ".zst")).write_bytes(pa.Codec("zstd").compress(open(db / "species_graph_info" / f, "rb").read(), asbytes=True))
+    ref = root / "wd_cli_ref"
+    ref.mkdir()
+    cwd = os.getcwd()
+    os.chdir(str(ref))
+    try:
+        eng.profile(str(db), str(ref), str(gaf), zip="serialize")
+    finally:
+        os.chdir(cwd)
+    for name, extra in (("wd_cli", []), ("wd_cli_zst", ["--zip", "zstd"])):
+        wd = root / name
+        wd.mkdir()
+        r = subprocess.run([exe, "-db", str(db), "-T", str(wd), "--gaf", str(gaf), "--species", "--strain", "--short-read", "--sample", "0"] + extra,
+                           cwd=str(wd), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        for f in ("species_abundance.txt", "strain_abundance.txt"):
+            assert open(wd / f).read() == open(ref / f).read(), (name, f)
+    r = subprocess.run([exe, "-db", str(db)], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    r = subprocess.run([exe, "-db", str(db), "-T", str(root), "--gaf", str(root / "nope.gaf"), "--species"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "valid file path" in r.stderr
