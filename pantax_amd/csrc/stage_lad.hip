@@ -361,7 +361,8 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
 constexpr int ROW_ITEMS = 8;
 __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
                                                        const unsigned long long *__restrict__ mask, uint32_t *__restrict__ n_rows,
-                                                       uint64_t *__restrict__ k0, uint64_t *__restrict__ k1, uint64_t *__restrict__ k2) {
+                                                       uint64_t *__restrict__ k0, uint64_t *__restrict__ k1, uint64_t *__restrict__ k2,
+                                                       int pack_shift /* >= 0: two-word rows {species << shift | mask, a} in k0, k1 */) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     const uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ROW_ITEMS;
@@ -394,9 +395,15 @@ __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, c
         const uint64_t v = base + i;
         uint32_t lo = 0, hi = S;   // species of node v: last s with node_base[s] <= v
         while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; }
-        k0[j] = lo - 1;
-        k1[j] = m[i];
-        k2[j] = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
+        const uint64_t abits = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
+        if (pack_shift >= 0) {
+            k0[j] = (pack_shift < 64 ? ((uint64_t)(lo - 1) << pack_shift) : 0ull) | m[i];
+            k1[j] = abits;
+        } else {
+            k0[j] = lo - 1;
+            k1[j] = m[i];
+            k2[j] = abits;
+        }
         ++j;
     }
 }
@@ -404,21 +411,27 @@ __global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t bound, const uin
                                                        const uint64_t *__restrict__ k1, uint8_t *__restrict__ head) {
     const uint64_t n = *d_n;   // rows actually present; the flags past n are zero so the scan over `bound` is exact
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < bound; i += (uint64_t)gridDim.x * 256)
-        head[i] = (i < n && (i == 0 || k0[i] != k0[i - 1] || k1[i] != k1[i - 1])) ? 1 : 0;
+        head[i] = (i < n && (i == 0 || k0[i] != k0[i - 1] || (k1 && k1[i] != k1[i - 1]))) ? 1 : 0;
 }
 __global__ void __launch_bounds__(256) pat_emit_kernel(const uint32_t *__restrict__ d_n, uint32_t k_cap, const uint64_t *__restrict__ k0,
                                                        const uint64_t *__restrict__ k1, const uint8_t *__restrict__ head,
                                                        const uint32_t *__restrict__ pidx, uint64_t *__restrict__ pat_mask,
                                                        uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species,
-                                                       uint32_t *__restrict__ overflow) {
+                                                       uint32_t *__restrict__ overflow, int pack_shift) {
     const uint64_t n = *d_n;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         if (!head[i]) continue;
         uint32_t j = pidx[i];
         if (j >= k_cap) { *overflow = 1; continue; }   // more patterns than this build sizes for: reported as PANTAX_HIP_E_LIMIT
-        pat_mask[j] = k1[i];
+        if (pack_shift >= 0) {
+            const uint64_t w = k0[i];
+            pat_mask[j] = pack_shift < 64 ? (w & ((1ull << pack_shift) - 1ull)) : w;
+            pat_species[j] = pack_shift < 64 ? (uint32_t)(w >> pack_shift) : 0u;
+        } else {
+            pat_mask[j] = k1[i];
+            pat_species[j] = (uint32_t)k0[i];
+        }
         pat_start[j] = (uint32_t)i;
-        pat_species[j] = (uint32_t)k0[i];
     }
 }
 
@@ -474,39 +487,49 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     int gridV = grid_for(V, 256, ctx->n_cu * 8);
     DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
     for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); PTX_HIP(ctx, kb[w].alloc(V)); }
+    // above the sample-sort limit the rows go through the radix sort; species and mask then share one key word
+    // whenever their bits fit (16-byte records instead of 24)
+    const int sp_bits = S > 1 ? bits_for(S - 1) : 0;
+    const bool use_sample = V <= SS_MAX_N;
+    const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64) ? pmax_bound : -1;
     {
         KTimer t(ctx, "row_emit_kernel");   // d_n was zeroed with the step's result arena
         const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
         hipLaunchKernelGGL(row_emit_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
-                           (unsigned long long *)lb->d_mask.p, d_n, ka[0].p, ka[1].p, ka[2].p);
+                           (unsigned long long *)lb->d_mask.p, d_n, ka[0].p, ka[1].p, ka[2].p, pack_shift);
     }
     SortBufs A, B;
-    A.nw = B.nw = 3;
+    A.nw = B.nw = pack_shift >= 0 ? 2 : 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
     bool in_b = false;
-    if (V <= SS_MAX_N) {   // few rows: sample sort (5 launches) instead of 10+ radix passes of 3 launches each
+    if (use_sample) {   // few rows: sample sort (6 launches) instead of 10+ radix passes of 3 launches each
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_ws_elems(V)));
         PTX_TRY(sample_sort3(ctx, A, B, V, dbm->d_ss_ws.p, d_n));
     } else {
         std::vector<SortPass> passes;
-        add_passes(passes, 2, 0, 63);                      // a > 0: sign bit clear
-        add_passes(passes, 1, 0, pmax_bound);              // mask bits that can be in use
-        if (S > 1) add_passes(passes, 0, 0, bits_for(S - 1));
+        if (pack_shift >= 0) {
+            add_passes(passes, 1, 0, 63);                      // a > 0: sign bit clear
+            add_passes(passes, 0, 0, pmax_bound + sp_bits);    // mask bits that can be in use, then the species
+        } else {
+            add_passes(passes, 2, 0, 63);
+            add_passes(passes, 1, 0, pmax_bound);
+            if (S > 1) add_passes(passes, 0, 0, sp_bits);
+        }
         PTX_TRY(radix_sort(ctx, A, B, V, passes.data(), (int)passes.size(), table.p, scan_tmp.p, &in_b, d_n));
     }
     SortBufs Sd = in_b ? B : A;
-    lb->row_a = reinterpret_cast<const double *>(Sd.k[2]);   // sorted abundances, used in place
+    lb->row_a = reinterpret_cast<const double *>(Sd.k[pack_shift >= 0 ? 1 : 2]);   // sorted abundances, used in place
     // patterns = runs of equal (species, mask)
     DevBuf<uint8_t> &head = dbm->d_pat_head;
     DevBuf<uint32_t> &pidx = dbm->d_pat_idx;
     PTX_HIP(ctx, head.alloc(V)); PTX_HIP(ctx, pidx.alloc(V));
     const uint64_t k_cap = std::min<uint64_t>(V, (uint64_t)S * 8192 + 65536);
     lb->k_cap = (uint32_t)k_cap;
-    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, d_n, Sd.k[0], Sd.k[1], head.p);
+    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, d_n, Sd.k[0], pack_shift >= 0 ? (const uint64_t *)nullptr : Sd.k[1], head.p);
     PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, V, scan_tmp.p, d_K));
     PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
     hipLaunchKernelGGL(pat_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, d_n, (uint32_t)k_cap, Sd.k[0], Sd.k[1], head.p, pidx.p,
-                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf);
+                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf, pack_shift);
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
     hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
                        lb->d_pat_start.p, lb->d_sp_pat_off.p);
