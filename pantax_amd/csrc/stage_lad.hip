@@ -216,17 +216,19 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 // ---------------------------------------------------------------------------------------------
 // node abundance + per-species statistics
 // ---------------------------------------------------------------------------------------------
-constexpr int STAT_CHUNKS = 256;  // workgroups per species; partials are combined in fixed order (deterministic)
+constexpr int STAT_CHUNKS = 256;  // most workgroups per species; partials are combined in fixed order (deterministic)
+// chunks per species actually used: ~2048 workgroups in all (one species: 256 chunks; a hundred species: 20)
+static inline uint32_t stat_chunks(uint32_t S) { uint32_t c = 2048u / (S ? S : 1u); return c < 1u ? 1u : (c > (uint32_t)STAT_CHUNKS ? (uint32_t)STAT_CHUNKS : c); }
 struct NodePartial { double mx, zs; unsigned long long nv, zc; };
 
 __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                          const unsigned long long *__restrict__ bases, double min_depth,
-                                                         double *__restrict__ ab_out, NodePartial *__restrict__ part) {
+                                                         double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
-    const uint32_t s = blockIdx.x / STAT_CHUNKS, ch = blockIdx.x % STAT_CHUNKS;
+    const uint32_t s = blockIdx.x / nch, ch = blockIdx.x % nch;
     const uint32_t b = node_base[s], e = node_base[s + 1];
-    const uint32_t per = (e - b + STAT_CHUNKS - 1) / STAT_CHUNKS;
+    const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     double mx = -INFINITY, zs = 0.0;
@@ -249,10 +251,10 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
 // one wave per species: lane l combines chunks l, l+64, ... in order, then a fixed-shape wave reduction
 __global__ void __launch_bounds__(64) node_stats_final_kernel(uint32_t S, const NodePartial *__restrict__ part, double *__restrict__ amax_out,
                                                               uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
-                                                              uint32_t *__restrict__ nzcnt_out) {
+                                                              uint32_t *__restrict__ nzcnt_out, uint32_t nch) {
     const uint32_t s = blockIdx.x;
     double mx = -INFINITY, zs = 0.0; unsigned long long nv = 0, zc = 0;
-    for (int c = threadIdx.x; c < STAT_CHUNKS; c += 64) { NodePartial p = part[(size_t)s * STAT_CHUNKS + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
+    for (uint32_t c = threadIdx.x; c < nch; c += 64) { NodePartial p = part[(size_t)s * nch + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
     mx = wave_reduce(mx, [](double x, double y) { return fmax(x, y); });
     zs = wave_reduce(zs, [](double x, double y) { return x + y; });
     nv = wave_reduce(nv, [](unsigned long long x, unsigned long long y) { return x + y; });
@@ -268,10 +270,11 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     PTX_HIP(ctx, lb->d_nzsum.alloc(S)); PTX_HIP(ctx, lb->d_nzcnt.alloc(S));
     PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
     KTimer t(ctx, "node_stats_kernel");
-    hipLaunchKernelGGL(node_stats_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
-                       (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p);
+    const uint32_t nch = stat_chunks(S);
+    hipLaunchKernelGGL(node_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
+                       (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
     hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
-                       lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p);
+                       lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p, nch);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1357,18 +1360,18 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
                                                         const unsigned long long *__restrict__ mask, const double *__restrict__ x1,
                                                         const double *__restrict__ x2, double *part /*[S][STAT_CHUNKS][2]*/,
                                                         uint32_t *__restrict__ done /*[S], zero between launches*/,
-                                                        const uint32_t *__restrict__ nvalid, double *__restrict__ obj1, double *__restrict__ obj2) {
+                                                        const uint32_t *__restrict__ nvalid, double *__restrict__ obj1, double *__restrict__ obj2, uint32_t nch) {
     __shared__ double red[4];
     __shared__ double xs1[LAD_MAXP], xs2[LAD_MAXP];
     __shared__ int s_last;
-    const int s = blockIdx.x / STAT_CHUNKS;
+    const int s = blockIdx.x / nch;
     if (sp_p[s] <= 0) return;
     const bool two = x2 && need2 && need2[s];
-    const uint32_t ch = blockIdx.x % STAT_CHUNKS;
+    const uint32_t ch = blockIdx.x % nch;
     if (threadIdx.x < LAD_MAXP) { xs1[threadIdx.x] = x1[(size_t)s * LAD_MAXP + threadIdx.x]; xs2[threadIdx.x] = two ? x2[(size_t)s * LAD_MAXP + threadIdx.x] : 0.0; }
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
-    const uint32_t per = (e - b + STAT_CHUNKS - 1) / STAT_CHUNKS;
+    const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     double acc1 = 0.0, acc2 = 0.0;
@@ -1383,16 +1386,17 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
     acc1 = block_sum_f64<256>(acc1, red);
     acc2 = block_sum_f64<256>(acc2, red);
     if (threadIdx.x == 0) {
-        part[((size_t)s * STAT_CHUNKS + ch) * 2] = acc1;
-        part[((size_t)s * STAT_CHUNKS + ch) * 2 + 1] = acc2;
+        part[((size_t)s * nch + ch) * 2] = acc1;
+        part[((size_t)s * nch + ch) * 2 + 1] = acc2;
         // release: the partials are visible device-wide before the count; acquire: the last arriver sees all of them
-        s_last = __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)STAT_CHUNKS - 1;
+        s_last = __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nch - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    // the last workgroup adds the partials: thread c takes chunk c (STAT_CHUNKS == block size), fixed-shape block sum
-    static_assert(STAT_CHUNKS == 256, "one partial per thread");
-    double t1 = part[((size_t)s * STAT_CHUNKS + threadIdx.x) * 2], t2 = part[((size_t)s * STAT_CHUNKS + threadIdx.x) * 2 + 1];
+    // the last workgroup adds the partials: thread c takes chunk c (nch <= block size), fixed-shape block sum
+    static_assert(STAT_CHUNKS <= 256, "one partial per thread");
+    double t1 = 0.0, t2 = 0.0;
+    if (threadIdx.x < nch) { t1 = part[((size_t)s * nch + threadIdx.x) * 2]; t2 = part[((size_t)s * nch + threadIdx.x) * 2 + 1]; }
     t1 = block_sum_f64<256>(t1, red);
     t2 = block_sum_f64<256>(t2, red);
     if (threadIdx.x != 0) return;
@@ -1410,8 +1414,9 @@ static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t 
         PTX_HIP(ctx, lb->d_obj_done.alloc(S));
         PTX_HIP(ctx, hipMemsetAsync(lb->d_obj_done.p, 0, lb->d_obj_done.bytes(), ctx->stream));   // the kernel leaves it zero
     }
-    hipLaunchKernelGGL(objective_kernel, dim3(S * STAT_CHUNKS), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, db->d_node_base.p, lb->d_ab.p,
-                       (unsigned long long *)lb->d_mask.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2);
+    const uint32_t nch = stat_chunks(S);
+    hipLaunchKernelGGL(objective_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, db->d_node_base.p, lb->d_ab.p,
+                       (unsigned long long *)lb->d_mask.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2, nch);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -82,17 +82,19 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
         if (valid) me = bucket[i];
         const uint32_t g = me.w;
         bool dup = false;
-        // lanes d below me in the same bucket: equal (b,c) marks both of us
+        // my place inside my bucket tells which lower lanes share it (entries of a bucket are contiguous): no id shuffle
+        uint32_t b0 = 0, b1 = 0;
+        if (valid) { b0 = bucket_off[g]; b1 = bucket_off[g + 1]; }
+        const uint32_t below = valid ? (uint32_t)(i - b0) : 0u;         // entries of my bucket before me
         for (int d = 1; d < 64; ++d) {
-            const uint32_t og = __shfl(g, lane - d), oy = __shfl(me.y, lane - d), oz = __shfl(me.z, lane - d);
-            const bool same = valid && lane >= d && og == g;
-            if (!__any(same)) break;   // buckets are contiguous: no pair at distance d means none further apart
+            const bool same = valid && lane >= d && (uint32_t)d <= below;
+            if (!__any(same)) break;   // no pair at distance d means none further apart
+            const uint32_t oy = __shfl(me.y, lane - d), oz = __shfl(me.z, lane - d);
             const unsigned long long eq = __ballot(same && oy == me.y && oz == me.z);
-            if ((eq >> lane) & 1ull) dup = true;                       // my partner is d below
+            if ((eq >> lane) & 1ull) dup = true;                            // my partner is d below
             if (lane + d < 64 && ((eq >> (lane + d)) & 1ull)) dup = true;   // my partner is d above
         }
         if (valid && !dup) {
-            const uint32_t b0 = bucket_off[g], b1 = bucket_off[g + 1];
             const uint64_t wend = base + 64;
             for (uint64_t j = b0; j < b1 && j < base && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
             for (uint64_t j = (wend > b0 ? wend : b0); j < b1 && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
