@@ -30,6 +30,20 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     PTX_HIP(ctx, hipSetDevice(ctx->device));
     if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step: the db was uploaded without graphs (ranges only)");
     const uint32_t S = db->S;
+    // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every
+    // run, profile.rs:2936), so it is built while the main stream bins the reads and takes the species decision
+    bool forked = false;
+    if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
+    if (!db->trio_built) {
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream2;
+        const int rc = trio_index_build(ctx, db);
+        const hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream2);
+        ctx->stream = main_stream;
+        if (rc != 0) return rc;
+        PTX_HIP(ctx, e);
+        forked = true;
+    }
     // a2 + a3 counters
     PTX_HIP(ctx, db->d_counters.alloc(bin_counter_words(S)));
     PTX_TRY(bin_reads_launch(ctx, db, reads, db->d_counters.p));
@@ -41,9 +55,8 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     PTX_TRY(species_profile_launch(ctx, db, reads, db->d_counters.p, db->d_avg_len.p, cfg->filtered, db->d_active.p, db->d_sp_abs.p));
     PTX_HIP(ctx, db->h_sp_out.reserve(sizeof(double) * S + S));
     PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
-    // a7 (the reference rebuilds trio_nodes_info every run, profile.rs:2936), a8
-    if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
-    if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
+    // a8 needs both
+    if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,

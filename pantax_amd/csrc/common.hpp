@@ -92,6 +92,8 @@ struct TimedLaunch {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)
+    hipEvent_t ev_fork = nullptr;
     std::string err;
     bool timing = false;
     std::string timing_filter;   // non-empty: only launches of this name are timed (two events per step instead of ~200)

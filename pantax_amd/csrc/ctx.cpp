@@ -85,6 +85,11 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate failed");
+    }
     if (ctx->d_scalars.alloc(64) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipMalloc failed");
@@ -104,6 +109,8 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     ctx->pin_down.release();
     ctx->pin_up.release();
     ctx->pin_text.release();
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
