@@ -236,7 +236,7 @@ struct Db {
     LadBatch lad;
     DevBuf<uint32_t> d_hap_nnz;              // [H]
     DevBuf<double> d_hap_mean;               // [H]
-    DevBuf<double> d_hap_part, d_hap_mean_sd; // two-level reduction scratch of the per-hap trio statistics
+    DevBuf<double> d_hap_part;               // chunk partials of the three passes of the per-hap trio statistics
     DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
     PinBuf h_arena;                  // pinned mirror of d_arena
     DevBuf<double> d_avg_len, d_sp_abs;   // resident step: species lengths in, predicted_coverage out (d_active holds keep)

@@ -157,18 +157,39 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 constexpr int HAP_CHUNKS = 32;   // workgroups per haplotype; partials are combined in fixed order
 struct HapPartial { double a, b; unsigned long long c; };
 
-// pass = 0: (sum, -, count) of non-zero abundances; 1: (sum of squared deviations); 2: (sum, -, count) of |z|<3
-__global__ void __launch_bounds__(256) hap_trio_pass_kernel(int pass, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
-                                                            const uint32_t *__restrict__ tlen, const double *__restrict__ mean_sd,
-                                                            HapPartial *__restrict__ part) {
+// pass = 0: (sum, count) of non-zero abundances; 1: (sum of squared deviations); 2: (sum, count) of |z|<3.
+// Every pass keeps its own chunk partials; a workgroup derives the mean / sd it needs from the partials of the
+// earlier passes itself (32 values, fixed order: every workgroup gets the same bits), so no combine launch sits
+// between the passes.
+__device__ __forceinline__ void hap_combine(const HapPartial *__restrict__ part, uint32_t h, double &acc, unsigned long long &cnt) {
+    acc = 0.0; cnt = 0;
+    for (int c = 0; c < HAP_CHUNKS; ++c) { const HapPartial p = part[(size_t)h * HAP_CHUNKS + c]; acc += p.a; cnt += p.c; }
+}
+__global__ void __launch_bounds__(256) hap_trio_pass_kernel(int pass, uint32_t H, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
+                                                            const uint32_t *__restrict__ tlen, HapPartial *__restrict__ part /*[3][H][HAP_CHUNKS]*/) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
+    __shared__ double s_mean, s_sd;
     const uint32_t h = blockIdx.x / HAP_CHUNKS, ch = blockIdx.x % HAP_CHUNKS;
+    const size_t PS = (size_t)H * HAP_CHUNKS;
+    if (pass && threadIdx.x == 0) {
+        double a0; unsigned long long c0;
+        hap_combine(part, h, a0, c0);
+        s_mean = c0 ? a0 / (double)c0 : 0.0;                                    // profile.rs:1037
+        s_sd = 0.0;
+        if (pass == 2) {
+            double a1; unsigned long long c1;
+            hap_combine(part + PS, h, a1, c1);
+            const double n = (double)(uint32_t)c0;
+            s_sd = n > 0 ? sqrt(a1 / n) : 0.0;                                  // :1038-1041
+        }
+    }
+    __syncthreads();
     const uint64_t b = hto[h], e = hto[h + 1];
     const uint64_t per = (e - b + HAP_CHUNKS - 1) / HAP_CHUNKS;
     uint64_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
-    const double mean = pass ? mean_sd[2 * h] : 0.0, sd = pass == 2 ? mean_sd[2 * h + 1] : 0.0;
+    const double mean = pass ? s_mean : 0.0, sd = pass == 2 ? s_sd : 0.0;
     double acc = 0.0; unsigned long long cnt = 0;
     if (!(pass == 2 && sd == 0.0))
         for (uint64_t u = lo + threadIdx.x; u < hi; u += 256) {
@@ -180,18 +201,19 @@ __global__ void __launch_bounds__(256) hap_trio_pass_kernel(int pass, const uint
         }
     acc = block_sum_f64<256>(acc, red);
     cnt = block_sum_u64<256>(cnt, redu);
-    if (threadIdx.x == 0) part[blockIdx.x] = {acc, 0.0, cnt};
+    if (threadIdx.x == 0) part[(size_t)pass * PS + blockIdx.x] = {acc, 0.0, cnt};
 }
-// combines the chunk partials of one pass: pass 0 -> mean (+count), pass 1 -> sd, pass 2 -> filtered mean
-__global__ void __launch_bounds__(64) hap_trio_combine_kernel(int pass, uint32_t H, const HapPartial *__restrict__ part, double *__restrict__ mean_sd,
-                                                              uint32_t *__restrict__ nnz_out, double *__restrict__ mean_out) {
+// per haplotype: the number of non-zero unique-trio abundances (pass 0) and the filtered mean (pass 2)
+__global__ void __launch_bounds__(64) hap_trio_final_kernel(uint32_t H, const HapPartial *__restrict__ part, uint32_t *__restrict__ nnz_out,
+                                                            double *__restrict__ mean_out) {
     uint32_t h = blockIdx.x * 64 + threadIdx.x;
     if (h >= H) return;
-    double acc = 0.0; unsigned long long cnt = 0;
-    for (int c = 0; c < HAP_CHUNKS; ++c) { acc += part[(size_t)h * HAP_CHUNKS + c].a; cnt += part[(size_t)h * HAP_CHUNKS + c].c; }
-    if (pass == 0) { nnz_out[h] = (uint32_t)cnt; mean_sd[2 * h] = cnt ? acc / (double)cnt : 0.0; mean_out[h] = 0.0; }   // :1037
-    else if (pass == 1) { double n = (double)nnz_out[h]; mean_sd[2 * h + 1] = n > 0 ? sqrt(acc / n) : 0.0; }              // :1038-1041
-    else mean_out[h] = cnt ? acc / (double)cnt : 0.0;   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+    const size_t PS = (size_t)H * HAP_CHUNKS;
+    double a0, a2; unsigned long long c0, c2;
+    hap_combine(part, h, a0, c0);
+    hap_combine(part + 2 * PS, h, a2, c2);
+    nnz_out[h] = (uint32_t)c0;
+    mean_out[h] = c2 ? a2 / (double)c2 : 0.0;   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
 }
 
 int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBuf<double> &d_mean) {
@@ -200,15 +222,13 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     if (db->H == 0) return 0;
     Db *dbm = const_cast<Db *>(db);
     const uint32_t H = (uint32_t)db->H;
-    PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)H * HAP_CHUNKS * 3));
-    PTX_HIP(ctx, dbm->d_hap_mean_sd.alloc((size_t)H * 2));
+    PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)3 * H * HAP_CHUNKS * 3));
     for (int pass = 0; pass < 3; ++pass) {
         KTimer t(ctx, "hap_trio_pass_kernel");
-        hipLaunchKernelGGL(hap_trio_pass_kernel, dim3(H * HAP_CHUNKS), dim3(256), 0, ctx->stream, pass, db->d_hap_trio_off.p, db->d_trio_bases.p,
-                           db->d_trio_len.p, dbm->d_hap_mean_sd.p, (HapPartial *)dbm->d_hap_part.p);
-        hipLaunchKernelGGL(hap_trio_combine_kernel, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, pass, H, (const HapPartial *)dbm->d_hap_part.p,
-                           dbm->d_hap_mean_sd.p, d_nnz.p, d_mean.p);
+        hipLaunchKernelGGL(hap_trio_pass_kernel, dim3(H * HAP_CHUNKS), dim3(256), 0, ctx->stream, pass, H, db->d_hap_trio_off.p, db->d_trio_bases.p,
+                           db->d_trio_len.p, (HapPartial *)dbm->d_hap_part.p);
     }
+    hipLaunchKernelGGL(hap_trio_final_kernel, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, H, (const HapPartial *)dbm->d_hap_part.p, d_nnz.p, d_mean.p);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
