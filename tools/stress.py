@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end stress: many small random configurations (species, haplotypes, reads, genome length,
+long reads, adversarial fraction, drop flags), the single-call step and the stage calls against the oracle:
+integers bit-exact, LP objectives and metrics to 1e-7.  usage: tools/stress.py [n_configs] [seed0]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import oracle as orc
+from pantax_amd import synth
+from pantax_amd.engine import Engine, metrics_to_dicts
+from tests.helpers import select_reads
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+eng = Engine(0)
+bad = 0
+for ci in range(n_cfg):
+    rng = np.random.default_rng(seed0 + ci)
+    S = int(rng.integers(1, 7)); H = int(rng.integers(1, 13)); R = int(rng.integers(200, 60000)); L = int(rng.integers(3000, 200000))
+    lr = bool(rng.random() < 0.25); adv = float(rng.choice([0.0, 0.001, 0.02])); pf = float(rng.choice([0.2, 0.5, 0.9]))
+    tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g" % (seed0 + ci, S, H, R, L, lr, adv, pf)
+    try:
+        sset = synth.make_set(seed0 + ci, S, H, R if not lr else max(50, R // 40), L, long_reads=lr, adversarial_frac=adv, present_frac=pf,
+                              single_strain_every=int(rng.choice([0, 2, 3])))
+        rd = sset.reads
+        flags = (rng.random(rd.n_reads) < float(rng.choice([0.0, 0.05]))).astype(np.uint8)
+        eng.upload_db(sset.species)
+        eng.upload_packed(rd, flags=flags if flags.any() else None)
+        sp, rc, bs, lm, uq = eng.rcls_profile()
+        ref_sp = orc.bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
+        assert np.array_equal(sp, ref_sp), "binning"
+        eng.db_reset(); eng.trio_nodes_info(fetch=False)
+        bases, cov, tb, nab = eng.get_node_abundances()
+        keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
+        okeep, oabs, _ = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+        assert np.array_equal(keep, okeep) and np.allclose(absolute, oabs, rtol=1e-12, atol=0), "species profile"
+        met, info = eng.strain_profiling(absolute, species_active=keep)
+        gm_all = metrics_to_dicts(met, eng.H)
+        nb = np.cumsum([0] + [g.n_nodes for g in sset.species]); hb = np.cumsum([0] + [g.n_paths for g in sset.species])
+        hto = eng.trio_nodes_info()[3].astype(np.int64)
+        for s, g in enumerate(sset.species):
+            G = orc.Graph(g.node_len, g.path_off, g.path_nodes); T = orc.TrioTable(G)
+            sel = np.nonzero((sp == s) & (flags == 0))[0]
+            so, nid, ps, pe = select_reads(rd, sel)
+            b, c, t, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+            assert np.array_equal(bases[nb[s]:nb[s + 1]], b), "bases sp %d" % s
+            assert np.array_equal(cov[nb[s]:nb[s + 1]], c), "cov sp %d" % s
+            assert np.array_equal(tb[hto[hb[s]]:hto[hb[s + 1]]], t), "trio bases sp %d" % s
+            if not keep[s]:
+                continue
+            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+            orc.abundance_constraint(absolute[s], omet)
+            assert info[s].n_candidates == nc and info[s].status1 == 0 and info[s].status2 == 0, "solver status sp %d" % s
+            if nc:
+                assert abs(info[s].obj1 - o1) <= 1e-9 * max(1.0, abs(o1)), "obj1 sp %d: %r vs %r" % (s, info[s].obj1, o1)
+            for gm, em in zip(gm_all[hb[s]:hb[s + 1]], orc.metrics_to_dicts(omet)):
+                for key, ev in em.items():
+                    gv = gm[key]
+                    if ev is None or gv is None or isinstance(ev, bool):
+                        assert gv == ev, (s, key, gv, ev)
+                    else:
+                        assert abs(gv - ev) <= 1e-7 * max(1.0, abs(ev)) + 1e-9, (s, key, gv, ev)
+        # the single-call step gives the same decisions and metrics as the stage calls
+        k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len())
+        assert np.array_equal(k2, keep) and np.array_equal(a2, absolute), "step species"
+        g2 = metrics_to_dicts(met2, eng.H)
+        for x, y in zip(g2, gm_all):
+            assert x == y or all((x[k] == y[k]) or (x[k] is not None and y[k] is not None and abs(x[k] - y[k]) <= 1e-12 * max(1.0, abs(y[k]))) for k in y), "step metrics"
+        print("ok  ", tag)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", tag, "->", e)
+print("%d configurations, %d failures" % (n_cfg, bad))
+sys.exit(1 if bad else 0)
