@@ -21,8 +21,6 @@ int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const 
 // a9 / a13 decisions on the device (the host redoes only the reporting arithmetic at the end of the step)
 struct FilterCfg { double fr, fc, sr; int shift; };
 int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc);
-int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
-                         uint8_t *d_fixed2, uint8_t *d_need2);
 
 // the strain step in two halves (api_strain.cpp): everything enqueued / the one wait + host reporting
 int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active);

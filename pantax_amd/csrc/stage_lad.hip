@@ -643,11 +643,6 @@ __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F,
     }
     F.need2[s] = need;
 }
-__global__ void __launch_bounds__(64) second_filter_kernel(uint32_t S, SecondFilterArgs F) {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s < S) second_filter_species(F, s);
-}
-
 int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc) {
     const uint32_t S = db->S;
     PTX_HIP(ctx, lb->d_hap_bit.alloc(db->H)); PTX_HIP(ctx, lb->d_p.alloc(S));
@@ -664,15 +659,6 @@ static SecondFilterArgs second_filter_args(const Db *db, LadBatch *lb, const Fil
     F.fixed2 = d_fixed2; F.need2 = d_need2;
     return F;
 }
-int second_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
-                         uint8_t *d_fixed2, uint8_t *d_need2) {
-    const uint32_t S = db->S;
-    hipLaunchKernelGGL(second_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S,
-                       second_filter_args(db, lb, fc, d_x1, d_status1, d_fixed2, d_need2));
-    PTX_HIP(ctx, hipGetLastError());
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------------
 // a12: the batched exact LAD solver
 // ---------------------------------------------------------------------------------------------
