@@ -63,12 +63,16 @@ def cpu_baseline(sset, sample_reads, cfg):
     sp = orc.bin_reads(step_off, node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
     counts = orc.species_counts(sp, rd.qlen[:n], rd.mapq[:n], len(sset.species))
     keep, absolute, _ = orc.species_profile(sp, rd.qlen[:n], counts, sset.avg_len())
-    t_lp = 0.0
+    t_bin = time.perf_counter() - t0
+    t_lp = t_trio = t_cov = 0.0
     for si, g in enumerate(sset.species):
         if not keep[si]:
             continue
+        t1 = time.perf_counter()
         G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
         T = orc.TrioTable(G)
+        t_trio += time.perf_counter() - t1
+        t1 = time.perf_counter()
         sel = np.nonzero(sp == si)[0]
         so = np.zeros(len(sel) + 1, dtype=np.uint64)
         ns = (step_off[1:] - step_off[:-1]).astype(np.int64)[sel]
@@ -76,6 +80,7 @@ def cpu_baseline(sset, sample_reads, cfg):
         starts = step_off[:-1].astype(np.int64)[sel]
         idx = np.repeat(starts, ns) + (np.arange(int(ns.sum())) - np.repeat(so[:-1].astype(np.int64), ns))
         b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, node_id[idx], rd.pstart[:n][sel], rd.pend[:n][sel])
+        t_cov += time.perf_counter() - t1
         t1 = time.perf_counter()
         rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
         t_lp += time.perf_counter() - t1
@@ -84,7 +89,9 @@ def cpu_baseline(sset, sample_reads, cfg):
     return dict(value=n / dt / 1e6, unit="Mreads/s", cores=1, kind="port",
                 sample="first %d reads of the same workload (all %d species), oracle bin+trio+coverage+filters+2 LP solves; "
                        "%.2f s total, %.2f s of it in the exact LAD solves" % (n, len(sset.species), dt, t_lp),
-                seconds=dt)
+                seconds=dt,
+                phases_s={"binning+species_profile": t_bin, "trio_index": t_trio, "node_coverage (incl. read selection)": t_cov,
+                          "filters+LP solves": t_lp})
 
 
 def pmc_traffic(kernel, args):
