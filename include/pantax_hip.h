@@ -40,6 +40,8 @@ typedef struct pantax_hip_ctx pantax_hip_ctx;     /* owns the HIP stream, scratc
 typedef struct pantax_hip_db pantax_hip_db;       /* device-resident graphs of the species this rank owns */
 typedef struct pantax_hip_reads pantax_hip_reads; /* device-resident packed alignment records */
 
+/* Threading: every entry point may be called from any host thread; calls that share a ctx are serialised inside
+ * (the reference calls its solver from rayon workers, profile.rs:3297-3304).  Error text is per calling thread. */
 int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices); /* n_devices == 1 */
 void pantax_hip_destroy(pantax_hip_ctx *ctx);
 const char *pantax_hip_last_error(const pantax_hip_ctx *ctx); /* ctx may be NULL: init errors */

@@ -13,7 +13,7 @@ extern "C" {
 int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax_hip_db **out) {
     if (!ctx || !g || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     uint32_t S = g->n_species;
     if (S == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: n_species == 0");
     std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
@@ -166,6 +166,8 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
 }
 
 void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
+    std::unique_lock<std::recursive_mutex> lk;
+    if (ctx) lk = std::unique_lock<std::recursive_mutex>(ctx->mu);
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     delete db;
 }
@@ -173,7 +175,7 @@ void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
 int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *r, pantax_hip_reads **out) {
     if (!ctx || !r || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     if (r->n_steps >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: %llu steps exceed the 32-bit step offset; split the batch", (unsigned long long)r->n_steps);
     if (r->n_reads && (r->step_off[0] != 0 || r->step_off[r->n_reads] != r->n_steps))
         return fail(ctx, PANTAX_HIP_E_INVALID, "reads_upload: step_off must start at 0 and end at n_steps");
@@ -198,6 +200,8 @@ int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *
 }
 
 void pantax_hip_reads_free(pantax_hip_ctx *ctx, pantax_hip_reads *reads) {
+    std::unique_lock<std::recursive_mutex> lk;
+    if (ctx) lk = std::unique_lock<std::recursive_mutex>(ctx->mu);
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     delete reads;
 }
@@ -205,7 +209,7 @@ void pantax_hip_reads_free(pantax_hip_ctx *ctx, pantax_hip_reads *reads) {
 int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hip_reads *reads, int32_t *species_idx_out,
                          int64_t *read_count_out, int64_t *base_sum_out, int64_t *less_multi_out, int64_t *uniq_count_out) {
     if (!ctx || !db || !reads) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     uint32_t S = db->S;
     DevBuf<unsigned long long> &d_cnt = const_cast<pantax_hip_db *>(db)->d_counters;
     PTX_HIP(ctx, d_cnt.alloc(bin_counter_words(S)));
@@ -232,7 +236,7 @@ int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_
                              int64_t *bases_per_node_out, uint64_t *node_base_cov_out, int64_t *trio_bases_out,
                              uint64_t *n_abort_out) {
     if (!ctx || !db || !reads) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     if (!reads->binned) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: call pantax_hip_bin_reads on these reads first");
     if (trio_bases_out && !db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: trio_bases requested but pantax_hip_trio_index has not run");
     const uint8_t *d_active = nullptr;

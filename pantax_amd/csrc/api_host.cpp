@@ -15,7 +15,7 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
     if (!ctx || !db || !reads || !read_count || !base_sum || !less_multi || !uniq_count || !avg_len || !keep_out || !absolute_out || !abundance_out)
         return PANTAX_HIP_E_INVALID;
     if (!reads->binned) return fail(ctx, PANTAX_HIP_E_STATE, "species_profile: call pantax_hip_bin_reads first");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     // profile.rs:312-319: distinct read_len among the first 1000 rows of the frame without "U" reads
     int64_t first_len = -1;
     bool equal = true;
@@ -62,6 +62,7 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
 
 int pantax_hip_db_reset(pantax_hip_ctx *ctx, pantax_hip_db *db) {
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     db->trio_built = false;
     db->cov_done = false;
     db->U = 0;

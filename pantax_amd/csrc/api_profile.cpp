@@ -49,7 +49,7 @@ std::string cell(bool has, double v, bool rnd = false) { return has ? fmt_f64(rn
 
 extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg) {
     if (!ctx || !cfg) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     // ---- check_args_valid (profile.rs:71-199)
     if (!cfg->species && !cfg->strain) return fail(ctx, PANTAX_HIP_E_INVALID, "Please choose profiling level with --species or/and --strain.");
     if (cfg->world_size > 1)

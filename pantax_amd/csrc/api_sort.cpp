@@ -9,7 +9,7 @@ using namespace ptx;
 extern "C" int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo) {
     if (!ctx || (n && (!k0 || !k1 || !k2))) return PANTAX_HIP_E_INVALID;
     if (n >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "sort_rows: %llu rows exceed 32-bit positions", (unsigned long long)n);
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     if (n == 0) return 0;
     if (algo == 2 && n > SS_MAX_N) return fail(ctx, PANTAX_HIP_E_LIMIT, "sort_rows: the sample sort takes at most %llu rows", (unsigned long long)SS_MAX_N);
     const bool sample = algo == 2 || (algo == 0 && n <= SS_MAX_N);

@@ -27,7 +27,7 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
                                        pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, uint8_t *pass_out,
                                        double *species_sum_all_out, double *species_sum_pass_out) {
     if (!ctx || !db || !reads || !avg_len || !cfg || !keep_out || !absolute_out || !met || !pass_out) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step: the db was uploaded without graphs (ranges only)");
     const uint32_t S = db->S;
     // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every

@@ -238,7 +238,7 @@ extern "C" {
 int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active,
                               const double *species_coverage, pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out) {
     if (!ctx || !db || !cfg || !met) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     const uint8_t *d_active = nullptr;
     if (species_active) { PTX_TRY(upload_small(ctx, db->d_active, species_active, db->S)); d_active = db->d_active.p; }
     PTX_TRY(strain_enqueue(ctx, db, cfg, d_active));
@@ -252,7 +252,7 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
     if (!ctx || !node_len || !node_abundance || !path_off || !path_nodes || !cand_path_idx || !x_out) return PANTAX_HIP_E_INVALID;
     if (n_cand == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: no candidate paths (the reference skips the solver, profile.rs:2968)");
     if (n_cand > (uint32_t)LAD_MAXP) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: %u candidate paths; this build handles <= %d", n_cand, LAD_MAXP);
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     // a one-species resident DB around the caller's graph
     int64_t rs = 1, re = n_nodes;
     uint64_t node_off[2] = {0, n_nodes}, hap_off[2] = {0, n_paths};

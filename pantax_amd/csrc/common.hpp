@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,12 @@ int fail(Ctx *ctx, int code, const char *fmt, ...);
             return ptx::fail((ctx), PANTAX_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                              __FILE__, __LINE__);                                                     \
     } while (0)
+// Entry of every C-ABI function that takes a ctx: calls on one ctx from several host threads (the reference calls its
+// solver from rayon workers, profile.rs:3297-3304) are serialised; the lock is recursive because entry points call
+// each other.  Also selects the ctx's device for the calling thread.
+#define PTX_ENTER(ctx)                                            \
+    std::lock_guard<std::recursive_mutex> ptx_lock__((ctx)->mu); \
+    PTX_HIP(ctx, hipSetDevice((ctx)->device))
 #define PTX_TRY(expr)               \
     do {                            \
         int rc__ = (expr);          \
@@ -90,6 +97,7 @@ struct TimedLaunch {
 };
 
 struct Ctx {
+    std::recursive_mutex mu;         // one call at a time per ctx (PTX_ENTER)
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)

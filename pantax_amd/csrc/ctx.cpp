@@ -5,7 +5,11 @@
 
 namespace ptx {
 
+// error text of the calling thread's last failed call: messages are per thread, so concurrent callers of one ctx
+// never read each other's
 static thread_local std::string g_init_err;
+static thread_local std::string g_thread_err;
+static thread_local const Ctx *g_thread_err_ctx = nullptr;
 
 int fail(Ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -13,7 +17,7 @@ int fail(Ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) { ctx->err = buf; g_thread_err = buf; g_thread_err_ctx = ctx; }
     else g_init_err = buf;
     return code;
 }
@@ -60,7 +64,11 @@ extern "C" {
 
 const char *pantax_hip_version(void) { return "pantax-hip 0.1.0 (gfx950)"; }
 
-const char *pantax_hip_last_error(const pantax_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+const char *pantax_hip_last_error(const pantax_hip_ctx *ctx) {
+    if (!ctx) return g_init_err.c_str();
+    if (g_thread_err_ctx == ctx) return g_thread_err.c_str();   // this thread's own last failure on this ctx
+    return ctx->err.c_str();
+}
 
 int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) {
     if (!out) return PANTAX_HIP_E_INVALID;
@@ -117,12 +125,14 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
 
 int pantax_hip_sync(pantax_hip_ctx *ctx) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
 int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     PTX_TRY(collect_timings(ctx));
     ctx->timing = on != 0;
     return 0;
@@ -130,12 +140,14 @@ int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on) {
 
 int pantax_hip_timing_filter(pantax_hip_ctx *ctx, const char *name) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     ctx->timing_filter = name ? name : "";
     return 0;
 }
 
 int pantax_hip_timing_reset(pantax_hip_ctx *ctx) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     PTX_TRY(collect_timings(ctx));
     ctx->acc.clear();
     return 0;
@@ -143,6 +155,7 @@ int pantax_hip_timing_reset(pantax_hip_ctx *ctx) {
 
 int pantax_hip_timing_get(pantax_hip_ctx *ctx, int cap, const char **names_out, uint64_t *launches_out, double *total_ms_out) {
     if (!ctx) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     PTX_TRY(collect_timings(ctx));
     int i = 0;
     for (auto &kv : ctx->acc) {

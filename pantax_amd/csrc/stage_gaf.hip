@@ -305,7 +305,7 @@ using namespace ptx;
 extern "C" int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path, pantax_hip_gaf **out) {
     if (!ctx || !path || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     pantax_hip_gaf *g = new pantax_hip_gaf();
     std::string e = g->mf.open(path);
     if (!e.empty()) { delete g; return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str()); }
@@ -319,7 +319,7 @@ extern "C" int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, 
     if (!ctx || !path || !reads_out) return PANTAX_HIP_E_INVALID;
     *reads_out = nullptr;
     if (gaf_out) *gaf_out = nullptr;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     std::unique_ptr<pantax_hip_gaf> g(new pantax_hip_gaf());
     std::unique_ptr<pantax_hip_reads> rd(new pantax_hip_reads());
     std::string e = g->mf.open(path);
@@ -332,7 +332,7 @@ extern "C" int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, 
 
 extern "C" int pantax_hip_reads_set_flags(pantax_hip_ctx *ctx, pantax_hip_reads *reads, const uint8_t *flags) {
     if (!ctx || !reads) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     reads->has_flags = flags != nullptr;
     if (flags) { PTX_TRY(upload(ctx, reads->d_flags, flags, reads->R)); PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
     reads->binned = false;   // the per-slot species carry the drop flags: bin again

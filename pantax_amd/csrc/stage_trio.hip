@@ -260,7 +260,7 @@ extern "C" {
 
 int pantax_hip_trio_index(pantax_hip_ctx *ctx, pantax_hip_db *db, uint64_t *n_unique_total_out) {
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
     if (n_unique_total_out) *n_unique_total_out = db->U;
     return 0;
@@ -270,7 +270,7 @@ int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *db, uint32_t *
                         uint64_t *hap_trio_off_out) {
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "trio_get: call pantax_hip_trio_index first");
-    PTX_HIP(ctx, hipSetDevice(ctx->device));
+    PTX_ENTER(ctx);
     std::vector<uint32_t> len32;
     if (abc_out && db->U) PTX_TRY(download(ctx, abc_out, db->d_trio_abc.p, 3 * db->U));
     if (hap_out && db->U) PTX_TRY(download(ctx, hap_out, db->d_trio_hap.p, db->U));

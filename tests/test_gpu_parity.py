@@ -274,3 +274,39 @@ def test_device_sorts_against_host_sort(eng, algo):
         exp = _host_sorted(k0, k1, k2)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (algo, len(k0))
+
+
+@pytest.mark.gpu
+def test_concurrent_solver_calls_on_one_ctx(eng, golden_dir):
+    """The reference calls its solver from rayon workers (profile.rs:3297-3304): pantax_hip_pao_solve from several host
+    threads on ONE ctx is legal -- calls are serialised inside -- and every thread gets the answer of its own call."""
+    import os
+    import threading
+    z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
+    cases = []
+    for i in range(int(z["n_cases"])):
+        mask, a, ub = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i]
+        p = len(ub)
+        po, pn = _paths_from_masks(mask, p)
+        cases.append((a, po, pn, p, (ub == 0).astype(np.uint8), float(z["obj_%d" % i])))
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                for ci, (a, po, pn, p, fz, objh) in enumerate(cases):
+                    if (ci + tid) % 2:
+                        continue
+                    x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), po, pn, np.arange(p), fixed_zero=fz)
+                    results[(tid, rep, ci)] = (obj, objh, st)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) > 40
+    for (tid, rep, ci), (obj, objh, st) in results.items():
+        assert st == 0 and obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (tid, rep, ci)
