@@ -70,14 +70,14 @@ __device__ __forceinline__ void mark_range(uint32_t *s_bm, uint32_t *__restrict_
 
 // read_nodes_len of position j (never the last position) recomputed from memory: the length aligned
 // at the node's FIRST occurrence in the read (profile.rs:879-882)
-__device__ __forceinline__ long long rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, uint32_t first_id,
-                                                    uint32_t nb, const uint4 *__restrict__ node_rec, long long len0, long long ps) {
+__device__ __forceinline__ uint32_t rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, uint32_t first_id,
+                                                   uint32_t nb, const uint4 *__restrict__ node_rec, uint32_t len0, uint32_t ps) {
     uint32_t idj = node_id[b + j];
     int jf = -1;
     for (uint32_t q = 0; q < j; ++q) if (node_id[b + q] == idj) { jf = (int)q; break; }
     uint32_t src = jf < 0 ? j : (uint32_t)jf;
     if (src == 0) return len0 - ps;
-    return (long long)node_rec[nb + (idj - first_id)].z;
+    return node_rec[nb + (idj - first_id)].z;
 }
 
 constexpr int COV_CHUNK = 1024;   // steps per workgroup
@@ -86,9 +86,9 @@ constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the no
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t *s_win, uint32_t wlo, uint32_t win_n, uint32_t v,
-                                          long long aln) {
+                                          uint32_t aln) {
     const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
-    if (off < win_n && aln < (1ll << 18)) atomicAdd(&s_win[off], (uint32_t)aln);   // <= 8192 steps x 2^18 < 2^32
+    if (off < win_n && aln < (1u << 18)) atomicAdd(&s_win[off], aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
 }
 
@@ -154,7 +154,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         if (ok) { rr = read_rec[slot]; sp = slot_species[slot]; }
         ok = ok && sp >= 0 && !(active && !active[sp]);             // "U" / dropped rows / unselected species
         const uint32_t b = rr.x, k = rr.y;
-        const long long ps = rr.z, pe = rr.w;
+        // positions, node lengths and aligned lengths are 32-bit quantities (the packed layout carries u32 columns and a
+        // walk cannot align 4 Gbp): only `target` needs a sign.
+        const uint32_t ps = rr.z, pe = rr.w;
         const uint32_t i = ok ? (uint32_t)(t - b) : 0u;
         uint32_t l = 0, v = 0, first_id = 0, nb = 0;
         if (ok) {
@@ -177,20 +179,20 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             tn = trio_node[nb + ta];                              // {first row, #rows}: usually 0-3 rows
         }
         uint64_t bo = 0;
-        long long nl = 0;
+        uint32_t nl = 0;
         if (ok) {
             const uint4 nr = node_rec[v];
             bo = ((uint64_t)nr.y << 32) | nr.x;
-            nl = (long long)nr.z;
+            nl = nr.z;
         }
         // first node length: from the lane that holds step b, else from memory
-        const long long nl_src = __shfl(nl, lane - dist);
-        long long len0 = nl;
-        if (ok && i > 0) len0 = !cross ? nl_src : (long long)node_rec[nb + (node_id[b] - first_id)].z;
-        const long long target = pe - ps;                         // profile.rs:800
+        const uint32_t nl_src = __shfl(nl, lane - dist);
+        uint32_t len0 = nl;
+        if (ok && i > 0) len0 = !cross ? nl_src : node_rec[nb + (node_id[b] - first_id)].z;
+        const long long target = (long long)pe - (long long)ps;   // profile.rs:800
         if (ok && k == 1) {                                       // :811
             if (target >= 0) {                                    // :821-827
-                if (target) add_bases(bases, s_win, wlo, win_n, v, target);
+                if (target) add_bases(bases, s_win, wlo, win_n, v, (uint32_t)target);
                 if (ps < pe && pe <= nl) mark_range(s_bm, bitmap, bw0, bwn, bo + ps, bo + pe);   // :832
             }
             ok = false;
@@ -200,11 +202,12 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             ok = false;
         }
         // ---- `seen` before this step = sum of the aligned lengths of steps 0..i-1: segmented wave scan
-        const long long contrib = ok ? (i == 0 ? nl - ps : nl) : 0;
-        long long incl = contrib;
+        const uint32_t contrib = ok ? (i == 0 ? nl - ps : nl) : 0u;
+        uint32_t incl = contrib;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            long long up = __shfl_up(incl, d);
+            if (d == 16 && !__any(dist >= 16)) break;             // short walks: four steps cover every read of the wave
+            uint32_t up = __shfl_up(incl, d);
             if (dist >= d) incl += up;
         }
         // ---- first occurrence of this node in the read (:879): compare with the earlier lanes
@@ -219,26 +222,26 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             }
         }
         if (ok && dupc != 255u) dmax = (int)dupc;
-        long long rl = 0;
+        uint32_t rl = 0;
         if (ok) {
             int jf = dmax ? (int)i - dmax : -1;
             if (cross) {                                          // finish from memory
                 const uint32_t nprev = i - (uint32_t)lane;
                 for (uint32_t j = 0; j < nprev; ++j) if (node_id[b + j] == id) { jf = (int)j; break; }
             }
-            long long aln, sidx;
+            uint32_t aln, sidx;
             if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
             else if (i == k - 1) {                                // :857-859
-                long long seen = incl - contrib;
+                uint32_t seen = incl - contrib;
                 if (cross) {
                     const uint32_t nprev = i - (uint32_t)lane;
                     seen += len0 - ps;
-                    for (uint32_t j = 1; j < nprev; ++j) seen += (long long)node_rec[nb + (node_id[b + j] - first_id)].z;
+                    for (uint32_t j = 1; j < nprev; ++j) seen += node_rec[nb + (node_id[b + j] - first_id)].z;
                 }
-                const long long tt = target < seen ? seen : target;
-                aln = tt - seen; sidx = 0;
+                aln = target > (long long)seen ? (uint32_t)(target - (long long)seen) : 0u;   // max(target - seen, 0)
+                sidx = 0;
             } else { aln = nl; sidx = 0; }                        // :860-862
-            long long hi = sidx + aln;
+            uint32_t hi = sidx + aln;
             if (hi > nl) hi = nl;                                 // :871
             mark_range(s_bm, bitmap, bw0, bwn, bo + sidx, bo + hi);
             if (jf < 0) {
@@ -247,7 +250,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             } else rl = (jf == 0) ? (len0 - ps) : nl;
         }
         if (WITH_TRIO) {                                          // :890-907
-            long long rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
+            uint32_t rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
             if (ok && i >= 2) {
                 if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, first_id, nb, node_rec, len0, ps);
                 if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, first_id, nb, node_rec, len0, ps);
@@ -257,8 +260,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     if (e.x == l1 && e.y == tc_) { row = (int)e.z; break; }
                 }
                 if (row >= 0) {
-                    const long long sum = rl2 + rl1 + rl;
-                    if (sum) atomicAdd(&trio_bases[row], (unsigned long long)sum);
+                    const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
+                    if (sum) atomicAdd(&trio_bases[row], sum);
                 }
             }
         }
