@@ -251,8 +251,7 @@ struct Db {
     DevBuf<uint8_t> d_sp_out;        // backing store of d_sp_abs + d_active in a resident step (one download)
     PinBuf h_sp_out;                 // [S f64 absolute][S u8 keep]
     // LP-row staging (lad_prepare)
-    DevBuf<uint8_t> d_pat_head;
-    DevBuf<uint32_t> d_pat_idx, d_scan_tmp, d_sort_table, d_ss_ws;
+    DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws;
     DevBuf<uint64_t> d_ka[3], d_kb[3];
 };
 

@@ -16,6 +16,7 @@
 #include "lad.hpp"
 #include "primitives.hpp"
 #include "wave.hpp"
+#include "scan_chained.hpp"
 
 namespace ptx {
 
@@ -430,22 +431,25 @@ __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, c
         ++j;
     }
 }
-__global__ void __launch_bounds__(256) pat_flag_kernel(uint64_t bound, const uint32_t *__restrict__ d_n, const uint64_t *__restrict__ k0,
-                                                       const uint64_t *__restrict__ k1, uint8_t *__restrict__ head) {
-    const uint64_t n = *d_n;   // rows actually present; the flags past n are zero so the scan over `bound` is exact
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < bound; i += (uint64_t)gridDim.x * 256)
-        head[i] = (i < n && (i == 0 || k0[i] != k0[i - 1] || (k1 && k1[i] != k1[i - 1]))) ? 1 : 0;
-}
-__global__ void __launch_bounds__(256) pat_emit_kernel(const uint32_t *__restrict__ d_n, uint32_t k_cap, const uint64_t *__restrict__ k0,
-                                                       const uint64_t *__restrict__ k1, const uint8_t *__restrict__ head,
-                                                       const uint32_t *__restrict__ pidx, uint64_t *__restrict__ pat_mask,
-                                                       uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species,
-                                                       uint32_t *__restrict__ overflow, int pack_shift) {
-    const uint64_t n = *d_n;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        if (!head[i]) continue;
-        uint32_t j = pidx[i];
-        if (j >= k_cap) { *overflow = 1; continue; }   // more patterns than this build sizes for: reported as PANTAX_HIP_E_LIMIT
+// Patterns = runs of equal (species, mask) in the sorted rows.  One chained-scan launch: the head flag of a row is
+// computed from the keys as it is loaded, and a head whose exclusive prefix is j emits pattern j on the spot.
+struct PatLoad {
+    const uint32_t *d_n;
+    const uint64_t *k0, *k1;   // k1 == null: species and mask share k0
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+        const uint64_t n = *d_n;   // rows actually present (the scan covers the host-side bound)
+        return (i < n && (i == 0 || k0[i] != k0[i - 1] || (k1 && k1[i] != k1[i - 1]))) ? 1u : 0u;
+    }
+};
+struct PatStore {
+    const uint64_t *k0, *k1;
+    uint32_t k_cap;
+    int pack_shift;
+    uint64_t *pat_mask;
+    uint32_t *pat_start, *pat_species, *overflow;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t j, uint32_t head) const {
+        if (!head) return;
+        if (j >= k_cap) { *overflow = 1; return; }   // more patterns than this build sizes for: reported as PANTAX_HIP_E_LIMIT
         if (pack_shift >= 0) {
             const uint64_t w = k0[i];
             pat_mask[j] = pack_shift < 64 ? (w & ((1ull << pack_shift) - 1ull)) : w;
@@ -456,7 +460,7 @@ __global__ void __launch_bounds__(256) pat_emit_kernel(const uint32_t *__restric
         }
         pat_start[j] = (uint32_t)i;
     }
-}
+};
 
 // species -> first pattern (patterns are sorted by species); entry S = K; also closes pat_start[K] = n_rows
 __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint32_t *__restrict__ d_K, uint32_t k_cap,
@@ -507,7 +511,6 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
     PTX_HIP(ctx, lb->d_counts.alloc(4));
     uint32_t *d_n = lb->d_counts.p, *d_K = lb->d_counts.p + 1, *d_ovf = lb->d_counts.p + 2;
-    int gridV = grid_for(V, 256, ctx->n_cu * 8);
     DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
     for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); PTX_HIP(ctx, kb[w].alloc(V)); }
     // above the sample-sort limit the rows go through the radix sort; species and mask then share one key word
@@ -543,16 +546,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     SortBufs Sd = in_b ? B : A;
     lb->row_a = reinterpret_cast<const double *>(Sd.k[pack_shift >= 0 ? 1 : 2]);   // sorted abundances, used in place
     // patterns = runs of equal (species, mask)
-    DevBuf<uint8_t> &head = dbm->d_pat_head;
-    DevBuf<uint32_t> &pidx = dbm->d_pat_idx;
-    PTX_HIP(ctx, head.alloc(V)); PTX_HIP(ctx, pidx.alloc(V));
     const uint64_t k_cap = std::min<uint64_t>(V, (uint64_t)S * 8192 + 65536);
     lb->k_cap = (uint32_t)k_cap;
-    hipLaunchKernelGGL(pat_flag_kernel, dim3(gridV), dim3(256), 0, ctx->stream, V, d_n, Sd.k[0], pack_shift >= 0 ? (const uint64_t *)nullptr : Sd.k[1], head.p);
-    PTX_TRY(exclusive_scan_u8(ctx, head.p, pidx.p, V, scan_tmp.p, d_K));
     PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
-    hipLaunchKernelGGL(pat_emit_kernel, dim3(gridV), dim3(256), 0, ctx->stream, d_n, (uint32_t)k_cap, Sd.k[0], Sd.k[1], head.p, pidx.p,
-                       lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf, pack_shift);
+    {
+        const uint64_t *pk1 = pack_shift >= 0 ? (const uint64_t *)nullptr : Sd.k[1];
+        PTX_TRY(exclusive_scan_fn(ctx, PatLoad{d_n, Sd.k[0], pk1},
+                                  PatStore{Sd.k[0], pk1, (uint32_t)k_cap, pack_shift, lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf},
+                                  V, d_K, "pattern_scan_kernel"));
+    }
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
     hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
                        lb->d_pat_start.p, lb->d_sp_pat_off.p);
