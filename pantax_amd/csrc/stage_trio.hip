@@ -20,6 +20,7 @@
 #include <algorithm>
 #include "primitives.hpp"
 #include "wave.hpp"
+#include "scan_chained.hpp"
 
 namespace ptx {
 
@@ -154,11 +155,18 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
     }
 }
 
-__global__ void __launch_bounds__(256) trio_node_kernel(uint64_t V, const uint32_t *__restrict__ trio_first, const uint32_t *__restrict__ first_cnt,
-                                                        uint2 *__restrict__ trio_node) {
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256)
-        trio_node[v] = make_uint2(trio_first[v], first_cnt[v]);
-}
+// scan of the per-node unique-window counts that also writes the lookup heads {first row, #rows} (CSR over the
+// smallest end node) -- the prefix and its consumer in one launch
+struct TrioFirstLoad { const uint32_t *cnt; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return cnt[i]; } };
+struct TrioFirstStore {
+    uint32_t *first;
+    uint2 *node;
+    uint64_t V;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t c) const {
+        first[i] = excl;
+        if (i < V) node[i] = make_uint2(excl, c);
+    }
+};
 
 __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint32_t *__restrict__ hap_tile_off, const uint32_t *__restrict__ tile_base,
                                                           uint64_t *__restrict__ hap_trio_off) {
@@ -212,7 +220,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
         }
         hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
-        PTX_TRY(exclusive_scan_u32(ctx, ts.first_cnt.p, db->d_trio_first.p, V + 1, ts.scan_tmp.p, nullptr));
+        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_trio_node.p, V}, V + 1, nullptr,
+                                  "exclusive_scan"));
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
@@ -236,9 +245,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
         db->U = 0;
         PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(db->d_trio_node.p, 0, (V ? V : 1) * sizeof(uint2), ctx->stream));
     }
-    hipLaunchKernelGGL(trio_node_kernel, dim3(grid_for(V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, V, db->d_trio_first.p,
-                       ts.first_cnt.p, db->d_trio_node.p);
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
     if (!db->trio_sizes_known) {
