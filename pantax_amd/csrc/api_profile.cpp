@@ -207,9 +207,11 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     std::vector<uint8_t> flags(hr.flags);
     {
         std::unordered_set<uint64_t> seen;
-        seen.reserve(R * 2);
+        if (hr.ids_distinct != 1) seen.reserve(R * 2);
         bool unique = true;
-        for (uint64_t r = 0; r < R && unique; ++r) if (sp_idx[r] >= 0 && !seen.insert(hr.id_hash[r]).second) unique = false;
+        // the device tokenizer has already sorted the id hashes: when no two reads share one, nothing can repeat
+        if (hr.ids_distinct != 1)
+            for (uint64_t r = 0; r < R && unique; ++r) if (sp_idx[r] >= 0 && !seen.insert(hr.id_hash[r]).second) unique = false;
         if (!unique) {   // process_with_duplicates: keep an id only if all of its (complete) alignments sit in one species
             std::unordered_map<uint64_t, int32_t> first;
             std::unordered_set<uint64_t> mixed;

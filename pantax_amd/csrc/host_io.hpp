@@ -35,6 +35,7 @@ struct HostReads {
     std::vector<uint64_t> id_hash;        // 64-bit hash of read_id (duplicate detection, profile.rs:369-378)
     std::vector<std::pair<uint64_t, uint32_t>> id_span;   // offset/len of read_id in the mapped file (binning report)
     uint64_t n_lines = 0;
+    int ids_distinct = -1;                // device tokenizer: 1 = no two reads share an id hash, 0 = some do; -1 = not checked
 };
 // tokenises the GAF columns rcls.rs:127-137 selects; keeps the mapping alive in `keep` for id_span
 struct MappedFile {

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <vector>
 #include "common.hpp"
 #include "host_io.hpp"
 #include "primitives.hpp"
@@ -193,6 +194,15 @@ static int upload_text(Ctx *ctx, uint8_t *d_dst, const char *text, uint64_t size
     return rc;
 }
 
+// after sorting the id hashes: how many adjacent pairs are equal (0 = every read id is distinct, the usual case, and
+// the host can skip its hash-set pass of the duplicate-id rule, profile.rs:361-437)
+__global__ void __launch_bounds__(256) dup_count_kernel(uint64_t n, const uint64_t *__restrict__ sorted, uint32_t *__restrict__ out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (uint64_t)gridDim.x * 256) c += sorted[i] == sorted[i - 1] ? 1u : 0u;
+    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 __global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t *__restrict__ v, uint32_t *__restrict__ out) {
     uint32_t m = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = max(m, v[i]);
@@ -279,6 +289,23 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         PTX_HIP(ctx, hipMemsetAsync(tot.p + 3, 0, sizeof(uint32_t), ctx->stream));
         if (T) hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(T, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, T, o32[1].p, tot.p + 3);
     }
+    // are all read ids distinct?  sort a copy of the hashes, count equal neighbours
+    DevBuf<uint64_t> hs_a, hs_b;
+    DevBuf<uint32_t> hs_table, dup_cnt;
+    uint32_t n_dup = 0;
+    if (R > 1) {
+        PTX_HIP(ctx, hs_a.alloc(R)); PTX_HIP(ctx, hs_b.alloc(R)); PTX_HIP(ctx, hs_table.alloc(sort_table_elems(R))); PTX_HIP(ctx, dup_cnt.alloc(1));
+        PTX_HIP(ctx, hipMemcpyAsync(hs_a.p, o_hash.p, R * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(dup_cnt.p, 0, sizeof(uint32_t), ctx->stream));
+        SortBufs A, B;
+        A.nw = B.nw = 1; A.k[0] = hs_a.p; B.k[0] = hs_b.p;
+        std::vector<SortPass> passes;
+        add_passes(passes, 0, 0, 64);
+        bool in_b = false;
+        PTX_TRY(radix_sort(ctx, A, B, R, passes.data(), (int)passes.size(), hs_table.p, scan_tmp.p, &in_b, nullptr));
+        hipLaunchKernelGGL(dup_count_kernel, dim3(grid_for(R, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, R, in_b ? hs_b.p : hs_a.p, dup_cnt.p);
+        PTX_TRY(download(ctx, &n_dup, dup_cnt.p, 1));
+    }
     uint32_t max_id = 0;
     PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
     PTX_TRY(download(ctx, id_off.data(), o32[5].p, R)); PTX_TRY(download(ctx, id_len.data(), o32[6].p, R));
@@ -296,6 +323,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     for (uint64_t k = 0; k < R; ++k) out.id_span[k] = {(uint64_t)id_off[k], id_len[k]};
     out.n_lines = R;
+    out.ids_distinct = n_dup == 0 ? 1 : 0;
     return 0;
 }
 

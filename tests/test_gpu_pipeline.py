@@ -18,7 +18,7 @@ def _read_tsv(path):
         return hdr, [line.rstrip("\n").split("\t") for line in f]
 
 
-def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4):
+def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_drop=None):
     from oracle import oracle as orc
     rd = sset.reads
     S = len(sset.species)
@@ -32,7 +32,8 @@ def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4):
             continue
         G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
         T = orc.TrioTable(G)
-        so, nid, ps, pe = select_reads(rd, np.nonzero(sp == s)[0])
+        mine = sp == s if strain_drop is None else (sp == s) & ~strain_drop
+        so, nid, ps, pe = select_reads(rd, np.nonzero(mine)[0])
         b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
         rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=fr, fc=fc, sr=sr)
         assert rc == 0
@@ -136,6 +137,47 @@ def test_profile_seam_resume_strain_only(world):
     finally:
         os.chdir(cwd)
     _check_outputs(str(wd), sset, exp_species, exp_strain)
+
+
+def test_profile_seam_duplicate_read_ids(world):
+    """Read ids that repeat (GraphAligner reports several alignments of a long read): an id whose alignments all bin to
+    one species keeps them all, an id seen in two species loses them all at the strain level, and the species table
+    still counts every row (profile.rs:361-463)."""
+    import copy
+    from pantax_amd import synth
+    sset, root, db, gaf, eng = world
+    rd = copy.copy(sset.reads)
+    R = rd.n_reads
+    _, _, sp = _oracle_tables(sset)
+    ids = ["S0R%d/1" % r for r in range(R)]
+    rng = np.random.default_rng(5)
+    mapped = np.nonzero(sp >= 0)[0]
+    drop = np.zeros(R, bool)
+    n_same = n_mixed = 0
+    for a, b in rng.choice(mapped, size=(3000, 2), replace=False):
+        ids[b] = ids[a]
+        if sp[a] == sp[b]:
+            n_same += 1
+        else:
+            drop[a] = drop[b] = True
+            n_mixed += 1
+    assert n_same > 50 and n_mixed > 50
+    rd.read_id = ids
+    gaf2 = root / "dup.gaf"
+    synth.write_gaf(rd, str(gaf2))
+    exp_species, exp_strain, _ = _oracle_tables(sset, strain_drop=drop)
+    wd = root / "wd_dup"
+    wd.mkdir()
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        eng.profile(str(db), str(wd), str(gaf2))
+    finally:
+        os.chdir(cwd)
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
+    # and the rule changes the answer here: without it the strain table differs
+    _, plain, _ = _oracle_tables(sset)
+    assert any(abs(a[2] - b[2]) > 1e-9 for a, b in zip(plain, exp_strain)) or len(plain) != len(exp_strain)
 
 
 def test_profile_seam_errors(world):
