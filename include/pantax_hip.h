@@ -141,7 +141,8 @@ typedef struct { /* the ProfilingConfig fields optimize_otu reads (types.rs:57-9
     double single_cov_ratio;               /* --sr 0.85 */
     int64_t min_depth;                     /* --min_depth 0 */
     int32_t shift;                         /* --shift */
-    int32_t sample_nodes;                  /* --sample: must be 0 (row sub-sampling, profile.rs:1394-1400, not implemented) */
+    int32_t sample_nodes;                  /* --sample (cli.rs:227 default 500000; pass 500 for --sample_test): a species with more valid
+                                            * LP rows keeps the rows of sample_sorted (profile.rs:1287-1295); 0 = never sample */
 } pantax_hip_strain_config;
 
 typedef struct { /* per species solver report */
@@ -174,7 +175,7 @@ int pantax_hip_abundance_filter(uint32_t n_species, const uint64_t *hap_off, con
 typedef struct {
     double unique_trio_nodes_fraction, unique_trio_nodes_mean_count_f, single_cov_ratio, single_cov_diff; /* --fr --fc --sr --sd */
     int64_t min_cov, min_depth;
-    int32_t shift, filtered, sample_nodes /* must be 0 */, rebuild_trio /* 1 = like the reference, every run */;
+    int32_t shift, filtered, sample_nodes /* as in pantax_hip_strain_config */, rebuild_trio /* 1 = like the reference, every run */;
 } pantax_hip_step_config;
 
 int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads,
@@ -188,6 +189,13 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
  * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
  * 2 = sample sort (n <= 600000). */
 int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo);
+
+/* a11 (sample_sorted, profile.rs:1287-1295): which of n_valid rows `StdRng::seed_from_u64(seed)` +
+ * `choose_multiple(sample_nodes)` keeps, as a bitmap over their ranks (bits_out: (n_valid+31)/32 words).  Host only.
+ * rand 0.9.2 / rand_chacha 0.9.0 (Cargo.lock) are restated, not linked: parity with the crates is unpinned. */
+int pantax_hip_sample_ranks(uint64_t n_valid, uint64_t sample_nodes, uint64_t seed, uint32_t *bits_out);
+/* one ChaCha block (64-bit counter, zero stream id, `rounds` = 8/12/20) of the generator above, for known-answer tests */
+int pantax_hip_chacha_block(const uint32_t *key8, uint64_t counter, int rounds, uint32_t *out16);
 
 /* ---- solver seam: one species, host buffers in, same meaning as X_opt's arguments
  * (profile.rs:2690-2698).  cand_path_idx = possible_paths_idx; fixed_zero[k]=1 pins x_k = 0

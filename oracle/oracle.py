@@ -46,7 +46,7 @@ class OrcHapMetrics(C.Structure):
 
 class OrcStrainConfig(C.Structure):
     _fields_ = [("unique_trio_nodes_fraction", C.c_double), ("unique_trio_nodes_mean_count_f", C.c_double),
-                ("single_cov_ratio", C.c_double), ("min_depth", C.c_int64), ("shift", C.c_int32)]
+                ("single_cov_ratio", C.c_double), ("min_depth", C.c_int64), ("shift", C.c_int32), ("sample_nodes", C.c_int32)]
 
 
 HAS = dict(fraction=1, freq_mean=2, ratio=4, first=8, divergence=16, second=32, rescue=64, total_diff=128)
@@ -186,8 +186,8 @@ def lad_objective(mask, abund, x):
     return lib().orc_lad_objective(C.c_uint64(len(mask)), _p(mask), _p(abund), C.c_uint32(len(x)), _p(x))
 
 
-def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False):
-    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift))
+def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0):
+    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes))
     H = graph.n_paths
     met = (OrcHapMetrics * H)()
     nc = C.c_uint32(0)
@@ -199,6 +199,21 @@ def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.
     rc = lib().orc_optimize_species(C.byref(graph.c), C.byref(trio.c), _p(bases), _p(cov), _p(tb), C.byref(cfg), met,
                                     C.byref(nc), C.byref(o1), C.byref(o2))
     return rc, met, nc.value, o1.value, o2.value
+
+
+def sample_sorted_positions(length, amount, seed=42):
+    """a11 (profile.rs:1287-1295): ascending positions rand 0.9.2's choose_multiple keeps (restated, parity unpinned)."""
+    out = np.zeros(max(amount, 1), dtype=np.uint32)
+    rc = lib().orc_sample_sorted_positions(C.c_uint32(length), C.c_uint32(amount), C.c_uint64(seed), _p(out))
+    assert rc == 0
+    return out[:amount]
+
+
+def chacha_block(key8, counter, rounds):
+    key = np.ascontiguousarray(key8, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    lib().orc_chacha_block(_p(key), C.c_uint64(counter), C.c_int(rounds), _p(out))
+    return out
 
 
 def abundance_constraint(species_cov, met):

@@ -580,6 +580,110 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
 /* ------------------------------------------------------------------ */
 static double round2(double x) { return round(x * 100.0) / 100.0; } /* f64::round = half away from zero */
 
+/* ------------------------------------------------------------------ */
+/* a11: sample_sorted, profile.rs:1287-1295 (rand 0.9.2, unpinned)     */
+/* ------------------------------------------------------------------ */
+#define ORC_ROTL32(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define ORC_QR(a, b, c, d) \
+    a += b; d ^= a; d = ORC_ROTL32(d, 16); c += d; b ^= c; b = ORC_ROTL32(b, 12); \
+    a += b; d ^= a; d = ORC_ROTL32(d, 8);  c += d; b ^= c; b = ORC_ROTL32(b, 7)
+
+void orc_chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]) {
+    uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u; /* "expand 32-byte k" */
+    uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+    uint32_t x12 = (uint32_t)counter, x13 = (uint32_t)(counter >> 32), x14 = 0, x15 = 0;
+    for (int i = 0; i < rounds / 2; ++i) {
+        ORC_QR(x0, x4, x8, x12); ORC_QR(x1, x5, x9, x13); ORC_QR(x2, x6, x10, x14); ORC_QR(x3, x7, x11, x15);   /* columns */
+        ORC_QR(x0, x5, x10, x15); ORC_QR(x1, x6, x11, x12); ORC_QR(x2, x7, x8, x13); ORC_QR(x3, x4, x9, x14);   /* diagonals */
+    }
+    out[0] = x0 + 0x61707865u; out[1] = x1 + 0x3320646eu; out[2] = x2 + 0x79622d32u; out[3] = x3 + 0x6b206574u;
+    out[4] = x4 + key[0]; out[5] = x5 + key[1]; out[6] = x6 + key[2]; out[7] = x7 + key[3];
+    out[8] = x8 + key[4]; out[9] = x9 + key[5]; out[10] = x10 + key[6]; out[11] = x11 + key[7];
+    out[12] = x12 + (uint32_t)counter; out[13] = x13 + (uint32_t)(counter >> 32); out[14] = x14; out[15] = x15;
+}
+
+/* StdRng (rand 0.9) = ChaCha12Rng behind a 4-block (64-word) buffer; words are handed out in keystream order */
+typedef struct { uint32_t key[8]; uint64_t block; uint32_t words[64]; int pos; } orc_stdrng;
+
+static void orc_stdrng_seed_from_u64(orc_stdrng *r, uint64_t state) {
+    /* rand_core SeedableRng::seed_from_u64: PCG32 output per 4 seed bytes (little endian) */
+    for (int i = 0; i < 8; ++i) {
+        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+        uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+        r->key[i] = rot ? ((xs >> rot) | (xs << (32 - rot))) : xs;
+    }
+    r->block = 0; r->pos = 64;
+}
+static uint32_t orc_stdrng_u32(orc_stdrng *r) {
+    if (r->pos == 64) {
+        for (int b = 0; b < 4; ++b) orc_chacha_block(r->key, r->block++, 12, r->words + 16 * b);
+        r->pos = 0;
+    }
+    return r->words[r->pos++];
+}
+/* UniformInt<u32>::sample_single_inclusive (Canon's method, one correction draw) */
+static uint32_t orc_range_inclusive(orc_stdrng *r, uint32_t low, uint32_t high) {
+    uint32_t range = high - low + 1u;
+    if (range == 0) return orc_stdrng_u32(r);
+    uint64_t wide = (uint64_t)orc_stdrng_u32(r) * (uint64_t)range;
+    uint32_t result = (uint32_t)(wide >> 32), lo_order = (uint32_t)wide;
+    if (lo_order > (uint32_t)(~range + 1u)) {
+        uint32_t new_hi = (uint32_t)(((uint64_t)orc_stdrng_u32(r) * (uint64_t)range) >> 32);
+        if ((uint32_t)(lo_order + new_hi) < lo_order) result += 1u; /* checked_add overflowed */
+    }
+    return low + result;
+}
+static int orc_cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+
+int orc_sample_sorted_positions(uint32_t length, uint32_t amount, uint64_t seed, uint32_t *out) {
+    if (amount > length) return -1; /* rand panics */
+    orc_stdrng rng;
+    orc_stdrng_seed_from_u64(&rng, seed);
+    int big = length >= 500000u;
+    int use_inplace, use_floyd = 0;
+    if (amount < 163) { /* rand::seq::index::sample: f32 cost model */
+        static const float C[2][2] = {{1.6f, 8.0f / 45.0f}, {10.0f, 70.0f / 9.0f}};
+        float amount_fp = (float)amount, m4 = C[0][big] * amount_fp;
+        use_inplace = amount > 11 && (float)length < (C[1][big] + m4) * amount_fp;
+        use_floyd = !use_inplace;
+    } else {
+        static const float C[2] = {270.0f, 330.0f / 9.0f};
+        use_inplace = (float)length < C[big] * (float)amount;
+    }
+    if (use_inplace) { /* sample_inplace: partial Fisher-Yates over 0..length */
+        uint32_t *idx = (uint32_t *)malloc((size_t)(length ? length : 1) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < length; ++i) idx[i] = i;
+        for (uint32_t i = 0; i < amount; ++i) {
+            uint32_t j = orc_range_inclusive(&rng, i, length - 1u);
+            uint32_t t = idx[i]; idx[i] = idx[j]; idx[j] = t;
+        }
+        memcpy(out, idx, (size_t)amount * sizeof(uint32_t));
+        free(idx);
+    } else if (use_floyd) { /* sample_floyd */
+        uint32_t n = 0;
+        for (uint32_t j = length - amount; j < length; ++j) {
+            uint32_t t = orc_range_inclusive(&rng, 0, j);
+            for (uint32_t q = 0; q < n; ++q) if (out[q] == t) { out[q] = j; break; }
+            out[n++] = t;
+        }
+    } else { /* sample_rejection: Uniform::new(0, length).sample until unseen */
+        uint8_t *seen = (uint8_t *)calloc((size_t)length / 8 + 1, 1);
+        uint32_t thresh = (uint32_t)(~length + 1u) % length;
+        for (uint32_t n = 0; n < amount;) {
+            uint64_t wide = (uint64_t)orc_stdrng_u32(&rng) * (uint64_t)length;
+            if ((uint32_t)wide < thresh) continue;
+            uint32_t pos = (uint32_t)(wide >> 32);
+            if (seen[pos >> 3] & (1u << (pos & 7))) continue;
+            seen[pos >> 3] |= (uint8_t)(1u << (pos & 7));
+            out[n++] = pos;
+        }
+        free(seen);
+    }
+    qsort(out, amount, sizeof(uint32_t), orc_cmp_u32); /* sampled.sort_unstable() */
+    return 0;
+}
+
+
 int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const int64_t *bases_per_node,
                          const uint64_t *node_base_cov, const int64_t *trio_bases,
                          const orc_strain_config *cfg, orc_hap_metrics *met,
@@ -644,6 +748,23 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
         float ratio[64]; double ub[64], x1[64], x2[64];
         orc_path_masks(g, nc, cand, node_base_cov, mask, ratio);
         for (uint32_t k = 0; k < nc; ++k) { met[cand[k]].path_cov_ratio = (double)ratio[k]; met[cand[k]].has |= ORC_HAS_RATIO; ub[k] = 1.05 * amax; }
+        /* a11: the LP sees only the sampled valid rows (profile.rs:2738-2752); amax and the ratios above do not */
+        if (cfg->sample_nodes > 0) {
+            uint32_t nv = 0;
+            for (uint32_t v = 0; v < V; ++v) nv += ab[v] > 0.0;
+            if (nv > (uint32_t)cfg->sample_nodes) {
+                uint32_t *valid = (uint32_t *)malloc((size_t)nv * sizeof(uint32_t)), *pos = (uint32_t *)malloc((size_t)cfg->sample_nodes * sizeof(uint32_t));
+                nv = 0;
+                for (uint32_t v = 0; v < V; ++v) if (ab[v] > 0.0) valid[nv++] = v;
+                orc_sample_sorted_positions(nv, (uint32_t)cfg->sample_nodes, 42, pos);
+                uint32_t q = 0;
+                for (uint32_t r = 0; r < nv; ++r) {
+                    if (q < (uint32_t)cfg->sample_nodes && pos[q] == r) { ++q; continue; }
+                    ab[valid[r]] = 0.0; /* not an LP row; ab is not read below except by the LP and its objective */
+                }
+                free(valid); free(pos);
+            }
+        }
         int32_t it, st;
         orc_lad_solve(V, mask, ab, nc, ub, x1, obj1_out, &it, &st);
         if (st != 0) { rc = -1; free(mask); goto done; }

@@ -133,7 +133,15 @@ typedef struct {
     double single_cov_ratio;               /* --sr 0.85 */
     int64_t min_depth;                     /* --min_depth 0 */
     int32_t shift;                         /* main.rs:119-124 */
+    int32_t sample_nodes;                  /* --sample (cli.rs:227 default 500000; --sample_test = 500); 0 = off */
 } orc_strain_config;
+
+/* a11: sample_sorted (profile.rs:1287-1295) = StdRng::seed_from_u64(seed) + slice::choose_multiple + sort.
+ * rand 0.9.2 / rand_chacha 0.9.0 are NOT under /root/reference (Cargo.lock pins them); this is a restatement of
+ * their published algorithm and is PARITY UNPINNED.  Writes the `amount` chosen positions of 0..length, ascending. */
+int orc_sample_sorted_positions(uint32_t length, uint32_t amount, uint64_t seed, uint32_t *out);
+/* one 64-byte ChaCha block (rounds = 20 / 12 / 8), 64-bit counter, zero stream id: for the keystream known answers */
+void orc_chacha_block(const uint32_t key[8], uint64_t counter, int rounds, uint32_t out[16]);
 
 /* first_filter_paths .. second solve for one species, given integer histogram
  * outputs. metrics_out is [n_paths]. n_candidates_out = possible_paths_idx.len().

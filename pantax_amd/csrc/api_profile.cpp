@@ -4,7 +4,10 @@
 // Host orchestration only; every per-read / per-node computation goes through the device stages.
 #include <sys/stat.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -59,8 +62,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (out_dir.empty()) out_dir = wd;
     if (!is_dir(db_dir)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax database directory '%s' is not a valid directory path", db_dir.c_str());
     if (!is_dir(wd)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax work directory '%s' is not a valid directory path", wd.c_str());
-    if (cfg->sample_nodes != 0)
-        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: --sample %d: LP row sub-sampling (profile.rs:1394-1400) is not implemented; pass --sample 0", cfg->sample_nodes);
+    if (cfg->sample_nodes < 0) return fail(ctx, PANTAX_HIP_E_INVALID, "profile: --sample %d", cfg->sample_nodes);
     const std::string zip = opt(cfg->zip);
     if (zip == "h5")
         return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: graph container '%s' is not available in this build (the reference gates it behind a cargo feature); use serialize / lz / zstd or GFA", zip.c_str());
@@ -76,6 +78,17 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (!is_file(gaf_path)) return fail(ctx, PANTAX_HIP_E_IO, "Specified GAF mapping file '%s' is not a valid file path", gaf_path.c_str());
     const std::string range_path = choose(opt(cfg->range_file), join(db_dir, "species_range.txt"));
     if (range_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species range file '%s' nor '%s' is a valid file path", opt(cfg->range_file).c_str(), join(db_dir, "species_range.txt").c_str());
+
+    // PANTAX_HIP_TRACE=1: wall time of each phase on stderr (the reference logs its phases through env_logger)
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pantax_hip_profile] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
 
     std::vector<RangeRow> ranges;
     std::string err = read_species_range(range_path, ranges);
@@ -94,6 +107,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     reads.rd = new pantax_hip_reads();
     PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr, reads.rd));
     const uint64_t R = hr.qlen.size();
+    lap("ranges + GAF tokenise");
 
     // ---- a2/a3: binning against ALL species ranges (ranges-only db), counters on device
     std::vector<int64_t> rs(S), re(S);
@@ -108,6 +122,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     std::vector<int64_t> rc(S), bs(S), lm(S), uq(S);
     PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, sp_idx.data(), rc.data(), bs.data(), lm.data(), uq.data()));
 
+    lap("bin all species");
     std::vector<SpeciesProfileRow> sp_profile;   // species_taxid, predicted_abundance, predicted_coverage
     if (full_path) {
         // optional binning report: read_id, mapq, species, read_len; no header (profile.rs:3337-3351)
@@ -170,6 +185,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         }
     }
 
+    lap("species table / report");
     // ---- a4: load_species_range (profile.rs:553-656)
     std::set<std::string> ds;
     const std::string ds_s = opt(cfg->designated_species);
@@ -224,6 +240,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         }
     }
 
+    lap("select + duplicate ids");
     // ---- a6: graphs of the selected species (optimize_otu file choice, profile.rs:2888-2932)
     const uint32_t Ss = (uint32_t)sel.size();
     std::vector<HostGraph> graphs(Ss);
@@ -243,6 +260,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
         if ((int64_t)graphs[i].node_len.size() != nvert) return fail(ctx, PANTAX_HIP_E_IO, "species %s: graph has %zu nodes but its range spans %lld", otu.c_str(), graphs[i].node_len.size(), (long long)nvert);
     }
+    lap("graph load");
     std::vector<uint32_t> use;   // selected species with a loaded graph
     for (uint32_t i = 0; i < Ss; ++i) if (loaded[i]) use.push_back(i);
     const uint32_t Su = (uint32_t)use.size();
@@ -266,9 +284,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         DbHolder sdb{ctx};
         pantax_hip_graphs g{Su, g_rs.data(), g_re.data(), node_off.data(), node_len.data(), hap_off.data(), path_off.data(), path_nodes.data()};
         PTX_TRY(pantax_hip_db_upload(ctx, &g, &sdb.db));
-        // re-upload reads with the strain-level drop flags; species binned against the selected ranges
-        // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
-        // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
+        lap("db upload");
         // the same resident reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
         // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
@@ -283,11 +299,12 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         uint64_t nU = 0, n_abort = 0;
         PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
         PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
-        pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, 0};
+        pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, cfg->sample_nodes};
         std::vector<double> cov(Su);
         for (uint32_t k = 0; k < Su; ++k) cov[k] = sel_cov[use[k]];
         met.resize(hap_names.size());
         PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data(), met.data(), info.data()));
+        lap("strain step");
     }
 
     // ---- a15: abundance_est (profile.rs:3091-3289)
@@ -341,5 +358,6 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", strain_file.c_str());
     f << header;
     for (auto &r : final_rows) f << r.line << '\n';
+    lap("tables");
     return 0;
 }

@@ -95,14 +95,14 @@ namespace ptx {
 int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active) {
     if (!db->cov_done) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_node_coverage first");
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_trio_index first");
-    if (cfg->sample_nodes != 0)
-        return fail(ctx, PANTAX_HIP_E_LIMIT, "strain_profile: --sample %d requested; row sub-sampling (profile.rs:1394-1400, rand 0.9.2 ChaCha12) is not implemented, run with sample 0", cfg->sample_nodes);
+    if (cfg->sample_nodes < 0) return fail(ctx, PANTAX_HIP_E_INVALID, "strain_profile: sample_nodes %d", cfg->sample_nodes);
     const uint32_t S = db->S;
     LadBatch &lb = db->lad;
     const ArenaLayout L(S, db->H);
     PTX_TRY(bind_arena(ctx, db, lb, L));
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
+    PTX_TRY(row_sample_apply(ctx, db, &lb, cfg->sample_nodes));                             // a11 (no-op unless a species is larger than --sample)
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
     PTX_TRY(first_filter_launch(ctx, db, &lb, d_active, fc));                               // a9 decision -> LP columns
     int pmax_bound = 1;                                                                     // columns per species <= min(#haps, 64)

@@ -12,7 +12,7 @@ static void usage() {
             "usage: pantax-hip -db <db_dir> --gaf <gfa_mapped.gaf> [-T <work_dir>] [--species] [--strain]\n"
             "  --short-read | --long-read     (sets --fr default 0.3 / 0.5)\n"
             "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
-            "  --min_cov N  --min_depth N  --sample N(must be 0)  --ds a,b,c  --smode 0|1  --no-filter\n"
+            "  --min_cov N  --min_depth N  --sample N (default 500000)  --ds a,b,c  --smode 0|1  --no-filter\n"
             "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
             "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n");
 }
@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
     memset(&c, 0, sizeof(c));
     std::string wd = "pantax_db_tmp";
     c.min_species_abundance = 1e-4; c.unique_trio_nodes_fraction = -1; c.unique_trio_nodes_mean_count_f = 0.46;
-    c.single_cov_ratio = 0.85; c.single_cov_diff = 0.2; c.filtered = 1; c.full = 1; c.mode = 2; c.sample_nodes = 0;
+    c.single_cov_ratio = 0.85; c.single_cov_diff = 0.2; c.filtered = 1; c.full = 1; c.mode = 2; c.sample_nodes = 500000;
     c.zip = "serialize"; c.world_size = 1;
     bool long_read = false;
     int device = 0;

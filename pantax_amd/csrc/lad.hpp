@@ -9,6 +9,8 @@ namespace ptx {
 int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_ntrio_nz /*[H]*/, DevBuf<double> &d_mean /*[H]*/);
 // node abundance + per-species stats
 int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth);
+// a11: species with more valid rows than sample_nodes keep the rows rand 0.9.2's choose_multiple(seed 42) would keep
+int row_sample_apply(Ctx *ctx, const Db *db, LadBatch *lb, int64_t sample_nodes);
 // a10: masks, ratios; then LP rows sorted and grouped into patterns
 int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int pmax_bound);
 // a12: one workgroup per species (those with d_p[s] > 0 and need[s], when given); variables with fixed[s*64+k]

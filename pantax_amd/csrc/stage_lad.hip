@@ -14,6 +14,7 @@
 // representation, one workgroup per species, all species of the batch in one launch.
 #include <algorithm>
 #include "lad.hpp"
+#include "row_sample.hpp"
 #include "primitives.hpp"
 #include "wave.hpp"
 #include "scan_chained.hpp"
@@ -297,6 +298,50 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
                        lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p, nch);
     PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a11: row sub-sampling (sample_sorted, profile.rs:1287-1295 and its call sites :1394-1400 / :2738-2752).
+// Only species with more valid rows than `sample_nodes` are touched, and only those cost a host round trip (their
+// row count n decides the chosen ranks).  The chosen set is a bitmap over the RANKS of the valid rows in node
+// order (row_sample.cpp); one chained scan ranks the valid nodes and clears the abundance of the unchosen ones in
+// the LP's copy, so row_emit_kernel and objective_kernel see exactly the sampled rows.  max a (the x bound),
+// path_cov_ratio and the single-path statistics were taken before and are not sampled (profile.rs:2700-2729).
+// ---------------------------------------------------------------------------------------------
+struct SampleLoad {
+    const double *ab;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return ab[i] > 0.0 ? 1u : 0u; }
+};
+struct SampleStore {
+    double *ab;
+    const uint32_t *bits;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t rank, uint32_t valid) const {
+        if (valid && !((bits[rank >> 5] >> (rank & 31)) & 1u)) ab[i] = 0.0;
+    }
+};
+
+int row_sample_apply(Ctx *ctx, const Db *db, LadBatch *lb, int64_t sample_nodes) {
+    const uint32_t S = db->S;
+    bool possible = false;
+    for (uint32_t s = 0; s < S && !possible; ++s) possible = (int64_t)(db->h_node_off[s + 1] - db->h_node_off[s]) > sample_nodes;
+    if (sample_nodes <= 0 || !possible) return 0;   // no species can have more valid rows than the limit
+    std::vector<uint32_t> nvalid(S);
+    PTX_TRY(download(ctx, nvalid.data(), lb->d_nvalid.p, S));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> bits;
+    DevBuf<uint32_t> d_bits;
+    for (uint32_t s = 0; s < S; ++s) {
+        if ((int64_t)nvalid[s] <= sample_nodes) continue;
+        sample_ranks(nvalid[s], (uint64_t)sample_nodes, 42, bits);
+        PTX_TRY(upload(ctx, d_bits, bits.data(), bits.size()));
+        double *ab = lb->d_ab.p + db->h_node_off[s];
+        PTX_TRY(exclusive_scan_fn(ctx, SampleLoad{ab}, SampleStore{ab, d_bits.p}, db->h_node_off[s + 1] - db->h_node_off[s], nullptr, "row_sample_kernel"));
+        nvalid[s] = (uint32_t)sample_nodes;                // n of the objective's 1/n (profile.rs:2755)
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_bits is reused by the next species
+    }
+    PTX_HIP(ctx, hipMemcpyAsync(lb->d_nvalid.p, nvalid.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

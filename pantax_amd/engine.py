@@ -212,7 +212,7 @@ class Engine:
         return met, info
 
     def profile_step(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
-                     rebuild_trio=True):
+                     rebuild_trio=True, sample_nodes=0):
         """One resident pass of the hot path in a single call (pantax_hip_profile_step): the host waits once.
         -> keep [S] uint8, predicted_coverage [S], metrics [H], info [S], pass [H] uint8, sum_all [S], sum_pass [S]"""
         if self._step_buf is None or self._step_buf[0] != (self.S, self.H):
@@ -222,7 +222,7 @@ class Engine:
             self._step_ptr = [p(a) if isinstance(a, np.ndarray) else a for a in self._step_buf[1:]]
         _, keep, absolute, met, info, passed, s_all, s_pass = self._step_buf
         avg = as_c(avg_len, np.float64)
-        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), 0, int(rebuild_trio))
+        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio))
         self._check(self.lib.pantax_hip_profile_step(self.ctx, self.db, self.reads, p(avg), C.byref(cfg), *self._step_ptr))
         if rebuild_trio:
             self.U = None
@@ -262,6 +262,23 @@ class Engine:
             filtered=int(filtered), full=int(full), force=int(force), mode=mode, sample_nodes=sample_nodes,
             designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1)
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
+
+    @staticmethod
+    def sample_ranks(n_valid, sample_nodes, seed=42):
+        """a11: bool [n_valid], True where sample_sorted (profile.rs:1287-1295) keeps the row of that rank.  Host only."""
+        bits = np.zeros((n_valid + 31) // 32, dtype=np.uint32)
+        rc = _ffi.load().pantax_hip_sample_ranks(C.c_uint64(n_valid), C.c_uint64(sample_nodes), C.c_uint64(seed), p(bits))
+        if rc != 0:
+            raise ValueError("sample_ranks(%d, %d)" % (n_valid, sample_nodes))
+        return np.unpackbits(bits.view(np.uint8), bitorder="little")[:n_valid].astype(bool)
+
+    @staticmethod
+    def chacha_block(key8, counter, rounds):
+        key = np.ascontiguousarray(key8, dtype=np.uint32)
+        out = np.zeros(16, dtype=np.uint32)
+        if _ffi.load().pantax_hip_chacha_block(p(key), C.c_uint64(counter), int(rounds), p(out)) != 0:
+            raise ValueError("chacha_block")
+        return out
 
     # ------------------------------------------------------------------ timing
     def sort_rows(self, k0, k1, k2, algo=0):

@@ -24,6 +24,7 @@ class StepConfig:
     min_depth: int = 0
     shift: bool = False
     filtered: bool = True
+    sample_nodes: int = 0                 # --sample (cli.rs:227: 500000 by default); 0 = never sub-sample the LP rows
     rebuild_trio: bool = True             # the reference rebuilds trio_nodes_info every run (profile.rs:2936)
 
 
@@ -80,7 +81,7 @@ def local_stage(eng, avg_len, cfg, single_call=True):
     if single_call:
         keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(
             avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
-            filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio)
+            filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
         keep, absolute, s_all, s_pass = keep.copy(), absolute.copy(), s_all.copy(), s_pass.copy()
         solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
                            for s in range(eng.S)], dtype=np.uint8)
@@ -97,7 +98,7 @@ def local_stage(eng, avg_len, cfg, single_call=True):
         eng.trio_nodes_info(fetch=False)
         eng.get_node_abundances(species_active=keep, fetch=False)
         met, info = eng.strain_profiling(absolute, species_active=keep, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr,
-                                         min_depth=cfg.min_depth, shift=cfg.shift)
+                                         min_depth=cfg.min_depth, shift=cfg.shift, sample_nodes=cfg.sample_nodes)
         solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
                            for s in range(eng.S)], dtype=np.uint8)
         passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)

@@ -241,6 +241,58 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
                     assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_nodes", [2000, 500, 1237])
+def test_strain_profiling_with_row_sampling(eng, sample_nodes):
+    """--sample N (a11, profile.rs:1287-1295, :2738-2752): species with more valid rows than N solve the LP on the sampled
+    rows only; the others are untouched.  Checked against the oracle's own restatement of the sampler and, for the rule
+    itself, against the unsampled run."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(77, 3, 6, 60000, 40000, present_frac=0.5)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    eng.trio_nodes_info(fetch=False)
+    eng.get_node_abundances(fetch=False)
+    met0, info0 = eng.strain_profiling(absolute, species_active=keep)
+    n_full = [info0[s].n_rows for s in range(eng.S)]
+    met, info = eng.strain_profiling(absolute, species_active=keep, sample_nodes=sample_nodes)
+    got = metrics_to_dicts(met, eng.H)
+    ref = _oracle_cov_per_species(sset, sp)
+    sampled = 0
+    for si, (G, T, b, c, t, na) in enumerate(ref):
+        if not keep[si]:
+            continue
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, sample_nodes=sample_nodes)
+        assert rc_ == 0
+        orc.abundance_constraint(absolute[si], omet)
+        exp = orc.metrics_to_dicts(omet)
+        h0 = int(eng.hap_off[si])
+        assert info[si].n_candidates == nc and info[si].status1 == 0 and info[si].status2 == 0
+        if nc:
+            assert info[si].n_rows == min(n_full[si], sample_nodes)
+            sampled += n_full[si] > sample_nodes
+            assert info[si].obj1 == pytest.approx(o1, rel=1e-9, abs=1e-12)
+            if not np.isnan(o2):
+                assert info[si].obj2 == pytest.approx(o2, rel=1e-9, abs=1e-12)
+        for h, e in enumerate(exp):
+            g = got[h0 + h]
+            for key, ev in e.items():
+                gv = g[key]
+                if ev is None or gv is None or isinstance(ev, bool):
+                    assert gv == ev, (si, h, key, gv, ev)
+                else:
+                    assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
+    assert sampled >= 1
+    # a limit nobody reaches changes nothing
+    met1, info1 = eng.strain_profiling(absolute, species_active=keep, sample_nodes=10**7)
+    assert metrics_to_dicts(met1, eng.H) == metrics_to_dicts(met0, eng.H)
+
+
 def _host_sorted(k0, k1, k2):
     order = np.lexsort((k2, k1, k0))
     return [k0[order], k1[order], k2[order]]

@@ -180,6 +180,21 @@ def test_profile_seam_duplicate_read_ids(world):
     assert any(abs(a[2] - b[2]) > 1e-9 for a, b in zip(plain, exp_strain)) or len(plain) != len(exp_strain)
 
 
+def test_profile_seam_default_sample_limit(world):
+    """--sample 500000 (the reference's default, cli.rs:227) leaves species with fewer valid rows alone."""
+    sset, root, db, gaf, eng = world
+    exp_species, exp_strain, sp = _oracle_tables(sset)
+    wd = root / "wd_sample"
+    wd.mkdir()
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        eng.profile(str(db), str(wd), str(gaf), sample_nodes=500000)
+    finally:
+        os.chdir(cwd)
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
+
+
 def test_profile_seam_errors(world):
     from pantax_amd.engine import PantaxHipError
     sset, root, db, gaf, eng = world
@@ -188,7 +203,7 @@ def test_profile_seam_errors(world):
     with pytest.raises(PantaxHipError):
         eng.profile(str(db), str(wd), str(root / "missing.gaf"))
     with pytest.raises(PantaxHipError):
-        eng.profile(str(db), str(wd), str(gaf), sample_nodes=500000)
+        eng.profile(str(db), str(wd), str(gaf), sample_nodes=-1)
     with pytest.raises(PantaxHipError):
         eng.profile(str(db), str(wd), str(gaf), species=False, strain=False)
 

@@ -98,3 +98,48 @@ def test_graph_codecs_lz4_and_zstd(small, tmp_path):
         bad.write_bytes(p.read_bytes()[: len(p.read_bytes()) // 2])
         with pytest.raises(Exception):
             pio.load_graph(bad, fmt)
+
+
+# ---------------------------------------------------------------------------------------------
+# a11: the generator behind sample_sorted (profile.rs:1287-1295).  rand 0.9.2 is not vendored under the reference, so
+# what can be pinned here is the ChaCha core (published keystreams) and that the library and the oracle, written
+# separately, restate the same sampler.
+# ---------------------------------------------------------------------------------------------
+CHACHA_ZERO_KEY = {   # first 32 keystream bytes, 256-bit zero key, zero nonce, block 0 (RFC 7539 A.1 #1; Strombergson TC1)
+    20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7",
+    12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f",
+    8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e",
+}
+
+
+def test_chacha_core_known_answers():
+    from oracle import oracle as orc
+    from pantax_amd.engine import Engine
+    z = np.zeros(8, dtype=np.uint32)
+    for rounds, hexs in CHACHA_ZERO_KEY.items():
+        for fn in (orc.chacha_block, Engine.chacha_block):
+            assert fn(z, 0, rounds)[:8].astype("<u4").tobytes().hex() == hexs
+    # RFC 7539 2.3.2 uses a 32-bit counter + 96-bit nonce; with a zero nonce the layouts coincide: block 1 of the zero key
+    blk1 = Engine.chacha_block(z, 1, 20).astype("<u4").tobytes().hex()
+    assert blk1.startswith("9f07e7be5551387a98ba977c732d080d")
+    assert (orc.chacha_block(z, 1, 20) == Engine.chacha_block(z, 1, 20)).all()
+    key = np.arange(8, dtype=np.uint32) * 0x01010101
+    assert (orc.chacha_block(key, 5, 12) == Engine.chacha_block(key, 5, 12)).all()
+
+
+def test_row_sampler_library_equals_oracle_and_is_a_sample():
+    from oracle import oracle as orc
+    from pantax_amd.engine import Engine
+    # every branch of rand::seq::index::sample: in-place (both cost-model halves), Floyd, rejection
+    for n, k in [(600000, 500000), (1000, 500), (200000, 500), (700000, 500), (50, 10), (1000, 20), (5000, 100),
+                 (501, 500), (20_000_000, 500000), (1, 1), (13, 12), (3000, 162), (3000, 163)]:
+        pos = orc.sample_sorted_positions(n, k)
+        bits = Engine.sample_ranks(n, k)
+        assert len(pos) == k and (np.diff(pos.astype(np.int64)) > 0).all() and pos[-1] < n
+        assert int(bits.sum()) == k and (np.nonzero(bits)[0] == pos).all(), (n, k)
+    # deterministic in (n, amount, seed); a different seed gives a different set
+    assert (orc.sample_sorted_positions(10000, 300) == orc.sample_sorted_positions(10000, 300)).all()
+    assert (orc.sample_sorted_positions(10000, 300, seed=43) != orc.sample_sorted_positions(10000, 300)).any()
+    # no gross bias: the mean chosen position sits in the middle
+    pos = orc.sample_sorted_positions(1_000_000, 500000).astype(np.float64)
+    assert abs(pos.mean() / 1e6 - 0.5) < 0.002
