@@ -269,7 +269,10 @@ struct Reads {
     uint64_t T_pad = 0;              // steps in the padded stream
     DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_slot_of;   // [T_pad] node ids, [T_pad] slot of each step, [R] read -> slot (~0: no walk)
     DevBuf<uint4> d_g_read_rec;      // [R'] {first step, #steps, pstart, pend}
-    DevBuf<uint8_t> d_g_step_dup;    // [T_pad] distance back to the first occurrence of the step's node in its walk (0 none, 255 = walk > 64 steps)
+    DevBuf<uint8_t> d_g_step_dup;    // [T_pad] walks <= 64 steps: distance back to the first occurrence of the step's node (0 none);
+                                     //         longer walks: 0x80 | (node occurred earlier in the walk)
+    DevBuf<uint32_t> d_long_sum;     // [R'] walks > 64 steps: node lengths of all steps but the last (walk_sum_kernel), else unused
+    uint32_t n_long = 0;             // walks of more than 64 steps
     DevBuf<int32_t> d_g_sp;          // [R'] species of the slot's read (-1: "U" or dropped row), written by the binning kernel
     bool binned = false;
 };

@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "primitives.hpp"
+#include "wave.hpp"
 
 namespace ptx {
 
@@ -68,15 +69,17 @@ __device__ __forceinline__ void mark_range(uint32_t *s_bm, uint32_t *__restrict_
     }
 }
 
-// read_nodes_len of position j (never the last position) recomputed from memory: the length aligned
-// at the node's FIRST occurrence in the read (profile.rs:879-882)
-__device__ __forceinline__ uint32_t rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, uint32_t first_id,
-                                                   uint32_t nb, const uint4 *__restrict__ node_rec, uint32_t len0, uint32_t ps) {
-    uint32_t idj = node_id[b + j];
-    int jf = -1;
-    for (uint32_t q = 0; q < j; ++q) if (node_id[b + q] == idj) { jf = (int)q; break; }
-    uint32_t src = jf < 0 ? j : (uint32_t)jf;
-    if (src == 0) return len0 - ps;
+// Step codes (g_step_dup): walks of <= 64 steps carry the distance back to the first occurrence of the step's node in
+// the walk (0 = none); longer walks carry STEP_LONG | (1 if the node occurred earlier in the walk).  Where the first
+// occurrence sits matters only through "is it step 0" (profile.rs:853-856 vs :860-862), i.e. id == id of step 0.
+constexpr uint32_t STEP_LONG = 0x80u;
+
+// read_nodes_len of position j (never the last position) of a long walk: the length aligned at the node's FIRST
+// occurrence in the read (profile.rs:879-882)
+__device__ __forceinline__ uint32_t rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup,
+                                                   uint32_t first_id, uint32_t nb, const uint4 *__restrict__ node_rec, uint32_t len0, uint32_t ps) {
+    const uint32_t idj = node_id[b + j];
+    if (j == 0 || ((step_dup[b + j] & 1u) && idj == node_id[b])) return len0 - ps;
     return node_rec[nb + (idj - first_id)].z;
 }
 
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
     const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases,
     uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
-    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort) {
+    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort, const uint32_t *__restrict__ long_sum) {
     __shared__ uint32_t s_win[COV_WIN];
     __shared__ uint32_t s_bm[COV_BWIN];
     const int lane = threadIdx.x & 63;
@@ -210,34 +213,18 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             uint32_t up = __shfl_up(incl, d);
             if (dist >= d) incl += up;
         }
-        // ---- first occurrence of this node in the read (:879): compare with the earlier lanes
-        // walks of <= 64 steps carry the answer from upload time (step_dup = distance back to the first occurrence,
-        // 0 = none); longer walks (code 255) compare through shuffles here and finish from memory below
-        int dmax = 0;
-        const bool scan_dup = ok && dupc == 255u;
-        if (__any(scan_dup)) {
-            for (int d = 1; __any(scan_dup && dist >= d); ++d) {
-                uint32_t other = __shfl_up(id, d);
-                if (scan_dup && dist >= d && other == id) dmax = d;
-            }
-        }
-        if (ok && dupc != 255u) dmax = (int)dupc;
+        // ---- first occurrence of this node in the read (:879): decided at upload time (step codes above)
+        const uint32_t id0 = __shfl(id, lane - dist);             // id of step 0 when the walk starts in this wave
         uint32_t rl = 0;
         if (ok) {
-            int jf = dmax ? (int)i - dmax : -1;
-            if (cross) {                                          // finish from memory
-                const uint32_t nprev = i - (uint32_t)lane;
-                for (uint32_t j = 0; j < nprev; ++j) if (node_id[b + j] == id) { jf = (int)j; break; }
-            }
+            int jf = -1;                                          // -1: first occurrence; 0: the node of step 0; 1: another earlier step
+            if (dupc & STEP_LONG) { if (dupc & 1u) jf = (id == (cross ? node_id[b] : id0)) ? 0 : 1; }
+            else if (dupc) jf = (int)i - (int)dupc;
             uint32_t aln, sidx;
             if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
             else if (i == k - 1) {                                // :857-859
                 uint32_t seen = incl - contrib;
-                if (cross) {
-                    const uint32_t nprev = i - (uint32_t)lane;
-                    seen += len0 - ps;
-                    for (uint32_t j = 1; j < nprev; ++j) seen += node_rec[nb + (node_id[b + j] - first_id)].z;
-                }
+                if (cross) seen = long_sum[slot] - ps;             // all steps but the last, from walk_sum_kernel
                 aln = target > (long long)seen ? (uint32_t)(target - (long long)seen) : 0u;   // max(target - seen, 0)
                 sidx = 0;
             } else { aln = nl; sidx = 0; }                        // :860-862
@@ -252,8 +239,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         if (WITH_TRIO) {                                          // :890-907
             uint32_t rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
             if (ok && i >= 2) {
-                if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, first_id, nb, node_rec, len0, ps);
-                if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, first_id, nb, node_rec, len0, ps);
+                if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, first_id, nb, node_rec, len0, ps);
+                if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, first_id, nb, node_rec, len0, ps);
                 int row = -1;
                 for (uint32_t j = 0; j < tn.y; ++j) {
                     const uint4 e = trio_ent[tn.x + j];
@@ -278,6 +265,43 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     }
 }
 
+// Walks of more than 64 steps: the last step needs `seen` = everything aligned before it (:857-859), which lives in
+// other waves.  One cheap pass over the steps of long walks adds the node lengths of all steps but the last into
+// long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
+__global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ step_read, const uint8_t *__restrict__ step_dup,
+                                                       const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
+                                                       const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ sp_first_id,
+                                                       const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec,
+                                                       uint32_t *__restrict__ long_sum) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)); base < T; base += (uint64_t)gridDim.x * 256) {
+        const uint64_t t = base + lane;
+        const uint32_t code = t < T ? step_dup[t] : 0u;
+        if (!__any(code & STEP_LONG)) continue;
+        uint32_t slot = NO_SLOT, nl = 0;
+        if (code & STEP_LONG) slot = step_read[t];
+        if (slot != NO_SLOT) {
+            const int sp = slot_species[slot];
+            const uint4 rr = read_rec[slot];
+            if (sp >= 0 && (uint32_t)(t - rr.x) + 1 < rr.y) {        // not the last step
+                const uint32_t first_id = sp_first_id[sp], nb = node_base[sp], id = node_id[t];
+                if (id >= first_id && id - first_id < node_base[sp + 1] - nb) nl = node_rec[nb + (id - first_id)].z;
+            }
+        }
+        // segmented sum over runs of equal slot (a walk's steps are contiguous), one atomic per run
+        const uint32_t prev = __shfl_up(slot, 1);
+        const bool head = lane == 0 || prev != slot;
+        const unsigned long long heads = __ballot(head);
+        uint32_t incl = nl;
+        const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));   // lane of my run's head
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane - d >= start) incl += up; }
+        const unsigned long long after = heads & ~((2ull << lane) - 1ull);
+        const bool tail = after ? (lane + 1 == __builtin_ctzll(after)) : lane == 63;
+        if (tail && slot != NO_SLOT && incl) atomicAdd(&long_sum[slot], incl);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Resident layout of the packed reads: grouped by the locus of their first node and padded so that
 // a walk of <= 64 steps never straddles a 64-step boundary.  Key = first node id >> shift (ids are
@@ -297,7 +321,8 @@ __global__ void __launch_bounds__(256) group_count_kernel(uint64_t R, const uint
 }
 __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
                                                          int shift, const uint32_t *__restrict__ base_r, uint32_t *__restrict__ cur_r,
-                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len) {
+                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len, uint32_t *__restrict__ n_long) {
+    uint32_t mine = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
         uint32_t slot = NO_SLOT;
@@ -305,8 +330,13 @@ __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint3
             const uint32_t key = node_id[b] >> shift;
             slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
             slot_len[slot] = k;
+            mine += k > 64 ? 1u : 0u;
         }
         slot_of[r] = slot;
+    }
+    if (__any(mine != 0)) {
+        mine = wave_reduce(mine, [](uint32_t x, uint32_t y) { return x + y; });
+        if ((threadIdx.x & 63) == 0) atomicAdd(n_long, mine);
     }
 }
 __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, const uint32_t *__restrict__ base_r /*[NB+1]*/,
@@ -335,18 +365,67 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint3
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
         const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
+        if (k > 64) continue;                            // laid out by group_fill_long_kernel, one workgroup per walk
         for (uint32_t i = 0; i < k; ++i) {
             const uint32_t id = node_id[b + i];
             g_node_id[sb + i] = id; g_step_read[sb + i] = slot;
-            uint32_t dup = 255u;                         // walks longer than a wave: decided in the coverage kernel
-            if (k <= 64) { dup = 0; for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = i - j; break; } }
+            uint32_t dup = 0;
+            for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = i - j; break; }
             g_step_dup[sb + i] = (uint8_t)dup;
+        }
+    }
+}
+
+// Walks of more than 64 steps: one workgroup copies the walk (coalesced) and decides for every step whether its node
+// occurred earlier in the walk -- an LDS hash of (node id -> smallest position) for walks of up to LONG_HASH/2 steps,
+// a plain scan of the earlier steps above that.
+constexpr uint32_t LONG_HASH = 8192;
+__global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+                                                              int shift, const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
+                                                              const uint32_t *__restrict__ slot_rel, uint32_t *__restrict__ g_node_id,
+                                                              uint32_t *__restrict__ g_step_read, uint8_t *__restrict__ g_step_dup) {
+    __shared__ uint32_t h_key[LONG_HASH], h_pos[LONG_HASH];
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    for (uint64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const uint32_t b = step_off[r], k = step_off[r + 1] - b;
+        if (k <= 64) continue;
+        const uint32_t slot = slot_of[r];
+        const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
+        for (uint32_t i = threadIdx.x; i < k; i += 256) { g_node_id[sb + i] = node_id[b + i]; g_step_read[sb + i] = slot; }
+        if (k <= LONG_HASH / 2) {
+            for (uint32_t i = threadIdx.x; i < LONG_HASH; i += 256) { h_key[i] = EMPTY; h_pos[i] = EMPTY; }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < k; i += 256) {
+                const uint32_t id = node_id[b + i];
+                uint32_t h = (id * 2654435761u) >> 19;             // 13 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&h_key[h], EMPTY, id);
+                    if (old == EMPTY || old == id) { atomicMin(&h_pos[h], i); break; }
+                    h = (h + 1) & (LONG_HASH - 1);
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < k; i += 256) {
+                const uint32_t id = node_id[b + i];
+                uint32_t h = (id * 2654435761u) >> 19;
+                while (h_key[h] != id) h = (h + 1) & (LONG_HASH - 1);
+                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | (h_pos[h] < i ? 1u : 0u));
+            }
+            __syncthreads();
+        } else {
+            for (uint32_t i = threadIdx.x; i < k; i += 256) {
+                const uint32_t id = node_id[b + i];
+                uint32_t dup = 0;
+                for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = 1; break; }
+                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | dup);
+            }
         }
     }
 }
 
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     rd->T_pad = 0;
+    rd->n_long = 0;
     PTX_HIP(ctx, rd->d_slot_of.alloc(rd->R ? rd->R : 1));
     PTX_HIP(ctx, rd->d_g_sp.alloc(rd->R ? rd->R : 1));
     if (rd->R == 0) return 0;
@@ -368,21 +447,31 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     hipLaunchKernelGGL(group_count_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, cnt_r);
     PTX_TRY(exclusive_scan_u32(ctx, cnt_r, base_r, NB + 1, scan_tmp.p, nullptr));
     PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));   // reused as cursors
+    uint32_t *d_total = (uint32_t *)ctx->d_scalars.p, *d_n_long = d_total + 1;
+    PTX_HIP(ctx, hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_r, cnt_r,
-                       rd->d_slot_of.p, slot_len.p);
+                       rd->d_slot_of.p, slot_len.p, d_n_long);
     hipLaunchKernelGGL(group_layout_kernel, dim3((NB + 255) / 256), dim3(256), 0, ctx->stream, NB, base_r, slot_len.p, slot_rel.p, size_s);
-    uint32_t *d_total = (uint32_t *)ctx->d_scalars.p;
     PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NB, scan_tmp.p, d_total));
-    uint32_t h_total = 0;
-    PTX_TRY(download(ctx, &h_total, d_total, 1));
+    uint32_t h_tot[2] = {0, 0};
+    PTX_TRY(download(ctx, h_tot, d_total, 2));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t h_total = h_tot[0];
+    rd->n_long = h_tot[1];
     if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
     rd->T_pad = h_total;
     PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0, rd->T_pad, ctx->stream));                             // pad steps carry no code
     hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
                        rd->d_pend.p, shift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
+    if (rd->n_long) {
+        const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
+        hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_s,
+                           rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
+        PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R));
+    }
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // temporaries are released on return
     return 0;
@@ -423,11 +512,18 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     unsigned long long *d_abort = db->d_abort;
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
     PTX_HIP(ctx, hipMemsetAsync(base, 0, total, ctx->stream));
+    if (rd->R && rd->T_pad && rd->n_long) {
+        PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
+        KTimer t(ctx, "walk_sum_kernel");
+        hipLaunchKernelGGL(walk_sum_kernel, dim3(grid_for(rd->T_pad, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
+                           rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, db->d_sp_first_id.p, db->d_node_base.p,
+                           db->d_node_rec.p, rd->d_long_sum.p);
+    }
     if (rd->R && rd->T_pad) {
         int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
 #define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_sp_first_id.p, \
-                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort
+                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p
         if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
         else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
 #undef COVS_ARGS

@@ -147,6 +147,62 @@ def test_long_reads_and_empty_inputs(eng):
     assert not bases.any() and not cov.any() and nab == 0
 
 
+def test_long_walks_with_revisits(eng):
+    """Walks of 65 .. 6000 steps (more than a wave, more than the upload-time hash holds) that come back to nodes they
+    have already visited, the first node included, with arbitrary start/end offsets: first-occurrence rule
+    (profile.rs:879-882), `seen` across waves (:857-859) and the trio windows at wave borders, bit for bit."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    sset = synth.make_set(91, 2, 4, 200, 200000, long_reads=True)
+    rng = np.random.default_rng(92)
+    offs, ids, ps, pe = [0], [], [], []
+    lens = [65, 66, 127, 128, 129, 200, 500, 1000, 2500, 4095, 4096, 4097, 6000] + list(rng.integers(65, 1500, size=120))
+    for n, k in enumerate(lens):
+        g = sset.species[n % 2]
+        h = int(rng.integers(0, g.n_paths))
+        path = g.path_nodes[int(g.path_off[h]):int(g.path_off[h + 1])]
+        walk = []
+        while len(walk) < k:                       # pieces of the path, each starting somewhere near what was already walked
+            if walk and rng.random() < 0.7:
+                at = int(np.clip(np.searchsorted(path, walk[int(rng.integers(0, len(walk)))]) + rng.integers(-3, 4), 0, len(path) - 1))
+            else:
+                at = int(rng.integers(0, len(path)))
+            piece = path[at:at + int(rng.integers(2, 400))]
+            if rng.random() < 0.5:
+                piece = piece[::-1]
+            walk.extend(int(x) for x in piece)
+            if rng.random() < 0.3:
+                walk.append(walk[0])              # back to the very first node
+        walk = np.array(walk[:k], dtype=np.int64)
+        total = int(g.node_len[walk].sum())
+        a = int(rng.integers(0, g.node_len[walk[0]] + 1))
+        mode = n % 4
+        b = a + [total - a - int(rng.integers(0, g.node_len[walk[-1]] + 1)), int(rng.integers(0, 50)), total + 77, total // 2][mode]
+        ids.append(walk + g.range_start)
+        offs.append(offs[-1] + k)
+        ps.append(a)
+        pe.append(max(b, 0))
+    R = len(lens)
+    rd = synth.PackedReads(np.array(offs, dtype=np.uint64), np.concatenate(ids).astype(np.uint32), np.zeros(offs[-1], np.uint8),
+                           np.array(ps, dtype=np.int64), np.array(pe, dtype=np.int64), np.full(R, 15000, np.int64), np.full(R, 60, np.int64),
+                           np.zeros(R, np.int64))
+    sset.reads = rd
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, *_ = eng.rcls_profile()
+    assert (sp == np.arange(R) % 2).all()
+    eng.trio_nodes_info(fetch=False)
+    bases, cov, tb, nab = eng.get_node_abundances()
+    assert nab == 0
+    trio_off = 0
+    for si, (G, T, b, c, t, na) in enumerate(_oracle_cov_per_species(sset, sp)):
+        lo, hi = int(eng.node_off[si]), int(eng.node_off[si + 1])
+        assert np.array_equal(bases[lo:hi], b) and np.array_equal(cov[lo:hi], c)
+        assert np.array_equal(tb[trio_off:trio_off + len(t)], t) and t.sum() > 0
+        trio_off += len(t)
+    assert trio_off == len(tb)
+
+
 def _paths_from_masks(mask, p):
     offs = [0]
     nodes = []
