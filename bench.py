@@ -142,12 +142,21 @@ def main():
     from pantax_amd.engine import Engine
     from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, profile_step
 
+    # PANTAX_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the
+    # exchange goes over gloo); the driver's runs use the default, RCCL with one GPU per rank
+    backend = os.environ.get("PANTAX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = TorchComm(device=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            comm = TorchComm(device=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            comm = TorchComm(device=None)
 
     # deterministic synthetic shard of this rank (seed = 20260501 + cfg index 2, + rank)
     seed = 20260501 + 2 + 1000 * rank
@@ -229,7 +238,7 @@ def main():
                          "end_to_end_mreads_per_s": args.reads / t_e2e / 1e6, "tables_equal_to_packed_input_run": bool(same)}
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -267,7 +276,8 @@ def main():
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
                                    "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),
-                       "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0},
+                       "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
+                       "exchange": "none" if world == 1 else ("rccl all_reduce" if backend == "nccl" else backend + " all_reduce (dry run)")},
             "from_gaf_text": gaf_extra,
             "roofline": roofline,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
@@ -279,10 +289,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sset, args.cpu_sample, cfg)
-        print(json.dumps(line))
-    eng.close()
+        print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()          # rank 0 is still timing the CPU baseline: nobody tears the communicator down before it is done
+    eng.close()
+    if world > 1:
         dist.destroy_process_group()
 
 
