@@ -190,6 +190,14 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
  * 2 = sample sort (n <= 600000). */
 int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo);
 
+/* filter_max_alignment_mt (gaf_filter.rs:44-97, called by alignment.rs:171 on long-read GAFs): per read id
+ * keep the line with the largest (matches, identity) if it also has mapq > 20 and span > 1000; one line per id.
+ * Parsed and grouped on the device; the kept lines are written in FILE ORDER (the reference's order and its choice
+ * among equal-best lines are rayon scheduling accidents; here: the first such line).  out_path NULL =
+ * "<stem>_filtered.gaf" beside the input.  Counters may be NULL. */
+int pantax_hip_gaf_filter(pantax_hip_ctx *ctx, const char *gaf_path, const char *out_path, uint64_t *n_lines,
+                          uint64_t *n_records, uint64_t *n_written);
+
 /* a11 (sample_sorted, profile.rs:1287-1295): which of n_valid rows `StdRng::seed_from_u64(seed)` +
  * `choose_multiple(sample_nodes)` keeps, as a bitmap over their ranks (bits_out: (n_valid+31)/32 words).  Host only.
  * rand 0.9.2 / rand_chacha 0.9.0 (Cargo.lock) are restated, not linked: parity with the crates is unpinned. */

@@ -201,6 +201,16 @@ def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.
     return rc, met, nc.value, o1.value, o2.value
 
 
+def gaf_filter(text):
+    """SURVEY 8f-3 (gaf_filter.rs:44-97): bool per raw line of `text` (bytes) = the line is written; also #records."""
+    keep = np.zeros(text.count(b"\n") + 2, dtype=np.uint8)
+    nrec = C.c_uint64(0)
+    lib().orc_gaf_filter.restype = C.c_int64
+    n = lib().orc_gaf_filter(C.c_char_p(text), C.c_uint64(len(text)), _p(keep), C.byref(nrec))
+    assert n >= 0
+    return keep[:n].astype(bool), nrec.value
+
+
 def sample_sorted_positions(length, amount, seed=42):
     """a11 (profile.rs:1287-1295): ascending positions rand 0.9.2's choose_multiple keeps (restated, parity unpinned)."""
     out = np.zeros(max(amount, 1), dtype=np.uint32)

@@ -829,3 +829,116 @@ int orc_abundance_constraint(double species_cov, uint32_t H, orc_hap_metrics *me
     }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* filter_max_alignment_mt, gaf_filter.rs:44-97           */
+/* ------------------------------------------------------------------ */
+typedef struct { const char *id; uint32_t id_len; uint64_t line; int32_t matches, mapq, span; double identity; } orc_aln;
+
+static int orc_is_space(char c) { return c == ' ' || (c >= 9 && c <= 13); }
+/* str::parse::<i32>() */
+static int orc_parse_i32(const char *b, const char *e, int32_t *out) {
+    if (b == e) return 0;
+    int neg = 0;
+    if (*b == '+' || *b == '-') { neg = *b == '-'; ++b; if (b == e) return 0; }
+    long long v = 0;
+    for (; b < e; ++b) { if (*b < '0' || *b > '9') return 0; v = v * 10 + (*b - '0'); if (v > 2147483648LL) return 0; }
+    if (neg) v = -v;
+    if (v > 2147483647LL) return 0;
+    *out = (int32_t)v;
+    return 1;
+}
+static int orc_word_ci(const char *b, const char *e, const char *w) {
+    size_t n = strlen(w);
+    if ((size_t)(e - b) != n) return 0;
+    for (size_t i = 0; i < n; ++i) if ((b[i] | 0x20) != w[i]) return 0;
+    return 1;
+}
+/* f64::from_str: [+-] (inf | infinity | nan | digits [. digits] [e [+-] digits]); value by the C library's correctly
+ * rounded strtod once the spelling is known to be one Rust accepts */
+static int orc_parse_f64(const char *b, const char *e, double *out) {
+    const char *p = b;
+    if (p < e && (*p == '+' || *p == '-')) ++p;
+    if (p == e) return 0;
+    if (!(orc_word_ci(p, e, "inf") || orc_word_ci(p, e, "infinity") || orc_word_ci(p, e, "nan"))) {
+        int nd = 0;
+        while (p < e && *p >= '0' && *p <= '9') { ++p; ++nd; }
+        if (p < e && *p == '.') { ++p; while (p < e && *p >= '0' && *p <= '9') { ++p; ++nd; } }
+        if (!nd) return 0;
+        if (p < e && (*p == 'e' || *p == 'E')) {
+            ++p;
+            if (p < e && (*p == '+' || *p == '-')) ++p;
+            if (p == e) return 0;
+            while (p < e) { if (*p < '0' || *p > '9') return 0; ++p; }
+        }
+        if (p != e) return 0;
+    }
+    char tmp[512];
+    size_t n = (size_t)(e - b);
+    char *z = n < sizeof(tmp) ? tmp : (char *)malloc(n + 1);
+    memcpy(z, b, n); z[n] = 0;
+    *out = strtod(z, NULL);
+    if (z != tmp) free(z);
+    return 1;
+}
+static int orc_aln_cmp(const void *a, const void *b) {
+    const orc_aln *x = (const orc_aln *)a, *y = (const orc_aln *)b;
+    uint32_t n = x->id_len < y->id_len ? x->id_len : y->id_len;
+    int c = memcmp(x->id, y->id, n);
+    if (c) return c;
+    if (x->id_len != y->id_len) return x->id_len < y->id_len ? -1 : 1;
+    return x->line < y->line ? -1 : x->line > y->line;
+}
+
+int64_t orc_gaf_filter(const char *text, uint64_t size, uint8_t *keep_out, uint64_t *n_records_out) {
+    uint64_t n_lines = 0, cap = 1024, n = 0;
+    orc_aln *rec = (orc_aln *)malloc(cap * sizeof(orc_aln));
+    for (uint64_t pos = 0; pos < size; ++n_lines) {
+        const char *nl = (const char *)memchr(text + pos, '\n', size - pos);
+        uint64_t end = nl ? (uint64_t)(nl - text) : size;
+        const char *b = text + pos, *e = text + end;
+        pos = end + 1;
+        keep_out[n_lines] = 0;
+        while (b < e && orc_is_space(*b)) ++b;             /* trim (also eats the '\r' lines() would drop) */
+        while (e > b && orc_is_space(e[-1])) --e;
+        const char *fb[16], *fe[16];
+        int nf = 0;
+        for (const char *q = b;;) {
+            const char *t = q;
+            while (t < e && *t != '\t') ++t;
+            fb[nf] = q; fe[nf] = t; ++nf;
+            if (t >= e || nf == 16) break;
+            q = t + 1;
+        }
+        if (nf < 16) continue;
+        orc_aln a;
+        int32_t s3, s2;
+        const char *ib = fb[15];
+        for (const char *c = fb[15]; c < fe[15]; ++c) if (*c == ':') ib = c + 1;
+        if (!orc_parse_i32(fb[9], fe[9], &a.matches) || !orc_parse_f64(ib, fe[15], &a.identity) || !orc_parse_i32(fb[11], fe[11], &a.mapq) ||
+            !orc_parse_i32(fb[3], fe[3], &s3) || !orc_parse_i32(fb[2], fe[2], &s2)) continue;
+        a.span = (int32_t)((uint32_t)s3 - (uint32_t)s2);
+        a.id = fb[0]; a.id_len = (uint32_t)(fe[0] - fb[0]); a.line = n_lines;
+        if (n == cap) { cap *= 2; rec = (orc_aln *)realloc(rec, cap * sizeof(orc_aln)); }
+        rec[n++] = a;
+    }
+    if (n_records_out) *n_records_out = n;
+    qsort(rec, n, sizeof(orc_aln), orc_aln_cmp);
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && rec[j].id_len == rec[i].id_len && memcmp(rec[j].id, rec[i].id, rec[i].id_len) == 0) ++j;
+        int32_t bm = rec[i].matches; double bi = rec[i].identity; int have = !(bi != bi);
+        for (uint64_t q = i; q < j; ++q) {                  /* best = max (matches, identity); a NaN identity never wins */
+            const orc_aln *r = &rec[q];
+            if (r->identity != r->identity) { if (r->matches > bm) { bm = r->matches; bi = r->identity; have = 0; } continue; }
+            if (r->matches > bm || (r->matches == bm && (!have || r->identity > bi))) { bm = r->matches; bi = r->identity; have = 1; }
+        }
+        if (have)
+            for (uint64_t q = i; q < j; ++q)
+                if (rec[q].mapq > 20 && rec[q].span > 1000 && rec[q].matches == bm && rec[q].identity == bi) { keep_out[rec[q].line] = 1; break; }
+        i = j;
+    }
+    free(rec);
+    return (int64_t)n_lines;
+}

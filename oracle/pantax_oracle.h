@@ -157,4 +157,13 @@ int orc_abundance_constraint(double species_coverage, uint32_t n_paths, orc_hap_
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- filter_max_alignment_mt (gaf_filter.rs:44-97) ----
+ * text = the whole GAF; lines end at '\n' (a '\r' before it is dropped, BufRead::lines).  keep_out[i] = 1 when raw
+ * line i is written.  parse_line (gaf_filter.rs:21-42): trim, split on tabs, >= 16 fields, i32 fields 9/11/3/2, f64 after
+ * the last ':' of field 15.  best per read id = max (matches, identity); written: mapq > 20, span > 1000, == best,
+ * one line per id -- the FIRST such line in file order (the reference's pick among ties and its output order depend
+ * on rayon's scheduling).  Returns the number of lines, or -1. */
+int64_t orc_gaf_filter(const char *text, uint64_t size, uint8_t *keep_out, uint64_t *n_records_out);
+
 #endif

@@ -1,0 +1,11 @@
+// gaf_scan.hpp -- shared front end of the device GAF readers (stage_gaf.hip, stage_gaf_filter.hip): the text goes to
+// HBM once through pinned chunks and every newline position is listed (two launches + one chained scan).
+#pragma once
+#include "common.hpp"
+
+namespace ptx {
+
+// d_txt: size + 16 bytes; nl_pos[n_nl] = byte offsets of the '\n's in order.  Line i = (nl_pos[i-1], nl_pos[i]).
+int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out);
+
+}  // namespace ptx

@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 #include "common.hpp"
+#include "gaf_scan.hpp"
 #include "host_io.hpp"
 #include "primitives.hpp"
 #include "wave.hpp"
@@ -194,6 +195,31 @@ static int upload_text(Ctx *ctx, uint8_t *d_dst, const char *text, uint64_t size
     return rc;
 }
 
+int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out) {
+    PTX_HIP(ctx, d_txt.alloc(size + 16));
+    PTX_TRY(upload_text(ctx, d_txt.p, text, size));
+    const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
+    DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
+    PTX_HIP(ctx, tile_cnt.alloc(n_tiles)); PTX_HIP(ctx, tile_base.alloc(n_tiles)); PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
+    {
+        KTimer t(ctx, "gaf_nl_count_kernel");
+        hipLaunchKernelGGL(gaf_nl_count_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_cnt.p);
+    }
+    PTX_TRY(exclusive_scan_u32(ctx, tile_cnt.p, tile_base.p, n_tiles, scan_tmp.p, tot.p));
+    uint32_t n_nl = 0;
+    PTX_TRY(download(ctx, &n_nl, tot.p, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PTX_HIP(ctx, nl_pos.alloc(n_nl ? n_nl : 1));
+    {
+        KTimer t(ctx, "gaf_nl_emit_kernel");
+        hipLaunchKernelGGL(gaf_nl_emit_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_base.p, nl_pos.p);
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the tile tables are released on return
+    *n_nl_out = n_nl;
+    return 0;
+}
+
 // after sorting the id hashes: how many adjacent pairs are equal (0 = every read id is distinct, the usual case, and
 // the host can skip its hash-set pass of the duplicate-id rule, profile.rs:361-437)
 __global__ void __launch_bounds__(256) dup_count_kernel(uint64_t n, const uint64_t *__restrict__ sorted, uint32_t *__restrict__ out) {
@@ -227,26 +253,11 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     if (size >= 0xFFFFFFF0ull) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu bytes exceed 32-bit text positions; split the input", (unsigned long long)size);
     DevBuf<uint8_t> d_txt;
-    PTX_HIP(ctx, d_txt.alloc(size + 16));
-    PTX_TRY(upload_text(ctx, d_txt.p, text, size));
-    const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
-    DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
-    PTX_HIP(ctx, tile_cnt.alloc(n_tiles)); PTX_HIP(ctx, tile_base.alloc(n_tiles)); PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
-    {
-        KTimer t(ctx, "gaf_nl_count_kernel");
-        hipLaunchKernelGGL(gaf_nl_count_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_cnt.p);
-    }
-    PTX_TRY(exclusive_scan_u32(ctx, tile_cnt.p, tile_base.p, n_tiles, scan_tmp.p, tot.p));
+    DevBuf<uint32_t> nl_pos, tot, scan_tmp;
     uint32_t n_nl = 0;
-    PTX_TRY(download(ctx, &n_nl, tot.p, 1));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl));
+    PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
     const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
-    DevBuf<uint32_t> nl_pos;
-    PTX_HIP(ctx, nl_pos.alloc(n_nl ? n_nl : 1));
-    {
-        KTimer t(ctx, "gaf_nl_emit_kernel");
-        hipLaunchKernelGGL(gaf_nl_emit_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_base.p, nl_pos.p);
-    }
     DevBuf<uint32_t> r32[8], ridx, soff;
     DevBuf<uint64_t> r_hash;
     DevBuf<uint8_t> r8[3];

@@ -263,6 +263,13 @@ class Engine:
             designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1)
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
 
+    def gaf_filter(self, gaf_path, out_path=None):
+        """filter_max_alignment_mt (gaf_filter.rs:44-97) on the device -> (lines, records, lines written)."""
+        nl, nr, nw = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.pantax_hip_gaf_filter(self.ctx, gaf_path.encode(), out_path.encode() if out_path else None,
+                                                   C.byref(nl), C.byref(nr), C.byref(nw)))
+        return nl.value, nr.value, nw.value
+
     @staticmethod
     def sample_ranks(n_valid, sample_nodes, seed=42):
         """a11: bool [n_valid], True where sample_sorted (profile.rs:1287-1295) keeps the row of that rank.  Host only."""

@@ -321,3 +321,41 @@ def test_cli_binary_matches_library_call(world):
     assert r.returncode != 0
     r = subprocess.run([exe, "-db", str(db), "-T", str(root), "--gaf", str(root / "nope.gaf"), "--species"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "valid file path" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(1, 200), (2, 5000), (3, 40000)])
+def test_device_gaf_filter_equals_oracle(eng, tmp_path, seed, n):
+    """pantax_hip_gaf_filter == filter_max_alignment_mt (gaf_filter.rs:44-97) as restated by the oracle: the written
+    lines are exactly the oracle's, in file order, with line ends normalised the way BufRead::lines + writeln! do."""
+    from oracle import oracle as orc
+    from tests.helpers import make_longread_gaf
+    txt = make_longread_gaf(seed, n)
+    gp = tmp_path / "gfa_mapped.gaf"
+    gp.write_bytes(txt)
+    n_lines, n_rec, n_written = eng.gaf_filter(str(gp))
+    keep, nrec = orc.gaf_filter(txt)
+    lines = txt.split(b"\n")
+    if txt.endswith(b"\n"):
+        lines = lines[:-1]
+    assert n_lines == len(lines) == len(keep) and n_rec == nrec and n_written == int(keep.sum()) > 0
+    exp = b"".join((lines[i][:-1] if lines[i].endswith(b"\r") else lines[i]) + b"\n" for i in np.nonzero(keep)[0])
+    out = tmp_path / "gfa_mapped_filtered.gaf"          # <stem>_filtered.gaf beside the input (gaf_filter.rs:46-49)
+    assert out.read_bytes() == exp
+    # explicit output path; filtering the filtered file changes nothing (idempotence)
+    out2 = tmp_path / "twice.gaf"
+    n2 = eng.gaf_filter(str(out), str(out2))
+    assert n2[0] == n_written and n2[2] == n_written and out2.read_bytes() == exp
+
+
+@pytest.mark.gpu
+def test_device_gaf_filter_edge_inputs(eng, tmp_path):
+    from pantax_amd.engine import PantaxHipError
+    empty = tmp_path / "empty.gaf"
+    empty.write_bytes(b"")
+    assert eng.gaf_filter(str(empty)) == (0, 0, 0) and (tmp_path / "empty_filtered.gaf").read_bytes() == b""
+    junk = tmp_path / "junk.gaf"
+    junk.write_bytes(b"\n\n@x\nnot\ta\trecord\n")
+    assert eng.gaf_filter(str(junk)) == (4, 0, 0)
+    with pytest.raises(PantaxHipError):
+        eng.gaf_filter(str(tmp_path / "missing.gaf"))

@@ -121,3 +121,47 @@ def test_optimize_species_synthetic():
     present = set(np.nonzero(g.truth_depth > 0)[0].tolist())
     called = {h for h, m in enumerate(d) if m["predicted_coverage"] not in (None, 0.0)}
     assert called == present
+
+
+def test_gaf_filter_hand_case():
+    """filter_max_alignment_mt (gaf_filter.rs:44-97) on lines small enough to decide by eye."""
+    from oracle import oracle as orc
+
+    def ln(rid, qs, qe, matches, mapq, ident, extra=""):
+        return "\t".join([rid, "20000", str(qs), str(qe), "+", ">1>2", "500", "0", "400", str(matches), "400", str(mapq),
+                          "NM:i:0", "AS:f:1", "dv:f:0", "id:f:" + ident]) + extra
+    lines = [
+        ln("a", 0, 5000, 900, 60, "0.99"),        # 0: best of a -> written
+        ln("a", 0, 5000, 800, 60, "1.0"),         # 1: fewer matches
+        ln("b", 0, 5000, 900, 60, "0.90"),        # 2: same matches, lower identity
+        ln("b", 0, 5000, 900, 20, "0.95"),        # 3: best of b but mapq 20 is not > 20 -> b writes nothing
+        ln("c", 0, 1000, 900, 60, "0.99"),        # 4: span 1000 is not > 1000
+        ln("d", 0, 1001, 900, 21, "0.99"),        # 5: written
+        ln("d", 0, 1001, 900, 21, "0.99"),        # 6: equal best: one line per id, the first
+        "e\t1\t2",                                # 7: not a record
+        ln("f", 0, 5000, 900, 60, "nan"),         # 8: NaN never equals the best
+        ln("g", 0, 5000, 900, 60, "9.9e-1") + "\r",   # 9: written, exponent spelling, CR dropped
+        "",                                       # 10
+        ln("h", 0, 5000, 900, 60, "0.5", "\tzz:Z:x"),   # 11: extra column, written
+    ]
+    keep, nrec = orc.gaf_filter("\n".join(lines).encode())
+    assert nrec == 10
+    assert np.nonzero(keep)[0].tolist() == [0, 5, 9, 11]
+    keep2, _ = orc.gaf_filter(("\n".join(lines) + "\n").encode())
+    assert keep2.tolist() == keep.tolist()
+
+
+def test_gaf_filter_generated_properties():
+    from oracle import oracle as orc
+    from tests.helpers import make_longread_gaf
+    txt = make_longread_gaf(3, 3000)
+    keep, nrec = orc.gaf_filter(txt)
+    lines = txt.split(b"\n")
+    if lines and lines[-1] == b"" and txt.endswith(b"\n"):
+        lines = lines[:-1]
+    assert len(keep) == len(lines) and 0 < keep.sum() < nrec
+    ids = [lines[i].strip().split(b"\t")[0] for i in np.nonzero(keep)[0]]
+    assert len(ids) == len(set(ids))              # one line per read id
+    for i in np.nonzero(keep)[0][:200]:
+        f = lines[i].strip().split(b"\t")
+        assert int(f[11]) > 20 and int(f[3]) - int(f[2]) > 1000
