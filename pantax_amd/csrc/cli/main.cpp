@@ -14,6 +14,8 @@ static void usage() {
             "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
             "  --min_cov N  --min_depth N  --sample N (default 500000)  --ds a,b,c  --smode 0|1  --no-filter\n"
             "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
+            "  --filter-gaf  first replace the GAF by its best alignment per read (long reads; alignment.rs:171-175, gaf_filter.rs)\n"
+            "  --filter-only <in.gaf> [<out.gaf>]   just write <stem>_filtered.gaf (or <out.gaf>) and exit\n"
             "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n");
 }
 
@@ -24,7 +26,8 @@ int main(int argc, char **argv) {
     c.min_species_abundance = 1e-4; c.unique_trio_nodes_fraction = -1; c.unique_trio_nodes_mean_count_f = 0.46;
     c.single_cov_ratio = 0.85; c.single_cov_diff = 0.2; c.filtered = 1; c.full = 1; c.mode = 2; c.sample_nodes = 500000;
     c.zip = "serialize"; c.world_size = 1;
-    bool long_read = false;
+    bool long_read = false, filter_gaf = false;
+    const char *filter_in = nullptr, *filter_out = nullptr;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -56,8 +59,20 @@ int main(int argc, char **argv) {
         else if (a == "--gfa") c.zip = nullptr;
         else if (a == "--zip") c.zip = next();        // serialize | lz | zstd (main.rs: --zip)
         else if (a == "--round") c.full = 0;
+        else if (a == "--filter-gaf") filter_gaf = true;
+        else if (a == "--filter-only") { filter_in = next(); if (i + 1 < argc && argv[i + 1][0] != '-') filter_out = argv[++i]; }
         else if (a == "--device") device = atoi(next());
         else { usage(); return 2; }
+    }
+    if (filter_in) {
+        pantax_hip_ctx *fctx = nullptr;
+        if (pantax_hip_init(&fctx, &device, 1) != 0) { fprintf(stderr, "pantax-hip: %s\n", pantax_hip_last_error(nullptr)); return 1; }
+        uint64_t nl = 0, nr = 0, nw = 0;
+        const int frc = pantax_hip_gaf_filter(fctx, filter_in, filter_out, &nl, &nr, &nw);
+        if (frc != 0) fprintf(stderr, "pantax-hip: error %d: %s\n", frc, pantax_hip_last_error(fctx));
+        else printf("Filtered GAF: %llu lines, %llu alignment records, %llu written\n", (unsigned long long)nl, (unsigned long long)nr, (unsigned long long)nw);
+        pantax_hip_destroy(fctx);
+        return frc == 0 ? 0 : 1;
     }
     if (!c.db || !c.input_aln_file) { usage(); return 2; }
     if (c.unique_trio_nodes_fraction < 0) c.unique_trio_nodes_fraction = long_read ? 0.5 : 0.3;   // main.rs:108-114
@@ -65,6 +80,13 @@ int main(int argc, char **argv) {
     pantax_hip_ctx *ctx = nullptr;
     int rc = pantax_hip_init(&ctx, &device, 1);
     if (rc != 0) { fprintf(stderr, "pantax-hip: %s\n", pantax_hip_last_error(nullptr)); return 1; }
+    std::string filtered;
+    if (filter_gaf) {   // alignment.rs:171-175: filter, then the filtered file takes the GAF's place
+        filtered = std::string(c.input_aln_file) + ".best.tmp";
+        rc = pantax_hip_gaf_filter(ctx, c.input_aln_file, filtered.c_str(), nullptr, nullptr, nullptr);
+        if (rc == 0 && rename(filtered.c_str(), c.input_aln_file) != 0) { fprintf(stderr, "pantax-hip: cannot replace %s\n", c.input_aln_file); rc = 1; }
+        if (rc != 0) { if (rc != 1) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx)); pantax_hip_destroy(ctx); return 1; }
+    }
     rc = pantax_hip_profile(ctx, &c);
     if (rc != 0) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx));
     pantax_hip_destroy(ctx);

@@ -11,6 +11,7 @@
 // counters are staged in an LDS histogram and flushed with one 64-bit atomic per touched bin.
 #include <algorithm>
 #include "common.hpp"
+#include "wave.hpp"
 
 namespace ptx {
 
@@ -63,15 +64,39 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
         int sp = -1;
         uint32_t q = 0;
         bool lm = false, uq = false;
+        uint32_t b = 0, e = 0;
+        if (r < R) { b = step_off[r]; e = step_off[r + 1]; }
+        uint32_t mn = 0xFFFFFFFFu, mx = 0;
+        // walks of more than 64 steps (long reads): the wave's four 16-lane rows each scan one such walk at a time (one
+        // 64-byte line per row and iteration), the row's min / max come from four DPP steps
+        const bool long_walk = e - b > 64u;
+        const int row = lane >> 4, rl = lane & 15;
+        for (unsigned long long todo = __ballot(long_walk); todo;) {
+            int src = -1;
+            unsigned long long t = todo;
+            for (int q = 0; q <= row && t; ++q) { src = (q == row) ? __ffsll((long long)t) - 1 : -1; t &= t - 1; }   // my row's walk: the row-th pending lane
+            for (int q = 0; q < 4 && todo; ++q) todo &= todo - 1;
+            const uint32_t bb = __shfl(b, src < 0 ? 0 : src), ee = __shfl(e, src < 0 ? 0 : src);
+            uint32_t m1 = 0xFFFFFFFFu, m2 = 0;
+            if (src >= 0)
+                for (uint32_t i = bb + rl; i < ee; i += 16) { const uint32_t v = node_id[i]; m1 = min(m1, v); m2 = max(m2, v); }
+            m1 = row_reduce(m1, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+            m2 = row_reduce(m2, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+            // the owner lane may sit in another row: fetch the result from the row that scanned its walk
+            for (int rr = 0; rr < 4; ++rr) {
+                const int owner = __shfl(src, rr * 16);
+                const uint32_t a1 = __shfl(m1, rr * 16), a2 = __shfl(m2, rr * 16);
+                if (owner >= 0 && lane == owner) { mn = a1; mx = a2; }
+            }
+        }
         if (r < R) {
-            uint32_t b = step_off[r], e = step_off[r + 1];
             if (e > b) {
-                uint32_t mn = 0xFFFFFFFFu, mx = 0;
-                for (uint32_t i = b; i < e; ++i) {
-                    uint32_t v = node_id[i];
-                    mn = min(mn, v);
-                    mx = max(mx, v);
-                }
+                if (!long_walk)
+                    for (uint32_t i = b; i < e; ++i) {
+                        uint32_t v = node_id[i];
+                        mn = min(mn, v);
+                        mx = max(mx, v);
+                    }
                 sp = find_species<SORTED>(mn, mx, rs, re, ridx, S);
             }
             species_out[r] = sp;

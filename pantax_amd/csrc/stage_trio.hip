@@ -18,6 +18,7 @@
 // Row order (species, hap, position) replaces the reference's FxHashSet iteration order, which
 // is arbitrary; results are compared as keyed sets.
 #include <algorithm>
+#include <cstdlib>
 #include "primitives.hpp"
 #include "wave.hpp"
 #include "scan_chained.hpp"
@@ -101,6 +102,75 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
             for (uint64_t j = (wend > b0 ? wend : b0); j < b1 && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
         }
         if (valid && !dup) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
+    }
+}
+// 3'. the same test through an LDS hash table, for graphs where many haplotypes share their nodes (buckets of tens of
+//     entries, nearly all of them equal): a workgroup owns the buckets that START inside its slice of UNIQ_CH
+//     entries (bucket_off is searched for the two slice ends), so every bucket is seen whole by one workgroup.  Each
+//     entry claims or joins the table slot of its (g, b, c) and counts itself there; unique <=> the count is 1.  O(1)
+//     per window instead of O(bucket).  A slice that does not fit the LDS copy (one bucket of thousands of entries)
+//     falls back to scanning the bucket in memory.
+constexpr uint32_t UNIQ_CH = 1024, UNIQ_CAP = 1536, UNIQ_SLOTS = 4096;
+__device__ __forceinline__ uint32_t uniq_hash(uint32_t g, uint32_t b, uint32_t c) {
+    uint32_t h = g * 0x9E3779B1u;
+    h = (h ^ b) * 0x85EBCA77u;
+    h = (h ^ c) * 0xC2B2AE3Du;
+    return (h ^ (h >> 15)) & (UNIQ_SLOTS - 1);
+}
+__global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint32_t V, const uint4 *__restrict__ bucket,
+                                                            const uint32_t *__restrict__ bucket_off, uint8_t *__restrict__ uniq_q,
+                                                            uint32_t *__restrict__ first_cnt) {
+    __shared__ uint32_t s_g[UNIQ_CAP], s_b[UNIQ_CAP], s_c[UNIQ_CAP];
+    __shared__ uint32_t s_tab[UNIQ_SLOTS], s_cnt[UNIQ_SLOTS];
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    // first bucket start >= x (bucket_off[0..V] ascending, bucket_off[V] = n_win)
+    auto first_start = [&](uint64_t x) -> uint64_t {
+        if (x >= n_win) return n_win;
+        uint32_t lo = 0, hi = V;                       // smallest v with bucket_off[v] >= x
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)bucket_off[mid] < x) lo = mid + 1; else hi = mid; }
+        return bucket_off[lo];
+    };
+    const uint64_t lo = first_start((uint64_t)blockIdx.x * UNIQ_CH), hi = first_start((uint64_t)(blockIdx.x + 1) * UNIQ_CH);
+    if (hi <= lo) return;
+    const uint32_t n = (uint32_t)(hi - lo);
+    if (n > UNIQ_CAP) {                                // oversized bucket(s): plain scan of each entry's bucket
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const uint4 me = bucket[i];
+            bool dup = false;
+            for (uint32_t j = bucket_off[me.w], e = bucket_off[me.w + 1]; j < e && !dup; ++j)
+                if (j != i) { const uint4 o = bucket[j]; dup = o.y == me.y && o.z == me.z; }
+            if (!dup) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[me.w], 1u); }
+        }
+        return;
+    }
+    for (uint32_t k = threadIdx.x; k < UNIQ_SLOTS; k += 256) { s_tab[k] = EMPTY; s_cnt[k] = 0; }
+    uint32_t my_q[UNIQ_CAP / 256], my_slot[UNIQ_CAP / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(UNIQ_CAP / 256); ++k) {
+        const uint32_t t = threadIdx.x + k * 256;
+        if (t < n) { const uint4 me = bucket[lo + t]; my_q[k] = me.x; s_b[t] = me.y; s_c[t] = me.z; s_g[t] = me.w; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(UNIQ_CAP / 256); ++k) {
+        const uint32_t t = threadIdx.x + k * 256;
+        if (t >= n) continue;
+        const uint32_t g = s_g[t], b = s_b[t], c = s_c[t];
+        uint32_t h = uniq_hash(g, b, c);
+        for (;;) {
+            uint32_t cur = s_tab[h];
+            if (cur == EMPTY) cur = atomicCAS(&s_tab[h], EMPTY, t);
+            if (cur == EMPTY || (s_g[cur] == g && s_b[cur] == b && s_c[cur] == c)) break;
+            h = (h + 1) & (UNIQ_SLOTS - 1);
+        }
+        atomicAdd(&s_cnt[h], 1u);
+        my_slot[k] = h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(UNIQ_CAP / 256); ++k) {
+        const uint32_t t = threadIdx.x + k * 256;
+        if (t < n && s_cnt[my_slot[k]] == 1u) { uniq_q[my_q[k]] = 1; atomicAdd(&first_cnt[s_g[t]], 1u); }
     }
 }
 // 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
@@ -215,8 +285,15 @@ int trio_index_build(Ctx *ctx, Db *db) {
         for (uint32_t h = 0; h < H; ++h) { uint64_t l = db->h_path_off[h + 1] - db->h_path_off[h]; if (l >= 3) n_win += l - 2; }
         if (n_win) {
             KTimer t(ctx, "trio_uniq_kernel");
-            hipLaunchKernelGGL(trio_uniq_kernel, dim3(grid_for(n_win, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_win, ts.bucket.p,
-                               ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
+            // mean bucket size decides: short buckets (few haplotypes per node) compare through shuffles, long ones hash
+            bool hashed = n_win > 16 * V;   // measured: 7 windows per node -> shuffles 0.050 vs hash 0.058 ms; 34 per node -> 4.66 vs 1.69 ms
+            if (const char *ev = std::getenv("PANTAX_UNIQ_HASH")) hashed = ev[0] == '1';
+            if (hashed)
+                hipLaunchKernelGGL(trio_uniq_lds_kernel, dim3((uint32_t)((n_win + UNIQ_CH - 1) / UNIQ_CH)), dim3(256), 0, ctx->stream, n_win, (uint32_t)V,
+                                   ts.bucket.p, ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
+            else
+                hipLaunchKernelGGL(trio_uniq_kernel, dim3(grid_for(n_win, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_win, ts.bucket.p,
+                                   ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
         hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0

@@ -42,6 +42,12 @@ __device__ __forceinline__ T wave_reduce(T v, Op op) {
     v = op(v, dpp<0xB1>(v)); v = op(v, dpp<0x4E>(v)); v = op(v, dpp<0x124>(v)); v = op(v, dpp<0x128>(v));
     return op(op(lane_get(v, 0), lane_get(v, 16)), op(lane_get(v, 32), lane_get(v, 48)));
 }
+// the first four steps alone: every lane holds the result of its own 16-lane row
+template <class T, class Op>
+__device__ __forceinline__ T row_reduce(T v, Op op) {
+    v = op(v, dpp<0xB1>(v)); v = op(v, dpp<0x4E>(v)); v = op(v, dpp<0x124>(v)); v = op(v, dpp<0x128>(v));
+    return v;
+}
 // lexicographic pair reductions: (a, b) "better" as decided by `better(a2, b2, a, b)`
 template <class A, class B, class Better>
 __device__ __forceinline__ void wave_reduce_pair(A &a, B &b, Better better) {

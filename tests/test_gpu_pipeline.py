@@ -346,6 +346,13 @@ def test_device_gaf_filter_equals_oracle(eng, tmp_path, seed, n):
     out2 = tmp_path / "twice.gaf"
     n2 = eng.gaf_filter(str(out), str(out2))
     assert n2[0] == n_written and n2[2] == n_written and out2.read_bytes() == exp
+    if seed == 2:   # the stand-alone front end
+        import subprocess
+        exe = os.path.join(ROOT, "pantax_amd", "lib", "pantax-hip")
+        out3 = tmp_path / "cli.gaf"
+        r = subprocess.run([exe, "--filter-only", str(gp), str(out3)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "%d written" % n_written in r.stdout, r.stderr
+        assert out3.read_bytes() == exp
 
 
 @pytest.mark.gpu
