@@ -70,10 +70,14 @@ def test_micro_coverage_golden(eng):
         assert tb.tolist() == e["trio_bases"]
 
 
-@pytest.mark.parametrize("seed,S,H,R,L", [(1, 1, 4, 3000, 15000), (2, 3, 6, 20000, 40000), (3, 5, 10, 50000, 30000)])
-def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L):
+@pytest.mark.parametrize("seed,S,H,R,L,uniq", [(1, 1, 4, 3000, 15000, None), (2, 3, 6, 20000, 40000, None), (3, 5, 10, 50000, 30000, None),
+                                                  (4, 2, 40, 20000, 20000, None),   # > 16 windows per node: the hashed uniqueness test
+                                                  (2, 3, 6, 20000, 40000, "1"), (4, 2, 40, 20000, 20000, "0")])   # and each form forced
+def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch):
     from oracle import oracle as orc
     from pantax_amd import synth
+    if uniq is not None:
+        monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)   # read by the library at every trio build
     sset = synth.make_set(seed, S, H, R, L, adversarial_frac=0.01, single_strain_every=4 if S >= 5 else 0)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -103,6 +107,27 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L):
             assert np.array_equal(hto[h0:h1 + 1] - hto[h0], T.hap_off)
             assert np.array_equal(tb[u0:u1], t)
     assert nab == tot_abort
+
+
+@pytest.mark.parametrize("uniq", ["0", "1"])
+def test_trio_index_with_huge_buckets(eng, uniq, monkeypatch):
+    """Paths that keep coming back to a handful of nodes: thousands of windows share their smallest end node, far more
+    than one workgroup's LDS table holds (the hashed form falls back to scanning the bucket), and most trios repeat."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)
+    rng = np.random.default_rng(17)
+    V, H, K = 9, 40, 300
+    node_len = rng.integers(1, 40, size=V).astype(np.int64)
+    walks = [rng.integers(0, V, size=K).astype(np.uint32) for _ in range(H)]
+    for h in range(0, H, 5):                       # and some stretches nobody else has
+        walks[h] = np.concatenate([walks[h], np.array([0, 8, 0, 8, 7, 7, 7, h % V, 3], dtype=np.uint32)])
+    path_off = np.concatenate([[0], np.cumsum([len(w) for w in walks])]).astype(np.uint64)
+    g = _G(node_len, path_off, np.concatenate(walks), 1)
+    eng.upload_db([g])
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    T = orc.TrioTable(orc.Graph(node_len, path_off, np.concatenate(walks)))
+    assert len(abc) == T.n_unique
+    assert np.array_equal(abc, T.abc) and np.array_equal(hap, T.hap) and np.array_equal(ln, T.len) and np.array_equal(hto, T.hap_off)
 
 
 def test_species_active_mask_and_flags(eng):
