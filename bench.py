@@ -140,7 +140,7 @@ def main():
     import torch
     from pantax_amd import synth
     from pantax_amd.engine import Engine
-    from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, profile_step
+    from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, profile_step, profile_steps_pipelined
 
     # PANTAX_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the
     # exchange goes over gloo); the driver's runs use the default, RCCL with one GPU per rank
@@ -199,9 +199,11 @@ def main():
     eng.timing_filter(dom)
     eng.timing_reset()
     barrier()
+    # K steps back to back; with N > 1 the all-reduce of step i is in flight while step i+1 computes (every step's tables
+    # are complete before the closing barrier)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species, rows_max=args.species * args.haps)
+    out = profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg, comm, shard_max=args.species,
+                                  rows_max=args.species * args.haps)[-1]
     barrier()
     dt = time.perf_counter() - t0
     timings = eng.timing_get()
@@ -213,8 +215,8 @@ def main():
     profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species, rows_max=args.species * args.haps)
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species, rows_max=args.species * args.haps)
+    profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg_cached, comm, shard_max=args.species,
+                            rows_max=args.species * args.haps)
     barrier()
     dt_cached = time.perf_counter() - t1
     # extra (not `value`): the same workload from GAF TEXT on disk -- device tokenizer (a1) -> resident reads -> one step
@@ -277,7 +279,7 @@ def main():
             "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
                                    "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),
                        "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
-                       "exchange": "none" if world == 1 else ("rccl all_reduce" if backend == "nccl" else backend + " all_reduce (dry run)")},
+                       "exchange": "none" if world == 1 else ("one rccl all_reduce per step, in flight during the next step" if backend == "nccl" else backend + " all_reduce (dry run)")},
             "from_gaf_text": gaf_extra,
             "roofline": roofline,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},

@@ -35,6 +35,12 @@ class LocalComm:
     def exchange(self, slab):
         return np.asarray(slab, dtype=np.float64)[None]
 
+    def exchange_begin(self, slab):
+        return np.asarray(slab, dtype=np.float64)[None]
+
+    def exchange_end(self, handle):
+        return handle
+
     def names(self, species_names, hap_names):
         return [list(species_names)], [list(hap_names)]
 
@@ -51,19 +57,32 @@ class TorchComm:
         self._names = None
         self._buf = None
 
-    def exchange(self, slab):
-        """slab [rows, k] float64, same shape on every rank -> [world, rows, k].  ONE all-reduce(sum) of a zero-padded
-        buffer: each rank fills only its own slice, so the sum IS the gather and a single small collective suffices
-        (xGMI is point-to-point: the cost of a step's exchange is one latency-bound ring pass over a few KB)."""
+    def exchange_begin(self, slab):
+        """slab [rows, k] float64, same shape on every rank.  Starts ONE all-reduce(sum) of a zero-padded
+        [world, rows, k] buffer: each rank fills only its own slice, so the sum IS the gather and a single small
+        collective suffices (xGMI is point-to-point: the cost of a step's exchange is one latency-bound ring pass over
+        a few KB).  Returns a handle for exchange_end; two buffers alternate, so one exchange may be in flight while
+        the next step's kernels run (the collective executes on RCCL's own stream)."""
         slab = np.asarray(slab, dtype=np.float64)
-        if self._buf is None or tuple(self._buf.shape[1:]) != slab.shape:
-            self._buf = self.torch.zeros((self.world,) + slab.shape, dtype=self.torch.float64,
-                                         device=self.device if self.device is not None else "cpu")
-        else:
-            self._buf.zero_()
-        self._buf[self.rank].copy_(self.torch.from_numpy(slab))
-        self.dist.all_reduce(self._buf, op=self.dist.ReduceOp.SUM)
-        return self._buf.cpu().numpy()
+        if self._buf is None or tuple(self._buf[0].shape[1:]) != slab.shape:
+            dev = self.device if self.device is not None else "cpu"
+            self._buf = [self.torch.zeros((self.world,) + slab.shape, dtype=self.torch.float64, device=dev) for _ in range(2)]
+            self._turn = 0
+        buf = self._buf[self._turn]
+        self._turn ^= 1
+        buf.zero_()
+        buf[self.rank].copy_(self.torch.from_numpy(slab))
+        work = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, async_op=True)
+        return (work, buf)
+
+    def exchange_end(self, handle):
+        """-> [world, rows, k] on the host."""
+        work, buf = handle
+        work.wait()
+        return buf.cpu().numpy()
+
+    def exchange(self, slab):
+        return self.exchange_end(self.exchange_begin(slab))
 
     def names(self, species_names, hap_names):
         """Static metadata: gathered once, not per step."""
@@ -122,11 +141,9 @@ def local_stage(eng, avg_len, cfg, single_call=True):
 _ROW_K = 10   # columns of the exchanged slab
 
 
-def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None, rows_max=None):
-    """The one cross-rank exchange + the final tables (pure host code: no device, testable under gloo).
-    Every rank contributes one fixed-shape slab: [n_species, n_rows | species: keep, predicted_coverage, sum of all
-    strain coverages, sum of passing | candidate strain rows: species, hap, coverage, Option bits, six metrics].
-    shard_max / rows_max: upper bounds of species / strain rows per rank (identical on all ranks)."""
+def finalize_begin(local, hap_names, comm, shard_max=None, rows_max=None):
+    """First half of finalize_stage: pack this rank's slab and START the exchange; returns a handle for finalize_end.
+    The collective runs while the caller enqueues its next step."""
     keep, absolute = local["keep"], local["absolute"]
     rows = local["rows"]
     S_loc = len(keep)
@@ -143,7 +160,21 @@ def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None, r
         r[0], r[1], r[2] = s_, h_, cov
         r[3] = sum(1 << i for i, v in enumerate(opt) if v is not None)
         r[4:4 + len(opt)] = [0.0 if v is None else v for v in opt]
-    glob = comm.exchange(slab)                                       # [world, rows, K]
+    return comm.exchange_begin(slab), S_max
+
+
+def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None, rows_max=None):
+    """The one cross-rank exchange + the final tables (pure host code: no device, testable under gloo).
+    Every rank contributes one fixed-shape slab: [n_species, n_rows | species: keep, predicted_coverage, sum of all
+    strain coverages, sum of passing | candidate strain rows: species, hap, coverage, Option bits, six metrics].
+    shard_max / rows_max: upper bounds of species / strain rows per rank (identical on all ranks)."""
+    return finalize_end(finalize_begin(local, hap_names, comm, shard_max, rows_max), species_names, hap_names, cfg, comm)
+
+
+def finalize_end(pending, species_names, hap_names, cfg, comm):
+    """Second half: wait for the exchange, derive the global normalisers, build the tables on rank 0."""
+    handle, S_max = pending
+    glob = comm.exchange_end(handle)                                 # [world, rows, K]
     W = glob.shape[0]
     n_sp = [int(round(glob[r, 0, 0])) for r in range(W)]
     n_rw = [int(round(glob[r, 0, 1])) for r in range(W)]
@@ -169,6 +200,30 @@ def finalize_stage(local, species_names, hap_names, cfg, comm, shard_max=None, r
     species_rows.sort(key=lambda t: -t[1])     # profile.rs:344
     strain_rows.sort(key=lambda t: -t[3])      # profile.rs:3247-3248
     return species_rows, strain_rows, n_active
+
+
+def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg=None, comm=None, shard_max=None, rows_max=None,
+                            next_input=None):
+    """n_steps passes back to back (a stream of samples): the exchange of step i is in flight while step i+1 computes,
+    and its tables are built after step i+1's single host wait.  next_input(i), if given, is called before step i to
+    swap in that step's reads.  Returns the list of (species_rows, strain_rows, stats), same as n_steps calls of
+    profile_step."""
+    cfg = cfg or StepConfig()
+    comm = comm or LocalComm()
+    out, pending = [], None
+    for i in range(n_steps):
+        if next_input is not None:
+            next_input(i)
+        local = local_stage(eng, avg_len, cfg, True)
+        nxt = (finalize_begin(local, hap_names, comm, shard_max, rows_max), local["stats"])
+        if pending is not None:
+            sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
+            out.append((sr, tr, dict(pending[1], n_active=n_active)))
+        pending = nxt
+    if pending is not None:
+        sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
+        out.append((sr, tr, dict(pending[1], n_active=n_active)))
+    return out
 
 
 def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, shard_max=None, single_call=True, rows_max=None):
