@@ -40,86 +40,152 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         *out = db.release();
         return 0;
     }
-    db->V = g->node_off[S];
-    db->H = g->hap_off[S];
-    db->P = g->path_off[db->H];
-    if (db->V >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu nodes on one GPU exceeds the 32-bit node index", (unsigned long long)db->V);
-    db->h_range_start.assign(g->range_start, g->range_start + S);
-    db->h_range_end.assign(g->range_end, g->range_end + S);
-    db->h_node_off.assign(g->node_off, g->node_off + S + 1);
-    db->h_hap_off.assign(g->hap_off, g->hap_off + S + 1);
-    db->h_path_off.assign(g->path_off, g->path_off + db->H + 1);
-    db->h_node_len.assign(g->node_len, g->node_len + db->V);
-    db->h_path_nodes.assign(g->path_nodes, g->path_nodes + db->P);
+    // full db: one part per species, pointing into the caller's flat arrays
+    std::vector<GraphPart> parts(S);
     for (uint32_t s = 0; s < S; ++s) {
-        if (g->range_start[s] < 1 || g->range_end[s] > 0xFFFFFFFFll || g->range_end[s] < g->range_start[s])
-            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u has an invalid node id range [%lld,%lld]", s, (long long)g->range_start[s], (long long)g->range_end[s]);
-        uint64_t nv = g->node_off[s + 1] - g->node_off[s];
+        const uint64_t h0 = g->hap_off[s], h1 = g->hap_off[s + 1];
+        parts[s] = GraphPart{g->node_len + g->node_off[s], g->node_off[s + 1] - g->node_off[s], h1 - h0, g->path_off + h0, g->path_nodes + g->path_off[h0]};
+    }
+    db.reset();
+    return db_upload_parts(ctx, S, g->range_start, g->range_end, parts.data(), out);
+}
+
+}  // extern "C"
+
+namespace ptx {
+
+// The resident DB from one part per species (the file seam hands over its parsed graphs as they are: nothing is
+// concatenated on the host).  part.path_off[h] - part.path_off[0] indexes part.path_nodes.
+int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out) {
+    std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
+    db->S = S;
+    const int n_thr = 8;
+    db->h_node_off.assign(S + 1, 0); db->h_hap_off.assign(S + 1, 0);
+    for (uint32_t s = 0; s < S; ++s) { db->h_node_off[s + 1] = db->h_node_off[s] + parts[s].n_nodes; db->h_hap_off[s + 1] = db->h_hap_off[s] + parts[s].n_haps; }
+    db->V = db->h_node_off[S];
+    db->H = db->h_hap_off[S];
+    db->h_path_off.assign(db->H + 1, 0);
+    for (uint32_t s = 0; s < S; ++s)
+        for (uint64_t h = 0; h < parts[s].n_haps; ++h) {
+            const uint64_t gh = db->h_hap_off[s] + h;
+            db->h_path_off[gh + 1] = db->h_path_off[gh] + (parts[s].path_off[h + 1] - parts[s].path_off[h]);
+        }
+    db->P = db->h_path_off[db->H];
+    if (db->V >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu nodes on one GPU exceeds the 32-bit node index", (unsigned long long)db->V);
+    db->h_range_start.assign(range_start, range_start + S);
+    db->h_range_end.assign(range_end, range_end + S);
+    for (uint32_t s = 0; s < S; ++s) {
+        if (range_start[s] < 1 || range_end[s] > 0xFFFFFFFFll || range_end[s] < range_start[s])
+            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u has an invalid node id range [%lld,%lld]", s, (long long)range_start[s], (long long)range_end[s]);
         // optimize_otu derives nvert from the range (profile.rs:2938); the graph must agree
-        if ((uint64_t)(g->range_end[s] - g->range_start[s] + 1) != nv)
-            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u range spans %lld ids but its graph has %llu nodes", s, (long long)(g->range_end[s] - g->range_start[s] + 1), (unsigned long long)nv);
+        if ((uint64_t)(range_end[s] - range_start[s] + 1) != parts[s].n_nodes)
+            return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u range spans %lld ids but its graph has %llu nodes", s, (long long)(range_end[s] - range_start[s] + 1), (unsigned long long)parts[s].n_nodes);
     }
     // binning table: sorted by start when the ranges are pairwise disjoint (sort_range.rs:25-33
     // builds them contiguous), otherwise file order + linear scan
     std::vector<uint32_t> order(S);
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g->range_start[a] < g->range_start[b]; });
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return range_start[a] < range_start[b]; });
     bool disjoint = true;
     for (uint32_t i = 0; i + 1 < S; ++i)
-        if (g->range_end[order[i]] >= g->range_start[order[i + 1]]) disjoint = false;
+        if (range_end[order[i]] >= range_start[order[i + 1]]) disjoint = false;
     db->ranges_sorted_disjoint = disjoint;
     if (!disjoint) std::iota(order.begin(), order.end(), 0u);
     std::vector<uint32_t> rs(S), re(S), first_id(S), node_base(S + 1), hap_species(db->H);
     for (uint32_t i = 0; i < S; ++i) {
-        rs[i] = (uint32_t)g->range_start[order[i]];
-        re[i] = (uint32_t)g->range_end[order[i]];
-        first_id[i] = (uint32_t)g->range_start[i];
-        node_base[i] = (uint32_t)g->node_off[i];
-        for (uint64_t h = g->hap_off[i]; h < g->hap_off[i + 1]; ++h) hap_species[h] = i;
+        rs[i] = (uint32_t)range_start[order[i]];
+        re[i] = (uint32_t)range_end[order[i]];
+        first_id[i] = (uint32_t)range_start[i];
+        node_base[i] = (uint32_t)db->h_node_off[i];
+        for (uint64_t h = db->h_hap_off[i]; h < db->h_hap_off[i + 1]; ++h) hap_species[h] = i;
     }
     node_base[S] = (uint32_t)db->V;
-    std::vector<uint64_t> bit_off(db->V + 1);
-    bit_off[0] = 0;
-    for (uint64_t v = 0; v < db->V; ++v) {
-        if (g->node_len[v] <= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: node %llu has length %lld (reference asserts > 0, profile.rs:494)", (unsigned long long)v, (long long)g->node_len[v]);
-        bit_off[v + 1] = bit_off[v] + (uint64_t)g->node_len[v];
-    }
-    db->L = bit_off[db->V];
+    // node tables: lengths checked, bit offsets (one coverage bit per graph base), the packed node record.  Species
+    // by species on a few threads: sums first, then every species fills its slice from its own base.
+    std::unique_ptr<uint64_t[]> bit_off(new uint64_t[db->V + 1]);
+    std::unique_ptr<uint32_t[]> len32(new uint32_t[db->V ? db->V : 1]);
+    std::unique_ptr<uint4[]> nrec(new uint4[db->V ? db->V : 1]);
+    std::vector<uint64_t> sp_bits(S + 1, 0);
+    std::vector<int64_t> bad_node(S, -1);
+    parallel_for(S, n_thr, [&](uint64_t s0, uint64_t s1) {
+        for (uint64_t s = s0; s < s1; ++s) {
+            uint64_t sum = 0;
+            for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
+                const int64_t l = parts[s].node_len[v];
+                if ((l <= 0 || l > 0xFFFFFFFFll) && bad_node[s] < 0) bad_node[s] = (int64_t)v;
+                sum += (uint64_t)l;
+            }
+            sp_bits[s + 1] = sum;
+        }
+    });
     for (uint32_t s = 0; s < S; ++s) {
-        uint64_t nv = g->node_off[s + 1] - g->node_off[s];
-        for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h)
-            for (uint64_t q = g->path_off[h]; q < g->path_off[h + 1]; ++q)
-                if (g->path_nodes[q] >= nv) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %llu walks node %u outside its species graph", (unsigned long long)h, g->path_nodes[q]);
+        if (bad_node[s] >= 0) {
+            const int64_t l = parts[s].node_len[bad_node[s]];
+            const unsigned long long v = (unsigned long long)(db->h_node_off[s] + (uint64_t)bad_node[s]);
+            if (l <= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: node %llu has length %lld (reference asserts > 0, profile.rs:494)", v, (long long)l);
+            return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: node %llu longer than 2^32", v);
+        }
+        sp_bits[s + 1] += sp_bits[s];
+    }
+    db->L = sp_bits[S];
+    bit_off[db->V] = db->L;
+    parallel_for(S, n_thr, [&](uint64_t s0, uint64_t s1) {
+        for (uint64_t s = s0; s < s1; ++s) {
+            uint64_t bo = sp_bits[s];
+            const uint64_t vb = db->h_node_off[s];
+            for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
+                const uint32_t l = (uint32_t)parts[s].node_len[v];
+                bit_off[vb + v] = bo;
+                len32[vb + v] = l;
+                nrec[vb + v] = make_uint4((uint32_t)bo, (uint32_t)(bo >> 32), l, 0u);
+                bo += l;
+            }
+        }
+    });
+    {   // every walk stays inside its species' graph (profile.rs:849 would panic)
+        std::vector<uint64_t> bad(db->H, ~0ull);
+        parallel_for(db->H, n_thr, [&](uint64_t h0, uint64_t h1) {
+            for (uint64_t h = h0; h < h1; ++h) {
+                const uint32_t s = hap_species[h];
+                const GraphPart &pt = parts[s];
+                const uint64_t lh = h - db->h_hap_off[s];
+                const uint32_t *pn = pt.path_nodes + (pt.path_off[lh] - pt.path_off[0]);
+                const uint64_t len = pt.path_off[lh + 1] - pt.path_off[lh];
+                uint32_t mx = 0;
+                for (uint64_t q = 0; q < len; ++q) mx = std::max(mx, pn[q]);
+                if (len && mx >= pt.n_nodes) bad[h] = mx;
+            }
+        });
+        for (uint64_t h = 0; h < db->H; ++h)
+            if (bad[h] != ~0ull) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %llu walks node %u outside its species graph", (unsigned long long)h, (uint32_t)bad[h]);
     }
     PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
     PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
     PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
-    PTX_TRY(upload(ctx, db->d_bit_off, bit_off.data(), db->V + 1));
-    std::vector<uint32_t> len32(db->V);
-    for (uint64_t v = 0; v < db->V; ++v) {
-        if (g->node_len[v] > 0xFFFFFFFFll) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: node %llu longer than 2^32", (unsigned long long)v);
-        len32[v] = (uint32_t)g->node_len[v];
+    PTX_HIP(ctx, db->d_bit_off.alloc(db->V + 1)); PTX_HIP(ctx, db->d_node_len.alloc(db->V)); PTX_HIP(ctx, db->d_node_rec.alloc(db->V));
+    PTX_HIP(ctx, db->d_path_nodes.alloc(db->P));
+    PTX_TRY(upload_big(ctx, db->d_bit_off.p, bit_off.get(), (db->V + 1) * sizeof(uint64_t)));
+    PTX_TRY(upload_big(ctx, db->d_node_len.p, len32.get(), db->V * sizeof(uint32_t)));
+    PTX_TRY(upload_big(ctx, db->d_node_rec.p, nrec.get(), db->V * sizeof(uint4)));
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint64_t q0 = db->h_path_off[db->h_hap_off[s]], q1 = db->h_path_off[db->h_hap_off[s + 1]];
+        PTX_TRY(upload_big(ctx, db->d_path_nodes.p + q0, parts[s].path_nodes, (q1 - q0) * sizeof(uint32_t)));
     }
-    PTX_TRY(upload(ctx, db->d_node_len, len32.data(), db->V));
-    std::vector<uint4> nrec(db->V);
-    for (uint64_t v = 0; v < db->V; ++v) nrec[v] = make_uint4((uint32_t)bit_off[v], (uint32_t)(bit_off[v] >> 32), len32[v], 0u);
-    PTX_TRY(upload(ctx, db->d_node_rec, nrec.data(), db->V));
-    PTX_TRY(upload(ctx, db->d_path_off, g->path_off, db->H + 1));
-    PTX_TRY(upload(ctx, db->d_path_nodes, g->path_nodes, db->P));
+    PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
     PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
-    PTX_TRY(upload(ctx, db->d_hap_off, g->hap_off, S + 1));
+    PTX_TRY(upload(ctx, db->d_hap_off, db->h_hap_off.data(), S + 1));
     {   // identical-walk test of first_filter_paths (profile.rs:1188-1190) is a property of the graphs: done once
         db->h_all_same.assign(S, 0);
         for (uint32_t s = 0; s < S; ++s) {
-            const uint64_t h0 = g->hap_off[s], h1 = g->hap_off[s + 1];
-            if (h1 - h0 < 2) continue;
+            const GraphPart &pt = parts[s];
+            if (pt.n_haps < 2) continue;
             bool same = true;
-            const uint64_t q0 = g->path_off[h0], l0 = g->path_off[h0 + 1] - q0;
-            for (uint64_t h = h0 + 1; h < h1 && same; ++h) {
-                const uint64_t q = g->path_off[h], l = g->path_off[h + 1] - q;
-                if (l != l0 || std::memcmp(g->path_nodes + q, g->path_nodes + q0, l0 * sizeof(uint32_t)) != 0) same = false;
+            const uint64_t l0 = pt.path_off[1] - pt.path_off[0];
+            for (uint64_t h = 1; h < pt.n_haps && same; ++h) {
+                const uint64_t q = pt.path_off[h] - pt.path_off[0], l = pt.path_off[h + 1] - pt.path_off[h];
+                if (l != l0 || std::memcmp(pt.path_nodes + q, pt.path_nodes, l0 * sizeof(uint32_t)) != 0) same = false;
             }
             db->h_all_same[s] = same;
         }
@@ -133,14 +199,14 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         constexpr uint64_t XCD = 8;
         for (uint32_t s = 0; s < S; ++s) {
             uint64_t maxlen = 0;
-            for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h) maxlen = std::max<uint64_t>(maxlen, g->path_off[h + 1] - g->path_off[h]);
+            for (uint64_t h = db->h_hap_off[s]; h < db->h_hap_off[s + 1]; ++h) maxlen = std::max<uint64_t>(maxlen, db->h_path_off[h + 1] - db->h_path_off[h]);
             const uint64_t n_chunks = (maxlen + PATH_TILE - 1) / PATH_TILE;
             for (uint64_t c0 = 0; c0 < n_chunks; c0 += XCD) {
                 // pad the workgroup ids so that the group starts on XCD 0
                 while (tiles.size() % XCD) tiles.push_back(make_uint2(0xFFFFFFFFu, 0u));
-                for (uint64_t h = g->hap_off[s]; h < g->hap_off[s + 1]; ++h)
+                for (uint64_t h = db->h_hap_off[s]; h < db->h_hap_off[s + 1]; ++h)
                     for (uint64_t c = c0; c < c0 + XCD; ++c) {
-                        const bool live = c < n_chunks && c * PATH_TILE < g->path_off[h + 1] - g->path_off[h];
+                        const bool live = c < n_chunks && c * PATH_TILE < db->h_path_off[h + 1] - db->h_path_off[h];
                         tiles.push_back(live ? make_uint2((uint32_t)h, (uint32_t)c) : make_uint2(0xFFFFFFFFu, 0u));
                     }
             }
@@ -150,7 +216,7 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
         // the same tiles numbered in path order (hap-major): rows of the trio table are numbered in that order
         std::vector<uint32_t> hap_tile_off(db->H + 1, 0), tile_rank(tiles.size());
         for (uint64_t h = 0; h < db->H; ++h)
-            hap_tile_off[h + 1] = hap_tile_off[h] + (uint32_t)((g->path_off[h + 1] - g->path_off[h] + PATH_TILE - 1) / PATH_TILE);
+            hap_tile_off[h + 1] = hap_tile_off[h] + (uint32_t)((db->h_path_off[h + 1] - db->h_path_off[h] + PATH_TILE - 1) / PATH_TILE);
         for (size_t i = 0; i < tiles.size(); ++i) tile_rank[i] = tiles[i].x == 0xFFFFFFFFu ? hap_tile_off[db->H] : hap_tile_off[tiles[i].x] + tiles[i].y;   // pads count into the spare last slot
         PTX_TRY(upload(ctx, db->d_tile_rank, tile_rank.data(), tile_rank.size()));
         PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
@@ -164,6 +230,10 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     *out = db.release();
     return 0;
 }
+
+}  // namespace ptx
+
+extern "C" {
 
 void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
     std::unique_lock<std::recursive_mutex> lk;

@@ -245,20 +245,27 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     const uint32_t Ss = (uint32_t)sel.size();
     std::vector<HostGraph> graphs(Ss);
     std::vector<uint8_t> loaded(Ss, 1);
-    for (uint32_t i = 0; i < Ss; ++i) {
-        const std::string &otu = ranges[sel[i]].species;
-        std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
-        std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
-        const std::string lz = bin + ".lz4", zst = bin + ".zst";
-        std::string e2;
-        if (zip == "serialize" && is_file(bin)) e2 = read_graph_bin(bin, graphs[i]);
-        else if (zip == "lz" && is_file(lz)) e2 = read_graph_zip(lz, 2, graphs[i]);
-        else if (zip == "zstd" && is_file(zst)) e2 = read_graph_zip(zst, 3, graphs[i]);
-        else if (is_file(gfa)) e2 = read_gfa(gfa, graphs[i]);
-        else return fail(ctx, PANTAX_HIP_E_IO, "gfa information file %s does not exist. Please check database.", gfa.c_str());
-        if (!e2.empty()) { loaded[i] = 0; continue; }            // "GFA read error" => species skipped (.ok()?)
-        const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
-        if ((int64_t)graphs[i].node_len.size() != nvert) return fail(ctx, PANTAX_HIP_E_IO, "species %s: graph has %zu nodes but its range spans %lld", otu.c_str(), graphs[i].node_len.size(), (long long)nvert);
+    {   // the graph files are independent: parsed by a few threads; the first problem in species order is reported
+        std::vector<std::string> hard(Ss);   // errors that end the run
+        parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
+            for (uint64_t i = i0; i < i1; ++i) {
+                const std::string &otu = ranges[sel[i]].species;
+                std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
+                std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
+                const std::string lz = bin + ".lz4", zst = bin + ".zst";
+                std::string e2;
+                if (zip == "serialize" && is_file(bin)) e2 = read_graph_bin(bin, graphs[i]);
+                else if (zip == "lz" && is_file(lz)) e2 = read_graph_zip(lz, 2, graphs[i]);
+                else if (zip == "zstd" && is_file(zst)) e2 = read_graph_zip(zst, 3, graphs[i]);
+                else if (is_file(gfa)) e2 = read_gfa(gfa, graphs[i]);
+                else { hard[i] = "gfa information file " + gfa + " does not exist. Please check database."; continue; }
+                if (!e2.empty()) { loaded[i] = 0; continue; }            // "GFA read error" => species skipped (.ok()?)
+                const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
+                if ((int64_t)graphs[i].node_len.size() != nvert)
+                    hard[i] = "species " + otu + ": graph has " + std::to_string(graphs[i].node_len.size()) + " nodes but its range spans " + std::to_string((long long)nvert);
+            }
+        });
+        for (uint32_t i = 0; i < Ss; ++i) if (!hard[i].empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", hard[i].c_str());
     }
     lap("graph load");
     std::vector<uint32_t> use;   // selected species with a loaded graph
@@ -269,21 +276,17 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     std::vector<uint64_t> hap_off(Su + 1, 0);
     std::vector<std::string> hap_names;
     if (Su) {
-        std::vector<int64_t> g_rs(Su), g_re(Su), node_len;
-        std::vector<uint64_t> node_off(Su + 1, 0), path_off{0};
-        std::vector<uint32_t> path_nodes;
-        for (uint32_t k = 0; k < Su; ++k) {
+        std::vector<int64_t> g_rs(Su), g_re(Su);
+        std::vector<GraphPart> parts(Su);
+        for (uint32_t k = 0; k < Su; ++k) {   // the parsed graphs go to the device as they are: one part per species
             const HostGraph &hg = graphs[use[k]];
             g_rs[k] = ranges[sel[use[k]]].start; g_re[k] = ranges[sel[use[k]]].end;
-            node_len.insert(node_len.end(), hg.node_len.begin(), hg.node_len.end());
-            node_off[k + 1] = node_len.size();
-            for (size_t h = 0; h < hg.hap_names.size(); ++h) { path_off.push_back(path_nodes.size() + hg.path_off[h + 1]); hap_names.push_back(hg.hap_names[h]); }
-            path_nodes.insert(path_nodes.end(), hg.path_nodes.begin(), hg.path_nodes.end());
+            parts[k] = GraphPart{hg.node_len.data(), hg.node_len.size(), hg.hap_names.size(), hg.path_off.data(), hg.path_nodes.data()};
+            hap_names.insert(hap_names.end(), hg.hap_names.begin(), hg.hap_names.end());
             hap_off[k + 1] = hap_names.size();
         }
         DbHolder sdb{ctx};
-        pantax_hip_graphs g{Su, g_rs.data(), g_re.data(), node_off.data(), node_len.data(), hap_off.data(), path_off.data(), path_nodes.data()};
-        PTX_TRY(pantax_hip_db_upload(ctx, &g, &sdb.db));
+        PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), &sdb.db));
         lap("db upload");
         // the same resident reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <functional>
 #include <mutex>
 #include <cstring>
 #include <string>
@@ -37,19 +38,30 @@ int fail(Ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 
 // ---- device buffer ---------------------------------------------------------------------------
+// Device allocations go through a small per-process cache: hipFree of a large buffer costs around a millisecond (it
+// waits for the device and unmaps), and the file seam allocates and releases some dozens of them per call.  A released
+// block is kept (up to DEV_CACHE_MAX bytes in all) and handed to the next request of a similar size; before a block
+// freed since the last device-wide wait is reused, the device is synchronised once -- the guarantee hipFree gave.
+constexpr size_t DEV_CACHE_MAX = 48ull << 30;
+hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out);
+void dev_cache_free(void *p, size_t cap);
+void dev_cache_trim();   // really free everything cached for the current device (pantax_hip_destroy)
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t cap = 0;      // bytes of the underlying allocation (owned buffers)
     bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) dev_cache_free(p, cap);
         p = nullptr;
         n = 0;
+        cap = 0;
         owned = true;
     }
     // non-owning window into a larger allocation (an arena that is zeroed / downloaded as one piece)
@@ -62,13 +74,13 @@ struct DevBuf {
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
-        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        hipError_t e = dev_cache_alloc((void **)&p, (count ? count : 1) * sizeof(T), &cap);
         if (e == hipSuccess) n = count ? count : 1;
         return e;
     }
     size_t bytes() const { return n * sizeof(T); }
     // take over another buffer's allocation
-    void take(DevBuf &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
+    void take(DevBuf &o) { release(); p = o.p; n = o.n; cap = o.cap; owned = o.owned; o.p = nullptr; o.n = 0; o.cap = 0; o.owned = true; }
 };
 
 // page-locked host staging (grow-only): a copy from / to pageable memory makes the runtime stage and wait,
@@ -194,8 +206,6 @@ struct Db {
     uint64_t V = 0, H = 0, P = 0, L = 0;
     std::vector<int64_t> h_range_start, h_range_end;
     std::vector<uint64_t> h_node_off, h_hap_off, h_path_off;
-    std::vector<int64_t> h_node_len;     // kept for host-side finishing (f64 divides)
-    std::vector<uint32_t> h_path_nodes;  // kept for the identical-paths test (profile.rs:1188-1190)
     bool ranges_sorted_disjoint = true;
     // binning tables
     DevBuf<uint32_t> d_rng_start, d_rng_end, d_rng_idx;  // sorted by start (or file order when overlapping)
@@ -283,6 +293,17 @@ int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
     if (n) PTX_HIP(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
+// one species' graph as the db upload takes it: node lengths, and the walks as a local CSR (path_off may start anywhere)
+struct GraphPart {
+    const int64_t *node_len; uint64_t n_nodes; uint64_t n_haps; const uint64_t *path_off; const uint32_t *path_nodes;
+};
+int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out);
+// large pageable host buffers (mmapped text, graph arrays) -> HBM through two pinned chunks: a few threads copy the next
+// chunk into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged
+// by one runtime thread at ~10 GB/s).  Returns after the last chunk has arrived.
+int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+// fn(begin, end) over [0, n) split across up to n_threads host threads (the calling thread takes the first slice)
+void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn);
 // small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)
 constexpr size_t PIN_UP_RING = 1u << 20, PIN_UP_MAX = 1u << 16;
 template <class T>

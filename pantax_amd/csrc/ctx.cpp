@@ -1,6 +1,8 @@
 // ctx.cpp -- context lifetime, error strings, HIP-event kernel timing (include/pantax_hip.h).
 #include <cstdarg>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include "common.hpp"
 
 namespace ptx {
@@ -121,6 +123,7 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    dev_cache_trim();   // nothing of this process stays cached on the device once a ctx is gone
 }
 
 int pantax_hip_sync(pantax_hip_ctx *ctx) {
@@ -170,3 +173,140 @@ int pantax_hip_timing_get(pantax_hip_ctx *ctx, int cap, const char **names_out, 
 }
 
 }  // extern "C"
+
+
+namespace ptx {
+
+// ---- device allocation cache (see common.hpp) ----
+namespace {
+struct DevCache {
+    struct Block { void *p; uint64_t epoch; };
+    struct PerDevice {
+        std::multimap<size_t, Block> free_blocks;   // by capacity
+        size_t cached_bytes = 0;
+        uint64_t free_epoch = 0, synced_epoch = 0;  // a block released at epoch e may be reused once synced_epoch >= e
+    };
+    std::mutex mu;
+    std::map<int, PerDevice> dev;
+};
+DevCache &dev_cache() { static DevCache c; return c; }
+inline size_t round_cap(size_t bytes) {
+    if (bytes <= (1u << 20)) return (bytes + 4095) & ~size_t(4095);
+    return (bytes + (1u << 20) - 1) & ~size_t((1u << 20) - 1);
+}
+}  // namespace
+
+hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out) {
+    const size_t want = round_cap(bytes ? bytes : 1);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevCache &c = dev_cache();
+    {
+        std::unique_lock<std::mutex> lk(c.mu);
+        DevCache::PerDevice &d = c.dev[dev];
+        auto it = d.free_blocks.lower_bound(want);
+        if (it != d.free_blocks.end() && it->first <= std::max(2 * want, want + (size_t(1) << 20))) {
+            const size_t cap = it->first;
+            const DevCache::Block b = it->second;
+            d.free_blocks.erase(it);
+            d.cached_bytes -= cap;
+            const bool need_sync = b.epoch > d.synced_epoch;
+            const uint64_t now = d.free_epoch;
+            lk.unlock();
+            if (need_sync) {   // kernels enqueued before the block was released may still be using it
+                (void)hipDeviceSynchronize();
+                std::lock_guard<std::mutex> g(c.mu);
+                DevCache::PerDevice &d2 = c.dev[dev];
+                if (now > d2.synced_epoch) d2.synced_epoch = now;
+            }
+            *p = b.p; *cap_out = cap;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {   // out of memory: give the cached blocks back and retry once
+        (void)hipGetLastError();
+        dev_cache_trim();
+        e = hipMalloc(p, want);
+    }
+    *cap_out = e == hipSuccess ? want : 0;
+    return e;
+}
+
+void dev_cache_free(void *p, size_t cap) {
+    if (!p) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevCache &c = dev_cache();
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        DevCache::PerDevice &d = c.dev[dev];
+        if (cap && d.cached_bytes + cap <= DEV_CACHE_MAX) {
+            d.free_blocks.emplace(cap, DevCache::Block{p, ++d.free_epoch});
+            d.cached_bytes += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void dev_cache_trim() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevCache &c = dev_cache();
+    std::multimap<size_t, DevCache::Block> blocks;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        DevCache::PerDevice &d = c.dev[dev];
+        blocks.swap(d.free_blocks);
+        d.cached_bytes = 0;
+    }
+    for (auto &kv : blocks) (void)hipFree(kv.second.p);
+}
+
+int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) {
+    if (size == 0) return 0;
+    constexpr uint64_t CH = 16ull << 20;
+    constexpr int NTH = 4;
+    if (size < (1ull << 20)) {   // small: not worth the staging
+        PTX_HIP(ctx, hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    PTX_HIP(ctx, ctx->pin_text.reserve(2 * CH));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int rc = 0;
+    uint64_t i = 0;
+    const uint8_t *text = static_cast<const uint8_t *>(src);
+    uint8_t *dst = static_cast<uint8_t *>(d_dst);
+    for (uint64_t off = 0; off < size && rc == 0; off += CH, ++i) {
+        const uint64_t n = std::min<uint64_t>(CH, size - off);
+        uint8_t *slot = ctx->pin_text.p + (i & 1) * CH;
+        if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
+        std::thread th[NTH];
+        for (int t = 0; t < NTH; ++t) {
+            const uint64_t b = n * t / NTH, e = n * (t + 1) / NTH;
+            th[t] = std::thread([=] { std::memcpy(slot + b, text + off + b, e - b); });
+        }
+        for (auto &t : th) t.join();
+        if (hipMemcpyAsync(dst + off, slot, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[i & 1], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    }
+    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    return rc;
+}
+
+void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn) {
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n) n_threads = n ? (int)n : 1;
+    if (n_threads == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
+    fn(0, n / n_threads);
+    for (auto &t : th) t.join();
+}
+
+}  // namespace ptx

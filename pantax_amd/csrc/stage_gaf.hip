@@ -165,39 +165,9 @@ __global__ void __launch_bounds__(256) gaf_fill_kernel(const uint8_t *__restrict
     if (in_run) o.node_id[w++] = (uint32_t)v;
 }
 
-// host text (usually an mmap of the page cache) -> HBM through two pinned chunks: a few threads copy the next chunk
-// into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged
-// by one runtime thread at ~10 GB/s)
-static int upload_text(Ctx *ctx, uint8_t *d_dst, const char *text, uint64_t size) {
-    constexpr uint64_t CH = 16ull << 20;
-    constexpr int NTH = 4;
-    PTX_HIP(ctx, ctx->pin_text.reserve(2 * CH));
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    int rc = 0;
-    uint64_t i = 0;
-    for (uint64_t off = 0; off < size && rc == 0; off += CH, ++i) {
-        const uint64_t n = std::min<uint64_t>(CH, size - off);
-        uint8_t *slot = ctx->pin_text.p + (i & 1) * CH;
-        if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
-        std::thread th[NTH];
-        for (int t = 0; t < NTH; ++t) {
-            const uint64_t b = n * t / NTH, e = n * (t + 1) / NTH;
-            th[t] = std::thread([=] { std::memcpy(slot + b, text + off + b, e - b); });
-        }
-        for (auto &t : th) t.join();
-        if (hipMemcpyAsync(d_dst + off, slot, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(ev[i & 1], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "text upload failed");
-    }
-    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "text upload failed");
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
-    return rc;
-}
-
 int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out) {
     PTX_HIP(ctx, d_txt.alloc(size + 16));
-    PTX_TRY(upload_text(ctx, d_txt.p, text, size));
+    PTX_TRY(upload_big(ctx, d_txt.p, text, size));
     const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
     DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
     PTX_HIP(ctx, tile_cnt.alloc(n_tiles)); PTX_HIP(ctx, tile_base.alloc(n_tiles)); PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));

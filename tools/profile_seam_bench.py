@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 from pantax_amd import synth
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-sset = synth.make_set(20260503, 1, 10, n, 5_000_000)
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+sset = synth.make_set(20260503, S, 10, n, 5_000_000)
 root = tempfile.mkdtemp()
 db = os.path.join(root, "db"); os.mkdir(db)
 t0 = time.perf_counter(); synth.write_db(sset, db); gaf = os.path.join(root, "gfa_mapped.gaf"); synth.write_gaf(sset.reads, gaf)
@@ -17,7 +18,7 @@ for i in range(3):
     wd = os.path.join(root, "wd%d" % i); os.mkdir(wd)
     cwd = os.getcwd(); os.chdir(wd)
     t0 = time.perf_counter()
-    eng.profile(db, wd, gaf, zip="serialize")
+    eng.profile(db, wd, gaf, zip="serialize", sample_nodes=500000)
     dt = time.perf_counter() - t0
     os.chdir(cwd)
     print("pantax_hip_profile call %d: %.1f ms (%.1f Mreads/s from files to files)" % (i, dt * 1e3, n / dt / 1e6))
