@@ -258,6 +258,89 @@ def test_pao_solve_vs_highs_golden(eng, golden_dir):
             assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
 
 
+def test_pao_solve_at_and_beyond_64_candidates(eng):
+    """64 candidate paths is what the membership word holds: solved (objective == the oracle's exact LAD, which SciPy-HiGHS
+    pins on the smaller golden cases); 65 is refused loudly, never approximated."""
+    from oracle import oracle as orc
+    from pantax_amd.engine import PantaxHipError
+    rng = np.random.default_rng(64)
+    n, p = 6000, 64
+    # haplotype-like membership: every node on a random subset of the paths, a few paths nearly everywhere
+    mask = np.zeros(n, dtype=np.uint64)
+    for k in range(p):
+        on = rng.random(n) < (0.9 if k < 3 else rng.uniform(0.05, 0.5))
+        mask |= (on.astype(np.uint64) << np.uint64(k))
+    mask[mask == 0] = 1
+    truth = np.where(rng.random(p) < 0.15, rng.uniform(1, 30, p), 0.0)
+    A = np.stack([((mask >> np.uint64(k)) & np.uint64(1)).astype(float) for k in range(p)], 1)
+    a = np.maximum(A @ truth + rng.normal(0, 0.5, n), 0.01)
+    po, pn = _paths_from_masks(mask, p)
+    x, ratio, obj, st = eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po, pn, np.arange(p))
+    ub = np.full(p, 1.05 * a.max())
+    xo, objo, it, sto = orc.lad_solve(mask, a, p, ub)
+    assert st == 0 and sto == 0
+    assert obj == pytest.approx(objo, rel=1e-9) and orc.lad_objective(mask, a, x) == pytest.approx(objo, rel=1e-9)
+    assert np.all(x >= -1e-12) and np.all(x <= ub + 1e-9)
+    # one more path than the word holds
+    po65 = np.concatenate([po, [po[-1] + 1]]).astype(np.uint64)
+    pn65 = np.concatenate([pn, [0]]).astype(np.uint32)
+    with pytest.raises(PantaxHipError) as e:
+        eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po65, pn65, np.arange(65))
+    assert "65 candidate paths" in str(e.value)
+
+
+def test_species_with_more_than_64_candidates_is_dropped_alone(eng):
+    """A species whose first filter leaves > 64 columns (70 haplotypes, no unique trio: every walk exists twice) is
+    reported with PANTAX_HIP_E_LIMIT and loses its rows, like a failed solve in the reference (profile.rs:2999-3003);
+    the species next to it is unaffected."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(70, 2, 4, 20000, 20000, present_frac=0.6)
+    g = sset.species[0]
+    rng = np.random.default_rng(71)
+    base = [g.path_nodes[int(g.path_off[h]):int(g.path_off[h + 1])] for h in range(g.n_paths)]
+    walks = []
+    for k in range(35):                       # 35 different walks, each twice -> 70 haplotypes, no trio occurs once
+        w = base[k % len(base)].copy()
+        cut = sorted(rng.integers(3, len(w) - 3, size=2))
+        w = np.concatenate([w[:cut[0]], w[cut[1]:]]) if k >= len(base) else w
+        walks += [w, w]
+    g.path_nodes = np.concatenate(walks).astype(np.uint32)
+    g.path_off = np.concatenate([[0], np.cumsum([len(w) for w in walks])]).astype(np.uint64)
+    g.hap_names = ["GCF_9%05d.1" % i for i in range(70)]
+    g.genome_len = np.array([int(g.node_len[w].sum()) for w in walks], dtype=np.int64)
+    g.truth_depth = np.zeros(70)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    assert keep.all()
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    assert hto[70] == 0                        # no unique trio in species 0
+    eng.get_node_abundances(fetch=False)
+    met, info = eng.strain_profiling(absolute, species_active=keep)
+    got = metrics_to_dicts(met, eng.H)
+    assert info[0].n_candidates == 70 and info[0].status1 != 0
+    assert all(all(v is None or v is False for v in d.values()) for d in got[:70])
+    # the oracle refuses the same species and agrees on the other one
+    ref = _oracle_cov_per_species(sset, sp)
+    G, T, b, c, t, na = ref[0]
+    assert orc.optimize_species(G, T, b, c, t)[0] != 0
+    G, T, b, c, t, na = ref[1]
+    rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+    assert rc_ == 0 and info[1].status1 == 0 and info[1].n_candidates == nc
+    orc.abundance_constraint(absolute[1], omet)
+    for h, e in enumerate(orc.metrics_to_dicts(omet)):
+        for key, ev in e.items():
+            gv = got[70 + h][key]
+            if ev is None or gv is None or isinstance(ev, bool):
+                assert gv == ev, (h, key, gv, ev)
+            else:
+                assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (h, key, gv, ev)
+
+
 def test_pao_solve_edge_cases(eng):
     # no covered node: x = 0
     po, pn = _paths_from_masks(np.array([1, 3], dtype=np.uint64), 2)
