@@ -223,8 +223,9 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     int64_t min_cov, min_depth;
     int32_t species, strain, shift, filtered, full, force, mode, sample_nodes;
     const char *designated_species; /* --ds or NULL */
-    const char *zip;                /* "serialize" | NULL (= GFA); "lz"/"zstd" are rejected (no codec here) */
-    /* multi-GPU: this process handles species i with i % world_size == rank; world_size 1 = all */
+    const char *zip;                /* "serialize" (.bin) | "lz" (.bin.lz4) | "zstd" (.bin.zst) | NULL (= GFA); "h5" is refused */
+    /* this entry drives ONE GPU: world_size must be 0 or 1 (rank 0).  Multi-GPU runs shard the species over one
+     * process per GPU through the stage calls + ONE all-reduce (pantax_amd/pipeline.py, bench.py) */
     int32_t rank, world_size;
 } pantax_hip_profiling_config;
 
