@@ -7,7 +7,8 @@ import numpy as np
 from pantax_amd import synth, io as pio
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-sset = synth.make_set(20260503, 1, 10, n, 5_000_000)
+long_reads = len(sys.argv) > 2 and sys.argv[2] == "long"   # HiFi-shaped lines (~700 node ids each)
+sset = synth.make_set(20260503, 1, 10, n, 5_000_000, long_reads=long_reads)
 d = tempfile.mkdtemp()
 p = os.path.join(d, "x.gaf")
 t0 = time.perf_counter(); synth.write_gaf(sset.reads, p); print("wrote %.1f MB in %.1f s" % (os.path.getsize(p) / 1e6, time.perf_counter() - t0))
