@@ -123,6 +123,13 @@ def test_chacha_core_known_answers():
     blk1 = Engine.chacha_block(z, 1, 20).astype("<u4").tobytes().hex()
     assert blk1.startswith("9f07e7be5551387a98ba977c732d080d")
     assert (orc.chacha_block(z, 1, 20) == Engine.chacha_block(z, 1, 20)).all()
+    # RFC 7539 A.1 test vector #3 (key = 00..01, block counter 1): the vector rand_chacha's own test_chacha_true_values_b uses
+    k3 = np.zeros(8, dtype=np.uint32)
+    k3[7] = 0x01000000
+    tv3 = ("3aeb5224ecf849929b9d828db1ced4dd832025e8018b8160b82284f3c949aa5a8eca00bbb4a73bdad192b5c42f73f2fd"
+           "4e273644c8b36125a64addeb006c13a0")
+    for fn in (orc.chacha_block, Engine.chacha_block):
+        assert fn(k3, 1, 20).astype("<u4").tobytes().hex() == tv3
     key = np.arange(8, dtype=np.uint32) * 0x01010101
     assert (orc.chacha_block(key, 5, 12) == Engine.chacha_block(key, 5, 12)).all()
 
