@@ -198,6 +198,14 @@ int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t
 int pantax_hip_gaf_filter(pantax_hip_ctx *ctx, const char *gaf_path, const char *out_path, uint64_t *n_lines,
                           uint64_t *n_records, uint64_t *n_written);
 
+/* device-ready images of the species of a resident db, one file per species (graph in the kernels' layouts +
+ * its unique-trio index): written from a db (the index is built first if needed; hap_names[H] in db order) and read
+ * back into a db whose trio index is already in place -- a6 becomes "map + copy", a7 a no-op. */
+int pantax_hip_db_save_images(pantax_hip_ctx *ctx, pantax_hip_db *db, const char *const *paths /*[S]*/,
+                              const char *const *hap_names /*[H]*/);
+int pantax_hip_db_load_images(pantax_hip_ctx *ctx, uint32_t n_species, const char *const *paths, const int64_t *range_start,
+                              const int64_t *range_end, pantax_hip_db **out);
+
 /* a11 (sample_sorted, profile.rs:1287-1295): which of n_valid rows `StdRng::seed_from_u64(seed)` +
  * `choose_multiple(sample_nodes)` keeps, as a bitmap over their ranks (bits_out: (n_valid+31)/32 words).  Host only.
  * rand 0.9.2 / rand_chacha 0.9.0 (Cargo.lock) are restated, not linked: parity with the crates is unpinned. */
@@ -227,6 +235,10 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     /* this entry drives ONE GPU: world_size must be 0 or 1 (rank 0).  Multi-GPU runs shard the species over one
      * process per GPU through the stage calls + ONE all-reduce (pantax_amd/pipeline.py, bench.py) */
     int32_t rank, world_size;
+    /* device-ready graph images <db>/species_graph_info/<otu>.hipdb (graphs + unique-trio index):
+     * 0 = ignore them, 1 = use them when every selected species has a fresh one, 2 = as 1, and write them after a run
+     * that had to parse the graphs */
+    int32_t image_cache;
 } pantax_hip_profiling_config;
 
 int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "pantax_hip_bin_reads", "pantax_hip_species_profile", "pantax_hip_db_reset", "pantax_hip_abundance_filter",
     "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
     "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_profile", "pantax_hip_profile_step", "pantax_hip_sort_rows",
-    "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter",
+    "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter", "pantax_hip_db_save_images", "pantax_hip_db_load_images",
     "pantax_hip_gaf_load", "pantax_hip_gaf_load_device", "pantax_hip_reads_load_gaf", "pantax_hip_reads_set_flags", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
     "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free",
     "pantax_hip_timing_enable", "pantax_hip_timing_filter", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
@@ -78,7 +78,7 @@ class ProfilingConfig(C.Structure):
                 ("single_cov_diff", C.c_double), ("min_cov", C.c_int64), ("min_depth", C.c_int64),
                 ("species", C.c_int32), ("strain", C.c_int32), ("shift", C.c_int32), ("filtered", C.c_int32),
                 ("full", C.c_int32), ("force", C.c_int32), ("mode", C.c_int32), ("sample_nodes", C.c_int32),
-                ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32)]
+                ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32), ("image_cache", C.c_int32)]
 
 
 def load():

@@ -1,6 +1,9 @@
 // api_core.cpp -- upload of the resident DB / reads and the a2/a3/a8 entry points of
 // include/pantax_hip.h.  Host code only; kernels live in the stage_*.hip files.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -60,6 +63,14 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
     db->S = S;
     const int n_thr = 8;
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     db->h_node_off.assign(S + 1, 0); db->h_hap_off.assign(S + 1, 0);
     for (uint32_t s = 0; s < S; ++s) { db->h_node_off[s + 1] = db->h_node_off[s] + parts[s].n_nodes; db->h_hap_off[s + 1] = db->h_hap_off[s] + parts[s].n_haps; }
     db->V = db->h_node_off[S];
@@ -100,6 +111,44 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         for (uint64_t h = db->h_hap_off[i]; h < db->h_hap_off[i + 1]; ++h) hap_species[h] = i;
     }
     node_base[S] = (uint32_t)db->V;
+    bool from_images = S > 0;
+    for (uint32_t s = 0; s < S; ++s) from_images = from_images && parts[s].fd >= 0 && parts[s].node_len32 != nullptr;
+    if (from_images) {
+        // device-ready images: the arrays stream from the files into HBM (pread into the pinned chunks) and the node
+        // tables, the zero-length and the walk checks run on the device
+        std::vector<uint64_t> sp_bits(S + 1, 0);
+        for (uint32_t s = 0; s < S; ++s) {
+            if (parts[s].n_bases >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u has %llu graph bases; images take < 2^32 per species", s, (unsigned long long)parts[s].n_bases);
+            sp_bits[s + 1] = sp_bits[s] + parts[s].n_bases;
+        }
+        db->L = sp_bits[S];
+        PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
+        PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
+        PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
+        PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
+        PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
+        PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
+        PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
+        PTX_HIP(ctx, db->d_bit_off.alloc(db->V + 1)); PTX_HIP(ctx, db->d_node_len.alloc(db->V)); PTX_HIP(ctx, db->d_node_rec.alloc(db->V));
+        PTX_HIP(ctx, db->d_path_nodes.alloc(db->P));
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint64_t q0 = db->h_path_off[db->h_hap_off[s]], q1 = db->h_path_off[db->h_hap_off[s + 1]];
+            PTX_TRY(upload_file(ctx, db->d_node_len.p + db->h_node_off[s], parts[s].fd, parts[s].off_node_len, parts[s].n_nodes * sizeof(uint32_t)));
+            PTX_TRY(upload_file(ctx, db->d_path_nodes.p + q0, parts[s].fd, parts[s].off_path_nodes, (q1 - q0) * sizeof(uint32_t)));
+        }
+        lap("image arrays -> HBM");
+        DevBuf<uint32_t> d_flags;
+        PTX_HIP(ctx, d_flags.alloc(2));
+        PTX_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(d_flags.p + 1, 0xFF, sizeof(uint32_t), ctx->stream));
+        PTX_TRY(node_tables_launch(ctx, db.get(), sp_bits.data(), d_flags.p));
+        uint32_t fl[2] = {0, 0};
+        PTX_TRY(download(ctx, fl, d_flags.p, 2));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl[0]) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a graph image holds a node of length 0 (reference asserts > 0, profile.rs:494)");
+        if (fl[1] != 0xFFFFFFFFu) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %u walks a node outside its species graph", fl[1] - 1);
+        lap("node tables + walk check (device)");
+    } else {
     // node tables: lengths checked, bit offsets (one coverage bit per graph base), the packed node record.  Species
     // by species on a few threads: sums first, then every species fills its slice from its own base.
     std::unique_ptr<uint64_t[]> bit_off(new uint64_t[db->V + 1]);
@@ -111,7 +160,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         for (uint64_t s = s0; s < s1; ++s) {
             uint64_t sum = 0;
             for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
-                const int64_t l = parts[s].node_len[v];
+                const int64_t l = parts[s].len(v);
                 if ((l <= 0 || l > 0xFFFFFFFFll) && bad_node[s] < 0) bad_node[s] = (int64_t)v;
                 sum += (uint64_t)l;
             }
@@ -120,7 +169,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     });
     for (uint32_t s = 0; s < S; ++s) {
         if (bad_node[s] >= 0) {
-            const int64_t l = parts[s].node_len[bad_node[s]];
+            const int64_t l = parts[s].len((uint64_t)bad_node[s]);
             const unsigned long long v = (unsigned long long)(db->h_node_off[s] + (uint64_t)bad_node[s]);
             if (l <= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: node %llu has length %lld (reference asserts > 0, profile.rs:494)", v, (long long)l);
             return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: node %llu longer than 2^32", v);
@@ -134,7 +183,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
             uint64_t bo = sp_bits[s];
             const uint64_t vb = db->h_node_off[s];
             for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
-                const uint32_t l = (uint32_t)parts[s].node_len[v];
+                const uint32_t l = (uint32_t)parts[s].len(v);
                 bit_off[vb + v] = bo;
                 len32[vb + v] = l;
                 nrec[vb + v] = make_uint4((uint32_t)bo, (uint32_t)(bo >> 32), l, 0u);
@@ -142,6 +191,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
             }
         }
     });
+    lap("node tables");
     {   // every walk stays inside its species' graph (profile.rs:849 would panic)
         std::vector<uint64_t> bad(db->H, ~0ull);
         parallel_for(db->H, n_thr, [&](uint64_t h0, uint64_t h1) {
@@ -159,6 +209,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         for (uint64_t h = 0; h < db->H; ++h)
             if (bad[h] != ~0ull) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %llu walks node %u outside its species graph", (unsigned long long)h, (uint32_t)bad[h]);
     }
+    lap("walk check");
     PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
@@ -173,14 +224,17 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         const uint64_t q0 = db->h_path_off[db->h_hap_off[s]], q1 = db->h_path_off[db->h_hap_off[s + 1]];
         PTX_TRY(upload_big(ctx, db->d_path_nodes.p + q0, parts[s].path_nodes, (q1 - q0) * sizeof(uint32_t)));
     }
-    PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
-    PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
+        PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
+        PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
+        lap("uploads");
+    }
     PTX_TRY(upload(ctx, db->d_hap_off, db->h_hap_off.data(), S + 1));
     {   // identical-walk test of first_filter_paths (profile.rs:1188-1190) is a property of the graphs: done once
         db->h_all_same.assign(S, 0);
         for (uint32_t s = 0; s < S; ++s) {
             const GraphPart &pt = parts[s];
             if (pt.n_haps < 2) continue;
+            if (pt.all_same >= 0) { db->h_all_same[s] = pt.all_same != 0; continue; }   // stated by the image
             bool same = true;
             const uint64_t l0 = pt.path_off[1] - pt.path_off[0];
             for (uint64_t h = 1; h < pt.n_haps && same; ++h) {
@@ -221,6 +275,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         PTX_TRY(upload(ctx, db->d_tile_rank, tile_rank.data(), tile_rank.size()));
         PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
     }
+    lap("tiles");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_node.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(1));

@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include "common.hpp"
+#include "db_image.hpp"
 #include "host_io.hpp"
 
 using namespace ptx;
@@ -25,6 +26,8 @@ using namespace ptx;
 namespace {
 
 bool is_file(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+// modification time in ns, 0 if the file is missing
+int64_t file_mtime(const std::string &p) { struct stat st; return (!p.empty() && stat(p.c_str(), &st) == 0) ? (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec : 0; }
 bool is_dir(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 std::string join(const std::string &a, const std::string &b) { return a.empty() ? b : (a.back() == '/' ? a + b : a + "/" + b); }
 std::string opt(const char *s) { return s ? std::string(s) : std::string(); }
@@ -245,7 +248,35 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     const uint32_t Ss = (uint32_t)sel.size();
     std::vector<HostGraph> graphs(Ss);
     std::vector<uint8_t> loaded(Ss, 1);
-    {   // the graph files are independent: parsed by a few threads; the first problem in species order is reported
+    // image_cache >= 1: device-ready images <db>/species_graph_info/<otu>.hipdb (db_image.cpp) stand in for
+    // the graph files AND the per-run unique-trio index when every selected species has one that is not older than its
+    // source; otherwise the graphs are parsed as usual (and, with image_cache == 2, the images are written afterwards)
+    auto source_of = [&](const std::string &otu) {
+        const std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
+        if (zip == "serialize" && is_file(bin)) return bin;
+        if (zip == "lz" && is_file(bin + ".lz4")) return bin + ".lz4";
+        if (zip == "zstd" && is_file(bin + ".zst")) return bin + ".zst";
+        return join(join(db_dir, "species_gfa"), otu + ".gfa");
+    };
+    auto image_of = [&](const std::string &otu) { return join(join(db_dir, "species_graph_info"), otu + ".hipdb"); };
+    std::vector<std::unique_ptr<SpeciesImage>> images(Ss);
+    bool use_images = cfg->image_cache >= 1 && Ss > 0;
+    if (use_images) {
+        std::vector<uint8_t> ok(Ss, 0);
+        parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
+            for (uint64_t i = i0; i < i1; ++i) {
+                const std::string &otu = ranges[sel[i]].species;
+                const std::string img = image_of(otu);
+                if (!is_file(img) || file_mtime(img) < file_mtime(source_of(otu))) continue;
+                images[i].reset(new SpeciesImage());
+                if (!images[i]->open(img).empty()) continue;                                   // unreadable image: parse instead
+                ok[i] = (int64_t)images[i]->V == ranges[sel[i]].end - ranges[sel[i]].start + 1;
+            }
+        });
+        for (uint32_t i = 0; i < Ss; ++i) use_images = use_images && ok[i];
+        if (!use_images) for (auto &im : images) im.reset();
+    }
+    if (!use_images) {   // the graph files are independent: parsed by a few threads; the first problem in species order is reported
         std::vector<std::string> hard(Ss);   // errors that end the run
         parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
@@ -278,15 +309,18 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (Su) {
         std::vector<int64_t> g_rs(Su), g_re(Su);
         std::vector<GraphPart> parts(Su);
+        std::vector<const SpeciesImage *> imp(Su);
         for (uint32_t k = 0; k < Su; ++k) {   // the parsed graphs go to the device as they are: one part per species
-            const HostGraph &hg = graphs[use[k]];
             g_rs[k] = ranges[sel[use[k]]].start; g_re[k] = ranges[sel[use[k]]].end;
-            parts[k] = GraphPart{hg.node_len.data(), hg.node_len.size(), hg.hap_names.size(), hg.path_off.data(), hg.path_nodes.data()};
-            hap_names.insert(hap_names.end(), hg.hap_names.begin(), hg.hap_names.end());
+            const std::vector<std::string> &names = use_images ? images[use[k]]->hap_names : graphs[use[k]].hap_names;
+            if (use_images) imp[k] = images[use[k]].get();
+            else { const HostGraph &hg = graphs[use[k]]; parts[k] = GraphPart{hg.node_len.data(), hg.node_len.size(), hg.hap_names.size(), hg.path_off.data(), hg.path_nodes.data()}; }
+            hap_names.insert(hap_names.end(), names.begin(), names.end());
             hap_off[k + 1] = hap_names.size();
         }
         DbHolder sdb{ctx};
-        PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), &sdb.db));
+        if (use_images) PTX_TRY(db_from_images(ctx, Su, imp.data(), g_rs.data(), g_re.data(), &sdb.db));   // trio index included
+        else PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), &sdb.db));
         lap("db upload");
         // the same resident reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
@@ -308,6 +342,11 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         met.resize(hap_names.size());
         PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data(), met.data(), info.data()));
         lap("strain step");
+        if (!use_images && cfg->image_cache == 2) {   // leave images behind for the next run
+            for (uint32_t k = 0; k < Su; ++k)
+                PTX_TRY(db_save_image(ctx, sdb.db, k, graphs[use[k]].hap_names, image_of(ranges[sel[use[k]]].species)));
+            lap("graph images written");
+        }
     }
 
     // ---- a15: abundance_est (profile.rs:3091-3289)

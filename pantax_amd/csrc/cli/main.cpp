@@ -14,6 +14,7 @@ static void usage() {
             "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
             "  --min_cov N  --min_depth N  --sample N (default 500000)  --ds a,b,c  --smode 0|1  --no-filter\n"
             "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
+            "  --image-cache 0|1|2  device-ready graph images <db>/species_graph_info/<otu>.hipdb: 1 = use, 2 = use and write\n"
             "  --filter-gaf  first replace the GAF by its best alignment per read (long reads; alignment.rs:171-175, gaf_filter.rs)\n"
             "  --filter-only <in.gaf> [<out.gaf>]   just write <stem>_filtered.gaf (or <out.gaf>) and exit\n"
             "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n");
@@ -60,6 +61,7 @@ int main(int argc, char **argv) {
         else if (a == "--zip") c.zip = next();        // serialize | lz | zstd (main.rs: --zip)
         else if (a == "--round") c.full = 0;
         else if (a == "--filter-gaf") filter_gaf = true;
+        else if (a == "--image-cache") c.image_cache = atoi(next());
         else if (a == "--filter-only") { filter_in = next(); if (i + 1 < argc && argv[i + 1][0] != '-') filter_out = argv[++i]; }
         else if (a == "--device") device = atoi(next());
         else { usage(); return 2; }

@@ -43,8 +43,8 @@ int fail(Ctx *ctx, int code, const char *fmt, ...);
 // block is kept (up to DEV_CACHE_MAX bytes in all) and handed to the next request of a similar size; before a block
 // freed since the last device-wide wait is reused, the device is synchronised once -- the guarantee hipFree gave.
 constexpr size_t DEV_CACHE_MAX = 48ull << 30;
-hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out);
-void dev_cache_free(void *p, size_t cap);
+hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out);
+void dev_cache_free(void *p, size_t cap, int dev);   // dev: the device the block was allocated on (the caller's current device may differ)
 void dev_cache_trim();   // really free everything cached for the current device (pantax_hip_destroy)
 
 template <class T>
@@ -52,13 +52,14 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     size_t cap = 0;      // bytes of the underlying allocation (owned buffers)
+    int dev = 0;         // device it lives on
     bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p && owned) dev_cache_free(p, cap);
+        if (p && owned) dev_cache_free(p, cap, dev);
         p = nullptr;
         n = 0;
         cap = 0;
@@ -74,13 +75,13 @@ struct DevBuf {
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
-        hipError_t e = dev_cache_alloc((void **)&p, (count ? count : 1) * sizeof(T), &cap);
+        hipError_t e = dev_cache_alloc((void **)&p, (count ? count : 1) * sizeof(T), &cap, &dev);
         if (e == hipSuccess) n = count ? count : 1;
         return e;
     }
     size_t bytes() const { return n * sizeof(T); }
     // take over another buffer's allocation
-    void take(DevBuf &o) { release(); p = o.p; n = o.n; cap = o.cap; owned = o.owned; o.p = nullptr; o.n = 0; o.cap = 0; o.owned = true; }
+    void take(DevBuf &o) { release(); p = o.p; n = o.n; cap = o.cap; dev = o.dev; owned = o.owned; o.p = nullptr; o.n = 0; o.cap = 0; o.owned = true; }
 };
 
 // page-locked host staging (grow-only): a copy from / to pageable memory makes the runtime stage and wait,
@@ -296,12 +297,22 @@ int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
 // one species' graph as the db upload takes it: node lengths, and the walks as a local CSR (path_off may start anywhere)
 struct GraphPart {
     const int64_t *node_len; uint64_t n_nodes; uint64_t n_haps; const uint64_t *path_off; const uint32_t *path_nodes;
+    const uint32_t *node_len32 = nullptr;   // used instead of node_len when set (device-ready images store 32-bit lengths)
+    // device-ready image (db_image.cpp): the arrays can be streamed from the file, the node tables are derived on the
+    // device, and what the image states about itself is taken as given
+    int fd = -1; uint64_t off_node_len = 0, off_path_nodes = 0; uint64_t n_bases = 0; int all_same = -1;
+    int64_t len(uint64_t v) const { return node_len32 ? (int64_t)node_len32[v] : node_len[v]; }
 };
+// stage_db.hip: node tables + walk check on the device (image loads), and the move of species-local trio rows
+int node_tables_launch(Ctx *ctx, Db *db, const uint64_t *sp_bits, uint32_t *d_flags);
+int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows);
 int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out);
 // large pageable host buffers (mmapped text, graph arrays) -> HBM through two pinned chunks: a few threads copy the next
 // chunk into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged
 // by one runtime thread at ~10 GB/s).  Returns after the last chunk has arrived.
 int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+// the same from an open file (pread straight into the pinned chunks: no page of the file is mapped or faulted in)
+int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t bytes);
 // fn(begin, end) over [0, n) split across up to n_threads host threads (the calling thread takes the first slice)
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn);
 // small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)

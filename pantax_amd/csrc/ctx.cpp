@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstring>
 #include <thread>
+#include <unistd.h>
 #include "common.hpp"
 
 namespace ptx {
@@ -196,10 +197,11 @@ inline size_t round_cap(size_t bytes) {
 }
 }  // namespace
 
-hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out) {
+hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out) {
     const size_t want = round_cap(bytes ? bytes : 1);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    *dev_out = dev;
     DevCache &c = dev_cache();
     {
         std::unique_lock<std::mutex> lk(c.mu);
@@ -233,10 +235,8 @@ hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out) {
     return e;
 }
 
-void dev_cache_free(void *p, size_t cap) {
+void dev_cache_free(void *p, size_t cap, int dev) {
     if (!p) return;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     DevCache &c = dev_cache();
     {
         std::lock_guard<std::mutex> g(c.mu);
@@ -264,11 +264,32 @@ void dev_cache_trim() {
     for (auto &kv : blocks) (void)hipFree(kv.second.p);
 }
 
-int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) {
+namespace {
+// [src + off, +n) or (fd, file_off + off, n) -> pinned slot, on a few threads (about 2 MB each: the copies are memory-bound)
+void stage_chunk(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64_t n) {
+    constexpr int NTH_MAX = 16;
+    static const int NTH_HW = (int)std::max(2u, std::min<unsigned>(NTH_MAX, std::thread::hardware_concurrency() / 2));
+    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>(NTH_HW, n >> 21));
+    auto piece = [=](int t) {
+        const uint64_t b = n * t / nth, e = n * (t + 1) / nth;
+        if (src) { std::memcpy(slot + b, src + pos + b, e - b); return; }
+        uint64_t done = b;
+        while (done < e) {   // pread may return short
+            const ssize_t r = ::pread(fd, slot + done, e - done, (off_t)(pos + done));
+            if (r <= 0) { std::memset(slot + done, 0, e - done); break; }   // truncated file: the caller validated sizes, zeros keep the run defined
+            done += (uint64_t)r;
+        }
+    };
+    std::thread th[NTH_MAX];
+    for (int t = 1; t < nth; ++t) th[t] = std::thread(piece, t);
+    piece(0);
+    for (int t = 1; t < nth; ++t) th[t].join();
+}
+
+int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_off, uint64_t size) {
     if (size == 0) return 0;
     constexpr uint64_t CH = 16ull << 20;
-    constexpr int NTH = 4;
-    if (size < (1ull << 20)) {   // small: not worth the staging
+    if (src && size < (1ull << 20)) {   // small: not worth the staging
         PTX_HIP(ctx, hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, ctx->stream));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return 0;
@@ -279,18 +300,12 @@ int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) {
     PTX_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     int rc = 0;
     uint64_t i = 0;
-    const uint8_t *text = static_cast<const uint8_t *>(src);
     uint8_t *dst = static_cast<uint8_t *>(d_dst);
     for (uint64_t off = 0; off < size && rc == 0; off += CH, ++i) {
         const uint64_t n = std::min<uint64_t>(CH, size - off);
         uint8_t *slot = ctx->pin_text.p + (i & 1) * CH;
         if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
-        std::thread th[NTH];
-        for (int t = 0; t < NTH; ++t) {
-            const uint64_t b = n * t / NTH, e = n * (t + 1) / NTH;
-            th[t] = std::thread([=] { std::memcpy(slot + b, text + off + b, e - b); });
-        }
-        for (auto &t : th) t.join();
+        stage_chunk(slot, static_cast<const uint8_t *>(src), fd, (src ? 0 : file_off) + off, n);
         if (hipMemcpyAsync(dst + off, slot, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipEventRecord(ev[i & 1], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     }
@@ -298,6 +313,10 @@ int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) {
     (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     return rc;
 }
+}  // namespace
+
+int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) { return upload_staged(ctx, d_dst, src, -1, 0, size); }
+int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t size) { return upload_staged(ctx, d_dst, nullptr, fd, file_off, size); }
 
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn) {
     if (n_threads < 1) n_threads = 1;

@@ -250,7 +250,7 @@ class Engine:
     def profile(self, db, wd, gaf, species=True, strain=True, output_dir=None, fr=0.3, fc=0.46, sr=0.85, sd=0.2,
                 min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,
                 mode=2, sample_nodes=0, designated_species=None, zip="serialize", out_binning_file=None,
-                reads_binning_file=None, range_file=None, species_len_file=None):
+                reads_binning_file=None, range_file=None, species_len_file=None, image_cache=0):
         """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out."""
         enc = lambda x: None if x is None else str(x).encode()
         cfg = _ffi.ProfilingConfig(
@@ -260,8 +260,35 @@ class Engine:
             unique_trio_nodes_fraction=fr, unique_trio_nodes_mean_count_f=fc, single_cov_ratio=sr, single_cov_diff=sd,
             min_cov=min_cov, min_depth=min_depth, species=int(species), strain=int(strain), shift=int(shift),
             filtered=int(filtered), full=int(full), force=int(force), mode=mode, sample_nodes=sample_nodes,
-            designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1)
+            designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1, image_cache=int(image_cache))
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
+
+    def save_images(self, paths, hap_names):
+        """one device-ready image per species of the resident db (graph + unique-trio index)."""
+        ps = (C.c_char_p * self.S)(*[x.encode() for x in paths])
+        hn = (C.c_char_p * max(self.H, 1))(*[x.encode() for x in hap_names])
+        self._check(self.lib.pantax_hip_db_save_images(self.ctx, self.db, ps, hn))
+
+    def load_images(self, paths, range_start, range_end, species):
+        """Resident db from images; `species` (the same graphs as objects) only supplies the host-side shapes the
+        wrapper keeps (node_off, hap_off) -- nothing of it is uploaded."""
+        if self.db:
+            self.lib.pantax_hip_db_free(self.ctx, self.db)
+            self.db = None
+        S = len(paths)
+        self.S = S
+        self.range_start = as_c(range_start, np.int64)
+        self.range_end = as_c(range_end, np.int64)
+        self.node_off = np.zeros(S + 1, dtype=np.uint64)
+        self.node_off[1:] = np.cumsum([len(g.node_len) for g in species])
+        self.hap_off = np.zeros(S + 1, dtype=np.uint64)
+        self.hap_off[1:] = np.cumsum([len(g.path_off) - 1 for g in species])
+        self.V, self.H = int(self.node_off[-1]), int(self.hap_off[-1])
+        ps = (C.c_char_p * S)(*[x.encode() for x in paths])
+        db = C.c_void_p()
+        self._check(self.lib.pantax_hip_db_load_images(self.ctx, C.c_uint32(S), ps, p(self.range_start), p(self.range_end), C.byref(db)))
+        self.db = db
+        self.U = None
 
     def gaf_filter(self, gaf_path, out_path=None):
         """filter_max_alignment_mt (gaf_filter.rs:44-97) on the device -> (lines, records, lines written)."""

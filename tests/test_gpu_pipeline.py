@@ -366,3 +366,73 @@ def test_device_gaf_filter_edge_inputs(eng, tmp_path):
     assert eng.gaf_filter(str(junk)) == (4, 0, 0)
     with pytest.raises(PantaxHipError):
         eng.gaf_filter(str(tmp_path / "missing.gaf"))
+
+
+@pytest.mark.gpu
+def test_graph_images_roundtrip_and_file_seam(world, tmp_path):
+    """device-ready images (graph + unique-trio index).  A db loaded from images has the trio table of the
+    db it was saved from and gives the same strain step; the file seam writes them (image_cache 2), uses them
+    (image_cache 1, no graph parse, no trio build), ignores a truncated or a stale one."""
+    from pantax_amd.engine import Engine, metrics_to_dicts
+    sset, root, db, gaf, eng0 = world
+    eng = Engine(0)
+    try:
+        rd = sset.reads
+        eng.upload_db(sset.species)
+        eng.upload_packed(rd)
+        trio_a = eng.trio_nodes_info()
+        sp, rc, bs, lm, uq = eng.rcls_profile()
+        keep, absolute, _ = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
+        cov_a = eng.get_node_abundances()
+        met_a = metrics_to_dicts(eng.strain_profiling(absolute, species_active=keep)[0], eng.H)
+        paths = [str(tmp_path / (g.name + ".hipdb")) for g in sset.species]
+        eng.save_images(paths, [hn for g in sset.species for hn in g.hap_names])
+        eng.load_images(paths, [g.range_start for g in sset.species], [g.range_end for g in sset.species], sset.species)
+        trio_b = eng.trio_nodes_info()                       # already in place: nothing is rebuilt
+        for a, b in zip(trio_a, trio_b):
+            assert np.array_equal(a, b)
+        eng.rcls_profile()
+        cov_b = eng.get_node_abundances()
+        for a, b in zip(cov_a[:3], cov_b[:3]):
+            assert np.array_equal(a, b)
+        met_b = metrics_to_dicts(eng.strain_profiling(absolute, species_active=keep)[0], eng.H)
+        assert met_a == met_b
+        # a truncated image is refused by the loader
+        bad = tmp_path / "bad.hipdb"
+        bad.write_bytes(open(paths[0], "rb").read()[:-40])
+        from pantax_amd.engine import PantaxHipError
+        with pytest.raises(PantaxHipError):
+            eng.load_images([str(bad)] + paths[1:], [g.range_start for g in sset.species], [g.range_end for g in sset.species], sset.species)
+    finally:
+        eng.close()
+    # ---- file seam
+    exp_species, exp_strain, _ = _oracle_tables(sset)
+    import shutil
+    db2 = root / "db_img"
+    shutil.copytree(db, db2)
+    cwd = os.getcwd()
+
+    def run(name, **kw):
+        wd = root / name
+        wd.mkdir()
+        os.chdir(str(wd))
+        try:
+            eng0.profile(str(db2), str(wd), str(gaf), **kw)
+        finally:
+            os.chdir(cwd)
+        _check_outputs(str(wd), sset, exp_species, exp_strain)
+        return wd
+    imgs = [db2 / "species_graph_info" / (g.name + ".hipdb") for g in sset.species]
+    run("wd_img0", image_cache=1)                            # no images yet: parsed, none written
+    assert not any(p.exists() for p in imgs)
+    run("wd_img_write", image_cache=2)
+    kept = [p for p in imgs if p.exists()]
+    assert kept                                              # one per species that went through the strain step
+    ref = run("wd_img_read", image_cache=1)
+    kept[0].write_bytes(kept[0].read_bytes()[:1000])         # damaged image: the run falls back to the graph files
+    run("wd_img_damaged", image_cache=1)
+    run("wd_img_rewrite", image_cache=2)                     # parsed again, and the images are written afresh
+    assert kept[0].stat().st_size > 1000
+    run("wd_img_read2", image_cache=1)
+    for f in ("species_abundance.txt", "strain_abundance.txt"):
+        assert open(ref / f).read() == open(root / "wd_img_write" / f).read()

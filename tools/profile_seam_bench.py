@@ -14,11 +14,12 @@ db = os.path.join(root, "db"); os.mkdir(db)
 t0 = time.perf_counter(); synth.write_db(sset, db); gaf = os.path.join(root, "gfa_mapped.gaf"); synth.write_gaf(sset.reads, gaf)
 print("wrote db + gaf (%.0f MB) in %.1f s" % (os.path.getsize(gaf) / 1e6, time.perf_counter() - t0))
 eng = Engine(0)
+IC = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 1: write graph images in call 0, use them afterwards
 for i in range(3):
     wd = os.path.join(root, "wd%d" % i); os.mkdir(wd)
     cwd = os.getcwd(); os.chdir(wd)
     t0 = time.perf_counter()
-    eng.profile(db, wd, gaf, zip="serialize", sample_nodes=500000)
+    eng.profile(db, wd, gaf, zip="serialize", sample_nodes=500000, image_cache=(2 if i == 0 else 1) if IC else 0)
     dt = time.perf_counter() - t0
     os.chdir(cwd)
     print("pantax_hip_profile call %d: %.1f ms (%.1f Mreads/s from files to files)" % (i, dt * 1e3, n / dt / 1e6))
