@@ -108,7 +108,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     HostReads hr;
     ReadsHolder reads{ctx};
     reads.rd = new pantax_hip_reads();
-    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr, reads.rd));
+    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr, reads.rd, mf.fd));
     const uint64_t R = hr.qlen.size();
     lap("ranges + GAF tokenise");
 

@@ -349,7 +349,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
 int trio_index_build(Ctx *ctx, Db *db);
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr);
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 
 }  // namespace ptx

@@ -165,9 +165,10 @@ __global__ void __launch_bounds__(256) gaf_fill_kernel(const uint8_t *__restrict
     if (in_run) o.node_id[w++] = (uint32_t)v;
 }
 
-int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out) {
+int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out, int fd) {
     PTX_HIP(ctx, d_txt.alloc(size + 16));
-    PTX_TRY(upload_big(ctx, d_txt.p, text, size));
+    if (fd >= 0) PTX_TRY(upload_file(ctx, d_txt.p, fd, 0, size));
+    else PTX_TRY(upload_big(ctx, d_txt.p, text, size));
     const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
     DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
     PTX_HIP(ctx, tile_cnt.alloc(n_tiles)); PTX_HIP(ctx, tile_base.alloc(n_tiles)); PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t
 // text (host, `size` bytes) -> HostReads, tokenised on the device.  With `resident` the packed reads stay in HBM
 // (the object is ready for pantax_hip_bin_reads) and only the columns host code needs come back: read_len, mapq,
 // flags, id hashes and id spans -- the walks (node_id, step_off, path_start, path_end) are not downloaded.
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident) {
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd) {
     out = HostReads();
     if (size == 0) {
         if (resident) {
@@ -225,7 +226,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     DevBuf<uint8_t> d_txt;
     DevBuf<uint32_t> nl_pos, tot, scan_tmp;
     uint32_t n_nl = 0;
-    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl));
+    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd));
     PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
     const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
     DevBuf<uint32_t> r32[8], ridx, soff;
@@ -318,7 +319,7 @@ extern "C" int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path,
     pantax_hip_gaf *g = new pantax_hip_gaf();
     std::string e = g->mf.open(path);
     if (!e.empty()) { delete g; return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str()); }
-    const int rc = gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads);
+    const int rc = gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, nullptr, g->mf.fd);
     if (rc != 0) { delete g; return rc; }
     *out = g;
     return 0;
@@ -333,7 +334,7 @@ extern "C" int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, 
     std::unique_ptr<pantax_hip_reads> rd(new pantax_hip_reads());
     std::string e = g->mf.open(path);
     if (!e.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str());
-    PTX_TRY(gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, rd.get()));
+    PTX_TRY(gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, rd.get(), g->mf.fd));
     *reads_out = rd.release();
     if (gaf_out) *gaf_out = g.release();
     return 0;

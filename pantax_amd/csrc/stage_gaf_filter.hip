@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) filter_pick_kernel(uint32_t n, const uint
 
 // keep_out[i] = 1 when raw line i (0-based, lines split at '\n') is written by the filter
 int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uint8_t> &keep_out, std::vector<uint32_t> &nl_out, uint64_t *n_records,
-                      uint64_t *n_kept_out) {
+                      uint64_t *n_kept_out, int fd) {
     keep_out.clear(); nl_out.clear();
     if (n_records) *n_records = 0;
     if (n_kept_out) *n_kept_out = 0;
@@ -213,7 +213,7 @@ int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uin
     DevBuf<uint8_t> d_txt;
     DevBuf<uint32_t> nl_pos;
     uint32_t n_nl = 0;
-    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl));
+    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd));
     const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
     DevBuf<uint64_t> hash, ident, hash_b;
     DevBuf<uint32_t> matches, f15b, f15e, line_a, line_b, table, scan_tmp, cnt;
@@ -299,7 +299,7 @@ extern "C" int pantax_hip_gaf_filter(pantax_hip_ctx *ctx, const char *gaf_path, 
     std::vector<uint8_t> keep;
     std::vector<uint32_t> nl;
     uint64_t nrec = 0, nkept = 0;
-    PTX_TRY(gaf_filter_device(ctx, mf.data, mf.size, keep, nl, &nrec, &nkept));
+    PTX_TRY(gaf_filter_device(ctx, mf.data, mf.size, keep, nl, &nrec, &nkept, mf.fd));
     FILE *f = std::fopen(out.c_str(), "wb");
     if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", out.c_str());
     std::vector<char> buf;
