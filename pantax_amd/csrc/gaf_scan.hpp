@@ -7,6 +7,7 @@ namespace ptx {
 
 // d_txt: size + 16 bytes; nl_pos[n_nl] = byte offsets of the '\n's in order.  Line i = (nl_pos[i-1], nl_pos[i]).
 int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out,
-                        int fd = -1 /* the open file behind `text`: uploaded with pread instead of through the mapping */);
+                        int fd = -1 /* the open file behind `text`: uploaded with pread instead of through the mapping */,
+                        uint64_t file_off = 0 /* where `text` starts in that file */);
 
 }  // namespace ptx

@@ -18,6 +18,7 @@
 // The text is read three times (byte-granular gathers per line: L2-friendly, each line is contiguous).
 // Algorithmic bytes: 3 N (text) + 4 T + 30 R (outputs).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -165,9 +166,9 @@ __global__ void __launch_bounds__(256) gaf_fill_kernel(const uint8_t *__restrict
     if (in_run) o.node_id[w++] = (uint32_t)v;
 }
 
-int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out, int fd) {
+int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out, int fd, uint64_t file_off) {
     PTX_HIP(ctx, d_txt.alloc(size + 16));
-    if (fd >= 0) PTX_TRY(upload_file(ctx, d_txt.p, fd, 0, size));
+    if (fd >= 0) PTX_TRY(upload_file(ctx, d_txt.p, fd, file_off, size));
     else PTX_TRY(upload_big(ctx, d_txt.p, text, size));
     const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
     DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
@@ -207,26 +208,19 @@ __global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-// text (host, `size` bytes) -> HostReads, tokenised on the device.  With `resident` the packed reads stay in HBM
-// (the object is ready for pantax_hip_bin_reads) and only the columns host code needs come back: read_len, mapq,
-// flags, id hashes and id spans -- the walks (node_id, step_off, path_start, path_end) are not downloaded.
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd) {
-    out = HostReads();
-    if (size == 0) {
-        if (resident) {
-            static const uint32_t zero = 0;
-            resident->R = resident->T = 0;
-            PTX_TRY(upload(ctx, resident->d_step_off, &zero, 1));
-            PTX_TRY(build_step_read(ctx, resident, 0));
-            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        return 0;
-    }
-    if (size >= 0xFFFFFFF0ull) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu bytes exceed 32-bit text positions; split the input", (unsigned long long)size);
+// one tokenised piece of the text (< 4 GiB: positions inside a piece are 32-bit), still on the device
+struct GafPiece {
+    uint64_t R = 0, T = 0;
+    DevBuf<uint32_t> o32[7];   // step_off (piece-local), node_id, pstart, pend, qlen, id_off (piece-local), id_len
+    DevBuf<uint8_t> o8[2];     // mapq, flags
+    DevBuf<uint64_t> o_hash;
+};
+
+static int tokenize_piece(Ctx *ctx, const char *text, uint64_t size, int fd, uint64_t file_off, GafPiece &pc) {
     DevBuf<uint8_t> d_txt;
     DevBuf<uint32_t> nl_pos, tot, scan_tmp;
     uint32_t n_nl = 0;
-    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd));
+    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd, file_off));
     PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
     const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
     DevBuf<uint32_t> r32[8], ridx, soff;
@@ -247,21 +241,107 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     PTX_TRY(download(ctx, rt, tot.p + 1, 2));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t R = rt[0], T = rt[1];
-    DevBuf<uint32_t> o32[7];
-    DevBuf<uint8_t> o8[2];
-    DevBuf<uint64_t> o_hash;
-    PTX_HIP(ctx, o32[0].alloc(R + 1)); PTX_HIP(ctx, o32[1].alloc(T ? T : 1));
-    for (int k = 2; k < 7; ++k) PTX_HIP(ctx, o32[k].alloc(R ? R : 1));
-    for (auto &b : o8) PTX_HIP(ctx, b.alloc(R ? R : 1));
-    PTX_HIP(ctx, o_hash.alloc(R ? R : 1));
-    GafOut go{o32[0].p, o32[1].p, o32[2].p, o32[3].p, o32[4].p, o32[5].p, o32[6].p, o8[0].p, o8[1].p, o_hash.p};
+    pc.R = R; pc.T = T;
+    PTX_HIP(ctx, pc.o32[0].alloc(R + 1)); PTX_HIP(ctx, pc.o32[1].alloc(T ? T : 1));
+    for (int k = 2; k < 7; ++k) PTX_HIP(ctx, pc.o32[k].alloc(R ? R : 1));
+    for (auto &b : pc.o8) PTX_HIP(ctx, b.alloc(R ? R : 1));
+    PTX_HIP(ctx, pc.o_hash.alloc(R ? R : 1));
+    GafOut go{pc.o32[0].p, pc.o32[1].p, pc.o32[2].p, pc.o32[3].p, pc.o32[4].p, pc.o32[5].p, pc.o32[6].p, pc.o8[0].p, pc.o8[1].p, pc.o_hash.p};
     {
         KTimer t(ctx, "gaf_fill_kernel");
         hipLaunchKernelGGL(gaf_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, n_raw, raw, ridx.p, soff.p, (uint32_t)R, (uint32_t)T, go);
     }
     PTX_HIP(ctx, hipGetLastError());
-    out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R); out.id_span.resize(R);
-    std::vector<uint32_t> id_off(R), id_len(R);
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the piece's text and raw columns are released on return
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) add_u32_offset_kernel(uint64_t n, uint32_t *__restrict__ v, uint32_t add) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) v[i] += add;
+}
+
+// text (host, `size` bytes) -> HostReads, tokenised on the device.  With `resident` the packed reads stay in HBM
+// (the object is ready for pantax_hip_bin_reads) and only the columns host code needs come back: read_len, mapq,
+// flags, id hashes and id spans -- the walks (node_id, step_off, path_start, path_end) are not downloaded.
+// Texts of 4 GiB and more are cut at line ends into pieces (32-bit positions inside a piece) whose packed columns are
+// joined on the device; PANTAX_GAF_PIECE_BYTES lowers the piece size (tests).
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd) {
+    out = HostReads();
+    if (size == 0) {
+        if (resident) {
+            static const uint32_t zero = 0;
+            resident->R = resident->T = 0;
+            PTX_TRY(upload(ctx, resident->d_step_off, &zero, 1));
+            PTX_TRY(build_step_read(ctx, resident, 0));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return 0;
+    }
+    uint64_t piece_max = 0xE0000000ull;   // 3.5 GiB
+    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < piece_max) piece_max = (uint64_t)v; }
+    std::vector<std::unique_ptr<GafPiece>> pcs;
+    std::vector<uint64_t> piece_off;
+    for (uint64_t off = 0; off < size;) {
+        uint64_t end = std::min<uint64_t>(size, off + piece_max);
+        if (end < size) {   // back to the last line end inside the piece
+            const void *nl = memrchr(text + off, '\n', (size_t)(end - off));
+            if (!nl) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: a line of more than %llu bytes at offset %llu", (unsigned long long)piece_max, (unsigned long long)off);
+            end = (uint64_t)(static_cast<const char *>(nl) - text) + 1;
+        }
+        pcs.emplace_back(new GafPiece());
+        piece_off.push_back(off);
+        PTX_TRY(tokenize_piece(ctx, text + off, end - off, fd, off, *pcs.back()));
+        off = end;
+    }
+    uint64_t R = 0, T = 0;
+    for (auto &pc : pcs) { R += pc->R; T += pc->T; }
+    if (R >= 0xFFFFFFFFull || T >= 0xFFFFFFFFull)
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu reads / %llu walk steps exceed the 32-bit offsets of one batch; split the input", (unsigned long long)R, (unsigned long long)T);
+    // id spans: piece-local 32-bit positions -> positions in the whole text
+    out.id_span.resize(R);
+    {
+        uint64_t r0 = 0;
+        std::vector<uint32_t> id_off, id_len;
+        for (size_t k = 0; k < pcs.size(); ++k) {
+            GafPiece &pc = *pcs[k];
+            id_off.resize(pc.R); id_len.resize(pc.R);
+            PTX_TRY(download(ctx, id_off.data(), pc.o32[5].p, pc.R)); PTX_TRY(download(ctx, id_len.data(), pc.o32[6].p, pc.R));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint64_t i = 0; i < pc.R; ++i) out.id_span[r0 + i] = {piece_off[k] + (uint64_t)id_off[i], id_len[i]};
+            r0 += pc.R;
+        }
+    }
+    // join the pieces (a single piece is used as it is)
+    DevBuf<uint32_t> o32[5];
+    DevBuf<uint8_t> o8[2];
+    DevBuf<uint64_t> o_hash;
+    if (pcs.size() == 1) {
+        for (int k = 0; k < 5; ++k) o32[k].take(pcs[0]->o32[k]);
+        o8[0].take(pcs[0]->o8[0]); o8[1].take(pcs[0]->o8[1]); o_hash.take(pcs[0]->o_hash);
+    } else {
+        PTX_HIP(ctx, o32[0].alloc(R + 1)); PTX_HIP(ctx, o32[1].alloc(T ? T : 1));
+        for (int k = 2; k < 5; ++k) PTX_HIP(ctx, o32[k].alloc(R ? R : 1));
+        for (auto &b : o8) PTX_HIP(ctx, b.alloc(R ? R : 1));
+        PTX_HIP(ctx, o_hash.alloc(R ? R : 1));
+        uint64_t r0 = 0, t0 = 0;
+        for (auto &pcp : pcs) {
+            GafPiece &pc = *pcp;
+            auto d2d = [&](void *dst, const void *src, uint64_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess; };
+            PTX_HIP(ctx, d2d(o32[0].p + r0, pc.o32[0].p, pc.R * 4)); PTX_HIP(ctx, d2d(o32[1].p + t0, pc.o32[1].p, pc.T * 4));
+            for (int k = 2; k < 5; ++k) PTX_HIP(ctx, d2d(o32[k].p + r0, pc.o32[k].p, pc.R * 4));
+            PTX_HIP(ctx, d2d(o8[0].p + r0, pc.o8[0].p, pc.R)); PTX_HIP(ctx, d2d(o8[1].p + r0, pc.o8[1].p, pc.R));
+            PTX_HIP(ctx, d2d(o_hash.p + r0, pc.o_hash.p, pc.R * 8));
+            if (pc.R && t0) hipLaunchKernelGGL(add_u32_offset_kernel, dim3(grid_for(pc.R, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, pc.R, o32[0].p + r0, (uint32_t)t0);
+            r0 += pc.R; t0 += pc.T;
+        }
+        const uint32_t t32 = (uint32_t)T;
+        PTX_HIP(ctx, hipMemcpyAsync(o32[0].p + R, &t32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        pcs.clear();
+    }
+    DevBuf<uint32_t> tot, scan_tmp;
+    PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
+    out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R);
     if (!resident) {
         out.step_off.resize(R + 1); out.node_id.resize(T); out.pstart.resize(R); out.pend.resize(R);
         PTX_TRY(download(ctx, out.step_off.data(), o32[0].p, R + 1));
@@ -290,7 +370,6 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     uint32_t max_id = 0;
     PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
-    PTX_TRY(download(ctx, id_off.data(), o32[5].p, R)); PTX_TRY(download(ctx, id_len.data(), o32[6].p, R));
     PTX_TRY(download(ctx, out.mapq.data(), o8[0].p, R)); PTX_TRY(download(ctx, out.flags.data(), o8[1].p, R));
     PTX_TRY(download(ctx, out.id_hash.data(), o_hash.p, R));
     if (resident) PTX_TRY(download(ctx, &max_id, tot.p + 3, 1));
@@ -303,7 +382,6 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         PTX_TRY(build_step_read(ctx, resident, max_id));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    for (uint64_t k = 0; k < R; ++k) out.id_span[k] = {(uint64_t)id_off[k], id_len[k]};
     out.n_lines = R;
     out.ids_distinct = n_dup == 0 ? 1 : 0;
     return 0;

@@ -217,12 +217,17 @@ def eng():
 
 
 @pytest.mark.gpu
-def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path):
+@pytest.mark.parametrize("piece", [None, "200000", "97"])
+def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkeypatch):
     """pantax_hip_gaf_load_device (GAF text tokenised by HIP kernels) gives the arrays of the host tokenizer bit for
     bit: a generated GAF plus every quirk of the format contract (comments, '*' nulls, CRLF, ragged and empty lines,
     no trailing newline, overflowing numbers, 13+ fields, digits inside non-numeric fields)."""
     from pantax_amd import io as pio, synth
-    sset = synth.make_set(77, 3, 4, 20000, 60000, with_ids=True)
+    # texts of 4 GiB and more are tokenised in pieces cut at line ends and joined on the device; a small piece size
+    # sends these small files through that path (97 bytes: nearly every line of the quirks file is its own piece)
+    if piece is not None:
+        monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", piece)
+    sset = synth.make_set(77, 3, 4, 20000 if piece != "97" else 300, 60000, with_ids=True)
     p1 = tmp_path / "gen.gaf"
     synth.write_gaf(sset.reads, p1)
     p2 = tmp_path / "quirks.gaf"
@@ -240,10 +245,16 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path):
         b"r8\n"
         b"r9\t90\t0\t90\t+\t>8>9\t200\t0\t90")
     for p in (p1, p2):
+        if piece == "97" and p is p1:
+            continue                      # its lines are longer than the piece: refused, see below
         host = pio.load_gaf(p, n_threads=3)
         dev = pio.load_gaf(p, engine=eng)
         for k in host:
             assert np.array_equal(host[k], dev[k]), (p.name, k)
+    if piece == "97":
+        from pantax_amd.engine import PantaxHipError
+        with pytest.raises(PantaxHipError):
+            pio.load_gaf(p1, engine=eng)   # a line longer than a piece
     empty = tmp_path / "empty.gaf"
     empty.write_bytes(b"")
     assert pio.load_gaf(empty, engine=eng)["step_off"].tolist() == [0]
@@ -254,11 +265,12 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path):
 
 
 @pytest.mark.gpu
-def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path):
+def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path, monkeypatch):
     """pantax_hip_reads_load_gaf (file -> device tokenizer -> resident reads, walks never on the host) gives the same
     binning, counters, coverage histogram and trio bases as uploading the host-tokenised arrays; drop flags can be
     replaced in place."""
     from pantax_amd import io as pio, synth
+    monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", "1000000")   # the resident form through the piece-wise tokenizer as well
     sset = synth.make_set(78, 3, 4, 30000, 80000)
     p1 = tmp_path / "gen.gaf"
     synth.write_gaf(sset.reads, p1)
