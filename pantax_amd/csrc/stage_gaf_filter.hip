@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "common.hpp"
@@ -202,54 +203,119 @@ __global__ void __launch_bounds__(256) filter_pick_kernel(uint32_t n, const uint
 
 }  // namespace
 
-// keep_out[i] = 1 when raw line i (0-based, lines split at '\n') is written by the filter
-int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uint8_t> &keep_out, std::vector<uint32_t> &nl_out, uint64_t *n_records,
+namespace {
+struct FilterPiece {   // the parsed lines of one piece of the text (< 4 GiB), on the device
+    uint32_t n_raw = 0;
+    DevBuf<uint64_t> hash, ident;
+    DevBuf<uint32_t> matches;
+    DevBuf<uint8_t> state, pass;
+};
+__global__ void __launch_bounds__(256) iota_u32_kernel(uint32_t n, uint32_t *__restrict__ v) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+}  // namespace
+
+// keep_out[i] = 1 when raw line i (0-based, lines split at '\n') is written by the filter; line_end[i] = offset of the
+// line's '\n' (or the text size for an unterminated last line).  Texts of 4 GiB and more are parsed in pieces cut at
+// line ends (PANTAX_GAF_PIECE_BYTES lowers the piece size for tests); the grouping by read id runs over all lines.
+int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uint8_t> &keep_out, std::vector<uint64_t> &line_end, uint64_t *n_records,
                       uint64_t *n_kept_out, int fd) {
-    keep_out.clear(); nl_out.clear();
+    keep_out.clear(); line_end.clear();
     if (n_records) *n_records = 0;
     if (n_kept_out) *n_kept_out = 0;
     if (size == 0) return 0;
-    if (size >= 0xFFFFFFF0ull) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_filter: %llu bytes exceed 32-bit text positions; split the input", (unsigned long long)size);
-    DevBuf<uint8_t> d_txt;
-    DevBuf<uint32_t> nl_pos;
-    uint32_t n_nl = 0;
-    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd));
-    const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
-    DevBuf<uint64_t> hash, ident, hash_b;
-    DevBuf<uint32_t> matches, f15b, f15e, line_a, line_b, table, scan_tmp, cnt;
-    DevBuf<uint8_t> state, pass, keep;
+    uint64_t piece_max = 0xE0000000ull;   // 3.5 GiB
+    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < piece_max) piece_max = (uint64_t)v; }
+    std::vector<std::unique_ptr<FilterPiece>> pcs;
+    uint64_t n_lines = 0, nrec = 0;
+    for (uint64_t off = 0; off < size;) {
+        uint64_t end = std::min<uint64_t>(size, off + piece_max);
+        if (end < size) {
+            const void *nl = memrchr(text + off, '\n', (size_t)(end - off));
+            if (!nl) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_filter: a line of more than %llu bytes at offset %llu", (unsigned long long)piece_max, (unsigned long long)off);
+            end = (uint64_t)(static_cast<const char *>(nl) - text) + 1;
+        }
+        const uint64_t psize = end - off;
+        const char *ptext = text + off;
+        DevBuf<uint8_t> d_txt;
+        DevBuf<uint32_t> nl_pos, f15b, f15e, line_tmp, cnt;
+        uint32_t n_nl = 0;
+        PTX_TRY(gaf_upload_and_scan(ctx, ptext, psize, d_txt, nl_pos, &n_nl, fd, off));
+        const uint32_t n_raw = n_nl + (ptext[psize - 1] != '\n' ? 1u : 0u);
+        pcs.emplace_back(new FilterPiece());
+        FilterPiece &pc = *pcs.back();
+        pc.n_raw = n_raw;
+        const size_t nr = n_raw ? n_raw : 1;
+        PTX_HIP(ctx, pc.hash.alloc(nr)); PTX_HIP(ctx, pc.ident.alloc(nr)); PTX_HIP(ctx, pc.matches.alloc(nr)); PTX_HIP(ctx, pc.state.alloc(nr)); PTX_HIP(ctx, pc.pass.alloc(nr));
+        PTX_HIP(ctx, f15b.alloc(nr)); PTX_HIP(ctx, f15e.alloc(nr)); PTX_HIP(ctx, line_tmp.alloc(nr)); PTX_HIP(ctx, cnt.alloc(1));
+        PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t), ctx->stream));
+        FilterRec rec{pc.hash.p, pc.ident.p, pc.matches.p, f15b.p, f15e.p, pc.state.p, pc.pass.p};
+        {
+            KTimer t(ctx, "filter_parse_kernel");
+            hipLaunchKernelGGL(filter_parse_kernel, dim3((n_raw + 255) / 256 ? (n_raw + 255) / 256 : 1), dim3(256), 0, ctx->stream, d_txt.p, psize, n_raw, n_nl,
+                               nl_pos.p, rec, line_tmp.p, cnt.p);
+        }
+        uint32_t n_slow = 0;
+        std::vector<uint8_t> h_state(n_raw);
+        std::vector<uint32_t> h_nl(n_nl);
+        PTX_TRY(download(ctx, &n_slow, cnt.p, 1));
+        PTX_TRY(download(ctx, h_state.data(), pc.state.p, n_raw));
+        PTX_TRY(download(ctx, h_nl.data(), nl_pos.p, n_nl));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint8_t st : h_state) nrec += st != 0;
+        for (uint32_t i = 0; i < n_nl; ++i) line_end.push_back(off + h_nl[i]);
+        if (n_raw > n_nl) line_end.push_back(size);
+        if (n_slow) {   // identities outside the exact fast path: the host's correctly rounded strtod, then back
+            std::vector<uint32_t> b(n_raw), e(n_raw);
+            std::vector<uint64_t> idb(n_raw);
+            PTX_TRY(download(ctx, b.data(), f15b.p, n_raw)); PTX_TRY(download(ctx, e.data(), f15e.p, n_raw));
+            PTX_TRY(download(ctx, idb.data(), pc.ident.p, n_raw));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t i = 0; i < n_raw; ++i) {
+                if (h_state[i] != 2) continue;
+                const std::string num(ptext + b[i], ptext + e[i]);   // already validated against f64::from_str's grammar
+                idb[i] = order_bits(std::strtod(num.c_str(), nullptr));
+            }
+            PTX_HIP(ctx, hipMemcpyAsync(pc.ident.p, idb.data(), n_raw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        n_lines += n_raw;
+        off = end;
+    }
+    if (n_lines >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_filter: %llu lines exceed 32-bit line numbers", (unsigned long long)n_lines);
+    const uint32_t n_raw = (uint32_t)n_lines;
     const size_t nr = n_raw ? n_raw : 1;
-    PTX_HIP(ctx, hash.alloc(nr)); PTX_HIP(ctx, ident.alloc(nr)); PTX_HIP(ctx, hash_b.alloc(nr)); PTX_HIP(ctx, matches.alloc(nr));
-    PTX_HIP(ctx, f15b.alloc(nr)); PTX_HIP(ctx, f15e.alloc(nr)); PTX_HIP(ctx, line_a.alloc(nr)); PTX_HIP(ctx, line_b.alloc(nr));
-    PTX_HIP(ctx, state.alloc(nr)); PTX_HIP(ctx, pass.alloc(nr)); PTX_HIP(ctx, keep.alloc(nr));
+    // all lines side by side (a single piece is used as it is)
+    DevBuf<uint64_t> hash, ident, hash_b;
+    DevBuf<uint32_t> matches, line_a, line_b, table, scan_tmp, cnt;
+    DevBuf<uint8_t> state, pass, keep;
+    if (pcs.size() == 1) {
+        hash.take(pcs[0]->hash); ident.take(pcs[0]->ident); matches.take(pcs[0]->matches); state.take(pcs[0]->state); pass.take(pcs[0]->pass);
+    } else {
+        PTX_HIP(ctx, hash.alloc(nr)); PTX_HIP(ctx, ident.alloc(nr)); PTX_HIP(ctx, matches.alloc(nr)); PTX_HIP(ctx, state.alloc(nr)); PTX_HIP(ctx, pass.alloc(nr));
+        uint64_t l0 = 0;
+        for (auto &pcp : pcs) {
+            FilterPiece &pc = *pcp;
+            if (pc.n_raw) {
+                PTX_HIP(ctx, hipMemcpyAsync(hash.p + l0, pc.hash.p, pc.n_raw * 8ull, hipMemcpyDeviceToDevice, ctx->stream));
+                PTX_HIP(ctx, hipMemcpyAsync(ident.p + l0, pc.ident.p, pc.n_raw * 8ull, hipMemcpyDeviceToDevice, ctx->stream));
+                PTX_HIP(ctx, hipMemcpyAsync(matches.p + l0, pc.matches.p, pc.n_raw * 4ull, hipMemcpyDeviceToDevice, ctx->stream));
+                PTX_HIP(ctx, hipMemcpyAsync(state.p + l0, pc.state.p, pc.n_raw, hipMemcpyDeviceToDevice, ctx->stream));
+                PTX_HIP(ctx, hipMemcpyAsync(pass.p + l0, pc.pass.p, pc.n_raw, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            l0 += pc.n_raw;
+        }
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        pcs.clear();
+    }
+    PTX_HIP(ctx, hash_b.alloc(nr)); PTX_HIP(ctx, line_a.alloc(nr)); PTX_HIP(ctx, line_b.alloc(nr)); PTX_HIP(ctx, keep.alloc(nr));
     PTX_HIP(ctx, table.alloc(sort_table_elems(nr))); PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(nr))); PTX_HIP(ctx, cnt.alloc(2));
     PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2 * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(keep.p, 0, nr, ctx->stream));
-    FilterRec rec{hash.p, ident.p, matches.p, f15b.p, f15e.p, state.p, pass.p};
     const uint32_t grid = (n_raw + 255) / 256 ? (n_raw + 255) / 256 : 1;
-    {
-        KTimer t(ctx, "filter_parse_kernel");
-        hipLaunchKernelGGL(filter_parse_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, size, n_raw, n_nl, nl_pos.p, rec, line_a.p, cnt.p);
-    }
-    uint32_t n_slow = 0;
-    PTX_TRY(download(ctx, &n_slow, cnt.p, 1));
-    std::vector<uint8_t> h_state(n_raw);
-    PTX_TRY(download(ctx, h_state.data(), state.p, n_raw));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_slow) {   // identities outside the exact fast path: the host's correctly rounded strtod, then back
-        std::vector<uint32_t> b(n_raw), e(n_raw);
-        std::vector<uint64_t> idb(n_raw);
-        PTX_TRY(download(ctx, b.data(), f15b.p, n_raw)); PTX_TRY(download(ctx, e.data(), f15e.p, n_raw));
-        PTX_TRY(download(ctx, idb.data(), ident.p, n_raw));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t i = 0; i < n_raw; ++i) {
-            if (h_state[i] != 2) continue;
-            const std::string s(text + b[i], text + e[i]);   // already validated against f64::from_str's grammar
-            idb[i] = order_bits(std::strtod(s.c_str(), nullptr));
-        }
-        PTX_HIP(ctx, hipMemcpyAsync(ident.p, idb.data(), n_raw * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(grid), dim3(256), 0, ctx->stream, n_raw, line_a.p);
+    FilterRec rec{hash.p, ident.p, matches.p, nullptr, nullptr, state.p, pass.p};
     SortBufs A, B;
     A.nw = B.nw = 1; A.k[0] = hash.p; B.k[0] = hash_b.p; A.v = line_a.p; B.v = line_b.p;
     std::vector<SortPass> passes;
@@ -262,14 +328,11 @@ int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uin
                            keep.p, cnt.p + 1);
     }
     PTX_HIP(ctx, hipGetLastError());
-    keep_out.resize(n_raw); nl_out.resize(n_nl);
+    keep_out.resize(n_raw);
     uint32_t n_kept = 0;
     PTX_TRY(download(ctx, keep_out.data(), keep.p, n_raw));
-    PTX_TRY(download(ctx, nl_out.data(), nl_pos.p, n_nl));
     PTX_TRY(download(ctx, &n_kept, cnt.p + 1, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t nrec = 0;
-    for (uint8_t s : h_state) nrec += s != 0;
     if (n_records) *n_records = nrec;
     if (n_kept_out) *n_kept_out = n_kept;
     return 0;
@@ -297,7 +360,7 @@ extern "C" int pantax_hip_gaf_filter(pantax_hip_ctx *ctx, const char *gaf_path, 
         out = dir + name + "_filtered.gaf";
     }
     std::vector<uint8_t> keep;
-    std::vector<uint32_t> nl;
+    std::vector<uint64_t> nl;   // end of every raw line
     uint64_t nrec = 0, nkept = 0;
     PTX_TRY(gaf_filter_device(ctx, mf.data, mf.size, keep, nl, &nrec, &nkept, mf.fd));
     FILE *f = std::fopen(out.c_str(), "wb");
@@ -307,7 +370,7 @@ extern "C" int pantax_hip_gaf_filter(pantax_hip_ctx *ctx, const char *gaf_path, 
     bool io_ok = true;
     for (size_t i = 0; i < keep.size(); ++i) {
         if (!keep[i]) continue;
-        const uint64_t b = i ? (uint64_t)nl[i - 1] + 1 : 0, e0 = i < nl.size() ? nl[i] : mf.size;
+        const uint64_t b = i ? nl[i - 1] + 1 : 0, e0 = nl[i];
         uint64_t e = e0;
         if (e > b && mf.data[e - 1] == '\r') --e;      // BufRead::lines drops "\r\n"; writeln! adds '\n'
         if (buf.size() + (e - b) + 1 > (1u << 20) && !buf.empty()) { io_ok = io_ok && std::fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
