@@ -18,7 +18,10 @@
 //   - `seen` (sum of aligned lengths before the last node): segmented wave scan over the lanes
 //   - first-occurrence test of a node inside the read: shuffle compare against the earlier lanes
 //   - (node, read_nodes_len) of steps i-1, i-2 for the 3-window: __shfl_up by 1 and 2
-// with a memory fallback only for the part of a read that lies in the previous wave.  The kernel
+// Walks of <= 64 steps never straddle a wave (padded stream).  Longer walks (HiFi / ONT reads, hundreds of steps) get
+// what lies in other waves from data prepared outside this kernel, all O(1) per step: a per-step "node occurred
+// earlier in the walk" flag computed at upload (group_fill_long_kernel, LDS hash per walk), the sum of the node
+// lengths before the last step from walk_sum_kernel, and plain loads for the two neighbours across a wave border.  The kernel
 // is bound by the number of divergent (one cache line per lane) vector-memory instructions, so the
 // tables it gathers from are packed into 16-byte records (one dwordx4 per lookup):
 //   read_rec[r] = {first step, #steps, pstart, pend}      node_rec[v] = {bit_off (u64), len, -}
@@ -103,8 +106,7 @@ __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases
 //
 // The kernel is latency-bound (a chain of dependent gathers per step), so the loads are ordered to keep
 // the chain short: {slot, node id} -> {read record, species of the slot} -> species tables (cached)
-// -> {node record, trio bucket head} -> {bitmap probe, trio entries}.  Walks of <= 64 steps never straddle
-// a wave (padded stream), so the memory fallbacks below run only for longer walks.
+// -> {node record, trio bucket head} -> {bitmap probe, trio entries}.
 template <bool WITH_TRIO>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
