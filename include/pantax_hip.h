@@ -232,13 +232,18 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     int32_t species, strain, shift, filtered, full, force, mode, sample_nodes;
     const char *designated_species; /* --ds or NULL */
     const char *zip;                /* "serialize" (.bin) | "lz" (.bin.lz4) | "zstd" (.bin.zst) | NULL (= GFA); "h5" is refused */
-    /* this entry drives ONE GPU: world_size must be 0 or 1 (rank 0).  Multi-GPU runs shard the species over one
-     * process per GPU through the stage calls + ONE all-reduce (pantax_amd/pipeline.py, bench.py) */
+    /* one process per GPU: with world_size > 1 this process takes the selected species i with i % world_size == rank
+     * (every rank reads the GAF and bins it; the species table is rank 0's).  The strain table needs two global sums and
+     * the rows of every rank: the library calls allreduce_sum (below) three times per run -- run mode, {failure flag, the
+     * two sums}, a barrier once the ranks' rows are in part files under wd -- and rank 0 writes the tables. */
     int32_t rank, world_size;
     /* device-ready graph images <db>/species_graph_info/<otu>.hipdb (graphs + unique-trio index):
      * 0 = ignore them, 1 = use them when every selected species has a fresh one, 2 = as 1, and write them after a run
      * that had to parse the graphs */
     int32_t image_cache;
+    /* world_size > 1: in-place sum over all ranks of buf[0..n) (e.g. ncclAllReduce + stream sync, MPI_Allreduce); 0 = ok */
+    int (*allreduce_sum)(void *user, double *buf, uint64_t n);
+    void *comm_user;
 } pantax_hip_profiling_config;
 
 int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);

@@ -78,7 +78,12 @@ class ProfilingConfig(C.Structure):
                 ("single_cov_diff", C.c_double), ("min_cov", C.c_int64), ("min_depth", C.c_int64),
                 ("species", C.c_int32), ("strain", C.c_int32), ("shift", C.c_int32), ("filtered", C.c_int32),
                 ("full", C.c_int32), ("force", C.c_int32), ("mode", C.c_int32), ("sample_nodes", C.c_int32),
-                ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32), ("image_cache", C.c_int32)]
+                ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32), ("image_cache", C.c_int32),
+                ("allreduce_sum", C.c_void_p), ("comm_user", C.c_void_p)]
+
+
+# int (*allreduce_sum)(void *user, double *buf, uint64_t n)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
 
 
 def load():

@@ -58,8 +58,17 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     PTX_ENTER(ctx);
     // ---- check_args_valid (profile.rs:71-199)
     if (!cfg->species && !cfg->strain) return fail(ctx, PANTAX_HIP_E_INVALID, "Please choose profiling level with --species or/and --strain.");
-    if (cfg->world_size > 1)
-        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: the file seam drives one GPU; multi-GPU runs shard species across processes through the stage API (pantax_amd.pipeline / bench.py)");
+    // one process per GPU: rank r takes the selected species i with i % world_size == r; the two global sums of the strain
+    // table (profile.rs:3198, :3243) and the hand-over of the rows go through the caller's all-reduce (RCCL / MPI / ...)
+    const int W = cfg->world_size > 1 ? cfg->world_size : 1;
+    const int rk = W > 1 ? cfg->rank : 0;
+    if (W > 1 && (!cfg->allreduce_sum || rk < 0 || rk >= W))
+        return fail(ctx, PANTAX_HIP_E_INVALID, "profile: world_size %d needs 0 <= rank < world_size and an allreduce_sum callback", W);
+    auto allreduce = [&](double *buf, uint64_t n) -> int {
+        if (W == 1) return 0;
+        const int rc = cfg->allreduce_sum(cfg->comm_user, buf, n);
+        return rc == 0 ? 0 : fail(ctx, PANTAX_HIP_E_STATE, "profile: the caller's allreduce_sum returned %d", rc);
+    };
     const std::string db_dir = opt(cfg->db), wd = opt(cfg->wd);
     std::string out_dir = opt(cfg->output_dir);
     if (out_dir.empty()) out_dir = wd;
@@ -72,8 +81,14 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     const std::string species_file = join(wd, "species_abundance.txt"), strain_file = join(wd, "strain_abundance.txt");
     const bool species_exists = !cfg->force && is_file(species_file);
     const bool strain_exists = !cfg->force && is_file(strain_file);
-    const bool full_path = cfg->species && !species_exists;
-    const bool strain_only = !full_path && cfg->strain && !strain_exists;
+    bool full_path = cfg->species && !species_exists;
+    bool strain_only = !full_path && cfg->strain && !strain_exists;
+    bool strain_done = strain_exists;
+    if (W > 1) {   // rank 0 looked at the work directory before anybody wrote to it: every rank follows its decision
+        double d[3] = {rk == 0 && full_path ? 1.0 : 0.0, rk == 0 && strain_only ? 1.0 : 0.0, rk == 0 && strain_done ? 1.0 : 0.0};
+        PTX_TRY(allreduce(d, 3));
+        full_path = d[0] != 0.0; strain_only = d[1] != 0.0; strain_done = d[2] != 0.0;
+    }
     if (!full_path && !strain_only) return 0;   // profile.rs:3419-3427: outputs already present
     mkdir(out_dir.c_str(), 0777);
 
@@ -130,7 +145,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (full_path) {
         // optional binning report: read_id, mapq, species, read_len; no header (profile.rs:3337-3351)
         const std::string report = opt(cfg->out_binning_file);
-        if (!report.empty() && report != "None") {
+        if (rk == 0 && !report.empty() && report != "None") {
             std::ofstream f(report);
             if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", report.c_str());
             for (uint64_t r = 0; r < R; ++r) {
@@ -154,11 +169,13 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
                                            keep.data(), absolute.data(), abundance.data()));
         for (uint32_t s = 0; s < S; ++s) if (keep[s]) sp_profile.push_back({ranges[s].species, abundance[s], absolute[s]});
         std::stable_sort(sp_profile.begin(), sp_profile.end(), [](const SpeciesProfileRow &a, const SpeciesProfileRow &b) { return a.abundance > b.abundance; });   // :344
-        std::ofstream f(join(out_dir, "species_abundance.txt"));
-        if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", join(out_dir, "species_abundance.txt").c_str());
-        f << "species_taxid\tpredicted_abundance\tpredicted_coverage\n";
-        for (auto &r : sp_profile) f << r.species << '\t' << fmt_f64(r.abundance) << '\t' << fmt_f64(r.coverage) << '\n';
-        if (!cfg->strain || strain_exists) return 0;
+        if (rk == 0) {
+            std::ofstream f(join(out_dir, "species_abundance.txt"));
+            if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", join(out_dir, "species_abundance.txt").c_str());
+            f << "species_taxid\tpredicted_abundance\tpredicted_coverage\n";
+            for (auto &r : sp_profile) f << r.species << '\t' << fmt_f64(r.abundance) << '\t' << fmt_f64(r.coverage) << '\n';
+        }
+        if (!cfg->strain || strain_done) return 0;
     } else {
         // strain only (profile.rs:3365-3417): species column comes from the saved binning file (positional join)
         std::string rb = choose(opt(cfg->reads_binning_file), join(wd, "reads_classification.tsv"));   // profile.rs:179-182
@@ -248,6 +265,14 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     const uint32_t Ss = (uint32_t)sel.size();
     std::vector<HostGraph> graphs(Ss);
     std::vector<uint8_t> loaded(Ss, 1);
+    std::vector<uint32_t> use;   // this rank's selected species with a loaded graph (indices into sel)
+    uint32_t Su = 0;
+    std::vector<pantax_hip_hap_metrics> met;
+    std::vector<pantax_hip_solve_info> info;
+    std::vector<uint64_t> hap_off(1, 0);
+    std::vector<std::string> hap_names;
+    // everything a rank does on its own shard; a failure here must not leave the other ranks waiting in the exchange below
+    auto shard = [&]() -> int {
     // image_cache >= 1: device-ready images <db>/species_graph_info/<otu>.hipdb (db_image.cpp) stand in for
     // the graph files AND the per-run unique-trio index when every selected species has one that is not older than its
     // source; otherwise the graphs are parsed as usual (and, with image_cache == 2, the images are written afterwards)
@@ -265,6 +290,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         std::vector<uint8_t> ok(Ss, 0);
         parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
+                if ((int)(i % (uint64_t)W) != rk) { ok[i] = 1; continue; }                         // another rank's species
                 const std::string &otu = ranges[sel[i]].species;
                 const std::string img = image_of(otu);
                 if (!is_file(img) || file_mtime(img) < file_mtime(source_of(otu))) continue;
@@ -280,6 +306,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         std::vector<std::string> hard(Ss);   // errors that end the run
         parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
+                if ((int)(i % (uint64_t)W) != rk) { loaded[i] = 0; continue; }                     // another rank's species
                 const std::string &otu = ranges[sel[i]].species;
                 std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
                 std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
@@ -299,13 +326,10 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         for (uint32_t i = 0; i < Ss; ++i) if (!hard[i].empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", hard[i].c_str());
     }
     lap("graph load");
-    std::vector<uint32_t> use;   // selected species with a loaded graph
-    for (uint32_t i = 0; i < Ss; ++i) if (loaded[i]) use.push_back(i);
-    const uint32_t Su = (uint32_t)use.size();
-    std::vector<pantax_hip_hap_metrics> met;
-    std::vector<pantax_hip_solve_info> info(Su);
-    std::vector<uint64_t> hap_off(Su + 1, 0);
-    std::vector<std::string> hap_names;
+    for (uint32_t i = 0; i < Ss; ++i) if (loaded[i] && (int)(i % (uint32_t)W) == rk) use.push_back(i);
+    Su = (uint32_t)use.size();
+    info.assign(Su, pantax_hip_solve_info{});
+    hap_off.assign(Su + 1, 0);
     if (Su) {
         std::vector<int64_t> g_rs(Su), g_re(Su);
         std::vector<GraphPart> parts(Su);
@@ -348,6 +372,9 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
             lap("graph images written");
         }
     }
+    return 0;
+    };   // shard
+    const int shard_rc = shard();
 
     // ---- a15: abundance_est (profile.rs:3091-3289)
     std::vector<GenomeRow> genomes;
@@ -356,10 +383,20 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     std::unordered_multimap<std::string, size_t> by_hap;
     for (size_t i = 0; i < genomes.size(); ++i) by_hap.emplace(genomes[i].hap_id, i);
     std::vector<uint8_t> reported(Su, 0), pass(hap_names.size() ? hap_names.size() : 1, 0);
-    for (uint32_t k = 0; k < Su; ++k) reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
     double sum_all = 0.0, sum_pass = 0.0;
-    if (Su) PTX_TRY(pantax_hip_abundance_filter(Su, hap_off.data(), met.data(), reported.data(), cfg->single_cov_diff, cfg->min_cov, pass.data(), &sum_all, &sum_pass, nullptr, nullptr));
-    struct OutRow { std::string line; double key; };
+    int local_rc = shard_rc;
+    if (local_rc == 0) {
+        for (uint32_t k = 0; k < Su; ++k) reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
+        if (Su) local_rc = pantax_hip_abundance_filter(Su, hap_off.data(), met.data(), reported.data(), cfg->single_cov_diff, cfg->min_cov, pass.data(), &sum_all, &sum_pass, nullptr, nullptr);
+    }
+    {   // the one exchange of the strain level: did every rank get through, and the two normalisers
+        double ex[3] = {local_rc != 0 ? 1.0 : 0.0, sum_all, sum_pass};
+        PTX_TRY(allreduce(ex, 3));
+        if (ex[0] != 0.0) return local_rc ? local_rc : fail(ctx, PANTAX_HIP_E_STATE, "profile: another rank failed on its species; no strain table was written");
+        sum_all = ex[1]; sum_pass = ex[2];
+    }
+    // rows keep (species position in the selection, running number) so that any merge reproduces the one-process order
+    struct OutRow { double key; uint32_t k, seq; std::string line; };
     auto row_text = [&](uint32_t k, uint64_t h, const GenomeRow *gr, double abund, bool has_abund, bool rnd) {
         const pantax_hip_hap_metrics &m = met[h];
         std::string s = ranges[sel[use[k]]].species;
@@ -376,24 +413,67 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         return s;
     };
     const char *header = "species_taxid\tstrain_taxid\tgenome_ID\tpredicted_coverage\tpredicted_abundance\tpath_base_cov\tunique_trio_fraction\tuniq_trio_cov_mean\tfirst_sol\tstrain_cov_diff\ttotal_cov_diff\n";
-    std::vector<OutRow> final_rows;
-    {
-        std::ofstream ori("ori_strain_abundance.txt");   // written to the current directory (profile.rs:3217)
-        if (ori) ori << header;
-        for (uint32_t k = 0; k < Su; ++k) {
-            if (!reported[k]) continue;
-            for (uint64_t h = hap_off[k]; h < hap_off[k + 1]; ++h) {
-                auto range = by_hap.equal_range(hap_names[h]);
-                std::vector<const GenomeRow *> grs;
-                for (auto it = range.first; it != range.second; ++it) grs.push_back(&genomes[it->second]);
-                if (grs.empty()) grs.push_back(nullptr);          // left join keeps the row with null metadata
-                const bool hs = met[h].has & PANTAX_HIP_HAS_SECOND;
-                for (const GenomeRow *gr : grs) {
-                    if (ori) ori << row_text(k, h, gr, hs ? met[h].second_sol / sum_all : 0.0, hs, false) << '\n';
-                    if (pass[h]) final_rows.push_back({row_text(k, h, gr, met[h].second_sol / sum_pass, true, !cfg->full), met[h].second_sol / sum_pass});   // :3250-3284
-                }
+    std::vector<OutRow> ori_rows, final_rows;
+    for (uint32_t k = 0; k < Su; ++k) {
+        if (!reported[k]) continue;
+        uint32_t seq = 0;
+        for (uint64_t h = hap_off[k]; h < hap_off[k + 1]; ++h) {
+            auto range = by_hap.equal_range(hap_names[h]);
+            std::vector<const GenomeRow *> grs;
+            for (auto it = range.first; it != range.second; ++it) grs.push_back(&genomes[it->second]);
+            if (grs.empty()) grs.push_back(nullptr);          // left join keeps the row with null metadata
+            const bool hs = met[h].has & PANTAX_HIP_HAS_SECOND;
+            for (const GenomeRow *gr : grs) {
+                ori_rows.push_back({0.0, use[k], seq, row_text(k, h, gr, hs ? met[h].second_sol / sum_all : 0.0, hs, false)});
+                if (pass[h]) final_rows.push_back({met[h].second_sol / sum_pass, use[k], seq, row_text(k, h, gr, met[h].second_sol / sum_pass, true, !cfg->full)});   // :3250-3284
+                ++seq;
             }
         }
+    }
+    if (W > 1) {   // rows of the other ranks reach rank 0 through part files in the work directory (one node, one file system)
+        auto part_name = [&](const char *what, int r) { return strain_file + "." + what + ".part" + std::to_string(r); };
+        auto write_part = [&](const std::string &path, const std::vector<OutRow> &rows) {
+            FILE *f = std::fopen(path.c_str(), "wb");
+            if (!f) return false;
+            bool ok = true;
+            for (const OutRow &r : rows) {
+                const uint32_t len = (uint32_t)r.line.size();
+                ok = ok && std::fwrite(&r.key, 8, 1, f) == 1 && std::fwrite(&r.k, 4, 1, f) == 1 && std::fwrite(&r.seq, 4, 1, f) == 1 && std::fwrite(&len, 4, 1, f) == 1 &&
+                     (len == 0 || std::fwrite(r.line.data(), 1, len, f) == len);
+            }
+            return std::fclose(f) == 0 && ok;
+        };
+        const bool wrote = write_part(part_name("ori", rk), ori_rows) && write_part(part_name("final", rk), final_rows);
+        double bar[1] = {wrote ? 0.0 : 1.0};
+        PTX_TRY(allreduce(bar, 1));                      // every part is on disk (or somebody could not write)
+        if (bar[0] != 0.0) return fail(ctx, PANTAX_HIP_E_IO, "profile: a rank could not write its part of the strain table under %s", wd.c_str());
+        if (rk != 0) { lap("tables"); return 0; }
+        auto read_part = [&](const std::string &path, std::vector<OutRow> &rows) {
+            FILE *f = std::fopen(path.c_str(), "rb");
+            if (!f) return false;
+            for (;;) {
+                OutRow r; uint32_t len = 0;
+                if (std::fread(&r.key, 8, 1, f) != 1) break;
+                if (std::fread(&r.k, 4, 1, f) != 1 || std::fread(&r.seq, 4, 1, f) != 1 || std::fread(&len, 4, 1, f) != 1) { std::fclose(f); return false; }
+                r.line.resize(len);
+                if (len && std::fread(&r.line[0], 1, len, f) != len) { std::fclose(f); return false; }
+                rows.push_back(std::move(r));
+            }
+            std::fclose(f);
+            std::remove(path.c_str());
+            return true;
+        };
+        ori_rows.clear(); final_rows.clear();
+        for (int r = 0; r < W; ++r)
+            if (!read_part(part_name("ori", r), ori_rows) || !read_part(part_name("final", r), final_rows))
+                return fail(ctx, PANTAX_HIP_E_IO, "profile: cannot read the part of rank %d under %s", r, wd.c_str());
+        auto by_pos = [](const OutRow &a, const OutRow &b) { return a.k != b.k ? a.k < b.k : a.seq < b.seq; };
+        std::sort(ori_rows.begin(), ori_rows.end(), by_pos);
+        std::sort(final_rows.begin(), final_rows.end(), by_pos);
+    }
+    {
+        std::ofstream ori("ori_strain_abundance.txt");   // written to the current directory (profile.rs:3217)
+        if (ori) { ori << header; for (auto &r : ori_rows) ori << r.line << '\n'; }
     }
     std::stable_sort(final_rows.begin(), final_rows.end(), [](const OutRow &a, const OutRow &b) { return a.key > b.key; });   // :3247-3248
     std::ofstream f(strain_file);

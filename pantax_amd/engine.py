@@ -250,7 +250,8 @@ class Engine:
     def profile(self, db, wd, gaf, species=True, strain=True, output_dir=None, fr=0.3, fc=0.46, sr=0.85, sd=0.2,
                 min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,
                 mode=2, sample_nodes=0, designated_species=None, zip="serialize", out_binning_file=None,
-                reads_binning_file=None, range_file=None, species_len_file=None, image_cache=0):
+                reads_binning_file=None, range_file=None, species_len_file=None, image_cache=0, rank=0, world_size=1,
+                allreduce=None):
         """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out."""
         enc = lambda x: None if x is None else str(x).encode()
         cfg = _ffi.ProfilingConfig(
@@ -260,7 +261,18 @@ class Engine:
             unique_trio_nodes_fraction=fr, unique_trio_nodes_mean_count_f=fc, single_cov_ratio=sr, single_cov_diff=sd,
             min_cov=min_cov, min_depth=min_depth, species=int(species), strain=int(strain), shift=int(shift),
             filtered=int(filtered), full=int(full), force=int(force), mode=mode, sample_nodes=sample_nodes,
-            designated_species=enc(designated_species), zip=enc(zip), rank=0, world_size=1, image_cache=int(image_cache))
+            designated_species=enc(designated_species), zip=enc(zip), rank=int(rank), world_size=int(world_size),
+            image_cache=int(image_cache))
+        cb = None
+        if allreduce is not None:   # allreduce(np.ndarray float64) sums it in place over the ranks
+            def _cb(_user, buf, n):
+                try:
+                    allreduce(np.ctypeslib.as_array(buf, shape=(int(n),)))
+                    return 0
+                except Exception:   # noqa: BLE001 -- reported through the return code
+                    return 1
+            cb = _ffi.ALLREDUCE_FN(_cb)
+            cfg.allreduce_sum = C.cast(cb, C.c_void_p)
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
 
     def save_images(self, paths, hap_names):

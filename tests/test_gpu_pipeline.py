@@ -450,3 +450,67 @@ def test_graph_images_roundtrip_and_file_seam(world, tmp_path):
     run("wd_img_read2", image_cache=1)
     for f in ("species_abundance.txt", "strain_abundance.txt"):
         assert open(ref / f).read() == open(root / "wd_img_write" / f).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_profile_seam_sharded_over_ranks(world, world_size):
+    """The file seam with world_size > 1 (one process per GPU in production; here the ranks are threads with their own
+    ctx on the one GPU and a barrier-based sum as the all-reduce): every rank handles the species i % world_size == rank,
+    the two global sums and the rows meet through the callback and the part files, rank 0 writes the same tables as a
+    single-rank run."""
+    import threading
+    from pantax_amd.engine import Engine
+    sset, root, db, gaf, eng0 = world
+    exp_species, exp_strain, _ = _oracle_tables(sset)
+    wd = root / ("wd_shard%d" % world_size)
+    wd.mkdir()
+    bar = threading.Barrier(world_size)
+    slots = [None] * world_size
+    total = [None]
+
+    def make_allreduce(rank):
+        def allreduce(buf):
+            slots[rank] = buf.copy()
+            if bar.wait() == 0:
+                total[0] = np.sum(slots, axis=0)
+            bar.wait()
+            buf[:] = total[0]
+            bar.wait()
+        return allreduce
+    errs = []
+
+    def run(rank):
+        eng = Engine(0)
+        try:
+            eng.profile(str(db), str(wd), str(gaf), rank=rank, world_size=world_size, allreduce=make_allreduce(rank),
+                        out_binning_file=str(wd / "reads_classification.tsv"))
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, e))
+            bar.abort()
+        finally:
+            eng.close()
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(world_size)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+    finally:
+        os.chdir(cwd)
+    assert not errs, errs
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
+    assert os.path.exists(wd / "ori_strain_abundance.txt") and os.path.exists(wd / "reads_classification.tsv")
+    assert not [f for f in os.listdir(wd) if ".part" in f]
+    # the rows are in the one-process order as well: same file as the single-rank run apart from the last digits of the sums
+    one = root / "wd_bin"
+    if (one / "strain_abundance.txt").exists():
+        a = [l.split("\t")[:3] for l in open(one / "strain_abundance.txt")]
+        b = [l.split("\t")[:3] for l in open(wd / "strain_abundance.txt")]
+        assert a == b
+    # a missing callback is refused
+    from pantax_amd.engine import PantaxHipError
+    with pytest.raises(PantaxHipError):
+        eng0.profile(str(db), str(wd), str(gaf), rank=0, world_size=2, force=True)
