@@ -15,17 +15,26 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 eng = Engine(0)
 bad = 0
+n_ambiguous = 0
 for ci in range(n_cfg):
     rng = np.random.default_rng(seed0 + ci)
-    S = int(rng.integers(1, 7)); H = int(rng.integers(1, 13)); R = int(rng.integers(200, 60000)); L = int(rng.integers(3000, 200000))
+    S = int(rng.integers(1, 7)); H = int(rng.integers(1, 13)) if rng.random() < 0.85 else int(rng.integers(20, 45)); R = int(rng.integers(200, 60000)); L = int(rng.integers(3000, 200000))
+    sample = int(rng.integers(200, 5000)) if rng.random() < 0.3 else 0      # --sample: species with more valid rows are sub-sampled
+    via_images = bool(rng.random() < 0.2)                                    # db saved to / loaded from device-ready images first
     lr = bool(rng.random() < 0.25); adv = float(rng.choice([0.0, 0.001, 0.02])); pf = float(rng.choice([0.2, 0.5, 0.9]))
-    tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g" % (seed0 + ci, S, H, R, L, lr, adv, pf)
+    tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g sample=%d images=%d" % (seed0 + ci, S, H, R, L, lr, adv, pf, sample, via_images)
     try:
         sset = synth.make_set(seed0 + ci, S, H, R if not lr else max(50, R // 40), L, long_reads=lr, adversarial_frac=adv, present_frac=pf,
                               single_strain_every=int(rng.choice([0, 2, 3])))
         rd = sset.reads
         flags = (rng.random(rd.n_reads) < float(rng.choice([0.0, 0.05]))).astype(np.uint8)
         eng.upload_db(sset.species)
+        if via_images:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                paths = [os.path.join(td, "%d.hipdb" % i) for i in range(S)]
+                eng.save_images(paths, [hn for g in sset.species for hn in g.hap_names])
+                eng.load_images(paths, [g.range_start for g in sset.species], [g.range_end for g in sset.species], sset.species)
         eng.upload_packed(rd, flags=flags if flags.any() else None)
         sp, rc, bs, lm, uq = eng.rcls_profile()
         ref_sp = orc.bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
@@ -35,7 +44,7 @@ for ci in range(n_cfg):
         keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
         okeep, oabs, _ = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
         assert np.array_equal(keep, okeep) and np.allclose(absolute, oabs, rtol=1e-12, atol=0), "species profile"
-        met, info = eng.strain_profiling(absolute, species_active=keep)
+        met, info = eng.strain_profiling(absolute, species_active=keep, sample_nodes=sample)
         gm_all = metrics_to_dicts(met, eng.H)
         nb = np.cumsum([0] + [g.n_nodes for g in sset.species]); hb = np.cumsum([0] + [g.n_paths for g in sset.species])
         hto = eng.trio_nodes_info()[3].astype(np.int64)
@@ -49,12 +58,35 @@ for ci in range(n_cfg):
             assert np.array_equal(tb[hto[hb[s]]:hto[hb[s + 1]]], t), "trio bases sp %d" % s
             if not keep[s]:
                 continue
-            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, sample_nodes=sample)
             orc.abundance_constraint(absolute[s], omet)
             assert info[s].n_candidates == nc and info[s].status1 == 0 and info[s].status2 == 0, "solver status sp %d" % s
             if nc:
                 assert abs(info[s].obj1 - o1) <= 1e-9 * max(1.0, abs(o1)), "obj1 sp %d: %r vs %r" % (s, info[s].obj1, o1)
-            for gm, em in zip(gm_all[hb[s]:hb[s + 1]], orc.metrics_to_dicts(omet)):
+            # Two places where "the" answer is not defined by the reference itself and a mismatch is not a failure:
+            #  * an LP whose optimum is a face, not a point (non-unique LAD optima): any x with the optimal
+            #    objective is right, and everything derived from first_sol follows it;
+            #  * a unique-trio abundance sitting exactly on |z| = 3 of zscore_filter (profile.rs:1046-1050): whether it
+            #    counts depends on the rounding of the mean / sd sums, whose order in the reference is a hash-set order.
+            ems = orc.metrics_to_dicts(omet)
+            gms = gm_all[hb[s]:hb[s + 1]]
+            cand = [h for h, em in enumerate(ems) if em["first_sol"] is not None]
+            degenerate = boundary = False
+            if nc and any(abs(gms[h]["first_sol"] - ems[h]["first_sol"]) > 1e-7 * max(1.0, abs(ems[h]["first_sol"])) for h in cand if gms[h]["first_sol"] is not None):
+                mask, _ = orc.path_masks(G, cand, c)
+                a = b / np.asarray(g.node_len, dtype=np.float64)
+                xg = np.array([gms[h]["first_sol"] for h in cand])
+                degenerate = abs(orc.lad_objective(mask, a, xg) - o1) <= 1e-9 * max(1.0, abs(o1))
+            for h in range(g.n_paths):
+                u0, u1 = int(T.hap_off[h]), int(T.hap_off[h + 1])
+                v = t[u0:u1] / np.asarray(T.len[u0:u1], dtype=np.float64)
+                v = v[v > 0]
+                if len(v) and v.std() > 0 and np.min(np.abs(np.abs((v - v.mean()) / v.std()) - 3.0)) < 1e-9:
+                    boundary = True
+            if degenerate or boundary:
+                n_ambiguous += 1
+                continue
+            for gm, em in zip(gms, ems):
                 for key, ev in em.items():
                     gv = gm[key]
                     if ev is None or gv is None or isinstance(ev, bool):
@@ -62,7 +94,7 @@ for ci in range(n_cfg):
                     else:
                         assert abs(gv - ev) <= 1e-7 * max(1.0, abs(ev)) + 1e-9, (s, key, gv, ev)
         # the single-call step gives the same decisions and metrics as the stage calls
-        k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len())
+        k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len(), sample_nodes=sample)
         assert np.array_equal(k2, keep) and np.array_equal(a2, absolute), "step species"
         g2 = metrics_to_dicts(met2, eng.H)
         for x, y in zip(g2, gm_all):
@@ -71,5 +103,5 @@ for ci in range(n_cfg):
     except AssertionError as e:
         bad += 1
         print("FAIL", tag, "->", e)
-print("%d configurations, %d failures" % (n_cfg, bad))
+print("%d configurations, %d failures, %d species skipped as ambiguous in the reference itself (LP optimal face / |z| = 3)" % (n_cfg, bad, n_ambiguous))
 sys.exit(1 if bad else 0)
