@@ -52,7 +52,7 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
     const size_t Hn = db->H ? db->H : 1;
     PTX_HIP(ctx, db->d_arena.alloc(L.total));
     uint8_t *b = db->d_arena.p;
-    PTX_HIP(ctx, hipMemsetAsync(b, 0, L.total, ctx->stream));   // unsolved species read back as x = 0, status 0, 0 pivots
+    if (!lb.prezeroed) PTX_HIP(ctx, hipMemsetAsync(b, 0, L.total, ctx->stream));   // unsolved species read back as x = 0, status 0, 0 pivots
     lb.d_amax.view(b + L.amax, S); lb.d_nzsum.view(b + L.nzsum, S); lb.d_obj.view(b + L.obj1, S); lb.d_obj2.view(b + L.obj2, S);
     lb.d_x.view(b + L.x1, (size_t)S * LAD_MAXP); lb.d_x2.view(b + L.x2, (size_t)S * LAD_MAXP);
     lb.d_ratio.view(b + L.ratio, (size_t)S * LAD_MAXP * 2);
@@ -90,6 +90,20 @@ int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, Strai
 
 namespace ptx {
 
+// The two zero-fills of the strain step (result arena, membership masks) issued ahead of time: in the resident step the
+// main stream idles before the coverage kernel while the trio index is built on the side stream, so they cost nothing
+// there instead of ~10 us between coverage and the first strain kernel.  strain_enqueue consumes the flag.
+int strain_prezero(Ctx *ctx, Db *db) {
+    LadBatch &lb = db->lad;
+    const ArenaLayout L(db->S, db->H);
+    lb.prezeroed = false;
+    PTX_TRY(bind_arena(ctx, db, lb, L));
+    PTX_HIP(ctx, lb.d_mask.alloc(db->V));
+    PTX_HIP(ctx, hipMemsetAsync(lb.d_mask.p, 0, db->V * sizeof(uint64_t), ctx->stream));
+    lb.prezeroed = true;
+    return 0;
+}
+
 // Enqueues the whole strain step and the download of its result arena; nothing waits for the host.
 // d_active: device [S] or null.
 int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active) {
@@ -110,6 +124,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
     PTX_TRY(fetch_arena_enqueue(ctx, db, L));
+    lb.prezeroed = false;
     return 0;
 }
 

@@ -158,6 +158,7 @@ constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership
 struct LadBatch {
     uint32_t S = 0;
     // per species (host mirrors + device)
+    bool prezeroed = false;             // the result arena and d_mask were zeroed ahead of strain_enqueue (strain_prezero)
     std::vector<int32_t> h_p;           // [S] number of candidates (0 = not solved)
     std::vector<uint32_t> h_cand;       // [S*LAD_MAXP] candidate -> hap index within species
     DevBuf<int32_t> d_p;

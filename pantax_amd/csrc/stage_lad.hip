@@ -536,7 +536,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     PTX_HIP(ctx, lb->d_mask.alloc(V));
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
-    PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
+    if (!lb->prezeroed) PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
     // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
     {
         KTimer t(ctx, "mask_kernel");
