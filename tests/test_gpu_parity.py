@@ -47,6 +47,38 @@ def test_micro_binning_golden(eng):
     assert lm.tolist() == e["less_multi"] and uq.tolist() == e["uniq_count"]
 
 
+def test_binning_with_overlapping_ranges_is_first_match_in_file_order(eng):
+    """species_range.txt rows that overlap or nest (never written by sort_range.rs, but legal input): the reference takes the
+    FIRST row, in file order, that contains [min, max] of the read's node ids (rcls.rs:237-258); the sorted-range binary
+    search must not be used then."""
+    from oracle import oracle as orc
+    rs = np.array([40, 1, 120, 300, 90], dtype=np.int64)       # deliberately not sorted, overlapping, one nested
+    re = np.array([160, 100, 130, 400, 95], dtype=np.int64)
+    gs = [_G(np.ones(int(e - s + 1), dtype=np.int64), np.array([0, 1], dtype=np.uint64), np.array([0], dtype=np.uint32), int(s)) for s, e in zip(rs, re)]
+    rng = np.random.default_rng(3)
+    walks = []
+    for _ in range(4000):
+        lo = int(rng.integers(1, 420))
+        k = int(rng.integers(1, 6))
+        walks.append(np.clip(lo + rng.integers(0, int(rng.choice([3, 15, 60])), size=k), 1, 450).astype(np.uint32))
+    walks += [np.array([40], np.uint32), np.array([160], np.uint32), np.array([161], np.uint32), np.array([1, 100], np.uint32),
+              np.array([90, 95], np.uint32), np.array([125], np.uint32), np.array([100, 101], np.uint32), np.zeros(0, np.uint32)]
+    step_off = np.concatenate([[0], np.cumsum([len(w) for w in walks])]).astype(np.uint64)
+    node_id = np.concatenate(walks)
+    R = len(walks)
+    qlen = rng.integers(50, 200, size=R)
+    mapq = rng.choice([0, 3, 30, 60], size=R)
+    eng.upload_db(gs)
+    eng.upload_reads(step_off, node_id, np.zeros(R), np.ones(R), qlen, mapq)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    ref = orc.bin_reads(step_off, node_id, rs, re)
+    assert np.array_equal(sp, ref)
+    assert (ref == 0).sum() > 0 and (ref == 1).sum() > 0 and (ref == 2).sum() == 0     # row 2 is shadowed by row 0
+    assert sp[R - 3] == 0 and sp[R - 4] == 0 and sp[R - 5] == 1                         # 125 -> row 0; [90,95] -> row 0; [1,100] -> row 1
+    for a, b in zip((rc, bs, lm, uq), orc.species_counts(ref, qlen, mapq, len(rs))):
+        assert np.array_equal(a, b)
+
+
 def test_micro_coverage_golden(eng):
     j, names, node_len, path_off, path_nodes, rs, step_off, node_id, pstart, pend = load_micro_cov()
     eng.upload_db([_G(node_len, path_off, path_nodes, rs)])
