@@ -396,9 +396,16 @@ def test_pao_solve_edge_cases(eng):
     assert st == 0 and obj == pytest.approx(0.0, abs=1e-9) and np.allclose(x, truth, atol=1e-8)
 
 
-@pytest.mark.parametrize("seed,S,H,R,L,pf", [(21, 2, 6, 30000, 40000, 0.5), (22, 4, 10, 80000, 30000, 0.4),
-                                             (23, 3, 5, 20000, 30000, 0.2)])
-def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
+@pytest.mark.parametrize("seed,S,H,R,L,pf,opts", [
+    (21, 2, 6, 30000, 40000, 0.5, {}), (22, 4, 10, 80000, 30000, 0.4, {}), (23, 3, 5, 20000, 30000, 0.2, {}),
+    # the option branches of first_filter_paths / second_filter_paths (profile.rs:1080-1285, main.rs:108-124)
+    (22, 4, 10, 80000, 30000, 0.4, dict(shift=True)),                       # --shift: coverage-dependent fraction threshold (:1140-1165)
+    (22, 4, 10, 80000, 30000, 0.4, dict(fr=0.5, fc=0.2, sr=0.4)),            # long-read fr, tighter divergence cut, looser rescue
+    (24, 3, 6, 6000, 30000, 0.6, dict(shift=True, fr=0.5)),                  # low depth: the shifted threshold drops below fr
+    (23, 3, 5, 20000, 30000, 0.2, dict(min_depth=3)),                        # --min_depth feeds the single-path statistics only (:2941-2944)
+    (25, 4, 1, 20000, 30000, 1.0, dict(min_depth=2)),                        # every species a single strain
+])
+def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     """optimize_otu + abundace_constraint (profile.rs:2884-3070) for every species, against the oracle."""
     from oracle import oracle as orc
     from pantax_amd import synth
@@ -411,18 +418,20 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
     keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
     eng.trio_nodes_info(fetch=False)
     eng.get_node_abundances(fetch=False)
-    met, info = eng.strain_profiling(absolute, species_active=keep)
+    met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
     got = metrics_to_dicts(met, eng.H)
     ref = _oracle_cov_per_species(sset, sp)
+    n_cols = 0
     for si, (G, T, b, c, t, na) in enumerate(ref):
         if not keep[si]:
             continue
-        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, **opts)
         assert rc_ == 0
         orc.abundance_constraint(absolute[si], omet)
         exp = orc.metrics_to_dicts(omet)
         h0 = int(eng.hap_off[si])
         assert info[si].n_candidates == nc and info[si].status1 == 0 and info[si].status2 == 0
+        n_cols += nc
         if nc:
             assert info[si].obj1 == pytest.approx(o1, rel=1e-9, abs=1e-12)
             if not np.isnan(o2):
@@ -435,10 +444,9 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf):
                     assert gv == ev, (si, h, key, gv, ev)
                 else:
                     assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
+    assert n_cols > 0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("sample_nodes", [2000, 500, 1237])
 def test_strain_profiling_with_row_sampling(eng, sample_nodes):
     """--sample N (a11, profile.rs:1287-1295, :2738-2752): species with more valid rows than N solve the LP on the sampled
     rows only; the others are untouched.  Checked against the oracle's own restatement of the sampler and, for the rule

@@ -18,7 +18,8 @@ def _read_tsv(path):
         return hdr, [line.rstrip("\n").split("\t") for line in f]
 
 
-def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_drop=None):
+def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_drop=None, min_cov=0, shift=False, min_depth=0, ds=None,
+                   mode=2):
     from oracle import oracle as orc
     rd = sset.reads
     S = len(sset.species)
@@ -30,12 +31,15 @@ def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_d
     for s, g in enumerate(sset.species):
         if not keep[s] or not abundance[s] > min_ab:
             continue
+        is_pan = 1 if g.n_paths > 1 else 0            # species_range.txt column 4 (load_species_range, profile.rs:553-656)
+        if (mode == 0 and is_pan != 0) or (mode == 1 and is_pan != 1) or (ds is not None and g.name not in ds):
+            continue
         G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
         T = orc.TrioTable(G)
         mine = sp == s if strain_drop is None else (sp == s) & ~strain_drop
         so, nid, ps, pe = select_reads(rd, np.nonzero(mine)[0])
         b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
-        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=fr, fc=fc, sr=sr)
+        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=fr, fc=fc, sr=sr, shift=shift, min_depth=min_depth)
         assert rc == 0
         orc.abundance_constraint(absolute[s], met)
         d = orc.metrics_to_dicts(met)
@@ -43,7 +47,7 @@ def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_d
             cov = m["predicted_coverage"]
             if cov is None:
                 continue
-            if (len(d) > 1 or (m["total_cov_diff"] is not None and m["total_cov_diff"] <= sd)) and cov >= 0 and cov != 0.0:
+            if (len(d) > 1 or (m["total_cov_diff"] is not None and m["total_cov_diff"] <= sd)) and cov >= min_cov and cov != 0.0:
                 rows.append((g.name, g.hap_names[h], m))
     tot = sum(r[2]["predicted_coverage"] for r in rows)
     out = [(sp_, hap, m["predicted_coverage"], m["predicted_coverage"] / tot, m) for sp_, hap, m in rows]
@@ -67,7 +71,7 @@ def world(tmp_path_factory):
     eng.close()
 
 
-def _check_outputs(wd, sset, exp_species, exp_strain):
+def _check_outputs(wd, sset, exp_species, exp_strain, rounded=False):
     hdr, rows = _read_tsv(os.path.join(wd, "species_abundance.txt"))
     assert hdr == ["species_taxid", "predicted_abundance", "predicted_coverage"]
     assert [r[0] for r in rows] == [r[0] for r in exp_species]
@@ -79,11 +83,17 @@ def _check_outputs(wd, sset, exp_species, exp_strain):
     assert len(rows) == len(exp_strain) and len(rows) > 0
     for r, (sp_, hap, cov, ab, m) in zip(rows, exp_strain):
         assert r[0] == sp_ and r[2].startswith(hap)
-        assert float(r[3]) == pytest.approx(cov, rel=1e-7) and float(r[4]) == pytest.approx(ab, rel=1e-7)
+        assert float(r[4]) == pytest.approx(ab, rel=1e-7)
+        if rounded:   # full = false: every metric column but predicted_abundance goes through .round(2) (profile.rs:3266-3284)
+            assert abs(float(r[3]) - cov) <= 0.005 + 1e-9 and len(r[3].partition(".")[2]) <= 2
+        else:
+            assert float(r[3]) == pytest.approx(cov, rel=1e-7)
         for col, key in [(5, "path_base_cov"), (6, "unique_trio_fraction"), (7, "uniq_trio_cov_mean"), (8, "first_sol"),
                          (9, "strain_cov_diff"), (10, "total_cov_diff")]:
             if m[key] is None:
                 assert r[col] == ""
+            elif rounded:
+                assert abs(float(r[col]) - m[key]) <= 0.005 + 1e-9 and len(r[col].partition(".")[2]) <= 2, (key, r)
             else:
                 assert float(r[col]) == pytest.approx(m[key], rel=1e-7, abs=1e-9), (key, r)
     assert abs(sum(float(r[4]) for r in rows) - 1.0) < 1e-9
@@ -193,6 +203,33 @@ def test_profile_seam_default_sample_limit(world):
     finally:
         os.chdir(cwd)
     _check_outputs(str(wd), sset, exp_species, exp_strain)
+
+
+@pytest.mark.parametrize("name,kw,okw,rounded", [
+    ("ds", dict(designated_species="1001, 1003"), dict(ds=["1001", "1003"]), False),              # --ds: only these species reach the strain level
+    ("mode0", dict(mode=0), dict(mode=0), False),                                                 # species with a single genome only (is_pan = 0)
+    ("mode1", dict(mode=1), dict(mode=1), False),                                                 # pan species only
+    ("cut", dict(min_species_abundance=0.2), dict(min_ab=0.2), False),                            # -a: species below the cut are not profiled
+    ("mincov", dict(min_cov=4, sd=0.05), dict(min_cov=4, sd=0.05), False),                        # --min_cov / --sd of abundance_est
+    ("shift", dict(shift=True, fr=0.5, min_depth=1), dict(shift=True, fr=0.5, min_depth=1), False),
+    ("round", dict(full=False), dict(), True),                                                    # two-decimal table
+])
+def test_profile_seam_options(world, name, kw, okw, rounded):
+    """The option branches of load_species_range / optimize_otu / abundance_est through the file seam (profile.rs:553-656,
+    :2884-3026, :3091-3289) against the oracle with the same options."""
+    sset, root, db, gaf, eng = world
+    exp_species, exp_strain, _ = _oracle_tables(sset, **okw)
+    if name != "round":
+        assert exp_strain != _oracle_tables(sset)[1]          # the option changes the answer on this data
+    wd = root / ("wd_opt_" + name)
+    wd.mkdir()
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        eng.profile(str(db), str(wd), str(gaf), **kw)
+    finally:
+        os.chdir(cwd)
+    _check_outputs(str(wd), sset, exp_species, exp_strain, rounded=rounded)
 
 
 def test_profile_seam_errors(world):
