@@ -447,6 +447,8 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     assert n_cols > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_nodes", [2000, 500, 1237])
 def test_strain_profiling_with_row_sampling(eng, sample_nodes):
     """--sample N (a11, profile.rs:1287-1295, :2738-2752): species with more valid rows than N solve the LP on the sampled
     rows only; the others are untouched.  Checked against the oracle's own restatement of the sampler and, for the rule
