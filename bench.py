@@ -219,6 +219,33 @@ def main():
                             rows_max=args.species * args.haps)
     barrier()
     dt_cached = time.perf_counter() - t1
+    # extra (not `value`): two independent passes in flight -- a second ctx with its own copy of the DB and the reads steps on a
+    # second host thread (a stream of samples processed two at a time).  One pass is a chain of ~100 short dependent
+    # kernels that cannot fill 256 CUs; two chains interleave on the device.
+    two_in_flight = None
+    if world == 1 and not args.no_gaf:
+        import threading
+        eng2 = Engine(local_rank)
+        eng2.upload_db(sset.species)
+        eng2.upload_packed(sset.reads)
+        eng2.sync()
+        profile_step(eng2, species_names, hap_names, avg_len, cfg)
+        outs2 = [None, None]
+
+        def run(e, slot):
+            outs2[slot] = profile_steps_pipelined(e, species_names, hap_names, avg_len, args.steps, cfg, LocalComm())[-1]
+        eng.sync(); eng2.sync()
+        t3 = time.perf_counter()
+        ths = [threading.Thread(target=run, args=(eng, 0)), threading.Thread(target=run, args=(eng2, 1))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        eng.sync(); eng2.sync()
+        dt2 = time.perf_counter() - t3
+        two_in_flight = {"steps": 2 * args.steps, "ms_per_step": dt2 / (2 * args.steps) * 1e3, "mreads_per_s": 2 * args.steps * args.reads / dt2 / 1e6,
+                         "tables_equal": bool(outs2[0][:2] == outs2[1][:2] == out[:2])}
+        eng2.close()
     # extra (not `value`): the same workload from GAF TEXT on disk -- device tokenizer (a1) -> resident reads -> one step
     gaf_extra = None
     if rank == 0 and not args.no_gaf:
@@ -281,6 +308,7 @@ def main():
                        "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
                        "exchange": "none" if world == 1 else ("one rccl all_reduce per step, in flight during the next step" if backend == "nccl" else backend + " all_reduce (dry run)")},
             "from_gaf_text": gaf_extra,
+            "two_passes_in_flight": two_in_flight,
             "roofline": roofline,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
             "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel only",
