@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gaf", action="store_true", help="skip the extra end-to-end-from-GAF-text measurement")
+    ap.add_argument("--no-gaf", action="store_true", help="skip the extra measurements (from GAF text, two passes in flight)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
