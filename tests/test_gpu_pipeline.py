@@ -551,3 +551,24 @@ def test_profile_seam_sharded_over_ranks(world, world_size):
     from pantax_amd.engine import PantaxHipError
     with pytest.raises(PantaxHipError):
         eng0.profile(str(db), str(wd), str(gaf), rank=0, world_size=2, force=True)
+
+
+@pytest.mark.gpu
+def test_device_gaf_filter_and_sampler_against_fixtures(eng, tmp_path, golden_dir):
+    """The same fixtures through the device filter and the library's sampler (no oracle call on this path)."""
+    import json
+    from pantax_amd.engine import Engine
+    g = json.load(open(os.path.join(golden_dir, "gaf_filter.json")))
+    txt = g["text"].encode("latin-1")
+    gp = tmp_path / "fx.gaf"
+    gp.write_bytes(txt)
+    n_lines, n_rec, n_written = eng.gaf_filter(str(gp), str(tmp_path / "fx_out.gaf"))
+    lines = txt.split(b"\n")
+    if txt.endswith(b"\n"):
+        lines = lines[:-1]
+    exp = b"".join((lines[i][:-1] if lines[i].endswith(b"\r") else lines[i]) + b"\n" for i in g["kept_lines"])
+    assert n_rec == g["n_records"] and n_written == len(g["kept_lines"]) and (tmp_path / "fx_out.gaf").read_bytes() == exp
+    z = json.load(open(os.path.join(golden_dir, "sampler_positions.json")))
+    for c in z["cases"]:
+        pos = np.nonzero(Engine.sample_ranks(c["n"], c["amount"], seed=c["seed"]))[0]
+        assert pos[:8].tolist() == c["first"] and pos[-4:].tolist() == c["last"] and int(pos.sum()) == c["sum"]

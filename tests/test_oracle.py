@@ -165,3 +165,18 @@ def test_gaf_filter_generated_properties():
     for i in np.nonzero(keep)[0][:200]:
         f = lines[i].strip().split(b"\t")
         assert int(f[11]) > 20 and int(f[3]) - int(f[2]) > 1000
+
+
+def test_sampler_and_gaf_filter_fixtures(golden_dir):
+    """The committed fixtures of the two load-time operators (generated by oracle/gen_golden_aux.py)."""
+    import json
+    import os
+    from oracle import oracle as orc
+    z = json.load(open(os.path.join(golden_dir, "sampler_positions.json")))
+    for c in z["cases"]:
+        pos = orc.sample_sorted_positions(c["n"], c["amount"], seed=c["seed"])
+        assert pos[:8].tolist() == c["first"] and pos[-4:].tolist() == c["last"]
+        assert int(pos.astype(np.uint64).sum()) == c["sum"] and int(np.bitwise_xor.reduce(pos.astype(np.uint32))) == c["xor"]
+    g = json.load(open(os.path.join(golden_dir, "gaf_filter.json")))
+    keep, nrec = orc.gaf_filter(g["text"].encode("latin-1"))
+    assert nrec == g["n_records"] and np.nonzero(keep)[0].tolist() == g["kept_lines"]
