@@ -82,7 +82,7 @@ int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, Strai
     r.counts = (const uint32_t *)(b + L.counts);
     r.nnz = (const uint32_t *)(b + L.nnz); r.hap_bit = (const int32_t *)(b + L.hap_bit);
     r.fixed2 = b + L.fixed2; r.need2 = b + L.need2;
-    if (r.counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "strain step: more than %u membership patterns on this GPU; this build sizes its pattern tables for S*8192+65536", lb.k_cap);
+    if (r.counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "strain step: more than %u membership patterns (internal: the pattern tables hold one entry per node)", lb.k_cap);
     return 0;
 }
 

@@ -591,7 +591,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     SortBufs Sd = in_b ? B : A;
     lb->row_a = reinterpret_cast<const double *>(Sd.k[pack_shift >= 0 ? 1 : 2]);   // sorted abundances, used in place
     // patterns = runs of equal (species, mask)
-    const uint64_t k_cap = std::min<uint64_t>(V, (uint64_t)S * 8192 + 65536);
+    const uint64_t k_cap = V;   // patterns are runs of rows and rows are nodes: never more than V, so the tables cannot overflow
     lb->k_cap = (uint32_t)k_cap;
     PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
     {

@@ -404,6 +404,7 @@ def test_pao_solve_edge_cases(eng):
     (24, 3, 6, 6000, 30000, 0.6, dict(shift=True, fr=0.5)),                  # low depth: the shifted threshold drops below fr
     (23, 3, 5, 20000, 30000, 0.2, dict(min_depth=3)),                        # --min_depth feeds the single-path statistics only (:2941-2944)
     (25, 4, 1, 20000, 30000, 1.0, dict(min_depth=2)),                        # every species a single strain
+    (26, 2, 40, 120000, 30000, 0.9, dict(fr=0.05)),                          # 30-40 LP columns per species, thousands of membership patterns
 ])
 def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     """optimize_otu + abundace_constraint (profile.rs:2884-3070) for every species, against the oracle."""
@@ -421,7 +422,7 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
     got = metrics_to_dicts(met, eng.H)
     ref = _oracle_cov_per_species(sset, sp)
-    n_cols = 0
+    n_cols = n_face = 0
     for si, (G, T, b, c, t, na) in enumerate(ref):
         if not keep[si]:
             continue
@@ -436,6 +437,16 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
             assert info[si].obj1 == pytest.approx(o1, rel=1e-9, abs=1e-12)
             if not np.isnan(o2):
                 assert info[si].obj2 == pytest.approx(o2, rel=1e-9, abs=1e-12)
+        # an LP whose optimum is a face, not a point (likely with tens of columns): any x with the optimal objective is
+        # right and what follows from first_sol follows it -- the objective was compared above, x is checked to attain it
+        cand = [h for h, e in enumerate(exp) if e["first_sol"] is not None]
+        if nc and any(got[h0 + h]["first_sol"] != pytest.approx(exp[h]["first_sol"], rel=1e-7, abs=1e-9) for h in cand):
+            mask, _ = orc.path_masks(G, cand, c)
+            xg = np.array([got[h0 + h]["first_sol"] for h in cand])
+            g_ = sset.species[si]
+            assert orc.lad_objective(mask, b / np.asarray(g_.node_len, dtype=np.float64), xg) == pytest.approx(o1, rel=1e-9), (si, "x is not optimal")
+            n_face += 1
+            continue
         for h, e in enumerate(exp):
             g = got[h0 + h]
             for key, ev in e.items():
@@ -444,7 +455,7 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
                     assert gv == ev, (si, h, key, gv, ev)
                 else:
                     assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
-    assert n_cols > 0
+    assert n_cols > 0 and (n_face == 0 or H >= 20)      # the small cases of this test have unique optima
 
 
 @pytest.mark.gpu
