@@ -711,7 +711,7 @@ static SecondFilterArgs second_filter_args(const Db *db, LadBatch *lb, const Fil
 // ---------------------------------------------------------------------------------------------
 constexpr int LAD_BLOCK = 256;
 constexpr int LAD_KWIDE = 16;    // patterns up to which a wave searches cooperatively / the line search runs wide rounds
-constexpr int LAD_KLDS = 64;     // patterns whose solver state fits the LDS arrays
+constexpr int LAD_KLDS = 256;    // patterns whose solver state fits the LDS arrays (72 B each); more go through global scratch
 enum { C_LB = 0, C_UB = 1, C_PAT = 2, C_FIXED = 3 };
 
 struct LadArgs {
@@ -791,7 +791,7 @@ __device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double
 // LDS of one solver workgroup
 template <int PS>
 struct LadLds {
-    static constexpr uint32_t IDX_N = 4096;                       // samples of the row index
+    static constexpr uint32_t IDX_N = PS <= 16 ? 4096 : 2048;     // samples of the row index (the 64-column instance spends its LDS on W and G)
     static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 512;    // cached candidate rows of a line search
     LadShared sh;
     double W[PS * PS];
@@ -1315,6 +1315,35 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             sh.act_i0[best] = sh.ent_i0; sh.act_i1[best] = sh.ent_i1;
         }
         __syncthreads();
+        // One row of N changed: W = N^-1 follows by a rank-one (Sherman-Morrison) update, O(p^2) instead of the O(p^3)
+        // elimination with its 4 barriers per column -- 110 of 200 us per pivot at p = 36.  With y = n_new^T W and
+        // z = y - e_best:  W' = W - (W e_best) z^T / y[best].  The inverse is rebuilt from scratch every 16th pivot and
+        // whenever y[best] is small, so rounding cannot accumulate; up to 8 columns the elimination is cheap and stays.
+        bool refactor = p <= 8 || (it & 15) == 15;
+        if (!refactor) {
+            if (tid < p) {
+                double y;
+                if (sh.act_type[best] == C_PAT) {
+                    y = 0.0;
+                    uint64_t m = P_pat_mask[sh.act_jk[best] - kofs];
+                    while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; y += W[j * PS + tid]; }
+                } else y = W[sh.act_jk[best] * PS + tid];
+                sh.fac[tid] = y;
+                sh.score[tid] = W[tid * PS + best];
+            }
+            __syncthreads();
+            const double alpha = sh.fac[best];
+            if (fabs(alpha) < 1e-7) refactor = true;   // (block-uniform: read from LDS after the barrier)
+            else {
+                const double ainv = 1.0 / alpha;
+                for (int i = tid; i < p * p; i += LAD_BLOCK) {
+                    const int j = i / p, cc = i % p;
+                    W[j * PS + cc] -= sh.score[j] * (sh.fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
+                }
+                __syncthreads();
+            }
+        }
+        if (refactor) {
         for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
             int r = i / (2 * p), cc = i % (2 * p);
             double v;
@@ -1350,6 +1379,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
         if (sh.done) break;
         for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = G[(i / p) * 2 * PS + p + (i % p)];
         __syncthreads();
+        }   // refactor
     }
     // ---- final vertex with the UNPERTURBED right-hand sides, clipped to the box
     __syncthreads();
