@@ -37,5 +37,6 @@ rows = eng.timing_get()
 for name, (launches, ms) in sorted(rows.items(), key=lambda r: -r[1][1])[:14]:
     print("  %-28s %6d launches %9.3f ms/step" % (name, launches // 3, ms / 3))
 info = out[3]
+print("per species (columns, patterns, pivots LP1, pivots LP2):", [(info[s].n_candidates, info[s].n_patterns, info[s].iters1, info[s].iters2) for s in range(min(eng.S, 6))])
 print("species solved:", sum(1 for s in range(eng.S) if info[s].n_candidates > 0 and info[s].status1 == 0), "of", eng.S,
       " max candidates", max(info[s].n_candidates for s in range(eng.S)))
