@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Probe: the strain step when nearly every haplotype is a candidate (4 species x 40 strains, 36 LP columns and 139
+membership patterns per species): prints the step time, the LP sizes / pivots and the kernel table."""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pantax_amd import synth
 from pantax_amd.engine import Engine
