@@ -563,7 +563,8 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
     }
     for (int j = 0; j < p; ++j) {
         double s = 0.0; for (int i = 0; i < p; ++i) s += W[j * p + i] * c[i];
-        if (s < 0.0) s = 0.0; if (s > ub[j]) s = ub[j];
+        if (s < 0.0) s = 0.0;
+        if (s > ub[j]) s = ub[j];
         x_out[j] = s;
     }
     if (obj_out) *obj_out = orc_lad_objective(n_nodes, mask, abund, n_cand, x_out);
