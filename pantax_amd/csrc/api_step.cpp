@@ -57,6 +57,8 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
     PTX_TRY(strain_prezero(ctx, db));   // zero-fills of the strain step, while this stream would wait for the trio index anyway
     struct PreZeroGuard { LadBatch &lb; ~PreZeroGuard() { lb.prezeroed = false; } } prezero_guard{db->lad};   // never outlives this call
+    PTX_TRY(coverage_prepare(ctx, db, reads, true));   // arena zero-fill + walk sums of long reads: need the binning, not the trio index
+    struct CovPrepGuard { Db *d; ~CovPrepGuard() { d->cov_prepared = false; } } covprep_guard{db};
     // a8 needs both
     if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));

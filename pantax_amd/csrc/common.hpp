@@ -230,6 +230,7 @@ struct Db {
     // unique-trio index (a7)
     bool trio_built = false;
     uint64_t U = 0;
+    bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
     DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
@@ -346,6 +347,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 
 // ---- stage entry points (host launchers, defined in the .hip files) ---------------------------
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
+int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db);
 struct HostReads;

@@ -500,7 +500,9 @@ __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_
     }
 }
 
-int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio) {
+// The part of the coverage pass that depends on the binning only -- zero-filling the result arena and the walk sums of
+// long reads: the resident step issues it while the trio index is still being built on the side stream.
+int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     const uint64_t words = (db->L + 31) / 32 + 1;
     const uint64_t U = with_trio ? db->U : 0;
     // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32]
@@ -511,7 +513,6 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     db->d_trio_bases.view(base + off_trio, U ? U : 1);
     db->d_abort = reinterpret_cast<unsigned long long *>(base + off_abort);
     db->d_bitmap.view(base + off_bm, words);
-    unsigned long long *d_abort = db->d_abort;
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
     PTX_HIP(ctx, hipMemsetAsync(base, 0, total, ctx->stream));
     if (rd->R && rd->T_pad && rd->n_long) {
@@ -521,6 +522,15 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
                            rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, db->d_sp_first_id.p, db->d_node_base.p,
                            db->d_node_rec.p, rd->d_long_sum.p);
     }
+    PTX_HIP(ctx, hipGetLastError());
+    db->cov_prepared = true;
+    return 0;
+}
+
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio) {
+    if (!db->cov_prepared) PTX_TRY(coverage_prepare(ctx, db, rd, with_trio));
+    db->cov_prepared = false;
+    unsigned long long *d_abort = db->d_abort;
     if (rd->R && rd->T_pad) {
         int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
