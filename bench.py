@@ -123,8 +123,8 @@ def highs_probe(sset, cfg, max_rows=20000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--species", type=int, default=1)
     ap.add_argument("--haps", type=int, default=10)
