@@ -528,19 +528,39 @@ def test_profile_seam_sharded_over_ranks(world, world_size):
         finally:
             eng.close()
     cwd = os.getcwd()
-    os.chdir(str(wd))
-    try:
-        ths = [threading.Thread(target=run, args=(r,)) for r in range(world_size)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join(timeout=300)
-    finally:
-        os.chdir(cwd)
-    assert not errs, errs
+
+    def launch(fn):
+        os.chdir(str(wd))
+        try:
+            ths = [threading.Thread(target=fn, args=(r,)) for r in range(world_size)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join(timeout=300)
+        finally:
+            os.chdir(cwd)
+        assert not errs, errs
+    launch(run)
     _check_outputs(str(wd), sset, exp_species, exp_strain)
     assert os.path.exists(wd / "ori_strain_abundance.txt") and os.path.exists(wd / "reads_classification.tsv")
     assert not [f for f in os.listdir(wd) if ".part" in f]
+    # the resume path over ranks (profile.rs:3365-3417): the strain table is gone, the species table and the report stay ->
+    # rank 0's view of the work directory decides for everybody, the strain level is redone from the saved binning
+    os.remove(wd / "strain_abundance.txt")
+    before = os.path.getmtime(wd / "species_abundance.txt")
+
+    def run_resume(rank):
+        eng = Engine(0)
+        try:
+            eng.profile(str(db), str(wd), str(gaf), rank=rank, world_size=world_size, allreduce=make_allreduce(rank))
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, e))
+            bar.abort()
+        finally:
+            eng.close()
+    launch(run_resume)
+    assert os.path.getmtime(wd / "species_abundance.txt") == before
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
     # the rows are in the one-process order as well: same file as the single-rank run apart from the last digits of the sums
     one = root / "wd_bin"
     if (one / "strain_abundance.txt").exists():
