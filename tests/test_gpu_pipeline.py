@@ -592,3 +592,58 @@ def test_device_gaf_filter_and_sampler_against_fixtures(eng, tmp_path, golden_di
     for c in z["cases"]:
         pos = np.nonzero(Engine.sample_ranks(c["n"], c["amount"], seed=c["seed"]))[0]
         assert pos[:8].tolist() == c["first"] and pos[-4:].tolist() == c["last"] and int(pos.sum()) == c["sum"]
+
+
+@pytest.mark.gpu
+def test_profile_seam_sharded_failure_reaches_every_rank(world):
+    """One rank cannot load a graph of its shard: it reports the failure through the exchange, every rank returns an
+    error (nobody is left waiting in the all-reduce) and no strain table appears."""
+    import shutil
+    import threading
+    from pantax_amd.engine import Engine, PantaxHipError
+    sset, root, db, gaf, eng0 = world
+    db2 = root / "db_broken"
+    shutil.copytree(db, db2)
+    exp_species, exp_strain, _ = _oracle_tables(sset)
+    profiled = sorted({r[0] for r in exp_strain})                 # species that reach the strain level, selection order = species table order
+    sel_order = [r[0] for r in exp_species if r[0] in profiled]
+    victim = sel_order[1]                                          # position 1 in the selection -> rank 1 of 2
+    for sub, ext in (("species_graph_info", ".bin"), ("species_gfa", ".gfa")):
+        os.remove(db2 / sub / (victim + ext))
+    wd = root / "wd_shard_fail"
+    wd.mkdir()
+    bar = threading.Barrier(2)
+    slots, total, errs = [None, None], [None], {}
+
+    def make_allreduce(rank):
+        def allreduce(buf):
+            slots[rank] = buf.copy()
+            if bar.wait(timeout=120) == 0:
+                total[0] = np.sum(slots, axis=0)
+            bar.wait(timeout=120)
+            buf[:] = total[0]
+            bar.wait(timeout=120)
+        return allreduce
+
+    def run(rank):
+        eng = Engine(0)
+        try:
+            eng.profile(str(db2), str(wd), str(gaf), rank=rank, world_size=2, allreduce=make_allreduce(rank))
+        except PantaxHipError as e:
+            errs[rank] = str(e)
+        finally:
+            eng.close()
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+            assert not t.is_alive()
+    finally:
+        os.chdir(cwd)
+    assert set(errs) == {0, 1}
+    assert "does not exist" in errs[1] and "another rank failed" in errs[0]
+    assert not os.path.exists(wd / "strain_abundance.txt") and os.path.exists(wd / "species_abundance.txt")
