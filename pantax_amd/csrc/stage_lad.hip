@@ -458,12 +458,21 @@ __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, c
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_rows, tot) : 0u;
     __syncthreads();
     uint32_t j = s_base + woff + incl - cnt;
+    uint32_t sp1 = 0;              // 1 + species of the previous emitted node of this thread (its nodes are consecutive)
 #pragma unroll
     for (int i = 0; i < ROW_ITEMS; ++i) {
         if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
         const uint64_t v = base + i;
-        uint32_t lo = 0, hi = S;   // species of node v: last s with node_base[s] <= v
-        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; }
+        uint32_t lo;
+        if (sp1 == 0) {            // species of node v: last s with node_base[s] <= v
+            uint32_t hi = S;
+            lo = 0;
+            while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; }
+        } else {
+            lo = sp1;
+            while (lo < S && node_base[lo] <= v) ++lo;   // at most a species border or two between neighbouring nodes
+        }
+        sp1 = lo;
         const uint64_t abits = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
         if (pack_shift >= 0) {
             k0[j] = (pack_shift < 64 ? ((uint64_t)(lo - 1) << pack_shift) : 0ull) | m[i];
