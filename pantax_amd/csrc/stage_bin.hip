@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
         for (unsigned long long todo = __ballot(long_walk); todo;) {
             int src = -1;
             unsigned long long t = todo;
-            for (int q = 0; q <= row && t; ++q) { src = (q == row) ? __ffsll((long long)t) - 1 : -1; t &= t - 1; }   // my row's walk: the row-th pending lane
-            for (int q = 0; q < 4 && todo; ++q) todo &= todo - 1;
+            for (int w_ = 0; w_ <= row && t; ++w_) { src = (w_ == row) ? __ffsll((long long)t) - 1 : -1; t &= t - 1; }   // my row's walk: the row-th pending lane
+            for (int w_ = 0; w_ < 4 && todo; ++w_) todo &= todo - 1;
             const uint32_t bb = __shfl(b, src < 0 ? 0 : src), ee = __shfl(e, src < 0 ? 0 : src);
             uint32_t m1 = 0xFFFFFFFFu, m2 = 0;
             if (src >= 0)

@@ -905,8 +905,8 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             P_sc_s[k - kofs] = sk; P_sc_lo[k - kofs] = lo; P_sc_up[k - kofs] = up;
             long long sigma = (long long)(lo - st) - (long long)(en - up);
             if (sigma && leader) {
-                uint64_t m = mk;
-                while (m) { int j = __ffsll((long long)m) - 1; m &= m - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                uint64_t bits = mk;
+                while (bits) { int j = __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
             }
         }
         __syncthreads();
@@ -1132,8 +1132,8 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                         if (leader) cand += ch - cl;
                         double w = fabs(rho) * (double)(ch - cl);
                         if (w > wbest) {
-                            uint32_t m = cl + (ch - cl) / 2;   // m-th breakpoint ahead (0-based) of this pattern
-                            uint32_t r = rho > 0 ? P_sc_up[k - kofs] + m : P_sc_lo[k - kofs] - 1 - m;
+                            uint32_t mth = cl + (ch - cl) / 2;   // mth breakpoint ahead (0-based) of this pattern
+                            uint32_t r = rho > 0 ? P_sc_up[k - kofs] + mth : P_sc_lo[k - kofs] - 1 - mth;
                             double av;
                             bool have = false;
                             if (approx) {   // a sampled row among the candidates serves as well as the exact median
@@ -1334,8 +1334,8 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 double y;
                 if (sh.act_type[best] == C_PAT) {
                     y = 0.0;
-                    uint64_t m = P_pat_mask[sh.act_jk[best] - kofs];
-                    while (m) { const int j = __ffsll((long long)m) - 1; m &= m - 1; y += W[j * PS + tid]; }
+                    uint64_t bits = P_pat_mask[sh.act_jk[best] - kofs];
+                    while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
                 } else y = W[sh.act_jk[best] * PS + tid];
                 sh.fac[tid] = y;
                 sh.score[tid] = W[tid * PS + best];
