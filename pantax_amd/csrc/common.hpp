@@ -285,6 +285,7 @@ struct Reads {
     DevBuf<uint8_t> d_g_step_dup;    // [T_pad] walks <= 64 steps: distance back to the first occurrence of the step's node (0 none);
                                      //         longer walks: 0x80 | (node occurred earlier in the walk)
     DevBuf<uint32_t> d_long_sum;     // [R'] walks > 64 steps: node lengths of all steps but the last (walk_sum_kernel), else unused
+    DevBuf<uint32_t> d_long_len0;    // [R'] walks > 64 steps: length of the walk's first node (walk_sum_kernel)
     uint32_t n_long = 0;             // walks of more than 64 steps
     DevBuf<int32_t> d_g_sp;          // [R'] species of the slot's read (-1: "U" or dropped row), written by the binning kernel
     bool binned = false;

@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
     const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases,
     uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
-    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort, const uint32_t *__restrict__ long_sum) {
+    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort, const uint32_t *__restrict__ long_sum,
+    const uint32_t *__restrict__ long_len0) {
     __shared__ uint32_t s_win[COV_WIN];
     __shared__ uint32_t s_bm[COV_BWIN];
     const int lane = threadIdx.x & 63;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         // first node length: from the lane that holds step b, else from memory
         const uint32_t nl_src = __shfl(nl, lane - dist);
         uint32_t len0 = nl;
-        if (ok && i > 0) len0 = !cross ? nl_src : node_rec[nb + (node_id[b] - first_id)].z;
+        if (ok && i > 0) len0 = !cross ? nl_src : long_len0[slot];   // first node of a long walk: noted by walk_sum_kernel
         const long long target = (long long)pe - (long long)ps;   // profile.rs:800
         if (ok && k == 1) {                                       // :811
             if (target >= 0) {                                    // :821-827
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
                                                        const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
                                                        const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ sp_first_id,
                                                        const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec,
-                                                       uint32_t *__restrict__ long_sum) {
+                                                       uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
     const int lane = threadIdx.x & 63;
     for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)); base < T; base += (uint64_t)gridDim.x * 256) {
         const uint64_t t = base + lane;
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
             if (sp >= 0 && (uint32_t)(t - rr.x) + 1 < rr.y) {        // not the last step
                 const uint32_t first_id = sp_first_id[sp], nb = node_base[sp], id = node_id[t];
                 if (id >= first_id && id - first_id < node_base[sp + 1] - nb) nl = node_rec[nb + (id - first_id)].z;
+                if (t == rr.x) long_len0[slot] = nl;                 // length of the walk's first node, for the lanes of later waves
             }
         }
         // segmented sum over runs of equal slot (a walk's steps are contiguous), one atomic per run
@@ -473,6 +475,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
         hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_s,
                            rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
         PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R));
+        PTX_HIP(ctx, rd->d_long_len0.alloc(rd->R));
     }
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // temporaries are released on return
@@ -520,7 +523,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
         KTimer t(ctx, "walk_sum_kernel");
         hipLaunchKernelGGL(walk_sum_kernel, dim3(grid_for(rd->T_pad, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
                            rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, db->d_sp_first_id.p, db->d_node_base.p,
-                           db->d_node_rec.p, rd->d_long_sum.p);
+                           db->d_node_rec.p, rd->d_long_sum.p, rd->d_long_len0.p);
     }
     PTX_HIP(ctx, hipGetLastError());
     db->cov_prepared = true;
@@ -535,7 +538,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
         KTimer t(ctx, "coverage_step_kernel");
 #define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_sp_first_id.p, \
-                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p
+                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, rd->d_long_len0.p
         if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
         else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
 #undef COVS_ARGS
