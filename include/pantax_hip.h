@@ -232,8 +232,9 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     int32_t species, strain, shift, filtered, full, force, mode, sample_nodes;
     const char *designated_species; /* --ds or NULL */
     const char *zip;                /* "serialize" (.bin) | "lz" (.bin.lz4) | "zstd" (.bin.zst) | NULL (= GFA); "h5" is refused */
-    /* one process per GPU: with world_size > 1 this process takes the selected species i with i % world_size == rank
-     * (every rank reads the GAF and bins it; the species table is rank 0's).  The strain table needs two global sums and
+    /* one process per GPU: with world_size > 1 this process takes its share of the selected species (longest-processing-
+     * time packing on reads + graph size, the same table on every rank; every rank reads the GAF and bins it; the species
+     * table is rank 0's).  The strain table needs two global sums and
      * the rows of every rank: the library calls allreduce_sum (below) three times per run -- run mode, {failure flag, the
      * two sums}, a barrier once the ranks' rows are in part files under wd -- and rank 0 writes the tables. */
     int32_t rank, world_size;

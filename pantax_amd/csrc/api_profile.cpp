@@ -271,6 +271,23 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     std::vector<pantax_hip_solve_info> info;
     std::vector<uint64_t> hap_off(1, 0);
     std::vector<std::string> hap_names;
+    // which rank takes which selected species: longest-processing-time packing on (reads binned to the species + its graph
+    // nodes), heaviest first onto the least loaded rank; every rank computes the same table from the same inputs
+    std::vector<int> owner(Ss, 0);
+    if (W > 1) {
+        std::vector<uint32_t> by_weight(Ss);
+        std::vector<double> weight(Ss), load(W, 0.0);
+        for (uint32_t i = 0; i < Ss; ++i) {
+            by_weight[i] = i;
+            weight[i] = (double)rc[sel[i]] * 8.0 + (double)(ranges[sel[i]].end - ranges[sel[i]].start + 1);   // ~8 walk steps per read
+        }
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+        for (uint32_t i : by_weight) {
+            int r = 0;
+            for (int q = 1; q < W; ++q) if (load[q] < load[r]) r = q;
+            owner[i] = r; load[r] += weight[i];
+        }
+    }
     // everything a rank does on its own shard; a failure here must not leave the other ranks waiting in the exchange below
     auto shard = [&]() -> int {
     // image_cache >= 1: device-ready images <db>/species_graph_info/<otu>.hipdb (db_image.cpp) stand in for
@@ -290,7 +307,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         std::vector<uint8_t> ok(Ss, 0);
         parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
-                if ((int)(i % (uint64_t)W) != rk) { ok[i] = 1; continue; }                         // another rank's species
+                if (owner[i] != rk) { ok[i] = 1; continue; }                                     // another rank's species
                 const std::string &otu = ranges[sel[i]].species;
                 const std::string img = image_of(otu);
                 if (!is_file(img) || file_mtime(img) < file_mtime(source_of(otu))) continue;
@@ -306,7 +323,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         std::vector<std::string> hard(Ss);   // errors that end the run
         parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
-                if ((int)(i % (uint64_t)W) != rk) { loaded[i] = 0; continue; }                     // another rank's species
+                if (owner[i] != rk) { loaded[i] = 0; continue; }                                 // another rank's species
                 const std::string &otu = ranges[sel[i]].species;
                 std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
                 std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
@@ -326,7 +343,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         for (uint32_t i = 0; i < Ss; ++i) if (!hard[i].empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", hard[i].c_str());
     }
     lap("graph load");
-    for (uint32_t i = 0; i < Ss; ++i) if (loaded[i] && (int)(i % (uint32_t)W) == rk) use.push_back(i);
+    for (uint32_t i = 0; i < Ss; ++i) if (loaded[i] && owner[i] == rk) use.push_back(i);
     Su = (uint32_t)use.size();
     info.assign(Su, pantax_hip_solve_info{});
     hap_off.assign(Su + 1, 0);
