@@ -28,6 +28,20 @@ class StepConfig:
     rebuild_trio: bool = True             # the reference rebuilds trio_nodes_info every run (profile.rs:2936)
 
 
+def partition_species(weights, world):
+    """Which rank takes which species: longest-processing-time packing -- heaviest first onto the least loaded
+    rank, ties to the lower rank; the C file seam uses the same rule with weight = 8 * reads binned + graph nodes.
+    -> list of rank per species."""
+    order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
+    load = [0.0] * world
+    owner = [0] * len(weights)
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += weights[i]
+    return owner
+
+
 class LocalComm:
     """world_size == 1: the exchange is the identity."""
     rank, world = 0, 1

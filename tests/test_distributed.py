@@ -57,3 +57,15 @@ def test_two_rank_finalize_matches_single_process(tmp_path):
     assert sum(r[3] for r in got["strain"]) == pytest.approx(1.0, rel=1e-12)
     # the species under the -a cut contributes no strain rows on either side
     assert not any(r[0] == "sp1_0" for r in got["strain"])
+
+
+def test_partition_species_is_balanced_and_deterministic():
+    from pantax_amd.pipeline import partition_species
+    rng = np.random.default_rng(4)
+    w = rng.lognormal(10, 1.5, size=200).tolist()
+    for world in (1, 2, 4, 8):
+        owner = partition_species(w, world)
+        assert owner == partition_species(w, world) and set(owner) == set(range(world))
+        load = [sum(x for x, o in zip(w, owner) if o == r) for r in range(world)]
+        assert max(load) <= sum(w) / world + max(w)          # the LPT guarantee
+    assert partition_species([5.0, 5.0, 1.0], 2) == [0, 1, 0]
