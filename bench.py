@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- PAO wall time / Mreads/s of the profiling hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already
-resident in HBM: read binning + species counters, species profile, unique-trio index (rebuilt per
-step like the reference does per run), node-coverage histogram, LP row grouping, the two PAO
-solves, filters and the abundance table.  Workload at N=1 = BASELINE.json configs[1]
-("Single-species E. coli, 10 strains, 1M synthetic short-read GAF"); with N ranks each rank owns
-its own species shard of that shape (weak scaling; species are independent sub-problems) and one
-RCCL all-reduce carries the normalisers.
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM: read
+binning + species counters, species profile, unique-trio index (rebuilt per step like the reference does per run,
+profile.rs:2936), node-coverage histogram, LP row grouping, the two PAO solves, filters and the abundance table.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+Workload at N=1 (default) = BASELINE.json configs[2], the largest single-GPU configuration:
+"100 species / 1k strains, 10M Illumina GAF, 1 MI355X" (10 strains per species, 5 Mbp genomes, 150 bp
+reads, seed 20260501 + 3).  `--workload cfg2` selects configs[1] (1 species, 1M reads).  With N ranks every rank owns
+its own shard of that shape (weak scaling: N x 100 species / N x 10M reads, i.e. cfg4's 1k species / 100M reads at
+N = 8 give or take 25 %; species are independent sub-problems) and one RCCL all-reduce per step carries the
+normalisers.  `--scaling strong` instead cuts ONE set of the given size over the ranks (longest-processing-time
+packing of the species, pipeline.partition_species; reads follow their species).
+
+    python bench.py                                   # cfg3, 1 GPU
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Beside `value` the line carries: `roofline` (dominant kernel, HIP events on the library's stream), `cpu_baseline` (the
+plain-C oracle on ALL host cores, one species per worker like profile.rs:3297-3319, plus SciPy-HiGHS legs on row samples
+of the same LP), `from_gaf_text` (GAF text on disk -> tables, PCIe + device tokenizer included), `pao_hard` (a
+synthetic variant whose first filter keeps all ten strains: the LP regime BASELINE.md section 2 flags).
 """
 import argparse
 import json
@@ -25,8 +34,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads, genome_len)
+    "cfg2": ("configs[1]: single-species E. coli-like, 10 strains, 1M short reads", 2, 1, 10, 1_000_000, 5_000_000),
+    "cfg3": ("configs[2]: 100 species / 1k strains, 10M short reads", 3, 100, 10, 10_000_000, 5_000_000),
+    "cfg4_share": ("configs[3] per-GPU share: 125 species / 1250 strains, 12.5M short reads", 4, 125, 10, 12_500_000, 5_000_000),
+}
 
-def algorithmic_bytes(sset, U):
+
+def algorithmic_bytes(sset, n_lp_rows):
     """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload."""
     rd = sset.reads
     R, T = rd.n_reads, len(rd.node_id)
@@ -42,106 +57,292 @@ def algorithmic_bytes(sset, U):
         "coverage_step_kernel": 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr,
         # a8 popcount: L/8 bitmap in + 8V cov out
         "popcount_kernel": L // 8 + 8 * V,
-        # a7 bucket scatter: 4P in + 16 B record per window out
+        # a7: SURVEY 8d "2 x 12 x (P - 2H) (write keys, read sorted) + 12U" is the whole index; the bucket scatter alone
+        # reads the walks (4P) and writes one 16-B record per window
         "trio_fill_kernel": 4 * P + 16 * max(P - 2 * H, 0),
+        "trio_count_kernel": 4 * P + 4 * V,
+        "trio_uniq_kernel": 16 * max(P - 2 * H, 0),
         # a10: 4P in + 8V mask out
         "mask_kernel": 4 * P + 8 * V,
-    }, dict(R=R, T=T, V=V, L=L, P=P, H=H, U=U)
+        "sort_hist_kernel": 8 * n_lp_rows,
+        "sort_scatter_kernel": 2 * 24 * n_lp_rows,
+    }, dict(R=R, T=T, V=V, L=L, P=P, H=H)
 
 
-def cpu_baseline(sset, sample_reads, cfg):
-    """The oracle (plain-C port of the reference algorithm) on ONE host core over a bounded sample:
-    the first `sample_reads` reads of the same workload through binning, trio index, coverage,
-    filters and both LP solves.  Reported beside the GPU number; it is a baseline, not the target."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+_CPU = {}   # state shared with forked workers (copy-on-write)
+
+
+def _cpu_bin_task(rng):
+    from oracle import oracle as orc
+    a, b = rng
+    sset = _CPU["sset"]
+    rd = sset.reads
+    return orc.bin_reads(rd.step_off[a:b + 1], rd.node_id, _CPU["rs"], _CPU["re"])
+
+
+def _species_lp(orc, g, G, b, c, md):
+    """The LP optimize_species solved for this species: candidate columns = haplotypes with a first_sol."""
+    cand = np.array([i for i, m in enumerate(md) if m["first_sol"] is not None], dtype=np.uint32)
+    if len(cand) == 0:
+        return None
+    mask, _ = orc.path_masks(G, cand, c)
+    ab = b / g.node_len
+    return mask, ab, len(cand)
+
+
+def _cpu_species_task(si):
     from oracle import oracle as orc
     from tests.helpers import select_reads
-    rd = sset.reads
-    n = min(sample_reads, rd.n_reads)
+    sset, cfg = _CPU["sset"], _CPU["cfg"]
+    g = sset.species[si]
     t0 = time.perf_counter()
-    step_off = rd.step_off[: n + 1]
-    node_id = rd.node_id[: int(step_off[-1])]
-    sp = orc.bin_reads(step_off, node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
-    counts = orc.species_counts(sp, rd.qlen[:n], rd.mapq[:n], len(sset.species))
-    keep, absolute, _ = orc.species_profile(sp, rd.qlen[:n], counts, sset.avg_len())
-    t_bin = time.perf_counter() - t0
-    t_lp = t_trio = t_cov = 0.0
-    for si, g in enumerate(sset.species):
-        if not keep[si]:
-            continue
-        t1 = time.perf_counter()
-        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
-        T = orc.TrioTable(G)
-        t_trio += time.perf_counter() - t1
-        t1 = time.perf_counter()
-        sel = np.nonzero(sp == si)[0]
-        so = np.zeros(len(sel) + 1, dtype=np.uint64)
-        ns = (step_off[1:] - step_off[:-1]).astype(np.int64)[sel]
-        so[1:] = np.cumsum(ns)
-        starts = step_off[:-1].astype(np.int64)[sel]
-        idx = np.repeat(starts, ns) + (np.arange(int(ns.sum())) - np.repeat(so[:-1].astype(np.int64), ns))
-        b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, node_id[idx], rd.pstart[:n][sel], rd.pend[:n][sel])
-        t_cov += time.perf_counter() - t1
-        t1 = time.perf_counter()
-        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
-        t_lp += time.perf_counter() - t1
-        orc.abundance_constraint(absolute[si], met)
+    G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+    T = orc.TrioTable(G)
+    t1 = time.perf_counter()
+    lo, n = _CPU["first"][si], _CPU["cnt"][si]
+    sel = np.sort(_CPU["order"][lo:lo + n])
+    so, nid, ps, pe = select_reads(sset.reads, sel)
+    b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+    t2 = time.perf_counter()
+    rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=cfg["fr"], fc=cfg["fc"], sr=cfg["sr"])
+    orc.abundance_constraint(_CPU["absolute"][si], met)
+    t3 = time.perf_counter()
+    n_rows = int(((b > 0)).sum())
+    return si, t1 - t0, t2 - t1, t3 - t2, nc, n_rows
+
+
+def _highs_task(job):
+    """SciPy's bundled HiGHS on the first `rows` (random order, seed 0) valid rows of one species' LP (the reference's
+    open backend, highs_opt profile.rs:2689-2882: x in [0, 1.05 max a], y_v >= +-(A x - a)_v, min (1/n) sum y), next
+    to the oracle's exact LAD on the same rows."""
+    from oracle import oracle as orc
+    from scipy import sparse
+    from scipy.optimize import linprog
+    import scipy
+    mask, ab, p, rows, tlimit = job
+    valid = np.nonzero((ab > 0))[0]
+    ub = 1.05 * float(ab.max())
+    take = valid[np.random.default_rng(0).permutation(len(valid))[:rows]]
+    take.sort()
+    m, a = mask[take], ab[take]
+    n = len(take)
+    A = sparse.csr_matrix(np.stack([((m >> np.uint64(k)) & np.uint64(1)).astype(float) for k in range(p)], 1))
+    I = sparse.identity(n, format="csr")
+    Aub = sparse.vstack([sparse.hstack([A, -I]), sparse.hstack([-A, -I])]).tocsr()
+    bub = np.concatenate([a, -a])
+    c = np.concatenate([np.zeros(p), np.ones(n) / n])
+    bounds = [(0, ub)] * p + [(0, None)] * n
+    t0 = time.perf_counter()
+    r = linprog(c, A_ub=Aub, b_ub=bub, bounds=bounds, method="highs", options={"time_limit": float(tlimit)})
     dt = time.perf_counter() - t0
-    return dict(value=n / dt / 1e6, unit="Mreads/s", cores=1, kind="port",
-                sample="first %d reads of the same workload (all %d species), oracle bin+trio+coverage+filters+2 LP solves; "
-                       "%.2f s total, %.2f s of it in the exact LAD solves" % (n, len(sset.species), dt, t_lp),
+    t1 = time.perf_counter()
+    x, obj, it, st = orc.lad_solve(m, a, p, np.full(p, ub))
+    dt_lad = time.perf_counter() - t1
+    return dict(rows=n, columns=p, patterns=int(len(np.unique(m))), highs_seconds=dt, highs_status=int(r.status),
+                highs_objective=(float(r.fun) if r.status == 0 else None), exact_lad_objective=float(obj), exact_lad_seconds=dt_lad,
+                time_limit_s=tlimit, scipy=scipy.__version__)
+
+
+def highs_legs(pool, lp, sizes, tlimit):
+    """-> list of per-size results, or a note when SciPy is not importable on this box."""
+    try:
+        import scipy.optimize  # noqa: F401
+    except Exception as e:   # noqa: BLE001
+        return {"note": "SciPy not importable here (%s): no HiGHS leg" % type(e).__name__}
+    mask, ab, p = lp
+    n_valid = int((ab > 0).sum())
+    jobs = [(mask, ab, p, min(s, n_valid), tlimit) for s in sizes]
+    return pool.map(_highs_task, jobs)
+
+
+def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit):
+    """The oracle (plain-C port of the reference algorithm) on ALL host cores over the whole workload: reads binned in
+    `cores` slices, then one species per worker (the reference's rayon par_iter over species, profile.rs:3297-3319)
+    through trio index, coverage, filters and both LP solves (the oracle's own exact LAD solver); the reference's open
+    solver, HiGHS, is timed on row samples of the largest species' LP (the full LP does not finish in minutes,
+    BASELINE.md section 2).  Runs BEFORE the GPU is initialised (forked workers)."""
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    rd = sset.reads
+    S = len(sset.species)
+    n = rd.n_reads
+    _CPU.update(sset=sset, cfg=dict(fr=cfg.fr, fc=cfg.fc, sr=cfg.sr),
+                rs=[g.range_start for g in sset.species], re=[g.range_end for g in sset.species])
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    cuts = np.linspace(0, n, cores + 1).astype(np.int64)
+    with ctx.Pool(cores) as pool:
+        parts = pool.map(_cpu_bin_task, [(int(cuts[i]), int(cuts[i + 1])) for i in range(cores)])
+    sp = np.concatenate(parts)
+    counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
+    keep, absolute, _ = orc.species_profile(sp, rd.qlen, counts, sset.avg_len())
+    t_bin = time.perf_counter() - t0
+    order = np.argsort(sp, kind="stable")
+    cnt = np.bincount(sp[sp >= 0], minlength=S)
+    first = np.searchsorted(sp[order], np.arange(S))
+    t_group = time.perf_counter() - t0 - t_bin
+    _CPU.update(order=order, cnt=cnt, first=first, absolute=absolute)
+    todo = [si for si in range(S) if keep[si]]
+    todo.sort(key=lambda si: -int(cnt[si]))                     # heaviest first
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_species_task, todo, chunksize=1)
+        dt = time.perf_counter() - t0
+        # HiGHS legs: the LP of the species with the most rows, on bounded row samples
+        highs = None
+        if res and highs_sizes:
+            si = max(res, key=lambda r: r[5])[0]
+            g = sset.species[si]
+            from tests.helpers import select_reads
+            G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+            T = orc.TrioTable(G)
+            sel = np.sort(order[first[si]:first[si] + cnt[si]])
+            so, nid, ps, pe = select_reads(rd, sel)
+            b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+            rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
+            lp = _species_lp(orc, g, G, b, c, orc.metrics_to_dicts(met))
+            if lp is not None:
+                highs = highs_legs(pool, lp, highs_sizes, highs_tlimit)
+                if isinstance(highs, list):
+                    highs = {"species": g.name, "full_lp_rows": int((lp[1] > 0).sum()), "legs": highs}
+    t_trio = sum(r[1] for r in res)
+    t_cov = sum(r[2] for r in res)
+    t_lp = sum(r[3] for r in res)
+    return dict(value=n / dt / 1e6, unit="Mreads/s", cores=cores, kind="port",
+                solver="oracle's exact active-set LAD (oracle/pantax_oracle.c, same optimum as HiGHS: tests/golden/lp_cases.npz); "
+                       "HiGHS itself timed in `highs` on row samples of one species' LP",
+                sample="the whole workload: %d reads, %d species, one species per worker on %d cores (fork pool); "
+                       "binning in %d read slices" % (n, S, cores, cores),
                 seconds=dt,
-                phases_s={"binning+species_profile": t_bin, "trio_index": t_trio, "node_coverage (incl. read selection)": t_cov,
-                          "filters+LP solves": t_lp})
+                phases_wall_s={"binning+species_profile": t_bin, "group_reads_by_species": t_group,
+                               "per-species (trio index, coverage, filters, 2 LP solves)": dt - t_bin - t_group},
+                phases_cpu_s_summed_over_workers={"trio_index": t_trio, "node_coverage (incl. read selection)": t_cov,
+                                                  "filters+LP solves": t_lp},
+                highs=highs)
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE,
-    separate passes, KB units -> bytes; profiles/r01_pmc_coverage.json).  Only valid for the default
-    workload the passes were collected on; None otherwise.  See the file for the gfx950 FETCH_SIZE caveat."""
+def pmc_traffic(kernel, wl):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, separate
+    passes, KB -> bytes; profiles/r02_pmc_<workload>.json, collected by tools/pmc_step.sh on the same workload).  None
+    when no file matches this workload."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_coverage.json")))
-        w = d["workload"]
-        if (w["reads"], w["species"], w["haps"], w["genome_len"]) != (args.reads, args.species, args.haps, args.genome_len):
-            return None
-        return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            if not (fn.startswith("r02_pmc_") and fn.endswith(".json")):
+                continue
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            w = d["workload"]
+            if (w["reads"], w["species"], w["haps"], w["genome_len"], w.get("seed")) != (wl["reads"], wl["species"], wl["haps"], wl["genome_len"], wl["seed"]):
+                continue
+            k = d["kernels"].get(kernel)
+            if k:
+                return k["hbm_bytes_per_launch"]
+    except Exception:   # noqa: BLE001
+        pass
+    return None
 
 
-def highs_probe(sset, cfg, max_rows=20000):
-    """Optional: time SciPy's bundled HiGHS on the species-0 LP restricted to max_rows covered nodes
-    (HiGHS is the reference's open solver, profile.rs:2689-2882; the full LP does not finish in
-    minutes)."""
-    try:
-        from scipy import sparse
-        from scipy.optimize import linprog
-    except Exception:
-        return None
-    return None  # filled in by tools/highs_probe.py when run by hand; kept out of the default path (minutes)
+def pao_hard_cpu(synth, seed, n_species):
+    """A benchmark LP that is not trivial (profile.rs:1428-1451 at the shape BASELINE.md section 2 flags): every strain of
+    a species is present (10 columns after the first filter, >= 30 membership patterns, ~3e5 rows per species).  CPU side:
+    the set, species 0 through the oracle (its objective is compared with the device's), and that species' LP for the
+    HiGHS legs."""
+    from oracle import oracle as orc
+    from tests.helpers import select_reads
+    sset = synth.make_set(seed, n_species, 10, 1_000_000 * n_species, 5_000_000, present_frac=1.0)
+    g = sset.species[0]
+    rd = sset.reads
+    sp = orc.bin_reads(rd.step_off, rd.node_id, [x.range_start for x in sset.species], [x.range_end for x in sset.species])
+    G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+    T = orc.TrioTable(G)
+    so, nid, ps, pe = select_reads(rd, np.nonzero(sp == 0)[0])
+    b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+    t0 = time.perf_counter()
+    rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb)
+    t_orc = time.perf_counter() - t0
+    lp = _species_lp(orc, g, G, b, c, orc.metrics_to_dicts(met))
+    info = dict(workload="%d species x 10 strains, ALL strains present (present_frac 1.0), %d reads, seed %d" % (n_species, rd.n_reads, seed),
+                oracle_optimize_species_s_species0=t_orc, oracle_obj1_species0=o1, n_candidates_oracle_species0=nc)
+    return sset, info, lp
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=1_000_000)
-    ap.add_argument("--species", type=int, default=1)
-    ap.add_argument("--haps", type=int, default=10)
-    ap.add_argument("--genome-len", type=int, default=5_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["custom"])
+    ap.add_argument("--reads", type=int, default=None)
+    ap.add_argument("--species", type=int, default=None)
+    ap.add_argument("--haps", type=int, default=None)
+    ap.add_argument("--genome-len", type=int, default=None)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-cores", type=int, default=0, help="workers of the CPU baseline (0 = all host cores)")
+    ap.add_argument("--highs-rows", default="2000,5000,10000", help="row samples of the HiGHS legs ('' = none)")
+    ap.add_argument("--highs-time-limit", type=float, default=25.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gaf", action="store_true", help="skip the extra measurements (from GAF text, two passes in flight)")
+    ap.add_argument("--no-gaf", action="store_true", help="skip the from-GAF-text measurement")
+    ap.add_argument("--no-hard", action="store_true", help="skip the pao_hard leg")
+    ap.add_argument("--hard-species", type=int, default=8)
     args = ap.parse_args()
+
+    base = WORKLOADS.get(args.workload, WORKLOADS["cfg3"])
+    label, seed_off = base[0], base[1]
+    n_species = args.species if args.species is not None else base[2]
+    n_haps = args.haps if args.haps is not None else base[3]
+    n_reads = args.reads if args.reads is not None else base[4]
+    genome_len = args.genome_len if args.genome_len is not None else base[5]
+    if (n_species, n_haps, n_reads, genome_len) != tuple(base[2:6]):
+        label = "custom"
+    highs_sizes = [int(x) for x in args.highs_rows.split(",") if x.strip()]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
     from pantax_amd import synth
-    from pantax_amd.engine import Engine
-    from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, profile_step, profile_steps_pipelined
+    from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, partition_species, profile_step, profile_steps_pipelined
+    cfg = StepConfig()
 
+    # deterministic synthetic input (SURVEY 8d; seed = 20260501 + cfg index): weak scaling = one such set per rank
+    # (+ 1000 x rank), strong scaling = ONE set, species packed onto the ranks by weight, reads follow their species
+    t_gen = time.perf_counter()
+    if args.scaling == "weak" or world == 1:
+        seed = 20260501 + seed_off + 1000 * rank
+        sset = synth.make_set(seed, n_species, n_haps, n_reads, genome_len)
+        for i, g in enumerate(sset.species):
+            g.name = "%d" % (100000 * rank + 1000 + i)
+        total_reads = n_reads * world
+    else:
+        seed = 20260501 + seed_off
+        full = synth.make_set(seed, n_species, n_haps, n_reads, genome_len)
+        sset = synth.shard_set(full, rank, world, partition_species)
+        total_reads = n_reads
+        del full
+    gen_s = time.perf_counter() - t_gen
+    species_names = [g.name for g in sset.species]
+    hap_names = [hn for g in sset.species for hn in g.hap_names]
+    avg_len = sset.avg_len()
+    S_loc = len(sset.species)
+    wl = dict(reads=n_reads, species=n_species, haps=n_haps, genome_len=genome_len, seed=seed)
+
+    # ---- CPU baseline first: forked workers, before anything initialises the GPU in this process (rank 0, N = 1 only)
+    cpu = None
+    cores = args.cpu_cores or (os.cpu_count() or 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sset, cfg, cores, highs_sizes, args.highs_time_limit)
+    hard = None
+    if rank == 0 and world == 1 and not args.no_hard:
+        import multiprocessing as mp
+        hard_set, hard, hard_lp = pao_hard_cpu(synth, 20260601, args.hard_species)
+        hard_names = [g.name for g in hard_set.species]
+        hard_haps = [h for g in hard_set.species for h in g.hap_names]
+        if hard_lp is not None and highs_sizes:
+            with mp.get_context("fork").Pool(min(cores, len(highs_sizes))) as pool:
+                hard["highs"] = highs_legs(pool, hard_lp, highs_sizes, args.highs_time_limit)
+            hard["lp_rows_species0"] = int((hard_lp[1] > 0).sum())
+            hard["lp_columns_species0"] = hard_lp[2]
+
+    import torch
+    from pantax_amd.engine import Engine
     # PANTAX_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the
     # exchange goes over gloo); the driver's runs use the default, RCCL with one GPU per rank
     backend = os.environ.get("PANTAX_BENCH_BACKEND", "nccl")
@@ -157,16 +358,12 @@ def main():
         else:
             dist.init_process_group(backend)
             comm = TorchComm(device=None)
-
-    # deterministic synthetic shard of this rank (seed = 20260501 + cfg index 2, + rank)
-    seed = 20260501 + 2 + 1000 * rank
-    sset = synth.make_set(seed, args.species, args.haps, args.reads, args.genome_len)
-    for i, g in enumerate(sset.species):
-        g.name = "%d" % (100000 * rank + 1000 + i)
-    species_names = [g.name for g in sset.species]
-    hap_names = [hn for g in sset.species for hn in g.hap_names]
-    avg_len = sset.avg_len()
-    cfg = StepConfig()
+    S_max, H_max = S_loc, len(hap_names)
+    if world > 1 and args.scaling == "strong":
+        import torch.distributed as dist
+        t = torch.tensor([S_loc, len(hap_names)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        S_max, H_max = int(t[0].item()), int(t[1].item())
 
     eng = Engine(local_rank)
     t_up = time.perf_counter()
@@ -192,7 +389,7 @@ def main():
         if i == 1:
             eng.timing_reset()      # the very first step also allocates: its launches are not representative
             n_warm_timed = 0
-        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=args.species, rows_max=args.species * args.haps)
+        out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=S_max, rows_max=H_max)
         n_warm_timed += 1
     warm = eng.timing_get() if args.warmup else {}
     dom = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else "coverage_step_kernel"
@@ -202,8 +399,7 @@ def main():
     # K steps back to back; with N > 1 the all-reduce of step i is in flight while step i+1 computes (every step's tables
     # are complete before the closing barrier)
     t0 = time.perf_counter()
-    out = profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg, comm, shard_max=args.species,
-                                  rows_max=args.species * args.haps)[-1]
+    out = profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg, comm, shard_max=S_max, rows_max=H_max)[-1]
     barrier()
     dt = time.perf_counter() - t0
     timings = eng.timing_get()
@@ -212,59 +408,61 @@ def main():
     # extra (not `value`): the same step when the unique-trio index, which depends on the DB only, stays
     # resident between steps instead of being rebuilt like the reference does on every run
     cfg_cached = StepConfig(rebuild_trio=False)
-    profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=args.species, rows_max=args.species * args.haps)
+    profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=S_max, rows_max=H_max)
     barrier()
     t1 = time.perf_counter()
-    profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg_cached, comm, shard_max=args.species,
-                            rows_max=args.species * args.haps)
+    profile_steps_pipelined(eng, species_names, hap_names, avg_len, args.steps, cfg_cached, comm, shard_max=S_max, rows_max=H_max)
     barrier()
     dt_cached = time.perf_counter() - t1
-    # extra (not `value`): two independent passes in flight -- a second ctx with its own copy of the DB and the reads steps on a
-    # second host thread (a stream of samples processed two at a time).  One pass is a chain of ~100 short dependent
-    # kernels that cannot fill 256 CUs; two chains interleave on the device.
-    two_in_flight = None
-    if world == 1 and not args.no_gaf:
-        import threading
-        eng2 = Engine(local_rank)
-        eng2.upload_db(sset.species)
-        eng2.upload_packed(sset.reads)
-        eng2.sync()
-        profile_step(eng2, species_names, hap_names, avg_len, cfg)
-        outs2 = [None, None]
-
-        def run(e, slot):
-            outs2[slot] = profile_steps_pipelined(e, species_names, hap_names, avg_len, args.steps, cfg, LocalComm())[-1]
-        eng.sync(); eng2.sync()
-        t3 = time.perf_counter()
-        ths = [threading.Thread(target=run, args=(eng, 0)), threading.Thread(target=run, args=(eng2, 1))]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        eng.sync(); eng2.sync()
-        dt2 = time.perf_counter() - t3
-        two_in_flight = {"steps": 2 * args.steps, "ms_per_step": dt2 / (2 * args.steps) * 1e3, "mreads_per_s": 2 * args.steps * args.reads / dt2 / 1e6,
-                         "tables_equal": bool(outs2[0][:2] == outs2[1][:2] == out[:2])}
-        eng2.close()
-    # extra (not `value`): the same workload from GAF TEXT on disk -- device tokenizer (a1) -> resident reads -> one step
+    # first-class extra: the same workload from GAF TEXT on disk -- pread + PCIe + device tokenizer (a1) -> resident reads -> one
+    # step -> tables.  Never `value` (the contract's value has its inputs resident in HBM).
     gaf_extra = None
-    if rank == 0 and not args.no_gaf:
+    if rank == 0 and world == 1 and not args.no_gaf:
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             gp = os.path.join(td, "reads.gaf")
+            t_w = time.perf_counter()
             synth.write_gaf(sset.reads, gp)
-            eng.load_reads_from_gaf(gp)                      # warm (allocations)
+            write_s = time.perf_counter() - t_w
+            eng.load_reads_from_gaf(gp)                      # warm (allocations, page cache)
             eng.sync()
             t2 = time.perf_counter()
             eng.load_reads_from_gaf(gp)
             eng.sync()
             t_load = time.perf_counter() - t2
-            out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, comm if world == 1 else LocalComm(), shard_max=args.species, rows_max=args.species * args.haps)
+            out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, LocalComm(), shard_max=S_max, rows_max=H_max)
             eng.sync()
             t_e2e = time.perf_counter() - t2
             same = out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]
             gaf_extra = {"gaf_bytes": os.path.getsize(gp), "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
-                         "end_to_end_mreads_per_s": args.reads / t_e2e / 1e6, "tables_equal_to_packed_input_run": bool(same)}
+                         "end_to_end_mreads_per_s": n_reads / t_e2e / 1e6, "gaf_gb_per_s": os.path.getsize(gp) / t_load / 1e9,
+                         "tables_equal_to_packed_input_run": bool(same), "gaf_written_in_s": write_s}
+    # extra: the non-trivial LP (pao_hard), timed with every launch bracketed
+    if hard is not None:
+        eng_h = Engine(local_rank)
+        eng_h.upload_db(hard_set.species)
+        eng_h.upload_packed(hard_set.reads)
+        h_avg = hard_set.avg_len()
+        profile_step(eng_h, hard_names, hard_haps, h_avg, cfg)
+        eng_h.timing_enable(True)
+        eng_h.timing_reset()
+        n_h = 3
+        t3 = time.perf_counter()
+        for _ in range(n_h):
+            out_h = profile_step(eng_h, hard_names, hard_haps, h_avg, cfg)
+        eng_h.sync()
+        t_h = (time.perf_counter() - t3) / n_h
+        kt_h = eng_h.timing_get()
+        eng_h.timing_enable(False)
+        st_h = out_h[2]
+        lad_ms = sum(v[1] for k, v in kt_h.items() if k.startswith("lad_")) / n_h
+        hard.update(reads=hard_set.reads.n_reads, ms_per_step_all_launches_bracketed=t_h * 1e3,
+                    lad_kernels_ms_per_step=lad_ms, lad_kernels_ms_per_species=lad_ms / max(len(hard_names), 1),
+                    n_candidates=st_h["n_cand"][:8],
+                    n_rows=st_h["n_rows"][:8], n_patterns=st_h["n_patterns"][:8], iters=st_h["iters"][:8],
+                    objective=st_h["obj"][:4], gpu_obj1_species0=st_h["obj"][0][0],
+                    kernels_ms_per_step={k: v[1] / n_h for k, v in sorted(kt_h.items(), key=lambda kv: -kv[1][1])[:8]})
+        eng_h.close()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -274,55 +472,63 @@ def main():
     if rank == 0:
         species_rows, strain_rows, stats = out
         ms_per_step = dt / args.steps * 1e3
-        total_reads = args.reads * world
         value = total_reads / (dt / args.steps) / 1e6
-        ab, dims = algorithmic_bytes(sset, eng.U or 0)
         n_lp_rows = int(sum(stats["n_rows"]))
-        ab["sort_hist_kernel"] = 8 * n_lp_rows             # one key word in
-        ab["sort_scatter_kernel"] = 2 * 24 * n_lp_rows     # three key words in, three out
+        ab, dims = algorithmic_bytes(sset, n_lp_rows)
         # dominant kernel by HIP-event time on the library's stream
-        kt = {k: v for k, v in timings.items()}
         roofline = None
-        if dom and dom in kt:
-            launches, tot_ms = kt[dom]
+        if dom and dom in timings:
+            launches, tot_ms = timings[dom]
             avg_ms = tot_ms / max(launches, 1)
-            bytes_per_launch = ab.get(dom)
-            if bytes_per_launch is not None:
-                per = bytes_per_launch
+            per = ab.get(dom)
+            if per is not None:
                 ach = per / (avg_ms * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                traffic=pmc_traffic(dom, args), avg_ms=avg_ms, algorithmic_bytes=per)
+                                traffic=pmc_traffic(dom, wl), avg_ms=avg_ms, launches_timed=launches, algorithmic_bytes=per)
             else:
                 roofline = dict(bound="hbm", kernel=dom, achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, traffic=None,
                                 avg_ms=avg_ms, algorithmic_bytes=0,
                                 note="no streaming-traffic model for this launch (latency-bound: the small-LP solver does "
                                      "O(#patterns*log n) searches per pivot)")
+        # the other large kernels against the same ruler (warm-up table; one launch per step each unless noted)
+        others = {}
+        for k, (launches, tot_ms) in warm.items():
+            if k in ab and launches:
+                a_ms = tot_ms / launches
+                others[k] = dict(avg_ms=a_ms, algorithmic_bytes=ab[k], frac=ab[k] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         line = {
             "metric": "PAO wall-time (s) + Mreads/s GAF->abundance (packed reads resident in HBM)",
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3, "upload_ms_once": upload_ms,
-            "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3,
+            "from_gaf_text_mreads_per_s": gaf_extra["end_to_end_mreads_per_s"] if gaf_extra else None,
+            "upload_ms_once": upload_ms, "synthetic_set_generated_in_s": gen_s,
+            "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
-            "config": {"workload": "cfg2: single-species E. coli-like, %d strains, %d short reads (150 bp) per GPU, "
-                                   "genome %d bp, V=%d nodes, T=%d steps" % (args.haps, args.reads, args.genome_len, dims["V"], dims["T"]),
-                       "species_per_gpu": args.species, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
+            "config": {"workload": "%s: %s -- %d species x %d strains, %d short reads (150 bp), genome %d bp %s; this rank: V=%d nodes, "
+                                   "P=%d path steps, T=%d walk steps, seed %d"
+                                   % (args.workload if label != "custom" else "custom", label, n_species, n_haps, n_reads, genome_len,
+                                      "per GPU" if args.scaling == "weak" else "in all (cut over the ranks)", dims["V"], dims["P"], dims["T"], seed),
+                       "species_per_gpu": S_loc, "strains_total": n_species * n_haps * (world if args.scaling == "weak" else 1),
+                       "reads_total": total_reads, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
                        "exchange": "none" if world == 1 else ("one rccl all_reduce per step, in flight during the next step" if backend == "nccl" else backend + " all_reduce (dry run)")},
             "from_gaf_text": gaf_extra,
-            "two_passes_in_flight": two_in_flight,
             "roofline": roofline,
+            "roofline_other_kernels": others,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
+            "launches_per_step": int(sum(v[0] for v in warm.values()) / max(n_warm_timed, 1)),
             "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel only",
             "solver": {"iters": stats["iters"][:4], "n_rows": stats["n_rows"][:4], "n_patterns": stats["n_patterns"][:4],
-                       "objective": stats["obj"][:4]},
+                       "objective": stats["obj"][:4], "lp_rows_total": n_lp_rows},
+            "pao_hard": hard,
             "result": {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
                        "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]},
         }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sset, args.cpu_sample, cfg)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()          # rank 0 is still timing the CPU baseline: nobody tears the communicator down before it is done
+        dist.barrier()
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -146,7 +146,7 @@ def local_stage(eng, avg_len, cfg, single_call=True):
             opt = lambda bit, v: v if m.has & bit else None
             rows.append((s, h, m.second_sol, opt(4, m.path_cov_ratio), opt(1, m.unique_trio_nodes_fraction),
                          opt(2, m.frequencies_mean), opt(8, m.first_sol), opt(16, m.divergence), opt(128, m.total_cov_diff)))
-    stats = dict(iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)],
+    stats = dict(iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)], n_cand=[info[s].n_candidates for s in range(eng.S)],
                  n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
                  obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)])
     return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)

@@ -266,6 +266,80 @@ def make_set(seed, n_species, H, n_reads, genome_len, long_reads=False, with_ids
     return SyntheticSet(species, reads)
 
 
+def _species_job(job):
+    seed_seq, name, h, genome_len, prefix, present_frac = job
+    return make_species(np.random.default_rng(seed_seq), name, h, genome_len, 1, prefix, present_frac=present_frac)
+
+
+def make_set_mp(seed, n_species, H, n_reads, genome_len, long_reads=False, adversarial_frac=0.001, present_frac=0.2, workers=None):
+    """make_set for the big configurations: species generated by a fork pool from per-species seed sequences (so the
+    result does not depend on the worker count), reads from one more child sequence.  Different sets than make_set for
+    the same seed -- the bench keeps make_set."""
+    import multiprocessing as mp
+    import os
+    workers = workers or min(os.cpu_count() or 1, 16)
+    ss = np.random.SeedSequence(seed).spawn(n_species + 1)
+    jobs = [(ss[s], str(1000 + s), H, genome_len, "GCF_%06d" % (s + 1), present_frac) for s in range(n_species)]
+    if workers > 1 and n_species > 1:
+        with mp.get_context("fork").Pool(min(workers, n_species)) as pool:
+            species = pool.map(_species_job, jobs, chunksize=1)
+    else:
+        species = [_species_job(j) for j in jobs]
+    start = 1
+    for g in species:
+        n = g.n_nodes
+        g.range_start, g.range_end = start, start + n - 1
+        start += n
+    reads = make_reads(np.random.default_rng(ss[n_species]), species, n_reads, long_reads=long_reads, adversarial_frac=adversarial_frac)
+    return SyntheticSet(species, reads)
+
+
+def cached_set(seed, n_species, H, n_reads, genome_len, cache_dir=None, **kw):
+    """make_set through a pickle cache (profiling drivers re-run the same workload once per counter pass); cache_dir
+    None = $PANTAX_SYNTH_CACHE, unset = no cache."""
+    import os
+    import pickle
+    cache_dir = cache_dir or os.environ.get("PANTAX_SYNTH_CACHE")
+    if not cache_dir:
+        return make_set(seed, n_species, H, n_reads, genome_len, **kw)
+    os.makedirs(cache_dir, exist_ok=True)
+    tag = "_".join("%s%s" % (k, v) for k, v in sorted(kw.items()))
+    fn = os.path.join(cache_dir, "set_%d_%d_%d_%d_%d_%s.pkl" % (seed, n_species, H, n_reads, genome_len, tag))
+    if os.path.exists(fn):
+        with open(fn, "rb") as f:
+            return pickle.load(f)
+    sset = make_set(seed, n_species, H, n_reads, genome_len, **kw)
+    tmp = fn + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        pickle.dump(sset, f, protocol=4)
+    os.replace(tmp, fn)
+    return sset
+
+
+def shard_set(full, rank, world, partition):
+    """The share of `full` that rank `rank` of `world` owns: species packed by weight (8 x reads + graph nodes, the rule of the
+    C file seam; `partition` = pipeline.partition_species), reads follow the species of their FIRST node (a walk that
+    leaves its species is "U" on any rank).  Graph node ids stay global, so every rank bins against its own ranges."""
+    starts = np.array([g.range_start for g in full.species], dtype=np.int64)
+    rd = full.reads
+    so = rd.step_off.astype(np.int64)
+    k = so[1:] - so[:-1]
+    first = np.where(k > 0, rd.node_id[np.minimum(so[:-1], max(len(rd.node_id) - 1, 0))].astype(np.int64), 0)
+    sp_of = np.searchsorted(starts, first, side="right") - 1
+    sp_of = np.where(k > 0, sp_of, 0)
+    cnt = np.bincount(sp_of, minlength=len(full.species))
+    owner = np.array(partition([8.0 * cnt[i] + g.n_nodes for i, g in enumerate(full.species)], world))
+    mine = np.nonzero(owner == rank)[0]
+    sel = np.nonzero(owner[sp_of] == rank)[0]
+    ns = k[sel]
+    new_off = np.zeros(len(sel) + 1, dtype=np.uint64)
+    new_off[1:] = np.cumsum(ns)
+    idx = np.repeat(so[:-1][sel], ns) + (np.arange(int(ns.sum())) - np.repeat(new_off[:-1].astype(np.int64), ns))
+    reads = PackedReads(new_off, rd.node_id[idx], rd.strand[idx], rd.pstart[sel], rd.pend[sel], rd.qlen[sel], rd.mapq[sel], rd.plen[sel],
+                        [rd.read_id[i] for i in sel] if rd.read_id else [])
+    return SyntheticSet([full.species[i] for i in mine], reads)
+
+
 def make_config(name, cfg_index=0, **kw):
     S, H, R, L, lr = CONFIGS[name]
     return make_set(20260501 + cfg_index, S, H, R, L, long_reads=lr, **kw)
@@ -316,8 +390,32 @@ def write_db(sset, db_dir, write_gfa=True, write_bin=True):
                     f.write(g.path_nodes[b:e].astype("<u8").tobytes())
 
 
-def write_gaf(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1"):
+def _native_gaf_writer():
+    """tools/native/libsynthgaf.so (C, built by __graft_entry__.build()): the same bytes as the loop below, ~1 GB/s."""
+    import ctypes as C
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "native", "libsynthgaf.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.synth_write_gaf.restype = C.c_int64
+    return lib
+
+
+def write_gaf(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1", native=True):
     """12 mandatory GAF columns + 4 fixed tags (constant column count)."""
+    lib = _native_gaf_writer() if (native and not reads.read_id) else None
+    if lib is not None:
+        import ctypes as C
+        a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+        so, nid, st = a(reads.step_off, np.uint64), a(reads.node_id, np.uint32), a(reads.strand, np.uint8)
+        cols = [a(x, np.int64) for x in (reads.pstart, reads.pend, reads.qlen, reads.mapq, reads.plen)]
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        n = lib.synth_write_gaf(str(path).encode(), 0, C.c_uint64(0), C.c_uint64(reads.n_reads), C.c_uint64(0), p(so), p(nid), p(st),
+                                *[p(c) for c in cols], tags.encode())
+        if n < 0:
+            raise IOError("synth_write_gaf(%s) failed: %d" % (path, n))
+        return
     with open(path, "w") as f:
         R = reads.n_reads
         for r in range(R):

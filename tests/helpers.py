@@ -93,3 +93,108 @@ def make_longread_gaf(seed, n_reads, path_ids=40):
     order = rng.permutation(len(lines))                               # alignments of a read are not adjacent in general
     txt = "\n".join(lines[i] for i in order)
     return (txt + ("\n" if seed % 2 else "")).encode()
+
+
+def expected_total_bases(sset, sp):
+    """Sum of bases_per_node over all nodes from the read records alone (numpy, no kernel logic), sized for 10^7..10^8
+    steps: one-node read -> target (dropped if < 0); otherwise seen = (len0 - ps) + interior lengths and the read
+    contributes seen + max(target - seen, 0), minus the aligned length of repeated node occurrences (profile.rs:879-882).
+    Repeats can only occur in walks that are not strictly monotone in node id; those few are handled read by read."""
+    rd = sset.reads
+    so = rd.step_off.astype(np.int64)
+    k = so[1:] - so[:-1]
+    gl = np.concatenate([g.node_len for g in sset.species])
+    base = np.cumsum([0] + [g.n_nodes for g in sset.species])[:-1]
+    first = np.array([g.range_start for g in sset.species])
+    nn = np.array([g.n_nodes for g in sset.species])
+    live = (sp >= 0) & (k > 0)
+    spc = np.where(sp >= 0, sp, 0).astype(np.int64)
+    sp_step = np.repeat(spc, k)
+    live_step = np.repeat(live, k)
+    loc = rd.node_id.astype(np.int64) - first[sp_step]
+    v = np.where(live_step & (loc >= 0) & (loc < nn[sp_step]), base[sp_step] + loc, 0)
+    del sp_step, loc
+    ln = gl[v]
+    c = np.concatenate([[0], np.cumsum(ln)])
+    tot_len = c[so[1:]] - c[so[:-1]]
+    idx0 = np.minimum(so[:-1], len(ln) - 1)
+    idxl = np.maximum(so[1:] - 1, 0)
+    len0 = np.where(k > 0, ln[idx0], 0)
+    lenl = np.where(k > 0, ln[idxl], 0)
+    target = rd.pend - rd.pstart
+    seen = tot_len - lenl - rd.pstart
+    multi = np.where(target > seen, target, seen)
+    single = np.where(target >= 0, target, 0)
+    abort = (k >= 2) & (rd.pstart > len0)
+    per_read = np.where(k == 1, single, multi)
+    per_read = np.where(live & ~abort, per_read, 0)
+    # walks that are not strictly monotone: candidates for repeated nodes
+    d = np.diff(v)
+    inner = np.ones(len(v), dtype=bool)
+    inner[so[:-1][k > 0]] = False                 # d[t-1] = v[t]-v[t-1] is a within-read difference iff t is not a read start
+    dd = np.zeros(len(v), dtype=np.int64)
+    dd[1:] = d
+    up = np.concatenate([[0], np.cumsum(inner & (dd > 0))])
+    dn = np.concatenate([[0], np.cumsum(inner & (dd < 0))])
+    n_up = up[so[1:]] - up[so[:-1]]
+    n_dn = dn[so[1:]] - dn[so[:-1]]
+    mono = (n_up == np.maximum(k - 1, 0)) | (n_dn == np.maximum(k - 1, 0))
+    rep_fix = 0
+    for r in np.nonzero(~mono & live & ~abort & (k >= 2))[0]:
+        ids = v[so[r]:so[r + 1]]
+        lens = ln[so[r]:so[r + 1]].copy()
+        lens[0] -= rd.pstart[r]
+        s_ = int(lens[:-1].sum())
+        lens[-1] = max(int(target[r]), s_) - s_
+        seen_nodes = set()
+        for j, n in enumerate(ids):
+            if n in seen_nodes:
+                rep_fix += int(lens[j])
+            seen_nodes.add(n)
+    return int(per_read.sum()) - rep_fix
+
+
+def oracle_species_checks(sset, sp, keep, absolute, bases, cov, tb, hto, gmet, info, species_idx, threads=8, strain_kw=None, lp=True):
+    """Species by species against the oracle (TEST checker), on `threads` host threads (the C calls release the GIL):
+    bit-exact bases / cov / trio bases, and -- when `lp` -- candidate count, LP objective (1e-9) and every reported metric.
+    -> list of (species, what) mismatches."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    rd = sset.reads
+    S = len(sset.species)
+    nb = np.cumsum([0] + [g.n_nodes for g in sset.species])
+    hb = np.cumsum([0] + [g.n_paths for g in sset.species])
+    order = np.argsort(sp, kind="stable")
+    cnt = np.bincount(sp[sp >= 0], minlength=S)
+    first = np.searchsorted(sp[order], np.arange(S))
+    strain_kw = strain_kw or {}
+
+    def one(s):
+        bad = []
+        g = sset.species[s]
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        sel = np.sort(order[first[s]:first[s] + cnt[s]])
+        so, nid, ps, pe = select_reads(rd, sel)
+        b, c, t, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        u0, u1 = int(hto[hb[s]]), int(hto[hb[s + 1]])
+        if not np.array_equal(bases[nb[s]:nb[s + 1]], b): bad.append((s, "bases"))
+        if not np.array_equal(cov[nb[s]:nb[s + 1]], c): bad.append((s, "cov"))
+        if u1 - u0 != T.n_unique or not np.array_equal(tb[u0:u1], t): bad.append((s, "trio_bases"))
+        if lp and keep[s]:
+            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, **strain_kw)
+            orc.abundance_constraint(absolute[s], omet)
+            if info[s].n_candidates != nc or info[s].status1 != 0: bad.append((s, "candidates %d vs %d status %d" % (info[s].n_candidates, nc, info[s].status1)))
+            elif nc and abs(info[s].obj1 - o1) > 1e-9 * max(1.0, abs(o1)): bad.append((s, "objective %r vs %r" % (info[s].obj1, o1)))
+            else:
+                for h, (gm, em) in enumerate(zip(gmet[hb[s]:hb[s + 1]], orc.metrics_to_dicts(omet))):
+                    for key, ev in em.items():
+                        gv = gm[key]
+                        if ev is None or isinstance(ev, bool):
+                            if gv != ev: bad.append((s, "%s[%d] %r vs %r" % (key, h, gv, ev)))
+                        elif gv is None or abs(gv - ev) > 1e-7 * abs(ev) + 1e-9: bad.append((s, "%s[%d] %r vs %r" % (key, h, gv, ev)))
+        return bad
+
+    with ThreadPoolExecutor(threads) as ex:
+        out = list(ex.map(one, species_idx))
+    return [b for lst in out for b in lst]

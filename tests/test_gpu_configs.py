@@ -1,0 +1,172 @@
+"""Every BASELINE.json GPU configuration at FULL size through the HIP path (cfg2 lives in test_gpu_fullsize.py):
+  cfg3        100 species x 10 strains, 10 M short reads                -- every species against the oracle
+  cfg4 share  125 species x 10 strains, 12.5 M short reads (1/8 of cfg4) -- size-independent properties + oracle on a sample
+  cfg5 share  125 species x 50 strains, 125 k HiFi-shaped reads (1/8 of cfg5: 6 250 of 50 k strains, total bases = cfg4's)
+                                                                        -- properties + oracle on a sample
+Properties: conservation of aligned bases (from the read records alone), counters partition the reads, order invariance
+under a permutation of the reads, idempotence, cov <= node length, LP local optimality, table normalisation.
+The sets come from synth.make_set_mp (species generated on all host cores)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import expected_total_bases, oracle_species_checks, select_reads
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 1, 32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pantax_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _bin_oracle(sset, threads):
+    """rcls.rs:237-258 on the host for all reads, in `threads` slices"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    rd = sset.reads
+    rs, re = [g.range_start for g in sset.species], [g.range_end for g in sset.species]
+    cuts = np.linspace(0, rd.n_reads, threads + 1).astype(np.int64)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: orc.bin_reads(rd.step_off[cuts[i]:cuts[i + 1] + 1], rd.node_id, rs, re), range(threads)))
+    return np.concatenate(parts)
+
+
+def _run_stages(eng, sset, fr=0.3):
+    from pantax_amd.engine import metrics_to_dicts
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
+    eng.db_reset()
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    met, info = eng.strain_profiling(absolute, species_active=keep, fr=fr)
+    return dict(sp=sp, counts=(rc, bs, lm, uq), keep=keep, absolute=absolute, hto=hto.astype(np.int64), bases=bases, cov=cov, tb=tb, nab=nab,
+                gmet=metrics_to_dicts(met, eng.H), info=info, trio=(abc, hap, ln))
+
+
+def _common_properties(sset, out):
+    rd = sset.reads
+    sp = out["sp"]
+    rc, bs, lm, uq = out["counts"]
+    assert rc.sum() + (sp < 0).sum() == rd.n_reads
+    assert bs.sum() == rd.qlen[sp >= 0].sum()
+    assert np.array_equal(rc, np.bincount(sp[sp >= 0], minlength=len(sset.species)))
+    assert np.array_equal(uq, np.bincount(sp[(sp >= 0) & (rd.mapq == 60)], minlength=len(sset.species)))
+    gl = np.concatenate([g.node_len for g in sset.species])
+    assert np.all(out["cov"] <= gl.astype(np.uint64))
+    assert int(out["bases"].sum()) == expected_total_bases(sset, sp)
+
+
+def _lp_local_optimality(eng, sset, out, s, n_probe=40):
+    """x of the solver seam minimises the LAD objective over the box: no probe direction lowers it (convexity)."""
+    from oracle import oracle as orc
+    g = sset.species[s]
+    nb = int(np.cumsum([0] + [x.n_nodes for x in sset.species])[s])
+    bases = out["bases"][nb:nb + g.n_nodes]
+    cov = out["cov"][nb:nb + g.n_nodes]
+    ab = bases / g.node_len
+    cand = np.arange(g.n_paths)
+    x, ratio, obj, st = eng.pao_solve(g.node_len, ab, cov, g.path_off, g.path_nodes, cand)
+    assert st == 0
+    mask = np.zeros(g.n_nodes, dtype=np.uint64)
+    for kk in range(g.n_paths):
+        mask[g.path_nodes[int(g.path_off[kk]):int(g.path_off[kk + 1])]] |= np.uint64(1 << kk)
+    f0 = orc.lad_objective(mask, ab, x)
+    assert f0 == pytest.approx(obj, rel=1e-9)
+    ub = 1.05 * ab.max()
+    rng = np.random.default_rng(s)
+    for trial in range(n_probe):
+        d = np.zeros(len(x))
+        if trial < 2 * min(len(x), 10):
+            d[trial // 2] = 1.0 if trial % 2 == 0 else -1.0
+        else:
+            d = rng.normal(size=len(x))
+        for step in (1e-6, 1e-3, 0.1):
+            y = np.clip(x + step * d, 0.0, ub)
+            assert orc.lad_objective(mask, ab, y) >= f0 - 1e-9 * max(1.0, f0)
+
+
+def _tables_normalised(eng, sset):
+    from pantax_amd.pipeline import StepConfig, profile_step
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    sp_rows, st_rows, stats = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    assert sum(r[1] for r in sp_rows) == pytest.approx(1.0, rel=1e-12)
+    assert sum(r[3] for r in st_rows) == pytest.approx(1.0, rel=1e-12)
+    return sp_rows, st_rows, stats
+
+
+def test_cfg3_full_size_every_species_against_oracle(eng):
+    from pantax_amd import synth
+    sset = synth.make_set_mp(20260504, 100, 10, 10_000_000, 5_000_000)
+    out = _run_stages(eng, sset)
+    assert np.array_equal(out["sp"], _bin_oracle(sset, THREADS))
+    _common_properties(sset, out)
+    bad = oracle_species_checks(sset, out["sp"], out["keep"], out["absolute"], out["bases"], out["cov"], out["tb"], out["hto"], out["gmet"],
+                                out["info"], range(len(sset.species)), threads=THREADS)
+    assert not bad, bad[:10]
+    # the single-call resident step gives normalised tables that name exactly the present strains of the kept species
+    sp_rows, st_rows, stats = _tables_normalised(eng, sset)
+    assert len(sp_rows) == int(out["keep"].sum())
+
+
+def test_cfg4_share_full_size_properties_and_oracle_sample(eng):
+    from pantax_amd import synth
+    sset = synth.make_set_mp(20260505, 125, 10, 12_500_000, 5_000_000)
+    rd = sset.reads
+    out = _run_stages(eng, sset)
+    assert np.array_equal(out["sp"], _bin_oracle(sset, THREADS))
+    _common_properties(sset, out)
+    # idempotence
+    b2, c2, t2, n2 = eng.get_node_abundances()
+    assert np.array_equal(b2, out["bases"]) and np.array_equal(c2, out["cov"]) and np.array_equal(t2, out["tb"]) and n2 == out["nab"]
+    # oracle on a species sample (incl. the one with the most and the fewest reads)
+    cnt = out["counts"][0]
+    sample = sorted({int(np.argmax(cnt)), int(np.argmin(cnt)), 0, 31, 62, 93, 124})
+    bad = oracle_species_checks(sset, out["sp"], out["keep"], out["absolute"], out["bases"], out["cov"], out["tb"], out["hto"], out["gmet"],
+                                out["info"], sample, threads=THREADS)
+    assert not bad, bad[:10]
+    _lp_local_optimality(eng, sset, out, sample[1])
+    # order invariance: the same reads in another order give the same integers
+    perm = np.random.default_rng(4).permutation(rd.n_reads)
+    so, nid, ps, pe = select_reads(rd, perm)
+    eng.upload_reads(so, nid, ps, pe, rd.qlen[perm], rd.mapq[perm])
+    sp_p, rc, bs, lm, uq = eng.rcls_profile()
+    assert np.array_equal(sp_p, out["sp"][perm])
+    for a, b in zip(out["counts"], (rc, bs, lm, uq)):
+        assert np.array_equal(a, b)
+    b_p, c_p, t_p, n_p = eng.get_node_abundances()
+    assert np.array_equal(b_p, out["bases"]) and np.array_equal(c_p, out["cov"]) and np.array_equal(t_p, out["tb"]) and n_p == out["nab"]
+    eng.upload_packed(rd)
+    _tables_normalised(eng, sset)
+
+
+def test_cfg5_share_full_size_long_reads_properties_and_oracle_sample(eng):
+    from pantax_amd import synth
+    sset = synth.make_set_mp(20260506, 125, 50, 125_000, 5_000_000, long_reads=True)
+    rd = sset.reads
+    assert (np.diff(rd.step_off.astype(np.int64)) > 64).mean() > 0.9          # walks longer than a wave: the long-read path
+    out = _run_stages(eng, sset, fr=0.5)                                        # long reads: --fr 0.5 (main.rs:108-114)
+    assert np.array_equal(out["sp"], _bin_oracle(sset, THREADS))
+    _common_properties(sset, out)
+    cnt = out["counts"][0]
+    sample = sorted({int(np.argmax(cnt)), int(np.argmin(cnt)), 0, 41, 83, 124})
+    bad = oracle_species_checks(sset, out["sp"], out["keep"], out["absolute"], out["bases"], out["cov"], out["tb"], out["hto"], out["gmet"],
+                                out["info"], sample, threads=THREADS, strain_kw=dict(fr=0.5))
+    assert not bad, bad[:10]
+    _lp_local_optimality(eng, sset, out, sample[0], n_probe=24)                 # a 50-column LP through the solver seam
+    perm = np.random.default_rng(5).permutation(rd.n_reads)
+    so, nid, ps, pe = select_reads(rd, perm)
+    eng.upload_reads(so, nid, ps, pe, rd.qlen[perm], rd.mapq[perm])
+    sp_p, *_ = eng.rcls_profile()
+    assert np.array_equal(sp_p, out["sp"][perm])
+    b_p, c_p, t_p, n_p = eng.get_node_abundances()
+    assert np.array_equal(b_p, out["bases"]) and np.array_equal(c_p, out["cov"]) and np.array_equal(t_p, out["tb"]) and n_p == out["nab"]
