@@ -276,6 +276,8 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
     }
     lap("tiles");
+    PTX_TRY(trio_runs_build(ctx, db.get()));
+    lap("node-block runs");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_node.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(1));

@@ -227,6 +227,17 @@ struct Db {
     uint64_t n_tiles = 0;
     DevBuf<uint32_t> d_tile_rank;    // [n_tiles] rank of the tile in path order (hap-major)
     DevBuf<uint32_t> d_hap_tile_off; // [H+1] first path-order tile of every haplotype
+    // node-block run table of the walks (trio_runs_build, stage_trio.hip; a layout table like d_tiles, built once at upload):
+    // every species' nodes are cut into blocks of TRIO_BLK nodes, every walk into maximal runs of consecutive positions
+    // whose nodes lie in ONE block; runs are grouped by block.  The unique-trio build then gives each block to one
+    // workgroup, which sees every window whose smallest end node lies in the block -- whatever haplotype it is on.
+    bool trio_block_ok = false;      // every species has < 2^27 nodes (the 64-bit LDS key packs (a in block, b, c)) and P < 2^32
+    uint32_t n_blocks = 0;
+    uint64_t n_runs = 0;
+    DevBuf<uint32_t> d_blk_base;     // [S+1] first block of every species
+    DevBuf<uint32_t> d_blk_species;  // [n_blocks]
+    DevBuf<uint32_t> d_blk_run_off;  // [n_blocks+1]
+    DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
     // unique-trio index (a7)
     bool trio_built = false;
     uint64_t U = 0;
@@ -351,6 +362,7 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db);
+int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run table
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1);

@@ -173,6 +173,100 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
         if (t < n && s_cnt[my_slot[k]] == 1u) { uniq_q[my_q[k]] = 1; atomicAdd(&first_cnt[s_g[t]], 1u); }
     }
 }
+// 3''. THE DEFAULT: uniqueness by node block, no global scatter at all.  Every species' nodes are cut into blocks of
+//      TRIO_BLK consecutive local ids; the walks were cut at upload into runs of consecutive positions inside one block
+//      (trio_runs_build below).  A window is OWNED by the position that holds its canonical smallest end a
+//      (profile.rs:672-678: a = w[0] unless w[0] > w[2]): position p owns (p, p+1, p+2) when n[p] <= n[p+2] and
+//      (p-2, p-1, p) when n[p] < n[p-2].  So the workgroup of a block meets EVERY occurrence of every window whose a lies
+//      in the block -- all haplotypes, both orientations -- and count_per_trio == 1 (profile.rs:688-709) is decided in an
+//      LDS hash table keyed by (a - block start, b, c) packed into 64 bits.  Collinear haplotypes collapse in LDS; HBM sees
+//      the walks once (4P) and one byte per UNIQUE window.  A block whose distinct windows overflow the table is redone
+//      in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences of a key fall into the same class).
+constexpr int TRIO_BLK_SHIFT = 8, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 2048;
+constexpr unsigned long long TB_EMPTY = ~0ull;
+__device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_q, uint32_t *s_over, uint32_t a_l, uint32_t b, uint32_t c,
+                                          uint32_t q, uint32_t sub_mask, uint32_t sub_j) {
+    const unsigned long long key = ((unsigned long long)a_l << 54) | ((unsigned long long)b << 27) | c;
+    const unsigned long long mix = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
+    if ((((uint32_t)(mix >> 20)) & sub_mask) != sub_j) return;
+    uint32_t h = (uint32_t)(mix >> 53) & (TB_SLOTS - 1);
+    for (int probes = 0; probes < TB_SLOTS; ++probes) {
+        unsigned long long cur = s_key[h];
+        if (cur == TB_EMPTY) cur = atomicCAS(&s_key[h], TB_EMPTY, key);
+        if (cur == TB_EMPTY || cur == key) { atomicAdd(&s_cnt[h], 1u); s_q[h] = q; return; }
+        h = (h + 1) & (TB_SLOTS - 1);
+    }
+    *s_over = 1u;
+}
+__global__ void __launch_bounds__(256) trio_block_kernel(const uint32_t *__restrict__ blk_species, const uint32_t *__restrict__ blk_base,
+                                                         const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ blk_run_off,
+                                                         const uint4 *__restrict__ runs, const uint32_t *__restrict__ path_nodes,
+                                                         uint8_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
+    __shared__ unsigned long long s_key[TB_SLOTS];
+    __shared__ uint32_t s_cnt[TB_SLOTS], s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over;
+    const uint32_t gb = blockIdx.x, sp = blk_species[gb], nb = node_base[sp], Vs = node_base[sp + 1] - nb;
+    const uint32_t n0 = (gb - blk_base[sp]) << TRIO_BLK_SHIFT;
+    const uint32_t nn = Vs - n0 < (uint32_t)TRIO_BLK ? Vs - n0 : (uint32_t)TRIO_BLK;
+    const uint32_t r0 = blk_run_off[gb], r1 = blk_run_off[gb + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t nsub = 1;; nsub <<= 1) {
+        for (int i = threadIdx.x; i < TRIO_BLK; i += 256) s_ncnt[i] = 0;
+        bool over = false;
+        for (uint32_t j = 0; j < nsub && !over; ++j) {
+            for (int i = threadIdx.x; i < TB_SLOTS; i += 256) { s_key[i] = TB_EMPTY; s_cnt[i] = 0; }
+            if (threadIdx.x == 0) s_over = 0;
+            __syncthreads();
+            for (uint32_t r = r0 + wave; r < r1; r += 4) {
+                const uint4 run = runs[r];                                   // {first position, #positions, walk begin, walk end}
+                for (uint32_t i = lane; i < run.y; i += 64) {
+                    const uint32_t p = run.x + i, x = path_nodes[p];
+                    if (p + 2 < run.w) {
+                        const uint32_t c = path_nodes[p + 2];
+                        if (x <= c) tb_insert(s_key, s_cnt, s_q, &s_over, x - n0, path_nodes[p + 1], c, p, nsub - 1, j);
+                    }
+                    if (p >= run.z + 2) {
+                        const uint32_t c = path_nodes[p - 2];
+                        if (x < c) tb_insert(s_key, s_cnt, s_q, &s_over, x - n0, path_nodes[p - 1], c, p - 2, nsub - 1, j);
+                    }
+                }
+            }
+            __syncthreads();
+            over = s_over != 0;
+            if (!over)
+                for (int i = threadIdx.x; i < TB_SLOTS; i += 256)
+                    if (s_key[i] != TB_EMPTY && s_cnt[i] == 1u) { uniq_q[s_q[i]] = 1; atomicAdd(&s_ncnt[(uint32_t)(s_key[i] >> 54)], 1u); }
+            __syncthreads();
+        }
+        if (!over) break;
+        if (nsub >= (1u << 20)) { if (threadIdx.x == 0) atomicAdd(err, 1u); break; }   // cannot happen short of 2^31 equal hashes; never silent
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nn; i += 256) first_cnt[nb + n0 + i] = s_ncnt[i];
+}
+
+// The run table (upload time, depends on the graphs only): heads = positions whose node lies in another block than their
+// predecessor's (or that start a walk); counted per block, scanned, then every head measures its run and files it.
+__global__ void __launch_bounds__(256) run_count_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ blk_base, uint32_t *__restrict__ blk_cnt) {
+    TILE_LOOP(q, h, qend) {
+        const uint32_t sp = hap_species[h], x = path_nodes[q];
+        const bool head = q == path_off[h] || (path_nodes[q - 1] >> TRIO_BLK_SHIFT) != (x >> TRIO_BLK_SHIFT);
+        if (head) atomicAdd(&blk_cnt[blk_base[sp] + (x >> TRIO_BLK_SHIFT)], 1u);
+    }
+}
+__global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ blk_run_off,
+                                                       uint32_t *__restrict__ cursor, uint4 *__restrict__ runs) {
+    TILE_LOOP(q, h, qend) {
+        const uint32_t sp = hap_species[h], x = path_nodes[q], bx = x >> TRIO_BLK_SHIFT;
+        const uint64_t qb = path_off[h];
+        const bool head = q == qb || (path_nodes[q - 1] >> TRIO_BLK_SHIFT) != bx;
+        if (!head) continue;
+        uint64_t e = q + 1;
+        while (e < qend && (path_nodes[e] >> TRIO_BLK_SHIFT) == bx) ++e;
+        const uint32_t gb = blk_base[sp] + bx;
+        runs[blk_run_off[gb] + atomicAdd(&cursor[gb], 1u)] = make_uint4((uint32_t)q, (uint32_t)(e - q), (uint32_t)qb, (uint32_t)qend);
+    }
+}
+
 // 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
 //     its first unique window (rows are numbered (species, hap, position))
 __global__ void __launch_bounds__(256) trio_tilecount_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank,
@@ -245,6 +339,47 @@ __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint
     hap_trio_off[h] = (uint64_t)tile_base[hap_tile_off[h]];   // entry n_tiles of the scan = total
 }
 
+int trio_runs_build(Ctx *ctx, Db *db) {
+    db->trio_block_ok = false;
+    db->n_blocks = 0; db->n_runs = 0;
+    if (db->P == 0 || db->P >= 0xFFFFFFFFull) return 0;
+    std::vector<uint32_t> blk_base(db->S + 1, 0);
+    for (uint32_t s = 0; s < db->S; ++s) {
+        const uint64_t Vs = db->h_node_off[s + 1] - db->h_node_off[s];
+        if (Vs >= (1ull << 27)) return 0;             // the packed LDS key holds 27-bit local ids: such a db keeps the bucket path
+        const uint64_t nb = (uint64_t)blk_base[s] + ((Vs + TRIO_BLK - 1) >> TRIO_BLK_SHIFT);
+        if (nb >= 0x7FFFFFFFull) return 0;
+        blk_base[s + 1] = (uint32_t)nb;
+    }
+    const uint32_t NB = blk_base[db->S];
+    std::vector<uint32_t> blk_species(NB);
+    for (uint32_t s = 0; s < db->S; ++s) std::fill(blk_species.begin() + blk_base[s], blk_species.begin() + blk_base[s + 1], s);
+    PTX_TRY(upload(ctx, db->d_blk_base, blk_base.data(), db->S + 1));
+    PTX_TRY(upload(ctx, db->d_blk_species, blk_species.data(), NB));
+    DevBuf<uint32_t> cnt, scan_tmp, tot;
+    PTX_HIP(ctx, cnt.alloc(2ull * (NB + 1)));
+    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB + 1)));
+    PTX_HIP(ctx, tot.alloc(1));
+    PTX_HIP(ctx, db->d_blk_run_off.alloc(NB + 1));
+    PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2ull * (NB + 1) * sizeof(uint32_t), ctx->stream));
+#define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
+    const dim3 tgrid((uint32_t)db->n_tiles);
+    hipLaunchKernelGGL(run_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_blk_base.p, cnt.p);
+    PTX_TRY(exclusive_scan_u32(ctx, cnt.p, db->d_blk_run_off.p, (uint64_t)NB + 1, scan_tmp.p, tot.p));
+    uint32_t h_tot = 0;
+    PTX_TRY(download(ctx, &h_tot, tot.p, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PTX_HIP(ctx, db->d_runs.alloc(h_tot ? h_tot : 1));
+    hipLaunchKernelGGL(run_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_blk_base.p, db->d_blk_run_off.p, cnt.p + (NB + 1), db->d_runs.p);
+#undef TRIO_GRAPH
+    PTX_HIP(ctx, hipGetLastError());
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the temporaries go out of scope
+    db->n_blocks = NB;
+    db->n_runs = h_tot;
+    db->trio_block_ok = true;
+    return 0;
+}
+
 int trio_index_build(Ctx *ctx, Db *db) {
     const uint64_t P = db->P, V = db->V;
     const uint32_t H = (uint32_t)db->H;
@@ -259,18 +394,28 @@ int trio_index_build(Ctx *ctx, Db *db) {
     ts.tile_cnt.view(ts.zero_arena.p + 4 * (V + 1), NT + 1);
     ts.uniq_q.view(ts.zero_arena.p + 4 * (V + 1) + (NT + 1), P ? P : 1);
     PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
-    PTX_HIP(ctx, ts.bucket.alloc(P));
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
     PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
-    PTX_HIP(ctx, ts.d_tot.alloc(2));
+    PTX_HIP(ctx, ts.d_tot.alloc(3));
+    PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, sizeof(uint32_t), ctx->stream));   // error word of trio_block_kernel
     PTX_HIP(ctx, hipMemsetAsync(ts.zero_arena.p, 0, zwords * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     PTX_HIP(ctx, db->d_trio_node.alloc(V));
-    uint32_t tot[2] = {0, 0};
+    uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
+    // which uniqueness path: by node block (default) or through global buckets (species of >= 2^27 nodes, or forced)
+    bool by_block = db->trio_block_ok;
+    if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
+    if (P && by_block) {
+        KTimer t(ctx, "trio_block_kernel");
+        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(256), 0, ctx->stream, db->d_blk_species.p, db->d_blk_base.p, db->d_node_base.p,
+                           db->d_blk_run_off.p, db->d_runs.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
+    }
     if (P) {
+        if (!by_block) {
+        PTX_HIP(ctx, ts.bucket.alloc(P));
         {
             KTimer t(ctx, "trio_count_kernel");
             hipLaunchKernelGGL(trio_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, ts.cnt.p);
@@ -295,6 +440,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
                 hipLaunchKernelGGL(trio_uniq_kernel, dim3(grid_for(n_win, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_win, ts.bucket.p,
                                    ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
+        }
         hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
         PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_trio_node.p, V}, V + 1, nullptr,
@@ -302,8 +448,9 @@ int trio_index_build(Ctx *ctx, Db *db) {
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
-            PTX_TRY(download(ctx, tot, ts.d_tot.p, 2));
+            PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
             PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (set PANTAX_TRIO_PATH=bucket)", tot[2]);
             db->U_known = tot[1];
         }
         const uint32_t Utot = (uint32_t)db->U_known;

@@ -108,7 +108,8 @@ def test_micro_coverage_golden(eng):
 def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch):
     from oracle import oracle as orc
     from pantax_amd import synth
-    if uniq is not None:
+    if uniq is not None:   # default: uniqueness by node block in LDS; forced: the global bucket path with either of its kernels
+        monkeypatch.setenv("PANTAX_TRIO_PATH", "bucket")
         monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)   # read by the library at every trio build
     sset = synth.make_set(seed, S, H, R, L, adversarial_frac=0.01, single_strain_every=4 if S >= 5 else 0)
     rd = sset.reads
@@ -141,12 +142,34 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch
     assert nab == tot_abort
 
 
-@pytest.mark.parametrize("uniq", ["0", "1"])
+@pytest.mark.parametrize("V,H,K", [(200, 40, 300), (700, 30, 500), (300, 3, 9000)])
+def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K):
+    """Random walks over a few hundred nodes: a node block meets thousands of DISTINCT windows, more than its LDS table
+    holds, so it is redone in sub-passes over key classes; walks jump between blocks at every step (runs of length 1)
+    and visit both orientations of the same window."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(V + H)
+    node_len = rng.integers(1, 40, size=V).astype(np.int64)
+    walks = [rng.integers(0, V, size=K).astype(np.uint32) for _ in range(H)]
+    walks[1] = np.concatenate([walks[0][::-1][:K // 2], walks[1]])            # reverse traversals of another walk's windows
+    walks[2] = np.concatenate([walks[2], np.array([5, 5, 5, 5, 6, 5, 6], dtype=np.uint32)])   # a == c windows and repeats
+    path_off = np.concatenate([[0], np.cumsum([len(w) for w in walks])]).astype(np.uint64)
+    g = _G(node_len, path_off, np.concatenate(walks), 1)
+    eng.upload_db([g])
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    T = orc.TrioTable(orc.Graph(node_len, path_off, np.concatenate(walks)))
+    assert len(abc) == T.n_unique
+    assert np.array_equal(abc, T.abc) and np.array_equal(hap, T.hap) and np.array_equal(ln, T.len) and np.array_equal(hto, T.hap_off)
+
+
+@pytest.mark.parametrize("uniq", ["0", "1", None])
 def test_trio_index_with_huge_buckets(eng, uniq, monkeypatch):
     """Paths that keep coming back to a handful of nodes: thousands of windows share their smallest end node, far more
     than one workgroup's LDS table holds (the hashed form falls back to scanning the bucket), and most trios repeat."""
     from oracle import oracle as orc
-    monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)
+    if uniq is not None:
+        monkeypatch.setenv("PANTAX_TRIO_PATH", "bucket")
+        monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)
     rng = np.random.default_rng(17)
     V, H, K = 9, 40, 300
     node_len = rng.integers(1, 40, size=V).astype(np.int64)

@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Print the essentials of a bench.py JSON line."""
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[0])
+print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  launches/step %s" % (d["value"], d["unit"], d["ms_per_step"], d["ms_per_step_trio_index_resident"], d.get("launches_per_step")))
+r = d["roofline"]
+print("roofline", r["kernel"], "avg_ms %.3f frac %.3f traffic %s" % (r["avg_ms"], r["frac"], r.get("traffic")))
+print("kernels", {k: round(v, 3) for k, v in list(d["kernels_ms_per_step"].items())[:16]})
+if d.get("from_gaf_text"): print("gaf", d["from_gaf_text"])
+if d.get("pao_hard"): print("hard", {k: v for k, v in d["pao_hard"].items() if k != "highs"})
+if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["seconds"])

@@ -1,0 +1,21 @@
+#!/bin/bash
+# one gpurun call: gpu tests, default bench, kernel trace and PMC passes at cfg3.  usage: gpu_round.sh <tag> [what...]
+tag=$1; shift
+what=${@:-tests bench trace pmc}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+nproc > gpurun_out/${tag}_nproc.txt; free -g >> gpurun_out/${tag}_nproc.txt
+for w in $what; do
+case $w in
+tests) ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -5 gpurun_out/${tag}_tests.log ;;
+newtests) ( time timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -25 gpurun_out/${tag}_tests.log ;;
+bench) ( time timeout 1200 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 1500 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err ;;
+qbench) ( time timeout 900 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 10 ) > gpurun_out/${tag}_qbench.json 2> gpurun_out/${tag}_qbench.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench.json; tail -3 gpurun_out/${tag}_qbench.err ;;
+qbench2) ( time timeout 900 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 20 ) > gpurun_out/${tag}_qbench2.json 2> gpurun_out/${tag}_qbench2.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench2.json; tail -3 gpurun_out/${tag}_qbench2.err ;;
+bench2) ( time timeout 600 python bench.py --workload cfg2 ) > gpurun_out/${tag}_bench_cfg2.json 2> gpurun_out/${tag}_bench_cfg2.err; tail -c 600 gpurun_out/${tag}_bench_cfg2.json; tail -3 gpurun_out/${tag}_bench_cfg2.err ;;
+trace) bash tools/kernel_trace.sh cfg3 ${tag}_cfg3 6 ;;
+trace2) bash tools/kernel_trace.sh cfg2 ${tag}_cfg2 10 ;;
+pmc) bash tools/pmc_step.sh cfg3 ${tag}_cfg3 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
+     python3 tools/pmc_collect.py gpurun_out/pmc_${tag}_cfg3 cfg3 gpurun_out/${tag}_pmc_cfg3.json ;;
+esac
+done
