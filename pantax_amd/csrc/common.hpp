@@ -237,6 +237,7 @@ struct Db {
     DevBuf<uint32_t> d_blk_base;     // [S+1] first block of every species
     DevBuf<uint32_t> d_blk_species;  // [n_blocks]
     DevBuf<uint32_t> d_blk_run_off;  // [n_blocks+1]
+    DevBuf<uint4> d_blk_rec;         // [n_blocks+1] {first run, end run, global first node, species-local first node}
     DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
     // unique-trio index (a7)
     bool trio_built = false;

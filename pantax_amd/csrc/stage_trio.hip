@@ -184,7 +184,10 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
 //      in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences of a key fall into the same class).
 constexpr int TRIO_BLK_SHIFT = 8, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 2048;
 constexpr unsigned long long TB_EMPTY = ~0ull;
-__device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s_cnt, uint32_t *s_q, uint32_t *s_over, uint32_t a_l, uint32_t b, uint32_t c,
+constexpr uint32_t TB_MULTI = 0xFFFFFFFFu;
+// slot = {64-bit key, u32 q}: q is the position of the window's only occurrence, or TB_MULTI once a second one arrived
+// (both sides use atomicMax, so the outcome does not depend on who comes first; positions are < 2^32 - 1)
+__device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s_q, uint32_t *s_over, uint32_t a_l, uint32_t b, uint32_t c,
                                           uint32_t q, uint32_t sub_mask, uint32_t sub_j) {
     const unsigned long long key = ((unsigned long long)a_l << 54) | ((unsigned long long)b << 27) | c;
     const unsigned long long mix = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
@@ -193,55 +196,56 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
     for (int probes = 0; probes < TB_SLOTS; ++probes) {
         unsigned long long cur = s_key[h];
         if (cur == TB_EMPTY) cur = atomicCAS(&s_key[h], TB_EMPTY, key);
-        if (cur == TB_EMPTY || cur == key) { atomicAdd(&s_cnt[h], 1u); s_q[h] = q; return; }
+        if (cur == TB_EMPTY) { atomicMax(&s_q[h], q); return; }
+        if (cur == key) { s_q[h] = TB_MULTI; return; }    // plain store of the maximum: nothing can undo it
         h = (h + 1) & (TB_SLOTS - 1);
     }
     *s_over = 1u;
 }
-__global__ void __launch_bounds__(256) trio_block_kernel(const uint32_t *__restrict__ blk_species, const uint32_t *__restrict__ blk_base,
-                                                         const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ blk_run_off,
-                                                         const uint4 *__restrict__ runs, const uint32_t *__restrict__ path_nodes,
-                                                         uint8_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
+// blk_rec[gb] = {first run, end run, global index of the block's first node, its species-local id}; entry n_blocks closes
+// the table (the node count of a block is the distance to the next block's first node)
+__global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
+                                                         const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
+                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
     __shared__ unsigned long long s_key[TB_SLOTS];
-    __shared__ uint32_t s_cnt[TB_SLOTS], s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over;
-    const uint32_t gb = blockIdx.x, sp = blk_species[gb], nb = node_base[sp], Vs = node_base[sp + 1] - nb;
-    const uint32_t n0 = (gb - blk_base[sp]) << TRIO_BLK_SHIFT;
-    const uint32_t nn = Vs - n0 < (uint32_t)TRIO_BLK ? Vs - n0 : (uint32_t)TRIO_BLK;
-    const uint32_t r0 = blk_run_off[gb], r1 = blk_run_off[gb + 1];
+    __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over;
+    const uint4 rec = blk_rec[blockIdx.x];
+    const uint32_t nn = blk_rec[blockIdx.x + 1].z - rec.z;
+    const uint32_t r0 = rec.x, r1 = rec.y, n0 = rec.w;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t nsub = 1;; nsub <<= 1) {
         for (int i = threadIdx.x; i < TRIO_BLK; i += 256) s_ncnt[i] = 0;
         bool over = false;
         for (uint32_t j = 0; j < nsub && !over; ++j) {
-            for (int i = threadIdx.x; i < TB_SLOTS; i += 256) { s_key[i] = TB_EMPTY; s_cnt[i] = 0; }
+            for (int i = threadIdx.x; i < TB_SLOTS; i += 256) { s_key[i] = TB_EMPTY; s_q[i] = 0; }
             if (threadIdx.x == 0) s_over = 0;
             __syncthreads();
             for (uint32_t r = r0 + wave; r < r1; r += 4) {
                 const uint4 run = runs[r];                                   // {first position, #positions, walk begin, walk end}
                 for (uint32_t i = lane; i < run.y; i += 64) {
                     const uint32_t p = run.x + i, x = path_nodes[p];
-                    if (p + 2 < run.w) {
-                        const uint32_t c = path_nodes[p + 2];
-                        if (x <= c) tb_insert(s_key, s_cnt, s_q, &s_over, x - n0, path_nodes[p + 1], c, p, nsub - 1, j);
-                    }
-                    if (p >= run.z + 2) {
-                        const uint32_t c = path_nodes[p - 2];
-                        if (x < c) tb_insert(s_key, s_cnt, s_q, &s_over, x - n0, path_nodes[p - 1], c, p - 2, nsub - 1, j);
-                    }
+                    const bool fw = p + 2 < run.w, bw = p >= run.z + 2;
+                    const uint32_t c1 = fw ? path_nodes[p + 2] : 0u, b1 = fw ? path_nodes[p + 1] : 0u;
+                    const uint32_t c2 = bw ? path_nodes[p - 2] : 0u, b2 = bw ? path_nodes[p - 1] : 0u;
+                    if (fw && x <= c1) tb_insert(s_key, s_q, &s_over, x - n0, b1, c1, p, nsub - 1, j);
+                    if (bw && x < c2) tb_insert(s_key, s_q, &s_over, x - n0, b2, c2, p - 2, nsub - 1, j);
                 }
             }
             __syncthreads();
             over = s_over != 0;
             if (!over)
-                for (int i = threadIdx.x; i < TB_SLOTS; i += 256)
-                    if (s_key[i] != TB_EMPTY && s_cnt[i] == 1u) { uniq_q[s_q[i]] = 1; atomicAdd(&s_ncnt[(uint32_t)(s_key[i] >> 54)], 1u); }
+                for (int i = threadIdx.x; i < TB_SLOTS; i += 256) {
+                    const unsigned long long k = s_key[i];
+                    const uint32_t q = s_q[i];
+                    if (k != TB_EMPTY && q != TB_MULTI) { uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
+                }
             __syncthreads();
         }
         if (!over) break;
         if (nsub >= (1u << 20)) { if (threadIdx.x == 0) atomicAdd(err, 1u); break; }   // cannot happen short of 2^31 equal hashes; never silent
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nn; i += 256) first_cnt[nb + n0 + i] = s_ncnt[i];
+    for (uint32_t i = threadIdx.x; i < nn; i += 256) first_cnt[rec.z + i] = s_ncnt[i];
 }
 
 // The run table (upload time, depends on the graphs only): heads = positions whose node lies in another block than their
@@ -374,6 +378,20 @@ int trio_runs_build(Ctx *ctx, Db *db) {
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the temporaries go out of scope
+    {   // one record per block for the build kernel: {first run, end run, global first node, species-local first node}
+        std::vector<uint32_t> run_off(NB + 1);
+        PTX_TRY(download(ctx, run_off.data(), db->d_blk_run_off.p, (size_t)NB + 1));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint4> rec(NB + 1);
+        for (uint32_t s = 0; s < db->S; ++s)
+            for (uint32_t gb = blk_base[s]; gb < blk_base[s + 1]; ++gb) {
+                const uint32_t n0 = (gb - blk_base[s]) << TRIO_BLK_SHIFT;
+                rec[gb] = make_uint4(run_off[gb], run_off[gb + 1], (uint32_t)db->h_node_off[s] + n0, n0);
+            }
+        rec[NB] = make_uint4(h_tot, h_tot, (uint32_t)db->V, 0u);
+        PTX_TRY(upload(ctx, db->d_blk_rec, rec.data(), rec.size()));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     db->n_blocks = NB;
     db->n_runs = h_tot;
     db->trio_block_ok = true;
@@ -410,8 +428,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
     if (P && by_block) {
         KTimer t(ctx, "trio_block_kernel");
-        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(256), 0, ctx->stream, db->d_blk_species.p, db->d_blk_base.p, db->d_node_base.p,
-                           db->d_blk_run_off.p, db->d_runs.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
+        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(256), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,
+                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
     }
     if (P) {
         if (!by_block) {

@@ -8,6 +8,7 @@ nproc > gpurun_out/${tag}_nproc.txt; free -g >> gpurun_out/${tag}_nproc.txt
 for w in $what; do
 case $w in
 tests) ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -5 gpurun_out/${tag}_tests.log ;;
+triotests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q ) > gpurun_out/${tag}_tests.log 2>&1; tail -4 gpurun_out/${tag}_tests.log ;;
 newtests) ( time timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -25 gpurun_out/${tag}_tests.log ;;
 bench) ( time timeout 1200 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 1500 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err ;;
 qbench) ( time timeout 900 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 10 ) > gpurun_out/${tag}_qbench.json 2> gpurun_out/${tag}_qbench.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench.json; tail -3 gpurun_out/${tag}_qbench.err ;;

@@ -16,7 +16,7 @@ for fn in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), r
     with open(fn, newline="") as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"].split("(")[0]
-            k = k.replace("void ptx::", "").replace("ptx::", "")
+            k = k.replace("void ptx::", "").replace("ptx::", "").split("<")[0]
             if k.startswith("__amd") or "at::" in k:
                 continue
             c = acc.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
