@@ -187,7 +187,8 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
 
 /* ---- the device sort of the LP row grouping as a host-buffer utility: rows (k0[i], k1[i], k2[i]) sorted
  * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
- * 2 = sample sort (n <= 600000). */
+ * 2 = sample sort (n <= 600000), 3 = the batched sort of the many-species step: rows arrive grouped by ascending k0
+ * (one segment per k0 value, each <= 600000 rows) and (k1, k2) is sorted inside every segment. */
 int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo);
 
 /* filter_max_alignment_mt (gaf_filter.rs:44-97, called by alignment.rs:171 on long-read GAFs): per read id

@@ -122,6 +122,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
             sp_bits[s + 1] = sp_bits[s] + parts[s].n_bases;
         }
         db->L = sp_bits[S];
+        if (db->L >= NODE_REC_MAX_BITS) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu graph bases on one GPU (limit 2^40)", (unsigned long long)db->L);
         PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
         PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
         PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
@@ -177,6 +178,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         sp_bits[s + 1] += sp_bits[s];
     }
     db->L = sp_bits[S];
+    if (db->L >= NODE_REC_MAX_BITS) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu graph bases on one GPU (limit 2^40)", (unsigned long long)db->L);
     bit_off[db->V] = db->L;
     parallel_for(S, n_thr, [&](uint64_t s0, uint64_t s1) {
         for (uint64_t s = s0; s < s1; ++s) {
@@ -186,7 +188,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
                 const uint32_t l = (uint32_t)parts[s].len(v);
                 bit_off[vb + v] = bo;
                 len32[vb + v] = l;
-                nrec[vb + v] = make_uint4((uint32_t)bo, (uint32_t)(bo >> 32), l, 0u);
+                nrec[vb + v] = nr_make(bo, l);
                 bo += l;
             }
         }
@@ -279,7 +281,6 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     PTX_TRY(trio_runs_build(ctx, db.get()));
     lap("node-block runs");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
-    PTX_HIP(ctx, db->d_trio_node.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(1));
     PTX_HIP(ctx, db->d_trio_bases.alloc(1));
     PTX_HIP(ctx, db->d_active.alloc(S));

@@ -216,7 +216,8 @@ struct Db {
     DevBuf<uint32_t> d_node_base;    // [S+1]
     DevBuf<uint64_t> d_bit_off;      // [V+1] prefix sum of node_len; node_len[v] = bit_off[v+1]-bit_off[v]
     DevBuf<uint32_t> d_node_len;     // [V] the same lengths as 4-byte gathers
-    DevBuf<uint4> d_node_rec;        // [V] {bit_off lo, bit_off hi, len, 0}: one 16-byte gather per step
+    DevBuf<uint4> d_node_rec;        // [V] {bit_off lo, bit_off hi (8 bits) | #lookup rows << 8, len, first lookup row}: one 16-byte gather per step
+                                     //     carries the node AND the head of its unique-trio lookup rows (written by every trio build)
     DevBuf<uint64_t> d_path_off;     // [H+1]
     DevBuf<uint32_t> d_path_nodes;   // [P]
     DevBuf<uint32_t> d_hap_species;  // [H]
@@ -246,7 +247,6 @@ struct Db {
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
     DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
-    DevBuf<uint2> d_trio_node;       // [V] {first lookup row, #rows} of the windows whose smallest end is this node
     DevBuf<uint4> d_trio_ent;        // [U] {b, c, row in (species,hap,position) order, 0}
     DevBuf<uint32_t> d_trio_abc;     // [3U] row order
     DevBuf<uint32_t> d_trio_hap;     // [U] hap index within species, row order
@@ -276,7 +276,7 @@ struct Db {
     DevBuf<uint8_t> d_sp_out;        // backing store of d_sp_abs + d_active in a resident step (one download)
     PinBuf h_sp_out;                 // [S f64 absolute][S u8 keep]
     // LP-row staging (lad_prepare)
-    DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws;
+    DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort
     DevBuf<uint64_t> d_ka[3], d_kb[3];
 };
 
@@ -299,9 +299,15 @@ struct Reads {
     DevBuf<uint32_t> d_long_sum;     // [R'] walks > 64 steps: node lengths of all steps but the last (walk_sum_kernel), else unused
     DevBuf<uint32_t> d_long_len0;    // [R'] walks > 64 steps: length of the walk's first node (walk_sum_kernel)
     uint32_t n_long = 0;             // walks of more than 64 steps
-    DevBuf<int32_t> d_g_sp;          // [R'] species of the slot's read (-1: "U" or dropped row), written by the binning kernel
+    DevBuf<uint4> d_g_slot_rec;      // [R'] {species of the slot's read (-1: "U" or dropped row), its first node id, node base, #nodes}, written by the binning kernel
     bool binned = false;
 };
+
+// node record fields (Db::d_node_rec): the coverage bitmap of one GPU holds < 2^40 bases and a node heads < 2^24 lookup rows
+constexpr uint64_t NODE_REC_MAX_BITS = 1ull << 40;
+constexpr uint32_t NODE_REC_MAX_ROWS = 1u << 24;
+__host__ __device__ inline uint64_t nr_bit_off(const uint4 &r) { return ((uint64_t)(r.y & 0xFFu) << 32) | r.x; }
+__host__ __device__ inline uint4 nr_make(uint64_t bit_off, uint32_t len) { return make_uint4((uint32_t)bit_off, (uint32_t)(bit_off >> 32) & 0xFFu, len, 0u); }
 
 template <class T>
 int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
@@ -320,7 +326,7 @@ struct GraphPart {
 };
 // stage_db.hip: node tables + walk check on the device (image loads), and the move of species-local trio rows
 int node_tables_launch(Ctx *ctx, Db *db, const uint64_t *sp_bits, uint32_t *d_flags);
-int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows);
+int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows, uint32_t *d_err /* counts nodes with >= 2^24 lookup rows */);
 int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out);
 // large pageable host buffers (mmapped text, graph arrays) -> HBM through two pinned chunks: a few threads copy the next
 // chunk into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged

@@ -163,7 +163,10 @@ int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *im, const in
     for (uint32_t s = 0; s < S; ++s)
         for (uint64_t h = 0; h < im[s]->H; ++h) db->h_hap_trio_off[db->h_hap_off[s] + h] = im[s]->hap_trio_off[h] + ubase[s];
     db->h_hap_trio_off[H] = Utot;
-    PTX_HIP(ctx, db->d_trio_first.alloc(V + 1)); PTX_HIP(ctx, db->d_trio_node.alloc(V ? V : 1)); PTX_HIP(ctx, db->d_trio_ent.alloc(Utot ? Utot : 1));
+    PTX_HIP(ctx, db->d_trio_first.alloc(V + 1)); PTX_HIP(ctx, db->d_trio_ent.alloc(Utot ? Utot : 1));
+    DevBuf<uint32_t> d_err;
+    PTX_HIP(ctx, d_err.alloc(1));
+    PTX_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, db->d_trio_abc.alloc(3 * (Utot ? Utot : 1))); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot ? Utot : 1)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot ? Utot : 1));
     for (uint32_t s = 0; s < S; ++s) {
         const SpeciesImage &g = *im[s];
@@ -173,12 +176,15 @@ int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *im, const in
         PTX_TRY(upload_file(ctx, db->d_trio_abc.p + 3 * ubase[s], g.mf.fd, g.off_trio_abc, 3 * g.U * sizeof(uint32_t)));
         PTX_TRY(upload_file(ctx, db->d_trio_hap.p + ubase[s], g.mf.fd, g.off_trio_hap, g.U * sizeof(uint32_t)));
         PTX_TRY(upload_file(ctx, db->d_trio_len.p + ubase[s], g.mf.fd, g.off_trio_len, g.U * sizeof(uint32_t)));
-        PTX_TRY(trio_rebase_launch(ctx, db.get(), s, ubase[s], g.U));
+        PTX_TRY(trio_rebase_launch(ctx, db.get(), s, ubase[s], g.U, d_err.p));
     }
     const uint32_t u32tot = (uint32_t)Utot;
     PTX_HIP(ctx, hipMemcpyAsync(db->d_trio_first.p + V, &u32tot, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PTX_TRY(upload(ctx, db->d_hap_trio_off, db->h_hap_trio_off.data(), H + 1));
+    uint32_t h_err = 0;
+    PTX_TRY(download(ctx, &h_err, d_err.p, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err) return fail(ctx, PANTAX_HIP_E_LIMIT, "graph images: %u nodes head 2^24 or more unique-trio rows", h_err);
     db->U = db->U_known = Utot;
     db->trio_sizes_known = true;
     db->trio_built = true;

@@ -41,6 +41,13 @@ constexpr uint64_t SS_MAX_N = 600000;
 size_t sample_sort_ws_elems(uint64_t n_bound);
 int sample_sort3(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n_bound, uint32_t *d_ws, const uint32_t *d_n);
 
+// The same for MANY independent segments in one batch (sample_sort_seg.hip): rows of segment s are
+// [seg_off[s], seg_off[s] + seg_cnt[s]) (device arrays), keys are two words (am, aa), every segment holds at most
+// seg_bound <= SS_MAX_N rows.  Sorted in place; (bm, ba) is scratch.  d_ws: >= sample_sort_seg_ws_elems(S, n_total_bound) u32.
+size_t sample_sort_seg_ws_elems(uint32_t S, uint64_t n_total_bound);
+int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t *ba, uint32_t S, uint64_t seg_bound, uint64_t n_total_bound,
+                    const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t *d_ws);
+
 // helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
 inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {
     for (int s = lo; s < hi; s += 8) out.push_back({word, s});

@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
     uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
     const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, const uint32_t *__restrict__ rs,
     const uint32_t *__restrict__ re, const uint32_t *__restrict__ ridx, int S, int32_t *__restrict__ species_out,
-    const uint32_t *__restrict__ slot_of, const uint8_t *__restrict__ flags, int32_t *__restrict__ slot_species,
+    const uint32_t *__restrict__ slot_of, const uint8_t *__restrict__ flags, uint4 *__restrict__ slot_rec,
+    const uint32_t *__restrict__ sp_first_id /* null: db without graphs */, const uint32_t *__restrict__ node_base,
     unsigned long long *__restrict__ counters_rep /* [BIN_REPL][4][S]: read_count, base_sum, less_multi, uniq_count */) {
     // every workgroup ends with a handful of global atomics on the same few words; spreading the workgroups
     // over BIN_REPL replicas keeps that tail from serialising (same-address atomics cost ~12 ns each)
@@ -102,7 +103,14 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
             species_out[r] = sp;
             // the coverage kernel walks the locus-grouped copy: hand it the species per slot, dropped rows as -1
             const uint32_t slot = slot_of[r];
-            if (slot != 0xFFFFFFFFu) slot_species[slot] = (flags && flags[r]) ? -1 : sp;
+            if (slot != 0xFFFFFFFFu) {   // {species, its first node id, node base, #nodes}: everything the coverage kernel needs to place a node id
+                uint4 rec = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+                if (sp >= 0 && !(flags && flags[r])) {
+                    rec.x = (uint32_t)sp;
+                    if (sp_first_id) { rec.y = sp_first_id[sp]; rec.z = node_base[sp]; rec.w = node_base[sp + 1] - rec.z; }
+                }
+                slot_rec[slot] = rec;
+            }
             if (sp >= 0) {
                 q = qlen[r];
                 uint32_t m = mapq[r];
@@ -195,7 +203,8 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
     {
         KTimer t(ctx, "bin_reads_kernel");
 #define BIN_ARGS rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_qlen.p, rd->d_mapq.p, db->d_rng_start.p, db->d_rng_end.p, \
-                 db->d_rng_idx.p, S, rd->d_species.p, rd->d_slot_of.p, rd->has_flags ? rd->d_flags.p : nullptr, rd->d_g_sp.p, d_counters
+                 db->d_rng_idx.p, S, rd->d_species.p, rd->d_slot_of.p, rd->has_flags ? rd->d_flags.p : nullptr, rd->d_g_slot_rec.p, \
+                 db->d_sp_first_id.p, db->d_node_base.p, d_counters
         if (db->ranges_sorted_disjoint) {
             if (lds) hipLaunchKernelGGL((bin_reads_kernel<true, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
             else hipLaunchKernelGGL((bin_reads_kernel<true, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);

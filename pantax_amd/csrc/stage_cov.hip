@@ -53,22 +53,27 @@ __device__ __forceinline__ uint32_t bm_peek(const uint32_t *p) {
 // Bits [g0,g1) of the coverage bit vector are marked through the workgroup's LDS bit window (words
 // [bw0, bw0 + COV_BWIN) of the global vector); words outside the window take the global test-then-OR path.  The window is ORed into memory once per workgroup.
 constexpr uint32_t COV_BWIN = 2048;   // 32-bit words: 64 kbit of graph bases
-__device__ __forceinline__ void lds_or(uint32_t *s_bm, uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
+constexpr int COV_WIN = 1024;         // nodes in the LDS window of `bases`
+// the two LDS windows of the coverage kernel live at file scope: helpers that received them as (generic) pointer arguments
+// made this compiler emit an illegal null check of the shared-memory aperture
+__shared__ uint32_t s_win[COV_WIN];
+__shared__ uint32_t s_bm[COV_BWIN];
+__device__ __forceinline__ void lds_or(uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
     const uint64_t off = w - bw0;     // unsigned wrap: words below the window are out of range too
     if (off < bwn) {
         if ((s_bm[off] & m) != m) atomicOr(&s_bm[off], m);
     } else if ((bm_peek(&bm[w]) & m) != m) atomicOr(&bm[w], m);
 }
-__device__ __forceinline__ void mark_range(uint32_t *s_bm, uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t g0, uint64_t g1) {
+__device__ __forceinline__ void mark_range(uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t g0, uint64_t g1) {
     if (g1 <= g0) return;
     uint64_t w0 = g0 >> 5, w1 = (g1 - 1) >> 5;
     uint32_t m0 = 0xFFFFFFFFu << (g0 & 31);
     uint32_t m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
-    if (w0 == w1) lds_or(s_bm, bm, bw0, bwn, w0, m0 & m1);
+    if (w0 == w1) lds_or(bm, bw0, bwn, w0, m0 & m1);
     else {
-        lds_or(s_bm, bm, bw0, bwn, w0, m0);
-        for (uint64_t w = w0 + 1; w < w1; ++w) lds_or(s_bm, bm, bw0, bwn, w, 0xFFFFFFFFu);
-        lds_or(s_bm, bm, bw0, bwn, w1, m1);
+        lds_or(bm, bw0, bwn, w0, m0);
+        for (uint64_t w = w0 + 1; w < w1; ++w) lds_or(bm, bw0, bwn, w, 0xFFFFFFFFu);
+        lds_or(bm, bw0, bwn, w1, m1);
     }
 }
 
@@ -86,62 +91,62 @@ __device__ __forceinline__ uint32_t rl_from_memory(uint32_t j, uint32_t b, const
     return node_rec[nb + (idj - first_id)].z;
 }
 
-constexpr int COV_CHUNK = 1024;   // steps per workgroup
-constexpr int COV_WIN = 1024;     // nodes in the LDS window
 constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the node of the chunk's first live step
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
-__device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t *s_win, uint32_t wlo, uint32_t win_n, uint32_t v,
-                                          uint32_t aln) {
+__device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t wlo, uint32_t win_n, uint32_t v, uint32_t aln) {
     const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
     if (off < win_n && aln < (1u << 18)) atomicAdd(&s_win[off], aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
 }
 
 // Steps arrive grouped by the locus of their read's first node (build_step_read below), so a workgroup's
-// chunk of COV_CHUNK consecutive steps lands in a narrow node window: `bases` is accumulated in an LDS
+// chunk of consecutive steps lands in a narrow node window: `bases` is accumulated in an LDS
 // window of COV_WIN nodes (32-bit LDS atomics) and flushed with one 64-bit global atomic per touched
 // node -- the LDS-staged segmented reduction of the scatter.  Nodes outside the window (or oversized
 // lengths) fall back to the global atomic; the result is identical either way.
 //
-// The kernel is latency-bound (a chain of dependent gathers per step), so the loads are ordered to keep
-// the chain short: {slot, node id} -> {read record, species of the slot} -> species tables (cached)
-// -> {node record, trio bucket head} -> {bitmap probe, trio entries}.
-template <bool WITH_TRIO>
+// The kernel is bound by the latency of its chain of dependent gathers times the gathers in flight, so
+//   * the chain is three levels: {slot, node id, step code} (stream) -> {read record, slot record} -> {node record}
+//     (-> a unique-trio entry where the node has any).  The slot record {species, first id, node base, #nodes} is
+//     written by the binning pass, so no species table is consulted here; the node record carries the lookup head of
+//     the unique-trio index (first row, #rows) next to bit offset and length, and a 3-window whose smaller end is the
+//     node two steps back takes the head from that lane by shuffle: ONE divergent 16-byte gather per step.
+//   * every wave works on U groups of 64 steps at once: the loads of one level are issued for all U groups before the
+//     first of them is waited for (U x the memory-level parallelism per wave; registers permitting).
+// PASSES such rounds share one pair of LDS windows (zeroing and flushing them is per workgroup).
+template <bool WITH_TRIO, int U, int PASSES>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
-    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
-    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active, const uint32_t *__restrict__ sp_first_id,
-    const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases,
-    uint32_t *__restrict__ bitmap, const uint2 *__restrict__ trio_node, const uint4 *__restrict__ trio_ent,
-    unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort, const uint32_t *__restrict__ long_sum,
-    const uint32_t *__restrict__ long_len0) {
-    __shared__ uint32_t s_win[COV_WIN];
-    __shared__ uint32_t s_bm[COV_BWIN];
-    const int lane = threadIdx.x & 63;
-    const uint64_t chunk_b = (uint64_t)blockIdx.x * COV_CHUNK;
-    uint64_t chunk_e = chunk_b + COV_CHUNK;
+    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint4 *__restrict__ slot_rec,
+    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active,
+    const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap,
+    const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort,
+    const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0) {
+    constexpr int CHUNK = COV_BLOCK * U * PASSES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t chunk_b = (uint64_t)blockIdx.x * CHUNK;
+    uint64_t chunk_e = chunk_b + CHUNK;
     if (chunk_e > T) chunk_e = T;
     for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
     for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
-    // window base: the node of the first live step among four probes of the chunk.  Every thread computes it
+    // window base: the node of the first live step among a few probes of the chunk.  Every thread computes it
     // (workgroup-uniform addresses), so nobody waits on a broadcast and the probes overlap the first gathers.
     uint32_t wlo = 0, win_n = 0, bwn = 0;
     uint64_t bw0 = 0;
 #pragma unroll
-    for (int c = 0; c < COV_CHUNK / COV_BLOCK; ++c) {
+    for (int c = 0; c < CHUNK / COV_BLOCK; ++c) {
         const uint64_t tc = chunk_b + (uint64_t)c * COV_BLOCK;
         if (win_n == 0 && tc < chunk_e) {
             const uint32_t slot = step_read[tc];
             if (slot != NO_SLOT) {
-                const int sp0 = slot_species[slot];
-                if (sp0 >= 0 && !(active && !active[sp0])) {
-                    const uint32_t id0 = node_id[tc], f0 = sp_first_id[sp0], nb0 = node_base[sp0];
-                    if (id0 >= f0 && id0 - f0 < node_base[sp0 + 1] - nb0) {
-                        const uint32_t v0 = nb0 + (id0 - f0);
+                const uint4 sr0 = slot_rec[slot];
+                if ((int)sr0.x >= 0 && !(active && !active[sr0.x])) {
+                    const uint32_t id0 = node_id[tc];
+                    if (id0 >= sr0.y && id0 - sr0.y < sr0.w) {
+                        const uint32_t v0 = sr0.z + (id0 - sr0.y);
                         wlo = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
                         win_n = COV_WIN;
-                        const uint4 nr0 = node_rec[wlo];           // bit window starts at the window's first node
-                        bw0 = (((uint64_t)nr0.y << 32) | nr0.x) >> 5;
+                        bw0 = nr_bit_off(node_rec[wlo]) >> 5;        // bit window starts at the window's first node
                         bwn = COV_BWIN;
                     }
                 }
@@ -149,109 +154,151 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         }
     }
     __syncthreads();
-    for (uint64_t base = chunk_b + (threadIdx.x - lane); base < chunk_e; base += COV_BLOCK) {
-        const uint64_t t = base + lane;
-        bool ok = t < chunk_e;
-        uint32_t slot = NO_SLOT, id = 0, dupc = 0;
-        if (ok) { slot = step_read[t]; id = node_id[t]; dupc = step_dup[t]; }
-        ok = ok && slot != NO_SLOT;
-        uint4 rr = make_uint4(0, 0, 0, 0);
-        int sp = -1;
-        if (ok) { rr = read_rec[slot]; sp = slot_species[slot]; }
-        ok = ok && sp >= 0 && !(active && !active[sp]);             // "U" / dropped rows / unselected species
-        const uint32_t b = rr.x, k = rr.y;
-        // positions, node lengths and aligned lengths are 32-bit quantities (the packed layout carries u32 columns and a
-        // walk cannot align 4 Gbp): only `target` needs a sign.
-        const uint32_t ps = rr.z, pe = rr.w;
-        const uint32_t i = ok ? (uint32_t)(t - b) : 0u;
-        uint32_t l = 0, v = 0, first_id = 0, nb = 0;
-        if (ok) {
-            first_id = sp_first_id[sp]; nb = node_base[sp];
-            const uint32_t Vs = node_base[sp + 1] - nb;
-            if (id < first_id || id - first_id >= Vs) { atomicAdd(n_abort, 1ull); ok = false; }
-            else { l = id - first_id; v = nb + l; }
-        }
-        const int dist = ok ? (int)min(i, (uint32_t)lane) : 0;   // earlier steps of my read held by lower lanes
-        const bool cross = ok && (int)i > lane;                   // the walk began before this wave (more than 64 steps)
-        // ---- gathers that only need (species, node): issued together
-        uint32_t l1 = __shfl_up(l, 1), l2 = __shfl_up(l, 2);
-        uint32_t tc_ = 0;
-        uint2 tn = make_uint2(0, 0);
-        if (WITH_TRIO && ok && i >= 2) {
-            if (lane < 1) l1 = node_id[b + i - 1] - first_id;
-            if (lane < 2) l2 = node_id[b + i - 2] - first_id;
-            uint32_t ta = l2; tc_ = l;
-            if (ta > tc_) { uint32_t tmp = ta; ta = tc_; tc_ = tmp; }
-            tn = trio_node[nb + ta];                              // {first row, #rows}: usually 0-3 rows
-        }
-        uint64_t bo = 0;
-        uint32_t nl = 0;
-        if (ok) {
-            const uint4 nr = node_rec[v];
-            bo = ((uint64_t)nr.y << 32) | nr.x;
-            nl = nr.z;
-        }
-        // first node length: from the lane that holds step b, else from memory
-        const uint32_t nl_src = __shfl(nl, lane - dist);
-        uint32_t len0 = nl;
-        if (ok && i > 0) len0 = !cross ? nl_src : long_len0[slot];   // first node of a long walk: noted by walk_sum_kernel
-        const long long target = (long long)pe - (long long)ps;   // profile.rs:800
-        if (ok && k == 1) {                                       // :811
-            if (target >= 0) {                                    // :821-827
-                if (target) add_bases(bases, s_win, wlo, win_n, v, (uint32_t)target);
-                if (ps < pe && pe <= nl) mark_range(s_bm, bitmap, bw0, bwn, bo + ps, bo + pe);   // :832
-            }
-            ok = false;
-        }
-        if (ok && ps > len0) {                                    // assert :854 -> whole read contributes nothing
-            if (i == 0) atomicAdd(n_abort, 1ull);
-            ok = false;
-        }
-        // ---- `seen` before this step = sum of the aligned lengths of steps 0..i-1: segmented wave scan
-        const uint32_t contrib = ok ? (i == 0 ? nl - ps : nl) : 0u;
-        uint32_t incl = contrib;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const uint64_t wbase = chunk_b + (uint64_t)((pass * (COV_BLOCK / 64) + wave) * U) * 64;   // this wave's U x 64 consecutive steps
+        if (wbase >= chunk_e) break;
+        // ---- level 1: the stream
+        uint32_t slot[U], id[U], dupc[U], ti[U];
+        bool ok[U];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            if (d == 16 && !__any(dist >= 16)) break;             // short walks: four steps cover every read of the wave
-            uint32_t up = __shfl_up(incl, d);
-            if (dist >= d) incl += up;
+        for (int u = 0; u < U; ++u) {
+            const uint64_t t = wbase + (uint64_t)u * 64 + lane;
+            ok[u] = t < chunk_e;
+            slot[u] = NO_SLOT; id[u] = 0; dupc[u] = 0;
+            ti[u] = (uint32_t)t;                                     // T_pad < 2^32 (build_step_read)
+            if (ok[u]) { slot[u] = step_read[t]; id[u] = node_id[t]; dupc[u] = step_dup[t]; }
+            ok[u] = ok[u] && slot[u] != NO_SLOT;
         }
-        // ---- first occurrence of this node in the read (:879): decided at upload time (step codes above)
-        const uint32_t id0 = __shfl(id, lane - dist);             // id of step 0 when the walk starts in this wave
-        uint32_t rl = 0;
-        if (ok) {
-            int jf = -1;                                          // -1: first occurrence; 0: the node of step 0; 1: another earlier step
-            if (dupc & STEP_LONG) { if (dupc & 1u) jf = (id == (cross ? node_id[b] : id0)) ? 0 : 1; }
-            else if (dupc) jf = (int)i - (int)dupc;
-            uint32_t aln, sidx;
-            if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
-            else if (i == k - 1) {                                // :857-859
-                uint32_t seen = incl - contrib;
-                if (cross) seen = long_sum[slot] - ps;             // all steps but the last, from walk_sum_kernel
-                aln = target > (long long)seen ? (uint32_t)(target - (long long)seen) : 0u;   // max(target - seen, 0)
-                sidx = 0;
-            } else { aln = nl; sidx = 0; }                        // :860-862
-            uint32_t hi = sidx + aln;
-            if (hi > nl) hi = nl;                                 // :871
-            mark_range(s_bm, bitmap, bw0, bwn, bo + sidx, bo + hi);
-            if (jf < 0) {
-                rl = aln;
-                if (aln) add_bases(bases, s_win, wlo, win_n, v, aln);     // :881
-            } else rl = (jf == 0) ? (len0 - ps) : nl;
+        // ---- level 2: per-read records
+        uint4 rr[U], sr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rr[u] = make_uint4(0u, 0u, 0u, 0u); sr[u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            if (ok[u]) { rr[u] = read_rec[slot[u]]; sr[u] = slot_rec[slot[u]]; }
         }
-        if (WITH_TRIO) {                                          // :890-907
-            uint32_t rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
-            if (ok && i >= 2) {
-                if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, first_id, nb, node_rec, len0, ps);
-                if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, first_id, nb, node_rec, len0, ps);
-                int row = -1;
-                for (uint32_t j = 0; j < tn.y; ++j) {
-                    const uint4 e = trio_ent[tn.x + j];
-                    if (e.x == l1 && e.y == tc_) { row = (int)e.z; break; }
+        // ---- level 3: the node record (issued before the species' `active` flag is known: a wasted gather at worst)
+        uint4 nr[U];
+        uint32_t l[U], act[U];
+        bool inr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = ok[u] && (int)sr[u].x >= 0;                       // "U" / dropped rows
+            nr[u] = make_uint4(0u, 0u, 0u, 0u); l[u] = 0; act[u] = 1u; inr[u] = false;
+            if (ok[u]) {
+                inr[u] = id[u] >= sr[u].y && id[u] - sr[u].y < sr[u].w;
+                if (inr[u]) { l[u] = id[u] - sr[u].y; nr[u] = node_rec[sr[u].z + l[u]]; }
+                if (active) act[u] = active[sr[u].x];
+            }
+        }
+        // ---- shuffles, the trio lookup head and the first trio entry (level 4), for all groups
+        uint32_t l1[U], l2[U], len0[U], tcc[U];
+        uint2 th[U];
+        uint4 e0[U];
+        int dist[U];
+        bool cross[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ok[u] && !act[u]) ok[u] = false;                      // unselected species
+            if (ok[u] && !inr[u]) { atomicAdd(n_abort, 1ull); ok[u] = false; }
+            if (!ok[u]) { l[u] = 0; nr[u] = make_uint4(0u, 0u, 0u, 0u); }
+            const uint32_t b = rr[u].x;
+            const uint32_t i = ok[u] ? ti[u] - b : 0u;
+            dist[u] = ok[u] ? (int)min(i, (uint32_t)lane) : 0;        // earlier steps of my read held by lower lanes
+            cross[u] = ok[u] && (int)i > lane;                        // the walk began before this wave (more than 64 steps)
+            l1[u] = __shfl_up(l[u], 1); l2[u] = __shfl_up(l[u], 2);
+            const uint32_t tf2 = __shfl_up(nr[u].w, 2), tn2 = __shfl_up(nr[u].y >> 8, 2);
+            th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (WITH_TRIO && ok[u] && i >= 2) {
+                if (lane < 1) l1[u] = node_id[b + i - 1] - sr[u].y;
+                if (lane < 2) l2[u] = node_id[b + i - 2] - sr[u].y;
+                // canonical window (min end, middle, max end); the lookup head belongs to the smaller end node
+                if (l[u] <= l2[u]) { th[u] = make_uint2(nr[u].w, nr[u].y >> 8); tcc[u] = l2[u]; }
+                else {
+                    tcc[u] = l[u];
+                    if (lane >= 2) th[u] = make_uint2(tf2, tn2);
+                    else { const uint4 r2 = node_rec[sr[u].z + l2[u]]; th[u] = make_uint2(r2.w, r2.y >> 8); }   // wave border of a long walk
                 }
-                if (row >= 0) {
-                    const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
-                    if (sum) atomicAdd(&trio_bases[row], sum);
+                if (th[u].y) e0[u] = trio_ent[th[u].x];
+            }
+            // first node length: from the lane that holds step b, else (long walk) noted by walk_sum_kernel
+            const uint32_t nl_src = __shfl(nr[u].z, lane - dist[u]);
+            len0[u] = nr[u].z;
+            if (ok[u] && i > 0) len0[u] = !cross[u] ? nl_src : long_len0[slot[u]];
+        }
+        // ---- per group: aligned lengths, bitmap, bases, trio bases
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t b = rr[u].x, k = rr[u].y, ps = rr[u].z, pe = rr[u].w;
+            // positions, node lengths and aligned lengths are 32-bit quantities (the packed layout carries u32 columns and a
+            // walk cannot align 4 Gbp): only `target` needs a sign.
+            const uint32_t i = ok[u] ? ti[u] - b : 0u;
+            const uint64_t bo = nr_bit_off(nr[u]);
+            const uint32_t nl = nr[u].z, v = sr[u].z + l[u];
+            bool live = ok[u];
+            const long long target = (long long)pe - (long long)ps;   // profile.rs:800
+            if (live && k == 1) {                                     // :811
+                if (target >= 0) {                                    // :821-827
+                    if (target) add_bases(bases, wlo, win_n, v, (uint32_t)target);
+                    if (ps < pe && pe <= nl) mark_range(bitmap, bw0, bwn, bo + ps, bo + pe);   // :832
+                }
+                live = false;
+            }
+            if (live && ps > len0[u]) {                               // assert :854 -> whole read contributes nothing
+                if (i == 0) atomicAdd(n_abort, 1ull);
+                live = false;
+            }
+            // ---- `seen` before this step = sum of the aligned lengths of steps 0..i-1: segmented wave scan
+            const uint32_t contrib = live ? (i == 0 ? nl - ps : nl) : 0u;
+            uint32_t incl = contrib;
+            const int dst = dist[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                if (d == 16 && !__any(dst >= 16)) break;              // short walks: four steps cover every read of the wave
+                uint32_t up = __shfl_up(incl, d);
+                if (dst >= d) incl += up;
+            }
+            // ---- first occurrence of this node in the read (:879): decided at upload time (step codes above)
+            const uint32_t id0 = __shfl(id[u], lane - dst);           // id of step 0 when the walk starts in this wave
+            uint32_t rl = 0;
+            if (live) {
+                int jf = -1;                                          // -1: first occurrence; 0: the node of step 0; 1: another earlier step
+                if (dupc[u] & STEP_LONG) { if (dupc[u] & 1u) jf = (id[u] == (cross[u] ? node_id[b] : id0)) ? 0 : 1; }
+                else if (dupc[u]) jf = (int)i - (int)dupc[u];
+                uint32_t aln, sidx;
+                if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
+                else if (i == k - 1) {                                // :857-859
+                    uint32_t seen = incl - contrib;
+                    if (cross[u]) seen = long_sum[slot[u]] - ps;      // all steps but the last, from walk_sum_kernel
+                    aln = target > (long long)seen ? (uint32_t)(target - (long long)seen) : 0u;   // max(target - seen, 0)
+                    sidx = 0;
+                } else { aln = nl; sidx = 0; }                        // :860-862
+                uint32_t hi = sidx + aln;
+                if (hi > nl) hi = nl;                                 // :871
+                mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
+                if (jf < 0) {
+                    rl = aln;
+                    if (aln) add_bases(bases, wlo, win_n, v, aln);     // :881
+                } else rl = (jf == 0) ? (len0[u] - ps) : nl;
+            }
+            if (WITH_TRIO) {                                          // :890-907
+                uint32_t rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
+                if (live && i >= 2) {
+                    if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
+                    if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
+                    int row = -1;
+                    if (th[u].y) {
+                        if (e0[u].x == l1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
+                        else
+                            for (uint32_t j = 1; j < th[u].y; ++j) {
+                                const uint4 e = trio_ent[th[u].x + j];
+                                if (e.x == l1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
+                            }
+                    }
+                    if (row >= 0) {
+                        const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
+                        if (sum) atomicAdd(&trio_bases[row], sum);
+                    }
                 }
             }
         }
@@ -272,9 +319,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 // other waves.  One cheap pass over the steps of long walks adds the node lengths of all steps but the last into
 // long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
 __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ step_read, const uint8_t *__restrict__ step_dup,
-                                                       const uint4 *__restrict__ read_rec, const int32_t *__restrict__ slot_species,
-                                                       const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ sp_first_id,
-                                                       const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec,
+                                                       const uint4 *__restrict__ read_rec, const uint4 *__restrict__ slot_rec,
+                                                       const uint32_t *__restrict__ node_id, const uint4 *__restrict__ node_rec,
                                                        uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
     const int lane = threadIdx.x & 63;
     for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)); base < T; base += (uint64_t)gridDim.x * 256) {
@@ -284,11 +330,11 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
         uint32_t slot = NO_SLOT, nl = 0;
         if (code & STEP_LONG) slot = step_read[t];
         if (slot != NO_SLOT) {
-            const int sp = slot_species[slot];
+            const uint4 sr = slot_rec[slot];
             const uint4 rr = read_rec[slot];
-            if (sp >= 0 && (uint32_t)(t - rr.x) + 1 < rr.y) {        // not the last step
-                const uint32_t first_id = sp_first_id[sp], nb = node_base[sp], id = node_id[t];
-                if (id >= first_id && id - first_id < node_base[sp + 1] - nb) nl = node_rec[nb + (id - first_id)].z;
+            if ((int)sr.x >= 0 && (uint32_t)(t - rr.x) + 1 < rr.y) {        // not the last step
+                const uint32_t id = node_id[t];
+                if (id >= sr.y && id - sr.y < sr.w) nl = node_rec[sr.z + (id - sr.y)].z;
                 if (t == rr.x) long_len0[slot] = nl;                 // length of the walk's first node, for the lanes of later waves
             }
         }
@@ -431,7 +477,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     rd->T_pad = 0;
     rd->n_long = 0;
     PTX_HIP(ctx, rd->d_slot_of.alloc(rd->R ? rd->R : 1));
-    PTX_HIP(ctx, rd->d_g_sp.alloc(rd->R ? rd->R : 1));
+    PTX_HIP(ctx, rd->d_g_slot_rec.alloc(rd->R ? rd->R : 1));
     if (rd->R == 0) return 0;
     if (rd->T == 0) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_slot_of.p, 0xFF, rd->R * sizeof(uint32_t), ctx->stream));
@@ -522,8 +568,8 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");
         hipLaunchKernelGGL(walk_sum_kernel, dim3(grid_for(rd->T_pad, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
-                           rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, db->d_sp_first_id.p, db->d_node_base.p,
-                           db->d_node_rec.p, rd->d_long_sum.p, rd->d_long_len0.p);
+                           rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, db->d_node_rec.p, rd->d_long_sum.p,
+                           rd->d_long_len0.p);
     }
     PTX_HIP(ctx, hipGetLastError());
     db->cov_prepared = true;
@@ -535,12 +581,27 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     db->cov_prepared = false;
     unsigned long long *d_abort = db->d_abort;
     if (rd->R && rd->T_pad) {
-        int grid = (int)((rd->T_pad + COV_CHUNK - 1) / COV_CHUNK);
+        // U groups of 64 steps in flight per wave, PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another
+        // instantiation, for measurements)
+        int shape = 22;
+        if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
         KTimer t(ctx, "coverage_step_kernel");
-#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_sp.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_sp_first_id.p, \
-                  db->d_node_base.p, db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_node.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, rd->d_long_len0.p
-        if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
-        else hipLaunchKernelGGL((coverage_step_kernel<false>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);
+#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
+                  db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, rd->d_long_len0.p
+#define COVS_LAUNCH(UU, PP)                                                                                                                  \
+        {                                                                                                                                    \
+            const int grid = (int)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));                       \
+            if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS); \
+            else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);          \
+        }
+        switch (shape) {
+            case 14: COVS_LAUNCH(1, 4) break;
+            case 21: COVS_LAUNCH(2, 1) break;
+            case 41: COVS_LAUNCH(4, 1) break;
+            case 42: COVS_LAUNCH(4, 2) break;
+            default: COVS_LAUNCH(2, 2) break;
+        }
+#undef COVS_LAUNCH
 #undef COVS_ARGS
     }
     PTX_HIP(ctx, hipGetLastError());

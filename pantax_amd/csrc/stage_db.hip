@@ -23,7 +23,7 @@ struct NodeTableStore {
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t l) const {
         const uint64_t bo = base + excl;
         bit_off[i] = bo;
-        node_rec[i] = make_uint4((uint32_t)bo, (uint32_t)(bo >> 32), l, 0u);
+        node_rec[i] = nr_make(bo, l);
     }
 };
 
@@ -42,12 +42,15 @@ __global__ void __launch_bounds__(256) walk_check_kernel(const uint64_t *__restr
 
 // species-local lookup heads / rows -> their place in the batch
 __global__ void __launch_bounds__(256) trio_rebase_kernel(uint32_t n_nodes, uint32_t n_rows, uint32_t row_base, uint32_t *__restrict__ first /* [n_nodes] slice */,
-                                                          uint32_t next_first_local /* = local first[n_nodes] */, uint2 *__restrict__ node,
-                                                          uint4 *__restrict__ ent /* [n_rows] slice */) {
+                                                          uint32_t next_first_local /* = local first[n_nodes] */, uint4 *__restrict__ node_rec,
+                                                          uint4 *__restrict__ ent /* [n_rows] slice */, uint32_t *__restrict__ err) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_nodes) {
         const uint32_t f = first[i], nx = i + 1 < n_nodes ? first[i + 1] : next_first_local;
-        node[i] = make_uint2(f + row_base, nx - f);
+        if (nx - f >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+        uint4 r = node_rec[i];
+        r.y = (r.y & 0xFFu) | ((nx - f) << 8); r.w = f + row_base;   // the lookup head rides in the node record
+        node_rec[i] = r;
     }
     if (i < n_rows) ent[i].z += row_base;
 }
@@ -70,13 +73,13 @@ int node_tables_launch(Ctx *ctx, Db *db, const uint64_t *sp_bits /*[S+1] prefix 
     return 0;
 }
 
-int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows) {
+int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows, uint32_t *d_err) {
     const uint64_t nb = db->h_node_off[s], n = db->h_node_off[s + 1] - nb;
     const uint32_t m = (uint32_t)std::max<uint64_t>(n, n_rows);
     if (m == 0) return 0;
     // heads first (they read the local firsts), then the firsts themselves move
     hipLaunchKernelGGL(trio_rebase_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t)n, (uint32_t)n_rows, (uint32_t)row_base,
-                       db->d_trio_first.p + nb, (uint32_t)n_rows, db->d_trio_node.p + nb, db->d_trio_ent.p + row_base);
+                       db->d_trio_first.p + nb, (uint32_t)n_rows, db->d_node_rec.p + nb, db->d_trio_ent.p + row_base, d_err);
     if (n && row_base) hipLaunchKernelGGL(add_u32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n, db->d_trio_first.p + nb, (uint32_t)row_base);
     PTX_HIP(ctx, hipGetLastError());
     return 0;

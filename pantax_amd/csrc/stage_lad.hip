@@ -373,12 +373,14 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
 }
 
 constexpr int RATIO_CHUNKS = 128;
+constexpr int ROW_ITEMS = 8;   // nodes per thread of the row compaction kernels
 // path_cov_ratio sums (profile.rs:1344-1361): per candidate k, sum of covered bases and of lengths over its
 // nodes.  The first 8 candidates (nearly always all of them) accumulate in registers and are combined by wave
 // reductions; 64 lanes hammering 2-4 LDS addresses with 64-bit atomics serialise.
 __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
-                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio) {
+                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio,
+                                                    const double *__restrict__ ab, uint32_t *__restrict__ seg_cnt /* null, or [S]: LP rows per species */) {
     __shared__ unsigned long long acc[LAD_MAXP * 2];
     const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
     if (sp_p[s] <= 0) return;
@@ -389,9 +391,11 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t n_rows = 0;
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
         if (!m) continue;
+        if (seg_cnt && ab[v] > 0.0) ++n_rows;   // an LP row: a_v > 0 on at least one candidate path
         const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -416,8 +420,74 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
             if (ls) atomicAdd(&acc[2 * k + 1], ls);
         }
     }
+    if (seg_cnt) {
+        n_rows = wave_reduce(n_rows, [](uint32_t x, uint32_t y) { return x + y; });
+        if ((threadIdx.x & 63) == 0 && n_rows) atomicAdd(&seg_cnt[s], n_rows);
+    }
     __syncthreads();
     if (threadIdx.x < LAD_MAXP * 2 && acc[threadIdx.x]) atomicAdd(&ratio[(size_t)s * LAD_MAXP * 2 + threadIdx.x], acc[threadIdx.x]);
+}
+
+// species segments of the LP rows: seg_off = exclusive prefix of the per-species row counts (one workgroup; S is a few
+// thousand at most), total -> *n_rows
+__global__ void __launch_bounds__(256) seg_scan_kernel(uint32_t S, const uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_off, uint32_t *__restrict__ n_rows) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < S; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < S ? seg_cnt[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(v, s_wave, &tot);
+        if (i < S) seg_off[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { seg_off[S] = carry; *n_rows = carry; }
+}
+// The rows again, species by species: a workgroup's tile of nodes nearly always lies inside one species, whose segment it
+// extends with one atomic; a tile across a species border places its rows one by one.  k0 = species, k1 = mask, k2 = a.
+__global__ void __launch_bounds__(256) row_emit_seg_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
+                                                           const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ seg_off,
+                                                           uint32_t *__restrict__ seg_cur, uint64_t *__restrict__ k0, uint64_t *__restrict__ k1,
+                                                           uint64_t *__restrict__ k2) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * 256 * ROW_ITEMS;
+    const uint64_t base = tile0 + (uint64_t)threadIdx.x * ROW_ITEMS;
+    // species of the tile's first and last node (workgroup-uniform searches)
+    auto species_of = [&](uint64_t v) { uint32_t lo = 0, hi = S; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; } return lo - 1; };
+    const uint64_t tile_last = tile0 + 256 * ROW_ITEMS - 1 < V ? tile0 + 256 * ROW_ITEMS - 1 : V - 1;
+    const uint32_t sp_a = species_of(tile0), sp_b = species_of(tile_last);
+    double a[ROW_ITEMS];
+    unsigned long long m[ROW_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < ROW_ITEMS; ++i) {
+        const uint64_t v = base + i;
+        a[i] = 0.0; m[i] = 0;
+        if (v < V) { a[i] = ab[v]; m[i] = mask[v]; }
+        cnt += (a[i] > 0.0 && m[i] != 0ull) ? 1u : 0u;
+    }
+    if (sp_a == sp_b) {
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(cnt, s_wave, &tot);
+        if (threadIdx.x == 0) s_base = tot ? seg_off[sp_a] + atomicAdd(&seg_cur[sp_a], tot) : 0u;
+        __syncthreads();
+        uint32_t j = s_base + ex;
+#pragma unroll
+        for (int i = 0; i < ROW_ITEMS; ++i) {
+            if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
+            k0[j] = sp_a; k1[j] = m[i]; k2[j] = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
+            ++j;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ROW_ITEMS; ++i) {
+            if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
+            const uint32_t sp = species_of(base + i);
+            const uint32_t j = seg_off[sp] + atomicAdd(&seg_cur[sp], 1u);
+            k0[j] = sp; k1[j] = m[i]; k2[j] = (uint64_t)__double_as_longlong(a[i]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,7 +497,6 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
 // One launch: every workgroup compacts its tile of nodes and claims its output range with a single atomic
 // on the row counter.  Row order across workgroups is arbitrary, which is immaterial: the rows are sorted by
 // their full key (species, mask, a) next, and rows with equal keys are indistinguishable.
-constexpr int ROW_ITEMS = 8;
 __global__ void __launch_bounds__(256) row_emit_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
                                                        const unsigned long long *__restrict__ mask, uint32_t *__restrict__ n_rows,
                                                        uint64_t *__restrict__ k0, uint64_t *__restrict__ k1, uint64_t *__restrict__ k2,
@@ -553,13 +622,26 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
                                db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
     }
+    // rows: compact -> sort by (species, mask, a)
+    Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
+    // Many species, each small enough for the sample sort: the rows are emitted species by species (segment sizes counted
+    // by the ratio pass) and every segment is sorted by (mask, a) in one batch -- three passes over the rows instead of the
+    // 11 of the LSD radix sort
+    uint64_t max_vs = 0;
+    for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
+    bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
+    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) { if (ev[0] == 'r') use_seg = false; }   // "radix": measurements / tests
+    uint32_t *d_seg_cnt = nullptr, *d_seg_cur = nullptr, *d_seg_off = nullptr;
+    if (use_seg) {
+        PTX_HIP(ctx, dbm->d_seg.alloc(3ull * S + 2));
+        d_seg_cnt = dbm->d_seg.p; d_seg_cur = d_seg_cnt + S; d_seg_off = d_seg_cur + S;
+        PTX_HIP(ctx, hipMemsetAsync(d_seg_cnt, 0, 2ull * S * sizeof(uint32_t), ctx->stream));
+    }
     {
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
-                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
+                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p, lb->d_ab.p, d_seg_cnt);
     }
-    // rows: compact -> sort by (species, mask, a)
-    Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
     DevBuf<uint32_t> &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
@@ -571,8 +653,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // whenever their bits fit (16-byte records instead of 24)
     const int sp_bits = S > 1 ? bits_for(S - 1) : 0;
     const bool use_sample = V <= SS_MAX_N;
-    const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64) ? pmax_bound : -1;
-    {
+    const int pack_shift = (!use_sample && !use_seg && sp_bits + pmax_bound <= 64) ? pmax_bound : -1;
+    if (use_seg) {
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, S, d_seg_cnt, d_seg_off, d_n);
+        KTimer t(ctx, "row_emit_kernel");
+        const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
+        hipLaunchKernelGGL(row_emit_seg_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
+                           (unsigned long long *)lb->d_mask.p, d_seg_off, d_seg_cur, ka[0].p, ka[1].p, ka[2].p);
+    } else {
         KTimer t(ctx, "row_emit_kernel");   // d_n was zeroed with the step's result arena
         const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
         hipLaunchKernelGGL(row_emit_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
@@ -582,7 +670,10 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     A.nw = B.nw = pack_shift >= 0 ? 2 : 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
     bool in_b = false;
-    if (use_sample) {   // few rows: sample sort (6 launches) instead of 10+ radix passes of 3 launches each
+    if (use_seg) {
+        PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_seg_ws_elems(S, V)));
+        PTX_TRY(sample_sort_seg(ctx, ka[1].p, ka[2].p, kb[1].p, kb[2].p, S, max_vs, V, d_seg_off, d_seg_cnt, dbm->d_ss_ws.p));
+    } else if (use_sample) {   // few rows: sample sort (6 launches) instead of 10+ radix passes of 3 launches each
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_ws_elems(V)));
         PTX_TRY(sample_sort3(ctx, A, B, V, dbm->d_ss_ws.p, d_n));
     } else {

@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
 constexpr int TRIO_BLK_SHIFT = 8, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 2048;
 constexpr unsigned long long TB_EMPTY = ~0ull;
 constexpr uint32_t TB_MULTI = 0xFFFFFFFFu;
+constexpr int TB_UNR = 4;
 // slot = {64-bit key, u32 q}: q is the position of the window's only occurrence, or TB_MULTI once a second one arrived
 // (both sides use atomicMax, so the outcome does not depend on who comes first; positions are < 2^32 - 1)
 __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s_q, uint32_t *s_over, uint32_t a_l, uint32_t b, uint32_t c,
@@ -208,11 +209,11 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                                                          const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
                                                          uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
     __shared__ unsigned long long s_key[TB_SLOTS];
-    __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over;
+    __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[256], s_wave[4];
+    __shared__ uint4 s_run[256];
     const uint4 rec = blk_rec[blockIdx.x];
     const uint32_t nn = blk_rec[blockIdx.x + 1].z - rec.z;
     const uint32_t r0 = rec.x, r1 = rec.y, n0 = rec.w;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t nsub = 1;; nsub <<= 1) {
         for (int i = threadIdx.x; i < TRIO_BLK; i += 256) s_ncnt[i] = 0;
         bool over = false;
@@ -220,16 +221,44 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
             for (int i = threadIdx.x; i < TB_SLOTS; i += 256) { s_key[i] = TB_EMPTY; s_q[i] = 0; }
             if (threadIdx.x == 0) s_over = 0;
             __syncthreads();
-            for (uint32_t r = r0 + wave; r < r1; r += 4) {
-                const uint4 run = runs[r];                                   // {first position, #positions, walk begin, walk end}
-                for (uint32_t i = lane; i < run.y; i += 64) {
-                    const uint32_t p = run.x + i, x = path_nodes[p];
-                    const bool fw = p + 2 < run.w, bw = p >= run.z + 2;
-                    const uint32_t c1 = fw ? path_nodes[p + 2] : 0u, b1 = fw ? path_nodes[p + 1] : 0u;
-                    const uint32_t c2 = bw ? path_nodes[p - 2] : 0u, b2 = bw ? path_nodes[p - 1] : 0u;
-                    if (fw && x <= c1) tb_insert(s_key, s_q, &s_over, x - n0, b1, c1, p, nsub - 1, j);
-                    if (bw && x < c2) tb_insert(s_key, s_q, &s_over, x - n0, b2, c2, p - 2, nsub - 1, j);
+            // the block's runs go to LDS 256 at a time; their positions are then handed out flat over the workgroup, four per
+            // thread and round with all loads of a round issued before the first table operation (a wave per run would walk
+            // run -> positions -> table three times in a row, each a dependent trip to memory)
+            for (uint32_t rb = r0; rb < r1; rb += 256) {
+                const uint32_t n_r = r1 - rb < 256u ? r1 - rb : 256u;
+                uint4 run = make_uint4(0u, 0u, 0u, 0u);
+                if (threadIdx.x < n_r) run = runs[rb + threadIdx.x];
+                uint32_t total;
+                const uint32_t excl = block_excl_scan<256>(run.y, s_wave, &total);
+                s_run[threadIdx.x] = run; s_pref[threadIdx.x] = excl;
+                __syncthreads();
+                for (uint32_t idx0 = threadIdx.x; idx0 < total; idx0 += 256 * TB_UNR) {
+                    uint32_t x[TB_UNR], pp[TB_UNR], b1[TB_UNR], c1[TB_UNR], b2[TB_UNR], c2[TB_UNR];
+                    bool fw[TB_UNR], bw[TB_UNR];
+#pragma unroll
+                    for (int u = 0; u < TB_UNR; ++u) {
+                        const uint32_t idx = idx0 + u * 256;
+                        fw[u] = bw[u] = false;
+                        x[u] = pp[u] = b1[u] = c1[u] = b2[u] = c2[u] = 0u;
+                        if (idx < total) {
+                            uint32_t lo = 0, hi = n_r;             // last run whose first flat index is <= idx
+                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= idx) lo = mid; else hi = mid; }
+                            const uint4 rn = s_run[lo];
+                            const uint32_t pos = rn.x + (idx - s_pref[lo]);
+                            pp[u] = pos;
+                            x[u] = path_nodes[pos];
+                            fw[u] = pos + 2 < rn.w; bw[u] = pos >= rn.z + 2;
+                            if (fw[u]) { b1[u] = path_nodes[pos + 1]; c1[u] = path_nodes[pos + 2]; }
+                            if (bw[u]) { b2[u] = path_nodes[pos - 1]; c2[u] = path_nodes[pos - 2]; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < TB_UNR; ++u) {
+                        if (fw[u] && x[u] <= c1[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
+                        if (bw[u] && x[u] < c2[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
+                    }
                 }
+                __syncthreads();   // s_run / s_pref are reused by the next 256 runs
             }
             __syncthreads();
             over = s_over != 0;
@@ -328,11 +357,17 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
 struct TrioFirstLoad { const uint32_t *cnt; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return cnt[i]; } };
 struct TrioFirstStore {
     uint32_t *first;
-    uint2 *node;
+    uint4 *node_rec;   // the head {first row, #rows} rides in the node record the coverage kernel gathers anyway
     uint64_t V;
+    uint32_t *err;
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t c) const {
         first[i] = excl;
-        if (i < V) node[i] = make_uint2(excl, c);
+        if (i < V) {
+            if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+            uint32_t *w = reinterpret_cast<uint32_t *>(node_rec + i);
+            w[1] = (w[1] & 0xFFu) | (c << 8);
+            w[3] = excl;
+        }
     }
 };
 
@@ -419,7 +454,6 @@ int trio_index_build(Ctx *ctx, Db *db) {
     PTX_HIP(ctx, hipMemsetAsync(ts.zero_arena.p, 0, zwords * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
-    PTX_HIP(ctx, db->d_trio_node.alloc(V));
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
@@ -461,14 +495,14 @@ int trio_index_build(Ctx *ctx, Db *db) {
         }
         hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
-        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_trio_node.p, V}, V + 1, nullptr,
+        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
                                   "exclusive_scan"));
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
             PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
             PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (set PANTAX_TRIO_PATH=bucket)", tot[2]);
+            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (PANTAX_TRIO_PATH=bucket), or nodes with 2^24 unique-trio rows", tot[2]);
             db->U_known = tot[1];
         }
         const uint32_t Utot = (uint32_t)db->U_known;
@@ -487,7 +521,9 @@ int trio_index_build(Ctx *ctx, Db *db) {
         db->U = 0;
         PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_trio_node.p, 0, (V ? V : 1) * sizeof(uint2), ctx->stream));
+        // no walks at all: every lookup head is empty (first_cnt sits in the zeroed arena)
+        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
+                                  "exclusive_scan"));
     }
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
