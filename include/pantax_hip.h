@@ -223,6 +223,36 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
                          const uint32_t *cand_path_idx, const uint8_t *fixed_zero, double *x_out,
                          float *path_cov_ratio_out, double *obj_out, int32_t *status_out);
 
+/* The same seam for MANY species in one call (SURVEY.md 8b "pao_solve_batch": what the GPU wants -- one workgroup per
+ * species, all LPs side by side).  A Rust caller that keeps its own first filter (profile.rs:2969-3009 inside the rayon loop
+ * of :3297-3319) collects the arguments of its X_opt calls as arrays of offsets and gets every species' answer back.
+ * Species s owns nodes [node_off[s], node_off[s+1]), haplotypes [hap_off[s], hap_off[s+1]) and candidates
+ * [cand_off[s], cand_off[s+1]); path_off indexes path_nodes over all haplotypes of the batch; cand_path_idx is the
+ * haplotype's index WITHIN its species.  status[s]: 0 solved (or nothing to solve: no candidates), PANTAX_HIP_E_LIMIT (> 64
+ * candidates), PANTAX_HIP_E_SOLVER -- per species, like the reference drops only the species whose solver failed
+ * (profile.rs:2999-3003); the call itself fails only on invalid arguments or a HIP error. */
+typedef struct {
+    uint32_t n_species;
+    const uint64_t *node_off;       /* [S+1] */
+    const int64_t *node_len;        /* [V] */
+    const double *node_abundance;   /* [V] */
+    const uint64_t *node_base_cov;  /* [V] or NULL (only path_cov_ratio needs it) */
+    const uint64_t *hap_off;        /* [S+1] */
+    const uint64_t *path_off;       /* [H+1] */
+    const uint32_t *path_nodes;     /* [P] species-local 0-based node ids */
+    const uint64_t *cand_off;       /* [S+1] */
+    const uint32_t *cand_path_idx;  /* [C] possible_paths_idx of every species, concatenated */
+    const uint8_t *fixed_zero;      /* [C] or NULL: 1 pins x_k = 0 (second solve, profile.rs:1484-1488) */
+} pantax_hip_species_batch;
+typedef struct {
+    double *x;              /* [C] out */
+    float *path_cov_ratio;  /* [C] out or NULL */
+    double *obj;            /* [S] out or NULL */
+    int32_t *status;        /* [S] out */
+    int32_t *iters;         /* [S] out or NULL: pivots of the active-set solver */
+} pantax_hip_solution_batch;
+int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_batch *in, const pantax_hip_solution_batch *out);
+
 /* ---- pipeline seam: files in, files out (profile.rs:3325) -------------------------------- */
 typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = reference default under db/wd */
     const char *db, *wd, *output_dir;

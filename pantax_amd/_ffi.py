@@ -18,7 +18,7 @@ SYMBOLS = [
     "pantax_hip_db_upload", "pantax_hip_db_free", "pantax_hip_reads_upload", "pantax_hip_reads_free",
     "pantax_hip_bin_reads", "pantax_hip_species_profile", "pantax_hip_db_reset", "pantax_hip_abundance_filter",
     "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
-    "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_profile", "pantax_hip_profile_step", "pantax_hip_sort_rows",
+    "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_pao_solve_batch", "pantax_hip_profile", "pantax_hip_profile_step", "pantax_hip_sort_rows",
     "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter", "pantax_hip_db_save_images", "pantax_hip_db_load_images",
     "pantax_hip_gaf_load", "pantax_hip_gaf_load_device", "pantax_hip_reads_load_gaf", "pantax_hip_reads_set_flags", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
     "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free",
@@ -67,6 +67,16 @@ class SolveInfo(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("status1", C.c_int32), ("status2", C.c_int32), ("iters1", C.c_int32),
                 ("iters2", C.c_int32), ("n_rows", C.c_uint32), ("n_patterns", C.c_uint32), ("obj1", C.c_double),
                 ("obj2", C.c_double)]
+
+
+class SpeciesBatch(C.Structure):
+    _fields_ = [("n_species", C.c_uint32), ("node_off", C.c_void_p), ("node_len", C.c_void_p), ("node_abundance", C.c_void_p),
+                ("node_base_cov", C.c_void_p), ("hap_off", C.c_void_p), ("path_off", C.c_void_p), ("path_nodes", C.c_void_p),
+                ("cand_off", C.c_void_p), ("cand_path_idx", C.c_void_p), ("fixed_zero", C.c_void_p)]
+
+
+class SolutionBatch(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("path_cov_ratio", C.c_void_p), ("obj", C.c_void_p), ("status", C.c_void_p), ("iters", C.c_void_p)]
 
 
 class ProfilingConfig(C.Structure):

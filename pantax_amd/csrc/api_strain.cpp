@@ -260,6 +260,85 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     return strain_finish(ctx, db, cfg, species_active, species_coverage, met, info_out, nullptr, nullptr);
 }
 
+int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_batch *in, const pantax_hip_solution_batch *out) {
+    if (!ctx || !in || !out || !in->node_off || !in->node_len || !in->node_abundance || !in->hap_off || !in->path_off || !in->path_nodes ||
+        !in->cand_off || !in->cand_path_idx || !out->x || !out->status)
+        return PANTAX_HIP_E_INVALID;
+    const uint32_t S = in->n_species;
+    if (S == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: n_species == 0");
+    PTX_ENTER(ctx);
+    const uint64_t V = in->node_off[S], H = in->hap_off[S];
+    // a resident DB around the caller's graphs: species s takes the node ids node_off[s]+1 .. node_off[s+1]
+    std::vector<int64_t> rs(S), re(S);
+    for (uint32_t s = 0; s < S; ++s) {
+        if (in->node_off[s + 1] <= in->node_off[s]) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u has no nodes", s);
+        rs[s] = (int64_t)in->node_off[s] + 1; re[s] = (int64_t)in->node_off[s + 1];
+    }
+    pantax_hip_graphs g{S, rs.data(), re.data(), in->node_off, in->node_len, in->hap_off, in->path_off, in->path_nodes};
+    pantax_hip_db *db = nullptr;
+    PTX_TRY(pantax_hip_db_upload(ctx, &g, &db));
+    std::unique_ptr<pantax_hip_db, void (*)(pantax_hip_db *)> guard(db, [](pantax_hip_db *d) { delete d; });
+    LadBatch &lb = db->lad;
+    lb.S = S;
+    const ArenaLayout L(S, H);
+    PTX_TRY(bind_arena(ctx, db, lb, L));
+    std::vector<uint32_t> cov32(V ? V : 1, 0);
+    if (in->node_base_cov) for (uint64_t v = 0; v < V; ++v) cov32[v] = (uint32_t)in->node_base_cov[v];
+    PTX_TRY(upload(ctx, db->d_cov, cov32.data(), V));
+    PTX_TRY(upload(ctx, lb.d_ab, in->node_abundance, V));
+    std::vector<double> amax(S);
+    std::vector<uint32_t> nvalid(S);
+    lb.h_p.assign(S, 0);
+    lb.h_cand.assign((size_t)S * LAD_MAXP, 0);
+    std::vector<uint8_t> fixed((size_t)S * LAD_MAXP, 0);
+    int pmax = 1;
+    for (uint32_t s = 0; s < S; ++s) {
+        double mx = -INFINITY; uint32_t nv = 0;
+        for (uint64_t v = in->node_off[s]; v < in->node_off[s + 1]; ++v) { mx = std::max(mx, in->node_abundance[v]); if (in->node_abundance[v] > 0.0) ++nv; }
+        amax[s] = mx; nvalid[s] = nv;
+        const uint64_t c0 = in->cand_off[s], c1 = in->cand_off[s + 1], nh = in->hap_off[s + 1] - in->hap_off[s];
+        out->status[s] = 0;
+        if (c1 - c0 > (uint64_t)LAD_MAXP) { out->status[s] = PANTAX_HIP_E_LIMIT; continue; }   // this species only (the reference has no cap: INTEGRATION.md)
+        for (uint64_t k = c0; k < c1; ++k) {
+            if (in->cand_path_idx[k] >= nh) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u candidate %llu names path %u of %llu", s, (unsigned long long)(k - c0), in->cand_path_idx[k], (unsigned long long)nh);
+            lb.h_cand[(size_t)s * LAD_MAXP + (k - c0)] = in->cand_path_idx[k];
+            fixed[(size_t)s * LAD_MAXP + (k - c0)] = (in->fixed_zero && in->fixed_zero[k]) ? 1 : 0;
+        }
+        lb.h_p[s] = (int32_t)(c1 - c0);
+        pmax = std::max(pmax, (int)(c1 - c0));
+    }
+    PTX_TRY(upload(ctx, lb.d_amax, amax.data(), S));
+    PTX_TRY(upload(ctx, lb.d_nvalid, nvalid.data(), S));
+    PTX_TRY(lad_prepare(ctx, db, &lb, false, pmax));
+    PTX_TRY(upload(ctx, lb.d_fixed2, fixed.data(), fixed.size()));
+    PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax, nullptr, lb.d_fixed2.p, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));
+    std::vector<double> x((size_t)S * LAD_MAXP), obj(S);
+    std::vector<unsigned long long> ratio((size_t)S * LAD_MAXP * 2);
+    std::vector<int32_t> st(S), it(S);
+    std::vector<uint32_t> counts(4);
+    PTX_TRY(download(ctx, x.data(), lb.d_x.p, x.size()));
+    PTX_TRY(download(ctx, obj.data(), lb.d_obj.p, S));
+    PTX_TRY(download(ctx, st.data(), lb.d_status.p, S));
+    PTX_TRY(download(ctx, it.data(), lb.d_iters.p, S));
+    PTX_TRY(download(ctx, ratio.data(), lb.d_ratio.p, ratio.size()));
+    PTX_TRY(download(ctx, counts.data(), lb.d_counts.p, 4));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve_batch: more membership patterns than this build sizes for");
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint64_t c0 = in->cand_off[s];
+        const int p = lb.h_p[s];
+        for (int k = 0; k < p; ++k) {
+            out->x[c0 + k] = x[(size_t)s * LAD_MAXP + k];
+            if (out->path_cov_ratio) out->path_cov_ratio[c0 + k] = (float)ratio[((size_t)s * LAD_MAXP + k) * 2] / (float)ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+        }
+        if (out->obj) out->obj[s] = (p > 0 && nvalid[s]) ? obj[s] : 0.0;
+        if (out->iters) out->iters[s] = p > 0 ? it[s] : 0;
+        if (p > 0 && st[s] != 0) out->status[s] = PANTAX_HIP_E_SOLVER;
+    }
+    return 0;
+}
+
+// one species = a batch of one (same kernels, same answers)
 int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *node_len, const double *node_abundance,
                          const uint64_t *node_base_cov, uint32_t n_paths, const uint64_t *path_off, const uint32_t *path_nodes,
                          uint32_t n_cand, const uint32_t *cand_path_idx, const uint8_t *fixed_zero, double *x_out,
@@ -268,53 +347,13 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
     if (n_cand == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: no candidate paths (the reference skips the solver, profile.rs:2968)");
     if (n_cand > (uint32_t)LAD_MAXP) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: %u candidate paths; this build handles <= %d", n_cand, LAD_MAXP);
     PTX_ENTER(ctx);
-    // a one-species resident DB around the caller's graph
-    int64_t rs = 1, re = n_nodes;
-    uint64_t node_off[2] = {0, n_nodes}, hap_off[2] = {0, n_paths};
-    pantax_hip_graphs g{1, &rs, &re, node_off, node_len, hap_off, path_off, path_nodes};
-    pantax_hip_db *db = nullptr;
-    PTX_TRY(pantax_hip_db_upload(ctx, &g, &db));
-    std::unique_ptr<pantax_hip_db, void (*)(pantax_hip_db *)> guard(db, [](pantax_hip_db *d) { delete d; });
-    LadBatch &lb = db->lad;
-    lb.S = 1;
-    const ArenaLayout L(1, n_paths);
-    PTX_TRY(bind_arena(ctx, db, lb, L));
-    std::vector<uint32_t> cov32(n_nodes, 0);
-    if (node_base_cov) for (uint32_t v = 0; v < n_nodes; ++v) cov32[v] = (uint32_t)node_base_cov[v];
-    PTX_TRY(upload(ctx, db->d_cov, cov32.data(), n_nodes));
-    PTX_TRY(upload(ctx, lb.d_ab, node_abundance, n_nodes));
-    double amax = -INFINITY; uint32_t nvalid = 0;
-    for (uint32_t v = 0; v < n_nodes; ++v) { amax = std::max(amax, node_abundance[v]); if (node_abundance[v] > 0.0) ++nvalid; }
-    PTX_TRY(upload(ctx, lb.d_amax, &amax, 1));
-    PTX_TRY(upload(ctx, lb.d_nvalid, &nvalid, 1));
-    lb.h_p.assign(1, (int32_t)n_cand);
-    lb.h_cand.assign(LAD_MAXP, 0);
-    for (uint32_t k = 0; k < n_cand; ++k) {
-        if (cand_path_idx[k] >= n_paths) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: candidate %u names path %u of %u", k, cand_path_idx[k], n_paths);
-        lb.h_cand[k] = cand_path_idx[k];
-    }
-    PTX_TRY(lad_prepare(ctx, db, &lb, false, (int)n_cand));
-    std::vector<uint8_t> fixed(LAD_MAXP, 0);
-    for (uint32_t k = 0; k < n_cand; ++k) fixed[k] = (fixed_zero && fixed_zero[k]) ? 1 : 0;
-    PTX_TRY(upload(ctx, lb.d_fixed2, fixed.data(), fixed.size()));
-    PTX_TRY(lad_solve_launch(ctx, db, &lb, (int)n_cand, nullptr, lb.d_fixed2.p, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));
-    std::vector<double> x(LAD_MAXP);
-    std::vector<unsigned long long> ratio(LAD_MAXP * 2);
-    std::vector<uint32_t> counts(4);
-    double obj = 0.0; int32_t st = 0, it = 0;
-    PTX_TRY(download(ctx, x.data(), lb.d_x.p, LAD_MAXP));
-    PTX_TRY(download(ctx, &obj, lb.d_obj.p, 1));
-    PTX_TRY(download(ctx, &st, lb.d_status.p, 1));
-    PTX_TRY(download(ctx, &it, lb.d_iters.p, 1));
-    PTX_TRY(download(ctx, ratio.data(), lb.d_ratio.p, ratio.size()));
-    PTX_TRY(download(ctx, counts.data(), lb.d_counts.p, 4));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: more membership patterns than this build sizes for");
-    for (uint32_t k = 0; k < n_cand; ++k) x_out[k] = x[k];
-    if (path_cov_ratio_out) for (uint32_t k = 0; k < n_cand; ++k) path_cov_ratio_out[k] = (float)ratio[2 * k] / (float)ratio[2 * k + 1];
-    if (obj_out) *obj_out = nvalid ? obj : 0.0;
-    if (status_out) *status_out = st;
-    if (st != 0) return fail(ctx, PANTAX_HIP_E_SOLVER, "pao_solve: LAD solver stopped with status %d after %d pivots", st, it);
+    const uint64_t node_off[2] = {0, n_nodes}, hap_off[2] = {0, n_paths}, cand_off[2] = {0, n_cand};
+    const pantax_hip_species_batch in{1, node_off, node_len, node_abundance, node_base_cov, hap_off, path_off, path_nodes, cand_off, cand_path_idx, fixed_zero};
+    int32_t st = 0, it = 0;
+    const pantax_hip_solution_batch out{x_out, path_cov_ratio_out, obj_out, &st, &it};
+    PTX_TRY(pantax_hip_pao_solve_batch(ctx, &in, &out));
+    if (status_out) *status_out = st == PANTAX_HIP_E_SOLVER ? 1 : st;
+    if (st != 0) return fail(ctx, PANTAX_HIP_E_SOLVER, "pao_solve: LAD solver stopped after %d pivots", it);
     return 0;
 }
 

@@ -206,8 +206,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             const uint32_t i = ok[u] ? ti[u] - b : 0u;
             dist[u] = ok[u] ? (int)min(i, (uint32_t)lane) : 0;        // earlier steps of my read held by lower lanes
             cross[u] = ok[u] && (int)i > lane;                        // the walk began before this wave (more than 64 steps)
-            l1[u] = __shfl_up(l[u], 1); l2[u] = __shfl_up(l[u], 2);
-            const uint32_t tf2 = __shfl_up(nr[u].w, 2), tn2 = __shfl_up(nr[u].y >> 8, 2);
+            // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
+            l1[u] = wave_shr1(l[u]); l2[u] = wave_shr1(l1[u]);
+            const uint32_t tf2 = wave_shr1(wave_shr1(nr[u].w)), tn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
             th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u);
             if (WITH_TRIO && ok[u] && i >= 2) {
                 if (lane < 1) l1[u] = node_id[b + i - 1] - sr[u].y;
@@ -248,16 +249,12 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 if (i == 0) atomicAdd(n_abort, 1ull);
                 live = false;
             }
-            // ---- `seen` before this step = sum of the aligned lengths of steps 0..i-1: segmented wave scan
+            // ---- `seen` before this step = sum of the aligned lengths of steps 0..i-1 of MY read: a plain wave prefix sum (DPP)
+            // minus its value at the lane that holds step 0 -- the steps of a read sit in consecutive lanes (mod 2^32 like the adds)
             const uint32_t contrib = live ? (i == 0 ? nl - ps : nl) : 0u;
-            uint32_t incl = contrib;
             const int dst = dist[u];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                if (d == 16 && !__any(dst >= 16)) break;              // short walks: four steps cover every read of the wave
-                uint32_t up = __shfl_up(incl, d);
-                if (dst >= d) incl += up;
-            }
+            const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
+            const uint32_t seen_in_wave = pexcl - __shfl(pexcl, lane - dst);
             // ---- first occurrence of this node in the read (:879): decided at upload time (step codes above)
             const uint32_t id0 = __shfl(id[u], lane - dst);           // id of step 0 when the walk starts in this wave
             uint32_t rl = 0;
@@ -268,7 +265,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 uint32_t aln, sidx;
                 if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
                 else if (i == k - 1) {                                // :857-859
-                    uint32_t seen = incl - contrib;
+                    uint32_t seen = seen_in_wave;
                     if (cross[u]) seen = long_sum[slot[u]] - ps;      // all steps but the last, from walk_sum_kernel
                     aln = target > (long long)seen ? (uint32_t)(target - (long long)seen) : 0u;   // max(target - seen, 0)
                     sidx = 0;
@@ -282,7 +279,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 } else rl = (jf == 0) ? (len0[u] - ps) : nl;
             }
             if (WITH_TRIO) {                                          // :890-907
-                uint32_t rl1 = __shfl_up(rl, 1), rl2 = __shfl_up(rl, 2);
+                uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(wave_shr1(rl));
                 if (live && i >= 2) {
                     if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
                     if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
@@ -583,7 +580,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     if (rd->R && rd->T_pad) {
         // U groups of 64 steps in flight per wave, PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another
         // instantiation, for measurements)
-        int shape = 22;
+        int shape = 14;
         if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
         KTimer t(ctx, "coverage_step_kernel");
 #define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
@@ -595,11 +592,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);          \
         }
         switch (shape) {
-            case 14: COVS_LAUNCH(1, 4) break;
+            case 22: COVS_LAUNCH(2, 2) break;
             case 21: COVS_LAUNCH(2, 1) break;
             case 41: COVS_LAUNCH(4, 1) break;
             case 42: COVS_LAUNCH(4, 2) break;
-            default: COVS_LAUNCH(2, 2) break;
+            default: COVS_LAUNCH(1, 4) break;
         }
 #undef COVS_LAUNCH
 #undef COVS_ARGS

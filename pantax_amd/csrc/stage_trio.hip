@@ -207,7 +207,7 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
 // the table (the node count of a block is the distance to the next block's first node)
 __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
                                                          const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
-                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
+                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, int ablate) {
     __shared__ unsigned long long s_key[TB_SLOTS];
     __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[256], s_wave[4];
     __shared__ uint4 s_run[256];
@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                             const uint4 rn = s_run[lo];
                             const uint32_t pos = rn.x + (idx - s_pref[lo]);
                             pp[u] = pos;
+                            if (ablate == 3) { x[u] = pos * 7u; fw[u] = true; b1[u] = pos; c1[u] = pos * 9u + 1u; continue; }
                             x[u] = path_nodes[pos];
                             fw[u] = pos + 2 < rn.w; bw[u] = pos >= rn.z + 2;
                             if (fw[u]) { b1[u] = path_nodes[pos + 1]; c1[u] = path_nodes[pos + 2]; }
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                     }
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
+                        if (ablate == 2) { if (x[u] + b1[u] + c1[u] + b2[u] + c2[u] == 0xFFFFFFF1u) s_over = 1; continue; }
                         if (fw[u] && x[u] <= c1[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
                         if (bw[u] && x[u] < c2[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
                     }
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                 for (int i = threadIdx.x; i < TB_SLOTS; i += 256) {
                     const unsigned long long k = s_key[i];
                     const uint32_t q = s_q[i];
-                    if (k != TB_EMPTY && q != TB_MULTI) { uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
+                    if (k != TB_EMPTY && q != TB_MULTI) { if (ablate != 1) uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
                 }
             __syncthreads();
         }
@@ -315,38 +317,50 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(TRIO_GRAPH_ARGS, co
 // 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
 //     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
 __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
-                                                          const uint64_t *__restrict__ bit_off, const uint8_t *__restrict__ uniq_q,
+                                                          const uint32_t *__restrict__ node_len, const uint8_t *__restrict__ uniq_q,
                                                           const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
                                                           uint32_t *__restrict__ cursor, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
                                                           uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
-    __shared__ uint32_t s_wave[4];
+    constexpr int NR = PATH_TILE / 256;   // rounds of 256 consecutive positions
+    __shared__ uint32_t s_wave[NR][4];
     const uint2 tile = tiles[blockIdx.x];
     if (tile.x == 0xFFFFFFFFu) return;   // filler tile
     const uint32_t h = tile.x;
     const uint64_t qend = path_off[h + 1], qt0 = path_off[h] + (uint64_t)tile.y * PATH_TILE;
     const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t carry = tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
-    for (int r = 0; r < PATH_TILE / 256; ++r) {          // 256 consecutive positions per round: row = carry + rank in the round
+    const uint32_t carry0 = tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
+    // all rounds at once: the flags of the four rounds are loaded together, ONE barrier orders the wave counts, and the
+    // gathers / writes of the unique windows of all rounds are in flight together (row = rank of the window in the tile)
+    uint32_t u[NR];
+    unsigned long long bal[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         const uint64_t q = qt0 + (uint64_t)r * 256 + threadIdx.x;
-        const uint32_t u = (q < qend) ? uniq_q[q] : 0u;
-        const unsigned long long bal = __ballot(u != 0);
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
+        u[r] = (q < qend) ? uniq_q[q] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bal[r] = __ballot(u[r] != 0);
+        if (lane == 0) s_wave[r][wave] = (uint32_t)__popcll(bal[r]);
+    }
+    __syncthreads();
+    uint32_t carry = carry0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
         uint32_t woff = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; if (w < wave) woff += t; tot += t; }
-        __syncthreads();
-        if (u) {
-            const uint32_t row = carry + woff + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[r][w]; if (w < wave) woff += t; tot += t; }
+        if (u[r]) {
+            const uint64_t q = qt0 + (uint64_t)r * 256 + threadIdx.x;
+            const uint32_t row = carry + woff + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
             uint32_t g, a, b, c;
             window_of(q, qend, nbase, path_nodes, g, a, b, c);
             const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
             trio_ent[j] = make_uint4(b, c, row, 0u);
             abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
             hap_out[row] = h - (uint32_t)hap_off[sidx];
-            len_out[row] = (uint32_t)((bit_off[nbase + a + 1] - bit_off[nbase + a]) + (bit_off[nbase + b + 1] - bit_off[nbase + b]) +
-                                      (bit_off[nbase + c + 1] - bit_off[nbase + c]));
+            len_out[row] = node_len[nbase + a] + node_len[nbase + b] + node_len[nbase + c];   // profile.rs:712
         }
         carry += tot;
     }
@@ -364,9 +378,10 @@ struct TrioFirstStore {
         first[i] = excl;
         if (i < V) {
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
-            uint32_t *w = reinterpret_cast<uint32_t *>(node_rec + i);
-            w[1] = (w[1] & 0xFFu) | (c << 8);
-            w[3] = excl;
+            uint4 r = node_rec[i];            // whole records in and out: neighbouring lanes fill whole cache lines, which a
+            r.y = (r.y & 0xFFu) | (c << 8);   // store of two of the four words would make the L2 read back first
+            r.w = excl;
+            node_rec[i] = r;
         }
     }
 };
@@ -463,7 +478,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
     if (P && by_block) {
         KTimer t(ctx, "trio_block_kernel");
         hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(256), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,
-                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
+                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, std::getenv("PANTAX_TRIO_ABLATE") ? std::atoi(std::getenv("PANTAX_TRIO_ABLATE")) : 0);
     }
     if (P) {
         if (!by_block) {
@@ -511,7 +526,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
-            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_bit_off.p,
+            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p,
                                ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.cursor2.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p,
                                db->d_trio_len.p);
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,

@@ -60,6 +60,23 @@ __device__ __forceinline__ void wave_reduce_pair(A &a, B &b, Better better) {
     a = ra; b = rb;
 }
 
+// whole-wave shift towards higher lanes by one: lane i receives lane i-1's value, lane 0 `fill` (DPP wave_shr:1 -- a VALU
+// move, where __shfl_up is a round trip through the LDS crossbar)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill = 0u) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes on the DPP path: row_shr 1/2/4/8 inside the 16-lane rows (zero fill), then the
+// row totals travel by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  Wraps modulo 2^32 like the adds do.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
 #pragma unroll

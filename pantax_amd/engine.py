@@ -246,6 +246,37 @@ class Engine:
                                                   C.byref(obj), C.byref(st)))
         return x, ratio, obj.value, st.value
 
+    def pao_solve_batch(self, species, fixed_zero=None):
+        """The solver seam for many species in ONE call (pantax_hip_pao_solve_batch).  species: list of
+        (node_len, node_abundance, node_base_cov or None, path_off, path_nodes, cand) per species; fixed_zero: list of
+        per-species uint8 arrays or None.  -> list of (x, ratio, obj, status, iters) per species."""
+        S = len(species)
+        node_off = np.zeros(S + 1, dtype=np.uint64); hap_off = np.zeros(S + 1, dtype=np.uint64); cand_off = np.zeros(S + 1, dtype=np.uint64)
+        node_off[1:] = np.cumsum([len(sp[0]) for sp in species])
+        hap_off[1:] = np.cumsum([len(sp[3]) - 1 for sp in species])
+        cand_off[1:] = np.cumsum([len(sp[5]) for sp in species])
+        node_len = as_c(np.concatenate([sp[0] for sp in species]), np.int64)
+        ab = as_c(np.concatenate([sp[1] for sp in species]), np.float64)
+        cov = as_c(np.concatenate([np.zeros(len(sp[0]), dtype=np.uint64) if sp[2] is None else sp[2] for sp in species]), np.uint64)
+        offs, base = [np.zeros(1, dtype=np.uint64)], 0
+        for sp in species:
+            po = np.asarray(sp[3], dtype=np.uint64)
+            offs.append(po[1:] + np.uint64(base)); base += int(po[-1])
+        path_off = as_c(np.concatenate(offs), np.uint64)
+        path_nodes = as_c(np.concatenate([sp[4] for sp in species]), np.uint32)
+        cand = as_c(np.concatenate([np.asarray(sp[5], dtype=np.uint32) for sp in species]), np.uint32)
+        fz = None
+        if fixed_zero is not None:
+            fz = as_c(np.concatenate([np.zeros(len(sp[5]), dtype=np.uint8) if f is None else f for sp, f in zip(species, fixed_zero)]), np.uint8)
+        Cn = len(cand)
+        x = np.zeros(max(Cn, 1)); ratio = np.zeros(max(Cn, 1), dtype=np.float32)
+        obj = np.zeros(S); st = np.zeros(S, dtype=np.int32); it = np.zeros(S, dtype=np.int32)
+        bi = _ffi.SpeciesBatch(S, p(node_off), p(node_len), p(ab), p(cov), p(hap_off), p(path_off), p(path_nodes), p(cand_off), p(cand), p(fz))
+        bo = _ffi.SolutionBatch(p(x), p(ratio), p(obj), p(st), p(it))
+        self._check(self.lib.pantax_hip_pao_solve_batch(self.ctx, C.byref(bi), C.byref(bo)))
+        co = cand_off.astype(np.int64)
+        return [(x[co[s]:co[s + 1]].copy(), ratio[co[s]:co[s + 1]].copy(), float(obj[s]), int(st[s]), int(it[s])) for s in range(S)]
+
     # ------------------------------------------------------------------ pipeline seam
     def profile(self, db, wd, gaf, species=True, strain=True, output_dir=None, fr=0.3, fc=0.46, sr=0.85, sd=0.2,
                 min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,

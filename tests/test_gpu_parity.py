@@ -313,6 +313,40 @@ def test_pao_solve_vs_highs_golden(eng, golden_dir):
             assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
 
 
+def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
+    """pantax_hip_pao_solve_batch (arrays of offsets in, solutions out, host buffers): all 11 golden LPs as ONE
+    batch == the same LPs solved one call at a time, objectives == SciPy-HiGHS; a species without candidates and one with
+    65 candidates sit in the same batch and only they are affected."""
+    import os
+    z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
+    species, fixed, objs = [], [], []
+    for i in range(int(z["n_cases"])):
+        mask, a, ub = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i]
+        p = len(ub)
+        po, pn = _paths_from_masks(mask, p)
+        species.append((np.ones(len(a), dtype=np.int64), a, None, po, pn, np.arange(p)))
+        fixed.append((ub == 0).astype(np.uint8))
+        objs.append(float(z["obj_%d" % i]))
+    single = [eng.pao_solve(sp[0], sp[1], np.zeros(len(sp[1]), dtype=np.uint64), sp[3], sp[4], sp[5], fixed_zero=f) for sp, f in zip(species, fixed)]
+    # + a species with nothing to solve, + one beyond the 64-column word
+    po2, pn2 = _paths_from_masks(np.array([1, 3, 2], dtype=np.uint64), 2)
+    species.append((np.ones(3, dtype=np.int64), np.array([1.0, 2.0, 3.0]), None, po2, pn2, np.zeros(0, dtype=np.uint32)))
+    fixed.append(np.zeros(0, dtype=np.uint8))
+    n65 = 200
+    m65 = (np.uint64(1) << (np.arange(n65, dtype=np.uint64) % np.uint64(64)))
+    po65, pn65 = _paths_from_masks(m65, 64)
+    po65 = np.concatenate([po65, [po65[-1] + 1]]).astype(np.uint64); pn65 = np.concatenate([pn65, [0]]).astype(np.uint32)
+    species.append((np.ones(n65, dtype=np.int64), np.ones(n65), None, po65, pn65, np.arange(65)))
+    fixed.append(np.zeros(65, dtype=np.uint8))
+    batch = eng.pao_solve_batch(species, fixed)
+    for i, ((x1, r1, o1, st1), (xb, rb, ob, stb, itb)) in enumerate(zip(single, batch)):
+        assert st1 == 0 and stb == 0
+        assert np.array_equal(x1, xb) and o1 == ob, i                      # the same kernels: bit for bit
+        assert ob == pytest.approx(objs[i], rel=1e-9, abs=1e-12), i
+    assert batch[-2][3] == 0 and len(batch[-2][0]) == 0
+    assert batch[-1][3] == -4                                               # PANTAX_HIP_E_LIMIT for that species only
+
+
 def test_pao_solve_at_and_beyond_64_candidates(eng):
     """64 candidate paths is what the membership word holds: solved (objective == the oracle's exact LAD, which SciPy-HiGHS
     pins on the smaller golden cases); 65 is refused loudly, never approximated."""

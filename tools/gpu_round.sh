@@ -19,6 +19,7 @@ pmctrio) bash tools/pmc_step.sh cfg3 ${tag}_trio "SQ_WAVES SQ_WAVE_CYCLES SQ_WAI
 import json;d=json.load(open('gpurun_out/${tag}_pmc_trio.json'))
 for k in ('trio_block_kernel','coverage_step_kernel','trio_lookup_kernel'):
     print(k, {a:(round(b) if isinstance(b,float) else b) for a,b in d['kernels'].get(k,{}).items()})" ;;
+trioablate) for ab in 0 1 2 3 4; do PANTAX_TRIO_ABLATE=$ab timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 3 --warmup 3 > gpurun_out/${tag}_ab$ab.json 2> gpurun_out/${tag}_ab$ab.err; echo "ablate $ab"; python3 tools/bench_summary.py gpurun_out/${tag}_ab$ab.json | head -3 | cut -c1-330; done ;;
 bench2) ( time timeout 900 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 20 ) > gpurun_out/${tag}_qbench2.json 2> gpurun_out/${tag}_qbench2.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench2.json; tail -3 gpurun_out/${tag}_qbench2.err ;;
 covshapes) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 5 --warmup 3 > gpurun_out/${tag}_cov$sh.json 2> gpurun_out/${tag}_cov$sh.err; echo "shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov$sh.json | head -3; done ;;
 covshapes2) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 10 --warmup 3 > gpurun_out/${tag}_cov2_$sh.json 2> gpurun_out/${tag}_cov2_$sh.err; echo "cfg2 shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov2_$sh.json | head -3; done ;;
@@ -27,6 +28,7 @@ pmctrio) bash tools/pmc_step.sh cfg3 ${tag}_trio "SQ_WAVES SQ_WAVE_CYCLES SQ_WAI
 import json;d=json.load(open('gpurun_out/${tag}_pmc_trio.json'))
 for k in ('trio_block_kernel','coverage_step_kernel','trio_lookup_kernel'):
     print(k, {a:(round(b) if isinstance(b,float) else b) for a,b in d['kernels'].get(k,{}).items()})" ;;
+trioablate) for ab in 0 1 2 3 4; do PANTAX_TRIO_ABLATE=$ab timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 3 --warmup 3 > gpurun_out/${tag}_ab$ab.json 2> gpurun_out/${tag}_ab$ab.err; echo "ablate $ab"; python3 tools/bench_summary.py gpurun_out/${tag}_ab$ab.json | head -3 | cut -c1-330; done ;;
 bench2) ( time timeout 600 python bench.py --workload cfg2 ) > gpurun_out/${tag}_bench_cfg2.json 2> gpurun_out/${tag}_bench_cfg2.err; tail -c 600 gpurun_out/${tag}_bench_cfg2.json; tail -3 gpurun_out/${tag}_bench_cfg2.err ;;
 trace) bash tools/kernel_trace.sh cfg3 ${tag}_cfg3 6 ;;
 trace2) bash tools/kernel_trace.sh cfg2 ${tag}_cfg2 10 ;;
