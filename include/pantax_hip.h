@@ -308,6 +308,10 @@ int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t
                           const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names);
 void pantax_hip_graph_free(pantax_hip_graph *g);
 
+/* the float text of the two tables (polars CsvWriter behind rcls.rs:409-420: shortest round-trip digits, "16.0" for integral
+ * values; exemplar rows README.md:343, :354).  Host only.  Returns the length, or < 0. */
+int pantax_hip_format_f64(double v, char *buf, size_t cap);
+
 /* ---- measurement: HIP-event timings of kernels launched on the ctx stream ---------------- */
 int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on);
 int pantax_hip_timing_reset(pantax_hip_ctx *ctx);

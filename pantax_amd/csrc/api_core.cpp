@@ -277,6 +277,19 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         PTX_TRY(upload(ctx, db->d_tile_rank, tile_rank.data(), tile_rank.size()));
         PTX_TRY(upload(ctx, db->d_hap_tile_off, hap_tile_off.data(), hap_tile_off.size()));
     }
+    {   // node tiles of the LP row compaction (2048 nodes each): which species they start and end in
+        const uint64_t TILE = 2048, nt = (db->V + TILE - 1) / TILE;
+        std::vector<uint2> tsp(nt ? nt : 1, make_uint2(0u, 0u));
+        uint32_t sp = 0;
+        for (uint64_t t = 0; t < nt; ++t) {
+            const uint64_t v0 = t * TILE, v1 = std::min<uint64_t>(db->V, v0 + TILE) - 1;
+            while (sp + 1 < S && db->h_node_off[sp + 1] <= v0) ++sp;
+            uint32_t sl = sp;
+            while (sl + 1 < S && db->h_node_off[sl + 1] <= v1) ++sl;
+            tsp[t] = make_uint2(sp, sl);
+        }
+        PTX_TRY(upload(ctx, db->d_emit_tile_sp, tsp.data(), tsp.size()));
+    }
     lap("tiles");
     PTX_TRY(trio_runs_build(ctx, db.get()));
     lap("node-block runs");

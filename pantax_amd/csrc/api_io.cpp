@@ -1,4 +1,5 @@
 // api_io.cpp -- C ABI over the host readers (a1 GAF tokenizer, a6 graph loaders). Host only.
+#include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/pantax_hip.h"
@@ -61,5 +62,13 @@ int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t
     return 0;
 }
 void pantax_hip_graph_free(pantax_hip_graph *g) { delete g; }
+
+int pantax_hip_format_f64(double v, char *buf, size_t cap) {
+    if (!buf || cap == 0) return PANTAX_HIP_E_INVALID;
+    const std::string s = fmt_f64(v);
+    if (s.size() + 1 > cap) return PANTAX_HIP_E_LIMIT;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
 
 }  // extern "C"

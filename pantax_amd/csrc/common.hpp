@@ -226,6 +226,7 @@ struct Db {
     std::vector<uint8_t> h_all_same;
     DevBuf<uint2> d_tiles;           // path tiles {hap, chunk} ordered (species, chunk, hap); one workgroup each
     uint64_t n_tiles = 0;
+    DevBuf<uint2> d_emit_tile_sp;    // [ceil(V / 2048)] {species of the first node, of the last node} of every 2048-node tile of the row compaction
     DevBuf<uint32_t> d_tile_rank;    // [n_tiles] rank of the tile in path order (hap-major)
     DevBuf<uint32_t> d_hap_tile_off; // [H+1] first path-order tile of every haplotype
     // node-block run table of the walks (trio_runs_build, stage_trio.hip; a layout table like d_tiles, built once at upload):

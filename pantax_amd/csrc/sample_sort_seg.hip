@@ -4,8 +4,8 @@
 // over 2e7 16-byte records (33 launches, 2.5 ms on MI355X); sample sort touches every row three times.
 //
 // Same scheme as sample_sort.hip, with blockIdx.y = segment:
-//   1. ssg_gather / ssg_sample : 4096 evenly spaced rows of the segment ranked against each other -> 1023 splitters
-//                                (a segment of <= 4096 rows is ranked completely right there)
+//   1. ssg_gather / ssg_sample : 4096 evenly spaced rows of the segment sorted in LDS -> 1023 splitters
+//                                (a segment of <= 4096 rows is sorted completely right there)
 //   2. ssg_hist                : bucket id of every row (binary search over the splitters in LDS; "equal to splitter j"
 //                                is its own bucket 2j+1 whose rows need no sorting -- coverage values tie massively);
 //                                bucket totals by one global atomic per (workgroup, non-empty bucket)
@@ -90,34 +90,25 @@ __global__ void __launch_bounds__(256) ssg_gather_kernel(Seg sg, const uint64_t 
     if (i == 0) { w[SG_OFF_FLAGS] = small ? 1u : 0u; w[SG_OFF_FLAGS + 1] = 0; }
     w[SG_OFF_CNT + i] = 0;   // bucket totals and cursors (2 x 2048 words = the 4096 threads of this segment's gather)
 }
-// 256 workgroups x 16 samples, 16 lanes per sample (sample_sort.hip: ss_sample_kernel)
-__global__ void __launch_bounds__(256) ssg_sample_kernel(Seg sg, uint64_t *__restrict__ bm, uint64_t *__restrict__ ba) {
+// One 1024-thread workgroup per segment sorts its 4096 samples in LDS (bitonic network: 78 steps of 2 compare-exchanges
+// per thread); every 4th one in rank order is a splitter.  Ranking by all-pairs compares, as the single-segment sort does,
+// costs 4096^2 LDS reads per segment -- 0.77 ms of LDS bandwidth for 100 segments; the segments' networks run side by side.
+__global__ void __launch_bounds__(1024) ssg_sample_kernel(Seg sg, uint64_t *__restrict__ bm, uint64_t *__restrict__ ba) {
     __shared__ uint64_t km[SG_SAMPLE], ka[SG_SAMPLE];
-    const uint32_t s = blockIdx.y, n = sg.cnt[s], o = sg.off[s];
+    const uint32_t s = blockIdx.x, n = sg.cnt[s], o = sg.off[s];
     if (n == 0) return;
     uint32_t *w = sg.w(s);
     const uint64_t *samp = reinterpret_cast<const uint64_t *>(w + SG_OFF_SAMP);
     uint64_t *spl = reinterpret_cast<uint64_t *>(w + SG_OFF_SPL);
     const bool small = n <= (uint32_t)SG_SAMPLE;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)SG_SAMPLE; i += 256) { km[i] = samp[i]; ka[i] = samp[SG_SAMPLE + i]; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)SG_SAMPLE; i += 1024) { km[i] = samp[i]; ka[i] = samp[SG_SAMPLE + i]; }
     __syncthreads();
-    const uint32_t s_idx = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
-    if (small && blockIdx.x * 16 >= n) return;   // nothing of this workgroup's samples is a row (uniform)
-    const Key2 me{km[s_idx], ka[s_idx]};
-    uint32_t cnt = 0;
-#pragma unroll 8
-    for (uint32_t it = 0; it < (uint32_t)SG_SAMPLE / 16; ++it) {
-        const uint32_t j = it * 16 + part;
-        const Key2 ot{km[j], ka[j]};
-        cnt += ((int)less2(ot, me) | ((int)eq2(ot, me) & (int)(j < s_idx))) ? 1u : 0u;
-    }
-    cnt += dpp<0xB1>(cnt); cnt += dpp<0x4E>(cnt); cnt += dpp<0x124>(cnt); cnt += dpp<0x128>(cnt);
-    if (part == 0) {
-        if (small) {
-            if (s_idx < n) { bm[o + cnt] = me.m; ba[o + cnt] = me.a; }   // copied back by the local kernel
-        } else if ((cnt & 3u) == 3u && (cnt >> 2) < (uint32_t)SG_NSPLIT) {
-            spl[cnt >> 2] = me.m; spl[1024 + (cnt >> 2)] = me.a;
-        }
+    bitonic2<1024>(km, ka, SG_SAMPLE);
+    if (small) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) { bm[o + i] = km[i]; ba[o + i] = ka[i]; }   // every row, sorted; copied back by the local kernel
+    } else {
+        for (uint32_t r = threadIdx.x; r < (uint32_t)SG_SAMPLE; r += 1024)
+            if ((r & 3u) == 3u && (r >> 2) < (uint32_t)SG_NSPLIT) { spl[r >> 2] = km[r]; spl[1024 + (r >> 2)] = ka[r]; }
     }
 }
 
@@ -279,7 +270,7 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
     const uint32_t nb = (uint32_t)((seg_bound + SG_TILE - 1) / SG_TILE);
     { KTimer t(ctx, "ss_sample_kernel");
       hipLaunchKernelGGL(ssg_gather_kernel, dim3(SG_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sg, am, aa);
-      hipLaunchKernelGGL(ssg_sample_kernel, dim3(SG_SAMPLE / 16, S), dim3(256), 0, ctx->stream, sg, bm, ba); }
+      hipLaunchKernelGGL(ssg_sample_kernel, dim3(S), dim3(1024), 0, ctx->stream, sg, bm, ba); }
     { KTimer t(ctx, "ss_hist_kernel");
       hipLaunchKernelGGL(ssg_hist_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, sg, am, aa); }
     { KTimer t(ctx, "ss_scatter_kernel");

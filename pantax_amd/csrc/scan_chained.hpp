@@ -22,24 +22,33 @@ constexpr uint64_t ST_AGG = 1, ST_PREFIX = 2;
 __device__ __forceinline__ uint64_t st_pack(uint32_t epoch, uint64_t flag, uint32_t v) { return ((uint64_t)epoch << 34) | (flag << 32) | v; }
 
 // load(i) -> value of item i (i < n); store(i, exclusive prefix, value) consumes it.  Loads of a tile happen before
-// its stores, so in-place scans are fine.
+// its stores, so in-place scans are fine.  Both functors are called in STRIPED order (consecutive lanes = consecutive
+// items): whatever they touch in memory is coalesced, also 16-byte records; the blocked order the scan itself wants
+// (8 consecutive items per thread) is reached through two padded LDS transposes.
 template <class Load, class Store>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(Load load, Store store, uint64_t n, uint32_t *__restrict__ ws, uint32_t epoch,
                                                                   uint32_t *__restrict__ total) {
     __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
     __shared__ uint32_t s_tile, s_excl;
+    __shared__ uint32_t s_v[SCAN_BLOCK * (SCAN_ITEMS + 1)], s_p[SCAN_BLOCK * (SCAN_ITEMS + 1)];   // one pad word per thread row: no bank conflicts
     uint32_t *ticket = ws;
     uint64_t *state = reinterpret_cast<uint64_t *>(ws + 2);
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile, nb = gridDim.x;
     const int lane = threadIdx.x & 63;
-    const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const uint64_t tile_base = (uint64_t)tile * SCAN_TILE;
     uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const uint64_t idx = base + i;
-        v[i] = idx < n ? load(idx) : 0u;
+    for (int k = 0; k < SCAN_ITEMS; ++k) {      // striped: item j = k * 256 + thread
+        const uint32_t j = k * SCAN_BLOCK + threadIdx.x;
+        const uint64_t idx = tile_base + j;
+        s_v[j + j / SCAN_ITEMS] = idx < n ? load(idx) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {      // blocked: thread t owns items 8t .. 8t+7
+        v[i] = s_v[threadIdx.x * (SCAN_ITEMS + 1) + i];
         s += v[i];
     }
     uint32_t tot;
@@ -73,9 +82,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(Load load, Sto
     off += s_excl;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        const uint64_t idx = base + i;
-        if (idx < n) store(idx, off, v[i]);
+        s_p[threadIdx.x * (SCAN_ITEMS + 1) + i] = off;
         off += v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t j = k * SCAN_BLOCK + threadIdx.x;
+        const uint64_t idx = tile_base + j;
+        if (idx < n) store(idx, s_p[j + j / SCAN_ITEMS], s_v[j + j / SCAN_ITEMS]);
     }
     if (tile == nb - 1 && threadIdx.x == 0) {
         if (total) *total = s_excl + tot;

@@ -379,8 +379,7 @@ constexpr int ROW_ITEMS = 8;   // nodes per thread of the row compaction kernels
 // reductions; 64 lanes hammering 2-4 LDS addresses with 64-bit atomics serialise.
 __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
-                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio,
-                                                    const double *__restrict__ ab, uint32_t *__restrict__ seg_cnt /* null, or [S]: LP rows per species */) {
+                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio) {
     __shared__ unsigned long long acc[LAD_MAXP * 2];
     const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
     if (sp_p[s] <= 0) return;
@@ -391,11 +390,9 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t n_rows = 0;
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
         if (!m) continue;
-        if (seg_cnt && ab[v] > 0.0) ++n_rows;   // an LP row: a_v > 0 on at least one candidate path
         const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -420,74 +417,58 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
             if (ls) atomicAdd(&acc[2 * k + 1], ls);
         }
     }
-    if (seg_cnt) {
-        n_rows = wave_reduce(n_rows, [](uint32_t x, uint32_t y) { return x + y; });
-        if ((threadIdx.x & 63) == 0 && n_rows) atomicAdd(&seg_cnt[s], n_rows);
-    }
     __syncthreads();
     if (threadIdx.x < LAD_MAXP * 2 && acc[threadIdx.x]) atomicAdd(&ratio[(size_t)s * LAD_MAXP * 2 + threadIdx.x], acc[threadIdx.x]);
 }
 
-// species segments of the LP rows: seg_off = exclusive prefix of the per-species row counts (one workgroup; S is a few
-// thousand at most), total -> *n_rows
-__global__ void __launch_bounds__(256) seg_scan_kernel(uint32_t S, const uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_off, uint32_t *__restrict__ n_rows) {
-    __shared__ uint32_t s_wave[4];
-    uint32_t carry = 0;
-    for (uint32_t b = 0; b < S; b += 256) {
-        const uint32_t i = b + threadIdx.x;
-        const uint32_t v = i < S ? seg_cnt[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<256>(v, s_wave, &tot);
-        if (i < S) seg_off[i] = carry + ex;
-        carry += tot;
+// The rows in NODE ORDER, hence species by species: an ordered compaction as ONE chained-scan launch (the flag of a node is
+// computed as it is loaded, a row is written at its exclusive prefix), then the segment bounds by binary search over the
+// emitted species keys.  pack_shift >= 0: rows {species << shift | mask, a} in (km, ka); otherwise {species, mask, a} in
+// (ksp, km, ka).  tile_sp (made at upload) = {species of the first node, of the last node} of every 2048-node tile.
+struct RowLoad {
+    const double *ab;
+    const unsigned long long *mask;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+        const double a = ab[i];
+        const unsigned long long m = mask[i];   // both loads unconditionally: they are issued together
+        return ((a > 0.0) & (m != 0ull)) ? 1u : 0u;
     }
-    if (threadIdx.x == 0) { seg_off[S] = carry; *n_rows = carry; }
-}
-// The rows again, species by species: a workgroup's tile of nodes nearly always lies inside one species, whose segment it
-// extends with one atomic; a tile across a species border places its rows one by one.  k0 = species, k1 = mask, k2 = a.
-__global__ void __launch_bounds__(256) row_emit_seg_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
-                                                           const unsigned long long *__restrict__ mask, const uint32_t *__restrict__ seg_off,
-                                                           uint32_t *__restrict__ seg_cur, uint64_t *__restrict__ k0, uint64_t *__restrict__ k1,
-                                                           uint64_t *__restrict__ k2) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * 256 * ROW_ITEMS;
-    const uint64_t base = tile0 + (uint64_t)threadIdx.x * ROW_ITEMS;
-    // species of the tile's first and last node (workgroup-uniform searches)
-    auto species_of = [&](uint64_t v) { uint32_t lo = 0, hi = S; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (node_base[mid] <= v) lo = mid + 1; else hi = mid; } return lo - 1; };
-    const uint64_t tile_last = tile0 + 256 * ROW_ITEMS - 1 < V ? tile0 + 256 * ROW_ITEMS - 1 : V - 1;
-    const uint32_t sp_a = species_of(tile0), sp_b = species_of(tile_last);
-    double a[ROW_ITEMS];
-    unsigned long long m[ROW_ITEMS];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < ROW_ITEMS; ++i) {
-        const uint64_t v = base + i;
-        a[i] = 0.0; m[i] = 0;
-        if (v < V) { a[i] = ab[v]; m[i] = mask[v]; }
-        cnt += (a[i] > 0.0 && m[i] != 0ull) ? 1u : 0u;
+};
+struct RowStore {
+    const double *ab;
+    const unsigned long long *mask;
+    const uint2 *tile_sp;
+    const uint32_t *node_base;
+    uint64_t *ksp, *km, *ka;
+    int pack_shift;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t j, uint32_t head) const {
+        if (!head) return;
+        const uint2 t = tile_sp[i >> 11];
+        uint32_t sp = t.x;
+        while (sp < t.y && node_base[sp + 1] <= i) ++sp;          // a species border or two inside the tile
+        const unsigned long long m = mask[i];
+        if (pack_shift >= 0) km[j] = ((uint64_t)sp << pack_shift) | m;
+        else { ksp[j] = sp; km[j] = m; }
+        ka[j] = (uint64_t)__double_as_longlong(ab[i]);            // positive doubles order like their bit patterns
     }
-    if (sp_a == sp_b) {
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan<256>(cnt, s_wave, &tot);
-        if (threadIdx.x == 0) s_base = tot ? seg_off[sp_a] + atomicAdd(&seg_cur[sp_a], tot) : 0u;
-        __syncthreads();
-        uint32_t j = s_base + ex;
-#pragma unroll
-        for (int i = 0; i < ROW_ITEMS; ++i) {
-            if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
-            k0[j] = sp_a; k1[j] = m[i]; k2[j] = (uint64_t)__double_as_longlong(a[i]);   // positive doubles order like their bit patterns
-            ++j;
+};
+__global__ void __launch_bounds__(256) seg_bounds_kernel(uint32_t S, const uint32_t *__restrict__ d_n, const uint64_t *__restrict__ ksp,
+                                                         const uint64_t *__restrict__ km, int pack_shift, uint32_t *__restrict__ seg_off,
+                                                         uint32_t *__restrict__ seg_cnt) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t n = *d_n;
+    auto first_of = [&](uint32_t sp) {                            // first row whose species is >= sp
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t k = pack_shift >= 0 ? (km[mid] >> pack_shift) : ksp[mid];
+            if (k < sp) lo = mid + 1; else hi = mid;
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < ROW_ITEMS; ++i) {
-            if (!(a[i] > 0.0 && m[i] != 0ull)) continue;
-            const uint32_t sp = species_of(base + i);
-            const uint32_t j = seg_off[sp] + atomicAdd(&seg_cur[sp], 1u);
-            k0[j] = sp; k1[j] = m[i]; k2[j] = (uint64_t)__double_as_longlong(a[i]);
-        }
-    }
+        return lo;
+    };
+    const uint32_t a = first_of(s), b = first_of(s + 1);
+    seg_off[s] = a; seg_cnt[s] = b - a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -616,31 +597,30 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
     if (!lb->prezeroed) PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
     // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
+    // rows: compact -> sort by (species, mask, a)
+    Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
+    // Many species, each small enough for the sample sort: the rows are emitted species by species (segment sizes counted
+    // by the mask pass) and every segment is sorted by (mask, a) in one batch -- three passes over the rows instead of the
+    // 11 of the LSD radix sort
+    uint64_t max_vs = 0;
+    for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
+    bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
+    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) { if (ev[0] == 'r') use_seg = false; }   // "radix": measurements / tests
+    uint32_t *d_seg_cnt = nullptr, *d_seg_off = nullptr;
+    if (use_seg) {
+        PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
+        d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
+    }
     {
         KTimer t(ctx, "mask_kernel");
         if (db->n_tiles)
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
                                db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
     }
-    // rows: compact -> sort by (species, mask, a)
-    Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
-    // Many species, each small enough for the sample sort: the rows are emitted species by species (segment sizes counted
-    // by the ratio pass) and every segment is sorted by (mask, a) in one batch -- three passes over the rows instead of the
-    // 11 of the LSD radix sort
-    uint64_t max_vs = 0;
-    for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
-    bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
-    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) { if (ev[0] == 'r') use_seg = false; }   // "radix": measurements / tests
-    uint32_t *d_seg_cnt = nullptr, *d_seg_cur = nullptr, *d_seg_off = nullptr;
-    if (use_seg) {
-        PTX_HIP(ctx, dbm->d_seg.alloc(3ull * S + 2));
-        d_seg_cnt = dbm->d_seg.p; d_seg_cur = d_seg_cnt + S; d_seg_off = d_seg_cur + S;
-        PTX_HIP(ctx, hipMemsetAsync(d_seg_cnt, 0, 2ull * S * sizeof(uint32_t), ctx->stream));
-    }
     {
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
-                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p, lb->d_ab.p, d_seg_cnt);
+                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
     }
     DevBuf<uint32_t> &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
@@ -653,13 +633,16 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // whenever their bits fit (16-byte records instead of 24)
     const int sp_bits = S > 1 ? bits_for(S - 1) : 0;
     const bool use_sample = V <= SS_MAX_N;
-    const int pack_shift = (!use_sample && !use_seg && sp_bits + pmax_bound <= 64) ? pmax_bound : -1;
+    const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64 && !(use_seg && pmax_bound >= 64)) ? pmax_bound : -1;
     if (use_seg) {
-        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, S, d_seg_cnt, d_seg_off, d_n);
-        KTimer t(ctx, "row_emit_kernel");
-        const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
-        hipLaunchKernelGGL(row_emit_seg_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
-                           (unsigned long long *)lb->d_mask.p, d_seg_off, d_seg_cur, ka[0].p, ka[1].p, ka[2].p);
+        if (pack_shift >= 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: internal (64 candidate columns and a packed species key)");
+        PTX_TRY(exclusive_scan_fn(ctx, RowLoad{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p},
+                                  RowStore{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, db->d_emit_tile_sp.p, db->d_node_base.p,
+                                           pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p, pack_shift >= 0 ? ka[0].p : ka[1].p,
+                                           pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift},
+                                  V, d_n, "row_emit_kernel"));
+        hipLaunchKernelGGL(seg_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, ctx->stream, S, d_n, pack_shift >= 0 ? (const uint64_t *)nullptr : ka[0].p,
+                           pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift, d_seg_off, d_seg_cnt);
     } else {
         KTimer t(ctx, "row_emit_kernel");   // d_n was zeroed with the step's result arena
         const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
@@ -672,7 +655,8 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     bool in_b = false;
     if (use_seg) {
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_seg_ws_elems(S, V)));
-        PTX_TRY(sample_sort_seg(ctx, ka[1].p, ka[2].p, kb[1].p, kb[2].p, S, max_vs, V, d_seg_off, d_seg_cnt, dbm->d_ss_ws.p));
+        const int w0 = pack_shift >= 0 ? 0 : 1;   // the two words that move: {packed species|mask, a} or {mask, a}
+        PTX_TRY(sample_sort_seg(ctx, ka[w0].p, ka[w0 + 1].p, kb[w0].p, kb[w0 + 1].p, S, max_vs, V, d_seg_off, d_seg_cnt, dbm->d_ss_ws.p));
     } else if (use_sample) {   // few rows: sample sort (6 launches) instead of 10+ radix passes of 3 launches each
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_ws_elems(V)));
         PTX_TRY(sample_sort3(ctx, A, B, V, dbm->d_ss_ws.p, d_n));

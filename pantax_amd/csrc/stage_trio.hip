@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
 //      LDS hash table keyed by (a - block start, b, c) packed into 64 bits.  Collinear haplotypes collapse in LDS; HBM sees
 //      the walks once (4P) and one byte per UNIQUE window.  A block whose distinct windows overflow the table is redone
 //      in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences of a key fall into the same class).
-constexpr int TRIO_BLK_SHIFT = 8, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 2048;
+constexpr int TRIO_BLK_SHIFT = 6, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 512;
 constexpr unsigned long long TB_EMPTY = ~0ull;
 constexpr uint32_t TB_MULTI = 0xFFFFFFFFu;
 constexpr int TB_UNR = 4;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
     const unsigned long long key = ((unsigned long long)a_l << 54) | ((unsigned long long)b << 27) | c;
     const unsigned long long mix = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
     if ((((uint32_t)(mix >> 20)) & sub_mask) != sub_j) return;
-    uint32_t h = (uint32_t)(mix >> 53) & (TB_SLOTS - 1);
+    uint32_t h = (uint32_t)(mix >> 55) & (TB_SLOTS - 1);
     for (int probes = 0; probes < TB_SLOTS; ++probes) {
         unsigned long long cur = s_key[h];
         if (cur == TB_EMPTY) cur = atomicCAS(&s_key[h], TB_EMPTY, key);
@@ -203,41 +203,43 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
     }
     *s_over = 1u;
 }
-// blk_rec[gb] = {first run, end run, global index of the block's first node, its species-local id}; entry n_blocks closes
-// the table (the node count of a block is the distance to the next block's first node)
-__global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
-                                                         const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
-                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, int ablate) {
+// ONE WAVE per block of TRIO_BLK nodes (a workgroup is one wave: no workgroup barrier anywhere, two dozen independent
+// waves per CU hide each other's trips to memory; a 256-thread workgroup per 256-node block spent most of its life in
+// barriers and fixed overhead).  blk_rec[gb] = {first run, end run, global index of the block's first node, its
+// species-local id}; entry n_blocks closes the table (a block's node count is the distance to the next block's first node).
+__global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
+                                                        const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
+                                                        uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
     __shared__ unsigned long long s_key[TB_SLOTS];
-    __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[256], s_wave[4];
-    __shared__ uint4 s_run[256];
+    __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[64];
+    __shared__ uint4 s_run[64];
     const uint4 rec = blk_rec[blockIdx.x];
     const uint32_t nn = blk_rec[blockIdx.x + 1].z - rec.z;
     const uint32_t r0 = rec.x, r1 = rec.y, n0 = rec.w;
+    const uint32_t lane = threadIdx.x;
     for (uint32_t nsub = 1;; nsub <<= 1) {
-        for (int i = threadIdx.x; i < TRIO_BLK; i += 256) s_ncnt[i] = 0;
+        s_ncnt[lane] = 0;
         bool over = false;
         for (uint32_t j = 0; j < nsub && !over; ++j) {
-            for (int i = threadIdx.x; i < TB_SLOTS; i += 256) { s_key[i] = TB_EMPTY; s_q[i] = 0; }
-            if (threadIdx.x == 0) s_over = 0;
+            for (int i = lane; i < TB_SLOTS; i += 64) { s_key[i] = TB_EMPTY; s_q[i] = 0; }
+            if (lane == 0) s_over = 0;
             __syncthreads();
-            // the block's runs go to LDS 256 at a time; their positions are then handed out flat over the workgroup, four per
-            // thread and round with all loads of a round issued before the first table operation (a wave per run would walk
-            // run -> positions -> table three times in a row, each a dependent trip to memory)
-            for (uint32_t rb = r0; rb < r1; rb += 256) {
-                const uint32_t n_r = r1 - rb < 256u ? r1 - rb : 256u;
+            // the block's runs go to LDS 64 at a time; their positions are then handed out flat over the wave, TB_UNR per
+            // lane and round, all loads of a round issued before the first table operation
+            for (uint32_t rb = r0; rb < r1; rb += 64) {
+                const uint32_t n_r = r1 - rb < 64u ? r1 - rb : 64u;
                 uint4 run = make_uint4(0u, 0u, 0u, 0u);
-                if (threadIdx.x < n_r) run = runs[rb + threadIdx.x];
-                uint32_t total;
-                const uint32_t excl = block_excl_scan<256>(run.y, s_wave, &total);
-                s_run[threadIdx.x] = run; s_pref[threadIdx.x] = excl;
+                if (lane < n_r) run = runs[rb + lane];
+                const uint32_t incl = wave_incl_scan_dpp(run.y);
+                const uint32_t total = __shfl(incl, 63);
+                s_run[lane] = run; s_pref[lane] = incl - run.y;
                 __syncthreads();
-                for (uint32_t idx0 = threadIdx.x; idx0 < total; idx0 += 256 * TB_UNR) {
+                for (uint32_t idx0 = lane; idx0 < total; idx0 += 64 * TB_UNR) {
                     uint32_t x[TB_UNR], pp[TB_UNR], b1[TB_UNR], c1[TB_UNR], b2[TB_UNR], c2[TB_UNR];
                     bool fw[TB_UNR], bw[TB_UNR];
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
-                        const uint32_t idx = idx0 + u * 256;
+                        const uint32_t idx = idx0 + u * 64;
                         fw[u] = bw[u] = false;
                         x[u] = pp[u] = b1[u] = c1[u] = b2[u] = c2[u] = 0u;
                         if (idx < total) {
@@ -246,7 +248,6 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                             const uint4 rn = s_run[lo];
                             const uint32_t pos = rn.x + (idx - s_pref[lo]);
                             pp[u] = pos;
-                            if (ablate == 3) { x[u] = pos * 7u; fw[u] = true; b1[u] = pos; c1[u] = pos * 9u + 1u; continue; }
                             x[u] = path_nodes[pos];
                             fw[u] = pos + 2 < rn.w; bw[u] = pos >= rn.z + 2;
                             if (fw[u]) { b1[u] = path_nodes[pos + 1]; c1[u] = path_nodes[pos + 2]; }
@@ -255,28 +256,26 @@ __global__ void __launch_bounds__(256) trio_block_kernel(const uint4 *__restrict
                     }
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
-                        if (ablate == 2) { if (x[u] + b1[u] + c1[u] + b2[u] + c2[u] == 0xFFFFFFF1u) s_over = 1; continue; }
                         if (fw[u] && x[u] <= c1[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
                         if (bw[u] && x[u] < c2[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
                     }
                 }
-                __syncthreads();   // s_run / s_pref are reused by the next 256 runs
+                __syncthreads();   // s_run / s_pref are reused by the next 64 runs
             }
-            __syncthreads();
             over = s_over != 0;
             if (!over)
-                for (int i = threadIdx.x; i < TB_SLOTS; i += 256) {
+                for (int i = lane; i < TB_SLOTS; i += 64) {
                     const unsigned long long k = s_key[i];
                     const uint32_t q = s_q[i];
-                    if (k != TB_EMPTY && q != TB_MULTI) { if (ablate != 1) uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
+                    if (k != TB_EMPTY && q != TB_MULTI) { uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
                 }
             __syncthreads();
         }
         if (!over) break;
-        if (nsub >= (1u << 20)) { if (threadIdx.x == 0) atomicAdd(err, 1u); break; }   // cannot happen short of 2^31 equal hashes; never silent
+        if (nsub >= (1u << 20)) { if (lane == 0) atomicAdd(err, 1u); break; }   // cannot happen short of 2^31 equal hashes; never silent
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nn; i += 256) first_cnt[rec.z + i] = s_ncnt[i];
+    if (lane < nn) first_cnt[rec.z + lane] = s_ncnt[lane];
 }
 
 // The run table (upload time, depends on the graphs only): heads = positions whose node lies in another block than their
@@ -477,8 +476,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
     if (P && by_block) {
         KTimer t(ctx, "trio_block_kernel");
-        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(256), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,
-                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, std::getenv("PANTAX_TRIO_ABLATE") ? std::atoi(std::getenv("PANTAX_TRIO_ABLATE")) : 0);
+        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(64), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,
+                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
     }
     if (P) {
         if (!by_block) {

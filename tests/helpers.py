@@ -198,3 +198,33 @@ def oracle_species_checks(sset, sp, keep, absolute, bases, cov, tb, hto, gmet, i
     with ThreadPoolExecutor(threads) as ex:
         out = list(ex.map(one, species_idx))
     return [b for lst in out for b in lst]
+
+
+def load_literal_case(k):
+    """tests/golden/literal_cov_<k>.json (generated by oracle/gen_golden_literal.py from the literal Python reading of
+    profile.rs:658-1026) -> graph arrays in the packed layouts + the expected outputs."""
+    with open(os.path.join(ROOT, "tests", "golden", "literal_cov_%d.json" % k)) as f:
+        j = json.load(f)
+    names = sorted(j["paths"].keys())
+    node_len = np.array(j["node_len"], dtype=np.int64)
+    path_off = np.zeros(len(names) + 1, dtype=np.uint64)
+    path_off[1:] = np.cumsum([len(j["paths"][n]) for n in names])
+    path_nodes = np.concatenate([np.array(j["paths"][n], dtype=np.uint32) for n in names])
+    step_off = np.zeros(len(j["reads"]) + 1, dtype=np.uint64)
+    step_off[1:] = np.cumsum([len(r["walk"]) for r in j["reads"]])
+    node_id = np.array([w for r in j["reads"] for w in r["walk"]], dtype=np.uint32)
+    pstart = np.array([r["read_start"] for r in j["reads"]], dtype=np.int64)
+    pend = np.array([r["read_end"] for r in j["reads"]], dtype=np.int64)
+    return j, names, node_len, path_off, path_nodes, j["range_start"], step_off, node_id, pstart, pend
+
+
+def check_against_literal(j, names, abc, hap, ln, tb, bases, cov, n_abort):
+    """abc/hap/ln/tb: a unique-trio table in any row order + its trio bases; compared as keyed sets with the fixture."""
+    ex = j["expect"]
+    got = {tuple(int(x) for x in abc[i]): (int(ln[i]), names[int(hap[i])], int(tb[i])) for i in range(len(abc))}
+    exp = {tuple(t["key"]): (t["len"], t["hap"], t["bases"]) for t in ex["unique_trios"]}
+    assert all(t["n_haps"] == 1 for t in ex["unique_trios"])          # a unique trio has exactly one owner (presence row is one-hot)
+    assert got == exp
+    assert [int(x) for x in bases] == ex["bases_per_node"]
+    assert [int(x) for x in cov] == ex["node_base_cov"]
+    assert int(n_abort) == ex["n_abort"]

@@ -142,6 +142,27 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch
     assert nab == tot_abort
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_coverage_and_trio_index_vs_literal_python_restatement(eng, k):
+    """The HIP path against fixtures from oracle/ref_literal.py -- the literal Python reading of profile.rs:658-1026 that
+    shares no code with the C oracle: unique-trio table (keyed), trio bases, bases_per_node, node_base_cov bit for bit."""
+    from tests.helpers import check_against_literal, load_literal_case
+    j, names, node_len, path_off, path_nodes, rs, step_off, node_id, pstart, pend = load_literal_case(k)
+    g = _G(node_len, path_off, path_nodes, rs)
+    eng.upload_db([g])
+    R = len(pstart)
+    eng.upload_reads(step_off, node_id, pstart, pend, np.full(R, 60), np.full(R, 60))
+    sp, *_ = eng.rcls_profile()
+    # a walk that leaves the species is "U" for the binning (rcls.rs:253-257) and never reaches get_node_abundances; the
+    # fixture holds one such read to pin the reference's index panic, which the HIP path therefore cannot count
+    so = step_off.astype(np.int64)
+    outside = [r for r in range(R) if any(not (rs <= int(x) < rs + len(node_len)) for x in node_id[so[r]:so[r + 1]])]
+    assert all(sp[r] == -1 for r in outside) and (sp == -1).sum() == len(outside) + sum(1 for r in range(R) if so[r] == so[r + 1])
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    check_against_literal(j, names, abc, hap, ln, tb, bases, cov, nab + len(outside))
+
+
 @pytest.mark.parametrize("V,H,K", [(200, 40, 300), (700, 30, 500), (300, 3, 9000)])
 def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K):
     """Random walks over a few hundred nodes: a node block meets thousands of DISTINCT windows, more than its LDS table
@@ -313,6 +334,28 @@ def test_pao_solve_vs_highs_golden(eng, golden_dir):
             assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
 
 
+def test_pao_solve_vs_reference_milp_model(eng, golden_dir):
+    """Solver seam against the reference's ACTUAL mixed-integer model (binary indicators + sum z <= npaths, second solve with
+    x_j == 0 rows; profile.rs:1363-1377, 1484-1488) solved by scipy.optimize.milp at the BASELINE.md section 2 shape (20 000 x
+    10, 60 % dense) and on integer-tied coverages: objective equal to 1e-9, pinned columns exactly zero."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "lp_milp_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, fixed = z["mask_%d" % i], z["a_%d" % i], z["fixed_%d" % i]
+        p = len(fixed)
+        po, pn = _paths_from_masks(mask, p)
+        x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), po, pn, np.arange(p), fixed_zero=fixed)
+        objm = float(z["obj_milp_%d" % i])
+        assert st == 0
+        assert obj == pytest.approx(objm, rel=1e-9, abs=1e-12), str(z["name_%d" % i])
+        assert orc.lad_objective(mask, a, x) == pytest.approx(objm, rel=1e-9, abs=1e-12)
+        assert np.all(x[fixed == 1] == 0.0) and np.all(x >= 0) and np.all(x <= 1.05 * a.max() + 1e-12)
+        xm = z["x_milp_%d" % i]
+        if np.abs(xm - z["x_lp_%d" % i]).sum() < 1e-9:      # both HiGHS runs landed on the same vertex: compare x too
+            assert np.abs(x - xm).sum() <= 1e-6 * max(1.0, np.abs(xm).sum()) or orc.lad_objective(mask, a, xm) == pytest.approx(obj, rel=1e-12)
+
+
 def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     """pantax_hip_pao_solve_batch (arrays of offsets in, solutions out, host buffers): all 11 golden LPs as ONE
     batch == the same LPs solved one call at a time, objectives == SciPy-HiGHS; a species without candidates and one with
@@ -341,7 +384,8 @@ def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     batch = eng.pao_solve_batch(species, fixed)
     for i, ((x1, r1, o1, st1), (xb, rb, ob, stb, itb)) in enumerate(zip(single, batch)):
         assert st1 == 0 and stb == 0
-        assert np.array_equal(x1, xb) and o1 == ob, i                      # the same kernels: bit for bit
+        assert np.array_equal(x1, xb), i                                   # the same solver kernel: bit for bit
+        assert o1 == pytest.approx(ob, rel=1e-13), i                       # the objective's chunked sum depends on the batch shape: last ulp
         assert ob == pytest.approx(objs[i], rel=1e-9, abs=1e-12), i
     assert batch[-2][3] == 0 and len(batch[-2][0]) == 0
     assert batch[-1][3] == -4                                               # PANTAX_HIP_E_LIMIT for that species only

@@ -150,3 +150,28 @@ def test_row_sampler_library_equals_oracle_and_is_a_sample():
     # no gross bias: the mean chosen position sits in the middle
     pos = orc.sample_sorted_positions(1_000_000, 500000).astype(np.float64)
     assert abs(pos.mean() / 1e6 - 0.5) < 0.002
+
+
+def test_table_float_text_matches_the_reference_exemplar_rows():
+    """The only known-answer rows the reference ships (README.md:343 species table, README.md:354 strain table): every float
+    cell re-emitted by the table writer's formatter is the same text (shortest round-trip digits, `16.0` / `1.0` for integral
+    values), and the header lines are the reference's (README.md:342, :353)."""
+    import ctypes as C
+    from pantax_amd import _ffi
+    lib = _ffi.load()
+    lib.pantax_hip_format_f64.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+
+    def fmt(v):
+        buf = C.create_string_buffer(64)
+        n = lib.pantax_hip_format_f64(v, buf, 64)
+        assert n > 0
+        return buf.value.decode()
+    species_row = "34\t0.5005489240249426\t6.723225501680235"
+    strain_row = "34\t34.4\tGCF_006401215.1_ASM640121v1\t16.0\t0.39983790355261384\t0.9967217217217217\t1.0\t15.54\t16.0\t0.01\t0.0010005002501250622"
+    for cell in species_row.split("\t")[1:] + strain_row.split("\t")[3:]:
+        assert fmt(float(cell)) == cell
+    # beyond the exemplar: values polars prints in scientific notation take ryu's exponent form (unverified against polars
+    # itself, which is not in this image: DESIGN.md); integral values keep their ".0"
+    assert fmt(0.0) == "0.0" and fmt(100.0) == "100.0" and fmt(1e-7) == "1e-7" and fmt(2.5e-10) == "2.5e-10"
+    buf = C.create_string_buffer(4)
+    assert lib.pantax_hip_format_f64(0.39983790355261384, buf, 4) < 0          # too small a buffer is an error, not a truncation
