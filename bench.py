@@ -41,8 +41,8 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
 }
 
 
-def algorithmic_bytes(sset, n_lp_rows):
-    """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload."""
+def algorithmic_bytes(sset, n_lp_rows, U=0):
+    """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload (U = unique trios)."""
     rd = sset.reads
     R, T = rd.n_reads, len(rd.node_id)
     V = sum(g.n_nodes for g in sset.species)
@@ -59,6 +59,12 @@ def algorithmic_bytes(sset, n_lp_rows):
         "popcount_kernel": L // 8 + 8 * V,
         # a7: SURVEY 8d "2 x 12 x (P - 2H) (write keys, read sorted) + 12U" is the whole index; the bucket scatter alone
         # reads the walks (4P) and writes one 16-B record per window
+        # node-block path of the index (the default): SURVEY 8d's whole-index figure 2 x 12 x (P - 2H) + 12U split over its
+        # two passes over the walks -- the block kernel forms every window's 12-byte key and decides count == 1 (the "write
+        # keys" half, plus the 4P of walk it reads, which 8d leaves out), the lookup kernel reads the decided keys back in
+        # walk order and writes the U unique rows (the "read sorted" half + 12U)
+        "trio_block_kernel": 4 * P + 12 * max(P - 2 * H, 0),
+        "trio_lookup_kernel": 12 * max(P - 2 * H, 0) + 12 * U,
         "trio_fill_kernel": 4 * P + 16 * max(P - 2 * H, 0),
         "trio_count_kernel": 4 * P + 4 * V,
         "trio_uniq_kernel": 16 * max(P - 2 * H, 0),
@@ -474,7 +480,9 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_reads / (dt / args.steps) / 1e6
         n_lp_rows = int(sum(stats["n_rows"]))
-        ab, dims = algorithmic_bytes(sset, n_lp_rows)
+        n_unique = int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
+        ab, dims = algorithmic_bytes(sset, n_lp_rows, n_unique)
+        dims["U"] = n_unique
         # dominant kernel by HIP-event time on the library's stream
         roofline = None
         if dom and dom in timings:
