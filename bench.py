@@ -10,8 +10,11 @@ Workload at N=1 (default) = BASELINE.json configs[2], the largest single-GPU con
 reads, seed 20260501 + 3).  `--workload cfg2` selects configs[1] (1 species, 1M reads).  With N ranks every rank owns
 its own shard of that shape (weak scaling: N x 100 species / N x 10M reads, i.e. cfg4's 1k species / 100M reads at
 N = 8 give or take 25 %; species are independent sub-problems) and one RCCL all-reduce per step carries the
-normalisers.  `--scaling strong` instead cuts ONE set of the given size over the ranks (longest-processing-time
-packing of the species, pipeline.partition_species; reads follow their species).
+normalisers.  `--scaling strong` instead cuts ONE set of the given size over the ranks the way the file seam does
+(SURVEY 8e): every rank takes a 1/N slice of the READS, bins it against all species ranges, the species are packed onto
+the ranks by weight (longest processing time first, pipeline.partition_species) and the packed records travel to the
+owner of their species in one RCCL all-to-all(v) over xGMI (pipeline.route_reads) -- once, before the timed steps
+(`ingest_route`); at N = 1 it is the default workload.
 
     python bench.py                                   # cfg3, 1 GPU
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -41,10 +44,9 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
 }
 
 
-def algorithmic_bytes(sset, n_lp_rows, U=0):
-    """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload (U = unique trios)."""
-    rd = sset.reads
-    R, T = rd.n_reads, len(rd.node_id)
+def algorithmic_bytes(sset, n_lp_rows, U, R, T):
+    """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload (U = unique trios, R reads,
+    T walk steps resident on this rank)."""
     V = sum(g.n_nodes for g in sset.species)
     L = int(sum(int(g.node_len.sum()) for g in sset.species))
     P = int(sum(int(g.path_off[-1]) for g in sset.species))
@@ -311,7 +313,9 @@ def main():
     # deterministic synthetic input (seed = 20260501 + cfg index): weak scaling = one such set per rank
     # (+ 1000 x rank), strong scaling = ONE set, species packed onto the ranks by weight, reads follow their species
     t_gen = time.perf_counter()
-    if args.scaling == "weak" or world == 1:
+    strong = args.scaling == "strong" and world > 1
+    full = None
+    if not strong:
         seed = 20260501 + seed_off + 1000 * rank
         sset = synth.make_set(seed, n_species, n_haps, n_reads, genome_len)
         for i, g in enumerate(sset.species):
@@ -319,15 +323,10 @@ def main():
         total_reads = n_reads * world
     else:
         seed = 20260501 + seed_off
-        full = synth.make_set(seed, n_species, n_haps, n_reads, genome_len)
-        sset = synth.shard_set(full, rank, world, partition_species)
+        full = synth.make_set(seed, n_species, n_haps, n_reads, genome_len)   # every rank generates the same set; it keeps a slice of the reads
+        sset = None
         total_reads = n_reads
-        del full
     gen_s = time.perf_counter() - t_gen
-    species_names = [g.name for g in sset.species]
-    hap_names = [hn for g in sset.species for hn in g.hap_names]
-    avg_len = sset.avg_len()
-    S_loc = len(sset.species)
     wl = dict(reads=n_reads, species=n_species, haps=n_haps, genome_len=genome_len, seed=seed)
 
     # ---- CPU baseline first: forked workers, before anything initialises the GPU in this process (rank 0, N = 1 only)
@@ -364,19 +363,46 @@ def main():
         else:
             dist.init_process_group(backend)
             comm = TorchComm(device=None)
+    eng = Engine(local_rank)
+    t_up = time.perf_counter()
+    ingest_route = None
+    if strong:
+        # this rank's slice of the reads (file order) is binned against ALL species ranges, the species are packed
+        # onto the ranks by the summed counts, and the packed records travel to their owners -- once, before the timed steps
+        from pantax_amd.pipeline import route_reads
+        rd = full.reads
+        a, b = n_reads * rank // world, n_reads * (rank + 1) // world
+        so = rd.step_off.astype(np.int64)
+        mapq = np.where((rd.mapq < 0) | (rd.mapq > 254), 255, rd.mapq)
+        eng.upload_ranges([g.range_start for g in full.species], [g.range_end for g in full.species])
+        eng.upload_reads(so[a:b + 1] - so[a], rd.node_id[so[a]:so[b]], rd.pstart[a:b], rd.pend[a:b], rd.qlen[a:b], mapq[a:b])
+        eng.sync()
+        t_r = time.perf_counter()
+        _, rc_loc, *_ = eng.rcls_profile(want_species=False)
+        rc_all = comm.allreduce_sum(rc_loc)
+        owner = partition_species([8.0 * float(rc_all[i]) + g.n_nodes for i, g in enumerate(full.species)], world)
+        rstats = route_reads(eng, owner, comm)
+        eng.sync()
+        ingest_route = dict(ms=(time.perf_counter() - t_r) * 1e3, **rstats,
+                            what="bin the slice against all ranges + one all-reduce of the counts + pack + all-to-all(v) + rebuild resident reads")
+        sset = synth.SyntheticSet([g for i, g in enumerate(full.species) if owner[i] == rank], None)
+        del full
+        eng.upload_db(sset.species)
+    else:
+        eng.upload_db(sset.species)
+        eng.upload_packed(sset.reads)          # inputs resident in HBM before the timed region
+    eng.sync()
+    upload_ms = (time.perf_counter() - t_up) * 1e3   # host->device of packed reads + graph (pageable memory, incl. numpy packing)
+    species_names = [g.name for g in sset.species]
+    hap_names = [hn for g in sset.species for hn in g.hap_names]
+    avg_len = sset.avg_len()
+    S_loc = len(sset.species)
     S_max, H_max = S_loc, len(hap_names)
-    if world > 1 and args.scaling == "strong":
+    if strong:
         import torch.distributed as dist
         t = torch.tensor([S_loc, len(hap_names)], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         S_max, H_max = int(t[0].item()), int(t[1].item())
-
-    eng = Engine(local_rank)
-    t_up = time.perf_counter()
-    eng.upload_db(sset.species)
-    eng.upload_packed(sset.reads)          # inputs resident in HBM before the timed region
-    eng.sync()
-    upload_ms = (time.perf_counter() - t_up) * 1e3   # host->device of packed reads + graph (pageable memory, incl. numpy packing)
 
     def barrier():
         if world > 1:
@@ -481,7 +507,7 @@ def main():
         value = total_reads / (dt / args.steps) / 1e6
         n_lp_rows = int(sum(stats["n_rows"]))
         n_unique = int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
-        ab, dims = algorithmic_bytes(sset, n_lp_rows, n_unique)
+        ab, dims = algorithmic_bytes(sset, n_lp_rows, n_unique, eng.R, eng.T)
         dims["U"] = n_unique
         # dominant kernel by HIP-event time on the library's stream
         roofline = None
@@ -509,7 +535,7 @@ def main():
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3,
             "from_gaf_text_mreads_per_s": gaf_extra["end_to_end_mreads_per_s"] if gaf_extra else None,
-            "upload_ms_once": upload_ms, "synthetic_set_generated_in_s": gen_s,
+            "upload_ms_once": upload_ms, "synthetic_set_generated_in_s": gen_s, "ingest_route": ingest_route,
             "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "%s: %s -- %d species x %d strains, %d short reads (150 bp), genome %d bp %s; this rank: V=%d nodes, "

@@ -166,6 +166,31 @@ int pantax_hip_abundance_filter(uint32_t n_species, const uint64_t *hap_off, con
                                 double *sum_all_out, double *sum_pass_out,
                                 double *species_sum_all_out /*[S] or NULL*/, double *species_sum_pass_out /*[S] or NULL*/);
 
+/* ---- SURVEY 8e, reads over N GPUs: bin where tokenised, route to the owner of the species ------------------------
+ * The reference groups the reads by species in one process (group_reads_by_species, profile.rs:439-463) and hands each
+ * species' records to its rayon task.  With one process per GPU every rank holds a 1/N slice of the reads (its byte range
+ * of the GAF): it bins the slice against ALL species ranges (pantax_hip_bin_reads), packs one message per owner rank
+ * (route_pack: stable partition on the device, order of the slice kept; "U" reads, reads of species nobody owns and reads
+ * with a drop flag are left behind), the host moves the messages (RCCL all-to-all(v) over xGMI on the device buffers, MPI,
+ * ...), and the owner builds resident reads from what it received (reads_from_routed: messages in source-rank order, so the
+ * result is the one-process read order restricted to the owner's species).
+ * Message layout, 32-bit words: n_steps[n] pstart[n] pend[n] qlen[n] mapq[n] node_id[n_steps_total]. */
+typedef struct pantax_hip_route pantax_hip_route;
+int pantax_hip_reads_route_pack(pantax_hip_ctx *ctx, const pantax_hip_db *db /* the db `reads` were binned against */,
+                                const pantax_hip_reads *reads, const int32_t *owner_of_species /*[S] rank, or < 0: nobody*/,
+                                int world_size /* <= 64 */, pantax_hip_route **out, uint64_t *n_reads_to /*[W] out*/,
+                                uint64_t *n_steps_to /*[W] out*/);
+/* the W messages, back to back in rank order: buf_out[word_off_out[d] .. word_off_out[d+1]) goes to rank d
+ * (word_off_out [W+1], may be NULL: 5 * n_reads_to + n_steps_to each).  on_device = 1: device pointer (valid until
+ * route_free), 0: pinned host copy. */
+int pantax_hip_route_buffer(pantax_hip_ctx *ctx, pantax_hip_route *route, int on_device, const uint32_t **buf_out,
+                            uint64_t *word_off_out);
+void pantax_hip_route_free(pantax_hip_ctx *ctx, pantax_hip_route *route);
+/* recv: the messages of ranks 0..W-1 for this rank, back to back (device pointer when on_device, else host memory);
+ * n_reads_from / n_steps_from [W] as announced by the senders.  The reads come out ready for pantax_hip_bin_reads. */
+int pantax_hip_reads_from_routed(pantax_hip_ctx *ctx, const uint32_t *recv, int on_device, int world_size,
+                                 const uint64_t *n_reads_from, const uint64_t *n_steps_from, pantax_hip_reads **out);
+
 /* ---- resident step: the in-memory core of profile::profile (profile.rs:3325-3364) between "GAF parsed"
  * and "tables written", over a db and reads that are already in HBM.  One call = rcls_profile ->
  * species_profiling -> trio_nodes_info (when rebuild_trio) -> get_node_abundances -> strain_profiling ->
@@ -264,10 +289,16 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     const char *designated_species; /* --ds or NULL */
     const char *zip;                /* "serialize" (.bin) | "lz" (.bin.lz4) | "zstd" (.bin.zst) | NULL (= GFA); "h5" is refused */
     /* one process per GPU: with world_size > 1 this process takes its share of the selected species (longest-processing-
-     * time packing on reads + graph size, the same table on every rank; every rank reads the GAF and bins it; the species
-     * table is rank 0's).  The strain table needs two global sums and
-     * the rows of every rank: the library calls allreduce_sum (below) three times per run -- run mode, {failure flag, the
-     * two sums}, a barrier once the ranks' rows are in part files under wd -- and rank 0 writes the tables. */
+     * time packing on reads + graph size, the same table on every rank) and rank 0 writes the tables.
+     * With `alltoallv` set the INPUT is sharded too: rank r tokenises and bins only its line-aligned 1/N byte range
+     * of the GAF, the species counters are summed over the ranks, the duplicate-id rule (profile.rs:361-437) is decided on
+     * (id hash, species) records exchanged by hash, and the packed records of every read travel to the rank that owns its
+     * species (pantax_hip_reads_route_pack / _from_routed) -- no rank ever reads the whole file.  Without it every rank
+     * tokenises the whole GAF (simple, but N x the ingest).
+     * Collectives per run: allreduce_sum a handful of times (run mode; {failure flag, counters}; {failure flag, the two
+     * normalisers}; barriers around the part files) -- every rank-local failure is carried in such a flag, so the ranks
+     * always leave together -- and, when sharded, alltoallv two to three times (id records; packed reads; the ids to drop,
+     * only if some id does span species). */
     int32_t rank, world_size;
     /* device-ready graph images <db>/species_graph_info/<otu>.hipdb (graphs + unique-trio index):
      * 0 = ignore them, 1 = use them when every selected species has a fresh one, 2 = as 1, and write them after a run
@@ -276,6 +307,14 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     /* world_size > 1: in-place sum over all ranks of buf[0..n) (e.g. ncclAllReduce + stream sync, MPI_Allreduce); 0 = ok */
     int (*allreduce_sum)(void *user, double *buf, uint64_t n);
     void *comm_user;
+    /* world_size > 1, optional (NULL = unsharded input): bytes send[send_off[j] .. send_off[j+1]) of rank i arrive as
+     * recv[recv_off[i] .. recv_off[i+1]) on rank j; both offset arrays have world_size + 1 entries and every rank passes
+     * recv offsets that match what the others send (the library exchanges the sizes through allreduce_sum first).
+     * E.g. ncclGroupStart + ncclSend/ncclRecv per peer + ncclGroupEnd + stream sync, or MPI_Alltoallv.  0 = ok.
+     * comm_device_buffers != 0: send / recv are DEVICE pointers of this ctx's GPU (RCCL moves HBM to HBM over xGMI);
+     * 0: host pointers (the library stages through pinned memory). */
+    int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off);
+    int32_t comm_device_buffers;
 } pantax_hip_profiling_config;
 
 int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);

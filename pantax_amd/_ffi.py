@@ -22,6 +22,7 @@ SYMBOLS = [
     "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter", "pantax_hip_db_save_images", "pantax_hip_db_load_images",
     "pantax_hip_gaf_load", "pantax_hip_gaf_load_device", "pantax_hip_reads_load_gaf", "pantax_hip_reads_set_flags", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
     "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free", "pantax_hip_format_f64",
+    "pantax_hip_reads_route_pack", "pantax_hip_route_buffer", "pantax_hip_route_free", "pantax_hip_reads_from_routed",
     "pantax_hip_timing_enable", "pantax_hip_timing_filter", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
 ]
 
@@ -89,11 +90,13 @@ class ProfilingConfig(C.Structure):
                 ("species", C.c_int32), ("strain", C.c_int32), ("shift", C.c_int32), ("filtered", C.c_int32),
                 ("full", C.c_int32), ("force", C.c_int32), ("mode", C.c_int32), ("sample_nodes", C.c_int32),
                 ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32), ("image_cache", C.c_int32),
-                ("allreduce_sum", C.c_void_p), ("comm_user", C.c_void_p)]
+                ("allreduce_sum", C.c_void_p), ("comm_user", C.c_void_p), ("alltoallv", C.c_void_p), ("comm_device_buffers", C.c_int32)]
 
 
 # int (*allreduce_sum)(void *user, double *buf, uint64_t n)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
+# int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
 
 
 def load():
@@ -112,6 +115,7 @@ def load():
         _lib.pantax_hip_reads_free.restype = None
         _lib.pantax_hip_gaf_free.restype = None
         _lib.pantax_hip_graph_free.restype = None
+        _lib.pantax_hip_route_free.restype = None
     return _lib
 
 

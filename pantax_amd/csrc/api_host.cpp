@@ -17,22 +17,16 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
     if (!reads->binned) return fail(ctx, PANTAX_HIP_E_STATE, "species_profile: call pantax_hip_bin_reads first");
     PTX_ENTER(ctx);
     // profile.rs:312-319: distinct read_len among the first 1000 rows of the frame without "U" reads
-    int64_t first_len = -1;
-    bool equal = true;
-    uint64_t seen = 0;
+    std::vector<uint32_t> head;
     auto scan = [&](const int32_t *sp, const uint32_t *ql, uint64_t n) {
-        for (uint64_t i = 0; i < n && seen < 1000; ++i) {
-            if (sp[i] < 0) continue;
-            if (seen == 0) first_len = ql[i]; else if ((int64_t)ql[i] != first_len) equal = false;
-            ++seen;
-        }
+        for (uint64_t i = 0; i < n && head.size() < 1000; ++i) if (sp[i] >= 0) head.push_back(ql[i]);
     };
     uint64_t off = reads->h_pre_species.size();
     scan(reads->h_pre_species.data(), reads->h_pre_qlen.data(), off);   // head fetched together with the counters
     uint64_t CH = 16384;   // rarely needed: fewer than 1000 binned reads among the first 2048 rows
     std::vector<int32_t> sp;
     std::vector<uint32_t> ql;
-    for (; off < reads->R && seen < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
+    for (; off < reads->R && head.size() < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
         uint64_t n = std::min<uint64_t>(CH, reads->R - off);
         sp.resize(n); ql.resize(n);
         PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
@@ -40,8 +34,19 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scan(sp.data(), ql.data(), n);
     }
-    if (seen == 0) equal = false;
-    const uint32_t S = db->S;
+    species_profile_host(db->S, head.data(), head.size(), read_count, base_sum, less_multi, uniq_count, avg_len, filtered, keep_out, absolute_out, abundance_out);
+    return 0;
+}
+
+}  // extern "C"
+
+// the scalar part of species_profiling (profile.rs:299-349) given the read lengths of the first (up to 1000) binned rows
+void ptx::species_profile_host(uint32_t S, const uint32_t *head_qlen, size_t n_head, const int64_t *read_count, const int64_t *base_sum,
+                               const int64_t *less_multi, const int64_t *uniq_count, const double *avg_len, int filtered, uint8_t *keep_out,
+                               double *absolute_out, double *abundance_out) {
+    int64_t first_len = n_head ? (int64_t)head_qlen[0] : -1;
+    bool equal = n_head != 0;
+    for (size_t i = 1; i < n_head && i < 1000; ++i) if ((int64_t)head_qlen[i] != first_len) equal = false;   // :312-319
     double total = 0.0;
     for (uint32_t s = 0; s < S; ++s) {
         keep_out[s] = 0; absolute_out[s] = 0.0; abundance_out[s] = 0.0;
@@ -57,8 +62,9 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
         total += absolute_out[s];
     }
     for (uint32_t s = 0; s < S; ++s) if (keep_out[s]) abundance_out[s] = absolute_out[s] / total;   // :341
-    return 0;
 }
+
+extern "C" {
 
 int pantax_hip_db_reset(pantax_hip_ctx *ctx, pantax_hip_db *db) {
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;

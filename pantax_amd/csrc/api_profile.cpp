@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "db_image.hpp"
 #include "host_io.hpp"
+#include "primitives.hpp"
 
 using namespace ptx;
 
@@ -53,21 +54,41 @@ std::string cell(bool has, double v, bool rnd = false) { return has ? fmt_f64(rn
 
 }  // namespace
 
-extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg) {
-    if (!ctx || !cfg) return PANTAX_HIP_E_INVALID;
+// first line start at or after byte `c` of the mapped text (a line starts at 0 or right after a '\n')
+static uint64_t line_start_at_or_after(const MappedFile &mf, uint64_t c) {
+    if (c == 0) return 0;
+    if (c >= mf.size) return mf.size;
+    const void *nl = std::memchr(mf.data + (c - 1), '\n', mf.size - (c - 1));
+    return nl ? (uint64_t)(static_cast<const char *>(nl) - mf.data) + 1 : mf.size;
+}
+
+static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg) {
     PTX_ENTER(ctx);
     // ---- check_args_valid (profile.rs:71-199)
     if (!cfg->species && !cfg->strain) return fail(ctx, PANTAX_HIP_E_INVALID, "Please choose profiling level with --species or/and --strain.");
-    // one process per GPU: rank r takes the selected species i with i % world_size == r; the two global sums of the strain
-    // table (profile.rs:3198, :3243) and the hand-over of the rows go through the caller's all-reduce (RCCL / MPI / ...)
+    // one process per GPU: the selected species are packed onto the ranks by weight; the two global sums of the strain table
+    // (profile.rs:3198, :3243) and the hand-over of the rows go through the caller's all-reduce (RCCL / MPI / ...).  With an
+    // alltoallv callback the input is sharded as well: every rank tokenises and bins its byte range of the GAF.
     const int W = cfg->world_size > 1 ? cfg->world_size : 1;
     const int rk = W > 1 ? cfg->rank : 0;
     if (W > 1 && (!cfg->allreduce_sum || rk < 0 || rk >= W))
         return fail(ctx, PANTAX_HIP_E_INVALID, "profile: world_size %d needs 0 <= rank < world_size and an allreduce_sum callback", W);
+    const bool sharded = W > 1 && cfg->alltoallv != nullptr;
+    if (sharded && W > 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: the sharded ingest routes reads to at most 64 ranks (world_size %d)", W);
     auto allreduce = [&](double *buf, uint64_t n) -> int {
         if (W == 1) return 0;
         const int rc = cfg->allreduce_sum(cfg->comm_user, buf, n);
         return rc == 0 ? 0 : fail(ctx, PANTAX_HIP_E_STATE, "profile: the caller's allreduce_sum returned %d", rc);
+    };
+    // every rank-local failure travels in a flag of the next collective: either all ranks go on or all return (nobody is
+    // left waiting in an exchange); the failing rank reports its own error, the others E_STATE
+    auto others_failed = [&]() { return fail(ctx, PANTAX_HIP_E_STATE, "profile: another rank failed; this rank stopped with it"); };
+    auto agree = [&](int local_rc) -> int {
+        if (W == 1) return local_rc;
+        double f = local_rc != 0 ? 1.0 : 0.0;
+        PTX_TRY(allreduce(&f, 1));
+        if (f != 0.0) return local_rc ? local_rc : others_failed();
+        return 0;
     };
     const std::string db_dir = opt(cfg->db), wd = opt(cfg->wd);
     std::string out_dir = opt(cfg->output_dir);
@@ -92,11 +113,6 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     if (!full_path && !strain_only) return 0;   // profile.rs:3419-3427: outputs already present
     mkdir(out_dir.c_str(), 0777);
 
-    const std::string gaf_path = opt(cfg->input_aln_file);
-    if (!is_file(gaf_path)) return fail(ctx, PANTAX_HIP_E_IO, "Specified GAF mapping file '%s' is not a valid file path", gaf_path.c_str());
-    const std::string range_path = choose(opt(cfg->range_file), join(db_dir, "species_range.txt"));
-    if (range_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species range file '%s' nor '%s' is a valid file path", opt(cfg->range_file).c_str(), join(db_dir, "species_range.txt").c_str());
-
     // PANTAX_HIP_TRACE=1: wall time of each phase on stderr (the reference logs its phases through env_logger)
     const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -104,69 +120,158 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         if (!trace) return;
         (void)hipDeviceSynchronize();
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[pantax_hip_profile] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        std::fprintf(stderr, "[pantax_hip_profile r%d] %-28s %9.3f ms\n", rk, what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
 
-    std::vector<RangeRow> ranges;
-    std::string err = read_species_range(range_path, ranges);
-    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
-    const uint32_t S = (uint32_t)ranges.size();
-    if (S == 0) return fail(ctx, PANTAX_HIP_E_IO, "species range file %s is empty", range_path.c_str());
+    // bytes between the ranks (sharded ingest).  The callback takes host or device pointers (comm_device_buffers); both
+    // forms are offered here so that neither the small id exchange nor the read payload is staged more than needed.
+    const bool dev_comm = cfg->comm_device_buffers != 0;
+    auto a2a = [&](const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off) -> int {
+        const int rc = cfg->alltoallv(cfg->comm_user, send, send_off, recv, recv_off);
+        return rc == 0 ? 0 : fail(ctx, PANTAX_HIP_E_STATE, "profile: the caller's alltoallv returned %d", rc);
+    };
+    auto a2a_host = [&](const void *send_h, const uint64_t *send_off, std::vector<uint8_t> &recv_h, const uint64_t *recv_off) -> int {
+        recv_h.resize(recv_off[W] ? recv_off[W] : 1);
+        if (!dev_comm) return a2a(send_h, send_off, recv_h.data(), recv_off);
+        DevBuf<uint8_t> ds, dr;
+        PTX_HIP(ctx, ds.alloc(send_off[W] ? send_off[W] : 1)); PTX_HIP(ctx, dr.alloc(recv_off[W] ? recv_off[W] : 1));
+        if (send_off[W]) PTX_HIP(ctx, hipMemcpyAsync(ds.p, send_h, send_off[W], hipMemcpyHostToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PTX_TRY(a2a(ds.p, send_off, dr.p, recv_off));
+        if (recv_off[W]) PTX_HIP(ctx, hipMemcpyAsync(recv_h.data(), dr.p, recv_off[W], hipMemcpyDeviceToHost, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    auto a2a_dev = [&](const void *send_d, const uint64_t *send_off, void *recv_d, const uint64_t *recv_off) -> int {
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (dev_comm) return a2a(send_d, send_off, recv_d, recv_off);
+        std::vector<uint8_t> hs(send_off[W] ? send_off[W] : 1), hrv(recv_off[W] ? recv_off[W] : 1);
+        if (send_off[W]) PTX_HIP(ctx, hipMemcpy(hs.data(), send_d, send_off[W], hipMemcpyDeviceToHost));
+        PTX_TRY(a2a(hs.data(), send_off, hrv.data(), recv_off));
+        if (recv_off[W]) PTX_TRY(upload_big(ctx, recv_d, hrv.data(), recv_off[W]));
+        return 0;
+    };
+    // who sends how many bytes to whom: every rank fills its row of a W x W matrix, one all-reduce (it also carries the
+    // failure flag of the phase before).  -> recv_off [W+1] of this rank
+    auto exchange_sizes = [&](const uint64_t *send_off, std::vector<uint64_t> &recv_off, int local_rc) -> int {
+        std::vector<double> m((size_t)W * W + 1, 0.0);
+        if (local_rc == 0) for (int j = 0; j < W; ++j) m[(size_t)rk * W + j] = (double)(send_off[j + 1] - send_off[j]);
+        m[(size_t)W * W] = local_rc != 0 ? 1.0 : 0.0;
+        PTX_TRY(allreduce(m.data(), m.size()));
+        if (m[(size_t)W * W] != 0.0) return local_rc ? local_rc : others_failed();
+        recv_off.assign(W + 1, 0);
+        for (int i = 0; i < W; ++i) recv_off[i + 1] = recv_off[i] + (uint64_t)m[(size_t)i * W + rk];
+        return 0;
+    };
 
-    // ---- a1: GAF -> packed reads (rcls.rs:119-146)
+    // ---- a1 + a2/a3, rank-local: ranges, GAF (this rank's byte range when sharded) -> packed reads in HBM, binned against
+    // ALL species ranges (ranges-only db), counters on the device
+    const std::string gaf_path = opt(cfg->input_aln_file);
+    std::vector<RangeRow> ranges;
+    uint32_t S = 0;
     MappedFile mf;
-    err = mf.open(gaf_path);
-    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
-    // tokenised on the device (stage_gaf.hip; host_io.cpp:parse_gaf is its checker): the packed reads stay in HBM,
-    // only read_len / mapq / flags / id hashes come back for the report and the duplicate-id rule
     HostReads hr;
     ReadsHolder reads{ctx};
-    reads.rd = new pantax_hip_reads();
-    PTX_TRY(gaf_tokenize_device(ctx, mf.data, mf.size, hr, reads.rd, mf.fd));
-    const uint64_t R = hr.qlen.size();
-    lap("ranges + GAF tokenise");
-
-    // ---- a2/a3: binning against ALL species ranges (ranges-only db), counters on device
-    std::vector<int64_t> rs(S), re(S);
-    for (uint32_t s = 0; s < S; ++s) { rs[s] = ranges[s].start; re[s] = ranges[s].end; }
     DbHolder bin_db{ctx};
-    {
+    uint64_t R = 0, text_begin = 0;
+    std::vector<int32_t> sp_idx;
+    std::vector<int64_t> rc, bs, lm, uq;
+    std::vector<int64_t> rs, re;
+    auto ingest = [&]() -> int {
+        if (!is_file(gaf_path)) return fail(ctx, PANTAX_HIP_E_IO, "Specified GAF mapping file '%s' is not a valid file path", gaf_path.c_str());
+        const std::string range_path = choose(opt(cfg->range_file), join(db_dir, "species_range.txt"));
+        if (range_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species range file '%s' nor '%s' is a valid file path", opt(cfg->range_file).c_str(), join(db_dir, "species_range.txt").c_str());
+        std::string err = read_species_range(range_path, ranges);
+        if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+        S = (uint32_t)ranges.size();
+        if (S == 0) return fail(ctx, PANTAX_HIP_E_IO, "species range file %s is empty", range_path.c_str());
+        err = mf.open(gaf_path);
+        if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+        // tokenised on the device (stage_gaf.hip; host_io.cpp:parse_gaf is its checker): the packed reads stay in HBM,
+        // only read_len / mapq / flags / id hashes come back for the report and the duplicate-id rule
+        uint64_t text_end = mf.size;
+        if (sharded) {
+            text_begin = line_start_at_or_after(mf, mf.size / (uint64_t)W * (uint64_t)rk);
+            text_end = rk + 1 == W ? mf.size : line_start_at_or_after(mf, mf.size / (uint64_t)W * (uint64_t)(rk + 1));
+        }
+        reads.rd = new pantax_hip_reads();
+        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded));
+        R = hr.qlen.size();
+        lap("ranges + GAF tokenise");
+        rs.resize(S); re.resize(S);
+        for (uint32_t s = 0; s < S; ++s) { rs[s] = ranges[s].start; re[s] = ranges[s].end; }
         pantax_hip_graphs g{};
         g.n_species = S; g.range_start = rs.data(); g.range_end = re.data();
         PTX_TRY(pantax_hip_db_upload(ctx, &g, &bin_db.db));
+        sp_idx.resize(R);
+        rc.resize(S); bs.resize(S); lm.resize(S); uq.resize(S);
+        PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, sp_idx.data(), rc.data(), bs.data(), lm.data(), uq.data()));
+        lap("bin all species");
+        return 0;
+    };
+    int local_rc = ingest();
+    // the read lengths of the first (up to 1000) binned rows of the FILE decide the equal-length branch (profile.rs:312-319)
+    std::vector<uint32_t> head;
+    if (local_rc == 0) for (uint64_t r = 0; r < R && head.size() < 1000; ++r) if (sp_idx[r] >= 0) head.push_back(hr.qlen[r]);
+    uint64_t read_base = 0, R_all = R;   // this rank's first read in file order; reads of the whole file
+    if (sharded) {
+        // one all-reduce: {failure flag, S (must agree), reads per rank, the four counters per species, every rank's head}
+        const size_t o_rank = 2, o_cnt = o_rank + W, o_head = o_cnt + 4 * (size_t)S;
+        double s_chk[2] = {local_rc != 0 ? 1.0 : 0.0, 0.0};
+        PTX_TRY(allreduce(s_chk, 1));   // S is only known to ranks that got through: settle the failure first
+        if (s_chk[0] != 0.0) return local_rc ? local_rc : others_failed();
+        std::vector<double> x(o_head + (size_t)W * 1001, 0.0);
+        x[o_rank + rk] = (double)R;
+        for (uint32_t s = 0; s < S; ++s) { x[o_cnt + s] = (double)rc[s]; x[o_cnt + S + s] = (double)bs[s]; x[o_cnt + 2 * (size_t)S + s] = (double)lm[s]; x[o_cnt + 3 * (size_t)S + s] = (double)uq[s]; }
+        x[o_head + (size_t)rk * 1001] = (double)head.size();
+        for (size_t i = 0; i < head.size(); ++i) x[o_head + (size_t)rk * 1001 + 1 + i] = (double)head[i];
+        PTX_TRY(allreduce(x.data(), x.size()));
+        R_all = 0;
+        for (int q = 0; q < W; ++q) { if (q < rk) read_base += (uint64_t)x[o_rank + q]; R_all += (uint64_t)x[o_rank + q]; }
+        for (uint32_t s = 0; s < S; ++s) { rc[s] = (int64_t)x[o_cnt + s]; bs[s] = (int64_t)x[o_cnt + S + s]; lm[s] = (int64_t)x[o_cnt + 2 * (size_t)S + s]; uq[s] = (int64_t)x[o_cnt + 3 * (size_t)S + s]; }
+        head.clear();
+        for (int q = 0; q < W && head.size() < 1000; ++q) {
+            const size_t n = (size_t)x[o_head + (size_t)q * 1001];
+            for (size_t i = 0; i < n && head.size() < 1000; ++i) head.push_back((uint32_t)x[o_head + (size_t)q * 1001 + 1 + i]);
+        }
+    } else {
+        PTX_TRY(agree(local_rc));
     }
-    std::vector<int32_t> sp_idx(R);
-    std::vector<int64_t> rc(S), bs(S), lm(S), uq(S);
-    PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, sp_idx.data(), rc.data(), bs.data(), lm.data(), uq.data()));
+    local_rc = 0;
 
-    lap("bin all species");
     std::vector<SpeciesProfileRow> sp_profile;   // species_taxid, predicted_abundance, predicted_coverage
+    const std::string report = opt(cfg->out_binning_file);
+    const bool want_report = full_path && !report.empty() && report != "None";
+    auto report_part = [&](int r) { return report + ".part" + std::to_string(r); };
+    auto species_level = [&]() -> int {
     if (full_path) {
-        // optional binning report: read_id, mapq, species, read_len; no header (profile.rs:3337-3351)
-        const std::string report = opt(cfg->out_binning_file);
-        if (rk == 0 && !report.empty() && report != "None") {
-            std::ofstream f(report);
-            if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", report.c_str());
+        // optional binning report: read_id, mapq, species, read_len; no header (profile.rs:3337-3351).  Sharded: every rank
+        // writes the rows of its byte range to a part file, rank 0 joins them in rank (= file) order below.
+        if (want_report && (rk == 0 || sharded)) {
+            const std::string path = sharded ? report_part(rk) : report;
+            std::ofstream f(path);
+            if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", path.c_str());
             for (uint64_t r = 0; r < R; ++r) {
-                f.write(mf.data + hr.id_span[r].first, hr.id_span[r].second);
+                f.write(mf.data + text_begin + hr.id_span[r].first, hr.id_span[r].second);
                 f << '\t';
                 if (hr.mapq[r] != 255) f << (int)hr.mapq[r];
                 f << '\t' << (sp_idx[r] >= 0 ? ranges[sp_idx[r]].species : std::string("U")) << '\t' << hr.qlen[r] << '\n';
             }
+            f.close();
+            if (!f) return fail(ctx, PANTAX_HIP_E_IO, "cannot write %s", path.c_str());
         }
         const std::string len_path = choose(opt(cfg->species_len_file), join(db_dir, "species_genomes_stats.txt"));
         if (len_path.empty()) return fail(ctx, PANTAX_HIP_E_IO, "Neither species length file '%s' nor '%s' is a valid file path", opt(cfg->species_len_file).c_str(), join(db_dir, "species_genomes_stats.txt").c_str());
         std::vector<std::pair<std::string, double>> lens;
-        err = read_species_len(len_path, lens);
+        std::string err = read_species_len(len_path, lens);
         if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
         std::unordered_map<std::string, double> len_of(lens.begin(), lens.end());
         std::vector<double> avg(S, 0.0);
         for (uint32_t s = 0; s < S; ++s) { auto it = len_of.find(ranges[s].species); if (it != len_of.end()) avg[s] = it->second; }
         std::vector<uint8_t> keep(S);
         std::vector<double> absolute(S), abundance(S);
-        PTX_TRY(pantax_hip_species_profile(ctx, bin_db.db, reads.rd, rc.data(), bs.data(), lm.data(), uq.data(), avg.data(), cfg->filtered,
-                                           keep.data(), absolute.data(), abundance.data()));
+        species_profile_host(S, head.data(), head.size(), rc.data(), bs.data(), lm.data(), uq.data(), avg.data(), cfg->filtered, keep.data(), absolute.data(), abundance.data());
         for (uint32_t s = 0; s < S; ++s) if (keep[s]) sp_profile.push_back({ranges[s].species, abundance[s], absolute[s]});
         std::stable_sort(sp_profile.begin(), sp_profile.end(), [](const SpeciesProfileRow &a, const SpeciesProfileRow &b) { return a.abundance > b.abundance; });   // :344
         if (rk == 0) {
@@ -175,35 +280,61 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
             f << "species_taxid\tpredicted_abundance\tpredicted_coverage\n";
             for (auto &r : sp_profile) f << r.species << '\t' << fmt_f64(r.abundance) << '\t' << fmt_f64(r.coverage) << '\n';
         }
-        if (!cfg->strain || strain_done) return 0;
     } else {
-        // strain only (profile.rs:3365-3417): species column comes from the saved binning file (positional join)
+        // strain only (profile.rs:3365-3417): species column comes from the saved binning file (positional join); a rank
+        // of the sharded ingest takes the rows of its own reads
         std::string rb = choose(opt(cfg->reads_binning_file), join(wd, "reads_classification.tsv"));   // profile.rs:179-182
         if (rb.empty()) return fail(ctx, PANTAX_HIP_E_IO, "reads binning file '%s' is not a valid file path", join(wd, "reads_classification.tsv").c_str());
         std::unordered_map<std::string, int32_t> idx_of;
         for (uint32_t s = 0; s < S; ++s) idx_of.emplace(ranges[s].species, (int32_t)s);
         std::ifstream f(rb);
         std::string line;
-        uint64_t r = 0;
+        uint64_t row = 0;
         while (std::getline(f, line)) {
-            if (r >= R) return fail(ctx, PANTAX_HIP_E_IO, "%s has more rows than the GAF (%llu)", rb.c_str(), (unsigned long long)R);
-            size_t t1 = line.find('\t'), t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1), t3 = t2 == std::string::npos ? t2 : line.find('\t', t2 + 1);
-            if (t2 == std::string::npos) return fail(ctx, PANTAX_HIP_E_IO, "malformed row in %s", rb.c_str());
-            std::string spn = line.substr(t2 + 1, t3 == std::string::npos ? std::string::npos : t3 - t2 - 1);
-            auto it = idx_of.find(spn);
-            sp_idx[r++] = it == idx_of.end() ? -1 : it->second;
+            if (row >= R_all) return fail(ctx, PANTAX_HIP_E_IO, "%s has more rows than the GAF (%llu)", rb.c_str(), (unsigned long long)R_all);
+            if (row >= read_base && row < read_base + R) {
+                size_t t1 = line.find('\t'), t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1), t3 = t2 == std::string::npos ? t2 : line.find('\t', t2 + 1);
+                if (t2 == std::string::npos) return fail(ctx, PANTAX_HIP_E_IO, "malformed row in %s", rb.c_str());
+                std::string spn = line.substr(t2 + 1, t3 == std::string::npos ? std::string::npos : t3 - t2 - 1);
+                auto it = idx_of.find(spn);
+                sp_idx[row - read_base] = it == idx_of.end() ? -1 : it->second;
+            }
+            ++row;
         }
-        if (r != R) return fail(ctx, PANTAX_HIP_E_IO, "%s has %llu rows but the GAF has %llu (the join is positional, profile.rs:3381-3384)", rb.c_str(), (unsigned long long)r, (unsigned long long)R);
+        if (row != R_all) return fail(ctx, PANTAX_HIP_E_IO, "%s has %llu rows but the GAF has %llu (the join is positional, profile.rs:3381-3384)", rb.c_str(), (unsigned long long)row, (unsigned long long)R_all);
         if (!is_file(species_file)) return fail(ctx, PANTAX_HIP_E_IO, "species abundance file '%s' is not a valid file path", species_file.c_str());
         std::ifstream sf(species_file);
         bool header = true;
         while (std::getline(sf, line)) {
             if (header) { header = false; continue; }
-            size_t t1 = line.find('\t'), t2 = line.find('\t', t1 + 1);
+            const size_t t1 = line.find('\t');
+            const size_t t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1);
             if (t1 == std::string::npos || t2 == std::string::npos) continue;
-            sp_profile.push_back({line.substr(0, t1), std::stod(line.substr(t1 + 1, t2 - t1 - 1)), std::stod(line.substr(t2 + 1))});
+            const std::string c1 = line.substr(t1 + 1, t2 - t1 - 1), c2 = line.substr(t2 + 1);
+            char *e1 = nullptr, *e2 = nullptr;
+            const double v1 = std::strtod(c1.c_str(), &e1), v2 = std::strtod(c2.c_str(), &e2);
+            if (e1 == c1.c_str() || e2 == c2.c_str()) return fail(ctx, PANTAX_HIP_E_IO, "malformed row in %s: '%s'", species_file.c_str(), line.c_str());
+            sp_profile.push_back({line.substr(0, t1), v1, v2});
         }
     }
+    return 0;
+    };   // species_level
+    local_rc = species_level();
+    PTX_TRY(agree(local_rc));   // also the barrier behind the report parts
+    if (want_report && sharded && rk == 0) {   // the parts in rank order = file order
+        std::ofstream out(report, std::ios::binary);
+        bool ok = (bool)out;
+        for (int r = 0; r < W && ok; ++r) {
+            std::ifstream in(report_part(r), std::ios::binary);
+            ok = (bool)in;
+            if (ok && in.peek() != std::ifstream::traits_type::eof()) out << in.rdbuf();
+            in.close();
+            std::remove(report_part(r).c_str());
+        }
+        out.close();
+        if (!ok || !out) local_rc = fail(ctx, PANTAX_HIP_E_IO, "cannot join the parts of %s", report.c_str());
+    }
+    if (full_path && (!cfg->strain || strain_done)) return agree(local_rc);
 
     lap("species table / report");
     // ---- a4: load_species_range (profile.rs:553-656)
@@ -227,7 +358,7 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         if (!ds.empty() && !ds.count(row.species)) continue;
         any_after_ds = true;
     }
-    if (!any_after_ds) return 0;        // reference: warn + exit(0) (profile.rs:595-598)
+    if (!any_after_ds) return agree(local_rc);   // reference: warn + exit(0) (profile.rs:595-598); the same decision on every rank
     for (auto &row : sp_profile) {
         if (!(row.abundance > cfg->min_species_abundance)) continue;                 // :602
         auto it = range_idx.find(row.species);
@@ -241,7 +372,8 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
 
     // ---- a5: rows with a null field are dropped; duplicate read ids (profile.rs:361-463)
     std::vector<uint8_t> flags(hr.flags);
-    {
+    if (strain_only) for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD;   // "U" in the saved report
+    if (!sharded) {
         std::unordered_set<uint64_t> seen;
         if (hr.ids_distinct != 1) seen.reserve(R * 2);
         bool unique = true;
@@ -257,6 +389,88 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
                 if (!ins.second && ins.first->second != sp_idx[r]) mixed.insert(hr.id_hash[r]);
             }
             for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0 && mixed.count(hr.id_hash[r])) flags[r] |= PANTAX_HIP_READ_DUPDROP;
+        }
+    } else {
+        // The same rule over N byte ranges: the alignments of one read id may sit in different ranks' slices, so every binned
+        // read sends (id hash, species, complete?) to the rank its hash selects; that rank sees ALL records of the id, decides
+        // "some id repeats" (the reference's `unique` flag, which covers incomplete rows too) and "this id spans species"
+        // (over complete rows); only when some id does repeat, the ids to drop are made known to every rank.
+        struct IdRec { uint64_t hash; int32_t sp; uint32_t complete; };
+        auto dest_of = [&](uint64_t h) { return (int)(((h * 0x9E3779B97F4A7C15ull) >> 33) % (uint64_t)W); };
+        std::vector<uint64_t> send_off(W + 1, 0), recv_off;
+        std::vector<IdRec> sendv;
+        if (local_rc == 0) {
+            std::vector<uint64_t> cur(W, 0);
+            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0) ++cur[dest_of(hr.id_hash[r])];
+            for (int j = 0; j < W; ++j) { send_off[j + 1] = send_off[j] + cur[j] * sizeof(IdRec); cur[j] = send_off[j] / sizeof(IdRec); }
+            sendv.resize(send_off[W] / sizeof(IdRec));
+            for (uint64_t r = 0; r < R; ++r)
+                if (sp_idx[r] >= 0) sendv[cur[dest_of(hr.id_hash[r])]++] = IdRec{hr.id_hash[r], sp_idx[r], flags[r] ? 0u : 1u};
+        }
+        PTX_TRY(exchange_sizes(send_off.data(), recv_off, local_rc));
+        std::vector<uint8_t> recvb;
+        PTX_TRY(a2a_host(sendv.data(), send_off.data(), recvb, recv_off.data()));
+        std::vector<uint64_t> mixed;
+        bool dup_any = false;
+        auto decide = [&]() -> int {
+            const uint64_t n = recv_off[W] / sizeof(IdRec);
+            std::vector<uint64_t> kh(n), kv(n);
+            const IdRec *in = reinterpret_cast<const IdRec *>(recvb.data());
+            for (uint64_t i = 0; i < n; ++i) { kh[i] = in[i].hash; kv[i] = ((uint64_t)in[i].complete << 32) | (uint32_t)in[i].sp; }
+            if (n > 65536) {   // by hash on the device (stable LSD radix sort, the payload word rides along)
+                DevBuf<uint64_t> a0, a1, b0, b1;
+                DevBuf<uint32_t> table, tmp;
+                PTX_TRY(upload(ctx, a0, kh.data(), n)); PTX_TRY(upload(ctx, a1, kv.data(), n));
+                PTX_HIP(ctx, b0.alloc(n)); PTX_HIP(ctx, b1.alloc(n)); PTX_HIP(ctx, table.alloc(sort_table_elems(n))); PTX_HIP(ctx, tmp.alloc(16));
+                SortBufs A, B;
+                A.nw = B.nw = 2; A.k[0] = a0.p; A.k[1] = a1.p; B.k[0] = b0.p; B.k[1] = b1.p;
+                std::vector<SortPass> passes;
+                add_passes(passes, 0, 0, 64);
+                bool in_b = false;
+                PTX_TRY(radix_sort(ctx, A, B, n, passes.data(), (int)passes.size(), table.p, tmp.p, &in_b, nullptr));
+                PTX_TRY(download(ctx, kh.data(), in_b ? b0.p : a0.p, n)); PTX_TRY(download(ctx, kv.data(), in_b ? b1.p : a1.p, n));
+                PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            } else {
+                std::vector<uint32_t> ord(n);
+                for (uint64_t i = 0; i < n; ++i) ord[i] = (uint32_t)i;
+                std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return kh[a] < kh[b]; });
+                std::vector<uint64_t> h2(n), v2(n);
+                for (uint64_t i = 0; i < n; ++i) { h2[i] = kh[ord[i]]; v2[i] = kv[ord[i]]; }
+                kh.swap(h2); kv.swap(v2);
+            }
+            for (uint64_t i = 0; i < n;) {
+                uint64_t j = i;
+                int64_t sp0 = -1;
+                bool mix = false;
+                for (; j < n && kh[j] == kh[i]; ++j) {
+                    if (!(kv[j] >> 32)) continue;                       // incomplete rows take no part in the species set
+                    const int64_t spj = (int64_t)(uint32_t)kv[j];
+                    if (sp0 < 0) sp0 = spj; else if (spj != sp0) mix = true;
+                }
+                if (j - i > 1) dup_any = true;
+                if (mix) mixed.push_back(kh[i]);
+                i = j;
+            }
+            return 0;
+        };
+        local_rc = decide();
+        std::vector<double> y(2 + (size_t)W, 0.0);
+        y[0] = local_rc != 0 ? 1.0 : 0.0; y[1] = dup_any ? 1.0 : 0.0; y[2 + rk] = (double)mixed.size();
+        PTX_TRY(allreduce(y.data(), y.size()));
+        if (y[0] != 0.0) return local_rc ? local_rc : others_failed();
+        uint64_t n_mixed_all = 0;
+        for (int q = 0; q < W; ++q) n_mixed_all += (uint64_t)y[2 + q];
+        if (y[1] != 0.0 && n_mixed_all) {   // process_with_duplicates: ids whose complete alignments span species are dropped everywhere
+            std::vector<uint64_t> so2(W + 1, 0), ro2(W + 1, 0), mine((size_t)W * mixed.size());
+            for (int j = 0; j < W; ++j) {
+                so2[j + 1] = so2[j] + mixed.size() * 8; ro2[j + 1] = ro2[j] + (uint64_t)y[2 + j] * 8;
+                std::copy(mixed.begin(), mixed.end(), mine.begin() + (size_t)j * mixed.size());
+            }
+            std::vector<uint8_t> allb;
+            PTX_TRY(a2a_host(mine.data(), so2.data(), allb, ro2.data()));
+            const uint64_t *am = reinterpret_cast<const uint64_t *>(allb.data());
+            std::unordered_set<uint64_t> drop(am, am + n_mixed_all);
+            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0 && drop.count(hr.id_hash[r])) flags[r] |= PANTAX_HIP_READ_DUPDROP;
         }
     }
 
@@ -287,6 +501,52 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
             for (int q = 1; q < W; ++q) if (load[q] < load[r]) r = q;
             owner[i] = r; load[r] += weight[i];
         }
+    }
+    // ---- the packed records of this rank's slice travel to the rank that owns their species; what arrives becomes
+    // this rank's resident reads (one-process read order restricted to its species).  Dropped rows, "U" reads and reads of
+    // unselected species stay behind -- none of them reaches get_node_abundances in the reference either.
+    if (sharded) {
+        Route rt;
+        std::vector<uint64_t> send_off(W + 1, 0);
+        auto pack = [&]() -> int {
+            std::vector<int32_t> owner_all(S, -1);
+            for (uint32_t i = 0; i < Ss; ++i) owner_all[sel[i]] = owner[i];
+            if (R) PTX_TRY(upload(ctx, reads.rd->d_flags, flags.data(), R));
+            reads.rd->has_flags = R != 0;
+            PTX_TRY(route_pack(ctx, bin_db.db, reads.rd, owner_all.data(), W, rt));
+            for (int j = 0; j <= W; ++j) send_off[j] = rt.word_off[j] * 4;
+            return 0;
+        };
+        if (local_rc == 0) local_rc = pack();
+        // {failure flag, bytes, reads, steps} of every (source, owner) pair in one all-reduce
+        std::vector<double> m(3 * (size_t)W * W + 1, 0.0);
+        if (local_rc == 0)
+            for (int j = 0; j < W; ++j) {
+                m[(size_t)rk * W + j] = (double)(send_off[j + 1] - send_off[j]);
+                m[(size_t)W * W + (size_t)rk * W + j] = (double)rt.n_reads[j];
+                m[2 * (size_t)W * W + (size_t)rk * W + j] = (double)rt.n_steps[j];
+            }
+        m[3 * (size_t)W * W] = local_rc != 0 ? 1.0 : 0.0;
+        PTX_TRY(allreduce(m.data(), m.size()));
+        if (m[3 * (size_t)W * W] != 0.0) return local_rc ? local_rc : others_failed();
+        std::vector<uint64_t> recv_off(W + 1, 0), nr_from(W), nt_from(W);
+        for (int i = 0; i < W; ++i) {
+            recv_off[i + 1] = recv_off[i] + (uint64_t)m[(size_t)i * W + rk];
+            nr_from[i] = (uint64_t)m[(size_t)W * W + (size_t)i * W + rk];
+            nt_from[i] = (uint64_t)m[2 * (size_t)W * W + (size_t)i * W + rk];
+        }
+        DevBuf<uint32_t> d_recv;
+        PTX_HIP(ctx, d_recv.alloc(recv_off[W] / 4 + 1));
+        PTX_TRY(a2a_dev(rt.d_send.p, send_off.data(), d_recv.p, recv_off.data()));
+        auto unpack = [&]() -> int {
+            std::unique_ptr<pantax_hip_reads> routed(new pantax_hip_reads());
+            PTX_TRY(reads_from_routed(ctx, d_recv.p, W, nr_from.data(), nt_from.data(), true, routed.get()));
+            pantax_hip_reads_free(ctx, reads.rd);
+            reads.rd = routed.release();
+            return 0;
+        };
+        local_rc = unpack();   // carried by the {failure flag, sums} all-reduce below
+        lap("route reads to owners");
     }
     // everything a rank does on its own shard; a failure here must not leave the other ranks waiting in the exchange below
     auto shard = [&]() -> int {
@@ -366,12 +626,8 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
         // the same resident reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
         // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
-        if (strain_only) {
-            // species from the saved report decide membership: a read whose recorded species differs from
-            // where its nodes bin now is dropped for that species
-            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD;
-        }
-        PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));
+        // (strain only: species from the saved report decide membership -- rows it calls "U" carry a drop flag, see a5 above)
+        if (!sharded) PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));   // sharded: flagged rows were not routed
         pantax_hip_reads *const sreads_rd = reads.rd;
         PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, nullptr));
         uint64_t nU = 0, n_abort = 0;
@@ -391,19 +647,29 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     }
     return 0;
     };   // shard
-    const int shard_rc = shard();
+    const int shard_rc = local_rc ? local_rc : shard();
 
     // ---- a15: abundance_est (profile.rs:3091-3289)
     std::vector<GenomeRow> genomes;
-    err = read_genomes_info(join(db_dir, "genomes_info.txt"), genomes);   // the reference always reads <db>/genomes_info.txt (:3099)
-    if (!err.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    local_rc = shard_rc;
+    if (local_rc == 0) {
+        const std::string err = read_genomes_info(join(db_dir, "genomes_info.txt"), genomes);   // the reference always reads <db>/genomes_info.txt (:3099)
+        if (!err.empty()) local_rc = fail(ctx, PANTAX_HIP_E_IO, "%s", err.c_str());
+    }
     std::unordered_multimap<std::string, size_t> by_hap;
     for (size_t i = 0; i < genomes.size(); ++i) by_hap.emplace(genomes[i].hap_id, i);
     std::vector<uint8_t> reported(Su, 0), pass(hap_names.size() ? hap_names.size() : 1, 0);
     double sum_all = 0.0, sum_pass = 0.0;
-    int local_rc = shard_rc;
     if (local_rc == 0) {
-        for (uint32_t k = 0; k < Su; ++k) reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
+        for (uint32_t k = 0; k < Su; ++k) {
+            reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
+            // the reference has no cap on candidate strains (dense nvert x npaths matrix, profile.rs:1333-1342); this build's LP
+            // holds 64 columns: such a species is left out of the table like a failed solve (profile.rs:2999-3003) -- say so
+            if (info[k].status1 == PANTAX_HIP_E_LIMIT || info[k].status2 == PANTAX_HIP_E_LIMIT)
+                std::fprintf(stderr, "[pantax_hip_profile] warning: species %s keeps %d candidate strains after the first filter, more than the %d "
+                                     "columns of this build's LP; it is left out of strain_abundance.txt\n",
+                             ranges[sel[use[k]]].species.c_str(), info[k].n_candidates, LAD_MAXP);
+        }
         if (Su) local_rc = pantax_hip_abundance_filter(Su, hap_off.data(), met.data(), reported.data(), cfg->single_cov_diff, cfg->min_cov, pass.data(), &sum_all, &sum_pass, nullptr, nullptr);
     }
     {   // the one exchange of the strain level: did every rank get through, and the two normalisers
@@ -499,4 +765,18 @@ extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profilin
     for (auto &r : final_rows) f << r.line << '\n';
     lap("tables");
     return 0;
+}
+
+// nothing throws across the boundary: an allocation failure or a parser exception becomes a status + message
+extern "C" int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg) {
+    if (!ctx || !cfg) return PANTAX_HIP_E_INVALID;
+    try {
+        return profile_impl(ctx, cfg);
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ctx, PANTAX_HIP_E_STATE, "profile: %s", e.what());
+    } catch (...) {
+        return fail(ctx, PANTAX_HIP_E_STATE, "profile: unknown exception");
+    }
 }

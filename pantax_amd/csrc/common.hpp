@@ -149,6 +149,9 @@ size_t bin_result_words(uint32_t S);
 struct Db; struct Reads;
 int species_profile_launch(Ctx *ctx, const Db *db, const Reads *rd, const unsigned long long *d_counters, const double *d_avg_len, int filtered,
                            uint8_t *d_keep, double *d_absolute);
+void species_profile_host(uint32_t S, const uint32_t *head_qlen, size_t n_head, const int64_t *read_count, const int64_t *base_sum,
+                          const int64_t *less_multi, const int64_t *uniq_count, const double *avg_len, int filtered, uint8_t *keep_out,
+                          double *absolute_out, double *abundance_out);
 constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
 constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership mask per node)
 
@@ -302,6 +305,7 @@ struct Reads {
     uint32_t n_long = 0;             // walks of more than 64 steps
     DevBuf<uint4> d_g_slot_rec;      // [R'] {species of the slot's read (-1: "U" or dropped row), its first node id, node base, #nodes}, written by the binning kernel
     bool binned = false;
+    bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip): no locus-grouped copy, no coverage pass
 };
 
 // node record fields (Db::d_node_rec): the coverage bitmap of one GPU holds < 2^40 bases and a node heads < 2^24 lookup rows
@@ -373,8 +377,18 @@ int trio_index_build(Ctx *ctx, Db *db);
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run table
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1);
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1, uint64_t file_base = 0, bool group = true);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
+// stage_route.hip: binned reads -> one message per owner rank, and back to resident reads on the owner
+struct Route {
+    int W = 0;
+    std::vector<uint64_t> n_reads, n_steps, word_off;   // per owner; word_off [W+1] (32-bit words)
+    DevBuf<uint32_t> d_send;                            // the W messages back to back
+    PinBuf h_send;                                      // host copy, made on demand
+    bool h_valid = false;
+};
+int route_pack(Ctx *ctx, const Db *db, const Reads *rd, const int32_t *owner_of_species, int W, Route &rt);
+int reads_from_routed(Ctx *ctx, const uint32_t *d_recv, int W, const uint64_t *n_reads_from, const uint64_t *n_steps_from, bool group, Reads *rd);
 
 }  // namespace ptx
 

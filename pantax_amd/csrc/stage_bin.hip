@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
             }
             species_out[r] = sp;
             // the coverage kernel walks the locus-grouped copy: hand it the species per slot, dropped rows as -1
-            const uint32_t slot = slot_of[r];
+            const uint32_t slot = slot_of ? slot_of[r] : 0xFFFFFFFFu;   // no grouped copy (a slice about to be routed away): species only
             if (slot != 0xFFFFFFFFu) {   // {species, its first node id, node base, #nodes}: everything the coverage kernel needs to place a node id
                 uint4 rec = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
                 if (sp >= 0 && !(flags && flags[r])) {
@@ -203,7 +203,7 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
     {
         KTimer t(ctx, "bin_reads_kernel");
 #define BIN_ARGS rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_qlen.p, rd->d_mapq.p, db->d_rng_start.p, db->d_rng_end.p, \
-                 db->d_rng_idx.p, S, rd->d_species.p, rd->d_slot_of.p, rd->has_flags ? rd->d_flags.p : nullptr, rd->d_g_slot_rec.p, \
+                 db->d_rng_idx.p, S, rd->d_species.p, rd->grouped ? rd->d_slot_of.p : nullptr, rd->has_flags ? rd->d_flags.p : nullptr, rd->d_g_slot_rec.p, \
                  db->d_sp_first_id.p, db->d_node_base.p, d_counters
         if (db->ranges_sorted_disjoint) {
             if (lds) hipLaunchKernelGGL((bin_reads_kernel<true, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);

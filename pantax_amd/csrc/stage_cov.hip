@@ -574,6 +574,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
 }
 
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio) {
+    if (!rd->grouped) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: these reads are a slice kept as plain columns (to be routed to their owner), not resident reads");
     if (!db->cov_prepared) PTX_TRY(coverage_prepare(ctx, db, rd, with_trio));
     db->cov_prepared = false;
     unsigned long long *d_abort = db->d_abort;

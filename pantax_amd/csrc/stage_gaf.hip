@@ -265,14 +265,17 @@ __global__ void __launch_bounds__(256) add_u32_offset_kernel(uint64_t n, uint32_
 // flags, id hashes and id spans -- the walks (node_id, step_off, path_start, path_end) are not downloaded.
 // Texts of 4 GiB and more are cut at line ends into pieces (32-bit positions inside a piece) whose packed columns are
 // joined on the device; PANTAX_GAF_PIECE_BYTES lowers the piece size (tests).
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd) {
+// `file_base`: where `text` starts in the file behind `fd` (a rank's byte range of a shared GAF); `group` = false leaves
+// the resident reads as plain columns (no locus-grouped copy: a slice that is binned and then routed away, stage_route.hip).
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd, uint64_t file_base, bool group) {
     out = HostReads();
+    if (resident) resident->grouped = group;
     if (size == 0) {
         if (resident) {
             static const uint32_t zero = 0;
             resident->R = resident->T = 0;
             PTX_TRY(upload(ctx, resident->d_step_off, &zero, 1));
-            PTX_TRY(build_step_read(ctx, resident, 0));
+            if (group) PTX_TRY(build_step_read(ctx, resident, 0));
             PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         return 0;
@@ -290,7 +293,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         }
         pcs.emplace_back(new GafPiece());
         piece_off.push_back(off);
-        PTX_TRY(tokenize_piece(ctx, text + off, end - off, fd, off, *pcs.back()));
+        PTX_TRY(tokenize_piece(ctx, text + off, end - off, fd, file_base + off, *pcs.back()));
         off = end;
     }
     uint64_t R = 0, T = 0;
@@ -379,7 +382,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         resident->d_step_off.take(o32[0]); resident->d_node_id.take(o32[1]); resident->d_pstart.take(o32[2]); resident->d_pend.take(o32[3]);
         resident->d_qlen.take(o32[4]); resident->d_mapq.take(o8[0]); resident->d_flags.take(o8[1]);
         resident->has_flags = true;
-        PTX_TRY(build_step_read(ctx, resident, max_id));
+        if (group) PTX_TRY(build_step_read(ctx, resident, max_id));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     out.n_lines = R;

@@ -87,6 +87,22 @@ class Engine:
         self.db = db
         self.U = None
 
+    def upload_ranges(self, range_start, range_end):
+        """A db of species RANGES only (no graphs): what the binning of a slice of reads needs before the reads are routed
+        to the owners of their species; the file seam bins against such a db too."""
+        if self.db:
+            self.lib.pantax_hip_db_free(self.ctx, self.db)
+            self.db = None
+        self.range_start = as_c(range_start, np.int64)
+        self.range_end = as_c(range_end, np.int64)
+        self.S = len(self.range_start)
+        self.V = self.H = 0
+        gs = _ffi.Graphs(self.S, p(self.range_start), p(self.range_end), None, None, None, None, None)
+        db = C.c_void_p()
+        self._check(self.lib.pantax_hip_db_upload(self.ctx, C.byref(gs), C.byref(db)))
+        self.db = db
+        self.U = None
+
     def upload_reads(self, step_off, node_id, pstart, pend, qlen, mapq, flags=None):
         if self.reads:
             self.lib.pantax_hip_reads_free(self.ctx, self.reads)
@@ -130,6 +146,56 @@ class Engine:
             return dict(qlen=arr(v.qlen, np.uint32), mapq=arr(v.mapq, np.uint8), flags=arr(v.flags, np.uint8))
         finally:
             self.lib.pantax_hip_gaf_free(gaf)
+
+    # ------------------------------------------------------------------ reads routed to the owner of their species
+    def route_pack(self, owner_of_species, world):
+        """The resident reads (binned against the resident db) as one message per owner rank (stable partition on the
+        device).  -> (route handle, n_reads_to [W], n_steps_to [W]); free the handle with route_free."""
+        own = as_c(owner_of_species, np.int32)
+        assert len(own) == self.S
+        nr = np.zeros(world, dtype=np.uint64)
+        nt = np.zeros(world, dtype=np.uint64)
+        rt = C.c_void_p()
+        self._check(self.lib.pantax_hip_reads_route_pack(self.ctx, self.db, self.reads, p(own), int(world), C.byref(rt), p(nr), p(nt)))
+        return rt, nr, nt
+
+    def route_buffer(self, route, world, on_device=False):
+        """-> (address of the W messages back to back, word offsets [W+1]); device pointer when on_device, else pinned host memory."""
+        buf = C.c_void_p()
+        off = np.zeros(world + 1, dtype=np.uint64)
+        self._check(self.lib.pantax_hip_route_buffer(self.ctx, route, int(bool(on_device)), C.byref(buf), p(off)))
+        return buf.value or 0, off
+
+    def route_messages(self, route, world):
+        """host copies of the W messages (uint32 arrays)"""
+        addr, off = self.route_buffer(route, world, on_device=False)
+        n = int(off[-1])
+        if n == 0:
+            return [np.zeros(0, dtype=np.uint32) for _ in range(world)]
+        whole = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint32)), shape=(n,))
+        return [whole[int(off[d]):int(off[d + 1])].copy() for d in range(world)]
+
+    def route_free(self, route):
+        self.lib.pantax_hip_route_free(self.ctx, route)
+
+    def reads_from_routed(self, recv, n_reads_from, n_steps_from, on_device=False):
+        """recv: the messages of ranks 0..W-1 for this rank back to back -- a uint32 numpy array (host) or, with on_device, the
+        integer address of device memory.  Replaces the resident reads."""
+        if self.reads:
+            self.lib.pantax_hip_reads_free(self.ctx, self.reads)
+            self.reads = None
+        nr = as_c(n_reads_from, np.uint64)
+        nt = as_c(n_steps_from, np.uint64)
+        if on_device:
+            ptr = C.c_void_p(int(recv))
+        else:
+            recv = as_c(recv, np.uint32)
+            ptr = p(recv)
+        rd = C.c_void_p()
+        self._check(self.lib.pantax_hip_reads_from_routed(self.ctx, ptr, int(bool(on_device)), len(nr), p(nr), p(nt), C.byref(rd)))
+        self.reads = rd
+        self.R = int(nr.sum())
+        self.T = int(nt.sum())
 
     def set_read_flags(self, flags):
         f = None if flags is None else as_c(flags, np.uint8)
@@ -282,8 +348,10 @@ class Engine:
                 min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,
                 mode=2, sample_nodes=0, designated_species=None, zip="serialize", out_binning_file=None,
                 reads_binning_file=None, range_file=None, species_len_file=None, image_cache=0, rank=0, world_size=1,
-                allreduce=None):
-        """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out."""
+                allreduce=None, alltoallv=None):
+        """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out.  allreduce(float64 array) sums in place over
+        the ranks; alltoallv(send uint8 array, send_off [W+1], recv uint8 array, recv_off [W+1]) moves bytes between the ranks
+        (host buffers) and switches on the sharded ingest."""
         enc = lambda x: None if x is None else str(x).encode()
         cfg = _ffi.ProfilingConfig(
             db=enc(db), wd=enc(wd), output_dir=enc(output_dir or wd), genomes_metadata=None, range_file=enc(range_file),
@@ -304,6 +372,23 @@ class Engine:
                     return 1
             cb = _ffi.ALLREDUCE_FN(_cb)
             cfg.allreduce_sum = C.cast(cb, C.c_void_p)
+        cb2 = None
+        if alltoallv is not None:
+            W = int(world_size)
+
+            def _cb2(_user, send, send_off, recv, recv_off):
+                try:
+                    so = np.ctypeslib.as_array(send_off, shape=(W + 1,)).astype(np.int64)
+                    ro = np.ctypeslib.as_array(recv_off, shape=(W + 1,)).astype(np.int64)
+                    sb = (np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(int(so[-1]),)) if so[-1] else np.zeros(0, dtype=np.uint8))
+                    rb = (np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(int(ro[-1]),)) if ro[-1] else np.zeros(0, dtype=np.uint8))
+                    alltoallv(sb, so, rb, ro)
+                    return 0
+                except Exception:   # noqa: BLE001 -- reported through the return code
+                    return 1
+            cb2 = _ffi.ALLTOALLV_FN(_cb2)
+            cfg.alltoallv = C.cast(cb2, C.c_void_p)
+            cfg.comm_device_buffers = 0
         self._check(self.lib.pantax_hip_profile(self.ctx, C.byref(cfg)))
 
     def save_images(self, paths, hap_names):

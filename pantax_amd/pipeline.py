@@ -58,6 +58,22 @@ class LocalComm:
     def names(self, species_names, hap_names):
         return [list(species_names)], [list(hap_names)]
 
+    def allreduce_sum(self, a):
+        return np.asarray(a, dtype=np.float64).copy()
+
+    def alltoall_counts(self, to):
+        return np.asarray(to, dtype=np.int64).copy()
+
+    def alltoallv_words(self, send, send_words, recv_words, on_device=False):
+        return send
+
+
+class _DeviceWords:
+    """A window of device memory owned by libpantax_hip (u32 words at `addr`) as an object torch.as_tensor understands."""
+
+    def __init__(self, addr, n_words):
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i4", "data": (int(addr), False), "version": 2}
+
 
 class TorchComm:
     """torch.distributed plumbing (backend nccl == RCCL on ROCm; gloo in the CPU tests).  ONE collective per step."""
@@ -98,6 +114,44 @@ class TorchComm:
     def exchange(self, slab):
         return self.exchange_end(self.exchange_begin(slab))
 
+    # ---- the packed reads travel to the owner of their species (ingest time, once per input) ----------------
+    def allreduce_sum(self, a):
+        """host array -> its sum over the ranks (float64)"""
+        dev = self.device if self.device is not None else "cpu"
+        t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def alltoall_counts(self, to):
+        """to [k, world] int64: what this rank sends to every rank (k quantities) -> [k, world]: what every rank sends here"""
+        to = np.ascontiguousarray(to, dtype=np.int64)
+        dev = self.device if self.device is not None else "cpu"
+        k = to.shape[0]
+        send = self.torch.from_numpy(np.ascontiguousarray(to.T)).to(dev)          # [world, k]: row j goes to rank j
+        recv = self.torch.empty_like(send)
+        self.dist.all_to_all_single(recv, send)
+        return recv.cpu().numpy().T.reshape(k, self.world)
+
+    def alltoallv_words(self, send, send_words, recv_words, on_device=False):
+        """All-to-all(v) of 32-bit words: send_words[j] words go to rank j, recv_words[i] arrive from rank i.
+        on_device (RCCL): `send` is the address of device memory, the result a CUDA int32 tensor (HBM to HBM over xGMI,
+        nothing staged); otherwise `send` is a uint32 numpy array and so is the result (gloo)."""
+        sw = [int(x) for x in send_words]
+        rw = [int(x) for x in recv_words]
+        if on_device:
+            src = (self.torch.as_tensor(_DeviceWords(send, sum(sw)), device=self.device) if sum(sw)
+                   else self.torch.empty(0, dtype=self.torch.int32, device=self.device))
+            dst = self.torch.empty(sum(rw), dtype=self.torch.int32, device=self.device)
+            self.dist.all_to_all_single(dst, src, output_split_sizes=rw, input_split_sizes=sw)
+            self.torch.cuda.synchronize()
+            return dst
+        src = self.torch.from_numpy(np.ascontiguousarray(send, dtype=np.uint32).view(np.int32))
+        dst = self.torch.empty(sum(rw), dtype=self.torch.int32)
+        if self.device is not None:   # RCCL with host staging
+            src, dst = src.to(self.device), dst.to(self.device)
+        self.dist.all_to_all_single(dst, src, output_split_sizes=rw, input_split_sizes=sw)
+        return dst.cpu().numpy().view(np.uint32)
+
     def names(self, species_names, hap_names):
         """Static metadata: gathered once, not per step."""
         if self._names is None:
@@ -105,6 +159,39 @@ class TorchComm:
             self.dist.all_gather_object(out, (list(species_names), list(hap_names)))
             self._names = ([o[0] for o in out], [o[1] for o in out])
         return self._names
+
+
+def route_reads(eng, owner_of_species, comm, on_device=None):
+    """`eng` holds a SLICE of the reads, binned against the ranges of ALL species (eng.rcls_profile on a db of
+    every species' range); owner_of_species[s] = rank that owns species s.  The packed records go to their owners
+    (pantax_hip_reads_route_pack -> one all-to-all of the sizes, one all-to-all(v) of the messages -> pantax_hip_reads_from_
+    routed) and become this rank's resident reads, in the one-process read order restricted to its species.
+    -> dict(sent_reads, sent_words, recv_reads, recv_words)"""
+    W = comm.world
+    rt, nr_to, nt_to = eng.route_pack(owner_of_species, W)
+    try:
+        words_to = 5 * nr_to.astype(np.int64) + nt_to.astype(np.int64)
+        got = comm.alltoall_counts(np.stack([nr_to.astype(np.int64), nt_to.astype(np.int64)]))
+        nr_from, nt_from = got[0], got[1]
+        words_from = 5 * nr_from + nt_from
+        local = W == 1 and on_device is None          # nothing to exchange: hand the one message over in place
+        if on_device is None:
+            on_device = getattr(comm, "device", None) is not None
+        if local:
+            addr, _ = eng.route_buffer(rt, W, on_device=True)
+            eng.reads_from_routed(addr, nr_from, nt_from, on_device=True)
+        elif on_device:
+            addr, _ = eng.route_buffer(rt, W, on_device=True)
+            recv = comm.alltoallv_words(addr, words_to, words_from, on_device=True)
+            eng.reads_from_routed(recv.data_ptr(), nr_from, nt_from, on_device=True)
+            del recv
+        else:
+            send = np.concatenate(eng.route_messages(rt, W))
+            recv = comm.alltoallv_words(send, words_to, words_from, on_device=False)
+            eng.reads_from_routed(recv, nr_from, nt_from, on_device=False)
+    finally:
+        eng.route_free(rt)
+    return dict(sent_reads=int(nr_to.sum()), sent_words=int(words_to.sum()), recv_reads=int(nr_from.sum()), recv_words=int(words_from.sum()))
 
 
 def local_stage(eng, avg_len, cfg, single_call=True):

@@ -59,6 +59,29 @@ def test_two_rank_finalize_matches_single_process(tmp_path):
     assert not any(r[0] == "sp1_0" for r in got["strain"])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_read_routing_exchange_over_gloo(tmp_path, world):
+    """every rank's messages reach their owners in source-rank order (sizes by one all-to-all, payload by one
+    all-to-all(v)); pairs that exchange nothing are fine."""
+    from tests.dist_route_worker import slice_messages
+    out = tmp_path / "route.json"
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_route_worker.py"), str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    sent = [slice_messages(r, world) for r in range(world)]
+    for d in range(world):
+        got = json.load(open("%s.%d" % (out, d)))
+        exp = np.concatenate([sent[r][0][d] for r in range(world)])
+        assert got["recv"] == exp.tolist()
+        assert got["nr"] == [int(sent[r][1][d]) for r in range(world)] and got["nt"] == [int(sent[r][2][d]) for r in range(world)]
+        assert got["stats"]["recv_words"] == len(exp)
+        assert got["tot"][0] == got["tot"][1] and got["tot"][2] == world       # every read sent is received by somebody
+
+
 def test_partition_species_is_balanced_and_deterministic():
     from pantax_amd.pipeline import partition_species
     rng = np.random.default_rng(4)
