@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include "lad.hpp"
+#include "primitives.hpp"
 
 using namespace ptx;
 
@@ -99,7 +100,7 @@ int strain_prezero(Ctx *ctx, Db *db) {
     lb.prezeroed = false;
     PTX_TRY(bind_arena(ctx, db, lb, L));
     PTX_HIP(ctx, lb.d_mask.alloc(db->V));
-    PTX_HIP(ctx, hipMemsetAsync(lb.d_mask.p, 0, db->V * sizeof(uint64_t), ctx->stream));
+    PTX_TRY(zero_fill(ctx, lb.d_mask.p, db->V * sizeof(uint64_t)));
     lb.prezeroed = true;
     return 0;
 }

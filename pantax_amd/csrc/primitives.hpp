@@ -12,6 +12,9 @@ size_t scan_tmp_elems(uint64_t n);
 int exclusive_scan_u32(Ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total);
 int exclusive_scan_u8(Ctx *ctx, const uint8_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total);
 
+// large zero fills (16-byte stores from every CU; small ranges go through hipMemsetAsync), on ctx->stream
+int zero_fill(Ctx *ctx, void *ptr, size_t bytes);
+
 // Records are structure-of-arrays: up to 3 u64 key words + one u32 payload.
 constexpr int SORT_MAX_WORDS = 3;
 struct SortBufs {

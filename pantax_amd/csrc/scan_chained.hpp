@@ -7,9 +7,12 @@
 
 namespace ptx {
 
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+// two tile shapes: 256 threads x 8 items for small inputs (many workgroups of little work), 512 x 16 above SCAN_BIG_N items --
+// every tile costs one ticket (a same-address atomic, ~12-25 ns each, served one after the other) and one hop of the
+// look-back chain, so on tens of millions of items 2048-item tiles make the scan ticket-bound (0.40 ms for 3.2e7 items,
+// 0.65 TB/s) where 8192-item tiles stream
+constexpr uint64_t SCAN_BIG_N = 1u << 22;
+constexpr int SCAN_TILE_SMALL = 256 * 8, SCAN_TILE_BIG = 512 * 16;
 
 // Single-pass chained scan (decoupled look-back): ONE launch per scan.  A workgroup takes a ticket (tiles are
 // therefore started in order, so the tiles it waits for are already running), scans its tile of SCAN_TILE items,
@@ -24,13 +27,15 @@ __device__ __forceinline__ uint64_t st_pack(uint32_t epoch, uint64_t flag, uint3
 // load(i) -> value of item i (i < n); store(i, exclusive prefix, value) consumes it.  Loads of a tile happen before
 // its stores, so in-place scans are fine.  Both functors are called in STRIPED order (consecutive lanes = consecutive
 // items): whatever they touch in memory is coalesced, also 16-byte records; the blocked order the scan itself wants
-// (8 consecutive items per thread) is reached through two padded LDS transposes.
-template <class Load, class Store>
+// (SCAN_ITEMS consecutive items per thread) is reached through two padded LDS transposes of one buffer; the loaded
+// values stay in registers for the store.
+template <int SCAN_BLOCK, int SCAN_ITEMS, class Load, class Store>
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(Load load, Store store, uint64_t n, uint32_t *__restrict__ ws, uint32_t epoch,
                                                                   uint32_t *__restrict__ total) {
+    constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
     __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
     __shared__ uint32_t s_tile, s_excl;
-    __shared__ uint32_t s_v[SCAN_BLOCK * (SCAN_ITEMS + 1)], s_p[SCAN_BLOCK * (SCAN_ITEMS + 1)];   // one pad word per thread row: no bank conflicts
+    __shared__ uint32_t s_v[SCAN_BLOCK * (SCAN_ITEMS + 1)];   // one pad word per thread row: no bank conflicts
     uint32_t *ticket = ws;
     uint64_t *state = reinterpret_cast<uint64_t *>(ws + 2);
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
@@ -38,21 +43,25 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(Load load, Sto
     const uint32_t tile = s_tile, nb = gridDim.x;
     const int lane = threadIdx.x & 63;
     const uint64_t tile_base = (uint64_t)tile * SCAN_TILE;
-    uint32_t v[SCAN_ITEMS], s = 0;
+    uint32_t raw[SCAN_ITEMS], v[SCAN_ITEMS], s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {      // striped: item j = k * 256 + thread
+    for (int k = 0; k < SCAN_ITEMS; ++k) {      // striped: item j = k * SCAN_BLOCK + thread
+        const uint64_t idx = tile_base + (uint32_t)(k * SCAN_BLOCK) + threadIdx.x;
+        raw[k] = idx < n ? load(idx) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
         const uint32_t j = k * SCAN_BLOCK + threadIdx.x;
-        const uint64_t idx = tile_base + j;
-        s_v[j + j / SCAN_ITEMS] = idx < n ? load(idx) : 0u;
+        s_v[j + j / SCAN_ITEMS] = raw[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {      // blocked: thread t owns items 8t .. 8t+7
+    for (int i = 0; i < SCAN_ITEMS; ++i) {      // blocked: thread t owns items ITEMS * t .. ITEMS * t + ITEMS - 1
         v[i] = s_v[threadIdx.x * (SCAN_ITEMS + 1) + i];
         s += v[i];
     }
     uint32_t tot;
-    uint32_t off = block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot);
+    uint32_t off = block_excl_scan<SCAN_BLOCK>(s, s_wave, &tot);   // its barriers also end every thread's reads of s_v
     if (threadIdx.x < 64) {
         uint32_t excl = 0;
         if (tile == 0) {
@@ -78,26 +87,24 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_chained_kernel(Load load, Sto
         }
         if (lane == 0) s_excl = excl;
     }
-    __syncthreads();
-    off += s_excl;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        s_p[threadIdx.x * (SCAN_ITEMS + 1) + i] = off;
+    for (int i = 0; i < SCAN_ITEMS; ++i) {      // prefixes relative to the tile, blocked, into the same buffer
+        s_v[threadIdx.x * (SCAN_ITEMS + 1) + i] = off;
         off += v[i];
     }
     __syncthreads();
+    const uint32_t excl = s_excl;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const uint32_t j = k * SCAN_BLOCK + threadIdx.x;
         const uint64_t idx = tile_base + j;
-        if (idx < n) store(idx, s_p[j + j / SCAN_ITEMS], s_v[j + j / SCAN_ITEMS]);
+        if (idx < n) store(idx, excl + s_v[j + j / SCAN_ITEMS], raw[k]);
     }
     if (tile == nb - 1 && threadIdx.x == 0) {
-        if (total) *total = s_excl + tot;
+        if (total) *total = excl + tot;
         *ticket = 0;   // every ticket of this launch has been taken
     }
 }
-
 
 template <class Load, class Store>
 int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_total, const char *timer_name) {
@@ -105,7 +112,9 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
         if (d_total) PTX_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
         return 0;
     }
-    const uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    const bool big = n >= SCAN_BIG_N;
+    const uint32_t tile_items = big ? SCAN_TILE_BIG : SCAN_TILE_SMALL;
+    const uint32_t nb = (uint32_t)((n + tile_items - 1) / tile_items);
     const size_t need = 2 + 2 * (size_t)nb;   // u32 words: ticket, pad, one u64 per tile
     if (ctx->d_scan_ws.n < need) {
         PTX_HIP(ctx, ctx->d_scan_ws.alloc(std::max<size_t>(need, 1u << 16)));
@@ -117,8 +126,8 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
         ctx->scan_epoch = 1;
     }
     KTimer t(ctx, timer_name);
-    hipLaunchKernelGGL((scan_chained_kernel<Load, Store>), dim3(nb), dim3(SCAN_BLOCK), 0, ctx->stream, load, store, n, ctx->d_scan_ws.p, ctx->scan_epoch,
-                       d_total);
+    if (big) hipLaunchKernelGGL((scan_chained_kernel<512, 16, Load, Store>), dim3(nb), dim3(512), 0, ctx->stream, load, store, n, ctx->d_scan_ws.p, ctx->scan_epoch, d_total);
+    else hipLaunchKernelGGL((scan_chained_kernel<256, 8, Load, Store>), dim3(nb), dim3(256), 0, ctx->stream, load, store, n, ctx->d_scan_ws.p, ctx->scan_epoch, d_total);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -560,7 +560,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     db->d_abort = reinterpret_cast<unsigned long long *>(base + off_abort);
     db->d_bitmap.view(base + off_bm, words);
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
-    PTX_HIP(ctx, hipMemsetAsync(base, 0, total, ctx->stream));
+    PTX_TRY(zero_fill(ctx, base, total));
     if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");

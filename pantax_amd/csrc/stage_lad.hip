@@ -595,7 +595,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     PTX_HIP(ctx, lb->d_mask.alloc(V));
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
-    if (!lb->prezeroed) PTX_HIP(ctx, hipMemsetAsync(lb->d_mask.p, 0, V * sizeof(uint64_t), ctx->stream));
+    if (!lb->prezeroed) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));
     // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
     // rows: compact -> sort by (species, mask, a)
     Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc

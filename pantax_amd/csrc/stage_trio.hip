@@ -453,27 +453,28 @@ int trio_index_build(Ctx *ctx, Db *db) {
     if (P >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu path steps exceed 32-bit positions", (unsigned long long)P);
     TrioScratch &ts = db->trio_scratch;
     const uint32_t NT = (uint32_t)db->n_tiles;
-    // everything that must start at zero lives in one arena: cnt | cursor | cursor2 | first_cnt | tile_cnt | uniq_q (bytes)
-    const size_t zwords = 4 * (V + 1) + (NT + 1) + (P + 3) / 4 + 1;
+    // which uniqueness path: by node block (default) or through global buckets (species of >= 2^27 nodes, or forced)
+    bool by_block = db->trio_block_ok;
+    if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
+    // everything that must start at zero lives in one arena: cursor2 | first_cnt | tile_cnt | uniq_q (bytes) [| cnt | cursor: bucket
+    // path only -- the node-block path never touches them, and zero-filling is what this arena costs]
+    const size_t zcommon = 2 * (V + 1) + (NT + 1) + (P + 3) / 4 + 1, zwords = zcommon + (by_block ? 0 : 2 * (V + 1));
     PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
-    ts.cnt.view(ts.zero_arena.p, V + 1); ts.cursor.view(ts.zero_arena.p + (V + 1), V + 1);
-    ts.cursor2.view(ts.zero_arena.p + 2 * (V + 1), V + 1); ts.first_cnt.view(ts.zero_arena.p + 3 * (V + 1), V + 1);
-    ts.tile_cnt.view(ts.zero_arena.p + 4 * (V + 1), NT + 1);
-    ts.uniq_q.view(ts.zero_arena.p + 4 * (V + 1) + (NT + 1), P ? P : 1);
+    ts.cursor2.view(ts.zero_arena.p, V + 1); ts.first_cnt.view(ts.zero_arena.p + (V + 1), V + 1);
+    ts.tile_cnt.view(ts.zero_arena.p + 2 * (V + 1), NT + 1);
+    ts.uniq_q.view(ts.zero_arena.p + 2 * (V + 1) + (NT + 1), P ? P : 1);
+    if (!by_block) { ts.cnt.view(ts.zero_arena.p + zcommon, V + 1); ts.cursor.view(ts.zero_arena.p + zcommon + (V + 1), V + 1); }
     PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
     PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
     PTX_HIP(ctx, ts.d_tot.alloc(3));
     PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, sizeof(uint32_t), ctx->stream));   // error word of trio_block_kernel
-    PTX_HIP(ctx, hipMemsetAsync(ts.zero_arena.p, 0, zwords * sizeof(uint32_t), ctx->stream));
+    PTX_TRY(zero_fill(ctx, ts.zero_arena.p, zwords * sizeof(uint32_t)));
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
-    // which uniqueness path: by node block (default) or through global buckets (species of >= 2^27 nodes, or forced)
-    bool by_block = db->trio_block_ok;
-    if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
     if (P && by_block) {
         KTimer t(ctx, "trio_block_kernel");
         hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(64), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,

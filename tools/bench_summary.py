@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print the essentials of a bench.py JSON line."""
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[0])
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
 print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  launches/step %s" % (d["value"], d["unit"], d["ms_per_step"], d["ms_per_step_trio_index_resident"], d.get("launches_per_step")))
 r = d["roofline"]
 print("roofline", r["kernel"], "avg_ms %.3f frac %.3f traffic %s" % (r["avg_ms"], r["frac"], r.get("traffic")))
