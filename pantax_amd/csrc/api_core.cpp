@@ -309,7 +309,8 @@ extern "C" {
 void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
     std::unique_lock<std::recursive_mutex> lk;
     if (ctx) lk = std::unique_lock<std::recursive_mutex>(ctx->mu);
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    // the side stream may still be building this db's trio index (a step that failed after the fork)
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2); }
     delete db;
 }
 

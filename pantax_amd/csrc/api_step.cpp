@@ -44,6 +44,12 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
         PTX_HIP(ctx, e);
         forked = true;
     }
+    // a failure between the fork and the join must not leave the index half built behind a `trio_built` flag: the next
+    // call would read it with no ordering against the side stream
+    struct ForkGuard {
+        Ctx *c; Db *d; bool armed;
+        ~ForkGuard() { if (armed) { (void)hipStreamSynchronize(c->stream2); d->trio_built = false; d->cov_done = false; } }
+    } fork_guard{ctx, db, forked};
     // a2 + a3 counters
     PTX_HIP(ctx, db->d_counters.alloc(bin_counter_words(S)));
     PTX_TRY(bin_reads_launch(ctx, db, reads, db->d_counters.p));
@@ -61,6 +67,7 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     struct CovPrepGuard { Db *d; ~CovPrepGuard() { d->cov_prepared = false; } } covprep_guard{db};
     // a8 needs both
     if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    fork_guard.armed = false;   // joined: everything later on the main stream is ordered behind the index
     PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,

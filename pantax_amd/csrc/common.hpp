@@ -116,6 +116,7 @@ struct Ctx {
     hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)
     hipEvent_t ev_fork = nullptr;
     std::string err;
+    std::mutex err_mu;               // guards `err` alone (fail() may run before PTX_ENTER)
     bool timing = false;
     std::string timing_filter;   // non-empty: only launches of this name are timed (two events per step instead of ~200)
     std::vector<TimedLaunch> pending;

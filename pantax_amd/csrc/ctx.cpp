@@ -20,8 +20,12 @@ int fail(Ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx) { ctx->err = buf; g_thread_err = buf; g_thread_err_ctx = ctx; }
-    else g_init_err = buf;
+    if (ctx) {
+        // the per-thread copy is what pantax_hip_last_error returns to the failing thread; the shared one (for other threads)
+        // has its own lock: fail() is also reached before an entry point takes the ctx lock
+        { std::lock_guard<std::mutex> g(ctx->err_mu); ctx->err = buf; }
+        g_thread_err = buf; g_thread_err_ctx = ctx;
+    } else g_init_err = buf;
     return code;
 }
 
@@ -70,7 +74,9 @@ const char *pantax_hip_version(void) { return "pantax-hip 0.1.0 (gfx950)"; }
 const char *pantax_hip_last_error(const pantax_hip_ctx *ctx) {
     if (!ctx) return g_init_err.c_str();
     if (g_thread_err_ctx == ctx) return g_thread_err.c_str();   // this thread's own last failure on this ctx
-    return ctx->err.c_str();
+    std::lock_guard<std::mutex> g(const_cast<pantax_hip_ctx *>(ctx)->err_mu);   // another thread's failure: a copy that outlives the lock
+    g_thread_err = ctx->err;
+    return g_thread_err.c_str();
 }
 
 int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) {

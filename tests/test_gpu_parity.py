@@ -497,6 +497,34 @@ def test_pao_solve_edge_cases(eng):
     assert st == 0 and obj == pytest.approx(0.0, abs=1e-9) and np.allclose(x, truth, atol=1e-8)
 
 
+def test_path_cov_ratio_beyond_f32_integer_range(eng):
+    """path_cov_ratio (profile.rs:1344-1357) once a path holds more than 2^24 bases: the reference accumulates both sums in f32
+    (in whatever order nalgebra's product walks the column), so from there on its last digits depend on the summation order.
+    This build forms both sums exactly and divides once in f32: it equals the correctly rounded quotient of the f32-rounded
+    exact sums, and the oracle's sequential f32 accumulation agrees to a few units of f32 precision -- the documented
+    divergence of INTEGRATION.md section 5.  Below 2^24 the two are identical (every other test)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(17)
+    V, p = 6000, 3
+    node_len = rng.integers(2000, 9000, size=V).astype(np.int64)          # ~3.3e7 bases per path: beyond 2^24 = 1.68e7
+    cov = (node_len * rng.random(V)).astype(np.uint64)
+    mask = rng.integers(1, 1 << p, size=V).astype(np.uint64)
+    mask[:10] = (1 << p) - 1
+    po, pn = _paths_from_masks(mask, p)
+    ab = cov / node_len
+    x, ratio, obj, st = eng.pao_solve(node_len, ab, cov, po, pn, np.arange(p))
+    assert st == 0
+    G = orc.Graph(node_len, po, pn)
+    _, ratio_orc = orc.path_masks(G, np.arange(p), cov)
+    for k in range(p):
+        on = ((mask >> np.uint64(k)) & np.uint64(1)).astype(bool)
+        s_cov, s_len = int(cov[on].sum()), int(node_len[on].sum())
+        assert s_len > (1 << 24)
+        assert np.float32(ratio[k]) == np.float32(s_cov) / np.float32(s_len)                 # exact sums, one f32 divide
+        assert abs(float(ratio[k]) - s_cov / s_len) <= 2.0 ** -23 * (s_cov / s_len)           # within one f32 ulp of the true ratio
+        assert abs(float(ratio_orc[k]) - float(ratio[k])) <= 64 * 2.0 ** -24 * float(ratio[k])   # the f32 running sums drift, a little
+
+
 @pytest.mark.parametrize("seed,S,H,R,L,pf,opts", [
     (21, 2, 6, 30000, 40000, 0.5, {}), (22, 4, 10, 80000, 30000, 0.4, {}), (23, 3, 5, 20000, 30000, 0.2, {}),
     # the option branches of first_filter_paths / second_filter_paths (profile.rs:1080-1285, main.rs:108-124)
