@@ -165,6 +165,8 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         return 0;
     };
 
+    const std::string report = opt(cfg->out_binning_file);
+    const bool want_report = full_path && !report.empty() && report != "None";
     // ---- a1 + a2/a3, rank-local: ranges, GAF (this rank's byte range when sharded) -> packed reads in HBM, binned against
     // ALL species ranges (ranges-only db), counters on the device
     const std::string gaf_path = opt(cfg->input_aln_file);
@@ -196,7 +198,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             text_end = rk + 1 == W ? mf.size : line_start_at_or_after(mf, mf.size / (uint64_t)W * (uint64_t)(rk + 1));
         }
         reads.rd = new pantax_hip_reads();
-        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded));
+        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded, /*want_id_spans=*/want_report));
         R = hr.qlen.size();
         lap("ranges + GAF tokenise");
         rs.resize(S); re.resize(S);
@@ -241,8 +243,6 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     local_rc = 0;
 
     std::vector<SpeciesProfileRow> sp_profile;   // species_taxid, predicted_abundance, predicted_coverage
-    const std::string report = opt(cfg->out_binning_file);
-    const bool want_report = full_path && !report.empty() && report != "None";
     auto report_part = [&](int r) { return report + ".part" + std::to_string(r); };
     auto species_level = [&]() -> int {
     if (full_path) {

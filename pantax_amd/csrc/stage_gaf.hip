@@ -18,6 +18,7 @@
 // The text is read three times (byte-granular gathers per line: L2-friendly, each line is contiguous).
 // Algorithmic bytes: 3 N (text) + 4 T + 30 R (outputs).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -220,7 +221,17 @@ static int tokenize_piece(Ctx *ctx, const char *text, uint64_t size, int fd, uin
     DevBuf<uint8_t> d_txt;
     DevBuf<uint32_t> nl_pos, tot, scan_tmp;
     uint32_t n_nl = 0;
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gaf_tokenize]   piece: %-25s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd, file_off));
+    lap("text upload + newline scan");
     PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
     const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
     DevBuf<uint32_t> r32[8], ridx, soff;
@@ -253,6 +264,7 @@ static int tokenize_piece(Ctx *ctx, const char *text, uint64_t size, int fd, uin
     }
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the piece's text and raw columns are released on return
+    lap("parse + scans + fill");
     return 0;
 }
 
@@ -267,9 +279,22 @@ __global__ void __launch_bounds__(256) add_u32_offset_kernel(uint64_t n, uint32_
 // joined on the device; PANTAX_GAF_PIECE_BYTES lowers the piece size (tests).
 // `file_base`: where `text` starts in the file behind `fd` (a rank's byte range of a shared GAF); `group` = false leaves
 // the resident reads as plain columns (no locus-grouped copy: a slice that is binned and then routed away, stage_route.hip).
-int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd, uint64_t file_base, bool group) {
+// `want_id_spans`: where every read id sits in the text (the binning report writes the ids back); 160 MB of host memory and
+// ~20 ms per 10 M reads that nobody else needs.
+int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd, uint64_t file_base, bool group,
+                        bool want_id_spans) {
     out = HostReads();
     if (resident) resident->grouped = group;
+    // PANTAX_HIP_TRACE=1: where the load spends its time (stderr)
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gaf_tokenize] %-34s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (size == 0) {
         if (resident) {
             static const uint32_t zero = 0;
@@ -296,13 +321,14 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         PTX_TRY(tokenize_piece(ctx, text + off, end - off, fd, file_base + off, *pcs.back()));
         off = end;
     }
+    lap("pieces: upload + scan + parse + fill");
     uint64_t R = 0, T = 0;
     for (auto &pc : pcs) { R += pc->R; T += pc->T; }
     if (R >= 0xFFFFFFFFull || T >= 0xFFFFFFFFull)
         return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu reads / %llu walk steps exceed the 32-bit offsets of one batch; split the input", (unsigned long long)R, (unsigned long long)T);
     // id spans: piece-local 32-bit positions -> positions in the whole text
-    out.id_span.resize(R);
-    {
+    if (want_id_spans) {
+        out.id_span.resize(R);
         uint64_t r0 = 0;
         std::vector<uint32_t> id_off, id_len;
         for (size_t k = 0; k < pcs.size(); ++k) {
@@ -310,7 +336,8 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
             id_off.resize(pc.R); id_len.resize(pc.R);
             PTX_TRY(download(ctx, id_off.data(), pc.o32[5].p, pc.R)); PTX_TRY(download(ctx, id_len.data(), pc.o32[6].p, pc.R));
             PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            for (uint64_t i = 0; i < pc.R; ++i) out.id_span[r0 + i] = {piece_off[k] + (uint64_t)id_off[i], id_len[i]};
+            const uint64_t base = piece_off[k], rr = r0;
+            parallel_for(pc.R, 8, [&](uint64_t i0, uint64_t i1) { for (uint64_t i = i0; i < i1; ++i) out.id_span[rr + i] = {base + (uint64_t)id_off[i], id_len[i]}; });
             r0 += pc.R;
         }
     }
@@ -354,6 +381,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         PTX_HIP(ctx, hipMemsetAsync(tot.p + 3, 0, sizeof(uint32_t), ctx->stream));
         if (T) hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(T, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, T, o32[1].p, tot.p + 3);
     }
+    lap("join pieces / id spans");
     // are all read ids distinct?  sort a copy of the hashes, count equal neighbours
     DevBuf<uint64_t> hs_a, hs_b;
     DevBuf<uint32_t> hs_table, dup_cnt;
@@ -371,12 +399,14 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         hipLaunchKernelGGL(dup_count_kernel, dim3(grid_for(R, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, R, in_b ? hs_b.p : hs_a.p, dup_cnt.p);
         PTX_TRY(download(ctx, &n_dup, dup_cnt.p, 1));
     }
+    lap("id-hash sort");
     uint32_t max_id = 0;
     PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
     PTX_TRY(download(ctx, out.mapq.data(), o8[0].p, R)); PTX_TRY(download(ctx, out.flags.data(), o8[1].p, R));
     PTX_TRY(download(ctx, out.id_hash.data(), o_hash.p, R));
     if (resident) PTX_TRY(download(ctx, &max_id, tot.p + 3, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lap("host columns download");
     if (resident) {
         resident->R = R; resident->T = T;
         resident->d_step_off.take(o32[0]); resident->d_node_id.take(o32[1]); resident->d_pstart.take(o32[2]); resident->d_pend.take(o32[3]);
@@ -384,6 +414,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         resident->has_flags = true;
         if (group) PTX_TRY(build_step_read(ctx, resident, max_id));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        lap("locus-grouped copy");
     }
     out.n_lines = R;
     out.ids_distinct = n_dup == 0 ? 1 : 0;

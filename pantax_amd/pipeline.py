@@ -114,6 +114,11 @@ class TorchComm:
     def exchange(self, slab):
         return self.exchange_end(self.exchange_begin(slab))
 
+    def thread_init(self):
+        """a helper thread that issues collectives on this communicator binds to the same device first"""
+        if self.device is not None:
+            self.torch.cuda.set_device(self.device)
+
     # ---- SURVEY 8e: the packed reads travel to the owner of their species (ingest time, once per input) ----------------
     def allreduce_sum(self, a):
         """host array -> its sum over the ranks (float64)"""
@@ -194,6 +199,23 @@ def route_reads(eng, owner_of_species, comm, on_device=None):
     return dict(sent_reads=int(nr_to.sum()), sent_words=int(words_to.sum()), recv_reads=int(nr_from.sum()), recv_words=int(words_from.sum()))
 
 
+# numpy layouts of pantax_hip_hap_metrics / pantax_hip_solve_info (include/pantax_hip.h; sizes checked against ctypes at import)
+_MET_DT = np.dtype([("has", "<u4"), ("is_rescue", "<i4"), ("unique_trio_nodes_fraction", "<f8"), ("frequencies_mean", "<f8"), ("path_cov_ratio", "<f8"),
+                    ("first_sol", "<f8"), ("divergence", "<f8"), ("second_sol", "<f8"), ("total_cov_diff", "<f8")])
+_INFO_DT = np.dtype({"names": ["n_candidates", "status1", "status2", "iters1", "iters2", "n_rows", "n_patterns", "obj1", "obj2"],
+                     "formats": ["<i4", "<i4", "<i4", "<i4", "<i4", "<u4", "<u4", "<f8", "<f8"], "offsets": [0, 4, 8, 12, 16, 20, 24, 32, 40], "itemsize": 48})
+
+
+def _check_struct_layouts():
+    import ctypes as C
+    from . import _ffi
+    assert C.sizeof(_ffi.HapMetrics) == _MET_DT.itemsize and C.sizeof(_ffi.SolveInfo) == _INFO_DT.itemsize
+    assert _ffi.SolveInfo.obj1.offset == 32 and _ffi.HapMetrics.second_sol.offset == _MET_DT.fields["second_sol"][1]
+
+
+_check_struct_layouts()
+
+
 def local_stage(eng, avg_len, cfg, single_call=True):
     """Everything a rank computes on its own species shard (device stages + host filters).
     single_call: the whole pass through pantax_hip_profile_step (one host wait); False drives the same stages
@@ -203,8 +225,11 @@ def local_stage(eng, avg_len, cfg, single_call=True):
             avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
             filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
         keep, absolute, s_all, s_pass = keep.copy(), absolute.copy(), s_all.copy(), s_pass.copy()
-        solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
-                           for s in range(eng.S)], dtype=np.uint8)
+        if eng.S < 16:
+            solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0 for s in range(eng.S)], dtype=np.uint8)
+        else:
+            inf0 = np.frombuffer(info, dtype=_INFO_DT, count=eng.S)
+            solved = ((keep != 0) & (inf0["status1"] == 0) & (inf0["status2"] == 0)).astype(np.uint8)
     else:
         # a2 + a3 counters on device, a3 finishing on host
         _, rc, bs, lm, uq = eng.rcls_profile(want_species=False)
@@ -222,24 +247,40 @@ def local_stage(eng, avg_len, cfg, single_call=True):
         solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
                            for s in range(eng.S)], dtype=np.uint8)
         passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)
-    rows = []   # candidate strain rows of this rank, before the global cut / normalisation
-    for s in range(eng.S):
-        if not solved[s]:
-            continue
-        for h in range(int(eng.hap_off[s]), int(eng.hap_off[s + 1])):
-            if not passed[h]:
+    # candidate strain rows of this rank, before the global cut / normalisation.  The C structs are read through numpy views
+    # (a thousand strains per step: field-by-field ctypes access was 0.2 ms of host time between two steps' kernels)
+    H = int(eng.hap_off[-1])
+    if H < 64:   # a handful of strains: plain field access is cheaper than setting up the views
+        rows = []
+        for s in range(eng.S):
+            if not solved[s]:
                 continue
-            m = met[h]
-            opt = lambda bit, v: v if m.has & bit else None
-            rows.append((s, h, m.second_sol, opt(4, m.path_cov_ratio), opt(1, m.unique_trio_nodes_fraction),
-                         opt(2, m.frequencies_mean), opt(8, m.first_sol), opt(16, m.divergence), opt(128, m.total_cov_diff)))
-    stats = dict(iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)], n_cand=[info[s].n_candidates for s in range(eng.S)],
-                 n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
-                 obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)])
+            for h in range(int(eng.hap_off[s]), int(eng.hap_off[s + 1])):
+                if not passed[h]:
+                    continue
+                mm = met[h]
+                o = lambda bit, v: v if mm.has & bit else None
+                rows.append((s, h, mm.second_sol, o(4, mm.path_cov_ratio), o(1, mm.unique_trio_nodes_fraction), o(2, mm.frequencies_mean),
+                             o(8, mm.first_sol), o(16, mm.divergence), o(128, mm.total_cov_diff)))
+        stats = dict(iters=[(info[s].iters1, info[s].iters2) for s in range(eng.S)], n_cand=[info[s].n_candidates for s in range(eng.S)],
+                     n_rows=[info[s].n_rows for s in range(eng.S)], n_patterns=[info[s].n_patterns for s in range(eng.S)],
+                     obj=[(info[s].obj1, info[s].obj2) for s in range(eng.S)])
+        return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
+    m = np.frombuffer(met, dtype=_MET_DT, count=H) if H else np.zeros(0, dtype=_MET_DT)
+    inf = np.frombuffer(info, dtype=_INFO_DT, count=eng.S)
+    sp_of_hap = np.repeat(np.arange(eng.S), np.diff(eng.hap_off.astype(np.int64)))
+    sel = np.nonzero((np.asarray(passed[:H]) != 0) & (solved[sp_of_hap] != 0))[0]
+    has = m["has"][sel]
+    cols = [(4, "path_cov_ratio"), (1, "unique_trio_nodes_fraction"), (2, "frequencies_mean"), (8, "first_sol"), (16, "divergence"), (128, "total_cov_diff")]
+    opt = [[v if f else None for v, f in zip(m[name][sel].tolist(), ((has & bit) != 0).tolist())] for bit, name in cols]
+    rows = list(zip(sp_of_hap[sel].tolist(), sel.tolist(), m["second_sol"][sel].tolist(), *opt))
+    stats = dict(iters=list(zip(inf["iters1"].tolist(), inf["iters2"].tolist())), n_cand=inf["n_candidates"].tolist(),
+                 n_rows=inf["n_rows"].tolist(), n_patterns=inf["n_patterns"].tolist(), obj=list(zip(inf["obj1"].tolist(), inf["obj2"].tolist())))
     return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
 
 
 _ROW_K = 10   # columns of the exchanged slab
+PIPELINE_THREAD_MIN_HAPS = 128   # profile_steps_pipelined: from this many strains per rank the tables are built on a helper thread
 
 
 def finalize_begin(local, hap_names, comm, shard_max=None, rows_max=None):
@@ -305,25 +346,48 @@ def finalize_end(pending, species_names, hap_names, cfg, comm):
 
 def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg=None, comm=None, shard_max=None, rows_max=None,
                             next_input=None):
-    """n_steps passes back to back (a stream of samples): the exchange of step i is in flight while step i+1 computes,
-    and its tables are built after step i+1's single host wait.  next_input(i), if given, is called before step i to
-    swap in that step's reads.  Returns the list of (species_rows, strain_rows, stats), same as n_steps calls of
-    profile_step."""
+    """n_steps passes back to back (a stream of samples).  Everything that follows a step's single host wait -- packing the
+    slab, the one all-reduce, the normalisers and the tables (host code, ~0.6 ms for 1000 strains) -- runs on a helper
+    thread while the NEXT step's kernels execute (the C call releases the interpreter lock while it waits for the device),
+    so neither the ring pass nor the table code sits between two steps' kernels.  Collectives are issued by the helper
+    thread only, in step order on every rank.  next_input(i), if given, is called before step i to swap in that step's
+    reads.  Returns the list of (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
+    from concurrent.futures import ThreadPoolExecutor
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
-    out, pending = [], None
-    for i in range(n_steps):
-        if next_input is not None:
-            next_input(i)
-        local = local_stage(eng, avg_len, cfg, True)
-        nxt = (finalize_begin(local, hap_names, comm, shard_max, rows_max), local["stats"])
+
+    def finish(local):
+        sr, tr, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max, rows_max)
+        return sr, tr, dict(local["stats"], n_active=n_active)
+
+    if len(hap_names) < PIPELINE_THREAD_MIN_HAPS:
+        # small batches (cfg2: ten strains, 0.5 ms per step): the hand-over to a helper thread costs more than the table code it
+        # would hide; the exchange of step i is still in flight while step i+1 computes, its tables follow that step's host wait
+        out, pending = [], None
+        for i in range(n_steps):
+            if next_input is not None:
+                next_input(i)
+            local = local_stage(eng, avg_len, cfg, True)
+            nxt = (finalize_begin(local, hap_names, comm, shard_max, rows_max), local["stats"])
+            if pending is not None:
+                sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
+                out.append((sr, tr, dict(pending[1], n_active=n_active)))
+            pending = nxt
         if pending is not None:
             sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
             out.append((sr, tr, dict(pending[1], n_active=n_active)))
-        pending = nxt
-    if pending is not None:
-        sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
-        out.append((sr, tr, dict(pending[1], n_active=n_active)))
+        return out
+    out, fut = [], None
+    with ThreadPoolExecutor(1, initializer=getattr(comm, "thread_init", None) or (lambda: None)) as ex:
+        for i in range(n_steps):
+            if next_input is not None:
+                next_input(i)
+            local = local_stage(eng, avg_len, cfg, True)      # enqueue + the step's one host wait
+            if fut is not None:
+                out.append(fut.result())                      # step i-1's tables: built while step i ran
+            fut = ex.submit(finish, local)
+        if fut is not None:
+            out.append(fut.result())
     return out
 
 

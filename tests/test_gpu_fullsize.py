@@ -228,6 +228,33 @@ def test_single_call_step_equals_stage_by_stage(eng, seed, S, H, R, L, filtered)
         assert a[2]["n_active"] == b[2]["n_active"]
 
 
+def test_stream_of_steps_with_tables_built_behind_the_next_step(eng, monkeypatch):
+    """profile_steps_pipelined (what bench.py times): the tables of step i are built on a helper thread while step i+1's
+    kernels run; with a different input per step the results equal one profile_step call per input, in order."""
+    from pantax_amd import synth
+    from pantax_amd.pipeline import StepConfig, profile_step, profile_steps_pipelined
+    sset = synth.make_set(77, 5, 4, 60000, 80000)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    avg = sset.avg_len()
+    rng = np.random.default_rng(3)
+    flag_sets = [None] + [(rng.random(rd.n_reads) < f).astype(np.uint8) for f in (0.3, 0.6, 0.1)]   # four different samples of the same reads
+    single = []
+    for fl in flag_sets:
+        eng.upload_packed(rd, fl)
+        single.append(profile_step(eng, names, haps, avg, StepConfig()))
+    from pantax_amd import pipeline
+    for min_haps in (1, 10 ** 9):                                   # helper-thread path, inline path
+        monkeypatch.setattr(pipeline, "PIPELINE_THREAD_MIN_HAPS", min_haps)
+        got = profile_steps_pipelined(eng, names, haps, avg, len(flag_sets), StepConfig(), next_input=lambda i: eng.upload_packed(rd, flag_sets[i]))
+        assert len(got) == len(single)
+        for a, b in zip(got, single):
+            assert a[0] == b[0] and a[1] == b[1] and a[2]["n_active"] == b[2]["n_active"]
+    assert any(x[1] != single[0][1] for x in single[1:])          # the inputs really differ
+
+
 def test_many_species_radix_path_against_oracle(eng):
     """8 species, 6.3e5 nodes in all: above the sample-sort limit, so the LP rows go through the LSD radix sort and
     eight workgroups solve their LPs side by side.  Every species against the oracle: bit-exact integers, equal

@@ -7,12 +7,13 @@ import numpy as np
 from pantax_amd import synth, pipeline
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import StepConfig, LocalComm
-sset = synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000)
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+sset = synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000) if wl == "cfg2" else synth.make_set(20260504, 100, 10, 10_000_000, 5_000_000)
 eng = Engine(0)
 eng.upload_db(sset.species); eng.upload_packed(sset.reads)
 names = [g.name for g in sset.species]; haps = [h for g in sset.species for h in g.hap_names]
 avg = sset.avg_len(); cfg = StepConfig(); comm = LocalComm()
-N = 200
+N = 200 if wl == "cfg2" else 20
 for _ in range(5): pipeline.profile_step(eng, names, haps, avg, cfg, comm)
 t0 = time.perf_counter()
 for _ in range(N): pipeline.profile_step(eng, names, haps, avg, cfg, comm)
