@@ -183,3 +183,45 @@ def test_rank_local_failure_before_the_strain_step_reaches_every_rank(world, sha
     assert set(errs) == {0, 1}, errs
     assert "cannot write" in errs[0] and "another rank failed" in errs[1]
     assert not os.path.exists(wd / "strain_abundance.txt")
+
+
+def test_sharded_ingest_with_slices_cut_into_pieces_and_long_walks(tmp_path_factory, monkeypatch):
+    """Every rank's byte range is itself tokenised in several pieces (PANTAX_GAF_PIECE_BYTES: the 4-GiB logic at small scale,
+    read from the file at the slice's offset) and the reads are long (walks of hundreds of steps, routed by the workgroup-wide
+    copy): tables == the one-process run of the same files, report byte-identical."""
+    from pantax_amd import synth
+    from pantax_amd.engine import Engine
+    sset = synth.make_set(55, 3, 4, 600, 60000, long_reads=True, present_frac=0.6, with_ids=False)
+    root = tmp_path_factory.mktemp("pantax_long")
+    db = root / "db"
+    db.mkdir()
+    synth.write_db(sset, str(db))
+    gaf = root / "long.gaf"
+    synth.write_gaf(sset.reads, str(gaf))
+    one = root / "wd_one"
+    one.mkdir()
+    eng0 = Engine(0)
+    cwd = os.getcwd()
+    os.chdir(str(one))
+    try:
+        eng0.profile(str(db), str(one), str(gaf), fr=0.5, out_binning_file=str(one / "reads_classification.tsv"))
+    finally:
+        os.chdir(cwd)
+        eng0.close()
+    monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", str(max(200000, os.path.getsize(gaf) // 11)))
+    wd = root / "wd_sharded"
+    wd.mkdir()
+
+    def call(eng, rank, comm):
+        eng.profile(str(db), str(wd), str(gaf), fr=0.5, rank=rank, world_size=3, allreduce=comm.allreduce(rank), alltoallv=comm.alltoallv(rank),
+                    out_binning_file=str(wd / "reads_classification.tsv"))
+    errs, comm = _run_ranks(3, wd, call)
+    assert not errs, errs
+    assert open(wd / "species_abundance.txt").read() == open(one / "species_abundance.txt").read()
+    assert open(wd / "reads_classification.tsv", "rb").read() == open(one / "reads_classification.tsv", "rb").read()
+    a = [l.rstrip("\n").split("\t") for l in open(one / "strain_abundance.txt")]
+    b = [l.rstrip("\n").split("\t") for l in open(wd / "strain_abundance.txt")]
+    assert len(a) > 1 and [r[:3] for r in a] == [r[:3] for r in b]
+    for ra, rb in zip(a[1:], b[1:]):
+        for x, y in zip(ra[3:], rb[3:]):
+            assert (x == "" and y == "") or float(x) == pytest.approx(float(y), rel=1e-9, abs=1e-12)
