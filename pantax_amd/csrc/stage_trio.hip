@@ -182,18 +182,22 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
 //      LDS hash table keyed by (a - block start, b, c) packed into 64 bits.  Collinear haplotypes collapse in LDS; HBM sees
 //      the walks once (4P) and one byte per UNIQUE window.  A block whose distinct windows overflow the table is redone
 //      in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences of a key fall into the same class).
-constexpr int TRIO_BLK_SHIFT = 6, TRIO_BLK = 1 << TRIO_BLK_SHIFT, TB_SLOTS = 512;
+constexpr int TRIO_BLK_SHIFT = 6, TRIO_BLK = 1 << TRIO_BLK_SHIFT;
 constexpr unsigned long long TB_EMPTY = ~0ull;
 constexpr uint32_t TB_MULTI = 0xFFFFFFFFu;
 constexpr int TB_UNR = 4;
 // slot = {64-bit key, u32 q}: q is the position of the window's only occurrence, or TB_MULTI once a second one arrived
 // (both sides use atomicMax, so the outcome does not depend on who comes first; positions are < 2^32 - 1)
+template <int TB_SLOTS>
 __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s_q, uint32_t *s_over, uint32_t a_l, uint32_t b, uint32_t c,
                                           uint32_t q, uint32_t sub_mask, uint32_t sub_j) {
     const unsigned long long key = ((unsigned long long)a_l << 54) | ((unsigned long long)b << 27) | c;
-    const unsigned long long mix = (key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull;
-    if ((((uint32_t)(mix >> 20)) & sub_mask) != sub_j) return;
-    uint32_t h = (uint32_t)(mix >> 55) & (TB_SLOTS - 1);
+    // hash of the key from full-rate 24-bit multiplies (a 64-bit multiply is four quarter-rate ones, and this kernel is bound
+    // by VALU issue): b and c are the block's neighbours, their low bits carry the entropy; the full key decides equality
+    uint32_t mix = __umul24(b, 0x9E3779u) + __umul24(c, 0x85EBCBu) + __umul24(a_l, 0x27D4EBu);
+    mix ^= mix >> 13;
+    if (((mix >> 16) & sub_mask) != sub_j) return;
+    uint32_t h = mix & (TB_SLOTS - 1);
     for (int probes = 0; probes < TB_SLOTS; ++probes) {
         unsigned long long cur = s_key[h];
         if (cur == TB_EMPTY) cur = atomicCAS(&s_key[h], TB_EMPTY, key);
@@ -207,6 +211,7 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
 // waves per CU hide each other's trips to memory; a 256-thread workgroup per 256-node block spent most of its life in
 // barriers and fixed overhead).  blk_rec[gb] = {first run, end run, global index of the block's first node, its
 // species-local id}; entry n_blocks closes the table (a block's node count is the distance to the next block's first node).
+template <int TB_SLOTS>
 __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
                                                         const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
@@ -234,6 +239,7 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                 const uint32_t total = __shfl(incl, 63);
                 s_run[lane] = run; s_pref[lane] = incl - run.y;
                 __syncthreads();
+                uint32_t lo_carry = 0;   // run of the last flat index handed out so far: the indices only grow, so does the run
                 for (uint32_t idx0 = lane; idx0 < total; idx0 += 64 * TB_UNR) {
                     uint32_t x[TB_UNR], pp[TB_UNR], b1[TB_UNR], c1[TB_UNR], b2[TB_UNR], c2[TB_UNR];
                     bool fw[TB_UNR], bw[TB_UNR];
@@ -242,9 +248,12 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                         const uint32_t idx = idx0 + u * 64;
                         fw[u] = bw[u] = false;
                         x[u] = pp[u] = b1[u] = c1[u] = b2[u] = c2[u] = 0u;
+                        uint32_t lo = lo_carry;
                         if (idx < total) {
-                            uint32_t lo = 0, hi = n_r;             // last run whose first flat index is <= idx
-                            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= idx) lo = mid; else hi = mid; }
+                            // last run whose first flat index is <= idx: a short walk forward from the previous group's last run
+                            // (runs are mostly longer than a wave, so a group of 64 indices crosses one or two run borders;
+                            // entries past the block's runs hold `total` and stop the walk)
+                            while (lo < 63u && s_pref[lo + 1] <= idx) ++lo;
                             const uint4 rn = s_run[lo];
                             const uint32_t pos = rn.x + (idx - s_pref[lo]);
                             pp[u] = pos;
@@ -253,11 +262,12 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                             if (fw[u]) { b1[u] = path_nodes[pos + 1]; c1[u] = path_nodes[pos + 2]; }
                             if (bw[u]) { b2[u] = path_nodes[pos - 1]; c2[u] = path_nodes[pos - 2]; }
                         }
+                        lo_carry = __shfl(lo, 63);   // lane 63 holds the group's largest index (or, past the end, the carry itself)
                     }
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
-                        if (fw[u] && x[u] <= c1[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
-                        if (bw[u] && x[u] < c2[u]) tb_insert(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
+                        if (fw[u] && x[u] <= c1[u]) tb_insert<TB_SLOTS>(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
+                        if (bw[u] && x[u] < c2[u]) tb_insert<TB_SLOTS>(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
                     }
                 }
                 __syncthreads();   // s_run / s_pref are reused by the next 64 runs
@@ -477,8 +487,15 @@ int trio_index_build(Ctx *ctx, Db *db) {
     const dim3 tgrid((uint32_t)db->n_tiles);
     if (P && by_block) {
         KTimer t(ctx, "trio_block_kernel");
-        hipLaunchKernelGGL(trio_block_kernel, dim3(db->n_blocks), dim3(64), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, db->d_path_nodes.p,
-                           ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2);
+        // LDS table slots per 64-node block (PANTAX_TB_SLOTS=512|256|128 picks another instantiation, for measurements): fewer
+        // slots = more blocks resident per CU (the kernel is bound by the latency of each wave's dependent loads), more blocks
+        // that need sub-passes
+        int slots = 256;
+        if (const char *ev = std::getenv("PANTAX_TB_SLOTS")) slots = std::atoi(ev);
+#define TB_LAUNCH(N) hipLaunchKernelGGL(trio_block_kernel<N>, dim3(db->n_blocks), dim3(64), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, \
+                                        db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2)
+        if (slots == 512) TB_LAUNCH(512); else if (slots == 128) TB_LAUNCH(128); else TB_LAUNCH(256);
+#undef TB_LAUNCH
     }
     if (P) {
         if (!by_block) {
