@@ -210,6 +210,18 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
                             uint8_t *pass_out /*[H]*/, double *species_sum_all_out /*[S] or NULL*/,
                             double *species_sum_pass_out /*[S] or NULL*/);
 
+/* The same step in two halves, for a caller that streams samples: `enqueue` puts the whole step on the device and returns
+ * without waiting; `collect` takes the OLDEST enqueued step of the db: its one host wait, the reporting arithmetic and the
+ * a15 filters (outputs as above).  Up to two steps of a db may be in flight, so step i+1 can be enqueued before step i is
+ * collected and the device never waits for the host between two steps.  The device still runs the steps strictly one after
+ * the other -- no kernel of step i+1 starts before the last kernel of step i -- so every step computes what the one-call form
+ * computes; `reads` / `avg_len` of an enqueued step must stay valid until its collect (avg_len is copied at enqueue). */
+int pantax_hip_profile_step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
+                                    const pantax_hip_step_config *cfg);
+int pantax_hip_profile_step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, double *absolute_out,
+                                    pantax_hip_hap_metrics *metrics_out, pantax_hip_solve_info *info_out, uint8_t *pass_out,
+                                    double *species_sum_all_out, double *species_sum_pass_out);
+
 /* ---- the device sort of the LP row grouping as a host-buffer utility: rows (k0[i], k1[i], k2[i]) sorted
  * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
  * 2 = sample sort (n <= 600000), 3 = the batched sort of the many-species step: rows arrive grouped by ascending k0

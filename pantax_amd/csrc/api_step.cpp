@@ -13,28 +13,28 @@
 using namespace ptx;
 
 namespace {
-struct SpOut { Db *db; uint8_t *keep; double *absolute; };
+struct SpOut { Db *db; uint8_t *keep; double *absolute; int slot; };
 void copy_species_out(void *arg) {   // runs right after the step's single wait
     SpOut *o = static_cast<SpOut *>(arg);
     const uint32_t S = o->db->S;
-    std::memcpy(o->absolute, o->db->h_sp_out.p, sizeof(double) * S);
-    std::memcpy(o->keep, o->db->h_sp_out.p + sizeof(double) * S, S);
+    std::memcpy(o->absolute, o->db->h_sp_out[o->slot].p, sizeof(double) * S);
+    std::memcpy(o->keep, o->db->h_sp_out[o->slot].p + sizeof(double) * S, S);
 }
-}  // namespace
 
-extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
-                                       const pantax_hip_step_config *cfg, uint8_t *keep_out, double *absolute_out,
-                                       pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, uint8_t *pass_out,
-                                       double *species_sum_all_out, double *species_sum_pass_out) {
-    if (!ctx || !db || !reads || !avg_len || !cfg || !keep_out || !absolute_out || !met || !pass_out) return PANTAX_HIP_E_INVALID;
-    PTX_ENTER(ctx);
+// Everything of one step enqueued on the device, nothing waited for.  The device runs steps strictly one after the other:
+// the side stream (unique-trio build) first waits for all the main-stream work enqueued so far, i.e. for the previous step.
+int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len, const pantax_hip_step_config *cfg) {
     if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step: the db was uploaded without graphs (ranges only)");
+    if (db->step_inflight >= 2) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step_enqueue: two steps of this db are already in flight; collect one first");
     const uint32_t S = db->S;
+    const int slot = db->step_enq;
     // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every
     // run, profile.rs:2936), so it is built while the main stream bins the reads and takes the species decision
     bool forked = false;
     if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
     if (!db->trio_built) {
+        PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));            // the previous step still reads the index it is about to replace
+        PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream2;
         const int rc = trio_index_build(ctx, db);
@@ -59,8 +59,8 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     db->d_sp_abs.view(db->d_sp_out.p, S);
     db->d_active.view(db->d_sp_out.p + sizeof(double) * S, S);
     PTX_TRY(species_profile_launch(ctx, db, reads, db->d_counters.p, db->d_avg_len.p, cfg->filtered, db->d_active.p, db->d_sp_abs.p));
-    PTX_HIP(ctx, db->h_sp_out.reserve(sizeof(double) * S + S));
-    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out.p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
+    PTX_HIP(ctx, db->h_sp_out[slot].reserve(sizeof(double) * S + S));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out[slot].p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
     PTX_TRY(strain_prezero(ctx, db));   // zero-fills of the strain step, while this stream would wait for the trio index anyway
     struct PreZeroGuard { LadBatch &lb; ~PreZeroGuard() { lb.prezeroed = false; } } prezero_guard{db->lad};   // never outlives this call
     PTX_TRY(coverage_prepare(ctx, db, reads, true));   // arena zero-fill + walk sums of long reads: need the binning, not the trio index
@@ -72,14 +72,57 @@ extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, p
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,
                                 cfg->shift, cfg->sample_nodes};
-    PTX_TRY(strain_enqueue(ctx, db, &sc, db->d_active.p));
-    SpOut so{db, keep_out, absolute_out};
+    PTX_TRY(strain_enqueue(ctx, db, &sc, db->d_active.p, slot));
+    db->step_cfg[slot] = *cfg;
+    db->step_enq ^= 1;
+    ++db->step_inflight;
+    return 0;
+}
+
+// The oldest enqueued step: its one host wait, the reporting arithmetic and the a15 filters (host scalars).
+int step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, double *absolute_out, pantax_hip_hap_metrics *met,
+                 pantax_hip_solve_info *info_out, uint8_t *pass_out, double *species_sum_all_out, double *species_sum_pass_out) {
+    if (db->step_inflight <= 0) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step_collect: no enqueued step of this db is waiting");
+    const uint32_t S = db->S;
+    const int slot = db->step_col;
+    const pantax_hip_step_config cfg = db->step_cfg[slot];
+    db->step_col ^= 1;
+    --db->step_inflight;   // also when the step turns out to have failed: its slot is free again
+    pantax_hip_strain_config sc{cfg.unique_trio_nodes_fraction, cfg.unique_trio_nodes_mean_count_f, cfg.single_cov_ratio, cfg.min_depth, cfg.shift,
+                                cfg.sample_nodes};
+    SpOut so{db, keep_out, absolute_out, slot};
     std::vector<pantax_hip_solve_info> info(S);
-    PTX_TRY(strain_finish(ctx, db, &sc, keep_out, absolute_out, met, info.data(), copy_species_out, &so));
+    PTX_TRY(strain_finish(ctx, db, &sc, keep_out, absolute_out, met, info.data(), copy_species_out, &so, slot));
     if (info_out) std::memcpy(info_out, info.data(), sizeof(pantax_hip_solve_info) * S);
-    // a15 filters (host scalars)
     std::vector<uint8_t> reported(S);
     for (uint32_t s = 0; s < S; ++s) reported[s] = (keep_out[s] && info[s].status1 == 0 && info[s].status2 == 0) ? 1 : 0;
-    return pantax_hip_abundance_filter(S, db->h_hap_off.data(), met, reported.data(), cfg->single_cov_diff, cfg->min_cov, pass_out, nullptr, nullptr,
+    return pantax_hip_abundance_filter(S, db->h_hap_off.data(), met, reported.data(), cfg.single_cov_diff, cfg.min_cov, pass_out, nullptr, nullptr,
                                        species_sum_all_out, species_sum_pass_out);
+}
+}  // namespace
+
+extern "C" int pantax_hip_profile_step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
+                                               const pantax_hip_step_config *cfg) {
+    if (!ctx || !db || !reads || !avg_len || !cfg) return PANTAX_HIP_E_INVALID;
+    PTX_ENTER(ctx);
+    return step_enqueue(ctx, db, reads, avg_len, cfg);
+}
+
+extern "C" int pantax_hip_profile_step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, double *absolute_out,
+                                               pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, uint8_t *pass_out,
+                                               double *species_sum_all_out, double *species_sum_pass_out) {
+    if (!ctx || !db || !keep_out || !absolute_out || !met || !pass_out) return PANTAX_HIP_E_INVALID;
+    PTX_ENTER(ctx);
+    return step_collect(ctx, db, keep_out, absolute_out, met, info_out, pass_out, species_sum_all_out, species_sum_pass_out);
+}
+
+extern "C" int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
+                                       const pantax_hip_step_config *cfg, uint8_t *keep_out, double *absolute_out,
+                                       pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, uint8_t *pass_out,
+                                       double *species_sum_all_out, double *species_sum_pass_out) {
+    if (!ctx || !db || !reads || !avg_len || !cfg || !keep_out || !absolute_out || !met || !pass_out) return PANTAX_HIP_E_INVALID;
+    PTX_ENTER(ctx);
+    if (db->step_inflight) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step: %d enqueued step(s) of this db have not been collected", db->step_inflight);
+    PTX_TRY(step_enqueue(ctx, db, reads, avg_len, cfg));
+    return step_collect(ctx, db, keep_out, absolute_out, met, info_out, pass_out, species_sum_all_out, species_sum_pass_out);
 }

@@ -66,14 +66,16 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
     return 0;
 }
 
-int fetch_arena_enqueue(Ctx *ctx, Db *db, const ArenaLayout &L) {
-    PTX_HIP(ctx, db->h_arena.reserve(L.total));
-    PTX_HIP(ctx, hipMemcpyAsync(db->h_arena.p, db->d_arena.p, L.total, hipMemcpyDeviceToHost, ctx->stream));   // the one host round trip of the step
+int fetch_arena_enqueue(Ctx *ctx, Db *db, const ArenaLayout &L, int slot) {
+    PTX_HIP(ctx, db->h_arena[slot].reserve(L.total));
+    PTX_HIP(ctx, hipMemcpyAsync(db->h_arena[slot].p, db->d_arena.p, L.total, hipMemcpyDeviceToHost, ctx->stream));   // the one host round trip of the step
+    if (!db->ev_step[slot]) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_step[slot], hipEventDisableTiming));
+    PTX_HIP(ctx, hipEventRecord(db->ev_step[slot], ctx->stream));   // a later step may already be enqueued behind it: the wait is for THIS step
     return 0;
 }
-int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r) {
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint8_t *b = db->h_arena.p;
+int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, StrainRaw &r, int slot) {
+    PTX_HIP(ctx, hipEventSynchronize(db->ev_step[slot]));
+    const uint8_t *b = db->h_arena[slot].p;
     r.amax = (const double *)(b + L.amax); r.nzsum = (const double *)(b + L.nzsum); r.obj1 = (const double *)(b + L.obj1); r.obj2 = (const double *)(b + L.obj2);
     r.x1 = (const double *)(b + L.x1); r.x2 = (const double *)(b + L.x2); r.ratio = (const unsigned long long *)(b + L.ratio);
     r.meanf = (const double *)(b + L.meanf);
@@ -107,7 +109,7 @@ int strain_prezero(Ctx *ctx, Db *db) {
 
 // Enqueues the whole strain step and the download of its result arena; nothing waits for the host.
 // d_active: device [S] or null.
-int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active) {
+int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active, int slot) {
     if (!db->cov_done) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_node_coverage first");
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_trio_index first");
     if (cfg->sample_nodes < 0) return fail(ctx, PANTAX_HIP_E_INVALID, "strain_profile: sample_nodes %d", cfg->sample_nodes);
@@ -124,7 +126,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
-    PTX_TRY(fetch_arena_enqueue(ctx, db, L));
+    PTX_TRY(fetch_arena_enqueue(ctx, db, L, slot));
     lb.prezeroed = false;
     return 0;
 }
@@ -133,7 +135,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
 // species_coverage: host [S] (may be null), read only after the wait -- a resident step fills them from the
 // device's own species decisions through `after_wait`.
 int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active, const double *species_coverage,
-                  pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, void (*after_wait)(void *), void *after_wait_arg) {
+                  pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, void (*after_wait)(void *), void *after_wait_arg, int slot) {
     const uint32_t S = db->S;
     const uint64_t H = db->H;
     std::memset(met, 0, sizeof(pantax_hip_hap_metrics) * H);
@@ -143,7 +145,7 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
     LadBatch &lb = db->lad;
     const ArenaLayout L(S, H);
     StrainRaw r;
-    PTX_TRY(fetch_arena_wait(ctx, db, lb, L, r));                                           // the one host round trip
+    PTX_TRY(fetch_arena_wait(ctx, db, lb, L, r, slot));                                         // the one host round trip
     if (after_wait) after_wait(after_wait_arg);
     lb.n_rows = r.counts[0]; lb.K = r.counts[1];
     lb.h_sp_pat_off.assign(r.sp_pat_off, r.sp_pat_off + S + 1);
@@ -257,8 +259,9 @@ int pantax_hip_strain_profile(pantax_hip_ctx *ctx, pantax_hip_db *db, const pant
     PTX_ENTER(ctx);
     const uint8_t *d_active = nullptr;
     if (species_active) { PTX_TRY(upload_small(ctx, db->d_active, species_active, db->S)); d_active = db->d_active.p; }
-    PTX_TRY(strain_enqueue(ctx, db, cfg, d_active));
-    return strain_finish(ctx, db, cfg, species_active, species_coverage, met, info_out, nullptr, nullptr);
+    if (db->step_inflight) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: %d enqueued step(s) of this db have not been collected", db->step_inflight);
+    PTX_TRY(strain_enqueue(ctx, db, cfg, d_active, 0));
+    return strain_finish(ctx, db, cfg, species_active, species_coverage, met, info_out, nullptr, nullptr, 0);
 }
 
 int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_batch *in, const pantax_hip_solution_batch *out) {

@@ -115,6 +115,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_seq = nullptr;     // orders the side stream behind everything enqueued on the main stream so far (steps run strictly one after the other on the device)
     std::string err;
     std::mutex err_mu;               // guards `err` alone (fail() may run before PTX_ENTER)
     bool timing = false;
@@ -276,10 +277,14 @@ struct Db {
     DevBuf<double> d_hap_mean;               // [H]
     DevBuf<double> d_hap_part;               // chunk partials of the three passes of the per-hap trio statistics
     DevBuf<uint8_t> d_arena;                 // every small result of the strain step, contiguous: one memset, one download
-    PinBuf h_arena;                  // pinned mirror of d_arena
+    PinBuf h_arena[2];               // pinned mirrors of d_arena: one per step in flight (a caller may enqueue step i+1 before it collects step i)
     DevBuf<double> d_avg_len, d_sp_abs;   // resident step: species lengths in, predicted_coverage out (d_active holds keep)
     DevBuf<uint8_t> d_sp_out;        // backing store of d_sp_abs + d_active in a resident step (one download)
-    PinBuf h_sp_out;                 // [S f64 absolute][S u8 keep]
+    PinBuf h_sp_out[2];              // [S f64 absolute][S u8 keep], per step in flight
+    hipEvent_t ev_step[2] = {nullptr, nullptr};   // recorded behind the last download of the step that uses the slot
+    pantax_hip_step_config step_cfg[2];
+    int step_enq = 0, step_col = 0, step_inflight = 0;   // slot of the next enqueue / the next collect; steps enqueued and not yet collected
+    ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); }
     // LP-row staging (lad_prepare)
     DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort
     DevBuf<uint64_t> d_ka[3], d_kb[3];

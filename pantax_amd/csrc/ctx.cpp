@@ -103,7 +103,8 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_seq, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate failed");
     }
@@ -128,6 +129,7 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     ctx->pin_text.release();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_seq) (void)hipEventDestroy(ctx->ev_seq);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     dev_cache_trim();   // nothing of this process stays cached on the device once a ctx is gone

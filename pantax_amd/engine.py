@@ -29,6 +29,8 @@ class Engine:
         self.reads = None
         self._keep = []
         self._step_buf = None
+        self._collect_buf = None
+        self._inflight = 0
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -62,6 +64,7 @@ class Engine:
         if self.db:
             self.lib.pantax_hip_db_free(self.ctx, self.db)
             self.db = None
+            self._inflight = 0
         S = len(species)
         self.S = S
         self.range_start = as_c([g.range_start for g in species], np.int64)
@@ -93,6 +96,7 @@ class Engine:
         if self.db:
             self.lib.pantax_hip_db_free(self.ctx, self.db)
             self.db = None
+            self._inflight = 0
         self.range_start = as_c(range_start, np.int64)
         self.range_end = as_c(range_end, np.int64)
         self.S = len(self.range_start)
@@ -294,6 +298,40 @@ class Engine:
             self.U = None
         return keep, absolute, met, info, passed[: self.H], s_all, s_pass
 
+    def profile_step_enqueue(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
+                             rebuild_trio=True, sample_nodes=0):
+        """First half of profile_step (pantax_hip_profile_step_enqueue): the whole step goes onto the device, nothing is waited
+        for.  Up to two steps may be in flight; the device runs them strictly one after the other."""
+        avg = as_c(avg_len, np.float64)
+        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio))
+        self._check(self.lib.pantax_hip_profile_step_enqueue(self.ctx, self.db, self.reads, p(avg), C.byref(cfg)))
+        self._inflight += 1
+        if rebuild_trio:
+            self.U = None
+
+    def profile_step_collect(self):
+        """Second half: the oldest enqueued step's host wait + results (same tuple as profile_step).  The arrays are reused by
+        the collect after next: copy what must live longer."""
+        if self._collect_buf is None or self._collect_buf[0] != (self.S, self.H):
+            mk = lambda: (np.zeros(self.S, dtype=np.uint8), np.zeros(self.S), (_ffi.HapMetrics * max(self.H, 1))(), (_ffi.SolveInfo * self.S)(),
+                          np.zeros(max(self.H, 1), dtype=np.uint8), np.zeros(self.S), np.zeros(self.S))
+            sets = [mk(), mk()]
+            self._collect_buf = ((self.S, self.H), sets, [[p(a) if isinstance(a, np.ndarray) else a for a in st] for st in sets], 0)
+        key, sets, ptrs, turn = self._collect_buf
+        self._collect_buf = (key, sets, ptrs, turn ^ 1)
+        keep, absolute, met, info, passed, s_all, s_pass = sets[turn]
+        self._inflight = max(self._inflight - 1, 0)           # the library frees the slot also when the step reports a failure
+        self._check(self.lib.pantax_hip_profile_step_collect(self.ctx, self.db, *ptrs[turn]))
+        return keep, absolute, met, info, passed[: self.H], s_all, s_pass
+
+    def drain_steps(self):
+        """collect (and drop) whatever enqueued steps are still in flight, e.g. after an exception between enqueue and collect"""
+        while self._inflight:
+            try:
+                self.profile_step_collect()
+            except PantaxHipError:
+                pass
+
     def pao_solve(self, node_len, node_abundance, node_base_cov, path_off, path_nodes, cand, fixed_zero=None):
         node_len = as_c(node_len, np.int64)
         ab = as_c(node_abundance, np.float64)
@@ -403,6 +441,7 @@ class Engine:
         if self.db:
             self.lib.pantax_hip_db_free(self.ctx, self.db)
             self.db = None
+            self._inflight = 0
         S = len(paths)
         self.S = S
         self.range_start = as_c(range_start, np.int64)

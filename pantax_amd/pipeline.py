@@ -216,14 +216,24 @@ def _check_struct_layouts():
 _check_struct_layouts()
 
 
+def local_enqueue(eng, avg_len, cfg):
+    """The device part of a step, enqueued and not waited for (pantax_hip_profile_step_enqueue); local_stage(..., "collect")
+    takes its results."""
+    eng.profile_step_enqueue(avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
+                             filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
+
+
 def local_stage(eng, avg_len, cfg, single_call=True):
     """Everything a rank computes on its own species shard (device stages + host filters).
     single_call: the whole pass through pantax_hip_profile_step (one host wait); False drives the same stages
     one C call at a time (rcls_profile, species_profiling, ... as the reference names them) -- identical results."""
     if single_call:
-        keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(
-            avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
-            filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
+        if single_call == "collect":    # second half of a step enqueued earlier (local_enqueue)
+            keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step_collect()
+        else:
+            keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(
+                avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
+                filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
         keep, absolute, s_all, s_pass = keep.copy(), absolute.copy(), s_all.copy(), s_pass.copy()
         if eng.S < 16:
             solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0 for s in range(eng.S)], dtype=np.uint8)
@@ -346,48 +356,60 @@ def finalize_end(pending, species_names, hap_names, cfg, comm):
 
 def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg=None, comm=None, shard_max=None, rows_max=None,
                             next_input=None):
-    """n_steps passes back to back (a stream of samples).  Everything that follows a step's single host wait -- packing the
-    slab, the one all-reduce, the normalisers and the tables (host code, ~0.6 ms for 1000 strains) -- runs on a helper
-    thread while the NEXT step's kernels execute (the C call releases the interpreter lock while it waits for the device),
-    so neither the ring pass nor the table code sits between two steps' kernels.  Collectives are issued by the helper
-    thread only, in step order on every rank.  next_input(i), if given, is called before step i to swap in that step's
-    reads.  Returns the list of (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
+    """n_steps passes back to back (a stream of samples) without the device ever waiting for the host between two of them:
+    * step i+1 is ENQUEUED before step i is collected (pantax_hip_profile_step_enqueue / _collect, two result slots): the
+      device runs the steps strictly one after the other -- the unique-trio build of step i+1 waits for the last kernel of
+      step i -- but the ~60 launches of a step, the host wait, the parsing of the result arena and the Python around the
+      call no longer sit between two steps' kernels;
+    * from PIPELINE_THREAD_MIN_HAPS strains per rank on, everything that follows a step's collect -- packing the slab, the
+      one all-reduce, the normalisers and the tables (~0.6 ms of host code for 1000 strains) -- runs on a helper thread;
+      below that the exchange of step i is started inline and completed after step i+1's collect.
+    Collectives are issued in step order on every rank.  next_input(i), if given, is called before step i is enqueued to
+    swap in that step's reads (the swap itself waits for the step that still uses the old ones).  Returns the list of
+    (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
     from concurrent.futures import ThreadPoolExecutor
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
+    if n_steps <= 0:
+        return []
 
     def finish(local):
         sr, tr, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max, rows_max)
         return sr, tr, dict(local["stats"], n_active=n_active)
 
-    if len(hap_names) < PIPELINE_THREAD_MIN_HAPS:
-        # small batches (cfg2: ten strains, 0.5 ms per step): the hand-over to a helper thread costs more than the table code it
-        # would hide; the exchange of step i is still in flight while step i+1 computes, its tables follow that step's host wait
-        out, pending = [], None
+    def enqueue(i):
+        if next_input is not None:
+            next_input(i)
+        local_enqueue(eng, avg_len, cfg)
+
+    threaded = len(hap_names) >= PIPELINE_THREAD_MIN_HAPS
+    out, fut, pending = [], None, None
+    ex = ThreadPoolExecutor(1, initializer=getattr(comm, "thread_init", None) or (lambda: None)) if threaded else None
+    try:
+        enqueue(0)
         for i in range(n_steps):
-            if next_input is not None:
-                next_input(i)
-            local = local_stage(eng, avg_len, cfg, True)
-            nxt = (finalize_begin(local, hap_names, comm, shard_max, rows_max), local["stats"])
-            if pending is not None:
-                sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
-                out.append((sr, tr, dict(pending[1], n_active=n_active)))
-            pending = nxt
+            if i + 1 < n_steps:
+                enqueue(i + 1)                                  # the device goes straight on after step i
+            local = local_stage(eng, avg_len, cfg, "collect")   # step i's one host wait
+            if threaded:
+                if fut is not None:
+                    out.append(fut.result())                    # step i-1's tables: built while step i ran
+                fut = ex.submit(finish, local)
+            else:
+                nxt = (finalize_begin(local, hap_names, comm, shard_max, rows_max), local["stats"])
+                if pending is not None:
+                    sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
+                    out.append((sr, tr, dict(pending[1], n_active=n_active)))
+                pending = nxt
+        if fut is not None:
+            out.append(fut.result())
         if pending is not None:
             sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
             out.append((sr, tr, dict(pending[1], n_active=n_active)))
-        return out
-    out, fut = [], None
-    with ThreadPoolExecutor(1, initializer=getattr(comm, "thread_init", None) or (lambda: None)) as ex:
-        for i in range(n_steps):
-            if next_input is not None:
-                next_input(i)
-            local = local_stage(eng, avg_len, cfg, True)      # enqueue + the step's one host wait
-            if fut is not None:
-                out.append(fut.result())                      # step i-1's tables: built while step i ran
-            fut = ex.submit(finish, local)
-        if fut is not None:
-            out.append(fut.result())
+    finally:
+        if ex is not None:
+            ex.shutdown()
+        eng.drain_steps()       # only non-empty after an exception between an enqueue and its collect
     return out
 
 

@@ -299,3 +299,44 @@ def test_many_species_radix_path_against_oracle(eng):
                     assert gm[key] == ev, (s, key)
                 else:
                     assert gm[key] == pytest.approx(ev, rel=1e-7, abs=1e-9), (s, key)
+
+
+def test_step_enqueue_collect_halves(eng):
+    """pantax_hip_profile_step_enqueue / _collect: step i+1 enqueued before step i is collected gives, step for step, what the
+    one-call form gives; a third enqueue without a collect, a collect without an enqueue and a one-call step while something is
+    in flight are refused."""
+    from pantax_amd import synth
+    from pantax_amd._ffi import PantaxHipError
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(78, 4, 5, 50000, 90000)
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    avg = sset.avg_len()
+
+    def snap(t):
+        keep, absolute, met, info, passed, s_all, s_pass = t
+        return (keep.copy(), absolute.copy(), metrics_to_dicts(met, eng.H), [(info[s].status1, info[s].obj1, info[s].obj2) for s in range(eng.S)],
+                np.array(passed).copy(), s_all.copy(), s_pass.copy())
+    ref_a = snap(eng.profile_step(avg, fr=0.3))
+    avg2 = np.asarray(avg, dtype=np.float64) * 2.0         # halves every predicted coverage: the two steps cannot be mistaken for one another
+    ref_b = snap(eng.profile_step(avg2, fr=0.3, rebuild_trio=False))
+    eng.profile_step_enqueue(avg, fr=0.3)
+    eng.profile_step_enqueue(avg2, fr=0.3, rebuild_trio=False)
+    with pytest.raises(PantaxHipError):
+        eng.profile_step_enqueue(avg)                      # two in flight already
+    with pytest.raises(PantaxHipError):
+        eng.profile_step(avg)                              # the one-call form needs an empty queue
+    got_a = snap(eng.profile_step_collect())
+    eng.profile_step_enqueue(avg, fr=0.3)                  # slot of step a again, while b is still in flight
+    got_b = snap(eng.profile_step_collect())
+    got_c = snap(eng.profile_step_collect())
+    with pytest.raises(PantaxHipError):
+        eng.profile_step_collect()
+    for got, ref in ((got_a, ref_a), (got_b, ref_b), (got_c, ref_a)):
+        for x, y in zip(got, ref):
+            if isinstance(x, np.ndarray):
+                assert np.array_equal(x, y)
+            else:
+                assert x == y
+    assert not np.array_equal(ref_a[1], ref_b[1])          # the two steps really differ
+    eng._inflight = 0
