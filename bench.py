@@ -404,6 +404,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         S_max, H_max = int(t[0].item()), int(t[1].item())
 
+    # one-time set-up of the step path (not the W warm-up steps of the contract, which follow): the first stream of steps that
+    # keeps one step enqueued ahead makes the HIP runtime grow its pools (a ~6 ms stall at the third enqueue, measured); it
+    # happens here, with the uploads, not inside the timed region
+    t_pr = time.perf_counter()
+    profile_steps_pipelined(eng, species_names, hap_names, avg_len, 3, cfg, comm, shard_max=S_max, rows_max=H_max)
+    eng.sync()
+    prime_ms = (time.perf_counter() - t_pr) * 1e3
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -417,16 +425,26 @@ def main():
     eng.timing_enable(True)
     eng.timing_reset()
     n_warm_timed = 0
-    for i in range(args.warmup):
-        if i == 1:
-            eng.timing_reset()      # the very first step also allocates: its launches are not representative
-            n_warm_timed = 0
+    if args.warmup:
+        # the very first step also allocates: its launches are not representative
         out = profile_step(eng, species_names, hap_names, avg_len, cfg, comm, shard_max=S_max, rows_max=H_max)
-        n_warm_timed += 1
+        n_warm_timed = 1
+    if args.warmup > 1:
+        # the remaining warm-up steps go through the path that is timed below (one step enqueued ahead): whatever the runtime
+        # sets up the first time two steps are in flight happens here, not in the timed region
+        eng.timing_reset()
+        n_warm_timed = args.warmup - 1
+        out = profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_warm_timed, cfg, comm, shard_max=S_max, rows_max=H_max)[-1]
     warm = eng.timing_get() if args.warmup else {}
     dom = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else "coverage_step_kernel"
     eng.timing_filter(dom)
     eng.timing_reset()
+    # host hygiene before the timed region: with torch imported the interpreter holds ~1e6 long-lived objects, and a full
+    # collection of the cyclic garbage collector (triggered by the tables' tuples every few dozen steps) stops the thread that
+    # enqueues the next step for 30-50 ms; frozen objects are not scanned again
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     # K steps back to back; with N > 1 the all-reduce of step i is in flight while step i+1 computes (every step's tables
     # are complete before the closing barrier)
@@ -535,7 +553,7 @@ def main():
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3,
             "from_gaf_text_mreads_per_s": gaf_extra["end_to_end_mreads_per_s"] if gaf_extra else None,
-            "upload_ms_once": upload_ms, "synthetic_set_generated_in_s": gen_s, "ingest_route": ingest_route,
+            "upload_ms_once": upload_ms, "step_path_primed_ms_once": prime_ms, "synthetic_set_generated_in_s": gen_s, "ingest_route": ingest_route,
             "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
             "config": {"workload": "%s: %s -- %d species x %d strains, %d short reads (150 bp), genome %d bp %s; this rank: V=%d nodes, "

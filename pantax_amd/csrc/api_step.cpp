@@ -6,6 +6,9 @@
 // other without a round trip.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "lad.hpp"
@@ -28,6 +31,16 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     if (db->step_inflight >= 2) return fail(ctx, PANTAX_HIP_E_STATE, "profile_step_enqueue: two steps of this db are already in flight; collect one first");
     const uint32_t S = db->S;
     const int slot = db->step_enq;
+    // debug aid (PANTAX_HIP_TRACE): host time of the sections of an enqueue that took more than 2 ms
+    const auto t_begin = std::chrono::steady_clock::now();
+    double marks[8] = {0}; int n_marks = 0;
+    auto mark = [&]() { if (n_marks < 8) marks[n_marks++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    struct SlowReport { double *m; int *n; ~SlowReport() {
+        if (*n && m[*n - 1] > 2.0 && std::getenv("PANTAX_HIP_TRACE")) {
+            std::fprintf(stderr, "[step_enqueue] slow call, ms at marks (trio enqueued, bin+species, prezero+cov prepare, coverage, strain):");
+            for (int i = 0; i < *n; ++i) std::fprintf(stderr, " %.2f", m[i]);
+            std::fprintf(stderr, "\n");
+        } } } slow_report{marks, &n_marks};
     // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every
     // run, profile.rs:2936), so it is built while the main stream bins the reads and takes the species decision
     bool forked = false;
@@ -50,6 +63,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
         Ctx *c; Db *d; bool armed;
         ~ForkGuard() { if (armed) { (void)hipStreamSynchronize(c->stream2); d->trio_built = false; d->cov_done = false; } }
     } fork_guard{ctx, db, forked};
+    mark();
     // a2 + a3 counters
     PTX_HIP(ctx, db->d_counters.alloc(bin_counter_words(S)));
     PTX_TRY(bin_reads_launch(ctx, db, reads, db->d_counters.p));
@@ -59,20 +73,24 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     db->d_sp_abs.view(db->d_sp_out.p, S);
     db->d_active.view(db->d_sp_out.p + sizeof(double) * S, S);
     PTX_TRY(species_profile_launch(ctx, db, reads, db->d_counters.p, db->d_avg_len.p, cfg->filtered, db->d_active.p, db->d_sp_abs.p));
-    PTX_HIP(ctx, db->h_sp_out[slot].reserve(sizeof(double) * S + S));
+    for (int k = 0; k < 2; ++k) PTX_HIP(ctx, db->h_sp_out[k].reserve(sizeof(double) * S + S));
     PTX_HIP(ctx, hipMemcpyAsync(db->h_sp_out[slot].p, db->d_sp_out.p, sizeof(double) * S + S, hipMemcpyDeviceToHost, ctx->stream));
+    mark();
     PTX_TRY(strain_prezero(ctx, db));   // zero-fills of the strain step, while this stream would wait for the trio index anyway
     struct PreZeroGuard { LadBatch &lb; ~PreZeroGuard() { lb.prezeroed = false; } } prezero_guard{db->lad};   // never outlives this call
     PTX_TRY(coverage_prepare(ctx, db, reads, true));   // arena zero-fill + walk sums of long reads: need the binning, not the trio index
     struct CovPrepGuard { Db *d; ~CovPrepGuard() { d->cov_prepared = false; } } covprep_guard{db};
+    mark();
     // a8 needs both
     if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     fork_guard.armed = false;   // joined: everything later on the main stream is ordered behind the index
     PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));
+    mark();
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,
                                 cfg->shift, cfg->sample_nodes};
     PTX_TRY(strain_enqueue(ctx, db, &sc, db->d_active.p, slot));
+    mark();
     db->step_cfg[slot] = *cfg;
     db->step_enq ^= 1;
     ++db->step_inflight;

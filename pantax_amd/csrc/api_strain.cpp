@@ -8,6 +8,9 @@
 // per-species results.  The host then only redoes the reporting arithmetic (rounded fractions,
 // divergence, abundance constraint) on those values, using the decisions the device took.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -67,9 +70,11 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
 }
 
 int fetch_arena_enqueue(Ctx *ctx, Db *db, const ArenaLayout &L, int slot) {
-    PTX_HIP(ctx, db->h_arena[slot].reserve(L.total));
+    for (int k = 0; k < 2; ++k) {   // both slots at once: the first step that runs AHEAD of another one must not pay for page-locking memory
+        PTX_HIP(ctx, db->h_arena[k].reserve(L.total));
+        if (!db->ev_step[k]) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_step[k], hipEventDisableTiming));
+    }
     PTX_HIP(ctx, hipMemcpyAsync(db->h_arena[slot].p, db->d_arena.p, L.total, hipMemcpyDeviceToHost, ctx->stream));   // the one host round trip of the step
-    if (!db->ev_step[slot]) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_step[slot], hipEventDisableTiming));
     PTX_HIP(ctx, hipEventRecord(db->ev_step[slot], ctx->stream));   // a later step may already be enqueued behind it: the wait is for THIS step
     return 0;
 }
@@ -116,17 +121,34 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     const uint32_t S = db->S;
     LadBatch &lb = db->lad;
     const ArenaLayout L(S, db->H);
+    const auto t_begin = std::chrono::steady_clock::now();
+    double marks[10] = {0}; int n_marks = 0;
+    auto mark = [&]() { if (n_marks < 10) marks[n_marks++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    struct SlowReport { double *m; int *n; ~SlowReport() {
+        if (*n && m[*n - 1] > 2.0 && std::getenv("PANTAX_HIP_TRACE")) {
+            std::fprintf(stderr, "[strain_enqueue] slow call, ms at marks (bind, hap stats, node stats, sample, first filter, lad prepare, lad pair, fetch):");
+            for (int i = 0; i < *n; ++i) std::fprintf(stderr, " %.2f", m[i]);
+            std::fprintf(stderr, "\n");
+        } } } slow_report{marks, &n_marks};
     PTX_TRY(bind_arena(ctx, db, lb, L));
+    mark();
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
+    mark();
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
-    PTX_TRY(row_sample_apply(ctx, db, &lb, cfg->sample_nodes));                             // a11 (no-op unless a species is larger than --sample)
+    mark();
+    PTX_TRY(row_sample_apply(ctx, db, &lb, cfg->sample_nodes));
+    mark();                             // a11 (no-op unless a species is larger than --sample)
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
     PTX_TRY(first_filter_launch(ctx, db, &lb, d_active, fc));                               // a9 decision -> LP columns
+    mark();
     int pmax_bound = 1;                                                                     // columns per species <= min(#haps, 64)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
+    mark();
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
+    mark();
     PTX_TRY(fetch_arena_enqueue(ctx, db, L, slot));
+    mark();
     lb.prezeroed = false;
     return 0;
 }

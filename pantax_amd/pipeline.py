@@ -10,6 +10,10 @@ metadata gathered once.
 """
 from dataclasses import dataclass
 
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor   # at import time: a first import inside a timed stream of steps costs milliseconds
+
 import numpy as np
 
 
@@ -367,7 +371,6 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
     Collectives are issued in step order on every rank.  next_input(i), if given, is called before step i is enqueued to
     swap in that step's reads (the swap itself waits for the step that still uses the old ones).  Returns the list of
     (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
-    from concurrent.futures import ThreadPoolExecutor
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
     if n_steps <= 0:
@@ -377,20 +380,30 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
         sr, tr, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max, rows_max)
         return sr, tr, dict(local["stats"], n_active=n_active)
 
+    _enq_ms = []
+
     def enqueue(i):
         if next_input is not None:
             next_input(i)
+        t_e = time.perf_counter()
         local_enqueue(eng, avg_len, cfg)
+        _enq_ms.append((time.perf_counter() - t_e) * 1e3)
 
     threaded = len(hap_names) >= PIPELINE_THREAD_MIN_HAPS
     out, fut, pending = [], None, None
     ex = ThreadPoolExecutor(1, initializer=getattr(comm, "thread_init", None) or (lambda: None)) if threaded else None
     try:
+        _trace = [time.perf_counter()] if os.environ.get("PANTAX_PIPE_TRACE") else None   # debug: when every step was collected
+        lookahead = os.environ.get("PANTAX_STEP_LOOKAHEAD", "1") != "0"    # 0: enqueue step i+1 only after step i's collect (measurements)
         enqueue(0)
         for i in range(n_steps):
-            if i + 1 < n_steps:
+            if lookahead and i + 1 < n_steps:
                 enqueue(i + 1)                                  # the device goes straight on after step i
             local = local_stage(eng, avg_len, cfg, "collect")   # step i's one host wait
+            if _trace is not None:
+                _trace.append(time.perf_counter())
+            if not lookahead and i + 1 < n_steps:
+                enqueue(i + 1)
             if threaded:
                 if fut is not None:
                     out.append(fut.result())                    # step i-1's tables: built while step i ran
@@ -409,6 +422,10 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
     finally:
         if ex is not None:
             ex.shutdown()
+        if _trace is not None:
+            import sys
+            print("[pipelined] ms between collects:", " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip(_trace, _trace[1:])), file=sys.stderr)
+            print("[pipelined] ms per enqueue call:", " ".join("%.2f" % x for x in _enq_ms), file=sys.stderr)
         eng.drain_steps()       # only non-empty after an exception between an enqueue and its collect
     return out
 
