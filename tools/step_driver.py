@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from bench import WORKLOADS
 from pantax_amd import synth
 from pantax_amd.engine import Engine
-from pantax_amd.pipeline import StepConfig, profile_step
+from pantax_amd.pipeline import StepConfig, profile_step, profile_steps_pipelined
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rebuild = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
@@ -19,8 +19,8 @@ haps = [h for g in sset.species for h in g.hap_names]
 eng = Engine(0)
 eng.upload_db(sset.species); eng.upload_packed(sset.reads)
 cfg = StepConfig(rebuild_trio=rebuild)
-for _ in range(n):
-    out = profile_step(eng, names, haps, sset.avg_len(), cfg)
+out = profile_step(eng, names, haps, sset.avg_len(), cfg)                                   # allocations
+out = profile_steps_pipelined(eng, names, haps, sset.avg_len(), n, cfg)[-1]                  # the path bench.py times: one step enqueued ahead
 eng.sync()
 print("step_driver: %s, %d steps, %d strain rows" % (wl, n, len(out[1])))
 eng.close()
