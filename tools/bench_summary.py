@@ -2,7 +2,7 @@
 """Print the essentials of a bench.py JSON line."""
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
-print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  launches/step %s" % (d["value"], d["unit"], d["ms_per_step"], d["ms_per_step_trio_index_resident"], d.get("launches_per_step")))
+print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  timer scopes/step %s" % (d["value"], d["unit"], d["ms_per_step"], d["ms_per_step_trio_index_resident"], d.get("kernel_timer_scopes_per_step", d.get("launches_per_step"))))
 r = d["roofline"]
 print("roofline", r["kernel"], "avg_ms %.3f frac %.3f traffic %s" % (r["avg_ms"], r["frac"], r.get("traffic")))
 print("kernels", {k: round(v, 3) for k, v in list(d["kernels_ms_per_step"].items())[:16]})

@@ -32,5 +32,7 @@ trace) bash tools/kernel_trace.sh cfg3 ${tag}_cfg3 6 ;;
 trace2) bash tools/kernel_trace.sh cfg2 ${tag}_cfg2 10 ;;
 pmc) bash tools/pmc_step.sh cfg3 ${tag}_cfg3 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
      python3 tools/pmc_collect.py gpurun_out/pmc_${tag}_cfg3 cfg3 gpurun_out/${tag}_pmc_cfg3.json ;;
+pmc2) bash tools/pmc_step.sh cfg2 ${tag}_cfg2 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU"
+     python3 tools/pmc_collect.py gpurun_out/pmc_${tag}_cfg2 cfg2 gpurun_out/${tag}_pmc_cfg2.json ;;
 esac
 done
