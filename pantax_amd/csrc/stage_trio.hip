@@ -313,15 +313,37 @@ __global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const ui
 
 // 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
 //     its first unique window (rows are numbered (species, hap, position))
-__global__ void __launch_bounds__(256) trio_tilecount_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank,
-                                                             const uint8_t *__restrict__ uniq_q, uint32_t *__restrict__ tile_cnt) {
-    __shared__ uint32_t s_wave[4];
+// ONE WAVE per tile, four tiles per workgroup: the 1024 flag bytes of a tile are five dword loads per lane (aligned down to a
+// dword, bytes outside the tile masked off) -- a workgroup per tile spent its time being launched (2.2e5 workgroups of 1 KB
+// each: 0.29 ms for 223 MB at cfg3).
+__global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
+                                                             const uint32_t *__restrict__ tile_rank, const uint8_t *__restrict__ uniq_q,
+                                                             uint32_t *__restrict__ tile_cnt) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint2 tile = tiles[t];
+    const int lane = threadIdx.x & 63;
     uint32_t c = 0;
-    TILE_LOOP(q, h, qend) c += uniq_q[q];
+    if (tile.x != 0xFFFFFFFFu) {   // not a filler tile
+        const uint64_t q0 = path_off[tile.x] + (uint64_t)tile.y * PATH_TILE;
+        uint64_t qe = path_off[tile.x + 1];
+        if (qe > q0 + PATH_TILE) qe = q0 + PATH_TILE;
+        const uint64_t a0 = q0 & ~3ull;
+        const uint32_t *words = reinterpret_cast<const uint32_t *>(uniq_q);   // the arena is dword-aligned and padded by a dword
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint64_t a = a0 + 4ull * (uint64_t)(lane + 64 * k);
+            if (a < qe) {
+                uint32_t w = words[a >> 2] & 0x01010101u;
+                // bytes a .. a+3 hold positions a .. a+3: keep those inside [q0, qe)
+                if (a < q0) w &= 0xFFFFFFFFu << (8u * (uint32_t)(q0 - a));
+                if (a + 4 > qe) w &= 0xFFFFFFFFu >> (8u * (uint32_t)(a + 4 - qe));
+                c += (uint32_t)__popc(w);
+            }
+        }
+    }
     c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[tile_rank[blockIdx.x]] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (lane == 0) tile_cnt[tile_rank[t]] = c;
 }
 // 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
 //     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
@@ -525,7 +547,8 @@ int trio_index_build(Ctx *ctx, Db *db) {
                                    ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
         }
-        hipLaunchKernelGGL(trio_tilecount_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, ts.uniq_q.p, ts.tile_cnt.p);
+        hipLaunchKernelGGL(trio_tilecount_kernel, dim3((NT + 3) / 4), dim3(256), 0, ctx->stream, NT, db->d_tiles.p, db->d_path_off.p, db->d_tile_rank.p,
+                           ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
         PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
                                   "exclusive_scan"));
