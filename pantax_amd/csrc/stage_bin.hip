@@ -169,6 +169,124 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_kernel(
     }
 }
 
+// The same pass for up to BIN_LDS_SPECIES species with EVERYTHING a read needs about the species in LDS (dynamic, sized by S:
+// 44 bytes per species): the ranges for the search, {first id, node base, node count} for the slot record, the counter
+// histogram.  The kernel is bound by its chain of dependent loads (PMC: 94 % of wave time waiting, 33 M VALU instructions
+// for 1e7 reads): with the tables in global memory a read cost ~17 dependent round trips (offsets, ~8 walk loads one after
+// the other, 7 search levels, 3 species-table loads); here it is the offsets, one batch of up to 8 walk loads issued
+// together (a second batch for walks of 9..64 steps), LDS searches, and the per-read columns, which are requested before
+// the species is known.
+template <bool SORTED>
+__global__ void __launch_bounds__(BIN_BLOCK) bin_reads_lds_kernel(
+    uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
+    const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, const uint32_t *__restrict__ rs,
+    const uint32_t *__restrict__ re, const uint32_t *__restrict__ ridx, int S, int32_t *__restrict__ species_out,
+    const uint32_t *__restrict__ slot_of, const uint8_t *__restrict__ flags, uint4 *__restrict__ slot_rec,
+    const uint32_t *__restrict__ sp_first_id /* null: db without graphs */, const uint32_t *__restrict__ node_base,
+    unsigned long long *__restrict__ counters_rep) {
+    extern __shared__ unsigned long long s_dyn[];
+    unsigned long long *s_base = s_dyn;                                   // [S]
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_dyn + S);    // [3S]
+    uint32_t *s_rs = s_cnt + 3 * S, *s_re = s_rs + S, *s_ridx = s_re + S; // [S] each, in search order
+    uint32_t *s_first = s_ridx + S, *s_nb = s_first + S, *s_nn = s_nb + S;   // [S] each, by species index
+    unsigned long long *__restrict__ counters = counters_rep + (size_t)(blockIdx.x % BIN_REPL) * 4 * S;
+    for (int i = threadIdx.x; i < S; i += BIN_BLOCK) {
+        s_base[i] = 0; s_cnt[i] = 0; s_cnt[S + i] = 0; s_cnt[2 * S + i] = 0;
+        s_rs[i] = rs[i]; s_re[i] = re[i]; s_ridx[i] = ridx[i];
+        s_first[i] = sp_first_id ? sp_first_id[i] : 0u;
+        s_nb[i] = sp_first_id ? node_base[i] : 0u;
+        s_nn[i] = sp_first_id ? node_base[i + 1] - node_base[i] : 0u;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * BIN_BLOCK + (threadIdx.x - lane); base < R; base += (uint64_t)gridDim.x * BIN_BLOCK) {
+        const uint64_t r = base + lane;
+        int sp = -1;
+        uint32_t b = 0, e = 0, q = 0, m = 255u, slot = 0xFFFFFFFFu;
+        uint8_t fl = 0;
+        if (r < R) {
+            b = step_off[r]; e = step_off[r + 1];
+            q = qlen[r]; m = mapq[r];                                     // requested now, used once the species is known
+            if (slot_of) slot = slot_of[r];
+            if (flags) fl = flags[r];
+        }
+        uint32_t mn = 0xFFFFFFFFu, mx = 0;
+        const uint32_t k = e - b;
+        const bool long_walk = k > 64u;
+        // walks of more than 64 steps (long reads): the wave's four 16-lane rows each scan one such walk at a time
+        const int row = lane >> 4, rl = lane & 15;
+        for (unsigned long long todo = __ballot(long_walk); todo;) {
+            int src = -1;
+            unsigned long long t = todo;
+            for (int w_ = 0; w_ <= row && t; ++w_) { src = (w_ == row) ? __ffsll((long long)t) - 1 : -1; t &= t - 1; }
+            for (int w_ = 0; w_ < 4 && todo; ++w_) todo &= todo - 1;
+            const uint32_t bb = __shfl(b, src < 0 ? 0 : src), ee = __shfl(e, src < 0 ? 0 : src);
+            uint32_t m1 = 0xFFFFFFFFu, m2 = 0;
+            if (src >= 0)
+                for (uint32_t i = bb + rl; i < ee; i += 16) { const uint32_t v = node_id[i]; m1 = min(m1, v); m2 = max(m2, v); }
+            m1 = row_reduce(m1, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+            m2 = row_reduce(m2, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+            for (int rr = 0; rr < 4; ++rr) {
+                const int owner = __shfl(src, rr * 16);
+                const uint32_t a1 = __shfl(m1, rr * 16), a2 = __shfl(m2, rr * 16);
+                if (owner >= 0 && lane == owner) { mn = a1; mx = a2; }
+            }
+        }
+        if (r < R && k && !long_walk) {
+            // up to 8 node ids in ONE batch of loads (the usual short read), the rest eight at a time
+            for (uint32_t i0 = b; i0 < e; i0 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = i0 + j < e ? node_id[i0 + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (i0 + j < e) { mn = min(mn, v[j]); mx = max(mx, v[j]); }
+            }
+        }
+        if (r < R) {
+            if (k) sp = find_species<SORTED>(mn, mx, s_rs, s_re, s_ridx, S);
+            species_out[r] = sp;
+            if (slot != 0xFFFFFFFFu) {
+                uint4 rec = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+                if (sp >= 0 && !fl) { rec.x = (uint32_t)sp; rec.y = s_first[sp]; rec.z = s_nb[sp]; rec.w = s_nn[sp]; }
+                slot_rec[slot] = rec;
+            }
+        }
+        const bool lm = sp >= 0 && m >= 3 && m <= 60, uq = sp >= 0 && m == 60;
+        if (sp < 0) q = 0;
+        const unsigned long long have = __ballot(sp >= 0);
+        if (have == 0) continue;
+        const int sp0 = __shfl(sp, __ffsll((long long)have) - 1);
+        const bool uniform = __all(sp < 0 || sp == sp0);
+        if (uniform) {
+            unsigned long long qs = q;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) qs += __shfl_down(qs, off);
+            const unsigned int c = __popcll(have), l = __popcll(__ballot(lm)), u = __popcll(__ballot(uq));
+            if (lane == 0) {
+                atomicAdd(&s_cnt[sp0], c); atomicAdd(&s_base[sp0], qs);
+                if (l) atomicAdd(&s_cnt[S + sp0], l);
+                if (u) atomicAdd(&s_cnt[2 * S + sp0], u);
+            }
+        } else if (sp >= 0) {
+            atomicAdd(&s_cnt[sp], 1u);
+            atomicAdd(&s_base[sp], (unsigned long long)q);
+            if (lm) atomicAdd(&s_cnt[S + sp], 1u);
+            if (uq) atomicAdd(&s_cnt[2 * S + sp], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += BIN_BLOCK) {
+        unsigned int c = s_cnt[i];
+        if (c) {
+            atomicAdd(&counters[i], (unsigned long long)c);
+            atomicAdd(&counters[S + i], s_base[i]);
+            unsigned int l = s_cnt[S + i], u = s_cnt[2 * S + i];
+            if (l) atomicAdd(&counters[2 * S + i], (unsigned long long)l);
+            if (u) atomicAdd(&counters[3 * S + i], (unsigned long long)u);
+        }
+    }
+}
+
 // sums the replicas and appends the head of (species, qlen) -- everything the host reads after binning sits in
 // one contiguous block: [4*S u64 sums][BIN_PREFIX i32 species][BIN_PREFIX u32 qlen]
 __global__ void __launch_bounds__(256) bin_reduce_kernel(int n, const unsigned long long *__restrict__ rep, unsigned long long *__restrict__ out,
@@ -205,11 +323,12 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
 #define BIN_ARGS rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_qlen.p, rd->d_mapq.p, db->d_rng_start.p, db->d_rng_end.p, \
                  db->d_rng_idx.p, S, rd->d_species.p, rd->grouped ? rd->d_slot_of.p : nullptr, rd->has_flags ? rd->d_flags.p : nullptr, rd->d_g_slot_rec.p, \
                  db->d_sp_first_id.p, db->d_node_base.p, d_counters
+        const size_t dyn = (size_t)S * 44;   // bin_reads_lds_kernel: 8 + 12 + 24 bytes per species
         if (db->ranges_sorted_disjoint) {
-            if (lds) hipLaunchKernelGGL((bin_reads_kernel<true, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+            if (lds) hipLaunchKernelGGL((bin_reads_lds_kernel<true>), dim3(grid), dim3(BIN_BLOCK), dyn, ctx->stream, BIN_ARGS);
             else hipLaunchKernelGGL((bin_reads_kernel<true, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
         } else {
-            if (lds) hipLaunchKernelGGL((bin_reads_kernel<false, true>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
+            if (lds) hipLaunchKernelGGL((bin_reads_lds_kernel<false>), dim3(grid), dim3(BIN_BLOCK), dyn, ctx->stream, BIN_ARGS);
             else hipLaunchKernelGGL((bin_reads_kernel<false, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);
         }
 #undef BIN_ARGS
