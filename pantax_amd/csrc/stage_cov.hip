@@ -315,37 +315,61 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 // Walks of more than 64 steps: the last step needs `seen` = everything aligned before it (:857-859), which lives in
 // other waves.  One cheap pass over the steps of long walks adds the node lengths of all steps but the last into
 // long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
+template <int WS_U>
 __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ step_read, const uint8_t *__restrict__ step_dup,
                                                        const uint4 *__restrict__ read_rec, const uint4 *__restrict__ slot_rec,
-                                                       const uint32_t *__restrict__ node_id, const uint4 *__restrict__ node_rec,
+                                                       const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ node_len,
                                                        uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
+    // WS_U groups of 64 steps per wave and round, the loads of a level issued for all of them before the first is used (the
+    // pass is a chain of three dependent levels: {code, slot, id} -> {slot record, read record} -> node length, a 4-byte
+    // gather from the plain length array, not the 16-byte node record)
     const int lane = threadIdx.x & 63;
-    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)); base < T; base += (uint64_t)gridDim.x * 256) {
-        const uint64_t t = base + lane;
-        const uint32_t code = t < T ? step_dup[t] : 0u;
-        if (!__any(code & STEP_LONG)) continue;
-        uint32_t slot = NO_SLOT, nl = 0;
-        if (code & STEP_LONG) slot = step_read[t];
-        if (slot != NO_SLOT) {
-            const uint4 sr = slot_rec[slot];
-            const uint4 rr = read_rec[slot];
-            if ((int)sr.x >= 0 && (uint32_t)(t - rr.x) + 1 < rr.y) {        // not the last step
-                const uint32_t id = node_id[t];
-                if (id >= sr.y && id - sr.y < sr.w) nl = node_rec[sr.z + (id - sr.y)].z;
-                if (t == rr.x) long_len0[slot] = nl;                 // length of the walk's first node, for the lanes of later waves
-            }
-        }
-        // segmented sum over runs of equal slot (a walk's steps are contiguous), one atomic per run
-        const uint32_t prev = __shfl_up(slot, 1);
-        const bool head = lane == 0 || prev != slot;
-        const unsigned long long heads = __ballot(head);
-        uint32_t incl = nl;
-        const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));   // lane of my run's head
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * WS_U;
+    for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)) * WS_U; base < T; base += stride) {
+        uint32_t code[WS_U], slot[WS_U], id[WS_U], nl[WS_U];
+        uint64_t t[WS_U];
+        bool any = false;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane - d >= start) incl += up; }
-        const unsigned long long after = heads & ~((2ull << lane) - 1ull);
-        const bool tail = after ? (lane + 1 == __builtin_ctzll(after)) : lane == 63;
-        if (tail && slot != NO_SLOT && incl) atomicAdd(&long_sum[slot], incl);
+        for (int u = 0; u < WS_U; ++u) {
+            t[u] = base + (uint64_t)u * 64 + lane;
+            code[u] = t[u] < T ? step_dup[t[u]] : 0u;
+            any = any || (code[u] & STEP_LONG);
+        }
+        if (!__any(any)) continue;
+#pragma unroll
+        for (int u = 0; u < WS_U; ++u) {
+            slot[u] = NO_SLOT; id[u] = 0;
+            if (code[u] & STEP_LONG) { slot[u] = step_read[t[u]]; id[u] = node_id[t[u]]; }
+        }
+        uint4 sr[WS_U], rr[WS_U];
+#pragma unroll
+        for (int u = 0; u < WS_U; ++u) {
+            sr[u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); rr[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (slot[u] != NO_SLOT) { sr[u] = slot_rec[slot[u]]; rr[u] = read_rec[slot[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < WS_U; ++u) {
+            nl[u] = 0;
+            const bool counted = slot[u] != NO_SLOT && (int)sr[u].x >= 0 && (uint32_t)(t[u] - rr[u].x) + 1 < rr[u].y;   // not the last step
+            if (counted && id[u] >= sr[u].y && id[u] - sr[u].y < sr[u].w) nl[u] = node_len[sr[u].z + (id[u] - sr[u].y)];
+        }
+#pragma unroll
+        for (int u = 0; u < WS_U; ++u) {
+            if (!__any(slot[u] != NO_SLOT)) continue;
+            if (slot[u] != NO_SLOT && (int)sr[u].x >= 0 && (uint32_t)(t[u] - rr[u].x) + 1 < rr[u].y && t[u] == rr[u].x)
+                long_len0[slot[u]] = nl[u];                          // length of the walk's first node, for the lanes of later waves
+            // segmented sum over runs of equal slot (a walk's steps are contiguous), one atomic per run
+            const uint32_t prev = __shfl_up(slot[u], 1);
+            const bool head = lane == 0 || prev != slot[u];
+            const unsigned long long heads = __ballot(head);
+            uint32_t incl = nl[u];
+            const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));   // lane of my run's head
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane - d >= start) incl += up; }
+            const unsigned long long after = heads & ~((2ull << lane) - 1ull);
+            const bool tail = after ? (lane + 1 == __builtin_ctzll(after)) : lane == 63;
+            if (tail && slot[u] != NO_SLOT && incl) atomicAdd(&long_sum[slot[u]], incl);
+        }
     }
 }
 
@@ -564,8 +588,8 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");
-        hipLaunchKernelGGL(walk_sum_kernel, dim3(grid_for(rd->T_pad, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
-                           rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, db->d_node_rec.p, rd->d_long_sum.p,
+        hipLaunchKernelGGL(walk_sum_kernel<4>, dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
+                           rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, db->d_node_len.p, rd->d_long_sum.p,
                            rd->d_long_len0.p);
     }
     PTX_HIP(ctx, hipGetLastError());
