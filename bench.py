@@ -568,7 +568,7 @@ def main():
             "roofline_other_kernels": others,
             "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
             # timer scopes, not dispatches: a scope brackets one stage (a sort = several launches).  Dispatches per step, counted in
-            # the rocprofv3 trace of this path: 43 at cfg3 (profiles/r02_z_cfg3_timeline.txt), fills and copies included
+            # the rocprofv3 trace of this path: 43 at cfg3 (profiles/r02_final_cfg3_timeline.txt), fills and copies included
             "kernel_timer_scopes_per_step": int(sum(v[0] for v in warm.values()) / max(n_warm_timed, 1)),
             "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel only",
             "solver": {"iters": stats["iters"][:4], "n_rows": stats["n_rows"][:4], "n_patterns": stats["n_patterns"][:4],
