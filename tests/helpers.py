@@ -228,3 +228,51 @@ def check_against_literal(j, names, abc, hap, ln, tb, bases, cov, n_abort):
     assert [int(x) for x in bases] == ex["bases_per_node"]
     assert [int(x) for x in cov] == ex["node_base_cov"]
     assert int(n_abort) == ex["n_abort"]
+
+
+def load_literal_strain_case(k):
+    """tests/golden/literal_strain_<k>.json (oracle/gen_golden_literal_strain.py: literal Python reading of the species /
+    strain level, LP by SciPy-HiGHS) -> (json, SyntheticSet built from it)."""
+    from pantax_amd import synth
+    with open(os.path.join(ROOT, "tests", "golden", "literal_strain_%d.json" % k)) as f:
+        j = json.load(f)
+    species = []
+    for sp in j["species"]:
+        names = list(sp["hap_names"])
+        assert names == sorted(names)
+        path_off = np.zeros(len(names) + 1, dtype=np.uint64)
+        path_off[1:] = np.cumsum([len(sp["paths"][n]) for n in names])
+        path_nodes = np.concatenate([np.array(sp["paths"][n], dtype=np.uint32) for n in names])
+        species.append(synth.SpeciesGraph(sp["name"], np.array(sp["node_len"], dtype=np.int64), path_off, path_nodes, names, sp["range_start"],
+                                          sp["range_end"], np.full(len(names), sp["genome_len"]), np.zeros(len(names))))
+    rd = j["reads"]
+    step_off = np.zeros(len(rd) + 1, dtype=np.uint64)
+    step_off[1:] = np.cumsum([len(r["walk"]) for r in rd])
+    reads = synth.PackedReads(step_off, np.array([v for r in rd for v in r["walk"]], dtype=np.uint32),
+                              np.array([s for r in rd for s in r["strand"]], dtype=np.uint8), np.array([r["read_start"] for r in rd], dtype=np.int64),
+                              np.array([r["read_end"] for r in rd], dtype=np.int64), np.array([r["read_len"] for r in rd], dtype=np.int64),
+                              np.array([255 if r["mapq"] is None else r["mapq"] for r in rd], dtype=np.int64), np.zeros(len(rd), dtype=np.int64))
+    return j, synth.SyntheticSet(species, reads)
+
+
+_LIT_FIELDS = [("unique_trio_nodes_fraction", "unique_trio_fraction", 0.0), ("frequencies_mean", "uniq_trio_cov_mean", 1e-9),
+               ("path_cov_ratio", "path_base_cov", 2e-6), ("first_sol", "first_sol", 1e-7), ("divergence", "strain_cov_diff", 0.0),
+               ("second_sol", "predicted_coverage", 1e-7), ("total_cov_diff", "total_cov_diff", 1e-7)]
+
+
+def check_metrics_against_literal(exp_metrics, got_dicts, where=""):
+    """exp_metrics: the fixture's HapMetrics of one species (hap order); got_dicts: metrics_to_dicts(...) of the same haps.
+    Option-ness must agree field by field; rounded fields exactly, LP-derived ones to 1e-7 (unique optima, checked when the
+    fixture was generated), the f32 ratio to f32 precision."""
+    assert len(exp_metrics) == len(got_dicts)
+    for h, (e, g) in enumerate(zip(exp_metrics, got_dicts)):
+        for ek, gk, tol in _LIT_FIELDS:
+            ev, gv = e[ek], g[gk]
+            assert (ev is None) == (gv is None), (where, h, ek, ev, gv)
+            if ev is None:
+                continue
+            if tol == 0.0:
+                assert ev == gv, (where, h, ek, ev, gv)
+            else:
+                assert abs(ev - gv) <= tol * max(1.0, abs(ev)), (where, h, ek, ev, gv)
+        assert bool(e["is_rescue"]) == bool(g["is_rescue"]), (where, h, e["is_rescue"], g["is_rescue"])

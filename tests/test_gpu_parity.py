@@ -736,3 +736,54 @@ def test_concurrent_solver_calls_on_one_ctx(eng, golden_dir):
     assert len(results) > 40
     for (tid, rep, ci), (obj, objh, st) in results.items():
         assert st == 0 and obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (tid, rep, ci)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_step_vs_literal_python_restatement_of_the_strain_level(eng, k):
+    """The HIP path against fixtures from oracle/ref_literal_strain.py -- the literal Python reading of rcls.rs:237-258 and
+    profile.rs:208-349, 1028-1285, 1297-1511 (LP by SciPy-HiGHS), 2884-3070, 3167-3248, which shares no code with the C oracle:
+    species of every read, the species table, every HapMetrics field of every haplotype (--shift, --filtered off, --min_depth,
+    single-strain species, null MAPQ among the cases) and the final strain rows; the one-call step and the table code."""
+    from pantax_amd.engine import metrics_to_dicts
+    from pantax_amd.pipeline import StepConfig, profile_step
+    from tests.helpers import check_metrics_against_literal, load_literal_strain_case
+    j, sset = load_literal_strain_case(k)
+    a, ex = j["args"], j["expect"]
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    sp, *_ = eng.rcls_profile()
+    assert [names[i] if i >= 0 else "U" for i in sp] == ex["read_species"]
+    keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(sset.avg_len(), fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_cov=a["min_cov"],
+                                                                          min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"])
+    d = metrics_to_dicts(met, eng.H)
+    tab = {r["species_taxid"]: r for r in ex["species_profile"]}
+    for s, g in enumerate(sset.species):
+        assert bool(keep[s]) == (g.name in tab)
+        if g.name in tab:
+            assert absolute[s] == pytest.approx(tab[g.name]["predicted_coverage"], rel=1e-12)
+        e = ex["per_species"].get(g.name)
+        if e is None:
+            continue
+        h0, h1 = int(eng.hap_off[s]), int(eng.hap_off[s + 1])
+        assert info[s].status1 == 0 and info[s].status2 == 0 and info[s].n_candidates == e["n_candidates"]
+        if e["obj1"] is not None:
+            assert info[s].obj1 == pytest.approx(e["obj1"], rel=1e-9, abs=1e-12)
+        if e["obj2"] is not None:
+            assert info[s].obj2 == pytest.approx(e["obj2"], rel=1e-9, abs=1e-12)
+        check_metrics_against_literal(e["metrics"], d[h0:h1], g.name)
+    # the tables as the stage API builds them (species order of the species table, normalisers, filters, sort)
+    cfg = StepConfig(fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_species_abundance=a["min_species_abundance"], min_cov=a["min_cov"],
+                     min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"])
+    species_rows, strain_rows, stats = profile_step(eng, names, haps, sset.avg_len(), cfg)
+    assert [r[0] for r in species_rows] == [r["species_taxid"] for r in ex["species_profile"]]
+    for r, e in zip(species_rows, ex["species_profile"]):
+        assert r[1] == pytest.approx(e["predicted_abundance"], rel=1e-12) and r[2] == pytest.approx(e["predicted_coverage"], rel=1e-12)
+    assert sorted((r[0], r[1]) for r in strain_rows) == sorted((e["species_taxid"], e["hap_id"]) for e in ex["final_rows"])
+    exp = {(e["species_taxid"], e["hap_id"]): e for e in ex["final_rows"]}
+    for r in strain_rows:
+        e = exp[(r[0], r[1])]
+        assert r[2] == pytest.approx(e["predicted_coverage"], rel=1e-7) and r[3] == pytest.approx(e["predicted_abundance"], rel=1e-7)
+    assert [r[3] for r in strain_rows] == sorted((r[3] for r in strain_rows), reverse=True)

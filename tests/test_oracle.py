@@ -214,3 +214,59 @@ def test_lad_solver_vs_reference_milp_model(golden_dir):
         assert st == 0
         assert obj == pytest.approx(float(z["obj_milp_%d" % i]), rel=1e-9, abs=1e-12), str(z["name_%d" % i])
         assert np.all(x[fixed == 1] == 0.0)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_oracle_equals_literal_python_restatement_of_the_strain_level(k):
+    """The C oracle against fixtures from oracle/ref_literal_strain.py, the literal Python reading of rcls.rs:237-258 and
+    profile.rs:208-349, 1028-1285, 1297-1511 (LP by SciPy-HiGHS), 2884-3070, 3167-3248 that shares no code with it: species of
+    every read, the species table, every HapMetrics field of every haplotype (--shift, --filtered off, --min_depth, single-strain
+    species, null MAPQ among the cases), the final strain rows."""
+    from oracle import oracle as orc
+    from tests.helpers import check_metrics_against_literal, load_literal_strain_case, select_reads
+    j, sset = load_literal_strain_case(k)
+    a, ex, rd = j["args"], j["expect"], sset.reads
+    S = len(sset.species)
+    names = [g.name for g in sset.species]
+    sp = orc.bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species])
+    assert [names[i] if i >= 0 else "U" for i in sp] == ex["read_species"]
+    counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, counts, sset.avg_len(), filtered=a["filtered"])
+    got_tab = sorted([(names[s], abundance[s], absolute[s]) for s in range(S) if keep[s]], key=lambda r: -r[1])
+    assert [r[0] for r in got_tab] == [r["species_taxid"] for r in ex["species_profile"]]
+    for g_, e_ in zip(got_tab, ex["species_profile"]):
+        assert g_[1] == pytest.approx(e_["predicted_abundance"], rel=1e-12) and g_[2] == pytest.approx(e_["predicted_coverage"], rel=1e-12)
+    rows = []
+    # species in the order of the species table (the strain level iterates the joined frame, profile.rs:600-640): ties of the
+    # final sort keep that order
+    for s in sorted(range(S), key=lambda i: (-(abundance[i] if keep[i] else -1.0), i)):
+        g = sset.species[s]
+        if not keep[s] or not abundance[s] > a["min_species_abundance"]:
+            assert g.name not in ex["per_species"]
+            continue
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        so, nid, ps, pe = select_reads(rd, np.nonzero(sp == s)[0])
+        b, c, tb, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        e = ex["per_species"][g.name]
+        assert (T.n_unique, na, int(b.sum()), int(tb.sum())) == (e["n_unique_trios"], e["n_abort"], e["bases_total"], e["trio_bases_total"])
+        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=a["fr"], fc=a["fc"], sr=a["sr"], shift=a["shift"], min_depth=a["min_depth"])
+        assert rc == 0 and nc == e["n_candidates"]
+        if e["obj1"] is not None:
+            assert o1 == pytest.approx(e["obj1"], rel=1e-9, abs=1e-12)
+        if e["obj2"] is not None:
+            assert o2 == pytest.approx(e["obj2"], rel=1e-9, abs=1e-12)
+        orc.abundance_constraint(absolute[s], met)
+        d = orc.metrics_to_dicts(met)
+        check_metrics_against_literal(e["metrics"], d, g.name)
+        for h, m in enumerate(d):
+            cov = m["predicted_coverage"]
+            if cov is None:
+                continue
+            if (len(d) > 1 or (m["total_cov_diff"] is not None and m["total_cov_diff"] <= a["sd"])) and cov >= a["min_cov"] and cov != 0.0:
+                rows.append((g.name, g.hap_names[h], cov))
+    tot = sum(r[2] for r in rows)
+    rows = sorted([(r[0], r[1], r[2], r[2] / tot) for r in rows], key=lambda r: -r[3])
+    assert [(r[0], r[1]) for r in rows] == [(e["species_taxid"], e["hap_id"]) for e in ex["final_rows"]]
+    for r, e in zip(rows, ex["final_rows"]):
+        assert r[2] == pytest.approx(e["predicted_coverage"], rel=1e-7) and r[3] == pytest.approx(e["predicted_abundance"], rel=1e-7)
