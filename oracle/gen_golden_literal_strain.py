@@ -45,7 +45,7 @@ def lp_is_unique(coeff, rows, abund, ub, fixed, x_ref, obj_ref):
     return True
 
 
-def make_case(seed, S, H, genome_len, n_reads, args, single_every=0, present_frac=0.5, mapq_null_every=0):
+def make_case(seed, S, H, genome_len, n_reads, args, single_every=0, present_frac=0.5, mapq_null_every=0, dup_ids=0, null_start_every=0):
     sset = synth.make_set(seed, S, H, n_reads, genome_len, adversarial_frac=0.01, single_strain_every=single_every, present_frac=present_frac)
     rd = sset.reads
     so = rd.step_off.astype(np.int64)
@@ -59,8 +59,17 @@ def make_case(seed, S, H, genome_len, n_reads, args, single_every=0, present_fra
         if mapq_null_every and r % mapq_null_every == 3:
             mq = None                                                                             # `*` in column 12
         reads.append(dict(walk=ids, strand=st, read_start=int(rd.pstart[r]), read_end=int(rd.pend[r]), read_len=int(rd.qlen[r]), mapq=mq))
-    for x in reads:
+    for r, x in enumerate(reads):
         x["path"] = "".join(("<" if s else ">") + str(v) for v, s in zip(x["walk"], x["strand"]))
+        x["read_id"] = "S0R%d/1" % r
+        x["read_path_len"] = int(rd.plen[r])
+        if null_start_every and r % null_start_every == 5:
+            x["read_start"] = None                                                                # `*` in column 8: counted at species level, dropped at strain level
+    if dup_ids:   # ids that repeat: pairs far apart in the file, within one species (kept, renamed) and across two (both dropped)
+        rng = np.random.default_rng(seed + 7)
+        pick = rng.choice(len(reads), size=(dup_ids, 2), replace=False)
+        for a_, b_ in pick:
+            reads[int(b_)]["read_id"] = reads[int(a_)]["read_id"]
     # ---- rcls + species level
     for x in reads:
         x["species"] = ls.process_single_read_simple(x["path"], species_info)
@@ -68,13 +77,16 @@ def make_case(seed, S, H, genome_len, n_reads, args, single_every=0, present_fra
     species_profile = ls.species_profiling(rcls_df, species_len, args["filtered"])
     # ---- strain level: load_species_range's -a cut, then optimize_otu per species (profile.rs:3297-3319)
     all_metrics, per_species, unique_ok = [], {}, True
+    clustered = ls.group_reads_by_species(rcls_df)                                                # profile.rs:3293
     for row in species_profile:
         if row["predicted_abundance"] is None or not row["predicted_abundance"] > args["min_species_abundance"]:
             continue
         g = [g for g in sset.species if g.name == row["species_taxid"]][0]
         nodes_len = [int(v) for v in g.node_len]
         paths = {hn: [int(v) for v in g.path_nodes[int(g.path_off[h]):int(g.path_off[h + 1])]] for h, hn in enumerate(g.hap_names)}
-        sp_reads = [x for x in rcls_df if x["species"] == g.name]                                 # group_reads_by_species (ids are unique here)
+        sp_reads = clustered.get(g.name)                                                          # read_clustered_by_species.get(otu) (:3301-3303)
+        if sp_reads is None:
+            continue
         met, obj1, obj2, extra = ls.optimize_otu(g.name, nodes_len, paths, int(g.range_start) - 1, int(g.range_end) - 1, sp_reads, args)   # start - 1, end - 1 (profile.rs:2886-2887)
         ls.abundace_constraint(species_profile, met)
         per_species[g.name] = dict(metrics=met, obj1=obj1, obj2=obj2, **extra)
@@ -87,7 +99,8 @@ def make_case(seed, S, H, genome_len, n_reads, args, single_every=0, present_fra
                       node_len=[int(v) for v in g.node_len], hap_names=list(g.hap_names),
                       paths={hn: [int(v) for v in g.path_nodes[int(g.path_off[h]):int(g.path_off[h + 1])]] for h, hn in enumerate(g.hap_names)})
                  for g in sset.species],
-        reads=[dict(walk=x["walk"], strand=x["strand"], read_start=x["read_start"], read_end=x["read_end"], read_len=x["read_len"], mapq=x["mapq"]) for x in reads],
+        reads=[dict(read_id=x["read_id"], walk=x["walk"], strand=x["strand"], read_path_len=x["read_path_len"], read_start=x["read_start"], read_end=x["read_end"],
+                    read_len=x["read_len"], mapq=x["mapq"]) for x in reads],
         expect=dict(read_species=[x["species"] for x in reads], species_profile=species_profile, per_species=per_species,
                     final_rows=[dict(species_taxid=m["otu"], hap_id=m["hap_id"], predicted_coverage=m["second_sol"], predicted_abundance=m["predicted_abundance"]) for m in final]))
     return case
@@ -110,8 +123,9 @@ def check_unique(case):
             for v in sp["paths"][haps[i]]:
                 coeff[v, k] = 1.0
         # node abundances again (cheap): the literal coverage of this species' reads
-        reads = [dict(path="".join(("<" if s else ">") + str(v) for v, s in zip(x["walk"], x["strand"])), read_start=x["read_start"], read_end=x["read_end"])
-                 for x, spn in zip(case["reads"], case["expect"]["read_species"]) if spn == sp["name"]]
+        df = [dict(x, path="".join(("<" if s else ">") + str(v) for v, s in zip(x["walk"], x["strand"])), species=spn)
+              for x, spn in zip(case["reads"], case["expect"]["read_species"]) if spn != "U"]
+        reads = ls.group_reads_by_species(df).get(sp["name"], [])
         uniq, ulen, rows = lit.trio_nodes_info(sp["node_len"], sp["paths"])
         ab = lit.get_node_abundances(sp["node_len"], uniq, ulen, sp["range_start"] - 1, reads)[0]
         valid = [v for v, a in enumerate(ab) if a > 0.0]
@@ -133,10 +147,13 @@ def main():
         (range(101, 140), 3, 4, 6000, 2500, dict(base), 0, 0.5, 0),
         (range(201, 240), 4, 5, 5000, 4000, dict(base, shift=True, fr=0.4), 3, 0.6, 0),
         (range(301, 340), 3, 3, 5000, 2500, dict(base, filtered=False, min_depth=2, fc=0.3), 2, 0.7, 17),
+        (range(401, 460), 4, 4, 5000, 4000, dict(base), 0, 0.6, 0, 150, 40),      # duplicate read ids + null read_start rows (a5)
     ]
-    for k, (seeds, S, H, gl, nr, args, single_every, pf, mqn) in enumerate(plans):
+    for k, plan in enumerate(plans):
+        seeds, S, H, gl, nr, args, single_every, pf, mqn = plan[:9]
+        dup_ids, null_start = (plan[9], plan[10]) if len(plan) > 9 else (0, 0)
         for seed in seeds:
-            case = make_case(seed, S, H, gl, nr, args, single_every, pf, mqn)
+            case = make_case(seed, S, H, gl, nr, args, single_every, pf, mqn, dup_ids, null_start)
             n_lp = sum(1 for v in case["expect"]["per_species"].values() if v["obj1"] is not None)
             if n_lp and len(case["expect"]["final_rows"]) >= 2 and check_unique(case):
                 break

@@ -8,6 +8,7 @@ with oracle/pantax_oracle.c.  Fixtures generated from this file (oracle/gen_gold
 tests/golden/literal_strain_*.json) are compared with the C oracle (CPU test) and with the HIP path (GPU test).
 
     process_single_read_simple      rcls.rs:237-258
+    dataframe_to_records_and_check_unique / process_with_duplicates / group_reads_by_species   profile.rs:361-463
     equal_length_read_cls           profile.rs:208-251
     non_equal_length_read_cls       profile.rs:253-297
     species_profiling               profile.rs:299-349
@@ -119,6 +120,46 @@ def species_profiling(rcls_df, species_len, filtered):
     # sort descending, nulls last (polars default for descending sorts puts nulls last)
     prof.sort(key=lambda r: (r["predicted_abundance"] is None, -(r["predicted_abundance"] or 0.0)))
     return prof
+
+
+# ---------------------------------------------------------------------------------------------- profile.rs:361-463
+def dataframe_to_records_and_check_unique(df):
+    """df: rows of the frame without "U" reads (read_id, path, read_path_len, read_start, read_end, species; None = null)"""
+    seen, unique, records = set(), True, []
+    for r in df:                                                      # :373
+        if r["read_id"] in seen:                                      # !seen.insert(read_id) (:375-377): before the null check
+            unique = False
+        seen.add(r["read_id"])
+        if all(r[k] is not None for k in ("path", "read_path_len", "read_start", "read_end", "species")):   # :379-385
+            records.append(dict(read_id=r["read_id"], path=r["path"], read_path_len=r["read_path_len"], read_start=r["read_start"],
+                                read_end=r["read_end"], species=r["species"]))
+    return records, unique
+
+
+def process_with_duplicates(records):
+    grouped = {}                                                      # FxHashMap<String, Vec<Record>> (:407-410)
+    for r in records:
+        grouped.setdefault(r["read_id"], []).append(r)
+    species_map = {}                                                  # BTreeMap (:412)
+    for _read_id, group in grouped.items():
+        species_set = set(r["species"] for r in group)                # :415
+        if len(species_set) == 1:                                     # :416
+            species = group[0]["species"]
+            entry = species_map.setdefault(species, [])
+            for i, r in enumerate(group):
+                rid = r["read_id"] if i == 0 else "%s_%d" % (r["read_id"], i + 1)   # :420-423
+                entry.append(dict(r, read_id=rid))
+    return species_map
+
+
+def group_reads_by_species(df):
+    records, unique = dataframe_to_records_and_check_unique(df)
+    if unique:                                                        # :441
+        m = {}
+        for r in records:
+            m.setdefault(r["species"], []).append(r)
+        return m
+    return process_with_duplicates(records)                           # :461
 
 
 # ---------------------------------------------------------------------------------------------- profile.rs:1028-1051

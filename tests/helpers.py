@@ -249,10 +249,23 @@ def load_literal_strain_case(k):
     step_off = np.zeros(len(rd) + 1, dtype=np.uint64)
     step_off[1:] = np.cumsum([len(r["walk"]) for r in rd])
     reads = synth.PackedReads(step_off, np.array([v for r in rd for v in r["walk"]], dtype=np.uint32),
-                              np.array([s for r in rd for s in r["strand"]], dtype=np.uint8), np.array([r["read_start"] for r in rd], dtype=np.int64),
+                              np.array([s for r in rd for s in r["strand"]], dtype=np.uint8),
+                              np.array([0 if r["read_start"] is None else r["read_start"] for r in rd], dtype=np.int64),   # null read_start: case 3, file seam only
                               np.array([r["read_end"] for r in rd], dtype=np.int64), np.array([r["read_len"] for r in rd], dtype=np.int64),
-                              np.array([255 if r["mapq"] is None else r["mapq"] for r in rd], dtype=np.int64), np.zeros(len(rd), dtype=np.int64))
+                              np.array([255 if r["mapq"] is None else r["mapq"] for r in rd], dtype=np.int64),
+                              np.array([r.get("read_path_len", 0) for r in rd], dtype=np.int64), [r.get("read_id", "S0R%d/1" % i) for i, r in enumerate(rd)])
     return j, synth.SyntheticSet(species, reads)
+
+
+def write_literal_gaf(j, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1"):
+    """the reads of a literal fixture as GAF text: 12 mandatory columns + 4 tags, `*` where the fixture holds a null"""
+    with open(path, "w") as f:
+        for r in j["reads"]:
+            walk = "".join(("<" if s else ">") + str(v) for v, s in zip(r["walk"], r["strand"])) or "*"
+            st = "*" if r["read_start"] is None else str(r["read_start"])
+            mq = "*" if r["mapq"] is None else str(r["mapq"])
+            ql = r["read_len"]
+            f.write("%s\t%d\t0\t%d\t+\t%s\t%d\t%s\t%d\t%d\t%d\t%s\t%s\n" % (r["read_id"], ql, ql, walk, r["read_path_len"], st, r["read_end"], ql, ql, mq, tags))
 
 
 _LIT_FIELDS = [("unique_trio_nodes_fraction", "unique_trio_fraction", 0.0), ("frequencies_mean", "uniq_trio_cov_mean", 1e-9),

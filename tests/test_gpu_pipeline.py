@@ -648,3 +648,41 @@ def test_profile_seam_sharded_failure_reaches_every_rank(world):
     own = [r for r in (0, 1) if "does not exist" in errs[r]]
     assert len(own) == 1 and "another rank failed" in errs[1 - own[0]]
     assert not os.path.exists(wd / "strain_abundance.txt") and os.path.exists(wd / "species_abundance.txt")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_profile_seam_vs_literal_python_restatement(tmp_path, k):
+    """Files in, tables out (pantax_hip_profile) against the fixtures of oracle/ref_literal_strain.py -- the literal Python
+    reading of the reference, LP by SciPy-HiGHS: the DB and the GAF are written from the fixture (`*` where it holds a null),
+    the two tables must hold the literal reading's rows.  Case 3 has duplicate read ids (kept inside one species, dropped
+    across two) and null read_start rows (counted in the species table, dropped at the strain level): profile.rs:361-463."""
+    from pantax_amd import synth
+    from pantax_amd.engine import Engine
+    from tests.helpers import load_literal_strain_case, write_literal_gaf
+    j, sset = load_literal_strain_case(k)
+    a, ex = j["args"], j["expect"]
+    db = tmp_path / "db"
+    db.mkdir()
+    synth.write_db(sset, str(db))
+    gaf = tmp_path / "reads.gaf"
+    write_literal_gaf(j, str(gaf))
+    wd = tmp_path / "wd"
+    wd.mkdir()
+    eng = Engine(0)
+    cwd = os.getcwd()
+    os.chdir(str(wd))
+    try:
+        eng.profile(str(db), str(wd), str(gaf), fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_species_abundance=a["min_species_abundance"],
+                    min_cov=a["min_cov"], min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"], sample_nodes=0)
+    finally:
+        os.chdir(cwd)
+        eng.close()
+    exp_species = [(r["species_taxid"], r["predicted_abundance"], r["predicted_coverage"]) for r in ex["species_profile"]]
+    key = {"path_base_cov": "path_cov_ratio", "unique_trio_fraction": "unique_trio_nodes_fraction", "uniq_trio_cov_mean": "frequencies_mean",
+           "first_sol": "first_sol", "strain_cov_diff": "divergence", "total_cov_diff": "total_cov_diff"}
+    exp_strain = []
+    for e in ex["final_rows"]:
+        m = [m for m in ex["per_species"][e["species_taxid"]]["metrics"] if m["hap_id"] == e["hap_id"]][0]
+        exp_strain.append((e["species_taxid"], e["hap_id"], e["predicted_coverage"], e["predicted_abundance"], {c: m[f] for c, f in key.items()}))
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
