@@ -1,5 +1,7 @@
 // api_io.cpp -- C ABI over the host readers (a1 GAF tokenizer, a6 graph loaders). Host only.
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/pantax_hip.h"
@@ -21,12 +23,16 @@ extern "C" {
 int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, const char **err_out) {
     if (!path || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
-    pantax_hip_gaf *g = new pantax_hip_gaf();
-    std::string e = g->mf.open(path);
-    if (e.empty()) e = parse_gaf(g->mf, g->reads, n_threads);
-    if (!e.empty()) { delete g; return io_fail(err_out, e); }
-    *out = g;
-    return 0;
+    try {   // nothing throws across the boundary (allocation failures of a large file included)
+        std::unique_ptr<pantax_hip_gaf> g(new pantax_hip_gaf());
+        std::string e = g->mf.open(path);
+        if (e.empty()) e = parse_gaf(g->mf, g->reads, n_threads);
+        if (!e.empty()) return io_fail(err_out, e);
+        *out = g.release();
+        return 0;
+    } catch (const std::exception &ex) {
+        return io_fail(err_out, std::string("gaf_load: ") + ex.what());
+    }
 }
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *v) {
     if (!gaf || !v) return PANTAX_HIP_E_INVALID;
@@ -43,12 +49,16 @@ void pantax_hip_gaf_free(pantax_hip_gaf *gaf) { delete gaf; }
 int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, const char **err_out) {
     if (!path || !out) return PANTAX_HIP_E_INVALID;
     *out = nullptr;
-    pantax_hip_graph *g = new pantax_hip_graph();
-    std::string e = format == 1 ? read_graph_bin(path, g->g) : (format == 2 || format == 3) ? read_graph_zip(path, format, g->g) : read_gfa(path, g->g);
-    if (!e.empty()) { delete g; return io_fail(err_out, e); }
-    for (auto &n : g->g.hap_names) g->names.push_back(n.c_str());
-    *out = g;
-    return 0;
+    try {
+        std::unique_ptr<pantax_hip_graph> g(new pantax_hip_graph());
+        std::string e = format == 1 ? read_graph_bin(path, g->g) : (format == 2 || format == 3) ? read_graph_zip(path, format, g->g) : read_gfa(path, g->g);
+        if (!e.empty()) return io_fail(err_out, e);
+        for (auto &n : g->g.hap_names) g->names.push_back(n.c_str());
+        *out = g.release();
+        return 0;
+    } catch (const std::exception &ex) {
+        return io_fail(err_out, std::string("graph_load: ") + ex.what());
+    }
 }
 int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t *n_haps, const int64_t **node_len,
                           const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names) {

@@ -1,4 +1,5 @@
 // ctx.cpp -- context lifetime, error strings, HIP-event kernel timing (include/pantax_hip.h).
+#include <exception>
 #include <cstdarg>
 #include <algorithm>
 #include <cstring>
@@ -330,10 +331,17 @@ void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, 
     if (n_threads < 1) n_threads = 1;
     if ((uint64_t)n_threads > n) n_threads = n ? (int)n : 1;
     if (n_threads == 1) { fn(0, n); return; }
+    // an exception on a worker thread would end the process (std::terminate): it is carried to the calling thread instead,
+    // where the extern "C" entry points turn it into a status
     std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back([&, t] { fn(n * t / n_threads, n * (t + 1) / n_threads); });
-    fn(0, n / n_threads);
+    std::vector<std::exception_ptr> err(n_threads);
+    for (int t = 1; t < n_threads; ++t)
+        th.emplace_back([&, t] {
+            try { fn(n * t / n_threads, n * (t + 1) / n_threads); } catch (...) { err[t] = std::current_exception(); }
+        });
+    try { fn(0, n / n_threads); } catch (...) { err[0] = std::current_exception(); }
     for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
 }  // namespace ptx
