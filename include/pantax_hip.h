@@ -366,7 +366,7 @@ int pantax_hip_format_f64(double v, char *buf, size_t cap);
 /* ---- measurement: HIP-event timings of kernels launched on the ctx stream ---------------- */
 int pantax_hip_timing_enable(pantax_hip_ctx *ctx, int on);
 int pantax_hip_timing_reset(pantax_hip_ctx *ctx);
-/* name != NULL/"": bracket only launches of that kernel (the event pairs of ~100 launches per step cost
+/* name != NULL/"": bracket only launches of that kernel, or of several ("a|b") (the event pairs of ~100 launches per step cost
  * ~0.15 ms; a throughput measurement that also wants one kernel's duration times just that one) */
 int pantax_hip_timing_filter(pantax_hip_ctx *ctx, const char *name);
 /* fills up to cap entries; returns the number of distinct kernel names (or <0) */

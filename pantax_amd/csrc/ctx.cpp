@@ -32,7 +32,17 @@ int fail(Ctx *ctx, int code, const char *fmt, ...) {
 
 KTimer::KTimer(Ctx *c, const char *nm) : ctx(c), name(nm) {
     if (!ctx->timing) return;
-    if (!ctx->timing_filter.empty() && ctx->timing_filter != nm) return;   // only the named launch is bracketed
+    if (!ctx->timing_filter.empty()) {   // only the named launches are bracketed ("a" or "a|b|c")
+        const std::string &f = ctx->timing_filter;
+        const size_t len = std::strlen(nm);
+        bool hit = false;
+        for (size_t pos = 0; pos <= f.size() && !hit;) {
+            const size_t bar = std::min(f.find('|', pos), f.size());
+            hit = bar - pos == len && f.compare(pos, len, nm) == 0;
+            pos = bar + 1;
+        }
+        if (!hit) return;
+    }
     if (!ctx->free_events.empty()) {
         start = ctx->free_events.back().first;
         stop = ctx->free_events.back().second;
