@@ -73,10 +73,13 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     const int rk = W > 1 ? cfg->rank : 0;
     if (W > 1 && (!cfg->allreduce_sum || rk < 0 || rk >= W))
         return fail(ctx, PANTAX_HIP_E_INVALID, "profile: world_size %d needs 0 <= rank < world_size and an allreduce_sum callback", W);
-    const bool sharded = W > 1 && cfg->alltoallv != nullptr;
+    // a one-rank world that is given the callbacks still goes through them (like an MPI program started on one rank): the
+    // whole multi-rank protocol, sharded ingest included, can be exercised on a single GPU
+    const bool use_comm = W > 1 || (cfg->world_size == 1 && cfg->allreduce_sum != nullptr);
+    const bool sharded = use_comm && cfg->alltoallv != nullptr;
     if (sharded && W > 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: the sharded ingest routes reads to at most 64 ranks (world_size %d)", W);
     auto allreduce = [&](double *buf, uint64_t n) -> int {
-        if (W == 1) return 0;
+        if (!use_comm) return 0;
         const int rc = cfg->allreduce_sum(cfg->comm_user, buf, n);
         return rc == 0 ? 0 : fail(ctx, PANTAX_HIP_E_STATE, "profile: the caller's allreduce_sum returned %d", rc);
     };
@@ -84,7 +87,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     // left waiting in an exchange); the failing rank reports its own error, the others E_STATE
     auto others_failed = [&]() { return fail(ctx, PANTAX_HIP_E_STATE, "profile: another rank failed; this rank stopped with it"); };
     auto agree = [&](int local_rc) -> int {
-        if (W == 1) return local_rc;
+        if (!use_comm) return local_rc;
         double f = local_rc != 0 ? 1.0 : 0.0;
         PTX_TRY(allreduce(&f, 1));
         if (f != 0.0) return local_rc ? local_rc : others_failed();
@@ -105,7 +108,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     bool full_path = cfg->species && !species_exists;
     bool strain_only = !full_path && cfg->strain && !strain_exists;
     bool strain_done = strain_exists;
-    if (W > 1) {   // rank 0 looked at the work directory before anybody wrote to it: every rank follows its decision
+    if (use_comm) {   // rank 0 looked at the work directory before anybody wrote to it: every rank follows its decision
         double d[3] = {rk == 0 && full_path ? 1.0 : 0.0, rk == 0 && strain_only ? 1.0 : 0.0, rk == 0 && strain_done ? 1.0 : 0.0};
         PTX_TRY(allreduce(d, 3));
         full_path = d[0] != 0.0; strain_only = d[1] != 0.0; strain_done = d[2] != 0.0;
@@ -713,7 +716,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             }
         }
     }
-    if (W > 1) {   // rows of the other ranks reach rank 0 through part files in the work directory (one node, one file system)
+    if (use_comm) {   // rows of the other ranks reach rank 0 through part files in the work directory (one node, one file system)
         auto part_name = [&](const char *what, int r) { return strain_file + "." + what + ".part" + std::to_string(r); };
         auto write_part = [&](const std::string &path, const std::vector<OutRow> &rows) {
             FILE *f = std::fopen(path.c_str(), "wb");

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include "../../../include/pantax_hip.h"
+#include "rccl_comm.hpp"
 
 static void usage() {
     fprintf(stderr,
@@ -17,7 +18,10 @@ static void usage() {
             "  --image-cache 0|1|2  device-ready graph images <db>/species_graph_info/<otu>.hipdb: 1 = use, 2 = use and write\n"
             "  --filter-gaf  first replace the GAF by its best alignment per read (long reads; alignment.rs:171-175, gaf_filter.rs)\n"
             "  --filter-only <in.gaf> [<out.gaf>]   just write <stem>_filtered.gaf (or <out.gaf>) and exit\n"
-            "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n");
+            "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n"
+            "  --ranks N --rank r   one process per GPU (start N of them; device = r unless --device): every rank tokenises 1/N of the\n"
+            "                       GAF, reads travel to the owner of their species over RCCL, rank 0 writes the tables\n"
+            "                       (defaults from WORLD_SIZE / RANK / LOCAL_RANK when set); --comm-id-file F (default <wd>/.pantax_hip_rccl_id)\n");
 }
 
 int main(int argc, char **argv) {
@@ -29,7 +33,11 @@ int main(int argc, char **argv) {
     c.zip = "serialize"; c.world_size = 1;
     bool long_read = false, filter_gaf = false;
     const char *filter_in = nullptr, *filter_out = nullptr;
-    int device = 0;
+    int device = -1, ranks = 0, rank = -1;
+    std::string id_file;
+    if (const char *ev = getenv("WORLD_SIZE")) ranks = atoi(ev);
+    if (const char *ev = getenv("RANK")) rank = atoi(ev);
+    if (const char *ev = getenv("LOCAL_RANK")) device = atoi(ev);
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -64,8 +72,14 @@ int main(int argc, char **argv) {
         else if (a == "--image-cache") c.image_cache = atoi(next());
         else if (a == "--filter-only") { filter_in = next(); if (i + 1 < argc && argv[i + 1][0] != '-') filter_out = argv[++i]; }
         else if (a == "--device") device = atoi(next());
+        else if (a == "--ranks") ranks = atoi(next());
+        else if (a == "--rank") rank = atoi(next());
+        else if (a == "--comm-id-file") id_file = next();
         else { usage(); return 2; }
     }
+    const bool use_rccl = ranks >= 1 && rank >= 0;   // also a one-rank world goes through the communicator when asked for
+    if (use_rccl && rank >= ranks) { fprintf(stderr, "pantax-hip: --rank %d of --ranks %d\n", rank, ranks); return 2; }
+    if (device < 0) device = use_rccl ? rank : 0;
     if (filter_in) {
         pantax_hip_ctx *fctx = nullptr;
         if (pantax_hip_init(&fctx, &device, 1) != 0) { fprintf(stderr, "pantax-hip: %s\n", pantax_hip_last_error(nullptr)); return 1; }
@@ -89,8 +103,16 @@ int main(int argc, char **argv) {
         if (rc == 0 && rename(filtered.c_str(), c.input_aln_file) != 0) { fprintf(stderr, "pantax-hip: cannot replace %s\n", c.input_aln_file); rc = 1; }
         if (rc != 0) { if (rc != 1) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx)); pantax_hip_destroy(ctx); return 1; }
     }
+    RcclComm comm;
+    if (use_rccl) {
+        if (id_file.empty()) id_file = wd + "/.pantax_hip_rccl_id";
+        if (!comm.init(rank, ranks, id_file)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
+        c.rank = rank; c.world_size = ranks; c.comm_user = &comm;
+        c.allreduce_sum = &RcclComm::allreduce_sum; c.alltoallv = &RcclComm::alltoallv; c.comm_device_buffers = 1;
+    }
     rc = pantax_hip_profile(ctx, &c);
-    if (rc != 0) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx));
+    if (rc != 0) fprintf(stderr, "pantax-hip: %serror %d: %s\n", use_rccl ? ("rank " + std::to_string(rank) + ": ").c_str() : "", rc, pantax_hip_last_error(ctx));
+    if (use_rccl) comm.destroy(id_file);
     pantax_hip_destroy(ctx);
     return rc == 0 ? 0 : 1;
 }

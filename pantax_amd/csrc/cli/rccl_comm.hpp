@@ -1,0 +1,99 @@
+// rccl_comm.hpp -- the two collectives pantax_hip_profile asks its host for, over RCCL (one process per GPU, xGMI between
+// them).  Used by the pantax-hip CLI with --ranks N --rank r; a Rust host would do the same through the rccl crate or FFI
+// (INTEGRATION.md section 3b'').
+//
+// Bootstrap without MPI: rank 0 creates the ncclUniqueId and publishes it through a file in the work directory (written
+// under a temporary name, then renamed); the other ranks wait for a file that is not older than their own start.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+struct RcclComm {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    double *d_buf = nullptr;
+    size_t d_cap = 0;
+    int rank = 0, world = 1;
+    std::string err;
+
+    bool fail(const std::string &what) { err = what; return false; }
+
+    bool init(int rank_, int world_, const std::string &id_file, double timeout_s = 300.0) {
+        rank = rank_; world = world_;
+        const auto t_start = std::chrono::system_clock::now();
+        ncclUniqueId id;
+        if (rank == 0) {
+            ::unlink(id_file.c_str());   // a file left behind by an earlier run
+            if (ncclGetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+            const std::string tmp = id_file + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { if (f) std::fclose(f); return fail("cannot write " + tmp); }
+            std::fclose(f);
+            if (std::rename(tmp.c_str(), id_file.c_str()) != 0) return fail("cannot publish " + id_file);
+        } else {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+            for (;;) {
+                struct stat st;
+                if (::stat(id_file.c_str(), &st) == 0 && (size_t)st.st_size == sizeof(id)) {
+                    const auto mt = std::chrono::system_clock::from_time_t(st.st_mtime);
+                    if (mt + std::chrono::seconds(2) >= t_start) {   // not a leftover of an earlier run
+                        FILE *f = std::fopen(id_file.c_str(), "rb");
+                        const bool ok = f && std::fread(&id, sizeof(id), 1, f) == 1;
+                        if (f) std::fclose(f);
+                        if (ok) break;
+                    }
+                }
+                if (std::chrono::steady_clock::now() > deadline) return fail("rank 0 did not publish " + id_file + " in time");
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+        if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) return fail("ncclCommInitRank failed");
+        return true;
+    }
+    void destroy(const std::string &id_file) {
+        if (comm) (void)ncclCommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (d_buf) (void)hipFree(d_buf);
+        if (rank == 0) ::unlink(id_file.c_str());
+        comm = nullptr; stream = nullptr; d_buf = nullptr;
+    }
+
+    // int (*allreduce_sum)(void *user, double *buf, uint64_t n): host buffer, summed in place over the ranks
+    static int allreduce_sum(void *user, double *buf, uint64_t n) {
+        RcclComm *c = static_cast<RcclComm *>(user);
+        if (n == 0) return 0;
+        if (n > c->d_cap) {
+            if (c->d_buf) (void)hipFree(c->d_buf);
+            c->d_buf = nullptr; c->d_cap = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&c->d_buf), n * sizeof(double)) != hipSuccess) return 1;
+            c->d_cap = n;
+        }
+        if (hipMemcpyAsync(c->d_buf, buf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return 2;
+        if (ncclAllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return 3;
+        if (hipMemcpyAsync(buf, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 4;
+        return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 5;
+    }
+    // int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off):
+    // DEVICE buffers (comm_device_buffers = 1), byte offsets [world + 1]
+    static int alltoallv(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off) {
+        RcclComm *c = static_cast<RcclComm *>(user);
+        const char *s = static_cast<const char *>(send);
+        char *r = static_cast<char *>(recv);
+        if (ncclGroupStart() != ncclSuccess) return 1;
+        for (int peer = 0; peer < c->world; ++peer) {
+            const uint64_t ns = send_off[peer + 1] - send_off[peer], nr = recv_off[peer + 1] - recv_off[peer];
+            if (ns && ncclSend(s + send_off[peer], ns, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) return 2;
+            if (nr && ncclRecv(r + recv_off[peer], nr, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) return 3;
+        }
+        if (ncclGroupEnd() != ncclSuccess) return 4;
+        return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 5;
+    }
+};

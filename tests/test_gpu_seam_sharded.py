@@ -225,3 +225,57 @@ def test_sharded_ingest_with_slices_cut_into_pieces_and_long_walks(tmp_path_fact
     for ra, rb in zip(a[1:], b[1:]):
         for x, y in zip(ra[3:], rb[3:]):
             assert (x == "" and y == "") or float(x) == pytest.approx(float(y), rel=1e-9, abs=1e-12)
+
+
+def test_one_rank_world_goes_through_the_callbacks(world):
+    """world_size 1 WITH the callbacks (an MPI-style program started on one rank): the whole multi-rank protocol -- byte range,
+    counter all-reduce, id-record exchange, read routing (everything to itself), part files -- runs, and gives the files of
+    the plain one-process call."""
+    sset, root, db, gaf, eng0 = world
+    exp_species, exp_strain, _ = _oracle_tables(sset)
+    one = root / "wd_one_plain"
+    one.mkdir()
+    cwd = os.getcwd()
+    os.chdir(str(one))
+    try:
+        eng0.profile(str(db), str(one), str(gaf), out_binning_file=str(one / "reads_classification.tsv"))
+    finally:
+        os.chdir(cwd)
+    wd = root / "wd_one_rank_comm"
+    wd.mkdir()
+
+    def call(eng, rank, comm):
+        eng.profile(str(db), str(wd), str(gaf), rank=0, world_size=1, allreduce=comm.allreduce(0), alltoallv=comm.alltoallv(0),
+                    out_binning_file=str(wd / "reads_classification.tsv"))
+    errs, comm = _run_ranks(1, wd, call)
+    assert not errs, errs
+    assert comm.calls["alltoallv"] == 2 and comm.calls["allreduce"] >= 4
+    _check_outputs(str(wd), sset, exp_species, exp_strain)
+    for f in ("species_abundance.txt", "strain_abundance.txt", "reads_classification.tsv"):
+        assert open(wd / f, "rb").read() == open(one / f, "rb").read(), f      # one rank: also the sums are the same bits
+
+
+def test_cli_over_rccl_with_one_rank(world):
+    """pantax-hip --ranks 1 --rank 0: the CLI's RCCL communicator (unique id through a file in the work directory,
+    ncclAllReduce for the sums, grouped ncclSend / ncclRecv on device buffers for the all-to-all(v)) carries the sharded
+    protocol; one rank is what a one-GPU box can run -- the N-rank protocol itself is covered by the thread-rank tests above."""
+    import subprocess
+    from tests.conftest import ROOT
+    sset, root, db, gaf, eng0 = world
+    exe = os.path.join(ROOT, "pantax_amd", "lib", "pantax-hip")
+    ref = root / "wd_cli_plain"
+    ref.mkdir()
+    wd = root / "wd_cli_rccl"
+    wd.mkdir()
+    base = [exe, "-db", str(db), "--gaf", str(gaf), "--species", "--strain", "--short-read", "--sample", "0"]
+    r0 = subprocess.run(base + ["-T", str(ref)], cwd=str(ref), capture_output=True, text=True, timeout=300)
+    assert r0.returncode == 0, r0.stderr
+    env = dict(os.environ, PANTAX_HIP_TRACE="1")
+    r1 = subprocess.run(base + ["-T", str(wd), "--ranks", "1", "--rank", "0"], cwd=str(wd), capture_output=True, text=True, timeout=300, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    assert "route reads to owners" in r1.stderr            # the sharded path ran (phase trace)
+    for f in ("species_abundance.txt", "strain_abundance.txt"):
+        assert open(wd / f).read() == open(ref / f).read(), f
+    assert not os.path.exists(wd / ".pantax_hip_rccl_id") and not [f for f in os.listdir(wd) if ".part" in f]
+    r2 = subprocess.run(base + ["-T", str(wd), "--ranks", "2", "--rank", "5"], capture_output=True, text=True, timeout=60)
+    assert r2.returncode != 0
