@@ -410,13 +410,18 @@ __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint3
         if ((threadIdx.x & 63) == 0) atomicAdd(n_long, mine);
     }
 }
-__global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, const uint32_t *__restrict__ base_r /*[NB+1]*/,
+// One thread lays out a UNIT of 2^g consecutive buckets; only units are rounded up to 64 steps.  (Rounding every 32-node
+// bucket cost 32 pad steps per bucket on average: with ten reads per bucket -- 1e7 reads over 3.2e7 nodes -- the padded
+// stream was 1.45 x the walk steps, and the coverage kernel spends a lane on every pad.)
+__global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, const uint32_t *__restrict__ base_r /*[NB+1]*/,
                                                            const uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_rel,
                                                            uint32_t *__restrict__ size_s) {
     const uint32_t key = blockIdx.x * 256 + threadIdx.x;
-    if (key >= NB) return;
+    const uint32_t NU = (NB + (1u << g) - 1) >> g;
+    if (key >= NU) return;
+    const uint32_t k0 = key << g, k1 = min(NB, (key + 1) << g);
     uint32_t pos = 0;
-    for (uint32_t s = base_r[key], e = base_r[key + 1]; s < e; ++s) {
+    for (uint32_t s = base_r[k0], e = base_r[k1]; s < e; ++s) {
         const uint32_t k = slot_len[s];
         if (k <= 64 && (pos & 63) + k > 64) pos = (pos + 63) & ~63u;
         slot_rel[s] = pos;
@@ -522,8 +527,13 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_r, cnt_r,
                        rd->d_slot_of.p, slot_len.p, d_n_long);
-    hipLaunchKernelGGL(group_layout_kernel, dim3((NB + 255) / 256), dim3(256), 0, ctx->stream, NB, base_r, slot_len.p, slot_rel.p, size_s);
-    PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NB, scan_tmp.p, d_total));
+    // layout units: 2^g buckets each, about 2048 walk steps per unit (the rounding of a unit to 64 steps then costs ~1.5 %)
+    int g = 0;
+    while (g < 12 && ((double)rd->T / (double)NB) * (double)(1u << g) < 2048.0) ++g;
+    const uint32_t NU = (NB + (1u << g) - 1) >> g;
+    hipLaunchKernelGGL(group_layout_kernel, dim3((NU + 255) / 256), dim3(256), 0, ctx->stream, NB, g, base_r, slot_len.p, slot_rel.p, size_s);
+    PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NU, scan_tmp.p, d_total));
+    const int ushift = shift + g;   // unit of a read = its first node id >> ushift
     uint32_t h_tot[2] = {0, 0};
     PTX_TRY(download(ctx, h_tot, d_total, 2));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -536,10 +546,10 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0, rd->T_pad, ctx->stream));                             // pad steps carry no code
     hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
-                       rd->d_pend.p, shift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
+                       rd->d_pend.p, ushift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
     if (rd->n_long) {
         const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
-        hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_s,
+        hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, ushift, base_s,
                            rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
         PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R));
         PTX_HIP(ctx, rd->d_long_len0.alloc(rd->R));
