@@ -615,7 +615,9 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     if (rd->R && rd->T_pad) {
         // U groups of 64 steps in flight per wave, PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another
         // instantiation, for measurements)
-        int shape = 14;
+        // 8 rounds per workgroup once the stream is long enough to keep every CU busy with 2048-step workgroups (the LDS
+        // windows are zeroed and flushed half as often: 1.10 -> 1.04 ms at 8e7 steps), 4 below (0.094 vs 0.100 ms at 8e6)
+        int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
         if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
         KTimer t(ctx, "coverage_step_kernel");
 #define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
@@ -631,6 +633,8 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             case 21: COVS_LAUNCH(2, 1) break;
             case 41: COVS_LAUNCH(4, 1) break;
             case 42: COVS_LAUNCH(4, 2) break;
+            case 18: COVS_LAUNCH(1, 8) break;
+            case 14: COVS_LAUNCH(1, 4) break;
             default: COVS_LAUNCH(1, 4) break;
         }
 #undef COVS_LAUNCH

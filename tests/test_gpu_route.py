@@ -174,5 +174,5 @@ dist.destroy_process_group()
 print("rccl route ok")
 ''' % ROOT
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "rccl route ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
