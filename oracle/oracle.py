@@ -158,15 +158,24 @@ def hap_trio_stats(trio, n_paths, trio_bases):
 def path_masks(graph, cand, node_base_cov):
     cand = np.ascontiguousarray(cand, dtype=np.uint32)
     cov = np.ascontiguousarray(node_base_cov, dtype=np.uint64)
-    mask = np.zeros(graph.n_nodes, dtype=np.uint64)
+    nw = max(1, (len(cand) + 63) // 64)     # one word per node up to 64 candidates, else an (n_nodes, nw) array
+    mask = np.zeros(graph.n_nodes if nw == 1 else (graph.n_nodes, nw), dtype=np.uint64)
     ratio = np.zeros(len(cand), dtype=np.float32)
     rc = lib().orc_path_masks(C.byref(graph.c), C.c_uint32(len(cand)), _p(cand), _p(cov), _p(mask), _p(ratio))
     assert rc == 0
     return mask, ratio
 
 
-def lad_solve(mask, abund, n_cand, ub):
+def _mask_words(mask, n_cand):
+    """(n,) uint64 for up to 64 columns, (n, ceil(n_cand / 64)) beyond."""
     mask = np.ascontiguousarray(mask, dtype=np.uint64)
+    nw = max(1, (n_cand + 63) // 64)
+    assert mask.shape == ((len(mask),) if nw == 1 and mask.ndim == 1 else (len(mask), nw)), (mask.shape, n_cand)
+    return mask
+
+
+def lad_solve(mask, abund, n_cand, ub):
+    mask = _mask_words(mask, n_cand)
     abund = np.ascontiguousarray(abund, dtype=np.float64)
     ub = np.ascontiguousarray(ub, dtype=np.float64)
     x = np.zeros(n_cand)
@@ -179,7 +188,7 @@ def lad_solve(mask, abund, n_cand, ub):
 
 
 def lad_objective(mask, abund, x):
-    mask = np.ascontiguousarray(mask, dtype=np.uint64)
+    mask = _mask_words(mask, len(x))
     abund = np.ascontiguousarray(abund, dtype=np.float64)
     x = np.ascontiguousarray(x, dtype=np.float64)
     lib().orc_lad_objective.restype = C.c_double

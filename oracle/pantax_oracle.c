@@ -4,6 +4,7 @@
  * reference lines it follows (paths relative to /root/reference/pantax/src).
  * "parity unpinned" by the reference's own tests; pinned by tests/golden/.
  */
+#define _GNU_SOURCE /* qsort_r */
 #include "pantax_oracle.h"
 #include <math.h>
 #include <stdlib.h>
@@ -315,17 +316,18 @@ int orc_hap_trio_stats(const orc_trio_table *t, uint32_t n_paths, const int64_t 
 /* ------------------------------------------------------------------ */
 int orc_path_masks(const orc_graph *g, uint32_t n_cand, const uint32_t *cand,
                    const uint64_t *node_base_cov, uint64_t *mask_out, float *ratio_out) {
-    if (n_cand > 64) return -1;
-    memset(mask_out, 0, (size_t)g->n_nodes * sizeof(uint64_t));
+    /* row v of the 0/1 matrix = ORC_NW(n_cand) words at mask_out + v * nw (one word up to 64 columns) */
+    const uint32_t nw = ORC_NW(n_cand);
+    memset(mask_out, 0, (size_t)g->n_nodes * nw * sizeof(uint64_t));
     for (uint32_t k = 0; k < n_cand; ++k) {
         uint32_t h = cand[k];
         for (uint64_t q = g->path_off[h]; q < g->path_off[h + 1]; ++q)
-            mask_out[g->path_nodes[q]] |= (1ull << k); /* coeff_matrix[(v,pos)] = 1.0 */
+            mask_out[(size_t)g->path_nodes[q] * nw + (k >> 6)] |= (1ull << (k & 63)); /* coeff_matrix[(v,pos)] = 1.0 */
     }
     for (uint32_t k = 0; k < n_cand; ++k) {
         float cov = 0.0f, len = 0.0f; /* f32 accumulation, profile.rs:1344-1357 */
         for (uint32_t v = 0; v < g->n_nodes; ++v)
-            if (mask_out[v] >> k & 1ull) { cov += (float)node_base_cov[v]; len += (float)g->node_len[v]; }
+            if (mask_out[(size_t)v * nw + (k >> 6)] >> (k & 63) & 1ull) { cov += (float)node_base_cov[v]; len += (float)g->node_len[v]; }
         ratio_out[k] = cov / len;
     }
     return 0;
@@ -334,12 +336,18 @@ int orc_path_masks(const orc_graph *g, uint32_t n_cand, const uint32_t *cand,
 /* ------------------------------------------------------------------ */
 /* a12: the PAO LP as an exact LAD active-set descent                   */
 /* ------------------------------------------------------------------ */
-typedef struct { uint64_t mask; double a; } lrow;
-static int cmp_lrow(const void *x, const void *y) {
+typedef struct { const uint64_t *m; double a; } lrow; /* m: the node's mask words */
+static int cmp_mask(const uint64_t *p, const uint64_t *q, uint32_t nw) {
+    for (uint32_t w = nw; w-- > 0;) if (p[w] != q[w]) return p[w] < q[w] ? -1 : 1;
+    return 0;
+}
+static int cmp_lrow(const void *x, const void *y, void *nwp) {
     const lrow *p = (const lrow *)x, *q = (const lrow *)y;
-    if (p->mask != q->mask) return p->mask < q->mask ? -1 : 1;
+    int c = cmp_mask(p->m, q->m, *(const uint32_t *)nwp);
+    if (c) return c;
     return p->a < q->a ? -1 : (p->a > q->a);
 }
+static int mask_any(const uint64_t *m, uint32_t nw) { for (uint32_t w = 0; w < nw; ++w) if (m[w]) return 1; return 0; }
 static uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -388,18 +396,19 @@ static uint64_t upper_bound_a(const lrow *r, uint64_t lo, uint64_t hi, double v)
     while (lo < hi) { uint64_t m = (lo + hi) / 2; if (r[m].a <= v) lo = m + 1; else hi = m; }
     return lo;
 }
-static double mdot(uint64_t mask, const double *x, int p) {
+static double mdot(const uint64_t *mask, const double *x, int p) {
     double s = 0.0;
-    for (int j = 0; j < p; ++j) if (mask >> j & 1ull) s += x[j];
+    for (int j = 0; j < p; ++j) if (mask[j >> 6] >> (j & 63) & 1ull) s += x[j];
     return s;
 }
 
 double orc_lad_objective(uint64_t n_nodes, const uint64_t *mask, const double *abund, uint32_t n_cand,
                          const double *x) {
     double s = 0.0; uint64_t n = 0;
+    const uint32_t nw = ORC_NW(n_cand);
     for (uint64_t v = 0; v < n_nodes; ++v) {
         if (!(abund[v] > 0.0)) continue; /* profile.rs:1380-1385 */
-        s += fabs(mdot(mask[v], x, (int)n_cand) - abund[v]);
+        s += fabs(mdot(mask + v * nw, x, (int)n_cand) - abund[v]);
         ++n;
     }
     return n ? s / (double)n : 0.0; /* profile.rs:1450 */
@@ -408,27 +417,30 @@ double orc_lad_objective(uint64_t n_nodes, const uint64_t *mask, const double *a
 int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, uint32_t n_cand,
                   const double *ub, double *x_out, double *obj_out, int32_t *iters_out, int32_t *status_out) {
     int p = (int)n_cand;
-    if (p > 64) return -1;
+    uint32_t nw = ORC_NW(n_cand);
     uint64_t n = 0; double amax = 0.0;
-    for (uint64_t v = 0; v < n_nodes; ++v) if (abund[v] > 0.0) { if (mask[v]) ++n; if (abund[v] > amax) amax = abund[v]; }
+    for (uint64_t v = 0; v < n_nodes; ++v) if (abund[v] > 0.0) { if (mask_any(mask + v * nw, nw)) ++n; if (abund[v] > amax) amax = abund[v]; }
     lrow *rows = (lrow *)malloc((n ? n : 1) * sizeof(lrow));
     uint64_t m = 0;
-    for (uint64_t v = 0; v < n_nodes; ++v) if (abund[v] > 0.0 && mask[v]) { rows[m].mask = mask[v]; rows[m].a = abund[v]; ++m; }
-    qsort(rows, n, sizeof(lrow), cmp_lrow);
+    for (uint64_t v = 0; v < n_nodes; ++v) if (abund[v] > 0.0 && mask_any(mask + v * nw, nw)) { rows[m].m = mask + v * nw; rows[m].a = abund[v]; ++m; }
+    qsort_r(rows, n, sizeof(lrow), cmp_lrow, &nw);
     /* patterns = runs of equal mask */
     uint32_t K = 0;
-    for (uint64_t i = 0; i < n; ++i) if (i == 0 || rows[i].mask != rows[i - 1].mask) ++K;
+    for (uint64_t i = 0; i < n; ++i) if (i == 0 || cmp_mask(rows[i].m, rows[i - 1].m, nw)) ++K;
     uint64_t *pst = (uint64_t *)malloc((K + 1) * sizeof(uint64_t));
     double *peps = (double *)malloc((K ? K : 1) * sizeof(double));
     int *pact = (int *)malloc((K ? K : 1) * sizeof(int));
     K = 0;
-    for (uint64_t i = 0; i < n; ++i) if (i == 0 || rows[i].mask != rows[i - 1].mask) pst[K++] = i;
+    for (uint64_t i = 0; i < n; ++i) if (i == 0 || cmp_mask(rows[i].m, rows[i - 1].m, nw)) pst[K++] = i;
     pst[K] = n;
     /* symbolic-perturbation substitute: shift every pattern's breakpoints by a distinct
      * tiny eps so that no two patterns tie at a vertex; removed again in the final x. */
     double delta = 1e-10 * (amax > 1.0 ? amax : 1.0);
-    for (uint32_t k = 0; k < K; ++k)
-        peps[k] = delta * (0.25 + 0.5 * (double)(splitmix64(rows[pst[k]].mask) >> 11) * (1.0 / 9007199254740992.0));
+    for (uint32_t k = 0; k < K; ++k) {
+        uint64_t hk = rows[pst[k]].m[0];
+        for (uint32_t w = 1; w < nw; ++w) hk = splitmix64(hk) ^ rows[pst[k]].m[w];
+        peps[k] = delta * (0.25 + 0.5 * (double)(splitmix64(hk) >> 11) * (1.0 / 9007199254740992.0));
+    }
 
     lcon *act = (lcon *)malloc((size_t)(p ? p : 1) * sizeof(lcon));
     double *N = (double *)calloc((size_t)(p ? p * p : 1), sizeof(double));
@@ -464,7 +476,7 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
         for (int j = 0; j < p; ++j) gvec[j] = 0.0;
         for (uint32_t k = 0; k < K; ++k) {
             uint64_t st = pst[k], en = pst[k + 1];
-            uint64_t mk = rows[st].mask;
+            const uint64_t *mk = rows[st].m;
             double sigma;
             if (pact[k] >= 0) {
                 plo[k] = act[pact[k]].i0; pup[k] = act[pact[k]].i1;
@@ -475,7 +487,7 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
                 pup[k] = upper_bound_a(rows, plo[k], en, sv);
             }
             sigma = (double)(plo[k] - st) - (double)(en - pup[k]);
-            for (int j = 0; j < p; ++j) if (mk >> j & 1ull) gvec[j] += sigma;
+            for (int j = 0; j < p; ++j) if (mk[j >> 6] >> (j & 63) & 1ull) gvec[j] += sigma;
         }
         /* multipliers: lam_i = -g . w_i, w_i = column i of W */
         int best = -1, bdir = 0; double bscore = -tol, bderiv = 0.0;
@@ -505,7 +517,7 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
         uint64_t nb = 0;
         for (uint32_t k = 0; k < K; ++k) {
             uint64_t st = pst[k], en = pst[k + 1];
-            uint64_t mk = rows[st].mask;
+            const uint64_t *mk = rows[st].m;
             double rho; double s0;
             if (pact[k] >= 0) {
                 if (pact[k] != best) continue; /* stays tight: n_i . d = 0 */
@@ -548,7 +560,7 @@ int orc_lad_solve(uint64_t n_nodes, const uint64_t *mask, const double *abund, u
         }
         act[best] = ent;
         for (int j = 0; j < p; ++j) N[best * p + j] = 0.0;
-        if (ent.type == C_PAT) { uint64_t mk = rows[pst[ent.k]].mask; for (int j = 0; j < p; ++j) if (mk >> j & 1ull) N[best * p + j] = 1.0; }
+        if (ent.type == C_PAT) { const uint64_t *mk = rows[pst[ent.k]].m; for (int j = 0; j < p; ++j) if (mk[j >> 6] >> (j & 63) & 1ull) N[best * p + j] = 1.0; }
         else N[best * p + ent.j] = 1.0;
         if (invert(N, W, p) != 0) { status = 3; break; }
     }
@@ -696,7 +708,8 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
     memset(met, 0, H * sizeof(orc_hap_metrics));
     uint32_t *cand = (uint32_t *)malloc((H ? H : 1) * sizeof(uint32_t));
     uint32_t nc = 0;
-    int same_path = 0, second_opt = 0;
+    int same_path = 0, second_opt = 0, rc = 0;
+    uint64_t *mask = NULL; float *ratio = NULL; double *ub = NULL, *x1 = NULL, *x2 = NULL; uint8_t *keep = NULL;
     uint64_t U = trio->n_unique;
     if (obj1_out) *obj1_out = NAN;
     if (obj2_out) *obj2_out = NAN;
@@ -742,11 +755,11 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
         }
     }
     *n_candidates_out = nc;
-    int rc = 0;
     if (nc > 0) {
-        if (nc > 64) { rc = -2; goto done; }
-        uint64_t *mask = (uint64_t *)malloc((V ? V : 1) * sizeof(uint64_t));
-        float ratio[64]; double ub[64], x1[64], x2[64];
+        /* no cap on the columns (dense nvert x npaths matrix in the reference, profile.rs:1333-1342) */
+        mask = (uint64_t *)malloc((size_t)(V ? V : 1) * ORC_NW(nc) * sizeof(uint64_t));
+        ratio = (float *)malloc(nc * sizeof(float));
+        ub = (double *)malloc(3 * (size_t)nc * sizeof(double)); x1 = ub + nc; x2 = x1 + nc;
         orc_path_masks(g, nc, cand, node_base_cov, mask, ratio);
         for (uint32_t k = 0; k < nc; ++k) { met[cand[k]].path_cov_ratio = (double)ratio[k]; met[cand[k]].has |= ORC_HAS_RATIO; ub[k] = 1.05 * amax; }
         /* a11: the LP sees only the sampled valid rows (profile.rs:2738-2752); amax and the ratios above do not */
@@ -768,10 +781,10 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
         }
         int32_t it, st;
         orc_lad_solve(V, mask, ab, nc, ub, x1, obj1_out, &it, &st);
-        if (st != 0) { rc = -1; free(mask); goto done; }
+        if (st != 0) { rc = -1; goto done; }
         for (uint32_t k = 0; k < nc; ++k) { met[cand[k]].first_sol = x1[k]; met[cand[k]].has |= ORC_HAS_FIRST; }
         /* second_filter_paths, profile.rs:1229-1285 */
-        uint8_t keep[64]; memset(keep, 0, sizeof(keep));
+        keep = (uint8_t *)calloc(nc, 1);
         if (H != 1 && U > 0) {
             second_opt = 1;
             for (uint32_t k = 0; k < nc; ++k) {
@@ -802,13 +815,12 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
         if (second_opt) { /* profile.rs:1482-1508 (Gurobi semantics) */
             for (uint32_t k = 0; k < nc; ++k) if (!keep[k]) ub[k] = 0.0;
             orc_lad_solve(V, mask, ab, nc, ub, x2, obj2_out, &it, &st);
-            if (st != 0) { rc = -1; free(mask); goto done; }
+            if (st != 0) { rc = -1; goto done; }
             for (uint32_t k = 0; k < nc; ++k) if (keep[k]) { met[cand[k]].second_sol = x2[k]; met[cand[k]].has |= ORC_HAS_SECOND; }
         }
-        free(mask);
     }
 done:
-    free(ab); free(cand);
+    free(ab); free(cand); free(mask); free(ratio); free(ub); free(keep);
     return rc;
 }
 

@@ -91,10 +91,12 @@ int orc_hap_trio_stats(const orc_trio_table *t, uint32_t n_paths, const int64_t 
 
 /* profile.rs:1333-1361 (== 2705-2729): 0/1 membership masks of the candidate
  * paths per node, and path_cov_ratio accumulated in f32 in ascending node order.
- * cand[k] = index into graph paths; bit k of mask[v] set iff node v on path cand[k].
- * n_cand <= 64. */
+ * cand[k] = index into graph paths; row v of the matrix = ORC_NW(n_cand) words at mask + v * ORC_NW(n_cand), bit k & 63
+ * of word k >> 6 set iff node v is on path cand[k] (one word per node up to 64 candidates; no cap on n_cand, like the
+ * reference's dense matrix). */
+#define ORC_NW(n_cand) ((uint32_t)(((n_cand) + 63u) / 64u ? ((n_cand) + 63u) / 64u : 1u))
 int orc_path_masks(const orc_graph *g, uint32_t n_cand, const uint32_t *cand,
-                   const uint64_t *node_base_cov, uint64_t *mask_out /*[V]*/, float *ratio_out /*[n_cand]*/);
+                   const uint64_t *node_base_cov, uint64_t *mask_out /*[V * ORC_NW(n_cand)]*/, float *ratio_out /*[n_cand]*/);
 
 /* The PAO LP (profile.rs:1312-1460 Gurobi form; 2754-2822 HiGHS form):
  *   min (1/n) sum_{v: a_v>0} | sum_{k in mask_v} x_k - a_v |,  0 <= x_k <= ub_k

@@ -41,12 +41,12 @@ struct ArenaLayout {
         auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
         const size_t Hn = H ? H : 1;
         amax = take(8 * S); nzsum = take(8 * S); obj1 = take(8 * S); obj2 = take(8 * S);
-        x1 = take(8 * (size_t)S * LAD_MAXP); x2 = take(8 * (size_t)S * LAD_MAXP); ratio = take(8 * (size_t)S * LAD_MAXP * 2);
+        x1 = take(8 * Hn); x2 = take(8 * Hn); ratio = take(8 * Hn * 2);   // per column; column k of species s lives at hap_off[s] + k
         meanf = take(8 * Hn);
         nvalid = take(4 * S); nzcnt = take(4 * S); sp_p = take(4 * S); sp_pat_off = take(4 * ((size_t)S + 1));
         st1 = take(4 * S); st2 = take(4 * S); it1 = take(4 * S); it2 = take(4 * S); counts = take(16);
         nnz = take(4 * Hn); hap_bit = take(4 * Hn);
-        fixed2 = take((size_t)S * LAD_MAXP); need2 = take(S);
+        fixed2 = take(Hn); need2 = take(S);
         total = off;
     }
 };
@@ -58,14 +58,14 @@ int bind_arena(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L) {
     uint8_t *b = db->d_arena.p;
     if (!lb.prezeroed) PTX_HIP(ctx, hipMemsetAsync(b, 0, L.total, ctx->stream));   // unsolved species read back as x = 0, status 0, 0 pivots
     lb.d_amax.view(b + L.amax, S); lb.d_nzsum.view(b + L.nzsum, S); lb.d_obj.view(b + L.obj1, S); lb.d_obj2.view(b + L.obj2, S);
-    lb.d_x.view(b + L.x1, (size_t)S * LAD_MAXP); lb.d_x2.view(b + L.x2, (size_t)S * LAD_MAXP);
-    lb.d_ratio.view(b + L.ratio, (size_t)S * LAD_MAXP * 2);
+    lb.d_x.view(b + L.x1, Hn); lb.d_x2.view(b + L.x2, Hn);
+    lb.d_ratio.view(b + L.ratio, Hn * 2);
     db->d_hap_mean.view(b + L.meanf, Hn);
     lb.d_nvalid.view(b + L.nvalid, S); lb.d_nzcnt.view(b + L.nzcnt, S); lb.d_p.view(b + L.sp_p, S); lb.d_sp_pat_off.view(b + L.sp_pat_off, (size_t)S + 1);
     lb.d_status.view(b + L.st1, S); lb.d_status2.view(b + L.st2, S); lb.d_iters.view(b + L.it1, S); lb.d_iters2.view(b + L.it2, S);
     lb.d_counts.view(b + L.counts, 4);
     db->d_hap_nnz.view(b + L.nnz, Hn); lb.d_hap_bit.view(b + L.hap_bit, Hn);
-    lb.d_fixed2.view(b + L.fixed2, (size_t)S * LAD_MAXP); lb.d_need2.view(b + L.need2, S);
+    lb.d_fixed2.view(b + L.fixed2, Hn); lb.d_need2.view(b + L.need2, S);
     return 0;
 }
 
@@ -141,7 +141,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
     PTX_TRY(first_filter_launch(ctx, db, &lb, d_active, fc));                               // a9 decision -> LP columns
     mark();
-    int pmax_bound = 1;                                                                     // columns per species <= min(#haps, 64)
+    int pmax_bound = 1;                                                                     // mask bits of a row key: min(#haps, 64) (wide species: a 64-bit hash)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
     mark();
@@ -184,7 +184,7 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
         const int p = r.sp_p[s];
         info[s].n_candidates = p < 0 ? -p : p;
         bool failed = false; int fail_code = 0;
-        if (p < 0) { failed = true; fail_code = PANTAX_HIP_E_LIMIT; }                        // > 64 candidate paths
+        if (p < 0) { failed = true; fail_code = PANTAX_HIP_E_LIMIT; }                        // > LAD_WIDEP candidate paths
         std::vector<uint64_t> cand(p > 0 ? p : 0);                                          // column k -> global hap
         for (uint64_t h = h0; h < h1; ++h) if (r.hap_bit[h] >= 0 && r.hap_bit[h] < p) cand[r.hap_bit[h]] = h;
         // first-filter metrics (set for every haplotype that was looked at, candidate or not)
@@ -209,9 +209,9 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
             for (int k = 0; k < p; ++k) {
                 pantax_hip_hap_metrics &m = met[cand[k]];
                 // f32 ratio of exact integer sums (profile.rs:1344-1361 accumulates in f32; identical while sums < 2^24)
-                const float cov = (float)r.ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)r.ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+                const float cov = (float)r.ratio[(h0 + k) * 2], len = (float)r.ratio[(h0 + k) * 2 + 1];
                 m.path_cov_ratio = (double)(cov / len); m.has |= PANTAX_HIP_HAS_RATIO;
-                m.first_sol = r.x1[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_FIRST;
+                m.first_sol = r.x1[h0 + k]; m.has |= PANTAX_HIP_HAS_FIRST;
             }
             if (trio_mode) {                                                                // second_filter_paths, :1234-1268
                 const bool rs = r.need2[s] != 0;                                            // LP 2 actually differed from LP 1
@@ -220,14 +220,14 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
                 for (int k = 0; k < p && !failed; ++k) {
                     pantax_hip_hap_metrics &m = met[cand[k]];
                     const double fm = (m.has & PANTAX_HIP_HAS_FREQ_MEAN) ? m.frequencies_mean : 0.0;
-                    const bool keep = !r.fixed2[(size_t)s * LAD_MAXP + k];
+                    const bool keep = !r.fixed2[h0 + k];
                     if (fm != 0.0) {                                                        // :1238
                         const double sol = m.first_sol;
                         const double f = round2(std::fabs(sol - fm) / (sol + fm));
                         m.divergence = f; m.has |= PANTAX_HIP_HAS_DIVERGENCE;
                         if (keep && f > cfg->unique_trio_nodes_mean_count_f) { m.is_rescue = 1; m.has |= PANTAX_HIP_HAS_RESCUE; }   // :1251-1259
                     }
-                    if (keep) { m.second_sol = rs ? r.x2[(size_t)s * LAD_MAXP + k] : r.x1[(size_t)s * LAD_MAXP + k]; m.has |= PANTAX_HIP_HAS_SECOND; }   // :1500-1508
+                    if (keep) { m.second_sol = rs ? r.x2[h0 + k] : r.x1[h0 + k]; m.has |= PANTAX_HIP_HAS_SECOND; }   // :1500-1508
                 }
             } else if (single_mode) {                                                       // :1269-1278
                 pantax_hip_hap_metrics &m = met[h0];
@@ -315,8 +315,8 @@ int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_bat
     std::vector<double> amax(S);
     std::vector<uint32_t> nvalid(S);
     lb.h_p.assign(S, 0);
-    lb.h_cand.assign((size_t)S * LAD_MAXP, 0);
-    std::vector<uint8_t> fixed((size_t)S * LAD_MAXP, 0);
+    lb.h_cand.assign(H ? H : 1, 0);
+    std::vector<uint8_t> fixed(H ? H : 1, 0);
     int pmax = 1;
     for (uint32_t s = 0; s < S; ++s) {
         double mx = -INFINITY; uint32_t nv = 0;
@@ -324,22 +324,23 @@ int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_bat
         amax[s] = mx; nvalid[s] = nv;
         const uint64_t c0 = in->cand_off[s], c1 = in->cand_off[s + 1], nh = in->hap_off[s + 1] - in->hap_off[s];
         out->status[s] = 0;
-        if (c1 - c0 > (uint64_t)LAD_MAXP) { out->status[s] = PANTAX_HIP_E_LIMIT; continue; }   // this species only (the reference has no cap: INTEGRATION.md)
+        if (c1 - c0 > nh) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u has %llu candidates for %llu paths", s, (unsigned long long)(c1 - c0), (unsigned long long)nh);
+        if (c1 - c0 > (uint64_t)LAD_WIDEP) { out->status[s] = PANTAX_HIP_E_LIMIT; continue; }   // this species only (the reference has no cap: INTEGRATION.md)
         for (uint64_t k = c0; k < c1; ++k) {
             if (in->cand_path_idx[k] >= nh) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u candidate %llu names path %u of %llu", s, (unsigned long long)(k - c0), in->cand_path_idx[k], (unsigned long long)nh);
-            lb.h_cand[(size_t)s * LAD_MAXP + (k - c0)] = in->cand_path_idx[k];
-            fixed[(size_t)s * LAD_MAXP + (k - c0)] = (in->fixed_zero && in->fixed_zero[k]) ? 1 : 0;
+            lb.h_cand[in->hap_off[s] + (k - c0)] = in->cand_path_idx[k];
+            fixed[in->hap_off[s] + (k - c0)] = (in->fixed_zero && in->fixed_zero[k]) ? 1 : 0;
         }
         lb.h_p[s] = (int32_t)(c1 - c0);
-        pmax = std::max(pmax, (int)(c1 - c0));
+        pmax = std::max(pmax, (int)std::min<uint64_t>(c1 - c0, LAD_MAXP));
     }
     PTX_TRY(upload(ctx, lb.d_amax, amax.data(), S));
     PTX_TRY(upload(ctx, lb.d_nvalid, nvalid.data(), S));
     PTX_TRY(lad_prepare(ctx, db, &lb, false, pmax));
     PTX_TRY(upload(ctx, lb.d_fixed2, fixed.data(), fixed.size()));
     PTX_TRY(lad_solve_launch(ctx, db, &lb, pmax, nullptr, lb.d_fixed2.p, lb.d_x.p, lb.d_obj.p, lb.d_status.p, lb.d_iters.p));
-    std::vector<double> x((size_t)S * LAD_MAXP), obj(S);
-    std::vector<unsigned long long> ratio((size_t)S * LAD_MAXP * 2);
+    std::vector<double> x(H ? H : 1), obj(S);
+    std::vector<unsigned long long> ratio((H ? H : 1) * 2);
     std::vector<int32_t> st(S), it(S);
     std::vector<uint32_t> counts(4);
     PTX_TRY(download(ctx, x.data(), lb.d_x.p, x.size()));
@@ -354,8 +355,8 @@ int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_bat
         const uint64_t c0 = in->cand_off[s];
         const int p = lb.h_p[s];
         for (int k = 0; k < p; ++k) {
-            out->x[c0 + k] = x[(size_t)s * LAD_MAXP + k];
-            if (out->path_cov_ratio) out->path_cov_ratio[c0 + k] = (float)ratio[((size_t)s * LAD_MAXP + k) * 2] / (float)ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+            out->x[c0 + k] = x[in->hap_off[s] + k];
+            if (out->path_cov_ratio) out->path_cov_ratio[c0 + k] = (float)ratio[(in->hap_off[s] + k) * 2] / (float)ratio[(in->hap_off[s] + k) * 2 + 1];
         }
         if (out->obj) out->obj[s] = (p > 0 && nvalid[s]) ? obj[s] : 0.0;
         if (out->iters) out->iters[s] = p > 0 ? it[s] : 0;
@@ -371,7 +372,7 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
                          float *path_cov_ratio_out, double *obj_out, int32_t *status_out) {
     if (!ctx || !node_len || !node_abundance || !path_off || !path_nodes || !cand_path_idx || !x_out) return PANTAX_HIP_E_INVALID;
     if (n_cand == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: no candidate paths (the reference skips the solver, profile.rs:2968)");
-    if (n_cand > (uint32_t)LAD_MAXP) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: %u candidate paths; this build handles <= %d", n_cand, LAD_MAXP);
+    if (n_cand > (uint32_t)LAD_WIDEP) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: %u candidate paths; this build handles <= %d", n_cand, LAD_WIDEP);
     PTX_ENTER(ctx);
     const uint64_t node_off[2] = {0, n_nodes}, hap_off[2] = {0, n_paths}, cand_off[2] = {0, n_cand};
     const pantax_hip_species_batch in{1, node_off, node_len, node_abundance, node_base_cov, hap_off, path_off, path_nodes, cand_off, cand_path_idx, fixed_zero};

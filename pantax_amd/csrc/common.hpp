@@ -155,7 +155,9 @@ void species_profile_host(uint32_t S, const uint32_t *head_qlen, size_t n_head, 
                           const int64_t *less_multi, const int64_t *uniq_count, const double *avg_len, int filtered, uint8_t *keep_out,
                           double *absolute_out, double *abundance_out);
 constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
-constexpr int LAD_MAXP = 64;  // candidate paths per species (one u64 membership mask per node)
+constexpr int LAD_MAXP = 64;     // candidate paths of a species on the one-word path (one u64 membership mask per node)
+constexpr int LAD_WIDE_NW = 4;   // mask words of a "wide" species (more than 64 candidate paths)
+constexpr int LAD_WIDEP = 64 * LAD_WIDE_NW;   // most candidate paths of one species
 
 // One batch = every species that has at least one candidate path, solved concurrently
 // (one workgroup per species; the LPs are block-diagonal: profile.rs:3297-3319 runs them as
@@ -165,12 +167,24 @@ struct LadBatch {
     // per species (host mirrors + device)
     bool prezeroed = false;             // the result arena and d_mask were zeroed ahead of strain_enqueue (strain_prezero)
     std::vector<int32_t> h_p;           // [S] number of candidates (0 = not solved)
-    std::vector<uint32_t> h_cand;       // [S*LAD_MAXP] candidate -> hap index within species
+    std::vector<uint32_t> h_cand;       // [H] at hap_off[s] + k: candidate k -> hap index within species
     DevBuf<int32_t> d_p;
     DevBuf<int32_t> d_hap_bit;          // [H] bit index of hap in its species' candidate list, -1 if none
     DevBuf<uint64_t> d_mask;            // [V] candidate membership mask per node (the 0/1 coeff matrix, row-wise)
     DevBuf<double> d_ab;                // [V] node_abundance = bases / len  (profile.rs:980-990)
-    DevBuf<unsigned long long> d_ratio; // [S*LAD_MAXP*2] sum cov, sum len per candidate (exact integers)
+    DevBuf<unsigned long long> d_ratio; // [H*2] at 2 * (hap_off[s] + k): sum cov, sum len of candidate k (exact integers)
+    // species that can have more than 64 candidates (more than 64 haplotypes): LAD_WIDE_NW mask words per node in a side
+    // array, d_mask then holds a 64-bit hash of those words (rows are grouped by it; the words of every pattern are
+    // collected after the grouping, and a hash collision is detected there, not assumed away)
+    const void *wide_for = nullptr;     // the Db the wide tables below were laid out for
+    uint32_t n_wide = 0;                // species with more than LAD_MAXP haplotypes
+    uint64_t Vw = 0;                    // their nodes
+    DevBuf<uint32_t> d_wide_off;        // [S] first slot of the species in the wide arrays, 0xFFFFFFFF for the others
+    DevBuf<uint32_t> d_wide_list;       // [n_wide] species ids
+    DevBuf<uint32_t> d_wide_slot;       // [S] index into d_wide_list (the solver's W / G scratch), 0xFFFFFFFF for the others
+    DevBuf<uint64_t> d_maskw;           // [Vw * NW]
+    DevBuf<uint64_t> d_pat_or, d_pat_and;   // [Vw * NW] OR / AND of the mask words of the nodes of every pattern
+    DevBuf<double> d_wide_W, d_wide_G;  // [n_wide] x (WIDEP^2, 2 WIDEP^2): basis inverse / elimination scratch of the wide solver
     // per species node stats
     DevBuf<double> d_amax;              // [S] max node abundance (profile.rs:1316-1319)
     DevBuf<uint32_t> d_nvalid;          // [S] #nodes with abundance > 0 (= n_eval, profile.rs:1380-1385, :1447)
@@ -193,9 +207,9 @@ struct LadBatch {
     DevBuf<double> d_pat_eps, d_sc_s, d_sc_rho;
     DevBuf<uint32_t> d_sc_lo, d_sc_up, d_ls_lo, d_ls_hi, d_ls_mid;
     // solver in/out per species
-    DevBuf<double> d_x, d_x2, d_obj, d_obj2;      // [S*LAD_MAXP] x of solve 1 / 2, [S] objectives
+    DevBuf<double> d_x, d_x2, d_obj, d_obj2;      // [H] x of solve 1 / 2 at hap_off[s] + k, [S] objectives
     DevBuf<int32_t> d_status, d_iters, d_status2, d_iters2;   // [S]
-    DevBuf<uint8_t> d_fixed2, d_need2;  // [S*LAD_MAXP], [S] second-solve decisions (second_filter_kernel)
+    DevBuf<uint8_t> d_fixed2, d_need2;  // [H] at hap_off[s] + k, [S]: second-solve decisions (second_filter_species)
 };
 
 

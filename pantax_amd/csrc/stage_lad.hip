@@ -145,6 +145,13 @@ __device__ __forceinline__ double mdot(uint64_t m, const double *x) {   // ascen
     while (m) { int j = __ffsll((long long)m) - 1; s += x[j]; m &= m - 1; }
     return s;
 }
+template <int NW>
+__device__ __forceinline__ double mdotw(const uint64_t *mw, const double *x) {   // ascending-bit order over NW mask words
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { uint64_t m = mw[w]; while (m) { int j = __ffsll((long long)m) - 1; s += x[64 * w + j]; m &= m - 1; } }
+    return s;
+}
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -357,18 +364,79 @@ __device__ __forceinline__ uint32_t find_hap_l(const uint64_t *__restrict__ path
 __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
                                                    const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
                                                    const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
-                                                   unsigned long long *__restrict__ mask) {
+                                                   unsigned long long *__restrict__ mask, const int32_t *__restrict__ sp_p,
+                                                   const uint32_t *__restrict__ wide_off /* null: no species can be wide */,
+                                                   unsigned long long *__restrict__ maskw) {
     const uint2 tile = tiles[blockIdx.x];   // {hap, chunk}: see stage_trio.hip
     if (tile.x == 0xFFFFFFFFu) return;      // filler tile
     const uint32_t h = tile.x;
     const int bit = hap_bit[h];
     if (bit < 0) return;
-    const unsigned long long m = 1ull << bit;
-    const uint32_t nb = node_base[hap_species[h]];
+    const uint32_t sp = hap_species[h];
+    const uint32_t nb = node_base[sp];
     const uint64_t q0 = path_off[h] + (uint64_t)tile.y * PATH_TILE, qend = path_off[h + 1];
+    if (wide_off && sp_p[sp] > LAD_MAXP) {   // wide species: LAD_WIDE_NW words per node in the side array
+        const unsigned long long m = 1ull << (bit & 63);
+        unsigned long long *base = maskw + (size_t)wide_off[sp] * LAD_WIDE_NW + (bit >> 6);
+        for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
+            unsigned long long *w = base + (size_t)path_nodes[q] * LAD_WIDE_NW;
+            if ((*w & m) == 0) atomicOr(w, m);
+        }
+        return;
+    }
+    const unsigned long long m = 1ull << bit;
     for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
         unsigned long long *w = &mask[nb + path_nodes[q]];
         if ((*w & m) == 0) atomicOr(w, m);   // coeff_matrix[(v,pos)] = 1.0 even for repeated visits (profile.rs:1336-1340)
+    }
+}
+
+// Wide species: the one-word "mask" of a node becomes a 64-bit hash of its mask words (0 stays 0), so that the row grouping
+// (sort by mask, runs of equal masks = patterns) works on it unchanged.  Equal hashes of different word sets are caught by
+// wide_pattern_kernel / the solver (status 7), never silently merged.
+constexpr int WIDE_CHUNKS = 64;
+__device__ __forceinline__ unsigned long long wide_hash(const unsigned long long *w) {
+    unsigned long long h = 0, any = 0;
+#pragma unroll
+    for (int i = 0; i < LAD_WIDE_NW; ++i) { any |= w[i]; h = splitmix64(h ^ (w[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))); }
+    return any ? (h ? h : 1ull) : 0ull;
+}
+__global__ void __launch_bounds__(256) mask_fold_kernel(const uint32_t *__restrict__ wide_list, const uint32_t *__restrict__ wide_off,
+                                                        const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
+                                                        const unsigned long long *__restrict__ maskw, unsigned long long *__restrict__ mask) {
+    const uint32_t s = wide_list[blockIdx.x / WIDE_CHUNKS], ch = blockIdx.x % WIDE_CHUNKS;
+    if (sp_p[s] <= LAD_MAXP) return;
+    const uint32_t b = node_base[s], n = node_base[s + 1] - b;
+    const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
+    for (uint32_t v = ch * 256 + threadIdx.x; v < n; v += WIDE_CHUNKS * 256) mask[b + v] = wide_hash(mw + (size_t)v * LAD_WIDE_NW);
+}
+
+// Wide species, after the patterns are known: every LP row's node finds its pattern (binary search of its hash among the
+// species' patterns, which are sorted by it) and ORs / ANDs its mask words into the pattern's slots.  OR == AND for every
+// pattern <=> all of its rows have the same words (the solver checks and reports status 7 otherwise).
+__global__ void __launch_bounds__(256) wide_pattern_kernel(const uint32_t *__restrict__ wide_list, const uint32_t *__restrict__ wide_off,
+                                                           const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
+                                                           const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
+                                                           const unsigned long long *__restrict__ maskw, const uint32_t *__restrict__ sp_pat_off,
+                                                           const uint64_t *__restrict__ pat_mask, unsigned long long *__restrict__ pat_or,
+                                                           unsigned long long *__restrict__ pat_and) {
+    const uint32_t s = wide_list[blockIdx.x / WIDE_CHUNKS], ch = blockIdx.x % WIDE_CHUNKS;
+    if (sp_p[s] <= LAD_MAXP) return;
+    const uint32_t b = node_base[s], n = node_base[s + 1] - b;
+    const uint32_t k0 = sp_pat_off[s], k1 = sp_pat_off[s + 1];
+    const size_t wo = (size_t)wide_off[s] * LAD_WIDE_NW;
+    for (uint32_t v = ch * 256 + threadIdx.x; v < n; v += WIDE_CHUNKS * 256) {
+        const unsigned long long hm = mask[b + v];
+        if (!(ab[b + v] > 0.0) || hm == 0ull) continue;
+        uint32_t lo = k0, hi = k1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pat_mask[mid] < hm) lo = mid + 1; else hi = mid; }
+        if (lo >= k1 || pat_mask[lo] != hm) continue;   // cannot happen: every such node is a row
+#pragma unroll
+        for (int i = 0; i < LAD_WIDE_NW; ++i) {
+            const unsigned long long w = maskw[wo + (size_t)v * LAD_WIDE_NW + i];
+            atomicOr(&pat_or[wo + (size_t)(lo - k0) * LAD_WIDE_NW + i], w);
+            atomicAnd(&pat_and[wo + (size_t)(lo - k0) * LAD_WIDE_NW + i], w);
+        }
     }
 }
 
@@ -379,16 +447,38 @@ constexpr int ROW_ITEMS = 8;   // nodes per thread of the row compaction kernels
 // reductions; 64 lanes hammering 2-4 LDS addresses with 64-bit atomics serialise.
 __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
-                                                    const int32_t *__restrict__ sp_p, unsigned long long *__restrict__ ratio) {
-    __shared__ unsigned long long acc[LAD_MAXP * 2];
+                                                    const int32_t *__restrict__ sp_p, const uint64_t *__restrict__ hap_off,
+                                                    const uint32_t *__restrict__ wide_off, const unsigned long long *__restrict__ maskw,
+                                                    unsigned long long *__restrict__ ratio) {
+    __shared__ unsigned long long acc[LAD_WIDEP * 2];
     const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
-    if (sp_p[s] <= 0) return;
-    if (threadIdx.x < LAD_MAXP * 2) acc[threadIdx.x] = 0;
+    const int p = sp_p[s];
+    if (p <= 0) return;
+    for (int i = threadIdx.x; i < 2 * p; i += 256) acc[i] = 0;
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + RATIO_CHUNKS - 1) / RATIO_CHUNKS;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
+    if (p > LAD_MAXP) {   // wide species: all candidates through the LDS accumulators
+        const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
+        for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+            const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+#pragma unroll
+            for (int i = 0; i < LAD_WIDE_NW; ++i) {
+                unsigned long long m = mw[(size_t)(v - b) * LAD_WIDE_NW + i];
+                while (m) {
+                    const int k = 64 * i + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (c) atomicAdd(&acc[2 * k], c);
+                    atomicAdd(&acc[2 * k + 1], l);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p; i += 256) if (acc[i]) atomicAdd(&ratio[2 * hap_off[s] + i], acc[i]);
+        return;
+    }
     unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
@@ -418,7 +508,7 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
         }
     }
     __syncthreads();
-    if (threadIdx.x < LAD_MAXP * 2 && acc[threadIdx.x]) atomicAdd(&ratio[(size_t)s * LAD_MAXP * 2 + threadIdx.x], acc[threadIdx.x]);
+    if ((int)threadIdx.x < 2 * p && acc[threadIdx.x]) atomicAdd(&ratio[2 * hap_off[s] + threadIdx.x], acc[threadIdx.x]);
 }
 
 // The rows in NODE ORDER, hence species by species: an ordered compaction as ONE chained-scan launch (the flag of a node is
@@ -589,13 +679,40 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     if (!cand_on_device) {
         std::vector<int32_t> hap_bit(H ? H : 1, -1);
         for (uint32_t s = 0; s < S; ++s)
-            for (int k = 0; k < lb->h_p[s]; ++k) hap_bit[db->h_hap_off[s] + lb->h_cand[(size_t)s * LAD_MAXP + k]] = k;
+            for (int k = 0; k < lb->h_p[s]; ++k) hap_bit[db->h_hap_off[s] + lb->h_cand[db->h_hap_off[s] + k]] = k;
         PTX_TRY(upload(ctx, lb->d_hap_bit, hap_bit.data(), hap_bit.size()));
         PTX_TRY(upload(ctx, lb->d_p, lb->h_p.data(), S));
     }
     PTX_HIP(ctx, lb->d_mask.alloc(V));
-    PTX_HIP(ctx, lb->d_ratio.alloc((size_t)S * LAD_MAXP * 2));
+    PTX_HIP(ctx, lb->d_ratio.alloc((size_t)(H ? H : 1) * 2));
     if (!lb->prezeroed) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));
+    // species that can be wide (more than 64 haplotypes): side arrays laid out once per db
+    if (lb->wide_for != (const void *)db) {
+        std::vector<uint32_t> off(S ? S : 1, 0xFFFFFFFFu), slot(S ? S : 1, 0xFFFFFFFFu), list;
+        uint64_t vw = 0;
+        for (uint32_t s = 0; s < S; ++s)
+            if (db->h_hap_off[s + 1] - db->h_hap_off[s] > (uint64_t)LAD_MAXP) {
+                off[s] = (uint32_t)vw; slot[s] = (uint32_t)list.size(); list.push_back(s);
+                vw += db->h_node_off[s + 1] - db->h_node_off[s];
+            }
+        if (vw >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: %llu nodes in species of more than %d haplotypes", (unsigned long long)vw, LAD_MAXP);
+        lb->n_wide = (uint32_t)list.size(); lb->Vw = vw;
+        if (lb->n_wide) {
+            PTX_TRY(upload(ctx, lb->d_wide_off, off.data(), S));
+            PTX_TRY(upload(ctx, lb->d_wide_slot, slot.data(), S));
+            PTX_TRY(upload(ctx, lb->d_wide_list, list.data(), list.size()));
+            PTX_HIP(ctx, lb->d_maskw.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_or.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_and.alloc(vw * LAD_WIDE_NW));
+            PTX_HIP(ctx, lb->d_wide_W.alloc((size_t)lb->n_wide * LAD_WIDEP * LAD_WIDEP));
+            PTX_HIP(ctx, lb->d_wide_G.alloc((size_t)lb->n_wide * LAD_WIDEP * 2 * LAD_WIDEP));
+        }
+        lb->wide_for = (const void *)db;
+    }
+    const bool wide = lb->n_wide != 0;
+    if (wide) {
+        PTX_TRY(zero_fill(ctx, lb->d_maskw.p, lb->Vw * LAD_WIDE_NW * sizeof(uint64_t)));
+        PTX_TRY(zero_fill(ctx, lb->d_pat_or.p, lb->Vw * LAD_WIDE_NW * sizeof(uint64_t)));
+        PTX_HIP(ctx, hipMemsetAsync(lb->d_pat_and.p, 0xFF, lb->Vw * LAD_WIDE_NW * sizeof(uint64_t), ctx->stream));
+    }
     // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
     // rows: compact -> sort by (species, mask, a)
     Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
@@ -615,13 +732,18 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         KTimer t(ctx, "mask_kernel");
         if (db->n_tiles)
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
-                               db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p);
+                               db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p,
+                               lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, (unsigned long long *)lb->d_maskw.p);
     }
     {
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
-                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, lb->d_ratio.p);
+                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, (const unsigned long long *)lb->d_maskw.p,
+                           lb->d_ratio.p);
     }
+    if (wide)
+        hipLaunchKernelGGL(mask_fold_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
+                           db->d_node_base.p, lb->d_p.p, (const unsigned long long *)lb->d_maskw.p, (unsigned long long *)lb->d_mask.p);
     DevBuf<uint32_t> &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
@@ -687,6 +809,10 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
     hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
                        lb->d_pat_start.p, lb->d_sp_pat_off.p);
+    if (wide)
+        hipLaunchKernelGGL(wide_pattern_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
+                           db->d_node_base.p, lb->d_p.p, lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, (const unsigned long long *)lb->d_maskw.p,
+                           lb->d_sp_pat_off.p, lb->d_pat_mask.p, (unsigned long long *)lb->d_pat_or.p, (unsigned long long *)lb->d_pat_and.p);
     PTX_HIP(ctx, lb->d_pat_eps.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_s.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_rho.alloc(k_cap));
     PTX_HIP(ctx, lb->d_sc_lo.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_up.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_lo.alloc(k_cap));
     PTX_HIP(ctx, lb->d_ls_hi.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_mid.alloc(k_cap));
@@ -723,12 +849,12 @@ __global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint
                     if (fm >= 1.0) { sh = fr + (0.8 - fr) * fm / 100.0; if (sh > 0.8) sh = 0.8; } else sh = fr * fm;
                     if (frac < sh) continue;
                 } else if (frac < fr) continue;                            // :1168
-                if (p < LAD_MAXP) hap_bit[h] = p;
+                if (p < LAD_WIDEP) hap_bit[h] = p;
                 ++p;
             }
         } else if (Hs == 1 || all_same[s]) { hap_bit[h0] = 0; p = 1; }     // :1191-1205, :1211-1224
-        else { for (uint64_t h = h0; h < h1; ++h) { if (p < LAD_MAXP) hap_bit[h] = p; ++p; } }   // :1208
-        if (p > LAD_MAXP) { for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1; p = -p; }   // this build: <= 64 columns; species fails
+        else { for (uint64_t h = h0; h < h1; ++h) { if (p < LAD_WIDEP) hap_bit[h] = p; ++p; } }   // :1208
+        if (p > LAD_WIDEP) { for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1; p = -p; }   // this build: <= 256 columns; species fails
     }
     sp_p[s] = p;
 }
@@ -750,7 +876,7 @@ struct SecondFilterArgs {
 __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F, uint32_t s) {
     const uint64_t h0 = F.hap_off[s], h1 = F.hap_off[s + 1];
     uint8_t need = 0;
-    for (int k = 0; k < LAD_MAXP; ++k) F.fixed2[(size_t)s * LAD_MAXP + k] = 0;
+    for (uint64_t h = h0; h < h1; ++h) F.fixed2[h] = 0;   // column k of the species lives at h0 + k
     if (F.sp_p[s] > 0 && F.status1[s] == 0 && (h1 - h0) != 1 && F.hto[h1] - F.hto[h0] > 0) {
         for (uint64_t h = h0; h < h1; ++h) {
             const int k = F.hap_bit[h];
@@ -758,18 +884,18 @@ __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F,
             const double fm = F.meanf[h];
             bool keep = false;
             if (fm != 0.0) {                                               // :1238
-                const double sol = F.x1[(size_t)s * LAD_MAXP + k];
+                const double sol = F.x1[h0 + k];
                 const double f = d_round2(fabs(sol - fm) / (sol + fm));
                 if (f > F.fc) {
                     if (f <= 0.6) {
                         const double frac_r = d_round2((double)F.nnz[h] / (double)(F.hto[h + 1] - F.hto[h]));
-                        const float cov = (float)F.ratio[((size_t)s * LAD_MAXP + k) * 2], len = (float)F.ratio[((size_t)s * LAD_MAXP + k) * 2 + 1];
+                        const float cov = (float)F.ratio[(h0 + k) * 2], len = (float)F.ratio[(h0 + k) * 2 + 1];
                         const double sc = frac_r * (double)(cov / len);
                         if (!(sc < F.sr || sol == 0.0)) keep = true;       // rescue
                     }
                 } else if (sol != 0.0) keep = true;
             }
-            if (!keep) { F.fixed2[(size_t)s * LAD_MAXP + k] = 1; need = 1; }
+            if (!keep) { F.fixed2[h0 + k] = 1; need = 1; }
         }
     }
     F.need2[s] = need;
@@ -807,17 +933,24 @@ struct LadArgs {
     uint32_t *sc_lo, *sc_up, *ls_lo, *ls_hi, *ls_mid;
     const int32_t *sp_p;
     const uint8_t *need;    // [S] or null: solve only species with need[s] != 0
-    const uint8_t *fixed;   // [S*LAD_MAXP] or null: variables pinned to zero
+    const uint8_t *fixed;   // [H] at col_off[s] + k, or null: variables pinned to zero
     const double *amax;
-    double *x_out;
+    double *x_out;          // [H] at col_off[s] + k
     int32_t *status, *iters;
+    const uint64_t *col_off;   // [S+1] first column slot of every species (= its first haplotype)
+    // wide species (more than LAD_MAXP columns): the mask words of pattern k of species s are
+    // pat_or[(wide_off[s] + k - sp_pat_off[s]) * NW ..]; W / G live in global scratch, slot wide_slot[s]
+    const uint32_t *wide_list, *wide_off, *wide_slot;
+    const uint64_t *pat_or, *pat_and;
+    double *wide_W, *wide_G;
 };
 
+template <int PS>
 struct LadShared {
-    double x[LAD_MAXP], c[LAD_MAXP], lam[LAD_MAXP], d[LAD_MAXP], ub[LAD_MAXP], fac[LAD_MAXP], score[LAD_MAXP], deriv[LAD_MAXP];
-    long long g[LAD_MAXP];
-    int act_type[LAD_MAXP], act_jk[LAD_MAXP], dir[LAD_MAXP];
-    uint32_t act_i0[LAD_MAXP], act_i1[LAD_MAXP];
+    double x[PS], c[PS], lam[PS], d[PS], ub[PS], fac[PS], score[PS], deriv[PS];
+    long long g[PS];
+    int act_type[PS], act_jk[PS], dir[PS];
+    uint32_t act_i0[PS], act_i1[PS];
     double red[LAD_BLOCK / 64];
     double red_t[LAD_BLOCK / 64];
     double xs[2][LAD_BLOCK / 64][4];   // double-buffered exchange slots of the line search: one barrier per exchange
@@ -873,13 +1006,13 @@ __device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double
     }
 #define PAT_LOOP(k) for (uint32_t k = k0 + (COOP ? (uint32_t)(tid >> 6) : (uint32_t)tid); k < k1; k += (COOP ? LAD_BLOCK / 64 : LAD_BLOCK))
 // LDS of one solver workgroup
-template <int PS>
+template <int PS, int NW>
 struct LadLds {
     static constexpr uint32_t IDX_N = PS <= 16 ? 4096 : 2048;     // samples of the row index (the 64-column instance spends its LDS on W and G)
     static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 512;    // cached candidate rows of a line search
-    LadShared sh;
-    double W[PS * PS];
-    double G[PS * 2 * PS];
+    LadShared<PS> sh;
+    double W[NW == 1 ? PS * PS : 1];          // wide species: W and G in global scratch (LadArgs::wide_W / wide_G)
+    double G[NW == 1 ? PS * 2 * PS : 1];
     // per-pattern solver state (species with at most LAD_KLDS patterns, the usual case; else the global scratch arrays)
     double L_s[LAD_KLDS], L_rho[LAD_KLDS], L_eps[LAD_KLDS];
     uint64_t L_mask[LAD_KLDS];
@@ -895,11 +1028,20 @@ struct LadLds {
 
 // USEL is a compile-time constant so that every access to the pattern state is a plain LDS (or plain global)
 // instruction; a run-time choice between the two would turn them all into flat accesses.
-template <int PS, bool USEL>
-__device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, const int s, const int p, const uint32_t k0, const uint32_t k1) {
-    constexpr uint32_t IDX_N = LadLds<PS>::IDX_N, CACHE_N = LadLds<PS>::CACHE_N;
-    LadShared &sh = m.sh;
-    double *W = m.W, *G = m.G, *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache = m.L_cache;
+template <int PS, bool USEL, int NW>
+__device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> &m, const int s, const int p, const uint32_t k0, const uint32_t k1) {
+    static_assert(NW == 1 || !USEL, "wide species keep their pattern state in global scratch");
+    constexpr uint32_t IDX_N = LadLds<PS, NW>::IDX_N, CACHE_N = LadLds<PS, NW>::CACHE_N;
+    LadShared<PS> &sh = m.sh;
+    double *W, *G;
+    const uint64_t *patw = nullptr;   // wide: mask words of pattern k at patw + (k - k0) * NW
+    if constexpr (NW == 1) { W = m.W; G = m.G; }
+    else {
+        W = A.wide_W + (size_t)A.wide_slot[s] * PS * PS; G = A.wide_G + (size_t)A.wide_slot[s] * PS * 2 * PS;
+        patw = A.pat_or + (size_t)A.wide_off[s] * NW;
+    }
+    const uint64_t c0 = A.col_off[s];
+    double *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache = m.L_cache;
     uint64_t *L_mask = m.L_mask;
     uint32_t *L_lo = m.L_lo, *L_up = m.L_up, *L_lslo = m.L_lslo, *L_lshi = m.L_lshi, *L_lsmid = m.L_lsmid, *L_start = m.L_start,
              *L_lsmid2 = m.L_lsmid2, *L_coff = m.L_coff, *L_cn = m.L_cn, *L_crow0 = m.L_crow0;
@@ -938,7 +1080,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
         P_pat_eps[kk - kofs] = delta * (0.25 + 0.5 * (double)(splitmix64(P_pat_mask[kk - kofs]) >> 11) * (1.0 / 9007199254740992.0));
     if (tid < p) {
         // box: 0 <= x <= 1.05 * max(a) (profile.rs:1327); pinned to 0 in the second solve (:1484-1488)
-        double u = (A.fixed && A.fixed[(size_t)s * LAD_MAXP + tid]) ? 0.0 : 1.05 * A.amax[s];
+        double u = (A.fixed && A.fixed[c0 + tid]) ? 0.0 : 1.05 * A.amax[s];
         sh.ub[tid] = u;
         sh.act_type[tid] = u > 0.0 ? C_LB : C_FIXED;
         sh.act_jk[tid] = tid;
@@ -947,9 +1089,17 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
     for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = (i / p == i % p) ? 1.0 : 0.0;
     if (tid == 0) { sh.done = 0; sh.status = 0; }
     __syncthreads();
+    if constexpr (NW > 1) {
+        // rows of one pattern must agree in every mask word (they were grouped by a hash of the words)
+        bool bad = false;
+        for (uint32_t kk = tid; kk < (k1 - k0) * NW; kk += LAD_BLOCK) bad |= patw[kk] != A.pat_and[(size_t)A.wide_off[s] * NW + kk];
+        if (bad) { sh.status = 7; sh.done = 1; }
+        __syncthreads();
+    }
     const int max_it = 200 * p + 2000;
     int it = 0;
-    for (; it < max_it; ++it) {
+    const bool skip = NW > 1 && sh.done;   // (block-uniform: written before the barrier above)
+    for (; it < max_it && !skip; ++it) {
         // ---- vertex of the perturbed problem: x = W c
         if (tid < p) {
             int ty = sh.act_type[tid];
@@ -966,13 +1116,14 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
         // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
         PAT_LOOP(k) {
             uint64_t mk = P_pat_mask[k - kofs];
+            const uint64_t *mw = NW > 1 ? patw + (size_t)(k - k0) * NW : nullptr;
             uint32_t st = P_pat_start[k - kofs], en = P_pat_start[(k + 1) - kofs];
             int ai = -1;
             for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
             uint32_t lo, up; double sk;
             if (ai >= 0) { lo = sh.act_i0[ai]; up = sh.act_i1[ai]; sk = ra.a[lo] + P_pat_eps[k - kofs]; }
             else {
-                sk = mdot(mk, sh.x);
+                if constexpr (NW == 1) sk = mdot(mk, sh.x); else sk = mdotw<NW>(mw, sh.x);
                 double sv = sk - P_pat_eps[k - kofs];
                 lo = lb(COOP, ra, st, en, sv);
                 up = ub_(COOP, ra, lo, en, sv);
@@ -980,8 +1131,15 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             P_sc_s[k - kofs] = sk; P_sc_lo[k - kofs] = lo; P_sc_up[k - kofs] = up;
             long long sigma = (long long)(lo - st) - (long long)(en - up);
             if (sigma && leader) {
-                uint64_t bits = mk;
-                while (bits) { int j = __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                if constexpr (NW == 1) {
+                    uint64_t bits = mk;
+                    while (bits) { int j = __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                } else {
+                    for (int w = 0; w < NW; ++w) {
+                        uint64_t bits = mw[w];
+                        while (bits) { int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1028,7 +1186,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
             double rho;
             if (ai >= 0) rho = (ai == best) ? bdir : 0.0;   // other tight patterns stay tight: n_i . d = 0
-            else { rho = mdot(mk, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(P_sc_up[k - kofs] - P_sc_lo[k - kofs]); }
+            else { if constexpr (NW == 1) rho = mdot(mk, sh.d); else rho = mdotw<NW>(patw + (size_t)(k - k0) * NW, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(P_sc_up[k - kofs] - P_sc_lo[k - kofs]); }
             P_sc_rho[k - kofs] = rho;
             P_ls_lo[k - kofs] = 0;
             P_ls_hi[k - kofs] = rho > 0 ? P_pat_start[(k + 1) - kofs] - P_sc_up[k - kofs] : rho < 0 ? P_sc_lo[k - kofs] - P_pat_start[k - kofs] : 0;
@@ -1409,8 +1567,16 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
                 double y;
                 if (sh.act_type[best] == C_PAT) {
                     y = 0.0;
-                    uint64_t bits = P_pat_mask[sh.act_jk[best] - kofs];
-                    while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
+                    if constexpr (NW == 1) {
+                        uint64_t bits = P_pat_mask[sh.act_jk[best] - kofs];
+                        while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
+                    } else {
+                        const uint64_t *mb = patw + (size_t)((uint32_t)sh.act_jk[best] - k0) * NW;
+                        for (int w = 0; w < NW; ++w) {
+                            uint64_t bits = mb[w];
+                            while (bits) { const int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
+                        }
+                    }
                 } else y = W[sh.act_jk[best] * PS + tid];
                 sh.fac[tid] = y;
                 sh.score[tid] = W[tid * PS + best];
@@ -1432,7 +1598,10 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             int r = i / (2 * p), cc = i % (2 * p);
             double v;
             if (cc >= p) v = (cc - p == r) ? 1.0 : 0.0;
-            else if (sh.act_type[r] == C_PAT) v = (P_pat_mask[sh.act_jk[r] - kofs] >> cc) & 1ull ? 1.0 : 0.0;
+            else if (sh.act_type[r] == C_PAT) {
+                if constexpr (NW == 1) v = (P_pat_mask[sh.act_jk[r] - kofs] >> cc) & 1ull ? 1.0 : 0.0;
+                else v = (patw[(size_t)((uint32_t)sh.act_jk[r] - k0) * NW + (cc >> 6)] >> (cc & 63)) & 1ull ? 1.0 : 0.0;
+            }
             else v = (sh.act_jk[r] == cc) ? 1.0 : 0.0;
             G[r * 2 * PS + cc] = v;
         }
@@ -1447,12 +1616,12 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
             __syncthreads();
             if (sh.done) break;
             int piv = sh.piv;
-            if (piv != col && tid < 2 * p) { double t = G[col * 2 * PS + tid]; G[col * 2 * PS + tid] = G[piv * 2 * PS + tid]; G[piv * 2 * PS + tid] = t; }
+            if (piv != col) for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) { double t = G[col * 2 * PS + c2]; G[col * 2 * PS + c2] = G[piv * 2 * PS + c2]; G[piv * 2 * PS + c2] = t; }
             __syncthreads();
             double dinv = 1.0 / G[col * 2 * PS + col];
             if (tid < p) sh.fac[tid] = G[tid * 2 * PS + col];
             __syncthreads();
-            if (tid < 2 * p) G[col * 2 * PS + tid] *= dinv;
+            for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) G[col * 2 * PS + c2] *= dinv;
             __syncthreads();
             for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
                 int r = i / (2 * p), cc = i % (2 * p);
@@ -1477,7 +1646,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
         for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
         if (v < 0.0) v = 0.0;
         if (v > sh.ub[tid]) v = sh.ub[tid];
-        A.x_out[(size_t)s * LAD_MAXP + tid] = v;
+        A.x_out[c0 + tid] = v;
     }
     if (tid == 0) {
         A.status[s] = (it >= max_it) ? 1 : sh.status;
@@ -1485,38 +1654,48 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS> &m, 
     }
 }
 
-template <int PS>
+// NW == 1: one workgroup per species of the db, species with more than LAD_MAXP columns are left to the wide launch;
+// NW > 1: one workgroup per entry of wide_list, species with at most LAD_MAXP columns were done by the other launch.
+template <int PS, int NW>
 __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
-    __shared__ LadLds<PS> m;
-    const int s = blockIdx.x;   // one workgroup per species of the db; species without work leave at once
+    __shared__ LadLds<PS, NW> m;
+    const int s = NW == 1 ? (int)blockIdx.x : (int)A.wide_list[blockIdx.x];
     const int p = A.sp_p[s];
+    if ((NW == 1) != (p <= LAD_MAXP)) return;
     if (A.need && !A.need[s]) return;
     if (p <= 0) { if (threadIdx.x == 0) { A.status[s] = 0; A.iters[s] = 0; } return; }
     const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
-    if (k1 - k0 <= (uint32_t)LAD_KLDS) lad_solve_body<PS, true>(A, m, s, p, k0, k1);
-    else lad_solve_body<PS, false>(A, m, s, p, k0, k1);
+    if constexpr (NW == 1) {
+        if (k1 - k0 <= (uint32_t)LAD_KLDS) lad_solve_body<PS, true, 1>(A, m, s, p, k0, k1);
+        else lad_solve_body<PS, false, 1>(A, m, s, p, k0, k1);
+    } else lad_solve_body<PS, false, NW>(A, m, s, p, k0, k1);
 }
 
 // Both LP solves of the strain step in ONE launch: solve, take the second-filter decision of this species
 // (one thread), and solve again with the dropped columns pinned to zero -- only where a column was dropped;
 // elsewhere LP2 == LP1 (m.reset() + no new constraint, profile.rs:1482-1490).
-template <int PS>
+template <int PS, int NW>
 __global__ void __launch_bounds__(LAD_BLOCK) lad_pair_kernel(LadArgs A1, LadArgs A2, SecondFilterArgs F) {
-    __shared__ LadLds<PS> m;
-    const int s = blockIdx.x;
+    __shared__ LadLds<PS, NW> m;
+    const int s = NW == 1 ? (int)blockIdx.x : (int)A1.wide_list[blockIdx.x];
     const int p = A1.sp_p[s];
+    if ((NW == 1) != (p <= LAD_MAXP)) return;
     const uint32_t k0 = A1.sp_pat_off[s], k1 = A1.sp_pat_off[s + 1];
-    const bool lds_state = k1 - k0 <= (uint32_t)LAD_KLDS;
+    const bool lds_state = NW == 1 && k1 - k0 <= (uint32_t)LAD_KLDS;
     if (p > 0) {
-        if (lds_state) lad_solve_body<PS, true>(A1, m, s, p, k0, k1);
-        else lad_solve_body<PS, false>(A1, m, s, p, k0, k1);
+        if constexpr (NW == 1) {
+            if (lds_state) lad_solve_body<PS, true, 1>(A1, m, s, p, k0, k1);
+            else lad_solve_body<PS, false, 1>(A1, m, s, p, k0, k1);
+        } else lad_solve_body<PS, false, NW>(A1, m, s, p, k0, k1);
     } else if (threadIdx.x == 0) { A1.status[s] = 0; A1.iters[s] = 0; }
     __syncthreads();   // x1 / status1 of this species are visible to the workgroup
     if (threadIdx.x == 0) second_filter_species(F, (uint32_t)s);
     __syncthreads();
     if (p <= 0 || !F.need2[s]) return;
-    if (lds_state) lad_solve_body<PS, true>(A2, m, s, p, k0, k1);
-    else lad_solve_body<PS, false>(A2, m, s, p, k0, k1);
+    if constexpr (NW == 1) {
+        if (lds_state) lad_solve_body<PS, true, 1>(A2, m, s, p, k0, k1);
+        else lad_solve_body<PS, false, 1>(A2, m, s, p, k0, k1);
+    } else lad_solve_body<PS, false, NW>(A2, m, s, p, k0, k1);
 }
 
 // objective (1/n) sum_{a_v>0} |m_v . x - a_v| over the nodes of each solved species (profile.rs:1440-1450),
@@ -1524,24 +1703,39 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_pair_kernel(LadArgs A1, LadArgs
 // the nodes.  The workgroup that finishes a species last adds the chunk partials in fixed order.
 __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need2,
                                                         const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
-                                                        const unsigned long long *__restrict__ mask, const double *__restrict__ x1,
+                                                        const unsigned long long *__restrict__ mask, const uint64_t *__restrict__ col_off,
+                                                        const uint32_t *__restrict__ wide_off, const unsigned long long *__restrict__ maskw,
+                                                        const double *__restrict__ x1,
                                                         const double *__restrict__ x2, double *part /*[S][STAT_CHUNKS][2]*/,
                                                         uint32_t *__restrict__ done /*[S], zero between launches*/,
                                                         const uint32_t *__restrict__ nvalid, double *__restrict__ obj1, double *__restrict__ obj2, uint32_t nch) {
     __shared__ double red[4];
-    __shared__ double xs1[LAD_MAXP], xs2[LAD_MAXP];
+    __shared__ double xs1[LAD_WIDEP], xs2[LAD_WIDEP];
     __shared__ int s_last;
     const int s = blockIdx.x / nch;
-    if (sp_p[s] <= 0) return;
+    const int p = sp_p[s];
+    if (p <= 0) return;
     const bool two = x2 && need2 && need2[s];
     const uint32_t ch = blockIdx.x % nch;
-    if (threadIdx.x < LAD_MAXP) { xs1[threadIdx.x] = x1[(size_t)s * LAD_MAXP + threadIdx.x]; xs2[threadIdx.x] = two ? x2[(size_t)s * LAD_MAXP + threadIdx.x] : 0.0; }
+    static_assert(LAD_WIDEP <= 256, "one column per thread");
+    if ((int)threadIdx.x < p) { xs1[threadIdx.x] = x1[col_off[s] + threadIdx.x]; xs2[threadIdx.x] = two ? x2[col_off[s] + threadIdx.x] : 0.0; }
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     double acc1 = 0.0, acc2 = 0.0;
+    if (p > LAD_MAXP) {   // wide species: the mask words of the node
+        const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
+        for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+            const double a = ab[v];
+            if (a > 0.0) {
+                const uint64_t *m4 = (const uint64_t *)(mw + (size_t)(v - b) * LAD_WIDE_NW);
+                acc1 += fabs(mdotw<LAD_WIDE_NW>(m4, xs1) - a);
+                if (two) acc2 += fabs(mdotw<LAD_WIDE_NW>(m4, xs2) - a);
+            }
+        }
+    } else
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         const double a = ab[v];
         if (a > 0.0) {
@@ -1583,30 +1777,34 @@ static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t 
     }
     const uint32_t nch = stat_chunks(S);
     hipLaunchKernelGGL(objective_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, db->d_node_base.p, lb->d_ab.p,
-                       (unsigned long long *)lb->d_mask.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2, nch);
+                       (unsigned long long *)lb->d_mask.p, db->d_hap_off.p, lb->d_wide_off.p, (const unsigned long long *)lb->d_maskw.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2, nch);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
 
-static LadArgs lad_args(LadBatch *lb, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x, int32_t *d_status, int32_t *d_iters) {
+static LadArgs lad_args(const Db *db, LadBatch *lb, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x, int32_t *d_status, int32_t *d_iters) {
     LadArgs A;
     A.row_a = lb->row_a; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
     A.pat_eps = lb->d_pat_eps.p; A.sc_s = lb->d_sc_s.p; A.sc_rho = lb->d_sc_rho.p;
     A.sc_lo = lb->d_sc_lo.p; A.sc_up = lb->d_sc_up.p; A.ls_lo = lb->d_ls_lo.p; A.ls_hi = lb->d_ls_hi.p; A.ls_mid = lb->d_ls_mid.p;
     A.sp_p = lb->d_p.p; A.need = d_need; A.fixed = d_fixed; A.amax = lb->d_amax.p; A.x_out = d_x; A.status = d_status; A.iters = d_iters;
+    A.col_off = db->d_hap_off.p;
+    A.wide_list = lb->d_wide_list.p; A.wide_off = lb->d_wide_off.p; A.wide_slot = lb->d_wide_slot.p;
+    A.pat_or = lb->d_pat_or.p; A.pat_and = lb->d_pat_and.p; A.wide_W = lb->d_wide_W.p; A.wide_G = lb->d_wide_G.p;
     return A;
 }
 
 // the strain step's two solves + second filter + both objectives: two launches
 int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const FilterCfg &fc) {
     const uint32_t S = db->S;
-    LadArgs A1 = lad_args(lb, nullptr, nullptr, lb->d_x.p, lb->d_status.p, lb->d_iters.p);
-    LadArgs A2 = lad_args(lb, nullptr, lb->d_fixed2.p, lb->d_x2.p, lb->d_status2.p, lb->d_iters2.p);
+    LadArgs A1 = lad_args(db, lb, nullptr, nullptr, lb->d_x.p, lb->d_status.p, lb->d_iters.p);
+    LadArgs A2 = lad_args(db, lb, nullptr, lb->d_fixed2.p, lb->d_x2.p, lb->d_status2.p, lb->d_iters2.p);
     SecondFilterArgs F = second_filter_args(db, lb, fc, lb->d_x.p, lb->d_status.p, lb->d_fixed2.p, lb->d_need2.p);
     {
         KTimer t(ctx, "lad_solve_kernel");
-        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
-        else hipLaunchKernelGGL((lad_pair_kernel<LAD_MAXP>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        else hipLaunchKernelGGL((lad_pair_kernel<LAD_MAXP, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        if (lb->n_wide) hipLaunchKernelGGL((lad_pair_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
     }
     PTX_HIP(ctx, hipGetLastError());
     return objective_launch(ctx, db, lb, lb->d_need2.p, lb->d_x.p, lb->d_x2.p, lb->d_obj.p, lb->d_obj2.p);
@@ -1615,11 +1813,12 @@ int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const 
 int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x,
                      double *d_obj, int32_t *d_status, int32_t *d_iters) {
     const uint32_t S = db->S;
-    LadArgs A = lad_args(lb, d_need, d_fixed, d_x, d_status, d_iters);
+    LadArgs A = lad_args(db, lb, d_need, d_fixed, d_x, d_status, d_iters);
     {
         KTimer t(ctx, "lad_solve_kernel");
-        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
-        else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        if (lb->n_wide) hipLaunchKernelGGL((lad_solve_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A);
     }
     PTX_HIP(ctx, hipGetLastError());
     return objective_launch(ctx, db, lb, nullptr, d_x, nullptr, d_obj, nullptr);

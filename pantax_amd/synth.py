@@ -97,7 +97,8 @@ def make_species(rng, name, H, genome_len, range_start, hap_prefix, frac_snp=0.3
         glen = np.array([node_len.sum()], dtype=np.int64)
         depth = np.array([rng.lognormal(depth_mu, depth_sigma)])
         return SpeciesGraph(name, node_len, path_off, path_nodes, hap_names, range_start, range_start + n - 1, glen, depth)
-    assert H <= 63
+    if H > 63:   # strain membership no longer fits one word: the same construction on a boolean matrix
+        return _make_species_wide(rng, name, H, genome_len, range_start, hap_names, frac_snp, frac_acc, mean_len, present_frac, depth_mu, depth_sigma)
     clades = _random_clades(rng, H)
     full = (1 << H) - 1
     est_sites = int(genome_len / (mean_len * (1 - frac_snp) + frac_snp) * 1.25) + 16
@@ -131,6 +132,48 @@ def make_species(rng, name, H, genome_len, range_start, hap_prefix, frac_snp=0.3
         sel = np.nonzero((member >> np.uint64(h)) & np.uint64(1))[0].astype(np.uint32)
         paths.append(sel)
         glen[h] = nlen[sel].sum()
+    path_off = np.zeros(H + 1, dtype=np.uint64)
+    path_off[1:] = np.cumsum([len(p) for p in paths])
+    path_nodes = np.concatenate(paths).astype(np.uint32)
+    n_present = max(1, int(round(present_frac * H)))
+    present = rng.choice(H, size=n_present, replace=False)
+    depth = np.zeros(H)
+    depth[present] = rng.lognormal(depth_mu, depth_sigma, size=n_present)
+    return SpeciesGraph(name, nlen, path_off, path_nodes, hap_names, range_start, range_start + V - 1, glen, depth)
+
+
+def _make_species_wide(rng, name, H, genome_len, range_start, hap_names, frac_snp, frac_acc, mean_len, present_frac, depth_mu, depth_sigma):
+    """make_species for more than 63 strains (membership as a nodes x strains boolean matrix instead of one word per node)."""
+    clades = _random_clades(rng, H)                      # Python integers: any number of strains
+    cb = np.zeros((len(clades), H), dtype=bool)
+    for i, m in enumerate(clades):
+        for h in range(H):
+            cb[i, h] = (m >> h) & 1
+    est_sites = int(genome_len / (mean_len * (1 - frac_snp) + frac_snp) * 1.25) + 16
+    kind = rng.choice(3, size=est_sites, p=[1 - frac_snp - frac_acc, frac_snp, frac_acc])  # 0 core 1 snp 2 acc
+    kind[0] = 0
+    kind[-1] = 0
+    seg_len = np.minimum(1024, 1 + rng.geometric(1.0 / mean_len, size=est_sites)).astype(np.int64)
+    clade_pick = rng.integers(0, len(clades), size=est_sites)
+    n_nodes_site = np.where(kind == 1, 2, 1)
+    node_site = np.repeat(np.arange(est_sites), n_nodes_site)
+    first_of_site = np.concatenate([[0], np.cumsum(n_nodes_site)[:-1]])
+    is_second = np.arange(len(node_site)) - first_of_site[node_site]
+    nk = kind[node_site]
+    member = cb[clade_pick[node_site]]
+    member[nk == 0] = True
+    flip = (nk == 1) & (is_second == 1)
+    member[flip] = ~member[flip]
+    nlen = np.where(nk == 1, 1, seg_len[node_site]).astype(np.int64)
+    cum0 = np.cumsum(np.where(member[:, 0], nlen, 0))
+    cut = int(np.searchsorted(cum0, genome_len)) + 1
+    cut = min(max(cut, 8), len(nlen))
+    while cut < len(nlen) and node_site[cut] == node_site[cut - 1]:
+        cut += 1
+    member, nlen = member[:cut], nlen[:cut]
+    V = cut
+    paths = [np.nonzero(member[:, h])[0].astype(np.uint32) for h in range(H)]
+    glen = np.array([nlen[p].sum() for p in paths], dtype=np.int64)
     path_off = np.zeros(H + 1, dtype=np.uint64)
     path_off[1:] = np.cumsum([len(p) for p in paths])
     path_nodes = np.concatenate(paths).astype(np.uint32)

@@ -305,10 +305,12 @@ def test_long_walks_with_revisits(eng):
 
 
 def _paths_from_masks(mask, p):
+    """mask: (n,) uint64, or (n, nw) words for more than 64 columns."""
     offs = [0]
     nodes = []
+    m2 = mask.reshape(len(mask), -1)
     for k in range(p):
-        sel = np.nonzero((mask >> np.uint64(k)) & np.uint64(1))[0]
+        sel = np.nonzero((m2[:, k >> 6] >> np.uint64(k & 63)) & np.uint64(1))[0]
         nodes.append(sel.astype(np.uint32))
         offs.append(offs[-1] + len(sel))
     return np.array(offs, dtype=np.uint64), (np.concatenate(nodes) if nodes else np.zeros(0, dtype=np.uint32))
@@ -359,7 +361,8 @@ def test_pao_solve_vs_reference_milp_model(eng, golden_dir):
 def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     """pantax_hip_pao_solve_batch (arrays of offsets in, solutions out, host buffers): all 11 golden LPs as ONE
     batch == the same LPs solved one call at a time, objectives == SciPy-HiGHS; a species without candidates and one with
-    65 candidates sit in the same batch and only they are affected."""
+    257 candidates (beyond the four mask words of a wide species) sit in the same batch and only they are affected; a species
+    with 65 candidates in that batch is solved by the wide kernel."""
     import os
     z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
     species, fixed, objs = [], [], []
@@ -371,7 +374,7 @@ def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
         fixed.append((ub == 0).astype(np.uint8))
         objs.append(float(z["obj_%d" % i]))
     single = [eng.pao_solve(sp[0], sp[1], np.zeros(len(sp[1]), dtype=np.uint64), sp[3], sp[4], sp[5], fixed_zero=f) for sp, f in zip(species, fixed)]
-    # + a species with nothing to solve, + one beyond the 64-column word
+    # + a species with nothing to solve, + one beyond the 64-column word (wide path), + one beyond the wide path
     po2, pn2 = _paths_from_masks(np.array([1, 3, 2], dtype=np.uint64), 2)
     species.append((np.ones(3, dtype=np.int64), np.array([1.0, 2.0, 3.0]), None, po2, pn2, np.zeros(0, dtype=np.uint32)))
     fixed.append(np.zeros(0, dtype=np.uint8))
@@ -381,19 +384,26 @@ def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     po65 = np.concatenate([po65, [po65[-1] + 1]]).astype(np.uint64); pn65 = np.concatenate([pn65, [0]]).astype(np.uint32)
     species.append((np.ones(n65, dtype=np.int64), np.ones(n65), None, po65, pn65, np.arange(65)))
     fixed.append(np.zeros(65, dtype=np.uint8))
+    po257 = np.arange(258, dtype=np.uint64); pn257 = (np.arange(257) % n65).astype(np.uint32)
+    species.append((np.ones(n65, dtype=np.int64), np.ones(n65), None, po257, pn257, np.arange(257)))
+    fixed.append(np.zeros(257, dtype=np.uint8))
     batch = eng.pao_solve_batch(species, fixed)
     for i, ((x1, r1, o1, st1), (xb, rb, ob, stb, itb)) in enumerate(zip(single, batch)):
         assert st1 == 0 and stb == 0
         assert np.array_equal(x1, xb), i                                   # the same solver kernel: bit for bit
         assert o1 == pytest.approx(ob, rel=1e-13), i                       # the objective's chunked sum depends on the batch shape: last ulp
         assert ob == pytest.approx(objs[i], rel=1e-9, abs=1e-12), i
-    assert batch[-2][3] == 0 and len(batch[-2][0]) == 0
+    assert batch[-3][3] == 0 and len(batch[-3][0]) == 0
+    # 65 columns: every node on exactly one of 64 paths with a = 1, path 64 visits node 0 as well -> objective 0 at x = 1
+    x65, r65, o65, st65, it65 = batch[-2]
+    assert st65 == 0 and o65 == pytest.approx(0.0, abs=1e-12) and np.allclose(x65[:64] + np.where(np.arange(64) == 0, x65[64], 0.0), 1.0)
     assert batch[-1][3] == -4                                               # PANTAX_HIP_E_LIMIT for that species only
 
 
 def test_pao_solve_at_and_beyond_64_candidates(eng):
-    """64 candidate paths is what the membership word holds: solved (objective == the oracle's exact LAD, which SciPy-HiGHS
-    pins on the smaller golden cases); 65 is refused loudly, never approximated."""
+    """64 candidate paths is what one membership word holds: solved (objective == the oracle's exact LAD, which SciPy-HiGHS
+    pins on the golden cases); 65 goes through the wide path (four words) and gives the same optimum with an unused extra
+    column; 257 is refused loudly, never approximated."""
     from oracle import oracle as orc
     from pantax_amd.engine import PantaxHipError
     rng = np.random.default_rng(64)
@@ -414,36 +424,66 @@ def test_pao_solve_at_and_beyond_64_candidates(eng):
     assert st == 0 and sto == 0
     assert obj == pytest.approx(objo, rel=1e-9) and orc.lad_objective(mask, a, x) == pytest.approx(objo, rel=1e-9)
     assert np.all(x >= -1e-12) and np.all(x <= ub + 1e-9)
-    # one more path than the word holds
+    # one more path than the word holds: the wide path, same LP plus a column that only touches node 0
     po65 = np.concatenate([po, [po[-1] + 1]]).astype(np.uint64)
     pn65 = np.concatenate([pn, [0]]).astype(np.uint32)
+    x65, ratio65, obj65, st65 = eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po65, pn65, np.arange(65))
+    mask65 = np.zeros((n, 2), dtype=np.uint64); mask65[:, 0] = mask; mask65[0, 1] = 1
+    xo65, objo65, it65, sto65 = orc.lad_solve(mask65, a, 65, np.full(65, 1.05 * a.max()))
+    assert st65 == 0 and sto65 == 0 and obj65 == pytest.approx(objo65, rel=1e-9) and obj65 <= obj * (1 + 1e-12)
+    assert orc.lad_objective(mask65, a, x65) == pytest.approx(objo65, rel=1e-9)
+    po257 = np.arange(258, dtype=np.uint64); pn257 = (np.arange(257) % n).astype(np.uint32)
     with pytest.raises(PantaxHipError) as e:
-        eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po65, pn65, np.arange(65))
-    assert "65 candidate paths" in str(e.value)
+        eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po257, pn257, np.arange(257))
+    assert "257 candidate paths" in str(e.value)
 
 
-def test_species_with_more_than_64_candidates_is_dropped_alone(eng):
-    """A species whose first filter leaves > 64 columns (70 haplotypes, no unique trio: every walk exists twice) is
-    reported with PANTAX_HIP_E_LIMIT and loses its rows, like a failed solve in the reference (profile.rs:2999-3003);
-    the species next to it is unaffected."""
+def test_pao_solve_wide_vs_highs_golden(eng, golden_dir):
+    """More than 64 candidate columns (65 .. 256: the wide path, four mask words per node, rows grouped by a hash of the
+    words and the grouping verified, W / G of the solver in global memory) on committed SciPy-HiGHS vectors: objective
+    equal to 1e-9 relative, bounds and pinned columns respected.  The reference's matrix has no column cap
+    (profile.rs:1333-1342)."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "lp_wide_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub, objh = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], float(z["obj_%d" % i])
+        p = len(ub)
+        po, pn = _paths_from_masks(mask, p)
+        x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), po, pn, np.arange(p),
+                                          fixed_zero=(ub == 0).astype(np.uint8))
+        assert st == 0, (i, p)
+        assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
+        assert orc.lad_objective(mask, a, x) == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+
+
+@pytest.mark.parametrize("n_walks", [35, 130])
+def test_species_with_more_than_64_candidates(eng, n_walks):
+    """A species whose first filter leaves more than 64 columns (no unique trio: every walk exists twice, so every haplotype
+    is a candidate, profile.rs:1208).  70 columns: solved on the wide path, objective == the oracle's (the LP is degenerate by
+    construction -- twin columns -- so x is compared through the objective and the twin sums).  260 columns: beyond the four
+    mask words, reported with PANTAX_HIP_E_LIMIT and dropped like a failed solve in the reference (profile.rs:2999-3003).
+    The species next to it is unaffected either way."""
     from oracle import oracle as orc
     from pantax_amd import synth
     from pantax_amd.engine import metrics_to_dicts
+    nh = 2 * n_walks
     sset = synth.make_set(70, 2, 4, 20000, 20000, present_frac=0.6)
     g = sset.species[0]
     rng = np.random.default_rng(71)
     base = [g.path_nodes[int(g.path_off[h]):int(g.path_off[h + 1])] for h in range(g.n_paths)]
     walks = []
-    for k in range(35):                       # 35 different walks, each twice -> 70 haplotypes, no trio occurs once
+    for k in range(n_walks):                  # different walks, each twice -> no trio occurs once
         w = base[k % len(base)].copy()
         cut = sorted(rng.integers(3, len(w) - 3, size=2))
         w = np.concatenate([w[:cut[0]], w[cut[1]:]]) if k >= len(base) else w
         walks += [w, w]
     g.path_nodes = np.concatenate(walks).astype(np.uint32)
     g.path_off = np.concatenate([[0], np.cumsum([len(w) for w in walks])]).astype(np.uint64)
-    g.hap_names = ["GCF_9%05d.1" % i for i in range(70)]
+    g.hap_names = ["GCF_9%05d.1" % i for i in range(nh)]
     g.genome_len = np.array([int(g.node_len[w].sum()) for w in walks], dtype=np.int64)
-    g.truth_depth = np.zeros(70)
+    g.truth_depth = np.zeros(nh)
     rd = sset.reads
     eng.upload_db(sset.species)
     eng.upload_packed(rd)
@@ -451,23 +491,37 @@ def test_species_with_more_than_64_candidates_is_dropped_alone(eng):
     keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
     assert keep.all()
     abc, hap, ln, hto = eng.trio_nodes_info()
-    assert hto[70] == 0                        # no unique trio in species 0
+    assert hto[nh] == 0                        # no unique trio in species 0
     eng.get_node_abundances(fetch=False)
     met, info = eng.strain_profiling(absolute, species_active=keep)
     got = metrics_to_dicts(met, eng.H)
-    assert info[0].n_candidates == 70 and info[0].status1 != 0
-    assert all(all(v is None or v is False for v in d.values()) for d in got[:70])
-    # the oracle refuses the same species and agrees on the other one
     ref = _oracle_cov_per_species(sset, sp)
     G, T, b, c, t, na = ref[0]
-    assert orc.optimize_species(G, T, b, c, t)[0] != 0
+    assert info[0].n_candidates == nh
+    if nh > 256:
+        assert info[0].status1 == -4           # PANTAX_HIP_E_LIMIT
+        assert all(all(v is None or v is False for v in d.values()) for d in got[:nh])
+    else:
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+        assert rc_ == 0 and nc == nh and info[0].status1 == 0 and info[0].status2 == 0
+        assert info[0].obj1 == pytest.approx(o1, rel=1e-9)          # no second solve in this branch (profile.rs:1279-1283)
+        orc.abundance_constraint(absolute[0], omet)
+        od = orc.metrics_to_dicts(omet)
+        for k in range(n_walks):               # twins share their walk: only the sum of the pair is determined ...
+            for key in ("path_base_cov",):
+                assert got[2 * k][key] == pytest.approx(od[2 * k][key], rel=1e-6) and got[2 * k + 1][key] == pytest.approx(od[2 * k + 1][key], rel=1e-6)
+        # ... and not even that where different walks cover the same nodes; the objective above and the LP's own value agree
+        mask, ratio = orc.path_masks(G, np.arange(nh), c)
+        ab = np.asarray(b, dtype=np.float64) / np.asarray(sset.species[0].node_len, dtype=np.float64)   # profile.rs:980-990
+        x1 = np.array([got[h]["first_sol"] for h in range(nh)])
+        assert orc.lad_objective(mask, ab, x1) == pytest.approx(o1, rel=1e-9)
     G, T, b, c, t, na = ref[1]
     rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
     assert rc_ == 0 and info[1].status1 == 0 and info[1].n_candidates == nc
     orc.abundance_constraint(absolute[1], omet)
     for h, e in enumerate(orc.metrics_to_dicts(omet)):
         for key, ev in e.items():
-            gv = got[70 + h][key]
+            gv = got[nh + h][key]
             if ev is None or gv is None or isinstance(ev, bool):
                 assert gv == ev, (h, key, gv, ev)
             else:
@@ -534,6 +588,10 @@ def test_path_cov_ratio_beyond_f32_integer_range(eng):
     (23, 3, 5, 20000, 30000, 0.2, dict(min_depth=3)),                        # --min_depth feeds the single-path statistics only (:2941-2944)
     (25, 4, 1, 20000, 30000, 1.0, dict(min_depth=2)),                        # every species a single strain
     (26, 2, 40, 120000, 30000, 0.9, dict(fr=0.05)),                          # 30-40 LP columns per species, thousands of membership patterns
+    # more than 64 LP columns per species: the wide path (four mask words per node, W / G of the solver in global memory)
+    (27, 2, 100, 300000, 30000, 0.9, dict(fr=0.05)),                         # 80-100 columns in both species
+    (28, 3, 150, 400000, 20000, 0.8, dict(fr=0.05)),                         # wide species next to a single-strain one in one batch
+    (29, 2, 100, 150000, 30000, 0.3, dict(fr=0.2)),                          # 100 haplotypes, fewer than 64 pass the first filter: one-word path
 ])
 def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     """optimize_otu + abundace_constraint (profile.rs:2884-3070) for every species, against the oracle."""

@@ -80,6 +80,20 @@ def test_lad_vs_highs_golden(golden_dir):
             assert np.abs(x - xh).sum() <= 1e-6 * max(1.0, np.abs(xh).sum()), (i, x, xh)
 
 
+def test_lad_wide_vs_highs_golden(golden_dir):
+    """More than 64 columns (mask rows of several words): the oracle's LAD solver against SciPy-HiGHS on the committed wide
+    cases (oracle/gen_golden_wide.py): 65 .. 256 columns, pinned columns, integer ties."""
+    z = np.load(os.path.join(golden_dir, "lp_wide_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i]
+        p = len(ub)
+        x, obj, it, st = orc.lad_solve(mask, a, p, ub)
+        assert st == 0
+        assert obj == pytest.approx(float(z["obj_%d" % i]), rel=1e-9, abs=1e-12), (i, p)
+        assert orc.lad_objective(mask, a, z["x_%d" % i]) == pytest.approx(float(z["obj_%d" % i]), rel=1e-9, abs=1e-12)
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+
+
 def test_lad_degenerate_and_edge_cases():
     # no valid rows -> x = 0
     x, obj, it, st = orc.lad_solve(np.array([1, 3], dtype=np.uint64), np.zeros(2), 2, np.array([1.0, 1.0]))
