@@ -30,7 +30,7 @@ typedef enum {
     PANTAX_HIP_E_INVALID = -1,       /* bad argument */
     PANTAX_HIP_E_HIP = -2,           /* HIP runtime error (message in last_error) */
     PANTAX_HIP_E_NO_DEVICE = -3,     /* no usable gfx950 device: the product never falls back to CPU */
-    PANTAX_HIP_E_LIMIT = -4,         /* size limit of this build (e.g. > 64 candidate paths) */
+    PANTAX_HIP_E_LIMIT = -4,         /* size limit of this build (e.g. > 256 candidate paths of one species) */
     PANTAX_HIP_E_SOLVER = -5,        /* LP did not reach optimality (reference: Err(e) => species dropped, profile.rs:2999-3003) */
     PANTAX_HIP_E_IO = -6,            /* file missing / malformed (pipeline seam) */
     PANTAX_HIP_E_STATE = -7          /* stage called before its prerequisite */
