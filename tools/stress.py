@@ -19,6 +19,8 @@ n_ambiguous = 0
 for ci in range(n_cfg):
     rng = np.random.default_rng(seed0 + ci)
     S = int(rng.integers(1, 7)); H = int(rng.integers(1, 13)) if rng.random() < 0.85 else int(rng.integers(20, 45)); R = int(rng.integers(200, 60000)); L = int(rng.integers(3000, 200000))
+    if rng.random() < 0.04 or os.environ.get("STRESS_WIDE"):                # species of 70-140 strains: more than 64 LP columns (the wide path) when enough are present
+        S = int(rng.integers(1, 4)); H = int(rng.integers(70, 141)); R = int(rng.integers(100000, 400000)); L = int(rng.integers(8000, 30000))
     sample = int(rng.integers(200, 5000)) if rng.random() < 0.3 else 0      # --sample: species with more valid rows are sub-sampled
     via_images = bool(rng.random() < 0.2)                                    # db saved to / loaded from device-ready images first
     lr = bool(rng.random() < 0.25); adv = float(rng.choice([0.0, 0.001, 0.02])); pf = float(rng.choice([0.2, 0.5, 0.9]))
@@ -75,6 +77,10 @@ for ci in range(n_cfg):
             if nc and any(abs(gms[h]["first_sol"] - ems[h]["first_sol"]) > 1e-7 * max(1.0, abs(ems[h]["first_sol"])) for h in cand if gms[h]["first_sol"] is not None):
                 mask, _ = orc.path_masks(G, cand, c)
                 a = b / np.asarray(g.node_len, dtype=np.float64)
+                if sample and int((a > 0).sum()) > sample:          # the LP saw the sampled rows only (profile.rs:2738-2752)
+                    valid = np.nonzero(a > 0)[0]
+                    kept = valid[orc.sample_sorted_positions(len(valid), sample, 42)]
+                    a2 = np.zeros_like(a); a2[kept] = a[kept]; a = a2
                 xg = np.array([gms[h]["first_sol"] for h in cand])
                 degenerate = abs(orc.lad_objective(mask, a, xg) - o1) <= 1e-9 * max(1.0, abs(o1))
             for h in range(g.n_paths):
@@ -86,13 +92,21 @@ for ci in range(n_cfg):
             if degenerate or boundary:
                 n_ambiguous += 1
                 continue
+            # the second LP can have an optimal face of its own (likely with tens of columns): same first solution, same
+            # decisions, same optimal value (obj2 above), another optimal x -> what follows from second_sol is as undefined
+            # as the solver's choice of vertex
+            if nc and not np.isnan(o2):   # (after the skip above: another optimal x1 pins other columns, and LP 2 is another LP)
+                assert abs(info[s].obj2 - o2) <= 1e-9 * max(1.0, abs(o2)), "obj2 sp %d: %r vs %r" % (s, info[s].obj2, o2)
+            face2 = False
             for gm, em in zip(gms, ems):
                 for key, ev in em.items():
                     gv = gm[key]
                     if ev is None or gv is None or isinstance(ev, bool):
                         assert gv == ev, (s, key, gv, ev)
-                    else:
-                        assert abs(gv - ev) <= 1e-7 * max(1.0, abs(ev)) + 1e-9, (s, key, gv, ev)
+                    elif abs(gv - ev) > 1e-7 * max(1.0, abs(ev)) + 1e-9:
+                        assert key in ("predicted_coverage", "total_cov_diff") and not np.isnan(o2), (s, key, gv, ev)
+                        face2 = True
+            n_ambiguous += face2
         # the single-call step gives the same decisions and metrics as the stage calls
         k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len(), sample_nodes=sample)
         assert np.array_equal(k2, keep) and np.array_equal(a2, absolute), "step species"
