@@ -215,10 +215,10 @@ struct LadBatch {
 
 // scratch of trio_index_build, kept across calls (grow-only) so a rebuild costs no hipMalloc
 struct TrioScratch {
-    DevBuf<uint32_t> zero_arena;   // cnt | cursor | cursor2 | first_cnt | uniq_q: cleared by one memset per build
-    DevBuf<uint32_t> cnt, cursor, cursor2, bucket_off, scan_tmp, first_cnt, d_tot, tile_cnt, tile_base;
+    DevBuf<uint32_t> zero_arena;   // tile_cnt | uniq_q | first_cnt | cnt | cursor: the part a build needs cleared goes first
+    DevBuf<uint32_t> cnt, cursor, bucket_off, scan_tmp, first_cnt, d_tot, tile_cnt, tile_base;
     DevBuf<uint4> bucket;   // (q, b, c, global first node) per window
-    DevBuf<uint8_t> uniq_q;
+    DevBuf<uint32_t> uniq_q;       // one bit per path position: its window occurs once in the species
 };
 
 // ---- resident DB -----------------------------------------------------------------------------

@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(256) trio_count_kernel(TRIO_GRAPH_ARGS, uint32
         if (window_of(q, qend, nb, path_nodes, g, a, b, c)) atomicAdd(&cnt[g], 1u);
     }
 }
+// uniq flags of the path positions: ONE BIT per position (a byte per position cost 8x the zero-fill before every build and
+// 8x the reads of the two passes that rank the unique windows)
+__device__ __forceinline__ void uniq_mark(uint32_t *__restrict__ bits, uint32_t q) { atomicOr(&bits[q >> 5], 1u << (q & 31u)); }
 // 2. scatter windows into their bucket (slot order inside a bucket is arbitrary and irrelevant)
 __global__ void __launch_bounds__(256) trio_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ bucket_off,
                                                         uint32_t *__restrict__ cursor, uint4 *__restrict__ bucket) {
@@ -74,7 +77,7 @@ __global__ void __launch_bounds__(256) trio_fill_kernel(TRIO_GRAPH_ARGS, const u
 //    16-byte load per window instead of one per pair); only the part of a bucket that lies outside the wave's
 //    64 entries is read from memory.
 __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const uint4 *__restrict__ bucket,
-                                                        const uint32_t *__restrict__ bucket_off, uint8_t *__restrict__ uniq_q,
+                                                        const uint32_t *__restrict__ bucket_off, uint32_t *__restrict__ uniq_q,
                                                         uint32_t *__restrict__ first_cnt) {
     const int lane = threadIdx.x & 63;
     for (uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) - lane; base < n_win; base += (uint64_t)gridDim.x * 256) {
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) trio_uniq_kernel(uint64_t n_win, const ui
             for (uint64_t j = b0; j < b1 && j < base && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
             for (uint64_t j = (wend > b0 ? wend : b0); j < b1 && !dup; ++j) { const uint4 o = bucket[j]; if (o.y == me.y && o.z == me.z) dup = true; }
         }
-        if (valid && !dup) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[g], 1u); }
+        if (valid && !dup) { uniq_mark(uniq_q, me.x); atomicAdd(&first_cnt[g], 1u); }
     }
 }
 // 3'. the same test through an LDS hash table, for graphs where many haplotypes share their nodes (buckets of tens of
@@ -118,7 +121,7 @@ __device__ __forceinline__ uint32_t uniq_hash(uint32_t g, uint32_t b, uint32_t c
     return (h ^ (h >> 15)) & (UNIQ_SLOTS - 1);
 }
 __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint32_t V, const uint4 *__restrict__ bucket,
-                                                            const uint32_t *__restrict__ bucket_off, uint8_t *__restrict__ uniq_q,
+                                                            const uint32_t *__restrict__ bucket_off, uint32_t *__restrict__ uniq_q,
                                                             uint32_t *__restrict__ first_cnt) {
     __shared__ uint32_t s_g[UNIQ_CAP], s_b[UNIQ_CAP], s_c[UNIQ_CAP];
     __shared__ uint32_t s_tab[UNIQ_SLOTS], s_cnt[UNIQ_SLOTS];
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
             bool dup = false;
             for (uint32_t j = bucket_off[me.w], e = bucket_off[me.w + 1]; j < e && !dup; ++j)
                 if (j != i) { const uint4 o = bucket[j]; dup = o.y == me.y && o.z == me.z; }
-            if (!dup) { uniq_q[me.x] = 1; atomicAdd(&first_cnt[me.w], 1u); }
+            if (!dup) { uniq_mark(uniq_q, me.x); atomicAdd(&first_cnt[me.w], 1u); }
         }
         return;
     }
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
 #pragma unroll
     for (int k = 0; k < (int)(UNIQ_CAP / 256); ++k) {
         const uint32_t t = threadIdx.x + k * 256;
-        if (t < n && s_cnt[my_slot[k]] == 1u) { uniq_q[my_q[k]] = 1; atomicAdd(&first_cnt[s_g[t]], 1u); }
+        if (t < n && s_cnt[my_slot[k]] == 1u) { uniq_mark(uniq_q, my_q[k]); atomicAdd(&first_cnt[s_g[t]], 1u); }
     }
 }
 // 3''. THE DEFAULT: uniqueness by node block, no global scatter at all.  Every species' nodes are cut into blocks of
@@ -213,7 +216,7 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
 // species-local id}; entry n_blocks closes the table (a block's node count is the distance to the next block's first node).
 template <int TB_SLOTS>
 __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
-                                                        const uint32_t *__restrict__ path_nodes, uint8_t *__restrict__ uniq_q,
+                                                        const uint32_t *__restrict__ path_nodes, uint32_t *__restrict__ uniq_q,
                                                         uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err) {
     __shared__ unsigned long long s_key[TB_SLOTS];
     __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[64];
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                 for (int i = lane; i < TB_SLOTS; i += 64) {
                     const unsigned long long k = s_key[i];
                     const uint32_t q = s_q[i];
-                    if (k != TB_EMPTY && q != TB_MULTI) { uniq_q[q] = 1; atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
+                    if (k != TB_EMPTY && q != TB_MULTI) { uniq_mark(uniq_q, q); atomicAdd(&s_ncnt[(uint32_t)(k >> 54)], 1u); }
                 }
             __syncthreads();
         }
@@ -313,12 +316,12 @@ __global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const ui
 
 // 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
 //     its first unique window (rows are numbered (species, hap, position))
-// ONE WAVE per tile, four tiles per workgroup: the 1024 flag bytes of a tile are five dword loads per lane (aligned down to a
-// dword, bytes outside the tile masked off) -- a workgroup per tile spent its time being launched (2.2e5 workgroups of 1 KB
-// each: 0.29 ms for 223 MB at cfg3).
+// ONE WAVE per tile, four tiles per workgroup: the 1024 flag bits of a tile are at most 33 dwords, one per lane (bits outside
+// the tile masked off) -- a workgroup per tile spent its time being launched.
 __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
-                                                             const uint32_t *__restrict__ tile_rank, const uint8_t *__restrict__ uniq_q,
+                                                             const uint32_t *__restrict__ tile_rank, const uint32_t *__restrict__ uniq_q,
                                                              uint32_t *__restrict__ tile_cnt) {
+    static_assert(PATH_TILE <= 63 * 32, "one flag word per lane");
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n_tiles) return;
     const uint2 tile = tiles[t];
@@ -328,18 +331,12 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, c
         const uint64_t q0 = path_off[tile.x] + (uint64_t)tile.y * PATH_TILE;
         uint64_t qe = path_off[tile.x + 1];
         if (qe > q0 + PATH_TILE) qe = q0 + PATH_TILE;
-        const uint64_t a0 = q0 & ~3ull;
-        const uint32_t *words = reinterpret_cast<const uint32_t *>(uniq_q);   // the arena is dword-aligned and padded by a dword
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint64_t a = a0 + 4ull * (uint64_t)(lane + 64 * k);
-            if (a < qe) {
-                uint32_t w = words[a >> 2] & 0x01010101u;
-                // bytes a .. a+3 hold positions a .. a+3: keep those inside [q0, qe)
-                if (a < q0) w &= 0xFFFFFFFFu << (8u * (uint32_t)(q0 - a));
-                if (a + 4 > qe) w &= 0xFFFFFFFFu >> (8u * (uint32_t)(a + 4 - qe));
-                c += (uint32_t)__popc(w);
-            }
+        const uint64_t a = (q0 & ~31ull) + 32ull * (uint64_t)lane;   // first position of this lane's word
+        if (a < qe) {
+            uint32_t w = uniq_q[a >> 5];
+            if (a < q0) w &= 0xFFFFFFFFu << (uint32_t)(q0 - a);
+            if (a + 32 > qe) w &= 0xFFFFFFFFu >> (uint32_t)(a + 32 - qe);
+            c = (uint32_t)__popc(w);
         }
     }
     c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
@@ -348,9 +345,9 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, c
 // 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
 //     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
 __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
-                                                          const uint32_t *__restrict__ node_len, const uint8_t *__restrict__ uniq_q,
+                                                          const uint32_t *__restrict__ node_len, const uint32_t *__restrict__ uniq_q,
                                                           const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
-                                                          uint32_t *__restrict__ cursor, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
+                                                          uint32_t *__restrict__ cursor /* = the per-node counts; zero afterwards */, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
                                                           uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
     constexpr int NR = PATH_TILE / 256;   // rounds of 256 consecutive positions
     __shared__ uint32_t s_wave[NR][4];
@@ -368,7 +365,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const uint64_t q = qt0 + (uint64_t)r * 256 + threadIdx.x;
-        u[r] = (q < qend) ? uniq_q[q] : 0u;
+        u[r] = (q < qend) ? (uniq_q[q >> 5] >> (uint32_t)(q & 31ull)) & 1u : 0u;
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -387,7 +384,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
             const uint32_t row = carry + woff + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
             uint32_t g, a, b, c;
             window_of(q, qend, nbase, path_nodes, g, a, b, c);
-            const uint32_t j = trio_first[g] + atomicAdd(&cursor[g], 1u);
+            const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
             trio_ent[j] = make_uint4(b, c, row, 0u);
             abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
             hap_out[row] = h - (uint32_t)hap_off[sidx];
@@ -488,20 +485,23 @@ int trio_index_build(Ctx *ctx, Db *db) {
     // which uniqueness path: by node block (default) or through global buckets (species of >= 2^27 nodes, or forced)
     bool by_block = db->trio_block_ok;
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
-    // everything that must start at zero lives in one arena: cursor2 | first_cnt | tile_cnt | uniq_q (bytes) [| cnt | cursor: bucket
-    // path only -- the node-block path never touches them, and zero-filling is what this arena costs]
-    const size_t zcommon = 2 * (V + 1) + (NT + 1) + (P + 3) / 4 + 1, zwords = zcommon + (by_block ? 0 : 2 * (V + 1));
+    // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
+    // The node-block path zero-fills tile_cnt and the bits only: its kernel STORES every node's count (the blocks cover all
+    // nodes), the lookup pass counts them back down to zero in place of a cursor array, and cnt / cursor belong to the bucket
+    // path -- zero-filling is what this arena costs (0.4 GB a build at cfg3 when the flags were bytes and all of it was cleared).
+    const size_t zbits = (P + 31) / 32 + 1, zhead = (NT + 1) + zbits, zwords = zhead + (V + 1) + (by_block ? 0 : 2 * (V + 1));
     PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
-    ts.cursor2.view(ts.zero_arena.p, V + 1); ts.first_cnt.view(ts.zero_arena.p + (V + 1), V + 1);
-    ts.tile_cnt.view(ts.zero_arena.p + 2 * (V + 1), NT + 1);
-    ts.uniq_q.view(ts.zero_arena.p + 2 * (V + 1) + (NT + 1), P ? P : 1);
-    if (!by_block) { ts.cnt.view(ts.zero_arena.p + zcommon, V + 1); ts.cursor.view(ts.zero_arena.p + zcommon + (V + 1), V + 1); }
+    ts.tile_cnt.view(ts.zero_arena.p, NT + 1);
+    ts.uniq_q.view(ts.zero_arena.p + (NT + 1), zbits);
+    ts.first_cnt.view(ts.zero_arena.p + zhead, V + 1);
+    if (!by_block) { ts.cnt.view(ts.zero_arena.p + zhead + (V + 1), V + 1); ts.cursor.view(ts.zero_arena.p + zhead + 2 * (V + 1), V + 1); }
     PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
     PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
     PTX_HIP(ctx, ts.d_tot.alloc(3));
     PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, sizeof(uint32_t), ctx->stream));   // error word of trio_block_kernel
-    PTX_TRY(zero_fill(ctx, ts.zero_arena.p, zwords * sizeof(uint32_t)));
+    PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block && P ? zhead : zwords) * sizeof(uint32_t)));
+    if (by_block && P) PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p + V, 0, sizeof(uint32_t), ctx->stream));   // the closing entry of the count scan
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
     PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     uint32_t tot[3] = {0, 0, 0};
@@ -567,7 +567,7 @@ int trio_index_build(Ctx *ctx, Db *db) {
         {
             KTimer t(ctx, "trio_lookup_kernel");
             hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p,
-                               ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.cursor2.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p,
+                               ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.first_cnt.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p,
                                db->d_trio_len.p);
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,
                                db->d_hap_trio_off.p);
