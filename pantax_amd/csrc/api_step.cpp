@@ -46,8 +46,14 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     bool forked = false;
     if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
     if (!db->trio_built) {
-        PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));            // the previous step still reads the index it is about to replace
-        PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
+        // the previous step still reads the index this build replaces -- up to its first filter (strain_enqueue records the event
+        // behind it); what follows there (masks, row sort, LPs, objective) runs beside the rebuild.  Without such an event
+        // (stage calls in between) the side stream waits for everything enqueued so far.
+        if (db->trio_free_valid && !std::getenv("PANTAX_TRIO_AFTER_STEP")) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
+        else {
+            PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));
+            PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
+        }
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream2;
         const int rc = trio_index_build(ctx, db);

@@ -140,6 +140,11 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     mark();                             // a11 (no-op unless a species is larger than --sample)
     const FilterCfg fc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->shift};
     PTX_TRY(first_filter_launch(ctx, db, &lb, d_active, fc));                               // a9 decision -> LP columns
+    // nothing below reads the unique-trio tables: the NEXT step may rebuild them from here on, beside this step's row
+    // sort and LPs (api_step.cpp)
+    if (!db->ev_trio_free) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_trio_free, hipEventDisableTiming));
+    PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream));
+    db->trio_free_valid = true;
     mark();
     int pmax_bound = 1;                                                                     // mask bits of a row key: min(#haps, 64) (wide species: a 64-bit hash)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));

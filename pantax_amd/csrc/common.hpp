@@ -128,6 +128,8 @@ struct Ctx {
     DevBuf<uint64_t> d_scalars;  // small counters (n_abort, ...)
     DevBuf<uint32_t> d_scan_ws;  // chained-scan workspace: ticket + one state word per tile (primitives.hip)
     uint32_t scan_epoch = 0;
+    DevBuf<uint32_t> d_scan_ws2; // the same for scans enqueued on the side stream (they may run beside scans of the main stream)
+    uint32_t scan_epoch2 = 0;
     PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
     PinBuf pin_text;             // two pinned chunks of the GAF text upload (stage_gaf.hip)
     PinBuf pin_up;               // ring of small uploads; a step syncs at least once, far before the ring wraps
@@ -170,6 +172,8 @@ struct LadBatch {
     std::vector<uint32_t> h_cand;       // [H] at hap_off[s] + k: candidate k -> hap index within species
     DevBuf<int32_t> d_p;
     DevBuf<int32_t> d_hap_bit;          // [H] bit index of hap in its species' candidate list, -1 if none
+    DevBuf<uint32_t> d_hap_nt;          // [H] unique-trio rows of every haplotype and [S] "the species has any", copied by the first
+    DevBuf<uint8_t> d_sp_trio;          //     filter: the second filter then needs no trio table (the next step may be rebuilding them)
     DevBuf<uint64_t> d_mask;            // [V] candidate membership mask per node (the 0/1 coeff matrix, row-wise)
     DevBuf<double> d_ab;                // [V] node_abundance = bases / len  (profile.rs:980-990)
     DevBuf<unsigned long long> d_ratio; // [H*2] at 2 * (hap_off[s] + k): sum cov, sum len of candidate k (exact integers)
@@ -298,7 +302,9 @@ struct Db {
     hipEvent_t ev_step[2] = {nullptr, nullptr};   // recorded behind the last download of the step that uses the slot
     pantax_hip_step_config step_cfg[2];
     int step_enq = 0, step_col = 0, step_inflight = 0;   // slot of the next enqueue / the next collect; steps enqueued and not yet collected
-    ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); }
+    hipEvent_t ev_trio_free = nullptr;   // recorded behind the last reader of the unique-trio tables in a step: the next step's rebuild waits
+    bool trio_free_valid = false;        // for this, not for the whole previous step (its row sort and LPs run beside the rebuild)
+    ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); if (ev_trio_free) (void)hipEventDestroy(ev_trio_free); }
     // LP-row staging (lad_prepare)
     DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort
     DevBuf<uint64_t> d_ka[3], d_kb[3];

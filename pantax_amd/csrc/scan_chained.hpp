@@ -116,18 +116,22 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
     const uint32_t tile_items = big ? SCAN_TILE_BIG : SCAN_TILE_SMALL;
     const uint32_t nb = (uint32_t)((n + tile_items - 1) / tile_items);
     const size_t need = 2 + 2 * (size_t)nb;   // u32 words: ticket, pad, one u64 per tile
-    if (ctx->d_scan_ws.n < need) {
-        PTX_HIP(ctx, ctx->d_scan_ws.alloc(std::max<size_t>(need, 1u << 16)));
-        PTX_HIP(ctx, hipMemsetAsync(ctx->d_scan_ws.p, 0, ctx->d_scan_ws.bytes(), ctx->stream));
-        ctx->scan_epoch = 0;
+    // one workspace per stream: launches of one stream follow each other, a scan of the side stream may run beside one of the main stream
+    const bool side = ctx->stream == ctx->stream2;
+    DevBuf<uint32_t> &ws = side ? ctx->d_scan_ws2 : ctx->d_scan_ws;
+    uint32_t &epoch = side ? ctx->scan_epoch2 : ctx->scan_epoch;
+    if (ws.n < need) {
+        PTX_HIP(ctx, ws.alloc(std::max<size_t>(need, 1u << 16)));
+        PTX_HIP(ctx, hipMemsetAsync(ws.p, 0, ws.bytes(), ctx->stream));
+        epoch = 0;
     }
-    if (++ctx->scan_epoch >= (1u << 30)) {   // epoch field wrapped: start over with a clean workspace
-        PTX_HIP(ctx, hipMemsetAsync(ctx->d_scan_ws.p, 0, ctx->d_scan_ws.bytes(), ctx->stream));
-        ctx->scan_epoch = 1;
+    if (++epoch >= (1u << 30)) {   // epoch field wrapped: start over with a clean workspace
+        PTX_HIP(ctx, hipMemsetAsync(ws.p, 0, ws.bytes(), ctx->stream));
+        epoch = 1;
     }
     KTimer t(ctx, timer_name);
-    if (big) hipLaunchKernelGGL((scan_chained_kernel<512, 16, Load, Store>), dim3(nb), dim3(512), 0, ctx->stream, load, store, n, ctx->d_scan_ws.p, ctx->scan_epoch, d_total);
-    else hipLaunchKernelGGL((scan_chained_kernel<256, 8, Load, Store>), dim3(nb), dim3(256), 0, ctx->stream, load, store, n, ctx->d_scan_ws.p, ctx->scan_epoch, d_total);
+    if (big) hipLaunchKernelGGL((scan_chained_kernel<512, 16, Load, Store>), dim3(nb), dim3(512), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
+    else hipLaunchKernelGGL((scan_chained_kernel<256, 8, Load, Store>), dim3(nb), dim3(256), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -611,6 +611,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     if (!rd->grouped) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: these reads are a slice kept as plain columns (to be routed to their owner), not resident reads");
     if (!db->cov_prepared) PTX_TRY(coverage_prepare(ctx, db, rd, with_trio));
     db->cov_prepared = false;
+    db->trio_free_valid = false;   // a reader of the unique-trio tables goes onto the stream: the event of an earlier strain step no longer covers them
     unsigned long long *d_abort = db->d_abort;
     if (rd->R && rd->T_pad) {
         // U groups of 64 steps in flight per wave, PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another

@@ -830,11 +830,13 @@ __device__ __forceinline__ double d_round2(double x) { return round(x * 100.0) /
 __global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint8_t *__restrict__ active, const uint64_t *__restrict__ hap_off,
                                                           const uint64_t *__restrict__ hto, const uint32_t *__restrict__ nnz,
                                                           const double *__restrict__ meanf, const uint8_t *__restrict__ all_same, double fr,
-                                                          int shift, int32_t *__restrict__ hap_bit, int32_t *__restrict__ sp_p) {
+                                                          int shift, int32_t *__restrict__ hap_bit, int32_t *__restrict__ sp_p,
+                                                          uint32_t *__restrict__ hap_nt, uint8_t *__restrict__ sp_trio) {
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
     if (s >= S) return;
     const uint64_t h0 = hap_off[s], h1 = hap_off[s + 1];
-    for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1;
+    for (uint64_t h = h0; h < h1; ++h) { hap_bit[h] = -1; hap_nt[h] = (uint32_t)(hto[h + 1] - hto[h]); }
+    sp_trio[s] = hto[h1] != hto[h0];
     int p = 0;
     if (h1 > h0 && !(active && !active[s])) {
         const uint64_t Hs = h1 - h0, Us = hto[h1] - hto[h0];
@@ -861,7 +863,9 @@ __global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint
 
 // second_filter_paths (profile.rs:1229-1285): which columns are pinned to zero in the second solve
 struct SecondFilterArgs {
-    const uint64_t *hap_off, *hto;
+    const uint64_t *hap_off;
+    const uint32_t *hap_nt;      // [H] unique-trio rows per haplotype, [S] any in the species: the first filter's copies
+    const uint8_t *sp_trio;
     const int32_t *hap_bit, *sp_p;
     const uint32_t *nnz;
     const double *meanf;
@@ -877,7 +881,7 @@ __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F,
     const uint64_t h0 = F.hap_off[s], h1 = F.hap_off[s + 1];
     uint8_t need = 0;
     for (uint64_t h = h0; h < h1; ++h) F.fixed2[h] = 0;   // column k of the species lives at h0 + k
-    if (F.sp_p[s] > 0 && F.status1[s] == 0 && (h1 - h0) != 1 && F.hto[h1] - F.hto[h0] > 0) {
+    if (F.sp_p[s] > 0 && F.status1[s] == 0 && (h1 - h0) != 1 && F.sp_trio[s]) {
         for (uint64_t h = h0; h < h1; ++h) {
             const int k = F.hap_bit[h];
             if (k < 0) continue;
@@ -888,7 +892,7 @@ __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F,
                 const double f = d_round2(fabs(sol - fm) / (sol + fm));
                 if (f > F.fc) {
                     if (f <= 0.6) {
-                        const double frac_r = d_round2((double)F.nnz[h] / (double)(F.hto[h + 1] - F.hto[h]));
+                        const double frac_r = d_round2((double)F.nnz[h] / (double)F.hap_nt[h]);
                         const float cov = (float)F.ratio[(h0 + k) * 2], len = (float)F.ratio[(h0 + k) * 2 + 1];
                         const double sc = frac_r * (double)(cov / len);
                         if (!(sc < F.sr || sol == 0.0)) keep = true;       // rescue
@@ -903,15 +907,16 @@ __device__ __forceinline__ void second_filter_species(const SecondFilterArgs &F,
 int first_filter_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_active, const FilterCfg &fc) {
     const uint32_t S = db->S;
     PTX_HIP(ctx, lb->d_hap_bit.alloc(db->H)); PTX_HIP(ctx, lb->d_p.alloc(S));
+    PTX_HIP(ctx, lb->d_hap_nt.alloc(db->H ? db->H : 1)); PTX_HIP(ctx, lb->d_sp_trio.alloc(S));
     hipLaunchKernelGGL(first_filter_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, S, d_active, db->d_hap_off.p, db->d_hap_trio_off.p,
-                       db->d_hap_nnz.p, db->d_hap_mean.p, db->d_all_same.p, fc.fr, fc.shift, lb->d_hap_bit.p, lb->d_p.p);
+                       db->d_hap_nnz.p, db->d_hap_mean.p, db->d_all_same.p, fc.fr, fc.shift, lb->d_hap_bit.p, lb->d_p.p, lb->d_hap_nt.p, lb->d_sp_trio.p);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
 static SecondFilterArgs second_filter_args(const Db *db, LadBatch *lb, const FilterCfg &fc, const double *d_x1, const int32_t *d_status1,
                                            uint8_t *d_fixed2, uint8_t *d_need2) {
     SecondFilterArgs F;
-    F.hap_off = db->d_hap_off.p; F.hto = db->d_hap_trio_off.p; F.hap_bit = lb->d_hap_bit.p; F.sp_p = lb->d_p.p; F.nnz = db->d_hap_nnz.p;
+    F.hap_off = db->d_hap_off.p; F.hap_nt = lb->d_hap_nt.p; F.sp_trio = lb->d_sp_trio.p; F.hap_bit = lb->d_hap_bit.p; F.sp_p = lb->d_p.p; F.nnz = db->d_hap_nnz.p;
     F.meanf = db->d_hap_mean.p; F.ratio = lb->d_ratio.p; F.x1 = d_x1; F.status1 = d_status1; F.fc = fc.fc; F.sr = fc.sr;
     F.fixed2 = d_fixed2; F.need2 = d_need2;
     return F;
