@@ -56,7 +56,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
         }
         hipStream_t main_stream = ctx->stream;
         ctx->stream = ctx->stream2;
-        const int rc = trio_index_build(ctx, db);
+        const int rc = trio_index_build(ctx, db, false);   // without the row-order export copies: no stage of the step reads them
         const hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream2);
         ctx->stream = main_stream;
         if (rc != 0) return rc;

@@ -266,6 +266,7 @@ struct Db {
     DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
     // unique-trio index (a7)
     bool trio_built = false;
+    bool trio_keys_built = false;   // d_trio_abc / d_trio_hap (row-order export copies) were written by the last build
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
@@ -399,7 +400,8 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
-int trio_index_build(Ctx *ctx, Db *db);
+int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
+int trio_keys_ensure(Ctx *ctx, Db *db);
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run table
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)

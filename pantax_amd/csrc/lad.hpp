@@ -29,6 +29,6 @@ int strain_prezero(Ctx *ctx, Db *db);   // optional, ahead of strain_enqueue: it
 int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *d_active, int slot);   // slot: which pinned result buffer / event (0 or 1)
 int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const uint8_t *species_active, const double *species_coverage,
                   pantax_hip_hap_metrics *met, pantax_hip_solve_info *info_out, void (*after_wait)(void *), void *after_wait_arg, int slot);
-int trio_index_build(Ctx *ctx, Db *db);
+int trio_index_build(Ctx *ctx, Db *db, bool with_keys);
 
 }  // namespace ptx

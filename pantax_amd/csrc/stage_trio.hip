@@ -344,6 +344,10 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, c
 }
 // 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
 //     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
+// KEYS: also the export copies in row order (canonical key, owner haplotype) that pantax_hip_trio_get and the db images hand
+// out; no stage of the step reads them (the key is in the lookup entry, the owner follows from hap_trio_off), so a step's
+// rebuild leaves them out (16 of the 36 bytes written per window) and the two exporters rebuild with them on demand.
+template <bool KEYS>
 __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
                                                           const uint32_t *__restrict__ node_len, const uint32_t *__restrict__ uniq_q,
                                                           const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
@@ -386,8 +390,10 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
             window_of(q, qend, nbase, path_nodes, g, a, b, c);
             const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
             trio_ent[j] = make_uint4(b, c, row, 0u);
-            abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-            hap_out[row] = h - (uint32_t)hap_off[sidx];
+            if (KEYS) {
+                abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
+                hap_out[row] = h - (uint32_t)hap_off[sidx];
+            }
             len_out[row] = node_len[nbase + a] + node_len[nbase + b] + node_len[nbase + c];   // profile.rs:712
         }
         carry += tot;
@@ -476,8 +482,9 @@ int trio_runs_build(Ctx *ctx, Db *db) {
     return 0;
 }
 
-int trio_index_build(Ctx *ctx, Db *db) {
+int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     const uint64_t P = db->P, V = db->V;
+    db->trio_keys_built = false;
     const uint32_t H = (uint32_t)db->H;
     if (P >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu path steps exceed 32-bit positions", (unsigned long long)P);
     TrioScratch &ts = db->trio_scratch;
@@ -566,9 +573,11 @@ int trio_index_build(Ctx *ctx, Db *db) {
         PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
         {
             KTimer t(ctx, "trio_lookup_kernel");
-            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p,
-                               ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.first_cnt.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p,
-                               db->d_trio_len.p);
+#define LOOKUP_ARGS TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p, ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.first_cnt.p, \
+                    db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p
+            if (with_keys) hipLaunchKernelGGL(trio_lookup_kernel<true>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
+            else hipLaunchKernelGGL(trio_lookup_kernel<false>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
+#undef LOOKUP_ARGS
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,
                                db->d_hap_trio_off.p);
         }
@@ -590,8 +599,17 @@ int trio_index_build(Ctx *ctx, Db *db) {
         db->trio_sizes_known = true;
     }
     db->trio_built = true;
+    db->trio_keys_built = with_keys;
     db->cov_done = false;
     return 0;
+}
+
+// the row-order export arrays (d_trio_abc, d_trio_hap) are wanted: rebuild with them unless they are there
+int trio_keys_ensure(Ctx *ctx, Db *db) {
+    if (db->trio_built && db->trio_keys_built) return 0;
+    if (db->step_inflight) return fail(ctx, PANTAX_HIP_E_STATE, "trio tables: %d enqueued step(s) of this db have not been collected", db->step_inflight);
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a step's rebuild on the side stream is over before the tables are replaced
+    return trio_index_build(ctx, db, true);
 }
 
 }  // namespace ptx
@@ -612,6 +630,11 @@ int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *db, uint32_t *
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "trio_get: call pantax_hip_trio_index first");
     PTX_ENTER(ctx);
+    if ((abc_out || hap_out) && !db->trio_keys_built) {   // the last build was a step's (no export copies): same tables, with them
+        const bool cov_done = db->cov_done;
+        PTX_TRY(trio_keys_ensure(ctx, const_cast<pantax_hip_db *>(db)));
+        const_cast<pantax_hip_db *>(db)->cov_done = cov_done;   // the rebuilt index is the same index: coverage results stay valid
+    }
     std::vector<uint32_t> len32;
     if (abc_out && db->U) PTX_TRY(download(ctx, abc_out, db->d_trio_abc.p, 3 * db->U));
     if (hap_out && db->U) PTX_TRY(download(ctx, hap_out, db->d_trio_hap.p, db->U));
