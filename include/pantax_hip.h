@@ -213,9 +213,10 @@ int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_r
 /* The same step in two halves, for a caller that streams samples: `enqueue` puts the whole step on the device and returns
  * without waiting; `collect` takes the OLDEST enqueued step of the db: its one host wait, the reporting arithmetic and the
  * a15 filters (outputs as above).  Up to two steps of a db may be in flight, so step i+1 can be enqueued before step i is
- * collected and the device never waits for the host between two steps.  The device still runs the steps strictly one after
- * the other -- no kernel of step i+1 starts before the last kernel of step i -- so every step computes what the one-call form
- * computes; `reads` / `avg_len` of an enqueued step must stay valid until its collect (avg_len is copied at enqueue). */
+ * collected and the device never waits for the host between two steps.  On the device the main-stream work of the steps runs
+ * one step after the other; only the unique-trio rebuild of step i+1 (side stream, rebuild_trio != 0) may start earlier:
+ * behind the first filter of step i -- the last reader of the index -- beside step i's masks, row sort and LPs, which read
+ * copies.  Every step computes what the one-call form computes; `reads` / `avg_len` of an enqueued step must stay valid until its collect (avg_len is copied at enqueue). */
 int pantax_hip_profile_step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
                                     const pantax_hip_step_config *cfg);
 int pantax_hip_profile_step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, double *absolute_out,

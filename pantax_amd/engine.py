@@ -301,7 +301,8 @@ class Engine:
     def profile_step_enqueue(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
                              rebuild_trio=True, sample_nodes=0):
         """First half of profile_step (pantax_hip_profile_step_enqueue): the whole step goes onto the device, nothing is waited
-        for.  Up to two steps may be in flight; the device runs them strictly one after the other."""
+        for.  Up to two steps may be in flight; the device runs their main-stream work one step after the other (the unique-trio
+        rebuild of the next step may start behind the previous step's first filter, its last reader)."""
         avg = as_c(avg_len, np.float64)
         cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio))
         self._check(self.lib.pantax_hip_profile_step_enqueue(self.ctx, self.db, self.reads, p(avg), C.byref(cfg)))

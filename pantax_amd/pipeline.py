@@ -362,8 +362,8 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
                             next_input=None):
     """n_steps passes back to back (a stream of samples) without the device ever waiting for the host between two of them:
     * step i+1 is ENQUEUED before step i is collected (pantax_hip_profile_step_enqueue / _collect, two result slots): the
-      device runs the steps strictly one after the other -- the unique-trio build of step i+1 waits for the last kernel of
-      step i -- but the ~60 launches of a step, the host wait, the parsing of the result arena and the Python around the
+      device runs the main-stream work of the steps one after the other -- only the unique-trio rebuild of step i+1 starts
+      earlier, behind step i's first filter (the index's last reader) -- and the ~60 launches of a step, the host wait, the parsing of the result arena and the Python around the
       call no longer sit between two steps' kernels;
     * from PIPELINE_THREAD_MIN_HAPS strains per rank on, everything that follows a step's collect -- packing the slab, the
       one all-reduce, the normalisers and the tables (~0.6 ms of host code for 1000 strains) -- runs on a helper thread;
