@@ -13,6 +13,8 @@
 // The solver is an exact active-set (Bloomfield-Steiger / Barrodale-Roberts) descent on that
 // representation, one workgroup per species, all species of the batch in one launch.
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include "lad.hpp"
 #include "row_sample.hpp"
 #include "primitives.hpp"
@@ -929,7 +931,16 @@ constexpr int LAD_KWIDE = 16;    // patterns up to which a wave searches coopera
 constexpr int LAD_KLDS = 256;    // patterns whose solver state fits the LDS arrays (72 B each); more go through global scratch
 enum { C_LB = 0, C_UB = 1, C_PAT = 2, C_FIXED = 3 };
 
+// -DLAD_PROFILE (tools/lad_phase_probe.sh builds such a library beside the product): thread 0 of every solver workgroup adds
+// the 100-MHz wall clock spent in each phase of a pivot to prof[species * 16 + phase] and counts the visits in [+ 8 + phase].
+#ifdef LAD_PROFILE
+#define LAD_TICK(ph) do { if (tid == 0 && A.prof) { const unsigned long long now_ = wall_clock64(); A.prof[(size_t)s * 16 + (ph)] += now_ - t_prev_; \
+                                                     A.prof[(size_t)s * 16 + 8 + (ph)] += 1; t_prev_ = now_; } } while (0)
+#else
+#define LAD_TICK(ph) do { } while (0)
+#endif
 struct LadArgs {
+    unsigned long long *prof;   // LAD_PROFILE builds only (null otherwise)
     const double *row_a;
     const uint64_t *pat_mask;
     const uint32_t *pat_start;
@@ -1002,8 +1013,8 @@ __device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double
         __syncthreads();                                                                                                   \
         const uint32_t total = L_coff[k1 - k0];                                                                            \
         for (uint32_t e = tid; e < total; e += LAD_BLOCK) {                                                                \
-            uint32_t kk = 0;                                                                                               \
-            while (kk + 1 < k1 - k0 && L_coff[kk + 1] <= e) ++kk;                                                          \
+            uint32_t kk = 0, kh = k1 - k0;   /* last pattern whose first cached row is <= e (empty patterns repeat offsets) */  \
+            while (kh - kk > 1) { const uint32_t km_ = (kk + kh) >> 1; if (L_coff[km_] <= e) kk = km_; else kh = km_; }         \
             L_cache[e] = ra.a[L_crow0[kk] + (e - L_coff[kk])];                                                             \
         }                                                                                                                  \
         __syncthreads();                                                                                                   \
@@ -1014,7 +1025,11 @@ __device__ __forceinline__ void crossed_range(bool COOP, const RowIdx &a, double
 template <int PS, int NW>
 struct LadLds {
     static constexpr uint32_t IDX_N = PS <= 16 ? 4096 : 2048;     // samples of the row index (the 64-column instance spends its LDS on W and G)
-    static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : 512;    // cached candidate rows of a line search
+    // cached candidate rows of a line search.  The 64-column instance has no LDS to spare, but its elimination scratch G is idle
+    // between two basis updates: the cache of a line search lives there (8192 rows instead of 512: with a hundred patterns the
+    // sample-only rounds leave a few thousand candidates, and the exact rounds then run in LDS instead of in memory)
+    static constexpr bool CACHE_IN_G = NW == 1 && PS > 16;
+    static constexpr uint32_t CACHE_N = PS <= 16 ? 2048 : CACHE_IN_G ? PS * 2 * PS : 512;
     LadShared<PS> sh;
     double W[NW == 1 ? PS * PS : 1];          // wide species: W and G in global scratch (LadArgs::wide_W / wide_G)
     double G[NW == 1 ? PS * 2 * PS : 1];
@@ -1023,7 +1038,7 @@ struct LadLds {
     uint64_t L_mask[LAD_KLDS];
     uint32_t L_lo[LAD_KLDS], L_up[LAD_KLDS], L_lslo[LAD_KLDS], L_lshi[LAD_KLDS], L_lsmid[LAD_KLDS], L_start[LAD_KLDS + 1];
     double L_idx[IDX_N];      // top level of every row search: every (1 << shift)-th row of the species' sorted rows
-    double L_cache[CACHE_N];
+    double L_cache[CACHE_IN_G ? 1 : CACHE_N];
     uint32_t L_lsmid2[LAD_KLDS], L_coff[LAD_KLDS + 1], L_cn[LAD_KLDS], L_crow0[LAD_KLDS];
     // wide rounds of the line search (species with at most LAD_KWIDE patterns): crossed-count bounds of every
     // pattern at 64 pivots, and the per-wave slope contributions at those pivots
@@ -1046,7 +1061,8 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         patw = A.pat_or + (size_t)A.wide_off[s] * NW;
     }
     const uint64_t c0 = A.col_off[s];
-    double *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache = m.L_cache;
+    double *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache;
+    if constexpr (LadLds<PS, NW>::CACHE_IN_G) L_cache = m.G; else L_cache = m.L_cache;
     uint64_t *L_mask = m.L_mask;
     uint32_t *L_lo = m.L_lo, *L_up = m.L_up, *L_lslo = m.L_lslo, *L_lshi = m.L_lshi, *L_lsmid = m.L_lsmid, *L_start = m.L_start,
              *L_lsmid2 = m.L_lsmid2, *L_coff = m.L_coff, *L_cn = m.L_cn, *L_crow0 = m.L_crow0;
@@ -1104,6 +1120,9 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
     const int max_it = 200 * p + 2000;
     int it = 0;
     const bool skip = NW > 1 && sh.done;   // (block-uniform: written before the barrier above)
+#ifdef LAD_PROFILE
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     for (; it < max_it && !skip; ++it) {
         // ---- vertex of the perturbed problem: x = W c
         if (tid < p) {
@@ -1111,11 +1130,21 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra.a[sh.act_i0[tid]] + P_pat_eps[sh.act_jk[tid] - kofs] : 0.0;
         }
         __syncthreads();
-        if (tid < p) {
-            double v = 0.0;
-            for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
-            sh.x[tid] = v;
-            sh.g[tid] = 0;
+        if constexpr (NW == 1) {
+            if (tid < p) {
+                double v = 0.0;
+                for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
+                sh.x[tid] = v;
+                sh.g[tid] = 0;
+            }
+        } else {
+            // W lives in global memory: a wave per row, lanes along the row (coalesced), instead of a thread per row
+            for (int j = tid >> 6; j < p; j += LAD_BLOCK / 64) {
+                double v = 0.0;
+                for (int i = tid & 63; i < p; i += 64) v += W[j * PS + i] * sh.c[i];
+                v = wave_reduce(v, [](double x_, double y_) { return x_ + y_; });
+                if ((tid & 63) == 0) { sh.x[j] = v; sh.g[j] = 0; }
+            }
         }
         __syncthreads();
         // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
@@ -1148,6 +1177,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             }
         }
         __syncthreads();
+        LAD_TICK(0);
         // ---- multipliers lam_i = -g . W[:,i]; steepest-edge choice of the constraint to relax
         if (tid < p) {
             double sdot = 0.0, nrm = 0.0;
@@ -1183,6 +1213,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             }
             sh.tmax = tmax; sh.bj = bj; sh.btype = bt;
         }
+        LAD_TICK(1);
         // ---- line search set-up: rate rho_k of every pattern along d
         double part = 0.0;
         PAT_LOOP(k) {
@@ -1200,6 +1231,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         if (tid == 0) { sh.ent_type = -1; sh.S_lo = S0; }
         __syncthreads();
         const double tmax = sh.tmax;
+        LAD_TICK(2);
         if (S0 >= -tol) {
             // degenerate: an unsplit tie group blocks the move at t = 0 -> it enters (step length 0)
             double tb = INFINITY; int kb = 0x7fffffff;
@@ -1245,6 +1277,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
                 }
                 __syncthreads();
             } else {
+                LAD_TICK(3);
                 // ---- narrow the bracket.  Rounds alternate between two pivots so that the search is
                 // both scale-free and robust to many patterns: (even) the median remaining breakpoint of
                 // the pattern that still holds the most weighted candidates, (odd) the midpoint in t.
@@ -1357,6 +1390,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
                     if (exact) approx = false;
                     __syncthreads();   // bracket state written by the owning waves is read by everyone below
                 }
+                LAD_TICK(4);
                 // After finished wide rounds the walk starts at once (few tie groups are left); should it not close within
                 // a few dozen groups, the binary rounds narrow further and the walk runs again without a cap.
                 for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1480,6 +1514,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
                     if (go_hi) { t_hi = t_mid; S_hi = S_mid; } else { t_lo = t_mid; S_lo = S_mid; }
                 }
                 (void)S_hi; (void)S_lo;
+                LAD_TICK(5);
                 // slope of the crossed set the walk starts from (sample-only rounds leave lower bounds in ls_lo, so
                 // it is recomputed from the counts; with exact counts it equals the slope at t_lo)
                 {
@@ -1553,6 +1588,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
 #undef RK
             }
         }
+        LAD_TICK(6);
         if (sh.done) break;
         if (sh.ent_type < 0) { if (tid == 0) { sh.status = 6; sh.done = 1; } __syncthreads(); break; }
         // ---- pivot: constraint `best` leaves, the entering one takes its slot; W = N^-1 by Gauss-Jordan
@@ -1611,26 +1647,35 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             G[r * 2 * PS + cc] = v;
         }
         __syncthreads();
+        static_assert(PS <= LAD_BLOCK, "one matrix row per thread in the pivot search");
         for (int col = 0; col < p; ++col) {
-            if (tid == 0) {
-                int piv = col; double bestv = fabs(G[col * 2 * PS + col]);
-                for (int r = col + 1; r < p; ++r) { double v = fabs(G[r * 2 * PS + col]); if (v > bestv) { bestv = v; piv = r; } }
-                sh.piv = piv;
-                if (bestv < 1e-12) { sh.status = 3; sh.done = 1; }
+            // partial pivoting, all rows at once: thread r loads G[r][col] (its elimination factor as well), rows >= col compete
+            // for the largest magnitude (ties: the smallest row, as a serial scan would choose); three barriers per column
+            double v = 0.0, cand_v = 0.0;
+            int cand_r = 0x7fffffff;
+            if (tid < p) { v = G[tid * 2 * PS + col]; sh.fac[tid] = v; if (tid >= col) { cand_v = v; cand_r = tid; } }
+            wave_reduce_pair(cand_v, cand_r, [](double v2, int r2, double v1, int r1) { return r2 != 0x7fffffff && (r1 == 0x7fffffff || fabs(v2) > fabs(v1) || (fabs(v2) == fabs(v1) && r2 < r1)); });
+            if ((tid & 63) == 0) { sh.red_t[tid >> 6] = cand_v; sh.red_k[tid >> 6] = cand_r; }
+            __syncthreads();
+            double pv = sh.red_t[0]; int piv = sh.red_k[0];
+#pragma unroll
+            for (int w = 1; w < LAD_BLOCK / 64; ++w) {
+                const double v2 = sh.red_t[w]; const int r2 = sh.red_k[w];
+                if (r2 != 0x7fffffff && (piv == 0x7fffffff || fabs(v2) > fabs(pv) || (fabs(v2) == fabs(pv) && r2 < piv))) { pv = v2; piv = r2; }
             }
-            __syncthreads();
-            if (sh.done) break;
-            int piv = sh.piv;
-            if (piv != col) for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) { double t = G[col * 2 * PS + c2]; G[col * 2 * PS + c2] = G[piv * 2 * PS + c2]; G[piv * 2 * PS + c2] = t; }
-            __syncthreads();
-            double dinv = 1.0 / G[col * 2 * PS + col];
-            if (tid < p) sh.fac[tid] = G[tid * 2 * PS + col];
-            __syncthreads();
-            for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) G[col * 2 * PS + c2] *= dinv;
+            if (!(fabs(pv) >= 1e-12)) { if (tid == 0) { sh.status = 3; sh.done = 1; } __syncthreads(); break; }   // (block-uniform)
+            const double dinv = 1.0 / pv;
+            // row `piv` scaled becomes row `col`; the old row `col` moves to `piv`
+            for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) {
+                const double a_ = G[col * 2 * PS + c2], b_ = G[piv * 2 * PS + c2];
+                G[col * 2 * PS + c2] = b_ * dinv;
+                if (piv != col) G[piv * 2 * PS + c2] = a_;
+            }
+            const double f_colrow = sh.fac[col];   // the factor of the row that now sits at `piv`
             __syncthreads();
             for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
-                int r = i / (2 * p), cc = i % (2 * p);
-                if (r != col) G[r * 2 * PS + cc] -= sh.fac[r] * G[col * 2 * PS + cc];
+                const int r = i / (2 * p), cc = i % (2 * p);
+                if (r != col) G[r * 2 * PS + cc] -= (r == piv ? f_colrow : sh.fac[r]) * G[col * 2 * PS + cc];
             }
             __syncthreads();
         }
@@ -1638,6 +1683,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = G[(i / p) * 2 * PS + p + (i % p)];
         __syncthreads();
         }   // refactor
+        LAD_TICK(7);
     }
     // ---- final vertex with the UNPERTURBED right-hand sides, clipped to the box
     __syncthreads();
@@ -1789,6 +1835,7 @@ static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t 
 
 static LadArgs lad_args(const Db *db, LadBatch *lb, const uint8_t *d_need, const uint8_t *d_fixed, double *d_x, int32_t *d_status, int32_t *d_iters) {
     LadArgs A;
+    A.prof = nullptr;
     A.row_a = lb->row_a; A.pat_mask = lb->d_pat_mask.p; A.pat_start = lb->d_pat_start.p; A.sp_pat_off = lb->d_sp_pat_off.p;
     A.pat_eps = lb->d_pat_eps.p; A.sc_s = lb->d_sc_s.p; A.sc_rho = lb->d_sc_rho.p;
     A.sc_lo = lb->d_sc_lo.p; A.sc_up = lb->d_sc_up.p; A.ls_lo = lb->d_ls_lo.p; A.ls_hi = lb->d_ls_hi.p; A.ls_mid = lb->d_ls_mid.p;
@@ -1799,12 +1846,45 @@ static LadArgs lad_args(const Db *db, LadBatch *lb, const uint8_t *d_need, const
     return A;
 }
 
+#ifdef LAD_PROFILE
+// phase table of the solver workgroups (profiling builds): zeroed before the launch, printed after it
+static const char *const LAD_PHASE_NAMES[8] = {"vertex+pattern pass", "multipliers+choice", "line-search setup", "bracket", "wide rounds",
+                                               "binary rounds", "walk", "basis update"};
+static int lad_prof_begin(Ctx *ctx, uint32_t S, DevBuf<unsigned long long> &buf, LadArgs &A) {
+    PTX_HIP(ctx, buf.alloc((size_t)S * 16));
+    PTX_HIP(ctx, hipMemsetAsync(buf.p, 0, buf.bytes(), ctx->stream));
+    A.prof = buf.p;
+    return 0;
+}
+static int lad_prof_end(Ctx *ctx, uint32_t S, DevBuf<unsigned long long> &buf, const int32_t *d_iters) {
+    std::vector<unsigned long long> h((size_t)S * 16);
+    std::vector<int32_t> it(S);
+    PTX_TRY(download(ctx, h.data(), buf.p, h.size()));
+    PTX_TRY(download(ctx, it.data(), d_iters, S));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t s = 0; s < S && s < 4; ++s) {
+        unsigned long long tot = 0;
+        for (int ph = 0; ph < 8; ++ph) tot += h[(size_t)s * 16 + ph];
+        if (!tot) continue;
+        std::fprintf(stderr, "[lad profile] species %u: %d pivots, %.1f us in the pivot loop (%.1f us per pivot)\n", s, it[s], tot * 0.01, it[s] ? tot * 0.01 / it[s] : 0.0);
+        for (int ph = 0; ph < 8; ++ph)
+            std::fprintf(stderr, "    %-22s %9.1f us  %5.1f %%  (%llu visits, %.2f us each)\n", LAD_PHASE_NAMES[ph], h[(size_t)s * 16 + ph] * 0.01,
+                         100.0 * h[(size_t)s * 16 + ph] / tot, h[(size_t)s * 16 + 8 + ph], h[(size_t)s * 16 + 8 + ph] ? h[(size_t)s * 16 + ph] * 0.01 / h[(size_t)s * 16 + 8 + ph] : 0.0);
+    }
+    return 0;
+}
+#endif
+
 // the strain step's two solves + second filter + both objectives: two launches
 int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const FilterCfg &fc) {
     const uint32_t S = db->S;
     LadArgs A1 = lad_args(db, lb, nullptr, nullptr, lb->d_x.p, lb->d_status.p, lb->d_iters.p);
     LadArgs A2 = lad_args(db, lb, nullptr, lb->d_fixed2.p, lb->d_x2.p, lb->d_status2.p, lb->d_iters2.p);
     SecondFilterArgs F = second_filter_args(db, lb, fc, lb->d_x.p, lb->d_status.p, lb->d_fixed2.p, lb->d_need2.p);
+#ifdef LAD_PROFILE
+    DevBuf<unsigned long long> prof;
+    PTX_TRY(lad_prof_begin(ctx, S, prof, A1));   // the first solve only
+#endif
     {
         KTimer t(ctx, "lad_solve_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
@@ -1812,6 +1892,9 @@ int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const 
         if (lb->n_wide) hipLaunchKernelGGL((lad_pair_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
     }
     PTX_HIP(ctx, hipGetLastError());
+#ifdef LAD_PROFILE
+    PTX_TRY(lad_prof_end(ctx, S, prof, lb->d_iters.p));
+#endif
     return objective_launch(ctx, db, lb, lb->d_need2.p, lb->d_x.p, lb->d_x2.p, lb->d_obj.p, lb->d_obj2.p);
 }
 
@@ -1819,6 +1902,10 @@ int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const
                      double *d_obj, int32_t *d_status, int32_t *d_iters) {
     const uint32_t S = db->S;
     LadArgs A = lad_args(db, lb, d_need, d_fixed, d_x, d_status, d_iters);
+#ifdef LAD_PROFILE
+    DevBuf<unsigned long long> prof;
+    PTX_TRY(lad_prof_begin(ctx, S, prof, A));
+#endif
     {
         KTimer t(ctx, "lad_solve_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
@@ -1826,6 +1913,9 @@ int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const
         if (lb->n_wide) hipLaunchKernelGGL((lad_solve_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A);
     }
     PTX_HIP(ctx, hipGetLastError());
+#ifdef LAD_PROFILE
+    PTX_TRY(lad_prof_end(ctx, S, prof, d_iters));
+#endif
     return objective_launch(ctx, db, lb, nullptr, d_x, nullptr, d_obj, nullptr);
 }
 
