@@ -286,9 +286,11 @@ void dev_cache_trim() {
 namespace {
 // [src + off, +n) or (fd, file_off + off, n) -> pinned slot, on a few threads (about 2 MB each: the copies are memory-bound)
 void stage_chunk(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64_t n) {
-    constexpr int NTH_MAX = 16;
-    static const int NTH_HW = (int)std::max(2u, std::min<unsigned>(NTH_MAX, std::thread::hardware_concurrency() / 2));
-    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>(NTH_HW, n >> 21));
+    constexpr int NTH_MAX = 64;
+    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 16;
+    static const int PIECE_SHIFT = std::getenv("PANTAX_STAGE_PIECE_KB") ? 10 + (int)std::log2((double)std::max(64, std::atoi(std::getenv("PANTAX_STAGE_PIECE_KB")))) : 21;
+    static const int NTH_HW = (int)std::max(2u, std::min<unsigned>((unsigned)std::min(NTH_MAX, std::max(1, NTH_ENV)), std::thread::hardware_concurrency() / 2));
+    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>(NTH_HW, n >> PIECE_SHIFT));
     auto piece = [=](int t) {
         const uint64_t b = n * t / nth, e = n * (t + 1) / nth;
         if (src) { std::memcpy(slot + b, src + pos + b, e - b); return; }
@@ -307,7 +309,7 @@ void stage_chunk(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64
 
 int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_off, uint64_t size) {
     if (size == 0) return 0;
-    constexpr uint64_t CH = 16ull << 20;
+    static const uint64_t CH = (uint64_t)(std::getenv("PANTAX_STAGE_CH_MB") ? std::max(1, std::atoi(std::getenv("PANTAX_STAGE_CH_MB"))) : 16) << 20;
     if (src && size < (1ull << 20)) {   // small: not worth the staging
         PTX_HIP(ctx, hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, ctx->stream));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
