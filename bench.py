@@ -5,16 +5,21 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 binning + species counters, species profile, unique-trio index (rebuilt per step like the reference does per run,
 profile.rs:2936), node-coverage histogram, LP row grouping, the two PAO solves, filters and the abundance table.
 
-Workload at N=1 (default) = BASELINE.json configs[2], the largest single-GPU configuration:
+Workload at N=1 (default) = BASELINE.json configs[2], the largest configuration BASELINE.json writes for one GPU:
 "100 species / 1k strains, 10M Illumina GAF, 1 MI355X" (10 strains per species, 5 Mbp genomes, 150 bp
-reads, seed 20260501 + 3).  `--workload cfg2` selects configs[1] (1 species, 1M reads).  With N ranks every rank owns
-its own shard of that shape (weak scaling: N x 100 species / N x 10M reads, i.e. cfg4's 1k species / 100M reads at
-N = 8 give or take 25 %; species are independent sub-problems) and one RCCL all-reduce per step carries the
-normalisers.  `--scaling strong` instead cuts ONE set of the given size over the ranks the way the file seam does
+reads, seed 20260501 + 3).  `--workload cfg2` selects configs[1] (1 species, 1M reads); `--workload cfg4` selects
+configs[3], the 8-GPU configuration the metric is quoted on (1k species / 10k strains, 100M reads): it fits ONE MI355X
+(V = 3.2e8 nodes, P = 2.2e9 path steps, T = 7.6e8 walk steps; measured once at 74 ms per step = 1.35 Greads/s,
+profiles/r02_bench_cfg4_one_gpu_quick.json) but stays opt-in: the default run must be quick and safe on any box (a second
+cfg4 run with the CPU-baseline legs lost its GPU box before it reported, cause undetermined).  With N
+ranks every rank owns its own shard of the default shape (weak scaling: N x 100 species / N x 10M reads, i.e. cfg4's 1k
+species / 100M reads at N = 8 give or take 25 %; species are independent sub-problems) and one RCCL all-reduce per step
+carries the normalisers.  `--scaling strong` instead cuts ONE set of the given size over the ranks the way the file seam does
 (SURVEY 8e): every rank takes a 1/N slice of the READS, bins it against all species ranges, the species are packed onto
 the ranks by weight (longest processing time first, pipeline.partition_species) and the packed records travel to the
 owner of their species in one RCCL all-to-all(v) over xGMI (pipeline.route_reads) -- once, before the timed steps
-(`ingest_route`); at N = 1 it is the default workload.
+(`ingest_route`); at N = 1 it is the default workload.  Larger workloads keep the extra legs bounded: the CPU baseline runs
+on the first 25M reads (all species, all host cores), the from-GAF-text leg on the first 10M reads.
 
     python bench.py                                   # cfg3, 1 GPU
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -41,7 +46,11 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
     "cfg2": ("configs[1]: single-species E. coli-like, 10 strains, 1M short reads", 2, 1, 10, 1_000_000, 5_000_000),
     "cfg3": ("configs[2]: 100 species / 1k strains, 10M short reads", 3, 100, 10, 10_000_000, 5_000_000),
     "cfg4_share": ("configs[3] per-GPU share: 125 species / 1250 strains, 12.5M short reads", 4, 125, 10, 12_500_000, 5_000_000),
+    # the configuration BASELINE.json's metric is quoted on ("at 10k strains"): it fits ONE MI355X (~100 GB of the 288 GB)
+    "cfg4": ("configs[3]: 1k species / 10k strains, 100M short reads -- the whole 8-GPU configuration", 5, 1000, 10, 100_000_000, 5_000_000),
 }
+CPU_SAMPLE_READS = 25_000_000    # the CPU baseline runs on the first reads of a larger workload (a bounded sample, ~20-30 s of all cores)
+GAF_SAMPLE_READS = 10_000_000    # the from-GAF-text leg writes / loads at most this many reads (1.4 GB of text)
 
 
 def algorithmic_bytes(sset, n_lp_rows, U, R, T):
@@ -164,7 +173,7 @@ def highs_legs(pool, lp, sizes, tlimit):
     return pool.map(_highs_task, jobs)
 
 
-def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit):
+def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit, n_limit=None):
     """The oracle (plain-C port of the reference algorithm) on ALL host cores over the whole workload: reads binned in
     `cores` slices, then one species per worker (the reference's rayon par_iter over species, profile.rs:3297-3319)
     through trio index, coverage, filters and both LP solves (the oracle's own exact LAD solver); the reference's open
@@ -174,7 +183,7 @@ def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit):
     from oracle import oracle as orc
     rd = sset.reads
     S = len(sset.species)
-    n = rd.n_reads
+    n = min(rd.n_reads, n_limit) if n_limit else rd.n_reads     # a read prefix of a larger workload, all species
     _CPU.update(sset=sset, cfg=dict(fr=cfg.fr, fc=cfg.fc, sr=cfg.sr),
                 rs=[g.range_start for g in sset.species], re=[g.range_end for g in sset.species])
     ctx = mp.get_context("fork")
@@ -183,8 +192,8 @@ def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit):
     with ctx.Pool(cores) as pool:
         parts = pool.map(_cpu_bin_task, [(int(cuts[i]), int(cuts[i + 1])) for i in range(cores)])
     sp = np.concatenate(parts)
-    counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
-    keep, absolute, _ = orc.species_profile(sp, rd.qlen, counts, sset.avg_len())
+    counts = orc.species_counts(sp, rd.qlen[:n], rd.mapq[:n], S)
+    keep, absolute, _ = orc.species_profile(sp, rd.qlen[:n], counts, sset.avg_len())
     t_bin = time.perf_counter() - t0
     order = np.argsort(sp, kind="stable")
     cnt = np.bincount(sp[sp >= 0], minlength=S)
@@ -219,8 +228,11 @@ def cpu_baseline(sset, cfg, cores, highs_sizes, highs_tlimit):
     return dict(value=n / dt / 1e6, unit="Mreads/s", cores=cores, kind="port",
                 solver="oracle's exact active-set LAD (oracle/pantax_oracle.c, same optimum as HiGHS: tests/golden/lp_cases.npz); "
                        "HiGHS itself timed in `highs` on row samples of one species' LP",
-                sample="the whole workload: %d reads, %d species, one species per worker on %d cores (fork pool); "
-                       "binning in %d read slices" % (n, S, cores, cores),
+                sample=("the whole workload: %d reads, %d species, one species per worker on %d cores (fork pool); "
+                        "binning in %d read slices" % (n, S, cores, cores)) if n == rd.n_reads else
+                       ("the first %d of the %d reads over ALL %d species (the per-species index build does not shrink with the reads: "
+                        "Mreads/s of the sample is a lower bound of the CPU's rate on the whole workload), one species per worker on %d "
+                        "cores (fork pool); binning in %d read slices" % (n, rd.n_reads, S, cores, cores)),
                 seconds=dt,
                 phases_wall_s={"binning+species_profile": t_bin, "group_reads_by_species": t_group,
                                "per-species (trio index, coverage, filters, 2 LP solves)": dt - t_bin - t_group},
@@ -336,7 +348,7 @@ def main():
     cpu = None
     cores = args.cpu_cores or (os.cpu_count() or 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sset, cfg, cores, highs_sizes, args.highs_time_limit)
+        cpu = cpu_baseline(sset, cfg, cores, highs_sizes, args.highs_time_limit, n_limit=CPU_SAMPLE_READS)
     hard = None
     if rank == 0 and world == 1 and not args.no_hard:
         import multiprocessing as mp
@@ -480,7 +492,8 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             gp = os.path.join(td, "reads.gaf")
             t_w = time.perf_counter()
-            synth.write_gaf(sset.reads, gp)
+            n_gaf = min(n_reads, GAF_SAMPLE_READS)
+            synth.write_gaf(synth.head_reads(sset.reads, n_gaf), gp)
             write_s = time.perf_counter() - t_w
             eng.load_reads_from_gaf(gp)                      # warm (allocations, page cache)
             eng.sync()
@@ -491,10 +504,11 @@ def main():
             out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, LocalComm(), shard_max=S_max, rows_max=H_max)
             eng.sync()
             t_e2e = time.perf_counter() - t2
-            same = out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]
-            gaf_extra = {"gaf_bytes": os.path.getsize(gp), "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
-                         "end_to_end_mreads_per_s": n_reads / t_e2e / 1e6, "gaf_gb_per_s": os.path.getsize(gp) / t_load / 1e9,
-                         "tables_equal_to_packed_input_run": bool(same), "gaf_written_in_s": write_s}
+            same = (out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]) if n_gaf == n_reads else None
+            gaf_extra = {"gaf_bytes": os.path.getsize(gp), "reads": n_gaf, "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
+                         "end_to_end_mreads_per_s": n_gaf / t_e2e / 1e6, "gaf_gb_per_s": os.path.getsize(gp) / t_load / 1e9,
+                         "tables_equal_to_packed_input_run": same, "gaf_written_in_s": write_s,
+                         "note": None if n_gaf == n_reads else "the first %d reads of the workload as GAF text, against the whole resident db" % n_gaf}
     # extra: the non-trivial LP (pao_hard), timed with every launch bracketed
     if hard is not None:
         eng_h = Engine(local_rank)

@@ -445,6 +445,14 @@ def _native_gaf_writer():
     return lib
 
 
+def head_reads(reads, k):
+    """The first k reads as a PackedReads of their own (views, no copies)."""
+    k = min(int(k), reads.n_reads)
+    t = int(reads.step_off[k])
+    return PackedReads(reads.step_off[:k + 1], reads.node_id[:t], reads.strand[:t], reads.pstart[:k], reads.pend[:k], reads.qlen[:k],
+                       reads.mapq[:k], reads.plen[:k], reads.read_id[:k] if reads.read_id else [])
+
+
 def write_gaf(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1", native=True):
     """12 mandatory GAF columns + 4 fixed tags (constant column count)."""
     lib = _native_gaf_writer() if (native and not reads.read_id) else None

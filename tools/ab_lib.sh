@@ -6,7 +6,7 @@ cp $L/libpantax_hip.so $L/ab_new.so
 for round in 1 2 3; do
   for v in old new; do
     cp $L/ab_$v.so $L/libpantax_hip.so
-    timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 10 "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
+    timeout 600 python bench.py --workload ${AB_WORKLOAD:-cfg3} --no-cpu-baseline --no-hard --no-gaf --steps 10 "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
     echo "$v: $(python3 tools/bench_summary.py gpurun_out/ab_$v.json | head -1)"
   done
 done

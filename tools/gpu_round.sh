@@ -11,7 +11,7 @@ tests) ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 ) 
 triotests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q ) > gpurun_out/${tag}_tests.log 2>&1; tail -4 gpurun_out/${tag}_tests.log ;;
 newtests) ( time timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -25 gpurun_out/${tag}_tests.log ;;
 bench) ( time timeout 1200 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 1500 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err ;;
-qbench) ( time timeout 900 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 10 ) > gpurun_out/${tag}_qbench.json 2> gpurun_out/${tag}_qbench.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench.json; tail -3 gpurun_out/${tag}_qbench.err ;;
+qbench) ( time timeout 900 python bench.py --workload cfg3 --no-cpu-baseline --no-hard --no-gaf --steps 10 ) > gpurun_out/${tag}_qbench.json 2> gpurun_out/${tag}_qbench.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench.json; tail -3 gpurun_out/${tag}_qbench.err ;;
 qcovshapes) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 5 --warmup 3 > gpurun_out/${tag}_cov$sh.json 2> gpurun_out/${tag}_cov$sh.err; echo "shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov$sh.json | head -3; done ;;
 covshapes2) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 10 --warmup 3 > gpurun_out/${tag}_cov2_$sh.json 2> gpurun_out/${tag}_cov2_$sh.err; echo "cfg2 shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov2_$sh.json | head -3; done ;;
 pmctrio) bash tools/pmc_step.sh cfg3 ${tag}_trio "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAVES_EQ_64 SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES"
@@ -22,6 +22,10 @@ for k in ('trio_block_kernel','coverage_step_kernel','trio_lookup_kernel','scan_
 qbench2) ( time timeout 900 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 20 ) > gpurun_out/${tag}_qbench2.json 2> gpurun_out/${tag}_qbench2.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench2.json; tail -3 gpurun_out/${tag}_qbench2.err ;;
 covshapes) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 5 --warmup 3 > gpurun_out/${tag}_cov$sh.json 2> gpurun_out/${tag}_cov$sh.err; echo "shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov$sh.json | head -3; done ;;
 bench2) ( time timeout 600 python bench.py --workload cfg2 ) > gpurun_out/${tag}_bench_cfg2.json 2> gpurun_out/${tag}_bench_cfg2.err; tail -c 600 gpurun_out/${tag}_bench_cfg2.json; tail -3 gpurun_out/${tag}_bench_cfg2.err ;;
+qbench4) ( time timeout 900 python bench.py --workload cfg4 --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench4.json 2> gpurun_out/${tag}_qbench4.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench4.json; tail -3 gpurun_out/${tag}_qbench4.err ;;
+trace4) bash tools/kernel_trace.sh cfg4 ${tag}_cfg4 4 ;;
+pmc4) bash tools/pmc_step.sh cfg4 ${tag}_cfg4 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU"
+     python3 tools/pmc_collect.py gpurun_out/pmc_${tag}_cfg4 cfg4 gpurun_out/${tag}_pmc_cfg4.json ;;
 trace) bash tools/kernel_trace.sh cfg3 ${tag}_cfg3 6 ;;
 trace2) bash tools/kernel_trace.sh cfg2 ${tag}_cfg2 10 ;;
 pmc) bash tools/pmc_step.sh cfg3 ${tag}_cfg3 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"

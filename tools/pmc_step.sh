@@ -5,12 +5,14 @@
 # (a group is a space-separated counter list in quotes); results -> gpurun_out/pmc_<tag>/g<i>/, summarised by
 # tools/pmc_collect.py into profiles/r02_pmc_<workload>.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export PANTAX_SYNTH_CACHE=/tmp/pantax_synth_cache
 wl=$1; tag=$2; shift 2
+# the generated set is pickled between passes -- except cfg4's (14 GB): that one is generated again in every pass
+if [ "$wl" != cfg4 ]; then export PANTAX_SYNTH_CACHE=/tmp/pantax_synth_cache; fi
+TMO=${PMC_TIMEOUT:-400}; if [ "$wl" = cfg4 ]; then TMO=${PMC_TIMEOUT:-1200}; fi
 mkdir -p gpurun_out/pmc_$tag
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/g$i -o g$i -- python3 tools/step_driver.py $wl 2 > gpurun_out/pmc_$tag/g$i.log 2>&1
+  timeout $TMO rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/g$i -o g$i -- python3 tools/step_driver.py $wl 2 > gpurun_out/pmc_$tag/g$i.log 2>&1
   echo "group $i ($grp) rc=$?"
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling driver: uploads one bench workload and runs N resident steps (pantax_hip_profile_step), nothing else.
-usage: step_driver.py [cfg2|cfg3|cfg4_share] [n_steps] [rebuild_trio 0/1]   (set PANTAX_SYNTH_CACHE to reuse the generated set)
+usage: step_driver.py [cfg2|cfg3|cfg4_share|cfg4] [n_steps] [rebuild_trio 0/1]   (set PANTAX_SYNTH_CACHE to reuse the generated set)
 Put it directly after `--` under rocprofv3 (tools/pmc_step.sh, tools/kernel_trace.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
