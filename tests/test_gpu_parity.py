@@ -646,6 +646,54 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S", [1000, 1024, 1025, 1500])
+def test_a_thousand_species_in_one_step(eng, S):
+    """Many species on one device (BASELINE configs[3] has 1000): the binning kernel keeps its range tables and counters in
+    LDS up to 1024 species (44 KB at 1000) and in memory beyond; every per-species launch geometry (statistics chunks, LP
+    workgroups, segmented row sort) is exercised with S in the thousands.  Species decisions and counters bit-exact, the step's
+    strain metrics against the oracle for a sample of species."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(4000 + S, S, 2, 150000, 3000, single_strain_every=4, present_frac=0.7)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    rs, re_ = [g.range_start for g in sset.species], [g.range_end for g in sset.species]
+    assert np.array_equal(sp, orc.bin_reads(rd.step_off, rd.node_id, rs, re_))
+    counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
+    assert all(np.array_equal(a, b) for a, b in zip((rc, bs, lm, uq), counts))
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    k2, a2, met, info, passed, sa, spp = eng.profile_step(sset.avg_len())
+    assert np.array_equal(k2, keep) and np.allclose(a2, absolute, rtol=1e-12, atol=0)
+    got = metrics_to_dicts(met, eng.H)
+    hb = np.cumsum([0] + [g.n_paths for g in sset.species])
+    checked = 0
+    for si in list(range(0, S, 97)) + [S - 1]:
+        if not keep[si]:
+            continue
+        g = sset.species[si]
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes); T = orc.TrioTable(G)
+        so, nid, ps, pe = select_reads(rd, np.nonzero(sp == si)[0])
+        b, c, t, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+        assert rc_ == 0 and info[si].n_candidates == nc and info[si].status1 == 0
+        if nc:
+            assert info[si].obj1 == pytest.approx(o1, rel=1e-9, abs=1e-12)
+        orc.abundance_constraint(absolute[si], omet)
+        for h, e in enumerate(orc.metrics_to_dicts(omet)):
+            for key, ev in e.items():
+                gv = got[hb[si] + h][key]
+                if ev is None or gv is None or isinstance(ev, bool):
+                    assert gv == ev, (si, h, key, gv, ev)
+                else:
+                    assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
+        checked += 1
+    assert checked >= 5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sample_nodes", [2000, 500, 1237])
 def test_strain_profiling_with_row_sampling(eng, sample_nodes):
     """--sample N (a11, profile.rs:1287-1295, :2738-2752): species with more valid rows than N solve the LP on the sampled
