@@ -646,6 +646,27 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 
 
 @pytest.mark.gpu
+def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
+    """A step's rebuild of the unique-trio index leaves out the row-order export copies (key, owner haplotype); trio_get
+    after a step rebuilds with them: same tables as the stage call gave before the step, the coverage results of the step
+    stay valid, and the next step is unaffected."""
+    from pantax_amd import synth
+    sset = synth.make_set(61, 3, 5, 20000, 30000, present_frac=0.6)
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    abc0, hap0, ln0, hto0 = eng.trio_nodes_info()
+    out1 = eng.profile_step(sset.avg_len())
+    met1 = bytes(out1[2]); keep1 = out1[0].copy()
+    abc1, hap1, ln1, hto1 = eng.trio_nodes_info()
+    assert np.array_equal(abc0, abc1) and np.array_equal(hap0, hap1) and np.array_equal(ln0, ln1) and np.array_equal(hto0, hto1)
+    bases, cov, tb, nab = eng.get_node_abundances()           # recomputed or still valid: either way the same numbers as in the step
+    out2 = eng.profile_step(sset.avg_len())
+    assert bytes(out2[2]) == met1 and np.array_equal(out2[0], keep1)
+    out3 = eng.profile_step(sset.avg_len(), rebuild_trio=False)
+    assert bytes(out3[2]) == met1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S", [1000, 1024, 1025, 1500])
 def test_a_thousand_species_in_one_step(eng, S):
     """Many species on one device (BASELINE configs[3] has 1000): the binning kernel keeps its range tables and counters in
