@@ -377,26 +377,32 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
         if (lane == 0) s_wave[r][wave] = (uint32_t)__popcll(bal[r]);
     }
     __syncthreads();
-    uint32_t carry = carry0;
+    // The unique windows are a few per cent of the positions: their tile-local ranks (the row numbers) compact them into an LDS
+    // list first, and the gathers / scatters of a window then run on DENSE lanes -- one round of 256 threads does what the
+    // four sparse rounds did with a handful of active lanes per wave each (every wave paid the full latency chain four times).
+    __shared__ uint16_t s_list[PATH_TILE];
+    uint32_t n_u = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         uint32_t woff = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[r][w]; if (w < wave) woff += t; tot += t; }
-        if (u[r]) {
-            const uint64_t q = qt0 + (uint64_t)r * 256 + threadIdx.x;
-            const uint32_t row = carry + woff + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
-            uint32_t g, a, b, c;
-            window_of(q, qend, nbase, path_nodes, g, a, b, c);
-            const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
-            trio_ent[j] = make_uint4(b, c, row, 0u);
-            if (KEYS) {
-                abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-                hap_out[row] = h - (uint32_t)hap_off[sidx];
-            }
-            len_out[row] = node_len[nbase + a] + node_len[nbase + b] + node_len[nbase + c];   // profile.rs:712
+        if (u[r]) s_list[n_u + woff + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull))] = (uint16_t)(r * 256 + (int)threadIdx.x);
+        n_u += tot;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_u; t += 256) {
+        const uint64_t q = qt0 + s_list[t];
+        const uint32_t row = carry0 + t;
+        uint32_t g, a, b, c;
+        window_of(q, qend, nbase, path_nodes, g, a, b, c);
+        const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
+        trio_ent[j] = make_uint4(b, c, row, 0u);
+        if (KEYS) {
+            abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
+            hap_out[row] = h - (uint32_t)hap_off[sidx];
         }
-        carry += tot;
+        len_out[row] = node_len[nbase + a] + node_len[nbase + b] + node_len[nbase + c];   // profile.rs:712
     }
 }
 
