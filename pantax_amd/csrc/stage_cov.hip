@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         // ---- shuffles, the trio lookup head and the first trio entry (level 4), for all groups
         uint32_t l1[U], l2[U], len0[U], tcc[U];
         uint2 th[U];
-        uint4 e0[U];
+        uint4 e0[U], e1[U];   // the first TWO lookup entries of the head: with one, 95 % of the waves held a lane whose window was
+                              // the node's second entry (8 % of the visits meet a head of two or more) and paid another dependent gather
         int dist[U];
         bool cross[U];
 #pragma unroll
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
             l1[u] = wave_shr1(l[u]); l2[u] = wave_shr1(l1[u]);
             const uint32_t tf2 = wave_shr1(wave_shr1(nr[u].w)), tn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
-            th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u);
+            th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
             if (WITH_TRIO && ok[u] && i >= 2) {
                 if (lane < 1) l1[u] = node_id[b + i - 1] - sr[u].y;
                 if (lane < 2) l2[u] = node_id[b + i - 2] - sr[u].y;
@@ -221,6 +222,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     else { const uint4 r2 = node_rec[sr[u].z + l2[u]]; th[u] = make_uint2(r2.w, r2.y >> 8); }   // wave border of a long walk
                 }
                 if (th[u].y) e0[u] = trio_ent[th[u].x];
+                if (th[u].y > 1) e1[u] = trio_ent[th[u].x + 1];
             }
             // first node length: from the lane that holds step b, else (long walk) noted by walk_sum_kernel
             const uint32_t nl_src = __shfl(nr[u].z, lane - dist[u]);
@@ -286,8 +288,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     int row = -1;
                     if (th[u].y) {
                         if (e0[u].x == l1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
+                        else if (th[u].y > 1 && e1[u].x == l1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
                         else
-                            for (uint32_t j = 1; j < th[u].y; ++j) {
+                            for (uint32_t j = 2; j < th[u].y; ++j) {
                                 const uint4 e = trio_ent[th[u].x + j];
                                 if (e.x == l1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
                             }
