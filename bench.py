@@ -568,6 +568,9 @@ def main():
                                      "O(#patterns*log n) searches per pivot)")
         # the runner-up of the timed steps, same ruler (the two are within a few per cent of each other at cfg3)
         if roofline is not None:
+            roofline["note"] = ("HIP-event durations of kernels that share the device: in a stream of steps the index rebuild of step i+1 "
+                                "(trio_block / trio_lookup, side stream, LOW priority) runs beside the tail of step i and is stretched by it; "
+                                "stand-alone times: DESIGN.md section 4")
             for k2 in top2:
                 if k2 != dom and k2 in timings and k2 in ab:
                     l2, t2 = timings[k2]
