@@ -210,6 +210,60 @@ def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.
     return rc, met, nc.value, o1.value, o2.value
 
 
+def par_bin_reads(step_off, node_id, range_start, range_end, threads):
+    """bin_reads in `threads` read slices on pthreads (oracle_parallel.c; bench.py's cpu_baseline)"""
+    step_off = np.ascontiguousarray(step_off, dtype=np.uint64)
+    node_id = np.ascontiguousarray(node_id, dtype=np.uint32)
+    rs = np.ascontiguousarray(range_start, dtype=np.int64)
+    re = np.ascontiguousarray(range_end, dtype=np.int64)
+    n = len(step_off) - 1
+    out = np.empty(n, dtype=np.int32)
+    rc = lib().orc_par_bin_reads(C.c_int(int(threads)), C.c_uint64(n), _p(step_off), _p(node_id), C.c_uint32(len(rs)), _p(rs), _p(re), _p(out))
+    assert rc == 0
+    return out
+
+
+def group_reads(species_idx, n_species):
+    """group_reads_by_species (profile.rs:439-463) as a stable counting sort -> first [S+1], order"""
+    sp = np.ascontiguousarray(species_idx, dtype=np.int32)
+    first = np.zeros(n_species + 1, dtype=np.uint64)
+    order = np.empty(len(sp), dtype=np.uint64)
+    rc = lib().orc_group_reads(C.c_uint64(len(sp)), _p(sp), C.c_uint32(n_species), _p(first), _p(order))
+    assert rc == 0
+    return first, order[: int(first[-1])]
+
+
+def par_profile_species(graphs, range_start, step_off, node_id, pstart, pend, first, order, keep, absolute, todo, threads,
+                        fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0, want_metrics=False):
+    """One species per worker thread, handed out in the order of `todo` (the rayon par_iter of profile.rs:3297-3319):
+    trio index, the species' reads, node coverage, filters + both solves, abundace_constraint -- all through the
+    single-threaded functions above.  graphs: list of Graph.  -> dict of per-species arrays (+ metrics when asked)."""
+    S = len(graphs)
+    garr = (OrcGraph * S)(*[g.c for g in graphs])
+    rs = np.ascontiguousarray(range_start, dtype=np.int64)
+    step_off = np.ascontiguousarray(step_off, dtype=np.uint64)
+    node_id = np.ascontiguousarray(node_id, dtype=np.uint32)
+    pstart = np.ascontiguousarray(pstart, dtype=np.int64)
+    pend = np.ascontiguousarray(pend, dtype=np.int64)
+    first = np.ascontiguousarray(first, dtype=np.uint64)
+    order = np.ascontiguousarray(order, dtype=np.uint64)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    absolute = np.ascontiguousarray(absolute, dtype=np.float64)
+    todo = np.ascontiguousarray(todo, dtype=np.uint32)
+    hap_off = np.zeros(S + 1, dtype=np.uint64)
+    hap_off[1:] = np.cumsum([g.n_paths for g in graphs])
+    met = (OrcHapMetrics * max(int(hap_off[-1]), 1))() if want_metrics else None
+    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes))
+    out = dict(rc=np.zeros(S, dtype=np.int32), n_cand=np.zeros(S, dtype=np.uint32), n_rows=np.zeros(S, dtype=np.uint64), obj1=np.zeros(S), obj2=np.zeros(S),
+               t_trio=np.zeros(S), t_cov=np.zeros(S), t_lp=np.zeros(S))
+    rc = lib().orc_par_profile_species(C.c_int(int(threads)), C.c_uint32(S), garr, _p(rs), _p(step_off), _p(node_id), _p(pstart), _p(pend), _p(first), _p(order),
+                                       _p(keep), _p(absolute), C.byref(cfg), C.c_uint32(len(todo)), _p(todo), _p(hap_off), met,
+                                       *[_p(out[k]) for k in ("rc", "n_cand", "n_rows", "obj1", "obj2", "t_trio", "t_cov", "t_lp")])
+    assert rc == 0
+    out["metrics"], out["hap_off"] = met, hap_off
+    return out
+
+
 def gaf_filter(text):
     """SURVEY 8f-3 (gaf_filter.rs:44-97): bool per raw line of `text` (bytes) = the line is written; also #records."""
     keep = np.zeros(text.count(b"\n") + 2, dtype=np.uint8)

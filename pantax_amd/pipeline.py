@@ -359,7 +359,7 @@ def finalize_end(pending, species_names, hap_names, cfg, comm):
 
 
 def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg=None, comm=None, shard_max=None, rows_max=None,
-                            next_input=None):
+                            next_input=None, threaded=None):
     """n_steps passes back to back (a stream of samples) without the device ever waiting for the host between two of them:
     * step i+1 is ENQUEUED before step i is collected (pantax_hip_profile_step_enqueue / _collect, two result slots): the
       device runs the main-stream work of the steps one after the other -- only the unique-trio rebuild of step i+1 starts
@@ -369,8 +369,10 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
       one all-reduce, the normalisers and the tables (~0.6 ms of host code for 1000 strains) -- runs on a helper thread;
       below that the exchange of step i is started inline and completed after step i+1's collect.
     Collectives are issued in step order on every rank.  next_input(i), if given, is called before step i is enqueued to
-    swap in that step's reads (the swap itself waits for the step that still uses the old ones).  Returns the list of
-    (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
+    swap in that step's reads (the swap itself waits for the step that still uses the old ones).  threaded: helper thread or
+    inline; with more than one rank pass a value that is the SAME on every rank (rows_max >= PIPELINE_THREAD_MIN_HAPS is what
+    bench.py passes): the default looks at this rank's own strains, and ranks of a strong-scaling run own different numbers.
+    Returns the list of (species_rows, strain_rows, stats), same as n_steps calls of profile_step."""
     cfg = cfg or StepConfig()
     comm = comm or LocalComm()
     if n_steps <= 0:
@@ -389,7 +391,8 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
         local_enqueue(eng, avg_len, cfg)
         _enq_ms.append((time.perf_counter() - t_e) * 1e3)
 
-    threaded = len(hap_names) >= PIPELINE_THREAD_MIN_HAPS
+    if threaded is None:
+        threaded = (rows_max if rows_max is not None else len(hap_names)) >= PIPELINE_THREAD_MIN_HAPS
     out, fut, pending = [], None, None
     ex = ThreadPoolExecutor(1, initializer=getattr(comm, "thread_init", None) or (lambda: None)) if threaded else None
     try:

@@ -337,6 +337,232 @@ def make_set_mp(seed, n_species, H, n_reads, genome_len, long_reads=False, adver
     return SyntheticSet(species, reads)
 
 
+# ---------------------------------------------------------------- native generator (tools/native/synth_set.c)
+N_CHUNKS = 256   # the reads of a native set come in this many independently generated chunks (ranks / samples take chunk ranges)
+
+
+def _native_set_lib():
+    """tools/native/libsynthset.so (C, built by __graft_entry__.build(); built on demand when missing)."""
+    import ctypes as C
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "native")
+    so = os.path.join(d, "libsynthset.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", d])
+    lib = C.CDLL(so)
+    lib.synth_gaf_size.restype = C.c_uint64
+    lib.synth_gaf_write_at.restype = C.c_int64
+    return lib
+
+
+class NativeSet:
+    """The synthetic set of SURVEY 8d as a pure function of (seed, species) and (seed, chunk, read) -- see synth_set.c.
+    Constructing it computes only the dimensions of every species (milliseconds each); graphs and reads are generated on
+    request, on `threads` host threads (the C calls release the GIL):
+        ns = NativeSet(seed, 1000, 10, 100_000_000, 5_000_000)
+        sset = ns.make()                      # everything: SyntheticSet(all graphs, all reads)
+        rd = ns.reads(32, 64)                 # chunks [32, 64) of N_CHUNKS: what rank 1 of 8 reads
+        gs = ns.graphs([3, 17])               # the graphs a rank owns
+    The set does not depend on the number of threads, chunks requested or ranks."""
+
+    def __init__(self, seed, n_species, H, n_reads, genome_len, long_reads=False, adversarial_frac=0.001, present_frac=0.2, read_len=150,
+                 threads=None):
+        import ctypes as C
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        if not 1 <= H <= 63:
+            raise ValueError("NativeSet: 1..63 strains per species")
+        self.lib = _native_set_lib()
+        self.seed, self.S, self.H, self.n_reads, self.genome_len = int(seed), int(n_species), int(H), int(n_reads), int(genome_len)
+        self.long_reads, self.adversarial_frac, self.read_len = bool(long_reads), float(adversarial_frac), int(read_len)
+        self.threads = threads or min(os.cpu_count() or 1, 64)
+
+        class Params(C.Structure):
+            _fields_ = [("seed", C.c_uint64), ("H", C.c_uint32), ("genome_len", C.c_int64), ("frac_snp", C.c_double), ("frac_acc", C.c_double),
+                        ("mean_len", C.c_double), ("present_frac", C.c_double), ("depth_mu", C.c_double), ("depth_sigma", C.c_double)]
+        self._par = Params(self.seed, self.H, self.genome_len, 0.30, 0.12, 32.0, float(present_frac), float(np.log(8.0)), 1.0)
+        S = self.S
+        self.V = np.zeros(S, dtype=np.uint64)
+        self.P = np.zeros(S, dtype=np.uint64)
+        self.path_len = np.zeros((S, H), dtype=np.uint64)
+        self.glen = np.zeros((S, H), dtype=np.int64)
+        self.depth = np.zeros((S, H), dtype=np.float64)
+        pv = lambda a, i: C.c_void_p(a.ctypes.data + i * a.strides[0])
+
+        def dims(s):
+            rc = self.lib.synth_species_dims(C.byref(self._par), C.c_uint32(s), pv(self.V, s), pv(self.P, s), pv(self.path_len, s), pv(self.glen, s),
+                                             pv(self.depth, s))
+            if rc != 0:
+                raise RuntimeError("synth_species_dims(%d) = %d" % (s, rc))
+        with ThreadPoolExecutor(self.threads) as ex:
+            list(ex.map(dims, range(S)))
+        self.range_start = np.ones(S, dtype=np.int64)
+        self.range_start[1:] = 1 + np.cumsum(self.V[:-1].astype(np.int64))
+        self.range_end = self.range_start + self.V.astype(np.int64) - 1
+        self.names = [str(1000 + s) for s in range(S)]
+        self._graphs = {}
+
+    def hap_names(self, s):
+        return sorted("GCF_%06d%03d.1" % (s + 1, h) for h in range(self.H))
+
+    def avg_len(self):
+        return self.glen.mean(axis=1).astype(np.float64)
+
+    def chunk_reads(self, c):
+        return self.n_reads // N_CHUNKS + (1 if c < self.n_reads % N_CHUNKS else 0)
+
+    def _graph(self, s):
+        import ctypes as C
+        g = self._graphs.get(s)
+        if g is None:
+            V, P = int(self.V[s]), int(self.P[s])
+            node_len = np.empty(V, dtype=np.int64)
+            path_off = np.empty(self.H + 1, dtype=np.uint64)
+            path_nodes = np.empty(P, dtype=np.uint32)
+            rc = self.lib.synth_species_fill(C.byref(self._par), C.c_uint32(s), C.c_uint64(V), C.c_void_p(node_len.ctypes.data),
+                                             C.c_void_p(path_off.ctypes.data), C.c_void_p(path_nodes.ctypes.data))
+            if rc != 0:
+                raise RuntimeError("synth_species_fill(%d) = %d" % (s, rc))
+            g = SpeciesGraph(self.names[s], node_len, path_off, path_nodes, self.hap_names(s), int(self.range_start[s]), int(self.range_end[s]),
+                             self.glen[s].copy(), self.depth[s].copy())
+            self._graphs[s] = g
+        return g
+
+    def graphs(self, idx=None, keep=True):
+        """SpeciesGraph objects of the species `idx` (all by default), generated on the host threads; keep=False does not
+        cache them inside the set."""
+        from concurrent.futures import ThreadPoolExecutor
+        idx = list(range(self.S)) if idx is None else [int(i) for i in idx]
+        with ThreadPoolExecutor(self.threads) as ex:
+            gs = list(ex.map(self._graph, idx))
+        if not keep:
+            for i in idx:
+                self._graphs.pop(i, None)
+        return gs
+
+    def drop_graphs(self, keep_idx=()):
+        keep_idx = set(int(i) for i in keep_idx)
+        for i in list(self._graphs):
+            if i not in keep_idx:
+                del self._graphs[i]
+
+    def reads(self, chunk_lo=0, chunk_hi=N_CHUNKS):
+        """PackedReads of chunks [chunk_lo, chunk_hi).  Needs the walks of every present strain of every species: the graphs are
+        generated (and cached; drop_graphs() frees them) first."""
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+        lib = self.lib
+        gs = self.graphs()
+        # present strains, read share = depth x genome length
+        ent = [(s, h) for s in range(self.S) for h in range(self.H) if self.depth[s, h] > 0]
+        w = np.array([self.depth[s, h] * self.glen[s, h] for s, h in ent], dtype=np.float64)
+        cum_w = np.cumsum(w) / w.sum()
+        cum_w[-1] = 1.0
+        n_st = len(ent)
+        walk_nodes = np.zeros(n_st, dtype=np.uint64)
+        walk_cum = np.zeros(n_st, dtype=np.uint64)
+        walk_len = np.zeros(n_st, dtype=np.uint64)
+        st_glen = np.zeros(n_st, dtype=np.int64)
+        st_start = np.zeros(n_st, dtype=np.int64)
+        cums = [None] * n_st
+
+        def prep(i):
+            s, h = ent[i]
+            g = gs[s]
+            b, e = int(g.path_off[h]), int(g.path_off[h + 1])
+            cum = np.empty(e - b, dtype=np.uint32)
+            lib.synth_walk_cum(C.c_void_p(g.node_len.ctypes.data), C.c_void_p(g.path_nodes.ctypes.data + 4 * b), C.c_uint64(e - b), C.c_void_p(cum.ctypes.data))
+            cums[i] = cum
+            walk_nodes[i] = g.path_nodes.ctypes.data + 4 * b
+            walk_cum[i] = cum.ctypes.data
+            walk_len[i] = e - b
+            st_glen[i] = self.glen[s, h]
+            st_start[i] = self.range_start[s]
+        with ThreadPoolExecutor(self.threads) as ex:
+            list(ex.map(prep, range(n_st)))
+
+        class Ctx(C.Structure):
+            _fields_ = [("seed", C.c_uint64), ("n_strains", C.c_uint32), ("cum_w", C.c_void_p), ("walk_nodes", C.c_void_p), ("walk_cum", C.c_void_p),
+                        ("walk_len", C.c_void_p), ("genome_len", C.c_void_p), ("range_start", C.c_void_p), ("n_species", C.c_uint32),
+                        ("species_start", C.c_void_p), ("long_reads", C.c_int32), ("read_len", C.c_int64), ("adversarial_frac", C.c_double)]
+        ctx = Ctx(self.seed, n_st, cum_w.ctypes.data, walk_nodes.ctypes.data, walk_cum.ctypes.data, walk_len.ctypes.data, st_glen.ctypes.data,
+                  st_start.ctypes.data, self.S, self.range_start.ctypes.data, int(self.long_reads), self.read_len, self.adversarial_frac)
+        chunks = list(range(int(chunk_lo), int(chunk_hi)))
+        cnt = np.array([self.chunk_reads(c) for c in chunks], dtype=np.int64)
+        first = np.concatenate([[0], np.cumsum(cnt)])
+        R = int(first[-1])
+        n_steps = np.empty(R, dtype=np.uint32)
+        at = lambda a, i: C.c_void_p(a.ctypes.data + int(i) * a.itemsize)
+
+        def count(k):
+            lib.synth_reads_count(C.byref(ctx), C.c_uint64(chunks[k]), C.c_uint64(0), C.c_uint64(int(cnt[k])), at(n_steps, first[k]))
+        with ThreadPoolExecutor(self.threads) as ex:
+            list(ex.map(count, range(len(chunks))))
+        step_off = np.zeros(R + 1, dtype=np.uint64)
+        np.cumsum(n_steps, out=step_off[1:])
+        del n_steps
+        T = int(step_off[-1])
+        node_id = np.empty(T, dtype=np.uint32)
+        strand = np.empty(T, dtype=np.uint8)
+        pstart, pend, qlen, mapq = (np.empty(R, dtype=np.int64) for _ in range(4))
+
+        def fill(k):
+            a = int(first[k])
+            lib.synth_reads_fill(C.byref(ctx), C.c_uint64(chunks[k]), C.c_uint64(0), C.c_uint64(int(cnt[k])), at(step_off, a), C.c_void_p(node_id.ctypes.data),
+                                 C.c_void_p(strand.ctypes.data), at(pstart, a), at(pend, a), at(qlen, a), at(mapq, a))
+        with ThreadPoolExecutor(self.threads) as ex:
+            list(ex.map(fill, range(len(chunks))))
+        return PackedReads(step_off, node_id, strand, pstart, pend, qlen, mapq, qlen, [])
+
+    def make(self, chunk_lo=0, chunk_hi=N_CHUNKS):
+        rd = self.reads(chunk_lo, chunk_hi)
+        return SyntheticSet(self.graphs(), rd)
+
+
+def make_set_native(seed, n_species, H, n_reads, genome_len, **kw):
+    """SyntheticSet from the native generator (all graphs, all reads)."""
+    return NativeSet(seed, n_species, H, n_reads, genome_len, **kw).make()
+
+
+def write_gaf_parallel(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1", threads=None):
+    """write_gaf on host threads (native set writer): the byte size of every slice of reads is computed first, then the slices
+    are written at their offsets of one pre-sized file.  Same bytes as write_gaf.  -> bytes written."""
+    import ctypes as C
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _native_set_lib()
+    threads = threads or min(os.cpu_count() or 1, 64)
+    R = reads.n_reads
+    a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+    so, nid, st = a(reads.step_off, np.uint64), a(reads.node_id, np.uint32), a(reads.strand, np.uint8)
+    ps, pe, ql, mq = (a(x, np.int64) for x in (reads.pstart, reads.pend, reads.qlen, reads.mapq))
+    if not np.array_equal(a(reads.plen, np.int64), ql):
+        raise ValueError("write_gaf_parallel: plen == qlen only")
+    pp = lambda x: C.c_void_p(x.ctypes.data)
+    n_sl = max(1, min(4 * threads, R // 4096 + 1))
+    cuts = np.linspace(0, R, n_sl + 1).astype(np.int64)
+    tg = tags.encode()
+
+    def size(i):
+        return lib.synth_gaf_size(C.c_uint64(int(cuts[i])), C.c_uint64(int(cuts[i + 1])), C.c_uint64(0), pp(so), pp(nid), pp(ps), pp(pe), pp(ql), pp(mq),
+                                  C.c_uint64(len(tg)))
+    with ThreadPoolExecutor(threads) as ex:
+        sizes = list(ex.map(size, range(n_sl)))
+    off = np.concatenate([[0], np.cumsum(np.array(sizes, dtype=np.int64))])
+    with open(path, "wb") as f:
+        f.truncate(int(off[-1]))
+
+    def write(i):
+        n = lib.synth_gaf_write_at(str(path).encode(), C.c_uint64(int(off[i])), C.c_uint64(int(cuts[i])), C.c_uint64(int(cuts[i + 1])), C.c_uint64(0),
+                                   pp(so), pp(nid), pp(st), pp(ps), pp(pe), pp(ql), pp(mq), tg)
+        if n != sizes[i]:
+            raise IOError("synth_gaf_write_at(%s) slice %d: %d of %d bytes" % (path, i, n, sizes[i]))
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(write, range(n_sl)))
+    return int(off[-1])
+
+
 def cached_set(seed, n_species, H, n_reads, genome_len, cache_dir=None, **kw):
     """make_set through a pickle cache (profiling drivers re-run the same workload once per counter pass); cache_dir
     None = $PANTAX_SYNTH_CACHE, unset = no cache."""

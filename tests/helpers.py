@@ -50,6 +50,15 @@ def select_reads(reads, sel):
     return new_off, reads.node_id[idx], reads.pstart[sel], reads.pend[sel]
 
 
+def slice_reads(reads, a, b):
+    """Reads [a, b) of a PackedReads as a PackedReads of their own (step offsets rebased, arrays are views)."""
+    from pantax_amd.synth import PackedReads
+    so = reads.step_off
+    t0, t1 = int(so[a]), int(so[b])
+    return PackedReads(so[a:b + 1] - so[a], reads.node_id[t0:t1], reads.strand[t0:t1], reads.pstart[a:b], reads.pend[a:b], reads.qlen[a:b],
+                       reads.mapq[a:b], reads.plen[a:b], reads.read_id[a:b] if reads.read_id else [])
+
+
 def make_longread_gaf(seed, n_reads, path_ids=40):
     """GAF text in GraphAligner's column layout (12 columns + NM, AS, dv, id tags) with several alignments per read, ties,
     low-mapq / short-span lines and every malformed spelling parse_line (gaf_filter.rs:21-42) has to reject."""
@@ -164,9 +173,10 @@ def oracle_species_checks(sset, sp, keep, absolute, bases, cov, tb, hto, gmet, i
     S = len(sset.species)
     nb = np.cumsum([0] + [g.n_nodes for g in sset.species])
     hb = np.cumsum([0] + [g.n_paths for g in sset.species])
-    order = np.argsort(sp, kind="stable")
-    cnt = np.bincount(sp[sp >= 0], minlength=S)
-    first = np.searchsorted(sp[order], np.arange(S))
+    first_, order = orc.group_reads(sp, S)         # reads grouped by species, file order inside (stable counting sort)
+    first = first_[:-1].astype(np.int64)
+    cnt = np.diff(first_.astype(np.int64))
+    order = order.astype(np.int64)
     strain_kw = strain_kw or {}
 
     def one(s):

@@ -1,5 +1,7 @@
 """Every BASELINE.json GPU configuration at FULL size through the HIP path (cfg2 lives in test_gpu_fullsize.py):
   cfg3        100 species x 10 strains, 10 M short reads                -- every species against the oracle
+  cfg4        1 000 species x 10 strains, 100 M short reads on ONE GPU (the bench line's set) -- binning of every read against
+                                                                           the oracle, properties, oracle on a species sample
   cfg4 share  125 species x 10 strains, 12.5 M short reads (1/8 of cfg4) -- size-independent properties + oracle on a sample
   cfg5 share  125 species x 50 strains, 125 k HiFi-shaped reads (1/8 of cfg5: 6 250 of 50 k strains, total bases = cfg4's)
                                                                         -- properties + oracle on a sample
@@ -11,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import expected_total_bases, oracle_species_checks, select_reads
+from tests.helpers import expected_total_bases, oracle_species_checks, select_reads, slice_reads
 
 pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 32)
@@ -27,14 +29,9 @@ def eng():
 
 def _bin_oracle(sset, threads):
     """rcls.rs:237-258 on the host for all reads, in `threads` slices"""
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     rd = sset.reads
-    rs, re = [g.range_start for g in sset.species], [g.range_end for g in sset.species]
-    cuts = np.linspace(0, rd.n_reads, threads + 1).astype(np.int64)
-    with ThreadPoolExecutor(threads) as ex:
-        parts = list(ex.map(lambda i: orc.bin_reads(rd.step_off[cuts[i]:cuts[i + 1] + 1], rd.node_id, rs, re), range(threads)))
-    return np.concatenate(parts)
+    return orc.par_bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species], threads)
 
 
 def _run_stages(eng, sset, fr=0.3):
@@ -170,3 +167,66 @@ def test_cfg5_share_full_size_long_reads_properties_and_oracle_sample(eng):
     assert np.array_equal(sp_p, out["sp"][perm])
     b_p, c_p, t_p, n_p = eng.get_node_abundances()
     assert np.array_equal(b_p, out["bases"]) and np.array_equal(c_p, out["cov"]) and np.array_equal(t_p, out["tb"]) and n_p == out["nab"]
+
+
+def test_cfg4_full_size_one_gpu_properties_and_oracle_sample(eng):
+    """BASELINE.json configs[3] -- the configuration the metric is quoted on, and bench.py's default set -- on ONE GPU at full size:
+    1 000 species / 10 000 strains / 100 M short reads (V = 3.2e8, P = 2.2e9, T = 7.6e8; the loop of profile.rs:3297-3319 at
+    that size)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from bench import native_set, workload_spec
+    spec = workload_spec("cfg4")
+    sset = native_set(spec, threads=THREADS).make()
+    rd = sset.reads
+    S = len(sset.species)
+    assert (S, rd.n_reads) == (1000, 100_000_000)
+    out = _run_stages(eng, sset)
+    sp = out["sp"]
+    # binning of every read against the oracle
+    assert np.array_equal(sp, _bin_oracle(sset, THREADS))
+    # counters partition the reads; coverage never exceeds a node; conservation of aligned bases from the read records alone
+    rc, bs, lm, uq = out["counts"]
+    assert rc.sum() + (sp < 0).sum() == rd.n_reads
+    assert np.array_equal(rc, np.bincount(sp[sp >= 0], minlength=S))
+    assert bs.sum() == rd.qlen[sp >= 0].sum()
+    assert np.array_equal(uq, np.bincount(sp[(sp >= 0) & (rd.mapq == 60)], minlength=S))
+    gl = np.concatenate([g.node_len for g in sset.species])
+    assert np.all(out["cov"] <= gl.astype(np.uint64))
+    del gl
+    cuts = np.linspace(0, rd.n_reads, 33).astype(np.int64)
+
+    def part(i):
+        from pantax_amd import synth
+        a, b = int(cuts[i]), int(cuts[i + 1])
+        return expected_total_bases(synth.SyntheticSet(sset.species, slice_reads(rd, a, b)), sp[a:b])
+    with ThreadPoolExecutor(8) as ex:
+        assert int(out["bases"].sum()) == sum(ex.map(part, range(32)))
+    # idempotence
+    b2, c2, t2, n2 = eng.get_node_abundances()
+    assert np.array_equal(b2, out["bases"]) and np.array_equal(c2, out["cov"]) and np.array_equal(t2, out["tb"]) and n2 == out["nab"]
+    del b2, c2, t2
+    # oracle on a species sample (incl. the ones with the most and the fewest reads): integers bit for bit, LP objective 1e-9, metrics
+    cnt = out["counts"][0]
+    sample = sorted({int(np.argmax(cnt)), int(np.argmin(cnt)), 0, 111, 333, 500, 777, 888, 999})
+    bad = oracle_species_checks(sset, sp, out["keep"], out["absolute"], out["bases"], out["cov"], out["tb"], out["hto"], out["gmet"],
+                                out["info"], sample, threads=THREADS)
+    assert not bad, bad[:10]
+    # order invariance: the same reads in another order (blocks of 4096 reads shuffled, every block reversed) give the same integers
+    nb = (rd.n_reads + 4095) // 4096
+    blocks = np.random.default_rng(44).permutation(nb)
+    perm = (blocks[:, None] * 4096 + np.arange(4095, -1, -1)[None, :]).ravel()
+    perm = perm[perm < rd.n_reads]
+    so, nid, ps, pe = select_reads(rd, perm)
+    eng.upload_reads(so, nid, ps, pe, rd.qlen[perm], rd.mapq[perm])
+    del so, nid
+    sp_p, rc_p, bs_p, lm_p, uq_p = eng.rcls_profile()
+    assert np.array_equal(sp_p, sp[perm])
+    for a, b in zip(out["counts"], (rc_p, bs_p, lm_p, uq_p)):
+        assert np.array_equal(a, b)
+    b_p, c_p, t_p, n_p = eng.get_node_abundances()
+    assert np.array_equal(b_p, out["bases"]) and np.array_equal(c_p, out["cov"]) and np.array_equal(t_p, out["tb"]) and n_p == out["nab"]
+    del b_p, c_p, t_p
+    # the single-call resident step: normalised tables over the kept species
+    eng.upload_packed(rd)
+    sp_rows, st_rows, stats = _tables_normalised(eng, sset)
+    assert len(sp_rows) == int(out["keep"].sum())

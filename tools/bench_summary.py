@@ -10,4 +10,9 @@ for k in ("runner_up", "coverage_step_kernel"):
 print("kernels", {k: round(v, 3) for k, v in list(d["kernels_ms_per_step"].items())[:16]})
 if d.get("from_gaf_text"): print("gaf", d["from_gaf_text"])
 if d.get("pao_hard"): print("hard", {k: v for k, v in d["pao_hard"].items() if k != "highs"})
-if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["seconds"])
+c = d.get("cpu_baseline")
+if c:
+    print("cpu", c.get("value"), c.get("cores"), c.get("seconds"), c.get("error"), c.get("mem_available_gb"), "waited", c.get("parent_waited_s_for_oracle_leg"))
+    h = c.get("highs") or {}
+    print("highs", [(l["rows"], round(l["highs_seconds"], 2)) for l in h.get("legs", [])], "full:", {k: v for k, v in (h.get("full_lp") or {}).items() if k != "what"})
+print("config", d["config"]["workload"], "| gen s", d.get("synthetic_set_generated_in_s"), "upload ms", d.get("upload_ms_once"), "host", d.get("host"))

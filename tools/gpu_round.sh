@@ -10,7 +10,10 @@ case $w in
 tests) ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -5 gpurun_out/${tag}_tests.log ;;
 triotests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q ) > gpurun_out/${tag}_tests.log 2>&1; tail -4 gpurun_out/${tag}_tests.log ;;
 newtests) ( time timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_tests.log 2>&1; tail -25 gpurun_out/${tag}_tests.log ;;
-bench) ( time timeout 1200 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 1500 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err ;;
+bench) ( time timeout 1500 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; python3 tools/bench_summary.py gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err ;;
+bench3) ( time timeout 900 python bench.py --workload cfg3 ) > gpurun_out/${tag}_bench_cfg3.json 2> gpurun_out/${tag}_bench_cfg3.err; python3 tools/bench_summary.py gpurun_out/${tag}_bench_cfg3.json; tail -5 gpurun_out/${tag}_bench_cfg3.err ;;
+flow) ( time timeout 600 python bench.py --workload cfg2 --highs-full-time-limit 10 --hard-species 2 ) > gpurun_out/${tag}_flow.json 2> gpurun_out/${tag}_flow.err; python3 tools/bench_summary.py gpurun_out/${tag}_flow.json; tail -5 gpurun_out/${tag}_flow.err ;;
+cfg4test) ( time timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k cfg4_full --durations=5 ) > gpurun_out/${tag}_cfg4test.log 2>&1; tail -12 gpurun_out/${tag}_cfg4test.log ;;
 qbench) ( time timeout 900 python bench.py --workload cfg3 --no-cpu-baseline --no-hard --no-gaf --steps 10 ) > gpurun_out/${tag}_qbench.json 2> gpurun_out/${tag}_qbench.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench.json; tail -3 gpurun_out/${tag}_qbench.err ;;
 qcovshapes) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 5 --warmup 3 > gpurun_out/${tag}_cov$sh.json 2> gpurun_out/${tag}_cov$sh.err; echo "shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov$sh.json | head -3; done ;;
 covshapes2) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --workload cfg2 --no-cpu-baseline --no-hard --no-gaf --steps 10 --warmup 3 > gpurun_out/${tag}_cov2_$sh.json 2> gpurun_out/${tag}_cov2_$sh.err; echo "cfg2 shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov2_$sh.json | head -3; done ;;

@@ -3,7 +3,6 @@
 # usage: kernel_trace.sh <workload> <tag> [steps]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 wl=$1; tag=$2; n=${3:-6}
-if [ "$wl" != cfg4 ]; then export PANTAX_SYNTH_CACHE=/tmp/pantax_synth_cache; fi
 timeout 1200 rocprofv3 --kernel-trace --stats -d gpurun_out/trace_$tag -o $tag -- python3 tools/step_driver.py $wl $n > gpurun_out/trace_$tag.log 2>&1
 echo "trace rc=$?"
 db=$(find gpurun_out/trace_$tag -name '*.db' | head -1)

@@ -8,7 +8,7 @@ usage: pmc_collect.py <dir with g*/..._counter_collection.csv> <workload> <out.j
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS
+from bench import workload_key, workload_spec
 src, wl, out = sys.argv[1], sys.argv[2], sys.argv[3]
 acc = {}    # kernel -> counter -> [sum, n]
 meta = {}
@@ -23,12 +23,11 @@ for fn in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), r
             c[0] += float(row["Counter_Value"]); c[1] += 1
             meta[k] = dict(vgpr=int(row["VGPR_Count"]), agpr=int(row["Accum_VGPR_Count"]), sgpr=int(row["SGPR_Count"]),
                            lds_bytes=int(row["LDS_Block_Size"]), workgroup=int(row["Workgroup_Size"]), scratch=int(row["Scratch_Size"]))
-_, off, S, H, R, L = WORKLOADS[wl]
 res = {"_comment": ["rocprofv3 --pmc passes over tools/step_driver.py %s 2 (two resident steps, all launches averaged), one counter group per run" % wl,
                     "(tools/pmc_step.sh); FETCH_SIZE / WRITE_SIZE are KB.  hbm_bytes_per_launch = (FETCH + WRITE) x 1024 raw;",
                     "hbm_bytes_fetch_x2 = the guide's gfx950 correction for wide coalesced reads applied to the whole fetch (upper bound).",
                     "waves/SIMD by VGPRs = floor(512 / vgpr_alloc) capped at 8 (unified 512-entry file per SIMD lane on gfx950)."],
-       "workload": dict(reads=R, species=S, haps=H, genome_len=L, seed=20260501 + off), "kernels": {}}
+       "workload": workload_key(workload_spec(wl)), "kernels": {}}
 for k, cs in sorted(acc.items()):
     d = {c: v[0] / v[1] for c, v in cs.items()}
     d["launches_seen"] = max(v[1] for v in cs.values())

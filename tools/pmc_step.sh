@@ -3,11 +3,10 @@
 # as /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 PMC slots) prescribes: FETCH_SIZE and WRITE_SIZE cannot
 # share a pass.  Every pass is wrapped in `timeout`.  usage: pmc_step.sh <workload> <tag> <group> [<group> ...]
 # (a group is a space-separated counter list in quotes); results -> gpurun_out/pmc_<tag>/g<i>/, summarised by
-# tools/pmc_collect.py into profiles/r02_pmc_<workload>.json
+# tools/pmc_collect.py into profiles/r<round>_pmc_<workload>.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 wl=$1; tag=$2; shift 2
-# the generated set is pickled between passes -- except cfg4's (14 GB): that one is generated again in every pass
-if [ "$wl" != cfg4 ]; then export PANTAX_SYNTH_CACHE=/tmp/pantax_synth_cache; fi
+# the set is generated again in every pass (native generator: seconds)
 TMO=${PMC_TIMEOUT:-400}; if [ "$wl" = cfg4 ]; then TMO=${PMC_TIMEOUT:-1200}; fi
 mkdir -p gpurun_out/pmc_$tag
 i=0

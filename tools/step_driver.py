@@ -1,19 +1,17 @@
 #!/usr/bin/env python3
 """Profiling driver: uploads one bench workload and runs N resident steps (pantax_hip_profile_step), nothing else.
-usage: step_driver.py [cfg2|cfg3|cfg4_share|cfg4] [n_steps] [rebuild_trio 0/1]   (set PANTAX_SYNTH_CACHE to reuse the generated set)
+usage: step_driver.py [cfg2|cfg3|cfg4_share|cfg4] [n_steps] [rebuild_trio 0/1]   (the set bench.py times: native generator, seconds)
 Put it directly after `--` under rocprofv3 (tools/pmc_step.sh, tools/kernel_trace.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS
-from pantax_amd import synth
+from bench import native_set, workload_spec
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import StepConfig, profile_step, profile_steps_pipelined
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rebuild = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
-_, off, S, H, R, L = WORKLOADS[wl]
-sset = synth.cached_set(20260501 + off, S, H, R, L)
+sset = native_set(workload_spec(wl)).make()
 names = [g.name for g in sset.species]
 haps = [h for g in sset.species for h in g.hap_names]
 eng = Engine(0)
