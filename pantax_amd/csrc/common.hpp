@@ -330,10 +330,21 @@ struct Reads {
     DevBuf<uint32_t> d_long_sum;     // [R'] walks > 64 steps: node lengths of all steps but the last (walk_sum_kernel), else unused
     DevBuf<uint32_t> d_long_len0;    // [R'] walks > 64 steps: length of the walk's first node (walk_sum_kernel)
     uint32_t n_long = 0;             // walks of more than 64 steps
-    DevBuf<uint4> d_g_slot_rec;      // [R'] {species of the slot's read (-1: "U" or dropped row), its first node id, node base, #nodes}, written by the binning kernel
+    DevBuf<uint2> d_g_slot_rec;      // [R'] {species of the slot's read (coding below), node base - first node id of that species}, written by the binning pass
+    DevBuf<uint2> d_g_qm;            // [R'] {read length, MAPQ} in slot order (the binning pass runs over the slots)
+    DevBuf<uint8_t> d_g_flag;        // [R'] drop flags in slot order, refreshed when the flags changed (g_flags_valid)
+    uint32_t n_slots = 0;            // reads that own a slot (non-empty walk)
+    bool g_flags_valid = false;
+    bool species_valid = false;      // d_species (file order) reflects the last binning pass; species_ensure() gathers it from the slots
     bool binned = false;
     bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip): no locus-grouped copy, no coverage pass
 };
+
+// slot record (Reads::d_g_slot_rec).x: >= 0 species, the coverage pass uses the slot; -1 "U"; <= -2: binned to species -x-2 but dropped
+// before get_node_abundances (drop flag) or, with .y == SLOT_ABORT, a read whose walk leaves the species' graph (index panic
+// of profile.rs:849: counted as an abort, skipped whole)
+constexpr uint32_t SLOT_ABORT = 1u;
+__host__ __device__ inline int slot_species(int32_t x) { return x >= -1 ? x : -x - 2; }
 
 // node record fields (Db::d_node_rec): the coverage bitmap of one GPU holds < 2^40 bases and a node heads < 2^24 lookup rows
 constexpr uint64_t NODE_REC_MAX_BITS = 1ull << 40;
@@ -398,6 +409,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 
 // ---- stage entry points (host launchers, defined in the .hip files) ---------------------------
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
+int species_ensure(Ctx *ctx, Reads *rd);   // d_species in file order (resident reads keep the species per slot)
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);

@@ -11,7 +11,8 @@ rows = db.execute("select %s, count(*), sum(end-start), avg(end-start), min(end-
 tot = sum(r[2] for r in rows) or 1
 print("%-64s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"))
 for n, c, t, a, mn, mx in rows:
-    n = n.split("(")[0][-64:]
+    n = n.replace("void ", "").replace("ptx::", "").replace("(anonymous namespace)::", "")
+    n = (n.split("<")[0] + ("<" + n.split("<", 1)[1].split(">(")[0] + ">" if "<" in n else "")).split("(")[0][:64]
     print("%-64s %8d %14d %12.0f %12d %12d %6.2f%%" % (n, c, t, a, mn, mx, 100.0 * t / tot))
 
 # optional: --timeline N  prints the last N dispatches (start offset, duration, gap to the previous end) in us
@@ -21,5 +22,5 @@ if "--timeline" in sys.argv:
     t0, prev = tl[0][1], None
     print("\n%-56s %10s %9s %9s" % ("dispatch", "start_us", "dur_us", "gap_us"))
     for n, st, en in tl:
-        print("%-56s %10.1f %9.1f %9.1f" % (n.split("(")[0][-56:], (st - t0) / 1e3, (en - st) / 1e3, (st - prev) / 1e3 if prev else 0.0))
+        print("%-56s %10.1f %9.1f %9.1f" % (n.replace("void ", "").replace("ptx::", "").split("(")[0][:56], (st - t0) / 1e3, (en - st) / 1e3, (st - prev) / 1e3 if prev else 0.0))
         prev = en
