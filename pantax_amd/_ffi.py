@@ -103,10 +103,12 @@ def load():
     """dlopen libpantax_hip.so (built by __graft_entry__.build() / make -C pantax_amd/csrc)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libpantax_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
-                              "pantax_amd has no CPU fallback")
-        _lib = C.CDLL(LIB_PATH)
+        # PANTAX_HIP_LIB: another build of the SAME library (A/B measurements, a -DLAD_PROFILE build) without touching the product file
+        path = os.environ.get("PANTAX_HIP_LIB") or LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError("%s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                              "pantax_amd has no CPU fallback" % path)
+        _lib = C.CDLL(path)
         _lib.pantax_hip_last_error.restype = C.c_char_p
         _lib.pantax_hip_last_error.argtypes = [C.c_void_p]
         _lib.pantax_hip_version.restype = C.c_char_p

@@ -360,7 +360,7 @@ int pantax_hip_bin_reads(pantax_hip_ctx *ctx, const pantax_hip_db *db, pantax_hi
     const size_t res_bytes = bin_result_words(S) * sizeof(unsigned long long);
     PTX_HIP(ctx, ctx->pin_down.reserve(res_bytes));
     PTX_HIP(ctx, hipMemcpyAsync(ctx->pin_down.p, d_cnt.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (species_idx_out) PTX_TRY(download(ctx, species_idx_out, reads->d_species.p, reads->R));
+    if (species_idx_out) { PTX_TRY(species_ensure(ctx, reads)); PTX_TRY(download(ctx, species_idx_out, reads->d_species.p, reads->R)); }
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned long long *h = reinterpret_cast<const unsigned long long *>(ctx->pin_down.p);
     const uint64_t npre = std::min<uint64_t>(reads->R, BIN_PREFIX);

@@ -29,6 +29,7 @@ int pantax_hip_species_profile(pantax_hip_ctx *ctx, const pantax_hip_db *db, pan
     for (; off < reads->R && head.size() < 1000; off += CH, CH = std::min<uint64_t>(CH * 8, 1 << 20)) {
         uint64_t n = std::min<uint64_t>(CH, reads->R - off);
         sp.resize(n); ql.resize(n);
+        PTX_TRY(species_ensure(ctx, reads));
         PTX_TRY(download(ctx, sp.data(), reads->d_species.p + off, n));
         PTX_TRY(download(ctx, ql.data(), reads->d_qlen.p + off, n));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));

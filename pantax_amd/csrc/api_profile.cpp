@@ -516,6 +516,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             for (uint32_t i = 0; i < Ss; ++i) owner_all[sel[i]] = owner[i];
             if (R) PTX_TRY(upload(ctx, reads.rd->d_flags, flags.data(), R));
             reads.rd->has_flags = R != 0;
+            reads.rd->g_flags_valid = false;
             PTX_TRY(route_pack(ctx, bin_db.db, reads.rd, owner_all.data(), W, rt));
             for (int j = 0; j <= W; ++j) send_off[j] = rt.word_off[j] * 4;
             return 0;

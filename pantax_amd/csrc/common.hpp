@@ -285,6 +285,7 @@ struct Db {
     unsigned long long *d_abort = nullptr;
     DevBuf<unsigned long long> d_bases;      // [V]
     DevBuf<uint32_t> d_bitmap;               // [ceil(L/32)+1]
+    DevBuf<uint32_t> d_full;                 // 1 bit per node: some step covered the node whole (its bits are then not marked one by one)
     DevBuf<uint32_t> d_cov;                  // [V]
     DevBuf<unsigned long long> d_trio_bases; // [U]
     DevBuf<uint8_t> d_active;                // [S]
@@ -340,11 +341,12 @@ struct Reads {
     bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip): no locus-grouped copy, no coverage pass
 };
 
-// slot record (Reads::d_g_slot_rec).x: >= 0 species, the coverage pass uses the slot; -1 "U"; <= -2: binned to species -x-2 but dropped
-// before get_node_abundances (drop flag) or, with .y == SLOT_ABORT, a read whose walk leaves the species' graph (index panic
-// of profile.rs:849: counted as an abort, skipped whole)
-constexpr uint32_t SLOT_ABORT = 1u;
-__host__ __device__ inline int slot_species(int32_t x) { return x >= -1 ? x : -x - 2; }
+// slot record (Reads::d_g_slot_rec).x: >= 0 species, the coverage pass uses the slot; -1 "U"; -2 - s: binned to species s but dropped
+// before get_node_abundances (drop flag); -2 - s - SLOT_ABORT: binned to species s, but the walk leaves the species' graph (index
+// panic of profile.rs:849: counted as an abort, skipped whole)
+constexpr int32_t SLOT_ABORT = 1 << 30;
+__host__ __device__ inline int slot_species(int32_t x) { return x >= -1 ? x : (-x - 2) & (SLOT_ABORT - 1); }
+__host__ __device__ inline bool slot_aborts(int32_t x) { return x < -1 && (-x - 2) >= SLOT_ABORT; }
 
 // node record fields (Db::d_node_rec): the coverage bitmap of one GPU holds < 2^40 bases and a node heads < 2^24 lookup rows
 constexpr uint64_t NODE_REC_MAX_BITS = 1ull << 40;

@@ -128,7 +128,7 @@ int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &
     for (uint64_t i = 0; i <= h.H; ++i) { po[i] = db->h_path_off[h0 + i] - q0; hto[i] = db->h_hap_trio_off[h0 + i] - u0; }
     if (tf[0] != (uint32_t)u0 || tf[h.V] != (uint32_t)u1) return fail(ctx, PANTAX_HIP_E_STATE, "db_save_image: lookup rows of species %u are not the contiguous block its table rows are", s);
     for (uint64_t i = 0; i <= h.V; ++i) tf[i] -= (uint32_t)u0;
-    for (uint64_t i = 0; i < h.U; ++i) te[i].z -= (uint32_t)u0;
+    for (uint64_t i = 0; i < h.U; ++i) { te[i].x -= (uint32_t)nb; te[i].y -= (uint32_t)nb; te[i].z -= (uint32_t)u0; }   // species-local (b, c, row) in the file
     std::memcpy(img.data() + L.names, joined.data(), joined.size());
     const uint64_t endmark = header_sum(h);
     std::memcpy(img.data() + L.end, &endmark, 8);

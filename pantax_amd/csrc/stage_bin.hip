@@ -267,9 +267,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_lds_kernel(
 // COALESCED.  (Round 2 ran in read order and scattered a 16-byte record per read over the slot array: WRITE_SIZE 368 MB for
 // 1e7 reads, 9x the algorithmic output; 13 ms at 1e8 reads.)  The per-read species array in file order is not written here:
 // species_ensure() scatters it from the slot records when a caller asks for it (report, routing).
-// Slot record: x >= 0 species, usable by the coverage pass; x == -1 "U"; x <= -2: binned to species -x-2 but the row is
-// dropped before get_node_abundances (drop flag) or would die there (y == SLOT_ABORT: a node id beyond the species' graph,
-// the index panic of profile.rs:849 -- counted as an abort, the whole read skipped like the oracle does).
+// Slot record (coding in common.hpp): x >= 0 species, usable by the coverage pass; x == -1 "U"; below: binned, but the row is
+// dropped before get_node_abundances (drop flag) or would die there (a node id beyond the species' graph, the index panic of
+// profile.rs:849 -- counted as an abort, the whole read skipped).
 template <bool SORTED, bool LDS_TAB>
 __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
     uint32_t n_slots, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ node_id, const uint2 *__restrict__ g_qm,
@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
                 if (LDS_TAB) { first = s_first[sp]; nb = s_nb[sp]; nn = s_nn[sp]; }
                 else if (sp_first_id) { first = sp_first_id[sp]; nb = node_base[sp]; nn = node_base[sp + 1] - nb; }
                 const bool leaves = mx - first >= nn;                 // a node id beyond the species' graph (range wider than the graph)
-                rec.x = (fl || leaves) ? (uint32_t)(-sp - 2) : (uint32_t)sp;
-                rec.y = (leaves && !fl) ? SLOT_ABORT : nb - first;
+                rec.x = fl ? (uint32_t)(-sp - 2) : leaves ? (uint32_t)(-sp - 2 - SLOT_ABORT) : (uint32_t)sp;
+                rec.y = nb - first;
             }
             slot_rec[r] = rec;
         }

@@ -53,11 +53,12 @@ __device__ __forceinline__ uint32_t bm_peek(const uint32_t *p) {
 // Bits [g0,g1) of the coverage bit vector are marked through the workgroup's LDS bit window (words
 // [bw0, bw0 + COV_BWIN) of the global vector); words outside the window take the global test-then-OR path.  The window is ORed into memory once per workgroup.
 constexpr uint32_t COV_BWIN = 2048;   // 32-bit words: 64 kbit of graph bases
-constexpr int COV_WIN = 1024;         // nodes in the LDS window of `bases`
-// the two LDS windows of the coverage kernel live at file scope: helpers that received them as (generic) pointer arguments
+constexpr int COV_WIN = 1024;         // nodes in the LDS window of `bases` (a multiple of 64 nodes from a multiple of 64: the full-node flags flush as ballots)
+// the LDS windows of the coverage kernel live at file scope: helpers that received them as (generic) pointer arguments
 // made this compiler emit an illegal null check of the shared-memory aperture
 __shared__ uint32_t s_win[COV_WIN];
 __shared__ uint32_t s_bm[COV_BWIN];
+__shared__ uint8_t s_full[COV_WIN];   // a step covered the whole node: its bits are not marked one by one (popcount_kernel takes the length)
 __device__ __forceinline__ void lds_or(uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
     const uint64_t off = w - bw0;     // unsigned wrap: words below the window are out of range too
     if (off < bwn) {
@@ -76,6 +77,19 @@ __device__ __forceinline__ void mark_range(uint32_t *__restrict__ bm, uint64_t b
         lds_or(bm, bw0, bwn, w1, m1);
     }
 }
+// the same for a range that lies inside the LDS bit window: 32-bit positions relative to the window, LDS only
+__device__ __forceinline__ void win_or(uint32_t w, uint32_t m) { if ((s_bm[w] & m) != m) atomicOr(&s_bm[w], m); }
+__device__ __forceinline__ void mark_window(uint32_t r0, uint32_t r1) {
+    if (r1 <= r0) return;
+    const uint32_t w0 = r0 >> 5, w1 = (r1 - 1) >> 5;
+    const uint32_t m0 = 0xFFFFFFFFu << (r0 & 31), m1 = 0xFFFFFFFFu >> (31 - ((r1 - 1) & 31));
+    if (w0 == w1) win_or(w0, m0 & m1);
+    else {
+        win_or(w0, m0);
+        for (uint32_t w = w0 + 1; w < w1; ++w) win_or(w, 0xFFFFFFFFu);
+        win_or(w1, m1);
+    }
+}
 
 // Step codes (g_step_dup): walks of <= 64 steps carry the distance back to the first occurrence of the step's node in
 // the walk (0 = none); longer walks carry STEP_LONG | (1 if the node occurred earlier in the walk).  Where the first
@@ -85,19 +99,34 @@ constexpr uint32_t STEP_LONG = 0x80u;
 // read_nodes_len of position j (never the last position) of a long walk: the length aligned at the node's FIRST
 // occurrence in the read (profile.rs:879-882)
 __device__ __forceinline__ uint32_t rl_from_memory(uint32_t j, uint32_t b, const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup,
-                                                   uint32_t first_id, uint32_t nb, const uint4 *__restrict__ node_rec, uint32_t len0, uint32_t ps) {
+                                                   uint32_t delta, const uint4 *__restrict__ node_rec, uint32_t len0, uint32_t ps) {
     const uint32_t idj = node_id[b + j];
     if (j == 0 || ((step_dup[b + j] & 1u) && idj == node_id[b])) return len0 - ps;
-    return node_rec[nb + (idj - first_id)].z;
+    return node_rec[idj + delta].z;
 }
 
-constexpr int COV_WIN_BACK = 128; // window starts this many nodes before the node of the chunk's first live step
+// -DCOV_ABLATE builds (never the product library: make OUT=../lib_prof EXTRA=-DCOV_ABLATE, loaded through PANTAX_HIP_LIB) read
+// PANTAX_COV_ABLATE: bit 0 no bit / flag marking, bit 1 no `bases`, bit 2 no unique-trio lookups -- wrong results, for timing only
+#ifdef COV_ABLATE
+#define ABL(bit) (ablate & (bit))
+#else
+#define ABL(bit) false
+#endif
+constexpr int COV_WIN_BACK = 128; // window starts (at least) this many nodes before the node of the chunk's first live step
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t wlo, uint32_t win_n, uint32_t v, uint32_t aln) {
     const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
     if (off < win_n && aln < (1u << 18)) atomicAdd(&s_win[off], aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
+}
+__device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t wlo, uint32_t win_n, uint32_t v) {
+    const uint32_t off = v - wlo;
+    if (off < win_n) s_full[off] = 1;     // plain byte stores of the same value: no atomic, nothing to lose
+    else {
+        const uint32_t m = 1u << (v & 31);
+        if (!(bm_peek(&full[v >> 5]) & m)) atomicOr(&full[v >> 5], m);
+    }
 }
 
 // Steps arrive grouped by the locus of their read's first node (build_step_read below), so a workgroup's
@@ -106,49 +135,61 @@ __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases
 // node -- the LDS-staged segmented reduction of the scatter.  Nodes outside the window (or oversized
 // lengths) fall back to the global atomic; the result is identical either way.
 //
-// The kernel is bound by the latency of its chain of dependent gathers times the gathers in flight, so
-//   * the chain is three levels: {slot, node id, step code} (stream) -> {read record, slot record} -> {node record}
-//     (-> a unique-trio entry where the node has any).  The slot record {species, first id, node base, #nodes} is
-//     written by the binning pass, so no species table is consulted here; the node record carries the lookup head of
-//     the unique-trio index (first row, #rows) next to bit offset and length, and a 3-window whose smaller end is the
-//     node two steps back takes the head from that lane by shuffle: ONE divergent 16-byte gather per step.
+// The kernel is bound by instruction issue and by the latency of its chain of dependent gathers, so
+//   * the chain is three levels: {slot, node id, step code} (stream) -> {read record (16 B), slot record (8 B)} -> {node record}
+//     (-> a unique-trio entry where the node has any).  The slot record {species, node base - first id} is written by the
+//     binning pass -- which also vouches that every id of the walk lies inside the species' graph, so a step places its node
+//     with ONE add and no range test; the node record carries the lookup head of the unique-trio index (first row, #rows)
+//     next to bit offset and length, and a 3-window whose smaller end is the node two steps back takes the head from that
+//     lane: ONE divergent 16-byte gather per step.  Everything is in global node indices (the lookup entries too).
+//   * a step that covers its whole node (every interior step of a read: profile.rs:860-862 with :870-873) sets ONE flag for
+//     the node instead of marking its bits word by word (popcount_kernel then takes the node's length); only the partial
+//     ranges -- first and last step of a read -- are marked in the bit window, in 32-bit positions relative to the window.
 //   * every wave works on U groups of 64 steps at once: the loads of one level are issued for all U groups before the
 //     first of them is waited for (U x the memory-level parallelism per wave; registers permitting).
-// PASSES such rounds share one pair of LDS windows (zeroing and flushing them is per workgroup).
+// PASSES such rounds share one set of LDS windows (zeroing and flushing them is per workgroup).  Workgroups are handed to
+// the XCDs round-robin by the dispatcher; XCD_MAP makes every XCD walk ONE contiguous eighth of the stream, so neighbouring
+// chunks -- which share the node records and bitmap lines at their seam -- meet in the same L2.
 template <bool WITH_TRIO, int U, int PASSES>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
-    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint4 *__restrict__ slot_rec,
+    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active,
-    const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap,
+    const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full,
     const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort,
-    const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0) {
+    const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0, uint32_t n_chunks, uint32_t xcd_map, uint32_t ablate) {
     constexpr int CHUNK = COV_BLOCK * U * PASSES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t chunk_b = (uint64_t)blockIdx.x * CHUNK;
+    uint32_t chunk = blockIdx.x;
+    if (xcd_map) {   // blockIdx -> XCD is round-robin over 8: XCD x takes chunks [x * per, (x + 1) * per)
+        const uint32_t per = (n_chunks + 7) / 8;
+        chunk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per || chunk >= n_chunks) return;
+    }
+    const uint64_t chunk_b = (uint64_t)chunk * CHUNK;
     uint64_t chunk_e = chunk_b + CHUNK;
     if (chunk_e > T) chunk_e = T;
     for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
     for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
+    for (int i = threadIdx.x; i < COV_WIN / 4; i += COV_BLOCK) reinterpret_cast<uint32_t *>(s_full)[i] = 0;
     // window base: the node of the first live step among a few probes of the chunk.  Every thread computes it
     // (workgroup-uniform addresses), so nobody waits on a broadcast and the probes overlap the first gathers.
-    uint32_t wlo = 0, win_n = 0, bwn = 0;
-    uint64_t bw0 = 0;
+    uint32_t wlo = 0, win_n = 0;
+    uint64_t bw0 = 0, bit0 = 0;
+    uint32_t bwn = 0;
 #pragma unroll
     for (int c = 0; c < CHUNK / COV_BLOCK; ++c) {
         const uint64_t tc = chunk_b + (uint64_t)c * COV_BLOCK;
         if (win_n == 0 && tc < chunk_e) {
             const uint32_t slot = step_read[tc];
             if (slot != NO_SLOT) {
-                const uint4 sr0 = slot_rec[slot];
+                const uint2 sr0 = slot_rec[slot];
                 if ((int)sr0.x >= 0 && !(active && !active[sr0.x])) {
-                    const uint32_t id0 = node_id[tc];
-                    if (id0 >= sr0.y && id0 - sr0.y < sr0.w) {
-                        const uint32_t v0 = sr0.z + (id0 - sr0.y);
-                        wlo = v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u;
-                        win_n = COV_WIN;
-                        bw0 = nr_bit_off(node_rec[wlo]) >> 5;        // bit window starts at the window's first node
-                        bwn = COV_BWIN;
-                    }
+                    const uint32_t v0 = node_id[tc] + sr0.y;
+                    wlo = (v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u) & ~63u;
+                    win_n = COV_WIN;
+                    bw0 = nr_bit_off(node_rec[wlo]) >> 5;        // bit window starts at the window's first node
+                    bit0 = bw0 << 5;
+                    bwn = COV_BWIN;
                 }
             }
         }
@@ -171,28 +212,32 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             ok[u] = ok[u] && slot[u] != NO_SLOT;
         }
         // ---- level 2: per-read records
-        uint4 rr[U], sr[U];
+        uint4 rr[U];
+        uint2 sr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            rr[u] = make_uint4(0u, 0u, 0u, 0u); sr[u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            rr[u] = make_uint4(0u, 0u, 0u, 0u); sr[u] = make_uint2(0xFFFFFFFFu, 0u);
             if (ok[u]) { rr[u] = read_rec[slot[u]]; sr[u] = slot_rec[slot[u]]; }
         }
         // ---- level 3: the node record (issued before the species' `active` flag is known: a wasted gather at worst)
         uint4 nr[U];
-        uint32_t l[U], act[U];
-        bool inr[U];
+        uint32_t v[U], act[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (ok[u] && slot_aborts((int32_t)sr[u].x) && ti[u] == rr[u].x) {                     // the walk leaves its species' graph (profile.rs:849)
+                const int sp = slot_species((int32_t)sr[u].x);
+                if (!active || active[sp]) atomicAdd(n_abort, 1ull);
+            }
             ok[u] = ok[u] && (int)sr[u].x >= 0;                       // "U" / dropped rows
-            nr[u] = make_uint4(0u, 0u, 0u, 0u); l[u] = 0; act[u] = 1u; inr[u] = false;
+            nr[u] = make_uint4(0u, 0u, 0u, 0u); v[u] = 0; act[u] = 1u;
             if (ok[u]) {
-                inr[u] = id[u] >= sr[u].y && id[u] - sr[u].y < sr[u].w;
-                if (inr[u]) { l[u] = id[u] - sr[u].y; nr[u] = node_rec[sr[u].z + l[u]]; }
+                v[u] = id[u] + sr[u].y;
+                nr[u] = node_rec[v[u]];
                 if (active) act[u] = active[sr[u].x];
             }
         }
         // ---- shuffles, the trio lookup head and the first trio entry (level 4), for all groups
-        uint32_t l1[U], l2[U], len0[U], tcc[U];
+        uint32_t v1[U], v2[U], len0[U], tcc[U];
         uint2 th[U];
         uint4 e0[U], e1[U];   // the first TWO lookup entries of the head: with one, 95 % of the waves held a lane whose window was
                               // the node's second entry (8 % of the visits meet a head of two or more) and paid another dependent gather
@@ -201,25 +246,24 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (ok[u] && !act[u]) ok[u] = false;                      // unselected species
-            if (ok[u] && !inr[u]) { atomicAdd(n_abort, 1ull); ok[u] = false; }
-            if (!ok[u]) { l[u] = 0; nr[u] = make_uint4(0u, 0u, 0u, 0u); }
+            if (!ok[u]) { v[u] = 0; nr[u] = make_uint4(0u, 0u, 0u, 0u); }
             const uint32_t b = rr[u].x;
             const uint32_t i = ok[u] ? ti[u] - b : 0u;
             dist[u] = ok[u] ? (int)min(i, (uint32_t)lane) : 0;        // earlier steps of my read held by lower lanes
             cross[u] = ok[u] && (int)i > lane;                        // the walk began before this wave (more than 64 steps)
             // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
-            l1[u] = wave_shr1(l[u]); l2[u] = wave_shr1(l1[u]);
+            v1[u] = wave_shr1(v[u]); v2[u] = wave_shr1(v1[u]);
             const uint32_t tf2 = wave_shr1(wave_shr1(nr[u].w)), tn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
             th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (WITH_TRIO && ok[u] && i >= 2) {
-                if (lane < 1) l1[u] = node_id[b + i - 1] - sr[u].y;
-                if (lane < 2) l2[u] = node_id[b + i - 2] - sr[u].y;
+            if (WITH_TRIO && !ABL(4u) && ok[u] && i >= 2) {
+                if (lane < 1) v1[u] = node_id[b + i - 1] + sr[u].y;
+                if (lane < 2) v2[u] = node_id[b + i - 2] + sr[u].y;
                 // canonical window (min end, middle, max end); the lookup head belongs to the smaller end node
-                if (l[u] <= l2[u]) { th[u] = make_uint2(nr[u].w, nr[u].y >> 8); tcc[u] = l2[u]; }
+                if (v[u] <= v2[u]) { th[u] = make_uint2(nr[u].w, nr[u].y >> 8); tcc[u] = v2[u]; }
                 else {
-                    tcc[u] = l[u];
+                    tcc[u] = v[u];
                     if (lane >= 2) th[u] = make_uint2(tf2, tn2);
-                    else { const uint4 r2 = node_rec[sr[u].z + l2[u]]; th[u] = make_uint2(r2.w, r2.y >> 8); }   // wave border of a long walk
+                    else { const uint4 r2 = node_rec[v2[u]]; th[u] = make_uint2(r2.w, r2.y >> 8); }   // wave border of a long walk
                 }
                 if (th[u].y) e0[u] = trio_ent[th[u].x];
                 if (th[u].y > 1) e1[u] = trio_ent[th[u].x + 1];
@@ -237,13 +281,19 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             // walk cannot align 4 Gbp): only `target` needs a sign.
             const uint32_t i = ok[u] ? ti[u] - b : 0u;
             const uint64_t bo = nr_bit_off(nr[u]);
-            const uint32_t nl = nr[u].z, v = sr[u].z + l[u];
+            const uint32_t nl = nr[u].z;
+            const uint64_t rel = bo - bit0;                           // the node inside the LDS bit window: 32-bit relative positions
+            const bool in_win = rel < (uint64_t)bwn * 32 && nl <= (uint64_t)bwn * 32 - rel;   // (a node that starts below the window wraps to a huge rel)
             bool live = ok[u];
             const long long target = (long long)pe - (long long)ps;   // profile.rs:800
             if (live && k == 1) {                                     // :811
                 if (target >= 0) {                                    // :821-827
-                    if (target) add_bases(bases, wlo, win_n, v, (uint32_t)target);
-                    if (ps < pe && pe <= nl) mark_range(bitmap, bw0, bwn, bo + ps, bo + pe);   // :832
+                    if (target && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], (uint32_t)target);
+                    if (ps < pe && pe <= nl && !ABL(1u)) {            // :832
+                        if (ps == 0 && pe == nl) mark_full(full, wlo, win_n, v[u]);
+                        else if (in_win) mark_window((uint32_t)rel + ps, (uint32_t)rel + pe);
+                        else mark_range(bitmap, bw0, bwn, bo + ps, bo + pe);
+                    }
                 }
                 live = false;
             }
@@ -274,25 +324,28 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 } else { aln = nl; sidx = 0; }                        // :860-862
                 uint32_t hi = sidx + aln;
                 if (hi > nl) hi = nl;                                 // :871
-                mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
+                if (ABL(1u)) {}
+                else if (sidx == 0 && hi == nl) { if (nl) mark_full(full, wlo, win_n, v[u]); }
+                else if (in_win) mark_window((uint32_t)rel + sidx, (uint32_t)rel + hi);
+                else mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
                 if (jf < 0) {
                     rl = aln;
-                    if (aln) add_bases(bases, wlo, win_n, v, aln);     // :881
+                    if (aln && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], aln);     // :881
                 } else rl = (jf == 0) ? (len0[u] - ps) : nl;
             }
             if (WITH_TRIO) {                                          // :890-907
                 uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(wave_shr1(rl));
-                if (live && i >= 2) {
-                    if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
-                    if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, sr[u].z, node_rec, len0[u], ps);
+                if (live && i >= 2 && !ABL(4u)) {
+                    if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, sr[u].y, node_rec, len0[u], ps);
+                    if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, node_rec, len0[u], ps);
                     int row = -1;
                     if (th[u].y) {
-                        if (e0[u].x == l1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
-                        else if (th[u].y > 1 && e1[u].x == l1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
+                        if (e0[u].x == v1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
+                        else if (th[u].y > 1 && e1[u].x == v1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
                         else
                             for (uint32_t j = 2; j < th[u].y; ++j) {
                                 const uint4 e = trio_ent[th[u].x + j];
-                                if (e.x == l1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
+                                if (e.x == v1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
                             }
                     }
                     if (row >= 0) {
@@ -304,11 +357,19 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         }
     }
     __syncthreads();
-    if (win_n)
+    if (win_n) {
         for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
             const uint32_t c = s_win[i];
             if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
+            // full-node flags: the window starts at a multiple of 64 nodes, so a wave's ballot is two whole words of the flag vector
+            const unsigned long long fb = __ballot(s_full[i] != 0);
+            if (fb && (lane & 31) == 0) {
+                const uint32_t m = (uint32_t)(fb >> (lane & 32));
+                uint32_t *w = &full[(wlo + i) >> 5];
+                if (m && (bm_peek(w) & m) != m) atomicOr(w, m);
+            }
         }
+    }
     for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
         const uint32_t m = s_bm[i];
         if (m && (bm_peek(&bitmap[bw0 + i]) & m) != m) atomicOr(&bitmap[bw0 + i], m);
@@ -320,7 +381,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 // long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
 template <int WS_U>
 __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ step_read, const uint8_t *__restrict__ step_dup,
-                                                       const uint4 *__restrict__ read_rec, const uint4 *__restrict__ slot_rec,
+                                                       const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
                                                        const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ node_len,
                                                        uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
     // WS_U groups of 64 steps per wave and round, the loads of a level issued for all of them before the first is used (the
@@ -344,17 +405,18 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
             slot[u] = NO_SLOT; id[u] = 0;
             if (code[u] & STEP_LONG) { slot[u] = step_read[t[u]]; id[u] = node_id[t[u]]; }
         }
-        uint4 sr[WS_U], rr[WS_U];
+        uint2 sr[WS_U];
+        uint4 rr[WS_U];
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
-            sr[u] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u); rr[u] = make_uint4(0u, 0u, 0u, 0u);
+            sr[u] = make_uint2(0xFFFFFFFFu, 0u); rr[u] = make_uint4(0u, 0u, 0u, 0u);
             if (slot[u] != NO_SLOT) { sr[u] = slot_rec[slot[u]]; rr[u] = read_rec[slot[u]]; }
         }
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
             nl[u] = 0;
             const bool counted = slot[u] != NO_SLOT && (int)sr[u].x >= 0 && (uint32_t)(t[u] - rr[u].x) + 1 < rr[u].y;   // not the last step
-            if (counted && id[u] >= sr[u].y && id[u] - sr[u].y < sr[u].w) nl[u] = node_len[sr[u].z + (id[u] - sr[u].y)];
+            if (counted) nl[u] = node_len[id[u] + sr[u].y];
         }
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
@@ -433,9 +495,10 @@ __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, c
     size_s[key] = (pos + 63) & ~63u;
 }
 __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
-                                                         const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, int shift,
+                                                         const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend,
+                                                         const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, int shift,
                                                          const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
-                                                         const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
+                                                         const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec, uint2 *__restrict__ g_qm,
                                                          uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read,
                                                          uint8_t *__restrict__ g_step_dup) {
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
@@ -444,6 +507,7 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint3
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
         const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
+        g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
         if (k > 64) continue;                            // laid out by group_fill_long_kernel, one workgroup per walk
         for (uint32_t i = 0; i < k; ++i) {
             const uint32_t id = node_id[b + i];
@@ -505,8 +569,12 @@ __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const 
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     rd->T_pad = 0;
     rd->n_long = 0;
+    rd->n_slots = 0;
+    rd->g_flags_valid = false;
+    rd->species_valid = false;
     PTX_HIP(ctx, rd->d_slot_of.alloc(rd->R ? rd->R : 1));
     PTX_HIP(ctx, rd->d_g_slot_rec.alloc(rd->R ? rd->R : 1));
+    PTX_HIP(ctx, rd->d_g_qm.alloc(rd->R ? rd->R : 1));
     if (rd->R == 0) return 0;
     if (rd->T == 0) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_slot_of.p, 0xFF, rd->R * sizeof(uint32_t), ctx->stream));
@@ -537,11 +605,13 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     hipLaunchKernelGGL(group_layout_kernel, dim3((NU + 255) / 256), dim3(256), 0, ctx->stream, NB, g, base_r, slot_len.p, slot_rel.p, size_s);
     PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NU, scan_tmp.p, d_total));
     const int ushift = shift + g;   // unit of a read = its first node id >> ushift
-    uint32_t h_tot[2] = {0, 0};
+    uint32_t h_tot[2] = {0, 0}, h_slots = 0;
     PTX_TRY(download(ctx, h_tot, d_total, 2));
+    PTX_TRY(download(ctx, &h_slots, base_r + NB, 1));   // reads that own a slot (non-empty walk)
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t h_total = h_tot[0];
     rd->n_long = h_tot[1];
+    rd->n_slots = h_slots;
     if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
     rd->T_pad = h_total;
     PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
@@ -549,7 +619,8 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0, rd->T_pad, ctx->stream));                             // pad steps carry no code
     hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
-                       rd->d_pend.p, ushift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
+                       rd->d_pend.p, rd->d_qlen.p, rd->d_mapq.p, ushift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_qm.p, rd->d_g_node_id.p,
+                       rd->d_g_step_read.p, rd->d_g_step_dup.p);
     if (rd->n_long) {
         const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
         hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, ushift, base_s,
@@ -563,12 +634,14 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
 }
 
 // node_base_cov[v] = number of covered bases (profile.rs:844/874, :1018-1023)
-__global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_t *__restrict__ bit_off,
+// a node some step covered whole carries a flag instead of marked bits (coverage_step_kernel): its count is its length
+__global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_t *__restrict__ bit_off, const uint32_t *__restrict__ full,
                                                        const uint32_t *__restrict__ bitmap, uint32_t *__restrict__ cov) {
     for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (uint64_t)gridDim.x * 256) {
         uint64_t g0 = bit_off[v], g1 = bit_off[v + 1];
         uint32_t c = 0;
-        if (g1 > g0) {
+        if ((full[v >> 5] >> (uint32_t)(v & 31)) & 1u) c = (uint32_t)(g1 - g0);
+        else if (g1 > g0) {
             uint64_t w0 = g0 >> 5, w1 = (g1 - 1) >> 5;
             uint32_t m0 = 0xFFFFFFFFu << (g0 & 31);
             uint32_t m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
@@ -588,14 +661,17 @@ __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     const uint64_t words = (db->L + 31) / 32 + 1;
     const uint64_t U = with_trio ? db->U : 0;
-    // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32]
-    const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = off_abort + 8, total = off_bm + words * 4;
+    // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32][full-node flags: 1 bit per node, padded by a window]
+    const uint64_t fwords = (db->V + COV_WIN + 63) / 32 + 2;
+    const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = off_abort + 8, off_full = off_bm + words * 4,
+                 total = off_full + fwords * 4;
     PTX_HIP(ctx, db->d_cov_arena.alloc(total));
     uint8_t *base = db->d_cov_arena.p;
     db->d_bases.view(base, db->V);
     db->d_trio_bases.view(base + off_trio, U ? U : 1);
     db->d_abort = reinterpret_cast<unsigned long long *>(base + off_abort);
     db->d_bitmap.view(base + off_bm, words);
+    db->d_full.view(base + off_full, fwords);
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
     PTX_TRY(zero_fill(ctx, base, total));
     if (rd->R && rd->T_pad && rd->n_long) {
@@ -624,11 +700,17 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
         if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
         KTimer t(ctx, "coverage_step_kernel");
+        // PANTAX_COV_XCD=1: every XCD walks one contiguous eighth of the stream (measured slower than launch order: 1.42 vs 1.30 ms at cfg3)
+        uint32_t xcd_map = 0, ablate = 0;
+        if (const char *ev = std::getenv("PANTAX_COV_XCD")) xcd_map = (uint32_t)std::atoi(ev);
+        if (const char *ev = std::getenv("PANTAX_COV_ABLATE")) ablate = (uint32_t)std::atoi(ev);
 #define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
-                  db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, rd->d_long_len0.p
+                  db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, \
+                  rd->d_long_len0.p, n_chunks, xcd_map, ablate
 #define COVS_LAUNCH(UU, PP)                                                                                                                  \
         {                                                                                                                                    \
-            const int grid = (int)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));                       \
+            const uint32_t n_chunks = (uint32_t)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));         \
+            const int grid = xcd_map ? (int)(((n_chunks + 7) / 8) * 8) : (int)n_chunks;                                                      \
             if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS); \
             else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);          \
         }
@@ -648,7 +730,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     if (db->V) {
         KTimer t(ctx, "popcount_kernel");
         hipLaunchKernelGGL(popcount_kernel, dim3(grid_for(db->V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, db->V,
-                           db->d_bit_off.p, db->d_bitmap.p, db->d_cov.p);
+                           db->d_bit_off.p, db->d_full.p, db->d_bitmap.p, db->d_cov.p);
     }
     PTX_HIP(ctx, hipGetLastError());
     db->cov_done = true;

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) walk_check_kernel(const uint64_t *__restr
 }
 
 // species-local lookup heads / rows -> their place in the batch
-__global__ void __launch_bounds__(256) trio_rebase_kernel(uint32_t n_nodes, uint32_t n_rows, uint32_t row_base, uint32_t *__restrict__ first /* [n_nodes] slice */,
+__global__ void __launch_bounds__(256) trio_rebase_kernel(uint32_t n_nodes, uint32_t n_rows, uint32_t row_base, uint32_t node_base, uint32_t *__restrict__ first /* [n_nodes] slice */,
                                                           uint32_t next_first_local /* = local first[n_nodes] */, uint4 *__restrict__ node_rec,
                                                           uint4 *__restrict__ ent /* [n_rows] slice */, uint32_t *__restrict__ err) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) trio_rebase_kernel(uint32_t n_nodes, uint
         r.y = (r.y & 0xFFu) | ((nx - f) << 8); r.w = f + row_base;   // the lookup head rides in the node record
         node_rec[i] = r;
     }
-    if (i < n_rows) ent[i].z += row_base;
+    if (i < n_rows) { uint4 e = ent[i]; e.x += node_base; e.y += node_base; e.z += row_base; ent[i] = e; }   // images hold species-local (b, c, row)
 }
 __global__ void __launch_bounds__(256) add_u32_kernel(uint32_t n, uint32_t *__restrict__ v, uint32_t add) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -78,7 +78,7 @@ int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t
     const uint32_t m = (uint32_t)std::max<uint64_t>(n, n_rows);
     if (m == 0) return 0;
     // heads first (they read the local firsts), then the firsts themselves move
-    hipLaunchKernelGGL(trio_rebase_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t)n, (uint32_t)n_rows, (uint32_t)row_base,
+    hipLaunchKernelGGL(trio_rebase_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t)n, (uint32_t)n_rows, (uint32_t)row_base, (uint32_t)nb,
                        db->d_trio_first.p + nb, (uint32_t)n_rows, db->d_node_rec.p + nb, db->d_trio_ent.p + row_base, d_err);
     if (n && row_base) hipLaunchKernelGGL(add_u32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)n, db->d_trio_first.p + nb, (uint32_t)row_base);
     PTX_HIP(ctx, hipGetLastError());

@@ -457,6 +457,7 @@ extern "C" int pantax_hip_reads_set_flags(pantax_hip_ctx *ctx, pantax_hip_reads 
     PTX_ENTER(ctx);
     reads->has_flags = flags != nullptr;
     if (flags) { PTX_TRY(upload(ctx, reads->d_flags, flags, reads->R)); PTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+    reads->g_flags_valid = false;
     reads->binned = false;   // the per-slot species carry the drop flags: bin again
     return 0;
 }

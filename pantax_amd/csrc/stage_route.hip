@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) route_max_kernel(uint64_t n, const uint32
 int route_pack(Ctx *ctx, const Db *db, const Reads *rd, const int32_t *owner_of_species, int W, Route &rt) {
     if (W < 1 || W > ROUTE_MAXW) return fail(ctx, PANTAX_HIP_E_LIMIT, "route_pack: %d owners (at most %d)", W, ROUTE_MAXW);
     if (!rd->binned) return fail(ctx, PANTAX_HIP_E_STATE, "route_pack: call pantax_hip_bin_reads on these reads first");
+    PTX_TRY(species_ensure(ctx, const_cast<Reads *>(rd)));   // resident (grouped) reads keep the species per slot
     for (uint32_t s = 0; s < db->S; ++s)
         if (owner_of_species[s] >= W) return fail(ctx, PANTAX_HIP_E_INVALID, "route_pack: species %u is owned by rank %d of %d", s, owner_of_species[s], W);
     rt.W = W;

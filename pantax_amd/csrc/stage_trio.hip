@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
         uint32_t g, a, b, c;
         window_of(q, qend, nbase, path_nodes, g, a, b, c);
         const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
-        trio_ent[j] = make_uint4(b, c, row, 0u);
+        trio_ent[j] = make_uint4(nbase + b, nbase + c, row, 0u);   // global node indices: the coverage pass works in them throughout
         if (KEYS) {
             abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
             hap_out[row] = h - (uint32_t)hap_off[sidx];
