@@ -53,7 +53,8 @@ __device__ __forceinline__ uint32_t bm_peek(const uint32_t *p) {
 // Bits [g0,g1) of the coverage bit vector are marked through the workgroup's LDS bit window (words
 // [bw0, bw0 + COV_BWIN) of the global vector); words outside the window take the global test-then-OR path.  The window is ORed into memory once per workgroup.
 constexpr uint32_t COV_BWIN = 2048;   // 32-bit words: 64 kbit of graph bases
-constexpr int COV_WIN = 1024;         // nodes in the LDS window of `bases` (a multiple of 64 nodes from a multiple of 64: the full-node flags flush as ballots)
+constexpr int COV_WIN = 2048;         // nodes in the LDS window of `bases` (a multiple of 64 nodes from a multiple of 64: the full-node flags flush as ballots);
+                                      // 2048 steps of 1e7 reads over 3.2e7 nodes span ~1000 nodes: 1024 overflowed on most chunks
 // the LDS windows of the coverage kernel live at file scope: helpers that received them as (generic) pointer arguments
 // made this compiler emit an illegal null check of the shared-memory aperture
 __shared__ uint32_t s_win[COV_WIN];
@@ -123,10 +124,7 @@ __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases
 __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t wlo, uint32_t win_n, uint32_t v) {
     const uint32_t off = v - wlo;
     if (off < win_n) s_full[off] = 1;     // plain byte stores of the same value: no atomic, nothing to lose
-    else {
-        const uint32_t m = 1u << (v & 31);
-        if (!(bm_peek(&full[v >> 5]) & m)) atomicOr(&full[v >> 5], m);
-    }
+    else atomicOr(&full[v >> 5], 1u << (v & 31));   // no test-before-set: the probe is a dependent round trip, the OR is fire-and-forget
 }
 
 // Steps arrive grouped by the locus of their read's first node (build_step_read below), so a workgroup's
@@ -290,7 +288,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 if (target >= 0) {                                    // :821-827
                     if (target && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], (uint32_t)target);
                     if (ps < pe && pe <= nl && !ABL(1u)) {            // :832
-                        if (ps == 0 && pe == nl) mark_full(full, wlo, win_n, v[u]);
+                        if (ps == 0 && pe == nl) { if (!ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
+                        else if (ABL(16u)) {}
                         else if (in_win) mark_window((uint32_t)rel + ps, (uint32_t)rel + pe);
                         else mark_range(bitmap, bw0, bwn, bo + ps, bo + pe);
                     }
@@ -325,7 +324,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 uint32_t hi = sidx + aln;
                 if (hi > nl) hi = nl;                                 // :871
                 if (ABL(1u)) {}
-                else if (sidx == 0 && hi == nl) { if (nl) mark_full(full, wlo, win_n, v[u]); }
+                else if (sidx == 0 && hi == nl) { if (nl && !ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
+                else if (ABL(16u)) {}
                 else if (in_win) mark_window((uint32_t)rel + sidx, (uint32_t)rel + hi);
                 else mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
                 if (jf < 0) {
@@ -365,14 +365,13 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             const unsigned long long fb = __ballot(s_full[i] != 0);
             if (fb && (lane & 31) == 0) {
                 const uint32_t m = (uint32_t)(fb >> (lane & 32));
-                uint32_t *w = &full[(wlo + i) >> 5];
-                if (m && (bm_peek(w) & m) != m) atomicOr(w, m);
+                if (m) atomicOr(&full[(wlo + i) >> 5], m);
             }
         }
     }
     for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
         const uint32_t m = s_bm[i];
-        if (m && (bm_peek(&bitmap[bw0 + i]) & m) != m) atomicOr(&bitmap[bw0 + i], m);
+        if (m) atomicOr(&bitmap[bw0 + i], m);     // nothing waits for these (a probe first would be a dependent round trip per word)
     }
 }
 
