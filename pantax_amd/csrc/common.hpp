@@ -324,10 +324,10 @@ struct Reads {
     // Walks of at most 64 steps never straddle a 64-step boundary of the stream (pad steps carry slot 0xFFFFFFFF),
     // so a wave of the coverage kernel always holds whole reads.
     uint64_t T_pad = 0;              // steps in the padded stream
-    DevBuf<uint32_t> d_g_node_id, d_g_step_read, d_slot_of;   // [T_pad] node ids, [T_pad] slot of each step, [R] read -> slot (~0: no walk)
+    DevBuf<uint32_t> d_g_node_id, d_g_group_slot, d_slot_of;  // [T_pad] node ids, [T_pad / 64] slot of the read that owns each 64-step group's first step, [R] read -> slot (~0: no walk)
     DevBuf<uint4> d_g_read_rec;      // [R'] {first step, #steps, pstart, pend}
-    DevBuf<uint8_t> d_g_step_dup;    // [T_pad] walks <= 64 steps: distance back to the first occurrence of the step's node (0 none);
-                                     //         longer walks: 0x80 | (node occurred earlier in the walk)
+    DevBuf<uint8_t> d_g_step_dup;    // [T_pad] step codes: walks <= 64 steps: distance back to the first occurrence of the step's node (0 none);
+                                     //         longer walks: 0x80 | (node occurred earlier in the walk); both | 0x40 on a walk's first step; pads 0xFF
     DevBuf<uint32_t> d_long_sum;     // [R'] walks > 64 steps: node lengths of all steps but the last (walk_sum_kernel), else unused
     DevBuf<uint32_t> d_long_len0;    // [R'] walks > 64 steps: length of the walk's first node (walk_sum_kernel)
     uint32_t n_long = 0;             // walks of more than 64 steps

@@ -96,6 +96,15 @@ __device__ __forceinline__ void mark_window(uint32_t r0, uint32_t r1) {
 // the walk (0 = none); longer walks carry STEP_LONG | (1 if the node occurred earlier in the walk).  Where the first
 // occurrence sits matters only through "is it step 0" (profile.rs:853-856 vs :860-862), i.e. id == id of step 0.
 constexpr uint32_t STEP_LONG = 0x80u;
+// ... and, both kinds, STEP_START on the first step of a walk; pad steps carry STEP_PAD.  The slots of the grouped copy follow
+// the stream (build_step_read lays the walks out in slot order), so a step's slot is not stored per step: group_slot[g] names
+// the read that owns the first step of the 64-step group g, and every later walk start in the group advances it by one.
+constexpr uint32_t STEP_START = 0x40u, STEP_PAD = 0xFFu, STEP_DIST = 0x3Fu;
+__device__ __forceinline__ uint32_t slot_in_group(uint32_t group_first_slot, uint32_t code, int lane) {
+    const unsigned long long starts = __ballot(code != STEP_PAD && (code & STEP_START)) & ~1ull;   // lane 0's walk is group_first_slot itself
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));   // starts in lower lanes
+    return group_first_slot + below + (uint32_t)((starts >> lane) & 1ull);
+}
 
 // read_nodes_len of position j (never the last position) of a long walk: the length aligned at the node's FIRST
 // occurrence in the read (profile.rs:879-882)
@@ -127,6 +136,160 @@ __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t 
     else atomicOr(&full[v >> 5], 1u << (v & 31));   // no test-before-set: the probe is a dependent round trip, the OR is fire-and-forget
 }
 
+// ---------------------------------------------------------------------------------------------
+// The short-read kernel: every 64-step group whose walks all have <= 64 steps (no STEP_LONG code: all of a short-read
+// sample).  Such walks never straddle a group, so a wave holds whole reads and NOTHING of a step's read lives outside the
+// wave: no border lanes, no walk sums, no per-step slot array.  Written for instruction count -- the kernel is bound by VALU /
+// SALU issue at full occupancy, not by bytes (round 2: 337 VALU + 270 SALU wave-instructions per 64 steps, most of the SALU
+// from exec-mask branches): loads are unconditional with a safe index on dead lanes, per-lane cases are selects, and only
+// the LDS / memory updates sit under a mask.  Groups that hold a step of a longer walk are left to coverage_step_kernel.
+// Levels: {code, node id} + group_slot (scalar) -> {read record 16 B, slot record 8 B} -> {node record 16 B, active byte}
+// -> two unique-trio entries.
+template <bool WITH_TRIO, int PASSES>
+__global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
+    uint32_t n_groups, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
+    const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
+    const uint4 *__restrict__ node_rec, const uint64_t *__restrict__ bit_off, uint64_t V, unsigned long long *__restrict__ bases,
+    uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
+    unsigned long long *__restrict__ n_abort, uint32_t ablate) {
+    constexpr int WAVES = COV_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t g0 = blockIdx.x * (uint32_t)(WAVES * PASSES);
+    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
+    for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
+    for (int i = threadIdx.x; i < COV_WIN / 4; i += COV_BLOCK) reinterpret_cast<uint32_t *>(s_full)[i] = 0;
+    // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
+    uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
+    uint64_t bw0 = 0;
+#pragma unroll 1
+    for (int c = 0; c < WAVES * PASSES && win_n == 0; ++c) {
+        const uint32_t g = g0 + (uint32_t)c;
+        if (g >= n_groups) break;
+        const uint32_t gs = group_slot[g];
+        if (gs == NO_SLOT) continue;
+        const uint2 sr0 = slot_rec[gs];
+        if ((int)sr0.x < 0 || (active && !active[sr0.x])) continue;
+        const uint32_t v0 = node_id[(uint64_t)g * 64] + sr0.y;
+        wlo = (v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u) & ~63u;
+        win_n = COV_WIN;
+        const uint64_t b_lo = bit_off[wlo], b_hi = bit_off[min((uint64_t)wlo + COV_WIN, V)];
+        bw0 = b_lo >> 5;
+        bit0_lo = (uint32_t)(bw0 << 5);
+        bwn = COV_BWIN;
+        // every node of the window has its bits inside the LDS bit window: a partial range is marked in 32-bit positions relative to it
+        mark_n = (b_hi - (bw0 << 5) <= (uint64_t)COV_BWIN * 32) ? (uint32_t)min((uint64_t)COV_WIN, V - wlo) : 0u;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const uint32_t g = g0 + (uint32_t)(pass * WAVES + wave);
+        if (g >= n_groups) break;
+        const uint64_t t = (uint64_t)g * 64 + lane;
+        // ---- level 1
+        const uint32_t code = step_code[t], id = node_id[t];
+        const uint32_t gs = group_slot[g];
+        const bool pad = code == STEP_PAD;
+        if (__all(pad) || __any(!pad && (code & STEP_LONG))) continue;     // nothing here / a longer walk's steps: coverage_step_kernel's group
+        // ---- level 2 (dead lanes read the group's first record: in range, and on a line that is fetched anyway)
+        const uint32_t slot = pad ? gs : slot_in_group(gs, code, lane);
+        const uint4 rr = read_rec[slot];
+        const uint2 sr = slot_rec[slot];
+        const int sp = (int)sr.x;
+        bool ok = !pad && sp >= 0;
+        // ---- level 3
+        const uint32_t v = ok ? id + sr.y : wlo;
+        const uint4 nr = node_rec[v];
+        if (active) ok = ok && active[ok ? sp : 0] != 0;
+        const uint32_t b = rr.x, k = rr.y, ps = rr.z, pe = rr.w;
+        const uint32_t i = (uint32_t)t - b;                                  // position in the walk (T_pad < 2^32)
+        if (__any(!pad && slot_aborts(sp))) {                               // rare: a walk that leaves its species' graph (profile.rs:849)
+            if (!pad && slot_aborts(sp) && i == 0 && (!active || active[slot_species(sp)])) atomicAdd(n_abort, 1ull);
+        }
+        const uint32_t nl = ok ? nr.z : 0u;
+        const int first_lane = lane - (int)i;                               // lane of step 0 of my read (live lanes)
+        const uint32_t len0 = __shfl(nl, first_lane);
+        // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as early as the head is known
+        const uint32_t v1 = wave_shr1(v), v2 = wave_shr1(v1);
+        const uint32_t hw2 = wave_shr1(wave_shr1(nr.w)), hn2 = wave_shr1(wave_shr1(nr.y >> 8));
+        const bool single = k == 1u;
+        const bool dead_read = !single && ps > len0;                          // assert :854 -> the whole read contributes nothing
+        bool live = ok && !dead_read && !(single && pe < ps);                // :821-827
+        uint32_t nh = 0, hx = 0, tcc = 0;
+        uint4 e0 = make_uint4(0u, 0u, 0u, 0u), e1 = e0;
+        if (WITH_TRIO && !ABL(4u)) {
+            const bool lo_end = v <= v2;                                      // canonical window (min end, middle, max end): the head belongs to the smaller end
+            hx = lo_end ? nr.w : hw2;
+            nh = (live && i >= 2u) ? (lo_end ? nr.y >> 8 : hn2) : 0u;
+            tcc = lo_end ? v2 : v;
+            e0 = trio_ent[nh ? hx : 0u];
+            e1 = trio_ent[nh > 1u ? hx + 1u : 0u];
+        }
+        if (__any(ok && dead_read && i == 0u)) { if (ok && dead_read && i == 0u) atomicAdd(n_abort, 1ull); }
+        // ---- aligned lengths: `seen` before this step = wave prefix sum of the walk's aligned lengths minus its value at the walk's first lane
+        const uint32_t contrib = (live && !single) ? (i == 0u ? nl - ps : nl) : 0u;
+        const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
+        const uint32_t seen = pexcl - __shfl(pexcl, first_lane);
+        const uint32_t tgt = pe - ps;                                         // target (profile.rs:800) where it is not negative
+        const bool last = i + 1u == k;
+        uint32_t aln = nl;                                                    // :860-862
+        if (last) aln = (pe >= ps && tgt > seen) ? tgt - seen : 0u;           // :857-859 max(target - seen, 0)
+        if (i == 0u) aln = single ? tgt : nl - ps;                            // :853-856, :828
+        const uint32_t sidx = i == 0u ? ps : 0u;
+        uint32_t hi = sidx + aln;
+        if (hi > nl) hi = nl;                                                 // :871
+        const bool markable = live && hi > sidx && !(single && !(ps < pe && pe <= nl));   // :832
+        const uint32_t dupd = code & STEP_DIST;                               // distance back to the node's first occurrence in the walk (0: this is it)
+        const uint32_t rl = !live ? 0u : dupd == 0u ? aln : (dupd == i ? len0 - ps : nl);   // read_nodes_len :879-882
+        const uint32_t off = v - wlo;                                         // unsigned wrap: nodes below the window are out of range too
+        const bool inw = off < win_n;
+        // ---- updates
+        if (live && dupd == 0u && aln && !ABL(2u)) {                          // :881 / :828
+            if (inw && aln < (1u << 18)) atomicAdd(&s_win[off], aln);
+            else atomicAdd(&bases[v], (unsigned long long)aln);
+        }
+        if (markable && !ABL(1u)) {
+            if (sidx == 0u && hi == nl) {                                     // the whole node: one flag
+                if (inw) s_full[off] = 1; else atomicOr(&full[v >> 5], 1u << (v & 31));
+            } else if (off < mark_n) {
+                const uint32_t rel = nr.x - bit0_lo;
+                mark_window(rel + sidx, rel + hi);
+            } else {
+                const uint64_t bo = nr_bit_off(nr);
+                mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
+            }
+        }
+        if (WITH_TRIO && !ABL(4u)) {                                          // :890-907
+            const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
+            int row = -1;
+            if (nh && e0.x == v1 && e0.y == tcc) row = (int)e0.z;
+            else if (nh > 1u && e1.x == v1 && e1.y == tcc) row = (int)e1.z;
+            else if (nh > 2u)
+                for (uint32_t j = 2; j < nh; ++j) {
+                    const uint4 e = trio_ent[hx + j];
+                    if (e.x == v1 && e.y == tcc) { row = (int)e.z; break; }
+                }
+            const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
+            if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
+        }
+    }
+    __syncthreads();
+    if (win_n) {
+        for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
+            const uint32_t c = s_win[i];
+            if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
+            const unsigned long long fb = __ballot(s_full[i] != 0);
+            if (fb && (lane & 31) == 0) {
+                const uint32_t m = (uint32_t)(fb >> (lane & 32));
+                if (m) atomicOr(&full[(wlo + i) >> 5], m);
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
+            const uint32_t m = s_bm[i];
+            if (m) atomicOr(&bitmap[bw0 + i], m);
+        }
+    }
+}
+
 // Steps arrive grouped by the locus of their read's first node (build_step_read below), so a workgroup's
 // chunk of consecutive steps lands in a narrow node window: `bases` is accumulated in an LDS
 // window of COV_WIN nodes (32-bit LDS atomics) and flushed with one 64-bit global atomic per touched
@@ -150,11 +313,12 @@ __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t 
 // chunks -- which share the node records and bitmap lines at their seam -- meet in the same L2.
 template <bool WITH_TRIO, int U, int PASSES>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
-    uint64_t T, const uint32_t *__restrict__ step_read, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
+    uint64_t T, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active,
     const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full,
     const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort,
-    const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0, uint32_t n_chunks, uint32_t xcd_map, uint32_t ablate) {
+    const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0, uint32_t n_chunks, uint32_t xcd_map, uint32_t ablate,
+    uint32_t only_long /* 1: groups without a step of a longer walk belong to coverage_fast_kernel */) {
     constexpr int CHUNK = COV_BLOCK * U * PASSES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t chunk = blockIdx.x;
@@ -178,7 +342,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     for (int c = 0; c < CHUNK / COV_BLOCK; ++c) {
         const uint64_t tc = chunk_b + (uint64_t)c * COV_BLOCK;
         if (win_n == 0 && tc < chunk_e) {
-            const uint32_t slot = step_read[tc];
+            const uint32_t slot = group_slot[tc >> 6];          // tc is a multiple of 64: the read that owns the group's first step
             if (slot != NO_SLOT) {
                 const uint2 sr0 = slot_rec[slot];
                 if ((int)sr0.x >= 0 && !(active && !active[sr0.x])) {
@@ -203,11 +367,15 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t t = wbase + (uint64_t)u * 64 + lane;
-            ok[u] = t < chunk_e;
-            slot[u] = NO_SLOT; id[u] = 0; dupc[u] = 0;
+            ok[u] = t < chunk_e;                                     // whole groups: T_pad and the chunk size are multiples of 64
+            slot[u] = NO_SLOT; id[u] = 0; dupc[u] = STEP_PAD;
             ti[u] = (uint32_t)t;                                     // T_pad < 2^32 (build_step_read)
-            if (ok[u]) { slot[u] = step_read[t]; id[u] = node_id[t]; dupc[u] = step_dup[t]; }
-            ok[u] = ok[u] && slot[u] != NO_SLOT;
+            if (ok[u]) { id[u] = node_id[t]; dupc[u] = step_dup[t]; }
+            const uint32_t gs = ok[u] ? group_slot[t >> 6] : NO_SLOT;
+            const uint32_t sl = slot_in_group(gs, dupc[u], lane);
+            ok[u] = ok[u] && dupc[u] != STEP_PAD;
+            if (only_long && !__any(ok[u] && (dupc[u] & STEP_LONG))) ok[u] = false;   // a short-read group: the other kernel's
+            if (ok[u]) slot[u] = sl;
         }
         // ---- level 2: per-read records
         uint4 rr[U];
@@ -312,7 +480,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             if (live) {
                 int jf = -1;                                          // -1: first occurrence; 0: the node of step 0; 1: another earlier step
                 if (dupc[u] & STEP_LONG) { if (dupc[u] & 1u) jf = (id[u] == (cross[u] ? node_id[b] : id0)) ? 0 : 1; }
-                else if (dupc[u]) jf = (int)i - (int)dupc[u];
+                else if (dupc[u] & STEP_DIST) jf = (int)i - (int)(dupc[u] & STEP_DIST);
                 uint32_t aln, sidx;
                 if (i == 0) { aln = nl - ps; sidx = ps; }             // :853-856
                 else if (i == k - 1) {                                // :857-859
@@ -379,7 +547,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 // other waves.  One cheap pass over the steps of long walks adds the node lengths of all steps but the last into
 // long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
 template <int WS_U>
-__global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ step_read, const uint8_t *__restrict__ step_dup,
+__global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ group_slot, const uint8_t *__restrict__ step_dup,
                                                        const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
                                                        const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ node_len,
                                                        uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
@@ -395,14 +563,16 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
             t[u] = base + (uint64_t)u * 64 + lane;
-            code[u] = t[u] < T ? step_dup[t[u]] : 0u;
-            any = any || (code[u] & STEP_LONG);
+            code[u] = t[u] < T ? step_dup[t[u]] : STEP_PAD;
+            any = any || (code[u] != STEP_PAD && (code[u] & STEP_LONG));
         }
         if (!__any(any)) continue;
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
             slot[u] = NO_SLOT; id[u] = 0;
-            if (code[u] & STEP_LONG) { slot[u] = step_read[t[u]]; id[u] = node_id[t[u]]; }
+            const uint32_t gs = t[u] < T ? group_slot[t[u] >> 6] : NO_SLOT;
+            const uint32_t sl = slot_in_group(gs, code[u], lane);
+            if (code[u] != STEP_PAD && (code[u] & STEP_LONG)) { slot[u] = sl; id[u] = node_id[t[u]]; }
         }
         uint2 sr[WS_U];
         uint4 rr[WS_U];
@@ -498,7 +668,7 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint3
                                                          const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, int shift,
                                                          const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
                                                          const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec, uint2 *__restrict__ g_qm,
-                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_step_read,
+                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
                                                          uint8_t *__restrict__ g_step_dup) {
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t slot = slot_of[r];
@@ -508,12 +678,13 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint3
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
         g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
         if (k > 64) continue;                            // laid out by group_fill_long_kernel, one workgroup per walk
+        if ((sb & 63u) == 0u) g_group_slot[sb >> 6] = slot;      // a walk of <= 64 steps lies inside one 64-step group
         for (uint32_t i = 0; i < k; ++i) {
             const uint32_t id = node_id[b + i];
-            g_node_id[sb + i] = id; g_step_read[sb + i] = slot;
+            g_node_id[sb + i] = id;
             uint32_t dup = 0;
             for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = i - j; break; }
-            g_step_dup[sb + i] = (uint8_t)dup;
+            g_step_dup[sb + i] = (uint8_t)(dup | (i == 0 ? STEP_START : 0u));
         }
     }
 }
@@ -525,7 +696,7 @@ constexpr uint32_t LONG_HASH = 8192;
 __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
                                                               int shift, const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
                                                               const uint32_t *__restrict__ slot_rel, uint32_t *__restrict__ g_node_id,
-                                                              uint32_t *__restrict__ g_step_read, uint8_t *__restrict__ g_step_dup) {
+                                                              uint32_t *__restrict__ g_group_slot, uint8_t *__restrict__ g_step_dup) {
     __shared__ uint32_t h_key[LONG_HASH], h_pos[LONG_HASH];
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     for (uint64_t r = blockIdx.x; r < R; r += gridDim.x) {
@@ -533,7 +704,10 @@ __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const 
         if (k <= 64) continue;
         const uint32_t slot = slot_of[r];
         const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
-        for (uint32_t i = threadIdx.x; i < k; i += 256) { g_node_id[sb + i] = node_id[b + i]; g_step_read[sb + i] = slot; }
+        for (uint32_t i = threadIdx.x; i < k; i += 256) {
+            g_node_id[sb + i] = node_id[b + i];
+            if (((sb + i) & 63u) == 0u) g_group_slot[(sb + i) >> 6] = slot;   // every group this walk's steps begin
+        }
         if (k <= LONG_HASH / 2) {
             for (uint32_t i = threadIdx.x; i < LONG_HASH; i += 256) { h_key[i] = EMPTY; h_pos[i] = EMPTY; }
             __syncthreads();
@@ -551,7 +725,7 @@ __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const 
                 const uint32_t id = node_id[b + i];
                 uint32_t h = (id * 2654435761u) >> 19;
                 while (h_key[h] != id) h = (h + 1) & (LONG_HASH - 1);
-                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | (h_pos[h] < i ? 1u : 0u));
+                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | (h_pos[h] < i ? 1u : 0u) | (i == 0 ? STEP_START : 0u));
             }
             __syncthreads();
         } else {
@@ -559,7 +733,7 @@ __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const 
                 const uint32_t id = node_id[b + i];
                 uint32_t dup = 0;
                 for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = 1; break; }
-                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | dup);
+                g_step_dup[sb + i] = (uint8_t)(STEP_LONG | dup | (i == 0 ? STEP_START : 0u));
             }
         }
     }
@@ -613,17 +787,17 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     rd->n_slots = h_slots;
     if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
     rd->T_pad = h_total;
-    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_read.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
+    PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_group_slot.alloc(rd->T_pad / 64 + 1)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_read.p, 0xFF, rd->T_pad * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0, rd->T_pad, ctx->stream));                             // pad steps carry no code
+    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_group_slot.p, 0xFF, (rd->T_pad / 64 + 1) * sizeof(uint32_t), ctx->stream));
+    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0xFF, rd->T_pad, ctx->stream));                          // STEP_PAD
     hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
                        rd->d_pend.p, rd->d_qlen.p, rd->d_mapq.p, ushift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_qm.p, rd->d_g_node_id.p,
-                       rd->d_g_step_read.p, rd->d_g_step_dup.p);
+                       rd->d_g_group_slot.p, rd->d_g_step_dup.p);
     if (rd->n_long) {
         const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
         hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, ushift, base_s,
-                           rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_step_read.p, rd->d_g_step_dup.p);
+                           rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);
         PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R));
         PTX_HIP(ctx, rd->d_long_len0.alloc(rd->R));
     }
@@ -676,7 +850,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");
-        hipLaunchKernelGGL(walk_sum_kernel<4>, dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_step_read.p,
+        hipLaunchKernelGGL(walk_sum_kernel<4>, dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_group_slot.p,
                            rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, db->d_node_len.p, rd->d_long_sum.p,
                            rd->d_long_len0.p);
     }
@@ -692,38 +866,52 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     db->trio_free_valid = false;   // a reader of the unique-trio tables goes onto the stream: the event of an earlier strain step no longer covers them
     unsigned long long *d_abort = db->d_abort;
     if (rd->R && rd->T_pad) {
-        // U groups of 64 steps in flight per wave, PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another
-        // instantiation, for measurements)
-        // 8 rounds per workgroup once the stream is long enough to keep every CU busy with 2048-step workgroups (the LDS
-        // windows are zeroed and flushed half as often: 1.10 -> 1.04 ms at 8e7 steps), 4 below (0.094 vs 0.100 ms at 8e6)
-        int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
-        if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
-        KTimer t(ctx, "coverage_step_kernel");
-        // PANTAX_COV_XCD=1: every XCD walks one contiguous eighth of the stream (measured slower than launch order: 1.42 vs 1.30 ms at cfg3)
         uint32_t xcd_map = 0, ablate = 0;
-        if (const char *ev = std::getenv("PANTAX_COV_XCD")) xcd_map = (uint32_t)std::atoi(ev);
-        if (const char *ev = std::getenv("PANTAX_COV_ABLATE")) ablate = (uint32_t)std::atoi(ev);
-#define COVS_ARGS rd->T_pad, rd->d_g_step_read.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
+        if (const char *ev = std::getenv("PANTAX_COV_XCD")) xcd_map = (uint32_t)std::atoi(ev);   // 1: every XCD walks one contiguous eighth of the stream (measured slower: 1.42 vs 1.30 ms at cfg3)
+        if (const char *ev = std::getenv("PANTAX_COV_ABLATE")) ablate = (uint32_t)std::atoi(ev);  // -DCOV_ABLATE builds only
+        const bool trio = with_trio && db->U;
+        KTimer t(ctx, "coverage_step_kernel");
+        // walks of <= 64 steps: the short-read kernel, one wave per 64-step group, PASSES groups per wave and workgroup (the LDS
+        // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
+        const uint32_t n_groups = (uint32_t)(rd->T_pad / 64);
+        if (rd->n_long < rd->n_slots && !std::getenv("PANTAX_COV_GENERAL")) {
+            constexpr int FP = 8;
+            const int grid = (int)((n_groups + (COV_BLOCK / 64) * FP - 1) / ((COV_BLOCK / 64) * FP));
+#define COVF_ARGS n_groups, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_node_rec.p, \
+                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate
+            if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, FP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVF_ARGS);
+            else hipLaunchKernelGGL((coverage_fast_kernel<false, FP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVF_ARGS);
+#undef COVF_ARGS
+        }
+        // groups that hold steps of longer walks (HiFi / ONT reads): the general kernel.  U groups of 64 steps in flight per wave,
+        // PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another instantiation, for measurements);
+        // PANTAX_COV_GENERAL=1 sends every group through it (measurements, and the tests force it).
+        if (rd->n_long || std::getenv("PANTAX_COV_GENERAL")) {
+            const uint32_t only_long = std::getenv("PANTAX_COV_GENERAL") ? 0u : 1u;
+            int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
+            if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
+#define COVS_ARGS rd->T_pad, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
                   db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, \
-                  rd->d_long_len0.p, n_chunks, xcd_map, ablate
+                  rd->d_long_len0.p, n_chunks, xcd_map, ablate, only_long
 #define COVS_LAUNCH(UU, PP)                                                                                                                  \
-        {                                                                                                                                    \
-            const uint32_t n_chunks = (uint32_t)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));         \
-            const int grid = xcd_map ? (int)(((n_chunks + 7) / 8) * 8) : (int)n_chunks;                                                      \
-            if (with_trio && db->U) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS); \
-            else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);          \
-        }
-        switch (shape) {
-            case 22: COVS_LAUNCH(2, 2) break;
-            case 21: COVS_LAUNCH(2, 1) break;
-            case 41: COVS_LAUNCH(4, 1) break;
-            case 42: COVS_LAUNCH(4, 2) break;
-            case 18: COVS_LAUNCH(1, 8) break;
-            case 14: COVS_LAUNCH(1, 4) break;
-            default: COVS_LAUNCH(1, 4) break;
-        }
+            {                                                                                                                                \
+                const uint32_t n_chunks = (uint32_t)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));     \
+                const int grid = xcd_map ? (int)(((n_chunks + 7) / 8) * 8) : (int)n_chunks;                                                  \
+                if (trio) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);  \
+                else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);      \
+            }
+            switch (shape) {
+                case 22: COVS_LAUNCH(2, 2) break;
+                case 21: COVS_LAUNCH(2, 1) break;
+                case 41: COVS_LAUNCH(4, 1) break;
+                case 42: COVS_LAUNCH(4, 2) break;
+                case 18: COVS_LAUNCH(1, 8) break;
+                case 14: COVS_LAUNCH(1, 4) break;
+                default: COVS_LAUNCH(1, 4) break;
+            }
 #undef COVS_LAUNCH
 #undef COVS_ARGS
+        }
     }
     PTX_HIP(ctx, hipGetLastError());
     if (db->V) {
