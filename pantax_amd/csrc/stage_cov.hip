@@ -57,38 +57,43 @@ constexpr int COV_WIN = 2048;         // nodes in the LDS window of `bases` (a m
                                       // 2048 steps of 1e7 reads over 3.2e7 nodes span ~1000 nodes: 1024 overflowed on most chunks
 // the LDS windows of the coverage kernel live at file scope: helpers that received them as (generic) pointer arguments
 // made this compiler emit an illegal null check of the shared-memory aperture
-__shared__ uint32_t s_win[COV_WIN];
-__shared__ uint32_t s_bm[COV_BWIN];
-__shared__ uint8_t s_full[COV_WIN];   // a step covered the whole node: its bits are not marked one by one (popcount_kernel takes the length)
-__device__ __forceinline__ void lds_or(uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
+// One dynamic LDS block per workgroup: [WIN u32 `bases` window][COV_BWIN u32 bit window][WIN u8 full-node flags: a step covered the
+// whole node, its bits are not marked one by one (popcount_kernel takes the length)].  WIN is a launch parameter of the
+// short-read kernel (a multiple of 256 nodes) and COV_WIN in the general one; helpers address the block by offsets.
+extern __shared__ uint32_t s_cov[];
+#define S_WIN(i) s_cov[(i)]
+#define S_BM(bmo, i) s_cov[(bmo) + (i)]
+#define S_FULL(bmo, i) reinterpret_cast<uint8_t *>(s_cov + (bmo) + COV_BWIN)[(i)]
+__host__ __device__ constexpr size_t cov_lds_bytes(int win) { return (size_t)win * 4 + COV_BWIN * 4 + (size_t)win; }
+__device__ __forceinline__ void lds_or(uint32_t *__restrict__ bm, uint32_t bmo, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
     const uint64_t off = w - bw0;     // unsigned wrap: words below the window are out of range too
     if (off < bwn) {
-        if ((s_bm[off] & m) != m) atomicOr(&s_bm[off], m);
+        if ((S_BM(bmo, off) & m) != m) atomicOr(&S_BM(bmo, off), m);
     } else if ((bm_peek(&bm[w]) & m) != m) atomicOr(&bm[w], m);
 }
-__device__ __forceinline__ void mark_range(uint32_t *__restrict__ bm, uint64_t bw0, uint32_t bwn, uint64_t g0, uint64_t g1) {
+__device__ __forceinline__ void mark_range(uint32_t *__restrict__ bm, uint32_t bmo, uint64_t bw0, uint32_t bwn, uint64_t g0, uint64_t g1) {
     if (g1 <= g0) return;
     uint64_t w0 = g0 >> 5, w1 = (g1 - 1) >> 5;
     uint32_t m0 = 0xFFFFFFFFu << (g0 & 31);
     uint32_t m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
-    if (w0 == w1) lds_or(bm, bw0, bwn, w0, m0 & m1);
+    if (w0 == w1) lds_or(bm, bmo, bw0, bwn, w0, m0 & m1);
     else {
-        lds_or(bm, bw0, bwn, w0, m0);
-        for (uint64_t w = w0 + 1; w < w1; ++w) lds_or(bm, bw0, bwn, w, 0xFFFFFFFFu);
-        lds_or(bm, bw0, bwn, w1, m1);
+        lds_or(bm, bmo, bw0, bwn, w0, m0);
+        for (uint64_t w = w0 + 1; w < w1; ++w) lds_or(bm, bmo, bw0, bwn, w, 0xFFFFFFFFu);
+        lds_or(bm, bmo, bw0, bwn, w1, m1);
     }
 }
 // the same for a range that lies inside the LDS bit window: 32-bit positions relative to the window, LDS only
-__device__ __forceinline__ void win_or(uint32_t w, uint32_t m) { if ((s_bm[w] & m) != m) atomicOr(&s_bm[w], m); }
-__device__ __forceinline__ void mark_window(uint32_t r0, uint32_t r1) {
+__device__ __forceinline__ void win_or(uint32_t bmo, uint32_t w, uint32_t m) { if ((S_BM(bmo, w) & m) != m) atomicOr(&S_BM(bmo, w), m); }
+__device__ __forceinline__ void mark_window(uint32_t bmo, uint32_t r0, uint32_t r1) {
     if (r1 <= r0) return;
     const uint32_t w0 = r0 >> 5, w1 = (r1 - 1) >> 5;
     const uint32_t m0 = 0xFFFFFFFFu << (r0 & 31), m1 = 0xFFFFFFFFu >> (31 - ((r1 - 1) & 31));
-    if (w0 == w1) win_or(w0, m0 & m1);
+    if (w0 == w1) win_or(bmo, w0, m0 & m1);
     else {
-        win_or(w0, m0);
-        for (uint32_t w = w0 + 1; w < w1; ++w) win_or(w, 0xFFFFFFFFu);
-        win_or(w1, m1);
+        win_or(bmo, w0, m0);
+        for (uint32_t w = w0 + 1; w < w1; ++w) win_or(bmo, w, 0xFFFFFFFFu);
+        win_or(bmo, w1, m1);
     }
 }
 
@@ -127,12 +132,12 @@ constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases, uint32_t wlo, uint32_t win_n, uint32_t v, uint32_t aln) {
     const uint32_t off = v - wlo;   // unsigned wrap puts nodes below the window out of range too
-    if (off < win_n && aln < (1u << 18)) atomicAdd(&s_win[off], aln);   // <= 8192 steps x 2^18 < 2^32
+    if (off < win_n && aln < (1u << 18)) atomicAdd(&S_WIN(off), aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
 }
 __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t wlo, uint32_t win_n, uint32_t v) {
     const uint32_t off = v - wlo;
-    if (off < win_n) s_full[off] = 1;     // plain byte stores of the same value: no atomic, nothing to lose
+    if (off < win_n) S_FULL(COV_WIN, off) = 1;     // plain byte stores of the same value: no atomic, nothing to lose
     else atomicOr(&full[v >> 5], 1u << (v & 31));   // no test-before-set: the probe is a dependent round trip, the OR is fire-and-forget
 }
 
@@ -145,7 +150,7 @@ __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t 
 // the LDS / memory updates sit under a mask.  Groups that hold a step of a longer walk are left to coverage_step_kernel.
 // Levels: {code, node id} + group_slot (scalar) -> {read record 16 B, slot record 8 B} -> {node record 16 B, active byte}
 // -> two unique-trio entries.
-template <bool WITH_TRIO, int PASSES>
+template <bool WITH_TRIO, int U, int PASSES, int WIN>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     uint32_t n_groups, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
@@ -153,16 +158,15 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
     unsigned long long *__restrict__ n_abort, uint32_t ablate) {
     constexpr int WAVES = COV_BLOCK / 64;
+    constexpr int GROUPS = WAVES * U * PASSES;                                // 64-step groups per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t g0 = blockIdx.x * (uint32_t)(WAVES * PASSES);
-    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
-    for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
-    for (int i = threadIdx.x; i < COV_WIN / 4; i += COV_BLOCK) reinterpret_cast<uint32_t *>(s_full)[i] = 0;
+    const uint32_t g0 = blockIdx.x * (uint32_t)GROUPS;
+    for (int i = threadIdx.x; i < (int)(cov_lds_bytes(WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the three windows, one block
     // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
     uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
     uint64_t bw0 = 0;
 #pragma unroll 1
-    for (int c = 0; c < WAVES * PASSES && win_n == 0; ++c) {
+    for (int c = 0; c < GROUPS && win_n == 0; ++c) {
         const uint32_t g = g0 + (uint32_t)c;
         if (g >= n_groups) break;
         const uint32_t gs = group_slot[g];
@@ -171,120 +175,154 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         if ((int)sr0.x < 0 || (active && !active[sr0.x])) continue;
         const uint32_t v0 = node_id[(uint64_t)g * 64] + sr0.y;
         wlo = (v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u) & ~63u;
-        win_n = COV_WIN;
-        const uint64_t b_lo = bit_off[wlo], b_hi = bit_off[min((uint64_t)wlo + COV_WIN, V)];
+        win_n = WIN;
+        const uint64_t b_lo = bit_off[wlo], b_hi = bit_off[min((uint64_t)wlo + WIN, V)];
         bw0 = b_lo >> 5;
         bit0_lo = (uint32_t)(bw0 << 5);
         bwn = COV_BWIN;
         // every node of the window has its bits inside the LDS bit window: a partial range is marked in 32-bit positions relative to it
-        mark_n = (b_hi - (bw0 << 5) <= (uint64_t)COV_BWIN * 32) ? (uint32_t)min((uint64_t)COV_WIN, V - wlo) : 0u;
+        mark_n = (b_hi - (bw0 << 5) <= (uint64_t)COV_BWIN * 32) ? (uint32_t)min((uint64_t)WIN, V - wlo) : 0u;
     }
-    __syncthreads();
+    // the barrier orders the LDS zero-fill only (a workgroup fence on the local address space): the window probes above are
+    // still in flight and are first needed by the updates of the first pass, behind that pass's own three levels of loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
-        const uint32_t g = g0 + (uint32_t)(pass * WAVES + wave);
-        if (g >= n_groups) break;
-        const uint64_t t = (uint64_t)g * 64 + lane;
+        const uint32_t gw = g0 + (uint32_t)((pass * WAVES + wave) * U);     // this wave's U consecutive groups
+        if (gw >= n_groups) break;
         // ---- level 1
-        const uint32_t code = step_code[t], id = node_id[t];
-        const uint32_t gs = group_slot[g];
-        const bool pad = code == STEP_PAD;
-        if (__all(pad) || __any(!pad && (code & STEP_LONG))) continue;     // nothing here / a longer walk's steps: coverage_step_kernel's group
+        uint32_t code[U], id[U], gs[U];
+        bool run[U];                                                          // wave-uniform: the group is this kernel's
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = gw + (uint32_t)u;
+            run[u] = g < n_groups;
+            const uint64_t t = (uint64_t)(run[u] ? g : gw) * 64 + lane;
+            code[u] = step_code[t]; id[u] = node_id[t];
+            gs[u] = group_slot[run[u] ? g : gw];
+        }
         // ---- level 2 (dead lanes read the group's first record: in range, and on a line that is fetched anyway)
-        const uint32_t slot = pad ? gs : slot_in_group(gs, code, lane);
-        const uint4 rr = read_rec[slot];
-        const uint2 sr = slot_rec[slot];
-        const int sp = (int)sr.x;
-        bool ok = !pad && sp >= 0;
+        uint4 rr[U];
+        uint2 sr[U];
+        bool pad[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pad[u] = code[u] == STEP_PAD;
+            run[u] = run[u] && !__all(pad[u]) && !__any(!pad[u] && (code[u] & STEP_LONG));   // nothing here / a longer walk's steps: coverage_step_kernel's group
+            const uint32_t sl = slot_in_group(gs[u], code[u], lane);
+            const uint32_t slot = (pad[u] || !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
+            rr[u] = read_rec[slot];
+            sr[u] = slot_rec[slot];
+        }
         // ---- level 3
-        const uint32_t v = ok ? id + sr.y : wlo;
-        const uint4 nr = node_rec[v];
-        if (active) ok = ok && active[ok ? sp : 0] != 0;
-        const uint32_t b = rr.x, k = rr.y, ps = rr.z, pe = rr.w;
-        const uint32_t i = (uint32_t)t - b;                                  // position in the walk (T_pad < 2^32)
-        if (__any(!pad && slot_aborts(sp))) {                               // rare: a walk that leaves its species' graph (profile.rs:849)
-            if (!pad && slot_aborts(sp) && i == 0 && (!active || active[slot_species(sp)])) atomicAdd(n_abort, 1ull);
+        uint4 nr[U];
+        uint32_t v[U], act[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = run[u] && !pad[u] && (int)sr[u].x >= 0;
+            v[u] = ok[u] ? id[u] + sr[u].y : wlo;
+            nr[u] = node_rec[v[u]];
+            act[u] = active ? active[ok[u] ? sr[u].x : 0u] : 1u;
         }
-        const uint32_t nl = ok ? nr.z : 0u;
-        const int first_lane = lane - (int)i;                               // lane of step 0 of my read (live lanes)
-        const uint32_t len0 = __shfl(nl, first_lane);
-        // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as early as the head is known
-        const uint32_t v1 = wave_shr1(v), v2 = wave_shr1(v1);
-        const uint32_t hw2 = wave_shr1(wave_shr1(nr.w)), hn2 = wave_shr1(wave_shr1(nr.y >> 8));
-        const bool single = k == 1u;
-        const bool dead_read = !single && ps > len0;                          // assert :854 -> the whole read contributes nothing
-        bool live = ok && !dead_read && !(single && pe < ps);                // :821-827
-        uint32_t nh = 0, hx = 0, tcc = 0;
-        uint4 e0 = make_uint4(0u, 0u, 0u, 0u), e1 = e0;
-        if (WITH_TRIO && !ABL(4u)) {
-            const bool lo_end = v <= v2;                                      // canonical window (min end, middle, max end): the head belongs to the smaller end
-            hx = lo_end ? nr.w : hw2;
-            nh = (live && i >= 2u) ? (lo_end ? nr.y >> 8 : hn2) : 0u;
-            tcc = lo_end ? v2 : v;
-            e0 = trio_ent[nh ? hx : 0u];
-            e1 = trio_ent[nh > 1u ? hx + 1u : 0u];
-        }
-        if (__any(ok && dead_read && i == 0u)) { if (ok && dead_read && i == 0u) atomicAdd(n_abort, 1ull); }
-        // ---- aligned lengths: `seen` before this step = wave prefix sum of the walk's aligned lengths minus its value at the walk's first lane
-        const uint32_t contrib = (live && !single) ? (i == 0u ? nl - ps : nl) : 0u;
-        const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
-        const uint32_t seen = pexcl - __shfl(pexcl, first_lane);
-        const uint32_t tgt = pe - ps;                                         // target (profile.rs:800) where it is not negative
-        const bool last = i + 1u == k;
-        uint32_t aln = nl;                                                    // :860-862
-        if (last) aln = (pe >= ps && tgt > seen) ? tgt - seen : 0u;           // :857-859 max(target - seen, 0)
-        if (i == 0u) aln = single ? tgt : nl - ps;                            // :853-856, :828
-        const uint32_t sidx = i == 0u ? ps : 0u;
-        uint32_t hi = sidx + aln;
-        if (hi > nl) hi = nl;                                                 // :871
-        const bool markable = live && hi > sidx && !(single && !(ps < pe && pe <= nl));   // :832
-        const uint32_t dupd = code & STEP_DIST;                               // distance back to the node's first occurrence in the walk (0: this is it)
-        const uint32_t rl = !live ? 0u : dupd == 0u ? aln : (dupd == i ? len0 - ps : nl);   // read_nodes_len :879-882
-        const uint32_t off = v - wlo;                                         // unsigned wrap: nodes below the window are out of range too
-        const bool inw = off < win_n;
-        // ---- updates
-        if (live && dupd == 0u && aln && !ABL(2u)) {                          // :881 / :828
-            if (inw && aln < (1u << 18)) atomicAdd(&s_win[off], aln);
-            else atomicAdd(&bases[v], (unsigned long long)aln);
-        }
-        if (markable && !ABL(1u)) {
-            if (sidx == 0u && hi == nl) {                                     // the whole node: one flag
-                if (inw) s_full[off] = 1; else atomicOr(&full[v >> 5], 1u << (v & 31));
-            } else if (off < mark_n) {
-                const uint32_t rel = nr.x - bit0_lo;
-                mark_window(rel + sidx, rel + hi);
-            } else {
-                const uint64_t bo = nr_bit_off(nr);
-                mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
+        // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as soon as the head is known
+        uint32_t i_[U], nl[U], len0[U], v1[U], nh[U], hx[U], tcc[U];
+        uint4 e0[U], e1[U];
+        bool live[U], single[U], dead_read[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sp = (int)sr[u].x;
+            const uint32_t gbase = (gw + (uint32_t)u) * 64u;
+            i_[u] = gbase + (uint32_t)lane - rr[u].x;                         // position in the walk (T_pad < 2^32)
+            if (__any(run[u] && !pad[u] && slot_aborts(sp))) {                // rare: a walk that leaves its species' graph (profile.rs:849)
+                if (run[u] && !pad[u] && slot_aborts(sp) && i_[u] == 0u && (!active || active[slot_species(sp)])) atomicAdd(n_abort, 1ull);
+            }
+            ok[u] = ok[u] && act[u] != 0u;
+            nl[u] = ok[u] ? nr[u].z : 0u;
+            len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
+            v1[u] = wave_shr1(v[u]);
+            const uint32_t v2 = wave_shr1(v1[u]);
+            const uint32_t hw2 = wave_shr1(wave_shr1(nr[u].w)), hn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
+            single[u] = rr[u].y == 1u;
+            dead_read[u] = !single[u] && rr[u].z > len0[u];                   // assert :854 -> the whole read contributes nothing
+            live[u] = ok[u] && !dead_read[u] && !(single[u] && rr[u].w < rr[u].z);   // :821-827
+            nh[u] = 0; hx[u] = 0; tcc[u] = 0;
+            e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = e0[u];
+            if (WITH_TRIO && !ABL(4u)) {
+                const bool lo_end = v[u] <= v2;                               // canonical window (min end, middle, max end): the head belongs to the smaller end
+                hx[u] = lo_end ? nr[u].w : hw2;
+                nh[u] = (live[u] && i_[u] >= 2u) ? (lo_end ? nr[u].y >> 8 : hn2) : 0u;
+                tcc[u] = lo_end ? v2 : v[u];
+                e0[u] = trio_ent[nh[u] ? hx[u] : 0u];
+                e1[u] = trio_ent[nh[u] > 1u ? hx[u] + 1u : 0u];
             }
         }
-        if (WITH_TRIO && !ABL(4u)) {                                          // :890-907
-            const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
-            int row = -1;
-            if (nh && e0.x == v1 && e0.y == tcc) row = (int)e0.z;
-            else if (nh > 1u && e1.x == v1 && e1.y == tcc) row = (int)e1.z;
-            else if (nh > 2u)
-                for (uint32_t j = 2; j < nh; ++j) {
-                    const uint4 e = trio_ent[hx + j];
-                    if (e.x == v1 && e.y == tcc) { row = (int)e.z; break; }
+        // ---- per group: aligned lengths and the updates
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t k = rr[u].y, ps = rr[u].z, pe = rr[u].w, i = i_[u];
+            if (__any(ok[u] && dead_read[u] && i == 0u)) { if (ok[u] && dead_read[u] && i == 0u) atomicAdd(n_abort, 1ull); }
+            // `seen` before this step = wave prefix sum of the walk's aligned lengths minus its value at the walk's first lane
+            const uint32_t contrib = (live[u] && !single[u]) ? (i == 0u ? nl[u] - ps : nl[u]) : 0u;
+            const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
+            const uint32_t seen = pexcl - __shfl(pexcl, lane - (int)i);
+            const uint32_t tgt = pe - ps;                                     // target (profile.rs:800) where it is not negative
+            uint32_t aln = nl[u];                                             // :860-862
+            if (i + 1u == k) aln = (pe >= ps && tgt > seen) ? tgt - seen : 0u;   // :857-859 max(target - seen, 0)
+            if (i == 0u) aln = single[u] ? tgt : nl[u] - ps;                  // :853-856, :828
+            const uint32_t sidx = i == 0u ? ps : 0u;
+            uint32_t hi = sidx + aln;
+            if (hi > nl[u]) hi = nl[u];                                       // :871
+            const bool markable = live[u] && hi > sidx && !(single[u] && !(ps < pe && pe <= nl[u]));   // :832
+            const uint32_t dupd = code[u] & STEP_DIST;                        // distance back to the node's first occurrence in the walk (0: this is it)
+            const uint32_t rl = !live[u] ? 0u : dupd == 0u ? aln : (dupd == i ? len0[u] - ps : nl[u]);   // read_nodes_len :879-882
+            const uint32_t off = v[u] - wlo;                                  // unsigned wrap: nodes below the window are out of range too
+            const bool inw = off < win_n;
+            if (live[u] && dupd == 0u && aln && !ABL(2u)) {                   // :881 / :828
+                if (inw && aln < (1u << 18)) atomicAdd(&S_WIN(off), aln);
+                else atomicAdd(&bases[v[u]], (unsigned long long)aln);
+            }
+            if (markable && !ABL(1u)) {
+                if (sidx == 0u && hi == nl[u]) {                              // the whole node: one flag
+                    if (inw) S_FULL(WIN, off) = 1; else atomicOr(&full[v[u] >> 5], 1u << (v[u] & 31));
+                } else if (off < mark_n) {
+                    const uint32_t rel = nr[u].x - bit0_lo;
+                    mark_window(WIN, rel + sidx, rel + hi);
+                } else {
+                    const uint64_t bo = nr_bit_off(nr[u]);
+                    mark_range(bitmap, WIN, bw0, bwn, bo + sidx, bo + hi);
                 }
-            const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
-            if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
+            }
+            if (WITH_TRIO && !ABL(4u)) {                                      // :890-907
+                const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
+                int row = -1;
+                if (nh[u] && e0[u].x == v1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
+                else if (nh[u] > 1u && e1[u].x == v1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
+                else if (nh[u] > 2u)
+                    for (uint32_t j = 2; j < nh[u]; ++j) {
+                        const uint4 e = trio_ent[hx[u] + j];
+                        if (e.x == v1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
+                    }
+                const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
+                if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
+            }
         }
     }
     __syncthreads();
     if (win_n) {
-        for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
-            const uint32_t c = s_win[i];
+        for (int i = threadIdx.x; i < WIN; i += COV_BLOCK) {
+            const uint32_t c = S_WIN(i);
             if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
-            const unsigned long long fb = __ballot(s_full[i] != 0);
+            const unsigned long long fb = __ballot(S_FULL(WIN, i) != 0);
             if (fb && (lane & 31) == 0) {
                 const uint32_t m = (uint32_t)(fb >> (lane & 32));
                 if (m) atomicOr(&full[(wlo + i) >> 5], m);
             }
         }
         for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
-            const uint32_t m = s_bm[i];
+            const uint32_t m = S_BM(WIN, i);
             if (m) atomicOr(&bitmap[bw0 + i], m);
         }
     }
@@ -330,9 +368,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     const uint64_t chunk_b = (uint64_t)chunk * CHUNK;
     uint64_t chunk_e = chunk_b + CHUNK;
     if (chunk_e > T) chunk_e = T;
-    for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) s_win[i] = 0;
-    for (int i = threadIdx.x; i < (int)COV_BWIN; i += COV_BLOCK) s_bm[i] = 0;
-    for (int i = threadIdx.x; i < COV_WIN / 4; i += COV_BLOCK) reinterpret_cast<uint32_t *>(s_full)[i] = 0;
+    for (int i = threadIdx.x; i < (int)(cov_lds_bytes(COV_WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;
     // window base: the node of the first live step among a few probes of the chunk.  Every thread computes it
     // (workgroup-uniform addresses), so nobody waits on a broadcast and the probes overlap the first gathers.
     uint32_t wlo = 0, win_n = 0;
@@ -458,8 +494,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     if (ps < pe && pe <= nl && !ABL(1u)) {            // :832
                         if (ps == 0 && pe == nl) { if (!ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
                         else if (ABL(16u)) {}
-                        else if (in_win) mark_window((uint32_t)rel + ps, (uint32_t)rel + pe);
-                        else mark_range(bitmap, bw0, bwn, bo + ps, bo + pe);
+                        else if (in_win) mark_window(COV_WIN, (uint32_t)rel + ps, (uint32_t)rel + pe);
+                        else mark_range(bitmap, COV_WIN, bw0, bwn, bo + ps, bo + pe);
                     }
                 }
                 live = false;
@@ -494,8 +530,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 if (ABL(1u)) {}
                 else if (sidx == 0 && hi == nl) { if (nl && !ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
                 else if (ABL(16u)) {}
-                else if (in_win) mark_window((uint32_t)rel + sidx, (uint32_t)rel + hi);
-                else mark_range(bitmap, bw0, bwn, bo + sidx, bo + hi);
+                else if (in_win) mark_window(COV_WIN, (uint32_t)rel + sidx, (uint32_t)rel + hi);
+                else mark_range(bitmap, COV_WIN, bw0, bwn, bo + sidx, bo + hi);
                 if (jf < 0) {
                     rl = aln;
                     if (aln && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], aln);     // :881
@@ -527,10 +563,10 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     __syncthreads();
     if (win_n) {
         for (int i = threadIdx.x; i < COV_WIN; i += COV_BLOCK) {
-            const uint32_t c = s_win[i];
+            const uint32_t c = S_WIN(i);
             if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
             // full-node flags: the window starts at a multiple of 64 nodes, so a wave's ballot is two whole words of the flag vector
-            const unsigned long long fb = __ballot(s_full[i] != 0);
+            const unsigned long long fb = __ballot(S_FULL(COV_WIN, i) != 0);
             if (fb && (lane & 31) == 0) {
                 const uint32_t m = (uint32_t)(fb >> (lane & 32));
                 if (m) atomicOr(&full[(wlo + i) >> 5], m);
@@ -538,7 +574,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         }
     }
     for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
-        const uint32_t m = s_bm[i];
+        const uint32_t m = S_BM(COV_WIN, i);
         if (m) atomicOr(&bitmap[bw0 + i], m);     // nothing waits for these (a probe first would be a dependent round trip per word)
     }
 }
@@ -835,7 +871,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     const uint64_t words = (db->L + 31) / 32 + 1;
     const uint64_t U = with_trio ? db->U : 0;
     // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32][full-node flags: 1 bit per node, padded by a window]
-    const uint64_t fwords = (db->V + COV_WIN + 63) / 32 + 2;
+    const uint64_t fwords = (db->V + 4096 + 63) / 32 + 2;     // padded by the largest LDS window
     const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = off_abort + 8, off_full = off_bm + words * 4,
                  total = off_full + fwords * 4;
     PTX_HIP(ctx, db->d_cov_arena.alloc(total));
@@ -875,12 +911,32 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
         const uint32_t n_groups = (uint32_t)(rd->T_pad / 64);
         if (rd->n_long < rd->n_slots && !std::getenv("PANTAX_COV_GENERAL")) {
-            constexpr int FP = 8;
-            const int grid = (int)((n_groups + (COV_BLOCK / 64) * FP - 1) / ((COV_BLOCK / 64) * FP));
+            // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps) over a 3072-node window;
+            // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
+            // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
+            int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
+            if (const char *ev = std::getenv("PANTAX_COVF_SHAPE")) fshape = std::atoi(ev);
 #define COVF_ARGS n_groups, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate
-            if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, FP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVF_ARGS);
-            else hipLaunchKernelGGL((coverage_fast_kernel<false, FP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVF_ARGS);
+#define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
+            {                                                                                                                            \
+                const int per = (COV_BLOCK / 64) * UU * PP;                                                                              \
+                const int grid = (int)((n_groups + per - 1) / per);                                                                      \
+                if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
+                else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
+            }
+            switch (fshape) {                                              // <U><PASSES><window / 1024>
+                case 182: COVF_LAUNCH(1, 8, 2048) break;
+                case 242: COVF_LAUNCH(2, 4, 2048) break;
+                case 282: COVF_LAUNCH(2, 8, 2048) break;
+                case 283: COVF_LAUNCH(2, 8, 3072) break;
+                case 284: COVF_LAUNCH(2, 8, 4096) break;
+                case 243: COVF_LAUNCH(2, 4, 3072) break;
+                case 442: COVF_LAUNCH(4, 4, 2048) break;
+                case 443: COVF_LAUNCH(4, 4, 3072) break;
+                default: COVF_LAUNCH(2, 4, 2048) break;
+            }
+#undef COVF_LAUNCH
 #undef COVF_ARGS
         }
         // groups that hold steps of longer walks (HiFi / ONT reads): the general kernel.  U groups of 64 steps in flight per wave,
@@ -897,8 +953,8 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             {                                                                                                                                \
                 const uint32_t n_chunks = (uint32_t)((rd->T_pad + (uint64_t)COV_BLOCK * UU * PP - 1) / ((uint64_t)COV_BLOCK * UU * PP));     \
                 const int grid = xcd_map ? (int)(((n_chunks + 7) / 8) * 8) : (int)n_chunks;                                                  \
-                if (trio) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);  \
-                else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), 0, ctx->stream, COVS_ARGS);      \
+                if (trio) hipLaunchKernelGGL((coverage_step_kernel<true, UU, PP>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(COV_WIN), ctx->stream, COVS_ARGS);  \
+                else hipLaunchKernelGGL((coverage_step_kernel<false, UU, PP>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(COV_WIN), ctx->stream, COVS_ARGS);      \
             }
             switch (shape) {
                 case 22: COVS_LAUNCH(2, 2) break;
