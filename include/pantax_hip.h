@@ -266,8 +266,8 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
  * of :3297-3319) collects the arguments of its X_opt calls as arrays of offsets and gets every species' answer back.
  * Species s owns nodes [node_off[s], node_off[s+1]), haplotypes [hap_off[s], hap_off[s+1]) and candidates
  * [cand_off[s], cand_off[s+1]); path_off indexes path_nodes over all haplotypes of the batch; cand_path_idx is the
- * haplotype's index WITHIN its species.  status[s]: 0 solved (or nothing to solve: no candidates), PANTAX_HIP_E_LIMIT (> 64
- * candidates), PANTAX_HIP_E_SOLVER -- per species, like the reference drops only the species whose solver failed
+ * haplotype's index WITHIN its species.  status[s]: 0 solved (or nothing to solve: no candidates), PANTAX_HIP_E_LIMIT (> 256
+ * candidates: 1..64 take the one-word path, 65..256 the wide path), PANTAX_HIP_E_SOLVER -- per species, like the reference drops only the species whose solver failed
  * (profile.rs:2999-3003); the call itself fails only on invalid arguments or a HIP error. */
 typedef struct {
     uint32_t n_species;

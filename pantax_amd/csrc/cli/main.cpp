@@ -21,7 +21,8 @@ static void usage() {
             "  --gfa (read species_gfa/*.gfa instead of species_graph_info/*.bin)  --zip serialize|lz|zstd  --round (2-decimal output)  --device N\n"
             "  --ranks N --rank r   one process per GPU (start N of them; device = r unless --device): every rank tokenises 1/N of the\n"
             "                       GAF, reads travel to the owner of their species over RCCL, rank 0 writes the tables\n"
-            "                       (defaults from WORLD_SIZE / RANK / LOCAL_RANK when set); --comm-id-file F (default <wd>/.pantax_hip_rccl_id)\n");
+            "                       (defaults from WORLD_SIZE / RANK / LOCAL_RANK when set); --comm-id-file F (default <wd>/.pantax_hip_rccl_id),\n"
+            "                       --comm-nonce N (default $MASTER_PORT or 0: the same for all ranks of one launch, different from the launch before)\n");
 }
 
 int main(int argc, char **argv) {
@@ -35,6 +36,7 @@ int main(int argc, char **argv) {
     const char *filter_in = nullptr, *filter_out = nullptr;
     int device = -1, ranks = 0, rank = -1;
     std::string id_file;
+    uint64_t nonce = getenv("MASTER_PORT") ? strtoull(getenv("MASTER_PORT"), nullptr, 10) : 0;   // per-launch nonce of the id file (rccl_comm.hpp)
     if (const char *ev = getenv("WORLD_SIZE")) ranks = atoi(ev);
     if (const char *ev = getenv("RANK")) rank = atoi(ev);
     if (const char *ev = getenv("LOCAL_RANK")) device = atoi(ev);
@@ -75,6 +77,7 @@ int main(int argc, char **argv) {
         else if (a == "--ranks") ranks = atoi(next());
         else if (a == "--rank") rank = atoi(next());
         else if (a == "--comm-id-file") id_file = next();
+        else if (a == "--comm-nonce") nonce = strtoull(next(), nullptr, 10);
         else { usage(); return 2; }
     }
     const bool use_rccl = ranks >= 1 && rank >= 0;   // also a one-rank world goes through the communicator when asked for
@@ -96,19 +99,27 @@ int main(int argc, char **argv) {
     pantax_hip_ctx *ctx = nullptr;
     int rc = pantax_hip_init(&ctx, &device, 1);
     if (rc != 0) { fprintf(stderr, "pantax-hip: %s\n", pantax_hip_last_error(nullptr)); return 1; }
-    std::string filtered;
-    if (filter_gaf) {   // alignment.rs:171-175: filter, then the filtered file takes the GAF's place
-        filtered = std::string(c.input_aln_file) + ".best.tmp";
-        rc = pantax_hip_gaf_filter(ctx, c.input_aln_file, filtered.c_str(), nullptr, nullptr, nullptr);
-        if (rc == 0 && rename(filtered.c_str(), c.input_aln_file) != 0) { fprintf(stderr, "pantax-hip: cannot replace %s\n", c.input_aln_file); rc = 1; }
-        if (rc != 0) { if (rc != 1) fprintf(stderr, "pantax-hip: error %d: %s\n", rc, pantax_hip_last_error(ctx)); pantax_hip_destroy(ctx); return 1; }
-    }
+    // the communicator first: with --filter-gaf only rank 0 rewrites the shared GAF, and the others must not open it before
+    // the rename (the sharded ingest assumes ONE immutable file) -- the all-reduce below is that barrier and carries a failure
+    // of the filter to every rank, so all of them leave together
     RcclComm comm;
     if (use_rccl) {
         if (id_file.empty()) id_file = wd + "/.pantax_hip_rccl_id";
-        if (!comm.init(rank, ranks, id_file)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
+        if (!comm.init(rank, ranks, id_file, nonce)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
         c.rank = rank; c.world_size = ranks; c.comm_user = &comm;
         c.allreduce_sum = &RcclComm::allreduce_sum; c.alltoallv = &RcclComm::alltoallv; c.comm_device_buffers = 1;
+    }
+    if (filter_gaf) {   // alignment.rs:171-175: filter, then the filtered file takes the GAF's place
+        int frc = 0;
+        if (!use_rccl || rank == 0) {
+            const std::string filtered = std::string(c.input_aln_file) + ".best.tmp";
+            frc = pantax_hip_gaf_filter(ctx, c.input_aln_file, filtered.c_str(), nullptr, nullptr, nullptr);
+            if (frc != 0) fprintf(stderr, "pantax-hip: error %d: %s\n", frc, pantax_hip_last_error(ctx));
+            else if (rename(filtered.c_str(), c.input_aln_file) != 0) { fprintf(stderr, "pantax-hip: cannot replace %s\n", c.input_aln_file); frc = 1; }
+        }
+        double failed = frc != 0 ? 1.0 : 0.0;
+        if (use_rccl && RcclComm::allreduce_sum(&comm, &failed, 1) != 0) { fprintf(stderr, "pantax-hip: rank %d: the exchange behind --filter-gaf failed\n", rank); failed = 1.0; }
+        if (failed != 0.0) { if (use_rccl) comm.destroy(id_file); pantax_hip_destroy(ctx); return 1; }
     }
     rc = pantax_hip_profile(ctx, &c);
     if (rc != 0) fprintf(stderr, "pantax-hip: %serror %d: %s\n", use_rccl ? ("rank " + std::to_string(rank) + ": ").c_str() : "", rc, pantax_hip_last_error(ctx));

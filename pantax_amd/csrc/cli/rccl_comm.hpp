@@ -3,7 +3,11 @@
 // (INTEGRATION.md section 3b'').
 //
 // Bootstrap without MPI: rank 0 creates the ncclUniqueId and publishes it through a file in the work directory (written
-// under a temporary name, then renamed); the other ranks wait for a file that is not older than their own start.
+// under a temporary name, then renamed) together with a per-launch NONCE (--comm-nonce, or $MASTER_PORT, or "0": the launcher
+// gives all ranks of one launch the same value and consecutive launches different ones); the other ranks wait for a file that
+// carries THEIR nonce -- a file a dead run left behind does not match (with the default nonce "0" the old 2-second mtime
+// rule still applies).  A rank that fails before or inside init leaves the others in ncclCommInitRank: like any RCCL job,
+// run the launch under a launcher-side timeout.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -25,30 +29,31 @@ struct RcclComm {
 
     bool fail(const std::string &what) { err = what; return false; }
 
-    bool init(int rank_, int world_, const std::string &id_file, double timeout_s = 300.0) {
+    bool init(int rank_, int world_, const std::string &id_file, uint64_t nonce = 0, double timeout_s = 300.0) {
         rank = rank_; world = world_;
         const auto t_start = std::chrono::system_clock::now();
         ncclUniqueId id;
+        struct Rec { uint64_t nonce; ncclUniqueId id; } rec;
         if (rank == 0) {
             ::unlink(id_file.c_str());   // a file left behind by an earlier run
             if (ncclGetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+            rec.nonce = nonce; rec.id = id;
             const std::string tmp = id_file + ".tmp";
             FILE *f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { if (f) std::fclose(f); return fail("cannot write " + tmp); }
+            if (!f || std::fwrite(&rec, sizeof(rec), 1, f) != 1) { if (f) std::fclose(f); return fail("cannot write " + tmp); }
             std::fclose(f);
             if (std::rename(tmp.c_str(), id_file.c_str()) != 0) return fail("cannot publish " + id_file);
         } else {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
             for (;;) {
                 struct stat st;
-                if (::stat(id_file.c_str(), &st) == 0 && (size_t)st.st_size == sizeof(id)) {
+                if (::stat(id_file.c_str(), &st) == 0 && (size_t)st.st_size == sizeof(rec)) {
                     const auto mt = std::chrono::system_clock::from_time_t(st.st_mtime);
-                    if (mt + std::chrono::seconds(2) >= t_start) {   // not a leftover of an earlier run
-                        FILE *f = std::fopen(id_file.c_str(), "rb");
-                        const bool ok = f && std::fread(&id, sizeof(id), 1, f) == 1;
-                        if (f) std::fclose(f);
-                        if (ok) break;
-                    }
+                    FILE *f = std::fopen(id_file.c_str(), "rb");
+                    const bool ok = f && std::fread(&rec, sizeof(rec), 1, f) == 1;
+                    if (f) std::fclose(f);
+                    // this launch's file: its nonce (and, without a launcher-given nonce, not older than this rank's start)
+                    if (ok && rec.nonce == nonce && (nonce != 0 || mt + std::chrono::seconds(2) >= t_start)) { id = rec.id; break; }
                 }
                 if (std::chrono::steady_clock::now() > deadline) return fail("rank 0 did not publish " + id_file + " in time");
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
@@ -88,12 +93,14 @@ struct RcclComm {
         const char *s = static_cast<const char *>(send);
         char *r = static_cast<char *>(recv);
         if (ncclGroupStart() != ncclSuccess) return 1;
-        for (int peer = 0; peer < c->world; ++peer) {
+        int bad = 0;
+        for (int peer = 0; peer < c->world && !bad; ++peer) {
             const uint64_t ns = send_off[peer + 1] - send_off[peer], nr = recv_off[peer + 1] - recv_off[peer];
-            if (ns && ncclSend(s + send_off[peer], ns, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) return 2;
-            if (nr && ncclRecv(r + recv_off[peer], nr, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) return 3;
+            if (ns && ncclSend(s + send_off[peer], ns, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) bad = 2;
+            if (!bad && nr && ncclRecv(r + recv_off[peer], nr, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) bad = 3;
         }
-        if (ncclGroupEnd() != ncclSuccess) return 4;
+        if (ncclGroupEnd() != ncclSuccess && !bad) bad = 4;   // the group is closed on every path
+        if (bad) return bad;
         return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 5;
     }
 };

@@ -132,8 +132,10 @@ struct Ctx {
     uint32_t scan_epoch2 = 0;
     PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
     PinBuf pin_text;             // two pinned chunks of the GAF text upload (stage_gaf.hip)
-    PinBuf pin_up;               // ring of small uploads; a step syncs at least once, far before the ring wraps
-    size_t pin_up_off = 0;
+    PinBuf pin_up;               // ring of small uploads, in two halves: a half is re-entered only after the copies issued from it
+    size_t pin_up_off = 0;       // on its last lap have run (an event per stream, recorded when the ring leaves the half) -- steps enqueued
+    hipEvent_t pin_up_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // back to back share it without a host wait in between
+    bool pin_up_ev_set[2] = {false, false};
 };
 
 // RAII-less timing scope: records events around a launch when ctx->timing is on
@@ -390,7 +392,23 @@ int upload_small(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
     PTX_HIP(ctx, dst.alloc(n));
     PTX_HIP(ctx, ctx->pin_up.reserve(PIN_UP_RING));
     size_t off = (ctx->pin_up_off + 63) & ~(size_t)63;
-    if (off + bytes > PIN_UP_RING) off = 0;
+    constexpr size_t HALF = PIN_UP_RING / 2;
+    const int h_old = ctx->pin_up_off ? (int)((ctx->pin_up_off - 1) / HALF) : 0;   // half of the last byte handed out
+    if (off < HALF && off + bytes > HALF) off = HALF;        // would straddle the middle: start of the upper half (bytes <= PIN_UP_MAX <= HALF)
+    if (off + bytes > PIN_UP_RING) off = 0;                  // past the end: start of the lower half
+    const int h_new = off >= HALF ? 1 : 0;
+    if (h_new != h_old) {
+        // leaving h_old: mark what was issued from it on either stream; entering h_new: its last lap's copies must have run
+        for (int k = 0; k < 2; ++k) {
+            hipStream_t st = k == 0 ? ctx->stream : ctx->stream2;
+            if (!st) continue;
+            if (!ctx->pin_up_ev[h_old][k]) PTX_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_up_ev[h_old][k], hipEventDisableTiming));
+            PTX_HIP(ctx, hipEventRecord(ctx->pin_up_ev[h_old][k], st));
+        }
+        ctx->pin_up_ev_set[h_old] = true;
+        if (ctx->pin_up_ev_set[h_new])
+            for (int k = 0; k < 2; ++k) if (ctx->pin_up_ev[h_new][k]) PTX_HIP(ctx, hipEventSynchronize(ctx->pin_up_ev[h_new][k]));
+    }
     std::memcpy(ctx->pin_up.p + off, src, bytes);
     ctx->pin_up_off = off + bytes;
     PTX_HIP(ctx, hipMemcpyAsync(dst.p, ctx->pin_up.p + off, bytes, hipMemcpyHostToDevice, ctx->stream));

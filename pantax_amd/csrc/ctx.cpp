@@ -144,6 +144,7 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     ctx->d_scan_ws.release();
     ctx->pin_down.release();
     ctx->pin_up.release();
+    for (auto &half : ctx->pin_up_ev) for (hipEvent_t &e : half) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     ctx->pin_text.release();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
