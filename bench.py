@@ -384,8 +384,9 @@ def pmc_traffic(kernel, key, corrected=False):
 
 
 def gaf_tmp_dir(need_bytes):
-    """where the from-GAF-text leg writes its file: the first of /dev/shm, $TMPDIR, /tmp with room for it"""
-    for d in ("/dev/shm", tempfile.gettempdir(), "/tmp"):
+    """where the from-GAF-text leg writes its file: the first of $TMPDIR, /tmp (a file system with a page cache, like a real
+    input), /dev/shm with room for it"""
+    for d in (tempfile.gettempdir(), "/tmp", "/dev/shm"):
         try:
             st = os.statvfs(d)
             if st.f_bavail * st.f_frsize > 1.25 * need_bytes + (1 << 30):
@@ -597,10 +598,10 @@ def main():
                 t_w = time.perf_counter()
                 gaf_bytes = synth.write_gaf_parallel(grd, gp, threads=host_threads)
                 write_s = time.perf_counter() - t_w
-                eng.load_reads_from_gaf(gp)                      # warm (allocations, page cache)
+                eng.load_reads_from_gaf(gp, columns=False)       # warm (allocations, page cache)
                 eng.sync()
                 t2 = time.perf_counter()
-                eng.load_reads_from_gaf(gp)
+                eng.load_reads_from_gaf(gp, columns=False)       # the walks stay in HBM; no host copy of the per-read columns is asked for
                 eng.sync()
                 t_load = time.perf_counter() - t2
                 out_gaf = profile_step(eng, species_names, hap_names, avg_len, cfg, LocalComm(), shard_max=S_max, rows_max=H_max)

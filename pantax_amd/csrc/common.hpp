@@ -131,7 +131,7 @@ struct Ctx {
     DevBuf<uint32_t> d_scan_ws2; // the same for scans enqueued on the side stream (they may run beside scans of the main stream)
     uint32_t scan_epoch2 = 0;
     PinBuf pin_down;             // staging of small downloads (valid until the next download through it)
-    PinBuf pin_text;             // two pinned chunks of the GAF text upload (stage_gaf.hip)
+    PinBuf pin_text;             // ring of pinned chunks of the large uploads (upload_staged: GAF text, graph arrays)
     PinBuf pin_up;               // ring of small uploads, in two halves: a half is re-entered only after the copies issued from it
     size_t pin_up_off = 0;       // on its last lap have run (an event per stream, recorded when the ring leaves the half) -- steps enqueued
     hipEvent_t pin_up_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // back to back share it without a host wait in between
@@ -381,6 +381,11 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
 int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
 // the same from an open file (pread straight into the pinned chunks: no page of the file is mapped or faulted in)
 int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t bytes);
+// a text in pieces [piece_off[k], piece_end[k]) with their own destinations, as ONE chunk pipeline on `stream` (the GAF load: piece k is
+// tokenised while k+1.. travel).  before_piece(k) may block until d_dst[k] is free (false aborts); after_piece(k) runs once the last
+// chunk of piece k has been enqueued (record an event there).  fd >= 0: pread from the file at file_base + offset, else from `text`.
+int upload_text_pieces(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off, const uint64_t *piece_end,
+                       hipStream_t stream, const std::function<bool(size_t)> &before_piece, const std::function<int(size_t)> &after_piece);
 // fn(begin, end) over [0, n) split across up to n_threads host threads (the calling thread takes the first slice)
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn);
 // small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)

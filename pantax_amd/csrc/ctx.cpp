@@ -3,6 +3,11 @@
 #include <cstdarg>
 #include <algorithm>
 #include <cstring>
+#include <functional>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include "common.hpp"
@@ -292,60 +297,139 @@ void dev_cache_trim() {
 }
 
 namespace {
-// [src + off, +n) or (fd, file_off + off, n) -> pinned slot, on a few threads (about 2 MB each: the copies are memory-bound)
-void stage_chunk(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64_t n) {
-    constexpr int NTH_MAX = 64;
-    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 16;
-    static const int PIECE_SHIFT = std::getenv("PANTAX_STAGE_PIECE_KB") ? 10 + (int)std::log2((double)std::max(64, std::atoi(std::getenv("PANTAX_STAGE_PIECE_KB")))) : 21;
-    static const int NTH_HW = (int)std::max(2u, std::min<unsigned>((unsigned)std::min(NTH_MAX, std::max(1, NTH_ENV)), std::thread::hardware_concurrency() / 2));
-    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>(NTH_HW, n >> PIECE_SHIFT));
-    auto piece = [=](int t) {
-        const uint64_t b = n * t / nth, e = n * (t + 1) / nth;
+// A crew of host threads that fills pinned slots -- [src + pos, +n) or (fd, pos, n) -- for the lifetime of ONE upload (round 2
+// created and joined 16 threads per 16-MB chunk: ~0.5 ms of thread start-up beside 0.6 ms of copy).  The box delivers 80 GB/s
+// of pread from the page cache on 8-16 threads and 56 GB/s of pinned host->device copy (tools/h2d_probe.py): the crew only has
+// to stay ahead of the DMA.
+struct StageCrew {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;
+    int done = 0, nth = 1;
+    bool quit = false;
+    uint8_t *slot = nullptr; const uint8_t *src = nullptr; int fd = -1; uint64_t pos = 0, n = 0;
+    std::vector<std::thread> th;
+    static void piece(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64_t n, int t, int nth) {
+        const uint64_t b = n * (uint64_t)t / (uint64_t)nth, e = n * (uint64_t)(t + 1) / (uint64_t)nth;
         if (src) { std::memcpy(slot + b, src + pos + b, e - b); return; }
-        uint64_t done = b;
-        while (done < e) {   // pread may return short
-            const ssize_t r = ::pread(fd, slot + done, e - done, (off_t)(pos + done));
-            if (r <= 0) { std::memset(slot + done, 0, e - done); break; }   // truncated file: the caller validated sizes, zeros keep the run defined
-            done += (uint64_t)r;
+        uint64_t at = b;
+        while (at < e) {   // pread may return short
+            const ssize_t r = ::pread(fd, slot + at, e - at, (off_t)(pos + at));
+            if (r <= 0) { std::memset(slot + at, 0, e - at); break; }   // truncated file: the caller validated sizes, zeros keep the run defined
+            at += (uint64_t)r;
         }
-    };
-    std::thread th[NTH_MAX];
-    for (int t = 1; t < nth; ++t) th[t] = std::thread(piece, t);
-    piece(0);
-    for (int t = 1; t < nth; ++t) th[t].join();
-}
-
-int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_off, uint64_t size) {
-    if (size == 0) return 0;
-    static const uint64_t CH = (uint64_t)(std::getenv("PANTAX_STAGE_CH_MB") ? std::max(1, std::atoi(std::getenv("PANTAX_STAGE_CH_MB"))) : 16) << 20;
-    if (src && size < (1ull << 20)) {   // small: not worth the staging
-        PTX_HIP(ctx, hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, ctx->stream));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return 0;
     }
-    PTX_HIP(ctx, ctx->pin_text.reserve(2 * CH));
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    PTX_HIP(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    explicit StageCrew(int n_threads) : nth(n_threads < 1 ? 1 : n_threads) {
+        for (int t = 1; t < nth; ++t)
+            th.emplace_back([this, t] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_go.wait(lk, [&] { return quit || gen != seen; });
+                    if (quit) return;
+                    seen = gen;
+                    uint8_t *sl = slot; const uint8_t *sr = src; const int f = fd; const uint64_t p = pos, nn = n;
+                    lk.unlock();
+                    piece(sl, sr, f, p, nn, t, nth);
+                    lk.lock();
+                    if (++done == nth - 1) cv_done.notify_one();
+                }
+            });
+    }
+    ~StageCrew() {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void fill(uint8_t *slot_, const uint8_t *src_, int fd_, uint64_t pos_, uint64_t n_) {
+        { std::lock_guard<std::mutex> g(mu); slot = slot_; src = src_; fd = fd_; pos = pos_; n = n_; done = 0; ++gen; }
+        cv_go.notify_all();
+        piece(slot_, src_, fd_, pos_, n_, 0, nth);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done == nth - 1; });
+    }
+};
+
+// host memory or a file -> HBM through a ring of pinned chunks: chunk i+1 (and i+2) is filled while chunk i is on its way.
+// Chunk size follows the transfer (a sixth of it, 4..64 MB: pinning memory costs ~0.1 ms per MB, once per ctx); `stream`
+// carries the copies.  The transfer may consist of several PIECES with their own destinations (the GAF load: a piece is
+// tokenised while the next ones travel): the chunk pipeline runs across the piece borders without draining; before_piece(k)
+// may block until piece k's destination is free (false aborts), after_piece(k) is called once the last chunk of piece k
+// has been enqueued (the caller records an event there).
+struct UploadPiece { void *d_dst; const uint8_t *src; uint64_t file_off, size; };
+int upload_staged_pieces(Ctx *ctx, const UploadPiece *pieces, size_t n_pieces, int fd, hipStream_t stream, PinBuf &ring,
+                         const std::function<bool(size_t)> &before_piece, const std::function<int(size_t)> &after_piece) {
+    uint64_t total = 0;
+    for (size_t k = 0; k < n_pieces; ++k) total += pieces[k].size;
+    constexpr int SLOTS = 3;
+    uint64_t CH = std::getenv("PANTAX_STAGE_CH_MB") ? (uint64_t)std::max(1, std::atoi(std::getenv("PANTAX_STAGE_CH_MB"))) << 20
+                                                    : std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
+    if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH && !std::getenv("PANTAX_STAGE_CH_MB")) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
+    PTX_HIP(ctx, ring.reserve(SLOTS * CH));
+    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 16;
+    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(NTH_ENV, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
+    StageCrew crew(nth);
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
+    for (auto &e : ev) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int rc = 0;
     uint64_t i = 0;
-    uint8_t *dst = static_cast<uint8_t *>(d_dst);
-    for (uint64_t off = 0; off < size && rc == 0; off += CH, ++i) {
-        const uint64_t n = std::min<uint64_t>(CH, size - off);
-        uint8_t *slot = ctx->pin_text.p + (i & 1) * CH;
-        if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
-        stage_chunk(slot, static_cast<const uint8_t *>(src), fd, (src ? 0 : file_off) + off, n);
-        if (hipMemcpyAsync(dst + off, slot, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(ev[i & 1], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    double t_wait = 0, t_fill = 0, t_enq = 0, t_gate = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = now();
+    for (size_t pk = 0; pk < n_pieces && rc == 0; ++pk) {
+        const UploadPiece &pc = pieces[pk];
+        const auto tg = now();
+        if (before_piece && !before_piece(pk)) { rc = PANTAX_HIP_E_STATE; break; }
+        t_gate += ms(tg, now());
+        uint8_t *dst = static_cast<uint8_t *>(pc.d_dst);
+        for (uint64_t off = 0; off < pc.size && rc == 0; off += CH, ++i) {
+            const uint64_t n = std::min<uint64_t>(CH, pc.size - off);
+            const int k = (int)(i % SLOTS);
+            uint8_t *slot = ring.p + (uint64_t)k * CH;
+            const auto t0 = now();
+            if (i >= SLOTS && hipEventSynchronize(ev[k]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
+            const auto t1 = now();
+            crew.fill(slot, pc.src, fd, (pc.src ? 0 : pc.file_off) + off, n);
+            const auto t2 = now();
+            if (hipMemcpyAsync(dst + off, slot, n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipEventRecord(ev[k], stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+            if (trace) { const auto t3 = now(); t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, t3); }
+        }
+        if (rc == 0 && after_piece) rc = after_piece(pk);
     }
-    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    const auto t4 = now();
+    if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    if (trace)
+        std::fprintf(stderr, "[upload_staged] %.1f MB in %.2f ms (%.1f GB/s): %zu piece(s), %llu chunks of %.0f MB, %d threads; waiting for a piece buffer %.2f, for a slot %.2f, "
+                     "filling %.2f, enqueue %.2f, drain %.2f ms\n", total / 1e6, ms(t_begin, now()), total / 1e6 / ms(t_begin, now()), n_pieces,
+                     (unsigned long long)i, CH / 1048576.0, nth, t_gate, t_wait, t_fill, t_enq, ms(t4, now()));
+    for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_off, uint64_t size, hipStream_t stream, PinBuf &ring) {
+    if (size == 0) return 0;
+    if (src && size < (1ull << 20)) {   // small: not worth the staging
+        PTX_HIP(ctx, hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, stream));
+        PTX_HIP(ctx, hipStreamSynchronize(stream));
+        return 0;
+    }
+    const UploadPiece pc{d_dst, static_cast<const uint8_t *>(src), file_off, size};
+    return upload_staged_pieces(ctx, &pc, 1, fd, stream, ring, nullptr, nullptr);
 }
 }  // namespace
 
-int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) { return upload_staged(ctx, d_dst, src, -1, 0, size); }
-int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t size) { return upload_staged(ctx, d_dst, nullptr, fd, file_off, size); }
+int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) { return upload_staged(ctx, d_dst, src, -1, 0, size, ctx->stream, ctx->pin_text); }
+int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t size) { return upload_staged(ctx, d_dst, nullptr, fd, file_off, size, ctx->stream, ctx->pin_text); }
+int upload_text_pieces(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off, const uint64_t *piece_end,
+                       hipStream_t stream, const std::function<bool(size_t)> &before_piece, const std::function<int(size_t)> &after_piece) {
+    std::vector<UploadPiece> pcs(n_pieces);
+    for (size_t k = 0; k < n_pieces; ++k)
+        pcs[k] = UploadPiece{d_dst[k], fd >= 0 ? nullptr : reinterpret_cast<const uint8_t *>(text) + piece_off[k], file_base + piece_off[k], piece_end[k] - piece_off[k]};
+    return upload_staged_pieces(ctx, pcs.data(), n_pieces, fd, stream, ctx->pin_text, before_piece, after_piece);
+}
 
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn) {
     if (n_threads < 1) n_threads = 1;

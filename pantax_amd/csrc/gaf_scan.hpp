@@ -10,4 +10,11 @@ int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_
                         int fd = -1 /* the open file behind `text`: uploaded with pread instead of through the mapping */,
                         uint64_t file_off = 0 /* where `text` starts in that file */);
 
+// the scan alone, for a text that is already in HBM (d_txt: size + 16 bytes)
+int gaf_scan_newlines(Ctx *ctx, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out);
+
+// ... with the caller's grow-only work buffers (nothing is released, nothing waited for at the end); d_txt: device pointer
+int gaf_scan_newlines_ws(Ctx *ctx, uint64_t size, const uint8_t *d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out, DevBuf<uint32_t> &tile_cnt,
+                         DevBuf<uint32_t> &tile_base, DevBuf<uint32_t> &tot, DevBuf<uint32_t> &scan_tmp);
+
 }  // namespace ptx

@@ -19,9 +19,11 @@
 // Algorithmic bytes: 3 N (text) + 4 T + 30 R (outputs).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "common.hpp"
@@ -144,14 +146,15 @@ struct GafOut {
     uint8_t *mapq, *flags;
     uint64_t *id_hash;
 };
+// `o` points at this piece's place in the joined columns; t_base = walk steps of the pieces before it (step offsets are global)
 __global__ void __launch_bounds__(256) gaf_fill_kernel(const uint8_t *__restrict__ txt, uint32_t n_raw, GafRaw r, const uint32_t *__restrict__ ridx,
-                                                       const uint32_t *__restrict__ soff, uint32_t n_reads, uint32_t n_steps, GafOut o) {
+                                                       const uint32_t *__restrict__ soff, uint32_t n_reads, uint32_t n_steps, uint32_t t_base, GafOut o) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) o.step_off[n_reads] = n_steps;
+    if (i == 0) o.step_off[n_reads] = t_base + n_steps;
     if (i >= n_raw || !r.valid[i]) return;
     const uint32_t k = ridx[i];
     uint32_t w = soff[i];
-    o.step_off[k] = w;
+    o.step_off[k] = t_base + w;
     o.pstart[k] = r.ps[i]; o.pend[k] = r.pe[i]; o.qlen[k] = r.ql[i]; o.mapq[k] = r.mq[i]; o.flags[k] = r.fl[i];
     o.id_off[k] = r.id_off[i]; o.id_len[k] = r.id_len[i]; o.id_hash[k] = r.id_hash[i];
     const uint32_t pb = r.path_b[i], pe = r.path_e[i];
@@ -171,12 +174,24 @@ int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_
     PTX_HIP(ctx, d_txt.alloc(size + 16));
     if (fd >= 0) PTX_TRY(upload_file(ctx, d_txt.p, fd, file_off, size));
     else PTX_TRY(upload_big(ctx, d_txt.p, text, size));
-    const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
+    return gaf_scan_newlines(ctx, size, d_txt, nl_pos, n_nl_out);
+}
+
+// newline positions of a text that is already in HBM
+int gaf_scan_newlines(Ctx *ctx, uint64_t size, DevBuf<uint8_t> &d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out) {
     DevBuf<uint32_t> tile_cnt, tile_base, tot, scan_tmp;
+    PTX_TRY(gaf_scan_newlines_ws(ctx, size, d_txt.p, nl_pos, n_nl_out, tile_cnt, tile_base, tot, scan_tmp));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the tile tables are released on return
+    return 0;
+}
+// ... with the caller's (grow-only) work buffers: nothing is released here, so no wait at the end
+int gaf_scan_newlines_ws(Ctx *ctx, uint64_t size, const uint8_t *d_txt, DevBuf<uint32_t> &nl_pos, uint32_t *n_nl_out, DevBuf<uint32_t> &tile_cnt,
+                         DevBuf<uint32_t> &tile_base, DevBuf<uint32_t> &tot, DevBuf<uint32_t> &scan_tmp) {
+    const uint32_t n_tiles = (uint32_t)((size + GAF_TILE - 1) / GAF_TILE);
     PTX_HIP(ctx, tile_cnt.alloc(n_tiles)); PTX_HIP(ctx, tile_base.alloc(n_tiles)); PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
     {
         KTimer t(ctx, "gaf_nl_count_kernel");
-        hipLaunchKernelGGL(gaf_nl_count_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_cnt.p);
+        hipLaunchKernelGGL(gaf_nl_count_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt, size, tile_cnt.p);
     }
     PTX_TRY(exclusive_scan_u32(ctx, tile_cnt.p, tile_base.p, n_tiles, scan_tmp.p, tot.p));
     uint32_t n_nl = 0;
@@ -185,10 +200,9 @@ int gaf_upload_and_scan(Ctx *ctx, const char *text, uint64_t size, DevBuf<uint8_
     PTX_HIP(ctx, nl_pos.alloc(n_nl ? n_nl : 1));
     {
         KTimer t(ctx, "gaf_nl_emit_kernel");
-        hipLaunchKernelGGL(gaf_nl_emit_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt.p, size, tile_base.p, nl_pos.p);
+        hipLaunchKernelGGL(gaf_nl_emit_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, d_txt, size, tile_base.p, nl_pos.p);
     }
     PTX_HIP(ctx, hipGetLastError());
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the tile tables are released on return
     *n_nl_out = n_nl;
     return 0;
 }
@@ -209,17 +223,61 @@ __global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-// one tokenised piece of the text (< 4 GiB: positions inside a piece are 32-bit), still on the device
-struct GafPiece {
-    uint64_t R = 0, T = 0;
-    DevBuf<uint32_t> o32[7];   // step_off (piece-local), node_id, pstart, pend, qlen, id_off (piece-local), id_len
+// The joined columns of all pieces (grow-only; sized from the first piece's density, so later pieces are written in place),
+// and the work buffers one piece after the other reuses -- no allocation is made or released between two pieces: the device
+// allocation cache hands a block out again only behind a device-wide wait, which would stall the upload that runs beside.
+struct GafJoined {
+    DevBuf<uint32_t> o32[7];   // step_off, node_id, pstart, pend, qlen, id_off (piece-local), id_len
     DevBuf<uint8_t> o8[2];     // mapq, flags
     DevBuf<uint64_t> o_hash;
+    uint64_t R = 0, T = 0, cap_r = 0, cap_t = 0;
+    std::vector<uint64_t> piece_r0;   // first read of every piece (id spans are piece-local)
+};
+struct GafWork {
+    DevBuf<uint32_t> nl_pos, tile_cnt, tile_base, tot, scan_tmp, r32[8], ridx, soff;
+    DevBuf<uint64_t> r_hash;
+    DevBuf<uint8_t> r8[3];
 };
 
-static int tokenize_piece(Ctx *ctx, const char *text, uint64_t size, int fd, uint64_t file_off, GafPiece &pc) {
-    DevBuf<uint8_t> d_txt;
-    DevBuf<uint32_t> nl_pos, tot, scan_tmp;
+// capacity for R reads / T steps in all (the present contents are kept)
+static int joined_reserve(Ctx *ctx, GafJoined &J, uint64_t need_r, uint64_t need_t) {
+    auto grow32 = [&](DevBuf<uint32_t> &b, uint64_t have, uint64_t want) -> int {
+        DevBuf<uint32_t> nb;
+        PTX_HIP(ctx, nb.alloc(want));
+        if (have) PTX_HIP(ctx, hipMemcpyAsync(nb.p, b.p, have * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        b.take(nb);
+        return 0;
+    };
+    if (need_t > J.cap_t || !J.o32[1].p) {
+        const uint64_t want = std::max<uint64_t>(need_t, J.cap_t + J.cap_t / 2);
+        PTX_TRY(grow32(J.o32[1], J.T, want ? want : 1));
+        J.cap_t = want;
+    }
+    if (need_r > J.cap_r || !J.o32[0].p) {
+        const uint64_t want = std::max<uint64_t>(need_r, J.cap_r + J.cap_r / 2);
+        PTX_TRY(grow32(J.o32[0], J.R ? J.R + 1 : 0, want + 1));
+        for (int k = 2; k < 7; ++k) PTX_TRY(grow32(J.o32[k], J.R, want ? want : 1));
+        for (auto &b : J.o8) {
+            DevBuf<uint8_t> nb;
+            PTX_HIP(ctx, nb.alloc(want ? want : 1));
+            if (J.R) PTX_HIP(ctx, hipMemcpyAsync(nb.p, b.p, J.R, hipMemcpyDeviceToDevice, ctx->stream));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            b.take(nb);
+        }
+        DevBuf<uint64_t> nh;
+        PTX_HIP(ctx, nh.alloc(want ? want : 1));
+        if (J.R) PTX_HIP(ctx, hipMemcpyAsync(nh.p, J.o_hash.p, J.R * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        J.o_hash.take(nh);
+        J.cap_r = want;
+    }
+    return 0;
+}
+
+// d_txt: the piece's text, uploaded (size + 16 bytes allocated); last_is_nl: its last byte is a line end; rest_bytes: text that
+// follows this piece (sizes the joined columns from this piece's density when they are first allocated)
+static int tokenize_piece(Ctx *ctx, const uint8_t *d_txt, uint64_t size, bool last_is_nl, uint64_t rest_bytes, GafWork &W, GafJoined &J) {
     uint32_t n_nl = 0;
     const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -230,40 +288,44 @@ static int tokenize_piece(Ctx *ctx, const char *text, uint64_t size, int fd, uin
         std::fprintf(stderr, "[gaf_tokenize]   piece: %-25s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    PTX_TRY(gaf_upload_and_scan(ctx, text, size, d_txt, nl_pos, &n_nl, fd, file_off));
-    lap("text upload + newline scan");
-    PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
-    const uint32_t n_raw = n_nl + (text[size - 1] != '\n' ? 1u : 0u);
-    DevBuf<uint32_t> r32[8], ridx, soff;
-    DevBuf<uint64_t> r_hash;
-    DevBuf<uint8_t> r8[3];
-    for (auto &b : r32) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
-    for (auto &b : r8) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
-    PTX_HIP(ctx, r_hash.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, ridx.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, soff.alloc(n_raw ? n_raw : 1));
-    GafRaw raw{r32[0].p, r32[1].p, r32[2].p, r32[3].p, r32[4].p, r32[5].p, r32[6].p, r32[7].p, r_hash.p, r8[0].p, r8[1].p, r8[2].p};
+    PTX_TRY(gaf_scan_newlines_ws(ctx, size, d_txt, W.nl_pos, &n_nl, W.tile_cnt, W.tile_base, W.tot, W.scan_tmp));
+    lap("newline scan");
+    const uint32_t n_raw = n_nl + (last_is_nl ? 0u : 1u);
+    for (auto &b : W.r32) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
+    for (auto &b : W.r8) PTX_HIP(ctx, b.alloc(n_raw ? n_raw : 1));
+    PTX_HIP(ctx, W.r_hash.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, W.ridx.alloc(n_raw ? n_raw : 1)); PTX_HIP(ctx, W.soff.alloc(n_raw ? n_raw : 1));
+    GafRaw raw{W.r32[0].p, W.r32[1].p, W.r32[2].p, W.r32[3].p, W.r32[4].p, W.r32[5].p, W.r32[6].p, W.r32[7].p, W.r_hash.p, W.r8[0].p, W.r8[1].p, W.r8[2].p};
     const uint32_t grid = (n_raw + 255) / 256 ? (n_raw + 255) / 256 : 1;
     {
         KTimer t(ctx, "gaf_parse_kernel");
-        hipLaunchKernelGGL(gaf_parse_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, size, n_raw, n_nl, nl_pos.p, raw);
+        hipLaunchKernelGGL(gaf_parse_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt, size, n_raw, n_nl, W.nl_pos.p, raw);
     }
-    PTX_TRY(exclusive_scan_u8(ctx, raw.valid, ridx.p, n_raw, scan_tmp.p, tot.p + 1));
-    PTX_TRY(exclusive_scan_u32(ctx, raw.steps, soff.p, n_raw, scan_tmp.p, tot.p + 2));
+    PTX_TRY(exclusive_scan_u8(ctx, raw.valid, W.ridx.p, n_raw, W.scan_tmp.p, W.tot.p + 1));
+    PTX_TRY(exclusive_scan_u32(ctx, raw.steps, W.soff.p, n_raw, W.scan_tmp.p, W.tot.p + 2));
     uint32_t rt[2] = {0, 0};
-    PTX_TRY(download(ctx, rt, tot.p + 1, 2));
+    PTX_TRY(download(ctx, rt, W.tot.p + 1, 2));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t R = rt[0], T = rt[1];
-    pc.R = R; pc.T = T;
-    PTX_HIP(ctx, pc.o32[0].alloc(R + 1)); PTX_HIP(ctx, pc.o32[1].alloc(T ? T : 1));
-    for (int k = 2; k < 7; ++k) PTX_HIP(ctx, pc.o32[k].alloc(R ? R : 1));
-    for (auto &b : pc.o8) PTX_HIP(ctx, b.alloc(R ? R : 1));
-    PTX_HIP(ctx, pc.o_hash.alloc(R ? R : 1));
-    GafOut go{pc.o32[0].p, pc.o32[1].p, pc.o32[2].p, pc.o32[3].p, pc.o32[4].p, pc.o32[5].p, pc.o32[6].p, pc.o8[0].p, pc.o8[1].p, pc.o_hash.p};
+    if (J.R + R >= 0xFFFFFFFFull || J.T + T >= 0xFFFFFFFFull)
+        return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu reads / %llu walk steps exceed the 32-bit offsets of one batch; split the input",
+                    (unsigned long long)(J.R + R), (unsigned long long)(J.T + T));
+    // room in the joined columns: first piece -> the whole text at this piece's density + 3 %; later pieces fit unless they are denser
+    uint64_t need_r = J.R + R, need_t = J.T + T;
+    if (need_r > J.cap_r || need_t > J.cap_t || !J.o32[0].p) {
+        const double f = 1.03 * (double)(size + rest_bytes) / (double)(size ? size : 1);
+        need_r = std::max<uint64_t>(need_r, std::min<uint64_t>(0xFFFFFFFEull, J.R + (uint64_t)((double)R * f) + 1024));
+        need_t = std::max<uint64_t>(need_t, std::min<uint64_t>(0xFFFFFFFEull, J.T + (uint64_t)((double)T * f) + 1024));
+        PTX_TRY(joined_reserve(ctx, J, need_r, need_t));
+    }
+    GafOut go{J.o32[0].p + J.R, J.o32[1].p + J.T, J.o32[2].p + J.R, J.o32[3].p + J.R, J.o32[4].p + J.R, J.o32[5].p + J.R, J.o32[6].p + J.R,
+              J.o8[0].p + J.R, J.o8[1].p + J.R, J.o_hash.p + J.R};
     {
         KTimer t(ctx, "gaf_fill_kernel");
-        hipLaunchKernelGGL(gaf_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt.p, n_raw, raw, ridx.p, soff.p, (uint32_t)R, (uint32_t)T, go);
+        hipLaunchKernelGGL(gaf_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt, n_raw, raw, W.ridx.p, W.soff.p, (uint32_t)R, (uint32_t)T, (uint32_t)J.T, go);
     }
     PTX_HIP(ctx, hipGetLastError());
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the piece's text and raw columns are released on return
+    J.piece_r0.push_back(J.R);
+    J.R += R; J.T += T;
     lap("parse + scans + fill");
     return 0;
 }
@@ -287,6 +349,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     if (resident) resident->grouped = group;
     // PANTAX_HIP_TRACE=1: where the load spends its time (stderr)
     const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -305,69 +368,125 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         }
         return 0;
     }
-    uint64_t piece_max = 0xE0000000ull;   // 3.5 GiB
-    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < piece_max) piece_max = (uint64_t)v; }
-    std::vector<std::unique_ptr<GafPiece>> pcs;
-    std::vector<uint64_t> piece_off;
+    // Pieces of the text (cut at line ends; positions inside a piece are 32-bit) travel on an upload stream of their own, fed by
+    // an uploader thread through the pinned ring, while this thread tokenises the piece before: PCIe and the tokenizer kernels
+    // work side by side.  Three text buffers rotate; the pieces' columns are written straight into the joined arrays.
+    // Piece size: a sixth of the text, 64 MB .. 1 GiB (PANTAX_GAF_PIECE_BYTES caps it; a line longer than that cap is refused).
+    uint64_t piece_max = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, size / 6));
+    bool capped = false;
+    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < 0xE0000000ull) { piece_max = (uint64_t)v; capped = true; } }
+    std::vector<uint64_t> piece_off, piece_end;
+    uint64_t longest = 0;
     for (uint64_t off = 0; off < size;) {
         uint64_t end = std::min<uint64_t>(size, off + piece_max);
         if (end < size) {   // back to the last line end inside the piece
             const void *nl = memrchr(text + off, '\n', (size_t)(end - off));
-            if (!nl) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: a line of more than %llu bytes at offset %llu", (unsigned long long)piece_max, (unsigned long long)off);
-            end = (uint64_t)(static_cast<const char *>(nl) - text) + 1;
+            if (!nl && !capped) {   // a line longer than the default piece: forward to its end (pieces stay below 3.5 GiB)
+                const uint64_t far = std::min<uint64_t>(size, off + 0xE0000000ull);
+                const void *fw = memchr(text + end, '\n', (size_t)(far - end));
+                if (fw) nl = fw;
+                else if (far == size) { end = size; nl = text; }
+            }
+            if (!nl) return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: a line of more than %llu bytes at offset %llu", (unsigned long long)(capped ? piece_max : 0xE0000000ull), (unsigned long long)off);
+            if (end != size) end = (uint64_t)(static_cast<const char *>(nl) - text) + 1;
         }
-        pcs.emplace_back(new GafPiece());
-        piece_off.push_back(off);
-        PTX_TRY(tokenize_piece(ctx, text + off, end - off, fd, file_base + off, *pcs.back()));
+        piece_off.push_back(off); piece_end.push_back(end);
+        longest = std::max(longest, end - off);
         off = end;
     }
-    lap("pieces: upload + scan + parse + fill");
-    uint64_t R = 0, T = 0;
-    for (auto &pc : pcs) { R += pc->R; T += pc->T; }
-    if (R >= 0xFFFFFFFFull || T >= 0xFFFFFFFFull)
-        return fail(ctx, PANTAX_HIP_E_LIMIT, "gaf_tokenize: %llu reads / %llu walk steps exceed the 32-bit offsets of one batch; split the input", (unsigned long long)R, (unsigned long long)T);
+    const size_t NP = piece_off.size();
+    GafJoined J;
+    {
+        constexpr size_t RING = 3;
+        struct Shared {
+            std::mutex mu;
+            std::condition_variable cv;
+            size_t uploaded = 0, tokenised = 0;   // pieces whose text is in HBM / whose text buffer is free again
+            int rc = 0;
+            bool stop = false;
+        } sh;
+        DevBuf<uint8_t> txt[RING];
+        for (size_t k = 0; k < std::min(RING, NP); ++k) PTX_HIP(ctx, txt[k].alloc(longest + 16));
+        GafWork W;
+        lap("setup: piece cuts, text buffers");
+        hipStream_t up_stream = nullptr;
+        PTX_HIP(ctx, hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking));
+        std::vector<hipEvent_t> ev_piece(NP, nullptr);
+        for (auto &e : ev_piece) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        std::vector<void *> dsts(NP);
+        for (size_t k = 0; k < NP; ++k) dsts[k] = txt[k % RING].p;
+        std::thread uploader([&] {
+            (void)hipSetDevice(ctx->device);
+            const int rc = upload_text_pieces(
+                ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream,
+                [&](size_t k) {   // the text buffer of piece k is free once piece k - RING has been tokenised
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    sh.cv.wait(lk, [&] { return sh.stop || k < sh.tokenised + RING; });
+                    return !sh.stop;
+                },
+                [&](size_t k) {   // all of piece k is on the upload stream: the tokenizer's stream waits for this event
+                    if (hipEventRecord(ev_piece[k], up_stream) != hipSuccess) return fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipEventRecord failed");
+                    std::lock_guard<std::mutex> g(sh.mu);
+                    sh.uploaded = k + 1;
+                    sh.cv.notify_all();
+                    return 0;
+                });
+            std::lock_guard<std::mutex> g(sh.mu);
+            if (rc != 0 && !sh.stop) { sh.rc = rc; sh.stop = true; }
+            sh.cv.notify_all();
+        });
+        int rc = 0;
+        std::thread prefault;   // the host columns (14 bytes per read) are allocated and page-faulted beside the upload, not after it
+        for (size_t k = 0; k < NP && rc == 0; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return sh.stop || sh.uploaded > k; });
+                if (sh.uploaded <= k) { rc = sh.rc ? sh.rc : PANTAX_HIP_E_HIP; break; }
+            }
+            if (hipStreamWaitEvent(ctx->stream, ev_piece[k], 0) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipStreamWaitEvent failed"); }
+            if (rc == 0) rc = tokenize_piece(ctx, txt[k % RING].p, piece_end[k] - piece_off[k], text[piece_end[k] - 1] == '\n', size - piece_end[k], W, J);
+            if (rc == 0 && k == 0 && NP > 1) {
+                const uint64_t est = J.cap_r;
+                prefault = std::thread([&out, est] { out.qlen.resize(est); out.mapq.resize(est); out.flags.resize(est); out.id_hash.resize(est); });
+            }
+            if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: piece %zu failed", k);   // the text buffer goes back to the uploader
+            std::lock_guard<std::mutex> g(sh.mu);
+            sh.tokenised = k + 1;
+            if (rc != 0) sh.stop = true;
+            sh.cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> g(sh.mu); if (rc != 0) sh.stop = true; sh.cv.notify_all(); }
+        uploader.join();
+        if (prefault.joinable()) prefault.join();
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(up_stream);
+        for (auto &e : ev_piece) if (e) (void)hipEventDestroy(e);
+        if (rc != 0) return rc;
+    }
+    lap("pieces: upload | scan + parse + fill");
+    const uint64_t R = J.R, T = J.T;
     // id spans: piece-local 32-bit positions -> positions in the whole text
     if (want_id_spans) {
         out.id_span.resize(R);
-        uint64_t r0 = 0;
-        std::vector<uint32_t> id_off, id_len;
-        for (size_t k = 0; k < pcs.size(); ++k) {
-            GafPiece &pc = *pcs[k];
-            id_off.resize(pc.R); id_len.resize(pc.R);
-            PTX_TRY(download(ctx, id_off.data(), pc.o32[5].p, pc.R)); PTX_TRY(download(ctx, id_len.data(), pc.o32[6].p, pc.R));
-            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const uint64_t base = piece_off[k], rr = r0;
-            parallel_for(pc.R, 8, [&](uint64_t i0, uint64_t i1) { for (uint64_t i = i0; i < i1; ++i) out.id_span[rr + i] = {base + (uint64_t)id_off[i], id_len[i]}; });
-            r0 += pc.R;
+        std::vector<uint32_t> id_off(R), id_len(R);
+        PTX_TRY(download(ctx, id_off.data(), J.o32[5].p, R)); PTX_TRY(download(ctx, id_len.data(), J.o32[6].p, R));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < NP; ++k) {
+            const uint64_t base = piece_off[k], ra = J.piece_r0[k], rb = k + 1 < NP ? J.piece_r0[k + 1] : R;
+            parallel_for(rb - ra, 8, [&](uint64_t i0, uint64_t i1) { for (uint64_t i = ra + i0; i < ra + i1; ++i) out.id_span[i] = {base + (uint64_t)id_off[i], id_len[i]}; });
         }
     }
-    // join the pieces (a single piece is used as it is)
     DevBuf<uint32_t> o32[5];
     DevBuf<uint8_t> o8[2];
     DevBuf<uint64_t> o_hash;
-    if (pcs.size() == 1) {
-        for (int k = 0; k < 5; ++k) o32[k].take(pcs[0]->o32[k]);
-        o8[0].take(pcs[0]->o8[0]); o8[1].take(pcs[0]->o8[1]); o_hash.take(pcs[0]->o_hash);
-    } else {
-        PTX_HIP(ctx, o32[0].alloc(R + 1)); PTX_HIP(ctx, o32[1].alloc(T ? T : 1));
-        for (int k = 2; k < 5; ++k) PTX_HIP(ctx, o32[k].alloc(R ? R : 1));
-        for (auto &b : o8) PTX_HIP(ctx, b.alloc(R ? R : 1));
-        PTX_HIP(ctx, o_hash.alloc(R ? R : 1));
-        uint64_t r0 = 0, t0 = 0;
-        for (auto &pcp : pcs) {
-            GafPiece &pc = *pcp;
-            auto d2d = [&](void *dst, const void *src, uint64_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess; };
-            PTX_HIP(ctx, d2d(o32[0].p + r0, pc.o32[0].p, pc.R * 4)); PTX_HIP(ctx, d2d(o32[1].p + t0, pc.o32[1].p, pc.T * 4));
-            for (int k = 2; k < 5; ++k) PTX_HIP(ctx, d2d(o32[k].p + r0, pc.o32[k].p, pc.R * 4));
-            PTX_HIP(ctx, d2d(o8[0].p + r0, pc.o8[0].p, pc.R)); PTX_HIP(ctx, d2d(o8[1].p + r0, pc.o8[1].p, pc.R));
-            PTX_HIP(ctx, d2d(o_hash.p + r0, pc.o_hash.p, pc.R * 8));
-            if (pc.R && t0) hipLaunchKernelGGL(add_u32_offset_kernel, dim3(grid_for(pc.R, 256, ctx->n_cu * 4)), dim3(256), 0, ctx->stream, pc.R, o32[0].p + r0, (uint32_t)t0);
-            r0 += pc.R; t0 += pc.T;
-        }
-        const uint32_t t32 = (uint32_t)T;
-        PTX_HIP(ctx, hipMemcpyAsync(o32[0].p + R, &t32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        pcs.clear();
+    for (int k = 0; k < 5; ++k) o32[k].take(J.o32[k]);
+    o8[0].take(J.o8[0]); o8[1].take(J.o8[1]); o_hash.take(J.o_hash);
+    if (!o32[0].p) {   // no piece at all
+        static const uint32_t zero = 0;
+        PTX_TRY(upload(ctx, o32[0], &zero, 1));
+        for (int k = 1; k < 5; ++k) PTX_HIP(ctx, o32[k].alloc(1));
+        for (auto &b8 : o8) PTX_HIP(ctx, b8.alloc(1));
+        PTX_HIP(ctx, o_hash.alloc(1));
     }
     DevBuf<uint32_t> tot, scan_tmp;
     PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
@@ -418,6 +537,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     out.n_lines = R;
     out.ids_distinct = n_dup == 0 ? 1 : 0;
+    if (trace) std::fprintf(stderr, "[gaf_tokenize] total inside gaf_tokenize_device      %9.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
     return 0;
 }
 

@@ -132,9 +132,10 @@ class Engine:
         mapq = np.where((reads.mapq < 0) | (reads.mapq > 254), 255, reads.mapq)
         self.upload_reads(reads.step_off, reads.node_id, reads.pstart, reads.pend, reads.qlen, mapq, flags)
 
-    def load_reads_from_gaf(self, path):
+    def load_reads_from_gaf(self, path, columns=True):
         """GAF file -> packed reads resident in HBM, tokenised on the device (pantax_hip_reads_load_gaf).
-        -> dict(qlen, mapq, flags) of the host-side columns; the walks stay on the device."""
+        -> dict(qlen, mapq, flags) of the host-side columns (columns=False: None, nothing is copied out); the walks stay on
+        the device."""
         if self.reads:
             self.lib.pantax_hip_reads_free(self.ctx, self.reads)
             self.reads = None
@@ -145,6 +146,8 @@ class Engine:
             v = _ffi.PackedReads()
             self.lib.pantax_hip_gaf_view(gaf, C.byref(v))
             self.R = int(v.n_reads)
+            if not columns:
+                return None
             arr = lambda ptr, dt: (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(self.R,)).copy()
                                    if self.R else np.zeros(0, dtype=dt))
             return dict(qlen=arr(v.qlen, np.uint32), mapq=arr(v.mapq, np.uint8), flags=arr(v.flags, np.uint8))
