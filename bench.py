@@ -503,6 +503,7 @@ def main():
         eng.upload_db(species)
         eng.upload_packed(rd)          # inputs resident in HBM before the timed region
     eng.sync()
+    R_res, T_res = eng.R, eng.T                      # reads / walk steps resident on this rank
     upload_ms = (time.perf_counter() - t_up) * 1e3   # host->device of packed reads + graph (pageable memory, incl. numpy packing)
     species_names = [g.name for g in species]
     hap_names = [hn for g in species for hn in g.hap_names]
@@ -608,9 +609,25 @@ def main():
                 eng.sync()
                 t_e2e = time.perf_counter() - t2
                 same = (out is not None and out_gaf[0] == out[0] and out_gaf[1] == out[1]) if n_gaf == n_reads else None
+                # the box's ceiling for this leg: pinned host -> device copy rate (1 GiB in 64-MB chunks, second pass)
+                h2d = None
+                try:
+                    pin = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+                    dv = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+                    for rep in range(2):
+                        torch.cuda.synchronize()
+                        t_h = time.perf_counter()
+                        for off in range(0, 1 << 30, 64 << 20):
+                            dv[off:off + (64 << 20)].copy_(pin[off:off + (64 << 20)], non_blocking=True)
+                        torch.cuda.synchronize()
+                        h2d = (1 << 30) / (time.perf_counter() - t_h) / 1e9
+                    del pin, dv
+                except Exception:   # noqa: BLE001
+                    pass
                 gaf_extra = {"gaf_bytes": gaf_bytes, "reads": n_gaf, "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
                              "end_to_end_s": t_e2e, "end_to_end_mreads_per_s": n_gaf / t_e2e / 1e6, "gaf_gb_per_s": gaf_bytes / t_load / 1e9,
                              "tables_equal_to_packed_input_run": same, "gaf_written_in_s": write_s, "gaf_dir": td_root,
+                             "pinned_h2d_ceiling_gb_per_s": h2d, "gaf_gb_per_s_of_ceiling": (gaf_bytes / t_load / 1e9 / h2d) if h2d else None,
                              "what": "GAF text on disk (page cache) -> pread + PCIe + device tokenizer -> resident grouped reads -> one step -> tables",
                              "note": None if n_gaf == n_reads else "the first %d reads of the workload as GAF text, against the whole resident db" % n_gaf}
     rd = None
@@ -660,7 +677,7 @@ def main():
         value = total_reads / (dt / args.steps) / 1e6
         n_lp_rows = int(sum(stats["n_rows"]))
         n_unique = int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
-        ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, eng.R, eng.T)
+        ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, R_res, T_res)
         dims["U"] = n_unique
         # dominant kernel by HIP-event time on the library's stream
         roofline = None

@@ -443,7 +443,7 @@ int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1, uint64_t file_base = 0, bool group = true,
-                        bool want_id_spans = false);
+                        bool want_id_spans = false, bool want_host_columns = true);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
 // stage_route.hip: binned reads -> one message per owner rank, and back to resident reads on the owner
 struct Route {

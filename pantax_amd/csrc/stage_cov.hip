@@ -662,7 +662,8 @@ __global__ void __launch_bounds__(256) group_count_kernel(uint64_t R, const uint
 }
 __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
                                                          int shift, const uint32_t *__restrict__ base_r, uint32_t *__restrict__ cur_r,
-                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len, uint32_t *__restrict__ n_long) {
+                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len, uint32_t *__restrict__ read_of,
+                                                         uint32_t *__restrict__ n_long) {
     uint32_t mine = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
@@ -671,6 +672,7 @@ __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint3
             const uint32_t key = node_id[b] >> shift;
             slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
             slot_len[slot] = k;
+            read_of[slot] = (uint32_t)r;
             mine += k > 64 ? 1u : 0u;
         }
         slot_of[r] = slot;
@@ -699,16 +701,17 @@ __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, c
     }
     size_s[key] = (pos + 63) & ~63u;
 }
-__global__ void __launch_bounds__(256) group_fill_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
-                                                         const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend,
+// In SLOT order (thread = slot): the walks land where the slots follow each other in the stream, so a wave writes one dense
+// region of the grouped arrays (its 4-byte stores combine in L2) and gathers the short source walks instead.  In read order
+// the same stores scattered single dwords over the whole stream: 72 GB written for 4 GB of payload at 1e8 reads (46 ms).
+__global__ void __launch_bounds__(256) group_fill_kernel(uint32_t n_slots, const uint32_t *__restrict__ read_of, const uint32_t *__restrict__ step_off,
+                                                         const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend,
                                                          const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, int shift,
-                                                         const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_of,
-                                                         const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec, uint2 *__restrict__ g_qm,
-                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
+                                                         const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
+                                                         uint2 *__restrict__ g_qm, uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
                                                          uint8_t *__restrict__ g_step_dup) {
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
-        const uint32_t slot = slot_of[r];
-        if (slot == NO_SLOT) continue;
+    for (uint32_t slot = blockIdx.x * 256 + threadIdx.x; slot < n_slots; slot += gridDim.x * 256) {
+        const uint32_t r = read_of[slot];
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
         const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
         g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
@@ -796,7 +799,8 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, cnt.alloc(4ull * (NB + 1) + 8));
     uint32_t *cnt_r = cnt.p, *base_r = cnt_r + (NB + 1), *size_s = base_r + (NB + 1), *base_s = size_s + (NB + 1);
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB + 1)));
-    PTX_HIP(ctx, slot_len.alloc(rd->R)); PTX_HIP(ctx, slot_rel.alloc(rd->R));
+    DevBuf<uint32_t> read_of;
+    PTX_HIP(ctx, slot_len.alloc(rd->R)); PTX_HIP(ctx, slot_rel.alloc(rd->R)); PTX_HIP(ctx, read_of.alloc(rd->R));
     PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R));
     PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));
     int gridR = grid_for(rd->R, 256, ctx->n_cu * 8);
@@ -806,7 +810,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     uint32_t *d_total = (uint32_t *)ctx->d_scalars.p, *d_n_long = d_total + 1;
     PTX_HIP(ctx, hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_r, cnt_r,
-                       rd->d_slot_of.p, slot_len.p, d_n_long);
+                       rd->d_slot_of.p, slot_len.p, read_of.p, d_n_long);
     // layout units: 2^g buckets each, about 2048 walk steps per unit (the rounding of a unit to 64 steps then costs ~1.5 %)
     int g = 0;
     while (g < 12 && ((double)rd->T / (double)NB) * (double)(1u << g) < 2048.0) ++g;
@@ -827,9 +831,10 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_group_slot.p, 0xFF, (rd->T_pad / 64 + 1) * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0xFF, rd->T_pad, ctx->stream));                          // STEP_PAD
-    hipLaunchKernelGGL(group_fill_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p,
-                       rd->d_pend.p, rd->d_qlen.p, rd->d_mapq.p, ushift, base_s, rd->d_slot_of.p, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_qm.p, rd->d_g_node_id.p,
-                       rd->d_g_group_slot.p, rd->d_g_step_dup.p);
+    if (rd->n_slots)
+        hipLaunchKernelGGL(group_fill_kernel, dim3(grid_for(rd->n_slots, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->n_slots, read_of.p, rd->d_step_off.p,
+                           rd->d_node_id.p, rd->d_pstart.p, rd->d_pend.p, rd->d_qlen.p, rd->d_mapq.p, ushift, base_s, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_qm.p,
+                           rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);
     if (rd->n_long) {
         const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
         hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, ushift, base_s,

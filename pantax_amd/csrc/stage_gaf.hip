@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) add_u32_offset_kernel(uint64_t n, uint32_
 // `want_id_spans`: where every read id sits in the text (the binning report writes the ids back); 160 MB of host memory and
 // ~20 ms per 10 M reads that nobody else needs.
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident, int fd, uint64_t file_base, bool group,
-                        bool want_id_spans) {
+                        bool want_id_spans, bool want_host_columns) {
     out = HostReads();
     if (resident) resident->grouped = group;
     // PANTAX_HIP_TRACE=1: where the load spends its time (stderr)
@@ -445,7 +445,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
             }
             if (hipStreamWaitEvent(ctx->stream, ev_piece[k], 0) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipStreamWaitEvent failed"); }
             if (rc == 0) rc = tokenize_piece(ctx, txt[k % RING].p, piece_end[k] - piece_off[k], text[piece_end[k] - 1] == '\n', size - piece_end[k], W, J);
-            if (rc == 0 && k == 0 && NP > 1) {
+            if (rc == 0 && k == 0 && NP > 1 && want_host_columns) {
                 const uint64_t est = J.cap_r;
                 prefault = std::thread([&out, est] { out.qlen.resize(est); out.mapq.resize(est); out.flags.resize(est); out.id_hash.resize(est); });
             }
@@ -490,7 +490,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     DevBuf<uint32_t> tot, scan_tmp;
     PTX_HIP(ctx, tot.alloc(4)); PTX_HIP(ctx, scan_tmp.alloc(16));
-    out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R);
+    if (want_host_columns) { out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R); }
     if (!resident) {
         out.step_off.resize(R + 1); out.node_id.resize(T); out.pstart.resize(R); out.pend.resize(R);
         PTX_TRY(download(ctx, out.step_off.data(), o32[0].p, R + 1));
@@ -520,9 +520,11 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     }
     lap("id-hash sort");
     uint32_t max_id = 0;
-    PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
-    PTX_TRY(download(ctx, out.mapq.data(), o8[0].p, R)); PTX_TRY(download(ctx, out.flags.data(), o8[1].p, R));
-    PTX_TRY(download(ctx, out.id_hash.data(), o_hash.p, R));
+    if (want_host_columns) {
+        PTX_TRY(download(ctx, out.qlen.data(), o32[4].p, R));
+        PTX_TRY(download(ctx, out.mapq.data(), o8[0].p, R)); PTX_TRY(download(ctx, out.flags.data(), o8[1].p, R));
+        PTX_TRY(download(ctx, out.id_hash.data(), o_hash.p, R));
+    }
     if (resident) PTX_TRY(download(ctx, &max_id, tot.p + 3, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     lap("host columns download");
@@ -566,7 +568,8 @@ extern "C" int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, 
     std::unique_ptr<pantax_hip_reads> rd(new pantax_hip_reads());
     std::string e = g->mf.open(path);
     if (!e.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str());
-    PTX_TRY(gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, rd.get(), g->mf.fd));
+    // without a gaf handle nobody can read the host-side columns (read_len, mapq, flags, id hashes): they are not downloaded
+    PTX_TRY(gaf_tokenize_device(ctx, g->mf.data, g->mf.size, g->reads, rd.get(), g->mf.fd, 0, true, false, gaf_out != nullptr));
     *reads_out = rd.release();
     if (gaf_out) *gaf_out = g.release();
     return 0;

@@ -140,14 +140,17 @@ class Engine:
             self.lib.pantax_hip_reads_free(self.ctx, self.reads)
             self.reads = None
         rd, gaf = C.c_void_p(), C.c_void_p()
+        if not columns:   # no gaf handle: the library does not bring the per-read host columns back at all
+            self._check(self.lib.pantax_hip_reads_load_gaf(self.ctx, str(path).encode(), C.byref(rd), None))
+            self.reads = rd
+            self.R = self.T = None       # not known on the host (the counters of a binning pass tell)
+            return None
         self._check(self.lib.pantax_hip_reads_load_gaf(self.ctx, str(path).encode(), C.byref(rd), C.byref(gaf)))
         self.reads = rd
         try:
             v = _ffi.PackedReads()
             self.lib.pantax_hip_gaf_view(gaf, C.byref(v))
             self.R = int(v.n_reads)
-            if not columns:
-                return None
             arr = lambda ptr, dt: (np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(self.R,)).copy()
                                    if self.R else np.zeros(0, dtype=dt))
             return dict(qlen=arr(v.qlen, np.uint32), mapq=arr(v.mapq, np.uint8), flags=arr(v.flags, np.uint8))
