@@ -767,6 +767,9 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
+    if os.environ.get("PANTAX_BENCH_RSS"):     # tools/strong_dry_run.sh: what a rank needs of the host
+        import resource
+        print("rank %d: peak host RSS %.1f GB" % (rank, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0), file=sys.stderr, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
