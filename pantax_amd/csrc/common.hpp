@@ -291,6 +291,7 @@ struct Db {
     DevBuf<uint32_t> d_cov;                  // [V]
     DevBuf<unsigned long long> d_trio_bases; // [U]
     DevBuf<uint8_t> d_active;                // [S]
+    DevBuf<uint8_t> d_ones;                  // [S] all ones: the `active` table of a coverage pass that deselects nothing
     DevBuf<unsigned long long> d_counters;   // [4*S] species counters of bin_reads
     // persistent scratch of the derived stages
     TrioScratch trio_scratch;
@@ -344,11 +345,8 @@ struct Reads {
 };
 
 // slot record (Reads::d_g_slot_rec).x: >= 0 species, the coverage pass uses the slot; -1 "U"; -2 - s: binned to species s but dropped
-// before get_node_abundances (drop flag); -2 - s - SLOT_ABORT: binned to species s, but the walk leaves the species' graph (index
-// panic of profile.rs:849: counted as an abort, skipped whole)
-constexpr int32_t SLOT_ABORT = 1 << 30;
-__host__ __device__ inline int slot_species(int32_t x) { return x >= -1 ? x : (-x - 2) & (SLOT_ABORT - 1); }
-__host__ __device__ inline bool slot_aborts(int32_t x) { return x < -1 && (-x - 2) >= SLOT_ABORT; }
+// before get_node_abundances (drop flag)
+__host__ __device__ inline int slot_species(int32_t x) { return x >= -1 ? x : -x - 2; }
 
 // node record fields (Db::d_node_rec): the coverage bitmap of one GPU holds < 2^40 bases and a node heads < 2^24 lookup rows
 constexpr uint64_t NODE_REC_MAX_BITS = 1ull << 40;

@@ -268,8 +268,9 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_reads_lds_kernel(
 // 1e7 reads, 9x the algorithmic output; 13 ms at 1e8 reads.)  The per-read species array in file order is not written here:
 // species_ensure() scatters it from the slot records when a caller asks for it (report, routing).
 // Slot record (coding in common.hpp): x >= 0 species, usable by the coverage pass; x == -1 "U"; below: binned, but the row is
-// dropped before get_node_abundances (drop flag) or would die there (a node id beyond the species' graph, the index panic of
-// profile.rs:849 -- counted as an abort, the whole read skipped).
+// dropped before get_node_abundances (drop flag).  A binned walk cannot leave its species' graph: its ids lie inside the
+// species' range (rcls.rs:253-257) and db_upload refuses a range that does not span exactly the graph's nodes (optimize_otu
+// derives nvert from the range, profile.rs:2938) -- which is why the coverage pass places a node with one add and no test.
 template <bool SORTED, bool LDS_TAB>
 __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
     uint32_t n_slots, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ node_id, const uint2 *__restrict__ g_qm,
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
     unsigned long long *s_base = s_dyn;                                   // [S]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_dyn + (LDS_TAB ? S : 0));    // [3S]
     uint32_t *s_rs = s_cnt + (LDS_TAB ? 3 * S : 0), *s_re = s_rs + (LDS_TAB ? S : 0), *s_ridx = s_re + (LDS_TAB ? S : 0);
-    uint32_t *s_first = s_ridx + (LDS_TAB ? S : 0), *s_nb = s_first + (LDS_TAB ? S : 0), *s_nn = s_nb + (LDS_TAB ? S : 0);
+    uint32_t *s_first = s_ridx + (LDS_TAB ? S : 0), *s_nb = s_first + (LDS_TAB ? S : 0);
     unsigned long long *__restrict__ counters = counters_rep + (size_t)(blockIdx.x % BIN_REPL) * 4 * S;
     if (LDS_TAB) {
         for (int i = threadIdx.x; i < S; i += BIN_BLOCK) {
@@ -288,7 +289,6 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
             s_rs[i] = rs[i]; s_re[i] = re[i]; s_ridx[i] = ridx[i];
             s_first[i] = sp_first_id ? sp_first_id[i] : 0u;
             s_nb[i] = sp_first_id ? node_base[i] : 0u;
-            s_nn[i] = sp_first_id ? node_base[i + 1] - node_base[i] : 0xFFFFFFFFu;
         }
         __syncthreads();
     }
@@ -339,11 +339,10 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
             if (k) sp = LDS_TAB ? find_species<SORTED>(mn, mx, s_rs, s_re, s_ridx, S) : find_species<SORTED>(mn, mx, rs, re, ridx, S);
             uint2 rec = make_uint2(0xFFFFFFFFu, 0u);
             if (sp >= 0) {
-                uint32_t first = 0, nb = 0, nn = 0xFFFFFFFFu;
-                if (LDS_TAB) { first = s_first[sp]; nb = s_nb[sp]; nn = s_nn[sp]; }
-                else if (sp_first_id) { first = sp_first_id[sp]; nb = node_base[sp]; nn = node_base[sp + 1] - nb; }
-                const bool leaves = mx - first >= nn;                 // a node id beyond the species' graph (range wider than the graph)
-                rec.x = fl ? (uint32_t)(-sp - 2) : leaves ? (uint32_t)(-sp - 2 - SLOT_ABORT) : (uint32_t)sp;
+                uint32_t first = 0, nb = 0;
+                if (LDS_TAB) { first = s_first[sp]; nb = s_nb[sp]; }
+                else if (sp_first_id) { first = sp_first_id[sp]; nb = node_base[sp]; }
+                rec.x = fl ? (uint32_t)(-sp - 2) : (uint32_t)sp;
                 rec.y = nb - first;
             }
             slot_rec[r] = rec;
@@ -449,7 +448,7 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
     unsigned long long *d_final = d_counters;
     d_counters = d_counters + bin_result_words(S);   // replicas
     const bool lds = S <= BIN_LDS_SPECIES;
-    const size_t dyn = (size_t)S * 44;   // LDS tables: 8 + 12 + 24 bytes per species
+    const size_t dyn = (size_t)S * (rd->grouped ? 40 : 32);   // LDS tables per species: 8 + 12 (counters) + 12 (ranges) + 8 ({first id, node base}; slot order only)
     if (rd->grouped) {
         // resident reads: slot order (coalesced slot records); drop flags reach the slots once per change
         const uint8_t *g_flag = nullptr;

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         const uint32_t gs = group_slot[g];
         if (gs == NO_SLOT) continue;
         const uint2 sr0 = slot_rec[gs];
-        if ((int)sr0.x < 0 || (active && !active[sr0.x])) continue;
+        if ((int)sr0.x < 0 || !active[sr0.x]) continue;
         const uint32_t v0 = node_id[(uint64_t)g * 64] + sr0.y;
         wlo = (v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u) & ~63u;
         win_n = WIN;
@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             ok[u] = run[u] && !pad[u] && (int)sr[u].x >= 0;
             v[u] = ok[u] ? id[u] + sr[u].y : wlo;
             nr[u] = node_rec[v[u]];
-            act[u] = active ? active[ok[u] ? sr[u].x : 0u] : 1u;
+            act[u] = active[ok[u] ? sr[u].x : 0u];      // never null here (the launcher passes all-ones when no species is deselected): an unconditional load
+                                                        // travels beside the node record; under a pointer test the compiler waited for it first
         }
         // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as soon as the head is known
         uint32_t i_[U], nl[U], len0[U], v1[U], nh[U], hx[U], tcc[U];
@@ -233,12 +234,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         bool live[U], single[U], dead_read[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int sp = (int)sr[u].x;
             const uint32_t gbase = (gw + (uint32_t)u) * 64u;
             i_[u] = gbase + (uint32_t)lane - rr[u].x;                         // position in the walk (T_pad < 2^32)
-            if (__any(run[u] && !pad[u] && slot_aborts(sp))) {                // rare: a walk that leaves its species' graph (profile.rs:849)
-                if (run[u] && !pad[u] && slot_aborts(sp) && i_[u] == 0u && (!active || active[slot_species(sp)])) atomicAdd(n_abort, 1ull);
-            }
             ok[u] = ok[u] && act[u] != 0u;
             nl[u] = ok[u] ? nr[u].z : 0u;
             len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
@@ -337,8 +334,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
 // The kernel is bound by instruction issue and by the latency of its chain of dependent gathers, so
 //   * the chain is three levels: {slot, node id, step code} (stream) -> {read record (16 B), slot record (8 B)} -> {node record}
 //     (-> a unique-trio entry where the node has any).  The slot record {species, node base - first id} is written by the
-//     binning pass -- which also vouches that every id of the walk lies inside the species' graph, so a step places its node
-//     with ONE add and no range test; the node record carries the lookup head of the unique-trio index (first row, #rows)
+//     binning pass; a binned walk lies inside its species' range and db_upload makes the range span exactly the graph, so a
+//     step places its node with ONE add and no range test; the node record carries the lookup head of the unique-trio index (first row, #rows)
 //     next to bit offset and length, and a 3-window whose smaller end is the node two steps back takes the head from that
 //     lane: ONE divergent 16-byte gather per step.  Everything is in global node indices (the lookup entries too).
 //   * a step that covers its whole node (every interior step of a read: profile.rs:860-862 with :870-873) sets ONE flag for
@@ -426,10 +423,6 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         uint32_t v[U], act[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (ok[u] && slot_aborts((int32_t)sr[u].x) && ti[u] == rr[u].x) {                     // the walk leaves its species' graph (profile.rs:849)
-                const int sp = slot_species((int32_t)sr[u].x);
-                if (!active || active[sp]) atomicAdd(n_abort, 1ull);
-            }
             ok[u] = ok[u] && (int)sr[u].x >= 0;                       // "U" / dropped rows
             nr[u] = make_uint4(0u, 0u, 0u, 0u); v[u] = 0; act[u] = 1u;
             if (ok[u]) {
@@ -911,6 +904,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         if (const char *ev = std::getenv("PANTAX_COV_XCD")) xcd_map = (uint32_t)std::atoi(ev);   // 1: every XCD walks one contiguous eighth of the stream (measured slower: 1.42 vs 1.30 ms at cfg3)
         if (const char *ev = std::getenv("PANTAX_COV_ABLATE")) ablate = (uint32_t)std::atoi(ev);  // -DCOV_ABLATE builds only
         const bool trio = with_trio && db->U;
+        const uint8_t *d_act_fast = d_active;
+        if (!d_act_fast) {   // the short-read kernel loads the flag unconditionally: all ones when no species is deselected
+            if (db->d_ones.n < db->S) { PTX_HIP(ctx, db->d_ones.alloc(db->S)); PTX_HIP(ctx, hipMemsetAsync(db->d_ones.p, 1, db->S, ctx->stream)); }
+            d_act_fast = db->d_ones.p;
+        }
         KTimer t(ctx, "coverage_step_kernel");
         // walks of <= 64 steps: the short-read kernel, one wave per 64-step group, PASSES groups per wave and workgroup (the LDS
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
@@ -921,7 +919,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
             int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
             if (const char *ev = std::getenv("PANTAX_COVF_SHAPE")) fshape = std::atoi(ev);
-#define COVF_ARGS n_groups, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, db->d_node_rec.p, \
+#define COVF_ARGS n_groups, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
             {                                                                                                                            \

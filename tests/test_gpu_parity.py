@@ -142,6 +142,42 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch
     assert nab == tot_abort
 
 
+@pytest.mark.parametrize("general", ["1", None])
+def test_coverage_kernels_agree_on_short_reads(eng, general, monkeypatch):
+    """Short reads take coverage_fast_kernel (one wave per 64-step group); PANTAX_COV_GENERAL=1 sends the same groups through
+    the general kernel that otherwise only sees the groups of longer walks.  Both must equal the oracle bit for bit."""
+    from pantax_amd import synth
+    if general:
+        monkeypatch.setenv("PANTAX_COV_GENERAL", general)
+    sset = synth.make_set(11, 4, 6, 60000, 50000, adversarial_frac=0.02, single_strain_every=4)
+    from oracle import oracle as orc
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, *_ = eng.rcls_profile()
+    eng.trio_nodes_info(fetch=False)
+    bases, cov, tb, nab = eng.get_node_abundances()
+    ref = _oracle_cov_per_species(sset, sp)
+    u0 = 0
+    for si, (G, T, b, c, t, na) in enumerate(ref):
+        lo, hi = int(eng.node_off[si]), int(eng.node_off[si + 1])
+        assert np.array_equal(bases[lo:hi], b) and np.array_equal(cov[lo:hi], c)
+        assert np.array_equal(tb[u0:u0 + T.n_unique], t)
+        u0 += T.n_unique
+    assert nab == sum(r[5] for r in ref)
+
+
+def test_range_wider_than_the_graph_is_refused_at_upload(eng):
+    """optimize_otu derives nvert from the species' range (profile.rs:2938), so a range that does not span exactly the graph's
+    nodes is not a database the reference could run; db_upload refuses it -- which is what lets the coverage pass place a node id
+    of a binned read (inside the range, rcls.rs:253-257) without a bounds test."""
+    from pantax_amd.engine import PantaxHipError
+    g = _G(np.array([10, 20, 30, 40, 50], dtype=np.int64), np.array([0, 5], dtype=np.uint64), np.arange(5, dtype=np.uint32), 101)
+    g.range_end = 110
+    with pytest.raises(PantaxHipError):
+        eng.upload_db([g])
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_coverage_and_trio_index_vs_literal_python_restatement(eng, k):
     """The HIP path against fixtures from oracle/ref_literal.py -- the literal Python reading of profile.rs:658-1026 that
@@ -456,6 +492,26 @@ def test_pao_solve_wide_vs_highs_golden(eng, golden_dir):
         assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
         assert orc.lad_objective(mask, a, x) == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
         assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+
+
+def test_wide_lp_solution_vector_where_the_optimum_determines_it(eng, golden_dir):
+    """65 .. 130 candidate columns (the wide path): not only the objective but x itself -- first_sol per strain -- against
+    SciPy-HiGHS on every column the optimal face pins down (tests/golden/lp_wide_unique_cases.npz from
+    oracle/gen_golden_wide_unique.py: per column min and max over the optimal face agree to 1e-8)."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "lp_wide_unique_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub, objh, xh, det = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], float(z["obj_%d" % i]), z["x_%d" % i], z["determined_%d" % i]
+        p = len(ub)
+        assert det.sum() >= p // 2
+        po, pn = _paths_from_masks(mask, p)
+        x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), po, pn, np.arange(p))
+        assert st == 0, (i, p)
+        assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
+        assert np.allclose(x[det], xh[det], rtol=1e-6, atol=1e-7), (i, p, np.abs(x - xh)[det].max())
+        xo, objo, _, sto = orc.lad_solve(mask, a, p, ub)                      # the checker itself, on the same columns
+        assert sto == 0 and np.allclose(xo[det], xh[det], rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("n_walks", [35, 130])
