@@ -694,30 +694,69 @@ __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, c
     }
     size_s[key] = (pos + 63) & ~63u;
 }
-// In SLOT order (thread = slot): the walks land where the slots follow each other in the stream, so a wave writes one dense
-// region of the grouped arrays (its 4-byte stores combine in L2) and gathers the short source walks instead.  In read order
-// the same stores scattered single dwords over the whole stream: 72 GB written for 4 GB of payload at 1e8 reads (46 ms).
+// In SLOT order, one WAVE per 64 consecutive slots: the lanes first file their slot's records (coalesced), then hand the steps
+// of the 64 walks out flat over the wave -- lane = step of the output stream, which the slots follow in order, so node ids and
+// step codes are written as dense runs and the short source walks are gathered.  (Thread per read in file order scattered
+// single dwords and bytes over the whole stream: 72 GB written for 4 GB of payload at 1e8 reads, 46 ms; thread per slot with
+// a private loop over its steps still re-read every walk k times for the first-occurrence codes: 41 ms.)  The code of a step
+// -- distance back to the first occurrence of its node in the walk -- comes from the lanes below (and, where a walk began in
+// the round before, from that round's ids).
 __global__ void __launch_bounds__(256) group_fill_kernel(uint32_t n_slots, const uint32_t *__restrict__ read_of, const uint32_t *__restrict__ step_off,
                                                          const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend,
                                                          const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, int shift,
                                                          const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
                                                          uint2 *__restrict__ g_qm, uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
                                                          uint8_t *__restrict__ g_step_dup) {
-    for (uint32_t slot = blockIdx.x * 256 + threadIdx.x; slot < n_slots; slot += gridDim.x * 256) {
-        const uint32_t r = read_of[slot];
-        const uint32_t b = step_off[r], k = step_off[r + 1] - b;
-        const uint32_t sb = base_s[node_id[b] >> shift] + slot_rel[slot];
-        g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
-        g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
-        if (k > 64) continue;                            // laid out by group_fill_long_kernel, one workgroup per walk
-        if ((sb & 63u) == 0u) g_group_slot[sb >> 6] = slot;      // a walk of <= 64 steps lies inside one 64-step group
-        for (uint32_t i = 0; i < k; ++i) {
-            const uint32_t id = node_id[b + i];
-            g_node_id[sb + i] = id;
-            uint32_t dup = 0;
-            for (uint32_t j = 0; j < i; ++j) if (node_id[b + j] == id) { dup = i - j; break; }
-            g_step_dup[sb + i] = (uint8_t)(dup | (i == 0 ? STEP_START : 0u));
+    __shared__ uint32_t s_excl[4][65], s_b[4][64], s_sb[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_waves = (n_slots + 63) / 64;
+    for (uint32_t w = blockIdx.x * 4 + wave; w < n_waves; w += gridDim.x * 4) {
+        const uint32_t slot = w * 64 + lane;
+        uint32_t b = 0, k = 0, sb = 0;
+        if (slot < n_slots) {
+            const uint32_t r = read_of[slot];
+            b = step_off[r]; k = step_off[r + 1] - b;
+            sb = base_s[node_id[b] >> shift] + slot_rel[slot];
+            g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
+            g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
+            if (k > 64) k = 0;                                       // laid out by group_fill_long_kernel, one workgroup per walk
+            else if ((sb & 63u) == 0u) g_group_slot[sb >> 6] = slot; // a walk of <= 64 steps lies inside one 64-step group
         }
+        const uint32_t incl = wave_incl_scan_dpp(k);
+        const uint32_t total = __shfl(incl, 63);
+        s_excl[wave][lane] = incl - k; s_b[wave][lane] = b; s_sb[wave][lane] = sb;
+        if (lane == 0) s_excl[wave][64] = total;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        uint32_t prev_id = 0;
+        for (uint32_t f0 = 0; f0 < total; f0 += 64) {
+            const uint32_t f = f0 + (uint32_t)lane;
+            const bool on = f < total;
+            uint32_t o = 0;                                          // owner: the last slot whose first flat step is <= f (walks of 0 steps own none)
+            if (on) {
+                uint32_t lo = 0, hi = 63;
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_excl[wave][mid] <= f) lo = mid; else hi = mid - 1; }
+                o = lo;
+            }
+            const uint32_t i = on ? f - s_excl[wave][o] : 0u;
+            const uint32_t id = on ? node_id[s_b[wave][o] + i] : 0u;
+            // first occurrence of my node among the i earlier steps of my walk: they sit in the lanes below, or in the round before
+            uint32_t dup = 0;
+            const uint32_t imax = wave_reduce(i, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+            for (uint32_t d = 1; d <= imax; ++d) {
+                const uint32_t cur = __shfl(id, (lane - (int)d) & 63), old = __shfl(prev_id, (lane - (int)d) & 63);
+                const uint32_t other = (int)d <= lane ? cur : old;
+                if (d <= i && other == id) dup = d;                   // the largest such distance = the first occurrence
+            }
+            if (on) {
+                const uint32_t dst = s_sb[wave][o] + i;
+                g_node_id[dst] = id;
+                g_step_dup[dst] = (uint8_t)(dup | (i == 0 ? STEP_START : 0u));
+            }
+            prev_id = id;
+        }
+        __builtin_amdgcn_wave_barrier();                             // the LDS rows are reused by this wave's next 64 slots
     }
 }
 
