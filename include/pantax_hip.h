@@ -343,8 +343,9 @@ int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, c
 int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path, pantax_hip_gaf **out);
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *view_out);
 /* file -> packed reads RESIDENT in HBM, tokenised on the device, ready for pantax_hip_bin_reads; the walks never
- * visit the host.  gaf_out (optional) receives the host-side columns (read_len, mapq, flags; its view has
- * node_id / step_off / pstart / pend = NULL). */
+ * visit the host.  The text travels in pieces on an upload stream (pread into a pinned ring on a few host threads) while the
+ * piece before is tokenised.  gaf_out (optional) receives the host-side columns (read_len, mapq, flags; its view has
+ * node_id / step_off / pstart / pend = NULL); with gaf_out == NULL those columns are not brought back at all. */
 int pantax_hip_reads_load_gaf(pantax_hip_ctx *ctx, const char *path, pantax_hip_reads **reads_out, pantax_hip_gaf **gaf_out);
 /* replace the per-read drop flags of resident reads (a5: null fields, duplicate ids); NULL clears them.  The reads
  * must be binned again afterwards. */
