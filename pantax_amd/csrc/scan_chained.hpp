@@ -2,6 +2,7 @@
 // the scanned values and consumers of the prefixes fuse into the one launch (device code + its host launcher).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 #include "wave.hpp"
 
@@ -11,8 +12,8 @@ namespace ptx {
 // every tile costs one ticket (a same-address atomic, ~12-25 ns each, served one after the other) and one hop of the
 // look-back chain, so on tens of millions of items 2048-item tiles make the scan ticket-bound (0.40 ms for 3.2e7 items,
 // 0.65 TB/s) where 8192-item tiles stream
-constexpr uint64_t SCAN_BIG_N = 1u << 22;
-constexpr int SCAN_TILE_SMALL = 256 * 8, SCAN_TILE_BIG = 512 * 16;
+constexpr uint64_t SCAN_BIG_N = 1u << 22, SCAN_HUGE_N = 1u << 26;
+constexpr int SCAN_TILE_SMALL = 256 * 8, SCAN_TILE_BIG = 512 * 16, SCAN_TILE_HUGE = 1024 * 16;   // 16384-item tiles from 2^26 items on (round 3: 3.2e8-item scans at cfg4)
 
 // Single-pass chained scan (decoupled look-back): ONE launch per scan.  A workgroup takes a ticket (tiles are
 // therefore started in order, so the tiles it waits for are already running), scans its tile of SCAN_TILE items,
@@ -112,8 +113,8 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
         if (d_total) PTX_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
         return 0;
     }
-    const bool big = n >= SCAN_BIG_N;
-    const uint32_t tile_items = big ? SCAN_TILE_BIG : SCAN_TILE_SMALL;
+    const bool big = n >= SCAN_BIG_N, huge = n >= SCAN_HUGE_N && !std::getenv("PANTAX_SCAN_NO_HUGE");
+    const uint32_t tile_items = huge ? SCAN_TILE_HUGE : big ? SCAN_TILE_BIG : SCAN_TILE_SMALL;
     const uint32_t nb = (uint32_t)((n + tile_items - 1) / tile_items);
     const size_t need = 2 + 2 * (size_t)nb;   // u32 words: ticket, pad, one u64 per tile
     // one workspace per stream: launches of one stream follow each other, a scan of the side stream may run beside one of the main stream
@@ -130,7 +131,8 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
         epoch = 1;
     }
     KTimer t(ctx, timer_name);
-    if (big) hipLaunchKernelGGL((scan_chained_kernel<512, 16, Load, Store>), dim3(nb), dim3(512), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
+    if (huge) hipLaunchKernelGGL((scan_chained_kernel<1024, 16, Load, Store>), dim3(nb), dim3(1024), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
+    else if (big) hipLaunchKernelGGL((scan_chained_kernel<512, 16, Load, Store>), dim3(nb), dim3(512), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
     else hipLaunchKernelGGL((scan_chained_kernel<256, 8, Load, Store>), dim3(nb), dim3(256), 0, ctx->stream, load, store, n, ws.p, epoch, d_total);
     PTX_HIP(ctx, hipGetLastError());
     return 0;

@@ -416,10 +416,13 @@ struct TrioFirstStore {
     uint32_t *err;
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t c) const {
         first[i] = excl;
-        if (i < V) {
+        // Only nodes that head unique windows carry a lookup head (8 % of them): which nodes those are and how many rows they head
+        // is a function of the graphs alone, so every rebuild writes the same values -- a node without rows keeps the "0 rows" of its
+        // upload-time record and is not touched (round 2 read and rewrote all V records per build: 32 bytes of traffic per node).
+        if (i < V && c) {
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
-            uint4 r = node_rec[i];            // whole records in and out: neighbouring lanes fill whole cache lines, which a
-            r.y = (r.y & 0xFFu) | (c << 8);   // store of two of the four words would make the L2 read back first
+            uint4 r = node_rec[i];
+            r.y = (r.y & 0xFFu) | (c << 8);
             r.w = excl;
             node_rec[i] = r;
         }

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Times the unique-trio index build of a bench workload (HIP events on the library's stream), several rebuilds.
+usage: [PANTAX_HIP_LIB=<build>] trio_probe.py [workload] [reps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import native_set, workload_spec
+from pantax_amd.engine import Engine
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ns = native_set(workload_spec(wl))
+eng = Engine(0)
+eng.upload_db(ns.graphs())
+eng.trio_nodes_info(fetch=False); eng.sync()
+eng.timing_enable(True)
+acc = {}
+for _ in range(reps):
+    eng.db_reset(); eng.timing_reset()
+    eng.trio_nodes_info(fetch=False); eng.sync()
+    for k, (n, ms) in eng.timing_get().items():
+        acc.setdefault(k, []).append(ms)
+print(os.environ.get("PANTAX_HIP_LIB", "product"), {k: round(min(v), 4) for k, v in sorted(acc.items(), key=lambda kv: -min(kv[1]))})
+eng.close()
