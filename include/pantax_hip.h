@@ -30,7 +30,7 @@ typedef enum {
     PANTAX_HIP_E_INVALID = -1,       /* bad argument */
     PANTAX_HIP_E_HIP = -2,           /* HIP runtime error (message in last_error) */
     PANTAX_HIP_E_NO_DEVICE = -3,     /* no usable gfx950 device: the product never falls back to CPU */
-    PANTAX_HIP_E_LIMIT = -4,         /* size limit of this build (e.g. > 256 candidate paths of one species) */
+    PANTAX_HIP_E_LIMIT = -4,         /* size limit of this build (32-bit node / step / row positions; > 30000 haplotypes in one species) */
     PANTAX_HIP_E_SOLVER = -5,        /* LP did not reach optimality (reference: Err(e) => species dropped, profile.rs:2999-3003) */
     PANTAX_HIP_E_IO = -6,            /* file missing / malformed (pipeline seam) */
     PANTAX_HIP_E_STATE = -7          /* stage called before its prerequisite */
@@ -266,8 +266,10 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
  * of :3297-3319) collects the arguments of its X_opt calls as arrays of offsets and gets every species' answer back.
  * Species s owns nodes [node_off[s], node_off[s+1]), haplotypes [hap_off[s], hap_off[s+1]) and candidates
  * [cand_off[s], cand_off[s+1]); path_off indexes path_nodes over all haplotypes of the batch; cand_path_idx is the
- * haplotype's index WITHIN its species.  status[s]: 0 solved (or nothing to solve: no candidates), PANTAX_HIP_E_LIMIT (> 256
- * candidates: 1..64 take the one-word path, 65..256 the wide path), PANTAX_HIP_E_SOLVER -- per species, like the reference drops only the species whose solver failed
+ * haplotype's index WITHIN its species.  Any number of candidates, as in the reference (dense nvert x npaths matrix,
+ * profile.rs:1333-1342): 1..64 take the one-word path, 65..256 four mask words, more than 256 haplotypes a solver whose mask words,
+ * basis inverse and column state are sized at run time.  status[s]: 0 solved (or nothing to solve: no candidates),
+ * PANTAX_HIP_E_SOLVER -- per species, like the reference drops only the species whose solver failed
  * (profile.rs:2999-3003); the call itself fails only on invalid arguments or a HIP error. */
 typedef struct {
     uint32_t n_species;

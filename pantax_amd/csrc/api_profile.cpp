@@ -667,12 +667,12 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     if (local_rc == 0) {
         for (uint32_t k = 0; k < Su; ++k) {
             reported[k] = (info[k].status1 == 0 && info[k].status2 == 0) ? 1 : 0;
-            // the reference has no cap on candidate strains (dense nvert x npaths matrix, profile.rs:1333-1342); this build's LP
-            // holds 256 columns (four mask words): such a species is left out of the table like a failed solve (profile.rs:2999-3003) -- say so
+            // (a limit of the solver's tables -- none is tied to the number of candidate strains -- drops the species like a failed
+            // solve in the reference, profile.rs:2999-3003: say so)
             if (info[k].status1 == PANTAX_HIP_E_LIMIT || info[k].status2 == PANTAX_HIP_E_LIMIT)
-                std::fprintf(stderr, "[pantax_hip_profile] warning: species %s keeps %d candidate strains after the first filter, more than the %d "
-                                     "columns of this build's LP; it is left out of strain_abundance.txt\n",
-                             ranges[sel[use[k]]].species.c_str(), info[k].n_candidates, LAD_WIDEP);
+                std::fprintf(stderr, "[pantax_hip_profile] warning: species %s (%d candidate strains after the first filter) exceeds a table of this "
+                                     "build's LP solver; it is left out of strain_abundance.txt\n",
+                             ranges[sel[use[k]]].species.c_str(), info[k].n_candidates);
         }
         if (Su) local_rc = pantax_hip_abundance_filter(Su, hap_off.data(), met.data(), reported.data(), cfg->single_cov_diff, cfg->min_cov, pass.data(), &sum_all, &sum_pass, nullptr, nullptr);
     }

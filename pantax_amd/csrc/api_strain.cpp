@@ -189,7 +189,7 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
         const int p = r.sp_p[s];
         info[s].n_candidates = p < 0 ? -p : p;
         bool failed = false; int fail_code = 0;
-        if (p < 0) { failed = true; fail_code = PANTAX_HIP_E_LIMIT; }                        // > LAD_WIDEP candidate paths
+        if (p < 0) { failed = true; fail_code = PANTAX_HIP_E_LIMIT; }                        // (not produced any more: the first filter keeps any number of columns)
         std::vector<uint64_t> cand(p > 0 ? p : 0);                                          // column k -> global hap
         for (uint64_t h = h0; h < h1; ++h) if (r.hap_bit[h] >= 0 && r.hap_bit[h] < p) cand[r.hap_bit[h]] = h;
         // first-filter metrics (set for every haplotype that was looked at, candidate or not)
@@ -330,7 +330,6 @@ int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_bat
         const uint64_t c0 = in->cand_off[s], c1 = in->cand_off[s + 1], nh = in->hap_off[s + 1] - in->hap_off[s];
         out->status[s] = 0;
         if (c1 - c0 > nh) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u has %llu candidates for %llu paths", s, (unsigned long long)(c1 - c0), (unsigned long long)nh);
-        if (c1 - c0 > (uint64_t)LAD_WIDEP) { out->status[s] = PANTAX_HIP_E_LIMIT; continue; }   // this species only (the reference has no cap: INTEGRATION.md)
         for (uint64_t k = c0; k < c1; ++k) {
             if (in->cand_path_idx[k] >= nh) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve_batch: species %u candidate %llu names path %u of %llu", s, (unsigned long long)(k - c0), in->cand_path_idx[k], (unsigned long long)nh);
             lb.h_cand[in->hap_off[s] + (k - c0)] = in->cand_path_idx[k];
@@ -377,7 +376,6 @@ int pantax_hip_pao_solve(pantax_hip_ctx *ctx, uint32_t n_nodes, const int64_t *n
                          float *path_cov_ratio_out, double *obj_out, int32_t *status_out) {
     if (!ctx || !node_len || !node_abundance || !path_off || !path_nodes || !cand_path_idx || !x_out) return PANTAX_HIP_E_INVALID;
     if (n_cand == 0) return fail(ctx, PANTAX_HIP_E_INVALID, "pao_solve: no candidate paths (the reference skips the solver, profile.rs:2968)");
-    if (n_cand > (uint32_t)LAD_WIDEP) return fail(ctx, PANTAX_HIP_E_LIMIT, "pao_solve: %u candidate paths; this build handles <= %d", n_cand, LAD_WIDEP);
     PTX_ENTER(ctx);
     const uint64_t node_off[2] = {0, n_nodes}, hap_off[2] = {0, n_paths}, cand_off[2] = {0, n_cand};
     const pantax_hip_species_batch in{1, node_off, node_len, node_abundance, node_base_cov, hap_off, path_off, path_nodes, cand_off, cand_path_idx, fixed_zero};

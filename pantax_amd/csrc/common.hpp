@@ -160,8 +160,8 @@ void species_profile_host(uint32_t S, const uint32_t *head_qlen, size_t n_head, 
                           double *absolute_out, double *abundance_out);
 constexpr int PATH_TILE = 1024;   // path positions per workgroup of the per-path-step kernels
 constexpr int LAD_MAXP = 64;     // candidate paths of a species on the one-word path (one u64 membership mask per node)
-constexpr int LAD_WIDE_NW = 4;   // mask words of a "wide" species (more than 64 candidate paths)
-constexpr int LAD_WIDEP = 64 * LAD_WIDE_NW;   // most candidate paths of one species
+constexpr int LAD_WIDE_NW = 4;   // mask words of a "wide" species (65 .. 256 haplotypes); more haplotypes ("huge"): whole groups of four words
+constexpr int LAD_WIDEP = 64 * LAD_WIDE_NW;   // candidate paths up to which a species' solver state is sized at compile time
 
 // One batch = every species that has at least one candidate path, solved concurrently
 // (one workgroup per species; the LPs are block-diagonal: profile.rs:3297-3319 runs them as
@@ -184,13 +184,19 @@ struct LadBatch {
     // collected after the grouping, and a hash collision is detected there, not assumed away)
     const void *wide_for = nullptr;     // the Db the wide tables below were laid out for
     uint32_t n_wide = 0;                // species with more than LAD_MAXP haplotypes
-    uint64_t Vw = 0;                    // their nodes
-    DevBuf<uint32_t> d_wide_off;        // [S] first slot of the species in the wide arrays, 0xFFFFFFFF for the others
+    uint32_t n_huge = 0;                // ... of them with more than LAD_WIDEP: mask words, W / G and the column state sized at run time
+    uint64_t Vw = 0;                    // their four-word mask groups (nodes x words per node / 4)
+    DevBuf<uint32_t> d_wide_off;        // [S] first four-word group of the species in the wide arrays, 0xFFFFFFFF for the others
+    DevBuf<uint32_t> d_wide_nw;         // [S] mask words per node and per pattern (LAD_WIDE_NW, or more for a huge species), 0 for the others
+    DevBuf<uint64_t> d_wide_woff;       // [n_wide] first double of W (G: twice that), then [n_wide] first column of the huge column state
+    DevBuf<double> d_huge_f64;          // huge species: x, c, d, ub, fac, score, deriv, g of lad_solve_body, 64 nw entries each
+    DevBuf<int> d_huge_i32;             //               act_type, act_jk, dir, act_i0, act_i1
+    DevBuf<int> d_pat_act;              // [K] huge species: the basis slot that holds pattern k, or -1
     DevBuf<uint32_t> d_wide_list;       // [n_wide] species ids
     DevBuf<uint32_t> d_wide_slot;       // [S] index into d_wide_list (the solver's W / G scratch), 0xFFFFFFFF for the others
     DevBuf<uint64_t> d_maskw;           // [Vw * NW]
     DevBuf<uint64_t> d_pat_or, d_pat_and;   // [Vw * NW] OR / AND of the mask words of the nodes of every pattern
-    DevBuf<double> d_wide_W, d_wide_G;  // [n_wide] x (WIDEP^2, 2 WIDEP^2): basis inverse / elimination scratch of the wide solver
+    DevBuf<double> d_wide_W, d_wide_G;  // per wide species (64 nw)^2 and 2 (64 nw)^2: basis inverse / elimination scratch of the wide solvers
     // per species node stats
     DevBuf<double> d_amax;              // [S] max node abundance (profile.rs:1316-1319)
     DevBuf<uint32_t> d_nvalid;          // [S] #nodes with abundance > 0 (= n_eval, profile.rs:1380-1385, :1447)

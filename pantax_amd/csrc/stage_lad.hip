@@ -154,6 +154,15 @@ __device__ __forceinline__ double mdotw(const uint64_t *mw, const double *x) {  
     for (int w = 0; w < NW; ++w) { uint64_t m = mw[w]; while (m) { int j = __ffsll((long long)m) - 1; s += x[64 * w + j]; m &= m - 1; } }
     return s;
 }
+template <int NW>   // NW == 0: nw words, a run-time number
+__device__ __forceinline__ double mdotx(const uint64_t *mw, int nw, const double *x) {
+    if constexpr (NW != 0) return mdotw<NW>(mw, x);
+    else {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) { uint64_t m = mw[w]; while (m) { int j = __ffsll((long long)m) - 1; s += x[64 * w + j]; m &= m - 1; } }
+        return s;
+    }
+}
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -368,7 +377,7 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
                                                    const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
                                                    unsigned long long *__restrict__ mask, const int32_t *__restrict__ sp_p,
                                                    const uint32_t *__restrict__ wide_off /* null: no species can be wide */,
-                                                   unsigned long long *__restrict__ maskw) {
+                                                   const uint32_t *__restrict__ wide_nw, unsigned long long *__restrict__ maskw) {
     const uint2 tile = tiles[blockIdx.x];   // {hap, chunk}: see stage_trio.hip
     if (tile.x == 0xFFFFFFFFu) return;      // filler tile
     const uint32_t h = tile.x;
@@ -377,11 +386,12 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
     const uint32_t sp = hap_species[h];
     const uint32_t nb = node_base[sp];
     const uint64_t q0 = path_off[h] + (uint64_t)tile.y * PATH_TILE, qend = path_off[h + 1];
-    if (wide_off && sp_p[sp] > LAD_MAXP) {   // wide species: LAD_WIDE_NW words per node in the side array
+    if (wide_off && sp_p[sp] > LAD_MAXP) {   // wide species: wide_nw[sp] (LAD_WIDE_NW or more) words per node in the side array
         const unsigned long long m = 1ull << (bit & 63);
+        const size_t nw = wide_nw[sp];
         unsigned long long *base = maskw + (size_t)wide_off[sp] * LAD_WIDE_NW + (bit >> 6);
         for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
-            unsigned long long *w = base + (size_t)path_nodes[q] * LAD_WIDE_NW;
+            unsigned long long *w = base + (size_t)path_nodes[q] * nw;
             if ((*w & m) == 0) atomicOr(w, m);
         }
         return;
@@ -397,27 +407,27 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
 // (sort by mask, runs of equal masks = patterns) works on it unchanged.  Equal hashes of different word sets are caught by
 // wide_pattern_kernel / the solver (status 7), never silently merged.
 constexpr int WIDE_CHUNKS = 64;
-__device__ __forceinline__ unsigned long long wide_hash(const unsigned long long *w) {
+__device__ __forceinline__ unsigned long long wide_hash(const unsigned long long *w, int nw) {
     unsigned long long h = 0, any = 0;
-#pragma unroll
-    for (int i = 0; i < LAD_WIDE_NW; ++i) { any |= w[i]; h = splitmix64(h ^ (w[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))); }
+    for (int i = 0; i < nw; ++i) { any |= w[i]; h = splitmix64(h ^ (w[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))); }
     return any ? (h ? h : 1ull) : 0ull;
 }
 __global__ void __launch_bounds__(256) mask_fold_kernel(const uint32_t *__restrict__ wide_list, const uint32_t *__restrict__ wide_off,
-                                                        const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
+                                                        const uint32_t *__restrict__ wide_nw, const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
                                                         const unsigned long long *__restrict__ maskw, unsigned long long *__restrict__ mask) {
     const uint32_t s = wide_list[blockIdx.x / WIDE_CHUNKS], ch = blockIdx.x % WIDE_CHUNKS;
     if (sp_p[s] <= LAD_MAXP) return;
     const uint32_t b = node_base[s], n = node_base[s + 1] - b;
     const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
-    for (uint32_t v = ch * 256 + threadIdx.x; v < n; v += WIDE_CHUNKS * 256) mask[b + v] = wide_hash(mw + (size_t)v * LAD_WIDE_NW);
+    const int nw = (int)wide_nw[s];
+    for (uint32_t v = ch * 256 + threadIdx.x; v < n; v += WIDE_CHUNKS * 256) mask[b + v] = wide_hash(mw + (size_t)v * nw, nw);
 }
 
 // Wide species, after the patterns are known: every LP row's node finds its pattern (binary search of its hash among the
 // species' patterns, which are sorted by it) and ORs / ANDs its mask words into the pattern's slots.  OR == AND for every
 // pattern <=> all of its rows have the same words (the solver checks and reports status 7 otherwise).
 __global__ void __launch_bounds__(256) wide_pattern_kernel(const uint32_t *__restrict__ wide_list, const uint32_t *__restrict__ wide_off,
-                                                           const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
+                                                           const uint32_t *__restrict__ wide_nw, const uint32_t *__restrict__ node_base, const int32_t *__restrict__ sp_p,
                                                            const double *__restrict__ ab, const unsigned long long *__restrict__ mask,
                                                            const unsigned long long *__restrict__ maskw, const uint32_t *__restrict__ sp_pat_off,
                                                            const uint64_t *__restrict__ pat_mask, unsigned long long *__restrict__ pat_or,
@@ -426,18 +436,17 @@ __global__ void __launch_bounds__(256) wide_pattern_kernel(const uint32_t *__res
     if (sp_p[s] <= LAD_MAXP) return;
     const uint32_t b = node_base[s], n = node_base[s + 1] - b;
     const uint32_t k0 = sp_pat_off[s], k1 = sp_pat_off[s + 1];
-    const size_t wo = (size_t)wide_off[s] * LAD_WIDE_NW;
+    const size_t wo = (size_t)wide_off[s] * LAD_WIDE_NW, nw = wide_nw[s];
     for (uint32_t v = ch * 256 + threadIdx.x; v < n; v += WIDE_CHUNKS * 256) {
         const unsigned long long hm = mask[b + v];
         if (!(ab[b + v] > 0.0) || hm == 0ull) continue;
         uint32_t lo = k0, hi = k1;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pat_mask[mid] < hm) lo = mid + 1; else hi = mid; }
         if (lo >= k1 || pat_mask[lo] != hm) continue;   // cannot happen: every such node is a row
-#pragma unroll
-        for (int i = 0; i < LAD_WIDE_NW; ++i) {
-            const unsigned long long w = maskw[wo + (size_t)v * LAD_WIDE_NW + i];
-            atomicOr(&pat_or[wo + (size_t)(lo - k0) * LAD_WIDE_NW + i], w);
-            atomicAnd(&pat_and[wo + (size_t)(lo - k0) * LAD_WIDE_NW + i], w);
+        for (size_t i = 0; i < nw; ++i) {
+            const unsigned long long w = maskw[wo + (size_t)v * nw + i];
+            atomicOr(&pat_or[wo + (size_t)(lo - k0) * nw + i], w);
+            atomicAnd(&pat_and[wo + (size_t)(lo - k0) * nw + i], w);
         }
     }
 }
@@ -450,37 +459,44 @@ constexpr int ROW_ITEMS = 8;   // nodes per thread of the row compaction kernels
 __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
                                                     const int32_t *__restrict__ sp_p, const uint64_t *__restrict__ hap_off,
-                                                    const uint32_t *__restrict__ wide_off, const unsigned long long *__restrict__ maskw,
-                                                    unsigned long long *__restrict__ ratio) {
+                                                    const uint32_t *__restrict__ wide_off, const uint32_t *__restrict__ wide_nw,
+                                                    const unsigned long long *__restrict__ maskw, unsigned long long *__restrict__ ratio) {
     __shared__ unsigned long long acc[LAD_WIDEP * 2];
     const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
     const int p = sp_p[s];
     if (p <= 0) return;
-    for (int i = threadIdx.x; i < 2 * p; i += 256) acc[i] = 0;
-    __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + RATIO_CHUNKS - 1) / RATIO_CHUNKS;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
-    if (p > LAD_MAXP) {   // wide species: all candidates through the LDS accumulators
+    if (p > LAD_MAXP) {   // wide species: the candidates through the LDS accumulators, LAD_WIDEP (four mask words) at a time
         const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
-        for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
-            const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+        const size_t nw = wide_nw[s];
+        for (int kb = 0; kb < p; kb += LAD_WIDEP) {
+            const int pn = p - kb < LAD_WIDEP ? p - kb : LAD_WIDEP;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * pn; i += 256) acc[i] = 0;
+            __syncthreads();
+            for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+                const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
 #pragma unroll
-            for (int i = 0; i < LAD_WIDE_NW; ++i) {
-                unsigned long long m = mw[(size_t)(v - b) * LAD_WIDE_NW + i];
-                while (m) {
-                    const int k = 64 * i + __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    if (c) atomicAdd(&acc[2 * k], c);
-                    atomicAdd(&acc[2 * k + 1], l);
+                for (int i = 0; i < LAD_WIDE_NW; ++i) {
+                    unsigned long long m = mw[(size_t)(v - b) * nw + (kb >> 6) + i];
+                    while (m) {
+                        const int k = 64 * i + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        if (c) atomicAdd(&acc[2 * k], c);
+                        atomicAdd(&acc[2 * k + 1], l);
+                    }
                 }
             }
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * pn; i += 256) if (acc[i]) atomicAdd(&ratio[2 * (hap_off[s] + kb) + i], acc[i]);
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * p; i += 256) if (acc[i]) atomicAdd(&ratio[2 * hap_off[s] + i], acc[i]);
         return;
     }
+    for (int i = threadIdx.x; i < 2 * p; i += 256) acc[i] = 0;
+    __syncthreads();
     unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
@@ -689,23 +705,38 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)(H ? H : 1) * 2));
     if (!lb->prezeroed) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));
     // species that can be wide (more than 64 haplotypes): side arrays laid out once per db
+    // More than LAD_WIDEP haplotypes ("huge"): as many mask words as the haplotypes need, rounded up to whole groups of
+    // LAD_WIDE_NW -- the reference has no cap on the LP columns (dense nvert x npaths matrix, profile.rs:1333-1342), and neither
+    // has this path; what grows is the scratch (W and G: 3 x (64 nw)^2 doubles per such species) and the time of one workgroup.
     if (lb->wide_for != (const void *)db) {
-        std::vector<uint32_t> off(S ? S : 1, 0xFFFFFFFFu), slot(S ? S : 1, 0xFFFFFFFFu), list;
-        uint64_t vw = 0;
-        for (uint32_t s = 0; s < S; ++s)
-            if (db->h_hap_off[s + 1] - db->h_hap_off[s] > (uint64_t)LAD_MAXP) {
-                off[s] = (uint32_t)vw; slot[s] = (uint32_t)list.size(); list.push_back(s);
-                vw += db->h_node_off[s + 1] - db->h_node_off[s];
-            }
-        if (vw >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: %llu nodes in species of more than %d haplotypes", (unsigned long long)vw, LAD_MAXP);
-        lb->n_wide = (uint32_t)list.size(); lb->Vw = vw;
+        std::vector<uint32_t> off(S ? S : 1, 0xFFFFFFFFu), slot(S ? S : 1, 0xFFFFFFFFu), nwv(S ? S : 1, 0u), list;
+        std::vector<uint64_t> woff, coff;
+        uint64_t vw = 0, wtot = 0, ctot = 0;
+        uint32_t n_huge = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint64_t Hs = db->h_hap_off[s + 1] - db->h_hap_off[s];
+            if (Hs <= (uint64_t)LAD_MAXP) continue;
+            if (Hs > 30000ull) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: species %u has %llu haplotypes; the basis inverse is indexed with 32 bits (30000 columns)", s, (unsigned long long)Hs);
+            const uint32_t nw = (uint32_t)((Hs + LAD_WIDEP - 1) / LAD_WIDEP) * LAD_WIDE_NW;
+            off[s] = (uint32_t)vw; slot[s] = (uint32_t)list.size(); list.push_back(s); nwv[s] = nw;
+            vw += (db->h_node_off[s + 1] - db->h_node_off[s]) * (nw / LAD_WIDE_NW);
+            woff.push_back(wtot); coff.push_back(ctot);
+            wtot += 64ull * nw * 64ull * nw;
+            if (nw > (uint32_t)LAD_WIDE_NW) { ++n_huge; ctot += 64ull * nw; }
+        }
+        if (vw >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: %llu four-word mask groups in species of more than %d haplotypes", (unsigned long long)vw, LAD_MAXP);
+        lb->n_wide = (uint32_t)list.size(); lb->n_huge = n_huge; lb->Vw = vw;
         if (lb->n_wide) {
             PTX_TRY(upload(ctx, lb->d_wide_off, off.data(), S));
             PTX_TRY(upload(ctx, lb->d_wide_slot, slot.data(), S));
+            PTX_TRY(upload(ctx, lb->d_wide_nw, nwv.data(), S));
             PTX_TRY(upload(ctx, lb->d_wide_list, list.data(), list.size()));
+            woff.insert(woff.end(), coff.begin(), coff.end());     // [n_wide] W offsets, then [n_wide] column-state offsets
+            PTX_TRY(upload(ctx, lb->d_wide_woff, woff.data(), woff.size()));
             PTX_HIP(ctx, lb->d_maskw.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_or.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_and.alloc(vw * LAD_WIDE_NW));
-            PTX_HIP(ctx, lb->d_wide_W.alloc((size_t)lb->n_wide * LAD_WIDEP * LAD_WIDEP));
-            PTX_HIP(ctx, lb->d_wide_G.alloc((size_t)lb->n_wide * LAD_WIDEP * 2 * LAD_WIDEP));
+            PTX_HIP(ctx, lb->d_wide_W.alloc(wtot));
+            PTX_HIP(ctx, lb->d_wide_G.alloc(2 * wtot));
+            if (n_huge) { PTX_HIP(ctx, lb->d_huge_f64.alloc(ctot * 8)); PTX_HIP(ctx, lb->d_huge_i32.alloc(ctot * 5)); }
         }
         lb->wide_for = (const void *)db;
     }
@@ -724,7 +755,10 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     uint64_t max_vs = 0;
     for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
     bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
-    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) { if (ev[0] == 'r') use_seg = false; }   // "radix": measurements / tests
+    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) {   // measurements / tests: "radix", or "seg" = the batched sort wherever it can run
+        if (ev[0] == 'r') use_seg = false;
+        if (ev[0] == 's') use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0;
+    }
     uint32_t *d_seg_cnt = nullptr, *d_seg_off = nullptr;
     if (use_seg) {
         PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
@@ -735,17 +769,17 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         if (db->n_tiles)
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
                                db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p,
-                               lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, (unsigned long long *)lb->d_maskw.p);
+                               lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, lb->d_wide_nw.p, (unsigned long long *)lb->d_maskw.p);
     }
     {
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
-                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, (const unsigned long long *)lb->d_maskw.p,
-                           lb->d_ratio.p);
+                           (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, lb->d_wide_nw.p,
+                           (const unsigned long long *)lb->d_maskw.p, lb->d_ratio.p);
     }
     if (wide)
         hipLaunchKernelGGL(mask_fold_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
-                           db->d_node_base.p, lb->d_p.p, (const unsigned long long *)lb->d_maskw.p, (unsigned long long *)lb->d_mask.p);
+                           lb->d_wide_nw.p, db->d_node_base.p, lb->d_p.p, (const unsigned long long *)lb->d_maskw.p, (unsigned long long *)lb->d_mask.p);
     DevBuf<uint32_t> &scan_tmp = dbm->d_scan_tmp, &table = dbm->d_sort_table;
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(V, 256ull * 2048))));
     PTX_HIP(ctx, table.alloc(sort_table_elems(V)));
@@ -813,11 +847,12 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
                        lb->d_pat_start.p, lb->d_sp_pat_off.p);
     if (wide)
         hipLaunchKernelGGL(wide_pattern_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
-                           db->d_node_base.p, lb->d_p.p, lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, (const unsigned long long *)lb->d_maskw.p,
+                           lb->d_wide_nw.p, db->d_node_base.p, lb->d_p.p, lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, (const unsigned long long *)lb->d_maskw.p,
                            lb->d_sp_pat_off.p, lb->d_pat_mask.p, (unsigned long long *)lb->d_pat_or.p, (unsigned long long *)lb->d_pat_and.p);
     PTX_HIP(ctx, lb->d_pat_eps.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_s.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_rho.alloc(k_cap));
     PTX_HIP(ctx, lb->d_sc_lo.alloc(k_cap)); PTX_HIP(ctx, lb->d_sc_up.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_lo.alloc(k_cap));
     PTX_HIP(ctx, lb->d_ls_hi.alloc(k_cap)); PTX_HIP(ctx, lb->d_ls_mid.alloc(k_cap));
+    if (lb->n_huge) PTX_HIP(ctx, lb->d_pat_act.alloc(k_cap));
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -853,12 +888,10 @@ __global__ void __launch_bounds__(64) first_filter_kernel(uint32_t S, const uint
                     if (fm >= 1.0) { sh = fr + (0.8 - fr) * fm / 100.0; if (sh > 0.8) sh = 0.8; } else sh = fr * fm;
                     if (frac < sh) continue;
                 } else if (frac < fr) continue;                            // :1168
-                if (p < LAD_WIDEP) hap_bit[h] = p;
-                ++p;
+                hap_bit[h] = p++;
             }
         } else if (Hs == 1 || all_same[s]) { hap_bit[h0] = 0; p = 1; }     // :1191-1205, :1211-1224
-        else { for (uint64_t h = h0; h < h1; ++h) { if (p < LAD_WIDEP) hap_bit[h] = p; ++p; } }   // :1208
-        if (p > LAD_WIDEP) { for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = -1; p = -p; }   // this build: <= 256 columns; species fails
+        else { for (uint64_t h = h0; h < h1; ++h) hap_bit[h] = p++; }      // :1208 (any number of columns: see lad_prepare)
     }
     sp_p[s] = p;
 }
@@ -959,6 +992,14 @@ struct LadArgs {
     const uint32_t *wide_list, *wide_off, *wide_slot;
     const uint64_t *pat_or, *pat_and;
     double *wide_W, *wide_G;
+    // wide_off counts groups of LAD_WIDE_NW words; a species of more than LAD_WIDEP haplotypes ("huge") has wide_nw[s] > LAD_WIDE_NW
+    // words per node and per pattern.  W of wide slot i starts at wide_woff[i] (G at twice that), rows of 64 * wide_nw doubles;
+    // the column state of a huge species (x, c, d, ub, ... of lad_solve_body) at wide_coff[i] columns into huge_f64 (x 8) / huge_i32 (x 5);
+    // pat_act[k] = the basis slot that holds pattern k, or -1 (huge species only)
+    const uint32_t *wide_nw;
+    const uint64_t *wide_woff, *wide_coff;
+    double *huge_f64;
+    int *huge_i32, *pat_act;
 };
 
 template <int PS>
@@ -1052,14 +1093,40 @@ template <int PS, bool USEL, int NW>
 __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> &m, const int s, const int p, const uint32_t k0, const uint32_t k1) {
     static_assert(NW == 1 || !USEL, "wide species keep their pattern state in global scratch");
     constexpr uint32_t IDX_N = LadLds<PS, NW>::IDX_N, CACHE_N = LadLds<PS, NW>::CACHE_N;
+    // NW == 0 ("huge", more than LAD_WIDEP haplotypes): the number of mask words and with it the row length of W / G are
+    // run-time values, and everything that is sized by the columns lives in global scratch -- any number of columns
+    constexpr bool HUGE = NW == 0;
+    const int nw = HUGE ? (int)A.wide_nw[s] : NW;
+    const int ps = HUGE ? 64 * nw : PS;               // row length of W (G: 2 * ps)
     LadShared<PS> &sh = m.sh;
     double *W, *G;
-    const uint64_t *patw = nullptr;   // wide: mask words of pattern k at patw + (k - k0) * NW
+    const uint64_t *patw = nullptr;   // wide: mask words of pattern k at patw + (k - k0) * nw
+    double *q_x, *q_c, *q_d, *q_ub, *q_fac, *q_score, *q_deriv;
+    long long *q_g;
+    int *q_type, *q_jk, *q_dir;
+    uint32_t *q_i0, *q_i1;
     if constexpr (NW == 1) { W = m.W; G = m.G; }
     else {
-        W = A.wide_W + (size_t)A.wide_slot[s] * PS * PS; G = A.wide_G + (size_t)A.wide_slot[s] * PS * 2 * PS;
-        patw = A.pat_or + (size_t)A.wide_off[s] * NW;
+        const uint64_t wo = A.wide_woff[A.wide_slot[s]];
+        W = A.wide_W + wo; G = A.wide_G + 2 * wo;
+        patw = A.pat_or + (size_t)A.wide_off[s] * LAD_WIDE_NW;
     }
+    if constexpr (HUGE) {
+        double *f = A.huge_f64 + (size_t)A.wide_coff[A.wide_slot[s]] * 8;
+        int *i32 = A.huge_i32 + (size_t)A.wide_coff[A.wide_slot[s]] * 5;
+        q_x = f; q_c = f + ps; q_d = f + 2 * ps; q_ub = f + 3 * ps; q_fac = f + 4 * ps; q_score = f + 5 * ps; q_deriv = f + 6 * ps;
+        q_g = reinterpret_cast<long long *>(f + 7 * (size_t)ps);
+        q_type = i32; q_jk = i32 + ps; q_dir = i32 + 2 * ps;
+        q_i0 = reinterpret_cast<uint32_t *>(i32 + 3 * (size_t)ps); q_i1 = reinterpret_cast<uint32_t *>(i32 + 4 * (size_t)ps);
+    } else {
+        q_x = sh.x; q_c = sh.c; q_d = sh.d; q_ub = sh.ub; q_fac = sh.fac; q_score = sh.score; q_deriv = sh.deriv; q_g = sh.g;
+        q_type = sh.act_type; q_jk = sh.act_jk; q_dir = sh.dir; q_i0 = sh.act_i0; q_i1 = sh.act_i1;
+    }
+    // which slot of the basis holds pattern k (-1: none).  Up to LAD_WIDEP columns the slots are scanned; beyond, a map is kept.
+    auto slot_of_pattern = [&](uint32_t k) -> int {
+        if constexpr (HUGE) return A.pat_act[k];
+        else { int ai = -1; for (int i = 0; i < p; ++i) if (q_type[i] == C_PAT && (uint32_t)q_jk[i] == k) ai = i; return ai; }
+    };
     const uint64_t c0 = A.col_off[s];
     double *L_s = m.L_s, *L_rho = m.L_rho, *L_eps = m.L_eps, *L_idx = m.L_idx, *L_cache;
     if constexpr (LadLds<PS, NW>::CACHE_IN_G) L_cache = m.G; else L_cache = m.L_cache;
@@ -1099,65 +1166,65 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
     const double delta = 1e-10 * (amax > 1.0 ? amax : 1.0);
     for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK)
         P_pat_eps[kk - kofs] = delta * (0.25 + 0.5 * (double)(splitmix64(P_pat_mask[kk - kofs]) >> 11) * (1.0 / 9007199254740992.0));
-    if (tid < p) {
+    for (int j = tid; j < p; j += LAD_BLOCK) {
         // box: 0 <= x <= 1.05 * max(a) (profile.rs:1327); pinned to 0 in the second solve (:1484-1488)
-        double u = (A.fixed && A.fixed[c0 + tid]) ? 0.0 : 1.05 * A.amax[s];
-        sh.ub[tid] = u;
-        sh.act_type[tid] = u > 0.0 ? C_LB : C_FIXED;
-        sh.act_jk[tid] = tid;
-        sh.act_i0[tid] = sh.act_i1[tid] = 0;
+        double u = (A.fixed && A.fixed[c0 + j]) ? 0.0 : 1.05 * A.amax[s];
+        q_ub[j] = u;
+        q_type[j] = u > 0.0 ? C_LB : C_FIXED;
+        q_jk[j] = j;
+        q_i0[j] = q_i1[j] = 0;
     }
-    for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = (i / p == i % p) ? 1.0 : 0.0;
+    if constexpr (HUGE) for (uint32_t kk = k0 + tid; kk < k1; kk += LAD_BLOCK) A.pat_act[kk] = -1;
+    for (int64_t i = tid; i < (int64_t)p * p; i += LAD_BLOCK) W[(i / p) * ps + (i % p)] = (i / p == i % p) ? 1.0 : 0.0;
     if (tid == 0) { sh.done = 0; sh.status = 0; }
     __syncthreads();
-    if constexpr (NW > 1) {
+    if constexpr (NW != 1) {
         // rows of one pattern must agree in every mask word (they were grouped by a hash of the words)
         bool bad = false;
-        for (uint32_t kk = tid; kk < (k1 - k0) * NW; kk += LAD_BLOCK) bad |= patw[kk] != A.pat_and[(size_t)A.wide_off[s] * NW + kk];
+        for (uint32_t kk = tid; kk < (k1 - k0) * (uint32_t)nw; kk += LAD_BLOCK) bad |= patw[kk] != A.pat_and[(size_t)A.wide_off[s] * LAD_WIDE_NW + kk];
         if (bad) { sh.status = 7; sh.done = 1; }
         __syncthreads();
     }
     const int max_it = 200 * p + 2000;
     int it = 0;
-    const bool skip = NW > 1 && sh.done;   // (block-uniform: written before the barrier above)
+    const bool skip = NW != 1 && sh.done;   // (block-uniform: written before the barrier above)
 #ifdef LAD_PROFILE
     unsigned long long t_prev_ = wall_clock64();
 #endif
     for (; it < max_it && !skip; ++it) {
         // ---- vertex of the perturbed problem: x = W c
-        if (tid < p) {
-            int ty = sh.act_type[tid];
-            sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra.a[sh.act_i0[tid]] + P_pat_eps[sh.act_jk[tid] - kofs] : 0.0;
+        for (int j = tid; j < p; j += LAD_BLOCK) {
+            int ty = q_type[j];
+            q_c[j] = ty == C_UB ? q_ub[q_jk[j]] : ty == C_PAT ? ra.a[q_i0[j]] + P_pat_eps[q_jk[j] - kofs] : 0.0;
         }
         __syncthreads();
         if constexpr (NW == 1) {
             if (tid < p) {
                 double v = 0.0;
-                for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
-                sh.x[tid] = v;
-                sh.g[tid] = 0;
+                for (int i = 0; i < p; ++i) v += W[tid * ps + i] * q_c[i];
+                q_x[tid] = v;
+                q_g[tid] = 0;
             }
         } else {
             // W lives in global memory: a wave per row, lanes along the row (coalesced), instead of a thread per row
             for (int j = tid >> 6; j < p; j += LAD_BLOCK / 64) {
                 double v = 0.0;
-                for (int i = tid & 63; i < p; i += 64) v += W[j * PS + i] * sh.c[i];
+                for (int i = tid & 63; i < p; i += 64) v += W[j * ps + i] * q_c[i];
                 v = wave_reduce(v, [](double x_, double y_) { return x_ + y_; });
-                if ((tid & 63) == 0) { sh.x[j] = v; sh.g[j] = 0; }
+                if ((tid & 63) == 0) { q_x[j] = v; q_g[j] = 0; }
             }
         }
         __syncthreads();
         // ---- pattern pass: position of every pattern, integer sub-gradient g = sum sigma_k m_k
         PAT_LOOP(k) {
             uint64_t mk = P_pat_mask[k - kofs];
-            const uint64_t *mw = NW > 1 ? patw + (size_t)(k - k0) * NW : nullptr;
+            const uint64_t *mw = NW != 1 ? patw + (size_t)(k - k0) * nw : nullptr;
             uint32_t st = P_pat_start[k - kofs], en = P_pat_start[(k + 1) - kofs];
-            int ai = -1;
-            for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
+            const int ai = slot_of_pattern(k);
             uint32_t lo, up; double sk;
-            if (ai >= 0) { lo = sh.act_i0[ai]; up = sh.act_i1[ai]; sk = ra.a[lo] + P_pat_eps[k - kofs]; }
+            if (ai >= 0) { lo = q_i0[ai]; up = q_i1[ai]; sk = ra.a[lo] + P_pat_eps[k - kofs]; }
             else {
-                if constexpr (NW == 1) sk = mdot(mk, sh.x); else sk = mdotw<NW>(mw, sh.x);
+                if constexpr (NW == 1) sk = mdot(mk, q_x); else sk = mdotx<NW>(mw, nw, q_x);
                 double sv = sk - P_pat_eps[k - kofs];
                 lo = lb(COOP, ra, st, en, sv);
                 up = ub_(COOP, ra, lo, en, sv);
@@ -1167,11 +1234,11 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             if (sigma && leader) {
                 if constexpr (NW == 1) {
                     uint64_t bits = mk;
-                    while (bits) { int j = __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                    while (bits) { int j = __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&q_g[j], (unsigned long long)sigma); }
                 } else {
-                    for (int w = 0; w < NW; ++w) {
+                    for (int w = 0; w < nw; ++w) {
                         uint64_t bits = mw[w];
-                        while (bits) { int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&sh.g[j], (unsigned long long)sigma); }
+                        while (bits) { int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; atomicAdd((unsigned long long *)&q_g[j], (unsigned long long)sigma); }
                     }
                 }
             }
@@ -1179,37 +1246,37 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         __syncthreads();
         LAD_TICK(0);
         // ---- multipliers lam_i = -g . W[:,i]; steepest-edge choice of the constraint to relax
-        if (tid < p) {
+        for (int i = tid; i < p; i += LAD_BLOCK) {
             double sdot = 0.0, nrm = 0.0;
-            for (int j = 0; j < p; ++j) { double w = W[j * PS + tid]; sdot += (double)sh.g[j] * w; nrm += w * w; }
+            for (int j = 0; j < p; ++j) { double w = W[j * ps + i]; sdot += (double)q_g[j] * w; nrm += w * w; }
             double lam = -sdot; nrm = sqrt(nrm);
-            double deriv = 0.0; int dir = 0; int ty = sh.act_type[tid];
+            double deriv = 0.0; int dir = 0; int ty = q_type[i];
             if (ty == C_PAT) {
-                double w = (double)(sh.act_i1[tid] - sh.act_i0[tid]);
+                double w = (double)(q_i1[i] - q_i0[i]);
                 if (lam > w + tol) { dir = +1; deriv = w - lam; } else if (lam < -w - tol) { dir = -1; deriv = w + lam; }
             } else if (ty == C_LB) { if (lam > tol) { dir = +1; deriv = -lam; } }
             else if (ty == C_UB) { if (lam < -tol) { dir = -1; deriv = lam; } }
-            sh.dir[tid] = dir; sh.deriv[tid] = deriv; sh.score[tid] = dir ? deriv / nrm : 0.0;
+            q_dir[i] = dir; q_deriv[i] = deriv; q_score[i] = dir ? deriv / nrm : 0.0;
         }
         __syncthreads();
         if (tid == 0) {
             int best = -1; double bs = -tol;
-            for (int i = 0; i < p; ++i) if (sh.dir[i] && sh.score[i] < bs) { bs = sh.score[i]; best = i; }
+            for (int i = 0; i < p; ++i) if (q_dir[i] && q_score[i] < bs) { bs = q_score[i]; best = i; }
             sh.best = best;
-            if (best < 0) sh.done = 1; else { sh.bdir = sh.dir[best]; sh.bderiv = sh.deriv[best]; }
+            if (best < 0) sh.done = 1; else { sh.bdir = q_dir[best]; sh.bderiv = q_deriv[best]; }
         }
         __syncthreads();
         if (sh.done) break;
         const int best = sh.best; const double bdir = (double)sh.bdir;
-        if (tid < p) sh.d[tid] = bdir * W[tid * PS + best];
+        for (int j = tid; j < p; j += LAD_BLOCK) q_d[j] = bdir * W[j * ps + best];
         __syncthreads();
         if (tid == 0) {   // ratio test against the box
             double tmax = INFINITY; int bj = -1, bt = C_LB;
             for (int j = 0; j < p; ++j) {
-                if (sh.ub[j] <= 0.0) continue;
-                double dj = sh.d[j];
-                if (dj < -1e-12) { double t = sh.x[j] / (-dj); if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_LB; } }
-                else if (dj > 1e-12) { double t = (sh.ub[j] - sh.x[j]) / dj; if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_UB; } }
+                if (q_ub[j] <= 0.0) continue;
+                double dj = q_d[j];
+                if (dj < -1e-12) { double t = q_x[j] / (-dj); if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_LB; } }
+                else if (dj > 1e-12) { double t = (q_ub[j] - q_x[j]) / dj; if (t < 0) t = 0; if (t < tmax) { tmax = t; bj = j; bt = C_UB; } }
             }
             sh.tmax = tmax; sh.bj = bj; sh.btype = bt;
         }
@@ -1218,11 +1285,10 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         double part = 0.0;
         PAT_LOOP(k) {
             uint64_t mk = P_pat_mask[k - kofs];
-            int ai = -1;
-            for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i;
+            const int ai = slot_of_pattern(k);
             double rho;
             if (ai >= 0) rho = (ai == best) ? bdir : 0.0;   // other tight patterns stay tight: n_i . d = 0
-            else { if constexpr (NW == 1) rho = mdot(mk, sh.d); else rho = mdotw<NW>(patw + (size_t)(k - k0) * NW, sh.d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(P_sc_up[k - kofs] - P_sc_lo[k - kofs]); }
+            else { if constexpr (NW == 1) rho = mdot(mk, q_d); else rho = mdotx<NW>(patw + (size_t)(k - k0) * nw, nw, q_d); if (fabs(rho) < 1e-12) rho = 0.0; if (leader) part += fabs(rho) * (double)(P_sc_up[k - kofs] - P_sc_lo[k - kofs]); }
             P_sc_rho[k - kofs] = rho;
             P_ls_lo[k - kofs] = 0;
             P_ls_hi[k - kofs] = rho > 0 ? P_pat_start[(k + 1) - kofs] - P_sc_up[k - kofs] : rho < 0 ? P_sc_lo[k - kofs] - P_pat_start[k - kofs] : 0;
@@ -1236,7 +1302,7 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             // degenerate: an unsplit tie group blocks the move at t = 0 -> it enters (step length 0)
             double tb = INFINITY; int kb = 0x7fffffff;
             PAT_LOOP(k)
-                if (P_sc_rho[k - kofs] != 0.0 && P_sc_up[k - kofs] > P_sc_lo[k - kofs]) { int ai = -1; for (int i = 0; i < p; ++i) if (sh.act_type[i] == C_PAT && (uint32_t)sh.act_jk[i] == k) ai = i; if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
+                if (P_sc_rho[k - kofs] != 0.0 && P_sc_up[k - kofs] > P_sc_lo[k - kofs]) { const int ai = slot_of_pattern(k); if (ai < 0 && (int)k < kb) { kb = (int)k; tb = 0.0; } }
             kb = wave_reduce(kb, [](int x, int y) { return x < y ? x : y; });
             if ((tid & 63) == 0) sh.red_k[tid >> 6] = kb;
             __syncthreads();
@@ -1593,45 +1659,72 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         if (sh.ent_type < 0) { if (tid == 0) { sh.status = 6; sh.done = 1; } __syncthreads(); break; }
         // ---- pivot: constraint `best` leaves, the entering one takes its slot; W = N^-1 by Gauss-Jordan
         if (tid == 0) {
-            sh.act_type[best] = sh.ent_type;
-            sh.act_jk[best] = (int)sh.ent_k;
-            sh.act_i0[best] = sh.ent_i0; sh.act_i1[best] = sh.ent_i1;
+            if constexpr (HUGE) {
+                if (q_type[best] == C_PAT) A.pat_act[q_jk[best]] = -1;
+                if (sh.ent_type == C_PAT) A.pat_act[sh.ent_k] = best;
+            }
+            q_type[best] = sh.ent_type;
+            q_jk[best] = (int)sh.ent_k;
+            q_i0[best] = sh.ent_i0; q_i1[best] = sh.ent_i1;
         }
         __syncthreads();
         // One row of N changed: W = N^-1 follows by a rank-one (Sherman-Morrison) update, O(p^2) instead of the O(p^3)
         // elimination with its 4 barriers per column -- 110 of 200 us per pivot at p = 36.  With y = n_new^T W and
         // z = y - e_best:  W' = W - (W e_best) z^T / y[best].  The inverse is rebuilt from scratch every 16th pivot and
         // whenever y[best] is small, so rounding cannot accumulate; up to 8 columns the elimination is cheap and stays.
-        bool refactor = p <= 8 || (it & 15) == 15;
+        // W in global memory (more than 64 columns): the O(p^3) rebuild by one workgroup costs 40 ms at 256 columns, 5 s at 1100 -- a
+        // hundred pivots' worth.  There the inverse is VERIFIED every 64th pivot instead (one probe vector: |N (W v) - v|, O(p^2) like
+        // a pivot) and rebuilt only if the probe fails, every 1024th pivot, or -- as everywhere -- when the update's divisor is small.
+        const int rebuild_mask = NW == 1 ? 15 : 1023;
+        bool refactor = p <= 8 || (it & rebuild_mask) == rebuild_mask;
         if (!refactor) {
-            if (tid < p) {
+            for (int c_ = tid; c_ < p; c_ += LAD_BLOCK) {
                 double y;
-                if (sh.act_type[best] == C_PAT) {
+                if (q_type[best] == C_PAT) {
                     y = 0.0;
                     if constexpr (NW == 1) {
-                        uint64_t bits = P_pat_mask[sh.act_jk[best] - kofs];
-                        while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
+                        uint64_t bits = P_pat_mask[q_jk[best] - kofs];
+                        while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * ps + c_]; }
                     } else {
-                        const uint64_t *mb = patw + (size_t)((uint32_t)sh.act_jk[best] - k0) * NW;
-                        for (int w = 0; w < NW; ++w) {
+                        const uint64_t *mb = patw + (size_t)((uint32_t)q_jk[best] - k0) * nw;
+                        for (int w = 0; w < nw; ++w) {
                             uint64_t bits = mb[w];
-                            while (bits) { const int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * PS + tid]; }
+                            while (bits) { const int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * ps + c_]; }
                         }
                     }
-                } else y = W[sh.act_jk[best] * PS + tid];
-                sh.fac[tid] = y;
-                sh.score[tid] = W[tid * PS + best];
+                } else y = W[q_jk[best] * ps + c_];
+                q_fac[c_] = y;
+                q_score[c_] = W[c_ * ps + best];
             }
             __syncthreads();
-            const double alpha = sh.fac[best];
+            const double alpha = q_fac[best];
             if (fabs(alpha) < 1e-7) refactor = true;   // (block-uniform: read from LDS after the barrier)
             else {
                 const double ainv = 1.0 / alpha;
                 for (int i = tid; i < p * p; i += LAD_BLOCK) {
                     const int j = i / p, cc = i % p;
-                    W[j * PS + cc] -= sh.score[j] * (sh.fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
+                    W[j * ps + cc] -= q_score[j] * (q_fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
                 }
                 __syncthreads();
+            }
+        }
+        if constexpr (NW != 1) {
+            if (!refactor && (it & 63) == 63) {   // (block-uniform)
+                auto probe_v = [](int i) { return 1.0 + 0.25 * (double)(i % 7); };
+                for (int j = tid >> 6; j < p; j += LAD_BLOCK / 64) {          // u = W v: a wave per row
+                    double a_ = 0.0;
+                    for (int i = tid & 63; i < p; i += 64) a_ += W[j * ps + i] * probe_v(i);
+                    a_ = wave_reduce(a_, [](double x_, double y_) { return x_ + y_; });
+                    if ((tid & 63) == 0) q_fac[j] = a_;
+                }
+                __syncthreads();
+                double worst = 0.0;
+                for (int i = tid; i < p; i += LAD_BLOCK) {                    // row i of N: a pattern's membership or a unit vector
+                    const double r_ = q_type[i] == C_PAT ? mdotx<NW>(patw + (size_t)((uint32_t)q_jk[i] - k0) * nw, nw, q_fac) : q_fac[q_jk[i]];
+                    worst = fmax(worst, fabs(r_ - probe_v(i)));
+                }
+                worst = block_max_f64<LAD_BLOCK>(worst, sh.red);
+                if (!(worst <= 1e-10)) refactor = true;
             }
         }
         if (refactor) {
@@ -1639,21 +1732,25 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             int r = i / (2 * p), cc = i % (2 * p);
             double v;
             if (cc >= p) v = (cc - p == r) ? 1.0 : 0.0;
-            else if (sh.act_type[r] == C_PAT) {
-                if constexpr (NW == 1) v = (P_pat_mask[sh.act_jk[r] - kofs] >> cc) & 1ull ? 1.0 : 0.0;
-                else v = (patw[(size_t)((uint32_t)sh.act_jk[r] - k0) * NW + (cc >> 6)] >> (cc & 63)) & 1ull ? 1.0 : 0.0;
+            else if (q_type[r] == C_PAT) {
+                if constexpr (NW == 1) v = (P_pat_mask[q_jk[r] - kofs] >> cc) & 1ull ? 1.0 : 0.0;
+                else v = (patw[(size_t)((uint32_t)q_jk[r] - k0) * nw + (cc >> 6)] >> (cc & 63)) & 1ull ? 1.0 : 0.0;
             }
-            else v = (sh.act_jk[r] == cc) ? 1.0 : 0.0;
-            G[r * 2 * PS + cc] = v;
+            else v = (q_jk[r] == cc) ? 1.0 : 0.0;
+            G[r * 2 * ps + cc] = v;
         }
         __syncthreads();
-        static_assert(PS <= LAD_BLOCK, "one matrix row per thread in the pivot search");
+        static_assert(HUGE || PS <= LAD_BLOCK, "one matrix row per thread in the pivot search");
         for (int col = 0; col < p; ++col) {
             // partial pivoting, all rows at once: thread r loads G[r][col] (its elimination factor as well), rows >= col compete
             // for the largest magnitude (ties: the smallest row, as a serial scan would choose); three barriers per column
-            double v = 0.0, cand_v = 0.0;
+            double cand_v = 0.0;
             int cand_r = 0x7fffffff;
-            if (tid < p) { v = G[tid * 2 * PS + col]; sh.fac[tid] = v; if (tid >= col) { cand_v = v; cand_r = tid; } }
+            for (int r = tid; r < p; r += LAD_BLOCK) {   // (one trip up to LAD_WIDEP columns)
+                const double v = G[r * 2 * ps + col];
+                q_fac[r] = v;
+                if (r >= col && (cand_r == 0x7fffffff || fabs(v) > fabs(cand_v))) { cand_v = v; cand_r = r; }   // ascending r: ties keep the smaller row
+            }
             wave_reduce_pair(cand_v, cand_r, [](double v2, int r2, double v1, int r1) { return r2 != 0x7fffffff && (r1 == 0x7fffffff || fabs(v2) > fabs(v1) || (fabs(v2) == fabs(v1) && r2 < r1)); });
             if ((tid & 63) == 0) { sh.red_t[tid >> 6] = cand_v; sh.red_k[tid >> 6] = cand_r; }
             __syncthreads();
@@ -1667,37 +1764,37 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             const double dinv = 1.0 / pv;
             // row `piv` scaled becomes row `col`; the old row `col` moves to `piv`
             for (int c2 = tid; c2 < 2 * p; c2 += LAD_BLOCK) {
-                const double a_ = G[col * 2 * PS + c2], b_ = G[piv * 2 * PS + c2];
-                G[col * 2 * PS + c2] = b_ * dinv;
-                if (piv != col) G[piv * 2 * PS + c2] = a_;
+                const double a_ = G[col * 2 * ps + c2], b_ = G[piv * 2 * ps + c2];
+                G[col * 2 * ps + c2] = b_ * dinv;
+                if (piv != col) G[piv * 2 * ps + c2] = a_;
             }
-            const double f_colrow = sh.fac[col];   // the factor of the row that now sits at `piv`
+            const double f_colrow = q_fac[col];   // the factor of the row that now sits at `piv`
             __syncthreads();
             for (int i = tid; i < p * 2 * p; i += LAD_BLOCK) {
                 const int r = i / (2 * p), cc = i % (2 * p);
-                if (r != col) G[r * 2 * PS + cc] -= (r == piv ? f_colrow : sh.fac[r]) * G[col * 2 * PS + cc];
+                if (r != col) G[r * 2 * ps + cc] -= (r == piv ? f_colrow : q_fac[r]) * G[col * 2 * ps + cc];
             }
             __syncthreads();
         }
         if (sh.done) break;
-        for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * PS + (i % p)] = G[(i / p) * 2 * PS + p + (i % p)];
+        for (int i = tid; i < p * p; i += LAD_BLOCK) W[(i / p) * ps + (i % p)] = G[(i / p) * 2 * ps + p + (i % p)];
         __syncthreads();
         }   // refactor
         LAD_TICK(7);
     }
     // ---- final vertex with the UNPERTURBED right-hand sides, clipped to the box
     __syncthreads();
-    if (tid < p) {
-        int ty = sh.act_type[tid];
-        sh.c[tid] = ty == C_UB ? sh.ub[sh.act_jk[tid]] : ty == C_PAT ? ra.a[sh.act_i0[tid]] : 0.0;
+    for (int j = tid; j < p; j += LAD_BLOCK) {
+        int ty = q_type[j];
+        q_c[j] = ty == C_UB ? q_ub[q_jk[j]] : ty == C_PAT ? ra.a[q_i0[j]] : 0.0;
     }
     __syncthreads();
-    if (tid < p) {
+    for (int j = tid; j < p; j += LAD_BLOCK) {
         double v = 0.0;
-        for (int i = 0; i < p; ++i) v += W[tid * PS + i] * sh.c[i];
+        for (int i = 0; i < p; ++i) v += W[j * ps + i] * q_c[i];
         if (v < 0.0) v = 0.0;
-        if (v > sh.ub[tid]) v = sh.ub[tid];
-        A.x_out[c0 + tid] = v;
+        if (v > q_ub[j]) v = q_ub[j];
+        A.x_out[c0 + j] = v;
     }
     if (tid == 0) {
         A.status[s] = (it >= max_it) ? 1 : sh.status;
@@ -1705,14 +1802,21 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
     }
 }
 
-// NW == 1: one workgroup per species of the db, species with more than LAD_MAXP columns are left to the wide launch;
-// NW > 1: one workgroup per entry of wide_list, species with at most LAD_MAXP columns were done by the other launch.
+// NW == 1: one workgroup per species of the db, species with more than LAD_MAXP columns are left to the wide launches;
+// NW == LAD_WIDE_NW / 0: one workgroup per entry of wide_list; the instance takes the species with more than LAD_MAXP columns
+// whose mask has LAD_WIDE_NW words / more words ("huge": more than LAD_WIDEP haplotypes).
+template <int NW>
+__device__ __forceinline__ bool lad_instance_takes(const LadArgs &A, int s, int p) {
+    if (NW == 1) return p <= LAD_MAXP;
+    if (p <= LAD_MAXP) return false;
+    return (NW == 0) == (A.wide_nw[s] > (uint32_t)LAD_WIDE_NW);
+}
 template <int PS, int NW>
 __global__ void __launch_bounds__(LAD_BLOCK) lad_solve_kernel(LadArgs A) {
     __shared__ LadLds<PS, NW> m;
     const int s = NW == 1 ? (int)blockIdx.x : (int)A.wide_list[blockIdx.x];
     const int p = A.sp_p[s];
-    if ((NW == 1) != (p <= LAD_MAXP)) return;
+    if (!lad_instance_takes<NW>(A, s, p)) return;
     if (A.need && !A.need[s]) return;
     if (p <= 0) { if (threadIdx.x == 0) { A.status[s] = 0; A.iters[s] = 0; } return; }
     const uint32_t k0 = A.sp_pat_off[s], k1 = A.sp_pat_off[s + 1];
@@ -1730,7 +1834,7 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_pair_kernel(LadArgs A1, LadArgs
     __shared__ LadLds<PS, NW> m;
     const int s = NW == 1 ? (int)blockIdx.x : (int)A1.wide_list[blockIdx.x];
     const int p = A1.sp_p[s];
-    if ((NW == 1) != (p <= LAD_MAXP)) return;
+    if (!lad_instance_takes<NW>(A1, s, p)) return;
     const uint32_t k0 = A1.sp_pat_off[s], k1 = A1.sp_pat_off[s + 1];
     const bool lds_state = NW == 1 && k1 - k0 <= (uint32_t)LAD_KLDS;
     if (p > 0) {
@@ -1755,8 +1859,8 @@ __global__ void __launch_bounds__(LAD_BLOCK) lad_pair_kernel(LadArgs A1, LadArgs
 __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need2,
                                                         const uint32_t *__restrict__ node_base, const double *__restrict__ ab,
                                                         const unsigned long long *__restrict__ mask, const uint64_t *__restrict__ col_off,
-                                                        const uint32_t *__restrict__ wide_off, const unsigned long long *__restrict__ maskw,
-                                                        const double *__restrict__ x1,
+                                                        const uint32_t *__restrict__ wide_off, const uint32_t *__restrict__ wide_nw,
+                                                        const unsigned long long *__restrict__ maskw, const double *__restrict__ x1,
                                                         const double *__restrict__ x2, double *part /*[S][STAT_CHUNKS][2]*/,
                                                         uint32_t *__restrict__ done /*[S], zero between launches*/,
                                                         const uint32_t *__restrict__ nvalid, double *__restrict__ obj1, double *__restrict__ obj2, uint32_t nch) {
@@ -1769,14 +1873,26 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
     const bool two = x2 && need2 && need2[s];
     const uint32_t ch = blockIdx.x % nch;
     static_assert(LAD_WIDEP <= 256, "one column per thread");
-    if ((int)threadIdx.x < p) { xs1[threadIdx.x] = x1[col_off[s] + threadIdx.x]; xs2[threadIdx.x] = two ? x2[col_off[s] + threadIdx.x] : 0.0; }
+    if ((int)threadIdx.x < p && p <= LAD_WIDEP) { xs1[threadIdx.x] = x1[col_off[s] + threadIdx.x]; xs2[threadIdx.x] = two ? x2[col_off[s] + threadIdx.x] : 0.0; }
     __syncthreads();
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
     if (hi > e) hi = e;
     double acc1 = 0.0, acc2 = 0.0;
-    if (p > LAD_MAXP) {   // wide species: the mask words of the node
+    if (p > LAD_MAXP && wide_nw[s] > (uint32_t)LAD_WIDE_NW) {   // huge species: any number of mask words, x read where the solver left it
+        const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
+        const int nw = (int)wide_nw[s];
+        const double *X1 = x1 + col_off[s], *X2 = two ? x2 + col_off[s] : nullptr;
+        for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
+            const double a = ab[v];
+            if (a > 0.0) {
+                const uint64_t *mn = (const uint64_t *)(mw + (size_t)(v - b) * nw);
+                acc1 += fabs(mdotx<0>(mn, nw, X1) - a);
+                if (two) acc2 += fabs(mdotx<0>(mn, nw, X2) - a);
+            }
+        }
+    } else if (p > LAD_MAXP) {   // wide species: the mask words of the node
         const unsigned long long *mw = maskw + (size_t)wide_off[s] * LAD_WIDE_NW;
         for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
             const double a = ab[v];
@@ -1828,7 +1944,7 @@ static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t 
     }
     const uint32_t nch = stat_chunks(S);
     hipLaunchKernelGGL(objective_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, db->d_node_base.p, lb->d_ab.p,
-                       (unsigned long long *)lb->d_mask.p, db->d_hap_off.p, lb->d_wide_off.p, (const unsigned long long *)lb->d_maskw.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2, nch);
+                       (unsigned long long *)lb->d_mask.p, db->d_hap_off.p, lb->d_wide_off.p, lb->d_wide_nw.p, (const unsigned long long *)lb->d_maskw.p, d_x1, d_x2, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p, d_obj1, d_obj2, nch);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1843,6 +1959,8 @@ static LadArgs lad_args(const Db *db, LadBatch *lb, const uint8_t *d_need, const
     A.col_off = db->d_hap_off.p;
     A.wide_list = lb->d_wide_list.p; A.wide_off = lb->d_wide_off.p; A.wide_slot = lb->d_wide_slot.p;
     A.pat_or = lb->d_pat_or.p; A.pat_and = lb->d_pat_and.p; A.wide_W = lb->d_wide_W.p; A.wide_G = lb->d_wide_G.p;
+    A.wide_nw = lb->d_wide_nw.p; A.wide_woff = lb->d_wide_woff.p; A.wide_coff = lb->d_wide_woff.p + lb->n_wide;
+    A.huge_f64 = lb->d_huge_f64.p; A.huge_i32 = lb->d_huge_i32.p; A.pat_act = lb->d_pat_act.p;
     return A;
 }
 
@@ -1889,7 +2007,8 @@ int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const 
         KTimer t(ctx, "lad_solve_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
         else hipLaunchKernelGGL((lad_pair_kernel<LAD_MAXP, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
-        if (lb->n_wide) hipLaunchKernelGGL((lad_pair_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        if (lb->n_wide > lb->n_huge) hipLaunchKernelGGL((lad_pair_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
+        if (lb->n_huge) hipLaunchKernelGGL((lad_pair_kernel<1, 0>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
     }
     PTX_HIP(ctx, hipGetLastError());
 #ifdef LAD_PROFILE
@@ -1910,7 +2029,8 @@ int lad_solve_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const
         KTimer t(ctx, "lad_solve_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_solve_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
         else hipLaunchKernelGGL((lad_solve_kernel<LAD_MAXP, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A);
-        if (lb->n_wide) hipLaunchKernelGGL((lad_solve_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        if (lb->n_wide > lb->n_huge) hipLaunchKernelGGL((lad_solve_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A);
+        if (lb->n_huge) hipLaunchKernelGGL((lad_solve_kernel<1, 0>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A);
     }
     PTX_HIP(ctx, hipGetLastError());
 #ifdef LAD_PROFILE

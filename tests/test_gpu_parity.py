@@ -396,9 +396,9 @@ def test_pao_solve_vs_reference_milp_model(eng, golden_dir):
 
 def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     """pantax_hip_pao_solve_batch (arrays of offsets in, solutions out, host buffers): all 11 golden LPs as ONE
-    batch == the same LPs solved one call at a time, objectives == SciPy-HiGHS; a species without candidates and one with
-    257 candidates (beyond the four mask words of a wide species) sit in the same batch and only they are affected; a species
-    with 65 candidates in that batch is solved by the wide kernel."""
+    batch == the same LPs solved one call at a time, objectives == SciPy-HiGHS; a species without candidates, one with 65
+    candidates (the wide kernel, four mask words) and one with 257 (more than four words: the kernel without a cap on the columns)
+    sit in the same batch."""
     import os
     z = np.load(os.path.join(golden_dir, "lp_cases.npz"))
     species, fixed, objs = [], [], []
@@ -433,13 +433,16 @@ def test_pao_solve_batch_equals_per_species_calls(eng, golden_dir):
     # 65 columns: every node on exactly one of 64 paths with a = 1, path 64 visits node 0 as well -> objective 0 at x = 1
     x65, r65, o65, st65, it65 = batch[-2]
     assert st65 == 0 and o65 == pytest.approx(0.0, abs=1e-12) and np.allclose(x65[:64] + np.where(np.arange(64) == 0, x65[64], 0.0), 1.0)
-    assert batch[-1][3] == -4                                               # PANTAX_HIP_E_LIMIT for that species only
+    # 257 columns: path k visits node k % 200 only, a = 1 -> the paths of every node sum to 1, objective 0
+    x257, r257, o257, st257, it257 = batch[-1]
+    assert st257 == 0 and o257 == pytest.approx(0.0, abs=1e-12)
+    assert np.allclose(np.bincount(np.arange(257) % n65, weights=x257, minlength=n65), 1.0)
 
 
 def test_pao_solve_at_and_beyond_64_candidates(eng):
     """64 candidate paths is what one membership word holds: solved (objective == the oracle's exact LAD, which SciPy-HiGHS
     pins on the golden cases); 65 goes through the wide path (four words) and gives the same optimum with an unused extra
-    column; 257 is refused loudly, never approximated."""
+    column; 257 and 600 columns (more than four words) go through the kernel that sizes its state at run time."""
     from oracle import oracle as orc
     from pantax_amd.engine import PantaxHipError
     rng = np.random.default_rng(64)
@@ -468,10 +471,20 @@ def test_pao_solve_at_and_beyond_64_candidates(eng):
     xo65, objo65, it65, sto65 = orc.lad_solve(mask65, a, 65, np.full(65, 1.05 * a.max()))
     assert st65 == 0 and sto65 == 0 and obj65 == pytest.approx(objo65, rel=1e-9) and obj65 <= obj * (1 + 1e-12)
     assert orc.lad_objective(mask65, a, x65) == pytest.approx(objo65, rel=1e-9)
-    po257 = np.arange(258, dtype=np.uint64); pn257 = (np.arange(257) % n).astype(np.uint32)
-    with pytest.raises(PantaxHipError) as e:
-        eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), po257, pn257, np.arange(257))
-    assert "257 candidate paths" in str(e.value)
+    # more than 256 columns: the same LP plus columns that each touch a few more nodes
+    for pw in (257, 600):
+        extra = [np.sort(rng.choice(n, size=int(rng.integers(1, 40)), replace=False)).astype(np.uint32) for _ in range(pw - p)]
+        pow_ = np.concatenate([po, po[-1] + np.cumsum([len(e_) for e_ in extra])]).astype(np.uint64)
+        pnw = np.concatenate([pn] + extra).astype(np.uint32)
+        nw = (pw + 63) // 64
+        maskw = np.zeros((n, nw), dtype=np.uint64); maskw[:, 0] = mask
+        for k, e_ in enumerate(extra):
+            maskw[e_, (p + k) >> 6] |= np.uint64(1) << np.uint64((p + k) & 63)
+        xw, ratiow, objw, stw = eng.pao_solve(np.ones(n, dtype=np.int64), a, np.zeros(n), pow_, pnw, np.arange(pw))
+        xow, objow, itw, stow = orc.lad_solve(maskw, a, pw, np.full(pw, 1.05 * a.max()))
+        assert stw == 0 and stow == 0 and objw == pytest.approx(objow, rel=1e-9) and objw <= obj * (1 + 1e-12)
+        assert orc.lad_objective(maskw, a, xw) == pytest.approx(objow, rel=1e-9)
+        assert np.all(xw >= -1e-12) and np.all(xw <= 1.05 * a.max() + 1e-9)
 
 
 def test_pao_solve_wide_vs_highs_golden(eng, golden_dir):
@@ -482,6 +495,25 @@ def test_pao_solve_wide_vs_highs_golden(eng, golden_dir):
     import os
     from oracle import oracle as orc
     z = np.load(os.path.join(golden_dir, "lp_wide_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub, objh = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], float(z["obj_%d" % i])
+        p = len(ub)
+        po, pn = _paths_from_masks(mask, p)
+        x, ratio, obj, st = eng.pao_solve(np.ones(len(a), dtype=np.int64), a, np.zeros(len(a), dtype=np.uint64), po, pn, np.arange(p),
+                                          fixed_zero=(ub == 0).astype(np.uint8))
+        assert st == 0, (i, p)
+        assert obj == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
+        assert orc.lad_objective(mask, a, x) == pytest.approx(objh, rel=1e-9, abs=1e-12), (i, p)
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+
+
+def test_pao_solve_huge_vs_highs_golden(eng, golden_dir):
+    """More than 256 candidate columns (257 .. 1100; the reference's dense matrix has no cap, profile.rs:1333-1342): mask words,
+    basis inverse and column state of the solver sized at run time, on committed SciPy-HiGHS vectors -- objective equal to 1e-9
+    relative, bounds and pinned columns respected."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(golden_dir, "lp_huge_cases.npz"))
     for i in range(int(z["n_cases"])):
         mask, a, ub, objh = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i], float(z["obj_%d" % i])
         p = len(ub)
@@ -514,13 +546,13 @@ def test_wide_lp_solution_vector_where_the_optimum_determines_it(eng, golden_dir
         assert sto == 0 and np.allclose(xo[det], xh[det], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("n_walks", [35, 130])
+@pytest.mark.parametrize("n_walks", [35, 130, 350])
 def test_species_with_more_than_64_candidates(eng, n_walks):
     """A species whose first filter leaves more than 64 columns (no unique trio: every walk exists twice, so every haplotype
-    is a candidate, profile.rs:1208).  70 columns: solved on the wide path, objective == the oracle's (the LP is degenerate by
-    construction -- twin columns -- so x is compared through the objective and the twin sums).  260 columns: beyond the four
-    mask words, reported with PANTAX_HIP_E_LIMIT and dropped like a failed solve in the reference (profile.rs:2999-3003).
-    The species next to it is unaffected either way."""
+    is a candidate, profile.rs:1208).  70 columns: solved on the wide path (four mask words), objective == the oracle's (the LP is
+    degenerate by construction -- twin columns -- so x is compared through the objective and the twin sums).  260 and 700 columns:
+    more than 256 haplotypes, the path without a cap (the reference has none, profile.rs:1333-1342): mask words, basis inverse and
+    column state sized at run time, same checks.  The species next to it is unaffected either way."""
     from oracle import oracle as orc
     from pantax_amd import synth
     from pantax_amd.engine import metrics_to_dicts
@@ -554,10 +586,7 @@ def test_species_with_more_than_64_candidates(eng, n_walks):
     ref = _oracle_cov_per_species(sset, sp)
     G, T, b, c, t, na = ref[0]
     assert info[0].n_candidates == nh
-    if nh > 256:
-        assert info[0].status1 == -4           # PANTAX_HIP_E_LIMIT
-        assert all(all(v is None or v is False for v in d.values()) for d in got[:nh])
-    else:
+    if True:
         rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
         assert rc_ == 0 and nc == nh and info[0].status1 == 0 and info[0].status2 == 0
         assert info[0].obj1 == pytest.approx(o1, rel=1e-9)          # no second solve in this branch (profile.rs:1279-1283)
@@ -699,6 +728,38 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
                 else:
                     assert gv == pytest.approx(ev, rel=1e-7, abs=1e-9), (si, h, key, gv, ev)
     assert n_cols > 0 and (n_face == 0 or H >= 20)      # the small cases of this test have unique optima
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,S,H,R,L,pf,opts", [
+    (22, 4, 10, 80000, 30000, 0.4, {}),                        # a handful of patterns per species
+    (26, 2, 40, 120000, 30000, 0.9, dict(fr=0.05)),            # thousands of patterns
+    (28, 3, 150, 400000, 20000, 0.8, dict(fr=0.05)),           # a wide species in the batch
+])
+def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
+    """The three row pipelines of lad_prepare -- whole-batch sample sort (small inputs), whole-batch radix sort, and the
+    node-order compaction + batched per-species sort of the many-species step (forced here at a small size) -- give the same
+    metrics, objectives, iteration counts, row and pattern counts bit for bit."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    eng.trio_nodes_info(fetch=False)
+    eng.get_node_abundances(fetch=False)
+    outs = []
+    for sort in (None, "seg", "radix"):
+        monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
+        met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
+        outs.append((np.frombuffer(bytes(memoryview(met)), dtype=np.uint8).copy(),
+                     [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in info]))
+    assert any(o[5] > 0 for o in outs[0][1])
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0])
+        assert str(o[1]) == str(outs[0][1])        # str: nan == nan
 
 
 @pytest.mark.gpu

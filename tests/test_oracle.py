@@ -94,6 +94,23 @@ def test_lad_wide_vs_highs_golden(golden_dir):
         assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
 
 
+def test_lad_huge_vs_highs_golden(golden_dir):
+    """More than 256 columns (the reference's matrix has no column cap, profile.rs:1333-1342): the oracle's LAD solver against
+    SciPy-HiGHS on the committed cases of oracle/gen_golden_huge.py, 257 .. 700 columns here (the 1100-column case takes the
+    oracle two minutes; the GPU test runs it against the committed optimum)."""
+    z = np.load(os.path.join(golden_dir, "lp_huge_cases.npz"))
+    for i in range(int(z["n_cases"])):
+        mask, a, ub = z["mask_%d" % i], z["a_%d" % i], z["ub_%d" % i]
+        p = len(ub)
+        assert orc.lad_objective(mask, a, z["x_%d" % i]) == pytest.approx(float(z["obj_%d" % i]), rel=1e-9, abs=1e-12)
+        if p > 700:
+            continue
+        x, obj, it, st = orc.lad_solve(mask, a, p, ub)
+        assert st == 0
+        assert obj == pytest.approx(float(z["obj_%d" % i]), rel=1e-9, abs=1e-12), (i, p)
+        assert np.all(x >= 0) and np.all(x <= ub + 1e-12)
+
+
 def test_lad_degenerate_and_edge_cases():
     # no valid rows -> x = 0
     x, obj, it, st = orc.lad_solve(np.array([1, 3], dtype=np.uint64), np.zeros(2), 2, np.array([1.0, 1.0]))
