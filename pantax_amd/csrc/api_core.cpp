@@ -293,6 +293,8 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     lap("tiles");
     PTX_TRY(trio_runs_build(ctx, db.get()));
     lap("node-block runs");
+    PTX_TRY(node_haps_build(ctx, db.get()));
+    lap("node -> haplotypes");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(1));
     PTX_HIP(ctx, db->d_trio_bases.alloc(1));

@@ -107,7 +107,7 @@ int strain_prezero(Ctx *ctx, Db *db) {
     lb.prezeroed = false;
     PTX_TRY(bind_arena(ctx, db, lb, L));
     PTX_HIP(ctx, lb.d_mask.alloc(db->V));
-    PTX_TRY(zero_fill(ctx, lb.d_mask.p, db->V * sizeof(uint64_t)));
+    if (!use_node_haps(db)) PTX_TRY(zero_fill(ctx, lb.d_mask.p, db->V * sizeof(uint64_t)));   // (the by-node mask kernel writes every word)
     lb.prezeroed = true;
     return 0;
 }

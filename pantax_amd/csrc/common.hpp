@@ -258,6 +258,10 @@ struct Db {
     DevBuf<uint2> d_tiles;           // path tiles {hap, chunk} ordered (species, chunk, hap); one workgroup each
     uint64_t n_tiles = 0;
     DevBuf<uint2> d_emit_tile_sp;    // [ceil(V / 2048)] {species of the first node, of the last node} of every 2048-node tile of the row compaction
+    // node -> haplotypes (node_haps_build, stage_lad.hip; built once at upload): bit j of d_node_haps[v] = the walk of haplotype j of the
+    // node's species visits v; species of more than 64 haplotypes are left at zero (nh_walk_too: there are such species)
+    DevBuf<uint64_t> d_node_haps;    // [V]
+    bool nh_built = false, nh_walk_too = false;
     DevBuf<uint32_t> d_tile_rank;    // [n_tiles] rank of the tile in path order (hap-major)
     DevBuf<uint32_t> d_hap_tile_off; // [H+1] first path-order tile of every haplotype
     // node-block run table of the walks (trio_runs_build, stage_trio.hip; a layout table like d_tiles, built once at upload):
@@ -444,6 +448,8 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run table
+int node_haps_build(Ctx *ctx, Db *db);   // end of db upload: node -> haplotypes (the LP's membership masks built by node)
+bool use_node_haps(const Db *db);
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1, uint64_t file_base = 0, bool group = true,

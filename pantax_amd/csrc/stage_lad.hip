@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
                                                    const uint32_t *__restrict__ node_base, const int32_t *__restrict__ hap_bit,
                                                    unsigned long long *__restrict__ mask, const int32_t *__restrict__ sp_p,
                                                    const uint32_t *__restrict__ wide_off /* null: no species can be wide */,
-                                                   const uint32_t *__restrict__ wide_nw, unsigned long long *__restrict__ maskw) {
+                                                   const uint32_t *__restrict__ wide_nw, unsigned long long *__restrict__ maskw,
+                                                   const uint64_t *__restrict__ by_node_hap_off /* non-null: species of <= 64 haplotypes were done by mask_nodes_kernel */) {
     const uint2 tile = tiles[blockIdx.x];   // {hap, chunk}: see stage_trio.hip
     if (tile.x == 0xFFFFFFFFu) return;      // filler tile
     const uint32_t h = tile.x;
@@ -396,11 +397,66 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
         }
         return;
     }
+    if (by_node_hap_off && by_node_hap_off[sp + 1] - by_node_hap_off[sp] <= 64ull) return;
     const unsigned long long m = 1ull << bit;
     for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
         unsigned long long *w = &mask[nb + path_nodes[q]];
         if ((*w & m) == 0) atomicOr(w, m);   // coeff_matrix[(v,pos)] = 1.0 even for repeated visits (profile.rs:1336-1340)
     }
+}
+
+// ---- the same matrix built BY NODE (round 3).  mask_kernel walks the candidates' paths and ORs a bit into the word of every
+// node it meets: 2.2e9 path steps at cfg4, a read-test-atomic on a 2.5-GB array each, 9 ms of a 58-ms step at 0.8 TB/s.  Which
+// haplotypes of its species visit a node depends on the database alone: node_haps_build writes that set once at upload as one
+// 64-bit word per node (bit j = haplotype j of the species; a layout table like d_tiles and the node-block runs), and the step
+// turns it into the candidates' word in registers -- one coalesced 8-byte load, a lookup in the species' haplotype -> column
+// table per set bit, one 8-byte store, zero words included: no atomics, no zero fill, every byte touched once.
+// Species of more than 64 haplotypes keep the path walk (their nodes get a zero here first).
+__global__ void __launch_bounds__(256) node_haps_fill_kernel(const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
+                                                             const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
+                                                             const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ hap_off,
+                                                             unsigned long long *__restrict__ node_haps) {
+    const uint2 tile = tiles[blockIdx.x];
+    if (tile.x == 0xFFFFFFFFu) return;
+    const uint32_t h = tile.x, sp = hap_species[h], nb = node_base[sp];
+    if (hap_off[sp + 1] - hap_off[sp] > 64ull) return;
+    const unsigned long long m = 1ull << (h - hap_off[sp]);
+    const uint64_t q0 = path_off[h] + (uint64_t)tile.y * PATH_TILE, qend = path_off[h + 1];
+    for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
+        unsigned long long *w = &node_haps[nb + path_nodes[q]];
+        if ((*w & m) == 0) atomicOr(w, m);
+    }
+}
+__global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2 *__restrict__ tile_sp, const uint32_t *__restrict__ node_base,
+                                                         const uint64_t *__restrict__ hap_off, const int32_t *__restrict__ sp_p,
+                                                         const int32_t *__restrict__ hap_bit, const unsigned long long *__restrict__ node_haps,
+                                                         unsigned long long *__restrict__ mask) {
+    __shared__ int s_bit[64];     // haplotype -> LP column of the species the workgroup starts in (nearly always its only one)
+    const uint64_t v0 = (uint64_t)blockIdx.x * 256, v = v0 + threadIdx.x;
+    const uint2 t0 = tile_sp[v0 >> 11];
+    uint32_t sp0 = t0.x;
+    while (sp0 < t0.y && node_base[sp0 + 1] <= v0) ++sp0;
+    {
+        const uint64_t h0 = hap_off[sp0], nh = hap_off[sp0 + 1] - h0;
+        if (threadIdx.x < 64) s_bit[threadIdx.x] = threadIdx.x < nh ? hap_bit[h0 + threadIdx.x] : -1;
+    }
+    __syncthreads();
+    if (v >= V) return;
+    const uint2 t = tile_sp[v >> 11];
+    uint32_t sp = sp0;
+    while (sp < t.y && node_base[sp + 1] <= v) ++sp;
+    const int p = sp_p[sp];
+    unsigned long long m = 0ull;
+    if (p > 0 && p <= LAD_MAXP) {
+        unsigned long long hm = node_haps[v];      // (zero for species of more than 64 haplotypes: the path walk fills those)
+        if (sp == sp0) {
+            while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = s_bit[j]; if (bit >= 0) m |= 1ull << bit; }
+        } else {
+            const int32_t *hb = hap_bit + hap_off[sp];
+            while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = hb[j]; if (bit >= 0) m |= 1ull << bit; }
+        }
+    }
+    mask[v] = m;      // coeff_matrix[(v,pos)] = 1.0 for every candidate path that visits v (profile.rs:1336-1340)
 }
 
 // Wide species: the one-word "mask" of a node becomes a 64-bit hash of its mask words (0 stays 0), so that the row grouping
@@ -687,6 +743,31 @@ __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint3
     if (s == S) pat_start[K] = n_rows;
 }
 
+// PANTAX_MASK=walk: the path-walk kernel although the table exists (measurements, tests)
+bool use_node_haps(const Db *db) {
+    if (!db->nh_built) return false;
+    const char *ev = std::getenv("PANTAX_MASK");
+    return !(ev && ev[0] == 'w');
+}
+// end of db upload: the node -> haplotypes words of mask_nodes_kernel (one launch over the path tiles)
+int node_haps_build(Ctx *ctx, Db *db) {
+    db->nh_built = false; db->nh_walk_too = false;
+    const uint64_t V = db->V;
+    if (!V || !db->P || !db->n_tiles) return 0;
+    bool any_small = false;
+    for (uint32_t s = 0; s < db->S; ++s) {
+        if (db->h_hap_off[s + 1] - db->h_hap_off[s] > 64) db->nh_walk_too = true; else any_small = true;
+    }
+    if (!any_small) return 0;
+    PTX_HIP(ctx, db->d_node_haps.alloc(V));
+    PTX_TRY(zero_fill(ctx, db->d_node_haps.p, V * sizeof(uint64_t)));
+    hipLaunchKernelGGL(node_haps_fill_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p,
+                       db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (unsigned long long *)db->d_node_haps.p);
+    PTX_HIP(ctx, hipGetLastError());
+    db->nh_built = true;
+    return 0;
+}
+
 // All of it is enqueued without a host round trip: the row count n and the pattern count K stay on the
 // device (lb->d_counts = {n_rows, K, overflow}); buffers are sized by their host-known bounds (n <= V,
 // K <= k_cap).  cand_on_device: lb->d_hap_bit / d_p were written by first_filter_kernel; otherwise they are
@@ -703,7 +784,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     PTX_HIP(ctx, lb->d_mask.alloc(V));
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)(H ? H : 1) * 2));
-    if (!lb->prezeroed) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));
+    if (!lb->prezeroed && !use_node_haps(db)) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));   // (mask_nodes_kernel writes every word)
     // species that can be wide (more than 64 haplotypes): side arrays laid out once per db
     // More than LAD_WIDEP haplotypes ("huge"): as many mask words as the haplotypes need, rounded up to whole groups of
     // LAD_WIDE_NW -- the reference has no cap on the LP columns (dense nvert x npaths matrix, profile.rs:1333-1342), and neither
@@ -766,10 +847,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     {
         KTimer t(ctx, "mask_kernel");
-        if (db->n_tiles)
+        const bool by_node = use_node_haps(db);
+        if (by_node && V)
+            hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 255) / 256)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
+                               lb->d_p.p, lb->d_hap_bit.p, (const unsigned long long *)db->d_node_haps.p, (unsigned long long *)lb->d_mask.p);
+        if (db->n_tiles && (!by_node || db->nh_walk_too))
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
                                db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p,
-                               lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, lb->d_wide_nw.p, (unsigned long long *)lb->d_maskw.p);
+                               lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, lb->d_wide_nw.p, (unsigned long long *)lb->d_maskw.p,
+                               by_node ? db->d_hap_off.p : (const uint64_t *)nullptr);
     }
     {
         KTimer t(ctx, "ratio_kernel");

@@ -738,8 +738,9 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 ])
 def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     """The three row pipelines of lad_prepare -- whole-batch sample sort (small inputs), whole-batch radix sort, and the
-    node-order compaction + batched per-species sort of the many-species step (forced here at a small size) -- give the same
-    metrics, objectives, iteration counts, row and pattern counts bit for bit."""
+    node-order compaction + batched per-species sort of the many-species step (forced here at a small size) -- and the two ways
+    of building the membership masks (by node from the node -> haplotypes table of the upload, or by walking the candidates'
+    paths, PANTAX_MASK=walk) give the same metrics, objectives, iteration counts, row and pattern counts bit for bit."""
     from oracle import oracle as orc
     from pantax_amd import synth
     sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
@@ -751,8 +752,9 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     eng.trio_nodes_info(fetch=False)
     eng.get_node_abundances(fetch=False)
     outs = []
-    for sort in (None, "seg", "radix"):
+    for sort, maskmode in ((None, None), ("seg", None), ("radix", None), (None, "walk"), ("seg", "walk")):
         monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
+        monkeypatch.delenv("PANTAX_MASK", raising=False) if maskmode is None else monkeypatch.setenv("PANTAX_MASK", maskmode)
         met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
         outs.append((np.frombuffer(bytes(memoryview(met)), dtype=np.uint8).copy(),
                      [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in info]))

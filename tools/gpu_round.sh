@@ -26,6 +26,8 @@ qbench2) ( time timeout 900 python bench.py --workload cfg2 --no-cpu-baseline --
 covshapes) for sh in 14 21 22 41 42; do PANTAX_COV_SHAPE=$sh timeout 600 python bench.py --no-cpu-baseline --no-hard --no-gaf --steps 5 --warmup 3 > gpurun_out/${tag}_cov$sh.json 2> gpurun_out/${tag}_cov$sh.err; echo "shape $sh"; python3 tools/bench_summary.py gpurun_out/${tag}_cov$sh.json | head -3; done ;;
 bench2) ( time timeout 600 python bench.py --workload cfg2 ) > gpurun_out/${tag}_bench_cfg2.json 2> gpurun_out/${tag}_bench_cfg2.err; tail -c 600 gpurun_out/${tag}_bench_cfg2.json; tail -3 gpurun_out/${tag}_bench_cfg2.err ;;
 qbench4) ( time timeout 900 python bench.py --workload cfg4 --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench4.json 2> gpurun_out/${tag}_qbench4.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench4.json; tail -3 gpurun_out/${tag}_qbench4.err ;;
+masktests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q -k "row_pipelines or strain_profiling or thousand or more_than_64 or literal or cfg2" ) > gpurun_out/${tag}_masktests.log 2>&1; tail -8 gpurun_out/${tag}_masktests.log ;;
+qbench4walk) ( time PANTAX_MASK=walk timeout 900 python bench.py --workload cfg4 --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench4walk.json 2> gpurun_out/${tag}_qbench4walk.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench4walk.json | head -4 ;;
 hugetests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=8 -k "huge or more_than_64 or beyond_64 or batch_equals or wide or row_pipelines" ) > gpurun_out/${tag}_hugetests.log 2>&1; tail -25 gpurun_out/${tag}_hugetests.log ;;
 trace4) bash tools/kernel_trace.sh cfg4 ${tag}_cfg4 4 ;;
 pmc4) bash tools/pmc_step.sh cfg4 ${tag}_cfg4 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
