@@ -28,6 +28,11 @@ bench2) ( time timeout 600 python bench.py --workload cfg2 ) > gpurun_out/${tag}
 qbench4) ( time timeout 900 python bench.py --workload cfg4 --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench4.json 2> gpurun_out/${tag}_qbench4.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench4.json; tail -3 gpurun_out/${tag}_qbench4.err ;;
 masktests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q -k "row_pipelines or strain_profiling or thousand or more_than_64 or literal or cfg2" ) > gpurun_out/${tag}_masktests.log 2>&1; tail -8 gpurun_out/${tag}_masktests.log ;;
 qbench4walk) ( time PANTAX_MASK=walk timeout 900 python bench.py --workload cfg4 --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench4walk.json 2> gpurun_out/${tag}_qbench4walk.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench4walk.json | head -4 ;;
+hardleg) ( time timeout 600 python bench.py --workload cfg2 --no-cpu-baseline --no-gaf --steps 5 ) > gpurun_out/${tag}_hardleg.json 2> gpurun_out/${tag}_hardleg.err; python3 -c "
+import json,sys
+d=json.loads([l for l in open('gpurun_out/${tag}_hardleg.json') if l.startswith('{')][-1]); h=d.get('pao_hard') or d.get('hard') or {}
+print('hard lad ms/species', h.get('lad_kernels_ms_per_species'), 'iters', h.get('iters'), 'step', h.get('ms_per_step_all_launches_bracketed'))"; tail -2 gpurun_out/${tag}_hardleg.err ;;
+lptests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pao_solve or strain_profiling or more_than_64 or row_pipelines or literal or concurrent" ) > gpurun_out/${tag}_lptests.log 2>&1; tail -6 gpurun_out/${tag}_lptests.log ;;
 hugetests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=8 -k "huge or more_than_64 or beyond_64 or batch_equals or wide or row_pipelines" ) > gpurun_out/${tag}_hugetests.log 2>&1; tail -25 gpurun_out/${tag}_hugetests.log ;;
 trace4) bash tools/kernel_trace.sh cfg4 ${tag}_cfg4 4 ;;
 pmc4) bash tools/pmc_step.sh cfg4 ${tag}_cfg4 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
