@@ -15,6 +15,7 @@
 //                                rank sort through memory, slow but exact)
 // The number of rows of a segment is only known on the device (seg_cnt); launch geometry comes from the host-side bound.
 #include <algorithm>
+#include <cstdlib>
 #include "primitives.hpp"
 #include "wave.hpp"
 
@@ -34,19 +35,21 @@ __device__ __forceinline__ bool less2(const Key2 &x, const Key2 &y) { return (x.
 __device__ __forceinline__ bool eq2(const Key2 &x, const Key2 &y) { return (x.m == y.m) & (x.a == y.a); }
 
 // per-segment workspace (u32 words), SG_WS_WORDS apart
-constexpr size_t SG_OFF_FLAGS = 0;                                  // [0] small segment, [1] #big buckets
+constexpr size_t SG_OFF_FLAGS = 0;                                  // [0] small segment, [1] #big buckets, [2] #medium buckets (wave path)
 constexpr size_t SG_OFF_SPL = 4;                                    // u64 [2][1024]
 constexpr size_t SG_OFF_SAMP = SG_OFF_SPL + 2 * 2 * 1024;           // u64 [2][4096]
 constexpr size_t SG_OFF_CNT = SG_OFF_SAMP + 2 * 2 * SG_SAMPLE;      // [2048] bucket totals      } zeroed at the start of every sort
 constexpr size_t SG_OFF_CUR = SG_OFF_CNT + SG_NBUCKET;              // [2048] bucket cursors     }  (by ssg_gather_kernel)
 constexpr size_t SG_OFF_START = SG_OFF_CUR + SG_NBUCKET;            // [2049]
 constexpr size_t SG_OFF_BIG = SG_OFF_START + SG_NBUCKET + 4;        // [2048]
-constexpr size_t SG_WS_WORDS = SG_OFF_BIG + SG_NBUCKET;
+constexpr size_t SG_OFF_MED = SG_OFF_BIG + SG_NBUCKET;              // [2048] buckets the wave kernel leaves to the workgroup-wide sort
+constexpr size_t SG_WS_WORDS = SG_OFF_MED + SG_NBUCKET;
 
 struct Seg {
     const uint32_t *off, *cnt;   // [S] first row and number of rows of every segment (device)
     uint32_t *ws;                // S x SG_WS_WORDS
     uint16_t *ids;               // one per row (global row index)
+    uint32_t wave_rows;          // segments of at most this many rows sort their small buckets a wave each (ssg_local_wave_kernel)
     __device__ __forceinline__ uint32_t *w(uint32_t s) const { return ws + (size_t)s * SG_WS_WORDS; }
 };
 
@@ -77,6 +80,42 @@ __device__ __forceinline__ void bitonic1(uint64_t *ka, uint32_t N) {
         }
 }
 
+// The same networks run by ONE wave on its own LDS rows (buckets of up to SG_WAVE_CAP rows): no workgroup barrier between the
+// steps, the four waves of a workgroup sort four buckets side by side.  A wave's LDS operations complete in order; the fences keep
+// the compiler from moving them across a step.
+constexpr int SG_WAVE_CAP = 256;
+__device__ __forceinline__ void wave_lds_step() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void bitonic2_wave(uint64_t *km, uint64_t *ka, uint32_t N) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < N / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const Key2 x{km[i], ka[i]}, y{km[l], ka[l]};
+                const bool up = (i & k) == 0;
+                if (up ? less2(y, x) : less2(x, y)) { km[i] = y.m; ka[i] = y.a; km[l] = x.m; ka[l] = x.a; }
+            }
+            wave_lds_step();
+        }
+}
+__device__ __forceinline__ void bitonic1_wave(uint64_t *ka, uint32_t N) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < N / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const uint64_t x = ka[i], y = ka[l];
+                const bool up = (i & k) == 0;
+                if (up ? (y < x) : (x < y)) { ka[i] = y; ka[l] = x; }
+            }
+            wave_lds_step();
+        }
+}
+
 __global__ void __launch_bounds__(256) ssg_gather_kernel(Seg sg, const uint64_t *__restrict__ km, const uint64_t *__restrict__ ka) {
     const uint32_t s = blockIdx.y, n = sg.cnt[s], o = sg.off[s];
     uint32_t *w = sg.w(s);
@@ -87,7 +126,7 @@ __global__ void __launch_bounds__(256) ssg_gather_kernel(Seg sg, const uint64_t 
     const bool ok = pos < n;
     samp[i] = ok ? km[o + pos] : ~0ull;
     samp[SG_SAMPLE + i] = ok ? ka[o + pos] : ~0ull;
-    if (i == 0) { w[SG_OFF_FLAGS] = small ? 1u : 0u; w[SG_OFF_FLAGS + 1] = 0; }
+    if (i == 0) { w[SG_OFF_FLAGS] = small ? 1u : 0u; w[SG_OFF_FLAGS + 1] = 0; w[SG_OFF_FLAGS + 2] = 0; }
     w[SG_OFF_CNT + i] = 0;   // bucket totals and cursors (2 x 2048 words = the 4096 threads of this segment's gather)
 }
 // One 1024-thread workgroup per segment sorts its 4096 samples in LDS (bitonic network: 78 steps of 2 compare-exchanges
@@ -190,6 +229,48 @@ __global__ void __launch_bounds__(256) ssg_scatter_kernel(Seg sg, const uint64_t
     }
 }
 
+// Segments of at most sg.wave_rows rows: a wave per bucket -- copies of the single-key buckets, sorts of up to SG_WAVE_CAP rows on the
+// wave's own LDS rows; larger buckets go on the segment's list for ssg_local_kernel<SG_CAP1>, which then does nothing else there.
+__global__ void __launch_bounds__(256) ssg_local_wave_kernel(Seg sg, uint64_t *__restrict__ am, uint64_t *__restrict__ aa,
+                                                             const uint64_t *__restrict__ bm, const uint64_t *__restrict__ ba) {
+    __shared__ uint64_t km[4 * SG_WAVE_CAP], ka[4 * SG_WAVE_CAP];
+    const uint32_t s = blockIdx.y, n = sg.cnt[s], o = sg.off[s];
+    uint32_t *w = sg.w(s);
+    if (n == 0 || n > sg.wave_rows || w[SG_OFF_FLAGS] != 0) return;
+    const uint32_t *bucket_start = w + SG_OFF_START;
+    uint32_t *med_list = w + SG_OFF_MED;
+    const uint64_t *spl = reinterpret_cast<const uint64_t *>(w + SG_OFF_SPL);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *wm = km + wave * SG_WAVE_CAP, *wa = ka + wave * SG_WAVE_CAP;
+    for (uint32_t bid = blockIdx.x * 4 + wave; bid < (uint32_t)SG_NBUCKET; bid += gridDim.x * 4) {
+        const uint32_t st = o + bucket_start[bid], m = bucket_start[bid + 1] - bucket_start[bid];
+        if (m == 0) continue;
+        if ((bid & 1u) || m == 1) {   // identical keys (or a single row): nothing to sort
+            for (uint32_t i = lane; i < m; i += 64) { am[st + i] = bm[st + i]; aa[st + i] = ba[st + i]; }
+            continue;
+        }
+        if (m > (uint32_t)SG_WAVE_CAP) { if (lane == 0) med_list[atomicAdd(&w[SG_OFF_FLAGS + 2], 1u)] = bid; continue; }
+        uint32_t N = 2;
+        while (N < m) N <<= 1;
+        wave_lds_step();              // the wave's rows are reused from its previous bucket
+        const uint32_t sj = bid >> 1;
+        if (sj > 0 && sj < (uint32_t)SG_NSPLIT && spl[sj - 1] == spl[sj]) {   // one mask between the two splitters: only `a` moves
+            const uint64_t mv = spl[sj];
+            for (uint32_t i = lane; i < N; i += 64) wa[i] = i < m ? ba[st + i] : ~0ull;
+            wave_lds_step();
+            bitonic1_wave(wa, N);
+            for (uint32_t i = lane; i < m; i += 64) { am[st + i] = mv; aa[st + i] = wa[i]; }
+            continue;
+        }
+        for (uint32_t i = lane; i < N; i += 64) {
+            if (i < m) { wm[i] = bm[st + i]; wa[i] = ba[st + i]; } else { wm[i] = ~0ull; wa[i] = ~0ull; }
+        }
+        wave_lds_step();
+        bitonic2_wave(wm, wa, N);
+        for (uint32_t i = lane; i < m; i += 64) { am[st + i] = wm[i]; aa[st + i] = wa[i]; }
+    }
+}
+
 // CAP = SG_CAP1: every bucket of 2..SG_CAP1 rows (+ the copies of single-key buckets, + the small-segment copy);
 // CAP = SG_CAP : the rest.  Rows come from b and end in a.
 template <int CAP>
@@ -207,9 +288,10 @@ __global__ void __launch_bounds__(256) ssg_local_kernel(Seg sg, uint64_t *__rest
     const uint32_t *bucket_start = w + SG_OFF_START;
     uint32_t *big_list = w + SG_OFF_BIG;
     const uint64_t *spl = reinterpret_cast<const uint64_t *>(w + SG_OFF_SPL);
-    const uint32_t n_work = CAP == SG_CAP1 ? (uint32_t)SG_NBUCKET : w[SG_OFF_FLAGS + 1];
+    const bool from_wave = CAP == SG_CAP1 && n <= sg.wave_rows;    // the wave kernel did the small buckets: only its list is left
+    const uint32_t n_work = from_wave ? w[SG_OFF_FLAGS + 2] : CAP == SG_CAP1 ? (uint32_t)SG_NBUCKET : w[SG_OFF_FLAGS + 1];
     for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
-        const uint32_t bid = CAP == SG_CAP1 ? wi : big_list[wi];
+        const uint32_t bid = from_wave ? w[SG_OFF_MED + wi] : CAP == SG_CAP1 ? wi : big_list[wi];
         const uint32_t st = o + bucket_start[bid], m = bucket_start[bid + 1] - bucket_start[bid];
         if (m == 0) continue;
         if ((bid & 1u) || m == 1) {   // identical keys (or a single row): nothing to sort
@@ -266,7 +348,11 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
     if (S == 0 || seg_bound == 0) return 0;
     if (seg_bound > SS_MAX_N) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_seg: a segment of %llu rows exceeds %llu", (unsigned long long)seg_bound, (unsigned long long)SS_MAX_N);
     if (S > 65535) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_seg: %u segments exceed the launch grid", S);
-    Seg sg{d_seg_off, d_seg_cnt, d_ws, reinterpret_cast<uint16_t *>(d_ws + (size_t)S * SG_WS_WORDS)};
+    Seg sg{d_seg_off, d_seg_cnt, d_ws, reinterpret_cast<uint16_t *>(d_ws + (size_t)S * SG_WS_WORDS), 0u};
+    // A wave's network is a longer chain of dependent LDS steps than the workgroup's; it pays through the number of buckets in flight:
+    // 1000 segments 4.1 -> 3.3 ms (cfg4), 100 segments 0.49 -> 0.78 ms (cfg3); 512-row wave buckets: 5.7 ms.  Hence by the number of segments.
+    sg.wave_rows = S >= 400 ? (uint32_t)SS_MAX_N : 0u;
+    if (const char *ev = std::getenv("PANTAX_SSG_WAVE_ROWS")) sg.wave_rows = (uint32_t)std::strtoul(ev, nullptr, 10);   // measurements
     const uint32_t nb = (uint32_t)((seg_bound + SG_TILE - 1) / SG_TILE);
     { KTimer t(ctx, "ss_sample_kernel");
       hipLaunchKernelGGL(ssg_gather_kernel, dim3(SG_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sg, am, aa);
@@ -276,6 +362,7 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
     { KTimer t(ctx, "ss_scatter_kernel");
       hipLaunchKernelGGL(ssg_scatter_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, sg, am, aa, bm, ba); }
     { KTimer t(ctx, "ss_local_kernel");
+      if (sg.wave_rows) hipLaunchKernelGGL(ssg_local_wave_kernel, dim3(SG_LOCAL_GRID, S), dim3(256), 0, ctx->stream, sg, am, aa, bm, ba);
       hipLaunchKernelGGL((ssg_local_kernel<SG_CAP1>), dim3(SG_LOCAL_GRID, S), dim3(256), 0, ctx->stream, sg, am, aa, bm, ba);
       hipLaunchKernelGGL((ssg_local_kernel<SG_CAP>), dim3(8, S), dim3(256), 0, ctx->stream, sg, am, aa, bm, ba); }
     PTX_HIP(ctx, hipGetLastError());

@@ -921,11 +921,15 @@ def test_device_sorts_against_host_sort(eng, algo):
 
 
 @pytest.mark.gpu
-def test_segmented_sample_sort_against_host_sort(eng):
+@pytest.mark.parametrize("wave_rows", [None, "1000000", "0"])
+def test_segmented_sample_sort_against_host_sort(eng, wave_rows, monkeypatch):
     """The batched row sort of the many-species step (sample_sort_seg.hip) through the host-buffer utility: segments of
     every size class side by side (empty neighbours cannot exist in this interface; 1 row, <= 4096 rows ranked by the
     sample kernel, tens of thousands of rows, massive ties, presorted, and an unrepresentative sample whose one bucket
-    exceeds the LDS capacities), each sorted by (k1, k2) on its own."""
+    exceeds the LDS capacities), each sorted by (k1, k2) on its own.  Buckets are sorted a workgroup each, or -- from 400
+    segments on, forced here through PANTAX_SSG_WAVE_ROWS -- a wave each up to 256 rows."""
+    if wave_rows is not None:
+        monkeypatch.setenv("PANTAX_SSG_WAVE_ROWS", wave_rows)
     rng = np.random.default_rng(7)
     segs = []
     for n in (1, 2, 63, 4095, 4096, 4097, 5000, 70000):
