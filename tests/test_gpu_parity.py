@@ -444,7 +444,6 @@ def test_pao_solve_at_and_beyond_64_candidates(eng):
     pins on the golden cases); 65 goes through the wide path (four words) and gives the same optimum with an unused extra
     column; 257 and 600 columns (more than four words) go through the kernel that sizes its state at run time."""
     from oracle import oracle as orc
-    from pantax_amd.engine import PantaxHipError
     rng = np.random.default_rng(64)
     n, p = 6000, 64
     # haplotype-like membership: every node on a random subset of the paths, a few paths nearly everywhere
@@ -586,20 +585,19 @@ def test_species_with_more_than_64_candidates(eng, n_walks):
     ref = _oracle_cov_per_species(sset, sp)
     G, T, b, c, t, na = ref[0]
     assert info[0].n_candidates == nh
-    if True:
-        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
-        assert rc_ == 0 and nc == nh and info[0].status1 == 0 and info[0].status2 == 0
-        assert info[0].obj1 == pytest.approx(o1, rel=1e-9)          # no second solve in this branch (profile.rs:1279-1283)
-        orc.abundance_constraint(absolute[0], omet)
-        od = orc.metrics_to_dicts(omet)
-        for k in range(n_walks):               # twins share their walk: only the sum of the pair is determined ...
-            for key in ("path_base_cov",):
-                assert got[2 * k][key] == pytest.approx(od[2 * k][key], rel=1e-6) and got[2 * k + 1][key] == pytest.approx(od[2 * k + 1][key], rel=1e-6)
-        # ... and not even that where different walks cover the same nodes; the objective above and the LP's own value agree
-        mask, ratio = orc.path_masks(G, np.arange(nh), c)
-        ab = np.asarray(b, dtype=np.float64) / np.asarray(sset.species[0].node_len, dtype=np.float64)   # profile.rs:980-990
-        x1 = np.array([got[h]["first_sol"] for h in range(nh)])
-        assert orc.lad_objective(mask, ab, x1) == pytest.approx(o1, rel=1e-9)
+    rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
+    assert rc_ == 0 and nc == nh and info[0].status1 == 0 and info[0].status2 == 0
+    assert info[0].obj1 == pytest.approx(o1, rel=1e-9)          # no second solve in this branch (profile.rs:1279-1283)
+    orc.abundance_constraint(absolute[0], omet)
+    od = orc.metrics_to_dicts(omet)
+    for k in range(n_walks):               # twins share their walk: only the sum of the pair is determined ...
+        for key in ("path_base_cov",):
+            assert got[2 * k][key] == pytest.approx(od[2 * k][key], rel=1e-6) and got[2 * k + 1][key] == pytest.approx(od[2 * k + 1][key], rel=1e-6)
+    # ... and not even that where different walks cover the same nodes; the objective above and the LP's own value agree
+    mask, ratio = orc.path_masks(G, np.arange(nh), c)
+    ab = np.asarray(b, dtype=np.float64) / np.asarray(sset.species[0].node_len, dtype=np.float64)   # profile.rs:980-990
+    x1 = np.array([got[h]["first_sol"] for h in range(nh)])
+    assert orc.lad_objective(mask, ab, x1) == pytest.approx(o1, rel=1e-9)
     G, T, b, c, t, na = ref[1]
     rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t)
     assert rc_ == 0 and info[1].status1 == 0 and info[1].n_candidates == nc
