@@ -300,7 +300,7 @@ namespace {
 // A crew of host threads that fills pinned slots -- [src + pos, +n) or (fd, pos, n) -- for the lifetime of ONE upload (round 2
 // created and joined 16 threads per 16-MB chunk: ~0.5 ms of thread start-up beside 0.6 ms of copy).  The box delivers 80 GB/s
 // of pread from the page cache on 8-16 threads and 56 GB/s of pinned host->device copy (tools/h2d_probe.py): the crew only has
-// to stay ahead of the DMA.
+// to stay ahead of the DMA (it takes 32 threads for that inside the pipeline: see upload_staged_pieces).
 struct StageCrew {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
@@ -366,7 +366,9 @@ int upload_staged_pieces(Ctx *ctx, const UploadPiece *pieces, size_t n_pieces, i
                                                     : std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
     if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH && !std::getenv("PANTAX_STAGE_CH_MB")) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
     PTX_HIP(ctx, ring.reserve(SLOTS * CH));
-    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 16;
+    // 32 threads: at 16 the crew, not the DMA, bounds a 15-GB load (filling 413 of 420 ms = 37 GB/s of pread; 32: 211 of 293 ms = 52 GB/s,
+    // 0.92 of the pinned copy rate); 48 and 64 fill no faster and slow the copies down (390 ms)
+    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 32;
     const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(NTH_ENV, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
     StageCrew crew(nth);
     hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
