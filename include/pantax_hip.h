@@ -223,6 +223,12 @@ int pantax_hip_profile_step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint
                                     pantax_hip_hap_metrics *metrics_out, pantax_hip_solve_info *info_out, uint8_t *pass_out,
                                     double *species_sum_all_out, double *species_sum_pass_out);
 
+/* A resident db that serves one sample after the other: the unique-trio index of the COMING run (trio_nodes_info, profile.rs:2936 --
+ * it depends on the graphs only) is started now, e.g. right before that run's GAF is loaded, so that it is built beside the PCIe
+ * transfer instead of in front of the coverage pass.  The next profile_step / _enqueue of the db with rebuild_trio != 0 uses it instead
+ * of building again (one build per run, as in the reference); nothing is waited for here. */
+int pantax_hip_trio_index_prefetch(pantax_hip_ctx *ctx, pantax_hip_db *db);
+
 /* ---- the device sort of the LP row grouping as a host-buffer utility: rows (k0[i], k1[i], k2[i]) sorted
  * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
  * 2 = sample sort (n <= 600000), 3 = the batched sort of the many-species step: rows arrive grouped by ascending k0

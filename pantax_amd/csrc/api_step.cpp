@@ -44,7 +44,8 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every
     // run, profile.rs:2936), so it is built while the main stream bins the reads and takes the species decision
     bool forked = false;
-    if (cfg->rebuild_trio) { db->trio_built = false; db->cov_done = false; db->U = 0; }
+    if (cfg->rebuild_trio && !(db->trio_prefetched && db->trio_built)) { db->trio_built = false; db->cov_done = false; db->U = 0; }
+    db->trio_prefetched = false;   // (a prefetched index serves ONE step: the run it was started for)
     if (!db->trio_built) {
         // the previous step still reads the index this build replaces -- up to its first filter (strain_enqueue records the event
         // behind it); what follows there (masks, row sort, LPs, objective) runs beside the rebuild.  Without such an event
@@ -124,6 +125,30 @@ int step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, doub
                                        species_sum_all_out, species_sum_pass_out);
 }
 }  // namespace
+
+// The per-run index build of the COMING step, started now: on the side stream behind the last reader of the index it replaces,
+// joined into the main stream at once -- whatever the caller enqueues next (the load of that run's reads, the step) is ordered behind
+// it, while copies on other streams and the host-side work of a load run beside it.
+extern "C" int pantax_hip_trio_index_prefetch(pantax_hip_ctx *ctx, pantax_hip_db *db) {
+    if (!ctx || !db) return PANTAX_HIP_E_INVALID;
+    PTX_ENTER(ctx);
+    if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "trio_index_prefetch: the db was uploaded without graphs (ranges only)");
+    db->trio_built = false; db->cov_done = false; db->U = 0; db->trio_prefetched = false;
+    if (db->trio_free_valid && !std::getenv("PANTAX_TRIO_AFTER_STEP")) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
+    else {
+        PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));
+        PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
+    }
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;
+    const int rc = trio_index_build(ctx, db, false);
+    const hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream2);
+    ctx->stream = main_stream;
+    if (rc != 0 || e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); db->trio_built = false; if (rc != 0) return rc; PTX_HIP(ctx, e); }
+    PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    db->trio_prefetched = true;
+    return 0;
+}
 
 extern "C" int pantax_hip_profile_step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads, const double *avg_len,
                                                const pantax_hip_step_config *cfg) {

@@ -278,6 +278,7 @@ struct Db {
     DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
     // unique-trio index (a7)
     bool trio_built = false;
+    bool trio_prefetched = false;   // pantax_hip_trio_index_prefetch built the index of the COMING step: that step's rebuild_trio is served by it
     bool trio_keys_built = false;   // d_trio_abc / d_trio_hap (row-order export copies) were written by the last build
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch

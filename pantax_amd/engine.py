@@ -304,6 +304,12 @@ class Engine:
             self.U = None
         return keep, absolute, met, info, passed[: self.H], s_all, s_pass
 
+    def trio_index_prefetch(self):
+        """pantax_hip_trio_index_prefetch: the unique-trio index of the COMING step is started now (side stream), e.g. before that
+        run's reads are loaded; the next step with rebuild_trio uses it instead of building again."""
+        self._check(self.lib.pantax_hip_trio_index_prefetch(self.ctx, self.db))
+        self.U = None
+
     def profile_step_enqueue(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
                              rebuild_trio=True, sample_nodes=0):
         """First half of profile_step (pantax_hip_profile_step_enqueue): the whole step goes onto the device, nothing is waited

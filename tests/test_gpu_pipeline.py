@@ -686,3 +686,35 @@ def test_profile_seam_vs_literal_python_restatement(tmp_path, k):
         m = [m for m in ex["per_species"][e["species_taxid"]]["metrics"] if m["hap_id"] == e["hap_id"]][0]
         exp_strain.append((e["species_taxid"], e["hap_id"], e["predicted_coverage"], e["predicted_abundance"], {c: m[f] for c, f in key.items()}))
     _check_outputs(str(wd), sset, exp_species, exp_strain)
+
+
+@pytest.mark.gpu
+def test_trio_index_prefetch_serves_the_next_step_only(eng):
+    """pantax_hip_trio_index_prefetch: the index build of the coming run started ahead of it (before the reads are uploaded) -- the
+    step that follows gives the tables of a plain step bit for bit and consumes the prefetch; the step after it rebuilds again;
+    a prefetch followed by a db reset is not used."""
+    from pantax_amd import synth
+    sset = synth.make_set(41, 4, 8, 60000, 30000, present_frac=0.5)
+    avg = sset.avg_len()
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    def snap(o):      # the step's outputs live in buffers the engine reuses: copies
+        return (o[0].copy(), o[1].copy(), bytes(memoryview(o[2])), str([(i.n_candidates, i.status1, i.iters1, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in o[3]]),
+                o[4].copy())
+
+    def same(a, b):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and np.array_equal(a[4], b[4])
+
+    ref = snap(eng.profile_step(avg))
+    assert ref[0].any()
+    eng.trio_index_prefetch()
+    eng.upload_packed(sset.reads)            # the "load" of the run the prefetch belongs to
+    same(snap(eng.profile_step(avg)), ref)
+    same(snap(eng.profile_step(avg)), ref)   # no prefetch in front of this one: it builds its own
+    eng.trio_index_prefetch()
+    eng.trio_index_prefetch()                # twice in a row: the second replaces the first
+    same(snap(eng.profile_step(avg)), ref)
+    eng.trio_index_prefetch()
+    eng.upload_db(sset.species)              # a new db: nothing of the prefetch survives
+    eng.upload_packed(sset.reads)
+    same(snap(eng.profile_step(avg)), ref)

@@ -34,6 +34,8 @@ d=json.loads([l for l in open('gpurun_out/${tag}_hardleg.json') if l.startswith(
 print('hard lad ms/species', h.get('lad_kernels_ms_per_species'), 'iters', h.get('iters'), 'step', h.get('ms_per_step_all_launches_bracketed'))"; tail -2 gpurun_out/${tag}_hardleg.err ;;
 lptests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pao_solve or strain_profiling or more_than_64 or row_pipelines or literal or concurrent" ) > gpurun_out/${tag}_lptests.log 2>&1; tail -6 gpurun_out/${tag}_lptests.log ;;
 sorttests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q -k "sort or row_pipelines or strain_profiling or thousand or cfg2 or cfg3" ) > gpurun_out/${tag}_sorttests.log 2>&1; tail -6 gpurun_out/${tag}_sorttests.log ;;
+prefetchtest) ( time timeout 600 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k "prefetch or step" ) > gpurun_out/${tag}_prefetchtest.log 2>&1; tail -5 gpurun_out/${tag}_prefetchtest.log ;;
+gafleg) for wl in cfg4 cfg3; do timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-hard --steps 4 > gpurun_out/${tag}_gafleg_$wl.json 2>/dev/null; python3 tools/bench_summary.py gpurun_out/${tag}_gafleg_$wl.json | grep -E "^value|^gaf" | cut -c1-330; done ;;
 hugetests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=8 -k "huge or more_than_64 or beyond_64 or batch_equals or wide or row_pipelines" ) > gpurun_out/${tag}_hugetests.log 2>&1; tail -25 gpurun_out/${tag}_hugetests.log ;;
 trace4) bash tools/kernel_trace.sh cfg4 ${tag}_cfg4 4 ;;
 pmc4) bash tools/pmc_step.sh cfg4 ${tag}_cfg4 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
