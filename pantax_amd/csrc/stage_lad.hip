@@ -431,32 +431,38 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
                                                          const uint64_t *__restrict__ hap_off, const int32_t *__restrict__ sp_p,
                                                          const int32_t *__restrict__ hap_bit, const unsigned long long *__restrict__ node_haps,
                                                          unsigned long long *__restrict__ mask) {
-    __shared__ int s_bit[64];     // haplotype -> LP column of the species the workgroup starts in (nearly always its only one)
-    const uint64_t v0 = (uint64_t)blockIdx.x * 256, v = v0 + threadIdx.x;
-    const uint2 t0 = tile_sp[v0 >> 11];
-    uint32_t sp0 = t0.x;
-    while (sp0 < t0.y && node_base[sp0 + 1] <= v0) ++sp0;
+    // one workgroup per 2048-node tile of d_emit_tile_sp (eight nodes per thread: the table below is set up once per 2048 nodes)
+    __shared__ int s_bit[64];     // haplotype -> LP column of the species the tile starts in (nearly always its only one)
+    const uint64_t v0 = (uint64_t)blockIdx.x * 2048;
+    const uint2 t = tile_sp[blockIdx.x];
+    const uint32_t sp0 = t.x;
     {
         const uint64_t h0 = hap_off[sp0], nh = hap_off[sp0 + 1] - h0;
         if (threadIdx.x < 64) s_bit[threadIdx.x] = threadIdx.x < nh ? hap_bit[h0 + threadIdx.x] : -1;
     }
+    const int p0 = sp_p[sp0];
+    const uint64_t end0 = sp0 < t.y ? (uint64_t)node_base[sp0 + 1] : V;     // first node that is not of the tile's first species any more
     __syncthreads();
-    if (v >= V) return;
-    const uint2 t = tile_sp[v >> 11];
-    uint32_t sp = sp0;
-    while (sp < t.y && node_base[sp + 1] <= v) ++sp;
-    const int p = sp_p[sp];
-    unsigned long long m = 0ull;
-    if (p > 0 && p <= LAD_MAXP) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint64_t v = v0 + (uint64_t)r * 256 + threadIdx.x;
+        if (v >= V) break;
         unsigned long long hm = node_haps[v];      // (zero for species of more than 64 haplotypes: the path walk fills those)
-        if (sp == sp0) {
-            while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = s_bit[j]; if (bit >= 0) m |= 1ull << bit; }
-        } else {
-            const int32_t *hb = hap_bit + hap_off[sp];
-            while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = hb[j]; if (bit >= 0) m |= 1ull << bit; }
+        unsigned long long m = 0ull;
+        if (v < end0) {
+            if (p0 > 0 && p0 <= LAD_MAXP)
+                while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = s_bit[j]; if (bit >= 0) m |= 1ull << bit; }
+        } else {                                    // a species border inside the tile: the few nodes behind it look their species up
+            uint32_t sp = sp0 + 1;
+            while (sp < t.y && node_base[sp + 1] <= v) ++sp;
+            const int p = sp_p[sp];
+            if (p > 0 && p <= LAD_MAXP) {
+                const int32_t *hb = hap_bit + hap_off[sp];
+                while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = hb[j]; if (bit >= 0) m |= 1ull << bit; }
+            }
         }
+        mask[v] = m;      // coeff_matrix[(v,pos)] = 1.0 for every candidate path that visits v (profile.rs:1336-1340)
     }
-    mask[v] = m;      // coeff_matrix[(v,pos)] = 1.0 for every candidate path that visits v (profile.rs:1336-1340)
 }
 
 // Wide species: the one-word "mask" of a node becomes a 64-bit hash of its mask words (0 stays 0), so that the row grouping
@@ -849,7 +855,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         KTimer t(ctx, "mask_kernel");
         const bool by_node = use_node_haps(db);
         if (by_node && V)
-            hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 255) / 256)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
+            hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 2047) / 2048)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
                                lb->d_p.p, lb->d_hap_bit.p, (const unsigned long long *)db->d_node_haps.p, (unsigned long long *)lb->d_mask.p);
         if (db->n_tiles && (!by_node || db->nh_walk_too))
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
