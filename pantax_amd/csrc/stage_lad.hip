@@ -261,7 +261,7 @@ constexpr int STAT_CHUNKS = 256;  // most workgroups per species; partials are c
 static inline uint32_t stat_chunks(uint32_t S) { uint32_t c = 2048u / (S ? S : 1u); return c < 1u ? 1u : (c > (uint32_t)STAT_CHUNKS ? (uint32_t)STAT_CHUNKS : c); }
 struct NodePartial { double mx, zs; unsigned long long nv, zc; };
 
-__global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
+__global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
                                                          const unsigned long long *__restrict__ bases, double min_depth,
                                                          double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
     __shared__ double red[4];
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
     double mx = -INFINITY, zs = 0.0;
     unsigned long long nv = 0, zc = 0;
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
-        double len = (double)(bit_off[v + 1] - bit_off[v]);
+        double len = (double)node_len[v];                        // (the 4-byte copy of the lengths: 4V instead of 8V of offsets)
         double ab = (double)(long long)bases[v] / len;           // profile.rs:987-988
         ab_out[v] = ab;
         mx = fmax(mx, ab);
@@ -311,7 +311,7 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
     KTimer t(ctx, "node_stats_kernel");
     const uint32_t nch = stat_chunks(S);
-    hipLaunchKernelGGL(node_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_bases.p,
+    hipLaunchKernelGGL(node_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p,
                        (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
     hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
                        lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p, nch);
@@ -518,7 +518,7 @@ constexpr int ROW_ITEMS = 8;   // nodes per thread of the row compaction kernels
 // path_cov_ratio sums (profile.rs:1344-1361): per candidate k, sum of covered bases and of lengths over its
 // nodes.  The first 8 candidates (nearly always all of them) accumulate in registers and are combined by wave
 // reductions; 64 lanes hammering 2-4 LDS addresses with 64-bit atomics serialise.
-__global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ bit_off,
+__global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
                                                     const int32_t *__restrict__ sp_p, const uint64_t *__restrict__ hap_off,
                                                     const uint32_t *__restrict__ wide_off, const uint32_t *__restrict__ wide_nw,
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
             for (int i = threadIdx.x; i < 2 * pn; i += 256) acc[i] = 0;
             __syncthreads();
             for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
-                const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+                const unsigned long long c = cov[v], l = node_len[v];
 #pragma unroll
                 for (int i = 0; i < LAD_WIDE_NW; ++i) {
                     unsigned long long m = mw[(size_t)(v - b) * nw + (kb >> 6) + i];
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
     for (uint32_t v = lo + threadIdx.x; v < hi; v += 256) {
         unsigned long long m = mask[v];
         if (!m) continue;
-        const unsigned long long c = cov[v], l = bit_off[v + 1] - bit_off[v];
+        const unsigned long long c = cov[v], l = node_len[v];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool on = (m >> k) & 1ull;
@@ -865,7 +865,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     {
         KTimer t(ctx, "ratio_kernel");
-        hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_bit_off.p, db->d_cov.p,
+        hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_cov.p,
                            (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, lb->d_wide_nw.p,
                            (const unsigned long long *)lb->d_maskw.p, lb->d_ratio.p);
     }
