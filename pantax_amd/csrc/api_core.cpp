@@ -291,6 +291,8 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         PTX_TRY(upload(ctx, db->d_emit_tile_sp, tsp.data(), tsp.size()));
     }
     lap("tiles");
+    PTX_TRY(trio_visits_build(ctx, db.get()));
+    lap("visit table");
     PTX_TRY(trio_runs_build(ctx, db.get()));
     lap("node-block runs");
     PTX_TRY(node_haps_build(ctx, db.get()));

@@ -267,14 +267,25 @@ struct Db {
     // node-block run table of the walks (trio_runs_build, stage_trio.hip; a layout table like d_tiles, built once at upload):
     // every species' nodes are cut into blocks of TRIO_BLK nodes, every walk into maximal runs of consecutive positions
     // whose nodes lie in ONE block; runs are grouped by block.  The unique-trio build then gives each block to one
-    // workgroup, which sees every window whose smallest end node lies in the block -- whatever haplotype it is on.
-    bool trio_block_ok = false;      // every species has < 2^27 nodes (the 64-bit LDS key packs (a in block, b, c)) and P < 2^32
+    // workgroup, which sees every window whose middle node lies in the block -- whatever haplotype it is on.  Only species the visit
+    // table leaves to this path have blocks.
+    // visit table of the walks (trio_visits_build, stage_trio.hip; the default path of the unique-trio build since round 4): the interior
+    // positions listed node by node in groups of 64 visits that no node straddles
+    bool trio_visit_ok = false;
+    uint32_t n_vgroups = 0;
+    std::vector<uint8_t> h_trio_slow; // [S] 1: the species holds a node with more than 64 visits (or the table was not built): node-block kernel
+    DevBuf<uint32_t> d_trio_slow;    // [S] the same
+    DevBuf<uint32_t> d_vis_pos;      // [64 n_vgroups] path position of the visit (the middle of its window), 0xFFFFFFFF pads at a group's tail
+    DevBuf<uint64_t> d_vis_head;     // [n_vgroups] bit l: lane l holds the first visit of a node
+    DevBuf<uint32_t> d_vis_nbase;    // [n_vgroups] node base of the group's species
+    DevBuf<uint32_t> d_node_visited; // [V / 32 + 2] bit v: node v has an interior visit
+    bool trio_block_ok = false;      // every species left to the node-block kernel has < 2^27 nodes (the 64-bit LDS key packs (middle in block, lo, hi)) and P < 2^32
     uint32_t n_blocks = 0;
     uint64_t n_runs = 0;
     DevBuf<uint32_t> d_blk_base;     // [S+1] first block of every species
     DevBuf<uint32_t> d_blk_species;  // [n_blocks]
     DevBuf<uint32_t> d_blk_run_off;  // [n_blocks+1]
-    DevBuf<uint4> d_blk_rec;         // [n_blocks+1] {first run, end run, global first node, species-local first node}
+    DevBuf<uint4> d_blk_rec;         // [n_blocks+1] {first run, end run, global first node, species-local first node / 64 | node count << 24}
     DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
     // unique-trio index (a7)
     bool trio_built = false;
@@ -284,8 +295,8 @@ struct Db {
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
-    DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the smallest end node (global node index)
-    DevBuf<uint4> d_trio_ent;        // [U] {b, c, row in (species,hap,position) order, 0}
+    DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the MIDDLE node of the window (global node index)
+    DevBuf<uint4> d_trio_ent;        // [U] {smaller end, larger end, row in (species,hap,position) order, 0}
     DevBuf<uint32_t> d_trio_abc;     // [3U] row order
     DevBuf<uint32_t> d_trio_hap;     // [U] hap index within species, row order
     DevBuf<uint32_t> d_trio_len;     // [U]
@@ -448,7 +459,8 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
-int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload: the node-block run table
+int trio_visits_build(Ctx *ctx, Db *db); // end of db upload: the visit table (and which species it leaves to the node-block kernel)
+int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload, after trio_visits_build: the node-block run table of those species
 int node_haps_build(Ctx *ctx, Db *db);   // end of db upload: node -> haplotypes (the LP's membership masks built by node)
 bool use_node_haps(const Db *db);
 struct HostReads;

@@ -8,7 +8,7 @@
 // Layout (little endian, every section padded to 16 bytes):
 //   header  : "PTXHIPDB", u32 version, u32 flags (bit 0 = all walks identical), u64 V, H, P, U, L, u64 name_bytes
 //   node_len u32[V] | path_off u64[H+1] | path_nodes u32[P] | names ('\n'-joined) |
-//   trio_first u32[V+1] (local) | trio_ent {b, c, local row, 0} u32x4[U] | trio_abc u32[3U] | trio_hap u32[U] |
+//   trio_first u32[V+1] (local; CSR over the middle node) | trio_ent {smaller end, larger end, local row, 0} u32x4[U] | trio_abc u32[3U] | trio_hap u32[U] |
 //   trio_len u32[U] | hap_trio_off u64[H+1] (local) | u64 end marker = header checksum
 #include <algorithm>
 #include <cstdio>
@@ -23,7 +23,7 @@ namespace ptx {
 
 namespace {
 constexpr char MAGIC[8] = {'P', 'T', 'X', 'H', 'I', 'P', 'D', 'B'};
-constexpr uint32_t VERSION = 1;
+constexpr uint32_t VERSION = 2;   // 2: the lookup rows are filed under the window's MIDDLE node {smaller end, larger end, row} (1: under the smaller end)
 struct Header { char magic[8]; uint32_t version, flags; uint64_t V, H, P, U, L, name_bytes; };
 inline uint64_t pad16(uint64_t n) { return (n + 15) & ~uint64_t(15); }
 inline uint64_t header_sum(const Header &h) {

@@ -25,7 +25,7 @@
 // is bound by the number of divergent (one cache line per lane) vector-memory instructions, so the
 // tables it gathers from are packed into 16-byte records (one dwordx4 per lookup):
 //   read_rec[r] = {first step, #steps, pstart, pend}      node_rec[v] = {bit_off (u64), len, -}
-//   trio_node[v] = {first row, #rows}                      trio_ent[j] = {b, c, row, -}
+//   lookup head of node v (rides in node_rec) = {first row, #rows} of the unique windows whose MIDDLE is v;  trio_ent[j] = {smaller end, larger end, row, -}
 // A read that reaches this kernel was binned to its species, so every node id lies inside the
 // species' id range (rcls.rs:253-257) and the index panic of profile.rs:849 cannot occur; an
 // out-of-range id (inconsistent external binning) is counted as an abort per step instead.
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                                                         // travels beside the node record; under a pointer test the compiler waited for it first
         }
         // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as soon as the head is known
-        uint32_t i_[U], nl[U], len0[U], v1[U], nh[U], hx[U], tcc[U];
+        uint32_t i_[U], nl[U], len0[U], nh[U], hx[U], tlo[U], thi[U];
         uint4 e0[U], e1[U];
         bool live[U], single[U], dead_read[U];
 #pragma unroll
@@ -239,19 +239,18 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             ok[u] = ok[u] && act[u] != 0u;
             nl[u] = ok[u] ? nr[u].z : 0u;
             len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
-            v1[u] = wave_shr1(v[u]);
-            const uint32_t v2 = wave_shr1(v1[u]);
-            const uint32_t hw2 = wave_shr1(wave_shr1(nr[u].w)), hn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
+            const uint32_t v2 = wave_shr1(wave_shr1(v[u]));
+            const uint32_t hw1 = wave_shr1(nr[u].w), hn1 = wave_shr1(nr[u].y >> 8);   // the lookup head of the window's MIDDLE node: the lane below
             single[u] = rr[u].y == 1u;
             dead_read[u] = !single[u] && rr[u].z > len0[u];                   // assert :854 -> the whole read contributes nothing
             live[u] = ok[u] && !dead_read[u] && !(single[u] && rr[u].w < rr[u].z);   // :821-827
-            nh[u] = 0; hx[u] = 0; tcc[u] = 0;
+            nh[u] = 0; hx[u] = 0; tlo[u] = 0; thi[u] = 0;
             e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = e0[u];
             if (WITH_TRIO && !ABL(4u)) {
-                const bool lo_end = v[u] <= v2;                               // canonical window (min end, middle, max end): the head belongs to the smaller end
-                hx[u] = lo_end ? nr[u].w : hw2;
-                nh[u] = (live[u] && i_[u] >= 2u) ? (lo_end ? nr[u].y >> 8 : hn2) : 0u;
-                tcc[u] = lo_end ? v2 : v[u];
+                // canonical window (min end, middle, max end): the rows are filed under the MIDDLE node, keyed by the two ends
+                hx[u] = hw1;
+                nh[u] = (live[u] && i_[u] >= 2u) ? hn1 : 0u;
+                tlo[u] = min(v[u], v2); thi[u] = max(v[u], v2);
                 e0[u] = trio_ent[nh[u] ? hx[u] : 0u];
                 e1[u] = trio_ent[nh[u] > 1u ? hx[u] + 1u : 0u];
             }
@@ -295,12 +294,12 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             if (WITH_TRIO && !ABL(4u)) {                                      // :890-907
                 const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
                 int row = -1;
-                if (nh[u] && e0[u].x == v1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
-                else if (nh[u] > 1u && e1[u].x == v1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
+                if (nh[u] && e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (int)e0[u].z;
+                else if (nh[u] > 1u && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (int)e1[u].z;
                 else if (nh[u] > 2u)
                     for (uint32_t j = 2; j < nh[u]; ++j) {
                         const uint4 e = trio_ent[hx[u] + j];
-                        if (e.x == v1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
+                        if (e.x == tlo[u] && e.y == thi[u]) { row = (int)e.z; break; }
                     }
                 const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
                 if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
@@ -336,8 +335,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
 //     (-> a unique-trio entry where the node has any).  The slot record {species, node base - first id} is written by the
 //     binning pass; a binned walk lies inside its species' range and db_upload makes the range span exactly the graph, so a
 //     step places its node with ONE add and no range test; the node record carries the lookup head of the unique-trio index (first row, #rows)
-//     next to bit offset and length, and a 3-window whose smaller end is the node two steps back takes the head from that
-//     lane: ONE divergent 16-byte gather per step.  Everything is in global node indices (the lookup entries too).
+//     next to bit offset and length, and a 3-window takes the head of its middle node from the lane below:
+//     ONE divergent 16-byte gather per step.  Everything is in global node indices (the lookup entries too).
 //   * a step that covers its whole node (every interior step of a read: profile.rs:860-862 with :870-873) sets ONE flag for
 //     the node instead of marking its bits word by word (popcount_kernel then takes the node's length); only the partial
 //     ranges -- first and last step of a read -- are marked in the bit window, in 32-bit positions relative to the window.
@@ -432,7 +431,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             }
         }
         // ---- shuffles, the trio lookup head and the first trio entry (level 4), for all groups
-        uint32_t v1[U], v2[U], len0[U], tcc[U];
+        uint32_t v1[U], v2[U], len0[U], tlo[U], thi[U];
         uint2 th[U];
         uint4 e0[U], e1[U];   // the first TWO lookup entries of the head: with one, 95 % of the waves held a lane whose window was
                               // the node's second entry (8 % of the visits meet a head of two or more) and paid another dependent gather
@@ -448,18 +447,15 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             cross[u] = ok[u] && (int)i > lane;                        // the walk began before this wave (more than 64 steps)
             // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
             v1[u] = wave_shr1(v[u]); v2[u] = wave_shr1(v1[u]);
-            const uint32_t tf2 = wave_shr1(wave_shr1(nr[u].w)), tn2 = wave_shr1(wave_shr1(nr[u].y >> 8));
-            th[u] = make_uint2(0u, 0u); tcc[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t tf1 = wave_shr1(nr[u].w), tn1 = wave_shr1(nr[u].y >> 8);
+            th[u] = make_uint2(0u, 0u); tlo[u] = 0; thi[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
             if (WITH_TRIO && !ABL(4u) && ok[u] && i >= 2) {
                 if (lane < 1) v1[u] = node_id[b + i - 1] + sr[u].y;
                 if (lane < 2) v2[u] = node_id[b + i - 2] + sr[u].y;
-                // canonical window (min end, middle, max end); the lookup head belongs to the smaller end node
-                if (v[u] <= v2[u]) { th[u] = make_uint2(nr[u].w, nr[u].y >> 8); tcc[u] = v2[u]; }
-                else {
-                    tcc[u] = v[u];
-                    if (lane >= 2) th[u] = make_uint2(tf2, tn2);
-                    else { const uint4 r2 = node_rec[v2[u]]; th[u] = make_uint2(r2.w, r2.y >> 8); }   // wave border of a long walk
-                }
+                // canonical window (min end, middle, max end); the lookup rows are filed under the MIDDLE node (the lane below), keyed by the two ends
+                tlo[u] = min(v[u], v2[u]); thi[u] = max(v[u], v2[u]);
+                if (lane >= 1) th[u] = make_uint2(tf1, tn1);
+                else { const uint4 r1 = node_rec[v1[u]]; th[u] = make_uint2(r1.w, r1.y >> 8); }   // wave border of a long walk
                 if (th[u].y) e0[u] = trio_ent[th[u].x];
                 if (th[u].y > 1) e1[u] = trio_ent[th[u].x + 1];
             }
@@ -537,12 +533,12 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, node_rec, len0[u], ps);
                     int row = -1;
                     if (th[u].y) {
-                        if (e0[u].x == v1[u] && e0[u].y == tcc[u]) row = (int)e0[u].z;
-                        else if (th[u].y > 1 && e1[u].x == v1[u] && e1[u].y == tcc[u]) row = (int)e1[u].z;
+                        if (e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (int)e0[u].z;
+                        else if (th[u].y > 1 && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (int)e1[u].z;
                         else
                             for (uint32_t j = 2; j < th[u].y; ++j) {
                                 const uint4 e = trio_ent[th[u].x + j];
-                                if (e.x == v1[u] && e.y == tcc[u]) { row = (int)e.z; break; }
+                                if (e.x == tlo[u] && e.y == thi[u]) { row = (int)e.z; break; }
                             }
                     }
                     if (row >= 0) {

@@ -7,9 +7,9 @@
 // a unique trio has exactly one owner, so an owner index per row carries the same information.
 //
 // Device plan (all species of the db in one batch; no sort needed):
-//   1. count windows per smallest-end node a (global node index)              [4P in, atomics on 4V]
+//   1. count windows per MIDDLE node b (global node index)                     [4P in, atomics on 4V]
 //   2. exclusive scan -> bucket offsets; scatter (q, b, c) into the buckets      [4P in, 12P out]
-//   3. a window is unique iff no other entry of its (short) bucket has the same (b,c)
+//   3. a window is unique iff no other entry of its (short) bucket has the same two ends (a,c)
 //   4. exclusive scan of uniq_q over q -> row number in (species, hap, position) order
 //   5. per-node counts of unique windows -> CSR lookup arrays (trio_first, trio_bc, trio_row)
 //   6. fill the row-order arrays (abc, hap, len) and hap_trio_off
@@ -40,17 +40,20 @@ namespace ptx {
     const uint64_t qt0__ = pad__ ? 0ull : path_off[h] + (uint64_t)tile__.y * PATH_TILE; \
     for (uint64_t q = qt0__ + threadIdx.x; q < qt0__ + PATH_TILE && q < qend; q += 256)
 
-// canonical window at q of hap h (profile.rs:672-678); false if q starts no window
+// canonical window that STARTS at q of hap h (profile.rs:672-678: the ends are swapped when w[0] > w[2], the middle stays):
+// (a, b, c) = (smaller end, middle, larger end); false if q starts no window.  Every occurrence of a window -- either
+// orientation, any haplotype -- has the same MIDDLE node, so g = the global index of b is the key every table of this file is
+// grouped by (round 4; rounds 1-3 grouped by the smaller end, which made a position own up to two windows).
 __device__ __forceinline__ bool window_of(uint64_t q, uint64_t qend, uint32_t nb, const uint32_t *__restrict__ path_nodes, uint32_t &g,
                                           uint32_t &a, uint32_t &b, uint32_t &c) {
     if (q + 2 >= qend) return false;
     a = path_nodes[q]; b = path_nodes[q + 1]; c = path_nodes[q + 2];
     if (a > c) { uint32_t t = a; a = c; c = t; }
-    g = nb + a;
+    g = nb + b;
     return true;
 }
 
-// 1. bucket sizes: windows per smallest-end node
+// 1. bucket sizes: windows per middle node
 __global__ void __launch_bounds__(256) trio_count_kernel(TRIO_GRAPH_ARGS, uint32_t *__restrict__ cnt) {
     TILE_LOOP(q, h, qend) {
         const uint32_t nb = node_base[hap_species[h]];
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(256) trio_fill_kernel(TRIO_GRAPH_ARGS, const u
         uint32_t g, a, b, c;
         if (!window_of(q, qend, nb, path_nodes, g, a, b, c)) continue;
         uint32_t slot = bucket_off[g] + atomicAdd(&cursor[g], 1u);
-        bucket[slot] = make_uint4((uint32_t)q, b, c, g);   // one 16-byte record per window
+        bucket[slot] = make_uint4((uint32_t)q, a, c, g);   // one 16-byte record per window: {start position, smaller end, larger end, middle}
     }
 }
 // 3. a window is unique iff no other window of its bucket has the same (b,c): count == 1 (profile.rs:688-709).
@@ -176,15 +179,16 @@ __global__ void __launch_bounds__(256) trio_uniq_lds_kernel(uint64_t n_win, uint
         if (t < n && s_cnt[my_slot[k]] == 1u) { uniq_mark(uniq_q, my_q[k]); atomicAdd(&first_cnt[s_g[t]], 1u); }
     }
 }
-// 3''. THE DEFAULT: uniqueness by node block, no global scatter at all.  Every species' nodes are cut into blocks of
+// 3''. Uniqueness by node block, no global scatter (round 2's default; since round 4 the path of species that hold a node with
+//      more than 64 visits -- everything else goes through the visit table below).  Every species' nodes are cut into blocks of
 //      TRIO_BLK consecutive local ids; the walks were cut at upload into runs of consecutive positions inside one block
-//      (trio_runs_build below).  A window is OWNED by the position that holds its canonical smallest end a
-//      (profile.rs:672-678: a = w[0] unless w[0] > w[2]): position p owns (p, p+1, p+2) when n[p] <= n[p+2] and
-//      (p-2, p-1, p) when n[p] < n[p-2].  So the workgroup of a block meets EVERY occurrence of every window whose a lies
-//      in the block -- all haplotypes, both orientations -- and count_per_trio == 1 (profile.rs:688-709) is decided in an
-//      LDS hash table keyed by (a - block start, b, c) packed into 64 bits.  Collinear haplotypes collapse in LDS; HBM sees
-//      the walks once (4P) and one byte per UNIQUE window.  A block whose distinct windows overflow the table is redone
-//      in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences of a key fall into the same class).
+//      (trio_runs_build below).  A window is OWNED by the position of its MIDDLE node: position p owns (p-1, p, p+1), whose
+//      canonical key is (min(n[p-1], n[p+1]), n[p], max(..)) (profile.rs:672-678) in either orientation.  So the wave of a block
+//      meets EVERY occurrence of every window whose middle lies in the block -- all haplotypes -- and count_per_trio == 1
+//      (profile.rs:688-709) is decided in an LDS hash table keyed by (middle - block start, smaller end, larger end) packed into
+//      64 bits.  Collinear haplotypes collapse in LDS; HBM sees the walks once (4P) and one bit per UNIQUE window.  A block whose
+//      distinct windows overflow the table is redone in 2, 4, ... sub-passes over disjoint key classes (exact: all occurrences
+//      of a key fall into the same class).
 constexpr int TRIO_BLK_SHIFT = 6, TRIO_BLK = 1 << TRIO_BLK_SHIFT;
 constexpr unsigned long long TB_EMPTY = ~0ull;
 constexpr uint32_t TB_MULTI = 0xFFFFFFFFu;
@@ -213,7 +217,8 @@ __device__ __forceinline__ void tb_insert(unsigned long long *s_key, uint32_t *s
 // ONE WAVE per block of TRIO_BLK nodes (a workgroup is one wave: no workgroup barrier anywhere, two dozen independent
 // waves per CU hide each other's trips to memory; a 256-thread workgroup per 256-node block spent most of its life in
 // barriers and fixed overhead).  blk_rec[gb] = {first run, end run, global index of the block's first node, its
-// species-local id}; entry n_blocks closes the table (a block's node count is the distance to the next block's first node).
+// species-local id / 64 | the block's node count << 24} (the blocks of one launch need not be neighbours: only the species the
+// visit table leaves to this kernel have any).
 template <int TB_SLOTS>
 __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict__ blk_rec, const uint4 *__restrict__ runs,
                                                         const uint32_t *__restrict__ path_nodes, uint32_t *__restrict__ uniq_q,
@@ -222,8 +227,8 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
     __shared__ uint32_t s_q[TB_SLOTS], s_ncnt[TRIO_BLK], s_over, s_pref[64];
     __shared__ uint4 s_run[64];
     const uint4 rec = blk_rec[blockIdx.x];
-    const uint32_t nn = blk_rec[blockIdx.x + 1].z - rec.z;
-    const uint32_t r0 = rec.x, r1 = rec.y, n0 = rec.w;
+    const uint32_t nn = rec.w >> 24;                                    // nodes of the block (the last block of a species holds fewer than 64)
+    const uint32_t r0 = rec.x, r1 = rec.y, n0 = (rec.w & 0xFFFFFFu) << TRIO_BLK_SHIFT;
     const uint32_t lane = threadIdx.x;
     for (uint32_t nsub = 1;; nsub <<= 1) {
         s_ncnt[lane] = 0;
@@ -244,13 +249,13 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                 __syncthreads();
                 uint32_t lo_carry = 0;   // run of the last flat index handed out so far: the indices only grow, so does the run
                 for (uint32_t idx0 = lane; idx0 < total; idx0 += 64 * TB_UNR) {
-                    uint32_t x[TB_UNR], pp[TB_UNR], b1[TB_UNR], c1[TB_UNR], b2[TB_UNR], c2[TB_UNR];
-                    bool fw[TB_UNR], bw[TB_UNR];
+                    uint32_t x[TB_UNR], pp[TB_UNR], b1[TB_UNR], c1[TB_UNR];
+                    bool md[TB_UNR];
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
                         const uint32_t idx = idx0 + u * 64;
-                        fw[u] = bw[u] = false;
-                        x[u] = pp[u] = b1[u] = c1[u] = b2[u] = c2[u] = 0u;
+                        md[u] = false;
+                        x[u] = pp[u] = b1[u] = c1[u] = 0u;
                         uint32_t lo = lo_carry;
                         if (idx < total) {
                             // last run whose first flat index is <= idx: a short walk forward from the previous group's last run
@@ -261,16 +266,14 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
                             const uint32_t pos = rn.x + (idx - s_pref[lo]);
                             pp[u] = pos;
                             x[u] = path_nodes[pos];
-                            fw[u] = pos + 2 < rn.w; bw[u] = pos >= rn.z + 2;
-                            if (fw[u]) { b1[u] = path_nodes[pos + 1]; c1[u] = path_nodes[pos + 2]; }
-                            if (bw[u]) { b2[u] = path_nodes[pos - 1]; c2[u] = path_nodes[pos - 2]; }
+                            md[u] = pos > rn.z && pos + 1 < rn.w;     // the middle of a window: a neighbour on either side inside the walk
+                            if (md[u]) { b1[u] = path_nodes[pos - 1]; c1[u] = path_nodes[pos + 1]; }
                         }
                         lo_carry = __shfl(lo, 63);   // lane 63 holds the group's largest index (or, past the end, the carry itself)
                     }
 #pragma unroll
                     for (int u = 0; u < TB_UNR; ++u) {
-                        if (fw[u] && x[u] <= c1[u]) tb_insert<TB_SLOTS>(s_key, s_q, &s_over, x[u] - n0, b1[u], c1[u], pp[u], nsub - 1, j);
-                        if (bw[u] && x[u] < c2[u]) tb_insert<TB_SLOTS>(s_key, s_q, &s_over, x[u] - n0, b2[u], c2[u], pp[u] - 2, nsub - 1, j);
+                        if (md[u]) tb_insert<TB_SLOTS>(s_key, s_q, &s_over, x[u] - n0, min(b1[u], c1[u]), max(b1[u], c1[u]), pp[u] - 1, nsub - 1, j);   // flagged at the window's START
                     }
                 }
                 __syncthreads();   // s_run / s_pref are reused by the next 64 runs
@@ -291,19 +294,177 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
     if (lane < nn) first_cnt[rec.z + lane] = s_ncnt[lane];
 }
 
+// 3v. THE DEFAULT (round 4): uniqueness through the VISIT TABLE -- the walks transposed.  All occurrences of a window share
+//     its middle node b (window_of above), so count_per_trio == 1 (profile.rs:688-709) is a question about the visits of b:
+//     among all interior positions p with n[p] = b -- every haplotype of the species -- does the unordered pair
+//     {n[p-1], n[p+1]} occur exactly once?  The visit table (trio_visits_build, once at upload: a layout of the walks like
+//     the tile and run tables, the CSC to the walks' CSR) lists the interior positions node by node in groups of 64: a
+//     node's visits never straddle a group (pads fill the tail), so ONE WAVE holds every visit of the handful of nodes of its
+//     group and decides them with lane shifts: lane l compares its pair with the lanes 1, 2, ... below it inside its node's
+//     stretch -- no hash table, no LDS, no atomics on the way to the decision.  A step reads the table (4 B per visit) and
+//     gathers the three consecutive walk entries of every visit (collinear haplotypes: the lanes of one haplotype read
+//     neighbouring addresses, the lines are reused by the next groups of the wave).  A species that holds a node with more
+//     than 64 interior visits (more than 64 haplotypes, or walks that keep returning to a node) is left to the node-block
+//     kernel above; both write the same two outputs: one flag bit per window start and the count of unique windows per node.
+constexpr uint32_t VIS_PAD = 0xFFFFFFFFu;
+constexpr int VIS_MAX = 64;            // visits of a node that one wave decides
+constexpr int VIS_CHUNK_SHIFT = 8;     // nodes per layout chunk (a chunk starts on a group border)
+struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
+
+template <int U>
+__global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
+                                                         const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
+                                                         uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t g0 = (blockIdx.x * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
+    for (uint32_t r = 0; r < rounds && g0 < NG; ++r, g0 += U) {
+        uint32_t q[U], nb[U];
+        uint64_t heads[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + (uint32_t)u < NG ? g0 + (uint32_t)u : g0;   // wave-uniform
+            q[u] = vis_pos[(uint64_t)g * 64 + lane];
+            heads[u] = vis_head[g]; nb[u] = vis_nbase[g];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // all U table loads leave before the first of them is waited for
+        U32x3 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            valid[u] = g0 + (uint32_t)u < NG && q[u] != VIS_PAD;
+            w[u] = *reinterpret_cast<const U32x3 *>(path_nodes + (valid[u] ? q[u] - 1u : 0u));   // an interior position: p - 1 and p + 1 exist
+        }
+        __builtin_amdgcn_sched_barrier(0);       // ... and all U gathers before the first decision
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t lo = min(w[u].x, w[u].z), hi = max(w[u].x, w[u].z);
+            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid[u]);
+            const unsigned long long hd = heads[u] & vmask;
+            // lanes whose stretch reaches at least d lanes down; d = 1: everyone but the heads
+            unsigned long long inb = vmask & ~hd, dup = 0ull;
+            uint32_t slo = lo, shi = hi;
+            for (int d = 1; inb; ++d) {
+                slo = wave_shr1z(slo); shi = wave_shr1z(shi);               // the pair of the lane d below (DPP moves)
+                const unsigned long long eq = __builtin_amdgcn_ballot_w64(slo == lo) & __builtin_amdgcn_ballot_w64(shi == hi) & inb;
+                dup |= eq | (eq >> d);                                       // both partners are not unique
+                inb &= ~(hd << d);                                           // the lane d above a head has no lane d + 1 below it in its stretch
+            }
+            const unsigned long long uq = vmask & ~dup;
+            if ((uq >> lane) & 1ull) uniq_mark(uniq_q, q[u] - 1u);          // flagged at the window's start
+            if ((hd >> lane) & 1ull) {                                      // the head lane stores its node's count of unique windows
+                const unsigned long long he = hd | (~vmask & (vmask + 1ull));   // the first pad lane closes the last stretch (pads sit at the tail)
+                const unsigned long long above = he & ~((2ull << lane) - 1ull);
+                const int end = above ? __builtin_ctzll(above) : 64;
+                const unsigned long long m = (end == 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
+                first_cnt[nb[u] + w[u].y] = (uint32_t)__popcll(uq & m);
+            }
+        }
+    }
+}
+
+// ---- the visit table (upload time; a function of the graphs alone) ----
+// interior visits per node (a position with a neighbour on either side inside its walk is the middle of one window)
+__global__ void __launch_bounds__(256) visit_count_kernel(TRIO_GRAPH_ARGS, uint32_t *__restrict__ cnt) {
+    TILE_LOOP(q, h, qend) {
+        if (q > path_off[h] && q + 1 < qend) atomicAdd(&cnt[node_base[hap_species[h]] + path_nodes[q]], 1u);
+    }
+}
+// visited[v] = the node has a visit (its count is stored by every build; the others read as zero), slow[s] = the species holds a
+// node with more than VIS_MAX visits
+__global__ void __launch_bounds__(256) visit_flags_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ cnt,
+                                                          uint32_t *__restrict__ visited, uint32_t *__restrict__ slow) {
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = v < V ? cnt[v] : 0u;
+    const unsigned long long bal = __ballot(c != 0u);
+    if ((threadIdx.x & 31) == 0 && v < V + 32) visited[v >> 5] = (uint32_t)(bal >> (threadIdx.x & 32));
+    if (c > (uint32_t)VIS_MAX) {
+        uint32_t lo = 0, hi = S;                                             // last s with node_base[s] <= v
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)node_base[mid] <= v) lo = mid; else hi = mid; }
+        slow[lo] = 1u;
+    }
+}
+// one thread packs the nodes of a chunk {first node, end node, node base of the species} into groups of 64 visits
+__global__ void __launch_bounds__(256) visit_layout_kernel(uint32_t NC, const uint4 *__restrict__ chunks, const uint32_t *__restrict__ cnt,
+                                                           uint32_t *__restrict__ chunk_groups) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= NC) return;
+    const uint4 ch = chunks[c];
+    uint32_t pos = 0;
+    for (uint32_t v = ch.x; v < ch.y; ++v) {
+        const uint32_t k = cnt[v];
+        if (!k) continue;
+        if ((pos & 63u) + k > 64u) pos = (pos + 63u) & ~63u;
+        pos += k;
+    }
+    chunk_groups[c] = (pos + 63u) >> 6;
+}
+__global__ void __launch_bounds__(256) visit_place_kernel(uint32_t NC, const uint4 *__restrict__ chunks, const uint32_t *__restrict__ cnt,
+                                                          const uint32_t *__restrict__ chunk_gbase, uint32_t *__restrict__ vslot,
+                                                          unsigned long long *__restrict__ head, uint32_t *__restrict__ gnbase) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= NC) return;
+    const uint4 ch = chunks[c];
+    const uint32_t base = chunk_gbase[c] << 6;
+    uint32_t pos = 0;
+    for (uint32_t v = ch.x; v < ch.y; ++v) {
+        const uint32_t k = cnt[v];
+        if (!k) continue;
+        if ((pos & 63u) + k > 64u) pos = (pos + 63u) & ~63u;
+        const uint32_t slot = base + pos;
+        vslot[v] = slot;
+        atomicOr(&head[slot >> 6], 1ull << (slot & 63u));
+        gnbase[slot >> 6] = ch.z;
+        pos += k;
+    }
+}
+__global__ void __launch_bounds__(256) visit_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ slow, const uint32_t *__restrict__ vslot,
+                                                         uint32_t *__restrict__ cnt /* counted back down to zero */, uint32_t *__restrict__ vis_pos) {
+    TILE_LOOP(q, h, qend) {
+        const uint32_t sp = hap_species[h];
+        if (slow[sp] || !(q > path_off[h] && q + 1 < qend)) continue;
+        const uint32_t g = node_base[sp] + path_nodes[q];
+        vis_pos[vslot[g] + atomicSub(&cnt[g], 1u) - 1u] = (uint32_t)q;
+    }
+}
+// the visits of every node in ascending position (the fill's atomics left them in arrival order): the table -- and with it the
+// order of a node's lookup rows -- is the same on every upload.  One wave per group, ranks by shuffles inside the node's stretch.
+__global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head) {
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= NG) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
+    const bool valid = q != VIS_PAD;
+    const unsigned long long vmask = __ballot(valid), hd = vis_head[g] & vmask;
+    const unsigned long long he = hd | (~vmask & (vmask + 1ull));
+    const unsigned long long upto = hd & ((2ull << lane) - 1ull), above = he & ~((2ull << lane) - 1ull);
+    const int start = upto ? 63 - __builtin_clzll(upto) : lane, end = above ? __builtin_ctzll(above) : 64;
+    int rank = 0;
+    for (int d = 1; d < 64; ++d) {
+        const bool dn = valid && lane - d >= start, up = valid && lane + d < end;
+        if (!__any(dn || up)) break;
+        const uint32_t a = __shfl(q, (lane - d) & 63), b = __shfl(q, (lane + d) & 63);
+        if (dn && a < q) ++rank;
+        if (up && b < q) ++rank;
+    }
+    if (valid) vis_pos[(uint64_t)g * 64 + start + rank] = q;   // every lane holds its value already: the stretch is rewritten in place
+}
+
 // The run table (upload time, depends on the graphs only): heads = positions whose node lies in another block than their
 // predecessor's (or that start a walk); counted per block, scanned, then every head measures its run and files it.
-__global__ void __launch_bounds__(256) run_count_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ blk_base, uint32_t *__restrict__ blk_cnt) {
+__global__ void __launch_bounds__(256) run_count_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ slow, const uint32_t *__restrict__ blk_base, uint32_t *__restrict__ blk_cnt) {
     TILE_LOOP(q, h, qend) {
         const uint32_t sp = hap_species[h], x = path_nodes[q];
+        if (!slow[sp]) continue;                       // the visit table's species
         const bool head = q == path_off[h] || (path_nodes[q - 1] >> TRIO_BLK_SHIFT) != (x >> TRIO_BLK_SHIFT);
         if (head) atomicAdd(&blk_cnt[blk_base[sp] + (x >> TRIO_BLK_SHIFT)], 1u);
     }
 }
-__global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ blk_run_off,
+__global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ slow, const uint32_t *__restrict__ blk_base, const uint32_t *__restrict__ blk_run_off,
                                                        uint32_t *__restrict__ cursor, uint4 *__restrict__ runs) {
     TILE_LOOP(q, h, qend) {
         const uint32_t sp = hap_species[h], x = path_nodes[q], bx = x >> TRIO_BLK_SHIFT;
+        if (!slow[sp]) continue;
         const uint64_t qb = path_off[h];
         const bool head = q == qb || (path_nodes[q - 1] >> TRIO_BLK_SHIFT) != bx;
         if (!head) continue;
@@ -342,7 +503,7 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, c
     c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
     if (lane == 0) tile_cnt[tile_rank[t]] = c;
 }
-// 4b. one pass over the unique windows: lookup arrays (CSR over the first node: (b,c) + row number in path
+// 4b. one pass over the unique windows: lookup arrays (CSR over the MIDDLE node: the two ends (a,c) + row number in path
 //     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
 // KEYS: also the export copies in row order (canonical key, owner haplotype) that pantax_hip_trio_get and the db images hand
 // out; no stage of the step reads them (the key is in the lookup entry, the owner follows from hap_trio_off), so a step's
@@ -397,7 +558,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
         uint32_t g, a, b, c;
         window_of(q, qend, nbase, path_nodes, g, a, b, c);
         const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
-        trio_ent[j] = make_uint4(nbase + b, nbase + c, row, 0u);   // global node indices: the coverage pass works in them throughout
+        trio_ent[j] = make_uint4(nbase + a, nbase + c, row, 0u);   // the two ends (the head g is the middle); global node indices: the coverage pass works in them throughout
         if (KEYS) {
             abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
             hap_out[row] = h - (uint32_t)hap_off[sidx];
@@ -407,8 +568,16 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
 }
 
 // scan of the per-node unique-window counts that also writes the lookup heads {first row, #rows} (CSR over the
-// smallest end node) -- the prefix and its consumer in one launch
-struct TrioFirstLoad { const uint32_t *cnt; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return cnt[i]; } };
+// middle node) -- the prefix and its consumer in one launch
+// `visited` (visit-table / node-block builds): a node without an interior visit is the middle of no window and no kernel of the
+// build stores its count -- it reads as zero here instead of being zero-filled before every build (4V bytes)
+struct TrioFirstLoad {
+    const uint32_t *cnt, *visited;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+        if (visited && !((visited[i >> 5] >> (uint32_t)(i & 31ull)) & 1u)) return 0u;
+        return cnt[i];
+    }
+};
 struct TrioFirstStore {
     uint32_t *first;
     uint4 *node_rec;   // the head {first row, #rows} rides in the node record the coverage kernel gathers anyway
@@ -436,19 +605,94 @@ __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint
     hap_trio_off[h] = (uint64_t)tile_base[hap_tile_off[h]];   // entry n_tiles of the scan = total
 }
 
+// The visit table (end of db upload).  Counting sort of the interior positions by their node: count -> which species stay
+// with the node-block kernel -> greedy packing of every 256-node chunk into groups of 64 visits (one thread per chunk; a
+// chunk starts on a group border, so the chunks pack independently) -> scan of the chunk sizes -> place -> fill -> sort.
+int trio_visits_build(Ctx *ctx, Db *db) {
+    db->trio_visit_ok = false;
+    db->n_vgroups = 0;
+    db->h_trio_slow.assign(db->S, 1);          // until shown otherwise every species is the node-block kernel's
+    const char *ev = std::getenv("PANTAX_TRIO_PATH");
+    const bool force_block = ev && ev[0] == 'b' && ev[1] == 'l';   // "block": every species through the node-block kernel (tests, measurements)
+    PTX_HIP(ctx, db->d_trio_slow.alloc(db->S ? db->S : 1));
+    PTX_HIP(ctx, hipMemsetAsync(db->d_trio_slow.p, 0, (db->S ? db->S : 1) * sizeof(uint32_t), ctx->stream));
+    PTX_HIP(ctx, db->d_node_visited.alloc(db->V / 32 + 2));
+    PTX_HIP(ctx, hipMemsetAsync(db->d_node_visited.p, 0, (db->V / 32 + 2) * sizeof(uint32_t), ctx->stream));
+    auto all_slow = [&]() -> int {
+        std::vector<uint32_t> ones(db->S ? db->S : 1, 1u);
+        PTX_TRY(upload(ctx, db->d_trio_slow, ones.data(), ones.size()));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    if (db->P == 0 || db->P >= 0xFFFFFFFFull || db->V == 0 || db->S == 0) return all_slow();
+    DevBuf<uint32_t> cnt, vslot, chunk_groups, chunk_gbase, scan_tmp, tot;
+    PTX_HIP(ctx, cnt.alloc(db->V + 1));
+    PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, (db->V + 1) * sizeof(uint32_t), ctx->stream));
+#define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
+    const dim3 tgrid((uint32_t)db->n_tiles);
+    hipLaunchKernelGGL(visit_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, cnt.p);
+    hipLaunchKernelGGL(visit_flags_kernel, dim3((uint32_t)((db->V + 256) / 256)), dim3(256), 0, ctx->stream, db->V, db->S, db->d_node_base.p, cnt.p,
+                       db->d_node_visited.p, db->d_trio_slow.p);
+    std::vector<uint32_t> slow(db->S);
+    PTX_TRY(download(ctx, slow.data(), db->d_trio_slow.p, db->S));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint4> chunks;
+    for (uint32_t s = 0; s < db->S; ++s) {
+        if (force_block) slow[s] = 1u;
+        if (slow[s]) continue;
+        for (uint64_t v = db->h_node_off[s]; v < db->h_node_off[s + 1]; v += (1u << VIS_CHUNK_SHIFT))
+            chunks.push_back(make_uint4((uint32_t)v, (uint32_t)std::min<uint64_t>(v + (1u << VIS_CHUNK_SHIFT), db->h_node_off[s + 1]), (uint32_t)db->h_node_off[s], 0u));
+    }
+    const uint32_t NC = (uint32_t)chunks.size();
+    if (NC == 0) return all_slow();
+    DevBuf<uint4> d_chunks;
+    PTX_TRY(upload(ctx, d_chunks, chunks.data(), chunks.size()));
+    PTX_HIP(ctx, chunk_groups.alloc(NC + 1)); PTX_HIP(ctx, chunk_gbase.alloc(NC + 1));
+    PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NC + 1))); PTX_HIP(ctx, tot.alloc(1));
+    PTX_HIP(ctx, hipMemsetAsync(chunk_groups.p + NC, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(visit_layout_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx->stream, NC, d_chunks.p, cnt.p, chunk_groups.p);
+    PTX_TRY(exclusive_scan_u32(ctx, chunk_groups.p, chunk_gbase.p, (uint64_t)NC + 1, scan_tmp.p, tot.p));
+    uint32_t NG = 0;
+    PTX_TRY(download(ctx, &NG, tot.p, 1));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((uint64_t)NG * 64 >= 0xFFFFFFFFull) return all_slow();   // slots are 32-bit
+    if (NG) {
+        PTX_HIP(ctx, db->d_vis_pos.alloc((uint64_t)NG * 64)); PTX_HIP(ctx, db->d_vis_head.alloc(NG)); PTX_HIP(ctx, db->d_vis_nbase.alloc(NG));
+        PTX_HIP(ctx, vslot.alloc(db->V));
+        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_pos.p, 0xFF, (uint64_t)NG * 64 * sizeof(uint32_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_head.p, 0, (uint64_t)NG * sizeof(uint64_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_nbase.p, 0, (uint64_t)NG * sizeof(uint32_t), ctx->stream));
+        PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
+        hipLaunchKernelGGL(visit_place_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx->stream, NC, d_chunks.p, cnt.p, chunk_gbase.p, vslot.p,
+                           reinterpret_cast<unsigned long long *>(db->d_vis_head.p), db->d_vis_nbase.p);
+        hipLaunchKernelGGL(visit_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_trio_slow.p, vslot.p, cnt.p, db->d_vis_pos.p);
+        hipLaunchKernelGGL(visit_sort_kernel, dim3((NG + 3) / 4), dim3(256), 0, ctx->stream, NG, db->d_vis_pos.p, db->d_vis_head.p);
+    } else PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
+#undef TRIO_GRAPH
+    PTX_HIP(ctx, hipGetLastError());
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the temporaries (and `slow`, `chunks`) go out of scope
+    for (uint32_t s = 0; s < db->S; ++s) db->h_trio_slow[s] = slow[s] ? 1 : 0;
+    db->n_vgroups = NG;
+    db->trio_visit_ok = true;
+    return 0;
+}
+
 int trio_runs_build(Ctx *ctx, Db *db) {
     db->trio_block_ok = false;
     db->n_blocks = 0; db->n_runs = 0;
     if (db->P == 0 || db->P >= 0xFFFFFFFFull) return 0;
     std::vector<uint32_t> blk_base(db->S + 1, 0);
     for (uint32_t s = 0; s < db->S; ++s) {
-        const uint64_t Vs = db->h_node_off[s + 1] - db->h_node_off[s];
+        const uint64_t Vs = db->h_trio_slow[s] ? db->h_node_off[s + 1] - db->h_node_off[s] : 0;   // blocks only where the visit table leaves a species to this path
         if (Vs >= (1ull << 27)) return 0;             // the packed LDS key holds 27-bit local ids: such a db keeps the bucket path
         const uint64_t nb = (uint64_t)blk_base[s] + ((Vs + TRIO_BLK - 1) >> TRIO_BLK_SHIFT);
         if (nb >= 0x7FFFFFFFull) return 0;
         blk_base[s + 1] = (uint32_t)nb;
     }
     const uint32_t NB = blk_base[db->S];
+    db->trio_block_ok = true;
+    if (NB == 0) return 0;                            // every species goes through the visit table
+    db->trio_block_ok = false;
     std::vector<uint32_t> blk_species(NB);
     for (uint32_t s = 0; s < db->S; ++s) std::fill(blk_species.begin() + blk_base[s], blk_species.begin() + blk_base[s + 1], s);
     PTX_TRY(upload(ctx, db->d_blk_base, blk_base.data(), db->S + 1));
@@ -461,13 +705,13 @@ int trio_runs_build(Ctx *ctx, Db *db) {
     PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2ull * (NB + 1) * sizeof(uint32_t), ctx->stream));
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
-    hipLaunchKernelGGL(run_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_blk_base.p, cnt.p);
+    hipLaunchKernelGGL(run_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_trio_slow.p, db->d_blk_base.p, cnt.p);
     PTX_TRY(exclusive_scan_u32(ctx, cnt.p, db->d_blk_run_off.p, (uint64_t)NB + 1, scan_tmp.p, tot.p));
     uint32_t h_tot = 0;
     PTX_TRY(download(ctx, &h_tot, tot.p, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PTX_HIP(ctx, db->d_runs.alloc(h_tot ? h_tot : 1));
-    hipLaunchKernelGGL(run_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_blk_base.p, db->d_blk_run_off.p, cnt.p + (NB + 1), db->d_runs.p);
+    hipLaunchKernelGGL(run_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_trio_slow.p, db->d_blk_base.p, db->d_blk_run_off.p, cnt.p + (NB + 1), db->d_runs.p);
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the temporaries go out of scope
@@ -479,7 +723,8 @@ int trio_runs_build(Ctx *ctx, Db *db) {
         for (uint32_t s = 0; s < db->S; ++s)
             for (uint32_t gb = blk_base[s]; gb < blk_base[s + 1]; ++gb) {
                 const uint32_t n0 = (gb - blk_base[s]) << TRIO_BLK_SHIFT;
-                rec[gb] = make_uint4(run_off[gb], run_off[gb + 1], (uint32_t)db->h_node_off[s] + n0, n0);
+                const uint32_t nn = (uint32_t)std::min<uint64_t>(TRIO_BLK, db->h_node_off[s + 1] - db->h_node_off[s] - n0);
+                rec[gb] = make_uint4(run_off[gb], run_off[gb + 1], (uint32_t)db->h_node_off[s] + n0, (gb - blk_base[s]) | (nn << 24));   // < 2^21 blocks per species (2^27 nodes)
             }
         rec[NB] = make_uint4(h_tot, h_tot, (uint32_t)db->V, 0u);
         PTX_TRY(upload(ctx, db->d_blk_rec, rec.data(), rec.size()));
@@ -498,13 +743,15 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     if (P >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu path steps exceed 32-bit positions", (unsigned long long)P);
     TrioScratch &ts = db->trio_scratch;
     const uint32_t NT = (uint32_t)db->n_tiles;
-    // which uniqueness path: by node block (default) or through global buckets (species of >= 2^27 nodes, or forced)
-    bool by_block = db->trio_block_ok;
+    // which uniqueness path: the visit table (default; species with a node of more than 64 visits: by node block), or through
+    // global buckets for the whole db (a species of >= 2^27 nodes among those left to the node-block kernel, or forced)
+    bool by_block = db->trio_block_ok && (db->trio_visit_ok || db->n_blocks);
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
     // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
-    // The node-block path zero-fills tile_cnt and the bits only: its kernel STORES every node's count (the blocks cover all
-    // nodes), the lookup pass counts them back down to zero in place of a cursor array, and cnt / cursor belong to the bucket
-    // path -- zero-filling is what this arena costs (0.4 GB a build at cfg3 when the flags were bytes and all of it was cleared).
+    // The visit-table / node-block path zero-fills tile_cnt and the bits only: its kernels STORE the count of every node that has
+    // a visit (the others read as zero through `d_node_visited`), the lookup pass counts them back down to zero in place of a cursor
+    // array, and cnt / cursor belong to the bucket path -- zero-filling is what this arena costs (0.4 GB a build at cfg3 when the
+    // flags were bytes and all of it was cleared).
     const size_t zbits = (P + 31) / 32 + 1, zhead = (NT + 1) + zbits, zwords = zhead + (V + 1) + (by_block ? 0 : 2 * (V + 1));
     PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
     ts.tile_cnt.view(ts.zero_arena.p, NT + 1);
@@ -523,7 +770,19 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
-    if (P && by_block) {
+    if (P && by_block && db->n_vgroups) {
+        KTimer t(ctx, "trio_visit_kernel");
+        // every wave walks U x rounds consecutive groups of 64 visits (PANTAX_TV_U / PANTAX_TV_ROUNDS pick another shape, for
+        // measurements): consecutive groups visit consecutive nodes, whose walk entries share cache lines
+        uint32_t U = 4, rounds = 4;
+        if (const char *ev = std::getenv("PANTAX_TV_U")) U = (uint32_t)std::atoi(ev);
+        if (const char *ev = std::getenv("PANTAX_TV_ROUNDS")) rounds = (uint32_t)std::max(1, std::atoi(ev));
+#define TV_LAUNCH(UU) hipLaunchKernelGGL(trio_visit_kernel<UU>, dim3((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds)), dim3(256), 0, ctx->stream, db->n_vgroups, \
+                                         rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p)
+        if (U == 1) TV_LAUNCH(1); else if (U == 2) TV_LAUNCH(2); else if (U == 8) TV_LAUNCH(8); else TV_LAUNCH(4);
+#undef TV_LAUNCH
+    }
+    if (P && by_block && db->n_blocks) {
         KTimer t(ctx, "trio_block_kernel");
         // LDS table slots per 64-node block (PANTAX_TB_SLOTS=512|256|128 picks another instantiation, for measurements): fewer
         // slots = more blocks resident per CU (the kernel is bound by the latency of each wave's dependent loads), more blocks
@@ -566,8 +825,8 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         hipLaunchKernelGGL(trio_tilecount_kernel, dim3((NT + 3) / 4), dim3(256), 0, ctx->stream, NT, db->d_tiles.p, db->d_path_off.p, db->d_tile_rank.p,
                            ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
-        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
-                                  "exclusive_scan"));
+        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, by_block ? db->d_node_visited.p : nullptr},
+                                  TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr, "exclusive_scan"));
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
@@ -595,7 +854,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
         // no walks at all: every lookup head is empty (first_cnt sits in the zeroed arena)
-        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
+        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, nullptr}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
                                   "exclusive_scan"));
     }
 #undef TRIO_GRAPH

@@ -65,6 +65,8 @@ __device__ __forceinline__ void wave_reduce_pair(A &a, B &b, Better better) {
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill = 0u) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
+// the same with a zero for lane 0 through bound_ctrl: no `old` operand, so a chain of shifts needs no register copies
+__device__ __forceinline__ uint32_t wave_shr1z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 // inclusive prefix sum over the 64 lanes on the DPP path: row_shr 1/2/4/8 inside the 16-lane rows (zero fill), then the
 // row totals travel by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  Wraps modulo 2^32 like the adds do.
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {

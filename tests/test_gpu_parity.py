@@ -104,11 +104,16 @@ def test_micro_coverage_golden(eng):
 
 @pytest.mark.parametrize("seed,S,H,R,L,uniq", [(1, 1, 4, 3000, 15000, None), (2, 3, 6, 20000, 40000, None), (3, 5, 10, 50000, 30000, None),
                                                   (4, 2, 40, 20000, 20000, None),   # > 16 windows per node: the hashed uniqueness test
-                                                  (2, 3, 6, 20000, 40000, "1"), (4, 2, 40, 20000, 20000, "0")])   # and each form forced
+                                                  (2, 3, 6, 20000, 40000, "1"), (4, 2, 40, 20000, 20000, "0"),   # and each form forced
+                                                  (2, 3, 6, 20000, 40000, "block"), (3, 5, 10, 50000, 30000, "block"), (4, 2, 40, 20000, 20000, "block")])
 def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch):
     from oracle import oracle as orc
     from pantax_amd import synth
-    if uniq is not None:   # default: uniqueness by node block in LDS; forced: the global bucket path with either of its kernels
+    # default: uniqueness through the visit table (species with a node of more than 64 visits: by node block in LDS); forced: every
+    # species by node block, or the global bucket path with either of its kernels
+    if uniq == "block":
+        monkeypatch.setenv("PANTAX_TRIO_PATH", "block")   # read by the library at db upload
+    elif uniq is not None:
         monkeypatch.setenv("PANTAX_TRIO_PATH", "bucket")
         monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)   # read by the library at every trio build
     sset = synth.make_set(seed, S, H, R, L, adversarial_frac=0.01, single_strain_every=4 if S >= 5 else 0)
@@ -199,12 +204,17 @@ def test_coverage_and_trio_index_vs_literal_python_restatement(eng, k):
     check_against_literal(j, names, abc, hap, ln, tb, bases, cov, nab + len(outside))
 
 
-@pytest.mark.parametrize("V,H,K", [(200, 40, 300), (700, 30, 500), (300, 3, 9000)])
-def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K):
+@pytest.mark.parametrize("path", ["block", None])
+@pytest.mark.parametrize("V,H,K", [(200, 40, 300), (700, 30, 500), (300, 3, 9000), (3000, 12, 4000)])
+def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K, path, monkeypatch):
     """Random walks over a few hundred nodes: a node block meets thousands of DISTINCT windows, more than its LDS table
     holds, so it is redone in sub-passes over key classes; walks jump between blocks at every step (runs of length 1)
-    and visit both orientations of the same window."""
+    and visit both orientations of the same window.  `path` None: whatever the upload chooses -- the visit table where no
+    node has more than 64 visits (700 x 30 x 500, 3000 x 12 x 4000: stretches of every length up to the limit, walks that
+    return to a node, windows with equal ends), the node-block kernel otherwise."""
     from oracle import oracle as orc
+    if path:
+        monkeypatch.setenv("PANTAX_TRIO_PATH", path)
     rng = np.random.default_rng(V + H)
     node_len = rng.integers(1, 40, size=V).astype(np.int64)
     walks = [rng.integers(0, V, size=K).astype(np.uint32) for _ in range(H)]
