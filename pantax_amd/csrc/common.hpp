@@ -231,6 +231,12 @@ struct TrioScratch {
     DevBuf<uint32_t> cnt, cursor, bucket_off, scan_tmp, first_cnt, d_tot, tile_cnt, tile_base;
     DevBuf<uint4> bucket;   // (q, b, c, global first node) per window
     DevBuf<uint32_t> uniq_q;       // one bit per path position: its window occurs once in the species
+    // rows filed from the visit kernel's records (a db the visit table covers whole)
+    DevBuf<uint64_t> vis_uq;       // [n_vgroups + 1] ballot of the unique visits of every group
+    DevBuf<uint4> vis_rec;         // [n_vgroups * 8] the first eight unique windows of every group {window start, smaller end, larger end, middle}
+    DevBuf<uint32_t> over_list;    // groups with more than eight
+    DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = slot of its first lookup row
+    DevBuf<uint32_t> word_base;    // [P / 32 + 2] flags before every word of uniq_q = row of the first window it flags
 };
 
 // ---- resident DB -----------------------------------------------------------------------------
@@ -291,6 +297,7 @@ struct Db {
     bool trio_built = false;
     bool trio_prefetched = false;   // pantax_hip_trio_index_prefetch built the index of the COMING step: that step's rebuild_trio is served by it
     bool trio_keys_built = false;   // d_trio_abc / d_trio_hap (row-order export copies) were written by the last build
+    bool trio_first_valid = false;  // d_trio_first holds the CSR offsets of the last build (trio_first_ensure derives them on request)
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
@@ -459,6 +466,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
+int trio_first_ensure(Ctx *ctx, Db *db); // d_trio_first (the db images store it)
 int trio_visits_build(Ctx *ctx, Db *db); // end of db upload: the visit table (and which species it leaves to the node-block kernel)
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload, after trio_visits_build: the node-block run table of those species
 int node_haps_build(Ctx *ctx, Db *db);   // end of db upload: node -> haplotypes (the LP's membership masks built by node)

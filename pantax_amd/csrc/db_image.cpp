@@ -90,6 +90,7 @@ int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &
     if (s >= db->S) return fail(ctx, PANTAX_HIP_E_INVALID, "db_save_image: species %u of %u", s, db->S);
     if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
     PTX_TRY(trio_keys_ensure(ctx, db));
+    PTX_TRY(trio_first_ensure(ctx, db));
     const uint64_t nb = db->h_node_off[s], ne = db->h_node_off[s + 1], h0 = db->h_hap_off[s], h1 = db->h_hap_off[s + 1];
     const uint64_t q0 = db->h_path_off[h0], q1 = db->h_path_off[h1], u0 = db->h_hap_trio_off[h0], u1 = db->h_hap_trio_off[h1];
     if (names.size() != h1 - h0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_save_image: %zu names for %llu haplotypes", names.size(), (unsigned long long)(h1 - h0));
@@ -189,6 +190,7 @@ int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *im, const in
     db->U = db->U_known = Utot;
     db->trio_sizes_known = true;
     db->trio_built = true;
+    db->trio_first_valid = true;
     db->trio_keys_built = true;
     db->cov_done = false;
     *out = db.release();

@@ -300,8 +300,9 @@ __global__ void __launch_bounds__(64) trio_block_kernel(const uint4 *__restrict_
 //     {n[p-1], n[p+1]} occur exactly once?  The visit table (trio_visits_build, once at upload: a layout of the walks like
 //     the tile and run tables, the CSC to the walks' CSR) lists the interior positions node by node in groups of 64: a
 //     node's visits never straddle a group (pads fill the tail), so ONE WAVE holds every visit of the handful of nodes of its
-//     group and decides them with lane shifts: lane l compares its pair with the lanes 1, 2, ... below it inside its node's
-//     stretch -- no hash table, no LDS, no atomics on the way to the decision.  A step reads the table (4 B per visit) and
+//     group; the visits of a node are kept sorted by their pair (an order of the table, like the order of an adjacency list), so
+//     equal pairs are neighbours and lane l decides its window by comparing its pair with the lanes l - 1 and l + 1 of its node's
+//     stretch -- no hash table, no LDS, no atomics, no loop on the way to the decision.  A step reads the table (4 B per visit) and
 //     gathers the three consecutive walk entries of every visit (collinear haplotypes: the lanes of one haplotype read
 //     neighbouring addresses, the lines are reused by the next groups of the wave).  A species that holds a node with more
 //     than 64 interior visits (more than 64 haplotypes, or walks that keep returning to a node) is left to the node-block
@@ -311,10 +312,25 @@ constexpr int VIS_MAX = 64;            // visits of a node that one wave decides
 constexpr int VIS_CHUNK_SHIFT = 8;     // nodes per layout chunk (a chunk starts on a group border)
 struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 
-template <int U>
+// -DTV_ABLATE builds (never the product library) read PANTAX_TV_ABLATE: bit 0 no flag atomics, bit 1 no count stores, bit 2 no
+// comparisons -- wrong results, for timing only
+#ifdef TV_ABLATE
+#define TV_ABL(bit) (ablate & (bit))
+#else
+#define TV_ABL(bit) false
+#endif
+// ROWS (a db that the visit table covers whole -- no species left to the node-block kernel): the wave also hands its unique windows
+// to trio_rows_kernel -- the group's ballot of unique visits and, for the first VIS_REC of them, a 16-byte record {window start, smaller
+// end, larger end, middle (global node indices)} -- instead of the per-node counts: the lookup rows are then filed in visit order, which
+// IS the order of a CSR over the middle node, by a scan over the groups' counts (a tenth of the nodes) and one pass over the records,
+// no scan over all nodes and no second pass over the walks.  Groups with more unique visits than records are listed in `over_list`.
+constexpr int VIS_REC = 8;
+template <int U, bool ROWS>
 __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                          const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
-                                                         uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt) {
+                                                         uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, uint32_t ablate,
+                                                         unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec, uint32_t *__restrict__ over_list,
+                                                         uint32_t *__restrict__ n_over) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t g0 = (blockIdx.x * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
@@ -341,18 +357,29 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
             const uint32_t lo = min(w[u].x, w[u].z), hi = max(w[u].x, w[u].z);
             const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid[u]);
             const unsigned long long hd = heads[u] & vmask;
-            // lanes whose stretch reaches at least d lanes down; d = 1: everyone but the heads
-            unsigned long long inb = vmask & ~hd, dup = 0ull;
-            uint32_t slo = lo, shi = hi;
-            for (int d = 1; inb; ++d) {
-                slo = wave_shr1z(slo); shi = wave_shr1z(shi);               // the pair of the lane d below (DPP moves)
-                const unsigned long long eq = __builtin_amdgcn_ballot_w64(slo == lo) & __builtin_amdgcn_ballot_w64(shi == hi) & inb;
-                dup |= eq | (eq >> d);                                       // both partners are not unique
-                inb &= ~(hd << d);                                           // the lane d above a head has no lane d + 1 below it in its stretch
-            }
+            // The visits of a node are SORTED by (smaller end, larger end) -- the table's order, fixed at upload -- so equal pairs sit in
+            // neighbouring lanes: a window occurs once iff its pair differs from the pair of the lane below AND of the lane above
+            // inside its node's stretch.  The order itself is checked on the way (a table that is not sorted is reported, never
+            // silently trusted): one DPP shift and three compares per visit, no loop over the stretch.
+            const unsigned long long inb = vmask & ~hd;                      // lanes with a lane of their own stretch below them
+            const uint32_t slo = wave_shr1z(lo), shi = wave_shr1z(hi);       // the pair of the lane below (DPP moves)
+            unsigned long long eq = __builtin_amdgcn_ballot_w64(slo == lo && shi == hi) & inb;
+            if (TV_ABL(4u)) eq = 0ull;
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(slo > lo || (slo == lo && shi > hi)) & inb;
+            if (bad && lane == 0) atomicAdd(err, 1u);
+            const unsigned long long dup = eq | (eq >> 1);                   // both partners are not unique
             const unsigned long long uq = vmask & ~dup;
-            if ((uq >> lane) & 1ull) uniq_mark(uniq_q, q[u] - 1u);          // flagged at the window's start
-            if ((hd >> lane) & 1ull) {                                      // the head lane stores its node's count of unique windows
+            if (((uq >> lane) & 1ull) && !TV_ABL(1u)) uniq_mark(uniq_q, q[u] - 1u);          // flagged at the window's start
+            if (ROWS) {
+                const uint32_t g = g0 + (uint32_t)u;
+                if (g < NG) {
+                    if (lane == 0) vis_uq[g] = uq;
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));   // unique visits in the lanes below
+                    if (((uq >> lane) & 1ull) && r < (uint32_t)VIS_REC && !TV_ABL(2u))
+                        vis_rec[(uint64_t)g * VIS_REC + r] = make_uint4(q[u] - 1u, nb[u] + lo, nb[u] + hi, nb[u] + w[u].y);
+                    if (__popcll(uq) > VIS_REC && lane == 0) over_list[atomicAdd(n_over, 1u)] = g;
+                }
+            } else if (((hd >> lane) & 1ull) && !TV_ABL(2u)) {                                      // the head lane stores its node's count of unique windows
                 const unsigned long long he = hd | (~vmask & (vmask + 1ull));   // the first pad lane closes the last stretch (pads sit at the tail)
                 const unsigned long long above = he & ~((2ull << lane) - 1ull);
                 const int end = above ? __builtin_ctzll(above) : 64;
@@ -427,14 +454,18 @@ __global__ void __launch_bounds__(256) visit_fill_kernel(TRIO_GRAPH_ARGS, const 
         vis_pos[vslot[g] + atomicSub(&cnt[g], 1u) - 1u] = (uint32_t)q;
     }
 }
-// the visits of every node in ascending position (the fill's atomics left them in arrival order): the table -- and with it the
-// order of a node's lookup rows -- is the same on every upload.  One wave per group, ranks by shuffles inside the node's stretch.
-__global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head) {
+// the visits of every node sorted by (smaller end, larger end, position) of their window (the fill's atomics left them in arrival
+// order): equal windows become neighbours, which is what trio_visit_kernel's two-neighbour test relies on -- and checks -- and the
+// table is the same on every upload.  One wave per group, ranks by shuffles inside the node's stretch.
+__global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
+                                                         const uint32_t *__restrict__ path_nodes) {
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= NG) return;
     const int lane = threadIdx.x & 63;
     const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
     const bool valid = q != VIS_PAD;
+    uint32_t lo = 0, hi = 0;
+    if (valid) { const uint32_t a = path_nodes[q - 1], c = path_nodes[q + 1]; lo = min(a, c); hi = max(a, c); }
     const unsigned long long vmask = __ballot(valid), hd = vis_head[g] & vmask;
     const unsigned long long he = hd | (~vmask & (vmask + 1ull));
     const unsigned long long upto = hd & ((2ull << lane) - 1ull), above = he & ~((2ull << lane) - 1ull);
@@ -443,9 +474,11 @@ __global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *
     for (int d = 1; d < 64; ++d) {
         const bool dn = valid && lane - d >= start, up = valid && lane + d < end;
         if (!__any(dn || up)) break;
-        const uint32_t a = __shfl(q, (lane - d) & 63), b = __shfl(q, (lane + d) & 63);
-        if (dn && a < q) ++rank;
-        if (up && b < q) ++rank;
+        const int ld = (lane - d) & 63, lu = (lane + d) & 63;
+        const uint32_t alo = __shfl(lo, ld), ahi = __shfl(hi, ld), aq = __shfl(q, ld);
+        const uint32_t blo = __shfl(lo, lu), bhi = __shfl(hi, lu), bq = __shfl(q, lu);
+        if (dn && (alo < lo || (alo == lo && (ahi < hi || (ahi == hi && aq < q))))) ++rank;
+        if (up && (blo < lo || (blo == lo && (bhi < hi || (bhi == hi && bq < q))))) ++rank;
     }
     if (valid) vis_pos[(uint64_t)g * 64 + start + rank] = q;   // every lane holds its value already: the stretch is rewritten in place
 }
@@ -598,6 +631,122 @@ struct TrioFirstStore {
     }
 };
 
+// ---- the rows of a db that the visit table covers whole (trio_visit_kernel<.., ROWS = true>) ----
+// rank of window start q among the unique windows in (species, hap, position) order = its row: the prefix of its flag word plus the
+// flags below it in the word
+struct FlagWordLoad { const uint32_t *bits; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popc(bits[i]); } };
+struct GroupCountLoad { const unsigned long long *uq; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popcll(uq[i]); } };
+struct PrefixStore { uint32_t *out; __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t) const { out[i] = excl; } };
+__device__ __forceinline__ uint32_t flag_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base, uint64_t q) {
+    return word_base[q >> 5] + (uint32_t)__popc(bits[q >> 5] & ((1u << (uint32_t)(q & 31ull)) - 1u));
+}
+// one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
+// length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
+template <bool KEYS>
+__device__ __forceinline__ void trio_row_emit(const uint4 rec, uint32_t slot, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base,
+                                              const uint32_t *__restrict__ node_len, uint32_t nbase, uint32_t H, const uint64_t *__restrict__ path_off,
+                                              const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ trio_ent,
+                                              uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
+    const uint32_t row = flag_rank(bits, word_base, rec.x);
+    trio_ent[slot] = make_uint4(rec.y, rec.z, row, 0u);
+    len_out[row] = node_len[rec.y] + node_len[rec.w] + node_len[rec.z];
+    if (KEYS) {
+        abc[3ull * row] = rec.y - nbase; abc[3ull * row + 1] = rec.w - nbase; abc[3ull * row + 2] = rec.z - nbase;
+        uint32_t lo = 0, hi = H;                                             // the walk that holds position rec.x: last h with path_off[h] <= q
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= (uint64_t)rec.x) lo = mid; else hi = mid; }
+        hap_out[row] = lo - (uint32_t)hap_off[hap_species[lo]];
+    }
+}
+// the lookup head of a node = {slot of its first row, number of its rows}, written into the node record by the lane that holds the
+// node's first unique window (records arrive in visit order: a node's windows are neighbours); `cnt` = rows of this node
+__device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t slot, uint32_t cnt, uint32_t *__restrict__ err) {
+    if (cnt >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+    uint4 r = node_rec[v];
+    r.y = (r.y & 0xFFu) | (cnt << 8);
+    r.w = slot;
+    node_rec[v] = r;
+}
+// EIGHT groups per wave, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
+// one coalesced kilobyte per wave; the slot of record r of group g is the scan of the groups' counts + r
+template <bool KEYS>
+__global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
+                                                        const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase,
+                                                        const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base,
+                                                        const uint32_t *__restrict__ node_len, uint32_t H, const uint64_t *__restrict__ path_off,
+                                                        const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec,
+                                                        uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
+                                                        uint32_t *__restrict__ len_out, uint32_t *__restrict__ err) {
+    static_assert(VIS_REC == 8, "eight lanes per group");
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + ((uint32_t)lane >> 3), r = (uint32_t)lane & 7u;
+    uint32_t cnt = 0;
+    if (g < NG) cnt = (uint32_t)__popcll(vis_uq[g]);
+    const bool on = cnt <= (uint32_t)VIS_REC && r < cnt;                     // an overflowing group is trio_rows_over_kernel's, whole
+    uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+    uint32_t slot = 0;
+    if (on) { rec = vis_rec[(uint64_t)g * VIS_REC + r]; slot = gprefix[g] + r; }
+    // first record of its node: the record below belongs to another node (or to another group)
+    const uint32_t below = wave_shr1(rec.w, 0xFFFFFFFFu);
+    const bool first = on && (r == 0u || below != rec.w);
+    const unsigned long long fm = __ballot(first), om = __ballot(on);
+    if (on) trio_row_emit<KEYS>(rec, slot, bits, word_base, node_len, vis_nbase[g], H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+    if (first) {
+        // rows of the node: up to the next first record, or to the end of the group's records
+        const unsigned long long grp = 0xFFull << (lane & ~7), stop = (fm | ~om) & grp & ~((2ull << lane) - 1ull);
+        const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
+        trio_head_store(node_rec, rec.w, slot, (uint32_t)(end - lane), err);
+    }
+}
+// a group with more than VIS_REC unique visits (a stretch of private sequence; every group of a single-strain species): one wave per
+// listed group reads the visits again, compacts the unique ones by their rank, and files them like the records
+template <bool KEYS>
+__global__ void __launch_bounds__(256) trio_rows_over_kernel(const uint32_t *__restrict__ n_over, const uint32_t *__restrict__ over_list,
+                                                             const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
+                                                             const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase,
+                                                             const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ bits,
+                                                             const uint32_t *__restrict__ word_base, const uint32_t *__restrict__ node_len, uint32_t H,
+                                                             const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ hap_species,
+                                                             const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec, uint4 *__restrict__ trio_ent,
+                                                             uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
+                                                             uint32_t *__restrict__ err) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = *n_over;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += gridDim.x * 4u) {
+        const uint32_t g = over_list[i];
+        const unsigned long long uq = vis_uq[g];
+        const uint32_t nb = vis_nbase[g];
+        const bool mine = (uq >> lane) & 1ull;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+        if (mine) {
+            const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
+            const uint32_t a = path_nodes[q - 1], b = path_nodes[q], c = path_nodes[q + 1];
+            rec = make_uint4(q - 1u, nb + min(a, c), nb + max(a, c), nb + b);
+        }
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));
+        // first unique visit of its node: the unique lane below holds another node (the visits of a node are neighbours)
+        const unsigned long long lower = uq & ((1ull << lane) - 1ull);
+        const uint32_t prev_w = __shfl(rec.w, lower ? 63 - __builtin_clzll(lower) : lane);
+        const bool first = mine && (!lower || prev_w != rec.w);
+        const unsigned long long fm = __ballot(first);
+        if (mine) trio_row_emit<KEYS>(rec, gprefix[g] + r, bits, word_base, node_len, nb, H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+        if (first) {
+            const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);     // the node's rows end at the next first lane
+            const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
+            trio_head_store(node_rec, rec.w, gprefix[g] + r, (uint32_t)__popcll(span), err);
+        }
+    }
+}
+// hap_trio_off[h] = rows before the first position of haplotype h (entry H: all rows)
+__global__ void __launch_bounds__(256) trio_hapoff_rank_kernel(uint32_t H, const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ bits,
+                                                               const uint32_t *__restrict__ word_base, uint64_t *__restrict__ hap_trio_off) {
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h > H) return;
+    hap_trio_off[h] = (uint64_t)flag_rank(bits, word_base, path_off[h]);
+}
+// the plain CSR offsets over the middle node (db images keep them; no stage of a step reads them): a scan of the row counts that
+// ride in the node records
+struct HeadCountLoad { const uint4 *node_rec; uint64_t V; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < V ? node_rec[i].y >> 8 : 0u; } };
+
 __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint32_t *__restrict__ hap_tile_off, const uint32_t *__restrict__ tile_base,
                                                           uint64_t *__restrict__ hap_trio_off) {
     uint32_t h = blockIdx.x * 256 + threadIdx.x;
@@ -666,7 +815,7 @@ int trio_visits_build(Ctx *ctx, Db *db) {
         hipLaunchKernelGGL(visit_place_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx->stream, NC, d_chunks.p, cnt.p, chunk_gbase.p, vslot.p,
                            reinterpret_cast<unsigned long long *>(db->d_vis_head.p), db->d_vis_nbase.p);
         hipLaunchKernelGGL(visit_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_trio_slow.p, vslot.p, cnt.p, db->d_vis_pos.p);
-        hipLaunchKernelGGL(visit_sort_kernel, dim3((NG + 3) / 4), dim3(256), 0, ctx->stream, NG, db->d_vis_pos.p, db->d_vis_head.p);
+        hipLaunchKernelGGL(visit_sort_kernel, dim3((NG + 3) / 4), dim3(256), 0, ctx->stream, NG, db->d_vis_pos.p, db->d_vis_head.p, db->d_path_nodes.p);
     } else PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
@@ -747,6 +896,10 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     // global buckets for the whole db (a species of >= 2^27 nodes among those left to the node-block kernel, or forced)
     bool by_block = db->trio_block_ok && (db->trio_visit_ok || db->n_blocks);
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
+    // a db the visit table covers whole files its rows from the visit kernel's records (trio_rows_kernel); with a species left to the
+    // node-block kernel -- or PANTAX_TRIO_ROWS=path -- the rows are filed by the pass over the walks (trio_lookup_kernel) as in rounds 1-3
+    bool rows_by_visit = by_block && P && db->n_vgroups && db->n_blocks == 0;
+    if (const char *ev = std::getenv("PANTAX_TRIO_ROWS")) { if (ev[0] == 'p') rows_by_visit = false; }
     // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
     // The visit-table / node-block path zero-fills tile_cnt and the bits only: its kernels STORE the count of every node that has
     // a visit (the others read as zero through `d_node_visited`), the lookup pass counts them back down to zero in place of a cursor
@@ -758,15 +911,20 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     ts.uniq_q.view(ts.zero_arena.p + (NT + 1), zbits);
     ts.first_cnt.view(ts.zero_arena.p + zhead, V + 1);
     if (!by_block) { ts.cnt.view(ts.zero_arena.p + zhead + (V + 1), V + 1); ts.cursor.view(ts.zero_arena.p + zhead + 2 * (V + 1), V + 1); }
-    PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
+    if (!by_block) PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
     PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
-    PTX_HIP(ctx, ts.d_tot.alloc(3));
-    PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, sizeof(uint32_t), ctx->stream));   // error word of trio_block_kernel
+    PTX_HIP(ctx, ts.d_tot.alloc(4));
+    PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, 2 * sizeof(uint32_t), ctx->stream));   // error word of the build kernels, length of the overflow list
+    if (rows_by_visit) {
+        PTX_HIP(ctx, ts.vis_uq.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.vis_rec.alloc((uint64_t)db->n_vgroups * VIS_REC));
+        PTX_HIP(ctx, ts.over_list.alloc(db->n_vgroups)); PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.word_base.alloc(zbits + 1));
+        PTX_HIP(ctx, hipMemsetAsync(ts.vis_uq.p + db->n_vgroups, 0, sizeof(uint64_t), ctx->stream));   // the closing entry of the count scan
+    }
     PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block && P ? zhead : zwords) * sizeof(uint32_t)));
     if (by_block && P) PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p + V, 0, sizeof(uint32_t), ctx->stream));   // the closing entry of the count scan
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
-    PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
+    if (!rows_by_visit) PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
@@ -777,9 +935,13 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         uint32_t U = 4, rounds = 4;
         if (const char *ev = std::getenv("PANTAX_TV_U")) U = (uint32_t)std::atoi(ev);
         if (const char *ev = std::getenv("PANTAX_TV_ROUNDS")) rounds = (uint32_t)std::max(1, std::atoi(ev));
-#define TV_LAUNCH(UU) hipLaunchKernelGGL(trio_visit_kernel<UU>, dim3((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds)), dim3(256), 0, ctx->stream, db->n_vgroups, \
-                                         rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p)
-        if (U == 1) TV_LAUNCH(1); else if (U == 2) TV_LAUNCH(2); else if (U == 8) TV_LAUNCH(8); else TV_LAUNCH(4);
+        uint32_t tv_ablate = 0;
+        if (const char *ev = std::getenv("PANTAX_TV_ABLATE")) tv_ablate = (uint32_t)std::atoi(ev);   // -DTV_ABLATE builds only
+#define TV_LAUNCH(UU, RR) hipLaunchKernelGGL((trio_visit_kernel<UU, RR>), dim3((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds)), dim3(256), 0, ctx->stream, db->n_vgroups, \
+                                         rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, tv_ablate,  \
+                                         reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p, ts.over_list.p, ts.d_tot.p + 3)
+        if (rows_by_visit) { if (U == 2) TV_LAUNCH(2, true); else if (U == 8) TV_LAUNCH(8, true); else TV_LAUNCH(4, true); }
+        else if (U == 1) TV_LAUNCH(1, false); else if (U == 2) TV_LAUNCH(2, false); else if (U == 8) TV_LAUNCH(8, false); else TV_LAUNCH(4, false);
 #undef TV_LAUNCH
     }
     if (P && by_block && db->n_blocks) {
@@ -822,6 +984,45 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                                    ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
         }
+        if (rows_by_visit) {
+            // rows in (species, hap, position) order = ranks of the flag bits: prefix of every flag word (total = U); slots in visit order =
+            // prefix of the groups' counts
+            PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, PrefixStore{ts.word_base.p}, zbits, ts.d_tot.p + 1, "exclusive_scan"));
+            PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
+                                      (uint64_t)db->n_vgroups + 1, nullptr, "exclusive_scan"));
+            if (!db->trio_sizes_known) {
+                PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
+                PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u visit groups out of order", tot[2]);
+                db->U_known = tot[1];
+            }
+            const uint32_t Utot = (uint32_t)db->U_known;
+            db->U = Utot;
+            PTX_HIP(ctx, db->d_trio_ent.alloc(Utot));
+            PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
+            {
+                KTimer t(ctx, "trio_rows_kernel");
+                const uint32_t NG = db->n_vgroups;
+#define ROWS_TAIL ts.uniq_q.p, ts.word_base.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
+                  db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2
+#define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, ROWS_TAIL
+#define OVER_ARGS ts.d_tot.p + 3, ts.over_list.p, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, db->d_vis_pos.p, db->d_vis_nbase.p, db->d_path_nodes.p, ROWS_TAIL
+                const dim3 rgrid((NG + 31) / 32), ogrid((uint32_t)std::min<uint64_t>(((uint64_t)NG + 3) / 4, (uint64_t)ctx->n_cu * 8));
+                if (with_keys) {
+                    hipLaunchKernelGGL(trio_rows_kernel<true>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
+                    hipLaunchKernelGGL(trio_rows_over_kernel<true>, ogrid, dim3(256), 0, ctx->stream, OVER_ARGS);
+                } else {
+                    hipLaunchKernelGGL(trio_rows_kernel<false>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
+                    hipLaunchKernelGGL(trio_rows_over_kernel<false>, ogrid, dim3(256), 0, ctx->stream, OVER_ARGS);
+                }
+#undef ROWS_ARGS
+#undef OVER_ARGS
+#undef ROWS_TAIL
+                hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.uniq_q.p, ts.word_base.p,
+                                   db->d_hap_trio_off.p);
+            }
+            db->trio_first_valid = false;   // the plain CSR offsets (db images) are derived on request: trio_first_ensure
+        } else {
         hipLaunchKernelGGL(trio_tilecount_kernel, dim3((NT + 3) / 4), dim3(256), 0, ctx->stream, NT, db->d_tiles.p, db->d_path_off.p, db->d_tile_rank.p,
                            ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
@@ -832,7 +1033,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (!db->trio_sizes_known) {
             PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
             PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (PANTAX_TRIO_PATH=bucket), or nodes with 2^24 unique-trio rows", tot[2]);
+            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (PANTAX_TRIO_PATH=bucket), nodes with 2^24 unique-trio rows, or visit groups out of order", tot[2]);
             db->U_known = tot[1];
         }
         const uint32_t Utot = (uint32_t)db->U_known;
@@ -849,6 +1050,8 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
             hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,
                                db->d_hap_trio_off.p);
         }
+        db->trio_first_valid = true;
+        }
     } else {
         db->U = 0;
         PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
@@ -856,6 +1059,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         // no walks at all: every lookup head is empty (first_cnt sits in the zeroed arena)
         PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, nullptr}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
                                   "exclusive_scan"));
+        db->trio_first_valid = true;
     }
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
@@ -869,6 +1073,15 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     db->trio_built = true;
     db->trio_keys_built = with_keys;
     db->cov_done = false;
+    return 0;
+}
+
+// d_trio_first (plain CSR offsets over the middle node) is wanted -- the db images store it: a scan of the heads' row counts
+int trio_first_ensure(Ctx *ctx, Db *db) {
+    if (db->trio_first_valid) return 0;
+    PTX_HIP(ctx, db->d_trio_first.alloc(db->V + 1));
+    PTX_TRY(exclusive_scan_fn(ctx, HeadCountLoad{db->d_node_rec.p, db->V}, PrefixStore{db->d_trio_first.p}, db->V + 1, nullptr, "exclusive_scan"));
+    db->trio_first_valid = true;
     return 0;
 }
 
