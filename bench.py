@@ -82,23 +82,32 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
     P = int(sum(int(g.path_off[-1]) for g in species))
     H = sum(g.n_paths for g in species)
     Wr = max(T - 2 * R, 0)
+    cov = 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr
+    win = max(P - 2 * H, 0)
     return {
+        # keys = the kernel names rocprofv3 shows (the library's timer labels are those names)
         # a2: 4T + 4R(offsets) + 4R(out)
+        "bin_slots_kernel": 4 * T + 4 * R + 4 * R,
         "bin_reads_kernel": 4 * T + 4 * R + 4 * R,
-        # a8 minus the popcount pass: 4T + 12R + 4V(node_len) + 8V(bases) + L/8(bitmap) + 12*Wr(trio probes)
-        "coverage_step_kernel": 4 * T + 12 * R + 4 * V + 8 * V + L // 8 + 12 * Wr,
+        # a8 minus the popcount pass: 4T + 12R + 4V(node_len) + 8V(bases) + L/8(bitmap) + 12*Wr(trio probes); the short-read kernel and
+        # the general one (groups that hold steps of longer walks) share the ruler
+        "coverage_fast_kernel": cov,
+        "coverage_step_kernel": cov,
         # a8 popcount: L/8 bitmap in + 8V cov out
         "popcount_kernel": L // 8 + 8 * V,
-        # a7, node-block path of the index (the default): SURVEY 8d's whole-index figure 2 x 12 x (P - 2H) + 12U split over its
-        # two passes over the walks -- the block kernel forms every window's 12-byte key and decides count == 1 (the "write
-        # keys" half, plus the 4P of walk it reads, which 8d leaves out), the lookup kernel reads the decided keys back in
-        # walk order and writes the U unique rows (the "read sorted" half + 12U)
-        "trio_block_kernel": 4 * P + 12 * max(P - 2 * H, 0),
-        "trio_lookup_kernel": 12 * max(P - 2 * H, 0) + 12 * U,
-        "trio_fill_kernel": 4 * P + 16 * max(P - 2 * H, 0),
+        # a7: SURVEY 8d's whole-index figure 2 x 12 x (P - 2H) + 12U split over the two halves of the build -- the pass that forms every
+        # window's 12-byte key and decides count == 1 (the "write keys" half, plus the 4P of walk it reads, which 8d leaves out): the
+        # visit-table kernel (round 4) or the node-block kernel; and the half that files the U unique rows ("read sorted" + 12U): the
+        # rows kernel or the pass over the walks.  The keys never travel through HBM: roofline.frac_by_counter_bytes is the other ruler
+        "trio_visit_kernel": 4 * P + 12 * win,
+        "trio_block_kernel": 4 * P + 12 * win,
+        "trio_rows_kernel": 12 * win + 12 * U,
+        "trio_lookup_kernel": 12 * win + 12 * U,
+        "trio_fill_kernel": 4 * P + 16 * win,
         "trio_count_kernel": 4 * P + 4 * V,
-        "trio_uniq_kernel": 16 * max(P - 2 * H, 0),
-        # a10: 4P in + 8V mask out
+        "trio_uniq_kernel": 16 * win,
+        # a10: the membership masks by node (8V node -> haplotypes in, 8V masks out) / by walk (4P in + 8V out)
+        "mask_nodes_kernel": 16 * V,
         "mask_kernel": 4 * P + 8 * V,
         "sort_hist_kernel": 8 * n_lp_rows,
         "sort_scatter_kernel": 2 * 24 * n_lp_rows,
@@ -179,7 +188,8 @@ def _oracle_lp_of_species(orc, ns, sset_species, rd, sp, first, order, s, cfgd):
     b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
     t0 = time.perf_counter()
     rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, **cfgd)
-    return _species_lp(orc, G, b, c, orc.metrics_to_dicts(met)), (time.perf_counter() - t0, nc, o1)
+    md = orc.metrics_to_dicts(met)
+    return _species_lp(orc, G, b, c, md), (time.perf_counter() - t0, nc, o1, [m["first_sol"] for m in md])
 
 
 def cpu_leg_child(args):
@@ -274,8 +284,9 @@ def cpu_leg_child(args):
             hrd = hset.reads
             hsp = orc.par_bin_reads(hrd.step_off, hrd.node_id, hns.range_start, hns.range_end, min(cores, 32))
             hfirst, horder = orc.group_reads(hsp, hs["species"])
-            lp, (t_orc, nc, o1) = _oracle_lp_of_species(orc, hns, hset.species, hrd, hsp, hfirst, horder, 0, {})
-            hard = dict(oracle_optimize_species_s_species0=t_orc, oracle_obj1_species0=o1, n_candidates_oracle_species0=nc)
+            lp, (t_orc, nc, o1, fs) = _oracle_lp_of_species(orc, hns, hset.species, hrd, hsp, hfirst, horder, 0, {})
+            hard = dict(oracle_optimize_species_s_species0=t_orc, oracle_obj1_species0=o1, n_candidates_oracle_species0=nc,
+                        oracle_first_sol_species0=fs, hap_names_species0=list(hset.species[0].hap_names))
             if lp is not None and have_scipy and highs_sizes:
                 hard["highs"] = [_highs_leg(lp, min(sz, int((lp[1] > 0).sum())), args.highs_time_limit) for sz in highs_sizes]
                 hard["lp_rows_species0"] = int((lp[1] > 0).sum())
@@ -360,24 +371,24 @@ class CpuLeg:
         return d
 
 
-def pmc_traffic(kernel, key, corrected=False):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, separate
-    passes, KB -> bytes; profiles/r*_pmc_<workload>.json, collected by tools/pmc_step.sh on the same workload; the newest
-    round that has this workload wins).  None when no file matches.  corrected: 2 x FETCH + WRITE -- the guide's gfx950
-    correction (FETCH_SIZE tallies 128-byte requests at 64 B for wide coalesced reads) applied to the whole fetch, i.e. an upper
-    bound; calibration on this path's own kernels: WRITE_SIZE is exact, FETCH_SIZE reads 0.5x on coalesced
-    streams and 1.0x on the node-block kernel's scattered 4-byte loads."""
+PMC_ROUND = "r04"   # profiles/<PMC_ROUND>_pmc_<workload>.json: the counter passes of THIS round's code; older files are never read
+
+
+def pmc_traffic(kernel, key, wl_name, corrected=False):
+    """HBM bytes per launch of `kernel` from THIS round's committed rocprofv3 --pmc passes of the same workload (FETCH_SIZE +
+    WRITE_SIZE, separate passes, KB -> bytes; profiles/<PMC_ROUND>_pmc_<workload>.json, collected by tools/pmc_step.sh).  None when
+    the file is missing, is of another workload, or does not hold the kernel -- never a number of an older round.  corrected:
+    2 x FETCH + WRITE -- the guide's gfx950 correction (FETCH_SIZE tallies 128-byte requests at 64 B for wide coalesced reads) applied
+    to the whole fetch, i.e. an upper bound."""
+    fn = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PMC_ROUND, wl_name))
     try:
-        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            if not (fn.startswith("r") and "_pmc_" in fn and fn.endswith(".json")):
-                continue
-            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            w = d.get("workload", {})
-            if any(w.get(k) != v for k, v in key.items()):
-                continue
-            k = d["kernels"].get(kernel)
-            if k and "hbm_bytes_per_launch" in k:
-                return k["hbm_bytes_fetch_x2"] if corrected else k["hbm_bytes_per_launch"]
+        d = json.load(open(fn))
+        w = d.get("workload", {})
+        if any(w.get(k) != v for k, v in key.items()):
+            return None
+        k = d["kernels"].get(kernel)
+        if k and "hbm_bytes_per_launch" in k:
+            return k["hbm_bytes_fetch_x2"] if corrected else k["hbm_bytes_per_launch"]
     except Exception:   # noqa: BLE001
         pass
     return None
@@ -396,9 +407,88 @@ def gaf_tmp_dir(need_bytes):
     return None
 
 
+def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9):
+    """north_star: strain abundances within L1 1e-4 of the solver-backed PAO.  For a sample of species (the one with the most and the
+    fewest reads + evenly spaced ones) the CHECKER (oracle/: trio index, coverage, both exact LAD solves, constraint -- whose LP
+    optimum equals SciPy-HiGHS on the golden fixtures) runs on the species' reads of THIS workload at full size, and the strain rows of
+    the timed GPU step are compared with it: relative L1 = sum |x_gpu - x_oracle| / sum |x_oracle| over the species' reported strains,
+    for the LP solution (first_sol) and for the final predicted coverage.  A species whose LP optimum is a face rather than a point is
+    listed (any point of the face is an optimum; the objectives are compared instead)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from tests.helpers import select_reads
+    t0 = time.perf_counter()
+    species_rows, strain_rows, stats = out
+    S = len(species)
+    sp, rc, *_ = eng.rcls_profile()
+    cnt = np.asarray(rc)
+    pick = sorted({int(np.argmax(cnt)), int(np.argmin(np.where(cnt > 0, cnt, cnt.max() + 1)))} | {int(i) for i in np.linspace(0, S - 1, max(n_sample - 2, 1)).astype(int)})
+    pick = [s for s in pick if any(r[0] == species[s].name for r in species_rows)]      # species the step kept
+    cov_of = {r[0]: r[2] for r in species_rows}
+    by_sp = {}
+    for r in strain_rows:
+        by_sp.setdefault(r[0], {})[r[1]] = r
+    sel_all = {s: np.nonzero(sp == s)[0] for s in pick}
+    cfgd = dict(fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
+
+    def one(s):
+        g = species[s]
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        so, nid, ps, pe = select_reads(rd, sel_all[s])
+        b, c, t, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        _, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, **cfgd)
+        orc.abundance_constraint(cov_of[g.name], met)
+        om = orc.metrics_to_dicts(met)
+        rows = by_sp.get(g.name, {})
+        d1 = n1 = d2 = n2 = 0.0
+        for h, hn in enumerate(g.hap_names):
+            if hn not in rows:
+                continue
+            e1, e2 = om[h]["first_sol"] or 0.0, om[h]["predicted_coverage"] or 0.0
+            d1 += abs(rows[hn][7] - e1); n1 += abs(e1)
+            d2 += abs(rows[hn][2] - e2); n2 += abs(e2)
+        return dict(species=g.name, reads=int(len(sel_all[s])), strains_reported=len(rows), candidates_oracle=int(nc),
+                    l1_first_sol=d1 / n1 if n1 else 0.0, l1_predicted_coverage=d2 / n2 if n2 else 0.0, oracle_obj1=o1)
+    with ThreadPoolExecutor(min(threads, max(len(pick), 1))) as ex:
+        per = list(ex.map(one, pick))
+    worst = max([max(p_["l1_first_sol"], p_["l1_predicted_coverage"]) for p_ in per], default=0.0)
+    return dict(abundance_l1_vs_oracle=worst, tolerance=1e-4, species_checked=len(per), per_species=per, seconds=time.perf_counter() - t0,
+                what="relative L1 of the timed step's strain rows against the oracle (exact LAD == HiGHS optimum on the fixtures) on the same reads, full size")
+
+
+def launch_ranks(n):
+    """One node, n ranks: python -m torch.distributed.run ... bench.py <the same arguments>, as a child process."""
+    import socket
+    with socket.socket() as sk:                       # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
+def launcher_selftest(rank, world):
+    """The launcher path without a GPU (CPU test): the ranks meet over gloo, rank 0 reports how many it saw."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(t.item()), "world_size": dist.get_world_size()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); without a launcher around it, --gpus N > 1 starts the N ranks itself")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
@@ -416,15 +506,25 @@ def main():
     ap.add_argument("--no-gaf", action="store_true", help="skip the from-GAF-text measurement")
     ap.add_argument("--gaf-reads", type=int, default=0, help="reads of the from-GAF-text leg (0 = the whole workload)")
     ap.add_argument("--no-hard", action="store_true", help="skip the pao_hard leg")
+    ap.add_argument("--no-l1", action="store_true", help="skip the abundance-L1-vs-oracle leg")
+    ap.add_argument("--detail-file", default=None, help="where the verbose side record goes (default gpurun_out/bench_detail_<workload>_n<N>.json)")
     ap.add_argument("--hard-species", type=int, default=8)
     ap.add_argument("--cpu-leg-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg_child:
         sys.exit(cpu_leg_child(args))
-
+    # ---- `python3 bench.py --gpus N` without a launcher around it: this process -- which has touched neither torch nor the GPU --
+    # starts the N ranks as a CHILD (never an exec) and relays rank 0's line and the exit code
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and args.gpus != world:
+        print("bench.py: --gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if args.launcher_selftest:
+        sys.exit(launcher_selftest(rank, world))
     spec = workload_spec(args.workload, args.species, args.haps, args.reads, args.genome_len)
     n_species, n_haps, n_reads, genome_len = spec["species"], spec["haps"], spec["reads"], spec["genome_len"]
 
@@ -447,6 +547,7 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     comm = LocalComm()
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -455,6 +556,11 @@ def main():
         else:
             dist.init_process_group(backend)
             comm = TorchComm(device=None)
+        assert dist.get_world_size() == world
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)                          # every rank is there (over RCCL with the default backend)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world
 
     # ---- deterministic synthetic input (seed = 20260501 + cfg index).  strong: ONE set; this rank generates its
     # slice of the reads (chunks of the generator) and, later, the graphs of the species it owns.  weak: one set per rank.
@@ -554,9 +660,10 @@ def main():
     warm = eng.timing_get() if args.warmup else {}
     # the two largest of the warm-up table are bracketed in the timed steps; the dominant kernel is the one with the larger
     # average THERE
-    top2 = [k for k, _ in sorted(warm.items(), key=lambda kv: -kv[1][1])[:2]] if warm else ["coverage_step_kernel"]
+    cov_kernel = "coverage_fast_kernel" if (not warm or "coverage_fast_kernel" in warm) else "coverage_step_kernel"   # short reads / long reads
+    top2 = [k for k, _ in sorted(warm.items(), key=lambda kv: -kv[1][1])[:2]] if warm else [cov_kernel]
     # ... and the coverage kernel always (the histogram is the path's named kernel)
-    eng.timing_filter("|".join(top2 + [k for k in ["coverage_step_kernel"] if k not in top2]))
+    eng.timing_filter("|".join(top2 + [k for k in [cov_kernel] if k not in top2]))
     eng.timing_reset()
     # host hygiene before the timed region: with torch imported the interpreter holds ~1e6 long-lived objects, and a full
     # collection of the cyclic garbage collector (triggered by the tables' tuples every few dozen steps) stops the thread that
@@ -571,6 +678,7 @@ def main():
     out = run_steps(args.steps)[-1]
     barrier()
     dt = time.perf_counter() - t0
+    cpu_child_alive = bool(leg.proc is not None and leg.proc.poll() is None)   # its single-threaded HiGHS legs ran beside the timed steps
     timings = eng.timing_get()
     eng.timing_enable(False)
     eng.timing_filter(None)
@@ -585,6 +693,12 @@ def main():
     dt_cached = time.perf_counter() - t1
     # first-class extra: the same workload from GAF TEXT on disk -- pread + PCIe + device tokenizer (a1) -> resident reads -> one
     # step -> tables.  Never `value` (the contract's value has its inputs resident in HBM).
+    l1 = None
+    if rank == 0 and world == 1 and not args.no_l1:
+        try:
+            l1 = abundance_l1_leg(eng, ns, species, rd, out, cfg, host_threads)
+        except Exception as e:   # noqa: BLE001 -- the line is printed regardless
+            l1 = {"error": "%s: %s" % (type(e).__name__, e)}
     gaf_extra = None
     if rank == 0 and world == 1 and not args.no_gaf:
         n_gaf = min(n_reads, args.gaf_reads) if args.gaf_reads else n_reads
@@ -668,6 +782,7 @@ def main():
                     n_candidates=st_h["n_cand"][:8],
                     n_rows=st_h["n_rows"][:8], n_patterns=st_h["n_patterns"][:8], iters=st_h["iters"][:8],
                     objective=st_h["obj"][:4], gpu_obj1_species0=st_h["obj"][0][0],
+                    gpu_first_sol_species0={r[1]: r[7] for r in out_h[1] if r[0] == hard_names[0]},
                     kernels_ms_per_step={k: v[1] / n_h for k, v in sorted(kt_h.items(), key=lambda kv: -kv[1][1])[:8]})
         eng_h.close()
         del hard_set, hns
@@ -685,93 +800,122 @@ def main():
         n_unique = int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
         ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, R_res, T_res)
         dims["U"] = n_unique
-        # dominant kernel by HIP-event time on the library's stream
+        tr = lambda k, corrected=False: pmc_traffic(k, wkey, spec["name"], corrected) if world == 1 else None
+
+        def ruler(k, launches, tot_ms):
+            """one kernel against the HBM roofline: SURVEY 8d's algorithmic bytes / HIP-event time, and -- the other ruler -- the bytes
+            the counters saw (this round's committed PMC passes of the same workload; None when there is none)"""
+            avg_ms = tot_ms / max(launches, 1)
+            per = ab.get(k, 0)
+            t_raw = tr(k)
+            d = dict(kernel=k, avg_ms=round(avg_ms, 4), launches_timed=launches, algorithmic_bytes=per,
+                     achieved=per / (avg_ms * 1e-3) / 1e9, frac=per / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=t_raw,
+                     traffic_fetch_x2=tr(k, True), frac_by_counter_bytes=(t_raw / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_raw else None)
+            return d
+        # dominant kernel by HIP-event time on the library's stream, in the timed steps
         roofline = None
         dom = max((k for k in top2 if k in timings), key=lambda k: timings[k][1] / max(timings[k][0], 1), default=None)
-        tr = lambda k, corrected=False: pmc_traffic(k, wkey, corrected) if world == 1 else None
-        if dom and dom in timings:
-            launches, tot_ms = timings[dom]
-            avg_ms = tot_ms / max(launches, 1)
-            per = ab.get(dom)
-            if per is not None:
-                ach = per / (avg_ms * 1e-3) / 1e9
-                roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                                traffic=tr(dom), traffic_fetch_x2=tr(dom, True), avg_ms=avg_ms, launches_timed=launches,
-                                algorithmic_bytes=per,
-                                traffic_source="committed rocprofv3 --pmc passes of this workload (profiles/r*_pmc_*.json), not measured in this run")
-            else:
-                roofline = dict(bound="hbm", kernel=dom, achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, traffic=None,
-                                avg_ms=avg_ms, algorithmic_bytes=0,
-                                note="no streaming-traffic model for this launch (latency-bound: the small-LP solver does "
-                                     "O(#patterns*log n) searches per pivot)")
-        # the runner-up of the timed steps, same ruler
-        if roofline is not None:
-            roofline["note"] = ("HIP-event durations of kernels that share the device: in a stream of steps the index rebuild of step i+1 "
-                                "(trio_block / trio_lookup, side stream, LOW priority) runs beside the tail of step i and is stretched by it; "
-                                "stand-alone times: DESIGN.md section 4")
+        if dom:
+            r0 = ruler(dom, *timings[dom])
+            roofline = dict(bound="hbm", kernel=dom, achieved=r0["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r0["frac"], traffic=r0["traffic"],
+                            frac_by_counter_bytes=r0["frac_by_counter_bytes"], traffic_fetch_x2=r0["traffic_fetch_x2"], avg_ms=r0["avg_ms"],
+                            launches_timed=r0["launches_timed"], algorithmic_bytes=r0["algorithmic_bytes"],
+                            traffic_source="profiles/%s_pmc_%s.json (committed --pmc passes, not this run)" % (PMC_ROUND, spec["name"]) if r0["traffic"] else
+                                           "no PMC record of this round for this workload: traffic null")
             for k2 in top2:
-                if k2 != dom and k2 in timings and k2 in ab:
-                    l2, t2 = timings[k2]
-                    a2 = t2 / max(l2, 1)
-                    roofline["runner_up"] = dict(kernel=k2, avg_ms=a2, algorithmic_bytes=ab[k2], frac=ab[k2] / (a2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 traffic=tr(k2), traffic_fetch_x2=tr(k2, True))
-            if "coverage_step_kernel" in timings and "coverage_step_kernel" in ab and roofline["kernel"] != "coverage_step_kernel" \
-                    and roofline.get("runner_up", {}).get("kernel") != "coverage_step_kernel":
-                l3, t3 = timings["coverage_step_kernel"]
-                a3 = t3 / max(l3, 1)
-                roofline["coverage_step_kernel"] = dict(avg_ms=a3, algorithmic_bytes=ab["coverage_step_kernel"], launches_timed=l3,
-                                                        frac=ab["coverage_step_kernel"] / (a3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                        traffic=tr("coverage_step_kernel"), traffic_fetch_x2=tr("coverage_step_kernel", True))
-        # the other large kernels against the same ruler (warm-up table; one launch per step each unless noted)
+                if k2 != dom and k2 in timings:
+                    r2 = ruler(k2, *timings[k2])
+                    roofline["runner_up"] = {k: r2[k] for k in ("kernel", "avg_ms", "algorithmic_bytes", "frac", "traffic", "frac_by_counter_bytes")}
+            if cov_kernel in timings and dom != cov_kernel and roofline.get("runner_up", {}).get("kernel") != cov_kernel:
+                r3 = ruler(cov_kernel, *timings[cov_kernel])
+                roofline["coverage"] = {k: r3[k] for k in ("kernel", "avg_ms", "algorithmic_bytes", "frac", "traffic", "frac_by_counter_bytes")}
+        # the other large kernels against the same rulers (warm-up table; stretched by what shares the device with them)
         others = {}
         for k, (launches, tot_ms) in warm.items():
             if k in ab and launches:
-                a_ms = tot_ms / launches
-                others[k] = dict(avg_ms=a_ms, algorithmic_bytes=ab[k], frac=ab[k] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                r_ = ruler(k, launches, tot_ms)
+                others[k] = {kk: r_[kk] for kk in ("avg_ms", "algorithmic_bytes", "frac", "traffic", "frac_by_counter_bytes")}
         # the CPU legs: whatever the child has by now (it is given the rest of its HiGHS time limit)
         cpu_res = leg.finish(timeout=args.highs_full_time_limit + 3 * args.highs_time_limit + 240) if leg.proc is not None else None
-        cpu = None
+        cpu, cpu_detail = None, None
         if cpu_res is not None:
-            cpu = cpu_res.get("cpu_baseline") or {"value": None, "unit": "Mreads/s", "cores": 0, "kind": "port", "sample": None}
+            cpu_detail = cpu_res.get("cpu_baseline") or {"value": None, "unit": "Mreads/s", "cores": 0, "kind": "port", "sample": None}
             if "error" in cpu_res:
-                cpu["error"] = cpu_res["error"]
-                cpu["traceback"] = cpu_res.get("traceback")
-            cpu["parent_waited_s_for_oracle_leg"] = cpu_wait_s
+                cpu_detail["error"] = cpu_res["error"]
+                cpu_detail["traceback"] = cpu_res.get("traceback")
+            cpu_detail["parent_waited_s_for_oracle_leg"] = cpu_wait_s
             if hard is not None and cpu_res.get("pao_hard_cpu"):
                 hard.update(cpu_res["pao_hard_cpu"])
+                o1h, g1h = hard.get("oracle_obj1_species0"), hard.get("gpu_obj1_species0")
+                if o1h is not None and g1h is not None:
+                    hard["objective_rel_diff_vs_oracle"] = abs(g1h - o1h) / max(1.0, abs(o1h))
+                fs, hn = hard.get("oracle_first_sol_species0"), hard.get("hap_names_species0")
+                if fs and hn and hard.get("gpu_first_sol_species0"):
+                    gfs = hard["gpu_first_sol_species0"]
+                    num = sum(abs(gfs.get(h_, 0.0) - (f_ or 0.0)) for h_, f_ in zip(hn, fs))
+                    den = sum(abs(f_ or 0.0) for f_ in fs)
+                    hard["abundance_l1_vs_oracle_species0"] = num / den if den else 0.0
+            hg = cpu_detail.get("highs") or {}
+            full = hg.get("full_lp") or {}
+            legs = hg.get("legs") or []
+            # the line's cpu_baseline: scalars and short strings only (the verbose record goes to the detail file)
+            cpu = dict(value=cpu_detail.get("value"), unit="Mreads/s", cores=cpu_detail.get("cores"), kind="port",
+                       sample=("first %d of %d reads over all %d species" % (cpu_detail.get("reads") or 0, n_reads, n_species)) if cpu_detail.get("reads") else None,
+                       seconds=cpu_detail.get("seconds"), solver="oracle exact LAD (== HiGHS optimum on the fixtures); HiGHS timed beside it",
+                       highs_full_lp_rows=hg.get("full_lp_rows"), highs_full_lp_seconds=full.get("highs_seconds"), highs_full_lp_finished=full.get("finished"),
+                       highs_10k_rows_seconds=next((l_["highs_seconds"] for l_ in legs if l_.get("rows") == 10000), None),
+                       child_alive_during_timed_steps=cpu_child_alive, species_failed=cpu_detail.get("species_failed"), error=cpu_detail.get("error"))
+        gx = gaf_extra or {}
         line = {
-            "metric": "PAO wall-time (s) + Mreads/s, packed reads resident in HBM -> abundance tables (GAF text -> tables: from_gaf_text)",
+            "metric": "PAO wall-time (s) + Mreads/s, packed reads resident in HBM -> abundance tables (GAF text -> tables: config.from_gaf_text_*)",
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "pao_wall_s": ms_per_step / 1e3,
-            "from_gaf_text_mreads_per_s": gaf_extra.get("end_to_end_mreads_per_s") if gaf_extra else None,
-            "from_gaf_text_wall_s": gaf_extra.get("end_to_end_s") if gaf_extra else None,
-            "upload_ms_once": upload_ms, "step_path_primed_ms_once": prime_ms, "synthetic_set_generated_in_s": gen_s, "ingest_route": ingest_route,
-            "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
-            "config": {"workload": "%s: %s -- %d species x %d strains, %d short reads (150 bp), genome %d bp %s; this rank: V=%d nodes, "
-                                   "P=%d path steps, T=%d walk steps, seed %d, generator %s"
-                                   % (spec["name"], spec["label"], n_species, n_haps, n_reads, genome_len,
-                                      "per GPU" if args.scaling == "weak" else "in all (one set, cut over the ranks)", dims["V"], dims["P"], dims["T"],
-                                      spec["seed"], GENERATOR),
-                       "species_per_gpu": S_loc, "strains_total": n_species * n_haps * (world if args.scaling == "weak" else 1),
-                       "reads_total": total_reads, "parallelism": "species-shard x%d" % world, "sample_nodes": 0,
-                       "exchange": "none" if world == 1 else ("one rccl all_reduce per step, in flight during the next step" if backend == "nccl" else backend + " all_reduce (dry run)")},
-            "from_gaf_text": gaf_extra,
+            "config": {"workload": "%s: %d species x %d strains, %d short reads (150 bp), genome %d bp, seed %d, generator %s"
+                                   % (spec["name"], n_species, n_haps, n_reads, genome_len, spec["seed"], GENERATOR),
+                       "baseline_config": spec["label"][:60], "set": "per GPU" if args.scaling == "weak" else "one set cut over the ranks",
+                       "V": dims["V"], "P": dims["P"], "T": dims["T"], "U": n_unique, "species_per_gpu": S_loc,
+                       "strains_total": n_species * n_haps * (world if args.scaling == "weak" else 1), "reads_total": total_reads,
+                       "parallelism": "species-shard x%d" % world, "rccl_ranks": ranks_seen if backend == "nccl" else None, "ranks_seen": ranks_seen,
+                       "exchange": "none" if world == 1 else ("one rccl all_reduce per step" if backend == "nccl" else backend + " all_reduce (dry run)"),
+                       "pao_wall_s": ms_per_step / 1e3, "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3,
+                       # the metric's own wording, GAF text on disk -> tables (never `value`)
+                       "from_gaf_text_s": gx.get("end_to_end_s"), "from_gaf_text_mreads_per_s": gx.get("end_to_end_mreads_per_s"),
+                       "from_gaf_text_to_resident_s": (gx.get("tokenize_to_resident_ms") or 0) / 1e3 or None, "gaf_gb": (gx.get("gaf_bytes") or 0) / 1e9 or None,
+                       "gaf_gb_per_s": gx.get("gaf_gb_per_s"), "pinned_h2d_ceiling_gb_per_s": gx.get("pinned_h2d_ceiling_gb_per_s"),
+                       "gaf_gb_per_s_of_ceiling": gx.get("gaf_gb_per_s_of_ceiling"), "tables_equal_to_packed_input_run": gx.get("tables_equal_to_packed_input_run"),
+                       "from_gaf_text_error": gx.get("error"),
+                       # north_star's tolerance: strain abundances against the solver-backed PAO (here: the oracle, == HiGHS on the fixtures)
+                       "abundance_l1_vs_oracle": (l1 or {}).get("abundance_l1_vs_oracle"), "abundance_l1_species_checked": (l1 or {}).get("species_checked"),
+                       "abundance_l1_tolerance": 1e-4, "abundance_l1_error": (l1 or {}).get("error"),
+                       "pao_hard_lad_ms_per_species": (hard or {}).get("lad_kernels_ms_per_species"),
+                       "pao_hard_objective_rel_diff_vs_oracle": (hard or {}).get("objective_rel_diff_vs_oracle"),
+                       "pao_hard_abundance_l1_vs_oracle": (hard or {}).get("abundance_l1_vs_oracle_species0"),
+                       "lp_rows_total": n_lp_rows, "n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
+                       "ingest_route_ms": (ingest_route or {}).get("ms"), "upload_ms_once": upload_ms, "sample_nodes": 0},
             "roofline": roofline,
-            "roofline_other_kernels": others,
-            "kernels_ms_per_step": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
-            # timer scopes, not dispatches: a scope brackets one stage (a sort = several launches)
-            "kernel_timer_scopes_per_step": int(sum(v[0] for v in warm.values()) / max(n_warm_timed, 1)),
-            "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel only",
-            "solver": {"iters": stats["iters"][:4], "n_rows": stats["n_rows"][:4], "n_patterns": stats["n_patterns"][:4],
-                       "objective": stats["obj"][:4], "lp_rows_total": n_lp_rows},
-            "pao_hard": hard,
-            "result": {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
-                       "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]},
-            "host": {"cores": os.cpu_count(), "mem_available_gb": _mem_available_gb()},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        line["kernels_ms_per_step"] = {k: round(v[1] / max(n_warm_timed, 1), 3) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])[:14]}
+        line["result"] = {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
+                          "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]}
+        # everything verbose goes to the side record: the line itself stays well under 8 KB (the driver keeps its tail)
+        detail = {"line": line, "from_gaf_text": gaf_extra, "cpu_baseline": cpu_detail, "pao_hard": hard, "abundance_l1": l1, "roofline_other_kernels": others,
+                  "kernels_ms_per_step_all": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
+                  "kernel_timer_scopes_per_step": int(sum(v[0] for v in warm.values()) / max(n_warm_timed, 1)),
+                  "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel, its runner-up and the coverage kernel only",
+                  "solver": {"iters": stats["iters"][:8], "n_rows": stats["n_rows"][:8], "n_patterns": stats["n_patterns"][:8], "objective": stats["obj"][:8]},
+                  "ingest_route": ingest_route, "step_path_primed_ms_once": prime_ms, "synthetic_set_generated_in_s": gen_s,
+                  "host": {"cores": os.cpu_count(), "mem_available_gb": _mem_available_gb()}}
+        dpath = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail_%s_n%d.json" % (spec["name"], world))
+        try:
+            os.makedirs(os.path.dirname(dpath), exist_ok=True)
+            with open(dpath, "w") as f:
+                json.dump(detail, f, indent=1)
+            line["detail_file"] = os.path.relpath(dpath, ROOT)
+        except OSError as e:
+            line["detail_file"] = "not written: %s" % e
         print(json.dumps(line), flush=True)
     if os.environ.get("PANTAX_BENCH_RSS"):     # tools/strong_dry_run.sh: what a rank needs of the host
         import resource

@@ -234,9 +234,8 @@ struct TrioScratch {
     // rows filed from the visit kernel's records (a db the visit table covers whole)
     DevBuf<uint64_t> vis_uq;       // [n_vgroups + 1] ballot of the unique visits of every group
     DevBuf<uint4> vis_rec;         // [n_vgroups * 8] the first eight unique windows of every group {window start, smaller end, larger end, middle}
-    DevBuf<uint32_t> over_list;    // groups with more than eight
     DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = slot of its first lookup row
-    DevBuf<uint32_t> word_base;    // [P / 32 + 2] flags before every word of uniq_q = row of the first window it flags
+    DevBuf<uint2> word_rank;       // [P / 32 + 2] {flags before the word of uniq_q = row of the first window it flags, the word}
 };
 
 // ---- resident DB -----------------------------------------------------------------------------

@@ -16,7 +16,7 @@ struct ScanStoreArray { uint32_t *out; __device__ __forceinline__ void operator(
 template <class T>
 static int exclusive_scan_impl(Ctx *ctx, const T *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
     (void)d_tmp;
-    return exclusive_scan_fn(ctx, ScanLoadArray<T>{d_in}, ScanStoreArray{d_out}, n, d_total, "exclusive_scan");
+    return exclusive_scan_fn(ctx, ScanLoadArray<T>{d_in}, ScanStoreArray{d_out}, n, d_total, "scan_chained_kernel");
 }
 int exclusive_scan_u32(Ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_tmp, uint32_t *d_total) {
     return exclusive_scan_impl<uint32_t>(ctx, d_in, d_out, n, d_tmp, d_total);

@@ -462,7 +462,7 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
             g_flag = rd->d_g_flag.p;
         }
         if (rd->n_slots) {
-            KTimer t(ctx, "bin_reads_kernel");
+            KTimer t(ctx, "bin_slots_kernel");
             const int grid = grid_for(rd->n_slots, BIN_BLOCK, ctx->n_cu * 8);
 #define BIN_ARGS rd->n_slots, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_qm.p, g_flag, db->d_rng_start.p, db->d_rng_end.p, db->d_rng_idx.p, S, \
                  rd->d_g_slot_rec.p, db->d_sp_first_id.p, db->d_node_base.p, d_counters

@@ -944,11 +944,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             if (db->d_ones.n < db->S) { PTX_HIP(ctx, db->d_ones.alloc(db->S)); PTX_HIP(ctx, hipMemsetAsync(db->d_ones.p, 1, db->S, ctx->stream)); }
             d_act_fast = db->d_ones.p;
         }
-        KTimer t(ctx, "coverage_step_kernel");
         // walks of <= 64 steps: the short-read kernel, one wave per 64-step group, PASSES groups per wave and workgroup (the LDS
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
         const uint32_t n_groups = (uint32_t)(rd->T_pad / 64);
         if (rd->n_long < rd->n_slots && !std::getenv("PANTAX_COV_GENERAL")) {
+            KTimer t(ctx, "coverage_fast_kernel");
             // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps) over a 3072-node window;
             // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
             // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
@@ -981,6 +981,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         // PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another instantiation, for measurements);
         // PANTAX_COV_GENERAL=1 sends every group through it (measurements, and the tests force it).
         if (rd->n_long || std::getenv("PANTAX_COV_GENERAL")) {
+            KTimer t(ctx, "coverage_step_kernel");
             const uint32_t only_long = std::getenv("PANTAX_COV_GENERAL") ? 0u : 1u;
             int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
             if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);

@@ -852,8 +852,8 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
     }
     {
-        KTimer t(ctx, "mask_kernel");
         const bool by_node = use_node_haps(db);
+        KTimer t(ctx, by_node ? "mask_nodes_kernel" : "mask_kernel");   // the names rocprofv3 shows
         if (by_node && V)
             hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 2047) / 2048)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
                                lb->d_p.p, lb->d_hap_bit.p, (const unsigned long long *)db->d_node_haps.p, (unsigned long long *)lb->d_mask.p);
@@ -890,7 +890,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
                                   RowStore{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, db->d_emit_tile_sp.p, db->d_node_base.p,
                                            pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p, pack_shift >= 0 ? ka[0].p : ka[1].p,
                                            pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift},
-                                  V, d_n, "row_emit_kernel"));
+                                  V, d_n, "scan_chained_kernel<Row>"));
         hipLaunchKernelGGL(seg_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, ctx->stream, S, d_n, pack_shift >= 0 ? (const uint64_t *)nullptr : ka[0].p,
                            pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift, d_seg_off, d_seg_cnt);
     } else {
@@ -932,7 +932,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         const uint64_t *pk1 = pack_shift >= 0 ? (const uint64_t *)nullptr : Sd.k[1];
         PTX_TRY(exclusive_scan_fn(ctx, PatLoad{d_n, Sd.k[0], pk1},
                                   PatStore{Sd.k[0], pk1, (uint32_t)k_cap, pack_shift, lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf},
-                                  V, d_K, "pattern_scan_kernel"));
+                                  V, d_K, "scan_chained_kernel<Pat>"));
     }
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
     hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
@@ -2096,7 +2096,7 @@ int lad_pair_launch(Ctx *ctx, const Db *db, LadBatch *lb, int pmax_bound, const 
     PTX_TRY(lad_prof_begin(ctx, S, prof, A1));   // the first solve only
 #endif
     {
-        KTimer t(ctx, "lad_solve_kernel");
+        KTimer t(ctx, "lad_pair_kernel");
         if (pmax_bound <= 16) hipLaunchKernelGGL((lad_pair_kernel<16, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
         else hipLaunchKernelGGL((lad_pair_kernel<LAD_MAXP, 1>), dim3(S), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);
         if (lb->n_wide > lb->n_huge) hipLaunchKernelGGL((lad_pair_kernel<LAD_WIDEP, LAD_WIDE_NW>), dim3(lb->n_wide), dim3(LAD_BLOCK), 0, ctx->stream, A1, A2, F);

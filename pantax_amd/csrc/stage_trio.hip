@@ -323,14 +323,14 @@ struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 // to trio_rows_kernel -- the group's ballot of unique visits and, for the first VIS_REC of them, a 16-byte record {window start, smaller
 // end, larger end, middle (global node indices)} -- instead of the per-node counts: the lookup rows are then filed in visit order, which
 // IS the order of a CSR over the middle node, by a scan over the groups' counts (a tenth of the nodes) and one pass over the records,
-// no scan over all nodes and no second pass over the walks.  Groups with more unique visits than records are listed in `over_list`.
+// no scan over all nodes and no second pass over the walks.  A group with more unique visits than records (one in seven at ten strains
+// per species) is read again by trio_rows_kernel.
 constexpr int VIS_REC = 8;
 template <int U, bool ROWS>
 __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                          const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
                                                          uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, uint32_t ablate,
-                                                         unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec, uint32_t *__restrict__ over_list,
-                                                         uint32_t *__restrict__ n_over) {
+                                                         unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t g0 = (blockIdx.x * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
@@ -377,7 +377,6 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));   // unique visits in the lanes below
                     if (((uq >> lane) & 1ull) && r < (uint32_t)VIS_REC && !TV_ABL(2u))
                         vis_rec[(uint64_t)g * VIS_REC + r] = make_uint4(q[u] - 1u, nb[u] + lo, nb[u] + hi, nb[u] + w[u].y);
-                    if (__popcll(uq) > VIS_REC && lane == 0) over_list[atomicAdd(n_over, 1u)] = g;
                 }
             } else if (((hd >> lane) & 1ull) && !TV_ABL(2u)) {                                      // the head lane stores its node's count of unique windows
                 const unsigned long long he = hd | (~vmask & (vmask + 1ull));   // the first pad lane closes the last stretch (pads sit at the tail)
@@ -637,17 +636,20 @@ struct TrioFirstStore {
 struct FlagWordLoad { const uint32_t *bits; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popc(bits[i]); } };
 struct GroupCountLoad { const unsigned long long *uq; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popcll(uq[i]); } };
 struct PrefixStore { uint32_t *out; __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t) const { out[i] = excl; } };
-__device__ __forceinline__ uint32_t flag_rank(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base, uint64_t q) {
-    return word_base[q >> 5] + (uint32_t)__popc(bits[q >> 5] & ((1u << (uint32_t)(q & 31ull)) - 1u));
+// {flags before the word, the word}: ONE 8-byte gather per rank
+struct FlagRankStore { uint2 *out; const uint32_t *bits; __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t) const { out[i] = make_uint2(excl, bits[i]); } };
+__device__ __forceinline__ uint32_t flag_rank(const uint2 *__restrict__ word_rank, uint64_t q) {
+    const uint2 w = word_rank[q >> 5];
+    return w.x + (uint32_t)__popc(w.y & ((1u << (uint32_t)(q & 31ull)) - 1u));
 }
 // one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
 // length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
 template <bool KEYS>
-__device__ __forceinline__ void trio_row_emit(const uint4 rec, uint32_t slot, const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base,
+__device__ __forceinline__ void trio_row_emit(const uint4 rec, uint32_t slot, const uint2 *__restrict__ word_rank,
                                               const uint32_t *__restrict__ node_len, uint32_t nbase, uint32_t H, const uint64_t *__restrict__ path_off,
                                               const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ trio_ent,
                                               uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
-    const uint32_t row = flag_rank(bits, word_base, rec.x);
+    const uint32_t row = flag_rank(word_rank, rec.x);
     trio_ent[slot] = make_uint4(rec.y, rec.z, row, 0u);
     len_out[row] = node_len[rec.y] + node_len[rec.w] + node_len[rec.z];
     if (KEYS) {
@@ -666,12 +668,45 @@ __device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, ui
     r.w = slot;
     node_rec[v] = r;
 }
+// a group with more than VIS_REC unique visits (a stretch of private sequence; every group of a single-strain species): the whole wave
+// reads the group's visits again, ranks the unique ones, and files them like the records
+template <bool KEYS>
+__device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
+                                                const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase,
+                                                const uint32_t *__restrict__ path_nodes, const uint2 *__restrict__ word_rank, const uint32_t *__restrict__ node_len, uint32_t H,
+                                                const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ hap_species,
+                                                const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec, uint4 *__restrict__ trio_ent,
+                                                uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
+                                                uint32_t *__restrict__ err) {
+    const unsigned long long uq = vis_uq[g];
+    const uint32_t nb = vis_nbase[g], base = gprefix[g];
+    const bool mine = (uq >> lane) & 1ull;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+    if (mine) {
+        const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
+        const U32x3 w = *reinterpret_cast<const U32x3 *>(path_nodes + (q - 1u));
+        rec = make_uint4(q - 1u, nb + min(w.x, w.z), nb + max(w.x, w.z), nb + w.y);
+    }
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));
+    // first unique visit of its node: the unique lane below holds another node (the visits of a node are neighbours)
+    const unsigned long long lower = uq & ((1ull << lane) - 1ull);
+    const uint32_t prev_w = __shfl(rec.w, lower ? 63 - __builtin_clzll(lower) : lane);
+    const bool first = mine && (!lower || prev_w != rec.w);
+    const unsigned long long fm = __ballot(first);
+    if (mine) trio_row_emit<KEYS>(rec, base + r, word_rank, node_len, nb, H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+    if (first) {
+        const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);     // the node's rows end at the next first lane
+        const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
+        trio_head_store(node_rec, rec.w, base + r, (uint32_t)__popcll(span), err);
+    }
+}
 // EIGHT groups per wave, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
 // one coalesced kilobyte per wave; the slot of record r of group g is the scan of the groups' counts + r
 template <bool KEYS>
 __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
                                                         const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase,
-                                                        const uint32_t *__restrict__ bits, const uint32_t *__restrict__ word_base,
+                                                        const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ path_nodes,
+                                                        const uint2 *__restrict__ word_rank,
                                                         const uint32_t *__restrict__ node_len, uint32_t H, const uint64_t *__restrict__ path_off,
                                                         const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec,
                                                         uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
@@ -681,7 +716,7 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     const uint32_t g = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + ((uint32_t)lane >> 3), r = (uint32_t)lane & 7u;
     uint32_t cnt = 0;
     if (g < NG) cnt = (uint32_t)__popcll(vis_uq[g]);
-    const bool on = cnt <= (uint32_t)VIS_REC && r < cnt;                     // an overflowing group is trio_rows_over_kernel's, whole
+    const bool on = cnt <= (uint32_t)VIS_REC && r < cnt;                     // an overflowing group is taken whole, below
     uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
     uint32_t slot = 0;
     if (on) { rec = vis_rec[(uint64_t)g * VIS_REC + r]; slot = gprefix[g] + r; }
@@ -689,59 +724,28 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     const uint32_t below = wave_shr1(rec.w, 0xFFFFFFFFu);
     const bool first = on && (r == 0u || below != rec.w);
     const unsigned long long fm = __ballot(first), om = __ballot(on);
-    if (on) trio_row_emit<KEYS>(rec, slot, bits, word_base, node_len, vis_nbase[g], H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+    if (on) trio_row_emit<KEYS>(rec, slot, word_rank, node_len, vis_nbase[g], H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
     if (first) {
         // rows of the node: up to the next first record, or to the end of the group's records
         const unsigned long long grp = 0xFFull << (lane & ~7), stop = (fm | ~om) & grp & ~((2ull << lane) - 1ull);
         const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
         trio_head_store(node_rec, rec.w, slot, (uint32_t)(end - lane), err);
     }
-}
-// a group with more than VIS_REC unique visits (a stretch of private sequence; every group of a single-strain species): one wave per
-// listed group reads the visits again, compacts the unique ones by their rank, and files them like the records
-template <bool KEYS>
-__global__ void __launch_bounds__(256) trio_rows_over_kernel(const uint32_t *__restrict__ n_over, const uint32_t *__restrict__ over_list,
-                                                             const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
-                                                             const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase,
-                                                             const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ bits,
-                                                             const uint32_t *__restrict__ word_base, const uint32_t *__restrict__ node_len, uint32_t H,
-                                                             const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ hap_species,
-                                                             const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec, uint4 *__restrict__ trio_ent,
-                                                             uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
-                                                             uint32_t *__restrict__ err) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t n = *n_over;
-    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += gridDim.x * 4u) {
-        const uint32_t g = over_list[i];
-        const unsigned long long uq = vis_uq[g];
-        const uint32_t nb = vis_nbase[g];
-        const bool mine = (uq >> lane) & 1ull;
-        uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
-        if (mine) {
-            const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
-            const uint32_t a = path_nodes[q - 1], b = path_nodes[q], c = path_nodes[q + 1];
-            rec = make_uint4(q - 1u, nb + min(a, c), nb + max(a, c), nb + b);
-        }
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));
-        // first unique visit of its node: the unique lane below holds another node (the visits of a node are neighbours)
-        const unsigned long long lower = uq & ((1ull << lane) - 1ull);
-        const uint32_t prev_w = __shfl(rec.w, lower ? 63 - __builtin_clzll(lower) : lane);
-        const bool first = mine && (!lower || prev_w != rec.w);
-        const unsigned long long fm = __ballot(first);
-        if (mine) trio_row_emit<KEYS>(rec, gprefix[g] + r, bits, word_base, node_len, nb, H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
-        if (first) {
-            const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);     // the node's rows end at the next first lane
-            const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
-            trio_head_store(node_rec, rec.w, gprefix[g] + r, (uint32_t)__popcll(span), err);
-        }
+    // the groups of this wave with more unique visits than records, one after the other
+    unsigned long long ov = __ballot(r == 0u && cnt > (uint32_t)VIS_REC);
+    while (ov) {
+        const int l = __builtin_ctzll(ov);
+        ov &= ov - 1ull;
+        trio_rows_group<KEYS>(g - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, path_nodes, word_rank, node_len, H,
+                              path_off, hap_species, hap_off, node_rec, trio_ent, abc, hap_out, len_out, err);
     }
 }
 // hap_trio_off[h] = rows before the first position of haplotype h (entry H: all rows)
-__global__ void __launch_bounds__(256) trio_hapoff_rank_kernel(uint32_t H, const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ bits,
-                                                               const uint32_t *__restrict__ word_base, uint64_t *__restrict__ hap_trio_off) {
+__global__ void __launch_bounds__(256) trio_hapoff_rank_kernel(uint32_t H, const uint64_t *__restrict__ path_off, const uint2 *__restrict__ word_rank,
+                                                               uint64_t *__restrict__ hap_trio_off) {
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h > H) return;
-    hap_trio_off[h] = (uint64_t)flag_rank(bits, word_base, path_off[h]);
+    hap_trio_off[h] = (uint64_t)flag_rank(word_rank, path_off[h]);
 }
 // the plain CSR offsets over the middle node (db images keep them; no stage of a step reads them): a scan of the row counts that
 // ride in the node records
@@ -918,7 +922,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, 2 * sizeof(uint32_t), ctx->stream));   // error word of the build kernels, length of the overflow list
     if (rows_by_visit) {
         PTX_HIP(ctx, ts.vis_uq.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.vis_rec.alloc((uint64_t)db->n_vgroups * VIS_REC));
-        PTX_HIP(ctx, ts.over_list.alloc(db->n_vgroups)); PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.word_base.alloc(zbits + 1));
+        PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.word_rank.alloc(zbits + 1));
         PTX_HIP(ctx, hipMemsetAsync(ts.vis_uq.p + db->n_vgroups, 0, sizeof(uint64_t), ctx->stream));   // the closing entry of the count scan
     }
     PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block && P ? zhead : zwords) * sizeof(uint32_t)));
@@ -939,7 +943,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (const char *ev = std::getenv("PANTAX_TV_ABLATE")) tv_ablate = (uint32_t)std::atoi(ev);   // -DTV_ABLATE builds only
 #define TV_LAUNCH(UU, RR) hipLaunchKernelGGL((trio_visit_kernel<UU, RR>), dim3((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds)), dim3(256), 0, ctx->stream, db->n_vgroups, \
                                          rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, tv_ablate,  \
-                                         reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p, ts.over_list.p, ts.d_tot.p + 3)
+                                         reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p)
         if (rows_by_visit) { if (U == 2) TV_LAUNCH(2, true); else if (U == 8) TV_LAUNCH(8, true); else TV_LAUNCH(4, true); }
         else if (U == 1) TV_LAUNCH(1, false); else if (U == 2) TV_LAUNCH(2, false); else if (U == 8) TV_LAUNCH(8, false); else TV_LAUNCH(4, false);
 #undef TV_LAUNCH
@@ -987,9 +991,9 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (rows_by_visit) {
             // rows in (species, hap, position) order = ranks of the flag bits: prefix of every flag word (total = U); slots in visit order =
             // prefix of the groups' counts
-            PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, PrefixStore{ts.word_base.p}, zbits, ts.d_tot.p + 1, "exclusive_scan"));
+            PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, FlagRankStore{ts.word_rank.p, ts.uniq_q.p}, zbits, ts.d_tot.p + 1, "scan_chained_kernel<FlagWord>"));
             PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
-                                      (uint64_t)db->n_vgroups + 1, nullptr, "exclusive_scan"));
+                                      (uint64_t)db->n_vgroups + 1, nullptr, "scan_chained_kernel<GroupCount>"));
             if (!db->trio_sizes_known) {
                 PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
                 PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1003,22 +1007,14 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
             {
                 KTimer t(ctx, "trio_rows_kernel");
                 const uint32_t NG = db->n_vgroups;
-#define ROWS_TAIL ts.uniq_q.p, ts.word_base.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
+#define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_pos.p, db->d_path_nodes.p, \
+                  ts.word_rank.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
                   db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2
-#define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, ROWS_TAIL
-#define OVER_ARGS ts.d_tot.p + 3, ts.over_list.p, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, db->d_vis_pos.p, db->d_vis_nbase.p, db->d_path_nodes.p, ROWS_TAIL
-                const dim3 rgrid((NG + 31) / 32), ogrid((uint32_t)std::min<uint64_t>(((uint64_t)NG + 3) / 4, (uint64_t)ctx->n_cu * 8));
-                if (with_keys) {
-                    hipLaunchKernelGGL(trio_rows_kernel<true>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
-                    hipLaunchKernelGGL(trio_rows_over_kernel<true>, ogrid, dim3(256), 0, ctx->stream, OVER_ARGS);
-                } else {
-                    hipLaunchKernelGGL(trio_rows_kernel<false>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
-                    hipLaunchKernelGGL(trio_rows_over_kernel<false>, ogrid, dim3(256), 0, ctx->stream, OVER_ARGS);
-                }
+                const dim3 rgrid((NG + 31) / 32);
+                if (with_keys) hipLaunchKernelGGL(trio_rows_kernel<true>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
+                else hipLaunchKernelGGL(trio_rows_kernel<false>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
 #undef ROWS_ARGS
-#undef OVER_ARGS
-#undef ROWS_TAIL
-                hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.uniq_q.p, ts.word_base.p,
+                hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.word_rank.p,
                                    db->d_hap_trio_off.p);
             }
             db->trio_first_valid = false;   // the plain CSR offsets (db images) are derived on request: trio_first_ensure
@@ -1027,7 +1023,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                            ts.uniq_q.p, ts.tile_cnt.p);
         PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
         PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, by_block ? db->d_node_visited.p : nullptr},
-                                  TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr, "exclusive_scan"));
+                                  TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr, "scan_chained_kernel<TrioFirst>"));
         // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
         // first build and needs no host round trip here
         if (!db->trio_sizes_known) {
@@ -1058,7 +1054,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
         // no walks at all: every lookup head is empty (first_cnt sits in the zeroed arena)
         PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, nullptr}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
-                                  "exclusive_scan"));
+                                  "scan_chained_kernel<TrioFirst>"));
         db->trio_first_valid = true;
     }
 #undef TRIO_GRAPH
@@ -1080,7 +1076,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
 int trio_first_ensure(Ctx *ctx, Db *db) {
     if (db->trio_first_valid) return 0;
     PTX_HIP(ctx, db->d_trio_first.alloc(db->V + 1));
-    PTX_TRY(exclusive_scan_fn(ctx, HeadCountLoad{db->d_node_rec.p, db->V}, PrefixStore{db->d_trio_first.p}, db->V + 1, nullptr, "exclusive_scan"));
+    PTX_TRY(exclusive_scan_fn(ctx, HeadCountLoad{db->d_node_rec.p, db->V}, PrefixStore{db->d_trio_first.p}, db->V + 1, nullptr, "scan_chained_kernel<HeadCount>"));
     db->trio_first_valid = true;
     return 0;
 }

@@ -1,18 +1,16 @@
 #!/usr/bin/env python3
-"""Print the essentials of a bench.py JSON line."""
+"""Print the essentials of a bench.py JSON line (and its length: the driver keeps about 8 KB of tail)."""
 import json, sys
-d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
-print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  timer scopes/step %s" % (d["value"], d["unit"], d["ms_per_step"], d["ms_per_step_trio_index_resident"], d.get("kernel_timer_scopes_per_step", d.get("launches_per_step"))))
+raw = [l for l in open(sys.argv[1]) if l.startswith("{")][0]
+d = json.loads(raw)
+c = d["config"]
+print("value %.1f %s  ms/step %.3f  (trio resident %.3f)  n_gpus %s  line %d bytes" % (d["value"], d["unit"], d["ms_per_step"], c.get("ms_per_step_trio_index_resident") or -1, d["n_gpus"], len(raw)))
 r = d["roofline"]
-print("roofline", r["kernel"], "avg_ms %.3f frac %.3f traffic %s" % (r["avg_ms"], r["frac"], r.get("traffic")))
-for k in ("runner_up", "coverage_step_kernel"):
-    if k in r: print("  %s: %s avg_ms %.3f frac %.3f" % (k, r[k].get("kernel", k), r[k]["avg_ms"], r[k]["frac"]))
+print("roofline", r["kernel"], "avg_ms %.3f frac %.3f by-counter %s traffic %s" % (r["avg_ms"], r["frac"], r.get("frac_by_counter_bytes"), r.get("traffic")))
+for k in ("runner_up", "coverage"):
+    if k in r: print("  %s: %s avg_ms %.3f frac %.3f by-counter %s" % (k, r[k].get("kernel", k), r[k]["avg_ms"], r[k]["frac"], r[k].get("frac_by_counter_bytes")))
 print("kernels", {k: round(v, 3) for k, v in list(d["kernels_ms_per_step"].items())[:16]})
-if d.get("from_gaf_text"): print("gaf", d["from_gaf_text"])
-if d.get("pao_hard"): print("hard", {k: v for k, v in d["pao_hard"].items() if k != "highs"})
-c = d.get("cpu_baseline")
-if c:
-    print("cpu", c.get("value"), c.get("cores"), c.get("seconds"), c.get("error"), c.get("mem_available_gb"), "waited", c.get("parent_waited_s_for_oracle_leg"))
-    h = c.get("highs") or {}
-    print("highs", [(l["rows"], round(l["highs_seconds"], 2)) for l in h.get("legs", [])], "full:", {k: v for k, v in (h.get("full_lp") or {}).items() if k != "what"})
-print("config", d["config"]["workload"], "| gen s", d.get("synthetic_set_generated_in_s"), "upload ms", d.get("upload_ms_once"), "host", d.get("host"))
+print("gaf", {k: c.get(k) for k in ("from_gaf_text_s", "from_gaf_text_to_resident_s", "from_gaf_text_mreads_per_s", "gaf_gb", "gaf_gb_per_s", "pinned_h2d_ceiling_gb_per_s", "gaf_gb_per_s_of_ceiling", "tables_equal_to_packed_input_run", "from_gaf_text_error")})
+print("l1", {k: c.get(k) for k in ("abundance_l1_vs_oracle", "abundance_l1_species_checked", "abundance_l1_error", "pao_hard_lad_ms_per_species", "pao_hard_objective_rel_diff_vs_oracle", "pao_hard_abundance_l1_vs_oracle")})
+if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"])
+print("config", c["workload"], "| ranks", c.get("ranks_seen"), c.get("exchange"), "| detail", d.get("detail_file"))
