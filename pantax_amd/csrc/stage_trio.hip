@@ -326,11 +326,19 @@ struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 // no scan over all nodes and no second pass over the walks.  A group with more unique visits than records (one in seven at ten strains
 // per species) is read again by trio_rows_kernel.
 constexpr int VIS_REC = 8;
+constexpr int TV_SLOT_BITS = 10, TV_SLOTS = 1 << TV_SLOT_BITS;   // LDS table of flag words per workgroup
 template <int U, bool ROWS>
 __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                          const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
                                                          uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, uint32_t ablate,
                                                          unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec) {
+    // The flag bits of the unique windows are combined per 32-position word in an LDS table before they go to memory: the windows
+    // around a private allele flag neighbouring positions of ONE walk, and a device-scope atomic is a trip to the memory side
+    // (1.8e8 of them cost 2.3 of the kernel's 7.2 ms at 1e4 strains).  {word index, bits}, open addressing, four probes; a word that
+    // finds no slot is flagged in memory directly.
+    __shared__ uint32_t s_fw[TV_SLOTS], s_fb[TV_SLOTS];
+    for (int i = threadIdx.x; i < TV_SLOTS; i += 256) { s_fw[i] = 0xFFFFFFFFu; s_fb[i] = 0u; }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t g0 = (blockIdx.x * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
@@ -369,7 +377,19 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
             if (bad && lane == 0) atomicAdd(err, 1u);
             const unsigned long long dup = eq | (eq >> 1);                   // both partners are not unique
             const unsigned long long uq = vmask & ~dup;
-            if (((uq >> lane) & 1ull) && !TV_ABL(1u)) uniq_mark(uniq_q, q[u] - 1u);          // flagged at the window's start
+            if (((uq >> lane) & 1ull) && !TV_ABL(1u)) {                     // flagged at the window's start
+                const uint32_t q0 = q[u] - 1u, word = q0 >> 5, bit = 1u << (q0 & 31u);
+                uint32_t h = (word * 0x9E3779B1u) >> (32 - TV_SLOT_BITS);
+                bool filed = false;
+#pragma unroll
+                for (int probe = 0; probe < 4 && !filed; ++probe) {
+                    uint32_t cur = s_fw[h];
+                    if (cur == 0xFFFFFFFFu) cur = atomicCAS(&s_fw[h], 0xFFFFFFFFu, word);
+                    if (cur == 0xFFFFFFFFu || cur == word) { atomicOr(&s_fb[h], bit); filed = true; }
+                    h = (h + 1u) & (TV_SLOTS - 1u);
+                }
+                if (!filed) atomicOr(&uniq_q[word], bit);
+            }
             if (ROWS) {
                 const uint32_t g = g0 + (uint32_t)u;
                 if (g < NG) {
@@ -387,6 +407,8 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
             }
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TV_SLOTS; i += 256) { const uint32_t wd = s_fw[i]; if (wd != 0xFFFFFFFFu) atomicOr(&uniq_q[wd], s_fb[i]); }
 }
 
 // ---- the visit table (upload time; a function of the graphs alone) ----
