@@ -21,7 +21,7 @@ SYMBOLS = [
     "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_pao_solve_batch", "pantax_hip_profile", "pantax_hip_profile_step", "pantax_hip_profile_step_enqueue", "pantax_hip_profile_step_collect", "pantax_hip_trio_index_prefetch", "pantax_hip_sort_rows",
     "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter", "pantax_hip_db_save_images", "pantax_hip_db_load_images",
     "pantax_hip_gaf_load", "pantax_hip_gaf_load_device", "pantax_hip_reads_load_gaf", "pantax_hip_reads_set_flags", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
-    "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free", "pantax_hip_format_f64",
+    "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free", "pantax_hip_format_f64", "pantax_hip_gaf_prune_text",
     "pantax_hip_reads_route_pack", "pantax_hip_route_buffer", "pantax_hip_route_free", "pantax_hip_reads_from_routed",
     "pantax_hip_timing_enable", "pantax_hip_timing_filter", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
 ]

@@ -412,6 +412,14 @@ int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t bytes
 // chunk of piece k has been enqueued (record an event there).  fd >= 0: pread from the file at file_base + offset, else from `text`.
 int upload_text_pieces(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off, const uint64_t *piece_end,
                        hipStream_t stream, const std::function<bool(size_t)> &before_piece, const std::function<int(size_t)> &after_piece);
+// the same with the columns the path never reads left behind (gaf_prune.cc; the text must be in memory -- the mapped file): piece k
+// arrives as pruned_size bytes (<= its size) at d_dst[k], handed to after_piece(k, pruned_size)
+int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off,
+                              const uint64_t *piece_end, hipStream_t stream, const std::function<bool(size_t)> &before_piece,
+                              const std::function<int(size_t, uint64_t)> &after_piece);
+// gaf_prune.cc: the lines that start in [begin, end) of text[0, size) with the unread fields emptied and the tags cut off -> out
+// (at most as many bytes as the lines hold); returns the bytes written
+uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out);
 // fn(begin, end) over [0, n) split across up to n_threads host threads (the calling thread takes the first slice)
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn);
 // small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)

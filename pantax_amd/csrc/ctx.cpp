@@ -2,6 +2,7 @@
 #include <exception>
 #include <cstdarg>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <chrono>
@@ -308,6 +309,7 @@ struct StageCrew {
     int done = 0, nth = 1;
     bool quit = false;
     uint8_t *slot = nullptr; const uint8_t *src = nullptr; int fd = -1; uint64_t pos = 0, n = 0;
+    const std::function<void(int, int)> *job = nullptr;   // run(): any per-thread job instead of the copy
     std::vector<std::thread> th;
     static void piece(uint8_t *slot, const uint8_t *src, int fd, uint64_t pos, uint64_t n, int t, int nth) {
         const uint64_t b = n * (uint64_t)t / (uint64_t)nth, e = n * (uint64_t)(t + 1) / (uint64_t)nth;
@@ -329,8 +331,9 @@ struct StageCrew {
                     if (quit) return;
                     seen = gen;
                     uint8_t *sl = slot; const uint8_t *sr = src; const int f = fd; const uint64_t p = pos, nn = n;
+                    const std::function<void(int, int)> *jb = job;
                     lk.unlock();
-                    piece(sl, sr, f, p, nn, t, nth);
+                    if (jb) (*jb)(t, nth); else piece(sl, sr, f, p, nn, t, nth);
                     lk.lock();
                     if (++done == nth - 1) cv_done.notify_one();
                 }
@@ -341,8 +344,16 @@ struct StageCrew {
         cv_go.notify_all();
         for (auto &t : th) t.join();
     }
+    void run(const std::function<void(int, int)> &fn) {   // fn(t, nth) on every thread of the crew; returns when all are done
+        { std::lock_guard<std::mutex> g(mu); job = &fn; done = 0; ++gen; }
+        cv_go.notify_all();
+        fn(0, nth);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return done == nth - 1; });
+        job = nullptr;
+    }
     void fill(uint8_t *slot_, const uint8_t *src_, int fd_, uint64_t pos_, uint64_t n_) {
-        { std::lock_guard<std::mutex> g(mu); slot = slot_; src = src_; fd = fd_; pos = pos_; n = n_; done = 0; ++gen; }
+        { std::lock_guard<std::mutex> g(mu); job = nullptr; slot = slot_; src = src_; fd = fd_; pos = pos_; n = n_; done = 0; ++gen; }
         cv_go.notify_all();
         piece(slot_, src_, fd_, pos_, n_, 0, nth);
         std::unique_lock<std::mutex> lk(mu);
@@ -422,6 +433,125 @@ int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_
     return upload_staged_pieces(ctx, &pc, 1, fd, stream, ring, nullptr, nullptr);
 }
 }  // namespace
+
+// The GAF load with the unread columns left behind (gaf_prune.cc): the crew does not copy the text into the pinned ring, it REWRITES it
+// there -- every thread prunes the lines of its own line-aligned range of the chunk into its own part of the slot, straight from the
+// mapped file (no pread copy in between) -- and the parts travel one after the other to consecutive device addresses, so the device
+// holds one contiguous pruned text per piece.  pruned_size[k] = bytes of piece k on the device.  A chunk that holds a line longer than
+// a thread's part of the slot travels unpruned (byte for byte: the tokenizer reads either form).
+int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off,
+                              const uint64_t *piece_end, hipStream_t stream, const std::function<bool(size_t)> &before_piece,
+                              const std::function<int(size_t, uint64_t)> &after_piece) {
+    PinBuf &ring = ctx->pin_text;
+    constexpr int SLOTS = 3;
+    static const int NTH_ENV = std::getenv("PANTAX_PRUNE_THREADS") ? std::atoi(std::getenv("PANTAX_PRUNE_THREADS")) : 64;
+    const int nth = std::max(1, std::min(NTH_ENV, (int)std::thread::hardware_concurrency() / 2 > 0 ? (int)std::thread::hardware_concurrency() / 2 : 1));
+    const uint64_t CH = 64ull << 20, MARGIN = 256ull << 10;
+    const uint64_t part = (CH + nth - 1) / nth + MARGIN;          // the longest range a thread prunes in one go
+    PTX_HIP(ctx, ring.reserve((uint64_t)SLOTS * (CH + part)));
+    const uint64_t slot_bytes = CH + part;
+    // every thread: its range of the text -> (pread: a private buffer that stays in its cache) -> pruned into a second private buffer ->
+    // copied to its place in the pinned slot, which is known once the threads before it have announced their sizes
+    // PANTAX_PRUNE_SRC=pread reads the text through private buffers instead of the mapping (measured 5 x slower per chunk on the box: 64
+    // threads inside pread on one file)
+    static const bool SRC_PREAD = std::getenv("PANTAX_PRUNE_SRC") && std::getenv("PANTAX_PRUNE_SRC")[0] == 'p';
+    if (!SRC_PREAD || !text) fd = text ? -1 : fd;
+    std::vector<std::vector<uint8_t>> in_buf(fd >= 0 ? nth : 0), out_buf(nth);
+    for (auto &v : in_buf) v.resize(part);
+    for (auto &v : out_buf) v.resize(part);
+    StageCrew crew(nth);
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
+    for (auto &e : ev) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint8_t *tx = reinterpret_cast<const uint8_t *>(text);
+    int rc = 0;
+    uint64_t i = 0, sent = 0, seen = 0;
+    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    double t_wait = 0, t_fill = 0, t_enq = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = now();
+    std::vector<uint64_t> cut(nth + 1);
+    std::unique_ptr<std::atomic<uint64_t>[]> pre(new std::atomic<uint64_t>[nth + 1]);   // pre[t] = bytes of the threads before t (UINT64_MAX: not yet known)
+    for (size_t pk = 0; pk < n_pieces && rc == 0; ++pk) {
+        if (before_piece && !before_piece(pk)) { rc = PANTAX_HIP_E_STATE; break; }
+        uint8_t *dst = static_cast<uint8_t *>(d_dst[pk]);
+        const uint64_t pb = piece_off[pk], pe = piece_end[pk];
+        uint64_t dev_off = 0;
+        // next line start at or behind `at` (the piece begins at a line start and ends behind a line end or at the end of the text)
+        auto align = [&](uint64_t at) -> uint64_t {
+            if (at <= pb) return pb;
+            if (at >= pe) return pe;
+            const void *nl = std::memchr(tx + at - 1, '\n', (size_t)(pe - (at - 1)));
+            return nl ? (uint64_t)(static_cast<const uint8_t *>(nl) - tx) + 1 : pe;
+        };
+        for (uint64_t pos = pb; pos < pe && rc == 0; ++i) {
+            const uint64_t cend = align(std::min(pe, pos + CH));
+            const int k = (int)(i % SLOTS);
+            uint8_t *slot = ring.p + (uint64_t)k * slot_bytes;
+            const auto t0 = now();
+            if (i >= SLOTS && hipEventSynchronize(ev[k]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
+            const auto t1 = now();
+            cut[0] = pos; cut[nth] = cend;
+            for (int t = 1; t < nth; ++t) cut[t] = std::max(cut[t - 1], std::min(cend, align(pos + (cend - pos) * (uint64_t)t / (uint64_t)nth)));
+            bool fits = cend - pos <= CH + part - MARGIN;
+            for (int t = 0; t < nth; ++t) fits = fits && cut[t + 1] - cut[t] <= part;
+            uint64_t n_out = 0;
+            if (fits) {
+                pre[0].store(0, std::memory_order_relaxed);
+                for (int t = 1; t <= nth; ++t) pre[t].store(~0ull, std::memory_order_relaxed);
+                const std::function<void(int, int)> job = [&](int t, int) {
+                    const uint64_t a = cut[t], b = cut[t + 1];
+                    uint64_t n = 0;
+                    if (b > a) {
+                        const uint8_t *src = tx + a;
+                        if (fd >= 0) {                                   // through a private buffer: the text is read once from the page cache, never mapped
+                            uint64_t at = 0;
+                            while (at < b - a) {
+                                const ssize_t r = ::pread(fd, in_buf[t].data() + at, b - a - at, (off_t)(file_base + a + at));
+                                if (r <= 0) { std::memset(in_buf[t].data() + at, '\n', b - a - at); break; }   // truncated file: sizes were validated by the caller
+                                at += (uint64_t)r;
+                            }
+                            src = in_buf[t].data();
+                        }
+                        n = gaf_prune_range(src, b - a, 0, b - a, true, out_buf[t].data());
+                    }
+                    uint64_t off;
+                    for (uint32_t spin = 0; (off = pre[t].load(std::memory_order_acquire)) == ~0ull; ++spin) { if (spin < 4096) __builtin_ia32_pause(); else std::this_thread::yield(); }
+                    pre[t + 1].store(off + n, std::memory_order_release);
+                    if (n) std::memcpy(slot + off, out_buf[t].data(), n);
+                };
+                crew.run(job);
+                n_out = pre[nth].load(std::memory_order_acquire);
+            }
+            const auto t2 = now();
+            if (fits) {
+                if (n_out && hipMemcpyAsync(dst + dev_off, slot, n_out, hipMemcpyHostToDevice, stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+                dev_off += n_out;
+            } else {
+                // a line longer than a thread's buffer: this chunk travels unpruned, in slot-sized blocks through the same slot
+                for (uint64_t off = pos; off < cend && rc == 0;) {
+                    const uint64_t n = std::min<uint64_t>(slot_bytes, cend - off);
+                    if (off != pos && hipStreamSynchronize(stream) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed"); break; }
+                    crew.fill(slot, fd >= 0 ? nullptr : tx, fd, (fd >= 0 ? file_base : 0) + off, n);
+                    if (hipMemcpyAsync(dst + dev_off, slot, n, hipMemcpyHostToDevice, stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+                    dev_off += n; off += n;
+                }
+            }
+            if (rc == 0 && hipEventRecord(ev[k], stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+            if (trace) { const auto t3 = now(); t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, t3); }
+            seen += cend - pos;
+            pos = cend;
+        }
+        sent += dev_off;
+        if (rc == 0 && after_piece) rc = after_piece(pk, dev_off);
+    }
+    if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    if (trace)
+        std::fprintf(stderr, "[upload_pruned] %.1f MB of text -> %.1f MB over PCIe in %.2f ms (%.1f GB/s of text): %zu piece(s), %llu chunks, %d threads; waiting for a slot %.2f, "
+                     "pruning %.2f, enqueue %.2f ms\n", seen / 1e6, sent / 1e6, ms(t_begin, now()), seen / 1e6 / ms(t_begin, now()), n_pieces, (unsigned long long)i, nth, t_wait, t_fill, t_enq);
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
 
 int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) { return upload_staged(ctx, d_dst, src, -1, 0, size, ctx->stream, ctx->pin_text); }
 int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t size) { return upload_staged(ctx, d_dst, nullptr, fd, file_off, size, ctx->stream, ctx->pin_text); }

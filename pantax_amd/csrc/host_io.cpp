@@ -324,7 +324,7 @@ static void parse_chunk(const char *b, const char *e, const char *base, HostRead
             uint8_t flag = 0;
             uint32_t ql = 0, ps = 0, pe = 0, pl = 0, mq = 255;
             if (nf > 1) parse_u32(fb[1], fe[1], ql);
-            bool path_null = nf <= 5 || (fe[5] - fb[5] == 1 && *fb[5] == '*');
+            bool path_null = nf <= 5 || fe[5] == fb[5] || (fe[5] - fb[5] == 1 && *fb[5] == '*');   // '*' and the empty field are null (the reader's null_values / missing_is_null)
             if (!path_null) {
                 for (const char *c = fb[5]; c < fe[5];) {       // regex \d+ over the walk (rcls.rs:242-245)
                     if (*c >= '0' && *c <= '9') {

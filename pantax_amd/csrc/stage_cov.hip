@@ -650,9 +650,14 @@ __global__ void __launch_bounds__(256) group_count_kernel(uint64_t R, const uint
     }
 }
 __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint32_t *__restrict__ step_off, const uint32_t *__restrict__ node_id,
-                                                         int shift, const uint32_t *__restrict__ base_r, uint32_t *__restrict__ cur_r,
-                                                         uint32_t *__restrict__ slot_of, uint32_t *__restrict__ slot_len, uint32_t *__restrict__ read_of,
+                                                         const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, const uint32_t *__restrict__ qlen,
+                                                         const uint8_t *__restrict__ mapq, int shift, const uint32_t *__restrict__ base_r, uint32_t *__restrict__ cur_r,
+                                                         uint32_t *__restrict__ slot_of, uint4 *__restrict__ g_read_rec, uint2 *__restrict__ g_qm,
                                                          uint32_t *__restrict__ n_long) {
+    // The per-read columns are read HERE, in file order (coalesced), and leave as the slot's two records -- {first step of the walk in
+    // the source columns (group_fill_kernel replaces it by the walk's place in the grouped stream), #steps, pstart, pend} and {read
+    // length, MAPQ}: the fill pass then reads one coalesced record per slot.  (Round 3 kept {#steps, read} per slot and let the fill
+    // pass gather six columns at random: 46 GB fetched for 4 GB of payload at 1e8 reads.)
     uint32_t mine = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += (uint64_t)gridDim.x * 256) {
         const uint32_t b = step_off[r], k = step_off[r + 1] - b;
@@ -660,8 +665,8 @@ __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint3
         if (k) {
             const uint32_t key = node_id[b] >> shift;
             slot = base_r[key] + atomicAdd(&cur_r[key], 1u);
-            slot_len[slot] = k;
-            read_of[slot] = (uint32_t)r;
+            g_read_rec[slot] = make_uint4(b, k, pstart[r], pend[r]);
+            g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
             mine += k > 64 ? 1u : 0u;
         }
         slot_of[r] = slot;
@@ -675,7 +680,7 @@ __global__ void __launch_bounds__(256) group_slot_kernel(uint64_t R, const uint3
 // bucket cost 32 pad steps per bucket on average: with ten reads per bucket -- 1e7 reads over 3.2e7 nodes -- the padded
 // stream was 1.45 x the walk steps, and the coverage kernel spends a lane on every pad.)
 __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, const uint32_t *__restrict__ base_r /*[NB+1]*/,
-                                                           const uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_rel,
+                                                           const uint4 *__restrict__ g_read_rec, uint32_t *__restrict__ slot_rel,
                                                            uint32_t *__restrict__ size_s) {
     const uint32_t key = blockIdx.x * 256 + threadIdx.x;
     const uint32_t NU = (NB + (1u << g) - 1) >> g;
@@ -683,7 +688,7 @@ __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, c
     const uint32_t k0 = key << g, k1 = min(NB, (key + 1) << g);
     uint32_t pos = 0;
     for (uint32_t s = base_r[k0], e = base_r[k1]; s < e; ++s) {
-        const uint32_t k = slot_len[s];
+        const uint32_t k = g_read_rec[s].y;
         if (k <= 64 && (pos & 63) + k > 64) pos = (pos + 63) & ~63u;
         slot_rel[s] = pos;
         pos += k;
@@ -697,11 +702,9 @@ __global__ void __launch_bounds__(256) group_layout_kernel(uint32_t NB, int g, c
 // a private loop over its steps still re-read every walk k times for the first-occurrence codes: 41 ms.)  The code of a step
 // -- distance back to the first occurrence of its node in the walk -- comes from the lanes below (and, where a walk began in
 // the round before, from that round's ids).
-__global__ void __launch_bounds__(256) group_fill_kernel(uint32_t n_slots, const uint32_t *__restrict__ read_of, const uint32_t *__restrict__ step_off,
-                                                         const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend,
-                                                         const uint32_t *__restrict__ qlen, const uint8_t *__restrict__ mapq, int shift,
+__global__ void __launch_bounds__(256) group_fill_kernel(uint32_t n_slots, const uint32_t *__restrict__ node_id, int shift,
                                                          const uint32_t *__restrict__ base_s, const uint32_t *__restrict__ slot_rel, uint4 *__restrict__ g_read_rec,
-                                                         uint2 *__restrict__ g_qm, uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
+                                                         uint32_t *__restrict__ g_node_id, uint32_t *__restrict__ g_group_slot,
                                                          uint8_t *__restrict__ g_step_dup) {
     __shared__ uint32_t s_excl[4][65], s_b[4][64], s_sb[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -710,11 +713,11 @@ __global__ void __launch_bounds__(256) group_fill_kernel(uint32_t n_slots, const
         const uint32_t slot = w * 64 + lane;
         uint32_t b = 0, k = 0, sb = 0;
         if (slot < n_slots) {
-            const uint32_t r = read_of[slot];
-            b = step_off[r]; k = step_off[r + 1] - b;
+            uint4 rec = g_read_rec[slot];                            // {first step in the source columns, #steps, pstart, pend}: group_slot_kernel
+            b = rec.x; k = rec.y;
             sb = base_s[node_id[b] >> shift] + slot_rel[slot];
-            g_read_rec[slot] = make_uint4(sb, k, pstart[r], pend[r]);
-            g_qm[slot] = make_uint2(qlen[r], (uint32_t)mapq[r]);    // slot-order copies for the binning pass
+            rec.x = sb;
+            g_read_rec[slot] = rec;
             if (k > 64) k = 0;                                       // laid out by group_fill_long_kernel, one workgroup per walk
             else if ((sb & 63u) == 0u) g_group_slot[sb >> 6] = slot; // a walk of <= 64 steps lies inside one 64-step group
         }
@@ -823,12 +826,11 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     int shift = 5;
     while (((uint64_t)max_node_id >> shift) + 1 > (1u << 20)) ++shift;
     const uint32_t NB = (uint32_t)(max_node_id >> shift) + 1;
-    DevBuf<uint32_t> cnt, scan_tmp, slot_len, slot_rel;
+    DevBuf<uint32_t> cnt, scan_tmp, slot_rel;
     PTX_HIP(ctx, cnt.alloc(4ull * (NB + 1) + 8));
     uint32_t *cnt_r = cnt.p, *base_r = cnt_r + (NB + 1), *size_s = base_r + (NB + 1), *base_s = size_s + (NB + 1);
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB + 1)));
-    DevBuf<uint32_t> read_of;
-    PTX_HIP(ctx, slot_len.alloc(rd->R)); PTX_HIP(ctx, slot_rel.alloc(rd->R)); PTX_HIP(ctx, read_of.alloc(rd->R));
+    PTX_HIP(ctx, slot_rel.alloc(rd->R));
     PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R));
     PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));
     int gridR = grid_for(rd->R, 256, ctx->n_cu * 8);
@@ -837,13 +839,13 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));   // reused as cursors
     uint32_t *d_total = (uint32_t *)ctx->d_scalars.p, *d_n_long = d_total + 1;
     PTX_HIP(ctx, hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, base_r, cnt_r,
-                       rd->d_slot_of.p, slot_len.p, read_of.p, d_n_long);
+    hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p, rd->d_pend.p,
+                       rd->d_qlen.p, rd->d_mapq.p, shift, base_r, cnt_r, rd->d_slot_of.p, rd->d_g_read_rec.p, rd->d_g_qm.p, d_n_long);
     // layout units: 2^g buckets each, about 2048 walk steps per unit (the rounding of a unit to 64 steps then costs ~1.5 %)
     int g = 0;
     while (g < 12 && ((double)rd->T / (double)NB) * (double)(1u << g) < 2048.0) ++g;
     const uint32_t NU = (NB + (1u << g) - 1) >> g;
-    hipLaunchKernelGGL(group_layout_kernel, dim3((NU + 255) / 256), dim3(256), 0, ctx->stream, NB, g, base_r, slot_len.p, slot_rel.p, size_s);
+    hipLaunchKernelGGL(group_layout_kernel, dim3((NU + 255) / 256), dim3(256), 0, ctx->stream, NB, g, base_r, rd->d_g_read_rec.p, slot_rel.p, size_s);
     PTX_TRY(exclusive_scan_u32(ctx, size_s, base_s, NU, scan_tmp.p, d_total));
     const int ushift = shift + g;   // unit of a read = its first node id >> ushift
     uint32_t h_tot[2] = {0, 0}, h_slots = 0;
@@ -860,9 +862,8 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_group_slot.p, 0xFF, (rd->T_pad / 64 + 1) * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0xFF, rd->T_pad, ctx->stream));                          // STEP_PAD
     if (rd->n_slots)
-        hipLaunchKernelGGL(group_fill_kernel, dim3(grid_for(rd->n_slots, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->n_slots, read_of.p, rd->d_step_off.p,
-                           rd->d_node_id.p, rd->d_pstart.p, rd->d_pend.p, rd->d_qlen.p, rd->d_mapq.p, ushift, base_s, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_qm.p,
-                           rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);
+        hipLaunchKernelGGL(group_fill_kernel, dim3(grid_for(rd->n_slots, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->n_slots, rd->d_node_id.p, ushift,
+                           base_s, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);
     if (rd->n_long) {
         const uint32_t gridL = (uint32_t)std::min<uint64_t>(rd->R, (uint64_t)ctx->n_cu * 64);
         hipLaunchKernelGGL(group_fill_long_kernel, dim3(gridL), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, ushift, base_s,

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) gaf_parse_kernel(const uint8_t *__restric
     uint8_t flag = 0;
     uint32_t ql = 0, ps = 0, pe = 0, pl = 0, mq = 255, steps = 0;
     if (nf > 1) dev_parse_u32(txt, fb[1], fe[1], ql);
-    const bool path_null = nf <= 5 || (fe[5] - fb[5] == 1 && txt[fb[5]] == '*');
+    const bool path_null = nf <= 5 || fe[5] == fb[5] || (fe[5] - fb[5] == 1 && txt[fb[5]] == '*');   // '*' and the empty field are null
     if (!path_null) {
         bool in_run = false;
         for (uint32_t c = fb[5]; c < fe[5]; ++c) {
@@ -216,6 +216,22 @@ __global__ void __launch_bounds__(256) dup_count_kernel(uint64_t n, const uint64
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+__global__ void __launch_bounds__(256) id_set_insert_kernel(uint32_t n, const uint64_t *__restrict__ hashes, unsigned long long *__restrict__ tab, uint64_t mask,
+                                                           uint32_t *__restrict__ dup) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long h = hashes[i];
+    if (!h) h = 1ull;                                  // 0 marks an empty slot (a false "equal" of the hashes 0 and 1 only sends the caller to its exact pass)
+    uint64_t slot = (h >> 5) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        const unsigned long long old = atomicCAS(&tab[slot], 0ull, h);
+        if (old == 0ull) return;
+        if (old == h) { atomicAdd(dup, 1u); return; }
+        slot = (slot + 1) & mask;
+    }
+    atomicAdd(dup, 1u);                                // a full table cannot happen (load <= 0.7): never silent
+}
+
 __global__ void __launch_bounds__(256) max_u32_kernel(uint64_t n, const uint32_t *__restrict__ v, uint32_t *__restrict__ out) {
     uint32_t m = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = max(m, v[i]);
@@ -230,6 +246,13 @@ struct GafJoined {
     DevBuf<uint32_t> o32[7];   // step_off, node_id, pstart, pend, qlen, id_off (piece-local), id_len
     DevBuf<uint8_t> o8[2];     // mapq, flags
     DevBuf<uint64_t> o_hash;
+    // "are all read ids distinct?" piece by piece, beside the upload: every piece's id hashes are inserted into an open-addressing set
+    // (sized from the first piece's density); an insert that meets its own value counts a duplicate.  A text that turns out denser than
+    // the set was sized for falls back to sorting the hashes after the last piece (round 3's path: 9 ms behind the last byte at 1e8 reads).
+    DevBuf<uint64_t> id_set;
+    DevBuf<uint32_t> dup_cnt;
+    uint64_t set_slots = 0;
+    bool set_ok = false;
     uint64_t R = 0, T = 0, cap_r = 0, cap_t = 0;
     std::vector<uint64_t> piece_r0;   // first read of every piece (id spans are piece-local)
 };
@@ -317,12 +340,24 @@ static int tokenize_piece(Ctx *ctx, const uint8_t *d_txt, uint64_t size, bool la
         need_t = std::max<uint64_t>(need_t, std::min<uint64_t>(0xFFFFFFFEull, J.T + (uint64_t)((double)T * f) + 1024));
         PTX_TRY(joined_reserve(ctx, J, need_r, need_t));
     }
+    if (!J.id_set.p) {   // first piece: the set for the whole text, twice the reads the joined columns were sized for
+        uint64_t slots = 1024;
+        while (slots < 2 * J.cap_r) slots <<= 1;
+        PTX_HIP(ctx, J.id_set.alloc(slots)); PTX_HIP(ctx, J.dup_cnt.alloc(1));
+        PTX_TRY(zero_fill(ctx, J.id_set.p, slots * sizeof(uint64_t)));
+        PTX_HIP(ctx, hipMemsetAsync(J.dup_cnt.p, 0, sizeof(uint32_t), ctx->stream));
+        J.set_slots = slots; J.set_ok = true;
+    }
+    if ((double)(J.R + R) > 0.7 * (double)J.set_slots) J.set_ok = false;
     GafOut go{J.o32[0].p + J.R, J.o32[1].p + J.T, J.o32[2].p + J.R, J.o32[3].p + J.R, J.o32[4].p + J.R, J.o32[5].p + J.R, J.o32[6].p + J.R,
               J.o8[0].p + J.R, J.o8[1].p + J.R, J.o_hash.p + J.R};
     {
         KTimer t(ctx, "gaf_fill_kernel");
         hipLaunchKernelGGL(gaf_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_txt, n_raw, raw, W.ridx.p, W.soff.p, (uint32_t)R, (uint32_t)T, (uint32_t)J.T, go);
     }
+    if (J.set_ok && R)
+        hipLaunchKernelGGL(id_set_insert_kernel, dim3((uint32_t)((R + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)R, J.o_hash.p + J.R,
+                           reinterpret_cast<unsigned long long *>(J.id_set.p), J.set_slots - 1, J.dup_cnt.p);
     PTX_HIP(ctx, hipGetLastError());
     J.piece_r0.push_back(J.R);
     J.R += R; J.T += T;
@@ -378,7 +413,10 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     std::vector<uint64_t> piece_off, piece_end;
     uint64_t longest = 0;
     for (uint64_t off = 0; off < size;) {
-        uint64_t end = std::min<uint64_t>(size, off + piece_max);
+        // the last stretch of the text travels in quarter pieces: the tokenizer's work on the LAST piece is what the load waits for
+        // behind the last byte (14 ms per GiB)
+        const uint64_t pm = (!capped && size - off <= piece_max && piece_max >= (256ull << 20)) ? piece_max / 4 : piece_max;
+        uint64_t end = std::min<uint64_t>(size, off + pm);
         if (end < size) {   // back to the last line end inside the piece
             const void *nl = memrchr(text + off, '\n', (size_t)(end - off));
             if (!nl && !capped) {   // a line longer than the default piece: forward to its end (pieces stay below 3.5 GiB)
@@ -415,22 +453,30 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         for (auto &e : ev_piece) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         std::vector<void *> dsts(NP);
         for (size_t k = 0; k < NP; ++k) dsts[k] = txt[k % RING].p;
+        // The columns the path never reads stay on the host (gaf_prune.cc: ~0.6 of the bytes of a short-read GAF travel) unless the
+        // caller wants the id spans -- positions in the ORIGINAL text -- or PANTAX_GAF_PRUNE=0 (measurements, tests)
+        bool prune = text != nullptr && !want_id_spans;
+        if (const char *ev = std::getenv("PANTAX_GAF_PRUNE")) prune = prune && ev[0] != '0';
+        std::vector<uint64_t> dev_size(NP);
+        for (size_t k = 0; k < NP; ++k) dev_size[k] = piece_end[k] - piece_off[k];
         std::thread uploader([&] {
             (void)hipSetDevice(ctx->device);
-            const int rc = upload_text_pieces(
-                ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream,
-                [&](size_t k) {   // the text buffer of piece k is free once piece k - RING has been tokenised
-                    std::unique_lock<std::mutex> lk(sh.mu);
-                    sh.cv.wait(lk, [&] { return sh.stop || k < sh.tokenised + RING; });
-                    return !sh.stop;
-                },
-                [&](size_t k) {   // all of piece k is on the upload stream: the tokenizer's stream waits for this event
-                    if (hipEventRecord(ev_piece[k], up_stream) != hipSuccess) return fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipEventRecord failed");
-                    std::lock_guard<std::mutex> g(sh.mu);
-                    sh.uploaded = k + 1;
-                    sh.cv.notify_all();
-                    return 0;
-                });
+            auto gate = [&](size_t k) {   // the text buffer of piece k is free once piece k - RING has been tokenised
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return sh.stop || k < sh.tokenised + RING; });
+                return !sh.stop;
+            };
+            auto arrived = [&](size_t k, uint64_t bytes) {   // all of piece k is on the upload stream: the tokenizer's stream waits for this event
+                if (hipEventRecord(ev_piece[k], up_stream) != hipSuccess) return fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipEventRecord failed");
+                std::lock_guard<std::mutex> g(sh.mu);
+                dev_size[k] = bytes;
+                sh.uploaded = k + 1;
+                sh.cv.notify_all();
+                return 0;
+            };
+            const int rc = prune ? upload_text_pieces_pruned(ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream, gate, arrived)
+                                 : upload_text_pieces(ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream, gate,
+                                                      [&](size_t k) { return arrived(k, piece_end[k] - piece_off[k]); });
             std::lock_guard<std::mutex> g(sh.mu);
             if (rc != 0 && !sh.stop) { sh.rc = rc; sh.stop = true; }
             sh.cv.notify_all();
@@ -444,7 +490,11 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
                 if (sh.uploaded <= k) { rc = sh.rc ? sh.rc : PANTAX_HIP_E_HIP; break; }
             }
             if (hipStreamWaitEvent(ctx->stream, ev_piece[k], 0) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "gaf_tokenize: hipStreamWaitEvent failed"); }
-            if (rc == 0) rc = tokenize_piece(ctx, txt[k % RING].p, piece_end[k] - piece_off[k], text[piece_end[k] - 1] == '\n', size - piece_end[k], W, J);
+            if (rc == 0) {
+                const uint64_t in_size = piece_end[k] - piece_off[k], ds = dev_size[k];   // what follows, at this piece's ratio of device bytes to text bytes
+                const uint64_t rest = in_size ? (uint64_t)((double)(size - piece_end[k]) * ((double)ds / (double)in_size)) : 0;
+                rc = tokenize_piece(ctx, txt[k % RING].p, ds, text[piece_end[k] - 1] == '\n', rest, W, J);
+            }
             if (rc == 0 && k == 0 && NP > 1 && want_host_columns) {
                 const uint64_t est = J.cap_r;
                 prefault = std::thread([&out, est] { out.qlen.resize(est); out.mapq.resize(est); out.flags.resize(est); out.id_hash.resize(est); });
@@ -505,7 +555,9 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     DevBuf<uint64_t> hs_a, hs_b;
     DevBuf<uint32_t> hs_table, dup_cnt;
     uint32_t n_dup = 0;
-    if (R > 1) {
+    if (J.set_ok) {                                     // decided piece by piece, beside the upload
+        if (R > 1) PTX_TRY(download(ctx, &n_dup, J.dup_cnt.p, 1));
+    } else if (R > 1) {
         PTX_HIP(ctx, hs_a.alloc(R)); PTX_HIP(ctx, hs_b.alloc(R)); PTX_HIP(ctx, hs_table.alloc(sort_table_elems(R))); PTX_HIP(ctx, dup_cnt.alloc(1));
         PTX_HIP(ctx, hipMemcpyAsync(hs_a.p, o_hash.p, R * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(dup_cnt.p, 0, sizeof(uint32_t), ctx->stream));

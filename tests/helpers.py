@@ -38,6 +38,41 @@ def load_micro_bin():
     return j, step_off, node_id, qlen, mapq, species, rs, re
 
 
+def gaf_quirks_text():
+    """Every quirk of the GAF contract (rcls.rs:119-137 through the reader it configures, oracle/gaf_reader.py): comments, '*' nulls in
+    every selected column, CR LF, ragged lines of every length, empty lines, empty fields, 13+ fields and long tags, non-integers in
+    integer columns, numbers beyond 32 bits, digits inside non-numeric path text, no trailing newline."""
+    long_tag = b"cs:Z:" + b":150" * 400
+    return (b"@HD\tVN:1.0\n"
+            b"r1\t150\t0\t150\t+\t>12<7>300\t400\t3\t153\t150\t150\t60\tNM:i:0\n"
+            b"r2\t150\t0\t150\t+\t*\t*\t*\t*\t*\t*\t255\n"
+            b"r3\t100\t0\t100\t+\t<5\t30\t20\t10\t100\t100\t*\r\n"
+            b"\n"
+            b"\r\n"
+            b"r5\t99999999999\t0\t1\t+\t>4294967296>7\t1\t99999999999\t5\t1\t1\t300\ta\tb\tc\n"
+            b"r6\tx12\t0\t1\t+\t>1>2\t12x\t3\t4\t1\t1\t7\n"
+            b"r7\t10\t0\t10\t+\tabc>>9<<10zz11\t5\t\t6\n"
+            b"@ comment in the middle\n"
+            b"r8\n"
+            b"*\t*\t*\t*\t*\t>3>4\t9\t1\t8\t*\t*\t17\n"                       # null id and length, the rest usable
+            b"r10\t150\t0\t150\t+\t>21>22>23\t*\t0\t150\t150\t150\t60\n"           # only read_path_len null
+            b"r11\t150\t0\t150\t+\t>21>22>23\t300\t*\t150\t150\t150\t60\n"         # only read_start null
+            b"r12\t150\t0\t150\t+\t>21>22>23\t300\t0\t*\t150\t150\t60\n"           # only read_end null
+            b"r13\t150\t0\t150\t+\t>21>22>23\t300\t0\t150\t150\t150\t60\t" + long_tag + b"\tNM:i:3\r\n"   # a long tag, CR LF behind it
+            b"r14\t150\t0\t150\t+\t>5\t300\t7\t9\t150\t150\t60\r\n"                # exactly twelve fields + CR LF
+            b"r15\t150\t0\t150\t+\t>5\t300\t7\t9\t150\t150\n"                       # eleven fields: no mapq column
+            b"r16\t150\t0\t150\t+\t>5\t300\t7\t9\t150\n"                            # ten
+            b"r17\t150\t0\t150\t+\t>5\n"                                             # six: the path is the last field
+            b"r18\t150\t0\t150\t+\n"                                                 # five: no path column
+            b"\t\t\t\t\t\t\t\t\t\t\t\n"                                             # twelve empty fields
+            b"r19 with spaces\t+150\t0\t150\t+\t>7 >8\t 300\t7 \t9\t150\t150\t 60\n"  # spaces are not separators; '+150', ' 300' are not integers
+            b"r20\t150\t0\t150\t+\t>007>08\t0300\t007\t0009\t150\t150\t060\n"       # leading zeros
+            b"r21\t150\t0\t150\t+\t>1>2\t300\t-1\t150\t150\t150\t60\n"             # a negative read_start is an integer in the reference; the packed layout has no sign
+            b"r22\t150\t0\t150\t+\t\t300\t0\t150\t150\t150\t60\n"                   # an EMPTY path field is a missing value: null
+            b"@tail comment\n"
+            b"r9\t90\t0\t90\t+\t>8>9\t200\t0\t90")
+
+
 def select_reads(reads, sel):
     """Sub-select reads `sel` (indices) from a PackedReads -> (step_off, node_id, pstart, pend)."""
     so = reads.step_off.astype(np.int64)

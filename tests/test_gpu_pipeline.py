@@ -254,6 +254,52 @@ def eng():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("piece", [None, "300000"])
+def test_resident_gaf_load_with_and_without_column_pruning(eng, tmp_path, piece, monkeypatch):
+    """pantax_hip_reads_load_gaf: the columns the path never reads stay on the host (gaf_prune.cc) unless PANTAX_GAF_PRUNE=0 -- either
+    way the resident reads are the reads of the text: same host columns, same species per read, same coverage integers; and those
+    of the packed upload of the generator's arrays.  The text carries every quirk of the format between its generated lines."""
+    from pantax_amd import synth
+    from tests.helpers import gaf_quirks_text
+    if piece is not None:
+        monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", piece)     # several pieces: the pruned pieces are joined on the device
+    sset = synth.make_set(78, 3, 4, 30000, 60000, with_ids=True)
+    p1 = tmp_path / "gen.gaf"
+    synth.write_gaf(sset.reads, p1)
+    gen = p1.read_bytes()
+    cut = gen.index(b"\n", len(gen) // 2) + 1
+    p = tmp_path / "mixed.gaf"
+    p.write_bytes(gen[:cut] + gaf_quirks_text() + b"\n" + gen[cut:])
+    eng.upload_db(sset.species)
+    got = []
+    for prune in ("1", "0"):
+        monkeypatch.setenv("PANTAX_GAF_PRUNE", prune)
+        cols = eng.load_reads_from_gaf(p)
+        sp, rc, bs, lm, uq = eng.rcls_profile()
+        eng.db_reset()
+        eng.trio_nodes_info()
+        bases, cov, tb, nab = eng.get_node_abundances()
+        got.append((cols, sp, (rc, bs, lm, uq), bases, cov, tb, nab))
+    a, b = got
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and a[6] == b[6]
+    # ... and the reads of the oracle's reading of the same text (oracle/gaf_reader.py), uploaded as packed arrays
+    from oracle import gaf_reader
+    w = gaf_reader.packed(p.read_bytes())
+    for k in a[0]:
+        assert np.array_equal(a[0][k], w[k]), ("oracle", k)
+    eng.upload_reads(w["step_off"], w["node_id"], w["pstart"], w["pend"], w["qlen"], w["mapq"], flags=w["flags"])
+    sp, *_ = eng.rcls_profile()
+    eng.db_reset()
+    eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    assert np.array_equal(sp, a[1])
+    assert np.array_equal(bases, a[3]) and np.array_equal(cov, a[4]) and np.array_equal(tb, a[5]) and nab == a[6]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("piece", [None, "200000", "97"])
 def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkeypatch):
     """pantax_hip_gaf_load_device (GAF text tokenised by HIP kernels) gives the arrays of the host tokenizer bit for
@@ -281,13 +327,19 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkey
         b"@ comment in the middle\n"
         b"r8\n"
         b"r9\t90\t0\t90\t+\t>8>9\t200\t0\t90")
-    for p in (p1, p2):
-        if piece == "97" and p is p1:
-            continue                      # its lines are longer than the piece: refused, see below
+    from oracle import gaf_reader
+    from tests.helpers import gaf_quirks_text
+    p3 = tmp_path / "quirks2.gaf"
+    p3.write_bytes(gaf_quirks_text())
+    for p in (p1, p2, p3):
+        if piece == "97" and p is not p2:
+            continue                      # their lines are longer than the piece: refused, see below
         host = pio.load_gaf(p, n_threads=3)
         dev = pio.load_gaf(p, engine=eng)
+        want = gaf_reader.packed(p.read_bytes())      # the reading of the format that is not this repo's tokenizer (oracle/gaf_reader.py)
         for k in host:
             assert np.array_equal(host[k], dev[k]), (p.name, k)
+            assert np.array_equal(want[k], dev[k]), (p.name, "oracle", k)
     if piece == "97":
         from pantax_amd.engine import PantaxHipError
         with pytest.raises(PantaxHipError):
