@@ -369,11 +369,12 @@ int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t
                           const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names);
 void pantax_hip_graph_free(pantax_hip_graph *g);
 
-/* The host side of the device GAF load (pantax_hip_reads_load_gaf without a gaf handle, pantax_hip_profile without the binning
- * report): the columns load_gaf_file_lazy drops (rcls.rs:127-137 keeps 1, 2, 6-9, 12) do not travel over PCIe.  Every line
- * that has twelve fields is rewritten with fields 3-5 and 10-11 empty and everything behind field 12 cut off; any other line
- * is copied byte for byte -- so the text parses, field by field, like the original.  This entry applies that rewrite to a
- * text in memory (tests, tools); out must hold `size` bytes, *out_size receives the bytes written.  Host only. */
+/* A prototype of the device GAF load's host side, OFF unless PANTAX_GAF_PRUNE=1 (round 4: it measured slower than the plain
+ * load -- the rewrite, not PCIe, then bounds the load): the columns load_gaf_file_lazy drops (rcls.rs:127-137 keeps 1, 2, 6-9,
+ * 12) do not travel over PCIe.  Every line that has twelve fields is rewritten with fields 3-5 and 10-11 empty and everything
+ * behind field 12 cut off; any other line is copied byte for byte -- so the text parses, field by field, like the original.
+ * This entry applies that rewrite to a text in memory (tests, tools); out must hold `size` bytes, *out_size receives the
+ * bytes written.  Host only. */
 int pantax_hip_gaf_prune_text(const char *text, uint64_t size, char *out, uint64_t *out_size);
 
 /* the float text of the two tables (polars CsvWriter behind rcls.rs:409-420: shortest round-trip digits, "16.0" for integral

@@ -453,10 +453,13 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         for (auto &e : ev_piece) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         std::vector<void *> dsts(NP);
         for (size_t k = 0; k < NP; ++k) dsts[k] = txt[k % RING].p;
-        // The columns the path never reads stay on the host (gaf_prune.cc: ~0.6 of the bytes of a short-read GAF travel) unless the
-        // caller wants the id spans -- positions in the ORIGINAL text -- or PANTAX_GAF_PRUNE=0 (measurements, tests)
-        bool prune = text != nullptr && !want_id_spans;
-        if (const char *ev = std::getenv("PANTAX_GAF_PRUNE")) prune = prune && ev[0] != '0';
+        // Prototype: the columns the path never reads stay on the host (gaf_prune.cc: 0.73 of the bytes of the synthetic short-read GAF
+        // travel); never when the caller wants the id spans -- positions in the ORIGINAL text.
+        // MEASURED SLOWER on the box (round 4, cfg4, 15.2 GB of text, 0.73 of it left after pruning): 0.87-0.92 s to resident reads with 64
+        // pruning threads against 0.33 s unpruned -- the rewrite runs at ~25 GB/s of text where the plain pread fill runs at 70 -- so it is
+        // OFF unless PANTAX_GAF_PRUNE=1; the tests run both ways (same columns, same tables).
+        bool prune = false;
+        if (const char *ev = std::getenv("PANTAX_GAF_PRUNE")) prune = ev[0] == '1' && text != nullptr && !want_id_spans;
         std::vector<uint64_t> dev_size(NP);
         for (size_t k = 0; k < NP; ++k) dev_size[k] = piece_end[k] - piece_off[k];
         std::thread uploader([&] {

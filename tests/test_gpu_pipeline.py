@@ -256,7 +256,7 @@ def eng():
 @pytest.mark.gpu
 @pytest.mark.parametrize("piece", [None, "300000"])
 def test_resident_gaf_load_with_and_without_column_pruning(eng, tmp_path, piece, monkeypatch):
-    """pantax_hip_reads_load_gaf: the columns the path never reads stay on the host (gaf_prune.cc) unless PANTAX_GAF_PRUNE=0 -- either
+    """pantax_hip_reads_load_gaf: the columns the path never reads stay on the host (gaf_prune.cc) when PANTAX_GAF_PRUNE=1 (a prototype that measured slower than the plain load and is off by default) -- either
     way the resident reads are the reads of the text: same host columns, same species per read, same coverage integers; and those
     of the packed upload of the generator's arrays.  The text carries every quirk of the format between its generated lines."""
     from pantax_amd import synth
