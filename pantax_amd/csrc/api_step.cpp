@@ -56,10 +56,10 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
             PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
         }
         hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->stream2;
+        ctx->stream_main = main_stream; ctx->stream = ctx->stream2;
         const int rc = trio_index_build(ctx, db, false);   // without the row-order export copies: no stage of the step reads them
         const hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream2);
-        ctx->stream = main_stream;
+        ctx->stream = main_stream; ctx->stream_main = nullptr;
         if (rc != 0) return rc;
         PTX_HIP(ctx, e);
         forked = true;
@@ -140,10 +140,10 @@ extern "C" int pantax_hip_trio_index_prefetch(pantax_hip_ctx *ctx, pantax_hip_db
         PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
     }
     hipStream_t main_stream = ctx->stream;
-    ctx->stream = ctx->stream2;
+    ctx->stream_main = main_stream; ctx->stream = ctx->stream2;
     const int rc = trio_index_build(ctx, db, false);
     const hipError_t e = hipEventRecord(ctx->ev_fork, ctx->stream2);
-    ctx->stream = main_stream;
+    ctx->stream = main_stream; ctx->stream_main = nullptr;
     if (rc != 0 || e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); db->trio_built = false; if (rc != 0) return rc; PTX_HIP(ctx, e); }
     PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     db->trio_prefetched = true;

@@ -22,7 +22,7 @@ static void usage() {
             "  --ranks N --rank r   one process per GPU (start N of them; device = r unless --device): every rank tokenises 1/N of the\n"
             "                       GAF, reads travel to the owner of their species over RCCL, rank 0 writes the tables\n"
             "                       (defaults from WORLD_SIZE / RANK / LOCAL_RANK when set); --comm-id-file F (default <wd>/.pantax_hip_rccl_id),\n"
-            "                       --comm-nonce N (default $MASTER_PORT or 0: the same for all ranks of one launch, different from the launch before)\n");
+            "                       --comm-nonce N (the same for all ranks of one launch; default from $TORCHELASTIC_RUN_ID / $MASTER_PORT; the id file must also be fresh)\n");
 }
 
 int main(int argc, char **argv) {
@@ -36,7 +36,15 @@ int main(int argc, char **argv) {
     const char *filter_in = nullptr, *filter_out = nullptr;
     int device = -1, ranks = 0, rank = -1;
     std::string id_file;
-    uint64_t nonce = getenv("MASTER_PORT") ? strtoull(getenv("MASTER_PORT"), nullptr, 10) : 0;   // per-launch nonce of the id file (rccl_comm.hpp)
+    // per-launch nonce of the id file (rccl_comm.hpp): something that changes from one launch to the next where the launcher offers it
+    // (torchrun: the run id + the restart count), else the rendezvous port; the file's age is checked in every case
+    uint64_t nonce = getenv("MASTER_PORT") ? strtoull(getenv("MASTER_PORT"), nullptr, 10) : 0;
+    if (const char *rid = getenv("TORCHELASTIC_RUN_ID")) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (const char *q = rid; *q; ++q) { h ^= (uint64_t)(unsigned char)*q; h *= 0x100000001b3ull; }
+        if (const char *rc = getenv("TORCHELASTIC_RESTART_COUNT")) h = h * 31 + strtoull(rc, nullptr, 10);
+        nonce ^= h ? h : 1;
+    }
     if (const char *ev = getenv("WORLD_SIZE")) ranks = atoi(ev);
     if (const char *ev = getenv("RANK")) rank = atoi(ev);
     if (const char *ev = getenv("LOCAL_RANK")) device = atoi(ev);

@@ -3,11 +3,12 @@
 // (INTEGRATION.md section 3b'').
 //
 // Bootstrap without MPI: rank 0 creates the ncclUniqueId and publishes it through a file in the work directory (written
-// under a temporary name, then renamed) together with a per-launch NONCE (--comm-nonce, or $MASTER_PORT, or "0": the launcher
-// gives all ranks of one launch the same value and consecutive launches different ones); the other ranks wait for a file that
-// carries THEIR nonce -- a file a dead run left behind does not match (with the default nonce "0" the old 2-second mtime
-// rule still applies).  A rank that fails before or inside init leaves the others in ncclCommInitRank: like any RCCL job,
-// run the launch under a launcher-side timeout.
+// under a temporary name, then renamed) together with a per-launch NONCE (--comm-nonce; default: $TORCHELASTIC_RUN_ID + restart
+// count when a launcher sets them, else $MASTER_PORT, else "0").  The other ranks accept a file only if it carries THEIR nonce
+// AND is not older than their own start minus two seconds -- both, always: a launcher may hand the same nonce to consecutive
+// launches (torchrun's default port never changes), and a file a killed run left behind with that nonce would send a rank that
+// starts before rank 0's unlink into ncclCommInitRank with a dead id (round-3 advisor finding).  A rank that fails before or
+// inside init leaves the others in ncclCommInitRank: like any RCCL job, run the launch under a launcher-side timeout.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -52,8 +53,8 @@ struct RcclComm {
                     FILE *f = std::fopen(id_file.c_str(), "rb");
                     const bool ok = f && std::fread(&rec, sizeof(rec), 1, f) == 1;
                     if (f) std::fclose(f);
-                    // this launch's file: its nonce (and, without a launcher-given nonce, not older than this rank's start)
-                    if (ok && rec.nonce == nonce && (nonce != 0 || mt + std::chrono::seconds(2) >= t_start)) { id = rec.id; break; }
+                    // this launch's file: its nonce AND not older than this rank's start (st_mtime has one-second resolution: two seconds of slack)
+                    if (ok && rec.nonce == nonce && mt + std::chrono::seconds(2) >= t_start) { id = rec.id; break; }
                 }
                 if (std::chrono::steady_clock::now() > deadline) return fail("rank 0 did not publish " + id_file + " in time");
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));

@@ -113,6 +113,7 @@ struct Ctx {
     std::recursive_mutex mu;         // one call at a time per ctx (PTX_ENTER)
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_main = nullptr;   // the main stream while `stream` is swapped to the side stream (api_step.cpp), else null
     hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_seq = nullptr;     // orders the side stream behind everything enqueued on the main stream so far (steps run strictly one after the other on the device)
@@ -437,9 +438,12 @@ int upload_small(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
     if (off + bytes > PIN_UP_RING) off = 0;                  // past the end: start of the lower half
     const int h_new = off >= HALF ? 1 : 0;
     if (h_new != h_old) {
-        // leaving h_old: mark what was issued from it on either stream; entering h_new: its last lap's copies must have run
+        // leaving h_old: mark what was issued from it on either stream; entering h_new: its last lap's copies must have run.  The
+        // records go onto the REAL main stream and the side stream: ctx->stream may be swapped to the side stream at this moment (the
+        // trio build of a step), and copies issued from this half on the main stream before the swap must be covered too
+        // (round-3 advisor finding)
         for (int k = 0; k < 2; ++k) {
-            hipStream_t st = k == 0 ? ctx->stream : ctx->stream2;
+            hipStream_t st = k == 0 ? (ctx->stream_main ? ctx->stream_main : ctx->stream) : ctx->stream2;
             if (!st) continue;
             if (!ctx->pin_up_ev[h_old][k]) PTX_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_up_ev[h_old][k], hipEventDisableTiming));
             PTX_HIP(ctx, hipEventRecord(ctx->pin_up_ev[h_old][k], st));

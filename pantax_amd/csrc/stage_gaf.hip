@@ -512,6 +512,12 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         uploader.join();
         if (prefault.joinable()) prefault.join();
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(up_stream);   // on every path: copies from the pinned ring into the text buffers may still be in flight (round-3 advisor finding)
+        if (rc != 0 && sh.rc != 0) {             // the uploader thread failed: its message sits in ITS thread's slot -- this thread reports it
+            std::string msg;
+            { std::lock_guard<std::mutex> g(ctx->err_mu); msg = ctx->err; }
+            (void)fail(ctx, rc, "%s", msg.c_str());
+        }
         (void)hipStreamDestroy(up_stream);
         for (auto &e : ev_piece) if (e) (void)hipEventDestroy(e);
         if (rc != 0) return rc;

@@ -821,8 +821,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
             woff.insert(woff.end(), coff.begin(), coff.end());     // [n_wide] W offsets, then [n_wide] column-state offsets
             PTX_TRY(upload(ctx, lb->d_wide_woff, woff.data(), woff.size()));
             PTX_HIP(ctx, lb->d_maskw.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_or.alloc(vw * LAD_WIDE_NW)); PTX_HIP(ctx, lb->d_pat_and.alloc(vw * LAD_WIDE_NW));
-            PTX_HIP(ctx, lb->d_wide_W.alloc(wtot));
-            PTX_HIP(ctx, lb->d_wide_G.alloc(2 * wtot));
+            // W and G are sized by ALL haplotypes of such a species (the candidate count is decided on the device, after the first filter):
+            // 3 x (64 nw)^2 doubles each -- 0.6 GB at 5 000 haplotypes, 22 GB at the 30 000 limit.  A db whose scratch does not fit is refused
+            // with the figure, not with a bare allocation error (INTEGRATION.md states the cost)
+            if (lb->d_wide_W.alloc(wtot) != hipSuccess || lb->d_wide_G.alloc(2 * wtot) != hipSuccess) {
+                (void)hipGetLastError();
+                lb->d_wide_W.release(); lb->d_wide_G.release();
+                return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: %.1f GB of solver scratch for the %u species of more than %d haplotypes do not fit in device memory "
+                            "(3 x (64 x words)^2 doubles per species)", 3.0 * (double)wtot * 8.0 / 1e9, (uint32_t)list.size(), LAD_MAXP);
+            }
             if (n_huge) { PTX_HIP(ctx, lb->d_huge_f64.alloc(ctot * 8)); PTX_HIP(ctx, lb->d_huge_i32.alloc(ctot * 5)); }
         }
         lb->wide_for = (const void *)db;
