@@ -49,7 +49,11 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
     "cfg4_share": ("configs[3] per-GPU share: 125 species / 1250 strains, 12.5M short reads", 4, 125, 10, 12_500_000, 5_000_000),
     # the configuration BASELINE.json's metric is quoted on ("at 10k strains"): it fits ONE MI355X (~100 GB of the 288 GB)
     "cfg4": ("configs[3]: 1k species / 10k strains, 100M short reads", 5, 1000, 10, 100_000_000, 5_000_000),
+    # configs[4] (HiFi gut mock, 50k strains, 8 GPUs) per-GPU share: 125 species x 50 strains, long reads N(15000, 3000^2) with the bases of
+    # cfg4's share (the long-read kernels: coverage_step_kernel, walk_sum_kernel; 50 candidate columns per species)
+    "cfg5_share": ("configs[4] per-GPU share: 125 species / 6250 strains, 125k HiFi-shaped reads", 6, 125, 50, 125_000, 5_000_000),
 }
+LONG_READ_WORKLOADS = ("cfg5_share",)
 DEFAULT_WORKLOAD = "cfg4"
 CPU_SAMPLE_READS = 25_000_000    # the CPU baseline runs on the first chunks of a larger workload (a bounded sample, ~10-30 s of all cores)
 GENERATOR = "native-v1"          # tools/native/synth_set.c; part of the workload key of the committed PMC files
@@ -62,16 +66,21 @@ def workload_spec(name, species=None, haps=None, reads=None, genome_len=None):
     R = reads if reads is not None else base[4]
     L = genome_len if genome_len is not None else base[5]
     custom = (S, H, R, L) != tuple(base[2:6])
-    return dict(name="custom" if custom else name, label="custom" if custom else base[0], seed=20260501 + base[1], species=S, haps=H, reads=R, genome_len=L)
+    return dict(name="custom" if custom else name, label="custom" if custom else base[0], seed=20260501 + base[1], species=S, haps=H, reads=R, genome_len=L,
+                long_reads=name in LONG_READ_WORKLOADS)
 
 
 def native_set(spec, threads=None, seed_shift=0):
     from pantax_amd import synth
-    return synth.NativeSet(spec["seed"] + seed_shift, spec["species"], spec["haps"], spec["reads"], spec["genome_len"], threads=threads)
+    return synth.NativeSet(spec["seed"] + seed_shift, spec["species"], spec["haps"], spec["reads"], spec["genome_len"], long_reads=spec.get("long_reads", False),
+                           threads=threads)
 
 
 def workload_key(spec):
-    return dict(reads=spec["reads"], species=spec["species"], haps=spec["haps"], genome_len=spec["genome_len"], seed=spec["seed"], generator=GENERATOR)
+    k = dict(reads=spec["reads"], species=spec["species"], haps=spec["haps"], genome_len=spec["genome_len"], seed=spec["seed"], generator=GENERATOR)
+    if spec.get("long_reads"):
+        k["long_reads"] = True
+    return k
 
 
 def algorithmic_bytes(species, n_lp_rows, U, R, T):
@@ -109,6 +118,8 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # a10: the membership masks by node (8V node -> haplotypes in, 8V masks out) / by walk (4P in + 8V out)
         "mask_nodes_kernel": 16 * V,
         "mask_kernel": 4 * P + 8 * V,
+        # a12's row compaction: abundance + mask of every node in (16V), the valid rows out (16 n)
+        "scan_chained_kernel<Row>": 16 * V + 16 * n_lp_rows,
         "sort_hist_kernel": 8 * n_lp_rows,
         "sort_scatter_kernel": 2 * 24 * n_lp_rows,
     }, dict(R=R, T=T, V=V, L=L, P=P, H=H)
@@ -207,9 +218,9 @@ def cpu_leg_child(args):
         from oracle import oracle as orc
         from pantax_amd import synth
         from pantax_amd.pipeline import StepConfig
-        cfg = StepConfig()
-        cfgd = dict(fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
         spec = workload_spec(args.workload, args.species, args.haps, args.reads, args.genome_len)
+        cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()
+        cfgd = dict(fr=cfg.fr, fc=cfg.fc, sr=cfg.sr)
         cores = args.cpu_cores or (os.cpu_count() or 1)
         t_g = time.perf_counter()
         ns = native_set(spec, threads=min(cores, 64))
@@ -537,7 +548,7 @@ def main():
 
     from pantax_amd import synth
     from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, partition_species, profile_step, profile_steps_pipelined
-    cfg = StepConfig()
+    cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()   # long reads: --fr 0.5 (main.rs:108-114)
     import torch
     from pantax_amd.engine import Engine
     # PANTAX_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the
@@ -684,7 +695,7 @@ def main():
     eng.timing_filter(None)
     # extra (not `value`): the same step when the unique-trio index, which depends on the DB only, stays
     # resident between steps instead of being rebuilt like the reference does on every run
-    cfg_cached = StepConfig(rebuild_trio=False)
+    cfg_cached = StepConfig(fr=cfg.fr, rebuild_trio=False)
     profile_step(eng, species_names, hap_names, avg_len, cfg_cached, comm, shard_max=S_max, rows_max=H_max)
     barrier()
     t1 = time.perf_counter()
@@ -871,8 +882,10 @@ def main():
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
-            "config": {"workload": "%s: %d species x %d strains, %d short reads (150 bp), genome %d bp, seed %d, generator %s"
-                                   % (spec["name"], n_species, n_haps, n_reads, genome_len, spec["seed"], GENERATOR),
+            "config": {"workload": "%s: %d species x %d strains, %d %s, genome %d bp, seed %d, generator %s"
+                                   % (spec["name"], n_species, n_haps, n_reads, "long reads N(15000, 3000^2) bp" if spec.get("long_reads") else "short reads (150 bp)",
+                                      genome_len, spec["seed"], GENERATOR),
+                       "gsteps_per_s": T_res * world / (dt / args.steps) / 1e9,
                        "baseline_config": spec["label"][:60], "set": "per GPU" if args.scaling == "weak" else "one set cut over the ranks",
                        "V": dims["V"], "P": dims["P"], "T": dims["T"], "U": n_unique, "species_per_gpu": S_loc,
                        "strains_total": n_species * n_haps * (world if args.scaling == "weak" else 1), "reads_total": total_reads,

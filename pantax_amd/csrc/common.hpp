@@ -367,6 +367,9 @@ struct Reads {
     DevBuf<uint2> d_g_qm;            // [R'] {read length, MAPQ} in slot order (the binning pass runs over the slots)
     DevBuf<uint8_t> d_g_flag;        // [R'] drop flags in slot order, refreshed when the flags changed (g_flags_valid)
     uint32_t n_slots = 0;            // reads that own a slot (non-empty walk)
+    DevBuf<uint2> d_g_items;         // [n_items] work items of the short-read coverage kernel: groups [x, y) whose reads start inside one block of 2048 node ids
+    uint32_t n_items = 0;
+    int item_blk_shift = 0;          // log2 of the node-block size the items were cut at (0: plain cuts of the stream)
     bool g_flags_valid = false;
     bool species_valid = false;      // d_species (file order) reflects the last binning pass; species_ensure() gathers it from the slots
     bool binned = false;

@@ -150,31 +150,40 @@ __device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t 
 // the LDS / memory updates sit under a mask.  Groups that hold a step of a longer walk are left to coverage_step_kernel.
 // Levels: {code, node id} + group_slot (scalar) -> {read record 16 B, slot record 8 B} -> {node record 16 B, active byte}
 // -> two unique-trio entries.
+// Workgroup = one ITEM of the read layout (build_step_read): up to COV_ITEM_GROUPS consecutive groups whose reads all START inside one
+// block of 2048 node ids.  (Round 3 gave every workgroup a fixed number of groups: where a species is thinly covered -- most species of a
+// Dirichlet-distributed sample -- 4096 steps span more nodes than the LDS windows hold, and every update outside them is a memory-side
+// atomic: 3.3 of the kernel's 10.6 ms at 1e4 strains.  By node block the windows cover the block whatever the depth, and a deeply
+// covered block is simply cut into more items.)
+constexpr uint32_t COV_ITEM_GROUPS = 64;
+constexpr int COV_BLK_SHIFT = 11;
 template <bool WITH_TRIO, int U, int PASSES, int WIN>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
-    uint32_t n_groups, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
+    const uint2 *__restrict__ items, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
     const uint4 *__restrict__ node_rec, const uint64_t *__restrict__ bit_off, uint64_t V, unsigned long long *__restrict__ bases,
     uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
-    unsigned long long *__restrict__ n_abort, uint32_t ablate) {
+    unsigned long long *__restrict__ n_abort, uint32_t ablate, int blk_shift) {
     constexpr int WAVES = COV_BLOCK / 64;
-    constexpr int GROUPS = WAVES * U * PASSES;                                // 64-step groups per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t g0 = blockIdx.x * (uint32_t)GROUPS;
+    const uint2 item = items[blockIdx.x];
+    const uint32_t g0 = item.x, n_groups = item.y;                            // this workgroup's groups [g0, n_groups)
     for (int i = threadIdx.x; i < (int)(cov_lds_bytes(WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the three windows, one block
     // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
     uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
     uint64_t bw0 = 0;
 #pragma unroll 1
-    for (int c = 0; c < GROUPS && win_n == 0; ++c) {
-        const uint32_t g = g0 + (uint32_t)c;
-        if (g >= n_groups) break;
+    for (uint32_t g = g0; g < n_groups && win_n == 0; ++g) {
         const uint32_t gs = group_slot[g];
         if (gs == NO_SLOT) continue;
         const uint2 sr0 = slot_rec[gs];
         if ((int)sr0.x < 0 || !active[sr0.x]) continue;
-        const uint32_t v0 = node_id[(uint64_t)g * 64] + sr0.y;
-        wlo = (v0 > (uint32_t)COV_WIN_BACK ? v0 - COV_WIN_BACK : 0u) & ~63u;
+        // the window starts at the item's NODE BLOCK, not at its first read: the reads of a bucket of the layout (512 ids wide at 3e8 nodes)
+        // are in no particular order, so later reads of the item may start hundreds of nodes in front of the first one -- every read of
+        // the item starts inside the block (build_step_read), and ids and node indices run in step inside a species
+        const uint32_t id0 = node_id[(uint64_t)g * 64], v0 = id0 + sr0.y, in_blk = id0 & ((1u << blk_shift) - 1u);
+        const uint32_t back = in_blk + 64u;
+        wlo = (v0 > back ? v0 - back : 0u) & ~63u;
         win_n = WIN;
         const uint64_t b_lo = bit_off[wlo], b_hi = bit_off[min((uint64_t)wlo + WIN, V)];
         bw0 = b_lo >> 5;
@@ -189,7 +198,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #pragma unroll 1
-    for (int pass = 0; pass < PASSES; ++pass) {
+    for (int pass = 0;; ++pass) {
         const uint32_t gw = g0 + (uint32_t)((pass * WAVES + wave) * U);     // this wave's U consecutive groups
         if (gw >= n_groups) break;
         // ---- level 1
@@ -282,11 +291,11 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             }
             if (markable && !ABL(1u)) {
                 if (sidx == 0u && hi == nl[u]) {                              // the whole node: one flag
-                    if (inw) S_FULL(WIN, off) = 1; else atomicOr(&full[v[u] >> 5], 1u << (v[u] & 31));
+                    if (inw) S_FULL(WIN, off) = 1; else if (!ABL(8u)) atomicOr(&full[v[u] >> 5], 1u << (v[u] & 31));
                 } else if (off < mark_n) {
                     const uint32_t rel = nr[u].x - bit0_lo;
                     mark_window(WIN, rel + sidx, rel + hi);
-                } else {
+                } else if (!ABL(8u)) {
                     const uint64_t bo = nr_bit_off(nr[u]);
                     mark_range(bitmap, WIN, bw0, bwn, bo + sidx, bo + hi);
                 }
@@ -312,11 +321,12 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             const uint32_t c = S_WIN(i);
             if (c) atomicAdd(&bases[wlo + i], (unsigned long long)c);
             const unsigned long long fb = __ballot(S_FULL(WIN, i) != 0);
-            if (fb && (lane & 31) == 0) {
+            if (fb && (lane & 31) == 0 && !ABL(32u)) {
                 const uint32_t m = (uint32_t)(fb >> (lane & 32));
                 if (m) atomicOr(&full[(wlo + i) >> 5], m);
             }
         }
+        if (!ABL(16u))
         for (uint32_t i = threadIdx.x; i < bwn; i += COV_BLOCK) {
             const uint32_t m = S_BM(WIN, i);
             if (m) atomicOr(&bitmap[bw0 + i], m);
@@ -809,10 +819,23 @@ __global__ void __launch_bounds__(256) group_fill_long_kernel(uint64_t R, const 
     }
 }
 
+// first group of every node block: the smallest group whose first step is the first step of a read that starts in the block (a group
+// that continues a longer walk, or holds only pads, starts no read)
+__global__ void __launch_bounds__(256) group_block_kernel(uint32_t n_groups, const uint32_t *__restrict__ group_slot, const uint32_t *__restrict__ g_node_id,
+                                                          const uint8_t *__restrict__ step_code, int bshift, uint32_t *__restrict__ first_g) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n_groups; g += gridDim.x * 256) {
+        if (group_slot[g] == NO_SLOT) continue;
+        const uint32_t code = step_code[(uint64_t)g * 64];
+        if (code == STEP_PAD || !(code & STEP_START)) continue;
+        atomicMin(&first_g[g_node_id[(uint64_t)g * 64] >> bshift], g);
+    }
+}
+
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     rd->T_pad = 0;
     rd->n_long = 0;
     rd->n_slots = 0;
+    rd->n_items = 0;
     rd->g_flags_valid = false;
     rd->species_valid = false;
     PTX_HIP(ctx, rd->d_slot_of.alloc(rd->R ? rd->R : 1));
@@ -870,6 +893,35 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
                            rd->d_slot_of.p, slot_rel.p, rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);
         PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R));
         PTX_HIP(ctx, rd->d_long_len0.alloc(rd->R));
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    // work items of the short-read coverage kernel: the groups cut at the borders of 2048-id node blocks (the stream is in the order of
+    // the reads' first nodes, bucket by bucket), a block's groups cut into items of COV_ITEM_GROUPS
+    {
+        const uint32_t n_groups = (uint32_t)(rd->T_pad / 64);
+        const int bshift = std::max(COV_BLK_SHIFT, shift);
+        const uint32_t NBLK = (uint32_t)(max_node_id >> bshift) + 1;
+        DevBuf<uint32_t> first_g;
+        PTX_HIP(ctx, first_g.alloc(NBLK + 1));
+        PTX_HIP(ctx, hipMemsetAsync(first_g.p, 0xFF, ((size_t)NBLK + 1) * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(group_block_kernel, dim3(grid_for(n_groups, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_groups, rd->d_g_group_slot.p, rd->d_g_node_id.p,
+                           rd->d_g_step_dup.p, bshift, first_g.p);
+        std::vector<uint32_t> fg((size_t)NBLK + 1);
+        PTX_TRY(download(ctx, fg.data(), first_g.p, (size_t)NBLK + 1));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        fg[NBLK] = n_groups;
+        bool monotone = true;
+        for (uint32_t b = NBLK; b-- > 0;) { if (fg[b] == 0xFFFFFFFFu) fg[b] = fg[b + 1]; else if (fg[b] > fg[b + 1]) monotone = false; }
+        fg[0] = 0;                                                  // groups in front of the first live one (pads) belong to the first block
+        std::vector<uint2> items;
+        if (monotone)
+            for (uint32_t b = 0; b < NBLK; ++b)
+                for (uint32_t g = fg[b]; g < fg[b + 1]; g += COV_ITEM_GROUPS) items.push_back(make_uint2(g, std::min(fg[b + 1], g + COV_ITEM_GROUPS)));
+        else   // cannot happen with the counting sort above; never silent: plain cuts of the stream
+            for (uint32_t g = 0; g < n_groups; g += COV_ITEM_GROUPS) items.push_back(make_uint2(g, std::min(n_groups, g + COV_ITEM_GROUPS)));
+        rd->n_items = (uint32_t)items.size();
+        rd->item_blk_shift = monotone ? bshift : 0;
+        PTX_TRY(upload(ctx, rd->d_g_items, items.data(), items.size()));
     }
     PTX_HIP(ctx, hipGetLastError());
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // temporaries are released on return
@@ -947,20 +999,18 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         }
         // walks of <= 64 steps: the short-read kernel, one wave per 64-step group, PASSES groups per wave and workgroup (the LDS
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
-        const uint32_t n_groups = (uint32_t)(rd->T_pad / 64);
-        if (rd->n_long < rd->n_slots && !std::getenv("PANTAX_COV_GENERAL")) {
+        if (rd->n_long < rd->n_slots && rd->n_items && !std::getenv("PANTAX_COV_GENERAL")) {
             KTimer t(ctx, "coverage_fast_kernel");
             // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps) over a 3072-node window;
             // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
             // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
             int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
             if (const char *ev = std::getenv("PANTAX_COVF_SHAPE")) fshape = std::atoi(ev);
-#define COVF_ARGS n_groups, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
-                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate
+#define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
+                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
             {                                                                                                                            \
-                const int per = (COV_BLOCK / 64) * UU * PP;                                                                              \
-                const int grid = (int)((n_groups + per - 1) / per);                                                                      \
+                const int grid = (int)rd->n_items;                                                                                       \
                 if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
                 else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
             }

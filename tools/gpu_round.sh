@@ -38,6 +38,8 @@ prefetchtest) ( time timeout 600 python -m pytest tests/test_gpu_pipeline.py -m 
 gafleg) for wl in cfg4 cfg3; do timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-hard --steps 4 > gpurun_out/${tag}_gafleg_$wl.json 2>/dev/null; python3 tools/bench_summary.py gpurun_out/${tag}_gafleg_$wl.json | grep -E "^value|^gaf" | cut -c1-330; done ;;
 hugetests) ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q --durations=8 -k "huge or more_than_64 or beyond_64 or batch_equals or wide or row_pipelines" ) > gpurun_out/${tag}_hugetests.log 2>&1; tail -25 gpurun_out/${tag}_hugetests.log ;;
 trace4) bash tools/kernel_trace.sh cfg4 ${tag}_cfg4 4 ;;
+qbench5) ( time timeout 900 python bench.py --workload cfg5_share --no-cpu-baseline --no-hard --no-gaf --steps 5 ) > gpurun_out/${tag}_qbench5.json 2> gpurun_out/${tag}_qbench5.err; python3 tools/bench_summary.py gpurun_out/${tag}_qbench5.json; tail -3 gpurun_out/${tag}_qbench5.err ;;
+trace5) bash tools/kernel_trace.sh cfg5_share ${tag}_cfg5share 4 ;;
 pmc4) bash tools/pmc_step.sh cfg4 ${tag}_cfg4 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"
      python3 tools/pmc_collect.py gpurun_out/pmc_${tag}_cfg4 cfg4 gpurun_out/${tag}_pmc_cfg4.json ;;
 trace) bash tools/kernel_trace.sh cfg3 ${tag}_cfg3 6 ;;

@@ -15,8 +15,13 @@ meta = {}
 for fn in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
     with open(fn, newline="") as f:
         for row in csv.DictReader(f):
-            k = row["Kernel_Name"].split("(")[0]
-            k = k.replace("void ptx::", "").replace("ptx::", "").split("<")[0]
+            full = row["Kernel_Name"].split("(")[0]
+            k = full.replace("void ptx::", "").replace("ptx::", "").split("<")[0]
+            if k == "scan_chained_kernel":      # one entry per instantiation, named like the library's timer labels (bench.py keys)
+                for tag in ("Row", "Pat", "TrioFirst", "FlagWord", "GroupCount", "HeadCount", "Sample", "Len"):
+                    if tag + "Load" in full:
+                        k = "scan_chained_kernel<%s>" % tag
+                        break
             if k.startswith("__amd") or "at::" in k:
                 continue
             c = acc.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
