@@ -847,7 +847,11 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
         return 0;
     }
     int shift = 5;
-    while (((uint64_t)max_node_id >> shift) + 1 > (1u << 20)) ++shift;
+    // buckets of 32 node ids up to 5e8 ids (round 4; 2^20 buckets before: 512-id buckets at 3e8 ids, whose reads are in no particular order --
+    // the coverage pass gathers node records along the stream, and neighbours in the stream should be neighbours in the graph)
+    int bucket_cap_bits = 24;
+    if (const char *ev = std::getenv("PANTAX_GROUP_BUCKET_BITS")) bucket_cap_bits = std::max(10, std::min(26, std::atoi(ev)));
+    while (((uint64_t)max_node_id >> shift) + 1 > (1ull << bucket_cap_bits)) ++shift;
     const uint32_t NB = (uint32_t)(max_node_id >> shift) + 1;
     DevBuf<uint32_t> cnt, scan_tmp, slot_rel;
     PTX_HIP(ctx, cnt.alloc(4ull * (NB + 1) + 8));
