@@ -236,12 +236,57 @@ __global__ void __launch_bounds__(64) hap_trio_final_kernel(uint32_t H, const Ha
     mean_out[h] = c2 ? a2 / (double)c2 : 0.0;   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
 }
 
+// The same three passes in ONE launch, a workgroup per haplotype (round 4; databases of thousands of haplotypes: the launch fills the
+// device with one workgroup each, the rows of a haplotype -- 1.8e4 x 12 bytes at ten strains per species -- stay in the L2 of its XCD between
+// the passes, and two of three launches go).  The order of the sums differs from the 32-chunk tree above (both are fixed orders; the
+// reference's own order is that of a hash set): results agree to rounding.
+__global__ void __launch_bounds__(256) hap_trio_fused_kernel(uint32_t H, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
+                                                             const uint32_t *__restrict__ tlen, uint32_t *__restrict__ nnz_out, double *__restrict__ mean_out) {
+    __shared__ double red[4];
+    __shared__ unsigned long long redu[4];
+    const uint32_t h = blockIdx.x;
+    const uint64_t b = hto[h], e = hto[h + 1];
+    double acc = 0.0; unsigned long long cnt = 0;
+    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+        const double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
+        if (x > 0.0) { acc += x; ++cnt; }                             // :1129-1133
+    }
+    const double a0 = block_sum_f64<256>(acc, red);
+    const unsigned long long c0 = block_sum_u64<256>(cnt, redu);
+    const double mean = c0 ? a0 / (double)c0 : 0.0;                   // :1037
+    acc = 0.0;
+    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+        const double x = (double)(long long)tb[u] / (double)tlen[u];
+        if (x > 0.0) acc += (x - mean) * (x - mean);
+    }
+    const double a1 = block_sum_f64<256>(acc, red);
+    const double n = (double)(uint32_t)c0;
+    const double sd = n > 0 ? sqrt(a1 / n) : 0.0;                     // :1038-1041
+    acc = 0.0; cnt = 0;
+    if (sd != 0.0)
+        for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
+            const double x = (double)(long long)tb[u] / (double)tlen[u];
+            if (x > 0.0 && fabs((x - mean) / sd) < 3.0) { acc += x; ++cnt; }   // :1047-1050
+        }
+    const double a2 = block_sum_f64<256>(acc, red);
+    const unsigned long long c2 = block_sum_u64<256>(cnt, redu);
+    if (threadIdx.x == 0) { nnz_out[h] = (uint32_t)c0; mean_out[h] = c2 ? a2 / (double)c2 : 0.0; }   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+}
+
 int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBuf<double> &d_mean) {
     PTX_HIP(ctx, d_nnz.alloc(db->H));
     PTX_HIP(ctx, d_mean.alloc(db->H));
     if (db->H == 0) return 0;
     Db *dbm = const_cast<Db *>(db);
     const uint32_t H = (uint32_t)db->H;
+    bool fused = H >= 2048;                                 // enough workgroups to fill the device (PANTAX_HAP_STATS=chunks|fused picks one, for tests)
+    if (const char *ev = std::getenv("PANTAX_HAP_STATS")) fused = ev[0] == 'f';
+    if (fused) {
+        KTimer t(ctx, "hap_trio_fused_kernel");
+        hipLaunchKernelGGL(hap_trio_fused_kernel, dim3(H), dim3(256), 0, ctx->stream, H, db->d_hap_trio_off.p, db->d_trio_bases.p, db->d_trio_len.p, d_nnz.p, d_mean.p);
+        PTX_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)3 * H * HAP_CHUNKS * 3));
     for (int pass = 0; pass < 3; ++pass) {
         KTimer t(ctx, "hap_trio_pass_kernel");

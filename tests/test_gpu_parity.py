@@ -739,6 +739,38 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,S,H,R,L,pf", [(31, 5, 10, 90000, 30000, 0.4), (32, 3, 30, 90000, 20000, 0.6)])
+def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, monkeypatch):
+    """a9's per-haplotype statistics of the unique-trio abundances (count of non-zero ones, z-score-filtered mean, profile.rs:1028-1147):
+    the three-pass kernel with 32 workgroups per haplotype and the one-launch kernel with a workgroup per haplotype (databases of
+    thousands of haplotypes) sum in different fixed orders -- the metrics they lead to agree to rounding, the decisions exactly --
+    and both agree with the oracle."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from pantax_amd.engine import metrics_to_dicts
+    sset = synth.make_set(seed, S, H, R, L, present_frac=pf)
+    rd = sset.reads
+    eng.upload_db(sset.species)
+    eng.upload_packed(rd)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
+    eng.trio_nodes_info(fetch=False)
+    eng.get_node_abundances(fetch=False)
+    outs = []
+    for mode in ("chunks", "fused"):
+        monkeypatch.setenv("PANTAX_HAP_STATS", mode)
+        met, info = eng.strain_profiling(absolute, species_active=keep)
+        outs.append((metrics_to_dicts(met, eng.H), [(i.n_candidates, i.status1, i.status2, i.n_rows, i.n_patterns) for i in info]))
+    assert outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        for k in a:
+            if a[k] is None or isinstance(a[k], bool):
+                assert a[k] == b[k], k
+            else:
+                assert b[k] is not None and abs(a[k] - b[k]) <= 1e-12 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,R,L,pf,opts", [
     (22, 4, 10, 80000, 30000, 0.4, {}),                        # a handful of patterns per species
     (26, 2, 40, 120000, 30000, 0.9, dict(fr=0.05)),            # thousands of patterns
