@@ -143,12 +143,16 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     // nothing below reads the unique-trio tables: the NEXT step may rebuild them from here on, beside this step's row
     // sort and LPs (api_step.cpp)
     if (!db->ev_trio_free) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_trio_free, hipEventDisableTiming));
-    PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream));
-    db->trio_free_valid = true;
+    // ... by default from behind the ROW COMPACTION (lad_prepare records the event there): the compaction is a chained scan whose tiles
+    // spin on their predecessors, and beside the rebuild's kernels its 3 ms stretched to 9-13 (round 4); PANTAX_TRIO_FREE=filter: from here
+    static const bool free_at_filter = std::getenv("PANTAX_TRIO_FREE") && std::getenv("PANTAX_TRIO_FREE")[0] == 'f';
+    db->trio_free_pending = !free_at_filter;
+    if (free_at_filter) { PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream)); db->trio_free_valid = true; }
     mark();
     int pmax_bound = 1;                                                                     // mask bits of a row key: min(#haps, 64) (wide species: a 64-bit hash)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
     PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
+    if (db->trio_free_pending) { PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream)); db->trio_free_valid = true; db->trio_free_pending = false; }
     mark();
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
     mark();

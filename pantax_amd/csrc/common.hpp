@@ -338,6 +338,7 @@ struct Db {
     int step_enq = 0, step_col = 0, step_inflight = 0;   // slot of the next enqueue / the next collect; steps enqueued and not yet collected
     hipEvent_t ev_trio_free = nullptr;   // recorded behind the last reader of the unique-trio tables in a step: the next step's rebuild waits
     bool trio_free_valid = false;        // for this, not for the whole previous step (its row sort and LPs run beside the rebuild)
+    bool trio_free_pending = false;      // the event is still to be recorded by lad_prepare, behind the row compaction
     ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); if (ev_trio_free) (void)hipEventDestroy(ev_trio_free); }
     // LP-row staging (lad_prepare)
     DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort

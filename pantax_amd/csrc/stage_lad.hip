@@ -951,6 +951,10 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         hipLaunchKernelGGL(row_emit_kernel, dim3(grid_rows ? grid_rows : 1), dim3(256), 0, ctx->stream, V, S, db->d_node_base.p, lb->d_ab.p,
                            (unsigned long long *)lb->d_mask.p, d_n, ka[0].p, ka[1].p, ka[2].p, pack_shift);
     }
+    if (dbm->trio_free_pending && dbm->ev_trio_free) {   // the next step's index rebuild may start from here (api_strain.cpp)
+        PTX_HIP(ctx, hipEventRecord(dbm->ev_trio_free, ctx->stream));
+        dbm->trio_free_valid = true; dbm->trio_free_pending = false;
+    }
     SortBufs A, B;
     A.nw = B.nw = pack_shift >= 0 ? 2 : 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
