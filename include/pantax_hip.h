@@ -343,11 +343,17 @@ int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *c
 /* ---- a1 / a6 host readers (no GPU needed): the file contracts of the pipeline seam, exposed so a
  * caller that keeps its own orchestration can still reuse the tokenizer and graph loaders ---------- */
 typedef struct pantax_hip_gaf pantax_hip_gaf;     /* owns the packed arrays of one tokenised GAF */
-/* load_gaf_file_lazy (rcls.rs:119-146): columns 1,2,6,7,8,9,12; '@' comment lines skipped; "*" = null
- * (=> PANTAX_HIP_READ_NULLFIELD for cols 6-9, mapq 255, qlen 0).  err_out (may be NULL) receives a
- * static/thread-local message on failure. */
+/* load_gaf_file_lazy (rcls.rs:119-146): columns 1,2,6,7,8,9,12; '@' comment lines and empty lines skipped; "*" AND the
+ * empty field = null (the reader's null_values / missing_is_null; => PANTAX_HIP_READ_NULLFIELD for cols 6-9, mapq 255,
+ * qlen 0); a non-integer in an integer column reads as null; integers above 2^32 - 1 are clamped to it (32-bit packed
+ * columns).  The rules are restated, independently of this library, in oracle/gaf_reader.py, which the tests compare
+ * every tokenizer with.  err_out (may be NULL) receives a static/thread-local message on failure. */
 int pantax_hip_gaf_load(const char *path, int n_threads, pantax_hip_gaf **out, const char **err_out);
-/* the same tokenisation on the device (text uploaded once, five launches): identical arrays */
+/* the same tokenisation on the device (text uploaded once, five launches): identical arrays.  LIMIT of the
+ * device readers (this entry, pantax_hip_reads_load_gaf, pantax_hip_gaf_filter): the text travels in pieces cut at line
+ * ends -- a sixth of the text, 64 MiB .. 1 GiB, less only through PANTAX_GAF_PIECE_BYTES -- and a piece holds whole lines:
+ * ONE LINE longer than 3.5 GiB (or than a lowered piece size) is refused with PANTAX_HIP_E_LIMIT.  A HiFi / ONT line with
+ * a long cs tag is kilobytes to megabytes: far inside the default. */
 int pantax_hip_gaf_load_device(pantax_hip_ctx *ctx, const char *path, pantax_hip_gaf **out);
 int pantax_hip_gaf_view(const pantax_hip_gaf *gaf, pantax_hip_packed_reads *view_out);
 /* file -> packed reads RESIDENT in HBM, tokenised on the device, ready for pantax_hip_bin_reads; the walks never
