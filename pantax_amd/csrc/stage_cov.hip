@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             nl[u] = ok[u] ? nr[u].z : 0u;
             len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
             const uint32_t v2 = wave_shr1(wave_shr1(v[u]));
-            const uint32_t hw1 = wave_shr1(nr[u].w), hn1 = wave_shr1(nr[u].y >> 8);   // the lookup head of the window's MIDDLE node: the lane below
+            const uint32_t hw1 = wave_shr1(nr[u].w), hy1 = wave_shr1(nr[u].y);         // the lookup head of the window's MIDDLE node: the lane below
             single[u] = rr[u].y == 1u;
             dead_read[u] = !single[u] && rr[u].z > len0[u];                   // assert :854 -> the whole read contributes nothing
             live[u] = ok[u] && !dead_read[u] && !(single[u] && rr[u].w < rr[u].z);   // :821-827
@@ -258,8 +258,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             if (WITH_TRIO && !ABL(4u)) {
                 // canonical window (min end, middle, max end): the rows are filed under the MIDDLE node, keyed by the two ends
                 hx[u] = hw1;
-                nh[u] = (live[u] && i_[u] >= 2u) ? hn1 : 0u;
                 tlo[u] = min(v[u], v2); thi[u] = max(v[u], v2);
+                // the node's pair filter: a window whose bit is clear is not among its rows -- nothing is fetched for it
+                nh[u] = (live[u] && i_[u] >= 2u && (nr_filter(hy1) & nr_pair_bit(tlo[u], thi[u]))) ? nr_rows(hy1) : 0u;
                 e0[u] = trio_ent[nh[u] ? hx[u] : 0u];
                 e1[u] = trio_ent[nh[u] > 1u ? hx[u] + 1u : 0u];
             }
@@ -457,15 +458,17 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             cross[u] = ok[u] && (int)i > lane;                        // the walk began before this wave (more than 64 steps)
             // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
             v1[u] = wave_shr1(v[u]); v2[u] = wave_shr1(v1[u]);
-            const uint32_t tf1 = wave_shr1(nr[u].w), tn1 = wave_shr1(nr[u].y >> 8);
+            const uint32_t tf1 = wave_shr1(nr[u].w), ty1 = wave_shr1(nr[u].y);
             th[u] = make_uint2(0u, 0u); tlo[u] = 0; thi[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
             if (WITH_TRIO && !ABL(4u) && ok[u] && i >= 2) {
                 if (lane < 1) v1[u] = node_id[b + i - 1] + sr[u].y;
                 if (lane < 2) v2[u] = node_id[b + i - 2] + sr[u].y;
                 // canonical window (min end, middle, max end); the lookup rows are filed under the MIDDLE node (the lane below), keyed by the two ends
                 tlo[u] = min(v[u], v2[u]); thi[u] = max(v[u], v2[u]);
-                if (lane >= 1) th[u] = make_uint2(tf1, tn1);
-                else { const uint4 r1 = node_rec[v1[u]]; th[u] = make_uint2(r1.w, r1.y >> 8); }   // wave border of a long walk
+                uint32_t hy = ty1;
+                if (lane >= 1) th[u].x = tf1;
+                else { const uint4 r1 = node_rec[v1[u]]; th[u].x = r1.w; hy = r1.y; }   // wave border of a long walk
+                th[u].y = (nr_filter(hy) & nr_pair_bit(tlo[u], thi[u])) ? nr_rows(hy) : 0u;   // the pair filter: nothing is fetched for a window whose bit is clear
                 if (th[u].y) e0[u] = trio_ent[th[u].x];
                 if (th[u].y > 1) e1[u] = trio_ent[th[u].x + 1];
             }

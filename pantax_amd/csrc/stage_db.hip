@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) trio_rebase_kernel(uint32_t n_nodes, uint
         const uint32_t f = first[i], nx = i + 1 < n_nodes ? first[i + 1] : next_first_local;
         if (nx - f >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
         uint4 r = node_rec[i];
-        r.y = (r.y & 0xFFu) | ((nx - f) << 8); r.w = f + row_base;   // the lookup head rides in the node record
+        r.y = nr_head(r.y, nx - f, 0xFFu); r.w = f + row_base;   // the lookup head rides in the node record (no filter: every row is fetched)
         node_rec[i] = r;
     }
     if (i < n_rows) { uint4 e = ent[i]; e.x += node_base; e.y += node_base; e.z += row_base; ent[i] = e; }   // images hold species-local (b, c, row)

@@ -645,7 +645,7 @@ struct TrioFirstStore {
         if (i < V && c) {
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
             uint4 r = node_rec[i];
-            r.y = (r.y & 0xFFu) | (c << 8);
+            r.y = nr_head(r.y, c, 0xFFu);                    // this path does not compute the pair filter
             r.w = excl;
             node_rec[i] = r;
         }
@@ -683,10 +683,10 @@ __device__ __forceinline__ void trio_row_emit(const uint4 rec, uint32_t slot, co
 }
 // the lookup head of a node = {slot of its first row, number of its rows}, written into the node record by the lane that holds the
 // node's first unique window (records arrive in visit order: a node's windows are neighbours); `cnt` = rows of this node
-__device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t slot, uint32_t cnt, uint32_t *__restrict__ err) {
+__device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t slot, uint32_t cnt, uint32_t filter, uint32_t *__restrict__ err) {
     if (cnt >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
     uint4 r = node_rec[v];
-    r.y = (r.y & 0xFFu) | (cnt << 8);
+    r.y = nr_head(r.y, cnt, filter);
     r.w = slot;
     node_rec[v] = r;
 }
@@ -716,11 +716,19 @@ __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsi
     const bool first = mine && (!lower || prev_w != rec.w);
     const unsigned long long fm = __ballot(first);
     if (mine) trio_row_emit<KEYS>(rec, base + r, word_rank, node_len, nb, H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
-    if (first) {
-        const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);     // the node's rows end at the next first lane
-        const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
-        trio_head_store(node_rec, rec.w, base + r, (uint32_t)__popcll(span), err);
+    // the node's rows end at the next first lane; its pair filter = OR of the bits of its unique lanes (every first lane walks its span: a node's
+    // unique visits, a handful; all lanes reach the shuffles)
+    const uint32_t pbit = mine ? nr_pair_bit(rec.y, rec.z) : 0u;
+    const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);
+    const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
+    uint32_t filt = 0u;
+    unsigned long long sp = first ? span : 0ull;
+    while (__any(sp != 0ull)) {
+        const int l = sp ? __builtin_ctzll(sp) : 0;
+        const uint32_t ob = __shfl(pbit, l);
+        if (sp) { filt |= ob; sp &= sp - 1ull; }
     }
+    if (first) trio_head_store(node_rec, rec.w, base + r, (uint32_t)__popcll(span), filt, err);
 }
 // EIGHT groups per wave, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
 // one coalesced kilobyte per wave; the slot of record r of group g is the scan of the groups' counts + r
@@ -747,11 +755,19 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     const bool first = on && (r == 0u || below != rec.w);
     const unsigned long long fm = __ballot(first), om = __ballot(on);
     if (on) trio_row_emit<KEYS>(rec, slot, word_rank, node_len, vis_nbase[g], H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+    // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
+    const uint32_t pbit = on ? nr_pair_bit(rec.y, rec.z) : 0u;
+    uint32_t filt = pbit;
+#pragma unroll
+    for (int d = 1; d < 8; ++d) {
+        const uint32_t ob = __shfl(pbit, (lane + d) & 63), ow = __shfl(rec.w, (lane + d) & 63);
+        if (((lane & 7) + d) < 8 && ow == rec.w) filt |= ob;
+    }
     if (first) {
         // rows of the node: up to the next first record, or to the end of the group's records
         const unsigned long long grp = 0xFFull << (lane & ~7), stop = (fm | ~om) & grp & ~((2ull << lane) - 1ull);
         const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
-        trio_head_store(node_rec, rec.w, slot, (uint32_t)(end - lane), err);
+        trio_head_store(node_rec, rec.w, slot, (uint32_t)(end - lane), filt, err);
     }
     // the groups of this wave with more unique visits than records, one after the other
     unsigned long long ov = __ballot(r == 0u && cnt > (uint32_t)VIS_REC);
@@ -771,7 +787,7 @@ __global__ void __launch_bounds__(256) trio_hapoff_rank_kernel(uint32_t H, const
 }
 // the plain CSR offsets over the middle node (db images keep them; no stage of a step reads them): a scan of the row counts that
 // ride in the node records
-struct HeadCountLoad { const uint4 *node_rec; uint64_t V; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < V ? node_rec[i].y >> 8 : 0u; } };
+struct HeadCountLoad { const uint4 *node_rec; uint64_t V; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < V ? nr_rows(node_rec[i].y) : 0u; } };
 
 __global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint32_t *__restrict__ hap_tile_off, const uint32_t *__restrict__ tile_base,
                                                           uint64_t *__restrict__ hap_trio_off) {
