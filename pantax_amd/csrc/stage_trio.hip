@@ -562,12 +562,16 @@ __global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, c
 // KEYS: also the export copies in row order (canonical key, owner haplotype) that pantax_hip_trio_get and the db images hand
 // out; no stage of the step reads them (the key is in the lookup entry, the owner follows from hap_trio_off), so a step's
 // rebuild leaves them out (16 of the 36 bytes written per window) and the two exporters rebuild with them on demand.
+// `only_slow` (mixed databases, round 4): the species the visit table covers file their rows through trio_rows_kernel; this pass then takes
+// only the tiles of the species left to the node-block kernel, and a window's row is the rank of its flag (`word_rank`) instead of
+// the tile's base + its rank in the tile.
 template <bool KEYS>
 __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
                                                           const uint32_t *__restrict__ node_len, const uint32_t *__restrict__ uniq_q,
                                                           const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
                                                           uint32_t *__restrict__ cursor /* = the per-node counts; zero afterwards */, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
-                                                          uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
+                                                          uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
+                                                          const uint32_t *__restrict__ only_slow, const uint2 *__restrict__ word_rank) {
     constexpr int NR = PATH_TILE / 256;   // rounds of 256 consecutive positions
     __shared__ uint32_t s_wave[NR][4];
     const uint2 tile = tiles[blockIdx.x];
@@ -575,8 +579,9 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
     const uint32_t h = tile.x;
     const uint64_t qend = path_off[h + 1], qt0 = path_off[h] + (uint64_t)tile.y * PATH_TILE;
     const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
+    if (only_slow && !only_slow[sidx]) return;                   // a species of the visit table
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t carry0 = tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
+    const uint32_t carry0 = word_rank ? 0u : tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
     // all rounds at once: the flags of the four rounds are loaded together, ONE barrier orders the wave counts, and the
     // gathers / writes of the unique windows of all rounds are in flight together (row = rank of the window in the tile)
     uint32_t u[NR];
@@ -608,7 +613,7 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_u; t += 256) {
         const uint64_t q = qt0 + s_list[t];
-        const uint32_t row = carry0 + t;
+        const uint32_t row = word_rank ? (word_rank[q >> 5].x + (uint32_t)__popc(word_rank[q >> 5].y & ((1u << (uint32_t)(q & 31ull)) - 1u))) : carry0 + t;
         uint32_t g, a, b, c;
         window_of(q, qend, nbase, path_nodes, g, a, b, c);
         const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
@@ -630,6 +635,40 @@ struct TrioFirstLoad {
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
         if (visited && !((visited[i >> 5] >> (uint32_t)(i & 31ull)) & 1u)) return 0u;
         return cnt[i];
+    }
+};
+// mixed databases: the lookup heads of the species left to the node-block kernel, filed BEHIND the rows of the visit table's species (slot base
+// = *u_fast, the total of the groups' counts); a node of a visit-table species reads as zero here
+struct SlowFirstLoad {
+    const uint32_t *cnt, *visited, *slow;
+    const uint2 *tile_sp;
+    const uint32_t *node_base;
+    uint64_t V;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+        if (i >= V) return 0u;
+        const uint2 t = tile_sp[i >> 11];
+        uint32_t sp = t.x;
+        while (sp < t.y && node_base[sp + 1] <= i) ++sp;
+        if (!slow[sp] || !((visited[i >> 5] >> (uint32_t)(i & 31ull)) & 1u)) return 0u;
+        return cnt[i];
+    }
+};
+struct SlowFirstStore {
+    uint32_t *first;
+    uint4 *node_rec;
+    uint64_t V;
+    const uint32_t *u_fast;
+    uint32_t *err;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t c) const {
+        if (i < V && c) {                                  // (trio_first is written for the nodes that have rows: what the lookup pass reads)
+            const uint32_t f = *u_fast + excl;
+            first[i] = f;
+            if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+            uint4 r = node_rec[i];
+            r.y = nr_head(r.y, c, 0xFFu);
+            r.w = f;
+            node_rec[i] = r;
+        }
     }
 };
 struct TrioFirstStore {
@@ -940,8 +979,12 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
     // a db the visit table covers whole files its rows from the visit kernel's records (trio_rows_kernel); with a species left to the
     // node-block kernel -- or PANTAX_TRIO_ROWS=path -- the rows are filed by the pass over the walks (trio_lookup_kernel) as in rounds 1-3
-    bool rows_by_visit = by_block && P && db->n_vgroups && db->n_blocks == 0;
+    // (a MIXED db -- some species on the node-block kernel -- files those species' rows by the pass over their walks, behind the others';
+    // when the row-order export copies are wanted, i.e. off the hot path, a mixed db takes the pass over the walks whole: the db images
+    // expect a species' lookup rows as one block in node order)
+    bool rows_by_visit = by_block && P && db->n_vgroups && (db->n_blocks == 0 || !with_keys);
     if (const char *ev = std::getenv("PANTAX_TRIO_ROWS")) { if (ev[0] == 'p') rows_by_visit = false; }
+    const bool mixed = rows_by_visit && db->n_blocks != 0;
     // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
     // The visit-table / node-block path zero-fills tile_cnt and the bits only: its kernels STORE the count of every node that has
     // a visit (the others read as zero through `d_node_visited`), the lookup pass counts them back down to zero in place of a cursor
@@ -966,7 +1009,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block && P ? zhead : zwords) * sizeof(uint32_t)));
     if (by_block && P) PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p + V, 0, sizeof(uint32_t), ctx->stream));   // the closing entry of the count scan
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
-    if (!rows_by_visit) PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
+    if (!rows_by_visit || mixed) PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
@@ -1055,6 +1098,15 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                 hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.word_rank.p,
                                    db->d_hap_trio_off.p);
             }
+            if (mixed) {   // the species of the node-block kernel: heads behind the visit table's rows, rows by the pass over their walks
+                PTX_TRY(exclusive_scan_fn(ctx, SlowFirstLoad{ts.first_cnt.p, db->d_node_visited.p, db->d_trio_slow.p, db->d_emit_tile_sp.p, db->d_node_base.p, V},
+                                          SlowFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.gprefix.p + db->n_vgroups, ts.d_tot.p + 2}, V, nullptr,
+                                          "scan_chained_kernel<SlowFirst>"));
+                KTimer t(ctx, "trio_lookup_kernel");
+                hipLaunchKernelGGL(trio_lookup_kernel<false>, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p, ts.uniq_q.p,
+                                   (const uint32_t *)nullptr, db->d_trio_first.p, ts.first_cnt.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p,
+                                   db->d_trio_slow.p, ts.word_rank.p);
+            }
             db->trio_first_valid = false;   // the plain CSR offsets (db images) are derived on request: trio_first_ensure
         } else {
         hipLaunchKernelGGL(trio_tilecount_kernel, dim3((NT + 3) / 4), dim3(256), 0, ctx->stream, NT, db->d_tiles.p, db->d_path_off.p, db->d_tile_rank.p,
@@ -1077,7 +1129,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         {
             KTimer t(ctx, "trio_lookup_kernel");
 #define LOOKUP_ARGS TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p, ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.first_cnt.p, \
-                    db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p
+                    db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, (const uint32_t *)nullptr, (const uint2 *)nullptr
             if (with_keys) hipLaunchKernelGGL(trio_lookup_kernel<true>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
             else hipLaunchKernelGGL(trio_lookup_kernel<false>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
 #undef LOOKUP_ARGS

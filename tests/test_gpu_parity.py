@@ -826,6 +826,45 @@ def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,S,H,every", [(71, 4, 80, 2), (72, 5, 70, 3)])
+def test_step_on_a_mixed_database(eng, seed, S, H, every, monkeypatch):
+    """A database that holds species of BOTH kinds -- single-strain species (the visit table's) beside species of 70-80 strains (a node with
+    more than 64 visits: node-block kernel).  The step's rebuild files the first kind's lookup rows from the visit kernel's records and the
+    second kind's by the pass over their walks, behind them; the stage calls (which want the export copies) take the pass over the walks for
+    the whole db.  Both give the same per-haplotype metrics, and those of the step with the rows forced through the walks (PANTAX_TRIO_ROWS=path);
+    the integers of the stage calls are checked against the oracle."""
+    from oracle import oracle as orc
+    from pantax_amd import synth
+    from tests.helpers import select_reads
+    sset = synth.make_set(seed, S, H, 60000, 12000, present_frac=0.3, single_strain_every=every)
+    assert any(g.n_paths == 1 for g in sset.species) and any(np.bincount(g.path_nodes).max() > 64 for g in sset.species)   # both kinds
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    out_mixed = eng.profile_step(sset.avg_len())
+    monkeypatch.setenv("PANTAX_TRIO_ROWS", "path")
+    out_path = eng.profile_step(sset.avg_len())
+    monkeypatch.delenv("PANTAX_TRIO_ROWS")
+    assert bytes(out_mixed[2]) == bytes(out_path[2]) and np.array_equal(out_mixed[0], out_path[0])
+    # stage calls on the same db: trio tables and coverage against the oracle, species by species
+    sp, *_ = eng.rcls_profile()
+    eng.db_reset()
+    abc, hap, ln, hto = eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    hb = np.cumsum([0] + [g.n_paths for g in sset.species])
+    for si, g in enumerate(sset.species):
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        so, nid, ps, pe = select_reads(sset.reads, np.nonzero(sp == si)[0])
+        b, c, t, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        lo, hi = int(eng.node_off[si]), int(eng.node_off[si + 1])
+        u0, u1 = int(hto[hb[si]]), int(hto[hb[si + 1]])
+        assert np.array_equal(bases[lo:hi], b) and np.array_equal(cov[lo:hi], c)
+        assert u1 - u0 == T.n_unique and np.array_equal(abc[u0:u1], T.abc) and np.array_equal(tb[u0:u1], t)
+    out_again = eng.profile_step(sset.avg_len())
+    assert bytes(out_again[2]) == bytes(out_mixed[2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S", [1000, 1024, 1025, 1500])
 def test_a_thousand_species_in_one_step(eng, S):
     """Many species on one device (BASELINE configs[3] has 1000): the binning kernel keeps its range tables and counters in
