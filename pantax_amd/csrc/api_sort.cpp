@@ -35,6 +35,47 @@ extern "C" int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return 0;
     }
+    if (algo == 4 || algo == 5) {   // the node-order sort: an entry with k1 == 0 or k2 not the bits of a positive double is no row and is dropped
+        std::vector<uint32_t> base{0};
+        std::vector<uint64_t> seg_val;
+        uint64_t bound = 0;
+        for (uint64_t i = 0; i < n;) {
+            uint64_t j = i;
+            while (j < n && k0[j] == k0[i]) ++j;
+            if (j < n && k0[j] < k0[i]) return fail(ctx, PANTAX_HIP_E_INVALID, "sort_rows: algo 4 takes entries grouped by ascending k0");
+            seg_val.push_back(k0[i]); base.push_back((uint32_t)j);
+            bound = std::max<uint64_t>(bound, j - i);
+            i = j;
+        }
+        const uint32_t S = (uint32_t)seg_val.size();
+        const int pack_shift = algo == 5 ? 8 : -1;   // algo 5: masks below 256, the segment number travels in the mask word
+        if (algo == 5) for (uint64_t i = 0; i < n; ++i) if (k1[i] >> 8) return fail(ctx, PANTAX_HIP_E_INVALID, "sort_rows: algo 5 takes k1 < 256");
+        DevBuf<uint64_t> dm, da, r16, osp, om, oa;
+        DevBuf<uint32_t> d_base, wsb, dn;
+        PTX_TRY(upload(ctx, dm, k1, n)); PTX_TRY(upload(ctx, da, k2, n));
+        PTX_TRY(upload(ctx, d_base, base.data(), base.size()));
+        PTX_HIP(ctx, r16.alloc(2 * n)); PTX_HIP(ctx, osp.alloc(n)); PTX_HIP(ctx, om.alloc(n)); PTX_HIP(ctx, oa.alloc(n)); PTX_HIP(ctx, dn.alloc(1));
+        PTX_HIP(ctx, wsb.alloc(sample_sort_nodes_ws_elems(S, bound, n)));
+        PTX_TRY(sample_sort_nodes(ctx, reinterpret_cast<const double *>(da.p), dm.p, d_base.p, S, bound, n, r16.p, pack_shift >= 0 ? (uint64_t *)nullptr : osp.p, om.p, oa.p,
+                                  pack_shift, wsb.p, dn.p));
+        uint32_t nv = 0;
+        PTX_TRY(download(ctx, &nv, dn.p, 1));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> hs(nv), hm(nv), ha(nv);
+        if (nv) {
+            if (pack_shift < 0) PTX_TRY(download(ctx, hs.data(), osp.p, nv));
+            PTX_TRY(download(ctx, hm.data(), om.p, nv)); PTX_TRY(download(ctx, ha.data(), oa.p, nv));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        for (uint64_t i = 0; i < n; ++i) {
+            if (i < nv) {
+                const uint64_t sp = pack_shift >= 0 ? (hm[i] >> pack_shift) : hs[i];
+                if (sp >= S) return fail(ctx, PANTAX_HIP_E_STATE, "sort_rows: segment %llu of %u in the output", (unsigned long long)sp, S);
+                k0[i] = seg_val[sp]; k1[i] = pack_shift >= 0 ? (hm[i] & 0xFFull) : hm[i]; k2[i] = ha[i];
+            } else k0[i] = k1[i] = k2[i] = 0;
+        }
+        return 0;
+    }
     const bool sample = algo == 2 || (algo == 0 && n <= SS_MAX_N);
     DevBuf<uint64_t> a[3], b[3];
     DevBuf<uint32_t> ws, tmp, dn;

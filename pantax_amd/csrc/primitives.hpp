@@ -51,6 +51,20 @@ size_t sample_sort_seg_ws_elems(uint32_t S, uint64_t n_total_bound);
 int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t *ba, uint32_t S, uint64_t seg_bound, uint64_t n_total_bound,
                     const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t *d_ws);
 
+// The batched sort WITHOUT the compaction in front of it (sample_sort_nodes.hip): segment s = the nodes [node_base[s], node_base[s + 1])
+// (at most seg_bound <= SS_MAX_N of them), a node is a row when ab > 0 and mask != 0.  The rows of all segments end up back to back in
+// (ksp, km, ka) -- ksp null: species << pack_shift | mask in km -- every segment sorted by (mask, a); *d_n = their number.
+// rows16: 2 V words of scratch; d_ws: >= sample_sort_nodes_ws_elems(S, seg_bound, V) u32.
+// pat (optional): the runs of equal mask inside every segment, in order -- pat_mask / pat_start (first row) / pat_species of run k,
+// sp_pat_off[s] = first run of segment s ([S + 1]), *d_K = their number, pat_start[K] = the row count.  Arrays of >= V (+ 1) entries.
+struct RowPatterns {
+    uint64_t *pat_mask;
+    uint32_t *pat_start, *pat_species, *sp_pat_off, *d_K;
+};
+size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V);
+int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
+                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat = nullptr);
+
 // helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
 inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {
     for (int s = lo; s < hi; s += 8) out.push_back({word, s});

@@ -1,0 +1,618 @@
+// sample_sort_nodes.hip -- the LP rows of MANY species sorted straight from the NODE arrays: no compaction pass.
+//
+// A row of the LP is a node with a_v > 0 and a non-empty membership mask (profile.rs:1380-1385); the solver wants every
+// species' rows ordered by (mask, a).  sample_sort_seg.hip sorts rows that a chained scan has compacted first (16V in,
+// 16n out, one more pass over everything).  Here a species' SEGMENT is its node range [node_base[s], node_base[s+1]) --
+// known on the host -- and the sort's own passes skip the nodes that are no rows:
+//   1. ssn_gather / ssn_sample : 4096 evenly spaced nodes of the segment, the rows among them sorted in LDS -> 1023 splitters at even
+//                                ranks of the valid samples, stored as an implicit search tree in breadth-first order (a level's
+//                                nodes are neighbours in LDS: the descent of 64 lanes meets no systematic bank conflict, where the
+//                                upper levels of a binary search over the sorted array all fall on ONE bank)
+//                                (a segment of <= 4096 nodes is sorted completely right there)
+//   2. ssn_hist                : bucket id of every row (ten tree levels; "equal to splitter j" is its own bucket 2j+1 whose rows need
+//                                no sorting -- coverage values tie massively).  A workgroup walks SEVERAL tiles of its segment with one
+//                                LDS histogram and stores it as a row of the segment's count matrix: no global atomics
+//   3. ssn_offsets / ssn_segscan: column sums of the matrix -> bucket starts, the matrix rewritten as every workgroup's first slot in
+//                                every bucket; rows per segment -> first output row of every segment, total row count
+//   4. ssn_scatter             : rows {mask, a} as 16-byte records into their bucket (slots from LDS counters seeded by the matrix row).
+//                                One 16-byte store per row is what this pass costs (tools/native/scatter_probe.hip: 2e8 rows into 2048
+//                                buckets 4.2 ms, 1024: 3.5, 256: 2.9; the real rows, which tie massively, take 3.15 ms either way)
+//   5. ssn_local_wave          : a wave per bucket pair (2j, 2j+1): up to 512 rows sorted IN REGISTERS (eight per lane: a bitonic
+//                                network whose cross-lane steps are ds_bpermute swaps and whose in-lane steps are plain selects -- no
+//                                LDS memory, no barriers), the tie bucket copied; written to the dense output of the segment
+//      ssn_local_wave2         : the buckets of 513 .. 1024 rows (a few per cent of them), sixteen rows per lane: a kernel of its own so
+//                                that its registers do not cost the first one its waves in flight (2.2 -> 3.1 ms when it was one)
+//      ssn_local               : the rare larger buckets through an LDS network (rank sort through memory above 4096)
+// The number of rows of a segment is only known on the device; launch geometry comes from the node counts.
+#include <algorithm>
+#include <cstdlib>
+#include "primitives.hpp"
+#include "wave.hpp"
+
+namespace ptx {
+
+namespace {
+#ifndef SN_LEVELS
+#define SN_LEVELS 10                             // levels of the splitter tree (-DSN_LEVELS=9: measurements)
+#endif
+constexpr int SN_SAMPLE = 4096;
+constexpr int SN_NLEAF = 1 << SN_LEVELS;         // 1024
+constexpr int SN_NSPLIT = SN_NLEAF - 1;          // 1023 splitters: three to four valid samples between two of them
+constexpr int SN_NBUCKET = 2 * SN_NLEAF;         // 2048 ids (the last odd one stays empty)
+constexpr int SN_ITEMS = 8;                      // nodes per thread and tile
+constexpr int SN_TILE = 256 * SN_ITEMS;
+constexpr int SN_CAP = 4096;
+constexpr int SN_WAVE_CAP = 512;                 // rows a wave of the first local kernel sorts in registers (eight per lane)
+constexpr int SN_WAVE_CAP2 = 1024;               // ... of the second one (sixteen per lane: more registers, fewer waves in flight)
+constexpr uint32_t SN_TARGET_WGS = 8192;         // workgroups of the two partition kernels over all segments
+constexpr uint16_t SN_NO_ROW = 0xFFFFu;
+
+struct Key2 { uint64_t m, a; };
+__device__ __forceinline__ bool less2(const Key2 &x, const Key2 &y) { return (x.m < y.m) | ((x.m == y.m) & (x.a < y.a)); }
+__device__ __forceinline__ bool eq2(const Key2 &x, const Key2 &y) { return (x.m == y.m) & (x.a == y.a); }
+
+// per-segment workspace (u32 words), SN_WS_WORDS apart (a multiple of four: the tree's 16-byte nodes stay aligned)
+constexpr size_t SN_OFF_FLAGS = 0;                                  // [0] small segment, [1] #buckets left to the workgroup-wide sort, [2] # left to the second wave kernel, [3] rows
+constexpr size_t SN_OFF_TREE = 4;                                   // {m, a} [SN_NLEAF], node k's children 2k and 2k+1 (node 0 unused)
+constexpr size_t SN_OFF_SAMP = SN_OFF_TREE + 4 * SN_NLEAF;          // u64 [2][4096]
+constexpr size_t SN_OFF_START = SN_OFF_SAMP + 2 * 2 * SN_SAMPLE;    // [SN_NBUCKET + 1]
+constexpr size_t SN_OFF_MED = SN_OFF_START + SN_NBUCKET + 4;        // [SN_NBUCKET] buckets the first wave kernel leaves to the second
+constexpr size_t SN_OFF_BIG = SN_OFF_MED + SN_NBUCKET;              // [SN_NBUCKET] buckets of more than SN_WAVE_CAP2 rows
+constexpr size_t SN_WS_WORDS = SN_OFF_BIG + SN_NBUCKET;
+static_assert(SN_WS_WORDS % 4 == 0, "16-byte tree nodes");
+
+struct Sn {
+    const uint32_t *node_base;   // [S + 1] (device)
+    const double *ab;            // [V] a_v (0 = no row)
+    const uint64_t *mask;        // [V] membership mask (0 = no row)
+    uint32_t *ws;                // S x SN_WS_WORDS
+    uint32_t *cntm;              // S x G x SN_NBUCKET: counts, then first slots
+    uint16_t *ids;               // [V] bucket id of every node, SN_NO_ROW for the others
+    uint32_t *seg_n, *seg_out;   // [S] rows of a segment, [S + 1] its first output row
+    ulonglong2 *rows;            // [V] scratch: the rows bucket by bucket, segment s from node_base[s]
+    uint64_t *ksp, *km, *ka;     // output: {species, mask, a} (ksp null: species << pack_shift | mask in km)
+    int pack_shift;
+    uint32_t G, per;             // partition workgroups per segment, tiles each of them walks
+    __device__ __forceinline__ uint32_t *w(uint32_t s) const { return ws + (size_t)s * SN_WS_WORDS; }
+    __device__ __forceinline__ uint64_t key_word(uint32_t s, uint64_t m) const { return pack_shift >= 0 ? (((uint64_t)s << pack_shift) | m) : m; }
+    __device__ __forceinline__ void put(uint32_t s, uint32_t pos, uint64_t m, uint64_t a) const {
+        km[pos] = key_word(s, m); ka[pos] = a;
+        if (ksp) ksp[pos] = s;
+    }
+};
+
+// sorted rank (0-based, among the SN_NSPLIT splitters) of tree node k, and back
+__device__ __forceinline__ uint32_t tree_rank(uint32_t k) {
+    const uint32_t l = 31u - (uint32_t)__builtin_clz(k), p = k - (1u << l);
+    return ((2u * p + 1u) << ((uint32_t)SN_LEVELS - 1u - l)) - 1u;
+}
+__device__ __forceinline__ uint32_t tree_node(uint32_t rank) {
+    const uint32_t q = rank + 1u, tz = (uint32_t)__builtin_ctz(q);
+    return (1u << ((uint32_t)SN_LEVELS - 1u - tz)) + ((q >> tz) >> 1);
+}
+
+template <int NT>
+__device__ __forceinline__ void bitonic2(uint64_t *km, uint64_t *ka, uint32_t N) {
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += NT) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const Key2 x{km[i], ka[i]}, y{km[l], ka[l]};
+                const bool up = (i & k) == 0;
+                if (up ? less2(y, x) : less2(x, y)) { km[i] = y.m; ka[i] = y.a; km[l] = x.m; ka[l] = x.a; }
+            }
+            __syncthreads();
+        }
+}
+// ---------------------------------------------------------------------------------------------
+// A wave's register network: 64 * L keys, lane l holds elements l * L .. l * L + L - 1 of the sequence being sorted.
+// Step (k, j) of the bitonic network pairs element i with i ^ j; j >= L: the partner sits in lane l ^ (j / L), same register
+// -- one ds_bpermute per 32-bit half, then the lane keeps the smaller or the larger key; j < L: both in this lane.
+// TWO: keys are (m, a); otherwise `a` alone moves (a bucket between two splitters of one mask).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int addr /* (partner lane) << 2 */) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <bool TWO>
+__device__ __forceinline__ void cmp_swap(uint64_t &m0, uint64_t &a0, uint64_t &m1, uint64_t &a1, bool up) {
+    // up: afterwards key0 <= key1; otherwise key0 >= key1
+    const bool lt10 = TWO ? less2(Key2{m1, a1}, Key2{m0, a0}) : (a1 < a0);
+    const bool lt01 = TWO ? less2(Key2{m0, a0}, Key2{m1, a1}) : (a0 < a1);
+    const bool sw = up ? lt10 : lt01;
+    const uint64_t ta = sw ? a1 : a0, tb = sw ? a0 : a1;
+    a0 = ta; a1 = tb;
+    if (TWO) { const uint64_t tm = sw ? m1 : m0, tn = sw ? m0 : m1; m0 = tm; m1 = tn; }
+}
+template <int L, bool TWO>
+__device__ __forceinline__ void wave_sort_regs(uint64_t (&m)[L], uint64_t (&a)[L]) {
+    const uint32_t lane = threadIdx.x & 63;
+    // stages whose direction depends on the element's place inside the lane (k < L)
+#pragma unroll
+    for (int k = 2; k < L; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int e = 0; e < L; ++e)
+                if ((e & j) == 0) cmp_swap<TWO>(m[e], a[e], m[e | j], a[e | j], (e & k) == 0);
+    // stages k = L .. 64 L: the direction is the lane's
+    for (uint32_t kl = 1; kl <= 64; kl <<= 1) {          // kl = k / L
+        const bool up = (lane & kl) == 0;
+        for (uint32_t jl = kl >> 1; jl > 0; jl >>= 1) {  // cross-lane steps: partner lane ^ jl
+            const int addr = (int)((lane ^ jl) << 2);
+            const bool keep_min = up == ((lane & jl) == 0);
+#pragma unroll
+            for (int e = 0; e < L; ++e) {
+                const uint64_t oa = lane_xor64(a[e], addr);
+                uint64_t om = 0;
+                if (TWO) om = lane_xor64(m[e], addr);
+                const bool o_lt = TWO ? less2(Key2{om, oa}, Key2{m[e], a[e]}) : (oa < a[e]);
+                const bool m_lt = TWO ? less2(Key2{m[e], a[e]}, Key2{om, oa}) : (a[e] < oa);
+                const bool take = keep_min ? o_lt : m_lt;
+                a[e] = take ? oa : a[e];
+                if (TWO) m[e] = take ? om : m[e];
+            }
+        }
+#pragma unroll
+        for (int j = L >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int e = 0; e < L; ++e)
+                if ((e & j) == 0) cmp_swap<TWO>(m[e], a[e], m[e | j], a[e | j], up);
+    }
+}
+// one bucket of n <= 64 L rows: src (16-byte records) -> sorted -> the segment's output at dst
+template <int L, bool TWO>
+__device__ __forceinline__ void wave_sort_bucket(const Sn &sn, uint32_t s, const ulonglong2 *__restrict__ src, uint32_t n, uint32_t dst, uint64_t mv) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t m[L], a[L];
+#pragma unroll
+    for (int e = 0; e < L; ++e) {                 // any assignment of rows to elements will do: coalesced loads
+        const uint32_t i = (uint32_t)e * 64u + lane;
+        m[e] = ~0ull; a[e] = ~0ull;               // pads sort behind every row
+        if (i < n) { const ulonglong2 r = src[i]; m[e] = r.x; a[e] = r.y; }
+    }
+    wave_sort_regs<L, TWO>(m, a);
+#pragma unroll
+    for (int e = 0; e < L; ++e) {
+        const uint32_t i = lane * (uint32_t)L + (uint32_t)e;
+        if (i < n) sn.put(s, dst + i, TWO ? m[e] : mv, a[e]);
+    }
+}
+
+__global__ void __launch_bounds__(256) ssn_gather_kernel(Sn sn) {
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
+    uint32_t *w = sn.w(s);
+    uint64_t *samp = reinterpret_cast<uint64_t *>(w + SN_OFF_SAMP);
+    const bool small = n <= (uint32_t)SN_SAMPLE;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;   // grid.x covers SN_SAMPLE
+    const uint64_t pos = small ? i : ((uint64_t)i * n) / SN_SAMPLE;
+    uint64_t m = ~0ull, a = ~0ull;                       // not a row: sorts last
+    if (pos < n) {
+        const double av = sn.ab[o + pos];
+        const uint64_t mv = sn.mask[o + pos];
+        if (av > 0.0 && mv != 0ull) { m = mv; a = (uint64_t)__double_as_longlong(av); }   // positive doubles order like their bit patterns
+    }
+    samp[i] = m; samp[SN_SAMPLE + i] = a;
+    if (i == 0) { w[SN_OFF_FLAGS] = small ? 1u : 0u; w[SN_OFF_FLAGS + 1] = 0; w[SN_OFF_FLAGS + 2] = 0; w[SN_OFF_FLAGS + 3] = 0; }
+}
+// One 1024-thread workgroup per segment sorts its 4096 samples in LDS; the splitters are the valid samples at even ranks.
+__global__ void __launch_bounds__(1024) ssn_sample_kernel(Sn sn) {
+    __shared__ uint64_t km[SN_SAMPLE], ka[SN_SAMPLE];
+    __shared__ uint32_t s_nv;
+    const uint32_t s = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
+    uint32_t *w = sn.w(s);
+    if (n == 0) { if (threadIdx.x == 0) sn.seg_n[s] = 0; return; }
+    const uint64_t *samp = reinterpret_cast<const uint64_t *>(w + SN_OFF_SAMP);
+    const bool small = n <= (uint32_t)SN_SAMPLE;
+    if (threadIdx.x == 0) s_nv = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)SN_SAMPLE; i += 1024) { km[i] = samp[i]; ka[i] = samp[SN_SAMPLE + i]; }
+    __syncthreads();
+    bitonic2<1024>(km, ka, SN_SAMPLE);
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)SN_SAMPLE; i += 1024) c += ka[i] != ~0ull ? 1u : 0u;
+    if (c) atomicAdd(&s_nv, c);
+    __syncthreads();
+    const uint32_t nv = s_nv;
+    if (small) {                                         // every row of the segment, sorted: copied out by the local kernel
+        for (uint32_t i = threadIdx.x; i < nv; i += 1024) sn.rows[o + i] = make_ulonglong2(km[i], ka[i]);
+        if (threadIdx.x == 0) { sn.seg_n[s] = nv; w[SN_OFF_FLAGS + 3] = nv; }
+        return;
+    }
+    ulonglong2 *tree = reinterpret_cast<ulonglong2 *>(w + SN_OFF_TREE);
+    for (uint32_t k = threadIdx.x; k < (uint32_t)SN_NLEAF; k += 1024) {
+        if (k == 0) { tree[0] = make_ulonglong2(~0ull, ~0ull); continue; }
+        const uint32_t j = tree_rank(k);                 // splitter j = the valid sample of rank (j + 1) nv / SN_NLEAF
+        uint32_t r = (uint32_t)(((uint64_t)(j + 1) * nv) >> SN_LEVELS);
+        if (r >= nv) r = nv ? nv - 1 : 0;
+        tree[k] = nv ? make_ulonglong2(km[r], ka[r]) : make_ulonglong2(~0ull, ~0ull);
+    }
+}
+
+// the tiles [t0, t1) of workgroup g of a segment of n nodes
+__device__ __forceinline__ void sn_tiles(const Sn &sn, uint32_t n, uint32_t g, uint32_t &t0, uint32_t &t1) {
+    const uint32_t nt = (n + SN_TILE - 1) / SN_TILE;
+    t0 = g * sn.per; t1 = t0 + sn.per;
+    if (t0 > nt) t0 = nt;
+    if (t1 > nt) t1 = nt;
+}
+
+__global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
+    __shared__ ulonglong2 tree[SN_NLEAF];
+    __shared__ uint32_t s_hist[SN_NBUCKET];
+    const uint32_t s = blockIdx.y, g = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
+    uint32_t *w = sn.w(s);
+    if (n == 0 || w[SN_OFF_FLAGS] != 0) return;
+    uint32_t t0, t1;
+    sn_tiles(sn, n, g, t0, t1);
+    const ulonglong2 *gt = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+    for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_hist[i] = 0;
+    if (t0 < t1) for (int i = threadIdx.x; i < SN_NLEAF; i += 256) tree[i] = gt[i];
+    __syncthreads();
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t base = t * SN_TILE + threadIdx.x;
+        double av[SN_ITEMS];
+        uint64_t mv[SN_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SN_ITEMS; ++r) {
+            const uint32_t i = base + (uint32_t)r * 256u;
+            av[r] = 0.0; mv[r] = 0;
+            if (i < n) { av[r] = sn.ab[o + i]; mv[r] = sn.mask[o + i]; }
+        }
+#pragma unroll
+        for (int r = 0; r < SN_ITEMS; ++r) {
+            const uint32_t i = base + (uint32_t)r * 256u;
+            if (i >= n) continue;
+            uint16_t id = SN_NO_ROW;
+            if (av[r] > 0.0 && mv[r] != 0ull) {
+                const Key2 key{mv[r], (uint64_t)__double_as_longlong(av[r])};
+                uint32_t k = 1;
+#pragma unroll
+                for (int l = 0; l < SN_LEVELS; ++l) { const ulonglong2 nd = tree[k]; k = 2u * k + (less2(Key2{nd.x, nd.y}, key) ? 1u : 0u); }
+                const uint32_t lo = k - (uint32_t)SN_NLEAF;   // splitters less than the key
+                uint32_t eq = 0;
+                if (lo < (uint32_t)SN_NSPLIT) { const ulonglong2 nd = tree[tree_node(lo)]; eq = eq2(Key2{nd.x, nd.y}, key) ? 1u : 0u; }
+                id = (uint16_t)(2u * lo + eq);
+                atomicAdd(&s_hist[id], 1u);
+            }
+            sn.ids[o + i] = id;
+        }
+    }
+    __syncthreads();
+    uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
+    for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) row[i] = s_hist[i];
+}
+
+// bucket starts of a segment; the count matrix becomes the first slot of every workgroup in every bucket
+__global__ void __launch_bounds__(256) ssn_offsets_kernel(Sn sn) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t s = blockIdx.x, n = sn.node_base[s + 1] - sn.node_base[s];
+    uint32_t *w = sn.w(s);
+    if (n == 0 || w[SN_OFF_FLAGS] != 0) return;          // (a small segment's row count is the sample kernel's)
+    uint32_t *cm = sn.cntm + (size_t)s * sn.G * SN_NBUCKET;
+    const uint32_t nt = (n + SN_TILE - 1) / SN_TILE, ng = (nt + sn.per - 1) / sn.per;   // workgroups that hold tiles
+    constexpr int BPT = SN_NBUCKET / 256;                 // consecutive buckets per thread (a multiple of four)
+    static_assert(BPT % 4 == 0 && BPT >= 4, "16-byte steps");
+    const uint32_t b0 = threadIdx.x * BPT;
+    uint32_t tot[BPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) tot[i] = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+#pragma unroll
+        for (int q = 0; q < BPT; q += 4) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(cm + (size_t)g * SN_NBUCKET + b0 + q);
+            tot[q] += c.x; tot[q + 1] += c.y; tot[q + 2] += c.z; tot[q + 3] += c.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) sum += tot[i];
+    uint32_t total;
+    uint32_t off = block_excl_scan<256>(sum, s_wave, &total);
+    uint32_t run[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) { run[i] = off; w[SN_OFF_START + b0 + i] = off; off += tot[i]; }
+    if (threadIdx.x == 255) w[SN_OFF_START + SN_NBUCKET] = off;
+    for (uint32_t g = 0; g < ng; ++g) {
+        uint32_t *p = cm + (size_t)g * SN_NBUCKET + b0;
+#pragma unroll
+        for (int q = 0; q < BPT; q += 4) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(p + q);
+            *reinterpret_cast<uint4 *>(p + q) = make_uint4(run[q], run[q + 1], run[q + 2], run[q + 3]);
+            run[q] += c.x; run[q + 1] += c.y; run[q + 2] += c.z; run[q + 3] += c.w;
+        }
+    }
+    if (threadIdx.x == 0) { sn.seg_n[s] = total; w[SN_OFF_FLAGS + 3] = total; }
+}
+// first output row of every segment (the rows of all segments lie back to back), and the total
+__global__ void __launch_bounds__(1024) ssn_segscan_kernel(uint32_t S, const uint32_t *__restrict__ seg_n, uint32_t *__restrict__ seg_out, uint32_t *__restrict__ d_n) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < S; base += 1024) {
+        const uint32_t i = base + threadIdx.x, v = i < S ? seg_n[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
+        if (i < S) seg_out[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { seg_out[S] = carry; *d_n = carry; }
+}
+
+__global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
+    __shared__ uint32_t s_slot[SN_NBUCKET];
+    const uint32_t s = blockIdx.y, g = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
+    const uint32_t *w = sn.w(s);
+    if (n == 0 || w[SN_OFF_FLAGS] != 0) return;
+    uint32_t t0, t1;
+    sn_tiles(sn, n, g, t0, t1);
+    if (t0 >= t1) return;
+    const uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
+    for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_slot[i] = row[i];
+    __syncthreads();
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t base = t * SN_TILE + threadIdx.x;
+        uint16_t id[SN_ITEMS];
+        double av[SN_ITEMS];
+        uint64_t mv[SN_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SN_ITEMS; ++r) {
+            const uint32_t i = base + (uint32_t)r * 256u;
+            id[r] = SN_NO_ROW; av[r] = 0.0; mv[r] = 0;
+            if (i < n) { id[r] = sn.ids[o + i]; av[r] = sn.ab[o + i]; mv[r] = sn.mask[o + i]; }
+        }
+#pragma unroll
+        for (int r = 0; r < SN_ITEMS; ++r) {
+            if (id[r] == SN_NO_ROW) continue;
+            const uint32_t pos = atomicAdd(&s_slot[id[r]], 1u);
+            sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
+        }
+    }
+}
+
+// A wave per bucket pair (2j, 2j + 1): the even bucket sorted in registers (more than SN_WAVE_CAP rows: left on the segment's
+// list for ssn_local_kernel), the odd one -- rows equal to splitter j -- copied.
+__global__ void __launch_bounds__(256) ssn_local_wave_kernel(Sn sn) {
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
+    uint32_t *w = sn.w(s);
+    if (nn == 0 || w[SN_OFF_FLAGS] != 0) return;
+    const uint32_t *bucket_start = w + SN_OFF_START;
+    const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+    const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);   // grid.x * 4 = SN_NLEAF pairs
+    const uint32_t out = sn.seg_out[s];
+    const uint32_t st = bucket_start[2 * j], st1 = bucket_start[2 * j + 1], st2 = bucket_start[2 * j + 2];
+    {   // the tie bucket (for the last j it is empty)
+        const uint32_t m = st2 - st1;
+        for (uint32_t i = lane; i < m; i += 64) { const ulonglong2 r = sn.rows[o + st1 + i]; sn.put(s, out + st1 + i, r.x, r.y); }
+    }
+    const uint32_t m = st1 - st;
+    if (m == 0) return;
+    const ulonglong2 *src = sn.rows + o + st;
+    if (m == 1) { if (lane == 0) { const ulonglong2 r = src[0]; sn.put(s, out + st, r.x, r.y); } return; }
+    if (m > (uint32_t)SN_WAVE_CAP) { if (lane == 0) w[SN_OFF_MED + atomicAdd(&w[SN_OFF_FLAGS + 2], 1u)] = 2 * j; return; }
+    // between two splitters with the same mask every row has that mask: only `a` moves through the network
+    bool one = false;
+    uint64_t mv = 0;
+    if (j > 0 && j < (uint32_t)SN_NSPLIT) {
+        const uint64_t ma = tree[tree_node(j - 1)].x, mb = tree[tree_node(j)].x;
+        one = ma == mb; mv = mb;
+    }
+    const uint32_t dst = out + st;
+    if (one) {
+        if (m <= 64) wave_sort_bucket<1, false>(sn, s, src, m, dst, mv);
+        else if (m <= 128) wave_sort_bucket<2, false>(sn, s, src, m, dst, mv);
+        else if (m <= 256) wave_sort_bucket<4, false>(sn, s, src, m, dst, mv);
+        else wave_sort_bucket<8, false>(sn, s, src, m, dst, mv);
+    } else {
+        if (m <= 64) wave_sort_bucket<1, true>(sn, s, src, m, dst, mv);
+        else if (m <= 128) wave_sort_bucket<2, true>(sn, s, src, m, dst, mv);
+        else if (m <= 256) wave_sort_bucket<4, true>(sn, s, src, m, dst, mv);
+        else wave_sort_bucket<8, true>(sn, s, src, m, dst, mv);
+    }
+}
+// The first kernel's list: a wave per bucket of 513 .. SN_WAVE_CAP2 rows, sixteen per lane; larger ones go on the next list
+__global__ void __launch_bounds__(256) ssn_local_wave2_kernel(Sn sn) {
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
+    uint32_t *w = sn.w(s);
+    if (nn == 0 || w[SN_OFF_FLAGS] != 0) return;
+    const uint32_t n_work = w[SN_OFF_FLAGS + 2];
+    const uint32_t *bucket_start = w + SN_OFF_START;
+    const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+    const uint32_t lane = threadIdx.x & 63, out = sn.seg_out[s];
+    for (uint32_t wi = blockIdx.x * 4 + (threadIdx.x >> 6); wi < n_work; wi += gridDim.x * 4) {
+        const uint32_t bid = w[SN_OFF_MED + wi], j = bid >> 1;
+        const uint32_t st = bucket_start[bid], m = bucket_start[bid + 1] - st;
+        if (m > (uint32_t)SN_WAVE_CAP2) { if (lane == 0) w[SN_OFF_BIG + atomicAdd(&w[SN_OFF_FLAGS + 1], 1u)] = bid; continue; }
+        bool one = false;
+        uint64_t mv = 0;
+        if (j > 0 && j < (uint32_t)SN_NSPLIT) {
+            const uint64_t ma = tree[tree_node(j - 1)].x, mb = tree[tree_node(j)].x;
+            one = ma == mb; mv = mb;
+        }
+        if (one) wave_sort_bucket<16, false>(sn, s, sn.rows + o + st, m, out + st, mv);
+        else wave_sort_bucket<16, true>(sn, s, sn.rows + o + st, m, out + st, mv);
+    }
+}
+
+// What the wave kernels leave: buckets of more than SN_WAVE_CAP2 rows (an LDS network up to SN_CAP rows, a rank sort through memory
+// above), and the copy of a small segment.
+__global__ void __launch_bounds__(256) ssn_local_kernel(Sn sn) {
+    __shared__ uint64_t km[SN_CAP], ka[SN_CAP];
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
+    if (nn == 0) return;
+    uint32_t *w = sn.w(s);
+    const uint32_t out = sn.seg_out[s];
+    if (w[SN_OFF_FLAGS] != 0) {      // small segment: the sample kernel sorted every row into the scratch
+        const uint32_t n = w[SN_OFF_FLAGS + 3];
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const ulonglong2 r = sn.rows[o + i]; sn.put(s, out + i, r.x, r.y); }
+        return;
+    }
+    const uint32_t *bucket_start = w + SN_OFF_START;
+    const uint32_t n_work = w[SN_OFF_FLAGS + 1];
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t bid = w[SN_OFF_BIG + wi];
+        const uint32_t st = bucket_start[bid], m = bucket_start[bid + 1] - st;
+        const ulonglong2 *src = sn.rows + o + st;
+        const uint32_t dst = out + st;
+        __syncthreads();   // LDS reuse across the buckets of this workgroup
+        if (m <= (uint32_t)SN_CAP) {
+            uint32_t N = 2;
+            while (N < m) N <<= 1;
+            for (uint32_t i = threadIdx.x; i < N; i += 256) {
+                if (i < m) { const ulonglong2 r = src[i]; km[i] = r.x; ka[i] = r.y; } else { km[i] = ~0ull; ka[i] = ~0ull; }
+            }
+            __syncthreads();
+            bitonic2<256>(km, ka, N);
+            for (uint32_t i = threadIdx.x; i < m; i += 256) sn.put(s, dst + i, km[i], ka[i]);
+            continue;
+        }
+        // oversized bucket (practically never): rank every row against the whole bucket through memory
+        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+            const ulonglong2 r = src[i];
+            const Key2 key{r.x, r.y};
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < m; ++q) {
+                const ulonglong2 t = src[q];
+                const Key2 ot{t.x, t.y};
+                if (less2(ot, key) || (eq2(ot, key) && q < i)) ++rank;
+            }
+            sn.put(s, dst + rank, key.m, key.a);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patterns = runs of equal mask in a segment's sorted rows (the solver's groups, lad_prepare).  No pass over the rows: a run can only
+// begin where the mask of the SPLITTERS changes -- between two splitters of one mask every row has that mask, and the row in front of
+// them is a copy of the lower splitter or a row behind it -- so one wave per segment walks the 1023 splitters and reads the rows of the
+// few bucket pairs at a change (and of the first and the last pair).  Heads are collected in order in the segment's part of the row
+// scratch, which the local kernels have finished with.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) ssn_heads_kernel(Sn sn, uint32_t *__restrict__ seg_k) {
+    const uint32_t s = blockIdx.x, o = sn.node_base[s], nn = sn.node_base[s + 1] - o, lane = threadIdx.x;
+    const uint32_t n = nn ? sn.seg_n[s] : 0u;
+    if (n == 0) { if (lane == 0) seg_k[s] = 0; return; }
+    const uint32_t *w = sn.w(s);
+    const uint32_t out = sn.seg_out[s];
+    ulonglong2 *heads = sn.rows + o;                      // {mask word as stored, first row of the run}
+    uint32_t cnt = 0;
+    auto scan_rows = [&](uint32_t r0, uint32_t r1) {      // rows [r0, r1) of the output, in order
+        for (uint32_t base = r0; base < r1; base += 64) {
+            const uint32_t i = base + lane;
+            const bool in = i < r1;
+            const uint64_t m = in ? sn.km[i] : 0ull, pm = (in && i > out) ? sn.km[i - 1] : 0ull;
+            const bool head = in && (i == out || m != pm);
+            const uint64_t bal = __ballot(head);
+            if (head) heads[cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_ulonglong2(m, (uint64_t)i);
+            cnt += (uint32_t)__popcll(bal);
+        }
+    };
+    if (w[SN_OFF_FLAGS] != 0) scan_rows(out, out + n);    // a small segment has no splitters
+    else {
+        const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+        const uint32_t *start = w + SN_OFF_START;
+        for (uint32_t jb = 0; jb < (uint32_t)SN_NLEAF; jb += 64) {
+            const uint32_t j = jb + lane;
+            bool c = j == 0 || j == (uint32_t)SN_NLEAF - 1;
+            if (!c) c = tree[tree_node(j)].x != tree[tree_node(j - 1)].x;
+            uint64_t bal = __ballot(c);
+            while (bal) {
+                const uint32_t jj = jb + (uint32_t)__builtin_ctzll(bal);
+                bal &= bal - 1;
+                scan_rows(out + start[2 * jj], out + start[2 * jj + 2]);
+            }
+        }
+    }
+    if (lane == 0) seg_k[s] = cnt;
+}
+// first pattern of every segment, the number of patterns, and the end of the last run
+__global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uint32_t *__restrict__ seg_k, uint32_t *__restrict__ sp_pat_off, uint32_t *__restrict__ d_K,
+                                                           const uint32_t *__restrict__ d_n, uint32_t *__restrict__ pat_start) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < S; base += 1024) {
+        const uint32_t i = base + threadIdx.x, v = i < S ? seg_k[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
+        if (i < S) sp_pat_off[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { sp_pat_off[S] = carry; *d_K = carry; pat_start[carry] = *d_n; }
+}
+__global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t *__restrict__ seg_k, const uint32_t *__restrict__ sp_pat_off, uint64_t *__restrict__ pat_mask,
+                                                          uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species) {
+    const uint32_t s = blockIdx.x, cnt = seg_k[s], k0 = sp_pat_off[s];
+    const ulonglong2 *heads = sn.rows + sn.node_base[s];
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const ulonglong2 h = heads[i];
+        pat_mask[k0 + i] = sn.pack_shift >= 0 ? (h.x & ((1ull << sn.pack_shift) - 1ull)) : h.x;
+        pat_start[k0 + i] = (uint32_t)h.y;
+        pat_species[k0 + i] = s;
+    }
+}
+
+void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
+    const uint64_t nt = std::max<uint64_t>(1, (seg_bound + SN_TILE - 1) / SN_TILE);   // tiles of the largest segment
+    uint64_t target = SN_TARGET_WGS;
+    if (const char *ev = std::getenv("PANTAX_SSN_WGS")) target = std::max<uint64_t>(1, std::strtoull(ev, nullptr, 10));   // measurements
+    uint64_t p = (nt * S + target - 1) / target;
+    if (p < 1) p = 1;
+    if (p > nt) p = nt;
+    *per = (uint32_t)p;
+    *G = (uint32_t)((nt + p - 1) / p);
+}
+}  // namespace
+
+size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
+    uint32_t G, per;
+    sn_geometry(S, seg_bound, &G, &per);
+    return (size_t)S * SN_WS_WORDS + (size_t)S * G * SN_NBUCKET + (V + 1) / 2 + 3 * (size_t)S + 16;
+}
+
+// Nodes of segment s: [node_base[s], node_base[s + 1]) (device array, the host knows that no segment exceeds seg_bound <= SS_MAX_N
+// nodes); a node is a row when ab > 0 and mask != 0.  Output: the rows of all segments back to back, every segment sorted by
+// (mask, a), in (ksp, km, ka) -- ksp null: species << pack_shift | mask in km; *d_n = the number of rows.  rows16: 2 V words of scratch.
+int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
+                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat) {
+    if (S == 0 || V == 0) {
+        PTX_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(uint32_t), ctx->stream));
+        if (pat) { PTX_HIP(ctx, hipMemsetAsync(pat->d_K, 0, sizeof(uint32_t), ctx->stream)); PTX_HIP(ctx, hipMemsetAsync(pat->sp_pat_off, 0, (S + 1) * sizeof(uint32_t), ctx->stream));
+                   PTX_HIP(ctx, hipMemsetAsync(pat->pat_start, 0, sizeof(uint32_t), ctx->stream)); }
+        return 0;
+    }
+    if (seg_bound > SS_MAX_N) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: a segment of %llu nodes exceeds %llu", (unsigned long long)seg_bound, (unsigned long long)SS_MAX_N);
+    if (S > 65535) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: %u segments exceed the launch grid", S);
+    Sn sn;
+    sn.node_base = d_node_base; sn.ab = ab; sn.mask = mask; sn.ws = d_ws;
+    sn_geometry(S, seg_bound, &sn.G, &sn.per);
+    sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
+    uint32_t *tail = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
+    sn.seg_n = tail; sn.seg_out = tail + S;                       // [S], [S + 1]
+    uint32_t *seg_k = tail + 2 * (size_t)S + 4;                   // [S] patterns of a segment
+    sn.ids = reinterpret_cast<uint16_t *>(tail + 3 * (size_t)S + 4);
+    sn.rows = reinterpret_cast<ulonglong2 *>(rows16);
+    sn.ksp = ksp; sn.km = km; sn.ka = ka; sn.pack_shift = pack_shift;
+    { KTimer t(ctx, "ssn_sample_kernel");
+      hipLaunchKernelGGL(ssn_gather_kernel, dim3(SN_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sn);
+      hipLaunchKernelGGL(ssn_sample_kernel, dim3(S), dim3(1024), 0, ctx->stream, sn); }
+    { KTimer t(ctx, "ssn_hist_kernel");
+      hipLaunchKernelGGL(ssn_hist_kernel, dim3(sn.G, S), dim3(256), 0, ctx->stream, sn); }
+    { KTimer t(ctx, "ssn_offsets_kernel");
+      hipLaunchKernelGGL(ssn_offsets_kernel, dim3(S), dim3(256), 0, ctx->stream, sn);
+      hipLaunchKernelGGL(ssn_segscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)sn.seg_n, sn.seg_out, d_n); }
+    { KTimer t(ctx, "ssn_scatter_kernel");
+      hipLaunchKernelGGL(ssn_scatter_kernel, dim3(sn.G, S), dim3(256), 0, ctx->stream, sn); }
+    { KTimer t(ctx, "ssn_local_wave_kernel");
+      hipLaunchKernelGGL(ssn_local_wave_kernel, dim3(SN_NLEAF / 4, S), dim3(256), 0, ctx->stream, sn);
+      hipLaunchKernelGGL(ssn_local_wave2_kernel, dim3(8, S), dim3(256), 0, ctx->stream, sn);
+      hipLaunchKernelGGL(ssn_local_kernel, dim3(8, S), dim3(256), 0, ctx->stream, sn); }
+    if (pat) {
+        KTimer t(ctx, "ssn_heads_kernel");
+        hipLaunchKernelGGL(ssn_heads_kernel, dim3(S), dim3(64), 0, ctx->stream, sn, seg_k);
+        hipLaunchKernelGGL(ssn_patscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)seg_k, pat->sp_pat_off, pat->d_K, (const uint32_t *)d_n, pat->pat_start);
+        hipLaunchKernelGGL(ssn_patfill_kernel, dim3(S), dim3(256), 0, ctx->stream, sn, (const uint32_t *)seg_k, (const uint32_t *)pat->sp_pat_off, pat->pat_mask, pat->pat_start,
+                           pat->pat_species);
+    }
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace ptx

@@ -894,12 +894,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     uint64_t max_vs = 0;
     for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
     bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
-    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) {   // measurements / tests: "radix", or "seg" = the batched sort wherever it can run
-        if (ev[0] == 'r') use_seg = false;
-        if (ev[0] == 's') use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0;
+    bool use_nodes = use_seg;   // ... straight from the node arrays (sample_sort_nodes.hip), without the compaction pass in front
+    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) {   // measurements / tests: "radix"; "seg" / "nodes" = one of the batched sorts wherever it can run
+        if (ev[0] == 'r') use_seg = use_nodes = false;
+        if (ev[0] == 's') { use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0; use_nodes = false; }
+        if (ev[0] == 'n') use_seg = use_nodes = max_vs <= SS_MAX_N && S <= 65535 && V > 0;
     }
     uint32_t *d_seg_cnt = nullptr, *d_seg_off = nullptr;
-    if (use_seg) {
+    if (use_seg && !use_nodes) {
         PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
         d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
     }
@@ -930,13 +932,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, lb->d_counts.alloc(4));
     uint32_t *d_n = lb->d_counts.p, *d_K = lb->d_counts.p + 1, *d_ovf = lb->d_counts.p + 2;
     DevBuf<uint64_t> *ka = dbm->d_ka, *kb = dbm->d_kb;
-    for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); PTX_HIP(ctx, kb[w].alloc(V)); }
+    for (int w = 0; w < 3; ++w) { PTX_HIP(ctx, ka[w].alloc(V)); if (!use_nodes) PTX_HIP(ctx, kb[w].alloc(V)); }
     // above the sample-sort limit the rows go through the radix sort; species and mask then share one key word
     // whenever their bits fit (16-byte records instead of 24)
     const int sp_bits = S > 1 ? bits_for(S - 1) : 0;
     const bool use_sample = V <= SS_MAX_N;
     const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64 && !(use_seg && pmax_bound >= 64)) ? pmax_bound : -1;
-    if (use_seg) {
+    if (use_nodes) {
+        if (pack_shift >= 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: internal (64 candidate columns and a packed species key)");
+    } else if (use_seg) {
         if (pack_shift >= 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: internal (64 candidate columns and a packed species key)");
         PTX_TRY(exclusive_scan_fn(ctx, RowLoad{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p},
                                   RowStore{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, db->d_emit_tile_sp.p, db->d_node_base.p,
@@ -959,7 +963,18 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     A.nw = B.nw = pack_shift >= 0 ? 2 : 3;
     for (int w = 0; w < 3; ++w) { A.k[w] = ka[w].p; B.k[w] = kb[w].p; }
     bool in_b = false;
-    if (use_seg) {
+    // patterns = runs of equal (species, mask)
+    const uint64_t k_cap = V;   // patterns are runs of rows and rows are nodes: never more than V, so the tables cannot overflow
+    lb->k_cap = (uint32_t)k_cap;
+    PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
+    PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
+    if (use_nodes) {   // no compaction: the sort's passes read the node arrays and skip the nodes that are no rows; the patterns come from its splitters
+        PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_nodes_ws_elems(S, max_vs, V)));
+        PTX_HIP(ctx, dbm->d_row16.alloc(2 * V));
+        const RowPatterns pat{lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, lb->d_sp_pat_off.p, d_K};
+        PTX_TRY(sample_sort_nodes(ctx, lb->d_ab.p, lb->d_mask.p, db->d_node_base.p, S, max_vs, V, dbm->d_row16.p, pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p,
+                                  pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat));
+    } else if (use_seg) {
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_seg_ws_elems(S, V)));
         const int w0 = pack_shift >= 0 ? 0 : 1;   // the two words that move: {packed species|mask, a} or {mask, a}
         PTX_TRY(sample_sort_seg(ctx, ka[w0].p, ka[w0 + 1].p, kb[w0].p, kb[w0 + 1].p, S, max_vs, V, d_seg_off, d_seg_cnt, dbm->d_ss_ws.p));
@@ -980,19 +995,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     SortBufs Sd = in_b ? B : A;
     lb->row_a = reinterpret_cast<const double *>(Sd.k[pack_shift >= 0 ? 1 : 2]);   // sorted abundances, used in place
-    // patterns = runs of equal (species, mask)
-    const uint64_t k_cap = V;   // patterns are runs of rows and rows are nodes: never more than V, so the tables cannot overflow
-    lb->k_cap = (uint32_t)k_cap;
-    PTX_HIP(ctx, lb->d_pat_mask.alloc(k_cap)); PTX_HIP(ctx, lb->d_pat_start.alloc(k_cap + 1)); PTX_HIP(ctx, lb->d_pat_species.alloc(k_cap));
-    {
+    if (!use_nodes) {
         const uint64_t *pk1 = pack_shift >= 0 ? (const uint64_t *)nullptr : Sd.k[1];
         PTX_TRY(exclusive_scan_fn(ctx, PatLoad{d_n, Sd.k[0], pk1},
                                   PatStore{Sd.k[0], pk1, (uint32_t)k_cap, pack_shift, lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, d_ovf},
                                   V, d_K, "scan_chained_kernel<Pat>"));
+        hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
+                           lb->d_pat_start.p, lb->d_sp_pat_off.p);
     }
-    PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
-    hipLaunchKernelGGL(sp_pat_off_kernel, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, S, d_K, (uint32_t)k_cap, lb->d_pat_species.p, d_n,
-                       lb->d_pat_start.p, lb->d_sp_pat_off.p);
     if (wide)
         hipLaunchKernelGGL(wide_pattern_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
                            lb->d_wide_nw.p, db->d_node_base.p, lb->d_p.p, lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, (const unsigned long long *)lb->d_maskw.p,

@@ -777,8 +777,9 @@ def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, monkeypatc
     (28, 3, 150, 400000, 20000, 0.8, dict(fr=0.05)),           # a wide species in the batch
 ])
 def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
-    """The three row pipelines of lad_prepare -- whole-batch sample sort (small inputs), whole-batch radix sort, and the
-    node-order compaction + batched per-species sort of the many-species step (forced here at a small size) -- and the two ways
+    """The four row pipelines of lad_prepare -- whole-batch sample sort (small inputs), whole-batch radix sort, the node-order
+    compaction + batched per-species sort (round 3's many-species step) and the batched sort straight from the node arrays (the
+    many-species step now; both forced here at a small size) -- and the two ways
     of building the membership masks (by node from the node -> haplotypes table of the upload, or by walking the candidates'
     paths, PANTAX_MASK=walk) give the same metrics, objectives, iteration counts, row and pattern counts bit for bit."""
     from oracle import oracle as orc
@@ -792,7 +793,7 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     eng.trio_nodes_info(fetch=False)
     eng.get_node_abundances(fetch=False)
     outs = []
-    for sort, maskmode in ((None, None), ("seg", None), ("radix", None), (None, "walk"), ("seg", "walk")):
+    for sort, maskmode in ((None, None), ("seg", None), ("nodes", None), ("radix", None), (None, "walk"), ("seg", "walk"), ("nodes", "walk")):
         monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
         monkeypatch.delenv("PANTAX_MASK", raising=False) if maskmode is None else monkeypatch.setenv("PANTAX_MASK", maskmode)
         met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
@@ -1029,6 +1030,50 @@ def test_segmented_sample_sort_against_host_sort(eng, wave_rows, monkeypatch):
     exp = _host_sorted(k0, k1, k2)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", [4, 5])
+def test_node_order_sample_sort_against_host_sort(eng, algo):
+    """The row sort of the many-species step (sample_sort_nodes.hip) through the host-buffer utility: it reads NODE arrays -- an entry
+    with an empty mask or without a positive abundance is no row and drops out -- and leaves the rows of all segments back to back.
+    Segments of every size class side by side: empty of rows, 1 row, <= 4096 nodes (sorted by the sample kernel), tens of
+    thousands, massive ties (single-key buckets), presorted / reversed, one mask (only the abundance moves through the register
+    network) and many, and unrepresentative samples whose one bucket exceeds the wave (512), the workgroup (1024) and the LDS
+    (4096) capacities.  algo 5: the segment number packed into the mask word, as the step does when the bits fit."""
+    rng = np.random.default_rng(11)
+    segs = []
+    for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 5000, 70000):
+        segs.append((rng.integers(0, 8, n), rng.integers(0, 2 ** 62, n)))                          # mask 0 = no row, 1 in 8
+    segs.append((np.zeros(300, np.uint64), rng.integers(1, 2 ** 62, 300)))                        # a small segment without rows
+    segs.append((np.zeros(9000, np.uint64), rng.integers(1, 2 ** 62, 9000)))                      # a large one without rows
+    n = 150000
+    segs.append((rng.integers(0, 3, n), rng.integers(0, 50, n)))                                  # 100 distinct keys, abundance 0 = no row
+    segs.append((np.ones(n, np.uint64), np.sort(rng.integers(1, 2 ** 62, n))))                    # presorted, one mask
+    segs.append((np.full(n, 7, np.uint64), np.sort(rng.integers(1, 2 ** 62, n))[::-1]))           # reversed
+    a = rng.integers(1, 2 ** 62, n).astype(np.uint64)
+    a[rng.random(n) < 0.5] |= np.uint64(1 << 63)                                                  # negative doubles: no rows
+    segs.append((rng.integers(1, 200, n), a))
+    for n, extra in ((8192, 0), (20000, 0), (6000, 700), (9000, 2500)):
+        # nodes 0, n/4096, 2n/4096, ... are the sample: small keys there, large distinct keys elsewhere -> one bucket holds the rest
+        k2 = rng.permutation(n).astype(np.uint64) + np.uint64(1 << 40)
+        pos = (np.arange(4096, dtype=np.uint64) * np.uint64(n)) // np.uint64(4096)
+        k2[pos] = np.arange(1, 4097, dtype=np.uint64)
+        m = np.ones(n, np.uint64)
+        if extra:                                                                                # ... of about `extra` rows: the others are no rows
+            rest = np.setdiff1d(np.arange(n), pos.astype(np.int64))
+            m[rest[extra:]] = 0
+        segs.append((m, k2))
+    k0 = np.concatenate([np.full(len(a), 3 * i + 1, dtype=np.uint64) for i, (a, b) in enumerate(segs)])
+    k1 = np.concatenate([np.asarray(a, dtype=np.uint64) for a, b in segs])
+    k2 = np.concatenate([np.asarray(b, dtype=np.uint64) for a, b in segs])
+    got = eng.sort_rows(k0, k1, k2, algo=algo)
+    row = (k1 != 0) & (k2 != 0) & (k2 < np.uint64(0x7FF0000000000000))
+    exp = _host_sorted(k0[row], k1[row], k2[row])
+    nv = int(row.sum())
+    for g, e in zip(got, exp):
+        assert np.array_equal(g[:nv], e)
+        assert not g[nv:].any()
 
 
 @pytest.mark.gpu

@@ -15,7 +15,7 @@ meta = {}
 for fn in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
     with open(fn, newline="") as f:
         for row in csv.DictReader(f):
-            full = row["Kernel_Name"].split("(")[0]
+            full = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             k = full.replace("void ptx::", "").replace("ptx::", "").split("<")[0]
             if k == "scan_chained_kernel":      # one entry per instantiation, named like the library's timer labels (bench.py keys)
                 for tag in ("Row", "Pat", "TrioFirst", "FlagWord", "GroupCount", "HeadCount", "Sample", "Len"):
