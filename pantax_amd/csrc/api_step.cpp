@@ -91,7 +91,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     // a8 needs both
     if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     fork_guard.armed = false;   // joined: everything later on the main stream is ordered behind the index
-    PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true));
+    PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true, std::getenv("PANTAX_COV_COUNT") == nullptr));   // (PANTAX_COV_COUNT=1: popcount_kernel as in the stage call)
     mark();
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,

@@ -320,6 +320,7 @@ int pantax_hip_pao_solve_batch(pantax_hip_ctx *ctx, const pantax_hip_species_bat
     std::vector<uint32_t> cov32(V ? V : 1, 0);
     if (in->node_base_cov) for (uint64_t v = 0; v < V; ++v) cov32[v] = (uint32_t)in->node_base_cov[v];
     PTX_TRY(upload(ctx, db->d_cov, cov32.data(), V));
+    db->cov_count_pending = false;
     PTX_TRY(upload(ctx, lb.d_ab, in->node_abundance, V));
     std::vector<double> amax(S);
     std::vector<uint32_t> nvalid(S);

@@ -300,6 +300,7 @@ struct Db {
     bool trio_first_valid = false;  // d_trio_first holds the CSR offsets of the last build (trio_first_ensure derives them on request)
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
+    bool cov_count_pending = false;  // d_cov of the last coverage pass is still to be counted from the bitmap (node_stats_launch does it)
     bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
     DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the MIDDLE node of the window (global node index)
@@ -486,7 +487,8 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int species_ensure(Ctx *ctx, Reads *rd);   // d_species in file order (resident reads keep the species per slot)
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
-int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio);
+// defer_count: leave node_base_cov (popcount_kernel) to the node statistics pass that follows in the resident step (db->cov_count_pending)
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count = false);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
 int trio_first_ensure(Ctx *ctx, Db *db); // d_trio_first (the db images store it)

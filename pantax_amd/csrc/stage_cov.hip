@@ -988,7 +988,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     return 0;
 }
 
-int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio) {
+int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count) {
     if (!rd->grouped) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: these reads are a slice kept as plain columns (to be routed to their owner), not resident reads");
     if (!db->cov_prepared) PTX_TRY(coverage_prepare(ctx, db, rd, with_trio));
     db->cov_prepared = false;
@@ -1067,7 +1067,8 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         }
     }
     PTX_HIP(ctx, hipGetLastError());
-    if (db->V) {
+    db->cov_count_pending = defer_count && db->V != 0;   // the resident step: node_stats_launch counts the covered bases in its own pass
+    if (db->V && !defer_count) {
         KTimer t(ctx, "popcount_kernel");
         hipLaunchKernelGGL(popcount_kernel, dim3(grid_for(db->V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, db->V,
                            db->d_bit_off.p, db->d_full.p, db->d_bitmap.p, db->d_cov.p);

@@ -303,7 +303,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 // ---------------------------------------------------------------------------------------------
 constexpr int STAT_CHUNKS = 256;  // most workgroups per species; partials are combined in fixed order (deterministic)
 // chunks per species actually used: ~2048 workgroups in all (one species: 256 chunks; a hundred species: 20)
-static inline uint32_t stat_chunks(uint32_t S) { uint32_t c = 2048u / (S ? S : 1u); return c < 1u ? 1u : (c > (uint32_t)STAT_CHUNKS ? (uint32_t)STAT_CHUNKS : c); }
+static inline uint32_t stat_chunks(uint32_t S, uint32_t target = 2048u) { uint32_t c = target / (S ? S : 1u); return c < 1u ? 1u : (c > (uint32_t)STAT_CHUNKS ? (uint32_t)STAT_CHUNKS : c); }
 struct NodePartial { double mx, zs; unsigned long long nv, zc; };
 
 __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
@@ -333,6 +333,93 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
     zc = block_sum_u64<256>(zc, redu);
     if (threadIdx.x == 0) part[blockIdx.x] = {mx, zs, nv, zc};
 }
+// The same pass with the covered-base count of every node folded in (node_base_cov, profile.rs:844/874, :1018-1023 -- popcount_kernel's
+// work, stage_cov.hip): in the resident step nothing reads the counts between the coverage pass and this one, and the two passes share
+// the node lengths.  The bit offset of a node comes from a running prefix of the lengths inside the workgroup's range (one 8-byte load
+// per workgroup instead of 8V bytes of offsets); 24V + L/8 bytes instead of 32V + L/8 for the two kernels.
+__global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
+                                                             const unsigned long long *__restrict__ bases, const uint64_t *__restrict__ bit_off,
+                                                             const uint32_t *__restrict__ full, const uint32_t *__restrict__ bitmap, double min_depth,
+                                                             uint32_t *__restrict__ cov_out, double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
+    __shared__ double red[4];
+    __shared__ unsigned long long redu[4];
+    __shared__ uint32_t s_wsum[2][16];
+    const uint32_t s = blockIdx.x / nch, ch = blockIdx.x % nch;
+    const uint32_t b = node_base[s], e = node_base[s + 1];
+    const uint32_t per = (e - b + nch - 1) / nch;
+    uint32_t lo = b + ch * per, hi = lo + per;
+    if (hi > e) hi = e;
+    double mx = -INFINITY, zs = 0.0;
+    unsigned long long nv = 0, zc = 0;
+    constexpr int NR = 4;                                        // 256-node stretches per round: their loads are in flight together
+    uint64_t run = lo < hi ? bit_off[lo] : 0ull;                 // bit offset of the first node of the coming round
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int buf = 0;
+    for (uint32_t v0 = lo; v0 < hi; v0 += 256 * NR, buf ^= 1) {
+        uint32_t l[NR], fw[NR], incl[NR];
+        unsigned long long bs[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint32_t v = v0 + (uint32_t)r * 256u + threadIdx.x;
+            const bool in = v < hi;
+            l[r] = in ? node_len[v] : 0u;
+            bs[r] = in ? bases[v] : 0ull;
+            fw[r] = in ? full[v >> 5] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            incl[r] = wave_incl_scan_dpp(l[r]);                  // (a species' bases fit 32 bits: checked at upload)
+            if (lane == 63) s_wsum[buf][r * 4 + wave] = incl[r];
+        }
+        __syncthreads();
+        uint32_t before = 0;                                     // lengths of the round in front of this thread's stretch r, wave by wave
+        uint64_t g0[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t t = s_wsum[buf][r * 4 + w];
+                if (w == (int)wave) g0[r] = run + before + incl[r] - l[r];
+                before += t;
+            }
+        }
+        run += before;
+        uint32_t bw0[NR], bw1[NR];                               // first and last bitmap word of every node: independent loads, issued together
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool any = l[r] != 0u;                         // (l = 0 outside the range)
+            bw0[r] = any ? bitmap[g0[r] >> 5] : 0u;
+            bw1[r] = any ? bitmap[(g0[r] + l[r] - 1) >> 5] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint32_t v = v0 + (uint32_t)r * 256u + threadIdx.x;
+            if (v >= hi) continue;
+            uint32_t c = 0;
+            if (l[r]) {
+                const uint64_t g1 = g0[r] + l[r], w0 = g0[r] >> 5, w1 = (g1 - 1) >> 5;
+                const uint32_t m0 = 0xFFFFFFFFu << (g0[r] & 31), m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
+                c = w0 == w1 ? __popc(bw0[r] & m0 & m1) : __popc(bw0[r] & m0) + __popc(bw1[r] & m1);
+                for (uint64_t w = w0 + 1; w < w1; ++w) c += __popc(bitmap[w]);     // nodes of more than 33 bases
+            }
+            if ((fw[r] >> (v & 31u)) & 1u) c = l[r];             // a step covered the whole node: a flag instead of marked bits
+            cov_out[v] = c;
+            const double len = (double)l[r];
+            const double ab = (double)(long long)bs[r] / len;    // profile.rs:987-988
+            ab_out[v] = ab;
+            mx = fmax(mx, ab);
+            if (ab > 0.0) ++nv;
+            const double o = ab > min_depth ? ab : 0.0;          // :2941-2944
+            if (o > 0.0) { zs += o; ++zc; }
+        }
+    }
+    __syncthreads();
+    mx = block_max_f64<256>(mx, red);
+    zs = block_sum_f64<256>(zs, red);
+    nv = block_sum_u64<256>(nv, redu);
+    zc = block_sum_u64<256>(zc, redu);
+    if (threadIdx.x == 0) part[blockIdx.x] = {mx, zs, nv, zc};
+}
 // one wave per species: lane l combines chunks l, l+64, ... in order, then a fixed-shape wave reduction
 __global__ void __launch_bounds__(64) node_stats_final_kernel(uint32_t S, const NodePartial *__restrict__ part, double *__restrict__ amax_out,
                                                               uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
@@ -354,8 +441,14 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     PTX_HIP(ctx, lb->d_amax.alloc(S)); PTX_HIP(ctx, lb->d_nvalid.alloc(S));
     PTX_HIP(ctx, lb->d_nzsum.alloc(S)); PTX_HIP(ctx, lb->d_nzcnt.alloc(S));
     PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
-    KTimer t(ctx, "node_stats_kernel");
-    const uint32_t nch = stat_chunks(S);
+    const bool with_cov = db->cov_count_pending;                 // the resident step left the covered-base counts to this pass
+    KTimer t(ctx, with_cov ? "node_cov_stats_kernel" : "node_stats_kernel");
+    const uint32_t nch = with_cov ? stat_chunks(S, 8192u) : stat_chunks(S);   // (the fused kernel holds fewer workgroups per CU: shorter ones, so that the last round is short)
+    if (with_cov) {
+        hipLaunchKernelGGL(node_cov_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
+        const_cast<Db *>(db)->cov_count_pending = false;
+    } else
     hipLaunchKernelGGL(node_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p,
                        (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
     hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
@@ -475,9 +568,15 @@ __global__ void __launch_bounds__(256) node_haps_fill_kernel(const uint2 *__rest
 __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2 *__restrict__ tile_sp, const uint32_t *__restrict__ node_base,
                                                          const uint64_t *__restrict__ hap_off, const int32_t *__restrict__ sp_p,
                                                          const int32_t *__restrict__ hap_bit, const unsigned long long *__restrict__ node_haps,
-                                                         unsigned long long *__restrict__ mask) {
+                                                         unsigned long long *__restrict__ mask, const uint32_t *__restrict__ cov,
+                                                         const uint32_t *__restrict__ node_len, unsigned long long *__restrict__ ratio) {
     // one workgroup per 2048-node tile of d_emit_tile_sp (eight nodes per thread: the table below is set up once per 2048 nodes)
+    // ratio != null: the path_cov_ratio sums of ratio_kernel (profile.rs:1344-1361) for every species this kernel builds the masks of,
+    // taken while the mask is in a register -- ratio_kernel's 8V bytes of masks are not read a second time
     __shared__ int s_bit[64];     // haplotype -> LP column of the species the tile starts in (nearly always its only one)
+    __shared__ unsigned long long acc[2 * LAD_MAXP];
+    if (ratio && threadIdx.x < 2 * LAD_MAXP) acc[threadIdx.x] = 0;
+    unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t v0 = (uint64_t)blockIdx.x * 2048;
     const uint2 t = tile_sp[blockIdx.x];
     const uint32_t sp0 = t.x;
@@ -493,10 +592,23 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
         const uint64_t v = v0 + (uint64_t)r * 256 + threadIdx.x;
         if (v >= V) break;
         unsigned long long hm = node_haps[v];      // (zero for species of more than 64 haplotypes: the path walk fills those)
+        const unsigned long long c = ratio ? cov[v] : 0ull, l = ratio ? node_len[v] : 0ull;
         unsigned long long m = 0ull;
         if (v < end0) {
             if (p0 > 0 && p0 <= LAD_MAXP)
                 while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = s_bit[j]; if (bit >= 0) m |= 1ull << bit; }
+            if (ratio && m) {                      // the first eight candidates (nearly always all) in registers, like ratio_kernel
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < p0) { const bool on = (m >> k) & 1ull; c8[k] += on ? c : 0ull; l8[k] += on ? l : 0ull; }   // (block-uniform: the columns that exist)
+                unsigned long long rest = m >> 8;
+                while (rest) {
+                    const int k = __ffsll((long long)rest) - 1 + 8;
+                    rest &= rest - 1;
+                    if (c) atomicAdd(&acc[2 * k], c);
+                    atomicAdd(&acc[2 * k + 1], l);
+                }
+            }
         } else {                                    // a species border inside the tile: the few nodes behind it look their species up
             uint32_t sp = sp0 + 1;
             while (sp < t.y && node_base[sp + 1] <= v) ++sp;
@@ -504,10 +616,30 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
             if (p > 0 && p <= LAD_MAXP) {
                 const int32_t *hb = hap_bit + hap_off[sp];
                 while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = hb[j]; if (bit >= 0) m |= 1ull << bit; }
+                unsigned long long rest = ratio ? m : 0ull;
+                while (rest) {
+                    const int k = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    if (c) atomicAdd(&ratio[2 * (hap_off[sp] + k)], c);
+                    atomicAdd(&ratio[2 * (hap_off[sp] + k) + 1], l);
+                }
             }
         }
         mask[v] = m;      // coeff_matrix[(v,pos)] = 1.0 for every candidate path that visits v (profile.rs:1336-1340)
     }
+    if (!ratio || p0 <= 0 || p0 > LAD_MAXP) return;            // (block-uniform)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= p0) break;
+        const unsigned long long cs = wave_reduce(c8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+        const unsigned long long ls = wave_reduce(l8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+        if ((threadIdx.x & 63) == 0) {
+            if (cs) atomicAdd(&acc[2 * k], cs);
+            if (ls) atomicAdd(&acc[2 * k + 1], ls);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * p0 && acc[threadIdx.x]) atomicAdd(&ratio[2 * hap_off[sp0] + threadIdx.x], acc[threadIdx.x]);
 }
 
 // Wide species: the one-word "mask" of a node becomes a 64-bit hash of its mask words (0 stays 0), so that the row grouping
@@ -567,11 +699,13 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ cov, const unsigned long long *__restrict__ mask,
                                                     const int32_t *__restrict__ sp_p, const uint64_t *__restrict__ hap_off,
                                                     const uint32_t *__restrict__ wide_off, const uint32_t *__restrict__ wide_nw,
-                                                    const unsigned long long *__restrict__ maskw, unsigned long long *__restrict__ ratio) {
+                                                    const unsigned long long *__restrict__ maskw, unsigned long long *__restrict__ ratio,
+                                                    int by_node_done /* the species of at most 64 haplotypes got their sums from mask_nodes_kernel */) {
     __shared__ unsigned long long acc[LAD_WIDEP * 2];
     const uint32_t s = blockIdx.x / RATIO_CHUNKS, ch = blockIdx.x % RATIO_CHUNKS;
     const int p = sp_p[s];
     if (p <= 0) return;
+    if (by_node_done && hap_off[s + 1] - hap_off[s] <= 64) return;
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + RATIO_CHUNKS - 1) / RATIO_CHUNKS;
     uint32_t lo = b + ch * per, hi = lo + per;
@@ -905,23 +1039,27 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
         d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
     }
+    const bool by_node = use_node_haps(db);
+    // the path_cov_ratio sums ride on the by-node mask pass (PANTAX_RATIO=kernel: ratio_kernel for every species, as in round 3)
+    static const bool ratio_sep = std::getenv("PANTAX_RATIO") && std::getenv("PANTAX_RATIO")[0] == 'k';
+    const bool ratio_by_node = by_node && V && !ratio_sep;
     {
-        const bool by_node = use_node_haps(db);
         KTimer t(ctx, by_node ? "mask_nodes_kernel" : "mask_kernel");   // the names rocprofv3 shows
         if (by_node && V)
             hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 2047) / 2048)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
-                               lb->d_p.p, lb->d_hap_bit.p, (const unsigned long long *)db->d_node_haps.p, (unsigned long long *)lb->d_mask.p);
+                               lb->d_p.p, lb->d_hap_bit.p, (const unsigned long long *)db->d_node_haps.p, (unsigned long long *)lb->d_mask.p,
+                               ratio_by_node ? db->d_cov.p : (const uint32_t *)nullptr, db->d_node_len.p, ratio_by_node ? lb->d_ratio.p : (unsigned long long *)nullptr);
         if (db->n_tiles && (!by_node || db->nh_walk_too))
             hipLaunchKernelGGL(mask_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p,
                                db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p, lb->d_hap_bit.p, (unsigned long long *)lb->d_mask.p,
                                lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, lb->d_wide_nw.p, (unsigned long long *)lb->d_maskw.p,
                                by_node ? db->d_hap_off.p : (const uint64_t *)nullptr);
     }
-    {
+    if (!ratio_by_node || db->nh_walk_too) {   // what the mask pass did not sum: species of more than 64 haplotypes (their masks come from the path walk)
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_cov.p,
                            (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, lb->d_wide_nw.p,
-                           (const unsigned long long *)lb->d_maskw.p, lb->d_ratio.p);
+                           (const unsigned long long *)lb->d_maskw.p, lb->d_ratio.p, ratio_by_node ? 1 : 0);
     }
     if (wide)
         hipLaunchKernelGGL(mask_fold_kernel, dim3(lb->n_wide * WIDE_CHUNKS), dim3(256), 0, ctx->stream, lb->d_wide_list.p, lb->d_wide_off.p,
