@@ -104,6 +104,8 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         "coverage_step_kernel": cov,
         # a8 popcount: L/8 bitmap in + 8V cov out
         "popcount_kernel": L // 8 + 8 * V,
+        # the resident step (round 4): popcount folded into the node statistics pass -- lengths 4V + bases 8V in, counts 4V + abundances 8V out, bitmap L/8
+        "node_cov_stats_kernel": 24 * V + L // 8,
         # a7: SURVEY 8d's whole-index figure 2 x 12 x (P - 2H) + 12U split over the two halves of the build -- the pass that forms every
         # window's 12-byte key and decides count == 1 (the "write keys" half, plus the 4P of walk it reads, which 8d leaves out): the
         # visit-table kernel (round 4) or the node-block kernel; and the half that files the U unique rows ("read sorted" + 12U): the
@@ -116,10 +118,14 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         "trio_count_kernel": 4 * P + 4 * V,
         "trio_uniq_kernel": 16 * win,
         # a10: the membership masks by node (8V node -> haplotypes in, 8V masks out) / by walk (4P in + 8V out)
-        "mask_nodes_kernel": 16 * V,
+        "mask_nodes_kernel": 24 * V,      # ... + 8V of counts and lengths since the path_cov_ratio sums ride on this pass (round 4; 16V before)
         "mask_kernel": 4 * P + 8 * V,
         # a12's row compaction: abundance + mask of every node in (16V), the valid rows out (16 n)
         "scan_chained_kernel<Row>": 16 * V + 16 * n_lp_rows,
+        # a12's rows sorted straight from the node arrays (sample_sort_nodes.hip, round 4): the two partition passes read abundance + mask of
+        # every node (16V) and a 2-byte bucket id; the scatter writes every row once (16 n)
+        "ssn_hist_kernel": 18 * V,
+        "ssn_scatter_kernel": 18 * V + 16 * n_lp_rows,
         "sort_hist_kernel": 8 * n_lp_rows,
         "sort_scatter_kernel": 2 * 24 * n_lp_rows,
     }, dict(R=R, T=T, V=V, L=L, P=P, H=H)

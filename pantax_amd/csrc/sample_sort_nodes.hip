@@ -14,18 +14,21 @@
 //                                LDS histogram and stores it as a row of the segment's count matrix: no global atomics
 //   3. ssn_offsets / ssn_segscan: column sums of the matrix -> bucket starts, the matrix rewritten as every workgroup's first slot in
 //                                every bucket; rows per segment -> first output row of every segment, total row count
-//   4. ssn_scatter             : rows {mask, a} as 16-byte records into their bucket (slots from LDS counters seeded by the matrix row).
+//   4. ssn_scatter             : rows {mask, a} as 16-byte records into their bucket (slots from LDS counters seeded by the matrix row);
+//                                a row of a tie bucket goes straight to the output -- its slot is its final place.
 //                                One 16-byte store per row is what this pass costs (tools/native/scatter_probe.hip: 2e8 rows into 2048
 //                                buckets 4.2 ms, 1024: 3.5, 256: 2.9; the real rows, which tie massively, take 3.15 ms either way)
-//   5. ssn_local_wave          : a wave per bucket pair (2j, 2j+1): up to 512 rows sorted IN REGISTERS (eight per lane: a bitonic
+//   5. ssn_local_wave          : a wave per even bucket: up to 512 rows sorted IN REGISTERS (eight per lane: a bitonic
 //                                network whose cross-lane steps are ds_bpermute swaps and whose in-lane steps are plain selects -- no
-//                                LDS memory, no barriers), the tie bucket copied; written to the dense output of the segment
+//                                LDS memory, no barriers), written to the dense output of the segment
 //      ssn_local_wave2         : the buckets of 513 .. 1024 rows (a few per cent of them), sixteen rows per lane: a kernel of its own so
 //                                that its registers do not cost the first one its waves in flight (2.2 -> 3.1 ms when it was one)
 //      ssn_local               : the rare larger buckets through an LDS network (rank sort through memory above 4096)
 // The number of rows of a segment is only known on the device; launch geometry comes from the node counts.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "primitives.hpp"
 #include "wave.hpp"
 
@@ -117,10 +120,9 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int addr /* (partner 
 }
 template <bool TWO>
 __device__ __forceinline__ void cmp_swap(uint64_t &m0, uint64_t &a0, uint64_t &m1, uint64_t &a1, bool up) {
-    // up: afterwards key0 <= key1; otherwise key0 >= key1
+    // up: afterwards key0 <= key1; otherwise key0 >= key1.  ONE comparison: equal keys may swap, which changes nothing
     const bool lt10 = TWO ? less2(Key2{m1, a1}, Key2{m0, a0}) : (a1 < a0);
-    const bool lt01 = TWO ? less2(Key2{m0, a0}, Key2{m1, a1}) : (a0 < a1);
-    const bool sw = up ? lt10 : lt01;
+    const bool sw = up == lt10;
     const uint64_t ta = sw ? a1 : a0, tb = sw ? a0 : a1;
     a0 = ta; a1 = tb;
     if (TWO) { const uint64_t tm = sw ? m1 : m0, tn = sw ? m0 : m1; m0 = tm; m1 = tn; }
@@ -148,8 +150,7 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&m)[L], uint64_t (&a)[L
                 uint64_t om = 0;
                 if (TWO) om = lane_xor64(m[e], addr);
                 const bool o_lt = TWO ? less2(Key2{om, oa}, Key2{m[e], a[e]}) : (oa < a[e]);
-                const bool m_lt = TWO ? less2(Key2{m[e], a[e]}, Key2{om, oa}) : (a[e] < oa);
-                const bool take = keep_min ? o_lt : m_lt;
+                const bool take = keep_min == o_lt;               // (keeping the larger one: an equal key may be taken, which changes nothing)
                 a[e] = take ? oa : a[e];
                 if (TWO) m[e] = take ? om : m[e];
             }
@@ -347,6 +348,7 @@ __global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
     if (t0 >= t1) return;
     const uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_slot[i] = row[i];
+    const uint32_t out = sn.seg_out[s];
     __syncthreads();
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t base = t * SN_TILE + threadIdx.x;
@@ -363,13 +365,15 @@ __global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
         for (int r = 0; r < SN_ITEMS; ++r) {
             if (id[r] == SN_NO_ROW) continue;
             const uint32_t pos = atomicAdd(&s_slot[id[r]], 1u);
-            sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
+            // a row equal to a splitter is in its final place already (its bucket holds copies of one key): straight to the output --
+            // most rows are such rows (cfg4: 64 %; long reads, whose coverage values are small integers: nearly all)
+            if (id[r] & 1u) sn.put(s, out + pos, mv[r], (uint64_t)__double_as_longlong(av[r]));
+            else sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
         }
     }
 }
 
-// A wave per bucket pair (2j, 2j + 1): the even bucket sorted in registers (more than SN_WAVE_CAP rows: left on the segment's
-// list for ssn_local_kernel), the odd one -- rows equal to splitter j -- copied.
+// A wave per even bucket 2j, sorted in registers (more than SN_WAVE_CAP rows: left on the segment's list for the second kernel).
 __global__ void __launch_bounds__(256) ssn_local_wave_kernel(Sn sn) {
     const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
@@ -378,11 +382,7 @@ __global__ void __launch_bounds__(256) ssn_local_wave_kernel(Sn sn) {
     const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
     const uint32_t lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);   // grid.x * 4 = SN_NLEAF pairs
     const uint32_t out = sn.seg_out[s];
-    const uint32_t st = bucket_start[2 * j], st1 = bucket_start[2 * j + 1], st2 = bucket_start[2 * j + 2];
-    {   // the tie bucket (for the last j it is empty)
-        const uint32_t m = st2 - st1;
-        for (uint32_t i = lane; i < m; i += 64) { const ulonglong2 r = sn.rows[o + st1 + i]; sn.put(s, out + st1 + i, r.x, r.y); }
-    }
+    const uint32_t st = bucket_start[2 * j], st1 = bucket_start[2 * j + 1];   // (the tie bucket 2j + 1 went to the output in the scatter pass)
     const uint32_t m = st1 - st;
     if (m == 0) return;
     const ulonglong2 *src = sn.rows + o + st;
@@ -486,50 +486,56 @@ __global__ void __launch_bounds__(256) ssn_local_kernel(Sn sn) {
 // few bucket pairs at a change (and of the first and the last pair).  Heads are collected in order in the segment's part of the row
 // scratch, which the local kernels have finished with.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) ssn_heads_kernel(Sn sn, uint32_t *__restrict__ seg_k) {
-    const uint32_t s = blockIdx.x, o = sn.node_base[s], nn = sn.node_base[s + 1] - o, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) ssn_heads_kernel(Sn sn, uint32_t *__restrict__ sub_k) {
+    // wave w of a segment (four per workgroup): the bucket pairs [64 w, 64 w + 64), its heads from slot start[128 w] of the scratch on
+    // (a range holds no more heads than rows); sub_k[s][w] = how many
+    constexpr int NW = SN_NLEAF / 64;
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o, lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t n = nn ? sn.seg_n[s] : 0u;
-    if (n == 0) { if (lane == 0) seg_k[s] = 0; return; }
     const uint32_t *w = sn.w(s);
-    const uint32_t out = sn.seg_out[s];
-    ulonglong2 *heads = sn.rows + o;                      // {mask word as stored, first row of the run}
+    const uint32_t out = n ? sn.seg_out[s] : 0u;
+    const bool small = n != 0 && w[SN_OFF_FLAGS] != 0;
+    const uint32_t *start = w + SN_OFF_START;
     uint32_t cnt = 0;
-    auto scan_rows = [&](uint32_t r0, uint32_t r1) {      // rows [r0, r1) of the output, in order
-        for (uint32_t base = r0; base < r1; base += 64) {
-            const uint32_t i = base + lane;
-            const bool in = i < r1;
-            const uint64_t m = in ? sn.km[i] : 0ull, pm = (in && i > out) ? sn.km[i - 1] : 0ull;
-            const bool head = in && (i == out || m != pm);
-            const uint64_t bal = __ballot(head);
-            if (head) heads[cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_ulonglong2(m, (uint64_t)i);
-            cnt += (uint32_t)__popcll(bal);
-        }
-    };
-    if (w[SN_OFF_FLAGS] != 0) scan_rows(out, out + n);    // a small segment has no splitters
-    else {
-        const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
-        const uint32_t *start = w + SN_OFF_START;
-        for (uint32_t jb = 0; jb < (uint32_t)SN_NLEAF; jb += 64) {
-            const uint32_t j = jb + lane;
+    if (n != 0 && (!small || wave == 0)) {
+        ulonglong2 *heads = sn.rows + o + (small ? 0u : start[2 * 64 * wave]);   // {mask word as stored, first row of the run}
+        auto scan_rows = [&](uint32_t r0, uint32_t r1) {      // rows [r0, r1) of the output, in order
+            for (uint32_t base = r0; base < r1; base += 64) {
+                const uint32_t i = base + lane;
+                const bool in = i < r1;
+                const uint64_t m = in ? sn.km[i] : 0ull, pm = (in && i > out) ? sn.km[i - 1] : 0ull;
+                const bool head = in && (i == out || m != pm);
+                const uint64_t bal = __ballot(head);
+                if (head) heads[cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_ulonglong2(m, (uint64_t)i);
+                cnt += (uint32_t)__popcll(bal);
+            }
+        };
+        if (small) scan_rows(out, out + n);                   // a small segment has no splitters
+        else {
+            const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+            const uint32_t j = 64 * wave + lane;
             bool c = j == 0 || j == (uint32_t)SN_NLEAF - 1;
             if (!c) c = tree[tree_node(j)].x != tree[tree_node(j - 1)].x;
             uint64_t bal = __ballot(c);
             while (bal) {
-                const uint32_t jj = jb + (uint32_t)__builtin_ctzll(bal);
+                const uint32_t jj = 64 * wave + (uint32_t)__builtin_ctzll(bal);
                 bal &= bal - 1;
                 scan_rows(out + start[2 * jj], out + start[2 * jj + 2]);
             }
         }
     }
-    if (lane == 0) seg_k[s] = cnt;
+    if (lane == 0) sub_k[(size_t)s * NW + wave] = cnt;
 }
 // first pattern of every segment, the number of patterns, and the end of the last run
-__global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uint32_t *__restrict__ seg_k, uint32_t *__restrict__ sp_pat_off, uint32_t *__restrict__ d_K,
+__global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uint32_t *__restrict__ sub_k, uint32_t *__restrict__ sp_pat_off, uint32_t *__restrict__ d_K,
                                                            const uint32_t *__restrict__ d_n, uint32_t *__restrict__ pat_start) {
+    constexpr int NW = SN_NLEAF / 64;
     __shared__ uint32_t s_wave[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < S; base += 1024) {
-        const uint32_t i = base + threadIdx.x, v = i < S ? seg_k[i] : 0u;
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v = 0;
+        if (i < S) for (int q = 0; q < NW; ++q) v += sub_k[(size_t)i * NW + q];
         uint32_t tot;
         const uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
         if (i < S) sp_pat_off[i] = carry + ex;
@@ -537,15 +543,23 @@ __global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uin
     }
     if (threadIdx.x == 0) { sp_pat_off[S] = carry; *d_K = carry; pat_start[carry] = *d_n; }
 }
-__global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t *__restrict__ seg_k, const uint32_t *__restrict__ sp_pat_off, uint64_t *__restrict__ pat_mask,
+__global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t *__restrict__ sub_k, const uint32_t *__restrict__ sp_pat_off, uint64_t *__restrict__ pat_mask,
                                                           uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species) {
-    const uint32_t s = blockIdx.x, cnt = seg_k[s], k0 = sp_pat_off[s];
-    const ulonglong2 *heads = sn.rows + sn.node_base[s];
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const ulonglong2 h = heads[i];
-        pat_mask[k0 + i] = sn.pack_shift >= 0 ? (h.x & ((1ull << sn.pack_shift) - 1ull)) : h.x;
-        pat_start[k0 + i] = (uint32_t)h.y;
-        pat_species[k0 + i] = s;
+    constexpr int NW = SN_NLEAF / 64;
+    const uint32_t s = blockIdx.x, k0 = sp_pat_off[s];
+    const uint32_t *w = sn.w(s);
+    const bool small = w[SN_OFF_FLAGS] != 0;
+    uint32_t before = 0;
+    for (int q = 0; q < NW; before += sub_k[(size_t)s * NW + q], ++q) {
+        const uint32_t cnt = sub_k[(size_t)s * NW + q];
+        if (cnt == 0) continue;
+        const ulonglong2 *heads = sn.rows + sn.node_base[s] + (small ? 0u : w[SN_OFF_START + 2 * 64 * q]);
+        for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+            const ulonglong2 h = heads[i];
+            pat_mask[k0 + before + i] = sn.pack_shift >= 0 ? (h.x & ((1ull << sn.pack_shift) - 1ull)) : h.x;
+            pat_start[k0 + before + i] = (uint32_t)h.y;
+            pat_species[k0 + before + i] = s;
+        }
     }
 }
 
@@ -564,7 +578,7 @@ void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
     uint32_t G, per;
     sn_geometry(S, seg_bound, &G, &per);
-    return (size_t)S * SN_WS_WORDS + (size_t)S * G * SN_NBUCKET + (V + 1) / 2 + 3 * (size_t)S + 16;
+    return (size_t)S * SN_WS_WORDS + (size_t)S * G * SN_NBUCKET + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 16;
 }
 
 // Nodes of segment s: [node_base[s], node_base[s + 1]) (device array, the host knows that no segment exceeds seg_bound <= SS_MAX_N
@@ -586,8 +600,8 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
     uint32_t *tail = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
     sn.seg_n = tail; sn.seg_out = tail + S;                       // [S], [S + 1]
-    uint32_t *seg_k = tail + 2 * (size_t)S + 4;                   // [S] patterns of a segment
-    sn.ids = reinterpret_cast<uint16_t *>(tail + 3 * (size_t)S + 4);
+    uint32_t *sub_k = tail + 2 * (size_t)S + 4;                   // [S][SN_NLEAF / 64] patterns found by each wave of ssn_heads_kernel
+    sn.ids = reinterpret_cast<uint16_t *>(sub_k + (size_t)(SN_NLEAF / 64) * S);
     sn.rows = reinterpret_cast<ulonglong2 *>(rows16);
     sn.ksp = ksp; sn.km = km; sn.ka = ka; sn.pack_shift = pack_shift;
     { KTimer t(ctx, "ssn_sample_kernel");
@@ -606,12 +620,35 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
       hipLaunchKernelGGL(ssn_local_kernel, dim3(8, S), dim3(256), 0, ctx->stream, sn); }
     if (pat) {
         KTimer t(ctx, "ssn_heads_kernel");
-        hipLaunchKernelGGL(ssn_heads_kernel, dim3(S), dim3(64), 0, ctx->stream, sn, seg_k);
-        hipLaunchKernelGGL(ssn_patscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)seg_k, pat->sp_pat_off, pat->d_K, (const uint32_t *)d_n, pat->pat_start);
-        hipLaunchKernelGGL(ssn_patfill_kernel, dim3(S), dim3(256), 0, ctx->stream, sn, (const uint32_t *)seg_k, (const uint32_t *)pat->sp_pat_off, pat->pat_mask, pat->pat_start,
+        hipLaunchKernelGGL(ssn_heads_kernel, dim3(SN_NLEAF / 256, S), dim3(256), 0, ctx->stream, sn, sub_k);
+        hipLaunchKernelGGL(ssn_patscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)sub_k, pat->sp_pat_off, pat->d_K, (const uint32_t *)d_n, pat->pat_start);
+        hipLaunchKernelGGL(ssn_patfill_kernel, dim3(S), dim3(256), 0, ctx->stream, sn, (const uint32_t *)sub_k, (const uint32_t *)pat->sp_pat_off, pat->pat_mask, pat->pat_start,
                            pat->pat_species);
     }
     PTX_HIP(ctx, hipGetLastError());
+    if (std::getenv("PANTAX_SSN_DEBUG")) {   // measurements: bucket statistics of this sort on stderr (synchronises)
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> h((size_t)S * SN_WS_WORDS);
+        PTX_HIP(ctx, hipMemcpy(h.data(), d_ws, h.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t n_small = 0, rows = 0, n_med = 0, n_big = 0, n_over = 0, max_b = 0, max_rows = 0, n512 = 0, n256 = 0, nb = 0;
+        for (uint32_t sg = 0; sg < S; ++sg) {
+            const uint32_t *w = h.data() + (size_t)sg * SN_WS_WORDS;
+            rows += w[SN_OFF_FLAGS + 3]; max_rows = std::max<uint64_t>(max_rows, w[SN_OFF_FLAGS + 3]);
+            if (w[SN_OFF_FLAGS]) { ++n_small; continue; }
+            n_med += w[SN_OFF_FLAGS + 2]; n_big += w[SN_OFF_FLAGS + 1];
+            for (int b = 0; b < SN_NBUCKET; b += 2) {
+                const uint32_t m = w[SN_OFF_START + b + 1] - w[SN_OFF_START + b];
+                if (!m) continue;
+                ++nb; max_b = std::max<uint64_t>(max_b, m);
+                if (m > 256) ++n256;
+                if (m > 512) ++n512;
+                if (m > (uint32_t)SN_CAP) ++n_over;
+            }
+        }
+        std::fprintf(stderr, "[ssn] S=%u small=%llu rows=%llu max rows/segment=%llu | even buckets in use %llu, >256: %llu, >512: %llu (list %llu), >1024: %llu, >4096: %llu, largest %llu | G=%u per=%u\n", S,
+                     (unsigned long long)n_small, (unsigned long long)rows, (unsigned long long)max_rows, (unsigned long long)nb, (unsigned long long)n256, (unsigned long long)n512,
+                     (unsigned long long)n_med, (unsigned long long)n_big, (unsigned long long)n_over, (unsigned long long)max_b, sn.G, sn.per);
+    }
     return 0;
 }
 

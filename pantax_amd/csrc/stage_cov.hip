@@ -135,10 +135,27 @@ __device__ __forceinline__ void add_bases(unsigned long long *__restrict__ bases
     if (off < win_n && aln < (1u << 18)) atomicAdd(&S_WIN(off), aln);   // <= 8192 steps x 2^18 < 2^32
     else atomicAdd(&bases[v], (unsigned long long)aln);
 }
-__device__ __forceinline__ void mark_full(uint32_t *__restrict__ full, uint32_t wlo, uint32_t win_n, uint32_t v) {
+// The full-node flag of node v (v = NO_FULL: none) -- called by ALL 64 lanes of a wave.  Inside the LDS window: plain byte stores of the
+// same value (no atomic, nothing to lose).  Outside: the steps of a long walk are neighbouring nodes, so dozens of lanes would OR
+// into the SAME 32-bit word -- memory-side atomics on one address run one after the other (1.0 of the kernel's 2.6 ms at cfg5's share);
+// the lanes of one word combine their bits first (DPP reduction) and the first of them issues ONE atomic per distinct word.
+constexpr uint32_t NO_FULL = 0xFFFFFFFFu;
+__device__ __forceinline__ void mark_full_wave(uint32_t *__restrict__ full, uint32_t wlo, uint32_t win_n, uint32_t v) {
     const uint32_t off = v - wlo;
-    if (off < win_n) S_FULL(COV_WIN, off) = 1;     // plain byte stores of the same value: no atomic, nothing to lose
-    else atomicOr(&full[v >> 5], 1u << (v & 31));   // no test-before-set: the probe is a dependent round trip, the OR is fire-and-forget
+    const bool have = v != NO_FULL;
+    if (have && off < win_n) S_FULL(COV_WIN, off) = 1;
+    const bool out = have && off >= win_n;
+    unsigned long long todo = __ballot(out);
+    const uint32_t w = v >> 5, bit = 1u << (v & 31);
+    const int lane = threadIdx.x & 63;
+    while (todo) {                                 // (wave-uniform) one round per distinct word: two to four for a stretch of a walk
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, leader);
+        const bool mine = out && w == wl;
+        const uint32_t orv = wave_reduce(mine ? bit : 0u, [](uint32_t x, uint32_t y) { return x | y; });
+        if (lane == leader) atomicOr(&full[wl], orv);   // no test-before-set: the probe is a dependent round trip, the OR is fire-and-forget
+        todo &= ~__ballot(mine);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,12 +506,13 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             const uint64_t rel = bo - bit0;                           // the node inside the LDS bit window: 32-bit relative positions
             const bool in_win = rel < (uint64_t)bwn * 32 && nl <= (uint64_t)bwn * 32 - rel;   // (a node that starts below the window wraps to a huge rel)
             bool live = ok[u];
+            uint32_t mfull = NO_FULL;                                 // the node this step covers whole (its flag is set below, by the whole wave)
             const long long target = (long long)pe - (long long)ps;   // profile.rs:800
             if (live && k == 1) {                                     // :811
                 if (target >= 0) {                                    // :821-827
                     if (target && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], (uint32_t)target);
                     if (ps < pe && pe <= nl && !ABL(1u)) {            // :832
-                        if (ps == 0 && pe == nl) { if (!ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
+                        if (ps == 0 && pe == nl) { if (!ABL(8u)) mfull = v[u]; }
                         else if (ABL(16u)) {}
                         else if (in_win) mark_window(COV_WIN, (uint32_t)rel + ps, (uint32_t)rel + pe);
                         else mark_range(bitmap, COV_WIN, bw0, bwn, bo + ps, bo + pe);
@@ -530,7 +548,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 uint32_t hi = sidx + aln;
                 if (hi > nl) hi = nl;                                 // :871
                 if (ABL(1u)) {}
-                else if (sidx == 0 && hi == nl) { if (nl && !ABL(8u)) mark_full(full, wlo, win_n, v[u]); }
+                else if (sidx == 0 && hi == nl) { if (nl && !ABL(8u)) mfull = v[u]; }
                 else if (ABL(16u)) {}
                 else if (in_win) mark_window(COV_WIN, (uint32_t)rel + sidx, (uint32_t)rel + hi);
                 else mark_range(bitmap, COV_WIN, bw0, bwn, bo + sidx, bo + hi);
@@ -539,6 +557,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                     if (aln && !ABL(2u)) add_bases(bases, wlo, win_n, v[u], aln);     // :881
                 } else rl = (jf == 0) ? (len0[u] - ps) : nl;
             }
+            mark_full_wave(full, wlo, win_n, mfull);
             if (WITH_TRIO) {                                          // :890-907
                 uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(wave_shr1(rl));
                 if (live && i >= 2 && !ABL(4u)) {
