@@ -343,7 +343,6 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
                                                              uint32_t *__restrict__ cov_out, double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
-    __shared__ uint32_t s_wsum[2][16];
     const uint32_t s = blockIdx.x / nch, ch = blockIdx.x % nch;
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + nch - 1) / nch;
@@ -351,39 +350,31 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
     if (hi > e) hi = e;
     double mx = -INFINITY, zs = 0.0;
     unsigned long long nv = 0, zc = 0;
-    constexpr int NR = 4;                                        // 256-node stretches per round: their loads are in flight together
-    uint64_t run = lo < hi ? bit_off[lo] : 0ull;                 // bit offset of the first node of the coming round
+    // every WAVE walks its own quarter of the workgroup's range with its own running bit offset: no LDS, no barrier in the loop --
+    // the waves of a CU hide each other's two dependent loads (lengths -> bitmap words)
+    constexpr int NR = 4;                                        // 64-node stretches per round: their loads are in flight together
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int buf = 0;
-    for (uint32_t v0 = lo; v0 < hi; v0 += 256 * NR, buf ^= 1) {
-        uint32_t l[NR], fw[NR], incl[NR];
+    const uint32_t quarter = ((hi > lo ? hi - lo : 0u) + 3u) / 4u;
+    const uint32_t wlo = min(hi, lo + wave * quarter), whi = min(hi, wlo + quarter);
+    uint64_t run = wlo < whi ? bit_off[wlo] : 0ull;              // bit offset of the first node of the coming round
+    for (uint32_t v0 = wlo; v0 < whi; v0 += 64 * NR) {
+        uint32_t l[NR], fw[NR];
         unsigned long long bs[NR];
+        uint64_t g0[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const uint32_t v = v0 + (uint32_t)r * 256u + threadIdx.x;
-            const bool in = v < hi;
+            const uint32_t v = v0 + (uint32_t)r * 64u + lane;
+            const bool in = v < whi;
             l[r] = in ? node_len[v] : 0u;
             bs[r] = in ? bases[v] : 0ull;
             fw[r] = in ? full[v >> 5] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            incl[r] = wave_incl_scan_dpp(l[r]);                  // (a species' bases fit 32 bits: checked at upload)
-            if (lane == 63) s_wsum[buf][r * 4 + wave] = incl[r];
+            const uint32_t incl = wave_incl_scan_dpp(l[r]);      // (a species' bases fit 32 bits: checked at upload)
+            g0[r] = run + incl - l[r];
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        __syncthreads();
-        uint32_t before = 0;                                     // lengths of the round in front of this thread's stretch r, wave by wave
-        uint64_t g0[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t t = s_wsum[buf][r * 4 + w];
-                if (w == (int)wave) g0[r] = run + before + incl[r] - l[r];
-                before += t;
-            }
-        }
-        run += before;
         uint32_t bw0[NR], bw1[NR];                               // first and last bitmap word of every node: independent loads, issued together
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -393,8 +384,8 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const uint32_t v = v0 + (uint32_t)r * 256u + threadIdx.x;
-            if (v >= hi) continue;
+            const uint32_t v = v0 + (uint32_t)r * 64u + lane;
+            if (v >= whi) continue;
             uint32_t c = 0;
             if (l[r]) {
                 const uint64_t g1 = g0[r] + l[r], w0 = g0[r] >> 5, w1 = (g1 - 1) >> 5;
