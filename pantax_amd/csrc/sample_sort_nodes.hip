@@ -14,8 +14,9 @@
 //                                LDS histogram and stores it as a row of the segment's count matrix: no global atomics
 //   3. ssn_offsets / ssn_segscan: column sums of the matrix -> bucket starts, the matrix rewritten as every workgroup's first slot in
 //                                every bucket; rows per segment -> first output row of every segment, total row count
-//   4. ssn_scatter             : rows {mask, a} as 16-byte records into their bucket (slots from LDS counters seeded by the matrix row);
-//                                a row of a tie bucket goes straight to the output -- its slot is its final place.
+//   4. ssn_scatter / ssn_ties  : rows {mask, a} as 16-byte records into their bucket (slots from LDS counters seeded by the matrix row) -- the rows
+//                                of the EVEN buckets only: a tie bucket holds copies of one key, so it is written as a fill of the output
+//                                (coalesced) and its rows never travel.
 //                                One 16-byte store per row is what this pass costs (tools/native/scatter_probe.hip: 2e8 rows into 2048
 //                                buckets 4.2 ms, 1024: 3.5, 256: 2.9; the real rows, which tie massively, take 3.15 ms either way)
 //   5. ssn_local_wave          : a wave per even bucket: up to 512 rows sorted IN REGISTERS (eight per lane: a bitonic
@@ -348,7 +349,6 @@ __global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
     if (t0 >= t1) return;
     const uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_slot[i] = row[i];
-    const uint32_t out = sn.seg_out[s];
     __syncthreads();
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t base = t * SN_TILE + threadIdx.x;
@@ -364,12 +364,38 @@ __global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
             if (id[r] == SN_NO_ROW) continue;
+            // a row equal to a splitter does not travel at all: its bucket holds copies of ONE key, which ssn_ties_kernel writes as a
+            // plain fill -- most rows are such rows (cfg4: 64 %; long reads, whose coverage values are small integers: nearly all)
+            if (id[r] & 1u) continue;
             const uint32_t pos = atomicAdd(&s_slot[id[r]], 1u);
-            // a row equal to a splitter is in its final place already (its bucket holds copies of one key): straight to the output --
-            // most rows are such rows (cfg4: 64 %; long reads, whose coverage values are small integers: nearly all)
-            if (id[r] & 1u) sn.put(s, out + pos, mv[r], (uint64_t)__double_as_longlong(av[r]));
-            else sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
+            sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
         }
+    }
+}
+
+// The tie buckets (2j + 1: the rows equal to splitter j) as fills of the output: a workgroup takes SN_TIE_ROWS consecutive rows of its
+// segment's output and walks the buckets that overlap them (a few large buckets hold most of the rows: by rows, not by buckets)
+constexpr uint32_t SN_TIE_ROWS = 8192;
+__global__ void __launch_bounds__(256) ssn_ties_kernel(Sn sn) {
+    __shared__ uint32_t s_start[SN_NBUCKET + 1];
+    const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
+    const uint32_t *w = sn.w(s);
+    if (nn == 0 || w[SN_OFF_FLAGS] != 0) return;
+    const uint32_t n = w[SN_OFF_FLAGS + 3], r0 = blockIdx.x * SN_TIE_ROWS;
+    if (r0 >= n) return;
+    const uint32_t r1 = min(n, r0 + SN_TIE_ROWS);
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)SN_NBUCKET; i += 256) s_start[i] = w[SN_OFF_START + i];
+    __syncthreads();
+    uint32_t lo = 0, hi = SN_NBUCKET;                            // first bucket that ends behind r0
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid + 1] <= r0) lo = mid + 1; else hi = mid; }
+    const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+    const uint32_t out = sn.seg_out[s];
+    for (uint32_t q = lo; q < (uint32_t)SN_NBUCKET && s_start[q] < r1; ++q) {
+        if (!(q & 1u)) continue;
+        const uint32_t a = max(s_start[q], r0), e = min(s_start[q + 1], r1);
+        if (e <= a) continue;                                    // (workgroup-uniform; a non-empty odd bucket has j < SN_NSPLIT)
+        const ulonglong2 key = tree[tree_node(q >> 1)];
+        for (uint32_t i = a + threadIdx.x; i < e; i += 256) sn.put(s, out + i, key.x, key.y);
     }
 }
 
@@ -614,6 +640,8 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
       hipLaunchKernelGGL(ssn_segscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)sn.seg_n, sn.seg_out, d_n); }
     { KTimer t(ctx, "ssn_scatter_kernel");
       hipLaunchKernelGGL(ssn_scatter_kernel, dim3(sn.G, S), dim3(256), 0, ctx->stream, sn); }
+    { KTimer t(ctx, "ssn_ties_kernel");
+      hipLaunchKernelGGL(ssn_ties_kernel, dim3((uint32_t)((seg_bound + SN_TIE_ROWS - 1) / SN_TIE_ROWS), S), dim3(256), 0, ctx->stream, sn); }
     { KTimer t(ctx, "ssn_local_wave_kernel");
       hipLaunchKernelGGL(ssn_local_wave_kernel, dim3(SN_NLEAF / 4, S), dim3(256), 0, ctx->stream, sn);
       hipLaunchKernelGGL(ssn_local_wave2_kernel, dim3(8, S), dim3(256), 0, ctx->stream, sn);
