@@ -122,10 +122,10 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         "mask_kernel": 4 * P + 8 * V,
         # a12's row compaction: abundance + mask of every node in (16V), the valid rows out (16 n)
         "scan_chained_kernel<Row>": 16 * V + 16 * n_lp_rows,
-        # a12's rows sorted straight from the node arrays (sample_sort_nodes.hip, round 4): the two partition passes read abundance + mask of
-        # every node (16V) and a 2-byte bucket id; the scatter writes every row once (16 n)
-        "ssn_hist_kernel": 18 * V,
-        "ssn_scatter_kernel": 18 * V + 16 * n_lp_rows,
+        # a12's rows sorted straight from the node arrays (sample_sort_nodes.hip, round 4): the histogram pass reads abundance + mask of every
+        # node (16V; it also stages the rows that have to travel, a data-dependent third of them: not counted); the scatter and the tie
+        # fills write every row once between them (16 n)
+        "ssn_hist_kernel": 16 * V,
         "sort_hist_kernel": 8 * n_lp_rows,
         "sort_scatter_kernel": 2 * 24 * n_lp_rows,
     }, dict(R=R, T=T, V=V, L=L, P=P, H=H)

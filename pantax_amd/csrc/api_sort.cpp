@@ -54,7 +54,7 @@ extern "C" int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k
         DevBuf<uint32_t> d_base, wsb, dn;
         PTX_TRY(upload(ctx, dm, k1, n)); PTX_TRY(upload(ctx, da, k2, n));
         PTX_TRY(upload(ctx, d_base, base.data(), base.size()));
-        PTX_HIP(ctx, r16.alloc(2 * n)); PTX_HIP(ctx, osp.alloc(n)); PTX_HIP(ctx, om.alloc(n)); PTX_HIP(ctx, oa.alloc(n)); PTX_HIP(ctx, dn.alloc(1));
+        PTX_HIP(ctx, r16.alloc(4 * n)); PTX_HIP(ctx, osp.alloc(n)); PTX_HIP(ctx, om.alloc(n)); PTX_HIP(ctx, oa.alloc(n)); PTX_HIP(ctx, dn.alloc(1));
         PTX_HIP(ctx, wsb.alloc(sample_sort_nodes_ws_elems(S, bound, n)));
         PTX_TRY(sample_sort_nodes(ctx, reinterpret_cast<const double *>(da.p), dm.p, d_base.p, S, bound, n, r16.p, pack_shift >= 0 ? (uint64_t *)nullptr : osp.p, om.p, oa.p,
                                   pack_shift, wsb.p, dn.p));

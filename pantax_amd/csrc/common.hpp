@@ -344,7 +344,7 @@ struct Db {
     // LP-row staging (lad_prepare)
     DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort
     DevBuf<uint64_t> d_ka[3], d_kb[3];
-    DevBuf<uint64_t> d_row16;   // [2 V] the 16-byte bucket records of the node-order row sort (sample_sort_nodes.hip)
+    DevBuf<uint64_t> d_row16;   // [4 V] the 16-byte staged and bucketed records of the node-order row sort (sample_sort_nodes.hip)
 };
 
 struct Reads {

@@ -54,7 +54,7 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
 // The batched sort WITHOUT the compaction in front of it (sample_sort_nodes.hip): segment s = the nodes [node_base[s], node_base[s + 1])
 // (at most seg_bound <= SS_MAX_N of them), a node is a row when ab > 0 and mask != 0.  The rows of all segments end up back to back in
 // (ksp, km, ka) -- ksp null: species << pack_shift | mask in km -- every segment sorted by (mask, a); *d_n = their number.
-// rows16: 2 V words of scratch; d_ws: >= sample_sort_nodes_ws_elems(S, seg_bound, V) u32.
+// rows16: 4 V words of scratch; d_ws: >= sample_sort_nodes_ws_elems(S, seg_bound, V) u32.
 // pat (optional): the runs of equal mask inside every segment, in order -- pat_mask / pat_start (first row) / pat_species of run k,
 // sp_pat_off[s] = first run of segment s ([S + 1]), *d_K = their number, pat_start[K] = the row count.  Arrays of >= V (+ 1) entries.
 struct RowPatterns {

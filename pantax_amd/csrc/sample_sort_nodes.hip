@@ -71,9 +71,11 @@ struct Sn {
     const uint64_t *mask;        // [V] membership mask (0 = no row)
     uint32_t *ws;                // S x SN_WS_WORDS
     uint32_t *cntm;              // S x G x SN_NBUCKET: counts, then first slots
-    uint16_t *ids;               // [V] bucket id of every node, SN_NO_ROW for the others
+    uint16_t *ids;               // [V] bucket id of every staged row (same places as `stage`)
+    uint32_t *stage_cnt;         // [S x G] rows a partition workgroup staged
     uint32_t *seg_n, *seg_out;   // [S] rows of a segment, [S + 1] its first output row
-    ulonglong2 *rows;            // [V] scratch: the rows bucket by bucket, segment s from node_base[s]
+    ulonglong2 *stage;           // [V] scratch: the rows that have to travel (even buckets), compacted per partition workgroup from the node of its first tile on
+    ulonglong2 *rows;            // [V] scratch: those rows bucket by bucket, segment s from node_base[s]
     uint64_t *ksp, *km, *ka;     // output: {species, mask, a} (ksp null: species << pack_shift | mask in km)
     int pack_shift;
     uint32_t G, per;             // partition workgroups per segment, tiles each of them walks
@@ -248,9 +250,16 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     uint32_t t0, t1;
     sn_tiles(sn, n, g, t0, t1);
     const ulonglong2 *gt = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
+    __shared__ uint32_t s_nstage;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_hist[i] = 0;
+    if (threadIdx.x == 0) s_nstage = 0;
     if (t0 < t1) for (int i = threadIdx.x; i < SN_NLEAF; i += 256) tree[i] = gt[i];
     __syncthreads();
+    // The rows of the EVEN buckets are the only ones that travel (a tie bucket is written as a fill): they are staged here, compacted and
+    // with their bucket id, in the node range of this workgroup's tiles -- the scatter pass reads 18 bytes per such row instead of
+    // abundance, mask and an id of EVERY node again
+    const uint32_t stage0 = o + t0 * SN_TILE;
+    const int lane = threadIdx.x & 63;
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t base = t * SN_TILE + threadIdx.x;
         double av[SN_ITEMS];
@@ -263,26 +272,37 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
         }
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
-            const uint32_t i = base + (uint32_t)r * 256u;
-            if (i >= n) continue;
-            uint16_t id = SN_NO_ROW;
-            if (av[r] > 0.0 && mv[r] != 0ull) {
-                const Key2 key{mv[r], (uint64_t)__double_as_longlong(av[r])};
+            uint32_t id = SN_NO_ROW;
+            const uint64_t abits = (uint64_t)__double_as_longlong(av[r]);
+            if (av[r] > 0.0 && mv[r] != 0ull) {                  // (nodes behind the segment's end were loaded as zeros)
+                const Key2 key{mv[r], abits};
                 uint32_t k = 1;
 #pragma unroll
                 for (int l = 0; l < SN_LEVELS; ++l) { const ulonglong2 nd = tree[k]; k = 2u * k + (less2(Key2{nd.x, nd.y}, key) ? 1u : 0u); }
                 const uint32_t lo = k - (uint32_t)SN_NLEAF;   // splitters less than the key
                 uint32_t eq = 0;
                 if (lo < (uint32_t)SN_NSPLIT) { const ulonglong2 nd = tree[tree_node(lo)]; eq = eq2(Key2{nd.x, nd.y}, key) ? 1u : 0u; }
-                id = (uint16_t)(2u * lo + eq);
+                id = 2u * lo + eq;
                 atomicAdd(&s_hist[id], 1u);
             }
-            sn.ids[o + i] = id;
+            const bool travels = id != SN_NO_ROW && !(id & 1u);
+            const unsigned long long bal = __ballot(travels);
+            if (bal) {                                           // (wave-uniform)
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_nstage, (uint32_t)__popcll(bal));
+                wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                if (travels) {
+                    const uint32_t pos = stage0 + wbase + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    sn.stage[pos] = make_ulonglong2(mv[r], abits);
+                    sn.ids[pos] = (uint16_t)id;
+                }
+            }
         }
     }
     __syncthreads();
     uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) row[i] = s_hist[i];
+    if (threadIdx.x == 0) sn.stage_cnt[(size_t)s * sn.G + g] = s_nstage;
 }
 
 // bucket starts of a segment; the count matrix becomes the first slot of every workgroup in every bucket
@@ -347,28 +367,30 @@ __global__ void __launch_bounds__(256) ssn_scatter_kernel(Sn sn) {
     uint32_t t0, t1;
     sn_tiles(sn, n, g, t0, t1);
     if (t0 >= t1) return;
+    const uint32_t cnt = sn.stage_cnt[(size_t)s * sn.G + g];
+    if (cnt == 0) return;
     const uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_slot[i] = row[i];
     __syncthreads();
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t base = t * SN_TILE + threadIdx.x;
-        uint16_t id[SN_ITEMS];
-        double av[SN_ITEMS];
-        uint64_t mv[SN_ITEMS];
+    // the staged rows of this workgroup (ssn_hist_kernel): the even buckets' rows only -- a row equal to a splitter does not travel at
+    // all, its bucket holds copies of ONE key and ssn_ties_kernel writes it as a plain fill (cfg4: 64 % of the rows; long reads, whose
+    // coverage values are small integers: nearly all)
+    const ulonglong2 *st = sn.stage + o + t0 * SN_TILE;
+    const uint16_t *sid = sn.ids + o + t0 * SN_TILE;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 256 * SN_ITEMS) {
+        ulonglong2 rec[SN_ITEMS];
+        uint32_t id[SN_ITEMS];
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
-            const uint32_t i = base + (uint32_t)r * 256u;
-            id[r] = SN_NO_ROW; av[r] = 0.0; mv[r] = 0;
-            if (i < n) { id[r] = sn.ids[o + i]; av[r] = sn.ab[o + i]; mv[r] = sn.mask[o + i]; }
+            const uint32_t k = k0 + (uint32_t)r * 256u + threadIdx.x;
+            id[r] = SN_NO_ROW; rec[r] = make_ulonglong2(0ull, 0ull);
+            if (k < cnt) { id[r] = sid[k]; rec[r] = st[k]; }
         }
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
             if (id[r] == SN_NO_ROW) continue;
-            // a row equal to a splitter does not travel at all: its bucket holds copies of ONE key, which ssn_ties_kernel writes as a
-            // plain fill -- most rows are such rows (cfg4: 64 %; long reads, whose coverage values are small integers: nearly all)
-            if (id[r] & 1u) continue;
             const uint32_t pos = atomicAdd(&s_slot[id[r]], 1u);
-            sn.rows[o + pos] = make_ulonglong2(mv[r], (uint64_t)__double_as_longlong(av[r]));
+            sn.rows[o + pos] = rec[r];
         }
     }
 }
@@ -604,12 +626,12 @@ void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
     uint32_t G, per;
     sn_geometry(S, seg_bound, &G, &per);
-    return (size_t)S * SN_WS_WORDS + (size_t)S * G * SN_NBUCKET + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 16;
+    return (size_t)S * SN_WS_WORDS + (size_t)S * G * (SN_NBUCKET + 1) + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 16;
 }
 
 // Nodes of segment s: [node_base[s], node_base[s + 1]) (device array, the host knows that no segment exceeds seg_bound <= SS_MAX_N
 // nodes); a node is a row when ab > 0 and mask != 0.  Output: the rows of all segments back to back, every segment sorted by
-// (mask, a), in (ksp, km, ka) -- ksp null: species << pack_shift | mask in km; *d_n = the number of rows.  rows16: 2 V words of scratch.
+// (mask, a), in (ksp, km, ka) -- ksp null: species << pack_shift | mask in km; *d_n = the number of rows.  rows16: 4 V words of scratch.
 int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
                       uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat) {
     if (S == 0 || V == 0) {
@@ -624,11 +646,13 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     sn.node_base = d_node_base; sn.ab = ab; sn.mask = mask; sn.ws = d_ws;
     sn_geometry(S, seg_bound, &sn.G, &sn.per);
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
-    uint32_t *tail = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
+    sn.stage_cnt = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
+    uint32_t *tail = sn.stage_cnt + (size_t)S * sn.G;
     sn.seg_n = tail; sn.seg_out = tail + S;                       // [S], [S + 1]
     uint32_t *sub_k = tail + 2 * (size_t)S + 4;                   // [S][SN_NLEAF / 64] patterns found by each wave of ssn_heads_kernel
     sn.ids = reinterpret_cast<uint16_t *>(sub_k + (size_t)(SN_NLEAF / 64) * S);
     sn.rows = reinterpret_cast<ulonglong2 *>(rows16);
+    sn.stage = reinterpret_cast<ulonglong2 *>(rows16) + V;
     sn.ksp = ksp; sn.km = km; sn.ka = ka; sn.pack_shift = pack_shift;
     { KTimer t(ctx, "ssn_sample_kernel");
       hipLaunchKernelGGL(ssn_gather_kernel, dim3(SN_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sn);

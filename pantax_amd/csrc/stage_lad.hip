@@ -1099,7 +1099,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     PTX_HIP(ctx, lb->d_sp_pat_off.alloc(S + 1));
     if (use_nodes) {   // no compaction: the sort's passes read the node arrays and skip the nodes that are no rows; the patterns come from its splitters
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_nodes_ws_elems(S, max_vs, V)));
-        PTX_HIP(ctx, dbm->d_row16.alloc(2 * V));
+        PTX_HIP(ctx, dbm->d_row16.alloc(4 * V));
         const RowPatterns pat{lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, lb->d_sp_pat_off.p, d_K};
         PTX_TRY(sample_sort_nodes(ctx, lb->d_ab.p, lb->d_mask.p, db->d_node_base.p, S, max_vs, V, dbm->d_row16.p, pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p,
                                   pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat));
