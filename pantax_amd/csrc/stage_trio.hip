@@ -331,7 +331,7 @@ template <int U, bool ROWS>
 __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                          const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
                                                          uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, uint32_t ablate,
-                                                         unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec) {
+                                                         unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec, uint32_t xcd_chunks) {
     // The flag bits of the unique windows are combined per 32-position word in an LDS table before they go to memory: the windows
     // around a private allele flag neighbouring positions of ONE walk, and a device-scope atomic is a trip to the memory side
     // (1.8e8 of them cost 2.3 of the kernel's 7.2 ms at 1e4 strains).  {word index, bits}, open addressing, four probes; a word that
@@ -341,7 +341,11 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t g0 = (blockIdx.x * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
+    // xcd_chunks != 0 (= the number of workgroups' worth of groups): workgroups go to the XCDs round-robin, so XCD x is given the x-th
+    // contiguous eighth of the table -- neighbouring chunks flag neighbouring words of the same walks, and meet in ONE L2
+    uint32_t blk = blockIdx.x;
+    if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) blk = 0xFFFFFFu; }
+    uint32_t g0 = blk == 0xFFFFFFu ? NG : (blk * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
     for (uint32_t r = 0; r < rounds && g0 < NG; ++r, g0 += U) {
         uint32_t q[U], nb[U];
         uint64_t heads[U];
@@ -779,10 +783,12 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
                                                         const uint32_t *__restrict__ node_len, uint32_t H, const uint64_t *__restrict__ path_off,
                                                         const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec,
                                                         uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
-                                                        uint32_t *__restrict__ len_out, uint32_t *__restrict__ err) {
+                                                        uint32_t *__restrict__ len_out, uint32_t *__restrict__ err, uint32_t xcd_chunks) {
     static_assert(VIS_REC == 8, "eight lanes per group");
     const int lane = threadIdx.x & 63;
-    const uint32_t g = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + ((uint32_t)lane >> 3), r = (uint32_t)lane & 7u;
+    uint32_t blk = blockIdx.x;          // xcd_chunks != 0: every XCD files one contiguous eighth of the groups (see trio_visit_kernel)
+    if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) return; }
+    const uint32_t g = (blk * 4u + (threadIdx.x >> 6)) * 8u + ((uint32_t)lane >> 3), r = (uint32_t)lane & 7u;
     uint32_t cnt = 0;
     if (g < NG) cnt = (uint32_t)__popcll(vis_uq[g]);
     const bool on = cnt <= (uint32_t)VIS_REC && r < cnt;                     // an overflowing group is taken whole, below
@@ -1013,6 +1019,9 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
+    // PANTAX_TRIO_XCD: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
+    uint32_t trio_xcd = 3;
+    if (const char *ev = std::getenv("PANTAX_TRIO_XCD")) trio_xcd = (uint32_t)std::atoi(ev);
     if (P && by_block && db->n_vgroups) {
         KTimer t(ctx, "trio_visit_kernel");
         // every wave walks U x rounds consecutive groups of 64 visits (PANTAX_TV_U / PANTAX_TV_ROUNDS pick another shape, for
@@ -1022,12 +1031,14 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (const char *ev = std::getenv("PANTAX_TV_ROUNDS")) rounds = (uint32_t)std::max(1, std::atoi(ev));
         uint32_t tv_ablate = 0;
         if (const char *ev = std::getenv("PANTAX_TV_ABLATE")) tv_ablate = (uint32_t)std::atoi(ev);   // -DTV_ABLATE builds only
-#define TV_LAUNCH(UU, RR) hipLaunchKernelGGL((trio_visit_kernel<UU, RR>), dim3((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds)), dim3(256), 0, ctx->stream, db->n_vgroups, \
+#define TV_CHUNKS(UU) ((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds))
+#define TV_LAUNCH(UU, RR) hipLaunchKernelGGL((trio_visit_kernel<UU, RR>), dim3((trio_xcd & 1u) ? ((TV_CHUNKS(UU) + 7u) / 8u) * 8u : TV_CHUNKS(UU)), dim3(256), 0, ctx->stream, db->n_vgroups, \
                                          rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, tv_ablate,  \
-                                         reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p)
+                                         reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p, (trio_xcd & 1u) ? TV_CHUNKS(UU) : 0u)
         if (rows_by_visit) { if (U == 2) TV_LAUNCH(2, true); else if (U == 8) TV_LAUNCH(8, true); else TV_LAUNCH(4, true); }
         else if (U == 1) TV_LAUNCH(1, false); else if (U == 2) TV_LAUNCH(2, false); else if (U == 8) TV_LAUNCH(8, false); else TV_LAUNCH(4, false);
 #undef TV_LAUNCH
+#undef TV_CHUNKS
     }
     if (P && by_block && db->n_blocks) {
         KTimer t(ctx, "trio_block_kernel");
@@ -1090,8 +1101,9 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                 const uint32_t NG = db->n_vgroups;
 #define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_pos.p, db->d_path_nodes.p, \
                   ts.word_rank.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
-                  db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2
-                const dim3 rgrid((NG + 31) / 32);
+                  db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2, (trio_xcd & 2u) ? rchunks : 0u
+                const uint32_t rchunks = (NG + 31) / 32;
+                const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);
                 if (with_keys) hipLaunchKernelGGL(trio_rows_kernel<true>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
                 else hipLaunchKernelGGL(trio_rows_kernel<false>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
 #undef ROWS_ARGS
