@@ -61,6 +61,7 @@ struct RowPatterns {
     uint64_t *pat_mask;
     uint32_t *pat_start, *pat_species, *sp_pat_off, *d_K;
 };
+constexpr uint64_t SSN_MAX_SEG = 1ull << 26;   // nodes of one segment (buckets grow with the segment: beyond 4096 rows they are sorted through memory)
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V);
 int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
                       uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat = nullptr);

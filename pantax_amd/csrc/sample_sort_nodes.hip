@@ -24,7 +24,8 @@
 //                                LDS memory, no barriers), written to the dense output of the segment
 //      ssn_local_wave2         : the buckets of 513 .. 1024 rows (a few per cent of them), sixteen rows per lane: a kernel of its own so
 //                                that its registers do not cost the first one its waves in flight (2.2 -> 3.1 ms when it was one)
-//      ssn_local               : the rare larger buckets through an LDS network (rank sort through memory above 4096)
+//      ssn_local               : the rare larger buckets through an LDS network; above 4096 rows (every bucket of a species of millions of
+//                                nodes) the network runs in place through memory, a workgroup per bucket
 // The number of rows of a segment is only known on the device; launch geometry comes from the node counts.
 #include <algorithm>
 #include <cstdio>
@@ -522,18 +523,34 @@ __global__ void __launch_bounds__(256) ssn_local_kernel(Sn sn) {
             for (uint32_t i = threadIdx.x; i < m; i += 256) sn.put(s, dst + i, km[i], ka[i]);
             continue;
         }
-        // oversized bucket (practically never): rank every row against the whole bucket through memory
-        for (uint32_t i = threadIdx.x; i < m; i += 256) {
-            const ulonglong2 r = src[i];
-            const Key2 key{r.x, r.y};
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < m; ++q) {
-                const ulonglong2 t = src[q];
-                const Key2 ot{t.x, t.y};
-                if (less2(ot, key) || (eq2(ot, key) && q < i)) ++rank;
+        // A bucket of more than SN_CAP rows (an unrepresentative sample; every bucket of a segment of millions of rows): the network runs
+        // IN PLACE in the scratch, through memory, by this one workgroup -- O(m log^2 m) where the rank sort it replaces was O(m^2).  The
+        // variant whose merges start with a MIRROR step compares upwards only, so the places behind m act as +inf pads without existing.
+        ulonglong2 *buf = sn.rows + o + st;
+        uint32_t N = 2;
+        while (N < m) N <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t l) {             // i < l < m: the smaller key to i
+            const ulonglong2 x = buf[i], y = buf[l];
+            if (less2(Key2{y.x, y.y}, Key2{x.x, x.y})) { buf[i] = y; buf[l] = x; }
+        };
+        for (uint32_t k = 2; k <= N; k <<= 1) {
+            const uint32_t hk = k >> 1;
+            for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
+                const uint32_t blk = t / hk, off = t - blk * hk, i = blk * k + off, l = blk * k + (k - 1u - off);
+                if (l < m) exchange(i, l);
             }
-            sn.put(s, dst + rank, key.m, key.a);
+            __threadfence_block();
+            __syncthreads();
+            for (uint32_t j = hk >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < N / 2; t += 256) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                    if (l < m) exchange(i, l);
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
         }
+        for (uint32_t i = threadIdx.x; i < m; i += 256) { const ulonglong2 r = buf[i]; sn.put(s, dst + i, r.x, r.y); }
     }
 }
 
@@ -650,7 +667,7 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
                    PTX_HIP(ctx, hipMemsetAsync(pat->pat_start, 0, sizeof(uint32_t), ctx->stream)); }
         return 0;
     }
-    if (seg_bound > SS_MAX_N) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: a segment of %llu nodes exceeds %llu", (unsigned long long)seg_bound, (unsigned long long)SS_MAX_N);
+    if (seg_bound > SSN_MAX_SEG) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: a segment of %llu nodes exceeds %llu", (unsigned long long)seg_bound, (unsigned long long)SSN_MAX_SEG);
     if (S > 65535) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: %u segments exceed the launch grid", S);
     Sn sn;
     sn.node_base = d_node_base; sn.ab = ab; sn.mask = mask; sn.ws = d_ws;

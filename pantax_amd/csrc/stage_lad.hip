@@ -1019,11 +1019,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     uint64_t max_vs = 0;
     for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
     bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
-    bool use_nodes = use_seg;   // ... straight from the node arrays (sample_sort_nodes.hip), without the compaction pass in front
+    // ... straight from the node arrays (sample_sort_nodes.hip), without the compaction pass in front -- and without the limit on a species' size
+    // (a graph of millions of nodes used to send the WHOLE batch through the radix sort)
+    bool use_nodes = V > SS_MAX_N && max_vs <= SSN_MAX_SEG && S <= 65535;
+    if (use_nodes) use_seg = true;
     if (const char *ev = std::getenv("PANTAX_ROW_SORT")) {   // measurements / tests: "radix"; "seg" / "nodes" = one of the batched sorts wherever it can run
         if (ev[0] == 'r') use_seg = use_nodes = false;
         if (ev[0] == 's') { use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0; use_nodes = false; }
-        if (ev[0] == 'n') use_seg = use_nodes = max_vs <= SS_MAX_N && S <= 65535 && V > 0;
+        if (ev[0] == 'n') use_seg = use_nodes = max_vs <= SSN_MAX_SEG && S <= 65535 && V > 0;
     }
     uint32_t *d_seg_cnt = nullptr, *d_seg_off = nullptr;
     if (use_seg && !use_nodes) {

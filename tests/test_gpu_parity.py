@@ -806,6 +806,25 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, monkeypatch):
+    """No limit on a species' size in the many-species row sort (round 4: a graph of more than 600 000 nodes used to send the whole
+    batch through the radix sort): two species of 1.75e6 nodes each -- buckets of more than a thousand rows, the second wave kernel and the LDS
+    network in use -- give the same step output, objectives, row and pattern counts as the radix pipeline."""
+    from pantax_amd import synth
+    sset = synth.NativeSet(20260777, 2, 4, 600_000, 28_000_000, present_frac=0.75, threads=8).make()
+    assert min(len(g.node_len) for g in sset.species) > 600_000
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    outs = []
+    for sort in (None, "radix"):
+        monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
+        out = eng.profile_step(sset.avg_len())
+        outs.append((out[0].copy(), bytes(out[2]), [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in out[3]]))
+    assert any(o[5] > 100_000 for o in outs[0][2])
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and str(outs[0][2]) == str(outs[1][2])
+
+
+@pytest.mark.gpu
 def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
     """A step's rebuild of the unique-trio index leaves out the row-order export copies (key, owner haplotype); trio_get
     after a step rebuilds with them: same tables as the stage call gave before the step, the coverage results of the step
@@ -1039,8 +1058,10 @@ def test_node_order_sample_sort_against_host_sort(eng, algo):
     with an empty mask or without a positive abundance is no row and drops out -- and leaves the rows of all segments back to back.
     Segments of every size class side by side: empty of rows, 1 row, <= 4096 nodes (sorted by the sample kernel), tens of
     thousands, massive ties (single-key buckets), presorted / reversed, one mask (only the abundance moves through the register
-    network) and many, and unrepresentative samples whose one bucket exceeds the wave (512), the workgroup (1024) and the LDS
-    (4096) capacities.  algo 5: the segment number packed into the mask word, as the step does when the bits fit."""
+    network) and many, a segment of three million nodes (no limit on a species' size: its buckets hold thousands of rows), and
+    unrepresentative samples whose one bucket exceeds the wave (512), the second wave kernel (1024) and the LDS (4096) capacities --
+    the last kind sorted in place through memory.  algo 5: the segment number packed into the mask word, as the step does when the
+    bits fit."""
     rng = np.random.default_rng(11)
     segs = []
     for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 5000, 70000):
@@ -1054,7 +1075,8 @@ def test_node_order_sample_sort_against_host_sort(eng, algo):
     a = rng.integers(1, 2 ** 62, n).astype(np.uint64)
     a[rng.random(n) < 0.5] |= np.uint64(1 << 63)                                                  # negative doubles: no rows
     segs.append((rng.integers(1, 200, n), a))
-    for n, extra in ((8192, 0), (20000, 0), (6000, 700), (9000, 2500)):
+    segs.append((rng.integers(1, 4, 3000000), rng.integers(1, 2 ** 62, 3000000)))                # millions of nodes: buckets of thousands of rows, many above 4096
+    for n, extra in ((8192, 0), (20000, 0), (60000, 0), (6000, 700), (9000, 2500)):
         # nodes 0, n/4096, 2n/4096, ... are the sample: small keys there, large distinct keys elsewhere -> one bucket holds the rest
         k2 = rng.permutation(n).astype(np.uint64) + np.uint64(1 << 40)
         pos = (np.arange(4096, dtype=np.uint64) * np.uint64(n)) // np.uint64(4096)
