@@ -707,6 +707,45 @@ __device__ __forceinline__ uint32_t flag_rank(const uint2 *__restrict__ word_ran
     const uint2 w = word_rank[q >> 5];
     return w.x + (uint32_t)__popc(w.y & ((1u << (uint32_t)(q & 31ull)) - 1u));
 }
+// The same ranks in three plain launches (tile sums, a scan of the sums by one workgroup, tile ranks): a chained scan's workgroups spin on
+// their predecessors, and beside the main stream's kernels of the step in flight that spinning stretched this one from 0.34 to 2.5 ms
+// (and held the slots it spun in) -- the rebuild of the NEXT step runs beside the current step's row sort and LPs
+constexpr int FR_WORDS = 16, FR_TILE = 256 * FR_WORDS;           // flag words per thread and per workgroup
+__global__ void __launch_bounds__(256) flag_tile_sum_kernel(const uint32_t *__restrict__ bits, uint64_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t base = (uint64_t)blockIdx.x * FR_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x; if (i < n) c += (uint32_t)__popc(bits[i]); }
+    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(1024) flag_tile_scan_kernel(uint32_t *__restrict__ sums, uint32_t n_tiles, uint32_t *__restrict__ total) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t i = base + threadIdx.x, v = i < n_tiles ? sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<1024>(v, s_wave, &tot);
+        if (i < n_tiles) sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ void __launch_bounds__(256) flag_tile_rank_kernel(const uint32_t *__restrict__ bits, uint64_t n, const uint32_t *__restrict__ sums, uint2 *__restrict__ out) {
+    __shared__ uint32_t s_wave[4];
+    const uint64_t base = (uint64_t)blockIdx.x * FR_TILE + (uint64_t)threadIdx.x * FR_WORDS;   // FR_WORDS consecutive words per thread (64 bytes in, 128 out)
+    uint32_t w[FR_WORDS], c = 0;
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { w[k] = base + k < n ? bits[base + k] : 0u; c += (uint32_t)__popc(w[k]); }
+    uint32_t tot;
+    uint32_t run = sums[blockIdx.x] + block_excl_scan<256>(c, s_wave, &tot);
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { if (base + k < n) out[base + k] = make_uint2(run, w[k]); run += (uint32_t)__popc(w[k]); }
+}
+
 // one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
 // length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
 template <bool KEYS>
@@ -1083,7 +1122,17 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (rows_by_visit) {
             // rows in (species, hap, position) order = ranks of the flag bits: prefix of every flag word (total = U); slots in visit order =
             // prefix of the groups' counts
-            PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, FlagRankStore{ts.word_rank.p, ts.uniq_q.p}, zbits, ts.d_tot.p + 1, "scan_chained_kernel<FlagWord>"));
+            static const bool chained_ranks = std::getenv("PANTAX_FLAG_RANK") && std::getenv("PANTAX_FLAG_RANK")[0] == 'c';   // measurements: the chained scan
+            if (chained_ranks)
+                PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, FlagRankStore{ts.word_rank.p, ts.uniq_q.p}, zbits, ts.d_tot.p + 1, "scan_chained_kernel<FlagWord>"));
+            else {
+                KTimer t(ctx, "flag_tile_rank_kernel");
+                const uint32_t n_tiles = (uint32_t)((zbits + FR_TILE - 1) / FR_TILE);
+                PTX_HIP(ctx, ts.flag_sums.alloc(n_tiles + 1));
+                hipLaunchKernelGGL(flag_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const uint32_t *)ts.uniq_q.p, zbits, ts.flag_sums.p);
+                hipLaunchKernelGGL(flag_tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.flag_sums.p, n_tiles, ts.d_tot.p + 1);
+                hipLaunchKernelGGL(flag_tile_rank_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const uint32_t *)ts.uniq_q.p, zbits, (const uint32_t *)ts.flag_sums.p, ts.word_rank.p);
+            }
             PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
                                       (uint64_t)db->n_vgroups + 1, nullptr, "scan_chained_kernel<GroupCount>"));
             if (!db->trio_sizes_known) {
