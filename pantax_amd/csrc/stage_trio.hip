@@ -812,9 +812,12 @@ __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsi
     }
     if (first) trio_head_store(node_rec, rec.w, base + r, (uint32_t)__popcll(span), filt, err);
 }
-// EIGHT groups per wave, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
-// one coalesced kilobyte per wave; the slot of record r of group g is the scan of the groups' counts + r
-template <bool KEYS>
+// EIGHT groups per batch, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
+// one coalesced kilobyte per batch; the slot of record r of group g is the scan of the groups' counts + r.  A wave takes U batches at
+// once, level by level -- counts, records, then the gathers every record depends on (its flag word's rank, three node lengths, the node
+// record its head goes into) -- so that U x the loads are in flight per wave: the kernel waits for memory 88 % of its wave cycles at 20
+// registers (`r04_pmc_cfg4.json`), not for a lack of waves.  (The launch takes U = 1: see there.)
+template <bool KEYS, int U>
 __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
                                                         const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase,
                                                         const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ path_nodes,
@@ -827,39 +830,89 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     const int lane = threadIdx.x & 63;
     uint32_t blk = blockIdx.x;          // xcd_chunks != 0: every XCD files one contiguous eighth of the groups (see trio_visit_kernel)
     if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) return; }
-    const uint32_t g = (blk * 4u + (threadIdx.x >> 6)) * 8u + ((uint32_t)lane >> 3), r = (uint32_t)lane & 7u;
-    uint32_t cnt = 0;
-    if (g < NG) cnt = (uint32_t)__popcll(vis_uq[g]);
-    const bool on = cnt <= (uint32_t)VIS_REC && r < cnt;                     // an overflowing group is taken whole, below
-    uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
-    uint32_t slot = 0;
-    if (on) { rec = vis_rec[(uint64_t)g * VIS_REC + r]; slot = gprefix[g] + r; }
-    // first record of its node: the record below belongs to another node (or to another group)
-    const uint32_t below = wave_shr1(rec.w, 0xFFFFFFFFu);
-    const bool first = on && (r == 0u || below != rec.w);
-    const unsigned long long fm = __ballot(first), om = __ballot(on);
-    if (on) trio_row_emit<KEYS>(rec, slot, word_rank, node_len, vis_nbase[g], H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
-    // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
-    const uint32_t pbit = on ? nr_pair_bit(rec.y, rec.z) : 0u;
-    uint32_t filt = pbit;
+    const uint32_t r = (uint32_t)lane & 7u;
+    uint32_t g[U], cnt[U], slot[U];
+    // ---- level 1: the groups' counts and first slots
 #pragma unroll
-    for (int d = 1; d < 8; ++d) {
-        const uint32_t ob = __shfl(pbit, (lane + d) & 63), ow = __shfl(rec.w, (lane + d) & 63);
-        if (((lane & 7) + d) < 8 && ow == rec.w) filt |= ob;
+    for (int u = 0; u < U; ++u) {
+        g[u] = ((blk * 4u + (threadIdx.x >> 6)) * (uint32_t)U + (uint32_t)u) * 8u + ((uint32_t)lane >> 3);
+        cnt[u] = 0; slot[u] = 0;
+        if (g[u] < NG) { cnt[u] = (uint32_t)__popcll(vis_uq[g[u]]); slot[u] = gprefix[g[u]] + r; }
     }
-    if (first) {
-        // rows of the node: up to the next first record, or to the end of the group's records
-        const unsigned long long grp = 0xFFull << (lane & ~7), stop = (fm | ~om) & grp & ~((2ull << lane) - 1ull);
-        const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
-        trio_head_store(node_rec, rec.w, slot, (uint32_t)(end - lane), filt, err);
+    // ---- level 2: the records
+    uint4 rec[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        on[u] = cnt[u] <= (uint32_t)VIS_REC && r < cnt[u];                     // an overflowing group is taken whole, below
+        rec[u] = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+        if (on[u]) rec[u] = vis_rec[(uint64_t)g[u] * VIS_REC + r];
+    }
+    // ---- level 3: what every record points at
+    uint2 wr[U];
+    uint32_t len3[U];
+    uint4 nrv[U];
+    bool first[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // first record of its node: the record below belongs to another node (or to another group)
+        const uint32_t below = wave_shr1(rec[u].w, 0xFFFFFFFFu);
+        first[u] = on[u] && (r == 0u || below != rec[u].w);
+        wr[u] = make_uint2(0u, 0u); len3[u] = 0; nrv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (on[u]) {
+            wr[u] = word_rank[rec[u].x >> 5];
+            len3[u] = node_len[rec[u].y] + node_len[rec[u].w] + node_len[rec[u].z];
+        }
+        if (first[u]) nrv[u] = node_rec[rec[u].w];
+    }
+    // ---- the rows, the heads
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long fm = __ballot(first[u]), om = __ballot(on[u]);
+        if (on[u]) {
+            // one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
+            // length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
+            const uint32_t row = wr[u].x + (uint32_t)__popc(wr[u].y & ((1u << (rec[u].x & 31u)) - 1u));
+            trio_ent[slot[u]] = make_uint4(rec[u].y, rec[u].z, row, 0u);
+            len_out[row] = len3[u];
+            if (KEYS) {
+                const uint32_t nbase = vis_nbase[g[u]];
+                abc[3ull * row] = rec[u].y - nbase; abc[3ull * row + 1] = rec[u].w - nbase; abc[3ull * row + 2] = rec[u].z - nbase;
+                uint32_t lo = 0, hi = H;                                     // the walk that holds position rec.x: last h with path_off[h] <= q
+                while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= (uint64_t)rec[u].x) lo = mid; else hi = mid; }
+                hap_out[row] = lo - (uint32_t)hap_off[hap_species[lo]];
+            }
+        }
+        // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
+        const uint32_t pbit = on[u] ? nr_pair_bit(rec[u].y, rec[u].z) : 0u;
+        uint32_t filt = pbit;
+#pragma unroll
+        for (int d = 1; d < 8; ++d) {
+            const uint32_t ob = __shfl(pbit, (lane + d) & 63), ow = __shfl(rec[u].w, (lane + d) & 63);
+            if (((lane & 7) + d) < 8 && ow == rec[u].w) filt |= ob;
+        }
+        if (first[u]) {
+            // rows of the node: up to the next first record, or to the end of the group's records
+            const unsigned long long grp = 0xFFull << (lane & ~7), stop = (fm | ~om) & grp & ~((2ull << lane) - 1ull);
+            const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
+            const uint32_t rows = (uint32_t)(end - lane);
+            if (rows >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+            uint4 nr = nrv[u];
+            nr.y = nr_head(nr.y, rows, filt);
+            nr.w = slot[u];
+            node_rec[rec[u].w] = nr;
+        }
     }
     // the groups of this wave with more unique visits than records, one after the other
-    unsigned long long ov = __ballot(r == 0u && cnt > (uint32_t)VIS_REC);
-    while (ov) {
-        const int l = __builtin_ctzll(ov);
-        ov &= ov - 1ull;
-        trio_rows_group<KEYS>(g - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, path_nodes, word_rank, node_len, H,
-                              path_off, hap_species, hap_off, node_rec, trio_ent, abc, hap_out, len_out, err);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        unsigned long long ov = __ballot(r == 0u && cnt[u] > (uint32_t)VIS_REC);
+        while (ov) {
+            const int l = __builtin_ctzll(ov);
+            ov &= ov - 1ull;
+            trio_rows_group<KEYS>(g[u] - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, path_nodes, word_rank, node_len, H,
+                                  path_off, hap_species, hap_off, node_rec, trio_ent, abc, hap_out, len_out, err);
+        }
     }
 }
 // hap_trio_off[h] = rows before the first position of haplotype h (entry H: all rows)
@@ -1151,10 +1204,18 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
 #define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_pos.p, db->d_path_nodes.p, \
                   ts.word_rank.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
                   db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2, (trio_xcd & 2u) ? rchunks : 0u
-                const uint32_t rchunks = (NG + 31) / 32;
+                // a wave takes PANTAX_ROWS_U = 1, 2 or 4 batches of eight groups at once.  Two halve what the kernel waits for memory (8.5 -> 6.0-6.6 ms
+                // inside the step) -- and the step gets SLOWER (32.3-32.6 -> 33.6-34.3 ms at cfg4): the current step's local sorts, which run beside
+                // it on the main stream, stretch from 1.1 to 3.8 ms.  Hence one.
+                uint32_t RU = 1;
+                if (const char *ev = std::getenv("PANTAX_ROWS_U")) RU = (uint32_t)std::atoi(ev);
+                if (RU != 2 && RU != 4) RU = 1;
+                const uint32_t rchunks = (NG + 32 * RU - 1) / (32 * RU);
                 const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);
-                if (with_keys) hipLaunchKernelGGL(trio_rows_kernel<true>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
-                else hipLaunchKernelGGL(trio_rows_kernel<false>, rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS);
+#define ROWS_LAUNCH(KK, UU) hipLaunchKernelGGL((trio_rows_kernel<KK, UU>), rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS)
+                if (with_keys) { if (RU == 2) ROWS_LAUNCH(true, 2); else if (RU == 4) ROWS_LAUNCH(true, 4); else ROWS_LAUNCH(true, 1); }
+                else { if (RU == 2) ROWS_LAUNCH(false, 2); else if (RU == 4) ROWS_LAUNCH(false, 4); else ROWS_LAUNCH(false, 1); }
+#undef ROWS_LAUNCH
 #undef ROWS_ARGS
                 hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.word_rank.p,
                                    db->d_hap_trio_off.p);
