@@ -565,6 +565,10 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
     // ratio != null: the path_cov_ratio sums of ratio_kernel (profile.rs:1344-1361) for every species this kernel builds the masks of,
     // taken while the mask is in a register -- ratio_kernel's 8V bytes of masks are not read a second time
     __shared__ int s_bit[64];     // haplotype -> LP column of the species the tile starts in (nearly always its only one)
+    // ... and the same map BYTE-WISE: s_tab[b][x] = the columns of the haplotypes 8b .. 8b+7 whose bits are set in x.  A node's mask is the OR
+    // of one entry per byte of its haplotype word (two lookups at ten haplotypes) instead of a loop over its set bits (the kernel was
+    // bound by VALU issue: 205 instructions per 64 nodes, `r04_pmc_cfg4.json`); building 256 entries per used byte costs a thread one entry
+    __shared__ unsigned long long s_tab[8][256];
     __shared__ unsigned long long acc[2 * LAD_MAXP];
     if (ratio && threadIdx.x < 2 * LAD_MAXP) acc[threadIdx.x] = 0;
     unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -577,6 +581,16 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
     }
     const int p0 = sp_p[sp0];
     const uint64_t end0 = sp0 < t.y ? (uint64_t)node_base[sp0 + 1] : V;     // first node that is not of the tile's first species any more
+    const int nbyte = (int)((hap_off[sp0 + 1] - hap_off[sp0] + 7) / 8);     // bytes of the haplotype word in use (block-uniform; > 8: a species the path walk fills)
+    __syncthreads();
+    if (p0 > 0 && p0 <= LAD_MAXP && nbyte <= 8) {
+        for (int b = 0; b < nbyte; ++b) {
+            unsigned long long e = 0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int bit = s_bit[8 * b + i]; if (((threadIdx.x >> i) & 1u) && bit >= 0) e |= 1ull << bit; }
+            s_tab[b][threadIdx.x] = e;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -586,8 +600,8 @@ __global__ void __launch_bounds__(256) mask_nodes_kernel(uint64_t V, const uint2
         const unsigned long long c = ratio ? cov[v] : 0ull, l = ratio ? node_len[v] : 0ull;
         unsigned long long m = 0ull;
         if (v < end0) {
-            if (p0 > 0 && p0 <= LAD_MAXP)
-                while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = s_bit[j]; if (bit >= 0) m |= 1ull << bit; }
+            if (p0 > 0 && p0 <= LAD_MAXP && nbyte <= 8)
+                for (int b = 0; b < nbyte; ++b) m |= s_tab[b][(hm >> (8 * b)) & 255ull];
             if (ratio && m) {                      // the first eight candidates (nearly always all) in registers, like ratio_kernel
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
