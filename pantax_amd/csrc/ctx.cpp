@@ -450,15 +450,16 @@ int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, con
     const uint64_t part = (CH + nth - 1) / nth + MARGIN;          // the longest range a thread prunes in one go
     PTX_HIP(ctx, ring.reserve((uint64_t)SLOTS * (CH + part)));
     const uint64_t slot_bytes = CH + part;
-    // every thread: its range of the text -> (pread: a private buffer that stays in its cache) -> pruned into a second private buffer ->
-    // copied to its place in the pinned slot, which is known once the threads before it have announced their sizes
-    // PANTAX_PRUNE_SRC=pread reads the text through private buffers instead of the mapping (measured 5 x slower per chunk on the box: 64
-    // threads inside pread on one file)
-    static const bool SRC_PREAD = std::getenv("PANTAX_PRUNE_SRC") && std::getenv("PANTAX_PRUNE_SRC")[0] == 'p';
-    if (!SRC_PREAD || !text) fd = text ? -1 : fd;
-    std::vector<std::vector<uint8_t>> in_buf(fd >= 0 ? nth : 0), out_buf(nth);
-    for (auto &v : in_buf) v.resize(part);
-    for (auto &v : out_buf) v.resize(part);
+    // Every thread, TWO passes over its range of the mapped text (about a megabyte: the second pass finds it in the core's caches): the
+    // size of its pruned lines; then -- all sizes known (a spin barrier inside the job) -- the lines themselves, straight into their place
+    // in the pinned slot.  The text is read from memory once and 0.73 of it written once; the first version went through two private
+    // buffers per thread and a copy (three passes through memory: 25-37 GB/s of text).  MEASURED (cfg4, 15.2 GB): no faster -- 0.81-1.05 s
+    // to resident reads, 3.7 ms per 64-MB chunk = 270 MB/s per thread: what the threads wait for is the MAPPING (a page-cache page enters
+    // the address space fault by fault, 64 threads on one mm), not the scan; `pread` into pinned memory never maps the text: 70 GB/s.
+    if (!text) return fail(ctx, PANTAX_HIP_E_INVALID, "upload_text_pieces_pruned: the text must be mapped");
+    fd = -1;
+    std::vector<uint64_t> part_size(nth + 1);
+    std::atomic<int> arrived{0};
     StageCrew crew(nth);
     hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
     for (auto &e : ev) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -471,7 +472,6 @@ int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, con
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_begin = now();
     std::vector<uint64_t> cut(nth + 1);
-    std::unique_ptr<std::atomic<uint64_t>[]> pre(new std::atomic<uint64_t>[nth + 1]);   // pre[t] = bytes of the threads before t (UINT64_MAX: not yet known)
     for (size_t pk = 0; pk < n_pieces && rc == 0; ++pk) {
         if (before_piece && !before_piece(pk)) { rc = PANTAX_HIP_E_STATE; break; }
         uint8_t *dst = static_cast<uint8_t *>(d_dst[pk]);
@@ -497,31 +497,20 @@ int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, con
             for (int t = 0; t < nth; ++t) fits = fits && cut[t + 1] - cut[t] <= part;
             uint64_t n_out = 0;
             if (fits) {
-                pre[0].store(0, std::memory_order_relaxed);
-                for (int t = 1; t <= nth; ++t) pre[t].store(~0ull, std::memory_order_relaxed);
+                arrived.store(0, std::memory_order_relaxed);
                 const std::function<void(int, int)> job = [&](int t, int) {
                     const uint64_t a = cut[t], b = cut[t + 1];
-                    uint64_t n = 0;
-                    if (b > a) {
-                        const uint8_t *src = tx + a;
-                        if (fd >= 0) {                                   // through a private buffer: the text is read once from the page cache, never mapped
-                            uint64_t at = 0;
-                            while (at < b - a) {
-                                const ssize_t r = ::pread(fd, in_buf[t].data() + at, b - a - at, (off_t)(file_base + a + at));
-                                if (r <= 0) { std::memset(in_buf[t].data() + at, '\n', b - a - at); break; }   // truncated file: sizes were validated by the caller
-                                at += (uint64_t)r;
-                            }
-                            src = in_buf[t].data();
-                        }
-                        n = gaf_prune_range(src, b - a, 0, b - a, true, out_buf[t].data());
-                    }
-                    uint64_t off;
-                    for (uint32_t spin = 0; (off = pre[t].load(std::memory_order_acquire)) == ~0ull; ++spin) { if (spin < 4096) __builtin_ia32_pause(); else std::this_thread::yield(); }
-                    pre[t + 1].store(off + n, std::memory_order_release);
-                    if (n) std::memcpy(slot + off, out_buf[t].data(), n);
+                    const uint64_t n = b > a ? gaf_prune_range(tx + a, b - a, 0, b - a, true, nullptr) : 0;   // the size pass
+                    part_size[t] = n;
+                    arrived.fetch_add(1, std::memory_order_acq_rel);
+                    for (uint32_t spin = 0; arrived.load(std::memory_order_acquire) < nth; ++spin) { if (spin < 1u << 14) __builtin_ia32_pause(); else std::this_thread::yield(); }
+                    uint64_t off = 0;
+                    for (int u = 0; u < t; ++u) off += part_size[u];
+                    if (n) gaf_prune_range(tx + a, b - a, 0, b - a, true, slot + off);
+                    if (t == nth - 1) part_size[nth] = off + n;
                 };
                 crew.run(job);
-                n_out = pre[nth].load(std::memory_order_acquire);
+                n_out = part_size[nth];
             }
             const auto t2 = now();
             if (fits) {

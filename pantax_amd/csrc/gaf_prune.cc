@@ -48,32 +48,35 @@ struct LineState {
 };
 
 // one complete line [b, nl) (nl = its '\n', or the end of the text when the last line has none) with its first n_tab <= 11
-// tab positions -> out; returns the new end of out
+// tab positions -> out; returns the new end of out.  COUNT: nothing is written, `out` only advances (the size pass of the two-pass
+// upload: every thread learns where its part of the chunk starts before anything is copied)
+template <bool COUNT>
 inline uint8_t *emit_line(const uint8_t *b, const uint8_t *nl, bool has_nl, const uint8_t *const *tab, int n_tab, uint8_t *out) {
     const uint8_t *le = nl;
     if (le > b && le[-1] == '\r') --le;                       // the tokenizer strips it before it splits the line
     if (n_tab < 11 || le == b || *b == '@' || tab[10] >= le) {   // fewer than twelve fields, empty, comment: byte for byte
         const size_t n = (size_t)(nl - b) + (has_nl ? 1u : 0u);
-        std::memcpy(out, b, n);
+        if (!COUNT) std::memcpy(out, b, n);
         return out + n;
     }
-    auto put = [&](const uint8_t *fb, const uint8_t *fe) { std::memcpy(out, fb, (size_t)(fe - fb)); out += fe - fb; };
-    put(b, tab[0]); *out++ = '\t';                            // f0
+    auto put = [&](const uint8_t *fb, const uint8_t *fe) { if (!COUNT) std::memcpy(out, fb, (size_t)(fe - fb)); out += fe - fb; };
+    put(b, tab[0]); if (!COUNT) *out = '\t'; ++out;           // f0
     put(tab[0] + 1, tab[1]);                                  // f1
-    std::memcpy(out, "\t\t\t\t", 4); out += 4;                // f2 f3 f4 empty
+    if (!COUNT) std::memcpy(out, "\t\t\t\t", 4); out += 4;    // f2 f3 f4 empty
     put(tab[4] + 1, tab[8]);                                  // f5 \t f6 \t f7 \t f8
-    std::memcpy(out, "\t\t\t", 3); out += 3;                  // f9 f10 empty
+    if (!COUNT) std::memcpy(out, "\t\t\t", 3); out += 3;      // f9 f10 empty
     const uint8_t *f11e = static_cast<const uint8_t *>(std::memchr(tab[10] + 1, '\t', (size_t)(le - (tab[10] + 1))));
     put(tab[10] + 1, f11e ? f11e : le);                       // f11, the tags behind it cut off
-    if (has_nl) *out++ = '\n';
+    if (has_nl) { if (!COUNT) *out = '\n'; ++out; }
     return out;
 }
 }  // namespace
 
 // Lines that START in [begin, end) of text [0, size), which must begin at a line start when begin == 0 -- the caller says whether
 // `begin` is a line start otherwise (byte begin - 1 is '\n').  A line that starts before `end` is finished beyond it.  out must hold
-// (end of the last such line) - (start of the first) bytes; returns the bytes written.
-uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out) {
+// (end of the last such line) - (start of the first) bytes; returns the bytes written.  out == nullptr: the same count, nothing written.
+template <bool COUNT>
+static uint64_t prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out) {
     if (begin >= size || begin >= end) return 0;
     const uint8_t *p = text + begin, *const e_all = text + size, *const e_own = text + (end < size ? end : size);
     if (!begin_is_line_start) {                               // skip the tail of a line that belongs to the range before
@@ -102,10 +105,15 @@ uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uin
         if (!nl && q < e_all) nl = static_cast<const uint8_t *>(std::memchr(q, '\n', (size_t)(e_all - q)));
         const bool has_nl = nl != nullptr;
         if (!nl) nl = e_all;
-        o = emit_line(st.line, nl, has_nl, st.tab, st.n_tab, o);
+        o = emit_line<COUNT>(st.line, nl, has_nl, st.tab, st.n_tab, o);
         p = nl + 1;
     }
     return (uint64_t)(o - out);
+}
+uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out) {
+    // (the count pass advances a pointer that is never dereferenced: it starts at the text so that the arithmetic stays inside an object)
+    if (!out) return prune_range<true>(text, size, begin, end, begin_is_line_start, const_cast<uint8_t *>(text));
+    return prune_range<false>(text, size, begin, end, begin_is_line_start, out);
 }
 
 }  // namespace ptx
