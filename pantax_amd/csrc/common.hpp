@@ -237,7 +237,7 @@ struct TrioScratch {
     DevBuf<uint4> vis_rec;         // [n_vgroups * 8] the first eight unique windows of every group {window start, smaller end, larger end, middle}
     DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = slot of its first lookup row
     DevBuf<uint2> word_rank;       // [P / 32 + 2] {flags before the word of uniq_q = row of the first window it flags, the word}
-    DevBuf<uint32_t> flag_sums;    // flags per tile of 4096 words, then their prefix (flag_tile_*_kernel)
+    DevBuf<uint32_t> flag_sums, group_sums;   // flags per tile of 4096 words / unique visits per tile of 4096 groups, then their prefix (flag_tile_*, group_tile_* kernels)
 };
 
 // ---- resident DB -----------------------------------------------------------------------------

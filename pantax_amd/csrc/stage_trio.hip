@@ -746,6 +746,30 @@ __global__ void __launch_bounds__(256) flag_tile_rank_kernel(const uint32_t *__r
     for (int k = 0; k < FR_WORDS; ++k) { if (base + k < n) out[base + k] = make_uint2(run, w[k]); run += (uint32_t)__popc(w[k]); }
 }
 
+// ... and the slots of the groups (prefix of their unique counts) the same way, the scan kernel shared
+__global__ void __launch_bounds__(256) group_tile_sum_kernel(const unsigned long long *__restrict__ uq, uint64_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t base = (uint64_t)blockIdx.x * FR_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x; if (i < n) c += (uint32_t)__popcll(uq[i]); }
+    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(256) group_tile_prefix_kernel(const unsigned long long *__restrict__ uq, uint64_t n, const uint32_t *__restrict__ sums, uint32_t *__restrict__ out) {
+    __shared__ uint32_t s_wave[4];
+    const uint64_t base = (uint64_t)blockIdx.x * FR_TILE + (uint64_t)threadIdx.x * FR_WORDS;
+    uint32_t w[FR_WORDS], c = 0;
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { w[k] = base + k < n ? (uint32_t)__popcll(uq[base + k]) : 0u; c += w[k]; }
+    uint32_t tot;
+    uint32_t run = sums[blockIdx.x] + block_excl_scan<256>(c, s_wave, &tot);
+#pragma unroll
+    for (int k = 0; k < FR_WORDS; ++k) { if (base + k < n) out[base + k] = run; run += w[k]; }
+}
+
 // one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
 // length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
 template <bool KEYS>
@@ -1186,8 +1210,19 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                 hipLaunchKernelGGL(flag_tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.flag_sums.p, n_tiles, ts.d_tot.p + 1);
                 hipLaunchKernelGGL(flag_tile_rank_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const uint32_t *)ts.uniq_q.p, zbits, (const uint32_t *)ts.flag_sums.p, ts.word_rank.p);
             }
-            PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
-                                      (uint64_t)db->n_vgroups + 1, nullptr, "scan_chained_kernel<GroupCount>"));
+            if (chained_ranks)
+                PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
+                                          (uint64_t)db->n_vgroups + 1, nullptr, "scan_chained_kernel<GroupCount>"));
+            else {
+                KTimer t(ctx, "group_tile_prefix_kernel");
+                const uint64_t ng1 = (uint64_t)db->n_vgroups + 1;
+                const uint32_t n_tiles = (uint32_t)((ng1 + FR_TILE - 1) / FR_TILE);
+                PTX_HIP(ctx, ts.group_sums.alloc(n_tiles + 1));
+                const unsigned long long *uq = reinterpret_cast<const unsigned long long *>(ts.vis_uq.p);
+                hipLaunchKernelGGL(group_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, ts.group_sums.p);
+                hipLaunchKernelGGL(flag_tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.group_sums.p, n_tiles, (uint32_t *)nullptr);
+                hipLaunchKernelGGL(group_tile_prefix_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, (const uint32_t *)ts.group_sums.p, ts.gprefix.p);
+            }
             if (!db->trio_sizes_known) {
                 PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
                 PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
