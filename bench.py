@@ -126,6 +126,8 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # node (16V; it also stages the rows that have to travel, a data-dependent third of them: not counted); the scatter and the tie
         # fills write every row once between them (16 n)
         "ssn_hist_kernel": 16 * V,
+        # the LP objective summed over the sorted rows (8 n) instead of over abundance + mask of every node
+        "objective_rows_kernel": 8 * n_lp_rows,
         "sort_hist_kernel": 8 * n_lp_rows,
         "sort_scatter_kernel": 2 * 24 * n_lp_rows,
     }, dict(R=R, T=T, V=V, L=L, P=P, H=H)

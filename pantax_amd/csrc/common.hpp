@@ -179,6 +179,8 @@ struct LadBatch {
     DevBuf<uint8_t> d_sp_trio;          //     filter: the second filter then needs no trio table (the next step may be rebuilding them)
     DevBuf<uint64_t> d_mask;            // [V] candidate membership mask per node (the 0/1 coeff matrix, row-wise)
     DevBuf<double> d_ab;                // [V] node_abundance = bases / len  (profile.rs:980-990)
+    DevBuf<double> d_c0;                // [S] sum of ab over the nodes with ab > 0 and no column (the row sort straight from the nodes sums it): the objective's part without rows
+    bool rows_c0_valid = false;         // ... is there for the rows lad_prepare has just sorted
     DevBuf<unsigned long long> d_ratio; // [H*2] at 2 * (hap_off[s] + k): sum cov, sum len of candidate k (exact integers)
     // species that can have more than 64 candidates (more than 64 haplotypes): LAD_WIDE_NW mask words per node in a side
     // array, d_mask then holds a 64-bit hash of those words (rows are grouped by it; the words of every pattern are

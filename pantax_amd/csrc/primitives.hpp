@@ -60,6 +60,7 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
 struct RowPatterns {
     uint64_t *pat_mask;
     uint32_t *pat_start, *pat_species, *sp_pat_off, *d_K;
+    double *c0;   // [S] or null: per segment the sum of ab over the nodes with ab > 0 and mask == 0 (the rows-free part of the LP's objective)
 };
 constexpr uint64_t SSN_MAX_SEG = 1ull << 26;   // nodes of one segment (buckets grow with the segment: beyond 4096 rows they are sorted through memory)
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V);

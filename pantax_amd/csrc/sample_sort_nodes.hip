@@ -74,6 +74,7 @@ struct Sn {
     uint32_t *cntm;              // S x G x SN_NBUCKET: counts, then first slots
     uint16_t *ids;               // [V] bucket id of every staged row (same places as `stage`)
     uint32_t *stage_cnt;         // [S x G] rows a partition workgroup staged
+    double *c0p, *c0;            // [S x G] / [S] (c0 null: not wanted) sum of the abundances of the nodes with a > 0 and an EMPTY mask: no rows, but |0 - a| of the objective
     uint32_t *seg_n, *seg_out;   // [S] rows of a segment, [S + 1] its first output row
     ulonglong2 *stage;           // [V] scratch: the rows that have to travel (even buckets), compacted per partition workgroup from the node of its first tile on
     ulonglong2 *rows;            // [V] scratch: those rows bucket by bucket, segment s from node_base[s]
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(1024) ssn_sample_kernel(Sn sn) {
     __shared__ uint32_t s_nv;
     const uint32_t s = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
-    if (n == 0) { if (threadIdx.x == 0) sn.seg_n[s] = 0; return; }
+    if (n == 0) { if (threadIdx.x == 0) { sn.seg_n[s] = 0; if (sn.c0) sn.c0[s] = 0.0; } return; }
     const uint64_t *samp = reinterpret_cast<const uint64_t *>(w + SN_OFF_SAMP);
     const bool small = n <= (uint32_t)SN_SAMPLE;
     if (threadIdx.x == 0) s_nv = 0;
@@ -222,6 +223,15 @@ __global__ void __launch_bounds__(1024) ssn_sample_kernel(Sn sn) {
     if (small) {                                         // every row of the segment, sorted: copied out by the local kernel
         for (uint32_t i = threadIdx.x; i < nv; i += 1024) sn.rows[o + i] = make_ulonglong2(km[i], ka[i]);
         if (threadIdx.x == 0) { sn.seg_n[s] = nv; w[SN_OFF_FLAGS + 3] = nv; }
+        if (sn.c0) {                                     // the segment's nodes without a column (fixed order: deterministic)
+            __shared__ double s_c[16];
+            double c = 0.0;
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) { const double av = sn.ab[o + i]; if (av > 0.0 && sn.mask[o + i] == 0ull) c += av; }
+            c = wave_reduce(c, [](double x, double y) { return x + y; });
+            if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+            __syncthreads();
+            if (threadIdx.x == 0) { double t = 0.0; for (int q = 0; q < 16; ++q) t += s_c[q]; sn.c0[s] = t; }
+        }
         return;
     }
     ulonglong2 *tree = reinterpret_cast<ulonglong2 *>(w + SN_OFF_TREE);
@@ -261,6 +271,7 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     // abundance, mask and an id of EVERY node again
     const uint32_t stage0 = o + t0 * SN_TILE;
     const int lane = threadIdx.x & 63;
+    double cacc = 0.0;                                           // abundances of this thread's nodes with an empty mask
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t base = t * SN_TILE + threadIdx.x;
         double av[SN_ITEMS];
@@ -275,6 +286,7 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
         for (int r = 0; r < SN_ITEMS; ++r) {
             uint32_t id = SN_NO_ROW;
             const uint64_t abits = (uint64_t)__double_as_longlong(av[r]);
+            if (av[r] > 0.0 && mv[r] == 0ull) cacc += av[r];
             if (av[r] > 0.0 && mv[r] != 0ull) {                  // (nodes behind the segment's end were loaded as zeros)
                 const Key2 key{mv[r], abits};
                 uint32_t k = 1;
@@ -304,6 +316,13 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     uint32_t *row = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) row[i] = s_hist[i];
     if (threadIdx.x == 0) sn.stage_cnt[(size_t)s * sn.G + g] = s_nstage;
+    if (sn.c0) {                                                 // (block-uniform) fixed-shape sum: deterministic
+        __shared__ double s_c[4];
+        cacc = wave_reduce(cacc, [](double x, double y) { return x + y; });
+        if (lane == 0) s_c[threadIdx.x >> 6] = cacc;
+        __syncthreads();
+        if (threadIdx.x == 0) sn.c0p[(size_t)s * sn.G + g] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+    }
 }
 
 // bucket starts of a segment; the count matrix becomes the first slot of every workgroup in every bucket
@@ -344,7 +363,10 @@ __global__ void __launch_bounds__(256) ssn_offsets_kernel(Sn sn) {
             run[q] += c.x; run[q + 1] += c.y; run[q + 2] += c.z; run[q + 3] += c.w;
         }
     }
-    if (threadIdx.x == 0) { sn.seg_n[s] = total; w[SN_OFF_FLAGS + 3] = total; }
+    if (threadIdx.x == 0) {
+        sn.seg_n[s] = total; w[SN_OFF_FLAGS + 3] = total;
+        if (sn.c0) { double t = 0.0; for (uint32_t g = 0; g < ng; ++g) t += sn.c0p[(size_t)s * sn.G + g]; sn.c0[s] = t; }   // in workgroup order
+    }
 }
 // first output row of every segment (the rows of all segments lie back to back), and the total
 __global__ void __launch_bounds__(1024) ssn_segscan_kernel(uint32_t S, const uint32_t *__restrict__ seg_n, uint32_t *__restrict__ seg_out, uint32_t *__restrict__ d_n) {
@@ -653,7 +675,7 @@ void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
     uint32_t G, per;
     sn_geometry(S, seg_bound, &G, &per);
-    return (size_t)S * SN_WS_WORDS + (size_t)S * G * (SN_NBUCKET + 1) + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 16;
+    return (size_t)S * SN_WS_WORDS + (size_t)S * G * (SN_NBUCKET + 1 + 2) + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 20;
 }
 
 // Nodes of segment s: [node_base[s], node_base[s + 1]) (device array, the host knows that no segment exceeds seg_bound <= SS_MAX_N
@@ -674,7 +696,11 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     sn_geometry(S, seg_bound, &sn.G, &sn.per);
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
     sn.stage_cnt = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
-    uint32_t *tail = sn.stage_cnt + (size_t)S * sn.G;
+    uint32_t *cw = sn.stage_cnt + (size_t)S * sn.G;               // [S x G] doubles, 8-byte aligned
+    cw += ((reinterpret_cast<uintptr_t>(cw) & 7u) ? 1 : 0);
+    sn.c0p = reinterpret_cast<double *>(cw);
+    sn.c0 = pat ? pat->c0 : nullptr;
+    uint32_t *tail = cw + 2 * (size_t)S * sn.G;
     sn.seg_n = tail; sn.seg_out = tail + S;                       // [S], [S + 1]
     uint32_t *sub_k = tail + 2 * (size_t)S + 4;                   // [S][SN_NLEAF / 64] patterns found by each wave of ssn_heads_kernel
     sn.ids = reinterpret_cast<uint16_t *>(sub_k + (size_t)(SN_NLEAF / 64) * S);

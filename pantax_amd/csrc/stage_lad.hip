@@ -964,6 +964,7 @@ int node_haps_build(Ctx *ctx, Db *db) {
 // uploaded from lb->h_p / h_cand (solver seam).  pmax_bound = upper bound of candidates per species.
 int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int pmax_bound) {
     const uint32_t S = db->S;
+    lb->rows_c0_valid = false;
     const uint64_t V = db->V, H = db->H;
     if (!cand_on_device) {
         std::vector<int32_t> hap_bit(H ? H : 1, -1);
@@ -1117,7 +1118,9 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     if (use_nodes) {   // no compaction: the sort's passes read the node arrays and skip the nodes that are no rows; the patterns come from its splitters
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_nodes_ws_elems(S, max_vs, V)));
         PTX_HIP(ctx, dbm->d_row16.alloc(4 * V));
-        const RowPatterns pat{lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, lb->d_sp_pat_off.p, d_K};
+        PTX_HIP(ctx, lb->d_c0.alloc(S));
+        const RowPatterns pat{lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, lb->d_sp_pat_off.p, d_K, lb->d_c0.p};
+        lb->rows_c0_valid = true;
         PTX_TRY(sample_sort_nodes(ctx, lb->d_ab.p, lb->d_mask.p, db->d_node_base.p, S, max_vs, V, dbm->d_row16.p, pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p,
                                   pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat));
     } else if (use_seg) {
@@ -2237,9 +2240,107 @@ __global__ void __launch_bounds__(256) objective_kernel(const int32_t *__restric
     done[s] = 0;
 }
 
+// The same objective from the SORTED ROWS (the many-species step, species of at most 64 columns): every row of a pattern has the pattern's
+// prediction, so the pass reads 8 bytes per row -- 1.6 GB at cfg4 where the pass over the nodes reads abundance and mask of every node,
+// 5.1 GB; the nodes with a > 0 and an empty mask, which are no rows, contribute the constant c0[s] that the row sort's histogram pass
+// summed on its way (fixed order).  The sums run in another order than objective_kernel's: equal to the last bits of a double, not bit for bit.
+__global__ void __launch_bounds__(256) pattern_pred_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need2, const uint32_t *__restrict__ sp_pat_off,
+                                                           const uint64_t *__restrict__ pat_mask, const uint64_t *__restrict__ col_off, const double *__restrict__ x1,
+                                                           const double *__restrict__ x2, double *__restrict__ pred1, double *__restrict__ pred2) {
+    __shared__ double xs1[LAD_MAXP], xs2[LAD_MAXP];
+    const int s = blockIdx.x, p = sp_p[s];
+    if (p <= 0 || p > LAD_MAXP) return;
+    const bool two = x2 && need2 && need2[s];
+    if ((int)threadIdx.x < p) { xs1[threadIdx.x] = x1[col_off[s] + threadIdx.x]; xs2[threadIdx.x] = two ? x2[col_off[s] + threadIdx.x] : 0.0; }
+    __syncthreads();
+    for (uint32_t k = sp_pat_off[s] + threadIdx.x; k < sp_pat_off[s + 1]; k += 256) {
+        const uint64_t mk = pat_mask[k];
+        pred1[k] = mdot(mk, xs1);
+        if (two) pred2[k] = mdot(mk, xs2);
+    }
+}
+__global__ void __launch_bounds__(256) objective_rows_kernel(const int32_t *__restrict__ sp_p, const uint8_t *__restrict__ need2, const uint32_t *__restrict__ sp_pat_off,
+                                                             const uint32_t *__restrict__ pat_start, const double *__restrict__ row_a, const double *__restrict__ pred1,
+                                                             const double *__restrict__ pred2, const double *__restrict__ c0, double *part /*[S][STAT_CHUNKS][2]*/,
+                                                             uint32_t *__restrict__ done /*[S], zero between launches*/, const uint32_t *__restrict__ nvalid,
+                                                             double *__restrict__ obj1, double *__restrict__ obj2, uint32_t nch, bool have2) {
+    __shared__ double red[4];
+    __shared__ int s_last;
+    const int s = blockIdx.x / nch;
+    const int p = sp_p[s];
+    if (p <= 0) return;
+    const bool two = have2 && need2 && need2[s];
+    const uint32_t ch = blockIdx.x % nch;
+    const uint32_t k0 = sp_pat_off[s], k1 = sp_pat_off[s + 1];
+    const uint32_t r0 = pat_start[k0], r1 = pat_start[k1];              // the species' rows (pat_start[K] = all rows)
+    const uint32_t per = (r1 - r0 + nch - 1) / nch;
+    uint32_t lo = r0 + ch * per, hi = lo + per;
+    if (lo > r1) lo = r1;
+    if (hi > r1) hi = r1;
+    double acc1 = 0.0, acc2 = 0.0;
+    constexpr uint32_t KL = 256;                                          // patterns whose starts and predictions ride in LDS (a species has a handful)
+    __shared__ uint32_t s_ps[KL + 1];
+    __shared__ double s_p1[KL], s_p2[KL];
+    const uint32_t K = k1 - k0;
+    if (K <= KL) {                                                        // (block-uniform)
+        for (uint32_t q = threadIdx.x; q <= K; q += 256) s_ps[q] = pat_start[k0 + q];
+        for (uint32_t q = threadIdx.x; q < K; q += 256) { s_p1[q] = pred1[k0 + q]; s_p2[q] = two ? pred2[k0 + q] : 0.0; }
+        __syncthreads();
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            uint32_t a = 0, b = K;                                        // last pattern that starts at or before row i
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (s_ps[m] <= i) a = m; else b = m; }
+            const double av = row_a[i];
+            acc1 += fabs(s_p1[a] - av);
+            if (two) acc2 += fabs(s_p2[a] - av);
+        }
+    } else
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint32_t a = k0, b = k1;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (pat_start[m] <= i) a = m; else b = m; }
+        const double av = row_a[i];
+        acc1 += fabs(pred1[a] - av);
+        if (two) acc2 += fabs(pred2[a] - av);
+    }
+    acc1 = block_sum_f64<256>(acc1, red);
+    acc2 = block_sum_f64<256>(acc2, red);
+    if (threadIdx.x == 0) {
+        part[((size_t)s * nch + ch) * 2] = acc1;
+        part[((size_t)s * nch + ch) * 2 + 1] = acc2;
+        s_last = __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nch - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double t1 = 0.0, t2 = 0.0;
+    if (threadIdx.x < nch) { t1 = part[((size_t)s * nch + threadIdx.x) * 2]; t2 = part[((size_t)s * nch + threadIdx.x) * 2 + 1]; }
+    t1 = block_sum_f64<256>(t1, red);
+    t2 = block_sum_f64<256>(t2, red);
+    if (threadIdx.x != 0) return;
+    obj1[s] = nvalid[s] ? (t1 + c0[s]) / (double)nvalid[s] : 0.0;
+    if (two) obj2[s] = nvalid[s] ? (t2 + c0[s]) / (double)nvalid[s] : 0.0;
+    done[s] = 0;
+}
+
 static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_need2, const double *d_x1, const double *d_x2, double *d_obj1,
                             double *d_obj2) {
     const uint32_t S = db->S;
+    static const bool by_nodes = std::getenv("PANTAX_OBJECTIVE") && std::getenv("PANTAX_OBJECTIVE")[0] == 'n';   // measurements / tests: the pass over the nodes
+    if (lb->rows_c0_valid && lb->n_wide == 0 && !by_nodes) {
+        KTimer t(ctx, "objective_rows_kernel");
+        PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
+        if (lb->d_obj_done.n < S) {
+            PTX_HIP(ctx, lb->d_obj_done.alloc(S));
+            PTX_HIP(ctx, hipMemsetAsync(lb->d_obj_done.p, 0, lb->d_obj_done.bytes(), ctx->stream));   // the kernel leaves it zero
+        }
+        const uint32_t nch = stat_chunks(S);
+        // (the solver's per-pattern scratch is free again: the predictions of both solutions go there)
+        hipLaunchKernelGGL(pattern_pred_kernel, dim3(S), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, lb->d_sp_pat_off.p, lb->d_pat_mask.p, db->d_hap_off.p, d_x1, d_x2,
+                           lb->d_sc_s.p, lb->d_sc_rho.p);
+        hipLaunchKernelGGL(objective_rows_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, lb->d_p.p, d_need2, lb->d_sp_pat_off.p, lb->d_pat_start.p, lb->row_a,
+                           (const double *)lb->d_sc_s.p, (const double *)lb->d_sc_rho.p, (const double *)lb->d_c0.p, lb->d_partial.p, lb->d_obj_done.p, lb->d_nvalid.p,
+                           d_obj1, d_obj2, nch, d_x2 != nullptr);
+        PTX_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     KTimer t(ctx, "objective_kernel");
     PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
     if (lb->d_obj_done.n < S) {

@@ -770,6 +770,16 @@ def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, monkeypatc
                 assert b[k] is not None and abs(a[k] - b[k]) <= 1e-12 * max(1.0, abs(a[k])), (k, a[k], b[k])
 
 
+def _same_infos(a, b):
+    """solve infos of two row pipelines: candidates, statuses, pivots, row and pattern counts equal; the objectives equal to the last bits
+    of a double (the many-species step sums them over the sorted rows, the other pipelines over the nodes: another order of additions)"""
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x[:7] == y[:7], (x, y)
+        for u, v in zip(x[7:], y[7:]):
+            assert (np.isnan(u) and np.isnan(v)) or abs(u - v) <= 1e-12 * max(1.0, abs(u), abs(v)), (x, y)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,R,L,pf,opts", [
     (22, 4, 10, 80000, 30000, 0.4, {}),                        # a handful of patterns per species
@@ -781,7 +791,8 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     compaction + batched per-species sort (round 3's many-species step) and the batched sort straight from the node arrays (the
     many-species step now; both forced here at a small size) -- and the two ways
     of building the membership masks (by node from the node -> haplotypes table of the upload, or by walking the candidates'
-    paths, PANTAX_MASK=walk) give the same metrics, objectives, iteration counts, row and pattern counts bit for bit."""
+    paths, PANTAX_MASK=walk) give the same metrics, iteration counts, row and pattern counts bit for bit, and the same objectives (to 1e-12: the sort straight
+    from the nodes sums them over the sorted rows)."""
     from oracle import oracle as orc
     from pantax_amd import synth
     sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
@@ -802,7 +813,7 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     assert any(o[5] > 0 for o in outs[0][1])
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0])
-        assert str(o[1]) == str(outs[0][1])        # str: nan == nan
+        _same_infos(o[1], outs[0][1])
 
 
 @pytest.mark.gpu
@@ -821,7 +832,8 @@ def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, monkeypatch)
         out = eng.profile_step(sset.avg_len())
         outs.append((out[0].copy(), bytes(out[2]), [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in out[3]]))
     assert any(o[5] > 100_000 for o in outs[0][2])
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and str(outs[0][2]) == str(outs[1][2])
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    _same_infos(outs[0][2], outs[1][2])
 
 
 @pytest.mark.gpu
