@@ -125,7 +125,7 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # a12's rows sorted straight from the node arrays (sample_sort_nodes.hip, round 4): the histogram pass reads abundance + mask of every
         # node (16V; it also stages the rows that have to travel, a data-dependent third of them: not counted); the scatter and the tie
         # fills write every row once between them (16 n)
-        "ssn_hist_kernel": 16 * V,
+        "ssn_hist_kernel": 24 * V,       # (the masks are formed in this pass since the end of round 4: haplotype words 8V + abundance 8V + covered bases 4V + lengths 4V)
         # the LP objective summed over the sorted rows (8 n) instead of over abundance + mask of every node
         "objective_rows_kernel": 8 * n_lp_rows,
         "sort_hist_kernel": 8 * n_lp_rows,

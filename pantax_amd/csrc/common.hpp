@@ -181,6 +181,7 @@ struct LadBatch {
     DevBuf<double> d_ab;                // [V] node_abundance = bases / len  (profile.rs:980-990)
     DevBuf<double> d_c0;                // [S] sum of ab over the nodes with ab > 0 and no column (the row sort straight from the nodes sums it): the objective's part without rows
     bool rows_c0_valid = false;         // ... is there for the rows lad_prepare has just sorted
+    bool masks_in_sort = false;         // the last lad_prepare formed the masks inside the row sort: d_mask holds nothing
     DevBuf<unsigned long long> d_ratio; // [H*2] at 2 * (hap_off[s] + k): sum cov, sum len of candidate k (exact integers)
     // species that can have more than 64 candidates (more than 64 haplotypes): LAD_WIDE_NW mask words per node in a side
     // array, d_mask then holds a 64-bit hash of those words (rows are grouped by it; the words of every pattern are

@@ -63,9 +63,20 @@ struct RowPatterns {
     double *c0;   // [S] or null: per segment the sum of ab over the nodes with ab > 0 and mask == 0 (the rows-free part of the LP's objective)
 };
 constexpr uint64_t SSN_MAX_SEG = 1ull << 26;   // nodes of one segment (buckets grow with the segment: beyond 4096 rows they are sorted through memory)
+// mask == null: the sort forms a node's membership mask itself from its haplotype word (and sums the candidates' covered bases and lengths
+// on the way: what mask_nodes_kernel does in a pass of its own) -- the mask array is then neither written nor read
+struct RowMaskSource {
+    const unsigned long long *node_haps = nullptr;   // [V] bit j: haplotype j of the node's species visits it
+    const uint64_t *hap_off = nullptr;               // [S + 1]
+    const int32_t *hap_bit = nullptr, *sp_p = nullptr;   // [H] LP column of a haplotype or -1; [S] columns of a species
+    const uint32_t *cov = nullptr, *node_len = nullptr;  // [V] covered bases, length
+    unsigned long long *ratio = nullptr;             // [2 H] at 2 (hap_off[s] + k): sum cov, sum len of column k
+    uint32_t max_haps = 0;                           // most haplotypes of a species (<= 64)
+};
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V);
 int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
-                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat = nullptr);
+                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat = nullptr,
+                      const RowMaskSource *haps = nullptr);
 
 // helper: passes covering bits [lo,hi) of a word, least significant first, appended to out
 inline void add_passes(std::vector<SortPass> &out, int word, int lo, int hi) {

@@ -69,7 +69,8 @@ static_assert(SN_WS_WORDS % 4 == 0, "16-byte tree nodes");
 struct Sn {
     const uint32_t *node_base;   // [S + 1] (device)
     const double *ab;            // [V] a_v (0 = no row)
-    const uint64_t *mask;        // [V] membership mask (0 = no row)
+    const uint64_t *mask;        // [V] membership mask (0 = no row); null: formed from the haplotype words (hp)
+    RowMaskSource hp;
     uint32_t *ws;                // S x SN_WS_WORDS
     uint32_t *cntm;              // S x G x SN_NBUCKET: counts, then first slots
     uint16_t *ids;               // [V] bucket id of every staged row (same places as `stage`)
@@ -88,6 +89,19 @@ struct Sn {
         if (ksp) ksp[pos] = s;
     }
 };
+
+// mask == null: the membership mask of node v of segment (= species) s from its haplotype word -- bit k of the mask = some haplotype of
+// column k visits the node (what mask_nodes_kernel writes, stage_lad.hip); the plain loop, for the few nodes the samplers look at
+__device__ __forceinline__ uint64_t sn_node_mask(const Sn &sn, uint32_t s, uint64_t v) {
+    if (sn.mask) return sn.mask[v];
+    const int p = sn.hp.sp_p[s];
+    const uint64_t h0 = sn.hp.hap_off[s], nh = sn.hp.hap_off[s + 1] - h0;
+    if (p <= 0 || p > 64 || nh > 64) return 0ull;
+    unsigned long long hm = sn.hp.node_haps[v];
+    uint64_t m = 0;
+    while (hm) { const int j = __ffsll((long long)hm) - 1; hm &= hm - 1; const int bit = sn.hp.hap_bit[h0 + j]; if (bit >= 0) m |= 1ull << bit; }
+    return m;
+}
 
 // sorted rank (0-based, among the SN_NSPLIT splitters) of tree node k, and back
 __device__ __forceinline__ uint32_t tree_rank(uint32_t k) {
@@ -196,7 +210,7 @@ __global__ void __launch_bounds__(256) ssn_gather_kernel(Sn sn) {
     uint64_t m = ~0ull, a = ~0ull;                       // not a row: sorts last
     if (pos < n) {
         const double av = sn.ab[o + pos];
-        const uint64_t mv = sn.mask[o + pos];
+        const uint64_t mv = av > 0.0 ? sn_node_mask(sn, s, o + pos) : 0ull;
         if (av > 0.0 && mv != 0ull) { m = mv; a = (uint64_t)__double_as_longlong(av); }   // positive doubles order like their bit patterns
     }
     samp[i] = m; samp[SN_SAMPLE + i] = a;
@@ -223,10 +237,22 @@ __global__ void __launch_bounds__(1024) ssn_sample_kernel(Sn sn) {
     if (small) {                                         // every row of the segment, sorted: copied out by the local kernel
         for (uint32_t i = threadIdx.x; i < nv; i += 1024) sn.rows[o + i] = make_ulonglong2(km[i], ka[i]);
         if (threadIdx.x == 0) { sn.seg_n[s] = nv; w[SN_OFF_FLAGS + 3] = nv; }
+        if (!sn.mask && sn.hp.ratio) {                   // masks from the haplotype words: this segment's column sums are this kernel's (the histogram pass skips it)
+            __shared__ unsigned long long s_r[128];
+            if (threadIdx.x < 128) s_r[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+                uint64_t m = sn_node_mask(sn, s, o + i);
+                const unsigned long long c = sn.hp.cov[o + i], l = sn.hp.node_len[o + i];
+                while (m) { const int k = __ffsll((long long)m) - 1; m &= m - 1; if (c) atomicAdd(&s_r[2 * k], c); atomicAdd(&s_r[2 * k + 1], l); }
+            }
+            __syncthreads();
+            if (threadIdx.x < 128 && s_r[threadIdx.x]) atomicAdd(&sn.hp.ratio[2 * sn.hp.hap_off[s] + threadIdx.x], s_r[threadIdx.x]);
+        }
         if (sn.c0) {                                     // the segment's nodes without a column (fixed order: deterministic)
             __shared__ double s_c[16];
             double c = 0.0;
-            for (uint32_t i = threadIdx.x; i < n; i += 1024) { const double av = sn.ab[o + i]; if (av > 0.0 && sn.mask[o + i] == 0ull) c += av; }
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) { const double av = sn.ab[o + i]; if (av > 0.0 && sn_node_mask(sn, s, o + i) == 0ull) c += av; }
             c = wave_reduce(c, [](double x, double y) { return x + y; });
             if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
             __syncthreads();
@@ -252,9 +278,16 @@ __device__ __forceinline__ void sn_tiles(const Sn &sn, uint32_t n, uint32_t g, u
     if (t1 > nt) t1 = nt;
 }
 
+// HAPS: no mask array -- the mask of a node is formed here from its haplotype word through byte-wise column tables in (dynamic) LDS, and the
+// candidates' covered bases and lengths (path_cov_ratio, profile.rs:1344-1361) are summed while it is in a register: mask_nodes_kernel's
+// pass (16V in, 8V out) and this pass's own 8V of masks are gone
+template <bool HAPS>
 __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     __shared__ ulonglong2 tree[SN_NLEAF];
     __shared__ uint32_t s_hist[SN_NBUCKET];
+    extern __shared__ unsigned long long s_dyn_tab[];             // HAPS: [nbyte][256] columns of the haplotypes 8b .. 8b+7 set in a byte value
+    __shared__ int s_bit[64];
+    __shared__ unsigned long long s_acc[2 * 64];
     const uint32_t s = blockIdx.y, g = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
     if (n == 0 || w[SN_OFF_FLAGS] != 0) return;
@@ -265,7 +298,28 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) s_hist[i] = 0;
     if (threadIdx.x == 0) s_nstage = 0;
     if (t0 < t1) for (int i = threadIdx.x; i < SN_NLEAF; i += 256) tree[i] = gt[i];
+    int p0 = 0, nbyte = 0;
+    uint64_t h0 = 0;
+    if (HAPS) {
+        h0 = sn.hp.hap_off[s];
+        const uint64_t nh = sn.hp.hap_off[s + 1] - h0;
+        p0 = sn.hp.sp_p[s];
+        if (p0 <= 0 || p0 > 64 || nh > 64) p0 = 0;                // no columns (or a species the path walk serves: never with HAPS)
+        nbyte = p0 ? (int)((nh + 7) / 8) : 0;
+        if (threadIdx.x < 64) s_bit[threadIdx.x] = (p0 && threadIdx.x < nh) ? sn.hp.hap_bit[h0 + threadIdx.x] : -1;
+        if (threadIdx.x < 128) s_acc[threadIdx.x] = 0;
+    }
     __syncthreads();
+    if (HAPS) {
+        for (int b = 0; b < nbyte; ++b) {
+            unsigned long long e = 0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int bit = s_bit[8 * b + i]; if (((threadIdx.x >> i) & 1u) && bit >= 0) e |= 1ull << bit; }
+            s_dyn_tab[b * 256 + threadIdx.x] = e;
+        }
+        __syncthreads();
+    }
+    unsigned long long c8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // The rows of the EVEN buckets are the only ones that travel (a tie bucket is written as a fill): they are staged here, compacted and
     // with their bucket id, in the node range of this workgroup's tiles -- the scatter pass reads 18 bytes per such row instead of
     // abundance, mask and an id of EVERY node again
@@ -276,14 +330,38 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
         const uint32_t base = t * SN_TILE + threadIdx.x;
         double av[SN_ITEMS];
         uint64_t mv[SN_ITEMS];
+        uint32_t cv[SN_ITEMS], lv[SN_ITEMS];
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
             const uint32_t i = base + (uint32_t)r * 256u;
-            av[r] = 0.0; mv[r] = 0;
-            if (i < n) { av[r] = sn.ab[o + i]; mv[r] = sn.mask[o + i]; }
+            av[r] = 0.0; mv[r] = 0; cv[r] = 0; lv[r] = 0;
+            if (i < n) {
+                av[r] = sn.ab[o + i];
+                if (HAPS) { mv[r] = sn.hp.node_haps[o + i]; cv[r] = sn.hp.cov[o + i]; lv[r] = sn.hp.node_len[o + i]; }
+                else mv[r] = sn.mask[o + i];
+            }
         }
 #pragma unroll
         for (int r = 0; r < SN_ITEMS; ++r) {
+            if (HAPS) {                                           // haplotype word -> columns, and the columns' sums
+                const unsigned long long hm = mv[r];
+                unsigned long long m = 0ull;
+                for (int b = 0; b < nbyte; ++b) m |= s_dyn_tab[b * 256 + (int)((hm >> (8 * b)) & 255ull)];
+                mv[r] = m;
+                if (m) {
+                    const unsigned long long c = cv[r], l = lv[r];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < p0) { const bool on = (m >> k) & 1ull; c8[k] += on ? c : 0ull; l8[k] += on ? l : 0ull; }   // (block-uniform: the columns that exist)
+                    unsigned long long rest = m >> 8;
+                    while (rest) {
+                        const int k = __ffsll((long long)rest) - 1 + 8;
+                        rest &= rest - 1;
+                        if (c) atomicAdd(&s_acc[2 * k], c);
+                        atomicAdd(&s_acc[2 * k + 1], l);
+                    }
+                }
+            }
             uint32_t id = SN_NO_ROW;
             const uint64_t abits = (uint64_t)__double_as_longlong(av[r]);
             if (av[r] > 0.0 && mv[r] == 0ull) cacc += av[r];
@@ -322,6 +400,20 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
         if (lane == 0) s_c[threadIdx.x >> 6] = cacc;
         __syncthreads();
         if (threadIdx.x == 0) sn.c0p[(size_t)s * sn.G + g] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+    }
+    if (HAPS && p0 > 0 && sn.hp.ratio) {                         // (block-uniform) exact integer sums: any order
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= p0) break;
+            const unsigned long long cs = wave_reduce(c8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+            const unsigned long long ls = wave_reduce(l8[k], [](unsigned long long x, unsigned long long y) { return x + y; });
+            if (lane == 0) {
+                if (cs) atomicAdd(&s_acc[2 * k], cs);
+                if (ls) atomicAdd(&s_acc[2 * k + 1], ls);
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * p0 && s_acc[threadIdx.x]) atomicAdd(&sn.hp.ratio[2 * h0 + threadIdx.x], s_acc[threadIdx.x]);
     }
 }
 
@@ -682,7 +774,8 @@ size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
 // nodes); a node is a row when ab > 0 and mask != 0.  Output: the rows of all segments back to back, every segment sorted by
 // (mask, a), in (ksp, km, ka) -- ksp null: species << pack_shift | mask in km; *d_n = the number of rows.  rows16: 4 V words of scratch.
 int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const uint32_t *d_node_base, uint32_t S, uint64_t seg_bound, uint64_t V,
-                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat) {
+                      uint64_t *rows16, uint64_t *ksp, uint64_t *km, uint64_t *ka, int pack_shift, uint32_t *d_ws, uint32_t *d_n, const RowPatterns *pat,
+                      const RowMaskSource *haps) {
     if (S == 0 || V == 0) {
         PTX_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(uint32_t), ctx->stream));
         if (pat) { PTX_HIP(ctx, hipMemsetAsync(pat->d_K, 0, sizeof(uint32_t), ctx->stream)); PTX_HIP(ctx, hipMemsetAsync(pat->sp_pat_off, 0, (S + 1) * sizeof(uint32_t), ctx->stream));
@@ -692,7 +785,9 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     if (seg_bound > SSN_MAX_SEG) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: a segment of %llu nodes exceeds %llu", (unsigned long long)seg_bound, (unsigned long long)SSN_MAX_SEG);
     if (S > 65535) return fail(ctx, PANTAX_HIP_E_LIMIT, "sample_sort_nodes: %u segments exceed the launch grid", S);
     Sn sn;
-    sn.node_base = d_node_base; sn.ab = ab; sn.mask = mask; sn.ws = d_ws;
+    sn.node_base = d_node_base; sn.ab = ab; sn.mask = haps ? nullptr : mask; sn.ws = d_ws;
+    if (haps) { if (haps->max_haps > 64) return fail(ctx, PANTAX_HIP_E_INVALID, "sample_sort_nodes: masks from haplotype words take species of at most 64 haplotypes"); sn.hp = *haps; }
+    else if (!mask) return fail(ctx, PANTAX_HIP_E_INVALID, "sample_sort_nodes: neither a mask array nor haplotype words");
     sn_geometry(S, seg_bound, &sn.G, &sn.per);
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
     sn.stage_cnt = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
@@ -711,7 +806,8 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
       hipLaunchKernelGGL(ssn_gather_kernel, dim3(SN_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sn);
       hipLaunchKernelGGL(ssn_sample_kernel, dim3(S), dim3(1024), 0, ctx->stream, sn); }
     { KTimer t(ctx, "ssn_hist_kernel");
-      hipLaunchKernelGGL(ssn_hist_kernel, dim3(sn.G, S), dim3(256), 0, ctx->stream, sn); }
+      if (haps) hipLaunchKernelGGL(ssn_hist_kernel<true>, dim3(sn.G, S), dim3(256), (size_t)((haps->max_haps + 7) / 8) * 256 * sizeof(unsigned long long), ctx->stream, sn);
+      else hipLaunchKernelGGL(ssn_hist_kernel<false>, dim3(sn.G, S), dim3(256), 0, ctx->stream, sn); }
     { KTimer t(ctx, "ssn_offsets_kernel");
       hipLaunchKernelGGL(ssn_offsets_kernel, dim3(S), dim3(256), 0, ctx->stream, sn);
       hipLaunchKernelGGL(ssn_segscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)sn.seg_n, sn.seg_out, d_n); }

@@ -1052,7 +1052,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // the path_cov_ratio sums ride on the by-node mask pass (PANTAX_RATIO=kernel: ratio_kernel for every species, as in round 3)
     static const bool ratio_sep = std::getenv("PANTAX_RATIO") && std::getenv("PANTAX_RATIO")[0] == 'k';
     const bool ratio_by_node = by_node && V && !ratio_sep;
-    {
+    // ... and where the rows are sorted straight from the node arrays and every species has at most 64 haplotypes, the masks are formed INSIDE the
+    // sort's histogram pass (ssn_hist_kernel<true>): no mask array, no pass of its own (PANTAX_MASK_PASS=1 keeps mask_nodes_kernel; so do the
+    // measurement modes that read the array afterwards)
+    static const bool mask_pass_env = (std::getenv("PANTAX_MASK_PASS") && std::getenv("PANTAX_MASK_PASS")[0] == '1') ||
+                                      (std::getenv("PANTAX_OBJECTIVE") && std::getenv("PANTAX_OBJECTIVE")[0] == 'n');
+    const bool masks_in_sort = use_nodes && ratio_by_node && !db->nh_walk_too && !wide && !mask_pass_env;
+    lb->masks_in_sort = masks_in_sort;
+    if (!masks_in_sort) {
         KTimer t(ctx, by_node ? "mask_nodes_kernel" : "mask_kernel");   // the names rocprofv3 shows
         if (by_node && V)
             hipLaunchKernelGGL(mask_nodes_kernel, dim3((uint32_t)((V + 2047) / 2048)), dim3(256), 0, ctx->stream, V, db->d_emit_tile_sp.p, db->d_node_base.p, db->d_hap_off.p,
@@ -1064,7 +1071,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
                                lb->d_p.p, wide ? lb->d_wide_off.p : (const uint32_t *)nullptr, lb->d_wide_nw.p, (unsigned long long *)lb->d_maskw.p,
                                by_node ? db->d_hap_off.p : (const uint64_t *)nullptr);
     }
-    if (!ratio_by_node || db->nh_walk_too) {   // what the mask pass did not sum: species of more than 64 haplotypes (their masks come from the path walk)
+    if (!masks_in_sort && (!ratio_by_node || db->nh_walk_too)) {   // what the mask pass did not sum: species of more than 64 haplotypes (their masks come from the path walk)
         KTimer t(ctx, "ratio_kernel");
         hipLaunchKernelGGL(ratio_kernel, dim3(S * RATIO_CHUNKS), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_cov.p,
                            (unsigned long long *)lb->d_mask.p, lb->d_p.p, db->d_hap_off.p, lb->d_wide_off.p, lb->d_wide_nw.p,
@@ -1121,8 +1128,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         PTX_HIP(ctx, lb->d_c0.alloc(S));
         const RowPatterns pat{lb->d_pat_mask.p, lb->d_pat_start.p, lb->d_pat_species.p, lb->d_sp_pat_off.p, d_K, lb->d_c0.p};
         lb->rows_c0_valid = true;
+        RowMaskSource hp;
+        if (masks_in_sort) {
+            uint32_t mh = 0;
+            for (uint32_t s_ = 0; s_ < S; ++s_) mh = std::max<uint32_t>(mh, (uint32_t)(db->h_hap_off[s_ + 1] - db->h_hap_off[s_]));
+            hp.node_haps = (const unsigned long long *)db->d_node_haps.p; hp.hap_off = db->d_hap_off.p; hp.hap_bit = lb->d_hap_bit.p; hp.sp_p = lb->d_p.p;
+            hp.cov = db->d_cov.p; hp.node_len = db->d_node_len.p; hp.ratio = lb->d_ratio.p; hp.max_haps = mh;
+        }
         PTX_TRY(sample_sort_nodes(ctx, lb->d_ab.p, lb->d_mask.p, db->d_node_base.p, S, max_vs, V, dbm->d_row16.p, pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p,
-                                  pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat));
+                                  pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat, masks_in_sort ? &hp : nullptr));
     } else if (use_seg) {
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_seg_ws_elems(S, V)));
         const int w0 = pack_shift >= 0 ? 0 : 1;   // the two words that move: {packed species|mask, a} or {mask, a}
@@ -2324,7 +2338,7 @@ static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t 
                             double *d_obj2) {
     const uint32_t S = db->S;
     static const bool by_nodes = std::getenv("PANTAX_OBJECTIVE") && std::getenv("PANTAX_OBJECTIVE")[0] == 'n';   // measurements / tests: the pass over the nodes
-    if (lb->rows_c0_valid && lb->n_wide == 0 && !by_nodes) {
+    if (lb->rows_c0_valid && lb->n_wide == 0 && (!by_nodes || lb->masks_in_sort)) {
         KTimer t(ctx, "objective_rows_kernel");
         PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
         if (lb->d_obj_done.n < S) {
