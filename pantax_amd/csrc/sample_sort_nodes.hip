@@ -44,7 +44,10 @@ constexpr int SN_SAMPLE = 4096;
 constexpr int SN_NLEAF = 1 << SN_LEVELS;         // 1024
 constexpr int SN_NSPLIT = SN_NLEAF - 1;          // 1023 splitters: three to four valid samples between two of them
 constexpr int SN_NBUCKET = 2 * SN_NLEAF;         // 2048 ids (the last odd one stays empty)
-constexpr int SN_ITEMS = 8;                      // nodes per thread and tile
+#ifndef SN_ITEMS_N
+#define SN_ITEMS_N 8
+#endif
+constexpr int SN_ITEMS = SN_ITEMS_N;                      // nodes per thread and tile
 constexpr int SN_TILE = 256 * SN_ITEMS;
 constexpr int SN_CAP = 4096;
 constexpr int SN_WAVE_CAP = 512;                 // rows a wave of the first local kernel sorts in registers (eight per lane)
