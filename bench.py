@@ -476,6 +476,103 @@ def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9):
                 what="relative L1 of the timed step's strain rows against the oracle (exact LAD == HiGHS optimum on the fixtures) on the same reads, full size")
 
 
+class _StderrCapture:
+    """fd 2 into a temporary file for the duration of the block (the library's phase times go to the C-level stderr)."""
+
+    def __enter__(self):
+        self.tmp = tempfile.TemporaryFile()
+        sys.stderr.flush()
+        self.saved = os.dup(2)
+        os.dup2(self.tmp.fileno(), 2)
+        return self
+
+    def __exit__(self, *a):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode(errors="replace")
+        self.tmp.close()
+
+
+def _seam_phases(text):
+    """'[pantax_hip_profile r0] phase   12.345 ms' lines -> {phase: ms} (the last value of a repeated phase wins)"""
+    out = {}
+    for ln in text.splitlines():
+        if ln.startswith("[pantax_hip_profile r0]") and ln.rstrip().endswith("ms"):
+            body = ln[len("[pantax_hip_profile r0]"):].rsplit(None, 2)
+            try:
+                out[body[0].strip()] = float(body[1])
+            except (IndexError, ValueError):
+                pass
+    return out
+
+
+def _read_table(path):
+    with open(path) as f:
+        f.readline()
+        return [ln.rstrip("\n").split("\t") for ln in f]
+
+
+def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads):
+    """The wall time the reference itself logs (profile.rs:3326-3327, :3429-3433): profile::profile, FILES to FILES, graph loading
+    included -- here pantax_hip_profile on a real DB directory of this workload (species_range.txt, species_genomes_stats.txt,
+    genomes_info.txt, one bincode `.bin` per species, zip.rs:171-190) + the GAF text.  cold: graphs from the `.bin` files (64-bit
+    values narrowed on their way into the pinned ring); warm: from the device-ready images a run with image_cache = 2 leaves behind.
+    Page cache warm in both (the files were just written).  Never `value`."""
+    from pantax_amd import synth
+    res = {}
+    db = os.path.join(td, "db")
+    os.mkdir(db)
+    t0 = time.perf_counter()
+    synth.write_db(synth.SyntheticSet(species, None), db, write_gfa=False, threads=threads)
+    res["db_written_in_s"] = time.perf_counter() - t0
+    gi = os.path.join(db, "species_graph_info")
+    res["db_bin_gb"] = sum(os.path.getsize(os.path.join(gi, f)) for f in os.listdir(gi)) / 1e9
+    cwd = os.getcwd()
+    eng.set_option("hip_trace", "1")
+
+    def call(name, image_cache):
+        wd = os.path.join(td, name)
+        os.mkdir(wd)
+        os.chdir(wd)
+        try:
+            with _StderrCapture() as cap:
+                t = time.perf_counter()
+                eng.profile(db, wd, gaf_path, zip="serialize", sample_nodes=0, image_cache=image_cache)
+                dt = time.perf_counter() - t
+        finally:
+            os.chdir(cwd)
+        return wd, dt, _seam_phases(cap.text)
+    try:
+        runs = {}
+        call("wd_prime", 0)                                  # allocations, page cache
+        wd_c, t_cold, ph_c = call("wd_cold", 0)
+        _, t_img, _ = call("wd_images", 2)                   # leaves the images behind (not timed as a result)
+        res["db_image_gb"] = sum(os.path.getsize(os.path.join(gi, f)) for f in os.listdir(gi) if f.endswith(".hipdb")) / 1e9
+        warm = [call("wd_warm%d" % i, 1) for i in range(2)]
+        wd_w, t_warm, ph_w = min(warm, key=lambda r: r[1])
+        db_keys = ("graph headers", "db upload")
+        res.update(files_to_tables_cold_s=t_cold, files_to_tables_warm_s=t_warm, files_to_tables_warm_s_both=[r[1] for r in warm],
+                   image_writing_run_s=t_img, db_load_cold_s=sum(ph_c.get(k, 0.0) for k in db_keys) / 1e3, db_load_warm_s=sum(ph_w.get(k, 0.0) for k in db_keys) / 1e3,
+                   gaf_load_s=ph_w.get("ranges + GAF tokenise", 0.0) / 1e3, strain_step_s=ph_w.get("strain step", 0.0) / 1e3,
+                   phases_ms_cold=ph_c, phases_ms_warm=ph_w, mreads_per_s_warm=n_reads / t_warm / 1e6, mreads_per_s_cold=n_reads / t_cold / 1e6)
+        # the tables of the seam against the resident step's (same species order, values to 1e-9) and cold against warm (same bytes)
+        same_bytes = all(open(os.path.join(wd_c, f)).read() == open(os.path.join(wd_w, f)).read() for f in ("species_abundance.txt", "strain_abundance.txt"))
+        tsp = _read_table(os.path.join(wd_w, "species_abundance.txt"))
+        tst = _read_table(os.path.join(wd_w, "strain_abundance.txt"))
+        eq = None
+        if out is not None:
+            sp_rows, st_rows, _ = out
+            close = lambda a, b: abs(a - b) <= 1e-9 * max(1.0, abs(b))
+            eq = len(tsp) == len(sp_rows) and len(tst) == len(st_rows)
+            eq = eq and all(t[0] == r[0] and close(float(t[1]), r[1]) and close(float(t[2]), r[2]) for t, r in zip(tsp, sp_rows))
+            eq = eq and all(t[0] == r[0] and t[2].startswith(r[1]) and close(float(t[3]), r[2]) and close(float(t[4]), r[3]) for t, r in zip(tst, st_rows))
+        res.update(cold_and_warm_tables_same_bytes=same_bytes, tables_equal_to_resident_step=eq, n_strain_rows=len(tst))
+    finally:
+        eng.set_option("hip_trace", None)
+    return res
+
+
 def launch_ranks(n):
     """One node, n ranks: python -m torch.distributed.run ... bench.py <the same arguments>, as a child process."""
     import socket
@@ -523,6 +620,7 @@ def main():
     ap.add_argument("--highs-full-time-limit", type=float, default=120.0, help="time limit of HiGHS on the FULL LP of one species (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gaf", action="store_true", help="skip the from-GAF-text measurement")
+    ap.add_argument("--no-seam", action="store_true", help="skip the files-to-files leg (pantax_hip_profile on a DB directory of the workload)")
     ap.add_argument("--gaf-reads", type=int, default=0, help="reads of the from-GAF-text leg (0 = the whole workload)")
     ap.add_argument("--no-hard", action="store_true", help="skip the pao_hard leg")
     ap.add_argument("--no-l1", action="store_true", help="skip the abundance-L1-vs-oracle leg")
@@ -719,10 +817,14 @@ def main():
         except Exception as e:   # noqa: BLE001 -- the line is printed regardless
             l1 = {"error": "%s: %s" % (type(e).__name__, e)}
     gaf_extra = None
+    seam = None
     if rank == 0 and world == 1 and not args.no_gaf:
         n_gaf = min(n_reads, args.gaf_reads) if args.gaf_reads else n_reads
         grd = synth.head_reads(rd, n_gaf)
         est = 145 * n_gaf                                   # ~144 bytes of text per short read
+        do_seam = not args.no_seam and n_gaf == n_reads
+        if do_seam:                                         # + the DB directory: 8 bytes per node and per path step (.bin), 4 (.hipdb)
+            est += 12 * (sum(g.n_nodes for g in species) + int(sum(int(g.path_off[-1]) for g in species)))
         td_root = gaf_tmp_dir(est)
         if td_root is None:
             gaf_extra = {"error": "no temporary directory with %.1f GB free for the GAF text" % (est / 1e9)}
@@ -763,6 +865,13 @@ def main():
                     del pin, dv
                 except Exception:   # noqa: BLE001
                     pass
+                if do_seam:
+                    try:
+                        eng.lib.pantax_hip_reads_free(eng.ctx, eng.reads)    # the seam loads its own reads and graphs: room in HBM
+                        eng.reads = None
+                        seam = file_seam_leg(eng, species, gp, td, host_threads, out, n_reads)
+                    except Exception as e:   # noqa: BLE001 -- the line is printed regardless
+                        seam = {"error": "%s: %s" % (type(e).__name__, e)}
                 gaf_extra = {"gaf_bytes": gaf_bytes, "reads": n_gaf, "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
                              "end_to_end_s": t_e2e, "end_to_end_ms_of_both_runs": [r[0] * 1e3 for r in runs], "end_to_end_mreads_per_s": n_gaf / t_e2e / 1e6, "gaf_gb_per_s": gaf_bytes / t_load / 1e9,
                              "tables_equal_to_packed_input_run": same, "gaf_written_in_s": write_s, "gaf_dir": td_root,
@@ -885,6 +994,7 @@ def main():
                        highs_10k_rows_seconds=next((l_["highs_seconds"] for l_ in legs if l_.get("rows") == 10000), None),
                        child_alive_during_timed_steps=cpu_child_alive, species_failed=cpu_detail.get("species_failed"), error=cpu_detail.get("error"))
         gx = gaf_extra or {}
+        sx = seam or {}
         line = {
             "metric": "PAO wall-time (s) + Mreads/s, packed reads resident in HBM -> abundance tables (GAF text -> tables: config.from_gaf_text_*)",
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -906,6 +1016,13 @@ def main():
                        "gaf_gb_per_s": gx.get("gaf_gb_per_s"), "pinned_h2d_ceiling_gb_per_s": gx.get("pinned_h2d_ceiling_gb_per_s"),
                        "gaf_gb_per_s_of_ceiling": gx.get("gaf_gb_per_s_of_ceiling"), "tables_equal_to_packed_input_run": gx.get("tables_equal_to_packed_input_run"),
                        "from_gaf_text_error": gx.get("error"),
+                       # the reference's own wall-time definition (profile.rs:3326-3327, :3429-3433): profile::profile files -> files, graph loading
+                       # included; cold = graphs from the bincode .bin files, warm = from device-ready images; page cache warm (never `value`)
+                       "files_to_tables_s": {"cold": sx.get("files_to_tables_cold_s"), "warm": sx.get("files_to_tables_warm_s")},
+                       "files_to_tables_mreads_per_s": {"cold": sx.get("mreads_per_s_cold"), "warm": sx.get("mreads_per_s_warm")},
+                       "db_load_s": {"cold": sx.get("db_load_cold_s"), "warm": sx.get("db_load_warm_s")}, "seam_gaf_load_s": sx.get("gaf_load_s"),
+                       "seam_strain_step_s": sx.get("strain_step_s"), "db_bin_gb": sx.get("db_bin_gb"), "db_image_gb": sx.get("db_image_gb"),
+                       "seam_tables_equal_to_resident_step": sx.get("tables_equal_to_resident_step"), "seam_error": sx.get("error"),
                        # north_star's tolerance: strain abundances against the solver-backed PAO (here: the oracle, == HiGHS on the fixtures)
                        "abundance_l1_vs_oracle": (l1 or {}).get("abundance_l1_vs_oracle"), "abundance_l1_species_checked": (l1 or {}).get("species_checked"),
                        "abundance_l1_tolerance": 1e-4, "abundance_l1_error": (l1 or {}).get("error"),
@@ -922,7 +1039,7 @@ def main():
         line["result"] = {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
                           "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]}
         # everything verbose goes to the side record: the line itself stays well under 8 KB (the driver keeps its tail)
-        detail = {"line": line, "from_gaf_text": gaf_extra, "cpu_baseline": cpu_detail, "pao_hard": hard, "abundance_l1": l1, "roofline_other_kernels": others,
+        detail = {"line": line, "from_gaf_text": gaf_extra, "file_seam": seam, "cpu_baseline": cpu_detail, "pao_hard": hard, "abundance_l1": l1, "roofline_other_kernels": others,
                   "kernels_ms_per_step_all": {k: v[1] / max(n_warm_timed, 1) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
                   "kernel_timer_scopes_per_step": int(sum(v[0] for v in warm.values()) / max(n_warm_timed, 1)),
                   "kernels_ms_per_step_source": "warm-up steps (every launch bracketed by HIP events); the timed steps bracket roofline.kernel, its runner-up and the coverage kernel only",

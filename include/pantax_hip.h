@@ -42,8 +42,17 @@ typedef struct pantax_hip_reads pantax_hip_reads; /* device-resident packed alig
 
 /* Threading: every entry point may be called from any host thread; calls that share a ctx are serialised inside
  * (the reference calls its solver from rayon workers, profile.rs:3297-3304).  Error text is per calling thread. */
-int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices); /* n_devices == 1 */
+/* ONE ctx drives ONE GPU, and a process holds one ctx per GPU it uses: the design is one process per GPU (a Rust host starts N
+ * processes, or N threads with one ctx each).  device_ids / n_devices keep SURVEY 8b's signature; n_devices must be 1, anything
+ * else is PANTAX_HIP_E_INVALID.  The environment is read HERE and nowhere else: every PANTAX_<OPTION> variable sets the option of
+ * that name (lower case) once; afterwards options change only through pantax_hip_set_option -- no entry point calls getenv on its
+ * way, so a host thread that changes the environment beside a running call cannot race with the library. */
+int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices);
 void pantax_hip_destroy(pantax_hip_ctx *ctx);
+/* options of a ctx: "hip_trace" (phase times on stderr), "stage_threads" (host threads that fill the pinned upload ring),
+ * "gaf_piece_bytes", and the switches that force one of the in-tree HIP paths for tests and measurements (pantax_amd/csrc/common.hpp
+ * CtxConfig lists them).  value NULL = the default.  PANTAX_HIP_E_INVALID for an unknown name or an unparsable value. */
+int pantax_hip_set_option(pantax_hip_ctx *ctx, const char *name, const char *value);
 const char *pantax_hip_last_error(const pantax_hip_ctx *ctx); /* ctx may be NULL: init errors */
 const char *pantax_hip_version(void);
 
@@ -60,6 +69,17 @@ typedef struct {
 } pantax_hip_graphs;
 
 int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax_hip_db **out);
+/* the same db from one `Graph` per species as the host holds them after load_from_zip_graph (zip.rs:236-283) -- nothing is
+ * concatenated on the host: the arrays travel species by species through one pinned chunk pipeline, lengths and walks are checked
+ * on the device (length > 0, profile.rs:494; every walk inside its graph, :849) */
+typedef struct {
+    uint64_t n_nodes, n_haps;
+    const int64_t *node_len;    /* [n_nodes] Graph::nodes_len */
+    const uint64_t *path_off;   /* [n_haps+1] local CSR of the walks, haplotypes in BTreeMap (byte) order */
+    const uint32_t *path_nodes; /* [path_off[n_haps] - path_off[0]] species-local 0-based node ids */
+} pantax_hip_graph_part;
+int pantax_hip_db_upload_parts(pantax_hip_ctx *ctx, uint32_t n_species, const int64_t *range_start, const int64_t *range_end,
+                               const pantax_hip_graph_part *parts, pantax_hip_db **out);
 void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db);
 
 /* ---- read side: packed form of the GAF columns rcls.rs:127-137 selects ------------------- */
@@ -377,14 +397,6 @@ int pantax_hip_graph_load(const char *path, int format, pantax_hip_graph **out, 
 int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t *n_haps, const int64_t **node_len,
                           const uint64_t **path_off, const uint32_t **path_nodes, const char *const **hap_names);
 void pantax_hip_graph_free(pantax_hip_graph *g);
-
-/* A prototype of the device GAF load's host side, OFF unless PANTAX_GAF_PRUNE=1 (round 4: it measured slower than the plain
- * load -- the rewrite, not PCIe, then bounds the load): the columns load_gaf_file_lazy drops (rcls.rs:127-137 keeps 1, 2, 6-9,
- * 12) do not travel over PCIe.  Every line that has twelve fields is rewritten with fields 3-5 and 10-11 empty and everything
- * behind field 12 cut off; any other line is copied byte for byte -- so the text parses, field by field, like the original.
- * This entry applies that rewrite to a text in memory (tests, tools); out must hold `size` bytes, *out_size receives the
- * bytes written.  Host only. */
-int pantax_hip_gaf_prune_text(const char *text, uint64_t size, char *out, uint64_t *out_size);
 
 /* the float text of the two tables (polars CsvWriter behind rcls.rs:409-420: shortest round-trip digits, "16.0" for integral
  * values; exemplar rows README.md:343, :354).  Host only.  Returns the length, or < 0. */

@@ -14,14 +14,14 @@ _lib = None
 
 # every symbol include/pantax_hip.h declares
 SYMBOLS = [
-    "pantax_hip_init", "pantax_hip_destroy", "pantax_hip_last_error", "pantax_hip_version",
-    "pantax_hip_db_upload", "pantax_hip_db_free", "pantax_hip_reads_upload", "pantax_hip_reads_free",
+    "pantax_hip_init", "pantax_hip_destroy", "pantax_hip_last_error", "pantax_hip_version", "pantax_hip_set_option",
+    "pantax_hip_db_upload", "pantax_hip_db_upload_parts", "pantax_hip_db_free", "pantax_hip_reads_upload", "pantax_hip_reads_free",
     "pantax_hip_bin_reads", "pantax_hip_species_profile", "pantax_hip_db_reset", "pantax_hip_abundance_filter",
     "pantax_hip_trio_index", "pantax_hip_trio_get", "pantax_hip_node_coverage",
     "pantax_hip_strain_profile", "pantax_hip_pao_solve", "pantax_hip_pao_solve_batch", "pantax_hip_profile", "pantax_hip_profile_step", "pantax_hip_profile_step_enqueue", "pantax_hip_profile_step_collect", "pantax_hip_trio_index_prefetch", "pantax_hip_sort_rows",
     "pantax_hip_sample_ranks", "pantax_hip_chacha_block", "pantax_hip_gaf_filter", "pantax_hip_db_save_images", "pantax_hip_db_load_images",
     "pantax_hip_gaf_load", "pantax_hip_gaf_load_device", "pantax_hip_reads_load_gaf", "pantax_hip_reads_set_flags", "pantax_hip_gaf_view", "pantax_hip_gaf_free",
-    "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free", "pantax_hip_format_f64", "pantax_hip_gaf_prune_text",
+    "pantax_hip_graph_load", "pantax_hip_graph_view", "pantax_hip_graph_free", "pantax_hip_format_f64",
     "pantax_hip_reads_route_pack", "pantax_hip_route_buffer", "pantax_hip_route_free", "pantax_hip_reads_from_routed",
     "pantax_hip_timing_enable", "pantax_hip_timing_filter", "pantax_hip_timing_reset", "pantax_hip_timing_get", "pantax_hip_sync",
 ]
@@ -37,6 +37,10 @@ class Graphs(C.Structure):
     _fields_ = [("n_species", C.c_uint32), ("range_start", C.c_void_p), ("range_end", C.c_void_p),
                 ("node_off", C.c_void_p), ("node_len", C.c_void_p), ("hap_off", C.c_void_p),
                 ("path_off", C.c_void_p), ("path_nodes", C.c_void_p)]
+
+
+class GraphPart(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_haps", C.c_uint64), ("node_len", C.c_void_p), ("path_off", C.c_void_p), ("path_nodes", C.c_void_p)]
 
 
 class PackedReads(C.Structure):

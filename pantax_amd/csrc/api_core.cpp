@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <string>
 #include "common.hpp"
 
 using namespace ptx;
@@ -46,27 +47,52 @@ int pantax_hip_db_upload(pantax_hip_ctx *ctx, const pantax_hip_graphs *g, pantax
     // full db: one part per species, pointing into the caller's flat arrays
     std::vector<GraphPart> parts(S);
     for (uint32_t s = 0; s < S; ++s) {
-        const uint64_t h0 = g->hap_off[s], h1 = g->hap_off[s + 1];
-        parts[s] = GraphPart{g->node_len + g->node_off[s], g->node_off[s + 1] - g->node_off[s], h1 - h0, g->path_off + h0, g->path_nodes + g->path_off[h0]};
+        const uint64_t h0 = g->hap_off[s], h1 = g->hap_off[s + 1], nn = g->node_off[s + 1] - g->node_off[s];
+        GraphPart &pt = parts[s];
+        pt.n_nodes = nn; pt.n_haps = h1 - h0; pt.path_off = g->path_off + h0;
+        pt.len_seg.src = g->node_len + g->node_off[s]; pt.len_seg.out_bytes = 4 * nn; pt.len_seg.narrow = true;
+        UploadSeg w;
+        w.src = g->path_nodes + g->path_off[h0]; w.out_bytes = 4 * (g->path_off[h1] - g->path_off[h0]);
+        pt.walk_segs.push_back(w);
     }
     db.reset();
-    return db_upload_parts(ctx, S, g->range_start, g->range_end, parts.data(), out);
+    return db_upload_parts(ctx, S, g->range_start, g->range_end, parts.data(), nullptr, out);
+}
+
+int pantax_hip_db_upload_parts(pantax_hip_ctx *ctx, uint32_t n_species, const int64_t *range_start, const int64_t *range_end,
+                               const pantax_hip_graph_part *gp, pantax_hip_db **out) {
+    if (!ctx || !range_start || !range_end || !gp || !out || n_species == 0) return PANTAX_HIP_E_INVALID;
+    *out = nullptr;
+    PTX_ENTER(ctx);
+    std::vector<GraphPart> parts(n_species);
+    for (uint32_t s = 0; s < n_species; ++s) {
+        if (!gp[s].path_off || (gp[s].n_nodes && !gp[s].node_len)) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload_parts: species %u has a null array", s);
+        GraphPart &pt = parts[s];
+        pt.n_nodes = gp[s].n_nodes; pt.n_haps = gp[s].n_haps; pt.path_off = gp[s].path_off;
+        pt.len_seg.src = gp[s].node_len; pt.len_seg.out_bytes = 4 * gp[s].n_nodes; pt.len_seg.narrow = true;
+        UploadSeg w;
+        w.src = gp[s].path_nodes; w.out_bytes = 4 * (gp[s].path_off[gp[s].n_haps] - gp[s].path_off[0]);
+        if (w.out_bytes && !w.src) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload_parts: species %u has a null array", s);
+        pt.walk_segs.push_back(w);
+    }
+    return db_upload_parts(ctx, n_species, range_start, range_end, parts.data(), nullptr, out);
 }
 
 }  // extern "C"
 
 namespace ptx {
 
-// The resident DB from one part per species (the file seam hands over its parsed graphs as they are: nothing is
-// concatenated on the host).  part.path_off[h] - part.path_off[0] indexes part.path_nodes.
-int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out) {
+// The resident DB from one part per species (the file seam hands over where every species' arrays lie: nothing is parsed,
+// concatenated or checked on the host).  part.path_off[h] - part.path_off[0] indexes the species' walks.
+int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, const std::string *files,
+                    pantax_hip_db **out) {
     std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
     db->S = S;
-    const int n_thr = 8;
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const bool trace = ctx->cfg.trace;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
@@ -111,142 +137,59 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         for (uint64_t h = db->h_hap_off[i]; h < db->h_hap_off[i + 1]; ++h) hap_species[h] = i;
     }
     node_base[S] = (uint32_t)db->V;
-    bool from_images = S > 0;
-    for (uint32_t s = 0; s < S; ++s) from_images = from_images && parts[s].fd >= 0 && parts[s].node_len32 != nullptr;
-    if (from_images) {
-        // device-ready images: the arrays stream from the files into HBM (pread into the pinned chunks) and the node
-        // tables, the zero-length and the walk checks run on the device
-        std::vector<uint64_t> sp_bits(S + 1, 0);
-        for (uint32_t s = 0; s < S; ++s) {
-            if (parts[s].n_bases >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u has %llu graph bases; images take < 2^32 per species", s, (unsigned long long)parts[s].n_bases);
-            sp_bits[s + 1] = sp_bits[s] + parts[s].n_bases;
-        }
-        db->L = sp_bits[S];
-        if (db->L >= NODE_REC_MAX_BITS) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu graph bases on one GPU (limit 2^40)", (unsigned long long)db->L);
-        PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
-        PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
-        PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
-        PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
-        PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
-        PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
-        PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
-        PTX_HIP(ctx, db->d_bit_off.alloc(db->V + 1)); PTX_HIP(ctx, db->d_node_len.alloc(db->V)); PTX_HIP(ctx, db->d_node_rec.alloc(db->V));
-        PTX_HIP(ctx, db->d_path_nodes.alloc(db->P));
-        for (uint32_t s = 0; s < S; ++s) {
-            const uint64_t q0 = db->h_path_off[db->h_hap_off[s]], q1 = db->h_path_off[db->h_hap_off[s + 1]];
-            PTX_TRY(upload_file(ctx, db->d_node_len.p + db->h_node_off[s], parts[s].fd, parts[s].off_node_len, parts[s].n_nodes * sizeof(uint32_t)));
-            PTX_TRY(upload_file(ctx, db->d_path_nodes.p + q0, parts[s].fd, parts[s].off_path_nodes, (q1 - q0) * sizeof(uint32_t)));
-        }
-        lap("image arrays -> HBM");
-        DevBuf<uint32_t> d_flags;
-        PTX_HIP(ctx, d_flags.alloc(2));
-        PTX_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(d_flags.p + 1, 0xFF, sizeof(uint32_t), ctx->stream));
-        PTX_TRY(node_tables_launch(ctx, db.get(), sp_bits.data(), d_flags.p));
-        uint32_t fl[2] = {0, 0};
-        PTX_TRY(download(ctx, fl, d_flags.p, 2));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (fl[0]) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a graph image holds a node of length 0 (reference asserts > 0, profile.rs:494)");
-        if (fl[1] != 0xFFFFFFFFu) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %u walks a node outside its species graph", fl[1] - 1);
-        lap("node tables + walk check (device)");
-    } else {
-    // node tables: lengths checked, bit offsets (one coverage bit per graph base), the packed node record.  Species
-    // by species on a few threads: sums first, then every species fills its slice from its own base.
-    std::unique_ptr<uint64_t[]> bit_off(new uint64_t[db->V + 1]);
-    std::unique_ptr<uint32_t[]> len32(new uint32_t[db->V ? db->V : 1]);
-    std::unique_ptr<uint4[]> nrec(new uint4[db->V ? db->V : 1]);
-    std::vector<uint64_t> sp_bits(S + 1, 0);
-    std::vector<int64_t> bad_node(S, -1);
-    parallel_for(S, n_thr, [&](uint64_t s0, uint64_t s1) {
-        for (uint64_t s = s0; s < s1; ++s) {
-            uint64_t sum = 0;
-            for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
-                const int64_t l = parts[s].len(v);
-                if ((l <= 0 || l > 0xFFFFFFFFll) && bad_node[s] < 0) bad_node[s] = (int64_t)v;
-                sum += (uint64_t)l;
-            }
-            sp_bits[s + 1] = sum;
-        }
-    });
-    for (uint32_t s = 0; s < S; ++s) {
-        if (bad_node[s] >= 0) {
-            const int64_t l = parts[s].len((uint64_t)bad_node[s]);
-            const unsigned long long v = (unsigned long long)(db->h_node_off[s] + (uint64_t)bad_node[s]);
-            if (l <= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: node %llu has length %lld (reference asserts > 0, profile.rs:494)", v, (long long)l);
-            return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: node %llu longer than 2^32", v);
-        }
-        sp_bits[s + 1] += sp_bits[s];
-    }
-    db->L = sp_bits[S];
-    if (db->L >= NODE_REC_MAX_BITS) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu graph bases on one GPU (limit 2^40)", (unsigned long long)db->L);
-    bit_off[db->V] = db->L;
-    parallel_for(S, n_thr, [&](uint64_t s0, uint64_t s1) {
-        for (uint64_t s = s0; s < s1; ++s) {
-            uint64_t bo = sp_bits[s];
-            const uint64_t vb = db->h_node_off[s];
-            for (uint64_t v = 0; v < parts[s].n_nodes; ++v) {
-                const uint32_t l = (uint32_t)parts[s].len(v);
-                bit_off[vb + v] = bo;
-                len32[vb + v] = l;
-                nrec[vb + v] = nr_make(bo, l);
-                bo += l;
-            }
-        }
-    });
-    lap("node tables");
-    {   // every walk stays inside its species' graph (profile.rs:849 would panic)
-        std::vector<uint64_t> bad(db->H, ~0ull);
-        parallel_for(db->H, n_thr, [&](uint64_t h0, uint64_t h1) {
-            for (uint64_t h = h0; h < h1; ++h) {
-                const uint32_t s = hap_species[h];
-                const GraphPart &pt = parts[s];
-                const uint64_t lh = h - db->h_hap_off[s];
-                const uint32_t *pn = pt.path_nodes + (pt.path_off[lh] - pt.path_off[0]);
-                const uint64_t len = pt.path_off[lh + 1] - pt.path_off[lh];
-                uint32_t mx = 0;
-                for (uint64_t q = 0; q < len; ++q) mx = std::max(mx, pn[q]);
-                if (len && mx >= pt.n_nodes) bad[h] = mx;
-            }
-        });
-        for (uint64_t h = 0; h < db->H; ++h)
-            if (bad[h] != ~0ull) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %llu walks node %u outside its species graph", (unsigned long long)h, (uint32_t)bad[h]);
-    }
-    lap("walk check");
     PTX_TRY(upload(ctx, db->d_rng_start, rs.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_end, re.data(), S));
     PTX_TRY(upload(ctx, db->d_rng_idx, order.data(), S));
     PTX_TRY(upload(ctx, db->d_sp_first_id, first_id.data(), S));
     PTX_TRY(upload(ctx, db->d_node_base, node_base.data(), S + 1));
+    PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
+    PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
+    PTX_TRY(upload(ctx, db->d_hap_off, db->h_hap_off.data(), S + 1));
+    db->h_all_same.assign(S, 0);
+    for (uint32_t s = 0; s < S; ++s) db->h_all_same[s] = parts[s].n_haps >= 2;   // until a walk differs (walks_same_kernel)
+    PTX_TRY(upload(ctx, db->d_all_same, db->h_all_same.data(), S));
     PTX_HIP(ctx, db->d_bit_off.alloc(db->V + 1)); PTX_HIP(ctx, db->d_node_len.alloc(db->V)); PTX_HIP(ctx, db->d_node_rec.alloc(db->V));
     PTX_HIP(ctx, db->d_path_nodes.alloc(db->P));
-    PTX_TRY(upload_big(ctx, db->d_bit_off.p, bit_off.get(), (db->V + 1) * sizeof(uint64_t)));
-    PTX_TRY(upload_big(ctx, db->d_node_len.p, len32.get(), db->V * sizeof(uint32_t)));
-    PTX_TRY(upload_big(ctx, db->d_node_rec.p, nrec.get(), db->V * sizeof(uint4)));
-    for (uint32_t s = 0; s < S; ++s) {
-        const uint64_t q0 = db->h_path_off[db->h_hap_off[s]], q1 = db->h_path_off[db->h_hap_off[s + 1]];
-        PTX_TRY(upload_big(ctx, db->d_path_nodes.p + q0, parts[s].path_nodes, (q1 - q0) * sizeof(uint32_t)));
-    }
-        PTX_TRY(upload(ctx, db->d_path_off, db->h_path_off.data(), db->H + 1));
-        PTX_TRY(upload(ctx, db->d_hap_species, hap_species.data(), db->H));
-        lap("uploads");
-    }
-    PTX_TRY(upload(ctx, db->d_hap_off, db->h_hap_off.data(), S + 1));
-    {   // identical-walk test of first_filter_paths (profile.rs:1188-1190) is a property of the graphs: done once
-        db->h_all_same.assign(S, 0);
+    {   // the two big arrays: every species' stretch of them, back to back, through ONE chunk pipeline each
+        std::vector<UploadSeg> segs;
+        std::vector<uint32_t> seg_species;
         for (uint32_t s = 0; s < S; ++s) {
-            const GraphPart &pt = parts[s];
-            if (pt.n_haps < 2) continue;
-            if (pt.all_same >= 0) { db->h_all_same[s] = pt.all_same != 0; continue; }   // stated by the image
-            bool same = true;
-            const uint64_t l0 = pt.path_off[1] - pt.path_off[0];
-            for (uint64_t h = 1; h < pt.n_haps && same; ++h) {
-                const uint64_t q = pt.path_off[h] - pt.path_off[0], l = pt.path_off[h + 1] - pt.path_off[h];
-                if (l != l0 || std::memcmp(pt.path_nodes + q, pt.path_nodes, l0 * sizeof(uint32_t)) != 0) same = false;
-            }
-            db->h_all_same[s] = same;
+            if (parts[s].len_seg.out_bytes != 4 * parts[s].n_nodes) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the node lengths do not cover its %llu nodes", s, (unsigned long long)parts[s].n_nodes);
+            segs.push_back(parts[s].len_seg); seg_species.push_back(s);
         }
-        PTX_TRY(upload(ctx, db->d_all_same, db->h_all_same.data(), S));
+        int64_t bad = -1;
+        PTX_TRY(upload_segments(ctx, db->d_node_len.p, segs.data(), segs.size(), files, &bad));
+        if (bad >= 0) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u holds a node of negative length or longer than 2^32 - 1 (reference asserts > 0, profile.rs:494)", seg_species[bad]);
+        segs.clear(); seg_species.clear();
+        for (uint32_t s = 0; s < S; ++s) {
+            uint64_t bytes = 0;
+            for (const UploadSeg &w : parts[s].walk_segs) { segs.push_back(w); seg_species.push_back(s); bytes += w.out_bytes; }
+            if (bytes != 4 * (db->h_path_off[db->h_hap_off[s + 1]] - db->h_path_off[db->h_hap_off[s]]))
+                return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the walks do not cover its path steps", s);
+        }
+        PTX_TRY(upload_segments(ctx, db->d_path_nodes.p, segs.data(), segs.size(), files, &bad));
+        if (bad >= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a haplotype of species %u walks a node index beyond 2^32", seg_species[bad]);
     }
+    lap("graph arrays -> HBM");
+    {   // node tables, the zero-length check, the walk check and the identical-walk test (first_filter_paths, profile.rs:1188-1190:
+        // a property of the graphs, done once) on the device
+        DevBuf<uint32_t> d_flags;
+        PTX_HIP(ctx, d_flags.alloc(2));
+        PTX_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(d_flags.p + 1, 0xFF, sizeof(uint32_t), ctx->stream));
+        PTX_TRY(node_tables_launch(ctx, db.get(), d_flags.p));
+        uint32_t fl[2] = {0, 0};
+        uint64_t L = 0;
+        PTX_TRY(download(ctx, fl, d_flags.p, 2));
+        PTX_TRY(download(ctx, &L, db->d_bit_off.p + db->V, 1));
+        PTX_TRY(download(ctx, db->h_all_same.data(), db->d_all_same.p, S));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl[0]) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a graph holds a node of length 0 (reference asserts > 0, profile.rs:494)");
+        if (fl[1] != 0xFFFFFFFFu) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: hap %u walks a node outside its species graph", fl[1] - 1);
+        db->L = L;
+        if (db->L >= NODE_REC_MAX_BITS) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu graph bases on one GPU (limit 2^40)", (unsigned long long)db->L);
+    }
+    lap("node tables + checks (device)");
     {   // path tiles, ordered (species, chunk group, hap, chunk in group): workgroup b runs on XCD b % 8, so the
         // tiles of ONE chunk (all haplotypes, largely collinear: same node buckets, same path neighbourhood) get
         // workgroup ids that are congruent mod 8 -- their bucket / mask writes meet in one XCD's L2 instead of

@@ -6,7 +6,6 @@
 #include <vector>
 #include "../../include/pantax_hip.h"
 #include "host_io.hpp"
-namespace ptx { uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out); }   // gaf_prune.cc
 
 using namespace ptx;
 
@@ -73,12 +72,6 @@ int pantax_hip_graph_view(const pantax_hip_graph *g, uint64_t *n_nodes, uint64_t
     return 0;
 }
 void pantax_hip_graph_free(pantax_hip_graph *g) { delete g; }
-
-int pantax_hip_gaf_prune_text(const char *text, uint64_t size, char *out, uint64_t *out_size) {
-    if ((!text && size) || !out || !out_size) return PANTAX_HIP_E_INVALID;
-    *out_size = size ? ptx::gaf_prune_range(reinterpret_cast<const uint8_t *>(text), size, 0, size, true, reinterpret_cast<uint8_t *>(out)) : 0;
-    return 0;
-}
 
 int pantax_hip_format_f64(double v, char *buf, size_t cap) {
     if (!buf || cap == 0) return PANTAX_HIP_E_INVALID;

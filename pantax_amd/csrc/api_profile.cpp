@@ -117,7 +117,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     mkdir(out_dir.c_str(), 0777);
 
     // PANTAX_HIP_TRACE=1: wall time of each phase on stderr (the reference logs its phases through env_logger)
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const bool trace = ctx->cfg.trace;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -554,9 +554,14 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     }
     // everything a rank does on its own shard; a failure here must not leave the other ranks waiting in the exchange below
     auto shard = [&]() -> int {
-    // image_cache >= 1: device-ready images <db>/species_graph_info/<otu>.hipdb (db_image.cpp) stand in for
-    // the graph files AND the per-run unique-trio index when every selected species has one that is not older than its
-    // source; otherwise the graphs are parsed as usual (and, with image_cache == 2, the images are written afterwards)
+    // Where every selected species' graph comes from (optimize_otu's file choice, profile.rs:2888-2932), decided species by species on
+    // a few dozen threads that read HEADERS only:
+    //   image_cache >= 1 and a device-ready image <db>/species_graph_info/<otu>.hipdb that is not older than its source (SURVEY 8f-2,
+    //     db_image.cpp): the arrays stream from the image;
+    //   zip "serialize" and <otu>.bin: the arrays stream from the bincode file itself, 64-bit values narrowed on their way into the
+    //     pinned ring (scan_graph_bin finds them with a dozen small reads; round 4 parsed every file into host vectors on 8 threads);
+    //   "lz" / "zstd" containers and GFA text: decoded / parsed into host memory first, then the same pipeline.
+    // With image_cache == 2 the species that did not come from an image leave one behind after the run.
     auto source_of = [&](const std::string &otu) {
         const std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
         if (zip == "serialize" && is_file(bin)) return bin;
@@ -565,48 +570,45 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         return join(join(db_dir, "species_gfa"), otu + ".gfa");
     };
     auto image_of = [&](const std::string &otu) { return join(join(db_dir, "species_graph_info"), otu + ".hipdb"); };
-    std::vector<std::unique_ptr<SpeciesImage>> images(Ss);
-    bool use_images = cfg->image_cache >= 1 && Ss > 0;
-    if (use_images) {
-        std::vector<uint8_t> ok(Ss, 0);
-        parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
-            for (uint64_t i = i0; i < i1; ++i) {
-                if (owner[i] != rk) { ok[i] = 1; continue; }                                     // another rank's species
-                const std::string &otu = ranges[sel[i]].species;
-                const std::string img = image_of(otu);
-                if (!is_file(img) || file_mtime(img) < file_mtime(source_of(otu))) continue;
-                images[i].reset(new SpeciesImage());
-                if (!images[i]->open(img).empty()) continue;                                   // unreadable image: parse instead
-                ok[i] = (int64_t)images[i]->V == ranges[sel[i]].end - ranges[sel[i]].start + 1;
-            }
-        });
-        for (uint32_t i = 0; i < Ss; ++i) use_images = use_images && ok[i];
-        if (!use_images) for (auto &im : images) im.reset();
-    }
-    if (!use_images) {   // the graph files are independent: parsed by a few threads; the first problem in species order is reported
-        std::vector<std::string> hard(Ss);   // errors that end the run
-        parallel_for(Ss, 8, [&](uint64_t i0, uint64_t i1) {
+    struct Source { int kind = 0; /* 0 none, 1 image, 2 streamed .bin, 3 host graph */ SpeciesImage img; BinIndex bin; std::string bin_path; std::vector<uint64_t> path_off; };
+    std::vector<Source> src(Ss);
+    {
+        std::vector<std::string> hard(Ss);   // errors that end the run; the first one in species order is reported
+        const int n_thr = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / (unsigned)std::max(1, W)));
+        parallel_for(Ss, n_thr, [&](uint64_t i0, uint64_t i1) {
             for (uint64_t i = i0; i < i1; ++i) {
                 if (owner[i] != rk) { loaded[i] = 0; continue; }                                 // another rank's species
                 const std::string &otu = ranges[sel[i]].species;
-                std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
-                std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
+                const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
+                Source &sc = src[i];
+                if (cfg->image_cache >= 1) {
+                    const std::string img = image_of(otu);
+                    if (is_file(img) && file_mtime(img) >= file_mtime(source_of(otu)) && sc.img.open(img).empty() && (int64_t)sc.img.V == nvert) { sc.kind = 1; continue; }
+                }
+                const std::string gfa = join(join(db_dir, "species_gfa"), otu + ".gfa");
+                const std::string bin = join(join(db_dir, "species_graph_info"), otu + ".bin");
                 const std::string lz = bin + ".lz4", zst = bin + ".zst";
                 std::string e2;
-                if (zip == "serialize" && is_file(bin)) e2 = read_graph_bin(bin, graphs[i]);
-                else if (zip == "lz" && is_file(lz)) e2 = read_graph_zip(lz, 2, graphs[i]);
-                else if (zip == "zstd" && is_file(zst)) e2 = read_graph_zip(zst, 3, graphs[i]);
-                else if (is_file(gfa)) e2 = read_gfa(gfa, graphs[i]);
+                uint64_t n_nodes = 0;
+                if (zip == "serialize" && is_file(bin)) {
+                    e2 = scan_graph_bin(bin, sc.bin);
+                    if (e2.empty() && sc.bin.names_ascending) {
+                        sc.kind = 2; sc.bin_path = bin; n_nodes = sc.bin.V;
+                        sc.path_off.assign(sc.bin.walk_len.size() + 1, 0);
+                        for (size_t h = 0; h < sc.bin.walk_len.size(); ++h) sc.path_off[h + 1] = sc.path_off[h] + sc.bin.walk_len[h];
+                    } else if (e2.empty()) { e2 = read_graph_bin(bin, graphs[i]); sc.kind = 3; n_nodes = graphs[i].node_len.size(); }   // keys out of order: the general parser sorts them
+                } else if (zip == "lz" && is_file(lz)) { e2 = read_graph_zip(lz, 2, graphs[i]); sc.kind = 3; n_nodes = graphs[i].node_len.size(); }
+                else if (zip == "zstd" && is_file(zst)) { e2 = read_graph_zip(zst, 3, graphs[i]); sc.kind = 3; n_nodes = graphs[i].node_len.size(); }
+                else if (is_file(gfa)) { e2 = read_gfa(gfa, graphs[i]); sc.kind = 3; n_nodes = graphs[i].node_len.size(); }
                 else { hard[i] = "gfa information file " + gfa + " does not exist. Please check database."; continue; }
-                if (!e2.empty()) { loaded[i] = 0; continue; }            // "GFA read error" => species skipped (.ok()?)
-                const int64_t nvert = ranges[sel[i]].end - ranges[sel[i]].start + 1;
-                if ((int64_t)graphs[i].node_len.size() != nvert)
-                    hard[i] = "species " + otu + ": graph has " + std::to_string(graphs[i].node_len.size()) + " nodes but its range spans " + std::to_string((long long)nvert);
+                if (!e2.empty()) { loaded[i] = 0; sc.kind = 0; continue; }            // "GFA read error" => species skipped (.ok()?)
+                if ((int64_t)n_nodes != nvert)
+                    hard[i] = "species " + otu + ": graph has " + std::to_string(n_nodes) + " nodes but its range spans " + std::to_string((long long)nvert);
             }
         });
         for (uint32_t i = 0; i < Ss; ++i) if (!hard[i].empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", hard[i].c_str());
     }
-    lap("graph load");
+    lap("graph headers");
     for (uint32_t i = 0; i < Ss; ++i) if (loaded[i] && owner[i] == rk) use.push_back(i);
     Su = (uint32_t)use.size();
     info.assign(Su, pantax_hip_solve_info{});
@@ -614,18 +616,40 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     if (Su) {
         std::vector<int64_t> g_rs(Su), g_re(Su);
         std::vector<GraphPart> parts(Su);
-        std::vector<const SpeciesImage *> imp(Su);
-        for (uint32_t k = 0; k < Su; ++k) {   // the parsed graphs go to the device as they are: one part per species
-            g_rs[k] = ranges[sel[use[k]]].start; g_re[k] = ranges[sel[use[k]]].end;
-            const std::vector<std::string> &names = use_images ? images[use[k]]->hap_names : graphs[use[k]].hap_names;
-            if (use_images) imp[k] = images[use[k]].get();
-            else { const HostGraph &hg = graphs[use[k]]; parts[k] = GraphPart{hg.node_len.data(), hg.node_len.size(), hg.hap_names.size(), hg.path_off.data(), hg.path_nodes.data()}; }
-            hap_names.insert(hap_names.end(), names.begin(), names.end());
+        std::vector<std::string> files(Su);
+        for (uint32_t k = 0; k < Su; ++k) {   // one part per species: where its two arrays lie
+            const uint32_t i = use[k];
+            g_rs[k] = ranges[sel[i]].start; g_re[k] = ranges[sel[i]].end;
+            const Source &sc = src[i];
+            GraphPart &pt = parts[k];
+            const std::vector<std::string> *names = nullptr;
+            if (sc.kind == 1) {
+                files[k] = sc.img.path; names = &sc.img.hap_names;
+                pt.n_nodes = sc.img.V; pt.n_haps = sc.img.H; pt.path_off = sc.img.path_off.data();
+                pt.len_seg.file = (int32_t)k; pt.len_seg.file_off = sc.img.off_node_len; pt.len_seg.out_bytes = 4 * sc.img.V;
+                UploadSeg w; w.file = (int32_t)k; w.file_off = sc.img.off_path_nodes; w.out_bytes = 4 * sc.img.P;
+                pt.walk_segs.push_back(w);
+            } else if (sc.kind == 2) {
+                files[k] = sc.bin_path; names = &sc.bin.hap_names;
+                pt.n_nodes = sc.bin.V; pt.n_haps = sc.bin.hap_names.size(); pt.path_off = sc.path_off.data();
+                pt.len_seg.file = (int32_t)k; pt.len_seg.file_off = sc.bin.off_node_len; pt.len_seg.out_bytes = 4 * sc.bin.V; pt.len_seg.narrow = true;
+                for (size_t h = 0; h < sc.bin.walk_len.size(); ++h) {
+                    UploadSeg w; w.file = (int32_t)k; w.file_off = sc.bin.walk_off[h]; w.out_bytes = 4 * sc.bin.walk_len[h]; w.narrow = true;
+                    pt.walk_segs.push_back(w);
+                }
+            } else {
+                const HostGraph &hg = graphs[i];
+                names = &hg.hap_names;
+                pt.n_nodes = hg.node_len.size(); pt.n_haps = hg.hap_names.size(); pt.path_off = hg.path_off.data();
+                pt.len_seg.src = hg.node_len.data(); pt.len_seg.out_bytes = 4 * hg.node_len.size(); pt.len_seg.narrow = true;
+                UploadSeg w; w.src = hg.path_nodes.data(); w.out_bytes = 4 * hg.path_nodes.size();
+                pt.walk_segs.push_back(w);
+            }
+            hap_names.insert(hap_names.end(), names->begin(), names->end());
             hap_off[k + 1] = hap_names.size();
         }
         DbHolder sdb{ctx};
-        if (use_images) PTX_TRY(db_from_images(ctx, Su, imp.data(), g_rs.data(), g_re.data(), &sdb.db));   // trio index included
-        else PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), &sdb.db));
+        PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), files.data(), &sdb.db));
         lap("db upload");
         // the same resident reads with the strain-level drop flags; species binned against the selected ranges
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
@@ -643,9 +667,12 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         met.resize(hap_names.size());
         PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data(), met.data(), info.data()));
         lap("strain step");
-        if (!use_images && cfg->image_cache == 2) {   // leave images behind for the next run
+        if (cfg->image_cache == 2) {   // leave images behind for the next run
             for (uint32_t k = 0; k < Su; ++k)
-                PTX_TRY(db_save_image(ctx, sdb.db, k, graphs[use[k]].hap_names, image_of(ranges[sel[use[k]]].species)));
+                if (src[use[k]].kind != 1) {
+                    const std::vector<std::string> names(hap_names.begin() + (ptrdiff_t)hap_off[k], hap_names.begin() + (ptrdiff_t)hap_off[k + 1]);
+                    PTX_TRY(db_save_image(ctx, sdb.db, k, names, image_of(ranges[sel[use[k]]].species)));
+                }
             lap("graph images written");
         }
     }

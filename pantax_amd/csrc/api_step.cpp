@@ -35,12 +35,12 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     const auto t_begin = std::chrono::steady_clock::now();
     double marks[8] = {0}; int n_marks = 0;
     auto mark = [&]() { if (n_marks < 8) marks[n_marks++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    struct SlowReport { double *m; int *n; ~SlowReport() {
-        if (*n && m[*n - 1] > 2.0 && std::getenv("PANTAX_HIP_TRACE")) {
+    struct SlowReport { double *m; int *n; bool on; ~SlowReport() {
+        if (*n && m[*n - 1] > 2.0 && on) {
             std::fprintf(stderr, "[step_enqueue] slow call, ms at marks (trio enqueued, bin+species, prezero+cov prepare, coverage, strain):");
             for (int i = 0; i < *n; ++i) std::fprintf(stderr, " %.2f", m[i]);
             std::fprintf(stderr, "\n");
-        } } } slow_report{marks, &n_marks};
+        } } } slow_report{marks, &n_marks, ctx->cfg.trace};
     // a7 first, on the side stream: the unique-trio index depends on the graphs only (the reference rebuilds it every
     // run, profile.rs:2936), so it is built while the main stream bins the reads and takes the species decision
     bool forked = false;
@@ -50,7 +50,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
         // the previous step still reads the index this build replaces -- up to its first filter (strain_enqueue records the event
         // behind it); what follows there (masks, row sort, LPs, objective) runs beside the rebuild.  Without such an event
         // (stage calls in between) the side stream waits for everything enqueued so far.
-        if (db->trio_free_valid && !std::getenv("PANTAX_TRIO_AFTER_STEP")) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
+        if (db->trio_free_valid && !ctx->cfg.trio_after_step) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
         else {
             PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));
             PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));
@@ -91,7 +91,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     // a8 needs both
     if (forked) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     fork_guard.armed = false;   // joined: everything later on the main stream is ordered behind the index
-    PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true, std::getenv("PANTAX_COV_COUNT") == nullptr));   // (PANTAX_COV_COUNT=1: popcount_kernel as in the stage call)
+    PTX_TRY(coverage_launch(ctx, db, reads, db->d_active.p, true, !ctx->cfg.cov_count));   // (PANTAX_COV_COUNT=1: popcount_kernel as in the stage call)
     mark();
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,
@@ -134,7 +134,7 @@ extern "C" int pantax_hip_trio_index_prefetch(pantax_hip_ctx *ctx, pantax_hip_db
     PTX_ENTER(ctx);
     if (db->d_node_rec.p == nullptr) return fail(ctx, PANTAX_HIP_E_STATE, "trio_index_prefetch: the db was uploaded without graphs (ranges only)");
     db->trio_built = false; db->cov_done = false; db->U = 0; db->trio_prefetched = false;
-    if (db->trio_free_valid && !std::getenv("PANTAX_TRIO_AFTER_STEP")) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
+    if (db->trio_free_valid && !ctx->cfg.trio_after_step) PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_trio_free, 0));
     else {
         PTX_HIP(ctx, hipEventRecord(ctx->ev_seq, ctx->stream));
         PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_seq, 0));

@@ -107,7 +107,7 @@ int strain_prezero(Ctx *ctx, Db *db) {
     lb.prezeroed = false;
     PTX_TRY(bind_arena(ctx, db, lb, L));
     PTX_HIP(ctx, lb.d_mask.alloc(db->V));
-    if (!use_node_haps(db)) PTX_TRY(zero_fill(ctx, lb.d_mask.p, db->V * sizeof(uint64_t)));   // (the by-node mask kernel writes every word)
+    if (!use_node_haps(ctx, db)) PTX_TRY(zero_fill(ctx, lb.d_mask.p, db->V * sizeof(uint64_t)));   // (the by-node mask kernel writes every word)
     lb.prezeroed = true;
     return 0;
 }
@@ -124,12 +124,12 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     const auto t_begin = std::chrono::steady_clock::now();
     double marks[10] = {0}; int n_marks = 0;
     auto mark = [&]() { if (n_marks < 10) marks[n_marks++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    struct SlowReport { double *m; int *n; ~SlowReport() {
-        if (*n && m[*n - 1] > 2.0 && std::getenv("PANTAX_HIP_TRACE")) {
+    struct SlowReport { double *m; int *n; bool on; ~SlowReport() {
+        if (*n && m[*n - 1] > 2.0 && on) {
             std::fprintf(stderr, "[strain_enqueue] slow call, ms at marks (bind, hap stats, node stats, sample, first filter, lad prepare, lad pair, fetch):");
             for (int i = 0; i < *n; ++i) std::fprintf(stderr, " %.2f", m[i]);
             std::fprintf(stderr, "\n");
-        } } } slow_report{marks, &n_marks};
+        } } } slow_report{marks, &n_marks, ctx->cfg.trace};
     PTX_TRY(bind_arena(ctx, db, lb, L));
     mark();
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
@@ -145,13 +145,19 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     if (!db->ev_trio_free) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_trio_free, hipEventDisableTiming));
     // ... by default from behind the ROW COMPACTION (lad_prepare records the event there): the compaction is a chained scan whose tiles
     // spin on their predecessors, and beside the rebuild's kernels its 3 ms stretched to 9-13 (round 4); PANTAX_TRIO_FREE=filter: from here
-    static const bool free_at_filter = std::getenv("PANTAX_TRIO_FREE") && std::getenv("PANTAX_TRIO_FREE")[0] == 'f';
+    const bool free_at_filter = ctx->cfg.trio_free_at_filter;
     db->trio_free_pending = !free_at_filter;
     if (free_at_filter) { PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream)); db->trio_free_valid = true; }
     mark();
     int pmax_bound = 1;                                                                     // mask bits of a row key: min(#haps, 64) (wide species: a 64-bit hash)
     for (uint32_t s = 0; s < S; ++s) pmax_bound = std::max<int>(pmax_bound, (int)std::min<uint64_t>(db->h_hap_off[s + 1] - db->h_hap_off[s], LAD_MAXP));
-    PTX_TRY(lad_prepare(ctx, db, &lb, true, pmax_bound));                                   // a10 + row grouping
+    {
+        const int rc_prep = lad_prepare(ctx, db, &lb, true, pmax_bound);                   // a10 + row grouping
+        if (rc_prep != 0) {   // failed before it recorded the event: no stale event may order the next step's rebuild (it falls back to ev_seq)
+            db->trio_free_pending = false; db->trio_free_valid = false;
+            return rc_prep;
+        }
+    }
     if (db->trio_free_pending) { PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream)); db->trio_free_valid = true; db->trio_free_pending = false; }
     mark();
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives

@@ -109,8 +109,37 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+// Every switch of the library, read ONCE from the environment by pantax_hip_init (PANTAX_<NAME>, upper case) and changed afterwards only
+// through pantax_hip_set_option: no entry point reads the environment on its way (a host that calls setenv / std::env::set_var beside a
+// running step would race with getenv).  Product switches first; the rest selects in-tree HIP paths for tests and measurements.
+struct CtxConfig {
+    bool trace = false;              // hip_trace: wall time of the phases of the pipeline seam / db upload / GAF load on stderr
+    int stage_threads = 32;          // host threads that fill the pinned upload ring (at 16 the filling, not the DMA, bounds a 15-GB load)
+    int stage_ch_mb = 0;             // chunk size of the ring in MB (0: from the transfer size)
+    bool stream_prio = true;         // main stream at the highest, side stream at the lowest priority
+    uint64_t gaf_piece_bytes = 0;    // largest piece of GAF text tokenised at once (0: a sixth of the text, 64 MiB .. 1 GiB)
+    // forced paths (tests compare them with the defaults)
+    std::string trio_path;           // "block": every species through the node-block kernel; "bucket": global buckets
+    std::string trio_rows;           // "path": lookup rows filed by the pass over the walks
+    int uniq_hash = -1;              // bucket path: 1 LDS hash / 0 shuffles (-1: by mean bucket size)
+    std::string hap_stats;           // "fused" / "chunks"
+    std::string mask;                // "walk": membership masks from the path walk
+    std::string row_sort;            // "radix" / "seg" / "nodes"
+    std::string objective;           // "nodes": the LP objective summed over the nodes
+    bool cov_general = false;        // every group through coverage_step_kernel
+    bool cov_count = false;          // resident step: popcount_kernel as in the stage call
+    // measurement shapes
+    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
+    uint32_t tv_ablate = 0, cov_ablate = 0;
+    uint32_t ssg_wave_rows = 0;
+    bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
+         trio_after_step = false;
+};
+int ctx_set_option(CtxConfig &cfg, const char *name, const char *value);   // 0, or PANTAX_HIP_E_INVALID for an unknown name / unparsable value
+
 struct Ctx {
     std::recursive_mutex mu;         // one call at a time per ctx (PTX_ENTER)
+    CtxConfig cfg;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_main = nullptr;   // the main stream while `stream` is swapped to the side stream (api_step.cpp), else null
@@ -406,19 +435,33 @@ int upload(Ctx *ctx, DevBuf<T> &dst, const T *src, size_t n) {
     if (n) PTX_HIP(ctx, hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
-// one species' graph as the db upload takes it: node lengths, and the walks as a local CSR (path_off may start anywhere)
-struct GraphPart {
-    const int64_t *node_len; uint64_t n_nodes; uint64_t n_haps; const uint64_t *path_off; const uint32_t *path_nodes;
-    const uint32_t *node_len32 = nullptr;   // used instead of node_len when set (device-ready images store 32-bit lengths)
-    // device-ready image (db_image.cpp): the arrays can be streamed from the file, the node tables are derived on the
-    // device, and what the image states about itself is taken as given
-    int fd = -1; uint64_t off_node_len = 0, off_path_nodes = 0; uint64_t n_bases = 0; int all_same = -1;
-    int64_t len(uint64_t v) const { return node_len32 ? (int64_t)node_len32[v] : node_len[v]; }
+// A stretch of a 32-bit device array as it lies on the host: in memory (`src`) or in a file (`file` = index into the paths the
+// upload is given, bytes from `file_off`); `narrow`: the source holds 64-bit little-endian integers (bincode's i64 lengths / usize
+// node ids, zip.rs:171-190) that become 32-bit ones on the way -- a value beyond 2^32 - 1 (or negative) fails the upload.
+struct UploadSeg {
+    const void *src = nullptr;
+    int32_t file = -1;
+    uint64_t file_off = 0;
+    uint64_t out_bytes = 0;   // bytes this stretch occupies on the device (a multiple of 4); the source holds twice as many when narrow
+    bool narrow = false;
 };
-// stage_db.hip: node tables + walk check on the device (image loads), and the move of species-local trio rows
-int node_tables_launch(Ctx *ctx, Db *db, const uint64_t *sp_bits, uint32_t *d_flags);
-int trio_rebase_launch(Ctx *ctx, Db *db, uint32_t s, uint64_t row_base, uint64_t n_rows, uint32_t *d_err /* counts nodes with >= 2^24 lookup rows */);
-int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out);
+// segments back to back -> d_dst, as ONE chunk pipeline through the pinned ring (a crew of host threads fills a chunk -- pread /
+// memcpy / narrowing -- while the chunks before it travel).  *bad_seg (optional) = first segment that held a value beyond 32 bits, or -1.
+int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg);
+
+// one species' graph as the db upload takes it: where its 32-bit node lengths and its walks (32-bit species-local node ids, haplotype
+// after haplotype) come from, and the walks' local CSR offsets (path_off may start anywhere).  Nothing of the big arrays is touched on
+// the host: lengths > 0, walks inside the graph and the identical-walk test are checked on the device (stage_db.hip).
+struct GraphPart {
+    uint64_t n_nodes = 0, n_haps = 0;
+    const uint64_t *path_off = nullptr;
+    UploadSeg len_seg;
+    std::vector<UploadSeg> walk_segs;
+};
+// stage_db.hip: node tables (global prefix of the lengths), walk check and identical-walk test on the device
+int node_tables_launch(Ctx *ctx, Db *db, uint32_t *d_flags /* [2]: {a node of length 0, 1 + first haplotype that leaves its graph (0xFFFFFFFF: none)} */);
+int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, const std::string *files,
+                    pantax_hip_db **out);
 // large pageable host buffers (mmapped text, graph arrays) -> HBM through two pinned chunks: a few threads copy the next
 // chunk into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged
 // by one runtime thread at ~10 GB/s).  Returns after the last chunk has arrived.
@@ -430,14 +473,6 @@ int upload_file(Ctx *ctx, void *d_dst, int fd, uint64_t file_off, uint64_t bytes
 // chunk of piece k has been enqueued (record an event there).  fd >= 0: pread from the file at file_base + offset, else from `text`.
 int upload_text_pieces(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off, const uint64_t *piece_end,
                        hipStream_t stream, const std::function<bool(size_t)> &before_piece, const std::function<int(size_t)> &after_piece);
-// the same with the columns the path never reads left behind (gaf_prune.cc; the text must be in memory -- the mapped file): piece k
-// arrives as pruned_size bytes (<= its size) at d_dst[k], handed to after_piece(k, pruned_size)
-int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off,
-                              const uint64_t *piece_end, hipStream_t stream, const std::function<bool(size_t)> &before_piece,
-                              const std::function<int(size_t, uint64_t)> &after_piece);
-// gaf_prune.cc: the lines that start in [begin, end) of text[0, size) with the unread fields emptied and the tags cut off -> out
-// (at most as many bytes as the lines hold); returns the bytes written
-uint64_t gaf_prune_range(const uint8_t *text, uint64_t size, uint64_t begin, uint64_t end, bool begin_is_line_start, uint8_t *out);
 // fn(begin, end) over [0, n) split across up to n_threads host threads (the calling thread takes the first slice)
 void parallel_for(uint64_t n, int n_threads, const std::function<void(uint64_t, uint64_t)> &fn);
 // small host -> device copies go through the pinned ring (the source may be reused as soon as this returns)
@@ -499,7 +534,7 @@ int trio_first_ensure(Ctx *ctx, Db *db); // d_trio_first (the db images store it
 int trio_visits_build(Ctx *ctx, Db *db); // end of db upload: the visit table (and which species it leaves to the node-block kernel)
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload, after trio_visits_build: the node-block run table of those species
 int node_haps_build(Ctx *ctx, Db *db);   // end of db upload: node -> haplotypes (the LP's membership masks built by node)
-bool use_node_haps(const Db *db);
+bool use_node_haps(const Ctx *ctx, const Db *db);
 struct HostReads;
 // stage_gaf.hip: text -> host columns (+ walks unless `resident` is given, which then owns the packed reads in HBM)
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1, uint64_t file_base = 0, bool group = true,

@@ -11,6 +11,10 @@
 #include <mutex>
 #include <thread>
 #include <unistd.h>
+#include <fcntl.h>
+#include <cctype>
+#include <cstddef>
+#include <cstdlib>
 #include "common.hpp"
 
 namespace ptx {
@@ -80,6 +84,56 @@ int collect_timings(Ctx *ctx) {
     return 0;
 }
 
+// ---- options: one table, filled from the environment at init, changed through pantax_hip_set_option ----
+namespace {
+enum OptKind { O_BOOL, O_INT, O_U32, O_U64, O_STR };
+struct OptDesc { const char *name; OptKind kind; size_t off; };
+#define OPT(nm, kind, field) {nm, kind, offsetof(CtxConfig, field)}
+const OptDesc OPTIONS[] = {
+    OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio),
+    OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("uniq_hash", O_INT, uniq_hash),
+    OPT("hap_stats", O_STR, hap_stats), OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
+    OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds),
+    OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
+    OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
+    OPT("cov_ablate", O_U32, cov_ablate), OPT("ssg_wave_rows", O_U32, ssg_wave_rows), OPT("ssn_debug", O_BOOL, ssn_debug),
+    OPT("scan_no_huge", O_BOOL, scan_no_huge), OPT("flag_rank_chained", O_BOOL, flag_rank_chained), OPT("ratio_kernel", O_BOOL, ratio_kernel),
+    OPT("mask_pass", O_BOOL, mask_pass), OPT("trio_free_at_filter", O_BOOL, trio_free_at_filter), OPT("trio_after_step", O_BOOL, trio_after_step),
+};
+#undef OPT
+}  // namespace
+
+int ctx_set_option(CtxConfig &cfg, const char *name, const char *value) {
+    if (!name) return PANTAX_HIP_E_INVALID;
+    static const CtxConfig defaults;
+    for (const OptDesc &o : OPTIONS) {
+        if (std::strcmp(o.name, name) != 0) continue;
+        char *dst = reinterpret_cast<char *>(&cfg) + o.off;
+        const char *def = reinterpret_cast<const char *>(&defaults) + o.off;
+        char *end = nullptr;
+        switch (o.kind) {
+        case O_BOOL: *reinterpret_cast<bool *>(dst) = value ? !(value[0] == '0' || value[0] == '\0' || value[0] == 'n' || value[0] == 'f') : *reinterpret_cast<const bool *>(def); return 0;
+        case O_INT: { if (!value) { *reinterpret_cast<int *>(dst) = *reinterpret_cast<const int *>(def); return 0; }
+                      const long v = std::strtol(value, &end, 10); if (end == value) return PANTAX_HIP_E_INVALID; *reinterpret_cast<int *>(dst) = (int)v; return 0; }
+        case O_U32: { if (!value) { *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(def); return 0; }
+                      const unsigned long long v = std::strtoull(value, &end, 10); if (end == value) return PANTAX_HIP_E_INVALID; *reinterpret_cast<uint32_t *>(dst) = (uint32_t)v; return 0; }
+        case O_U64: { if (!value) { *reinterpret_cast<uint64_t *>(dst) = *reinterpret_cast<const uint64_t *>(def); return 0; }
+                      const unsigned long long v = std::strtoull(value, &end, 10); if (end == value) return PANTAX_HIP_E_INVALID; *reinterpret_cast<uint64_t *>(dst) = (uint64_t)v; return 0; }
+        case O_STR: *reinterpret_cast<std::string *>(dst) = value ? value : ""; return 0;
+        }
+    }
+    return PANTAX_HIP_E_INVALID;
+}
+
+// the environment, once: PANTAX_<NAME> for every option of the table
+static void config_from_env(CtxConfig &cfg) {
+    for (const OptDesc &o : OPTIONS) {
+        std::string env = "PANTAX_";
+        for (const char *p = o.name; *p; ++p) env += (char)std::toupper((unsigned char)*p);
+        if (const char *v = std::getenv(env.c_str())) (void)ctx_set_option(cfg, o.name, v);
+    }
+}
+
 }  // namespace ptx
 
 using namespace ptx;
@@ -87,6 +141,13 @@ using namespace ptx;
 extern "C" {
 
 const char *pantax_hip_version(void) { return "pantax-hip 0.1.0 (gfx950)"; }
+
+int pantax_hip_set_option(pantax_hip_ctx *ctx, const char *name, const char *value) {
+    if (!ctx || !name) return PANTAX_HIP_E_INVALID;
+    std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
+    const int rc = ctx_set_option(ctx->cfg, name, value);
+    return rc == 0 ? 0 : fail(ctx, rc, "set_option: unknown option or unparsable value: %s=%s", name, value ? value : "(default)");
+}
 
 const char *pantax_hip_last_error(const pantax_hip_ctx *ctx) {
     if (!ctx) return g_init_err.c_str();
@@ -115,13 +176,13 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
     pantax_hip_ctx *ctx = new pantax_hip_ctx();
     ctx->device = dev;
     ctx->n_cu = prop.multiProcessorCount;
+    config_from_env(ctx->cfg);   // the only place the library reads the environment
     // The main stream at the highest priority, the side stream (index rebuild) at the lowest: in a stream of steps the rebuild for
     // step i+1 runs beside the tail of step i, which is the critical chain -- the rebuild has 2 ms of slack and fills what the
     // chain's narrow kernels (sample ranking, the LP workgroups) leave idle instead of taking wave slots from its wide ones
-    // (cfg3: 6.80 -> 6.51 ms per step; PANTAX_STREAM_PRIO=0 = equal priorities, for measurements)
+    // (cfg3: 6.80 -> 6.51 ms per step; option stream_prio=0 = equal priorities, for measurements)
     int prio_lo = 0, prio_hi = 0;
-    const char *prio_env = std::getenv("PANTAX_STREAM_PRIO");
-    const bool prio = !(prio_env && prio_env[0] == '0') && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
+    const bool prio = ctx->cfg.stream_prio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi;
     if ((e = prio ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -373,20 +434,19 @@ int upload_staged_pieces(Ctx *ctx, const UploadPiece *pieces, size_t n_pieces, i
     uint64_t total = 0;
     for (size_t k = 0; k < n_pieces; ++k) total += pieces[k].size;
     constexpr int SLOTS = 3;
-    uint64_t CH = std::getenv("PANTAX_STAGE_CH_MB") ? (uint64_t)std::max(1, std::atoi(std::getenv("PANTAX_STAGE_CH_MB"))) << 20
-                                                    : std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
-    if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH && !std::getenv("PANTAX_STAGE_CH_MB")) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
+    uint64_t CH = ctx->cfg.stage_ch_mb > 0 ? (uint64_t)ctx->cfg.stage_ch_mb << 20
+                                           : std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
+    if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH && ctx->cfg.stage_ch_mb <= 0) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
     PTX_HIP(ctx, ring.reserve(SLOTS * CH));
     // 32 threads: at 16 the crew, not the DMA, bounds a 15-GB load (filling 413 of 420 ms = 37 GB/s of pread; 32: 211 of 293 ms = 52 GB/s,
     // 0.92 of the pinned copy rate); 48 and 64 fill no faster and slow the copies down (390 ms)
-    static const int NTH_ENV = std::getenv("PANTAX_STAGE_THREADS") ? std::atoi(std::getenv("PANTAX_STAGE_THREADS")) : 32;
-    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(NTH_ENV, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
+    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(ctx->cfg.stage_threads, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
     StageCrew crew(nth);
     hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
     for (auto &e : ev) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int rc = 0;
     uint64_t i = 0;
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const bool trace = ctx->cfg.trace;
     double t_wait = 0, t_fill = 0, t_enq = 0, t_gate = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -434,112 +494,121 @@ int upload_staged(Ctx *ctx, void *d_dst, const void *src, int fd, uint64_t file_
 }
 }  // namespace
 
-// The GAF load with the unread columns left behind (gaf_prune.cc): the crew does not copy the text into the pinned ring, it REWRITES it
-// there -- every thread prunes the lines of its own line-aligned range of the chunk into its own part of the slot, straight from the
-// mapped file (no pread copy in between) -- and the parts travel one after the other to consecutive device addresses, so the device
-// holds one contiguous pruned text per piece.  pruned_size[k] = bytes of piece k on the device.  A chunk that holds a line longer than
-// a thread's part of the slot travels unpruned (byte for byte: the tokenizer reads either form).
-int upload_text_pieces_pruned(Ctx *ctx, size_t n_pieces, void *const *d_dst, const char *text, int fd, uint64_t file_base, const uint64_t *piece_off,
-                              const uint64_t *piece_end, hipStream_t stream, const std::function<bool(size_t)> &before_piece,
-                              const std::function<int(size_t, uint64_t)> &after_piece) {
-    PinBuf &ring = ctx->pin_text;
+// ---- many stretches (files / memory, as they are or narrowed from 64 to 32 bits) -> ONE contiguous device range ----
+// The db load of the pipeline seam (a6): 1 000 species' graphs are 2 000 stretches of a few megabytes in as many files.  One upload per
+// stretch (round 4) created a crew of threads and drained the copy queue 2 000 times; here the stretches are one logical byte string
+// that travels in 64-MB chunks like the GAF text: every thread of the crew fills its share of the chunk -- whatever stretches it spans --
+// and the chunk leaves as one DMA.  Files are opened by the thread that needs them (one descriptor per thread at a time: no limit on
+// the number of species), bincode's 64-bit integers are narrowed on the way into the pinned chunk (read in 64-KB blocks: L2-resident).
+namespace {
+struct SegFiller {
+    const UploadSeg *segs; size_t n_segs; const std::string *files;
+    std::vector<uint64_t> prefix;            // [n_segs + 1] device byte offsets
+    std::atomic<int64_t> bad{-1}, io_fail{-1};
+    void note(std::atomic<int64_t> &a, int64_t k) { int64_t cur = a.load(); while ((cur < 0 || k < cur) && !a.compare_exchange_weak(cur, k)) {} }
+    // device bytes [b, e) of the logical string -> out (which points at byte b)
+    void fill(uint8_t *out, uint64_t b, uint64_t e) {
+        size_t k = (size_t)(std::upper_bound(prefix.begin(), prefix.end(), b) - prefix.begin()) - 1;
+        int fd = -1, fd_file = -1;
+        std::vector<uint64_t> tmp;
+        for (; b < e && k < n_segs; ++k) {
+            const UploadSeg &s = segs[k];
+            const uint64_t so = b - prefix[k], n = std::min(e, prefix[k + 1]) - b;
+            if (n == 0) continue;
+            const uint8_t *src = static_cast<const uint8_t *>(s.src);
+            if (!src && s.file != fd_file) {
+                if (fd >= 0) ::close(fd);
+                fd = ::open(files[s.file].c_str(), O_RDONLY);
+                fd_file = s.file;
+                if (fd < 0) note(io_fail, (int64_t)k);
+            }
+            auto read_at = [&](uint8_t *dst, uint64_t off, uint64_t len) {
+                if (src) { std::memcpy(dst, src + off, len); return; }
+                uint64_t at = 0;
+                while (fd >= 0 && at < len) {
+                    const ssize_t r = ::pread(fd, dst + at, len - at, (off_t)(s.file_off + off + at));
+                    if (r <= 0) break;
+                    at += (uint64_t)r;
+                }
+                if (at < len) { std::memset(dst + at, 0, len - at); note(io_fail, (int64_t)k); }   // zeros keep the run defined; the caller fails
+            };
+            if (!s.narrow) read_at(out, so, n);
+            else {
+                constexpr uint64_t BLK = 8192;                        // 64-bit values per block
+                uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+                uint64_t hi = 0;
+                for (uint64_t i0 = so / 4, i1 = (so + n) / 4; i0 < i1; i0 += BLK) {
+                    const uint64_t m = std::min(BLK, i1 - i0);
+                    const uint64_t *in;
+                    if (src) in = reinterpret_cast<const uint64_t *>(src) + i0;
+                    else { tmp.resize(BLK); read_at(reinterpret_cast<uint8_t *>(tmp.data()), 8 * i0, 8 * m); in = tmp.data(); }
+                    uint32_t *o = o32 + (i0 - so / 4);
+                    for (uint64_t i = 0; i < m; ++i) { const uint64_t x = in[i]; o[i] = (uint32_t)x; hi |= x; }
+                }
+                if (hi >> 32) note(bad, (int64_t)k);
+            }
+            out += n; b += n;
+        }
+        if (fd >= 0) ::close(fd);
+    }
+};
+}  // namespace
+
+int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg) {
+    if (bad_seg) *bad_seg = -1;
+    SegFiller f{segs, n_segs, files};
+    f.prefix.assign(n_segs + 1, 0);
+    for (size_t k = 0; k < n_segs; ++k) {
+        if (segs[k].out_bytes % 4) return fail(ctx, PANTAX_HIP_E_INVALID, "upload_segments: stretch %zu is not a whole number of 32-bit words", k);
+        f.prefix[k + 1] = f.prefix[k] + segs[k].out_bytes;
+    }
+    const uint64_t total = f.prefix[n_segs];
+    if (total == 0) return 0;
     constexpr int SLOTS = 3;
-    static const int NTH_ENV = std::getenv("PANTAX_PRUNE_THREADS") ? std::atoi(std::getenv("PANTAX_PRUNE_THREADS")) : 64;
-    const int nth = std::max(1, std::min(NTH_ENV, (int)std::thread::hardware_concurrency() / 2 > 0 ? (int)std::thread::hardware_concurrency() / 2 : 1));
-    const uint64_t CH = 64ull << 20, MARGIN = 256ull << 10;
-    const uint64_t part = (CH + nth - 1) / nth + MARGIN;          // the longest range a thread prunes in one go
-    PTX_HIP(ctx, ring.reserve((uint64_t)SLOTS * (CH + part)));
-    const uint64_t slot_bytes = CH + part;
-    // Every thread, TWO passes over its range of the mapped text (about a megabyte: the second pass finds it in the core's caches): the
-    // size of its pruned lines; then -- all sizes known (a spin barrier inside the job) -- the lines themselves, straight into their place
-    // in the pinned slot.  The text is read from memory once and 0.73 of it written once; the first version went through two private
-    // buffers per thread and a copy (three passes through memory: 25-37 GB/s of text).  MEASURED (cfg4, 15.2 GB): no faster -- 0.81-1.05 s
-    // to resident reads, 3.7 ms per 64-MB chunk = 270 MB/s per thread: what the threads wait for is the MAPPING (a page-cache page enters
-    // the address space fault by fault, 64 threads on one mm), not the scan; `pread` into pinned memory never maps the text: 70 GB/s.
-    if (!text) return fail(ctx, PANTAX_HIP_E_INVALID, "upload_text_pieces_pruned: the text must be mapped");
-    fd = -1;
-    std::vector<uint64_t> part_size(nth + 1);
-    std::atomic<int> arrived{0};
+    PinBuf &ring = ctx->pin_text;
+    uint64_t CH = std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
+    if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
+    PTX_HIP(ctx, ring.reserve(SLOTS * CH));
+    const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(ctx->cfg.stage_threads, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
     StageCrew crew(nth);
     hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr};
     for (auto &e : ev) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    const uint8_t *tx = reinterpret_cast<const uint8_t *>(text);
     int rc = 0;
-    uint64_t i = 0, sent = 0, seen = 0;
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
-    double t_wait = 0, t_fill = 0, t_enq = 0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto t_begin = now();
-    std::vector<uint64_t> cut(nth + 1);
-    for (size_t pk = 0; pk < n_pieces && rc == 0; ++pk) {
-        if (before_piece && !before_piece(pk)) { rc = PANTAX_HIP_E_STATE; break; }
-        uint8_t *dst = static_cast<uint8_t *>(d_dst[pk]);
-        const uint64_t pb = piece_off[pk], pe = piece_end[pk];
-        uint64_t dev_off = 0;
-        // next line start at or behind `at` (the piece begins at a line start and ends behind a line end or at the end of the text)
-        auto align = [&](uint64_t at) -> uint64_t {
-            if (at <= pb) return pb;
-            if (at >= pe) return pe;
-            const void *nl = std::memchr(tx + at - 1, '\n', (size_t)(pe - (at - 1)));
-            return nl ? (uint64_t)(static_cast<const uint8_t *>(nl) - tx) + 1 : pe;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_fill = 0, t_wait = 0;
+    uint64_t i = 0;
+    for (uint64_t c0 = 0; c0 < total && rc == 0; c0 += CH, ++i) {
+        const uint64_t c1 = std::min(total, c0 + CH);
+        const int k = (int)(i % SLOTS);
+        uint8_t *slot = ring.p + (uint64_t)k * CH;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (i >= SLOTS && hipEventSynchronize(ev[k]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
+        const auto t1 = std::chrono::steady_clock::now();
+        const std::function<void(int, int)> job = [&](int t, int n) {
+            const uint64_t words = (c1 - c0) / 4;
+            const uint64_t b = c0 + 4 * (words * (uint64_t)t / (uint64_t)n), e = c0 + 4 * (words * (uint64_t)(t + 1) / (uint64_t)n);
+            if (e > b) f.fill(slot + (b - c0), b, e);
         };
-        for (uint64_t pos = pb; pos < pe && rc == 0; ++i) {
-            const uint64_t cend = align(std::min(pe, pos + CH));
-            const int k = (int)(i % SLOTS);
-            uint8_t *slot = ring.p + (uint64_t)k * slot_bytes;
-            const auto t0 = now();
-            if (i >= SLOTS && hipEventSynchronize(ev[k]) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "hipEventSynchronize failed"); break; }
-            const auto t1 = now();
-            cut[0] = pos; cut[nth] = cend;
-            for (int t = 1; t < nth; ++t) cut[t] = std::max(cut[t - 1], std::min(cend, align(pos + (cend - pos) * (uint64_t)t / (uint64_t)nth)));
-            bool fits = cend - pos <= CH + part - MARGIN;
-            for (int t = 0; t < nth; ++t) fits = fits && cut[t + 1] - cut[t] <= part;
-            uint64_t n_out = 0;
-            if (fits) {
-                arrived.store(0, std::memory_order_relaxed);
-                const std::function<void(int, int)> job = [&](int t, int) {
-                    const uint64_t a = cut[t], b = cut[t + 1];
-                    const uint64_t n = b > a ? gaf_prune_range(tx + a, b - a, 0, b - a, true, nullptr) : 0;   // the size pass
-                    part_size[t] = n;
-                    arrived.fetch_add(1, std::memory_order_acq_rel);
-                    for (uint32_t spin = 0; arrived.load(std::memory_order_acquire) < nth; ++spin) { if (spin < 1u << 14) __builtin_ia32_pause(); else std::this_thread::yield(); }
-                    uint64_t off = 0;
-                    for (int u = 0; u < t; ++u) off += part_size[u];
-                    if (n) gaf_prune_range(tx + a, b - a, 0, b - a, true, slot + off);
-                    if (t == nth - 1) part_size[nth] = off + n;
-                };
-                crew.run(job);
-                n_out = part_size[nth];
-            }
-            const auto t2 = now();
-            if (fits) {
-                if (n_out && hipMemcpyAsync(dst + dev_off, slot, n_out, hipMemcpyHostToDevice, stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
-                dev_off += n_out;
-            } else {
-                // a line longer than a thread's buffer: this chunk travels unpruned, in slot-sized blocks through the same slot
-                for (uint64_t off = pos; off < cend && rc == 0;) {
-                    const uint64_t n = std::min<uint64_t>(slot_bytes, cend - off);
-                    if (off != pos && hipStreamSynchronize(stream) != hipSuccess) { rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed"); break; }
-                    crew.fill(slot, fd >= 0 ? nullptr : tx, fd, (fd >= 0 ? file_base : 0) + off, n);
-                    if (hipMemcpyAsync(dst + dev_off, slot, n, hipMemcpyHostToDevice, stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
-                    dev_off += n; off += n;
-                }
-            }
-            if (rc == 0 && hipEventRecord(ev[k], stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
-            if (trace) { const auto t3 = now(); t_wait += ms(t0, t1); t_fill += ms(t1, t2); t_enq += ms(t2, t3); }
-            seen += cend - pos;
-            pos = cend;
-        }
-        sent += dev_off;
-        if (rc == 0 && after_piece) rc = after_piece(pk, dev_off);
+        crew.run(job);
+        const auto t2 = std::chrono::steady_clock::now();
+        t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_fill += std::chrono::duration<double, std::milli>(t2 - t1).count();
+        if (hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + c0, slot, c1 - c0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[k], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     }
-    if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
-    if (trace)
-        std::fprintf(stderr, "[upload_pruned] %.1f MB of text -> %.1f MB over PCIe in %.2f ms (%.1f GB/s of text): %zu piece(s), %llu chunks, %d threads; waiting for a slot %.2f, "
-                     "pruning %.2f, enqueue %.2f ms\n", seen / 1e6, sent / 1e6, ms(t_begin, now()), seen / 1e6 / ms(t_begin, now()), n_pieces, (unsigned long long)i, nth, t_wait, t_fill, t_enq);
+    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     for (auto &e : ev) (void)hipEventDestroy(e);
-    return rc;
+    if (ctx->cfg.trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        std::fprintf(stderr, "[upload_segments] %.1f MB in %.2f ms (%.1f GB/s): %zu stretches, %llu chunks of %.0f MB, %d threads; waiting for a slot %.2f, filling %.2f ms\n",
+                     total / 1e6, ms, total / 1e6 / ms, n_segs, (unsigned long long)i, CH / 1048576.0, nth, t_wait, t_fill);
+    }
+    if (rc) return rc;
+    if (f.io_fail.load() >= 0) {
+        const UploadSeg &s = segs[f.io_fail.load()];
+        return fail(ctx, PANTAX_HIP_E_IO, "cannot read %s (bytes from %llu)", s.file >= 0 ? files[s.file].c_str() : "<memory>", (unsigned long long)s.file_off);
+    }
+    if (bad_seg) *bad_seg = f.bad.load();
+    return 0;
 }
 
 int upload_big(Ctx *ctx, void *d_dst, const void *src, uint64_t size) { return upload_staged(ctx, d_dst, src, -1, 0, size, ctx->stream, ctx->pin_text); }

@@ -1,15 +1,21 @@
 // db_image.cpp -- SURVEY 8f-2: a device-ready image of one species' graph beside the reference's containers
 // (<db>/species_graph_info/<otu>.bin of zip.rs:171-190 stays the source of truth; the image is a cache this library
-// writes and reads).  An image holds what the resident DB holds for the species, in the layouts the kernels use, so
-// loading is "map the file, copy to HBM": 32-bit node lengths, the walks as a CSR of 32-bit local node ids, the
-// haplotype names, and the unique-trio index of a7 (trio_nodes_info, profile.rs:658-740) -- lookup CSR over the
-// smallest end node plus the (hap, position)-ordered rows -- so that a7 is a load-time no-op.
+// writes and reads).  An image holds the graph in the layouts the kernels use -- 32-bit node lengths, the walks as a CSR of
+// 32-bit local node ids, the haplotype names -- so loading is "pread into the pinned ring, DMA": half the bytes of the `.bin`
+// (usize ids are 64-bit there) and no narrowing on the way.
+//
+// Version 3 (round 5) no longer stores the unique-trio index of a7.  Measured at 10 000 strains (cfg4): the stored index is
+// 7.8 GB = 0.14 s of PCIe at the box's 56 GB/s, the device REBUILDS it from the walks in 16 ms (trio_visit_kernel +
+// trio_rows_kernel) on top of a visit table built in 75 ms -- and that work can run beside the next transfer, the PCIe bytes cannot.
+// The same holds for the visit table itself (4 bytes per path step: 8.9 GB = 0.16 s against 75 ms of kernels).  So the image is
+// the graph alone and a7 stays a per-run device build, as in the reference (profile.rs:2936).
 //
 // Layout (little endian, every section padded to 16 bytes):
-//   header  : "PTXHIPDB", u32 version, u32 flags (bit 0 = all walks identical), u64 V, H, P, U, L, u64 name_bytes
-//   node_len u32[V] | path_off u64[H+1] | path_nodes u32[P] | names ('\n'-joined) |
-//   trio_first u32[V+1] (local; CSR over the middle node) | trio_ent {smaller end, larger end, local row, 0} u32x4[U] | trio_abc u32[3U] | trio_hap u32[U] |
-//   trio_len u32[U] | hap_trio_off u64[H+1] (local) | u64 end marker = header checksum
+//   header  : "PTXHIPDB", u32 version, u32 flags (0), u64 V, H, P, L, u64 name_bytes
+//   node_len u32[V] | path_off u64[H+1] | path_nodes u32[P] | names ('\n'-joined) | u64 end marker = header checksum
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -23,8 +29,8 @@ namespace ptx {
 
 namespace {
 constexpr char MAGIC[8] = {'P', 'T', 'X', 'H', 'I', 'P', 'D', 'B'};
-constexpr uint32_t VERSION = 2;   // 2: the lookup rows are filed under the window's MIDDLE node {smaller end, larger end, row} (1: under the smaller end)
-struct Header { char magic[8]; uint32_t version, flags; uint64_t V, H, P, U, L, name_bytes; };
+constexpr uint32_t VERSION = 3;   // 3: the graph alone (2: + the unique-trio index filed under the middle node; 1: under the smaller end)
+struct Header { char magic[8]; uint32_t version, flags; uint64_t V, H, P, L, name_bytes; };
 inline uint64_t pad16(uint64_t n) { return (n + 15) & ~uint64_t(15); }
 inline uint64_t header_sum(const Header &h) {
     uint64_t x = 0xcbf29ce484222325ull;
@@ -33,72 +39,80 @@ inline uint64_t header_sum(const Header &h) {
     return x;
 }
 struct Layout {
-    uint64_t node_len, path_off, path_nodes, names, trio_first, trio_ent, trio_abc, trio_hap, trio_len, hto, end, total;
+    uint64_t node_len, path_off, path_nodes, names, end, total;
     explicit Layout(const Header &h) {
         uint64_t o = pad16(sizeof(Header));
         auto take = [&](uint64_t bytes) { const uint64_t at = o; o += pad16(bytes); return at; };
         node_len = take(4 * h.V); path_off = take(8 * (h.H + 1)); path_nodes = take(4 * h.P); names = take(h.name_bytes);
-        trio_first = take(4 * (h.V + 1)); trio_ent = take(16 * h.U); trio_abc = take(12 * h.U); trio_hap = take(4 * h.U); trio_len = take(4 * h.U);
-        hto = take(8 * (h.H + 1)); end = take(8);
+        end = take(8);
         total = o;
     }
 };
+struct Fd {
+    int fd = -1;
+    ~Fd() { if (fd >= 0) ::close(fd); }
+};
+bool pread_all(int fd, void *dst, uint64_t n, uint64_t off) {
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    uint64_t at = 0;
+    while (at < n) {
+        const ssize_t r = ::pread(fd, d + at, n - at, (off_t)(off + at));
+        if (r <= 0) return false;
+        at += (uint64_t)r;
+    }
+    return true;
+}
 }  // namespace
 
-std::string SpeciesImage::open(const std::string &path) {
-    const std::string e = mf.open(path);
-    if (!e.empty()) return e;
-    if (mf.size < sizeof(Header)) return path + ": not a pantax-hip graph image (too short)";
+std::string SpeciesImage::open(const std::string &p) {
+    path = p;
+    Fd f;
+    f.fd = ::open(p.c_str(), O_RDONLY);
+    if (f.fd < 0) return "cannot open graph image " + p;
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) return "cannot stat " + p;
+    const uint64_t size = (uint64_t)st.st_size;
     Header h;
-    std::memcpy(&h, mf.data, sizeof(h));
-    if (std::memcmp(h.magic, MAGIC, 8) != 0) return path + ": not a pantax-hip graph image";
-    if (h.version != VERSION) return path + ": graph image version " + std::to_string(h.version) + ", this build reads " + std::to_string(VERSION);
-    if (h.V >= 0xFFFFFFFFull || h.P >= 0xFFFFFFFFull || h.U > h.P || h.H > h.P + 1) return path + ": implausible graph image header";
+    if (size < sizeof(Header) || !pread_all(f.fd, &h, sizeof(h), 0)) return p + ": not a pantax-hip graph image (too short)";
+    if (std::memcmp(h.magic, MAGIC, 8) != 0) return p + ": not a pantax-hip graph image";
+    if (h.version != VERSION) return p + ": graph image version " + std::to_string(h.version) + ", this build reads " + std::to_string(VERSION);
+    if (h.V >= 0xFFFFFFFFull || h.P >= 0xFFFFFFFFull || h.H > h.P + 1 || h.name_bytes > (1ull << 32)) return p + ": implausible graph image header";
     const Layout L(h);
-    if (L.total != mf.size) return path + ": graph image is truncated or has trailing bytes";
+    if (L.total != size) return p + ": graph image is truncated or has trailing bytes";
     uint64_t endmark = 0;
-    std::memcpy(&endmark, mf.data + L.end, 8);
-    if (endmark != header_sum(h)) return path + ": graph image end marker does not match its header";
-    V = h.V; H = h.H; P = h.P; U = h.U; L_bases = h.L; all_same = (h.flags & 1u) != 0;
-    off_node_len = L.node_len; off_path_nodes = L.path_nodes; off_trio_first = L.trio_first; off_trio_ent = L.trio_ent; off_trio_abc = L.trio_abc;
-    off_trio_hap = L.trio_hap; off_trio_len = L.trio_len;
-    node_len = reinterpret_cast<const uint32_t *>(mf.data + L.node_len);
-    path_off = reinterpret_cast<const uint64_t *>(mf.data + L.path_off);
-    path_nodes = reinterpret_cast<const uint32_t *>(mf.data + L.path_nodes);
-    trio_first = reinterpret_cast<const uint32_t *>(mf.data + L.trio_first);
-    trio_ent = reinterpret_cast<const uint4 *>(mf.data + L.trio_ent);
-    trio_abc = reinterpret_cast<const uint32_t *>(mf.data + L.trio_abc);
-    trio_hap = reinterpret_cast<const uint32_t *>(mf.data + L.trio_hap);
-    trio_len = reinterpret_cast<const uint32_t *>(mf.data + L.trio_len);
-    hap_trio_off = reinterpret_cast<const uint64_t *>(mf.data + L.hto);
-    if (path_off[0] != 0 || path_off[H] != P || hap_trio_off[0] != 0 || hap_trio_off[H] != U || trio_first[0] != 0 || trio_first[V] != U)
-        return path + ": graph image offsets are inconsistent";
+    if (!pread_all(f.fd, &endmark, 8, L.end) || endmark != header_sum(h)) return p + ": graph image end marker does not match its header";
+    V = h.V; H = h.H; P = h.P; L_bases = h.L;
+    off_node_len = L.node_len; off_path_nodes = L.path_nodes;
+    path_off.assign(H + 1, 0);
+    if (!pread_all(f.fd, path_off.data(), 8 * (H + 1), L.path_off)) return p + ": cannot read the walk offsets";
+    if (path_off[0] != 0 || path_off[H] != P) return p + ": graph image offsets are inconsistent";
+    for (uint64_t i = 0; i < H; ++i) if (path_off[i] > path_off[i + 1]) return p + ": graph image offsets are inconsistent";
+    std::string names(h.name_bytes, '\0');
+    if (h.name_bytes && !pread_all(f.fd, &names[0], h.name_bytes, L.names)) return p + ": cannot read the haplotype names";
     hap_names.clear();
-    const char *nb = mf.data + L.names, *ne = nb + h.name_bytes;
-    for (const char *p = nb; p < ne;) {
-        const char *q = static_cast<const char *>(std::memchr(p, '\n', (size_t)(ne - p)));
-        if (!q) q = ne;
-        hap_names.emplace_back(p, q);
-        p = q + 1;
+    const char *nb = names.data(), *ne = nb + names.size();
+    for (const char *q = nb; q < ne;) {
+        const char *e = static_cast<const char *>(std::memchr(q, '\n', (size_t)(ne - q)));
+        if (!e) e = ne;
+        hap_names.emplace_back(q, e);
+        q = e + 1;
     }
-    if (hap_names.size() != H) return path + ": graph image holds " + std::to_string(hap_names.size()) + " names for " + std::to_string(H) + " haplotypes";
+    if (H && names.empty()) hap_names.assign(1, "");     // one haplotype with an empty name
+    if (hap_names.size() != H) return p + ": graph image holds " + std::to_string(hap_names.size()) + " names for " + std::to_string(H) + " haplotypes";
     return "";
 }
 
-// one species of a resident db (trio index built) -> file
+// one species of a resident db -> file
 int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &names, const std::string &path) {
     if (s >= db->S) return fail(ctx, PANTAX_HIP_E_INVALID, "db_save_image: species %u of %u", s, db->S);
-    if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
-    PTX_TRY(trio_keys_ensure(ctx, db));
-    PTX_TRY(trio_first_ensure(ctx, db));
     const uint64_t nb = db->h_node_off[s], ne = db->h_node_off[s + 1], h0 = db->h_hap_off[s], h1 = db->h_hap_off[s + 1];
-    const uint64_t q0 = db->h_path_off[h0], q1 = db->h_path_off[h1], u0 = db->h_hap_trio_off[h0], u1 = db->h_hap_trio_off[h1];
+    const uint64_t q0 = db->h_path_off[h0], q1 = db->h_path_off[h1];
     if (names.size() != h1 - h0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_save_image: %zu names for %llu haplotypes", names.size(), (unsigned long long)(h1 - h0));
     Header h;
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, MAGIC, 8);
-    h.version = VERSION; h.flags = db->h_all_same[s] ? 1u : 0u;
-    h.V = ne - nb; h.H = h1 - h0; h.P = q1 - q0; h.U = u1 - u0;
+    h.version = VERSION; h.flags = 0;
+    h.V = ne - nb; h.H = h1 - h0; h.P = q1 - q0;
     std::string joined;
     for (size_t i = 0; i < names.size(); ++i) {
         if (names[i].find('\n') != std::string::npos) return fail(ctx, PANTAX_HIP_E_INVALID, "db_save_image: haplotype name with a line break");
@@ -113,23 +127,11 @@ int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &
     const Layout L(h);
     std::vector<uint8_t> img(L.total, 0);
     std::memcpy(img.data(), &h, sizeof(h));
-    uint32_t *tf = reinterpret_cast<uint32_t *>(img.data() + L.trio_first);
-    uint4 *te = reinterpret_cast<uint4 *>(img.data() + L.trio_ent);
-    uint64_t *po = reinterpret_cast<uint64_t *>(img.data() + L.path_off), *hto = reinterpret_cast<uint64_t *>(img.data() + L.hto);
+    uint64_t *po = reinterpret_cast<uint64_t *>(img.data() + L.path_off);
     PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.node_len), db->d_node_len.p + nb, h.V));
     PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.path_nodes), db->d_path_nodes.p + q0, h.P));
-    PTX_TRY(download(ctx, tf, db->d_trio_first.p + nb, h.V + 1));
-    if (h.U) {
-        PTX_TRY(download(ctx, te, db->d_trio_ent.p + u0, h.U));
-        PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.trio_abc), db->d_trio_abc.p + 3 * u0, 3 * h.U));
-        PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.trio_hap), db->d_trio_hap.p + u0, h.U));
-        PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.trio_len), db->d_trio_len.p + u0, h.U));
-    }
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint64_t i = 0; i <= h.H; ++i) { po[i] = db->h_path_off[h0 + i] - q0; hto[i] = db->h_hap_trio_off[h0 + i] - u0; }
-    if (tf[0] != (uint32_t)u0 || tf[h.V] != (uint32_t)u1) return fail(ctx, PANTAX_HIP_E_STATE, "db_save_image: lookup rows of species %u are not the contiguous block its table rows are", s);
-    for (uint64_t i = 0; i <= h.V; ++i) tf[i] -= (uint32_t)u0;
-    for (uint64_t i = 0; i < h.U; ++i) { te[i].x -= (uint32_t)nb; te[i].y -= (uint32_t)nb; te[i].z -= (uint32_t)u0; }   // species-local (b, c, row) in the file
+    for (uint64_t i = 0; i <= h.H; ++i) po[i] = db->h_path_off[h0 + i] - q0;
     std::memcpy(img.data() + L.names, joined.data(), joined.size());
     const uint64_t endmark = header_sum(h);
     std::memcpy(img.data() + L.end, &endmark, 8);
@@ -141,60 +143,62 @@ int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &
     return 0;
 }
 
-// images -> resident db with its trio index in place.  The big arrays stream from the files (pread into pinned chunks,
-// DMA); the node tables, the walk check and the move of the species-local trio rows to their place in the batch run
-// on the device (stage_db.hip) -- the host touches the headers, the walk offsets and the names only.
+// images -> resident db: the two arrays of every species stream from the files (pread into the pinned ring, DMA); the node tables and
+// the checks run on the device (stage_db.hip) -- the host touches the headers, the walk offsets and the names only
 int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *im, const int64_t *range_start, const int64_t *range_end, pantax_hip_db **out) {
     *out = nullptr;
     std::vector<GraphPart> parts(S);
+    std::vector<std::string> files(S);
     for (uint32_t s = 0; s < S; ++s) {
-        parts[s] = GraphPart{nullptr, im[s]->V, im[s]->H, im[s]->path_off, im[s]->path_nodes};
-        parts[s].node_len32 = im[s]->node_len;
-        parts[s].fd = im[s]->mf.fd; parts[s].off_node_len = im[s]->off_node_len; parts[s].off_path_nodes = im[s]->off_path_nodes;
-        parts[s].n_bases = im[s]->L_bases; parts[s].all_same = im[s]->all_same ? 1 : 0;
+        files[s] = im[s]->path;
+        GraphPart &pt = parts[s];
+        pt.n_nodes = im[s]->V; pt.n_haps = im[s]->H; pt.path_off = im[s]->path_off.data();
+        pt.len_seg.file = (int32_t)s; pt.len_seg.file_off = im[s]->off_node_len; pt.len_seg.out_bytes = 4 * im[s]->V;
+        UploadSeg w;
+        w.file = (int32_t)s; w.file_off = im[s]->off_path_nodes; w.out_bytes = 4 * im[s]->P;
+        pt.walk_segs.push_back(w);
     }
-    pantax_hip_db *raw = nullptr;
-    PTX_TRY(db_upload_parts(ctx, S, range_start, range_end, parts.data(), &raw));
-    std::unique_ptr<pantax_hip_db> db(raw);
-    const uint64_t V = db->V, H = db->H;
-    std::vector<uint64_t> ubase(S + 1, 0);
-    for (uint32_t s = 0; s < S; ++s) ubase[s + 1] = ubase[s] + im[s]->U;
-    const uint64_t Utot = ubase[S];
-    if (Utot >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "graph images: %llu unique trios exceed 32-bit rows", (unsigned long long)Utot);
-    db->h_hap_trio_off.assign(H + 1, 0);
-    for (uint32_t s = 0; s < S; ++s)
-        for (uint64_t h = 0; h < im[s]->H; ++h) db->h_hap_trio_off[db->h_hap_off[s] + h] = im[s]->hap_trio_off[h] + ubase[s];
-    db->h_hap_trio_off[H] = Utot;
-    PTX_HIP(ctx, db->d_trio_first.alloc(V + 1)); PTX_HIP(ctx, db->d_trio_ent.alloc(Utot ? Utot : 1));
-    DevBuf<uint32_t> d_err;
-    PTX_HIP(ctx, d_err.alloc(1));
-    PTX_HIP(ctx, hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, db->d_trio_abc.alloc(3 * (Utot ? Utot : 1))); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot ? Utot : 1)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot ? Utot : 1));
-    for (uint32_t s = 0; s < S; ++s) {
-        const SpeciesImage &g = *im[s];
-        const uint64_t nb = db->h_node_off[s];
-        PTX_TRY(upload_file(ctx, db->d_trio_first.p + nb, g.mf.fd, g.off_trio_first, g.V * sizeof(uint32_t)));   // entry V of the image = its U
-        PTX_TRY(upload_file(ctx, db->d_trio_ent.p + ubase[s], g.mf.fd, g.off_trio_ent, g.U * sizeof(uint4)));
-        PTX_TRY(upload_file(ctx, db->d_trio_abc.p + 3 * ubase[s], g.mf.fd, g.off_trio_abc, 3 * g.U * sizeof(uint32_t)));
-        PTX_TRY(upload_file(ctx, db->d_trio_hap.p + ubase[s], g.mf.fd, g.off_trio_hap, g.U * sizeof(uint32_t)));
-        PTX_TRY(upload_file(ctx, db->d_trio_len.p + ubase[s], g.mf.fd, g.off_trio_len, g.U * sizeof(uint32_t)));
-        PTX_TRY(trio_rebase_launch(ctx, db.get(), s, ubase[s], g.U, d_err.p));
+    return db_upload_parts(ctx, S, range_start, range_end, parts.data(), files.data(), out);
+}
+
+// ---- bincode-1 `Graph` (types.rs:51-55): where its arrays lie ----
+std::string scan_graph_bin(const std::string &path, BinIndex &out) {
+    out = BinIndex();
+    Fd f;
+    f.fd = ::open(path.c_str(), O_RDONLY);
+    if (f.fd < 0) return "cannot open serialized graph " + path;
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) return "cannot stat " + path;
+    const uint64_t n = (uint64_t)st.st_size;
+    uint64_t off = 0;
+    auto rd64 = [&](uint64_t &v) { if (off + 8 > n || !pread_all(f.fd, &v, 8, off)) return false; off += 8; return true; };
+    uint64_t nn = 0;
+    if (!rd64(nn) || nn > (n - off) / 8) return "truncated graph file " + path;
+    out.V = nn; out.off_node_len = off;
+    off += nn * 8;
+    uint64_t m = 0;
+    if (!rd64(m)) return "truncated graph file " + path;
+    if (m > (n - off) / 16) return "corrupt graph file " + path;
+    // one small read per haplotype carries its key length, its key and -- for keys of the usual size -- the length of its walk
+    std::vector<char> buf(4096);
+    for (uint64_t i = 0; i < m; ++i) {
+        if (off + 8 > n) return "truncated graph file " + path;
+        const uint64_t got = std::min<uint64_t>(buf.size(), n - off);
+        if (!pread_all(f.fd, buf.data(), got, off)) return "cannot read " + path;
+        uint64_t kl = 0, vl = 0;
+        std::memcpy(&kl, buf.data(), 8);
+        if (kl > (1u << 20) || off + 8 + kl + 8 > n) return "corrupt graph file " + path;
+        std::string key(kl, '\0');
+        if (8 + kl + 8 <= got) { std::memcpy(&key[0], buf.data() + 8, kl); std::memcpy(&vl, buf.data() + 8 + kl, 8); }
+        else if (!pread_all(f.fd, &key[0], kl, off + 8) || !pread_all(f.fd, &vl, 8, off + 8 + kl)) return "cannot read " + path;
+        off += 8 + kl + 8;
+        if (vl > (n - off) / 8) return "truncated graph file " + path;
+        if (!out.hap_names.empty() && !(out.hap_names.back() < key)) out.names_ascending = false;
+        out.hap_names.push_back(std::move(key));
+        out.walk_off.push_back(off); out.walk_len.push_back(vl);
+        off += vl * 8;
     }
-    const uint32_t u32tot = (uint32_t)Utot;
-    PTX_HIP(ctx, hipMemcpyAsync(db->d_trio_first.p + V, &u32tot, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PTX_TRY(upload(ctx, db->d_hap_trio_off, db->h_hap_trio_off.data(), H + 1));
-    uint32_t h_err = 0;
-    PTX_TRY(download(ctx, &h_err, d_err.p, 1));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_err) return fail(ctx, PANTAX_HIP_E_LIMIT, "graph images: %u nodes head 2^24 or more unique-trio rows", h_err);
-    db->U = db->U_known = Utot;
-    db->trio_sizes_known = true;
-    db->trio_built = true;
-    db->trio_first_valid = true;
-    db->trio_keys_built = true;
-    db->cov_done = false;
-    *out = db.release();
-    return 0;
+    return "";
 }
 
 }  // namespace ptx
@@ -220,11 +224,10 @@ extern "C" int pantax_hip_db_load_images(pantax_hip_ctx *ctx, uint32_t n_species
     PTX_ENTER(ctx);
     std::vector<std::unique_ptr<SpeciesImage>> im(n_species);
     std::vector<const SpeciesImage *> ptr(n_species);
-    for (uint32_t s = 0; s < n_species; ++s) {
-        im[s].reset(new SpeciesImage());
-        const std::string e = im[s]->open(paths[s] ? paths[s] : "");
-        if (!e.empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", e.c_str());
-        ptr[s] = im[s].get();
-    }
+    std::vector<std::string> errs(n_species);
+    parallel_for(n_species, 16, [&](uint64_t i0, uint64_t i1) {
+        for (uint64_t s = i0; s < i1; ++s) { im[s].reset(new SpeciesImage()); errs[s] = im[s]->open(paths[s] ? paths[s] : ""); ptr[s] = im[s].get(); }
+    });
+    for (uint32_t s = 0; s < n_species; ++s) if (!errs[s].empty()) return fail(ctx, PANTAX_HIP_E_IO, "%s", errs[s].c_str());
     return db_from_images(ctx, n_species, ptr.data(), range_start, range_end, out);
 }

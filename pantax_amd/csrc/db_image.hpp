@@ -7,19 +7,27 @@
 
 namespace ptx {
 
-struct SpeciesImage {   // a mapped image file; the pointers look into the mapping
-    MappedFile mf;
-    uint64_t V = 0, H = 0, P = 0, U = 0, L_bases = 0;
-    bool all_same = false;
-    const uint32_t *node_len = nullptr, *path_nodes = nullptr, *trio_first = nullptr, *trio_abc = nullptr, *trio_hap = nullptr, *trio_len = nullptr;
-    const uint64_t *path_off = nullptr, *hap_trio_off = nullptr;
-    const uint4 *trio_ent = nullptr;
+struct SpeciesImage {   // the header, walk offsets and names of an image file; the big arrays stay in the file until the upload streams them
+    std::string path;
+    uint64_t V = 0, H = 0, P = 0, L_bases = 0;
+    std::vector<uint64_t> path_off;       // [H+1]
     std::vector<std::string> hap_names;
-    uint64_t off_node_len = 0, off_path_nodes = 0, off_trio_first = 0, off_trio_ent = 0, off_trio_abc = 0, off_trio_hap = 0, off_trio_len = 0;   // byte offsets in the file
+    uint64_t off_node_len = 0, off_path_nodes = 0;   // byte offsets in the file
     std::string open(const std::string &path);   // "" or an error text
 };
 
 int db_save_image(Ctx *ctx, Db *db, uint32_t species, const std::vector<std::string> &hap_names, const std::string &path);
 int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *images, const int64_t *range_start, const int64_t *range_end, pantax_hip_db **out);
+
+// where the arrays of a bincode-1 `Graph` file lie (zip.rs:171-190: u64 len + i64s; u64 map len; per entry u64 key len + bytes + u64
+// vec len + u64s), read with a handful of small preads: the file seam streams the arrays from there straight into the pinned upload
+// ring (64-bit values narrowed on the way) instead of parsing the file into host vectors first
+struct BinIndex {
+    uint64_t V = 0, off_node_len = 0;
+    std::vector<std::string> hap_names;           // in file order = BTreeMap order
+    std::vector<uint64_t> walk_off, walk_len;     // per haplotype: byte offset of its u64 node ids, their number
+    bool names_ascending = true;                  // byte-wise strictly ascending, as a BTreeMap serialises
+};
+std::string scan_graph_bin(const std::string &path, BinIndex &out);   // "" or an error text
 
 }  // namespace ptx

@@ -757,8 +757,7 @@ __global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t 
 
 void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
     const uint64_t nt = std::max<uint64_t>(1, (seg_bound + SN_TILE - 1) / SN_TILE);   // tiles of the largest segment
-    uint64_t target = SN_TARGET_WGS;
-    if (const char *ev = std::getenv("PANTAX_SSN_WGS")) target = std::max<uint64_t>(1, std::strtoull(ev, nullptr, 10));   // measurements
+    const uint64_t target = SN_TARGET_WGS;
     uint64_t p = (nt * S + target - 1) / target;
     if (p < 1) p = 1;
     if (p > nt) p = nt;
@@ -830,7 +829,7 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
                            pat->pat_species);
     }
     PTX_HIP(ctx, hipGetLastError());
-    if (std::getenv("PANTAX_SSN_DEBUG")) {   // measurements: bucket statistics of this sort on stderr (synchronises)
+    if (ctx->cfg.ssn_debug) {   // measurements: bucket statistics of this sort on stderr (synchronises)
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<uint32_t> h((size_t)S * SN_WS_WORDS);
         PTX_HIP(ctx, hipMemcpy(h.data(), d_ws, h.size() * 4, hipMemcpyDeviceToHost));

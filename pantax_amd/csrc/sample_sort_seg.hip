@@ -352,7 +352,7 @@ int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t
     // A wave's network is a longer chain of dependent LDS steps than the workgroup's; it pays through the number of buckets in flight:
     // 1000 segments 4.1 -> 3.3 ms (cfg4), 100 segments 0.49 -> 0.78 ms (cfg3); 512-row wave buckets: 5.7 ms.  Hence by the number of segments.
     sg.wave_rows = S >= 400 ? (uint32_t)SS_MAX_N : 0u;
-    if (const char *ev = std::getenv("PANTAX_SSG_WAVE_ROWS")) sg.wave_rows = (uint32_t)std::strtoul(ev, nullptr, 10);   // measurements
+    if (ctx->cfg.ssg_wave_rows) sg.wave_rows = ctx->cfg.ssg_wave_rows;   // measurements / tests
     const uint32_t nb = (uint32_t)((seg_bound + SG_TILE - 1) / SG_TILE);
     { KTimer t(ctx, "ss_sample_kernel");
       hipLaunchKernelGGL(ssg_gather_kernel, dim3(SG_SAMPLE / 256, S), dim3(256), 0, ctx->stream, sg, am, aa);

@@ -113,7 +113,7 @@ int exclusive_scan_fn(Ctx *ctx, Load load, Store store, uint64_t n, uint32_t *d_
         if (d_total) PTX_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint32_t), ctx->stream));
         return 0;
     }
-    const bool big = n >= SCAN_BIG_N, huge = n >= SCAN_HUGE_N && !std::getenv("PANTAX_SCAN_NO_HUGE");
+    const bool big = n >= SCAN_BIG_N, huge = n >= SCAN_HUGE_N && !ctx->cfg.scan_no_huge;
     const uint32_t tile_items = huge ? SCAN_TILE_HUGE : big ? SCAN_TILE_BIG : SCAN_TILE_SMALL;
     const uint32_t nb = (uint32_t)((n + tile_items - 1) / tile_items);
     const size_t need = 2 + 2 * (size_t)nb;   // u32 words: ticket, pad, one u64 per tile

@@ -872,7 +872,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     // buckets of 32 node ids up to 5e8 ids (round 4; 2^20 buckets before: 512-id buckets at 3e8 ids, whose reads are in no particular order --
     // the coverage pass gathers node records along the stream, and neighbours in the stream should be neighbours in the graph)
     int bucket_cap_bits = 24;
-    if (const char *ev = std::getenv("PANTAX_GROUP_BUCKET_BITS")) bucket_cap_bits = std::max(10, std::min(26, std::atoi(ev)));
+    if (ctx->cfg.group_bucket_bits) bucket_cap_bits = std::max(10, std::min(26, ctx->cfg.group_bucket_bits));
     while (((uint64_t)max_node_id >> shift) + 1 > (1ull << bucket_cap_bits)) ++shift;
     const uint32_t NB = (uint32_t)(max_node_id >> shift) + 1;
     DevBuf<uint32_t> cnt, scan_tmp, slot_rel;
@@ -1014,9 +1014,9 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     db->trio_free_valid = false;   // a reader of the unique-trio tables goes onto the stream: the event of an earlier strain step no longer covers them
     unsigned long long *d_abort = db->d_abort;
     if (rd->R && rd->T_pad) {
-        uint32_t xcd_map = 0, ablate = 0;
-        if (const char *ev = std::getenv("PANTAX_COV_XCD")) xcd_map = (uint32_t)std::atoi(ev);   // 1: every XCD walks one contiguous eighth of the stream (measured slower: 1.42 vs 1.30 ms at cfg3)
-        if (const char *ev = std::getenv("PANTAX_COV_ABLATE")) ablate = (uint32_t)std::atoi(ev);  // -DCOV_ABLATE builds only
+        const uint32_t xcd_map = (uint32_t)ctx->cfg.cov_xcd;   // 1: every XCD walks one contiguous eighth of the stream (measured slower: 1.42 vs 1.30 ms at cfg3)
+        const uint32_t ablate = ctx->cfg.cov_ablate;           // -DCOV_ABLATE builds only
+        const bool cov_general = ctx->cfg.cov_general;
         const bool trio = with_trio && db->U;
         const uint8_t *d_act_fast = d_active;
         if (!d_act_fast) {   // the short-read kernel loads the flag unconditionally: all ones when no species is deselected
@@ -1025,13 +1025,13 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         }
         // walks of <= 64 steps: the short-read kernel, one wave per 64-step group, PASSES groups per wave and workgroup (the LDS
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
-        if (rd->n_long < rd->n_slots && rd->n_items && !std::getenv("PANTAX_COV_GENERAL")) {
+        if (rd->n_long < rd->n_slots && rd->n_items && !cov_general) {
             KTimer t(ctx, "coverage_fast_kernel");
             // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps) over a 3072-node window;
             // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
             // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
             int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
-            if (const char *ev = std::getenv("PANTAX_COVF_SHAPE")) fshape = std::atoi(ev);
+            if (ctx->cfg.covf_shape > 0) fshape = ctx->cfg.covf_shape;
 #define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
@@ -1057,11 +1057,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         // groups that hold steps of longer walks (HiFi / ONT reads): the general kernel.  U groups of 64 steps in flight per wave,
         // PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another instantiation, for measurements);
         // PANTAX_COV_GENERAL=1 sends every group through it (measurements, and the tests force it).
-        if (rd->n_long || std::getenv("PANTAX_COV_GENERAL")) {
+        if (rd->n_long || cov_general) {
             KTimer t(ctx, "coverage_step_kernel");
-            const uint32_t only_long = std::getenv("PANTAX_COV_GENERAL") ? 0u : 1u;
+            const uint32_t only_long = cov_general ? 0u : 1u;
             int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;
-            if (const char *ev = std::getenv("PANTAX_COV_SHAPE")) shape = std::atoi(ev);
+            if (ctx->cfg.cov_shape > 0) shape = ctx->cfg.cov_shape;
 #define COVS_ARGS rd->T_pad, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_active, \
                   db->d_node_rec.p, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, rd->d_long_sum.p, \
                   rd->d_long_len0.p, n_chunks, xcd_map, ablate, only_long

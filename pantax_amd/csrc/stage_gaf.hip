@@ -302,7 +302,7 @@ static int joined_reserve(Ctx *ctx, GafJoined &J, uint64_t need_r, uint64_t need
 // follows this piece (sizes the joined columns from this piece's density when they are first allocated)
 static int tokenize_piece(Ctx *ctx, const uint8_t *d_txt, uint64_t size, bool last_is_nl, uint64_t rest_bytes, GafWork &W, GafJoined &J) {
     uint32_t n_nl = 0;
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const bool trace = ctx->cfg.trace;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -383,7 +383,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     out = HostReads();
     if (resident) resident->grouped = group;
     // PANTAX_HIP_TRACE=1: where the load spends its time (stderr)
-    const bool trace = std::getenv("PANTAX_HIP_TRACE") != nullptr;
+    const bool trace = ctx->cfg.trace;
     const auto t_enter = std::chrono::steady_clock::now();
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -409,7 +409,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     // Piece size: a sixth of the text, 64 MB .. 1 GiB (PANTAX_GAF_PIECE_BYTES caps it; a line longer than that cap is refused).
     uint64_t piece_max = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, size / 6));
     bool capped = false;
-    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < 0xE0000000ull) { piece_max = (uint64_t)v; capped = true; } }
+    if (ctx->cfg.gaf_piece_bytes && ctx->cfg.gaf_piece_bytes < 0xE0000000ull) { piece_max = ctx->cfg.gaf_piece_bytes; capped = true; }
     std::vector<uint64_t> piece_off, piece_end;
     uint64_t longest = 0;
     for (uint64_t off = 0; off < size;) {
@@ -453,13 +453,6 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         for (auto &e : ev_piece) PTX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         std::vector<void *> dsts(NP);
         for (size_t k = 0; k < NP; ++k) dsts[k] = txt[k % RING].p;
-        // Prototype: the columns the path never reads stay on the host (gaf_prune.cc: 0.73 of the bytes of the synthetic short-read GAF
-        // travel); never when the caller wants the id spans -- positions in the ORIGINAL text.
-        // MEASURED SLOWER on the box (round 4, cfg4, 15.2 GB of text, 0.73 of it left after pruning): 0.87-0.92 s to resident reads with 64
-        // pruning threads against 0.33 s unpruned -- the rewrite runs at ~25 GB/s of text where the plain pread fill runs at 70 -- so it is
-        // OFF unless PANTAX_GAF_PRUNE=1; the tests run both ways (same columns, same tables).
-        bool prune = false;
-        if (const char *ev = std::getenv("PANTAX_GAF_PRUNE")) prune = ev[0] == '1' && text != nullptr && !want_id_spans;
         std::vector<uint64_t> dev_size(NP);
         for (size_t k = 0; k < NP; ++k) dev_size[k] = piece_end[k] - piece_off[k];
         std::thread uploader([&] {
@@ -477,9 +470,8 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
                 sh.cv.notify_all();
                 return 0;
             };
-            const int rc = prune ? upload_text_pieces_pruned(ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream, gate, arrived)
-                                 : upload_text_pieces(ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream, gate,
-                                                      [&](size_t k) { return arrived(k, piece_end[k] - piece_off[k]); });
+            const int rc = upload_text_pieces(ctx, NP, dsts.data(), text, fd, file_base, piece_off.data(), piece_end.data(), up_stream, gate,
+                                              [&](size_t k) { return arrived(k, piece_end[k] - piece_off[k]); });
             std::lock_guard<std::mutex> g(sh.mu);
             if (rc != 0 && !sh.stop) { sh.rc = rc; sh.stop = true; }
             sh.cv.notify_all();
@@ -567,6 +559,8 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     if (J.set_ok) {                                     // decided piece by piece, beside the upload
         if (R > 1) PTX_TRY(download(ctx, &n_dup, J.dup_cnt.p, 1));
     } else if (R > 1) {
+        J.id_set.release();                             // the set overflowed (16 bytes per read of HBM): gone before the sort's buffers come
+
         PTX_HIP(ctx, hs_a.alloc(R)); PTX_HIP(ctx, hs_b.alloc(R)); PTX_HIP(ctx, hs_table.alloc(sort_table_elems(R))); PTX_HIP(ctx, dup_cnt.alloc(1));
         PTX_HIP(ctx, hipMemcpyAsync(hs_a.p, o_hash.p, R * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(dup_cnt.p, 0, sizeof(uint32_t), ctx->stream));

@@ -226,7 +226,7 @@ int gaf_filter_device(Ctx *ctx, const char *text, uint64_t size, std::vector<uin
     if (n_kept_out) *n_kept_out = 0;
     if (size == 0) return 0;
     uint64_t piece_max = 0xE0000000ull;   // 3.5 GiB
-    if (const char *ev = std::getenv("PANTAX_GAF_PIECE_BYTES")) { const long long v = std::atoll(ev); if (v > 0 && (uint64_t)v < piece_max) piece_max = (uint64_t)v; }
+    if (ctx->cfg.gaf_piece_bytes && ctx->cfg.gaf_piece_bytes < piece_max) piece_max = ctx->cfg.gaf_piece_bytes;
     std::vector<std::unique_ptr<FilterPiece>> pcs;
     uint64_t n_lines = 0, nrec = 0;
     for (uint64_t off = 0; off < size;) {

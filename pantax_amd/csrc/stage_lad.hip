@@ -280,7 +280,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     Db *dbm = const_cast<Db *>(db);
     const uint32_t H = (uint32_t)db->H;
     bool fused = H >= 2048;                                 // enough workgroups to fill the device (PANTAX_HAP_STATS=chunks|fused picks one, for tests)
-    if (const char *ev = std::getenv("PANTAX_HAP_STATS")) fused = ev[0] == 'f';
+    if (!ctx->cfg.hap_stats.empty()) fused = ctx->cfg.hap_stats[0] == 'f';
     if (fused) {
         KTimer t(ctx, "hap_trio_fused_kernel");
         hipLaunchKernelGGL(hap_trio_fused_kernel, dim3(H), dim3(256), 0, ctx->stream, H, db->d_hap_trio_off.p, db->d_trio_bases.p, db->d_trio_len.p, d_nnz.p, d_mean.p);
@@ -933,12 +933,8 @@ __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint3
     if (s == S) pat_start[K] = n_rows;
 }
 
-// PANTAX_MASK=walk: the path-walk kernel although the table exists (measurements, tests)
-bool use_node_haps(const Db *db) {
-    if (!db->nh_built) return false;
-    const char *ev = std::getenv("PANTAX_MASK");
-    return !(ev && ev[0] == 'w');
-}
+// option mask=walk: the path-walk kernel although the table exists (measurements, tests)
+bool use_node_haps(const Ctx *ctx, const Db *db) { return db->nh_built && ctx->cfg.mask != "walk"; }
 // end of db upload: the node -> haplotypes words of mask_nodes_kernel (one launch over the path tiles)
 int node_haps_build(Ctx *ctx, Db *db) {
     db->nh_built = false; db->nh_walk_too = false;
@@ -975,7 +971,7 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     }
     PTX_HIP(ctx, lb->d_mask.alloc(V));
     PTX_HIP(ctx, lb->d_ratio.alloc((size_t)(H ? H : 1) * 2));
-    if (!lb->prezeroed && !use_node_haps(db)) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));   // (mask_nodes_kernel writes every word)
+    if (!lb->prezeroed && !use_node_haps(ctx, db)) PTX_TRY(zero_fill(ctx, lb->d_mask.p, V * sizeof(uint64_t)));   // (mask_nodes_kernel writes every word)
     // species that can be wide (more than 64 haplotypes): side arrays laid out once per db
     // More than LAD_WIDEP haplotypes ("huge"): as many mask words as the haplotypes need, rounded up to whole groups of
     // LAD_WIDE_NW -- the reference has no cap on the LP columns (dense nvert x npaths matrix, profile.rs:1333-1342), and neither
@@ -1038,7 +1034,8 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // (a graph of millions of nodes used to send the WHOLE batch through the radix sort)
     bool use_nodes = V > SS_MAX_N && max_vs <= SSN_MAX_SEG && S <= 65535;
     if (use_nodes) use_seg = true;
-    if (const char *ev = std::getenv("PANTAX_ROW_SORT")) {   // measurements / tests: "radix"; "seg" / "nodes" = one of the batched sorts wherever it can run
+    if (!ctx->cfg.row_sort.empty()) {   // measurements / tests: "radix"; "seg" / "nodes" = one of the batched sorts wherever it can run
+        const char *ev = ctx->cfg.row_sort.c_str();
         if (ev[0] == 'r') use_seg = use_nodes = false;
         if (ev[0] == 's') { use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0; use_nodes = false; }
         if (ev[0] == 'n') use_seg = use_nodes = max_vs <= SSN_MAX_SEG && S <= 65535 && V > 0;
@@ -1048,15 +1045,14 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
         d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
     }
-    const bool by_node = use_node_haps(db);
+    const bool by_node = use_node_haps(ctx, db);
     // the path_cov_ratio sums ride on the by-node mask pass (PANTAX_RATIO=kernel: ratio_kernel for every species, as in round 3)
-    static const bool ratio_sep = std::getenv("PANTAX_RATIO") && std::getenv("PANTAX_RATIO")[0] == 'k';
+    const bool ratio_sep = ctx->cfg.ratio_kernel;
     const bool ratio_by_node = by_node && V && !ratio_sep;
     // ... and where the rows are sorted straight from the node arrays and every species has at most 64 haplotypes, the masks are formed INSIDE the
     // sort's histogram pass (ssn_hist_kernel<true>): no mask array, no pass of its own (PANTAX_MASK_PASS=1 keeps mask_nodes_kernel; so do the
     // measurement modes that read the array afterwards)
-    static const bool mask_pass_env = (std::getenv("PANTAX_MASK_PASS") && std::getenv("PANTAX_MASK_PASS")[0] == '1') ||
-                                      (std::getenv("PANTAX_OBJECTIVE") && std::getenv("PANTAX_OBJECTIVE")[0] == 'n');
+    const bool mask_pass_env = ctx->cfg.mask_pass || ctx->cfg.objective == "nodes";
     const bool masks_in_sort = use_nodes && ratio_by_node && !db->nh_walk_too && !wide && !mask_pass_env;
     lb->masks_in_sort = masks_in_sort;
     if (!masks_in_sort) {
@@ -2337,7 +2333,7 @@ __global__ void __launch_bounds__(256) objective_rows_kernel(const int32_t *__re
 static int objective_launch(Ctx *ctx, const Db *db, LadBatch *lb, const uint8_t *d_need2, const double *d_x1, const double *d_x2, double *d_obj1,
                             double *d_obj2) {
     const uint32_t S = db->S;
-    static const bool by_nodes = std::getenv("PANTAX_OBJECTIVE") && std::getenv("PANTAX_OBJECTIVE")[0] == 'n';   // measurements / tests: the pass over the nodes
+    const bool by_nodes = ctx->cfg.objective == "nodes";   // measurements / tests: the pass over the nodes
     if (lb->rows_c0_valid && lb->n_wide == 0 && (!by_nodes || lb->masks_in_sort)) {
         KTimer t(ctx, "objective_rows_kernel");
         PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));

@@ -971,8 +971,7 @@ int trio_visits_build(Ctx *ctx, Db *db) {
     db->trio_visit_ok = false;
     db->n_vgroups = 0;
     db->h_trio_slow.assign(db->S, 1);          // until shown otherwise every species is the node-block kernel's
-    const char *ev = std::getenv("PANTAX_TRIO_PATH");
-    const bool force_block = ev && ev[0] == 'b' && ev[1] == 'l';   // "block": every species through the node-block kernel (tests, measurements)
+    const bool force_block = ctx->cfg.trio_path == "block";   // every species through the node-block kernel (tests, measurements)
     PTX_HIP(ctx, db->d_trio_slow.alloc(db->S ? db->S : 1));
     PTX_HIP(ctx, hipMemsetAsync(db->d_trio_slow.p, 0, (db->S ? db->S : 1) * sizeof(uint32_t), ctx->stream));
     PTX_HIP(ctx, db->d_node_visited.alloc(db->V / 32 + 2));
@@ -1105,14 +1104,14 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     // which uniqueness path: the visit table (default; species with a node of more than 64 visits: by node block), or through
     // global buckets for the whole db (a species of >= 2^27 nodes among those left to the node-block kernel, or forced)
     bool by_block = db->trio_block_ok && (db->trio_visit_ok || db->n_blocks);
-    if (const char *ev = std::getenv("PANTAX_TRIO_PATH")) { if (ev[0] == 'b' && ev[1] == 'u') by_block = false; }
+    if (ctx->cfg.trio_path == "bucket") by_block = false;
     // a db the visit table covers whole files its rows from the visit kernel's records (trio_rows_kernel); with a species left to the
     // node-block kernel -- or PANTAX_TRIO_ROWS=path -- the rows are filed by the pass over the walks (trio_lookup_kernel) as in rounds 1-3
     // (a MIXED db -- some species on the node-block kernel -- files those species' rows by the pass over their walks, behind the others';
     // when the row-order export copies are wanted, i.e. off the hot path, a mixed db takes the pass over the walks whole: the db images
     // expect a species' lookup rows as one block in node order)
     bool rows_by_visit = by_block && P && db->n_vgroups && (db->n_blocks == 0 || !with_keys);
-    if (const char *ev = std::getenv("PANTAX_TRIO_ROWS")) { if (ev[0] == 'p') rows_by_visit = false; }
+    if (ctx->cfg.trio_rows == "path") rows_by_visit = false;
     const bool mixed = rows_by_visit && db->n_blocks != 0;
     // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
     // The visit-table / node-block path zero-fills tile_cnt and the bits only: its kernels STORE the count of every node that has
@@ -1143,17 +1142,13 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
     // PANTAX_TRIO_XCD: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
-    uint32_t trio_xcd = 3;
-    if (const char *ev = std::getenv("PANTAX_TRIO_XCD")) trio_xcd = (uint32_t)std::atoi(ev);
+    const uint32_t trio_xcd = (uint32_t)ctx->cfg.trio_xcd;
     if (P && by_block && db->n_vgroups) {
         KTimer t(ctx, "trio_visit_kernel");
         // every wave walks U x rounds consecutive groups of 64 visits (PANTAX_TV_U / PANTAX_TV_ROUNDS pick another shape, for
         // measurements): consecutive groups visit consecutive nodes, whose walk entries share cache lines
-        uint32_t U = 4, rounds = 4;
-        if (const char *ev = std::getenv("PANTAX_TV_U")) U = (uint32_t)std::atoi(ev);
-        if (const char *ev = std::getenv("PANTAX_TV_ROUNDS")) rounds = (uint32_t)std::max(1, std::atoi(ev));
-        uint32_t tv_ablate = 0;
-        if (const char *ev = std::getenv("PANTAX_TV_ABLATE")) tv_ablate = (uint32_t)std::atoi(ev);   // -DTV_ABLATE builds only
+        const uint32_t U = (uint32_t)ctx->cfg.tv_u, rounds = (uint32_t)std::max(1, ctx->cfg.tv_rounds);
+        const uint32_t tv_ablate = ctx->cfg.tv_ablate;   // -DTV_ABLATE builds only
 #define TV_CHUNKS(UU) ((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds))
 #define TV_LAUNCH(UU, RR) hipLaunchKernelGGL((trio_visit_kernel<UU, RR>), dim3((trio_xcd & 1u) ? ((TV_CHUNKS(UU) + 7u) / 8u) * 8u : TV_CHUNKS(UU)), dim3(256), 0, ctx->stream, db->n_vgroups, \
                                          rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, tv_ablate,  \
@@ -1168,8 +1163,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         // LDS table slots per 64-node block (PANTAX_TB_SLOTS=512|256|128 picks another instantiation, for measurements): fewer
         // slots = more blocks resident per CU (the kernel is bound by the latency of each wave's dependent loads), more blocks
         // that need sub-passes
-        int slots = 256;
-        if (const char *ev = std::getenv("PANTAX_TB_SLOTS")) slots = std::atoi(ev);
+        const int slots = ctx->cfg.tb_slots;
 #define TB_LAUNCH(N) hipLaunchKernelGGL(trio_block_kernel<N>, dim3(db->n_blocks), dim3(64), 0, ctx->stream, db->d_blk_rec.p, db->d_runs.p, \
                                         db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2)
         if (slots == 512) TB_LAUNCH(512); else if (slots == 128) TB_LAUNCH(128); else TB_LAUNCH(256);
@@ -1194,7 +1188,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
             KTimer t(ctx, "trio_uniq_kernel");
             // mean bucket size decides: short buckets (few haplotypes per node) compare through shuffles, long ones hash
             bool hashed = n_win > 16 * V;   // measured: 7 windows per node -> shuffles 0.050 vs hash 0.058 ms; 34 per node -> 4.66 vs 1.69 ms
-            if (const char *ev = std::getenv("PANTAX_UNIQ_HASH")) hashed = ev[0] == '1';
+            if (ctx->cfg.uniq_hash >= 0) hashed = ctx->cfg.uniq_hash == 1;
             if (hashed)
                 hipLaunchKernelGGL(trio_uniq_lds_kernel, dim3((uint32_t)((n_win + UNIQ_CH - 1) / UNIQ_CH)), dim3(256), 0, ctx->stream, n_win, (uint32_t)V,
                                    ts.bucket.p, ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
@@ -1206,7 +1200,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (rows_by_visit) {
             // rows in (species, hap, position) order = ranks of the flag bits: prefix of every flag word (total = U); slots in visit order =
             // prefix of the groups' counts
-            static const bool chained_ranks = std::getenv("PANTAX_FLAG_RANK") && std::getenv("PANTAX_FLAG_RANK")[0] == 'c';   // measurements: the chained scan
+            const bool chained_ranks = ctx->cfg.flag_rank_chained;   // measurements: the chained scan
             if (chained_ranks)
                 PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, FlagRankStore{ts.word_rank.p, ts.uniq_q.p}, zbits, ts.d_tot.p + 1, "scan_chained_kernel<FlagWord>"));
             else {
@@ -1249,8 +1243,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                 // a wave takes PANTAX_ROWS_U = 1, 2 or 4 batches of eight groups at once.  Two halve what the kernel waits for memory (8.5 -> 6.0-6.6 ms
                 // inside the step) -- and the step gets SLOWER (32.3-32.6 -> 33.6-34.3 ms at cfg4): the current step's local sorts, which run beside
                 // it on the main stream, stretch from 1.1 to 3.8 ms.  Hence one.
-                uint32_t RU = 1;
-                if (const char *ev = std::getenv("PANTAX_ROWS_U")) RU = (uint32_t)std::atoi(ev);
+                uint32_t RU = (uint32_t)ctx->cfg.rows_u;
                 if (RU != 2 && RU != 4) RU = 1;
                 const uint32_t rchunks = (NG + 32 * RU - 1) / (32 * RU);
                 const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);

@@ -57,6 +57,11 @@ class Engine:
     def sync(self):
         self._check(self.lib.pantax_hip_sync(self.ctx))
 
+    def set_option(self, name, value=None):
+        """pantax_hip_set_option: a switch of this ctx (common.hpp CtxConfig); value None = its default.  The library reads the
+        environment only once, at init."""
+        self._check(self.lib.pantax_hip_set_option(self.ctx, name.encode(), None if value is None else str(value).encode()))
+
     # ------------------------------------------------------------------ uploads
     def upload_db(self, species):
         """species: list of objects with node_len, path_off, path_nodes, range_start, range_end
@@ -73,18 +78,46 @@ class Engine:
         self.node_off[1:] = np.cumsum([len(g.node_len) for g in species])
         self.hap_off = np.zeros(S + 1, dtype=np.uint64)
         self.hap_off[1:] = np.cumsum([len(g.path_off) - 1 for g in species])
-        self.node_len = as_c(np.concatenate([g.node_len for g in species]), np.int64)
+        self.V = int(self.node_off[-1])
+        self.H = int(self.hap_off[-1])
+        # one part per species (pantax_hip_db_upload_parts): the arrays travel as they are, nothing is concatenated on the host
+        keep = []
+        parts = (_ffi.GraphPart * S)()
+        for i, g in enumerate(species):
+            nl, po, pn = as_c(g.node_len, np.int64), as_c(g.path_off, np.uint64), as_c(g.path_nodes, np.uint32)
+            keep.append((nl, po, pn))
+            parts[i] = _ffi.GraphPart(len(nl), len(po) - 1, nl.ctypes.data, po.ctypes.data, pn.ctypes.data if len(pn) else None)
+        db = C.c_void_p()
+        self._check(self.lib.pantax_hip_db_upload_parts(self.ctx, C.c_uint32(S), p(self.range_start), p(self.range_end), parts, C.byref(db)))
+        self.db = db
+        self.U = None
+
+    def upload_db_flat(self, species):
+        """The same db through pantax_hip_db_upload (SURVEY 8b's struct of flat arrays: all species concatenated by the caller)."""
+        if self.db:
+            self.lib.pantax_hip_db_free(self.ctx, self.db)
+            self.db = None
+            self._inflight = 0
+        S = len(species)
+        self.S = S
+        self.range_start = as_c([g.range_start for g in species], np.int64)
+        self.range_end = as_c([g.range_end for g in species], np.int64)
+        self.node_off = np.zeros(S + 1, dtype=np.uint64)
+        self.node_off[1:] = np.cumsum([len(g.node_len) for g in species])
+        self.hap_off = np.zeros(S + 1, dtype=np.uint64)
+        self.hap_off[1:] = np.cumsum([len(g.path_off) - 1 for g in species])
+        node_len = as_c(np.concatenate([g.node_len for g in species]), np.int64)
         offs = [np.zeros(1, dtype=np.uint64)]
         base = 0
         for g in species:
             offs.append(np.asarray(g.path_off[1:], dtype=np.uint64) + np.uint64(base))
             base += int(g.path_off[-1])
-        self.path_off = as_c(np.concatenate(offs), np.uint64)
-        self.path_nodes = as_c(np.concatenate([g.path_nodes for g in species]), np.uint32)
+        path_off = as_c(np.concatenate(offs), np.uint64)
+        path_nodes = as_c(np.concatenate([g.path_nodes for g in species]), np.uint32)
         self.V = int(self.node_off[-1])
         self.H = int(self.hap_off[-1])
-        gs = _ffi.Graphs(S, p(self.range_start), p(self.range_end), p(self.node_off), p(self.node_len),
-                         p(self.hap_off), p(self.path_off), p(self.path_nodes))
+        gs = _ffi.Graphs(S, p(self.range_start), p(self.range_end), p(self.node_off), p(node_len),
+                         p(self.hap_off), p(path_off), p(path_nodes))
         db = C.c_void_p()
         self._check(self.lib.pantax_hip_db_upload(self.ctx, C.byref(gs), C.byref(db)))
         self.db = db

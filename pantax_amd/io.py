@@ -38,18 +38,6 @@ def load_gaf(path, n_threads=4, engine=None):
         lib.pantax_hip_gaf_free(h)
 
 
-def prune_gaf_text(text: bytes) -> bytes:
-    """The rewrite the device GAF load applies on the host before the text travels (pantax_hip_gaf_prune_text): lines of twelve
-    fields keep fields 1, 2, 6-9, 12 (the others emptied, the tags cut off), any other line is copied byte for byte."""
-    lib = _ffi.load()
-    out = C.create_string_buffer(max(len(text), 1))
-    n = C.c_uint64(0)
-    rc = lib.pantax_hip_gaf_prune_text(text, C.c_uint64(len(text)), out, C.byref(n))
-    if rc != 0:
-        raise _ffi.PantaxHipError(rc, "gaf_prune_text")
-    return out.raw[:n.value]
-
-
 def load_graph(path, fmt="gfa"):
     """-> (node_len int64 [V], hap_names [H] (byte order), path_off uint64 [H+1], path_nodes uint32 [P])"""
     lib = _ffi.load()

@@ -15,3 +15,21 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def set_opt():
+    """set_opt(eng, name, value): a library option (pantax_hip_set_option) for the duration of the test; value None = default.
+    The library reads the environment only at pantax_hip_init, so tests switch its in-tree paths through the ctx."""
+    done = []
+
+    def _set(eng, name, value):
+        eng.set_option(name, value)
+        done.append((eng, name))
+    yield _set
+    for eng, name in done:
+        try:
+            if eng.ctx:
+                eng.set_option(name, None)
+        except Exception:   # noqa: BLE001
+            pass

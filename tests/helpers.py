@@ -334,3 +334,100 @@ def check_metrics_against_literal(exp_metrics, got_dicts, where=""):
             else:
                 assert abs(ev - gv) <= tol * max(1.0, abs(ev)), (where, h, ek, ev, gv)
         assert bool(e["is_rescue"]) == bool(g["is_rescue"]), (where, h, e["is_rescue"], g["is_rescue"])
+
+
+def oracle_strain_level(sset, sp, keep, absolute, species_idx, threads=8, **strain_kw):
+    """The oracle's strain level (trio index, coverage, filters, both LPs, abundace_constraint) for the species `species_idx`, on
+    `threads` host threads -> {species index: (metrics dicts per haplotype, candidates, objective 1)}.  TEST checker."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    rd = sset.reads
+    first_, order = orc.group_reads(sp, len(sset.species))
+    first_ = first_.astype(np.int64)
+    order = order.astype(np.int64)
+
+    def one(s):
+        g = sset.species[s]
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        T = orc.TrioTable(G)
+        sel = np.sort(order[first_[s]:first_[s + 1]])
+        so, nid, ps, pe = select_reads(rd, sel)
+        b, c, t, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
+        rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, **strain_kw)
+        assert rc_ == 0
+        orc.abundance_constraint(absolute[s], omet)
+        return s, (orc.metrics_to_dicts(omet), nc, o1)
+    todo = [int(s) for s in species_idx if keep[s]]
+    with ThreadPoolExecutor(threads) as ex:
+        return dict(ex.map(one, todo))
+
+
+def oracle_passing_rows(sset, level, sd=0.2, min_cov=0):
+    """abundance_est's row filter (profile.rs:3219-3245) over the oracle's strain level -> {species name: {hap name: metrics}}"""
+    out = {}
+    for s, (d, nc, o1) in level.items():
+        g = sset.species[s]
+        rows = {}
+        for h, m in enumerate(d):
+            cov = m["predicted_coverage"]
+            if cov is None:
+                continue
+            if (len(d) > 1 or (m["total_cov_diff"] is not None and m["total_cov_diff"] <= sd)) and cov >= min_cov and cov != 0.0:
+                rows[g.hap_names[h]] = m
+        out[g.name] = rows
+    return out
+
+
+_STEP_ROW_FIELDS = [(2, "predicted_coverage", 1e-7), (4, "path_base_cov", 2e-6), (5, "unique_trio_fraction", 0.0), (6, "uniq_trio_cov_mean", 1e-9),
+                    (7, "first_sol", 1e-7), (8, "strain_cov_diff", 0.0), (9, "total_cov_diff", 1e-7)]
+
+
+def check_step_rows_against_oracle(strain_rows, expected, l1_tol=1e-4):
+    """strain_rows: the step's table (pipeline.finalize_end); expected: oracle_passing_rows(...) of SOME species.  For each of them the
+    step must report exactly the oracle's strains, every metric within its tolerance (rounded ones exactly), and the species' relative L1
+    of the LP solution and of the predicted coverage within l1_tol (north_star: 1e-4).  -> worst relative L1."""
+    got = {}
+    for r in strain_rows:
+        if r[0] in expected:
+            got.setdefault(r[0], {})[r[1]] = r
+    worst = 0.0
+    for name, rows in expected.items():
+        g = got.get(name, {})
+        assert set(g) == set(rows), (name, sorted(set(g) ^ set(rows)))
+        d1 = n1 = d2 = n2 = 0.0
+        for hap, m in rows.items():
+            r = g[hap]
+            for col, key, tol in _STEP_ROW_FIELDS:
+                ev, gv = m[key], r[col]
+                assert (ev is None) == (gv is None), (name, hap, key, ev, gv)
+                if ev is None:
+                    continue
+                if tol == 0.0:
+                    assert ev == gv, (name, hap, key, ev, gv)
+                else:
+                    assert abs(ev - gv) <= tol * max(1.0, abs(ev)), (name, hap, key, ev, gv)
+            d1 += abs(r[7] - (m["first_sol"] or 0.0)); n1 += abs(m["first_sol"] or 0.0)
+            d2 += abs(r[2] - m["predicted_coverage"]); n2 += abs(m["predicted_coverage"])
+        worst = max(worst, d1 / n1 if n1 else 0.0, d2 / n2 if n2 else 0.0)
+    assert worst <= l1_tol, worst
+    return worst
+
+
+def oracle_tables_parallel(sset, threads=8, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, min_cov=0):
+    """Both tables of profile::profile from the oracle, species on `threads` host threads (the full-size configurations) ->
+    (species rows [(name, abundance, coverage)], strain rows [(species, hap, coverage, abundance, metrics)]) in table order."""
+    from oracle import oracle as orc
+    rd = sset.reads
+    S = len(sset.species)
+    sp = orc.par_bin_reads(rd.step_off, rd.node_id, [g.range_start for g in sset.species], [g.range_end for g in sset.species], threads)
+    counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
+    keep, absolute, abundance = orc.species_profile(sp, rd.qlen, counts, sset.avg_len())
+    species_rows = sorted([(sset.species[s].name, abundance[s], absolute[s]) for s in range(S) if keep[s]], key=lambda r: -r[1])
+    sel = [s for s in range(S) if keep[s] and abundance[s] > min_ab]
+    level = oracle_strain_level(sset, sp, keep, absolute, sel, threads=threads, fr=fr, fc=fc, sr=sr)
+    passing = oracle_passing_rows(sset, level, sd=sd, min_cov=min_cov)
+    rows = [(g.name, hap, m) for s in sel for g in [sset.species[s]] for hap, m in passing[g.name].items()]
+    tot = sum(r[2]["predicted_coverage"] for r in rows)
+    out = [(sp_, hap, m["predicted_coverage"], m["predicted_coverage"] / tot, m) for sp_, hap, m in rows]
+    out.sort(key=lambda r: -r[3])
+    return species_rows, out, sp

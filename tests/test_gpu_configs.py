@@ -13,7 +13,8 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import expected_total_bases, oracle_species_checks, select_reads, slice_reads
+from tests.helpers import (check_step_rows_against_oracle, expected_total_bases, oracle_passing_rows, oracle_species_checks, oracle_strain_level,
+                           oracle_tables_parallel, select_reads, slice_reads)
 
 pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 32)
@@ -101,18 +102,61 @@ def _tables_normalised(eng, sset):
     return sp_rows, st_rows, stats
 
 
-def test_cfg3_full_size_every_species_against_oracle(eng):
+@pytest.fixture(scope="module")
+def cfg3_set():
     from pantax_amd import synth
-    sset = synth.make_set_mp(20260504, 100, 10, 10_000_000, 5_000_000)
+    return synth.make_set_mp(20260504, 100, 10, 10_000_000, 5_000_000)
+
+
+def test_cfg3_full_size_every_species_against_oracle(eng, cfg3_set):
+    sset = cfg3_set
     out = _run_stages(eng, sset)
     assert np.array_equal(out["sp"], _bin_oracle(sset, THREADS))
     _common_properties(sset, out)
     bad = oracle_species_checks(sset, out["sp"], out["keep"], out["absolute"], out["bases"], out["cov"], out["tb"], out["hto"], out["gmet"],
                                 out["info"], range(len(sset.species)), threads=THREADS)
     assert not bad, bad[:10]
-    # the single-call resident step gives normalised tables that name exactly the present strains of the kept species
+    # the single-call resident step gives normalised tables ...
     sp_rows, st_rows, stats = _tables_normalised(eng, sset)
     assert len(sp_rows) == int(out["keep"].sum())
+    # ... whose strain rows are the oracle's for EVERY species: the step path (node_cov_stats_kernel, masks formed in the row sort,
+    # objective over the rows, the rows kernel without export copies) against the checker, not only the stage calls above
+    level = oracle_strain_level(sset, out["sp"], out["keep"], out["absolute"], range(len(sset.species)), threads=THREADS)
+    active = {r[0] for r in sp_rows if r[1] > 1e-4}                    # load_species_range's -a cut (profile.rs:602)
+    check_step_rows_against_oracle(st_rows, {k: v for k, v in oracle_passing_rows(sset, level).items() if k in active})
+
+
+def test_cfg3_file_seam_every_species_against_oracle(eng, cfg3_set, tmp_path_factory):
+    """BASELINE configs[2] through the DROP-IN seam (pantax_hip_profile == profile::profile, profile.rs:3325: files in, files out;
+    rows a6 + a16 + (b) + f2 at size): 100 `.bin` graphs + 1.4 GB of GAF text on disk -> the two tables, compared with the oracle's
+    tables for every species; cold from the bincode files (images written on the way), then from the device-ready images -- same bytes."""
+    from pantax_amd import synth
+    from tests.test_gpu_pipeline import _check_outputs
+    sset = cfg3_set
+    root = tmp_path_factory.mktemp("cfg3_seam")
+    db = root / "db"
+    db.mkdir()
+    synth.write_db(sset, str(db), write_gfa=False, threads=THREADS)
+    gaf = root / "gfa_mapped.gaf"
+    synth.write_gaf_parallel(sset.reads, str(gaf), threads=THREADS)
+    exp_species, exp_strain, _ = oracle_tables_parallel(sset, threads=THREADS)
+    cwd = os.getcwd()
+    outs = []
+    for name, ic in (("wd_cold", 2), ("wd_warm", 1)):
+        wd = root / name
+        wd.mkdir()
+        os.chdir(str(wd))
+        try:
+            eng.profile(str(db), str(wd), str(gaf), zip="serialize", sample_nodes=0, image_cache=ic)
+        finally:
+            os.chdir(cwd)
+        _check_outputs(str(wd), sset, exp_species, exp_strain)
+        outs.append(wd)
+    assert len(list((db / "species_graph_info").glob("*.hipdb"))) == len([r for r in exp_species if r[1] > 1e-4])   # one image per selected species
+    for f in ("species_abundance.txt", "strain_abundance.txt"):
+        assert open(outs[0] / f).read() == open(outs[1] / f).read()
+    import shutil
+    shutil.rmtree(str(root), ignore_errors=True)
 
 
 def test_cfg4_share_full_size_properties_and_oracle_sample(eng):
@@ -230,3 +274,10 @@ def test_cfg4_full_size_one_gpu_properties_and_oracle_sample(eng):
     eng.upload_packed(rd)
     sp_rows, st_rows, stats = _tables_normalised(eng, sset)
     assert len(sp_rows) == int(out["keep"].sum())
+    # ... and the STEP's strain rows at the bench's size against the oracle for the sampled species (what bench.py's abundance-L1 leg
+    # checks after its timed region, here inside the suite): integers of the metrics exactly, LP-derived ones to 1e-7, L1 <= 1e-4
+    level = oracle_strain_level(sset, sp, out["keep"], out["absolute"], sample, threads=THREADS)
+    active = {r[0] for r in sp_rows if r[1] > 1e-4}                    # load_species_range's -a cut (profile.rs:602)
+    expected = {k: v for k, v in oracle_passing_rows(sset, level).items() if k in active}
+    assert len(expected) >= 5
+    check_step_rows_against_oracle(st_rows, expected)

@@ -106,16 +106,16 @@ def test_micro_coverage_golden(eng):
                                                   (4, 2, 40, 20000, 20000, None),   # > 16 windows per node: the hashed uniqueness test
                                                   (2, 3, 6, 20000, 40000, "1"), (4, 2, 40, 20000, 20000, "0"),   # and each form forced
                                                   (2, 3, 6, 20000, 40000, "block"), (3, 5, 10, 50000, 30000, "block"), (4, 2, 40, 20000, 20000, "block")])
-def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch):
+def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, set_opt):
     from oracle import oracle as orc
     from pantax_amd import synth
     # default: uniqueness through the visit table (species with a node of more than 64 visits: by node block in LDS); forced: every
     # species by node block, or the global bucket path with either of its kernels
     if uniq == "block":
-        monkeypatch.setenv("PANTAX_TRIO_PATH", "block")   # read by the library at db upload
+        set_opt(eng, "trio_path", "block")   # read by the library at db upload
     elif uniq is not None:
-        monkeypatch.setenv("PANTAX_TRIO_PATH", "bucket")
-        monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)   # read by the library at every trio build
+        set_opt(eng, "trio_path", "bucket")
+        set_opt(eng, "uniq_hash", uniq)   # read by the library at every trio build
     sset = synth.make_set(seed, S, H, R, L, adversarial_frac=0.01, single_strain_every=4 if S >= 5 else 0)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -148,12 +148,12 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, monkeypatch
 
 
 @pytest.mark.parametrize("general", ["1", None])
-def test_coverage_kernels_agree_on_short_reads(eng, general, monkeypatch):
+def test_coverage_kernels_agree_on_short_reads(eng, general, set_opt):
     """Short reads take coverage_fast_kernel (one wave per 64-step group); PANTAX_COV_GENERAL=1 sends the same groups through
     the general kernel that otherwise only sees the groups of longer walks.  Both must equal the oracle bit for bit."""
     from pantax_amd import synth
     if general:
-        monkeypatch.setenv("PANTAX_COV_GENERAL", general)
+        set_opt(eng, "cov_general", general)
     sset = synth.make_set(11, 4, 6, 60000, 50000, adversarial_frac=0.02, single_strain_every=4)
     from oracle import oracle as orc
     rd = sset.reads
@@ -206,7 +206,7 @@ def test_coverage_and_trio_index_vs_literal_python_restatement(eng, k):
 
 @pytest.mark.parametrize("path", ["block", None])
 @pytest.mark.parametrize("V,H,K", [(200, 40, 300), (700, 30, 500), (300, 3, 9000), (3000, 12, 4000)])
-def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K, path, monkeypatch):
+def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K, path, set_opt):
     """Random walks over a few hundred nodes: a node block meets thousands of DISTINCT windows, more than its LDS table
     holds, so it is redone in sub-passes over key classes; walks jump between blocks at every step (runs of length 1)
     and visit both orientations of the same window.  `path` None: whatever the upload chooses -- the visit table where no
@@ -214,7 +214,7 @@ def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K, path, monkeyp
     return to a node, windows with equal ends), the node-block kernel otherwise."""
     from oracle import oracle as orc
     if path:
-        monkeypatch.setenv("PANTAX_TRIO_PATH", path)
+        set_opt(eng, "trio_path", path)
     rng = np.random.default_rng(V + H)
     node_len = rng.integers(1, 40, size=V).astype(np.int64)
     walks = [rng.integers(0, V, size=K).astype(np.uint32) for _ in range(H)]
@@ -230,13 +230,13 @@ def test_trio_index_block_path_overflowing_lds_table(eng, V, H, K, path, monkeyp
 
 
 @pytest.mark.parametrize("uniq", ["0", "1", None])
-def test_trio_index_with_huge_buckets(eng, uniq, monkeypatch):
+def test_trio_index_with_huge_buckets(eng, uniq, set_opt):
     """Paths that keep coming back to a handful of nodes: thousands of windows share their smallest end node, far more
     than one workgroup's LDS table holds (the hashed form falls back to scanning the bucket), and most trios repeat."""
     from oracle import oracle as orc
     if uniq is not None:
-        monkeypatch.setenv("PANTAX_TRIO_PATH", "bucket")
-        monkeypatch.setenv("PANTAX_UNIQ_HASH", uniq)
+        set_opt(eng, "trio_path", "bucket")
+        set_opt(eng, "uniq_hash", uniq)
     rng = np.random.default_rng(17)
     V, H, K = 9, 40, 300
     node_len = rng.integers(1, 40, size=V).astype(np.int64)
@@ -740,7 +740,7 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,R,L,pf", [(31, 5, 10, 90000, 30000, 0.4), (32, 3, 30, 90000, 20000, 0.6)])
-def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, monkeypatch):
+def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, set_opt):
     """a9's per-haplotype statistics of the unique-trio abundances (count of non-zero ones, z-score-filtered mean, profile.rs:1028-1147):
     the three-pass kernel with 32 workgroups per haplotype and the one-launch kernel with a workgroup per haplotype (databases of
     thousands of haplotypes) sum in different fixed orders -- the metrics they lead to agree to rounding, the decisions exactly --
@@ -758,7 +758,7 @@ def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, monkeypatc
     eng.get_node_abundances(fetch=False)
     outs = []
     for mode in ("chunks", "fused"):
-        monkeypatch.setenv("PANTAX_HAP_STATS", mode)
+        set_opt(eng, "hap_stats", mode)
         met, info = eng.strain_profiling(absolute, species_active=keep)
         outs.append((metrics_to_dicts(met, eng.H), [(i.n_candidates, i.status1, i.status2, i.n_rows, i.n_patterns) for i in info]))
     assert outs[0][1] == outs[1][1]
@@ -786,7 +786,7 @@ def _same_infos(a, b):
     (26, 2, 40, 120000, 30000, 0.9, dict(fr=0.05)),            # thousands of patterns
     (28, 3, 150, 400000, 20000, 0.8, dict(fr=0.05)),           # a wide species in the batch
 ])
-def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
+def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, set_opt):
     """The four row pipelines of lad_prepare -- whole-batch sample sort (small inputs), whole-batch radix sort, the node-order
     compaction + batched per-species sort (round 3's many-species step) and the batched sort straight from the node arrays (the
     many-species step now; both forced here at a small size) -- and the two ways
@@ -805,8 +805,8 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
     eng.get_node_abundances(fetch=False)
     outs = []
     for sort, maskmode in ((None, None), ("seg", None), ("nodes", None), ("radix", None), (None, "walk"), ("seg", "walk"), ("nodes", "walk")):
-        monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
-        monkeypatch.delenv("PANTAX_MASK", raising=False) if maskmode is None else monkeypatch.setenv("PANTAX_MASK", maskmode)
+        set_opt(eng, "row_sort", sort)
+        set_opt(eng, "mask", maskmode)
         met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
         outs.append((np.frombuffer(bytes(memoryview(met)), dtype=np.uint8).copy(),
                      [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in info]))
@@ -817,7 +817,7 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, monkeypatch):
+def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, set_opt):
     """No limit on a species' size in the many-species row sort (round 4: a graph of more than 600 000 nodes used to send the whole
     batch through the radix sort): two species of 1.75e6 nodes each -- buckets of more than a thousand rows, the second wave kernel and the LDS
     network in use -- give the same step output, objectives, row and pattern counts as the radix pipeline."""
@@ -828,7 +828,7 @@ def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, monkeypatch)
     eng.upload_packed(sset.reads)
     outs = []
     for sort in (None, "radix"):
-        monkeypatch.delenv("PANTAX_ROW_SORT", raising=False) if sort is None else monkeypatch.setenv("PANTAX_ROW_SORT", sort)
+        set_opt(eng, "row_sort", sort)
         out = eng.profile_step(sset.avg_len())
         outs.append((out[0].copy(), bytes(out[2]), [(i.n_candidates, i.status1, i.status2, i.iters1, i.iters2, i.n_rows, i.n_patterns, i.obj1, i.obj2) for i in out[3]]))
     assert any(o[5] > 100_000 for o in outs[0][2])
@@ -859,7 +859,7 @@ def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,every", [(71, 4, 80, 2), (72, 5, 70, 3)])
-def test_step_on_a_mixed_database(eng, seed, S, H, every, monkeypatch):
+def test_step_on_a_mixed_database(eng, seed, S, H, every, set_opt):
     """A database that holds species of BOTH kinds -- single-strain species (the visit table's) beside species of 70-80 strains (a node with
     more than 64 visits: node-block kernel).  The step's rebuild files the first kind's lookup rows from the visit kernel's records and the
     second kind's by the pass over their walks, behind them; the stage calls (which want the export copies) take the pass over the walks for
@@ -873,9 +873,9 @@ def test_step_on_a_mixed_database(eng, seed, S, H, every, monkeypatch):
     eng.upload_db(sset.species)
     eng.upload_packed(sset.reads)
     out_mixed = eng.profile_step(sset.avg_len())
-    monkeypatch.setenv("PANTAX_TRIO_ROWS", "path")
+    set_opt(eng, "trio_rows", "path")
     out_path = eng.profile_step(sset.avg_len())
-    monkeypatch.delenv("PANTAX_TRIO_ROWS")
+    set_opt(eng, "trio_rows", None)
     assert bytes(out_mixed[2]) == bytes(out_path[2]) and np.array_equal(out_mixed[0], out_path[0])
     # stage calls on the same db: trio tables and coverage against the oracle, species by species
     sp, *_ = eng.rcls_profile()
@@ -1033,14 +1033,14 @@ def test_device_sorts_against_host_sort(eng, algo):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wave_rows", [None, "1000000", "0"])
-def test_segmented_sample_sort_against_host_sort(eng, wave_rows, monkeypatch):
+def test_segmented_sample_sort_against_host_sort(eng, wave_rows, set_opt):
     """The batched row sort of the many-species step (sample_sort_seg.hip) through the host-buffer utility: segments of
     every size class side by side (empty neighbours cannot exist in this interface; 1 row, <= 4096 rows ranked by the
     sample kernel, tens of thousands of rows, massive ties, presorted, and an unrepresentative sample whose one bucket
     exceeds the LDS capacities), each sorted by (k1, k2) on its own.  Buckets are sorted a workgroup each, or -- from 400
     segments on, forced here through PANTAX_SSG_WAVE_ROWS -- a wave each up to 256 rows."""
     if wave_rows is not None:
-        monkeypatch.setenv("PANTAX_SSG_WAVE_ROWS", wave_rows)
+        set_opt(eng, "ssg_wave_rows", wave_rows)
     rng = np.random.default_rng(7)
     segs = []
     for n in (1, 2, 63, 4095, 4096, 4097, 5000, 70000):

@@ -255,14 +255,14 @@ def eng():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("piece", [None, "300000"])
-def test_resident_gaf_load_with_and_without_column_pruning(eng, tmp_path, piece, monkeypatch):
-    """pantax_hip_reads_load_gaf: the columns the path never reads stay on the host (gaf_prune.cc) when PANTAX_GAF_PRUNE=1 (a prototype that measured slower than the plain load and is off by default) -- either
-    way the resident reads are the reads of the text: same host columns, same species per read, same coverage integers; and those
-    of the packed upload of the generator's arrays.  The text carries every quirk of the format between its generated lines."""
+def test_resident_gaf_load_equals_the_gaf_reader_oracle(eng, tmp_path, piece, set_opt):
+    """pantax_hip_reads_load_gaf: the resident reads are the reads of the text -- the host columns, the species per read and the
+    coverage integers of the packed upload of what oracle/gaf_reader.py (a reading of load_gaf_file_lazy, rcls.rs:119-146, that is not
+    this library's tokenizer) makes of the same text.  The text carries every quirk of the format between its generated lines."""
     from pantax_amd import synth
     from tests.helpers import gaf_quirks_text
     if piece is not None:
-        monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", piece)     # several pieces: the pruned pieces are joined on the device
+        set_opt(eng, "gaf_piece_bytes", piece)     # several pieces, joined on the device
     sset = synth.make_set(78, 3, 4, 30000, 60000, with_ids=True)
     p1 = tmp_path / "gen.gaf"
     synth.write_gaf(sset.reads, p1)
@@ -271,20 +271,12 @@ def test_resident_gaf_load_with_and_without_column_pruning(eng, tmp_path, piece,
     p = tmp_path / "mixed.gaf"
     p.write_bytes(gen[:cut] + gaf_quirks_text() + b"\n" + gen[cut:])
     eng.upload_db(sset.species)
-    got = []
-    for prune in ("1", "0"):
-        monkeypatch.setenv("PANTAX_GAF_PRUNE", prune)
-        cols = eng.load_reads_from_gaf(p)
-        sp, rc, bs, lm, uq = eng.rcls_profile()
-        eng.db_reset()
-        eng.trio_nodes_info()
-        bases, cov, tb, nab = eng.get_node_abundances()
-        got.append((cols, sp, (rc, bs, lm, uq), bases, cov, tb, nab))
-    a, b = got
-    for k in a[0]:
-        assert np.array_equal(a[0][k], b[0][k]), k
-    assert np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5]) and a[6] == b[6]
+    cols = eng.load_reads_from_gaf(p)
+    sp, rc, bs, lm, uq = eng.rcls_profile()
+    eng.db_reset()
+    eng.trio_nodes_info()
+    bases, cov, tb, nab = eng.get_node_abundances()
+    a = (cols, sp, (rc, bs, lm, uq), bases, cov, tb, nab)
     # ... and the reads of the oracle's reading of the same text (oracle/gaf_reader.py), uploaded as packed arrays
     from oracle import gaf_reader
     w = gaf_reader.packed(p.read_bytes())
@@ -301,7 +293,7 @@ def test_resident_gaf_load_with_and_without_column_pruning(eng, tmp_path, piece,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("piece", [None, "200000", "97"])
-def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkeypatch):
+def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, set_opt):
     """pantax_hip_gaf_load_device (GAF text tokenised by HIP kernels) gives the arrays of the host tokenizer bit for
     bit: a generated GAF plus every quirk of the format contract (comments, '*' nulls, CRLF, ragged and empty lines,
     no trailing newline, overflowing numbers, 13+ fields, digits inside non-numeric fields)."""
@@ -309,7 +301,7 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkey
     # texts of 4 GiB and more are tokenised in pieces cut at line ends and joined on the device; a small piece size
     # sends these small files through that path (97 bytes: nearly every line of the quirks file is its own piece)
     if piece is not None:
-        monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", piece)
+        set_opt(eng, "gaf_piece_bytes", piece)
     sset = synth.make_set(77, 3, 4, 20000 if piece != "97" else 300, 60000, with_ids=True)
     p1 = tmp_path / "gen.gaf"
     synth.write_gaf(sset.reads, p1)
@@ -354,12 +346,12 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, monkey
 
 
 @pytest.mark.gpu
-def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path, monkeypatch):
+def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path, set_opt):
     """pantax_hip_reads_load_gaf (file -> device tokenizer -> resident reads, walks never on the host) gives the same
     binning, counters, coverage histogram and trio bases as uploading the host-tokenised arrays; drop flags can be
     replaced in place."""
     from pantax_amd import io as pio, synth
-    monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", "1000000")   # the resident form through the piece-wise tokenizer as well
+    set_opt(eng, "gaf_piece_bytes", "1000000")   # the resident form through the piece-wise tokenizer as well
     sset = synth.make_set(78, 3, 4, 30000, 80000)
     p1 = tmp_path / "gen.gaf"
     synth.write_gaf(sset.reads, p1)
@@ -426,13 +418,13 @@ def test_cli_binary_matches_library_call(world):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,n,piece", [(1, 200, None), (2, 5000, None), (3, 40000, None), (2, 5000, "100000"), (4, 300, "4000")])
-def test_device_gaf_filter_equals_oracle(eng, tmp_path, seed, n, piece, monkeypatch):
+def test_device_gaf_filter_equals_oracle(eng, tmp_path, seed, n, piece, set_opt):
     """pantax_hip_gaf_filter == filter_max_alignment_mt (gaf_filter.rs:44-97) as restated by the oracle: the written
     lines are exactly the oracle's, in file order, with line ends normalised the way BufRead::lines + writeln! do."""
     from oracle import oracle as orc
     from tests.helpers import make_longread_gaf
     if piece is not None:   # texts of 4 GiB and more go through in pieces; the alignments of a read land in different ones
-        monkeypatch.setenv("PANTAX_GAF_PIECE_BYTES", piece)
+        set_opt(eng, "gaf_piece_bytes", piece)
     txt = make_longread_gaf(seed, n)
     gp = tmp_path / "gfa_mapped.gaf"
     gp.write_bytes(txt)
@@ -473,9 +465,10 @@ def test_device_gaf_filter_edge_inputs(eng, tmp_path):
 
 @pytest.mark.gpu
 def test_graph_images_roundtrip_and_file_seam(world, tmp_path):
-    """device-ready images (graph + unique-trio index).  A db loaded from images has the trio table of the
-    db it was saved from and gives the same strain step; the file seam writes them (image_cache 2), uses them
-    (image_cache 1, no graph parse, no trio build), ignores a truncated or a stale one."""
+    """device-ready images (the graph in the kernels' layouts; format 3 no longer stores the unique-trio index -- the device
+    rebuilds it faster than PCIe delivers it, db_image.cpp).  A db loaded from images has the trio table of the db it was saved from
+    (built on the device from the streamed walks) and gives the same strain step; the file seam writes them (image_cache 2), uses them
+    (image_cache 1: no graph parse), and falls back to the graph file of a species whose image is truncated or stale."""
     from pantax_amd.engine import Engine, metrics_to_dicts
     sset, root, db, gaf, eng0 = world
     eng = Engine(0)
@@ -491,7 +484,7 @@ def test_graph_images_roundtrip_and_file_seam(world, tmp_path):
         paths = [str(tmp_path / (g.name + ".hipdb")) for g in sset.species]
         eng.save_images(paths, [hn for g in sset.species for hn in g.hap_names])
         eng.load_images(paths, [g.range_start for g in sset.species], [g.range_end for g in sset.species], sset.species)
-        trio_b = eng.trio_nodes_info()                       # already in place: nothing is rebuilt
+        trio_b = eng.trio_nodes_info()                       # built from the walks the images delivered
         for a, b in zip(trio_a, trio_b):
             assert np.array_equal(a, b)
         eng.rcls_profile()

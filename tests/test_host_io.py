@@ -68,37 +68,6 @@ def test_host_tokenizer_equals_the_gaf_reader_oracle(tmp_path, small):
                 assert np.array_equal(want[k], got[k]), (name, nt, k)
 
 
-def test_gaf_pruning_changes_no_column(tmp_path, small):
-    """gaf_prune.cc (the columns the path never reads stay on the host): the pruned text reads -- by the oracle AND by the host
-    tokenizer -- exactly like the original, line for line, quirks included; it is shorter; pruning it again changes nothing; and
-    a range of lines pruned on its own is the matching part of the whole."""
-    from oracle import gaf_reader
-    from tests.helpers import gaf_quirks_text
-    sset, root = small
-    for name, text in (("quirks", gaf_quirks_text()), ("generated", (root / "x.gaf").read_bytes())):
-        pr = pio.prune_gaf_text(text)
-        assert len(pr) < len(text) and pio.prune_gaf_text(pr) == pr
-        assert pr.count(b"\n") == text.count(b"\n")
-        want, got = gaf_reader.packed(text), gaf_reader.packed(pr)
-        assert gaf_reader.read_ids(pr) == gaf_reader.read_ids(text)
-        for k in want:
-            assert np.array_equal(want[k], got[k]), (name, k)
-        p = tmp_path / (name + "_pruned.gaf")
-        p.write_bytes(pr)
-        host = pio.load_gaf(p, n_threads=3)
-        for k in want:
-            assert np.array_equal(want[k], host[k]), (name, "host tokenizer on the pruned text", k)
-    # line by line: a line with twelve fields keeps fields 1, 2, 6-9, 12; any other line is copied
-    for line in gaf_quirks_text().split(b"\n"):
-        out = pio.prune_gaf_text(line + b"\n")
-        f = (line[:-1] if line.endswith(b"\r") else line).split(b"\t")
-        if len(f) >= 12 and line and not line.startswith(b"@"):
-            assert out == b"\t".join([f[0], f[1], b"", b"", b"", f[5], f[6], f[7], f[8], b"", b"", f[11]]) + b"\n"
-        else:
-            assert out == line + b"\n"
-    assert pio.prune_gaf_text(b"") == b"" and pio.prune_gaf_text(b"no newline") == b"no newline"
-
-
 def test_graph_loaders_agree(small):
     """read_gfa (profile.rs:466-545) and the bincode .bin reader (zip.rs:236-247) give the generator's graph."""
     sset, root = small
