@@ -106,17 +106,22 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         "popcount_kernel": L // 8 + 8 * V,
         # the resident step (round 4): popcount folded into the node statistics pass -- lengths 4V + bases 8V in, counts 4V + abundances 8V out, bitmap L/8
         "node_cov_stats_kernel": 24 * V + L // 8,
-        # a7: SURVEY 8d's whole-index figure 2 x 12 x (P - 2H) + 12U split over the two halves of the build -- the pass that forms every
-        # window's 12-byte key and decides count == 1 (the "write keys" half, plus the 4P of walk it reads, which 8d leaves out): the
-        # visit-table kernel (round 4) or the node-block kernel; and the half that files the U unique rows ("read sorted" + 12U): the
-        # rows kernel or the pass over the walks.  The keys never travel through HBM: roofline.frac_by_counter_bytes is the other ruler
-        "trio_visit_kernel": 4 * P + 12 * win,
+        # a7 (round 5: bytes the launch MUST move, not a split of SURVEY 8d's whole-index figure -- that one is roofline.a7_stage).
+        # trio_visit_kernel: the visit table (4 bytes per visit slot, ~64/60 of the interior positions: pads) + every walk entry once (4P) +
+        # per group of 64 visits the head mask, node base and ballot (20 B) + one 16-byte record per unique window.
+        # trio_rows_kernel: the records (16U) + per group ballot, first row, species (16 B) + three node lengths per row (12U) + the rows it
+        # files: entry 8 + length 4 + owner 2 bytes (14U); the 16-byte read-modify-write of the heads' node records is left out (the number
+        # of nodes that head rows is not known to the harness: ~0.14 U at ten strains per species).
+        "trio_visit_kernel": 4 * (P * 64 // 60) + 4 * P + 20 * (P // 60) + 16 * U,
+        "trio_rows_kernel": 16 * U + 16 * (P // 60) + 12 * U + 14 * U,
+        # the node-block / bucket / pass-over-the-walks kernels (species the visit table does not cover; forced paths): SURVEY 8d's halves
         "trio_block_kernel": 4 * P + 12 * win,
-        "trio_rows_kernel": 12 * win + 12 * U,
         "trio_lookup_kernel": 12 * win + 12 * U,
         "trio_fill_kernel": 4 * P + 16 * win,
         "trio_count_kernel": 4 * P + 4 * V,
         "trio_uniq_kernel": 16 * win,
+        # a9: per-haplotype statistics by key, three passes over {trio_bases 8, length 4, owner 2} of every row
+        "hap_rows_pass_kernel": 3 * 14 * U,
         # a10: the membership masks by node (8V node -> haplotypes in, 8V masks out) / by walk (4P in + 8V out)
         "mask_nodes_kernel": 24 * V,      # ... + 8V of counts and lengths since the path_cov_ratio sums ride on this pass (round 4; 16V before)
         "mask_kernel": 4 * P + 8 * V,
@@ -390,7 +395,7 @@ class CpuLeg:
         return d
 
 
-PMC_ROUND = "r04"   # profiles/<PMC_ROUND>_pmc_<workload>.json: the counter passes of THIS round's code; older files are never read
+PMC_ROUND = "r05"   # profiles/<PMC_ROUND>_pmc_<workload>.json: the counter passes of THIS round's code; older files are never read
 
 
 def pmc_traffic(kernel, key, wl_name, corrected=False):
@@ -542,6 +547,7 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads):
                 dt = time.perf_counter() - t
         finally:
             os.chdir(cwd)
+        res.setdefault("trace", {})[name] = cap.text[-6000:]
         return wd, dt, _seam_phases(cap.text)
     try:
         runs = {}
@@ -957,6 +963,15 @@ def main():
             if cov_kernel in timings and dom != cov_kernel and roofline.get("runner_up", {}).get("kernel") != cov_kernel:
                 r3 = ruler(cov_kernel, *timings[cov_kernel])
                 roofline["coverage"] = {k: r3[k] for k in ("kernel", "avg_ms", "algorithmic_bytes", "frac", "traffic", "frac_by_counter_bytes")}
+        # SURVEY 8d's whole-index figure for a7 (2 x 12 x (P - 2H) keys written and read + 12U) against the SUM of the rebuild's kernels (warm-up
+        # table): the stage's ruler; the kernels above are measured by the bytes they themselves must move
+        if roofline is not None:
+            a7_k = ("trio_visit_kernel", "group_tile_prefix_kernel", "trio_rows_kernel", "trio_block_kernel", "trio_lookup_kernel", "trio_canon_kernel",
+                    "scan_chained_kernel<SlowFirst>", "scan_chained_kernel<TrioFirst>", "scan_chained_kernel<GroupCount>")
+            a7_ms = sum(warm[k][1] for k in a7_k if k in warm) / max(n_warm_timed, 1)
+            a7_b = 2 * 12 * max(dims["P"] - 2 * dims["H"], 0) + 12 * n_unique
+            if a7_ms > 0:
+                roofline["a7_stage"] = dict(algorithmic_bytes_8d=a7_b, ms_per_step_sum_of_kernels=round(a7_ms, 3), frac=a7_b / (a7_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         # the other large kernels against the same rulers (warm-up table; stretched by what shares the device with them)
         others = {}
         for k, (launches, tot_ms) in warm.items():

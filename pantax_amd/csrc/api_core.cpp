@@ -333,13 +333,21 @@ int pantax_hip_node_coverage(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_
         PTX_TRY(upload_small(ctx, db->d_active, species_active, db->S));
         d_active = db->d_active.p;
     }
+    // trio_bases are handed out in the table's export order, (species, hap, position) -- the order of pantax_hip_trio_get --, not in the order
+    // the rows are filed in: the permutation is made before the pass (it may rebuild the index with the window starts: same rows)
+    if (trio_bases_out && db->U) PTX_TRY(trio_export_ensure(ctx, db));
     PTX_TRY(coverage_launch(ctx, db, reads, d_active, db->trio_built));
     unsigned long long *d_abort = db->d_abort;
     unsigned long long h_abort = 0;
     std::vector<uint32_t> cov32;
+    DevBuf<unsigned long long> tb_export;
     if (bases_per_node_out) PTX_TRY(download(ctx, (unsigned long long *)bases_per_node_out, db->d_bases.p, db->V));
     if (node_base_cov_out) { cov32.resize(db->V); PTX_TRY(download(ctx, cov32.data(), db->d_cov.p, db->V)); }
-    if (trio_bases_out && db->U) PTX_TRY(download(ctx, (unsigned long long *)trio_bases_out, db->d_trio_bases.p, db->U));
+    if (trio_bases_out && db->U) {
+        PTX_HIP(ctx, tb_export.alloc(db->U));
+        PTX_TRY(trio_export_u64(ctx, db, db->d_trio_bases.p, tb_export.p));
+        PTX_TRY(download(ctx, (unsigned long long *)trio_bases_out, tb_export.p, db->U));
+    }
     if (!bases_per_node_out && !node_base_cov_out && !trio_bases_out && !n_abort_out) return 0;   // everything stays on the device: no host sync
     PTX_TRY(download(ctx, &h_abort, d_abort, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));

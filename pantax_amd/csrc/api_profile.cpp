@@ -201,24 +201,48 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             text_end = rk + 1 == W ? mf.size : line_start_at_or_after(mf, mf.size / (uint64_t)W * (uint64_t)(rk + 1));
         }
         reads.rd = new pantax_hip_reads();
-        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded, /*want_id_spans=*/want_report));
-        R = hr.qlen.size();
+        // The per-read host columns (read_len, mapq, flags, id hash: 14 bytes per read) and the species of every read come back over PCIe only
+        // for a caller that uses them: the binning report, the strain-only resume, the sharded ingest -- or, later, the duplicate-id rule when
+        // two reads do share an id (host_cols below).  A plain run on distinct ids needs the species COUNTERS and the first rows only.
+        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded, /*want_id_spans=*/want_report,
+                                    /*want_host_columns=*/false));
+        R = reads.rd->R;
         lap("ranges + GAF tokenise");
         rs.resize(S); re.resize(S);
         for (uint32_t s = 0; s < S; ++s) { rs[s] = ranges[s].start; re[s] = ranges[s].end; }
         pantax_hip_graphs g{};
         g.n_species = S; g.range_start = rs.data(); g.range_end = re.data();
         PTX_TRY(pantax_hip_db_upload(ctx, &g, &bin_db.db));
-        sp_idx.resize(R);
         rc.resize(S); bs.resize(S); lm.resize(S); uq.resize(S);
-        PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, sp_idx.data(), rc.data(), bs.data(), lm.data(), uq.data()));
+        PTX_TRY(pantax_hip_bin_reads(ctx, bin_db.db, reads.rd, nullptr, rc.data(), bs.data(), lm.data(), uq.data()));
         lap("bin all species");
         return 0;
     };
+    bool have_cols = false;
+    auto host_cols = [&]() -> int {   // the host columns + the species of every read (file order), once
+        if (have_cols) return 0;
+        PTX_TRY(reads_host_columns(ctx, reads.rd, hr));
+        sp_idx.resize(R);
+        if (R) {
+            PTX_TRY(species_ensure(ctx, reads.rd));
+            PTX_TRY(download(ctx, sp_idx.data(), reads.rd->d_species.p, R));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        have_cols = true;
+        lap("host columns + species of every read");
+        return 0;
+    };
     int local_rc = ingest();
-    // the read lengths of the first (up to 1000) binned rows of the FILE decide the equal-length branch (profile.rs:312-319)
+    if (local_rc == 0 && (want_report || sharded || strain_only)) local_rc = host_cols();
+    // the read lengths of the first (up to 1000) binned rows of the FILE decide the equal-length branch (profile.rs:312-319): they are among the
+    // first rows the binning pass hands back with its counters, unless those hold fewer than 1000 binned rows of a longer file
     std::vector<uint32_t> head;
-    if (local_rc == 0) for (uint64_t r = 0; r < R && head.size() < 1000; ++r) if (sp_idx[r] >= 0) head.push_back(hr.qlen[r]);
+    if (local_rc == 0 && !have_cols) {
+        const std::vector<int32_t> &ps = reads.rd->h_pre_species;
+        for (size_t r = 0; r < ps.size() && head.size() < 1000; ++r) if (ps[r] >= 0) head.push_back(reads.rd->h_pre_qlen[r]);
+        if (head.size() < 1000 && (uint64_t)ps.size() < R) { head.clear(); local_rc = host_cols(); }
+    }
+    if (local_rc == 0 && have_cols) for (uint64_t r = 0; r < R && head.size() < 1000; ++r) if (sp_idx[r] >= 0) head.push_back(hr.qlen[r]);
     uint64_t read_base = 0, R_all = R;   // this rank's first read in file order; reads of the whole file
     if (sharded) {
         // one all-reduce: {failure flag, S (must agree), reads per rank, the four counters per species, every rank's head}
@@ -374,8 +398,13 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     }
 
     // ---- a5: rows with a null field are dropped; duplicate read ids (profile.rs:361-463)
+    // (the device tokenizer has already compared the id hashes: when no two reads share one -- short reads -- nothing can repeat, the flags the
+    // tokenizer left on the device stand as they are and no per-read column visits the host)
+    if (local_rc == 0 && !sharded && hr.ids_distinct != 1) local_rc = host_cols();
+    PTX_TRY(agree(local_rc));
     std::vector<uint8_t> flags(hr.flags);
-    if (strain_only) for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD;   // "U" in the saved report
+    bool flags_dirty = false;
+    if (strain_only) { flags_dirty = true; for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] < 0) flags[r] |= PANTAX_HIP_READ_NULLFIELD; }   // "U" in the saved report
     if (!sharded) {
         std::unordered_set<uint64_t> seen;
         if (hr.ids_distinct != 1) seen.reserve(R * 2);
@@ -391,7 +420,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
                 auto ins = first.emplace(hr.id_hash[r], sp_idx[r]);
                 if (!ins.second && ins.first->second != sp_idx[r]) mixed.insert(hr.id_hash[r]);
             }
-            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0 && mixed.count(hr.id_hash[r])) flags[r] |= PANTAX_HIP_READ_DUPDROP;
+            for (uint64_t r = 0; r < R; ++r) if (sp_idx[r] >= 0 && mixed.count(hr.id_hash[r])) { flags[r] |= PANTAX_HIP_READ_DUPDROP; flags_dirty = true; }
         }
     } else {
         // The same rule over N byte ranges: the alignments of one read id may sit in different ranks' slices, so every binned
@@ -655,12 +684,15 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
         // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
         // (strain only: species from the saved report decide membership -- rows it calls "U" carry a drop flag, see a5 above)
-        if (!sharded) PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));   // sharded: flagged rows were not routed
+        if (!sharded && flags_dirty) PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));   // sharded: flagged rows were not routed; else the tokenizer's flags stand
         pantax_hip_reads *const sreads_rd = reads.rd;
         PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, nullptr));
+        lap("  flags + bin selected");
         uint64_t nU = 0, n_abort = 0;
         PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
+        lap("  trio index");
         PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
+        lap("  node coverage");
         pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, cfg->sample_nodes};
         std::vector<double> cov(Su);
         for (uint32_t k = 0; k < Su; ++k) cov[k] = sel_cov[use[k]];

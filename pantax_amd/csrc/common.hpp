@@ -40,9 +40,11 @@ int fail(Ctx *ctx, int code, const char *fmt, ...);
 // ---- device buffer ---------------------------------------------------------------------------
 // Device allocations go through a small per-process cache: hipFree of a large buffer costs around a millisecond (it
 // waits for the device and unmaps), and the file seam allocates and releases some dozens of them per call.  A released
-// block is kept (up to DEV_CACHE_MAX bytes in all) and handed to the next request of a similar size; before a block
+// block is kept (up to dev_cache_max() bytes in all) and handed to the next request of a similar size; before a block
 // freed since the last device-wide wait is reused, the device is synchronised once -- the guarantee hipFree gave.
-constexpr size_t DEV_CACHE_MAX = 48ull << 30;
+// cap of the cache: three quarters of the device's memory (a db of 1e4 strains with its scratch is ~100 GB: under the 48 GB of round 4 every
+// call of the pipeline seam paid 0.7-1.2 s of hipMalloc for the blocks that did not fit the cache)
+size_t dev_cache_max();
 hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out);
 void dev_cache_free(void *p, size_t cap, int dev);   // dev: the device the block was allocated on (the caller's current device may differ)
 void dev_cache_trim();   // really free everything cached for the current device (pantax_hip_destroy)
@@ -122,7 +124,6 @@ struct CtxConfig {
     std::string trio_path;           // "block": every species through the node-block kernel; "bucket": global buckets
     std::string trio_rows;           // "path": lookup rows filed by the pass over the walks
     int uniq_hash = -1;              // bucket path: 1 LDS hash / 0 shuffles (-1: by mean bucket size)
-    std::string hap_stats;           // "fused" / "chunks"
     std::string mask;                // "walk": membership masks from the path walk
     std::string row_sort;            // "radix" / "seg" / "nodes"
     std::string objective;           // "nodes": the LP objective summed over the nodes
@@ -260,16 +261,17 @@ struct LadBatch {
 
 // scratch of trio_index_build, kept across calls (grow-only) so a rebuild costs no hipMalloc
 struct TrioScratch {
-    DevBuf<uint32_t> zero_arena;   // tile_cnt | uniq_q | first_cnt | cnt | cursor: the part a build needs cleared goes first
-    DevBuf<uint32_t> cnt, cursor, bucket_off, scan_tmp, first_cnt, d_tot, tile_cnt, tile_base;
+    DevBuf<uint32_t> zero_arena;   // uniq_q | first_cnt [| cnt | cursor]: what a build of the PATH route needs cleared goes first
+    DevBuf<uint32_t> cnt, cursor, bucket_off, scan_tmp, first_cnt, d_tot;
     DevBuf<uint4> bucket;   // (q, b, c, global first node) per window
-    DevBuf<uint32_t> uniq_q;       // one bit per path position: its window occurs once in the species
-    // rows filed from the visit kernel's records (a db the visit table covers whole)
+    DevBuf<uint32_t> uniq_q;       // path route: one bit per path position: its window occurs once in the species
+    DevBuf<uint32_t> row_q;        // path route: window start of the row filed at every slot (the canonical order inside a node is made from it)
+    // rows filed from the visit kernel's records (the species the visit table covers)
     DevBuf<uint64_t> vis_uq;       // [n_vgroups + 1] ballot of the unique visits of every group
     DevBuf<uint4> vis_rec;         // [n_vgroups * 8] the first eight unique windows of every group {window start, smaller end, larger end, middle}
-    DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = slot of its first lookup row
-    DevBuf<uint2> word_rank;       // [P / 32 + 2] {flags before the word of uniq_q = row of the first window it flags, the word}
-    DevBuf<uint32_t> flag_sums, group_sums;   // flags per tile of 4096 words / unique visits per tile of 4096 groups, then their prefix (flag_tile_*, group_tile_* kernels)
+    DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = row of its first unique window
+    DevBuf<uint32_t> group_sums;   // unique visits per tile of 4096 groups, then their prefix (group_tile_* kernels)
+    DevBuf<uint32_t> hap_cnt;      // [H] first build of a db: rows per haplotype (-> hap_trio_off)
 };
 
 // ---- resident DB -----------------------------------------------------------------------------
@@ -317,6 +319,7 @@ struct Db {
     DevBuf<uint32_t> d_vis_pos;      // [64 n_vgroups] path position of the visit (the middle of its window), 0xFFFFFFFF pads at a group's tail
     DevBuf<uint64_t> d_vis_head;     // [n_vgroups] bit l: lane l holds the first visit of a node
     DevBuf<uint32_t> d_vis_nbase;    // [n_vgroups] node base of the group's species
+    DevBuf<uint32_t> d_vis_sp;       // [n_vgroups] the group's species (the rows kernel finds a window's haplotype among that species' walks)
     DevBuf<uint32_t> d_node_visited; // [V / 32 + 2] bit v: node v has an interior visit
     bool trio_block_ok = false;      // every species left to the node-block kernel has < 2^27 nodes (the 64-bit LDS key packs (middle in block, lo, hi)) and P < 2^32
     uint32_t n_blocks = 0;
@@ -326,23 +329,36 @@ struct Db {
     DevBuf<uint32_t> d_blk_run_off;  // [n_blocks+1]
     DevBuf<uint4> d_blk_rec;         // [n_blocks+1] {first run, end run, global first node, species-local first node / 64 | node count << 24}
     DevBuf<uint4> d_runs;            // [n_runs] {first position, #positions, walk begin, walk end} (global path positions)
-    // unique-trio index (a7)
+    // unique-trio index (a7).  ROWS ARE NUMBERED IN THE ORDER THEY ARE FILED (round 5): the species of the visit table in table order -- node after
+    // node, a node's rows sorted by their pair of ends --, behind them the species left to the pass over the walks, node after node in the same
+    // canonical order.  A row IS its lookup entry: d_trio_ent[r], d_trio_len[r], d_trio_hap[r], d_trio_bases[r] belong together, the lookup head
+    // of a node {first row, #rows} rides in its node record.  The (species, hap, position) order the C ABI hands out (pantax_hip_trio_get,
+    // trio_bases of pantax_hip_node_coverage) is a permutation made on request (trio_export_ensure): it costs nothing on the step's path.
     bool trio_built = false;
     bool trio_prefetched = false;   // pantax_hip_trio_index_prefetch built the index of the COMING step: that step's rebuild_trio is served by it
-    bool trio_keys_built = false;   // d_trio_abc / d_trio_hap (row-order export copies) were written by the last build
-    bool trio_first_valid = false;  // d_trio_first holds the CSR offsets of the last build (trio_first_ensure derives them on request)
+    bool trio_keys_built = false;   // d_trio_q (window start of every row: what the export order is made from) was written by the last build
+    bool trio_perm_valid = false;   // d_trio_perm holds the export order of the last build
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool cov_count_pending = false;  // d_cov of the last coverage pass is still to be counted from the bitmap (node_stats_launch does it)
-    bool trio_sizes_known = false;   // U and hap_trio_off depend on the graphs only: kept across db_reset
+    bool trio_sizes_known = false;   // U, the rows per haplotype and per species depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
-    DevBuf<uint32_t> d_trio_first;   // [V+1] CSR over the MIDDLE node of the window (global node index)
-    DevBuf<uint4> d_trio_ent;        // [U] {smaller end, larger end, row in (species,hap,position) order, 0}
-    DevBuf<uint32_t> d_trio_abc;     // [3U] row order
-    DevBuf<uint32_t> d_trio_hap;     // [U] hap index within species, row order
-    DevBuf<uint32_t> d_trio_len;     // [U]
-    DevBuf<uint64_t> d_hap_trio_off; // [H+1]
+    bool trio_layout_fast = false;   // the sizes were learnt by a build that filed the visit table's species from its records (else: every species by the pass over the walks)
+    DevBuf<uint32_t> d_trio_first;   // [V+1] path route: first row of every node (scratch of the build; the heads in node_rec are what the step reads)
+    DevBuf<uint2> d_trio_ent;        // [U] {smaller end, larger end} of the window (global node indices); the middle is the node that heads the row
+    DevBuf<uint32_t> d_trio_len;     // [U] summed length of the window's three nodes (profile.rs:712)
+    DevBuf<uint16_t> d_trio_hap;     // [U] the haplotype that owns the row, as an index within its species
+    DevBuf<uint32_t> d_trio_q;       // [U] window start (path position) of the row: export builds only
+    DevBuf<uint32_t> d_trio_perm;    // [U] row of the e-th window in (species, hap, position) order: export builds only
+    DevBuf<uint64_t> d_hap_trio_off; // [H+1] prefix of the rows per haplotype = offsets of the export order (the first filter reads the counts)
     std::vector<uint64_t> h_hap_trio_off;
+    // per-haplotype statistics by key (hap_trio_stats_launch): the rows of a species are one contiguous block, cut into chunks
+    std::vector<uint32_t> h_sp_row_order; // [S] the species in filing order
+    DevBuf<uint4> d_stat_chunks;     // {species, first row, end row, first partial} per chunk of rows
+    uint32_t n_stat_chunks = 0;
+    uint64_t n_stat_partials = 0;    // sum over chunks of the haplotypes of their species
+    uint32_t stat_lds_haps = 0;      // most haplotypes of a species whose chunk accumulators live in LDS
+    DevBuf<uint32_t> d_sp_chunk_off; // [S+1] first chunk of every species (species without rows: empty range)
     // coverage state (a8), resident for the strain step
     bool cov_done = false;
     // d_bases, d_trio_bases, the abort counter and d_bitmap are windows of one arena: one memset per coverage pass
@@ -384,6 +400,7 @@ struct Reads {
     uint64_t R = 0, T = 0;
     DevBuf<uint32_t> d_step_off, d_node_id, d_pstart, d_pend, d_qlen;
     DevBuf<uint8_t> d_mapq, d_flags;
+    DevBuf<uint64_t> d_id_hash;      // 64-bit hash of every read id (device tokenizer; the duplicate-id rule, profile.rs:361-437): fetched by the host only when two reads share one
     bool has_flags = false;
     DevBuf<int32_t> d_species;
     std::vector<int32_t> h_pre_species;   // first rows of species/qlen, fetched with the counters (equal-length test)
@@ -424,7 +441,7 @@ constexpr uint32_t NODE_REC_MAX_ROWS = 1u << 16;
 // the steps have a middle node with rows, 8 % hit one).  A builder that does not compute the filter stores 0xFF (never wrong, never skips).
 __host__ __device__ inline uint32_t nr_rows(uint32_t y) { return (y >> 8) & 0xFFFFu; }
 __host__ __device__ inline uint32_t nr_filter(uint32_t y) { return y >> 24; }
-__host__ __device__ inline uint32_t nr_head(uint32_t y_old, uint32_t rows, uint32_t filter) { return (y_old & 0xFFu) | (rows << 8) | (filter << 24); }
+__host__ __device__ inline uint32_t nr_head(uint32_t y_old, uint32_t rows, uint32_t filter) { return (y_old & 0xFFu) | ((rows & 0xFFFFu) << 8) | (filter << 24); }   // (a count beyond the field is reported by the builders, never spilt into the filter)
 __host__ __device__ inline uint32_t nr_pair_bit(uint32_t lo, uint32_t hi) { return 1u << (((lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u)) >> 29); }
 __host__ __device__ inline uint64_t nr_bit_off(const uint4 &r) { return ((uint64_t)(r.y & 0xFFu) << 32) | r.x; }
 __host__ __device__ inline uint4 nr_make(uint64_t bit_off, uint32_t len) { return make_uint4((uint32_t)bit_off, (uint32_t)(bit_off >> 32) & 0xFFu, len, 0u); }
@@ -530,7 +547,9 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count = false);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
-int trio_first_ensure(Ctx *ctx, Db *db); // d_trio_first (the db images store it)
+int trio_export_ensure(Ctx *ctx, Db *db); // d_trio_perm: the (species, hap, position) order of the rows, for the exporters
+int trio_export_u64(Ctx *ctx, Db *db, const unsigned long long *d_src, unsigned long long *d_dst);   // d_dst[e] = d_src[row of e]
+int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint64_t *sp_rows);       // first build of a db: the chunk table of hap_trio_stats_launch
 int trio_visits_build(Ctx *ctx, Db *db); // end of db upload: the visit table (and which species it leaves to the node-block kernel)
 int trio_runs_build(Ctx *ctx, Db *db);   // end of db upload, after trio_visits_build: the node-block run table of those species
 int node_haps_build(Ctx *ctx, Db *db);   // end of db upload: node -> haplotypes (the LP's membership masks built by node)
@@ -540,6 +559,9 @@ struct HostReads;
 int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &out, Reads *resident = nullptr, int fd = -1, uint64_t file_base = 0, bool group = true,
                         bool want_id_spans = false, bool want_host_columns = true);
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id);
+// the per-read host columns of resident reads (read_len, mapq, flags, id hashes), on request: a caller that needs none of them -- the
+// pipeline seam on distinct read ids without a binning report -- never brings 14 bytes per read back over PCIe
+int reads_host_columns(Ctx *ctx, const Reads *rd, HostReads &out);
 // stage_route.hip: binned reads -> one message per owner rank, and back to resident reads on the owner
 struct Route {
     int W = 0;

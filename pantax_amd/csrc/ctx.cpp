@@ -92,7 +92,7 @@ struct OptDesc { const char *name; OptKind kind; size_t off; };
 const OptDesc OPTIONS[] = {
     OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio),
     OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("uniq_hash", O_INT, uniq_hash),
-    OPT("hap_stats", O_STR, hap_stats), OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
+    OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
     OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
@@ -291,6 +291,15 @@ inline size_t round_cap(size_t bytes) {
 }
 }  // namespace
 
+size_t dev_cache_max() {
+    static const size_t cap = [] {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)(48ull << 30);
+        return total_b / 4 * 3;
+    }();
+    return cap;
+}
+
 hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out) {
     const size_t want = round_cap(bytes ? bytes : 1);
     int dev = 0;
@@ -335,7 +344,7 @@ void dev_cache_free(void *p, size_t cap, int dev) {
     {
         std::lock_guard<std::mutex> g(c.mu);
         DevCache::PerDevice &d = c.dev[dev];
-        if (cap && d.cached_bytes + cap <= DEV_CACHE_MAX) {
+        if (cap && d.cached_bytes + cap <= dev_cache_max()) {
             d.free_blocks.emplace(cap, DevCache::Block{p, ++d.free_epoch});
             d.cached_bytes += cap;
             return;
@@ -534,7 +543,7 @@ struct SegFiller {
             };
             if (!s.narrow) read_at(out, so, n);
             else {
-                constexpr uint64_t BLK = 8192;                        // 64-bit values per block
+                constexpr uint64_t BLK = 131072;                      // 64-bit values per block: a megabyte per pread
                 uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
                 uint64_t hi = 0;
                 for (uint64_t i0 = so / 4, i1 = (so + n) / 4; i0 < i1; i0 += BLK) {

@@ -25,7 +25,7 @@
 // is bound by the number of divergent (one cache line per lane) vector-memory instructions, so the
 // tables it gathers from are packed into 16-byte records (one dwordx4 per lookup):
 //   read_rec[r] = {first step, #steps, pstart, pend}      node_rec[v] = {bit_off (u64), len, -}
-//   lookup head of node v (rides in node_rec) = {first row, #rows} of the unique windows whose MIDDLE is v;  trio_ent[j] = {smaller end, larger end, row, -}
+//   lookup head of node v (rides in node_rec) = {first row, #rows} of the unique windows whose MIDDLE is v;  trio_ent[j] = {smaller end, larger end} -- j IS the row (round 5: rows are numbered in filing order)
 // A read that reaches this kernel was binned to its species, so every node id lies inside the
 // species' id range (rcls.rs:253-257) and the index panic of profile.rs:849 cannot occur; an
 // out-of-range id (inconsistent external binning) is counted as an abort per step instead.
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
     const uint4 *__restrict__ node_rec, const uint64_t *__restrict__ bit_off, uint64_t V, unsigned long long *__restrict__ bases,
-    uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
+    uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint2 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
     unsigned long long *__restrict__ n_abort, uint32_t ablate, int blk_shift) {
     constexpr int WAVES = COV_BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         }
         // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as soon as the head is known
         uint32_t i_[U], nl[U], len0[U], nh[U], hx[U], tlo[U], thi[U];
-        uint4 e0[U], e1[U];
+        uint2 e0[U], e1[U];
         bool live[U], single[U], dead_read[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             dead_read[u] = !single[u] && rr[u].z > len0[u];                   // assert :854 -> the whole read contributes nothing
             live[u] = ok[u] && !dead_read[u] && !(single[u] && rr[u].w < rr[u].z);   // :821-827
             nh[u] = 0; hx[u] = 0; tlo[u] = 0; thi[u] = 0;
-            e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = e0[u];
+            e0[u] = make_uint2(0u, 0u); e1[u] = e0[u];
             if (WITH_TRIO && !ABL(4u)) {
                 // canonical window (min end, middle, max end): the rows are filed under the MIDDLE node, keyed by the two ends
                 hx[u] = hw1;
@@ -320,13 +320,13 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             }
             if (WITH_TRIO && !ABL(4u)) {                                      // :890-907
                 const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
-                int row = -1;
-                if (nh[u] && e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (int)e0[u].z;
-                else if (nh[u] > 1u && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (int)e1[u].z;
+                long long row = -1;                                              // a row IS its lookup entry (round 5): the index of the entry that matches
+                if (nh[u] && e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (long long)hx[u];
+                else if (nh[u] > 1u && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (long long)hx[u] + 1;
                 else if (nh[u] > 2u)
                     for (uint32_t j = 2; j < nh[u]; ++j) {
-                        const uint4 e = trio_ent[hx[u] + j];
-                        if (e.x == tlo[u] && e.y == thi[u]) { row = (int)e.z; break; }
+                        const uint2 e = trio_ent[hx[u] + j];
+                        if (e.x == tlo[u] && e.y == thi[u]) { row = (long long)hx[u] + j; break; }
                     }
                 const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
                 if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
     uint64_t T, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_dup, const uint8_t *__restrict__ active,
     const uint4 *__restrict__ node_rec, unsigned long long *__restrict__ bases, uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full,
-    const uint4 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort,
+    const uint2 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases, unsigned long long *__restrict__ n_abort,
     const uint32_t *__restrict__ long_sum, const uint32_t *__restrict__ long_len0, uint32_t n_chunks, uint32_t xcd_map, uint32_t ablate,
     uint32_t only_long /* 1: groups without a step of a longer walk belong to coverage_fast_kernel */) {
     constexpr int CHUNK = COV_BLOCK * U * PASSES;
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         // ---- shuffles, the trio lookup head and the first trio entry (level 4), for all groups
         uint32_t v1[U], v2[U], len0[U], tlo[U], thi[U];
         uint2 th[U];
-        uint4 e0[U], e1[U];   // the first TWO lookup entries of the head: with one, 95 % of the waves held a lane whose window was
+        uint2 e0[U], e1[U];   // the first TWO lookup entries of the head: with one, 95 % of the waves held a lane whose window was
                               // the node's second entry (8 % of the visits meet a head of two or more) and paid another dependent gather
         int dist[U];
         bool cross[U];
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             // neighbours one and two lanes down: DPP wave shifts (VALU), not LDS-crossbar shuffles
             v1[u] = wave_shr1(v[u]); v2[u] = wave_shr1(v1[u]);
             const uint32_t tf1 = wave_shr1(nr[u].w), ty1 = wave_shr1(nr[u].y);
-            th[u] = make_uint2(0u, 0u); tlo[u] = 0; thi[u] = 0; e0[u] = make_uint4(0u, 0u, 0u, 0u); e1[u] = make_uint4(0u, 0u, 0u, 0u);
+            th[u] = make_uint2(0u, 0u); tlo[u] = 0; thi[u] = 0; e0[u] = make_uint2(0u, 0u); e1[u] = make_uint2(0u, 0u);
             if (WITH_TRIO && !ABL(4u) && ok[u] && i >= 2) {
                 if (lane < 1) v1[u] = node_id[b + i - 1] + sr[u].y;
                 if (lane < 2) v2[u] = node_id[b + i - 2] + sr[u].y;
@@ -563,14 +563,14 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 if (live && i >= 2 && !ABL(4u)) {
                     if (lane < 1) rl1 = rl_from_memory(i - 1, b, node_id, step_dup, sr[u].y, node_rec, len0[u], ps);
                     if (lane < 2) rl2 = rl_from_memory(i - 2, b, node_id, step_dup, sr[u].y, node_rec, len0[u], ps);
-                    int row = -1;
+                    long long row = -1;                                      // a row IS its lookup entry: the index of the entry that matches
                     if (th[u].y) {
-                        if (e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (int)e0[u].z;
-                        else if (th[u].y > 1 && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (int)e1[u].z;
+                        if (e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (long long)th[u].x;
+                        else if (th[u].y > 1 && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (long long)th[u].x + 1;
                         else
                             for (uint32_t j = 2; j < th[u].y; ++j) {
-                                const uint4 e = trio_ent[th[u].x + j];
-                                if (e.x == tlo[u] && e.y == thi[u]) { row = (int)e.z; break; }
+                                const uint2 e = trio_ent[th[u].x + j];
+                                if (e.x == tlo[u] && e.y == thi[u]) { row = (long long)th[u].x + j; break; }
                             }
                     }
                     if (row >= 0) {

@@ -586,7 +586,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     if (resident) {
         resident->R = R; resident->T = T;
         resident->d_step_off.take(o32[0]); resident->d_node_id.take(o32[1]); resident->d_pstart.take(o32[2]); resident->d_pend.take(o32[3]);
-        resident->d_qlen.take(o32[4]); resident->d_mapq.take(o8[0]); resident->d_flags.take(o8[1]);
+        resident->d_qlen.take(o32[4]); resident->d_mapq.take(o8[0]); resident->d_flags.take(o8[1]); resident->d_id_hash.take(o_hash);
         resident->has_flags = true;
         if (group) PTX_TRY(build_step_read(ctx, resident, max_id));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -595,6 +595,19 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
     out.n_lines = R;
     out.ids_distinct = n_dup == 0 ? 1 : 0;
     if (trace) std::fprintf(stderr, "[gaf_tokenize] total inside gaf_tokenize_device      %9.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count());
+    return 0;
+}
+
+int reads_host_columns(Ctx *ctx, const Reads *rd, HostReads &out) {
+    const uint64_t R = rd->R;
+    if (R && (!rd->d_qlen.p || !rd->d_mapq.p || !rd->d_flags.p || !rd->d_id_hash.p)) return fail(ctx, PANTAX_HIP_E_STATE, "reads_host_columns: these reads were not tokenised on the device");
+    out.qlen.resize(R); out.mapq.resize(R); out.flags.resize(R); out.id_hash.resize(R);
+    if (R) {
+        PTX_TRY(download(ctx, out.qlen.data(), rd->d_qlen.p, R));
+        PTX_TRY(download(ctx, out.mapq.data(), rd->d_mapq.p, R)); PTX_TRY(download(ctx, out.flags.data(), rd->d_flags.p, R));
+        PTX_TRY(download(ctx, out.id_hash.data(), rd->d_id_hash.p, R));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return 0;
 }
 

@@ -171,106 +171,107 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// a9: per-hap unique-trio statistics.  One workgroup per haplotype; three passes over its rows
-// (they are contiguous because trio rows are ordered (species, hap, position)).
+// a9: per-hap unique-trio statistics, BY KEY (round 5).  The rows of the index are numbered in filing order -- node after node --, so
+// the rows of one haplotype are scattered over its species' block; every row carries its owner (d_trio_hap).  The block of a species
+// is cut into chunks of rows; ONE WAVE takes a chunk and keeps an accumulator per haplotype of the species (in LDS; in the chunk's own
+// row of the partials for a species of more than HS_LDS_HAPS haplotypes): per 64 rows it walks the distinct owners among its lanes --
+// neighbouring rows are windows around the same private allele, a handful of owners -- and adds each owner's lanes by a DPP reduction
+// in fixed lane order.  A chunk's partials are then added in chunk order by one wave per species.  Every sum has a fixed order: same bits
+// on every run (the reference's own order is that of a hash set).  Three passes like zscore_filter (profile.rs:1028-1051): (sum, count)
+// of the non-zero abundances -> mean; squared deviations -> sd; (sum, count) of |z| < 3 -> the filtered mean.
 // ---------------------------------------------------------------------------------------------
-constexpr int HAP_CHUNKS = 32;   // workgroups per haplotype; partials are combined in fixed order
-struct HapPartial { double a, b; unsigned long long c; };
+constexpr uint32_t HS_CHUNK_ROWS = 1024, HS_LDS_HAPS = 1024;
+struct HapAcc { double a; uint32_t c, n; };   // sum, count of the pass, rows seen (pass 0)
 
-// pass = 0: (sum, count) of non-zero abundances; 1: (sum of squared deviations); 2: (sum, count) of |z|<3.
-// Every pass keeps its own chunk partials; a workgroup derives the mean / sd it needs from the partials of the
-// earlier passes itself (32 values, fixed order: every workgroup gets the same bits), so no combine launch sits
-// between the passes.
-__device__ __forceinline__ void hap_combine(const HapPartial *__restrict__ part, uint32_t h, double &acc, unsigned long long &cnt) {
-    acc = 0.0; cnt = 0;
-    for (int c = 0; c < HAP_CHUNKS; ++c) { const HapPartial p = part[(size_t)h * HAP_CHUNKS + c]; acc += p.a; cnt += p.c; }
-}
-__global__ void __launch_bounds__(256) hap_trio_pass_kernel(int pass, uint32_t H, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
-                                                            const uint32_t *__restrict__ tlen, HapPartial *__restrict__ part /*[3][H][HAP_CHUNKS]*/) {
-    __shared__ double red[4];
-    __shared__ unsigned long long redu[4];
-    __shared__ double s_mean, s_sd;
-    const uint32_t h = blockIdx.x / HAP_CHUNKS, ch = blockIdx.x % HAP_CHUNKS;
-    const size_t PS = (size_t)H * HAP_CHUNKS;
-    if (pass && threadIdx.x == 0) {
-        double a0; unsigned long long c0;
-        hap_combine(part, h, a0, c0);
-        s_mean = c0 ? a0 / (double)c0 : 0.0;                                    // profile.rs:1037
-        s_sd = 0.0;
-        if (pass == 2) {
-            double a1; unsigned long long c1;
-            hap_combine(part + PS, h, a1, c1);
-            const double n = (double)(uint32_t)c0;
-            s_sd = n > 0 ? sqrt(a1 / n) : 0.0;                                  // :1038-1041
+template <int PASS>
+__global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off, const uint16_t *__restrict__ row_hap,
+                                                           const unsigned long long *__restrict__ tb, const uint32_t *__restrict__ tlen,
+                                                           const double *__restrict__ mean0, const double *__restrict__ sd, HapAcc *__restrict__ part) {
+    extern __shared__ HapAcc s_hap_acc[];
+    const uint4 ch = chunks[blockIdx.x];                       // {species, first row, end row, first partial}
+    const uint32_t h0 = (uint32_t)hap_off[ch.x], Hs = (uint32_t)hap_off[ch.x + 1] - h0;
+    const int lane = threadIdx.x;
+    const bool in_lds = Hs <= HS_LDS_HAPS;
+    HapAcc *acc = in_lds ? s_hap_acc : part + ch.w;            // (the partials were zero-filled before the pass)
+    if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) acc[h] = HapAcc{0.0, 0u, 0u};
+    __syncthreads();
+    for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
+        const uint32_t row = r0 + (uint32_t)lane;
+        const bool valid = row < ch.z;
+        uint32_t h = 0xFFFFFFFFu;
+        double val = 0.0;
+        bool flag = false;
+        if (valid) {
+            h = row_hap[row];
+            const double x = (double)(long long)tb[row] / (double)tlen[row];   // profile.rs:1013-1014
+            if (x > 0.0) {                                                      // :1129-1133
+                if (PASS == 0) { val = x; flag = true; }
+                else {
+                    const double m = mean0[h0 + h];
+                    if (PASS == 1) { val = (x - m) * (x - m); flag = true; }
+                    else { const double s_ = sd[h0 + h]; if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; } }   // :1043-1050
+                }
+            }
+        }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(todo));
+            const bool mine = valid && h == hh;
+            const unsigned long long sel = __ballot(mine);
+            const double v = wave_reduce(mine ? val : 0.0, [](double x, double y) { return x + y; });
+            const uint32_t c = (uint32_t)__popcll(__ballot(mine && flag));
+            if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
+            todo &= ~sel;
         }
     }
     __syncthreads();
-    const uint64_t b = hto[h], e = hto[h + 1];
-    const uint64_t per = (e - b + HAP_CHUNKS - 1) / HAP_CHUNKS;
-    uint64_t lo = b + ch * per, hi = lo + per;
-    if (hi > e) hi = e;
-    const double mean = pass ? s_mean : 0.0, sd = pass == 2 ? s_sd : 0.0;
-    double acc = 0.0; unsigned long long cnt = 0;
-    if (!(pass == 2 && sd == 0.0))
-        for (uint64_t u = lo + threadIdx.x; u < hi; u += 256) {
-            double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
-            if (!(x > 0.0)) continue;                                // :1129-1133
-            if (pass == 0) { acc += x; ++cnt; }
-            else if (pass == 1) acc += (x - mean) * (x - mean);
-            else if (fabs((x - mean) / sd) < 3.0) { acc += x; ++cnt; }   // :1047-1050
-        }
-    acc = block_sum_f64<256>(acc, red);
-    cnt = block_sum_u64<256>(cnt, redu);
-    if (threadIdx.x == 0) part[(size_t)pass * PS + blockIdx.x] = {acc, 0.0, cnt};
+    if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
 }
-// per haplotype: the number of non-zero unique-trio abundances (pass 0) and the filtered mean (pass 2)
-__global__ void __launch_bounds__(64) hap_trio_final_kernel(uint32_t H, const HapPartial *__restrict__ part, uint32_t *__restrict__ nnz_out,
-                                                            double *__restrict__ mean_out) {
-    uint32_t h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= H) return;
-    const size_t PS = (size_t)H * HAP_CHUNKS;
-    double a0, a2; unsigned long long c0, c2;
-    hap_combine(part, h, a0, c0);
-    hap_combine(part + 2 * PS, h, a2, c2);
-    nnz_out[h] = (uint32_t)c0;
-    mean_out[h] = c2 ? a2 / (double)c2 : 0.0;   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+// one wave per species: the chunks' partials added in chunk order
+template <int PASS>
+__global__ void __launch_bounds__(64) hap_combine_kernel(const uint32_t *__restrict__ sp_chunk_off, const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off,
+                                                         const HapAcc *__restrict__ part, uint32_t *__restrict__ nnz, double *__restrict__ mean0, double *__restrict__ sd,
+                                                         double *__restrict__ meanf) {
+    const uint32_t s = blockIdx.x, c0 = sp_chunk_off[s], c1 = sp_chunk_off[s + 1];
+    const uint32_t h0 = (uint32_t)hap_off[s], Hs = (uint32_t)hap_off[s + 1] - h0;
+    for (uint32_t h = threadIdx.x; h < Hs; h += 64) {
+        double a = 0.0;
+        unsigned long long c = 0;
+        for (uint32_t k = c0; k < c1; ++k) { const HapAcc p = part[chunks[k].w + h]; a += p.a; c += p.c; }
+        if (PASS == 0) { nnz[h0 + h] = (uint32_t)c; mean0[h0 + h] = c ? a / (double)c : 0.0; }              // profile.rs:1037
+        else if (PASS == 1) { const double n = (double)nnz[h0 + h]; sd[h0 + h] = n > 0 ? sqrt(a / n) : 0.0; }   // :1038-1041
+        else meanf[h0 + h] = c ? a / (double)c : 0.0;                 // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+    }
 }
 
-// The same three passes in ONE launch, a workgroup per haplotype (round 4; databases of thousands of haplotypes: the launch fills the
-// device with one workgroup each, the rows of a haplotype -- 1.8e4 x 12 bytes at ten strains per species -- stay in the L2 of its XCD between
-// the passes, and two of three launches go).  The order of the sums differs from the 32-chunk tree above (both are fixed orders; the
-// reference's own order is that of a hash set): results agree to rounding.
-__global__ void __launch_bounds__(256) hap_trio_fused_kernel(uint32_t H, const uint64_t *__restrict__ hto, const unsigned long long *__restrict__ tb,
-                                                             const uint32_t *__restrict__ tlen, uint32_t *__restrict__ nnz_out, double *__restrict__ mean_out) {
-    __shared__ double red[4];
-    __shared__ unsigned long long redu[4];
-    const uint32_t h = blockIdx.x;
-    const uint64_t b = hto[h], e = hto[h + 1];
-    double acc = 0.0; unsigned long long cnt = 0;
-    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-        const double x = (double)(long long)tb[u] / (double)tlen[u];   // profile.rs:1013-1014
-        if (x > 0.0) { acc += x; ++cnt; }                             // :1129-1133
-    }
-    const double a0 = block_sum_f64<256>(acc, red);
-    const unsigned long long c0 = block_sum_u64<256>(cnt, redu);
-    const double mean = c0 ? a0 / (double)c0 : 0.0;                   // :1037
-    acc = 0.0;
-    for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-        const double x = (double)(long long)tb[u] / (double)tlen[u];
-        if (x > 0.0) acc += (x - mean) * (x - mean);
-    }
-    const double a1 = block_sum_f64<256>(acc, red);
-    const double n = (double)(uint32_t)c0;
-    const double sd = n > 0 ? sqrt(a1 / n) : 0.0;                     // :1038-1041
-    acc = 0.0; cnt = 0;
-    if (sd != 0.0)
-        for (uint64_t u = b + threadIdx.x; u < e; u += 256) {
-            const double x = (double)(long long)tb[u] / (double)tlen[u];
-            if (x > 0.0 && fabs((x - mean) / sd) < 3.0) { acc += x; ++cnt; }   // :1047-1050
+// first build of a db (trio_index_build): the blocks of rows of the species -> chunks of rows, a row of partials per chunk
+int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint64_t *sp_rows) {
+    const uint32_t S = db->S;
+    std::vector<uint4> chunks;
+    std::vector<uint32_t> sp_off(S + 1, 0);
+    uint64_t n_part = 0;
+    uint32_t lds_haps = 1;
+    for (uint32_t s = 0; s < S; ++s) {
+        sp_off[s] = (uint32_t)chunks.size();
+        const uint64_t Hs = db->h_hap_off[s + 1] - db->h_hap_off[s];
+        if (Hs <= HS_LDS_HAPS) lds_haps = std::max<uint32_t>(lds_haps, (uint32_t)Hs);
+        // a chunk holds at least eight rows per haplotype of its species: the partials stay an eighth of the rows at most
+        const uint64_t per = std::max<uint64_t>(HS_CHUNK_ROWS, ((8 * Hs + 63) / 64) * 64);
+        for (uint64_t r = 0; r < sp_rows[s]; r += per) {
+            if (n_part + Hs >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "hap statistics: more than 2^32 chunk partials");
+            chunks.push_back(make_uint4(s, (uint32_t)(sp_first_row[s] + r), (uint32_t)(sp_first_row[s] + std::min<uint64_t>(sp_rows[s], r + per)), (uint32_t)n_part));
+            n_part += Hs;
         }
-    const double a2 = block_sum_f64<256>(acc, red);
-    const unsigned long long c2 = block_sum_u64<256>(cnt, redu);
-    if (threadIdx.x == 0) { nnz_out[h] = (uint32_t)c0; mean_out[h] = c2 ? a2 / (double)c2 : 0.0; }   // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+    }
+    sp_off[S] = (uint32_t)chunks.size();
+    db->n_stat_chunks = (uint32_t)chunks.size();
+    db->n_stat_partials = n_part;
+    db->stat_lds_haps = lds_haps;
+    if (chunks.empty()) chunks.push_back(make_uint4(0u, 0u, 0u, 0u));
+    PTX_TRY(upload(ctx, db->d_stat_chunks, chunks.data(), chunks.size()));
+    PTX_TRY(upload(ctx, db->d_sp_chunk_off, sp_off.data(), sp_off.size()));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging vectors go out of scope
+    return 0;
 }
 
 int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBuf<double> &d_mean) {
@@ -278,22 +279,22 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     PTX_HIP(ctx, d_mean.alloc(db->H));
     if (db->H == 0) return 0;
     Db *dbm = const_cast<Db *>(db);
-    const uint32_t H = (uint32_t)db->H;
-    bool fused = H >= 2048;                                 // enough workgroups to fill the device (PANTAX_HAP_STATS=chunks|fused picks one, for tests)
-    if (!ctx->cfg.hap_stats.empty()) fused = ctx->cfg.hap_stats[0] == 'f';
-    if (fused) {
-        KTimer t(ctx, "hap_trio_fused_kernel");
-        hipLaunchKernelGGL(hap_trio_fused_kernel, dim3(H), dim3(256), 0, ctx->stream, H, db->d_hap_trio_off.p, db->d_trio_bases.p, db->d_trio_len.p, d_nnz.p, d_mean.p);
-        PTX_HIP(ctx, hipGetLastError());
-        return 0;
-    }
-    PTX_HIP(ctx, dbm->d_hap_part.alloc((size_t)3 * H * HAP_CHUNKS * 3));
-    for (int pass = 0; pass < 3; ++pass) {
-        KTimer t(ctx, "hap_trio_pass_kernel");
-        hipLaunchKernelGGL(hap_trio_pass_kernel, dim3(H * HAP_CHUNKS), dim3(256), 0, ctx->stream, pass, H, db->d_hap_trio_off.p, db->d_trio_bases.p,
-                           db->d_trio_len.p, (HapPartial *)dbm->d_hap_part.p);
-    }
-    hipLaunchKernelGGL(hap_trio_final_kernel, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, H, (const HapPartial *)dbm->d_hap_part.p, d_nnz.p, d_mean.p);
+    const uint32_t S = db->S, NC = db->n_stat_chunks;
+    const uint64_t H = db->H;
+    PTX_HIP(ctx, dbm->d_hap_part.alloc(2 * (size_t)std::max<uint64_t>(db->n_stat_partials, 1) + 2 * H));   // the chunks' partials (16 B each), then mean and sd of pass 0 / 1
+    HapAcc *part = reinterpret_cast<HapAcc *>(dbm->d_hap_part.p);
+    double *mean0 = dbm->d_hap_part.p + 2 * (size_t)std::max<uint64_t>(db->n_stat_partials, 1), *sd = mean0 + H;
+    const size_t lds = (size_t)db->stat_lds_haps * sizeof(HapAcc);
+    KTimer t(ctx, "hap_rows_pass_kernel");
+#define HS_PASS(PP)                                                                                                                                            \
+    PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                                                        \
+    if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
+                               (const uint16_t *)db->d_trio_hap.p, (const unsigned long long *)db->d_trio_bases.p, (const uint32_t *)db->d_trio_len.p,          \
+                               (const double *)mean0, (const double *)sd, part);                                                                               \
+    hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(64), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
+                       (const uint64_t *)db->d_hap_off.p, (const HapAcc *)part, d_nnz.p, mean0, sd, d_mean.p);
+    HS_PASS(0) HS_PASS(1) HS_PASS(2)
+#undef HS_PASS
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -319,30 +319,23 @@ struct __attribute__((packed, aligned(4))) U32x3 { uint32_t x, y, z; };
 #else
 #define TV_ABL(bit) false
 #endif
-// ROWS (a db that the visit table covers whole -- no species left to the node-block kernel): the wave also hands its unique windows
-// to trio_rows_kernel -- the group's ballot of unique visits and, for the first VIS_REC of them, a 16-byte record {window start, smaller
-// end, larger end, middle (global node indices)} -- instead of the per-node counts: the lookup rows are then filed in visit order, which
-// IS the order of a CSR over the middle node, by a scan over the groups' counts (a tenth of the nodes) and one pass over the records,
-// no scan over all nodes and no second pass over the walks.  A group with more unique visits than records (one in seven at ten strains
-// per species) is read again by trio_rows_kernel.
+// ROWS (the default): the wave hands its unique windows to trio_rows_kernel -- the group's ballot of unique visits and, for the first VIS_REC
+// of them, a 16-byte record {window start, smaller end, larger end, middle (global node indices)}.  The rows of the index are then numbered IN
+// THIS ORDER (round 5): a row = the rank of its visit among the unique visits of the table, i.e. a scan over the groups' counts (a tenth of the
+// nodes) and one pass over the records -- no flag bit per path position, no ranks of flags, no scatter in (hap, position) order.  A group with more
+// unique visits than records (one in seven at ten strains per species) is read again by trio_rows_kernel.
+// !ROWS (option trio_rows=path; tests): one flag bit per unique window start + the count of unique windows per node, the inputs of the pass over
+// the walks (trio_lookup_kernel) that also serves the species the visit table leaves to the node-block kernel.
 constexpr int VIS_REC = 8;
-constexpr int TV_SLOT_BITS = 10, TV_SLOTS = 1 << TV_SLOT_BITS;   // LDS table of flag words per workgroup
 template <int U, bool ROWS>
 __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                          const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ path_nodes,
                                                          uint32_t *__restrict__ uniq_q, uint32_t *__restrict__ first_cnt, uint32_t *__restrict__ err, uint32_t ablate,
                                                          unsigned long long *__restrict__ vis_uq, uint4 *__restrict__ vis_rec, uint32_t xcd_chunks) {
-    // The flag bits of the unique windows are combined per 32-position word in an LDS table before they go to memory: the windows
-    // around a private allele flag neighbouring positions of ONE walk, and a device-scope atomic is a trip to the memory side
-    // (1.8e8 of them cost 2.3 of the kernel's 7.2 ms at 1e4 strains).  {word index, bits}, open addressing, four probes; a word that
-    // finds no slot is flagged in memory directly.
-    __shared__ uint32_t s_fw[TV_SLOTS], s_fb[TV_SLOTS];
-    for (int i = threadIdx.x; i < TV_SLOTS; i += 256) { s_fw[i] = 0xFFFFFFFFu; s_fb[i] = 0u; }
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // xcd_chunks != 0 (= the number of workgroups' worth of groups): workgroups go to the XCDs round-robin, so XCD x is given the x-th
-    // contiguous eighth of the table -- neighbouring chunks flag neighbouring words of the same walks, and meet in ONE L2
+    // contiguous eighth of the table -- neighbouring chunks read neighbouring lines of the same walks, and meet in ONE L2
     uint32_t blk = blockIdx.x;
     if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) blk = 0xFFFFFFu; }
     uint32_t g0 = blk == 0xFFFFFFu ? NG : (blk * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
@@ -381,38 +374,26 @@ __global__ void __launch_bounds__(256) trio_visit_kernel(uint32_t NG, uint32_t r
             if (bad && lane == 0) atomicAdd(err, 1u);
             const unsigned long long dup = eq | (eq >> 1);                   // both partners are not unique
             const unsigned long long uq = vmask & ~dup;
-            if (((uq >> lane) & 1ull) && !TV_ABL(1u)) {                     // flagged at the window's start
-                const uint32_t q0 = q[u] - 1u, word = q0 >> 5, bit = 1u << (q0 & 31u);
-                uint32_t h = (word * 0x9E3779B1u) >> (32 - TV_SLOT_BITS);
-                bool filed = false;
-#pragma unroll
-                for (int probe = 0; probe < 4 && !filed; ++probe) {
-                    uint32_t cur = s_fw[h];
-                    if (cur == 0xFFFFFFFFu) cur = atomicCAS(&s_fw[h], 0xFFFFFFFFu, word);
-                    if (cur == 0xFFFFFFFFu || cur == word) { atomicOr(&s_fb[h], bit); filed = true; }
-                    h = (h + 1u) & (TV_SLOTS - 1u);
-                }
-                if (!filed) atomicOr(&uniq_q[word], bit);
-            }
             if (ROWS) {
                 const uint32_t g = g0 + (uint32_t)u;
                 if (g < NG) {
                     if (lane == 0) vis_uq[g] = uq;
-                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));   // unique visits in the lanes below
-                    if (((uq >> lane) & 1ull) && r < (uint32_t)VIS_REC && !TV_ABL(2u))
-                        vis_rec[(uint64_t)g * VIS_REC + r] = make_uint4(q[u] - 1u, nb[u] + lo, nb[u] + hi, nb[u] + w[u].y);
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));   // unique visits in the lanes below
+                    if (((uq >> lane) & 1ull) && rk < (uint32_t)VIS_REC && !TV_ABL(2u))
+                        vis_rec[(uint64_t)g * VIS_REC + rk] = make_uint4(q[u] - 1u, nb[u] + lo, nb[u] + hi, nb[u] + w[u].y);
                 }
-            } else if (((hd >> lane) & 1ull) && !TV_ABL(2u)) {                                      // the head lane stores its node's count of unique windows
-                const unsigned long long he = hd | (~vmask & (vmask + 1ull));   // the first pad lane closes the last stretch (pads sit at the tail)
-                const unsigned long long above = he & ~((2ull << lane) - 1ull);
-                const int end = above ? __builtin_ctzll(above) : 64;
-                const unsigned long long m = (end == 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
-                first_cnt[nb[u] + w[u].y] = (uint32_t)__popcll(uq & m);
+            } else {
+                if (((uq >> lane) & 1ull) && !TV_ABL(1u)) uniq_mark(uniq_q, q[u] - 1u);          // flagged at the window's start
+                if (((hd >> lane) & 1ull) && !TV_ABL(2u)) {                                      // the head lane stores its node's count of unique windows
+                    const unsigned long long he = hd | (~vmask & (vmask + 1ull));   // the first pad lane closes the last stretch (pads sit at the tail)
+                    const unsigned long long above = he & ~((2ull << lane) - 1ull);
+                    const int end = above ? __builtin_ctzll(above) : 64;
+                    const unsigned long long m = (end == 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
+                    first_cnt[nb[u] + w[u].y] = (uint32_t)__popcll(uq & m);
+                }
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < TV_SLOTS; i += 256) { const uint32_t wd = s_fw[i]; if (wd != 0xFFFFFFFFu) atomicOr(&uniq_q[wd], s_fb[i]); }
 }
 
 // ---- the visit table (upload time; a function of the graphs alone) ----
@@ -453,7 +434,7 @@ __global__ void __launch_bounds__(256) visit_layout_kernel(uint32_t NC, const ui
 }
 __global__ void __launch_bounds__(256) visit_place_kernel(uint32_t NC, const uint4 *__restrict__ chunks, const uint32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ chunk_gbase, uint32_t *__restrict__ vslot,
-                                                          unsigned long long *__restrict__ head, uint32_t *__restrict__ gnbase) {
+                                                          unsigned long long *__restrict__ head, uint32_t *__restrict__ gnbase, uint32_t *__restrict__ gsp) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= NC) return;
     const uint4 ch = chunks[c];
@@ -467,6 +448,7 @@ __global__ void __launch_bounds__(256) visit_place_kernel(uint32_t NC, const uin
         vslot[v] = slot;
         atomicOr(&head[slot >> 6], 1ull << (slot & 63u));
         gnbase[slot >> 6] = ch.z;
+        gsp[slot >> 6] = ch.w;
         pos += k;
     }
 }
@@ -533,49 +515,50 @@ __global__ void __launch_bounds__(256) run_fill_kernel(TRIO_GRAPH_ARGS, const ui
     }
 }
 
-// 4a. unique windows per path tile; a scan of these counts in path order gives every tile the row number of
-//     its first unique window (rows are numbered (species, hap, position))
-// ONE WAVE per tile, four tiles per workgroup: the 1024 flag bits of a tile are at most 33 dwords, one per lane (bits outside
-// the tile masked off) -- a workgroup per tile spent its time being launched.
-__global__ void __launch_bounds__(256) trio_tilecount_kernel(uint32_t n_tiles, const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
-                                                             const uint32_t *__restrict__ tile_rank, const uint32_t *__restrict__ uniq_q,
-                                                             uint32_t *__restrict__ tile_cnt) {
-    static_assert(PATH_TILE <= 63 * 32, "one flag word per lane");
-    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tiles) return;
-    const uint2 tile = tiles[t];
-    const int lane = threadIdx.x & 63;
-    uint32_t c = 0;
-    if (tile.x != 0xFFFFFFFFu) {   // not a filler tile
-        const uint64_t q0 = path_off[tile.x] + (uint64_t)tile.y * PATH_TILE;
-        uint64_t qe = path_off[tile.x + 1];
-        if (qe > q0 + PATH_TILE) qe = q0 + PATH_TILE;
-        const uint64_t a = (q0 & ~31ull) + 32ull * (uint64_t)lane;   // first position of this lane's word
-        if (a < qe) {
-            uint32_t w = uniq_q[a >> 5];
-            if (a < q0) w &= 0xFFFFFFFFu << (uint32_t)(q0 - a);
-            if (a + 32 > qe) w &= 0xFFFFFFFFu >> (uint32_t)(a + 32 - qe);
-            c = (uint32_t)__popc(w);
-        }
-    }
-    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
-    if (lane == 0) tile_cnt[tile_rank[t]] = c;
+// ---- rows of the index ----------------------------------------------------------------------------------------------------------------
+// A ROW is a unique window; its number is the place it is FILED at (round 5; rounds 1-4 numbered the rows in (species, hap, position) order,
+// which cost a flag bit per path position, the ranks of those flags and a scattered store per row: 15.5 GB of traffic for 6 GB of payload at
+// 1e4 strains).  Everything the step reads is indexed by that number: the lookup entry {smaller end, larger end} (the coverage pass finds a
+// window under its MIDDLE node, whose record carries {first row, #rows}), the window's length (profile.rs:712), the haplotype that owns it,
+// and the coverage pass's trio_bases.  The rows of a node are neighbours, sorted by their pair of ends -- a canonical order, the same on
+// every build and on both routes below -- and the rows of a species are one block.
+
+// the haplotype whose walk holds path position q: last h in [h0, h1) with path_off[h] <= q
+__device__ __forceinline__ uint32_t hap_of_position(const uint64_t *__restrict__ path_off, uint32_t h0, uint32_t h1, uint32_t q) {
+    uint32_t lo = h0, hi = h1;
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= (uint64_t)q) lo = mid; else hi = mid; }
+    return lo;
 }
-// 4b. one pass over the unique windows: lookup arrays (CSR over the MIDDLE node: the two ends (a,c) + row number in path
-//     order) and the row-order arrays (canonical key, owner hap, length profile.rs:712)
-// KEYS: also the export copies in row order (canonical key, owner haplotype) that pantax_hip_trio_get and the db images hand
-// out; no stage of the step reads them (the key is in the lookup entry, the owner follows from hap_trio_off), so a step's
-// rebuild leaves them out (16 of the 36 bytes written per window) and the two exporters rebuild with them on demand.
-// `only_slow` (mixed databases, round 4): the species the visit table covers file their rows through trio_rows_kernel; this pass then takes
-// only the tiles of the species left to the node-block kernel, and a window's row is the rank of its flag (`word_rank`) instead of
-// the tile's base + its rank in the tile.
-template <bool KEYS>
-__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ tile_rank, const uint64_t *__restrict__ hap_off,
-                                                          const uint32_t *__restrict__ node_len, const uint32_t *__restrict__ uniq_q,
-                                                          const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ trio_first,
-                                                          uint32_t *__restrict__ cursor /* = the per-node counts; zero afterwards */, uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc,
-                                                          uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
-                                                          const uint32_t *__restrict__ only_slow, const uint2 *__restrict__ word_rank) {
+// what filing a row writes (dense stores in row order) -- KEYS: also the window start, from which the exporters make the
+// (species, hap, position) order; FIRST (first build of a db): the rows per haplotype are counted (-> hap_trio_off)
+struct RowOut {
+    const uint32_t *node_len;
+    const uint64_t *path_off, *hap_off;
+    uint2 *ent;
+    uint32_t *len;
+    uint16_t *hap;
+    uint32_t *q;
+    uint32_t *hap_cnt;
+};
+template <bool KEYS, bool FIRST>
+__device__ __forceinline__ void row_file(const RowOut &o, uint32_t row, uint32_t q0, uint32_t lo, uint32_t hi, uint32_t mid, uint32_t sp) {
+    const uint32_t h0 = (uint32_t)o.hap_off[sp], h = hap_of_position(o.path_off, h0, (uint32_t)o.hap_off[sp + 1], q0);
+    o.ent[row] = make_uint2(lo, hi);
+    o.len[row] = o.node_len[lo] + o.node_len[mid] + o.node_len[hi];
+    o.hap[row] = (uint16_t)(h - h0);
+    if (KEYS) o.q[row] = q0;
+    if (FIRST) atomicAdd(&o.hap_cnt[h], 1u);
+}
+
+// ---- PATH ROUTE: rows filed by a pass over the walks (species the visit table leaves to the node-block kernel; whole databases on the
+// bucket path or under the options trio_path / trio_rows).  Its inputs are one flag bit per unique window start and the count of unique
+// windows per node; a scan of the counts gives every node its block of rows (and its lookup head), the pass over the walks drops every unique
+// window into its node's block in ARRIVAL order, and trio_canon_kernel then puts every block into the canonical order -- sorted by the pair
+// of ends, which is distinct inside a node by the very definition of a unique window -- and files the rows.
+// `only_slow` (mixed databases): only the tiles of the species left to the node-block kernel.
+__global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ uniq_q, const uint32_t *__restrict__ trio_first,
+                                                          uint32_t *__restrict__ cursor /* = the per-node counts; zero afterwards */, uint2 *__restrict__ trio_ent,
+                                                          uint32_t *__restrict__ row_q, const uint32_t *__restrict__ only_slow) {
     constexpr int NR = PATH_TILE / 256;   // rounds of 256 consecutive positions
     __shared__ uint32_t s_wave[NR][4];
     const uint2 tile = tiles[blockIdx.x];
@@ -585,9 +568,8 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
     const uint32_t sidx = hap_species[h], nbase = node_base[sidx];
     if (only_slow && !only_slow[sidx]) return;                   // a species of the visit table
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t carry0 = word_rank ? 0u : tile_base[tile_rank[blockIdx.x]];   // row of the tile's first unique window
     // all rounds at once: the flags of the four rounds are loaded together, ONE barrier orders the wave counts, and the
-    // gathers / writes of the unique windows of all rounds are in flight together (row = rank of the window in the tile)
+    // gathers / writes of the unique windows of all rounds are in flight together
     uint32_t u[NR];
     unsigned long long bal[NR];
 #pragma unroll
@@ -601,9 +583,8 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
         if (lane == 0) s_wave[r][wave] = (uint32_t)__popcll(bal[r]);
     }
     __syncthreads();
-    // The unique windows are a few per cent of the positions: their tile-local ranks (the row numbers) compact them into an LDS
-    // list first, and the gathers / scatters of a window then run on DENSE lanes -- one round of 256 threads does what the
-    // four sparse rounds did with a handful of active lanes per wave each (every wave paid the full latency chain four times).
+    // The unique windows are a few per cent of the positions: they are compacted into an LDS list first, and the gathers / scatters of a
+    // window then run on DENSE lanes
     __shared__ uint16_t s_list[PATH_TILE];
     uint32_t n_u = 0;
 #pragma unroll
@@ -617,16 +598,43 @@ __global__ void __launch_bounds__(256) trio_lookup_kernel(TRIO_GRAPH_ARGS, const
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_u; t += 256) {
         const uint64_t q = qt0 + s_list[t];
-        const uint32_t row = word_rank ? (word_rank[q >> 5].x + (uint32_t)__popc(word_rank[q >> 5].y & ((1u << (uint32_t)(q & 31ull)) - 1u))) : carry0 + t;
         uint32_t g, a, b, c;
         window_of(q, qend, nbase, path_nodes, g, a, b, c);
         const uint32_t j = trio_first[g] + atomicSub(&cursor[g], 1u) - 1u;   // the node's own count, counted down: no cursor array to zero
-        trio_ent[j] = make_uint4(nbase + a, nbase + c, row, 0u);   // the two ends (the head g is the middle); global node indices: the coverage pass works in them throughout
-        if (KEYS) {
-            abc[3ull * row] = a; abc[3ull * row + 1] = b; abc[3ull * row + 2] = c;
-            hap_out[row] = h - (uint32_t)hap_off[sidx];
+        trio_ent[j] = make_uint2(nbase + a, nbase + c);                      // global node indices: the coverage pass works in them throughout
+        row_q[j] = (uint32_t)q;
+    }
+}
+// one thread per node that heads rows (path route): its block of rows sorted by (smaller end, larger end) -- insertion sort, a handful of rows;
+// a hub of a thousand distinct neighbour pairs is a millisecond of one thread at load time -- and filed
+template <bool KEYS, bool FIRST>
+__global__ void __launch_bounds__(256) trio_canon_kernel(uint64_t V, uint32_t S, const uint32_t *__restrict__ node_base, const uint4 *__restrict__ node_rec,
+                                                         const uint32_t *__restrict__ trio_first, const uint32_t *__restrict__ visited,
+                                                         const uint32_t *__restrict__ only_slow, uint32_t *__restrict__ row_q, RowOut o) {
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    if (visited && !((visited[v >> 5] >> (uint32_t)(v & 31ull)) & 1u)) return;
+    const uint32_t n = nr_rows(node_rec[v].y);
+    if (n == 0) return;
+    uint32_t lo = 0, hi = S;                                             // last s with node_base[s] <= v
+    while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)node_base[mid] <= v) lo = mid; else hi = mid; }
+    const uint32_t sp = lo;
+    if (only_slow && !only_slow[sp]) return;                             // a species of the visit table: trio_rows_kernel files its rows
+    const uint32_t f = trio_first[v];
+    for (uint32_t i = 1; i < n; ++i) {
+        const uint2 e = o.ent[f + i];
+        const uint32_t q = row_q[f + i];
+        uint32_t j = i;
+        for (; j > 0; --j) {
+            const uint2 p = o.ent[f + j - 1];
+            if (p.x < e.x || (p.x == e.x && p.y <= e.y)) break;
+            o.ent[f + j] = p; row_q[f + j] = row_q[f + j - 1];
         }
-        len_out[row] = node_len[nbase + a] + node_len[nbase + b] + node_len[nbase + c];   // profile.rs:712
+        if (j != i) { o.ent[f + j] = e; row_q[f + j] = q; }
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint2 e = o.ent[f + i];
+        row_file<KEYS, FIRST>(o, f + i, row_q[f + i], e.x, e.y, (uint32_t)v, sp);
     }
 }
 
@@ -641,7 +649,7 @@ struct TrioFirstLoad {
         return cnt[i];
     }
 };
-// mixed databases: the lookup heads of the species left to the node-block kernel, filed BEHIND the rows of the visit table's species (slot base
+// mixed databases: the lookup heads of the species left to the node-block kernel, filed BEHIND the rows of the visit table's species (row base
 // = *u_fast, the total of the groups' counts); a node of a visit-table species reads as zero here
 struct SlowFirstLoad {
     const uint32_t *cnt, *visited, *slow;
@@ -688,41 +696,22 @@ struct TrioFirstStore {
         if (i < V && c) {
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
             uint4 r = node_rec[i];
-            r.y = nr_head(r.y, c, 0xFFu);                    // this path does not compute the pair filter
+            r.y = nr_head(r.y, c, 0xFFu);                    // this route does not compute the pair filter
             r.w = excl;
             node_rec[i] = r;
         }
     }
 };
 
-// ---- the rows of a db that the visit table covers whole (trio_visit_kernel<.., ROWS = true>) ----
-// rank of window start q among the unique windows in (species, hap, position) order = its row: the prefix of its flag word plus the
-// flags below it in the word
-struct FlagWordLoad { const uint32_t *bits; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popc(bits[i]); } };
+// ---- FAST ROUTE: the rows of the species the visit table covers, filed from trio_visit_kernel<.., ROWS = true>'s records ----
+// the first row of every group = the prefix of the groups' counts of unique visits, in three plain launches (tile sums, a scan of the sums
+// by one workgroup, tile prefixes): a chained scan's workgroups spin on their predecessors, and beside the main stream's kernels of the step in
+// flight that spinning stretched a 0.34-ms scan to 2.5 ms (and held the slots it spun in) -- the rebuild of the NEXT step runs beside the
+// current step's row sort and LPs
 struct GroupCountLoad { const unsigned long long *uq; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t)__popcll(uq[i]); } };
 struct PrefixStore { uint32_t *out; __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t) const { out[i] = excl; } };
-// {flags before the word, the word}: ONE 8-byte gather per rank
-struct FlagRankStore { uint2 *out; const uint32_t *bits; __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t) const { out[i] = make_uint2(excl, bits[i]); } };
-__device__ __forceinline__ uint32_t flag_rank(const uint2 *__restrict__ word_rank, uint64_t q) {
-    const uint2 w = word_rank[q >> 5];
-    return w.x + (uint32_t)__popc(w.y & ((1u << (uint32_t)(q & 31ull)) - 1u));
-}
-// The same ranks in three plain launches (tile sums, a scan of the sums by one workgroup, tile ranks): a chained scan's workgroups spin on
-// their predecessors, and beside the main stream's kernels of the step in flight that spinning stretched this one from 0.34 to 2.5 ms
-// (and held the slots it spun in) -- the rebuild of the NEXT step runs beside the current step's row sort and LPs
-constexpr int FR_WORDS = 16, FR_TILE = 256 * FR_WORDS;           // flag words per thread and per workgroup
-__global__ void __launch_bounds__(256) flag_tile_sum_kernel(const uint32_t *__restrict__ bits, uint64_t n, uint32_t *__restrict__ sums) {
-    __shared__ uint32_t s_w[4];
-    const uint64_t base = (uint64_t)blockIdx.x * FR_TILE;
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < FR_WORDS; ++k) { const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x; if (i < n) c += (uint32_t)__popc(bits[i]); }
-    c = wave_reduce(c, [](uint32_t x, uint32_t y) { return x + y; });
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-__global__ void __launch_bounds__(1024) flag_tile_scan_kernel(uint32_t *__restrict__ sums, uint32_t n_tiles, uint32_t *__restrict__ total) {
+constexpr int FR_WORDS = 16, FR_TILE = 256 * FR_WORDS;           // counts per thread and per workgroup
+__global__ void __launch_bounds__(1024) tile_scan_kernel(uint32_t *__restrict__ sums, uint32_t n_tiles, uint32_t *__restrict__ total) {
     __shared__ uint32_t s_wave[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
@@ -735,8 +724,7 @@ __global__ void __launch_bounds__(1024) flag_tile_scan_kernel(uint32_t *__restri
     if (threadIdx.x == 0 && total) *total = carry;
 }
 // (element i of a tile = stretch k, thread t: i = k * 256 + t -- coalesced loads and stores; a stretch's prefix = one DPP scan per wave
-// + the four wave sums through LDS; FR_WORDS consecutive words per thread had every wave instruction touch 64 different lines: 0.39 ms
-// where this takes 0.15)
+// + the four wave sums through LDS)
 template <class Count, class Emit>
 __device__ __forceinline__ void tile_prefix(uint64_t n, uint32_t start, Count count, Emit emit) {
     __shared__ uint32_t s_w[2][4];
@@ -757,11 +745,6 @@ __device__ __forceinline__ void tile_prefix(uint64_t n, uint32_t start, Count co
         run += tot;
     }
 }
-__global__ void __launch_bounds__(256) flag_tile_rank_kernel(const uint32_t *__restrict__ bits, uint64_t n, const uint32_t *__restrict__ sums, uint2 *__restrict__ out) {
-    tile_prefix(n, sums[blockIdx.x], [&](uint64_t i) { return (uint32_t)__popc(bits[i]); }, [&](uint64_t i, uint32_t excl) { out[i] = make_uint2(excl, bits[i]); });
-}
-
-// ... and the slots of the groups (prefix of their unique counts) the same way, the scan kernel shared
 __global__ void __launch_bounds__(256) group_tile_sum_kernel(const unsigned long long *__restrict__ uq, uint64_t n, uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_w[4];
     const uint64_t base = (uint64_t)blockIdx.x * FR_TILE;
@@ -777,44 +760,23 @@ __global__ void __launch_bounds__(256) group_tile_prefix_kernel(const unsigned l
     tile_prefix(n, sums[blockIdx.x], [&](uint64_t i) { return (uint32_t)__popcll(uq[i]); }, [&](uint64_t i, uint32_t excl) { out[i] = excl; });
 }
 
-// one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
-// length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
-template <bool KEYS>
-__device__ __forceinline__ void trio_row_emit(const uint4 rec, uint32_t slot, const uint2 *__restrict__ word_rank,
-                                              const uint32_t *__restrict__ node_len, uint32_t nbase, uint32_t H, const uint64_t *__restrict__ path_off,
-                                              const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ trio_ent,
-                                              uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
-    const uint32_t row = flag_rank(word_rank, rec.x);
-    trio_ent[slot] = make_uint4(rec.y, rec.z, row, 0u);
-    len_out[row] = node_len[rec.y] + node_len[rec.w] + node_len[rec.z];
-    if (KEYS) {
-        abc[3ull * row] = rec.y - nbase; abc[3ull * row + 1] = rec.w - nbase; abc[3ull * row + 2] = rec.z - nbase;
-        uint32_t lo = 0, hi = H;                                             // the walk that holds position rec.x: last h with path_off[h] <= q
-        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= (uint64_t)rec.x) lo = mid; else hi = mid; }
-        hap_out[row] = lo - (uint32_t)hap_off[hap_species[lo]];
-    }
-}
-// the lookup head of a node = {slot of its first row, number of its rows}, written into the node record by the lane that holds the
+// the lookup head of a node = {its first row, the number of its rows}, written into the node record by the lane that holds the
 // node's first unique window (records arrive in visit order: a node's windows are neighbours); `cnt` = rows of this node
-__device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t slot, uint32_t cnt, uint32_t filter, uint32_t *__restrict__ err) {
+__device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t row, uint32_t cnt, uint32_t filter, uint32_t *__restrict__ err) {
     if (cnt >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
     uint4 r = node_rec[v];
     r.y = nr_head(r.y, cnt, filter);
-    r.w = slot;
+    r.w = row;
     node_rec[v] = r;
 }
 // a group with more than VIS_REC unique visits (a stretch of private sequence; every group of a single-strain species): the whole wave
 // reads the group's visits again, ranks the unique ones, and files them like the records
-template <bool KEYS>
+template <bool KEYS, bool FIRST>
 __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
-                                                const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase,
-                                                const uint32_t *__restrict__ path_nodes, const uint2 *__restrict__ word_rank, const uint32_t *__restrict__ node_len, uint32_t H,
-                                                const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ hap_species,
-                                                const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec, uint4 *__restrict__ trio_ent,
-                                                uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out,
-                                                uint32_t *__restrict__ err) {
+                                                const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
+                                                const uint32_t *__restrict__ path_nodes, uint4 *__restrict__ node_rec, const RowOut &o, uint32_t *__restrict__ err) {
     const unsigned long long uq = vis_uq[g];
-    const uint32_t nb = vis_nbase[g], base = gprefix[g];
+    const uint32_t nb = vis_nbase[g], sp = vis_sp[g], base = gprefix[g];
     const bool mine = (uq >> lane) & 1ull;
     uint4 rec = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
     if (mine) {
@@ -828,47 +790,42 @@ __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsi
     const uint32_t prev_w = __shfl(rec.w, lower ? 63 - __builtin_clzll(lower) : lane);
     const bool first = mine && (!lower || prev_w != rec.w);
     const unsigned long long fm = __ballot(first);
-    if (mine) trio_row_emit<KEYS>(rec, base + r, word_rank, node_len, nb, H, path_off, hap_species, hap_off, trio_ent, abc, hap_out, len_out);
+    if (mine) row_file<KEYS, FIRST>(o, base + r, rec.x, rec.y, rec.z, rec.w, sp);
     // the node's rows end at the next first lane; its pair filter = OR of the bits of its unique lanes (every first lane walks its span: a node's
     // unique visits, a handful; all lanes reach the shuffles)
     const uint32_t pbit = mine ? nr_pair_bit(rec.y, rec.z) : 0u;
     const unsigned long long nxt = fm & ~((2ull << lane) - 1ull);
     const unsigned long long span = uq & ~((1ull << lane) - 1ull) & (nxt ? (1ull << __builtin_ctzll(nxt)) - 1ull : ~0ull);
     uint32_t filt = 0u;
-    unsigned long long sp = first ? span : 0ull;
-    while (__any(sp != 0ull)) {
-        const int l = sp ? __builtin_ctzll(sp) : 0;
+    unsigned long long sp_ = first ? span : 0ull;
+    while (__any(sp_ != 0ull)) {
+        const int l = sp_ ? __builtin_ctzll(sp_) : 0;
         const uint32_t ob = __shfl(pbit, l);
-        if (sp) { filt |= ob; sp &= sp - 1ull; }
+        if (sp_) { filt |= ob; sp_ &= sp_ - 1ull; }
     }
     if (first) trio_head_store(node_rec, rec.w, base + r, (uint32_t)__popcll(span), filt, err);
 }
 // EIGHT groups per batch, lane = (group, record): the records of a group that did not overflow (<= VIS_REC unique visits) are read as
-// one coalesced kilobyte per batch; the slot of record r of group g is the scan of the groups' counts + r.  A wave takes U batches at
-// once, level by level -- counts, records, then the gathers every record depends on (its flag word's rank, three node lengths, the node
-// record its head goes into) -- so that U x the loads are in flight per wave: the kernel waits for memory 88 % of its wave cycles at 20
-// registers (`r04_pmc_cfg4.json`), not for a lack of waves.  (The launch takes U = 1: see there.)
-template <bool KEYS, int U>
+// one coalesced kilobyte per batch; the row of record r of group g is the scan of the groups' counts + r.  A wave takes U batches at
+// once, level by level -- counts, records, then the gathers every record depends on (three node lengths, its species' walk offsets, the node
+// record its head goes into) -- so that U x the loads are in flight per wave.  Every store is dense in row order except the heads.
+template <bool KEYS, bool FIRST, int U>
 __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
-                                                        const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase,
+                                                        const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
                                                         const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ path_nodes,
-                                                        const uint2 *__restrict__ word_rank,
-                                                        const uint32_t *__restrict__ node_len, uint32_t H, const uint64_t *__restrict__ path_off,
-                                                        const uint32_t *__restrict__ hap_species, const uint64_t *__restrict__ hap_off, uint4 *__restrict__ node_rec,
-                                                        uint4 *__restrict__ trio_ent, uint32_t *__restrict__ abc, uint32_t *__restrict__ hap_out,
-                                                        uint32_t *__restrict__ len_out, uint32_t *__restrict__ err, uint32_t xcd_chunks) {
+                                                        uint4 *__restrict__ node_rec, RowOut o, uint32_t *__restrict__ err, uint32_t xcd_chunks) {
     static_assert(VIS_REC == 8, "eight lanes per group");
     const int lane = threadIdx.x & 63;
     uint32_t blk = blockIdx.x;          // xcd_chunks != 0: every XCD files one contiguous eighth of the groups (see trio_visit_kernel)
     if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) return; }
     const uint32_t r = (uint32_t)lane & 7u;
-    uint32_t g[U], cnt[U], slot[U];
-    // ---- level 1: the groups' counts and first slots
+    uint32_t g[U], cnt[U], row[U], sp[U];
+    // ---- level 1: the groups' counts, first rows and species
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         g[u] = ((blk * 4u + (threadIdx.x >> 6)) * (uint32_t)U + (uint32_t)u) * 8u + ((uint32_t)lane >> 3);
-        cnt[u] = 0; slot[u] = 0;
-        if (g[u] < NG) { cnt[u] = (uint32_t)__popcll(vis_uq[g[u]]); slot[u] = gprefix[g[u]] + r; }
+        cnt[u] = 0; row[u] = 0; sp[u] = 0;
+        if (g[u] < NG) { cnt[u] = (uint32_t)__popcll(vis_uq[g[u]]); row[u] = gprefix[g[u]] + r; sp[u] = vis_sp[g[u]]; }
     }
     // ---- level 2: the records
     uint4 rec[U];
@@ -880,8 +837,7 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         if (on[u]) rec[u] = vis_rec[(uint64_t)g[u] * VIS_REC + r];
     }
     // ---- level 3: what every record points at
-    uint2 wr[U];
-    uint32_t len3[U];
+    uint32_t len3[U], h0[U], h1[U];
     uint4 nrv[U];
     bool first[U];
 #pragma unroll
@@ -889,10 +845,10 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         // first record of its node: the record below belongs to another node (or to another group)
         const uint32_t below = wave_shr1(rec[u].w, 0xFFFFFFFFu);
         first[u] = on[u] && (r == 0u || below != rec[u].w);
-        wr[u] = make_uint2(0u, 0u); len3[u] = 0; nrv[u] = make_uint4(0u, 0u, 0u, 0u);
+        len3[u] = 0; h0[u] = 0; h1[u] = 0; nrv[u] = make_uint4(0u, 0u, 0u, 0u);
         if (on[u]) {
-            wr[u] = word_rank[rec[u].x >> 5];
-            len3[u] = node_len[rec[u].y] + node_len[rec[u].w] + node_len[rec[u].z];
+            len3[u] = o.node_len[rec[u].y] + o.node_len[rec[u].w] + o.node_len[rec[u].z];
+            h0[u] = (uint32_t)o.hap_off[sp[u]]; h1[u] = (uint32_t)o.hap_off[sp[u] + 1];
         }
         if (first[u]) nrv[u] = node_rec[rec[u].w];
     }
@@ -901,18 +857,12 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     for (int u = 0; u < U; ++u) {
         const unsigned long long fm = __ballot(first[u]), om = __ballot(on[u]);
         if (on[u]) {
-            // one unique window -> its lookup row {smaller end, larger end, row} at `slot` (visit order = CSR order over the middle node), its
-            // length in row order (profile.rs:712), on request the row-order export copies (canonical key, owner haplotype)
-            const uint32_t row = wr[u].x + (uint32_t)__popc(wr[u].y & ((1u << (rec[u].x & 31u)) - 1u));
-            trio_ent[slot[u]] = make_uint4(rec[u].y, rec[u].z, row, 0u);
-            len_out[row] = len3[u];
-            if (KEYS) {
-                const uint32_t nbase = vis_nbase[g[u]];
-                abc[3ull * row] = rec[u].y - nbase; abc[3ull * row + 1] = rec[u].w - nbase; abc[3ull * row + 2] = rec[u].z - nbase;
-                uint32_t lo = 0, hi = H;                                     // the walk that holds position rec.x: last h with path_off[h] <= q
-                while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (path_off[mid] <= (uint64_t)rec[u].x) lo = mid; else hi = mid; }
-                hap_out[row] = lo - (uint32_t)hap_off[hap_species[lo]];
-            }
+            const uint32_t h = hap_of_position(o.path_off, h0[u], h1[u], rec[u].x);
+            o.ent[row[u]] = make_uint2(rec[u].y, rec[u].z);
+            o.len[row[u]] = len3[u];
+            o.hap[row[u]] = (uint16_t)(h - h0[u]);
+            if (KEYS) o.q[row[u]] = rec[u].x;
+            if (FIRST) atomicAdd(&o.hap_cnt[h], 1u);
         }
         // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
         const uint32_t pbit = on[u] ? nr_pair_bit(rec[u].y, rec[u].z) : 0u;
@@ -930,7 +880,7 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
             if (rows >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
             uint4 nr = nrv[u];
             nr.y = nr_head(nr.y, rows, filt);
-            nr.w = slot[u];
+            nr.w = row[u];
             node_rec[rec[u].w] = nr;
         }
     }
@@ -941,27 +891,32 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         while (ov) {
             const int l = __builtin_ctzll(ov);
             ov &= ov - 1ull;
-            trio_rows_group<KEYS>(g[u] - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, path_nodes, word_rank, node_len, H,
-                                  path_off, hap_species, hap_off, node_rec, trio_ent, abc, hap_out, len_out, err);
+            trio_rows_group<KEYS, FIRST>(g[u] - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, vis_sp, path_nodes, node_rec, o, err);
         }
     }
 }
-// hap_trio_off[h] = rows before the first position of haplotype h (entry H: all rows)
-__global__ void __launch_bounds__(256) trio_hapoff_rank_kernel(uint32_t H, const uint64_t *__restrict__ path_off, const uint2 *__restrict__ word_rank,
-                                                               uint64_t *__restrict__ hap_trio_off) {
-    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
-    if (h > H) return;
-    hap_trio_off[h] = (uint64_t)flag_rank(word_rank, path_off[h]);
-}
-// the plain CSR offsets over the middle node (db images keep them; no stage of a step reads them): a scan of the row counts that
-// ride in the node records
-struct HeadCountLoad { const uint4 *node_rec; uint64_t V; __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return i < V ? nr_rows(node_rec[i].y) : 0u; } };
 
-__global__ void __launch_bounds__(256) trio_hapoff_kernel(uint32_t H, const uint32_t *__restrict__ hap_tile_off, const uint32_t *__restrict__ tile_base,
-                                                          uint64_t *__restrict__ hap_trio_off) {
-    uint32_t h = blockIdx.x * 256 + threadIdx.x;
-    if (h > H) return;
-    hap_trio_off[h] = (uint64_t)tile_base[hap_tile_off[h]];   // entry n_tiles of the scan = total
+// ---- the export order: rows listed in (species, hap, position) order = ascending window start (the walks are one CSR over all haplotypes) ----
+__global__ void __launch_bounds__(256) trio_iota_kernel(uint32_t n, uint32_t *__restrict__ v, const uint32_t *__restrict__ q, unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { v[i] = i; key[i] = q[i]; }
+}
+// export copies of the table in that order: canonical key (species-local), owner haplotype, length
+__global__ void __launch_bounds__(256) trio_export_kernel(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ q, const uint32_t *__restrict__ path_nodes,
+                                                          const uint16_t *__restrict__ hap, const uint32_t *__restrict__ len, uint32_t *__restrict__ abc_out,
+                                                          uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t row = perm[e], p = q[row];
+    uint32_t a = path_nodes[p], b = path_nodes[p + 1], c = path_nodes[p + 2];
+    if (a > c) { const uint32_t t = a; a = c; c = t; }                     // profile.rs:672-678
+    if (abc_out) { abc_out[3ull * e] = a; abc_out[3ull * e + 1] = b; abc_out[3ull * e + 2] = c; }
+    if (hap_out) hap_out[e] = hap[row];
+    if (len_out) len_out[e] = len[row];
+}
+__global__ void __launch_bounds__(256) gather_u64_kernel(uint32_t n, const uint32_t *__restrict__ perm, const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) dst[e] = src[perm[e]];
 }
 
 // The visit table (end of db upload).  Counting sort of the interior positions by their node: count -> which species stay
@@ -999,7 +954,7 @@ int trio_visits_build(Ctx *ctx, Db *db) {
         if (force_block) slow[s] = 1u;
         if (slow[s]) continue;
         for (uint64_t v = db->h_node_off[s]; v < db->h_node_off[s + 1]; v += (1u << VIS_CHUNK_SHIFT))
-            chunks.push_back(make_uint4((uint32_t)v, (uint32_t)std::min<uint64_t>(v + (1u << VIS_CHUNK_SHIFT), db->h_node_off[s + 1]), (uint32_t)db->h_node_off[s], 0u));
+            chunks.push_back(make_uint4((uint32_t)v, (uint32_t)std::min<uint64_t>(v + (1u << VIS_CHUNK_SHIFT), db->h_node_off[s + 1]), (uint32_t)db->h_node_off[s], s));
     }
     const uint32_t NC = (uint32_t)chunks.size();
     if (NC == 0) return all_slow();
@@ -1015,14 +970,15 @@ int trio_visits_build(Ctx *ctx, Db *db) {
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((uint64_t)NG * 64 >= 0xFFFFFFFFull) return all_slow();   // slots are 32-bit
     if (NG) {
-        PTX_HIP(ctx, db->d_vis_pos.alloc((uint64_t)NG * 64)); PTX_HIP(ctx, db->d_vis_head.alloc(NG)); PTX_HIP(ctx, db->d_vis_nbase.alloc(NG));
+        PTX_HIP(ctx, db->d_vis_pos.alloc((uint64_t)NG * 64)); PTX_HIP(ctx, db->d_vis_head.alloc(NG)); PTX_HIP(ctx, db->d_vis_nbase.alloc(NG)); PTX_HIP(ctx, db->d_vis_sp.alloc(NG));
         PTX_HIP(ctx, vslot.alloc(db->V));
         PTX_HIP(ctx, hipMemsetAsync(db->d_vis_pos.p, 0xFF, (uint64_t)NG * 64 * sizeof(uint32_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_vis_head.p, 0, (uint64_t)NG * sizeof(uint64_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(db->d_vis_nbase.p, 0, (uint64_t)NG * sizeof(uint32_t), ctx->stream));
+        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_sp.p, 0, (uint64_t)NG * sizeof(uint32_t), ctx->stream));
         PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
         hipLaunchKernelGGL(visit_place_kernel, dim3((NC + 255) / 256), dim3(256), 0, ctx->stream, NC, d_chunks.p, cnt.p, chunk_gbase.p, vslot.p,
-                           reinterpret_cast<unsigned long long *>(db->d_vis_head.p), db->d_vis_nbase.p);
+                           reinterpret_cast<unsigned long long *>(db->d_vis_head.p), db->d_vis_nbase.p, db->d_vis_sp.p);
         hipLaunchKernelGGL(visit_fill_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_trio_slow.p, vslot.p, cnt.p, db->d_vis_pos.p);
         hipLaunchKernelGGL(visit_sort_kernel, dim3((NG + 3) / 4), dim3(256), 0, ctx->stream, NG, db->d_vis_pos.p, db->d_vis_head.p, db->d_path_nodes.p);
     } else PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
@@ -1094,58 +1050,65 @@ int trio_runs_build(Ctx *ctx, Db *db) {
     return 0;
 }
 
+// The index of a db: uniqueness (visit table; node blocks or global buckets for what it does not cover), then the rows.
+//   FAST route (species of the visit table): trio_visit_kernel<ROWS> -> prefix of the groups' counts -> trio_rows_kernel.
+//   PATH route (the other species; the whole db under trio_path=bucket / trio_rows=path): flags + per-node counts -> scan of the counts
+//   (heads) -> trio_lookup_kernel -> trio_canon_kernel.  In a mixed db the path route's rows follow the fast route's.
+// with_keys: the window start of every row is kept as well (d_trio_q): what the exporters build the (species, hap, position) order from.
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     const uint64_t P = db->P, V = db->V;
     db->trio_keys_built = false;
-    const uint32_t H = (uint32_t)db->H;
+    db->trio_perm_valid = false;
+    const uint32_t H = (uint32_t)db->H, S = db->S;
     if (P >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu path steps exceed 32-bit positions", (unsigned long long)P);
     TrioScratch &ts = db->trio_scratch;
-    const uint32_t NT = (uint32_t)db->n_tiles;
     // which uniqueness path: the visit table (default; species with a node of more than 64 visits: by node block), or through
     // global buckets for the whole db (a species of >= 2^27 nodes among those left to the node-block kernel, or forced)
     bool by_block = db->trio_block_ok && (db->trio_visit_ok || db->n_blocks);
     if (ctx->cfg.trio_path == "bucket") by_block = false;
-    // a db the visit table covers whole files its rows from the visit kernel's records (trio_rows_kernel); with a species left to the
-    // node-block kernel -- or PANTAX_TRIO_ROWS=path -- the rows are filed by the pass over the walks (trio_lookup_kernel) as in rounds 1-3
-    // (a MIXED db -- some species on the node-block kernel -- files those species' rows by the pass over their walks, behind the others';
-    // when the row-order export copies are wanted, i.e. off the hot path, a mixed db takes the pass over the walks whole: the db images
-    // expect a species' lookup rows as one block in node order)
-    bool rows_by_visit = by_block && P && db->n_vgroups && (db->n_blocks == 0 || !with_keys);
+    bool rows_by_visit = by_block && P && db->n_vgroups;
     if (ctx->cfg.trio_rows == "path") rows_by_visit = false;
-    const bool mixed = rows_by_visit && db->n_blocks != 0;
-    // One arena, the part that must start at zero first: tile_cnt | uniq bits (one per path position) | first_cnt [| cnt | cursor].
-    // The visit-table / node-block path zero-fills tile_cnt and the bits only: its kernels STORE the count of every node that has
-    // a visit (the others read as zero through `d_node_visited`), the lookup pass counts them back down to zero in place of a cursor
-    // array, and cnt / cursor belong to the bucket path -- zero-filling is what this arena costs (0.4 GB a build at cfg3 when the
-    // flags were bytes and all of it was cleared).
-    const size_t zbits = (P + 31) / 32 + 1, zhead = (NT + 1) + zbits, zwords = zhead + (V + 1) + (by_block ? 0 : 2 * (V + 1));
-    PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
-    ts.tile_cnt.view(ts.zero_arena.p, NT + 1);
-    ts.uniq_q.view(ts.zero_arena.p + (NT + 1), zbits);
-    ts.first_cnt.view(ts.zero_arena.p + zhead, V + 1);
-    if (!by_block) { ts.cnt.view(ts.zero_arena.p + zhead + (V + 1), V + 1); ts.cursor.view(ts.zero_arena.p + zhead + 2 * (V + 1), V + 1); }
-    if (!by_block) PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
+    const bool path_route = P && (!rows_by_visit || db->n_blocks != 0);   // some (or all) rows are filed by the pass over the walks
+    const bool mixed = rows_by_visit && path_route;
+    // first build of a db -- or the first one that files the species in another order (the options trio_rows / trio_path changed between two
+    // builds: tests): sizes, rows per haplotype and the chunk table of the per-haplotype statistics are (re)learnt
+    const bool first_build = !db->trio_sizes_known || db->trio_layout_fast != rows_by_visit;
+    // One arena for what the path route needs cleared: uniq bits (one per path position) | first_cnt [| cnt | cursor].  The visit-table /
+    // node-block kernels STORE the count of every node that has a visit (the others read as zero through `d_node_visited`), the lookup
+    // pass counts them back down to zero in place of a cursor array; cnt / cursor belong to the bucket path.  The fast route clears nothing.
+    const size_t zbits = (P + 31) / 32 + 1;
+    if (path_route) {
+        const size_t zwords = zbits + (V + 1) + (by_block ? 0 : 2 * (V + 1));
+        PTX_HIP(ctx, ts.zero_arena.alloc(zwords));
+        ts.uniq_q.view(ts.zero_arena.p, zbits);
+        ts.first_cnt.view(ts.zero_arena.p + zbits, V + 1);
+        if (!by_block) { ts.cnt.view(ts.zero_arena.p + zbits + (V + 1), V + 1); ts.cursor.view(ts.zero_arena.p + zbits + 2 * (V + 1), V + 1); }
+        if (!by_block) PTX_HIP(ctx, ts.bucket_off.alloc(V + 1));
+        PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block ? zbits : zwords) * sizeof(uint32_t)));
+        if (by_block) PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p + V, 0, sizeof(uint32_t), ctx->stream));   // the closing entry of the count scan
+        PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
+    }
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
-    PTX_HIP(ctx, ts.tile_base.alloc(NT + 1));
     PTX_HIP(ctx, ts.d_tot.alloc(4));
-    PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p + 2, 0, 2 * sizeof(uint32_t), ctx->stream));   // error word of the build kernels, length of the overflow list
+    PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p, 0, 4 * sizeof(uint32_t), ctx->stream));   // {-, rows of the fast route, error word of the build kernels, rows of the path route}
     if (rows_by_visit) {
         PTX_HIP(ctx, ts.vis_uq.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.vis_rec.alloc((uint64_t)db->n_vgroups * VIS_REC));
-        PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.word_rank.alloc(zbits + 1));
+        PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1));
         PTX_HIP(ctx, hipMemsetAsync(ts.vis_uq.p + db->n_vgroups, 0, sizeof(uint64_t), ctx->stream));   // the closing entry of the count scan
     }
-    PTX_TRY(zero_fill(ctx, ts.zero_arena.p, (by_block && P ? zhead : zwords) * sizeof(uint32_t)));
-    if (by_block && P) PTX_HIP(ctx, hipMemsetAsync(ts.first_cnt.p + V, 0, sizeof(uint32_t), ctx->stream));   // the closing entry of the count scan
+    if (first_build) {
+        PTX_HIP(ctx, ts.hap_cnt.alloc(H + 1));
+        PTX_HIP(ctx, hipMemsetAsync(ts.hap_cnt.p, 0, ((size_t)H + 1) * sizeof(uint32_t), ctx->stream));
+    }
     PTX_HIP(ctx, db->d_hap_trio_off.alloc(H + 1));
-    if (!rows_by_visit || mixed) PTX_HIP(ctx, db->d_trio_first.alloc(V + 1));
-    uint32_t tot[3] = {0, 0, 0};
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
-    // PANTAX_TRIO_XCD: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
+    // trio_xcd: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
     const uint32_t trio_xcd = (uint32_t)ctx->cfg.trio_xcd;
+    // ---- uniqueness
     if (P && by_block && db->n_vgroups) {
         KTimer t(ctx, "trio_visit_kernel");
-        // every wave walks U x rounds consecutive groups of 64 visits (PANTAX_TV_U / PANTAX_TV_ROUNDS pick another shape, for
+        // every wave walks U x rounds consecutive groups of 64 visits (tv_u / tv_rounds pick another shape, for
         // measurements): consecutive groups visit consecutive nodes, whose walk entries share cache lines
         const uint32_t U = (uint32_t)ctx->cfg.tv_u, rounds = (uint32_t)std::max(1, ctx->cfg.tv_rounds);
         const uint32_t tv_ablate = ctx->cfg.tv_ablate;   // -DTV_ABLATE builds only
@@ -1154,13 +1117,13 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                                          rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_path_nodes.p, ts.uniq_q.p, ts.first_cnt.p, ts.d_tot.p + 2, tv_ablate,  \
                                          reinterpret_cast<unsigned long long *>(ts.vis_uq.p), ts.vis_rec.p, (trio_xcd & 1u) ? TV_CHUNKS(UU) : 0u)
         if (rows_by_visit) { if (U == 2) TV_LAUNCH(2, true); else if (U == 8) TV_LAUNCH(8, true); else TV_LAUNCH(4, true); }
-        else if (U == 1) TV_LAUNCH(1, false); else if (U == 2) TV_LAUNCH(2, false); else if (U == 8) TV_LAUNCH(8, false); else TV_LAUNCH(4, false);
+        else if (U == 2) TV_LAUNCH(2, false); else if (U == 8) TV_LAUNCH(8, false); else TV_LAUNCH(4, false);
 #undef TV_LAUNCH
 #undef TV_CHUNKS
     }
     if (P && by_block && db->n_blocks) {
         KTimer t(ctx, "trio_block_kernel");
-        // LDS table slots per 64-node block (PANTAX_TB_SLOTS=512|256|128 picks another instantiation, for measurements): fewer
+        // LDS table slots per 64-node block (tb_slots = 512 | 256 | 128 picks another instantiation, for measurements): fewer
         // slots = more blocks resident per CU (the kernel is bound by the latency of each wave's dependent loads), more blocks
         // that need sub-passes
         const int slots = ctx->cfg.tb_slots;
@@ -1169,8 +1132,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (slots == 512) TB_LAUNCH(512); else if (slots == 128) TB_LAUNCH(128); else TB_LAUNCH(256);
 #undef TB_LAUNCH
     }
-    if (P) {
-        if (!by_block) {
+    if (P && !by_block) {
         PTX_HIP(ctx, ts.bucket.alloc(P));
         {
             KTimer t(ctx, "trio_count_kernel");
@@ -1196,122 +1158,116 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
                 hipLaunchKernelGGL(trio_uniq_kernel, dim3(grid_for(n_win, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, n_win, ts.bucket.p,
                                    ts.bucket_off.p, ts.uniq_q.p, ts.first_cnt.p);
         }
+    }
+    // ---- sizes: the first row of every group (fast route) and of every node (path route); on a db's first build the totals come back
+    if (rows_by_visit) {
+        if (ctx->cfg.flag_rank_chained)
+            PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
+                                      (uint64_t)db->n_vgroups + 1, ts.d_tot.p + 1, "scan_chained_kernel<GroupCount>"));
+        else {
+            KTimer t(ctx, "group_tile_prefix_kernel");
+            const uint64_t ng1 = (uint64_t)db->n_vgroups + 1;
+            const uint32_t n_tiles = (uint32_t)((ng1 + FR_TILE - 1) / FR_TILE);
+            PTX_HIP(ctx, ts.group_sums.alloc(n_tiles + 1));
+            const unsigned long long *uq = reinterpret_cast<const unsigned long long *>(ts.vis_uq.p);
+            hipLaunchKernelGGL(group_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, ts.group_sums.p);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.group_sums.p, n_tiles, ts.d_tot.p + 1);
+            hipLaunchKernelGGL(group_tile_prefix_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, (const uint32_t *)ts.group_sums.p, ts.gprefix.p);
         }
-        if (rows_by_visit) {
-            // rows in (species, hap, position) order = ranks of the flag bits: prefix of every flag word (total = U); slots in visit order =
-            // prefix of the groups' counts
-            const bool chained_ranks = ctx->cfg.flag_rank_chained;   // measurements: the chained scan
-            if (chained_ranks)
-                PTX_TRY(exclusive_scan_fn(ctx, FlagWordLoad{ts.uniq_q.p}, FlagRankStore{ts.word_rank.p, ts.uniq_q.p}, zbits, ts.d_tot.p + 1, "scan_chained_kernel<FlagWord>"));
-            else {
-                KTimer t(ctx, "flag_tile_rank_kernel");
-                const uint32_t n_tiles = (uint32_t)((zbits + FR_TILE - 1) / FR_TILE);
-                PTX_HIP(ctx, ts.flag_sums.alloc(n_tiles + 1));
-                hipLaunchKernelGGL(flag_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const uint32_t *)ts.uniq_q.p, zbits, ts.flag_sums.p);
-                hipLaunchKernelGGL(flag_tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.flag_sums.p, n_tiles, ts.d_tot.p + 1);
-                hipLaunchKernelGGL(flag_tile_rank_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const uint32_t *)ts.uniq_q.p, zbits, (const uint32_t *)ts.flag_sums.p, ts.word_rank.p);
-            }
-            if (chained_ranks)
-                PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
-                                          (uint64_t)db->n_vgroups + 1, nullptr, "scan_chained_kernel<GroupCount>"));
-            else {
-                KTimer t(ctx, "group_tile_prefix_kernel");
-                const uint64_t ng1 = (uint64_t)db->n_vgroups + 1;
-                const uint32_t n_tiles = (uint32_t)((ng1 + FR_TILE - 1) / FR_TILE);
-                PTX_HIP(ctx, ts.group_sums.alloc(n_tiles + 1));
-                const unsigned long long *uq = reinterpret_cast<const unsigned long long *>(ts.vis_uq.p);
-                hipLaunchKernelGGL(group_tile_sum_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, ts.group_sums.p);
-                hipLaunchKernelGGL(flag_tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ts.group_sums.p, n_tiles, (uint32_t *)nullptr);
-                hipLaunchKernelGGL(group_tile_prefix_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, uq, ng1, (const uint32_t *)ts.group_sums.p, ts.gprefix.p);
-            }
-            if (!db->trio_sizes_known) {
-                PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
-                PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u visit groups out of order", tot[2]);
-                db->U_known = tot[1];
-            }
-            const uint32_t Utot = (uint32_t)db->U_known;
-            db->U = Utot;
-            PTX_HIP(ctx, db->d_trio_ent.alloc(Utot));
-            PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
-            {
-                KTimer t(ctx, "trio_rows_kernel");
-                const uint32_t NG = db->n_vgroups;
-#define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_pos.p, db->d_path_nodes.p, \
-                  ts.word_rank.p, db->d_node_len.p, H, db->d_path_off.p, db->d_hap_species.p, db->d_hap_off.p, db->d_node_rec.p, db->d_trio_ent.p, \
-                  db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, ts.d_tot.p + 2, (trio_xcd & 2u) ? rchunks : 0u
-                // a wave takes PANTAX_ROWS_U = 1, 2 or 4 batches of eight groups at once.  Two halve what the kernel waits for memory (8.5 -> 6.0-6.6 ms
-                // inside the step) -- and the step gets SLOWER (32.3-32.6 -> 33.6-34.3 ms at cfg4): the current step's local sorts, which run beside
-                // it on the main stream, stretch from 1.1 to 3.8 ms.  Hence one.
-                uint32_t RU = (uint32_t)ctx->cfg.rows_u;
-                if (RU != 2 && RU != 4) RU = 1;
-                const uint32_t rchunks = (NG + 32 * RU - 1) / (32 * RU);
-                const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);
-#define ROWS_LAUNCH(KK, UU) hipLaunchKernelGGL((trio_rows_kernel<KK, UU>), rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS)
-                if (with_keys) { if (RU == 2) ROWS_LAUNCH(true, 2); else if (RU == 4) ROWS_LAUNCH(true, 4); else ROWS_LAUNCH(true, 1); }
-                else { if (RU == 2) ROWS_LAUNCH(false, 2); else if (RU == 4) ROWS_LAUNCH(false, 4); else ROWS_LAUNCH(false, 1); }
+    }
+    if (path_route) {
+        if (mixed)   // the species of the node-block kernel: heads behind the visit table's rows
+            PTX_TRY(exclusive_scan_fn(ctx, SlowFirstLoad{ts.first_cnt.p, db->d_node_visited.p, db->d_trio_slow.p, db->d_emit_tile_sp.p, db->d_node_base.p, V},
+                                      SlowFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 1, ts.d_tot.p + 2}, V, ts.d_tot.p + 3,
+                                      "scan_chained_kernel<SlowFirst>"));
+        else
+            PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, by_block ? db->d_node_visited.p : nullptr},
+                                      TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, ts.d_tot.p + 3, "scan_chained_kernel<TrioFirst>"));
+    }
+    uint32_t tot[4] = {0, 0, 0, 0};
+    if (first_build) {   // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the first build
+        PTX_TRY(download(ctx, tot, ts.d_tot.p, 4));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        db->U_known = (uint64_t)tot[1] + tot[3];
+        if (db->U_known >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %llu unique trios exceed 32-bit rows", (unsigned long long)db->U_known);
+    }
+    const uint32_t Utot = (uint32_t)db->U_known;
+    db->U = Utot;
+    PTX_HIP(ctx, db->d_trio_ent.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot));
+    if (with_keys) PTX_HIP(ctx, db->d_trio_q.alloc(Utot));
+    if (path_route) PTX_HIP(ctx, ts.row_q.alloc(Utot));
+    const RowOut ro{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, db->d_trio_hap.p, db->d_trio_q.p, ts.hap_cnt.p};
+    // ---- the rows
+    if (rows_by_visit) {
+        KTimer t(ctx, "trio_rows_kernel");
+        const uint32_t NG = db->n_vgroups;
+        // a wave takes rows_u = 1, 2 or 4 batches of eight groups at once.  Two halve what the kernel waits for memory -- and the step got SLOWER
+        // in round 4 (the current step's local sorts, which run beside it on the main stream, stretched from 1.1 to 3.8 ms).  Hence one.
+        uint32_t RU = (uint32_t)ctx->cfg.rows_u;
+        if (RU != 2 && RU != 4) RU = 1;
+        const uint32_t rchunks = (NG + 32 * RU - 1) / (32 * RU);
+        const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);
+#define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_sp.p, db->d_vis_pos.p, \
+                  db->d_path_nodes.p, db->d_node_rec.p, ro, ts.d_tot.p + 2, (trio_xcd & 2u) ? rchunks : 0u
+#define ROWS_LAUNCH(KK, FF, UU) hipLaunchKernelGGL((trio_rows_kernel<KK, FF, UU>), rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS)
+#define ROWS_PICK(KK, FF) { if (RU == 2) ROWS_LAUNCH(KK, FF, 2); else if (RU == 4) ROWS_LAUNCH(KK, FF, 4); else ROWS_LAUNCH(KK, FF, 1); }
+        if (with_keys) { if (first_build) ROWS_PICK(true, true) else ROWS_PICK(true, false) }
+        else { if (first_build) ROWS_PICK(false, true) else ROWS_PICK(false, false) }
+#undef ROWS_PICK
 #undef ROWS_LAUNCH
 #undef ROWS_ARGS
-                hipLaunchKernelGGL(trio_hapoff_rank_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_path_off.p, ts.word_rank.p,
-                                   db->d_hap_trio_off.p);
-            }
-            if (mixed) {   // the species of the node-block kernel: heads behind the visit table's rows, rows by the pass over their walks
-                PTX_TRY(exclusive_scan_fn(ctx, SlowFirstLoad{ts.first_cnt.p, db->d_node_visited.p, db->d_trio_slow.p, db->d_emit_tile_sp.p, db->d_node_base.p, V},
-                                          SlowFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.gprefix.p + db->n_vgroups, ts.d_tot.p + 2}, V, nullptr,
-                                          "scan_chained_kernel<SlowFirst>"));
-                KTimer t(ctx, "trio_lookup_kernel");
-                hipLaunchKernelGGL(trio_lookup_kernel<false>, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p, ts.uniq_q.p,
-                                   (const uint32_t *)nullptr, db->d_trio_first.p, ts.first_cnt.p, db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p,
-                                   db->d_trio_slow.p, ts.word_rank.p);
-            }
-            db->trio_first_valid = false;   // the plain CSR offsets (db images) are derived on request: trio_first_ensure
-        } else {
-        hipLaunchKernelGGL(trio_tilecount_kernel, dim3((NT + 3) / 4), dim3(256), 0, ctx->stream, NT, db->d_tiles.p, db->d_path_off.p, db->d_tile_rank.p,
-                           ts.uniq_q.p, ts.tile_cnt.p);
-        PTX_TRY(exclusive_scan_u32(ctx, ts.tile_cnt.p, ts.tile_base.p, (uint64_t)NT + 1, ts.scan_tmp.p, ts.d_tot.p + 1));   // entry NT is never written: stays 0
-        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, by_block ? db->d_node_visited.p : nullptr},
-                                  TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr, "scan_chained_kernel<TrioFirst>"));
-        // U is a function of the graphs alone: a rebuild (pantax_hip_db_reset) reuses the size learnt by the
-        // first build and needs no host round trip here
-        if (!db->trio_sizes_known) {
-            PTX_TRY(download(ctx, tot, ts.d_tot.p, 3));
-            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (tot[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u node blocks could not be resolved in LDS (PANTAX_TRIO_PATH=bucket), nodes with 2^24 unique-trio rows, or visit groups out of order", tot[2]);
-            db->U_known = tot[1];
-        }
-        const uint32_t Utot = (uint32_t)db->U_known;
-        db->U = Utot;
-        PTX_HIP(ctx, db->d_trio_ent.alloc(Utot));
-        PTX_HIP(ctx, db->d_trio_abc.alloc(3ull * Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
+    }
+    if (path_route) {
         {
             KTimer t(ctx, "trio_lookup_kernel");
-#define LOOKUP_ARGS TRIO_GRAPH, db->d_tile_rank.p, db->d_hap_off.p, db->d_node_len.p, ts.uniq_q.p, ts.tile_base.p, db->d_trio_first.p, ts.first_cnt.p, \
-                    db->d_trio_ent.p, db->d_trio_abc.p, db->d_trio_hap.p, db->d_trio_len.p, (const uint32_t *)nullptr, (const uint2 *)nullptr
-            if (with_keys) hipLaunchKernelGGL(trio_lookup_kernel<true>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
-            else hipLaunchKernelGGL(trio_lookup_kernel<false>, tgrid, dim3(256), 0, ctx->stream, LOOKUP_ARGS);
-#undef LOOKUP_ARGS
-            hipLaunchKernelGGL(trio_hapoff_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, ctx->stream, H, db->d_hap_tile_off.p, ts.tile_base.p,
-                               db->d_hap_trio_off.p);
+            hipLaunchKernelGGL(trio_lookup_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, (const uint32_t *)ts.uniq_q.p, (const uint32_t *)db->d_trio_first.p,
+                               ts.first_cnt.p, db->d_trio_ent.p, ts.row_q.p, mixed ? (const uint32_t *)db->d_trio_slow.p : (const uint32_t *)nullptr);
         }
-        db->trio_first_valid = true;
-        }
-    } else {
-        db->U = 0;
-        PTX_HIP(ctx, hipMemsetAsync(db->d_hap_trio_off.p, 0, (H + 1) * sizeof(uint64_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_trio_first.p, 0, (V + 1) * sizeof(uint32_t), ctx->stream));
-        // no walks at all: every lookup head is empty (first_cnt sits in the zeroed arena)
-        PTX_TRY(exclusive_scan_fn(ctx, TrioFirstLoad{ts.first_cnt.p, nullptr}, TrioFirstStore{db->d_trio_first.p, db->d_node_rec.p, V, ts.d_tot.p + 2}, V + 1, nullptr,
-                                  "scan_chained_kernel<TrioFirst>"));
-        db->trio_first_valid = true;
+        KTimer t(ctx, "trio_canon_kernel");
+        const dim3 cgrid((uint32_t)((V + 255) / 256));
+#define CANON_LAUNCH(KK, FF) hipLaunchKernelGGL((trio_canon_kernel<KK, FF>), cgrid, dim3(256), 0, ctx->stream, V, S, (const uint32_t *)db->d_node_base.p,               \
+                                                (const uint4 *)db->d_node_rec.p, (const uint32_t *)db->d_trio_first.p, by_block ? (const uint32_t *)db->d_node_visited.p \
+                                                : (const uint32_t *)nullptr, mixed ? (const uint32_t *)db->d_trio_slow.p : (const uint32_t *)nullptr, ts.row_q.p, ro)
+        if (with_keys) { if (first_build) CANON_LAUNCH(true, true); else CANON_LAUNCH(true, false); }
+        else { if (first_build) CANON_LAUNCH(false, true); else CANON_LAUNCH(false, false); }
+#undef CANON_LAUNCH
     }
 #undef TRIO_GRAPH
     PTX_HIP(ctx, hipGetLastError());
-    if (!db->trio_sizes_known) {
-        db->h_hap_trio_off.resize(H + 1);
-        PTX_TRY(download(ctx, db->h_hap_trio_off.data(), db->d_hap_trio_off.p, H + 1));
+    if (first_build) {
+        // rows per haplotype -> hap_trio_off (the counts the first filter reads; the offsets of the export order), rows per species -> the
+        // chunk table of the per-haplotype statistics; the error word of the build kernels is read HERE, behind all of them
+        std::vector<uint32_t> hc(H + 1, 0);
+        uint32_t err = 0;
+        PTX_TRY(download(ctx, hc.data(), ts.hap_cnt.p, H));
+        PTX_TRY(download(ctx, &err, ts.d_tot.p + 2, 1));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (!P) db->U_known = 0;
+        if (err) return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u problems in the build kernels: a node that heads 2^16 or more unique-trio rows, node blocks that could not be "
+                                                      "resolved in LDS (trio_path=bucket), or visit groups out of order", err);
+        db->h_hap_trio_off.assign(H + 1, 0);
+        for (uint32_t h = 0; h < H; ++h) db->h_hap_trio_off[h + 1] = db->h_hap_trio_off[h] + hc[h];
+        if (db->h_hap_trio_off[H] != db->U_known)
+            return fail(ctx, PANTAX_HIP_E_STATE, "trio_index: %llu rows were filed but %llu counted", (unsigned long long)db->h_hap_trio_off[H], (unsigned long long)db->U_known);
+        PTX_TRY(upload(ctx, db->d_hap_trio_off, db->h_hap_trio_off.data(), H + 1));
+        // filing order of the species: those of the fast route first (in species order), then those of the path route
+        db->h_sp_row_order.clear();
+        for (int pass = 0; pass < 2; ++pass)
+            for (uint32_t s = 0; s < S; ++s) {
+                const bool fast = rows_by_visit && !db->h_trio_slow[s];
+                if (fast == (pass == 0)) db->h_sp_row_order.push_back(s);
+            }
+        {
+            uint64_t at = 0;
+            std::vector<uint64_t> first(S, 0), cnt(S, 0);
+            for (uint32_t s : db->h_sp_row_order) {
+                cnt[s] = db->h_hap_trio_off[db->h_hap_off[s + 1]] - db->h_hap_trio_off[db->h_hap_off[s]];
+                first[s] = at; at += cnt[s];
+            }
+            PTX_TRY(hap_stats_layout(ctx, db, first.data(), cnt.data()));
+        }
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         db->trio_sizes_known = true;
+        db->trio_layout_fast = rows_by_visit;
     }
     db->trio_built = true;
     db->trio_keys_built = with_keys;
@@ -1319,21 +1275,46 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     return 0;
 }
 
-// d_trio_first (plain CSR offsets over the middle node) is wanted -- the db images store it: a scan of the heads' row counts
-int trio_first_ensure(Ctx *ctx, Db *db) {
-    if (db->trio_first_valid) return 0;
-    PTX_HIP(ctx, db->d_trio_first.alloc(db->V + 1));
-    PTX_TRY(exclusive_scan_fn(ctx, HeadCountLoad{db->d_node_rec.p, db->V}, PrefixStore{db->d_trio_first.p}, db->V + 1, nullptr, "scan_chained_kernel<HeadCount>"));
-    db->trio_first_valid = true;
-    return 0;
-}
-
-// the row-order export arrays (d_trio_abc, d_trio_hap) are wanted: rebuild with them unless they are there
+// the window start of every row is wanted (the exporters): rebuild with it unless it is there
 int trio_keys_ensure(Ctx *ctx, Db *db) {
     if (db->trio_built && db->trio_keys_built) return 0;
     if (db->step_inflight) return fail(ctx, PANTAX_HIP_E_STATE, "trio tables: %d enqueued step(s) of this db have not been collected", db->step_inflight);
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a step's rebuild on the side stream is over before the tables are replaced
     return trio_index_build(ctx, db, true);
+}
+
+// d_trio_perm[e] = the row of the e-th window in (species, hap, position) order: the rows sorted by their window start (the walks of all
+// haplotypes are one CSR in that order).  Off the step's path: only pantax_hip_trio_get and the trio_bases of pantax_hip_node_coverage ask.
+int trio_export_ensure(Ctx *ctx, Db *db) {
+    PTX_TRY(trio_keys_ensure(ctx, db));
+    if (db->trio_perm_valid) return 0;
+    const uint64_t U = db->U;
+    PTX_HIP(ctx, db->d_trio_perm.alloc(U ? U : 1));
+    if (U) {
+        DevBuf<uint64_t> ka, kb;
+        DevBuf<uint32_t> vb, table, tmp;
+        PTX_HIP(ctx, ka.alloc(U)); PTX_HIP(ctx, kb.alloc(U)); PTX_HIP(ctx, vb.alloc(U)); PTX_HIP(ctx, table.alloc(sort_table_elems(U))); PTX_HIP(ctx, tmp.alloc(16));
+        hipLaunchKernelGGL(trio_iota_kernel, dim3((uint32_t)((U + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)U, db->d_trio_perm.p, (const uint32_t *)db->d_trio_q.p,
+                           reinterpret_cast<unsigned long long *>(ka.p));
+        SortBufs A, B;
+        A.nw = B.nw = 1; A.k[0] = ka.p; B.k[0] = kb.p; A.v = db->d_trio_perm.p; B.v = vb.p;
+        std::vector<SortPass> passes;
+        add_passes(passes, 0, 0, bits_for(db->P ? db->P : 1));
+        bool in_b = false;
+        PTX_TRY(radix_sort(ctx, A, B, U, passes.data(), (int)passes.size(), table.p, tmp.p, &in_b, nullptr));
+        if (in_b) PTX_HIP(ctx, hipMemcpyAsync(db->d_trio_perm.p, vb.p, U * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the sort's buffers go out of scope
+    }
+    db->trio_perm_valid = true;
+    return 0;
+}
+
+// rows in export order: out[e] = src[row of e] (trio_bases of pantax_hip_node_coverage)
+int trio_export_u64(Ctx *ctx, Db *db, const unsigned long long *d_src, unsigned long long *d_dst) {
+    PTX_TRY(trio_export_ensure(ctx, db));
+    if (db->U) hipLaunchKernelGGL(gather_u64_kernel, dim3((uint32_t)((db->U + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)db->U, (const uint32_t *)db->d_trio_perm.p, d_src, d_dst);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 }  // namespace ptx
@@ -1349,22 +1330,34 @@ int pantax_hip_trio_index(pantax_hip_ctx *ctx, pantax_hip_db *db, uint64_t *n_un
     return 0;
 }
 
-int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *db, uint32_t *abc_out, uint32_t *hap_out, int64_t *len_out,
+int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *cdb, uint32_t *abc_out, uint32_t *hap_out, int64_t *len_out,
                         uint64_t *hap_trio_off_out) {
-    if (!ctx || !db) return PANTAX_HIP_E_INVALID;
+    if (!ctx || !cdb) return PANTAX_HIP_E_INVALID;
+    pantax_hip_db *db = const_cast<pantax_hip_db *>(cdb);
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "trio_get: call pantax_hip_trio_index first");
     PTX_ENTER(ctx);
-    if ((abc_out || hap_out) && !db->trio_keys_built) {   // the last build was a step's (no export copies): same tables, with them
+    const uint64_t U = db->U;
+    if ((abc_out || hap_out || len_out) && U) {
+        // the table in (species, hap, position) order is an export: the rows are permuted on the device (the last build may have been a
+        // step's, without the window starts: the same index is built again with them -- coverage results stay valid, a row keeps its number)
         const bool cov_done = db->cov_done;
-        PTX_TRY(trio_keys_ensure(ctx, const_cast<pantax_hip_db *>(db)));
-        const_cast<pantax_hip_db *>(db)->cov_done = cov_done;   // the rebuilt index is the same index: coverage results stay valid
+        PTX_TRY(trio_export_ensure(ctx, db));
+        db->cov_done = cov_done;
+        DevBuf<uint32_t> d_abc, d_hap, d_len;
+        if (abc_out) PTX_HIP(ctx, d_abc.alloc(3 * U));
+        if (hap_out) PTX_HIP(ctx, d_hap.alloc(U));
+        if (len_out) PTX_HIP(ctx, d_len.alloc(U));
+        hipLaunchKernelGGL(trio_export_kernel, dim3((uint32_t)((U + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)U, (const uint32_t *)db->d_trio_perm.p,
+                           (const uint32_t *)db->d_trio_q.p, (const uint32_t *)db->d_path_nodes.p, (const uint16_t *)db->d_trio_hap.p, (const uint32_t *)db->d_trio_len.p,
+                           abc_out ? d_abc.p : (uint32_t *)nullptr, hap_out ? d_hap.p : (uint32_t *)nullptr, len_out ? d_len.p : (uint32_t *)nullptr);
+        PTX_HIP(ctx, hipGetLastError());
+        std::vector<uint32_t> len32;
+        if (abc_out) PTX_TRY(download(ctx, abc_out, d_abc.p, 3 * U));
+        if (hap_out) PTX_TRY(download(ctx, hap_out, d_hap.p, U));
+        if (len_out) { len32.resize(U); PTX_TRY(download(ctx, len32.data(), d_len.p, U)); }
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (len_out) for (uint64_t u = 0; u < U; ++u) len_out[u] = len32[u];
     }
-    std::vector<uint32_t> len32;
-    if (abc_out && db->U) PTX_TRY(download(ctx, abc_out, db->d_trio_abc.p, 3 * db->U));
-    if (hap_out && db->U) PTX_TRY(download(ctx, hap_out, db->d_trio_hap.p, db->U));
-    if (len_out && db->U) { len32.resize(db->U); PTX_TRY(download(ctx, len32.data(), db->d_trio_len.p, db->U)); }
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (len_out) for (uint64_t u = 0; u < db->U; ++u) len_out[u] = len32[u];
     if (hap_trio_off_out) for (uint64_t h = 0; h <= db->H; ++h) hap_trio_off_out[h] = db->h_hap_trio_off[h];
     return 0;
 }

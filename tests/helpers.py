@@ -426,7 +426,13 @@ def oracle_tables_parallel(sset, threads=8, fr=0.3, fc=0.46, sr=0.85, sd=0.2, mi
     sel = [s for s in range(S) if keep[s] and abundance[s] > min_ab]
     level = oracle_strain_level(sset, sp, keep, absolute, sel, threads=threads, fr=fr, fc=fc, sr=sr)
     passing = oracle_passing_rows(sset, level, sd=sd, min_cov=min_cov)
-    rows = [(g.name, hap, m) for s in sel for g in [sset.species[s]] for hap, m in passing[g.name].items()]
+    # rows enter the final sort in species-table order (load_species_range walks species_abundance.txt, profile.rs:553-656), haplotypes in
+    # BTreeMap order; the sort by abundance is stable here and in the library (equal LAD solutions -- ratios of small integers -- do tie;
+    # polars leaves the order of ties open)
+    idx_of = {g.name: i for i, g in enumerate(sset.species)}
+    in_sel = set(sel)
+    rows = [(name, hap, passing[name][hap]) for name, _, _ in species_rows if idx_of[name] in in_sel
+            for hap in sset.species[idx_of[name]].hap_names if hap in passing[name]]
     tot = sum(r[2]["predicted_coverage"] for r in rows)
     out = [(sp_, hap, m["predicted_coverage"], m["predicted_coverage"] / tot, m) for sp_, hap, m in rows]
     out.sort(key=lambda r: -r[3])

@@ -740,11 +740,11 @@ def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,R,L,pf", [(31, 5, 10, 90000, 30000, 0.4), (32, 3, 30, 90000, 20000, 0.6)])
-def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, set_opt):
-    """a9's per-haplotype statistics of the unique-trio abundances (count of non-zero ones, z-score-filtered mean, profile.rs:1028-1147):
-    the three-pass kernel with 32 workgroups per haplotype and the one-launch kernel with a workgroup per haplotype (databases of
-    thousands of haplotypes) sum in different fixed orders -- the metrics they lead to agree to rounding, the decisions exactly --
-    and both agree with the oracle."""
+def test_hap_trio_statistics_by_key_whatever_the_row_order(eng, seed, S, H, R, L, pf, set_opt):
+    """a9's per-haplotype statistics of the unique-trio abundances (count of non-zero ones, z-score-filtered mean, profile.rs:1028-1147) are
+    taken BY KEY over rows numbered in filing order (round 5).  The two routes that file rows -- from the visit kernel's records, and by the
+    pass over the walks (option trio_rows=path) -- number them differently, so the sums run in different fixed orders: the metrics agree to
+    rounding, the decisions exactly; the same route twice gives the same bits (every sum has a fixed order)."""
     from oracle import oracle as orc
     from pantax_amd import synth
     from pantax_amd.engine import metrics_to_dicts
@@ -754,13 +754,15 @@ def test_hap_trio_statistics_kernels_agree(eng, seed, S, H, R, L, pf, set_opt):
     eng.upload_packed(rd)
     sp, rc, bs, lm, uq = eng.rcls_profile()
     keep, absolute, abundance = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
-    eng.trio_nodes_info(fetch=False)
-    eng.get_node_abundances(fetch=False)
     outs = []
-    for mode in ("chunks", "fused"):
-        set_opt(eng, "hap_stats", mode)
+    for mode in (None, "path", None):
+        set_opt(eng, "trio_rows", mode)
+        eng.db_reset()
+        eng.trio_nodes_info(fetch=False)
+        eng.get_node_abundances(fetch=False)
         met, info = eng.strain_profiling(absolute, species_active=keep)
         outs.append((metrics_to_dicts(met, eng.H), [(i.n_candidates, i.status1, i.status2, i.n_rows, i.n_patterns) for i in info]))
+    assert outs[0] == outs[2]
     assert outs[0][1] == outs[1][1]
     for a, b in zip(outs[0][0], outs[1][0]):
         for k in a:
