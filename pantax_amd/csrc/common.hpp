@@ -357,7 +357,8 @@ struct Db {
     DevBuf<uint4> d_stat_chunks;     // {species, first row, end row, first partial} per chunk of rows
     uint32_t n_stat_chunks = 0;
     uint64_t n_stat_partials = 0;    // sum over chunks of the haplotypes of their species
-    uint32_t stat_lds_haps = 0;      // most haplotypes of a species whose chunk accumulators live in LDS
+    uint32_t stat_lds_haps = 0;      // most haplotypes of a species whose chunk accumulators live in LDS (65 .. 1024; up to 64: lane registers)
+    bool stat_global_rows = false;   // a species of more than 1024 haplotypes accumulates in its chunks' own (zero-filled) rows of partials
     DevBuf<uint32_t> d_sp_chunk_off; // [S+1] first chunk of every species (species without rows: empty range)
     // coverage state (a8), resident for the strain step
     bool cov_done = false;

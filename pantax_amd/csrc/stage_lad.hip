@@ -191,26 +191,38 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
     const uint4 ch = chunks[blockIdx.x];                       // {species, first row, end row, first partial}
     const uint32_t h0 = (uint32_t)hap_off[ch.x], Hs = (uint32_t)hap_off[ch.x + 1] - h0;
     const int lane = threadIdx.x;
-    const bool in_lds = Hs <= HS_LDS_HAPS;
-    HapAcc *acc = in_lds ? s_hap_acc : part + ch.w;            // (the partials were zero-filled before the pass)
+    // Up to 64 haplotypes per species (every species of the BASELINE configurations): LANE h keeps the accumulators of haplotype h in
+    // registers -- the sum of an owner's lanes is wave-uniform after the DPP reduction, the owner's lane adds it; no LDS, no memory between two
+    // batches of rows.  The first version kept the accumulators in LDS and lane 0 did a read-modify-write per owner and batch: 6.1 ms for the
+    // three passes at 1e4 strains against 0.85 for round 4's kernel over contiguous rows.  Mean and sd of pass 0 / 1 ride in lane h too and
+    // reach a row's lane by one bpermute.
+    const bool in_reg = Hs <= 64u;
+    const bool in_lds = !in_reg && Hs <= HS_LDS_HAPS;
+    HapAcc *acc = in_lds ? s_hap_acc : part + ch.w;            // (more than 64 haplotypes: LDS; beyond HS_LDS_HAPS the chunk's own, zero-filled row of partials)
     if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) acc[h] = HapAcc{0.0, 0u, 0u};
     __syncthreads();
+    double r_a = 0.0, my_mean = 0.0, my_sd = 0.0;
+    uint32_t r_c = 0, r_n = 0;
+    if (in_reg && PASS >= 1 && (uint32_t)lane < Hs) { my_mean = mean0[h0 + lane]; if (PASS == 2) my_sd = sd[h0 + lane]; }
     for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
         const uint32_t row = r0 + (uint32_t)lane;
         const bool valid = row < ch.z;
         uint32_t h = 0xFFFFFFFFu;
-        double val = 0.0;
-        bool flag = false;
+        double x = 0.0;
         if (valid) {
             h = row_hap[row];
-            const double x = (double)(long long)tb[row] / (double)tlen[row];   // profile.rs:1013-1014
-            if (x > 0.0) {                                                      // :1129-1133
-                if (PASS == 0) { val = x; flag = true; }
-                else {
-                    const double m = mean0[h0 + h];
-                    if (PASS == 1) { val = (x - m) * (x - m); flag = true; }
-                    else { const double s_ = sd[h0 + h]; if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; } }   // :1043-1050
-                }
+            x = (double)(long long)tb[row] / (double)tlen[row];                // profile.rs:1013-1014
+        }
+        double val = 0.0;
+        bool flag = false;
+        if (PASS == 0) { if (x > 0.0) { val = x; flag = true; } }                 // :1129-1133
+        else {
+            double m, s_ = 0.0;
+            if (in_reg) { m = __shfl(my_mean, (int)(h & 63u)); if (PASS == 2) s_ = __shfl(my_sd, (int)(h & 63u)); }
+            else { m = valid ? mean0[h0 + h] : 0.0; if (PASS == 2) s_ = valid ? sd[h0 + h] : 0.0; }
+            if (x > 0.0) {
+                if (PASS == 1) { val = (x - m) * (x - m); flag = true; }
+                else if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; }   // :1043-1050
             }
         }
         unsigned long long todo = __ballot(valid);
@@ -218,14 +230,16 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(todo));
             const bool mine = valid && h == hh;
             const unsigned long long sel = __ballot(mine);
-            const double v = wave_reduce(mine ? val : 0.0, [](double x, double y) { return x + y; });
+            const double v = wave_reduce(mine ? val : 0.0, [](double a_, double b_) { return a_ + b_; });
             const uint32_t c = (uint32_t)__popcll(__ballot(mine && flag));
-            if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
+            if (in_reg) { if ((uint32_t)lane == hh) { r_a += v; r_c += c; r_n += (uint32_t)__popcll(sel); } }
+            else if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
             todo &= ~sel;
         }
     }
     __syncthreads();
-    if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
+    if (in_reg) { if ((uint32_t)lane < Hs) part[ch.w + lane] = HapAcc{r_a, r_c, r_n}; }
+    else if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
 }
 // one wave per species: the chunks' partials added in chunk order
 template <int PASS>
@@ -251,10 +265,12 @@ int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint6
     std::vector<uint32_t> sp_off(S + 1, 0);
     uint64_t n_part = 0;
     uint32_t lds_haps = 1;
+    bool global_rows = false;
     for (uint32_t s = 0; s < S; ++s) {
         sp_off[s] = (uint32_t)chunks.size();
         const uint64_t Hs = db->h_hap_off[s + 1] - db->h_hap_off[s];
-        if (Hs <= HS_LDS_HAPS) lds_haps = std::max<uint32_t>(lds_haps, (uint32_t)Hs);
+        if (Hs > 64 && Hs <= HS_LDS_HAPS) lds_haps = std::max<uint32_t>(lds_haps, (uint32_t)Hs);
+        if (Hs > HS_LDS_HAPS && sp_rows[s]) global_rows = true;
         // a chunk holds at least eight rows per haplotype of its species: the partials stay an eighth of the rows at most
         const uint64_t per = std::max<uint64_t>(HS_CHUNK_ROWS, ((8 * Hs + 63) / 64) * 64);
         for (uint64_t r = 0; r < sp_rows[s]; r += per) {
@@ -267,6 +283,7 @@ int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint6
     db->n_stat_chunks = (uint32_t)chunks.size();
     db->n_stat_partials = n_part;
     db->stat_lds_haps = lds_haps;
+    db->stat_global_rows = global_rows;
     if (chunks.empty()) chunks.push_back(make_uint4(0u, 0u, 0u, 0u));
     PTX_TRY(upload(ctx, db->d_stat_chunks, chunks.data(), chunks.size()));
     PTX_TRY(upload(ctx, db->d_sp_chunk_off, sp_off.data(), sp_off.size()));
@@ -287,7 +304,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     const size_t lds = (size_t)db->stat_lds_haps * sizeof(HapAcc);
     KTimer t(ctx, "hap_rows_pass_kernel");
 #define HS_PASS(PP)                                                                                                                                            \
-    PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                                                        \
+    if (db->stat_global_rows) PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                            \
     if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
                                (const uint16_t *)db->d_trio_hap.p, (const unsigned long long *)db->d_trio_bases.p, (const uint32_t *)db->d_trio_len.p,          \
                                (const double *)mean0, (const double *)sd, part);                                                                               \

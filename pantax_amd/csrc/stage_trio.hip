@@ -836,8 +836,19 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         rec[u] = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
         if (on[u]) rec[u] = vis_rec[(uint64_t)g[u] * VIS_REC + r];
     }
+    // the owner of a window = the haplotype whose walk holds its start.  The eight groups of a batch nearly always belong to ONE species: the
+    // walk offsets of that species' haplotypes (up to 64) are loaded once, lane j holds offset j, and every lane counts the offsets at or
+    // below its position by reading them lane after lane -- ALU work beside the record loads instead of a binary search of four dependent
+    // loads behind them (the kernel waits for memory: every level of the chain shows).  Lanes of another species take the search.
+    uint32_t sp0[U], h00[U], hs0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long live = __ballot(g[u] < NG);
+        sp0[u] = (uint32_t)__builtin_amdgcn_readlane((int)sp[u], live ? __builtin_ctzll(live) : 0);
+        h00[u] = (uint32_t)o.hap_off[sp0[u]]; hs0[u] = (uint32_t)o.hap_off[sp0[u] + 1] - h00[u];
+    }
     // ---- level 3: what every record points at
-    uint32_t len3[U], h0[U], h1[U];
+    uint32_t len3[U], woff[U];
     uint4 nrv[U];
     bool first[U];
 #pragma unroll
@@ -845,24 +856,30 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         // first record of its node: the record below belongs to another node (or to another group)
         const uint32_t below = wave_shr1(rec[u].w, 0xFFFFFFFFu);
         first[u] = on[u] && (r == 0u || below != rec[u].w);
-        len3[u] = 0; h0[u] = 0; h1[u] = 0; nrv[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (on[u]) {
-            len3[u] = o.node_len[rec[u].y] + o.node_len[rec[u].w] + o.node_len[rec[u].z];
-            h0[u] = (uint32_t)o.hap_off[sp[u]]; h1[u] = (uint32_t)o.hap_off[sp[u] + 1];
-        }
+        len3[u] = 0; nrv[u] = make_uint4(0u, 0u, 0u, 0u);
+        woff[u] = ((uint32_t)lane < hs0[u] && hs0[u] <= 64u) ? (uint32_t)o.path_off[h00[u] + (uint32_t)lane] : 0xFFFFFFFFu;   // P < 2^32
+        if (on[u]) len3[u] = o.node_len[rec[u].y] + o.node_len[rec[u].w] + o.node_len[rec[u].z];
         if (first[u]) nrv[u] = node_rec[rec[u].w];
     }
     // ---- the rows, the heads
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const unsigned long long fm = __ballot(first[u]), om = __ballot(on[u]);
+        uint32_t hl = 0;                                                     // owner within the species: offsets at or below the position, minus one
+        if (hs0[u] <= 64u) {
+            for (uint32_t j = 1; j < hs0[u]; ++j) hl += (uint32_t)__builtin_amdgcn_readlane((int)woff[u], (int)j) <= rec[u].x ? 1u : 0u;
+        }
         if (on[u]) {
-            const uint32_t h = hap_of_position(o.path_off, h0[u], h1[u], rec[u].x);
+            uint32_t hb = h00[u];
+            if (hs0[u] > 64u || sp[u] != sp0[u]) {                           // a species of more than 64 haplotypes, or not the batch's first species
+                hb = (uint32_t)o.hap_off[sp[u]];
+                hl = hap_of_position(o.path_off, hb, (uint32_t)o.hap_off[sp[u] + 1], rec[u].x) - hb;
+            }
             o.ent[row[u]] = make_uint2(rec[u].y, rec[u].z);
             o.len[row[u]] = len3[u];
-            o.hap[row[u]] = (uint16_t)(h - h0[u]);
+            o.hap[row[u]] = (uint16_t)hl;
             if (KEYS) o.q[row[u]] = rec[u].x;
-            if (FIRST) atomicAdd(&o.hap_cnt[h], 1u);
+            if (FIRST) atomicAdd(&o.hap_cnt[hb + hl], 1u);
         }
         // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
         const uint32_t pbit = on[u] ? nr_pair_bit(rec[u].y, rec[u].z) : 0u;

@@ -444,3 +444,77 @@ def profile_step(eng, species_names, hap_names, avg_len, cfg=None, comm=None, sh
     species_rows, strain_rows, n_active = finalize_stage(local, species_names, hap_names, cfg, comm, shard_max, rows_max)
     stats = dict(local["stats"], n_active=n_active)
     return species_rows, strain_rows, stats
+
+
+# ---------------------------------------------------------------------------------------------- several dbs on ONE GPU
+# A resident db addresses its path steps with 32 bits (include/pantax_hip.h: PANTAX_HIP_E_LIMIT beyond 2^32 - 1 positions).  A database
+# of more path steps than that -- BASELINE configs[4]: 1 000 species x 50 strains = 1.1e10 -- is cut BY SPECIES into several dbs that share
+# the GPU: species are independent from a4 on (profile.rs:3297-3319), so every db is stepped on its own ctx (its own streams: the device
+# interleaves them) with the reads of its species, and the dbs' results meet exactly like those of ranks -- the slabs of finalize_begin,
+# the global normalisers of profile.rs:341, :3198, :3243 in finalize_end -- only without a collective: they are in one process.
+class _SlabComm:
+    rank, world = 0, 1
+
+    def exchange_begin(self, slab):
+        return np.asarray(slab, dtype=np.float64)
+
+
+class _ManyComm:
+    rank = 0
+
+    def __init__(self, species_names_list, hap_names_list):
+        self.world = len(species_names_list)
+        self._names = ([list(x) for x in species_names_list], [list(x) for x in hap_names_list])
+
+    def exchange_end(self, handle):
+        return handle
+
+    def names(self, species_names, hap_names):
+        return self._names
+
+
+def split_species_by_path_steps(path_steps, limit=3_600_000_000):
+    """contiguous groups of species whose path steps sum to at most `limit` (< 2^32 with room for the padded visit table) -> list of
+    (first species, end species)"""
+    groups, a, acc = [], 0, 0
+    for i, p in enumerate(path_steps):
+        p = int(p)
+        if p > limit:
+            raise ValueError("species %d alone has %d path steps" % (i, p))
+        if acc + p > limit:
+            groups.append((a, i))
+            a, acc = i, 0
+        acc += p
+    groups.append((a, len(path_steps)))
+    return groups
+
+
+def finalize_many(locals_, species_names_list, hap_names_list, cfg):
+    """the tables of one sample over K dbs: every db's local stage -> one slab each -> the same finalisation K ranks get"""
+    S_max = max(len(l["keep"]) for l in locals_)
+    R_max = max(max(len(h), 1) for h in hap_names_list)
+    slabs = [finalize_begin(l, h, _SlabComm(), S_max, R_max)[0] for l, h in zip(locals_, hap_names_list)]
+    sr, tr, n_active = finalize_end((np.stack(slabs), S_max), None, None, cfg, _ManyComm(species_names_list, hap_names_list))
+    stats = {k: [x for l in locals_ for x in l["stats"][k]] for k in locals_[0]["stats"]}
+    return sr, tr, dict(stats, n_active=n_active)
+
+
+def profile_steps_many(engs, species_names_list, hap_names_list, avg_len_list, n_steps, cfg=None):
+    """n_steps samples over K dbs that share the GPU, one step enqueued ahead on every db (see profile_steps_pipelined) -> list of
+    (species_rows, strain_rows, stats)"""
+    cfg = cfg or StepConfig()
+    K = len(engs)
+    out = []
+    try:
+        for k in range(K):
+            local_enqueue(engs[k], avg_len_list[k], cfg)
+        for i in range(n_steps):
+            if i + 1 < n_steps:
+                for k in range(K):
+                    local_enqueue(engs[k], avg_len_list[k], cfg)
+            locals_ = [local_stage(engs[k], avg_len_list[k], cfg, "collect") for k in range(K)]
+            out.append(finalize_many(locals_, species_names_list, hap_names_list, cfg))
+    finally:
+        for e in engs:
+            e.drain_steps()
+    return out

@@ -92,3 +92,36 @@ def test_partition_species_is_balanced_and_deterministic():
         load = [sum(x for x, o in zip(w, owner) if o == r) for r in range(world)]
         assert max(load) <= sum(w) / world + max(w)          # the LPT guarantee
     assert partition_species([5.0, 5.0, 1.0], 2) == [0, 1, 0]
+
+
+def test_several_dbs_on_one_gpu_finalize_like_ranks():
+    """A database of more than 2^32 path positions is cut by species into several dbs that share the GPU (pipeline.finalize_many /
+    profile_steps_many; BASELINE configs[4] at full size): their slabs meet like those of ranks -- the tables equal those of ONE db holding
+    every species -- and the species are cut into contiguous groups under the position limit."""
+    from pantax_amd.pipeline import LocalComm, StepConfig, finalize_many, finalize_stage, split_species_by_path_steps
+    from tests.dist_worker import fake_local, names
+    assert split_species_by_path_steps([5, 5, 5, 9, 1, 10], limit=10) == [(0, 2), (2, 3), (3, 5), (5, 6)]
+    assert split_species_by_path_steps([1, 2, 3]) == [(0, 3)]
+    with pytest.raises(ValueError):
+        split_species_by_path_steps([11], limit=10)
+    n_species = [4, 6, 3]
+    loc = [dict(fake_local(r, n), stats=dict(obj=[(0.0, 0.0)] * n)) for r, n in enumerate(n_species)]
+    sn_l, hn_l = zip(*[names(r, n) for r, n in enumerate(n_species)])
+    got_species, got_strain, stats = finalize_many(loc, sn_l, hn_l, StepConfig())
+    sn, hn, rows = [], [], []
+    s_off = h_off = 0
+    for r, n in enumerate(n_species):
+        sn += sn_l[r]
+        hn += hn_l[r]
+        rows += [(s + s_off, h + h_off) + tuple(rest) for (s, h, *rest) in loc[r]["rows"]]
+        s_off += n
+        h_off += 3 * n
+    merged = dict(keep=np.concatenate([l["keep"] for l in loc]), absolute=np.concatenate([l["absolute"] for l in loc]),
+                  s_all=np.concatenate([l["s_all"] for l in loc]), s_pass=np.concatenate([l["s_pass"] for l in loc]), rows=rows)
+    exp_species, exp_strain, _ = finalize_stage(merged, sn, hn, StepConfig(), LocalComm())
+    assert [r[0] for r in got_species] == [r[0] for r in exp_species] and [(r[0], r[1]) for r in got_strain] == [(r[0], r[1]) for r in exp_strain]
+    for g, e in zip(got_species, exp_species):
+        assert g[1] == pytest.approx(e[1], rel=1e-12) and g[2] == pytest.approx(e[2], rel=1e-12)
+    for g, e in zip(got_strain, exp_strain):
+        assert g[2] == pytest.approx(e[2], rel=1e-12) and g[3] == pytest.approx(e[3], rel=1e-12)
+    assert len(stats["obj"]) == sum(n_species)
