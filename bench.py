@@ -52,8 +52,11 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
     # configs[4] (HiFi gut mock, 50k strains, 8 GPUs) per-GPU share: 125 species x 50 strains, long reads N(15000, 3000^2) with the bases of
     # cfg4's share (the long-read kernels: coverage_step_kernel, walk_sum_kernel; 50 candidate columns per species)
     "cfg5_share": ("configs[4] per-GPU share: 125 species / 6250 strains, 125k HiFi-shaped reads", 6, 125, 50, 125_000, 5_000_000),
+    # configs[4] at its size on ONE GPU: 1 000 species x 50 strains = 1.1e10 path steps, more than one resident db addresses -> the species are
+    # cut into several dbs that share the GPU (run_many_dbs)
+    "cfg5": ("configs[4]: 1k species / 50k strains, 1M HiFi-shaped reads", 7, 1000, 50, 1_000_000, 5_000_000),
 }
-LONG_READ_WORKLOADS = ("cfg5_share",)
+LONG_READ_WORKLOADS = ("cfg5_share", "cfg5")
 DEFAULT_WORKLOAD = "cfg4"
 CPU_SAMPLE_READS = 25_000_000    # the CPU baseline runs on the first chunks of a larger workload (a bounded sample, ~10-30 s of all cores)
 GENERATOR = "native-v1"          # tools/native/synth_set.c; part of the workload key of the committed PMC files
@@ -431,7 +434,7 @@ def gaf_tmp_dir(need_bytes):
     return None
 
 
-def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9):
+def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9, sp=None, rc=None):
     """north_star: strain abundances within L1 1e-4 of the solver-backed PAO.  For a sample of species (the one with the most and the
     fewest reads + evenly spaced ones) the CHECKER (oracle/: trio index, coverage, both exact LAD solves, constraint -- whose LP
     optimum equals SciPy-HiGHS on the golden fixtures) runs on the species' reads of THIS workload at full size, and the strain rows of
@@ -444,7 +447,8 @@ def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9):
     t0 = time.perf_counter()
     species_rows, strain_rows, stats = out
     S = len(species)
-    sp, rc, *_ = eng.rcls_profile()
+    if sp is None:
+        sp, rc, *_ = eng.rcls_profile()
     cnt = np.asarray(rc)
     pick = sorted({int(np.argmax(cnt)), int(np.argmin(np.where(cnt > 0, cnt, cnt.max() + 1)))} | {int(i) for i in np.linspace(0, S - 1, max(n_sample - 2, 1)).astype(int)})
     pick = [s for s in pick if any(r[0] == species[s].name for r in species_rows)]      # species the step kept
@@ -579,6 +583,163 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads):
     return res
 
 
+def run_many_dbs(args, spec, local_rank):
+    """A workload of more path steps than one resident db addresses (32-bit positions: BASELINE configs[4] at its size, 1 000 species x 50
+    strains = 1.1e10 path steps) on ONE GPU: the species are cut into contiguous groups under the limit, every group is a db on a ctx of its
+    own with the reads of its species (species are independent from a4 on, profile.rs:3297-3319), the dbs are stepped side by side and their
+    results meet like those of ranks (pipeline.profile_steps_many) -- the global normalisers of profile.rs:341, :3198, :3243 over all of them."""
+    from pantax_amd import synth
+    from pantax_amd.engine import Engine
+    from pantax_amd.pipeline import StepConfig, profile_steps_many, split_species_by_path_steps
+    import torch
+    cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()
+    n_species, n_haps, n_reads, genome_len = spec["species"], spec["haps"], spec["reads"], spec["genome_len"]
+    host_threads = max(1, min(64, os.cpu_count() or 1))
+    torch.cuda.set_device(local_rank)
+    t_gen = time.perf_counter()
+    ns = native_set(spec, threads=host_threads)
+    rd = ns.reads()
+    species = ns.graphs()
+    gen_s = time.perf_counter() - t_gen
+    groups = split_species_by_path_steps(ns.P)
+    K = len(groups)
+    # the reads of every db: by the species that holds their first node (a walk that leaves its species is "U" wherever it is binned)
+    so = rd.step_off.astype(np.int64)
+    klen = np.diff(so)
+    first = np.where(klen > 0, rd.node_id[np.minimum(so[:-1], max(len(rd.node_id) - 1, 0))].astype(np.int64), 0)
+    sp_of = np.clip(np.searchsorted(ns.range_start, first, side="right") - 1, 0, n_species - 1)
+    t_up = time.perf_counter()
+    engs, names_l, haps_l, avg_l, R_l, T_l = [], [], [], [], [], []
+    avg_all = ns.avg_len()
+    mapq = np.where((rd.mapq < 0) | (rd.mapq > 254), 255, rd.mapq)
+    for gi, (a, b) in enumerate(groups):
+        sel = np.nonzero((sp_of >= a) & (sp_of < b) & ((klen > 0) | (gi == 0)))[0]
+        nsteps = klen[sel]
+        off = np.zeros(len(sel) + 1, dtype=np.int64)
+        np.cumsum(nsteps, out=off[1:])
+        idx = np.repeat(so[:-1][sel] - off[:-1], nsteps) + np.arange(int(off[-1]), dtype=np.int64)
+        eng = Engine(local_rank)
+        eng.upload_db(species[a:b])
+        eng.upload_reads(off, rd.node_id[idx], rd.pstart[sel], rd.pend[sel], rd.qlen[sel], mapq[sel])
+        eng.sync()
+        engs.append(eng)
+        names_l.append([g.name for g in species[a:b]])
+        haps_l.append([hn for g in species[a:b] for hn in g.hap_names])
+        avg_l.append(avg_all[a:b])
+        R_l.append(len(sel)); T_l.append(int(off[-1]))
+        del idx
+    upload_ms = (time.perf_counter() - t_up) * 1e3
+    run = lambda n, c=cfg: profile_steps_many(engs, names_l, haps_l, avg_l, n, c)
+
+    def barrier():
+        torch.cuda.synchronize()
+        for e in engs:
+            e.sync()
+
+    def timings():
+        tot = {}
+        for e in engs:
+            for k, (n, ms) in e.timing_get().items():
+                a = tot.setdefault(k, [0, 0.0])
+                a[0] += n; a[1] += ms
+        return tot
+    run(2)
+    barrier()
+    for e in engs:
+        e.timing_enable(True); e.timing_reset()
+    n_warm = max(args.warmup, 1)
+    out = run(n_warm)[-1]
+    warm = timings()
+    cov_kernel = "coverage_fast_kernel" if "coverage_fast_kernel" in warm else "coverage_step_kernel"
+    top2 = [k for k, _ in sorted(warm.items(), key=lambda kv: -kv[1][1])[:2]]
+    for e in engs:
+        e.timing_filter("|".join(top2 + [k for k in [cov_kernel] if k not in top2])); e.timing_reset()
+    import gc
+    gc.collect(); gc.freeze()
+    barrier()
+    t0 = time.perf_counter()
+    out = run(args.steps)[-1]
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = timings()
+    for e in engs:
+        e.timing_enable(False); e.timing_filter(None)
+    cfg_cached = StepConfig(fr=cfg.fr, rebuild_trio=False)
+    run(1, cfg_cached)
+    barrier()
+    t1 = time.perf_counter()
+    run(args.steps, cfg_cached)
+    barrier()
+    dt_cached = time.perf_counter() - t1
+    # abundance L1 against the oracle for a sample of species (species binned on the host by the oracle's own rule)
+    l1 = None
+    if not args.no_l1:
+        try:
+            from oracle import oracle as orc
+            sp = orc.par_bin_reads(rd.step_off, rd.node_id, ns.range_start, ns.range_end, host_threads)
+            cnt = np.bincount(sp[sp >= 0], minlength=n_species)
+            l1 = abundance_l1_leg(None, ns, species, rd, out, cfg, host_threads, n_sample=7, sp=sp, rc=cnt)
+        except Exception as e:   # noqa: BLE001 -- the line is printed regardless
+            l1 = {"error": "%s: %s" % (type(e).__name__, e)}
+    species_rows, strain_rows, stats = out
+    ms_per_step = dt / args.steps * 1e3
+    n_lp_rows = int(sum(stats["n_rows"]))
+    n_unique = int(sum(e.trio_nodes_info(fetch=False) for e in engs))
+    ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, sum(R_l), sum(T_l))
+
+    def ruler(k):
+        launches, tot_ms = tm[k]
+        per_step_ms = tot_ms / args.steps
+        return dict(kernel=k, ms_per_step_summed_over_the_dbs=round(per_step_ms, 4), launches_timed=launches, algorithmic_bytes=ab.get(k, 0),
+                    achieved=ab.get(k, 0) / (per_step_ms * 1e-3) / 1e9, frac=ab.get(k, 0) / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    roofline = None
+    dom = max((k for k in top2 if k in tm), key=lambda k: tm[k][1], default=None)
+    if dom:
+        r0 = ruler(dom)
+        roofline = dict(bound="hbm", kernel=dom, achieved=r0["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=r0["frac"], traffic=None,
+                        avg_ms=r0["ms_per_step_summed_over_the_dbs"], launches_timed=r0["launches_timed"], algorithmic_bytes=r0["algorithmic_bytes"],
+                        note="bytes of the whole workload over the kernel's time per step summed over the %d dbs' launches" % K,
+                        traffic_source="no PMC record for this workload: traffic null")
+        for k2 in top2 + [cov_kernel]:
+            if k2 != dom and k2 in tm:
+                r2 = ruler(k2)
+                roofline["coverage" if k2 == cov_kernel and k2 not in top2 else "runner_up"] = {k: r2[k] for k in ("kernel", "ms_per_step_summed_over_the_dbs", "algorithmic_bytes", "frac")}
+    line = {
+        "metric": "PAO wall-time (s) + Mreads/s, packed reads resident in HBM -> abundance tables",
+        "value": n_reads / (dt / args.steps) / 1e6, "unit": "Mreads/s", "n_gpus": 1, "steps": args.steps, "warmup": n_warm,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+        "config": {"workload": "%s: %d species x %d strains, %d %s, genome %d bp, seed %d, generator %s"
+                               % (spec["name"], n_species, n_haps, n_reads, "long reads N(15000, 3000^2) bp" if spec.get("long_reads") else "short reads (150 bp)",
+                                  genome_len, spec["seed"], GENERATOR),
+                   "baseline_config": spec["label"][:60], "dbs_on_the_gpu": K, "species_per_db": [b - a for a, b in groups],
+                   "why_several_dbs": "a resident db addresses its path steps with 32 bits; %d path steps are cut by species (species are independent)" % dims["P"],
+                   "gsteps_per_s": sum(T_l) / (dt / args.steps) / 1e9, "V": dims["V"], "P": dims["P"], "T": dims["T"], "U": n_unique,
+                   "strains_total": n_species * n_haps, "reads_total": n_reads, "parallelism": "species-shard x1 (%d dbs side by side)" % K,
+                   "pao_wall_s": ms_per_step / 1e3, "ms_per_step_trio_index_resident": dt_cached / args.steps * 1e3,
+                   "abundance_l1_vs_oracle": (l1 or {}).get("abundance_l1_vs_oracle"), "abundance_l1_species_checked": (l1 or {}).get("species_checked"),
+                   "abundance_l1_tolerance": 1e-4, "abundance_l1_error": (l1 or {}).get("error"),
+                   "lp_rows_total": n_lp_rows, "n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows), "upload_ms_once": upload_ms,
+                   "synthetic_set_generated_in_s": gen_s, "sample_nodes": 0},
+        "roofline": roofline,
+        "kernels_ms_per_step": {k: round(v[1] / n_warm, 3) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])[:14]},
+        "result": {"n_species_rows": len(species_rows), "n_strain_rows": len(strain_rows),
+                   "top_strains": [(r[0], r[1], round(r[2], 4), round(r[3], 6)) for r in strain_rows[:3]]},
+    }
+    detail = {"line": line, "abundance_l1": l1, "kernels_ms_per_step_all": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
+              "reads_per_db": R_l, "steps_per_db": T_l, "host": {"cores": os.cpu_count(), "mem_available_gb": _mem_available_gb()}}
+    dpath = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail_%s_n1.json" % spec["name"])
+    try:
+        os.makedirs(os.path.dirname(dpath), exist_ok=True)
+        with open(dpath, "w") as f:
+            json.dump(detail, f, indent=1)
+        line["detail_file"] = os.path.relpath(dpath, ROOT)
+    except OSError as e:
+        line["detail_file"] = "not written: %s" % e
+    print(json.dumps(line), flush=True)
+    for e in engs:
+        e.close()
+
+
 def launch_ranks(n):
     """One node, n ranks: python -m torch.distributed.run ... bench.py <the same arguments>, as a child process."""
     import socket
@@ -650,6 +811,11 @@ def main():
         sys.exit(launcher_selftest(rank, world))
     spec = workload_spec(args.workload, args.species, args.haps, args.reads, args.genome_len)
     n_species, n_haps, n_reads, genome_len = spec["species"], spec["haps"], spec["reads"], spec["genome_len"]
+    if spec["name"] == "cfg5":          # more path steps than one resident db addresses: several dbs on the one GPU (N = 1 only)
+        if world != 1:
+            print("bench.py: --workload cfg5 runs on one GPU (over N GPUs every rank holds its share: --workload cfg5_share --scaling weak)", file=sys.stderr)
+            sys.exit(2)
+        return run_many_dbs(args, spec, local_rank)
 
     # ---- CPU legs: a child process, started before anything initialises the GPU here (rank 0, N = 1 only).  The parent waits
     # for the oracle leg -- it uses every core -- and then goes on beside the child's single-threaded HiGHS legs.

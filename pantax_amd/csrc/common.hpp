@@ -12,9 +12,17 @@
 #include <vector>
 #include "../../include/pantax_hip.h"
 
+#ifndef TRIO_LH_PACK
+#define TRIO_LH_PACK 0   // 1: length and owner of a row in ONE 8-byte record (measurement builds)
+#endif
 namespace ptx {
 
 struct Ctx;
+#if TRIO_LH_PACK
+using trio_len_t = uint2;
+#else
+using trio_len_t = uint32_t;
+#endif
 
 // ---- error plumbing: HIP errors become PANTAX_HIP_E_HIP + message, never abort -------------
 int fail(Ctx *ctx, int code, const char *fmt, ...);
@@ -346,8 +354,12 @@ struct Db {
     bool trio_layout_fast = false;   // the sizes were learnt by a build that filed the visit table's species from its records (else: every species by the pass over the walks)
     DevBuf<uint32_t> d_trio_first;   // [V+1] path route: first row of every node (scratch of the build; the heads in node_rec are what the step reads)
     DevBuf<uint2> d_trio_ent;        // [U] {smaller end, larger end} of the window (global node indices); the middle is the node that heads the row
+#if TRIO_LH_PACK
+    DevBuf<uint2> d_trio_len;        // [U] {summed length of the window's three nodes (profile.rs:712), the haplotype that owns the row as an index within its species}
+#else
     DevBuf<uint32_t> d_trio_len;     // [U] summed length of the window's three nodes (profile.rs:712)
     DevBuf<uint16_t> d_trio_hap;     // [U] the haplotype that owns the row, as an index within its species
+#endif
     DevBuf<uint32_t> d_trio_q;       // [U] window start (path position) of the row: export builds only
     DevBuf<uint32_t> d_trio_perm;    // [U] row of the e-th window in (species, hap, position) order: export builds only
     DevBuf<uint64_t> d_hap_trio_off; // [H+1] prefix of the rows per haplotype = offsets of the export order (the first filter reads the counts)
@@ -548,6 +560,11 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count = false);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
+#if TRIO_LH_PACK
+#define TRIO_HAP_PTR(db) ((const uint16_t *)nullptr)
+#else
+#define TRIO_HAP_PTR(db) ((const uint16_t *)(db)->d_trio_hap.p)
+#endif
 int trio_export_ensure(Ctx *ctx, Db *db); // d_trio_perm: the (species, hap, position) order of the rows, for the exporters
 int trio_export_u64(Ctx *ctx, Db *db, const unsigned long long *d_src, unsigned long long *d_dst);   // d_dst[e] = d_src[row of e]
 int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint64_t *sp_rows);       // first build of a db: the chunk table of hap_trio_stats_launch

@@ -181,40 +181,45 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // of the non-zero abundances -> mean; squared deviations -> sd; (sum, count) of |z| < 3 -> the filtered mean.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t HS_CHUNK_ROWS = 1024, HS_LDS_HAPS = 1024;
+constexpr int HS_SLAB = 16;   // haplotypes whose accumulators a lane keeps in registers at a time
 struct HapAcc { double a; uint32_t c, n; };   // sum, count of the pass, rows seen (pass 0)
 
 template <int PASS>
 __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off, const uint16_t *__restrict__ row_hap,
-                                                           const unsigned long long *__restrict__ tb, const uint32_t *__restrict__ tlen,
+                                                           const unsigned long long *__restrict__ tb, const trio_len_t *__restrict__ tlen,
                                                            const double *__restrict__ mean0, const double *__restrict__ sd, HapAcc *__restrict__ part) {
     extern __shared__ HapAcc s_hap_acc[];
     const uint4 ch = chunks[blockIdx.x];                       // {species, first row, end row, first partial}
     const uint32_t h0 = (uint32_t)hap_off[ch.x], Hs = (uint32_t)hap_off[ch.x + 1] - h0;
     const int lane = threadIdx.x;
-    // Up to 64 haplotypes per species (every species of the BASELINE configurations): LANE h keeps the accumulators of haplotype h in
-    // registers -- the sum of an owner's lanes is wave-uniform after the DPP reduction, the owner's lane adds it; no LDS, no memory between two
-    // batches of rows.  The first version kept the accumulators in LDS and lane 0 did a read-modify-write per owner and batch: 6.1 ms for the
-    // three passes at 1e4 strains against 0.85 for round 4's kernel over contiguous rows.  Mean and sd of pass 0 / 1 ride in lane h too and
-    // reach a row's lane by one bpermute.
+    // Up to 64 haplotypes per species (every species of the BASELINE configurations): every LANE keeps its own accumulators for a slab of
+    // HS_SLAB haplotypes in registers and adds its rows to them by compare-and-select -- no cross-lane traffic and no scalar round trip inside
+    // the loop over the rows; the lanes meet once per chunk and slab (DPP reductions, fixed order).  Version 1 of this kernel walked the distinct
+    // owners of every 64 rows (readlane -> ballot -> DPP reduction -> owner's lane adds): ~150 cycles of scalar / vector ping-pong per owner,
+    // 2.0 ms a pass at 1e4 strains whether the accumulators sat in LDS or in registers (round 4's kernel over contiguous rows: 0.85 ms for
+    // all three).  A species of 17 .. 64 haplotypes reads its rows once per slab.  Mean and sd of pass 0 / 1 ride in lane h and reach a row's
+    // lane by one bpermute.
     const bool in_reg = Hs <= 64u;
     const bool in_lds = !in_reg && Hs <= HS_LDS_HAPS;
     HapAcc *acc = in_lds ? s_hap_acc : part + ch.w;            // (more than 64 haplotypes: LDS; beyond HS_LDS_HAPS the chunk's own, zero-filled row of partials)
     if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) acc[h] = HapAcc{0.0, 0u, 0u};
     __syncthreads();
-    double r_a = 0.0, my_mean = 0.0, my_sd = 0.0;
-    uint32_t r_c = 0, r_n = 0;
+    double my_mean = 0.0, my_sd = 0.0;
     if (in_reg && PASS >= 1 && (uint32_t)lane < Hs) { my_mean = mean0[h0 + lane]; if (PASS == 2) my_sd = sd[h0 + lane]; }
-    for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
-        const uint32_t row = r0 + (uint32_t)lane;
-        const bool valid = row < ch.z;
-        uint32_t h = 0xFFFFFFFFu;
+    auto row_value = [&](uint32_t row, bool valid, uint32_t &h, double &val, bool &flag) {
+        h = 0xFFFFFFFFu;
         double x = 0.0;
         if (valid) {
+#if TRIO_LH_PACK
+            const uint2 lh = tlen[row];
+            h = lh.y;
+            x = (double)(long long)tb[row] / (double)lh.x;                    // profile.rs:1013-1014
+#else
             h = row_hap[row];
             x = (double)(long long)tb[row] / (double)tlen[row];                // profile.rs:1013-1014
+#endif
         }
-        double val = 0.0;
-        bool flag = false;
+        val = 0.0; flag = false;
         if (PASS == 0) { if (x > 0.0) { val = x; flag = true; } }                 // :1129-1133
         else {
             double m, s_ = 0.0;
@@ -225,21 +230,53 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
                 else if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; }   // :1043-1050
             }
         }
+    };
+    if (in_reg) {
+        for (uint32_t slab = 0; slab * HS_SLAB < Hs; ++slab) {
+            double a_[HS_SLAB];
+            uint32_t c_[HS_SLAB];
+#pragma unroll
+            for (int k = 0; k < HS_SLAB; ++k) { a_[k] = 0.0; c_[k] = 0u; }
+            for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
+                const uint32_t row = r0 + (uint32_t)lane;
+                uint32_t h; double val; bool flag;
+                row_value(row, row < ch.z, h, val, flag);
+                const uint32_t j = h - slab * HS_SLAB;                         // (a lane without a row: no slab holds it)
+#pragma unroll
+                for (int k = 0; k < HS_SLAB; ++k) {
+                    const bool m_ = j == (uint32_t)k;
+                    a_[k] += m_ ? val : 0.0;
+                    c_[k] += (m_ && flag) ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HS_SLAB; ++k) {
+                const double v = wave_reduce(a_[k], [](double x, double y) { return x + y; });
+                const uint32_t c = wave_reduce(c_[k], [](uint32_t x, uint32_t y) { return x + y; });
+                const uint32_t hh = slab * HS_SLAB + (uint32_t)k;
+                if (lane == 0 && hh < Hs) part[ch.w + hh] = HapAcc{v, c, 0u};
+            }
+        }
+        return;
+    }
+    for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
+        const uint32_t row = r0 + (uint32_t)lane;
+        const bool valid = row < ch.z;
+        uint32_t h; double val; bool flag;
+        row_value(row, valid, h, val, flag);
         unsigned long long todo = __ballot(valid);
         while (todo) {
             const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(todo));
             const bool mine = valid && h == hh;
             const unsigned long long sel = __ballot(mine);
-            const double v = wave_reduce(mine ? val : 0.0, [](double a_, double b_) { return a_ + b_; });
+            const double v = wave_reduce(mine ? val : 0.0, [](double a2, double b2) { return a2 + b2; });
             const uint32_t c = (uint32_t)__popcll(__ballot(mine && flag));
-            if (in_reg) { if ((uint32_t)lane == hh) { r_a += v; r_c += c; r_n += (uint32_t)__popcll(sel); } }
-            else if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
+            if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
             todo &= ~sel;
         }
     }
     __syncthreads();
-    if (in_reg) { if ((uint32_t)lane < Hs) part[ch.w + lane] = HapAcc{r_a, r_c, r_n}; }
-    else if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
+    if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
 }
 // one wave per species: the chunks' partials added in chunk order
 template <int PASS>
@@ -306,7 +343,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 #define HS_PASS(PP)                                                                                                                                            \
     if (db->stat_global_rows) PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                            \
     if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
-                               (const uint16_t *)db->d_trio_hap.p, (const unsigned long long *)db->d_trio_bases.p, (const uint32_t *)db->d_trio_len.p,          \
+                               TRIO_HAP_PTR(db), (const unsigned long long *)db->d_trio_bases.p, (const trio_len_t *)db->d_trio_len.p,          \
                                (const double *)mean0, (const double *)sd, part);                                                                               \
     hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(64), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
                        (const uint64_t *)db->d_hap_off.p, (const HapAcc *)part, d_nnz.p, mean0, sd, d_mean.p);

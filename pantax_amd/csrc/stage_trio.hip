@@ -417,20 +417,49 @@ __global__ void __launch_bounds__(256) visit_flags_kernel(uint64_t V, uint32_t S
         slow[lo] = 1u;
     }
 }
-// one thread packs the nodes of a chunk {first node, end node, node base of the species} into groups of 64 visits
+// one thread packs the nodes of a chunk {first node, end node, node base of the species, species} into groups of 64 visits that no node
+// straddles: FIRST FIT over a few open groups (round 5; rounds 4's next-fit closed a group as soon as the next node did not fit -- one
+// 50-visit node per group at fifty strains per species, 22 % pads; 7 % at ten).  The order of the nodes inside a chunk is then the order of
+// their placement, not of their ids: nothing depends on it (a node's visits stay one stretch of one group, its rows one block).
+constexpr int VIS_OPEN = 4;
+struct VisPack {
+    uint32_t fill[VIS_OPEN], gidx[VIS_OPEN], n_groups;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < VIS_OPEN; ++j) { fill[j] = 64u; gidx[j] = 0u; }
+        n_groups = 0u;
+    }
+    // -> slot of the node's first visit, relative to the chunk's first group
+    __device__ __forceinline__ uint32_t place(uint32_t k) {
+        int best = -1;
+#pragma unroll
+        for (int j = VIS_OPEN - 1; j >= 0; --j) if (fill[j] + k <= 64u) best = j;       // the first open group it fits
+        if (best < 0) {                                                                 // none: the fullest one is closed, a new group opened in its place
+            best = 0;
+#pragma unroll
+            for (int j = 1; j < VIS_OPEN; ++j) if (fill[j] > fill[best]) best = j;
+#pragma unroll
+            for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { fill[j] = 0u; gidx[j] = n_groups; }
+            ++n_groups;
+        }
+        uint32_t slot = 0;
+#pragma unroll
+        for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { slot = gidx[j] * 64u + fill[j]; fill[j] += k; }
+        return slot;
+    }
+};
 __global__ void __launch_bounds__(256) visit_layout_kernel(uint32_t NC, const uint4 *__restrict__ chunks, const uint32_t *__restrict__ cnt,
                                                            uint32_t *__restrict__ chunk_groups) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= NC) return;
     const uint4 ch = chunks[c];
-    uint32_t pos = 0;
+    VisPack pk;
+    pk.init();
     for (uint32_t v = ch.x; v < ch.y; ++v) {
         const uint32_t k = cnt[v];
-        if (!k) continue;
-        if ((pos & 63u) + k > 64u) pos = (pos + 63u) & ~63u;
-        pos += k;
+        if (k) (void)pk.place(k);
     }
-    chunk_groups[c] = (pos + 63u) >> 6;
+    chunk_groups[c] = pk.n_groups;
 }
 __global__ void __launch_bounds__(256) visit_place_kernel(uint32_t NC, const uint4 *__restrict__ chunks, const uint32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ chunk_gbase, uint32_t *__restrict__ vslot,
@@ -439,17 +468,16 @@ __global__ void __launch_bounds__(256) visit_place_kernel(uint32_t NC, const uin
     if (c >= NC) return;
     const uint4 ch = chunks[c];
     const uint32_t base = chunk_gbase[c] << 6;
-    uint32_t pos = 0;
+    VisPack pk;
+    pk.init();
     for (uint32_t v = ch.x; v < ch.y; ++v) {
         const uint32_t k = cnt[v];
         if (!k) continue;
-        if ((pos & 63u) + k > 64u) pos = (pos + 63u) & ~63u;
-        const uint32_t slot = base + pos;
+        const uint32_t slot = base + pk.place(k);
         vslot[v] = slot;
         atomicOr(&head[slot >> 6], 1ull << (slot & 63u));
         gnbase[slot >> 6] = ch.z;
         gsp[slot >> 6] = ch.w;
-        pos += k;
     }
 }
 __global__ void __launch_bounds__(256) visit_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ slow, const uint32_t *__restrict__ vslot,
@@ -535,17 +563,23 @@ struct RowOut {
     const uint32_t *node_len;
     const uint64_t *path_off, *hap_off;
     uint2 *ent;
-    uint32_t *len;
+    trio_len_t *len;
     uint16_t *hap;
     uint32_t *q;
     uint32_t *hap_cnt;
+    __device__ __forceinline__ void put_len_hap(uint32_t row, uint32_t l, uint32_t h) const {
+#if TRIO_LH_PACK
+        len[row] = make_uint2(l, h);
+#else
+        len[row] = l; hap[row] = (uint16_t)h;
+#endif
+    }
 };
 template <bool KEYS, bool FIRST>
 __device__ __forceinline__ void row_file(const RowOut &o, uint32_t row, uint32_t q0, uint32_t lo, uint32_t hi, uint32_t mid, uint32_t sp) {
     const uint32_t h0 = (uint32_t)o.hap_off[sp], h = hap_of_position(o.path_off, h0, (uint32_t)o.hap_off[sp + 1], q0);
     o.ent[row] = make_uint2(lo, hi);
-    o.len[row] = o.node_len[lo] + o.node_len[mid] + o.node_len[hi];
-    o.hap[row] = (uint16_t)(h - h0);
+    o.put_len_hap(row, o.node_len[lo] + o.node_len[mid] + o.node_len[hi], h - h0);
     if (KEYS) o.q[row] = q0;
     if (FIRST) atomicAdd(&o.hap_cnt[h], 1u);
 }
@@ -876,8 +910,7 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
                 hl = hap_of_position(o.path_off, hb, (uint32_t)o.hap_off[sp[u] + 1], rec[u].x) - hb;
             }
             o.ent[row[u]] = make_uint2(rec[u].y, rec[u].z);
-            o.len[row[u]] = len3[u];
-            o.hap[row[u]] = (uint16_t)hl;
+            o.put_len_hap(row[u], len3[u], hl);
             if (KEYS) o.q[row[u]] = rec[u].x;
             if (FIRST) atomicAdd(&o.hap_cnt[hb + hl], 1u);
         }
@@ -920,7 +953,7 @@ __global__ void __launch_bounds__(256) trio_iota_kernel(uint32_t n, uint32_t *__
 }
 // export copies of the table in that order: canonical key (species-local), owner haplotype, length
 __global__ void __launch_bounds__(256) trio_export_kernel(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ q, const uint32_t *__restrict__ path_nodes,
-                                                          const uint16_t *__restrict__ hap, const uint32_t *__restrict__ len, uint32_t *__restrict__ abc_out,
+                                                          const uint16_t *__restrict__ hap, const trio_len_t *__restrict__ len, uint32_t *__restrict__ abc_out,
                                                           uint32_t *__restrict__ hap_out, uint32_t *__restrict__ len_out) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -928,8 +961,13 @@ __global__ void __launch_bounds__(256) trio_export_kernel(uint32_t n, const uint
     uint32_t a = path_nodes[p], b = path_nodes[p + 1], c = path_nodes[p + 2];
     if (a > c) { const uint32_t t = a; a = c; c = t; }                     // profile.rs:672-678
     if (abc_out) { abc_out[3ull * e] = a; abc_out[3ull * e + 1] = b; abc_out[3ull * e + 2] = c; }
+#if TRIO_LH_PACK
+    if (hap_out) hap_out[e] = len[row].y;
+    if (len_out) len_out[e] = len[row].x;
+#else
     if (hap_out) hap_out[e] = hap[row];
     if (len_out) len_out[e] = len[row];
+#endif
 }
 __global__ void __launch_bounds__(256) gather_u64_kernel(uint32_t n, const uint32_t *__restrict__ perm, const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
@@ -1210,10 +1248,13 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     }
     const uint32_t Utot = (uint32_t)db->U_known;
     db->U = Utot;
-    PTX_HIP(ctx, db->d_trio_ent.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot)); PTX_HIP(ctx, db->d_trio_hap.alloc(Utot));
+    PTX_HIP(ctx, db->d_trio_ent.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
+#if !TRIO_LH_PACK
+    PTX_HIP(ctx, db->d_trio_hap.alloc(Utot));
+#endif
     if (with_keys) PTX_HIP(ctx, db->d_trio_q.alloc(Utot));
     if (path_route) PTX_HIP(ctx, ts.row_q.alloc(Utot));
-    const RowOut ro{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, db->d_trio_hap.p, db->d_trio_q.p, ts.hap_cnt.p};
+    const RowOut ro{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, const_cast<uint16_t *>(TRIO_HAP_PTR(db)), db->d_trio_q.p, ts.hap_cnt.p};
     // ---- the rows
     if (rows_by_visit) {
         KTimer t(ctx, "trio_rows_kernel");
@@ -1365,7 +1406,7 @@ int pantax_hip_trio_get(pantax_hip_ctx *ctx, const pantax_hip_db *cdb, uint32_t 
         if (hap_out) PTX_HIP(ctx, d_hap.alloc(U));
         if (len_out) PTX_HIP(ctx, d_len.alloc(U));
         hipLaunchKernelGGL(trio_export_kernel, dim3((uint32_t)((U + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)U, (const uint32_t *)db->d_trio_perm.p,
-                           (const uint32_t *)db->d_trio_q.p, (const uint32_t *)db->d_path_nodes.p, (const uint16_t *)db->d_trio_hap.p, (const uint32_t *)db->d_trio_len.p,
+                           (const uint32_t *)db->d_trio_q.p, (const uint32_t *)db->d_path_nodes.p, TRIO_HAP_PTR(db), (const trio_len_t *)db->d_trio_len.p,
                            abc_out ? d_abc.p : (uint32_t *)nullptr, hap_out ? d_hap.p : (uint32_t *)nullptr, len_out ? d_len.p : (uint32_t *)nullptr);
         PTX_HIP(ctx, hipGetLastError());
         std::vector<uint32_t> len32;

@@ -48,6 +48,17 @@ class Engine:
             self.lib.pantax_hip_destroy(self.ctx)
             self.ctx = None
 
+    def release(self):
+        """free the resident db and reads (HBM), keep the ctx"""
+        if self.ctx:
+            if self.reads:
+                self.lib.pantax_hip_reads_free(self.ctx, self.reads)
+                self.reads = None
+            if self.db:
+                self.lib.pantax_hip_db_free(self.ctx, self.db)
+                self.db = None
+            self._inflight = 0
+
     def __enter__(self):
         return self
 

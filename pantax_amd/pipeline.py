@@ -474,19 +474,26 @@ class _ManyComm:
 
 
 def split_species_by_path_steps(path_steps, limit=3_600_000_000):
-    """contiguous groups of species whose path steps sum to at most `limit` (< 2^32 with room for the padded visit table) -> list of
-    (first species, end species)"""
-    groups, a, acc = [], 0, 0
-    for i, p in enumerate(path_steps):
-        p = int(p)
+    """contiguous groups of species whose path steps sum to at most `limit` (< 2^32 with room for the padded visit table), as few groups as
+    that takes and about equally heavy -> list of (first species, end species)"""
+    ps = [int(p) for p in path_steps]
+    for i, p in enumerate(ps):
         if p > limit:
             raise ValueError("species %d alone has %d path steps" % (i, p))
-        if acc + p > limit:
-            groups.append((a, i))
-            a, acc = i, 0
-        acc += p
-    groups.append((a, len(path_steps)))
-    return groups
+    total = sum(ps)
+    K = max(1, -(-total // limit))
+    while True:
+        target = -(-total // K)
+        groups, a, acc = [], 0, 0
+        for i, p in enumerate(ps):
+            if acc and (acc + p > limit or (acc + p > target and len(groups) < K - 1)):
+                groups.append((a, i))
+                a, acc = i, 0
+            acc += p
+        groups.append((a, len(ps)))
+        if all(sum(ps[x:y]) <= limit for x, y in groups):
+            return groups
+        K += 1
 
 
 def finalize_many(locals_, species_names_list, hap_names_list, cfg):

@@ -100,7 +100,11 @@ def test_several_dbs_on_one_gpu_finalize_like_ranks():
     every species -- and the species are cut into contiguous groups under the position limit."""
     from pantax_amd.pipeline import LocalComm, StepConfig, finalize_many, finalize_stage, split_species_by_path_steps
     from tests.dist_worker import fake_local, names
-    assert split_species_by_path_steps([5, 5, 5, 9, 1, 10], limit=10) == [(0, 2), (2, 3), (3, 5), (5, 6)]
+    ps = [5, 5, 5, 9, 1, 10]
+    gr = split_species_by_path_steps(ps, limit=10)
+    assert gr[0][0] == 0 and gr[-1][1] == len(ps) and all(a[1] == b[0] for a, b in zip(gr, gr[1:])) and all(0 < sum(ps[a:b]) <= 10 for a, b in gr)
+    assert split_species_by_path_steps([3] * 10, limit=16) == [(0, 5), (5, 10)]          # as few groups as the limit allows, about equally heavy
+    assert split_species_by_path_steps([11_300_000] * 1000) == [(0, 250), (250, 500), (500, 750), (750, 1000)]   # BASELINE configs[4]: four dbs
     assert split_species_by_path_steps([1, 2, 3]) == [(0, 3)]
     with pytest.raises(ValueError):
         split_species_by_path_steps([11], limit=10)

@@ -281,3 +281,86 @@ def test_cfg4_full_size_one_gpu_properties_and_oracle_sample(eng):
     expected = {k: v for k, v in oracle_passing_rows(sset, level).items() if k in active}
     assert len(expected) >= 5
     check_step_rows_against_oracle(st_rows, expected)
+
+
+def test_cfg5_full_size_one_gpu_as_four_dbs(eng):
+    """BASELINE.json configs[4] at ITS size on ONE GPU: 1 000 species x 50 strains (50 000 strains, 1.1e10 path steps), 1e6 HiFi-shaped reads of
+    ~680 steps.  One resident db addresses 2^32 path steps, so the species are cut into four dbs that share the GPU, each with the reads of its
+    species, stepped side by side and finalised like ranks (pipeline.profile_steps_many; species are independent from a4 on, profile.rs:3297-3319).
+    Checked: the tables are normalised over ALL dbs; the strain rows of a species sample (the species with the most reads, one of every db)
+    equal the oracle's -- metrics field by field, abundance L1 <= 1e-4; the coverage integers of two species bit for bit; the second sample
+    through the same dbs gives the same tables."""
+    from bench import native_set, workload_spec
+    from oracle import oracle as orc
+    from pantax_amd.engine import Engine
+    from pantax_amd.pipeline import StepConfig, profile_steps_many, split_species_by_path_steps
+    eng.release()                                    # the module's engine still holds the previous test's 100 GB
+    spec = workload_spec("cfg5")
+    ns = native_set(spec, threads=THREADS)
+    rd = ns.reads()
+    species = ns.graphs()
+    from pantax_amd import synth
+    sset = synth.SyntheticSet(species, rd)
+    S = len(species)
+    assert (S, rd.n_reads) == (1000, 1_000_000) and int(ns.P.sum()) > 2 ** 32
+    groups = split_species_by_path_steps(ns.P)
+    assert len(groups) >= 3
+    so = rd.step_off.astype(np.int64)
+    klen = np.diff(so)
+    first = np.where(klen > 0, rd.node_id[np.minimum(so[:-1], len(rd.node_id) - 1)].astype(np.int64), 0)
+    sp_of = np.clip(np.searchsorted(ns.range_start, first, side="right") - 1, 0, S - 1)
+    mapq = np.where((rd.mapq < 0) | (rd.mapq > 254), 255, rd.mapq)
+    cfg = StepConfig(fr=0.5)                         # long reads: --fr 0.5 (main.rs:108-114)
+    engs, names_l, haps_l, avg_l, sels = [], [], [], [], []
+    try:
+        for gi, (a, b) in enumerate(groups):
+            sel = np.nonzero((sp_of >= a) & (sp_of < b) & ((klen > 0) | (gi == 0)))[0]
+            so_k, nid_k, ps_k, pe_k = select_reads(rd, sel)
+            e = Engine(0)
+            e.upload_db(species[a:b])
+            e.upload_reads(so_k, nid_k, ps_k, pe_k, rd.qlen[sel], mapq[sel])
+            engs.append(e); sels.append(sel)
+            names_l.append([g.name for g in species[a:b]])
+            haps_l.append([hn for g in species[a:b] for hn in g.hap_names])
+            avg_l.append(ns.avg_len()[a:b])
+        outs = profile_steps_many(engs, names_l, haps_l, avg_l, 2, cfg)
+        sp_rows, st_rows, stats = outs[0]
+        assert (outs[1][0], outs[1][1]) == (sp_rows, st_rows)
+        assert sum(r[1] for r in sp_rows) == pytest.approx(1.0, rel=1e-12) and sum(r[3] for r in st_rows) == pytest.approx(1.0, rel=1e-12)
+        assert {r[0] for r in st_rows} <= {r[0] for r in sp_rows} and len({r[0] for r in st_rows}) > 900
+        # the oracle on a species sample: binning of every read, the species table, then the strain level of the sample
+        sp = orc.par_bin_reads(rd.step_off, rd.node_id, ns.range_start, ns.range_end, THREADS)
+        counts = orc.species_counts(sp, rd.qlen, rd.mapq, S)
+        keep, absolute, abundance = orc.species_profile(sp, rd.qlen, counts, ns.avg_len())
+        exp_sp = sorted([(species[s].name, abundance[s], absolute[s]) for s in range(S) if keep[s]], key=lambda r: -r[1])
+        assert [r[0] for r in sp_rows] == [r[0] for r in exp_sp]
+        for g_, e_ in zip(sp_rows, exp_sp):
+            assert g_[1] == pytest.approx(e_[1], rel=1e-12) and g_[2] == pytest.approx(e_[2], rel=1e-12)
+        sample = sorted({int(np.argmax(counts[0]))} | {a + (b - a) // 3 for a, b in groups})
+        level = oracle_strain_level(sset, sp, keep, absolute, sample, threads=THREADS, fr=0.5)
+        active = {r[0] for r in sp_rows if r[1] > 1e-4}
+        expected = {k: v for k, v in oracle_passing_rows(sset, level).items() if k in active}
+        assert len(expected) >= 3
+        check_step_rows_against_oracle(st_rows, expected)
+        # coverage integers of two species of the second db, through its stage calls, against the oracle
+        a, b = groups[1]
+        e1 = engs[1]
+        e1.rcls_profile(want_species=False)
+        e1.db_reset()
+        abc, hap, ln, hto = e1.trio_nodes_info()
+        bases, cov, tb, nab = e1.get_node_abundances()
+        nb = np.cumsum([0] + [g.n_nodes for g in species[a:b]])
+        hb = np.cumsum([0] + [g.n_paths for g in species[a:b]])
+        for s in (a + 1, b - 2):
+            g = species[s]
+            G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+            T = orc.TrioTable(G)
+            so_s, nid_s, ps_s, pe_s = select_reads(rd, np.nonzero(sp == s)[0])
+            ob, oc, ot, _ = orc.node_coverage(G, T, g.range_start, so_s, nid_s, ps_s, pe_s)
+            k = s - a
+            assert np.array_equal(bases[nb[k]:nb[k + 1]], ob) and np.array_equal(cov[nb[k]:nb[k + 1]], oc)
+            u0, u1 = int(hto[hb[k]]), int(hto[hb[k + 1]])
+            assert u1 - u0 == T.n_unique and np.array_equal(abc[u0:u1], T.abc) and np.array_equal(tb[u0:u1], ot)
+    finally:
+        for e in engs:
+            e.close()
