@@ -127,6 +127,7 @@ struct CtxConfig {
     int stage_threads = 32;          // host threads that fill the pinned upload ring (at 16 the filling, not the DMA, bounds a 15-GB load)
     int stage_ch_mb = 0;             // chunk size of the ring in MB (0: from the transfer size)
     bool stream_prio = true;         // main stream at the highest, side stream at the lowest priority
+    bool numa_bind = true;           // the upload crew and its pinned ring live on the GPU's NUMA node
     uint64_t gaf_piece_bytes = 0;    // largest piece of GAF text tokenised at once (0: a sixth of the text, 64 MiB .. 1 GiB)
     // forced paths (tests compare them with the defaults)
     std::string trio_path;           // "block": every species through the node-block kernel; "bucket": global buckets
@@ -138,7 +139,7 @@ struct CtxConfig {
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
-    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
+    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0, cov_trio_win = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
     uint32_t ssg_wave_rows = 0;
     bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
@@ -146,9 +147,19 @@ struct CtxConfig {
 };
 int ctx_set_option(CtxConfig &cfg, const char *name, const char *value);   // 0, or PANTAX_HIP_E_INVALID for an unknown name / unparsable value
 
+// The host side of the big uploads (GAF text, graph arrays) is a crew of threads that pread into a pinned ring while the DMA engine empties
+// it: both want the memory of the GPU's own NUMA node -- a filler on the far socket writes the ring across the inter-socket link, and the DMA
+// reads it back the same way (round 4: 0.365 .. 0.49 s for the same 15-GB load from box to box).  pantax_hip_init looks the node up
+// (/sys/bus/pci/devices/<gpu>/numa_node); the crew's threads are bound to its CPUs and the ring is allocated from it (option numa_bind=0: off).
+struct NumaInfo {
+    int node = -1;                   // -1: unknown / a single node: nothing is bound
+    std::vector<int> cpus;           // the node's CPUs
+};
+
 struct Ctx {
     std::recursive_mutex mu;         // one call at a time per ctx (PTX_ENTER)
     CtxConfig cfg;
+    NumaInfo numa;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_main = nullptr;   // the main stream while `stream` is swapped to the side stream (api_step.cpp), else null

@@ -12,6 +12,10 @@
 #include <thread>
 #include <unistd.h>
 #include <fcntl.h>
+#include <sched.h>
+#include <pthread.h>
+#include <sys/syscall.h>
+#include <fstream>
 #include <cctype>
 #include <cstddef>
 #include <cstdlib>
@@ -90,12 +94,12 @@ enum OptKind { O_BOOL, O_INT, O_U32, O_U64, O_STR };
 struct OptDesc { const char *name; OptKind kind; size_t off; };
 #define OPT(nm, kind, field) {nm, kind, offsetof(CtxConfig, field)}
 const OptDesc OPTIONS[] = {
-    OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio),
+    OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind),
     OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("uniq_hash", O_INT, uniq_hash),
     OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
-    OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
+    OPT("covf_shape", O_INT, covf_shape), OPT("cov_trio_win", O_INT, cov_trio_win), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
     OPT("cov_ablate", O_U32, cov_ablate), OPT("ssg_wave_rows", O_U32, ssg_wave_rows), OPT("ssn_debug", O_BOOL, ssn_debug),
     OPT("scan_no_huge", O_BOOL, scan_no_huge), OPT("flag_rank_chained", O_BOOL, flag_rank_chained), OPT("ratio_kernel", O_BOOL, ratio_kernel),
     OPT("mask_pass", O_BOOL, mask_pass), OPT("trio_free_at_filter", O_BOOL, trio_free_at_filter), OPT("trio_after_step", O_BOOL, trio_after_step),
@@ -177,6 +181,29 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
     ctx->device = dev;
     ctx->n_cu = prop.multiProcessorCount;
     config_from_env(ctx->cfg);   // the only place the library reads the environment
+    {   // the GPU's NUMA node and its CPUs (sysfs); anything missing = nothing is bound
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) == hipSuccess) {
+            for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+            std::ifstream f(std::string("/sys/bus/pci/devices/") + bus + "/numa_node");
+            int node = -1;
+            if (f >> node && node >= 0) {
+                std::ifstream g("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+                std::string list;
+                if (std::getline(g, list)) {
+                    for (size_t pos = 0; pos < list.size();) {
+                        const size_t comma = std::min(list.find(',', pos), list.size());
+                        const std::string part = list.substr(pos, comma - pos);
+                        const size_t dash = part.find('-');
+                        const int a = std::atoi(part.c_str()), b = dash == std::string::npos ? a : std::atoi(part.c_str() + dash + 1);
+                        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) ctx->numa.cpus.push_back(c);
+                        pos = comma + 1;
+                    }
+                    if (!ctx->numa.cpus.empty()) ctx->numa.node = node;
+                }
+            }
+        }
+    }
     // The main stream at the highest priority, the side stream (index rebuild) at the lowest: in a stream of steps the rebuild for
     // step i+1 runs beside the tail of step i, which is the critical chain -- the rebuild has 2 ms of slack and fills what the
     // chain's narrow kernels (sample ranking, the LP workgroups) leave idle instead of taking wave slots from its wide ones
@@ -372,6 +399,36 @@ namespace {
 // created and joined 16 threads per 16-MB chunk: ~0.5 ms of thread start-up beside 0.6 ms of copy).  The box delivers 80 GB/s
 // of pread from the page cache on 8-16 threads and 56 GB/s of pinned host->device copy (tools/h2d_probe.py): the crew only has
 // to stay ahead of the DMA (it takes 32 threads for that inside the pipeline: see upload_staged_pieces).
+// bind the calling thread to a NUMA node's CPUs (and, while `prefer` is set, its new pages to that node: the pinned ring is allocated under
+// it); restores what was there when it goes out of scope
+struct NumaBind {
+    cpu_set_t saved;
+    bool bound = false, policy = false;
+    NumaBind(const Ctx *ctx, bool prefer) {
+        if (!ctx->cfg.numa_bind || ctx->numa.node < 0 || ctx->numa.cpus.empty()) return;
+        if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+        cpu_set_t want;
+        CPU_ZERO(&want);
+        int n = 0;
+        for (int c : ctx->numa.cpus) if (CPU_ISSET(c, &saved)) { CPU_SET(c, &want); ++n; }   // only CPUs this process may use (cgroups / taskset)
+        if (n == 0) return;
+        bound = sched_setaffinity(0, sizeof(want), &want) == 0;
+        if (bound && prefer && ctx->numa.node < 1024) {
+#ifdef SYS_set_mempolicy
+            unsigned long mask[16] = {0};
+            mask[ctx->numa.node / 64] = 1ul << (ctx->numa.node % 64);
+            policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul) == 0;
+#endif
+        }
+    }
+    ~NumaBind() {
+#ifdef SYS_set_mempolicy
+        if (policy) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+#endif
+        if (bound) (void)sched_setaffinity(0, sizeof(saved), &saved);
+    }
+};
+
 struct StageCrew {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;

@@ -711,9 +711,8 @@ struct SlowFirstStore {
             first[i] = f;
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
             uint4 r = node_rec[i];
-            r.y = nr_head(r.y, c, 0xFFu);
-            r.w = f;
-            node_rec[i] = r;
+            const uint32_t y_new = nr_head(r.y, c, 0xFFu);
+            if (r.y != y_new || r.w != f) { r.y = y_new; r.w = f; node_rec[i] = r; }
         }
     }
 };
@@ -730,9 +729,8 @@ struct TrioFirstStore {
         if (i < V && c) {
             if (c >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
             uint4 r = node_rec[i];
-            r.y = nr_head(r.y, c, 0xFFu);                    // this route does not compute the pair filter
-            r.w = excl;
-            node_rec[i] = r;
+            const uint32_t y_new = nr_head(r.y, c, 0xFFu);   // this route does not compute the pair filter
+            if (r.y != y_new || r.w != excl) { r.y = y_new; r.w = excl; node_rec[i] = r; }
         }
     }
 };
@@ -799,9 +797,8 @@ __global__ void __launch_bounds__(256) group_tile_prefix_kernel(const unsigned l
 __device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, uint32_t v, uint32_t row, uint32_t cnt, uint32_t filter, uint32_t *__restrict__ err) {
     if (cnt >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
     uint4 r = node_rec[v];
-    r.y = nr_head(r.y, cnt, filter);
-    r.w = row;
-    node_rec[v] = r;
+    const uint32_t y_new = nr_head(r.y, cnt, filter);
+    if (r.y != y_new || r.w != row) { r.y = y_new; r.w = row; node_rec[v] = r; }   // (stored only where it is not there yet: see trio_rows_kernel)
 }
 // a group with more than VIS_REC unique visits (a stretch of private sequence; every group of a single-strain species): the whole wave
 // reads the group's visits again, ranks the unique ones, and files them like the records
@@ -928,10 +925,12 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
             const int end = stop ? __builtin_ctzll(stop) : (lane & ~7) + 8;
             const uint32_t rows = (uint32_t)(end - lane);
             if (rows >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+            // the head of a node is a function of the graphs alone: every rebuild computes it again, and STORES it only where the record does
+            // not hold it yet (the first build of a db) -- a 16-byte store into a line of eight records dirties a 64-byte sector, and the heads
+            // of 1e4 strains were 4.5 of the 7.4 GB this kernel wrote per build (`r05_pmc_trio_probe`)
             uint4 nr = nrv[u];
-            nr.y = nr_head(nr.y, rows, filt);
-            nr.w = row[u];
-            node_rec[rec[u].w] = nr;
+            const uint32_t y_new = nr_head(nr.y, rows, filt);
+            if (nr.y != y_new || nr.w != row[u]) { nr.y = y_new; nr.w = row[u]; node_rec[rec[u].w] = nr; }
         }
     }
     // the groups of this wave with more unique visits than records, one after the other
