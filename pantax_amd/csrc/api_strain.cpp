@@ -90,6 +90,8 @@ int fetch_arena_wait(Ctx *ctx, Db *db, LadBatch &lb, const ArenaLayout &L, Strai
     r.counts = (const uint32_t *)(b + L.counts);
     r.nnz = (const uint32_t *)(b + L.nnz); r.hap_bit = (const int32_t *)(b + L.hap_bit);
     r.fixed2 = b + L.fixed2; r.need2 = b + L.need2;
+    if (r.counts[3]) return fail(ctx, PANTAX_HIP_E_STATE, "strain step: %u problems in the kernels that built the unique-trio index this step read (visit groups out of order, "
+                                                           "or group offsets that are not this visit table's)", r.counts[3]);
     if (r.counts[2]) return fail(ctx, PANTAX_HIP_E_LIMIT, "strain step: more than %u membership patterns (internal: the pattern tables hold one entry per node)", lb.k_cap);
     return 0;
 }
@@ -131,6 +133,10 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
             std::fprintf(stderr, "\n");
         } } } slow_report{marks, &n_marks, ctx->cfg.trace};
     PTX_TRY(bind_arena(ctx, db, lb, L));
+    // the error word of the index build this step reads (a REBUILD does not wait for the host: its kernels' complaints -- a visit group out of order,
+    // group offsets that are not this table's -- come back with the step's results); taken here, before the next step's rebuild may clear it
+    if (db->trio_scratch.d_tot.p)
+        PTX_HIP(ctx, hipMemcpyAsync(lb.d_counts.p + 3, db->trio_scratch.d_tot.p + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     mark();
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     mark();

@@ -139,9 +139,10 @@ struct CtxConfig {
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
-    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0, cov_trio_win = 0;
+    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
     uint32_t ssg_wave_rows = 0;
+    bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)
     bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
          trio_after_step = false;
 };
@@ -288,7 +289,9 @@ struct TrioScratch {
     // rows filed from the visit kernel's records (the species the visit table covers)
     DevBuf<uint64_t> vis_uq;       // [n_vgroups + 1] ballot of the unique visits of every group
     DevBuf<uint4> vis_rec;         // [n_vgroups * 8] the first eight unique windows of every group {window start, smaller end, larger end, middle}
-    DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = row of its first unique window
+    DevBuf<uint32_t> gprefix;      // [n_vgroups + 1] unique visits before the group = row of its first unique window; a function of the graphs alone: the first build's
+                                   // values stay with the visit table and let later builds file in one pass (verified there)
+    uint32_t gprefix_for = 0;      // the number of groups gprefix was computed for (0: not yet)
     DevBuf<uint32_t> group_sums;   // unique visits per tile of 4096 groups, then their prefix (group_tile_* kernels)
     DevBuf<uint32_t> hap_cnt;      // [H] first build of a db: rows per haplotype (-> hap_trio_off)
 };

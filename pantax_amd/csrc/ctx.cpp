@@ -95,11 +95,11 @@ struct OptDesc { const char *name; OptKind kind; size_t off; };
 #define OPT(nm, kind, field) {nm, kind, offsetof(CtxConfig, field)}
 const OptDesc OPTIONS[] = {
     OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind),
-    OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("uniq_hash", O_INT, uniq_hash),
+    OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("trio_two_pass", O_BOOL, trio_two_pass), OPT("uniq_hash", O_INT, uniq_hash),
     OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
-    OPT("covf_shape", O_INT, covf_shape), OPT("cov_trio_win", O_INT, cov_trio_win), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
+    OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
     OPT("cov_ablate", O_U32, cov_ablate), OPT("ssg_wave_rows", O_U32, ssg_wave_rows), OPT("ssn_debug", O_BOOL, ssn_debug),
     OPT("scan_no_huge", O_BOOL, scan_no_huge), OPT("flag_rank_chained", O_BOOL, flag_rank_chained), OPT("ratio_kernel", O_BOOL, ratio_kernel),
     OPT("mask_pass", O_BOOL, mask_pass), OPT("trio_free_at_filter", O_BOOL, trio_free_at_filter), OPT("trio_after_step", O_BOOL, trio_after_step),
@@ -503,6 +503,7 @@ int upload_staged_pieces(Ctx *ctx, const UploadPiece *pieces, size_t n_pieces, i
     uint64_t CH = ctx->cfg.stage_ch_mb > 0 ? (uint64_t)ctx->cfg.stage_ch_mb << 20
                                            : std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
     if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH && ctx->cfg.stage_ch_mb <= 0) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
+    NumaBind numa_bind(ctx, true);   // the ring's pages, this thread and the crew it starts: on the GPU's NUMA node until the upload is over
     PTX_HIP(ctx, ring.reserve(SLOTS * CH));
     // 32 threads: at 16 the crew, not the DMA, bounds a 15-GB load (filling 413 of 420 ms = 37 GB/s of pread; 32: 211 of 293 ms = 52 GB/s,
     // 0.92 of the pinned copy rate); 48 and 64 fill no faster and slow the copies down (390 ms)
@@ -542,8 +543,8 @@ int upload_staged_pieces(Ctx *ctx, const UploadPiece *pieces, size_t n_pieces, i
     if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     if (trace)
         std::fprintf(stderr, "[upload_staged] %.1f MB in %.2f ms (%.1f GB/s): %zu piece(s), %llu chunks of %.0f MB, %d threads; waiting for a piece buffer %.2f, for a slot %.2f, "
-                     "filling %.2f, enqueue %.2f, drain %.2f ms\n", total / 1e6, ms(t_begin, now()), total / 1e6 / ms(t_begin, now()), n_pieces,
-                     (unsigned long long)i, CH / 1048576.0, nth, t_gate, t_wait, t_fill, t_enq, ms(t4, now()));
+                     "filling %.2f, enqueue %.2f, drain %.2f ms; NUMA node %d (%s)\n", total / 1e6, ms(t_begin, now()), total / 1e6 / ms(t_begin, now()), n_pieces,
+                     (unsigned long long)i, CH / 1048576.0, nth, t_gate, t_wait, t_fill, t_enq, ms(t4, now()), ctx->numa.node, numa_bind.bound ? "bound" : "not bound");
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }
@@ -634,6 +635,7 @@ int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs,
     PinBuf &ring = ctx->pin_text;
     uint64_t CH = std::min<uint64_t>(64ull << 20, std::max<uint64_t>(4ull << 20, ((total / 6) + (1 << 20) - 1) & ~(uint64_t)((1 << 20) - 1)));
     if (ring.n >= SLOTS * (4ull << 20) && ring.n / SLOTS > CH) CH = std::min<uint64_t>(64ull << 20, (ring.n / SLOTS) & ~(uint64_t)((1 << 20) - 1));   // a larger ring is there already
+    NumaBind numa_bind(ctx, true);   // the ring's pages, this thread and the crew it starts: on the GPU's NUMA node until the upload is over
     PTX_HIP(ctx, ring.reserve(SLOTS * CH));
     const int nth = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, std::min(ctx->cfg.stage_threads, (int)std::thread::hardware_concurrency() / 2)), CH >> 20));
     StageCrew crew(nth);

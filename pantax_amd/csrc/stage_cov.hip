@@ -65,10 +65,6 @@ extern __shared__ uint32_t s_cov[];
 #define S_BM(bmo, i) s_cov[(bmo) + (i)]
 #define S_FULL(bmo, i) reinterpret_cast<uint8_t *>(s_cov + (bmo) + COV_BWIN)[(i)]
 __host__ __device__ constexpr size_t cov_lds_bytes(int win) { return (size_t)win * 4 + COV_BWIN * 4 + (size_t)win; }
-// the short-read kernel may add a window over the rows of the unique-trio index (round 5: rows are numbered node after node, so the rows
-// of the nodes of a workgroup's window are one stretch of TWIN rows from the first row of its first nodes): [TWIN u32 trio_bases][1 u32]
-#define S_TRIO(win, i) s_cov[(win) + COV_BWIN + (win) / 4 + (i)]
-__host__ __device__ constexpr size_t covf_lds_bytes(int win, int twin) { return cov_lds_bytes(win) + (twin ? (size_t)twin * 4 + 4 : 0); }
 __device__ __forceinline__ void lds_or(uint32_t *__restrict__ bm, uint32_t bmo, uint64_t bw0, uint32_t bwn, uint64_t w, uint32_t m) {
     const uint64_t off = w - bw0;     // unsigned wrap: words below the window are out of range too
     if (off < bwn) {
@@ -178,7 +174,7 @@ __device__ __forceinline__ void mark_full_wave(uint32_t *__restrict__ full, uint
 // covered block is simply cut into more items.)
 constexpr uint32_t COV_ITEM_GROUPS = 64;
 constexpr int COV_BLK_SHIFT = 11;
-template <bool WITH_TRIO, int U, int PASSES, int WIN, int TWIN>
+template <bool WITH_TRIO, int U, int PASSES, int WIN>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
@@ -189,7 +185,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint2 item = items[blockIdx.x];
     const uint32_t g0 = item.x, n_groups = item.y;                            // this workgroup's groups [g0, n_groups)
-    for (int i = threadIdx.x; i < (int)(covf_lds_bytes(WIN, WITH_TRIO ? TWIN : 0) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the windows, one block
+    for (int i = threadIdx.x; i < (int)(cov_lds_bytes(WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the three windows, one block
     // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
     uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
     uint64_t bw0 = 0;
@@ -218,22 +214,6 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    // the row window: rows are numbered node after node (256-node chunks of the visit table), so the unique-trio rows of this window's nodes
-    // start at the smallest first row among the heads of its first 256 nodes; the adds of the workgroup's reads meet in LDS and leave as one
-    // memory-side add per touched row (7.8e7 of them at 1e4 strains: a read depth of adds per row before)
-    uint32_t trow0 = 0xFFFFFFFFu;
-    if (WITH_TRIO && TWIN) {
-        if (win_n) {
-            const uint64_t vv = (uint64_t)wlo + threadIdx.x;
-            const uint4 hr = node_rec[vv < V ? vv : (uint64_t)wlo];
-            if (nr_rows(hr.y)) atomicMax(&S_TRIO(WIN, TWIN), ~hr.w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        const uint32_t t = S_TRIO(WIN, TWIN);
-        trow0 = t ? ~t : 0xFFFFFFFFu;
-    }
 #pragma unroll 1
     for (int pass = 0;; ++pass) {
         const uint32_t gw = g0 + (uint32_t)((pass * WAVES + wave) * U);     // this wave's U consecutive groups
@@ -349,20 +329,11 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                         if (e.x == tlo[u] && e.y == thi[u]) { row = (long long)hx[u] + j; break; }
                     }
                 const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
-                if (row >= 0 && sum) {
-                    const uint32_t toff = (uint32_t)row - trow0;                 // unsigned wrap: rows below the window are out of range too
-                    if (TWIN && toff < (uint32_t)TWIN && sum < (1ull << 18)) atomicAdd(&S_TRIO(WIN, toff), (uint32_t)sum);   // <= 8192 steps x 2^18 < 2^32
-                    else atomicAdd(&trio_bases[row], sum);
-                }
+                if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
             }
         }
     }
     __syncthreads();
-    if (WITH_TRIO && TWIN && trow0 != 0xFFFFFFFFu)
-        for (int i = threadIdx.x; i < TWIN; i += COV_BLOCK) {
-            const uint32_t c = S_TRIO(WIN, i);
-            if (c) atomicAdd(&trio_bases[(uint64_t)trow0 + i], (unsigned long long)c);
-        }
     if (win_n) {
         for (int i = threadIdx.x; i < WIN; i += COV_BLOCK) {
             const uint32_t c = S_WIN(i);
@@ -1060,17 +1031,14 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
             // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
             int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
-            int twin = ctx->cfg.cov_trio_win;                                 // rows in the LDS window of trio_bases (0: none)
             if (ctx->cfg.covf_shape > 0) fshape = ctx->cfg.covf_shape;
 #define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
             {                                                                                                                            \
                 const int grid = (int)rd->n_items;                                                                                       \
-                if (trio && twin == 2048) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW, 2048>), dim3(grid), dim3(COV_BLOCK), covf_lds_bytes(WW, 2048), ctx->stream, COVF_ARGS); \
-                else if (trio && twin == 1024) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW, 1024>), dim3(grid), dim3(COV_BLOCK), covf_lds_bytes(WW, 1024), ctx->stream, COVF_ARGS); \
-                else if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW, 0>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
-                else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW, 0>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
+                if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
+                else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
             }
             switch (fshape) {                                              // <U><PASSES><window / 1024>
                 case 182: COVF_LAUNCH(1, 8, 2048) break;

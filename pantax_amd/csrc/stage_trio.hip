@@ -945,6 +945,128 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
     }
 }
 
+// ---- REBUILDS of a db whose group offsets are known: uniqueness and filing in ONE pass over the visit table -------------------------------
+// The first row of every group of 64 visits (gprefix) is a function of the graphs alone, like the group boundaries of the visit table themselves:
+// the db's first build learns it (trio_visit_kernel<ROWS> -> prefix of the groups' counts -> trio_rows_kernel) and keeps it with the table.  Every
+// later build -- the per-run rebuild of a resident step, profile.rs:2936 -- decides the uniqueness of every window again and files every row again,
+// in the kernel that took the decision: no records through memory, no scan, no second kernel.  The offsets are VERIFIED on the way: a group whose
+// count of unique visits is not what its neighbours' offsets say raises the error word (it comes back with the step's results).
+// A group holds about five unique visits, so filing from the deciding lanes would run everything behind the decision at a twelfth of the lanes (first
+// version: 14.6 ms at 1e4 strains against 5.6 + 7.0 for the two kernels -- the kernel is bound by VALU issue, 64-lane instructions per group).  Instead
+// every wave QUEUES its unique windows in LDS -- consecutive groups of one species have consecutive rows -- and files the queue on dense lanes, lane =
+// row, whenever the next group would not fit: coalesced stores of 64 consecutive rows, one pass over the species' walk offsets per ~12 groups.
+struct FileQueue {
+    uint4 rec[64];       // {window start, smaller end, larger end, middle} (global node indices), in visit order = row order
+};
+template <bool KEYS>
+__device__ __forceinline__ void trio_file_flush(const FileQueue &qu, uint32_t cnt, uint32_t row0, uint32_t sp, int lane, uint4 *__restrict__ node_rec, const RowOut &o,
+                                                uint32_t *__restrict__ err) {
+    const bool on = (uint32_t)lane < cnt;
+    const uint4 rec = on ? qu.rec[lane] : make_uint4(0u, 0u, 0u, 0xFFFFFFFFu);
+    const uint32_t h0 = (uint32_t)o.hap_off[sp], hs = (uint32_t)o.hap_off[sp + 1] - h0;      // wave-uniform
+    // the owner of a window = the haplotype whose walk holds its start: the species' walk offsets (up to 64) sit one per lane and every lane counts those
+    // at or below its start (trio_rows_kernel)
+    const uint32_t woff = ((uint32_t)lane < hs && hs <= 64u) ? (uint32_t)o.path_off[h0 + (uint32_t)lane] : 0xFFFFFFFFu;   // P < 2^32
+    // first row of its node: the row below belongs to another node (a node's unique visits are neighbours, and groups -- hence queues -- hold whole nodes)
+    const uint32_t below = wave_shr1(rec.w, 0xFFFFFFFFu);
+    const bool first = on && (lane == 0 || below != rec.w);
+    uint32_t len3 = 0;
+    uint4 nrv = make_uint4(0u, 0u, 0u, 0u);
+    if (on) len3 = o.node_len[rec.y] + o.node_len[rec.w] + o.node_len[rec.z];
+    if (first) nrv = node_rec[rec.w];
+    const unsigned long long fm = __ballot(first), om = __ballot(on);
+    uint32_t hl = 0;
+    if (hs <= 64u) { for (uint32_t j = 1; j < hs; ++j) hl += (uint32_t)__builtin_amdgcn_readlane((int)woff, (int)j) <= rec.x ? 1u : 0u; }
+    const uint32_t row = row0 + (uint32_t)lane;
+    if (on) {
+        if (hs > 64u) hl = hap_of_position(o.path_off, h0, h0 + hs, rec.x) - h0;
+        o.ent[row] = make_uint2(rec.y, rec.z);
+        o.put_len_hap(row, len3, hl);
+        if (KEYS) o.q[row] = rec.x;
+    }
+    // the node's rows end at the next first lane; its pair filter = OR of its rows' bits (every first lane walks its span: a handful of lanes)
+    const uint32_t pbit = on ? nr_pair_bit(rec.y, rec.z) : 0u;
+    const unsigned long long nxt = (fm | ~om) & ~((2ull << lane) - 1ull);
+    const int end = nxt ? __builtin_ctzll(nxt) : 64;
+    const unsigned long long span = first ? ((end == 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull)) : 0ull;
+    uint32_t filt = 0u;
+    unsigned long long sp_ = span;
+    while (__any(sp_ != 0ull)) {
+        const int l = sp_ ? __builtin_ctzll(sp_) : 0;
+        const uint32_t ob = __shfl(pbit, l);
+        if (sp_) { filt |= ob; sp_ &= sp_ - 1ull; }
+    }
+    if (first) {
+        const uint32_t rows = (uint32_t)(end - lane);
+        if (rows >= NODE_REC_MAX_ROWS) atomicAdd(err, 1u);
+        uint4 nr = nrv;
+        const uint32_t y_new = nr_head(nr.y, rows, filt);
+        if (nr.y != y_new || nr.w != row) { nr.y = y_new; nr.w = row; node_rec[rec.w] = nr; }   // (stored only where it is not there yet: trio_rows_kernel)
+    }
+}
+template <int U, bool KEYS>
+__global__ void __launch_bounds__(256) trio_file_kernel(uint32_t NG, uint32_t rounds, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
+                                                        const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp, const uint32_t *__restrict__ gprefix,
+                                                        const uint32_t *__restrict__ path_nodes, uint4 *__restrict__ node_rec, RowOut o, uint32_t *__restrict__ err,
+                                                        uint32_t xcd_chunks) {
+    __shared__ FileQueue queues[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    FileQueue &qu = queues[wave];
+    uint32_t blk = blockIdx.x;
+    if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) blk = 0xFFFFFFu; }
+    uint32_t g0 = blk == 0xFFFFFFu ? NG : (blk * 4u + wave) * ((uint32_t)U * rounds);      // this wave's U x rounds consecutive groups
+    uint32_t q_cnt = 0, q_row0 = 0, q_sp = 0;                                              // the queue: entries, row of the first, their species (wave-uniform)
+    for (uint32_t r = 0; r < rounds && g0 < NG; ++r, g0 += U) {
+        uint32_t q[U], nb[U], sp[U], base[U], want[U];
+        uint64_t heads[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + (uint32_t)u < NG ? g0 + (uint32_t)u : g0;   // wave-uniform
+            q[u] = vis_pos[(uint64_t)g * 64 + lane];
+            heads[u] = vis_head[g]; nb[u] = vis_nbase[g]; sp[u] = vis_sp[g];
+            base[u] = gprefix[g]; want[u] = gprefix[g + 1] - base[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // all U table loads leave before the first of them is waited for
+        U32x3 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            valid[u] = g0 + (uint32_t)u < NG && q[u] != VIS_PAD;
+            w[u] = *reinterpret_cast<const U32x3 *>(path_nodes + (valid[u] ? q[u] - 1u : 0u));   // an interior position: p - 1 and p + 1 exist
+        }
+        __builtin_amdgcn_sched_barrier(0);       // ... and all U gathers before the first decision
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // the decision: trio_visit_kernel's
+            const uint32_t lo = min(w[u].x, w[u].z), hi = max(w[u].x, w[u].z);
+            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid[u]);
+            const unsigned long long hd = heads[u] & vmask;
+            const unsigned long long inb = vmask & ~hd;                      // lanes with a lane of their own stretch below them
+            const uint32_t slo = wave_shr1z(lo), shi = wave_shr1z(hi);       // the pair of the lane below (DPP moves)
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(slo == lo && shi == hi) & inb;
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(slo > lo || (slo == lo && shi > hi)) & inb;
+            const unsigned long long dup = eq | (eq >> 1);                   // both partners are not unique
+            const unsigned long long uq = vmask & ~dup;
+            const uint32_t n_g = (uint32_t)__popcll(uq);                     // wave-uniform
+            if (g0 + (uint32_t)u < NG && (bad || n_g != want[u]) && lane == 0) atomicAdd(err, 1u);   // table out of order / offsets that are not this table's
+            if (n_g == 0u) continue;
+            // the queue holds consecutive rows of one species: file it first where this group does not fit behind them
+            if (q_cnt && (q_cnt + n_g > 64u || sp[u] != q_sp || base[u] != q_row0 + q_cnt)) {
+                trio_file_flush<KEYS>(qu, q_cnt, q_row0, q_sp, lane, node_rec, o, err);
+                q_cnt = 0;
+            }
+            if (q_cnt == 0u) { q_row0 = base[u]; q_sp = sp[u]; }
+            if ((uq >> lane) & 1ull) {
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(uq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)uq, 0u));   // unique visits in the lanes below
+                qu.rec[q_cnt + rk] = make_uint4(q[u] - 1u, nb[u] + lo, nb[u] + hi, nb[u] + w[u].y);
+            }
+            q_cnt += n_g;
+        }
+    }
+    if (q_cnt) trio_file_flush<KEYS>(qu, q_cnt, q_row0, q_sp, lane, node_rec, o, err);
+}
+
 // ---- the export order: rows listed in (species, hap, position) order = ascending window start (the walks are one CSR over all haplotypes) ----
 __global__ void __launch_bounds__(256) trio_iota_kernel(uint32_t n, uint32_t *__restrict__ v, const uint32_t *__restrict__ q, unsigned long long *__restrict__ key) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1145,9 +1267,12 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     PTX_HIP(ctx, ts.scan_tmp.alloc(16));
     PTX_HIP(ctx, ts.d_tot.alloc(4));
     PTX_HIP(ctx, hipMemsetAsync(ts.d_tot.p, 0, 4 * sizeof(uint32_t), ctx->stream));   // {-, rows of the fast route, error word of the build kernels, rows of the path route}
-    if (rows_by_visit) {
+    // a rebuild of a db whose group offsets are known: uniqueness and filing of the visit table's species in one pass (trio_file_kernel)
+    const bool fused = rows_by_visit && !first_build && ts.gprefix.p != nullptr && ts.gprefix_for == db->n_vgroups && !ctx->cfg.trio_two_pass;
+    if (rows_by_visit && !fused) {
         PTX_HIP(ctx, ts.vis_uq.alloc(db->n_vgroups + 1)); PTX_HIP(ctx, ts.vis_rec.alloc((uint64_t)db->n_vgroups * VIS_REC));
         PTX_HIP(ctx, ts.gprefix.alloc(db->n_vgroups + 1));
+        ts.gprefix_for = 0;
         PTX_HIP(ctx, hipMemsetAsync(ts.vis_uq.p + db->n_vgroups, 0, sizeof(uint64_t), ctx->stream));   // the closing entry of the count scan
     }
     if (first_build) {
@@ -1159,8 +1284,28 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     const dim3 tgrid((uint32_t)db->n_tiles);
     // trio_xcd: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
     const uint32_t trio_xcd = (uint32_t)ctx->cfg.trio_xcd;
+    if (fused) {
+        PTX_HIP(ctx, db->d_trio_ent.alloc(db->U_known)); PTX_HIP(ctx, db->d_trio_len.alloc(db->U_known));
+#if !TRIO_LH_PACK
+        PTX_HIP(ctx, db->d_trio_hap.alloc(db->U_known));
+#endif
+        if (with_keys) PTX_HIP(ctx, db->d_trio_q.alloc(db->U_known));
+        const RowOut ro0{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, const_cast<uint16_t *>(TRIO_HAP_PTR(db)), db->d_trio_q.p, ts.hap_cnt.p};
+        KTimer t(ctx, "trio_file_kernel");
+        const uint32_t U = (uint32_t)ctx->cfg.tv_u, rounds = (uint32_t)std::max(1, ctx->cfg.tv_rounds);
+#define TF_CHUNKS(UU) ((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds))
+#define TF_LAUNCH(UU, KK) hipLaunchKernelGGL((trio_file_kernel<UU, KK>), dim3((trio_xcd & 1u) ? ((TF_CHUNKS(UU) + 7u) / 8u) * 8u : TF_CHUNKS(UU)), dim3(256), 0, ctx->stream, db->n_vgroups, \
+                                         rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_vis_sp.p, (const uint32_t *)ts.gprefix.p, db->d_path_nodes.p, db->d_node_rec.p, ro0, \
+                                         ts.d_tot.p + 2, (trio_xcd & 1u) ? TF_CHUNKS(UU) : 0u)
+        if (with_keys) { if (U == 2) TF_LAUNCH(2, true); else TF_LAUNCH(4, true); }
+        else { if (U == 2) TF_LAUNCH(2, false); else TF_LAUNCH(4, false); }
+#undef TF_LAUNCH
+#undef TF_CHUNKS
+        // the rows of the fast route (the base of the path route's rows in a mixed db) = the closing entry of the offsets
+        PTX_HIP(ctx, hipMemcpyAsync(ts.d_tot.p + 1, ts.gprefix.p + db->n_vgroups, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     // ---- uniqueness
-    if (P && by_block && db->n_vgroups) {
+    if (P && by_block && db->n_vgroups && !fused) {
         KTimer t(ctx, "trio_visit_kernel");
         // every wave walks U x rounds consecutive groups of 64 visits (tv_u / tv_rounds pick another shape, for
         // measurements): consecutive groups visit consecutive nodes, whose walk entries share cache lines
@@ -1214,7 +1359,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         }
     }
     // ---- sizes: the first row of every group (fast route) and of every node (path route); on a db's first build the totals come back
-    if (rows_by_visit) {
+    if (rows_by_visit && !fused) {
         if (ctx->cfg.flag_rank_chained)
             PTX_TRY(exclusive_scan_fn(ctx, GroupCountLoad{reinterpret_cast<const unsigned long long *>(ts.vis_uq.p)}, PrefixStore{ts.gprefix.p},
                                       (uint64_t)db->n_vgroups + 1, ts.d_tot.p + 1, "scan_chained_kernel<GroupCount>"));
@@ -1255,7 +1400,8 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     if (path_route) PTX_HIP(ctx, ts.row_q.alloc(Utot));
     const RowOut ro{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, const_cast<uint16_t *>(TRIO_HAP_PTR(db)), db->d_trio_q.p, ts.hap_cnt.p};
     // ---- the rows
-    if (rows_by_visit) {
+    if (rows_by_visit && !fused) {
+        ts.gprefix_for = db->n_vgroups;                 // the offsets this launch files by stay with the table: later builds file in one pass (trio_file_kernel)
         KTimer t(ctx, "trio_rows_kernel");
         const uint32_t NG = db->n_vgroups;
         // a wave takes rows_u = 1, 2 or 4 batches of eight groups at once.  Two halve what the kernel waits for memory -- and the step got SLOWER
@@ -1325,6 +1471,8 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         db->trio_sizes_known = true;
         db->trio_layout_fast = rows_by_visit;
+        // later builds file in one pass and need neither the records (16 B x 8 per group: 4.7 GB at 1e4 strains) nor the groups' ballots
+        if (rows_by_visit && !ctx->cfg.trio_two_pass) { ts.vis_rec.release(); ts.vis_uq.release(); }
     }
     db->trio_built = true;
     db->trio_keys_built = with_keys;

@@ -506,12 +506,21 @@ def finalize_many(locals_, species_names_list, hap_names_list, cfg):
     return sr, tr, dict(stats, n_active=n_active)
 
 
-def profile_steps_many(engs, species_names_list, hap_names_list, avg_len_list, n_steps, cfg=None):
+def profile_steps_many(engs, species_names_list, hap_names_list, avg_len_list, n_steps, cfg=None, one_after_the_other=False):
     """n_steps samples over K dbs that share the GPU, one step enqueued ahead on every db (see profile_steps_pipelined) -> list of
-    (species_rows, strain_rows, stats)"""
+    (species_rows, strain_rows, stats).  one_after_the_other: every db's step is collected before the next db's is enqueued -- nothing
+    overlaps, so a per-kernel clock sees every kernel with the GPU to itself (measurements; slower)."""
     cfg = cfg or StepConfig()
     K = len(engs)
     out = []
+    if one_after_the_other:
+        for i in range(n_steps):
+            locals_ = []
+            for k in range(K):
+                local_enqueue(engs[k], avg_len_list[k], cfg)
+                locals_.append(local_stage(engs[k], avg_len_list[k], cfg, "collect"))
+            out.append(finalize_many(locals_, species_names_list, hap_names_list, cfg))
+        return out
     try:
         for k in range(K):
             local_enqueue(engs[k], avg_len_list[k], cfg)

@@ -860,6 +860,38 @@ def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,S,H,every", [(81, 6, 12, 0), (82, 5, 70, 2), (83, 3, 1, 0)])
+def test_rebuild_in_one_pass_files_the_rows_of_the_first_build(eng, seed, S, H, every, set_opt):
+    """The first index build of a db goes visit kernel -> records -> prefix of the groups' counts -> rows kernel and keeps the groups' offsets with
+    the visit table; every later build (a step's rebuild, db_reset + trio_index) decides and files in ONE kernel by those offsets
+    (trio_file_kernel).  Same tables, same step, with and without the window starts (export copies), on a db of one route and of both; the
+    option trio_two_pass sends every build down the first build's road."""
+    from pantax_amd import synth
+    kw = dict(single_strain_every=every) if every else {}
+    sset = synth.make_set(seed, S, H, 40000, 12000, present_frac=0.5, **kw)
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    first = eng.trio_nodes_info()                       # first build (with the export copies)
+    eng.db_reset()
+    again = eng.trio_nodes_info()                       # one pass, with the window starts
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    step1 = eng.profile_step(sset.avg_len())            # one pass, without
+    after = eng.trio_nodes_info()
+    for a, b in zip(first, after):
+        assert np.array_equal(a, b)
+    set_opt(eng, "trio_two_pass", 1)
+    step2 = eng.profile_step(sset.avg_len())
+    two = eng.trio_nodes_info()
+    set_opt(eng, "trio_two_pass", None)
+    for a, b in zip(first, two):
+        assert np.array_equal(a, b)
+    assert bytes(step1[2]) == bytes(step2[2]) and np.array_equal(step1[0], step2[0])
+    step3 = eng.profile_step(sset.avg_len())
+    assert bytes(step3[2]) == bytes(step1[2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,S,H,every", [(71, 4, 80, 2), (72, 5, 70, 3)])
 def test_step_on_a_mixed_database(eng, seed, S, H, every, set_opt):
     """A database that holds species of BOTH kinds -- single-strain species (the visit table's) beside species of 70-80 strains (a node with

@@ -176,3 +176,31 @@ print("rccl route ok")
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "rccl route ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_bench_over_two_gpus_gives_the_one_gpu_tables():
+    """`python bench.py --gpus 2 --workload cfg3` over RCCL on TWO devices (the driver's SCALE run; skipped on a one-GPU box): the species are
+    sharded over the ranks, the reads routed in one all-to-all(v) on device buffers, one all-reduce per step -- and the tables are those of
+    N = 1 (same rows, same top strains), the line says rccl_ranks = 2 and carries the abundance-L1 figure, the route time and the ranks' step
+    times (profile.rs:3297-3319: species are independent; :341, :3198, :3243 the normalisers that cross ranks)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from tests.conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    common = ["--workload", "cfg3", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-gaf", "--no-hard"]
+    lines = []
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    one, two = lines
+    assert two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2
+    assert two["result"]["n_species_rows"] == one["result"]["n_species_rows"] and two["result"]["n_strain_rows"] == one["result"]["n_strain_rows"]
+    for a, b in zip(one["result"]["top_strains"], two["result"]["top_strains"]):
+        assert a[:2] == b[:2] and a[2] == pytest.approx(b[2], rel=1e-9) and a[3] == pytest.approx(b[3], rel=1e-9)
+    assert two["config"]["abundance_l1_vs_oracle"] is not None and two["config"]["abundance_l1_vs_oracle"] <= 1e-4
+    assert two["config"]["ingest_route_ms"] is not None and len(two["config"]["ms_per_step_ranks_min_max"]) == 2
