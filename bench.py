@@ -117,6 +117,11 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # of nodes that head rows is not known to the harness: ~0.14 U at ten strains per species).
         "trio_visit_kernel": 4 * (P * 64 // 60) + 4 * P + 20 * (P // 60) + 16 * U,
         "trio_rows_kernel": 16 * U + 16 * (P // 60) + 12 * U + 14 * U,
+        # trio_file_kernel (every build of a db but its first: decision and filing in one pass): the visit table (4 bytes per visit slot; first-fit
+        # packing: ~1 % pads) + every walk entry once (4P) + per group head mask, node base, species, first row (24 B) + three node lengths per
+        # row (12U) + the rows: entry 8 + length 4 + owner 2 bytes (14U).  The heads' 16-byte node records (read, rewritten only where they differ)
+        # are left out as above.
+        "trio_file_kernel": 4 * (P * 64 // 63) + 4 * P + 24 * (P // 63) + 12 * U + 14 * U,
         # the node-block / bucket / pass-over-the-walks kernels (species the visit table does not cover; forced paths): SURVEY 8d's halves
         "trio_block_kernel": 4 * P + 12 * win,
         "trio_lookup_kernel": 12 * win + 12 * U,
@@ -1151,7 +1156,7 @@ def main():
         # SURVEY 8d's whole-index figure for a7 (2 x 12 x (P - 2H) keys written and read + 12U) against the SUM of the rebuild's kernels (warm-up
         # table): the stage's ruler; the kernels above are measured by the bytes they themselves must move
         if roofline is not None:
-            a7_k = ("trio_visit_kernel", "group_tile_prefix_kernel", "trio_rows_kernel", "trio_block_kernel", "trio_lookup_kernel", "trio_canon_kernel",
+            a7_k = ("trio_file_kernel", "trio_visit_kernel", "group_tile_prefix_kernel", "trio_rows_kernel", "trio_block_kernel", "trio_lookup_kernel", "trio_canon_kernel",
                     "scan_chained_kernel<SlowFirst>", "scan_chained_kernel<TrioFirst>", "scan_chained_kernel<GroupCount>")
             a7_ms = sum(warm[k][1] for k in a7_k if k in warm) / max(n_warm_timed, 1)
             a7_b = 2 * 12 * max(dims["P"] - 2 * dims["H"], 0) + 12 * n_unique

@@ -241,7 +241,7 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     PTX_TRY(node_haps_build(ctx, db.get()));
     lap("node -> haplotypes");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
-    PTX_HIP(ctx, db->d_trio_ent.alloc(1));
+    PTX_HIP(ctx, db->d_trio_ent.alloc(2));
     PTX_HIP(ctx, db->d_trio_bases.alloc(1));
     PTX_HIP(ctx, db->d_active.alloc(S));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope

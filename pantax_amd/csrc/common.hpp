@@ -139,7 +139,7 @@ struct CtxConfig {
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
-    int tv_u = 4, tv_rounds = 4, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
+    int tv_u = 4, tv_rounds = 4, tf_u = 4, tf_rounds = 2, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
     uint32_t ssg_wave_rows = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)

@@ -173,6 +173,7 @@ __device__ __forceinline__ void mark_full_wave(uint32_t *__restrict__ full, uint
 // atomic: 3.3 of the kernel's 10.6 ms at 1e4 strains.  By node block the windows cover the block whatever the depth, and a deeply
 // covered block is simply cut into more items.)
 constexpr uint32_t COV_ITEM_GROUPS = 64;
+struct __attribute__((packed, aligned(4))) EntPair { uint32_t a, b, c, d; };     // two neighbouring lookup entries {smaller end, larger end}
 constexpr int COV_BLK_SHIFT = 11;
 template <bool WITH_TRIO, int U, int PASSES, int WIN>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
@@ -278,8 +279,10 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                 tlo[u] = min(v[u], v2); thi[u] = max(v[u], v2);
                 // the node's pair filter: a window whose bit is clear is not among its rows -- nothing is fetched for it
                 nh[u] = (live[u] && i_[u] >= 2u && (nr_filter(hy1) & nr_pair_bit(tlo[u], thi[u]))) ? nr_rows(hy1) : 0u;
-                e0[u] = trio_ent[nh[u] ? hx[u] : 0u];
-                e1[u] = trio_ent[nh[u] > 1u ? hx[u] + 1u : 0u];
+                // the head's first TWO entries in one 16-byte load (entries are 8 bytes since round 5; the pair is dword-aligned, and the array has one
+                // entry of slack behind its last row)
+                const EntPair ep = *reinterpret_cast<const EntPair *>(trio_ent + (nh[u] ? hx[u] : 0u));
+                e0[u] = make_uint2(ep.a, ep.b); e1[u] = make_uint2(ep.c, ep.d);
             }
         }
         // ---- per group: aligned lengths and the updates
@@ -486,8 +489,10 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
                 if (lane >= 1) th[u].x = tf1;
                 else { const uint4 r1 = node_rec[v1[u]]; th[u].x = r1.w; hy = r1.y; }   // wave border of a long walk
                 th[u].y = (nr_filter(hy) & nr_pair_bit(tlo[u], thi[u])) ? nr_rows(hy) : 0u;   // the pair filter: nothing is fetched for a window whose bit is clear
-                if (th[u].y) e0[u] = trio_ent[th[u].x];
-                if (th[u].y > 1) e1[u] = trio_ent[th[u].x + 1];
+                if (th[u].y) {
+                    const EntPair ep = *reinterpret_cast<const EntPair *>(trio_ent + th[u].x);   // two entries, one load (one entry of slack behind the last row)
+                    e0[u] = make_uint2(ep.a, ep.b); e1[u] = make_uint2(ep.c, ep.d);
+                }
             }
             // first node length: from the lane that holds step b, else (long walk) noted by walk_sum_kernel
             const uint32_t nl_src = __shfl(nr[u].z, lane - dist[u]);

@@ -500,20 +500,23 @@ __global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *
     const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
     const bool valid = q != VIS_PAD;
     uint32_t lo = 0, hi = 0;
-    if (valid) { const uint32_t a = path_nodes[q - 1], c = path_nodes[q + 1]; lo = min(a, c); hi = max(a, c); }
+    if (valid) { const U32x3 w = *reinterpret_cast<const U32x3 *>(path_nodes + (q - 1u)); lo = min(w.x, w.z); hi = max(w.x, w.z); }
     const unsigned long long vmask = __ballot(valid), hd = vis_head[g] & vmask;
     const unsigned long long he = hd | (~vmask & (vmask + 1ull));
     const unsigned long long upto = hd & ((2ull << lane) - 1ull), above = he & ~((2ull << lane) - 1ull);
     const int start = upto ? 63 - __builtin_clzll(upto) : lane, end = above ? __builtin_ctzll(above) : 64;
     int rank = 0;
+    // every pair of a stretch is compared ONCE, by its upper lane (positions are distinct: the order is total and strict); the lower lane reads the
+    // outcome from the ballot -- three shuffles per distance instead of six (28.8 ms at 1e4 strains, 213 ms per db at fifty strains per species before)
     for (int d = 1; d < 64; ++d) {
-        const bool dn = valid && lane - d >= start, up = valid && lane + d < end;
-        if (!__any(dn || up)) break;
-        const int ld = (lane - d) & 63, lu = (lane + d) & 63;
+        const bool dn = valid && lane - d >= start;
+        if (!__any(dn)) break;
+        const int ld = (lane - d) & 63;
         const uint32_t alo = __shfl(lo, ld), ahi = __shfl(hi, ld), aq = __shfl(q, ld);
-        const uint32_t blo = __shfl(lo, lu), bhi = __shfl(hi, lu), bq = __shfl(q, lu);
-        if (dn && (alo < lo || (alo == lo && (ahi < hi || (ahi == hi && aq < q))))) ++rank;
-        if (up && (blo < lo || (blo == lo && (bhi < hi || (bhi == hi && bq < q))))) ++rank;
+        const bool below_first = alo < lo || (alo == lo && (ahi < hi || (ahi == hi && aq < q)));
+        const unsigned long long mine_first = __ballot(dn && !below_first);      // bit l: lane l sorts before its partner l - d
+        if (dn && below_first) ++rank;
+        if (valid && lane + d < end && ((mine_first >> ((lane + d) & 63)) & 1ull)) ++rank;
     }
     if (valid) vis_pos[(uint64_t)g * 64 + start + rank] = q;   // every lane holds its value already: the stretch is rewritten in place
 }
@@ -575,13 +578,26 @@ struct RowOut {
 #endif
     }
 };
+// FIRST builds count the rows per haplotype.  One memory-side atomic per row on the ten counters of the species every wave of the GPU is filing at that
+// moment took 104 ms at 1e4 strains (1.8e8 adds on 1e4 addresses, `r05_cfg4_kernel_stats`): a workgroup of the rows kernel counts in an LDS window of
+// 1024 haplotypes from the species of its first group on (groups are in species order) and adds what it counted once, at its end.
+constexpr uint32_t HAPCNT_WIN = 1024;
+struct HapCount {
+    uint32_t *lds;       // [HAPCNT_WIN] or null: straight to memory
+    uint32_t base;       // global haplotype of lds[0]
+    uint32_t *glob;
+    __device__ __forceinline__ void add(uint32_t h) const {
+        const uint32_t rel = h - base;
+        if (lds && rel < HAPCNT_WIN) atomicAdd(&lds[rel], 1u); else atomicAdd(&glob[h], 1u);
+    }
+};
 template <bool KEYS, bool FIRST>
-__device__ __forceinline__ void row_file(const RowOut &o, uint32_t row, uint32_t q0, uint32_t lo, uint32_t hi, uint32_t mid, uint32_t sp) {
+__device__ __forceinline__ void row_file(const RowOut &o, uint32_t row, uint32_t q0, uint32_t lo, uint32_t hi, uint32_t mid, uint32_t sp, const HapCount &hc) {
     const uint32_t h0 = (uint32_t)o.hap_off[sp], h = hap_of_position(o.path_off, h0, (uint32_t)o.hap_off[sp + 1], q0);
     o.ent[row] = make_uint2(lo, hi);
     o.put_len_hap(row, o.node_len[lo] + o.node_len[mid] + o.node_len[hi], h - h0);
     if (KEYS) o.q[row] = q0;
-    if (FIRST) atomicAdd(&o.hap_cnt[h], 1u);
+    if (FIRST) hc.add(h);
 }
 
 // ---- PATH ROUTE: rows filed by a pass over the walks (species the visit table leaves to the node-block kernel; whole databases on the
@@ -668,7 +684,7 @@ __global__ void __launch_bounds__(256) trio_canon_kernel(uint64_t V, uint32_t S,
     }
     for (uint32_t i = 0; i < n; ++i) {
         const uint2 e = o.ent[f + i];
-        row_file<KEYS, FIRST>(o, f + i, row_q[f + i], e.x, e.y, (uint32_t)v, sp);
+        row_file<KEYS, FIRST>(o, f + i, row_q[f + i], e.x, e.y, (uint32_t)v, sp, HapCount{nullptr, 0u, o.hap_cnt});
     }
 }
 
@@ -805,7 +821,8 @@ __device__ __forceinline__ void trio_head_store(uint4 *__restrict__ node_rec, ui
 template <bool KEYS, bool FIRST>
 __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
                                                 const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
-                                                const uint32_t *__restrict__ path_nodes, uint4 *__restrict__ node_rec, const RowOut &o, uint32_t *__restrict__ err) {
+                                                const uint32_t *__restrict__ path_nodes, uint4 *__restrict__ node_rec, const RowOut &o, uint32_t *__restrict__ err,
+                                                const HapCount &hc) {
     const unsigned long long uq = vis_uq[g];
     const uint32_t nb = vis_nbase[g], sp = vis_sp[g], base = gprefix[g];
     const bool mine = (uq >> lane) & 1ull;
@@ -821,7 +838,7 @@ __device__ __forceinline__ void trio_rows_group(uint32_t g, int lane, const unsi
     const uint32_t prev_w = __shfl(rec.w, lower ? 63 - __builtin_clzll(lower) : lane);
     const bool first = mine && (!lower || prev_w != rec.w);
     const unsigned long long fm = __ballot(first);
-    if (mine) row_file<KEYS, FIRST>(o, base + r, rec.x, rec.y, rec.z, rec.w, sp);
+    if (mine) row_file<KEYS, FIRST>(o, base + r, rec.x, rec.y, rec.z, rec.w, sp, hc);
     // the node's rows end at the next first lane; its pair filter = OR of the bits of its unique lanes (every first lane walks its span: a node's
     // unique visits, a handful; all lanes reach the shuffles)
     const uint32_t pbit = mine ? nr_pair_bit(rec.y, rec.z) : 0u;
@@ -844,11 +861,21 @@ template <bool KEYS, bool FIRST, int U>
 __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsigned long long *__restrict__ vis_uq, const uint32_t *__restrict__ gprefix,
                                                         const uint4 *__restrict__ vis_rec, const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
                                                         const uint32_t *__restrict__ vis_pos, const uint32_t *__restrict__ path_nodes,
-                                                        uint4 *__restrict__ node_rec, RowOut o, uint32_t *__restrict__ err, uint32_t xcd_chunks) {
+                                                        uint4 *__restrict__ node_rec, RowOut o, uint32_t *__restrict__ err, uint32_t xcd_chunks, uint32_t iters) {
     static_assert(VIS_REC == 8, "eight lanes per group");
     const int lane = threadIdx.x & 63;
-    uint32_t blk = blockIdx.x;          // xcd_chunks != 0: every XCD files one contiguous eighth of the groups (see trio_visit_kernel)
-    if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) return; }
+    // FIRST builds: a workgroup takes `iters` consecutive chunks and counts the rows per haplotype in LDS (HapCount)
+    __shared__ uint32_t s_hapcnt[FIRST ? HAPCNT_WIN : 1];
+    HapCount hc{nullptr, 0u, o.hap_cnt};
+    if (FIRST) {
+        for (uint32_t i = threadIdx.x; i < HAPCNT_WIN; i += blockDim.x) s_hapcnt[i] = 0u;
+        const uint32_t gfirst = blockIdx.x * iters * 32u * (uint32_t)U;
+        hc.lds = s_hapcnt; hc.base = (uint32_t)o.hap_off[vis_sp[gfirst < NG ? gfirst : NG - 1u]];
+        __syncthreads();
+    }
+    for (uint32_t it = 0; it < iters; ++it) {
+    uint32_t blk = blockIdx.x * iters + it;          // xcd_chunks != 0 (rebuilds, iters == 1): every XCD files one contiguous eighth of the groups (see trio_visit_kernel)
+    if (xcd_chunks) { blk = (blockIdx.x & 7u) * ((xcd_chunks + 7u) / 8u) + (blockIdx.x >> 3); if (blk >= xcd_chunks) break; }
     const uint32_t r = (uint32_t)lane & 7u;
     uint32_t g[U], cnt[U], row[U], sp[U];
     // ---- level 1: the groups' counts, first rows and species
@@ -909,7 +936,7 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
             o.ent[row[u]] = make_uint2(rec[u].y, rec[u].z);
             o.put_len_hap(row[u], len3[u], hl);
             if (KEYS) o.q[row[u]] = rec[u].x;
-            if (FIRST) atomicAdd(&o.hap_cnt[hb + hl], 1u);
+            if (FIRST) hc.add(hb + hl);
         }
         // the pair filter of a node = OR of its rows' bits: the rows of a node are neighbouring lanes (at most eight)
         const uint32_t pbit = on[u] ? nr_pair_bit(rec[u].y, rec[u].z) : 0u;
@@ -940,8 +967,13 @@ __global__ void __launch_bounds__(256) trio_rows_kernel(uint32_t NG, const unsig
         while (ov) {
             const int l = __builtin_ctzll(ov);
             ov &= ov - 1ull;
-            trio_rows_group<KEYS, FIRST>(g[u] - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, vis_sp, path_nodes, node_rec, o, err);
+            trio_rows_group<KEYS, FIRST>(g[u] - ((uint32_t)lane >> 3) + ((uint32_t)l >> 3), lane, vis_uq, gprefix, vis_pos, vis_nbase, vis_sp, path_nodes, node_rec, o, err, hc);
         }
+    }
+    }   // iters
+    if (FIRST) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < HAPCNT_WIN; i += blockDim.x) { const uint32_t c = s_hapcnt[i]; if (c) atomicAdd(&o.hap_cnt[hc.base + i], c); }
     }
 }
 
@@ -1285,20 +1317,23 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     // trio_xcd: bit 0 the visit kernel, bit 1 the rows kernel take their workgroups in XCD-contiguous chunks (measurements)
     const uint32_t trio_xcd = (uint32_t)ctx->cfg.trio_xcd;
     if (fused) {
-        PTX_HIP(ctx, db->d_trio_ent.alloc(db->U_known)); PTX_HIP(ctx, db->d_trio_len.alloc(db->U_known));
+        PTX_HIP(ctx, db->d_trio_ent.alloc(db->U_known + 1)); PTX_HIP(ctx, db->d_trio_len.alloc(db->U_known));   // (+ 1: the coverage pass loads entries in pairs)
 #if !TRIO_LH_PACK
         PTX_HIP(ctx, db->d_trio_hap.alloc(db->U_known));
 #endif
         if (with_keys) PTX_HIP(ctx, db->d_trio_q.alloc(db->U_known));
         const RowOut ro0{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, const_cast<uint16_t *>(TRIO_HAP_PTR(db)), db->d_trio_q.p, ts.hap_cnt.p};
         KTimer t(ctx, "trio_file_kernel");
-        const uint32_t U = (uint32_t)ctx->cfg.tv_u, rounds = (uint32_t)std::max(1, ctx->cfg.tv_rounds);
+        // U groups in flight x `rounds` rounds per wave (tf_u / tf_rounds pick another shape, for measurements).  Two rounds, where the visit kernel of
+        // the first build takes four: 7.1 against 8.6 ms at 1e4 strains, 5.3 against 5.9 at the fifty-strain share (a wave that is filing its queue
+        // has no loads in flight; shorter waves, more of them in turn)
+        const uint32_t U = (uint32_t)ctx->cfg.tf_u, rounds = (uint32_t)std::max(1, ctx->cfg.tf_rounds);
 #define TF_CHUNKS(UU) ((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds))
 #define TF_LAUNCH(UU, KK) hipLaunchKernelGGL((trio_file_kernel<UU, KK>), dim3((trio_xcd & 1u) ? ((TF_CHUNKS(UU) + 7u) / 8u) * 8u : TF_CHUNKS(UU)), dim3(256), 0, ctx->stream, db->n_vgroups, \
                                          rounds, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p, db->d_vis_sp.p, (const uint32_t *)ts.gprefix.p, db->d_path_nodes.p, db->d_node_rec.p, ro0, \
                                          ts.d_tot.p + 2, (trio_xcd & 1u) ? TF_CHUNKS(UU) : 0u)
-        if (with_keys) { if (U == 2) TF_LAUNCH(2, true); else TF_LAUNCH(4, true); }
-        else { if (U == 2) TF_LAUNCH(2, false); else TF_LAUNCH(4, false); }
+        if (with_keys) { if (U == 2) TF_LAUNCH(2, true); else if (U == 8) TF_LAUNCH(8, true); else TF_LAUNCH(4, true); }
+        else { if (U == 2) TF_LAUNCH(2, false); else if (U == 8) TF_LAUNCH(8, false); else TF_LAUNCH(4, false); }
 #undef TF_LAUNCH
 #undef TF_CHUNKS
         // the rows of the fast route (the base of the path route's rows in a mixed db) = the closing entry of the offsets
@@ -1392,7 +1427,7 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
     }
     const uint32_t Utot = (uint32_t)db->U_known;
     db->U = Utot;
-    PTX_HIP(ctx, db->d_trio_ent.alloc(Utot)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));
+    PTX_HIP(ctx, db->d_trio_ent.alloc((size_t)Utot + 1)); PTX_HIP(ctx, db->d_trio_len.alloc(Utot));   // (+ 1: the coverage pass loads entries in pairs)
 #if !TRIO_LH_PACK
     PTX_HIP(ctx, db->d_trio_hap.alloc(Utot));
 #endif
@@ -1409,9 +1444,12 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         uint32_t RU = (uint32_t)ctx->cfg.rows_u;
         if (RU != 2 && RU != 4) RU = 1;
         const uint32_t rchunks = (NG + 32 * RU - 1) / (32 * RU);
-        const dim3 rgrid((trio_xcd & 2u) ? ((rchunks + 7u) / 8u) * 8u : rchunks);
+        // a first build counts the rows per haplotype: 64 chunks per workgroup share one set of LDS counters (no XCD chunking there)
+        const uint32_t iters = first_build ? 64u : 1u;
+        const bool rxcd = (trio_xcd & 2u) && !first_build;
+        const dim3 rgrid(first_build ? (rchunks + iters - 1) / iters : rxcd ? ((rchunks + 7u) / 8u) * 8u : rchunks);
 #define ROWS_ARGS NG, reinterpret_cast<const unsigned long long *>(ts.vis_uq.p), ts.gprefix.p, ts.vis_rec.p, db->d_vis_nbase.p, db->d_vis_sp.p, db->d_vis_pos.p, \
-                  db->d_path_nodes.p, db->d_node_rec.p, ro, ts.d_tot.p + 2, (trio_xcd & 2u) ? rchunks : 0u
+                  db->d_path_nodes.p, db->d_node_rec.p, ro, ts.d_tot.p + 2, rxcd ? rchunks : 0u, iters
 #define ROWS_LAUNCH(KK, FF, UU) hipLaunchKernelGGL((trio_rows_kernel<KK, FF, UU>), rgrid, dim3(256), 0, ctx->stream, ROWS_ARGS)
 #define ROWS_PICK(KK, FF) { if (RU == 2) ROWS_LAUNCH(KK, FF, 2); else if (RU == 4) ROWS_LAUNCH(KK, FF, 4); else ROWS_LAUNCH(KK, FF, 1); }
         if (with_keys) { if (first_build) ROWS_PICK(true, true) else ROWS_PICK(true, false) }
