@@ -139,7 +139,7 @@ struct CtxConfig {
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
-    int tv_u = 4, tv_rounds = 4, tf_u = 4, tf_rounds = 2, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
+    int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
     uint32_t ssg_wave_rows = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)
@@ -381,6 +381,9 @@ struct Db {
     // per-haplotype statistics by key (hap_trio_stats_launch): the rows of a species are one contiguous block, cut into chunks
     std::vector<uint32_t> h_sp_row_order; // [S] the species in filing order
     DevBuf<uint4> d_stat_chunks;     // {species, first row, end row, first partial} per chunk of rows
+    DevBuf<double> d_hs_x;         // [U] a9 statistics: the non-zero rows' abundances, compacted chunk by chunk (written by pass 0 of every step)
+    DevBuf<uint16_t> d_hs_h;       // [U] ... their owners
+    DevBuf<uint32_t> d_hs_n;       // [n_stat_chunks] ... entries per chunk
     uint32_t n_stat_chunks = 0;
     uint64_t n_stat_partials = 0;    // sum over chunks of the haplotypes of their species
     uint32_t stat_lds_haps = 0;      // most haplotypes of a species whose chunk accumulators live in LDS (65 .. 1024; up to 64: lane registers)

@@ -187,18 +187,26 @@ struct HapAcc { double a; uint32_t c, n; };   // sum, count of the pass, rows se
 template <int PASS>
 __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off, const uint16_t *__restrict__ row_hap,
                                                            const unsigned long long *__restrict__ tb, const trio_len_t *__restrict__ tlen,
-                                                           const double *__restrict__ mean0, const double *__restrict__ sd, HapAcc *__restrict__ part) {
+                                                           const double *__restrict__ mean0, const double *__restrict__ sd, HapAcc *__restrict__ part,
+                                                           double *__restrict__ cx, uint16_t *__restrict__ chh, uint32_t *__restrict__ cn) {
     extern __shared__ HapAcc s_hap_acc[];
+    __shared__ uint32_t s_qrow[128];
+    __shared__ unsigned long long s_qtb[128];
     const uint4 ch = chunks[blockIdx.x];                       // {species, first row, end row, first partial}
     const uint32_t h0 = (uint32_t)hap_off[ch.x], Hs = (uint32_t)hap_off[ch.x + 1] - h0;
     const int lane = threadIdx.x;
+    // Only rows with a NON-ZERO abundance count in any of the three statistics (profile.rs:1129-1133: `> 0.0`), and most rows are zero (the strains that
+    // are not in the sample; a fifth of the rows at the BASELINE configurations).  Pass 0 reads the abundances of all rows (8 bytes each), QUEUES the
+    // non-zero ones in LDS and handles them 64 at a time on dense lanes: length and owner are gathered, the f64 division is done, and {owner, value} go
+    // to the chunk's stretch of a compacted copy -- passes 1 and 2 read that copy alone.  Before: three passes over {8, 4, 2} bytes of every row with a
+    // division per row and pass, bound by VALU issue (184 wave-instructions per 64 rows: 0.8 ms a pass at 1e4 strains).
     // Up to 64 haplotypes per species (every species of the BASELINE configurations): every LANE keeps its own accumulators for a slab of
     // HS_SLAB haplotypes in registers and adds its rows to them by compare-and-select -- no cross-lane traffic and no scalar round trip inside
     // the loop over the rows; the lanes meet once per chunk and slab (DPP reductions, fixed order).  Version 1 of this kernel walked the distinct
     // owners of every 64 rows (readlane -> ballot -> DPP reduction -> owner's lane adds): ~150 cycles of scalar / vector ping-pong per owner,
     // 2.0 ms a pass at 1e4 strains whether the accumulators sat in LDS or in registers (round 4's kernel over contiguous rows: 0.85 ms for
-    // all three).  A species of 17 .. 64 haplotypes reads its rows once per slab.  Mean and sd of pass 0 / 1 ride in lane h and reach a row's
-    // lane by one bpermute.
+    // all three).  A species of 17 .. 64 haplotypes reads its compacted rows once per slab.  Mean and sd of pass 0 / 1 ride in lane h and reach
+    // a row's lane by one bpermute.
     const bool in_reg = Hs <= 64u;
     const bool in_lds = !in_reg && Hs <= HS_LDS_HAPS;
     HapAcc *acc = in_lds ? s_hap_acc : part + ch.w;            // (more than 64 haplotypes: LDS; beyond HS_LDS_HAPS the chunk's own, zero-filled row of partials)
@@ -206,30 +214,56 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
     __syncthreads();
     double my_mean = 0.0, my_sd = 0.0;
     if (in_reg && PASS >= 1 && (uint32_t)lane < Hs) { my_mean = mean0[h0 + lane]; if (PASS == 2) my_sd = sd[h0 + lane]; }
-    auto row_value = [&](uint32_t row, bool valid, uint32_t &h, double &val, bool &flag) {
-        h = 0xFFFFFFFFu;
-        double x = 0.0;
-        if (valid) {
-#if TRIO_LH_PACK
-            const uint2 lh = tlen[row];
-            h = lh.y;
-            x = (double)(long long)tb[row] / (double)lh.x;                    // profile.rs:1013-1014
-#else
-            h = row_hap[row];
-            x = (double)(long long)tb[row] / (double)tlen[row];                // profile.rs:1013-1014
-#endif
-        }
+    uint32_t n_c = PASS == 0 ? 0u : cn[blockIdx.x];           // non-zero rows of the chunk = entries of its compacted stretch [ch.y, ch.y + n_c)
+    // what a compacted entry {h, x > 0} adds in this pass (all lanes come here: the shuffles)
+    auto pass_value = [&](uint32_t h, double x, bool valid, double &val, bool &flag) {
         val = 0.0; flag = false;
-        if (PASS == 0) { if (x > 0.0) { val = x; flag = true; } }                 // :1129-1133
-        else {
-            double m, s_ = 0.0;
-            if (in_reg) { m = __shfl(my_mean, (int)(h & 63u)); if (PASS == 2) s_ = __shfl(my_sd, (int)(h & 63u)); }
-            else { m = valid ? mean0[h0 + h] : 0.0; if (PASS == 2) s_ = valid ? sd[h0 + h] : 0.0; }
-            if (x > 0.0) {
-                if (PASS == 1) { val = (x - m) * (x - m); flag = true; }
-                else if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; }   // :1043-1050
-            }
+        if (PASS == 0) { if (valid) { val = x; flag = true; } return; }             // :1129-1133
+        double m, s_ = 0.0;
+        if (in_reg) { m = __shfl(my_mean, (int)(h & 63u)); if (PASS == 2) s_ = __shfl(my_sd, (int)(h & 63u)); }
+        else { m = valid ? mean0[h0 + h] : 0.0; if (PASS == 2) s_ = valid ? sd[h0 + h] : 0.0; }
+        if (valid) {
+            if (PASS == 1) { val = (x - m) * (x - m); flag = true; }
+            else if (s_ != 0.0 && fabs((x - m) / s_) < 3.0) { val = x; flag = true; }   // :1043-1050
         }
+    };
+    // pass 0: the chunk's rows -> its compacted stretch, every dense batch of up to 64 entries handed to `sink` on the way
+    auto compact_rows = [&](auto &&sink) {
+        uint32_t qh = 0, qn = 0, nw = 0;                       // queue head, entries queued, entries written (wave-uniform)
+        auto drain = [&](uint32_t nb) {
+            const bool v = (uint32_t)lane < nb;
+            const uint32_t row = s_qrow[(qh + (uint32_t)lane) & 127u];
+            const unsigned long long t = s_qtb[(qh + (uint32_t)lane) & 127u];
+            uint32_t h = 0xFFFFFFFFu;
+            double x = 0.0;
+            if (v) {
+#if TRIO_LH_PACK
+                const uint2 lh = tlen[row];
+                h = lh.y;
+                x = (double)(long long)t / (double)lh.x;                       // profile.rs:1013-1014
+#else
+                h = row_hap[row];
+                x = (double)(long long)t / (double)tlen[row];                  // profile.rs:1013-1014
+#endif
+                cx[ch.y + nw + (uint32_t)lane] = x; chh[ch.y + nw + (uint32_t)lane] = (uint16_t)h;
+            }
+            sink(h, x, v);
+            qh = (qh + nb) & 127u; qn -= nb; nw += nb;
+        };
+        for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
+            const uint32_t row = r0 + (uint32_t)lane;
+            const unsigned long long t = row < ch.z ? tb[row] : 0ull;
+            const bool nz = (long long)t > 0;
+            const unsigned long long bal = __ballot(nz);
+            if (nz) {
+                const uint32_t idx = (qh + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) & 127u;
+                s_qrow[idx] = row; s_qtb[idx] = t;
+            }
+            qn += (uint32_t)__popcll(bal);
+            if (qn >= 64u) drain(64u);
+        }
+        if (qn) drain(qn);
+        n_c = nw;
     };
     if (in_reg) {
         for (uint32_t slab = 0; slab * HS_SLAB < Hs; ++slab) {
@@ -237,16 +271,26 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             uint32_t c_[HS_SLAB];
 #pragma unroll
             for (int k = 0; k < HS_SLAB; ++k) { a_[k] = 0.0; c_[k] = 0u; }
-            for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
-                const uint32_t row = r0 + (uint32_t)lane;
-                uint32_t h; double val; bool flag;
-                row_value(row, row < ch.z, h, val, flag);
-                const uint32_t j = h - slab * HS_SLAB;                         // (a lane without a row: no slab holds it)
+            auto sink_reg = [&](uint32_t h, double val, bool flag) {
+                const uint32_t j = h - slab * HS_SLAB;                         // (a lane without an entry: no slab holds it)
 #pragma unroll
                 for (int k = 0; k < HS_SLAB; ++k) {
                     const bool m_ = j == (uint32_t)k;
                     a_[k] += m_ ? val : 0.0;
                     c_[k] += (m_ && flag) ? 1u : 0u;
+                }
+            };
+            if (PASS == 0 && slab == 0) compact_rows([&](uint32_t h, double x, bool v) { sink_reg(h, v ? x : 0.0, v); });
+            else {
+                if (PASS == 0 && slab == 1) __threadfence();                   // the compacted stretch was written by this very wave
+                for (uint32_t r0 = 0; r0 < n_c; r0 += 64) {
+                    const uint32_t i = r0 + (uint32_t)lane;
+                    const bool v = i < n_c;
+                    const uint32_t h = v ? (uint32_t)chh[ch.y + i] : 0xFFFFFFFFu;
+                    const double x = v ? cx[ch.y + i] : 0.0;
+                    double val; bool flag;
+                    pass_value(h, x, v, val, flag);
+                    sink_reg(h, val, flag);
                 }
             }
 #pragma unroll
@@ -257,13 +301,10 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
                 if (lane == 0 && hh < Hs) part[ch.w + hh] = HapAcc{v, c, 0u};
             }
         }
+        if (PASS == 0 && lane == 0) cn[blockIdx.x] = n_c;
         return;
     }
-    for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
-        const uint32_t row = r0 + (uint32_t)lane;
-        const bool valid = row < ch.z;
-        uint32_t h; double val; bool flag;
-        row_value(row, valid, h, val, flag);
+    auto sink_gen = [&](uint32_t h, double val, bool flag, bool valid) {
         unsigned long long todo = __ballot(valid);
         while (todo) {
             const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, __builtin_ctzll(todo));
@@ -274,11 +315,22 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             if (lane == 0) { HapAcc t = acc[hh]; t.a += v; t.c += c; t.n += (uint32_t)__popcll(sel); acc[hh] = t; }
             todo &= ~sel;
         }
-    }
+    };
+    if (PASS == 0) compact_rows([&](uint32_t h, double x, bool v) { sink_gen(h, v ? x : 0.0, v, v); });
+    else
+        for (uint32_t r0 = 0; r0 < n_c; r0 += 64) {
+            const uint32_t i = r0 + (uint32_t)lane;
+            const bool v = i < n_c;
+            const uint32_t h = v ? (uint32_t)chh[ch.y + i] : 0xFFFFFFFFu;
+            const double x = v ? cx[ch.y + i] : 0.0;
+            double val; bool flag;
+            pass_value(h, x, v, val, flag);
+            sink_gen(h, val, flag, v);
+        }
     __syncthreads();
     if (in_lds) for (uint32_t h = lane; h < Hs; h += 64) part[ch.w + h] = acc[h];
+    if (PASS == 0 && lane == 0) cn[blockIdx.x] = n_c;
 }
-// one wave per species: the chunks' partials added in chunk order
 template <int PASS>
 __global__ void __launch_bounds__(64) hap_combine_kernel(const uint32_t *__restrict__ sp_chunk_off, const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off,
                                                          const HapAcc *__restrict__ part, uint32_t *__restrict__ nnz, double *__restrict__ mean0, double *__restrict__ sd,
@@ -339,12 +391,14 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     HapAcc *part = reinterpret_cast<HapAcc *>(dbm->d_hap_part.p);
     double *mean0 = dbm->d_hap_part.p + 2 * (size_t)std::max<uint64_t>(db->n_stat_partials, 1), *sd = mean0 + H;
     const size_t lds = (size_t)db->stat_lds_haps * sizeof(HapAcc);
+    // the compacted copy of the non-zero rows {value, owner}, chunk by chunk in place of the chunk's rows, and its length per chunk
+    PTX_HIP(ctx, dbm->d_hs_x.alloc(std::max<uint64_t>(db->U, 1))); PTX_HIP(ctx, dbm->d_hs_h.alloc(std::max<uint64_t>(db->U, 1))); PTX_HIP(ctx, dbm->d_hs_n.alloc(std::max<uint32_t>(NC, 1)));
     KTimer t(ctx, "hap_rows_pass_kernel");
 #define HS_PASS(PP)                                                                                                                                            \
     if (db->stat_global_rows) PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                            \
     if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
                                TRIO_HAP_PTR(db), (const unsigned long long *)db->d_trio_bases.p, (const trio_len_t *)db->d_trio_len.p,          \
-                               (const double *)mean0, (const double *)sd, part);                                                                               \
+                               (const double *)mean0, (const double *)sd, part, dbm->d_hs_x.p, dbm->d_hs_h.p, dbm->d_hs_n.p);                                  \
     hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(64), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
                        (const uint64_t *)db->d_hap_off.p, (const HapAcc *)part, d_nnz.p, mean0, sd, d_mean.p);
     HS_PASS(0) HS_PASS(1) HS_PASS(2)

@@ -1324,9 +1324,10 @@ int trio_index_build(Ctx *ctx, Db *db, bool with_keys) {
         if (with_keys) PTX_HIP(ctx, db->d_trio_q.alloc(db->U_known));
         const RowOut ro0{db->d_node_len.p, db->d_path_off.p, db->d_hap_off.p, db->d_trio_ent.p, db->d_trio_len.p, const_cast<uint16_t *>(TRIO_HAP_PTR(db)), db->d_trio_q.p, ts.hap_cnt.p};
         KTimer t(ctx, "trio_file_kernel");
-        // U groups in flight x `rounds` rounds per wave (tf_u / tf_rounds pick another shape, for measurements).  Two rounds, where the visit kernel of
-        // the first build takes four: 7.1 against 8.6 ms at 1e4 strains, 5.3 against 5.9 at the fifty-strain share (a wave that is filing its queue
-        // has no loads in flight; shorter waves, more of them in turn)
+        // U groups in flight x `rounds` rounds per wave (tf_u / tf_rounds pick another shape, for measurements).  EIGHT groups per wave, all in flight
+        // at once, where the visit kernel of the first build takes 4 x 4: ms at 1e4 strains / at the fifty-strain share -- 8 x 1: 6.75 / 5.08, 4 x 2: 7.03 /
+        // 5.33, 2 x 4: 7.23, 2 x 3: 7.35, 4 x 4: 8.65 / 5.90, 4 x 3: 8.64, 4 x 1: 8.72 / 7.14, 2 x 1: 11.2 / 9.1 (a wave that is filing its queue has no
+        // loads in flight: short waves, many of them in turn -- but not so short that the queue is filed half empty)
         const uint32_t U = (uint32_t)ctx->cfg.tf_u, rounds = (uint32_t)std::max(1, ctx->cfg.tf_rounds);
 #define TF_CHUNKS(UU) ((db->n_vgroups + 4u * UU * rounds - 1u) / (4u * UU * rounds))
 #define TF_LAUNCH(UU, KK) hipLaunchKernelGGL((trio_file_kernel<UU, KK>), dim3((trio_xcd & 1u) ? ((TF_CHUNKS(UU) + 7u) / 8u) * 8u : TF_CHUNKS(UU)), dim3(256), 0, ctx->stream, db->n_vgroups, \
