@@ -755,9 +755,21 @@ def run_many_dbs(args, spec, local_rank):
 def launch_ranks(n):
     """One node, n ranks: python -m torch.distributed.run ... bench.py <the same arguments>, as a child process."""
     import socket
-    with socket.socket() as sk:                       # a free port for the rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # a free port for the rendezvous.  Bind-then-close leaves a window in which a second bench started at the same moment may be given the same port
+    # (round-4 advisor finding): the port is drawn from this process's own slice of the dynamic range first (pid-keyed), so two launchers only collide
+    # if the kernel hands both the same fallback
+    port = None
+    for k in range(16):
+        cand = 20000 + (os.getpid() * 16 + k) % 40000
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", cand)); port = cand; break
+            except OSError:
+                continue
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)

@@ -251,11 +251,11 @@ int pantax_hip_trio_index_prefetch(pantax_hip_ctx *ctx, pantax_hip_db *db);
 
 /* ---- the device sort of the LP row grouping as a host-buffer utility: rows (k0[i], k1[i], k2[i]) sorted
  * ascending as tuples, in place.  algo: 0 = what the strain step would pick for n rows, 1 = LSD radix sort,
- * 2 = sample sort (n <= 600000), 3 = the batched sort of the many-species step: rows arrive grouped by ascending k0
- * (one segment per k0 value, each <= 600000 rows) and (k1, k2) is sorted inside every segment; 4 = the same straight from the
- * node arrays (segments of any size): an entry whose k1 is 0 or whose k2 is not the bit pattern of a positive double is no row -- the rows come back
+ * 2 = sample sort (n <= 600000), 4 = the batched sort of the many-species step: entries arrive grouped by ascending k0
+ * (one segment per k0 value, of any size), (k1, k2) is sorted inside every segment, straight from the node arrays: an entry
+ * whose k1 is 0 or whose k2 is not the bit pattern of a positive double is no row -- the rows come back
  * sorted in the first entries, the rest of the three arrays is zeroed; 5 = 4 with k1 < 256 and the segment number packed into
- * the mask word on the device (the step's two-word records). */
+ * the mask word on the device (the step's two-word records).  (3, round 3's segmented sort, is gone: PANTAX_HIP_E_INVALID.) */
 int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k0, uint64_t *k1, uint64_t *k2, int algo);
 
 /* filter_max_alignment_mt (gaf_filter.rs:44-97, called by alignment.rs:171 on long-read GAFs): per read id

@@ -13,28 +13,7 @@ extern "C" int pantax_hip_sort_rows(pantax_hip_ctx *ctx, uint64_t n, uint64_t *k
     PTX_ENTER(ctx);
     if (n == 0) return 0;
     if (algo == 2 && n > SS_MAX_N) return fail(ctx, PANTAX_HIP_E_LIMIT, "sort_rows: the sample sort takes at most %llu rows", (unsigned long long)SS_MAX_N);
-    if (algo == 3) {   // segmented: k0 = segment id (rows of a segment adjacent, ids ascending), (k1, k2) sorted inside every segment
-        std::vector<uint32_t> off, cnt;
-        uint64_t bound = 0;
-        for (uint64_t i = 0; i < n;) {
-            uint64_t j = i;
-            while (j < n && k0[j] == k0[i]) ++j;
-            if (j < n && k0[j] < k0[i]) return fail(ctx, PANTAX_HIP_E_INVALID, "sort_rows: algo 3 takes rows grouped by ascending k0");
-            off.push_back((uint32_t)i); cnt.push_back((uint32_t)(j - i));
-            bound = std::max<uint64_t>(bound, j - i);
-            i = j;
-        }
-        DevBuf<uint64_t> a1, a2, b1, b2;
-        DevBuf<uint32_t> d_off, d_cnt, wsb;
-        PTX_TRY(upload(ctx, a1, k1, n)); PTX_TRY(upload(ctx, a2, k2, n));
-        PTX_HIP(ctx, b1.alloc(n)); PTX_HIP(ctx, b2.alloc(n));
-        PTX_TRY(upload(ctx, d_off, off.data(), off.size())); PTX_TRY(upload(ctx, d_cnt, cnt.data(), cnt.size()));
-        PTX_HIP(ctx, wsb.alloc(sample_sort_seg_ws_elems((uint32_t)off.size(), n)));
-        PTX_TRY(sample_sort_seg(ctx, a1.p, a2.p, b1.p, b2.p, (uint32_t)off.size(), bound, n, d_off.p, d_cnt.p, wsb.p));
-        PTX_TRY(download(ctx, k1, a1.p, n)); PTX_TRY(download(ctx, k2, a2.p, n));
-        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return 0;
-    }
+    if (algo == 3) return fail(ctx, PANTAX_HIP_E_INVALID, "sort_rows: algo 3 (round 3's segmented sort) is gone; 4 / 5 are the batched sort of the many-species step");
     if (algo == 4 || algo == 5) {   // the node-order sort: an entry with k1 == 0 or k2 not the bits of a positive double is no row and is dropped
         std::vector<uint32_t> base{0};
         std::vector<uint64_t> seg_val;

@@ -38,16 +38,18 @@ int main(int argc, char **argv) {
     std::string id_file;
     // per-launch nonce of the id file (rccl_comm.hpp): something that changes from one launch to the next where the launcher offers it
     // (torchrun: the run id + the restart count), else the rendezvous port; the file's age is checked in every case
-    uint64_t nonce = getenv("MASTER_PORT") ? strtoull(getenv("MASTER_PORT"), nullptr, 10) : 0;
-    if (const char *rid = getenv("TORCHELASTIC_RUN_ID")) {
+    // (the launcher's variables are read here, once, before any thread exists: the one place the CLI looks at the environment)
+    auto env = [](const char *name) -> const char * { return std::getenv(name); };
+    uint64_t nonce = env("MASTER_PORT") ? strtoull(env("MASTER_PORT"), nullptr, 10) : 0;
+    if (const char *rid = env("TORCHELASTIC_RUN_ID")) {
         uint64_t h = 0xcbf29ce484222325ull;
         for (const char *q = rid; *q; ++q) { h ^= (uint64_t)(unsigned char)*q; h *= 0x100000001b3ull; }
-        if (const char *rc = getenv("TORCHELASTIC_RESTART_COUNT")) h = h * 31 + strtoull(rc, nullptr, 10);
+        if (const char *rc = env("TORCHELASTIC_RESTART_COUNT")) h = h * 31 + strtoull(rc, nullptr, 10);
         nonce ^= h ? h : 1;
     }
-    if (const char *ev = getenv("WORLD_SIZE")) ranks = atoi(ev);
-    if (const char *ev = getenv("RANK")) rank = atoi(ev);
-    if (const char *ev = getenv("LOCAL_RANK")) device = atoi(ev);
+    if (const char *ev = env("WORLD_SIZE")) ranks = atoi(ev);
+    if (const char *ev = env("RANK")) rank = atoi(ev);
+    if (const char *ev = env("LOCAL_RANK")) device = atoi(ev);
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };

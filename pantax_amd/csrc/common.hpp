@@ -121,7 +121,7 @@ struct TimedLaunch {
 
 // Every switch of the library, read ONCE from the environment by pantax_hip_init (PANTAX_<NAME>, upper case) and changed afterwards only
 // through pantax_hip_set_option: no entry point reads the environment on its way (a host that calls setenv / std::env::set_var beside a
-// running step would race with getenv).  Product switches first; the rest selects in-tree HIP paths for tests and measurements.
+// running step would race with a read of the environment).  Product switches first; the rest selects in-tree HIP paths for tests and measurements.
 struct CtxConfig {
     bool trace = false;              // hip_trace: wall time of the phases of the pipeline seam / db upload / GAF load on stderr
     int stage_threads = 32;          // host threads that fill the pinned upload ring (at 16 the filling, not the DMA, bounds a 15-GB load)
@@ -134,14 +134,13 @@ struct CtxConfig {
     std::string trio_rows;           // "path": lookup rows filed by the pass over the walks
     int uniq_hash = -1;              // bucket path: 1 LDS hash / 0 shuffles (-1: by mean bucket size)
     std::string mask;                // "walk": membership masks from the path walk
-    std::string row_sort;            // "radix" / "seg" / "nodes"
+    std::string row_sort;            // "radix" / "nodes"
     std::string objective;           // "nodes": the LP objective summed over the nodes
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
     int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
-    uint32_t ssg_wave_rows = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)
     bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
          trio_after_step = false;
@@ -421,7 +420,7 @@ struct Db {
     bool trio_free_pending = false;      // the event is still to be recorded by lad_prepare, behind the row compaction
     ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); if (ev_trio_free) (void)hipEventDestroy(ev_trio_free); }
     // LP-row staging (lad_prepare)
-    DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws, d_seg;   // d_seg: per-species row counts / cursors / offsets of the segmented row sort
+    DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws;
     DevBuf<uint64_t> d_ka[3], d_kb[3];
     DevBuf<uint64_t> d_row16;   // [4 V] the 16-byte staged and bucketed records of the node-order row sort (sample_sort_nodes.hip)
 };

@@ -100,7 +100,7 @@ const OptDesc OPTIONS[] = {
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
     OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
-    OPT("cov_ablate", O_U32, cov_ablate), OPT("ssg_wave_rows", O_U32, ssg_wave_rows), OPT("ssn_debug", O_BOOL, ssn_debug),
+    OPT("cov_ablate", O_U32, cov_ablate), OPT("ssn_debug", O_BOOL, ssn_debug),
     OPT("scan_no_huge", O_BOOL, scan_no_huge), OPT("flag_rank_chained", O_BOOL, flag_rank_chained), OPT("ratio_kernel", O_BOOL, ratio_kernel),
     OPT("mask_pass", O_BOOL, mask_pass), OPT("trio_free_at_filter", O_BOOL, trio_free_at_filter), OPT("trio_after_step", O_BOOL, trio_after_step),
 };

@@ -44,13 +44,6 @@ constexpr uint64_t SS_MAX_N = 600000;
 size_t sample_sort_ws_elems(uint64_t n_bound);
 int sample_sort3(Ctx *ctx, SortBufs a, SortBufs b, uint64_t n_bound, uint32_t *d_ws, const uint32_t *d_n);
 
-// The same for MANY independent segments in one batch (sample_sort_seg.hip): rows of segment s are
-// [seg_off[s], seg_off[s] + seg_cnt[s]) (device arrays), keys are two words (am, aa), every segment holds at most
-// seg_bound <= SS_MAX_N rows.  Sorted in place; (bm, ba) is scratch.  d_ws: >= sample_sort_seg_ws_elems(S, n_total_bound) u32.
-size_t sample_sort_seg_ws_elems(uint32_t S, uint64_t n_total_bound);
-int sample_sort_seg(Ctx *ctx, uint64_t *am, uint64_t *aa, uint64_t *bm, uint64_t *ba, uint32_t S, uint64_t seg_bound, uint64_t n_total_bound,
-                    const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t *d_ws);
-
 // The batched sort WITHOUT the compaction in front of it (sample_sort_nodes.hip): segment s = the nodes [node_base[s], node_base[s + 1])
 // (at most seg_bound <= SS_MAX_N of them), a node is a row when ab > 0 and mask != 0.  The rows of all segments end up back to back in
 // (ksp, km, ka) -- ksp null: species << pack_shift | mask in km -- every segment sorted by (mask, a); *d_n = their number.

@@ -1,8 +1,8 @@
 // sample_sort_nodes.hip -- the LP rows of MANY species sorted straight from the NODE arrays: no compaction pass.
 //
 // A row of the LP is a node with a_v > 0 and a non-empty membership mask (profile.rs:1380-1385); the solver wants every
-// species' rows ordered by (mask, a).  sample_sort_seg.hip sorts rows that a chained scan has compacted first (16V in,
-// 16n out, one more pass over everything).  Here a species' SEGMENT is its node range [node_base[s], node_base[s+1]) --
+// species' rows ordered by (mask, a).  Round 3 sorted rows that a chained scan had compacted first (16V in, 16n out, one more
+// pass over everything; deleted in round 5).  Here a species' SEGMENT is its node range [node_base[s], node_base[s+1]) --
 // known on the host -- and the sort's own passes skip the nodes that are no rows:
 //   1. ssn_gather / ssn_sample : 4096 evenly spaced nodes of the segment, the rows among them sorted in LDS -> 1023 splitters at even
 //                                ranks of the valid samples, stored as an implicit search tree in breadth-first order (a level's

@@ -884,55 +884,6 @@ __global__ void __launch_bounds__(256) ratio_kernel(const uint32_t *__restrict__
     if ((int)threadIdx.x < 2 * p && acc[threadIdx.x]) atomicAdd(&ratio[2 * hap_off[s] + threadIdx.x], acc[threadIdx.x]);
 }
 
-// The rows in NODE ORDER, hence species by species: an ordered compaction as ONE chained-scan launch (the flag of a node is
-// computed as it is loaded, a row is written at its exclusive prefix), then the segment bounds by binary search over the
-// emitted species keys.  pack_shift >= 0: rows {species << shift | mask, a} in (km, ka); otherwise {species, mask, a} in
-// (ksp, km, ka).  tile_sp (made at upload) = {species of the first node, of the last node} of every 2048-node tile.
-struct RowLoad {
-    const double *ab;
-    const unsigned long long *mask;
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
-        const double a = ab[i];
-        const unsigned long long m = mask[i];   // both loads unconditionally: they are issued together
-        return ((a > 0.0) & (m != 0ull)) ? 1u : 0u;
-    }
-};
-struct RowStore {
-    const double *ab;
-    const unsigned long long *mask;
-    const uint2 *tile_sp;
-    const uint32_t *node_base;
-    uint64_t *ksp, *km, *ka;
-    int pack_shift;
-    __device__ __forceinline__ void operator()(uint64_t i, uint32_t j, uint32_t head) const {
-        if (!head) return;
-        const uint2 t = tile_sp[i >> 11];
-        uint32_t sp = t.x;
-        while (sp < t.y && node_base[sp + 1] <= i) ++sp;          // a species border or two inside the tile
-        const unsigned long long m = mask[i];
-        if (pack_shift >= 0) km[j] = ((uint64_t)sp << pack_shift) | m;
-        else { ksp[j] = sp; km[j] = m; }
-        ka[j] = (uint64_t)__double_as_longlong(ab[i]);            // positive doubles order like their bit patterns
-    }
-};
-__global__ void __launch_bounds__(256) seg_bounds_kernel(uint32_t S, const uint32_t *__restrict__ d_n, const uint64_t *__restrict__ ksp,
-                                                         const uint64_t *__restrict__ km, int pack_shift, uint32_t *__restrict__ seg_off,
-                                                         uint32_t *__restrict__ seg_cnt) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= S) return;
-    const uint32_t n = *d_n;
-    auto first_of = [&](uint32_t sp) {                            // first row whose species is >= sp
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint64_t k = pack_shift >= 0 ? (km[mid] >> pack_shift) : ksp[mid];
-            if (k < sp) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const uint32_t a = first_of(s), b = first_of(s + 1);
-    seg_off[s] = a; seg_cnt[s] = b - a;
-}
 
 // ---------------------------------------------------------------------------------------------
 // LP rows: nodes with a_v > 0 (valid rows, profile.rs:1380-1385) and a non-empty mask; rows with an
@@ -1133,26 +1084,15 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // d_ratio and d_counts live in the step's result arena, which the caller has just zeroed
     // rows: compact -> sort by (species, mask, a)
     Db *dbm = const_cast<Db *>(db);   // staging buffers live in the db so repeated steps do not hipMalloc
-    // Many species, each small enough for the sample sort: the rows are emitted species by species (segment sizes counted
-    // by the mask pass) and every segment is sorted by (mask, a) in one batch -- three passes over the rows instead of the
-    // 11 of the LSD radix sort
+    // Many species: the rows are sorted species by species straight from the node arrays (sample_sort_nodes.hip) -- no compaction pass in front, no limit
+    // on a species' size below 2^26 nodes (round 3's compaction + segmented sample sort, unreachable since round 4, was deleted in round 5)
     uint64_t max_vs = 0;
     for (uint32_t s_ = 0; s_ < S; ++s_) max_vs = std::max<uint64_t>(max_vs, db->h_node_off[s_ + 1] - db->h_node_off[s_]);
-    bool use_seg = V > SS_MAX_N && max_vs <= SS_MAX_N && S <= 65535;
-    // ... straight from the node arrays (sample_sort_nodes.hip), without the compaction pass in front -- and without the limit on a species' size
-    // (a graph of millions of nodes used to send the WHOLE batch through the radix sort)
     bool use_nodes = V > SS_MAX_N && max_vs <= SSN_MAX_SEG && S <= 65535;
-    if (use_nodes) use_seg = true;
-    if (!ctx->cfg.row_sort.empty()) {   // measurements / tests: "radix"; "seg" / "nodes" = one of the batched sorts wherever it can run
+    if (!ctx->cfg.row_sort.empty()) {   // measurements / tests: "radix" = the whole-batch sorts at any size; "nodes" = the batched sort wherever it can run
         const char *ev = ctx->cfg.row_sort.c_str();
-        if (ev[0] == 'r') use_seg = use_nodes = false;
-        if (ev[0] == 's') { use_seg = max_vs <= SS_MAX_N && S <= 65535 && V > 0; use_nodes = false; }
-        if (ev[0] == 'n') use_seg = use_nodes = max_vs <= SSN_MAX_SEG && S <= 65535 && V > 0;
-    }
-    uint32_t *d_seg_cnt = nullptr, *d_seg_off = nullptr;
-    if (use_seg && !use_nodes) {
-        PTX_HIP(ctx, dbm->d_seg.alloc(2ull * S + 2));
-        d_seg_cnt = dbm->d_seg.p; d_seg_off = d_seg_cnt + S;
+        if (ev[0] == 'r') use_nodes = false;
+        if (ev[0] == 'n') use_nodes = max_vs <= SSN_MAX_SEG && S <= 65535 && V > 0;
     }
     const bool by_node = use_node_haps(ctx, db);
     // the path_cov_ratio sums ride on the by-node mask pass (PANTAX_RATIO=kernel: ratio_kernel for every species, as in round 3)
@@ -1196,18 +1136,9 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
     // whenever their bits fit (16-byte records instead of 24)
     const int sp_bits = S > 1 ? bits_for(S - 1) : 0;
     const bool use_sample = V <= SS_MAX_N;
-    const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64 && !(use_seg && pmax_bound >= 64)) ? pmax_bound : -1;
+    const int pack_shift = (!use_sample && sp_bits + pmax_bound <= 64 && !(use_nodes && pmax_bound >= 64)) ? pmax_bound : -1;
     if (use_nodes) {
         if (pack_shift >= 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: internal (64 candidate columns and a packed species key)");
-    } else if (use_seg) {
-        if (pack_shift >= 64) return fail(ctx, PANTAX_HIP_E_LIMIT, "lad_prepare: internal (64 candidate columns and a packed species key)");
-        PTX_TRY(exclusive_scan_fn(ctx, RowLoad{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p},
-                                  RowStore{lb->d_ab.p, (const unsigned long long *)lb->d_mask.p, db->d_emit_tile_sp.p, db->d_node_base.p,
-                                           pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p, pack_shift >= 0 ? ka[0].p : ka[1].p,
-                                           pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift},
-                                  V, d_n, "scan_chained_kernel<Row>"));
-        hipLaunchKernelGGL(seg_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, ctx->stream, S, d_n, pack_shift >= 0 ? (const uint64_t *)nullptr : ka[0].p,
-                           pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift, d_seg_off, d_seg_cnt);
     } else {
         KTimer t(ctx, "row_emit_kernel");   // d_n was zeroed with the step's result arena
         const uint32_t grid_rows = (uint32_t)((V + 256ull * ROW_ITEMS - 1) / (256ull * ROW_ITEMS));
@@ -1242,10 +1173,6 @@ int lad_prepare(Ctx *ctx, const Db *db, LadBatch *lb, bool cand_on_device, int p
         }
         PTX_TRY(sample_sort_nodes(ctx, lb->d_ab.p, lb->d_mask.p, db->d_node_base.p, S, max_vs, V, dbm->d_row16.p, pack_shift >= 0 ? (uint64_t *)nullptr : ka[0].p,
                                   pack_shift >= 0 ? ka[0].p : ka[1].p, pack_shift >= 0 ? ka[1].p : ka[2].p, pack_shift, dbm->d_ss_ws.p, d_n, &pat, masks_in_sort ? &hp : nullptr));
-    } else if (use_seg) {
-        PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_seg_ws_elems(S, V)));
-        const int w0 = pack_shift >= 0 ? 0 : 1;   // the two words that move: {packed species|mask, a} or {mask, a}
-        PTX_TRY(sample_sort_seg(ctx, ka[w0].p, ka[w0 + 1].p, kb[w0].p, kb[w0 + 1].p, S, max_vs, V, d_seg_off, d_seg_cnt, dbm->d_ss_ws.p));
     } else if (use_sample) {   // few rows: sample sort (6 launches) instead of 10+ radix passes of 3 launches each
         PTX_HIP(ctx, dbm->d_ss_ws.alloc(sample_sort_ws_elems(V)));
         PTX_TRY(sample_sort3(ctx, A, B, V, dbm->d_ss_ws.p, d_n));

@@ -806,7 +806,7 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, set_opt):
     eng.trio_nodes_info(fetch=False)
     eng.get_node_abundances(fetch=False)
     outs = []
-    for sort, maskmode in ((None, None), ("seg", None), ("nodes", None), ("radix", None), (None, "walk"), ("seg", "walk"), ("nodes", "walk")):
+    for sort, maskmode in ((None, None), ("nodes", None), ("radix", None), (None, "walk"), ("nodes", "walk"), ("radix", "walk")):
         set_opt(eng, "row_sort", sort)
         set_opt(eng, "mask", maskmode)
         met, info = eng.strain_profiling(absolute, species_active=keep, **opts)
@@ -1063,38 +1063,6 @@ def test_device_sorts_against_host_sort(eng, algo):
         exp = _host_sorted(k0, k1, k2)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e), (algo, len(k0))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("wave_rows", [None, "1000000", "0"])
-def test_segmented_sample_sort_against_host_sort(eng, wave_rows, set_opt):
-    """The batched row sort of the many-species step (sample_sort_seg.hip) through the host-buffer utility: segments of
-    every size class side by side (empty neighbours cannot exist in this interface; 1 row, <= 4096 rows ranked by the
-    sample kernel, tens of thousands of rows, massive ties, presorted, and an unrepresentative sample whose one bucket
-    exceeds the LDS capacities), each sorted by (k1, k2) on its own.  Buckets are sorted a workgroup each, or -- from 400
-    segments on, forced here through PANTAX_SSG_WAVE_ROWS -- a wave each up to 256 rows."""
-    if wave_rows is not None:
-        set_opt(eng, "ssg_wave_rows", wave_rows)
-    rng = np.random.default_rng(7)
-    segs = []
-    for n in (1, 2, 63, 4095, 4096, 4097, 5000, 70000):
-        segs.append((rng.integers(0, 8, n), rng.integers(0, 2 ** 63, n)))
-    n = 150000
-    segs.append((rng.integers(0, 2, n), rng.integers(0, 50, n)))                                  # 100 distinct keys
-    segs.append((np.zeros(n, np.uint64), np.sort(rng.integers(0, 2 ** 62, n))))                  # presorted
-    segs.append((np.zeros(n, np.uint64), np.sort(rng.integers(0, 2 ** 62, n))[::-1]))            # reversed
-    for n in (8192, 20000):
-        k2 = rng.permutation(n).astype(np.uint64) + np.uint64(1 << 40)
-        pos = (np.arange(4096, dtype=np.uint64) * np.uint64(n)) // np.uint64(4096)
-        k2[pos] = np.arange(4096, dtype=np.uint64)
-        segs.append((np.zeros(n, np.uint64), k2))
-    k0 = np.concatenate([np.full(len(a), 3 * i + 1, dtype=np.uint64) for i, (a, b) in enumerate(segs)])
-    k1 = np.concatenate([np.asarray(a, dtype=np.uint64) for a, b in segs])
-    k2 = np.concatenate([np.asarray(b, dtype=np.uint64) for a, b in segs])
-    got = eng.sort_rows(k0, k1, k2, algo=3)
-    exp = _host_sorted(k0, k1, k2)
-    for g, e in zip(got, exp):
-        assert np.array_equal(g, e)
 
 
 @pytest.mark.gpu
