@@ -39,6 +39,8 @@
 #include "common.hpp"
 #include "primitives.hpp"
 #include "wave.hpp"
+// bools are combined with & and | on purpose in the coverage kernels (no short-circuit control flow: every operand is a plain comparison or a vote)
+#pragma clang diagnostic ignored "-Wbitwise-instead-of-logical"
 
 namespace ptx {
 
@@ -105,8 +107,12 @@ constexpr uint32_t STEP_LONG = 0x80u;
 // the stream (build_step_read lays the walks out in slot order), so a step's slot is not stored per step: group_slot[g] names
 // the read that owns the first step of the 64-step group g, and every later walk start in the group advances it by one.
 constexpr uint32_t STEP_START = 0x40u, STEP_PAD = 0xFFu, STEP_DIST = 0x3Fu;
+// ballots / votes of a bool WITHOUT the detour through an int predicate (__ballot(int) costs a v_cndmask + v_cmp per call: the kernel is bound by VALU issue)
+__device__ __forceinline__ unsigned long long ballot1(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool any1(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+__device__ __forceinline__ bool none1(bool b) { return __builtin_amdgcn_ballot_w64(b) == 0ull; }
 __device__ __forceinline__ uint32_t slot_in_group(uint32_t group_first_slot, uint32_t code, int lane) {
-    const unsigned long long starts = __ballot(code != STEP_PAD && (code & STEP_START)) & ~1ull;   // lane 0's walk is group_first_slot itself
+    const unsigned long long starts = ballot1((code != STEP_PAD) & ((code & STEP_START) != 0u)) & ~1ull;   // lane 0's walk is group_first_slot itself
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));   // starts in lower lanes
     return group_first_slot + below + (uint32_t)((starts >> lane) & 1ull);
 }
@@ -237,9 +243,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             pad[u] = code[u] == STEP_PAD;
-            run[u] = run[u] && !__all(pad[u]) && !__any(!pad[u] && (code[u] & STEP_LONG));   // nothing here / a longer walk's steps: coverage_step_kernel's group
+            run[u] = run[u] & any1(!pad[u]) & none1(!pad[u] & ((code[u] & STEP_LONG) != 0u));   // nothing here / a longer walk's steps: coverage_step_kernel's group
             const uint32_t sl = slot_in_group(gs[u], code[u], lane);
-            const uint32_t slot = (pad[u] || !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
+            const uint32_t slot = (pad[u] | !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
             rr[u] = read_rec[slot];
             sr[u] = slot_rec[slot];
         }
@@ -249,7 +255,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ok[u] = run[u] && !pad[u] && (int)sr[u].x >= 0;
+            ok[u] = run[u] & !pad[u] & ((int)sr[u].x >= 0);
             v[u] = ok[u] ? id[u] + sr[u].y : wlo;
             nr[u] = node_rec[v[u]];
             act[u] = active[ok[u] ? sr[u].x : 0u];      // never null here (the launcher passes all-ones when no species is deselected): an unconditional load
@@ -263,14 +269,14 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         for (int u = 0; u < U; ++u) {
             const uint32_t gbase = (gw + (uint32_t)u) * 64u;
             i_[u] = gbase + (uint32_t)lane - rr[u].x;                         // position in the walk (T_pad < 2^32)
-            ok[u] = ok[u] && act[u] != 0u;
+            ok[u] = ok[u] & (act[u] != 0u);
             nl[u] = ok[u] ? nr[u].z : 0u;
             len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
             const uint32_t v2 = wave_shr1(wave_shr1(v[u]));
             const uint32_t hw1 = wave_shr1(nr[u].w), hy1 = wave_shr1(nr[u].y);         // the lookup head of the window's MIDDLE node: the lane below
             single[u] = rr[u].y == 1u;
-            dead_read[u] = !single[u] && rr[u].z > len0[u];                   // assert :854 -> the whole read contributes nothing
-            live[u] = ok[u] && !dead_read[u] && !(single[u] && rr[u].w < rr[u].z);   // :821-827
+            dead_read[u] = !single[u] & (rr[u].z > len0[u]);                  // assert :854 -> the whole read contributes nothing
+            live[u] = ok[u] & !dead_read[u] & !(single[u] & (rr[u].w < rr[u].z));   // :821-827
             nh[u] = 0; hx[u] = 0; tlo[u] = 0; thi[u] = 0;
             e0[u] = make_uint2(0u, 0u); e1[u] = e0[u];
             if (WITH_TRIO && !ABL(4u)) {
@@ -278,7 +284,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                 hx[u] = hw1;
                 tlo[u] = min(v[u], v2); thi[u] = max(v[u], v2);
                 // the node's pair filter: a window whose bit is clear is not among its rows -- nothing is fetched for it
-                nh[u] = (live[u] && i_[u] >= 2u && (nr_filter(hy1) & nr_pair_bit(tlo[u], thi[u]))) ? nr_rows(hy1) : 0u;
+                nh[u] = (live[u] & (i_[u] >= 2u) & ((nr_filter(hy1) & nr_pair_bit(tlo[u], thi[u])) != 0u)) ? nr_rows(hy1) : 0u;
                 // the head's first TWO entries in one 16-byte load (entries are 8 bytes since round 5; the pair is dword-aligned, and the array has one
                 // entry of slack behind its last row)
                 const EntPair ep = *reinterpret_cast<const EntPair *>(trio_ent + (nh[u] ? hx[u] : 0u));
@@ -289,25 +295,25 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t k = rr[u].y, ps = rr[u].z, pe = rr[u].w, i = i_[u];
-            if (__any(ok[u] && dead_read[u] && i == 0u)) { if (ok[u] && dead_read[u] && i == 0u) atomicAdd(n_abort, 1ull); }
+            if (any1(ok[u] & dead_read[u] & (i == 0u))) { if (ok[u] & dead_read[u] & (i == 0u)) atomicAdd(n_abort, 1ull); }
             // `seen` before this step = wave prefix sum of the walk's aligned lengths minus its value at the walk's first lane
-            const uint32_t contrib = (live[u] && !single[u]) ? (i == 0u ? nl[u] - ps : nl[u]) : 0u;
+            const uint32_t contrib = (live[u] & !single[u]) ? (i == 0u ? nl[u] - ps : nl[u]) : 0u;
             const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
             const uint32_t seen = pexcl - __shfl(pexcl, lane - (int)i);
             const uint32_t tgt = pe - ps;                                     // target (profile.rs:800) where it is not negative
             uint32_t aln = nl[u];                                             // :860-862
-            if (i + 1u == k) aln = (pe >= ps && tgt > seen) ? tgt - seen : 0u;   // :857-859 max(target - seen, 0)
+            if (i + 1u == k) aln = ((pe >= ps) & (tgt > seen)) ? tgt - seen : 0u;   // :857-859 max(target - seen, 0)
             if (i == 0u) aln = single[u] ? tgt : nl[u] - ps;                  // :853-856, :828
             const uint32_t sidx = i == 0u ? ps : 0u;
             uint32_t hi = sidx + aln;
             if (hi > nl[u]) hi = nl[u];                                       // :871
-            const bool markable = live[u] && hi > sidx && !(single[u] && !(ps < pe && pe <= nl[u]));   // :832
+            const bool markable = live[u] & (hi > sidx) & !(single[u] & !((ps < pe) & (pe <= nl[u])));   // :832
             const uint32_t dupd = code[u] & STEP_DIST;                        // distance back to the node's first occurrence in the walk (0: this is it)
             const uint32_t rl = !live[u] ? 0u : dupd == 0u ? aln : (dupd == i ? len0[u] - ps : nl[u]);   // read_nodes_len :879-882
             const uint32_t off = v[u] - wlo;                                  // unsigned wrap: nodes below the window are out of range too
             const bool inw = off < win_n;
-            if (live[u] && dupd == 0u && aln && !ABL(2u)) {                   // :881 / :828
-                if (inw && aln < (1u << 18)) atomicAdd(&S_WIN(off), aln);
+            if (live[u] & (dupd == 0u) & (aln != 0u) && !ABL(2u)) {           // :881 / :828
+                if (inw & (aln < (1u << 18))) atomicAdd(&S_WIN(off), aln);
                 else atomicAdd(&bases[v[u]], (unsigned long long)aln);
             }
             if (markable && !ABL(1u)) {
@@ -323,16 +329,20 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             }
             if (WITH_TRIO && !ABL(4u)) {                                      // :890-907
                 const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
-                long long row = -1;                                              // a row IS its lookup entry (round 5): the index of the entry that matches
-                if (nh[u] && e0[u].x == tlo[u] && e0[u].y == thi[u]) row = (long long)hx[u];
-                else if (nh[u] > 1u && e1[u].x == tlo[u] && e1[u].y == thi[u]) row = (long long)hx[u] + 1;
-                else if (nh[u] > 2u)
-                    for (uint32_t j = 2; j < nh[u]; ++j) {
-                        const uint2 e = trio_ent[hx[u] + j];
-                        if (e.x == tlo[u] && e.y == thi[u]) { row = (long long)hx[u] + j; break; }
-                    }
-                const unsigned long long sum = (unsigned long long)rl2 + rl1 + rl;
-                if (row >= 0 && sum) atomicAdd(&trio_bases[row], sum);
+                // a row IS its lookup entry (round 5): the index of the entry that matches (rows are 32-bit; NO_ROW: none)
+                constexpr uint32_t NO_ROW = 0xFFFFFFFFu;
+                const bool m0 = (nh[u] != 0u) & (e0[u].x == tlo[u]) & (e0[u].y == thi[u]);
+                const bool m1 = (nh[u] > 1u) & (e1[u].x == tlo[u]) & (e1[u].y == thi[u]);
+                uint32_t row = m0 ? hx[u] : m1 ? hx[u] + 1u : NO_ROW;
+                if (any1(!(m0 | m1) & (nh[u] > 2u))) {
+                    if (!(m0 | m1) & (nh[u] > 2u))
+                        for (uint32_t j = 2; j < nh[u]; ++j) {
+                            const uint2 e = trio_ent[hx[u] + j];
+                            if (e.x == tlo[u] && e.y == thi[u]) { row = hx[u] + j; break; }
+                        }
+                }
+                const uint32_t sum = rl2 + rl1 + rl;                             // three node lengths: far below 2^32
+                if ((row != NO_ROW) & (sum != 0u)) atomicAdd(&trio_bases[row], (unsigned long long)sum);
             }
         }
     }

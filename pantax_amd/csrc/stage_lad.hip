@@ -332,24 +332,43 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
     if (PASS == 0 && lane == 0) cn[blockIdx.x] = n_c;
 }
 template <int PASS>
-__global__ void __launch_bounds__(64) hap_combine_kernel(const uint32_t *__restrict__ sp_chunk_off, const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off,
-                                                         const HapAcc *__restrict__ part, uint32_t *__restrict__ nnz, double *__restrict__ mean0, double *__restrict__ sd,
-                                                         double *__restrict__ meanf) {
+__global__ void __launch_bounds__(256) hap_combine_kernel(const uint32_t *__restrict__ sp_chunk_off, const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off,
+                                                          const HapAcc *__restrict__ part, uint32_t *__restrict__ nnz, double *__restrict__ mean0, double *__restrict__ sd,
+                                                          double *__restrict__ meanf) {
+    // one workgroup per species; the chunks' partials of a haplotype are summed by `parts` threads (chunk c by thread c mod parts, in chunk order), the
+    // parts then in part order: a fixed order of additions, whatever the launch (same bits every run)
+    __shared__ double s_a[256];
+    __shared__ unsigned long long s_c[256];
     const uint32_t s = blockIdx.x, c0 = sp_chunk_off[s], c1 = sp_chunk_off[s + 1];
     const uint32_t h0 = (uint32_t)hap_off[s], Hs = (uint32_t)hap_off[s + 1] - h0;
-    for (uint32_t h = threadIdx.x; h < Hs; h += 64) {
+    uint32_t width = 256;                                  // threads side by side over the haplotypes: the power of two >= Hs, at most 256
+    if (Hs <= 128u) { width = 8; while (width < Hs) width <<= 1; }
+    const uint32_t parts = 256u / width, hl = threadIdx.x % width, pt = threadIdx.x / width;
+    for (uint32_t hb = 0; hb < Hs; hb += width) {
+        const uint32_t h = hb + hl;
         double a = 0.0;
         unsigned long long c = 0;
-        for (uint32_t k = c0; k < c1; ++k) { const HapAcc p = part[chunks[k].w + h]; a += p.a; c += p.c; }
-        if (PASS == 0) { nnz[h0 + h] = (uint32_t)c; mean0[h0 + h] = c ? a / (double)c : 0.0; }              // profile.rs:1037
-        else if (PASS == 1) { const double n = (double)nnz[h0 + h]; sd[h0 + h] = n > 0 ? sqrt(a / n) : 0.0; }   // :1038-1041
-        else meanf[h0 + h] = c ? a / (double)c : 0.0;                 // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+        if (h < Hs) for (uint32_t k = c0 + pt; k < c1; k += parts) { const HapAcc p = part[chunks[k].w + h]; a += p.a; c += p.c; }
+        s_a[threadIdx.x] = a; s_c[threadIdx.x] = c;
+        __syncthreads();
+        if (pt == 0 && h < Hs) {
+            for (uint32_t q = 1; q < parts; ++q) { a += s_a[q * width + hl]; c += s_c[q * width + hl]; }
+            if (PASS == 0) { nnz[h0 + h] = (uint32_t)c; mean0[h0 + h] = c ? a / (double)c : 0.0; }              // profile.rs:1037
+            else if (PASS == 1) { const double n = (double)nnz[h0 + h]; sd[h0 + h] = n > 0 ? sqrt(a / n) : 0.0; }   // :1038-1041
+            else meanf[h0 + h] = c ? a / (double)c : 0.0;                 // sd == 0 -> empty -> 0.0 (:1043-1045, :1143-1147)
+        }
+        __syncthreads();
     }
 }
 
 // first build of a db (trio_index_build): the blocks of rows of the species -> chunks of rows, a row of partials per chunk
 int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint64_t *sp_rows) {
     const uint32_t S = db->S;
+    // rows per chunk (= per wave): 1024 where that gives a few thousand chunks; small dbs take shorter chunks, down to 128 rows, so that the pass has
+    // waves for every CU (one species x 10 strains: 176 chunks of 1024 rows ran as 176 waves, 0.05 ms a pass)
+    uint64_t total_rows = 0;
+    for (uint32_t s = 0; s < S; ++s) total_rows += sp_rows[s];
+    const uint64_t chunk_rows = std::min<uint64_t>(HS_CHUNK_ROWS, std::max<uint64_t>(128, ((total_rows / 4096 + 63) / 64) * 64));
     std::vector<uint4> chunks;
     std::vector<uint32_t> sp_off(S + 1, 0);
     uint64_t n_part = 0;
@@ -361,7 +380,7 @@ int hap_stats_layout(Ctx *ctx, Db *db, const uint64_t *sp_first_row, const uint6
         if (Hs > 64 && Hs <= HS_LDS_HAPS) lds_haps = std::max<uint32_t>(lds_haps, (uint32_t)Hs);
         if (Hs > HS_LDS_HAPS && sp_rows[s]) global_rows = true;
         // a chunk holds at least eight rows per haplotype of its species: the partials stay an eighth of the rows at most
-        const uint64_t per = std::max<uint64_t>(HS_CHUNK_ROWS, ((8 * Hs + 63) / 64) * 64);
+        const uint64_t per = std::max<uint64_t>(chunk_rows, ((8 * Hs + 63) / 64) * 64);
         for (uint64_t r = 0; r < sp_rows[s]; r += per) {
             if (n_part + Hs >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "hap statistics: more than 2^32 chunk partials");
             chunks.push_back(make_uint4(s, (uint32_t)(sp_first_row[s] + r), (uint32_t)(sp_first_row[s] + std::min<uint64_t>(sp_rows[s], r + per)), (uint32_t)n_part));
@@ -399,7 +418,7 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
     if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
                                TRIO_HAP_PTR(db), (const unsigned long long *)db->d_trio_bases.p, (const trio_len_t *)db->d_trio_len.p,          \
                                (const double *)mean0, (const double *)sd, part, dbm->d_hs_x.p, dbm->d_hs_h.p, dbm->d_hs_n.p);                                  \
-    hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(64), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
+    hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(256), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
                        (const uint64_t *)db->d_hap_off.p, (const HapAcc *)part, d_nnz.p, mean0, sd, d_mean.p);
     HS_PASS(0) HS_PASS(1) HS_PASS(2)
 #undef HS_PASS
