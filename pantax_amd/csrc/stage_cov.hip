@@ -1042,10 +1042,13 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         // windows are zeroed and flushed once per workgroup).  Skipped when every walk is longer.
         if (rd->n_long < rd->n_slots && rd->n_items && !cov_general) {
             KTimer t(ctx, "coverage_fast_kernel");
-            // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps) over a 3072-node window;
-            // 2 x 8 (4096 steps) on streams of 2^28 steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms
-            // at 8e7 steps, 11.7 vs 9.8 ms at 8e8)
-            int fshape = rd->T_pad >= (1ull << 28) ? 283 : 243;
+            // groups in flight per wave, rounds per workgroup, nodes in the LDS window: 2 x 4 groups (2048 steps); 2 x 8 (4096 steps) on streams of 2^28
+            // steps and more, where a workgroup's start-up chain costs more (measured: 0.711 vs 0.768 ms at 8e7 steps, 11.7 vs 9.8 ms at 8e8).  The window:
+            // 2304 nodes since round 5 -- an item's reads start inside one block of 2048 ids and the window begins 64..127 nodes in front of it, so 2304
+            // hold every short read; the 3072 of rounds 3-4 cost 23.5 KB of LDS per workgroup = SIX waves per SIMD where the registers allow eight (19.7 KB:
+            // eight).  The kernel waits for its gathers two thirds of the time: 6.46 -> 5.77 ms at 1e8 reads, 0.708 -> 0.639 at 1e7 (2048 nodes: 7.3 / 0.77,
+            // the reads at a block's end fall off the window)
+            int fshape = rd->T_pad >= (1ull << 28) ? 2823 : 2423;
             if (ctx->cfg.covf_shape > 0) fshape = ctx->cfg.covf_shape;
 #define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
@@ -1062,6 +1065,10 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
                 case 283: COVF_LAUNCH(2, 8, 3072) break;
                 case 284: COVF_LAUNCH(2, 8, 4096) break;
                 case 243: COVF_LAUNCH(2, 4, 3072) break;
+                case 2823: COVF_LAUNCH(2, 8, 2304) break;                  // <U><PASSES><window / 256 as two digits - 70>: windows between 2048 and 3072 nodes
+                case 2825: COVF_LAUNCH(2, 8, 2560) break;
+                case 2423: COVF_LAUNCH(2, 4, 2304) break;
+                case 2425: COVF_LAUNCH(2, 4, 2560) break;
                 case 442: COVF_LAUNCH(4, 4, 2048) break;
                 case 443: COVF_LAUNCH(4, 4, 3072) break;
                 default: COVF_LAUNCH(2, 4, 2048) break;

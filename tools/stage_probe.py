@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of environment switches on ONE process / ONE box: uploads a bench workload once, then times the binning and coverage
-stages (HIP events on the library's stream) under every setting, alternating.  The library reads its PANTAX_* switches at
-launch time, so one process can flip them.
-usage: stage_probe.py <workload> <reps> VAR=a,b[,c] [VAR2=x,y]   e.g. stage_probe.py cfg3 5 PANTAX_COV_XCD=0,1 PANTAX_COV_SHAPE=14,18"""
+"""A/B of library options on ONE process / ONE box: uploads a bench workload once, then times the binning and coverage
+stages (HIP events on the library's stream) under every setting, alternating (pantax_hip_set_option between the runs).
+usage: stage_probe.py <workload> <reps> option=a,b[,c] [option2=x,y]   e.g. stage_probe.py cfg3 5 cov_xcd=0,1 covf_shape=283,2823"""
 import itertools, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,7 +20,7 @@ acc = {c: {} for c in combos}
 for rep in range(reps):
     for c in combos:
         for (k, _), v in zip(switches, c):
-            os.environ[k] = v
+            eng.set_option(k, v)
         eng.timing_reset()
         eng.rcls_profile(want_species=False)
         eng.get_node_abundances(fetch=False)
