@@ -221,6 +221,22 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    // Level 1 of round r + 1 is requested at the top of round r (round 5): the stream loads are the one level that comes from HBM every time, and the
+    // kernel waits for its four dependent levels two thirds of the time -- three more registers per group in flight (64 in all: still eight waves per
+    // SIMD) take the first level off the chain: 5.70 -> 5.21 ms at 1e8 reads, 0.62 -> 0.57 at 1e7 (same box, alternating builds).  -DCOV_NO_PREFETCH:
+    // the round-4 loop, for measurements.
+#ifndef COV_NO_PREFETCH
+    uint32_t n_code[U], n_id[U], n_gs[U];
+    {
+        const uint32_t gw0 = g0 + (uint32_t)(wave * U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = gw0 + (uint32_t)u < n_groups ? gw0 + (uint32_t)u : (gw0 < n_groups ? gw0 : g0);
+            const uint64_t t = (uint64_t)g * 64 + lane;
+            n_code[u] = step_code[t]; n_id[u] = node_id[t]; n_gs[u] = group_slot[g];
+        }
+    }
+#endif
 #pragma unroll 1
     for (int pass = 0;; ++pass) {
         const uint32_t gw = g0 + (uint32_t)((pass * WAVES + wave) * U);     // this wave's U consecutive groups
@@ -228,6 +244,19 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         // ---- level 1
         uint32_t code[U], id[U], gs[U];
         bool run[U];                                                          // wave-uniform: the group is this kernel's
+#ifndef COV_NO_PREFETCH
+        {
+            const uint32_t gn = gw + (uint32_t)(WAVES * U);                    // the coming round's groups
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                run[u] = gw + (uint32_t)u < n_groups;
+                code[u] = n_code[u]; id[u] = n_id[u]; gs[u] = n_gs[u];
+                const uint32_t g = gn + (uint32_t)u < n_groups ? gn + (uint32_t)u : gw;
+                const uint64_t t = (uint64_t)g * 64 + lane;
+                n_code[u] = step_code[t]; n_id[u] = node_id[t]; n_gs[u] = group_slot[g];
+            }
+        }
+#else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t g = gw + (uint32_t)u;
@@ -236,6 +265,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             code[u] = step_code[t]; id[u] = node_id[t];
             gs[u] = group_slot[run[u] ? g : gw];
         }
+#endif
         // ---- level 2 (dead lanes read the group's first record: in range, and on a line that is fetched anyway)
         uint4 rr[U];
         uint2 sr[U];
