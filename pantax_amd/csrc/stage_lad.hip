@@ -488,30 +488,19 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
     const uint32_t quarter = ((hi > lo ? hi - lo : 0u) + 3u) / 4u;
     const uint32_t wlo = min(hi, lo + wave * quarter), whi = min(hi, wlo + quarter);
     uint64_t run = wlo < whi ? bit_off[wlo] : 0ull;              // bit offset of the first node of the coming round
-    // the three streams of round r + 1 are requested at the top of round r (round 5: the kernel waited for memory 86 % of its wave cycles -- streams,
-    // then the two bitmap words that depend on them; with the next round's streams in flight behind the bitmap loads one level is off the chain)
-    uint32_t nl[NR], nfw[NR];
-    unsigned long long nbs[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const uint32_t v = wlo + (uint32_t)r * 64u + lane;
-        const bool in = v < whi;
-        nl[r] = in ? node_len[v] : 0u;
-        nbs[r] = in ? bases[v] : 0ull;
-        nfw[r] = in ? full[v >> 5] : 0u;
-    }
+    // (requesting the three streams of round r + 1 at the top of round r -- what took a dependent level off the coverage kernel's chain -- LOST here:
+    // 2.55 -> 3.17 ms at 1e4 strains, 16 more registers for a kernel whose rounds are already four stretches deep)
     for (uint32_t v0 = wlo; v0 < whi; v0 += 64 * NR) {
         uint32_t l[NR], fw[NR];
         unsigned long long bs[NR];
         uint64_t g0[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            l[r] = nl[r]; bs[r] = nbs[r]; fw[r] = nfw[r];
-            const uint32_t v = v0 + (uint32_t)(NR + r) * 64u + lane;       // the coming round's node
+            const uint32_t v = v0 + (uint32_t)r * 64u + lane;
             const bool in = v < whi;
-            nl[r] = in ? node_len[v] : 0u;
-            nbs[r] = in ? bases[v] : 0ull;
-            nfw[r] = in ? full[v >> 5] : 0u;
+            l[r] = in ? node_len[v] : 0u;
+            bs[r] = in ? bases[v] : 0ull;
+            fw[r] = in ? full[v >> 5] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
