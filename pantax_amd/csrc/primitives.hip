@@ -29,25 +29,28 @@ int exclusive_scan_u8(Ctx *ctx, const uint8_t *d_in, uint32_t *d_out, uint64_t n
 // zero fill of large device ranges: 16-byte stores from every CU.  The runtime's fill kernel behind hipMemsetAsync
 // reached about 1 TB/s on the arenas of a 100-species step (0.4 GB in 0.40 ms); a step zeroes 1-2 GB.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *__restrict__ p, uint64_t n16) {
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *__restrict__ p, uint64_t n16, uint32_t word) {
+    const uint4 z = make_uint4(word, word, word, word);
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + 3 * stride < n16; i += 4 * stride) { p[i] = z; p[i + stride] = z; p[i + 2 * stride] = z; p[i + 3 * stride] = z; }
     for (; i < n16; i += stride) p[i] = z;
 }
-int zero_fill(Ctx *ctx, void *ptr, size_t bytes) {
+// every byte of [ptr, ptr + bytes) = `byte` (0x00 / 0xFF fills of the upload-time tables: 9 GB of visit-table pads at 1e4 strains)
+int byte_fill(Ctx *ctx, void *ptr, int byte, size_t bytes) {
     if (bytes == 0) return 0;
     uint8_t *p = static_cast<uint8_t *>(ptr);
-    if (bytes < (1u << 20)) { PTX_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream)); return 0; }
+    if (bytes < (1u << 20)) { PTX_HIP(ctx, hipMemsetAsync(p, byte, bytes, ctx->stream)); return 0; }
     const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
-    if (head) PTX_HIP(ctx, hipMemsetAsync(p, 0, head, ctx->stream));
+    if (head) PTX_HIP(ctx, hipMemsetAsync(p, byte, head, ctx->stream));
     const uint64_t n16 = (bytes - head) / 16;
     const size_t tail = bytes - head - n16 * 16;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for(n16 / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(p + head), n16);
-    if (tail) PTX_HIP(ctx, hipMemsetAsync(p + head + n16 * 16, 0, tail, ctx->stream));
+    const uint32_t word = 0x01010101u * (uint32_t)(byte & 0xFF);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for(n16 / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, reinterpret_cast<uint4 *>(p + head), n16, word);
+    if (tail) PTX_HIP(ctx, hipMemsetAsync(p + head + n16 * 16, byte, tail, ctx->stream));
     return 0;
 }
+int zero_fill(Ctx *ctx, void *ptr, size_t bytes) { return byte_fill(ctx, ptr, 0, bytes); }
 
 // ---------------------------------------------------------------------------------------------
 // radix sort

@@ -14,6 +14,7 @@ int exclusive_scan_u8(Ctx *ctx, const uint8_t *d_in, uint32_t *d_out, uint64_t n
 
 // large zero fills (16-byte stores from every CU; small ranges go through hipMemsetAsync), on ctx->stream
 int zero_fill(Ctx *ctx, void *ptr, size_t bytes);
+int byte_fill(Ctx *ctx, void *ptr, int byte, size_t bytes);   // every byte = `byte`, 16-byte stores from every CU
 
 // Records are structure-of-arrays: up to 3 u64 key words + one u32 payload.
 constexpr int SORT_MAX_WORDS = 3;

@@ -926,11 +926,11 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     PTX_HIP(ctx, scan_tmp.alloc(scan_tmp_elems(NB + 1)));
     PTX_HIP(ctx, slot_rel.alloc(rd->R));
     PTX_HIP(ctx, rd->d_g_read_rec.alloc(rd->R));
-    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));
+    PTX_TRY(zero_fill(ctx, cnt_r, (NB + 1) * sizeof(uint32_t)));
     int gridR = grid_for(rd->R, 256, ctx->n_cu * 8);
     hipLaunchKernelGGL(group_count_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, shift, cnt_r);
     PTX_TRY(exclusive_scan_u32(ctx, cnt_r, base_r, NB + 1, scan_tmp.p, nullptr));
-    PTX_HIP(ctx, hipMemsetAsync(cnt_r, 0, (NB + 1) * sizeof(uint32_t), ctx->stream));   // reused as cursors
+    PTX_TRY(zero_fill(ctx, cnt_r, (NB + 1) * sizeof(uint32_t)));   // reused as cursors
     uint32_t *d_total = (uint32_t *)ctx->d_scalars.p, *d_n_long = d_total + 1;
     PTX_HIP(ctx, hipMemsetAsync(d_n_long, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(group_slot_kernel, dim3(gridR), dim3(256), 0, ctx->stream, rd->R, rd->d_step_off.p, rd->d_node_id.p, rd->d_pstart.p, rd->d_pend.p,
@@ -952,9 +952,9 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     if ((uint64_t)h_total < rd->T) return fail(ctx, PANTAX_HIP_E_LIMIT, "reads_upload: padded step stream exceeds 32-bit positions");
     rd->T_pad = h_total;
     PTX_HIP(ctx, rd->d_g_node_id.alloc(rd->T_pad)); PTX_HIP(ctx, rd->d_g_group_slot.alloc(rd->T_pad / 64 + 1)); PTX_HIP(ctx, rd->d_g_step_dup.alloc(rd->T_pad));
-    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_group_slot.p, 0xFF, (rd->T_pad / 64 + 1) * sizeof(uint32_t), ctx->stream));
-    PTX_HIP(ctx, hipMemsetAsync(rd->d_g_step_dup.p, 0xFF, rd->T_pad, ctx->stream));                          // STEP_PAD
+    PTX_TRY(byte_fill(ctx, rd->d_g_node_id.p, 0, rd->T_pad * sizeof(uint32_t)));
+    PTX_TRY(byte_fill(ctx, rd->d_g_group_slot.p, 0xFF, (rd->T_pad / 64 + 1) * sizeof(uint32_t)));
+    PTX_TRY(byte_fill(ctx, rd->d_g_step_dup.p, 0xFF, rd->T_pad));                                            // STEP_PAD
     if (rd->n_slots)
         hipLaunchKernelGGL(group_fill_kernel, dim3(grid_for(rd->n_slots, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->n_slots, rd->d_node_id.p, ushift,
                            base_s, slot_rel.p, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_group_slot.p, rd->d_g_step_dup.p);

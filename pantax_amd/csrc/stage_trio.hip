@@ -1161,7 +1161,7 @@ int trio_visits_build(Ctx *ctx, Db *db) {
     if (db->P == 0 || db->P >= 0xFFFFFFFFull || db->V == 0 || db->S == 0) return all_slow();
     DevBuf<uint32_t> cnt, vslot, chunk_groups, chunk_gbase, scan_tmp, tot;
     PTX_HIP(ctx, cnt.alloc(db->V + 1));
-    PTX_HIP(ctx, hipMemsetAsync(cnt.p, 0, (db->V + 1) * sizeof(uint32_t), ctx->stream));
+    PTX_TRY(zero_fill(ctx, cnt.p, (db->V + 1) * sizeof(uint32_t)));
 #define TRIO_GRAPH db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p, db->d_hap_species.p, db->d_node_base.p
     const dim3 tgrid((uint32_t)db->n_tiles);
     hipLaunchKernelGGL(visit_count_kernel, tgrid, dim3(256), 0, ctx->stream, TRIO_GRAPH, cnt.p);
@@ -1194,10 +1194,10 @@ int trio_visits_build(Ctx *ctx, Db *db) {
     if (NG) {
         PTX_HIP(ctx, db->d_vis_pos.alloc((uint64_t)NG * 64)); PTX_HIP(ctx, db->d_vis_head.alloc(NG)); PTX_HIP(ctx, db->d_vis_nbase.alloc(NG)); PTX_HIP(ctx, db->d_vis_sp.alloc(NG));
         PTX_HIP(ctx, vslot.alloc(db->V));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_pos.p, 0xFF, (uint64_t)NG * 64 * sizeof(uint32_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_head.p, 0, (uint64_t)NG * sizeof(uint64_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_nbase.p, 0, (uint64_t)NG * sizeof(uint32_t), ctx->stream));
-        PTX_HIP(ctx, hipMemsetAsync(db->d_vis_sp.p, 0, (uint64_t)NG * sizeof(uint32_t), ctx->stream));
+        PTX_TRY(byte_fill(ctx, db->d_vis_pos.p, 0xFF, (uint64_t)NG * 64 * sizeof(uint32_t)));
+        PTX_TRY(byte_fill(ctx, db->d_vis_head.p, 0, (uint64_t)NG * sizeof(uint64_t)));
+        PTX_TRY(byte_fill(ctx, db->d_vis_nbase.p, 0, (uint64_t)NG * sizeof(uint32_t)));
+        PTX_TRY(byte_fill(ctx, db->d_vis_sp.p, 0, (uint64_t)NG * sizeof(uint32_t)));
         PTX_TRY(upload(ctx, db->d_trio_slow, slow.data(), slow.size()));
         hipLaunchKernelGGL(visit_pack_kernel<true>, dim3((NC + VP_CHUNKS - 1) / VP_CHUNKS), dim3(64), 0, ctx->stream, NC, d_chunks.p, cnt.p, (uint32_t *)nullptr,
                            (const uint32_t *)chunk_gbase.p, vslot.p, reinterpret_cast<unsigned long long *>(db->d_vis_head.p), db->d_vis_nbase.p, db->d_vis_sp.p);

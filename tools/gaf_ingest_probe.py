@@ -22,7 +22,7 @@ with tempfile.TemporaryDirectory(dir=root) as td:
     del rd
     eng = Engine(0)
     eng.upload_db(ns.graphs())
-    eng.load_reads_from_gaf(gp); eng.sync()                     # page cache, pinned ring, work buffers
+    eng.load_reads_from_gaf(gp, columns=False); eng.sync()      # page cache, pinned ring, work buffers
     best = {v: [] for v in variants}
     for _ in range(reps):
         for var in variants:
@@ -30,7 +30,7 @@ with tempfile.TemporaryDirectory(dir=root) as td:
             for k, v in sets:
                 eng.set_option(k, v)
             t0 = time.perf_counter()
-            eng.load_reads_from_gaf(gp); eng.sync()
+            eng.load_reads_from_gaf(gp, columns=False); eng.sync()
             best[var].append(time.perf_counter() - t0)
             for k, v in sets:
                 eng.set_option(k, None)
