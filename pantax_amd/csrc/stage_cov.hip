@@ -460,6 +460,16 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
         }
     }
     __syncthreads();
+    // the stream loads of round r + 1 are requested at the top of round r, as in the short-read kernel (-DCOV_NO_PREFETCH: the round-4 loop)
+#ifndef COV_NO_PREFETCH
+    uint32_t n_id[U], n_dupc[U], n_gs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t t = chunk_b + (uint64_t)(wave * U + u) * 64 + lane;
+        const uint64_t tc = t < chunk_e ? t : chunk_b;              // (in range; dead lanes of a round are masked by `ok`)
+        n_id[u] = node_id[tc]; n_dupc[u] = step_dup[tc]; n_gs[u] = group_slot[tc >> 6];
+    }
+#endif
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
         const uint64_t wbase = chunk_b + (uint64_t)((pass * (COV_BLOCK / 64) + wave) * U) * 64;   // this wave's U x 64 consecutive steps
@@ -473,8 +483,19 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
             ok[u] = t < chunk_e;                                     // whole groups: T_pad and the chunk size are multiples of 64
             slot[u] = NO_SLOT; id[u] = 0; dupc[u] = STEP_PAD;
             ti[u] = (uint32_t)t;                                     // T_pad < 2^32 (build_step_read)
+#ifndef COV_NO_PREFETCH
+            uint32_t gs_now = NO_SLOT;
+            if (ok[u]) { id[u] = n_id[u]; dupc[u] = n_dupc[u]; gs_now = n_gs[u]; }
+            {
+                const uint64_t tn = t + (uint64_t)COV_BLOCK * U;    // the same lane's step in the coming round
+                const uint64_t tc = (pass + 1 < PASSES && tn < chunk_e) ? tn : chunk_b;
+                n_id[u] = node_id[tc]; n_dupc[u] = step_dup[tc]; n_gs[u] = group_slot[tc >> 6];
+            }
+            const uint32_t gs = gs_now;
+#else
             if (ok[u]) { id[u] = node_id[t]; dupc[u] = step_dup[t]; }
             const uint32_t gs = ok[u] ? group_slot[t >> 6] : NO_SLOT;
+#endif
             const uint32_t sl = slot_in_group(gs, dupc[u], lane);
             ok[u] = ok[u] && dupc[u] != STEP_PAD;
             if (only_long && !__any(ok[u] && (dupc[u] & STEP_LONG))) ok[u] = false;   // a short-read group: the other kernel's

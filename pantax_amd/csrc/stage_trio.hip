@@ -424,13 +424,16 @@ __global__ void __launch_bounds__(256) visit_flags_kernel(uint64_t V, uint32_t S
 constexpr int VIS_OPEN = 4;
 struct VisPack {
     uint32_t fill[VIS_OPEN], gidx[VIS_OPEN], n_groups;
+    unsigned long long heads[VIS_OPEN];                  // head lanes of the open groups (bit = a node's first visit)
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int j = 0; j < VIS_OPEN; ++j) { fill[j] = 64u; gidx[j] = 0u; }
+        for (int j = 0; j < VIS_OPEN; ++j) { fill[j] = 64u; gidx[j] = 0xFFFFFFFFu; heads[j] = 0ull; }
         n_groups = 0u;
     }
-    // -> slot of the node's first visit, relative to the chunk's first group
-    __device__ __forceinline__ uint32_t place(uint32_t k) {
+    // -> slot of the node's first visit, relative to the chunk's first group.  A group that is closed to make room is handed to `closed`
+    // (group index relative to the chunk, its head mask): a group belongs to ONE chunk, so its mask is a plain store of the packing thread
+    template <class Closed>
+    __device__ __forceinline__ uint32_t place(uint32_t k, Closed &&closed) {
         int best = -1;
 #pragma unroll
         for (int j = VIS_OPEN - 1; j >= 0; --j) if (fill[j] + k <= 64u) best = j;       // the first open group it fits
@@ -439,13 +442,18 @@ struct VisPack {
 #pragma unroll
             for (int j = 1; j < VIS_OPEN; ++j) if (fill[j] > fill[best]) best = j;
 #pragma unroll
-            for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { fill[j] = 0u; gidx[j] = n_groups; }
+            for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { if (gidx[j] != 0xFFFFFFFFu) closed(gidx[j], heads[j]); fill[j] = 0u; gidx[j] = n_groups; heads[j] = 0ull; }
             ++n_groups;
         }
         uint32_t slot = 0;
 #pragma unroll
-        for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { slot = gidx[j] * 64u + fill[j]; fill[j] += k; }
+        for (int j = 0; j < VIS_OPEN; ++j) if (j == best) { slot = gidx[j] * 64u + fill[j]; heads[j] |= 1ull << fill[j]; fill[j] += k; }
         return slot;
+    }
+    template <class Closed>
+    __device__ __forceinline__ void finish(Closed &&closed) {
+#pragma unroll
+        for (int j = 0; j < VIS_OPEN; ++j) if (gidx[j] != 0xFFFFFFFFu) closed(gidx[j], heads[j]);
     }
 };
 // PLACE = false: the number of groups every chunk needs (-> scan -> first group of every chunk); PLACE = true: the nodes' slots, the groups' head
@@ -472,25 +480,26 @@ __global__ void __launch_bounds__(64) visit_pack_kernel(uint32_t NC, const uint4
         if (lane < nj) { const uint4 ch = chunks[c0 + lane]; n = ch.y - ch.x; }
         VisPack pk;
         pk.init();
+        // a group's head mask: one plain 8-byte store by the packing thread when the group is closed (the first version issued one memory-side
+        // atomicOr per NODE: 3.2e8 at 1e4 strains, 15 of the kernel's 17 ms)
+        const uint32_t gb = (PLACE && lane < nj) ? chunk_gbase[c0 + lane] : 0u;
+        auto closed = [&](uint32_t g, unsigned long long m) { if (PLACE) head[gb + g] = m; };
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t k = s_cnt[lane * VP_CNT_STRIDE + i];
             if (!k) continue;
-            const uint32_t slot = pk.place(k);                                   // relative to the chunk's first group: below 256 groups x 64
+            const uint32_t slot = pk.place(k, closed);                           // relative to the chunk's first group: below 256 groups x 64
             if (PLACE) s_slot[lane * VP_SLOT_STRIDE + i] = (uint16_t)slot;
         }
+        pk.finish(closed);
         if (!PLACE) { if (lane < nj) chunk_groups[c0 + lane] = pk.n_groups; return; }
     }
     __syncthreads();
     for (uint32_t j = 0; j < nj; ++j) {
         const uint4 ch = chunks[c0 + j];
-        const uint32_t base = chunk_gbase[c0 + j] << 6;
-        for (uint32_t i = lane; i < ch.y - ch.x; i += 64) {
-            if (!s_cnt[j * VP_CNT_STRIDE + i]) continue;
-            const uint32_t slot = base + s_slot[j * VP_SLOT_STRIDE + i];
-            vslot[ch.x + i] = slot;
-            atomicOr(&head[slot >> 6], 1ull << (slot & 63u));
-            if ((slot & 63u) == 0u) { gnbase[slot >> 6] = ch.z; gsp[slot >> 6] = ch.w; }   // the node that opened the group
-        }
+        const uint32_t gbase = chunk_gbase[c0 + j], base = gbase << 6, ng = chunk_gbase[c0 + j + 1] - gbase;
+        for (uint32_t i = lane; i < ch.y - ch.x; i += 64)
+            if (s_cnt[j * VP_CNT_STRIDE + i]) vslot[ch.x + i] = base + s_slot[j * VP_SLOT_STRIDE + i];
+        for (uint32_t g = lane; g < ng; g += 64) { gnbase[gbase + g] = ch.z; gsp[gbase + g] = ch.w; }   // the chunk's groups: its species' node base / species
     }
 }
 __global__ void __launch_bounds__(256) visit_fill_kernel(TRIO_GRAPH_ARGS, const uint32_t *__restrict__ slow, const uint32_t *__restrict__ vslot,
