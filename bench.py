@@ -284,6 +284,14 @@ def cpu_leg_child(args):
                               "after_oracle": _mem_available_gb()}, cgroup_memory_limit_gb=res["cgroup_memory_limit_gb"])
         res["stage"] = "oracle_done"
         publish()
+        # the HiGHS legs wait for the parent's timed steps to be over (round-3/4 advisor finding: they ran beside them): the parent drops a file
+        t_go = time.time()
+        while not os.path.exists(out_path + ".go") and time.time() - t_go < 900:
+            if os.getppid() == 1:                  # the parent is gone: nobody will read the HiGHS legs
+                res["stage"] = "done"; publish()
+                return
+            time.sleep(0.1)
+        res["waited_for_the_timed_steps_s"] = time.time() - t_go
         # ---- HiGHS legs (single thread each, sequential): row samples + the FULL LP of the species with the most LP rows
         highs_sizes = [int(x) for x in args.highs_rows.split(",") if x.strip()]
         try:
@@ -383,9 +391,18 @@ class CpuLeg:
             time.sleep(0.2)
         return self._read()
 
+    def go(self):
+        """the timed steps are over: the child may start its HiGHS legs"""
+        if self.path is not None:
+            try:
+                open(self.path + ".go", "w").close()
+            except OSError:
+                pass
+
     def finish(self, timeout):
         if self.proc is None:
             return None
+        self.go()
         try:
             self.proc.wait(timeout=timeout)
         except subprocess.TimeoutExpired:
@@ -396,10 +413,11 @@ class CpuLeg:
         if self.proc.returncode not in (0, None) and "error" not in d:
             self.errfile.seek(0)
             d["error"] = (self.err or "child exit code %s" % self.proc.returncode) + ": " + self.errfile.read()[-1500:].decode(errors="replace")
-        try:
-            os.unlink(self.path)
-        except OSError:
-            pass
+        for f in (self.path, self.path + ".go"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
         return d
 
 
@@ -1004,7 +1022,8 @@ def main():
     out = run_steps(args.steps)[-1]
     barrier()
     dt = time.perf_counter() - t0
-    cpu_child_alive = bool(leg.proc is not None and leg.proc.poll() is None)   # its single-threaded HiGHS legs ran beside the timed steps
+    cpu_child_alive = False                         # the child's HiGHS legs wait for this point (it sleeps on a file between its oracle leg and them)
+    leg.go()
     timings = eng.timing_get()
     eng.timing_enable(False)
     eng.timing_filter(None)
