@@ -361,6 +361,8 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
     int32_t comm_device_buffers;
 } pantax_hip_profiling_config;
 
+/* A selection whose graphs hold more path steps than one resident db addresses (2^32: BASELINE configs[4] on one GPU) goes through the device in
+ * groups of species, one after the other, inside the call -- no limit on the size of the DB other than the device memory a single group needs. */
 int pantax_hip_profile(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *cfg);
 
 /* ---- a1 / a6 host readers (no GPU needed): the file contracts of the pipeline seam, exposed so a

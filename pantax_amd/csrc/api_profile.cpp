@@ -677,35 +677,59 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             hap_names.insert(hap_names.end(), names->begin(), names->end());
             hap_off[k + 1] = hap_names.size();
         }
-        DbHolder sdb{ctx};
-        PTX_TRY(db_upload_parts(ctx, Su, g_rs.data(), g_re.data(), parts.data(), files.data(), &sdb.db));
-        lap("db upload");
-        // the same resident reads with the strain-level drop flags; species binned against the selected ranges
-        // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
-        // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
-        // (strain only: species from the saved report decide membership -- rows it calls "U" carry a drop flag, see a5 above)
-        if (!sharded && flags_dirty) PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data()));   // sharded: flagged rows were not routed; else the tokenizer's flags stand
-        pantax_hip_reads *const sreads_rd = reads.rd;
-        PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, nullptr));
-        lap("  flags + bin selected");
-        uint64_t nU = 0, n_abort = 0;
-        PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
-        lap("  trio index");
-        PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
-        lap("  node coverage");
-        pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, cfg->sample_nodes};
+        met.resize(hap_names.size());
         std::vector<double> cov(Su);
         for (uint32_t k = 0; k < Su; ++k) cov[k] = sel_cov[use[k]];
-        met.resize(hap_names.size());
-        PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data(), met.data(), info.data()));
-        lap("strain step");
-        if (cfg->image_cache == 2) {   // leave images behind for the next run
-            for (uint32_t k = 0; k < Su; ++k)
-                if (src[use[k]].kind != 1) {
-                    const std::vector<std::string> names(hap_names.begin() + (ptrdiff_t)hap_off[k], hap_names.begin() + (ptrdiff_t)hap_off[k + 1]);
-                    PTX_TRY(db_save_image(ctx, sdb.db, k, names, image_of(ranges[sel[use[k]]].species)));
+        // A resident db addresses its path steps with 32 bits.  A selection of more than that (BASELINE configs[4] on one GPU: 1.1e10) is cut into
+        // contiguous groups of species under the limit, and the groups go through the device ONE AFTER THE OTHER -- db upload, binning of the same
+        // resident reads (the reads of the other groups' species fall outside every range: "U"), index, coverage, strain step; species are
+        // independent from a4 on (profile.rs:3297-3319), their rows meet in the table code below exactly as those of one db would.
+        const uint64_t steps_max = ctx->cfg.db_path_steps_max ? ctx->cfg.db_path_steps_max : 3500000000ull;
+        bool flags_set = false;
+        for (uint32_t k0 = 0; k0 < Su;) {
+            uint32_t k1 = k0;
+            uint64_t steps = 0, nodes = 0;
+            while (k1 < Su) {
+                const uint64_t ps = parts[k1].path_off[parts[k1].n_haps] - parts[k1].path_off[0];
+                if (k1 > k0 && (steps + ps > steps_max || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
+                steps += ps; nodes += parts[k1].n_nodes; ++k1;
+            }
+            const uint32_t Sg = k1 - k0;
+            // the file indices of a group's segments are relative to the group's file list
+            std::vector<GraphPart> gparts(parts.begin() + k0, parts.begin() + k1);
+            if (k0)
+                for (GraphPart &pt : gparts) {
+                    if (pt.len_seg.file >= 0) pt.len_seg.file -= (int32_t)k0;
+                    for (UploadSeg &w : pt.walk_segs) if (w.file >= 0) w.file -= (int32_t)k0;
                 }
-            lap("graph images written");
+            DbHolder sdb{ctx};
+            PTX_TRY(db_upload_parts(ctx, Sg, g_rs.data() + k0, g_re.data() + k0, gparts.data(), files.data() + k0, &sdb.db));
+            lap(Sg == Su ? "db upload" : "db upload (a group of the species)");
+            // the same resident reads with the strain-level drop flags; species binned against the selected ranges
+            // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
+            // where only selected species are looked up in the per-species read map, profile.rs:3301-3303)
+            // (strain only: species from the saved report decide membership -- rows it calls "U" carry a drop flag, see a5 above)
+            if (!sharded && flags_dirty && !flags_set) { PTX_TRY(pantax_hip_reads_set_flags(ctx, reads.rd, flags.data())); flags_set = true; }   // sharded: flagged rows were not routed; else the tokenizer's flags stand
+            pantax_hip_reads *const sreads_rd = reads.rd;
+            PTX_TRY(pantax_hip_bin_reads(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, nullptr));
+            lap("  flags + bin selected");
+            uint64_t nU = 0, n_abort = 0;
+            PTX_TRY(pantax_hip_trio_index(ctx, sdb.db, &nU));
+            lap("  trio index");
+            PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
+            lap("  node coverage");
+            pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, cfg->sample_nodes};
+            PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data() + k0, met.data() + hap_off[k0], info.data() + k0));
+            lap("strain step");
+            if (cfg->image_cache == 2) {   // leave images behind for the next run
+                for (uint32_t k = k0; k < k1; ++k)
+                    if (src[use[k]].kind != 1) {
+                        const std::vector<std::string> names(hap_names.begin() + (ptrdiff_t)hap_off[k], hap_names.begin() + (ptrdiff_t)hap_off[k + 1]);
+                        PTX_TRY(db_save_image(ctx, sdb.db, k - k0, names, image_of(ranges[sel[use[k]]].species)));
+                    }
+                lap("graph images written");
+            }
+            k0 = k1;
         }
     }
     return 0;

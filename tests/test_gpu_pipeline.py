@@ -128,6 +128,42 @@ def test_profile_seam_bin_and_gfa(world):
         assert [r[2] for r in rep[:200]] == [names[i] if i >= 0 else "U" for i in sp[:200]]
 
 
+@pytest.mark.parametrize("zip_,image_cache", [("serialize", 0), (None, 0), ("serialize", 1)])
+def test_profile_seam_in_groups_of_species_writes_the_same_files(world, zip_, image_cache, set_opt):
+    """A selection of more path steps than one resident db addresses (2^32: BASELINE configs[4] on one GPU) goes through the device in groups of
+    species, one after the other, inside ONE pantax_hip_profile call (species are independent from a4 on, profile.rs:3297-3319).  Forced here by a
+    tiny limit (option db_path_steps_max: every species a group of its own, then two per group): the tables are the same BYTES as the one-db
+    run's -- from bincode files, GFA text and device-ready images."""
+    sset, root, db, gaf, eng = world
+    cwd = os.getcwd()
+    outs = {}
+    steps = sorted(int(g.path_off[-1]) for g in sset.species)
+    if image_cache:   # leave images behind first -- in a copy of the db: the module's db directory stays free of images for the other tests
+        import shutil
+        db = root / "db_groups_img"
+        shutil.copytree(world[2], db)
+        wd0 = root / ("wd_groups_img_prime_%s" % zip_)
+        wd0.mkdir()
+        os.chdir(str(wd0))
+        try:
+            eng.profile(str(db), str(wd0), str(gaf), zip=zip_, image_cache=2)
+        finally:
+            os.chdir(cwd)
+    for name, limit in [("one", None), ("each", 1), ("pairs", steps[-1] + steps[-2])]:
+        wd = root / ("wd_groups_%s_%s_%d" % (name, zip_, image_cache))
+        wd.mkdir()
+        set_opt(eng, "db_path_steps_max", limit)
+        os.chdir(str(wd))
+        try:
+            eng.profile(str(db), str(wd), str(gaf), zip=zip_, image_cache=image_cache)
+        finally:
+            os.chdir(cwd)
+            set_opt(eng, "db_path_steps_max", None)
+        outs[name] = [open(wd / f, "rb").read() for f in ("species_abundance.txt", "strain_abundance.txt", "ori_strain_abundance.txt")]
+    assert len(outs["one"][1].splitlines()) > 2
+    assert outs["each"] == outs["one"] and outs["pairs"] == outs["one"]
+
+
 def test_profile_seam_resume_strain_only(world):
     """--strain after an earlier --species run (profile.rs:3365-3417): same strain table."""
     sset, root, db, gaf, eng = world
