@@ -684,14 +684,21 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         // contiguous groups of species under the limit, and the groups go through the device ONE AFTER THE OTHER -- db upload, binning of the same
         // resident reads (the reads of the other groups' species fall outside every range: "U"), index, coverage, strain step; species are
         // independent from a4 on (profile.rs:3297-3319), their rows meet in the table code below exactly as those of one db would.
-        const uint64_t steps_max = ctx->cfg.db_path_steps_max ? ctx->cfg.db_path_steps_max : 3500000000ull;
+        // (3e9, not 2^32: the visit table of the index holds a slot per interior path step PLUS pads -- a fifth more at fifty strains per species, where
+        // every 64-slot group holds one 50-visit node -- and its slots are 32-bit too; beyond them the whole db falls back to the node-block kernel,
+        // correct but slower.)  The groups are balanced: ceil(total / limit) of them, each filled up to total / groups.
+        const uint64_t steps_max = ctx->cfg.db_path_steps_max ? ctx->cfg.db_path_steps_max : 3000000000ull;
+        uint64_t steps_total = 0;
+        for (uint32_t k = 0; k < Su; ++k) steps_total += parts[k].path_off[parts[k].n_haps] - parts[k].path_off[0];
+        const uint64_t n_groups = std::max<uint64_t>(1, (steps_total + steps_max - 1) / steps_max);
+        const uint64_t steps_target = std::min<uint64_t>(steps_max, (steps_total + n_groups - 1) / n_groups);
         bool flags_set = false;
         for (uint32_t k0 = 0; k0 < Su;) {
             uint32_t k1 = k0;
             uint64_t steps = 0, nodes = 0;
             while (k1 < Su) {
                 const uint64_t ps = parts[k1].path_off[parts[k1].n_haps] - parts[k1].path_off[0];
-                if (k1 > k0 && (steps + ps > steps_max || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
+                if (k1 > k0 && (steps + ps > steps_target || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
                 steps += ps; nodes += parts[k1].n_nodes; ++k1;
             }
             const uint32_t Sg = k1 - k0;

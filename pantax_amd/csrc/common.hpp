@@ -129,7 +129,7 @@ struct CtxConfig {
     bool stream_prio = true;         // main stream at the highest, side stream at the lowest priority
     bool numa_bind = true;           // the upload crew and its pinned ring live on the GPU's NUMA node
     uint64_t gaf_piece_bytes = 0;    // largest piece of GAF text tokenised at once (0: a sixth of the text, 64 MiB .. 1 GiB)
-    uint64_t db_path_steps_max = 0;  // path steps per resident db of the file seam (0: 3.5e9); a selection beyond it goes through the device group by group (tests lower it)
+    uint64_t db_path_steps_max = 0;  // path steps per resident db of the file seam (0: 3e9); a selection beyond it goes through the device group by group (tests lower it)
     // forced paths (tests compare them with the defaults)
     std::string trio_path;           // "block": every species through the node-block kernel; "bucket": global buckets
     std::string trio_rows;           // "path": lookup rows filed by the pass over the walks
