@@ -1120,6 +1120,8 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
                 case 2825: COVF_LAUNCH(2, 8, 2560) break;
                 case 2423: COVF_LAUNCH(2, 4, 2304) break;
                 case 2425: COVF_LAUNCH(2, 4, 2560) break;
+                case 1823: COVF_LAUNCH(1, 8, 2304) break;
+                case 4423: COVF_LAUNCH(4, 4, 2304) break;
                 case 442: COVF_LAUNCH(4, 4, 2048) break;
                 case 443: COVF_LAUNCH(4, 4, 3072) break;
                 default: COVF_LAUNCH(2, 4, 2048) break;
