@@ -677,11 +677,12 @@ __global__ void __launch_bounds__(256) mask_kernel(const uint2 *__restrict__ til
 __global__ void __launch_bounds__(256) node_haps_fill_kernel(const uint2 *__restrict__ tiles, const uint64_t *__restrict__ path_off,
                                                              const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ hap_species,
                                                              const uint32_t *__restrict__ node_base, const uint64_t *__restrict__ hap_off,
-                                                             unsigned long long *__restrict__ node_haps) {
+                                                             unsigned long long *__restrict__ node_haps, uint32_t fast, const uint32_t *__restrict__ fast_slow) {
     const uint2 tile = tiles[blockIdx.x];
     if (tile.x == 0xFFFFFFFFu) return;
     const uint32_t h = tile.x, sp = hap_species[h], nb = node_base[sp];
     if (hap_off[sp + 1] - hap_off[sp] > 64ull) return;
+    if (fast && !fast_slow[sp]) return;                     // a species of the visit table: node_haps_visits_kernel
     const unsigned long long m = 1ull << (h - hap_off[sp]);
     const uint64_t q0 = path_off[h] + (uint64_t)tile.y * PATH_TILE, qend = path_off[h + 1];
     for (uint64_t q = q0 + threadIdx.x; q < q0 + PATH_TILE && q < qend; q += 256) {
@@ -1018,6 +1019,56 @@ __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint3
 }
 
 // option mask=walk: the path-walk kernel although the table exists (measurements, tests)
+// ... from the VISIT TABLE where a species has one (round 5): the interior visits of a node sit in one stretch of one 64-lane group, so the word of a node
+// is the OR over its stretch of (1 << owner of the visit's position) -- one wave per group, the owners from the species' walk offsets held one per lane
+// (as in the filing of the index rows), one ballot per haplotype of the species, one plain 8-byte store per node; the two END positions of every walk
+// are no interior visits and come in by atomics afterwards (node_haps_ends_kernel).  The pass over the walks above issued a probe + an atomic per path
+// step: 21 ms at 1e4 strains, 50-62 ms per db of 2.8e9 path steps at fifty strains per species.
+__global__ void __launch_bounds__(256) node_haps_visits_kernel(uint32_t NG, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
+                                                               const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
+                                                               const uint64_t *__restrict__ path_off, const uint64_t *__restrict__ hap_off,
+                                                               const uint32_t *__restrict__ path_nodes, unsigned long long *__restrict__ node_haps) {
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= NG) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
+    const bool valid = q != 0xFFFFFFFFu;
+    const uint32_t sp = vis_sp[g], nb = vis_nbase[g];
+    const uint32_t h0 = (uint32_t)hap_off[sp], hs = (uint32_t)hap_off[sp + 1] - h0;
+    if (hs > 64u) return;                                  // (a species of more than 64 haplotypes takes the path walk for its masks, whatever its index path)
+    const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid), hd = vis_head[g] & vmask;
+    const uint32_t woff = (uint32_t)lane < hs ? (uint32_t)path_off[h0 + (uint32_t)lane] : 0xFFFFFFFFu;     // P < 2^32 where a visit table exists
+    uint32_t hl = 0;                                                                     // owner within the species: walk offsets at or below the position, minus one
+    for (uint32_t j = 1; j < hs; ++j) hl += (uint32_t)__builtin_amdgcn_readlane((int)woff, (int)j) <= q ? 1u : 0u;
+    const bool head = (hd >> lane) & 1ull;
+    const uint32_t mid = head ? path_nodes[q] : 0u;                                      // the stretch's node (its first visit names it)
+    // my stretch = lanes [lane, next head or first pad)
+    const unsigned long long he = hd | (~vmask & (vmask + 1ull));
+    const unsigned long long above = he & ~((2ull << lane) - 1ull);
+    const int end = above ? __builtin_ctzll(above) : 64;
+    const unsigned long long range = (end == 64 ? ~0ull : (1ull << end) - 1ull) & ~((1ull << lane) - 1ull);
+    unsigned long long word = 0ull;
+    for (uint32_t j = 0; j < hs; ++j) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && hl == j);
+        if (bal & range) word |= 1ull << j;
+    }
+    if (head) node_haps[nb + mid] = word;
+}
+// the first and the last position of every walk of a visit-table species (a walk of one or two positions has no interior visit at all)
+__global__ void __launch_bounds__(256) node_haps_ends_kernel(uint32_t H, const uint64_t *__restrict__ path_off, const uint32_t *__restrict__ path_nodes,
+                                                             const uint32_t *__restrict__ hap_species, const uint32_t *__restrict__ node_base,
+                                                             const uint64_t *__restrict__ hap_off, const uint32_t *__restrict__ slow,
+                                                             unsigned long long *__restrict__ node_haps) {
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= H) return;
+    const uint32_t sp = hap_species[h];
+    if (slow[sp] || hap_off[sp + 1] - hap_off[sp] > 64ull) return;
+    const uint64_t b = path_off[h], e = path_off[h + 1];
+    if (e == b) return;
+    const unsigned long long m = 1ull << (h - hap_off[sp]);
+    atomicOr(&node_haps[node_base[sp] + path_nodes[b]], m);
+    atomicOr(&node_haps[node_base[sp] + path_nodes[e - 1]], m);
+}
 bool use_node_haps(const Ctx *ctx, const Db *db) { return db->nh_built && ctx->cfg.mask != "walk"; }
 // end of db upload: the node -> haplotypes words of mask_nodes_kernel (one launch over the path tiles)
 int node_haps_build(Ctx *ctx, Db *db) {
@@ -1031,8 +1082,19 @@ int node_haps_build(Ctx *ctx, Db *db) {
     if (!any_small) return 0;
     PTX_HIP(ctx, db->d_node_haps.alloc(V));
     PTX_TRY(zero_fill(ctx, db->d_node_haps.p, V * sizeof(uint64_t)));
-    hipLaunchKernelGGL(node_haps_fill_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p,
-                       db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (unsigned long long *)db->d_node_haps.p);
+    // the species of the visit table from the table, the others by the pass over their walks
+    const bool by_visits = db->trio_visit_ok && db->n_vgroups && db->P < 0xFFFFFFFFull;
+    bool any_walk = !by_visits;
+    if (by_visits) for (uint32_t s = 0; s < db->S; ++s) if (db->h_trio_slow[s] && db->h_hap_off[s + 1] - db->h_hap_off[s] <= 64) any_walk = true;
+    if (by_visits) {
+        hipLaunchKernelGGL(node_haps_visits_kernel, dim3((db->n_vgroups + 3) / 4), dim3(256), 0, ctx->stream, db->n_vgroups, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p,
+                           db->d_vis_sp.p, db->d_path_off.p, db->d_hap_off.p, db->d_path_nodes.p, (unsigned long long *)db->d_node_haps.p);
+        hipLaunchKernelGGL(node_haps_ends_kernel, dim3((uint32_t)((db->H + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)db->H, db->d_path_off.p, db->d_path_nodes.p,
+                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, db->d_trio_slow.p, (unsigned long long *)db->d_node_haps.p);
+    }
+    if (any_walk)
+        hipLaunchKernelGGL(node_haps_fill_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p,
+                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (unsigned long long *)db->d_node_haps.p, by_visits ? 1u : 0u, db->d_trio_slow.p);
     PTX_HIP(ctx, hipGetLastError());
     db->nh_built = true;
     return 0;

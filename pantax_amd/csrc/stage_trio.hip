@@ -527,6 +527,23 @@ __global__ void __launch_bounds__(256) visit_sort_kernel(uint32_t NG, uint32_t *
     const unsigned long long he = hd | (~vmask & (vmask + 1ull));
     const unsigned long long upto = hd & ((2ull << lane) - 1ull), above = he & ~((2ull << lane) - 1ull);
     const int start = upto ? 63 - __builtin_clzll(upto) : lane, end = above ? __builtin_ctzll(above) : 64;
+    // LONG stretches (a node of dozens of visits: fifty strains per species): the ranks below cost a round per distance, 49 of them -- the whole wave
+    // is sorted instead by (stretch, smaller end, larger end, position) in a bitonic network of 21 exchanges, pads (stretch 64) last: a lane's
+    // sorted place IS its slot, because the stretches are the wave's lanes in order (115 -> 70 ms per db of 2.8e9 path steps)
+    if (__builtin_amdgcn_ballot_w64(valid && end - start > 24) != 0ull) {
+        uint32_t k0 = valid ? (uint32_t)start : 64u, k1 = lo, k2 = hi, k3 = q;
+        for (int k = 2; k <= 64; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int partner = lane ^ j;
+                const uint32_t p0 = __shfl(k0, partner), p1 = __shfl(k1, partner), p2 = __shfl(k2, partner), p3 = __shfl(k3, partner);
+                const bool p_less = p0 < k0 || (p0 == k0 && (p1 < k1 || (p1 == k1 && (p2 < k2 || (p2 == k2 && p3 < k3)))));
+                const bool keep_min = ((lane & k) == 0) == (lane < partner);     // ascending blocks keep the smaller key in the lower lane
+                const bool take = keep_min ? p_less : !p_less;                   // (keys are distinct: positions differ; pads equal each other -- either stays)
+                if (take && !(p0 == k0 && p1 == k1 && p2 == k2 && p3 == k3)) { k0 = p0; k1 = p1; k2 = p2; k3 = p3; }
+            }
+        if (k0 != 64u) vis_pos[(uint64_t)g * 64 + lane] = k3;
+        return;
+    }
     int rank = 0;
     // every pair of a stretch is compared ONCE, by its upper lane (positions are distinct: the order is total and strict); the lower lane reads the
     // outcome from the ballot -- three shuffles per distance instead of six (28.8 ms at 1e4 strains, 213 ms per db at fifty strains per species before)
