@@ -1027,15 +1027,16 @@ __global__ void __launch_bounds__(256) sp_pat_off_kernel(uint32_t S, const uint3
 __global__ void __launch_bounds__(256) node_haps_visits_kernel(uint32_t NG, const uint32_t *__restrict__ vis_pos, const uint64_t *__restrict__ vis_head,
                                                                const uint32_t *__restrict__ vis_nbase, const uint32_t *__restrict__ vis_sp,
                                                                const uint64_t *__restrict__ path_off, const uint64_t *__restrict__ hap_off,
-                                                               const uint32_t *__restrict__ path_nodes, unsigned long long *__restrict__ node_haps) {
+                                                               const uint32_t *__restrict__ path_nodes, const uint32_t *__restrict__ by_walk,
+                                                               unsigned long long *__restrict__ node_haps) {
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= NG) return;
+    if (by_walk[vis_sp[g]]) return;                        // (wave-uniform) a species of many haplotypes: the pass over its walks is cheaper
     const int lane = threadIdx.x & 63;
     const uint32_t q = vis_pos[(uint64_t)g * 64 + lane];
     const bool valid = q != 0xFFFFFFFFu;
     const uint32_t sp = vis_sp[g], nb = vis_nbase[g];
     const uint32_t h0 = (uint32_t)hap_off[sp], hs = (uint32_t)hap_off[sp + 1] - h0;
-    if (hs > 64u) return;                                  // (a species of more than 64 haplotypes takes the path walk for its masks, whatever its index path)
     const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid), hd = vis_head[g] & vmask;
     const uint32_t woff = (uint32_t)lane < hs ? (uint32_t)path_off[h0 + (uint32_t)lane] : 0xFFFFFFFFu;     // P < 2^32 where a visit table exists
     uint32_t hl = 0;                                                                     // owner within the species: walk offsets at or below the position, minus one
@@ -1062,7 +1063,7 @@ __global__ void __launch_bounds__(256) node_haps_ends_kernel(uint32_t H, const u
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h >= H) return;
     const uint32_t sp = hap_species[h];
-    if (slow[sp] || hap_off[sp + 1] - hap_off[sp] > 64ull) return;
+    if (slow[sp]) return;                                  // (slow = the species' words come from the pass over its walks)
     const uint64_t b = path_off[h], e = path_off[h + 1];
     if (e == b) return;
     const unsigned long long m = 1ull << (h - hap_off[sp]);
@@ -1082,19 +1083,30 @@ int node_haps_build(Ctx *ctx, Db *db) {
     if (!any_small) return 0;
     PTX_HIP(ctx, db->d_node_haps.alloc(V));
     PTX_TRY(zero_fill(ctx, db->d_node_haps.p, V * sizeof(uint64_t)));
-    // the species of the visit table from the table, the others by the pass over their walks
-    const bool by_visits = db->trio_visit_ok && db->n_vgroups && db->P < 0xFFFFFFFFull;
-    bool any_walk = !by_visits;
-    if (by_visits) for (uint32_t s = 0; s < db->S; ++s) if (db->h_trio_slow[s] && db->h_hap_off[s + 1] - db->h_hap_off[s] <= 64) any_walk = true;
-    if (by_visits) {
+    // the species of the visit table with up to NH_VISIT_HAPS haplotypes from the table, the others by the pass over their walks (the table kernel costs a
+    // readlane + a ballot per haplotype of the species and group: at fifty haplotypes 78 ms per db of 2.8e9 path steps against 50 for the walks' atomics;
+    // at ten: ms against tens of ms)
+    constexpr uint64_t NH_VISIT_HAPS = 16;
+    const bool table = db->trio_visit_ok && db->n_vgroups && db->P < 0xFFFFFFFFull;
+    std::vector<uint32_t> by_walk(db->S ? db->S : 1, 1u);
+    bool any_walk = false, any_visits = false;
+    for (uint32_t s = 0; s < db->S; ++s) {
+        const uint64_t hs = db->h_hap_off[s + 1] - db->h_hap_off[s];
+        by_walk[s] = (table && !db->h_trio_slow[s] && hs <= NH_VISIT_HAPS) ? 0u : 1u;
+        if (hs <= 64) { if (by_walk[s]) any_walk = true; else any_visits = true; }
+    }
+    DevBuf<uint32_t> d_by_walk;
+    PTX_TRY(upload(ctx, d_by_walk, by_walk.data(), by_walk.size()));
+    if (any_visits) {
         hipLaunchKernelGGL(node_haps_visits_kernel, dim3((db->n_vgroups + 3) / 4), dim3(256), 0, ctx->stream, db->n_vgroups, db->d_vis_pos.p, db->d_vis_head.p, db->d_vis_nbase.p,
-                           db->d_vis_sp.p, db->d_path_off.p, db->d_hap_off.p, db->d_path_nodes.p, (unsigned long long *)db->d_node_haps.p);
+                           db->d_vis_sp.p, db->d_path_off.p, db->d_hap_off.p, db->d_path_nodes.p, (const uint32_t *)d_by_walk.p, (unsigned long long *)db->d_node_haps.p);
         hipLaunchKernelGGL(node_haps_ends_kernel, dim3((uint32_t)((db->H + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)db->H, db->d_path_off.p, db->d_path_nodes.p,
-                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, db->d_trio_slow.p, (unsigned long long *)db->d_node_haps.p);
+                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (const uint32_t *)d_by_walk.p, (unsigned long long *)db->d_node_haps.p);
     }
     if (any_walk)
         hipLaunchKernelGGL(node_haps_fill_kernel, dim3((uint32_t)db->n_tiles), dim3(256), 0, ctx->stream, db->d_tiles.p, db->d_path_off.p, db->d_path_nodes.p,
-                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (unsigned long long *)db->d_node_haps.p, by_visits ? 1u : 0u, db->d_trio_slow.p);
+                           db->d_hap_species.p, db->d_node_base.p, db->d_hap_off.p, (unsigned long long *)db->d_node_haps.p, 1u, (const uint32_t *)d_by_walk.p);
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_by_walk goes out of scope
     PTX_HIP(ctx, hipGetLastError());
     db->nh_built = true;
     return 0;
