@@ -25,7 +25,7 @@ with tempfile.TemporaryDirectory(dir=root) as td:
     print("GAF: %.2f GB written in %.1f s under %s" % (nb / 1e9, time.perf_counter() - t0, root), flush=True)
     del rd
     eng = Engine(0)
-    res = bench.file_seam_leg(eng, species, gp, td, threads, None, spec["reads"])
+    res = bench.file_seam_leg(eng, species, gp, td, threads, None, spec["reads"], fr=0.5 if spec.get("long_reads") else 0.3)
     eng.close()
 res["workload"] = spec["name"]
 print(json.dumps(res, indent=1))
