@@ -1,6 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && mkdir -p gpurun_out
-( time timeout 1500 python bench.py --detail-file gpurun_out/r5_final_detail_default.json > gpurun_out/r5_final_bench_default.json 2> gpurun_out/r5_final_bench_default.err ) 2> gpurun_out/r5_final_bench_default.time
-echo "default bench exit $?"; tail -3 gpurun_out/r5_final_bench_default.time
-timeout 900 python bench.py --workload cfg5_share --no-cpu-baseline --no-hard --steps 10 --detail-file gpurun_out/r5_final_detail_cfg5_share.json > gpurun_out/r5_final_bench_cfg5_share.json 2> gpurun_out/r5_final_bench_cfg5_share.err
-echo "cfg5_share exit $?"
+timeout 1700 python tools/stress.py 800 110000 > gpurun_out/r5_stress_d.log 2>&1; echo "stress d exit $?"; tail -1 gpurun_out/r5_stress_d.log | cut -c1-300
+PANTAX_COV_GENERAL=1 timeout 900 python tools/stress.py 300 120000 > gpurun_out/r5_stress_covgen.log 2>&1; echo "stress cov_general exit $?"; tail -1 gpurun_out/r5_stress_covgen.log | cut -c1-300
+PANTAX_MASK=walk timeout 900 python tools/stress.py 300 130000 > gpurun_out/r5_stress_maskwalk.log 2>&1; echo "stress mask=walk exit $?"; tail -1 gpurun_out/r5_stress_maskwalk.log | cut -c1-300
