@@ -140,6 +140,7 @@ struct CtxConfig {
     bool cov_general = false;        // every group through coverage_step_kernel
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
+    int cov_item_groups = 0;         // groups of 64 steps per work item of the short-read coverage kernel (0: 64)
     int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)

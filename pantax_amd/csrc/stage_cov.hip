@@ -178,7 +178,7 @@ __device__ __forceinline__ void mark_full_wave(uint32_t *__restrict__ full, uint
 // Dirichlet-distributed sample -- 4096 steps span more nodes than the LDS windows hold, and every update outside them is a memory-side
 // atomic: 3.3 of the kernel's 10.6 ms at 1e4 strains.  By node block the windows cover the block whatever the depth, and a deeply
 // covered block is simply cut into more items.)
-constexpr uint32_t COV_ITEM_GROUPS = 64;
+constexpr uint32_t COV_ITEM_GROUPS = 128;     // (64 until the end of round 5: a block of 2048 ids holds ~80 groups at 1e8 reads, cut as 64 + 17; whole blocks as ONE item: 5.2 -> 5.0 ms)
 struct __attribute__((packed, aligned(4))) EntPair { uint32_t a, b, c, d; };     // two neighbouring lookup entries {smaller end, larger end}
 constexpr int COV_BLK_SHIFT = 11;
 template <bool WITH_TRIO, int U, int PASSES, int WIN>
@@ -1024,9 +1024,15 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
         for (uint32_t b = NBLK; b-- > 0;) { if (fg[b] == 0xFFFFFFFFu) fg[b] = fg[b + 1]; else if (fg[b] > fg[b + 1]) monotone = false; }
         fg[0] = 0;                                                  // groups in front of the first live one (pads) belong to the first block
         std::vector<uint2> items;
+        const uint32_t cap = ctx->cfg.cov_item_groups > 0 ? (uint32_t)ctx->cfg.cov_item_groups : COV_ITEM_GROUPS;
         if (monotone)
             for (uint32_t b = 0; b < NBLK; ++b)
-                for (uint32_t g = fg[b]; g < fg[b + 1]; g += COV_ITEM_GROUPS) items.push_back(make_uint2(g, std::min(fg[b + 1], g + COV_ITEM_GROUPS)));
+            {   // a block's groups in EQUAL items of at most `cap` groups (81 groups: 41 + 40, not 64 + 17 -- a workgroup zeroes and flushes its LDS windows once per item)
+                const uint32_t n = fg[b + 1] - fg[b];
+                if (!n) continue;
+                const uint32_t k = (n + cap - 1) / cap, per = (n + k - 1) / k;
+                for (uint32_t g = fg[b]; g < fg[b + 1]; g += per) items.push_back(make_uint2(g, std::min(fg[b + 1], g + per)));
+            }
         else   // cannot happen with the counting sort above; never silent: plain cuts of the stream
             for (uint32_t g = 0; g < n_groups; g += COV_ITEM_GROUPS) items.push_back(make_uint2(g, std::min(n_groups, g + COV_ITEM_GROUPS)));
         rd->n_items = (uint32_t)items.size();
