@@ -108,6 +108,11 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
             db->h_path_off[gh + 1] = db->h_path_off[gh] + (parts[s].path_off[h + 1] - parts[s].path_off[h]);
         }
     db->P = db->h_path_off[db->H];
+    // a row's owner within its species travels in 16 bits (d_trio_hap, the statistics by key) and the basis inverse of the LP is indexed with 32:
+    // the bound lad_prepare states, checked here so that no stage entry point ever sees a truncated owner
+    for (uint32_t s = 0; s < S; ++s)
+        if (parts[s].n_haps > 30000ull)
+            return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u has %llu haplotypes (limit 30000 per species)", s, (unsigned long long)parts[s].n_haps);
     if (db->V >= 0xFFFFFFFFull) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: %llu nodes on one GPU exceeds the 32-bit node index", (unsigned long long)db->V);
     db->h_range_start.assign(range_start, range_start + S);
     db->h_range_end.assign(range_end, range_end + S);

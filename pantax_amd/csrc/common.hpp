@@ -52,7 +52,8 @@ int fail(Ctx *ctx, int code, const char *fmt, ...);
 // freed since the last device-wide wait is reused, the device is synchronised once -- the guarantee hipFree gave.
 // cap of the cache: three quarters of the device's memory (a db of 1e4 strains with its scratch is ~100 GB: under the 48 GB of round 4 every
 // call of the pipeline seam paid 0.7-1.2 s of hipMalloc for the blocks that did not fit the cache)
-size_t dev_cache_max();
+size_t dev_cache_max(int dev);
+void dev_cache_set_max(long long bytes);   // < 0: per-device default
 hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out);
 void dev_cache_free(void *p, size_t cap, int dev);   // dev: the device the block was allocated on (the caller's current device may differ)
 void dev_cache_trim();   // really free everything cached for the current device (pantax_hip_destroy)
@@ -127,6 +128,7 @@ struct CtxConfig {
     int stage_threads = 32;          // host threads that fill the pinned upload ring (at 16 the filling, not the DMA, bounds a 15-GB load)
     int stage_ch_mb = 0;             // chunk size of the ring in MB (0: from the transfer size)
     bool stream_prio = true;         // main stream at the highest, side stream at the lowest priority
+    int dev_cache_gb = -1;           // cap of the per-process cache of released device blocks in GB (-1: min(3/4 of the device, 9/10 of what was free at first use); 0: nothing cached)
     bool numa_bind = true;           // the upload crew and its pinned ring live on the GPU's NUMA node
     uint64_t gaf_piece_bytes = 0;    // largest piece of GAF text tokenised at once (0: a sixth of the text, 64 MiB .. 1 GiB)
     uint64_t db_path_steps_max = 0;  // path steps per resident db of the file seam (0: 3e9); a selection beyond it goes through the device group by group (tests lower it)

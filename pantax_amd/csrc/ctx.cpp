@@ -94,7 +94,7 @@ enum OptKind { O_BOOL, O_INT, O_U32, O_U64, O_STR };
 struct OptDesc { const char *name; OptKind kind; size_t off; };
 #define OPT(nm, kind, field) {nm, kind, offsetof(CtxConfig, field)}
 const OptDesc OPTIONS[] = {
-    OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind),
+    OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind), OPT("dev_cache_gb", O_INT, dev_cache_gb),
     OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("db_path_steps_max", O_U64, db_path_steps_max), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("trio_two_pass", O_BOOL, trio_two_pass), OPT("uniq_hash", O_INT, uniq_hash),
     OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_count", O_BOOL, cov_count), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
@@ -150,6 +150,7 @@ int pantax_hip_set_option(pantax_hip_ctx *ctx, const char *name, const char *val
     if (!ctx || !name) return PANTAX_HIP_E_INVALID;
     std::lock_guard<std::recursive_mutex> ptx_lock__(ctx->mu);
     const int rc = ctx_set_option(ctx->cfg, name, value);
+    if (rc == 0 && std::strcmp(name, "dev_cache_gb") == 0) dev_cache_set_max(ctx->cfg.dev_cache_gb < 0 ? -1 : (long long)ctx->cfg.dev_cache_gb << 30);
     return rc == 0 ? 0 : fail(ctx, rc, "set_option: unknown option or unparsable value: %s=%s", name, value ? value : "(default)");
 }
 
@@ -181,6 +182,7 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
     ctx->device = dev;
     ctx->n_cu = prop.multiProcessorCount;
     config_from_env(ctx->cfg);   // the only place the library reads the environment
+    if (ctx->cfg.dev_cache_gb >= 0) dev_cache_set_max((long long)ctx->cfg.dev_cache_gb << 30);
     {   // the GPU's NUMA node and its CPUs (sysfs); anything missing = nothing is bound
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) == hipSuccess) {
@@ -318,13 +320,32 @@ inline size_t round_cap(size_t bytes) {
 }
 }  // namespace
 
-size_t dev_cache_max() {
-    static const size_t cap = [] {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)(48ull << 30);
-        return total_b / 4 * 3;
-    }();
+// The cap is PER DEVICE and sized from what is free when the device is first used: min(3/4 of the device, 9/10 of what was free) -- a process
+// that shares its GPU (N ranks of a dry run on one device, parallel test workers) must not sit on memory its siblings need.  `dev_cache_gb`
+// (option / pantax_hip_set_option) overrides it for every device of the process; 0 caches nothing.
+static std::atomic<long long> g_dev_cache_cap_override{-1};
+void dev_cache_set_max(long long bytes) { g_dev_cache_cap_override.store(bytes); }
+size_t dev_cache_max(int dev) {
+    const long long ov = g_dev_cache_cap_override.load();
+    if (ov >= 0) return (size_t)ov;
+    static std::mutex mu;
+    static std::map<int, size_t> caps;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = caps.find(dev);
+    if (it != caps.end()) return it->second;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    size_t free_b = 0, total_b = 0, cap = (size_t)(48ull << 30);
+    if (cur != dev) (void)hipSetDevice(dev);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b != 0) cap = std::min(total_b / 4 * 3, free_b / 10 * 9);
+    if (cur != dev) (void)hipSetDevice(cur);
+    caps[dev] = cap;
     return cap;
+}
+// a sibling process is short of memory when less than an eighth of the device is free: big blocks are then given back instead of kept
+static bool dev_memory_is_tight() {
+    size_t free_b = 0, total_b = 0;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b != 0 && free_b < total_b / 8;
 }
 
 hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out) {
@@ -371,7 +392,8 @@ void dev_cache_free(void *p, size_t cap, int dev) {
     {
         std::lock_guard<std::mutex> g(c.mu);
         DevCache::PerDevice &d = c.dev[dev];
-        if (cap && d.cached_bytes + cap <= dev_cache_max()) {
+        // (the memory query costs microseconds: only blocks of 64 MB and more pay it)
+        if (cap && d.cached_bytes + cap <= dev_cache_max(dev) && !(cap >= (size_t(64) << 20) && dev_memory_is_tight())) {
             d.free_blocks.emplace(cap, DevCache::Block{p, ++d.free_epoch});
             d.cached_bytes += cap;
             return;

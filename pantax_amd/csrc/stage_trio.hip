@@ -1609,7 +1609,22 @@ extern "C" {
 int pantax_hip_trio_index(pantax_hip_ctx *ctx, pantax_hip_db *db, uint64_t *n_unique_total_out) {
     if (!ctx || !db) return PANTAX_HIP_E_INVALID;
     PTX_ENTER(ctx);
-    if (!db->trio_built) PTX_TRY(trio_index_build(ctx, db));
+    if (!db->trio_built) {
+        const bool rebuild = db->trio_sizes_known;
+        PTX_TRY(trio_index_build(ctx, db));
+        // a db's FIRST build reads the error word of its kernels itself; a rebuild (after pantax_hip_db_reset) leaves it for the pipelined step to
+        // fetch with its results.  A stage caller consumes the index right away (trio_get, node_coverage): the word is read here, behind the build
+        if (rebuild && db->trio_scratch.d_tot.p) {
+            uint32_t err = 0;
+            PTX_TRY(download(ctx, &err, db->trio_scratch.d_tot.p + 2, 1));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (err) {
+                db->trio_built = false;
+                return fail(ctx, PANTAX_HIP_E_LIMIT, "trio_index: %u problems in the rebuild's kernels: visit groups out of order / offsets that are not this table's, or a node "
+                                                     "that heads 2^16 or more unique-trio rows", err);
+            }
+        }
+    }
     if (n_unique_total_out) *n_unique_total_out = db->U;
     return 0;
 }

@@ -51,6 +51,8 @@ class Engine:
     def release(self):
         """free the resident db and reads (HBM), keep the ctx"""
         if self.ctx:
+            if self.db and self._inflight:
+                self.drain_steps()                                # enqueued steps still read the db and the reads
             if self.reads:
                 self.lib.pantax_hip_reads_free(self.ctx, self.reads)
                 self.reads = None

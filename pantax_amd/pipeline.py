@@ -338,7 +338,8 @@ def finalize_end(pending, species_names, hap_names, cfg, comm):
     total_abs = sum(float(b[:, 1].sum()) for b in sp_blk)            # profile.rs:341
     act = [(b[:, 0] == 1) & (b[:, 1] > 0) & (b[:, 1] / total_abs > cfg.min_species_abundance) for b in sp_blk]   # profile.rs:602
     g_pass = sum(float(b[a, 3].sum()) for b, a in zip(sp_blk, act))  # profile.rs:3243
-    n_active = int(act[comm.rank].sum())
+    # a rank counts its own species; the K dbs of one GPU (finalize_many) are one rank's species: all of them
+    n_active = int(sum(a.sum() for a in act)) if getattr(comm, "counts_every_block", False) else int(act[comm.rank].sum())
     all_sn, all_hn = comm.names(species_names, hap_names)          # collective on its first call only (cached)
     if comm.rank != 0:
         return [], [], n_active
@@ -461,6 +462,7 @@ class _SlabComm:
 
 class _ManyComm:
     rank = 0
+    counts_every_block = True
 
     def __init__(self, species_names_list, hap_names_list):
         self.world = len(species_names_list)
@@ -473,8 +475,9 @@ class _ManyComm:
         return self._names
 
 
-def split_species_by_path_steps(path_steps, limit=3_600_000_000):
-    """contiguous groups of species whose path steps sum to at most `limit` (< 2^32 with room for the padded visit table), as few groups as
+def split_species_by_path_steps(path_steps, limit=3_000_000_000):
+    """contiguous groups of species whose path steps sum to at most `limit` (the C seam's cap, api_profile.cpp `db_path_steps_max`: the visit
+    table's pads -- about 20 % at 50 strains -- share the 32-bit slots with the steps), as few groups as
     that takes and about equally heavy -> list of (first species, end species)"""
     ps = [int(p) for p in path_steps]
     for i, p in enumerate(ps):
