@@ -139,7 +139,9 @@ struct CtxConfig {
     std::string mask;                // "walk": membership masks from the path walk
     std::string row_sort;            // "radix" / "nodes"
     std::string objective;           // "nodes": the LP objective summed over the nodes
-    bool cov_general = false;        // every group through coverage_step_kernel
+    bool cov_general = false;        // every group through the kernel of the longer walks (coverage_fast_kernel<.., LONG>; cov_long=step: coverage_step_kernel)
+    std::string cov_long;            // "step": round 5's coverage_step_kernel for the groups that hold steps of walks of more than 64 steps
+    int covl_shape = -1;             // shape of the long-walk kernel: <U><groups per workgroup / 8><window / 1024><back / 256> (default 2234)
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     // measurement shapes
     int cov_item_groups = 0;         // groups of 64 steps per work item of the short-read coverage kernel (0: 64)

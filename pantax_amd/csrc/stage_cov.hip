@@ -181,17 +181,49 @@ __device__ __forceinline__ void mark_full_wave(uint32_t *__restrict__ full, uint
 constexpr uint32_t COV_ITEM_GROUPS = 128;     // (64 until the end of round 5: a block of 2048 ids holds ~80 groups at 1e8 reads, cut as 64 + 17; whole blocks as ONE item: 5.2 -> 5.0 ms)
 struct __attribute__((packed, aligned(4))) EntPair { uint32_t a, b, c, d; };     // two neighbouring lookup entries {smaller end, larger end}
 constexpr int COV_BLK_SHIFT = 11;
-template <bool WITH_TRIO, int U, int PASSES, int WIN>
+//
+// LONG (round 6): the same select-only body for the groups that hold steps of walks of MORE than 64 steps (HiFi / ONT reads; round 5 sent them through
+// coverage_step_kernel, whose per-lane branches for wave-straddling walks -- dependent loads under an exec mask for the two neighbours across a wave
+// border, for the first node of the walk, for the walk sums -- made it the kernel furthest from its roofline: 0.16 of peak with no wasted traffic).
+// What a step of such a walk needs from OTHER waves is fetched unconditionally and wave-uniformly:
+//   * the two steps in front of the wave (ids, step codes, node records): addresses that depend on the group alone -> scalar loads, issued with the
+//     level they belong to (ids / codes with the stream, node records with the node gather), never a dependent load behind a per-lane test;
+//   * per slot {length of the walk's first node, sum of the node lengths before the last step} (walk_sum_kernel) and the id of the walk's first
+//     step: gathers with the read record / the node record, for every lane (the lanes of one walk share the address);
+// and every per-lane case is a select.  only_long != 0: groups without a step of a longer walk are the plain instantiation's.
+template <int WIN>
+__device__ __forceinline__ void mark_full_out_wave(uint32_t *__restrict__ full, bool out, uint32_t v) {
+    // the steps of a long walk are neighbouring nodes: dozens of lanes would OR into the SAME word, and memory-side atomics on one address run one
+    // after the other -- the lanes of a word combine their bits first and ONE of them issues the atomic (wave-uniform loop, called by all 64 lanes)
+    unsigned long long todo = ballot1(out);
+    const uint32_t w = v >> 5, bit = 1u << (v & 31);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, leader);
+        const bool mine = out & (w == wl);
+        const uint32_t orv = wave_reduce(mine ? bit : 0u, [](uint32_t x, uint32_t y) { return x | y; });
+        if (lane == leader) atomicOr(&full[wl], orv);
+        todo &= ~ballot1(mine);
+    }
+}
+template <bool WITH_TRIO, int U, int PASSES, int WIN, bool LONG = false>
 __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     const uint2 *__restrict__ items, const uint32_t *__restrict__ group_slot, const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
     const uint32_t *__restrict__ node_id, const uint8_t *__restrict__ step_code, const uint8_t *__restrict__ active,
     const uint4 *__restrict__ node_rec, const uint64_t *__restrict__ bit_off, uint64_t V, unsigned long long *__restrict__ bases,
     uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint2 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
-    unsigned long long *__restrict__ n_abort, uint32_t ablate, int blk_shift) {
+    unsigned long long *__restrict__ n_abort, uint32_t ablate, int blk_shift,
+    const uint32_t *__restrict__ long_sum = nullptr, const uint32_t *__restrict__ long_len0 = nullptr, uint32_t only_long = 0u,
+    uint32_t chunk_groups = 0u, uint32_t total_groups = 0u, uint32_t win_back = 0u) {
     constexpr int WAVES = COV_BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint2 item = items[blockIdx.x];
-    const uint32_t g0 = item.x, n_groups = item.y;                            // this workgroup's groups [g0, n_groups)
+    // this workgroup's groups [g0, n_groups): an item of the read layout -- or, LONG, a plain cut of the stream: a long walk begins anywhere in a group,
+    // so hardly any group starts with the first step of a read and the layout's items are arbitrary cuts anyway; the windows then begin `win_back` nodes
+    // in front of the first live step's node (a reverse-strand walk runs DOWN from its first node, the key the stream is ordered by)
+    uint32_t g0, n_groups;
+    if constexpr (LONG) { g0 = blockIdx.x * chunk_groups; n_groups = min(g0 + chunk_groups, total_groups); }
+    else { const uint2 item = items[blockIdx.x]; g0 = item.x; n_groups = item.y; }
     for (int i = threadIdx.x; i < (int)(cov_lds_bytes(WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the three windows, one block
     // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
     uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
@@ -206,7 +238,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         // are in no particular order, so later reads of the item may start hundreds of nodes in front of the first one -- every read of
         // the item starts inside the block (build_step_read), and ids and node indices run in step inside a species
         const uint32_t id0 = node_id[(uint64_t)g * 64], v0 = id0 + sr0.y, in_blk = id0 & ((1u << blk_shift) - 1u);
-        const uint32_t back = in_blk + 64u;
+        const uint32_t back = LONG ? win_back : in_blk + 64u;
         wlo = (v0 > back ? v0 - back : 0u) & ~63u;
         win_n = WIN;
         const uint64_t b_lo = bit_off[wlo], b_hi = bit_off[min((uint64_t)wlo + WIN, V)];
@@ -270,14 +302,29 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         uint4 rr[U];
         uint2 sr[U];
         bool pad[U];
+        uint32_t ll0[U], lsum[U];                                             // LONG: first node length / sum of the lengths before the last step, by slot
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             pad[u] = code[u] == STEP_PAD;
-            run[u] = run[u] & any1(!pad[u]) & none1(!pad[u] & ((code[u] & STEP_LONG) != 0u));   // nothing here / a longer walk's steps: coverage_step_kernel's group
+            const bool has_long = any1(!pad[u] & ((code[u] & STEP_LONG) != 0u));
+            // nothing here / a group of the OTHER instantiation (steps of a longer walk: LONG's; none: the plain one's, unless LONG takes every group)
+            run[u] = run[u] & any1(!pad[u]) & (LONG ? (has_long | (only_long == 0u)) : !has_long);
             const uint32_t sl = slot_in_group(gs[u], code[u], lane);
             const uint32_t slot = (pad[u] | !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
             rr[u] = read_rec[slot];
             sr[u] = slot_rec[slot];
+            if constexpr (LONG) { ll0[u] = long_len0[slot]; lsum[u] = long_sum[slot]; }
+        }
+        // LONG: the two steps in front of the wave's group (wave-uniform addresses: position of the group - 1, - 2; the dword of step codes in front of it)
+        uint32_t h_id1[U], h_id2[U], h_codes[U];
+        if constexpr (LONG) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t gu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gw + (uint32_t)u));
+                const uint64_t t0 = (uint64_t)(run[u] && gu != 0u ? gu : 1u) * 64;     // (group 0 has nothing in front of it: any in-range address)
+                h_id1[u] = node_id[t0 - 1]; h_id2[u] = node_id[t0 - 2];
+                h_codes[u] = *reinterpret_cast<const uint32_t *>(step_code + t0 - 4);
+            }
         }
         // ---- level 3
         uint4 nr[U];
@@ -291,19 +338,47 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             act[u] = active[ok[u] ? sr[u].x : 0u];      // never null here (the launcher passes all-ones when no species is deselected): an unconditional load
                                                         // travels beside the node record; under a pointer test the compiler waited for it first
         }
+        // LONG: id of the walk's first step (one address per walk) and the node records of the two steps in front of the wave (wave-uniform: the
+        // walk of lane 0, when it began one / two steps or more before this group)
+        uint32_t idf[U], i0_[U], hv1[U], hv2[U];
+        uint4 nrh1[U], nrh2[U];
+        if constexpr (LONG) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                idf[u] = node_id[rr[u].x];
+                const uint32_t gbase = (gw + (uint32_t)u) * 64u;
+                const bool ok0 = __builtin_amdgcn_readfirstlane((int)ok[u]) != 0;
+                i0_[u] = ok0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(gbase - rr[u].x)) : 0u;      // lane 0's position in its walk
+                const uint32_t delta0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sr[u].y);
+                hv1[u] = i0_[u] >= 1u ? h_id1[u] + delta0 : wlo;
+                hv2[u] = i0_[u] >= 2u ? h_id2[u] + delta0 : wlo;
+                nrh1[u] = node_rec[hv1[u]]; nrh2[u] = node_rec[hv2[u]];
+            }
+        }
         // ---- level 4: the unique-trio entries of the window (i-2, i-1, i), requested as soon as the head is known
         uint32_t i_[U], nl[U], len0[U], nh[U], hx[U], tlo[U], thi[U];
         uint2 e0[U], e1[U];
-        bool live[U], single[U], dead_read[U];
+        bool live[U], single[U], dead_read[U], cross[U];
+        int dist[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t gbase = (gw + (uint32_t)u) * 64u;
             i_[u] = gbase + (uint32_t)lane - rr[u].x;                         // position in the walk (T_pad < 2^32)
             ok[u] = ok[u] & (act[u] != 0u);
             nl[u] = ok[u] ? nr[u].z : 0u;
+            if constexpr (LONG) {
+                dist[u] = (int)min(ok[u] ? i_[u] : 0u, (uint32_t)lane);       // earlier steps of my walk held by lower lanes
+                cross[u] = ok[u] & (i_[u] > (uint32_t)lane);                  // the walk began before this wave
+                const uint32_t in_wave = __shfl(nl[u], lane - dist[u]);
+                len0[u] = cross[u] ? ll0[u] : in_wave;
+            } else
             len0[u] = __shfl(nl[u], lane - (int)i_[u]);                       // length of the walk's first node: the lane of step 0 (live lanes)
-            const uint32_t v2 = wave_shr1(wave_shr1(v[u]));
-            const uint32_t hw1 = wave_shr1(nr[u].w), hy1 = wave_shr1(nr[u].y);         // the lookup head of the window's MIDDLE node: the lane below
+            uint32_t v2 = wave_shr1(wave_shr1(v[u]));
+            uint32_t hw1 = wave_shr1(nr[u].w), hy1 = wave_shr1(nr[u].y);         // the lookup head of the window's MIDDLE node: the lane below
+            if constexpr (LONG) {                                             // across the wave border: the records fetched for the steps in front of the group
+                v2 = lane == 0 ? hv2[u] : lane == 1 ? hv1[u] : v2;
+                hw1 = lane == 0 ? nrh1[u].w : hw1; hy1 = lane == 0 ? nrh1[u].y : hy1;
+            }
             single[u] = rr[u].y == 1u;
             dead_read[u] = !single[u] & (rr[u].z > len0[u]);                  // assert :854 -> the whole read contributes nothing
             live[u] = ok[u] & !dead_read[u] & !(single[u] & (rr[u].w < rr[u].z));   // :821-827
@@ -329,7 +404,8 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             // `seen` before this step = wave prefix sum of the walk's aligned lengths minus its value at the walk's first lane
             const uint32_t contrib = (live[u] & !single[u]) ? (i == 0u ? nl[u] - ps : nl[u]) : 0u;
             const uint32_t pexcl = wave_incl_scan_dpp(contrib) - contrib;
-            const uint32_t seen = pexcl - __shfl(pexcl, lane - (int)i);
+            uint32_t seen = pexcl - __shfl(pexcl, lane - (LONG ? dist[u] : (int)i));
+            if constexpr (LONG) seen = cross[u] ? lsum[u] - ps : seen;        // (used by a walk's last step only) all steps but the last: walk_sum_kernel
             const uint32_t tgt = pe - ps;                                     // target (profile.rs:800) where it is not negative
             uint32_t aln = nl[u];                                             // :860-862
             if (i + 1u == k) aln = ((pe >= ps) & (tgt > seen)) ? tgt - seen : 0u;   // :857-859 max(target - seen, 0)
@@ -339,16 +415,25 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             if (hi > nl[u]) hi = nl[u];                                       // :871
             const bool markable = live[u] & (hi > sidx) & !(single[u] & !((ps < pe) & (pe <= nl[u])));   // :832
             const uint32_t dupd = code[u] & STEP_DIST;                        // distance back to the node's first occurrence in the walk (0: this is it)
-            const uint32_t rl = !live[u] ? 0u : dupd == 0u ? aln : (dupd == i ? len0[u] - ps : nl[u]);   // read_nodes_len :879-882
+            bool earlier = dupd != 0u, at_step0 = dupd == i;                  // the node occurred earlier in the walk / its first occurrence is step 0
+            if constexpr (LONG) {                                             // a longer walk's code: STEP_LONG | occurred earlier
+                const bool lc = (code[u] & STEP_LONG) != 0u;
+                const uint32_t id_first = cross[u] ? idf[u] : __shfl(id[u], lane - dist[u]);
+                earlier = lc ? (code[u] & 1u) != 0u : earlier;
+                at_step0 = lc ? id[u] == id_first : at_step0;
+            }
+            const uint32_t rl = !live[u] ? 0u : !earlier ? aln : (at_step0 ? len0[u] - ps : nl[u]);   // read_nodes_len :879-882
             const uint32_t off = v[u] - wlo;                                  // unsigned wrap: nodes below the window are out of range too
             const bool inw = off < win_n;
-            if (live[u] & (dupd == 0u) & (aln != 0u) && !ABL(2u)) {           // :881 / :828
+            if (live[u] & !earlier & (aln != 0u) && !ABL(2u)) {               // :881 / :828
                 if (inw & (aln < (1u << 18))) atomicAdd(&S_WIN(off), aln);
                 else atomicAdd(&bases[v[u]], (unsigned long long)aln);
             }
+            const bool whole = markable & (sidx == 0u) & (hi == nl[u]);       // the whole node: one flag
+            if constexpr (LONG) { if (!ABL(1u) && !ABL(8u)) mark_full_out_wave<WIN>(full, whole & !inw, v[u]); }
             if (markable && !ABL(1u)) {
-                if (sidx == 0u && hi == nl[u]) {                              // the whole node: one flag
-                    if (inw) S_FULL(WIN, off) = 1; else if (!ABL(8u)) atomicOr(&full[v[u] >> 5], 1u << (v[u] & 31));
+                if (whole) {
+                    if (inw) S_FULL(WIN, off) = 1; else if (!LONG && !ABL(8u)) atomicOr(&full[v[u] >> 5], 1u << (v[u] & 31));
                 } else if (off < mark_n) {
                     const uint32_t rel = nr[u].x - bit0_lo;
                     mark_window(WIN, rel + sidx, rel + hi);
@@ -358,7 +443,18 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                 }
             }
             if (WITH_TRIO && !ABL(4u)) {                                      // :890-907
-                const uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
+                uint32_t rl1 = wave_shr1(rl), rl2 = wave_shr1(rl1);
+                if constexpr (LONG) {
+                    // read_nodes_len of the two steps in front of the wave (never a walk's last step): the length aligned at the node's FIRST occurrence
+                    // in the read -- wave-uniform values of lane 0's walk (lane 1 uses them only when it continues that walk)
+                    const uint32_t idf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)idf[u]), l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)len0[u]),
+                                   ps0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps);
+                    const uint32_t c1 = h_codes[u] >> 24, c2 = (h_codes[u] >> 16) & 0xFFu;
+                    const uint32_t rlh1 = ((i0_[u] == 1u) | (((c1 & 1u) != 0u) & (h_id1[u] == idf0))) ? l0 - ps0 : nrh1[u].z;
+                    const uint32_t rlh2 = ((i0_[u] == 2u) | (((c2 & 1u) != 0u) & (h_id2[u] == idf0))) ? l0 - ps0 : nrh2[u].z;
+                    rl2 = lane == 0 ? rlh2 : lane == 1 ? rlh1 : rl2;
+                    rl1 = lane == 0 ? rlh1 : rl1;
+                }
                 // a row IS its lookup entry (round 5): the index of the entry that matches (rows are 32-bit; NO_ROW: none)
                 constexpr uint32_t NO_ROW = 0xFFFFFFFFu;
                 const bool m0 = (nh[u] != 0u) & (e0[u].x == tlo[u]) & (e0[u].y == thi[u]);
@@ -1156,7 +1252,39 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         // groups that hold steps of longer walks (HiFi / ONT reads): the general kernel.  U groups of 64 steps in flight per wave,
         // PASSES rounds per workgroup (PANTAX_COV_SHAPE=<U><PASSES> picks another instantiation, for measurements);
         // PANTAX_COV_GENERAL=1 sends every group through it (measurements, and the tests force it).
-        if (rd->n_long || cov_general) {
+        const bool long_by_step = ctx->cfg.cov_long == "step";   // round 5's kernel for the groups of longer walks (measurements, and the tests compare the two)
+        if ((rd->n_long || cov_general) && !long_by_step) {
+            // round 6: the select-only body (coverage_fast_kernel<.., LONG>) over plain cuts of the stream.  covl_shape = <U><groups per workgroup / 8><window /
+            // 1024 nodes><nodes in front of the first step / 256>: default 2 groups in flight per wave, 16 groups (1024 steps, ~2 HiFi reads) per workgroup,
+            // a 3072-node window that begins 1024 nodes in front of the first live step (reverse-strand walks run down from their first node)
+            KTimer t(ctx, "coverage_long_kernel");
+            if (!rd->d_long_sum.p) { PTX_HIP(ctx, rd->d_long_sum.alloc(rd->R)); PTX_HIP(ctx, rd->d_long_len0.alloc(rd->R)); }   // (cov_general over short reads: never read)
+            const uint32_t only_long = cov_general ? 0u : 1u;
+            int shape = ctx->cfg.covl_shape > 0 ? ctx->cfg.covl_shape : 2834;
+            // (four digits <U><G><W><B>, or five <U><GG><W><B> for more than 72 groups per workgroup)
+            const int su = shape >= 10000 ? shape / 10000 : shape / 1000, sg = shape >= 10000 ? shape / 100 % 100 : shape / 100 % 10, sw = shape / 10 % 10, sb = shape % 10;
+            const uint32_t chunk_groups = (uint32_t)std::max(1, sg) * 8u, total_groups = (uint32_t)(rd->T_pad / 64), win_back = (uint32_t)sb * 256u;
+            const int grid = (int)((total_groups + chunk_groups - 1) / chunk_groups);
+#define COVL_ARGS (const uint2 *)nullptr, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
+                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, 0, \
+                  (const uint32_t *)rd->d_long_sum.p, (const uint32_t *)rd->d_long_len0.p, only_long, chunk_groups, total_groups, win_back
+#define COVL_LAUNCH(UU, WW)                                                                                                                  \
+            {                                                                                                                                \
+                if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, 1, WW, true>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVL_ARGS); \
+                else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, 1, WW, true>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVL_ARGS);  \
+            }
+            if (grid > 0) switch (su * 10 + sw) {
+                case 12: COVL_LAUNCH(1, 2048) break;
+                case 13: COVL_LAUNCH(1, 3072) break;
+                case 14: COVL_LAUNCH(1, 4096) break;
+                case 22: COVL_LAUNCH(2, 2048) break;
+                case 24: COVL_LAUNCH(2, 4096) break;
+                default: COVL_LAUNCH(2, 3072) break;
+            }
+#undef COVL_LAUNCH
+#undef COVL_ARGS
+        }
+        if ((rd->n_long || cov_general) && long_by_step) {
             KTimer t(ctx, "coverage_step_kernel");
             const uint32_t only_long = cov_general ? 0u : 1u;
             int shape = rd->T_pad >= (1ull << 25) ? 18 : 14;

@@ -147,13 +147,18 @@ def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, set_opt):
     assert nab == tot_abort
 
 
-@pytest.mark.parametrize("general", ["1", None])
-def test_coverage_kernels_agree_on_short_reads(eng, general, set_opt):
-    """Short reads take coverage_fast_kernel (one wave per 64-step group); PANTAX_COV_GENERAL=1 sends the same groups through
-    the general kernel that otherwise only sees the groups of longer walks.  Both must equal the oracle bit for bit."""
+@pytest.mark.parametrize("general,long_kernel,shape", [("1", None, None), ("1", "step", None), ("1", None, "1222"), ("1", None, "2448"), (None, None, None)])
+def test_coverage_kernels_agree_on_short_reads(eng, general, long_kernel, shape, set_opt):
+    """Short reads take coverage_fast_kernel (one wave per 64-step group); cov_general=1 sends the same groups through
+    the kernel that otherwise only sees the groups of longer walks -- round 6's select-only instantiation in several shapes, or round 5's
+    coverage_step_kernel (cov_long=step).  All must equal the oracle bit for bit."""
     from pantax_amd import synth
     if general:
         set_opt(eng, "cov_general", general)
+    if long_kernel:
+        set_opt(eng, "cov_long", long_kernel)
+    if shape:
+        set_opt(eng, "covl_shape", shape)
     sset = synth.make_set(11, 4, 6, 60000, 50000, adversarial_frac=0.02, single_strain_every=4)
     from oracle import oracle as orc
     rd = sset.reads
@@ -274,9 +279,12 @@ def test_species_active_mask_and_flags(eng):
         assert np.array_equal(bases[lo:hi], b) and np.array_equal(cov[lo:hi], c)
 
 
-def test_long_reads_and_empty_inputs(eng):
+@pytest.mark.parametrize("long_kernel", [None, "step"])
+def test_long_reads_and_empty_inputs(eng, long_kernel, set_opt):
     from oracle import oracle as orc
     from pantax_amd import synth
+    if long_kernel:
+        set_opt(eng, "cov_long", long_kernel)
     sset = synth.make_set(5, 2, 5, 300, 60000, long_reads=True)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -294,12 +302,18 @@ def test_long_reads_and_empty_inputs(eng):
     assert not bases.any() and not cov.any() and nab == 0
 
 
-def test_long_walks_with_revisits(eng):
-    """Walks of 65 .. 6000 steps (more than a wave, more than the upload-time hash holds) that come back to nodes they
+@pytest.mark.parametrize("long_kernel,shape", [(None, None), (None, "1120"), (None, "2242"), (None, "2848"), ("step", None)])
+def test_long_walks_with_revisits(eng, long_kernel, shape, set_opt):
+    """(every shape of the long-walk kernel -- groups in flight, groups per workgroup, window size, window start -- and round 5's kernel)
+    Walks of 65 .. 6000 steps (more than a wave, more than the upload-time hash holds) that come back to nodes they
     have already visited, the first node included, with arbitrary start/end offsets: first-occurrence rule
     (profile.rs:879-882), `seen` across waves (:857-859) and the trio windows at wave borders, bit for bit."""
     from oracle import oracle as orc
     from pantax_amd import synth
+    if long_kernel:
+        set_opt(eng, "cov_long", long_kernel)
+    if shape:
+        set_opt(eng, "covl_shape", shape)
     sset = synth.make_set(91, 2, 4, 200, 200000, long_reads=True)
     rng = np.random.default_rng(92)
     offs, ids, ps, pe = [0], [], [], []
@@ -348,6 +362,45 @@ def test_long_walks_with_revisits(eng):
         assert np.array_equal(tb[trio_off:trio_off + len(t)], t) and t.sum() > 0
         trio_off += len(t)
     assert trio_off == len(tb)
+
+
+@pytest.mark.parametrize("long_kernel,shape", [(None, None), (None, "1232"), ("step", None)])
+def test_short_and_long_reads_in_one_sample(eng, long_kernel, shape, set_opt):
+    """A sample that mixes 150-bp reads with HiFi-shaped ones (both strands, adversarial records): the groups that hold a step of a longer walk
+    go to the long-walk kernel, the others to the short-read one, and a group may hold walks of both kinds.  Bit for bit against the oracle."""
+    from pantax_amd import synth
+    if long_kernel:
+        set_opt(eng, "cov_long", long_kernel)
+    if shape:
+        set_opt(eng, "covl_shape", shape)
+    a = synth.make_set(23, 3, 5, 900, 120000, long_reads=True, adversarial_frac=0.02)
+    b = synth.make_set(23, 3, 5, 40000, 120000, adversarial_frac=0.02)
+    ra, rb = a.reads, b.reads
+    assert all(np.array_equal(x.path_nodes, y.path_nodes) for x, y in zip(a.species, b.species))      # the same graphs
+    order = np.random.default_rng(5).permutation(ra.n_reads + rb.n_reads)
+    lens = np.concatenate([np.diff(ra.step_off.astype(np.int64)), np.diff(rb.step_off.astype(np.int64))])
+    starts = np.concatenate([ra.step_off[:-1].astype(np.int64), rb.step_off[:-1].astype(np.int64) + int(ra.step_off[-1])])
+    ids_all = np.concatenate([ra.node_id, rb.node_id])
+    strand_all = np.concatenate([ra.strand, rb.strand])
+    offs = np.concatenate([[0], np.cumsum(lens[order])]).astype(np.uint64)
+    idx = np.repeat(starts[order] - offs[:-1].astype(np.int64), lens[order]) + np.arange(int(offs[-1]))
+    cat = lambda f: np.concatenate([getattr(ra, f), getattr(rb, f)])[order]
+    rd = synth.PackedReads(offs, ids_all[idx].astype(np.uint32), strand_all[idx], cat("pstart"), cat("pend"), cat("qlen"), cat("mapq"), cat("plen"))
+    a.reads = rd
+    assert (lens > 64).any() and (lens <= 64).any()
+    eng.upload_db(a.species)
+    eng.upload_packed(rd)
+    sp, *_ = eng.rcls_profile()
+    eng.trio_nodes_info(fetch=False)
+    bases, cov, tb, nab = eng.get_node_abundances()
+    ref = _oracle_cov_per_species(a, sp)
+    u0 = 0
+    for si, (G, T, b_, c, t, na) in enumerate(ref):
+        lo, hi = int(eng.node_off[si]), int(eng.node_off[si + 1])
+        assert np.array_equal(bases[lo:hi], b_) and np.array_equal(cov[lo:hi], c)
+        assert np.array_equal(tb[u0:u0 + T.n_unique], t)
+        u0 += T.n_unique
+    assert nab == sum(r[5] for r in ref)
 
 
 def _paths_from_masks(mask, p):
