@@ -163,7 +163,17 @@ typedef struct { /* the ProfilingConfig fields optimize_otu reads (types.rs:57-9
     int32_t shift;                         /* --shift */
     int32_t sample_nodes;                  /* --sample (cli.rs:227 default 500000; pass 500 for --sample_test): a species with more valid
                                             * LP rows keeps the rows of sample_sorted (profile.rs:1287-1295); 0 = never sample */
+    int32_t solver_semantics;              /* which backend's handling of the SECOND solve's solution is reproduced (the LP and its optimum are the same for all):
+                                            * PANTAX_HIP_SEMANTICS_GUROBI (0, default; also cplex / cbc / glpk): every candidate that survives
+                                            * second_filter_paths takes its own x of the second solve (profile.rs:1500-1508);
+                                            * PANTAX_HIP_SEMANTICS_HIGHS (1): highs_opt first cuts the solution to its first K columns, K = number of
+                                            * survivors, and zips THAT with the candidates (profile.rs:2865-2879) -- a survivor at candidate position
+                                            * >= K is left without a second_sol (it then counts as 0, :3036, and is dropped from the table, :3237).
+                                            * What a maintainer without a Gurobi licence can diff against is `--solver highs`: this switch makes that
+                                            * diff come out empty. */
 } pantax_hip_strain_config;
+#define PANTAX_HIP_SEMANTICS_GUROBI 0
+#define PANTAX_HIP_SEMANTICS_HIGHS 1
 
 typedef struct { /* per species solver report */
     int32_t n_candidates, status1, status2, iters1, iters2;
@@ -221,6 +231,7 @@ typedef struct {
     double unique_trio_nodes_fraction, unique_trio_nodes_mean_count_f, single_cov_ratio, single_cov_diff; /* --fr --fc --sr --sd */
     int64_t min_cov, min_depth;
     int32_t shift, filtered, sample_nodes /* as in pantax_hip_strain_config */, rebuild_trio /* 1 = like the reference, every run */;
+    int32_t solver_semantics;              /* as in pantax_hip_strain_config */
 } pantax_hip_step_config;
 
 int pantax_hip_profile_step(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads,
@@ -359,6 +370,11 @@ typedef struct { /* ProfilingConfig (types.rs:57-91) as plain C; NULL path = ref
      * 0: host pointers (the library stages through pinned memory). */
     int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off);
     int32_t comm_device_buffers;
+    int32_t sample_test;            /* --sample_test (cli.rs:230-232): sample_sorted keeps 500 rows whatever --sample says (profile.rs:1387-1393, :2738-2744) */
+    int32_t solver_semantics;       /* --solver: PANTAX_HIP_SEMANTICS_HIGHS for "highs", PANTAX_HIP_SEMANTICS_GUROBI for every other backend (pantax_hip_strain_config) */
+    double minimization_min_cov;    /* types.rs:72 (main.rs:150 sets 0; no CLI flag).  It only shifts the indicator rows z_i >= (x_i - this) / (2 max), and the
+                                     * indicators are bound by nothing but sum z <= npaths (profile.rs:1374-1378): INERT at any value.  Mirrored for
+                                     * completeness of the struct; negative or non-finite values are refused. */
 } pantax_hip_profiling_config;
 
 /* A selection whose graphs hold more path steps than one resident db addresses (2^32: BASELINE configs[4] on one GPU) goes through the device in

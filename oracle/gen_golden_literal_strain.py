@@ -148,13 +148,25 @@ def main():
         (range(201, 240), 4, 5, 5000, 4000, dict(base, shift=True, fr=0.4), 3, 0.6, 0),
         (range(301, 340), 3, 3, 5000, 2500, dict(base, filtered=False, min_depth=2, fc=0.3), 2, 0.7, 17),
         (range(401, 460), 4, 4, 5000, 4000, dict(base), 0, 0.6, 0, 150, 40),      # duplicate read ids + null read_start rows (a5)
+        # --solver highs (round 6): highs_opt's slice of the second solution (profile.rs:2865-2879) -- most strains present and a tight --fc, so that
+        # candidates fall in the second filter and a survivor sits BEHIND one that fell: under Gurobi's reading it would keep its second_sol
+        (range(501, 700), 2, 5, 6000, 5000, dict(base, solver="highs", fc=0.08, sr=0.99), 0, 0.8, 0),
     ]
+    only = [int(x) for x in sys.argv[1:]]           # plan indices to (re)write; none = all
     for k, plan in enumerate(plans):
+        if only and k not in only:
+            continue
         seeds, S, H, gl, nr, args, single_every, pf, mqn = plan[:9]
         dup_ids, null_start = (plan[9], plan[10]) if len(plan) > 9 else (0, 0)
         for seed in seeds:
             case = make_case(seed, S, H, gl, nr, args, single_every, pf, mqn, dup_ids, null_start)
             n_lp = sum(1 for v in case["expect"]["per_species"].values() if v["obj1"] is not None)
+            if args.get("solver") == "highs":       # the slice must matter: the same case read Gurobi's way hands out more second solutions
+                other = make_case(seed, S, H, gl, nr, dict(args, solver="gurobi"), single_every, pf, mqn, dup_ids, null_start)
+                n_h = sum(m["second_sol"] is not None for v in case["expect"]["per_species"].values() for m in v["metrics"])
+                n_g = sum(m["second_sol"] is not None for v in other["expect"]["per_species"].values() for m in v["metrics"])
+                if not (0 < n_h < n_g):
+                    continue
             if n_lp and len(case["expect"]["final_rows"]) >= 2 and check_unique(case):
                 break
         else:

@@ -46,7 +46,8 @@ class OrcHapMetrics(C.Structure):
 
 class OrcStrainConfig(C.Structure):
     _fields_ = [("unique_trio_nodes_fraction", C.c_double), ("unique_trio_nodes_mean_count_f", C.c_double),
-                ("single_cov_ratio", C.c_double), ("min_depth", C.c_int64), ("shift", C.c_int32), ("sample_nodes", C.c_int32)]
+                ("single_cov_ratio", C.c_double), ("min_depth", C.c_int64), ("shift", C.c_int32), ("sample_nodes", C.c_int32),
+                ("solver_semantics", C.c_int32)]
 
 
 HAS = dict(fraction=1, freq_mean=2, ratio=4, first=8, divergence=16, second=32, rescue=64, total_diff=128)
@@ -195,8 +196,8 @@ def lad_objective(mask, abund, x):
     return lib().orc_lad_objective(C.c_uint64(len(mask)), _p(mask), _p(abund), C.c_uint32(len(x)), _p(x))
 
 
-def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0):
-    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes))
+def optimize_species(graph, trio, bases, cov, trio_bases, fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0, solver_semantics=0):
+    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes), int(solver_semantics))
     H = graph.n_paths
     met = (OrcHapMetrics * H)()
     nc = C.c_uint32(0)
@@ -234,7 +235,7 @@ def group_reads(species_idx, n_species):
 
 
 def par_profile_species(graphs, range_start, step_off, node_id, pstart, pend, first, order, keep, absolute, todo, threads,
-                        fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0, want_metrics=False):
+                        fr=0.3, fc=0.46, sr=0.85, min_depth=0, shift=False, sample_nodes=0, want_metrics=False, solver_semantics=0):
     """One species per worker thread, handed out in the order of `todo` (the rayon par_iter of profile.rs:3297-3319):
     trio index, the species' reads, node coverage, filters + both solves, abundace_constraint -- all through the
     single-threaded functions above.  graphs: list of Graph.  -> dict of per-species arrays (+ metrics when asked)."""
@@ -253,7 +254,7 @@ def par_profile_species(graphs, range_start, step_off, node_id, pstart, pend, fi
     hap_off = np.zeros(S + 1, dtype=np.uint64)
     hap_off[1:] = np.cumsum([g.n_paths for g in graphs])
     met = (OrcHapMetrics * max(int(hap_off[-1]), 1))() if want_metrics else None
-    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes))
+    cfg = OrcStrainConfig(fr, fc, sr, min_depth, int(shift), int(sample_nodes), int(solver_semantics))
     out = dict(rc=np.zeros(S, dtype=np.int32), n_cand=np.zeros(S, dtype=np.uint32), n_rows=np.zeros(S, dtype=np.uint64), obj1=np.zeros(S), obj2=np.zeros(S),
                t_trio=np.zeros(S), t_cov=np.zeros(S), t_lp=np.zeros(S))
     rc = lib().orc_par_profile_species(C.c_int(int(threads)), C.c_uint32(S), garr, _p(rs), _p(step_off), _p(node_id), _p(pstart), _p(pend), _p(first), _p(order),

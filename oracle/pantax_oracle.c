@@ -812,11 +812,15 @@ int orc_optimize_species(const orc_graph *g, const orc_trio_table *trio, const i
         } else {
             for (uint32_t k = 0; k < nc; ++k) { met[cand[k]].second_sol = met[cand[k]].first_sol; met[cand[k]].has |= ORC_HAS_SECOND; }
         }
-        if (second_opt) { /* profile.rs:1482-1508 (Gurobi semantics) */
+        if (second_opt) { /* profile.rs:1482-1508 (Gurobi semantics); :2849-2879 (highs_opt) */
             for (uint32_t k = 0; k < nc; ++k) if (!keep[k]) ub[k] = 0.0;
             orc_lad_solve(V, mask, ab, nc, ub, x2, obj2_out, &it, &st);
             if (st != 0) { rc = -1; goto done; }
-            for (uint32_t k = 0; k < nc; ++k) if (keep[k]) { met[cand[k]].second_sol = x2[k]; met[cand[k]].has |= ORC_HAS_SECOND; }
+            /* highs_opt: `sols2 = &all_sols[..min(len, second_possible_paths_idx.len())]`, then `possible_paths_idx.iter().zip(sols2)` (:2865, :2871):
+             * only the first K candidate positions are visited, K = number of survivors */
+            uint32_t k_lim = nc;
+            if (cfg->solver_semantics == 1) { k_lim = 0; for (uint32_t k = 0; k < nc; ++k) k_lim += keep[k] ? 1u : 0u; }
+            for (uint32_t k = 0; k < nc && k < k_lim; ++k) if (keep[k]) { met[cand[k]].second_sol = x2[k]; met[cand[k]].has |= ORC_HAS_SECOND; }
         }
     }
 done:

@@ -136,6 +136,8 @@ typedef struct {
     int64_t min_depth;                     /* --min_depth 0 */
     int32_t shift;                         /* main.rs:119-124 */
     int32_t sample_nodes;                  /* --sample (cli.rs:227 default 500000; --sample_test = 500); 0 = off */
+    int32_t solver_semantics;              /* 0: second solve's x handed out as Gurobi / cplex / cbc / glpk do (profile.rs:1500-1508); 1: as highs_opt does,
+                                            * first cut to K = #survivors columns, then zipped with the candidates (profile.rs:2865-2879) */
 } orc_strain_config;
 
 /* a11: sample_sorted (profile.rs:1287-1295) = StdRng::seed_from_u64(seed) + slice::choose_multiple + sort.

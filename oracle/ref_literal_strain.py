@@ -320,7 +320,11 @@ def gurobi_opt(var, nvert, paths, node_abundance_vec, node_base_cov, node_len, a
         return obj1, None
     fixed = [idx not in var["second_possible_paths_idx"] for idx in var["possible_paths_idx"]]   # :1484-1488
     sols2, obj2 = _solve_lad(coeff, valid_nodes, node_abundance_vec, 1.05 * max_val, fixed)
-    for path_idx, sol in zip(var["possible_paths_idx"], sols2):                               # :1500-1508
+    if args.get("solver", "gurobi") == "highs":
+        # highs_opt (profile.rs:2849-2879): `let sols2 = &all_sols[..all_sols.len().min(opt_var.second_possible_paths_idx.len())];` -- the solution is cut
+        # to as many columns as candidates SURVIVED (:2865), and THAT slice is zipped with all the candidates (:2871): zip stops at the shorter one
+        sols2 = sols2[:min(len(sols2), len(var["second_possible_paths_idx"]))]
+    for path_idx, sol in zip(var["possible_paths_idx"], sols2):                               # :1500-1508 / :2871-2879
         if path_idx in var["second_possible_paths_idx"]:
             var["hap_metrics"][path_idx]["second_sol"] = sol
     return obj1, obj2

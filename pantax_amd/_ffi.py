@@ -58,14 +58,14 @@ class HapMetrics(C.Structure):
 class StrainConfig(C.Structure):
     _fields_ = [("unique_trio_nodes_fraction", C.c_double), ("unique_trio_nodes_mean_count_f", C.c_double),
                 ("single_cov_ratio", C.c_double), ("min_depth", C.c_int64), ("shift", C.c_int32),
-                ("sample_nodes", C.c_int32)]
+                ("sample_nodes", C.c_int32), ("solver_semantics", C.c_int32)]
 
 
 class StepConfig(C.Structure):
     _fields_ = [("unique_trio_nodes_fraction", C.c_double), ("unique_trio_nodes_mean_count_f", C.c_double),
                 ("single_cov_ratio", C.c_double), ("single_cov_diff", C.c_double), ("min_cov", C.c_int64),
                 ("min_depth", C.c_int64), ("shift", C.c_int32), ("filtered", C.c_int32), ("sample_nodes", C.c_int32),
-                ("rebuild_trio", C.c_int32)]
+                ("rebuild_trio", C.c_int32), ("solver_semantics", C.c_int32)]
 
 
 class SolveInfo(C.Structure):
@@ -94,7 +94,8 @@ class ProfilingConfig(C.Structure):
                 ("species", C.c_int32), ("strain", C.c_int32), ("shift", C.c_int32), ("filtered", C.c_int32),
                 ("full", C.c_int32), ("force", C.c_int32), ("mode", C.c_int32), ("sample_nodes", C.c_int32),
                 ("designated_species", C.c_char_p), ("zip", C.c_char_p), ("rank", C.c_int32), ("world_size", C.c_int32), ("image_cache", C.c_int32),
-                ("allreduce_sum", C.c_void_p), ("comm_user", C.c_void_p), ("alltoallv", C.c_void_p), ("comm_device_buffers", C.c_int32)]
+                ("allreduce_sum", C.c_void_p), ("comm_user", C.c_void_p), ("alltoallv", C.c_void_p), ("comm_device_buffers", C.c_int32),
+                ("sample_test", C.c_int32), ("solver_semantics", C.c_int32), ("minimization_min_cov", C.c_double)]
 
 
 # int (*allreduce_sum)(void *user, double *buf, uint64_t n)

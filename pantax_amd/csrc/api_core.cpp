@@ -86,17 +86,22 @@ namespace ptx {
 // concatenated or checked on the host).  part.path_off[h] - part.path_off[0] indexes the species' walks.
 int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, const std::string *files,
                     pantax_hip_db **out) {
+    *out = nullptr;
+    pantax_hip_db *db = nullptr;
+    PTX_TRY(db_upload_begin(ctx, S, range_start, range_end, parts, &db));
+    std::unique_ptr<pantax_hip_db> hold(db);
+    const auto t0 = std::chrono::steady_clock::now();
+    PTX_TRY(db_upload_arrays(ctx, db, parts, files, nullptr));
+    if (ctx->cfg.trace) std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms\n", "graph arrays -> HBM", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    PTX_TRY(db_upload_finish(ctx, db));
+    *out = hold.release();
+    return 0;
+}
+
+int db_upload_begin(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out) {
+    *out = nullptr;
     std::unique_ptr<pantax_hip_db> db(new pantax_hip_db());
     db->S = S;
-    const bool trace = ctx->cfg.trace;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!trace) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-        t_prev = now;
-    };
     db->h_node_off.assign(S + 1, 0); db->h_hap_off.assign(S + 1, 0);
     for (uint32_t s = 0; s < S; ++s) { db->h_node_off[s + 1] = db->h_node_off[s] + parts[s].n_nodes; db->h_hap_off[s + 1] = db->h_hap_off[s] + parts[s].n_haps; }
     db->V = db->h_node_off[S];
@@ -155,34 +160,124 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
     PTX_TRY(upload(ctx, db->d_all_same, db->h_all_same.data(), S));
     PTX_HIP(ctx, db->d_bit_off.alloc(db->V + 1)); PTX_HIP(ctx, db->d_node_len.alloc(db->V)); PTX_HIP(ctx, db->d_node_rec.alloc(db->V));
     PTX_HIP(ctx, db->d_path_nodes.alloc(db->P));
-    {   // the two big arrays: every species' stretch of them, back to back, through ONE chunk pipeline each
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the small uploads above are over: whoever loads the arrays (another thread, another stream) finds the tables in place
+    *out = db.release();
+    return 0;
+}
+
+int db_upload_arrays(Ctx *ctx, pantax_hip_db *db, const GraphPart *parts, const std::string *files, hipStream_t stream_arg) {
+    const uint32_t S = db->S;
+    const hipStream_t stream = stream_arg ? stream_arg : ctx->stream;
+    // small tables go through plain asynchronous copies from vectors that live until the closing wait (not through the ctx's staging buffers:
+    // this may be a loader thread beside the thread that owns them)
+    auto put = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) : hipSuccess; };
+    {   // the two big arrays: every species' stretch of them, back to back, through ONE chunk pipeline each.  Species that come PACKED (image
+        // format 4: 16-bit lengths, walks as blocks of deltas) send their packed sections through pipelines of their own into scratch, and
+        // kernels unpack them into their stretches of the arrays; in the plain pipelines those stretches are holes (nothing is filled for them).
         std::vector<UploadSeg> segs;
         std::vector<uint32_t> seg_species;
-        for (uint32_t s = 0; s < S; ++s) {
-            if (parts[s].len_seg.out_bytes != 4 * parts[s].n_nodes) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the node lengths do not cover its %llu nodes", s, (unsigned long long)parts[s].n_nodes);
-            segs.push_back(parts[s].len_seg); seg_species.push_back(s);
-        }
+        uint32_t n_len16 = 0, n_packed = 0;
+        for (uint32_t s = 0; s < S; ++s) { n_len16 += parts[s].len16 ? 1u : 0u; n_packed += parts[s].packed ? 1u : 0u; }
         int64_t bad = -1;
-        PTX_TRY(upload_segments(ctx, db->d_node_len.p, segs.data(), segs.size(), files, &bad));
-        if (bad >= 0) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u holds a node of negative length or longer than 2^32 - 1 (reference asserts > 0, profile.rs:494)", seg_species[bad]);
-        segs.clear(); seg_species.clear();
-        for (uint32_t s = 0; s < S; ++s) {
-            uint64_t bytes = 0;
-            for (const UploadSeg &w : parts[s].walk_segs) { segs.push_back(w); seg_species.push_back(s); bytes += w.out_bytes; }
-            if (bytes != 4 * (db->h_path_off[db->h_hap_off[s + 1]] - db->h_path_off[db->h_hap_off[s]]))
-                return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the walks do not cover its path steps", s);
+        // ---- node lengths: the plain pipeline first (holes travel as garbage), then the 16-bit stretches and the kernel that widens them into place
+        if (n_len16 < S) {
+            for (uint32_t s = 0; s < S; ++s) {
+                UploadSeg sg = parts[s].len_seg;
+                if (parts[s].len16) { sg = UploadSeg(); sg.hole = true; sg.out_bytes = 4 * parts[s].n_nodes; }
+                else if (sg.out_bytes != 4 * parts[s].n_nodes) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the node lengths do not cover its %llu nodes", s, (unsigned long long)parts[s].n_nodes);
+                segs.push_back(sg); seg_species.push_back(s);
+            }
+            PTX_TRY(upload_segments(ctx, db->d_node_len.p, segs.data(), segs.size(), files, &bad, stream));
+            if (bad >= 0) return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: species %u holds a node of negative length or longer than 2^32 - 1 (reference asserts > 0, profile.rs:494)", seg_species[bad]);
+            segs.clear(); seg_species.clear();
         }
-        PTX_TRY(upload_segments(ctx, db->d_path_nodes.p, segs.data(), segs.size(), files, &bad));
-        if (bad >= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a haplotype of species %u walks a node index beyond 2^32", seg_species[bad]);
+        DevBuf<uint16_t> d_len16;
+        DevBuf<WidenSpecies> d_wt;
+        if (n_len16) {
+            std::vector<WidenSpecies> wt;
+            uint64_t at = 0;
+            for (uint32_t s = 0; s < S; ++s) {
+                if (!parts[s].len16) continue;
+                if (parts[s].len_seg.out_bytes != ((2 * parts[s].n_nodes + 3) & ~3ull)) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the 16-bit node lengths do not cover its %llu nodes", s, (unsigned long long)parts[s].n_nodes);
+                wt.push_back(WidenSpecies{at, db->h_node_off[s], parts[s].n_nodes});
+                segs.push_back(parts[s].len_seg);
+                at += parts[s].len_seg.out_bytes / 2;
+            }
+            PTX_HIP(ctx, d_len16.alloc(at ? at : 1));
+            PTX_HIP(ctx, d_wt.alloc(wt.size()));
+            PTX_HIP(ctx, put(d_wt.p, wt.data(), wt.size() * sizeof(WidenSpecies)));
+            PTX_TRY(upload_segments(ctx, d_len16.p, segs.data(), segs.size(), files, nullptr, stream));
+            PTX_TRY(lens_widen_launch(ctx, d_wt.p, (uint32_t)wt.size(), at, d_len16.p, db->d_node_len.p, stream_arg));
+            PTX_HIP(ctx, hipStreamSynchronize(stream));   // the scratch and its table go out of scope
+            segs.clear();
+        }
+        // ---- walks
+        DevBuf<uint32_t> d_pk_first, d_pk_off;
+        DevBuf<uint8_t> d_pk_payload;
+        DevBuf<UnpackSpecies> d_ut;
+        std::vector<UnpackSpecies> ut;
+        uint64_t nb_tot = 0, noff_tot = 0, pay_units = 0;
+        if (n_packed) {
+            std::vector<UploadSeg> s_first, s_off, s_pay;
+            for (uint32_t s = 0; s < S; ++s) {
+                if (!parts[s].packed) continue;
+                const PackedWalks &pk = parts[s].pk;
+                const uint64_t Ps = db->h_path_off[db->h_hap_off[s + 1]] - db->h_path_off[db->h_hap_off[s]];
+                if (pk.n_blocks != (Ps + PK_BLOCK - 1) / PK_BLOCK || pk.payload_bytes % PK_UNIT || pk.first_seg.out_bytes != 4 * pk.n_blocks ||
+                    pk.off_seg.out_bytes != 4 * (pk.n_blocks + 1) || pk.payload_seg.out_bytes != pk.payload_bytes)
+                    return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the packed walks do not cover its path steps", s);
+                if (nb_tot + pk.n_blocks >= 0xFFFFFFFFull || pay_units + pk.payload_bytes / PK_UNIT >= 0xFFFFFFFFull)
+                    return fail(ctx, PANTAX_HIP_E_LIMIT, "db_upload: more than 2^32 blocks of packed walks");
+                ut.push_back(UnpackSpecies{(uint32_t)nb_tot, (uint32_t)noff_tot, (uint32_t)pay_units, (uint32_t)db->h_path_off[db->h_hap_off[s]], (uint32_t)Ps});
+                s_first.push_back(pk.first_seg); s_off.push_back(pk.off_seg); s_pay.push_back(pk.payload_seg);
+                nb_tot += pk.n_blocks; noff_tot += pk.n_blocks + 1; pay_units += pk.payload_bytes / PK_UNIT;
+            }
+            PTX_HIP(ctx, d_pk_first.alloc(nb_tot ? nb_tot : 1)); PTX_HIP(ctx, d_pk_off.alloc(noff_tot ? noff_tot : 1)); PTX_HIP(ctx, d_pk_payload.alloc(pay_units ? pay_units * PK_UNIT : 1));
+            PTX_HIP(ctx, d_ut.alloc(ut.size()));
+            PTX_HIP(ctx, put(d_ut.p, ut.data(), ut.size() * sizeof(UnpackSpecies)));
+            PTX_TRY(upload_segments(ctx, d_pk_first.p, s_first.data(), s_first.size(), files, nullptr, stream));
+            PTX_TRY(upload_segments(ctx, d_pk_off.p, s_off.data(), s_off.size(), files, nullptr, stream));
+            PTX_TRY(upload_segments(ctx, d_pk_payload.p, s_pay.data(), s_pay.size(), files, nullptr, stream));
+        }
+        if (n_packed < S) {
+            for (uint32_t s = 0; s < S; ++s) {
+                const uint64_t want = 4 * (db->h_path_off[db->h_hap_off[s + 1]] - db->h_path_off[db->h_hap_off[s]]);
+                if (parts[s].packed) { UploadSeg sg; sg.hole = true; sg.out_bytes = want; segs.push_back(sg); seg_species.push_back(s); continue; }
+                uint64_t bytes = 0;
+                for (const UploadSeg &w : parts[s].walk_segs) { segs.push_back(w); seg_species.push_back(s); bytes += w.out_bytes; }
+                if (bytes != want) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: species %u: the walks do not cover its path steps", s);
+            }
+            PTX_TRY(upload_segments(ctx, db->d_path_nodes.p, segs.data(), segs.size(), files, &bad, stream));
+            if (bad >= 0) return fail(ctx, PANTAX_HIP_E_INVALID, "db_upload: a haplotype of species %u walks a node index beyond 2^32", seg_species[bad]);
+        }
+        if (n_packed) {   // (behind the plain pipeline: the holes' garbage is overwritten)
+            PTX_TRY(walks_unpack_launch(ctx, d_ut.p, (uint32_t)ut.size(), (uint32_t)nb_tot, d_pk_first.p, d_pk_off.p, d_pk_payload.p, db->d_path_nodes.p, stream_arg));
+            PTX_HIP(ctx, hipStreamSynchronize(stream));   // the scratch goes out of scope
+        }
     }
-    lap("graph arrays -> HBM");
+    PTX_HIP(ctx, hipStreamSynchronize(stream));
+    return 0;
+}
+
+int db_upload_finish(Ctx *ctx, pantax_hip_db *db_raw) {
+    Db *const db = db_raw;
+    const uint32_t S = db->S;
+    const bool trace = ctx->cfg.trace;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     {   // node tables, the zero-length check, the walk check and the identical-walk test (first_filter_paths, profile.rs:1188-1190:
         // a property of the graphs, done once) on the device
         DevBuf<uint32_t> d_flags;
         PTX_HIP(ctx, d_flags.alloc(2));
         PTX_HIP(ctx, hipMemsetAsync(d_flags.p, 0, sizeof(uint32_t), ctx->stream));
         PTX_HIP(ctx, hipMemsetAsync(d_flags.p + 1, 0xFF, sizeof(uint32_t), ctx->stream));
-        PTX_TRY(node_tables_launch(ctx, db.get(), d_flags.p));
+        PTX_TRY(node_tables_launch(ctx, db, d_flags.p));
         uint32_t fl[2] = {0, 0};
         uint64_t L = 0;
         PTX_TRY(download(ctx, fl, d_flags.p, 2));
@@ -239,18 +334,17 @@ int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int6
         PTX_TRY(upload(ctx, db->d_emit_tile_sp, tsp.data(), tsp.size()));
     }
     lap("tiles");
-    PTX_TRY(trio_visits_build(ctx, db.get()));
+    PTX_TRY(trio_visits_build(ctx, db));
     lap("visit table");
-    PTX_TRY(trio_runs_build(ctx, db.get()));
+    PTX_TRY(trio_runs_build(ctx, db));
     lap("node-block runs");
-    PTX_TRY(node_haps_build(ctx, db.get()));
+    PTX_TRY(node_haps_build(ctx, db));
     lap("node -> haplotypes");
     PTX_HIP(ctx, db->d_trio_first.alloc(1));
     PTX_HIP(ctx, db->d_trio_ent.alloc(2));
     PTX_HIP(ctx, db->d_trio_bases.alloc(1));
     PTX_HIP(ctx, db->d_active.alloc(S));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
-    *out = db.release();
     return 0;
 }
 

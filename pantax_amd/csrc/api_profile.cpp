@@ -99,6 +99,10 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
     if (!is_dir(db_dir)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax database directory '%s' is not a valid directory path", db_dir.c_str());
     if (!is_dir(wd)) return fail(ctx, PANTAX_HIP_E_IO, "Specified PanTax work directory '%s' is not a valid directory path", wd.c_str());
     if (cfg->sample_nodes < 0) return fail(ctx, PANTAX_HIP_E_INVALID, "profile: --sample %d", cfg->sample_nodes);
+    if (cfg->solver_semantics != PANTAX_HIP_SEMANTICS_GUROBI && cfg->solver_semantics != PANTAX_HIP_SEMANTICS_HIGHS)
+        return fail(ctx, PANTAX_HIP_E_INVALID, "profile: solver_semantics %d", cfg->solver_semantics);
+    if (!(cfg->minimization_min_cov >= 0.0) || !std::isfinite(cfg->minimization_min_cov))
+        return fail(ctx, PANTAX_HIP_E_INVALID, "profile: minimization_min_cov %g", cfg->minimization_min_cov);
     const std::string zip = opt(cfg->zip);
     if (zip == "h5")
         return fail(ctx, PANTAX_HIP_E_LIMIT, "profile: graph container '%s' is not available in this build (the reference gates it behind a cargo feature); use serialize / lz / zstd or GFA", zip.c_str());
@@ -204,7 +208,9 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         // The per-read host columns (read_len, mapq, flags, id hash: 14 bytes per read) and the species of every read come back over PCIe only
         // for a caller that uses them: the binning report, the strain-only resume, the sharded ingest -- or, later, the duplicate-id rule when
         // two reads do share an id (host_cols below).  A plain run on distinct ids needs the species COUNTERS and the first rows only.
-        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/!sharded, /*want_id_spans=*/want_report,
+        // (no locus-grouped copy yet: the species decision needs the counters only -- the plain columns are binned in file order --, and the copy is
+        // built while the first graphs travel, on an otherwise idle device; round 5 built it here, 27 ms behind the last byte of the GAF at 1e8 reads)
+        PTX_TRY(gaf_tokenize_device(ctx, mf.data + text_begin, text_end - text_begin, hr, reads.rd, mf.fd, text_begin, /*group=*/false, /*want_id_spans=*/want_report,
                                     /*want_host_columns=*/false));
         R = reads.rd->R;
         lap("ranges + GAF tokenise");
@@ -654,10 +660,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             const std::vector<std::string> *names = nullptr;
             if (sc.kind == 1) {
                 files[k] = sc.img.path; names = &sc.img.hap_names;
-                pt.n_nodes = sc.img.V; pt.n_haps = sc.img.H; pt.path_off = sc.img.path_off.data();
-                pt.len_seg.file = (int32_t)k; pt.len_seg.file_off = sc.img.off_node_len; pt.len_seg.out_bytes = 4 * sc.img.V;
-                UploadSeg w; w.file = (int32_t)k; w.file_off = sc.img.off_path_nodes; w.out_bytes = 4 * sc.img.P;
-                pt.walk_segs.push_back(w);
+                sc.img.fill_part(pt, (int32_t)k);
             } else if (sc.kind == 2) {
                 files[k] = sc.bin_path; names = &sc.bin.hap_names;
                 pt.n_nodes = sc.bin.V; pt.n_haps = sc.bin.hap_names.size(); pt.path_off = sc.path_off.data();
@@ -690,27 +693,83 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         const uint64_t steps_max = ctx->cfg.db_path_steps_max ? ctx->cfg.db_path_steps_max : 3000000000ull;
         uint64_t steps_total = 0;
         for (uint32_t k = 0; k < Su; ++k) steps_total += parts[k].path_off[parts[k].n_haps] - parts[k].path_off[0];
-        const uint64_t n_groups = std::max<uint64_t>(1, (steps_total + steps_max - 1) / steps_max);
+        // Round 6: the groups are also what lets the graphs TRAVEL beside the work on them -- group g + 1 goes from its files to HBM on a loader thread and
+        // a copy stream of its own (db_upload_arrays) while this thread builds group g's tables and runs its index, coverage and strain step.  A selection
+        // of 2e8 path steps and more is therefore cut into four groups even when one db could hold it (option db_groups: 1 = one db, n = that many).
+        uint64_t n_groups = std::max<uint64_t>(1, (steps_total + steps_max - 1) / steps_max);
+        if (ctx->cfg.db_groups > 0) n_groups = std::max<uint64_t>(n_groups, (uint64_t)ctx->cfg.db_groups);
+        else if (steps_total >= 200000000ull && Su >= 8) n_groups = std::max<uint64_t>(n_groups, 4);
+        n_groups = std::min<uint64_t>(n_groups, Su);
         const uint64_t steps_target = std::min<uint64_t>(steps_max, (steps_total + n_groups - 1) / n_groups);
-        bool flags_set = false;
+        struct Group { uint32_t k0, k1; std::vector<GraphPart> gparts; };
+        std::vector<Group> groups;
         for (uint32_t k0 = 0; k0 < Su;) {
             uint32_t k1 = k0;
             uint64_t steps = 0, nodes = 0;
             while (k1 < Su) {
                 const uint64_t ps = parts[k1].path_off[parts[k1].n_haps] - parts[k1].path_off[0];
-                if (k1 > k0 && (steps + ps > steps_target || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
+                // (half a species over the target still joins this group: the groups come out even, without a small one at the end)
+                if (k1 > k0 && (steps + ps > steps_max || steps + ps / 2 > steps_target || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
                 steps += ps; nodes += parts[k1].n_nodes; ++k1;
             }
-            const uint32_t Sg = k1 - k0;
             // the file indices of a group's segments are relative to the group's file list
-            std::vector<GraphPart> gparts(parts.begin() + k0, parts.begin() + k1);
+            Group g{k0, k1, std::vector<GraphPart>(parts.begin() + k0, parts.begin() + k1)};
             if (k0)
-                for (GraphPart &pt : gparts) {
+                for (GraphPart &pt : g.gparts) {
                     if (pt.len_seg.file >= 0) pt.len_seg.file -= (int32_t)k0;
                     for (UploadSeg &w : pt.walk_segs) if (w.file >= 0) w.file -= (int32_t)k0;
+                    for (UploadSeg *w : {&pt.pk.first_seg, &pt.pk.off_seg, &pt.pk.payload_seg}) if (w->file >= 0) w->file -= (int32_t)k0;
                 }
-            DbHolder sdb{ctx};
-            PTX_TRY(db_upload_parts(ctx, Sg, g_rs.data() + k0, g_re.data() + k0, gparts.data(), files.data() + k0, &sdb.db));
+            groups.push_back(std::move(g));
+            k0 = k1;
+        }
+        const bool piped = groups.size() > 1;
+        if (piped && !ctx->stream_up) PTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_up, hipStreamNonBlocking));
+        // the loader: ONE group in flight.  begin() on this thread (small uploads through the ctx's staging), the arrays on the loader thread.
+        struct Loader {
+            pantax_hip_ctx *ctx;
+            std::thread th;
+            DbHolder db;
+            int rc = 0;
+            std::string err;
+            double ms = 0;
+            explicit Loader(pantax_hip_ctx *c) : ctx(c), db{c} {}
+            void join() { if (th.joinable()) th.join(); }
+            ~Loader() { join(); }
+        };
+        auto start_load = [&](const Group &g, Loader &L) -> int {
+            const uint32_t Sg = g.k1 - g.k0;
+            PTX_TRY(db_upload_begin(ctx, Sg, g_rs.data() + g.k0, g_re.data() + g.k0, g.gparts.data(), &L.db.db));
+            const GraphPart *gp = g.gparts.data();
+            const std::string *gf = files.data() + g.k0;
+            pantax_hip_db *dbp = L.db.db;
+            if (!piped) {
+                const auto t0 = std::chrono::steady_clock::now();
+                L.rc = db_upload_arrays(ctx, dbp, gp, gf, nullptr);
+                L.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return L.rc;
+            }
+            L.th = std::thread([this_ctx = ctx, dbp, gp, gf, &L] {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (hipSetDevice(this_ctx->device) != hipSuccess) L.rc = fail(this_ctx, PANTAX_HIP_E_HIP, "hipSetDevice on the graph loader thread");
+                else L.rc = db_upload_arrays(this_ctx, dbp, gp, gf, this_ctx->stream_up);
+                if (L.rc) L.err = pantax_hip_last_error(this_ctx);     // this thread's message: handed to the thread that reports
+                L.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            });
+            return 0;
+        };
+        bool flags_set = false;
+        std::unique_ptr<Loader> cur(new Loader(ctx)), next;
+        PTX_TRY(start_load(groups[0], *cur));
+        if (!sharded) { PTX_TRY(reads_group(ctx, reads.rd)); lap("locus-grouped copy of the reads"); }   // (sharded: reads_from_routed grouped what arrived)
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const uint32_t k0 = groups[gi].k0, k1 = groups[gi].k1, Sg = k1 - k0;
+            cur->join();
+            if (cur->rc) return piped ? fail(ctx, cur->rc, "%s", cur->err.c_str()) : cur->rc;
+            if (ctx->cfg.trace) std::fprintf(stderr, "[db_upload]            %-28s %9.3f ms%s\n", "graph arrays -> HBM", cur->ms, piped ? " (loader thread, beside the group before)" : "");
+            if (gi + 1 < groups.size()) { next.reset(new Loader(ctx)); PTX_TRY(start_load(groups[gi + 1], *next)); }
+            DbHolder &sdb = cur->db;
+            PTX_TRY(db_upload_finish(ctx, sdb.db));
             lap(Sg == Su ? "db upload" : "db upload (a group of the species)");
             // the same resident reads with the strain-level drop flags; species binned against the selected ranges
             // (reads of unselected species fall outside every range => "U" => skipped, as in the reference
@@ -725,7 +784,9 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
             lap("  trio index");
             PTX_TRY(pantax_hip_node_coverage(ctx, sdb.db, sreads_rd, nullptr, nullptr, nullptr, nullptr, &n_abort));
             lap("  node coverage");
-            pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift, cfg->sample_nodes};
+            // --sample_test: 500 rows whatever --sample says (profile.rs:1387-1393)
+            pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth, cfg->shift,
+                                        cfg->sample_test ? 500 : cfg->sample_nodes, cfg->solver_semantics};
             PTX_TRY(pantax_hip_strain_profile(ctx, sdb.db, &sc, nullptr, cov.data() + k0, met.data() + hap_off[k0], info.data() + k0));
             lap("strain step");
             if (cfg->image_cache == 2) {   // leave images behind for the next run
@@ -736,7 +797,7 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
                     }
                 lap("graph images written");
             }
-            k0 = k1;
+            cur = std::move(next);
         }
     }
     return 0;

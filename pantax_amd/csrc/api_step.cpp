@@ -95,7 +95,7 @@ int step_enqueue(pantax_hip_ctx *ctx, pantax_hip_db *db, pantax_hip_reads *reads
     mark();
     // a9 .. a14
     pantax_hip_strain_config sc{cfg->unique_trio_nodes_fraction, cfg->unique_trio_nodes_mean_count_f, cfg->single_cov_ratio, cfg->min_depth,
-                                cfg->shift, cfg->sample_nodes};
+                                cfg->shift, cfg->sample_nodes, cfg->solver_semantics};
     PTX_TRY(strain_enqueue(ctx, db, &sc, db->d_active.p, slot));
     mark();
     db->step_cfg[slot] = *cfg;
@@ -114,7 +114,7 @@ int step_collect(pantax_hip_ctx *ctx, pantax_hip_db *db, uint8_t *keep_out, doub
     db->step_col ^= 1;
     --db->step_inflight;   // also when the step turns out to have failed: its slot is free again
     pantax_hip_strain_config sc{cfg.unique_trio_nodes_fraction, cfg.unique_trio_nodes_mean_count_f, cfg.single_cov_ratio, cfg.min_depth, cfg.shift,
-                                cfg.sample_nodes};
+                                cfg.sample_nodes, cfg.solver_semantics};
     SpOut so{db, keep_out, absolute_out, slot};
     std::vector<pantax_hip_solve_info> info(S);
     PTX_TRY(strain_finish(ctx, db, &sc, keep_out, absolute_out, met, info.data(), copy_species_out, &so, slot));

@@ -120,6 +120,8 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     if (!db->cov_done) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_node_coverage first");
     if (!db->trio_built) return fail(ctx, PANTAX_HIP_E_STATE, "strain_profile: call pantax_hip_trio_index first");
     if (cfg->sample_nodes < 0) return fail(ctx, PANTAX_HIP_E_INVALID, "strain_profile: sample_nodes %d", cfg->sample_nodes);
+    if (cfg->solver_semantics != PANTAX_HIP_SEMANTICS_GUROBI && cfg->solver_semantics != PANTAX_HIP_SEMANTICS_HIGHS)
+        return fail(ctx, PANTAX_HIP_E_INVALID, "strain_profile: solver_semantics %d", cfg->solver_semantics);
     const uint32_t S = db->S;
     LadBatch &lb = db->lad;
     const ArenaLayout L(S, db->H);
@@ -138,9 +140,13 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     if (db->trio_scratch.d_tot.p)
         PTX_HIP(ctx, hipMemcpyAsync(lb.d_counts.p + 3, db->trio_scratch.d_tot.p + 2, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     mark();
+    // the resident step (the coverage pass left its counts to node_stats_launch): this call's two statistics passes are the only readers of the coverage
+    // arena, once -- they zero it for the next step's coverage pass.  A stage caller may read bases / trio_bases again, so nothing is cleaned for it.
+    db->cov_self_clean = db->cov_count_pending && ctx->cfg.cov_self_clean && db->U != 0;
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     mark();
     PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
+    if (db->cov_self_clean) { db->cov_arena_clean = true; db->cov_done = false; db->cov_self_clean = false; }   // (cov_done: the arena no longer holds a coverage result)
     mark();
     PTX_TRY(row_sample_apply(ctx, db, &lb, cfg->sample_nodes));
     mark();                             // a11 (no-op unless a species is larger than --sample)
@@ -236,6 +242,11 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
             }
             if (trio_mode) {                                                                // second_filter_paths, :1234-1268
                 const bool rs = r.need2[s] != 0;                                            // LP 2 actually differed from LP 1
+                // highs_opt keeps the first K columns of the second solution, K = number of survivors, and zips them with the candidates
+                // (profile.rs:2865-2879): a survivor at position >= K gets no second_sol.  Gurobi & co: every survivor its own x (:1500-1508)
+                int n_keep = 0;
+                for (int k = 0; k < p; ++k) n_keep += r.fixed2[h0 + k] ? 0 : 1;
+                const int k_lim = cfg->solver_semantics == PANTAX_HIP_SEMANTICS_HIGHS ? n_keep : p;
                 info[s].status2 = rs ? r.st2[s] : r.st1[s]; info[s].iters2 = rs ? r.it2[s] : 0; info[s].obj2 = rs ? r.obj2[s] : r.obj1[s];
                 if (info[s].status2 != 0) { failed = true; fail_code = PANTAX_HIP_E_SOLVER; }
                 for (int k = 0; k < p && !failed; ++k) {
@@ -248,7 +259,7 @@ int strain_finish(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const u
                         m.divergence = f; m.has |= PANTAX_HIP_HAS_DIVERGENCE;
                         if (keep && f > cfg->unique_trio_nodes_mean_count_f) { m.is_rescue = 1; m.has |= PANTAX_HIP_HAS_RESCUE; }   // :1251-1259
                     }
-                    if (keep) { m.second_sol = rs ? r.x2[h0 + k] : r.x1[h0 + k]; m.has |= PANTAX_HIP_HAS_SECOND; }   // :1500-1508
+                    if (keep && k < k_lim) { m.second_sol = rs ? r.x2[h0 + k] : r.x1[h0 + k]; m.has |= PANTAX_HIP_HAS_SECOND; }   // :1500-1508 / :2871-2879
                 }
             } else if (single_mode) {                                                       // :1269-1278
                 pantax_hip_hap_metrics &m = met[h0];

@@ -13,7 +13,8 @@ static void usage() {
             "usage: pantax-hip -db <db_dir> --gaf <gfa_mapped.gaf> [-T <work_dir>] [--species] [--strain]\n"
             "  --short-read | --long-read     (sets --fr default 0.3 / 0.5)\n"
             "  --fr F  --fc F(0.46)  -a F(1e-4)  --sr F(0.85)  --sd F(0.2)  --shift true|false\n"
-            "  --min_cov N  --min_depth N  --sample N (default 500000)  --ds a,b,c  --smode 0|1  --no-filter\n"
+            "  --min_cov N  --min_depth N  --sample N (default 500000)  --sample_test  --ds a,b,c  --smode 0|1  --no-filter\n"
+            "  --solver gurobi|highs|cplex|cbc|glpk   whose second-solve semantics to reproduce (the LP optimum is the same; default gurobi)\n"
             "  --force  -R <reads_classification.tsv>  --range-file F  --species-len-file F  --reads-binning-file F\n"
             "  --image-cache 0|1|2  device-ready graph images <db>/species_graph_info/<otu>.hipdb: 1 = use, 2 = use and write\n"
             "  --filter-gaf  first replace the GAF by its best alignment per read (long reads; alignment.rs:171-175, gaf_filter.rs)\n"
@@ -69,6 +70,11 @@ int main(int argc, char **argv) {
         else if (a == "--min_cov") c.min_cov = atoll(next());
         else if (a == "--min_depth") c.min_depth = atoll(next());
         else if (a == "--sample") c.sample_nodes = atoi(next());
+        else if (a == "--sample_test" || a == "--sample-test") c.sample_test = 1;      // cli.rs:230-232
+        else if (a == "--solver") {                                                    // cli.rs:158-160: whose handling of the second solve is reproduced
+            const char *sv = next();
+            c.solver_semantics = !strcasecmp(sv, "highs") ? PANTAX_HIP_SEMANTICS_HIGHS : PANTAX_HIP_SEMANTICS_GUROBI;   // gurobi, cplex, cbc, glpk agree (profile.rs:1500, :1906, :2125, :2672)
+        }
         else if (a == "--ds") c.designated_species = next();
         else if (a == "--smode") c.mode = atoi(next());
         else if (a == "--no-filter") c.filtered = 0;

@@ -131,6 +131,7 @@ struct CtxConfig {
     int dev_cache_gb = -1;           // cap of the per-process cache of released device blocks in GB (-1: min(3/4 of the device, 9/10 of what was free at first use); 0: nothing cached)
     bool numa_bind = true;           // the upload crew and its pinned ring live on the GPU's NUMA node
     uint64_t gaf_piece_bytes = 0;    // largest piece of GAF text tokenised at once (0: a sixth of the text, 64 MiB .. 1 GiB)
+    int db_groups = 0;               // file seam: groups of species that go through the device one after the other, the next one's graphs travelling meanwhile (0: by size; 1: one db)
     uint64_t db_path_steps_max = 0;  // path steps per resident db of the file seam (0: 3e9); a selection beyond it goes through the device group by group (tests lower it)
     // forced paths (tests compare them with the defaults)
     std::string trio_path;           // "block": every species through the node-block kernel; "bucket": global buckets
@@ -143,6 +144,9 @@ struct CtxConfig {
     std::string cov_long;            // "step": round 5's coverage_step_kernel for the groups that hold steps of walks of more than 64 steps
     int covl_shape = -1;             // shape of the long-walk kernel: <U><groups per workgroup / 8><window / 1024><back / 256> (default 2234)
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
+    bool cov_self_clean = false;     // resident step: the last readers of the coverage arena zero it instead of a zero fill in front of every coverage pass.  OFF: measured
+                                     // slower (node_cov_stats_kernel 2.5 -> 6.9 ms with the stores among its loads against 1.5 ms of zero fill at 1e4 strains)
+    bool cov_arena_verify = false;   // tests: a coverage pass that skips its zero fill first checks that the arena IS zero (fails with PANTAX_HIP_E_STATE)
     // measurement shapes
     int cov_item_groups = 0;         // groups of 64 steps per work item of the short-read coverage kernel (0: 64)
     int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
@@ -170,6 +174,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_main = nullptr;   // the main stream while `stream` is swapped to the side stream (api_step.cpp), else null
     hipStream_t stream2 = nullptr;   // side stream of the resident step (the trio index does not depend on the reads)
+    hipStream_t stream_up = nullptr; // copy stream of the file seam's graph loader thread (round 6; created on first use): the next group of species travels while this one's tables are built
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_seq = nullptr;     // orders the side stream behind everything enqueued on the main stream so far (steps run strictly one after the other on the device)
     std::string err;
@@ -368,6 +373,11 @@ struct Db {
     uint64_t U = 0;
     bool cov_prepared = false;       // coverage_prepare ran for the coming coverage_launch
     bool cov_count_pending = false;  // d_cov of the last coverage pass is still to be counted from the bitmap (node_stats_launch does it)
+    // round 6: in the resident step the last readers of the coverage arena (hap_rows_pass_kernel<0>: trio_bases; node_cov_stats_kernel: bases, bit vector,
+    // full-node flags) zero what they read, and the next coverage pass skips its zero fill.  cov_self_clean: this step's readers clean (set by
+    // strain_enqueue); cov_arena_clean + its signature: the arena is all zero in exactly this layout (reset by whatever dirties it).
+    bool cov_self_clean = false, cov_arena_clean = false;
+    uint64_t cov_arena_sig = 0;
     bool trio_sizes_known = false;   // U, the rows per haplotype and per species depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
     bool trio_layout_fast = false;   // the sizes were learnt by a build that filed the visit table's species from its records (else: every species by the pass over the walks)
@@ -461,7 +471,8 @@ struct Reads {
     bool g_flags_valid = false;
     bool species_valid = false;      // d_species (file order) reflects the last binning pass; species_ensure() gathers it from the slots
     bool binned = false;
-    bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip): no locus-grouped copy, no coverage pass
+    bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip; the file seam until its graphs travel): no locus-grouped copy, no coverage pass
+    uint32_t max_node_id = 0;        // largest node id of the walks (the device tokenizer notes it: what a later reads_group() sizes its buckets by)
 };
 
 // slot record (Reads::d_g_slot_rec).x: >= 0 species, the coverage pass uses the slot; -1 "U"; -2 - s: binned to species s but dropped
@@ -496,24 +507,51 @@ struct UploadSeg {
     uint64_t file_off = 0;
     uint64_t out_bytes = 0;   // bytes this stretch occupies on the device (a multiple of 4); the source holds twice as many when narrow
     bool narrow = false;
+    bool hole = false;        // nothing is filled (the bytes travel as they lie in the ring): a stretch another pass writes on the device
 };
 // segments back to back -> d_dst, as ONE chunk pipeline through the pinned ring (a crew of host threads fills a chunk -- pread /
 // memcpy / narrowing -- while the chunks before it travel).  *bad_seg (optional) = first segment that held a value beyond 32 bits, or -1.
-int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg);
+int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg, hipStream_t stream = nullptr /* null: ctx->stream */);
 
 // one species' graph as the db upload takes it: where its 32-bit node lengths and its walks (32-bit species-local node ids, haplotype
 // after haplotype) come from, and the walks' local CSR offsets (path_off may start anywhere).  Nothing of the big arrays is touched on
 // the host: lengths > 0, walks inside the graph and the identical-walk test are checked on the device (stage_db.hip).
+// Round 6 (image format 4): the walks of a species PACKED -- blocks of PK_BLOCK consecutive positions of its concatenated walks, every block
+// {first node id (u32), zigzag deltas of 1, 2 or 4 bytes, PK_BLOCK of them (the first is 0)}; node ids run along a walk in steps of one or
+// two (a pangenome graph is numbered along its backbone), so 97 % of the blocks take one byte per step: the walks cross PCIe at a quarter
+// of their size and are unpacked in HBM (walks_unpack_kernel, stage_db.hip).  `off` = payload offset of every block in units of PK_UNIT bytes
+// (n_blocks + 1 entries; a block's width is the difference).  Node lengths may lie as u16 (every length of the species below 2^16).
+constexpr uint32_t PK_BLOCK = 256, PK_UNIT = 256;
+struct PackedWalks {
+    uint64_t n_blocks = 0, payload_bytes = 0;   // payload: n_blocks blocks of PK_BLOCK x {1, 2, 4} bytes
+    UploadSeg first_seg, off_seg, payload_seg;  // u32[n_blocks] | u32[n_blocks + 1] | bytes
+};
 struct GraphPart {
     uint64_t n_nodes = 0, n_haps = 0;
     const uint64_t *path_off = nullptr;
-    UploadSeg len_seg;
-    std::vector<UploadSeg> walk_segs;
+    UploadSeg len_seg;                 // len16: out_bytes = 2 * n_nodes rounded up to 4 (u16 lengths, widened on the device)
+    bool len16 = false;
+    std::vector<UploadSeg> walk_segs;  // empty when `packed`
+    bool packed = false;
+    PackedWalks pk;
 };
+// stage_db.hip: the packed walks / 16-bit lengths of the species that have them -> d_path_nodes / d_node_len (the others' stretches are left alone)
+struct UnpackSpecies { uint32_t blk_base, off_base, payload_base /* PK_UNIT bytes */, out_base, n_steps; };
+int walks_unpack_launch(Ctx *ctx, const UnpackSpecies *d_table, uint32_t n_species, uint32_t n_blocks, const uint32_t *d_first, const uint32_t *d_off,
+                        const uint8_t *d_payload, uint32_t *d_path_nodes, hipStream_t stream = nullptr /* null: ctx->stream (timed) */);
+struct WidenSpecies { uint64_t src_base /* u16 index */, dst_base; uint64_t n; };
+int lens_widen_launch(Ctx *ctx, const WidenSpecies *d_table, uint32_t n_species, uint64_t n_total, const uint16_t *d_len16, uint32_t *d_node_len, hipStream_t stream = nullptr);
 // stage_db.hip: node tables (global prefix of the lengths), walk check and identical-walk test on the device
 int node_tables_launch(Ctx *ctx, Db *db, uint32_t *d_flags /* [2]: {a node of length 0, 1 + first haplotype that leaves its graph (0xFFFFFFFF: none)} */);
 int db_upload_parts(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, const std::string *files,
                     pantax_hip_db **out);
+// the same in three steps (round 6: the file seam loads the NEXT group of species on a thread of its own while this group's tables are built):
+// begin -- host tables, small uploads, the big arrays allocated (calling thread, ctx->stream); arrays -- node lengths and walks from their files into
+// HBM, unpacked where they come packed (any thread that has made the ctx's device current; `stream`: its copy stream, waited for before it returns;
+// touches neither ctx->stream nor the ctx's staging buffers); finish -- node tables, checks, tiles, visit table, node -> haplotypes (ctx->stream)
+int db_upload_begin(Ctx *ctx, uint32_t S, const int64_t *range_start, const int64_t *range_end, const GraphPart *parts, pantax_hip_db **out);
+int db_upload_arrays(Ctx *ctx, pantax_hip_db *db, const GraphPart *parts, const std::string *files, hipStream_t stream);
+int db_upload_finish(Ctx *ctx, pantax_hip_db *db);
 // large pageable host buffers (mmapped text, graph arrays) -> HBM through two pinned chunks: a few threads copy the next
 // chunk into pinned memory while the previous one is on its way over PCIe (a plain copy from pageable memory is staged
 // by one runtime thread at ~10 GB/s).  Returns after the last chunk has arrived.
@@ -580,6 +618,9 @@ int species_ensure(Ctx *ctx, Reads *rd);   // d_species in file order (resident 
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 // defer_count: leave node_base_cov (popcount_kernel) to the node statistics pass that follows in the resident step (db->cov_count_pending)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count = false);
+// the locus-grouped copy of reads that were tokenised / uploaded as plain columns (round 6: the file seam bins the plain columns for the species
+// decision and builds the copy while the first graphs travel); no-op on grouped reads
+int reads_group(Ctx *ctx, Reads *rd);
 int trio_index_build(Ctx *ctx, Db *db, bool with_keys = true);
 int trio_keys_ensure(Ctx *ctx, Db *db);
 #if TRIO_LH_PACK

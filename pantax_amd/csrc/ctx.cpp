@@ -95,9 +95,9 @@ struct OptDesc { const char *name; OptKind kind; size_t off; };
 #define OPT(nm, kind, field) {nm, kind, offsetof(CtxConfig, field)}
 const OptDesc OPTIONS[] = {
     OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind), OPT("dev_cache_gb", O_INT, dev_cache_gb),
-    OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("db_path_steps_max", O_U64, db_path_steps_max), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("trio_two_pass", O_BOOL, trio_two_pass), OPT("uniq_hash", O_INT, uniq_hash),
+    OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("db_path_steps_max", O_U64, db_path_steps_max), OPT("db_groups", O_INT, db_groups), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("trio_two_pass", O_BOOL, trio_two_pass), OPT("uniq_hash", O_INT, uniq_hash),
     OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
-    OPT("cov_general", O_BOOL, cov_general), OPT("cov_long", O_STR, cov_long), OPT("covl_shape", O_INT, covl_shape), OPT("cov_count", O_BOOL, cov_count), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
+    OPT("cov_general", O_BOOL, cov_general), OPT("cov_long", O_STR, cov_long), OPT("covl_shape", O_INT, covl_shape), OPT("cov_count", O_BOOL, cov_count), OPT("cov_self_clean", O_BOOL, cov_self_clean), OPT("cov_arena_verify", O_BOOL, cov_arena_verify), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
     OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
     OPT("cov_ablate", O_U32, cov_ablate), OPT("ssn_debug", O_BOOL, ssn_debug),
@@ -243,6 +243,7 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     for (auto &half : ctx->pin_up_ev) for (hipEvent_t &e : half) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     ctx->pin_text.release();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream_up) { (void)hipStreamSynchronize(ctx->stream_up); (void)hipStreamDestroy(ctx->stream_up); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_seq) (void)hipEventDestroy(ctx->ev_seq);
     (void)hipStreamDestroy(ctx->stream);
@@ -604,6 +605,7 @@ struct SegFiller {
             const UploadSeg &s = segs[k];
             const uint64_t so = b - prefix[k], n = std::min(e, prefix[k + 1]) - b;
             if (n == 0) continue;
+            if (s.hole) { out += n; b += n; continue; }
             const uint8_t *src = static_cast<const uint8_t *>(s.src);
             if (!src && s.file != fd_file) {
                 if (fd >= 0) ::close(fd);
@@ -643,7 +645,8 @@ struct SegFiller {
 };
 }  // namespace
 
-int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg) {
+int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs, const std::string *files, int64_t *bad_seg, hipStream_t stream_arg) {
+    const hipStream_t stream = stream_arg ? stream_arg : ctx->stream;
     if (bad_seg) *bad_seg = -1;
     SegFiller f{segs, n_segs, files};
     f.prefix.assign(n_segs + 1, 0);
@@ -682,10 +685,10 @@ int upload_segments(Ctx *ctx, void *d_dst, const UploadSeg *segs, size_t n_segs,
         crew.run(job);
         const auto t2 = std::chrono::steady_clock::now();
         t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_fill += std::chrono::duration<double, std::milli>(t2 - t1).count();
-        if (hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + c0, slot, c1 - c0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(ev[k], ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+        if (hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + c0, slot, c1 - c0, hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipEventRecord(ev[k], stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     }
-    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
+    if (rc == 0 && hipStreamSynchronize(stream) != hipSuccess) rc = fail(ctx, PANTAX_HIP_E_HIP, "upload failed");
     for (auto &e : ev) (void)hipEventDestroy(e);
     if (ctx->cfg.trace) {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -10,9 +10,15 @@
 // The same holds for the visit table itself (4 bytes per path step: 8.9 GB = 0.16 s against 75 ms of kernels).  So the image is
 // the graph alone and a7 stays a per-run device build, as in the reference (profile.rs:2936).
 //
+// Version 4 (round 6) packs the image for the trip over PCIe, which is what bounds a warm load: the walks as blocks of 256 positions of
+// zigzag DELTAS (1, 2 or 4 bytes per step, chosen per block; common.hpp PackedWalks) -- node ids run along a walk in steps of one or two,
+// so 97 % of the blocks take one byte per step -- and the node lengths as u16 when every length of the species is below 2^16.  At 1e4
+// strains: 10.2 GB -> 3.0 GB per db, unpacked in HBM in a few milliseconds (stage_db.hip).
+//
 // Layout (little endian, every section padded to 16 bytes):
-//   header  : "PTXHIPDB", u32 version, u32 flags (0), u64 V, H, P, L, u64 name_bytes
-//   node_len u32[V] | path_off u64[H+1] | path_nodes u32[P] | names ('\n'-joined) | u64 end marker = header checksum
+//   header  : "PTXHIPDB", u32 version, u32 flags (bit 0: u16 node lengths), u64 V, H, P, L, u64 name_bytes, u64 n_blocks, u64 payload_bytes
+//   node_len u16/u32[V] | path_off u64[H+1] | blk_first u32[n_blocks] | blk_off u32[n_blocks+1] (units of 256 bytes) | payload |
+//   names ('\n'-joined) | u64 end marker = header checksum
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -29,8 +35,9 @@ namespace ptx {
 
 namespace {
 constexpr char MAGIC[8] = {'P', 'T', 'X', 'H', 'I', 'P', 'D', 'B'};
-constexpr uint32_t VERSION = 3;   // 3: the graph alone (2: + the unique-trio index filed under the middle node; 1: under the smaller end)
-struct Header { char magic[8]; uint32_t version, flags; uint64_t V, H, P, L, name_bytes; };
+constexpr uint32_t VERSION = 4;   // 4: packed walks, 16-bit lengths; 3: the graph alone (2: + the unique-trio index filed under the middle node; 1: under the smaller end)
+constexpr uint32_t FLAG_LEN16 = 1u;
+struct Header { char magic[8]; uint32_t version, flags; uint64_t V, H, P, L, name_bytes, n_blocks, payload_bytes; };
 inline uint64_t pad16(uint64_t n) { return (n + 15) & ~uint64_t(15); }
 inline uint64_t header_sum(const Header &h) {
     uint64_t x = 0xcbf29ce484222325ull;
@@ -39,11 +46,12 @@ inline uint64_t header_sum(const Header &h) {
     return x;
 }
 struct Layout {
-    uint64_t node_len, path_off, path_nodes, names, end, total;
+    uint64_t node_len, path_off, blk_first, blk_off, payload, names, end, total;
     explicit Layout(const Header &h) {
         uint64_t o = pad16(sizeof(Header));
         auto take = [&](uint64_t bytes) { const uint64_t at = o; o += pad16(bytes); return at; };
-        node_len = take(4 * h.V); path_off = take(8 * (h.H + 1)); path_nodes = take(4 * h.P); names = take(h.name_bytes);
+        node_len = take(((h.flags & FLAG_LEN16) ? 2 : 4) * h.V); path_off = take(8 * (h.H + 1));
+        blk_first = take(4 * h.n_blocks); blk_off = take(4 * (h.n_blocks + 1)); payload = take(h.payload_bytes); names = take(h.name_bytes);
         end = take(8);
         total = o;
     }
@@ -76,13 +84,16 @@ std::string SpeciesImage::open(const std::string &p) {
     if (size < sizeof(Header) || !pread_all(f.fd, &h, sizeof(h), 0)) return p + ": not a pantax-hip graph image (too short)";
     if (std::memcmp(h.magic, MAGIC, 8) != 0) return p + ": not a pantax-hip graph image";
     if (h.version != VERSION) return p + ": graph image version " + std::to_string(h.version) + ", this build reads " + std::to_string(VERSION);
-    if (h.V >= 0xFFFFFFFFull || h.P >= 0xFFFFFFFFull || h.H > h.P + 1 || h.name_bytes > (1ull << 32)) return p + ": implausible graph image header";
+    if (h.V >= 0xFFFFFFFFull || h.P >= 0xFFFFFFFFull || h.H > h.P + 1 || h.name_bytes > (1ull << 32) || h.n_blocks != (h.P + PK_BLOCK - 1) / PK_BLOCK ||
+        h.payload_bytes % PK_UNIT || h.payload_bytes > 4ull * PK_BLOCK * h.n_blocks || h.payload_bytes < (uint64_t)PK_BLOCK * h.n_blocks)
+        return p + ": implausible graph image header";
     const Layout L(h);
     if (L.total != size) return p + ": graph image is truncated or has trailing bytes";
     uint64_t endmark = 0;
     if (!pread_all(f.fd, &endmark, 8, L.end) || endmark != header_sum(h)) return p + ": graph image end marker does not match its header";
     V = h.V; H = h.H; P = h.P; L_bases = h.L;
-    off_node_len = L.node_len; off_path_nodes = L.path_nodes;
+    off_node_len = L.node_len; len16 = (h.flags & FLAG_LEN16) != 0;
+    n_blocks = h.n_blocks; payload_bytes = h.payload_bytes; off_blk_first = L.blk_first; off_blk_off = L.blk_off; off_payload = L.payload;
     path_off.assign(H + 1, 0);
     if (!pread_all(f.fd, path_off.data(), 8 * (H + 1), L.path_off)) return p + ": cannot read the walk offsets";
     if (path_off[0] != 0 || path_off[H] != P) return p + ": graph image offsets are inconsistent";
@@ -100,6 +111,20 @@ std::string SpeciesImage::open(const std::string &p) {
     if (H && names.empty()) hap_names.assign(1, "");     // one haplotype with an empty name
     if (hap_names.size() != H) return p + ": graph image holds " + std::to_string(hap_names.size()) + " names for " + std::to_string(H) + " haplotypes";
     return "";
+}
+
+// where the image's sections lie, as the db upload takes them (file = index of the image among the upload's files)
+void SpeciesImage::fill_part(GraphPart &pt, int32_t file) const {
+    pt.n_nodes = V; pt.n_haps = H; pt.path_off = path_off.data();
+    pt.len_seg = UploadSeg(); pt.len_seg.file = file; pt.len_seg.file_off = off_node_len;
+    pt.len16 = len16;
+    pt.len_seg.out_bytes = len16 ? ((2 * V + 3) & ~3ull) : 4 * V;      // (sections are padded to 16 bytes in the file: the two bytes behind an odd stretch are there)
+    pt.walk_segs.clear();
+    pt.packed = true;
+    pt.pk.n_blocks = n_blocks; pt.pk.payload_bytes = payload_bytes;
+    pt.pk.first_seg = UploadSeg(); pt.pk.first_seg.file = file; pt.pk.first_seg.file_off = off_blk_first; pt.pk.first_seg.out_bytes = 4 * n_blocks;
+    pt.pk.off_seg = UploadSeg(); pt.pk.off_seg.file = file; pt.pk.off_seg.file_off = off_blk_off; pt.pk.off_seg.out_bytes = 4 * (n_blocks + 1);
+    pt.pk.payload_seg = UploadSeg(); pt.pk.payload_seg.file = file; pt.pk.payload_seg.file_off = off_payload; pt.pk.payload_seg.out_bytes = payload_bytes;
 }
 
 // one species of a resident db -> file
@@ -124,13 +149,53 @@ int db_save_image(Ctx *ctx, Db *db, uint32_t s, const std::vector<std::string> &
     PTX_TRY(download(ctx, &bo[0], db->d_bit_off.p + nb, 1)); PTX_TRY(download(ctx, &bo[1], db->d_bit_off.p + ne, 1));
     PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h.L = bo[1] - bo[0];
+    // node lengths and walks from the device, packed on the host (once per species and database)
+    std::vector<uint32_t> lens(h.V), walk(h.P);
+    PTX_TRY(download(ctx, lens.data(), db->d_node_len.p + nb, h.V));
+    PTX_TRY(download(ctx, walk.data(), db->d_path_nodes.p + q0, h.P));
+    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t lmax = 0;
+    for (uint32_t l : lens) lmax = std::max(lmax, l);
+    if (lmax < 65536u) h.flags |= FLAG_LEN16;
+    h.n_blocks = (h.P + PK_BLOCK - 1) / PK_BLOCK;
+    std::vector<uint32_t> blk_first(h.n_blocks), blk_off(h.n_blocks + 1, 0);
+    std::vector<uint8_t> payload;
+    payload.reserve((size_t)h.P + (size_t)h.P / 16 + 1024);
+    {
+        uint32_t zz[PK_BLOCK];
+        for (uint64_t b = 0; b < h.n_blocks; ++b) {
+            const uint64_t p0 = b * PK_BLOCK, n = std::min<uint64_t>(PK_BLOCK, h.P - p0);
+            blk_first[b] = walk[p0];
+            uint32_t mx = 0;
+            zz[0] = 0;
+            for (uint64_t i = 1; i < n; ++i) {
+                const int64_t d = (int64_t)walk[p0 + i] - (int64_t)walk[p0 + i - 1];   // |d| < 2^32: zigzag of the 32-bit difference (wraps like the decoder's adds)
+                const uint32_t d32 = (uint32_t)d;
+                zz[i] = (d32 << 1) ^ (uint32_t)((int32_t)d32 >> 31);
+                mx = std::max(mx, zz[i]);
+            }
+            // a difference of 2^31 and more does not survive the 32-bit zigzag: cannot occur (node ids below 2^32 - 1 differ by less than 2^32, and the
+            // decoder adds modulo 2^32 -- the round trip is exact for every pair of 32-bit ids)
+            for (uint64_t i = n; i < PK_BLOCK; ++i) zz[i] = 0;
+            const uint32_t w = mx < 256u ? 1u : mx < 65536u ? 2u : 4u;
+            const size_t at = payload.size();
+            payload.resize(at + (size_t)PK_BLOCK * w);
+            if (w == 1) for (uint32_t i = 0; i < PK_BLOCK; ++i) payload[at + i] = (uint8_t)zz[i];
+            else if (w == 2) for (uint32_t i = 0; i < PK_BLOCK; ++i) { const uint16_t x = (uint16_t)zz[i]; std::memcpy(&payload[at + 2 * i], &x, 2); }
+            else std::memcpy(&payload[at], zz, sizeof(zz));
+            blk_off[b + 1] = blk_off[b] + w * (PK_BLOCK / PK_UNIT);
+        }
+    }
+    h.payload_bytes = payload.size();
     const Layout L(h);
     std::vector<uint8_t> img(L.total, 0);
     std::memcpy(img.data(), &h, sizeof(h));
     uint64_t *po = reinterpret_cast<uint64_t *>(img.data() + L.path_off);
-    PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.node_len), db->d_node_len.p + nb, h.V));
-    PTX_TRY(download(ctx, reinterpret_cast<uint32_t *>(img.data() + L.path_nodes), db->d_path_nodes.p + q0, h.P));
-    PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h.flags & FLAG_LEN16) { uint16_t *o = reinterpret_cast<uint16_t *>(img.data() + L.node_len); for (uint64_t v = 0; v < h.V; ++v) o[v] = (uint16_t)lens[v]; }
+    else std::memcpy(img.data() + L.node_len, lens.data(), 4 * h.V);
+    std::memcpy(img.data() + L.blk_first, blk_first.data(), 4 * h.n_blocks);
+    std::memcpy(img.data() + L.blk_off, blk_off.data(), 4 * (h.n_blocks + 1));
+    if (!payload.empty()) std::memcpy(img.data() + L.payload, payload.data(), payload.size());
     for (uint64_t i = 0; i <= h.H; ++i) po[i] = db->h_path_off[h0 + i] - q0;
     std::memcpy(img.data() + L.names, joined.data(), joined.size());
     const uint64_t endmark = header_sum(h);
@@ -153,10 +218,7 @@ int db_from_images(Ctx *ctx, uint32_t S, const SpeciesImage *const *im, const in
         files[s] = im[s]->path;
         GraphPart &pt = parts[s];
         pt.n_nodes = im[s]->V; pt.n_haps = im[s]->H; pt.path_off = im[s]->path_off.data();
-        pt.len_seg.file = (int32_t)s; pt.len_seg.file_off = im[s]->off_node_len; pt.len_seg.out_bytes = 4 * im[s]->V;
-        UploadSeg w;
-        w.file = (int32_t)s; w.file_off = im[s]->off_path_nodes; w.out_bytes = 4 * im[s]->P;
-        pt.walk_segs.push_back(w);
+        im[s]->fill_part(pt, (int32_t)s);
     }
     return db_upload_parts(ctx, S, range_start, range_end, parts.data(), files.data(), out);
 }

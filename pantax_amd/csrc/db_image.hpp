@@ -12,8 +12,11 @@ struct SpeciesImage {   // the header, walk offsets and names of an image file; 
     uint64_t V = 0, H = 0, P = 0, L_bases = 0;
     std::vector<uint64_t> path_off;       // [H+1]
     std::vector<std::string> hap_names;
-    uint64_t off_node_len = 0, off_path_nodes = 0;   // byte offsets in the file
+    uint64_t off_node_len = 0;                        // byte offsets in the file
+    bool len16 = false;                               // node lengths as u16
+    uint64_t n_blocks = 0, payload_bytes = 0, off_blk_first = 0, off_blk_off = 0, off_payload = 0;   // the packed walks (common.hpp PackedWalks)
     std::string open(const std::string &path);   // "" or an error text
+    void fill_part(GraphPart &pt, int32_t file) const;
 };
 
 int db_save_image(Ctx *ctx, Db *db, uint32_t species, const std::vector<std::string> &hap_names, const std::string &path);

@@ -1140,6 +1140,14 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
     return 0;
 }
 
+int reads_group(Ctx *ctx, Reads *rd) {
+    if (rd->grouped) return 0;
+    PTX_TRY(build_step_read(ctx, rd, rd->max_node_id));
+    rd->grouped = true;
+    rd->binned = false;          // the species of a read now live in its slot record: the next binning pass writes them
+    return 0;
+}
+
 // node_base_cov[v] = number of covered bases (profile.rs:844/874, :1018-1023)
 // a node some step covered whole carries a flag instead of marked bits (coverage_step_kernel): its count is its length
 __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_t *__restrict__ bit_off, const uint32_t *__restrict__ full,
@@ -1163,6 +1171,12 @@ __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_
     }
 }
 
+__global__ void __launch_bounds__(256) count_nonzero_words_kernel(const uint32_t *__restrict__ p, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += p[i] != 0u;
+    if (c) atomicAdd(out, c);
+}
+
 // The part of the coverage pass that depends on the binning only -- zero-filling the result arena and the walk sums of
 // long reads: the resident step issues it while the trio index is still being built on the side stream.
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
@@ -1180,7 +1194,27 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     db->d_bitmap.view(base + off_bm, words);
     db->d_full.view(base + off_full, fwords);
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
-    PTX_TRY(zero_fill(ctx, base, total));
+    // the resident step's last readers left the arena zeroed (cov_arena_clean) unless its layout or place changed since: only the abort counter is reset
+    const uint64_t sig = (uint64_t)(uintptr_t)base ^ ((uint64_t)total * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)off_bm << 1) ^ ((uint64_t)off_full << 2) ^ (uint64_t)off_trio;
+    if (db->cov_arena_clean && db->cov_arena_sig == sig) {
+        if (ctx->cfg.cov_arena_verify) {
+            DevBuf<unsigned long long> d_nz;
+            PTX_HIP(ctx, d_nz.alloc(1));
+            PTX_HIP(ctx, hipMemsetAsync(d_nz.p, 0, 8, ctx->stream));
+            PTX_HIP(ctx, hipMemsetAsync(db->d_abort, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(count_nonzero_words_kernel, dim3(grid_for(total / 4, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t *>(base), (uint64_t)(total / 4), d_nz.p);
+            unsigned long long nz = 0;
+            PTX_TRY(download(ctx, &nz, d_nz.p, 1));
+            PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (nz) return fail(ctx, PANTAX_HIP_E_STATE, "coverage_prepare: %llu non-zero words in an arena its last readers should have left clean", nz);
+        }
+        PTX_HIP(ctx, hipMemsetAsync(db->d_abort, 0, 8, ctx->stream));
+    } else {
+        KTimer t(ctx, "zero_fill_kernel");   // (the arena's fill is a kernel of the step like any other: timed with them)
+        PTX_TRY(zero_fill(ctx, base, total));
+    }
+    db->cov_arena_clean = false;   // the coming pass writes it
+    db->cov_arena_sig = sig;
     if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");

@@ -3,6 +3,7 @@
 // passes over V and P -- the per-node tables (bit offsets = global prefix of the lengths, the packed node records), the checks the
 // reference makes while parsing (a node of length 0, profile.rs:494; a walk that leaves its graph would panic at :849) and the
 // identical-walk test of first_filter_paths (profile.rs:1188-1190).  Nothing here is on the step's path.
+#include <memory>
 #include "common.hpp"
 #include "primitives.hpp"
 #include "wave.hpp"
@@ -115,7 +116,72 @@ __global__ void __launch_bounds__(256) walks_same_kernel(const uint64_t *__restr
         if (__syncthreads_or(diff)) { if (threadIdx.x == 0) all_same[s] = 0; return; }
     }
 }
+
+// ---- image format 4 (round 6): packed walks / 16-bit node lengths -> the arrays the kernels read ----
+// One WAVE per block of PK_BLOCK positions: its species by a binary search over the species' first blocks (wave-uniform loads), then four rounds
+// of 64 zigzag deltas -> a wave prefix sum on top of the block's first id and the rounds before.  A block whose width is not 1, 2 or 4 (a damaged
+// file) is written as 0xFFFFFFFF: the walk check that follows every upload reports it.
+__global__ void __launch_bounds__(256) walks_unpack_kernel(const UnpackSpecies *__restrict__ table, uint32_t n_species, uint32_t n_blocks, const uint32_t *__restrict__ first,
+                                                           const uint32_t *__restrict__ off, const uint8_t *__restrict__ payload, uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (gb >= n_blocks) return;
+    uint32_t lo = 0, hi = n_species - 1;                               // the last species whose first block is <= gb
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (table[mid].blk_base <= gb) lo = mid; else hi = mid - 1; }
+    const UnpackSpecies sp = table[lo];
+    const uint32_t b = gb - sp.blk_base;
+    const uint32_t o0 = off[sp.off_base + b], o1 = off[sp.off_base + b + 1], w = o1 - o0;
+    const uint64_t pos0 = (uint64_t)b * PK_BLOCK;
+    const uint32_t n_in = (uint32_t)min((uint64_t)PK_BLOCK, (uint64_t)sp.n_steps - pos0);
+    const uint8_t *src = payload + ((uint64_t)sp.payload_base + o0) * PK_UNIT;
+    uint32_t *dst = out + (uint64_t)sp.out_base + pos0;
+    const bool good = w == 1u || w == 2u || w == 4u;
+    uint32_t carry = first[gb];
+#pragma unroll
+    for (uint32_t r = 0; r < PK_BLOCK / 64; ++r) {
+        const uint32_t i = r * 64u + (uint32_t)lane;
+        uint32_t zz = 0;
+        if (good && i < n_in) zz = w == 1u ? (uint32_t)src[i] : w == 2u ? (uint32_t)reinterpret_cast<const uint16_t *>(src)[i] : reinterpret_cast<const uint32_t *>(src)[i];
+        const uint32_t d = (zz >> 1) ^ (0u - (zz & 1u));               // zigzag -> two's complement
+        const uint32_t incl = wave_incl_scan_dpp(d);
+        if (i < n_in) dst[i] = good ? carry + incl : 0xFFFFFFFFu;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+}
+// 16-bit node lengths -> 32-bit: a wave takes 1024 consecutive source entries (the species' stretches lie back to back, each padded to 4 bytes)
+__global__ void __launch_bounds__(256) lens_widen_kernel(const WidenSpecies *__restrict__ table, uint32_t n_species, uint64_t n_total, const uint16_t *__restrict__ src,
+                                                         uint32_t *__restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t e0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 1024;
+    if (e0 >= n_total) return;
+    uint32_t lo = 0, hi = n_species - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (table[mid].src_base <= e0 + (uint64_t)lane) lo = mid; else hi = mid - 1; }
+    uint32_t s = lo;
+    for (uint32_t r = 0; r < 16; ++r) {
+        const uint64_t i = e0 + (uint64_t)r * 64 + (uint64_t)lane;
+        if (i >= n_total) break;
+        while (s + 1 < n_species && table[s + 1].src_base <= i) ++s;
+        const uint64_t k = i - table[s].src_base;
+        if (k < table[s].n) dst[table[s].dst_base + k] = (uint32_t)src[i];     // (the pad entry behind an odd stretch belongs to nobody)
+    }
+}
 }  // namespace
+
+int walks_unpack_launch(Ctx *ctx, const UnpackSpecies *d_table, uint32_t n_species, uint32_t n_blocks, const uint32_t *d_first, const uint32_t *d_off,
+                        const uint8_t *d_payload, uint32_t *d_path_nodes, hipStream_t stream) {
+    if (!n_blocks || !n_species) return 0;
+    std::unique_ptr<KTimer> t(stream ? nullptr : new KTimer(ctx, "walks_unpack_kernel"));   // (the launch timers belong to ctx->stream and its thread)
+    hipLaunchKernelGGL(walks_unpack_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, stream ? stream : ctx->stream, d_table, n_species, n_blocks, d_first, d_off, d_payload, d_path_nodes);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
+int lens_widen_launch(Ctx *ctx, const WidenSpecies *d_table, uint32_t n_species, uint64_t n_total, const uint16_t *d_len16, uint32_t *d_node_len, hipStream_t stream) {
+    if (!n_total || !n_species) return 0;
+    std::unique_ptr<KTimer> t(stream ? nullptr : new KTimer(ctx, "lens_widen_kernel"));
+    hipLaunchKernelGGL(lens_widen_kernel, dim3((uint32_t)((n_total + 4095) / 4096)), dim3(256), 0, stream ? stream : ctx->stream, d_table, n_species, n_total, d_len16, d_node_len);
+    PTX_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 int node_tables_launch(Ctx *ctx, Db *db, uint32_t *d_flags) {
     const uint64_t V = db->V;

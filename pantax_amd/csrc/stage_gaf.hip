@@ -589,6 +589,7 @@ int gaf_tokenize_device(Ctx *ctx, const char *text, uint64_t size, HostReads &ou
         resident->d_step_off.take(o32[0]); resident->d_node_id.take(o32[1]); resident->d_pstart.take(o32[2]); resident->d_pend.take(o32[3]);
         resident->d_qlen.take(o32[4]); resident->d_mapq.take(o8[0]); resident->d_flags.take(o8[1]); resident->d_id_hash.take(o_hash);
         resident->has_flags = true;
+        resident->max_node_id = max_id;
         if (group) PTX_TRY(build_step_read(ctx, resident, max_id));
         PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         lap("locus-grouped copy");

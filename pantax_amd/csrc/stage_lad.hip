@@ -186,9 +186,9 @@ struct HapAcc { double a; uint32_t c, n; };   // sum, count of the pass, rows se
 
 template <int PASS>
 __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restrict__ chunks, const uint64_t *__restrict__ hap_off, const uint16_t *__restrict__ row_hap,
-                                                           const unsigned long long *__restrict__ tb, const trio_len_t *__restrict__ tlen,
+                                                           unsigned long long *tb /* read, and -- clean != 0, pass 0 -- zeroed behind the read */, const trio_len_t *__restrict__ tlen,
                                                            const double *__restrict__ mean0, const double *__restrict__ sd, HapAcc *__restrict__ part,
-                                                           double *__restrict__ cx, uint16_t *__restrict__ chh, uint32_t *__restrict__ cn) {
+                                                           double *__restrict__ cx, uint16_t *__restrict__ chh, uint32_t *__restrict__ cn, uint32_t clean) {
     extern __shared__ HapAcc s_hap_acc[];
     __shared__ uint32_t s_qrow[128];
     __shared__ unsigned long long s_qtb[128];
@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             const uint32_t row = r0 + (uint32_t)lane;
             const unsigned long long t = row < ch.z ? tb[row] : 0ull;
             const bool nz = (long long)t > 0;
+            // the resident step: pass 0 is the only reader of the coverage pass's trio_bases -- it leaves them zeroed for the next step's pass (round 6)
+            if (PASS == 0 && clean && t != 0ull) tb[row] = 0ull;
             const unsigned long long bal = __ballot(nz);
             if (nz) {
                 const uint32_t idx = (qh + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) & 127u;
@@ -416,8 +418,8 @@ int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_nnz, DevBu
 #define HS_PASS(PP)                                                                                                                                            \
     if (db->stat_global_rows) PTX_TRY(zero_fill(ctx, part, (size_t)std::max<uint64_t>(db->n_stat_partials, 1) * sizeof(HapAcc)));                            \
     if (NC) hipLaunchKernelGGL(hap_rows_pass_kernel<PP>, dim3(NC), dim3(64), lds, ctx->stream, (const uint4 *)db->d_stat_chunks.p, (const uint64_t *)db->d_hap_off.p, \
-                               TRIO_HAP_PTR(db), (const unsigned long long *)db->d_trio_bases.p, (const trio_len_t *)db->d_trio_len.p,          \
-                               (const double *)mean0, (const double *)sd, part, dbm->d_hs_x.p, dbm->d_hs_h.p, dbm->d_hs_n.p);                                  \
+                               TRIO_HAP_PTR(db), (unsigned long long *)db->d_trio_bases.p, (const trio_len_t *)db->d_trio_len.p,          \
+                               (const double *)mean0, (const double *)sd, part, dbm->d_hs_x.p, dbm->d_hs_h.p, dbm->d_hs_n.p, db->cov_self_clean ? 1u : 0u);            \
     hipLaunchKernelGGL(hap_combine_kernel<PP>, dim3(S), dim3(256), 0, ctx->stream, (const uint32_t *)db->d_sp_chunk_off.p, (const uint4 *)db->d_stat_chunks.p,  \
                        (const uint64_t *)db->d_hap_off.p, (const HapAcc *)part, d_nnz.p, mean0, sd, d_mean.p);
     HS_PASS(0) HS_PASS(1) HS_PASS(2)
@@ -465,9 +467,14 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
 // work, stage_cov.hip): in the resident step nothing reads the counts between the coverage pass and this one, and the two passes share
 // the node lengths.  The bit offset of a node comes from a running prefix of the lengths inside the workgroup's range (one 8-byte load
 // per workgroup instead of 8V bytes of offsets); 24V + L/8 bytes instead of 32V + L/8 for the two kernels.
+// CLEAN (round 6): this pass is the LAST reader of `bases`, the bit vector and the full-node flags in the resident step -- it leaves them zeroed for
+// the next step's coverage pass (only what is not zero is written: the lines are in the caches, a node some step covered whole has no marked bits),
+// instead of a 4-GB zero fill per step in front of it.  A word of flags / bits that a wave shares with its neighbours (the ends of its range of nodes)
+// loses this wave's bits only, atomically; a word that is all its own is stored.  (No __restrict__ on the three arrays: they are read and written here.)
+template <bool CLEAN>
 __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
-                                                             const unsigned long long *__restrict__ bases, const uint64_t *__restrict__ bit_off,
-                                                             const uint32_t *__restrict__ full, const uint32_t *__restrict__ bitmap, double min_depth,
+                                                             unsigned long long *bases, const uint64_t *__restrict__ bit_off,
+                                                             uint32_t *full, uint32_t *bitmap, double min_depth,
                                                              uint32_t *__restrict__ cov_out, double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
@@ -502,6 +509,7 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
             bs[r] = in ? bases[v] : 0ull;
             fw[r] = in ? full[v >> 5] : 0u;
         }
+        const uint64_t round_b0 = run;                           // the bits of this round's nodes: [round_b0, run) once the lengths are summed
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const uint32_t incl = wave_incl_scan_dpp(l[r]);      // (a species' bases fit 32 bits: checked at upload)
@@ -524,7 +532,19 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
                 const uint64_t g1 = g0[r] + l[r], w0 = g0[r] >> 5, w1 = (g1 - 1) >> 5;
                 const uint32_t m0 = 0xFFFFFFFFu << (g0[r] & 31), m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
                 c = w0 == w1 ? __popc(bw0[r] & m0 & m1) : __popc(bw0[r] & m0) + __popc(bw1[r] & m1);
-                for (uint64_t w = w0 + 1; w < w1; ++w) c += __popc(bitmap[w]);     // nodes of more than 33 bases
+                for (uint64_t w = w0 + 1; w < w1; ++w) {                           // nodes of more than 33 bases
+                    const uint32_t x = bitmap[w];
+                    c += __popc(x);
+                    if (CLEAN && x) bitmap[w] = 0u;                                // (a word inside one node is that node's alone)
+                }
+                if constexpr (CLEAN) {
+                    // A word is zeroed by the node that holds its LAST bit, with a plain store of what that lane has loaded anyway -- when all of the word's
+                    // bits belong to THIS round of this wave [round_b0, run): every other node that touches the word has then been read, in this very round.
+                    // The (at most two) words that reach over the round's ends lose this round's bits atomically, below.
+                    const bool in0 = (w0 << 5) >= round_b0 && (w0 << 5) + 32 <= run, in1 = (w1 << 5) >= round_b0 && (w1 << 5) + 32 <= run;
+                    if (bw0[r] && in0 && (w0 << 5) + 32 <= g1) bitmap[w0] = 0u;
+                    if (w1 != w0 && bw1[r] && in1 && (g1 & 31) == 0) bitmap[w1] = 0u;
+                }
             }
             if ((fw[r] >> (v & 31u)) & 1u) c = l[r];             // a step covered the whole node: a flag instead of marked bits
             cov_out[v] = c;
@@ -535,6 +555,27 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
             if (ab > 0.0) ++nv;
             const double o = ab > min_depth ? ab : 0.0;          // :2941-2944
             if (o > 0.0) { zs += o; ++zc; }
+        }
+        if constexpr (CLEAN) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const uint32_t v = v0 + (uint32_t)r * 64u + lane;
+                const bool in = v < whi;
+                if (in && bs[r] != 0ull) bases[v] = 0ull;
+                // the flags of this stretch's nodes, word by word: the first lane of every word's run of lanes clears the run's bits
+                if (in && (lane == 0u || (v & 31u) == 0u)) {
+                    const uint32_t n = min(min(32u - (v & 31u), 64u - lane), whi - v);
+                    const uint32_t m = (n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << (v & 31u);
+                    if (fw[r] & m) { if (m == 0xFFFFFFFFu) full[v >> 5] = 0u; else atomicAnd(&full[v >> 5], ~m); }
+                }
+            }
+            if (run > round_b0 && lane < 2u) {                   // the words over the round's two ends: this round's bits of them, atomically (lane 0: the first, lane 1: the last)
+                const uint64_t ws = round_b0 >> 5, we = (run - 1) >> 5;
+                const uint32_t ms = 0xFFFFFFFFu << (round_b0 & 31), me = 0xFFFFFFFFu >> (31 - (uint32_t)((run - 1) & 31));
+                const bool s_part = (round_b0 & 31) != 0, e_part = (run & 31) != 0;
+                if (lane == 0u && (s_part || (ws == we && e_part))) atomicAnd(&bitmap[ws], ~(ws == we ? ms & me : ms));
+                if (lane == 1u && e_part && we != ws) atomicAnd(&bitmap[we], ~me);
+            }
         }
     }
     __syncthreads();
@@ -569,7 +610,11 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     KTimer t(ctx, with_cov ? "node_cov_stats_kernel" : "node_stats_kernel");
     const uint32_t nch = with_cov ? stat_chunks(S, 8192u) : stat_chunks(S);   // (the fused kernel holds fewer workgroups per CU: shorter ones, so that the last round is short)
     if (with_cov) {
-        hipLaunchKernelGGL(node_cov_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+        if (db->cov_self_clean)
+        hipLaunchKernelGGL(node_cov_stats_kernel<true>, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
+        else
+        hipLaunchKernelGGL(node_cov_stats_kernel<false>, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
                            db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
         const_cast<Db *>(db)->cov_count_pending = false;
     } else

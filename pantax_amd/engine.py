@@ -324,8 +324,9 @@ class Engine:
         return bases, cov, (tb[: self.U] if tb is not None else None), n_abort.value
 
     def strain_profiling(self, species_coverage, species_active=None, fr=0.3, fc=0.46, sr=0.85, min_depth=0,
-                         shift=False, sample_nodes=0):
-        cfg = _ffi.StrainConfig(fr, fc, sr, min_depth, int(shift), sample_nodes)
+                         shift=False, sample_nodes=0, solver_semantics=0):
+        """solver_semantics: 0 = Gurobi's handling of the second solve (profile.rs:1500-1508), 1 = highs_opt's (profile.rs:2865-2879)"""
+        cfg = _ffi.StrainConfig(fr, fc, sr, min_depth, int(shift), sample_nodes, int(solver_semantics))
         act = None if species_active is None else as_c(species_active, np.uint8)
         cov = as_c(species_coverage, np.float64)
         met = (_ffi.HapMetrics * max(self.H, 1))()
@@ -334,7 +335,7 @@ class Engine:
         return met, info
 
     def profile_step(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
-                     rebuild_trio=True, sample_nodes=0):
+                     rebuild_trio=True, sample_nodes=0, solver_semantics=0):
         """One resident pass of the hot path in a single call (pantax_hip_profile_step): the host waits once.
         -> keep [S] uint8, predicted_coverage [S], metrics [H], info [S], pass [H] uint8, sum_all [S], sum_pass [S]"""
         if self._step_buf is None or self._step_buf[0] != (self.S, self.H):
@@ -344,7 +345,7 @@ class Engine:
             self._step_ptr = [p(a) if isinstance(a, np.ndarray) else a for a in self._step_buf[1:]]
         _, keep, absolute, met, info, passed, s_all, s_pass = self._step_buf
         avg = as_c(avg_len, np.float64)
-        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio))
+        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio), int(solver_semantics))
         self._check(self.lib.pantax_hip_profile_step(self.ctx, self.db, self.reads, p(avg), C.byref(cfg), *self._step_ptr))
         if rebuild_trio:
             self.U = None
@@ -357,12 +358,12 @@ class Engine:
         self.U = None
 
     def profile_step_enqueue(self, avg_len, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_cov=0, min_depth=0, shift=False, filtered=True,
-                             rebuild_trio=True, sample_nodes=0):
+                             rebuild_trio=True, sample_nodes=0, solver_semantics=0):
         """First half of profile_step (pantax_hip_profile_step_enqueue): the whole step goes onto the device, nothing is waited
         for.  Up to two steps may be in flight; the device runs their main-stream work one step after the other (the unique-trio
         rebuild of the next step may start behind the previous step's first filter, its last reader)."""
         avg = as_c(avg_len, np.float64)
-        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio))
+        cfg = _ffi.StepConfig(fr, fc, sr, sd, min_cov, min_depth, int(shift), int(filtered), int(sample_nodes), int(rebuild_trio), int(solver_semantics))
         self._check(self.lib.pantax_hip_profile_step_enqueue(self.ctx, self.db, self.reads, p(avg), C.byref(cfg)))
         self._inflight += 1
         if rebuild_trio:
@@ -445,7 +446,7 @@ class Engine:
                 min_species_abundance=1e-4, min_cov=0, min_depth=0, shift=False, filtered=True, full=True, force=False,
                 mode=2, sample_nodes=0, designated_species=None, zip="serialize", out_binning_file=None,
                 reads_binning_file=None, range_file=None, species_len_file=None, image_cache=0, rank=0, world_size=1,
-                allreduce=None, alltoallv=None):
+                allreduce=None, alltoallv=None, sample_test=False, solver_semantics=0, minimization_min_cov=0.0):
         """profile::profile(ProfilingConfig) (profile.rs:3325): files in, files out.  allreduce(float64 array) sums in place over
         the ranks; alltoallv(send uint8 array, send_off [W+1], recv uint8 array, recv_off [W+1]) moves bytes between the ranks
         (host buffers) and switches on the sharded ingest."""
@@ -458,7 +459,8 @@ class Engine:
             min_cov=min_cov, min_depth=min_depth, species=int(species), strain=int(strain), shift=int(shift),
             filtered=int(filtered), full=int(full), force=int(force), mode=mode, sample_nodes=sample_nodes,
             designated_species=enc(designated_species), zip=enc(zip), rank=int(rank), world_size=int(world_size),
-            image_cache=int(image_cache))
+            image_cache=int(image_cache), sample_test=int(sample_test), solver_semantics=int(solver_semantics),
+            minimization_min_cov=float(minimization_min_cov))
         cb = None
         if allreduce is not None:   # allreduce(np.ndarray float64) sums it in place over the ranks
             def _cb(_user, buf, n):

@@ -30,6 +30,7 @@ class StepConfig:
     filtered: bool = True
     sample_nodes: int = 0                 # --sample (cli.rs:227: 500000 by default); 0 = never sub-sample the LP rows
     rebuild_trio: bool = True             # the reference rebuilds trio_nodes_info every run (profile.rs:2936)
+    solver_semantics: int = 0             # 0: Gurobi's handling of the second solve's solution (profile.rs:1500-1508), 1: highs_opt's (profile.rs:2865-2879)
 
 
 def partition_species(weights, world):
@@ -224,7 +225,7 @@ def local_enqueue(eng, avg_len, cfg):
     """The device part of a step, enqueued and not waited for (pantax_hip_profile_step_enqueue); local_stage(..., "collect")
     takes its results."""
     eng.profile_step_enqueue(avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
-                             filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
+                             filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes, solver_semantics=cfg.solver_semantics)
 
 
 def local_stage(eng, avg_len, cfg, single_call=True):
@@ -237,7 +238,7 @@ def local_stage(eng, avg_len, cfg, single_call=True):
         else:
             keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(
                 avg_len, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr, sd=cfg.sd, min_cov=cfg.min_cov, min_depth=cfg.min_depth, shift=cfg.shift,
-                filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes)
+                filtered=cfg.filtered, rebuild_trio=cfg.rebuild_trio, sample_nodes=cfg.sample_nodes, solver_semantics=cfg.solver_semantics)
         keep, absolute, s_all, s_pass = keep.copy(), absolute.copy(), s_all.copy(), s_pass.copy()
         if eng.S < 16:
             solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0 for s in range(eng.S)], dtype=np.uint8)
@@ -257,7 +258,7 @@ def local_stage(eng, avg_len, cfg, single_call=True):
         eng.trio_nodes_info(fetch=False)
         eng.get_node_abundances(species_active=keep, fetch=False)
         met, info = eng.strain_profiling(absolute, species_active=keep, fr=cfg.fr, fc=cfg.fc, sr=cfg.sr,
-                                         min_depth=cfg.min_depth, shift=cfg.shift, sample_nodes=cfg.sample_nodes)
+                                         min_depth=cfg.min_depth, shift=cfg.shift, sample_nodes=cfg.sample_nodes, solver_semantics=cfg.solver_semantics)
         solved = np.array([1 if (keep[s] and info[s].status1 == 0 and info[s].status2 == 0) else 0
                            for s in range(eng.S)], dtype=np.uint8)
         passed, s_all, s_pass = eng.abundance_filter(met, solved, cfg.sd, cfg.min_cov)

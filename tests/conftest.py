@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# every ctx of the test processes (and of the CLI binaries they start) checks, before a coverage pass that skips its zero fill, that the arena its
+# last readers were to leave clean IS all zero (round 6: self-cleaning coverage arena); the library reads the environment in pantax_hip_init
+os.environ.setdefault("PANTAX_COV_ARENA_VERIFY", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

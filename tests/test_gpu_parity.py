@@ -1202,7 +1202,7 @@ def test_concurrent_solver_calls_on_one_ctx(eng, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [0, 1, 2])
+@pytest.mark.parametrize("k", [0, 1, 2, 4])
 def test_step_vs_literal_python_restatement_of_the_strain_level(eng, k):
     """The HIP path against fixtures from oracle/ref_literal_strain.py -- the literal Python reading of rcls.rs:237-258 and
     profile.rs:208-349, 1028-1285, 1297-1511 (LP by SciPy-HiGHS), 2884-3070, 3167-3248, which shares no code with the C oracle:
@@ -1220,7 +1220,8 @@ def test_step_vs_literal_python_restatement_of_the_strain_level(eng, k):
     sp, *_ = eng.rcls_profile()
     assert [names[i] if i >= 0 else "U" for i in sp] == ex["read_species"]
     keep, absolute, met, info, passed, s_all, s_pass = eng.profile_step(sset.avg_len(), fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_cov=a["min_cov"],
-                                                                          min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"])
+                                                                          min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"],
+                                                                          solver_semantics=1 if a.get("solver") == "highs" else 0)   # (case 4: --solver highs)
     d = metrics_to_dicts(met, eng.H)
     tab = {r["species_taxid"]: r for r in ex["species_profile"]}
     for s, g in enumerate(sset.species):
@@ -1239,8 +1240,12 @@ def test_step_vs_literal_python_restatement_of_the_strain_level(eng, k):
         check_metrics_against_literal(e["metrics"], d[h0:h1], g.name)
     # the tables as the stage API builds them (species order of the species table, normalisers, filters, sort)
     cfg = StepConfig(fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_species_abundance=a["min_species_abundance"], min_cov=a["min_cov"],
-                     min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"])
+                     min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"], solver_semantics=1 if a.get("solver") == "highs" else 0)
     species_rows, strain_rows, stats = profile_step(eng, names, haps, sset.avg_len(), cfg)
+    if a.get("solver") == "highs":   # ... and the slice does matter in this fixture: Gurobi's reading keeps more strains
+        import dataclasses
+        _, rows_g, _ = profile_step(eng, names, haps, sset.avg_len(), dataclasses.replace(cfg, solver_semantics=0))
+        assert len(rows_g) > len(strain_rows)
     assert [r[0] for r in species_rows] == [r["species_taxid"] for r in ex["species_profile"]]
     for r, e in zip(species_rows, ex["species_profile"]):
         assert r[1] == pytest.approx(e["predicted_abundance"], rel=1e-12) and r[2] == pytest.approx(e["predicted_coverage"], rel=1e-12)

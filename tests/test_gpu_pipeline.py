@@ -19,7 +19,7 @@ def _read_tsv(path):
 
 
 def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_drop=None, min_cov=0, shift=False, min_depth=0, ds=None,
-                   mode=2):
+                   mode=2, sample_nodes=0, solver_semantics=0):
     from oracle import oracle as orc
     rd = sset.reads
     S = len(sset.species)
@@ -39,7 +39,8 @@ def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_d
         mine = sp == s if strain_drop is None else (sp == s) & ~strain_drop
         so, nid, ps, pe = select_reads(rd, np.nonzero(mine)[0])
         b, c, tb, _ = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
-        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=fr, fc=fc, sr=sr, shift=shift, min_depth=min_depth)
+        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=fr, fc=fc, sr=sr, shift=shift, min_depth=min_depth, sample_nodes=sample_nodes,
+                                                   solver_semantics=solver_semantics)
         assert rc == 0
         orc.abundance_constraint(absolute[s], met)
         d = orc.metrics_to_dicts(met)
@@ -249,6 +250,10 @@ def test_profile_seam_default_sample_limit(world):
     ("mincov", dict(min_cov=4, sd=0.05), dict(min_cov=4, sd=0.05), False),                        # --min_cov / --sd of abundance_est
     ("shift", dict(shift=True, fr=0.5, min_depth=1), dict(shift=True, fr=0.5, min_depth=1), False),
     ("round", dict(full=False), dict(), True),                                                    # two-decimal table
+    # --sample_test (cli.rs:230-232): 500 rows of sample_sorted whatever --sample says (profile.rs:1387-1393, :2738-2744)
+    ("sample_test", dict(sample_test=True, sample_nodes=500000), dict(sample_nodes=500), False),
+    # --solver highs: the second solve's solution through highs_opt's slice (profile.rs:2865-2879); a tight --fc makes candidates fall in the second filter
+    ("highs", dict(solver_semantics=1, fc=0.05, sr=0.99), dict(solver_semantics=1, fc=0.05, sr=0.99), False),
 ])
 def test_profile_seam_options(world, name, kw, okw, rounded):
     """The option branches of load_species_range / optimize_otu / abundance_est through the file seam (profile.rs:553-656,
@@ -257,6 +262,8 @@ def test_profile_seam_options(world, name, kw, okw, rounded):
     exp_species, exp_strain, _ = _oracle_tables(sset, **okw)
     if name != "round":
         assert exp_strain != _oracle_tables(sset)[1]          # the option changes the answer on this data
+    if name == "highs":                                       # ... and so does the slice itself: Gurobi's reading of the same options gives other rows
+        assert exp_strain != _oracle_tables(sset, fc=0.05, sr=0.99)[1]
     wd = root / ("wd_opt_" + name)
     wd.mkdir()
     cwd = os.getcwd()
@@ -732,7 +739,7 @@ def test_profile_seam_sharded_failure_reaches_every_rank(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4])
 def test_profile_seam_vs_literal_python_restatement(tmp_path, k):
     """Files in, tables out (pantax_hip_profile) against the fixtures of oracle/ref_literal_strain.py -- the literal Python
     reading of the reference, LP by SciPy-HiGHS: the DB and the GAF are written from the fixture (`*` where it holds a null),
@@ -755,7 +762,8 @@ def test_profile_seam_vs_literal_python_restatement(tmp_path, k):
     os.chdir(str(wd))
     try:
         eng.profile(str(db), str(wd), str(gaf), fr=a["fr"], fc=a["fc"], sr=a["sr"], sd=a["sd"], min_species_abundance=a["min_species_abundance"],
-                    min_cov=a["min_cov"], min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"], sample_nodes=0)
+                    min_cov=a["min_cov"], min_depth=a["min_depth"], shift=a["shift"], filtered=a["filtered"], sample_nodes=0,
+                    solver_semantics=1 if a.get("solver") == "highs" else 0)      # (case 4: --solver highs, profile.rs:2865-2879)
     finally:
         os.chdir(cwd)
         eng.close()

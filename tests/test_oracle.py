@@ -247,7 +247,7 @@ def test_lad_solver_vs_reference_milp_model(golden_dir):
         assert np.all(x[fixed == 1] == 0.0)
 
 
-@pytest.mark.parametrize("k", [0, 1, 2])
+@pytest.mark.parametrize("k", [0, 1, 2, 4])
 def test_oracle_equals_literal_python_restatement_of_the_strain_level(k):
     """The C oracle against fixtures from oracle/ref_literal_strain.py, the literal Python reading of rcls.rs:237-258 and
     profile.rs:208-349, 1028-1285, 1297-1511 (LP by SciPy-HiGHS), 2884-3070, 3167-3248 that shares no code with it: species of
@@ -281,7 +281,9 @@ def test_oracle_equals_literal_python_restatement_of_the_strain_level(k):
         b, c, tb, na = orc.node_coverage(G, T, g.range_start, so, nid, ps, pe)
         e = ex["per_species"][g.name]
         assert (T.n_unique, na, int(b.sum()), int(tb.sum())) == (e["n_unique_trios"], e["n_abort"], e["bases_total"], e["trio_bases_total"])
-        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=a["fr"], fc=a["fc"], sr=a["sr"], shift=a["shift"], min_depth=a["min_depth"])
+        # (case 4: --solver highs -- the second solve's solution handed out through highs_opt's slice, profile.rs:2865-2879)
+        rc, met, nc, o1, o2 = orc.optimize_species(G, T, b, c, tb, fr=a["fr"], fc=a["fc"], sr=a["sr"], shift=a["shift"], min_depth=a["min_depth"],
+                                                   solver_semantics=1 if a.get("solver") == "highs" else 0)
         assert rc == 0 and nc == e["n_candidates"]
         if e["obj1"] is not None:
             assert o1 == pytest.approx(e["obj1"], rel=1e-9, abs=1e-12)
