@@ -74,7 +74,7 @@ def workload_spec(name, species=None, haps=None, reads=None, genome_len=None):
 
 
 def native_set(spec, threads=None, seed_shift=0):
-    from pantax_amd import synth
+    import synthdata as synth
     return synth.NativeSet(spec["seed"] + seed_shift, spec["species"], spec["haps"], spec["reads"], spec["genome_len"], long_reads=spec.get("long_reads", False),
                            threads=threads)
 
@@ -242,7 +242,7 @@ def cpu_leg_child(args):
         os.replace(tmp, out_path)
     try:
         from oracle import oracle as orc
-        from pantax_amd import synth
+        import synthdata as synth
         from pantax_amd.pipeline import StepConfig
         spec = workload_spec(args.workload, args.species, args.haps, args.reads, args.genome_len)
         cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()
@@ -556,7 +556,7 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
     genomes_info.txt, one bincode `.bin` per species, zip.rs:171-190) + the GAF text.  cold: graphs from the `.bin` files (64-bit
     values narrowed on their way into the pinned ring); warm: from the device-ready images a run with image_cache = 2 leaves behind.
     Page cache warm in both (the files were just written).  Never `value`."""
-    from pantax_amd import synth
+    import synthdata as synth
     res = {}
     db = os.path.join(td, "db")
     os.mkdir(db)
@@ -629,7 +629,7 @@ def run_many_dbs(args, spec, local_rank):
     strains = 1.1e10 path steps) on ONE GPU: the species are cut into contiguous groups under the limit, every group is a db on a ctx of its
     own with the reads of its species (species are independent from a4 on, profile.rs:3297-3319), the dbs are stepped side by side and their
     results meet like those of ranks (pipeline.profile_steps_many) -- the global normalisers of profile.rs:341, :3198, :3243 over all of them."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import Engine
     from pantax_amd.pipeline import StepConfig, profile_steps_many, split_species_by_path_steps
     import torch
@@ -886,7 +886,7 @@ def main():
     leg.wait_stage(("oracle_done", "done", "failed"), timeout=900)
     cpu_wait_s = time.perf_counter() - t_cpu_wait
 
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, partition_species, profile_step, profile_steps_pipelined
     cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()   # long reads: --fr 0.5 (main.rs:108-114)
     import torch

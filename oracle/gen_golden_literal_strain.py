@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 import ref_literal_strain as ls          # noqa: E402
-from pantax_amd import synth             # noqa: E402
+import synthdata as synth             # noqa: E402
 
 
 def lp_is_unique(coeff, rows, abund, ub, fixed, x_ref, obj_ref):

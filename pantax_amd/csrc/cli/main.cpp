@@ -23,7 +23,8 @@ static void usage() {
             "  --ranks N --rank r   one process per GPU (start N of them; device = r unless --device): every rank tokenises 1/N of the\n"
             "                       GAF, reads travel to the owner of their species over RCCL, rank 0 writes the tables\n"
             "                       (defaults from WORLD_SIZE / RANK / LOCAL_RANK when set); --comm-id-file F (default <wd>/.pantax_hip_rccl_id),\n"
-            "                       --comm-nonce N (the same for all ranks of one launch; default from $TORCHELASTIC_RUN_ID / $MASTER_PORT; the id file must also be fresh)\n");
+            "                       --comm-nonce N (the same for all ranks of one launch; default from $TORCHELASTIC_RUN_ID / $MASTER_PORT; the id file must also be fresh),\n"
+            "                       --comm-timeout S (default 300: a rank whose peers do not complete the RCCL bootstrap in time aborts it and exits non-zero)\n");
 }
 
 int main(int argc, char **argv) {
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
     // (the launcher's variables are read here, once, before any thread exists: the one place the CLI looks at the environment)
     auto env = [](const char *name) -> const char * { return std::getenv(name); };
     uint64_t nonce = env("MASTER_PORT") ? strtoull(env("MASTER_PORT"), nullptr, 10) : 0;
+    double comm_timeout = 300.0;     // --comm-timeout: seconds the whole RCCL bootstrap may take before this rank gives up and exits non-zero
     if (const char *rid = env("TORCHELASTIC_RUN_ID")) {
         uint64_t h = 0xcbf29ce484222325ull;
         for (const char *q = rid; *q; ++q) { h ^= (uint64_t)(unsigned char)*q; h *= 0x100000001b3ull; }
@@ -94,6 +96,7 @@ int main(int argc, char **argv) {
         else if (a == "--rank") rank = atoi(next());
         else if (a == "--comm-id-file") id_file = next();
         else if (a == "--comm-nonce") nonce = strtoull(next(), nullptr, 10);
+        else if (a == "--comm-timeout") comm_timeout = atof(next());
         else { usage(); return 2; }
     }
     const bool use_rccl = ranks >= 1 && rank >= 0;   // also a one-rank world goes through the communicator when asked for
@@ -121,7 +124,7 @@ int main(int argc, char **argv) {
     RcclComm comm;
     if (use_rccl) {
         if (id_file.empty()) id_file = wd + "/.pantax_hip_rccl_id";
-        if (!comm.init(rank, ranks, id_file, nonce)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
+        if (!comm.init(rank, ranks, id_file, nonce, comm_timeout)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
         c.rank = rank; c.world_size = ranks; c.comm_user = &comm;
         c.allreduce_sum = &RcclComm::allreduce_sum; c.alltoallv = &RcclComm::alltoallv; c.comm_device_buffers = 1;
     }

@@ -7,13 +7,17 @@
 // count when a launcher sets them, else $MASTER_PORT, else "0").  The other ranks accept a file only if it carries THEIR nonce
 // AND is not older than their own start minus two seconds -- both, always: a launcher may hand the same nonce to consecutive
 // launches (torchrun's default port never changes), and a file a killed run left behind with that nonce would send a rank that
-// starts before rank 0's unlink into ncclCommInitRank with a dead id (round-3 advisor finding).  A rank that fails before or
-// inside init leaves the others in ncclCommInitRank: like any RCCL job, run the launch under a launcher-side timeout.
+// starts before rank 0's unlink into ncclCommInitRank with a dead id (round-3 advisor finding).
+// Round 6: the bootstrap has an IN-PROCESS deadline (--comm-timeout, default 300 s for the whole init).  The communicator is created NON-BLOCKING
+// (ncclCommInitRankConfig, config.blocking = 0) and its state polled with ncclCommGetAsyncError: a peer that never starts, or dies inside the
+// bootstrap, leaves this rank in ncclInProgress -- at the deadline the communicator is aborted (ncclCommAbort) and init() fails, so the process exits
+// non-zero by itself instead of hanging until a launcher-side timeout (nothing is re-exec'ed: a process that touched the GPU only ever exits).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -61,8 +65,37 @@ struct RcclComm {
             }
         }
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-        if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) return fail("ncclCommInitRank failed");
+        // non-blocking bootstrap under what is left of the deadline
+        const auto deadline2 = std::chrono::steady_clock::now() + std::chrono::duration<double>(std::max(1.0, timeout_s - std::chrono::duration<double>(std::chrono::system_clock::now() - t_start).count()));
+        ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
+        config.blocking = 0;
+        ncclResult_t rc = ncclCommInitRankConfig(&comm, world, id, rank, &config);
+        if (rc != ncclSuccess && rc != ncclInProgress) { comm = nullptr; return fail(std::string("ncclCommInitRankConfig failed: ") + ncclGetErrorString(rc)); }
+        for (;;) {
+            ncclResult_t state = ncclSuccess;
+            if (ncclCommGetAsyncError(comm, &state) != ncclSuccess) state = ncclInternalError;
+            if (state == ncclSuccess) break;
+            if (state != ncclInProgress) { (void)ncclCommAbort(comm); comm = nullptr; return fail(std::string("RCCL bootstrap failed: ") + ncclGetErrorString(state)); }
+            if (std::chrono::steady_clock::now() > deadline2) {
+                (void)ncclCommAbort(comm); comm = nullptr;
+                return fail("RCCL bootstrap did not complete within the deadline (a rank of this launch never started, or died): communicator aborted");
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
         return true;
+    }
+    // a collective enqueued on a non-blocking communicator may return ncclInProgress: wait for it to be accepted (same deadline rule as the bootstrap)
+    bool settle(ncclResult_t rc, double timeout_s = 300.0) {
+        if (rc == ncclSuccess) return true;
+        if (rc != ncclInProgress) return false;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+        for (;;) {
+            ncclResult_t state = ncclSuccess;
+            if (ncclCommGetAsyncError(comm, &state) != ncclSuccess) return false;
+            if (state == ncclSuccess) return true;
+            if (state != ncclInProgress || std::chrono::steady_clock::now() > deadline) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
     void destroy(const std::string &id_file) {
         if (comm) (void)ncclCommDestroy(comm);
@@ -83,7 +116,7 @@ struct RcclComm {
             c->d_cap = n;
         }
         if (hipMemcpyAsync(c->d_buf, buf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return 2;
-        if (ncclAllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return 3;
+        if (!c->settle(ncclAllReduce(c->d_buf, c->d_buf, n, ncclDouble, ncclSum, c->comm, c->stream))) return 3;
         if (hipMemcpyAsync(buf, c->d_buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 4;
         return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 5;
     }
@@ -95,12 +128,13 @@ struct RcclComm {
         char *r = static_cast<char *>(recv);
         if (ncclGroupStart() != ncclSuccess) return 1;
         int bad = 0;
+        auto ok = [](ncclResult_t rc) { return rc == ncclSuccess || rc == ncclInProgress; };   // (inside a group of a non-blocking communicator the calls only queue)
         for (int peer = 0; peer < c->world && !bad; ++peer) {
             const uint64_t ns = send_off[peer + 1] - send_off[peer], nr = recv_off[peer + 1] - recv_off[peer];
-            if (ns && ncclSend(s + send_off[peer], ns, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) bad = 2;
-            if (!bad && nr && ncclRecv(r + recv_off[peer], nr, ncclUint8, peer, c->comm, c->stream) != ncclSuccess) bad = 3;
+            if (ns && !ok(ncclSend(s + send_off[peer], ns, ncclUint8, peer, c->comm, c->stream))) bad = 2;
+            if (!bad && nr && !ok(ncclRecv(r + recv_off[peer], nr, ncclUint8, peer, c->comm, c->stream))) bad = 3;
         }
-        if (ncclGroupEnd() != ncclSuccess && !bad) bad = 4;   // the group is closed on every path
+        if (!c->settle(ncclGroupEnd()) && !bad) bad = 4;   // the group is closed on every path
         if (bad) return bad;
         return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 5;
     }

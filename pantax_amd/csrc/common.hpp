@@ -472,6 +472,7 @@ struct Reads {
     bool species_valid = false;      // d_species (file order) reflects the last binning pass; species_ensure() gathers it from the slots
     bool binned = false;
     bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip; the file seam until its graphs travel): no locus-grouped copy, no coverage pass
+    std::vector<uint32_t> h_item_block;   // node block (first node id >> item_blk_shift) of every work item of the short-read coverage kernel, ascending (host)
     uint32_t max_node_id = 0;        // largest node id of the walks (the device tokenizer notes it: what a later reads_group() sizes its buckets by)
 };
 

@@ -1120,6 +1120,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
         for (uint32_t b = NBLK; b-- > 0;) { if (fg[b] == 0xFFFFFFFFu) fg[b] = fg[b + 1]; else if (fg[b] > fg[b + 1]) monotone = false; }
         fg[0] = 0;                                                  // groups in front of the first live one (pads) belong to the first block
         std::vector<uint2> items;
+        rd->h_item_block.clear();
         const uint32_t cap = ctx->cfg.cov_item_groups > 0 ? (uint32_t)ctx->cfg.cov_item_groups : COV_ITEM_GROUPS;
         if (monotone)
             for (uint32_t b = 0; b < NBLK; ++b)
@@ -1127,7 +1128,7 @@ int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
                 const uint32_t n = fg[b + 1] - fg[b];
                 if (!n) continue;
                 const uint32_t k = (n + cap - 1) / cap, per = (n + k - 1) / k;
-                for (uint32_t g = fg[b]; g < fg[b + 1]; g += per) items.push_back(make_uint2(g, std::min(fg[b + 1], g + per)));
+                for (uint32_t g = fg[b]; g < fg[b + 1]; g += per) { items.push_back(make_uint2(g, std::min(fg[b + 1], g + per))); rd->h_item_block.push_back(b); }
             }
         else   // cannot happen with the counting sort above; never silent: plain cuts of the stream
             for (uint32_t g = 0; g < n_groups; g += COV_ITEM_GROUPS) items.push_back(make_uint2(g, std::min(n_groups, g + COV_ITEM_GROUPS)));
@@ -1255,12 +1256,25 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             // the reads at a block's end fall off the window)
             int fshape = rd->T_pad >= (1ull << 28) ? 2823 : 2423;
             if (ctx->cfg.covf_shape > 0) fshape = ctx->cfg.covf_shape;
-#define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
+            // Only the items whose node block meets the db's id range hold reads of its species (round 6: the file seam runs a selection group by group over
+            // the same resident reads -- a read that starts outside the range is "U" for this db, and streaming its steps only to find that out cost a group
+            // of a quarter of the species 6.5 ms where the whole selection as one db took 8).  Every read of an item starts inside the item's block.
+            uint32_t item0 = 0, item1 = rd->n_items;
+            if (rd->h_item_block.size() == rd->n_items && rd->item_blk_shift > 0 && db->S && !db->h_range_start.empty()) {
+                int64_t lo = db->h_range_start[0], hi = db->h_range_end[0];
+                for (uint32_t s2 = 1; s2 < db->S; ++s2) { lo = std::min(lo, db->h_range_start[s2]); hi = std::max(hi, db->h_range_end[s2]); }
+                const uint32_t b_lo = (uint32_t)std::max<int64_t>(lo, 0) >> rd->item_blk_shift, b_hi = (uint32_t)std::min<int64_t>(std::max<int64_t>(hi, 0), 0xFFFFFFFFll) >> rd->item_blk_shift;
+                item0 = (uint32_t)(std::lower_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_lo) - rd->h_item_block.begin());
+                item1 = (uint32_t)(std::upper_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_hi) - rd->h_item_block.begin());
+                // (groups in front of the first live one belong to block 0's first item: pads only)
+            }
+#define COVF_ARGS rd->d_g_items.p + item0, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
                   db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
             {                                                                                                                            \
-                const int grid = (int)rd->n_items;                                                                                       \
-                if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
+                const int grid = (int)(item1 - item0);                                                                                   \
+                if (grid <= 0) {}                                                                                                        \
+                else if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
                 else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
             }
             switch (fshape) {                                              // <U><PASSES><window / 1024>

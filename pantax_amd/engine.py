@@ -78,7 +78,7 @@ class Engine:
     # ------------------------------------------------------------------ uploads
     def upload_db(self, species):
         """species: list of objects with node_len, path_off, path_nodes, range_start, range_end
-        (pantax_amd.synth.SpeciesGraph or pantax_amd.io graphs), haplotypes in byte order."""
+        (synthdata.SpeciesGraph or pantax_amd.io graphs), haplotypes in byte order."""
         if self.db:
             self.lib.pantax_hip_db_free(self.ctx, self.db)
             self.db = None
@@ -174,7 +174,7 @@ class Engine:
         self.reads = rd
 
     def upload_packed(self, reads, flags=None):
-        """reads: pantax_amd.synth.PackedReads (int64 host arrays)"""
+        """reads: synthdata.PackedReads (int64 host arrays)"""
         mapq = np.where((reads.mapq < 0) | (reads.mapq > 254), 255, reads.mapq)
         self.upload_reads(reads.step_off, reads.node_id, reads.pstart, reads.pend, reads.qlen, mapq, flags)
 

@@ -87,7 +87,7 @@ def select_reads(reads, sel):
 
 def slice_reads(reads, a, b):
     """Reads [a, b) of a PackedReads as a PackedReads of their own (step offsets rebased, arrays are views)."""
-    from pantax_amd.synth import PackedReads
+    from synthdata import PackedReads
     so = reads.step_off
     t0, t1 = int(so[a]), int(so[b])
     return PackedReads(so[a:b + 1] - so[a], reads.node_id[t0:t1], reads.strand[t0:t1], reads.pstart[a:b], reads.pend[a:b], reads.qlen[a:b],
@@ -278,7 +278,7 @@ def check_against_literal(j, names, abc, hap, ln, tb, bases, cov, n_abort):
 def load_literal_strain_case(k):
     """tests/golden/literal_strain_<k>.json (oracle/gen_golden_literal_strain.py: literal Python reading of the species /
     strain level, LP by SciPy-HiGHS) -> (json, SyntheticSet built from it)."""
-    from pantax_amd import synth
+    import synthdata as synth
     with open(os.path.join(ROOT, "tests", "golden", "literal_strain_%d.json" % k)) as f:
         j = json.load(f)
     species = []

@@ -104,7 +104,7 @@ def _tables_normalised(eng, sset):
 
 @pytest.fixture(scope="module")
 def cfg3_set():
-    from pantax_amd import synth
+    import synthdata as synth
     return synth.make_set_mp(20260504, 100, 10, 10_000_000, 5_000_000)
 
 
@@ -130,7 +130,7 @@ def test_cfg3_file_seam_every_species_against_oracle(eng, cfg3_set, tmp_path_fac
     """BASELINE configs[2] through the DROP-IN seam (pantax_hip_profile == profile::profile, profile.rs:3325: files in, files out;
     rows a6 + a16 + (b) + f2 at size): 100 `.bin` graphs + 1.4 GB of GAF text on disk -> the two tables, compared with the oracle's
     tables for every species; cold from the bincode files (images written on the way), then from the device-ready images -- same bytes."""
-    from pantax_amd import synth
+    import synthdata as synth
     from tests.test_gpu_pipeline import _check_outputs
     sset = cfg3_set
     root = tmp_path_factory.mktemp("cfg3_seam")
@@ -160,7 +160,7 @@ def test_cfg3_file_seam_every_species_against_oracle(eng, cfg3_set, tmp_path_fac
 
 
 def test_cfg4_share_full_size_properties_and_oracle_sample(eng):
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set_mp(20260505, 125, 10, 12_500_000, 5_000_000)
     rd = sset.reads
     out = _run_stages(eng, sset)
@@ -191,7 +191,7 @@ def test_cfg4_share_full_size_properties_and_oracle_sample(eng):
 
 
 def test_cfg5_share_full_size_long_reads_properties_and_oracle_sample(eng):
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set_mp(20260506, 125, 50, 125_000, 5_000_000, long_reads=True)
     rd = sset.reads
     assert (np.diff(rd.step_off.astype(np.int64)) > 64).mean() > 0.9          # walks longer than a wave: the long-read path
@@ -240,7 +240,7 @@ def test_cfg4_full_size_one_gpu_properties_and_oracle_sample(eng):
     cuts = np.linspace(0, rd.n_reads, 33).astype(np.int64)
 
     def part(i):
-        from pantax_amd import synth
+        import synthdata as synth
         a, b = int(cuts[i]), int(cuts[i + 1])
         return expected_total_bases(synth.SyntheticSet(sset.species, slice_reads(rd, a, b)), sp[a:b])
     with ThreadPoolExecutor(8) as ex:
@@ -299,7 +299,7 @@ def test_cfg5_full_size_one_gpu_as_four_dbs(eng):
     ns = native_set(spec, threads=THREADS)
     rd = ns.reads()
     species = ns.graphs()
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.SyntheticSet(species, rd)
     S = len(species)
     assert (S, rd.n_reads) == (1000, 1_000_000) and int(ns.P.sum()) > 2 ** 32

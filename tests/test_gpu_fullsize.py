@@ -20,7 +20,7 @@ def eng():
 
 @pytest.fixture(scope="module")
 def cfg2():
-    from pantax_amd import synth
+    import synthdata as synth
     return synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000)
 
 
@@ -158,7 +158,7 @@ def test_cfg2_lp_local_optimality(eng, cfg2):
 def test_multispecies_order_invariance_and_linearity(eng):
     """20 species / 1M reads: the integer outputs do not depend on read order (atomics, locus grouping) and
     are additive over a split of the read set; the bitmap count is monotone and sub-additive."""
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set(77, 20, 8, 1_000_000, 400_000, single_strain_every=7)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -208,7 +208,7 @@ def test_step_normalisation(eng, cfg2):
 def test_single_call_step_equals_stage_by_stage(eng, seed, S, H, R, L, filtered):
     """pantax_hip_profile_step (device-side species decision, one host wait) == the same stages called one
     by one with the species decision taken on the host: identical tables, bit for bit."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.pipeline import StepConfig, profile_step
     sset = synth.make_set(seed, S, H, R, L)
     eng.upload_db(sset.species)
@@ -231,7 +231,7 @@ def test_single_call_step_equals_stage_by_stage(eng, seed, S, H, R, L, filtered)
 def test_stream_of_steps_with_tables_built_behind_the_next_step(eng, monkeypatch):
     """profile_steps_pipelined (what bench.py times): the tables of step i are built on a helper thread while step i+1's
     kernels run; with a different input per step the results equal one profile_step call per input, in order."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.pipeline import StepConfig, profile_step, profile_steps_pipelined
     sset = synth.make_set(77, 5, 4, 60000, 80000)
     rd = sset.reads
@@ -260,7 +260,7 @@ def test_many_species_radix_path_against_oracle(eng):
     eight workgroups solve their LPs side by side.  Every species against the oracle: bit-exact integers, equal
     objectives and metrics."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(4242, 8, 10, 800_000, 1_250_000)
     rd = sset.reads
@@ -305,7 +305,7 @@ def test_step_enqueue_collect_halves(eng):
     """pantax_hip_profile_step_enqueue / _collect: step i+1 enqueued before step i is collected gives, step for step, what the
     one-call form gives; a third enqueue without a collect, a collect without an enqueue and a one-call step while something is
     in flight are refused."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd._ffi import PantaxHipError
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(78, 4, 5, 50000, 90000)

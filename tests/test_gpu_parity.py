@@ -108,7 +108,7 @@ def test_micro_coverage_golden(eng):
                                                   (2, 3, 6, 20000, 40000, "block"), (3, 5, 10, 50000, 30000, "block"), (4, 2, 40, 20000, 20000, "block")])
 def test_binning_and_coverage_vs_oracle(eng, seed, S, H, R, L, uniq, set_opt):
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     # default: uniqueness through the visit table (species with a node of more than 64 visits: by node block in LDS); forced: every
     # species by node block, or the global bucket path with either of its kernels
     if uniq == "block":
@@ -152,7 +152,7 @@ def test_coverage_kernels_agree_on_short_reads(eng, general, long_kernel, shape,
     """Short reads take coverage_fast_kernel (one wave per 64-step group); cov_general=1 sends the same groups through
     the kernel that otherwise only sees the groups of longer walks -- round 6's select-only instantiation in several shapes, or round 5's
     coverage_step_kernel (cov_long=step).  All must equal the oracle bit for bit."""
-    from pantax_amd import synth
+    import synthdata as synth
     if general:
         set_opt(eng, "cov_general", general)
     if long_kernel:
@@ -259,7 +259,7 @@ def test_trio_index_with_huge_buckets(eng, uniq, set_opt):
 
 def test_species_active_mask_and_flags(eng):
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set(9, 3, 4, 6000, 15000)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -282,7 +282,7 @@ def test_species_active_mask_and_flags(eng):
 @pytest.mark.parametrize("long_kernel", [None, "step"])
 def test_long_reads_and_empty_inputs(eng, long_kernel, set_opt):
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     if long_kernel:
         set_opt(eng, "cov_long", long_kernel)
     sset = synth.make_set(5, 2, 5, 300, 60000, long_reads=True)
@@ -309,7 +309,7 @@ def test_long_walks_with_revisits(eng, long_kernel, shape, set_opt):
     have already visited, the first node included, with arbitrary start/end offsets: first-occurrence rule
     (profile.rs:879-882), `seen` across waves (:857-859) and the trio windows at wave borders, bit for bit."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     if long_kernel:
         set_opt(eng, "cov_long", long_kernel)
     if shape:
@@ -368,7 +368,7 @@ def test_long_walks_with_revisits(eng, long_kernel, shape, set_opt):
 def test_short_and_long_reads_in_one_sample(eng, long_kernel, shape, set_opt):
     """A sample that mixes 150-bp reads with HiFi-shaped ones (both strands, adversarial records): the groups that hold a step of a longer walk
     go to the long-walk kernel, the others to the short-read one, and a group may hold walks of both kinds.  Bit for bit against the oracle."""
-    from pantax_amd import synth
+    import synthdata as synth
     if long_kernel:
         set_opt(eng, "cov_long", long_kernel)
     if shape:
@@ -616,7 +616,7 @@ def test_species_with_more_than_64_candidates(eng, n_walks):
     more than 256 haplotypes, the path without a cap (the reference has none, profile.rs:1333-1342): mask words, basis inverse and
     column state sized at run time, same checks.  The species next to it is unaffected either way."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     nh = 2 * n_walks
     sset = synth.make_set(70, 2, 4, 20000, 20000, present_frac=0.6)
@@ -742,7 +742,7 @@ def test_path_cov_ratio_beyond_f32_integer_range(eng):
 def test_strain_profiling_vs_oracle(eng, seed, S, H, R, L, pf, opts):
     """optimize_otu + abundace_constraint (profile.rs:2884-3070) for every species, against the oracle."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
     rd = sset.reads
@@ -799,7 +799,7 @@ def test_hap_trio_statistics_by_key_whatever_the_row_order(eng, seed, S, H, R, L
     pass over the walks (option trio_rows=path) -- number them differently, so the sums run in different fixed orders: the metrics agree to
     rounding, the decisions exactly; the same route twice gives the same bits (every sum has a fixed order)."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(seed, S, H, R, L, present_frac=pf)
     rd = sset.reads
@@ -849,7 +849,7 @@ def test_row_pipelines_agree(eng, seed, S, H, R, L, pf, opts, set_opt):
     paths, PANTAX_MASK=walk) give the same metrics, iteration counts, row and pattern counts bit for bit, and the same objectives (to 1e-12: the sort straight
     from the nodes sums them over the sorted rows)."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set(seed, S, H, R, L, present_frac=pf, single_strain_every=3 if S >= 3 else 0)
     rd = sset.reads
     eng.upload_db(sset.species)
@@ -876,7 +876,7 @@ def test_species_of_a_million_nodes_keeps_the_batched_row_sort(eng, set_opt):
     """No limit on a species' size in the many-species row sort (round 4: a graph of more than 600 000 nodes used to send the whole
     batch through the radix sort): two species of 1.75e6 nodes each -- buckets of more than a thousand rows, the second wave kernel and the LDS
     network in use -- give the same step output, objectives, row and pattern counts as the radix pipeline."""
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.NativeSet(20260777, 2, 4, 600_000, 28_000_000, present_frac=0.75, threads=8).make()
     assert min(len(g.node_len) for g in sset.species) > 600_000
     eng.upload_db(sset.species)
@@ -896,7 +896,7 @@ def test_trio_tables_fetched_after_a_step_are_the_stage_call_tables(eng):
     """A step's rebuild of the unique-trio index leaves out the row-order export copies (key, owner haplotype); trio_get
     after a step rebuilds with them: same tables as the stage call gave before the step, the coverage results of the step
     stay valid, and the next step is unaffected."""
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set(61, 3, 5, 20000, 30000, present_frac=0.6)
     eng.upload_db(sset.species)
     eng.upload_packed(sset.reads)
@@ -919,7 +919,7 @@ def test_rebuild_in_one_pass_files_the_rows_of_the_first_build(eng, seed, S, H, 
     the visit table; every later build (a step's rebuild, db_reset + trio_index) decides and files in ONE kernel by those offsets
     (trio_file_kernel).  Same tables, same step, with and without the window starts (export copies), on a db of one route and of both; the
     option trio_two_pass sends every build down the first build's road."""
-    from pantax_amd import synth
+    import synthdata as synth
     kw = dict(single_strain_every=every) if every else {}
     sset = synth.make_set(seed, S, H, 40000, 12000, present_frac=0.5, **kw)
     eng.upload_db(sset.species)
@@ -953,7 +953,7 @@ def test_step_on_a_mixed_database(eng, seed, S, H, every, set_opt):
     the whole db.  Both give the same per-haplotype metrics, and those of the step with the rows forced through the walks (PANTAX_TRIO_ROWS=path);
     the integers of the stage calls are checked against the oracle."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from tests.helpers import select_reads
     sset = synth.make_set(seed, S, H, 60000, 12000, present_frac=0.3, single_strain_every=every)
     assert any(g.n_paths == 1 for g in sset.species) and any(np.bincount(g.path_nodes).max() > 64 for g in sset.species)   # both kinds
@@ -991,7 +991,7 @@ def test_a_thousand_species_in_one_step(eng, S):
     workgroups, segmented row sort) is exercised with S in the thousands.  Species decisions and counters bit-exact, the step's
     strain metrics against the oracle for a sample of species."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(4000 + S, S, 2, 150000, 3000, single_strain_every=4, present_frac=0.7)
     rd = sset.reads
@@ -1038,7 +1038,7 @@ def test_strain_profiling_with_row_sampling(eng, sample_nodes):
     rows only; the others are untouched.  Checked against the oracle's own restatement of the sampler and, for the rule
     itself, against the unsampled run."""
     from oracle import oracle as orc
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import metrics_to_dicts
     sset = synth.make_set(77, 3, 6, 60000, 40000, present_frac=0.5)
     rd = sset.reads

@@ -58,7 +58,7 @@ def _oracle_tables(sset, fr=0.3, fc=0.46, sr=0.85, sd=0.2, min_ab=1e-4, strain_d
 
 @pytest.fixture(scope="module")
 def world(tmp_path_factory):
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import Engine
     sset = synth.make_set(31, 4, 5, 30000, 30000, present_frac=0.4, single_strain_every=4, with_ids=False)
     root = tmp_path_factory.mktemp("pantax")
@@ -191,7 +191,7 @@ def test_profile_seam_duplicate_read_ids(world):
     one species keeps them all, an id seen in two species loses them all at the strain level, and the species table
     still counts every row (profile.rs:361-463)."""
     import copy
-    from pantax_amd import synth
+    import synthdata as synth
     sset, root, db, gaf, eng = world
     rd = copy.copy(sset.reads)
     R = rd.n_reads
@@ -302,7 +302,7 @@ def test_resident_gaf_load_equals_the_gaf_reader_oracle(eng, tmp_path, piece, se
     """pantax_hip_reads_load_gaf: the resident reads are the reads of the text -- the host columns, the species per read and the
     coverage integers of the packed upload of what oracle/gaf_reader.py (a reading of load_gaf_file_lazy, rcls.rs:119-146, that is not
     this library's tokenizer) makes of the same text.  The text carries every quirk of the format between its generated lines."""
-    from pantax_amd import synth
+    import synthdata as synth
     from tests.helpers import gaf_quirks_text
     if piece is not None:
         set_opt(eng, "gaf_piece_bytes", piece)     # several pieces, joined on the device
@@ -340,7 +340,8 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, set_op
     """pantax_hip_gaf_load_device (GAF text tokenised by HIP kernels) gives the arrays of the host tokenizer bit for
     bit: a generated GAF plus every quirk of the format contract (comments, '*' nulls, CRLF, ragged and empty lines,
     no trailing newline, overflowing numbers, 13+ fields, digits inside non-numeric fields)."""
-    from pantax_amd import io as pio, synth
+    from pantax_amd import io as pio
+    import synthdata as synth
     # texts of 4 GiB and more are tokenised in pieces cut at line ends and joined on the device; a small piece size
     # sends these small files through that path (97 bytes: nearly every line of the quirks file is its own piece)
     if piece is not None:
@@ -393,7 +394,8 @@ def test_resident_reads_from_gaf_equal_uploaded_reads(eng, tmp_path, set_opt):
     """pantax_hip_reads_load_gaf (file -> device tokenizer -> resident reads, walks never on the host) gives the same
     binning, counters, coverage histogram and trio bases as uploading the host-tokenised arrays; drop flags can be
     replaced in place."""
-    from pantax_amd import io as pio, synth
+    from pantax_amd import io as pio
+    import synthdata as synth
     set_opt(eng, "gaf_piece_bytes", "1000000")   # the resident form through the piece-wise tokenizer as well
     sset = synth.make_set(78, 3, 4, 30000, 80000)
     p1 = tmp_path / "gen.gaf"
@@ -457,6 +459,27 @@ def test_cli_binary_matches_library_call(world):
     assert r.returncode != 0
     r = subprocess.run([exe, "-db", str(db), "-T", str(root), "--gaf", str(root / "nope.gaf"), "--species"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "valid file path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_rank_whose_peer_never_starts_gives_up_at_its_deadline(world):
+    """--ranks 2 --rank 0 with nobody behind rank 1: the RCCL bootstrap is non-blocking and polled (cli/rccl_comm.hpp), so rank 0 aborts the
+    communicator at --comm-timeout and exits non-zero by itself -- no launcher-side timeout needed, nothing hangs."""
+    import subprocess
+    import time
+    sset, root, db, gaf, eng = world
+    exe = os.path.join(ROOT, "pantax_amd", "lib", "pantax-hip")
+    wd = root / "wd_lonely_rank"
+    wd.mkdir()
+    t0 = time.time()
+    r = subprocess.run([exe, "-db", str(db), "-T", str(wd), "--gaf", str(gaf), "--species", "--strain", "--short-read", "--sample", "0",
+                        "--ranks", "2", "--rank", "0", "--device", "0", "--comm-timeout", "6", "--comm-nonce", "4242"],
+                       cwd=str(wd), capture_output=True, text=True, timeout=180)
+    dt = time.time() - t0
+    assert r.returncode != 0, r.stderr
+    assert "deadline" in r.stderr or "bootstrap" in r.stderr, r.stderr
+    assert dt < 120, dt
+    assert not os.path.exists(wd / "strain_abundance.txt")
 
 
 @pytest.mark.gpu
@@ -745,7 +768,7 @@ def test_profile_seam_vs_literal_python_restatement(tmp_path, k):
     reading of the reference, LP by SciPy-HiGHS: the DB and the GAF are written from the fixture (`*` where it holds a null),
     the two tables must hold the literal reading's rows.  Case 3 has duplicate read ids (kept inside one species, dropped
     across two) and null read_start rows (counted in the species table, dropped at the strain level): profile.rs:361-463."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import Engine
     from tests.helpers import load_literal_strain_case, write_literal_gaf
     j, sset = load_literal_strain_case(k)
@@ -782,7 +805,7 @@ def test_trio_index_prefetch_serves_the_next_step_only(eng):
     """pantax_hip_trio_index_prefetch: the index build of the coming run started ahead of it (before the reads are uploaded) -- the
     step that follows gives the tables of a plain step bit for bit and consumes the prefetch; the step after it rebuilds again;
     a prefetch followed by a db reset is not used."""
-    from pantax_amd import synth
+    import synthdata as synth
     sset = synth.make_set(41, 4, 8, 60000, 30000, present_frac=0.5)
     avg = sset.avg_len()
     eng.upload_db(sset.species)

@@ -42,7 +42,7 @@ def _expected_message(cols, sp, flags, owner, d):
 @pytest.mark.parametrize("seed,S,H,R,L,W,long_reads", [(11, 5, 4, 30000, 20000, 2, False), (12, 7, 3, 50001, 15000, 3, False),
                                                       (13, 3, 4, 900, 60000, 4, True), (14, 6, 3, 20000, 15000, 8, False)])
 def test_route_messages_and_owner_coverage_equal_one_process(eng, seed, S, H, R, L, W, long_reads):
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.pipeline import partition_species
     sset = synth.make_set(seed, S, H, R, L, long_reads=long_reads)
     rd = sset.reads
@@ -103,7 +103,7 @@ def test_route_messages_and_owner_coverage_equal_one_process(eng, seed, S, H, R,
 
 def test_route_edge_cases(eng):
     """no reads at all, a slice whose reads all stay behind, an owner that receives nothing, and the argument checks"""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd._ffi import PantaxHipError
     sset = synth.make_set(21, 2, 3, 500, 8000)
     eng.upload_db(sset.species)
@@ -144,7 +144,7 @@ def test_route_reads_through_rccl_on_device_buffers(tmp_path):
 import os, sys, numpy as np
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import TorchComm, route_reads
 torch.cuda.set_device(0)

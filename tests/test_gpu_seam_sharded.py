@@ -130,7 +130,7 @@ def test_sharded_ingest_duplicate_ids_across_slices(world):
     """An id whose alignments sit in DIFFERENT ranks' byte ranges: same species -> all kept, two species -> all dropped at the
     strain level (profile.rs:361-463), exactly as the one-process run decides."""
     import copy
-    from pantax_amd import synth
+    import synthdata as synth
     sset, root, db, gaf, eng0 = world
     rd = copy.copy(sset.reads)
     R = rd.n_reads
@@ -189,7 +189,7 @@ def test_sharded_ingest_with_slices_cut_into_pieces_and_long_walks(tmp_path_fact
     """Every rank's byte range is itself tokenised in several pieces (PANTAX_GAF_PIECE_BYTES: the 4-GiB logic at small scale,
     read from the file at the slice's offset) and the reads are long (walks of hundreds of steps, routed by the workgroup-wide
     copy): tables == the one-process run of the same files, report byte-identical."""
-    from pantax_amd import synth
+    import synthdata as synth
     from pantax_amd.engine import Engine
     sset = synth.make_set(55, 3, 4, 600, 60000, long_reads=True, present_frac=0.6, with_ids=False)
     root = tmp_path_factory.mktemp("pantax_long")

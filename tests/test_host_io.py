@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from pantax_amd import io as pio
-from pantax_amd import synth
+import synthdata as synth
 
 
 @pytest.fixture(scope="module")

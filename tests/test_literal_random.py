@@ -81,7 +81,7 @@ def test_strain_level_literal_reading_equals_c_oracle_on_random_cases(block):
     import gen_golden_literal_strain as ggs
     from oracle import oracle as orc
     from tests.helpers import check_metrics_against_literal, select_reads
-    from pantax_amd import synth
+    import synthdata as synth
     per = N_STRAIN_CASES // 6
     n_species_full = n_species_face = n_highs_differs = n_highs = 0
     for i in range(block * per, (block + 1) * per):

@@ -3,7 +3,7 @@
 around the oracle that bench.py's cpu_baseline uses (oracle/oracle_parallel.c)."""
 import numpy as np
 
-from pantax_amd import synth
+import synthdata as synth
 
 
 def _set(threads=4):

@@ -137,7 +137,7 @@ def test_lad_degenerate_and_edge_cases():
 def test_optimize_species_synthetic():
     """optimize_otu (profile.rs:2884-3026) on a small synthetic species: present strains are
     recovered, absent strains get no predicted coverage."""
-    from pantax_amd import synth
+    import synthdata as synth
     from tests.helpers import select_reads
     rng = np.random.default_rng(11)
     g = synth.make_species(rng, "1000", 6, 40000, 1, "GCF_000001", present_frac=0.5)

@@ -5,7 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 Ss = [int(x) for x in sys.argv[2:]] or [100, 400, 1000]

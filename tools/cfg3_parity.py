@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as orc
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 from tests.helpers import select_reads
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 100

@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 sset = synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000)

@@ -4,7 +4,8 @@ import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from pantax_amd import synth, io as pio
+from pantax_amd import io as pio
+import synthdata as synth
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 long_reads = len(sys.argv) > 2 and sys.argv[2] == "long"   # HiFi-shaped lines (~700 node ids each)

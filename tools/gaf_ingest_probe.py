@@ -5,7 +5,7 @@ import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

@@ -6,7 +6,7 @@ import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import native_set, workload_spec
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 ns = native_set(workload_spec(wl))

@@ -5,7 +5,7 @@ import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 sset = synth.make_set(99, 4, 40, 2_000_000, 2_000_000, present_frac=0.9)
 eng = Engine(0); eng.upload_db(sset.species); eng.upload_packed(sset.reads)

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 if os.environ.get("PANTAX_DEBUG_TORCH"):
     import torch
     torch.cuda.set_device(0); torch.cuda.synchronize()
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import StepConfig, profile_steps_pipelined, profile_step
 S, R, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -4,7 +4,7 @@ cfg2 workload, second call (allocations warm), graphs from .bin."""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1

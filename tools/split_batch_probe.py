@@ -5,7 +5,7 @@ import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000

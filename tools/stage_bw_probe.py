@@ -4,7 +4,7 @@ PANTAX_STAGE_* settings to size the staging.  usage: stage_bw_probe.py [reads]""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 p = sys.argv[2] if len(sys.argv) > 2 else os.path.join(tempfile.gettempdir(), "stage_probe_%d.gaf" % n)

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import StepConfig
 sset = synth.make_set(20260503, 1, 10, 1_000_000, 5_000_000)

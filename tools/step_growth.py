@@ -3,7 +3,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 S, R, L = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 40

@@ -4,7 +4,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from pantax_amd import synth, pipeline
+from pantax_amd import pipeline
+import synthdata as synth
 from pantax_amd.engine import Engine
 from pantax_amd.pipeline import StepConfig, LocalComm
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as orc
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine, metrics_to_dicts
 from tests.helpers import select_reads
 

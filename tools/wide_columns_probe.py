@@ -5,7 +5,7 @@ the objectives of the first species with the oracle.  usage: wide_columns_probe.
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from pantax_amd import synth
+import synthdata as synth
 from pantax_amd.engine import Engine
 from tests.helpers import select_reads
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
