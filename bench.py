@@ -55,6 +55,9 @@ WORKLOADS = {   # name: (BASELINE.json config, seed offset, species, haps, reads
     # configs[4] at its size on ONE GPU: 1 000 species x 50 strains = 1.1e10 path steps, more than one resident db addresses -> the species are
     # cut into several dbs that share the GPU (run_many_dbs)
     "cfg5": ("configs[4]: 1k species / 50k strains, 1M HiFi-shaped reads", 7, 1000, 50, 1_000_000, 5_000_000),
+    # round 6: the shape of the database PanTax ships -- 8 778 species with the strains-per-species histogram of the reference's genomes_info.txt
+    # (7 465 single-genome species as 1024-bp chunk graphs, build_eq1.rs:26-36; the rest 2 .. 10 strains), 5e7 short reads (synthdata.RefDbSet)
+    "refdb": ("reference-DB shape: 8778 species / 13404 strains (7465 single-strain chunk graphs), 50M short reads", 7, 8778, 10, 50_000_000, 5_000_000),
 }
 LONG_READ_WORKLOADS = ("cfg5_share", "cfg5")
 DEFAULT_WORKLOAD = "cfg4"
@@ -68,6 +71,9 @@ def workload_spec(name, species=None, haps=None, reads=None, genome_len=None):
     H = haps if haps is not None else base[3]
     R = reads if reads is not None else base[4]
     L = genome_len if genome_len is not None else base[5]
+    if name == "refdb":     # --species N scales every count of the histogram (tests, quick runs); --reads as given
+        return dict(name="refdb", label=base[0], seed=20260501 + base[1], species=S, haps=H, reads=R, genome_len=L, long_reads=False, refdb=True,
+                    scale=S / float(base[2]))
     custom = (S, H, R, L) != tuple(base[2:6])
     return dict(name="custom" if custom else name, label="custom" if custom else base[0], seed=20260501 + base[1], species=S, haps=H, reads=R, genome_len=L,
                 long_reads=name in LONG_READ_WORKLOADS)
@@ -75,6 +81,8 @@ def workload_spec(name, species=None, haps=None, reads=None, genome_len=None):
 
 def native_set(spec, threads=None, seed_shift=0):
     import synthdata as synth
+    if spec["name"] == "refdb" or spec.get("refdb"):
+        return synth.RefDbSet(spec["seed"] + seed_shift, spec["reads"], spec["genome_len"], scale=spec.get("scale", 1.0), threads=threads)
     return synth.NativeSet(spec["seed"] + seed_shift, spec["species"], spec["haps"], spec["reads"], spec["genome_len"], long_reads=spec.get("long_reads", False),
                            threads=threads)
 
@@ -133,8 +141,9 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         "trio_fill_kernel": 4 * P + 16 * win,
         "trio_count_kernel": 4 * P + 4 * V,
         "trio_uniq_kernel": 16 * win,
-        # a9: per-haplotype statistics by key, three passes over {trio_bases 8, length 4, owner 2} of every row
-        "hap_rows_pass_kernel": 3 * 14 * U,
+        # a9: per-haplotype statistics by key.  Pass 0 reads the abundance of EVERY row (8U) and compacts the non-zero ones; length, owner and the two later
+        # passes touch those only -- how many is not known to the harness, so the ruler is the compulsory 8U (rounds 4-5 counted 3 x 14 U: three full passes)
+        "hap_rows_pass_kernel": 8 * U,
         # a10: the membership masks by node (8V node -> haplotypes in, 8V masks out) / by walk (4P in + 8V out)
         "mask_nodes_kernel": 24 * V,      # ... + 8V of counts and lengths since the path_cov_ratio sums ride on this pass (round 4; 16V before)
         "mask_kernel": 4 * P + 8 * V,
@@ -462,7 +471,7 @@ def gaf_tmp_dir(need_bytes):
     return None
 
 
-def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9, sp=None, rc=None):
+def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9, sp=None, rc=None, extra_pick=()):
     """north_star: strain abundances within L1 1e-4 of the solver-backed PAO.  For a sample of species (the one with the most and the
     fewest reads + evenly spaced ones) the CHECKER (oracle/: trio index, coverage, both exact LAD solves, constraint -- whose LP
     optimum equals SciPy-HiGHS on the golden fixtures) runs on the species' reads of THIS workload at full size, and the strain rows of
@@ -479,7 +488,9 @@ def abundance_l1_leg(eng, ns, species, rd, out, cfg, threads, n_sample=9, sp=Non
         sp, rc, *_ = eng.rcls_profile()
     cnt = np.asarray(rc)
     pick = sorted({int(np.argmax(cnt)), int(np.argmin(np.where(cnt > 0, cnt, cnt.max() + 1)))} | {int(i) for i in np.linspace(0, S - 1, max(n_sample - 2, 1)).astype(int)})
-    pick = [s for s in pick if any(r[0] == species[s].name for r in species_rows)]      # species the step kept
+    pick = sorted(set(pick) | {int(x) for x in extra_pick})
+    kept_names = {r[0] for r in species_rows}
+    pick = [s for s in pick if species[s].name in kept_names]      # species the step kept
     cov_of = {r[0]: r[2] for r in species_rows}
     by_sp = {}
     for r in strain_rows:
@@ -579,7 +590,8 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
                 dt = time.perf_counter() - t
         finally:
             os.chdir(cwd)
-        res.setdefault("trace", {})[name] = cap.text[-6000:]
+        # (the per-piece lines of the tokenizer and the per-pipeline lines of the graph loader are dropped: a hundred of them per run)
+        res.setdefault("trace", {})[name] = "\n".join(l for l in cap.text.splitlines() if "[gaf_tokenize]   piece" not in l and "[upload_segments]" not in l)[-9000:]
         return wd, dt, _seam_phases(cap.text)
     try:
         runs = {}
@@ -881,6 +893,10 @@ def main():
 
     # ---- CPU legs: a child process, started before anything initialises the GPU here (rank 0, N = 1 only).  The parent waits
     # for the oracle leg -- it uses every core -- and then goes on beside the child's single-threaded HiGHS legs.
+    if spec.get("refdb"):
+        args.no_cpu_baseline = True      # the CPU baseline belongs to the headline workload (cfg4); 8 778 oracle species would not fit the bounded sample
+        args.no_seam = True              # (the file seam is exercised at cfg4; a DB directory of 8 778 species is a test of the file system)
+        args.no_hard = True
     leg = CpuLeg(args, rank, world)
     t_cpu_wait = time.perf_counter()
     leg.wait_stage(("oracle_done", "done", "failed"), timeout=900)
@@ -926,6 +942,11 @@ def main():
         c_lo, c_hi = 0, synth.N_CHUNKS
         ns.names = ["%d" % (100000 * rank + 1000 + i) for i in range(n_species)]
         total_reads = n_reads * world
+    if spec.get("refdb"):
+        if world != 1:
+            print("bench.py: --workload refdb runs on one GPU", file=sys.stderr)
+            sys.exit(2)
+        n_species, n_haps = ns.S, "1..10"
     rd = ns.reads(c_lo, c_hi)                       # generates (and caches) all graphs: the walks of every present strain are needed
     gen_s = time.perf_counter() - t_gen
     wkey = workload_key(spec)
@@ -1076,7 +1097,14 @@ def main():
     l1 = None
     if rank == 0 and not args.no_l1:
         try:
-            if world == 1:
+            if world == 1 and spec.get("refdb"):
+                # the reference-DB shape: the sample must hold single-strain species (H = 1: the chunk graphs, no LP beyond one column), the species
+                # with the most strains / nodes and the one with the most reads
+                kept = {r[0] for r in out[0]}
+                singles = [s for s in range(len(species)) if species[s].n_paths == 1 and species[s].name in kept][:3]
+                big = int(np.argmax([g.n_nodes for g in species]))
+                l1 = abundance_l1_leg(eng, ns, species, rd, out, cfg, host_threads, n_sample=12, extra_pick=singles + [big, len(species) - 1])
+            elif world == 1:
                 l1 = abundance_l1_leg(eng, ns, species, rd, out, cfg, host_threads)
             else:
                 # N > 1: rank 0 holds the tables of ALL ranks' species; it generates the whole set once more on the host (the ranks kept only
@@ -1283,13 +1311,13 @@ def main():
             "value": value, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
-            "config": {"workload": "%s: %d species x %d strains, %d %s, genome %d bp, seed %d, generator %s"
+            "config": {"workload": "%s: %d species x %s strains, %d %s, genome %d bp, seed %d, generator %s"
                                    % (spec["name"], n_species, n_haps, n_reads, "long reads N(15000, 3000^2) bp" if spec.get("long_reads") else "short reads (150 bp)",
                                       genome_len, spec["seed"], GENERATOR),
                        "gsteps_per_s": T_res * world / (dt / args.steps) / 1e9,
                        "baseline_config": spec["label"][:60], "set": "per GPU" if args.scaling == "weak" else "one set cut over the ranks",
                        "V": dims["V"], "P": dims["P"], "T": dims["T"], "U": n_unique, "species_per_gpu": S_loc,
-                       "strains_total": n_species * n_haps * (world if args.scaling == "weak" else 1), "reads_total": total_reads,
+                       "strains_total": (int(ns.n_haps.sum()) if spec.get("refdb") else n_species * n_haps * (world if args.scaling == "weak" else 1)), "reads_total": total_reads,
                        "parallelism": "species-shard x%d" % world, "rccl_ranks": ranks_seen if backend == "nccl" else None, "ranks_seen": ranks_seen,
                        "exchange": "none" if world == 1 else ("one rccl all_reduce per step" if backend == "nccl" else backend + " all_reduce (dry run)"),
                        "pao_wall_s": ms_per_step / 1e3,

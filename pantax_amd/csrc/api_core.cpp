@@ -356,8 +356,15 @@ void pantax_hip_db_free(pantax_hip_ctx *ctx, pantax_hip_db *db) {
     std::unique_lock<std::recursive_mutex> lk;
     if (ctx) lk = std::unique_lock<std::recursive_mutex>(ctx->mu);
     // the side stream may still be building this db's trio index (a step that failed after the fork)
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2); }
-    delete db;
+    bool idle = false;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        idle = hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (ctx->stream2) idle = hipStreamSynchronize(ctx->stream2) == hipSuccess && idle;
+    }
+    // a db is used by its ctx's two streams only (its arrays arrived on the loader's stream, which the loader waited for): behind the two waits its blocks are idle
+    if (idle) { DevCacheIdleFrees scope; delete db; }
+    else delete db;
 }
 
 int pantax_hip_reads_upload(pantax_hip_ctx *ctx, const pantax_hip_packed_reads *r, pantax_hip_reads **out) {

@@ -703,15 +703,20 @@ static int profile_impl(pantax_hip_ctx *ctx, const pantax_hip_profiling_config *
         const uint64_t steps_target = std::min<uint64_t>(steps_max, (steps_total + n_groups - 1) / n_groups);
         struct Group { uint32_t k0, k1; std::vector<GraphPart> gparts; };
         std::vector<Group> groups;
+        uint64_t cum = 0;                                  // path steps of the groups cut so far
         for (uint32_t k0 = 0; k0 < Su;) {
             uint32_t k1 = k0;
             uint64_t steps = 0, nodes = 0;
+            // the group ends where the running total comes closest to its share of the whole ((g + 1) / n of the steps): even groups, and the last of the n
+            // takes whatever is left -- no small one behind it (the hard limits still cut: 32-bit path steps and node indices of one db)
+            const uint64_t boundary = groups.size() + 1 >= n_groups ? ~0ull : (uint64_t)((double)steps_total * (double)(groups.size() + 1) / (double)n_groups);
+            (void)steps_target;
             while (k1 < Su) {
                 const uint64_t ps = parts[k1].path_off[parts[k1].n_haps] - parts[k1].path_off[0];
-                // (half a species over the target still joins this group: the groups come out even, without a small one at the end)
-                if (k1 > k0 && (steps + ps > steps_max || steps + ps / 2 > steps_target || nodes + parts[k1].n_nodes > 0xF0000000ull)) break;
+                if (k1 > k0 && (steps + ps > steps_max || nodes + parts[k1].n_nodes > 0xF0000000ull || (boundary != ~0ull && cum + steps + ps / 2 > boundary))) break;
                 steps += ps; nodes += parts[k1].n_nodes; ++k1;
             }
+            cum += steps;
             // the file indices of a group's segments are relative to the group's file list
             Group g{k0, k1, std::vector<GraphPart>(parts.begin() + k0, parts.begin() + k1)};
             if (k0)

@@ -57,6 +57,8 @@ void dev_cache_set_max(long long bytes);   // < 0: per-device default
 hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out);
 void dev_cache_free(void *p, size_t cap, int dev);   // dev: the device the block was allocated on (the caller's current device may differ)
 void dev_cache_trim();   // really free everything cached for the current device (pantax_hip_destroy)
+void dev_cache_register_stream(int dev, hipStream_t st, bool add);   // a ctx's compute streams: what a released block may still be in use on
+struct DevCacheIdleFrees { DevCacheIdleFrees(); ~DevCacheIdleFrees(); };   // scope: blocks released by this thread are idle already (see ctx.cpp)
 
 template <class T>
 struct DevBuf {
@@ -411,6 +413,10 @@ struct Db {
     unsigned long long *d_abort = nullptr;
     DevBuf<unsigned long long> d_bases;      // [V]
     DevBuf<uint32_t> d_bitmap;               // [ceil(L/32)+1]
+    uint64_t item_sel_layout = 0;            // ... made for the reads layout of this id (Reads::layout_id); n entries; on = the kernel takes the list (off: every item)
+    uint32_t item_sel_n = 0;
+    bool item_sel_on = false;
+    DevBuf<uint32_t> d_item_sel;             // the work items of the short-read coverage kernel that meet the id ranges of this db's species (a db of SOME of the species)
     DevBuf<uint32_t> d_full;                 // 1 bit per node: some step covered the node whole (its bits are then not marked one by one)
     DevBuf<uint32_t> d_cov;                  // [V]
     DevBuf<unsigned long long> d_trio_bases; // [U]
@@ -472,6 +478,7 @@ struct Reads {
     bool species_valid = false;      // d_species (file order) reflects the last binning pass; species_ensure() gathers it from the slots
     bool binned = false;
     bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip; the file seam until its graphs travel): no locus-grouped copy, no coverage pass
+    uint64_t layout_id = 0;          // a new number for every locus-grouped copy built (build_step_read)
     std::vector<uint32_t> h_item_block;   // node block (first node id >> item_blk_shift) of every work item of the short-read coverage kernel, ascending (host)
     uint32_t max_node_id = 0;        // largest node id of the walks (the device tokenizer notes it: what a later reads_group() sizes its buckets by)
 };

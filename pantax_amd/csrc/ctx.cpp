@@ -222,6 +222,8 @@ int pantax_hip_init(pantax_hip_ctx **out, const int *device_ids, int n_devices) 
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipStreamCreate failed");
     }
+    dev_cache_register_stream(dev, ctx->stream, true);
+    dev_cache_register_stream(dev, ctx->stream2, true);
     if (ctx->d_scalars.alloc(64) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PANTAX_HIP_E_HIP, "hipMalloc failed");
@@ -242,10 +244,11 @@ void pantax_hip_destroy(pantax_hip_ctx *ctx) {
     ctx->pin_up.release();
     for (auto &half : ctx->pin_up_ev) for (hipEvent_t &e : half) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     ctx->pin_text.release();
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); dev_cache_register_stream(ctx->device, ctx->stream2, false); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->stream_up) { (void)hipStreamSynchronize(ctx->stream_up); (void)hipStreamDestroy(ctx->stream_up); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_seq) (void)hipEventDestroy(ctx->ev_seq);
+    dev_cache_register_stream(ctx->device, ctx->stream, false);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     dev_cache_trim();   // nothing of this process stays cached on the device once a ctx is gone
@@ -310,6 +313,7 @@ struct DevCache {
         std::multimap<size_t, Block> free_blocks;   // by capacity
         size_t cached_bytes = 0;
         uint64_t free_epoch = 0, synced_epoch = 0;  // a block released at epoch e may be reused once synced_epoch >= e
+        std::vector<hipStream_t> streams;           // the compute streams of the ctx's on this device: what "the device is idle" means for a cached block
     };
     std::mutex mu;
     std::map<int, PerDevice> dev;
@@ -366,9 +370,14 @@ hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out
             d.cached_bytes -= cap;
             const bool need_sync = b.epoch > d.synced_epoch;
             const uint64_t now = d.free_epoch;
+            const std::vector<hipStream_t> streams = d.streams;
             lk.unlock();
             if (need_sync) {   // kernels enqueued before the block was released may still be using it
-                (void)hipDeviceSynchronize();
+                // every kernel of this library runs on a ctx's main or side stream (copy streams -- the GAF upload's, the graph loader's -- are waited
+                // for by their owners before they release anything): those are waited for, not the whole device -- a device-wide wait also sits
+                // out the graph loader's transfers of the NEXT group of species (round 6)
+                if (streams.empty()) (void)hipDeviceSynchronize();
+                else for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
                 std::lock_guard<std::mutex> g(c.mu);
                 DevCache::PerDevice &d2 = c.dev[dev];
                 if (now > d2.synced_epoch) d2.synced_epoch = now;
@@ -387,6 +396,13 @@ hipError_t dev_cache_alloc(void **p, size_t bytes, size_t *cap_out, int *dev_out
     return e;
 }
 
+// blocks released inside such a scope are known to be idle (the caller has waited for every stream that could have used them): they may be handed out
+// again without the device-wide wait -- which would also wait for whatever ELSE is in flight, e.g. the graph loader's copy stream (round 6: that wait
+// cost every group of the file seam ~4 ms per stage that allocated)
+static thread_local int g_frees_are_idle = 0;
+DevCacheIdleFrees::DevCacheIdleFrees() { ++g_frees_are_idle; }
+DevCacheIdleFrees::~DevCacheIdleFrees() { --g_frees_are_idle; }
+
 void dev_cache_free(void *p, size_t cap, int dev) {
     if (!p) return;
     DevCache &c = dev_cache();
@@ -395,12 +411,20 @@ void dev_cache_free(void *p, size_t cap, int dev) {
         DevCache::PerDevice &d = c.dev[dev];
         // (the memory query costs microseconds: only blocks of 64 MB and more pay it)
         if (cap && d.cached_bytes + cap <= dev_cache_max(dev) && !(cap >= (size_t(64) << 20) && dev_memory_is_tight())) {
-            d.free_blocks.emplace(cap, DevCache::Block{p, ++d.free_epoch});
+            d.free_blocks.emplace(cap, DevCache::Block{p, g_frees_are_idle ? 0 : ++d.free_epoch});
             d.cached_bytes += cap;
             return;
         }
     }
     (void)hipFree(p);
+}
+
+void dev_cache_register_stream(int dev, hipStream_t st, bool add) {
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    auto &v = c.dev[dev].streams;
+    v.erase(std::remove(v.begin(), v.end(), st), v.end());
+    if (add) v.push_back(st);
 }
 
 void dev_cache_trim() {

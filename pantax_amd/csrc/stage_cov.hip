@@ -35,6 +35,9 @@
 // Layout: node arrays of all resident species are concatenated; a node's coverage bitmap starts
 // at bit bit_off[v] of one global bit vector (1 bit per graph base instead of the reference's
 // 1 byte, profile.rs:776-781).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include "common.hpp"
 #include "primitives.hpp"
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     uint32_t *__restrict__ bitmap, uint32_t *__restrict__ full, const uint2 *__restrict__ trio_ent, unsigned long long *__restrict__ trio_bases,
     unsigned long long *__restrict__ n_abort, uint32_t ablate, int blk_shift,
     const uint32_t *__restrict__ long_sum = nullptr, const uint32_t *__restrict__ long_len0 = nullptr, uint32_t only_long = 0u,
-    uint32_t chunk_groups = 0u, uint32_t total_groups = 0u, uint32_t win_back = 0u) {
+    uint32_t chunk_groups = 0u, uint32_t total_groups = 0u, uint32_t win_back = 0u, const uint32_t *__restrict__ item_sel = nullptr) {
     constexpr int WAVES = COV_BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // this workgroup's groups [g0, n_groups): an item of the read layout -- or, LONG, a plain cut of the stream: a long walk begins anywhere in a group,
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     // in front of the first live step's node (a reverse-strand walk runs DOWN from its first node, the key the stream is ordered by)
     uint32_t g0, n_groups;
     if constexpr (LONG) { g0 = blockIdx.x * chunk_groups; n_groups = min(g0 + chunk_groups, total_groups); }
-    else { const uint2 item = items[blockIdx.x]; g0 = item.x; n_groups = item.y; }
+    else { const uint2 item = items[item_sel ? item_sel[blockIdx.x] : blockIdx.x]; g0 = item.x; n_groups = item.y; }   // (item_sel: the items a db of SOME of the species launches)
     for (int i = threadIdx.x; i < (int)(cov_lds_bytes(WIN) / 4); i += COV_BLOCK) s_cov[i] = 0;      // the three windows, one block
     // window base: the node of the first step of the first group that has a live one (workgroup-uniform scalar loads)
     uint32_t wlo = 0, win_n = 0, mark_n = 0, bit0_lo = 0, bwn = 0;
@@ -1034,6 +1037,8 @@ __global__ void __launch_bounds__(256) group_block_kernel(uint32_t n_groups, con
 }
 
 int build_step_read(Ctx *ctx, Reads *rd, uint32_t max_node_id) {
+    static std::atomic<uint64_t> next_layout{1};
+    rd->layout_id = next_layout.fetch_add(1);       // (what a db's list of work items is made for)
     rd->T_pad = 0;
     rd->n_long = 0;
     rd->n_slots = 0;
@@ -1230,7 +1235,17 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
 
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count) {
     if (!rd->grouped) return fail(ctx, PANTAX_HIP_E_STATE, "node_coverage: these reads are a slice kept as plain columns (to be routed to their owner), not resident reads");
+    const bool trace = ctx->cfg.trace && !defer_count;     // (the stage call of the file seam: where its milliseconds go)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[node_coverage]        %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (!db->cov_prepared) PTX_TRY(coverage_prepare(ctx, db, rd, with_trio));
+    lap("arena + zero fill");
     db->cov_prepared = false;
     db->trio_free_valid = false;   // a reader of the unique-trio tables goes onto the stream: the event of an earlier strain step no longer covers them
     unsigned long long *d_abort = db->d_abort;
@@ -1256,23 +1271,42 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
             // the reads at a block's end fall off the window)
             int fshape = rd->T_pad >= (1ull << 28) ? 2823 : 2423;
             if (ctx->cfg.covf_shape > 0) fshape = ctx->cfg.covf_shape;
-            // Only the items whose node block meets the db's id range hold reads of its species (round 6: the file seam runs a selection group by group over
-            // the same resident reads -- a read that starts outside the range is "U" for this db, and streaming its steps only to find that out cost a group
-            // of a quarter of the species 6.5 ms where the whole selection as one db took 8).  Every read of an item starts inside the item's block.
-            uint32_t item0 = 0, item1 = rd->n_items;
-            if (rd->h_item_block.size() == rd->n_items && rd->item_blk_shift > 0 && db->S && !db->h_range_start.empty()) {
-                int64_t lo = db->h_range_start[0], hi = db->h_range_end[0];
-                for (uint32_t s2 = 1; s2 < db->S; ++s2) { lo = std::min(lo, db->h_range_start[s2]); hi = std::max(hi, db->h_range_end[s2]); }
-                const uint32_t b_lo = (uint32_t)std::max<int64_t>(lo, 0) >> rd->item_blk_shift, b_hi = (uint32_t)std::min<int64_t>(std::max<int64_t>(hi, 0), 0xFFFFFFFFll) >> rd->item_blk_shift;
-                item0 = (uint32_t)(std::lower_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_lo) - rd->h_item_block.begin());
-                item1 = (uint32_t)(std::upper_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_hi) - rd->h_item_block.begin());
-                // (groups in front of the first live one belong to block 0's first item: pads only)
+            // Only the items whose node block meets the id range of one of the db's species hold reads of its species (round 6: the file seam runs a selection
+            // group by group over the same resident reads -- a read that starts outside every range is "U" for this db, and streaming its steps only to
+            // find that out cost a group of a quarter of the species 6 ms where the whole selection as one db took 8).  Every read of an item starts inside
+            // the item's block.  The groups of the seam are contiguous in the order of the species TABLE (by abundance), not of the ids: the items are
+            // picked species by species into a list (a few hundred KB), not as one range.
+            uint32_t n_sel = rd->n_items;
+            const uint32_t *d_sel = nullptr;
+            if (db->item_sel_layout == rd->layout_id && rd->layout_id != 0) {        // the list made for these reads' layout by an earlier pass of this db
+                n_sel = db->item_sel_n;
+                d_sel = db->item_sel_on ? db->d_item_sel.p : nullptr;
+            } else if (rd->h_item_block.size() == rd->n_items && rd->item_blk_shift > 0 && db->S && !db->h_range_start.empty()) {
+                std::vector<std::pair<uint32_t, uint32_t>> rg;       // item ranges of the species, then merged
+                for (uint32_t s2 = 0; s2 < db->S; ++s2) {
+                    const uint32_t b_lo = (uint32_t)std::max<int64_t>(db->h_range_start[s2], 0) >> rd->item_blk_shift;
+                    const uint32_t b_hi = (uint32_t)std::min<int64_t>(std::max<int64_t>(db->h_range_end[s2], 0), 0xFFFFFFFFll) >> rd->item_blk_shift;
+                    const uint32_t i_lo = (uint32_t)(std::lower_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_lo) - rd->h_item_block.begin());
+                    const uint32_t i_hi = (uint32_t)(std::upper_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_hi) - rd->h_item_block.begin());
+                    if (i_hi > i_lo) rg.emplace_back(i_lo, i_hi);
+                }
+                std::sort(rg.begin(), rg.end());
+                std::vector<uint32_t> sel;
+                uint32_t done = 0;
+                for (const auto &r : rg) for (uint32_t i = std::max(r.first, done); i < r.second; ++i) { sel.push_back(i); done = i + 1; }
+                if (sel.size() + sel.size() / 8 < rd->n_items) {     // (worth the indirection)
+                    n_sel = (uint32_t)sel.size();
+                    if (n_sel) { PTX_TRY(upload(ctx, db->d_item_sel, sel.data(), sel.size())); d_sel = db->d_item_sel.p; }
+                }
+                db->item_sel_layout = rd->layout_id; db->item_sel_n = n_sel; db->item_sel_on = d_sel != nullptr || n_sel == 0;
             }
-#define COVF_ARGS rd->d_g_items.p + item0, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
-                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift
+            if (trace) std::fprintf(stderr, "[node_coverage]        %u of %u items launched\n", n_sel, rd->n_items);
+#define COVF_ARGS rd->d_g_items.p, rd->d_g_group_slot.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, rd->d_g_step_dup.p, d_act_fast, db->d_node_rec.p, \
+                  db->d_bit_off.p, db->V, db->d_bases.p, db->d_bitmap.p, db->d_full.p, db->d_trio_ent.p, db->d_trio_bases.p, d_abort, ablate, rd->item_blk_shift, \
+                  (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, 0u, 0u, d_sel
 #define COVF_LAUNCH(UU, PP, WW)                                                                                                             \
             {                                                                                                                            \
-                const int grid = (int)(item1 - item0);                                                                                   \
+                const int grid = (int)n_sel;                                                                                             \
                 if (grid <= 0) {}                                                                                                        \
                 else if (trio) hipLaunchKernelGGL((coverage_fast_kernel<true, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS); \
                 else hipLaunchKernelGGL((coverage_fast_kernel<false, UU, PP, WW>), dim3(grid), dim3(COV_BLOCK), cov_lds_bytes(WW), ctx->stream, COVF_ARGS);  \
@@ -1361,6 +1395,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
         }
     }
     PTX_HIP(ctx, hipGetLastError());
+    lap("coverage kernels");
     db->cov_count_pending = defer_count && db->V != 0;   // the resident step: node_stats_launch counts the covered bases in its own pass
     if (db->V && !defer_count) {
         KTimer t(ctx, "popcount_kernel");
@@ -1368,6 +1403,7 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
                            db->d_bit_off.p, db->d_full.p, db->d_bitmap.p, db->d_cov.p);
     }
     PTX_HIP(ctx, hipGetLastError());
+    lap("popcount");
     db->cov_done = true;
     return 0;
 }

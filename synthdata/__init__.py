@@ -715,3 +715,159 @@ def write_gaf(reads, path, tags="NM:i:0\tAS:i:150\tdv:f:0\tid:f:1", native=True)
             f.write("%s\t%d\t0\t%d\t+\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%s\n" % (
                 rid, ql, ql, walk, int(reads.plen[r]), int(reads.pstart[r]), int(reads.pend[r]), ql, ql,
                 int(reads.mapq[r]), tags))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# A workload shaped like the database PanTax ships: the reference's genomes_info.txt lists 13 404 genomes of
+# 8 778 species -- 7 465 of them with ONE genome, whose "pangenome" is the genome cut into 1024-bp chunks (build_eq1.rs:26-36,
+# constants.rs:3), the others with 2 .. 10.  Only the HISTOGRAM of genomes per species is taken from that file (numbers, no content).
+# The set is composed of blocks of species with the same number of strains, one after the other in node-id order: the singletons (chunk
+# graphs, reads drawn here) and one NativeSet per strain count 2 .. 10 (its node ids shifted behind the blocks before it).
+# ---------------------------------------------------------------------------------------------------------------------------------------
+REFDB_STRAINS_PER_SPECIES = {1: 7465, 2: 514, 3: 219, 4: 118, 5: 73, 6: 57, 7: 51, 8: 30, 9: 32, 10: 219}
+
+
+class RefDbSet:
+    """ns = RefDbSet(seed, n_reads); ns.make() -> SyntheticSet.  `scale` shrinks every species count (tests): scale=0.01 -> 88 species.
+    Interface of NativeSet where bench.py / the tests use it: S, names, range_start, range_end, V, P, graphs(), reads(), avg_len(), make()."""
+
+    def __init__(self, seed, n_reads, genome_len=5_000_000, scale=1.0, present_frac=0.2, threads=None, read_len=150, adversarial_frac=0.001):
+        import os
+        self.seed, self.n_reads, self.genome_len, self.read_len = int(seed), int(n_reads), int(genome_len), int(read_len)
+        self.threads = threads or min(os.cpu_count() or 1, 64)
+        rng = np.random.default_rng(self.seed)
+        counts = {h: max(1, int(round(c * scale))) for h, c in REFDB_STRAINS_PER_SPECIES.items()}
+        self.counts = counts
+        # ---- block of singletons: genome length jittered +-10 %, a fifth of the species present with a log-normal depth
+        n1 = counts[1]
+        self.single_glen = (genome_len * (0.9 + 0.2 * rng.random(n1))).astype(np.int64)
+        self.single_depth = np.where(rng.random(n1) < present_frac, rng.lognormal(np.log(8.0), 1.0, n1), 0.0)
+        if not self.single_depth.any():
+            self.single_depth[0] = 8.0
+        self.single_V = np.maximum(3, -(-self.single_glen // 1024)).astype(np.int64)          # as _species_graph of make_set: at least three chunks
+        # ---- one NativeSet per strain count (dimensions only until graphs() / reads())
+        self.blocks = []                                                                       # (h, NativeSet)
+        for h in range(2, 11):
+            self.blocks.append((h, NativeSet(self.seed + 100 * h, counts[h], h, 1, genome_len, present_frac=present_frac, read_len=read_len,
+                                             adversarial_frac=adversarial_frac, threads=self.threads)))
+        # read shares: depth x genome length of the present strains
+        w = [float((self.single_depth * self.single_glen).sum())] + [float((b.depth * b.glen).sum()) for _, b in self.blocks]
+        share = np.array(w) / sum(w)
+        nr = np.floor(share * self.n_reads).astype(np.int64)
+        nr[0] += self.n_reads - int(nr.sum())
+        self.block_reads = nr
+        for (h, b), n in zip(self.blocks, nr[1:]):
+            b.n_reads = int(n)
+        # ---- global numbering: the singletons first, then the blocks
+        Vs = [self.single_V] + [b.V.astype(np.int64) for _, b in self.blocks]
+        self.V = np.concatenate(Vs).astype(np.uint64)
+        self.P = np.concatenate([self.single_V] + [b.P.astype(np.int64) for _, b in self.blocks]).astype(np.uint64)
+        self.S = len(self.V)
+        self.range_start = np.ones(self.S, dtype=np.int64)
+        self.range_start[1:] = 1 + np.cumsum(self.V[:-1].astype(np.int64))
+        self.range_end = self.range_start + self.V.astype(np.int64) - 1
+        self.block_first_species = np.concatenate([[0], np.cumsum([len(v) for v in Vs])]).astype(np.int64)
+        self.n_haps = np.concatenate([np.ones(n1, dtype=np.int64)] + [np.full(b.S, h, dtype=np.int64) for h, b in self.blocks])
+        self.names = [str(100000 + s) for s in range(self.S)]
+        self._graphs = {}
+
+    def hap_names(self, s):
+        return sorted("GCF_%07d%03d.1" % (s + 1, k) for k in range(int(self.n_haps[s])))
+
+    def avg_len(self):
+        out = [self.single_glen.astype(np.float64)] + [b.avg_len() for _, b in self.blocks]
+        return np.concatenate(out)
+
+    def _block_of(self, s):
+        k = int(np.searchsorted(self.block_first_species, s, side="right") - 1)
+        return k, s - int(self.block_first_species[k])
+
+    def _graph(self, s):
+        g = self._graphs.get(s)
+        if g is None:
+            k, j = self._block_of(s)
+            if k == 0:
+                n = int(self.single_V[j])
+                node_len = np.full(n, 1024, dtype=np.int64)
+                node_len[-1] = max(1, int(self.single_glen[j]) - 1024 * (n - 1))
+                g = SpeciesGraph(self.names[s], node_len, np.array([0, n], dtype=np.uint64), np.arange(n, dtype=np.uint32), self.hap_names(s),
+                                 int(self.range_start[s]), int(self.range_end[s]), np.array([int(node_len.sum())], dtype=np.int64),
+                                 np.array([float(self.single_depth[j])]))
+            else:
+                h, b = self.blocks[k - 1]
+                sub = b._graph(j)
+                g = SpeciesGraph(self.names[s], sub.node_len, sub.path_off, sub.path_nodes, self.hap_names(s), int(self.range_start[s]), int(self.range_end[s]),
+                                 sub.genome_len, sub.truth_depth)
+            self._graphs[s] = g
+        return g
+
+    def graphs(self, idx=None, keep=True):
+        from concurrent.futures import ThreadPoolExecutor
+        idx = list(range(self.S)) if idx is None else [int(i) for i in idx]
+        with ThreadPoolExecutor(self.threads) as ex:
+            gs = list(ex.map(self._graph, idx))
+        if not keep:
+            for i in idx:
+                self._graphs.pop(i, None)
+        return gs
+
+    def drop_graphs(self, keep_idx=()):
+        keep_idx = set(int(i) for i in keep_idx)
+        for i in list(self._graphs):
+            if i not in keep_idx:
+                del self._graphs[i]
+        for _, b in self.blocks:
+            b.drop_graphs(())
+
+    def _single_reads(self):
+        """Reads on the chunk graphs: uniform start on a present genome, read_len bases, either strand, MAPQ as SURVEY 8d."""
+        n = int(self.block_reads[0])
+        rng = np.random.default_rng(self.seed + 7)
+        w = self.single_depth * self.single_glen
+        sp = rng.choice(len(w), size=n, p=w / w.sum())
+        glen = np.array([max(1, int(self.single_glen[j]) - 1024 * (int(self.single_V[j]) - 1)) + 1024 * (int(self.single_V[j]) - 1) for j in range(len(w))], dtype=np.int64)
+        L = self.read_len
+        start = (rng.random(n) * np.maximum(glen[sp] - L, 1)).astype(np.int64)
+        n0, n1 = start // 1024, np.minimum((start + L - 1) // 1024, self.single_V[sp] - 1)
+        k = (n1 - n0 + 1).astype(np.int64)                          # one or two chunks (a read is shorter than a chunk)
+        rev = rng.random(n) < 0.5
+        base = self.range_start[sp]                                 # global id of the species' chunk 0
+        step_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(k, out=step_off[1:])
+        T = int(step_off[-1])
+        node_id = np.empty(T, dtype=np.uint32)
+        strand = np.repeat(rev.astype(np.uint8), k)
+        first = step_off[:-1].astype(np.int64)
+        a = np.where(rev, n1, n0)                                   # first step of the walk
+        node_id[first] = (base + a).astype(np.uint32)
+        two = k == 2
+        node_id[first[two] + 1] = (base[two] + np.where(rev[two], n0[two], n1[two])).astype(np.uint32)
+        last_len = (glen[sp] - 1024 * (self.single_V[sp] - 1))
+        len1 = np.where(n1 == self.single_V[sp] - 1, last_len, 1024)   # length of the read's last chunk (forward order)
+        plen = np.where(two, 1024 + len1, np.where(n0 == self.single_V[sp] - 1, last_len, 1024))
+        ps_f = start - 1024 * n0
+        ps = np.where(rev, plen - (ps_f + L), ps_f)
+        pe = ps + L
+        mapq = np.where(rng.random(n) < 0.85, 60, rng.integers(0, 60, n)).astype(np.int64)
+        qlen = np.full(n, L, dtype=np.int64)
+        return PackedReads(step_off, node_id, strand, ps.astype(np.int64), pe.astype(np.int64), qlen, mapq, qlen, [])   # (GAF column 7 = read length, as NativeSet writes it)
+
+    def reads(self, chunk_lo=0, chunk_hi=N_CHUNKS):
+        if (chunk_lo, chunk_hi) != (0, N_CHUNKS):
+            raise ValueError("RefDbSet: the whole set only (one GPU)")
+        parts = [self._single_reads()]
+        for k, (h, b) in enumerate(self.blocks):
+            if b.n_reads <= 0:
+                continue
+            r = b.reads()
+            shift = np.uint32(int(self.range_start[int(self.block_first_species[k + 1])]) - 1)      # the block's id 1 -> its first global id
+            r.node_id += shift
+            parts.append(r)
+            b.drop_graphs(())
+        offs = np.concatenate([[0]] + [p.step_off[1:].astype(np.int64) + sum(int(q.step_off[-1]) for q in parts[:i]) for i, p in enumerate(parts)]).astype(np.uint64)
+        cat = lambda f: np.concatenate([getattr(p, f) for p in parts])
+        return PackedReads(offs, cat("node_id"), cat("strand"), cat("pstart"), cat("pend"), cat("qlen"), cat("mapq"), cat("plen"), [])
+
+    def make(self):
+        rd = self.reads()
+        return SyntheticSet(self.graphs(), rd)

@@ -159,6 +159,61 @@ def test_cfg3_file_seam_every_species_against_oracle(eng, cfg3_set, tmp_path_fac
     shutil.rmtree(str(root), ignore_errors=True)
 
 
+def test_reference_db_shape_every_species_against_oracle(eng, tmp_path_factory):
+    """The shape of the database PanTax ships (synthdata.RefDbSet: the strains-per-species histogram of the reference's genomes_info.txt -- 85 % of the
+    species hold ONE genome, a chain of 1024-bp chunks, build_eq1.rs:26-36; the others 2 .. 10 strains) at a twentieth of its species count: ~440
+    species, 1.2 M reads.  H = 1 species (no trio table, the single-path branches of the filters, profile.rs:1191-1224, :1269-1278), thousands-of-nodes
+    graphs beside 3e5-node ones, many tiny LPs.  Through the FILE seam (graphs in groups, image cache on the second run) and through the resident
+    step: both tables against the oracle for every species."""
+    import synthdata as synth
+    from pantax_amd.pipeline import StepConfig, profile_step
+    from tests.test_gpu_pipeline import _check_outputs
+    ns = synth.RefDbSet(20260507, 1_200_000, scale=0.05, threads=THREADS)
+    sset = ns.make()
+    assert sum(1 for g in sset.species if g.n_paths == 1) > 300 and max(g.n_paths for g in sset.species) == 10
+    exp_species, exp_strain, _ = oracle_tables_parallel(sset, threads=THREADS)
+    singles = {g.name for g in sset.species if g.n_paths == 1}
+    assert sum(1 for r in exp_strain if r[0] in singles) >= 20 and sum(1 for r in exp_strain if r[0] not in singles) >= 10   # both kinds reach the table
+    # resident step
+    eng.upload_db(sset.species)
+    eng.upload_packed(sset.reads)
+    names = [g.name for g in sset.species]
+    haps = [h for g in sset.species for h in g.hap_names]
+    sp_rows, st_rows, _ = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    assert [r[0] for r in sp_rows] == [r[0] for r in exp_species]
+    for r, e in zip(sp_rows, exp_species):
+        assert r[1] == pytest.approx(e[1], rel=1e-12) and r[2] == pytest.approx(e[2], rel=1e-12)
+    assert sorted((r[0], r[1]) for r in st_rows) == sorted((r[0], r[1]) for r in exp_strain)
+    exp = {(r[0], r[1]): r for r in exp_strain}
+    for r in st_rows:
+        e = exp[(r[0], r[1])]
+        assert r[2] == pytest.approx(e[2], rel=1e-7) and r[3] == pytest.approx(e[3], rel=1e-7)
+    eng.release()
+    # file seam, graphs in several groups
+    root = tmp_path_factory.mktemp("refdb_seam")
+    db = root / "db"
+    db.mkdir()
+    synth.write_db(sset, str(db), write_gfa=False, threads=THREADS)
+    gaf = root / "gfa_mapped.gaf"
+    synth.write_gaf_parallel(sset.reads, str(gaf), threads=THREADS)
+    cwd = os.getcwd()
+    eng.set_option("db_groups", "3")
+    try:
+        for name, ic in (("wd_cold", 2), ("wd_warm", 1)):
+            wd = root / name
+            wd.mkdir()
+            os.chdir(str(wd))
+            try:
+                eng.profile(str(db), str(wd), str(gaf), zip="serialize", sample_nodes=0, image_cache=ic)
+            finally:
+                os.chdir(cwd)
+            _check_outputs(str(wd), sset, exp_species, exp_strain)
+    finally:
+        eng.set_option("db_groups", None)
+    import shutil
+    shutil.rmtree(str(root), ignore_errors=True)
+
+
 def test_cfg4_share_full_size_properties_and_oracle_sample(eng):
     import synthdata as synth
     sset = synth.make_set_mp(20260505, 125, 10, 12_500_000, 5_000_000)
