@@ -124,7 +124,12 @@ int main(int argc, char **argv) {
     RcclComm comm;
     if (use_rccl) {
         if (id_file.empty()) id_file = wd + "/.pantax_hip_rccl_id";
-        if (!comm.init(rank, ranks, id_file, nonce, comm_timeout)) { fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str()); pantax_hip_destroy(ctx); return 1; }
+        if (!comm.init(rank, ranks, id_file, nonce, comm_timeout)) {
+            fprintf(stderr, "pantax-hip: rank %d: %s\n", rank, comm.err.c_str());
+            if (comm.abandoned) { if (rank == 0) ::unlink(id_file.c_str()); fflush(stderr); _exit(3); }   // the bootstrap thread is still inside RCCL: no teardown may wait for it
+            pantax_hip_destroy(ctx);
+            return 1;
+        }
         c.rank = rank; c.world_size = ranks; c.comm_user = &comm;
         c.allreduce_sum = &RcclComm::allreduce_sum; c.alltoallv = &RcclComm::alltoallv; c.comm_device_buffers = 1;
     }

@@ -8,10 +8,10 @@
 // AND is not older than their own start minus two seconds -- both, always: a launcher may hand the same nonce to consecutive
 // launches (torchrun's default port never changes), and a file a killed run left behind with that nonce would send a rank that
 // starts before rank 0's unlink into ncclCommInitRank with a dead id (round-3 advisor finding).
-// Round 6: the bootstrap has an IN-PROCESS deadline (--comm-timeout, default 300 s for the whole init).  The communicator is created NON-BLOCKING
-// (ncclCommInitRankConfig, config.blocking = 0) and its state polled with ncclCommGetAsyncError: a peer that never starts, or dies inside the
-// bootstrap, leaves this rank in ncclInProgress -- at the deadline the communicator is aborted (ncclCommAbort) and init() fails, so the process exits
-// non-zero by itself instead of hanging until a launcher-side timeout (nothing is re-exec'ed: a process that touched the GPU only ever exits).
+// Round 6: the bootstrap has an IN-PROCESS deadline (--comm-timeout, default 300 s for the whole init).  ncclCommInitRank runs on a helper thread and
+// the calling thread waits for it with a deadline: a peer that never starts, or dies inside the bootstrap, no longer leaves this rank waiting
+// for a launcher-side timeout -- init() fails, and the process leaves with _exit (the helper is still inside RCCL and cannot be cancelled;
+// nothing is re-exec'ed: a process that touched the GPU only ever exits).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -19,6 +19,9 @@
 #include <unistd.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -65,25 +68,35 @@ struct RcclComm {
             }
         }
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-        // non-blocking bootstrap under what is left of the deadline
-        const auto deadline2 = std::chrono::steady_clock::now() + std::chrono::duration<double>(std::max(1.0, timeout_s - std::chrono::duration<double>(std::chrono::system_clock::now() - t_start).count()));
-        ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
-        config.blocking = 0;
-        ncclResult_t rc = ncclCommInitRankConfig(&comm, world, id, rank, &config);
-        if (rc != ncclSuccess && rc != ncclInProgress) { comm = nullptr; return fail(std::string("ncclCommInitRankConfig failed: ") + ncclGetErrorString(rc)); }
-        for (;;) {
-            ncclResult_t state = ncclSuccess;
-            if (ncclCommGetAsyncError(comm, &state) != ncclSuccess) state = ncclInternalError;
-            if (state == ncclSuccess) break;
-            if (state != ncclInProgress) { (void)ncclCommAbort(comm); comm = nullptr; return fail(std::string("RCCL bootstrap failed: ") + ncclGetErrorString(state)); }
-            if (std::chrono::steady_clock::now() > deadline2) {
-                (void)ncclCommAbort(comm); comm = nullptr;
-                return fail("RCCL bootstrap did not complete within the deadline (a rank of this launch never started, or died): communicator aborted");
+        // The bootstrap under what is left of the deadline: ncclCommInitRank on a helper thread, this thread waits on a condition variable.  (A
+        // non-blocking communicator -- config.blocking = 0 + ncclCommGetAsyncError -- was tried first: in this RCCL the call itself sits in the
+        // bootstrap's rendezvous until every rank has connected, so it never returned to be polled.)  At the deadline the helper is left behind,
+        // `abandoned` is set and the caller must leave the process with _exit: the stuck thread cannot be cancelled, and nothing may wait for it.
+        const double left_s = std::max(1.0, timeout_s - std::chrono::duration<double>(std::chrono::system_clock::now() - t_start).count());
+        struct Boot { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
+        auto boot = std::make_shared<Boot>();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::thread([boot, id, dev, w = world, r = rank] {
+            (void)hipSetDevice(dev);
+            ncclComm_t c = nullptr;
+            const ncclResult_t rc = ncclCommInitRank(&c, w, id, r);
+            std::lock_guard<std::mutex> g(boot->mu);
+            boot->rc = rc; boot->comm = c; boot->done = true;
+            boot->cv.notify_all();
+        }).detach();
+        {
+            std::unique_lock<std::mutex> lk(boot->mu);
+            if (!boot->cv.wait_for(lk, std::chrono::duration<double>(left_s), [&] { return boot->done; })) {
+                abandoned = true;
+                return fail("RCCL bootstrap did not complete within the deadline (a rank of this launch never started, or died); giving up");
             }
-            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            if (boot->rc != ncclSuccess) return fail(std::string("ncclCommInitRank failed: ") + ncclGetErrorString(boot->rc));
+            comm = boot->comm;
         }
         return true;
     }
+    bool abandoned = false;   // init() gave up at its deadline with the bootstrap thread still inside RCCL: leave the process with _exit
     // a collective enqueued on a non-blocking communicator may return ncclInProgress: wait for it to be accepted (same deadline rule as the bootstrap)
     bool settle(ncclResult_t rc, double timeout_s = 300.0) {
         if (rc == ncclSuccess) return true;

@@ -1286,7 +1286,11 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
                 for (uint32_t s2 = 0; s2 < db->S; ++s2) {
                     const uint32_t b_lo = (uint32_t)std::max<int64_t>(db->h_range_start[s2], 0) >> rd->item_blk_shift;
                     const uint32_t b_hi = (uint32_t)std::min<int64_t>(std::max<int64_t>(db->h_range_end[s2], 0), 0xFFFFFFFFll) >> rd->item_blk_shift;
-                    const uint32_t i_lo = (uint32_t)(std::lower_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_lo) - rd->h_item_block.begin());
+                    uint32_t i_lo = (uint32_t)(std::lower_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_lo) - rd->h_item_block.begin());
+                    // An item carries the block of the FIRST read of its groups; the last group of the item in front may run on into this block (a group is
+                    // 64 steps of consecutive reads, and where reads are sparse a layout unit spans several blocks): its reads of block b_lo are this
+                    // species' too.  One item back is enough -- the next group already begins with a read of b_lo and opens an item of that block.
+                    if (i_lo > 0) --i_lo;
                     const uint32_t i_hi = (uint32_t)(std::upper_bound(rd->h_item_block.begin(), rd->h_item_block.end(), b_hi) - rd->h_item_block.begin());
                     if (i_hi > i_lo) rg.emplace_back(i_lo, i_hi);
                 }

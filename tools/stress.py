@@ -24,7 +24,9 @@ for ci in range(n_cfg):
     sample = int(rng.integers(200, 5000)) if rng.random() < 0.3 else 0      # --sample: species with more valid rows are sub-sampled
     via_images = bool(rng.random() < 0.2)                                    # db saved to / loaded from device-ready images first
     lr = bool(rng.random() < 0.25); adv = float(rng.choice([0.0, 0.001, 0.02])); pf = float(rng.choice([0.2, 0.5, 0.9]))
-    tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g sample=%d images=%d" % (seed0 + ci, S, H, R, L, lr, adv, pf, sample, via_images)
+    sem = 1 if os.environ.get("STRESS_HIGHS") else 0                         # STRESS_HIGHS=1: highs_opt's handling of the second solve (profile.rs:2865-2879), a tight --fc
+    fc = 0.08 if sem else 0.46
+    tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g sample=%d images=%d highs=%d" % (seed0 + ci, S, H, R, L, lr, adv, pf, sample, via_images, sem)
     try:
         sset = synth.make_set(seed0 + ci, S, H, R if not lr else max(50, R // 40), L, long_reads=lr, adversarial_frac=adv, present_frac=pf,
                               single_strain_every=int(rng.choice([0, 2, 3])))
@@ -46,7 +48,7 @@ for ci in range(n_cfg):
         keep, absolute, abundance = eng.species_profiling((rc, bs, lm, uq), sset.avg_len())
         okeep, oabs, _ = orc.species_profile(sp, rd.qlen, (rc, bs, lm, uq), sset.avg_len())
         assert np.array_equal(keep, okeep) and np.allclose(absolute, oabs, rtol=1e-12, atol=0), "species profile"
-        met, info = eng.strain_profiling(absolute, species_active=keep, sample_nodes=sample)
+        met, info = eng.strain_profiling(absolute, species_active=keep, sample_nodes=sample, solver_semantics=sem, fc=fc)
         gm_all = metrics_to_dicts(met, eng.H)
         nb = np.cumsum([0] + [g.n_nodes for g in sset.species]); hb = np.cumsum([0] + [g.n_paths for g in sset.species])
         hto = eng.trio_nodes_info()[3].astype(np.int64)
@@ -60,7 +62,7 @@ for ci in range(n_cfg):
             assert np.array_equal(tb[hto[hb[s]]:hto[hb[s + 1]]], t), "trio bases sp %d" % s
             if not keep[s]:
                 continue
-            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, sample_nodes=sample)
+            rc_, omet, nc, o1, o2 = orc.optimize_species(G, T, b, c, t, sample_nodes=sample, solver_semantics=sem, fc=fc)
             orc.abundance_constraint(absolute[s], omet)
             assert info[s].n_candidates == nc and info[s].status1 == 0 and info[s].status2 == 0, "solver status sp %d" % s
             if nc:
@@ -108,7 +110,7 @@ for ci in range(n_cfg):
                         face2 = True
             n_ambiguous += face2
         # the single-call step gives the same decisions and metrics as the stage calls
-        k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len(), sample_nodes=sample)
+        k2, a2, met2, info2, passed2, sa2, spp2 = eng.profile_step(sset.avg_len(), sample_nodes=sample, solver_semantics=sem, fc=fc)
         assert np.array_equal(k2, keep) and np.array_equal(a2, absolute), "step species"
         g2 = metrics_to_dicts(met2, eng.H)
         for x, y in zip(g2, gm_all):
