@@ -561,23 +561,19 @@ def _read_table(path):
         return [ln.rstrip("\n").split("\t") for ln in f]
 
 
-def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
-    """The wall time the reference itself logs (profile.rs:3326-3327, :3429-3433): profile::profile, FILES to FILES, graph loading
-    included -- here pantax_hip_profile on a real DB directory of this workload (species_range.txt, species_genomes_stats.txt,
-    genomes_info.txt, one bincode `.bin` per species, zip.rs:171-190) + the GAF text.  cold: graphs from the `.bin` files (64-bit
-    values narrowed on their way into the pinned ring); warm: from the device-ready images a run with image_cache = 2 leaves behind.
-    Page cache warm in both (the files were just written).  Never `value`."""
-    import synthdata as synth
-    res = {}
-    db = os.path.join(td, "db")
-    os.mkdir(db)
-    t0 = time.perf_counter()
-    synth.write_db(synth.SyntheticSet(species, None), db, write_gfa=False, threads=threads)
-    res["db_written_in_s"] = time.perf_counter() - t0
+def seam_child(spec_path):
+    """`bench.py --seam-child <json>`: the pantax_hip_profile calls of the files -> tables leg in a process of their own -- what a `pantax-hip` run is: a
+    fresh process, nothing resident, no torch (the parent's interpreter with torch's thread pools loaded ran the same call 0.1 s slower and noisier:
+    the crew that fills the pinned ring competes for the host).  Writes its result (times, phases, traces, work directories) to <json>.out."""
+    with open(spec_path) as f:
+        a = json.load(f)
+    from pantax_amd.engine import Engine
+    db, td, gaf_path, fr = a["db"], a["td"], a["gaf"], a["fr"]
     gi = os.path.join(db, "species_graph_info")
-    res["db_bin_gb"] = sum(os.path.getsize(os.path.join(gi, f)) for f in os.listdir(gi)) / 1e9
-    cwd = os.getcwd()
+    res = {}
+    eng = Engine(int(a.get("device", 0)))
     eng.set_option("hip_trace", "1")
+    cwd = os.getcwd()
 
     def call(name, image_cache):
         wd = os.path.join(td, name)
@@ -594,7 +590,6 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
         res.setdefault("trace", {})[name] = "\n".join(l for l in cap.text.splitlines() if "[gaf_tokenize]   piece" not in l and "[upload_segments]" not in l)[-9000:]
         return wd, dt, _seam_phases(cap.text)
     try:
-        runs = {}
         call("wd_prime", 0)                                  # allocations, page cache
         wd_c, t_cold, ph_c = call("wd_cold", 0)
         _, t_img, _ = call("wd_images", 2)                   # leaves the images behind (not timed as a result)
@@ -602,10 +597,52 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
         warm = [call("wd_warm%d" % i, 1) for i in range(2)]
         wd_w, t_warm, ph_w = min(warm, key=lambda r: r[1])
         db_keys = ("graph headers", "db upload", "db upload (a group of the species)")   # (with groups: what this thread waited for the loader + the tables it built)
+        n_reads = a["n_reads"]
         res.update(files_to_tables_cold_s=t_cold, files_to_tables_warm_s=t_warm, files_to_tables_warm_s_both=[r[1] for r in warm],
                    image_writing_run_s=t_img, db_load_cold_s=sum(ph_c.get(k, 0.0) for k in db_keys) / 1e3, db_load_warm_s=sum(ph_w.get(k, 0.0) for k in db_keys) / 1e3,
                    gaf_load_s=ph_w.get("ranges + GAF tokenise", 0.0) / 1e3, strain_step_s=ph_w.get("strain step", 0.0) / 1e3,
-                   phases_ms_cold=ph_c, phases_ms_warm=ph_w, mreads_per_s_warm=n_reads / t_warm / 1e6, mreads_per_s_cold=n_reads / t_cold / 1e6)
+                   phases_ms_cold=ph_c, phases_ms_warm=ph_w, mreads_per_s_warm=n_reads / t_warm / 1e6, mreads_per_s_cold=n_reads / t_cold / 1e6,
+                   wd_cold=wd_c, wd_warm=wd_w, process="a child process of bench.py (fresh, no torch): what a pantax-hip run is")
+    except Exception as e:   # noqa: BLE001 -- reported to the parent
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        eng.close()
+    with open(spec_path + ".out", "w") as f:
+        json.dump(res, f)
+    return 0
+
+
+def file_seam_leg(local_rank, species, gaf_path, td, threads, out, n_reads, fr=0.3):
+    """The wall time the reference itself logs (profile.rs:3326-3327, :3429-3433): profile::profile, FILES to FILES, graph loading
+    included -- here pantax_hip_profile on a real DB directory of this workload (species_range.txt, species_genomes_stats.txt,
+    genomes_info.txt, one bincode `.bin` per species, zip.rs:171-190) + the GAF text.  cold: graphs from the `.bin` files (64-bit
+    values narrowed on their way into the pinned ring); warm: from the device-ready images a run with image_cache = 2 leaves behind.
+    Page cache warm in both (the files were just written).  The calls run in a CHILD process (seam_child); this process writes the DB
+    directory before and compares the tables after.  Never `value`."""
+    import subprocess
+    import synthdata as synth
+    res = {}
+    db = os.path.join(td, "db")
+    os.mkdir(db)
+    t0 = time.perf_counter()
+    synth.write_db(synth.SyntheticSet(species, None), db, write_gfa=False, threads=threads)
+    res["db_written_in_s"] = time.perf_counter() - t0
+    gi = os.path.join(db, "species_graph_info")
+    res["db_bin_gb"] = sum(os.path.getsize(os.path.join(gi, f)) for f in os.listdir(gi)) / 1e9
+    spec_path = os.path.join(td, "seam_child.json")
+    with open(spec_path, "w") as f:
+        json.dump(dict(db=db, td=td, gaf=gaf_path, fr=fr, n_reads=n_reads, device=local_rank), f)
+    env = dict(os.environ)
+    env.pop("PANTAX_HIP_TRACE", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--seam-child", spec_path], env=env, timeout=1500)
+    if r.returncode != 0 or not os.path.exists(spec_path + ".out"):
+        raise RuntimeError("the seam child exited with %d" % r.returncode)
+    with open(spec_path + ".out") as f:
+        res.update(json.load(f))
+    if res.get("error"):
+        raise RuntimeError(res["error"])
+    wd_c, wd_w = res.pop("wd_cold"), res.pop("wd_warm")
+    if True:
         # the tables of the seam against the resident step's (same species order, values to 1e-9) and cold against warm (same bytes)
         same_bytes = all(open(os.path.join(wd_c, f)).read() == open(os.path.join(wd_w, f)).read() for f in ("species_abundance.txt", "strain_abundance.txt"))
         tsp = _read_table(os.path.join(wd_w, "species_abundance.txt"))
@@ -631,8 +668,6 @@ def file_seam_leg(eng, species, gaf_path, td, threads, out, n_reads, fr=0.3):
             same_order = all(t[0] == r[0] for t, r in zip(tsp, sp_rows)) and all(t[0] == r[0] and t[2].startswith(r[1]) for t, r in zip(tst, st_rows))
             res["rows_in_the_same_order_as_resident_step"] = same_order
         res.update(cold_and_warm_tables_same_bytes=same_bytes, tables_equal_to_resident_step=eq, n_strain_rows=len(tst))
-    finally:
-        eng.set_option("hip_trace", None)
     return res
 
 
@@ -868,9 +903,12 @@ def main():
     ap.add_argument("--detail-file", default=None, help="where the verbose side record goes (default gpurun_out/bench_detail_<workload>_n<N>.json)")
     ap.add_argument("--hard-species", type=int, default=8)
     ap.add_argument("--cpu-leg-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--seam-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg_child:
         sys.exit(cpu_leg_child(args))
+    if args.seam_child:
+        sys.exit(seam_child(args.seam_child))
     # ---- `python3 bench.py --gpus N` without a launcher around it: this process -- which has touched neither torch nor the GPU --
     # starts the N ranks as a CHILD (never an exec) and relays rank 0's line and the exit code
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
@@ -1119,6 +1157,7 @@ def main():
             l1 = {"error": "%s: %s" % (type(e).__name__, e)}
     gaf_extra = None
     seam = None
+    n_unique_early = None
     if rank == 0 and world == 1 and not args.no_gaf:
         n_gaf = min(n_reads, args.gaf_reads) if args.gaf_reads else n_reads
         grd = synth.head_reads(rd, n_gaf)
@@ -1168,9 +1207,14 @@ def main():
                     pass
                 if do_seam:
                     try:
-                        eng.lib.pantax_hip_reads_free(eng.ctx, eng.reads)    # the seam loads its own reads and graphs: room in HBM
-                        eng.reads = None
-                        seam = file_seam_leg(eng, species, gp, td, host_threads, out, n_reads, fr=cfg.fr)
+                        # The files -> tables leg is what a `pantax-hip` process does: a fresh process, nothing resident.  It runs in a child (seam_child);
+                        # the resident db and reads of the legs above (~110 GB at cfg4) and the blocks this process keeps cached for them are given back
+                        # first (a ctx's destruction trims the cache).  Inside this interpreter (torch and its thread pools loaded) the same call took
+                        # 0.58-0.60 s against 0.47-0.50 in a fresh process (tools/seam_bench.py).  The step's index size is noted before.
+                        n_unique_early = int(eng.trio_nodes_info(fetch=False))
+                        eng.close()
+                        seam = file_seam_leg(local_rank, species, gp, td, host_threads, out, n_reads, fr=cfg.fr)
+                        eng = Engine(local_rank)
                     except Exception as e:   # noqa: BLE001 -- the line is printed regardless
                         seam = {"error": "%s: %s" % (type(e).__name__, e)}
                 gaf_extra = {"gaf_bytes": gaf_bytes, "reads": n_gaf, "tokenize_to_resident_ms": t_load * 1e3, "end_to_end_ms": t_e2e * 1e3,
@@ -1228,7 +1272,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total_reads / (dt / args.steps) / 1e6
         n_lp_rows = int(sum(stats["n_rows"]))
-        n_unique = int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
+        n_unique = n_unique_early if n_unique_early is not None else int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
         ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, R_res, T_res)
         dims["U"] = n_unique
         tr = lambda k, corrected=False: pmc_traffic(k, wkey, spec["name"], corrected) if world == 1 else None

@@ -148,6 +148,7 @@ struct CtxConfig {
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     bool cov_self_clean = false;     // resident step: the last readers of the coverage arena zero it instead of a zero fill in front of every coverage pass.  OFF: measured
                                      // slower (node_cov_stats_kernel 2.5 -> 6.9 ms with the stores among its loads against 1.5 ms of zero fill at 1e4 strains)
+    bool ncs_no_prefix = false;      // node statistics of long-node graphs through the per-lane word loop (round 5's kernel; tests compare, measurements)
     bool cov_arena_verify = false;   // tests: a coverage pass that skips its zero fill first checks that the arena IS zero (fails with PANTAX_HIP_E_STATE)
     // measurement shapes
     int cov_item_groups = 0;         // groups of 64 steps per work item of the short-read coverage kernel (0: 64)
@@ -397,6 +398,8 @@ struct Db {
     std::vector<uint64_t> h_hap_trio_off;
     // per-haplotype statistics by key (hap_trio_stats_launch): the rows of a species are one contiguous block, cut into chunks
     std::vector<uint32_t> h_sp_row_order; // [S] the species in filing order
+    struct NodeChunks { DevBuf<uint32_t> d_chunk_sp, d_sp_off; uint32_t n = 0; };   // node statistics: chunk -> species, first chunk of every species (chunks by size)
+    NodeChunks node_chunks[2];       // [0] node_stats_kernel, [1] node_cov_stats_kernel
     DevBuf<uint4> d_stat_chunks;     // {species, first row, end row, first partial} per chunk of rows
     DevBuf<double> d_hs_x;         // [U] a9 statistics: the non-zero rows' abundances, compacted chunk by chunk (written by pass 0 of every step)
     DevBuf<uint16_t> d_hs_h;       // [U] ... their owners

@@ -438,10 +438,13 @@ struct NodePartial { double mx, zs; unsigned long long nv, zc; };
 
 __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
                                                          const unsigned long long *__restrict__ bases, double min_depth,
-                                                         double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
+                                                         double *__restrict__ ab_out, NodePartial *__restrict__ part,
+                                                         const uint32_t *__restrict__ chunk_sp, const uint32_t *__restrict__ sp_chunk_off) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
-    const uint32_t s = blockIdx.x / nch, ch = blockIdx.x % nch;
+    // chunks by SIZE (round 6): a species takes chunks in proportion to its nodes -- with one workgroup per species (what an even split gave a db of
+    // thousands of species) the 3e5-node graphs of the multi-strain species ran beside 5e3-node chunk graphs: 12.4 ms at the reference-DB shape
+    const uint32_t s = chunk_sp[blockIdx.x], nch = sp_chunk_off[s + 1] - sp_chunk_off[s], ch = blockIdx.x - sp_chunk_off[s];
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
@@ -471,14 +474,21 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
 // the next step's coverage pass (only what is not zero is written: the lines are in the caches, a node some step covered whole has no marked bits),
 // instead of a 4-GB zero fill per step in front of it.  A word of flags / bits that a wave shares with its neighbours (the ends of its range of nodes)
 // loses this wave's bits only, atomically; a word that is all its own is stored.  (No __restrict__ on the three arrays: they are read and written here.)
-template <bool CLEAN>
+// LONGN (round 6): graphs of LONG nodes -- a single-genome species is a chain of 1024-bp chunks (build_eq1.rs:26-36), 32 bitmap words per node.  The
+// per-lane loop over a node's interior words walks 64 different cache lines per iteration (12.4 ms at the reference-DB shape).  Instead the wave reads
+// the words of its whole 64-node stretch coalesced, keeps the running count of set bits in front of every word in LDS (a DPP prefix sum per 64 words),
+// and a node's covered bases are the difference of that prefix at its two ends -- two LDS reads per node, whatever its length.
+constexpr uint32_t NCS_PWORDS = 2304;   // words of one stretch the prefix holds (64 nodes x 1152 bases); a longer stretch takes the per-lane loop
+extern __shared__ uint32_t s_ncs_prefix[];
+template <bool CLEAN, bool LONGN = false>
 __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
                                                              unsigned long long *bases, const uint64_t *__restrict__ bit_off,
                                                              uint32_t *full, uint32_t *bitmap, double min_depth,
-                                                             uint32_t *__restrict__ cov_out, double *__restrict__ ab_out, NodePartial *__restrict__ part, uint32_t nch) {
+                                                             uint32_t *__restrict__ cov_out, double *__restrict__ ab_out, NodePartial *__restrict__ part,
+                                                             const uint32_t *__restrict__ chunk_sp, const uint32_t *__restrict__ sp_chunk_off) {
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
-    const uint32_t s = blockIdx.x / nch, ch = blockIdx.x % nch;
+    const uint32_t s = chunk_sp[blockIdx.x], nch = sp_chunk_off[s + 1] - sp_chunk_off[s], ch = blockIdx.x - sp_chunk_off[s];   // (chunks by size: node_stats_kernel)
     const uint32_t b = node_base[s], e = node_base[s + 1];
     const uint32_t per = (e - b + nch - 1) / nch;
     uint32_t lo = b + ch * per, hi = lo + per;
@@ -510,12 +520,15 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
             fw[r] = in ? full[v >> 5] : 0u;
         }
         const uint64_t round_b0 = run;                           // the bits of this round's nodes: [round_b0, run) once the lengths are summed
+        uint64_t sb[NR + 1];                                     // first bit of every stretch (wave-uniform)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const uint32_t incl = wave_incl_scan_dpp(l[r]);      // (a species' bases fit 32 bits: checked at upload)
+            sb[r] = run;
             g0[r] = run + incl - l[r];
             run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
+        sb[NR] = run;
         uint32_t bw0[NR], bw1[NR];                               // first and last bitmap word of every node: independent loads, issued together
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -526,8 +539,39 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const uint32_t v = v0 + (uint32_t)r * 64u + lane;
+            bool coop = false;                                   // (wave-uniform) this stretch's counts come from the prefix in LDS
+            uint64_t wa = 0;
+            if constexpr (LONGN) {
+                const uint64_t b0 = sb[r], b1 = sb[r + 1];
+                const bool has_long = __builtin_amdgcn_ballot_w64(l[r] > 64u) != 0ull;
+                wa = b0 >> 5;
+                const uint64_t nw = b1 > b0 ? ((b1 - 1) >> 5) - wa + 1 : 0;
+                coop = has_long && nw <= (uint64_t)NCS_PWORDS;
+                if (coop) {
+                    uint32_t *pw = s_ncs_prefix + wave * NCS_PWORDS;
+                    uint32_t carry = 0;
+                    for (uint32_t k = 0; k < (uint32_t)nw; k += 64) {
+                        const uint32_t i = k + lane;
+                        const uint32_t pc = i < (uint32_t)nw ? (uint32_t)__popc(bitmap[wa + i]) : 0u;
+                        const uint32_t incl = wave_incl_scan_dpp(pc);
+                        if (i < (uint32_t)nw) pw[i] = carry + incl - pc;          // set bits in front of word i of the stretch
+                        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                }
+            }
             if (v >= whi) continue;
             uint32_t c = 0;
+            if (LONGN && coop) {
+                if (l[r]) {
+                    const uint64_t g1 = g0[r] + l[r], w0 = g0[r] >> 5, w1 = (g1 - 1) >> 5;
+                    const uint32_t below0 = (1u << (g0[r] & 31)) - 1u, m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
+                    const uint32_t *pw = s_ncs_prefix + wave * NCS_PWORDS;
+                    c = (pw[w1 - wa] + (uint32_t)__popc(bw1[r] & m1)) - (pw[w0 - wa] + (uint32_t)__popc(bw0[r] & below0));
+                }
+            } else
             if (l[r]) {
                 const uint64_t g1 = g0[r] + l[r], w0 = g0[r] >> 5, w1 = (g1 - 1) >> 5;
                 const uint32_t m0 = 0xFFFFFFFFu << (g0[r] & 31), m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
@@ -588,10 +632,10 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
 // one wave per species: lane l combines chunks l, l+64, ... in order, then a fixed-shape wave reduction
 __global__ void __launch_bounds__(64) node_stats_final_kernel(uint32_t S, const NodePartial *__restrict__ part, double *__restrict__ amax_out,
                                                               uint32_t *__restrict__ nvalid_out, double *__restrict__ nzsum_out,
-                                                              uint32_t *__restrict__ nzcnt_out, uint32_t nch) {
-    const uint32_t s = blockIdx.x;
+                                                              uint32_t *__restrict__ nzcnt_out, const uint32_t *__restrict__ sp_chunk_off) {
+    const uint32_t s = blockIdx.x, c0 = sp_chunk_off[s], nch = sp_chunk_off[s + 1] - c0;
     double mx = -INFINITY, zs = 0.0; unsigned long long nv = 0, zc = 0;
-    for (uint32_t c = threadIdx.x; c < nch; c += 64) { NodePartial p = part[(size_t)s * nch + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
+    for (uint32_t c = threadIdx.x; c < nch; c += 64) { NodePartial p = part[(size_t)c0 + c]; mx = fmax(mx, p.mx); zs += p.zs; nv += p.nv; zc += p.zc; }
     mx = wave_reduce(mx, [](double x, double y) { return fmax(x, y); });
     zs = wave_reduce(zs, [](double x, double y) { return x + y; });
     nv = wave_reduce(nv, [](unsigned long long x, unsigned long long y) { return x + y; });
@@ -607,21 +651,41 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
     PTX_HIP(ctx, lb->d_nzsum.alloc(S)); PTX_HIP(ctx, lb->d_nzcnt.alloc(S));
     PTX_HIP(ctx, lb->d_partial.alloc((size_t)S * STAT_CHUNKS * 4));
     const bool with_cov = db->cov_count_pending;                 // the resident step left the covered-base counts to this pass
+    // the chunk table of this db (made once per variant): ~8192 workgroups in all for the fused kernel (it holds fewer workgroups per CU: shorter ones, so
+    // that the last round is short), ~2048 for the plain one; every species at least one chunk and at most STAT_CHUNKS, in proportion to its nodes
+    Db *dbm = const_cast<Db *>(db);
+    Db::NodeChunks &nc = dbm->node_chunks[with_cov ? 1 : 0];
+    if (nc.n == 0 && S) {
+        const double target = std::max(1.0, (double)db->V / (with_cov ? 8192.0 : 2048.0));
+        std::vector<uint32_t> off(S + 1, 0), sp;
+        for (uint32_t s2 = 0; s2 < S; ++s2) {
+            const double vs = (double)(db->h_node_off[s2 + 1] - db->h_node_off[s2]);
+            const uint32_t k = (uint32_t)std::min<double>((double)STAT_CHUNKS, std::max(1.0, std::floor(vs / target + 0.5)));
+            off[s2 + 1] = off[s2] + k;
+            sp.insert(sp.end(), k, s2);
+        }
+        PTX_TRY(upload(ctx, nc.d_sp_off, off.data(), off.size()));
+        PTX_TRY(upload(ctx, nc.d_chunk_sp, sp.data(), sp.size()));
+        PTX_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (once per db: the staging vectors go out of scope)
+        nc.n = off[S];
+    }
     KTimer t(ctx, with_cov ? "node_cov_stats_kernel" : "node_stats_kernel");
-    const uint32_t nch = with_cov ? stat_chunks(S, 8192u) : stat_chunks(S);   // (the fused kernel holds fewer workgroups per CU: shorter ones, so that the last round is short)
     if (with_cov) {
         if (db->cov_self_clean)
-        hipLaunchKernelGGL(node_cov_stats_kernel<true>, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
-                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
+        hipLaunchKernelGGL(node_cov_stats_kernel<true>, dim3(nc.n), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
+        else if (db->V && db->L / db->V >= 48 && !ctx->cfg.ncs_no_prefix)   // long nodes on average (chunk graphs of single-genome species among them): counts from a per-stretch prefix in LDS
+        hipLaunchKernelGGL((node_cov_stats_kernel<false, true>), dim3(nc.n), dim3(256), (size_t)4 * NCS_PWORDS * sizeof(uint32_t), ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
         else
-        hipLaunchKernelGGL(node_cov_stats_kernel<false>, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
-                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
-        const_cast<Db *>(db)->cov_count_pending = false;
+        hipLaunchKernelGGL(node_cov_stats_kernel<false>, dim3(nc.n), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
+                           db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
+        dbm->cov_count_pending = false;
     } else
-    hipLaunchKernelGGL(node_stats_kernel, dim3(S * nch), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p,
-                       (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p, nch);
+    hipLaunchKernelGGL(node_stats_kernel, dim3(nc.n), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p,
+                       (double)min_depth, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
     hipLaunchKernelGGL(node_stats_final_kernel, dim3(S), dim3(64), 0, ctx->stream, S, (const NodePartial *)lb->d_partial.p,
-                       lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p, nch);
+                       lb->d_amax.p, lb->d_nvalid.p, lb->d_nzsum.p, lb->d_nzcnt.p, (const uint32_t *)nc.d_sp_off.p);
     PTX_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -180,6 +180,13 @@ def test_reference_db_shape_every_species_against_oracle(eng, tmp_path_factory):
     names = [g.name for g in sset.species]
     haps = [h for g in sset.species for h in g.hap_names]
     sp_rows, st_rows, _ = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    # (long nodes on average: the node statistics take their covered-base counts from a per-stretch prefix in LDS; round 5's per-lane word loop gives the same tables)
+    eng.set_option("ncs_no_prefix", "1")
+    try:
+        sp_rows_b, st_rows_b, _ = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    finally:
+        eng.set_option("ncs_no_prefix", None)
+    assert sp_rows_b == sp_rows and st_rows_b == st_rows
     assert [r[0] for r in sp_rows] == [r[0] for r in exp_species]
     for r, e in zip(sp_rows, exp_species):
         assert r[1] == pytest.approx(e[1], rel=1e-12) and r[2] == pytest.approx(e[2], rel=1e-12)

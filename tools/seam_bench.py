@@ -7,6 +7,10 @@ sys.path.insert(0, ROOT)
 import bench
 import synthdata as synth
 from pantax_amd.engine import Engine
+if os.environ.get("SEAM_WITH_TORCH"):      # experiment: does a process that has initialised torch's HIP context load more slowly?
+    import torch
+    torch.cuda.set_device(0)
+    _t = torch.ones(1, device="cuda") if os.environ["SEAM_WITH_TORCH"] == "2" else None
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 spec = bench.workload_spec(wl, reads=int(sys.argv[2]) if len(sys.argv) > 2 else None)
 threads = max(1, min(64, os.cpu_count() or 1))
@@ -24,9 +28,7 @@ with tempfile.TemporaryDirectory(dir=root) as td:
     nb = synth.write_gaf_parallel(rd, gp, threads=threads)
     print("GAF: %.2f GB written in %.1f s under %s" % (nb / 1e9, time.perf_counter() - t0, root), flush=True)
     del rd
-    eng = Engine(0)
-    res = bench.file_seam_leg(eng, species, gp, td, threads, None, spec["reads"], fr=0.5 if spec.get("long_reads") else 0.3)
-    eng.close()
+    res = bench.file_seam_leg(0, species, gp, td, threads, None, spec["reads"], fr=0.5 if spec.get("long_reads") else 0.3)   # (the calls run in a child process)
 res["workload"] = spec["name"]
 print(json.dumps(res, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
