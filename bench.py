@@ -435,7 +435,7 @@ class CpuLeg:
         return d
 
 
-PMC_ROUND = "r05"   # profiles/<PMC_ROUND>_pmc_<workload>.json: the counter passes of THIS round's code; older files are never read
+PMC_ROUND = "r06"   # profiles/<PMC_ROUND>_pmc_<workload>.json: the counter passes of THIS round's code; older files are never read
 
 
 def pmc_traffic(kernel, key, wl_name, corrected=False):
@@ -450,7 +450,9 @@ def pmc_traffic(kernel, key, wl_name, corrected=False):
         w = d.get("workload", {})
         if any(w.get(k) != v for k, v in key.items()):
             return None
-        k = d["kernels"].get(kernel)
+        # (the long-walk coverage kernel is an instantiation of coverage_fast_kernel: the profiler lists it under that name -- in a long-read workload,
+        # where the short-read instantiation is not launched, the entry is the long-walk kernel's)
+        k = d["kernels"].get(kernel) or (d["kernels"].get("coverage_fast_kernel") if kernel == "coverage_long_kernel" and key.get("long_reads") else None)
         if k and "hbm_bytes_per_launch" in k:
             return k["hbm_bytes_fetch_x2"] if corrected else k["hbm_bytes_per_launch"]
     except Exception:   # noqa: BLE001
@@ -944,6 +946,12 @@ def main():
     from pantax_amd.pipeline import LocalComm, StepConfig, TorchComm, partition_species, profile_step, profile_steps_pipelined
     cfg = StepConfig(fr=0.5) if spec.get("long_reads") else StepConfig()   # long reads: --fr 0.5 (main.rs:108-114)
     import torch
+    # torch is here for torch.distributed only; its intra-op pool (one thread per core by default) is not needed and competes with the library's own
+    # host threads (the crew that fills the pinned upload ring)
+    try:
+        torch.set_num_threads(max(1, min(4, os.cpu_count() or 1)))
+    except Exception:   # noqa: BLE001
+        pass
     from pantax_amd.engine import Engine
     # PANTAX_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, the
     # exchange goes over gloo); the driver's runs use the default, RCCL with one GPU per rank
