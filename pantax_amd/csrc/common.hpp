@@ -8,6 +8,7 @@
 #include <functional>
 #include <mutex>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/pantax_hip.h"
@@ -148,6 +149,8 @@ struct CtxConfig {
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
     bool cov_self_clean = false;     // resident step: the last readers of the coverage arena zero it instead of a zero fill in front of every coverage pass.  OFF: measured
                                      // slower (node_cov_stats_kernel 2.5 -> 6.9 ms with the stores among its loads against 1.5 ms of zero fill at 1e4 strains)
+    bool walk_sum_in_bin = false;    // the walk sums of long reads inside the binning pass instead of by walk_sum_kernel.  OFF: measured -- the row of 16 lanes that streams a
+                                     // long walk in bin_slots_kernel adds 0.63 ms there at the cfg5 share where walk_sum_kernel takes 0.38 (cfg5 at full size: +2.7 against 2.9)
     bool ncs_no_prefix = false;      // node statistics of long-node graphs through the per-lane word loop (round 5's kernel; tests compare, measurements)
     bool cov_arena_verify = false;   // tests: a coverage pass that skips its zero fill first checks that the arena IS zero (fails with PANTAX_HIP_E_STATE)
     // measurement shapes
@@ -310,7 +313,9 @@ struct TrioScratch {
 };
 
 // ---- resident DB -----------------------------------------------------------------------------
+inline uint64_t next_db_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
 struct Db {
+    const uint64_t uid = next_db_uid();   // never reused: what resident reads remember a db by (Reads::long_sums_db)
     uint32_t S = 0;
     uint64_t V = 0, H = 0, P = 0, L = 0;
     std::vector<int64_t> h_range_start, h_range_end;
@@ -482,6 +487,7 @@ struct Reads {
     bool binned = false;
     bool grouped = true;             // false: columns only (a slice that will be routed away, stage_route.hip; the file seam until its graphs travel): no locus-grouped copy, no coverage pass
     uint64_t layout_id = 0;          // a new number for every locus-grouped copy built (build_step_read)
+    uint64_t long_sums_db = 0;       // Db::uid of the db whose binning pass filled d_long_sum / d_long_len0 (0: nobody: walk_sum_kernel does it)
     std::vector<uint32_t> h_item_block;   // node block (first node id >> item_blk_shift) of every work item of the short-read coverage kernel, ascending (host)
     uint32_t max_node_id = 0;        // largest node id of the walks (the device tokenizer notes it: what a later reads_group() sizes its buckets by)
 };

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
     uint32_t n_slots, const uint4 *__restrict__ read_rec, const uint32_t *__restrict__ node_id, const uint2 *__restrict__ g_qm,
     const uint8_t *__restrict__ g_flag /* null: no drop flags */, const uint32_t *__restrict__ rs, const uint32_t *__restrict__ re,
     const uint32_t *__restrict__ ridx, int S, uint2 *__restrict__ slot_rec, const uint32_t *__restrict__ sp_first_id /* null: db without graphs */,
-    const uint32_t *__restrict__ node_base, unsigned long long *__restrict__ counters_rep) {
+    const uint32_t *__restrict__ node_base, unsigned long long *__restrict__ counters_rep,
+    const uint32_t *__restrict__ node_len /* null: no walk sums */, uint32_t *__restrict__ long_sum, uint32_t *__restrict__ long_len0) {
     extern __shared__ unsigned long long s_dyn[];
     unsigned long long *s_base = s_dyn;                                   // [S]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_dyn + (LDS_TAB ? S : 0));    // [3S]
@@ -320,6 +321,21 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
                 for (uint32_t i = bb + rl; i < ee; i += 16) { const uint32_t v = node_id[i]; m1 = min(m1, v); m2 = max(m2, v); }
             m1 = row_reduce(m1, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
             m2 = row_reduce(m2, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+            // Round 6: the walk sums of the long-read coverage pass (profile.rs:857-859: `seen` of a walk's last step = the node lengths of all steps before
+            // it; and the length of its first node) are taken HERE, by the row that has just streamed the walk's ids and now knows its species -- a second
+            // pass over ids that are in the caches, one 4-byte gather per step -- instead of by walk_sum_kernel (2.9 of cfg5's 28 ms per step), which found
+            // every step's walk again through the slot of its group, the read record and the slot record.
+            if (node_len) {
+                const int sp_w = src >= 0 && ee > bb ? (LDS_TAB ? find_species<SORTED>(m1, m2, s_rs, s_re, s_ridx, S) : find_species<SORTED>(m1, m2, rs, re, ridx, S)) : -1;
+                uint32_t sum = 0, l0 = 0;
+                if (sp_w >= 0) {
+                    const uint32_t delta = (LDS_TAB ? s_nb[sp_w] : node_base[sp_w]) - (LDS_TAB ? s_first[sp_w] : sp_first_id[sp_w]);
+                    for (uint32_t i = bb + rl; i + 1 < ee; i += 16) { const uint32_t ln = node_len[node_id[i] + delta]; sum += ln; if (i == bb) l0 = ln; }
+                }
+                sum = row_reduce(sum, [](uint32_t x, uint32_t y) { return x + y; });
+                l0 = row_reduce(l0, [](uint32_t x, uint32_t y) { return x | y; });
+                if (src >= 0 && rl == 0) { const uint64_t slot = base + (uint64_t)src; long_sum[slot] = sp_w >= 0 ? sum : 0u; long_len0[slot] = l0; }
+            }
             for (int rr_ = 0; rr_ < 4; ++rr_) {
                 const int owner = __shfl(src, rr_ * 16);
                 const uint32_t a1 = __shfl(m1, rr_ * 16), a2 = __shfl(m2, rr_ * 16);
@@ -464,8 +480,12 @@ int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_co
         if (rd->n_slots) {
             KTimer t(ctx, "bin_slots_kernel");
             const int grid = grid_for(rd->n_slots, BIN_BLOCK, ctx->n_cu * 8);
+            // (option walk_sum_in_bin: walk sums of long walks on the way -- a db with graphs, reads that hold walks of more than 64 steps)
+            const bool sums = rd->n_long && db->d_node_len.p && db->d_sp_first_id.p && rd->d_long_sum.p && rd->d_long_len0.p && ctx->cfg.walk_sum_in_bin;
+            rd->long_sums_db = sums ? db->uid : 0;
 #define BIN_ARGS rd->n_slots, rd->d_g_read_rec.p, rd->d_g_node_id.p, rd->d_g_qm.p, g_flag, db->d_rng_start.p, db->d_rng_end.p, db->d_rng_idx.p, S, \
-                 rd->d_g_slot_rec.p, db->d_sp_first_id.p, db->d_node_base.p, d_counters
+                 rd->d_g_slot_rec.p, db->d_sp_first_id.p, db->d_node_base.p, d_counters, sums ? (const uint32_t *)db->d_node_len.p : (const uint32_t *)nullptr, \
+                 rd->d_long_sum.p, rd->d_long_len0.p
             if (db->ranges_sorted_disjoint) {
                 if (lds) hipLaunchKernelGGL((bin_slots_kernel<true, true>), dim3(grid), dim3(BIN_BLOCK), dyn, ctx->stream, BIN_ARGS);
                 else hipLaunchKernelGGL((bin_slots_kernel<true, false>), dim3(grid), dim3(BIN_BLOCK), 0, ctx->stream, BIN_ARGS);

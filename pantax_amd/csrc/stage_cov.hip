@@ -1221,7 +1221,9 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     }
     db->cov_arena_clean = false;   // the coming pass writes it
     db->cov_arena_sig = sig;
-    if (rd->R && rd->T_pad && rd->n_long) {
+    if (rd->R && rd->T_pad && rd->n_long && rd->long_sums_db != 0 && rd->long_sums_db == db->uid) {
+        // the binning pass of these reads against THIS db took the walk sums on its way (bin_slots_kernel, round 6)
+    } else if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");
         hipLaunchKernelGGL(walk_sum_kernel<4>, dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_group_slot.p,

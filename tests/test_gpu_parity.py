@@ -302,7 +302,7 @@ def test_long_reads_and_empty_inputs(eng, long_kernel, set_opt):
     assert not bases.any() and not cov.any() and nab == 0
 
 
-@pytest.mark.parametrize("long_kernel,shape", [(None, None), (None, "1120"), (None, "2242"), (None, "2848"), ("step", None)])
+@pytest.mark.parametrize("long_kernel,shape", [(None, None), (None, "1120"), (None, "2242"), (None, "2848"), ("step", None), ("walk_sum_in_bin", None)])
 def test_long_walks_with_revisits(eng, long_kernel, shape, set_opt):
     """(every shape of the long-walk kernel -- groups in flight, groups per workgroup, window size, window start -- and round 5's kernel)
     Walks of 65 .. 6000 steps (more than a wave, more than the upload-time hash holds) that come back to nodes they
@@ -310,7 +310,9 @@ def test_long_walks_with_revisits(eng, long_kernel, shape, set_opt):
     (profile.rs:879-882), `seen` across waves (:857-859) and the trio windows at wave borders, bit for bit."""
     from oracle import oracle as orc
     import synthdata as synth
-    if long_kernel:
+    if long_kernel == "walk_sum_in_bin":         # the walk sums inside the binning pass instead of by walk_sum_kernel
+        set_opt(eng, "walk_sum_in_bin", "1")
+    elif long_kernel:
         set_opt(eng, "cov_long", long_kernel)
     if shape:
         set_opt(eng, "covl_shape", shape)
