@@ -294,16 +294,30 @@ __global__ void __launch_bounds__(BIN_BLOCK) bin_slots_kernel(
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    for (uint64_t base = (uint64_t)blockIdx.x * BIN_BLOCK + (threadIdx.x - lane); base < n_slots; base += (uint64_t)gridDim.x * BIN_BLOCK) {
+    // (round 6: the records of the NEXT slot of this thread are requested while this one's walk is read -- the pass is a chain of two dependent levels
+    // per slot, record -> walk ids, and a thread takes ~190 slots one after the other at 1e8 reads)
+    const uint64_t stride = (uint64_t)gridDim.x * BIN_BLOCK;
+    uint4 n_rr = make_uint4(0u, 0u, 0u, 0u);
+    uint2 n_qm = make_uint2(0u, 255u);
+    uint8_t n_fl = 0;
+    {
+        const uint64_t r0 = (uint64_t)blockIdx.x * BIN_BLOCK + threadIdx.x;
+        if (r0 < n_slots) { n_rr = read_rec[r0]; n_qm = g_qm[r0]; if (g_flag) n_fl = g_flag[r0]; }
+    }
+    for (uint64_t base = (uint64_t)blockIdx.x * BIN_BLOCK + (threadIdx.x - lane); base < n_slots; base += stride) {
         const uint64_t r = base + lane;
         int sp = -1;
         uint32_t b = 0, e = 0, q = 0, m = 255u;
         uint8_t fl = 0;
         if (r < n_slots) {
-            const uint4 rr = read_rec[r];
-            const uint2 qm = g_qm[r];
+            const uint4 rr = n_rr;
+            const uint2 qm = n_qm;
             b = rr.x; e = rr.x + rr.y; q = qm.x; m = qm.y;
-            if (g_flag) fl = g_flag[r];
+            fl = n_fl;
+        }
+        {
+            const uint64_t rn = r + stride;
+            if (rn < n_slots) { n_rr = read_rec[rn]; n_qm = g_qm[rn]; if (g_flag) n_fl = g_flag[rn]; }
         }
         uint32_t mn = 0xFFFFFFFFu, mx = 0;
         const uint32_t k = e - b;
