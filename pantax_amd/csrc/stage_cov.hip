@@ -272,6 +272,31 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         }
     }
 #endif
+    // The plain instantiation takes TWO levels off the chain (round 6): the stream loads run two rounds ahead and the read / slot records of the coming
+    // round are requested at the top of this one -- nine more registers per group in flight, 5.30 -> 5.13 ms at 1e8 reads (-DCOV_NO_PF2: one level)
+#if !defined(COV_NO_PF2) && !defined(COV_NO_PREFETCH)
+    constexpr bool PF2 = !LONG;
+#else
+    constexpr bool PF2 = false;
+#endif
+    uint32_t c_code[U], c_id[U], c_gs[U];      // PF2: this round's level 1 ...
+    uint4 c_rr[U];                             // ... and level 2, requested a round ago
+    uint2 c_sr[U];
+    if constexpr (PF2) {
+        const uint32_t gw0 = g0 + (uint32_t)(wave * U), gw1 = gw0 + (uint32_t)(WAVES * U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c_code[u] = n_code[u]; c_id[u] = n_id[u]; c_gs[u] = n_gs[u];           // round 0 (requested above)
+            const uint32_t g = gw1 + (uint32_t)u < n_groups ? gw1 + (uint32_t)u : (gw0 < n_groups ? gw0 : g0);
+            const uint64_t t = (uint64_t)g * 64 + lane;
+            n_code[u] = step_code[t]; n_id[u] = node_id[t]; n_gs[u] = group_slot[g];   // round 1
+            const bool pad0 = c_code[u] == STEP_PAD;
+            const bool run0 = (gw0 + (uint32_t)u < n_groups) & any1(!pad0) & none1(!pad0 & ((c_code[u] & STEP_LONG) != 0u));
+            const uint32_t sl = slot_in_group(c_gs[u], c_code[u], lane);
+            const uint32_t slot = (pad0 | !run0) ? (c_gs[u] == NO_SLOT ? 0u : c_gs[u]) : sl;
+            c_rr[u] = read_rec[slot]; c_sr[u] = slot_rec[slot];
+        }
+    }
 #pragma unroll 1
     for (int pass = 0;; ++pass) {
         const uint32_t gw = g0 + (uint32_t)((pass * WAVES + wave) * U);     // this wave's U consecutive groups
@@ -279,7 +304,29 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         // ---- level 1
         uint32_t code[U], id[U], gs[U];
         bool run[U];                                                          // wave-uniform: the group is this kernel's
+        uint4 rr[U];
+        uint2 sr[U];
 #ifndef COV_NO_PREFETCH
+        if constexpr (PF2) {
+            const uint32_t gn = gw + (uint32_t)(WAVES * U), g2 = gn + (uint32_t)(WAVES * U);   // the coming round's groups, and the one behind it
+            uint32_t m_code[U], m_id[U], m_gs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                run[u] = gw + (uint32_t)u < n_groups;
+                code[u] = c_code[u]; id[u] = c_id[u]; gs[u] = c_gs[u]; rr[u] = c_rr[u]; sr[u] = c_sr[u];
+                const uint32_t g = g2 + (uint32_t)u < n_groups ? g2 + (uint32_t)u : gw;
+                const uint64_t t = (uint64_t)g * 64 + lane;
+                m_code[u] = step_code[t]; m_id[u] = node_id[t]; m_gs[u] = group_slot[g];
+                // level 2 of the coming round (its level 1 was requested a round ago)
+                const bool padn = n_code[u] == STEP_PAD;
+                const bool runn = (gn + (uint32_t)u < n_groups) & any1(!padn) & none1(!padn & ((n_code[u] & STEP_LONG) != 0u));
+                const uint32_t sl = slot_in_group(n_gs[u], n_code[u], lane);
+                const uint32_t slot = (padn | !runn) ? (n_gs[u] == NO_SLOT ? 0u : n_gs[u]) : sl;
+                c_rr[u] = read_rec[slot]; c_sr[u] = slot_rec[slot];
+                c_code[u] = n_code[u]; c_id[u] = n_id[u]; c_gs[u] = n_gs[u];
+                n_code[u] = m_code[u]; n_id[u] = m_id[u]; n_gs[u] = m_gs[u];
+            }
+        } else
         {
             const uint32_t gn = gw + (uint32_t)(WAVES * U);                    // the coming round's groups
 #pragma unroll
@@ -302,8 +349,6 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
         }
 #endif
         // ---- level 2 (dead lanes read the group's first record: in range, and on a line that is fetched anyway)
-        uint4 rr[U];
-        uint2 sr[U];
         bool pad[U];
         uint32_t ll0[U], lsum[U];                                             // LONG: first node length / sum of the lengths before the last step, by slot
 #pragma unroll
@@ -314,8 +359,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             run[u] = run[u] & any1(!pad[u]) & (LONG ? (has_long | (only_long == 0u)) : !has_long);
             const uint32_t sl = slot_in_group(gs[u], code[u], lane);
             const uint32_t slot = (pad[u] | !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
-            rr[u] = read_rec[slot];
-            sr[u] = slot_rec[slot];
+            if constexpr (!PF2) { rr[u] = read_rec[slot]; sr[u] = slot_rec[slot]; }     // (PF2: requested a round ago)
             if constexpr (LONG) { ll0[u] = long_len0[slot]; lsum[u] = long_sum[slot]; }
         }
         // LONG: the two steps in front of the wave's group (wave-uniform addresses: position of the group - 1, - 2; the dword of step codes in front of it)
