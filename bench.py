@@ -1072,6 +1072,13 @@ def main():
     # Warm-up steps bracket EVERY launch with HIP events (per-kernel table, dominant kernel); the timed steps
     # bracket only that dominant kernel: ~200 event records per step cost ~0.15 ms, which is not part of the path.
     out = None
+    # host hygiene, ahead of the warm-up steps so that the device goes from them straight into the timed region (round 6: between the two, the 0.1 s of this
+    # collection let the clocks drop -- the first timed step took 2-3 ms longer than the rest): with torch imported the interpreter holds ~1e6 long-lived
+    # objects, and a full collection of the cyclic garbage collector (triggered by the tables' tuples every few dozen steps) stops the thread that
+    # enqueues the next step for 30-50 ms; frozen objects are not scanned again
+    import gc
+    gc.collect()
+    gc.freeze()
     eng.timing_enable(True)
     eng.timing_reset()
     n_warm_timed = 0
@@ -1094,19 +1101,16 @@ def main():
     # ... and the coverage kernel always (the histogram is the path's named kernel)
     eng.timing_filter("|".join(top2 + [k for k in [cov_kernel] if k not in top2]))
     eng.timing_reset()
-    # host hygiene before the timed region: with torch imported the interpreter holds ~1e6 long-lived objects, and a full
-    # collection of the cyclic garbage collector (triggered by the tables' tuples every few dozen steps) stops the thread that
-    # enqueues the next step for 30-50 ms; frozen objects are not scanned again
-    import gc
-    gc.collect()
-    gc.freeze()
     barrier()
     # K steps back to back; with N > 1 the all-reduce of step i is in flight while step i+1 computes (every step's tables
     # are complete before the closing barrier)
     t0 = time.perf_counter()
     out = run_steps(args.steps)[-1]
+    t_steps = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("PANTAX_PIPE_TRACE"):
+        print("[bench] timed region: %.2f ms of steps + %.2f ms in the closing barrier" % (t_steps * 1e3, (dt - t_steps) * 1e3), file=sys.stderr)
     cpu_child_alive = False                         # the child's HiGHS legs wait (it sleeps on a file between its oracle leg and them) ...
     timings = eng.timing_get()
     eng.timing_enable(False)

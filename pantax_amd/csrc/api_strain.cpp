@@ -142,6 +142,12 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     mark();
     // the resident step (the coverage pass left its counts to node_stats_launch): this call's two statistics passes are the only readers of the coverage
     // arena, once -- they zero it for the next step's coverage pass.  A stage caller may read bases / trio_bases again, so nothing is cleaned for it.
+    // cov_clean_async: the fill goes onto the side stream instead, in front of the LPs (below) -- not while every kernel is being clocked (a bracket on the side
+    // stream measures the overlap, and the per-kernel table wants the fill's own time).  -1: from 1 GiB of arena on (cfg4: 4.8 GB, 17.73 -> 17.42 ms a step; the reference-DB shape 27.7 -> 27.3; at 0.4 GB the
+    // two events cost more than the 0.07 ms fill)
+    const bool clocked = ctx->timing && ctx->timing_filter.empty();     // (named launches only: the fill overlaps, unbracketed)
+    const bool clean_async = db->cov_count_pending && !ctx->cfg.cov_self_clean && !clocked &&
+                             (ctx->cfg.cov_clean_async > 0 || (ctx->cfg.cov_clean_async < 0 && db->cov_arena_total >= ((size_t)1 << 30)));
     db->cov_self_clean = db->cov_count_pending && ctx->cfg.cov_self_clean && db->U != 0;
     PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
     mark();
@@ -172,6 +178,7 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     }
     if (db->trio_free_pending) { PTX_HIP(ctx, hipEventRecord(db->ev_trio_free, ctx->stream)); db->trio_free_valid = true; db->trio_free_pending = false; }
     mark();
+    if (clean_async) PTX_TRY(coverage_arena_clean_async(ctx, db));   // beside the LPs: one workgroup per species, most of the memory system idle
     PTX_TRY(lad_pair_launch(ctx, db, &lb, pmax_bound, fc));                                 // LP 1 -> a13 decision -> LP 2, objectives
     mark();
     PTX_TRY(fetch_arena_enqueue(ctx, db, L, slot));

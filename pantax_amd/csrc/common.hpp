@@ -147,6 +147,7 @@ struct CtxConfig {
     std::string cov_long;            // "step": round 5's coverage_step_kernel for the groups that hold steps of walks of more than 64 steps
     int covl_shape = -1;             // shape of the long-walk kernel: <U><groups per workgroup / 8><window / 1024><back / 256> (default 2234)
     bool cov_count = false;          // resident step: popcount_kernel as in the stage call
+    int cov_clean_async = -1;        // resident step: the coverage arena's zero fill goes onto the side stream, beside the LPs (1; -1: arenas of 1 GiB and more); 0: in front of the coverage pass
     bool cov_self_clean = false;     // resident step: the last readers of the coverage arena zero it instead of a zero fill in front of every coverage pass.  OFF: measured
                                      // slower (node_cov_stats_kernel 2.5 -> 6.9 ms with the stores among its loads against 1.5 ms of zero fill at 1e4 strains)
     bool walk_sum_in_bin = false;    // the walk sums of long reads inside the binning pass instead of by walk_sum_kernel.  OFF: measured -- the row of 16 lanes that streams a
@@ -156,7 +157,7 @@ struct CtxConfig {
     // measurement shapes
     int cov_item_groups = 0;         // groups of 64 steps per work item of the short-read coverage kernel (0: 64)
     int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
-    uint32_t tv_ablate = 0, cov_ablate = 0;
+    uint32_t tv_ablate = 0, cov_ablate = 0, ssn_ablate = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)
     bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
          trio_after_step = false;
@@ -386,6 +387,11 @@ struct Db {
     // strain_enqueue); cov_arena_clean + its signature: the arena is all zero in exactly this layout (reset by whatever dirties it).
     bool cov_self_clean = false, cov_arena_clean = false;
     uint64_t cov_arena_sig = 0;
+    // ... or (cov_clean_async) the arena is zero-filled on the SIDE stream from behind those readers, beside the step's row sort and LPs: the next coverage
+    // pass waits for ev_cov_clean instead of filling in front of itself
+    size_t cov_arena_total = 0;
+    hipEvent_t ev_cov_read = nullptr, ev_cov_clean = nullptr;
+    bool cov_clean_pending = false;
     bool trio_sizes_known = false;   // U, the rows per haplotype and per species depend on the graphs only: kept across db_reset
     uint64_t U_known = 0;
     bool trio_layout_fast = false;   // the sizes were learnt by a build that filed the visit table's species from its records (else: every species by the pass over the walks)
@@ -448,7 +454,8 @@ struct Db {
     hipEvent_t ev_trio_free = nullptr;   // recorded behind the last reader of the unique-trio tables in a step: the next step's rebuild waits
     bool trio_free_valid = false;        // for this, not for the whole previous step (its row sort and LPs run beside the rebuild)
     bool trio_free_pending = false;      // the event is still to be recorded by lad_prepare, behind the row compaction
-    ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); if (ev_trio_free) (void)hipEventDestroy(ev_trio_free); }
+    ~Db() { for (hipEvent_t e : ev_step) if (e) (void)hipEventDestroy(e); if (ev_trio_free) (void)hipEventDestroy(ev_trio_free);
+            if (ev_cov_read) (void)hipEventDestroy(ev_cov_read); if (ev_cov_clean) (void)hipEventDestroy(ev_cov_clean); }
     // LP-row staging (lad_prepare)
     DevBuf<uint32_t> d_scan_tmp, d_sort_table, d_ss_ws;
     DevBuf<uint64_t> d_ka[3], d_kb[3];
@@ -632,6 +639,7 @@ inline int grid_for(uint64_t work, int block, int max_blocks = 256 * 8) {
 // ---- stage entry points (host launchers, defined in the .hip files) ---------------------------
 int bin_reads_launch(Ctx *ctx, const Db *db, Reads *rd, unsigned long long *d_counters /*[4*S]*/);
 int species_ensure(Ctx *ctx, Reads *rd);   // d_species in file order (resident reads keep the species per slot)
+int coverage_arena_clean_async(Ctx *ctx, Db *db);   // resident step: the arena's zero fill on the side stream (option cov_clean_async)
 int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio);   // optional, ahead of coverage_launch (needs the binning and db->U only)
 // defer_count: leave node_base_cov (popcount_kernel) to the node statistics pass that follows in the resident step (db->cov_count_pending)
 int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool with_trio, bool defer_count = false);

@@ -85,6 +85,7 @@ struct Sn {
     uint64_t *ksp, *km, *ka;     // output: {species, mask, a} (ksp null: species << pack_shift | mask in km)
     int pack_shift;
     uint32_t G, per;             // partition workgroups per segment, tiles each of them walks
+    uint32_t ablate;             // -DSSN_ABLATE builds: parts of ssn_hist_kernel left out (measurements; the results are wrong)
     __device__ __forceinline__ uint32_t *w(uint32_t s) const { return ws + (size_t)s * SN_WS_WORDS; }
     __device__ __forceinline__ uint64_t key_word(uint32_t s, uint64_t m) const { return pack_shift >= 0 ? (((uint64_t)s << pack_shift) | m) : m; }
     __device__ __forceinline__ void put(uint32_t s, uint32_t pos, uint64_t m, uint64_t a) const {
@@ -284,6 +285,15 @@ __device__ __forceinline__ void sn_tiles(const Sn &sn, uint32_t n, uint32_t g, u
 // HAPS: no mask array -- the mask of a node is formed here from its haplotype word through byte-wise column tables in (dynamic) LDS, and the
 // candidates' covered bases and lengths (path_cov_ratio, profile.rs:1344-1361) are summed while it is in a register: mask_nodes_kernel's
 // pass (16V in, 8V out) and this pass's own 8V of masks are gone
+// -DSSN_ABLATE + option ssn_ablate (tools/r6_ssn_ablate.sh): 1 no column tables, 2 no column sums, 4 no sums beyond column 8, 8 no tree descent, 16 no
+// histogram, 32 nothing staged.  Round 6 at cfg4: 1.98 ms whole, 1.34 ms with ALL of them left out -- the kernel is its four input streams (24 B a node
+// at 4.5 TB/s); the LDS conflicts round 5's counters showed cost 0.1 ms (tables), 0.1 (sums), 0 (histogram), and 512-thread workgroups (six waves per
+// SIMD behind the same tables instead of four) were slower, 2.06 ms
+#ifdef SSN_ABLATE
+#define SSN_ABL(b) ((sn.ablate & (b)) != 0u)
+#else
+#define SSN_ABL(b) false
+#endif
 template <bool HAPS>
 __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     __shared__ ulonglong2 tree[SN_NLEAF];
@@ -349,14 +359,16 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
             if (HAPS) {                                           // haplotype word -> columns, and the columns' sums
                 const unsigned long long hm = mv[r];
                 unsigned long long m = 0ull;
+                if (SSN_ABL(1u)) m = hm & ((p0 >= 64 ? 0ull : (1ull << p0)) - 1ull);
+                else
                 for (int b = 0; b < nbyte; ++b) m |= s_dyn_tab[b * 256 + (int)((hm >> (8 * b)) & 255ull)];
                 mv[r] = m;
-                if (m) {
+                if (m && !SSN_ABL(2u)) {
                     const unsigned long long c = cv[r], l = lv[r];
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
                         if (k < p0) { const bool on = (m >> k) & 1ull; c8[k] += on ? c : 0ull; l8[k] += on ? l : 0ull; }   // (block-uniform: the columns that exist)
-                    unsigned long long rest = m >> 8;
+                    unsigned long long rest = SSN_ABL(4u) ? 0ull : m >> 8;
                     while (rest) {
                         const int k = __ffsll((long long)rest) - 1 + 8;
                         rest &= rest - 1;
@@ -371,15 +383,17 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
             if (av[r] > 0.0 && mv[r] != 0ull) {                  // (nodes behind the segment's end were loaded as zeros)
                 const Key2 key{mv[r], abits};
                 uint32_t k = 1;
+                if (SSN_ABL(8u)) k = (uint32_t)SN_NLEAF + ((uint32_t)(abits >> 30) & (uint32_t)(SN_NLEAF - 1));
+                else
 #pragma unroll
                 for (int l = 0; l < SN_LEVELS; ++l) { const ulonglong2 nd = tree[k]; k = 2u * k + (less2(Key2{nd.x, nd.y}, key) ? 1u : 0u); }
                 const uint32_t lo = k - (uint32_t)SN_NLEAF;   // splitters less than the key
                 uint32_t eq = 0;
-                if (lo < (uint32_t)SN_NSPLIT) { const ulonglong2 nd = tree[tree_node(lo)]; eq = eq2(Key2{nd.x, nd.y}, key) ? 1u : 0u; }
+                if (lo < (uint32_t)SN_NSPLIT && !SSN_ABL(8u)) { const ulonglong2 nd = tree[tree_node(lo)]; eq = eq2(Key2{nd.x, nd.y}, key) ? 1u : 0u; }
                 id = 2u * lo + eq;
-                atomicAdd(&s_hist[id], 1u);
+                if (!SSN_ABL(16u)) atomicAdd(&s_hist[id], 1u);
             }
-            const bool travels = id != SN_NO_ROW && !(id & 1u);
+            const bool travels = id != SN_NO_ROW && !(id & 1u) && !SSN_ABL(32u);
             const unsigned long long bal = __ballot(travels);
             if (bal) {                                           // (wave-uniform)
                 uint32_t wbase = 0;
@@ -791,6 +805,7 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     if (haps) { if (haps->max_haps > 64) return fail(ctx, PANTAX_HIP_E_INVALID, "sample_sort_nodes: masks from haplotype words take species of at most 64 haplotypes"); sn.hp = *haps; }
     else if (!mask) return fail(ctx, PANTAX_HIP_E_INVALID, "sample_sort_nodes: neither a mask array nor haplotype words");
     sn_geometry(S, seg_bound, &sn.G, &sn.per);
+    sn.ablate = ctx->cfg.ssn_ablate;
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
     sn.stage_cnt = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
     uint32_t *cw = sn.stage_cnt + (size_t)S * sn.G;               // [S x G] doubles, 8-byte aligned

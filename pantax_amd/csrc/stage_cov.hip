@@ -1246,6 +1246,11 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     PTX_HIP(ctx, db->d_cov.alloc(db->V));
     // the resident step's last readers left the arena zeroed (cov_arena_clean) unless its layout or place changed since: only the abort counter is reset
     const uint64_t sig = (uint64_t)(uintptr_t)base ^ ((uint64_t)total * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)off_bm << 1) ^ ((uint64_t)off_full << 2) ^ (uint64_t)off_trio;
+    db->cov_arena_total = total;
+    if (db->cov_clean_pending) {   // a fill on the side stream (coverage_arena_clean_async): over before anything here touches the arena
+        PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, db->ev_cov_clean, 0));
+        db->cov_clean_pending = false;
+    }
     if (db->cov_arena_clean && db->cov_arena_sig == sig) {
         if (ctx->cfg.cov_arena_verify) {
             DevBuf<unsigned long long> d_nz;
@@ -1276,6 +1281,32 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     }
     PTX_HIP(ctx, hipGetLastError());
     db->cov_prepared = true;
+    return 0;
+}
+
+// The resident step's zero fill of the coverage arena, taken off the main stream (round 6): enqueued on the side stream behind everything the main stream
+// holds so far (the arena's last readers among it), it runs beside what the main stream gets next -- strain_enqueue calls it in front of the LPs, one
+// workgroup per species, which leave most of the memory system idle (behind the node statistics, i.e. beside the row sort's bandwidth-bound passes: no
+// gain; in two bursts, one beside the sort's sampling kernels: less gain; behind the LPs: a third of the gain).  The next coverage_prepare waits for
+// ev_cov_clean.
+int coverage_arena_clean_async(Ctx *ctx, Db *db) {
+    if (!db->d_cov_arena.p || !db->cov_arena_total || !ctx->stream2) return 0;
+    uint8_t *f_ptr = db->d_cov_arena.p;
+    const size_t f_n = db->cov_arena_total;
+    if (!db->ev_cov_read) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_cov_read, hipEventDisableTiming));
+    if (!db->ev_cov_clean) PTX_HIP(ctx, hipEventCreateWithFlags(&db->ev_cov_clean, hipEventDisableTiming));
+    PTX_HIP(ctx, hipEventRecord(db->ev_cov_read, ctx->stream));
+    PTX_HIP(ctx, hipStreamWaitEvent(ctx->stream2, db->ev_cov_read, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream_main = main_stream; ctx->stream = ctx->stream2;
+    int rc;
+    rc = zero_fill(ctx, f_ptr, f_n);
+    const hipError_t e = hipEventRecord(db->ev_cov_clean, ctx->stream2);
+    ctx->stream = main_stream; ctx->stream_main = nullptr;
+    if (rc != 0) return rc;
+    PTX_HIP(ctx, e);
+    db->cov_done = false;          // the arena no longer holds a coverage result
+    db->cov_arena_clean = true; db->cov_clean_pending = true;
     return 0;
 }
 

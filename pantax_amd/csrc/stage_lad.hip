@@ -284,7 +284,10 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             };
             if (PASS == 0 && slab == 0) compact_rows([&](uint32_t h, double x, bool v) { sink_reg(h, v ? x : 0.0, v); });
             else {
-                if (PASS == 0 && slab == 1) __threadfence();                   // the compacted stretch was written by this very wave
+                // the compacted stretch was written by this very wave, entry i by the lane that reads it back: ordering within the wave is all that is
+                // needed.  (Until round 6 a __threadfence() stood here: agent scope = write-back + invalidate of the XCD's L2 on gfx950, by every chunk's
+                // wave -- species of more than HS_SLAB haplotypes paid 0.84 ms for pass 0 at 125 x 50 strains where 1000 x 10 strains paid 0.53.)
+                if (PASS == 0 && slab == 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 for (uint32_t r0 = 0; r0 < n_c; r0 += 64) {
                     const uint32_t i = r0 + (uint32_t)lane;
                     const bool v = i < n_c;

@@ -286,15 +286,34 @@ def local_stage(eng, avg_len, cfg, single_call=True):
     sp_of_hap = np.repeat(np.arange(eng.S), np.diff(eng.hap_off.astype(np.int64)))
     sel = np.nonzero((np.asarray(passed[:H]) != 0) & (solved[sp_of_hap] != 0))[0]
     has = m["has"][sel]
-    cols = [(4, "path_cov_ratio"), (1, "unique_trio_nodes_fraction"), (2, "frequencies_mean"), (8, "first_sol"), (16, "divergence"), (128, "total_cov_diff")]
-    opt = [[v if f else None for v, f in zip(m[name][sel].tolist(), ((has & bit) != 0).tolist())] for bit, name in cols]
-    rows = list(zip(sp_of_hap[sel].tolist(), sel.tolist(), m["second_sol"][sel].tolist(), *opt))
+    # the candidate rows as ONE array in the layout of the exchanged slab (finalize_begin): no Python object per strain between a step's collect and its
+    # tables (round 6: the tuples of 1e4 strains were 6.8 ms a step on the helper thread -- and the last step's tables are inside every timed region)
+    rows_np = np.zeros((len(sel), _ROW_K))
+    rows_np[:, 0], rows_np[:, 1], rows_np[:, 2] = sp_of_hap[sel], sel, m["second_sol"][sel]
+    for i, (bit, name) in enumerate(_OPT_COLS):
+        f = (has & bit) != 0
+        rows_np[:, 3] += f * float(1 << i)
+        rows_np[:, 4 + i] = np.where(f, m[name][sel], 0.0)
     stats = dict(iters=list(zip(inf["iters1"].tolist(), inf["iters2"].tolist())), n_cand=inf["n_candidates"].tolist(),
                  n_rows=inf["n_rows"].tolist(), n_patterns=inf["n_patterns"].tolist(), obj=list(zip(inf["obj1"].tolist(), inf["obj2"].tolist())))
-    return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows=rows, stats=stats)
+    return dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass, rows_np=rows_np, stats=stats)
 
 
 _ROW_K = 10   # columns of the exchanged slab
+# the Option<f64> columns of a strain row, in the slab's order: (bit of pantax_hip_hap_metrics.has, field)
+_OPT_COLS = [(4, "path_cov_ratio"), (1, "unique_trio_nodes_fraction"), (2, "frequencies_mean"), (8, "first_sol"), (16, "divergence"), (128, "total_cov_diff")]
+
+
+def rows_to_array(rows):
+    """candidate strain rows as tuples (species, hap, coverage, six Option values) -> the slab's layout [n, _ROW_K]: species, hap, coverage,
+    bit i = option i is Some, the six values (0.0 for None)"""
+    out = np.zeros((len(rows), _ROW_K))
+    for j, (s_, h_, cov, *opt) in enumerate(rows):
+        r = out[j]
+        r[0], r[1], r[2] = s_, h_, cov
+        r[3] = sum(1 << i for i, v in enumerate(opt) if v is not None)
+        r[4:4 + len(opt)] = [0.0 if v is None else v for v in opt]
+    return out
 PIPELINE_THREAD_MIN_HAPS = 128   # profile_steps_pipelined: from this many strains per rank the tables are built on a helper thread
 
 
@@ -302,7 +321,7 @@ def finalize_begin(local, hap_names, comm, shard_max=None, rows_max=None):
     """First half of finalize_stage: pack this rank's slab and START the exchange; returns a handle for finalize_end.
     The collective runs while the caller enqueues its next step."""
     keep, absolute = local["keep"], local["absolute"]
-    rows = local["rows"]
+    rows = local["rows_np"] if "rows_np" in local else rows_to_array(local["rows"])
     S_loc = len(keep)
     S_max = S_loc if shard_max is None else shard_max
     R_max = max(len(hap_names), 1) if rows_max is None else rows_max
@@ -312,11 +331,7 @@ def finalize_begin(local, hap_names, comm, shard_max=None, rows_max=None):
     slab[1:1 + S_loc, 1] = np.where(keep == 1, absolute, 0.0)
     slab[1:1 + S_loc, 2] = local["s_all"]
     slab[1:1 + S_loc, 3] = local["s_pass"]
-    for j, (s_, h_, cov, *opt) in enumerate(rows):
-        r = slab[1 + S_max + j]
-        r[0], r[1], r[2] = s_, h_, cov
-        r[3] = sum(1 << i for i, v in enumerate(opt) if v is not None)
-        r[4:4 + len(opt)] = [0.0 if v is None else v for v in opt]
+    slab[1 + S_max:1 + S_max + len(rows)] = rows
     return comm.exchange_begin(slab), S_max
 
 
@@ -344,19 +359,29 @@ def finalize_end(pending, species_names, hap_names, cfg, comm):
     all_sn, all_hn = comm.names(species_names, hap_names)          # collective on its first call only (cached)
     if comm.rank != 0:
         return [], [], n_active
-    species_rows, strain_rows = [], []
+    # the tables column by column (numpy), one tuple per row only at the very end; both sorts are stable and descending, like the list sorts they replace
+    species_rows, strain_rows, sp_key, st_key = [], [], [], []
     for r in range(W):
         b = sp_blk[r]
-        species_rows += [(all_sn[r][s], float(b[s, 1] / total_abs), float(b[s, 1])) for s in range(n_sp[r]) if b[s, 0] == 1]
-        for row in glob[r, 1 + S_max:1 + S_max + n_rw[r]]:
-            s_, h_ = int(round(row[0])), int(round(row[1]))
-            if not act[r][s_]:
-                continue
-            has = int(round(row[3]))
-            strain_rows.append((all_sn[r][s_], all_hn[r][h_], float(row[2]), float(row[2] / g_pass)) +
-                               tuple(float(row[4 + i]) if has >> i & 1 else None for i in range(6)))
-    species_rows.sort(key=lambda t: -t[1])     # profile.rs:344
-    strain_rows.sort(key=lambda t: -t[3])      # profile.rs:3247-3248
+        kept = np.nonzero(b[:, 0] == 1)[0]
+        ab = b[kept, 1] / total_abs
+        sn_r, hn_r = all_sn[r], all_hn[r]
+        species_rows += list(zip([sn_r[s] for s in kept.tolist()], ab.tolist(), b[kept, 1].tolist()))
+        sp_key.append(ab)
+        blk = glob[r, 1 + S_max:1 + S_max + n_rw[r]]
+        s_idx = np.rint(blk[:, 0]).astype(np.int64)
+        on = act[r][s_idx] if len(s_idx) else np.zeros(0, dtype=bool)
+        blk, s_idx = blk[on], s_idx[on]
+        h_idx = np.rint(blk[:, 1]).astype(np.int64)
+        has = np.rint(blk[:, 3]).astype(np.int64)
+        st_ab = blk[:, 2] / g_pass if len(blk) else np.zeros(0)
+        opt = [[v if f else None for v, f in zip(blk[:, 4 + i].tolist(), ((has >> i) & 1).astype(bool).tolist())] for i in range(6)]
+        strain_rows += list(zip([sn_r[s] for s in s_idx.tolist()], [hn_r[h] for h in h_idx.tolist()], blk[:, 2].tolist(), st_ab.tolist(), *opt))
+        st_key.append(st_ab)
+    if species_rows:
+        species_rows = [species_rows[i] for i in np.argsort(-np.concatenate(sp_key), kind="stable").tolist()]     # profile.rs:344
+    if strain_rows:
+        strain_rows = [strain_rows[i] for i in np.argsort(-np.concatenate(st_key), kind="stable").tolist()]       # profile.rs:3247-3248
     return species_rows, strain_rows, n_active
 
 
@@ -424,9 +449,13 @@ def profile_steps_pipelined(eng, species_names, hap_names, avg_len, n_steps, cfg
         if pending is not None:
             sr, tr, n_active = finalize_end(pending[0], species_names, hap_names, cfg, comm)
             out.append((sr, tr, dict(pending[1], n_active=n_active)))
+        if _trace is not None:
+            _trace.append(time.perf_counter())                  # (the last step's tables)
     finally:
         if ex is not None:
             ex.shutdown()
+        if _trace is not None:
+            _trace.append(time.perf_counter())                  # (the helper thread joined)
         if _trace is not None:
             import sys
             print("[pipelined] ms between collects:", " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip(_trace, _trace[1:])), file=sys.stderr)

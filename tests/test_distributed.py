@@ -129,3 +129,40 @@ def test_several_dbs_on_one_gpu_finalize_like_ranks():
     for g, e in zip(got_strain, exp_strain):
         assert g[2] == pytest.approx(e[2], rel=1e-12) and g[3] == pytest.approx(e[3], rel=1e-12)
     assert len(stats["obj"]) == sum(n_species)
+
+
+def test_tables_built_column_wise_equal_the_row_by_row_reading():
+    """finalize_end builds the tables from numpy columns (round 6); the row-by-row reading of the same slab -- profile.rs:341-344 (species
+    normaliser, descending), :602 (-a cut), :3243-3248 (strain normaliser over the passing strains, descending) -- is restated here."""
+    from pantax_amd.pipeline import LocalComm, StepConfig, finalize_stage, rows_to_array
+    rng = np.random.default_rng(7)
+    S, per = 40, 5
+    keep = (rng.random(S) < 0.8).astype(np.uint8)
+    absolute = np.where(rng.random(S) < 0.9, rng.random(S) * 30, 1e-9)
+    absolute[3] = absolute[4]                                         # a tie: both sorts are stable
+    s_all, s_pass = rng.random(S) * 10, rng.random(S) * 5
+    rows = []
+    for s in range(S):
+        for h in range(per):
+            if keep[s] and rng.random() < 0.6:
+                rows.append((s, s * per + h, float(rng.random() * 9)) + tuple(None if rng.random() < 0.3 else float(rng.random()) for _ in range(6)))
+    rows[5] = rows[5][:2] + (rows[6][2],) + rows[5][3:]               # equal coverages next to each other
+    sn = ["sp%d" % s for s in range(S)]
+    hn = ["h%d" % h for h in range(S * per)]
+    cfg = StepConfig()
+    base = dict(keep=keep, absolute=absolute, s_all=s_all, s_pass=s_pass)
+    got_a = finalize_stage(dict(base, rows=rows), sn, hn, cfg, LocalComm())
+    got_b = finalize_stage(dict(base, rows_np=rows_to_array(rows)), sn, hn, cfg, LocalComm())
+    assert got_a == got_b
+    total_abs = float(np.where(keep == 1, absolute, 0.0).sum())
+    act = [bool(keep[s] == 1 and absolute[s] > 0 and absolute[s] / total_abs > cfg.min_species_abundance) for s in range(S)]
+    g_pass = float(sum(s_pass[s] for s in range(S) if act[s]))
+    exp_species = [(sn[s], float(absolute[s] / total_abs), float(absolute[s])) for s in range(S) if keep[s] == 1]
+    exp_species.sort(key=lambda t: -t[1])
+    exp_strain = [(sn[s], hn[h], cov, cov / g_pass) + tuple(opt) for (s, h, cov, *opt) in rows if act[s]]
+    exp_strain.sort(key=lambda t: -t[3])
+    assert got_a[0] == exp_species
+    assert [r[:2] for r in got_a[1]] == [r[:2] for r in exp_strain]
+    for g, e in zip(got_a[1], exp_strain):
+        assert g[4:] == e[4:] and g[2] == e[2] and g[3] == pytest.approx(e[3], rel=1e-15)
+    assert any(v is None for r in got_a[1] for v in r[4:]) and len(got_a[1]) > 20
