@@ -692,10 +692,14 @@ __global__ void __launch_bounds__(256) ssn_local_kernel(Sn sn) {
 // few bucket pairs at a change (and of the first and the last pair).  Heads are collected in order in the segment's part of the row
 // scratch, which the local kernels have finished with.
 // ---------------------------------------------------------------------------------------------
+#ifndef SN_HEAD_PAIRS
+#define SN_HEAD_PAIRS 64                          // bucket pairs a wave of ssn_heads_kernel looks at (round 6: 16 and 4 measured slower or equal)
+#endif
+constexpr int SN_HP = SN_HEAD_PAIRS, SN_NWH = SN_NLEAF / SN_HP;   // ... and the waves per segment
 __global__ void __launch_bounds__(256) ssn_heads_kernel(Sn sn, uint32_t *__restrict__ sub_k) {
-    // wave w of a segment (four per workgroup): the bucket pairs [64 w, 64 w + 64), its heads from slot start[128 w] of the scratch on
+    // wave w of a segment (four per workgroup): the bucket pairs [HP w, HP w + HP), its heads from slot start[2 HP w] of the scratch on
     // (a range holds no more heads than rows); sub_k[s][w] = how many
-    constexpr int NW = SN_NLEAF / 64;
+    constexpr int NW = SN_NWH, HP = SN_HP;
     const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o, lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t n = nn ? sn.seg_n[s] : 0u;
     const uint32_t *w = sn.w(s);
@@ -704,7 +708,7 @@ __global__ void __launch_bounds__(256) ssn_heads_kernel(Sn sn, uint32_t *__restr
     const uint32_t *start = w + SN_OFF_START;
     uint32_t cnt = 0;
     if (n != 0 && (!small || wave == 0)) {
-        ulonglong2 *heads = sn.rows + o + (small ? 0u : start[2 * 64 * wave]);   // {mask word as stored, first row of the run}
+        ulonglong2 *heads = sn.rows + o + (small ? 0u : start[2 * HP * wave]);   // {mask word as stored, first row of the run}
         auto scan_rows = [&](uint32_t r0, uint32_t r1) {      // rows [r0, r1) of the output, in order
             for (uint32_t base = r0; base < r1; base += 64) {
                 const uint32_t i = base + lane;
@@ -719,14 +723,17 @@ __global__ void __launch_bounds__(256) ssn_heads_kernel(Sn sn, uint32_t *__restr
         if (small) scan_rows(out, out + n);                   // a small segment has no splitters
         else {
             const ulonglong2 *tree = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
-            const uint32_t j = 64 * wave + lane;
+            const uint32_t j = HP * wave + (lane < (uint32_t)HP ? lane : 0u);
             bool c = j == 0 || j == (uint32_t)SN_NLEAF - 1;
             if (!c) c = tree[tree_node(j)].x != tree[tree_node(j - 1)].x;
-            uint64_t bal = __ballot(c);
+            uint64_t bal = __ballot(c && lane < (uint32_t)HP);
             while (bal) {
-                const uint32_t jj = 64 * wave + (uint32_t)__builtin_ctzll(bal);
+                const uint32_t jj = HP * wave + (uint32_t)__builtin_ctzll(bal);
                 bal &= bal - 1;
-                scan_rows(out + start[2 * jj], out + start[2 * jj + 2]);
+                // the odd bucket of the pair holds copies of ONE key (splitter jj): a head can only be its first row -- the rest is not read (round 6:
+                // with fifty strains nearly every splitter changes the mask, and a tie bucket of 1e5 rows kept one wave reading for the whole 0.43 ms)
+                const uint32_t e0 = start[2 * jj + 1], e1 = start[2 * jj + 2];
+                scan_rows(out + start[2 * jj], out + (e1 > e0 ? e0 + 1u : e1));
             }
         }
     }
@@ -735,7 +742,7 @@ __global__ void __launch_bounds__(256) ssn_heads_kernel(Sn sn, uint32_t *__restr
 // first pattern of every segment, the number of patterns, and the end of the last run
 __global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uint32_t *__restrict__ sub_k, uint32_t *__restrict__ sp_pat_off, uint32_t *__restrict__ d_K,
                                                            const uint32_t *__restrict__ d_n, uint32_t *__restrict__ pat_start) {
-    constexpr int NW = SN_NLEAF / 64;
+    constexpr int NW = SN_NWH;
     __shared__ uint32_t s_wave[16];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < S; base += 1024) {
@@ -751,7 +758,7 @@ __global__ void __launch_bounds__(1024) ssn_patscan_kernel(uint32_t S, const uin
 }
 __global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t *__restrict__ sub_k, const uint32_t *__restrict__ sp_pat_off, uint64_t *__restrict__ pat_mask,
                                                           uint32_t *__restrict__ pat_start, uint32_t *__restrict__ pat_species) {
-    constexpr int NW = SN_NLEAF / 64;
+    constexpr int NW = SN_NWH;
     const uint32_t s = blockIdx.x, k0 = sp_pat_off[s];
     const uint32_t *w = sn.w(s);
     const bool small = w[SN_OFF_FLAGS] != 0;
@@ -759,7 +766,7 @@ __global__ void __launch_bounds__(256) ssn_patfill_kernel(Sn sn, const uint32_t 
     for (int q = 0; q < NW; before += sub_k[(size_t)s * NW + q], ++q) {
         const uint32_t cnt = sub_k[(size_t)s * NW + q];
         if (cnt == 0) continue;
-        const ulonglong2 *heads = sn.rows + sn.node_base[s] + (small ? 0u : w[SN_OFF_START + 2 * 64 * q]);
+        const ulonglong2 *heads = sn.rows + sn.node_base[s] + (small ? 0u : w[SN_OFF_START + 2 * SN_HP * q]);
         for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
             const ulonglong2 h = heads[i];
             pat_mask[k0 + before + i] = sn.pack_shift >= 0 ? (h.x & ((1ull << sn.pack_shift) - 1ull)) : h.x;
@@ -783,7 +790,7 @@ void sn_geometry(uint32_t S, uint64_t seg_bound, uint32_t *G, uint32_t *per) {
 size_t sample_sort_nodes_ws_elems(uint32_t S, uint64_t seg_bound, uint64_t V) {
     uint32_t G, per;
     sn_geometry(S, seg_bound, &G, &per);
-    return (size_t)S * SN_WS_WORDS + (size_t)S * G * (SN_NBUCKET + 1 + 2) + (V + 1) / 2 + (2 + (size_t)(SN_NLEAF / 64)) * (size_t)S + 20;
+    return (size_t)S * SN_WS_WORDS + (size_t)S * G * (SN_NBUCKET + 1 + 2) + (V + 1) / 2 + (2 + (size_t)SN_NWH) * (size_t)S + 20;
 }
 
 // Nodes of segment s: [node_base[s], node_base[s + 1]) (device array, the host knows that no segment exceeds seg_bound <= SS_MAX_N
@@ -814,8 +821,8 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     sn.c0 = pat ? pat->c0 : nullptr;
     uint32_t *tail = cw + 2 * (size_t)S * sn.G;
     sn.seg_n = tail; sn.seg_out = tail + S;                       // [S], [S + 1]
-    uint32_t *sub_k = tail + 2 * (size_t)S + 4;                   // [S][SN_NLEAF / 64] patterns found by each wave of ssn_heads_kernel
-    sn.ids = reinterpret_cast<uint16_t *>(sub_k + (size_t)(SN_NLEAF / 64) * S);
+    uint32_t *sub_k = tail + 2 * (size_t)S + 4;                   // [S][SN_NWH] patterns found by each wave of ssn_heads_kernel
+    sn.ids = reinterpret_cast<uint16_t *>(sub_k + (size_t)SN_NWH * S);
     sn.rows = reinterpret_cast<ulonglong2 *>(rows16);
     sn.stage = reinterpret_cast<ulonglong2 *>(rows16) + V;
     sn.ksp = ksp; sn.km = km; sn.ka = ka; sn.pack_shift = pack_shift;
@@ -838,7 +845,7 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
       hipLaunchKernelGGL(ssn_local_kernel, dim3(8, S), dim3(256), 0, ctx->stream, sn); }
     if (pat) {
         KTimer t(ctx, "ssn_heads_kernel");
-        hipLaunchKernelGGL(ssn_heads_kernel, dim3(SN_NLEAF / 256, S), dim3(256), 0, ctx->stream, sn, sub_k);
+        hipLaunchKernelGGL(ssn_heads_kernel, dim3(SN_NWH / 4, S), dim3(256), 0, ctx->stream, sn, sub_k);
         hipLaunchKernelGGL(ssn_patscan_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, (const uint32_t *)sub_k, pat->sp_pat_off, pat->d_K, (const uint32_t *)d_n, pat->pat_start);
         hipLaunchKernelGGL(ssn_patfill_kernel, dim3(S), dim3(256), 0, ctx->stream, sn, (const uint32_t *)sub_k, (const uint32_t *)pat->sp_pat_off, pat->pat_mask, pat->pat_start,
                            pat->pat_species);
