@@ -152,6 +152,7 @@ struct CtxConfig {
                                      // slower (node_cov_stats_kernel 2.5 -> 6.9 ms with the stores among its loads against 1.5 ms of zero fill at 1e4 strains)
     bool walk_sum_in_bin = false;    // the walk sums of long reads inside the binning pass instead of by walk_sum_kernel.  OFF: measured -- the row of 16 lanes that streams a
                                      // long walk in bin_slots_kernel adds 0.63 ms there at the cfg5 share where walk_sum_kernel takes 0.38 (cfg5 at full size: +2.7 against 2.9)
+    int ncs_prefix_min = 48;         // average node length (bases) from which the node statistics count covered bases through the per-stretch prefix in LDS
     bool ncs_no_prefix = false;      // node statistics of long-node graphs through the per-lane word loop (round 5's kernel; tests compare, measurements)
     bool cov_arena_verify = false;   // tests: a coverage pass that skips its zero fill first checks that the arena IS zero (fails with PANTAX_HIP_E_STATE)
     // measurement shapes

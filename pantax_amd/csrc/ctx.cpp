@@ -97,7 +97,7 @@ const OptDesc OPTIONS[] = {
     OPT("hip_trace", O_BOOL, trace), OPT("stage_threads", O_INT, stage_threads), OPT("stage_ch_mb", O_INT, stage_ch_mb), OPT("stream_prio", O_BOOL, stream_prio), OPT("numa_bind", O_BOOL, numa_bind), OPT("dev_cache_gb", O_INT, dev_cache_gb),
     OPT("gaf_piece_bytes", O_U64, gaf_piece_bytes), OPT("db_path_steps_max", O_U64, db_path_steps_max), OPT("db_groups", O_INT, db_groups), OPT("trio_path", O_STR, trio_path), OPT("trio_rows", O_STR, trio_rows), OPT("trio_two_pass", O_BOOL, trio_two_pass), OPT("uniq_hash", O_INT, uniq_hash),
     OPT("mask", O_STR, mask), OPT("row_sort", O_STR, row_sort), OPT("objective", O_STR, objective),
-    OPT("cov_general", O_BOOL, cov_general), OPT("cov_long", O_STR, cov_long), OPT("covl_shape", O_INT, covl_shape), OPT("cov_count", O_BOOL, cov_count), OPT("cov_self_clean", O_BOOL, cov_self_clean), OPT("cov_clean_async", O_INT, cov_clean_async), OPT("cov_arena_verify", O_BOOL, cov_arena_verify), OPT("ncs_no_prefix", O_BOOL, ncs_no_prefix), OPT("walk_sum_in_bin", O_BOOL, walk_sum_in_bin), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
+    OPT("cov_general", O_BOOL, cov_general), OPT("cov_long", O_STR, cov_long), OPT("covl_shape", O_INT, covl_shape), OPT("cov_count", O_BOOL, cov_count), OPT("cov_self_clean", O_BOOL, cov_self_clean), OPT("cov_clean_async", O_INT, cov_clean_async), OPT("cov_arena_verify", O_BOOL, cov_arena_verify), OPT("ncs_no_prefix", O_BOOL, ncs_no_prefix), OPT("ncs_prefix_min", O_INT, ncs_prefix_min), OPT("walk_sum_in_bin", O_BOOL, walk_sum_in_bin), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
     OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
     OPT("cov_ablate", O_U32, cov_ablate), OPT("ssn_ablate", O_U32, ssn_ablate), OPT("ssn_debug", O_BOOL, ssn_debug),

@@ -677,7 +677,7 @@ int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth) {
         if (db->cov_self_clean)
         hipLaunchKernelGGL(node_cov_stats_kernel<true>, dim3(nc.n), dim3(256), 0, ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
                            db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
-        else if (db->V && db->L / db->V >= 48 && !ctx->cfg.ncs_no_prefix)   // long nodes on average (chunk graphs of single-genome species among them): counts from a per-stretch prefix in LDS
+        else if (db->V && db->L / db->V >= (uint64_t)ctx->cfg.ncs_prefix_min && !ctx->cfg.ncs_no_prefix)   // long nodes on average (chunk graphs of single-genome species among them): counts from a per-stretch prefix in LDS
         hipLaunchKernelGGL((node_cov_stats_kernel<false, true>), dim3(nc.n), dim3(256), (size_t)4 * NCS_PWORDS * sizeof(uint32_t), ctx->stream, db->d_node_base.p, db->d_node_len.p, db->d_bases.p, db->d_bit_off.p,
                            db->d_full.p, db->d_bitmap.p, (double)min_depth, db->d_cov.p, lb->d_ab.p, (NodePartial *)lb->d_partial.p, (const uint32_t *)nc.d_chunk_sp.p, (const uint32_t *)nc.d_sp_off.p);
         else

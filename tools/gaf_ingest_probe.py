@@ -34,6 +34,11 @@ with tempfile.TemporaryDirectory(dir=root) as td:
             best[var].append(time.perf_counter() - t0)
             for k, v in sets:
                 eng.set_option(k, None)
+    # one more run with every launch clocked: the tokenizer's kernels, per run
+    eng.timing_enable(True); eng.timing_reset()
+    eng.load_reads_from_gaf(gp, columns=False); eng.sync()
+    print("kernels (ms per run):", {k: round(ms, 3) for k, (n, ms) in sorted(eng.timing_get().items(), key=lambda kv: -kv[1][1])[:8]})
+    eng.timing_enable(False)
     for var in variants:
         t = min(best[var])
         print("%-40s %.1f ms = %.1f GB/s (runs: %s)" % (var or "defaults", t * 1e3, nb / t / 1e9, " ".join("%.1f" % (x * 1e3) for x in best[var])))
