@@ -82,38 +82,6 @@ struct GafRaw {   // per raw line, before the comment / empty lines are squeezed
     uint8_t *mq, *fl, *valid;
 };
 
-// A line's bytes through an 8-byte window in registers (round 6): the text is read by aligned 8-byte loads, one per eight bytes a thread walks, instead of a
-// 1-byte load -- and its L1 round trip -- per byte; rounds 2-5 walked every line byte by byte (13.8 ms per 693-MB piece, as long as the piece's PCIe transfer).
-// The loads reach at most 7 bytes in front of / behind the range asked for: inside the allocation (the text buffers are 256-byte aligned and 16 bytes longer
-// than the text).
-struct TxtWin {
-    const uint8_t *txt;
-    uintptr_t cur = ~(uintptr_t)0;
-    uint64_t w = 0;
-    __device__ __forceinline__ explicit TxtWin(const uint8_t *t) : txt(t) {}
-    __device__ __forceinline__ void seek(uintptr_t a8) { if (a8 != cur) { w = *reinterpret_cast<const uint64_t *>(a8); cur = a8; } }
-    __device__ __forceinline__ uint32_t at(uint32_t pos) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(txt) + pos;
-        seek(a & ~(uintptr_t)7);
-        return (uint32_t)(w >> ((a & 7u) * 8u)) & 0xFFu;
-    }
-    // first position in [from, end) that holds byte `ch` (end: none), eight bytes per step: zero-byte test of w ^ ch-in-every-byte
-    __device__ __forceinline__ uint32_t find(uint32_t from, uint32_t end, uint32_t ch) {
-        const uint64_t pat = 0x0101010101010101ull * (uint64_t)ch;
-        uint32_t t = from;
-        while (t < end) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(txt) + t;
-            seek(a & ~(uintptr_t)7);
-            const uint32_t skip = (uint32_t)(a & 7u);
-            const uint64_t x = (w ^ pat) | ((1ull << (8u * skip)) - 1ull);          // the bytes in front of `t`: never a match
-            const uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // (the LOWEST set flag is exact: borrows only travel upwards)
-            if (z) { const uint32_t hit = t - skip + ((uint32_t)__builtin_ctzll(z) >> 3); return hit < end ? hit : end; }
-            t += 8u - skip;
-        }
-        return end;
-    }
-};
-
 __device__ __forceinline__ bool dev_parse_u32(TxtWin &tw, uint32_t b, uint32_t e, uint32_t &out) {
     if (b == e) return false;
     uint64_t v = 0;

@@ -137,13 +137,20 @@ __global__ void __launch_bounds__(256) filter_parse_kernel(const uint8_t *__rest
     while (le > p && is_ws(txt[le - 1])) --le;
     uint32_t fb[16], fe[16];
     int nf = 0;
-    uint32_t q = p;
-    for (;;) {                                          // the first 16 fields; more may follow
-        uint32_t t = q;
-        while (t < le && txt[t] != '\t') ++t;
-        fb[nf] = q; fe[nf] = t; ++nf;
-        if (t >= le || nf == 16) break;
-        q = t + 1;
+    {                                                   // the first 16 fields; more may follow.  Tabs found eight bytes per step (TxtWin), static indices
+        TxtWin tw(txt);
+        uint32_t q = p;
+        bool more = true;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            fb[f] = fe[f] = le;
+            if (more) {
+                const uint32_t t = tw.find(q, le, '\t');
+                fb[f] = q; fe[f] = t; nf = f + 1;
+                more = t < le;
+                q = t + 1;
+            }
+        }
     }
     uint8_t state = 0, pass = 0;
     uint64_t h = ((uint64_t)i + 1) * 0x9E3779B97F4A7C15ull, ident = 0;   // non-records: singletons in the sort (odd multiplier = bijection)
