@@ -1221,6 +1221,61 @@ __global__ void __launch_bounds__(256) popcount_kernel(uint64_t V, const uint64_
     }
 }
 
+// The same counts for graphs of LONG nodes (a single-genome species is a chain of 1024-bp chunks, build_eq1.rs:26-36: 32 words of the bit vector per
+// node): the per-thread loop above walks 64 different cache lines per iteration (11 ms at the reference-DB shape).  Here a wave takes 64 consecutive nodes,
+// reads the words of the whole stretch coalesced, keeps the number of set bits in front of every word in LDS (a DPP prefix sum per 64 words) and takes a
+// node's count as the difference of that prefix at its two ends -- node_cov_stats_kernel<.., LONGN>'s scheme (stage_lad.hip) for the stage call.
+constexpr uint32_t PCL_WORDS = 2304;   // words of one stretch the prefix holds; a longer stretch takes the per-lane loop
+__global__ void __launch_bounds__(256) popcount_long_kernel(uint64_t V, const uint64_t *__restrict__ bit_off, const uint32_t *__restrict__ full,
+                                                            const uint32_t *__restrict__ bitmap, uint32_t *__restrict__ cov) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_prefix[4 * PCL_WORDS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *pw = s_prefix + wave * PCL_WORDS;
+    const uint64_t n_str = (V + 63) / 64;
+    for (uint64_t st = (uint64_t)blockIdx.x * 4 + wave; st < n_str; st += (uint64_t)gridDim.x * 4) {
+        const uint64_t v = st * 64 + lane;
+        const bool in = v < V;
+        const uint64_t g0 = in ? bit_off[v] : 0ull, g1 = in ? bit_off[v + 1] : 0ull;
+        const uint64_t b0 = __shfl(g0, 0);                                             // (lane 0 is always inside)
+        const uint32_t last = (uint32_t)min((uint64_t)63, V - 1 - st * 64);
+        const uint64_t b1 = __shfl(g1, (int)last);
+        // (from the 16-byte boundary at or below the stretch's first word: four words per lane and load; what the last load reads beyond the stretch is
+        // inside the arena -- the flags follow the bit vector -- and never looked up)
+        const uint64_t wa = (b0 >> 5) & ~3ull, nw = b1 > b0 ? ((b1 - 1) >> 5) - wa + 1 : 0;
+        const bool coop = nw <= (uint64_t)PCL_WORDS && __builtin_amdgcn_ballot_w64(in && g1 - g0 > 64ull) != 0ull;   // (wave-uniform)
+        if (coop) {
+            uint32_t carry = 0;
+            for (uint32_t k = 0; k < (uint32_t)nw; k += 256) {
+                const uint32_t i = k + 4u * lane;
+                const uint4 x = i < (uint32_t)nw ? *reinterpret_cast<const uint4 *>(bitmap + wa + i) : make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t p0 = (uint32_t)__popc(x.x), p1 = p0 + (uint32_t)__popc(x.y), p2 = p1 + (uint32_t)__popc(x.z), p3 = p2 + (uint32_t)__popc(x.w);
+                const uint32_t incl = wave_incl_scan_dpp(p3);
+                const uint32_t base = carry + incl - p3;                                 // set bits in front of this lane's four words
+                if (i < (uint32_t)nw) *reinterpret_cast<uint4 *>(pw + i) = make_uint4(base, base + p0, base + p1, base + p2);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+        uint32_t c = 0;
+        if (in && g1 > g0) {
+            const uint64_t w0 = g0 >> 5, w1 = (g1 - 1) >> 5;
+            const uint32_t m0 = 0xFFFFFFFFu << (g0 & 31), m1 = 0xFFFFFFFFu >> (31 - (uint32_t)((g1 - 1) & 31));
+            if ((full[v >> 5] >> (uint32_t)(v & 31)) & 1u) c = (uint32_t)(g1 - g0);
+            else if (coop) c = (pw[w1 - wa] + (uint32_t)__popc(bitmap[w1] & m1)) - (pw[w0 - wa] + (uint32_t)__popc(bitmap[w0] & ~m0));
+            else if (w0 == w1) c = __popc(bitmap[w0] & m0 & m1);
+            else {
+                c = __popc(bitmap[w0] & m0);
+                for (uint64_t w = w0 + 1; w < w1; ++w) c += __popc(bitmap[w]);
+                c += __popc(bitmap[w1] & m1);
+            }
+        }
+        if (coop) __builtin_amdgcn_wave_barrier();                                      // (the prefix is rewritten by the next stretch)
+        if (in) cov[v] = c;
+    }
+}
+
 __global__ void __launch_bounds__(256) count_nonzero_words_kernel(const uint32_t *__restrict__ p, uint64_t n, unsigned long long *__restrict__ out) {
     unsigned long long c = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += p[i] != 0u;
@@ -1234,7 +1289,7 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     const uint64_t U = with_trio ? db->U : 0;
     // one arena, one memset: [bases V u64][trio_bases U u64][abort u64][bitmap words u32][full-node flags: 1 bit per node, padded by a window]
     const uint64_t fwords = (db->V + 4096 + 63) / 32 + 2;     // padded by the largest LDS window
-    const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = off_abort + 8, off_full = off_bm + words * 4,
+    const size_t off_trio = db->V * 8, off_abort = off_trio + (U ? U : 1) * 8, off_bm = (off_abort + 8 + 15) & ~(size_t)15 /* (16-byte loads of the bit vector) */, off_full = off_bm + words * 4,
                  total = off_full + fwords * 4;
     PTX_HIP(ctx, db->d_cov_arena.alloc(total));
     uint8_t *base = db->d_cov_arena.p;
@@ -1480,6 +1535,10 @@ int coverage_launch(Ctx *ctx, Db *db, Reads *rd, const uint8_t *d_active, bool w
     db->cov_count_pending = defer_count && db->V != 0;   // the resident step: node_stats_launch counts the covered bases in its own pass
     if (db->V && !defer_count) {
         KTimer t(ctx, "popcount_kernel");
+        if (db->L / db->V >= (uint64_t)ctx->cfg.ncs_prefix_min && !ctx->cfg.ncs_no_prefix)     // long nodes on average: counts from a per-stretch prefix in LDS
+            hipLaunchKernelGGL(popcount_long_kernel, dim3(grid_for((db->V + 63) / 64, 4, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, db->V,
+                               db->d_bit_off.p, db->d_full.p, db->d_bitmap.p, db->d_cov.p);
+        else
         hipLaunchKernelGGL(popcount_kernel, dim3(grid_for(db->V, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, db->V,
                            db->d_bit_off.p, db->d_full.p, db->d_bitmap.p, db->d_cov.p);
     }

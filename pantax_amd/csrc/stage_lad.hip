@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256) node_stats_kernel(const uint32_t *__restr
 // the words of its whole 64-node stretch coalesced, keeps the running count of set bits in front of every word in LDS (a DPP prefix sum per 64 words),
 // and a node's covered bases are the difference of that prefix at its two ends -- two LDS reads per node, whatever its length.
 constexpr uint32_t NCS_PWORDS = 2304;   // words of one stretch the prefix holds (64 nodes x 1152 bases); a longer stretch takes the per-lane loop
-extern __shared__ uint32_t s_ncs_prefix[];
+extern __shared__ __attribute__((aligned(16))) uint32_t s_ncs_prefix[];
 template <bool CLEAN, bool LONGN = false>
 __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__restrict__ node_base, const uint32_t *__restrict__ node_len,
                                                              unsigned long long *bases, const uint64_t *__restrict__ bit_off,
@@ -547,17 +547,19 @@ __global__ void __launch_bounds__(256) node_cov_stats_kernel(const uint32_t *__r
             if constexpr (LONGN) {
                 const uint64_t b0 = sb[r], b1 = sb[r + 1];
                 const bool has_long = __builtin_amdgcn_ballot_w64(l[r] > 64u) != 0ull;
-                wa = b0 >> 5;
+                wa = (b0 >> 5) & ~3ull;                                  // (from a 16-byte boundary: four words per lane and load; the tail read beyond the stretch is inside the arena)
                 const uint64_t nw = b1 > b0 ? ((b1 - 1) >> 5) - wa + 1 : 0;
                 coop = has_long && nw <= (uint64_t)NCS_PWORDS;
                 if (coop) {
                     uint32_t *pw = s_ncs_prefix + wave * NCS_PWORDS;
                     uint32_t carry = 0;
-                    for (uint32_t k = 0; k < (uint32_t)nw; k += 64) {
-                        const uint32_t i = k + lane;
-                        const uint32_t pc = i < (uint32_t)nw ? (uint32_t)__popc(bitmap[wa + i]) : 0u;
-                        const uint32_t incl = wave_incl_scan_dpp(pc);
-                        if (i < (uint32_t)nw) pw[i] = carry + incl - pc;          // set bits in front of word i of the stretch
+                    for (uint32_t k = 0; k < (uint32_t)nw; k += 256) {
+                        const uint32_t i = k + 4u * lane;
+                        const uint4 x = i < (uint32_t)nw ? *reinterpret_cast<const uint4 *>(bitmap + wa + i) : make_uint4(0u, 0u, 0u, 0u);
+                        const uint32_t p0 = (uint32_t)__popc(x.x), p1 = p0 + (uint32_t)__popc(x.y), p2 = p1 + (uint32_t)__popc(x.z), p3 = p2 + (uint32_t)__popc(x.w);
+                        const uint32_t incl = wave_incl_scan_dpp(p3);
+                        const uint32_t base = carry + incl - p3;              // set bits in front of this lane's four words
+                        if (i < (uint32_t)nw) *reinterpret_cast<uint4 *>(pw + i) = make_uint4(base, base + p0, base + p1, base + p2);
                         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");

@@ -187,6 +187,29 @@ def test_reference_db_shape_every_species_against_oracle(eng, tmp_path_factory):
     finally:
         eng.set_option("ncs_no_prefix", None)
     assert sp_rows_b == sp_rows and st_rows_b == st_rows
+    # the STAGE call's covered bases (popcount pass -- what the file seam runs; long nodes: popcount_long_kernel's per-stretch prefix) against the plain
+    # per-thread loop, and against the oracle for a sample of the species (every twentieth: single-genome chains and pangenome graphs)
+    from oracle import oracle as orc
+    from tests.helpers import select_reads
+    sp_of_read = eng.rcls_profile()[0]
+    eng.trio_nodes_info(fetch=False)
+    bases_a, cov_a, _, _ = eng.get_node_abundances()
+    eng.set_option("ncs_no_prefix", "1")
+    try:
+        bases_b, cov_b, _, _ = eng.get_node_abundances()
+    finally:
+        eng.set_option("ncs_no_prefix", None)
+    assert np.array_equal(cov_a, cov_b) and np.array_equal(bases_a, bases_b) and int(cov_a.sum()) > 0
+    checked = 0
+    for si in range(0, len(sset.species), 20):
+        g = sset.species[si]
+        G = orc.Graph(g.node_len, g.path_off, g.path_nodes)
+        so, nid, ps, pe = select_reads(sset.reads, np.nonzero(sp_of_read == si)[0])
+        b_ref, c_ref = orc.node_coverage(G, orc.TrioTable(G), g.range_start, so, nid, ps, pe)[:2]
+        lo, hi = int(eng.node_off[si]), int(eng.node_off[si + 1])
+        assert np.array_equal(cov_a[lo:hi], c_ref) and np.array_equal(bases_a[lo:hi], b_ref)
+        checked += int(c_ref.sum() > 0)
+    assert checked >= 5
     assert [r[0] for r in sp_rows] == [r[0] for r in exp_species]
     for r, e in zip(sp_rows, exp_species):
         assert r[1] == pytest.approx(e[1], rel=1e-12) and r[2] == pytest.approx(e[2], rel=1e-12)
