@@ -376,6 +376,17 @@ def test_device_gaf_tokenizer_equals_host_tokenizer(eng, tmp_path, piece, set_op
         for k in host:
             assert np.array_equal(host[k], dev[k]), (p.name, k)
             assert np.array_equal(want[k], dev[k]), (p.name, "oracle", k)
+    # every alignment of the lines against the tokenizer's 8-byte window (TxtWin): the quirks behind a comment line of 0 .. 16 bytes, plus fields of 7, 8 and
+    # 9 bytes, empty fields side by side and a tab as a line's last byte
+    body = p2.read_bytes() + b"\nq1\t1234567\t0\t1\t+\t>12345678>123456789\t12345678\t1\t123456789\t1\t1\t60\n" \
+                             b"q2\t\t\t\t\t\t\t\t\t\t\t\nq3\t8\t0\t8\t+\t>1\t9\t0\t8\t8\t8\t60\t\nq4\t8\t0\t8\t+\t>1>2>3>4>5>6>7>8>9>10>11>12>13>14>15>16>17\t9\t0\t8\t8\t8\t0"
+    for k in range(17):
+        pk = tmp_path / ("shift%d.gaf" % k)
+        pk.write_bytes(b"@" + b"x" * k + b"\n" + body)
+        dev = pio.load_gaf(pk, engine=eng)
+        want = gaf_reader.packed(pk.read_bytes())
+        for key in want:
+            assert np.array_equal(want[key], dev[key]), (k, key)
     if piece == "97":
         from pantax_amd.engine import PantaxHipError
         with pytest.raises(PantaxHipError):
@@ -525,6 +536,22 @@ def test_device_gaf_filter_edge_inputs(eng, tmp_path):
     junk = tmp_path / "junk.gaf"
     junk.write_bytes(b"\n\n@x\nnot\ta\trecord\n")
     assert eng.gaf_filter(str(junk)) == (4, 0, 0)
+    # every alignment of the lines against the field splitter's 8-byte window: the same records behind a first line of 0 .. 8 bytes
+    from oracle import oracle as orc
+    from tests.helpers import make_longread_gaf
+    base = make_longread_gaf(9, 60)
+    for k in range(9):
+        txt = b"#" * k + b"\n" + base
+        gp = tmp_path / ("shift%d.gaf" % k)
+        gp.write_bytes(txt)
+        n_lines, n_rec, n_written = eng.gaf_filter(str(gp))
+        keep, nrec = orc.gaf_filter(txt)
+        lines = txt.split(b"\n")
+        if txt.endswith(b"\n"):
+            lines = lines[:-1]
+        assert (n_lines, n_rec, n_written) == (len(lines), nrec, int(keep.sum()))
+        exp = b"".join((lines[i][:-1] if lines[i].endswith(b"\r") else lines[i]) + b"\n" for i in np.nonzero(keep)[0])
+        assert (tmp_path / ("shift%d_filtered.gaf" % k)).read_bytes() == exp
     with pytest.raises(PantaxHipError):
         eng.gaf_filter(str(tmp_path / "missing.gaf"))
 
