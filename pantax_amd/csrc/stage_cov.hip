@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
     uint32_t c_code[U], c_id[U], c_gs[U];      // PF2: this round's level 1 ...
     uint4 c_rr[U];                             // ... and level 2, requested a round ago
     uint2 c_sr[U];
+    bool c_run[U];                             // ... and whether the group is this kernel's at all (wave-uniform: decided once, when its records are requested)
+#pragma unroll
+    for (int u = 0; u < U; ++u) c_run[u] = false;
     if constexpr (PF2) {
         const uint32_t gw0 = g0 + (uint32_t)(wave * U), gw1 = gw0 + (uint32_t)(WAVES * U);
 #pragma unroll
@@ -295,6 +298,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             const uint32_t sl = slot_in_group(c_gs[u], c_code[u], lane);
             const uint32_t slot = (pad0 | !run0) ? (c_gs[u] == NO_SLOT ? 0u : c_gs[u]) : sl;
             c_rr[u] = read_rec[slot]; c_sr[u] = slot_rec[slot];
+            c_run[u] = run0;
         }
     }
 #pragma unroll 1
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
             uint32_t m_code[U], m_id[U], m_gs[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                run[u] = gw + (uint32_t)u < n_groups;
+                run[u] = c_run[u];
                 code[u] = c_code[u]; id[u] = c_id[u]; gs[u] = c_gs[u]; rr[u] = c_rr[u]; sr[u] = c_sr[u];
                 const uint32_t g = g2 + (uint32_t)u < n_groups ? g2 + (uint32_t)u : gw;
                 const uint64_t t = (uint64_t)g * 64 + lane;
@@ -323,6 +327,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
                 const uint32_t sl = slot_in_group(n_gs[u], n_code[u], lane);
                 const uint32_t slot = (padn | !runn) ? (n_gs[u] == NO_SLOT ? 0u : n_gs[u]) : sl;
                 c_rr[u] = read_rec[slot]; c_sr[u] = slot_rec[slot];
+                c_run[u] = runn;
                 c_code[u] = n_code[u]; c_id[u] = n_id[u]; c_gs[u] = n_gs[u];
                 n_code[u] = m_code[u]; n_id[u] = m_id[u]; n_gs[u] = m_gs[u];
             }
@@ -354,9 +359,11 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_fast_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             pad[u] = code[u] == STEP_PAD;
-            const bool has_long = any1(!pad[u] & ((code[u] & STEP_LONG) != 0u));
-            // nothing here / a group of the OTHER instantiation (steps of a longer walk: LONG's; none: the plain one's, unless LONG takes every group)
-            run[u] = run[u] & any1(!pad[u]) & (LONG ? (has_long | (only_long == 0u)) : !has_long);
+            if constexpr (!PF2) {
+                const bool has_long = any1(!pad[u] & ((code[u] & STEP_LONG) != 0u));
+                // nothing here / a group of the OTHER instantiation (steps of a longer walk: LONG's; none: the plain one's, unless LONG takes every group)
+                run[u] = run[u] & any1(!pad[u]) & (LONG ? (has_long | (only_long == 0u)) : !has_long);
+            }
             const uint32_t sl = slot_in_group(gs[u], code[u], lane);
             const uint32_t slot = (pad[u] | !run[u]) ? (gs[u] == NO_SLOT ? 0u : gs[u]) : sl;
             if constexpr (!PF2) { rr[u] = read_rec[slot]; sr[u] = slot_rec[slot]; }     // (PF2: requested a round ago)

@@ -1,3 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -m gpu -k "tokenizer or filter_edge" 2>&1 | tail -3
+for wl in cfg4 cfg3; do
+echo "$wl: $(timeout 600 python tools/stage_probe.py $wl 4 2>&1 | tail -1 | cut -c1-200)"
+done
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
