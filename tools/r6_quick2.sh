@@ -1,6 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for wl in cfg4 cfg3; do
-echo "$wl: $(timeout 600 python tools/stage_probe.py $wl 4 2>&1 | tail -1 | cut -c1-200)"
-done
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+timeout 600 python tools/stress.py 1 712253 2>&1 | tail -2 | cut -c1-300
