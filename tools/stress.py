@@ -106,7 +106,7 @@ for ci in range(n_cfg):
                     if ev is None or gv is None or isinstance(ev, bool):
                         assert gv == ev, (s, key, gv, ev)
                     elif abs(gv - ev) > 1e-7 * max(1.0, abs(ev)) + 1e-9:
-                        # strain_cov_diff = round2(|x - f| / (x + f)) (profile.rs:1245-1247): a raw value within 1e-7 of a rounding boundary rounds
+                        # strain_cov_diff = round2(|x - f| / (x + f)) (profile.rs:1240-1242): a raw value within 1e-7 of a rounding boundary rounds
                         # either way with the last bits of the LP solution x -- one step apart, the solution itself equal to 1e-7 (checked above)
                         if key == "strain_cov_diff" and abs(gv - ev) <= 0.0100001 and em["first_sol"] is not None and em["uniq_trio_cov_mean"]:
                             raw = abs(em["first_sol"] - em["uniq_trio_cov_mean"]) / (em["first_sol"] + em["uniq_trio_cov_mean"]) * 100.0
