@@ -1,7 +1,6 @@
 #!/bin/bash
-# the whole GPU suite + the default bench run on the round's last code
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6_records_pytest.log 2>&1
-echo "pytest exit $?"; tail -2 gpurun_out/r6_records_pytest.log
-timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/r6_records_detail_default.json > gpurun_out/r6_records_bench_default.json 2> gpurun_out/r6_records_bench_default.err
-echo "default bench exit $?"; python3 tools/bench_summary.py gpurun_out/r6_records_bench_default.json | cut -c1-400 | head -12
+STRESS_REFDB=1 timeout 2400 python tools/stress.py 300 760000 > gpurun_out/r6_stress_refdb.log 2>&1
+tail -1 gpurun_out/r6_stress_refdb.log; grep "^FAIL" gpurun_out/r6_stress_refdb.log | head -5 | cut -c1-300
+STRESS_REFDB=1 PANTAX_NCS_NO_PREFIX=1 timeout 2400 python tools/stress.py 100 770000 > gpurun_out/r6_stress_refdb_noprefix.log 2>&1
+tail -1 gpurun_out/r6_stress_refdb_noprefix.log

@@ -9,6 +9,7 @@ run cleanasync ${3:-400} 720000 PANTAX_COV_CLEAN_ASYNC=1 PANTAX_COV_ARENA_VERIFY
 run general ${4:-200} 730000 PANTAX_COV_GENERAL=1
 run highs ${5:-200} 740000 STRESS_HIGHS=1
 run wide 30 750000 STRESS_WIDE=1
+run refdb ${6:-60} 760000 STRESS_REFDB=1
 exit 0
 fi
 run default 1500 610000 X=1

@@ -28,8 +28,14 @@ for ci in range(n_cfg):
     fc = 0.08 if sem else 0.46
     tag = "cfg %d: S=%d H=%d R=%d L=%d long=%d adv=%g pf=%g sample=%d images=%d highs=%d" % (seed0 + ci, S, H, R, L, lr, adv, pf, sample, via_images, sem)
     try:
-        sset = synth.make_set(seed0 + ci, S, H, R if not lr else max(50, R // 40), L, long_reads=lr, adversarial_frac=adv, present_frac=pf,
-                              single_strain_every=int(rng.choice([0, 2, 3])))
+        if os.environ.get("STRESS_REFDB"):   # the shape of the shipped DB in small: single-genome chains of 1024-bp chunks beside 2 .. 10-strain graphs (the long-node kernels)
+            sset = synth.RefDbSet(seed0 + ci, max(R, 20000), genome_len=int(rng.integers(40_000, 400_000)), scale=float(rng.choice([0.002, 0.004])),
+                                  present_frac=float(rng.choice([0.2, 0.6])), threads=4).make()
+            S = len(sset.species)
+            tag += " refdb S=%d" % S
+        else:
+            sset = synth.make_set(seed0 + ci, S, H, R if not lr else max(50, R // 40), L, long_reads=lr, adversarial_frac=adv, present_frac=pf,
+                                  single_strain_every=int(rng.choice([0, 2, 3])))
         rd = sset.reads
         flags = (rng.random(rd.n_reads) < float(rng.choice([0.0, 0.05]))).astype(np.uint8)
         eng.upload_db(sset.species)
