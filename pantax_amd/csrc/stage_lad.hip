@@ -154,12 +154,25 @@ __device__ __forceinline__ double mdotw(const uint64_t *mw, const double *x) {  
     for (int w = 0; w < NW; ++w) { uint64_t m = mw[w]; while (m) { int j = __ffsll((long long)m) - 1; s += x[64 * w + j]; m &= m - 1; } }
     return s;
 }
+// s += x[base + j] over the set bits j of m in ascending order, FOUR loads in flight (the additions keep their order: same bits as one at a time)
+__device__ __forceinline__ void mdot_word4(uint64_t m, const double *x, int base, double &s) {
+    while (m) {
+        int j[4]; bool on[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { on[r] = m != 0ull; j[r] = on[r] ? __ffsll((long long)m) - 1 : 0; m &= m - 1; }   // (0 & anything = 0: an empty m stays empty)
+        double t[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = x[base + j[r]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (on[r]) s += t[r];
+    }
+}
 template <int NW>   // NW == 0: nw words, a run-time number
 __device__ __forceinline__ double mdotx(const uint64_t *mw, int nw, const double *x) {
     if constexpr (NW != 0) return mdotw<NW>(mw, x);
     else {
         double s = 0.0;
-        for (int w = 0; w < nw; ++w) { uint64_t m = mw[w]; while (m) { int j = __ffsll((long long)m) - 1; s += x[64 * w + j]; m &= m - 1; } }
+        for (int w = 0; w < nw; ++w) mdot_word4(mw[w], x, 64 * w, s);
         return s;
     }
 }
@@ -1771,12 +1784,23 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
                 q_g[tid] = 0;
             }
         } else {
-            // W lives in global memory: a wave per row, lanes along the row (coalesced), instead of a thread per row
-            for (int j = tid >> 6; j < p; j += LAD_BLOCK / 64) {
-                double v = 0.0;
-                for (int i = tid & 63; i < p; i += 64) v += W[j * ps + i] * q_c[i];
-                v = wave_reduce(v, [](double x_, double y_) { return x_ + y_; });
-                if ((tid & 63) == 0) { q_x[j] = v; q_g[j] = 0; }
+            // W lives in global memory: a wave per row, lanes along the row (coalesced), instead of a thread per row -- four rows of a wave in flight
+            // (round 6: their loads overlap; every row's sum keeps its order of additions: same bits)
+            constexpr int XR = 4;
+            for (int j0 = (tid >> 6) * XR; j0 < p; j0 += (LAD_BLOCK / 64) * XR) {
+                double v[XR];
+#pragma unroll
+                for (int r = 0; r < XR; ++r) v[r] = 0.0;
+                for (int i = tid & 63; i < p; i += 64) {
+                    const double ci = q_c[i];
+#pragma unroll
+                    for (int r = 0; r < XR; ++r) if (j0 + r < p) v[r] += W[(j0 + r) * ps + i] * ci;
+                }
+#pragma unroll
+                for (int r = 0; r < XR; ++r) {
+                    const double vr = wave_reduce(v[r], [](double x_, double y_) { return x_ + y_; });
+                    if ((tid & 63) == 0 && j0 + r < p) { q_x[j0 + r] = vr; q_g[j0 + r] = 0; }
+                }
             }
         }
         __syncthreads();
@@ -1813,7 +1837,19 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
         // ---- multipliers lam_i = -g . W[:,i]; steepest-edge choice of the constraint to relax
         for (int i = tid; i < p; i += LAD_BLOCK) {
             double sdot = 0.0, nrm = 0.0;
-            for (int j = 0; j < p; ++j) { double w = W[j * ps + i]; sdot += (double)q_g[j] * w; nrm += w * w; }
+            if constexpr (NW == 1) {
+                for (int j = 0; j < p; ++j) { double w = W[j * ps + i]; sdot += (double)q_g[j] * w; nrm += w * w; }
+            } else {   // W in global memory: eight rows' loads in flight, the sums in the same order (same bits)
+                int j = 0;
+                for (; j + 8 <= p; j += 8) {
+                    double w8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) w8[r] = W[(j + r) * ps + i];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { sdot += (double)q_g[j + r] * w8[r]; nrm += w8[r] * w8[r]; }
+                }
+                for (; j < p; ++j) { double w = W[j * ps + i]; sdot += (double)q_g[j] * w; nrm += w * w; }
+            }
             double lam = -sdot; nrm = sqrt(nrm);
             double deriv = 0.0; int dir = 0; int ty = q_type[i];
             if (ty == C_PAT) {
@@ -2252,9 +2288,18 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
                         while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * ps + c_]; }
                     } else {
                         const uint64_t *mb = patw + (size_t)((uint32_t)q_jk[best] - k0) * nw;
-                        for (int w = 0; w < nw; ++w) {
+                        for (int w = 0; w < nw; ++w) {     // four rows' loads in flight, added in bit order (same bits as one at a time)
                             uint64_t bits = mb[w];
-                            while (bits) { const int j = 64 * w + __ffsll((long long)bits) - 1; bits &= bits - 1; y += W[j * ps + c_]; }
+                            while (bits) {
+                                int jj[4]; bool on[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { on[r] = bits != 0ull; jj[r] = on[r] ? 64 * w + __ffsll((long long)bits) - 1 : 0; bits &= bits - 1; }
+                                double t4[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) t4[r] = W[jj[r] * ps + c_];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) if (on[r]) y += t4[r];
+                            }
                         }
                     }
                 } else y = W[q_jk[best] * ps + c_];
@@ -2266,9 +2311,17 @@ __device__ __forceinline__ void lad_solve_body(const LadArgs &A, LadLds<PS, NW> 
             if (fabs(alpha) < 1e-7) refactor = true;   // (block-uniform: read from LDS after the barrier)
             else {
                 const double ainv = 1.0 / alpha;
-                for (int i = tid; i < p * p; i += LAD_BLOCK) {
-                    const int j = i / p, cc = i % p;
-                    W[j * ps + cc] -= q_score[j] * (q_fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
+                if constexpr (NW == 1) {
+                    for (int i = tid; i < p * p; i += LAD_BLOCK) {
+                        const int j = i / p, cc = i % p;
+                        W[j * ps + cc] -= q_score[j] * (q_fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
+                    }
+                } else {   // W in global memory: a wave per row, lanes along it -- coalesced, no divisions; every element's arithmetic is the line above
+                    for (int j = tid >> 6; j < p; j += LAD_BLOCK / 64) {
+                        const double sj = q_score[j];
+#pragma unroll 4
+                        for (int cc = tid & 63; cc < p; cc += 64) W[j * ps + cc] -= sj * (q_fac[cc] - (cc == best ? 1.0 : 0.0)) * ainv;
+                    }
                 }
                 __syncthreads();
             }
