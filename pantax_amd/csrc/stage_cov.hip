@@ -1349,7 +1349,8 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
 // The resident step's zero fill of the coverage arena, taken off the main stream (round 6): enqueued on the side stream behind everything the main stream
 // holds so far (the arena's last readers among it), it runs beside what the main stream gets next -- strain_enqueue calls it in front of the LPs, one
 // workgroup per species, which leave most of the memory system idle (behind the node statistics, i.e. beside the row sort's bandwidth-bound passes: no
-// gain; in two bursts, one beside the sort's sampling kernels: less gain; behind the LPs: a third of the gain).  The next coverage_prepare waits for
+// gain; in two bursts, one beside the sort's sampling kernels: less gain; behind the LPs: a third of the gain; at the start of the NEXT step beside its binning
+// pass, which waits for gathers at 0.3 of the HBM rate: the same 0.3 ms as here -- a streaming fill slows a latency-bound neighbour by what it takes).  The next coverage_prepare waits for
 // ev_cov_clean.
 int coverage_arena_clean_async(Ctx *ctx, Db *db) {
     if (!db->d_cov_arena.p || !db->cov_arena_total || !ctx->stream2) return 0;
