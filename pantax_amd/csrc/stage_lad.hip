@@ -280,6 +280,39 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
         if (qn) drain(qn);
         n_c = nw;
     };
+#ifndef HS_NO_TRANSPOSE
+    if (in_reg && Hs > (uint32_t)HS_SLAB) {
+        // 17 .. 64 haplotypes (round 6): LANE h owns haplotype h.  The entries that count are handed round one by one (two readlanes for the value, one for the
+        // owner: scalar broadcasts) and the owner's lane adds -- in entry order, a fixed order of additions; no slabs that read the compacted rows again, no
+        // reductions at the end.  (-DHS_NO_TRANSPOSE: the slabs of 16 below, as up to 16 haplotypes.)
+        double acc_t = 0.0;
+        uint32_t cnt_t = 0;
+        auto sink_t = [&](uint32_t h, double val, bool flag) {
+            unsigned long long todo = __ballot(flag);
+            while (todo) {
+                const int e = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                todo &= todo - 1ull;
+                const uint32_t he = (uint32_t)__builtin_amdgcn_readlane((int)h, e);
+                const double ve = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(val), e), __builtin_amdgcn_readlane(__double2loint(val), e));
+                if ((uint32_t)lane == he) { acc_t += ve; ++cnt_t; }
+            }
+        };
+        if (PASS == 0) compact_rows([&](uint32_t h, double x, bool v) { sink_t(h, v ? x : 0.0, v); });
+        else
+            for (uint32_t r0 = 0; r0 < n_c; r0 += 64) {
+                const uint32_t i = r0 + (uint32_t)lane;
+                const bool v = i < n_c;
+                const uint32_t h = v ? (uint32_t)chh[ch.y + i] : 0xFFFFFFFFu;
+                const double x = v ? cx[ch.y + i] : 0.0;
+                double val; bool flag;
+                pass_value(h, x, v, val, flag);
+                sink_t(h, val, flag);
+            }
+        if ((uint32_t)lane < Hs) part[ch.w + (uint32_t)lane] = HapAcc{acc_t, cnt_t, 0u};
+        if (PASS == 0 && lane == 0) cn[blockIdx.x] = n_c;
+        return;
+    }
+#endif
     if (in_reg) {
         for (uint32_t slab = 0; slab * HS_SLAB < Hs; ++slab) {
             double a_[HS_SLAB];
