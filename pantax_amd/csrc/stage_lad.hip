@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
         n_c = nw;
     };
 #ifndef HS_NO_TRANSPOSE
-    if (in_reg && Hs > (uint32_t)HS_SLAB) {
+    if (in_reg && Hs > (uint32_t)HS_SLAB) {                   // (up to 16 haplotypes the one slab below is faster: 1.02 against 1.46 ms at ten)
         // 17 .. 64 haplotypes (round 6): LANE h owns haplotype h.  The entries that count are handed round one by one (two readlanes for the value, one for the
         // owner: scalar broadcasts) and the owner's lane adds -- in entry order, a fixed order of additions; no slabs that read the compacted rows again, no
         // reductions at the end.  (-DHS_NO_TRANSPOSE: the slabs of 16 below, as up to 16 haplotypes.)
@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
                 const uint32_t j = h - slab * HS_SLAB;                         // (a lane without an entry: no slab holds it)
 #pragma unroll
                 for (int k = 0; k < HS_SLAB; ++k) {
+                    if (slab * HS_SLAB + (uint32_t)k >= Hs) break;                // (chunk-uniform) haplotypes the species does not have: 2.09 -> 1.62 ms at the reference-DB shape
                     const bool m_ = j == (uint32_t)k;
                     a_[k] += m_ ? val : 0.0;
                     c_[k] += (m_ && flag) ? 1u : 0u;
@@ -346,6 +347,7 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             }
 #pragma unroll
             for (int k = 0; k < HS_SLAB; ++k) {
+                if (slab * HS_SLAB + (uint32_t)k >= Hs) break;
                 const double v = wave_reduce(a_[k], [](double x, double y) { return x + y; });
                 const uint32_t c = wave_reduce(c_[k], [](uint32_t x, uint32_t y) { return x + y; });
                 const uint32_t hh = slab * HS_SLAB + (uint32_t)k;
