@@ -263,19 +263,31 @@ __global__ void __launch_bounds__(64) hap_rows_pass_kernel(const uint4 *__restri
             sink(h, x, v);
             qh = (qh + nb) & 127u; qn -= nb; nw += nb;
         };
-        for (uint32_t r0 = ch.y; r0 < ch.z; r0 += 64) {
-            const uint32_t row = r0 + (uint32_t)lane;
-            const unsigned long long t = row < ch.z ? tb[row] : 0ull;
-            const bool nz = (long long)t > 0;
-            // the resident step: pass 0 is the only reader of the coverage pass's trio_bases -- it leaves them zeroed for the next step's pass (round 6)
-            if (PASS == 0 && clean && t != 0ull) tb[row] = 0ull;
-            const unsigned long long bal = __ballot(nz);
-            if (nz) {
-                const uint32_t idx = (qh + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) & 127u;
-                s_qrow[idx] = row; s_qtb[idx] = t;
+#ifndef HS_TB_AHEAD
+#define HS_TB_AHEAD 4
+#endif
+        constexpr int TA = HS_TB_AHEAD;                        // stretches of 64 rows whose abundances are requested together (one at a time: a round trip per stretch)
+        for (uint32_t rb = ch.y; rb < ch.z; rb += 64u * TA) {
+            unsigned long long tq[TA];
+#pragma unroll
+            for (int q = 0; q < TA; ++q) { const uint32_t row = rb + 64u * (uint32_t)q + (uint32_t)lane; tq[q] = row < ch.z ? tb[row] : 0ull; }
+#pragma unroll
+            for (int q = 0; q < TA; ++q) {
+                const uint32_t r0 = rb + 64u * (uint32_t)q;
+                if (r0 >= ch.z) break;                             // (chunk-uniform)
+                const uint32_t row = r0 + (uint32_t)lane;
+                const unsigned long long t = tq[q];
+                const bool nz = (long long)t > 0;
+                // the resident step: pass 0 is the only reader of the coverage pass's trio_bases -- it leaves them zeroed for the next step's pass (round 6)
+                if (PASS == 0 && clean && t != 0ull) tb[row] = 0ull;
+                const unsigned long long bal = __ballot(nz);
+                if (nz) {
+                    const uint32_t idx = (qh + qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) & 127u;
+                    s_qrow[idx] = row; s_qtb[idx] = t;
+                }
+                qn += (uint32_t)__popcll(bal);
+                if (qn >= 64u) drain(64u);
             }
-            qn += (uint32_t)__popcll(bal);
-            if (qn >= 64u) drain(64u);
         }
         if (qn) drain(qn);
         n_c = nw;
