@@ -869,10 +869,12 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
             const uint32_t prev = __shfl_up(slot[u], 1);
             const bool head = lane == 0 || prev != slot[u];
             const unsigned long long heads = __ballot(head);
-            uint32_t incl = nl[u];
             const int start = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));   // lane of my run's head
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane - d >= start) incl += up; }
+            // (one DPP prefix sum of the wave minus its value in front of the run's head -- 64 lengths stay far below 2^32 --; a segmented shuffle scan of six
+            // bpermutes stood here until round 6)
+            const uint32_t sc = wave_incl_scan_dpp(nl[u]);
+            const uint32_t front = __shfl(sc, start > 0 ? start - 1 : 0);
+            const uint32_t incl = sc - (start > 0 ? front : 0u);
             const unsigned long long after = heads & ~((2ull << lane) - 1ull);
             const bool tail = after ? (lane + 1 == __builtin_ctzll(after)) : lane == 63;
             if (tail && slot[u] != NO_SLOT && incl) atomicAdd(&long_sum[slot[u]], incl);
