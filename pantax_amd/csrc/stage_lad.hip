@@ -2644,9 +2644,14 @@ __global__ void __launch_bounds__(256) objective_rows_kernel(const int32_t *__re
         for (uint32_t q = threadIdx.x; q <= K; q += 256) s_ps[q] = pat_start[k0 + q];
         for (uint32_t q = threadIdx.x; q < K; q += 256) { s_p1[q] = pred1[k0 + q]; s_p2[q] = two ? pred2[k0 + q] : 0.0; }
         __syncthreads();
+        uint32_t a = 0;                                                   // last pattern that starts at or before row i: searched for the thread's first row,
+        {                                                                 // walked on from there (its rows ascend: round 6 -- a search per row was eight dependent LDS reads)
+            const uint32_t i0 = lo + threadIdx.x;
+            uint32_t b = K;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (s_ps[m] <= i0) a = m; else b = m; }
+        }
         for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-            uint32_t a = 0, b = K;                                        // last pattern that starts at or before row i
-            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (s_ps[m] <= i) a = m; else b = m; }
+            while (a + 1 < K && s_ps[a + 1] <= i) ++a;
             const double av = row_a[i];
             acc1 += fabs(s_p1[a] - av);
             if (two) acc2 += fabs(s_p2[a] - av);
