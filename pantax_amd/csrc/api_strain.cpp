@@ -148,10 +148,12 @@ int strain_enqueue(Ctx *ctx, Db *db, const pantax_hip_strain_config *cfg, const 
     const bool clocked = ctx->timing && ctx->timing_filter.empty();     // (named launches only: the fill overlaps, unbracketed)
     const bool clean_async = db->cov_count_pending && !ctx->cfg.cov_self_clean && !clocked &&
                              (ctx->cfg.cov_clean_async > 0 || (ctx->cfg.cov_clean_async < 0 && db->cov_arena_total >= ((size_t)1 << 30)));
+    // the species flags the coverage pass of THIS step masked its reads with (the resident step: cov_count_pending): the two statistics passes skip what it skipped
+    const uint8_t *skip_absent = db->cov_count_pending ? d_active : nullptr;
     db->cov_self_clean = db->cov_count_pending && ctx->cfg.cov_self_clean && db->U != 0;
-    PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean));                 // a9 statistics
+    PTX_TRY(hap_trio_stats_launch(ctx, db, db->d_hap_nnz, db->d_hap_mean, skip_absent));                 // a9 statistics
     mark();
-    PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth));                               // abundances + per-species stats
+    PTX_TRY(node_stats_launch(ctx, db, &lb, cfg->min_depth, skip_absent));                               // abundances + per-species stats
     if (db->cov_self_clean) { db->cov_arena_clean = true; db->cov_done = false; db->cov_self_clean = false; }   // (cov_done: the arena no longer holds a coverage result)
     mark();
     PTX_TRY(row_sample_apply(ctx, db, &lb, cfg->sample_nodes));

@@ -160,6 +160,7 @@ struct CtxConfig {
     int tv_u = 4, tv_rounds = 4, tf_u = 8, tf_rounds = 1, rows_u = 1, tb_slots = 256, trio_xcd = 3, cov_shape = -1, covf_shape = -1, cov_xcd = 0, group_bucket_bits = 0;
     uint32_t tv_ablate = 0, cov_ablate = 0, ssn_ablate = 0;
     bool trio_two_pass = false;      // every build through records + prefix + rows kernel, as a db's first build (tests, measurements)
+    bool no_absent_skip = false;     // the statistics / histogram passes of the step read the species the species level dropped like the others (tests compare, measurements)
     bool ssn_debug = false, scan_no_huge = false, flag_rank_chained = false, ratio_kernel = false, mask_pass = false, trio_free_at_filter = false,
          trio_after_step = false;
 };

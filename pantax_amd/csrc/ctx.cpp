@@ -100,7 +100,7 @@ const OptDesc OPTIONS[] = {
     OPT("cov_general", O_BOOL, cov_general), OPT("cov_long", O_STR, cov_long), OPT("covl_shape", O_INT, covl_shape), OPT("cov_count", O_BOOL, cov_count), OPT("cov_self_clean", O_BOOL, cov_self_clean), OPT("cov_clean_async", O_INT, cov_clean_async), OPT("cov_arena_verify", O_BOOL, cov_arena_verify), OPT("ncs_no_prefix", O_BOOL, ncs_no_prefix), OPT("ncs_prefix_min", O_INT, ncs_prefix_min), OPT("walk_sum_in_bin", O_BOOL, walk_sum_in_bin), OPT("cov_item_groups", O_INT, cov_item_groups), OPT("tv_u", O_INT, tv_u), OPT("tv_rounds", O_INT, tv_rounds), OPT("tf_u", O_INT, tf_u), OPT("tf_rounds", O_INT, tf_rounds),
     OPT("rows_u", O_INT, rows_u), OPT("tb_slots", O_INT, tb_slots), OPT("trio_xcd", O_INT, trio_xcd), OPT("cov_shape", O_INT, cov_shape),
     OPT("covf_shape", O_INT, covf_shape), OPT("cov_xcd", O_INT, cov_xcd), OPT("group_bucket_bits", O_INT, group_bucket_bits), OPT("tv_ablate", O_U32, tv_ablate),
-    OPT("cov_ablate", O_U32, cov_ablate), OPT("ssn_ablate", O_U32, ssn_ablate), OPT("ssn_debug", O_BOOL, ssn_debug),
+    OPT("cov_ablate", O_U32, cov_ablate), OPT("ssn_ablate", O_U32, ssn_ablate), OPT("no_absent_skip", O_BOOL, no_absent_skip), OPT("ssn_debug", O_BOOL, ssn_debug),
     OPT("scan_no_huge", O_BOOL, scan_no_huge), OPT("flag_rank_chained", O_BOOL, flag_rank_chained), OPT("ratio_kernel", O_BOOL, ratio_kernel),
     OPT("mask_pass", O_BOOL, mask_pass), OPT("trio_free_at_filter", O_BOOL, trio_free_at_filter), OPT("trio_after_step", O_BOOL, trio_after_step),
 };

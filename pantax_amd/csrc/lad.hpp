@@ -6,9 +6,10 @@
 namespace ptx {
 
 // a9: per-hap unique-trio statistics (zscore_filter profile.rs:1028-1051; :1114-1147)
-int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_ntrio_nz /*[H]*/, DevBuf<double> &d_mean /*[H]*/);
+int hap_trio_stats_launch(Ctx *ctx, const Db *db, DevBuf<uint32_t> &d_ntrio_nz /*[H]*/, DevBuf<double> &d_mean /*[H]*/,
+                          const uint8_t *d_active = nullptr /* device [S] or null: species the coverage pass skipped are not read */);
 // node abundance + per-species stats
-int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth);
+int node_stats_launch(Ctx *ctx, const Db *db, LadBatch *lb, int64_t min_depth, const uint8_t *d_active = nullptr);
 // a11: species with more valid rows than sample_nodes keep the rows rand 0.9.2's choose_multiple(seed 42) would keep
 int row_sample_apply(Ctx *ctx, const Db *db, LadBatch *lb, int64_t sample_nodes);
 // a10: masks, ratios; then LP rows sorted and grouped into patterns

@@ -85,6 +85,7 @@ struct Sn {
     uint64_t *ksp, *km, *ka;     // output: {species, mask, a} (ksp null: species << pack_shift | mask in km)
     int pack_shift;
     uint32_t G, per;             // partition workgroups per segment, tiles each of them walks
+    uint32_t skip_empty;         // segments without LP columns are not read by the histogram pass (option no_absent_skip: 0)
     uint32_t ablate;             // -DSSN_ABLATE builds: parts of ssn_hist_kernel left out (measurements; the results are wrong)
     __device__ __forceinline__ uint32_t *w(uint32_t s) const { return ws + (size_t)s * SN_WS_WORDS; }
     __device__ __forceinline__ uint64_t key_word(uint32_t s, uint64_t m) const { return pack_shift >= 0 ? (((uint64_t)s << pack_shift) | m) : m; }
@@ -304,6 +305,14 @@ __global__ void __launch_bounds__(256) ssn_hist_kernel(Sn sn) {
     const uint32_t s = blockIdx.y, g = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
     if (n == 0 || w[SN_OFF_FLAGS] != 0) return;
+    // a species without LP columns (the species level dropped it, or no haplotype passed the first filter) has no rows: an empty histogram, nothing staged,
+    // nothing read (round 6: the work follows the species that are present in the sample; its c0 is never used -- objective_rows_kernel leaves such species out)
+    if (HAPS && sn.skip_empty && sn.hp.sp_p[s] <= 0) {           // (workgroup-uniform)
+        uint32_t *row0 = sn.cntm + ((size_t)s * sn.G + g) * SN_NBUCKET;
+        for (int i = threadIdx.x; i < SN_NBUCKET; i += 256) row0[i] = 0u;
+        if (threadIdx.x == 0) { sn.stage_cnt[(size_t)s * sn.G + g] = 0u; if (sn.c0) sn.c0p[(size_t)s * sn.G + g] = 0.0; }
+        return;
+    }
     uint32_t t0, t1;
     sn_tiles(sn, n, g, t0, t1);
     const ulonglong2 *gt = reinterpret_cast<const ulonglong2 *>(w + SN_OFF_TREE);
@@ -813,6 +822,7 @@ int sample_sort_nodes(Ctx *ctx, const double *ab, const uint64_t *mask, const ui
     else if (!mask) return fail(ctx, PANTAX_HIP_E_INVALID, "sample_sort_nodes: neither a mask array nor haplotype words");
     sn_geometry(S, seg_bound, &sn.G, &sn.per);
     sn.ablate = ctx->cfg.ssn_ablate;
+    sn.skip_empty = ctx->cfg.no_absent_skip ? 0u : 1u;
     sn.cntm = d_ws + (size_t)S * SN_WS_WORDS;
     sn.stage_cnt = sn.cntm + (size_t)S * sn.G * SN_NBUCKET;
     uint32_t *cw = sn.stage_cnt + (size_t)S * sn.G;               // [S x G] doubles, 8-byte aligned

@@ -187,6 +187,13 @@ def test_reference_db_shape_every_species_against_oracle(eng, tmp_path_factory):
     finally:
         eng.set_option("ncs_no_prefix", None)
     assert sp_rows_b == sp_rows and st_rows_b == st_rows
+    # (four fifths of the species are absent from the sample: the statistics and histogram passes of the step do not read them -- same tables when they do)
+    eng.set_option("no_absent_skip", "1")
+    try:
+        sp_rows_c, st_rows_c, _ = profile_step(eng, names, haps, sset.avg_len(), StepConfig())
+    finally:
+        eng.set_option("no_absent_skip", None)
+    assert sp_rows_c == sp_rows and st_rows_c == st_rows
     # the STAGE call's covered bases (popcount pass -- what the file seam runs; long nodes: popcount_long_kernel's per-stretch prefix) against the plain
     # per-thread loop, and against the oracle for a sample of the species (every twentieth: single-genome chains and pangenome graphs)
     from oracle import oracle as orc
