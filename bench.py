@@ -94,11 +94,16 @@ def workload_key(spec):
     return k
 
 
-def algorithmic_bytes(species, n_lp_rows, U, R, T):
+def algorithmic_bytes(species, n_lp_rows, U, R, T, kept=None, with_columns=None):
     """SURVEY.md section 8d per-stage compulsory traffic for ONE step of this rank's workload (U = unique trios, R reads,
-    T walk steps resident on this rank)."""
+    T walk steps resident on this rank).  kept: names of the species the species level kept (None: all) -- the statistics and histogram passes
+    of the resident step do not read the others (round 6): their rulers count the kept species' nodes, plus the 12 bytes of zeros a dropped node is given;
+    with_columns: names of the species with at least one LP column (the histogram pass of the row sort reads those alone)."""
     V = sum(g.n_nodes for g in species)
     L = int(sum(int(g.node_len.sum()) for g in species))
+    V_k = V if kept is None else sum(g.n_nodes for g in species if g.name in kept)
+    L_k = L if kept is None else int(sum(int(g.node_len.sum()) for g in species if g.name in kept))
+    V_c = V_k if with_columns is None else sum(g.n_nodes for g in species if g.name in with_columns)
     P = int(sum(int(g.path_off[-1]) for g in species))
     H = sum(g.n_paths for g in species)
     Wr = max(T - 2 * R, 0)
@@ -121,7 +126,7 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # a8 popcount: L/8 bitmap in + 8V cov out
         "popcount_kernel": L // 8 + 8 * V,
         # the resident step (round 4): popcount folded into the node statistics pass -- lengths 4V + bases 8V in, counts 4V + abundances 8V out, bitmap L/8
-        "node_cov_stats_kernel": 24 * V + L // 8,
+        "node_cov_stats_kernel": 24 * V_k + L_k // 8 + 12 * (V - V_k),
         # a7 (round 5: bytes the launch MUST move, not a split of SURVEY 8d's whole-index figure, which counts 12-byte keys this design never moves).
         # trio_visit_kernel: the visit table (4 bytes per visit slot, ~64/60 of the interior positions: pads) + every walk entry once (4P) +
         # per group of 64 visits the head mask, node base and ballot (20 B) + one 16-byte record per unique window.
@@ -152,7 +157,7 @@ def algorithmic_bytes(species, n_lp_rows, U, R, T):
         # a12's rows sorted straight from the node arrays (sample_sort_nodes.hip, round 4): the histogram pass reads abundance + mask of every
         # node (16V; it also stages the rows that have to travel, a data-dependent third of them: not counted); the scatter and the tie
         # fills write every row once between them (16 n)
-        "ssn_hist_kernel": 24 * V,       # (the masks are formed in this pass since the end of round 4: haplotype words 8V + abundance 8V + covered bases 4V + lengths 4V)
+        "ssn_hist_kernel": 24 * V_c,     # (the masks are formed in this pass since the end of round 4: haplotype words 8V + abundance 8V + covered bases 4V + lengths 4V)
         # the LP objective summed over the sorted rows (8 n) instead of over abundance + mask of every node
         "objective_rows_kernel": 8 * n_lp_rows,
         "sort_hist_kernel": 8 * n_lp_rows,
@@ -1287,7 +1292,8 @@ def main():
         value = total_reads / (dt / args.steps) / 1e6
         n_lp_rows = int(sum(stats["n_rows"]))
         n_unique = n_unique_early if n_unique_early is not None else int(eng.trio_nodes_info(fetch=False))      # after the timed region: only its size is wanted
-        ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, R_res, T_res)
+        ab, dims = algorithmic_bytes(species, n_lp_rows, n_unique, R_res, T_res, kept={r[0] for r in species_rows} if world == 1 else None,
+                                      with_columns={g.name for g, nc in zip(species, stats["n_cand"]) if nc > 0} if world == 1 and len(stats.get("n_cand", [])) == len(species) else None)
         dims["U"] = n_unique
         tr = lambda k, corrected=False: pmc_traffic(k, wkey, spec["name"], corrected) if world == 1 else None
 

@@ -213,6 +213,8 @@ __global__ void __launch_bounds__(256) ssn_gather_kernel(Sn sn) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;   // grid.x covers SN_SAMPLE
     const uint64_t pos = small ? i : ((uint64_t)i * n) / SN_SAMPLE;
     uint64_t m = ~0ull, a = ~0ull;                       // not a row: sorts last
+    const bool dead = !sn.mask && sn.skip_empty && sn.hp.sp_p[s] <= 0;   // a segment without LP columns has no rows: nothing sampled, nothing sorted (round 6)
+    if (dead) { if (i == 0) { w[SN_OFF_FLAGS] = small ? 1u : 0u; w[SN_OFF_FLAGS + 1] = 0; w[SN_OFF_FLAGS + 2] = 0; w[SN_OFF_FLAGS + 3] = 0; } return; }
     if (pos < n) {
         const double av = sn.ab[o + pos];
         const uint64_t mv = av > 0.0 ? sn_node_mask(sn, s, o + pos) : 0ull;
@@ -228,6 +230,10 @@ __global__ void __launch_bounds__(1024) ssn_sample_kernel(Sn sn) {
     const uint32_t s = blockIdx.x, o = sn.node_base[s], n = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
     if (n == 0) { if (threadIdx.x == 0) { sn.seg_n[s] = 0; if (sn.c0) sn.c0[s] = 0.0; } return; }
+    if (!sn.mask && sn.skip_empty && sn.hp.sp_p[s] <= 0) {   // (see ssn_gather_kernel; the histogram pass writes the empty counts of a large segment)
+        if (threadIdx.x == 0) { sn.seg_n[s] = 0; w[SN_OFF_FLAGS + 3] = 0; if (sn.c0) sn.c0[s] = 0.0; }
+        return;
+    }
     const uint64_t *samp = reinterpret_cast<const uint64_t *>(w + SN_OFF_SAMP);
     const bool small = n <= (uint32_t)SN_SAMPLE;
     if (threadIdx.x == 0) s_nv = 0;
