@@ -580,6 +580,8 @@ __global__ void __launch_bounds__(256) ssn_ties_kernel(Sn sn) {
 
 // A wave per even bucket 2j, sorted in registers (more than SN_WAVE_CAP rows: left on the segment's list for the second kernel).
 __global__ void __launch_bounds__(256) ssn_local_wave_kernel(Sn sn) {
+    // (flat grids whose waves / workgroups walk several (segment, bucket) items were measured in round 6 for this kernel and the tie fills: 1.10 -> 1.32 ms here at
+    // cfg4, +0.2 ms a step at the reference-DB shape with its 2.3 million mostly idle workgroups -- starting workgroups that find nothing is not the cost)
     const uint32_t s = blockIdx.y, o = sn.node_base[s], nn = sn.node_base[s + 1] - o;
     uint32_t *w = sn.w(s);
     if (nn == 0 || w[SN_OFF_FLAGS] != 0) return;
