@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(COV_BLOCK) coverage_step_kernel(
 // Walks of more than 64 steps: the last step needs `seen` = everything aligned before it (:857-859), which lives in
 // other waves.  One cheap pass over the steps of long walks adds the node lengths of all steps but the last into
 // long_sum[slot] (one atomic per wave and walk); launched only when the upload saw such walks.
-template <int WS_U>
+template <int WS_U, bool EAGER = false>   // EAGER (most walks are long): the node ids and group slots are requested WITH the step codes, not behind the test for a long step
 __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_t *__restrict__ group_slot, const uint8_t *__restrict__ step_dup,
                                                        const uint4 *__restrict__ read_rec, const uint2 *__restrict__ slot_rec,
                                                        const uint32_t *__restrict__ node_id, const uint32_t *__restrict__ node_len,
@@ -830,22 +830,25 @@ __global__ void __launch_bounds__(256) walk_sum_kernel(uint64_t T, const uint32_
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256 * WS_U;
     for (uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x - lane)) * WS_U; base < T; base += stride) {
-        uint32_t code[WS_U], slot[WS_U], id[WS_U], nl[WS_U];
+        uint32_t code[WS_U], slot[WS_U], id[WS_U], nl[WS_U], gs_e[WS_U], id_e[WS_U];
         uint64_t t[WS_U];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
             t[u] = base + (uint64_t)u * 64 + lane;
             code[u] = t[u] < T ? step_dup[t[u]] : STEP_PAD;
-            any = any || (code[u] != STEP_PAD && (code[u] & STEP_LONG));
+            if constexpr (EAGER) { gs_e[u] = t[u] < T ? group_slot[t[u] >> 6] : NO_SLOT; id_e[u] = t[u] < T ? node_id[t[u]] : 0u; }
         }
+#pragma unroll
+        for (int u = 0; u < WS_U; ++u) any = any || (code[u] != STEP_PAD && (code[u] & STEP_LONG));
         if (!__any(any)) continue;
 #pragma unroll
         for (int u = 0; u < WS_U; ++u) {
             slot[u] = NO_SLOT; id[u] = 0;
-            const uint32_t gs = t[u] < T ? group_slot[t[u] >> 6] : NO_SLOT;
+            uint32_t gs;
+            if constexpr (EAGER) gs = gs_e[u]; else gs = t[u] < T ? group_slot[t[u] >> 6] : NO_SLOT;
             const uint32_t sl = slot_in_group(gs, code[u], lane);
-            if (code[u] != STEP_PAD && (code[u] & STEP_LONG)) { slot[u] = sl; id[u] = node_id[t[u]]; }
+            if (code[u] != STEP_PAD && (code[u] & STEP_LONG)) { slot[u] = sl; if constexpr (EAGER) id[u] = id_e[u]; else id[u] = node_id[t[u]]; }
         }
         uint2 sr[WS_U];
         uint4 rr[WS_U];
@@ -1339,7 +1342,8 @@ int coverage_prepare(Ctx *ctx, Db *db, Reads *rd, bool with_trio) {
     } else if (rd->R && rd->T_pad && rd->n_long) {
         PTX_HIP(ctx, hipMemsetAsync(rd->d_long_sum.p, 0, rd->R * sizeof(uint32_t), ctx->stream));
         KTimer t(ctx, "walk_sum_kernel");
-        hipLaunchKernelGGL(walk_sum_kernel<4>, dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_group_slot.p,
+        const bool eager = (uint64_t)rd->n_long * 2 > rd->n_slots;      // most walks are long: one dependent level less (0.363 -> 0.333 ms at the cfg5 share)
+        hipLaunchKernelGGL((eager ? walk_sum_kernel<4, true> : walk_sum_kernel<4, false>), dim3(grid_for(rd->T_pad / 4 + 1, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rd->T_pad, rd->d_g_group_slot.p,
                            rd->d_g_step_dup.p, rd->d_g_read_rec.p, rd->d_g_slot_rec.p, rd->d_g_node_id.p, db->d_node_len.p, rd->d_long_sum.p,
                            rd->d_long_len0.p);
     }
